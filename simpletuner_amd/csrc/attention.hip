@@ -1,0 +1,218 @@
+// attention.hip — K7 forward: joint non-causal attention over [txt || img] latent patch tokens.
+//   O = softmax(scale * Q K^T + key_bias) V          (flux/transformer.py:200-207 → F.scaled_dot_product_attention)
+//
+// gfx950 design: flash-style, LDS-tiled over 64-key tiles, online softmax entirely in registers.
+//   * workgroup = 4 waves x 32 queries; 2 workgroups resident per CU (64 KiB LDS each, <=256 VGPR).
+//   * scores are computed TRANSPOSED (S^T = K Q^T: K tile = MFMA A from LDS, Q = MFMA B held in registers),
+//     so a lane owns one query column: row max / row sum are register reductions + one xor-32 exchange.
+//   * K rows are fetched in perm23 order, so exp(S^T) registers are already the B operand of
+//     O^T += V^T P^T  (attn_common.h) — P never leaves the register file.
+//   * V arrives pre-transposed (Vt [B,H,d,Sp], written by the QKV epilogue kernel), so the V^T tile is a
+//     plain row-major LDS image read with ds_read_b128.
+//   * both LDS tiles use XOR-swizzled 16-byte chunks (conflict-free for the 16-lane ds_read_b128 groups).
+//   * register-staged double buffering: next tile's global loads are issued before the MFMA work and
+//     written to the other LDS buffer after it (T14 async-stage split).
+#include "attn_common.h"
+
+#define ATT_THREADS 256
+#define QB 128  // queries per workgroup
+#define KB 64   // keys per tile
+
+template <int HD>
+__global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
+                                                            bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
+                                                            int S, int Sp, float scale2) {
+  constexpr int KROWB = HD * 2;          // bytes per K tile row
+  constexpr int KT_BYTES = KB * KROWB;   // K tile
+  constexpr int VT_BYTES = HD * 128;     // V^T tile: HD rows x 64 keys
+  constexpr int BUF = KT_BYTES + VT_BYTES;
+  constexpr int NKS = HD / 16;           // MFMA k-steps over the head dim
+  constexpr int NDT = HD / 32;           // 32-row d tiles of O^T
+  constexpr int KCH = KT_BYTES / 16 / ATT_THREADS;  // 16-B chunks per thread
+  constexpr int VCH = VT_BYTES / 16 / ATT_THREADS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + head;
+  const int q0 = blockIdx.x * QB + wv * 32;
+  const int qi = min(q0 + l31, S - 1);
+
+  const bf16* Kg = K + bh * (int64_t)S * HD;
+  const bf16* Vg = Vt + bh * (int64_t)HD * Sp;
+
+  // Q fragments (MFMA B operand): lane -> query l31, head channels 16ks + 8h .. +8
+  bf16x8 qf[NKS];
+  {
+    const bf16* qrow = Q + (bh * S + qi) * (int64_t)HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+  }
+
+  f32x16 acc_o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  bf16x8 kreg[KCH], vreg[VCH];
+  auto load_tile = [&](int kt) {
+    const int key0 = kt * KB;
+#pragma unroll
+    for (int p = 0; p < KCH; p++) {
+      const int id = p * ATT_THREADS + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      kreg[p] = *(const bf16x8*)(Kg + (int64_t)min(key0 + row, S - 1) * HD + c * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < VCH; p++) {
+      const int id = p * ATT_THREADS + tid;
+      const int row = id >> 3, c = id & 7;
+      vreg[p] = *(const bf16x8*)(Vg + (int64_t)row * Sp + key0 + c * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* ks = smem + buf * BUF;
+    char* vs = ks + KT_BYTES;
+#pragma unroll
+    for (int p = 0; p < KCH; p++) {
+      const int id = p * ATT_THREADS + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
+    }
+#pragma unroll
+    for (int p = 0; p < VCH; p++) {
+      const int id = p * ATT_THREADS + tid;
+      const int row = id >> 3, c = id & 7;
+      *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
+    }
+  };
+
+  const int nkt = (S + KB - 1) / KB;
+  const int krow_p = perm23(l31);  // K tile row (within a 32-key sub-block) this lane feeds as MFMA A row l31
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* ks = smem + buf * BUF;
+    const char* vs = ks + KT_BYTES;
+    const int key0 = kt * KB;
+
+    // ---- S^T = K Q^T for the two 32-key sub-blocks ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sacc[sb][r] = 0.f;
+      const int row = 32 * sb + krow_p;
+#pragma unroll
+      for (int ks_ = 0; ks_ < NKS; ks_++) {
+        bf16x8 kf = *(const bf16x8*)(ks + lds_off<KROWB>(row, 2 * ks_ + h));
+        sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks_], sacc[sb], 0, 0, 0);
+      }
+    }
+    // ---- scale, bias, mask; online softmax ----
+    float p[2][16];
+    const bool tail = (key0 + KB > S);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float s = sacc[sb][r] * scale2;
+        if (key_bias != nullptr || tail) {
+          const int key = key0 + 32 * sb + acc_row(r, h);
+          if (key_bias != nullptr) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
+          if (key >= S) s = -INFINITY;
+        }
+        p[sb][r] = s;
+        mt = fmaxf(mt, s);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        p[sb][r] = fast_exp2(p[sb][r] - m_new);
+        ls += p[sb][r];
+      }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+      for (int m = 0; m < 2; m++) pf[sb][m] = pack8(&p[sb][8 * m]);
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) {
+      const int row = 32 * dt + l31;
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          bf16x8 vf = *(const bf16x8*)(vs + lds_off<128>(row, 4 * sb + 2 * m + h));
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sb][m], acc_o[dt], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- finish: combine the two half-lanes' partial sums, normalise, store ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  const int q = q0 + l31;
+  if (q < S) {
+    bf16* orow = O + ((int64_t)b * S + q) * ld_o + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        bf16x4 o;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc_o[dt][4 * a + bb] * inv);
+        *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
+      }
+    if (h == 0) lse2[bh * S + q] = m_run + __log2f(l_tot);
+  }
+}
+
+extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
+                              int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale) {
+  ST_REQUIRE(Q && K && Vt && O && lse2, "attn_fwd: null pointer");
+  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && ld_o % 4 == 0, "attn_fwd: bad shape S=%d Sp=%d", S, Sp);
+  if (d != 128 && d != 64) { st355_set_error("attn_fwd: head_dim %d not built", d); return ST355_ENOSYS; }
+  const double flops = 4.0 * (double)B * H * (double)S * S * d;
+  const double bytes = 2.0 * (double)B * H * S * d * 4.0;
+  ProfScope ps(stream, ST355_K_ATTN_FWD, flops, bytes);
+  dim3 grid((S + QB - 1) / QB, H, B), block(ATT_THREADS);
+  const float scale2 = scale * LOG2E;
+  if (d == 128) {
+    const int lds = 2 * (KB * 256 + 128 * 128);
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(k_attn_fwd<128>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                       key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
+  } else {
+    const int lds = 2 * (KB * 128 + 64 * 128);
+    hipLaunchKernelGGL(k_attn_fwd<64>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                       key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
+  }
+  return st355_check_launch("attn_fwd");
+}

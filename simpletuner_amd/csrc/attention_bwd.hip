@@ -1,0 +1,468 @@
+// attention_bwd.hip — K7 backward (what autograd does through F.scaled_dot_product_attention in the reference,
+// trainer.py:7126).  Three launches, no atomics, deterministic:
+//   prep : delta[q] = sum_d O[q,d] dO[q,d]   and   dO^T (head-major, transposed, zero padded)
+//   dKdV : per 128-key workgroup, loop over 64-query tiles:  P, dS recomputed;  dV^T += dO^T P ; dK^T += Q^T dS
+//   dQ   : per 256-query workgroup, loop over 64-key tiles:                        dQ^T += K^T dS^T
+// Both main kernels reuse the forward's register-resident softmax trick (attn_common.h): the tile whose rows
+// become the next contraction index is fetched in perm23 order, so P / dS go straight from accumulator
+// registers into the next MFMA's B operand.  Operands whose contraction index is the token axis (Q^T, K^T, dO^T)
+// are read from pre-transposed head-major copies (written by the QKV epilogue kernel / prep), never transposed
+// in LDS.
+#include "attn_common.h"
+
+#define TPB 130
+
+// ------------------------------------------------------------------------------------------------
+// prep
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ O, int64_t ld_o, const bf16* __restrict__ dO,
+                                                      int64_t ld_do, float* __restrict__ delta, bf16* __restrict__ dOt, int H, int S,
+                                                      int Sp) {
+  constexpr int TPR = HD / 8;
+  constexpr int TOK_PER_PASS = 256 / TPR;
+  __shared__ __attribute__((aligned(16))) bf16 tile[64 * TPB];
+  const int tid = threadIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int c = tid % TPR;
+  const int64_t bh = (int64_t)b * H + head;
+  for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    const int t = t0 + tl;
+    const bool valid = t < S;
+    const int tt = valid ? t : S - 1;
+    bf16x8 ov = *(const bf16x8*)(O + ((int64_t)b * S + tt) * ld_o + (int64_t)head * HD + c * 8);
+    bf16x8 gv = *(const bf16x8*)(dO + ((int64_t)b * S + tt) * ld_do + (int64_t)head * HD + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += bf2f(ov[j]) * bf2f(gv[j]);
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (valid && c == 0) delta[bh * S + t] = s;
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) gv[j] = f2bf(0.f);
+    }
+    uint32_t* tp = (uint32_t*)(&tile[tl * TPB + c * 8]);
+    const u32x4 gw = *(const u32x4*)&gv;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tp[j] = gw[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < HD * 8; i += 256) {
+    const int d = i >> 3, tc = i & 7;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = tile[(tc * 8 + e) * TPB + d];
+    *(bf16x8*)(dOt + (bh * HD + d) * (int64_t)Sp + t0 + tc * 8) = o;  // rows are 128-B aligned (Sp % 64 == 0)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ kernel: 8 waves x 32 queries
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                       const bf16* __restrict__ Kt, const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                       const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
+                                                       const float* __restrict__ delta, const float* __restrict__ key_bias,
+                                                       bf16* __restrict__ dQ, int H, int S, int Sp, float scale, float scale2) {
+  constexpr int NT = 512;
+  constexpr int KROWB = HD * 2;
+  constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
+  constexpr int TT_BYTES = HD * 128;     // K^T tile (HD rows x 64 keys)
+  constexpr int BUF = 2 * KT_BYTES + TT_BYTES;
+  constexpr int NKS = HD / 16, NDT = HD / 32;
+  constexpr int KCH = KT_BYTES / 16 / NT;
+  constexpr int TCH = TT_BYTES / 16 / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + head;
+  const int q0 = blockIdx.x * 256 + wv * 32;
+  const int q = q0 + l31;
+  const int qi = min(q, S - 1);
+
+  const bf16* Kg = K + bh * (int64_t)S * HD;
+  const bf16* Ktg = Kt + bh * (int64_t)HD * Sp;
+  const bf16* Vg = Vrows + (int64_t)b * S * ld_v + (int64_t)head * HD;
+
+  bf16x8 qf[NKS], dof[NKS];
+  {
+    const bf16* qrow = Q + (bh * S + qi) * (int64_t)HD + 8 * h;
+    const bf16* drow = dO + ((int64_t)b * S + qi) * ld_do + (int64_t)head * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+      dof[ks] = *(const bf16x8*)(drow + 16 * ks);
+    }
+  }
+  const float lse_q = lse2[bh * S + qi];
+  const float delta_q = delta[bh * S + qi];
+
+  f32x16 acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[dt][r] = 0.f;
+
+  bf16x8 kreg[KCH], vreg[KCH], treg[TCH];
+  auto load_tile = [&](int kt) {
+    const int key0 = kt * 64;
+#pragma unroll
+    for (int p = 0; p < KCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      const int key = min(key0 + row, S - 1);
+      kreg[p] = *(const bf16x8*)(Kg + (int64_t)key * HD + c * 8);
+      vreg[p] = *(const bf16x8*)(Vg + (int64_t)key * ld_v + c * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < TCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id >> 3, c = id & 7;
+      treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Sp + key0 + c * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* ks = smem + buf * BUF;
+    char* vs = ks + KT_BYTES;
+    char* ts = vs + KT_BYTES;
+#pragma unroll
+    for (int p = 0; p < KCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
+      *(bf16x8*)(vs + lds_off<KROWB>(row, c)) = vreg[p];
+    }
+#pragma unroll
+    for (int p = 0; p < TCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id >> 3, c = id & 7;
+      *(bf16x8*)(ts + lds_off<128>(row, c)) = treg[p];
+    }
+  };
+
+  const int nkt = (S + 63) / 64;
+  const int krow_p = perm23(l31);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* ks = smem + buf * BUF;
+    const char* vs = ks + KT_BYTES;
+    const char* ts = vs + KT_BYTES;
+    const int key0 = kt * 64;
+    const bool tail = key0 + 64 > S;
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      const int row = 32 * sb + krow_p;
+#pragma unroll
+      for (int ks_ = 0; ks_ < NKS; ks_++) {
+        bf16x8 kf = *(const bf16x8*)(ks + lds_off<KROWB>(row, 2 * ks_ + h));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks_], sacc, 0, 0, 0);
+        bf16x8 vf = *(const bf16x8*)(vs + lds_off<KROWB>(row, 2 * ks_ + h));
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks_], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float s = sacc[r] * scale2;
+        float pv;
+        if (key_bias != nullptr || tail) {
+          const int key = key0 + 32 * sb + acc_row(r, h);
+          if (key_bias != nullptr) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
+          pv = (key < S) ? fast_exp2(s - lse_q) : 0.f;
+        } else {
+          pv = fast_exp2(s - lse_q);
+        }
+        ds[r] = pv * (dpacc[r] - delta_q);
+      }
+      bf16x8 dsf[2];
+      dsf[0] = pack8(&ds[0]);
+      dsf[1] = pack8(&ds[8]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++) {
+        const int trow = 32 * dt + l31;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          bf16x8 tf = *(const bf16x8*)(ts + lds_off<128>(trow, 4 * sb + 2 * m + h));
+          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[m], acc[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (q < S) {
+    bf16* orow = dQ + (bh * S + q) * (int64_t)HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        bf16x4 o;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
+        *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK/dV kernel: 4 waves x 32 keys, one wave per SIMD (accumulators: 2 x HD x 32 fp32 per wave)
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                        const bf16* __restrict__ Qt, const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                        const bf16* __restrict__ dO, int64_t ld_do, const bf16* __restrict__ dOt,
+                                                        const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                        const float* __restrict__ key_bias, bf16* __restrict__ dK,
+                                                        bf16* __restrict__ dVrows, int64_t ld_dv, int H, int S, int Sp, float scale,
+                                                        float scale2) {
+  constexpr int NT = 256;
+  constexpr int QROWB = HD * 2;
+  constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major)
+  constexpr int TT_BYTES = HD * 128;     // Q^T tile / dO^T tile (HD rows x 64 queries)
+  constexpr int STAT_BYTES = 2 * 64 * 4; // lse2 + delta for the 64 queries
+  constexpr int BUF = 2 * QT_BYTES + 2 * TT_BYTES + STAT_BYTES;
+  constexpr int NKS = HD / 16, NDT = HD / 32;
+  constexpr int QCH = QT_BYTES / 16 / NT;
+  constexpr int TCH = TT_BYTES / 16 / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + head;
+  const int key = blockIdx.x * 128 + wv * 32 + l31;
+  const int keyi = min(key, S - 1);
+
+  const bf16* Qg = Q + bh * (int64_t)S * HD;
+  const bf16* Qtg = Qt + bh * (int64_t)HD * Sp;
+  const bf16* dOtg = dOt + bh * (int64_t)HD * Sp;
+  const bf16* dOg = dO + (int64_t)b * S * ld_do + (int64_t)head * HD;
+
+  bf16x8 kf[NKS], vf[NKS];
+  {
+    const bf16* krow = K + (bh * S + keyi) * (int64_t)HD + 8 * h;
+    const bf16* vrow = Vrows + ((int64_t)b * S + keyi) * ld_v + (int64_t)head * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      kf[ks] = *(const bf16x8*)(krow + 16 * ks);
+      vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
+    }
+  }
+  const float kb2 = key_bias ? key_bias[(int64_t)b * S + keyi] * LOG2E : 0.f;
+
+  f32x16 acc_dk[NDT], acc_dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_dk[dt][r] = 0.f; acc_dv[dt][r] = 0.f; }
+
+  bf16x8 qreg[QCH], greg[QCH], qtreg[TCH], gtreg[TCH];
+  float st_lse = 0.f, st_delta = 0.f;
+  auto load_tile = [&](int qt) {
+    const int qq0 = qt * 64;
+#pragma unroll
+    for (int p = 0; p < QCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      const int qq = min(qq0 + row, S - 1);
+      qreg[p] = *(const bf16x8*)(Qg + (int64_t)qq * HD + c * 8);
+      greg[p] = *(const bf16x8*)(dOg + (int64_t)qq * ld_do + c * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < TCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id >> 3, c = id & 7;
+      qtreg[p] = *(const bf16x8*)(Qtg + (int64_t)row * Sp + qq0 + c * 8);
+      gtreg[p] = *(const bf16x8*)(dOtg + (int64_t)row * Sp + qq0 + c * 8);
+    }
+    if (tid < 64) {
+      const int qq = qq0 + tid;
+      st_lse = (qq < S) ? lse2[bh * S + qq] : INFINITY;   // +inf -> P = exp2(-inf) = 0 for padded queries
+      st_delta = (qq < S) ? delta[bh * S + qq] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* qs = smem + buf * BUF;
+    char* gs = qs + QT_BYTES;
+    char* qts = gs + QT_BYTES;
+    char* gts = qts + TT_BYTES;
+    float* stat = (float*)(gts + TT_BYTES);
+#pragma unroll
+    for (int p = 0; p < QCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      *(bf16x8*)(qs + lds_off<QROWB>(row, c)) = qreg[p];
+      *(bf16x8*)(gs + lds_off<QROWB>(row, c)) = greg[p];
+    }
+#pragma unroll
+    for (int p = 0; p < TCH; p++) {
+      const int id = p * NT + tid;
+      const int row = id >> 3, c = id & 7;
+      *(bf16x8*)(qts + lds_off<128>(row, c)) = qtreg[p];
+      *(bf16x8*)(gts + lds_off<128>(row, c)) = gtreg[p];
+    }
+    if (tid < 64) { stat[tid] = st_lse; stat[64 + tid] = st_delta; }
+  };
+
+  const int nqt = (S + 63) / 64;
+  const int qrow_p = perm23(l31);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; qt++) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) load_tile(qt + 1);
+    const char* qs = smem + buf * BUF;
+    const char* gs = qs + QT_BYTES;
+    const char* qts = gs + QT_BYTES;
+    const char* gts = qts + TT_BYTES;
+    const float* stat = (const float*)(gts + TT_BYTES);
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      const int row = 32 * qb + qrow_p;
+#pragma unroll
+      for (int ks_ = 0; ks_ < NKS; ks_++) {
+        bf16x8 qf = *(const bf16x8*)(qs + lds_off<QROWB>(row, 2 * ks_ + h));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks_], sacc, 0, 0, 0);
+        bf16x8 gf = *(const bf16x8*)(gs + lds_off<QROWB>(row, 2 * ks_ + h));
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks_], dpacc, 0, 0, 0);
+      }
+      // accumulator register r <-> query 32qb + 16(r>>3) + 8h + (r&7): stats are contiguous 8-float runs
+      float lse_r[16], del_r[16];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const float* sp = stat + 32 * qb + 16 * m + 8 * h;
+        *(f32x4*)&lse_r[8 * m] = *(const f32x4*)sp;
+        *(f32x4*)&lse_r[8 * m + 4] = *(const f32x4*)(sp + 4);
+        *(f32x4*)&del_r[8 * m] = *(const f32x4*)(sp + 64);
+        *(f32x4*)&del_r[8 * m + 4] = *(const f32x4*)(sp + 68);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        pr[r] = fast_exp2(sacc[r] * scale2 + kb2 - lse_r[r]);
+        ds[r] = pr[r] * (dpacc[r] - del_r[r]);
+      }
+      bf16x8 pf[2], dsf[2];
+      pf[0] = pack8(&pr[0]); pf[1] = pack8(&pr[8]);
+      dsf[0] = pack8(&ds[0]); dsf[1] = pack8(&ds[8]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++) {
+        const int trow = 32 * dt + l31;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const int ch = 4 * qb + 2 * m + h;
+          bf16x8 gtf = *(const bf16x8*)(gts + lds_off<128>(trow, ch));
+          acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf[m], acc_dv[dt], 0, 0, 0);
+          bf16x8 qtf = *(const bf16x8*)(qts + lds_off<128>(trow, ch));
+          acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[m], acc_dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (qt + 1 < nqt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (key < S) {
+    bf16* krow = dK + (bh * S + key) * (int64_t)HD;
+    bf16* vrow = dVrows + ((int64_t)b * S + key) * ld_dv + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+          ok[bb] = f2bf(acc_dk[dt][4 * a + bb] * scale);
+          ov[bb] = f2bf(acc_dv[dt][4 * a + bb]);
+        }
+        *(bf16x4*)(krow + 32 * dt + 8 * a + 4 * h) = ok;
+        *(bf16x4*)(vrow + 32 * dt + 8 * a + 4 * h) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
+  return round256((size_t)B * H * S * sizeof(float)) + round256((size_t)B * H * d * Sp * 2);
+}
+
+extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
+                              int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
+                              const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp,
+                              int d, float scale, void* workspace) {
+  ST_REQUIRE(Q && K && Qt && Kt && v_rows && O && dO && lse2 && dQ && dK && dv_rows && workspace, "attn_bwd: null pointer");
+  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S, "attn_bwd: bad shape S=%d Sp=%d", S, Sp);
+  ST_REQUIRE(ld_v % 8 == 0 && ld_o % 8 == 0 && ld_do % 8 == 0 && ld_dv % 4 == 0, "attn_bwd: leading dimensions must be multiples of 8");
+  ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
+  if (d != 128 && d != 64) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
+  float* delta = (float*)workspace;
+  bf16* dOt = (bf16*)((char*)workspace + round256((size_t)B * H * S * sizeof(float)));
+  const float scale2 = scale * LOG2E;
+  const double fl_unit = 2.0 * (double)B * H * (double)S * S * d;  // one S x S x d contraction
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  {
+    ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
+    dim3 grid(Sp / 64, H, B);
+    if (d == 128)
+      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, delta, dOt, H, S, Sp);
+    else
+      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, delta, dOt, H, S, Sp);
+    if ((rc = st355_check_launch("attn_bwd_prep")) != 0) return rc;
+  }
+  {
+    ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * S * d * 8.0);
+    dim3 grid((S + 127) / 128, H, B);
+    if (d == 128) {
+      const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv<128>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, lse2, (const float*)delta, key_bias,
+                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+    } else {
+      const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, lse2, (const float*)delta, key_bias,
+                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+    }
+    if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
+  }
+  {
+    ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * S * d * 6.0);
+    dim3 grid((S + 255) / 256, H, B);
+    if (d == 128) {
+      const int lds = 2 * (2 * 64 * 256 + 128 * 128);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dq<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp,
+                         scale, scale2);
+    } else {
+      const int lds = 2 * (2 * 64 * 128 + 64 * 128);
+      hipLaunchKernelGGL(k_attn_bwd_dq<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp,
+                         scale, scale2);
+    }
+    if ((rc = st355_check_launch("attn_bwd_dq")) != 0) return rc;
+  }
+  return ST355_OK;
+}

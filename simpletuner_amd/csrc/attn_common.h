@@ -1,0 +1,35 @@
+// attn_common.h — shared pieces of the attention kernels (forward, dQ, dK/dV).
+//
+// MFMA shape: v_mfma_f32_32x32x16_bf16.  Fragment maps (lane l, h = l>>5):
+//   A[i][k] : i = l&31, k = 8h + j (j = 0..7)        B[k][n] : n = l&31, k = 8h + j
+//   C[r][n] : n = l&31, r = 8a + 4h + b  for register index 4a + b (a,b = 0..3)
+//
+// "Row permutation" trick: when a 32-row operand tile is the MFMA A operand and its rows become the
+// contraction index of the NEXT MFMA, rows are fetched in the order  pi(i) = i with bits 2 and 3 swapped.
+// Then a lane's accumulator registers 8m..8m+7 (m = 0,1) hold rows 16m + 8h + {0..7} — exactly the 8
+// consecutive k-slots the next MFMA's B operand wants from that lane: no cross-lane traffic, no LDS bounce.
+#pragma once
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+// actual row (0..31) held by accumulator register reg of a lane with half h, after the perm23 fetch order
+__device__ __forceinline__ int acc_row(int reg, int h) { return 16 * (reg >> 3) + 8 * h + (reg & 7); }
+
+// swizzled byte offset inside a row-major LDS tile whose rows are ROWB bytes (128 or 256)
+template <int ROWB>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  if (ROWB == 256) return row * 256 + ((chunk ^ (row & 15)) << 4);
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = f2bf(v[j]);
+  return o;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

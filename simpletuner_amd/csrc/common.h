@@ -1,0 +1,82 @@
+// common.h — shared device helpers + host-side launch bookkeeping for libst355 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/st355.h"
+
+// ------------------------------------------------------------------------------------------------
+// device types
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }  // RNE (v_cvt_pk_bf16_f32 on gfx950)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximated GELU (diffusers "gelu-approximate" / nn.GELU(approximate="tanh"))
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));  // tanh(u)
+  return 0.5f * x * (1.f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));
+  float du = k0 * (1.f + 3.f * k1 * x2);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+
+// XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b%8): gives each XCD a
+// contiguous chunk of the logical grid so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: error text + launch profiler
+// ------------------------------------------------------------------------------------------------
+void st355_set_error(const char* fmt, ...);
+int st355_check_launch(const char* what);
+
+struct ProfScope {
+  int idx;
+  void* stream;
+  ProfScope(void* stream, int klass, double flops, double bytes);
+  ~ProfScope();
+};
+
+#define ST_REQUIRE(cond, ...)                \
+  do {                                       \
+    if (!(cond)) {                           \
+      st355_set_error(__VA_ARGS__);          \
+      return ST355_EINVAL;                   \
+    }                                        \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

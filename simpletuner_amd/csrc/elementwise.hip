@@ -1,0 +1,317 @@
+// elementwise.hip — HBM-streaming kernels of the step: noising + target (K1), MSE + dL/dpred (K13),
+// Flux pack/unpack (K3), timestep projection / SiLU / add (K4), gated-residual backward scaling.
+// All are bandwidth-bound: 16-byte vector accesses, grid-stride loops, no LDS staging.
+#include "common.h"
+
+#define EW_THREADS 256
+static inline int ew_blocks(int64_t work_items) {
+  int64_t b = cdiv64(work_items, EW_THREADS);
+  if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+  float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  float r = sqrtf(-2.0f * __logf(u1));
+  float s, c;
+  __sincosf(6.283185307179586f * u2, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+// ---- K1: flow noising + target --------------------------------------------------------------------
+template <bool GEN>
+__global__ void __launch_bounds__(EW_THREADS) k_flow_noise_mix(const bf16* __restrict__ x, const bf16* __restrict__ noise,
+                                                              const float* __restrict__ sigma, bf16* __restrict__ xt,
+                                                              bf16* __restrict__ target, bf16* __restrict__ noise_out,
+                                                              int64_t batch, int64_t per_sample, uint64_t seed,
+                                                              uint64_t offset) {
+  const int64_t nvec = (batch * per_sample) >> 3;  // 8 elements per item
+  const int64_t vec_per_sample = per_sample >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / vec_per_sample;
+    const float s = sigma[b];
+    bf16x8 xv = *(const bf16x8*)(x + i * 8);
+    float n[8];
+    if (GEN) {
+      uint32_t r[4];
+      philox4x32_10(2 * (uint64_t)i + offset, seed, r);
+      box_muller(r[0], r[1], n[0], n[1]);
+      box_muller(r[2], r[3], n[2], n[3]);
+      philox4x32_10(2 * (uint64_t)i + 1 + offset, seed, r);
+      box_muller(r[0], r[1], n[4], n[5]);
+      box_muller(r[2], r[3], n[6], n[7]);
+      // the reference's noise is a weight-dtype tensor (randn_like(latents)): round to bf16 first
+#pragma unroll
+      for (int j = 0; j < 8; j++) n[j] = bf2f(f2bf(n[j]));
+    } else {
+      bf16x8 nv = *(const bf16x8*)(noise + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) n[j] = bf2f(nv[j]);
+    }
+    bf16x8 o_xt, o_tg, o_n;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float xf = bf2f(xv[j]);
+      o_xt[j] = f2bf((1.0f - s) * xf + s * n[j]);
+      o_tg[j] = f2bf(n[j] - xf);
+      o_n[j] = f2bf(n[j]);
+    }
+    *(bf16x8*)(xt + i * 8) = o_xt;
+    if (target) *(bf16x8*)(target + i * 8) = o_tg;
+    if (GEN && noise_out) *(bf16x8*)(noise_out + i * 8) = o_n;
+  }
+}
+
+extern "C" int st355_flow_noise_mix(void* stream, const void* x, const void* noise, const float* sigma, void* x_t,
+                                    void* target, void* noise_out, int64_t batch, int64_t per_sample, uint64_t seed,
+                                    uint64_t offset) {
+  ST_REQUIRE(x && sigma && x_t, "flow_noise_mix: null pointer");
+  ST_REQUIRE(per_sample % 8 == 0 && batch > 0, "flow_noise_mix: per_sample (%ld) must be a multiple of 8", (long)per_sample);
+  const int64_t n = batch * per_sample;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 4.0 * n, (noise ? 8.0 : 6.0) * n);
+  int blocks = ew_blocks(n / 8);
+  if (noise)
+    hipLaunchKernelGGL(k_flow_noise_mix<false>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)noise, sigma, (bf16*)x_t, (bf16*)target, (bf16*)noise_out, batch, per_sample, seed, offset);
+  else
+    hipLaunchKernelGGL(k_flow_noise_mix<true>, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)noise, sigma, (bf16*)x_t, (bf16*)target, (bf16*)noise_out, batch, per_sample, seed, offset);
+  return st355_check_launch("flow_noise_mix");
+}
+
+__global__ void __launch_bounds__(EW_THREADS) k_ddpm_noise_mix(const bf16* __restrict__ x, const bf16* __restrict__ noise,
+                                                              const float* __restrict__ sa, const float* __restrict__ ss,
+                                                              bf16* __restrict__ xt, bf16* __restrict__ vt, int64_t batch,
+                                                              int64_t per_sample) {
+  const int64_t nvec = (batch * per_sample) >> 3;
+  const int64_t vec_per_sample = per_sample >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / vec_per_sample;
+    const float a = sa[b], s = ss[b];
+    bf16x8 xv = *(const bf16x8*)(x + i * 8);
+    bf16x8 nv = *(const bf16x8*)(noise + i * 8);
+    bf16x8 o_xt, o_v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float xf = bf2f(xv[j]), nf = bf2f(nv[j]);
+      o_xt[j] = f2bf(a * xf + s * nf);
+      o_v[j] = f2bf(a * nf - s * xf);
+    }
+    *(bf16x8*)(xt + i * 8) = o_xt;
+    if (vt) *(bf16x8*)(vt + i * 8) = o_v;
+  }
+}
+extern "C" int st355_ddpm_noise_mix(void* stream, const void* x, const void* noise, const float* sqrt_acp,
+                                    const float* sqrt_1macp, void* x_t, void* v_target, int64_t batch, int64_t per_sample) {
+  ST_REQUIRE(x && noise && sqrt_acp && sqrt_1macp && x_t, "ddpm_noise_mix: null pointer");
+  ST_REQUIRE(per_sample % 8 == 0 && batch > 0, "ddpm_noise_mix: per_sample must be a multiple of 8");
+  const int64_t n = batch * per_sample;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 6.0 * n, 8.0 * n);
+  hipLaunchKernelGGL(k_ddpm_noise_mix, dim3(ew_blocks(n / 8)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
+                     (const bf16*)noise, sqrt_acp, sqrt_1macp, (bf16*)x_t, (bf16*)v_target, batch, per_sample);
+  return st355_check_launch("ddpm_noise_mix");
+}
+
+// ---- K13: MSE ---------------------------------------------------------------------------------
+// grid = (blocks_per_sample, B). Each block reduces its slice in fp32 and adds one value per sample.
+__global__ void __launch_bounds__(EW_THREADS) k_mse(const bf16* __restrict__ pred, const bf16* __restrict__ target,
+                                                   const float* __restrict__ weight, float* __restrict__ per_sample_acc,
+                                                   bf16* __restrict__ dpred, int64_t per_sample, float dscale) {
+  const int b = blockIdx.y;
+  const float w = weight ? weight[b] : 1.0f;
+  const int64_t vecs = per_sample >> 3;
+  const bf16* p = pred + (int64_t)b * per_sample;
+  const bf16* t = target + (int64_t)b * per_sample;
+  bf16* d = dpred ? dpred + (int64_t)b * per_sample : nullptr;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (int64_t)gridDim.x * blockDim.x) {
+    bf16x8 pv = *(const bf16x8*)(p + i * 8);
+    bf16x8 tv = *(const bf16x8*)(t + i * 8);
+    bf16x8 dv;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float df = bf2f(pv[j]) - bf2f(tv[j]);
+      acc += df * df;
+      dv[j] = f2bf(dscale * w * df);
+    }
+    if (d) *(bf16x8*)(d + i * 8) = dv;
+  }
+  acc = wave_sum(acc);
+  __shared__ float red[EW_THREADS / WAVE];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < EW_THREADS / WAVE; i++) s += red[i];
+    atomicAdd(&per_sample_acc[b], s * w);
+  }
+}
+__global__ void k_mse_finalize(float* per_sample_acc, float* loss, int B, float inv_per_sample) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; b++) {
+      float v = per_sample_acc[b] * inv_per_sample;
+      per_sample_acc[b] = v;
+      s += v;
+    }
+    loss[0] = s / (float)B;
+  }
+}
+extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target, const float* weight, float* loss_out,
+                              float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
+  ST_REQUIRE(pred && target && loss_out && per_sample_out, "mse_loss: null pointer (per_sample_out is required scratch)");
+  ST_REQUIRE(per_sample % 8 == 0 && batch > 0 && batch < 65536, "mse_loss: bad shape");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 3.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
+  hipMemsetAsync(per_sample_out, 0, sizeof(float) * batch, (hipStream_t)stream);
+  int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
+  if (bx > 512) bx = 512;
+  const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
+  hipLaunchKernelGGL(k_mse, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+                     (const bf16*)target, weight, per_sample_out, (bf16*)dpred, per_sample, dscale);
+  hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
+                     1.0f / (float)per_sample);
+  return st355_check_launch("mse_loss");
+}
+
+// ---- K3: Flux pack / unpack -------------------------------------------------------------------------
+// packed[b, h2*W2 + w2, c*4 + dh*2 + dw] = lat[b, c, 2*h2 + dh, 2*w2 + dw]
+template <bool PACK>
+__global__ void __launch_bounds__(EW_THREADS) k_flux_pack(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int C,
+                                                         int H, int W) {
+  const int64_t total = (int64_t)B * C * H * W;
+  const int H2 = H >> 1, W2 = W >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes the PACKED layout (coalesced on the packed side)
+    int64_t r = i;
+    const int ch4 = (int)(r % (4 * C)); r /= (4 * C);
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2); r /= H2;
+    const int b = (int)r;
+    const int c = ch4 >> 2, dh = (ch4 >> 1) & 1, dw = ch4 & 1;
+    const int64_t li = (((int64_t)b * C + c) * H + (2 * h2 + dh)) * W + (2 * w2 + dw);
+    if (PACK) dst[i] = src[li];
+    else dst[li] = src[i];
+  }
+}
+extern "C" int st355_flux_pack(void* stream, const void* latents, void* packed, int B, int C, int H, int W) {
+  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0), "flux_pack: bad args");
+  const int64_t n = (int64_t)B * C * H * W;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 4.0 * n);
+  hipLaunchKernelGGL(k_flux_pack<true>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)latents,
+                     (bf16*)packed, B, C, H, W);
+  return st355_check_launch("flux_pack");
+}
+extern "C" int st355_flux_unpack(void* stream, const void* packed, void* latents, int B, int C, int H, int W) {
+  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0), "flux_unpack: bad args");
+  const int64_t n = (int64_t)B * C * H * W;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 4.0 * n);
+  hipLaunchKernelGGL(k_flux_pack<false>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)packed,
+                     (bf16*)latents, B, C, H, W);
+  return st355_check_launch("flux_unpack");
+}
+
+// ---- K4 helpers ------------------------------------------------------------------------------------
+// Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) i / half)
+__global__ void k_timestep_proj(const float* __restrict__ t, bf16* __restrict__ out, int B, int dim, float scale) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[b] * scale * f;
+  out[(int64_t)b * dim + k] = f2bf(cosf(a));
+  out[(int64_t)b * dim + half + k] = f2bf(sinf(a));
+}
+extern "C" int st355_timestep_proj(void* stream, const float* t, void* out, int B, int dim, float scale) {
+  ST_REQUIRE(t && out && dim % 2 == 0 && B > 0, "timestep_proj: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 2.0 * B * dim);
+  int n = B * (dim / 2);
+  hipLaunchKernelGGL(k_timestep_proj, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16*)out, B, dim, scale);
+  return st355_check_launch("timestep_proj");
+}
+
+template <int OP>  // 0 silu, 1 add
+__global__ void __launch_bounds__(EW_THREADS) k_unary_binary(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                            bf16* __restrict__ y, int64_t n) {
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    bf16x8 av = *(const bf16x8*)(a + i * 8), bv, o;
+    if (OP == 1) bv = *(const bf16x8*)(b + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float f = bf2f(av[j]);
+      if (OP == 0) o[j] = f2bf(f / (1.f + __expf(-f)));
+      else o[j] = f2bf(f + bf2f(bv[j]));
+    }
+    *(bf16x8*)(y + i * 8) = o;
+  }
+  // tail (n not a multiple of 8)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    int64_t i = (nvec << 3) + threadIdx.x;
+    float f = bf2f(a[i]);
+    y[i] = (OP == 0) ? f2bf(f / (1.f + __expf(-f))) : f2bf(f + bf2f(b[i]));
+  }
+}
+extern "C" int st355_silu(void* stream, const void* x, void* y, int64_t n) {
+  ST_REQUIRE(x && y && n > 0, "silu: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 4.0 * n, 4.0 * n);
+  hipLaunchKernelGGL(k_unary_binary<0>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
+                     (const bf16*)nullptr, (bf16*)y, n);
+  return st355_check_launch("silu");
+}
+extern "C" int st355_add(void* stream, const void* a, const void* b, void* y, int64_t n) {
+  ST_REQUIRE(a && b && y && n > 0, "add: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 1.0 * n, 6.0 * n);
+  hipLaunchKernelGGL(k_unary_binary<1>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)a,
+                     (const bf16*)b, (bf16*)y, n);
+  return st355_check_launch("add");
+}
+
+__global__ void __launch_bounds__(EW_THREADS) k_scale_cols(const bf16* __restrict__ in, int64_t ld_in, const bf16* __restrict__ gate,
+                                                          int64_t gate_stride, int64_t rows_per_batch, bf16* __restrict__ out,
+                                                          int64_t ld_out, int64_t M, int64_t N) {
+  const int64_t nv = N >> 3;
+  const int64_t total = M * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / nv, c = (i % nv) * 8;
+    const int64_t b = m / rows_per_batch;
+    bf16x8 v = *(const bf16x8*)(in + m * ld_in + c);
+    bf16x8 g = *(const bf16x8*)(gate + b * gate_stride + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f2bf(bf2f(v[j]) * bf2f(g[j]));
+    *(bf16x8*)(out + m * ld_out + c) = o;
+  }
+}
+extern "C" int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* gate, int64_t gate_stride,
+                                int64_t rows_per_batch, void* out, int64_t ld_out, int64_t M, int64_t N) {
+  ST_REQUIRE(in && gate && out && N % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && gate_stride % 8 == 0 && rows_per_batch > 0,
+             "scale_cols: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 1.0 * M * N, 4.0 * M * N);
+  hipLaunchKernelGGL(k_scale_cols, dim3(ew_blocks(M * N / 8)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)in, ld_in,
+                     (const bf16*)gate, gate_stride, rows_per_batch, (bf16*)out, ld_out, M, N);
+  return st355_check_launch("scale_cols");
+}

@@ -1,0 +1,403 @@
+// norm_rope.hip — the memory-bound glue of an MMDiT block:
+//   K5  AdaLN modulate          y = LN(x) * (1 + scale_b) + shift_b           (fwd + bwd)
+//   K6  per-head RMSNorm(q,k) + RoPE + head-major re-layout of q,k,v          (fwd + bwd)
+// Each kernel is one pass over HBM with 16-byte accesses; rows live in registers between the
+// statistics pass and the normalise pass (no re-read).
+#include "common.h"
+
+// ================================================================================================
+// K5: LayerNorm (no affine) + modulation. One wave per row, NC 16-byte chunks per lane.
+// ================================================================================================
+template <int NC>
+__global__ void __launch_bounds__(256) k_ln_mod_fwd(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ scale,
+                                                   const bf16* __restrict__ shift, int64_t mod_stride, int64_t rows_per_batch,
+                                                   bf16* __restrict__ y, int64_t ldy, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t b = row / rows_per_batch;
+  const bf16* xr = x + row * ldx;
+  float v[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+      bf16x8 t = *(const bf16x8*)(xr + idx);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { v[c][j] = bf2f(t[j]); s += v[c][j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[c][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { float d = v[c][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const bf16* sc = scale + b * mod_stride;
+  const bf16* sh = shift + b * mod_stride;
+  bf16* yr = y + row * ldy;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+      bf16x8 scv = *(const bf16x8*)(sc + idx);
+      bf16x8 shv = *(const bf16x8*)(sh + idx);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = f2bf((v[c][j] - mean) * rstd * (1.f + bf2f(scv[j])) + bf2f(shv[j]));
+      *(bf16x8*)(yr + idx) = o;
+    }
+  }
+}
+
+extern "C" int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,
+                                     int64_t mod_stride, int64_t rows_per_batch, void* y, int64_t ldy, int64_t rows, int D,
+                                     float eps) {
+  ST_REQUIRE(x && scale && shift && y, "ln_modulate_fwd: null pointer");
+  ST_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 8 == 0 && rows > 0 && rows_per_batch > 0,
+             "ln_modulate_fwd: bad shape D=%d", D);
+  ProfScope ps(stream, ST355_K_LN_MOD, 8.0 * rows * D, 4.0 * rows * D);
+  dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+#define LAUNCH(NC)                                                                                                       \
+  hipLaunchKernelGGL(k_ln_mod_fwd<NC>, grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)scale,       \
+                     (const bf16*)shift, mod_stride, rows_per_batch, (bf16*)y, ldy, rows, D, eps)
+  if (D <= 512) LAUNCH(1);
+  else if (D <= 1024) LAUNCH(2);
+  else if (D <= 1536) LAUNCH(3);
+  else if (D <= 2048) LAUNCH(4);
+  else if (D <= 3072) LAUNCH(6);
+  else LAUNCH(8);
+#undef LAUNCH
+  return st355_check_launch("ln_modulate_fwd");
+}
+
+// backward: g = dy*(1+scale); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres];  dxg = gate*dx
+template <int NC>
+__global__ void __launch_bounds__(256) k_ln_mod_bwd(const bf16* __restrict__ dy, int64_t lddy, const bf16* __restrict__ x,
+                                                   int64_t ldx, const bf16* __restrict__ scale, int64_t mod_stride,
+                                                   int64_t rows_per_batch, const bf16* __restrict__ dres, int64_t lddres,
+                                                   const bf16* __restrict__ gate, int64_t gate_stride, bf16* __restrict__ dx,
+                                                   int64_t lddx, bf16* __restrict__ dxg, int64_t lddxg, int64_t rows, int D,
+                                                   float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t b = row / rows_per_batch;
+  const bf16* xr = x + row * ldx;
+  const bf16* dyr = dy + row * lddy;
+  const bf16* sc = scale + b * mod_stride;
+  float v[NC][8], g[NC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+      bf16x8 t = *(const bf16x8*)(xr + idx);
+      bf16x8 d = *(const bf16x8*)(dyr + idx);
+      bf16x8 scv = *(const bf16x8*)(sc + idx);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        v[c][j] = bf2f(t[j]);
+        s += v[c][j];
+        g[c][j] = bf2f(d[j]) * (1.f + bf2f(scv[j]));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { v[c][j] = 0.f; g[c][j] = 0.f; }
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { float d = v[c][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float xh = (v[c][j] - mean) * rstd;
+        v[c][j] = xh;
+        sg += g[c][j];
+        sgx += g[c][j] * xh;
+      }
+    }
+  }
+  const float c1 = wave_sum(sg) / (float)D;
+  const float c2 = wave_sum(sgx) / (float)D;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = rstd * (g[c][j] - c1 - v[c][j] * c2);
+      if (dres) {
+        bf16x8 r = *(const bf16x8*)(dres + row * lddres + idx);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] += bf2f(r[j]);
+      }
+      bf16x8 ov;
+#pragma unroll
+      for (int j = 0; j < 8; j++) ov[j] = f2bf(o[j]);
+      *(bf16x8*)(dx + row * lddx + idx) = ov;
+      if (dxg) {
+        bf16x8 gv = *(const bf16x8*)(gate + b * gate_stride + idx);
+        bf16x8 og;
+#pragma unroll
+        for (int j = 0; j < 8; j++) og[j] = f2bf(bf2f(ov[j]) * bf2f(gv[j]));
+        *(bf16x8*)(dxg + row * lddxg + idx) = og;
+      }
+    }
+  }
+}
+
+extern "C" int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* scale,
+                                     int64_t mod_stride, int64_t rows_per_batch, const void* dres, int64_t lddres,
+                                     const void* gate, int64_t gate_stride, void* dx, int64_t lddx, void* dxg, int64_t lddxg,
+                                     int64_t rows, int D, float eps) {
+  ST_REQUIRE(dy && x && scale && dx, "ln_modulate_bwd: null pointer");
+  ST_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && mod_stride % 8 == 0 && rows > 0 &&
+                 rows_per_batch > 0, "ln_modulate_bwd: bad shape D=%d", D);
+  if (dres) ST_REQUIRE(lddres % 8 == 0, "ln_modulate_bwd: lddres");
+  if (dxg) ST_REQUIRE(gate && gate_stride % 8 == 0 && lddxg % 8 == 0, "ln_modulate_bwd: gate missing for dxg");
+  ProfScope ps(stream, ST355_K_LN_MOD, 16.0 * rows * D, (6.0 + (dres ? 2.0 : 0.0) + (dxg ? 2.0 : 0.0)) * rows * D);
+  dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+#define LAUNCH(NC)                                                                                                        \
+  hipLaunchKernelGGL(k_ln_mod_bwd<NC>, grid, block, 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const bf16*)x, ldx,     \
+                     (const bf16*)scale, mod_stride, rows_per_batch, (const bf16*)dres, lddres, (const bf16*)gate,          \
+                     gate_stride, (bf16*)dx, lddx, (bf16*)dxg, lddxg, rows, D, eps)
+  if (D <= 512) LAUNCH(1);
+  else if (D <= 1024) LAUNCH(2);
+  else if (D <= 1536) LAUNCH(3);
+  else if (D <= 2048) LAUNCH(4);
+  else if (D <= 3072) LAUNCH(6);
+  else LAUNCH(8);
+#undef LAUNCH
+  return st355_check_launch("ln_modulate_bwd");
+}
+
+// ================================================================================================
+// K6: RMSNorm(q,k) + RoPE + re-layout.  grid = (ceil(S_part/64), H, B), 256 threads.
+// A thread owns 8 contiguous head channels (4 rotation pairs) of one token; HD/8 threads share a
+// token-head row and reduce sum(x^2) with xor-shuffles.  Transposed copies go through an LDS tile
+// with an odd dword pitch (2-way conflicts at most).
+// ================================================================================================
+#define TP 130  // LDS pitch (elements) of the [64 tok][HD] staging tile: 65 dwords -> odd
+
+template <int HD>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = HD / 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int HD>
+__global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict__ qkv, int64_t ld, const bf16* __restrict__ wq,
+                                                         const bf16* __restrict__ wk, const float* __restrict__ cosT,
+                                                         const float* __restrict__ sinT, bf16* __restrict__ Q, bf16* __restrict__ K,
+                                                         bf16* __restrict__ Qt, bf16* __restrict__ Kt, bf16* __restrict__ Vt, int H,
+                                                         int S_part, int pos0, int S, int Sp, float eps) {
+  constexpr int TPR = HD / 8;            // threads per token row
+  constexpr int TOK_PER_PASS = 256 / TPR;
+  __shared__ __attribute__((aligned(16))) bf16 tile[3][64 * TP];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int c = tid % TPR;               // 16-byte chunk inside the head row
+  const int64_t Dm = (int64_t)H * HD;    // model width
+  const int64_t bh = (int64_t)b * H + h;
+
+  float wqv[8], wkv[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    wqv[j] = wq ? bf2f(wq[c * 8 + j]) : 1.f;
+    wkv[j] = wk ? bf2f(wk[c * 8 + j]) : 1.f;
+  }
+
+  for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    const int t = t0 + tl;
+    const bool valid = t < S_part;
+    const int tt = valid ? t : S_part - 1;
+    const bf16* row = qkv + ((int64_t)b * S_part + tt) * ld + (int64_t)h * HD + c * 8;
+    bf16x8 qv = *(const bf16x8*)(row);
+    bf16x8 kv = *(const bf16x8*)(row + Dm);
+    bf16x8 vv = *(const bf16x8*)(row + 2 * Dm);
+    const int pos = pos0 + tt;
+    const float* cp = cosT + (int64_t)pos * HD + c * 8;
+    const float* sp = sinT + (int64_t)pos * HD + c * 8;
+    float cs[8], sn[8];
+    *(f32x4*)&cs[0] = *(const f32x4*)cp; *(f32x4*)&cs[4] = *(const f32x4*)(cp + 4);
+    *(f32x4*)&sn[0] = *(const f32x4*)sp; *(f32x4*)&sn[4] = *(const f32x4*)(sp + 4);
+    float qf[8], kf[8], sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { qf[j] = bf2f(qv[j]); kf[j] = bf2f(kv[j]); sq += qf[j] * qf[j]; sk += kf[j] * kf[j]; }
+    const float rq = wq ? rsqrtf(group_sum<HD>(sq) / (float)HD + eps) : 1.f;
+    const float rk = wk ? rsqrtf(group_sum<HD>(sk) / (float)HD + eps) : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { qf[j] *= rq * wqv[j]; kf[j] *= rk * wkv[j]; }
+    bf16x8 qo, ko;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      // out = x*cos + rot(x)*sin, rot = (-x_imag, x_real) on interleaved pairs (flux/transformer.py:91-98)
+      qo[j] = f2bf(qf[j] * cs[j] - qf[j + 1] * sn[j]);
+      qo[j + 1] = f2bf(qf[j + 1] * cs[j + 1] + qf[j] * sn[j + 1]);
+      ko[j] = f2bf(kf[j] * cs[j] - kf[j + 1] * sn[j]);
+      ko[j + 1] = f2bf(kf[j + 1] * cs[j + 1] + kf[j] * sn[j + 1]);
+    }
+    if (valid) {
+      const int64_t o = (bh * S + pos) * HD + c * 8;
+      *(bf16x8*)(Q + o) = qo;
+      *(bf16x8*)(K + o) = ko;
+    }
+    // stage for the transposed copies (4-byte LDS writes: rows are only 4-byte aligned at pitch 130)
+    uint32_t* tq = (uint32_t*)(&tile[0][tl * TP + c * 8]);
+    uint32_t* tk = (uint32_t*)(&tile[1][tl * TP + c * 8]);
+    uint32_t* tv = (uint32_t*)(&tile[2][tl * TP + c * 8]);
+    const u32x4 qw = *(const u32x4*)&qo, kw = *(const u32x4*)&ko, vw = *(const u32x4*)&vv;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { tq[j] = qw[j]; tk[j] = kw[j]; tv[j] = vw[j]; }
+  }
+  __syncthreads();
+  // transposed rows: each thread emits 8 consecutive tokens of one channel
+  const int pbase = pos0 + t0;
+  const int nvalid = min(64, S_part - t0);
+  for (int i = tid; i < HD * 8; i += 256) {
+    const int d = i >> 3, tc = i & 7;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      bf16* dst = (w == 0 ? Qt : (w == 1 ? Kt : Vt)) + (bh * HD + d) * (int64_t)Sp + pbase + tc * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = tile[w][(tc * 8 + e) * TP + d];
+      if (tc * 8 + 8 <= nvalid && (((uintptr_t)dst) & 15) == 0) {
+        *(bf16x8*)dst = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (tc * 8 + e < nvalid) dst[e] = o[e];
+      }
+    }
+  }
+}
+
+extern "C" int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const void* wq, const void* wk,
+                                      const float* cos, const float* sin, void* Q, void* K, void* Qt, void* Kt, void* Vt, int B,
+                                      int H, int d, int S_part, int pos0, int S, int Sp, float eps) {
+  ST_REQUIRE(qkv && cos && sin && Q && K && Qt && Kt && Vt, "qk_norm_rope_fwd: null pointer");
+  ST_REQUIRE(ld_qkv % 8 == 0 && Sp % 64 == 0 && Sp >= S && pos0 + S_part <= S && S_part > 0, "qk_norm_rope_fwd: bad shape");
+  ST_REQUIRE(d == 128 || d == 64, "qk_norm_rope_fwd: head_dim %d not built", d);
+  const double n = (double)B * S_part * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 20.0 * n, (6.0 + 10.0) * n);
+  dim3 grid((S_part + 63) / 64, H, B), block(256);
+  if (d == 128)
+    hipLaunchKernelGGL(k_qk_norm_rope_fwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, (const bf16*)wq,
+                       (const bf16*)wk, cos, sin, (bf16*)Q, (bf16*)K, (bf16*)Qt, (bf16*)Kt, (bf16*)Vt, H, S_part, pos0, S, Sp, eps);
+  else
+    hipLaunchKernelGGL(k_qk_norm_rope_fwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, (const bf16*)wq,
+                       (const bf16*)wk, cos, sin, (bf16*)Q, (bf16*)K, (bf16*)Qt, (bf16*)Kt, (bf16*)Vt, H, S_part, pos0, S, Sp, eps);
+  return st355_check_launch("qk_norm_rope_fwd");
+}
+
+// backward of RoPE (transpose of the rotation) then RMSNorm:  y = x * r * w, r = rsqrt(mean(x^2)+eps)
+//   dx = r*w*dy - x * r^3 * mean(x*w*dy)
+template <int HD>
+__global__ void __launch_bounds__(256) k_qk_norm_rope_bwd(const bf16* __restrict__ dQ, const bf16* __restrict__ dK,
+                                                         const bf16* __restrict__ qkv, int64_t ld, const bf16* __restrict__ wq,
+                                                         const bf16* __restrict__ wk, const float* __restrict__ cosT,
+                                                         const float* __restrict__ sinT, bf16* __restrict__ dqkv, int64_t ldd, int H,
+                                                         int S_part, int pos0, int S, float eps) {
+  constexpr int TPR = HD / 8;
+  constexpr int TOK_PER_PASS = 256 / TPR;
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int c = tid % TPR;
+  const int64_t Dm = (int64_t)H * HD;
+  const int64_t bh = (int64_t)b * H + h;
+  float wv[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    wv[0][j] = wq ? bf2f(wq[c * 8 + j]) : 1.f;
+    wv[1][j] = wk ? bf2f(wk[c * 8 + j]) : 1.f;
+  }
+  for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    const int t = t0 + tl;
+    const bool valid = t < S_part;
+    const int tt = valid ? t : S_part - 1;
+    const int pos = pos0 + tt;
+    const float* cp = cosT + (int64_t)pos * HD + c * 8;
+    const float* sp = sinT + (int64_t)pos * HD + c * 8;
+    float cs[8], sn[8];
+    *(f32x4*)&cs[0] = *(const f32x4*)cp; *(f32x4*)&cs[4] = *(const f32x4*)(cp + 4);
+    *(f32x4*)&sn[0] = *(const f32x4*)sp; *(f32x4*)&sn[4] = *(const f32x4*)(sp + 4);
+    const bf16* xrow = qkv + ((int64_t)b * S_part + tt) * ld + (int64_t)h * HD + c * 8;
+    bf16* drow = dqkv + ((int64_t)b * S_part + tt) * ldd + (int64_t)h * HD + c * 8;
+    const int64_t go = (bh * S + pos) * HD + c * 8;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const bool has_norm = (w == 0) ? (wq != nullptr) : (wk != nullptr);
+      bf16x8 gv = *(const bf16x8*)((w == 0 ? dQ : dK) + go);
+      bf16x8 xv = *(const bf16x8*)(xrow + w * Dm);
+      float g[8], dy[8], xf[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { g[j] = bf2f(gv[j]); xf[j] = bf2f(xv[j]); }
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        // forward: o0 = y0*c0 - y1*s0 ; o1 = y1*c1 + y0*s1   =>  dy0 = g0*c0 + g1*s1 ; dy1 = g1*c1 - g0*s0
+        dy[j] = g[j] * cs[j] + g[j + 1] * sn[j + 1];
+        dy[j + 1] = g[j + 1] * cs[j + 1] - g[j] * sn[j];
+      }
+      bf16x8 o;
+      if (has_norm) {
+        float sx = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sx += xf[j] * xf[j]; sxy += xf[j] * wv[w][j] * dy[j]; }
+        const float r = rsqrtf(group_sum<HD>(sx) / (float)HD + eps);
+        const float m = group_sum<HD>(sxy) / (float)HD;
+        const float r3m = r * r * r * m;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = f2bf(r * wv[w][j] * dy[j] - xf[j] * r3m);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = f2bf(dy[j]);
+      }
+      if (valid) *(bf16x8*)(drow + w * Dm) = o;
+    }
+  }
+}
+
+extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv, const void* wq,
+                                      const void* wk, const float* cos, const float* sin, void* dqkv, int64_t ld_dqkv, int B, int H,
+                                      int d, int S_part, int pos0, int S, float eps) {
+  ST_REQUIRE(dQ && dK && qkv && cos && sin && dqkv, "qk_norm_rope_bwd: null pointer");
+  ST_REQUIRE(ld_qkv % 8 == 0 && ld_dqkv % 8 == 0 && pos0 + S_part <= S && S_part > 0, "qk_norm_rope_bwd: bad shape");
+  ST_REQUIRE(d == 128 || d == 64, "qk_norm_rope_bwd: head_dim %d not built", d);
+  const double n = (double)B * S_part * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 30.0 * n, 12.0 * n);
+  dim3 grid((S_part + 63) / 64, H, B), block(256);
+  if (d == 128)
+    hipLaunchKernelGGL(k_qk_norm_rope_bwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK,
+                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps);
+  else
+    hipLaunchKernelGGL(k_qk_norm_rope_bwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK,
+                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps);
+  return st355_check_launch("qk_norm_rope_bwd");
+}
