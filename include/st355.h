@@ -83,7 +83,7 @@ int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* ga
                      int64_t rows_per_batch, void* out, int64_t ld_out, int64_t M, int64_t N);
 
 /* ---- GEMM family (K4,K8,K9,K11,K12): C[M,N] = A[M,K] B[N,K]^T (+ A2[M,K2] B2[N,K2]^T) ---------- */
-enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3 };
+enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3, ST355_EPI_ADD = 4 /* C = acc + aux_in */ };
 typedef struct st355_gemm_args {
   const void* A;  int64_t lda;      /* activations [M,K]  bf16                                         */
   const void* B;  int64_t ldb;      /* weights     [N,K]  bf16 (nn.Linear.weight layout)               */
@@ -118,7 +118,8 @@ int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy, const void
                           void* dx, int64_t lddx, void* dxg, int64_t lddxg, int64_t rows, int D, float eps);
 
 /* ---- K6: per-head RMSNorm(q,k) + RoPE + head-major re-layout (flux/transformer.py:127-141, 73-98) ---- */
-/* qkv: [B*S_part, 3*H*d] token-major (q | k | v).  Token t of batch b lands at joint position pos0 + t.
+/* qkv: JOINT buffer [B*S, 3*H*d] token-major (q | k | v); this call handles the S_part tokens of every batch that sit at
+ * joint positions pos0 .. pos0+S_part-1 (row b*S + pos0 + t) — one call per stream (txt / img) because their norm weights differ.
  * Outputs (joint sequence length S, padded Sp multiple of 64):
  *   Q,K : [B,H,S,d]  bf16 (normed + rotated);  Qt,Kt,Vt : [B,H,d,Sp] bf16 (transposed copies; pad stays 0)
  * cos,sin: [S,d] fp32 interleave-repeated tables (FluxPosEmbed).  wq,wk: [d] bf16 RMSNorm weights (NULL => no norm). */
@@ -161,10 +162,14 @@ int st355_ema_update(void* stream, void* shadow, const void* param, int64_t n, f
 /* K15: sum of squares (fp32 out[0]) and max-abs (out[1]) of a flat gradient; out zeroed by the call */
 int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2);
 
-/* LoRA operand packing (K12): from fp32 A[r,K], B[N,r] make the bf16 GEMM operands
- *   A_pad [64,K] (rows>=r zero), A_T [K,64], Bs_pad [N,64] = scale*B, Bs_T [64,N]. */
+/* LoRA operand packing (K12): from fp32 A[r,K], B[N,r] write the bf16 GEMM operands of ONE adapter into the (zero-initialised)
+ * block-structured operands of a fused projection group with K2 padded low-rank columns and N_total outputs:
+ *   A_cat   [K2,K]       rows  k2_off..k2_off+r-1      = A
+ *   A_cat_T [K,K2]       cols  k2_off..                = A^T
+ *   B_blk   [N_total,K2] rows n_off..n_off+N-1, cols k2_off.. = scale*B      (block diagonal across the group)
+ *   B_blk_T [K2,N_total] the transpose of B_blk */
 int st355_lora_pack(void* stream, const float* A, const float* Bm, int r, int K, int N, float scale,
-                    void* A_pad, void* A_T, void* Bs_pad, void* Bs_T);
+                    void* A_cat, void* A_cat_T, void* B_blk, void* B_blk_T, int K2, int k2_off, int N_total, int n_off);
 
 #ifdef __cplusplus
 }

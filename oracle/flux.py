@@ -1,0 +1,343 @@
+"""Plain-torch CPU restatement of the Flux.1 MMDiT forward (autograd supplies the backward).  TEST INFRASTRUCTURE.
+
+Control flow follows the reference's in-tree transformer:
+    FluxTransformer2DModel.forward        simpletuner/helpers/models/flux/transformer.py:940-1513
+    FluxTransformerBlock.forward          .../flux/transformer.py:607-687   (_ffn_forward :563-605)
+    FluxSingleTransformerBlock.forward    .../flux/transformer.py:473-510   (_ffn_forward :453-471)
+    FluxAttnProcessor2_0.__call__         .../flux/transformer.py:116-224
+    _apply_rotary_emb_anyshape            .../flux/transformer.py:73-98
+    Flux._model_predict_single            simpletuner/helpers/models/flux/model.py:707-864
+    pack/unpack/prepare_latent_image_ids  simpletuner/helpers/models/flux/__init__.py:25-63
+Leaf modules come from diffusers (>=0.36, un-vendored; SURVEY.md Appendix A lists the in-tree corroboration):
+    Timesteps / TimestepEmbedding / CombinedTimestep(Guidance)TextProjEmbeddings, AdaLayerNormZero(-Single/-Continuous),
+    RMSNorm, FluxPosEmbed (theta 1e4, axes (16,56,56)), FeedForward("gelu-approximate"), Attention projections.
+LoRA follows peft's LoraLayer: y = base(x) + scaling * lora_B(lora_A(x)), scaling = alpha / r
+    (corroborated in-tree at simpletuner/helpers/training/quantisation/peft_workarounds.py:70-116).
+
+Parameters are a flat dict keyed by the diffusers state-dict names, so the same dict initialises the HIP model.
+PARITY UNPINNED: the reference holds no golden tensors for this network.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class FluxConfig:
+    # flux/transformer.py:725-742 defaults (Flux.1-dev sets guidance_embeds=True)
+    in_channels: int = 64
+    num_layers: int = 19
+    num_single_layers: int = 38
+    attention_head_dim: int = 128
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = True
+    axes_dims_rope: Tuple[int, ...] = (16, 56, 56)
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter construction (seed-deterministic synthetic weights)
+# ------------------------------------------------------------------------------------------------
+def param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
+    D, d = cfg.inner_dim, cfg.attention_head_dim
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(name, out_f, in_f):
+        s[name + ".weight"] = (out_f, in_f)
+        s[name + ".bias"] = (out_f,)
+
+    lin("x_embedder", D, cfg.in_channels)
+    lin("context_embedder", D, cfg.joint_attention_dim)
+    lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    if cfg.guidance_embeds:
+        lin("time_text_embed.guidance_embedder.linear_1", D, 256)
+        lin("time_text_embed.guidance_embedder.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", D, cfg.pooled_projection_dim)
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}."
+        lin(p + "norm1.linear", 6 * D, D)
+        lin(p + "norm1_context.linear", 6 * D, D)
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(p + "attn." + n, D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            s[p + f"attn.{n}.weight"] = (d,)
+        lin(p + "ff.net.0.proj", 4 * D, D)
+        lin(p + "ff.net.2", D, 4 * D)
+        lin(p + "ff_context.net.0.proj", 4 * D, D)
+        lin(p + "ff_context.net.2", D, 4 * D)
+    for i in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{i}."
+        lin(p + "norm.linear", 3 * D, D)
+        lin(p + "proj_mlp", 4 * D, D)
+        lin(p + "proj_out", D, 5 * D)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(p + "attn." + n, D, D)
+        for n in ("norm_q", "norm_k"):
+            s[p + f"attn.{n}.weight"] = (d,)
+    lin("norm_out.linear", 2 * D, D)
+    lin("proj_out", cfg.in_channels, D)
+    return s
+
+
+def init_params(cfg: FluxConfig, seed: int = 42, dtype=torch.float32, std: float = 0.02, device="cpu") -> Dict[str, torch.Tensor]:
+    """weights ~ N(0, std^2) scaled by 1/sqrt(fan_in/256) so activations stay O(1) through many blocks; biases small
+    nonzero; RMSNorm weights ~ 1; AdaLN linears nonzero so gates pass gradient (true zero-init would block it)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_added_q.weight") or name.endswith("norm_added_k.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = shape[1]
+            t = torch.randn(shape, generator=g) * (1.0 / math.sqrt(fan_in))
+        out[name] = t.to(dtype=dtype, device=device)
+    return out
+
+
+def lora_targets(cfg: FluxConfig, which: str = "default"):
+    """peft target modules for Flux (flux/model.py:65 DEFAULT_LORA_TARGET = to_k,to_q,to_v,to_out.0 (+add_*_proj, to_add_out
+    for 'all')).  'default' here = the attention projections of both streams + single blocks."""
+    t = []
+    for i in range(cfg.num_layers):
+        p = f"transformer_blocks.{i}.attn."
+        t += [p + n for n in ("to_q", "to_k", "to_v", "to_out.0")]
+        if which == "all":
+            t += [p + n for n in ("add_q_proj", "add_k_proj", "add_v_proj", "to_add_out")]
+    for i in range(cfg.num_single_layers):
+        p = f"single_transformer_blocks.{i}.attn."
+        t += [p + n for n in ("to_q", "to_k", "to_v")]
+    return t
+
+
+def init_lora(cfg: FluxConfig, params, rank: int, seed: int = 7, b_std: float = 1e-3, dtype=torch.float32, which="default"):
+    """A ~ kaiming-uniform(a=sqrt(5)) (peft default), B ~ N(0, b_std^2) (true init is 0; nonzero so the delta is visible)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lora = {}
+    for name in lora_targets(cfg, which):
+        out_f, in_f = params[name + ".weight"].shape
+        bound = 1.0 / math.sqrt(in_f)
+        A = (torch.rand(rank, in_f, generator=g) * 2 - 1) * bound
+        Bm = torch.randn(out_f, rank, generator=g) * b_std
+        lora[name] = (A.to(dtype), Bm.to(dtype))
+    return lora
+
+
+# ------------------------------------------------------------------------------------------------
+# leaves
+# ------------------------------------------------------------------------------------------------
+def timestep_proj(t: torch.Tensor, dim: int = 256) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) (fp32)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([emb.cos(), emb.sin()], dim=-1)  # flip_sin_to_cos=True -> cos first
+
+
+def linear(x, P, name, lora=None, lora_scale: float = 1.0):
+    y = F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    if lora is not None and name in lora:
+        A, Bm = lora[name]
+        y = y + lora_scale * F.linear(F.linear(x, A.to(x.dtype)), Bm.to(x.dtype))
+    return y
+
+
+def mlp_embed(x, P, prefix):  # TimestepEmbedding / PixArtAlphaTextProjection(act="silu")
+    return linear(F.silu(linear(x, P, prefix + ".linear_1")), P, prefix + ".linear_2")
+
+
+def time_text_embed(P, cfg, timestep, guidance, pooled):
+    dt = pooled.dtype
+    emb = mlp_embed(timestep_proj(timestep).to(dt), P, "time_text_embed.timestep_embedder")
+    if cfg.guidance_embeds:
+        emb = emb + mlp_embed(timestep_proj(guidance).to(dt), P, "time_text_embed.guidance_embedder")
+    return emb + mlp_embed(pooled, P, "time_text_embed.text_embedder")
+
+
+def layer_norm(x, eps=1e-6):
+    return F.layer_norm(x, (x.shape[-1],), eps=eps)
+
+
+def rms_norm(x, w, eps=1e-6):
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
+
+
+def rope_tables(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10000.0):
+    """FluxPosEmbed: per axis freqs = 1/theta^(arange(0,d,2)/d) in float64; cos/sin repeat_interleave(2) -> fp32 [S, sum(d)]."""
+    cos_out, sin_out = [], []
+    pos = ids.float()
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+        f = torch.outer(pos[:, i].to(torch.float64), freqs)
+        cos_out.append(f.cos().repeat_interleave(2, dim=1).float())
+        sin_out.append(f.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos_out, dim=-1), torch.cat(sin_out, dim=-1)
+
+
+def apply_rope(x, cos, sin):
+    """flux/transformer.py:73-98 (use_real, unbind_dim=-1): out = x*cos + stack[-x_imag, x_real]*sin, computed in >= fp32."""
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    ct = torch.promote_types(x.dtype, torch.float32)
+    return (x.to(ct) * cos[None, None].to(ct) + rot.to(ct) * sin[None, None].to(ct)).to(x.dtype)
+
+
+def sdpa(q, k, v, key_bias=None):
+    scale = 1.0 / math.sqrt(q.shape[-1])
+    s = (q @ k.transpose(-1, -2)) * scale
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    return s.softmax(-1) @ v
+
+
+def prepare_latent_image_ids(height: int, width: int) -> torch.Tensor:
+    """flux/__init__.py:48-63 -> [ (H/2)(W/2), 3 ] fp32"""
+    ids = torch.zeros(height // 2, width // 2, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(height // 2)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(width // 2)[None, :]
+    return ids.reshape(-1, 3).float()
+
+
+def pack_latents(latents):
+    B, C, H, W = latents.shape
+    return latents.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), C * 4)
+
+
+def unpack_latents(packed, H, W):
+    """flux/__init__.py:34-45 with height/width already in latent units (vae_scale_factor folded)."""
+    B, N, ch = packed.shape
+    x = packed.view(B, H // 2, W // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+    return x.reshape(B, ch // 4, H, W)
+
+
+# ------------------------------------------------------------------------------------------------
+# blocks
+# ------------------------------------------------------------------------------------------------
+def _heads(x, H):
+    B, S, D = x.shape
+    return x.view(B, S, H, D // H).transpose(1, 2)
+
+
+def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None, taps=None):
+    p = f"transformer_blocks.{i}."
+    H = cfg.num_attention_heads
+    st = F.silu(temb)
+    m = linear(st, P, p + "norm1.linear")
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m.chunk(6, dim=1)
+    c = linear(st, P, p + "norm1_context.linear")
+    c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c.chunk(6, dim=1)
+    n = layer_norm(hidden) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    cn = layer_norm(enc) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
+
+    a = p + "attn."
+    q = rms_norm(_heads(linear(n, P, a + "to_q", lora, lora_scale), H), P[a + "norm_q.weight"])
+    k = rms_norm(_heads(linear(n, P, a + "to_k", lora, lora_scale), H), P[a + "norm_k.weight"])
+    v = _heads(linear(n, P, a + "to_v", lora, lora_scale), H)
+    cq = rms_norm(_heads(linear(cn, P, a + "add_q_proj", lora, lora_scale), H), P[a + "norm_added_q.weight"])
+    ck = rms_norm(_heads(linear(cn, P, a + "add_k_proj", lora, lora_scale), H), P[a + "norm_added_k.weight"])
+    cv = _heads(linear(cn, P, a + "add_v_proj", lora, lora_scale), H)
+    q = torch.cat([cq, q], dim=2); k = torch.cat([ck, k], dim=2); v = torch.cat([cv, v], dim=2)   # [txt || img]
+    q = apply_rope(q, cos, sin); k = apply_rope(k, cos, sin)
+    o = sdpa(q, k, v, key_bias)
+    B, _, S, _ = o.shape
+    o = o.transpose(1, 2).reshape(B, S, -1)
+    T = enc.shape[1]
+    co, io = o[:, :T], o[:, T:]
+    if taps is not None:
+        taps[f"d{i}.attn"] = o
+    hidden = hidden + gate_msa[:, None] * linear(io, P, a + "to_out.0", lora, lora_scale)
+    enc = enc + c_gate_msa[:, None] * linear(co, P, a + "to_add_out", lora, lora_scale)
+
+    n2 = layer_norm(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    ff = linear(F.gelu(linear(n2, P, p + "ff.net.0.proj"), approximate="tanh"), P, p + "ff.net.2")
+    hidden = hidden + gate_mlp[:, None] * ff
+    cn2 = layer_norm(enc) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+    cff = linear(F.gelu(linear(cn2, P, p + "ff_context.net.0.proj"), approximate="tanh"), P, p + "ff_context.net.2")
+    enc = enc + c_gate_mlp[:, None] * cff
+    enc = torch.nan_to_num(enc, nan=0.0, posinf=65504, neginf=-65504)
+    return enc, hidden
+
+
+def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None):
+    p = f"single_transformer_blocks.{i}."
+    H = cfg.num_attention_heads
+    m = linear(F.silu(temb), P, p + "norm.linear")
+    shift, scale, gate = m.chunk(3, dim=1)
+    n = layer_norm(x) * (1 + scale[:, None]) + shift[:, None]
+    a = p + "attn."
+    q = rms_norm(_heads(linear(n, P, a + "to_q", lora, lora_scale), H), P[a + "norm_q.weight"])
+    k = rms_norm(_heads(linear(n, P, a + "to_k", lora, lora_scale), H), P[a + "norm_k.weight"])
+    v = _heads(linear(n, P, a + "to_v", lora, lora_scale), H)
+    q = apply_rope(q, cos, sin); k = apply_rope(k, cos, sin)
+    o = sdpa(q, k, v, key_bias)
+    B, _, S, _ = o.shape
+    o = o.transpose(1, 2).reshape(B, S, -1)
+    mlp = F.gelu(linear(n, P, p + "proj_mlp"), approximate="tanh")
+    out = x + gate[:, None] * linear(torch.cat([o, mlp], dim=2), P, p + "proj_out")
+    return torch.nan_to_num(out, nan=0.0, posinf=65504, neginf=-65504)
+
+
+def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                 guidance=None, lora=None, lora_scale: float = 1.0, key_bias=None, taps=None):
+    """flux/transformer.py:940-1513.  hidden_states [B,S_img,64] packed latents; timestep in [0,1] (multiplied by 1000 here,
+    :1003); guidance likewise (:1007).  Returns [B,S_img,64]."""
+    hidden = linear(hidden_states, P, "x_embedder")
+    t = timestep.float() * 1000
+    g = guidance.float() * 1000 if (guidance is not None and cfg.guidance_embeds) else None
+    temb = time_text_embed(P, cfg, t, g, pooled_projections)
+    enc = linear(encoder_hidden_states, P, "context_embedder")
+    ids = torch.cat((txt_ids, img_ids), dim=0)
+    cos, sin = rope_tables(ids, cfg.axes_dims_rope)
+    if taps is not None:
+        taps["temb"] = temb; taps["x_embed"] = hidden; taps["ctx_embed"] = enc
+    for i in range(cfg.num_layers):
+        enc, hidden = double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora, lora_scale, key_bias, taps)
+        if taps is not None:
+            taps[f"d{i}.img"] = hidden; taps[f"d{i}.txt"] = enc
+    x = torch.cat([enc, hidden], dim=1)
+    T = enc.shape[1]
+    for i in range(cfg.num_single_layers):
+        x = single_block(P, cfg, i, x, temb, cos, sin, lora, lora_scale, key_bias)
+        if taps is not None:
+            taps[f"s{i}"] = x
+    hidden = x[:, T:]
+    emb = linear(F.silu(temb), P, "norm_out.linear")
+    scale, shift = emb.chunk(2, dim=1)          # AdaLayerNormContinuous: scale FIRST
+    hidden = layer_norm(hidden) * (1 + scale[:, None]) + shift[:, None]
+    return linear(hidden, P, "proj_out")
+
+
+def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, guidance_value: float = 1.0, lora=None,
+                       lora_scale=1.0, taps=None):
+    """Flux._model_predict_single (flux/model.py:707-864): pack, ids, t/1000, guidance vector, transformer, unpack."""
+    B, C, Hh, Ww = noisy_latents.shape
+    packed = pack_latents(noisy_latents)
+    img_ids = prepare_latent_image_ids(Hh, Ww)
+    txt_ids = torch.zeros(prompt_embeds.shape[1], 3)
+    guidance = torch.full((B,), float(guidance_value)) if cfg.guidance_embeds else None
+    out = flux_forward(P, cfg, packed, prompt_embeds, pooled, timesteps / 1000.0, img_ids, txt_ids, guidance, lora, lora_scale,
+                       taps=taps)
+    return unpack_latents(out, Hh, Ww)
+
+
+def train_flops_per_image(cfg: FluxConfig, S_img: int, S_txt: int, lora: bool = True) -> float:
+    """per block 2*S*12D^2 (linears) + 4*S^2*D (attention) forward; LoRA step = 2x linears + 3x attention."""
+    D = cfg.inner_dim
+    S = S_img + S_txt
+    nblk = cfg.num_layers + cfg.num_single_layers
+    lin = nblk * 2.0 * S * 12 * D * D
+    att = nblk * 4.0 * S * S * D
+    return (2 * lin + 3 * att) if lora else 3 * (lin + att)

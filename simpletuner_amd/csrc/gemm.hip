@@ -168,6 +168,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm_bf16(GemmP p) {
           bf16x4 rv = *(const bf16x4*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
           for (int b = 0; b < 4; b++) v[b] = bf2f(rv[b]) + bf2f(gv[b]) * v[b];
+        } else if (EPI == ST355_EPI_ADD) {
+          bf16x4 rv = *(const bf16x4*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] += bf2f(rv[b]);
         } else if (EPI == ST355_EPI_MUL_GELU_GRAD) {
           bf16x4 hv = *(const bf16x4*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
@@ -208,7 +212,8 @@ extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
   if (a->epilogue == ST355_EPI_GATE_RESIDUAL)
     ST_REQUIRE(a->gate && a->aux_in && a->rows_per_batch > 0 && a->gate_stride % 4 == 0 && a->ld_aux_in % 4 == 0,
                "gemm: gate/residual epilogue operands missing");
-  if (a->epilogue == ST355_EPI_MUL_GELU_GRAD) ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad epilogue needs aux_in");
+  if (a->epilogue == ST355_EPI_MUL_GELU_GRAD || a->epilogue == ST355_EPI_ADD)
+    ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad/add epilogue needs aux_in");
   if (a->epilogue == ST355_EPI_GELU && a->aux_out) ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
 
   GemmP p;
@@ -228,6 +233,7 @@ extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
     case ST355_EPI_GELU: return launch_gemm<ST355_EPI_GELU>(stream, p);
     case ST355_EPI_GATE_RESIDUAL: return launch_gemm<ST355_EPI_GATE_RESIDUAL>(stream, p);
     case ST355_EPI_MUL_GELU_GRAD: return launch_gemm<ST355_EPI_MUL_GELU_GRAD>(stream, p);
+    case ST355_EPI_ADD: return launch_gemm<ST355_EPI_ADD>(stream, p);
     default: st355_set_error("gemm: unknown epilogue %d", a->epilogue); return ST355_EINVAL;
   }
 }

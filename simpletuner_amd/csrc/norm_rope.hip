@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict
     const int t = t0 + tl;
     const bool valid = t < S_part;
     const int tt = valid ? t : S_part - 1;
-    const bf16* row = qkv + ((int64_t)b * S_part + tt) * ld + (int64_t)h * HD + c * 8;
+    const bf16* row = qkv + ((int64_t)b * S + pos0 + tt) * ld + (int64_t)h * HD + c * 8;
     bf16x8 qv = *(const bf16x8*)(row);
     bf16x8 kv = *(const bf16x8*)(row + Dm);
     bf16x8 vv = *(const bf16x8*)(row + 2 * Dm);
@@ -348,8 +348,8 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_bwd(const bf16* __restrict
     float cs[8], sn[8];
     *(f32x4*)&cs[0] = *(const f32x4*)cp; *(f32x4*)&cs[4] = *(const f32x4*)(cp + 4);
     *(f32x4*)&sn[0] = *(const f32x4*)sp; *(f32x4*)&sn[4] = *(const f32x4*)(sp + 4);
-    const bf16* xrow = qkv + ((int64_t)b * S_part + tt) * ld + (int64_t)h * HD + c * 8;
-    bf16* drow = dqkv + ((int64_t)b * S_part + tt) * ldd + (int64_t)h * HD + c * 8;
+    const bf16* xrow = qkv + ((int64_t)b * S + pos0 + tt) * ld + (int64_t)h * HD + c * 8;
+    bf16* drow = dqkv + ((int64_t)b * S + pos0 + tt) * ldd + (int64_t)h * HD + c * 8;
     const int64_t go = (bh * S + pos) * HD + c * 8;
 #pragma unroll
     for (int w = 0; w < 2; w++) {

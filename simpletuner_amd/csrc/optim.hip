@@ -177,31 +177,33 @@ extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_
   return st355_check_launch("grad_norm");
 }
 
-// LoRA operand packer: A[r,K], B[N,r] fp32 -> A_pad[64,K], A_T[K,64], Bs_pad[N,64], Bs_T[64,N]  (bf16, zero padded)
+// LoRA operand packer (block-structured; see st355.h)
 __global__ void __launch_bounds__(OP_THREADS) k_lora_pack(const float* __restrict__ A, const float* __restrict__ Bm, int r, int K, int N,
-                                                         float scale, bf16* __restrict__ A_pad, bf16* __restrict__ A_T,
-                                                         bf16* __restrict__ Bs_pad, bf16* __restrict__ Bs_T) {
-  const int64_t nA = 64LL * K, nB = 64LL * N;
+                                                         float scale, bf16* __restrict__ A_cat, bf16* __restrict__ A_cat_T,
+                                                         bf16* __restrict__ B_blk, bf16* __restrict__ B_blk_T, int K2, int k2_off,
+                                                         int N_total, int n_off) {
+  const int64_t nA = (int64_t)r * K, nB = (int64_t)r * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < nA) {
       const int j = (int)(i / K), k = (int)(i % K);
-      const bf16 val = f2bf(j < r ? A[(int64_t)j * K + k] : 0.f);
-      A_pad[i] = val;
-      A_T[(int64_t)k * 64 + j] = val;
+      const bf16 val = f2bf(A[i]);
+      A_cat[(int64_t)(k2_off + j) * K + k] = val;
+      A_cat_T[(int64_t)k * K2 + k2_off + j] = val;
     } else {
       const int64_t t = i - nA;
       const int j = (int)(t / N), n = (int)(t % N);
-      const bf16 val = f2bf(j < r ? scale * Bm[(int64_t)n * r + j] : 0.f);
-      Bs_T[t] = val;
-      Bs_pad[(int64_t)n * 64 + j] = val;
+      const bf16 val = f2bf(scale * Bm[(int64_t)n * r + j]);
+      B_blk_T[(int64_t)(k2_off + j) * N_total + n_off + n] = val;
+      B_blk[(int64_t)(n_off + n) * K2 + k2_off + j] = val;
     }
   }
 }
-extern "C" int st355_lora_pack(void* stream, const float* A, const float* Bm, int r, int K, int N, float scale, void* A_pad, void* A_T,
-                               void* Bs_pad, void* Bs_T) {
-  ST_REQUIRE(A && Bm && A_pad && A_T && Bs_pad && Bs_T && r > 0 && r <= 64 && K > 0 && N > 0, "lora_pack: bad args");
-  ProfScope ps(stream, ST355_K_OPTIM, 0, 4.0 * r * (K + N) + 4.0 * 64 * (K + N));
-  hipLaunchKernelGGL(k_lora_pack, dim3(op_blocks(64LL * (K + N))), dim3(OP_THREADS), 0, (hipStream_t)stream, A, Bm, r, K, N, scale,
-                     (bf16*)A_pad, (bf16*)A_T, (bf16*)Bs_pad, (bf16*)Bs_T);
+extern "C" int st355_lora_pack(void* stream, const float* A, const float* Bm, int r, int K, int N, float scale, void* A_cat, void* A_cat_T,
+                               void* B_blk, void* B_blk_T, int K2, int k2_off, int N_total, int n_off) {
+  ST_REQUIRE(A && Bm && A_cat && A_cat_T && B_blk && B_blk_T && r > 0 && K > 0 && N > 0, "lora_pack: bad args");
+  ST_REQUIRE(K2 % 64 == 0 && k2_off >= 0 && k2_off + r <= K2 && n_off >= 0 && n_off + N <= N_total, "lora_pack: block out of range");
+  ProfScope ps(stream, ST355_K_OPTIM, 0, 8.0 * r * (K + N));
+  hipLaunchKernelGGL(k_lora_pack, dim3(op_blocks((int64_t)r * (K + N))), dim3(OP_THREADS), 0, (hipStream_t)stream, A, Bm, r, K, N, scale,
+                     (bf16*)A_cat, (bf16*)A_cat_T, (bf16*)B_blk, (bf16*)B_blk_T, K2, k2_off, N_total, n_off);
   return st355_check_launch("lora_pack");
 }

@@ -1,0 +1,135 @@
+"""ctypes binding of libst355.so (include/st355.h).
+
+This is the ONLY way the Python host reaches compute: there is no eager/PyTorch fallback.  If the shared
+library is missing (or was not built for gfx950) every op raises `St355Unavailable` — loudly — instead of
+silently running something else (task rule: the product path must fail when the HIP extension is missing).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libst355.so"
+
+# every symbol include/st355.h declares; tests check the .so exports exactly these
+SYMBOLS = [
+    "st355_version", "st355_arch", "st355_last_error",
+    "st355_prof_enable", "st355_prof_reset", "st355_prof_collect",
+    "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss",
+    "st355_flux_pack", "st355_flux_unpack",
+    "st355_timestep_proj", "st355_silu", "st355_add", "st355_scale_cols",
+    "st355_gemm_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn",
+    "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
+    "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd",
+    "st355_attn_fwd", "st355_attn_bwd_workspace", "st355_attn_bwd",
+    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_ema_update", "st355_grad_norm",
+    "st355_lora_pack",
+]
+
+KERNEL_CLASSES = [
+    "gemm", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_prep",
+    "ln_mod", "qk_rope", "skinny", "elementwise", "optim",
+]
+
+EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD = 0, 1, 2, 3, 4
+
+
+class St355Unavailable(RuntimeError):
+    pass
+
+
+class St355Error(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("A2", C.c_void_p), ("lda2", C.c_int64),
+        ("B2", C.c_void_p), ("ldb2", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K2", C.c_int32),
+        ("bias", C.c_void_p),
+        ("epilogue", C.c_int32),
+        ("aux_out", C.c_void_p), ("ld_aux_out", C.c_int64),
+        ("aux_in", C.c_void_p), ("ld_aux_in", C.c_int64),
+        ("gate", C.c_void_p), ("gate_stride", C.c_int64), ("rows_per_batch", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+    sz = C.c_size_t
+    sig = {
+        "st355_version": (C.c_int, []),
+        "st355_arch": (C.c_char_p, []),
+        "st355_last_error": (C.c_char_p, []),
+        "st355_prof_enable": (C.c_int, [i32]),
+        "st355_prof_reset": (C.c_int, []),
+        "st355_prof_collect": (C.c_int, [vp, vp, vp, vp, i32]),
+        "st355_flow_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, u64, u64]),
+        "st355_ddpm_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64]),
+        "st355_mse_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32]),
+        "st355_flux_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
+        "st355_flux_unpack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
+        "st355_timestep_proj": (C.c_int, [vp, vp, vp, i32, i32, f32]),
+        "st355_silu": (C.c_int, [vp, vp, vp, i64]),
+        "st355_add": (C.c_int, [vp, vp, vp, vp, i64]),
+        "st355_scale_cols": (C.c_int, [vp, vp, i64, vp, i64, i64, vp, i64, i64, i64]),
+        "st355_gemm_bf16": (C.c_int, [vp, C.POINTER(GemmArgs)]),
+        "st355_skinny_tn_workspace": (sz, [i64, i64, i32]),
+        "st355_skinny_tn": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, i32, f32, i32, vp]),
+        "st355_ln_modulate_fwd": (C.c_int, [vp, vp, i64, vp, vp, i64, i64, vp, i64, i64, i32, f32]),
+        "st355_ln_modulate_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, f32]),
+        "st355_qk_norm_rope_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32]),
+        "st355_qk_norm_rope_bwd": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32]),
+        "st355_attn_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32]),
+        "st355_attn_bwd_workspace": (sz, [i32, i32, i32, i32, i32]),
+        "st355_attn_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64,
+                                      i32, i32, i32, i32, i32, f32, vp]),
+        "st355_adamw_ema_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, f32]),
+        "st355_adamw_ema_step_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, f32]),
+        "st355_ema_update": (C.c_int, [vp, vp, vp, i64, f32, i32]),
+        "st355_grad_norm": (C.c_int, [vp, vp, i64, i32, vp]),
+        "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises St355Unavailable if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("ST355_LIB", LIB_PATH))
+    if not path.exists():
+        raise St355Unavailable(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950).  There is no CPU/eager fallback for the train step."
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # pragma: no cover
+        raise St355Unavailable(f"cannot load {path}: {e}") from e
+    _lib = _declare(lib)
+    return _lib
+
+
+def is_built() -> bool:
+    return Path(os.environ.get("ST355_LIB", LIB_PATH)).exists()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().st355_last_error().decode("utf-8", "replace")
+        raise St355Error(f"{what or 'st355 call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,361 @@
+"""Tensor-level wrappers over the C ABI (include/st355.h).
+
+torch is used here only as the owner of device memory and of the HIP stream: every wrapper validates
+shapes/dtypes, allocates the outputs, and passes raw device pointers + the current stream to libst355.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, GemmArgs  # noqa: F401
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _l.St355Error(f"{name}: expected a device tensor (the train step has no CPU path)")
+    if t.dtype != dtype:
+        raise _l.St355Error(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def _rows(t: torch.Tensor, name: str) -> int:
+    """leading dimension (elements) of a 2-D row-major view"""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _l.St355Error(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming ops
+# ------------------------------------------------------------------------------------------------
+def flow_noise_mix(x, sigma, noise=None, seed: int = 0, offset: int = 0, want_target: bool = True):
+    """x_t = (1-σ)x + σn ; target = n - x   (common.py:4975-4992, 4610-4611).  Returns (x_t, target, noise)."""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(sigma, F32, "sigma")
+    x = x.contiguous()
+    B = x.shape[0]
+    per = x.numel() // B
+    x_t = torch.empty_like(x)
+    target = torch.empty_like(x) if want_target else None
+    if noise is not None:
+        _chk(noise, BF16, "noise")
+        noise = noise.contiguous()
+        noise_out = None
+    else:
+        noise_out = torch.empty_like(x)
+    _l.check(L.st355_flow_noise_mix(_stream(), _ptr(x), _ptr(noise), _ptr(sigma), _ptr(x_t), _ptr(target), _ptr(noise_out),
+                                    B, per, seed, offset), "flow_noise_mix")
+    return x_t, target, (noise if noise is not None else noise_out)
+
+
+def ddpm_noise_mix(x, noise, sqrt_acp, sqrt_1macp, want_v: bool = True):
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(noise, BF16, "noise"); _chk(sqrt_acp, F32, "sqrt_acp"); _chk(sqrt_1macp, F32, "sqrt_1macp")
+    x = x.contiguous(); noise = noise.contiguous()
+    B = x.shape[0]
+    x_t = torch.empty_like(x)
+    v = torch.empty_like(x) if want_v else None
+    _l.check(L.st355_ddpm_noise_mix(_stream(), _ptr(x), _ptr(noise), _ptr(sqrt_acp), _ptr(sqrt_1macp), _ptr(x_t), _ptr(v),
+                                    B, x.numel() // B), "ddpm_noise_mix")
+    return x_t, v
+
+
+def mse_loss(pred, target, weight=None, want_grad: bool = True, grad_scale: float = 1.0):
+    """mean_b(mean_chw((pred-target)^2 * w_b)) in fp32 + fused d(loss)/d(pred).  Returns (loss[1], per_sample[B], dpred)."""
+    L = _l.load()
+    _chk(pred, BF16, "pred"); _chk(target, BF16, "target")
+    pred = pred.contiguous(); target = target.contiguous()
+    B = pred.shape[0]
+    loss = torch.empty(1, dtype=F32, device=pred.device)
+    per_sample = torch.empty(B, dtype=F32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    if weight is not None:
+        _chk(weight, F32, "weight")
+    _l.check(L.st355_mse_loss(_stream(), _ptr(pred), _ptr(target), _ptr(weight), _ptr(loss), _ptr(per_sample), _ptr(dpred),
+                              B, pred.numel() // B, grad_scale), "mse_loss")
+    return loss, per_sample, dpred
+
+
+def flux_pack(latents):
+    L = _l.load()
+    _chk(latents, BF16, "latents")
+    latents = latents.contiguous()
+    B, Cc, H, W = latents.shape
+    out = torch.empty(B, (H // 2) * (W // 2), Cc * 4, dtype=BF16, device=latents.device)
+    _l.check(L.st355_flux_pack(_stream(), _ptr(latents), _ptr(out), B, Cc, H, W), "flux_pack")
+    return out
+
+
+def flux_unpack(packed, Cc: int, H: int, W: int):
+    L = _l.load()
+    _chk(packed, BF16, "packed")
+    packed = packed.contiguous()
+    B = packed.shape[0]
+    out = torch.empty(B, Cc, H, W, dtype=BF16, device=packed.device)
+    _l.check(L.st355_flux_unpack(_stream(), _ptr(packed), _ptr(out), B, Cc, H, W), "flux_unpack")
+    return out
+
+
+def timestep_proj(t, dim: int, scale: float = 1.0):
+    L = _l.load()
+    _chk(t, F32, "t")
+    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    _l.check(L.st355_timestep_proj(_stream(), _ptr(t.contiguous()), _ptr(out), t.shape[0], dim, scale), "timestep_proj")
+    return out
+
+
+def silu(x):
+    L = _l.load()
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _l.check(L.st355_silu(_stream(), _ptr(x), _ptr(y), x.numel()), "silu")
+    return y
+
+
+def add(a, b):
+    L = _l.load()
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    a = a.contiguous(); b = b.contiguous()
+    y = torch.empty_like(a)
+    _l.check(L.st355_add(_stream(), _ptr(a), _ptr(b), _ptr(y), a.numel()), "add")
+    return y
+
+
+def scale_cols(x, gate, rows_per_batch: int, out=None):
+    """out[m,n] = x[m,n] * gate[m // rows_per_batch, n]"""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(gate, BF16, "gate")
+    ldx = _rows(x, "x"); gs = _rows(gate, "gate")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    _l.check(L.st355_scale_cols(_stream(), _ptr(x), ldx, _ptr(gate), gs, rows_per_batch, _ptr(out), _rows(out, "out"), M, N),
+             "scale_cols")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
+         gate=None, rows_per_batch: int = 0):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue (see st355.h)."""
+    L = _l.load()
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    M, K = a.shape
+    N, Kw = w.shape
+    if K != Kw:
+        raise _l.St355Error(f"gemm: K mismatch {K} vs {Kw}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    g = GemmArgs()
+    g.A, g.lda = _ptr(a), _rows(a, "a")
+    g.B, g.ldb = _ptr(w), _rows(w, "w")
+    g.C, g.ldc = _ptr(out), _rows(out, "out")
+    g.M, g.N, g.K, g.K2 = M, N, K, 0
+    if a2 is not None:
+        _chk(a2, BF16, "a2"); _chk(b2, BF16, "b2")
+        if a2.shape[0] != M or b2.shape[0] != N or a2.shape[1] != b2.shape[1]:
+            raise _l.St355Error("gemm: low-rank extension shape mismatch")
+        g.A2, g.lda2 = _ptr(a2), _rows(a2, "a2")
+        g.B2, g.ldb2 = _ptr(b2), _rows(b2, "b2")
+        g.K2 = a2.shape[1]
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+        g.bias = _ptr(bias.contiguous())
+    g.epilogue = epilogue
+    if aux_out is not None:
+        _chk(aux_out, BF16, "aux_out")
+        g.aux_out, g.ld_aux_out = _ptr(aux_out), _rows(aux_out, "aux_out")
+    if aux_in is not None:
+        _chk(aux_in, BF16, "aux_in")
+        g.aux_in, g.ld_aux_in = _ptr(aux_in), _rows(aux_in, "aux_in")
+    if gate is not None:
+        _chk(gate, BF16, "gate")
+        g.gate, g.gate_stride = _ptr(gate), _rows(gate, "gate")
+        g.rows_per_batch = rows_per_batch
+    _l.check(L.st355_gemm_bf16(_stream(), C.byref(g)), "gemm_bf16")
+    return out
+
+
+_skinny_ws = {}
+
+
+def skinny_tn(Lm, R, out, so_p: int, so_r: int, r_used: int, alpha: float = 1.0, accumulate: bool = False):
+    """out[p*so_p + r*so_r] (+)= alpha * sum_m Lm[m,p] * R[m,r]   (fp32 out; rank-space LoRA gradients)."""
+    L = _l.load()
+    _chk(Lm, BF16, "L"); _chk(R, BF16, "R"); _chk(out, F32, "out")
+    M, P = Lm.shape
+    Rn = R.shape[1]
+    need = L.st355_skinny_tn_workspace(M, P, Rn)
+    key = (Lm.device.index,)
+    ws = _skinny_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=F32, device=Lm.device)
+        _skinny_ws[key] = ws
+    _l.check(L.st355_skinny_tn(_stream(), _ptr(Lm), _rows(Lm, "L"), _ptr(R), _rows(R, "R"), _ptr(out), so_p, so_r, M, P, Rn,
+                               r_used, alpha, 1 if accumulate else 0, _ptr(ws)), "skinny_tn")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# AdaLN / RMSNorm + RoPE
+# ------------------------------------------------------------------------------------------------
+def ln_modulate_fwd(x, scale, shift, rows_per_batch: int, eps: float = 1e-6, out=None):
+    """y = LN(x) * (1 + scale[b]) + shift[b]; scale/shift are [B, D] views sharing one row stride."""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(scale, BF16, "scale"); _chk(shift, BF16, "shift")
+    rows, D = x.shape
+    ms = _rows(scale, "scale")
+    if _rows(shift, "shift") != ms:
+        raise _l.St355Error("ln_modulate_fwd: scale and shift must share a row stride")
+    if out is None:
+        out = torch.empty(rows, D, dtype=BF16, device=x.device)
+    _l.check(L.st355_ln_modulate_fwd(_stream(), _ptr(x), _rows(x, "x"), _ptr(scale), _ptr(shift), ms, rows_per_batch,
+                                     _ptr(out), _rows(out, "out"), rows, D, eps), "ln_modulate_fwd")
+    return out
+
+
+def ln_modulate_bwd(dy, x, scale, rows_per_batch: int, dres=None, gate=None, eps: float = 1e-6, want_gated: bool = False):
+    """dx = dres + LNbwd(dy*(1+scale));  dxg = gate[b]*dx (if want_gated).  Returns (dx, dxg)."""
+    L = _l.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(scale, BF16, "scale")
+    rows, D = x.shape
+    dx = torch.empty(rows, D, dtype=BF16, device=x.device)
+    dxg = torch.empty(rows, D, dtype=BF16, device=x.device) if want_gated else None
+    if dres is not None:
+        _chk(dres, BF16, "dres")
+    if want_gated:
+        _chk(gate, BF16, "gate")
+    _l.check(L.st355_ln_modulate_bwd(_stream(), _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(scale), _rows(scale, "scale"),
+                                     rows_per_batch, _ptr(dres), _rows(dres, "dres") if dres is not None else 0,
+                                     _ptr(gate) if want_gated else None, _rows(gate, "gate") if want_gated else 0,
+                                     _ptr(dx), D, _ptr(dxg), D, rows, D, eps), "ln_modulate_bwd")
+    return dx, dxg
+
+
+def qk_norm_rope_fwd(qkv, wq, wk, cos, sin, Q, K, Qt, Kt, Vt, B, H, d, S_part, pos0, S, Sp, eps: float = 1e-6):
+    L = _l.load()
+    _chk(qkv, BF16, "qkv"); _chk(cos, F32, "cos"); _chk(sin, F32, "sin")
+    _l.check(L.st355_qk_norm_rope_fwd(_stream(), _ptr(qkv), _rows(qkv, "qkv"), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin),
+                                      _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(Vt), B, H, d, S_part, pos0, S, Sp, eps),
+             "qk_norm_rope_fwd")
+
+
+def qk_norm_rope_bwd(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S, eps: float = 1e-6):
+    L = _l.load()
+    _chk(dQ, BF16, "dQ"); _chk(dK, BF16, "dK"); _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
+    _l.check(L.st355_qk_norm_rope_bwd(_stream(), _ptr(dQ), _ptr(dK), _ptr(qkv), _rows(qkv, "qkv"), _ptr(wq), _ptr(wk),
+                                      _ptr(cos), _ptr(sin), _ptr(dqkv), _rows(dqkv, "dqkv"), B, H, d, S_part, pos0, S, eps),
+             "qk_norm_rope_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale: float, key_bias=None):
+    """O: 2-D token-major view [B*S, >=H*d]; lse2 [B,H,S] fp32."""
+    L = _l.load()
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    _l.check(L.st355_attn_fwd(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(lse2),
+                              B, H, S, Sp, d, scale), "attn_fwd")
+
+
+_attn_ws = {}
+
+
+def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale: float, key_bias=None):
+    L = _l.load()
+    need = L.st355_attn_bwd_workspace(B, H, S, Sp, d)
+    key = (Q.device.index,)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
+        _attn_ws[key] = ws
+    _l.check(L.st355_attn_bwd(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
+                              _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
+                              _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, S, Sp, d, scale, _ptr(ws)),
+             "attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / EMA
+# ------------------------------------------------------------------------------------------------
+def adamw_ema_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2,
+                   grad_scale: float = 1.0, ema=None, ema_decay: float = 0.0, p_bf16=None):
+    L = _l.load()
+    if p.dtype == F32:
+        for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+            _chk(t, F32, n)
+        _l.check(L.st355_adamw_ema_step(_stream(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), _ptr(p_bf16), p.numel(),
+                                        lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay), "adamw_ema_step")
+    else:
+        _chk(p, BF16, "p"); _chk(g, BF16, "g"); _chk(m, F32, "m"); _chk(v, F32, "v")
+        _l.check(L.st355_adamw_ema_step_bf16(_stream(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(),
+                                             lr, beta1, beta2, eps, weight_decay, step, grad_scale, ema_decay),
+                 "adamw_ema_step_bf16")
+
+
+def ema_update(shadow, param, decay: float):
+    L = _l.load()
+    if shadow.dtype != param.dtype:
+        raise _l.St355Error("ema_update: dtype mismatch")
+    _l.check(L.st355_ema_update(_stream(), _ptr(shadow), _ptr(param), shadow.numel(), decay, shadow.element_size()), "ema_update")
+
+
+def grad_norm(g):
+    """returns fp32 [2] device tensor: (sum of squares, max |g|)"""
+    L = _l.load()
+    out = torch.empty(2, dtype=F32, device=g.device)
+    _l.check(L.st355_grad_norm(_stream(), _ptr(g), g.numel(), g.element_size(), _ptr(out)), "grad_norm")
+    return out
+
+
+def lora_pack(A, Bm, scale: float, A_cat, A_cat_T, B_blk, B_blk_T, k2_off: int = 0, n_off: int = 0):
+    """write one adapter (A [r,K], B [N,r], fp32) into the block-structured bf16 operands of a fused projection group"""
+    L = _l.load()
+    _chk(A, F32, "A"); _chk(Bm, F32, "B")
+    r, K = A.shape
+    N = Bm.shape[0]
+    K2 = A_cat.shape[0]
+    N_total = B_blk.shape[0]
+    if A_cat.shape != (K2, K) or A_cat_T.shape != (K, K2) or B_blk.shape != (N_total, K2) or B_blk_T.shape != (K2, N_total):
+        raise _l.St355Error("lora_pack: operand shapes inconsistent")
+    for t in (A_cat, A_cat_T, B_blk, B_blk_T):
+        if not t.is_contiguous():
+            raise _l.St355Error("lora_pack: packed operands must be contiguous")
+    _l.check(L.st355_lora_pack(_stream(), _ptr(A.contiguous()), _ptr(Bm.contiguous()), r, K, N, scale, _ptr(A_cat), _ptr(A_cat_T),
+                               _ptr(B_blk), _ptr(B_blk_T), K2, k2_off, N_total, n_off), "lora_pack")
+
+
+# ------------------------------------------------------------------------------------------------
+# profiler
+# ------------------------------------------------------------------------------------------------
+def prof_enable(on: bool):
+    _l.load().st355_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    _l.load().st355_prof_reset()
+
+
+def prof_collect():
+    n = len(_l.KERNEL_CLASSES)
+    ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
+    _l.load().st355_prof_collect(ms, la, fl, by, n)
+    return {k: {"ms": ms[i], "launches": la[i], "flops": fl[i], "bytes": by[i]} for i, k in enumerate(_l.KERNEL_CLASSES)}

@@ -1,0 +1,459 @@
+"""GPU parity of every HIP kernel, called through the C ABI (simpletuner_amd.ops -> libst355.so), against a
+plain fp32 PyTorch statement of the same op on the same seeded inputs.
+
+Tolerances (stated per test): bf16 outputs carry one rounding (2^-8 relative); a contraction of length K in
+bf16 inputs / fp32 accumulation adds ~sqrt(K)*2^-9 relative noise on top.  Integer/index work (pack/unpack) is bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, ref):
+    a = a.float(); ref = ref.float()
+    return ((a - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
+def maxabs(a, ref):
+    return (a.float() - ref.float()).abs().max().item()
+
+
+def report(name, a, ref):
+    r, m = rel(a, ref), maxabs(a, ref)
+    print(f"[parity] {name}: rel_l2={r:.3e} max_abs={m:.3e} ref_max={ref.float().abs().max().item():.3e}")
+    return r, m
+
+
+def gelu_tanh(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simpletuner_amd import ops as o
+
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# library / streaming
+# ------------------------------------------------------------------------------------------------
+def test_library_identity():
+    from simpletuner_amd import lib
+
+    L = lib.load()
+    assert L.st355_arch() == b"gfx950"
+    assert L.st355_version() >= 1
+
+
+def test_flow_noise_mix_given_noise(ops):
+    torch.manual_seed(0)
+    x = torch.randn(3, 16, 32, 32, device=dev()).to(BF16)
+    n = torch.randn_like(x.float()).to(BF16)
+    sig = torch.tensor([0.25, 0.5, 0.9], device=dev())
+    xt, tg, n_out = ops.flow_noise_mix(x, sig, noise=n)
+    s = sig.view(-1, 1, 1, 1)
+    ref_xt = ((1 - s) * x.float() + s * n.float())
+    ref_tg = n.float() - x.float()
+    r1, _ = report("flow x_t", xt, ref_xt)
+    r2, _ = report("flow target", tg, ref_tg)
+    assert r1 < 4e-3 and r2 < 4e-3  # one bf16 rounding
+    assert n_out is n or torch.equal(n_out, n)
+
+
+def test_flow_noise_mix_generated_noise_statistics(ops):
+    x = torch.zeros(4, 16, 128, 128, device=dev(), dtype=BF16)
+    sig = torch.ones(4, device=dev())
+    xt, tg, n = ops.flow_noise_mix(x, sig, noise=None, seed=1234, offset=0)
+    nf = n.float()
+    print(f"[parity] philox normal: mean={nf.mean().item():.4f} std={nf.std().item():.4f} kurt={(nf**4).mean().item():.3f}")
+    assert abs(nf.mean().item()) < 5e-3 and abs(nf.std().item() - 1.0) < 5e-3 and abs((nf ** 4).mean().item() - 3.0) < 0.1
+    assert torch.equal(xt, n) and torch.equal(tg, n)  # sigma=1, x=0
+    _, _, n2 = ops.flow_noise_mix(x, sig, noise=None, seed=1234, offset=0)
+    assert torch.equal(n, n2)  # counter-based: reproducible
+    _, _, n3 = ops.flow_noise_mix(x, sig, noise=None, seed=1234, offset=x.numel() // 4)
+    assert not torch.equal(n, n3)
+
+
+def test_ddpm_noise_mix(ops):
+    torch.manual_seed(1)
+    x = torch.randn(2, 4, 64, 64, device=dev()).to(BF16)
+    n = torch.randn(2, 4, 64, 64, device=dev()).to(BF16)
+    acp = torch.tensor([0.9, 0.2], device=dev())
+    a, s = acp.sqrt(), (1 - acp).sqrt()
+    xt, v = ops.ddpm_noise_mix(x, n, a, s)
+    av, sv = a.view(-1, 1, 1, 1), s.view(-1, 1, 1, 1)
+    assert report("ddpm x_t", xt, av * x.float() + sv * n.float())[0] < 4e-3
+    assert report("ddpm v", v, av * n.float() - sv * x.float())[0] < 4e-3
+
+
+def test_mse_loss_and_grad(ops):
+    torch.manual_seed(2)
+    p = torch.randn(4, 16, 32, 32, device=dev()).to(BF16)
+    t = torch.randn(4, 16, 32, 32, device=dev()).to(BF16)
+    w = torch.tensor([1.0, 0.5, 2.0, 0.25], device=dev())
+    for weight in (None, w):
+        pf = p.float().requires_grad_(True)
+        l = ((pf - t.float()) ** 2)
+        if weight is not None:
+            l = l * weight.view(-1, 1, 1, 1)
+        per = l.mean(dim=(1, 2, 3))
+        ref = per.mean()
+        ref.backward()
+        loss, per_s, dp = ops.mse_loss(p, t, weight=weight)
+        print(f"[parity] mse loss={loss.item():.7f} ref={ref.item():.7f}")
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        assert torch.allclose(per_s, per.detach(), rtol=1e-5, atol=1e-6)
+        assert report("mse dpred", dp, pf.grad)[0] < 4e-3
+
+
+def test_flux_pack_unpack_bit_exact(ops):
+    torch.manual_seed(3)
+    lat = torch.randn(2, 16, 24, 40, device=dev()).to(BF16)
+    B, Cc, H, W = lat.shape
+    # reference: flux/__init__.py:25-45
+    ref = lat.view(B, Cc, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), Cc * 4)
+    packed = ops.flux_pack(lat)
+    assert torch.equal(packed, ref)
+    back = ops.flux_unpack(packed, Cc, H, W)
+    assert torch.equal(back, lat)
+
+
+def test_timestep_proj_silu_add_scale(ops):
+    t = torch.tensor([0.0, 0.1234, 0.5, 1.0], device=dev())
+    out = ops.timestep_proj(t, 256, 1000.0)
+    half = 128
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, device=dev(), dtype=torch.float32) / half)
+    ang = (t * 1000.0)[:, None] * freqs[None]
+    ref = torch.cat([ang.cos(), ang.sin()], dim=-1)
+    # fp32 cos/sin of arguments up to 1000 rad: allow 2e-3 absolute (bf16 output rounding is 4e-3 relative)
+    assert report("timestep_proj", out, ref)[1] < 8e-3
+    x = torch.randn(5, 3072, device=dev()).to(BF16)
+    y = torch.randn(5, 3072, device=dev()).to(BF16)
+    assert report("silu", ops.silu(x), torch.nn.functional.silu(x.float()))[0] < 4e-3
+    assert report("add", ops.add(x, y), x.float() + y.float())[0] < 4e-3
+    big = torch.randn(2 * 96, 512, device=dev()).to(BF16)
+    gate = torch.randn(2, 6 * 512, device=dev()).to(BF16)[:, 1024:1536]
+    ref = big.float().view(2, 96, 512) * gate.float()[:, None, :]
+    assert report("scale_cols", ops.scale_cols(big, gate, 96), ref.view(-1, 512))[0] < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 256), (1, 3072, 256), (4608, 3072, 3072), (512, 64, 3072)])
+def test_gemm_plain(ops, M, N, K):
+    torch.manual_seed(10)
+    a = torch.randn(M, K, device=dev()).to(BF16)
+    w = (torch.randn(N, K, device=dev()) * 0.05).to(BF16)
+    out = ops.gemm(a, w)
+    ref = a.float() @ w.float().t()
+    r, _ = report(f"gemm {M}x{N}x{K}", out, ref)
+    assert r < 5e-3
+    # transpose detector: asymmetric operands -> out^T must NOT match
+    if M == N:
+        assert rel(out.t(), ref) > 0.1
+
+
+def test_gemm_identity_asymmetric(ops):
+    # A = I (padded), asymmetric B: catches row/col swaps in the C write (cdna guide §3 "A=I-check")
+    K = 128
+    a = torch.eye(K, device=dev()).to(BF16)
+    w = (torch.arange(200 * K, device=dev(), dtype=torch.float32).view(200, K) % 251 - 125).to(BF16)
+    out = ops.gemm(a, w)
+    assert torch.equal(out.float(), w.float().t())
+
+
+def test_gemm_bias_gelu_aux(ops):
+    torch.manual_seed(11)
+    M, N, K = 260, 384, 192
+    a = torch.randn(M, K, device=dev()).to(BF16)
+    w = (torch.randn(N, K, device=dev()) * 0.1).to(BF16)
+    b = torch.randn(N, device=dev()).to(BF16)
+    pre = torch.empty(M, N, device=dev(), dtype=BF16)
+    out = ops.gemm(a, w, bias=b, epilogue=ops.EPI_GELU, aux_out=pre)
+    ref_pre = a.float() @ w.float().t() + b.float()
+    assert report("gemm+bias pre-act", pre, ref_pre)[0] < 5e-3
+    assert report("gemm+bias+gelu", out, gelu_tanh(pre.float()))[0] < 5e-3
+    out2 = ops.gemm(a, w, bias=b)
+    assert report("gemm+bias", out2, ref_pre)[0] < 5e-3
+
+
+def test_gemm_gate_residual_strided(ops):
+    torch.manual_seed(12)
+    B, S, D, K = 2, 150, 256, 320
+    a = torch.randn(B * S, K, device=dev()).to(BF16)
+    w = (torch.randn(D, K, device=dev()) * 0.1).to(BF16)
+    bias = torch.randn(D, device=dev()).to(BF16)
+    mod = torch.randn(B, 6 * D, device=dev()).to(BF16)
+    gate = mod[:, 2 * D:3 * D]
+    resid_full = torch.randn(B * S, 2 * D, device=dev()).to(BF16)
+    resid = resid_full[:, D:]            # strided residual view
+    out_full = torch.zeros(B * S, 3 * D, device=dev(), dtype=BF16)
+    out = out_full[:, D:2 * D]           # strided output view
+    ops.gemm(a, w, bias=bias, out=out, epilogue=ops.EPI_GATE_RESIDUAL, aux_in=resid, gate=gate, rows_per_batch=S)
+    ref = resid.float().view(B, S, D) + gate.float()[:, None, :] * (a.float() @ w.float().t() + bias.float()).view(B, S, D)
+    assert report("gemm gate+residual", out, ref.view(B * S, D))[0] < 5e-3
+    assert out_full[:, :D].abs().max().item() == 0 and out_full[:, 2 * D:].abs().max().item() == 0
+
+
+def test_gemm_mul_gelu_grad(ops):
+    torch.manual_seed(13)
+    M, N, K = 200, 512, 128
+    dy = torch.randn(M, K, device=dev()).to(BF16)
+    wT = (torch.randn(N, K, device=dev()) * 0.1).to(BF16)
+    pre = torch.randn(M, N, device=dev()).to(BF16)
+    out = ops.gemm(dy, wT, epilogue=ops.EPI_MUL_GELU_GRAD, aux_in=pre)
+    pf = pre.float().requires_grad_(True)
+    gelu_tanh(pf).backward(dy.float() @ wT.float().t())
+    assert report("gemm * gelu'", out, pf.grad)[0] < 6e-3
+
+
+def test_gemm_lora_extension(ops):
+    """fused base + low-rank: y = x W^T + b + (x A^T)(sB)^T  (peft LoraLayer; common.py:1094-1117)"""
+    torch.manual_seed(14)
+    M, N, K, r, s = 384, 256, 512, 32, 0.5
+    x = torch.randn(M, K, device=dev()).to(BF16)
+    W = (torch.randn(N, K, device=dev()) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev()).to(BF16)
+    A = torch.randn(r, K, device=dev()) * 0.05
+    Bm = torch.randn(N, r, device=dev()) * 0.05
+    A_pad = torch.zeros(64, K, device=dev(), dtype=BF16); A_T = torch.zeros(K, 64, device=dev(), dtype=BF16)
+    Bs_pad = torch.zeros(N, 64, device=dev(), dtype=BF16); Bs_T = torch.zeros(64, N, device=dev(), dtype=BF16)
+    ops.lora_pack(A, Bm, s, A_pad, A_T, Bs_pad, Bs_T)
+    assert torch.equal(A_pad[:r], A.to(BF16)) and A_pad[r:].abs().max().item() == 0
+    assert torch.equal(A_T, A_pad.t()) and torch.equal(Bs_T, Bs_pad.t())
+    assert torch.equal(Bs_pad[:, :r], (s * Bm).to(BF16)) and Bs_pad[:, r:].abs().max().item() == 0
+    t = ops.gemm(x, A_pad)                       # x A^T  [M,64]
+    y = ops.gemm(x, W, bias=bias, a2=t, b2=Bs_pad)
+    ref = x.float() @ W.float().t() + bias.float() + (x.float() @ A_pad.float().t()).to(BF16).float() @ Bs_pad.float().t()
+    assert report("lora fused fwd", y, ref)[0] < 5e-3
+    exact = x.float() @ W.float().t() + bias.float() + s * (x.float() @ A.t()) @ Bm.t()
+    assert report("lora fused fwd vs fp32 LoRA", y, exact)[0] < 8e-3
+
+
+@pytest.mark.parametrize("M,P,Rn,r", [(300, 256, 64, 32), (4608, 3072, 64, 32), (1000, 136, 32, 16)])
+def test_skinny_tn(ops, M, P, Rn, r):
+    torch.manual_seed(15)
+    Lm = torch.randn(M, P, device=dev()).to(BF16)
+    R = torch.randn(M, Rn, device=dev()).to(BF16)
+    out = torch.zeros(P, r, device=dev())
+    ops.skinny_tn(Lm, R, out, r, 1, r, alpha=0.5)
+    ref = 0.5 * Lm.float().t() @ R.float()[:, :r]
+    assert report(f"skinny_tn {M}x{P}x{Rn}", out, ref)[0] < 1e-5 * math.sqrt(M) + 1e-6
+    # transposed output + accumulate
+    outT = torch.ones(r, P, device=dev())
+    ops.skinny_tn(Lm, R, outT, 1, P, r, alpha=1.0, accumulate=True)
+    assert report("skinny_tn^T acc", outT, 1.0 + (Lm.float().t() @ R.float()[:, :r]).t())[0] < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# AdaLN, RMSNorm + RoPE
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [3072, 1536, 1152, 256])
+def test_ln_modulate_fwd_bwd(ops, D):
+    torch.manual_seed(20)
+    B, S = 2, 70
+    x = (torch.randn(B * S, D, device=dev()) * 2 + 0.3).to(BF16)
+    mod = (torch.randn(B, 6 * D, device=dev()) * 0.5).to(BF16)
+    shift, scale, gate = mod[:, :D], mod[:, D:2 * D], mod[:, 2 * D:3 * D]
+    y = ops.ln_modulate_fwd(x, scale, shift, S)
+    xf = x.float().view(B, S, D).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6) * (1 + scale.float()[:, None]) + shift.float()[:, None]
+    assert report(f"ln_mod fwd D={D}", y, ref.view(B * S, D))[0] < 4e-3
+    dy = torch.randn(B * S, D, device=dev()).to(BF16)
+    dres = torch.randn(B * S, D, device=dev()).to(BF16)
+    ref.backward(dy.float().view(B, S, D))
+    dx, dxg = ops.ln_modulate_bwd(dy, x, scale, S, dres=dres, gate=gate, want_gated=True)
+    ref_dx = xf.grad.view(B * S, D) + dres.float()
+    assert report(f"ln_mod bwd D={D}", dx, ref_dx)[0] < 6e-3
+    assert report("ln_mod bwd gated", dxg, (dx.float().view(B, S, D) * gate.float()[:, None]).view(B * S, D))[0] < 4e-3
+    dx2, none = ops.ln_modulate_bwd(dy, x, scale, S)
+    assert none is None and report("ln_mod bwd (no dres)", dx2, xf.grad.view(B * S, D))[0] < 6e-3
+
+
+def _rope_tables(S, d, device):
+    # FluxPosEmbed-like interleave-repeated tables with arbitrary (non-trivial) angles
+    ang = torch.rand(S, d // 2, device=device, dtype=torch.float64) * 6.0
+    cos = ang.cos().repeat_interleave(2, dim=1).float().contiguous()
+    sin = ang.sin().repeat_interleave(2, dim=1).float().contiguous()
+    return cos, sin
+
+
+def _ref_norm_rope(x, w, cos, sin, eps=1e-6):
+    # x [B,H,S,d] fp32; diffusers RMSNorm then flux/transformer.py:73-98
+    if w is not None:
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return x * cos[None, None] + rot * sin[None, None]
+
+
+@pytest.mark.parametrize("d,H,S_txt,S_img", [(128, 3, 64, 128), (128, 2, 40, 100), (64, 4, 77, 150)])
+def test_qk_norm_rope_fwd_bwd(ops, d, H, S_txt, S_img):
+    torch.manual_seed(21)
+    B = 2
+    S = S_txt + S_img
+    Sp = (S + 63) // 64 * 64
+    D = H * d
+    cos, sin = _rope_tables(S, d, dev())
+    wq = (1 + 0.2 * torch.randn(d, device=dev())).to(BF16)
+    wk = (1 + 0.2 * torch.randn(d, device=dev())).to(BF16)
+    Q = torch.zeros(B, H, S, d, device=dev(), dtype=BF16); K = torch.zeros_like(Q)
+    Qt = torch.zeros(B, H, d, Sp, device=dev(), dtype=BF16); Kt = torch.zeros_like(Qt); Vt = torch.zeros_like(Qt)
+    parts = [("txt", S_txt, 0), ("img", S_img, S_txt)]
+    wq2 = (1 + 0.2 * torch.randn(d, device=dev())).to(BF16)   # the txt stream has its own norm weights (norm_added_q/k)
+    wk2 = (1 + 0.2 * torch.randn(d, device=dev())).to(BF16)
+    wts = {"txt": (wq2, wk2), "img": (wq, wk)}
+    qkv = torch.randn(B * S, 3 * D, device=dev()).to(BF16)       # JOINT buffer, row b*S + pos
+    for name, Sp_, pos0 in parts:
+        ops.qk_norm_rope_fwd(qkv, wts[name][0], wts[name][1], cos, sin, Q, K, Qt, Kt, Vt, B, H, d, Sp_, pos0, S, Sp)
+    q, k, v = qkv.float().view(B, S, 3, H, d).permute(2, 0, 3, 1, 4)
+    q = q.contiguous().requires_grad_(True); k = k.contiguous().requires_grad_(True)
+    wq_full = torch.cat([wq2.float().expand(S_txt, d), wq.float().expand(S_img, d)], 0)   # per-position weights
+    wk_full = torch.cat([wk2.float().expand(S_txt, d), wk.float().expand(S_img, d)], 0)
+    Qr = _ref_norm_rope(q, wq_full, cos, sin); Kr = _ref_norm_rope(k, wk_full, cos, sin)
+    assert report("rope Q", Q, Qr)[0] < 4e-3 and report("rope K", K, Kr)[0] < 4e-3
+    assert torch.equal(Qt[..., :S], Q.transpose(2, 3)) and torch.equal(Kt[..., :S], K.transpose(2, 3))
+    assert torch.equal(Vt[..., :S], v.to(BF16).transpose(2, 3))
+    if Sp > S:
+        assert Qt[..., S:].abs().max().item() == 0 and Vt[..., S:].abs().max().item() == 0
+    # backward
+    dQ = torch.randn(B, H, S, d, device=dev()).to(BF16); dK = torch.randn(B, H, S, d, device=dev()).to(BF16)
+    (Qr * dQ.float()).sum().backward(retain_graph=True)
+    (Kr * dK.float()).sum().backward()
+    dqkv = torch.zeros(B * S, 3 * D, device=dev(), dtype=BF16)
+    for name, Sp_, pos0 in parts:
+        ops.qk_norm_rope_bwd(dQ, dK, qkv, wts[name][0], wts[name][1], cos, sin, dqkv, B, H, d, Sp_, pos0, S)
+    ref_dq = q.grad.permute(0, 2, 1, 3).reshape(B * S, D)
+    ref_dk = k.grad.permute(0, 2, 1, 3).reshape(B * S, D)
+    assert report("rope bwd dq", dqkv[:, :D], ref_dq)[0] < 6e-3
+    assert report("rope bwd dk", dqkv[:, D:2 * D], ref_dk)[0] < 6e-3
+    assert dqkv[:, 2 * D:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
+    torch.manual_seed(seed)
+    Sp = (S + 63) // 64 * 64
+    D = H * d
+    scale = 1.0 / math.sqrt(d)
+    q = torch.randn(B, H, S, d, device=dev()).to(BF16)
+    k = torch.randn(B, H, S, d, device=dev()).to(BF16)
+    qkv_rows = torch.randn(B * S, 3 * D, device=dev()).to(BF16)   # V lives token-major in the qkv buffer
+    v_rows = qkv_rows[:, 2 * D:]
+    v = v_rows.float().view(B, S, H, d).permute(0, 2, 1, 3)
+    if spike:  # force the online-softmax rescale branch: one key dominates late in the sequence
+        k[:, :, S - 3] = (q[:, :, 5] * 4.0).to(BF16)
+    kb = None
+    if bias:
+        kb = torch.zeros(B, S, device=dev())
+        kb[:, S // 3: S // 2] = -10000.0   # PixArt-style additive mask (pixart/controlnet.py:224-232)
+        kb[:, 0] = 0.5
+    Qt = torch.zeros(B, H, d, Sp, device=dev(), dtype=BF16); Kt = torch.zeros_like(Qt); Vt = torch.zeros_like(Qt)
+    Qt[..., :S] = q.transpose(2, 3); Kt[..., :S] = k.transpose(2, 3); Vt[..., :S] = v.to(BF16).transpose(2, 3)
+    O = torch.zeros(B * S, D, device=dev(), dtype=BF16)
+    lse2 = torch.zeros(B, H, S, device=dev())
+    ops.attn_fwd(q, k, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=kb)
+    qf = q.float().requires_grad_(True); kf = k.float().requires_grad_(True); vf = v.clone().requires_grad_(True)
+    s = (qf @ kf.transpose(2, 3)) * scale
+    if kb is not None:
+        s = s + kb[:, None, None, :]
+    p = s.softmax(-1)
+    o_ref = p @ vf
+    r, m = report(f"attn fwd B{B} H{H} S{S} d{d} bias={bias} spike={spike}", O.view(B, S, H, d).permute(0, 2, 1, 3), o_ref)
+    lse_ref = torch.logsumexp(s, -1) / math.log(2.0)
+    ml = maxabs(lse2, lse_ref)
+    print(f"[parity] lse2 max_abs={ml:.3e}")
+    assert r < 8e-3 and ml < 2e-2
+    # backward
+    dO = torch.randn(B * S, D, device=dev()).to(BF16)
+    o_ref.backward(dO.float().view(B, S, H, d).permute(0, 2, 1, 3))
+    dQ = torch.zeros(B, H, S, d, device=dev(), dtype=BF16); dK = torch.zeros_like(dQ)
+    dqkv = torch.zeros(B * S, 3 * D, device=dev(), dtype=BF16)
+    ops.attn_bwd(q, k, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
+    r1, _ = report("attn bwd dQ", dQ, qf.grad)
+    r2, _ = report("attn bwd dK", dK, kf.grad)
+    r3, _ = report("attn bwd dV", dqkv[:, 2 * D:].reshape(B, S, H, d).permute(0, 2, 1, 3), vf.grad)
+    assert r1 < 2e-2 and r2 < 2e-2 and r3 < 2e-2
+    assert dqkv[:, :2 * D].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64)])
+def test_attention_fwd_bwd(ops, B, H, S, d):
+    _attn_case(ops, B, H, S, d)
+
+
+def test_attention_key_bias_and_rescale_branch(ops):
+    _attn_case(ops, 1, 2, 320, 128, bias=True)
+    _attn_case(ops, 1, 2, 448, 128, spike=True)
+    _attn_case(ops, 1, 2, 200, 64, bias=True, spike=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / EMA
+# ------------------------------------------------------------------------------------------------
+def test_adamw_matches_torch_and_ema(ops):
+    torch.manual_seed(40)
+    n = 100003
+    p0 = torch.randn(n, device=dev())
+    p = p0.clone(); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
+    ema = p0.clone(); pb = torch.empty(n, device=dev(), dtype=BF16)
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([tp], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ema_ref = p0.clone()
+    for step in range(1, 6):
+        g = torch.randn(n, device=dev()) * (0.1 * step)
+        tp.grad = g.clone()
+        opt.step()
+        ops.adamw_ema_step(p, g, m, v, step, 1e-3, ema=ema, ema_decay=0.99, p_bf16=pb)
+        ema_ref.sub_((1 - 0.99) * (ema_ref - tp.data))
+    d = maxabs(p, tp.data)
+    print(f"[parity] adamw vs torch.optim.AdamW after 5 steps: max_abs={d:.3e}")
+    # |p| ~ 4 -> fp32 ulp 4.8e-7; torch's foreach/fused kernels order the same ops differently: allow 8 ulp
+    assert d < 4e-6
+    assert maxabs(ema, ema_ref) < 4e-6
+    assert torch.equal(pb, p.to(BF16))
+
+
+def test_adamw_bf16_arena(ops):
+    torch.manual_seed(41)
+    n = 8 * 4099
+    p0 = torch.randn(n, device=dev()).to(BF16)
+    p = p0.clone(); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev()); ema = p0.clone()
+    pr = p0.float(); mr = torch.zeros(n, device=dev()); vr = torch.zeros(n, device=dev())
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 1e-2
+    for step in range(1, 4):
+        g = (torch.randn(n, device=dev()) * 0.1).to(BF16)
+        ops.adamw_ema_step(p, g, m, v, step, lr, ema=ema, ema_decay=0.9)
+        gf = g.float()
+        pr = pr * (1 - lr * wd)
+        mr = mr + (gf - mr) * (1 - b1)
+        vr = vr * b2 + (1 - b2) * gf * gf
+        pr = pr - (lr / (1 - b1 ** step)) * (mr / (vr.sqrt() / math.sqrt(1 - b2 ** step) + eps))
+        pr = pr.to(BF16).float()
+    assert report("adamw bf16 arena", p, pr)[1] < 2e-2
+    assert maxabs(m, mr) < 1e-6
+
+
+def test_ema_update_and_grad_norm(ops):
+    torch.manual_seed(42)
+    s = torch.randn(1000, device=dev()); p = torch.randn(1000, device=dev())
+    ref = s - (1 - 0.999) * (s - p)
+    ops.ema_update(s, p, 0.999)
+    assert maxabs(s, ref) < 1e-6                      # tests/test_ema.py:39-105 tolerance (atol 1e-6)
+    g = torch.randn(12345, device=dev())
+    out = ops.grad_norm(g)
+    assert abs(out[0].item() - (g * g).sum().item()) < 1e-3 * (g * g).sum().item()
+    assert out[1].item() == g.abs().max().item()
