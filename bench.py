@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native diffusion train step.
+
+Workload (BASELINE.json configs[2], per-GPU replica): Flux.1-dev MMDiT (19 double + 38 single blocks, D=3072, 24x128 heads,
+guidance embeds), LoRA rank 32 on the attention projections, 1024^2 (latents [B,16,128,128] -> 4096 image tokens + 512 T5
+tokens), bf16, AdamW; synthetic latents / text embeddings and random-init weights of the true architecture (no network here).
+One "step" = prepare_batch (in-kernel noise + flow noising + target) -> MMDiT forward -> MSE -> hand-written backward ->
+(bucketed RCCL all-reduce for N>1) -> fused AdamW, exactly what Trainer.train_step runs.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel class (the bf16 MFMA
+GEMM, measured live with hipEvent pairs on the launch stream by libst355's profiler) and `cpu_baseline` (the oracle timed on
+the host cores for a bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table); never the 2:1-sparse figure
+
+
+def train_flops_per_image(n_blocks: int, D: int, S: int) -> float:
+    """per block forward = 2*S*12*D^2 (linears) + 4*S^2*D (attention); LoRA train step (no base wgrad, no
+    recompute) = 2 x linears (fwd + dgrad) + 3 x attention (fwd + 2x bwd).  Flux.1-dev @1024^2: 1.64e14 FLOP / image."""
+    lin = n_blocks * 2.0 * S * 12 * D * D
+    att = n_blocks * 4.0 * S * S * D
+    return 2 * lin + 3 * att
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="per-GPU batch (images)")
+    ap.add_argument("--layers", type=int, default=19)
+    ap.add_argument("--single-layers", type=int, default=38)
+    ap.add_argument("--rank", type=int, default=32)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """the oracle (plain-torch restatement of the reference path) on the host cores: 1 double + 1 single Flux block at full width
+    and full sequence, forward + autograd backward, fp32; extrapolated linearly in block count to the 19+38 stack."""
+    from oracle import flux as OF
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = OF.FluxConfig(num_layers=1, num_single_layers=1)
+    P = OF.init_params(cfg, seed=1)
+    D = cfg.inner_dim
+    lat = args.res // 8
+    S_img, S_txt = (lat // 2) ** 2, 512
+    B = 1
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(B, S_img, D, generator=g).requires_grad_(True)
+    txt = torch.randn(B, S_txt, D, generator=g).requires_grad_(True)
+    temb = torch.randn(B, D, generator=g)
+    ids = torch.cat([torch.zeros(S_txt, 3), OF.prepare_latent_image_ids(lat, lat)], 0)
+    cos, sin = OF.rope_tables(ids)
+    t0 = time.time()
+    e, h = OF.double_block(P, cfg, 0, img, txt, temb, cos, sin)
+    (e.float().pow(2).mean() + h.float().pow(2).mean()).backward()
+    t_double = time.time() - t0
+    x = torch.randn(B, S_img + S_txt, D, generator=g).requires_grad_(True)
+    t0 = time.time()
+    y = OF.single_block(P, cfg, 0, x, temb, cos, sin)
+    y.float().pow(2).mean().backward()
+    t_single = time.time() - t0
+    step_s = t_double * args.layers + t_single * args.single_layers
+    return {
+        "value": round(B / step_s, 6), "unit": "images/s", "cores": cores, "kind": "port",
+        "sample": f"oracle (plain torch fp32, autograd) 1 double + 1 single Flux block fwd+bwd at D=3072, S={S_img}+{S_txt}, B=1: "
+                  f"{t_double:.1f}s + {t_single:.1f}s, extrapolated x{args.layers}/x{args.single_layers} blocks = {step_s:.0f} s/step",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path for the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL over xGMI on ROCm
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from simpletuner_amd import ops
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+
+    cfg = default_config(lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3)
+    acc = St355Accelerator(dev)
+    plugin = Flux(cfg, acc)
+    plugin.load_model(num_layers=args.layers, num_single_layers=args.single_layers, guidance_embeds=True)
+    plugin.add_lora_adapter()
+    trainer = Trainer(cfg, plugin, acc)
+
+    lat = args.res // 8
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    def make_batch():
+        return {
+            "latent_batch": torch.randn(B, 16, lat, lat, device=dev, generator=gen).to(torch.bfloat16),
+            "prompt_embeds": torch.randn(B, 512, 4096, device=dev, generator=gen).to(torch.bfloat16),
+            "add_text_embeds": torch.randn(B, 768, device=dev, generator=gen).to(torch.bfloat16),
+        }
+    batches = [make_batch() for _ in range(2)]   # resident in HBM before the timed region
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step(dict(batches[i % 2]))
+    sync()
+    if not args.no_prof:
+        ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(dict(batches[i % 2]))
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_prof:
+        ops.prof_enable(False)
+        prof = ops.prof_collect()
+        ops.prof_reset()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        S_img, S_txt = (lat // 2) ** 2, 512
+        step_flops = train_flops_per_image(args.layers + args.single_layers, 3072, S_img + S_txt) * B
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        roof = None
+        kernels = None
+        if prof is not None:
+            g = prof["gemm"]
+            if g["ms"] > 0:
+                ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": "k_gemm_bf16 (all epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 1),
+                        "share_of_step": round(g["ms"] / (elapsed * 1e3), 3)}
+            kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 2), "launches_per_step": v["launches"] // args.steps,
+                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None,
+                           "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
+                       for k, v in prof.items() if v["launches"]}
+        out = {
+            "metric": "training images/sec (whole node), Flux.1-dev LoRA r32 1024^2 train step",
+            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
+                                   f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+            "step_model_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "loss": round(loss_val, 5),
+            "roofline": roof,
+            "kernels": kernels,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""Flux model-family plugin — drop-in for simpletuner/helpers/models/flux/model.py on MI355X.
+
+Same class attributes and step-path methods as the reference plugin (flux/model.py:49-114, 630-864):
+`Flux(config, accelerator)`, `prepare_batch`, `model_predict -> {"model_prediction": [B,16,H,W]}`, `loss_with_logs`,
+`get_trained_component`, `add_lora_adapter`.  `model_predict` divides the timesteps by 1000 in the batch dict exactly like
+the reference (flux/model.py:739-745; pinned by tests/test_flux_model.py:213 there).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..foundation import ModelFoundation, ModelRegistry, ModelTypes, PredictionTypes
+from .transformer import FluxTransformer2DModel
+
+BF16 = torch.bfloat16
+
+
+def prepare_latent_image_ids(batch_size, height, width, device, dtype):
+    """flux/__init__.py:48-63 — [ (H/2)(W/2), 3 ] fp32 ids (row, col in channels 1, 2)"""
+    ids = torch.zeros(height // 2, width // 2, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(height // 2)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(width // 2)[None, :]
+    return ids.reshape(-1, 3).to(device=device, dtype=torch.float32)
+
+
+def pack_latents(latents, batch_size=None, num_channels_latents=None, height=None, width=None):
+    """flux/__init__.py:25-31 (HIP permute kernel)"""
+    return ops.flux_pack(latents)
+
+
+def unpack_latents(latents, height, width, vae_scale_factor):
+    """flux/__init__.py:34-45: height/width are PIXEL sizes, vae_scale_factor=16 -> token grid; returns [B, C/4, 2h, 2w]"""
+    h, w = height // vae_scale_factor, width // vae_scale_factor
+    return ops.flux_unpack(latents, latents.shape[-1] // 4, h * 2, w * 2)
+
+
+class Flux(ModelFoundation):
+    NAME = "Flux.1"
+    PREDICTION_TYPE = PredictionTypes.FLOW_MATCHING
+    MODEL_TYPE = ModelTypes.TRANSFORMER
+    MODEL_CLASS = FluxTransformer2DModel
+    MODEL_SUBFOLDER = "transformer"
+    LATENT_CHANNEL_COUNT = 16
+    DEFAULT_MODEL_FLAVOUR = "dev"
+    DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
+    HUGGINGFACE_PATHS = {"dev": "black-forest-labs/flux.1-dev", "schnell": "black-forest-labs/flux.1-schnell"}
+
+    def __init__(self, config, accelerator):
+        super().__init__(config, accelerator)
+        self._ids_cache = {}
+
+    # ---- loading (common.py:3400 load_model).  Checkpoints are absent offline: synthetic init or a provided state dict ----
+    def load_model(self, state_dict=None, **arch):
+        self.model = FluxTransformer2DModel(device=self.accelerator.device, **arch)
+        if state_dict is not None:
+            self.model.load_flat_state(state_dict)
+        else:
+            self.model.init_synthetic(seed=int(getattr(self.config, "seed", 42) or 42))
+        return self.model
+
+    def add_lora_adapter(self):
+        """common.py:1049-1128"""
+        if getattr(self.config, "model_type", "lora") != "lora":
+            raise NotImplementedError("full-rank Flux training is not wired yet (round 2: wgrad GEMM)")
+        targets = "all" if getattr(self.config, "flux_lora_target", "default") in ("all", "all+ffs", "context") else "default"
+        params = self.unwrap_model(self.model).add_lora_adapter(rank=int(self.config.lora_rank),
+                                                                alpha=getattr(self.config, "lora_alpha", None), targets=targets,
+                                                                seed=int(getattr(self.config, "seed", 42) or 42) + 7,
+                                                                init_b_std=float(getattr(self.config, "lora_init_b_std", 0.0)))
+        self.unwrap_model(self.model).prepare_for_training()
+        return params
+
+    def _flux_guidance_scales(self, prepared_batch, batch_size):
+        mode = getattr(self.config, "flux_guidance_mode", "constant")
+        if mode != "constant":
+            raise NotImplementedError("only flux_guidance_mode=constant is implemented")
+        return [float(getattr(self.config, "flux_guidance_value", 1.0))] * batch_size
+
+    def model_predict(self, prepared_batch: dict):
+        return self._model_predict_single(prepared_batch)
+
+    def _model_predict_single(self, prepared_batch: dict):
+        """flux/model.py:707-864"""
+        lat = prepared_batch["latents"]
+        B, Cc, Hh, Ww = lat.shape
+        dev = self.accelerator.device
+        packed = pack_latents(prepared_batch["noisy_latents"].to(device=dev, dtype=BF16))
+        comp = self.get_trained_component()
+        guidance = None
+        if getattr(comp.config, "guidance_embeds", False):
+            guidance = torch.tensor(self._flux_guidance_scales(prepared_batch, B), device=dev)
+        key = (Hh, Ww, prepared_batch["prompt_embeds"].shape[1])
+        if key not in self._ids_cache:
+            self._ids_cache[key] = (prepare_latent_image_ids(B, Hh, Ww, dev, BF16),
+                                    torch.zeros(prepared_batch["prompt_embeds"].shape[1], 3, device=dev, dtype=torch.float32))
+        img_ids, text_ids = self._ids_cache[key]
+        # "divide it by 1000 for now because we scale it by 1000 in the transformer model" (flux/model.py:739-745, 790)
+        prepared_batch["timesteps"] = prepared_batch["timesteps"].to(device=dev, dtype=torch.float32) / 1000.0
+        if getattr(self.config, "flux_attention_masked_training", False):
+            raise NotImplementedError("flux_attention_masked_training is not implemented on the st355 path")
+        model_pred = self.model(
+            hidden_states=packed,
+            timestep=prepared_batch["timesteps"],
+            guidance=guidance,
+            pooled_projections=prepared_batch["add_text_embeds"].to(device=dev, dtype=BF16),
+            encoder_hidden_states=prepared_batch["prompt_embeds"].to(device=dev, dtype=BF16),
+            txt_ids=text_ids,
+            img_ids=img_ids,
+            joint_attention_kwargs=None,
+            return_dict=False,
+        )[0]
+        return {
+            "model_prediction": _UnpackFn.apply(model_pred, Hh * 8, Ww * 8),
+            "crepa_hidden_states": None,
+            "hidden_states_buffer": None,
+        }
+
+
+class _UnpackFn(torch.autograd.Function):
+    """unpack_latents with pack_latents as its backward (both are pure permutes, K3)"""
+
+    @staticmethod
+    def forward(ctx, packed, height, width):
+        return unpack_latents(packed.contiguous(), height=height, width=width, vae_scale_factor=16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.flux_pack(g.to(BF16).contiguous()), None, None
+
+
+ModelRegistry.register("flux", Flux)

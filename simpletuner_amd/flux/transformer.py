@@ -1,0 +1,625 @@
+"""FluxTransformer2DModel — the MI355X-native trained component for the Flux.1 MMDiT.
+
+Mirrors the reference's module surface (simpletuner/helpers/models/flux/transformer.py:690-1513): same constructor
+arguments, same `forward(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+guidance, ..., return_dict)` contract, same state-dict keys as the diffusers checkpoint, `.config`, `.parameters()`,
+DDP-wrappable, usable as `ModelFoundation.MODEL_CLASS`.  Nothing here is a torch op on the hot path: forward and the
+hand-written backward are sequences of libst355 launches (simpletuner_amd.ops); torch owns memory, streams and autograd's
+outer edge (one autograd.Function for the whole network, so `accelerator.backward(loss)` works unchanged).
+
+Storage layout (designed for 288 GB HBM, not for a 24 GB card):
+  * projection weights that share an input live FUSED in one buffer ([to_q|to_k|to_v] -> [3D,D]); the per-projection
+    nn.Parameters are views into it, so checkpoints load straight into the fused layout and nothing is duplicated;
+  * all AdaLN modulation linears of all 57 blocks (+norm_out) are one [342D+2D, D] matrix: the per-step modulation
+    is ONE skinny GEMM on SiLU(temb) instead of 115 launches;
+  * frozen-base (LoRA) training keeps a K-major transposed copy of every weight used by a dgrad GEMM (W^T), so the
+    backward reuses the same NT kernel (costs +1x weights of HBM; 2 x 24 GB for Flux.1-dev);
+  * LoRA adapters live in two flat fp32 arenas (params, grads) -> one fused AdamW(+EMA) launch and one RCCL all-reduce.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers to register parameters under dotted (checkpoint) names
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    pass
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Holder())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], param)
+
+
+def _frozen(t: torch.Tensor) -> nn.Parameter:
+    return nn.Parameter(t, requires_grad=False)
+
+
+class LoraGroup:
+    """LoRA adapters of the projections that share one input (one fused GEMM).  peft semantics: y += (alpha/r) B A x."""
+
+    def __init__(self, K: int, N_total: int, targets: List[Tuple[str, int, int]], rank: int, alpha: float, device):
+        self.K, self.N_total, self.targets = K, N_total, targets
+        self.rank, self.scale = rank, alpha / rank
+        self.r_pad = 32 if rank <= 32 else 64
+        assert rank <= 64, "LoRA rank > 64 not supported by the rank-space kernels yet"
+        self.K2 = (len(targets) * self.r_pad + 63) // 64 * 64
+        z = lambda *s: torch.zeros(*s, dtype=BF16, device=device)
+        self.A_cat, self.A_cat_T = z(self.K2, K), z(K, self.K2)
+        self.B_blk, self.B_blk_T = z(N_total, self.K2), z(self.K2, N_total)
+        self.A: List[torch.Tensor] = []   # fp32 params (views into the flat arena), filled by the owner
+        self.B: List[torch.Tensor] = []
+        self.gA: List[torch.Tensor] = []  # fp32 grad views
+        self.gB: List[torch.Tensor] = []
+        self.flat_lo = self.flat_hi = 0   # this group's [lo, hi) element range inside the flat gradient arena
+
+    def pack(self):
+        for g, (_, n_off, _) in enumerate(self.targets):
+            ops.lora_pack(self.A[g], self.B[g], self.scale, self.A_cat, self.A_cat_T, self.B_blk, self.B_blk_T,
+                          k2_off=g * self.r_pad, n_off=n_off)
+
+    def grads(self, x, T, dy, U, accumulate: bool, sync=None):
+        """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r])."""
+        for g, (_, n_off, N) in enumerate(self.targets):
+            c0 = g * self.r_pad
+            ops.skinny_tn(dy[:, n_off:n_off + N], T[:, c0:c0 + self.r_pad], self.gB[g], self.rank, 1, self.rank,
+                          alpha=self.scale, accumulate=accumulate)
+            ops.skinny_tn(x, U[:, c0:c0 + self.r_pad], self.gA[g], 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
+        if sync is not None:
+            sync.ready(self.flat_lo, self.flat_hi)
+
+
+class FluxTransformer2DModel(nn.Module):
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, num_layers: int = 19, num_single_layers: int = 38,
+                 attention_head_dim: int = 128, num_attention_heads: int = 24, joint_attention_dim: int = 4096,
+                 pooled_projection_dim: int = 768, guidance_embeds: bool = False, axes_dims_rope: Tuple[int, ...] = (16, 56, 56),
+                 device=None, **_ignored):
+        super().__init__()
+        self.config = SimpleNamespace(patch_size=patch_size, in_channels=in_channels, num_layers=num_layers,
+                                      num_single_layers=num_single_layers, attention_head_dim=attention_head_dim,
+                                      num_attention_heads=num_attention_heads, joint_attention_dim=joint_attention_dim,
+                                      pooled_projection_dim=pooled_projection_dim, guidance_embeds=guidance_embeds,
+                                      axes_dims_rope=tuple(axes_dims_rope))
+        if attention_head_dim not in (64, 128):
+            raise ValueError("attention_head_dim must be 64 or 128 (kernels built for these)")
+        self.out_channels = in_channels
+        self.H, self.hd = num_attention_heads, attention_head_dim
+        self.D = D = self.H * self.hd
+        self.inner_dim = D
+        if D % 64 or joint_attention_dim % 64 or pooled_projection_dim % 64 or in_channels % 64:
+            raise ValueError("all contraction dims must be multiples of 64")
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = self.device_
+        e = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+
+        # ---- embedders ----
+        def lin(name, out_f, in_f):
+            w, b = e(out_f, in_f), e(out_f)
+            _attach(self, name + ".weight", _frozen(w)); _attach(self, name + ".bias", _frozen(b))
+            return SimpleNamespace(w=w, b=b, wT=None)
+
+        self.l_x = lin("x_embedder", D, in_channels)
+        self.l_ctx = lin("context_embedder", D, joint_attention_dim)
+        self.l_t1 = lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+        self.l_t2 = lin("time_text_embed.timestep_embedder.linear_2", D, D)
+        if guidance_embeds:
+            self.l_g1 = lin("time_text_embed.guidance_embedder.linear_1", D, 256)
+            self.l_g2 = lin("time_text_embed.guidance_embedder.linear_2", D, D)
+        self.l_p1 = lin("time_text_embed.text_embedder.linear_1", D, pooled_projection_dim)
+        self.l_p2 = lin("time_text_embed.text_embedder.linear_2", D, D)
+
+        # ---- one matrix for every AdaLN modulation linear ----
+        self.mod_total = (num_layers * 12 + num_single_layers * 3 + 2) * D
+        self.mod_w, self.mod_b = e(self.mod_total, D), e(self.mod_total)
+        off = 0
+
+        def mod_slice(name, n):
+            nonlocal off
+            _attach(self, name + ".weight", _frozen(self.mod_w[off:off + n])); _attach(self, name + ".bias", _frozen(self.mod_b[off:off + n]))
+            o = off
+            off += n
+            return o
+
+        def fused(prefix, names, out_each, in_f):
+            n = len(names)
+            w, b = e(n * out_each, in_f), e(n * out_each)
+            for j, nm in enumerate(names):
+                _attach(self, f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
+                _attach(self, f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
+            return SimpleNamespace(w=w, b=b, wT=None, lora=None)
+
+        def normw(name):
+            w = torch.ones(self.hd, dtype=BF16, device=dev)
+            _attach(self, name + ".weight", _frozen(w))
+            return w
+
+        self.double: List[SimpleNamespace] = []
+        for i in range(num_layers):
+            p = f"transformer_blocks.{i}."
+            blk = SimpleNamespace()
+            blk.mod_off = mod_slice(p + "norm1.linear", 6 * D)
+            blk.mod_off_c = mod_slice(p + "norm1_context.linear", 6 * D)
+            blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
+            blk.add_qkv = fused(p + "attn.", ["add_q_proj", "add_k_proj", "add_v_proj"], D, D)
+            blk.to_out = fused(p + "attn.", ["to_out.0"], D, D)
+            blk.to_add_out = fused(p + "attn.", ["to_add_out"], D, D)
+            blk.norm_q, blk.norm_k = normw(p + "attn.norm_q"), normw(p + "attn.norm_k")
+            blk.norm_added_q, blk.norm_added_k = normw(p + "attn.norm_added_q"), normw(p + "attn.norm_added_k")
+            blk.ff1 = fused(p, ["ff.net.0.proj"], 4 * D, D)
+            blk.ff2 = fused(p, ["ff.net.2"], D, 4 * D)
+            blk.ffc1 = fused(p, ["ff_context.net.0.proj"], 4 * D, D)
+            blk.ffc2 = fused(p, ["ff_context.net.2"], D, 4 * D)
+            self.double.append(blk)
+        self.single: List[SimpleNamespace] = []
+        for i in range(num_single_layers):
+            p = f"single_transformer_blocks.{i}."
+            blk = SimpleNamespace()
+            blk.mod_off = mod_slice(p + "norm.linear", 3 * D)
+            blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
+            blk.norm_q, blk.norm_k = normw(p + "attn.norm_q"), normw(p + "attn.norm_k")
+            blk.proj_mlp = fused(p, ["proj_mlp"], 4 * D, D)
+            blk.proj_out = fused(p, ["proj_out"], D, 5 * D)
+            self.single.append(blk)
+        self.mod_off_out = mod_slice("norm_out.linear", 2 * D)
+        assert off == self.mod_total
+        self.l_out = lin("proj_out", patch_size * patch_size * self.out_channels, D)
+
+        self.lora_groups: List[LoraGroup] = []
+        self.lora_flat: Optional[torch.Tensor] = None
+        self.lora_grad_flat: Optional[torch.Tensor] = None
+        self._lora_params: List[nn.Parameter] = []
+        self._rope_cache: Dict = {}
+        self._prepared = False
+        self.accumulate_lora_grads = False
+        self.gradient_checkpointing = False
+        self.grad_sync = None            # training.grad_sync.GradSync over lora_grad_flat (data-parallel replicas)
+        self._last_grad_flat = None
+
+    # ------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load_flat_state(self, state: Dict[str, torch.Tensor]):
+        """copy a {checkpoint name: tensor} dict into the fused buffers (names = diffusers state-dict keys)"""
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state and ".lora_" not in k]
+        if missing:
+            raise KeyError(f"missing weights: {missing[:5]} ... ({len(missing)})")
+        for k, v in state.items():
+            if k in own:
+                own[k].data.copy_(v.to(device=own[k].device, dtype=own[k].dtype))
+        self._prepared = False
+
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 42):
+        """seed-deterministic random init on device, same distribution family as oracle.flux.init_params (benchmarks)."""
+        g = torch.Generator(device=self.device_).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if ".lora_" in name:
+                continue
+            if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+                p.data.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=self.device_))
+            elif name.endswith(".bias"):
+                p.data.copy_(0.02 * torch.randn(p.shape, generator=g, device=self.device_))
+            else:
+                p.data.copy_(torch.randn(p.shape, generator=g, device=self.device_, dtype=BF16) * (1.0 / math.sqrt(p.shape[1])))
+        self._prepared = False
+
+    @torch.no_grad()
+    def prepare_for_training(self):
+        """build the K-major transposed copies the dgrad GEMMs read (frozen base => done once)."""
+        def tr(l):
+            l.wT = l.w.t().contiguous()
+        for blk in self.double:
+            for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2):
+                tr(l)
+        for blk in self.single:
+            for l in (blk.qkv, blk.proj_mlp, blk.proj_out):
+                tr(l)
+        tr(self.l_out)
+        self._prepared = True
+
+    # ------------------------------------------------------------------------------------------------
+    # LoRA (peft-compatible naming: <module>.lora_A.default.weight / lora_B.default.weight)
+    # ------------------------------------------------------------------------------------------------
+    def add_lora_adapter(self, rank: int = 32, alpha: Optional[float] = None, targets: str = "default", seed: int = 7,
+                         init_b_std: float = 0.0):
+        """common.py:1049-1128 (LoraConfig(r, lora_alpha, target_modules)).  targets: 'default' = attn to_q,to_k,to_v,to_out.0
+        (+ single-block to_q,to_k,to_v); 'all' adds the context-stream projections."""
+        alpha = float(rank if alpha is None else alpha)
+        D, dev = self.D, self.device_
+        plan = []  # (group, name, n_off, N, K)
+        self.lora_groups = []
+
+        def group(lin, prefix, names, K):
+            g = LoraGroup(K, lin.w.shape[0], [(prefix + n, j * (lin.w.shape[0] // len(names)), lin.w.shape[0] // len(names))
+                                              for j, n in enumerate(names)], rank, alpha, dev)
+            lin.lora = g
+            self.lora_groups.append(g)
+            for (name, n_off, N) in g.targets:
+                plan.append((g, name, N, K))
+
+        for i, blk in enumerate(self.double):
+            p = f"transformer_blocks.{i}.attn."
+            group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
+            group(blk.to_out, p, ["to_out.0"], D)
+            if targets == "all":
+                group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
+                group(blk.to_add_out, p, ["to_add_out"], D)
+        for i, blk in enumerate(self.single):
+            group(blk.qkv, f"single_transformer_blocks.{i}.attn.", ["to_q", "to_k", "to_v"], D)
+        total = sum(rank * K + N * rank for (_, _, N, K) in plan)
+        total = (total + 7) // 8 * 8
+        self.lora_flat = torch.zeros(total, dtype=F32, device=dev)
+        self.lora_grad_flat = torch.zeros(total, dtype=F32, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        off = 0
+        self._lora_params = []
+        for (g, name, N, K) in plan:
+            if not g.A:
+                g.flat_lo = off
+            g.flat_hi = off + rank * K + N * rank
+            a = self.lora_flat[off:off + rank * K].view(rank, K); ga = self.lora_grad_flat[off:off + rank * K].view(rank, K)
+            off += rank * K
+            b = self.lora_flat[off:off + N * rank].view(N, rank); gb = self.lora_grad_flat[off:off + N * rank].view(N, rank)
+            off += N * rank
+            bound = 1.0 / math.sqrt(K)   # kaiming_uniform(a=sqrt(5)) on [r,K] (peft default for lora_A)
+            a.copy_((torch.rand(rank, K, generator=gen, device=dev) * 2 - 1) * bound)
+            if init_b_std > 0:
+                b.copy_(torch.randn(N, rank, generator=gen, device=dev) * init_b_std)
+            pa, pb = nn.Parameter(a), nn.Parameter(b)
+            _attach(self, name + ".lora_A.default.weight", pa); _attach(self, name + ".lora_B.default.weight", pb)
+            g.A.append(pa.data); g.B.append(pb.data); g.gA.append(ga); g.gB.append(gb)
+            self._lora_params += [pa, pb]
+        return self._lora_params
+
+    def trainable_parameters(self):
+        return list(self._lora_params)
+
+    # ------------------------------------------------------------------------------------------------
+    # rope tables (FluxPosEmbed, theta=1e4, float64 frequencies -> fp32 tables); cached per id layout
+    # ------------------------------------------------------------------------------------------------
+    def _rope(self, txt_ids: torch.Tensor, img_ids: torch.Tensor):
+        key = (txt_ids.shape[0], img_ids.shape[0], float(img_ids[-1, 1]), float(img_ids[-1, 2]), float(img_ids[0, 0]))
+        hit = self._rope_cache.get(key)
+        if hit is not None:
+            return hit
+        ids = torch.cat((txt_ids, img_ids), dim=0).float().cpu()
+        cos_l, sin_l = [], []
+        for i, d in enumerate(self.config.axes_dims_rope):
+            freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+            f = torch.outer(ids[:, i].to(torch.float64), freqs)
+            cos_l.append(f.cos().repeat_interleave(2, dim=1).float()); sin_l.append(f.sin().repeat_interleave(2, dim=1).float())
+        out = (torch.cat(cos_l, -1).contiguous().to(self.device_), torch.cat(sin_l, -1).contiguous().to(self.device_))
+        self._rope_cache[key] = out
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    # forward / backward engines
+    # ------------------------------------------------------------------------------------------------
+    def _lin_fwd(self, lin, x, **kw):
+        """y = x W^T + b (+ LoRA K-extension).  Returns (y, T) where T = x A^T (kept for the rank-space backward)."""
+        T = None
+        if lin.lora is not None:
+            T = ops.gemm(x, lin.lora.A_cat)
+            kw.update(a2=T, b2=lin.lora.B_blk)
+        return ops.gemm(x, lin.w, bias=lin.b, **kw), T
+
+    def _lin_bwd(self, lin, dy, x=None, T=None, **kw):
+        """dx = dy W (+ LoRA K-extension (dy sB) A); also writes the adapter gradients when the projection has one."""
+        U = None
+        if lin.lora is not None:
+            U = ops.gemm(dy, lin.lora.B_blk_T)
+            kw.update(a2=U, b2=lin.lora.A_cat_T)
+        dx = ops.gemm(dy, lin.wT, **kw)
+        if lin.lora is not None:
+            lin.lora.grads(x, T, dy, U, self.accumulate_lora_grads, self.grad_sync)
+        return dx
+
+    def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool):
+        D, H, hd = self.D, self.H, self.hd
+        B, Si, _ = hidden_states.shape
+        St = encoder_hidden_states.shape[1]
+        S = Si + St
+        Sp = (S + 63) // 64 * 64
+        dev = self.device_
+        for g in self.lora_groups:
+            g.pack()
+        cos, sin = self._rope(txt_ids, img_ids)
+        # ---- embeddings (flux/transformer.py:1001-1064) ----
+        img = ops.gemm(hidden_states.reshape(B * Si, -1).contiguous(), self.l_x.w, bias=self.l_x.b)
+        txt = ops.gemm(encoder_hidden_states.reshape(B * St, -1).contiguous(), self.l_ctx.w, bias=self.l_ctx.b)
+        t32 = timestep.to(device=dev, dtype=F32).contiguous()
+        temb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(t32, 256, 1000.0), self.l_t1.w, bias=self.l_t1.b)), self.l_t2.w, bias=self.l_t2.b)
+        if self.config.guidance_embeds:
+            if guidance is None:
+                raise ValueError("guidance_embeds=True requires a guidance tensor")
+            g32 = guidance.to(device=dev, dtype=F32).contiguous()
+            gemb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(g32, 256, 1000.0), self.l_g1.w, bias=self.l_g1.b)), self.l_g2.w, bias=self.l_g2.b)
+            temb = ops.add(temb, gemb)
+        pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
+        temb = ops.add(temb, pemb)
+        mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
+        ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, dbl=[], sgl=[])
+        scale = 1.0 / math.sqrt(hd)
+
+        def alloc_heads():
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+            mk = torch.zeros if Sp > S else torch.empty
+            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+            return Q, K, Qt, Kt, Vt
+
+        # ---- double blocks (flux/transformer.py:607-687) ----
+        for blk in self.double:
+            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+            n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+            n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
+            qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
+            T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
+            for b in range(B):
+                kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
+                kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+                ops.gemm(n_txt[b * St:(b + 1) * St], blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t)
+                ops.gemm(n_img[b * Si:(b + 1) * Si], blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i)
+            Q, K, Qt, Kt, Vt = alloc_heads()
+            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
+            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
+            del Vt
+            x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
+            T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
+            T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
+            for b in range(B):
+                O_t, O_i = O[b * S:b * S + St], O[b * S + St:(b + 1) * S]
+                kw_i, kw_t = {}, {}
+                if T_o is not None:
+                    ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
+                    kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
+                if T_ao is not None:
+                    ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
+                    kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
+                ops.gemm(O_i, blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
+                         aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i)
+                ops.gemm(O_t, blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
+                         aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t)
+            # MLPs
+            n2 = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
+            hact = ops.gemm(n2, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
+            x2_img = ops.gemm(hact, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si)
+            n2 = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
+            hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
+            hact = ops.gemm(n2, blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)
+            x2_txt = ops.gemm(hact, blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)
+            del n2, hact
+            if save:
+                ctx.dbl.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
+                                               Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
+                                               hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
+            img, txt = x2_img, x2_txt
+
+        # ---- joint sequence [txt || img] (flux/transformer.py:1332) ----
+        if B == 1:
+            x = torch.cat([txt, img], dim=0)
+        else:
+            x = torch.cat([txt.view(B, St, D), img.view(B, Si, D)], dim=1).reshape(B * S, D)
+        del img, txt
+        # ---- single blocks (flux/transformer.py:473-510) ----
+        for blk in self.single:
+            ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+            n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
+            qkv, T = self._lin_fwd(blk.qkv, n)
+            Q, K, Qt, Kt, Vt = alloc_heads()
+            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
+            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
+            del Vt
+            hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
+            hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
+            # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
+            x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
+                             aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S)
+            del hact
+            if save:
+                ctx.sgl.append(SimpleNamespace(x=x, n=n, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T))
+            x = x_out
+        # ---- output head (flux/transformer.py:1501-1506): AdaLayerNormContinuous chunk order is (scale, shift) ----
+        if B == 1:
+            x_img = x[St:]
+        else:
+            x_img = x.view(B, S, D)[:, St:].reshape(B * Si, D)
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        n_out = ops.ln_modulate_fwd(x_img, mo[:, :D], mo[:, D:2 * D], Si)
+        out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
+        if save:
+            ctx.x_img_final = x_img
+        return out.view(B, Si, -1), ctx
+
+    def _engine_backward(self, ctx, dout):
+        """hand-written backward for frozen-base (LoRA) training: dX chain + rank-space adapter gradients."""
+        if not self._prepared:
+            raise RuntimeError("call prepare_for_training() after loading weights (builds the K-major dgrad operands)")
+        D, H, hd = self.D, self.H, self.hd
+        B, Si, St, S, Sp, mod, cos, sin = ctx.B, ctx.Si, ctx.St, ctx.S, ctx.Sp, ctx.mod, ctx.cos, ctx.sin
+        dev = self.device_
+        scale = 1.0 / math.sqrt(hd)
+        dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        dn = ops.gemm(dout, self.l_out.wT)
+        dx_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
+        dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
+        if B == 1:
+            dx[St:] = dx_img
+        else:
+            dx.view(B, S, D)[:, St:] = dx_img.view(B, Si, D)
+        del dn, dx_img
+
+        def attn_backward(sv, dO, dqkv):
+            dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
+            ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
+            return dQ, dK
+
+        # ---- single blocks, reversed ----
+        dxg = None
+        for li in range(len(self.single) - 1, -1, -1):
+            blk, sv = self.single[li], ctx.sgl[li]
+            ctx.sgl[li] = None
+            ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+            g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
+            dO = ops.gemm(g, blk.proj_out.wT[:D])
+            dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
+            dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
+            del g, dhpre
+            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            dQ, dK = attn_backward(sv, dO, dqkv)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, S, 0, S)
+            del dQ, dK, dO
+            dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
+            if li > 0:
+                gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D]
+                dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx, gate=gprev, want_gated=True)
+            else:
+                dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
+            del dn, dn_mlp, dqkv, sv
+        # ---- split the joint gradient ----
+        if B == 1:
+            d_txt, d_img = dx[:St], dx[St:]
+        else:
+            d_txt = dx.view(B, S, D)[:, :St].reshape(B * St, D); d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
+        # ---- double blocks, reversed ----
+        for li in range(len(self.double) - 1, -1, -1):
+            blk, sv = self.double[li], ctx.dbl[li]
+            ctx.dbl[li] = None
+            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+            dO = torch.empty(B * S, D, dtype=BF16, device=dev)
+            d_x1 = {}
+            for (name, dcur, x1, hpre, f1, f2, m_, rows, to_o, T_o_) in (
+                    ("img", d_img, sv.x1_img, sv.hpre_img, blk.ff1, blk.ff2, mi, Si, blk.to_out, sv.T_o),
+                    ("txt", d_txt, sv.x1_txt, sv.hpre_txt, blk.ffc1, blk.ffc2, mt, St, blk.to_add_out, sv.T_ao)):
+                g = ops.scale_cols(dcur, m_[:, 5 * D:6 * D], rows)
+                dhpre = ops.gemm(g, f2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=hpre)
+                dn2 = ops.gemm(dhpre, f1.wT)
+                del g, dhpre
+                dx1, dx1g = ops.ln_modulate_bwd(dn2, x1, m_[:, 4 * D:5 * D], rows, dres=dcur, gate=m_[:, 2 * D:3 * D], want_gated=True)
+                d_x1[name] = dx1
+                del dn2
+                # attention output projection: dO rows of this stream (+ adapter grads)
+                lo = St if name == "img" else 0
+                if to_o.lora is not None:
+                    U = ops.gemm(dx1g, to_o.lora.B_blk_T)
+                for b in range(B):
+                    kw = dict(a2=U[b * rows:(b + 1) * rows], b2=to_o.lora.A_cat_T) if to_o.lora is not None else {}
+                    ops.gemm(dx1g[b * rows:(b + 1) * rows], to_o.wT, out=dO[b * S + lo:b * S + lo + rows], **kw)
+                if to_o.lora is not None:
+                    if B == 1:
+                        O_rows = sv.O[lo:lo + rows]
+                    else:
+                        O_rows = sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
+                    to_o.lora.grads(O_rows, T_o_, dx1g, U, self.accumulate_lora_grads, self.grad_sync)
+                    del U
+                del dx1g
+            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            dQ, dK = attn_backward(sv, dO, dqkv)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, 0, S)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
+            del dQ, dK, dO
+            last = li == 0
+            for (name, lin, n_in, T_, m_, rows, xin) in (("img", blk.qkv, sv.n_img, sv.T_img, mi, Si, sv.img),
+                                                         ("txt", blk.add_qkv, sv.n_txt, sv.T_txt, mt, St, sv.txt)):
+                lo = St if name == "img" else 0
+                if B == 1:
+                    dq_rows = dqkv[lo:lo + rows]
+                else:
+                    dq_rows = dqkv.view(B, S, 3 * D)[:, lo:lo + rows].reshape(B * rows, 3 * D)
+                if last and lin.lora is None:
+                    continue                      # nothing trainable upstream of the first block's context stream
+                dn = self._lin_bwd(lin, dq_rows, x=n_in, T=T_)
+                if last:
+                    continue                      # frozen embedders: the chain stops here
+                dxin, _ = ops.ln_modulate_bwd(dn, xin, m_[:, D:2 * D], rows, dres=d_x1[name])
+                if name == "img":
+                    d_img = dxin
+                else:
+                    d_txt = dxin
+                del dn
+            del dqkv, sv, d_x1
+        return None
+
+    # ------------------------------------------------------------------------------------------------
+    # public forward (reference signature: flux/transformer.py:940-960)
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None, txt_ids=None,
+                guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, **unsupported):
+        if attention_mask is not None:
+            raise NotImplementedError("flux_attention_masked_training is not wired to the HIP path yet")
+        for k, v in unsupported.items():
+            if v is not None and v is not False:
+                raise NotImplementedError(f"FluxTransformer2DModel(st355): argument {k!r} is not supported on the HIP path")
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        if timestep.ndim != 1:
+            raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
+        need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
+        if need_grad:
+            out = _FluxFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids,
+                                *self._lora_params)
+        else:
+            with torch.no_grad():
+                out, _ = self._engine_forward(hidden_states.to(BF16), encoder_hidden_states.to(BF16), pooled_projections, timestep,
+                                              guidance, img_ids, txt_ids, save=False)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+
+class _FluxFn(torch.autograd.Function):
+    """one autograd node for the whole network: forward = kernel sequence, backward = hand-written kernel sequence"""
+
+    @staticmethod
+    def forward(fctx, model, hidden_states, enc, pooled, timestep, guidance, img_ids, txt_ids, *lora_params):
+        out, ctx = model._engine_forward(hidden_states.detach().to(BF16), enc.detach().to(BF16), pooled.detach(), timestep.detach(),
+                                         None if guidance is None else guidance.detach(), img_ids, txt_ids, save=True)
+        fctx.model, fctx.ectx, fctx.n_lora = model, ctx, len(lora_params)
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
+        model._engine_backward(fctx.ectx, dout)
+        fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_scale_from_sync = model.grad_sync.finish()   # all slices reduced (SUM); optimizer folds 1/world
+        # hand autograd a private flat copy (one 4 B/param copy) so .grad never aliases the arena the next backward overwrites;
+        # the per-parameter grads stay views of ONE contiguous buffer, which the fused optimizer / RCCL all-reduce exploit.
+        gflat = model.lora_grad_flat.clone()
+        model._last_grad_flat = gflat
+        grads, off = [], 0
+        for p in model._lora_params:
+            n = p.numel()
+            grads.append(gflat[off:off + n].view_as(p))
+            off += n
+        return (None,) * 8 + tuple(grads)

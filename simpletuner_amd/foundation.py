@@ -1,0 +1,262 @@
+"""Model-family plugin surface, mirroring the reference's duck-typed contract:
+
+    ModelRegistry.register / get / model_families        simpletuner/helpers/models/registry.py:54-98
+    PredictionTypes / ModelTypes                         simpletuner/helpers/models/common.py:368-392
+    ModelFoundation.prepare_batch                        simpletuner/helpers/models/common.py:5862-6041
+                   .sample_flow_sigmas                   simpletuner/helpers/models/common.py:4994-5090
+                   ._prepare_flow_noisy_latents          simpletuner/helpers/models/common.py:4975-4992
+                   .get_prediction_target / flow target  simpletuner/helpers/models/common.py:4610-4658
+                   .loss / loss_with_logs / aux loss     simpletuner/helpers/models/common.py:6217-6430, xm_mixin.py:476-485
+    apply_flow_schedule_shift                            simpletuner/helpers/training/custom_schedule.py:443-478
+
+Same method names, argument meaning, batch-dict keys and error behaviour; the bulk arithmetic (noising, target, MSE and
+its gradient) runs in libst355 (ops.flow_noise_mix / ops.mse_loss).  Per-sample scalars ([B]-sized sigma math) stay in torch.
+Only the options used by the BASELINE configs are implemented; anything else raises NotImplementedError (never a silent
+different path).
+"""
+from __future__ import annotations
+
+import math
+from enum import Enum
+from typing import Any, Dict, Optional, Type
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+class PredictionTypes(Enum):
+    EPSILON = "epsilon"
+    SAMPLE = "sample"
+    V_PREDICTION = "v_prediction"
+    FLOW_MATCHING = "flow_matching"
+
+    @staticmethod
+    def from_str(label):
+        if label in ("eps", "epsilon"):
+            return PredictionTypes.EPSILON
+        if label in ("vpred", "v_prediction", "v-prediction"):
+            return PredictionTypes.V_PREDICTION
+        if label in ("sample", "x_prediction", "x-prediction"):
+            return PredictionTypes.SAMPLE
+        if label in ("flow", "flow_matching", "flow-matching"):
+            return PredictionTypes.FLOW_MATCHING
+        raise NotImplementedError
+
+
+class ModelTypes(Enum):
+    UNET = "unet"
+    TRANSFORMER = "transformer"
+    VAE = "vae"
+    TEXT_ENCODER = "text_encoder"
+
+
+class ModelRegistry:
+    """registry.py:54-98 (the metadata-JSON lazy path is the reference's own; a drop-in only needs register/get)."""
+    _registry: Dict[str, Type[Any]] = {}
+
+    @classmethod
+    def register(cls, family: str, model_class: Type[Any]) -> None:
+        cls._registry[family.lower()] = model_class
+
+    @classmethod
+    def get(cls, family: str):
+        return cls._registry.get(family.lower())
+
+    @classmethod
+    def model_families(cls) -> Dict[str, Type[Any]]:
+        return dict(cls._registry)
+
+
+def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5, max_shift: float = 1.15):
+    """diffusers.pipelines.flux.pipeline_flux.calculate_shift (imported at flux/__init__.py:5)"""
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+def apply_flow_schedule_shift(args, noise_scheduler, sigmas, noise):
+    """custom_schedule.py:443-478"""
+    shift = None
+    if getattr(args, "flow_schedule_shift", None) is not None and args.flow_schedule_shift > 0:
+        shift = args.flow_schedule_shift
+    elif getattr(args, "flow_schedule_auto_shift", False):
+        if noise.ndim == 5:
+            num_frames, height, width = noise.shape[-3:]
+        else:
+            num_frames = 1
+            height, width = noise.shape[-2:]
+        cfg = getattr(noise_scheduler, "config", None)
+        patch_size = getattr(cfg, "patch_size", 2) or 2
+        if patch_size <= 0:
+            patch_size = 2
+        seq_len = num_frames * (height // patch_size) * (width // patch_size)
+        mu = calculate_shift(seq_len, getattr(cfg, "base_image_seq_len", 256), getattr(cfg, "max_image_seq_len", 4096),
+                             getattr(cfg, "base_shift", 0.5), getattr(cfg, "max_shift", 1.15))
+        shift = math.exp(mu)
+    if shift is not None:
+        sigmas = (sigmas * shift) / (1 + (shift - 1) * sigmas)
+    return sigmas
+
+
+class ModelFoundation:
+    """the subset of common.py's ModelFoundation that the step loop touches (trainer.py:6951-7568)."""
+    NAME = "foundation"
+    PREDICTION_TYPE = PredictionTypes.FLOW_MATCHING
+    MODEL_TYPE = ModelTypes.TRANSFORMER
+    MODEL_CLASS = None
+    LATENT_CHANNEL_COUNT = 16
+    DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
+    DDP_FIND_UNUSED_PARAMETERS = False
+
+    def __init__(self, config, accelerator):
+        self.config = config
+        self.accelerator = accelerator
+        self.model = None
+        self.noise_schedule = None
+        self._noise_step = 0
+
+    # ---- component plumbing (common.py:3691, 3781) ----
+    def get_trained_component(self, base_model: bool = False, unwrap_model: bool = True):
+        return self.unwrap_model(self.model) if unwrap_model else self.model
+
+    def set_prepared_model(self, model, base_model: bool = False):
+        self.model = model
+
+    @staticmethod
+    def unwrap_model(model):
+        return getattr(model, "module", model)
+
+    def uses_noise_schedule(self) -> bool:
+        return self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING
+
+    def setup_training_noise_schedule(self):
+        return None
+
+    def flow_matching_target_direction(self) -> float:
+        return 1.0
+
+    # ---- sigma / timestep sampling (common.py:4994-5090) ----
+    def sample_flow_sigmas(self, batch: dict, state: dict):
+        cfg = self.config
+        bsz = batch["latents"].shape[0]
+        dev = self.accelerator.device
+        for unsupported in ("mixflow_enabled", "flow_custom_timesteps", "flux_fast_schedule"):
+            if getattr(cfg, unsupported, None):
+                raise NotImplementedError(f"{unsupported} is not implemented on the st355 path")
+        if getattr(cfg, "flow_use_uniform_schedule", False):
+            sigmas = torch.rand((bsz,), device=dev)
+        elif getattr(cfg, "flow_use_beta_schedule", False):
+            dist = torch.distributions.Beta(cfg.flow_beta_schedule_alpha, cfg.flow_beta_schedule_beta)
+            sigmas = dist.sample((bsz,)).to(device=dev)
+        else:
+            normal = torch.randn((bsz,), device=dev)
+            sigmas = torch.sigmoid(getattr(cfg, "flow_sigmoid_scale", 1.0) * normal)
+        sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, batch["noise_shape_ref"])
+        return sigmas, sigmas * 1000.0
+
+    # ---- prepare_batch (common.py:5862-6041) ----
+    def prepare_batch(self, batch: dict, state: dict) -> dict:
+        if not batch:
+            return batch
+        dev, wd = self.accelerator.device, self.config.weight_dtype
+        if wd != BF16:
+            raise NotImplementedError("the st355 path computes in bf16 (mixed_precision=bf16)")
+        if batch.get("prompt_embeds") is not None and hasattr(batch["prompt_embeds"], "to"):
+            batch["encoder_hidden_states"] = batch["prompt_embeds"].to(device=dev, dtype=wd)
+        pooled = batch.get("add_text_embeds")
+        time_ids = batch.get("batch_time_ids")
+        batch["added_cond_kwargs"] = {}
+        if pooled is not None and hasattr(pooled, "to"):
+            batch["added_cond_kwargs"]["text_embeds"] = pooled.to(device=dev, dtype=wd)
+        if time_ids is not None and hasattr(time_ids, "to"):
+            batch["added_cond_kwargs"]["time_ids"] = time_ids.to(device=dev, dtype=wd)
+        latents = batch.get("latent_batch")
+        if not hasattr(latents, "to"):
+            raise ValueError("Received invalid value for latents.")
+        batch["latents"] = latents.to(device=dev, dtype=wd).contiguous()
+        mask = batch.get("encoder_attention_mask")
+        if mask is not None and hasattr(mask, "to"):
+            batch["encoder_attention_mask"] = mask.to(device=dev, dtype=wd)
+        if getattr(self.config, "input_perturbation", 0) != 0 or getattr(self.config, "offset_noise", False):
+            raise NotImplementedError("input_perturbation / offset_noise are not implemented on the st355 path")
+
+        lat = batch["latents"]
+        batch["noise_shape_ref"] = lat
+        if self.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING:
+            batch["sigmas"], batch["timesteps"] = self.sample_flow_sigmas(batch=batch, state=state)
+            sig = batch["sigmas"].to(device=dev, dtype=torch.float32).contiguous()
+            given = batch.get("noise")          # tests / parity runs inject the reference's noise; else Philox in-kernel
+            seed = int(getattr(self.config, "seed", 42) or 0) + 1_000_003 * int(getattr(self.accelerator, "process_index", 0))
+            per_call = (lat.numel() + 3) // 4
+            noisy, target, noise = ops.flow_noise_mix(lat, sig, noise=given, seed=seed, offset=self._noise_step * per_call)
+            self._noise_step += 1
+            batch["noise"] = noise
+            batch["input_noise"] = noise
+            batch["noisy_latents"] = noisy
+            batch["flow_target"] = target      # n - x (common.py:4610-4611), consumed by get_prediction_target
+            self.expand_sigmas(batch)
+        else:
+            raise NotImplementedError("DDPM families are wired in the UNet plugin (round 2)")
+        batch.pop("noise_shape_ref", None)
+        return self.prepare_batch_conditions(batch=batch, state=state)
+
+    def expand_sigmas(self, batch: dict) -> dict:
+        s = batch["sigmas"]
+        batch["sigmas"] = s.reshape(s.shape[0], *([1] * (batch["latents"].dim() - 1)))
+        return batch
+
+    def prepare_batch_conditions(self, batch: dict, state: dict) -> dict:
+        return batch
+
+    # ---- targets / loss (common.py:4635-4658, 6217-6430) ----
+    def get_prediction_target(self, prepared_batch: dict):
+        if prepared_batch.get("target") is not None:
+            return prepared_batch["target"]
+        if self.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING:
+            t = prepared_batch.get("flow_target")
+            if t is None:
+                # (noise - latents), one extra streaming pass only when the fused target was not kept
+                _, t, _ = ops.flow_noise_mix(prepared_batch["latents"], torch.zeros(prepared_batch["latents"].shape[0],
+                                             device=prepared_batch["latents"].device), noise=prepared_batch["noise"])
+            return t
+        if self.PREDICTION_TYPE is PredictionTypes.EPSILON:
+            return prepared_batch["noise"]
+        if self.PREDICTION_TYPE is PredictionTypes.SAMPLE:
+            return prepared_batch["latents"]
+        raise ValueError(f"Unknown prediction type {self.PREDICTION_TYPE}.")
+
+    def loss(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True):
+        target = self.get_prediction_target(prepared_batch)
+        model_pred = model_output["model_prediction"]
+        if target is None:
+            raise ValueError("Target is None. Cannot compute loss.")
+        if getattr(self.config, "loss_type", "l2") != "l2":
+            raise NotImplementedError("only loss_type=l2 is implemented on the st355 path")
+        if prepared_batch.get("loss_mask_type") or prepared_batch.get("conditioning_type") in ("mask", "segmentation"):
+            raise NotImplementedError("conditioning-mask losses are not implemented on the st355 path")
+        return _MSELossFn.apply(model_pred, target)
+
+    def loss_with_logs(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True):
+        return self.loss(prepared_batch, model_output, apply_conditioning_mask), None
+
+    def auxiliary_loss(self, model_output, prepared_batch: dict, loss: torch.Tensor):
+        return loss, None
+
+
+class _MSELossFn(torch.autograd.Function):
+    """mean_b(mean_chw((pred - target)^2)) in fp32 with the gradient produced by the same kernel pass (K13)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, _per, dpred = ops.mse_loss(pred.to(BF16), target.to(BF16), want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        # g is the upstream scalar (1.0, or the loss scale); fold it without a host sync
+        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None

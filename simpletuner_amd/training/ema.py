@@ -1,0 +1,138 @@
+"""EMAModel — same constructor / step / copy_to / store / restore / state_dict surface as the reference's
+simpletuner/helpers/training/ema.py:40-648, with the update executed by st355_ema_update (one launch over the flat
+arena when the tracked parameters are contiguous, else one launch per tensor).
+
+Decay schedule restated from ema.py:322-349; update `s -= (1-d)(s-p)` from ema.py:393-433 (K17).
+Deviation (documented): the reference keeps the shadow on rank 0 only under DDP; replicas here are
+bit-identical after the gradient all-reduce, so every rank may keep a shadow — `rank0_only=True` restores the reference
+behaviour (other ranks skip the update).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict, Iterable, Optional, Union
+
+import torch
+
+from .. import ops
+from .optimizer import _contiguous_run
+
+
+def should_update_ema(args, step) -> bool:
+    """ema.py:29-37"""
+    interval = getattr(args, "ema_update_interval", None)
+    if interval is None:
+        return True
+    return step % interval == 0
+
+
+class EMAModel:
+    def __init__(self, args, accelerator, parameters: Iterable[torch.nn.Parameter], decay: float = 0.9999, min_decay: float = 0.0,
+                 update_after_step: int = 0, warmup_steps: int = 0, use_ema_warmup: bool = False, inv_gamma: Union[float, int] = 1.0,
+                 power: Union[float, int] = 2 / 3, foreach: bool = True, model_cls: Optional[Any] = None,
+                 model_config: Dict[str, Any] = None, rank0_only: bool = False, **kwargs):
+        parameters = list(parameters)
+        self.args, self.accelerator = args, accelerator
+        self.decay, self.min_decay = decay, min_decay
+        self.update_after_step, self.warmup_steps = update_after_step, max(0, int(warmup_steps))
+        self.use_ema_warmup, self.inv_gamma, self.power = use_ema_warmup, inv_gamma, power
+        self.optimization_step = 0
+        self.cur_decay_value = None
+        self.temp_stored_params = None
+        self.model_cls, self.model_config = model_cls, model_config
+        self.rank0_only = rank0_only
+        tracked = [p for p in parameters]
+        self._flat = _contiguous_run([p.data for p in tracked]) and len(tracked) > 0
+        if self._flat:
+            n = sum(p.numel() for p in tracked)
+            self.shadow_flat = torch.as_strided(tracked[0].data, (n,), (1,)).clone()
+            self.shadow_params, off = [], 0
+            for p in tracked:
+                self.shadow_params.append(self.shadow_flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        else:
+            self.shadow_flat = None
+            self.shadow_params = [p.clone().detach() for p in tracked]
+
+    # ---- ema.py:322-349 ----
+    def get_decay(self, optimization_step: int = None) -> float:
+        if optimization_step is None:
+            optimization_step = self.optimization_step
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if self.warmup_steps > 0:
+            if optimization_step < self.warmup_steps:
+                return 0.0
+            return self.decay
+        if step <= 0:
+            return 0.0
+        if self.use_ema_warmup:
+            cur = 1 - (1 + step / self.inv_gamma) ** -self.power
+        else:
+            cur = (1 + step) / (10 + step)
+        cur = min(cur, self.decay)
+        return max(cur, self.min_decay)
+
+    # ---- ema.py:352-433 ----
+    @torch.no_grad()
+    def step(self, parameters: Iterable[torch.nn.Parameter], global_step: int = None):
+        if not should_update_ema(self.args, global_step):
+            return
+        if self.rank0_only and getattr(self.accelerator, "process_index", 0) != 0:
+            return
+        parameters = list(parameters)
+        if len(parameters) != len(self.shadow_params):
+            raise ValueError("EMAModel.step: parameter list does not match the tracked shadow parameters")
+        if global_step is not None:
+            self.optimization_step = global_step
+        else:
+            self.optimization_step += 1
+        decay = self.get_decay(self.optimization_step)
+        self.cur_decay_value = decay
+        if self._flat and _contiguous_run([p.data for p in parameters]):
+            n = self.shadow_flat.numel()
+            ops.ema_update(self.shadow_flat, torch.as_strided(parameters[0].data, (n,), (1,)), decay)
+            return
+        for s, p in zip(self.shadow_params, parameters):
+            if p.requires_grad:
+                ops.ema_update(s.view(-1), p.data.to(s.dtype).contiguous().view(-1), decay)
+            else:
+                s.copy_(p.data.to(s.dtype))
+
+    def copy_to(self, parameters: Iterable[torch.nn.Parameter]) -> None:
+        for s, p in zip(self.shadow_params, list(parameters)):
+            p.data.copy_(s.to(device=p.device, dtype=p.dtype))
+
+    def store(self, parameters: Iterable[torch.nn.Parameter]) -> None:
+        self.temp_stored_params = [p.detach().clone() for p in parameters]
+
+    def restore(self, parameters: Iterable[torch.nn.Parameter]) -> None:
+        if self.temp_stored_params is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        for c, p in zip(self.temp_stored_params, parameters):
+            p.data.copy_(c.data)
+        self.temp_stored_params = None
+
+    def to(self, device=None, dtype=None, non_blocking=False):
+        return self   # shadows live next to the parameters in HBM (288 GB: no CPU shuttle, ema.py:357-359/432-433 not needed)
+
+    def parameter_count(self) -> int:
+        return sum(p.numel() for p in self.shadow_params)
+
+    def state_dict(self) -> dict:
+        """ema.py:236-286 layout: scalars + shadow_params.i"""
+        sd = dict(decay=self.decay, min_decay=self.min_decay, optimization_step=self.optimization_step,
+                  update_after_step=self.update_after_step, use_ema_warmup=self.use_ema_warmup, inv_gamma=self.inv_gamma,
+                  power=self.power, warmup_steps=self.warmup_steps)
+        for i, s in enumerate(self.shadow_params):
+            sd[f"shadow_params.{i}"] = s.detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        sd = copy.copy(state_dict)
+        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power", "warmup_steps"):
+            if k in sd:
+                setattr(self, k, sd[k])
+        for i, s in enumerate(self.shadow_params):
+            key = f"shadow_params.{i}"
+            if key in sd:
+                s.copy_(sd[key].to(device=s.device, dtype=s.dtype))

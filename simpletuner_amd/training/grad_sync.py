@@ -1,0 +1,78 @@
+"""Data-parallel gradient synchronisation for replicas (C1): what DDP's reducer does in the reference
+(trainer.py:1034-1041, 4564-4571), re-designed for MI355X:
+
+  * gradients live in ONE flat arena, filled back-to-front as the hand-written backward walks the blocks in reverse;
+  * every time a bucket's worth of finished gradient has accumulated, an asynchronous all-reduce (RCCL over xGMI with the
+    `nccl` backend; `gloo` in CPU tests) is issued on that contiguous slice — it overlaps the remaining backward kernels;
+  * SUM is used and the 1/world_size averaging is folded into the optimizer kernel's grad_scale (no extra pass over HBM);
+  * `no_sync()` mirrors DDP/accelerate semantics for gradient accumulation (trainer.py:7009).
+Ring-vs-direct algorithm choice is RCCL's; bucket size is chosen for the per-link xGMI bound: 32 MiB slices keep each of
+the 7 links busy for ~0.2 ms (2*G/N per link at ~153 GB/s), long enough to amortise launch latency, short enough to overlap.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None):
+        self.flat = flat_grad
+        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.pg = process_group
+        self.enabled = True
+        self._works: List = []
+        self._lo: Optional[int] = None   # pending [lo, hi) finished-but-unsent region
+        self._hi: Optional[int] = None
+        self.launched_slices: List = []  # (lo, hi) of every all-reduce issued in the current backward (tests inspect it)
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
+
+    def begin(self):
+        self._works, self._lo, self._hi, self.launched_slices = [], None, None, []
+
+    def _fire(self, lo: int, hi: int):
+        if hi <= lo:
+            return
+        self.launched_slices.append((lo, hi))
+        if self.world_size > 1 and self.enabled:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def ready(self, lo: int, hi: int):
+        """the backward finished gradient elements [lo, hi) (any order; adjacent regions are merged)"""
+        if self._lo is None:
+            self._lo, self._hi = lo, hi
+        elif hi == self._lo:
+            self._lo = lo
+        elif lo == self._hi:
+            self._hi = hi
+        else:                                  # not adjacent: flush what we have, start a new region
+            self._fire(self._lo, self._hi)
+            self._lo, self._hi = lo, hi
+        if self._hi - self._lo >= self.bucket_elems:
+            self._fire(self._lo, self._hi)
+            self._lo = self._hi = None
+
+    def finish(self) -> float:
+        """flush, wait (stream-side for nccl) and return the factor the optimizer must fold in (1/world_size)"""
+        if self._lo is not None:
+            self._fire(self._lo, self._hi)
+            self._lo = self._hi = None
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return 1.0 / self.world_size if self.enabled else 1.0
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old = self.enabled
+        self.enabled = False
+        try:
+            yield
+        finally:
+            self.enabled = old

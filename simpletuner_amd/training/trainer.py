@@ -1,0 +1,138 @@
+"""Minimal host harness that replays the reference's step order — `Trainer.train()` inner loop,
+simpletuner/helpers/training/trainer.py:6951-7568 — around the plugin surface, so the drop-in boundary
+can be exercised where SimpleTuner itself cannot be imported.  Where SimpleTuner is installed, its own
+Trainer drives the same plugin / optimizer / EMA objects.
+
+    prepare_batch -> model_predict -> loss_with_logs -> auxiliary_loss -> (gather avg loss) -> backward
+      -> grad norm / clip -> optimizer.step -> zero_grad -> lr_scheduler.step -> ema.step
+
+Differences from the reference, all on purpose (SURVEY.md §3.3 "per-step host syncs"): no per-step `.item()` — the loss
+stays a device scalar and is read back only when logged; no barriers in the step; the 1/world averaging and the clip
+coefficient are folded into the optimizer kernel (grad_scale) instead of extra passes over the gradients.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Callable, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .ema import EMAModel
+from .grad_sync import GradSync
+from .multi_process import gather_sample_weighted_scalar
+from .optimizer import St355AdamW
+
+
+class St355Accelerator:
+    """the slice of accelerate.Accelerator the step path touches (device, ranks, backward, sync flags)."""
+
+    def __init__(self, device=None, gradient_accumulation_steps: int = 1):
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.sync_gradients = True
+        self.is_dist = dist.is_available() and dist.is_initialized()
+        self.process_index = dist.get_rank() if self.is_dist else 0
+        self.num_processes = dist.get_world_size() if self.is_dist else 1
+        self.is_main_process = self.process_index == 0
+
+    def backward(self, loss: torch.Tensor):
+        loss.backward()
+
+    def wait_for_everyone(self):
+        if self.is_dist:
+            dist.barrier()
+
+
+def default_config(**over) -> SimpleNamespace:
+    """the config keys the drop-in honours (SURVEY.md §5 'Config / flags'), with the examples' defaults"""
+    cfg = dict(model_family="flux", model_type="lora", lora_rank=32, lora_alpha=None, mixed_precision="bf16",
+               weight_dtype=torch.bfloat16, base_weight_dtype=torch.bfloat16, optimizer="st355-adamw", learning_rate=1e-4,
+               adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8, adam_weight_decay=1e-2, use_ema=False, ema_decay=0.9999,
+               ema_update_interval=None, ema_device="accelerator", ema_cpu_only=False, flow_schedule_shift=3.0,
+               flow_schedule_auto_shift=False, flow_sigmoid_scale=1.0, flow_use_uniform_schedule=False, flow_use_beta_schedule=False,
+               flux_fast_schedule=False, flux_guidance_mode="constant", flux_guidance_value=1.0, flux_attention_masked_training=False,
+               flux_lora_target="default", snr_gamma=None, loss_type="l2", max_grad_norm=0.0, grad_clip_method="norm",
+               gradient_accumulation_steps=1, train_batch_size=1, gradient_checkpointing=False, input_perturbation=0,
+               offset_noise=False, seed=42, lora_init_b_std=0.0)
+    cfg.update(over)
+    return SimpleNamespace(**cfg)
+
+
+class Trainer:
+    def __init__(self, config, model_plugin, accelerator: Optional[St355Accelerator] = None, lr_lambda: Optional[Callable] = None):
+        self.config = config
+        self.accelerator = accelerator or model_plugin.accelerator
+        self.model = model_plugin
+        comp = self.model.get_trained_component()
+        self.params = [p for p in comp.parameters() if p.requires_grad]
+        self.optimizer = St355AdamW(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
+                                    eps=config.adam_epsilon, weight_decay=config.adam_weight_decay)
+        self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda) if lr_lambda else None
+        self.ema_model = None
+        if getattr(config, "use_ema", False):
+            self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)
+        self._overlapped_sync = config.gradient_accumulation_steps == 1
+        if self.accelerator.num_processes > 1 and getattr(comp, "lora_grad_flat", None) is not None and self._overlapped_sync:
+            comp.grad_sync = GradSync(comp.lora_grad_flat)      # replicas: bucketed all-reduce overlapped with backward
+        self.state = {"global_step": 0, "micro_step": 0}
+        self.last_loss = None          # device scalar, no host sync
+        self.last_grad_norm = None
+
+    def train_step(self, raw_batch: dict) -> torch.Tensor:
+        cfg, acc = self.config, self.accelerator
+        comp = self.model.get_trained_component()
+        prepared = self.model.prepare_batch(raw_batch, self.state)                       # trainer.py:6964
+        self.state["micro_step"] += 1
+        boundary = self.state["micro_step"] % cfg.gradient_accumulation_steps == 0       # accelerator.accumulate (:7009)
+        acc.sync_gradients = boundary
+        sync = getattr(comp, "grad_sync", None)
+        if sync is not None:
+            sync.enabled = boundary
+        pred = self.model.model_predict(prepared)                                        # :7097 -> :6085
+        loss, _ = self.model.loss_with_logs(prepared, pred)
+        loss, _ = self.model.auxiliary_loss(pred, prepared, loss)
+        if cfg.gradient_accumulation_steps > 1:
+            loss = loss / cfg.gradient_accumulation_steps
+        self.last_loss = gather_sample_weighted_scalar(loss, prepared["latents"].shape[0], acc)   # :7114 (C2)
+        acc.backward(loss)                                                               # :7126
+        if not boundary:
+            return self.last_loss
+        grad_scale = getattr(comp, "grad_scale_from_sync", 1.0) if sync is not None else 1.0
+        if acc.num_processes > 1 and not self._overlapped_sync:
+            # gradient accumulation: reduce the ACCUMULATED .grad once at the boundary (DDP no_sync semantics, trainer.py:7009)
+            from .optimizer import _contiguous_run
+            grads = [p.grad for p in self.params]
+            if not _contiguous_run(grads):
+                raise RuntimeError("accumulated gradients are not one flat arena")
+            n = sum(g.numel() for g in grads)
+            dist.all_reduce(torch.as_strided(grads[0], (n,), (1,)), op=dist.ReduceOp.SUM)
+            grad_scale = 1.0 / acc.num_processes
+        if getattr(cfg, "max_grad_norm", 0) and cfg.max_grad_norm > 0:                   # :7138-7217
+            gflat = getattr(comp, "_last_grad_flat", None)
+            if gflat is None:
+                raise NotImplementedError("gradient clipping needs the flat gradient arena")
+            stats = ops.grad_norm(gflat)
+            norm = stats[0].sqrt() * grad_scale
+            self.last_grad_norm = norm
+            coef = (cfg.max_grad_norm / (norm + 1e-6)).clamp(max=1.0)
+            grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
+        self.optimizer.grad_scale = grad_scale
+        self.optimizer.step()                                                            # :7239
+        self.optimizer.zero_grad(set_to_none=True)                                       # :7253
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()                                                     # :7293
+        self.state["global_step"] += 1
+        if self.ema_model is not None:
+            self.ema_model.step(self.params, self.state["global_step"])                  # :7352
+        return self.last_loss
+
+    def train(self, batches: Iterable[dict], max_steps: int):
+        losses = []
+        for i, b in enumerate(batches):
+            if i >= max_steps:
+                break
+            losses.append(self.train_step(b))
+        return losses

@@ -1,0 +1,119 @@
+"""Model-level GPU parity: the HIP Flux train step (through the plugin surface -> C ABI) vs the CPU oracle on identical
+weights, noised latents and timesteps.
+
+Stated tolerances (parity for the network itself is UNPINNED in the reference — no golden tensors — so these
+are our own bars): bf16 kernels vs fp32 oracle — prediction rel-L2 <= 2e-2 and cosine >= 0.9995; loss |delta| <= 1e-3 (north
+star); LoRA gradients rel-L2 <= 5e-2 and cosine >= 0.999 per adapter matrix; 10-step loss curve |delta| <= 1e-3 with AdamW.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import parity_utils as PU  # noqa: E402
+
+
+def _build(layers, single, B, lat_h, lat_w, S_txt, rank=16, seed=3, lr=1e-3):
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+
+    dev = torch.device("cuda:0")
+    cfg = default_config(lora_rank=rank, train_batch_size=B, seed=seed, lora_init_b_std=0.02, learning_rate=lr, flow_schedule_shift=3.0)
+    acc = St355Accelerator(dev)
+    plugin = Flux(cfg, acc)
+    plugin.load_model(**PU.small_flux_cfg(layers=layers, single=single))
+    plugin.add_lora_adapter()
+    trainer = Trainer(cfg, plugin, acc)
+    cpu, devt = PU.make_inputs(B, lat_h, lat_w, S_txt, 128, 64, dev, seed=seed)
+    return plugin, trainer, cpu, devt
+
+
+def _batch(devt):
+    return {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
+
+
+@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(1, 1, 1, 16, 16, 64), (2, 2, 2, 16, 16, 32), (1, 2, 1, 16, 24, 40)])
+def test_flux_step_matches_oracle(layers, single, B, lat_h, lat_w, S_txt):
+    plugin, trainer, cpu, devt = _build(layers, single, B, lat_h, lat_w, S_txt)
+    model = plugin.get_trained_component()
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)     # identical timesteps on both sides
+    P, lora, scale = PU.oracle_state(model)
+    prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+    # noising / target algebra vs the reference formulas (common.py:4975-4992, 4610-4611)
+    s = cpu["sigmas"].view(-1, 1, 1, 1)
+    assert PU.rel_l2(prepared["noisy_latents"], (1 - s) * cpu["latents"] + s * cpu["noise"]) < 4e-3
+    assert PU.rel_l2(plugin.get_prediction_target(prepared), cpu["noise"] - cpu["latents"]) < 4e-3
+    ts_before = prepared["timesteps"].clone()
+    out = plugin.model_predict(prepared)
+    assert torch.allclose(prepared["timesteps"], ts_before / 1000.0)          # flux/model.py:739-745 (tests/test_flux_model.py:213)
+    loss, _ = plugin.loss_with_logs(prepared, out)
+    loss.backward()
+    o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu)
+    r = PU.rel_l2(out["model_prediction"], o_pred); c = PU.cos_sim(out["model_prediction"], o_pred)
+    print(f"[parity] flux pred L{layers}+{single} B{B}: rel_l2={r:.3e} cos={c:.6f}  loss hip={loss.item():.6f} oracle={o_loss.item():.6f}")
+    assert r < 2e-2 and c > 0.9995
+    assert abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key = name.split(".lora_")[0]
+        ref = o_grads[key][0 if ".lora_A." in name else 1]
+        assert p.grad is not None, name
+        rg, cg = PU.rel_l2(p.grad, ref), PU.cos_sim(p.grad, ref)
+        worst = max(worst, (rg, name))
+        assert rg < 5e-2 and cg > 0.999, f"{name}: rel={rg:.3e} cos={cg:.5f}"
+    print(f"[parity] flux lora grads: worst rel_l2={worst[0]:.3e} at {worst[1]}")
+
+
+def test_flux_loss_curve_matches_oracle_adamw():
+    """10 optimizer steps, identical noise/timesteps each step: HIP (bf16 compute, fused fp32 AdamW) vs oracle (fp32, torch.optim.AdamW)."""
+    plugin, trainer, cpu, devt = _build(1, 1, 2, 16, 16, 32, rank=8, lr=2e-3)
+    model = plugin.get_trained_component()
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    P, lora, scale = PU.oracle_state(model)
+    ocfg = PU.oracle_cfg(model)
+    names = sorted(lora)
+    params = {k: (torch.nn.Parameter(lora[k][0].clone()), torch.nn.Parameter(lora[k][1].clone())) for k in names}
+    opt = torch.optim.AdamW([t for k in names for t in params[k]], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    hip_losses, ora_losses = [], []
+    for step in range(10):
+        hip_losses.append(trainer.train_step(_batch(devt)).item())
+        opt.zero_grad()
+        s = cpu["sigmas"].view(-1, 1, 1, 1)
+        noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
+        target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
+        pred = PU.OF.flux_model_predict(P, ocfg, noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, 1.0,
+                                        lora={k: params[k] for k in names}, lora_scale=scale)
+        l = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+        l.backward(); opt.step()
+        ora_losses.append(l.item())
+    d = max(abs(a - b) for a, b in zip(hip_losses, ora_losses))
+    print("[parity] loss curve hip   :", [round(x, 5) for x in hip_losses])
+    print("[parity] loss curve oracle:", [round(x, 5) for x in ora_losses])
+    print(f"[parity] max |delta loss| over 10 steps = {d:.3e}")
+    assert d < 1e-3 * max(1.0, max(ora_losses))
+    assert hip_losses[-1] < hip_losses[0]          # it trains
+
+
+def test_ema_and_clipping_in_the_loop():
+    from simpletuner_amd.training.ema import EMAModel
+
+    plugin, trainer, cpu, devt = _build(1, 1, 1, 16, 16, 32, rank=8, lr=1e-3)
+    trainer.config.max_grad_norm = 0.01
+    trainer.ema_model = EMAModel(trainer.config, trainer.accelerator, trainer.params, decay=0.9)
+    p0 = [p.detach().clone() for p in trainer.params]
+    shadow_ref = [p.clone() for p in p0]
+    for step in range(1, 4):
+        trainer.train_step(_batch(devt))
+        d = trainer.ema_model.get_decay(step)
+        for s, p in zip(shadow_ref, trainer.params):
+            s.sub_((1 - d) * (s - p.detach()))
+    assert trainer.last_grad_norm is not None and math.isfinite(trainer.last_grad_norm.item())
+    for s, e in zip(shadow_ref, trainer.ema_model.shadow_params):
+        assert torch.allclose(s, e, atol=1e-6)     # tests/test_ema.py tolerance (atol 1e-6)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(p0, trainer.params))
