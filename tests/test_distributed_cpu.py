@@ -1,0 +1,56 @@
+"""world_size-2 `gloo` tests of the N>1 path (runs in the CPU-only container): the bucketed gradient all-reduce driven in
+back-to-front order like the hand-written backward, the folded 1/world scale, no_sync semantics, and the sample-weighted loss
+gather (port of the reference's one real multi-process test, tests/test_distributed_batch_layout.py:48-119)."""
+import os
+import tempfile
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, init_file, out_dir):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from simpletuner_amd.training.grad_sync import GradSync
+    from simpletuner_amd.training.multi_process import any_rank_reached_epoch_end, gather_sample_weighted_scalar
+
+    res = {}
+    # --- C1: bucketed all-reduce over a flat gradient arena, slices finishing back-to-front ---
+    n = 10_000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)          # rank r holds (r+1) * arange
+    gs = GradSync(flat, bucket_bytes=4 * 2048)
+    gs.begin()
+    edges = list(range(n, 0, -700)) + [0]
+    for hi, lo in zip(edges[:-1], edges[1:]):
+        gs.ready(lo, hi)
+    scale = gs.finish()
+    res["scale"] = scale
+    res["avg_ok"] = torch.allclose(flat * scale, torch.arange(n, dtype=torch.float32) * (1 + 2) / 2)
+    res["n_buckets"] = len(gs.launched_slices)
+    # --- no_sync: nothing is reduced, scale stays 1 ---
+    flat2 = torch.full((100,), float(rank + 1))
+    gs2 = GradSync(flat2)
+    with gs2.no_sync():
+        gs2.begin(); gs2.ready(0, 100); s2 = gs2.finish()
+    res["nosync_ok"] = (s2 == 1.0) and bool((flat2 == rank + 1).all())
+    # --- C2: weighted loss: rank0 loss 2.0 (1 sample), rank1 loss 4.0 (3 samples) -> 3.5 ---
+    loss = torch.tensor(2.0 if rank == 0 else 4.0)
+    res["weighted"] = gather_sample_weighted_scalar(loss, 1 if rank == 0 else 3).item()
+    # --- C3: epoch-end consensus (MAX) ---
+    res["epoch_end"] = any_rank_reached_epoch_end(rank == 1, torch.device("cpu"))
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo_grad_sync_and_loss_gather():
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, init_file, d), nprocs=2, join=True)
+        for r in range(2):
+            res = torch.load(os.path.join(d, f"r{r}.pt"))
+            assert res["scale"] == 0.5
+            assert res["avg_ok"]
+            assert res["n_buckets"] >= 3
+            assert res["nosync_ok"]
+            assert abs(res["weighted"] - 3.5) < 1e-6
+            assert res["epoch_end"] is True

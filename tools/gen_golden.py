@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by EXECUTING THE REFERENCE'S OWN CODE in this container.
+
+The reference package cannot be imported here (python 3.10 < required 3.12; diffusers/peft absent), so the
+self-contained, pure-torch functions on the hot path are pulled out of the reference source files BY AST at generation
+time (never copied into this repo), compiled in a namespace that provides only `torch`/`math`, and run on seeded inputs.
+The resulting tensors are committed as small fixtures; tests/test_golden_cpu.py pins the oracle to them and
+tests/test_golden_gpu.py pins the HIP kernels to them.  /root/reference is read ONLY by this script, never at test time.
+
+    python tools/gen_golden.py            (writes tests/golden/reference_vectors.pt)
+"""
+from __future__ import annotations
+
+import ast
+import math
+import sys
+import types
+from pathlib import Path
+
+import torch
+
+REF = Path("/root/reference/simpletuner")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden" / "reference_vectors.pt"
+
+
+def extract(path: Path, names, extra_ns=None, class_name=None):
+    """compile the named top-level functions (or methods of `class_name`) of a reference file, in isolation"""
+    src = path.read_text()
+    tree = ast.parse(src)
+    body = tree.body
+    if class_name is not None:
+        cls = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == class_name)
+        body = cls.body
+    picked = [n for n in body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in picked}
+    if missing:
+        raise KeyError(f"{path}: missing {missing}")
+    for n in picked:
+        n.decorator_list = []
+    mod = ast.Module(body=picked, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = {"torch": torch, "math": math, "Optional": None, "__builtins__": __builtins__}
+    ns.update(extra_ns or {})
+    exec(compile(mod, str(path), "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def main():
+    torch.manual_seed(1234)
+    G = {}
+    cite = {}
+
+    # ---- Flux pack / unpack / ids (flux/__init__.py:25-63) ----
+    p = REF / "helpers/models/flux/__init__.py"
+    pack_latents, unpack_latents, prepare_latent_image_ids = extract(p, ["pack_latents", "unpack_latents", "prepare_latent_image_ids"])
+    lat = torch.randn(2, 16, 12, 20).to(torch.bfloat16)
+    packed = pack_latents(lat, 2, 16, 12, 20)
+    G["pack.in"] = lat; G["pack.out"] = packed
+    G["unpack.out"] = unpack_latents(packed, 12 * 8, 20 * 8, 16)
+    G["ids.12x20"] = prepare_latent_image_ids(2, 12, 20, "cpu", torch.float32)
+    cite["pack"] = "simpletuner/helpers/models/flux/__init__.py:25-63"
+
+    # ---- RoPE application (flux/transformer.py:73-98) ----
+    p = REF / "helpers/models/flux/transformer.py"
+    (apply_rope,) = extract(p, ["_apply_rotary_emb_anyshape"])
+    S, d = 24, 128
+    ang = torch.rand(S, d // 2, dtype=torch.float64) * 6
+    cos = ang.cos().repeat_interleave(2, dim=1).float(); sin = ang.sin().repeat_interleave(2, dim=1).float()
+    x = torch.randn(2, 3, S, d).to(torch.bfloat16)
+    G["rope.x"] = x; G["rope.cos"] = cos; G["rope.sin"] = sin
+    G["rope.out_bf16"] = apply_rope(x, (cos, sin))
+    G["rope.out_fp32"] = apply_rope(x.float(), (cos, sin))
+    cite["rope"] = "simpletuner/helpers/models/flux/transformer.py:73-98"
+
+    # ---- flow schedule shift (custom_schedule.py:443-478) ----
+    p = REF / "helpers/training/custom_schedule.py"
+    (shift_fn,) = extract(p, ["apply_flow_schedule_shift"], extra_ns={"calculate_shift_flux": None})
+    sig = torch.tensor([0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99])
+    for sh in (1.0, 3.0, 0.5):
+        args = types.SimpleNamespace(flow_schedule_shift=sh, flow_schedule_auto_shift=False)
+        G[f"shift.{sh}"] = shift_fn(args, None, sig.clone(), torch.zeros(1, 16, 8, 8))
+    G["shift.in"] = sig
+    args = types.SimpleNamespace(flow_schedule_shift=None, flow_schedule_auto_shift=False)
+    G["shift.none"] = shift_fn(args, None, sig.clone(), torch.zeros(1, 16, 8, 8))
+    cite["shift"] = "simpletuner/helpers/training/custom_schedule.py:443-478"
+
+    # ---- EMA decay schedule (ema.py:322-349) ----
+    p = REF / "helpers/training/ema.py"
+    (get_decay,) = extract(p, ["get_decay"], class_name="EMAModel")
+    rows = []
+    for (decay, min_decay, uas, warm, use_w, inv_g, power) in [(0.9999, 0.0, 0, 0, False, 1.0, 2 / 3), (0.999, 0.0, 0, 0, False, 1.0, 2 / 3),
+                                                              (0.9, 0.0, 0, 3, False, 1.0, 2 / 3), (0.9999, 0.5, 10, 0, True, 1.0, 0.75)]:
+        self_ = types.SimpleNamespace(decay=decay, min_decay=min_decay, update_after_step=uas, warmup_steps=warm, use_ema_warmup=use_w,
+                                      inv_gamma=inv_g, power=power, optimization_step=0)
+        for step in (0, 1, 2, 3, 4, 10, 11, 12, 100, 1000, 100000):
+            rows.append([decay, min_decay, uas, warm, float(use_w), inv_g, power, step, get_decay(self_, step)])
+    G["ema.decay_table"] = torch.tensor(rows, dtype=torch.float64)
+    # update formula ema.py:423 (foreach) / :430 (loop): s -= (1-d)(s-p); known answers from tests/test_ema.py:39-105
+    s0 = torch.randn(257); pp = torch.randn(257)
+    s_foreach = [s0.clone()]
+    torch._foreach_sub_(s_foreach, torch._foreach_sub(s_foreach, [pp]), alpha=1 - 0.999)
+    G["ema.s0"] = s0; G["ema.p"] = pp; G["ema.s1_decay0.999"] = s_foreach[0]
+    cite["ema"] = "simpletuner/helpers/training/ema.py:322-349, 423"
+
+    # ---- sample-weighted loss gather (context_parallel_sync.py:327-348) ----
+    p = REF / "helpers/data_backend/runtime/context_parallel_sync.py"
+    import numbers
+    fns = extract(p, ["_normalize_parallel_size", "gather_sample_weighted_scalar"], extra_ns={"numbers": numbers})
+
+    class FakeAcc:
+        num_processes = 2
+
+        def gather(self, t):
+            # rank 0: loss 2.0 with 1 sample ; rank 1: loss 4.0 with 3 samples  -> weighted mean 3.5 (tests/test_distributed_batch_layout.py:224-235)
+            return torch.stack([torch.tensor([2.0 * 1, 1.0]), torch.tensor([4.0 * 3, 3.0])]).reshape(-1)
+
+    G["gather.weighted"] = fns[1](torch.tensor(2.0), 1, FakeAcc())
+    cite["gather"] = "simpletuner/helpers/data_backend/runtime/context_parallel_sync.py:327-348"
+
+    # ---- flow noising / target known answers (tests/test_flux_model.py:122-124, tests/test_mixflow.py:45-92) ----
+    # the reference formulas are one-liners inside methods with heavy `self`; pinned by their own tests' expectations:
+    x0 = torch.randn(2, 16, 4, 4); n0 = torch.randn(2, 16, 4, 4)
+    G["flow.x"] = x0; G["flow.n"] = n0
+    G["flow.noisy_sigma0.25"] = 0.75 * x0 + 0.25 * n0       # expected_noisy, tests/test_flux_model.py:122
+    G["flow.target"] = n0 - x0                              # tests/test_flux_model.py:124
+    cite["flow"] = "tests/test_flux_model.py:122-124 (expected values of common.py:4990, 4610-4611)"
+
+    G["_cite"] = cite
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    torch.save(G, OUT)
+    print(f"wrote {OUT} ({OUT.stat().st_size} bytes): {len(G) - 1} tensors")
+
+
+if __name__ == "__main__":
+    if not REF.exists():
+        sys.exit("reference tree not present (this script only runs in the build container)")
+    main()
