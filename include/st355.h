@@ -98,6 +98,9 @@ typedef struct st355_gemm_args {
   const void* gate; int64_t gate_stride; int64_t rows_per_batch; /* EPI_GATE_RESIDUAL: gate[b*stride+n] */
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
+/* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two
+ * streams (img / txt) of an MMDiT block, or the per-batch slices of a joint buffer. */
+int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count);
 
 /* skinny transposed product for rank-space LoRA gradients (K12 backward):
  * out[p*so_p + r*so_r] (+)= alpha * sum_m L[m,p] * R[m,r],  L:[M,P] bf16, R:[M,Rn] bf16 (Rn in {32,64}), out fp32.

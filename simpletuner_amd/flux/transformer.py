@@ -368,6 +368,8 @@ class FluxTransformer2DModel(nn.Module):
             return Q, K, Qt, Kt, Vt
 
         # ---- double blocks (flux/transformer.py:607-687) ----
+        # the img (4096-row) and txt (512-row) streams use different weights but the same epilogues: every pair of
+        # projections goes out as ONE grouped launch, so the txt tiles fill the tail wave of the img GEMM.
         for blk in self.double:
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
             n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
@@ -375,11 +377,13 @@ class FluxTransformer2DModel(nn.Module):
             qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
             T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
             T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
+            probs = []
             for b in range(B):
                 kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
                 kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
-                ops.gemm(n_txt[b * St:(b + 1) * St], blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t)
-                ops.gemm(n_img[b * Si:(b + 1) * Si], blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i)
+                probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i))
+                probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t))
+            ops.gemm_grouped(probs)
             Q, K, Qt, Kt, Vt = alloc_heads()
             ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
             ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
@@ -389,6 +393,7 @@ class FluxTransformer2DModel(nn.Module):
             x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
             T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
             T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
+            probs = []
             for b in range(B):
                 O_t, O_i = O[b * S:b * S + St], O[b * S + St:(b + 1) * S]
                 kw_i, kw_t = {}, {}
@@ -398,26 +403,26 @@ class FluxTransformer2DModel(nn.Module):
                 if T_ao is not None:
                     ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
                     kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
-                ops.gemm(O_i, blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
-                         aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i)
-                ops.gemm(O_t, blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
-                         aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t)
+                probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
+                                  aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
+                probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
+                                  aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t))
+            ops.gemm_grouped(probs)
             # MLPs
-            n2 = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
-            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
-            hact = ops.gemm(n2, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
-            x2_img = ops.gemm(hact, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si)
-            n2 = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
-            hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
-            hact = ops.gemm(n2, blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)
-            x2_txt = ops.gemm(hact, blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)
-            del n2, hact
+            n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+            n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
+            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
+            h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
+                                         dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
+            x2_img, x2_txt = ops.gemm_grouped([
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
+                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+            del n2_i, n2_t, h_i, h_t
             if save:
                 ctx.dbl.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
                                                Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
                                                hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
             img, txt = x2_img, x2_txt
-
         # ---- joint sequence [txt || img] (flux/transformer.py:1332) ----
         if B == 1:
             x = torch.cat([txt, img], dim=0)
@@ -506,63 +511,64 @@ class FluxTransformer2DModel(nn.Module):
             d_txt, d_img = dx[:St], dx[St:]
         else:
             d_txt = dx.view(B, S, D)[:, :St].reshape(B * St, D); d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
-        # ---- double blocks, reversed ----
+        # ---- double blocks, reversed (img / txt pairs as grouped launches) ----
         for li in range(len(self.double) - 1, -1, -1):
             blk, sv = self.double[li], ctx.dbl[li]
             ctx.dbl[li] = None
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+            dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
+                                           dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
+            dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+            del g_i, g_t, dh_i, dh_t
+            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+            dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
+            del dn2_i, dn2_t
+            # attention output projections: dO rows of both streams (+ adapter grads)
             dO = torch.empty(B * S, D, dtype=BF16, device=dev)
-            d_x1 = {}
-            for (name, dcur, x1, hpre, f1, f2, m_, rows, to_o, T_o_) in (
-                    ("img", d_img, sv.x1_img, sv.hpre_img, blk.ff1, blk.ff2, mi, Si, blk.to_out, sv.T_o),
-                    ("txt", d_txt, sv.x1_txt, sv.hpre_txt, blk.ffc1, blk.ffc2, mt, St, blk.to_add_out, sv.T_ao)):
-                g = ops.scale_cols(dcur, m_[:, 5 * D:6 * D], rows)
-                dhpre = ops.gemm(g, f2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=hpre)
-                dn2 = ops.gemm(dhpre, f1.wT)
-                del g, dhpre
-                dx1, dx1g = ops.ln_modulate_bwd(dn2, x1, m_[:, 4 * D:5 * D], rows, dres=dcur, gate=m_[:, 2 * D:3 * D], want_gated=True)
-                d_x1[name] = dx1
-                del dn2
-                # attention output projection: dO rows of this stream (+ adapter grads)
-                lo = St if name == "img" else 0
-                if to_o.lora is not None:
-                    U = ops.gemm(dx1g, to_o.lora.B_blk_T)
-                for b in range(B):
-                    kw = dict(a2=U[b * rows:(b + 1) * rows], b2=to_o.lora.A_cat_T) if to_o.lora is not None else {}
-                    ops.gemm(dx1g[b * rows:(b + 1) * rows], to_o.wT, out=dO[b * S + lo:b * S + lo + rows], **kw)
-                if to_o.lora is not None:
-                    if B == 1:
-                        O_rows = sv.O[lo:lo + rows]
-                    else:
-                        O_rows = sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
-                    to_o.lora.grads(O_rows, T_o_, dx1g, U, self.accumulate_lora_grads, self.grad_sync)
-                    del U
-                del dx1g
+            U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
+            U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if blk.to_add_out.lora is not None else None
+            probs = []
+            for b in range(B):
+                kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
+                kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
+                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S + St:(b + 1) * S], **kw_i))
+                probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S:b * S + St], **kw_t))
+            ops.gemm_grouped(probs)
+            for (lin, U, T_, dxg, lo, rows) in ((blk.to_out, U_i, sv.T_o, dx1g_i, St, Si), (blk.to_add_out, U_t, sv.T_ao, dx1g_t, 0, St)):
+                if lin.lora is not None:
+                    O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
+                    lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+            del dx1g_i, dx1g_t, U_i, U_t
             dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
             dQ, dK = attn_backward(sv, dO, dqkv)
             ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, 0, S)
             ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
             del dQ, dK, dO
             last = li == 0
-            for (name, lin, n_in, T_, m_, rows, xin) in (("img", blk.qkv, sv.n_img, sv.T_img, mi, Si, sv.img),
-                                                         ("txt", blk.add_qkv, sv.n_txt, sv.T_txt, mt, St, sv.txt)):
-                lo = St if name == "img" else 0
-                if B == 1:
-                    dq_rows = dqkv[lo:lo + rows]
-                else:
-                    dq_rows = dqkv.view(B, S, 3 * D)[:, lo:lo + rows].reshape(B * rows, 3 * D)
-                if last and lin.lora is None:
-                    continue                      # nothing trainable upstream of the first block's context stream
-                dn = self._lin_bwd(lin, dq_rows, x=n_in, T=T_)
-                if last:
-                    continue                      # frozen embedders: the chain stops here
-                dxin, _ = ops.ln_modulate_bwd(dn, xin, m_[:, D:2 * D], rows, dres=d_x1[name])
-                if name == "img":
-                    d_img = dxin
-                else:
-                    d_txt = dxin
-                del dn
-            del dqkv, sv, d_x1
+            if B == 1:
+                dq_i, dq_t = dqkv[St:], dqkv[:St]
+            else:
+                dq_i = dqkv.view(B, S, 3 * D)[:, St:].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, :St].reshape(B * St, 3 * D)
+            streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
+            if last:
+                streams = [s_ for s_ in streams if s_[1].lora is not None]   # frozen embedders: only adapter grads remain to compute
+            probs, Us = [], {}
+            for (name, lin, dq, n_in, T_) in streams:
+                kw = {}
+                if lin.lora is not None:
+                    Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
+                    kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
+                if not last:
+                    probs.append(dict(a=dq, w=lin.wT, **kw))
+            dns = ops.gemm_grouped(probs) if probs else []
+            for (name, lin, dq, n_in, T_) in streams:
+                if lin.lora is not None:
+                    lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
+            if not last:
+                d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+                d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
+            del dqkv, sv, dns
         return None
 
     # ------------------------------------------------------------------------------------------------

@@ -152,10 +152,8 @@ def scale_cols(x, gate, rows_per_batch: int, out=None):
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
-def gemm(a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
-         gate=None, rows_per_batch: int = 0):
-    """out[M,N] = a[M,K] @ w[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue (see st355.h)."""
-    L = _l.load()
+def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
+               gate=None, rows_per_batch: int = 0):
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
     M, K = a.shape
     N, Kw = w.shape
@@ -163,7 +161,6 @@ def gemm(a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, 
         raise _l.St355Error(f"gemm: K mismatch {K} vs {Kw}")
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    g = GemmArgs()
     g.A, g.lda = _ptr(a), _rows(a, "a")
     g.B, g.ldb = _ptr(w), _rows(w, "w")
     g.C, g.ldc = _ptr(out), _rows(out, "out")
@@ -177,7 +174,9 @@ def gemm(a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, 
         g.K2 = a2.shape[1]
     if bias is not None:
         _chk(bias, BF16, "bias")
-        g.bias = _ptr(bias.contiguous())
+        if not bias.is_contiguous():
+            raise _l.St355Error("gemm: bias must be contiguous")
+        g.bias = _ptr(bias)
     g.epilogue = epilogue
     if aux_out is not None:
         _chk(aux_out, BF16, "aux_out")
@@ -189,8 +188,30 @@ def gemm(a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, 
         _chk(gate, BF16, "gate")
         g.gate, g.gate_stride = _ptr(gate), _rows(gate, "gate")
         g.rows_per_batch = rows_per_batch
+    return out
+
+
+def gemm(a, w, **kw):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ a2[M,K2] @ b2[N,K2]^T) with a fused epilogue (see st355.h).
+    kwargs: bias, out, epilogue, a2, b2, aux_out, aux_in, gate, rows_per_batch."""
+    L = _l.load()
+    g = GemmArgs()
+    out = _gemm_args(g, a, w, **kw)
     _l.check(L.st355_gemm_bf16(_stream(), C.byref(g)), "gemm_bf16")
     return out
+
+
+def gemm_grouped(problems):
+    """run several independent GEMMs that share one epilogue kind in as few launches as possible.
+    problems: list of dicts with keys a, w and the kwargs of gemm().  Returns the list of outputs."""
+    L = _l.load()
+    arr = (GemmArgs * len(problems))()
+    outs = []
+    for g, pr in zip(arr, problems):
+        pr = dict(pr)
+        outs.append(_gemm_args(g, pr.pop("a"), pr.pop("w"), **pr))
+    _l.check(L.st355_gemm_bf16_grouped(_stream(), arr, len(problems)), "gemm_bf16_grouped")
+    return outs
 
 
 _skinny_ws = {}
