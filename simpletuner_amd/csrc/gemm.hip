@@ -61,16 +61,16 @@ __device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& pm, i
 
 // ---- shared epilogue: acc[i][j] is D[n_local][m_local] of the wave's 64x64 sub-tile at (mw0, nw0) ----
 // lane: token m = mw0 + j*32 + (lane&31); features nw0 + i*32 + 8a + 4*(lane>>5) + b for register 4a+b
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], int mw0, int nw0, int lane) {
+template <int EPI, int NI = 2, int NJ = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][NJ], int mw0, int nw0, int lane) {
   const int khalf = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < NJ; j++) {
     const int m = mw0 + j * 32 + (lane & 31);
     if (m >= p.M) continue;
     const int64_t bidx = (EPI == ST355_EPI_GATE_RESIDUAL) ? (int64_t)(m / p.rows_per_batch) : 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NI; i++) {
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         const int n = nw0 + i * 32 + 8 * a + 4 * khalf;
@@ -251,6 +251,135 @@ __global__ void __launch_bounds__(P3_THREADS, 2) k_gemm_p3(GemmGroup g) {
 }
 
 // =================================================================================================
+// k_gemm_p4: 256x256 tile, BK=32, FOUR-slot LDS-DMA ring (4 x 32 KiB), 8 waves (2 x 4), wave tile 128 tokens x 64 features.
+// Doubling the wave tile halves the LDS bytes read per MFMA (0.75 -> 6 fragments per 8 MFMAs vs 4 per 4), which is what
+// bounds k_gemm_p3 (LDS ~80 % busy at 34 % MFMA utilisation).  Loads are issued three K-slots ahead; vmcnt(8) retires the
+// oldest slot (4 LDS-DMAs per wave per slot) and leaves two slots in flight across the raw barrier.
+// LDS rows are 64 B: chunk' = chunk ^ ((row>>2)&3) spreads a 16-lane ds_read_b128 group over all 16 slots of a 256-B bank row.
+// =================================================================================================
+#define P4_BM 256
+#define P4_BN 256
+#define P4_BK 32
+#define P4_THREADS 512
+#define P4_XBYTES (P4_BM * P4_BK * 2)       // 16 KiB
+#define P4_SLOT (2 * P4_XBYTES)             // 32 KiB
+#define P4_LDS (4 * P4_SLOT)                // 128 KiB
+
+template <int EPI>
+__global__ void __launch_bounds__(P4_THREADS, 2) k_gemm_p4(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;     // 2 (tokens, 128 each) x 4 (features, 64 each)
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int pi = id >= g.tiles0 ? 1 : 0;
+  if (pi) id -= g.tiles0;
+  const GemmP& p = g.p[pi];
+  const int nbm = (p.M + P4_BM - 1) / P4_BM, nbn = (p.N + P4_BN - 1) / P4_BN;
+  int pm, pn;
+  tile_coords(id, nbm, nbn, pm, pn);
+  const int m0 = pm * P4_BM, n0 = pn * P4_BN;
+  const int nt1 = p.K / P4_BK;
+  const int nt = nt1 + p.K2 / P4_BK;
+
+  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
+  const int64_t la2 = p.lda2, lb2 = p.ldb2;
+  const int M = p.M, N = p.N;
+  // staging: one LDS-DMA instruction = 16 rows x 64 B; this wave issues instructions 2wv, 2wv+1 of the X and of the W tile
+  const int st_row = lane >> 2, st_cp = lane & 3;
+  int64_t xo[2], wo[2];
+  int xrow[2], wrow[2], sc[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int row = (wv * 2 + j) * 16 + st_row;
+    sc[j] = (st_cp ^ ((row >> 2) & 3)) * 8;
+    xrow[j] = min(m0 + row, M - 1);
+    wrow[j] = min(n0 + row, N - 1);
+    xo[j] = (int64_t)xrow[j] * p.lda + sc[j];
+    wo[j] = (int64_t)wrow[j] * p.ldb + sc[j];
+  }
+  auto stage = [&](int t, int slot) {
+    char* xs = smem + slot * P4_SLOT;
+    char* ws = xs + P4_XBYTES;
+    if (t < nt1) {
+      const int k0 = t * P4_BK;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        glds16(A1 + xo[j] + k0, xs + (wv * 2 + j) * 1024);
+        glds16(B1 + wo[j] + k0, ws + (wv * 2 + j) * 1024);
+      }
+    } else {
+      const int k0 = (t - nt1) * P4_BK;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        glds16(A2 + (int64_t)xrow[j] * la2 + sc[j] + k0, xs + (wv * 2 + j) * 1024);
+        glds16(B2 + (int64_t)wrow[j] * lb2 + sc[j] + k0, ws + (wv * 2 + j) * 1024);
+      }
+    }
+  };
+
+  int w_off[2], w_sw[2], x_off[4], x_sw[4];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int wr = wn * 64 + i * 32 + (lane & 31);
+    w_off[i] = wr * 64; w_sw[i] = (wr >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int xr = wm * 128 + j * 32 + (lane & 31);
+    x_off[j] = xr * 64; x_sw[j] = (xr >> 2) & 3;
+  }
+  const int khalf = lane >> 5;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- prologue: up to three slots in flight ----
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  if (nt > 2) stage(2, 2);
+  if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int t = 0; t < nt; t++) {
+    if (t + 3 < nt) stage(t + 3, (cur + 3) & 3);     // the slot read during iteration t-1
+    const char* xs = smem + cur * P4_SLOT;
+    const char* ws = xs + P4_XBYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int c = 2 * ks + khalf;
+      bf16x8 wf[2], xf[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) wf[i] = *(const bf16x8*)(ws + w_off[i] + ((c ^ w_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; j++) xf[j] = *(const bf16x8*)(xs + x_off[j] + ((c ^ x_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      // retire slot t+1; slots t+2, t+3 (4 LDS-DMAs each) stay in flight across the barrier
+      if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    cur = (cur + 1) & 3;
+  }
+  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// =================================================================================================
 // k_gemm_s2: 128x128x64, 4 waves, double buffer (small problems)
 // =================================================================================================
 #define S2_BM 128
@@ -323,7 +452,7 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
 static int validate(const st355_gemm_args* a) {
   ST_REQUIRE(a && a->A && a->B && a->C, "gemm: null pointer");
   ST_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "gemm: empty shape M=%d N=%d K=%d", a->M, a->N, a->K);
-  ST_REQUIRE(a->K % BK == 0 && a->K2 % BK == 0, "gemm: K (%d) and K2 (%d) must be multiples of 64", a->K, a->K2);
+  ST_REQUIRE(a->K % BK == 0 && a->K2 % BK == 0, "gemm: K (%d) and K2 (%d) must be multiples of 64", a->K, a->K2);  // (the BK=32 schedule needs only 32)
   ST_REQUIRE(a->N % 4 == 0 && a->ldc % 4 == 0, "gemm: N (%d) and ldc must be multiples of 4", a->N);
   ST_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 (16-byte rows)");
   ST_REQUIRE(((uintptr_t)a->A % 16 == 0) && ((uintptr_t)a->B % 16 == 0) && ((uintptr_t)a->C % 8 == 0), "gemm: misaligned pointer");
@@ -375,13 +504,22 @@ static int launch_p3(void* stream, const GemmGroup& g, int tiles) {
   return st355_check_launch("gemm_p3");
 }
 
+template <int EPI>
+static int launch_p4(void* stream, const GemmGroup& g, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_p4<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS); attr_set = true; }
+  hipLaunchKernelGGL(k_gemm_p4<EPI>, dim3(tiles), dim3(P4_THREADS), P4_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_p4");
+}
+static int p4_tiles(const GemmP& p) { return ((p.M + P4_BM - 1) / P4_BM) * ((p.N + P4_BN - 1) / P4_BN); }
+
 static int p3_tiles(const GemmP& p) { return ((p.M + P3_BM - 1) / P3_BM) * ((p.N + P3_BN - 1) / P3_BN); }
 
 static int gemm_impl_choice() {
   static int c = -1;
   if (c < 0) {
-    const char* e = getenv("ST355_GEMM_IMPL");   // "s2" forces the small-tile schedule (A/B testing)
-    c = (e && e[0] == 's') ? 0 : 1;
+    const char* e = getenv("ST355_GEMM_IMPL");   // A/B testing: "s2" small tile only, "p3" no 256x256 schedule, default all
+    c = (e && e[0] == 's') ? 0 : ((e && e[0] == 'p' && e[1] == '3') ? 1 : 2);
   }
   return c;
 }
@@ -398,7 +536,13 @@ static int gemm_impl_choice() {
 static int run_one(void* stream, const st355_gemm_args* a) {
   GemmP p = to_p(a);
   // the deep-pipelined schedule needs enough tiles to fill 256 CUs; tiny problems stay on the 128x128 schedule
-  const bool big = gemm_impl_choice() == 1 && p.M > 128 && p3_tiles(p) >= 128;
+  // 256x256 tiles only when they (nearly) fill the 256 CUs at one workgroup each
+  if (gemm_impl_choice() == 2 && p4_tiles(p) >= 200) {
+    GemmGroup g;
+    g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    DISPATCH_EPI(launch_p4, a->epilogue, stream, g, g.tiles0);
+  }
+  const bool big = gemm_impl_choice() >= 1 && p.M > 128 && p3_tiles(p) >= 128;
   if (big) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p3_tiles(p);
@@ -423,7 +567,27 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
   }
   int i = 0;
   while (i < count) {
-    if (i + 1 < count && gemm_impl_choice() == 1) {
+    if (i + 1 < count && gemm_impl_choice() == 2) {
+      GemmGroup g;
+      g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);
+      g.tiles0 = p4_tiles(g.p[0]);
+      const int tiles = g.tiles0 + p4_tiles(g.p[1]);
+      if (tiles >= 200) {
+        ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]));
+        int rc;
+        switch (args[i].epilogue) {
+          case ST355_EPI_NONE: rc = launch_p4<ST355_EPI_NONE>(stream, g, tiles); break;
+          case ST355_EPI_GELU: rc = launch_p4<ST355_EPI_GELU>(stream, g, tiles); break;
+          case ST355_EPI_GATE_RESIDUAL: rc = launch_p4<ST355_EPI_GATE_RESIDUAL>(stream, g, tiles); break;
+          case ST355_EPI_MUL_GELU_GRAD: rc = launch_p4<ST355_EPI_MUL_GELU_GRAD>(stream, g, tiles); break;
+          default: rc = launch_p4<ST355_EPI_ADD>(stream, g, tiles); break;
+        }
+        if (rc) return rc;
+        i += 2;
+        continue;
+      }
+    }
+    if (i + 1 < count && gemm_impl_choice() >= 1) {
       GemmGroup g;
       g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);
       g.tiles0 = p3_tiles(g.p[0]);
