@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--rank", type=int, default=32)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
     return ap.parse_args()
 
@@ -146,6 +147,8 @@ def main():
     if not args.no_prof:
         ops.prof_enable(False)
         prof = ops.prof_collect()
+        if args.prof_dump and rank == 0:
+            ops.prof_dump(args.prof_dump)
         ops.prof_reset()
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:

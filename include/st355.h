@@ -49,6 +49,8 @@ int st355_prof_enable(int on);        /* 1: bracket every launch with hipEvents;
 int st355_prof_reset(void);
 /* synchronises the recorded events and fills per-class totals: ms, launches, algorithmic flops, bytes */
 int st355_prof_collect(double* ms, int64_t* launches, double* flops, double* bytes, int n_classes);
+/* writes one CSV line per recorded launch (class,ms,flops,bytes,shape tag) — per-shape roofline tables in profiles/ */
+int st355_prof_dump(const char* path);
 
 /* ---- K1/K2: flow-matching noising + target (common.py:4975-4992, 4610-4611) ----------------- */
 /* x_t = (1-sigma_b) x + sigma_b n ; target = n - x.  x,n,x_t,target: [B, per_sample] bf16; sigma fp32 [B].

@@ -67,7 +67,7 @@ int st355_check_launch(const char* what);
 struct ProfScope {
   int idx;
   void* stream;
-  ProfScope(void* stream, int klass, double flops, double bytes);
+  ProfScope(void* stream, int klass, double flops, double bytes, const char* tag_fmt = nullptr, ...);
   ~ProfScope();
 };
 

@@ -21,9 +21,33 @@
 //               512-row txt GEMM fills the tail of the 4096-row img GEMM instead of running at 19% occupancy).
 //   k_gemm_s2   128 x 128 x 64 tile, 4 waves, double-buffered, one drained barrier per K-tile; used for small problems.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 #define BK 64
+
+// Optional in-kernel timeline (tools/gemm_lab.hip builds this file with -DST355_TRACE): waves 0 and 4 of one workgroup stamp
+// s_memtime at the section boundaries of two k-steps; the stamps stay in SGPRs until the kernel ends.
+#ifdef ST355_TRACE
+#define TR_T0 40
+#define TR_MARKS 12
+__device__ uint64_t st355_trace_buf[2][TR_MARKS];
+#define TR_DECL uint64_t tr_[TR_MARKS] = {}
+// the stamp stays an un-consumed SMEM result (no s_waitcnt is forced at the mark itself)
+#define TR(t, k)                                                  \
+  do {                                                            \
+    if ((t) == TR_T0) tr_[k] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+#define TR_FLUSH(wv, lane)                                                              \
+  do {                                                                                  \
+    if (blockIdx.x == 64 && (lane) == 0 && ((wv) & 3) == 0)                              \
+      for (int k_ = 0; k_ < TR_MARKS; k_++) st355_trace_buf[(wv) >> 2][k_] = tr_[k_];    \
+  } while (0)
+#else
+#define TR_DECL
+#define TR(t, k)
+#define TR_FLUSH(wv, lane)
+#endif
 
 struct GemmP {
   const bf16* A; int64_t lda;
@@ -254,7 +278,8 @@ __global__ void __launch_bounds__(P3_THREADS, 2) k_gemm_p3(GemmGroup g) {
 // k_gemm_p4: 256x256 tile, BK=32, FOUR-slot LDS-DMA ring (4 x 32 KiB), 8 waves (2 x 4), wave tile 128 tokens x 64 features.
 // Doubling the wave tile halves the LDS bytes read per MFMA (0.75 -> 6 fragments per 8 MFMAs vs 4 per 4), which is what
 // bounds k_gemm_p3 (LDS ~80 % busy at 34 % MFMA utilisation).  Loads are issued three K-slots ahead; vmcnt(8) retires the
-// oldest slot (4 LDS-DMAs per wave per slot) and leaves two slots in flight across the raw barrier.
+// slot needed next (4 LDS-DMAs per wave per slot) and leaves two slots in flight across the raw barrier; fragment loads are
+// software-pipelined one k-step ahead (across slots), and MFMA clusters run at raised wave priority (T5).
 // LDS rows are 64 B: chunk' = chunk ^ ((row>>2)&3) spreads a 16-lane ds_read_b128 group over all 16 slots of a 256-B bank row.
 // =================================================================================================
 #define P4_BM 256
@@ -340,7 +365,28 @@ __global__ void __launch_bounds__(P4_THREADS, 2) k_gemm_p4(GemmGroup g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // ---- prologue: up to three slots in flight ----
+  // Software-pipelined fragment loads: the ring invariant is shifted by one iteration (slot t+1 is landed AND published
+  // before iteration t starts), so while the MFMAs of one k-step run, the ds_read_b128s of the next k-step — possibly of the
+  // next slot — are already in flight.  LDS latency no longer serialises with the matrix pipe after every barrier.
+  auto load_frags = [&](int slot, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[4]) {
+    const char* xs = smem + slot * P4_SLOT;
+    const char* ws = xs + P4_XBYTES;
+    const int c = 2 * ks + khalf;
+#pragma unroll
+    for (int i = 0; i < 2; i++) wf[i] = *(const bf16x8*)(ws + w_off[i] + ((c ^ w_sw[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < 4; j++) xf[j] = *(const bf16x8*)(xs + x_off[j] + ((c ^ x_sw[j]) << 4));
+  };
+  auto mma8 = [&](const bf16x8 (&wf)[2], const bf16x8 (&xf)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: three slots in flight; slot 0 retired and published ----
   stage(0, 0);
   if (nt > 1) stage(1, 1);
   if (nt > 2) stage(2, 2);
@@ -348,34 +394,424 @@ __global__ void __launch_bounds__(P4_THREADS, 2) k_gemm_p4(GemmGroup g) {
   else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  int cur = 0;
+  bf16x8 wa[2], xa[4], wb[2], xb[4];
+  load_frags(0, 0, wa, xa);
   for (int t = 0; t < nt; t++) {
-    if (t + 3 < nt) stage(t + 3, (cur + 3) & 3);     // the slot read during iteration t-1
-    const char* xs = smem + cur * P4_SLOT;
-    const char* ws = xs + P4_XBYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int c = 2 * ks + khalf;
-      bf16x8 wf[2], xf[4];
-#pragma unroll
-      for (int i = 0; i < 2; i++) wf[i] = *(const bf16x8*)(ws + w_off[i] + ((c ^ w_sw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < 4; j++) xf[j] = *(const bf16x8*)(xs + x_off[j] + ((c ^ x_sw[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    }
+    const int cur = t & 3;
+    if (t + 3 < nt) stage(t + 3, (t + 3) & 3);        // slot (t-1)&3: its last reads completed before the previous barrier
+    load_frags(cur, 1, wb, xb);                       // k-step 1 of this slot, in flight under the first MFMA cluster
+    mma8(wa, xa);
     if (t + 1 < nt) {
-      // retire slot t+1; slots t+2, t+3 (4 LDS-DMAs each) stay in flight across the barrier
+      // retire + publish slot t+1 (the oldest outstanding); slots t+2, t+3 stay in flight across the barrier
       if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of slot `cur` has landed: it may be refilled after the barrier
       __builtin_amdgcn_s_barrier();
+      load_frags((t + 1) & 3, 0, wa, xa);             // k-step 0 of the next slot, in flight under the second MFMA cluster
     }
-    cur = (cur + 1) & 3;
+    mma8(wb, xb);
   }
+  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// =================================================================================================
+// k_gemm_pp: 256x256 tile, BK=32, four-slot LDS-DMA ring — the PING-PONG schedule (cdna_hip_programming.md T3+T4+T5).
+// The 8 waves are two groups (wm = 0 / 1 = the two 128-token halves; one wave of each group per SIMD).  Group 1 runs ONE
+// barrier behind group 0, so in every barrier interval one wave of each SIMD issues its 8 MFMAs (256 matrix-pipe cycles, at
+// raised priority) while its partner issues the ds_read_b128s of its next phase + one LDS-DMA piece: the matrix pipe never
+// waits for LDS latency, and the loads never wait for the matrix pipe.
+// A k-step (K=32, slot = t&3) is two phases:  A(t): W(64 feat) x X0(64 tok) -> acc[:,0:2];  B(t): W(kept) x X1 -> acc[:,2:4].
+// Ring protocol (q = global phase, R_q / M_q = its load / MFMA section):
+//   * W(t+2) is issued in R_A(t), X(t+3) in R_B(t): a region is refilled >= 2 phases after its last read (one phase for the
+//     lgkmcnt, one for the other group's stagger) — WAR-safe without extra barriers;
+//   * the only VM wait is at the end of R_B(t): vmcnt(6) retires everything of k-step t+1 (three 2-piece issues stay in
+//     flight across the barriers); k-step t+1 is first read one phase later (R_A(t+1)) — RAW-safe for both groups.
+// =================================================================================================
+#define PP_BM 256
+#define PP_BN 256
+#define PP_BK 32
+#define PP_THREADS 512
+#define PP_XBYTES (PP_BM * PP_BK * 2)       // 16 KiB
+#define PP_SLOT (2 * PP_XBYTES)             // 32 KiB
+#define PP_LDS (4 * PP_SLOT)                // 128 KiB
+#define PP_BARRIER()                                   \
+  do {                                                 \
+    asm volatile("" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+  } while (0)
+
+template <int EPI>
+__global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;     // wm: group (128-token half); wn: 64-feature column of the tile
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int pi = id >= g.tiles0 ? 1 : 0;
+  if (pi) id -= g.tiles0;
+  const GemmP& p = g.p[pi];
+  const int nbm = (p.M + PP_BM - 1) / PP_BM, nbn = (p.N + PP_BN - 1) / PP_BN;
+  int pm, pn;
+  tile_coords(id, nbm, nbn, pm, pn);
+  const int m0 = pm * PP_BM, n0 = pn * PP_BN;
+  const int nt1 = p.K / PP_BK;
+  const int nt = nt1 + p.K2 / PP_BK;
+
+  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
+  const int64_t la2 = p.lda2, lb2 = p.ldb2;
+  const int M = p.M, N = p.N;
+  // staging: one LDS-DMA instruction = 16 rows x 64 B; this wave issues pieces 2wv, 2wv+1 of the X and of the W tile
+  const int st_row = lane >> 2, st_cp = lane & 3;
+  int64_t xo[2], wo[2];
+  int xrow[2], wrow[2], sc[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int row = (wv * 2 + j) * 16 + st_row;
+    sc[j] = (st_cp ^ ((row >> 2) & 3)) * 8;
+    xrow[j] = min(m0 + row, M - 1);
+    wrow[j] = min(n0 + row, N - 1);
+    xo[j] = (int64_t)xrow[j] * p.lda + sc[j];
+    wo[j] = (int64_t)wrow[j] * p.ldb + sc[j];
+  }
+  auto stage_x = [&](int u) {
+    char* xs = smem + (u & 3) * PP_SLOT;
+    if (u < nt1) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16(A1 + xo[j] + u * PP_BK, xs + (wv * 2 + j) * 1024);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16(A2 + (int64_t)xrow[j] * la2 + sc[j] + (u - nt1) * PP_BK, xs + (wv * 2 + j) * 1024);
+    }
+  };
+  auto stage_w = [&](int u) {
+    char* ws = smem + (u & 3) * PP_SLOT + PP_XBYTES;
+    if (u < nt1) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16(B1 + wo[j] + u * PP_BK, ws + (wv * 2 + j) * 1024);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16(B2 + (int64_t)wrow[j] * lb2 + sc[j] + (u - nt1) * PP_BK, ws + (wv * 2 + j) * 1024);
+    }
+  };
+
+  // fragment addresses (bytes inside a slot's X / W image; 64-B rows, chunk' = chunk ^ ((row>>2)&3))
+  const int khalf = lane >> 5;
+  int w_a[2][2], x_a[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int wr = wn * 64 + i * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) w_a[i][ks] = PP_XBYTES + wr * 64 + (((2 * ks + khalf) ^ ((wr >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int xr = wm * 128 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) x_a[j][ks] = xr * 64 + (((2 * ks + khalf) ^ ((xr >> 2) & 3)) << 4);
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- prologue: X(0) W(0) X(1) W(1) X(2) in the ring's issue order; k-step 0 retired + published ----
+  stage_x(0); stage_w(0);
+  if (nt > 1) { stage_x(1); stage_w(1); }
+  if (nt > 2) stage_x(2);
+  if (nt > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();                           // group 1 runs one barrier interval behind group 0
+
+  bf16x8 wf[2][2], xf[2][2];
+  TR_DECL;
+  for (int t = 0; t < nt; t++) {
+    const char* sl = smem + (t & 3) * PP_SLOT;
+    // ---------------- phase A: W x X0 ----------------
+    TR(t, 0);
+    if (t + 2 < nt) stage_w(t + 2);
+    TR(t, 1);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) wf[i][ks] = *(const bf16x8*)(sl + w_a[i][ks]);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) xf[j][ks] = *(const bf16x8*)(sl + x_a[j][ks]);
+    TR(t, 2);
+    PP_BARRIER();
+    TR(t, 3);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    TR(t, 4);
+    PP_BARRIER();
+    // ---------------- phase B: W (kept) x X1 ----------------
+    TR(t, 5);
+    if (t + 3 < nt) stage_x(t + 3);
+    TR(t, 6);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) xf[j][ks] = *(const bf16x8*)(sl + x_a[2 + j][ks]);
+    if (t + 1 < nt) {                                  // retire k-step t+1: X(t+2) W(t+2) X(t+3) may stay in flight
+      if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TR(t, 7);
+    PP_BARRIER();
+    TR(t, 8);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], xf[j][ks], acc[i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    TR(t, 9);
+    PP_BARRIER();
+    TR(t, 10);
+  }
+  TR_FLUSH(wv, lane);
+  if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
+  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// =================================================================================================
+// k_gemm_pq: 256x256 tile, BK=64 (128-byte rows = whole cache lines: the LDS-DMA path moves 43.7 B/clk/CU with 128-B rows but
+// only 29 B/clk/CU with 64-B rows — tools/probes/glds_probe.hip), ping-pong schedule as k_gemm_pp.
+// A K-tile (64 KiB) is four 16-KiB REGIONS, grouped by the phase that reads them rather than by tile rows:
+//   XA = the first 64 tokens of each group's 128 (tile rows 0-63, 128-191)   XB = the last 64 (64-127, 192-255)
+//   WA = the first 32 features of each wave's 64                            WB = the last 32
+// Phases of K-tile t (buffer t&1):  P0: WA x XA (reads XA, WA)   P1: WB x XA (reads WB)   P2: WB x XB (reads XB)   P3: WA x XB (-)
+// Each phase = 8 MFMAs (2 accumulators x 4 k-steps) and ONE region refill (2 LDS-DMA pieces per wave), issued in the order
+//   ... XA(t+2)@P2  WA(t+2)@P3  WB(t+2)@P0'  XB(t+2)@P1' ...   — every region is refilled >= 2 phases after its last read
+// (WAR-safe across the one-barrier stagger of the two wave groups) and retired by the uniform  s_waitcnt vmcnt(8)  at the end of
+// each phase's load section, 4 phases after its issue (RAW-safe: it is first read one phase after that wait).
+// =================================================================================================
+#define PQ_BM 256
+#define PQ_BN 256
+#define PQ_BK 64
+#define PQ_THREADS 512
+#define PQ_REGION 16384
+#define PQ_BUF (4 * PQ_REGION)              // 64 KiB: [XA][XB][WA][WB]
+#define PQ_LDS (2 * PQ_BUF)                 // 128 KiB
+#ifndef PQ_PRIO
+#define PQ_PRIO 1                           // raise the wave priority around the MFMA clusters (T5)
+#endif
+#ifndef PQ_GL
+#define PQ_GL 1                             // where a phase issues its LDS-DMA pieces: 0 before the ds_reads, 1 after them, 2 at the end of the previous MFMA section
+#endif
+
+__device__ __forceinline__ void wait_vm_rt(int n) {    // n = LDS-DMA pieces that may stay in flight (even, 0..8)
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;     // wm: group (128-token half); wn: 64-feature column of the tile
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int pi = id >= g.tiles0 ? 1 : 0;
+  if (pi) id -= g.tiles0;
+  const GemmP& p = g.p[pi];
+  const int nbm = (p.M + PQ_BM - 1) / PQ_BM, nbn = (p.N + PQ_BN - 1) / PQ_BN;
+  int pm, pn;
+  tile_coords(id, nbm, nbn, pm, pn);
+  const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
+  const int nt1 = p.K / PQ_BK;
+  const int nt = nt1 + p.K2 / PQ_BK;
+
+  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
+  const int64_t la2 = p.lda2, lb2 = p.ldb2;
+  const int M = p.M, N = p.N;
+  // staging: a piece = 8 region rows x 128 B; this wave issues pieces 2wv, 2wv+1 of whichever region is being refilled.
+  // region row lr -> tile row:  X: (lr>>6)*128 + (lr&63) [+64 for XB]     W: (lr>>5)*64 + (lr&31) [+32 for WB]
+  // Addresses are (uniform 64-bit base of the tile's first row + k) + a 32-bit per-lane byte offset: the LDS-DMA takes the
+  // SGPR-base + VGPR-offset form, so the K loop spends no VALU (and only 8 VGPRs) on addressing.
+  const char* xbase = (const char*)A1 + (int64_t)m0 * p.lda * 2;
+  const char* wbase = (const char*)B1 + (int64_t)n0 * p.ldb * 2;
+  const uint32_t lda_b = (uint32_t)p.lda * 2, ldb_b = (uint32_t)p.ldb * 2;
+  auto x_rel = [&](int lr, int r) { return min(m0 + (lr >> 6) * 128 + (lr & 63) + r * 64, M - 1) - m0; };
+  auto w_rel = [&](int lr, int r) { return min(n0 + (lr >> 5) * 64 + (lr & 31) + r * 32, N - 1) - n0; };
+  uint32_t xo[2][2], wo[2][2];               // [region A/B][piece] byte offsets from xbase / wbase
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int lr = (wv * 2 + j) * 8 + (lane >> 3);
+    const uint32_t scb = (uint32_t)(((lane & 7) ^ ((lr >> 1) & 7)) * 16);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      xo[r][j] = (uint32_t)x_rel(lr, r) * lda_b + scb;
+      wo[r][j] = (uint32_t)w_rel(lr, r) * ldb_b + scb;
+    }
+  }
+  auto stage_ext = [&](const bf16* base, int64_t ld, int row0, bool is_x, int r, int k0, char* dst) {   // low-rank K-extension (rare)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int lr = (wv * 2 + j) * 8 + (lane >> 3);
+      const int rel = is_x ? x_rel(lr, r) : w_rel(lr, r);
+      glds16(base + (int64_t)(row0 + rel) * ld + ((lane & 7) ^ ((lr >> 1) & 7)) * 8 + k0, dst + j * 1024);
+    }
+  };
+  auto stage_x = [&](int u, int r) {        // r = 0: XA, 1: XB
+    char* dst = smem + (u & 1) * PQ_BUF + r * PQ_REGION + wv * 2048;
+    if (u < nt1) {
+      const char* kb = xbase + u * (PQ_BK * 2);
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + xo[r][j]), dst + j * 1024);
+    } else {
+      stage_ext(A2, la2, m0, true, r, (u - nt1) * PQ_BK, dst);
+    }
+  };
+  auto stage_w = [&](int u, int r) {        // r = 0: WA, 1: WB
+    char* dst = smem + (u & 1) * PQ_BUF + (2 + r) * PQ_REGION + wv * 2048;
+    if (u < nt1) {
+      const char* kb = wbase + u * (PQ_BK * 2);
+#pragma unroll
+      for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + wo[r][j]), dst + j * 1024);
+    } else {
+      stage_ext(B2, lb2, n0, false, r, (u - nt1) * PQ_BK, dst);
+    }
+  };
+  // the refill of phase q = 4t+ph:  P0: WB(t+1)  P1: XB(t+1)  P2: XA(t+2)  P3: WA(t+2)
+  auto refill = [&](int t, int ph, bool check) {      // check = false in the steady-state loop (every refill exists there)
+    if (ph == 0) { if (!check || t + 1 < nt) stage_w(t + 1, 1); }
+    else if (ph == 1) { if (!check || t + 1 < nt) stage_x(t + 1, 1); }
+    else if (ph == 2) { if (!check || t + 2 < nt) stage_x(t + 2, 0); }
+    else { if (!check || t + 2 < nt) stage_w(t + 2, 0); }
+  };
+
+  // fragment addresses: region row (lane&31) + block base, 16-byte chunk (2ks+khalf) ^ ((row>>1)&7)
+  const int khalf = lane >> 5;
+  const int l31 = lane & 31;
+  int xk[4], wk[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    const int ch = ((2 * ks + khalf) ^ ((l31 >> 1) & 7)) << 4;
+    xk[ks] = (wm * 64 + l31) * 128 + ch;                       // + j*4096 (block), + region, + buffer
+    wk[ks] = 2 * PQ_REGION + (wn * 32 + l31) * 128 + ch;
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- prologue: XA(0) WA(0) WB(0) XB(0) XA(1) WA(1) in ring order; XA(0), WA(0) retired + published ----
+  stage_x(0, 0); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1);
+  if (nt > 1) { stage_x(1, 0); stage_w(1, 0); }
+  wait_vm_rt(nt > 1 ? 8 : 4);
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();                           // group 1 runs one barrier interval behind group 0
+
+  bf16x8 xf[2][4], w0f[4], w1f[4];
+  TR_DECL;
+#define PQ_MMA(WF, I, J0, T, PH)                                                                              \
+  do {                                                                                                        \
+    if (PQ_PRIO) __builtin_amdgcn_s_setprio(1);                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                        \
+      _Pragma("unroll") for (int j = 0; j < 2; j++)                                                           \
+        acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ks], xf[j][ks], acc[I][J0 + j], 0, 0, 0); \
+      if (PQ_GL == 3 && ks == 1) { __builtin_amdgcn_sched_barrier(0); refill(T, PH, TAIL); __builtin_amdgcn_sched_barrier(0); } \
+    }                                                                                                         \
+    if (PQ_PRIO) __builtin_amdgcn_s_setprio(0);                                                               \
+  } while (0)
+
+  auto body = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    const char* bf = smem + (t & 1) * PQ_BUF;
+    // allowed in-flight pieces at the end of each phase's load section (8 in steady state)
+    const int rem = nt - 1 - t;                        // K-tiles after this one
+    // ---------------- P0: WA x XA ----------------
+    TR(t, 0);
+    if (PQ_GL == 0) refill(t, 0, TAIL);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) xf[j][ks] = *(const bf16x8*)(bf + xk[ks] + j * 4096);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) w0f[ks] = *(const bf16x8*)(bf + wk[ks]);
+    if (PQ_GL == 1) refill(t, 0, TAIL);
+    TR(t, 1);
+    if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 2));
+    PP_BARRIER();
+    TR(t, 2);
+    PQ_MMA(w0f, 0, 0, t, 1);
+    if (PQ_GL == 2) refill(t, 1, TAIL);
+    TR(t, 3);
+    PP_BARRIER();
+    // ---------------- P1: WB x XA ----------------
+    if (PQ_GL == 0) refill(t, 1, TAIL);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) w1f[ks] = *(const bf16x8*)(bf + wk[ks] + PQ_REGION);
+    if (PQ_GL == 1) refill(t, 1, TAIL);
+    TR(t, 4);
+    if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 0));
+    PP_BARRIER();
+    TR(t, 5);
+    PQ_MMA(w1f, 1, 0, t, 2);
+    if (PQ_GL == 2) refill(t, 2, TAIL);
+    TR(t, 6);
+    PP_BARRIER();
+    // ---------------- P2: WB x XB ----------------
+    if (PQ_GL == 0) refill(t, 2, TAIL);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) xf[j][ks] = *(const bf16x8*)(bf + xk[ks] + PQ_REGION + j * 4096);
+    if (PQ_GL == 1) refill(t, 2, TAIL);
+    TR(t, 7);
+    if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 6 : 0));
+    PP_BARRIER();
+    TR(t, 8);
+    PQ_MMA(w1f, 1, 2, t, 3);
+    if (PQ_GL == 2) refill(t, 3, TAIL);
+    TR(t, 9);
+    PP_BARRIER();
+    // ---------------- P3: WA x XB ----------------
+    if (PQ_GL == 0) refill(t, 3, TAIL);
+    if (PQ_GL == 1) refill(t, 3, TAIL);
+    if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+    PP_BARRIER();
+    TR(t, 10);
+    PQ_MMA(w0f, 0, 2, t + 1, 0);
+    if (PQ_GL == 2) refill(t + 1, 0, TAIL);
+    TR(t, 11);
+    PP_BARRIER();
+  };
+  if (PQ_GL == 2 || PQ_GL == 3) refill(0, 0, true);
+  int t = 0;
+  for (; t < nt - 2; t++) body(t, std::false_type{});
+  for (; t < nt; t++) body(t, std::true_type{});
+#undef PQ_MMA
+  TR_FLUSH(wv, lane);
+  if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
   gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
@@ -511,6 +947,20 @@ static int launch_p4(void* stream, const GemmGroup& g, int tiles) {
   hipLaunchKernelGGL(k_gemm_p4<EPI>, dim3(tiles), dim3(P4_THREADS), P4_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_p4");
 }
+template <int EPI>
+static int launch_pp(void* stream, const GemmGroup& g, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pp<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); attr_set = true; }
+  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(tiles), dim3(PP_THREADS), PP_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_pp");
+}
+template <int EPI>
+static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  hipLaunchKernelGGL(k_gemm_pq<EPI>, dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_pq");
+}
 static int p4_tiles(const GemmP& p) { return ((p.M + P4_BM - 1) / P4_BM) * ((p.N + P4_BN - 1) / P4_BN); }
 
 static int p3_tiles(const GemmP& p) { return ((p.M + P3_BM - 1) / P3_BM) * ((p.N + P3_BN - 1) / P3_BN); }
@@ -518,10 +968,28 @@ static int p3_tiles(const GemmP& p) { return ((p.M + P3_BM - 1) / P3_BM) * ((p.N
 static int gemm_impl_choice() {
   static int c = -1;
   if (c < 0) {
-    const char* e = getenv("ST355_GEMM_IMPL");   // A/B testing: "s2" small tile only, "p3" no 256x256 schedule, default all
-    c = (e && e[0] == 's') ? 0 : ((e && e[0] == 'p' && e[1] == '3') ? 1 : 2);
+    // A/B testing: ST355_GEMM_IMPL = s2 (128x128 only) | p3 (+256x128 ring) | p4 (+256x256 lock-step ring) | pp (256x256 BK=32 ping-pong) | pq (default: 256x256 BK=64 ping-pong)
+    const char* e = getenv("ST355_GEMM_IMPL");
+    c = 4;
+    if (e && e[0] == 'p' && e[1] == 'p') c = 3;
+    else if (e && e[0] == 's') c = 0;
+    else if (e && e[0] == 'p' && e[1] == '3') c = 1;
+    else if (e && e[0] == 'p' && e[1] == '4') c = 2;
   }
   return c;
+}
+
+// the 256x256 schedules run one workgroup per CU: only worth it when the tiles (nearly) fill the 256 CUs
+static int min_tiles_256() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ST355_GEMM_MIN_TILES"); v = e ? atoi(e) : 200; }
+  return v;
+}
+
+template <int EPI>
+static int launch_256(void* stream, const GemmGroup& g, int tiles) {
+  const int c = gemm_impl_choice();
+  return c == 4 ? launch_pq<EPI>(stream, g, tiles) : (c == 3 ? launch_pp<EPI>(stream, g, tiles) : launch_p4<EPI>(stream, g, tiles));
 }
 
 #define DISPATCH_EPI(fn, epi, ...)                                                           \
@@ -537,10 +1005,10 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   GemmP p = to_p(a);
   // the deep-pipelined schedule needs enough tiles to fill 256 CUs; tiny problems stay on the 128x128 schedule
   // 256x256 tiles only when they (nearly) fill the 256 CUs at one workgroup each
-  if (gemm_impl_choice() == 2 && p4_tiles(p) >= 200) {
+  if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256()) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
-    DISPATCH_EPI(launch_p4, a->epilogue, stream, g, g.tiles0);
+    DISPATCH_EPI(launch_256, a->epilogue, stream, g, g.tiles0);
   }
   const bool big = gemm_impl_choice() >= 1 && p.M > 128 && p3_tiles(p) >= 128;
   if (big) {
@@ -554,7 +1022,7 @@ static int run_one(void* stream, const st355_gemm_args* a) {
 extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
   int rc = validate(a);
   if (rc) return rc;
-  ProfScope ps(stream, ST355_K_GEMM, gemm_flops(a), gemm_bytes(a));
+  ProfScope ps(stream, ST355_K_GEMM, gemm_flops(a), gemm_bytes(a), "%dx%dx%d+%d e%d", a->M, a->N, a->K, a->K2, a->epilogue);
   return run_one(stream, a);
 }
 
@@ -567,20 +1035,21 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
   }
   int i = 0;
   while (i < count) {
-    if (i + 1 < count && gemm_impl_choice() == 2) {
+    if (i + 1 < count && gemm_impl_choice() >= 2) {
       GemmGroup g;
       g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);
       g.tiles0 = p4_tiles(g.p[0]);
       const int tiles = g.tiles0 + p4_tiles(g.p[1]);
-      if (tiles >= 200) {
-        ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]));
+      if (tiles >= min_tiles_256()) {
+        ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),
+                     "%d&%dx%dx%d+%d e%d", args[i].M, args[i + 1].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
         int rc;
         switch (args[i].epilogue) {
-          case ST355_EPI_NONE: rc = launch_p4<ST355_EPI_NONE>(stream, g, tiles); break;
-          case ST355_EPI_GELU: rc = launch_p4<ST355_EPI_GELU>(stream, g, tiles); break;
-          case ST355_EPI_GATE_RESIDUAL: rc = launch_p4<ST355_EPI_GATE_RESIDUAL>(stream, g, tiles); break;
-          case ST355_EPI_MUL_GELU_GRAD: rc = launch_p4<ST355_EPI_MUL_GELU_GRAD>(stream, g, tiles); break;
-          default: rc = launch_p4<ST355_EPI_ADD>(stream, g, tiles); break;
+          case ST355_EPI_NONE: rc = launch_256<ST355_EPI_NONE>(stream, g, tiles); break;
+          case ST355_EPI_GELU: rc = launch_256<ST355_EPI_GELU>(stream, g, tiles); break;
+          case ST355_EPI_GATE_RESIDUAL: rc = launch_256<ST355_EPI_GATE_RESIDUAL>(stream, g, tiles); break;
+          case ST355_EPI_MUL_GELU_GRAD: rc = launch_256<ST355_EPI_MUL_GELU_GRAD>(stream, g, tiles); break;
+          default: rc = launch_256<ST355_EPI_ADD>(stream, g, tiles); break;
         }
         if (rc) return rc;
         i += 2;
@@ -593,7 +1062,8 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
       g.tiles0 = p3_tiles(g.p[0]);
       const int tiles = g.tiles0 + p3_tiles(g.p[1]);
       if (tiles >= 128) {
-        ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]));
+        ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),
+                     "%d&%dx%dx%d+%d e%d", args[i].M, args[i + 1].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
         int rc;
         switch (args[i].epilogue) {
           case ST355_EPI_NONE: rc = launch_p3<ST355_EPI_NONE>(stream, g, tiles); break;
@@ -607,7 +1077,7 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
         continue;
       }
     }
-    ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]), gemm_bytes(&args[i]));
+    ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]), gemm_bytes(&args[i]), "%dx%dx%d+%d e%d g", args[i].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
     int rc = run_one(stream, &args[i]);
     if (rc) return rc;
     i += 1;

@@ -31,6 +31,7 @@ struct ProfRec {
   hipEvent_t a, b;
   int klass;
   double flops, bytes;
+  char tag[48];
 };
 static std::mutex g_pm;
 static bool g_prof_on = false;
@@ -48,10 +49,17 @@ static hipEvent_t get_event() {
   return e;
 }
 
-ProfScope::ProfScope(void* s, int klass, double flops, double bytes) : idx(-1), stream(s) {
+ProfScope::ProfScope(void* s, int klass, double flops, double bytes, const char* tag_fmt, ...) : idx(-1), stream(s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_pm);
   ProfRec r;
+  r.tag[0] = 0;
+  if (tag_fmt) {
+    va_list ap;
+    va_start(ap, tag_fmt);
+    vsnprintf(r.tag, sizeof(r.tag), tag_fmt, ap);
+    va_end(ap);
+  }
   r.a = get_event();
   r.b = get_event();
   r.klass = klass;
@@ -101,5 +109,20 @@ extern "C" int st355_prof_collect(double* ms, int64_t* launches, double* flops, 
       bytes[r.klass] += r.bytes;
     }
   }
+  return ST355_OK;
+}
+
+// one CSV line per recorded launch: class,ms,flops,bytes,tag  (call after the stream is idle; bench.py --prof-dump)
+extern "C" int st355_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_pm);
+  FILE* f = fopen(path, "w");
+  if (!f) { st355_set_error("prof_dump: cannot open %s", path); return ST355_EINVAL; }
+  fprintf(f, "class,ms,flops,bytes,tag\n");
+  for (auto& r : g_recs) {
+    float t = 0;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    fprintf(f, "%d,%.5f,%.6g,%.6g,%s\n", r.klass, t, r.flops, r.bytes, r.tag);
+  }
+  fclose(f);
   return ST355_OK;
 }

@@ -16,7 +16,7 @@ LIB_PATH = _HERE / "csrc" / "libst355.so"
 # every symbol include/st355.h declares; tests check the .so exports exactly these
 SYMBOLS = [
     "st355_version", "st355_arch", "st355_last_error",
-    "st355_prof_enable", "st355_prof_reset", "st355_prof_collect",
+    "st355_prof_enable", "st355_prof_reset", "st355_prof_collect", "st355_prof_dump",
     "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss",
     "st355_flux_pack", "st355_flux_unpack",
     "st355_timestep_proj", "st355_silu", "st355_add", "st355_scale_cols",
@@ -73,6 +73,7 @@ def _declare(lib):
         "st355_prof_enable": (C.c_int, [i32]),
         "st355_prof_reset": (C.c_int, []),
         "st355_prof_collect": (C.c_int, [vp, vp, vp, vp, i32]),
+        "st355_prof_dump": (C.c_int, [C.c_char_p]),
         "st355_flow_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, u64, u64]),
         "st355_ddpm_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64]),
         "st355_mse_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32]),

@@ -375,6 +375,11 @@ def prof_reset():
     _l.load().st355_prof_reset()
 
 
+def prof_dump(path: str):
+    """one CSV line per recorded launch (class index, ms, algorithmic flops / bytes, shape tag)"""
+    _l.check(_l.load().st355_prof_dump(str(path).encode()), "prof_dump")
+
+
 def prof_collect():
     n = len(_l.KERNEL_CLASSES)
     ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()

@@ -1,0 +1,128 @@
+// gemm_lab — standalone GEMM schedule lab for libst355 (no torch: starts in milliseconds on a fresh GPU box).
+//   tools/gemm_lab [impl ...]      impl in {s2,p3,p4,pp}; default: all.  Re-executes itself per impl (the choice is cached per process).
+// For every shape: checks st355_gemm_bf16 against a naive fp32-accumulate reference kernel on uniform random operands (every
+// element, transpose-detecting), then times 30 launches with hipEvents and prints TFLOP/s.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DST355_TRACE] tools/gemm_lab.hip -o tools/gemm_lab
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/wait.h>
+#include <vector>
+#include "../simpletuner_amd/csrc/runtime.hip"   // the lab compiles the library sources in (so -DST355_TRACE can instrument them)
+#include "../simpletuner_amd/csrc/gemm.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void k_fill(bf16* p, int64_t n, uint32_t seed, float scale) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    p[i] = (bf16)(((h >> 8) * (1.f / 8388608.f) - 1.f) * scale);
+  }
+}
+// C_ref[m,n] = sum_k A[m,k] B[n,k] (+ A2 B2), fp32
+__global__ void k_ref(const bf16* A, const bf16* B, const bf16* A2, const bf16* B2, float* C, int M, int N, int K, int K2) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; k++) s += (float)A[(int64_t)m * K + k] * (float)B[(int64_t)n * K + k];
+  for (int k = 0; k < K2; k++) s += (float)A2[(int64_t)m * K2 + k] * (float)B2[(int64_t)n * K2 + k];
+  C[(int64_t)m * N + n] = s;
+}
+__global__ void k_cmp(const bf16* C, const float* R, int64_t n, float* out /*max abs err, max abs ref*/, unsigned long long* bad, float atol, float rtol) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float d = fabsf((float)C[i] - R[i]);
+    if (!(d <= atol + rtol * fabsf(R[i]))) atomicAdd(bad, 1ull);
+    atomicMax((int*)&out[0], __float_as_int(d));
+    atomicMax((int*)&out[1], __float_as_int(fabsf(R[i])));
+  }
+}
+
+struct Shape { int M, N, K, K2; };
+
+int main(int argc, char** argv) {
+  if (argc > 1 && strcmp(argv[1], "--child") != 0) {
+    for (int i = 1; i < argc; i++) {
+      setenv("ST355_GEMM_IMPL", argv[i], 1);
+      fflush(stdout);
+      if (fork() == 0) { execl(argv[0], argv[0], "--child", (char*)0); _exit(3); }
+      int st; wait(&st);
+    }
+    return 0;
+  }
+  setenv("ST355_GEMM_MIN_TILES", "1", 0);   // force the 256x256 schedules on the small verification shapes too
+  const char* impl = getenv("ST355_GEMM_IMPL");
+  printf("== impl %s\n", impl ? impl : "default");
+  const Shape check[] = {{512, 512, 256, 0}, {768, 1280, 192, 64}, {4608, 3072, 3072, 64}, {300, 520, 128, 0}};
+  const Shape perf[] = {{4608, 3072, 3072, 0}, {4608, 9216, 3072, 0}, {4608, 12288, 3072, 0}, {4608, 3072, 12288, 0},
+                        {18432, 3072, 3072, 0}, {18432, 12288, 3072, 0}, {18432, 3072, 12288, 0}, {8192, 8192, 8192, 0}, {4096, 4096, 4096, 0}};
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  auto run = [&](const Shape& s, bool verify) {
+    bf16 *A, *B, *A2 = nullptr, *B2 = nullptr, *C;
+    CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&B, (size_t)s.N * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
+    k_fill<<<1024, 256, 0, st>>>(A, (int64_t)s.M * s.K, 1u, 1.f);
+    k_fill<<<1024, 256, 0, st>>>(B, (int64_t)s.N * s.K, 2u, 0.05f);
+    if (s.K2) {
+      CK(hipMalloc(&A2, (size_t)s.M * s.K2 * 2)); CK(hipMalloc(&B2, (size_t)s.N * s.K2 * 2));
+      k_fill<<<256, 256, 0, st>>>(A2, (int64_t)s.M * s.K2, 3u, 1.f);
+      k_fill<<<256, 256, 0, st>>>(B2, (int64_t)s.N * s.K2, 4u, 0.05f);
+    }
+    CK(hipMemsetAsync(C, 0xff, (size_t)s.M * s.N * 2, st));
+    st355_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = s.K; a.B = B; a.ldb = s.K; a.A2 = A2; a.lda2 = s.K2; a.B2 = B2; a.ldb2 = s.K2;
+    a.C = C; a.ldc = s.N; a.M = s.M; a.N = s.N; a.K = s.K; a.K2 = s.K2; a.epilogue = ST355_EPI_NONE;
+    int rc = st355_gemm_bf16(st, &a);
+    if (rc) { printf("  gemm rc=%d: %s\n", rc, st355_last_error()); exit(2); }
+    if (verify) {
+      float* R; float* out; unsigned long long* bad;
+      CK(hipMalloc(&R, (size_t)s.M * s.N * 4)); CK(hipMalloc(&out, 8)); CK(hipMalloc(&bad, 8));
+      CK(hipMemsetAsync(out, 0, 8, st)); CK(hipMemsetAsync(bad, 0, 8, st));
+      k_ref<<<dim3((s.N + 255) / 256, s.M), 256, 0, st>>>(A, B, A2, B2, R, s.M, s.N, s.K, s.K2);
+      k_cmp<<<1024, 256, 0, st>>>(C, R, (int64_t)s.M * s.N, out, bad, 2e-2f, 1e-2f);
+      float h[2]; unsigned long long hb;
+      CK(hipMemcpyAsync(h, out, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      printf("  check %5d x %5d x %5d (+%d): max|err| %.4f  max|ref| %.3f  bad %llu  %s\n", s.M, s.N, s.K, s.K2, h[0], h[1], hb, hb ? "FAIL" : "ok");
+      CK(hipFree(R)); CK(hipFree(out)); CK(hipFree(bad));
+    } else {
+      for (int i = 0; i < 5; i++) st355_gemm_bf16(st, &a);
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      const int iters = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 30;
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; i++) st355_gemm_bf16(st, &a);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("  %6d x %6d x %6d: %8.1f us  %8.1f TFLOP/s\n", s.M, s.N, s.K, ms * 1e3, 2.0 * s.M * s.N * (double)s.K / ms / 1e9);
+#ifdef ST355_TRACE
+      uint64_t tb[2][TR_MARKS];
+      CK(hipMemcpyFromSymbol(tb, HIP_SYMBOL(st355_trace_buf), sizeof(tb)));
+      for (int w = 0; w < 2; w++) {
+        printf("    trace wave %d k-tile %d: start %+6lld  section cycles:", w * 4, TR_T0, (long long)(tb[w][0] - tb[0][0]));
+        for (int k = 1; k < TR_MARKS; k++) printf(" %5lld", (long long)(tb[w][k] - tb[w][k - 1]));
+        printf("   total %lld\n", (long long)(tb[w][TR_MARKS - 1] - tb[w][0]));
+      }
+#endif
+    }
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    if (A2) { CK(hipFree(A2)); CK(hipFree(B2)); }
+  };
+  if (const char* one = getenv("LAB_SHAPE")) {          // LAB_SHAPE=M,N,K : one timed shape only (for rocprofv3 --pmc runs)
+    Shape s = {0, 0, 0, 0};
+    sscanf(one, "%d,%d,%d", &s.M, &s.N, &s.K);
+    run(s, false);
+    return 0;
+  }
+  for (const Shape& s : check) run(s, true);
+  for (const Shape& s : perf) run(s, false);
+  return 0;
+}
