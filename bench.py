@@ -119,6 +119,7 @@ def main():
 
     lat = args.res // 8
     B = args.batch
+    torch.manual_seed(42 + rank)              # sigma sampling draws from the global device generator (examples' `seed: 42`)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     def make_batch():
         return {

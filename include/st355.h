@@ -141,7 +141,7 @@ int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const v
  * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
 int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias,
                    void* O, int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale);
-/* workspace bytes for st355_attn_bwd (holds delta [B,H,S] fp32 and dO^T [B,H,d,Sp] bf16) */
+/* workspace bytes for st355_attn_bwd (holds delta and a padded lse copy [B,H,Sp] fp32 and dO^T [B,H,d,Sp] bf16) */
 size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d);
 /* V is read token-major from the qkv buffer: V[b,pos,h,:] = v_base + ((b*S_rows + pos) * ld_v + h*d) ... see DESIGN.md.
  * v_rows: [B*S, >=H*d] token-major with row stride ld_v (joint order).  dV is written the same way (dv_rows, ld_dv).

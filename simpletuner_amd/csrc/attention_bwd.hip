@@ -8,6 +8,7 @@
 // registers into the next MFMA's B operand.  Operands whose contraction index is the token axis (Q^T, K^T, dO^T)
 // are read from pre-transposed head-major copies (written by the QKV epilogue kernel / prep), never transposed
 // in LDS.
+#include <stdlib.h>
 #include "attn_common.h"
 
 #define TPB 130
@@ -17,8 +18,8 @@
 // ------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ O, int64_t ld_o, const bf16* __restrict__ dO,
-                                                      int64_t ld_do, float* __restrict__ delta, bf16* __restrict__ dOt, int H, int S,
-                                                      int Sp) {
+                                                      int64_t ld_do, const float* __restrict__ lse2, float* __restrict__ delta,
+                                                      float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp) {
   constexpr int TPR = HD / 8;
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TPB];
@@ -38,7 +39,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
     for (int j = 0; j < 8; j++) s += bf2f(ov[j]) * bf2f(gv[j]);
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (valid && c == 0) delta[bh * S + t] = s;
+    if (c == 0) {   // stats are written in the padded [B*H, Sp] layout: padded queries get delta 0 and lse +inf (=> P = 0)
+      delta[bh * Sp + t] = valid ? s : 0.f;
+      lsep[bh * Sp + t] = valid ? lse2[bh * S + t] : INFINITY;
+    }
     if (!valid) {
 #pragma unroll
       for (int j = 0; j < 8; j++) gv[j] = f2bf(0.f);
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     }
   }
   const float lse_q = lse2[bh * S + qi];
-  const float delta_q = delta[bh * S + qi];
+  const float delta_q = delta[bh * (int64_t)Sp + qi];
 
   f32x16 acc[NDT];
 #pragma unroll
@@ -288,8 +292,8 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
     }
     if (tid < 64) {
       const int qq = qq0 + tid;
-      st_lse = (qq < S) ? lse2[bh * S + qq] : INFINITY;   // +inf -> P = exp2(-inf) = 0 for padded queries
-      st_delta = (qq < S) ? delta[bh * S + qq] : 0.f;
+      st_lse = (qq < S) ? lse2[bh * (int64_t)Sp + qq] : INFINITY;     // lse2 = the padded copy written by prep   // +inf -> P = exp2(-inf) = 0 for padded queries
+      st_delta = (qq < S) ? delta[bh * (int64_t)Sp + qq] : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -396,10 +400,204 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// dK/dV kernel, second generation: 8 waves x 32 keys (256 keys per workgroup, two waves per SIMD so one wave's softmax VALU and
+// LDS reads overlap the other's MFMAs), the four 16-KiB query-tile images (Q, dO row-major; Q^T, dO^T) and the 64 lse/delta
+// pairs arrive by LDS-DMA (global_load_lds, swizzle applied to the SOURCE address) into a double buffer: no staging VGPRs and no
+// ds_write pass (the first-generation kernel spent ~830 LDS cycles per tile on ds_write_b128 alone).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void a_glds16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void a_glds4(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+template <int HD>
+__global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                         const bf16* __restrict__ Qt, const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                         const bf16* __restrict__ dO, int64_t ld_do, const bf16* __restrict__ dOt,
+                                                         const float* __restrict__ lsep, const float* __restrict__ delta,
+                                                         const float* __restrict__ key_bias, bf16* __restrict__ dK,
+                                                         bf16* __restrict__ dVrows, int64_t ld_dv, int H, int S, int Sp, float scale,
+                                                         float scale2) {
+  constexpr int QROWB = HD * 2;
+  constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major)
+  constexpr int TT_BYTES = HD * 128;     // Q^T tile / dO^T tile (HD rows x 64 queries)
+  constexpr int STAT_BYTES = 2 * 64 * 4;
+  constexpr int BUF = 2 * QT_BYTES + 2 * TT_BYTES + STAT_BYTES;
+  constexpr int NKS = HD / 16, NDT = HD / 32;
+  constexpr int QPW = QT_BYTES / 1024 / 8;   // 1-KiB DMA pieces per wave per row-major tile (HD=128: 2)
+  constexpr int TPW = TT_BYTES / 1024 / 8;   // ... per transposed tile
+  constexpr int RPP = 1024 / QROWB;          // rows per piece of a row-major tile (HD=128: 4)
+  constexpr int CPR = QROWB / 16;            // 16-byte chunks per row (16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + head;
+  const int key = blockIdx.x * 256 + wv * 32 + l31;
+  const int keyi = min(key, S - 1);
+
+  const bf16* Qg = Q + bh * (int64_t)S * HD;
+  const bf16* Qtg = Qt + bh * (int64_t)HD * Sp;
+  const bf16* dOtg = dOt + bh * (int64_t)HD * Sp;
+  const bf16* dOg = dO + (int64_t)b * S * ld_do + (int64_t)head * HD;
+  const float* lse_g = lsep + bh * (int64_t)Sp;
+  const float* del_g = delta + bh * (int64_t)Sp;
+
+  bf16x8 kf[NKS], vf[NKS];
+  {
+    const bf16* krow = K + (bh * S + keyi) * (int64_t)HD + 8 * h;
+    const bf16* vrow = Vrows + ((int64_t)b * S + keyi) * ld_v + (int64_t)head * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      kf[ks] = *(const bf16x8*)(krow + 16 * ks);
+      vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
+    }
+  }
+  const float kb2 = key_bias ? key_bias[(int64_t)b * S + keyi] * LOG2E : 0.f;
+
+  f32x16 acc_dk[NDT], acc_dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_dk[dt][r] = 0.f; acc_dv[dt][r] = 0.f; }
+
+  // DMA sources are rebuilt per tile from the lane id (a handful of VALU ops per piece): nothing address-like stays live
+  // across the MFMA work, which needs every register it can get.
+  auto stage = [&](int qt, int buf) {
+    const int qq0 = qt * 64;
+    char* qs = smem + buf * BUF;
+    char* gs = qs + QT_BYTES;
+    char* qts = gs + QT_BYTES;
+    char* gts = qts + TT_BYTES;
+    char* stat = gts + TT_BYTES;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));     // everything below is re-derived from the lane id each tile (never spilled, never hoisted)
+#pragma unroll
+    for (int p = 0; p < QPW; p++) {
+      const int row = (wv * QPW + p) * RPP + ln / CPR;             // tile row = query
+      const int col = ((ln % CPR) ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7))) * 8;
+      const int qq = min(qq0 + row, S - 1);
+      a_glds16(Qg + (uint32_t)(qq * HD + col), qs + (wv * QPW + p) * 1024);
+      a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + (wv * QPW + p) * 1024);
+    }
+#pragma unroll
+    for (int p = 0; p < TPW; p++) {
+      const int row = (wv * TPW + p) * 8 + (ln >> 3);              // tile row = head channel
+      const uint32_t off = (uint32_t)(row * Sp + ((ln & 7) ^ ((row >> 1) & 7)) * 8 + qq0);
+      a_glds16(Qtg + off, qts + (wv * TPW + p) * 1024);
+      a_glds16(dOtg + off, gts + (wv * TPW + p) * 1024);
+    }
+    if (wv == 0) a_glds4(lse_g + qq0 + ln, stat);
+    if (wv == 1) a_glds4(del_g + qq0 + ln, stat + 256);
+  };
+
+  const int nqt = (S + 63) / 64;
+  // per-lane LDS read bases; every fragment address is base ^ (chunk_pair << 4) + an immediate (the XOR swizzles act on bit 0
+  // = lane half h, folded into the base, and on bits 1.. = the k-step, applied per read)
+  const int qrow_p = perm23(l31);
+  const int q_base0 = (HD == 128) ? qrow_p * 256 + ((h ^ (qrow_p & 15)) << 4) : qrow_p * 128 + ((h ^ ((qrow_p >> 1) & 7)) << 4);
+  const int t_base0 = QT_BYTES * 2 + l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
+  const int s_base0 = 2 * QT_BYTES + 2 * TT_BYTES + 32 * h;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int qt = 0; qt < nqt; qt++) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);      // the other buffer's last reads finished before the previous barrier
+    // laundered through an empty asm so that the address arithmetic below is NOT hoisted out of the loop into (spilled) registers
+    int q_base = q_base0 + buf * BUF, t_base = t_base0 + buf * BUF, s_base = s_base0 + buf * BUF;
+    asm volatile("" : "+v"(q_base), "+v"(t_base), "+v"(s_base));
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      // Register budget (<= 256 with two waves per SIMD): 128 dK/dV accumulators + 64 K/V fragments are fixed, so LDS fragments
+      // are consumed in pairs (sched_barrier pins the order; the partner wave on the SIMD covers the LDS latency).
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int k2 = 0; k2 < NKS; k2 += 2) {
+        const char* q0p = smem + (q_base ^ ((2 * k2) << 4)) + qb * 32 * QROWB;
+        const char* q1p = smem + (q_base ^ ((2 * k2 + 2) << 4)) + qb * 32 * QROWB;
+        bf16x8 qf0 = *(const bf16x8*)(q0p);
+        bf16x8 qf1 = *(const bf16x8*)(q1p);
+        bf16x8 gf0 = *(const bf16x8*)(q0p + QT_BYTES);
+        bf16x8 gf1 = *(const bf16x8*)(q1p + QT_BYTES);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf0, kf[k2], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf0, vf[k2], dpacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1, kf[k2 + 1], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf1, vf[k2 + 1], dpacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // accumulator register r <-> query 32qb + 16(r>>3) + 8h + (r&7): stats are contiguous 4-float runs
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+#pragma unroll
+        for (int q4 = 0; q4 < 2; q4++) {
+          const float* sp = (const float*)(smem + s_base) + 32 * qb + 16 * m + 4 * q4;
+          const f32x4 lse4 = *(const f32x4*)sp;
+          const f32x4 del4 = *(const f32x4*)(sp + 64);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int ri = 8 * m + 4 * q4 + r;
+            const float pr = fast_exp2(sacc[ri] * scale2 + kb2 - lse4[r]);
+            const float dsv = pr * (dpacc[ri] - del4[r]);
+            pf[m][4 * q4 + r] = f2bf(pr);
+            dsf[m][4 * q4 + r] = f2bf(dsv);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++) {
+        const char* t0p = smem + (t_base ^ ((4 * qb) << 4)) + dt * 4096;
+        const char* t1p = smem + (t_base ^ ((4 * qb + 2) << 4)) + dt * 4096;
+        bf16x8 qtf0 = *(const bf16x8*)(t0p);
+        bf16x8 gtf0 = *(const bf16x8*)(t0p + TT_BYTES);
+        bf16x8 qtf1 = *(const bf16x8*)(t1p);
+        bf16x8 gtf1 = *(const bf16x8*)(t1p + TT_BYTES);
+        acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf0, pf[0], acc_dv[dt], 0, 0, 0);
+        acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf0, dsf[0], acc_dk[dt], 0, 0, 0);
+        acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf1, pf[1], acc_dv[dt], 0, 0, 0);
+        acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf1, dsf[1], acc_dk[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // next tile landed (it was issued a whole tile of MFMA work ago) + every wave done reading this buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (key < S) {
+    bf16* krow = dK + (bh * S + key) * (int64_t)HD;
+    bf16* vrow = dVrows + ((int64_t)b * S + key) * ld_dv + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+          ok[bb] = f2bf(acc_dk[dt][4 * a + bb] * scale);
+          ov[bb] = f2bf(acc_dv[dt][4 * a + bb]);
+        }
+        *(bf16x4*)(krow + 32 * dt + 8 * a + 4 * h) = ok;
+        *(bf16x4*)(vrow + 32 * dt + 8 * a + 4 * h) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
-  return round256((size_t)B * H * S * sizeof(float)) + round256((size_t)B * H * d * Sp * 2);
+  return 2 * round256((size_t)B * H * Sp * sizeof(float)) + round256((size_t)B * H * d * Sp * 2);   // delta, lse (padded) + dO^T
 }
 
 extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
@@ -412,7 +610,10 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
   ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
   if (d != 128 && d != 64) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
   float* delta = (float*)workspace;
-  bf16* dOt = (bf16*)((char*)workspace + round256((size_t)B * H * S * sizeof(float)));
+  float* lsep = (float*)((char*)workspace + round256((size_t)B * H * Sp * sizeof(float)));
+  bf16* dOt = (bf16*)((char*)workspace + 2 * round256((size_t)B * H * Sp * sizeof(float)));
+  static int dkv_gen = -1;
+  if (dkv_gen < 0) { const char* e = getenv("ST355_ATTN_DKV"); dkv_gen = (e && e[0] == '1') ? 1 : 2; }   // A/B: 1 = first-generation kernel
   const float scale2 = scale * LOG2E;
   const double fl_unit = 2.0 * (double)B * H * (double)S * S * d;  // one S x S x d contraction
   hipStream_t st = (hipStream_t)stream;
@@ -421,29 +622,48 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
     ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
     dim3 grid(Sp / 64, H, B);
     if (d == 128)
-      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, delta, dOt, H, S, Sp);
+      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
     else
-      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, delta, dOt, H, S, Sp);
+      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
     if ((rc = st355_check_launch("attn_bwd_prep")) != 0) return rc;
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * S * d * 8.0);
-    dim3 grid((S + 127) / 128, H, B);
-    if (d == 128) {
-      const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv<128>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, lse2, (const float*)delta, key_bias,
-                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+    if (dkv_gen == 2) {
+      dim3 grid((S + 255) / 256, H, B);
+      if (d == 128) {
+        const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        hipLaunchKernelGGL(k_attn_bwd_dkv2<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
+                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+      } else {
+        const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        hipLaunchKernelGGL(k_attn_bwd_dkv2<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
+                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+      }
     } else {
-      const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, lse2, (const float*)delta, key_bias,
-                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
-    }
+      dim3 grid((S + 127) / 128, H, B);
+      if (d == 128) {
+        const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        hipLaunchKernelGGL(k_attn_bwd_dkv<128>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
+                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+      } else {
+        const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
+                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+      }
+  }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
   {
