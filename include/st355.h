@@ -98,6 +98,8 @@ typedef struct st355_gemm_args {
   void*       aux_out; int64_t ld_aux_out; /* EPI_GELU: optional pre-activation store [M,N] bf16       */
   const void* aux_in;  int64_t ld_aux_in;  /* EPI_GATE_RESIDUAL: residual; EPI_MUL_GELU_GRAD: pre-act    */
   const void* gate; int64_t gate_stride; int64_t rows_per_batch; /* EPI_GATE_RESIDUAL: gate[b*stride+n] */
+  void*       workspace; int64_t workspace_bytes; /* optional fp32 scratch (256-B aligned): lets thin problems (N <= 128, e.g. the
+                                                    LoRA down-projection x A^T) run split-K over all CUs; NULL => never split */
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two

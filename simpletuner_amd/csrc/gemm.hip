@@ -25,6 +25,7 @@
 #include "common.h"
 
 #define BK 64
+#define EPI_SPLITK 100        // internal: k_gemm_s2 writes fp32 K-slice slabs instead of C
 
 // Optional in-kernel timeline (tools/gemm_lab.hip builds this file with -DST355_TRACE): waves 0 and 4 of one workgroup stamp
 // s_memtime at the section boundaries of two k-steps; the stamps stay in SGPRs until the kernel ends.
@@ -60,6 +61,7 @@ struct GemmP {
   bf16* aux_out; int64_t ld_aux_out;
   const bf16* aux_in; int64_t ld_aux_in;
   const bf16* gate; int64_t gate_stride; int64_t rows_per_batch;
+  float* partial; int ksplit;          // split-K (k_gemm_s2 only): fp32 slabs [ksplit][M][N]
 };
 
 struct GemmGroup {
@@ -834,10 +836,15 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
   const int wm = wv >> 1, wn = wv & 1;
   const int nbm = (p.M + S2_BM - 1) / S2_BM, nbn = (p.N + S2_BN - 1) / S2_BN;
   int pm, pn;
-  tile_coords(xcd_remap(blockIdx.x, nbm * nbn), nbm, nbn, pm, pn);
+  // split-K: blockIdx.x = slice * tiles + tile; slice s owns K-tiles [s*per, min(nt1, (s+1)*per))  (no K2 segment when splitting)
+  const int tiles = nbm * nbn;
+  const int slice = (EPI == EPI_SPLITK) ? blockIdx.x / tiles : 0;
+  tile_coords(xcd_remap((EPI == EPI_SPLITK) ? blockIdx.x % tiles : blockIdx.x, tiles), nbm, nbn, pm, pn);
   const int m0 = pm * S2_BM, n0 = pn * S2_BN;
   const int nt1 = p.K / BK;
-  const int nt = nt1 + p.K2 / BK;
+  const int per = (EPI == EPI_SPLITK) ? (nt1 + p.ksplit - 1) / p.ksplit : 0;
+  const int t_first = (EPI == EPI_SPLITK) ? slice * per : 0;
+  const int nt = (EPI == EPI_SPLITK) ? min(nt1, t_first + per) : nt1 + p.K2 / BK;
   const int st_row = lane >> 3, st_cp = lane & 7;
   auto stage = [&](int t, int buf) {
     const bf16* Ap; const bf16* Bp; int64_t la, lb; int k0;
@@ -870,16 +877,55 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  stage(0, 0);
+  if (t_first < nt) stage(t_first, 0);
   __syncthreads();
-  for (int t = 0; t < nt; t++) {
-    const int buf = t & 1;
+  for (int t = t_first; t < nt; t++) {
+    const int buf = (t - t_first) & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const char* xs = smem + buf * S2_STAGE;
     mma_tile(xs, xs + S2_TILE, x_off, x_sw, w_off, w_sw, khalf, acc);
     __syncthreads();
   }
-  gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  if (EPI == EPI_SPLITK) {
+    // fp32 slab of this K slice: same lane -> (token, 4 consecutive features) map as gemm_epilogue, 16-byte stores
+    float* slab = p.partial + (int64_t)slice * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const int n = n0 + wn * 64 + i * 32 + 8 * a + 4 * khalf;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
+          *(f32x4*)(slab + (int64_t)m * p.N + n) = v;
+        }
+    }
+  } else {
+    gemm_epilogue<(EPI == EPI_SPLITK) ? ST355_EPI_NONE : EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  }
+}
+
+// fixed-order sum of the K-slice slabs (+ bias) -> bf16 C
+__global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ slabs, int ksplit, const bf16* __restrict__ bias,
+                                                      bf16* __restrict__ C, int64_t ldc, int M, int N) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread = 4 consecutive features
+  const int n4 = N / 4;
+  if (i4 >= (int64_t)M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 % n4) * 4;
+  f32x4 s = *(const f32x4*)(slabs + (int64_t)m * N + n);
+  for (int k = 1; k < ksplit; k++) {
+    const f32x4 v = *(const f32x4*)(slabs + ((int64_t)k * M + m) * N + n);
+    s += v;
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int b = 0; b < 4; b++) o[b] = f2bf(s[b] + (bias ? bf2f(bias[n + b]) : 0.f));
+  *(bf16x4*)(C + (int64_t)m * ldc + n) = o;
 }
 
 // =================================================================================================
@@ -915,6 +961,7 @@ static GemmP to_p(const st355_gemm_args* a) {
   p.aux_out = (bf16*)a->aux_out; p.ld_aux_out = a->ld_aux_out;
   p.aux_in = (const bf16*)a->aux_in; p.ld_aux_in = a->ld_aux_in;
   p.gate = (const bf16*)a->gate; p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch;
+  p.partial = nullptr; p.ksplit = 1;
   return p;
 }
 
@@ -1001,8 +1048,32 @@ static int launch_256(void* stream, const GemmGroup& g, int tiles) {
     default: return fn<ST355_EPI_ADD>(__VA_ARGS__);                                          \
   }
 
+static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int ksplit) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); attr_set = true; }
+  p.partial = (float*)a->workspace; p.ksplit = ksplit;
+  const int tiles = ((p.M + S2_BM - 1) / S2_BM) * ((p.N + S2_BN - 1) / S2_BN);
+  hipLaunchKernelGGL(k_gemm_s2<EPI_SPLITK>, dim3(tiles * ksplit), dim3(S2_THREADS), S2_LDS, (hipStream_t)stream, p);
+  int rc = st355_check_launch("gemm_s2_splitk");
+  if (rc) return rc;
+  const int64_t n4 = (int64_t)p.M * (p.N / 4);
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)p.partial, ksplit,
+                     p.bias, p.C, p.ldc, p.M, p.N);
+  return st355_check_launch("gemm_splitk_reduce");
+}
+
 static int run_one(void* stream, const st355_gemm_args* a) {
   GemmP p = to_p(a);
+  // thin problems (the LoRA rank-space projections: N <= 128, K in the thousands) stream A once and have only M/128 tiles: split
+  // K so that >= 2 workgroups per CU are in flight, partial sums through the caller's fp32 workspace (fixed-order reduce)
+  if (a->workspace && p.N <= S2_BN && p.K2 == 0 && a->epilogue == ST355_EPI_NONE && p.K >= 1024 && p.M >= 512) {
+    const int tiles = (p.M + S2_BM - 1) / S2_BM;
+    int ks = (512 + tiles - 1) / tiles;
+    const int nt1 = p.K / BK;
+    if (ks > nt1 / 4) ks = nt1 / 4;                       // >= 4 K-tiles per slice
+    if (ks > 16) ks = 16;
+    if (ks >= 2 && (int64_t)ks * p.M * p.N * 4 <= a->workspace_bytes && ((uintptr_t)a->workspace % 16) == 0) return launch_splitk(stream, p, a, ks);
+  }
   // the deep-pipelined schedule needs enough tiles to fill 256 CUs; tiny problems stay on the 128x128 schedule
   // 256x256 tiles only when they (nearly) fill the 256 CUs at one workgroup each
   if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256()) {

@@ -1,9 +1,12 @@
 // skinny.hip — rank-space LoRA gradients (K12 backward):  out[P, r] = alpha * sum_m L[m,P] * R[m,r]
 //   dB = s * dY^T (x A^T)      (L = dY [M,N],  R = T [M,r])
 //   dA^T = x^T (dY sB)         (L = x  [M,K],  R = U [M,r])
-// The contraction runs over the TOKEN axis, which is the slow axis of both operands, so MFMA would need
-// transposed operand images; r <= 64 makes this a bandwidth-class op (reads L once), done on the VALU from
-// LDS tiles with fp32 accumulation.  Deterministic: split-M partials + a fixed-order reduce.
+// The contraction runs over the TOKEN axis, which is the slow axis of both operands: the MFMA fragments (8 consecutive
+// tokens per lane) are gathered from the ROW-MAJOR LDS tiles by gfx950's transposing LDS read (ds_read_b64_tr_b16: in a 16-lane
+// group, lane 4i+s points at 4 contiguous bf16 of tile row i and lane j receives column j of the 4x16 block), so nothing is
+// transposed in memory.  r <= 64 makes this a bandwidth-class op (reads L once).  Deterministic: split-M partials + a
+// fixed-order reduce.  (k_skinny_tn is the first-generation fp32-VALU version, kept for A/B: ST355_SKINNY=1.)
+#include <stdlib.h>
 #include "common.h"
 
 #define SK_PT 128   // columns of L per workgroup
@@ -79,6 +82,100 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 lds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+// LDS pitches = 64 B (mod 256 B): the four tile rows a 32-lane half touches sit in four disjoint 16-bank windows
+#define SK_LP (SK_PT + 32)      // 160 elements = 320 B
+template <int RN>
+__global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
+                                                       float* __restrict__ ws, int64_t M, int64_t P) {
+  constexpr int RT = RN / 32;                  // 32-wide r blocks
+  constexpr int RP = (RN == 32) ? 32 : 96;     // R tile pitch in elements (64 B / 192 B)
+  __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS * SK_LP];
+  __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS * RP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
+  const int64_t mbase = (int64_t)blockIdx.y * SK_MC;
+  f32x16 acc[RT];
+#pragma unroll
+  for (int j = 0; j < RT; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  // transposing-read geometry: group g = lane>>4, i = (lane>>2)&3 (tile row within the 4-row block), s = lane&3 (4-column segment)
+  const int g = lane >> 4, ti = (lane >> 2) & 3, tsg = lane & 3;
+  const int row_l = 8 * (g >> 1) + ti;                                   // + 16*ks + 4*rd
+  const int a_col = 32 * wv + 16 * (g & 1) + 4 * tsg;                    // this wave's 32 columns of the L tile
+  const int b_col = 16 * (g & 1) + 4 * tsg;                              // + 32*j
+
+  bf16x8 lreg[2], rreg;
+  auto load = [&](int ms) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int id = k * 256 + tid;
+      const int row = id >> 4, c = id & 15;
+      const int64_t m = mbase + ms + row;
+      if (m < M && p0 + c * 8 < P) lreg[k] = *(const bf16x8*)(L + m * ldl + p0 + c * 8);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) lreg[k][j] = f2bf(0.f);
+      }
+    }
+    if (tid < SK_MS * RN / 8) {
+      const int row = tid / (RN / 8), c = tid % (RN / 8);
+      const int64_t m = mbase + ms + row;
+      if (m < M) rreg = *(const bf16x8*)(R + m * ldr + c * 8);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) rreg[j] = f2bf(0.f);
+      }
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int id = k * 256 + tid;
+      *(bf16x8*)(&Ls[(id >> 4) * SK_LP + (id & 15) * 8]) = lreg[k];
+    }
+    if (tid < SK_MS * RN / 8) *(bf16x8*)(&Rs[(tid / (RN / 8)) * RP + (tid % (RN / 8)) * 8]) = rreg;
+  };
+  load(0);
+  for (int ms = 0; ms < SK_MC; ms += SK_MS) {
+    store();
+    __syncthreads();
+    if (ms + SK_MS < SK_MC) load(ms + SK_MS);          // next sub-tile's global loads fly under the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < SK_MS / 16; ks++) {
+      const bf16* lp = &Ls[(16 * ks + row_l) * SK_LP + a_col];
+      const s16x4 a0 = lds_tr16(lp), a1 = lds_tr16(lp + 4 * SK_LP);
+      bf16x8 af;
+      *(s16x4*)&af = a0;
+      *((s16x4*)&af + 1) = a1;
+#pragma unroll
+      for (int j = 0; j < RT; j++) {
+        const bf16* rp = &Rs[(16 * ks + row_l) * RP + b_col + 32 * j];
+        const s16x4 b0 = lds_tr16(rp), b1 = lds_tr16(rp + 4 * RP);
+        bf16x8 bfr;
+        *(s16x4*)&bfr = b0;
+        *((s16x4*)&bfr + 1) = b1;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D[i = p][j = r]: lane -> r = lane&31, register reg -> p = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* w = ws + ((int64_t)blockIdx.y * P) * RN;
+#pragma unroll
+  for (int j = 0; j < RT; j++)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int64_t pp = p0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (pp < P) w[pp * RN + 32 * j + (lane & 31)] = acc[j][reg];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_skinny_reduce(const float* __restrict__ ws, float* __restrict__ out, int64_t so_p, int64_t so_r,
                                                       int64_t P, int RN, int r_used, int nchunks, float alpha, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,7 +200,15 @@ extern "C" int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const v
   const int nchunks = (int)cdiv64(M, SK_MC);
   ProfScope ps(stream, ST355_K_SKINNY, 2.0 * M * P * Rn, 2.0 * M * (P + Rn) + 8.0 * nchunks * P * Rn);
   dim3 grid((unsigned)cdiv64(P, SK_PT), nchunks);
-  if (Rn == 32)
+  static int gen = -1;
+  if (gen < 0) { const char* e = getenv("ST355_SKINNY"); gen = (e && e[0] == '1') ? 1 : 2; }
+  if (gen == 2 && Rn == 32)
+    hipLaunchKernelGGL(k_skinny_tn_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
+                       (float*)workspace, M, P);
+  else if (gen == 2)
+    hipLaunchKernelGGL(k_skinny_tn_mfma<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
+                       (float*)workspace, M, P);
+  else if (Rn == 32)
     hipLaunchKernelGGL(k_skinny_tn<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
                        (float*)workspace, M, P);
   else

@@ -57,6 +57,7 @@ class GemmArgs(C.Structure):
         ("aux_out", C.c_void_p), ("ld_aux_out", C.c_int64),
         ("aux_in", C.c_void_p), ("ld_aux_in", C.c_int64),
         ("gate", C.c_void_p), ("gate_stride", C.c_int64), ("rows_per_batch", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

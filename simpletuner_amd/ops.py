@@ -152,6 +152,19 @@ def scale_cols(x, gate, rows_per_batch: int, out=None):
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+_gemm_ws = {}
+_GEMM_WS_BYTES = 64 << 20
+
+
+def _gemm_workspace(dev):
+    """caller-owned fp32 scratch for the split-K path of thin GEMMs (libst355 never allocates)"""
+    ws = _gemm_ws.get(dev.index)
+    if ws is None:
+        ws = torch.empty(_GEMM_WS_BYTES // 4, dtype=F32, device=dev)
+        _gemm_ws[dev.index] = ws
+    return ws
+
+
 def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
                gate=None, rows_per_batch: int = 0):
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
@@ -178,6 +191,9 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
             raise _l.St355Error("gemm: bias must be contiguous")
         g.bias = _ptr(bias)
     g.epilogue = epilogue
+    if N <= 128 and M >= 1024:
+        ws = _gemm_workspace(a.device)
+        g.workspace, g.workspace_bytes = _ptr(ws), ws.numel() * 4
     if aux_out is not None:
         _chk(aux_out, BF16, "aux_out")
         g.aux_out, g.ld_aux_out = _ptr(aux_out), _rows(aux_out, "aux_out")

@@ -150,7 +150,8 @@ def test_timestep_proj_silu_add_scale(ops):
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 256), (1, 3072, 256), (4608, 3072, 3072), (512, 64, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 256), (1, 3072, 256), (4608, 3072, 3072), (512, 64, 3072),
+                                   (4608, 128, 9216), (2000, 96, 3072), (4096, 64, 3072)])   # last three: split-K (thin N) path
 def test_gemm_plain(ops, M, N, K):
     torch.manual_seed(10)
     a = torch.randn(M, K, device=dev()).to(BF16)
