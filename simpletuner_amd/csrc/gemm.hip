@@ -143,6 +143,96 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
   }
 }
 
+// ---- coalesced epilogue for the 256x256 schedules (wave tile 128 tokens x 64 features) ----
+// The accumulator layout gives a lane 4 consecutive features of ONE token: direct stores touch 32 rows x 16 B per instruction and
+// the L2 has to merge eight instructions into each 128-byte line (rocprofv3 WRITE_SIZE showed 2-2.4x the algorithmic bytes on the
+// two-output GELU epilogue).  Here the wave transposes through its own slice of the (now idle) LDS ring in two 64-token passes,
+// fp32, so that 8 consecutive lanes own one token's 64 features: bias / residual / pre-activation reads and all stores are whole
+// 128-byte lines, and the epilogue arithmetic is still done once in fp32 before the single rounding to bf16.
+#define EPL_PITCH 272                         // bytes per staged token row: 64 fp32 + 16 B pad (bank spread for the b128 writes)
+#define EPL_WAVE (64 * EPL_PITCH)             // 17 KiB per wave
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;          // read side: 8 lanes per token row, 8 features each
+  const int n = nw0 + rc * 8;
+  const bool n_ok = n < p.N;
+  float bias8[8];
+#pragma unroll
+  for (int b = 0; b < 8; b++) bias8[b] = 0.f;
+  if (p.bias && n_ok) {
+    const bf16x8 bv = *(const bf16x8*)(p.bias + n);
+#pragma unroll
+    for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
+  }
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+    // write: token row jj*32 + l31, features i*32 + 8a + 4khalf .. +4
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+    // read back token-major (same wave: LDS operations of one wave complete in order)
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      if (m >= p.M || !n_ok) continue;
+      float v[8];
+#pragma unroll
+      for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
+      if (EPI == ST355_EPI_GELU) {
+        if (p.aux_out) {
+          bf16x8 pre;
+#pragma unroll
+          for (int b = 0; b < 8; b++) pre[b] = f2bf(v[b]);
+          *(bf16x8*)(p.aux_out + (int64_t)m * p.ld_aux_out + n) = pre;
+#pragma unroll
+          for (int b = 0; b < 8; b++) v[b] = bf2f(pre[b]);   // activation of the stored (rounded) pre-activation
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = gelu_tanh(v[b]);
+      } else if (EPI == ST355_EPI_GATE_RESIDUAL) {
+        const int64_t bidx = (int64_t)(m / p.rows_per_batch);
+        const bf16x8 gv = *(const bf16x8*)(p.gate + bidx * p.gate_stride + n);
+        const bf16x8 rv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = bf2f(rv[b]) + bf2f(gv[b]) * v[b];
+      } else if (EPI == ST355_EPI_ADD) {
+        const bf16x8 rv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] += bf2f(rv[b]);
+      } else if (EPI == ST355_EPI_MUL_GELU_GRAD) {
+        const bf16x8 hv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] *= gelu_tanh_grad(bf2f(hv[b]));
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int b = 0; b < 8; b++) o[b] = f2bf(v[b]);
+      *(bf16x8*)(p.C + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+// the coalesced path needs 16-byte alignment of every row it touches with bf16x8 accesses
+__device__ __forceinline__ bool epl_aligned(const GemmP& p) {
+  bool ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
+  if (p.bias) ok = ok && (((uintptr_t)p.bias & 15) == 0);
+  if (p.aux_out) ok = ok && (p.ld_aux_out % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0);
+  if (p.aux_in) ok = ok && (p.ld_aux_in % 8 == 0) && (((uintptr_t)p.aux_in & 15) == 0);
+  if (p.gate) ok = ok && (p.gate_stride % 8 == 0) && (((uintptr_t)p.gate & 15) == 0);
+  return ok;
+}
+
 // one K=64 tile of MFMA work for a wave: 4 k-steps x (2 W frags + 2 X frags -> 4 MFMAs)
 __device__ __forceinline__ void mma_tile(const char* xs, const char* ws, const int (&x_off)[2], const int (&x_sw)[2],
                                          const int (&w_off)[2], const int (&w_sw)[2], int khalf, f32x16 (&acc)[2][2]) {
@@ -613,7 +703,7 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmGroup g) {
 #define PQ_THREADS 512
 #define PQ_REGION 16384
 #define PQ_BUF (4 * PQ_REGION)              // 64 KiB: [XA][XB][WA][WB]
-#define PQ_LDS (2 * PQ_BUF)                 // 128 KiB
+#define PQ_LDS (8 * 64 * 272)              // 136 KiB: two 64-KiB K-tile buffers; the epilogue transpose uses 8 x 17 KiB
 #ifndef PQ_PRIO
 #define PQ_PRIO 1                           // raise the wave priority around the MFMA clusters (T5)
 #endif
@@ -814,7 +904,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #undef PQ_MMA
   TR_FLUSH(wv, lane);
   if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
-  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  // every wave is past its last ring read and no LDS-DMA is in flight: the ring is free for the epilogue transpose
+  if (epl_aligned(p)) gemm_epilogue_lds<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  else gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // =================================================================================================

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>      e.g. r01b
+# 1) rocprofv3 --kernel-trace --stats of the default bench command        -> gpurun_out/prof_<tag>/stats_*.csv
+# 2) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no other tracing) -> gpurun_out/prof_<tag>/pmc_*.csv
+# then tools/profile_summarise.py turns them into profiles/<tag>_kernel_stats.csv and profiles/<tag>_hbm_traffic.json
+tag=${1:-r01b}
+export TMPDIR=/tmp
+R=$PWD
+out=$R/gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $out/bench_pmc_$c.log 2>&1
+done
+cd $R
+python tools/profile_summarise.py $out $tag
