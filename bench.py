@@ -55,6 +55,8 @@ def hbm_traffic_per_gemm_launch():
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="flux", choices=["flux", "sd3"],
+                    help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -112,22 +114,40 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path for the product")
+    if os.environ.get("ST355_BENCH_SHARE_GPU") == "1":     # plumbing test only: all ranks on cuda:0 over gloo (a 1-GPU box cannot run RCCL)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL over xGMI on ROCm
+        if os.environ.get("ST355_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL over xGMI on ROCm
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from simpletuner_amd import ops
-    from simpletuner_amd.flux.model import Flux
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
-    cfg = default_config(lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3)
+    cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3)
     acc = St355Accelerator(dev)
-    plugin = Flux(cfg, acc)
-    plugin.load_model(num_layers=args.layers, num_single_layers=args.single_layers, guidance_embeds=True)
+    if args.model == "flux":
+        from simpletuner_amd.flux.model import Flux
+        plugin = Flux(cfg, acc)
+        plugin.load_model(num_layers=args.layers, num_single_layers=args.single_layers, guidance_embeds=True)
+        n_blocks, D_model, S_txt, txt_dim, pooled_dim = args.layers + args.single_layers, 3072, 512, 4096, 768
+        desc = (f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
+                f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights")
+    else:
+        from simpletuner_amd.sd3.model import SD3
+        plugin = SD3(cfg, acc)
+        n_l = 24 if args.layers == 19 else args.layers          # SD3-Medium: 24 joint blocks, 24 x 64 heads
+        plugin.load_model(sample_size=128, num_layers=n_l, num_attention_heads=24, attention_head_dim=64, caption_projection_dim=1536,
+                          pooled_projection_dim=2048, pos_embed_max_size=192)
+        n_blocks, D_model, S_txt, txt_dim, pooled_dim = n_l, 1536, 231, 4096, 2048
+        desc = (f"SD3-Medium MMDiT ({n_l} joint blocks, D=1536, 24x64 heads) LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0, "
+                f"{args.res}^2 (S=4096+231), AdamW, random-init weights")
     plugin.add_lora_adapter()
     trainer = Trainer(cfg, plugin, acc)
 
@@ -138,8 +158,8 @@ def main():
     def make_batch():
         return {
             "latent_batch": torch.randn(B, 16, lat, lat, device=dev, generator=gen).to(torch.bfloat16),
-            "prompt_embeds": torch.randn(B, 512, 4096, device=dev, generator=gen).to(torch.bfloat16),
-            "add_text_embeds": torch.randn(B, 768, device=dev, generator=gen).to(torch.bfloat16),
+            "prompt_embeds": torch.randn(B, S_txt, txt_dim, device=dev, generator=gen).to(torch.bfloat16),
+            "add_text_embeds": torch.randn(B, pooled_dim, device=dev, generator=gen).to(torch.bfloat16),
         }
     batches = [make_batch() for _ in range(2)]   # resident in HBM before the timed region
 
@@ -172,8 +192,8 @@ def main():
     loss_val = float(loss.item())
 
     if rank == 0:
-        S_img, S_txt = (lat // 2) ** 2, 512
-        step_flops = train_flops_per_image(args.layers + args.single_layers, 3072, S_img + S_txt) * B
+        S_img = (lat // 2) ** 2
+        step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         roof = None
@@ -193,12 +213,11 @@ def main():
                            "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
                        for k, v in prof.items() if v["launches"]}
         out = {
-            "metric": "training images/sec (whole node), Flux.1-dev LoRA r32 1024^2 train step",
+            "metric": f"training images/sec (whole node), {'Flux.1-dev' if args.model == 'flux' else 'SD3-Medium'} LoRA r{args.rank} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
-                                   f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights",
+            "config": {"workload": desc,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "step_model_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -207,7 +226,7 @@ def main():
             "kernels": kernels,
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "flux":
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
     if world > 1:

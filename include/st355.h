@@ -74,6 +74,10 @@ int st355_mse_loss(void* stream, const void* pred, const void* target, const flo
 int st355_flux_pack(void* stream, const void* latents /*[B,C,H,W]*/, void* packed /*[B,(H/2)(W/2),4C]*/,
                     int B, int C, int H, int W);
 int st355_flux_unpack(void* stream, const void* packed, void* latents, int B, int C, int H, int W);
+/* general 2x2 (un)patchify.  order 0: feature = c*4+dh*2+dw (Flux pack == PatchEmbed Conv2d(k=2,s=2) im2col in weight.flatten(1)
+ * order); order 1: feature = (dh*2+dw)*C + c (the "nhwpqc->nchpwq" unpatchify of SD3 / PixArt, sd3/transformer.py:879-902). */
+int st355_patchify(void* stream, const void* latents, void* packed, int B, int C, int H, int W, int order);
+int st355_unpatchify(void* stream, const void* packed, void* latents, int B, int C, int H, int W, int order);
 
 /* ---- K4 helpers: sinusoidal timestep projection (flip_sin_to_cos, shift 0), SiLU, add -------- */
 int st355_timestep_proj(void* stream, const float* t /*[B]*/, void* out /*[B,dim] bf16*/, int B, int dim,

@@ -198,9 +198,11 @@ extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target
 
 // ---- K3: Flux pack / unpack -------------------------------------------------------------------------
 // packed[b, h2*W2 + w2, c*4 + dh*2 + dw] = lat[b, c, 2*h2 + dh, 2*w2 + dw]
-template <bool PACK>
-__global__ void __launch_bounds__(EW_THREADS) k_flux_pack(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int C,
-                                                         int H, int W) {
+template <bool PACK, int ORDER>
+__global__ void __launch_bounds__(EW_THREADS) k_patchify(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int C,
+                                                        int H, int W) {
+  // 2x2 patches.  ORDER 0: feature = c*4 + dh*2 + dw  (Flux pack_latents == Conv2d(k=2,s=2) im2col, weight.flatten(1) order)
+  //               ORDER 1: feature = (dh*2 + dw)*C + c (the "nhwpqc->nchpwq" unpatchify of SD3 / PixArt, sd3/transformer.py:879-902)
   const int64_t total = (int64_t)B * C * H * W;
   const int H2 = H >> 1, W2 = W >> 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -210,27 +212,39 @@ __global__ void __launch_bounds__(EW_THREADS) k_flux_pack(const bf16* __restrict
     const int w2 = (int)(r % W2); r /= W2;
     const int h2 = (int)(r % H2); r /= H2;
     const int b = (int)r;
-    const int c = ch4 >> 2, dh = (ch4 >> 1) & 1, dw = ch4 & 1;
+    int c, dh, dw;
+    if (ORDER == 0) { c = ch4 >> 2; dh = (ch4 >> 1) & 1; dw = ch4 & 1; }
+    else { c = ch4 % C; dh = (ch4 / C) >> 1; dw = (ch4 / C) & 1; }
     const int64_t li = (((int64_t)b * C + c) * H + (2 * h2 + dh)) * W + (2 * w2 + dw);
     if (PACK) dst[i] = src[li];
     else dst[li] = src[i];
   }
 }
-extern "C" int st355_flux_pack(void* stream, const void* latents, void* packed, int B, int C, int H, int W) {
-  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0), "flux_pack: bad args");
+extern "C" int st355_patchify(void* stream, const void* latents, void* packed, int B, int C, int H, int W, int order) {
+  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0) && (order == 0 || order == 1), "patchify: bad args");
   const int64_t n = (int64_t)B * C * H * W;
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 4.0 * n);
-  hipLaunchKernelGGL(k_flux_pack<true>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)latents,
-                     (bf16*)packed, B, C, H, W);
-  return st355_check_launch("flux_pack");
+  if (order == 0)
+    hipLaunchKernelGGL((k_patchify<true, 0>), dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)latents, (bf16*)packed, B, C, H, W);
+  else
+    hipLaunchKernelGGL((k_patchify<true, 1>), dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)latents, (bf16*)packed, B, C, H, W);
+  return st355_check_launch("patchify");
+}
+extern "C" int st355_unpatchify(void* stream, const void* packed, void* latents, int B, int C, int H, int W, int order) {
+  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0) && (order == 0 || order == 1), "unpatchify: bad args");
+  const int64_t n = (int64_t)B * C * H * W;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 4.0 * n);
+  if (order == 0)
+    hipLaunchKernelGGL((k_patchify<false, 0>), dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)packed, (bf16*)latents, B, C, H, W);
+  else
+    hipLaunchKernelGGL((k_patchify<false, 1>), dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)packed, (bf16*)latents, B, C, H, W);
+  return st355_check_launch("unpatchify");
+}
+extern "C" int st355_flux_pack(void* stream, const void* latents, void* packed, int B, int C, int H, int W) {
+  return st355_patchify(stream, latents, packed, B, C, H, W, 0);
 }
 extern "C" int st355_flux_unpack(void* stream, const void* packed, void* latents, int B, int C, int H, int W) {
-  ST_REQUIRE(latents && packed && (H % 2 == 0) && (W % 2 == 0), "flux_unpack: bad args");
-  const int64_t n = (int64_t)B * C * H * W;
-  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0, 4.0 * n);
-  hipLaunchKernelGGL(k_flux_pack<false>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)packed,
-                     (bf16*)latents, B, C, H, W);
-  return st355_check_launch("flux_unpack");
+  return st355_unpatchify(stream, packed, latents, B, C, H, W, 0);
 }
 
 // ---- K4 helpers ------------------------------------------------------------------------------------

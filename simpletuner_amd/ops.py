@@ -110,6 +110,27 @@ def flux_unpack(packed, Cc: int, H: int, W: int):
     return out
 
 
+def patchify(latents, order: int = 0):
+    """[B,C,H,W] -> [B,(H/2)(W/2),4C]; order 0 = (c,dh,dw) features (Flux pack / PatchEmbed im2col), 1 = (dh,dw,c) (SD3/PixArt)"""
+    L = _l.load()
+    _chk(latents, BF16, "latents")
+    latents = latents.contiguous()
+    B, Cc, H, W = latents.shape
+    out = torch.empty(B, (H // 2) * (W // 2), Cc * 4, dtype=BF16, device=latents.device)
+    _l.check(L.st355_patchify(_stream(), _ptr(latents), _ptr(out), B, Cc, H, W, order), "patchify")
+    return out
+
+
+def unpatchify(packed, Cc: int, H: int, W: int, order: int = 0):
+    L = _l.load()
+    _chk(packed, BF16, "packed")
+    packed = packed.contiguous()
+    B = packed.shape[0]
+    out = torch.empty(B, Cc, H, W, dtype=BF16, device=packed.device)
+    _l.check(L.st355_unpatchify(_stream(), _ptr(packed), _ptr(out), B, Cc, H, W, order), "unpatchify")
+    return out
+
+
 def timestep_proj(t, dim: int, scale: float = 1.0):
     L = _l.load()
     _chk(t, F32, "t")

@@ -1,0 +1,500 @@
+"""SD3Transformer2DModel — the MI355X-native trained component for the SD3 MMDiT (joint transformer blocks).
+
+Mirrors the reference's module surface (simpletuner/helpers/models/sd3/transformer.py:244-911): same constructor arguments,
+`forward(hidden_states[B,16,H,W], encoder_hidden_states, pooled_projections, timestep (0..1000), return_dict)` contract, the
+diffusers state-dict keys (`pos_embed.proj.weight` stays the Conv2d [D,C,p,p] tensor; `pos_embed.pos_embed` the sincos buffer),
+`.config`, `.parameters()`.  Forward and the hand-written backward are sequences of libst355 launches — the same kernels as
+the Flux double block at D = 1536 / head_dim 64:
+  * PatchEmbed = 2x2 patchify (im2col order) + ONE GEMM whose epilogue adds bias and the centre-cropped position table;
+  * joint attention over [sample || context] (sd3 order, `JointAttnProcessor2_0`), no RoPE (identity tables), optional q/k RMSNorm;
+  * the last block is `context_pre_only`: its context stream only feeds K/V/Q (AdaLayerNormContinuous, chunk order scale,shift);
+  * every AdaLN modulation linear of all blocks (+norm_out) is one matrix -> one skinny GEMM per step;
+  * unpatchify "nhwpqc->nchpwq" is the order-1 permute kernel.
+Frozen-base (LoRA) training only for now: the full fine-tune of BASELINE.json configs[3] needs the TN weight-gradient GEMM
+(DESIGN.md §7).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..flux.transformer import LoraGroup, _attach, _frozen
+from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def sincos_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scale: float = 1.0) -> torch.Tensor:
+    """diffusers get_2d_sincos_pos_embed: [grid_size^2, embed_dim] fp32 (w axis first, sin then cos per axis)"""
+    ar = torch.arange(grid_size, dtype=torch.float32) / (grid_size / base_size) / interpolation_scale
+    gw = ar[None, :].expand(grid_size, grid_size).reshape(-1).double()      # meshgrid(grid_w, grid_h): w varies fastest
+    gh = ar[:, None].expand(grid_size, grid_size).reshape(-1).double()
+
+    def one_d(dim, pos):
+        omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+        out = pos[:, None] * omega[None, :]
+        return torch.cat([out.sin(), out.cos()], dim=1)
+
+    return torch.cat([one_d(embed_dim // 2, gw), one_d(embed_dim // 2, gh)], dim=1).float()
+
+
+class SD3Transformer2DModel(nn.Module):
+    def __init__(self, sample_size: int = 128, patch_size: int = 2, in_channels: int = 16, num_layers: int = 18,
+                 attention_head_dim: int = 64, num_attention_heads: int = 18, joint_attention_dim: int = 4096,
+                 caption_projection_dim: int = 1152, pooled_projection_dim: int = 2048, out_channels: int = 16,
+                 pos_embed_max_size: int = 96, dual_attention_layers: Tuple[int, ...] = (), qk_norm: Optional[str] = None,
+                 device=None, **_ignored):
+        super().__init__()
+        if patch_size != 2:
+            raise ValueError("patch_size must be 2 (the patchify kernels are 2x2)")
+        if tuple(dual_attention_layers):
+            raise NotImplementedError("SD3.5 dual attention layers are not built on the st355 path yet")
+        if attention_head_dim not in (64, 128):
+            raise ValueError("attention_head_dim must be 64 or 128 (kernels built for these)")
+        if qk_norm not in (None, "rms_norm"):
+            raise ValueError("qk_norm must be None or 'rms_norm'")
+        self.H, self.hd = num_attention_heads, attention_head_dim
+        self.D = D = self.H * self.hd
+        self.inner_dim = D
+        if caption_projection_dim != D:
+            raise ValueError("caption_projection_dim must equal num_attention_heads * attention_head_dim")
+        self.config = SimpleNamespace(sample_size=sample_size, patch_size=patch_size, in_channels=in_channels, num_layers=num_layers,
+                                      attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
+                                      joint_attention_dim=joint_attention_dim, caption_projection_dim=caption_projection_dim,
+                                      pooled_projection_dim=pooled_projection_dim, out_channels=out_channels,
+                                      pos_embed_max_size=pos_embed_max_size, dual_attention_layers=(), qk_norm=qk_norm)
+        self.out_channels = out_channels
+        if D % 64 or joint_attention_dim % 64 or pooled_projection_dim % 64 or (4 * in_channels) % 64:
+            raise ValueError("all contraction dims must be multiples of 64")
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = self.device_
+        e = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+
+        def lin(name, out_f, in_f):
+            w, b = e(out_f, in_f), e(out_f)
+            _attach(self, name + ".weight", _frozen(w)); _attach(self, name + ".bias", _frozen(b))
+            return SimpleNamespace(w=w, b=b, wT=None, lora=None)
+
+        # PatchEmbed: the Conv2d weight keeps its checkpoint shape; the GEMM reads it as [D, C*p*p]
+        conv_w, conv_b = e(D, in_channels, 2, 2), e(D)
+        _attach(self, "pos_embed.proj.weight", _frozen(conv_w)); _attach(self, "pos_embed.proj.bias", _frozen(conv_b))
+        self.l_patch = SimpleNamespace(w=conv_w.view(D, 4 * in_channels), b=conv_b)
+        if not hasattr(self, "pos_embed"):
+            raise RuntimeError("pos_embed holder missing")
+        self.pos_embed.register_buffer("pos_embed", torch.zeros(1, pos_embed_max_size * pos_embed_max_size, D, dtype=F32, device=dev))
+        self.l_t1 = lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+        self.l_t2 = lin("time_text_embed.timestep_embedder.linear_2", D, D)
+        self.l_p1 = lin("time_text_embed.text_embedder.linear_1", D, pooled_projection_dim)
+        self.l_p2 = lin("time_text_embed.text_embedder.linear_2", D, D)
+        self.l_ctx = lin("context_embedder", D, joint_attention_dim)
+
+        self.mod_total = (num_layers * 12 - 4 + 2) * D          # last block: norm1_context is AdaLayerNormContinuous (2D)
+        self.mod_w, self.mod_b = e(self.mod_total, D), e(self.mod_total)
+        off = 0
+
+        def mod_slice(name, n):
+            nonlocal off
+            _attach(self, name + ".weight", _frozen(self.mod_w[off:off + n])); _attach(self, name + ".bias", _frozen(self.mod_b[off:off + n]))
+            o = off
+            off += n
+            return o
+
+        def fused(prefix, names, out_each, in_f):
+            n = len(names)
+            w, b = e(n * out_each, in_f), e(n * out_each)
+            for j, nm in enumerate(names):
+                _attach(self, f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
+                _attach(self, f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
+            return SimpleNamespace(w=w, b=b, wT=None, lora=None)
+
+        def normw(name):
+            if qk_norm is None:
+                return None
+            w = torch.ones(self.hd, dtype=BF16, device=dev)
+            _attach(self, name + ".weight", _frozen(w))
+            return w
+
+        self.blocks: List[SimpleNamespace] = []
+        for i in range(num_layers):
+            p = f"transformer_blocks.{i}."
+            blk = SimpleNamespace(last=(i == num_layers - 1))
+            blk.mod_off = mod_slice(p + "norm1.linear", 6 * D)
+            blk.mod_off_c = mod_slice(p + "norm1_context.linear", (2 if blk.last else 6) * D)
+            blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
+            blk.add_qkv = fused(p + "attn.", ["add_q_proj", "add_k_proj", "add_v_proj"], D, D)
+            blk.to_out = fused(p + "attn.", ["to_out.0"], D, D)
+            blk.to_add_out = None if blk.last else fused(p + "attn.", ["to_add_out"], D, D)
+            blk.norm_q, blk.norm_k = normw(p + "attn.norm_q"), normw(p + "attn.norm_k")
+            blk.norm_added_q, blk.norm_added_k = normw(p + "attn.norm_added_q"), normw(p + "attn.norm_added_k")
+            blk.ff1 = fused(p, ["ff.net.0.proj"], 4 * D, D)
+            blk.ff2 = fused(p, ["ff.net.2"], D, 4 * D)
+            blk.ffc1 = None if blk.last else fused(p, ["ff_context.net.0.proj"], 4 * D, D)
+            blk.ffc2 = None if blk.last else fused(p, ["ff_context.net.2"], D, 4 * D)
+            self.blocks.append(blk)
+        self.mod_off_out = mod_slice("norm_out.linear", 2 * D)
+        assert off == self.mod_total
+        self.l_out = lin("proj_out", 4 * out_channels, D)
+
+        self.lora_groups: List[LoraGroup] = []
+        self.lora_flat: Optional[torch.Tensor] = None
+        self.lora_grad_flat: Optional[torch.Tensor] = None
+        self._lora_params: List[nn.Parameter] = []
+        self._cache: Dict = {}
+        self._prepared = False
+        self.accumulate_lora_grads = False
+        self.gradient_checkpointing = False
+        self.grad_sync = None
+        self._last_grad_flat = None
+
+    # ------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load_flat_state(self, state: Dict[str, torch.Tensor]):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state and ".lora_" not in k]
+        if missing:
+            raise KeyError(f"missing weights: {missing[:5]} ... ({len(missing)})")
+        for k, v in state.items():
+            if k in own:
+                own[k].data.copy_(v.to(device=own[k].device, dtype=own[k].dtype))
+        if "pos_embed.pos_embed" in state:
+            self.pos_embed.pos_embed.copy_(state["pos_embed.pos_embed"].to(self.device_, F32))
+        self._prepared = False
+        self._cache.clear()
+
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 42):
+        g = torch.Generator(device=self.device_).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if ".lora_" in name:
+                continue
+            if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+                p.data.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=self.device_))
+            elif name.endswith(".bias"):
+                p.data.copy_(0.02 * torch.randn(p.shape, generator=g, device=self.device_))
+            else:
+                fan_in = p[0].numel()
+                p.data.copy_(torch.randn(p.shape, generator=g, device=self.device_, dtype=BF16) * (1.0 / math.sqrt(fan_in)))
+        c = self.config
+        self.pos_embed.pos_embed.copy_(sincos_2d(self.D, c.pos_embed_max_size, c.sample_size // c.patch_size)[None].to(self.device_))
+        self._prepared = False
+        self._cache.clear()
+
+    @torch.no_grad()
+    def prepare_for_training(self):
+        """K-major transposed copies for the dgrad GEMMs (frozen base => built once)"""
+        for blk in self.blocks:
+            for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2):
+                if l is not None:
+                    l.wT = l.w.t().contiguous()
+        self.l_out.wT = self.l_out.w.t().contiguous()
+        self._prepared = True
+
+    # ------------------------------------------------------------------------------------------------
+    # LoRA (peft naming), sd3/model.py:122 DEFAULT_LORA_TARGET = to_k,to_q,to_v,to_out.0
+    # ------------------------------------------------------------------------------------------------
+    def add_lora_adapter(self, rank: int = 32, alpha: Optional[float] = None, targets: str = "default", seed: int = 7, init_b_std: float = 0.0):
+        alpha = float(rank if alpha is None else alpha)
+        D, dev = self.D, self.device_
+        plan = []
+        self.lora_groups = []
+
+        def group(lin, prefix, names, K):
+            g = LoraGroup(K, lin.w.shape[0], [(prefix + n, j * (lin.w.shape[0] // len(names)), lin.w.shape[0] // len(names))
+                                              for j, n in enumerate(names)], rank, alpha, dev)
+            lin.lora = g
+            self.lora_groups.append(g)
+            for (name, n_off, N) in g.targets:
+                plan.append((g, name, N, K))
+
+        for i, blk in enumerate(self.blocks):
+            p = f"transformer_blocks.{i}.attn."
+            group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
+            group(blk.to_out, p, ["to_out.0"], D)
+            if targets == "all":
+                group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
+                if blk.to_add_out is not None:
+                    group(blk.to_add_out, p, ["to_add_out"], D)
+        total = sum(rank * K + N * rank for (_, _, N, K) in plan)
+        total = (total + 7) // 8 * 8
+        self.lora_flat = torch.zeros(total, dtype=F32, device=dev)
+        self.lora_grad_flat = torch.zeros(total, dtype=F32, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        off = 0
+        self._lora_params = []
+        for (g, name, N, K) in plan:
+            if not g.A:
+                g.flat_lo = off
+            a = self.lora_flat[off:off + rank * K].view(rank, K); ga = self.lora_grad_flat[off:off + rank * K].view(rank, K)
+            off += rank * K
+            b = self.lora_flat[off:off + N * rank].view(N, rank); gb = self.lora_grad_flat[off:off + N * rank].view(N, rank)
+            off += N * rank
+            bound = 1.0 / math.sqrt(K)
+            a.copy_((torch.rand(rank, K, generator=gen, device=dev) * 2 - 1) * bound)
+            if init_b_std > 0:
+                b.copy_(torch.randn(N, rank, generator=gen, device=dev) * init_b_std)
+            pa, pb = nn.Parameter(a), nn.Parameter(b)
+            _attach(self, name + ".lora_A.default.weight", pa); _attach(self, name + ".lora_B.default.weight", pb)
+            g.A.append(pa.data); g.B.append(pb.data); g.gA.append(ga); g.gB.append(gb)
+            g.flat_hi = off
+            self._lora_params += [pa, pb]
+        return self._lora_params
+
+    def trainable_parameters(self):
+        return list(self._lora_params)
+
+    # ------------------------------------------------------------------------------------------------
+    def _tables(self, h: int, w: int, S: int, B: int):
+        """cropped position table expanded over the batch ([B*h*w, D] bf16) and identity RoPE tables (SD3 has no RoPE)"""
+        key = (h, w, S, B)
+        hit = self._cache.get(key)
+        if hit is None:
+            mx = self.config.pos_embed_max_size
+            if h > mx or w > mx:
+                raise ValueError(f"latent grid {h}x{w} exceeds pos_embed_max_size {mx}")
+            top, left = (mx - h) // 2, (mx - w) // 2
+            pos = self.pos_embed.pos_embed[0].view(mx, mx, self.D)[top:top + h, left:left + w].reshape(h * w, self.D).to(BF16)
+            pos = pos[None].expand(B, -1, -1).reshape(B * h * w, self.D).contiguous()
+            cos = torch.ones(S, self.hd, dtype=F32, device=self.device_); sin = torch.zeros(S, self.hd, dtype=F32, device=self.device_)
+            hit = (pos, cos, sin)
+            self._cache[key] = hit
+        return hit
+
+    def _engine_forward(self, latents, enc, pooled, timestep, save: bool):
+        D, H, hd = self.D, self.H, self.hd
+        B, C, Hh, Ww = latents.shape
+        h, w = Hh // 2, Ww // 2
+        Si, St = h * w, enc.shape[1]
+        S = Si + St
+        Sp = (S + 63) // 64 * 64
+        dev = self.device_
+        for g in self.lora_groups:
+            g.pack()
+        pos, cos, sin = self._tables(h, w, S, B)
+        # ---- embeddings (sd3/transformer.py:623-700) ----
+        img = ops.gemm(ops.patchify(latents, order=0).view(B * Si, 4 * C), self.l_patch.w, bias=self.l_patch.b, epilogue=EPI_ADD, aux_in=pos)
+        txt = ops.gemm(enc.reshape(B * St, -1).contiguous(), self.l_ctx.w, bias=self.l_ctx.b)
+        t32 = timestep.to(device=dev, dtype=F32).contiguous()
+        temb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(t32, 256, 1.0), self.l_t1.w, bias=self.l_t1.b)), self.l_t2.w, bias=self.l_t2.b)
+        pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
+        temb = ops.add(temb, pemb)
+        mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)
+        ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, blocks=[], C=C, Hh=Hh, Ww=Ww)
+        scale = 1.0 / math.sqrt(hd)
+        for blk in self.blocks:
+            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
+            n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+            if blk.last:
+                mt = mod[:, blk.mod_off_c:blk.mod_off_c + 2 * D]
+                n_txt = ops.ln_modulate_fwd(txt, mt[:, :D], mt[:, D:2 * D], St)          # AdaLayerNormContinuous: (scale, shift)
+            else:
+                mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+                n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
+            qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
+            T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
+            probs = []
+            for b in range(B):
+                kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+                kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
+                probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S:b * S + Si], **kw_i))
+                probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S + Si:(b + 1) * S], **kw_t))
+            ops.gemm_grouped(probs)
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+            mk = torch.zeros if Sp > S else torch.empty
+            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, 0, S, Sp)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, Si, S, Sp)
+            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
+            del Vt
+            x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
+            x1_txt = None if blk.last else torch.empty(B * St, D, dtype=BF16, device=dev)
+            T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
+            T_ao = (torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev)
+                    if (not blk.last and blk.to_add_out.lora is not None) else None)
+            probs = []
+            for b in range(B):
+                O_i, O_t = O[b * S:b * S + Si], O[b * S + Si:(b + 1) * S]
+                kw_i, kw_t = {}, {}
+                if T_o is not None:
+                    ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
+                    kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
+                probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
+                                  aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
+                if not blk.last:
+                    if T_ao is not None:
+                        ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
+                        kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
+                    probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St],
+                                      epilogue=EPI_GATE_RESIDUAL, aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D],
+                                      rows_per_batch=St, **kw_t))
+            ops.gemm_grouped(probs)
+            n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
+            hpre_txt = x2_txt = None
+            if blk.last:
+                h_i = ops.gemm(n2_i, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
+                x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si)
+            else:
+                n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
+                hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
+                h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
+                                             dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
+                x2_img, x2_txt = ops.gemm_grouped([
+                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
+                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+            if save:
+                ctx.blocks.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
+                                                  Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
+                                                  hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
+            img, txt = x2_img, x2_txt
+        # ---- output head: AdaLayerNormContinuous (scale, shift), proj_out, unpatchify "nhwpqc->nchpwq" ----
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        n_out = ops.ln_modulate_fwd(img, mo[:, :D], mo[:, D:2 * D], Si)
+        out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
+        if save:
+            ctx.x_img_final = img
+        return ops.unpatchify(out.view(B, Si, -1), self.out_channels, Hh, Ww, order=1), ctx
+
+    def _engine_backward(self, ctx, dout):
+        if not self._prepared:
+            raise RuntimeError("call prepare_for_training() after loading weights (builds the K-major dgrad operands)")
+        D, H, hd = self.D, self.H, self.hd
+        B, Si, St, S, Sp, mod, cos, sin = ctx.B, ctx.Si, ctx.St, ctx.S, ctx.Sp, ctx.mod, ctx.cos, ctx.sin
+        dev = self.device_
+        scale = 1.0 / math.sqrt(hd)
+        dpk = ops.patchify(dout.to(BF16).contiguous(), order=1).view(B * Si, -1)
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        dn = ops.gemm(dpk, self.l_out.wT)
+        d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
+        d_txt = None
+        del dn, dpk
+        for li in range(len(self.blocks) - 1, -1, -1):
+            blk, sv = self.blocks[li], ctx.blocks[li]
+            ctx.blocks[li] = None
+            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
+            mt = mod[:, blk.mod_off_c:blk.mod_off_c + (2 if blk.last else 6) * D]
+            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)
+            if blk.last:
+                dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
+                dn2_i = ops.gemm(dh_i, blk.ff1.wT)
+                dx1_t = dx1g_t = None
+            else:
+                g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+                dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
+                                               dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
+                dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+                dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
+                del g_t, dh_t, dn2_t
+            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+            del g_i, dh_i, dn2_i
+            # attention output projections -> dO rows of both streams (+ adapter grads); a context_pre_only block has no txt rows
+            dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
+            U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
+            U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if (not blk.last and blk.to_add_out.lora is not None) else None
+            probs = []
+            for b in range(B):
+                kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
+                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S:b * S + Si], **kw_i))
+                if not blk.last:
+                    kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
+                    probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S + Si:(b + 1) * S], **kw_t))
+            ops.gemm_grouped(probs)
+            pairs = [(blk.to_out, U_i, sv.T_o, dx1g_i, 0, Si)]
+            if not blk.last:
+                pairs.append((blk.to_add_out, U_t, sv.T_ao, dx1g_t, Si, St))
+            for (lin, U, T_, dxg, lo, rows) in pairs:
+                if lin.lora is not None:
+                    O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
+                    lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+            del dx1g_i, dx1g_t, U_i, U_t
+            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
+            ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, 0, S)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, Si, S)
+            del dQ, dK, dO
+            first = li == 0
+            if B == 1:
+                dq_i, dq_t = dqkv[:Si], dqkv[Si:]
+            else:
+                dq_i = dqkv.view(B, S, 3 * D)[:, :Si].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, Si:].reshape(B * St, 3 * D)
+            streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
+            if first:
+                streams = [s_ for s_ in streams if s_[1].lora is not None]     # frozen embedders: only adapter grads remain
+            probs, Us = [], {}
+            for (name, lin, dq, n_in, T_) in streams:
+                kw = {}
+                if lin.lora is not None:
+                    Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
+                    kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
+                if not first:
+                    probs.append(dict(a=dq, w=lin.wT, **kw))
+            dns = ops.gemm_grouped(probs) if probs else []
+            for (name, lin, dq, n_in, T_) in streams:
+                if lin.lora is not None:
+                    lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
+            if not first:
+                d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+                c_scale = mt[:, :D] if blk.last else mt[:, D:2 * D]
+                d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, c_scale, St, dres=dx1_t)
+            del dqkv, sv, dns
+        return None
+
+    # ------------------------------------------------------------------------------------------------
+    # public forward (reference signature: sd3/transformer.py:560-575)
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, block_controlnet_hidden_states=None,
+                joint_attention_kwargs=None, return_dict: bool = True, **unsupported):
+        if block_controlnet_hidden_states is not None:
+            raise NotImplementedError("SD3 ControlNet residuals are not wired to the st355 path yet")
+        for k, v in unsupported.items():
+            if v is not None and v is not False:
+                raise NotImplementedError(f"SD3Transformer2DModel(st355): argument {k!r} is not supported on the HIP path")
+        if timestep.ndim != 1:
+            raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
+        need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
+        if need_grad:
+            out = _SD3Fn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, *self._lora_params)
+        else:
+            with torch.no_grad():
+                out, _ = self._engine_forward(hidden_states.to(BF16), encoder_hidden_states.to(BF16), pooled_projections, timestep, save=False)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+
+class _SD3Fn(torch.autograd.Function):
+    """one autograd node for the whole network (see flux/transformer.py::_FluxFn)"""
+
+    @staticmethod
+    def forward(fctx, model, latents, enc, pooled, timestep, *lora_params):
+        out, ctx = model._engine_forward(latents.detach().to(BF16), enc.detach().to(BF16), pooled.detach(), timestep.detach(), save=True)
+        fctx.model, fctx.ectx = model, ctx
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
+        model._engine_backward(fctx.ectx, dout)
+        fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_scale_from_sync = model.grad_sync.finish()
+        gflat = model.lora_grad_flat.clone()
+        model._last_grad_flat = gflat
+        grads, off = [], 0
+        for p in model._lora_params:
+            n = p.numel()
+            grads.append(gflat[off:off + n].view_as(p))
+            off += n
+        return (None,) * 5 + tuple(grads)
