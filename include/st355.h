@@ -168,6 +168,16 @@ int st355_adamw_ema_step(void* stream, float* p, const float* g, float* m, float
 int st355_adamw_ema_step_bf16(void* stream, void* p, const void* g, float* m, float* v, void* ema,
                               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int64_t step, float grad_scale, float ema_decay);
+/* AdamWBF16.step — the reference examples' default optimizer (optimizers/adamw_bfloat16/__init__.py:55-180, stochastic/__init__.py:
+ * 47-124): p, exp_avg, exp_avg_sq and the compensation buffer `shift` are all bf16 arenas of n elements; one fused pass (18 B/param).
+ * seg_end/seg_decay (device arrays, nseg entries): exclusive end offset of every parameter tensor inside the arena and the weight decay
+ * the host schedule releases for it THIS step (0 unless its owed decay crossed 5e-3).  rand_bits: optional int32 [4][n] stochastic-
+ * rounding draws in [0,65536) in the reference's order (exp_avg, shift, p, shift) — parity tests inject the reference's own draws;
+ * NULL => counter-based Philox4x32-10 (seed, offset).  Hyper-parameters are doubles: they are narrowed exactly where ATen narrows them. */
+int st355_adamw_bf16_sr_step(void* stream, void* p, const void* g, void* exp_avg, void* exp_avg_sq, void* shift, int64_t n,
+                             int64_t step, double lr, double beta1, double beta2, double eps, const int64_t* seg_end,
+                             const float* seg_decay, int nseg, const int32_t* rand_bits, uint64_t seed, uint64_t offset,
+                             float grad_scale);
 /* standalone EMA: s -= (1-decay) (s - p)   (ema.py:423); fp32 or bf16 by elem_bytes in {4,2} */
 int st355_ema_update(void* stream, void* shadow, const void* param, int64_t n, float decay, int elem_bytes);
 /* K15: sum of squares (fp32 out[0]) and max-abs (out[1]) of a flat gradient; out zeroed by the call */

@@ -71,3 +71,57 @@ def ema_get_decay(optimization_step, decay, min_decay=0.0, update_after_step=0, 
 def ema_update(shadow, param, decay):
     """ema.py:423: s -= (1 - d) (s - p)"""
     return shadow - (1 - decay) * (shadow - param)
+
+
+# ------------------------------------------------------------------------------------------------
+# AdamWBF16 — the examples' default optimizer (all-bf16 state, stochastic rounding, compensated summation)
+# ------------------------------------------------------------------------------------------------
+def stochastic_round_bf16(x_f32: torch.Tensor, rand16: torch.Tensor) -> torch.Tensor:
+    """copy_stochastic_ (optimizers/adamw_bfloat16/stochastic/__init__.py:47-72): add a random 16-bit integer to the fp32 bit pattern,
+    clear the low 16 bits, keep the high half as bf16.  `rand16` int32 in [0, 65536)."""
+    bits = (x_f32.contiguous().view(torch.int32) + rand16.to(torch.int32)) & -65536
+    return bits.view(torch.float32).to(torch.bfloat16)
+
+
+def adamw_bf16_decay_schedule(accumulated_decay: float, weight_decay: float, lr: float, threshold: float = 5e-3):
+    """optimizers/adamw_bfloat16/__init__.py:92-95: the decay is only APPLIED once the owed amount exceeds the threshold.
+    Returns (decay_this_iteration, new_accumulated_decay)."""
+    acc = accumulated_decay + weight_decay * lr
+    dec = acc if acc > threshold else 0.0
+    return dec, acc - dec
+
+
+def adamw_bf16_step(p, g, m, v, shift, step: int, lr: float, beta1: float, beta2: float, eps: float, decay_this_iteration: float, draws,
+                    decay_alpha: str = "fp32"):
+    """_make_step (optimizers/adamw_bfloat16/__init__.py:113-180) with the four stochastic-rounding draws injected.  All state bf16.
+    Note the reference's add_stochastic_(input, other, alpha) computes  other + alpha * input  (stochastic/__init__.py:90-101), so the
+    first moment is  SR(g + (1 - beta1) * (beta1 * m))  — restated as is.  Every intermediate that the reference materialises in bf16 is
+    rounded to bf16 here (RNE), every fp32 temporary stays fp32.
+    decay_alpha: how the scalar of `shift.add_(p, alpha=-decay)` (a plain bf16 add) is held.  "fp32" = opmath scalar, what ATen's GPU
+    kernels do (and what libst355 does); "aten_cpu" = what ATen's CPU kernel did when the golden fixture was generated: the vectorised
+    body (32-element chunks) holds alpha as bf16 and computes in fp32, the scalar tail (n % 32 elements) also rounds the product
+    to bf16 — quirks of the host library, reproduced only so that the fixture pins this restatement bit for bit."""
+    bf, f = torch.bfloat16, torch.float32
+    m1 = (m.to(f) * beta1).to(bf)                                        # exp_avg.mul_(beta1)
+    m_new = stochastic_round_bf16(g.to(f) + (1 - beta1) * m1.to(f), draws[0])   # add_stochastic_(exp_avg, grad, alpha=1-beta1)
+    v1 = (v.to(f) * beta2).to(bf)                                        # exp_avg_sq.mul_(beta2)
+    v_new = torch.addcmul(v1.to(f), g.to(f), g.to(f), value=1 - beta2).to(bf)   # .addcmul_(grad, grad, value=1-beta2)
+    denom = (v_new.to(f).sqrt().to(bf).to(f) + eps).to(bf)               # exp_avg_sq.sqrt().add_(eps)
+    dc = (1 - beta2 ** step) ** 0.5
+    res = torch.addcdiv(shift.to(f), m_new.to(f), denom.to(f), value=-lr * dc)   # addcdiv_stochastic_(shift, exp_avg, denom, value)
+    shift1 = stochastic_round_bf16(res, draws[1])
+    p_new = stochastic_round_bf16(shift1.to(f) + p.to(f), draws[2])      # add_stochastic_(p, shift)
+    err = (p.to(f) - p_new.to(f)).to(bf)                                 # buffer.sub_(p)  (bf16)
+    shift2 = stochastic_round_bf16(err.to(f) + shift1.to(f), draws[3])   # add_stochastic_(shift, buffer - p)
+    if decay_this_iteration > 0:                                          # shift.add_(p, alpha=-decay)  (plain bf16 add)
+        a32 = torch.tensor(-decay_this_iteration, dtype=f)
+        if decay_alpha == "aten_cpu":
+            abf = a32.to(bf).to(f)                                        # the CPU kernel holds alpha as a bf16 scalar
+            n = shift2.numel()
+            body = (shift2.to(f) + abf * p_new.to(f)).to(bf).flatten()   # 32-wide vector body: fp32 arithmetic on the widened lanes
+            t0 = n - n % 32                                              # scalar tail: c10::BFloat16 arithmetic, the product is rounded too
+            body[t0:] = (shift2.flatten()[t0:].to(f) + (abf * p_new.flatten()[t0:].to(f)).to(bf).to(f)).to(bf)
+            shift2 = body.view(shift2.shape)
+        else:
+            shift2 = (shift2.to(f) + a32 * p_new.to(f)).to(bf)
+    return p_new, m_new, v_new, shift2

@@ -50,6 +50,26 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
 }
 
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = c[i];
+}
 // XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b%8): gives each XCD a
 // contiguous chunk of the logical grid so neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

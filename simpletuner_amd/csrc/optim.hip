@@ -1,6 +1,7 @@
 // optim.hip — K15/K16/K17: one-pass fused AdamW (+EMA) over a flat parameter arena, standalone EMA,
 // gradient norm, and the LoRA operand packer.  All HBM-streaming: 16-byte accesses, one read and one write
 // of every state word per step (22-28 B/param depending on layout).
+#include <math.h>
 #include "common.h"
 
 #define OP_THREADS 256
@@ -125,6 +126,123 @@ extern "C" int st355_adamw_ema_step_bf16(void* stream, void* p, const void* g, f
   hipLaunchKernelGGL(k_adamw_bf16, dim3(op_blocks(n / 8)), dim3(OP_THREADS), 0, (hipStream_t)stream, (bf16*)p, (const bf16*)g, m, v,
                      (bf16*)ema, n, c);
   return st355_check_launch("adamw_ema_step_bf16");
+}
+
+// ---- K16b: AdamWBF16 — the reference examples' default optimizer ------------------------------------------------------------
+// optimizers/adamw_bfloat16/__init__.py:55-180 (+ stochastic/__init__.py:47-124): parameter, both moments and a compensation buffer
+// ("shift": what should have been added to p but was lost to bf16 truncation) are ALL bf16; the first moment, the shift and the
+// parameter are updated with stochastic rounding (a random 16-bit integer added to the fp32 bit pattern before truncation); weight
+// decay is owed per tensor and applied to `shift` only once it exceeds 5e-3.  The reference runs ~25 small kernels per parameter
+// tensor with fp32 temporaries; here it is ONE pass over a flat arena: 5 bf16 reads + 4 bf16 writes = 18 B/param.
+// Every operation below keeps the reference's order and rounding points (no FMA contraction: the fp32 temporaries of the reference
+// are separate multiply / add / divide results), so that with the same random draws the states are bit-identical.
+struct Bf16OptC {
+  float beta1, one_m_beta1, beta2, one_m_beta2, eps, value /* -lr * sqrt(1 - beta2^step) */, grad_scale;
+};
+
+__device__ __forceinline__ bf16 sr_bf16(float x, uint32_t r16) {           // copy_stochastic_
+  const uint32_t bits = (__float_as_uint(x) + r16) & 0xFFFF0000u;
+  return __builtin_bit_cast(bf16, (uint16_t)(bits >> 16));
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void adamw_bf16_one(bf16& p, bf16 g_in, bf16& m, bf16& v, bf16& sh, const Bf16OptC& c, float decay,
+                                               const uint32_t (&r)[4]) {
+  float g = bf2f(g_in);
+  if (c.grad_scale != 1.f) g = bf2f(f2bf(g * c.grad_scale));              // a scaled gradient is a bf16 tensor in the reference too
+  const bf16 m1 = f2bf(bf2f(m) * c.beta1);                                // exp_avg.mul_(beta1)
+  const bf16 m_new = sr_bf16(g + c.one_m_beta1 * bf2f(m1), r[0]);         // add_stochastic_(exp_avg, grad, alpha): other + alpha*input (sic)
+  const bf16 v1 = f2bf(bf2f(v) * c.beta2);                                // exp_avg_sq.mul_(beta2)
+  const bf16 v_new = f2bf(bf2f(v1) + (c.one_m_beta2 * g) * g);            // .addcmul_(grad, grad, value=1-beta2)
+  const bf16 denom = f2bf(bf2f(f2bf(sqrtf(bf2f(v_new)))) + c.eps);        // exp_avg_sq.sqrt().add_(eps)
+  const bf16 sh1 = sr_bf16(bf2f(sh) + (c.value * bf2f(m_new)) / bf2f(denom), r[1]);   // addcdiv_stochastic_(shift, exp_avg, denom, value)
+  const bf16 p_new = sr_bf16(bf2f(sh1) + bf2f(p), r[2]);                  // add_stochastic_(p, shift)
+  const bf16 err = f2bf(bf2f(p) - bf2f(p_new));                           // buffer.sub_(p)
+  bf16 sh2 = sr_bf16(bf2f(err) + bf2f(sh1), r[3]);                        // add_stochastic_(shift, buffer - p)
+  if (decay > 0.f) sh2 = f2bf(bf2f(sh2) + (-decay) * bf2f(p_new));        // shift.add_(p, alpha=-decay): opmath (fp32) alpha, as ATen's GPU kernels
+  p = p_new; m = m_new; v = v_new; sh = sh2;
+}
+
+// seg_end[nseg]: exclusive end offsets of the parameter tensors inside the arena; seg_decay[nseg]: this step's decay per tensor
+__device__ __forceinline__ int seg_of(const int64_t* seg_end, int nseg, int64_t i) {
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (i < seg_end[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(OP_THREADS) k_adamw_bf16_sr(bf16* __restrict__ p, const bf16* __restrict__ g, bf16* __restrict__ m,
+                                                             bf16* __restrict__ v, bf16* __restrict__ sh, int64_t n, Bf16OptC c,
+                                                             const int64_t* __restrict__ seg_end, const float* __restrict__ seg_decay,
+                                                             int nseg, const int32_t* __restrict__ rand_bits, uint64_t seed,
+                                                             uint64_t offset) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = i * 8;
+    bf16x8 pb = *(bf16x8*)(p + e0), gb = *(const bf16x8*)(g + e0), mb = *(bf16x8*)(m + e0), vb = *(bf16x8*)(v + e0), sb = *(bf16x8*)(sh + e0);
+    int s0 = 0, s1 = 0;
+    if (nseg > 1) { s0 = seg_of(seg_end, nseg, e0); s1 = (e0 + 7 < seg_end[s0]) ? s0 : seg_of(seg_end, nseg, e0 + 7); }
+    const float d0 = nseg > 0 ? seg_decay[s0] : 0.f;
+    uint32_t rr[4][8];
+    if (rand_bits) {                                     // injected draws (parity tests): rand_bits[k*n + e], values in [0, 65536)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) rr[k][j] = (uint32_t)rand_bits[(int64_t)k * n + e0 + j];
+    } else {                                             // 32 sixteen-bit draws from 4 Philox4x32-10 blocks (counter = group index)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t o[4];
+        philox4x32_10(4 * (uint64_t)i + k + offset, seed, o);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { rr[k][2 * q] = o[q] & 0xFFFFu; rr[k][2 * q + 1] = o[q] >> 16; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float d = d0;
+      if (s1 != s0) d = seg_decay[seg_of(seg_end, nseg, e0 + j)];
+      const uint32_t r4[4] = {rr[0][j], rr[1][j], rr[2][j], rr[3][j]};
+      bf16 pj = pb[j], mj = mb[j], vj = vb[j], sj = sb[j];
+      adamw_bf16_one(pj, gb[j], mj, vj, sj, c, d, r4);
+      pb[j] = pj; mb[j] = mj; vb[j] = vj; sb[j] = sj;
+    }
+    *(bf16x8*)(p + e0) = pb; *(bf16x8*)(m + e0) = mb; *(bf16x8*)(v + e0) = vb; *(bf16x8*)(sh + e0) = sb;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {      // tail elements
+    const int64_t e = (nv << 3) + threadIdx.x;
+    const float d = nseg > 0 ? seg_decay[seg_of(seg_end, nseg, e)] : 0.f;
+    uint32_t r4[4];
+    if (rand_bits) {
+      for (int k = 0; k < 4; k++) r4[k] = (uint32_t)rand_bits[(int64_t)k * n + e];
+    } else {
+      uint32_t o[4];
+      philox4x32_10(4 * (uint64_t)nv + 4 * (uint64_t)threadIdx.x + offset, seed ^ 0x9E3779B97F4A7C15ull, o);
+      for (int k = 0; k < 4; k++) r4[k] = o[k] & 0xFFFFu;
+    }
+    bf16 pj = p[e], mj = m[e], vj = v[e], sj = sh[e];
+    adamw_bf16_one(pj, g[e], mj, vj, sj, c, d, r4);
+    p[e] = pj; m[e] = mj; v[e] = vj; sh[e] = sj;
+  }
+}
+#pragma clang fp contract(fast)
+
+extern "C" int st355_adamw_bf16_sr_step(void* stream, void* p, const void* g, void* m, void* v, void* shift, int64_t n, int64_t step,
+                                        double lr, double beta1, double beta2, double eps, const int64_t* seg_end, const float* seg_decay,
+                                        int nseg, const int32_t* rand_bits, uint64_t seed, uint64_t offset, float grad_scale) {
+  ST_REQUIRE(p && g && m && v && shift && n > 0 && step >= 1, "adamw_bf16_sr_step: bad args");
+  ST_REQUIRE(nseg == 0 || (seg_end && seg_decay), "adamw_bf16_sr_step: segment tables missing");
+  ST_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)shift % 16 == 0),
+             "adamw_bf16_sr_step: arena must be 16-byte aligned");
+  ProfScope ps(stream, ST355_K_OPTIM, 20.0 * n, 18.0 * n);
+  Bf16OptC c;          // the double -> float conversions happen where ATen converts its Python scalars
+  c.beta1 = (float)beta1; c.one_m_beta1 = (float)(1.0 - beta1); c.beta2 = (float)beta2; c.one_m_beta2 = (float)(1.0 - beta2);
+  c.eps = (float)eps; c.value = (float)(-lr * sqrt(1.0 - pow(beta2, (double)step))); c.grad_scale = grad_scale;
+  hipLaunchKernelGGL(k_adamw_bf16_sr, dim3(op_blocks(n / 8 + 1)), dim3(OP_THREADS), 0, (hipStream_t)stream, (bf16*)p, (const bf16*)g,
+                     (bf16*)m, (bf16*)v, (bf16*)shift, n, c, seg_end, seg_decay, nseg, rand_bits, seed, offset);
+  return st355_check_launch("adamw_bf16_sr_step");
 }
 
 // s -= (1-d) (s - p)      (ema.py:423: torch._foreach_sub_(s, torch._foreach_sub(s, p), alpha=1-d))

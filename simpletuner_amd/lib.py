@@ -24,7 +24,7 @@ SYMBOLS = [
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd",
     "st355_attn_fwd", "st355_attn_bwd_workspace", "st355_attn_bwd",
-    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_ema_update", "st355_grad_norm",
+    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm",
     "st355_lora_pack",
 ]
 
@@ -100,6 +100,8 @@ def _declare(lib):
                                       i32, i32, i32, i32, i32, f32, vp]),
         "st355_adamw_ema_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, f32]),
         "st355_adamw_ema_step_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, f32]),
+        "st355_adamw_bf16_sr_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, i32,
+                                               vp, u64, u64, f32]),
         "st355_ema_update": (C.c_int, [vp, vp, vp, i64, f32, i32]),
         "st355_grad_norm": (C.c_int, [vp, vp, i64, i32, vp]),
         "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),

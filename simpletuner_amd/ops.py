@@ -32,6 +32,11 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise _l.St355Error(f"{name}: expected dtype {dtype}, got {t.dtype}")
 
 
+def _dev(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _l.St355Error(f"{name}: expected a device tensor (the train step has no CPU path)")
+
+
 def _rows(t: torch.Tensor, name: str) -> int:
     """leading dimension (elements) of a 2-D row-major view"""
     if t.dim() != 2 or t.stride(1) != 1:
@@ -399,6 +404,31 @@ def lora_pack(A, Bm, scale: float, A_cat, A_cat_T, B_blk, B_blk_T, k2_off: int =
             raise _l.St355Error("lora_pack: packed operands must be contiguous")
     _l.check(L.st355_lora_pack(_stream(), _ptr(A.contiguous()), _ptr(Bm.contiguous()), r, K, N, scale, _ptr(A_cat), _ptr(A_cat_T),
                                _ptr(B_blk), _ptr(B_blk_T), K2, k2_off, N_total, n_off), "lora_pack")
+
+
+def adamw_bf16_sr_step(p, g, m, v, shift, step: int, lr: float, beta1: float, beta2: float, eps: float, seg_end=None, seg_decay=None,
+                       rand_bits=None, seed: int = 0, offset: int = 0, grad_scale: float = 1.0):
+    """AdamWBF16.step over flat bf16 arenas (p, exp_avg, exp_avg_sq, shift updated in place).  seg_end int64 / seg_decay fp32 device
+    arrays describe the parameter tensors inside the arena and the decay released for each this step; rand_bits int32 [4, n] injects the
+    stochastic-rounding draws (tests), else in-kernel Philox."""
+    L = _l.load()
+    for t, nm in ((p, "p"), (g, "g"), (m, "exp_avg"), (v, "exp_avg_sq"), (shift, "shift")):
+        _chk(t, BF16, nm)
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise _l.St355Error(f"adamw_bf16_sr_step: {nm} must be a contiguous arena of the same length")
+    nseg = 0
+    if seg_end is not None:
+        if seg_end.dtype != torch.int64 or seg_decay.dtype != F32 or seg_end.numel() != seg_decay.numel():
+            raise _l.St355Error("adamw_bf16_sr_step: seg_end must be int64 and seg_decay fp32, same length")
+        _dev(seg_end, "seg_end"); _dev(seg_decay, "seg_decay")
+        nseg = seg_end.numel()
+    if rand_bits is not None:
+        if rand_bits.dtype != torch.int32 or rand_bits.numel() != 4 * p.numel() or not rand_bits.is_contiguous():
+            raise _l.St355Error("adamw_bf16_sr_step: rand_bits must be a contiguous int32 [4, n] tensor")
+        _dev(rand_bits, "rand_bits")
+    _l.check(L.st355_adamw_bf16_sr_step(_stream(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shift), p.numel(), int(step), float(lr),
+                                        float(beta1), float(beta2), float(eps), _ptr(seg_end), _ptr(seg_decay), nseg, _ptr(rand_bits),
+                                        int(seed), int(offset), float(grad_scale)), "adamw_bf16_sr_step")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -94,11 +94,114 @@ class St355AdamW(torch.optim.Optimizer):
         return loss
 
 
+class St355AdamWBF16(torch.optim.Optimizer):
+    """AdamWBF16 — the reference examples' default optimizer (optimizers/adamw_bfloat16/__init__.py:20-111), as ONE fused launch.
+
+    Same constructor (keyword-only lr, betas, eps, weight_decay), same `step(zero_grad=False)`, same per-parameter state keys
+    (`step`, `exp_avg`, `exp_avg_sq`, `shift`, `accumulated_decay`) so `accelerator.save_state` round-trips; the states are views of
+    flat bf16 arenas.  The per-tensor delayed-decay schedule (decay owed += weight_decay*lr; applied only above 5e-3; random initial
+    phase per tensor) is host arithmetic exactly as in the reference; the element-wise math is st355_adamw_bf16_sr_step.
+    Parameters must be bf16 and, for the fused path, views of one contiguous arena (as the full-fine-tune engine allocates them);
+    otherwise one launch per tensor.  `rand_bits_hook(p_index, step) -> int32[4, n]` lets parity tests inject the reference's draws."""
+    decay_threshold = 5e-3
+
+    def __init__(self, params, *, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, seed: int = 0):
+        if not 0.0 <= eps:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 0: {betas[0]}")
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 1: {betas[1]}")
+        if not 0.0 <= weight_decay:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        super().__init__(params, dict(betas=betas, eps=eps, weight_decay=weight_decay, lr=lr))
+        self.grad_scale = 1.0
+        self.seed = int(seed)
+        self.rand_bits_hook = None
+        self._launches = 0
+        self._flat = {}
+
+    def _init_group(self, gi, group):
+        ps = [p for p in group["params"] if p.requires_grad]
+        for p in ps:
+            assert p.dtype == torch.bfloat16, "only bfloat 16 is supported."
+        ok = _contiguous_run([p.data for p in ps])
+        n = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        st = dict(ok=ok, ps=ps, n=n, step=0)
+        mk = lambda: torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        st["m"], st["v"], st["shift"] = mk(), mk(), mk()
+        ends, off = [], 0
+        for p in ps:
+            k = p.numel()
+            # "Each weight has its own starting point to avoid simultaneous updates in all weights" (:80-84)
+            self.state[p] = dict(step=0.0, exp_avg=st["m"][off:off + k].view_as(p), exp_avg_sq=st["v"][off:off + k].view_as(p),
+                                 shift=st["shift"][off:off + k].view_as(p), accumulated_decay=float(torch.rand([]) * self.decay_threshold))
+            off += k
+            ends.append(off)
+        st["seg_end"] = torch.tensor(ends, dtype=torch.int64, device=dev)
+        self._flat[gi] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, zero_grad: bool = False, closure=None):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi) or self._init_group(gi, group)
+            ps = st["ps"]
+            if any(p.grad is None for p in ps):
+                raise RuntimeError("St355AdamWBF16 expects a gradient for every parameter of the group (fused arena step)")
+            beta1, beta2 = group["betas"]
+            lr = group["lr"]
+            st["step"] += 1
+            decays = []
+            for p in ps:                                   # reference :89-95, host scalars
+                s = self.state[p]
+                s["step"] += 1
+                s["accumulated_decay"] += group["weight_decay"] * lr
+                acc = s["accumulated_decay"]
+                dec = acc if acc > self.decay_threshold else 0.0
+                s["accumulated_decay"] -= dec
+                decays.append(dec)
+            seg_decay = torch.tensor(decays, dtype=F32, device=ps[0].device)
+            grads = [p.grad for p in ps]
+            fused = st["ok"] and _contiguous_run(grads) and self.rand_bits_hook is None
+            if fused:
+                pflat = torch.as_strided(ps[0].data, (st["n"],), (1,))
+                gflat = torch.as_strided(grads[0], (st["n"],), (1,))
+                ops.adamw_bf16_sr_step(pflat, gflat, st["m"], st["v"], st["shift"], st["step"], lr, beta1, beta2, group["eps"],
+                                       seg_end=st["seg_end"], seg_decay=seg_decay, seed=self.seed, offset=4 * st["n"] * st["step"],
+                                       grad_scale=self.grad_scale)
+                self._launches += 1
+            else:
+                off = 0
+                for i, p in enumerate(ps):
+                    k = p.numel()
+                    g = p.grad.contiguous().view(-1)
+                    rb = self.rand_bits_hook(i, st["step"]) if self.rand_bits_hook is not None else None
+                    ops.adamw_bf16_sr_step(p.data.view(-1), g, st["m"][off:off + k], st["v"][off:off + k], st["shift"][off:off + k],
+                                           st["step"], lr, beta1, beta2, group["eps"], seg_end=st["seg_end"][i:i + 1] - off,
+                                           seg_decay=seg_decay[i:i + 1], rand_bits=rb, seed=self.seed + i,
+                                           offset=4 * k * st["step"], grad_scale=self.grad_scale)
+                    self._launches += 1
+                    off += k
+            if zero_grad:
+                for p in ps:
+                    p.grad.zero_()
+        return loss
+
+
 # what `optimizer_choices["st355-adamw"]` looks like in the reference's registry (optimizer_param.py:76-96)
 OPTIMIZER_CHOICE = {
     "st355-adamw": {
         "precision": "any",
         "default_settings": {"betas": (0.9, 0.999), "weight_decay": 1e-2, "eps": 1e-8},
         "class": St355AdamW,
-    }
+    },
+    # the reference's own "adamw_bf16" entry (optimizer_param.py), with the fused class substituted
+    "adamw_bf16": {
+        "precision": "bf16",
+        "default_settings": {"betas": (0.9, 0.999), "weight_decay": 1e-2, "eps": 1e-6},
+        "class": St355AdamWBF16,
+    },
 }

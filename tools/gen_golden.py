@@ -45,7 +45,68 @@ def extract(path: Path, names, extra_ns=None, class_name=None):
     return [ns[n] for n in names]
 
 
+def gen_adamw_bf16():
+    """AdamWBF16 (the examples' default optimizer): run the reference CLASS ITSELF (optimizers/adamw_bfloat16/__init__.py:20-180 +
+    stochastic/__init__.py:47-124, imported from /root/reference by file path — pure torch) for 4 steps on two bf16 tensors, recording
+    every random draw (`torch.randint_like` of copy_stochastic_, `torch.rand` of the decay phase) so the oracle / the HIP kernel can be
+    fed the SAME stochastic-rounding bits and must reproduce the states bit for bit."""
+    import importlib.util
+
+    pkg_dir = REF / "helpers/training/optimizers/adamw_bfloat16"
+    spec = importlib.util.spec_from_file_location("ref_adamw_bf16", pkg_dir / "__init__.py", submodule_search_locations=[str(pkg_dir)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_adamw_bf16"] = mod
+    spec.loader.exec_module(mod)
+
+    torch.manual_seed(4321)
+    draws, rands = [], []
+    real_randint_like, real_rand = torch.randint_like, torch.rand
+
+    def rec_randint_like(*a, **k):
+        r = real_randint_like(*a, **k)
+        draws.append(r.clone())
+        return r
+
+    def rec_rand(*a, **k):
+        r = real_rand(*a, **k)
+        rands.append(float(r))
+        return r
+
+    shapes = [(37, 29), (515,)]
+    params = [torch.nn.Parameter((torch.randn(s) * 0.5).to(torch.bfloat16)) for s in shapes]
+    lr, wd, betas, eps = 1e-2, 0.2, (0.9, 0.999), 1e-8
+    opt = mod.AdamWBF16(params, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    G = {"p0": [p.detach().clone() for p in params], "lr": lr, "wd": wd, "betas": betas, "eps": eps, "steps": []}
+    torch.randint_like, torch.rand = rec_randint_like, rec_rand
+    try:
+        for step in range(4):
+            grads = [(torch.randn(s) * (0.1 + 0.3 * step)).to(torch.bfloat16) for s in shapes]
+            for p, g in zip(params, grads):
+                p.grad = g.clone()
+            draws.clear()
+            opt.step()
+            assert len(draws) == 4 * len(params), len(draws)     # exp_avg, shift(addcdiv), p, shift(error) per parameter
+            G["steps"].append({
+                "grads": grads,
+                "draws": [[d.clone() for d in draws[4 * i:4 * i + 4]] for i in range(len(params))],
+                "p": [p.detach().clone() for p in params],
+                "exp_avg": [opt.state[p]["exp_avg"].clone() for p in params],
+                "exp_avg_sq": [opt.state[p]["exp_avg_sq"].clone() for p in params],
+                "shift": [opt.state[p]["shift"].clone() for p in params],
+                "accumulated_decay": [float(opt.state[p]["accumulated_decay"]) for p in params],
+            })
+    finally:
+        torch.randint_like, torch.rand = real_randint_like, real_rand
+    G["accumulated_decay0"] = list(rands)      # torch.rand([]) * decay_threshold is the initial value (lazy state init, first step)
+    G["decay_threshold"] = float(mod.AdamWBF16.decay_threshold)
+    G["_cite"] = "simpletuner/helpers/training/optimizers/adamw_bfloat16/__init__.py:55-180; stochastic/__init__.py:47-124"
+    out = OUT.parent / "adamw_bf16_vectors.pt"
+    torch.save(G, out)
+    print(f"wrote {out}: {len(G['steps'])} steps x {len(shapes)} tensors; initial decay draws {rands}")
+
+
 def main():
+    gen_adamw_bf16()
     torch.manual_seed(1234)
     G = {}
     cite = {}
