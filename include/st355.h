@@ -110,6 +110,15 @@ int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
  * streams (img / txt) of an MMDiT block, or the per-batch slices of a joint buffer. */
 int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count);
 
+/* weight-gradient GEMM (what autograd does for nn.Linear.weight in a full fine-tune, trainer.py:7126):
+ *   C[P,Q] (+)= sum_m L[m,P] * R[m,Q]      e.g. dW[N,K] = dY[M,N]^T X[M,K]  (L = dY, R = X, C = dW in nn.Linear.weight layout)
+ * both operands carry the contraction index m on their slow axis; Mc must be a multiple of 64 (zero-pad the token rows). bf16 in/out,
+ * fp32 accumulate, 256x256 tiles (same ring schedule as the forward GEMM; fragments via the transposing LDS read).  A weight matrix
+ * has few tiles next to the token count: with a workspace the contraction is sliced over the CUs (fixed-order fp32 reduce). */
+int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
+                       int64_t Mc, int P, int Q, int accumulate, void* workspace /* optional fp32 scratch for split-K */,
+                       int64_t workspace_bytes);
+
 /* skinny transposed product for rank-space LoRA gradients (K12 backward):
  * out[p*so_p + r*so_r] (+)= alpha * sum_m L[m,p] * R[m,r],  L:[M,P] bf16, R:[M,Rn] bf16 (Rn in {32,64}), out fp32.
  * workspace: fp32, at least st355_skinny_tn_workspace(M,P,Rn) bytes. accumulate!=0 adds into out. */

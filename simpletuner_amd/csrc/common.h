@@ -70,6 +70,19 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint3
 #pragma unroll
   for (int i = 0; i < 4; i++) out[i] = c[i];
 }
+// gfx950 transposing LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane 4i+s supplies the address of 4 contiguous bf16 of
+// "row" i (i = 0..3) and lane j receives {row0[j], row1[j], row2[j], row3[j]} — column j of the 4x16 block (tools/probes/tr_probe.hip).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 lds_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 lds_tr16x2(const void* p0, const void* p1) {   // two transposed reads -> one MFMA k-fragment
+  bf16x8 f;
+  *(s16x4*)&f = lds_tr16(p0);
+  *((s16x4*)&f + 1) = lds_tr16(p1);
+  return f;
+}
+
 // XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b%8): gives each XCD a
 // contiguous chunk of the logical grid so neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

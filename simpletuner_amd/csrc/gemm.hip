@@ -187,6 +187,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
       const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
       const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
       if (m >= p.M || !n_ok) continue;
+      if (EPI == EPI_SPLITK) {                        // fp32 K-slice slab (p.partial already points at this slice)
+        float* dst = p.partial + (int64_t)m * p.N + n;
+        *(f32x4*)dst = lo;
+        *(f32x4*)(dst + 4) = hi;
+        continue;
+      }
       float v[8];
 #pragma unroll
       for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
@@ -719,7 +725,11 @@ __device__ __forceinline__ void wait_vm_rt(int n) {    // n = LDS-DMA pieces tha
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI>
+// TN = true: the "weight-gradient" form  C[P,Q] = sum_m L[m,P] R[m,Q]  (GemmP: A = L, B = R, M = P, N = Q, K = contraction length):
+// both operands have the contraction index as their SLOW axis.  The ring, the phases and the epilogue are unchanged; a region is
+// then [64 contraction rows][128 output columns] (256-byte rows, 16-byte chunks XOR-ed with (row&3)<<2 on the DMA source side) and
+// the MFMA fragments are gathered by the transposing LDS read (two ds_read_b64_tr_b16 per k-fragment).
+template <int EPI, bool TN>
 __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -727,7 +737,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;     // wm: group (128-token half); wn: 64-feature column of the tile
 
-  int id = xcd_remap(blockIdx.x, gridDim.x);
+  // split-K (EPI_SPLITK): blockIdx = slice * tiles0 + tile; slice s owns K-tiles [s*per, min(all, (s+1)*per)) and writes an fp32 slab
+  const int slice = (EPI == EPI_SPLITK) ? blockIdx.x / g.tiles0 : 0;
+  int id = (EPI == EPI_SPLITK) ? xcd_remap(blockIdx.x % g.tiles0, g.tiles0) : xcd_remap(blockIdx.x, gridDim.x);
   const int pi = id >= g.tiles0 ? 1 : 0;
   if (pi) id -= g.tiles0;
   const GemmP& p = g.p[pi];
@@ -735,8 +747,11 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   int pm, pn;
   tile_coords(id, nbm, nbn, pm, pn);
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
-  const int nt1 = p.K / PQ_BK;
-  const int nt = nt1 + p.K2 / PQ_BK;
+  const int nt_all = p.K / PQ_BK;
+  const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
+  const int t_first = slice * per;
+  const int nt1 = (EPI == EPI_SPLITK) ? max(0, min(nt_all, t_first + per) - t_first) : nt_all;
+  const int nt = nt1 + ((EPI == EPI_SPLITK) ? 0 : p.K2 / PQ_BK);
 
   const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
   const int64_t la2 = p.lda2, lb2 = p.ldb2;
@@ -745,20 +760,36 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // region row lr -> tile row:  X: (lr>>6)*128 + (lr&63) [+64 for XB]     W: (lr>>5)*64 + (lr&31) [+32 for WB]
   // Addresses are (uniform 64-bit base of the tile's first row + k) + a 32-bit per-lane byte offset: the LDS-DMA takes the
   // SGPR-base + VGPR-offset form, so the K loop spends no VALU (and only 8 VGPRs) on addressing.
-  const char* xbase = (const char*)A1 + (int64_t)m0 * p.lda * 2;
-  const char* wbase = (const char*)B1 + (int64_t)n0 * p.ldb * 2;
+  const char* xbase = TN ? (const char*)A1 + (int64_t)m0 * 2 : (const char*)A1 + (int64_t)m0 * p.lda * 2;
+  const char* wbase = TN ? (const char*)B1 + (int64_t)n0 * 2 : (const char*)B1 + (int64_t)n0 * p.ldb * 2;
   const uint32_t lda_b = (uint32_t)p.lda * 2, ldb_b = (uint32_t)p.ldb * 2;
+  const int64_t xk_step = TN ? (int64_t)PQ_BK * lda_b : PQ_BK * 2;     // bytes per K-tile along the contraction
+  const int64_t wk_step = TN ? (int64_t)PQ_BK * ldb_b : PQ_BK * 2;
+  xbase += t_first * xk_step; wbase += t_first * wk_step;
   auto x_rel = [&](int lr, int r) { return min(m0 + (lr >> 6) * 128 + (lr & 63) + r * 64, M - 1) - m0; };
   auto w_rel = [&](int lr, int r) { return min(n0 + (lr >> 5) * 64 + (lr & 31) + r * 32, N - 1) - n0; };
   uint32_t xo[2][2], wo[2][2];               // [region A/B][piece] byte offsets from xbase / wbase
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int lr = (wv * 2 + j) * 8 + (lane >> 3);
-    const uint32_t scb = (uint32_t)(((lane & 7) ^ ((lr >> 1) & 7)) * 16);
+    if (TN) {
+      // piece = 4 contraction rows x 256 B; LDS chunk position c <- source chunk c ^ ((row&3)<<2)
+      const int r4 = (wv * 2 + j) * 4 + (lane >> 4);
+      const int cs = (lane & 15) ^ ((r4 & 3) << 2);
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      xo[r][j] = (uint32_t)x_rel(lr, r) * lda_b + scb;
-      wo[r][j] = (uint32_t)w_rel(lr, r) * ldb_b + scb;
+      for (int r = 0; r < 2; r++) {
+        const int xc = min(m0 + (cs >> 3) * 128 + (cs & 7) * 8 + r * 64, M - 8) - m0;     // output-row (p) columns of L
+        const int wc = min(n0 + (cs >> 2) * 64 + (cs & 3) * 8 + r * 32, N - 8) - n0;      // output-col (q) columns of R
+        xo[r][j] = (uint32_t)r4 * lda_b + (uint32_t)(xc * 2);
+        wo[r][j] = (uint32_t)r4 * ldb_b + (uint32_t)(wc * 2);
+      }
+    } else {
+      const int lr = (wv * 2 + j) * 8 + (lane >> 3);
+      const uint32_t scb = (uint32_t)(((lane & 7) ^ ((lr >> 1) & 7)) * 16);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        xo[r][j] = (uint32_t)x_rel(lr, r) * lda_b + scb;
+        wo[r][j] = (uint32_t)w_rel(lr, r) * ldb_b + scb;
+      }
     }
   }
   auto stage_ext = [&](const bf16* base, int64_t ld, int row0, bool is_x, int r, int k0, char* dst) {   // low-rank K-extension (rare)
@@ -772,7 +803,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   auto stage_x = [&](int u, int r) {        // r = 0: XA, 1: XB
     char* dst = smem + (u & 1) * PQ_BUF + r * PQ_REGION + wv * 2048;
     if (u < nt1) {
-      const char* kb = xbase + u * (PQ_BK * 2);
+      const char* kb = xbase + u * xk_step;
 #pragma unroll
       for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + xo[r][j]), dst + j * 1024);
     } else {
@@ -782,7 +813,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   auto stage_w = [&](int u, int r) {        // r = 0: WA, 1: WB
     char* dst = smem + (u & 1) * PQ_BUF + (2 + r) * PQ_REGION + wv * 2048;
     if (u < nt1) {
-      const char* kb = wbase + u * (PQ_BK * 2);
+      const char* kb = wbase + u * wk_step;
 #pragma unroll
       for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + wo[r][j]), dst + j * 1024);
     } else {
@@ -807,6 +838,19 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     xk[ks] = (wm * 64 + l31) * 128 + ch;                       // + j*4096 (block), + region, + buffer
     wk[ks] = 2 * PQ_REGION + (wn * 32 + l31) * 128 + ch;
   }
+  // TN: transposed-read bases.  group g = lane>>4, ti = (lane>>2)&3 (row inside a 4-row block), ts = lane&3 (4-column segment)
+  const int tg = lane >> 4, tti = (lane >> 2) & 3, tts = lane & 3;
+  const int t_row = (8 * (tg >> 1) + tti) * 256 + (tts & 1) * 8;
+  const int xt = t_row + (((wm * 8 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);                  // ^ (j<<6), + ks*4096 + rd*1024
+  const int wt = 2 * PQ_REGION + t_row + (((wn * 4 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);
+  auto ld_x = [&](const char* base, int j, int ks) -> bf16x8 {
+    if (TN) { const char* q = base + (xt ^ (j << 6)) + ks * 4096; return lds_tr16x2(q, q + 1024); }
+    return *(const bf16x8*)(base + xk[ks] + j * 4096);
+  };
+  auto ld_w = [&](const char* base, int ks) -> bf16x8 {
+    if (TN) { const char* q = base + wt + ks * 4096; return lds_tr16x2(q, q + 1024); }
+    return *(const bf16x8*)(base + wk[ks]);
+  };
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -846,9 +890,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) xf[j][ks] = *(const bf16x8*)(bf + xk[ks] + j * 4096);
+      for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf, j, ks);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) w0f[ks] = *(const bf16x8*)(bf + wk[ks]);
+    for (int ks = 0; ks < 4; ks++) w0f[ks] = ld_w(bf, ks);
     if (PQ_GL == 1) refill(t, 0, TAIL);
     TR(t, 1);
     if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 2));
@@ -861,7 +905,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     // ---------------- P1: WB x XA ----------------
     if (PQ_GL == 0) refill(t, 1, TAIL);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) w1f[ks] = *(const bf16x8*)(bf + wk[ks] + PQ_REGION);
+    for (int ks = 0; ks < 4; ks++) w1f[ks] = ld_w(bf + PQ_REGION, ks);
     if (PQ_GL == 1) refill(t, 1, TAIL);
     TR(t, 4);
     if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 0));
@@ -876,7 +920,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) xf[j][ks] = *(const bf16x8*)(bf + xk[ks] + PQ_REGION + j * 4096);
+      for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf + PQ_REGION, j, ks);
     if (PQ_GL == 1) refill(t, 2, TAIL);
     TR(t, 7);
     if (!TAIL) wait_vm_rt(8); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 6 : 0));
@@ -905,7 +949,12 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   TR_FLUSH(wv, lane);
   if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
   // every wave is past its last ring read and no LDS-DMA is in flight: the ring is free for the epilogue transpose
-  if (epl_aligned(p)) gemm_epilogue_lds<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  if (EPI == EPI_SPLITK) {
+    GemmP ps = p;
+    ps.partial = p.partial + (int64_t)slice * p.M * p.N;
+    ps.bias = nullptr;
+    gemm_epilogue_lds<EPI>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (epl_aligned(p)) gemm_epilogue_lds<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   else gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
@@ -1004,7 +1053,7 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
 
 // fixed-order sum of the K-slice slabs (+ bias) -> bf16 C
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ slabs, int ksplit, const bf16* __restrict__ bias,
-                                                      bf16* __restrict__ C, int64_t ldc, int M, int N) {
+                                                      bf16* __restrict__ C, int64_t ldc, int M, int N, int accumulate) {
   const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread = 4 consecutive features
   const int n4 = N / 4;
   if (i4 >= (int64_t)M * n4) return;
@@ -1017,6 +1066,11 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   bf16x4 o;
 #pragma unroll
   for (int b = 0; b < 4; b++) o[b] = f2bf(s[b] + (bias ? bf2f(bias[n + b]) : 0.f));
+  if (accumulate) {
+    const bf16x4 c0 = *(const bf16x4*)(C + (int64_t)m * ldc + n);
+#pragma unroll
+    for (int b = 0; b < 4; b++) o[b] = f2bf(s[b] + bf2f(c0[b]));
+  }
   *(bf16x4*)(C + (int64_t)m * ldc + n) = o;
 }
 
@@ -1096,8 +1150,8 @@ static int launch_pp(void* stream, const GemmGroup& g, int tiles) {
 template <int EPI>
 static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
-  hipLaunchKernelGGL(k_gemm_pq<EPI>, dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq");
 }
 static int p4_tiles(const GemmP& p) { return ((p.M + P4_BM - 1) / P4_BM) * ((p.N + P4_BN - 1) / P4_BN); }
@@ -1150,7 +1204,7 @@ static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int k
   if (rc) return rc;
   const int64_t n4 = (int64_t)p.M * (p.N / 4);
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)p.partial, ksplit,
-                     p.bias, p.C, p.ldc, p.M, p.N);
+                     p.bias, p.C, p.ldc, p.M, p.N, 0);
   return st355_check_launch("gemm_splitk_reduce");
 }
 
@@ -1187,6 +1241,53 @@ extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
   if (rc) return rc;
   ProfScope ps(stream, ST355_K_GEMM, gemm_flops(a), gemm_bytes(a), "%dx%dx%d+%d e%d", a->M, a->N, a->K, a->K2, a->epilogue);
   return run_one(stream, a);
+}
+
+// ---- weight-gradient form -------------------------------------------------------------------------------------------------------
+template <int EPI>
+static int launch_tn(void* stream, const GemmGroup& g, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  hipLaunchKernelGGL((k_gemm_pq<EPI, true>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_tn");
+}
+
+extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
+                                  int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes) {
+  ST_REQUIRE(L && R && C && Mc > 0 && P > 0 && Q > 0, "gemm_tn: bad args");
+  ST_REQUIRE(Mc % PQ_BK == 0, "gemm_tn: the contraction length (%lld rows) must be a multiple of 64 (pad the operands with zero rows)", (long long)Mc);
+  ST_REQUIRE(P % 8 == 0 && Q % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0 && ldc % 8 == 0, "gemm_tn: P, Q and the leading dimensions must be multiples of 8");
+  ST_REQUIRE(((uintptr_t)L % 16 == 0) && ((uintptr_t)R % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_tn: misaligned pointer");
+  ST_REQUIRE(Mc * (int64_t)(ldl > ldr ? ldl : ldr) * 2 < ((int64_t)1 << 31) * 64, "gemm_tn: operand too large for 32-bit tile offsets");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)L; p.lda = ldl; p.B = (const bf16*)R; p.ldb = ldr; p.C = (bf16*)C; p.ldc = ldc;
+  p.M = P; p.N = Q; p.K = (int)Mc; p.K2 = 0; p.ksplit = 1;
+  if (accumulate) { p.aux_in = (const bf16*)C; p.ld_aux_in = ldc; }
+  GemmGroup g;
+  g.p[0] = p; g.p[1] = p;
+  g.tiles0 = ((P + PQ_BM - 1) / PQ_BM) * ((Q + PQ_BN - 1) / PQ_BN);
+  ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)Mc * P * Q, 2.0 * ((double)Mc * (P + Q) + (double)P * Q * (accumulate ? 2 : 1)), "TN %dx%dx%lld", P, Q, (long long)Mc);
+  // weight matrices are small next to the token count: when the output has too few 256x256 tiles for 256 CUs, slice the contraction
+  // (fp32 slabs in the caller's workspace, fixed-order reduce — deterministic)
+  const int nt_all = (int)(Mc / PQ_BK);
+  int ks = (384 + g.tiles0 - 1) / g.tiles0;
+  if (ks > nt_all / 8) ks = nt_all / 8;                // >= 8 K-tiles per slice
+  if (ks > 16) ks = 16;
+  if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * 4 <= workspace_bytes) {
+    g.p[0].partial = (float*)workspace; g.p[0].ksplit = ks; g.p[0].aux_in = nullptr;
+    g.p[1] = g.p[0];
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI_SPLITK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+    hipLaunchKernelGGL((k_gemm_pq<EPI_SPLITK, true>), dim3(g.tiles0 * ks), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+    int rc = st355_check_launch("gemm_tn_splitk");
+    if (rc) return rc;
+    const int64_t n4 = (int64_t)P * (Q / 4);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ks,
+                       (const bf16*)nullptr, (bf16*)C, ldc, P, Q, accumulate);
+    return st355_check_launch("gemm_tn_splitk_reduce");
+  }
+  return accumulate ? launch_tn<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_tn<ST355_EPI_NONE>(stream, g, g.tiles0);
 }
 
 extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count) {

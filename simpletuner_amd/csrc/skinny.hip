@@ -82,10 +82,6 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
   }
 }
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ s16x4 lds_tr16(const bf16* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-}
 
 // LDS pitches = 64 B (mod 256 B): the four tile rows a 32-lane half touches sit in four disjoint 16-bank windows
 #define SK_LP (SK_PT + 32)      // 160 elements = 320 B

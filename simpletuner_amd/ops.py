@@ -182,11 +182,11 @@ _gemm_ws = {}
 _GEMM_WS_BYTES = 64 << 20
 
 
-def _gemm_workspace(dev):
-    """caller-owned fp32 scratch for the split-K path of thin GEMMs (libst355 never allocates)"""
+def _gemm_workspace(dev, nbytes: int = _GEMM_WS_BYTES):
+    """caller-owned fp32 scratch for the split-K paths (thin GEMMs, weight gradients); libst355 never allocates"""
     ws = _gemm_ws.get(dev.index)
-    if ws is None:
-        ws = torch.empty(_GEMM_WS_BYTES // 4, dtype=F32, device=dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, dtype=F32, device=dev)
         _gemm_ws[dev.index] = ws
     return ws
 
@@ -254,6 +254,25 @@ def gemm_grouped(problems):
         outs.append(_gemm_args(g, pr.pop("a"), pr.pop("w"), **pr))
     _l.check(L.st355_gemm_bf16_grouped(_stream(), arr, len(problems)), "gemm_bf16_grouped")
     return outs
+
+
+def gemm_tn(Lm, R, out=None, accumulate: bool = False):
+    """out[P,Q] (+)= Lm[M,P]^T @ R[M,Q]  — the weight-gradient form (dW = dY^T X).  M must be a multiple of 64 (zero-padded rows)."""
+    L = _l.load()
+    _chk(Lm, BF16, "L"); _chk(R, BF16, "R")
+    M, P = Lm.shape
+    if R.shape[0] != M:
+        raise _l.St355Error("gemm_tn: operands must share the contraction length")
+    Q = R.shape[1]
+    if out is None:
+        if accumulate:
+            raise _l.St355Error("gemm_tn: accumulate needs an output tensor")
+        out = torch.empty(P, Q, dtype=BF16, device=Lm.device)
+    _chk(out, BF16, "out")
+    ws = _gemm_workspace(Lm.device, 256 << 20)
+    _l.check(L.st355_gemm_tn_bf16(_stream(), _ptr(Lm), _rows(Lm, "L"), _ptr(R), _rows(R, "R"), _ptr(out), _rows(out, "out"), M, P, Q,
+                                  1 if accumulate else 0, _ptr(ws), ws.numel() * 4), "gemm_tn_bf16")
+    return out
 
 
 _skinny_ws = {}

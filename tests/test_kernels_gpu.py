@@ -165,6 +165,28 @@ def test_gemm_plain(ops, M, N, K):
         assert rel(out.t(), ref) > 0.1
 
 
+@pytest.mark.parametrize("M,P,Q", [(64, 256, 256), (192, 512, 264), (4096, 1536, 1536), (960, 136, 3072), (4352, 3072, 768)])
+def test_gemm_tn_weight_gradient(ops, M, P, Q):
+    """dW[P,Q] = dY[M,P]^T X[M,Q] (+ accumulate): contraction over the slow axis of both operands (transposing LDS reads)"""
+    torch.manual_seed(21)
+    dy = (torch.randn(M, P, device=dev()) * 0.5).to(BF16)
+    x = torch.randn(M, Q, device=dev()).to(BF16)
+    out = ops.gemm_tn(dy, x)
+    ref = dy.float().t() @ x.float()
+    r, _ = report(f"gemm_tn {P}x{Q} over {M}", out, ref)
+    assert r < 5e-3
+    if P == Q:
+        assert rel(out.t(), ref) > 0.1                      # transpose detector
+    acc0 = torch.randn(P, Q, device=dev()).to(BF16)
+    acc = acc0.clone()
+    ops.gemm_tn(dy, x, out=acc, accumulate=True)
+    assert report("gemm_tn accumulate", acc, ref + acc0.float())[0] < 6e-3
+    # strided operands: column slices of wider buffers (how the engine hands per-projection dY blocks)
+    wide = torch.randn(M, P + 64, device=dev()).to(BF16)
+    o2 = ops.gemm_tn(wide[:, 32:32 + P] if False else wide[:, 64:], x)
+    assert report("gemm_tn strided L", o2, wide[:, 64:].float().t() @ x.float())[0] < 5e-3
+
+
 def test_gemm_identity_asymmetric(ops):
     # A = I (padded), asymmetric B: catches row/col swaps in the C write (cdna guide §3 "A=I-check")
     K = 128

@@ -124,5 +124,23 @@ int main(int argc, char** argv) {
   }
   for (const Shape& s : check) run(s, true);
   for (const Shape& s : perf) run(s, false);
+  // weight-gradient (TN) form: C[P,Q] = L[M,P]^T R[M,Q]; Shape {M=P, N=Q, K=contraction}
+  for (const Shape& s : {Shape{3072, 3072, 4608, 0}, Shape{12288, 3072, 4608, 0}, Shape{3072, 12288, 18432, 0}, Shape{1536, 1536, 16384, 0},
+                         Shape{6144, 1536, 16384, 0}, Shape{8192, 8192, 8192, 0}}) {
+    bf16 *Lm, *Rm, *C;
+    static void* tws = nullptr;
+    if (!tws) CK(hipMalloc(&tws, (size_t)512 << 20));
+    CK(hipMalloc(&Lm, (size_t)s.K * s.M * 2)); CK(hipMalloc(&Rm, (size_t)s.K * s.N * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
+    k_fill<<<1024, 256, 0, st>>>(Lm, (int64_t)s.K * s.M, 5u, 1.f);
+    k_fill<<<1024, 256, 0, st>>>(Rm, (int64_t)s.K * s.N, 6u, 0.05f);
+    for (int i = 0; i < 3; i++) st355_gemm_tn_bf16(st, Lm, s.M, Rm, s.N, C, s.N, s.K, s.M, s.N, 0, tws, (int64_t)512 << 20);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 20; i++) st355_gemm_tn_bf16(st, Lm, s.M, Rm, s.N, C, s.N, s.K, s.M, s.N, 0, tws, (int64_t)512 << 20);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    printf("  TN %6d x %6d over %6d: %8.1f us  %8.1f TFLOP/s\n", s.M, s.N, s.K, ms * 1e3, 2.0 * s.M * s.N * (double)s.K / ms / 1e9);
+    CK(hipFree(Lm)); CK(hipFree(Rm)); CK(hipFree(C));
+  }
   return 0;
 }
