@@ -99,7 +99,8 @@ typedef struct st355_gemm_args {
   int32_t M, N, K, K2;              /* K, K2 multiples of 64 (K2 may be 0); N multiple of 4            */
   const void* bias;                 /* [N] bf16 or NULL                                                */
   int32_t epilogue;                 /* ST355_EPI_*                                                     */
-  void*       aux_out; int64_t ld_aux_out; /* EPI_GELU: optional pre-activation store [M,N] bf16       */
+  void*       aux_out; int64_t ld_aux_out; /* EPI_GELU: optional pre-activation store [M,N] bf16; EPI_GATE_RESIDUAL: optional
+                                              store of the un-gated branch output (acc + bias) for the gate gradient */
   const void* aux_in;  int64_t ld_aux_in;  /* EPI_GATE_RESIDUAL: residual; EPI_MUL_GELU_GRAD: pre-act    */
   const void* gate; int64_t gate_stride; int64_t rows_per_batch; /* EPI_GATE_RESIDUAL: gate[b*stride+n] */
   void*       workspace; int64_t workspace_bytes; /* optional fp32 scratch (256-B aligned): lets thin problems (N <= 128, e.g. the
@@ -118,6 +119,17 @@ int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count
 int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
                        int64_t Mc, int P, int Q, int accumulate, void* workspace /* optional fp32 scratch for split-K */,
                        int64_t workspace_bytes);
+
+/* token-axis reductions of the full fine-tune backward (bias gradients, AdaLN modulation shift / scale / gate gradients):
+ *   out[b*out_stride + n] (+)= sum_{t in batch b} a[t,n] * (b ? b[t,n] : 1)        rows = nb * rows_per_batch, fp32 out
+ * mode 1 finishes a modulation-scale gradient from the saved LN output n = xhat(1+scale)+shift:
+ *   out = (sum_t dY*n - shift_b * prev_b) / (1 + scale_b)   with prev = the matching dshift row.  Deterministic two-level tree. */
+size_t st355_colsum_workspace(int64_t rows, int N, int64_t rows_per_batch);
+int st355_colsum_prod(void* stream, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int N,
+                      int64_t rows_per_batch, float* out, int64_t out_stride, int mode, const float* prev, int64_t prev_stride,
+                      const void* shift, const void* scale, int64_t mod_stride, int accumulate, void* workspace);
+/* dst[c, r] = src[r, c]  (bf16; rows, cols multiples of 8): refreshes the K-major weight copies after an optimizer step */
+int st355_transpose_bf16(void* stream, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols);
 
 /* skinny transposed product for rank-space LoRA gradients (K12 backward):
  * out[p*so_p + r*so_r] (+)= alpha * sum_m L[m,p] * R[m,r],  L:[M,P] bf16, R:[M,Rn] bf16 (Rn in {32,64}), out fp32.

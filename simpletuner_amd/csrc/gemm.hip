@@ -121,6 +121,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
 #pragma unroll
           for (int b = 0; b < 4; b++) v[b] = gelu_tanh(v[b]);
         } else if (EPI == ST355_EPI_GATE_RESIDUAL) {
+          if (p.aux_out) {                                   // full fine-tune: keep the un-gated branch output y (d gate = sum dOut * y)
+            bf16x4 yv;
+#pragma unroll
+            for (int b = 0; b < 4; b++) yv[b] = f2bf(v[b]);
+            *(bf16x4*)(p.aux_out + (int64_t)m * p.ld_aux_out + n) = yv;
+          }
           bf16x4 gv = *(const bf16x4*)(p.gate + bidx * p.gate_stride + n);
           bf16x4 rv = *(const bf16x4*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
 #pragma unroll
@@ -208,6 +214,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] = gelu_tanh(v[b]);
       } else if (EPI == ST355_EPI_GATE_RESIDUAL) {
+        if (p.aux_out) {                                     // full fine-tune: keep the un-gated branch output y (d gate = sum dOut * y)
+          bf16x8 yv;
+#pragma unroll
+          for (int b = 0; b < 8; b++) yv[b] = f2bf(v[b]);
+          *(bf16x8*)(p.aux_out + (int64_t)m * p.ld_aux_out + n) = yv;
+        }
         const int64_t bidx = (int64_t)(m / p.rows_per_batch);
         const bf16x8 gv = *(const bf16x8*)(p.gate + bidx * p.gate_stride + n);
         const bf16x8 rv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
@@ -1093,7 +1105,8 @@ static int validate(const st355_gemm_args* a) {
                "gemm: gate/residual epilogue operands missing");
   if (a->epilogue == ST355_EPI_MUL_GELU_GRAD || a->epilogue == ST355_EPI_ADD)
     ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad/add epilogue needs aux_in");
-  if (a->epilogue == ST355_EPI_GELU && a->aux_out) ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
+  if ((a->epilogue == ST355_EPI_GELU || a->epilogue == ST355_EPI_GATE_RESIDUAL) && a->aux_out)
+    ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
   ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_ADD, "gemm: unknown epilogue %d", a->epilogue);
   return ST355_OK;
 }

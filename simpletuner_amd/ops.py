@@ -275,6 +275,46 @@ def gemm_tn(Lm, R, out=None, accumulate: bool = False):
     return out
 
 
+_colsum_ws = {}
+
+
+def colsum_prod(a, out, b=None, rows_per_batch: Optional[int] = None, mode: int = 0, prev=None, shift=None, scale=None, accumulate: bool = False):
+    """out[bi, :] (+)= sum over the rows of batch bi of a (* b).  out: fp32 2-D view [nb, N] (row stride free).  mode 1: see st355.h."""
+    L = _l.load()
+    _chk(a, BF16, "a"); _chk(out, F32, "out")
+    rows, N = a.shape
+    rpb = rows if rows_per_batch is None else rows_per_batch
+    if b is not None:
+        _chk(b, BF16, "b")
+    need = L.st355_colsum_workspace(rows, N, rpb)
+    ws = _colsum_ws.get(a.device.index)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=F32, device=a.device)
+        _colsum_ws[a.device.index] = ws
+    ms = 0
+    if mode == 1:
+        _chk(shift, BF16, "shift"); _chk(scale, BF16, "scale"); _chk(prev, F32, "prev")
+        ms = _rows(shift, "shift")
+        if _rows(scale, "scale") != ms:
+            raise _l.St355Error("colsum_prod: shift and scale must share a row stride")
+    _l.check(L.st355_colsum_prod(_stream(), _ptr(a), _rows(a, "a"), _ptr(b), _rows(b, "b") if b is not None else 0, rows, N, rpb, _ptr(out),
+                                 _rows(out, "out"), mode, _ptr(prev), _rows(prev, "prev") if prev is not None else 0, _ptr(shift), _ptr(scale),
+                                 ms, 1 if accumulate else 0, _ptr(ws)), "colsum_prod")
+    return out
+
+
+def transpose(src, out=None):
+    """out[c, r] = src[r, c] (bf16)"""
+    L = _l.load()
+    _chk(src, BF16, "src")
+    R, Cn = src.shape
+    if out is None:
+        out = torch.empty(Cn, R, dtype=BF16, device=src.device)
+    _chk(out, BF16, "out")
+    _l.check(L.st355_transpose_bf16(_stream(), _ptr(src), _rows(src, "src"), _ptr(out), _rows(out, "out"), R, Cn), "transpose_bf16")
+    return out
+
+
 _skinny_ws = {}
 
 

@@ -187,6 +187,47 @@ def test_gemm_tn_weight_gradient(ops, M, P, Q):
     assert report("gemm_tn strided L", o2, wide[:, 64:].float().t() @ x.float())[0] < 5e-3
 
 
+def test_colsum_prod_and_transpose(ops):
+    """token-axis reductions of the full fine-tune backward + the bf16 transpose that refreshes W^T"""
+    torch.manual_seed(31)
+    B, S, N = 3, 231, 1536
+    dy = torch.randn(B * S, N, device=dev()).to(BF16); y = torch.randn(B * S, N, device=dev()).to(BF16)
+    out = torch.zeros(B, 2 * N, device=dev(), dtype=torch.float32)[:, N:]                 # strided fp32 destination (a slice of dmod)
+    ops.colsum_prod(dy, out, rows_per_batch=S)
+    assert report("colsum per batch", out, dy.float().view(B, S, N).sum(1))[0] < 1e-5
+    ops.colsum_prod(dy, out, b=y, rows_per_batch=S, accumulate=True)
+    assert report("colsum prod accumulate", out, dy.float().view(B, S, N).sum(1) + (dy.float() * y.float()).view(B, S, N).sum(1))[0] < 1e-5
+    bias = torch.zeros(1, N, device=dev(), dtype=torch.float32)
+    ops.colsum_prod(dy, bias)
+    assert report("bias grad", bias[0], dy.float().sum(0))[0] < 1e-5
+    # modulation-scale gradient from the saved LN output (mode 1)
+    x = torch.randn(B * S, N, device=dev()).to(BF16)
+    mod = (torch.randn(B, 2 * N, device=dev()) * 0.3).to(BF16)
+    shift, scale = mod[:, :N], mod[:, N:]
+    n = ops.ln_modulate_fwd(x, scale, shift, S)
+    dsh = torch.zeros(B, N, device=dev(), dtype=torch.float32); dsc = torch.zeros_like(dsh)
+    ops.colsum_prod(dy, dsh, rows_per_batch=S)
+    ops.colsum_prod(dy, dsc, b=n, rows_per_batch=S, mode=1, prev=dsh, shift=shift, scale=scale)
+    xh = torch.nn.functional.layer_norm(x.float(), (N,), eps=1e-6)
+    ref = (dy.float() * xh).view(B, S, N).sum(1)
+    assert report("dscale via saved n", dsc, ref)[0] < 2e-2
+    w = torch.randn(1536, 4608, device=dev()).to(BF16)
+    assert torch.equal(ops.transpose(w), w.t().contiguous())
+    assert torch.equal(ops.transpose(w[:, 512:1536]), w[:, 512:1536].t().contiguous())
+
+
+def test_gemm_gate_residual_keeps_branch_output(ops):
+    torch.manual_seed(32)
+    B, S, D, K = 2, 300, 512, 256
+    a = torch.randn(B * S, K, device=dev()).to(BF16); w = (torch.randn(D, K, device=dev()) * 0.1).to(BF16)
+    bias = torch.randn(D, device=dev()).to(BF16); gate = torch.randn(B, D, device=dev()).to(BF16); res = torch.randn(B * S, D, device=dev()).to(BF16)
+    ybr = torch.empty(B * S, D, device=dev(), dtype=BF16)
+    out = ops.gemm(a, w, bias=bias, epilogue=ops.EPI_GATE_RESIDUAL, aux_in=res, gate=gate, rows_per_batch=S, aux_out=ybr)
+    y = a.float() @ w.float().t() + bias.float()
+    assert report("un-gated branch output", ybr, y)[0] < 5e-3
+    assert report("gated residual", out, res.float() + (gate.float()[:, None, :] * y.view(B, S, D)).view(B * S, D))[0] < 5e-3
+
+
 def test_gemm_identity_asymmetric(ops):
     # A = I (padded), asymmetric B: catches row/col swaps in the C write (cdna guide §3 "A=I-check")
     K = 128
