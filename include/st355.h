@@ -84,6 +84,7 @@ int st355_timestep_proj(void* stream, const float* t /*[B]*/, void* out /*[B,dim
                         float scale /* applied to t first, e.g. 1000 */);
 int st355_silu(void* stream, const void* x, void* y, int64_t n);
 int st355_add(void* stream, const void* a, const void* b, void* y, int64_t n);
+int st355_silu_bwd(void* stream, const void* x, const void* dy, void* dx, int64_t n);   /* dx = dy * silu'(x) */
 /* out[m,n] = in[m,n] * gate[(m / rows_per_batch) * gate_stride + n]  (gated-residual backward) */
 int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* gate, int64_t gate_stride,
                      int64_t rows_per_batch, void* out, int64_t ld_out, int64_t M, int64_t N);

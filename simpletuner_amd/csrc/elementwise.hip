@@ -253,12 +253,13 @@ __global__ void __launch_bounds__(EW_THREADS) k_unary_binary(const bf16* __restr
   const int64_t nvec = n >> 3;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     bf16x8 av = *(const bf16x8*)(a + i * 8), bv, o;
-    if (OP == 1) bv = *(const bf16x8*)(b + i * 8);
+    if (OP >= 1) bv = *(const bf16x8*)(b + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float f = bf2f(av[j]);
       if (OP == 0) o[j] = f2bf(f / (1.f + __expf(-f)));
-      else o[j] = f2bf(f + bf2f(bv[j]));
+      else if (OP == 1) o[j] = f2bf(f + bf2f(bv[j]));
+      else { const float sg = 1.f / (1.f + __expf(-f)); o[j] = f2bf(bf2f(bv[j]) * sg * (1.f + f * (1.f - sg))); }   // OP 2: dy * silu'(x)
     }
     *(bf16x8*)(y + i * 8) = o;
   }
@@ -266,7 +267,9 @@ __global__ void __launch_bounds__(EW_THREADS) k_unary_binary(const bf16* __restr
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     int64_t i = (nvec << 3) + threadIdx.x;
     float f = bf2f(a[i]);
-    y[i] = (OP == 0) ? f2bf(f / (1.f + __expf(-f))) : f2bf(f + bf2f(b[i]));
+    if (OP == 0) y[i] = f2bf(f / (1.f + __expf(-f)));
+    else if (OP == 1) y[i] = f2bf(f + bf2f(b[i]));
+    else { const float sg = 1.f / (1.f + __expf(-f)); y[i] = f2bf(bf2f(b[i]) * sg * (1.f + f * (1.f - sg))); }
   }
 }
 extern "C" int st355_silu(void* stream, const void* x, void* y, int64_t n) {
@@ -275,6 +278,14 @@ extern "C" int st355_silu(void* stream, const void* x, void* y, int64_t n) {
   hipLaunchKernelGGL(k_unary_binary<0>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
                      (const bf16*)nullptr, (bf16*)y, n);
   return st355_check_launch("silu");
+}
+/* dx = dy * silu'(x) */
+extern "C" int st355_silu_bwd(void* stream, const void* x, const void* dy, void* dx, int64_t n) {
+  ST_REQUIRE(x && dy && dx && n > 0, "silu_bwd: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 8.0 * n, 6.0 * n);
+  hipLaunchKernelGGL(k_unary_binary<2>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
+                     (const bf16*)dy, (bf16*)dx, n);
+  return st355_check_launch("silu_bwd");
 }
 extern "C" int st355_add(void* stream, const void* a, const void* b, void* y, int64_t n) {
   ST_REQUIRE(a && b && y && n > 0, "add: bad args");

@@ -153,6 +153,16 @@ def silu(x):
     return y
 
 
+def silu_bwd(x, dy):
+    """dx = dy * silu'(x)"""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
+    x = x.contiguous(); dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    _l.check(L.st355_silu_bwd(_stream(), _ptr(x), _ptr(dy), _ptr(dx), x.numel()), "silu_bwd")
+    return dx
+
+
 def add(a, b):
     L = _l.load()
     _chk(a, BF16, "a"); _chk(b, BF16, "b")

@@ -44,6 +44,10 @@ class SD3(ModelFoundation):
         comp.prepare_for_training()
         return params
 
+    def enable_full_finetune(self):
+        """model_type == "full" (BASELINE.json configs[3]): every transformer parameter trains (bf16 params + bf16 grads in two arenas)"""
+        return self.unwrap_model(self.model).enable_full_finetune()
+
     def model_predict(self, prepared_batch: dict):
         return self._model_predict_single(prepared_batch)
 

@@ -74,20 +74,60 @@ class SD3Transformer2DModel(nn.Module):
             raise ValueError("all contraction dims must be multiples of 64")
         self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         dev = self.device_
-        e = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        # every weight / bias / modulation row is a view of ONE bf16 arena (allocation order = arena order): the full fine-tune then
+        # has one gradient arena of the same layout, ONE fused optimizer launch and contiguous slices for the RCCL all-reduce.
+        # Pass 1 counts (meta tensors), pass 2 hands out the views.
+        self._arena_numel = 0
+        self._counting = True
+        self._build(lambda *s_: self._alloc(s_))
+        self.arena = torch.zeros(self._arena_numel, dtype=BF16, device=dev)
+        self._arena_numel = 0
+        self._counting = False
+        self._build(lambda *s_: self._alloc(s_))
+        self.pos_embed.register_buffer("pos_embed", torch.zeros(1, pos_embed_max_size * pos_embed_max_size, D, dtype=F32, device=dev))
+
+        self.lora_groups: List[LoraGroup] = []
+        self.lora_flat: Optional[torch.Tensor] = None
+        self.lora_grad_flat: Optional[torch.Tensor] = None
+        self._lora_params: List[nn.Parameter] = []
+        self._cache: Dict = {}
+        self._prepared = False
+        self.accumulate_lora_grads = False
+        self.gradient_checkpointing = False
+        self.grad_sync = None
+        self._last_grad_flat = None
+        self.full = False
+
+    def _alloc(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n_pad = (n + 7) // 8 * 8                      # every tensor starts 16-byte aligned inside the arena
+        off = self._arena_numel
+        self._arena_numel += n_pad
+        if self._counting:
+            return torch.empty(*shape, dtype=BF16, device="meta")
+        return self.arena[off:off + n].view(*shape)
+
+    def _reg(self, name, param):
+        if not self._counting:
+            _attach(self, name, param)
+
+    def _build(self, e):
+        c = self.config
+        D, dev = self.D, self.device_
+        in_channels, out_channels, num_layers, qk_norm = c.in_channels, c.out_channels, c.num_layers, c.qk_norm
+        joint_attention_dim, pooled_projection_dim = c.joint_attention_dim, c.pooled_projection_dim
 
         def lin(name, out_f, in_f):
             w, b = e(out_f, in_f), e(out_f)
-            _attach(self, name + ".weight", _frozen(w)); _attach(self, name + ".bias", _frozen(b))
+            self._reg(name + ".weight", _frozen(w)); self._reg(name + ".bias", _frozen(b))
             return SimpleNamespace(w=w, b=b, wT=None, lora=None)
 
         # PatchEmbed: the Conv2d weight keeps its checkpoint shape; the GEMM reads it as [D, C*p*p]
         conv_w, conv_b = e(D, in_channels, 2, 2), e(D)
-        _attach(self, "pos_embed.proj.weight", _frozen(conv_w)); _attach(self, "pos_embed.proj.bias", _frozen(conv_b))
+        self._reg("pos_embed.proj.weight", _frozen(conv_w)); self._reg("pos_embed.proj.bias", _frozen(conv_b))
         self.l_patch = SimpleNamespace(w=conv_w.view(D, 4 * in_channels), b=conv_b)
-        if not hasattr(self, "pos_embed"):
-            raise RuntimeError("pos_embed holder missing")
-        self.pos_embed.register_buffer("pos_embed", torch.zeros(1, pos_embed_max_size * pos_embed_max_size, D, dtype=F32, device=dev))
         self.l_t1 = lin("time_text_embed.timestep_embedder.linear_1", D, 256)
         self.l_t2 = lin("time_text_embed.timestep_embedder.linear_2", D, D)
         self.l_p1 = lin("time_text_embed.text_embedder.linear_1", D, pooled_projection_dim)
@@ -100,7 +140,7 @@ class SD3Transformer2DModel(nn.Module):
 
         def mod_slice(name, n):
             nonlocal off
-            _attach(self, name + ".weight", _frozen(self.mod_w[off:off + n])); _attach(self, name + ".bias", _frozen(self.mod_b[off:off + n]))
+            self._reg(name + ".weight", _frozen(self.mod_w[off:off + n])); self._reg(name + ".bias", _frozen(self.mod_b[off:off + n]))
             o = off
             off += n
             return o
@@ -109,15 +149,17 @@ class SD3Transformer2DModel(nn.Module):
             n = len(names)
             w, b = e(n * out_each, in_f), e(n * out_each)
             for j, nm in enumerate(names):
-                _attach(self, f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
-                _attach(self, f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
+                self._reg(f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
+                self._reg(f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
             return SimpleNamespace(w=w, b=b, wT=None, lora=None)
 
         def normw(name):
             if qk_norm is None:
                 return None
-            w = torch.ones(self.hd, dtype=BF16, device=dev)
-            _attach(self, name + ".weight", _frozen(w))
+            w = e(self.hd)
+            if not self._counting:
+                w.fill_(1.0)
+            self._reg(name + ".weight", _frozen(w))
             return w
 
         self.blocks: List[SimpleNamespace] = []
@@ -141,16 +183,6 @@ class SD3Transformer2DModel(nn.Module):
         assert off == self.mod_total
         self.l_out = lin("proj_out", 4 * out_channels, D)
 
-        self.lora_groups: List[LoraGroup] = []
-        self.lora_flat: Optional[torch.Tensor] = None
-        self.lora_grad_flat: Optional[torch.Tensor] = None
-        self._lora_params: List[nn.Parameter] = []
-        self._cache: Dict = {}
-        self._prepared = False
-        self.accumulate_lora_grads = False
-        self.gradient_checkpointing = False
-        self.grad_sync = None
-        self._last_grad_flat = None
 
     # ------------------------------------------------------------------------------------------------
     # weights
@@ -247,9 +279,6 @@ class SD3Transformer2DModel(nn.Module):
             self._lora_params += [pa, pb]
         return self._lora_params
 
-    def trainable_parameters(self):
-        return list(self._lora_params)
-
     # ------------------------------------------------------------------------------------------------
     def _tables(self, h: int, w: int, S: int, B: int):
         """cropped position table expanded over the batch ([B*h*w, D] bf16) and identity RoPE tables (SD3 has no RoPE)"""
@@ -267,7 +296,7 @@ class SD3Transformer2DModel(nn.Module):
             self._cache[key] = hit
         return hit
 
-    def _engine_forward(self, latents, enc, pooled, timestep, save: bool):
+    def _engine_forward(self, latents, enc, pooled, timestep, save: bool, full: bool = False):
         D, H, hd = self.D, self.H, self.hd
         B, C, Hh, Ww = latents.shape
         h, w = Hh // 2, Ww // 2
@@ -279,14 +308,22 @@ class SD3Transformer2DModel(nn.Module):
             g.pack()
         pos, cos, sin = self._tables(h, w, S, B)
         # ---- embeddings (sd3/transformer.py:623-700) ----
-        img = ops.gemm(ops.patchify(latents, order=0).view(B * Si, 4 * C), self.l_patch.w, bias=self.l_patch.b, epilogue=EPI_ADD, aux_in=pos)
-        txt = ops.gemm(enc.reshape(B * St, -1).contiguous(), self.l_ctx.w, bias=self.l_ctx.b)
+        patches = ops.patchify(latents, order=0).view(B * Si, 4 * C)
+        img = ops.gemm(patches, self.l_patch.w, bias=self.l_patch.b, epilogue=EPI_ADD, aux_in=pos)
+        enc2d = enc.reshape(B * St, -1).contiguous()
+        txt = ops.gemm(enc2d, self.l_ctx.w, bias=self.l_ctx.b)
         t32 = timestep.to(device=dev, dtype=F32).contiguous()
-        temb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(t32, 256, 1.0), self.l_t1.w, bias=self.l_t1.b)), self.l_t2.w, bias=self.l_t2.b)
-        pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
-        temb = ops.add(temb, pemb)
-        mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)
+        tproj = ops.timestep_proj(t32, 256, 1.0)
+        t1 = ops.gemm(tproj, self.l_t1.w, bias=self.l_t1.b); st1 = ops.silu(t1)
+        pooled_b = pooled.to(BF16).contiguous()
+        p1 = ops.gemm(pooled_b, self.l_p1.w, bias=self.l_p1.b); sp1 = ops.silu(p1)
+        temb = ops.add(ops.gemm(st1, self.l_t2.w, bias=self.l_t2.b), ops.gemm(sp1, self.l_p2.w, bias=self.l_p2.b))
+        st = ops.silu(temb)
+        mod = ops.gemm(st, self.mod_w, bias=self.mod_b)
         ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, blocks=[], C=C, Hh=Hh, Ww=Ww)
+        if full and save:
+            ctx.emb = SimpleNamespace(patches=patches, enc2d=enc2d, tproj=tproj, t1=t1, st1=st1, pooled=pooled_b, p1=p1, sp1=sp1, temb=temb, st=st)
+        ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
         scale = 1.0 / math.sqrt(hd)
         for blk in self.blocks:
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
@@ -320,41 +357,53 @@ class SD3Transformer2DModel(nn.Module):
             T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
             T_ao = (torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev)
                     if (not blk.last and blk.to_add_out.lora is not None) else None)
+            ya_i, ya_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
             probs = []
             for b in range(B):
                 O_i, O_t = O[b * S:b * S + Si], O[b * S + Si:(b + 1) * S]
                 kw_i, kw_t = {}, {}
+                if ya_i is not None:
+                    kw_i["aux_out"] = ya_i[b * Si:(b + 1) * Si]
+                if ya_t is not None:
+                    kw_t["aux_out"] = ya_t[b * St:(b + 1) * St]
                 if T_o is not None:
                     ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
-                    kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
+                    kw_i.update(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
                 probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
                                   aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
                 if not blk.last:
                     if T_ao is not None:
                         ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
-                        kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
+                        kw_t.update(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
                     probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St],
                                       epilogue=EPI_GATE_RESIDUAL, aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D],
                                       rows_per_batch=St, **kw_t))
             ops.gemm_grouped(probs)
             n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
             hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
-            hpre_txt = x2_txt = None
+            hpre_txt = x2_txt = n2_t = h_t = None
+            yf_i, yf_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
+            kf_i = dict(aux_out=yf_i) if yf_i is not None else {}
+            kf_t = dict(aux_out=yf_t) if yf_t is not None else {}
             if blk.last:
                 h_i = ops.gemm(n2_i, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
-                x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si)
+                x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D],
+                                  rows_per_batch=Si, **kf_i)
             else:
                 n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
                 hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
                 h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
                                              dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
                 x2_img, x2_txt = ops.gemm_grouped([
-                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
-                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
+                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
             if save:
-                ctx.blocks.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
-                                                  Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
-                                                  hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
+                sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K,
+                                     Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
+                                     hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
+                if full:    # a full fine-tune also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
+                    sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
+                ctx.blocks.append(sv)
             img, txt = x2_img, x2_txt
         # ---- output head: AdaLayerNormContinuous (scale, shift), proj_out, unpatchify "nhwpqc->nchpwq" ----
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
@@ -362,6 +411,8 @@ class SD3Transformer2DModel(nn.Module):
         out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
         if save:
             ctx.x_img_final = img
+            if full:
+                ctx.n_out = n_out
         return ops.unpatchify(out.view(B, Si, -1), self.out_channels, Hh, Ww, order=1), ctx
 
     def _engine_backward(self, ctx, dout):
@@ -450,6 +501,193 @@ class SD3Transformer2DModel(nn.Module):
         return None
 
     # ------------------------------------------------------------------------------------------------
+    # full fine-tune (BASELINE.json configs[3]): every weight, bias and modulation row trains
+    # ------------------------------------------------------------------------------------------------
+    def _all_linears(self):
+        ls = [self.l_patch, self.l_t1, self.l_t2, self.l_p1, self.l_p2, self.l_ctx, self.l_out]
+        for blk in self.blocks:
+            ls += [l for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2) if l is not None]
+        return ls
+
+    def enable_full_finetune(self):
+        """gradient arena with the weight arena's layout; every base parameter becomes trainable (bf16 params, bf16 grads)"""
+        if self.config.qk_norm is not None:
+            raise NotImplementedError("full fine-tune with q/k RMSNorm weights is not built yet (SD3-Medium has none)")
+        if self.lora_groups:
+            raise RuntimeError("full fine-tune and LoRA adapters are exclusive")
+        self.full = True
+        self.grad_arena = torch.zeros_like(self.arena)
+        base = self.arena.data_ptr()
+
+        def gview(t):
+            off = (t.data_ptr() - base) // 2
+            return self.grad_arena[off:off + t.numel()].view(t.shape)
+
+        for l in self._all_linears():
+            l.gw, l.gb = gview(l.w), gview(l.b)
+        self.g_mod_w, self.g_mod_b = gview(self.mod_w), gview(self.mod_b)
+        ps = sorted([p for n, p in self.named_parameters() if ".lora_" not in n], key=lambda p: p.data_ptr())
+        for p in ps:
+            p.requires_grad_(True)
+        self._full_params = ps
+        self._full_offsets = [((p.data_ptr() - base) // 2, p.numel()) for p in ps]
+        self.prepare_for_training()
+        for l in (self.l_t2, self.l_p2):
+            l.wT = l.w.t().contiguous()
+        return ps
+
+    def trainable_parameters(self):
+        return list(self._full_params) if getattr(self, "full", False) else list(self._lora_params)
+
+    def _refresh_transposed(self):
+        """W^T follows the weights (2 B read + 2 B write per parameter; ~1 ms for SD3-Medium)"""
+        for l in self._all_linears():
+            if getattr(l, "wT", None) is not None:
+                ops.transpose(l.w, out=l.wT)
+
+    def _engine_backward_full(self, ctx, dout):
+        D, H, hd = self.D, self.H, self.hd
+        B, Si, St, S, Sp, mod, cos, sin = ctx.B, ctx.Si, ctx.St, ctx.S, ctx.Sp, ctx.mod, ctx.cos, ctx.sin
+        dev = self.device_
+        scale = 1.0 / math.sqrt(hd)
+        self._refresh_transposed()
+        dmod = torch.zeros(B, self.mod_total, dtype=F32, device=dev)        # d loss / d (modulation linear output)
+        tmp_b = {}
+
+        def P64(t):
+            """zero-padded copy with a multiple of 64 rows (the TN GEMM's contraction granule); no copy when already aligned"""
+            r = t.shape[0]
+            if r % 64 == 0 and t.is_contiguous():
+                return t
+            o = torch.zeros((r + 63) // 64 * 64, t.shape[1], dtype=BF16, device=dev)
+            o[:r] = t
+            return o
+
+        def wgrad(lin, dy, x):
+            """dW = dY^T X ; db = colsum(dY)   (into the gradient arena views of `lin`)"""
+            ops.gemm_tn(P64(dy), P64(x), out=lin.gw)
+            N = dy.shape[1]
+            t = tmp_b.get(N)
+            if t is None:
+                t = tmp_b[N] = torch.empty(1, N, dtype=F32, device=dev)
+            ops.colsum_prod(dy, t)
+            lin.gb.copy_(t[0])
+
+        def mod_grads(dn, n_saved, m, rows, k_shift, k_scale, dm):
+            """d shift / d scale of one AdaLN instance (chunk indices k_* inside its modulation slice m / dm)"""
+            dsh = dm[:, k_shift * D:(k_shift + 1) * D]
+            ops.colsum_prod(dn, dsh, rows_per_batch=rows)
+            ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=n_saved, rows_per_batch=rows, mode=1, prev=dsh,
+                            shift=m[:, k_shift * D:(k_shift + 1) * D], scale=m[:, k_scale * D:(k_scale + 1) * D])
+
+        def rows_of(t, lo, n):                       # rows [lo, lo+n) of every batch element of a joint [B*S, C] buffer, contiguous
+            return t[lo:lo + n] if B == 1 else t.view(B, S, -1)[:, lo:lo + n].reshape(B * n, -1)
+
+        # ---- head ----
+        dpk = ops.patchify(dout.to(BF16).contiguous(), order=1).view(B * Si, -1)
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        dmo = dmod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        wgrad(self.l_out, dpk, ctx.n_out)
+        dn = ops.gemm(dpk, self.l_out.wT)
+        mod_grads(dn, ctx.n_out, mo, Si, 1, 0, dmo)                        # AdaLayerNormContinuous: (scale, shift)
+        d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
+        d_txt = None
+        del dn, dpk
+        for li in range(len(self.blocks) - 1, -1, -1):
+            blk, sv = self.blocks[li], ctx.blocks[li]
+            ctx.blocks[li] = None
+            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; dmi = dmod[:, blk.mod_off:blk.mod_off + 6 * D]
+            nct = 2 if blk.last else 6
+            mt = mod[:, blk.mod_off_c:blk.mod_off_c + nct * D]; dmt = dmod[:, blk.mod_off_c:blk.mod_off_c + nct * D]
+            # ---- MLP branch ----
+            ops.colsum_prod(d_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)           # d gate_mlp
+            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)
+            wgrad(blk.ff2, g_i, sv.h_i)
+            dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
+            wgrad(blk.ff1, dh_i, sv.n2_i)
+            dn2_i = ops.gemm(dh_i, blk.ff1.wT)
+            mod_grads(dn2_i, sv.n2_i, mi, Si, 3, 4, dmi)
+            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+            ops.colsum_prod(dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)           # d gate_msa
+            del g_i, dh_i, dn2_i
+            dx1_t = dx1g_t = None
+            if not blk.last:
+                ops.colsum_prod(d_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
+                g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+                wgrad(blk.ffc2, g_t, sv.h_t)
+                dh_t = ops.gemm(g_t, blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)
+                wgrad(blk.ffc1, dh_t, sv.n2_t)
+                dn2_t = ops.gemm(dh_t, blk.ffc1.wT)
+                mod_grads(dn2_t, sv.n2_t, mt, St, 3, 4, dmt)
+                dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
+                ops.colsum_prod(dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
+                del g_t, dh_t, dn2_t
+            # ---- attention output projections ----
+            O_i = rows_of(sv.O, 0, Si)
+            wgrad(blk.to_out, dx1g_i, O_i)
+            dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
+            probs = []
+            for b in range(B):
+                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S:b * S + Si]))
+                if not blk.last:
+                    probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S + Si:(b + 1) * S]))
+            ops.gemm_grouped(probs)
+            if not blk.last:
+                wgrad(blk.to_add_out, dx1g_t, rows_of(sv.O, Si, St))
+            del dx1g_i, dx1g_t, O_i
+            # ---- attention ----
+            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
+            ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, 0, S)
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, Si, S)
+            del dQ, dK, dO
+            dq_i, dq_t = rows_of(dqkv, 0, Si), rows_of(dqkv, Si, St)
+            wgrad(blk.qkv, dq_i, sv.n_img)
+            wgrad(blk.add_qkv, dq_t, sv.n_txt)
+            dn_i, dn_t = ops.gemm_grouped([dict(a=dq_i, w=blk.qkv.wT), dict(a=dq_t, w=blk.add_qkv.wT)])
+            mod_grads(dn_i, sv.n_img, mi, Si, 0, 1, dmi)
+            d_img, _ = ops.ln_modulate_bwd(dn_i, sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+            if blk.last:
+                mod_grads(dn_t, sv.n_txt, mt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
+                d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, :D], St, dres=None)
+            else:
+                mod_grads(dn_t, sv.n_txt, mt, St, 0, 1, dmt)
+                d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
+            del dqkv, sv, dn_i, dn_t, dq_i, dq_t
+        # ---- embedders ----
+        em = ctx.emb
+        wgrad(self.l_patch, d_img, em.patches)                              # PatchEmbed conv == GEMM on the patches; the position table is a buffer
+        wgrad(self.l_ctx, d_txt, em.enc2d)
+        # modulation linear: mod = silu(temb) W_mod^T + b
+        Bp = (B + 63) // 64 * 64
+        dmod_p = torch.zeros(Bp, self.mod_total, dtype=BF16, device=dev); dmod_p[:B] = dmod
+        st_p = torch.zeros(Bp, D, dtype=BF16, device=dev); st_p[:B] = em.st
+        ops.gemm_tn(dmod_p, st_p, out=self.g_mod_w)
+        tb = torch.empty(1, self.mod_total, dtype=F32, device=dev)
+        ops.colsum_prod(dmod_p, tb)
+        self.g_mod_b.copy_(tb[0])
+        dmod_t = ops.transpose(dmod_p[:8 * ((B + 7) // 8)])                 # [mod_total, B8]
+        dst = ops.transpose(ops.gemm_tn(self.mod_w, dmod_t))[:B].contiguous()   # d silu(temb) = dmod @ W_mod  ->  [B, D]
+        dtemb = ops.silu_bwd(em.temb, dst)
+
+        def mlp_bwd(l1, l2, x_in, pre1, act1, dy):
+            """TimestepEmbedding / text projection: y = l2(silu(l1(x)))"""
+            dyp = torch.zeros(Bp, dy.shape[1], dtype=BF16, device=dev); dyp[:B] = dy
+            a1p = torch.zeros(Bp, act1.shape[1], dtype=BF16, device=dev); a1p[:B] = act1
+            ops.gemm_tn(dyp, a1p, out=l2.gw)
+            tb2 = torch.empty(1, dy.shape[1], dtype=F32, device=dev); ops.colsum_prod(dyp, tb2); l2.gb.copy_(tb2[0])
+            d1 = ops.silu_bwd(pre1, ops.gemm(dy, l2.wT))
+            d1p = torch.zeros(Bp, d1.shape[1], dtype=BF16, device=dev); d1p[:B] = d1
+            xp = torch.zeros(Bp, x_in.shape[1], dtype=BF16, device=dev); xp[:B] = x_in
+            ops.gemm_tn(d1p, xp, out=l1.gw)
+            ops.colsum_prod(d1p, tb2); l1.gb.copy_(tb2[0])
+
+        mlp_bwd(self.l_t1, self.l_t2, em.tproj, em.t1, em.st1, dtemb)
+        mlp_bwd(self.l_p1, self.l_p2, em.pooled, em.p1, em.sp1, dtemb)
+        return None
+
+    # ------------------------------------------------------------------------------------------------
     # public forward (reference signature: sd3/transformer.py:560-575)
     # ------------------------------------------------------------------------------------------------
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, block_controlnet_hidden_states=None,
@@ -461,8 +699,10 @@ class SD3Transformer2DModel(nn.Module):
                 raise NotImplementedError(f"SD3Transformer2DModel(st355): argument {k!r} is not supported on the HIP path")
         if timestep.ndim != 1:
             raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
-        need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
-        if need_grad:
+        need_grad = torch.is_grad_enabled() and (len(self._lora_params) > 0 or getattr(self, "full", False))
+        if need_grad and getattr(self, "full", False):
+            out = _SD3FullFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, *self._full_params)
+        elif need_grad:
             out = _SD3Fn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, *self._lora_params)
         else:
             with torch.no_grad():
@@ -497,4 +737,24 @@ class _SD3Fn(torch.autograd.Function):
             n = p.numel()
             grads.append(gflat[off:off + n].view_as(p))
             off += n
+        return (None,) * 5 + tuple(grads)
+
+
+class _SD3FullFn(torch.autograd.Function):
+    """full fine-tune: one autograd node; backward fills the bf16 gradient arena and hands autograd views of a private copy"""
+
+    @staticmethod
+    def forward(fctx, model, latents, enc, pooled, timestep, *params):
+        out, ctx = model._engine_forward(latents.detach().to(BF16), enc.detach().to(BF16), pooled.detach(), timestep.detach(), save=True, full=True)
+        fctx.model, fctx.ectx = model, ctx
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        model._engine_backward_full(fctx.ectx, dout)
+        fctx.ectx = None
+        gflat = model.grad_arena.clone()
+        model._last_grad_flat = gflat
+        grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]
         return (None,) * 5 + tuple(grads)

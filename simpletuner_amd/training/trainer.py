@@ -67,7 +67,9 @@ class Trainer:
         self.accelerator = accelerator or model_plugin.accelerator
         self.model = model_plugin
         comp = self.model.get_trained_component()
-        self.params = [p for p in comp.parameters() if p.requires_grad]
+        # arena order when the component exposes it (fused one-launch optimizer step), else registration order
+        self.params = (comp.trainable_parameters() if hasattr(comp, "trainable_parameters")
+                       else [p for p in comp.parameters() if p.requires_grad])
         self.optimizer = St355AdamW(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
                                     eps=config.adam_epsilon, weight_decay=config.adam_weight_decay)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda) if lr_lambda else None
