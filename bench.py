@@ -57,6 +57,8 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="flux", choices=["flux", "sd3"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
+    ap.add_argument("--full", action="store_true", help="sd3 only: full fine-tune (every parameter trains, bf16 AdamW arena) + EMA — BASELINE configs[3]")
+    ap.add_argument("--optimizer", default="st355-adamw", choices=["st355-adamw", "adamw_bf16"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -130,7 +132,9 @@ def main():
     from simpletuner_amd import ops
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
-    cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3)
+    cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3,
+                         model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
+                         learning_rate=1e-5 if args.full else 1e-4)
     acc = St355Accelerator(dev)
     if args.model == "flux":
         from simpletuner_amd.flux.model import Flux
@@ -148,7 +152,13 @@ def main():
         n_blocks, D_model, S_txt, txt_dim, pooled_dim = n_l, 1536, 231, 4096, 2048
         desc = (f"SD3-Medium MMDiT ({n_l} joint blocks, D=1536, 24x64 heads) LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0, "
                 f"{args.res}^2 (S=4096+231), AdamW, random-init weights")
-    plugin.add_lora_adapter()
+    if args.full:
+        if args.model != "sd3":
+            raise SystemExit("--full is wired for --model sd3 only")
+        plugin.enable_full_finetune()
+        desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", "FULL fine-tune (2.0 B bf16 params) + EMA")
+    else:
+        plugin.add_lora_adapter()
     trainer = Trainer(cfg, plugin, acc)
 
     lat = args.res // 8
@@ -194,6 +204,8 @@ def main():
     if rank == 0:
         S_img = (lat // 2) ** 2
         step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
+        if args.full:        # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
+            step_flops = 3.0 * (n_blocks * 2.0 * (S_img + S_txt) * 12 * D_model * D_model + n_blocks * 4.0 * (S_img + S_txt) ** 2 * D_model) * B
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         roof = None

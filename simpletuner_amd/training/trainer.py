@@ -23,7 +23,7 @@ from .. import ops
 from .ema import EMAModel
 from .grad_sync import GradSync
 from .multi_process import gather_sample_weighted_scalar
-from .optimizer import St355AdamW
+from .optimizer import OPTIMIZER_CHOICE, St355AdamW, St355AdamWBF16
 
 
 class St355Accelerator:
@@ -70,8 +70,14 @@ class Trainer:
         # arena order when the component exposes it (fused one-launch optimizer step), else registration order
         self.params = (comp.trainable_parameters() if hasattr(comp, "trainable_parameters")
                        else [p for p in comp.parameters() if p.requires_grad])
-        self.optimizer = St355AdamW(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
-                                    eps=config.adam_epsilon, weight_decay=config.adam_weight_decay)
+        # optimizer_param.py:76-96 registry semantics: name -> class (+ default settings)
+        if getattr(config, "optimizer", "st355-adamw") == "adamw_bf16":
+            self.optimizer = St355AdamWBF16(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
+                                            eps=OPTIMIZER_CHOICE["adamw_bf16"]["default_settings"]["eps"], weight_decay=config.adam_weight_decay,
+                                            seed=int(getattr(config, "seed", 0) or 0))
+        else:
+            self.optimizer = St355AdamW(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
+                                        eps=config.adam_epsilon, weight_decay=config.adam_weight_decay)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda) if lr_lambda else None
         self.ema_model = None
         if getattr(config, "use_ema", False):
