@@ -59,6 +59,9 @@ def parse():
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
     ap.add_argument("--full", action="store_true", help="sd3 only: full fine-tune (every parameter trains, bf16 AdamW arena) + EMA — BASELINE configs[3]")
     ap.add_argument("--optimizer", default="st355-adamw", choices=["st355-adamw", "adamw_bf16"])
+    ap.add_argument("--buckets", action="store_true",
+                    help="sd3: cycle the mixed aspect buckets of SURVEY.md §8(d) (latents 128x128, 96x168, 168x96, 112x144, 144x112), one bucket "
+                         "per step, each rank starting at a different one (BASELINE configs[3])")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -165,13 +168,23 @@ def main():
     B = args.batch
     torch.manual_seed(42 + rank)              # sigma sampling draws from the global device generator (examples' `seed: 42`)
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
-    def make_batch():
+    def make_batch(hh=None, ww=None):
+        hh, ww = hh or lat, ww or lat
         return {
-            "latent_batch": torch.randn(B, 16, lat, lat, device=dev, generator=gen).to(torch.bfloat16),
+            "latent_batch": torch.randn(B, 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
             "prompt_embeds": torch.randn(B, S_txt, txt_dim, device=dev, generator=gen).to(torch.bfloat16),
             "add_text_embeds": torch.randn(B, pooled_dim, device=dev, generator=gen).to(torch.bfloat16),
         }
-    batches = [make_batch() for _ in range(2)]   # resident in HBM before the timed region
+    if args.buckets:
+        if args.model != "sd3":
+            raise SystemExit("--buckets is wired for --model sd3 only (Flux bench keeps the single 1024^2 bucket of configs[2])")
+        shapes = [(128, 128), (96, 168), (168, 96), (112, 144), (144, 112)]
+        shapes = shapes[rank % 5:] + shapes[:rank % 5]
+        batches = [make_batch(h_, w_) for (h_, w_) in shapes]
+        desc += "; mixed aspect buckets " + ",".join(f"{h_}x{w_}" for h_, w_ in shapes) + " (latent), one per step"
+    else:
+        batches = [make_batch() for _ in range(2)]   # resident in HBM before the timed region
+    nb_ = len(batches)
 
     def sync():
         if world > 1:
@@ -179,13 +192,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        trainer.train_step(dict(batches[i % 2]))
+        trainer.train_step(dict(batches[i % nb_]))
     sync()
     if not args.no_prof:
         ops.prof_reset(); ops.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.train_step(dict(batches[i % 2]))
+        loss = trainer.train_step(dict(batches[i % nb_]))
     sync()
     elapsed = time.perf_counter() - t0
     prof = None
@@ -225,7 +238,8 @@ def main():
                            "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
                        for k, v in prof.items() if v["launches"]}
         out = {
-            "metric": f"training images/sec (whole node), {'Flux.1-dev' if args.model == 'flux' else 'SD3-Medium'} LoRA r{args.rank} {args.res}^2 train step",
+            "metric": f"training images/sec (whole node), {'Flux.1-dev' if args.model == 'flux' else 'SD3-Medium'} "
+                      f"{'full fine-tune + EMA' if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

@@ -163,9 +163,10 @@ class SD3Transformer2DModel(nn.Module):
             return w
 
         self.blocks: List[SimpleNamespace] = []
+        self._blocks_arena_lo = self._arena_numel
         for i in range(num_layers):
             p = f"transformer_blocks.{i}."
-            blk = SimpleNamespace(last=(i == num_layers - 1))
+            blk = SimpleNamespace(last=(i == num_layers - 1), arena_lo=self._arena_numel)
             blk.mod_off = mod_slice(p + "norm1.linear", 6 * D)
             blk.mod_off_c = mod_slice(p + "norm1_context.linear", (2 if blk.last else 6) * D)
             blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
@@ -178,9 +179,11 @@ class SD3Transformer2DModel(nn.Module):
             blk.ff2 = fused(p, ["ff.net.2"], D, 4 * D)
             blk.ffc1 = None if blk.last else fused(p, ["ff_context.net.0.proj"], 4 * D, D)
             blk.ffc2 = None if blk.last else fused(p, ["ff_context.net.2"], D, 4 * D)
+            blk.arena_hi = self._arena_numel
             self.blocks.append(blk)
         self.mod_off_out = mod_slice("norm_out.linear", 2 * D)
         assert off == self.mod_total
+        self._head_arena_lo = self._arena_numel
         self.l_out = lin("proj_out", 4 * out_channels, D)
 
 
@@ -593,9 +596,15 @@ class SD3Transformer2DModel(nn.Module):
         d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
         d_txt = None
         del dn, dpk
+        sync = self.grad_sync
+        if sync is not None:
+            sync.ready(self._head_arena_lo, self.grad_arena.numel())        # proj_out gradients are final
         for li in range(len(self.blocks) - 1, -1, -1):
             blk, sv = self.blocks[li], ctx.blocks[li]
             ctx.blocks[li] = None
+            if sync is not None and li + 1 < len(self.blocks):
+                nb = self.blocks[li + 1]
+                sync.ready(nb.arena_lo, nb.arena_hi)                          # the block processed last iteration: its slice can go out
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; dmi = dmod[:, blk.mod_off:blk.mod_off + 6 * D]
             nct = 2 if blk.last else 6
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + nct * D]; dmt = dmod[:, blk.mod_off_c:blk.mod_off_c + nct * D]
@@ -685,6 +694,8 @@ class SD3Transformer2DModel(nn.Module):
 
         mlp_bwd(self.l_t1, self.l_t2, em.tproj, em.t1, em.st1, dtemb)
         mlp_bwd(self.l_p1, self.l_p2, em.pooled, em.p1, em.sp1, dtemb)
+        if sync is not None:
+            sync.ready(0, self.blocks[0].arena_hi)                            # embedders, modulation matrix, block 0
         return None
 
     # ------------------------------------------------------------------------------------------------
@@ -752,8 +763,12 @@ class _SD3FullFn(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dout):
         model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
         model._engine_backward_full(fctx.ectx, dout)
         fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_scale_from_sync = model.grad_sync.finish()   # every slice reduced (SUM over replicas); the optimizer folds 1/world
         gflat = model.grad_arena.clone()
         model._last_grad_flat = gflat
         grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]

@@ -83,8 +83,12 @@ class Trainer:
         if getattr(config, "use_ema", False):
             self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)
         self._overlapped_sync = config.gradient_accumulation_steps == 1
-        if self.accelerator.num_processes > 1 and getattr(comp, "lora_grad_flat", None) is not None and self._overlapped_sync:
-            comp.grad_sync = GradSync(comp.lora_grad_flat)      # replicas: bucketed all-reduce overlapped with backward
+        if self.accelerator.num_processes > 1 and self._overlapped_sync:
+            # replicas: bucketed all-reduce of the flat gradient arena, overlapped with the hand-written backward
+            if getattr(comp, "full", False) and getattr(comp, "grad_arena", None) is not None:
+                comp.grad_sync = GradSync(comp.grad_arena, bucket_bytes=128 << 20)
+            elif getattr(comp, "lora_grad_flat", None) is not None:
+                comp.grad_sync = GradSync(comp.lora_grad_flat)
         self.state = {"global_step": 0, "micro_step": 0}
         self.last_loss = None          # device scalar, no host sync
         self.last_grad_norm = None
