@@ -69,6 +69,11 @@ int st355_ddpm_noise_mix(void* stream, const void* x, const void* noise, const f
 int st355_mse_loss(void* stream, const void* pred, const void* target, const float* weight,
                    float* loss_out, float* per_sample_out, void* dpred,
                    int64_t batch, int64_t per_sample, float grad_scale);
+/* conditional_loss (common.py:6132-6166) with reduction "none" -> per-sample mean -> batch mean (common.py:6426-6429).
+ * loss_type 0 = l2 (== st355_mse_loss), 1 = huber 2c(sqrt(d^2+c^2)-c), 2 = smooth_l1 2(sqrt(d^2+c^2)-c); huber_c fp32 [B] (scheduled
+ * huber gives one c per sample, common.py:6252-6272; constant = the same value B times); weight as in st355_mse_loss. */
+int st355_cond_loss(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
+                    float* loss_out, float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale);
 
 /* ---- K3: Flux 2x2 pack / unpack (flux/__init__.py:25-45) ------------------------------------ */
 int st355_flux_pack(void* stream, const void* latents /*[B,C,H,W]*/, void* packed /*[B,(H/2)(W/2),4C]*/,

@@ -11,6 +11,8 @@ AdamW against torch.optim.AdamW itself.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 
@@ -125,3 +127,56 @@ def adamw_bf16_step(p, g, m, v, shift, step: int, lr: float, beta1: float, beta2
         else:
             shift2 = (shift2.to(f) + a32 * p_new.to(f)).to(bf)
     return p_new, m_new, v_new, shift2
+
+
+# ------------------------------------------------------------------------------------------------
+# loss variants and SNR helpers
+# ------------------------------------------------------------------------------------------------
+def conditional_loss_elementwise(pred, target, loss_type: str = "l2", huber_c=0.1):
+    """ModelFoundation.conditional_loss with reduction='none' (common.py:6132-6166); huber_c may be a per-sample tensor [B] (scheduled)"""
+    d2 = (pred.float() - target.float()) ** 2
+    if loss_type == "l2":
+        return d2
+    c = huber_c if not torch.is_tensor(huber_c) else huber_c.float().view(-1, *([1] * (pred.dim() - 1)))
+    root = torch.sqrt(d2 + c ** 2) - c
+    if loss_type == "huber":
+        return 2 * c * root
+    if loss_type == "smooth_l1":
+        return 2 * root
+    raise NotImplementedError(loss_type)
+
+
+def conditional_loss(pred, target, loss_type: str = "l2", huber_c=0.1, weight=None):
+    """element loss -> [x per-sample weight] -> mean over CHW -> mean over the batch (common.py:6397-6398, 6426-6429)"""
+    el = conditional_loss_elementwise(pred, target, loss_type, huber_c)
+    if weight is not None:
+        el = el * weight.float().view(-1, *([1] * (pred.dim() - 1)))
+    per = el.mean(dim=list(range(1, el.dim())))
+    return per.mean(), per
+
+
+def scheduled_huber_c(timesteps, schedule: str, base_c: float, flow_matching: bool, num_train_timesteps: int = 1000, alphas_cumprod=None):
+    """ModelFoundation.compute_scheduled_huber_c (common.py:6168-6216)"""
+    if schedule == "constant":
+        return torch.full_like(timesteps.float(), base_c)
+    if schedule == "exponential":
+        alpha = -math.log(base_c) / num_train_timesteps
+        return torch.exp(-alpha * timesteps.float())
+    if schedule == "snr":
+        if flow_matching:
+            s = timesteps.float() / 1000
+            s = ((1.0 - s) / (s + 0.0001)) ** 0.5
+        else:
+            a = alphas_cumprod[timesteps.long()]
+            s = ((1.0 - a) / a) ** 0.5
+        return (1 - base_c) / (1 + s) ** 2 + base_c
+    raise NotImplementedError(schedule)
+
+
+def compute_snr(timesteps, alphas_cumprod, use_soft_min: bool = False, sigma_data: float = 1.0):
+    """min_snr_gamma.py:4-46: (alpha/sigma)^2 with alpha = sqrt(acp[t]), sigma = sqrt(1 - acp[t]); soft-min variant"""
+    alpha = (alphas_cumprod ** 0.5)[timesteps.long()].float()
+    sigma = ((1.0 - alphas_cumprod) ** 0.5)[timesteps.long()].float()
+    if use_soft_min:
+        return (sigma * sigma_data) ** 2 / (sigma ** 2 + sigma_data ** 2) ** 2
+    return (alpha / sigma) ** 2

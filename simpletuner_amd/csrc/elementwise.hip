@@ -176,6 +176,68 @@ extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target
   return st355_check_launch("mse_loss");
 }
 
+// ---- K13b: conditional_loss (common.py:6132-6166): l2 | huber | smooth_l1, reduction "none" -> per-sample mean -> batch mean --------
+//   huber:     2c (sqrt(d^2 + c^2) - c)        d/dpred = 2c d / sqrt(d^2 + c^2)
+//   smooth_l1: 2  (sqrt(d^2 + c^2) - c)        d/dpred = 2  d / sqrt(d^2 + c^2)
+// huber_c is per sample (scheduled huber, common.py:6252-6272) or one value broadcast by the host; weight[b] as in st355_mse_loss.
+template <int TYPE>
+__global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict__ pred, const bf16* __restrict__ target,
+                                                         const float* __restrict__ weight, const float* __restrict__ huber_c,
+                                                         float* __restrict__ per_sample_acc, bf16* __restrict__ dpred,
+                                                         int64_t per_sample, float dscale) {
+  const int b = blockIdx.y;
+  const float w = weight ? weight[b] : 1.0f;
+  const float c = huber_c[b], c2 = c * c;
+  const float k = (TYPE == 1) ? 2.f * c : 2.f;
+  const int64_t vecs = per_sample >> 3;
+  const bf16* p = pred + (int64_t)b * per_sample;
+  const bf16* t = target + (int64_t)b * per_sample;
+  bf16* d = dpred ? dpred + (int64_t)b * per_sample : nullptr;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (int64_t)gridDim.x * blockDim.x) {
+    bf16x8 pv = *(const bf16x8*)(p + i * 8);
+    bf16x8 tv = *(const bf16x8*)(t + i * 8);
+    bf16x8 dv;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float df = bf2f(pv[j]) - bf2f(tv[j]);
+      const float r = sqrtf(df * df + c2);
+      acc += k * (r - c);
+      dv[j] = f2bf(0.5f * dscale * w * k * df / r);      // dscale carries the 2/(n B) of the l2 convention: undo the 2
+    }
+    if (d) *(bf16x8*)(d + i * 8) = dv;
+  }
+  acc = wave_sum(acc);
+  __shared__ float red[EW_THREADS / WAVE];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < EW_THREADS / WAVE; i++) s += red[i];
+    atomicAdd(&per_sample_acc[b], s * w);
+  }
+}
+extern "C" int st355_cond_loss(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
+                               float* loss_out, float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
+  if (loss_type == 0) return st355_mse_loss(stream, pred, target, weight, loss_out, per_sample_out, dpred, batch, per_sample, grad_scale);
+  ST_REQUIRE(pred && target && loss_out && per_sample_out && huber_c, "cond_loss: null pointer");
+  ST_REQUIRE((loss_type == 1 || loss_type == 2) && per_sample % 8 == 0 && batch > 0 && batch < 65536, "cond_loss: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 6.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
+  hipMemsetAsync(per_sample_out, 0, sizeof(float) * batch, (hipStream_t)stream);
+  int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
+  if (bx > 512) bx = 512;
+  const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
+  if (loss_type == 1)
+    hipLaunchKernelGGL(k_cond_loss<1>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale);
+  else
+    hipLaunchKernelGGL(k_cond_loss<2>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale);
+  hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
+                     1.0f / (float)per_sample);
+  return st355_check_launch("cond_loss");
+}
+
 // ---- K3: Flux pack / unpack -------------------------------------------------------------------------
 // packed[b, h2*W2 + w2, c*4 + dh*2 + dw] = lat[b, c, 2*h2 + dh, 2*w2 + dw]
 template <bool PACK, int ORDER>

@@ -722,6 +722,9 @@ __global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmGroup g) {
 #define PQ_REGION 16384
 #define PQ_BUF (4 * PQ_REGION)              // 64 KiB: [XA][XB][WA][WB]
 #define PQ_LDS (8 * 64 * 272)              // 136 KiB: two 64-KiB K-tile buffers; the epilogue transpose uses 8 x 17 KiB
+#ifndef PQ_ABL
+#define PQ_ABL 0                            // lab-only ablations (wrong results!): bit 0 = no fragment reads in the loop, bit 1 = no LDS-DMA refills
+#endif
 #ifndef PQ_PRIO
 #define PQ_PRIO 1                           // raise the wave priority around the MFMA clusters (T5)
 #endif
@@ -834,6 +837,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   };
   // the refill of phase q = 4t+ph:  P0: WB(t+1)  P1: XB(t+1)  P2: XA(t+2)  P3: WA(t+2)
   auto refill = [&](int t, int ph, bool check) {      // check = false in the steady-state loop (every refill exists there)
+    if (PQ_ABL & 2) return;
     if (ph == 0) { if (!check || t + 1 < nt) stage_w(t + 1, 1); }
     else if (ph == 1) { if (!check || t + 1 < nt) stage_x(t + 1, 1); }
     else if (ph == 2) { if (!check || t + 2 < nt) stage_x(t + 2, 0); }
@@ -856,10 +860,12 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const int xt = t_row + (((wm * 8 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);                  // ^ (j<<6), + ks*4096 + rd*1024
   const int wt = 2 * PQ_REGION + t_row + (((wn * 4 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);
   auto ld_x = [&](const char* base, int j, int ks) -> bf16x8 {
+    if (PQ_ABL & 1) { bf16x8 z; for (int q_ = 0; q_ < 8; q_++) z[q_] = (bf16)(float)(lane + j + ks); asm volatile("" : "+v"(z)); return z; }
     if (TN) { const char* q = base + (xt ^ (j << 6)) + ks * 4096; return lds_tr16x2(q, q + 1024); }
     return *(const bf16x8*)(base + xk[ks] + j * 4096);
   };
   auto ld_w = [&](const char* base, int ks) -> bf16x8 {
+    if (PQ_ABL & 1) { bf16x8 z; for (int q_ = 0; q_ < 8; q_++) z[q_] = (bf16)(float)(lane + ks); asm volatile("" : "+v"(z)); return z; }
     if (TN) { const char* q = base + wt + ks * 4096; return lds_tr16x2(q, q + 1024); }
     return *(const bf16x8*)(base + wk[ks]);
   };
@@ -874,6 +880,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // ---- prologue: XA(0) WA(0) WB(0) XB(0) XA(1) WA(1) in ring order; XA(0), WA(0) retired + published ----
   stage_x(0, 0); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1);
   if (nt > 1) { stage_x(1, 0); stage_w(1, 0); }
+  if (PQ_ABL & 2) wait_vm_rt(0); else
   wait_vm_rt(nt > 1 ? 8 : 4);
   PP_BARRIER();
   if (wm == 1) PP_BARRIER();                           // group 1 runs one barrier interval behind group 0

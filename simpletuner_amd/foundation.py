@@ -233,17 +233,57 @@ class ModelFoundation:
         model_pred = model_output["model_prediction"]
         if target is None:
             raise ValueError("Target is None. Cannot compute loss.")
-        if getattr(self.config, "loss_type", "l2") != "l2":
-            raise NotImplementedError("only loss_type=l2 is implemented on the st355 path")
+        loss_type = getattr(self.config, "loss_type", "l2")
+        if loss_type not in ("l2", "huber", "smooth_l1"):
+            raise NotImplementedError(f"Unsupported Loss Type {loss_type}")
         if prepared_batch.get("loss_mask_type") or prepared_batch.get("conditioning_type") in ("mask", "segmentation"):
             raise NotImplementedError("conditioning-mask losses are not implemented on the st355 path")
-        return _MSELossFn.apply(model_pred, target)
+        if loss_type == "l2":
+            return _MSELossFn.apply(model_pred, target)
+        # huber / smooth_l1 (common.py:6248-6281): one huber_c per sample — constant, or scheduled on the timestep (common.py:6168-6216)
+        huber_c = self.compute_scheduled_huber_c(prepared_batch["timesteps"]).to(device=model_pred.device, dtype=torch.float32)
+        huber_c = huber_c.reshape(-1).expand(model_pred.shape[0]).contiguous()
+        return _CondLossFn.apply(model_pred, target, loss_type, huber_c)
+
+    def compute_scheduled_huber_c(self, timesteps: torch.Tensor) -> torch.Tensor:
+        """common.py:6168-6216 (flow-matching branch of the "snr" schedule: sigma = ((1 - t/1000) / (t/1000 + 1e-4))^0.5)"""
+        import math
+        schedule = getattr(self.config, "huber_schedule", "constant")
+        base = float(getattr(self.config, "huber_c", 0.1))
+        t = timesteps.to(torch.float32)
+        if schedule == "constant":
+            return torch.full_like(t, base)
+        if schedule == "exponential":
+            alpha = -math.log(base) / float(getattr(self.config, "num_train_timesteps", 1000))
+            return torch.exp(-alpha * t)
+        if schedule == "snr":
+            if self.PREDICTION_TYPE != PredictionTypes.FLOW_MATCHING:
+                raise NotImplementedError("huber_schedule=snr is wired for flow-matching models only on the st355 path")
+            s = t / 1000
+            s = ((1.0 - s) / (s + 0.0001)) ** 0.5
+            return (1 - base) / (1 + s) ** 2 + base
+        raise NotImplementedError(f"Unknown Huber loss schedule {schedule}")
 
     def loss_with_logs(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True):
         return self.loss(prepared_batch, model_output, apply_conditioning_mask), None
 
     def auxiliary_loss(self, model_output, prepared_batch: dict, loss: torch.Tensor):
         return loss, None
+
+
+class _CondLossFn(torch.autograd.Function):
+    """huber / smooth_l1 (conditional_loss) -> per-sample mean -> batch mean, gradient from the same kernel pass"""
+
+    @staticmethod
+    def forward(ctx, pred, target, loss_type, huber_c):
+        loss, _per, dpred = ops.cond_loss(pred.to(BF16), target.to(BF16), loss_type, huber_c, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None, None
 
 
 class _MSELossFn(torch.autograd.Function):

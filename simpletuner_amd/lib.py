@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "csrc" / "libst355.so"
 SYMBOLS = [
     "st355_version", "st355_arch", "st355_last_error",
     "st355_prof_enable", "st355_prof_reset", "st355_prof_collect", "st355_prof_dump",
-    "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss",
+    "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss", "st355_cond_loss",
     "st355_flux_pack", "st355_flux_unpack", "st355_patchify", "st355_unpatchify",
     "st355_timestep_proj", "st355_silu", "st355_silu_bwd", "st355_add", "st355_scale_cols",
     "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_tn_bf16", "st355_colsum_workspace", "st355_colsum_prod", "st355_transpose_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn",
@@ -78,6 +78,7 @@ def _declare(lib):
         "st355_flow_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, u64, u64]),
         "st355_ddpm_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64]),
         "st355_mse_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32]),
+        "st355_cond_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32]),
         "st355_flux_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_flux_unpack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_patchify": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32]),

@@ -95,6 +95,29 @@ def mse_loss(pred, target, weight=None, want_grad: bool = True, grad_scale: floa
     return loss, per_sample, dpred
 
 
+LOSS_TYPES = {"l2": 0, "huber": 1, "smooth_l1": 2}
+
+
+def cond_loss(pred, target, loss_type: str = "l2", huber_c=0.1, weight=None, want_grad: bool = True, grad_scale: float = 1.0):
+    """conditional_loss(reduction='none') -> per-sample mean -> batch mean (common.py:6132-6166, 6426-6429) + fused d(loss)/d(pred).
+    huber_c: float or fp32 device tensor [B] (scheduled huber).  Returns (loss[1], per_sample[B], dpred)."""
+    L = _l.load()
+    _chk(pred, BF16, "pred"); _chk(target, BF16, "target")
+    pred = pred.contiguous(); target = target.contiguous()
+    B = pred.shape[0]
+    loss = torch.empty(1, dtype=F32, device=pred.device)
+    per_sample = torch.empty(B, dtype=F32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    if not torch.is_tensor(huber_c):
+        huber_c = torch.full((B,), float(huber_c), dtype=F32, device=pred.device)
+    _chk(huber_c, F32, "huber_c")
+    if weight is not None:
+        _chk(weight, F32, "weight")
+    _l.check(L.st355_cond_loss(_stream(), _ptr(pred), _ptr(target), _ptr(weight), _ptr(huber_c.contiguous()), LOSS_TYPES[loss_type], _ptr(loss),
+                               _ptr(per_sample), _ptr(dpred), B, pred.numel() // B, grad_scale), "cond_loss")
+    return loss, per_sample, dpred
+
+
 def flux_pack(latents):
     L = _l.load()
     _chk(latents, BF16, "latents")

@@ -105,8 +105,52 @@ def gen_adamw_bf16():
     print(f"wrote {out}: {len(G['steps'])} steps x {len(shapes)} tensors; initial decay draws {rands}")
 
 
+def gen_loss():
+    """conditional_loss / compute_scheduled_huber_c (common.py:6132-6216) and compute_snr (min_snr_gamma.py:4-46): the reference METHODS
+    lifted by AST and run on seeded inputs -> tests/golden/loss_vectors.pt (oracle + HIP kernel are pinned to these)."""
+    import enum
+    import torch.nn.functional as F
+
+    class PredictionTypes(enum.Enum):
+        EPSILON = "epsilon"; V_PREDICTION = "v_prediction"; FLOW_MATCHING = "flow_matching"
+
+    (compute_snr,) = extract(REF / "helpers/training/min_snr_gamma.py", ["compute_snr"])
+    cond_loss, sched_c = extract(REF / "helpers/models/common.py", ["conditional_loss", "compute_scheduled_huber_c"], class_name="ModelFoundation",
+                                 extra_ns={"F": F, "PredictionTypes": PredictionTypes, "compute_snr": compute_snr})
+    torch.manual_seed(777)
+    G = {}
+    pred = torch.randn(3, 16, 8, 8); target = torch.randn(3, 16, 8, 8)
+    G["pred"], G["target"] = pred.to(torch.bfloat16), target.to(torch.bfloat16)
+    pf, tf = G["pred"].float(), G["target"].float()            # the reference calls conditional_loss on .float() tensors (common.py:6275-6281)
+    for lt in ("l2", "huber", "smooth_l1"):
+        for c in (0.1, 0.03):
+            el = cond_loss(None, pf, tf, reduction="none", loss_type=lt, huber_c=c)
+            G[f"{lt}.c{c}.per_sample"] = el.mean(dim=[1, 2, 3])
+            G[f"{lt}.c{c}.loss"] = el.mean(dim=[1, 2, 3]).mean()                      # common.py:6426-6429
+    ts = torch.tensor([10.0, 250.0, 500.0, 900.0, 999.0])
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2      # DDPM "scaled_linear" (SD1.5 / SDXL scheduler_config)
+    acp = torch.cumprod(1.0 - betas, dim=0)
+    sched = types.SimpleNamespace(alphas_cumprod=acp, config=types.SimpleNamespace(num_train_timesteps=1000))
+    G["timesteps"] = ts; G["alphas_cumprod"] = acp
+    for schedule in ("constant", "exponential", "snr"):
+        for ptype in (PredictionTypes.FLOW_MATCHING, PredictionTypes.EPSILON):
+            self_ = types.SimpleNamespace(config=types.SimpleNamespace(loss_type="huber", huber_schedule=schedule, huber_c=0.1),
+                                          noise_schedule=sched, PREDICTION_TYPE=ptype)
+            t_in = ts if ptype == PredictionTypes.FLOW_MATCHING else ts.long()
+            G[f"huber_c.{schedule}.{ptype.value}"] = torch.as_tensor(sched_c(self_, t_in)).float()
+    tl = torch.tensor([0, 1, 250, 500, 998, 999])
+    G["snr.t"] = tl
+    G["snr"] = compute_snr(tl, sched)
+    G["snr.soft_min"] = compute_snr(tl, sched, use_soft_min=True, sigma_data=1.0)
+    G["_cite"] = "simpletuner/helpers/models/common.py:6132-6216; simpletuner/helpers/training/min_snr_gamma.py:4-46"
+    out = OUT.parent / "loss_vectors.pt"
+    torch.save(G, out)
+    print(f"wrote {out}: {len(G)} entries")
+
+
 def main():
     gen_adamw_bf16()
+    gen_loss()
     torch.manual_seed(1234)
     G = {}
     cite = {}
