@@ -228,6 +228,27 @@ def test_gemm_gate_residual_keeps_branch_output(ops):
     assert report("gated residual", out, res.float() + (gate.float()[:, None, :] * y.view(B, S, D)).view(B * S, D))[0] < 5e-3
 
 
+def test_gemm_ring_race_screen(ops):
+    """the LDS-DMA ring (counted vmcnt + raw barriers, two wave groups one barrier apart) is only correct if every read sits behind
+    the wait + barrier that retires its region: screen for rare early reads — many runs over shapes with different K-tile counts
+    (1, 2, 3 tiles exercise the prologue / tail counts), uneven M, concurrent launches; results must be bit-identical run to run and
+    match the fp32 reference."""
+    torch.manual_seed(77)
+    for (M, N, K) in [(4608, 3072, 64), (4608, 3072, 128), (4608, 3072, 192), (4352, 4608, 1536), (8192, 8192, 2048)]:
+        a = torch.randn(M, K, device=dev()).to(BF16); w = (torch.randn(N, K, device=dev()) * 0.05).to(BF16)
+        ref = a.float() @ w.float().t()
+        first = ops.gemm(a, w)
+        assert report(f"race-screen gemm {M}x{N}x{K}", first, ref)[0] < 5e-3
+        for _ in range(12):
+            assert torch.equal(ops.gemm(a, w), first)
+    for (M, P, Q) in [(64, 3072, 1536), (128, 1536, 3072), (4096, 3072, 3072)]:
+        l = torch.randn(M, P, device=dev()).to(BF16); r = torch.randn(M, Q, device=dev()).to(BF16)
+        first = ops.gemm_tn(l, r)
+        assert report(f"race-screen gemm_tn {P}x{Q} over {M}", first, l.float().t() @ r.float())[0] < 5e-3
+        for _ in range(12):
+            assert torch.equal(ops.gemm_tn(l, r), first)
+
+
 def test_gemm_identity_asymmetric(ops):
     # A = I (padded), asymmetric B: catches row/col swaps in the C write (cdna guide §3 "A=I-check")
     K = 128
