@@ -117,6 +117,16 @@ int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
  * streams (img / txt) of an MMDiT block, or the per-batch slices of a joint buffer. */
 int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count);
 
+/* ---- K19: fp8-native Linear (helpers/training/quantisation/fp8_native.py:25-119) ------------------------------------------------------
+ * weights: OCP e4m3fn bytes [N,K] + one fp32 scale per output row (quantize_weight_to_fp8: scale = max(amax_row,1e-12)/448);
+ * inputs: OCP e5m2 bytes [M,K], ONE scale per call = 57344/amax(x) held as a bf16 scalar like the reference's tensor arithmetic;
+ * scale_a[0] = float(bf16(1/input_scale)).  linear: out = (x_q W_q^T) * scale_a * w_scale[n] + bias -> bf16 (torch._scaled_mm row-wise
+ * scaling, use_fast_accum) on v_mfma_f32_32x32x16_fp8_bf8 with fp32 accumulation.  K multiple of 128.  workspace: 4 bytes. */
+int st355_fp8_quantize_weight(void* stream, const void* w_bf16, int64_t ldw, void* q_e4m3, float* scale, int N, int K);
+int st355_fp8_quantize_act(void* stream, const void* x_bf16, int64_t ldx, void* q_e5m2, float* scale_a, int64_t M, int K, void* workspace);
+int st355_linear_fp8(void* stream, const void* xq, int64_t ldx, const float* scale_a, const void* wq, int64_t ldw,
+                     const float* w_scale, const void* bias, void* out, int64_t ldo, int M, int N, int K);
+
 /* weight-gradient GEMM (what autograd does for nn.Linear.weight in a full fine-tune, trainer.py:7126):
  *   C[P,Q] (+)= sum_m L[m,P] * R[m,Q]      e.g. dW[N,K] = dY[M,N]^T X[M,K]  (L = dY, R = X, C = dW in nn.Linear.weight layout)
  * both operands carry the contraction index m on their slow axis; Mc must be a multiple of 64 (zero-pad the token rows). bf16 in/out,

@@ -180,3 +180,35 @@ def compute_snr(timesteps, alphas_cumprod, use_soft_min: bool = False, sigma_dat
     if use_soft_min:
         return (sigma * sigma_data) ** 2 / (sigma ** 2 + sigma_data ** 2) ** 2
     return (alpha / sigma) ** 2
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8-native Linear (quantisation/fp8_native.py:25-119)
+# ------------------------------------------------------------------------------------------------
+FP8_E4M3_MAX = 448.0
+FP8_E5M2_MAX = 57344.0
+
+
+def fp8_quantize_weight(weight):
+    """quantize_weight_to_fp8 (:25-30): per-output-row scale = max(amax, 1e-12) / 448; q = clamp(w / scale, +-448) -> e4m3fn"""
+    w = weight.detach().float()
+    amax = w.abs().amax(dim=1, keepdim=True).clamp(min=1e-12)
+    scale = amax / FP8_E4M3_MAX
+    q = (w / scale).clamp(-FP8_E4M3_MAX, FP8_E4M3_MAX).to(torch.float8_e4m3fn)
+    return q, scale.squeeze(1)
+
+
+def fp8_quantize_act(x_2d):
+    """_Fp8NativeLinearFn.forward (:56-60).  The arithmetic runs on bf16 TENSORS in the reference, so the scale is a bf16 scalar and the
+    scaled activations are rounded to bf16 before the e5m2 conversion; scale_a = float(bf16(1 / input_scale))."""
+    input_scale = (FP8_E5M2_MAX / x_2d.detach().abs().amax().clamp(min=1e-12)).clamp(max=FP8_E5M2_MAX)
+    x_q = (x_2d * input_scale).clamp(-FP8_E5M2_MAX, FP8_E5M2_MAX).to(torch.float8_e5m2)
+    return x_q, input_scale.reciprocal().to(torch.float32)
+
+
+def fp8_linear(x_q, scale_a, w_q, w_scale, bias=None, out_dtype=torch.bfloat16):
+    """torch._scaled_mm(x_q, w_q.T, scale_a [M,1], scale_b [1,N], bias) with row-wise scales, accumulated in fp32 (:64-75)"""
+    out = (x_q.float() @ w_q.float().t()) * scale_a.float().reshape(-1, 1) * w_scale.float().reshape(1, -1)
+    if bias is not None:
+        out = out + bias.float()
+    return out.to(out_dtype)

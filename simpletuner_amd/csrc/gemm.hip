@@ -61,7 +61,8 @@ struct GemmP {
   bf16* aux_out; int64_t ld_aux_out;
   const bf16* aux_in; int64_t ld_aux_in;
   const bf16* gate; int64_t gate_stride; int64_t rows_per_batch;
-  float* partial; int ksplit;          // split-K (k_gemm_s2 only): fp32 slabs [ksplit][M][N]
+  float* partial; int ksplit;          // split-K: fp32 slabs [ksplit][M][N]
+  const float* scale_a; const float* scale_b;   // fp8 Linear: out = acc * scale_a[0] * scale_b[n] (+ bias); NULL otherwise
 };
 
 struct GemmGroup {
@@ -200,8 +201,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
         continue;
       }
       float v[8];
+      if (p.scale_b) {                                  // fp8 Linear: row-wise scaling of torch._scaled_mm (fp8_native.py:64-75)
+        const float sa = p.scale_a[0];
+        const f32x4 s0 = *(const f32x4*)(p.scale_b + n), s1 = *(const f32x4*)(p.scale_b + n + 4);
 #pragma unroll
-      for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
+        for (int b = 0; b < 4; b++) { v[b] = lo[b] * (sa * s0[b]) + bias8[b]; v[4 + b] = hi[b] * (sa * s1[b]) + bias8[4 + b]; }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
+      }
       if (EPI == ST355_EPI_GELU) {
         if (p.aux_out) {
           bf16x8 pre;
@@ -750,8 +758,14 @@ __device__ __forceinline__ void wait_vm_rt(int n) {    // n = LDS-DMA pieces tha
 // both operands have the contraction index as their SLOW axis.  The ring, the phases and the epilogue are unchanged; a region is
 // then [64 contraction rows][128 output columns] (256-byte rows, 16-byte chunks XOR-ed with (row&3)<<2 on the DMA source side) and
 // the MFMA fragments are gathered by the transposing LDS read (two ds_read_b64_tr_b16 per k-fragment).
-template <int EPI, bool TN>
+// F8 = true: the fp8-native Linear (fp8.hip): A = e5m2 activations, B = e4m3 weights, one byte per element.  The byte geometry of the
+// ring is unchanged (128-byte rows = 128 K-elements per K-tile, same swizzle); a phase then runs 16 MFMAs (8 k-steps of
+// v_mfma_f32_32x32x16_fp8_bf8) on fragments fetched with 8-byte reads, i.e. twice the MFMA work per LDS-DMA byte.
+template <int EPI, bool TN, bool F8 = false>
 __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
+  constexpr int ES = F8 ? 1 : 2;               // bytes per operand element
+  constexpr int KSN = F8 ? 8 : 4;              // k-steps (MFMAs per accumulator) per K-tile
+  static_assert(!(F8 && TN), "fp8 weight gradients are not built");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -768,7 +782,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   int pm, pn;
   tile_coords(id, nbm, nbn, pm, pn);
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
-  const int nt_all = p.K / PQ_BK;
+  const int nt_all = p.K / (PQ_BK * 2 / ES);
   const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
   const int t_first = slice * per;
   const int nt1 = (EPI == EPI_SPLITK) ? max(0, min(nt_all, t_first + per) - t_first) : nt_all;
@@ -781,9 +795,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // region row lr -> tile row:  X: (lr>>6)*128 + (lr&63) [+64 for XB]     W: (lr>>5)*64 + (lr&31) [+32 for WB]
   // Addresses are (uniform 64-bit base of the tile's first row + k) + a 32-bit per-lane byte offset: the LDS-DMA takes the
   // SGPR-base + VGPR-offset form, so the K loop spends no VALU (and only 8 VGPRs) on addressing.
-  const char* xbase = TN ? (const char*)A1 + (int64_t)m0 * 2 : (const char*)A1 + (int64_t)m0 * p.lda * 2;
-  const char* wbase = TN ? (const char*)B1 + (int64_t)n0 * 2 : (const char*)B1 + (int64_t)n0 * p.ldb * 2;
-  const uint32_t lda_b = (uint32_t)p.lda * 2, ldb_b = (uint32_t)p.ldb * 2;
+  const char* xbase = TN ? (const char*)A1 + (int64_t)m0 * 2 : (const char*)A1 + (int64_t)m0 * p.lda * ES;
+  const char* wbase = TN ? (const char*)B1 + (int64_t)n0 * 2 : (const char*)B1 + (int64_t)n0 * p.ldb * ES;
+  const uint32_t lda_b = (uint32_t)p.lda * ES, ldb_b = (uint32_t)p.ldb * ES;
   const int64_t xk_step = TN ? (int64_t)PQ_BK * lda_b : PQ_BK * 2;     // bytes per K-tile along the contraction
   const int64_t wk_step = TN ? (int64_t)PQ_BK * ldb_b : PQ_BK * 2;
   xbase += t_first * xk_step; wbase += t_first * wk_step;
@@ -879,6 +893,16 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const int t_row = (8 * (tg >> 1) + tti) * 256 + (tts & 1) * 8;
   const int xt = t_row + (((wm * 8 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);                  // ^ (j<<6), + ks*4096 + rd*1024
   const int wt = 2 * PQ_REGION + t_row + (((wn * 4 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);
+  // fp8: lane reads the 8 bytes k = 16 ks + 8 khalf .. +8 of its row: 16-byte chunk ks (swizzled), half khalf
+  int xk8[8], wk8[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    const int ch = ((ks ^ ((l31 >> 1) & 7)) << 4) + khalf * 8;
+    xk8[ks] = (wm * 64 + l31) * 128 + ch;
+    wk8[ks] = 2 * PQ_REGION + (wn * 32 + l31) * 128 + ch;
+  }
+  auto ld_x8 = [&](const char* base, int j, int ks) -> long { return *(const long*)(base + xk8[ks] + j * 4096); };
+  auto ld_w8 = [&](const char* base, int ks) -> long { return *(const long*)(base + wk8[ks]); };
   auto ld_x = [&](const char* base, int j, int ks) -> bf16x8 {
     if (PQ_ABL & 1) { bf16x8 z; for (int q_ = 0; q_ < 8; q_++) z[q_] = (bf16)(float)(lane + j + ks); asm volatile("" : "+v"(z)); return z; }
     if (TN) { const char* q = base + (xt ^ (j << 6)) + ks * 4096; return lds_tr16x2(q, q + 1024); }
@@ -906,10 +930,16 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   if (wm == 1) PP_BARRIER();                           // group 1 runs one barrier interval behind group 0
 
   bf16x8 xf[2][4], w0f[4], w1f[4];
+  long xf8[2][8], w0f8[8], w1f8[8];              // fp8 fragments (the unused set is dead code for the other instantiation)
   TR_DECL;
 #define PQ_MMA(WF, I, J0, T, PH)                                                                              \
   do {                                                                                                        \
     if (PQ_PRIO) __builtin_amdgcn_s_setprio(1);                                                               \
+    if (F8) {                                                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ks++)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
+          acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(WF##8[ks], xf8[j][ks], acc[I][J0 + j], 0, 0, 0); \
+    } else                                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                        \
       _Pragma("unroll") for (int j = 0; j < 2; j++)                                                           \
         acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ks], xf[j][ks], acc[I][J0 + j], 0, 0, 0); \
@@ -929,9 +959,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf, j, ks);
+      for (int ks = 0; ks < KSN; ks++) { if (F8) xf8[j][ks] = ld_x8(bf, j, ks); else xf[j][ks & 3] = ld_x(bf, j, ks & 3); }
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) w0f[ks] = ld_w(bf, ks);
+    for (int ks = 0; ks < KSN; ks++) { if (F8) w0f8[ks] = ld_w8(bf, ks); else w0f[ks & 3] = ld_w(bf, ks & 3); }
     if (PQ_GL == 1) refill(t, 0, TAIL);
     TR(t, 1);
     if (!TAIL) wait_vm_rt(PQ_VM); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 2));
@@ -944,7 +974,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     // ---------------- P1: WB x XA ----------------
     if (PQ_GL == 0) refill(t, 1, TAIL);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) w1f[ks] = ld_w(bf + PQ_REGION, ks);
+    for (int ks = 0; ks < KSN; ks++) { if (F8) w1f8[ks] = ld_w8(bf + PQ_REGION, ks); else w1f[ks & 3] = ld_w(bf + PQ_REGION, ks & 3); }
     if (PQ_GL == 1) refill(t, 1, TAIL);
     TR(t, 4);
     if (!TAIL) wait_vm_rt(PQ_VM); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 8 : 0));
@@ -959,7 +989,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf + PQ_REGION, j, ks);
+      for (int ks = 0; ks < KSN; ks++) { if (F8) xf8[j][ks] = ld_x8(bf + PQ_REGION, j, ks); else xf[j][ks & 3] = ld_x(bf + PQ_REGION, j, ks & 3); }
     if (PQ_GL == 1) refill(t, 2, TAIL);
     TR(t, 7);
     if (!TAIL) wait_vm_rt(PQ_VM); else wait_vm_rt(rem >= 2 ? 8 : (rem == 1 ? 6 : 0));
@@ -1149,6 +1179,7 @@ static GemmP to_p(const st355_gemm_args* a) {
   p.aux_in = (const bf16*)a->aux_in; p.ld_aux_in = a->ld_aux_in;
   p.gate = (const bf16*)a->gate; p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch;
   p.partial = nullptr; p.ksplit = 1;
+  p.scale_a = nullptr; p.scale_b = nullptr;
   return p;
 }
 
@@ -1282,6 +1313,28 @@ extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
   if (rc) return rc;
   ProfScope ps(stream, ST355_K_GEMM, gemm_flops(a), gemm_bytes(a), "%dx%dx%d+%d e%d", a->M, a->N, a->K, a->K2, a->epilogue);
   return run_one(stream, a);
+}
+
+// ---- fp8-native Linear (fp8_native.py:41-119) -----------------------------------------------------------------------------------------
+extern "C" int st355_linear_fp8(void* stream, const void* xq, int64_t ldx, const float* scale_a, const void* wq, int64_t ldw,
+                                const float* w_scale, const void* bias, void* out, int64_t ldo, int M, int N, int K) {
+  ST_REQUIRE(xq && wq && scale_a && w_scale && out && M > 0 && N > 0 && K > 0, "linear_fp8: bad args");
+  ST_REQUIRE(K % 128 == 0 && N % 8 == 0 && ldx % 16 == 0 && ldw % 16 == 0 && ldo % 8 == 0, "linear_fp8: K must be a multiple of 128, N of 8, rows 16-byte aligned");
+  ST_REQUIRE(((uintptr_t)xq % 16 == 0) && ((uintptr_t)wq % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)w_scale % 16 == 0), "linear_fp8: misaligned pointer");
+  ST_REQUIRE(256 * (ldx > ldw ? ldx : ldw) + (int64_t)K < ((int64_t)1 << 31), "linear_fp8: a 256-row tile must fit 32-bit buffer offsets");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)xq; p.lda = ldx; p.B = (const bf16*)wq; p.ldb = ldw; p.C = (bf16*)out; p.ldc = ldo;
+  p.M = M; p.N = N; p.K = K; p.K2 = 0; p.ksplit = 1;
+  p.bias = (const bf16*)bias; p.scale_a = scale_a; p.scale_b = w_scale;
+  GemmGroup g;
+  g.p[0] = p; g.p[1] = p;
+  g.tiles0 = ((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);
+  ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)M * N * K, (double)M * K + (double)N * K + 2.0 * (double)M * N, "F8 %dx%dx%d", M, N, K);
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<ST355_EPI_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  hipLaunchKernelGGL((k_gemm_pq<ST355_EPI_NONE, false, true>), dim3(g.tiles0), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("linear_fp8");
 }
 
 // ---- weight-gradient form -------------------------------------------------------------------------------------------------------

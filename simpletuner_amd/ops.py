@@ -289,6 +289,48 @@ def gemm_grouped(problems):
     return outs
 
 
+def fp8_quantize_weight(w):
+    """quantize_weight_to_fp8 (fp8_native.py:25-30): returns (q uint8 [N,K] holding e4m3fn bytes, scale fp32 [N])"""
+    L = _l.load()
+    _chk(w, BF16, "w")
+    N, K = w.shape
+    q = torch.empty(N, K, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(N, dtype=F32, device=w.device)
+    _l.check(L.st355_fp8_quantize_weight(_stream(), _ptr(w), _rows(w, "w"), _ptr(q), _ptr(scale), N, K), "fp8_quantize_weight")
+    return q, scale
+
+
+def fp8_quantize_act(x):
+    """per-call e5m2 quantisation of the activations (fp8_native.py:58-60): returns (q uint8 [M,K], scale_a fp32 [1] = 1/input_scale)"""
+    L = _l.load()
+    _chk(x, BF16, "x")
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    scale_a = torch.empty(1, dtype=F32, device=x.device)
+    ws = torch.empty(1, dtype=torch.int32, device=x.device)
+    _l.check(L.st355_fp8_quantize_act(_stream(), _ptr(x), _rows(x, "x"), _ptr(q), _ptr(scale_a), M, K, _ptr(ws)), "fp8_quantize_act")
+    return q, scale_a
+
+
+def linear_fp8(xq, scale_a, wq, w_scale, bias=None, out=None):
+    """out = (xq wq^T) * scale_a * w_scale[n] + bias  -> bf16   (torch._scaled_mm with row-wise scales, fp8_native.py:64-75)"""
+    L = _l.load()
+    for t, nm in ((xq, "xq"), (wq, "wq")):
+        _dev(t, nm)
+        if t.dtype != torch.uint8 or not t.is_contiguous():
+            raise _l.St355Error(f"linear_fp8: {nm} must be a contiguous uint8 (fp8 bytes) tensor")
+    _chk(scale_a, F32, "scale_a"); _chk(w_scale, F32, "w_scale")
+    M, K = xq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=xq.device)
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    _l.check(L.st355_linear_fp8(_stream(), _ptr(xq), K, _ptr(scale_a), _ptr(wq), K, _ptr(w_scale), _ptr(bias), _ptr(out), _rows(out, "out"),
+                                M, N, K), "linear_fp8")
+    return out
+
+
 def gemm_tn(Lm, R, out=None, accumulate: bool = False):
     """out[P,Q] (+)= Lm[M,P]^T @ R[M,Q]  — the weight-gradient form (dW = dY^T X).  M must be a multiple of 64 (zero-padded rows)."""
     L = _l.load()

@@ -148,9 +148,62 @@ def gen_loss():
     print(f"wrote {out}: {len(G)} entries")
 
 
+def gen_fp8():
+    """fp8-native Linear (quantisation/fp8_native.py:25-119): the reference MODULE imported by file path (pure torch).  Weight quantisation is
+    its own function; for the forward, torch._scaled_mm is replaced by a recorder so that the reference's own code produces the e5m2
+    activations and the scale vectors it would hand to the device GEMM (the CPU backend of _scaled_mm has no row-wise mode)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_fp8_native", REF / "helpers/training/quantisation/fp8_native.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_fp8_native"] = mod
+    spec.loader.exec_module(mod)
+    torch.manual_seed(2468)
+    G = {}
+    w = (torch.randn(264, 384) * 0.05).to(torch.bfloat16)
+    w[5] = 0                                            # an all-zero row exercises the amax clamp
+    bias = torch.randn(264).to(torch.bfloat16)
+    x = (torch.randn(3, 50, 384) * 1.7).to(torch.bfloat16)
+    q, sc = mod.quantize_weight_to_fp8(w)
+    G["w"], G["bias"], G["x"] = w, bias, x
+    G["w_q"], G["w_scale"] = q.view(torch.uint8), sc
+    rec = {}
+    real = torch._scaled_mm
+
+    def recorder(a, b, scale_a=None, scale_b=None, bias=None, out_dtype=None, use_fast_accum=False):
+        rec.update(x_q=a.clone().view(torch.uint8), scale_a=scale_a.clone(), scale_b=scale_b.clone(), b_is_wT=bool(torch.equal(b.t().view(torch.uint8), q.view(torch.uint8))))
+        out = (a.float() @ b.float()) * scale_a * scale_b              # row-wise scaling semantics of _scaled_mm, fp32
+        if bias is not None:
+            out = out + bias.float()
+        return out.to(out_dtype)
+
+    mod._scaled_mm_supported = lambda t: True
+    torch._scaled_mm = recorder
+    try:
+        out = mod._Fp8NativeLinearFn.apply(x, q, sc, bias, 264)
+    finally:
+        torch._scaled_mm = real
+    assert rec["b_is_wT"]
+    G["x_q"], G["scale_a"], G["scale_b"] = rec["x_q"], rec["scale_a"], rec["scale_b"]
+    G["out_fp32_semantics"] = out                           # reference control flow + fp32 emulation of the device GEMM
+    go = torch.randn(3, 50, 264).to(torch.bfloat16)
+    xg = x.clone().requires_grad_(True)
+    torch._scaled_mm = recorder
+    try:
+        mod._Fp8NativeLinearFn.apply(xg, q, sc, bias, 264).backward(go)
+    finally:
+        torch._scaled_mm = real
+    G["grad_out"], G["grad_x"] = go, xg.grad                # backward = dequantised-weight matmul (fp8_native.py:107-115)
+    G["_cite"] = "simpletuner/helpers/training/quantisation/fp8_native.py:25-119"
+    out_p = OUT.parent / "fp8_vectors.pt"
+    torch.save(G, out_p)
+    print(f"wrote {out_p}: scale_a {float(rec['scale_a'][0])}")
+
+
 def main():
     gen_adamw_bf16()
     gen_loss()
+    gen_fp8()
     torch.manual_seed(1234)
     G = {}
     cite = {}
