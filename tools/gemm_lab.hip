@@ -45,6 +45,12 @@ __global__ void k_cmp(const bf16* C, const float* R, int64_t n, float* out /*max
 
 struct Shape { int M, N, K, K2; };
 
+__global__ void k_fill8(uint8_t* p, int64_t n, uint32_t seed) {   // pseudo-random FINITE fp8 bit patterns (mask keeps e5m2 < inf, e4m3 != NaN)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + seed * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (uint8_t)(h & 0xB7u);
+  }
+}
 int main(int argc, char** argv) {
   if (argc > 1 && strcmp(argv[1], "--child") != 0) {
     for (int i = 1; i < argc; i++) {
@@ -122,8 +128,28 @@ int main(int argc, char** argv) {
     run(s, false);
     return 0;
   }
+  if (!getenv("LAB_F8")) {
   for (const Shape& s : check) run(s, true);
   for (const Shape& s : perf) run(s, false);
+  }
+  // fp8-native Linear (e5m2 activations x e4m3 weights, row scales in the epilogue): timing only, parity is tests/test_fp8_linear.py
+  for (const Shape& s : {Shape{4608, 3072, 3072, 0}, Shape{18432, 3072, 3072, 0}, Shape{18432, 12288, 3072, 0}, Shape{18432, 3072, 12288, 0},
+                         Shape{8192, 8192, 8192, 0}, Shape{16384, 16384, 8192, 0}}) {
+    uint8_t *X, *W; float *sa, *ws; bf16* C;
+    CK(hipMalloc(&X, (size_t)s.M * s.K)); CK(hipMalloc(&W, (size_t)s.N * s.K)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
+    CK(hipMalloc(&sa, 4)); CK(hipMalloc(&ws, (size_t)s.N * 4));
+    k_fill8<<<1024, 256, 0, st>>>(X, (int64_t)s.M * s.K, 7u); k_fill8<<<1024, 256, 0, st>>>(W, (int64_t)s.N * s.K, 8u);
+    CK(hipMemsetAsync(sa, 0x3c, 4, st)); CK(hipMemsetAsync(ws, 0x3c, (size_t)s.N * 4, st));
+    for (int i = 0; i < 3; i++) st355_linear_fp8(st, X, s.K, sa, W, s.K, ws, nullptr, C, s.N, s.M, s.N, s.K);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 20; i++) st355_linear_fp8(st, X, s.K, sa, W, s.K, ws, nullptr, C, s.N, s.M, s.N, s.K);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    printf("  F8 %6d x %6d x %6d: %8.1f us  %8.1f TFLOP/s\n", s.M, s.N, s.K, ms * 1e3, 2.0 * s.M * s.N * (double)s.K / ms / 1e9);
+    CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(sa)); CK(hipFree(ws));
+  }
+  if (getenv("LAB_F8")) return 0;
   // weight-gradient (TN) form: C[P,Q] = L[M,P]^T R[M,Q]; Shape {M=P, N=Q, K=contraction}
   for (const Shape& s : {Shape{3072, 3072, 4608, 0}, Shape{12288, 3072, 4608, 0}, Shape{3072, 12288, 18432, 0}, Shape{1536, 1536, 16384, 0},
                          Shape{6144, 1536, 16384, 0}, Shape{8192, 8192, 8192, 0}}) {
