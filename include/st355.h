@@ -229,6 +229,60 @@ int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, floa
 int st355_lora_pack(void* stream, const float* A, const float* Bm, int r, int K, int N, float scale,
                     void* A_cat, void* A_cat_T, void* B_blk, void* B_blk_T, int K2, int k2_off, int N_total, int n_off);
 
+/* ==== UNet path (SDXL / SD1.5: sdxl/model.py:350-367, sd1x/model.py:224-270 call diffusers' UNet2DConditionModel — un-vendored) ==== */
+/* "grid buffer": [st355_conv_grid_rows(B,H,W), C] bf16 — position (b,y,x) of the zero-bordered (H+2)x(W+2) image b at row
+ * (b*(H+2)+y)*(W+2)+x; border positions hold ZERO; 64 zero rows follow the last image.  Kernels keep the border zero and never write the
+ * tail, so a buffer that was zero-filled once can be re-used.  A 3x3 stride-1 pad-1 convolution is then ONE GEMM over the grid whose K
+ * loop walks the nine taps as row-shifted views of x (no im2col); taps == 1 is the 1x1 conv / pre-gathered-columns case.
+ *   out[pos, co] = sum_{tap,ci} x[pos + shift(tap), ci] * w[co, tap*Cin + ci] + bias[co] + img_add[image(pos), co] + residual[pos, co]
+ * w: [Cout, taps*Cin] (= torch Conv2d weight.permute(0,2,3,1)); Cin % 64 == 0, Cout % 8 == 0; img_add: [B, >=Cout] rows (the ResnetBlock2D
+ * time-embedding projection) or NULL; residual: grid [.., Cout] or NULL. */
+int64_t st355_conv_grid_rows(int B, int H, int W);
+int st355_conv_bf16(void* stream, const void* x, const void* w, const void* bias, const void* img_add, int64_t img_add_stride,
+                    const void* residual, void* out, int B, int H, int W, int Cin, int Cout, int taps);
+/* dw[co, tap*Cin + ci] (+)= sum_pos dy[pos, co] * x[pos + shift(tap), ci]   (one TN GEMM per tap; workspace: optional fp32 split-K scratch) */
+int st355_conv_wgrad_bf16(void* stream, const void* x, const void* dy, void* dw, int B, int H, int W, int Cin, int Cout, int taps,
+                          int accumulate, void* workspace, int64_t workspace_bytes);
+/* layout passes (conv.hip) */
+int st355_grid_from_nchw(void* stream, const void* x /*[B,C,H,W] bf16*/, void* grid /*[.., Cpad]*/, int B, int C, int H, int W, int Cpad);
+int st355_grid_to_nchw(void* stream, const void* grid, void* y, int B, int C, int H, int W, int Cpad);
+/* columns on the OUTPUT grid of a 3x3 pad-1 conv with stride 1|2: col[(b,yo,xo), tap*C + c]; columns >= 9*C up to Kpad are zero */
+int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad);
+int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad);   /* adjoint (gather form) */
+int st355_upsample2x(void* stream, const void* x /*grid H,W*/, void* y /*grid 2H,2W*/, int B, int H, int W, int C);
+int st355_upsample2x_bwd(void* stream, const void* dy, void* dx, int B, int H, int W, int C);
+int st355_tokens_to_grid(void* stream, const void* tokens /*[B*H*W, C]*/, const void* residual /*grid or NULL*/, void* grid, int B, int H, int W, int C);
+int st355_grid_to_tokens(void* stream, const void* grid, void* tokens, int B, int H, int W, int C);
+/* GroupNorm(groups, affine) [+ SiLU] on a grid buffer; stats: [B,C,2] fp32 (mean, rstd per channel) saved for backward.
+ * out_tokens / dy_tokens: the normalised output / its gradient live as dense tokens [B*H*W, C] instead of a grid. */
+size_t st355_groupnorm_workspace(int B, int H, int W, int C);
+int st355_groupnorm_fwd(void* stream, const void* x, const void* gamma, const void* beta, void* y, float* stats, int B, int H, int W, int C,
+                        int groups, float eps, int silu, int out_tokens, void* workspace);
+/* dx = GN'(dy) (+ dadd, a grid-shaped gradient arriving on the same x through another path); dgamma/dbeta: fp32 [C] or NULL */
+int st355_groupnorm_bwd(void* stream, const void* dy, const void* x, const void* gamma, const void* beta, const float* stats, const void* dadd,
+                        void* dx, float* dgamma, float* dbeta, int B, int H, int W, int C, int groups, int silu, int dy_tokens,
+                        int accumulate_params, void* workspace);
+/* affine LayerNorm of BasicTransformerBlock (norm1/2/3): y = LN(x)*weight + bias;  bwd: dx = dres + LN'(dy*weight) */
+int st355_layernorm_fwd(void* stream, const void* x, int64_t ldx, const void* weight, const void* bias, void* y, int64_t ldy, int64_t rows, int D, float eps);
+int st355_layernorm_bwd(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* weight, const void* dres, int64_t lddres,
+                        void* dx, int64_t lddx, int64_t rows, int D, float eps);
+size_t st355_layernorm_param_grads_workspace(int D);
+int st355_layernorm_param_grads(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t rows, int D, float eps, float* dweight,
+                                float* dbias, int accumulate, void* workspace);
+/* GEGLU (FeedForward activation_fn="geglu"): h = [value | gate] (row stride ldh), out = value * gelu_erf(gate) */
+int st355_geglu_fwd(void* stream, const void* h, int64_t ldh, void* out, int64_t M, int F);
+int st355_geglu_bwd(void* stream, const void* h, int64_t ldh, const void* dout, void* dh, int64_t lddh, int64_t M, int F);
+/* plain head split / merge (no norm / RoPE): token-major column block -> [B,H,S,d] and/or transposed [B,H,d,Sp]; and back */
+int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp);
+int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S);
+/* cross-attention (UNet attn2 over the text tokens; PixArt cross-attention): Sq queries against Sk keys.  Layouts as st355_attn_fwd/bwd with
+ * Q,Qt,O,dO,lse2 over Sq (Sqp) and K,Kt,Vt,v_rows,dv_rows,key_bias over Sk (Skp); workspace = st355_attn_bwd_workspace(B,H,Sq,Sqp,d). */
+int st355_attn_cross_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O, int64_t ld_o, float* lse2,
+                         int B, int H, int Sq, int Sk, int Skp, int d, float scale);
+int st355_attn_cross_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows, int64_t ld_v, const void* O,
+                         int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, void* dQ, void* dK, void* dv_rows,
+                         int64_t ld_dv, int B, int H, int Sq, int Sqp, int Sk, int Skp, int d, float scale, void* workspace);
+
 #ifdef __cplusplus
 }
 #endif

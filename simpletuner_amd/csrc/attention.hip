@@ -23,7 +23,7 @@ template <int HD>
 __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
                                                             bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
-                                                            int S, int Sp, float scale2) {
+                                                            int Sq, int S, int Sp, float scale2) {   // Sq queries; S keys (padded Sp)
   constexpr int KROWB = HD * 2;          // bytes per K tile row
   constexpr int KT_BYTES = KB * KROWB;   // K tile
   constexpr int VT_BYTES = HD * 128;     // V^T tile: HD rows x 64 keys
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
   const int head = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + head;
   const int q0 = blockIdx.x * QB + wv * 32;
-  const int qi = min(q0 + l31, S - 1);
+  const int qi = min(q0 + l31, Sq - 1);
 
   const bf16* Kg = K + bh * (int64_t)S * HD;
   const bf16* Vg = Vt + bh * (int64_t)HD * Sp;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
   // Q fragments (MFMA B operand): lane -> query l31, head channels 16ks + 8h .. +8
   bf16x8 qf[NKS];
   {
-    const bf16* qrow = Q + (bh * S + qi) * (int64_t)HD + 8 * h;
+    const bf16* qrow = Q + (bh * Sq + qi) * (int64_t)HD + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
   }
@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int q = q0 + l31;
-  if (q < S) {
-    bf16* orow = O + ((int64_t)b * S + q) * ld_o + (int64_t)head * HD;
+  if (q < Sq) {
+    bf16* orow = O + ((int64_t)b * Sq + q) * ld_o + (int64_t)head * HD;
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
         for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc_o[dt][4 * a + bb] * inv);
         *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
       }
-    if (h == 0) lse2[bh * S + q] = m_run + __log2f(l_tot);
+    if (h == 0) lse2[bh * Sq + q] = m_run + __log2f(l_tot);
   }
 }
 
@@ -394,13 +394,13 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd2(const bf16* __restrict__ Q
   }
 }
 
-extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
-                              int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale) {
+static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
+                         int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale) {
   ST_REQUIRE(Q && K && Vt && O && lse2, "attn_fwd: null pointer");
-  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && ld_o % 4 == 0, "attn_fwd: bad shape S=%d Sp=%d", S, Sp);
+  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sq > 0 && Sp % 64 == 0 && Sp >= S && ld_o % 4 == 0, "attn_fwd: bad shape S=%d Sp=%d", S, Sp);
   if (d != 128 && d != 64) { st355_set_error("attn_fwd: head_dim %d not built", d); return ST355_ENOSYS; }
-  const double flops = 4.0 * (double)B * H * (double)S * S * d;
-  const double bytes = 2.0 * (double)B * H * S * d * 4.0;
+  const double flops = 4.0 * (double)B * H * (double)Sq * S * d;
+  const double bytes = 2.0 * (double)B * H * (Sq + S) * d * 2.0;
   ProfScope ps(stream, ST355_K_ATTN_FWD, flops, bytes);
   const float scale2 = scale * LOG2E;
   static int gen = -1;
@@ -408,7 +408,7 @@ extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const 
   // measured 761-786 TFLOP/s in-step.  ST355_ATTN_FWD=2 selects k_attn_fwd2 (8 waves, LDS-DMA, half-tile stagger): correct (same
   // parity tests) but 635-700 TFLOP/s — the forward is VALU/latency-shaped and loses the decoupling of two independent workgroups.
   if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '2') ? 2 : 1; }
-  if (gen == 2) {
+  if (gen == 2 && Sq == S) {
     dim3 grid2((S + 255) / 256, H, B);
     if (d == 128) {
       const int lds = 2 * (KB * 256 + 128 * 128);
@@ -423,17 +423,27 @@ extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const 
     }
     return st355_check_launch("attn_fwd2");
   }
-  dim3 grid((S + QB - 1) / QB, H, B), block(ATT_THREADS);
+  dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);
   if (d == 128) {
     const int lds = 2 * (KB * 256 + 128 * 128);
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
     hipLaunchKernelGGL(k_attn_fwd<128>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                       key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
+                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
   } else {
     const int lds = 2 * (KB * 128 + 64 * 128);
     hipLaunchKernelGGL(k_attn_fwd<64>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                       key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
+                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
   }
   return st355_check_launch("attn_fwd");
+}
+extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
+                              int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale) {
+  return attn_fwd_impl(stream, Q, K, Vt, key_bias, O, ld_o, lse2, B, H, S, S, Sp, d, scale);
+}
+// cross-attention (UNet attn2 over the 77 text tokens, PixArt cross-attention): Sq queries [B,H,Sq,d] against Sk keys [B,H,Sk,d], Vt [B,H,d,Skp];
+// O: [B*Sq, ld_o] token-major, lse2 [B,H,Sq]; key_bias [B,Sk] additive or NULL
+extern "C" int st355_attn_cross_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
+                                    int64_t ld_o, float* lse2, int B, int H, int Sq, int Sk, int Skp, int d, float scale) {
+  return attn_fwd_impl(stream, Q, K, Vt, key_bias, O, ld_o, lse2, B, H, Sq, Sk, Skp, d, scale);
 }

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
                                                        const bf16* __restrict__ Kt, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                        const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                        const float* __restrict__ delta, const float* __restrict__ key_bias,
-                                                       bf16* __restrict__ dQ, int H, int S, int Sp, float scale, float scale2) {
+                                                       bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk, int Skp, float scale, float scale2) {
   constexpr int NT = 512;
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
@@ -87,24 +87,24 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   const int64_t bh = (int64_t)b * H + head;
   const int q0 = blockIdx.x * 256 + wv * 32;
   const int q = q0 + l31;
-  const int qi = min(q, S - 1);
+  const int qi = min(q, Sq - 1);
 
-  const bf16* Kg = K + bh * (int64_t)S * HD;
-  const bf16* Ktg = Kt + bh * (int64_t)HD * Sp;
-  const bf16* Vg = Vrows + (int64_t)b * S * ld_v + (int64_t)head * HD;
+  const bf16* Kg = K + bh * (int64_t)Sk * HD;
+  const bf16* Ktg = Kt + bh * (int64_t)HD * Skp;
+  const bf16* Vg = Vrows + (int64_t)b * Sk * ld_v + (int64_t)head * HD;
 
   bf16x8 qf[NKS], dof[NKS];
   {
-    const bf16* qrow = Q + (bh * S + qi) * (int64_t)HD + 8 * h;
-    const bf16* drow = dO + ((int64_t)b * S + qi) * ld_do + (int64_t)head * HD + 8 * h;
+    const bf16* qrow = Q + (bh * Sq + qi) * (int64_t)HD + 8 * h;
+    const bf16* drow = dO + ((int64_t)b * Sq + qi) * ld_do + (int64_t)head * HD + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) {
       qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
       dof[ks] = *(const bf16x8*)(drow + 16 * ks);
     }
   }
-  const float lse_q = lse2[bh * S + qi];
-  const float delta_q = delta[bh * (int64_t)Sp + qi];
+  const float lse_q = lse2[bh * Sq + qi];
+  const float delta_q = delta[bh * (int64_t)Sqp + qi];
 
   f32x16 acc[NDT];
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     for (int p = 0; p < KCH; p++) {
       const int id = p * NT + tid;
       const int row = id / (HD / 8), c = id % (HD / 8);
-      const int key = min(key0 + row, S - 1);
+      const int key = min(key0 + row, Sk - 1);
       kreg[p] = *(const bf16x8*)(Kg + (int64_t)key * HD + c * 8);
       vreg[p] = *(const bf16x8*)(Vg + (int64_t)key * ld_v + c * 8);
     }
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     for (int p = 0; p < TCH; p++) {
       const int id = p * NT + tid;
       const int row = id >> 3, c = id & 7;
-      treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Sp + key0 + c * 8);
+      treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Skp + key0 + c * 8);
     }
   };
   auto store_tile = [&](int buf) {
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     }
   };
 
-  const int nkt = (S + 63) / 64;
+  const int nkt = (Sk + 63) / 64;
   const int krow_p = perm23(l31);
   load_tile(0);
   store_tile(0);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     const char* vs = ks + KT_BYTES;
     const char* ts = vs + KT_BYTES;
     const int key0 = kt * 64;
-    const bool tail = key0 + 64 > S;
+    const bool tail = key0 + 64 > Sk;
 #pragma unroll
     for (int sb = 0; sb < 2; sb++) {
       f32x16 sacc, dpacc;
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
         float pv;
         if (key_bias != nullptr || tail) {
           const int key = key0 + 32 * sb + acc_row(r, h);
-          if (key_bias != nullptr) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
-          pv = (key < S) ? fast_exp2(s - lse_q) : 0.f;
+          if (key_bias != nullptr) s += key_bias[(int64_t)b * Sk + min(key, Sk - 1)] * LOG2E;
+          pv = (key < Sk) ? fast_exp2(s - lse_q) : 0.f;
         } else {
           pv = fast_exp2(s - lse_q);
         }
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     if (kt + 1 < nkt) store_tile(buf ^ 1);
     __syncthreads();
   }
-  if (q < S) {
-    bf16* orow = dQ + (bh * S + q) * (int64_t)HD;
+  if (q < Sq) {
+    bf16* orow = dQ + (bh * Sq + q) * (int64_t)HD;
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
                                                         const bf16* __restrict__ dO, int64_t ld_do, const bf16* __restrict__ dOt,
                                                         const float* __restrict__ lse2, const float* __restrict__ delta,
                                                         const float* __restrict__ key_bias, bf16* __restrict__ dK,
-                                                        bf16* __restrict__ dVrows, int64_t ld_dv, int H, int S, int Sp, float scale,
+                                                        bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, int Skp, float scale,
                                                         float scale2) {
   constexpr int NT = 256;
   constexpr int QROWB = HD * 2;
@@ -246,24 +246,24 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
   const int head = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + head;
   const int key = blockIdx.x * 128 + wv * 32 + l31;
-  const int keyi = min(key, S - 1);
+  const int keyi = min(key, Sk - 1);
 
-  const bf16* Qg = Q + bh * (int64_t)S * HD;
-  const bf16* Qtg = Qt + bh * (int64_t)HD * Sp;
-  const bf16* dOtg = dOt + bh * (int64_t)HD * Sp;
-  const bf16* dOg = dO + (int64_t)b * S * ld_do + (int64_t)head * HD;
+  const bf16* Qg = Q + bh * (int64_t)Sq * HD;
+  const bf16* Qtg = Qt + bh * (int64_t)HD * Sqp;
+  const bf16* dOtg = dOt + bh * (int64_t)HD * Sqp;
+  const bf16* dOg = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
 
   bf16x8 kf[NKS], vf[NKS];
   {
-    const bf16* krow = K + (bh * S + keyi) * (int64_t)HD + 8 * h;
-    const bf16* vrow = Vrows + ((int64_t)b * S + keyi) * ld_v + (int64_t)head * HD + 8 * h;
+    const bf16* krow = K + (bh * Sk + keyi) * (int64_t)HD + 8 * h;
+    const bf16* vrow = Vrows + ((int64_t)b * Sk + keyi) * ld_v + (int64_t)head * HD + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) {
       kf[ks] = *(const bf16x8*)(krow + 16 * ks);
       vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
     }
   }
-  const float kb2 = key_bias ? key_bias[(int64_t)b * S + keyi] * LOG2E : 0.f;
+  const float kb2 = key_bias ? key_bias[(int64_t)b * Sk + keyi] * LOG2E : 0.f;
 
   f32x16 acc_dk[NDT], acc_dv[NDT];
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
     for (int p = 0; p < QCH; p++) {
       const int id = p * NT + tid;
       const int row = id / (HD / 8), c = id % (HD / 8);
-      const int qq = min(qq0 + row, S - 1);
+      const int qq = min(qq0 + row, Sq - 1);
       qreg[p] = *(const bf16x8*)(Qg + (int64_t)qq * HD + c * 8);
       greg[p] = *(const bf16x8*)(dOg + (int64_t)qq * ld_do + c * 8);
     }
@@ -287,13 +287,13 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
     for (int p = 0; p < TCH; p++) {
       const int id = p * NT + tid;
       const int row = id >> 3, c = id & 7;
-      qtreg[p] = *(const bf16x8*)(Qtg + (int64_t)row * Sp + qq0 + c * 8);
-      gtreg[p] = *(const bf16x8*)(dOtg + (int64_t)row * Sp + qq0 + c * 8);
+      qtreg[p] = *(const bf16x8*)(Qtg + (int64_t)row * Sqp + qq0 + c * 8);
+      gtreg[p] = *(const bf16x8*)(dOtg + (int64_t)row * Sqp + qq0 + c * 8);
     }
     if (tid < 64) {
       const int qq = qq0 + tid;
-      st_lse = (qq < S) ? lse2[bh * (int64_t)Sp + qq] : INFINITY;     // lse2 = the padded copy written by prep   // +inf -> P = exp2(-inf) = 0 for padded queries
-      st_delta = (qq < S) ? delta[bh * (int64_t)Sp + qq] : 0.f;
+      st_lse = (qq < Sq) ? lse2[bh * (int64_t)Sqp + qq] : INFINITY;     // lse2 = the padded copy written by prep   // +inf -> P = exp2(-inf) = 0 for padded queries
+      st_delta = (qq < Sq) ? delta[bh * (int64_t)Sqp + qq] : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
     if (tid < 64) { stat[tid] = st_lse; stat[64 + tid] = st_delta; }
   };
 
-  const int nqt = (S + 63) / 64;
+  const int nqt = (Sq + 63) / 64;
   const int qrow_p = perm23(l31);
   load_tile(0);
   store_tile(0);
@@ -380,9 +380,9 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict_
     if (qt + 1 < nqt) store_tile(buf ^ 1);
     __syncthreads();
   }
-  if (key < S) {
-    bf16* krow = dK + (bh * S + key) * (int64_t)HD;
-    bf16* vrow = dVrows + ((int64_t)b * S + key) * ld_dv + (int64_t)head * HD;
+  if (key < Sk) {
+    bf16* krow = dK + (bh * Sk + key) * (int64_t)HD;
+    bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
                                                          const bf16* __restrict__ dO, int64_t ld_do, const bf16* __restrict__ dOt,
                                                          const float* __restrict__ lsep, const float* __restrict__ delta,
                                                          const float* __restrict__ key_bias, bf16* __restrict__ dK,
-                                                         bf16* __restrict__ dVrows, int64_t ld_dv, int H, int S, int Sp, float scale,
+                                                         bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, int Skp, float scale,
                                                          float scale2) {
   constexpr int QROWB = HD * 2;
   constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major)
@@ -438,26 +438,26 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
   const int head = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + head;
   const int key = blockIdx.x * 256 + wv * 32 + l31;
-  const int keyi = min(key, S - 1);
+  const int keyi = min(key, Sk - 1);
 
-  const bf16* Qg = Q + bh * (int64_t)S * HD;
-  const bf16* Qtg = Qt + bh * (int64_t)HD * Sp;
-  const bf16* dOtg = dOt + bh * (int64_t)HD * Sp;
-  const bf16* dOg = dO + (int64_t)b * S * ld_do + (int64_t)head * HD;
-  const float* lse_g = lsep + bh * (int64_t)Sp;
-  const float* del_g = delta + bh * (int64_t)Sp;
+  const bf16* Qg = Q + bh * (int64_t)Sq * HD;
+  const bf16* Qtg = Qt + bh * (int64_t)HD * Sqp;
+  const bf16* dOtg = dOt + bh * (int64_t)HD * Sqp;
+  const bf16* dOg = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
+  const float* lse_g = lsep + bh * (int64_t)Sqp;
+  const float* del_g = delta + bh * (int64_t)Sqp;
 
   bf16x8 kf[NKS], vf[NKS];
   {
-    const bf16* krow = K + (bh * S + keyi) * (int64_t)HD + 8 * h;
-    const bf16* vrow = Vrows + ((int64_t)b * S + keyi) * ld_v + (int64_t)head * HD + 8 * h;
+    const bf16* krow = K + (bh * Sk + keyi) * (int64_t)HD + 8 * h;
+    const bf16* vrow = Vrows + ((int64_t)b * Sk + keyi) * ld_v + (int64_t)head * HD + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) {
       kf[ks] = *(const bf16x8*)(krow + 16 * ks);
       vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
     }
   }
-  const float kb2 = key_bias ? key_bias[(int64_t)b * S + keyi] * LOG2E : 0.f;
+  const float kb2 = key_bias ? key_bias[(int64_t)b * Sk + keyi] * LOG2E : 0.f;
 
   f32x16 acc_dk[NDT], acc_dv[NDT];
 #pragma unroll
@@ -480,14 +480,14 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
     for (int p = 0; p < QPW; p++) {
       const int row = (wv * QPW + p) * RPP + ln / CPR;             // tile row = query
       const int col = ((ln % CPR) ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7))) * 8;
-      const int qq = min(qq0 + row, S - 1);
+      const int qq = min(qq0 + row, Sq - 1);
       a_glds16(Qg + (uint32_t)(qq * HD + col), qs + (wv * QPW + p) * 1024);
       a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + (wv * QPW + p) * 1024);
     }
 #pragma unroll
     for (int p = 0; p < TPW; p++) {
       const int row = (wv * TPW + p) * 8 + (ln >> 3);              // tile row = head channel
-      const uint32_t off = (uint32_t)(row * Sp + ((ln & 7) ^ ((row >> 1) & 7)) * 8 + qq0);
+      const uint32_t off = (uint32_t)(row * Sqp + ((ln & 7) ^ ((row >> 1) & 7)) * 8 + qq0);
       a_glds16(Qtg + off, qts + (wv * TPW + p) * 1024);
       a_glds16(dOtg + off, gts + (wv * TPW + p) * 1024);
     }
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
     if (wv == 1) a_glds4(del_g + qq0 + ln, stat + 256);
   };
 
-  const int nqt = (S + 63) / 64;
+  const int nqt = (Sq + 63) / 64;
   // per-lane LDS read bases; every fragment address is base ^ (chunk_pair << 4) + an immediate (the XOR swizzles act on bit 0
   // = lane half h, folded into the base, and on bits 1.. = the k-step, applied per read)
   const int qrow_p = perm23(l31);
@@ -574,9 +574,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  if (key < S) {
-    bf16* krow = dK + (bh * S + key) * (int64_t)HD;
-    bf16* vrow = dVrows + ((int64_t)b * S + key) * ld_dv + (int64_t)head * HD;
+  if (key < Sk) {
+    bf16* krow = dK + (bh * Sk + key) * (int64_t)HD;
+    bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -596,16 +596,16 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
 // ------------------------------------------------------------------------------------------------
 static inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
+extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {   // S, Sp: the QUERY length and its padding
   return 2 * round256((size_t)B * H * Sp * sizeof(float)) + round256((size_t)B * H * d * Sp * 2);   // delta, lse (padded) + dO^T
 }
 
-extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
+static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
                               int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
-                              const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp,
+                              const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp, int Sk, int Skp,
                               int d, float scale, void* workspace) {
   ST_REQUIRE(Q && K && Qt && Kt && v_rows && O && dO && lse2 && dQ && dK && dv_rows && workspace, "attn_bwd: null pointer");
-  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S, "attn_bwd: bad shape S=%d Sp=%d", S, Sp);
+  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && Sk > 0 && Skp % 64 == 0 && Skp >= Sk, "attn_bwd: bad shape S=%d Sp=%d Sk=%d Skp=%d", S, Sp, Sk, Skp);
   ST_REQUIRE(ld_v % 8 == 0 && ld_o % 8 == 0 && ld_do % 8 == 0 && ld_dv % 4 == 0, "attn_bwd: leading dimensions must be multiples of 8");
   ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
   if (d != 128 && d != 64) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
@@ -615,7 +615,7 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
   static int dkv_gen = -1;
   if (dkv_gen < 0) { const char* e = getenv("ST355_ATTN_DKV"); dkv_gen = (e && e[0] == '1') ? 1 : 2; }   // A/B: 1 = first-generation kernel
   const float scale2 = scale * LOG2E;
-  const double fl_unit = 2.0 * (double)B * H * (double)S * S * d;  // one S x S x d contraction
+  const double fl_unit = 2.0 * (double)B * H * (double)S * Sk * d;  // one Sq x Sk x d contraction
   hipStream_t st = (hipStream_t)stream;
   int rc;
   {
@@ -628,61 +628,74 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
     if ((rc = st355_check_launch("attn_bwd_prep")) != 0) return rc;
   }
   {
-    ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * S * d * 8.0);
+    ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 4.0);
     if (dkv_gen == 2) {
-      dim3 grid((S + 255) / 256, H, B);
+      dim3 grid((Sk + 255) / 256, H, B);
       if (d == 128) {
         const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
         hipLaunchKernelGGL(k_attn_bwd_dkv2<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
                            (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
-                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
       } else {
         const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
         hipLaunchKernelGGL(k_attn_bwd_dkv2<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
                            (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
-                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
       }
     } else {
-      dim3 grid((S + 127) / 128, H, B);
+      dim3 grid((Sk + 127) / 128, H, B);
       if (d == 128) {
         const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
         hipLaunchKernelGGL(k_attn_bwd_dkv<128>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
                            (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
-                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
       } else {
         const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
         hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
                            (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
-                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, scale, scale2);
+                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
       }
   }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
   {
-    ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * S * d * 6.0);
+    ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     if (d == 128) {
       const int lds = 2 * (2 * 64 * 256 + 128 * 128);
       static bool set = false;
       if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
       hipLaunchKernelGGL(k_attn_bwd_dq<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
                          scale, scale2);
     } else {
       const int lds = 2 * (2 * 64 * 128 + 64 * 128);
       hipLaunchKernelGGL(k_attn_bwd_dq<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
                          scale, scale2);
     }
     if ((rc = st355_check_launch("attn_bwd_dq")) != 0) return rc;
   }
   return ST355_OK;
+}
+extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
+                              int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
+                              const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp,
+                              int d, float scale, void* workspace) {
+  return attn_bwd_impl(stream, Q, K, Qt, Kt, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, dQ, dK, dv_rows, ld_dv, B, H, S, Sp, S, Sp, d, scale, workspace);
+}
+// cross-attention backward: Q,Qt over Sq (padded Sqp) queries; K,Kt, v_rows / dv_rows ([B*Sk, ld]) over Sk (padded Skp) keys; workspace sized for (Sq, Sqp)
+extern "C" int st355_attn_cross_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
+                                    int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
+                                    const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int Sq, int Sqp,
+                                    int Sk, int Skp, int d, float scale, void* workspace) {
+  return attn_bwd_impl(stream, Q, K, Qt, Kt, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, dQ, dK, dv_rows, ld_dv, B, H, Sq, Sqp, Sk, Skp, d, scale, workspace);
 }

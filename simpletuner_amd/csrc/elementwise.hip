@@ -382,3 +382,51 @@ extern "C" int st355_scale_cols(void* stream, const void* in, int64_t ld_in, con
                      (const bf16*)gate, gate_stride, rows_per_batch, (bf16*)out, ld_out, M, N);
   return st355_check_launch("scale_cols");
 }
+
+// ---- GEGLU (diffusers FeedForward activation_fn="geglu" inside the UNet's BasicTransformerBlock): proj -> [value | gate], out = value * gelu(gate),
+// gelu = the exact erf form (F.gelu default).  h: [M, 2F] row stride ldh; out: [M, F].  Backward writes dh = [dout*gelu(gate) | dout*value*gelu'(gate)].
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.39894228040143268f * __expf(-0.5f * g * g);
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_geglu(const bf16* __restrict__ h, int64_t ldh, const bf16* __restrict__ dout, bf16* __restrict__ out, int64_t ldo, int64_t M,
+                                              int F) {
+  const int f8 = F / 8;
+  const int64_t n = M * f8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / f8;
+    const int c = (int)(i % f8) * 8;
+    const bf16x8 v = *(const bf16x8*)(h + m * ldh + c), g = *(const bf16x8*)(h + m * ldh + F + c);
+    if (!BWD) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = f2bf(bf2f(v[j]) * gelu_erf(bf2f(g[j])));
+      *(bf16x8*)(out + m * ldo + c) = o;
+    } else {
+      const bf16x8 d = *(const bf16x8*)(dout + m * F + c);
+      bf16x8 dv, dg;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float gg = bf2f(g[j]), dd = bf2f(d[j]);
+        dv[j] = f2bf(dd * gelu_erf(gg));
+        dg[j] = f2bf(dd * bf2f(v[j]) * gelu_erf_grad(gg));
+      }
+      *(bf16x8*)(out + m * ldo + c) = dv;
+      *(bf16x8*)(out + m * ldo + F + c) = dg;
+    }
+  }
+}
+extern "C" int st355_geglu_fwd(void* stream, const void* h, int64_t ldh, void* out, int64_t M, int F) {
+  ST_REQUIRE(h && out && M > 0 && F % 8 == 0 && ldh % 8 == 0, "geglu_fwd: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 12.0 * M * F, 6.0 * M * F);
+  hipLaunchKernelGGL(k_geglu<false>, dim3(ew_blocks(M * (F / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, ldh, (const bf16*)nullptr, (bf16*)out,
+                     (int64_t)F, M, F);
+  return st355_check_launch("geglu_fwd");
+}
+extern "C" int st355_geglu_bwd(void* stream, const void* h, int64_t ldh, const void* dout, void* dh, int64_t lddh, int64_t M, int F) {
+  ST_REQUIRE(h && dout && dh && M > 0 && F % 8 == 0 && ldh % 8 == 0 && lddh % 8 == 0, "geglu_bwd: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 24.0 * M * F, 10.0 * M * F);
+  hipLaunchKernelGGL(k_geglu<true>, dim3(ew_blocks(M * (F / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, ldh, (const bf16*)dout, (bf16*)dh, lddh, M, F);
+  return st355_check_launch("geglu_bwd");
+}

@@ -63,7 +63,30 @@ struct GemmP {
   const bf16* gate; int64_t gate_stride; int64_t rows_per_batch;
   float* partial; int ksplit;          // split-K: fp32 slabs [ksplit][M][N]
   const float* scale_a; const float* scale_b;   // fp8 Linear: out = acc * scale_a[0] * scale_b[n] (+ bias); NULL otherwise
+  // convolution-as-GEMM over a zero-bordered NHWC grid (conv.hip / st355_conv_bf16): rows = grid positions, K = taps * Cin.
+  // K-tile u reads the A rows shifted by (ty*Wp + tx) positions, tap = u / conv_tpt = 3*ty + tx (taps == 9; no shift when taps == 1);
+  // the epilogue adds img_add[image, n] and writes ZERO on border positions.  conv_taps == 0: plain GEMM.
+  int conv_taps, conv_tpt, conv_wp, conv_hp;
+  int64_t conv_row0;                            // grid position of GEMM row 0 (border test / image index)
+  const bf16* img_add; int64_t img_add_stride;
 };
+
+// grid position -> (is border, image index)
+__device__ __forceinline__ bool conv_border(const GemmP& p, int m, int& img) {
+  const int64_t pos = p.conv_row0 + m;
+  const int per = p.conv_hp * p.conv_wp;
+  img = (int)(pos / per);
+  const int q = (int)(pos - (int64_t)img * per);
+  const int y = q / p.conv_wp, x = q - y * p.conv_wp;
+  return y == 0 || y == p.conv_hp - 1 || x == 0 || x == p.conv_wp - 1;
+}
+// element offset (A operand) of K-tile u in conv mode
+__device__ __forceinline__ int64_t conv_koff(const GemmP& p, int u, int64_t lda, int bk) {
+  const int tap = u / p.conv_tpt, c = u - tap * p.conv_tpt;
+  const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;               // tap / 3 for tap < 9
+  const int shift = p.conv_taps == 9 ? ty * p.conv_wp + tx : 0;
+  return (int64_t)shift * lda + (int64_t)c * bk;
+}
 
 struct GemmGroup {
   GemmP p[2];
@@ -96,6 +119,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
     const int m = mw0 + j * 32 + (lane & 31);
     if (m >= p.M) continue;
     const int64_t bidx = (EPI == ST355_EPI_GATE_RESIDUAL) ? (int64_t)(m / p.rows_per_batch) : 0;
+    int img = 0;
+    const bool border = p.conv_taps ? conv_border(p, m, img) : false;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
 #pragma unroll
@@ -109,6 +134,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
           bf16x4 bv = *(const bf16x4*)(p.bias + n);
 #pragma unroll
           for (int b = 0; b < 4; b++) v[b] += bf2f(bv[b]);
+        }
+        if (p.img_add) {
+          bf16x4 tv = *(const bf16x4*)(p.img_add + (int64_t)img * p.img_add_stride + n);
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] += bf2f(tv[b]);
         }
         if (EPI == ST355_EPI_GELU) {
           if (p.aux_out) {
@@ -143,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
         }
         bf16x4 o;
 #pragma unroll
-        for (int b = 0; b < 4; b++) o[b] = f2bf(v[b]);
+        for (int b = 0; b < 4; b++) o[b] = f2bf(border ? 0.f : v[b]);
         *(bf16x4*)(p.C + (int64_t)m * p.ldc + n) = o;
       }
     }
@@ -200,6 +230,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
         *(f32x4*)(dst + 4) = hi;
         continue;
       }
+      int img = 0;
+      const bool border = p.conv_taps ? conv_border(p, m, img) : false;
       float v[8];
       if (p.scale_b) {                                  // fp8 Linear: row-wise scaling of torch._scaled_mm (fp8_native.py:64-75)
         const float sa = p.scale_a[0];
@@ -209,6 +241,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
       } else {
 #pragma unroll
         for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
+      }
+      if (p.img_add) {
+        const bf16x8 tv = *(const bf16x8*)(p.img_add + (int64_t)img * p.img_add_stride + n);
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] += bf2f(tv[b]);
       }
       if (EPI == ST355_EPI_GELU) {
         if (p.aux_out) {
@@ -244,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
       }
       bf16x8 o;
 #pragma unroll
-      for (int b = 0; b < 8; b++) o[b] = f2bf(v[b]);
+      for (int b = 0; b < 8; b++) o[b] = f2bf(border ? 0.f : v[b]);
       *(bf16x8*)(p.C + (int64_t)m * p.ldc + n) = o;
     }
   }
@@ -256,6 +293,7 @@ __device__ __forceinline__ bool epl_aligned(const GemmP& p) {
   if (p.aux_out) ok = ok && (p.ld_aux_out % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0);
   if (p.aux_in) ok = ok && (p.ld_aux_in % 8 == 0) && (((uintptr_t)p.aux_in & 15) == 0);
   if (p.gate) ok = ok && (p.gate_stride % 8 == 0) && (((uintptr_t)p.gate & 15) == 0);
+  if (p.img_add) ok = ok && (p.img_add_stride % 8 == 0) && (((uintptr_t)p.img_add & 15) == 0);
   return ok;
 }
 
@@ -800,7 +838,10 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const uint32_t lda_b = (uint32_t)p.lda * ES, ldb_b = (uint32_t)p.ldb * ES;
   const int64_t xk_step = TN ? (int64_t)PQ_BK * lda_b : PQ_BK * 2;     // bytes per K-tile along the contraction
   const int64_t wk_step = TN ? (int64_t)PQ_BK * ldb_b : PQ_BK * 2;
-  xbase += t_first * xk_step; wbase += t_first * wk_step;
+  const bool conv = !TN && !F8 && p.conv_taps != 0;
+  if (!conv) xbase += t_first * xk_step;
+  wbase += t_first * wk_step;
+
   auto x_rel = [&](int lr, int r) { return min(m0 + (lr >> 6) * 128 + (lr & 63) + r * 64, M - 1) - m0; };
   auto w_rel = [&](int lr, int r) { return min(n0 + (lr >> 5) * 64 + (lr & 31) + r * 32, N - 1) - n0; };
   uint32_t xo[2][2], wo[2][2];               // [region A/B][piece] byte offsets from xbase / wbase
@@ -840,13 +881,14 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   auto stage_x = [&](int u, int r) {        // r = 0: XA, 1: XB
     char* dst = smem + (u & 1) * PQ_BUF + r * PQ_REGION + wv * 2048;
     if (u < nt1) {
+      const int x_ko = conv ? (int)(conv_koff(p, u + t_first, p.lda, PQ_BK) * 2) : (int)(u * xk_step);
       if (PQ_BUFLD) {       // measured +6..7 % over global_load_lds with 64-bit per-lane addresses (8192^3: 1317 -> 1414 TFLOP/s)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, xo[r][j], (int)(u * xk_step), 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, xo[r][j], x_ko, 0, 0);
         return;
       }
-      const char* kb = xbase + u * xk_step;
+      const char* kb = xbase + x_ko;
 #pragma unroll
       for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + xo[r][j]), dst + j * 1024);
     } else {
@@ -1060,6 +1102,7 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
     const bf16* Ap; const bf16* Bp; int64_t la, lb; int k0;
     if (t < nt1) { Ap = p.A; la = p.lda; Bp = p.B; lb = p.ldb; k0 = t * BK; }
     else { Ap = p.A2; la = p.lda2; Bp = p.B2; lb = p.ldb2; k0 = (t - nt1) * BK; }
+    const int64_t ka = (p.conv_taps && t < nt1) ? conv_koff(p, t, la, BK) : (int64_t)k0;
     char* xs = smem + buf * S2_STAGE;
     char* ws = xs + S2_TILE;
 #pragma unroll
@@ -1067,7 +1110,7 @@ __global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
       const int r0 = (wv * 4 + j) * 8;
       const int row = r0 + st_row;
       const int c = st_cp ^ ((row >> 1) & 7);
-      glds16(Ap + (int64_t)min(m0 + row, p.M - 1) * la + k0 + c * 8, xs + r0 * 128);
+      glds16(Ap + (int64_t)min(m0 + row, p.M - 1) * la + ka + c * 8, xs + r0 * 128);
       glds16(Bp + (int64_t)min(n0 + row, p.N - 1) * lb + k0 + c * 8, ws + r0 * 128);
     }
   };
@@ -1180,6 +1223,7 @@ static GemmP to_p(const st355_gemm_args* a) {
   p.gate = (const bf16*)a->gate; p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch;
   p.partial = nullptr; p.ksplit = 1;
   p.scale_a = nullptr; p.scale_b = nullptr;
+  p.conv_taps = 0; p.conv_tpt = 1; p.conv_wp = 0; p.conv_hp = 0; p.conv_row0 = 0; p.img_add = nullptr; p.img_add_stride = 0;
   return p;
 }
 
@@ -1382,6 +1426,63 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
     return st355_check_launch("gemm_tn_splitk_reduce");
   }
   return accumulate ? launch_tn<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_tn<ST355_EPI_NONE>(stream, g, g.tiles0);
+}
+
+// ---- convolution over a zero-bordered NHWC grid (SDXL / SD1.5 UNet, VAE: diffusers ResnetBlock2D / Downsample2D / Upsample2D convs) -------
+// grid buffer = [st355_conv_grid_rows(B,H,W), C] bf16: position (b, y, x) of the (H+2) x (W+2) padded image b is row (b*(H+2)+y)*(W+2)+x,
+// border positions hold ZERO, and 64 zero rows follow the last image (so that shifted / 64-rounded reads stay inside the buffer).
+// 3x3 stride-1 pad-1 conv == ONE GEMM over the grid whose K loop walks the 9 taps as row-shifted views of x (no im2col); 1x1 conv and
+// pre-gathered columns (stride 2, tiny Cin) are the taps == 1 case.  Rows [Wp+1, rows - Wp - 1) are computed (every read stays inside
+// the images); the first / last Wp+1 positions are border positions and are zero-filled here.
+extern "C" int64_t st355_conv_grid_rows(int B, int H, int W) { return (int64_t)B * (H + 2) * (W + 2) + 64; }
+
+extern "C" int st355_conv_bf16(void* stream, const void* x, const void* w, const void* bias, const void* img_add, int64_t img_add_stride,
+                               const void* residual, void* out, int B, int H, int W, int Cin, int Cout, int taps) {
+  ST_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0, "conv: bad args");
+  ST_REQUIRE(taps == 1 || taps == 9, "conv: taps must be 1 or 9");
+  ST_REQUIRE(Cin % BK == 0 && Cout % 8 == 0, "conv: Cin (%d) must be a multiple of 64 and Cout (%d) of 8", Cin, Cout);
+  ST_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)out % 16 == 0), "conv: misaligned pointer");
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t Mtot = (int64_t)B * Hp * Wp, p0 = Wp + 1, Mc = Mtot - 2 * p0;
+  ST_REQUIRE(Mc > 0 && Mc < ((int64_t)1 << 31), "conv: grid too large");
+  ST_REQUIRE(256 * (int64_t)Cin * 2 + (2 * (int64_t)Wp + 2) * Cin * 2 + Cin * 2 < ((int64_t)1 << 31), "conv: a tile must fit 32-bit offsets");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16*)x + (taps == 9 ? 0 : p0 * Cin); p.lda = Cin;
+  p.B = (const bf16*)w; p.ldb = (int64_t)taps * Cin;
+  p.C = (bf16*)out + p0 * Cout; p.ldc = Cout;
+  p.M = (int)Mc; p.N = Cout; p.K = taps * Cin; p.K2 = 0; p.ksplit = 1;
+  p.bias = (const bf16*)bias;
+  if (residual) { p.aux_in = (const bf16*)residual + p0 * Cout; p.ld_aux_in = Cout; }
+  p.conv_taps = taps; p.conv_tpt = Cin / BK; p.conv_wp = Wp; p.conv_hp = Hp; p.conv_row0 = p0;
+  p.img_add = (const bf16*)img_add; p.img_add_stride = img_add_stride;
+  hipMemsetAsync(out, 0, (size_t)p0 * Cout * 2, (hipStream_t)stream);
+  hipMemsetAsync((bf16*)out + (Mtot - p0) * Cout, 0, (size_t)p0 * Cout * 2, (hipStream_t)stream);
+  ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)Mc * Cout * taps * Cin, 2.0 * ((double)Mtot * Cin + (double)Cout * taps * Cin + (double)Mtot * Cout * (residual ? 2 : 1)),
+               "CONV%d %dx%dx%d b%d %dx%d", taps, (int)Mc, Cout, taps * Cin, B, H, W);
+  if (gemm_impl_choice() >= 4 && p4_tiles(p) >= min_tiles_256()) {
+    GemmGroup g;
+    g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    return residual ? launch_pq<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_pq<ST355_EPI_NONE>(stream, g, g.tiles0);
+  }
+  return residual ? launch_s2<ST355_EPI_ADD>(stream, p) : launch_s2<ST355_EPI_NONE>(stream, p);
+}
+
+// weight gradient of the same convolution: dw[co, tap*Cin + ci] = sum_pos dy[pos, co] * x[pos + shift(tap), ci]  (one TN GEMM per tap;
+// border rows of dy are zero, so rounding the contraction up to 64 rows only adds zero terms)
+extern "C" int st355_conv_wgrad_bf16(void* stream, const void* x, const void* dy, void* dw, int B, int H, int W, int Cin, int Cout, int taps,
+                                     int accumulate, void* workspace, int64_t workspace_bytes) {
+  ST_REQUIRE(x && dy && dw && (taps == 1 || taps == 9), "conv_wgrad: bad args");
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t Mtot = (int64_t)B * Hp * Wp, p0 = Wp + 1;
+  const int64_t Mc = ((Mtot - 2 * p0 + 63) / 64) * 64;
+  for (int tap = 0; tap < taps; tap++) {
+    const int64_t shift = taps == 9 ? (int64_t)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
+    int rc = st355_gemm_tn_bf16(stream, (const bf16*)dy + p0 * Cout, Cout, (const bf16*)x + (p0 + shift) * Cin, Cin, (bf16*)dw + (int64_t)tap * Cin,
+                                (int64_t)taps * Cin, Mc, Cout, Cin, accumulate, workspace, workspace_bytes);
+    if (rc) return rc;
+  }
+  return ST355_OK;
 }
 
 extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count) {

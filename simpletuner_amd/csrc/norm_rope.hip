@@ -11,7 +11,7 @@
 template <int NC>
 __global__ void __launch_bounds__(256) k_ln_mod_fwd(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ scale,
                                                    const bf16* __restrict__ shift, int64_t mod_stride, int64_t rows_per_batch,
-                                                   bf16* __restrict__ y, int64_t ldy, int64_t rows, int D, float eps) {
+                                                   bf16* __restrict__ y, int64_t ldy, int64_t rows, int D, float eps, float one) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -53,15 +53,15 @@ __global__ void __launch_bounds__(256) k_ln_mod_fwd(const bf16* __restrict__ x, 
       bf16x8 shv = *(const bf16x8*)(sh + idx);
       bf16x8 o;
 #pragma unroll
-      for (int j = 0; j < 8; j++) o[j] = f2bf((v[c][j] - mean) * rstd * (1.f + bf2f(scv[j])) + bf2f(shv[j]));
+      for (int j = 0; j < 8; j++) o[j] = f2bf((v[c][j] - mean) * rstd * (one + bf2f(scv[j])) + bf2f(shv[j]));
       *(bf16x8*)(yr + idx) = o;
     }
   }
 }
 
-extern "C" int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,
+static int ln_fwd_impl(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,
                                      int64_t mod_stride, int64_t rows_per_batch, void* y, int64_t ldy, int64_t rows, int D,
-                                     float eps) {
+                                     float eps, float one) {
   ST_REQUIRE(x && scale && shift && y, "ln_modulate_fwd: null pointer");
   ST_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 8 == 0 && rows > 0 && rows_per_batch > 0,
              "ln_modulate_fwd: bad shape D=%d", D);
@@ -69,7 +69,7 @@ extern "C" int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, c
   dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
 #define LAUNCH(NC)                                                                                                       \
   hipLaunchKernelGGL(k_ln_mod_fwd<NC>, grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)scale,       \
-                     (const bf16*)shift, mod_stride, rows_per_batch, (bf16*)y, ldy, rows, D, eps)
+                     (const bf16*)shift, mod_stride, rows_per_batch, (bf16*)y, ldy, rows, D, eps, one)
   if (D <= 512) LAUNCH(1);
   else if (D <= 1024) LAUNCH(2);
   else if (D <= 1536) LAUNCH(3);
@@ -79,6 +79,16 @@ extern "C" int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, c
 #undef LAUNCH
   return st355_check_launch("ln_modulate_fwd");
 }
+extern "C" int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,
+                                     int64_t mod_stride, int64_t rows_per_batch, void* y, int64_t ldy, int64_t rows, int D,
+                                     float eps) {
+  return ln_fwd_impl(stream, x, ldx, scale, shift, mod_stride, rows_per_batch, y, ldy, rows, D, eps, 1.f);
+}
+// plain affine LayerNorm  y = LN(x) * weight + bias  (the UNet's BasicTransformerBlock norm1/2/3, eps 1e-5): same kernel, weight in place of (1+scale)
+extern "C" int st355_layernorm_fwd(void* stream, const void* x, int64_t ldx, const void* weight, const void* bias, void* y, int64_t ldy, int64_t rows, int D,
+                                   float eps) {
+  return ln_fwd_impl(stream, x, ldx, weight, bias, 0, rows, y, ldy, rows, D, eps, 0.f);
+}
 
 // backward: g = dy*(1+scale); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres];  dxg = gate*dx
 template <int NC>
@@ -87,7 +97,7 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd(const bf16* __restrict__ dy,
                                                    int64_t rows_per_batch, const bf16* __restrict__ dres, int64_t lddres,
                                                    const bf16* __restrict__ gate, int64_t gate_stride, bf16* __restrict__ dx,
                                                    int64_t lddx, bf16* __restrict__ dxg, int64_t lddxg, int64_t rows, int D,
-                                                   float eps) {
+                                                   float eps, float one) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -108,7 +118,7 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd(const bf16* __restrict__ dy,
       for (int j = 0; j < 8; j++) {
         v[c][j] = bf2f(t[j]);
         s += v[c][j];
-        g[c][j] = bf2f(d[j]) * (1.f + bf2f(scv[j]));
+        g[c][j] = bf2f(d[j]) * (one + bf2f(scv[j]));
       }
     } else {
 #pragma unroll
@@ -169,10 +179,10 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd(const bf16* __restrict__ dy,
   }
 }
 
-extern "C" int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* scale,
+static int ln_bwd_impl(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* scale,
                                      int64_t mod_stride, int64_t rows_per_batch, const void* dres, int64_t lddres,
                                      const void* gate, int64_t gate_stride, void* dx, int64_t lddx, void* dxg, int64_t lddxg,
-                                     int64_t rows, int D, float eps) {
+                                     int64_t rows, int D, float eps, float one) {
   ST_REQUIRE(dy && x && scale && dx, "ln_modulate_bwd: null pointer");
   ST_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && mod_stride % 8 == 0 && rows > 0 &&
                  rows_per_batch > 0, "ln_modulate_bwd: bad shape D=%d", D);
@@ -183,7 +193,7 @@ extern "C" int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy,
 #define LAUNCH(NC)                                                                                                        \
   hipLaunchKernelGGL(k_ln_mod_bwd<NC>, grid, block, 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const bf16*)x, ldx,     \
                      (const bf16*)scale, mod_stride, rows_per_batch, (const bf16*)dres, lddres, (const bf16*)gate,          \
-                     gate_stride, (bf16*)dx, lddx, (bf16*)dxg, lddxg, rows, D, eps)
+                     gate_stride, (bf16*)dx, lddx, (bf16*)dxg, lddxg, rows, D, eps, one)
   if (D <= 512) LAUNCH(1);
   else if (D <= 1024) LAUNCH(2);
   else if (D <= 1536) LAUNCH(3);
@@ -192,6 +202,98 @@ extern "C" int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy,
   else LAUNCH(8);
 #undef LAUNCH
   return st355_check_launch("ln_modulate_bwd");
+}
+extern "C" int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* scale,
+                                     int64_t mod_stride, int64_t rows_per_batch, const void* dres, int64_t lddres,
+                                     const void* gate, int64_t gate_stride, void* dx, int64_t lddx, void* dxg, int64_t lddxg,
+                                     int64_t rows, int D, float eps) {
+  return ln_bwd_impl(stream, dy, lddy, x, ldx, scale, mod_stride, rows_per_batch, dres, lddres, gate, gate_stride, dx, lddx, dxg, lddxg, rows, D, eps, 1.f);
+}
+// dx = dres + LNbwd(dy * weight)   (weight / bias gradients: st355_colsum_prod on dy and dy * xhat)
+extern "C" int st355_layernorm_bwd(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* weight, const void* dres, int64_t lddres,
+                                   void* dx, int64_t lddx, int64_t rows, int D, float eps) {
+  return ln_bwd_impl(stream, dy, lddy, x, ldx, weight, 0, rows, dres, lddres, nullptr, 0, dx, lddx, nullptr, 0, rows, D, eps, 0.f);
+}
+
+// affine LayerNorm parameter gradients: dweight[c] = sum_rows dy*xhat, dbias[c] = sum_rows dy.  A wave walks rows (stride = waves in the grid) with the
+// row in registers (statistics recomputed), a lane owns the same channels for every row, partials [wave][D][2] -> fixed-order reduce.
+template <int NC>
+__global__ void __launch_bounds__(256) k_ln_param_partials(const bf16* __restrict__ dy, int64_t lddy, const bf16* __restrict__ x, int64_t ldx, int64_t rows, int D,
+                                                          float eps, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  float aw[NC][8], ab[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; c++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) { aw[c][j] = 0.f; ab[c][j] = 0.f; }
+  for (int64_t row = wave; row < rows; row += nw) {
+    float v[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int idx = (c * 64 + lane) * 8;
+      if (idx < D) {
+        const bf16x8 t = *(const bf16x8*)(x + row * ldx + idx);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { v[c][j] = bf2f(t[j]); s += v[c][j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[c][j] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int idx = (c * 64 + lane) * 8;
+      if (idx < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float d = v[c][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int idx = (c * 64 + lane) * 8;
+      if (idx < D) {
+        const bf16x8 d = *(const bf16x8*)(dy + row * lddy + idx);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float g = bf2f(d[j]); aw[c][j] += g * (v[c][j] - mean) * rstd; ab[c][j] += g; }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (idx < D) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { partial[((int64_t)wave * D + idx + j) * 2] = aw[c][j]; partial[((int64_t)wave * D + idx + j) * 2 + 1] = ab[c][j]; }
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nw, int D, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                        int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int w = 0; w < nw; w++) { a += partial[((int64_t)w * D + c) * 2]; b += partial[((int64_t)w * D + c) * 2 + 1]; }
+  if (accumulate) { dweight[c] += a; dbias[c] += b; } else { dweight[c] = a; dbias[c] = b; }
+}
+#define LNP_BLOCKS 256
+extern "C" size_t st355_layernorm_param_grads_workspace(int D) { return (size_t)LNP_BLOCKS * 4 * D * 2 * 4; }
+extern "C" int st355_layernorm_param_grads(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t rows, int D, float eps, float* dweight,
+                                           float* dbias, int accumulate, void* workspace) {
+  ST_REQUIRE(dy && x && dweight && dbias && workspace && rows > 0 && D % 8 == 0 && D <= 2048 && ldx % 8 == 0 && lddy % 8 == 0, "layernorm_param_grads: bad args");
+  ProfScope ps(stream, ST355_K_LN_MOD, 8.0 * rows * D, 4.0 * rows * D);
+#define LAUNCH(NC) hipLaunchKernelGGL(k_ln_param_partials<NC>, dim3(LNP_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, lddy, (const bf16*)x, ldx, rows, D, eps, (float*)workspace)
+  if (D <= 512) LAUNCH(1);
+  else if (D <= 1024) LAUNCH(2);
+  else if (D <= 1536) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, LNP_BLOCKS * 4, D, dweight, dbias, accumulate);
+  return st355_check_launch("layernorm_param_grads");
 }
 
 // ================================================================================================
@@ -400,4 +502,83 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
     hipLaunchKernelGGL(k_qk_norm_rope_bwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK,
                        (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps);
   return st355_check_launch("qk_norm_rope_bwd");
+}
+
+// ================================================================================================
+// plain head split / merge (no norm, no RoPE): the UNet's attention (diffusers Attention with AttnProcessor2_0: q,k,v -> [B,H,S,d]).
+//   split: src [B*S, ld] token-major (the caller offsets the pointer to the q / k / v column block) -> X [B,H,S,d] and/or Xt [B,H,d,Sp]
+//   merge: dX [B,H,S,d] -> dst [B*S, ld] token-major
+// ================================================================================================
+template <int HD>
+__global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src, int64_t ld, bf16* __restrict__ X, bf16* __restrict__ Xt, int H, int S, int Sp) {
+  constexpr int TPR = HD / 8;
+  constexpr int TOK_PER_PASS = 256 / TPR;
+  __shared__ __attribute__((aligned(16))) bf16 tile[64 * TP];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int c = tid % TPR;
+  const int64_t bh = (int64_t)b * H + h;
+  for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    const int t = t0 + tl;
+    const bool valid = t < S;
+    const int tt = valid ? t : S - 1;
+    const bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * S + tt) * ld + (int64_t)h * HD + c * 8);
+    if (valid && X) *(bf16x8*)(X + (bh * S + t) * HD + c * 8) = v;
+    uint32_t* tq = (uint32_t*)(&tile[tl * TP + c * 8]);
+    const u32x4 w = *(const u32x4*)&v;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tq[j] = w[j];
+  }
+  if (!Xt) return;
+  __syncthreads();
+  const int nvalid = min(64, S - t0);
+  for (int i = tid; i < HD * 8; i += 256) {
+    const int d = i >> 3, tc = i & 7;
+    bf16* dst = Xt + (bh * HD + d) * (int64_t)Sp + t0 + tc * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = tile[(tc * 8 + e) * TP + d];
+    if (tc * 8 + 8 <= nvalid) {
+      *(bf16x8*)dst = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (tc * 8 + e < nvalid) dst[e] = o[e];
+    }
+  }
+}
+template <int HD>
+__global__ void __launch_bounds__(256) k_head_merge(const bf16* __restrict__ dX, bf16* __restrict__ dst, int64_t ld, int H, int S) {
+  constexpr int TPR = HD / 8;
+  const int64_t n = (int64_t)gridDim.z * H * S * TPR;   // gridDim.z = B
+  (void)n;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int t = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, c = threadIdx.x % TPR;
+  if (t >= S) return;
+  const int64_t bh = (int64_t)b * H + h;
+  *(bf16x8*)(dst + ((int64_t)b * S + t) * ld + (int64_t)h * HD + c * 8) = *(const bf16x8*)(dX + (bh * S + t) * HD + c * 8);
+}
+extern "C" int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp) {
+  ST_REQUIRE(src && (X || Xt) && ld % 8 == 0 && S > 0 && (!Xt || (Sp % 64 == 0 && Sp >= S)), "head_split: bad args");
+  ST_REQUIRE(d == 128 || d == 64, "head_split: head_dim %d not built", d);
+  ST_REQUIRE(((uintptr_t)src % 16) == 0, "head_split: misaligned source");
+  const double n = (double)B * S * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, (2.0 + (X ? 2.0 : 0.0) + (Xt ? 2.0 : 0.0)) * n);
+  dim3 grid((S + 63) / 64, H, B), block(256);
+  if (d == 128) hipLaunchKernelGGL(k_head_split<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
+  else hipLaunchKernelGGL(k_head_split<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
+  return st355_check_launch("head_split");
+}
+extern "C" int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S) {
+  ST_REQUIRE(dX && dst && ld % 8 == 0 && S > 0, "head_merge: bad args");
+  ST_REQUIRE(d == 128 || d == 64, "head_merge: head_dim %d not built", d);
+  ST_REQUIRE(((uintptr_t)dst % 16) == 0, "head_merge: misaligned destination");
+  const double n = (double)B * S * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, 4.0 * n);
+  const int tpb = 256 / (d / 8);
+  dim3 grid((S + tpb - 1) / tpb, H, B), block(256);
+  if (d == 128) hipLaunchKernelGGL(k_head_merge<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
+  else hipLaunchKernelGGL(k_head_merge<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
+  return st355_check_launch("head_merge");
 }

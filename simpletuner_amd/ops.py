@@ -586,3 +586,247 @@ def prof_collect():
     ms = (C.c_double * n)(); la = (C.c_int64 * n)(); fl = (C.c_double * n)(); by = (C.c_double * n)()
     _l.load().st355_prof_collect(ms, la, fl, by, n)
     return {k: {"ms": ms[i], "launches": la[i], "flops": fl[i], "bytes": by[i]} for i, k in enumerate(_l.KERNEL_CLASSES)}
+
+
+# ------------------------------------------------------------------------------------------------
+# UNet path: grid buffers, convolution-as-GEMM, GroupNorm, GEGLU, affine LayerNorm, cross-attention
+# ------------------------------------------------------------------------------------------------
+def grid_rows(B: int, H: int, W: int) -> int:
+    return int(_l.load().st355_conv_grid_rows(B, H, W))
+
+
+_grid_pool = {}
+
+
+def grid_zeros(B: int, H: int, W: int, C_: int, device, pool: bool = False):
+    """a zero-filled grid buffer [grid_rows, C] (border + 64 tail rows stay zero: kernels never write them non-zero)"""
+    return torch.zeros(grid_rows(B, H, W), C_, dtype=BF16, device=device)
+
+
+def grid_from_nchw(x, Cpad: int):
+    L = _l.load()
+    _chk(x, BF16, "x")
+    B, Cn, H, W = x.shape
+    g = grid_zeros(B, H, W, Cpad, x.device)
+    _l.check(L.st355_grid_from_nchw(_stream(), _ptr(x.contiguous()), _ptr(g), B, Cn, H, W, Cpad), "grid_from_nchw")
+    return g
+
+
+def grid_to_nchw(g, B: int, Cn: int, H: int, W: int):
+    L = _l.load()
+    _chk(g, BF16, "grid")
+    y = torch.empty(B, Cn, H, W, dtype=BF16, device=g.device)
+    _l.check(L.st355_grid_to_nchw(_stream(), _ptr(g), _ptr(y), B, Cn, H, W, g.shape[1]), "grid_to_nchw")
+    return y
+
+
+def conv(x, w, B: int, H: int, W: int, bias=None, img_add=None, residual=None, taps: int = 9, out=None):
+    """grid conv (3x3 stride 1 pad 1 for taps=9; 1x1 / pre-gathered columns for taps=1).  x: grid [.., Cin]; w: [Cout, taps*Cin]"""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    if w.shape[1] != taps * Cin or not w.is_contiguous() or not x.is_contiguous():
+        raise _l.St355Error(f"conv: weight {tuple(w.shape)} does not match taps*Cin = {taps}*{Cin} (or non-contiguous operands)")
+    if x.shape[0] != grid_rows(B, H, W):
+        raise _l.St355Error(f"conv: x has {x.shape[0]} rows, a ({B},{H},{W}) grid has {grid_rows(B, H, W)}")
+    if out is None:
+        out = grid_zeros(B, H, W, Cout, x.device)
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    if img_add is not None:
+        _chk(img_add, BF16, "img_add")
+    if residual is not None:
+        _chk(residual, BF16, "residual")
+    _l.check(L.st355_conv_bf16(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(img_add), _rows(img_add, "img_add") if img_add is not None else 0,
+                               _ptr(residual), _ptr(out), B, H, W, Cin, Cout, taps), "conv_bf16")
+    return out
+
+
+def conv_wgrad(x, dy, dw, B: int, H: int, W: int, taps: int = 9, accumulate: bool = False):
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(dw, BF16, "dw")
+    Cin, Cout = x.shape[1], dy.shape[1]
+    if tuple(dw.shape) != (Cout, taps * Cin) or not dw.is_contiguous():
+        raise _l.St355Error(f"conv_wgrad: dw must be a contiguous [{Cout}, {taps * Cin}] tensor")
+    ws = _gemm_workspace(x.device)
+    _l.check(L.st355_conv_wgrad_bf16(_stream(), _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, taps, 1 if accumulate else 0, _ptr(ws),
+                                     ws.numel() * ws.element_size()), "conv_wgrad_bf16")
+    return dw
+
+
+def im2col3x3(x, B: int, H: int, W: int, stride: int = 1):
+    L = _l.load()
+    _chk(x, BF16, "x")
+    Cn = x.shape[1]
+    Kpad = (9 * Cn + 63) // 64 * 64
+    col = grid_zeros(B, H // stride, W // stride, Kpad, x.device)
+    _l.check(L.st355_im2col3x3(_stream(), _ptr(x), _ptr(col), B, H, W, Cn, stride, Kpad), "im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, B: int, H: int, W: int, Cn: int, stride: int = 1):
+    L = _l.load()
+    _chk(dcol, BF16, "dcol")
+    dx = grid_zeros(B, H, W, Cn, dcol.device)
+    _l.check(L.st355_col2im3x3(_stream(), _ptr(dcol), _ptr(dx), B, H, W, Cn, stride, dcol.shape[1]), "col2im3x3")
+    return dx
+
+
+def upsample2x(x, B: int, H: int, W: int):
+    L = _l.load()
+    _chk(x, BF16, "x")
+    y = grid_zeros(B, 2 * H, 2 * W, x.shape[1], x.device)
+    _l.check(L.st355_upsample2x(_stream(), _ptr(x), _ptr(y), B, H, W, x.shape[1]), "upsample2x")
+    return y
+
+
+def upsample2x_bwd(dy, B: int, H: int, W: int):
+    L = _l.load()
+    _chk(dy, BF16, "dy")
+    dx = grid_zeros(B, H, W, dy.shape[1], dy.device)
+    _l.check(L.st355_upsample2x_bwd(_stream(), _ptr(dy), _ptr(dx), B, H, W, dy.shape[1]), "upsample2x_bwd")
+    return dx
+
+
+def tokens_to_grid(tokens, B: int, H: int, W: int, residual=None):
+    L = _l.load()
+    _chk(tokens, BF16, "tokens")
+    g = grid_zeros(B, H, W, tokens.shape[1], tokens.device)
+    _l.check(L.st355_tokens_to_grid(_stream(), _ptr(tokens), _ptr(residual), _ptr(g), B, H, W, tokens.shape[1]), "tokens_to_grid")
+    return g
+
+
+def grid_to_tokens(g, B: int, H: int, W: int):
+    L = _l.load()
+    _chk(g, BF16, "grid")
+    t = torch.empty(B * H * W, g.shape[1], dtype=BF16, device=g.device)
+    _l.check(L.st355_grid_to_tokens(_stream(), _ptr(g), _ptr(t), B, H, W, g.shape[1]), "grid_to_tokens")
+    return t
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(B, H, W, Cn, device):
+    need = _l.load().st355_groupnorm_workspace(B, H, W, Cn)
+    ws = _gn_ws.get(device.index)
+    if ws is None or ws.numel() < need:
+        ws = _gn_ws[device.index] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
+def groupnorm_fwd(x, gamma, beta, B: int, H: int, W: int, groups: int = 32, eps: float = 1e-5, silu: bool = True, out_tokens: bool = False):
+    """returns (y, stats).  y: grid [.., C] or dense tokens [B*H*W, C]; stats [B,C,2] fp32 for the backward"""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    Cn = x.shape[1]
+    y = torch.empty(B * H * W, Cn, dtype=BF16, device=x.device) if out_tokens else grid_zeros(B, H, W, Cn, x.device)
+    stats = torch.empty(B, Cn, 2, dtype=F32, device=x.device)
+    _l.check(L.st355_groupnorm_fwd(_stream(), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, H, W, Cn, groups, eps, 1 if silu else 0,
+                                   1 if out_tokens else 0, _ptr(_gn_workspace(B, H, W, Cn, x.device))), "groupnorm_fwd")
+    return y, stats
+
+
+def groupnorm_bwd(dy, x, gamma, beta, stats, B: int, H: int, W: int, groups: int = 32, silu: bool = True, dy_tokens: bool = False, dadd=None,
+                  dgamma=None, dbeta=None, accumulate_params: bool = False):
+    L = _l.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(stats, F32, "stats")
+    Cn = x.shape[1]
+    dx = grid_zeros(B, H, W, Cn, x.device)
+    _l.check(L.st355_groupnorm_bwd(_stream(), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dadd), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                   B, H, W, Cn, groups, 1 if silu else 0, 1 if dy_tokens else 0, 1 if accumulate_params else 0,
+                                   _ptr(_gn_workspace(B, H, W, Cn, x.device))), "groupnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, weight, bias, eps: float = 1e-5, out=None):
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(weight, BF16, "weight"); _chk(bias, BF16, "bias")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty(rows, D, dtype=BF16, device=x.device)
+    _l.check(L.st355_layernorm_fwd(_stream(), _ptr(x), _rows(x, "x"), _ptr(weight), _ptr(bias), _ptr(out), _rows(out, "out"), rows, D, eps), "layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dy, x, weight, dres=None, eps: float = 1e-5):
+    L = _l.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(weight, BF16, "weight")
+    rows, D = x.shape
+    dx = torch.empty(rows, D, dtype=BF16, device=x.device)
+    _l.check(L.st355_layernorm_bwd(_stream(), _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(weight), _ptr(dres),
+                                   _rows(dres, "dres") if dres is not None else 0, _ptr(dx), _rows(dx, "dx"), rows, D, eps), "layernorm_bwd")
+    return dx
+
+
+_lnp_ws = {}
+
+
+def layernorm_param_grads(dy, x, dweight, dbias, eps: float = 1e-5, accumulate: bool = False):
+    L = _l.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dweight, F32, "dweight"); _chk(dbias, F32, "dbias")
+    rows, D = x.shape
+    need = L.st355_layernorm_param_grads_workspace(D)
+    ws = _lnp_ws.get(x.device.index)
+    if ws is None or ws.numel() < need:
+        ws = _lnp_ws[x.device.index] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _l.check(L.st355_layernorm_param_grads(_stream(), _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), rows, D, eps, _ptr(dweight), _ptr(dbias),
+                                           1 if accumulate else 0, _ptr(ws)), "layernorm_param_grads")
+
+
+def geglu_fwd(h):
+    L = _l.load()
+    _chk(h, BF16, "h")
+    M, F2 = h.shape
+    out = torch.empty(M, F2 // 2, dtype=BF16, device=h.device)
+    _l.check(L.st355_geglu_fwd(_stream(), _ptr(h), _rows(h, "h"), _ptr(out), M, F2 // 2), "geglu_fwd")
+    return out
+
+
+def geglu_bwd(h, dout):
+    L = _l.load()
+    _chk(h, BF16, "h"); _chk(dout, BF16, "dout")
+    M, F2 = h.shape
+    dh = torch.empty(M, F2, dtype=BF16, device=h.device)
+    _l.check(L.st355_geglu_bwd(_stream(), _ptr(h), _rows(h, "h"), _ptr(dout.contiguous()), _ptr(dh), _rows(dh, "dh"), M, F2 // 2), "geglu_bwd")
+    return dh
+
+
+def head_split(src, B: int, H: int, d: int, S: int, want_x: bool = True, want_xt: bool = True):
+    """src: 2-D column-block view [B*S, H*d] (row stride free) -> (X [B,H,S,d] | None, Xt [B,H,d,Sp] | None, Sp)"""
+    L = _l.load()
+    _chk(src, BF16, "src")
+    Sp = (S + 63) // 64 * 64
+    X = torch.empty(B, H, S, d, dtype=BF16, device=src.device) if want_x else None
+    Xt = torch.zeros(B, H, d, Sp, dtype=BF16, device=src.device) if want_xt else None
+    _l.check(L.st355_head_split(_stream(), _ptr(src), _rows(src, "src"), _ptr(X), _ptr(Xt), B, H, d, S, Sp), "head_split")
+    return X, Xt, Sp
+
+
+def head_merge(dX, dst, B: int, H: int, d: int, S: int):
+    L = _l.load()
+    _chk(dX, BF16, "dX"); _chk(dst, BF16, "dst")
+    _l.check(L.st355_head_merge(_stream(), _ptr(dX), _ptr(dst), _rows(dst, "dst"), B, H, d, S), "head_merge")
+    return dst
+
+
+def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale: float, key_bias=None):
+    L = _l.load()
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    _l.check(L.st355_attn_cross_fwd(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(lse2),
+                                    B, H, Sq, Sk, Skp, d, scale), "attn_cross_fwd")
+
+
+def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale: float, key_bias=None):
+    L = _l.load()
+    need = L.st355_attn_bwd_workspace(B, H, Sq, Sqp, d)
+    key = (Q.device.index,)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
+        _attn_ws[key] = ws
+    _l.check(L.st355_attn_cross_bwd(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
+                                    _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
+                                    _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, Sq, Sqp, Sk, Skp, d, scale, _ptr(ws)),
+             "attn_cross_bwd")
