@@ -1,0 +1,204 @@
+"""Plain-torch CPU restatement of the conv UNet forward of SDXL / SD1.5 (autograd supplies the backward).  TEST INFRASTRUCTURE.
+
+The reference calls the network positionally and never vendors it:
+    SDXL._model_predict_single        simpletuner/helpers/models/sdxl/model.py:306-373  (sample, timestep, encoder_hidden_states,
+                                      added_cond_kwargs={"text_embeds", "time_ids"}, return_dict=False)[0]
+    StableDiffusion1._model_predict_single   simpletuner/helpers/models/sd1x/model.py:224-270
+    FlowMapUNet2DConditionModel       simpletuner/helpers/models/unet_flowmap.py:23-44 (a thin subclass of diffusers' class)
+The arithmetic is diffusers' `UNet2DConditionModel` (>= 0.36, un-vendored) — restated here from its published
+module definitions: Timesteps(flip_sin_to_cos, shift 0) -> TimestepEmbedding; "text_time" addition embedding (SDXL); conv_in; Down /
+CrossAttnDown blocks of ResnetBlock2D (GroupNorm32 eps 1e-5 -> SiLU -> conv3x3 -> + time_emb_proj(SiLU(emb)) -> GroupNorm -> SiLU -> conv3x3,
+1x1 conv_shortcut when channels change) and Transformer2DModel (GroupNorm32 eps 1e-6 -> proj_in -> BasicTransformerBlock x N: LayerNorm ->
+self-attention -> LayerNorm -> cross-attention over the text tokens -> LayerNorm -> GEGLU feed-forward, all residual -> proj_out -> + input);
+Downsample2D (conv3x3 stride 2 pad 1); mid block; Up blocks (concat skip, resnets, nearest-2x Upsample2D + conv3x3); conv_norm_out -> SiLU ->
+conv_out.  State-dict keys and tensor shapes are diffusers' (conv weights [O,I,kh,kw]).
+PARITY UNPINNED: the reference holds no golden tensor for this network and diffusers is not installable here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .flux import timestep_proj
+
+
+@dataclass
+class UNetConfig:
+    # defaults = stabilityai/stable-diffusion-xl-base-1.0 unet/config.json
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280)
+    layers_per_block: int = 2
+    down_block_types: Tuple[str, ...] = ("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D")
+    up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
+    transformer_layers_per_block: Tuple[int, ...] = (1, 2, 10)
+    attention_head_dim: Tuple[int, ...] = (5, 10, 20)           # (mis-named in diffusers: the NUMBER of heads per block)
+    cross_attention_dim: int = 2048
+    use_linear_projection: bool = True
+    addition_embed_type: Optional[str] = "text_time"
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+
+    @staticmethod
+    def sd15():
+        return UNetConfig(block_out_channels=(320, 640, 1280, 1280),
+                          down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                          up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                          transformer_layers_per_block=(1, 1, 1, 1), attention_head_dim=(8, 8, 8, 8), cross_attention_dim=768,
+                          use_linear_projection=False, addition_embed_type=None)
+
+
+def _lin(x, P, name):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _conv(x, P, name, stride=1, padding=1):
+    return F.conv2d(x, P[name + ".weight"], P.get(name + ".bias"), stride=stride, padding=padding)
+
+
+def resnet(P, p, x, emb, groups, eps):
+    h = F.silu(F.group_norm(x, groups, P[p + "norm1.weight"], P[p + "norm1.bias"], eps))
+    h = _conv(h, P, p + "conv1")
+    h = h + _lin(F.silu(emb), P, p + "time_emb_proj")[:, :, None, None]
+    h = F.silu(F.group_norm(h, groups, P[p + "norm2.weight"], P[p + "norm2.bias"], eps))
+    h = _conv(h, P, p + "conv2")
+    if (p + "conv_shortcut.weight") in P:
+        x = _conv(x, P, p + "conv_shortcut", padding=0)
+    return x + h
+
+
+def _attention(P, p, x, ctx, heads):
+    B, S, C = x.shape
+    q = _lin(x, P, p + "to_q")
+    k = _lin(ctx, P, p + "to_k")
+    v = _lin(ctx, P, p + "to_v")
+    d = C // heads
+    q, k, v = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v
+    return _lin(o.transpose(1, 2).reshape(B, S, C), P, p + "to_out.0")
+
+
+def basic_block(P, p, h, ctx, heads):
+    C = h.shape[-1]
+    n = F.layer_norm(h, (C,), P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
+    h = _attention(P, p + "attn1.", n, n, heads) + h
+    n = F.layer_norm(h, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5)
+    h = _attention(P, p + "attn2.", n, ctx, heads) + h
+    n = F.layer_norm(h, (C,), P[p + "norm3.weight"], P[p + "norm3.bias"], 1e-5)
+    val, gate = _lin(n, P, p + "ff.net.0.proj").chunk(2, dim=-1)
+    return _lin(val * F.gelu(gate), P, p + "ff.net.2") + h
+
+
+def transformer2d(P, p, x, ctx, heads, n_layers, groups, linear_proj):
+    B, C, H, W = x.shape
+    res = x
+    h = F.group_norm(x, groups, P[p + "norm.weight"], P[p + "norm.bias"], 1e-6)
+    if linear_proj:
+        h = _lin(h.permute(0, 2, 3, 1).reshape(B, H * W, C), P, p + "proj_in")
+    else:
+        h = _conv(h, P, p + "proj_in", padding=0).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    for k in range(n_layers):
+        h = basic_block(P, f"{p}transformer_blocks.{k}.", h, ctx, heads)
+    if linear_proj:
+        h = _lin(h, P, p + "proj_out").reshape(B, H, W, C).permute(0, 3, 1, 2)
+    else:
+        h = _conv(h.reshape(B, H, W, C).permute(0, 3, 1, 2), P, p + "proj_out", padding=0)
+    return h + res
+
+
+def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None):
+    """UNet2DConditionModel.forward -> [B, out_channels, H, W]"""
+    g, eps = cfg.norm_num_groups, cfg.norm_eps
+    dt = sample.dtype
+    c0 = cfg.block_out_channels[0]
+    t_emb = timestep_proj(timesteps.to(sample.device).expand(sample.shape[0]), c0).to(dt)
+    emb = _lin(F.silu(_lin(t_emb, P, "time_embedding.linear_1")), P, "time_embedding.linear_2")
+    if cfg.addition_embed_type == "text_time":
+        text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+        tid = timestep_proj(time_ids.flatten(), cfg.addition_time_embed_dim).reshape(text_embeds.shape[0], -1)
+        add = torch.cat([text_embeds.to(dt), tid.to(dt)], dim=-1)
+        emb = emb + _lin(F.silu(_lin(add, P, "add_embedding.linear_1")), P, "add_embedding.linear_2")
+    ctx = encoder_hidden_states.to(dt)
+    x = _conv(sample, P, "conv_in")
+    skips = [x]
+    nb = len(cfg.block_out_channels)
+    for i, typ in enumerate(cfg.down_block_types):
+        for j in range(cfg.layers_per_block):
+            x = resnet(P, f"down_blocks.{i}.resnets.{j}.", x, emb, g, eps)
+            if typ.startswith("CrossAttn"):
+                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}.", x, ctx, cfg.attention_head_dim[i], cfg.transformer_layers_per_block[i], g,
+                                  cfg.use_linear_projection)
+            skips.append(x)
+        if i < nb - 1:
+            x = _conv(x, P, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+            skips.append(x)
+    x = resnet(P, "mid_block.resnets.0.", x, emb, g, eps)
+    x = transformer2d(P, "mid_block.attentions.0.", x, ctx, cfg.attention_head_dim[-1], cfg.transformer_layers_per_block[-1], g, cfg.use_linear_projection)
+    x = resnet(P, "mid_block.resnets.1.", x, emb, g, eps)
+    for i, typ in enumerate(cfg.up_block_types):
+        ri = nb - 1 - i                                   # the up path walks the channel list in reverse
+        for j in range(cfg.layers_per_block + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet(P, f"up_blocks.{i}.resnets.{j}.", x, emb, g, eps)
+            if typ.startswith("CrossAttn"):
+                x = transformer2d(P, f"up_blocks.{i}.attentions.{j}.", x, ctx, cfg.attention_head_dim[ri], cfg.transformer_layers_per_block[ri], g,
+                                  cfg.use_linear_projection)
+        if i < nb - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(x, P, f"up_blocks.{i}.upsamplers.0.conv")
+    x = F.silu(F.group_norm(x, g, P["conv_norm_out.weight"], P["conv_norm_out.bias"], eps))
+    return _conv(x, P, "conv_out")
+
+
+def unet_flops_fwd(cfg: UNetConfig, H: int, W: int, ctx_len: int = 77) -> float:
+    """multiply-add = 2 FLOPs; conv 2*k*k*Cin*Cout*H*W, linears 2*M*N*K, attention 4*Sq*Sk*C; per image (SURVEY.md §8d asks for this counter)"""
+    fl = 0.0
+    ch = cfg.block_out_channels
+    nb = len(ch)
+
+    def conv(cin, cout, h, w, k=3):
+        return 2.0 * k * k * cin * cout * h * w
+
+    def res(cin, cout, h, w):
+        return conv(cin, cout, h, w) + conv(cout, cout, h, w) + (conv(cin, cout, h, w, 1) if cin != cout else 0.0) + 2.0 * 4 * ch[0] * cout
+
+    def tr(c, h, w, n):
+        s = h * w
+        per = 2.0 * s * c * c * 4 + 4.0 * s * s * c + 2.0 * s * c * c * 2 + 2.0 * ctx_len * cfg.cross_attention_dim * c * 2 + 4.0 * s * ctx_len * c \
+            + 2.0 * s * c * 8 * c + 2.0 * s * 4 * c * c
+        return n * per + 2 * 2.0 * s * c * c
+
+    h, w = H, W
+    fl += conv(cfg.in_channels, ch[0], h, w)
+    skip_ch = [ch[0]]
+    cin = ch[0]
+    for i, typ in enumerate(cfg.down_block_types):
+        for j in range(cfg.layers_per_block):
+            fl += res(cin, ch[i], h, w)
+            cin = ch[i]
+            if typ.startswith("CrossAttn"):
+                fl += tr(cin, h, w, cfg.transformer_layers_per_block[i])
+            skip_ch.append(cin)
+        if i < nb - 1:
+            h, w = h // 2, w // 2
+            fl += conv(cin, cin, h, w)
+            skip_ch.append(cin)
+    fl += 2 * res(cin, cin, h, w) + tr(cin, h, w, cfg.transformer_layers_per_block[-1])
+    for i, typ in enumerate(cfg.up_block_types):
+        ri = nb - 1 - i
+        for j in range(cfg.layers_per_block + 1):
+            fl += res(cin + skip_ch.pop(), ch[ri], h, w)
+            cin = ch[ri]
+            if typ.startswith("CrossAttn"):
+                fl += tr(cin, h, w, cfg.transformer_layers_per_block[ri])
+        if i < nb - 1:
+            h, w = 2 * h, 2 * w
+            fl += conv(cin, cin, h, w)
+    fl += conv(cin, cfg.out_channels, h, w)
+    return fl

@@ -649,9 +649,9 @@ def conv_wgrad(x, dy, dw, B: int, H: int, W: int, taps: int = 9, accumulate: boo
     Cin, Cout = x.shape[1], dy.shape[1]
     if tuple(dw.shape) != (Cout, taps * Cin) or not dw.is_contiguous():
         raise _l.St355Error(f"conv_wgrad: dw must be a contiguous [{Cout}, {taps * Cin}] tensor")
-    ws = _gemm_workspace(x.device)
+    ws = _gemm_workspace(x.device, 256 << 20)
     _l.check(L.st355_conv_wgrad_bf16(_stream(), _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, taps, 1 if accumulate else 0, _ptr(ws),
-                                     ws.numel() * ws.element_size()), "conv_wgrad_bf16")
+                                     ws.numel() * 4), "conv_wgrad_bf16")
     return dw
 
 
