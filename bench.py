@@ -55,8 +55,10 @@ def hbm_traffic_per_gemm_launch():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="flux", choices=["flux", "sd3"],
+    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
+    ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
+                    "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
     ap.add_argument("--full", action="store_true", help="sd3 only: full fine-tune (every parameter trains, bf16 AdamW arena) + EMA — BASELINE configs[3]")
     ap.add_argument("--optimizer", default="st355-adamw", choices=["st355-adamw", "adamw_bf16"])
     ap.add_argument("--buckets", action="store_true",
@@ -137,7 +139,7 @@ def main():
 
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3,
                          model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
-                         learning_rate=1e-5 if args.full else 1e-4)
+                         learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph))
     acc = St355Accelerator(dev)
     if args.model == "flux":
         from simpletuner_amd.flux.model import Flux
@@ -146,6 +148,19 @@ def main():
         n_blocks, D_model, S_txt, txt_dim, pooled_dim = args.layers + args.single_layers, 3072, 512, 4096, 768
         desc = (f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
                 f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights")
+    elif args.model == "sdxl":
+        # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4 (always the full fine-tune)
+        from simpletuner_amd.sdxl.model import SDXL
+        from oracle.unet import UNetConfig, unet_flops_fwd     # FLOP counter only (test infrastructure; nothing of the oracle is executed in the step)
+        args.full = True
+        cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
+        plugin = SDXL(cfg, acc)
+        plugin.load_model()
+        S_txt, txt_dim, pooled_dim = 77, 2048, 1280
+        n_blocks, D_model = 0, 0
+        sdxl_fwd_flops = unet_flops_fwd(UNetConfig(), args.res // 8, args.res // 8, 77)
+        desc = (f"SDXL UNet2DConditionModel (320/640/1280 ch, 2/10-layer transformers at 64^2/32^2, 2.6 B params) FULL fine-tune bf16, "
+                f"{args.res}^2 ({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
     else:
         from simpletuner_amd.sd3.model import SD3
         plugin = SD3(cfg, acc)
@@ -156,8 +171,8 @@ def main():
         desc = (f"SD3-Medium MMDiT ({n_l} joint blocks, D=1536, 24x64 heads) LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0, "
                 f"{args.res}^2 (S=4096+231), AdamW, random-init weights")
     if args.full:
-        if args.model != "sd3":
-            raise SystemExit("--full is wired for --model sd3 only")
+        if args.model not in ("sd3", "sdxl"):
+            raise SystemExit("--full is wired for --model sd3 / sdxl only")
         plugin.enable_full_finetune()
         desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", "FULL fine-tune (2.0 B bf16 params) + EMA")
     else:
@@ -170,11 +185,14 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     def make_batch(hh=None, ww=None):
         hh, ww = hh or lat, ww or lat
-        return {
-            "latent_batch": torch.randn(B, 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
+        b = {
+            "latent_batch": torch.randn(B, 4 if args.model == "sdxl" else 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
             "prompt_embeds": torch.randn(B, S_txt, txt_dim, device=dev, generator=gen).to(torch.bfloat16),
             "add_text_embeds": torch.randn(B, pooled_dim, device=dev, generator=gen).to(torch.bfloat16),
         }
+        if args.model == "sdxl":       # time_ids [B,6] = (1024,1024,0,0,1024,1024)
+            b["batch_time_ids"] = torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * B, device=dev, dtype=torch.bfloat16)
+        return b
     if args.buckets:
         if args.model != "sd3":
             raise SystemExit("--buckets is wired for --model sd3 only (Flux bench keeps the single 1024^2 bucket of configs[2])")
@@ -217,7 +235,9 @@ def main():
     if rank == 0:
         S_img = (lat // 2) ** 2
         step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
-        if args.full:        # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
+        if args.model == "sdxl":   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
+            step_flops = 3.0 * sdxl_fwd_flops * B
+        elif args.full:      # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
             step_flops = 3.0 * (n_blocks * 2.0 * (S_img + S_txt) * 12 * D_model * D_model + n_blocks * 4.0 * (S_img + S_txt) ** 2 * D_model) * B
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -238,7 +258,7 @@ def main():
                            "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
                        for k, v in prof.items() if v["launches"]}
         out = {
-            "metric": f"training images/sec (whole node), {'Flux.1-dev' if args.model == 'flux' else 'SD3-Medium'} "
+            "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL')[args.model]} "
                       f"{'full fine-tune + EMA' if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

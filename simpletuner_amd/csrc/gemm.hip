@@ -1412,6 +1412,7 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
   int ks = (384 + g.tiles0 - 1) / g.tiles0;
   if (ks > nt_all / 8) ks = nt_all / 8;                // >= 8 K-tiles per slice
   if (ks > 16) ks = 16;
+  if (ks >= 2) { const int per = (nt_all + ks - 1) / ks; ks = (nt_all + per - 1) / per; }   // no empty K-slices (the ring prologue assumes >= 1 K-tile)
   if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * 4 <= workspace_bytes) {
     g.p[0].partial = (float*)workspace; g.p[0].ksplit = ks; g.p[0].aux_in = nullptr;
     g.p[1] = g.p[0];

@@ -154,10 +154,17 @@ __global__ void __launch_bounds__(64) k_gn_finalize_bwd(const float* __restrict_
 // dgamma[c] (+)= sum_{b,chunk} B_c ; dbeta[c] (+)= sum_{b,chunk} A_c      (fixed order)
 __global__ void __launch_bounds__(256) k_gn_param_grads(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
                                                       int nchunks, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  float pa = 0.f, pb = 0.f;
+  if (c < C)
+    for (int i = sl; i < B * nchunks; i += 8) { const float* src = partial + ((int64_t)i * C + c) * 2; pa += src[0]; pb += src[1]; }
+  red[sl][threadIdx.x & 31][0] = pa; red[sl][threadIdx.x & 31][1] = pb;
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
   float a = 0.f, bsum = 0.f;
-  for (int i = 0; i < B * nchunks; i++) { const float* src = partial + ((int64_t)i * C + c) * 2; a += src[0]; bsum += src[1]; }
+#pragma unroll
+  for (int q = 0; q < 8; q++) { a += red[q][threadIdx.x & 31][0]; bsum += red[q][threadIdx.x & 31][1]; }
   if (accumulate) { dgamma[c] += bsum; dbeta[c] += a; } else { dgamma[c] = bsum; dbeta[c] = a; }
 }
 
@@ -248,7 +255,7 @@ extern "C" int st355_groupnorm_bwd(void* stream, const void* dy, const void* x, 
   hipLaunchKernelGGL(k_gn_finalize_bwd, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, (const float*)partial, stats, (const bf16*)gamma, coef, C, groups, nch,
                      (float)((double)H * W * (C / groups)));
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(k_gn_param_grads, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, dgamma, dbeta, B, C, nch, accumulate_params);
+    hipLaunchKernelGGL(k_gn_param_grads, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)partial, dgamma, dbeta, B, C, nch, accumulate_params);
   const int64_t n = (int64_t)B * (H + 2) * (W + 2) * (C / 8);
   hipLaunchKernelGGL(k_gn_apply_bwd, dim3((unsigned)std::min<int64_t>(cdiv64(n, GN_THREADS), 65536)), dim3(GN_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
                      (const bf16*)dy, stats, (const bf16*)gamma, (const bf16*)beta, (const float*)coef, (const bf16*)dadd, (bf16*)dx, B, H, W, C, silu, dy_tokens);

@@ -274,13 +274,20 @@ __global__ void __launch_bounds__(256) k_ln_param_partials(const bf16* __restric
 }
 __global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nw, int D, float* __restrict__ dweight, float* __restrict__ dbias,
                                                         int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+  __shared__ float red[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  float pa = 0.f, pb = 0.f;
+  if (c < D)
+    for (int w = sl; w < nw; w += 8) { pa += partial[((int64_t)w * D + c) * 2]; pb += partial[((int64_t)w * D + c) * 2 + 1]; }
+  red[sl][threadIdx.x & 31][0] = pa; red[sl][threadIdx.x & 31][1] = pb;
+  __syncthreads();
+  if (sl != 0 || c >= D) return;
   float a = 0.f, b = 0.f;
-  for (int w = 0; w < nw; w++) { a += partial[((int64_t)w * D + c) * 2]; b += partial[((int64_t)w * D + c) * 2 + 1]; }
+#pragma unroll
+  for (int q = 0; q < 8; q++) { a += red[q][threadIdx.x & 31][0]; b += red[q][threadIdx.x & 31][1]; }
   if (accumulate) { dweight[c] += a; dbias[c] += b; } else { dweight[c] = a; dbias[c] = b; }
 }
-#define LNP_BLOCKS 256
+#define LNP_BLOCKS 128
 extern "C" size_t st355_layernorm_param_grads_workspace(int D) { return (size_t)LNP_BLOCKS * 4 * D * 2 * 4; }
 extern "C" int st355_layernorm_param_grads(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t rows, int D, float eps, float* dweight,
                                            float* dbias, int accumulate, void* workspace) {
@@ -292,7 +299,7 @@ extern "C" int st355_layernorm_param_grads(void* stream, const void* dy, int64_t
   else if (D <= 1536) LAUNCH(3);
   else LAUNCH(4);
 #undef LAUNCH
-  hipLaunchKernelGGL(k_ln_param_reduce, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, LNP_BLOCKS * 4, D, dweight, dbias, accumulate);
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((D + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, LNP_BLOCKS * 4, D, dweight, dbias, accumulate);
   return st355_check_launch("layernorm_param_grads");
 }
 

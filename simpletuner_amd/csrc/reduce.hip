@@ -50,10 +50,18 @@ __global__ void __launch_bounds__(256) k_colsum_finalize(const float* __restrict
                                                         int64_t out_stride, int mode, const float* __restrict__ prev, int64_t prev_stride,
                                                         const bf16* __restrict__ shift, const bf16* __restrict__ scale, int64_t mod_stride,
                                                         int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
-  if (c >= N) return;
+  // 32 columns x 8 chunk-slices per block: the chunk loop is 8x shorter and still summed in a fixed order
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5, bi = blockIdx.y;
+  float part = 0.f;
+  if (c < N)
+    for (int k = sl; k < nchunks; k += 8) part += ws[((int64_t)bi * nchunks + k) * N + c];
+  red[sl][threadIdx.x & 31] = part;
+  __syncthreads();
+  if (sl != 0 || c >= N) return;
   float s = 0.f;
-  for (int k = 0; k < nchunks; k++) s += ws[((int64_t)bi * nchunks + k) * N + c];
+#pragma unroll
+  for (int q = 0; q < 8; q++) s += red[q][threadIdx.x & 31];
   if (mode == 1) {
     const float sh = bf2f(shift[bi * mod_stride + c]), sc = 1.f + bf2f(scale[bi * mod_stride + c]);
     s = (s - sh * prev[bi * prev_stride + c]) / (fabsf(sc) > 1e-6f ? sc : (sc < 0.f ? -1e-6f : 1e-6f));
@@ -80,7 +88,7 @@ extern "C" int st355_colsum_prod(void* stream, const void* a, int64_t lda, const
                      (const bf16*)b, ldb, rows_per_batch, N, (float*)workspace, nchunks);
   int rc = st355_check_launch("colsum_prod");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_colsum_finalize, dim3((N + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nchunks, N, out,
+  hipLaunchKernelGGL(k_colsum_finalize, dim3((N + 31) / 32, nb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nchunks, N, out,
                      out_stride, mode, prev, prev_stride, (const bf16*)shift, (const bf16*)scale, mod_stride, accumulate);
   return st355_check_launch("colsum_finalize");
 }

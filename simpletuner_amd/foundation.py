@@ -101,6 +101,43 @@ def apply_flow_schedule_shift(args, noise_scheduler, sigmas, noise):
     return sigmas
 
 
+class DDPMSchedule:
+    """the training-side arithmetic of diffusers' DDPMScheduler as the reference configures it for SD1.5 / SDXL (common.py:4529-4550; the
+    checkpoint's scheduler_config.json: beta_schedule "scaled_linear", beta_start 0.00085, beta_end 0.012, 1000 steps)."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012, beta_schedule: str = "scaled_linear",
+                 prediction_type: str = "epsilon", device=None):
+        from types import SimpleNamespace
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(beta_schedule)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type, beta_schedule=beta_schedule)
+        self._sa = self.alphas_cumprod.sqrt().to(device)
+        self._sb = (1.0 - self.alphas_cumprod).sqrt().to(device)
+
+    def mix_coefficients(self, timesteps):
+        return self._sa[timesteps].contiguous(), self._sb[timesteps].contiguous()
+
+    def sample_timesteps(self, bsz: int, segmented: bool = True):
+        """uniform weights (generate_timestep_weights default); bsz > 1: one draw from each of bsz equal segments, high to low
+        (segmented_timestep_selection, custom_schedule.py:18-58); drawn on the host: no device sync"""
+        T = self.config.num_train_timesteps
+        if bsz == 1 or not segmented:
+            return torch.multinomial(torch.ones(T), bsz, replacement=True).long()
+        seg = max(T // bsz, 1)
+        out = []
+        for i in range(bsz):
+            start = T - 1 - i * seg
+            end = max(start - seg, 0) if i != bsz - 1 else 0
+            w = torch.ones(start + 1 - end)
+            out.append(end + int(torch.multinomial(w / w.sum(), 1).item()))
+        return torch.tensor(out, dtype=torch.long)
+
+
 class ModelFoundation:
     """the subset of common.py's ModelFoundation that the step loop touches (trainer.py:6951-7568)."""
     NAME = "foundation"
@@ -133,7 +170,9 @@ class ModelFoundation:
         return self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING
 
     def setup_training_noise_schedule(self):
-        return None
+        if self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING:
+            self.noise_schedule = DDPMSchedule(prediction_type=self.PREDICTION_TYPE.value, device=self.accelerator.device)
+        return self.noise_schedule
 
     def flow_matching_target_direction(self) -> float:
         return 1.0
@@ -199,7 +238,26 @@ class ModelFoundation:
             batch["flow_target"] = target      # n - x (common.py:4610-4611), consumed by get_prediction_target
             self.expand_sigmas(batch)
         else:
-            raise NotImplementedError("DDPM families are wired in the UNet plugin (round 2)")
+            # DDPM families (common.py:5983-6002): discrete timesteps (segmented selection when bsz > 1, custom_schedule.py:18-58), noise =
+            # randn_like(latents) (or injected), x_t = sqrt(acp_t) x + sqrt(1 - acp_t) n in fp32 then cast (DDPMScheduler.add_noise)
+            if self.noise_schedule is None:
+                self.setup_training_noise_schedule()
+            sched = self.noise_schedule
+            bsz = lat.shape[0]
+            given_t = batch.get("timesteps")
+            if given_t is None:
+                given_t = sched.sample_timesteps(bsz, segmented=not getattr(self.config, "disable_segmented_timestep_sampling", False))
+            batch["timesteps"] = given_t.to(device=dev).long()
+            noise = batch.get("noise")
+            if noise is None:
+                noise = torch.randn_like(lat)
+            a, b = sched.mix_coefficients(batch["timesteps"])
+            noisy, vel = ops.ddpm_noise_mix(lat, noise.to(device=dev, dtype=wd), a, b, want_v=self.PREDICTION_TYPE is PredictionTypes.V_PREDICTION)
+            batch["noise"] = noise
+            batch["input_noise"] = noise
+            batch["noisy_latents"] = noisy
+            if vel is not None:
+                batch["velocity_target"] = vel
         batch.pop("noise_shape_ref", None)
         return self.prepare_batch_conditions(batch=batch, state=state)
 
@@ -224,6 +282,8 @@ class ModelFoundation:
             return t
         if self.PREDICTION_TYPE is PredictionTypes.EPSILON:
             return prepared_batch["noise"]
+        if self.PREDICTION_TYPE is PredictionTypes.V_PREDICTION:
+            return prepared_batch["velocity_target"]        # noise_schedule.get_velocity (common.py:4649-4653), fused into the noising pass
         if self.PREDICTION_TYPE is PredictionTypes.SAMPLE:
             return prepared_batch["latents"]
         raise ValueError(f"Unknown prediction type {self.PREDICTION_TYPE}.")

@@ -89,6 +89,13 @@ class Trainer:
                 comp.grad_sync = GradSync(comp.grad_arena, bucket_bytes=128 << 20)
             elif getattr(comp, "lora_grad_flat", None) is not None:
                 comp.grad_sync = GradSync(comp.lora_grad_flat)
+        # hip_graph: predict + loss + backward of one (shape-keyed) step are captured once into a hipGraph and replayed — the UNet step is
+        # ~7000 short launches and otherwise bound by the host's launch rate.  Single process, no gradient accumulation, fixed shapes per key.
+        self._use_graph = bool(getattr(config, "hip_graph", False))
+        if self._use_graph and (self.accelerator.num_processes > 1 or config.gradient_accumulation_steps != 1):
+            raise NotImplementedError("hip_graph: single-process, gradient_accumulation_steps == 1 only")
+        self._graphs = {}
+        self._graph_warm = {}
         self.state = {"global_step": 0, "micro_step": 0}
         self.last_loss = None          # device scalar, no host sync
         self.last_grad_norm = None
@@ -103,13 +110,17 @@ class Trainer:
         sync = getattr(comp, "grad_sync", None)
         if sync is not None:
             sync.enabled = boundary
-        pred = self.model.model_predict(prepared)                                        # :7097 -> :6085
-        loss, _ = self.model.loss_with_logs(prepared, pred)
-        loss, _ = self.model.auxiliary_loss(pred, prepared, loss)
-        if cfg.gradient_accumulation_steps > 1:
-            loss = loss / cfg.gradient_accumulation_steps
-        self.last_loss = gather_sample_weighted_scalar(loss, prepared["latents"].shape[0], acc)   # :7114 (C2)
-        acc.backward(loss)                                                               # :7126
+        if self._use_graph:
+            loss = self._graph_forward_backward(prepared)
+            self.last_loss = gather_sample_weighted_scalar(loss, prepared["latents"].shape[0], acc)
+        else:
+            pred = self.model.model_predict(prepared)                                    # :7097 -> :6085
+            loss, _ = self.model.loss_with_logs(prepared, pred)
+            loss, _ = self.model.auxiliary_loss(pred, prepared, loss)
+            if cfg.gradient_accumulation_steps > 1:
+                loss = loss / cfg.gradient_accumulation_steps
+            self.last_loss = gather_sample_weighted_scalar(loss, prepared["latents"].shape[0], acc)   # :7114 (C2)
+            acc.backward(loss)                                                           # :7126
         if not boundary:
             return self.last_loss
         grad_scale = getattr(comp, "grad_scale_from_sync", 1.0) if sync is not None else 1.0
@@ -133,13 +144,65 @@ class Trainer:
             grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
         self.optimizer.grad_scale = grad_scale
         self.optimizer.step()                                                            # :7239
-        self.optimizer.zero_grad(set_to_none=True)                                       # :7253
+        if not self._use_graph:                                                          # graph mode: the captured backward re-writes the same .grad tensors
+            self.optimizer.zero_grad(set_to_none=True)                                   # :7253
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()                                                     # :7293
         self.state["global_step"] += 1
         if self.ema_model is not None:
             self.ema_model.step(self.params, self.state["global_step"])                  # :7352
         return self.last_loss
+
+    # ------------------------------------------------------------------------------------------------
+    def _eager_forward_backward(self, prepared):
+        pred = self.model.model_predict(prepared)
+        loss, _ = self.model.loss_with_logs(prepared, pred)
+        loss, _ = self.model.auxiliary_loss(pred, prepared, loss)
+        self.accelerator.backward(loss)
+        return loss
+
+    def _graph_forward_backward(self, prepared):
+        def tensors(d, prefix=""):
+            for k, v in d.items():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    yield prefix + k, v
+                elif isinstance(v, dict):
+                    yield from tensors(v, prefix + k + "/")
+
+        def clone_tree(d):
+            return {k: (v.clone() if isinstance(v, torch.Tensor) and v.is_cuda else clone_tree(v) if isinstance(v, dict) else v) for k, v in d.items()}
+
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in tensors(prepared))
+        entry = self._graphs.get(key)
+        if entry is None:
+            # warm-up ON A SIDE STREAM (workspaces, kernel attributes, allocator pools, and AccumulateGrad nodes bound to the capture-side stream:
+            # a node created on the default stream and kept alive breaks capture), then capture one step
+            static = clone_tree(prepared)
+            self.last_loss = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    for p in self.params:
+                        p.grad = None
+                    loss = self._eager_forward_backward(static)
+                    del loss
+            torch.cuda.current_stream().wait_stream(side)
+            for p in self.params:
+                p.grad = None
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._eager_forward_backward(static)
+            entry = self._graphs[key] = (g, static, loss.detach(), [p.grad for p in self.params])
+        g, static, loss, grads = entry
+        st = dict(tensors(static))
+        for k, v in tensors(prepared):
+            st[k].copy_(v)
+        g.replay()
+        for p, gr in zip(self.params, grads):
+            p.grad = gr
+        return loss
 
     def train(self, batches: Iterable[dict], max_steps: int):
         losses = []

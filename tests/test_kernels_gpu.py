@@ -165,7 +165,7 @@ def test_gemm_plain(ops, M, N, K):
         assert rel(out.t(), ref) > 0.1
 
 
-@pytest.mark.parametrize("M,P,Q", [(64, 256, 256), (192, 512, 264), (4096, 1536, 1536), (960, 136, 3072), (4352, 3072, 768)])
+@pytest.mark.parametrize("M,P,Q", [(64, 256, 256), (192, 512, 264), (4096, 1536, 1536), (960, 136, 3072), (4352, 3072, 768), (8640, 640, 640), (8704, 320, 640)])
 def test_gemm_tn_weight_gradient(ops, M, P, Q):
     """dW[P,Q] = dY[M,P]^T X[M,Q] (+ accumulate): contraction over the slow axis of both operands (transposing LDS reads)"""
     torch.manual_seed(21)
