@@ -209,14 +209,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace_loss = os.environ.get("ST355_BENCH_TRACE_LOSS") == "1"      # debugging aid: per-step loss (forces a host sync per step)
     for i in range(args.warmup):
-        trainer.train_step(dict(batches[i % nb_]))
+        l_ = trainer.train_step(dict(batches[i % nb_]))
+        if trace_loss:
+            print(f"[bench] warmup {i} loss {float(l_):.5f}", file=sys.stderr)
     sync()
     if not args.no_prof:
         ops.prof_reset(); ops.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.train_step(dict(batches[i % nb_]))
+        if trace_loss:
+            comp_ = plugin.get_trained_component()
+            gf_ = getattr(comp_, "_last_grad_flat", None)
+            print(f"[bench] step {i} loss {float(loss):.5f} grad_nan {bool(torch.isnan(gf_.float()).any()) if gf_ is not None else None} "
+                  f"w_nan {bool(torch.isnan(comp_.arena.float()).any()) if hasattr(comp_, 'arena') else None}", file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
     prof = None

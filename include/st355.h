@@ -235,6 +235,7 @@ int st355_lora_pack(void* stream, const float* A, const float* Bm, int r, int K,
  * tail, so a buffer that was zero-filled once can be re-used.  A 3x3 stride-1 pad-1 convolution is then ONE GEMM over the grid whose K
  * loop walks the nine taps as row-shifted views of x (no im2col); taps == 1 is the 1x1 conv / pre-gathered-columns case.
  *   out[pos, co] = sum_{tap,ci} x[pos + shift(tap), ci] * w[co, tap*Cin + ci] + bias[co] + img_add[image(pos), co] + residual[pos, co]
+ * `out` must be a grid buffer too (its first / last W+3 positions are border positions no GEMM row covers: they keep the caller's zeros).
  * w: [Cout, taps*Cin] (= torch Conv2d weight.permute(0,2,3,1)); Cin % 64 == 0, Cout % 8 == 0; img_add: [B, >=Cout] rows (the ResnetBlock2D
  * time-embedding projection) or NULL; residual: grid [.., Cout] or NULL. */
 int64_t st355_conv_grid_rows(int B, int H, int W);

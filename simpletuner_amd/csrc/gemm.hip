@@ -61,7 +61,8 @@ struct GemmP {
   bf16* aux_out; int64_t ld_aux_out;
   const bf16* aux_in; int64_t ld_aux_in;
   const bf16* gate; int64_t gate_stride; int64_t rows_per_batch;
-  float* partial; int ksplit;          // split-K: fp32 slabs [ksplit][M][N]
+  float* partial; int ksplit;          // split-K: fp32 slabs [ksplit][M][part_ld]
+  int64_t part_ld;                     // slab row stride (N, or 9*N when the nine conv-wgrad taps share one launch)
   const float* scale_a; const float* scale_b;   // fp8 Linear: out = acc * scale_a[0] * scale_b[n] (+ bias); NULL otherwise
   // convolution-as-GEMM over a zero-bordered NHWC grid (conv.hip / st355_conv_bf16): rows = grid positions, K = taps * Cin.
   // K-tile u reads the A rows shifted by (ty*Wp + tx) positions, tap = u / conv_tpt = 3*ty + tx (taps == 9; no shift when taps == 1);
@@ -225,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
       const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
       if (m >= p.M || !n_ok) continue;
       if (EPI == EPI_SPLITK) {                        // fp32 K-slice slab (p.partial already points at this slice)
-        float* dst = p.partial + (int64_t)m * p.N + n;
+        float* dst = p.partial + (int64_t)m * p.part_ld + n;
         *(f32x4*)dst = lo;
         *(f32x4*)(dst + 4) = hi;
         continue;
@@ -817,8 +818,13 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   if (pi) id -= g.tiles0;
   const GemmP& p = g.p[pi];
   const int nbm = (p.M + PQ_BM - 1) / PQ_BM, nbn = (p.N + PQ_BN - 1) / PQ_BN;
+  // TN with conv_taps == 9 (weight gradient of a 3x3 convolution, st355_conv_wgrad_bf16): the nine taps are nine column blocks of the output
+  // ([P, 9*N], block tap at columns tap*N) whose R operand is the SAME matrix shifted by (ty*Wp + tx) contraction rows: one launch for all taps
+  const int wtaps = (TN && p.conv_taps == 9) ? 9 : 1;
   int pm, pn;
-  tile_coords(id, nbm, nbn, pm, pn);
+  tile_coords(id, nbm, nbn * wtaps, pm, pn);
+  const int wtap = pn / nbn;
+  pn -= wtap * nbn;
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
   const int nt_all = p.K / (PQ_BK * 2 / ES);
   const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
@@ -834,7 +840,8 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // Addresses are (uniform 64-bit base of the tile's first row + k) + a 32-bit per-lane byte offset: the LDS-DMA takes the
   // SGPR-base + VGPR-offset form, so the K loop spends no VALU (and only 8 VGPRs) on addressing.
   const char* xbase = TN ? (const char*)A1 + (int64_t)m0 * 2 : (const char*)A1 + (int64_t)m0 * p.lda * ES;
-  const char* wbase = TN ? (const char*)B1 + (int64_t)n0 * 2 : (const char*)B1 + (int64_t)n0 * p.ldb * ES;
+  const char* wbase = TN ? (const char*)B1 + (int64_t)n0 * 2 + (int64_t)((wtap / 3) * p.conv_wp + (wtap % 3)) * (wtaps > 1 ? p.ldb * 2 : 0)
+                         : (const char*)B1 + (int64_t)n0 * p.ldb * ES;
   const uint32_t lda_b = (uint32_t)p.lda * ES, ldb_b = (uint32_t)p.ldb * ES;
   const int64_t xk_step = TN ? (int64_t)PQ_BK * lda_b : PQ_BK * 2;     // bytes per K-tile along the contraction
   const int64_t wk_step = TN ? (int64_t)PQ_BK * ldb_b : PQ_BK * 2;
@@ -1062,8 +1069,15 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // every wave is past its last ring read and no LDS-DMA is in flight: the ring is free for the epilogue transpose
   if (EPI == EPI_SPLITK) {
     GemmP ps = p;
-    ps.partial = p.partial + (int64_t)slice * p.M * p.N;
+    ps.partial = p.partial + (int64_t)slice * p.M * p.part_ld + (int64_t)wtap * p.N;
     ps.bias = nullptr;
+    ps.conv_taps = 0;
+    gemm_epilogue_lds<EPI>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (wtaps > 1) {
+    GemmP ps = p;
+    ps.C = p.C + (int64_t)wtap * p.N;
+    if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
+    ps.conv_taps = 0;
     gemm_epilogue_lds<EPI>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   } else if (epl_aligned(p)) gemm_epilogue_lds<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   else gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
@@ -1221,7 +1235,7 @@ static GemmP to_p(const st355_gemm_args* a) {
   p.aux_out = (bf16*)a->aux_out; p.ld_aux_out = a->ld_aux_out;
   p.aux_in = (const bf16*)a->aux_in; p.ld_aux_in = a->ld_aux_in;
   p.gate = (const bf16*)a->gate; p.gate_stride = a->gate_stride; p.rows_per_batch = a->rows_per_batch;
-  p.partial = nullptr; p.ksplit = 1;
+  p.partial = nullptr; p.ksplit = 1; p.part_ld = a->N;
   p.scale_a = nullptr; p.scale_b = nullptr;
   p.conv_taps = 0; p.conv_tpt = 1; p.conv_wp = 0; p.conv_hp = 0; p.conv_row0 = 0; p.img_add = nullptr; p.img_add_stride = 0;
   return p;
@@ -1390,8 +1404,9 @@ static int launch_tn(void* stream, const GemmGroup& g, int tiles) {
   return st355_check_launch("gemm_tn");
 }
 
-extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
-                                  int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes) {
+// taps == 9: C is [P, 9*Q]; column block `tap` = L^T (R shifted by (tap/3)*wp + tap%3 rows)  — the 3x3 convolution weight gradient in one launch
+static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
+                        int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes, int taps, int wp) {
   ST_REQUIRE(L && R && C && Mc > 0 && P > 0 && Q > 0, "gemm_tn: bad args");
   ST_REQUIRE(Mc % PQ_BK == 0, "gemm_tn: the contraction length (%lld rows) must be a multiple of 64 (pad the operands with zero rows)", (long long)Mc);
   ST_REQUIRE(P % 8 == 0 && Q % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0 && ldc % 8 == 0, "gemm_tn: P, Q and the leading dimensions must be multiples of 8");
@@ -1400,12 +1415,13 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.A = (const bf16*)L; p.lda = ldl; p.B = (const bf16*)R; p.ldb = ldr; p.C = (bf16*)C; p.ldc = ldc;
-  p.M = P; p.N = Q; p.K = (int)Mc; p.K2 = 0; p.ksplit = 1;
+  p.M = P; p.N = Q; p.K = (int)Mc; p.K2 = 0; p.ksplit = 1; p.part_ld = (int64_t)taps * Q;
+  p.conv_taps = taps == 9 ? 9 : 0; p.conv_wp = wp;
   if (accumulate) { p.aux_in = (const bf16*)C; p.ld_aux_in = ldc; }
   GemmGroup g;
   g.p[0] = p; g.p[1] = p;
-  g.tiles0 = ((P + PQ_BM - 1) / PQ_BM) * ((Q + PQ_BN - 1) / PQ_BN);
-  ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)Mc * P * Q, 2.0 * ((double)Mc * (P + Q) + (double)P * Q * (accumulate ? 2 : 1)), "TN %dx%dx%lld", P, Q, (long long)Mc);
+  g.tiles0 = ((P + PQ_BM - 1) / PQ_BM) * ((Q + PQ_BN - 1) / PQ_BN) * taps;
+  ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)Mc * P * Q * taps, 2.0 * ((double)Mc * (P + Q) + (double)P * Q * taps * (accumulate ? 2 : 1)), "TN%d %dx%dx%lld", taps, P, Q, (long long)Mc);
   // weight matrices are small next to the token count: when the output has too few 256x256 tiles for 256 CUs, slice the contraction
   // (fp32 slabs in the caller's workspace, fixed-order reduce — deterministic)
   const int nt_all = (int)(Mc / PQ_BK);
@@ -1413,7 +1429,7 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
   if (ks > nt_all / 8) ks = nt_all / 8;                // >= 8 K-tiles per slice
   if (ks > 16) ks = 16;
   if (ks >= 2) { const int per = (nt_all + ks - 1) / ks; ks = (nt_all + per - 1) / per; }   // no empty K-slices (the ring prologue assumes >= 1 K-tile)
-  if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * 4 <= workspace_bytes) {
+  if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * taps * 4 <= workspace_bytes) {
     g.p[0].partial = (float*)workspace; g.p[0].ksplit = ks; g.p[0].aux_in = nullptr;
     g.p[1] = g.p[0];
     static bool attr_set = false;
@@ -1421,12 +1437,17 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
     hipLaunchKernelGGL((k_gemm_pq<EPI_SPLITK, true>), dim3(g.tiles0 * ks), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
     int rc = st355_check_launch("gemm_tn_splitk");
     if (rc) return rc;
-    const int64_t n4 = (int64_t)P * (Q / 4);
+    const int64_t n4 = (int64_t)P * (Q * taps / 4);
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ks,
-                       (const bf16*)nullptr, (bf16*)C, ldc, P, Q, accumulate);
+                       (const bf16*)nullptr, (bf16*)C, ldc, P, Q * taps, accumulate);
     return st355_check_launch("gemm_tn_splitk_reduce");
   }
   return accumulate ? launch_tn<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_tn<ST355_EPI_NONE>(stream, g, g.tiles0);
+}
+
+extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
+                                  int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes) {
+  return gemm_tn_impl(stream, L, ldl, R, ldr, C, ldc, Mc, P, Q, accumulate, workspace, workspace_bytes, 1, 0);
 }
 
 // ---- convolution over a zero-bordered NHWC grid (SDXL / SD1.5 UNet, VAE: diffusers ResnetBlock2D / Downsample2D / Upsample2D convs) -------
@@ -1434,7 +1455,7 @@ extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, cons
 // border positions hold ZERO, and 64 zero rows follow the last image (so that shifted / 64-rounded reads stay inside the buffer).
 // 3x3 stride-1 pad-1 conv == ONE GEMM over the grid whose K loop walks the 9 taps as row-shifted views of x (no im2col); 1x1 conv and
 // pre-gathered columns (stride 2, tiny Cin) are the taps == 1 case.  Rows [Wp+1, rows - Wp - 1) are computed (every read stays inside
-// the images); the first / last Wp+1 positions are border positions and are zero-filled here.
+// the images); the first / last Wp+1 positions are border positions and are left untouched (zero in a grid buffer).
 extern "C" int64_t st355_conv_grid_rows(int B, int H, int W) { return (int64_t)B * (H + 2) * (W + 2) + 64; }
 
 extern "C" int st355_conv_bf16(void* stream, const void* x, const void* w, const void* bias, const void* img_add, int64_t img_add_stride,
@@ -1457,8 +1478,8 @@ extern "C" int st355_conv_bf16(void* stream, const void* x, const void* w, const
   if (residual) { p.aux_in = (const bf16*)residual + p0 * Cout; p.ld_aux_in = Cout; }
   p.conv_taps = taps; p.conv_tpt = Cin / BK; p.conv_wp = Wp; p.conv_hp = Hp; p.conv_row0 = p0;
   p.img_add = (const bf16*)img_add; p.img_add_stride = img_add_stride;
-  hipMemsetAsync(out, 0, (size_t)p0 * Cout * 2, (hipStream_t)stream);
-  hipMemsetAsync((bf16*)out + (Mtot - p0) * Cout, 0, (size_t)p0 * Cout * 2, (hipStream_t)stream);
+  // the first / last Wp+1 positions are border positions that no GEMM row covers: they keep the caller's zeros (grid buffers are allocated
+  // zero-filled and no kernel ever writes a border position non-zero), which saves two memset launches per convolution
   ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)Mc * Cout * taps * Cin, 2.0 * ((double)Mtot * Cin + (double)Cout * taps * Cin + (double)Mtot * Cout * (residual ? 2 : 1)),
                "CONV%d %dx%dx%d b%d %dx%d", taps, (int)Mc, Cout, taps * Cin, B, H, W);
   if (gemm_impl_choice() >= 4 && p4_tiles(p) >= min_tiles_256()) {
@@ -1477,12 +1498,10 @@ extern "C" int st355_conv_wgrad_bf16(void* stream, const void* x, const void* dy
   const int Hp = H + 2, Wp = W + 2;
   const int64_t Mtot = (int64_t)B * Hp * Wp, p0 = Wp + 1;
   const int64_t Mc = ((Mtot - 2 * p0 + 63) / 64) * 64;
-  for (int tap = 0; tap < taps; tap++) {
-    const int64_t shift = taps == 9 ? (int64_t)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
-    int rc = st355_gemm_tn_bf16(stream, (const bf16*)dy + p0 * Cout, Cout, (const bf16*)x + (p0 + shift) * Cin, Cin, (bf16*)dw + (int64_t)tap * Cin,
-                                (int64_t)taps * Cin, Mc, Cout, Cin, accumulate, workspace, workspace_bytes);
-    if (rc) return rc;
-  }
+  if (taps == 9)      // all nine taps in one launch: R = x from the grid start (p0 + shift(tap) >= 0 for every tap)
+    return gemm_tn_impl(stream, (const bf16*)dy + p0 * Cout, Cout, (const bf16*)x, Cin, dw, (int64_t)9 * Cin, Mc, Cout, Cin, accumulate, workspace, workspace_bytes, 9, Wp);
+  int rc = st355_gemm_tn_bf16(stream, (const bf16*)dy + p0 * Cout, Cout, (const bf16*)x + p0 * Cin, Cin, dw, Cin, Mc, Cout, Cin, accumulate, workspace, workspace_bytes);
+  if (rc) return rc;
   return ST355_OK;
 }
 

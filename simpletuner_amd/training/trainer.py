@@ -192,14 +192,27 @@ class Trainer:
                 p.grad = None
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
                 loss = self._eager_forward_backward(static)
             entry = self._graphs[key] = (g, static, loss.detach(), [p.grad for p in self.params])
         g, static, loss, grads = entry
         st = dict(tensors(static))
         for k, v in tensors(prepared):
             st[k].copy_(v)
+        import os as _os
+        dbg = _os.environ.get("ST355_DEBUG_NAN") in ("1", "post")
+        comp = self.model.get_trained_component()
+        if _os.environ.get("ST355_DEBUG_NAN") == "1":
+            print("[dbg] pre-replay: w_nan", bool(torch.isnan(comp.arena).any()), "inputs_nan", {k: bool(torch.isnan(v.float()).any()) for k, v in st.items() if v.is_floating_point()}, flush=True)
+        gs = _os.environ.get("ST355_GRAPH_SYNC", "")
+        if "pre" in gs:
+            torch.cuda.current_stream().synchronize()
         g.replay()
+        if "post" in gs:
+            torch.cuda.current_stream().synchronize()
+        if dbg:
+            print("[dbg] post-replay: loss", float(loss), "w_nan", bool(torch.isnan(comp.arena).any()), "grad_nan", bool(torch.isnan(comp.grad_arena).any()),
+                  "gflat_nan", bool(torch.isnan(comp._last_grad_flat).any()), "static_nan", [k for k, v in st.items() if v.is_floating_point() and bool(torch.isnan(v.float()).any())], flush=True)
         for p, gr in zip(self.params, grads):
             p.grad = gr
         return loss
