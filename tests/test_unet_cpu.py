@@ -1,0 +1,95 @@
+"""CPU-side checks of the UNet path's host logic: the DDPM training schedule (diffusers DDPMScheduler arithmetic as configured for SD1.5 / SDXL:
+scaled_linear betas 0.00085 -> 0.012, 1000 steps), the segmented timestep selection (custom_schedule.py:18-58), the oracle UNet's structure
+(state-dict round trip through the native layouts) and its FLOP counter against the figures SURVEY.md §8(d) quotes."""
+import math
+
+import torch
+
+from oracle.unet import UNetConfig, unet_flops_fwd, unet_forward
+from simpletuner_amd.foundation import DDPMSchedule
+
+
+def test_ddpm_schedule_known_values():
+    s = DDPMSchedule()
+    acp = s.alphas_cumprod
+    assert acp.shape == (1000,)
+    assert abs(acp[0].item() - (1 - 0.00085)) < 1e-7
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+    ref = torch.cumprod(1 - betas, 0)
+    assert torch.allclose(acp.double(), ref, atol=2e-6)
+    assert abs(acp[999].item() - 0.0046600) < 2e-5                 # the well-known terminal SNR of the SD schedule
+    a, b = s.mix_coefficients(torch.tensor([0, 500, 999]))
+    assert torch.allclose(a * a + b * b, torch.ones(3), atol=1e-6)
+
+
+def test_segmented_timestep_selection_covers_one_segment_each():
+    s = DDPMSchedule()
+    torch.manual_seed(0)
+    for bsz in (2, 4, 7):
+        seg = 1000 // bsz
+        for _ in range(20):
+            t = s.sample_timesteps(bsz)
+            assert t.shape == (bsz,) and t.dtype == torch.long
+            for i in range(bsz):
+                start = 999 - i * seg
+                end = max(start - seg, 0) if i != bsz - 1 else 0
+                assert end <= int(t[i]) <= start
+    assert s.sample_timesteps(1).shape == (1,)
+
+
+def test_unet_flop_counter_matches_published_figures():
+    assert abs(unet_flops_fwd(UNetConfig(), 128, 128) / 1e12 - 6.76) < 0.05        # SDXL @1024^2: "~6.0 TFLOP" published, 6.76 counted (incl. attention)
+    assert abs(unet_flops_fwd(UNetConfig.sd15(), 64, 64) / 1e12 - 0.80) < 0.02      # SD1.5 @512^2: 0.8 TFLOP
+
+
+def test_oracle_unet_runs_and_is_conditioned():
+    cfg = UNetConfig(block_out_channels=(32, 64), layers_per_block=1, down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                     up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 1), attention_head_dim=(1, 2), cross_attention_dim=32,
+                     projection_class_embeddings_input_dim=16 + 6 * 8, addition_time_embed_dim=8, norm_num_groups=8)
+    g = torch.Generator().manual_seed(0)
+    P = {}
+
+    def lin(n, o, i, bias=True):
+        P[n + ".weight"] = torch.randn(o, i, generator=g) / math.sqrt(i)
+        if bias:
+            P[n + ".bias"] = torch.randn(o, generator=g) * 0.02
+
+    def conv(n, o, i, k=3):
+        P[n + ".weight"] = torch.randn(o, i, k, k, generator=g) / math.sqrt(i * k * k)
+        P[n + ".bias"] = torch.randn(o, generator=g) * 0.02
+
+    def norm(n, c):
+        P[n + ".weight"] = torch.ones(c); P[n + ".bias"] = torch.zeros(c)
+
+    def res(p, i, o):
+        norm(p + "norm1", i); conv(p + "conv1", o, i); lin(p + "time_emb_proj", o, 128); norm(p + "norm2", o); conv(p + "conv2", o, o)
+        if i != o:
+            conv(p + "conv_shortcut", o, i, 1)
+
+    def tr(p, c):
+        norm(p + "norm", c); lin(p + "proj_in", c, c); lin(p + "proj_out", c, c)
+        q = p + "transformer_blocks.0."
+        for nm in ("norm1", "norm2", "norm3"):
+            norm(q + nm, c)
+        for a, kd in (("attn1.", c), ("attn2.", 32)):
+            lin(q + a + "to_q", c, c, False); lin(q + a + "to_k", c, kd, False); lin(q + a + "to_v", c, kd, False); lin(q + a + "to_out.0", c, c)
+        lin(q + "ff.net.0.proj", 8 * c, c); lin(q + "ff.net.2", c, 4 * c)
+
+    conv("conv_in", 32, 4); lin("time_embedding.linear_1", 128, 32); lin("time_embedding.linear_2", 128, 128)
+    lin("add_embedding.linear_1", 128, 64); lin("add_embedding.linear_2", 128, 128)
+    res("down_blocks.0.resnets.0.", 32, 32); conv("down_blocks.0.downsamplers.0.conv", 32, 32)
+    res("down_blocks.1.resnets.0.", 32, 64); tr("down_blocks.1.attentions.0.", 64)
+    res("mid_block.resnets.0.", 64, 64); tr("mid_block.attentions.0.", 64); res("mid_block.resnets.1.", 64, 64)
+    res("up_blocks.0.resnets.0.", 128, 64); tr("up_blocks.0.attentions.0.", 64); res("up_blocks.0.resnets.1.", 96, 64); tr("up_blocks.0.attentions.1.", 64)
+    conv("up_blocks.0.upsamplers.0.conv", 64, 64)
+    res("up_blocks.1.resnets.0.", 96, 32); res("up_blocks.1.resnets.1.", 64, 32)
+    norm("conv_norm_out", 32); conv("conv_out", 4, 32)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    ctx = torch.randn(2, 5, 32, generator=g)
+    add = {"text_embeds": torch.randn(2, 16, generator=g), "time_ids": torch.tensor([[64.0, 64, 0, 0, 64, 64]] * 2)}
+    y1 = unet_forward(P, cfg, x, torch.tensor([10.0, 900.0]), ctx, add)
+    y2 = unet_forward(P, cfg, x, torch.tensor([500.0, 900.0]), ctx, add)
+    y3 = unet_forward(P, cfg, x, torch.tensor([10.0, 900.0]), ctx * 0.5, add)
+    assert y1.shape == (2, 4, 8, 8) and torch.isfinite(y1).all()
+    assert not torch.allclose(y1[0], y2[0]) and torch.allclose(y1[1], y2[1], atol=1e-5)       # timestep conditioning is per sample
+    assert not torch.allclose(y1, y3)                                                           # cross-attention sees the text tokens
