@@ -247,9 +247,12 @@ int st355_conv_wgrad_bf16(void* stream, const void* x, const void* dy, void* dw,
 /* layout passes (conv.hip) */
 int st355_grid_from_nchw(void* stream, const void* x /*[B,C,H,W] bf16*/, void* grid /*[.., Cpad]*/, int B, int C, int H, int W, int Cpad);
 int st355_grid_to_nchw(void* stream, const void* grid, void* y, int B, int C, int H, int W, int Cpad);
-/* columns on the OUTPUT grid of a 3x3 pad-1 conv with stride 1|2: col[(b,yo,xo), tap*C + c]; columns >= 9*C up to Kpad are zero */
-int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad);
-int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad);   /* adjoint (gather form) */
+/* columns on the OUTPUT grid of a 3x3 conv with stride 1|2: col[(b,yo,xo), tap*C + c]; columns >= 9*C up to Kpad are zero.
+ * pad 1: symmetric padding 1 (UNet Downsample2D, conv_in);  pad 0 (stride 2 only): the VAE encoder's Downsample2D = F.pad(x,(0,1,0,1)) + pad-0 conv */
+int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad, int pad);
+int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad, int pad);   /* adjoint (gather form) */
+/* in-place row softmax of a bf16 matrix: x[r, :n] = softmax(scale * x[r, :n]) (fp32 math) — the single-head d=512 attention of the VAE mid block */
+int st355_softmax_rows(void* stream, void* x, int64_t ldx, int64_t rows, int n, float scale);
 int st355_upsample2x(void* stream, const void* x /*grid H,W*/, void* y /*grid 2H,2W*/, int B, int H, int W, int C);
 int st355_upsample2x_bwd(void* stream, const void* dy, void* dx, int B, int H, int W, int C);
 int st355_tokens_to_grid(void* stream, const void* tokens /*[B*H*W, C]*/, const void* residual /*grid or NULL*/, void* grid, int B, int H, int W, int C);

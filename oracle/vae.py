@@ -1,0 +1,108 @@
+"""Plain-torch CPU restatement of AutoencoderKL.encode (the VAE latent encode of the hot path).  TEST INFRASTRUCTURE.
+
+Reference seam: VAECache.encode_images -> model.encode_with_vae -> vae.encode(samples).latent_dist.sample() -> scale_vae_latents_for_cache
+(simpletuner/helpers/caching/vae.py:1238-1396, models/common.py:2767-2772, models/foundation_mixins.py:67-79: (z - shift_factor) * scaling_factor,
+or z * scaling_factor when the VAE has no shift).  The network is diffusers' AutoencoderKL encoder (un-vendored; SURVEY.md Appendix A marks the
+architecture UNCORROBORATED in-tree) restated from its published definition: conv_in 3x3 -> DownEncoderBlock2D x4 (ResnetBlock2D without time
+embedding: GroupNorm32 eps 1e-6 -> SiLU -> conv3x3 -> GroupNorm -> SiLU -> conv3x3, 1x1 conv_shortcut on channel change; Downsample2D with
+padding 0 = F.pad(x,(0,1,0,1)) + conv3x3 stride 2) -> UNetMidBlock2D (resnet, single-head attention of dim C with GroupNorm + residual, resnet)
+-> GroupNorm -> SiLU -> conv_out (2*latent channels) [-> quant_conv 1x1] -> DiagonalGaussianDistribution(mean, logvar clamp [-30, 20]).
+PARITY UNPINNED: no golden tensor exists in the reference for this network and diffusers is not installable here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class VAEConfig:
+    # defaults = SDXL VAE (madebyollin/sdxl-vae-fp16-fix config): 4 latent channels, scaling 0.13025, quant_conv on
+    in_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.13025
+    shift_factor: Optional[float] = None
+    use_quant_conv: bool = True
+
+    @staticmethod
+    def flux():          # FLUX.1 VAE: 16 latent channels, shift + scale, no quant_conv
+        return VAEConfig(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False)
+
+
+def _conv(x, P, name, stride=1, padding=1):
+    return F.conv2d(x, P[name + ".weight"], P.get(name + ".bias"), stride=stride, padding=padding)
+
+
+def _resnet(P, p, x, groups):
+    h = _conv(F.silu(F.group_norm(x, groups, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-6)), P, p + "conv1")
+    h = _conv(F.silu(F.group_norm(h, groups, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-6)), P, p + "conv2")
+    if (p + "conv_shortcut.weight") in P:
+        x = _conv(x, P, p + "conv_shortcut", padding=0)
+    return x + h
+
+
+def _mid_attention(P, p, x, groups):
+    B, C, H, W = x.shape
+    h = F.group_norm(x, groups, P[p + "group_norm.weight"], P[p + "group_norm.bias"], 1e-6).view(B, C, H * W).transpose(1, 2)
+    q = F.linear(h, P[p + "to_q.weight"], P[p + "to_q.bias"])
+    k = F.linear(h, P[p + "to_k.weight"], P[p + "to_k.bias"])
+    v = F.linear(h, P[p + "to_v.weight"], P[p + "to_v.bias"])
+    o = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), dim=-1) @ v
+    o = F.linear(o, P[p + "to_out.0.weight"], P[p + "to_out.0.bias"])
+    return o.transpose(1, 2).reshape(B, C, H, W) + x
+
+
+def encode_moments(P: Dict[str, torch.Tensor], cfg: VAEConfig, x: torch.Tensor):
+    """AutoencoderKL.encode -> the distribution parameters [B, 2*latent, H/8, W/8] (mean | logvar)"""
+    g = cfg.norm_num_groups
+    h = _conv(x, P, "encoder.conv_in")
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            h = _resnet(P, f"encoder.down_blocks.{i}.resnets.{j}.", h, g)
+        if i < nb - 1:
+            h = _conv(F.pad(h, (0, 1, 0, 1)), P, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+    h = _resnet(P, "encoder.mid_block.resnets.0.", h, g)
+    h = _mid_attention(P, "encoder.mid_block.attentions.0.", h, g)
+    h = _resnet(P, "encoder.mid_block.resnets.1.", h, g)
+    h = F.silu(F.group_norm(h, g, P["encoder.conv_norm_out.weight"], P["encoder.conv_norm_out.bias"], 1e-6))
+    h = _conv(h, P, "encoder.conv_out")
+    if cfg.use_quant_conv:
+        h = _conv(h, P, "quant_conv", padding=0)
+    return h
+
+
+def sample_and_scale(moments: torch.Tensor, cfg: VAEConfig, eps: Optional[torch.Tensor] = None):
+    """DiagonalGaussianDistribution.sample (mean + exp(0.5*clamp(logvar,-30,20)) * eps; eps None -> mode) then scale_vae_latents_for_cache"""
+    mean, logvar = moments.chunk(2, dim=1)
+    z = mean if eps is None else mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps
+    if cfg.shift_factor is not None:
+        return (z - cfg.shift_factor) * cfg.scaling_factor
+    return z * cfg.scaling_factor
+
+
+def encoder_flops(cfg: VAEConfig, H: int, W: int) -> float:
+    """forward FLOPs per image (multiply-add = 2)"""
+    def conv(ci, co, h, w, k=3):
+        return 2.0 * k * k * ci * co * h * w
+    ch = cfg.block_out_channels
+    fl = conv(cfg.in_channels, ch[0], H, W)
+    cin, h, w = ch[0], H, W
+    for i, co in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            fl += conv(cin, co, h, w) + conv(co, co, h, w) + (conv(cin, co, h, w, 1) if cin != co else 0)
+            cin = co
+        if i < len(ch) - 1:
+            h, w = h // 2, w // 2
+            fl += conv(cin, cin, h, w)
+    s = h * w
+    fl += 4 * conv(cin, cin, h, w) + 2.0 * s * cin * cin * 4 + 4.0 * s * s * cin
+    fl += conv(cin, 2 * cfg.latent_channels, h, w)
+    return fl

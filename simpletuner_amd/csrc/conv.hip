@@ -44,7 +44,7 @@ extern "C" int st355_grid_to_nchw(void* stream, const void* grid, void* y, int B
 // ---- 3x3 column gather (stride 1 or 2, pad 1) onto the OUTPUT grid: col[(b,yo,xo), tap*C + c] = x[(b, s*(yo-1)+ky, s*(xo-1)+kx), c] ------
 // used only where the shifted-view GEMM does not apply: the two stride-2 Downsample2D convs, conv_in (C = 4 -> 8) and conv_out's input
 // gradient (C = 4 -> 8).  One thread = one 8-channel (16-byte) chunk; columns >= 9*C (the pad to a multiple of 64) are written as zero.
-__global__ void __launch_bounds__(256) k_im2col3x3(const bf16* __restrict__ x, bf16* __restrict__ col, int B, int H, int W, int C, int stride, int Kpad) {
+__global__ void __launch_bounds__(256) k_im2col3x3(const bf16* __restrict__ x, bf16* __restrict__ col, int B, int H, int W, int C, int stride, int Kpad, int off) {
   const int Ho = H / stride, Wo = W / stride, Hop = Ho + 2, Wop = Wo + 2, Hp = H + 2, Wp = W + 2;
   const int kc = Kpad / 8, c8 = C / 8;
   const int64_t n = (int64_t)B * Hop * Wop * kc;
@@ -58,14 +58,14 @@ __global__ void __launch_bounds__(256) k_im2col3x3(const bf16* __restrict__ x, b
     const int tap = ch / c8, cc = ch - tap * c8;
     if (tap < 9 && yo >= 1 && yo <= Ho && xo >= 1 && xo <= Wo) {
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int yi = stride * (yo - 1) + ky, xi = stride * (xo - 1) + kx;       // padded input coordinates, always inside [0,H+1]x[0,W+1]
+      const int yi = stride * (yo - 1) + ky + off, xi = stride * (xo - 1) + kx + off;   // padded input coordinates, always inside [0,H+1]x[0,W+1]
       v = *(const bf16x8*)(x + (((int64_t)b * Hp + yi) * Wp + xi) * C + cc * 8);
     }
     *(bf16x8*)(col + pos * Kpad + ch * 8) = v;
   }
 }
 // adjoint: dx[(b,yi,xi), c] = sum over taps with s*(yo-1)+ky == yi, s*(xo-1)+kx == xi of dcol[(b,yo,xo), tap*C + c]   (gather form, fixed order)
-__global__ void __launch_bounds__(256) k_col2im3x3(const bf16* __restrict__ dcol, bf16* __restrict__ dx, int B, int H, int W, int C, int stride, int Kpad) {
+__global__ void __launch_bounds__(256) k_col2im3x3(const bf16* __restrict__ dcol, bf16* __restrict__ dx, int B, int H, int W, int C, int stride, int Kpad, int off) {
   const int Ho = H / stride, Wo = W / stride, Hop = Ho + 2, Wop = Wo + 2, Hp = H + 2, Wp = W + 2;
   const int c8 = C / 8;
   const int64_t n = (int64_t)B * Hp * Wp * c8;
@@ -78,12 +78,12 @@ __global__ void __launch_bounds__(256) k_col2im3x3(const bf16* __restrict__ dcol
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
     if (yi >= 1 && yi <= H && xi >= 1 && xi <= W) {
       for (int ky = 0; ky < 3; ky++) {
-        const int ty = yi - ky;
+        const int ty = yi - ky - off;
         if (ty < 0 || ty % stride) continue;
         const int yo = ty / stride + 1;
         if (yo < 1 || yo > Ho) continue;
         for (int kx = 0; kx < 3; kx++) {
-          const int tx = xi - kx;
+          const int tx = xi - kx - off;
           if (tx < 0 || tx % stride) continue;
           const int xo = tx / stride + 1;
           if (xo < 1 || xo > Wo) continue;
@@ -99,22 +99,23 @@ __global__ void __launch_bounds__(256) k_col2im3x3(const bf16* __restrict__ dcol
     *(bf16x8*)(dx + pos * C + cc * 8) = o;
   }
 }
-extern "C" int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad) {
+extern "C" int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad, int pad) {
   ST_REQUIRE(x && col && C % 8 == 0 && Kpad % 8 == 0 && Kpad >= 9 * C && (stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0,
              "im2col3x3: bad args (C=%d Kpad=%d stride=%d)", C, Kpad, stride);
+  ST_REQUIRE(pad == 1 || (pad == 0 && stride == 2), "im2col3x3: pad 0 is the stride-2 (0,1,0,1)-padded form only");
   const int64_t n = (int64_t)B * (H / stride + 2) * (W / stride + 2) * (Kpad / 8);
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 0.0, 32.0 * n);
   hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 65536)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)col, B, H, W, C,
-                     stride, Kpad);
+                     stride, Kpad, pad ? 0 : 1);
   return st355_check_launch("im2col3x3");
 }
-extern "C" int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad) {
+extern "C" int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad, int pad) {
   ST_REQUIRE(dcol && dx && C % 8 == 0 && Kpad % 8 == 0 && Kpad >= 9 * C && (stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0,
              "col2im3x3: bad args");
   const int64_t n = (int64_t)B * (H + 2) * (W + 2) * (C / 8);
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 0.0, 16.0 * n * (1 + 9.0 / (stride * stride)));
   hipLaunchKernelGGL(k_col2im3x3, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 65536)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcol, (bf16*)dx, B, H, W, C,
-                     stride, Kpad);
+                     stride, Kpad, pad ? 0 : 1);
   return st355_check_launch("col2im3x3");
 }
 

@@ -430,3 +430,72 @@ extern "C" int st355_geglu_bwd(void* stream, const void* h, int64_t ldh, const v
   hipLaunchKernelGGL(k_geglu<true>, dim3(ew_blocks(M * (F / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, ldh, (const bf16*)dout, (bf16*)dh, lddh, M, F);
   return st355_check_launch("geglu_bwd");
 }
+
+// ---- in-place row softmax (bf16 storage, fp32 math): the VAE mid-block attention is ONE head of dim 512 over H*W tokens (diffusers Attention with
+// heads=1 inside UNetMidBlock2D of AutoencoderKL) — scores are a plain GEMM, this kernel turns them into probabilities, P.V is a plain GEMM.
+// One 256-thread block per row; the row (<= 64 Ki elements) is kept in registers between the max / sum / write passes.
+template <int MAXC>                            // 256 threads * 8 elements * MAXC chunks cover the row
+__global__ void __launch_bounds__(256) k_softmax_rows(bf16* __restrict__ x, int64_t ldx, int n, float scale) {
+  __shared__ float red[4];
+  bf16* row = x + (int64_t)blockIdx.x * ldx;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float v[MAXC][8];
+  const int nch = (n + 2047) / 2048;
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    if (c < nch) {
+      const int i = (c * 256 + tid) * 8;
+      if (i < n) {
+        const bf16x8 t = *(const bf16x8*)(row + i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { v[c][j] = (i + j < n) ? bf2f(t[j]) * scale : -INFINITY; m = fmaxf(m, v[c][j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[c][j] = -INFINITY;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { v[c][j] = __expf(v[c][j] - m); s += v[c][j]; }
+    }
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+    if (c < nch) {
+      const int i = (c * 256 + tid) * 8;
+      if (i < n) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = f2bf(v[c][j] * inv);
+        *(bf16x8*)(row + i) = o;
+      }
+    }
+}
+extern "C" int st355_softmax_rows(void* stream, void* x, int64_t ldx, int64_t rows, int n, float scale) {
+  ST_REQUIRE(x && rows > 0 && n > 0 && n % 8 == 0 && n <= 65536 && ldx % 8 == 0, "softmax_rows: n must be a multiple of 8 and <= 65536");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 5.0 * rows * n, 4.0 * rows * n);
+#define SM_LAUNCH(MC) hipLaunchKernelGGL(k_softmax_rows<MC>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (bf16*)x, ldx, n, scale)
+  const int nch = (n + 2047) / 2048;
+  if (nch <= 1) SM_LAUNCH(1);
+  else if (nch <= 2) SM_LAUNCH(2);
+  else if (nch <= 4) SM_LAUNCH(4);
+  else if (nch <= 8) SM_LAUNCH(8);
+  else if (nch <= 16) SM_LAUNCH(16);
+  else SM_LAUNCH(32);
+#undef SM_LAUNCH
+  return st355_check_launch("softmax_rows");
+}

@@ -27,7 +27,7 @@ SYMBOLS = [
     "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm",
     "st355_lora_pack",
     # UNet path (SDXL / SD1.5)
-    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3",
+    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows",
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
     "st355_groupnorm_workspace", "st355_groupnorm_fwd", "st355_groupnorm_bwd",
     "st355_layernorm_fwd", "st355_layernorm_bwd", "st355_layernorm_param_grads_workspace", "st355_layernorm_param_grads",
@@ -125,8 +125,9 @@ def _declare(lib):
         "st355_conv_wgrad_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64]),
         "st355_grid_from_nchw": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32]),
         "st355_grid_to_nchw": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32]),
-        "st355_im2col3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),
-        "st355_col2im3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),
+        "st355_im2col3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
+        "st355_col2im3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
+        "st355_softmax_rows": (C.c_int, [vp, vp, i64, i64, i32, f32]),
         "st355_upsample2x": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_upsample2x_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_tokens_to_grid": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -655,21 +655,21 @@ def conv_wgrad(x, dy, dw, B: int, H: int, W: int, taps: int = 9, accumulate: boo
     return dw
 
 
-def im2col3x3(x, B: int, H: int, W: int, stride: int = 1):
+def im2col3x3(x, B: int, H: int, W: int, stride: int = 1, pad: int = 1):
     L = _l.load()
     _chk(x, BF16, "x")
     Cn = x.shape[1]
     Kpad = (9 * Cn + 63) // 64 * 64
     col = grid_zeros(B, H // stride, W // stride, Kpad, x.device)
-    _l.check(L.st355_im2col3x3(_stream(), _ptr(x), _ptr(col), B, H, W, Cn, stride, Kpad), "im2col3x3")
+    _l.check(L.st355_im2col3x3(_stream(), _ptr(x), _ptr(col), B, H, W, Cn, stride, Kpad, pad), "im2col3x3")
     return col
 
 
-def col2im3x3(dcol, B: int, H: int, W: int, Cn: int, stride: int = 1):
+def col2im3x3(dcol, B: int, H: int, W: int, Cn: int, stride: int = 1, pad: int = 1):
     L = _l.load()
     _chk(dcol, BF16, "dcol")
     dx = grid_zeros(B, H, W, Cn, dcol.device)
-    _l.check(L.st355_col2im3x3(_stream(), _ptr(dcol), _ptr(dx), B, H, W, Cn, stride, dcol.shape[1]), "col2im3x3")
+    _l.check(L.st355_col2im3x3(_stream(), _ptr(dcol), _ptr(dx), B, H, W, Cn, stride, dcol.shape[1], pad), "col2im3x3")
     return dx
 
 
@@ -830,3 +830,11 @@ def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq,
                                     _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
                                     _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, Sq, Sqp, Sk, Skp, d, scale, _ptr(ws)),
              "attn_cross_bwd")
+
+
+def softmax_rows_(x, scale: float = 1.0):
+    """in place: x[r, :] = softmax(scale * x[r, :]) over the last dim of a 2-D bf16 view"""
+    L = _l.load()
+    _chk(x, BF16, "x")
+    _l.check(L.st355_softmax_rows(_stream(), _ptr(x), _rows(x, "x"), x.shape[0], x.shape[1], scale), "softmax_rows")
+    return x
