@@ -55,7 +55,7 @@ def hbm_traffic_per_gemm_launch():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl"],
+    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "vae"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
                     "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
@@ -114,6 +114,61 @@ def cpu_baseline(args):
     }
 
 
+def bench_vae(args, dev, rank, world):
+    """secondary workload: the VAE latent encode of the hot path — AutoencoderKL.encode + sample + scale of a
+    [B,3,res,res] batch with the SDXL VAE architecture (128/256/512/512 channels), random-init weights; a 'step' = one batch encode"""
+    import torch.distributed as dist
+    from simpletuner_amd import ops
+    from simpletuner_amd.vae.autoencoder_kl import AutoencoderKL
+    from oracle.vae import VAEConfig, encoder_flops          # FLOP counter only
+    vae = AutoencoderKL(device=dev)
+    vae.load_state_dict(vae.synthetic_state_dict(42))
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    x = (torch.rand(B, 3, args.res, args.res, device=dev, generator=gen) * 2 - 1).to(torch.bfloat16)
+    for _ in range(args.warmup):
+        z = vae.encode_scaled(x, generator=gen)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_prof:
+        ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        z = vae.encode_scaled(x, generator=gen)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_prof:
+        ops.prof_enable(False); prof = ops.prof_collect(); ops.prof_reset()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        fl = encoder_flops(VAEConfig(), args.res, args.res) * B
+        ms = elapsed / args.steps * 1e3
+        roof = kernels = None
+        if prof is not None and prof["gemm"]["ms"] > 0:
+            g = prof["gemm"]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_gemm_* (conv-as-GEMM)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": g["launches"] // args.steps,
+                    "share_of_step": round(g["ms"] / (elapsed * 1e3), 3)}
+            kernels = {k: {"ms_per_step": round(v["ms"] / args.steps, 2), "launches_per_step": v["launches"] // args.steps} for k, v in prof.items() if v["launches"]}
+        print(json.dumps({"metric": f"VAE latent encode images/sec (whole node), AutoencoderKL (SDXL VAE architecture) {args.res}^2", "value": round(world * B * args.steps / elapsed, 3),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"AutoencoderKL.encode + sample + scale, [B,3,{args.res},{args.res}] -> [B,4,{args.res // 8},{args.res // 8}], 128/256/512/512 ch, random-init weights",
+                                     "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                          "step_model_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "latent_std": round(float(z.float().std()), 4), "roofline": roof, "kernels": kernels,
+                          "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,6 +191,8 @@ def main():
 
     from simpletuner_amd import ops
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+    if args.model == "vae":
+        return bench_vae(args, dev, rank, world)
 
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3,
                          model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
