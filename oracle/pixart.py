@@ -1,0 +1,169 @@
+"""Plain-torch CPU restatement of the PixArt-Sigma DiT forward and its ControlNet-Transformer wrapper (autograd = backward).  TEST INFRASTRUCTURE.
+
+Control flow follows the reference's in-tree files:
+    PixArtTransformer2DModel.forward                     simpletuner/helpers/models/pixart/transformer.py:499-788 (mask -> bias :566-568, blocks, final
+                                                         modulation + proj_out + unpatchify "nhwpqc->nchpwq")
+    ada_norm_single block arithmetic                     .../pixart/transformer.py:95-145 (table + t -> shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp;
+                                                         cross-attention WITHOUT a pre-norm; gates on self-attention and MLP only)
+    PixArtSigmaControlNetAdapterBlock / ...TransformerModel   .../pixart/controlnet.py:17-110, 166-326 (zero-init before_proj on block 0 input,
+                                                         copied blocks, zero-init after_proj, residual into the trunk BEFORE trunk blocks 1..N)
+    PixartSigma._model_predict_single / _controlnet_predict_single   .../pixart/model.py:274-319, 399-458 (chunk(2, dim=1)[0] drops the learned variance)
+Leaf modules are diffusers' (un-vendored): PatchEmbed (conv p=2 + 2-D sincos table with interpolation_scale / base_size),
+AdaLayerNormSingle (PixArtAlphaCombinedTimestepSizeEmbeddings + SiLU + Linear D->6D), PixArtAlphaTextProjection (Linear, GELU-tanh, Linear),
+Attention (bias on q/k/v/out), FeedForward("gelu-approximate").
+PARITY UNPINNED: the reference holds no golden tensor for this network.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .flux import timestep_proj
+
+
+@dataclass
+class PixArtConfig:
+    # PixArt-Sigma XL/2 (pixart/transformer.py:210-230)
+    num_attention_heads: int = 16
+    attention_head_dim: int = 72
+    in_channels: int = 4
+    out_channels: int = 8
+    num_layers: int = 28
+    cross_attention_dim: int = 1152
+    sample_size: int = 128
+    patch_size: int = 2
+    caption_channels: int = 4096
+    use_additional_conditions: Optional[bool] = None
+    interpolation_scale: Optional[float] = None
+
+    @property
+    def D(self):
+        return self.num_attention_heads * self.attention_head_dim
+
+    @property
+    def additional(self):
+        return (self.sample_size == 128) if self.use_additional_conditions is None else self.use_additional_conditions
+
+    @property
+    def interp(self):
+        return self.interpolation_scale if self.interpolation_scale is not None else max(self.sample_size // 64, 1)
+
+
+def sincos_2d_hw(embed_dim: int, h: int, w: int, base_size: int, interpolation_scale: float) -> torch.Tensor:
+    """diffusers get_2d_sincos_pos_embed for a (h, w) grid: [h*w, embed_dim] (first half from the w coordinate, sin then cos per half)"""
+    gh = (torch.arange(h, dtype=torch.float32) / (h / base_size) / interpolation_scale).double()
+    gw = (torch.arange(w, dtype=torch.float32) / (w / base_size) / interpolation_scale).double()
+    cw = gw[None, :].expand(h, w).reshape(-1)
+    chh = gh[:, None].expand(h, w).reshape(-1)
+
+    def one_d(dim, pos):
+        omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+        out = pos[:, None] * omega[None, :]
+        return torch.cat([out.sin(), out.cos()], dim=1)
+
+    return torch.cat([one_d(embed_dim // 2, cw), one_d(embed_dim // 2, chh)], dim=1).float()
+
+
+def _lin(x, P, name):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def patch_embed(P, cfg: PixArtConfig, x, prefix="pos_embed."):
+    B, C, H, W = x.shape
+    h, w = H // cfg.patch_size, W // cfg.patch_size
+    t = F.conv2d(x, P[prefix + "proj.weight"], P[prefix + "proj.bias"], stride=cfg.patch_size).flatten(2).transpose(1, 2)
+    pos = sincos_2d_hw(cfg.D, h, w, cfg.sample_size // cfg.patch_size, cfg.interp).to(t.dtype)
+    return t + pos[None]
+
+
+def adaln_single(P, cfg: PixArtConfig, timestep, resolution, aspect_ratio, B, dtype):
+    """-> (linear(silu(emb)) [B,6D], emb [B,D])"""
+    def tee(x, p):
+        return _lin(F.silu(_lin(x, P, p + ".linear_1")), P, p + ".linear_2")
+    emb = tee(timestep_proj(timestep.expand(B), 256).to(dtype), "adaln_single.emb.timestep_embedder")
+    if cfg.additional:
+        r = tee(timestep_proj(resolution.flatten().float(), 256).to(dtype), "adaln_single.emb.resolution_embedder").reshape(B, -1)
+        a = tee(timestep_proj(aspect_ratio.flatten().float(), 256).to(dtype), "adaln_single.emb.aspect_ratio_embedder").reshape(B, -1)
+        emb = emb + torch.cat([r, a], dim=1)
+    return _lin(F.silu(emb), P, "adaln_single.linear"), emb
+
+
+def _attn(P, p, x, ctx, H, bias=None):
+    B, S, D = x.shape
+    q, k, v = _lin(x, P, p + "to_q"), _lin(ctx, P, p + "to_k"), _lin(ctx, P, p + "to_v")
+    d = D // H
+    q, k, v = (t.view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    s = q @ k.transpose(-1, -2) / math.sqrt(d)
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    return _lin((s.softmax(-1) @ v).transpose(1, 2).reshape(B, S, D), P, p + "to_out.0")
+
+
+def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6):
+    """pixart/transformer.py:95-145 with timestep [B, 6D]"""
+    B, S, D = h.shape
+    mod = P[p + "scale_shift_table"][None] + t6.reshape(B, 6, D)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
+    n = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale_msa) + shift_msa
+    h = gate_msa * _attn(P, p + "attn1.", n, n, cfg.num_attention_heads) + h
+    h = _attn(P, p + "attn2.", h, ctx, cfg.num_attention_heads, ctx_bias) + h
+    n = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale_mlp) + shift_mlp
+    ff = _lin(F.gelu(_lin(n, P, p + "ff.net.0.proj"), approximate="tanh"), P, p + "ff.net.2")
+    return gate_mlp * ff + h
+
+
+def _head(P, cfg: PixArtConfig, h, emb, hh, ww):
+    D = cfg.D
+    shift, scale = (P["scale_shift_table"][None] + emb[:, None]).chunk(2, dim=1)
+    h = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale) + shift
+    h = _lin(h, P, "proj_out")
+    p = cfg.patch_size
+    h = h.reshape(-1, hh, ww, p, p, cfg.out_channels)
+    return torch.einsum("nhwpqc->nchpwq", h).reshape(-1, cfg.out_channels, hh * p, ww * p)
+
+
+def _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio):
+    B = latents.shape[0]
+    dt = latents.dtype
+    bias = None if mask is None else (1 - mask.to(dt)) * -10000.0                         # pixart/transformer.py:566-568
+    h = patch_embed(P, cfg, latents)
+    t6, emb = adaln_single(P, cfg, timestep, resolution, aspect_ratio, B, dt)
+    ctx = _lin(F.gelu(_lin(enc.to(dt), P, "caption_projection.linear_1"), approximate="tanh"), P, "caption_projection.linear_2")
+    return h, t6, emb, ctx, bias
+
+
+def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, mask, timestep, resolution=None, aspect_ratio=None):
+    """PixArtTransformer2DModel.forward -> [B, out_channels, H, W]"""
+    hh, ww = latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size
+    h, t6, emb, ctx, bias = _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio)
+    for i in range(cfg.num_layers):
+        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6)
+    return _head(P, cfg, h, emb, hh, ww)
+
+
+def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc, mask, timestep, resolution=None, aspect_ratio=None):
+    """PixArtSigmaControlNetTransformerModel.forward (pixart/controlnet.py:208-326).  P: trunk weights; C: adapter weights
+    (`controlnet_blocks.{i}.before_proj|transformer_block.*|after_proj`)."""
+    hh, ww = latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size
+    h, t6, emb, ctx, bias = _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio)
+    cs = patch_embed(P, cfg, cond)
+    for i in range(cfg.num_layers):
+        if 0 < i <= n_ctrl:
+            p = f"controlnet_blocks.{i - 1}."
+            if i == 1:
+                cs = h + _lin(cs, C, p + "before_proj")
+            cs = block(C, p + "transformer_block.", cfg, cs, ctx, bias, t6)
+            h = h + _lin(cs, C, p + "after_proj")
+        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6)
+    return _head(P, cfg, h, emb, hh, ww)
+
+
+def pixart_flops_fwd(cfg: PixArtConfig, H: int, W: int, ctx_len: int = 300, n_ctrl: int = 0) -> float:
+    D = cfg.D
+    S = (H // cfg.patch_size) * (W // cfg.patch_size)
+    blk = 2.0 * S * (4 * D * D + 2 * D * D + 8 * D * D) + 2.0 * ctx_len * 2 * D * D + 4.0 * S * S * D + 4.0 * S * ctx_len * D
+    return (cfg.num_layers + n_ctrl) * blk + n_ctrl * 2.0 * S * D * D + 2.0 * S * D * (cfg.patch_size ** 2) * (cfg.in_channels + cfg.out_channels)

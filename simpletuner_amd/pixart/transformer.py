@@ -1,0 +1,586 @@
+"""PixArt-Sigma DiT and its ControlNet-Transformer wrapper on the MI355X path.
+
+Mirrors the reference's module surface: `PixArtTransformer2DModel` (simpletuner/helpers/models/pixart/transformer.py:146-853: same constructor
+arguments and diffusers state-dict keys, `forward(hidden_states, encoder_hidden_states, timestep, added_cond_kwargs, encoder_attention_mask,
+return_dict)`), `PixArtSigmaControlNetAdapterModel` / `PixArtSigmaControlNetTransformerModel` (pixart/controlnet.py:17-326: zero-init `before_proj`
+on the first copied block, copied blocks 0..N-1, zero-init `after_proj`, residual into the trunk BEFORE trunk blocks 1..N, `from_transformer`).
+BASELINE.json configs[4] trains the ControlNet branch only: the trunk is frozen (forward + input gradients), the adapter is a full fine-tune
+(weight gradients through the TN GEMM into one bf16 gradient arena -> one fused optimizer launch).
+
+Kernels: the MMDiT set (AdaLN modulate, GEMM with GELU / gate-residual epilogues, flash attention fwd/bwd) + the cross-attention entry points with
+the additive key bias of the text mask.  head_dim 72 is not an MFMA-friendly width: the q/k/v projections are stored with each head zero-padded to
+128 channels (and the out-projections with the matching zero K columns), so the head_dim-128 attention kernels run unchanged with scale 1/sqrt(72);
+the padding costs 1.78x on the attention FLOPs — the head_dim-80/96 kernel variants are the open item.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..flux.transformer import _attach, _frozen
+from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+HP = 128          # padded head width
+
+
+def sincos_2d_hw(embed_dim: int, h: int, w: int, base_size: int, interpolation_scale: float) -> torch.Tensor:
+    """diffusers get_2d_sincos_pos_embed on a (h, w) grid (first half from the w coordinate; sin then cos)"""
+    gh = (torch.arange(h, dtype=torch.float32) / (h / base_size) / interpolation_scale).double()
+    gw = (torch.arange(w, dtype=torch.float32) / (w / base_size) / interpolation_scale).double()
+    cw = gw[None, :].expand(h, w).reshape(-1)
+    chh = gh[:, None].expand(h, w).reshape(-1)
+
+    def one_d(dim, pos):
+        omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+        out = pos[:, None] * omega[None, :]
+        return torch.cat([out.sin(), out.cos()], dim=1)
+
+    return torch.cat([one_d(embed_dim // 2, cw), one_d(embed_dim // 2, chh)], dim=1).float()
+
+
+def _p64(t):
+    r = t.shape[0]
+    if r % 64 == 0 and t.is_contiguous():
+        return t
+    o = torch.zeros((r + 63) // 64 * 64, t.shape[1], dtype=BF16, device=t.device)
+    o[:r] = t
+    return o
+
+
+class _Block:
+    """one BasicTransformerBlock(ada_norm_single): true parameters (diffusers shapes, views of an arena) + the head-padded working copies"""
+
+    def __init__(self, owner, prefix: str, D: int, H: int, hd: int, Dc: int, alloc, trainable: bool):
+        self.prefix, self.D, self.H, self.hd, self.trainable = prefix, D, H, hd, trainable
+        P = {}
+        for nm, shape in (("attn1.to_q", (D, D)), ("attn1.to_k", (D, D)), ("attn1.to_v", (D, D)), ("attn1.to_out.0", (D, D)),
+                          ("attn2.to_q", (D, D)), ("attn2.to_k", (D, Dc)), ("attn2.to_v", (D, Dc)), ("attn2.to_out.0", (D, D)),
+                          ("ff.net.0.proj", (4 * D, D)), ("ff.net.2", (D, 4 * D))):
+            P[nm + ".weight"] = alloc(prefix + nm + ".weight", shape)
+            P[nm + ".bias"] = alloc(prefix + nm + ".bias", (shape[0],))
+        P["scale_shift_table"] = alloc(prefix + "scale_shift_table", (6, D))
+        self.P = P
+        self.G: Dict[str, torch.Tensor] = {}          # gradient views (trainable blocks)
+        self.W = None                                  # padded working copies
+
+    @torch.no_grad()
+    def refresh(self, dev):
+        """head-padded working weights: q/k/v rows of head h at [h*128, h*128+72), out-projection columns likewise; + K-major copies for dgrad"""
+        P, D, H, hd = self.P, self.D, self.H, self.hd
+        Dp = H * HP
+
+        def pad_rows(ws, bs):                                        # list of [D, K] -> [len*Dp, K]
+            K = ws[0].shape[1]
+            w = torch.zeros(len(ws), H, HP, K, dtype=BF16, device=dev)
+            b = torch.zeros(len(ws), H, HP, dtype=BF16, device=dev)
+            for j, (wj, bj) in enumerate(zip(ws, bs)):
+                w[j, :, :hd] = wj.view(H, hd, K)
+                b[j, :, :hd] = bj.view(H, hd)
+            return w.view(len(ws) * Dp, K), b.view(len(ws) * Dp)
+
+        def pad_cols(w):                                             # [N, D] -> [N, Dp]
+            o = torch.zeros(w.shape[0], H, HP, dtype=BF16, device=dev)
+            o[:, :, :hd] = w.view(w.shape[0], H, hd)
+            return o.view(w.shape[0], Dp)
+
+        W = SimpleNamespace()
+        W.qkv_w, W.qkv_b = pad_rows([P[f"attn1.to_{n}.weight"] for n in "qkv"], [P[f"attn1.to_{n}.bias"] for n in "qkv"])
+        W.out1_w, W.out1_b = pad_cols(P["attn1.to_out.0.weight"]), P["attn1.to_out.0.bias"]
+        W.q2_w, W.q2_b = pad_rows([P["attn2.to_q.weight"]], [P["attn2.to_q.bias"]])
+        W.kv2_w, W.kv2_b = pad_rows([P["attn2.to_k.weight"], P["attn2.to_v.weight"]], [P["attn2.to_k.bias"], P["attn2.to_v.bias"]])
+        W.out2_w, W.out2_b = pad_cols(P["attn2.to_out.0.weight"]), P["attn2.to_out.0.bias"]
+        W.ff1_w, W.ff1_b, W.ff2_w, W.ff2_b = P["ff.net.0.proj.weight"], P["ff.net.0.proj.bias"], P["ff.net.2.weight"], P["ff.net.2.bias"]
+        for n in ("qkv", "out1", "q2", "out2", "ff1", "ff2"):
+            setattr(W, n + "_wT", getattr(W, n + "_w").t().contiguous())
+        self.W = W
+
+
+class PixArtTransformer2DModel(nn.Module):
+    def __init__(self, num_attention_heads: int = 16, attention_head_dim: int = 72, in_channels: int = 4, out_channels: Optional[int] = 8,
+                 num_layers: int = 28, cross_attention_dim: Optional[int] = 1152, sample_size: int = 128, patch_size: int = 2,
+                 interpolation_scale: Optional[float] = None, use_additional_conditions: Optional[bool] = None, caption_channels: Optional[int] = 4096,
+                 norm_type: str = "ada_norm_single", device=None, **_ignored):
+        super().__init__()
+        if norm_type != "ada_norm_single" or patch_size != 2:
+            raise NotImplementedError("PixArt(st355): ada_norm_single blocks with patch_size 2 only")
+        H, hd = num_attention_heads, attention_head_dim
+        D = H * hd
+        if hd > HP or D % 64 or (cross_attention_dim or D) != D or caption_channels is None or caption_channels % 64:
+            raise ValueError("PixArt(st355): head_dim <= 128, inner dim a multiple of 64, cross_attention_dim == inner dim, caption_channels % 64 == 0")
+        if use_additional_conditions is None:
+            use_additional_conditions = sample_size == 128
+        out_channels = in_channels if out_channels is None else out_channels
+        self.config = SimpleNamespace(num_attention_heads=H, attention_head_dim=hd, in_channels=in_channels, out_channels=out_channels, num_layers=num_layers,
+                                      cross_attention_dim=D, sample_size=sample_size, patch_size=patch_size, caption_channels=caption_channels,
+                                      interpolation_scale=interpolation_scale if interpolation_scale is not None else max(sample_size // 64, 1),
+                                      use_additional_conditions=use_additional_conditions, norm_type=norm_type)
+        self.inner_dim, self.H, self.hd, self.out_channels = D, H, hd, out_channels
+        self.use_additional_conditions = use_additional_conditions
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = self.device_
+        self._specs = []
+
+        def alloc(name, shape):
+            t = torch.zeros(*shape, dtype=BF16, device=dev)
+            _attach(self, name, _frozen(t))
+            return t
+
+        self.P = {}
+        for nm, shape in (("pos_embed.proj.weight", (D, in_channels, 2, 2)), ("pos_embed.proj.bias", (D,)),
+                          ("adaln_single.emb.timestep_embedder.linear_1.weight", (D, 256)), ("adaln_single.emb.timestep_embedder.linear_1.bias", (D,)),
+                          ("adaln_single.emb.timestep_embedder.linear_2.weight", (D, D)), ("adaln_single.emb.timestep_embedder.linear_2.bias", (D,)),
+                          ("adaln_single.linear.weight", (6 * D, D)), ("adaln_single.linear.bias", (6 * D,)),
+                          ("caption_projection.linear_1.weight", (D, caption_channels)), ("caption_projection.linear_1.bias", (D,)),
+                          ("caption_projection.linear_2.weight", (D, D)), ("caption_projection.linear_2.bias", (D,)),
+                          ("scale_shift_table", (2, D)), ("proj_out.weight", (4 * out_channels, D)), ("proj_out.bias", (4 * out_channels,))):
+            self.P[nm] = alloc(nm, shape)
+        if use_additional_conditions:
+            sd_ = D // 3
+            for e in ("resolution_embedder", "aspect_ratio_embedder"):
+                for nm, shape in ((f"adaln_single.emb.{e}.linear_1.weight", (sd_, 256)), (f"adaln_single.emb.{e}.linear_1.bias", (sd_,)),
+                                  (f"adaln_single.emb.{e}.linear_2.weight", (sd_, sd_)), (f"adaln_single.emb.{e}.linear_2.bias", (sd_,))):
+                    self.P[nm] = alloc(nm, shape)
+        self.blocks: List[_Block] = [_Block(self, f"transformer_blocks.{i}.", D, H, hd, D, alloc, trainable=False) for i in range(num_layers)]
+        self._prepared = False
+        self._cache: Dict = {}
+
+    # ---- weights ----
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 42):
+        g = torch.Generator(device=self.device_).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("scale_shift_table"):
+                p.data.copy_(torch.randn(p.shape, generator=g, device=self.device_) / math.sqrt(self.inner_dim))
+            elif name.endswith(".bias"):
+                p.data.copy_(0.02 * torch.randn(p.shape, generator=g, device=self.device_))
+            else:
+                p.data.copy_(torch.randn(p.shape, generator=g, device=self.device_) / math.sqrt(p[0].numel()))
+        self._prepared = False
+
+    @torch.no_grad()
+    def load_flat_state(self, state: Dict[str, torch.Tensor]):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state]
+        if missing:
+            raise KeyError(f"missing weights: {missing[:5]} ... ({len(missing)})")
+        for k, v in state.items():
+            if k in own:
+                own[k].data.copy_(v.to(device=own[k].device, dtype=own[k].dtype))
+        self._prepared = False
+
+    @torch.no_grad()
+    def prepare(self):
+        for b in self.blocks:
+            b.refresh(self.device_)
+        P = self.P
+        self.patch_w = P["pos_embed.proj.weight"].reshape(self.inner_dim, -1)
+        K = self.patch_w.shape[1]
+        if K % 64:                                                   # 4 latent channels * 4 = 16 -> K granule 64
+            w = torch.zeros(self.inner_dim, 64, dtype=BF16, device=self.device_); w[:, :K] = self.patch_w; self.patch_w = w
+        n_out = P["proj_out.weight"].shape[0]
+        self.proj_out_wT = torch.zeros(self.inner_dim, (n_out + 63) // 64 * 64, dtype=BF16, device=self.device_)
+        self.proj_out_wT[:, :n_out] = P["proj_out.weight"].t()
+        self._prepared = True
+
+    # ---- shared pieces ----
+    def _pos(self, h, w, B):
+        key = (h, w, B)
+        hit = self._cache.get(key)
+        if hit is None:
+            c = self.config
+            pos = sincos_2d_hw(self.inner_dim, h, w, c.sample_size // c.patch_size, c.interpolation_scale).to(self.device_, BF16)
+            hit = self._cache[key] = pos[None].expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
+        return hit
+
+    def _patch_embed(self, x):
+        B, C, Hh, Ww = x.shape
+        pt = ops.patchify(x.to(BF16).contiguous(), order=0).view(B * (Hh // 2) * (Ww // 2), 4 * C)
+        if pt.shape[1] != self.patch_w.shape[1]:
+            pp = torch.zeros(pt.shape[0], self.patch_w.shape[1], dtype=BF16, device=pt.device); pp[:, :pt.shape[1]] = pt; pt = pp
+        return ops.gemm(pt, self.patch_w, bias=self.P["pos_embed.proj.bias"], epilogue=EPI_ADD, aux_in=self._pos(Hh // 2, Ww // 2, B))
+
+    def _mlp(self, x, prefix):
+        P = self.P
+        return ops.gemm(ops.silu(ops.gemm(x, P[prefix + ".linear_1.weight"], bias=P[prefix + ".linear_1.bias"])), P[prefix + ".linear_2.weight"],
+                        bias=P[prefix + ".linear_2.bias"])
+
+    def _conditioning(self, timestep, added_cond_kwargs, B, Hh, Ww):
+        """AdaLayerNormSingle: (t6 [B,6D], emb [B,D])"""
+        dev = self.device_
+        t32 = timestep.to(device=dev, dtype=F32).reshape(-1).expand(B).contiguous()
+        emb = self._mlp(ops.timestep_proj(t32, 256, 1.0), "adaln_single.emb.timestep_embedder")
+        if self.use_additional_conditions:
+            ack = added_cond_kwargs or {}
+            res = ack.get("resolution")
+            ar = ack.get("aspect_ratio")
+            if res is None:
+                res = torch.tensor([[Hh, Ww]], device=dev, dtype=F32).expand(B, -1)
+            if ar is None:
+                ar = torch.tensor([[float(Hh / Ww)]], device=dev, dtype=F32).expand(B, -1)
+            r = self._mlp(ops.timestep_proj(res.to(device=dev, dtype=F32).reshape(-1).contiguous(), 256, 1.0), "adaln_single.emb.resolution_embedder").reshape(B, -1)
+            a = self._mlp(ops.timestep_proj(ar.to(device=dev, dtype=F32).reshape(-1).contiguous(), 256, 1.0), "adaln_single.emb.aspect_ratio_embedder").reshape(B, -1)
+            emb = ops.add(emb, torch.cat([r, a], dim=1).contiguous())
+        t6 = ops.gemm(ops.silu(emb), self.P["adaln_single.linear.weight"], bias=self.P["adaln_single.linear.bias"])
+        return t6, emb
+
+    def _caption(self, enc):
+        B, Sk, _ = enc.shape
+        P = self.P
+        e = ops.gemm(enc.to(BF16).reshape(B * Sk, -1).contiguous(), P["caption_projection.linear_1.weight"], bias=P["caption_projection.linear_1.bias"],
+                     epilogue=EPI_GELU)
+        return ops.gemm(e, P["caption_projection.linear_2.weight"], bias=P["caption_projection.linear_2.bias"])
+
+    # ---- one block: forward (optionally saving) and backward ----
+    def _block_fwd(self, blk: _Block, h, ctx2d, kbias, t6, B, S, Sk, save: bool):
+        D, H, W = self.inner_dim, self.H, blk.W
+        Dp = H * HP
+        scale = 1.0 / math.sqrt(self.hd)
+        mod = (blk.P["scale_shift_table"].view(1, 6 * D) + t6).contiguous()             # [B, 6D] (tiny)
+        m = [mod[:, k * D:(k + 1) * D] for k in range(6)]                               # shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        train = save and blk.trainable
+        n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
+        qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
+        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S)
+        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S)
+        _, Vt, _ = ops.head_split(qkv[:, 2 * Dp:], B, H, HP, S, want_x=False)
+        O = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
+        lse = torch.empty(B, H, S, dtype=F32, device=h.device)
+        ops.attn_fwd(Q, K, Vt, O, lse, B, H, S, Sp, HP, scale)
+        ya = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
+        h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=S, aux_out=ya)
+        q2 = ops.gemm(h1, W.q2_w, bias=W.q2_b)
+        kv = ops.gemm(ctx2d, W.kv2_w, bias=W.kv2_b)
+        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S)
+        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk)
+        _, V2t, _ = ops.head_split(kv[:, Dp:], B, H, HP, Sk, want_x=False)
+        O2 = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
+        lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)
+        ops.attn_cross_fwd(Q2, K2, V2t, O2, lse2, B, H, S, Sk, Skp, HP, scale, key_bias=kbias)
+        h2 = ops.gemm(O2, W.out2_w, bias=W.out2_b, epilogue=EPI_ADD, aux_in=h1)
+        n2 = ops.ln_modulate_fwd(h2, m[4], m[3], S)
+        pre = torch.empty(B * S, 4 * D, dtype=BF16, device=h.device) if save else None
+        a = ops.gemm(n2, W.ff1_w, bias=W.ff1_b, epilogue=EPI_GELU, aux_out=pre)
+        yf = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
+        h3 = ops.gemm(a, W.ff2_w, bias=W.ff2_b, epilogue=EPI_GATE_RESIDUAL, gate=m[5], aux_in=h2, rows_per_batch=S, aux_out=yf)
+        sv = None
+        if save:
+            sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
+                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
+        return h3, sv
+
+    def _block_bwd(self, blk: _Block, sv, d3, ctx2d, kbias, B, S, Sk):
+        """d3 = dL/d(block output) -> dL/d(block input); fills blk.G for trainable blocks"""
+        D, H, W = self.inner_dim, self.H, blk.W
+        Dp = H * HP
+        scale = 1.0 / math.sqrt(self.hd)
+        m = sv.m
+        tr = blk.trainable
+        dmod = torch.zeros(B, 6 * D, dtype=F32, device=d3.device) if tr else None
+
+        def wgrad(name, dy, x, unpad):
+            if not tr:
+                return
+            gw = ops.gemm_tn(_p64(dy), _p64(x))
+            tb = torch.empty(1, dy.shape[1], dtype=F32, device=dy.device)
+            ops.colsum_prod(dy, tb)
+            unpad(gw, tb[0])
+
+        def unpad_rows(names):                       # padded output rows -> the true [D, K] gradients of the listed projections
+            def f(gw, gb):
+                K = gw.shape[1]
+                g4, b3 = gw.view(len(names), H, HP, K), gb.view(len(names), H, HP)
+                for j, nm in enumerate(names):
+                    blk.G[nm + ".weight"].view(H, self.hd, K).copy_(g4[j, :, :self.hd])
+                    blk.G[nm + ".bias"].view(H, self.hd).copy_(b3[j, :, :self.hd])
+            return f
+
+        def unpad_cols(nm):                          # padded input columns -> true [N, D]
+            def f(gw, gb):
+                blk.G[nm + ".weight"].view(gw.shape[0], H, self.hd).copy_(gw.view(gw.shape[0], H, HP)[:, :, :self.hd])
+                blk.G[nm + ".bias"].copy_(gb)
+            return f
+
+        def plain(nm):
+            def f(gw, gb):
+                blk.G[nm + ".weight"].copy_(gw); blk.G[nm + ".bias"].copy_(gb)
+            return f
+
+        def mod_grads(dn, n_saved, k_shift, k_scale):
+            if not tr:
+                return
+            dsh = dmod[:, k_shift * D:(k_shift + 1) * D]
+            ops.colsum_prod(dn, dsh, rows_per_batch=S)
+            ops.colsum_prod(dn, dmod[:, k_scale * D:(k_scale + 1) * D], b=n_saved, rows_per_batch=S, mode=1, prev=dsh, shift=m[k_shift], scale=m[k_scale])
+
+        # ---- feed-forward ----
+        dyf = ops.scale_cols(d3, m[5], S)
+        if tr:
+            ops.colsum_prod(d3, dmod[:, 5 * D:6 * D], b=sv.yf, rows_per_batch=S)
+        wgrad("ff2", dyf, sv.a, plain("ff.net.2"))
+        dpre = ops.gemm(dyf, W.ff2_wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.pre)
+        wgrad("ff1", dpre, sv.n2, plain("ff.net.0.proj"))
+        dn2 = ops.gemm(dpre, W.ff1_wT)
+        mod_grads(dn2, sv.n2, 3, 4)
+        d2, _ = ops.ln_modulate_bwd(dn2, sv.h2, m[4], S, dres=d3)
+        # ---- cross-attention (no pre-norm, no gate) ----
+        wgrad("out2", d2, sv.O2, unpad_cols("attn2.to_out.0"))
+        dO2 = ops.gemm(d2, W.out2_wT)
+        dq2 = torch.empty_like(sv.q2)
+        dkv = torch.empty_like(sv.kv)
+        dQ, dK = torch.empty_like(sv.Q2), torch.empty_like(sv.K2)
+        ops.attn_cross_bwd(sv.Q2, sv.K2, sv.Q2t, sv.K2t, sv.kv[:, Dp:], sv.O2, dO2, sv.lse2, dQ, dK, dkv[:, Dp:], B, H, S, sv.Sp, Sk, sv.Skp, HP, scale, key_bias=kbias)
+        ops.head_merge(dQ, dq2, B, H, HP, S)
+        ops.head_merge(dK, dkv[:, :Dp], B, H, HP, Sk)
+        wgrad("q2", dq2, sv.h1, unpad_rows(["attn2.to_q"]))
+        wgrad("kv2", dkv, ctx2d, unpad_rows(["attn2.to_k", "attn2.to_v"]))
+        d1 = ops.gemm(dq2, W.q2_wT, epilogue=EPI_ADD, aux_in=d2)
+        # ---- self-attention ----
+        dya = ops.scale_cols(d1, m[2], S)
+        if tr:
+            ops.colsum_prod(d1, dmod[:, 2 * D:3 * D], b=sv.ya, rows_per_batch=S)
+        wgrad("out1", dya, sv.O, unpad_cols("attn1.to_out.0"))
+        dO = ops.gemm(dya, W.out1_wT)
+        dqkv = torch.empty_like(sv.qkv)
+        dQ, dK = torch.empty_like(sv.Q), torch.empty_like(sv.K)
+        ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * Dp:], sv.O, dO, sv.lse, dQ, dK, dqkv[:, 2 * Dp:], B, H, S, sv.Sp, HP, scale)
+        ops.head_merge(dQ, dqkv[:, :Dp], B, H, HP, S)
+        ops.head_merge(dK, dqkv[:, Dp:2 * Dp], B, H, HP, S)
+        wgrad("qkv", dqkv, sv.n1, unpad_rows(["attn1.to_q", "attn1.to_k", "attn1.to_v"]))
+        dn1 = ops.gemm(dqkv, W.qkv_wT)
+        mod_grads(dn1, sv.n1, 0, 1)
+        d0, _ = ops.ln_modulate_bwd(dn1, sv.h, m[1], S, dres=d1)
+        if tr:
+            blk.G["scale_shift_table"].copy_(dmod.sum(0).view(6, D))
+        return d0
+
+    def _head(self, h, emb, B, hh, ww):
+        D = self.inner_dim
+        mod = (self.P["scale_shift_table"].view(1, 2 * D) + torch.cat([emb, emb], dim=1)).contiguous()      # (shift, scale)
+        n = ops.ln_modulate_fwd(h, mod[:, D:], mod[:, :D], hh * ww)
+        pk = ops.gemm(n, self.P["proj_out.weight"], bias=self.P["proj_out.bias"])
+        out = ops.unpatchify(pk.view(B, hh * ww, -1), self.out_channels, 2 * hh, 2 * ww, order=1)
+        return out, mod
+
+    def _head_bwd(self, dout, h_final, mod, B, hh, ww):
+        D = self.inner_dim
+        dpk = ops.patchify(dout.to(BF16).contiguous(), order=1).view(B * hh * ww, -1)
+        dp = torch.zeros(dpk.shape[0], self.proj_out_wT.shape[1], dtype=BF16, device=dpk.device)
+        dp[:, :dpk.shape[1]] = dpk
+        dn = ops.gemm(dp, self.proj_out_wT)
+        dh, _ = ops.ln_modulate_bwd(dn, h_final, mod[:, D:], hh * ww)
+        return dh
+
+    @staticmethod
+    def _key_bias(mask, B, Sk, dev):
+        if mask is None:
+            return None
+        return ((1.0 - mask.to(device=dev, dtype=F32).reshape(B, Sk)) * -10000.0).contiguous()        # pixart/transformer.py:566-568
+
+    @torch.no_grad()
+    def _forward_trunk(self, latents, enc, mask, timestep, added_cond_kwargs):
+        if not self._prepared:
+            self.prepare()
+        B, _, Hh, Ww = latents.shape
+        hh, ww = Hh // 2, Ww // 2
+        S, Sk = hh * ww, enc.shape[1]
+        h = self._patch_embed(latents)
+        t6, emb = self._conditioning(timestep, added_cond_kwargs, B, Hh, Ww)
+        ctx2d = self._caption(enc)
+        kb = self._key_bias(mask, B, Sk, self.device_)
+        for blk in self.blocks:
+            h, _ = self._block_fwd(blk, h, ctx2d, kb, t6, B, S, Sk, save=False)
+        out, _ = self._head(h, emb, B, hh, ww)
+        return out
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None, cross_attention_kwargs=None, attention_mask=None,
+                encoder_attention_mask=None, return_dict: bool = True, **unsupported):
+        for k, v in unsupported.items():
+            if v is not None and v is not False:
+                raise NotImplementedError(f"PixArtTransformer2DModel(st355): argument {k!r} is not supported on the HIP path")
+        if attention_mask is not None or cross_attention_kwargs:
+            raise NotImplementedError("PixArt(st355): self-attention masks / cross_attention_kwargs are not supported")
+        out = self._forward_trunk(hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs)
+        return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+
+class PixArtSigmaControlNetTransformerModel(nn.Module):
+    """trunk (frozen) + ControlNet adapter (trainable): pixart/controlnet.py:166-326.  `num_layers` copied blocks; `from_transformer` semantics:
+    the adapter blocks start as copies of trunk blocks 0..N-1, before/after projections start at zero."""
+
+    def __init__(self, transformer: PixArtTransformer2DModel, num_layers: int = 13, init_from_transformer: bool = True):
+        super().__init__()
+        self.transformer = transformer
+        self.blocks_num = num_layers
+        self.config = transformer.config
+        T = transformer
+        D, dev = T.inner_dim, T.device_
+        specs = []
+
+        def alloc(name, shape):
+            s = SimpleNamespace(name=name, shape=shape, numel=int(torch.tensor(shape).prod()))
+            specs.append(s)
+            return s
+
+        self._cblocks_specs = []
+        shells = []
+        for i in range(num_layers):
+            p = f"controlnet.controlnet_blocks.{i}."
+            extra = {}
+            if i == 0:
+                extra["before_proj.weight"], extra["before_proj.bias"] = alloc(p + "before_proj.weight", (D, D)), alloc(p + "before_proj.bias", (D,))
+            blk = _Block(self, p + "transformer_block.", D, T.H, T.hd, D, alloc, trainable=True)
+            extra["after_proj.weight"], extra["after_proj.bias"] = alloc(p + "after_proj.weight", (D, D)), alloc(p + "after_proj.bias", (D,))
+            shells.append((blk, extra))
+        total = 0
+        for s in specs:
+            s.off = total
+            total += (s.numel + 7) // 8 * 8
+        self.arena = torch.zeros(total, dtype=BF16, device=dev)
+        self.grad_arena = torch.zeros(total, dtype=BF16, device=dev)
+        params = []
+        for s in specs:
+            s.t = self.arena[s.off:s.off + s.numel].view(*s.shape)
+            s.g = self.grad_arena[s.off:s.off + s.numel].view(*s.shape)
+            par = nn.Parameter(s.t, requires_grad=True)
+            _attach(self, s.name, par)
+            params.append(par)
+        self._params = params
+        self._offsets = [(s.off, s.numel) for s in specs]
+        self.cblocks = []
+        for blk, extra in shells:
+            blk.G = {k: v.g for k, v in blk.P.items()}
+            blk.P = {k: v.t for k, v in blk.P.items()}
+            ex = SimpleNamespace(**{k.replace(".", "_"): v.t for k, v in extra.items()})
+            ex.G = {k: v.g for k, v in extra.items()}
+            self.cblocks.append((blk, ex))
+        if init_from_transformer:
+            with torch.no_grad():
+                for i, (blk, _) in enumerate(self.cblocks):
+                    for k, v in blk.P.items():
+                        v.copy_(T.blocks[i].P[k])
+        self.full = True
+        self.grad_sync = None
+        self._last_grad_flat = None
+
+    def trainable_parameters(self):
+        return list(self._params)
+
+    @torch.no_grad()
+    def init_adapter_synthetic(self, seed: int = 7, std: float = 0.02):
+        """non-zero before/after projections (true zero-init would give zero gradients everywhere but after_proj on the first step)"""
+        g = torch.Generator(device=self.transformer.device_).manual_seed(seed)
+        for _, ex in self.cblocks:
+            for k in vars(ex):
+                if k.endswith("proj_weight"):
+                    getattr(ex, k).copy_(torch.randn(getattr(ex, k).shape, generator=g, device=self.transformer.device_) * std)
+
+    def adapter_state_dict(self) -> Dict[str, torch.Tensor]:
+        """adapter weights under the reference's names (`controlnet_blocks.{i}.before_proj|transformer_block.*|after_proj`)"""
+        sd = {}
+        for i, (blk, ex) in enumerate(self.cblocks):
+            p = f"controlnet_blocks.{i}."
+            for k, v in blk.P.items():
+                sd[p + "transformer_block." + k] = v.detach().clone()
+            for k in ("before_proj", "after_proj"):
+                if hasattr(ex, k + "_weight"):
+                    sd[p + k + ".weight"], sd[p + k + ".bias"] = getattr(ex, k + "_weight").detach().clone(), getattr(ex, k + "_bias").detach().clone()
+        return sd
+
+    def _engine_forward(self, latents, cond, enc, mask, timestep, added_cond_kwargs, save: bool):
+        T = self.transformer
+        if not T._prepared:
+            T.prepare()
+        dev = T.device_
+        B, _, Hh, Ww = latents.shape
+        hh, ww = Hh // 2, Ww // 2
+        S, Sk = hh * ww, enc.shape[1]
+        for blk, _ in self.cblocks:
+            blk.refresh(dev)                                   # the adapter's padded working copies follow its parameters
+        h = T._patch_embed(latents)
+        cs = T._patch_embed(cond)
+        t6, emb = T._conditioning(timestep, added_cond_kwargs, B, Hh, Ww)
+        ctx2d = T._caption(enc)
+        kb = T._key_bias(mask, B, Sk, dev)
+        ctx = SimpleNamespace(B=B, S=S, Sk=Sk, hh=hh, ww=ww, ctx2d=ctx2d, kb=kb, trunk=[], ctrl=[], cs_in=[], cs0=cs)
+        for i, tb in enumerate(T.blocks):
+            if 0 < i <= self.blocks_num:
+                blk, ex = self.cblocks[i - 1]
+                if i == 1:
+                    cs = ops.gemm(cs, ex.before_proj_weight, bias=ex.before_proj_bias, epilogue=EPI_ADD, aux_in=h)
+                cs, svc = T._block_fwd(blk, cs, ctx2d, kb, t6, B, S, Sk, save)
+                h = ops.gemm(cs, ex.after_proj_weight, bias=ex.after_proj_bias, epilogue=EPI_ADD, aux_in=h)
+                if save:
+                    ctx.ctrl.append(svc); ctx.cs_in.append(cs)
+            h, sv = T._block_fwd(tb, h, ctx2d, kb, t6, B, S, Sk, save and i >= 1)
+            if save:
+                ctx.trunk.append(sv)
+        out, mod_out = T._head(h, emb, B, hh, ww)
+        if save:
+            ctx.h_final, ctx.mod_out = h, mod_out
+        return out, ctx
+
+    def _engine_backward(self, ctx, dout):
+        T = self.transformer
+        B, S, Sk = ctx.B, ctx.S, ctx.Sk
+        dh = T._head_bwd(dout, ctx.h_final, ctx.mod_out, B, ctx.hh, ctx.ww)
+        dcs = None
+        for i in range(len(T.blocks) - 1, 0, -1):                  # trunk block 0 has nothing trainable upstream of it
+            dh = T._block_bwd(T.blocks[i], ctx.trunk[i], dh, ctx.ctx2d, ctx.kb, B, S, Sk)
+            ctx.trunk[i] = None
+            if i <= self.blocks_num:
+                blk, ex = self.cblocks[i - 1]
+                cs_out = ctx.cs_in[i - 1]
+                # h' = h + after_proj(cs_out):  d after_proj, d cs_out (+ what the next control block sent back)
+                ops.gemm_tn(_p64(dh), _p64(cs_out), out=ex.G["after_proj.weight"])
+                tb = torch.empty(1, dh.shape[1], dtype=F32, device=dh.device)
+                ops.colsum_prod(dh, tb); ex.G["after_proj.bias"].copy_(tb[0])
+                wT = ex.after_proj_weight.t().contiguous()
+                dcs = ops.gemm(dh, wT) if dcs is None else ops.gemm(dh, wT, epilogue=EPI_ADD, aux_in=dcs)
+                dcs = T._block_bwd(blk, ctx.ctrl[i - 1], dcs, ctx.ctx2d, ctx.kb, B, S, Sk)
+                ctx.ctrl[i - 1] = None
+                if i == 1:                                         # cs_in = h + before_proj(cs0): h gets dcs too (unused: nothing trainable before it)
+                    ops.gemm_tn(_p64(dcs), _p64(ctx.cs0), out=ex.G["before_proj.weight"])
+                    ops.colsum_prod(dcs, tb); ex.G["before_proj.bias"].copy_(tb[0])
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, controlnet_cond=None, added_cond_kwargs=None, cross_attention_kwargs=None,
+                attention_mask=None, encoder_attention_mask=None, return_dict: bool = True):
+        if attention_mask is not None or cross_attention_kwargs:
+            raise NotImplementedError("PixArt ControlNet(st355): self-attention masks / cross_attention_kwargs are not supported")
+        if controlnet_cond is None:
+            out = self.transformer._forward_trunk(hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs)
+        elif torch.is_grad_enabled():
+            out = _CtrlFn.apply(self, hidden_states, controlnet_cond, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs, *self._params)
+        else:
+            with torch.no_grad():
+                out, _ = self._engine_forward(hidden_states, controlnet_cond, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs, False)
+        return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+
+class _CtrlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, model, latents, cond, enc, mask, timestep, ack, *params):
+        out, ctx = model._engine_forward(latents.detach(), cond.detach(), enc.detach(), None if mask is None else mask.detach(), timestep.detach(), ack, True)
+        fctx.model, fctx.ectx = model, ctx
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
+        model._engine_backward(fctx.ectx, dout)
+        fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_sync.ready(0, model.grad_arena.numel())
+            model.grad_scale_from_sync = model.grad_sync.finish()
+        gflat = model.grad_arena.clone()
+        model._last_grad_flat = gflat
+        grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._offsets, model._params)]
+        return (None,) * 7 + tuple(grads)
