@@ -55,8 +55,9 @@ def hbm_traffic_per_gemm_launch():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "vae"],
+    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "pixart", "vae"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
+    ap.add_argument("--lora", action="store_true", help="sdxl only: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA)")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
                     "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
     ap.add_argument("--full", action="store_true", help="sd3 only: full fine-tune (every parameter trains, bf16 AdamW arena) + EMA — BASELINE configs[3]")
@@ -209,15 +210,36 @@ def main():
         # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4 (always the full fine-tune)
         from simpletuner_amd.sdxl.model import SDXL
         from oracle.unet import UNetConfig, unet_flops_fwd     # FLOP counter only (test infrastructure; nothing of the oracle is executed in the step)
-        args.full = True
-        cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
+        sdxl_lora = bool(args.lora)
+        args.full = not sdxl_lora
+        cfg.model_type, cfg.use_ema, cfg.learning_rate = ("lora" if sdxl_lora else "full"), False, (1e-4 if sdxl_lora else 1e-5)
         plugin = SDXL(cfg, acc)
         plugin.load_model()
         S_txt, txt_dim, pooled_dim = 77, 2048, 1280
         n_blocks, D_model = 0, 0
         sdxl_fwd_flops = unet_flops_fwd(UNetConfig(), args.res // 8, args.res // 8, 77)
-        desc = (f"SDXL UNet2DConditionModel (320/640/1280 ch, 2/10-layer transformers at 64^2/32^2, 2.6 B params) FULL fine-tune bf16, "
+        desc = (f"SDXL UNet2DConditionModel (320/640/1280 ch, 2/10-layer transformers at 64^2/32^2, 2.6 B params) "
+                f"{f'LoRA r{args.rank} on attn1/attn2 to_q/to_k/to_v/to_out.0' if sdxl_lora else 'FULL fine-tune bf16'}, "
                 f"{args.res}^2 ({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
+    elif args.model == "pixart":
+        # BASELINE.json configs[4]: PixArt-Sigma DiT, ControlNet branch (13 copied blocks) trained, 2K latents (256^2 x 4), T5 ctx 300 with mask
+        from simpletuner_amd.pixart.model import PixartSigma
+        from oracle.pixart import PixArtConfig, pixart_flops_fwd       # FLOP counter only
+        cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
+        plugin = PixartSigma(cfg, acc)
+        plugin.load_model(sample_size=256 if args.res >= 2048 else 128)
+        plugin.controlnet_init(num_layers=13, synthetic_adapter=True)
+        S_txt, txt_dim, pooled_dim = 300, 4096, 0
+        n_blocks, D_model = 0, 0
+        lat_ = args.res // 8
+        pc = PixArtConfig(sample_size=256 if args.res >= 2048 else 128)
+        f_trunk = pixart_flops_fwd(pc, lat_, lat_, 300, 0)
+        f_blk = f_trunk / 28.0
+        # trunk: forward (28) + input gradients through blocks 1..27 (2x forward each: attention bwd = 2x fwd, linears dgrad = 1x -> ~1.7x; counted 1x
+        # for the linears and 2x for attention is folded into 2x here);  adapter (13): forward + dgrad + wgrad = 3x
+        pix_step_flops = f_trunk + 2.0 * 27 * f_blk + 3.0 * 13 * f_blk
+        desc = (f"PixArt-Sigma XL/2 (28 blocks, 16x72 heads, D=1152) ControlNet-Transformer branch (13 copied blocks + zero-init projections) trained, trunk "
+                f"frozen, {args.res}^2 ({lat_}^2 latents, S={(lat_ // 2) ** 2}), T5 ctx 300 (120 valid), epsilon objective, AdamW, random-init weights")
     else:
         from simpletuner_amd.sd3.model import SD3
         plugin = SD3(cfg, acc)
@@ -227,12 +249,14 @@ def main():
         n_blocks, D_model, S_txt, txt_dim, pooled_dim = n_l, 1536, 231, 4096, 2048
         desc = (f"SD3-Medium MMDiT ({n_l} joint blocks, D=1536, 24x64 heads) LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0, "
                 f"{args.res}^2 (S=4096+231), AdamW, random-init weights")
-    if args.full:
+    if args.model == "pixart":
+        pass
+    elif args.full:
         if args.model not in ("sd3", "sdxl"):
             raise SystemExit("--full is wired for --model sd3 / sdxl only")
         plugin.enable_full_finetune()
         desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", "FULL fine-tune (2.0 B bf16 params) + EMA")
-    else:
+    elif args.model != "pixart":
         plugin.add_lora_adapter()
     trainer = Trainer(cfg, plugin, acc)
 
@@ -243,12 +267,17 @@ def main():
     def make_batch(hh=None, ww=None):
         hh, ww = hh or lat, ww or lat
         b = {
-            "latent_batch": torch.randn(B, 4 if args.model == "sdxl" else 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
+            "latent_batch": torch.randn(B, 4 if args.model in ("sdxl", "pixart") else 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
             "prompt_embeds": torch.randn(B, S_txt, txt_dim, device=dev, generator=gen).to(torch.bfloat16),
-            "add_text_embeds": torch.randn(B, pooled_dim, device=dev, generator=gen).to(torch.bfloat16),
+            "add_text_embeds": torch.randn(B, max(pooled_dim, 8), device=dev, generator=gen).to(torch.bfloat16),
         }
         if args.model == "sdxl":       # time_ids [B,6] = (1024,1024,0,0,1024,1024)
             b["batch_time_ids"] = torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * B, device=dev, dtype=torch.bfloat16)
+        if args.model == "pixart":     # ctx [B,300,4096] with mask (first 120 valid), conditioning_latents of the latent shape
+            del b["add_text_embeds"]
+            m_ = torch.zeros(B, S_txt, device=dev, dtype=torch.bfloat16); m_[:, :120] = 1
+            b["encoder_attention_mask"] = m_
+            b["conditioning_latents"] = torch.randn(B, 4, hh, ww, device=dev, generator=gen).to(torch.bfloat16)
         return b
     if args.buckets:
         if args.model != "sd3":
@@ -309,7 +338,11 @@ def main():
     if rank == 0:
         S_img = (lat // 2) ** 2
         step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
-        if args.model == "sdxl":   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
+        if args.model == "pixart":
+            step_flops = pix_step_flops * B
+        elif args.model == "sdxl" and not args.full:   # LoRA: forward + input gradients (no base weight gradients): 2x forward, attention bwd 2x
+            step_flops = 2.0 * sdxl_fwd_flops * B
+        elif args.model == "sdxl":   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
             step_flops = 3.0 * sdxl_fwd_flops * B
         elif args.full:      # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
             step_flops = 3.0 * (n_blocks * 2.0 * (S_img + S_txt) * 12 * D_model * D_model + n_blocks * 4.0 * (S_img + S_txt) ** 2 * D_model) * B
@@ -334,8 +367,8 @@ def main():
                            "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
                        for k, v in prof.items() if v["launches"]}
         out = {
-            "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL')[args.model]} "
-                      f"{'full fine-tune + EMA' if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
+            "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL', pixart='PixArt-Sigma')[args.model]} "
+                      f"{'ControlNet branch' if args.model == 'pixart' else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

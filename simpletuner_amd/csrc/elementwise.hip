@@ -3,6 +3,17 @@
 // All are bandwidth-bound: 16-byte vector accesses, grid-stride loops, no LDS staging.
 #include "common.h"
 
+// zero-fill as a KERNEL (not hipMemsetAsync): memset nodes inside a captured hipGraph were observed to misbehave on replay (ROCm 7.2), and the
+// trainer replays the whole predict + loss + backward as one graph
+static __global__ void k_zero_words(uint32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline void zero_words(void* stream, void* p, int n_words) {
+  hipLaunchKernelGGL(k_zero_words, dim3((n_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint32_t*)p, n_words);
+}
+
+
 #define EW_THREADS 256
 static inline int ew_blocks(int64_t work_items) {
   int64_t b = cdiv64(work_items, EW_THREADS);
@@ -165,7 +176,7 @@ extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target
   ST_REQUIRE(pred && target && loss_out && per_sample_out, "mse_loss: null pointer (per_sample_out is required scratch)");
   ST_REQUIRE(per_sample % 8 == 0 && batch > 0 && batch < 65536, "mse_loss: bad shape");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 3.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
-  hipMemsetAsync(per_sample_out, 0, sizeof(float) * batch, (hipStream_t)stream);
+  zero_words(stream, per_sample_out, (int)batch);
   int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
   if (bx > 512) bx = 512;
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
@@ -223,7 +234,7 @@ extern "C" int st355_cond_loss(void* stream, const void* pred, const void* targe
   ST_REQUIRE(pred && target && loss_out && per_sample_out && huber_c, "cond_loss: null pointer");
   ST_REQUIRE((loss_type == 1 || loss_type == 2) && per_sample % 8 == 0 && batch > 0 && batch < 65536, "cond_loss: bad args");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 6.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
-  hipMemsetAsync(per_sample_out, 0, sizeof(float) * batch, (hipStream_t)stream);
+  zero_words(stream, per_sample_out, (int)batch);
   int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
   if (bx > 512) bx = 512;
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);

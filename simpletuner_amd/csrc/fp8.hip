@@ -5,6 +5,17 @@
 // The quantisers are HBM-streaming passes; the contraction is k_gemm_pq<EPI, false, /*F8=*/true> in gemm.hip (v_mfma_f32_32x32x16_fp8_bf8).
 #include "common.h"
 
+// zero-fill as a KERNEL (not hipMemsetAsync): memset nodes inside a captured hipGraph were observed to misbehave on replay (ROCm 7.2), and the
+// trainer replays the whole predict + loss + backward as one graph
+static __global__ void k_zero_words(uint32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline void zero_words(void* stream, void* p, int n_words) {
+  hipLaunchKernelGGL(k_zero_words, dim3((n_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint32_t*)p, n_words);
+}
+
+
 // fp32 -> e4m3fn / e5m2 bytes (gfx950 = OCP formats; v_cvt_pk_* round to nearest even and saturate to the finite maximum)
 __device__ __forceinline__ uint8_t to_e4m3(float v) { return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0u, false) & 0xFFu); }
 // e5m2: the hardware v_cvt_pk_bf8_f32 by default; -DST355_FP8_SOFT_CVT keeps an integer round-to-nearest-even restatement (normal range:
@@ -113,7 +124,7 @@ extern "C" int st355_fp8_quantize_weight(void* stream, const void* w, int64_t ld
 extern "C" int st355_fp8_quantize_act(void* stream, const void* x, int64_t ldx, void* q, float* scale_a, int64_t M, int K, void* workspace) {
   ST_REQUIRE(x && q && scale_a && workspace && M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "fp8_quantize_act: bad args");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 4.0 * M * K, 5.0 * M * K);
-  hipMemsetAsync(workspace, 0, 4, (hipStream_t)stream);
+  zero_words(stream, workspace, 1);
   int64_t blocks = cdiv64(M * (K / 8), 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, M, K, (uint32_t*)workspace);

@@ -4,6 +4,17 @@
 #include <math.h>
 #include "common.h"
 
+// zero-fill as a KERNEL (not hipMemsetAsync): memset nodes inside a captured hipGraph were observed to misbehave on replay (ROCm 7.2), and the
+// trainer replays the whole predict + loss + backward as one graph
+static __global__ void k_zero_words(uint32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline void zero_words(void* stream, void* p, int n_words) {
+  hipLaunchKernelGGL(k_zero_words, dim3((n_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint32_t*)p, n_words);
+}
+
+
 #define OP_THREADS 256
 static inline int op_blocks(int64_t items) {
   int64_t b = cdiv64(items, OP_THREADS);
@@ -287,7 +298,7 @@ __global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ 
 extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2) {
   ST_REQUIRE(g && out2 && n > 0 && (elem_bytes == 4 || elem_bytes == 2), "grad_norm: bad args");
   ProfScope ps(stream, ST355_K_OPTIM, 3.0 * n, (double)elem_bytes * n);
-  hipMemsetAsync(out2, 0, 2 * sizeof(float), (hipStream_t)stream);
+  zero_words(stream, out2, 2);
   if (elem_bytes == 4)
     hipLaunchKernelGGL(k_grad_norm<float>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (const float*)g, n, out2);
   else

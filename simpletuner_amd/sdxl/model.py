@@ -4,7 +4,7 @@ Same class attributes and step-path methods as the reference plugin (sdxl/model.
 `prepare_batch` (DDPM epsilon objective: discrete timesteps + `noise_schedule.add_noise`, common.py:5983-6002), `model_predict ->
 {"model_prediction": [B,4,H,W]}` calling the UNet positionally `(noisy_latents, timesteps, encoder_hidden_states, add_text_embeds,
 added_cond_kwargs={"text_embeds","time_ids"}, return_dict=False)[0]`, `loss_with_logs`, `get_trained_component`.  Full fine-tune
-(BASELINE.json configs[1]); LoRA on the UNet is not built yet.
+(BASELINE.json configs[1]) and LoRA on the attention projections (the metric's "SDXL-LoRA").
 """
 from __future__ import annotations
 
@@ -37,7 +37,10 @@ class SDXL(ModelFoundation):
         return self.model
 
     def add_lora_adapter(self):
-        raise NotImplementedError("LoRA adapters on the UNet are not built on the st355 path yet (full fine-tune only)")
+        """peft LoRA on DEFAULT_LORA_TARGET (to_k,to_q,to_v,to_out.0 of every attn1 / attn2): the "SDXL-LoRA" workload of BASELINE.json's metric"""
+        comp = self.unwrap_model(self.model)
+        return comp.add_lora_adapter(rank=int(self.config.lora_rank), alpha=getattr(self.config, "lora_alpha", None),
+                                     seed=int(getattr(self.config, "seed", 42) or 42) + 7, init_b_std=float(getattr(self.config, "lora_init_b_std", 0.0)))
 
     def enable_full_finetune(self):
         return self.unwrap_model(self.model).enable_full_finetune()

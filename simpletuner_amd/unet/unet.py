@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..flux.transformer import _attach, _frozen
+from ..flux.transformer import LoraGroup, _attach, _frozen
 from ..ops import EPI_ADD, EPI_NONE
 
 BF16 = torch.bfloat16
@@ -118,6 +118,9 @@ class UNet2DConditionModel(nn.Module):
         self._last_grad_flat = None
         self._full_params: List[nn.Parameter] = []
         self._tmp: Dict = {}
+        self.lora_groups: List[LoraGroup] = []
+        self.lora_flat = self.lora_grad_flat = None
+        self._lora_params: List[nn.Parameter] = []
 
     # ------------------------------------------------------------------------------------------------
     # construction: parameter slots in arena order + the layer graph
@@ -132,13 +135,13 @@ class UNet2DConditionModel(nn.Module):
 
     def _lin(self, name, out_f, in_f, bias=True):
         return SimpleNamespace(kind="lin", name=name, w=self._slot(name + ".weight", out_f, in_f), b=self._slot(name + ".bias", out_f, kind="b") if bias else None,
-                               wT=None, N=out_f, K=in_f)
+                               wT=None, N=out_f, K=in_f, lora=None)
 
     def _lin_fused(self, prefix, names, out_each, in_f):
         """projections that share an input stored as one matrix; the per-projection diffusers keys are row-slices (registered as views later)"""
         views = [(f"{prefix}{nm}.weight", j * out_each, (j + 1) * out_each) for j, nm in enumerate(names)]
         l = SimpleNamespace(kind="lin", name=prefix + "+".join(names), w=self._slot(prefix + "+".join(names) + ".weight", len(names) * out_each, in_f, views=views),
-                            b=None, wT=None, N=len(names) * out_each, K=in_f, fused=(prefix, names, out_each))
+                            b=None, wT=None, N=len(names) * out_each, K=in_f, fused=(prefix, names, out_each), lora=None)
         return l
 
     def _conv(self, name, cin, cout, taps=9, cout_pad=None, cin_cols=None):
@@ -347,8 +350,14 @@ class UNet2DConditionModel(nn.Module):
         self._full_params = ps
         base = self.arena.data_ptr()
         self._full_offsets = [((p.data_ptr() - base) // 2, p.numel()) for p in ps]
+        self._alloc_transposed()
+        return ps
+
+    def _alloc_transposed(self):
         dev = self.device_
         for l in self._all_layers():
+            if l.wT is not None:
+                continue
             if l.kind == "conv" and l is not self.l_conv_in:
                 if l.taps == 9 and l is not self.l_conv_out and not self._is_down(l):
                     l.wT = torch.empty(l.cin, 9 * l.cout, dtype=BF16, device=dev)          # flipped taps, transposed: the dgrad conv's weight
@@ -358,13 +367,69 @@ class UNet2DConditionModel(nn.Module):
                     l.wT = torch.empty(l.w.shape[1], l.cout, dtype=BF16, device=dev)       # plain transpose (1x1 shortcut, stride-2 columns)
             elif l.kind == "lin":
                 l.wT = torch.empty(l.K, l.N, dtype=BF16, device=dev)
-        return ps
+
+    # ------------------------------------------------------------------------------------------------
+    # LoRA (peft naming) on the attention projections: DEFAULT_LORA_TARGET to_k,to_q,to_v,to_out.0 (sdxl/model.py, common.py:1049-1128)
+    # ------------------------------------------------------------------------------------------------
+    def add_lora_adapter(self, rank: int = 16, alpha: Optional[float] = None, seed: int = 7, init_b_std: float = 0.0):
+        if self.full:
+            raise RuntimeError("full fine-tune and LoRA adapters are exclusive")
+        alpha = float(rank if alpha is None else alpha)
+        dev = self.device_
+        plan = []
+        self.lora_groups = []
+
+        def group(lin, prefix, names):
+            each = lin.N // len(names)
+            g = LoraGroup(lin.K, lin.N, [(prefix + n, j * each, each) for j, n in enumerate(names)], rank, alpha, dev)
+            lin.lora = g
+            self.lora_groups.append(g)
+            for (name, _, N) in g.targets:
+                plan.append((g, name, N, lin.K))
+
+        def tr(t, p):
+            for k, b in enumerate(t.blocks):
+                q = f"{p}transformer_blocks.{k}."
+                group(b.qkv, q + "attn1.", ["to_q", "to_k", "to_v"]); group(b.out1, q + "attn1.", ["to_out.0"])
+                group(b.q2, q + "attn2.", ["to_q"]); group(b.kv2, q + "attn2.", ["to_k", "to_v"]); group(b.out2, q + "attn2.", ["to_out.0"])
+
+        for i, blk in enumerate(self.down):
+            for j, t in enumerate(blk.attns):
+                tr(t, f"down_blocks.{i}.attentions.{j}.")
+        tr(self.mid.attn, "mid_block.attentions.0.")
+        for i, blk in enumerate(self.up):
+            for j, t in enumerate(blk.attns):
+                tr(t, f"up_blocks.{i}.attentions.{j}.")
+        total = (sum(rank * K + N * rank for (_, _, N, K) in plan) + 7) // 8 * 8
+        self.lora_flat = torch.zeros(total, dtype=F32, device=dev)
+        self.lora_grad_flat = torch.zeros(total, dtype=F32, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        off = 0
+        self._lora_params = []
+        for (g, name, N, K) in plan:
+            if not g.A:
+                g.flat_lo = off
+            a = self.lora_flat[off:off + rank * K].view(rank, K); ga = self.lora_grad_flat[off:off + rank * K].view(rank, K)
+            off += rank * K
+            b = self.lora_flat[off:off + N * rank].view(N, rank); gb = self.lora_grad_flat[off:off + N * rank].view(N, rank)
+            off += N * rank
+            a.copy_((torch.rand(rank, K, generator=gen, device=dev) * 2 - 1) / math.sqrt(K))
+            if init_b_std > 0:
+                b.copy_(torch.randn(N, rank, generator=gen, device=dev) * init_b_std)
+            pa, pb = nn.Parameter(a), nn.Parameter(b)
+            _attach(self, name + ".lora_A.default.weight", pa); _attach(self, name + ".lora_B.default.weight", pb)
+            g.A.append(pa.data); g.B.append(pb.data); g.gA.append(ga); g.gB.append(gb)
+            g.flat_hi = off
+            self._lora_params += [pa, pb]
+        self._alloc_transposed()
+        self._refresh_transposed()                       # frozen base: the K-major copies are built once
+        return self._lora_params
 
     def _is_down(self, l):
         return any(blk.down is l for blk in self.down)
 
     def trainable_parameters(self):
-        return list(self._full_params)
+        return list(self._full_params) if self.full else list(self._lora_params)
 
     @torch.no_grad()
     def _refresh_transposed(self):
@@ -393,13 +458,25 @@ class UNet2DConditionModel(nn.Module):
     # ops with their backward closures
     # ------------------------------------------------------------------------------------------------
     def _linear(self, T, l, x, residual=None, need_dx=True):
-        y = ops.gemm(x, l.w.t, bias=None if l.b is None else l.b.t, epilogue=EPI_ADD if residual is not None else EPI_NONE, aux_in=residual)
+        lo = l.lora
+        kw = {}
+        Tl = None
+        if lo is not None:                                  # y = x W^T + (s B)(A x): the low-rank term rides the GEMM's K-extension
+            Tl = ops.gemm(x, lo.A_cat)
+            kw = dict(a2=Tl, b2=lo.B_blk)
+        y = ops.gemm(x, l.w.t, bias=None if l.b is None else l.b.t, epilogue=EPI_ADD if residual is not None else EPI_NONE, aux_in=residual, **kw)
         if T is not None:
             def bwd(dy):
-                ops.gemm_tn(_p64(dy), _p64(x), out=l.w.g)
-                if l.b is not None:
-                    self._bias_grad(dy, l.b)
-                dx = ops.gemm(dy, l.wT) if need_dx else None
+                if self.full:
+                    ops.gemm_tn(_p64(dy), _p64(x), out=l.w.g)
+                    if l.b is not None:
+                        self._bias_grad(dy, l.b)
+                kb = {}
+                if lo is not None:
+                    U = ops.gemm(dy, lo.B_blk_T)
+                    lo.grads(x, Tl, dy, U, False, None)
+                    kb = dict(a2=U, b2=lo.A_cat_T)
+                dx = ops.gemm(dy, l.wT, **kb) if need_dx else None
                 return dx, (dy if residual is not None else None)
             T.rec([y], [x if need_dx else None, residual], bwd)
         return y
@@ -410,8 +487,9 @@ class UNet2DConditionModel(nn.Module):
             n = B * (H + 2) * (W + 2)
 
             def bwd(dy):
-                ops.conv_wgrad(x, dy, l.w.g, B, H, W, taps=l.taps)
-                self._bias_grad(dy, l.b, rows=n)
+                if self.full:
+                    ops.conv_wgrad(x, dy, l.w.g, B, H, W, taps=l.taps)
+                    self._bias_grad(dy, l.b, rows=n)
                 dx = ops.conv(dy, l.wT, B, H, W, taps=l.taps)
                 dadd = None
                 if img_add is not None:
@@ -427,10 +505,11 @@ class UNet2DConditionModel(nn.Module):
         if T is not None:
             def bwd(dy):
                 Cn = x.shape[1]
-                dg, db = self._f32(Cn), self._f32(Cn, 1)
+                dg, db = (self._f32(Cn), self._f32(Cn, 1).view(Cn)) if self.full else (None, None)
                 dx = ops.groupnorm_bwd(dy, x, nm.w.t, nm.b.t, stats, B, H, W, groups=self.config.norm_num_groups, silu=silu, dy_tokens=tokens, dgamma=dg,
-                                       dbeta=db.view(Cn))
-                nm.w.g.copy_(dg); nm.b.g.copy_(db.view(Cn))
+                                       dbeta=db)
+                if self.full:
+                    nm.w.g.copy_(dg); nm.b.g.copy_(db)
                 return (dx,)
             T.rec([y], [x], bwd)
         return y
@@ -439,10 +518,11 @@ class UNet2DConditionModel(nn.Module):
         n = ops.layernorm_fwd(h, nm.w.t, nm.b.t, eps=1e-5)
         if T is not None:
             def bwd(dn):
-                D = h.shape[1]
-                dw, db = self._f32(D), self._f32(D, 1)
-                ops.layernorm_param_grads(dn, h, dw, db.view(D), eps=1e-5)
-                nm.w.g.copy_(dw); nm.b.g.copy_(db.view(D))
+                if self.full:
+                    D = h.shape[1]
+                    dw, db = self._f32(D), self._f32(D, 1)
+                    ops.layernorm_param_grads(dn, h, dw, db.view(D), eps=1e-5)
+                    nm.w.g.copy_(dw); nm.b.g.copy_(db.view(D))
                 return (ops.layernorm_bwd(dn, h, nm.w.t, eps=1e-5),)
             T.rec([n], [h], bwd)
         return n
@@ -527,6 +607,8 @@ class UNet2DConditionModel(nn.Module):
         c = self.config
         dev = self.device_
         T = Tape() if save else None
+        for g_ in self.lora_groups:
+            g_.pack()
         B, Cin, H, W = sample.shape
         nb = len(c.block_out_channels)
         # ---- embeddings ----
@@ -559,8 +641,9 @@ class UNet2DConditionModel(nn.Module):
         x = ops.conv(col, self.l_conv_in.w.t, B, H, W, bias=self.l_conv_in.b.t, taps=1)
         if T is not None:
             def bwd_in(dy, col=col, H=H, W=W):
-                ops.conv_wgrad(col, dy, self.l_conv_in.w.g, B, H, W, taps=1)
-                self._bias_grad(dy, self.l_conv_in.b, rows=B * (H + 2) * (W + 2))
+                if self.full:
+                    ops.conv_wgrad(col, dy, self.l_conv_in.w.g, B, H, W, taps=1)
+                    self._bias_grad(dy, self.l_conv_in.b, rows=B * (H + 2) * (W + 2))
                 return (None,)
             T.rec([x], [None], bwd_in)
         skips = [x]
@@ -601,8 +684,9 @@ class UNet2DConditionModel(nn.Module):
             def bwd_out(dout, x=x, H=h_, W=w_):
                 l = self.l_conv_out
                 dyg = ops.grid_from_nchw(dout.to(BF16).contiguous(), 8)
-                ops.conv_wgrad(x, dyg, l.w.g, B, H, W, taps=9)
-                self._bias_grad(dyg, l.b, rows=B * (H + 2) * (W + 2))
+                if self.full:
+                    ops.conv_wgrad(x, dyg, l.w.g, B, H, W, taps=9)
+                    self._bias_grad(dyg, l.b, rows=B * (H + 2) * (W + 2))
                 dcol = ops.im2col3x3(dyg, B, H, W, stride=1)
                 return (ops.conv(dcol, l.wT, B, H, W, taps=1),)
             T.rec([out], [x], bwd_out)
@@ -615,8 +699,9 @@ class UNet2DConditionModel(nn.Module):
             n = B * (H // 2 + 2) * (W // 2 + 2)
 
             def bwd(dy):
-                ops.conv_wgrad(col, dy, l.w.g, B, H // 2, W // 2, taps=1)
-                self._bias_grad(dy, l.b, rows=n)
+                if self.full:
+                    ops.conv_wgrad(col, dy, l.w.g, B, H // 2, W // 2, taps=1)
+                    self._bias_grad(dy, l.b, rows=n)
                 dcol = torch.empty(dy.shape[0], col.shape[1], dtype=BF16, device=dy.device)
                 ops.gemm(dy[:n], l.wT, out=dcol[:n])
                 return (ops.col2im3x3(dcol, B, H, W, x.shape[1], stride=2),)
@@ -636,9 +721,9 @@ class UNet2DConditionModel(nn.Module):
             if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
                 raise ValueError("addition_embed_type 'text_time' needs added_cond_kwargs['text_embeds'] and ['time_ids']")
             te, ti = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
-        if torch.is_grad_enabled() and self.full:
+        if torch.is_grad_enabled() and (self.full or self._lora_params):
             dummy = te if te is not None else encoder_hidden_states
-            out = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, dummy, ti, *self._full_params)
+            out = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, dummy, ti, *(self._full_params if self.full else self._lora_params))
         else:
             with torch.no_grad():
                 out, _ = self._engine_forward(sample, timestep, encoder_hidden_states, te, ti, save=False)
@@ -663,13 +748,21 @@ class _UNetFn(torch.autograd.Function):
         model = fctx.model
         if model.grad_sync is not None:
             model.grad_sync.begin()
-        model._refresh_transposed()
+        if model.full:
+            model._refresh_transposed()
         fctx.tape.backward(fctx.out, dout.contiguous())
         fctx.tape = None
+        arena = model.grad_arena if model.full else model.lora_grad_flat
         if model.grad_sync is not None:
-            model.grad_sync.ready(0, model.grad_arena.numel())
+            model.grad_sync.ready(0, arena.numel())
             model.grad_scale_from_sync = model.grad_sync.finish()
-        gflat = model.grad_arena.clone()
+        gflat = arena.clone()
         model._last_grad_flat = gflat
-        grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]
+        if model.full:
+            grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]
+        else:
+            grads, off = [], 0
+            for p in model._lora_params:
+                grads.append(gflat[off:off + p.numel()].view_as(p))
+                off += p.numel()
         return (None,) * 6 + tuple(grads)

@@ -78,3 +78,40 @@ def test_unet_full_finetune_gradients_match_autograd():
             worst = (r / tol, f"{s.name}: {r:.3e}")
         assert r < tol, (s.name, r)
     print(f"[unet grads] {len(m._specs)} tensors, worst (relative to its tolerance) {worst[1]}")
+
+
+def test_unet_lora_gradients_match_autograd():
+    """frozen base + peft-style LoRA (y = W x + (alpha/r) B A x) on every attn1 / attn2 projection: prediction and every adapter gradient vs autograd"""
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    dev = "cuda:0"
+    rank, alpha = 16, 16.0
+    m = UNet2DConditionModel(device=dev, **SMALL)
+    m.init_synthetic(6)
+    params = m.add_lora_adapter(rank=rank, alpha=alpha, seed=3, init_b_std=0.05)
+    P = {k: v.float().cpu() for k, v in m.diffusers_state_dict().items()}
+    lora = {n: p.detach().float().cpu().requires_grad_(True) for n, p in m.named_parameters() if ".lora_" in n}
+    assert len(lora) == len(params) == 2 * 8 * 8 and all(p.requires_grad for p in params)        # 8 transformer layers x (q,k,v,out) x 2 attentions x (A,B)
+    # oracle: merge the adapters into effective weights (exactly what the fused K-extension computes), autograd through the merge
+    Pe = dict(P)
+    for n in lora:
+        if ".lora_A." in n:
+            base = n.replace(".lora_A.default.weight", "")
+            Pe[base + ".weight"] = P[base + ".weight"] + (alpha / rank) * lora[base + ".lora_B.default.weight"] @ lora[n]
+    sample, t, ehs, te, ti = _inputs(2, 16, 16, dev, seed=2)
+    target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(8))
+    out = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": ti.to(dev)}, return_dict=False)[0]
+    loss = ((out.float() - target.to(dev)) ** 2).mean()
+    loss.backward()
+    ref = unet_forward(Pe, UNetConfig(**SMALL), sample.float(), t, ehs.float(), {"text_embeds": te.float(), "time_ids": ti.float()})
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-2
+    ((ref - target) ** 2).mean().backward()
+    worst = (0.0, "")
+    for n, p in m.named_parameters():
+        if ".lora_" not in n:
+            assert p.grad is None
+            continue
+        r = _rel(p.grad.cpu(), lora[n].grad)
+        if r > worst[0]:
+            worst = (r, n)
+        assert r < 6e-2, (n, r)
+    print(f"[unet lora grads] {len(lora)} tensors, worst {worst[1]}: {worst[0]:.3e}")
