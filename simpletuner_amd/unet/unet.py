@@ -443,6 +443,15 @@ class UNet2DConditionModel(nn.Module):
             else:
                 ops.transpose(l.w.t, out=l.wT)
 
+    def _ready(self, *slots):
+        """gradient slices that are final: hand them to the bucketed all-reduce (overlaps the rest of the backward); adjacent slices merge"""
+        gs = self.grad_sync
+        if gs is None or not self.full:
+            return
+        for sl in slots:
+            if sl is not None:
+                gs.ready(sl.off, sl.off + (sl.numel + 7) // 8 * 8)
+
     def _f32(self, *shape):
         t = self._tmp.get(shape)
         if t is None:
@@ -471,6 +480,7 @@ class UNet2DConditionModel(nn.Module):
                     ops.gemm_tn(_p64(dy), _p64(x), out=l.w.g)
                     if l.b is not None:
                         self._bias_grad(dy, l.b)
+                    self._ready(l.b, l.w) if (l.b is not None and l.b.off > l.w.off) else self._ready(l.w, l.b)
                 kb = {}
                 if lo is not None:
                     U = ops.gemm(dy, lo.B_blk_T)
@@ -490,6 +500,7 @@ class UNet2DConditionModel(nn.Module):
                 if self.full:
                     ops.conv_wgrad(x, dy, l.w.g, B, H, W, taps=l.taps)
                     self._bias_grad(dy, l.b, rows=n)
+                    self._ready(l.b, l.w)
                 dx = ops.conv(dy, l.wT, B, H, W, taps=l.taps)
                 dadd = None
                 if img_add is not None:
@@ -510,6 +521,7 @@ class UNet2DConditionModel(nn.Module):
                                        dbeta=db)
                 if self.full:
                     nm.w.g.copy_(dg); nm.b.g.copy_(db)
+                    self._ready(nm.b, nm.w)
                 return (dx,)
             T.rec([y], [x], bwd)
         return y
@@ -523,6 +535,7 @@ class UNet2DConditionModel(nn.Module):
                     dw, db = self._f32(D), self._f32(D, 1)
                     ops.layernorm_param_grads(dn, h, dw, db.view(D), eps=1e-5)
                     nm.w.g.copy_(dw); nm.b.g.copy_(db.view(D))
+                    self._ready(nm.b, nm.w)
                 return (ops.layernorm_bwd(dn, h, nm.w.t, eps=1e-5),)
             T.rec([n], [h], bwd)
         return n
@@ -644,6 +657,7 @@ class UNet2DConditionModel(nn.Module):
                 if self.full:
                     ops.conv_wgrad(col, dy, self.l_conv_in.w.g, B, H, W, taps=1)
                     self._bias_grad(dy, self.l_conv_in.b, rows=B * (H + 2) * (W + 2))
+                    self._ready(self.l_conv_in.b, self.l_conv_in.w)
                 return (None,)
             T.rec([x], [None], bwd_in)
         skips = [x]
@@ -687,6 +701,7 @@ class UNet2DConditionModel(nn.Module):
                 if self.full:
                     ops.conv_wgrad(x, dyg, l.w.g, B, H, W, taps=9)
                     self._bias_grad(dyg, l.b, rows=B * (H + 2) * (W + 2))
+                    self._ready(l.b, l.w)
                 dcol = ops.im2col3x3(dyg, B, H, W, stride=1)
                 return (ops.conv(dcol, l.wT, B, H, W, taps=1),)
             T.rec([out], [x], bwd_out)
@@ -702,6 +717,7 @@ class UNet2DConditionModel(nn.Module):
                 if self.full:
                     ops.conv_wgrad(col, dy, l.w.g, B, H // 2, W // 2, taps=1)
                     self._bias_grad(dy, l.b, rows=n)
+                    self._ready(l.b, l.w)
                 dcol = torch.empty(dy.shape[0], col.shape[1], dtype=BF16, device=dy.device)
                 ops.gemm(dy[:n], l.wT, out=dcol[:n])
                 return (ops.col2im3x3(dcol, B, H, W, x.shape[1], stride=2),)
@@ -754,8 +770,12 @@ class _UNetFn(torch.autograd.Function):
         fctx.tape = None
         arena = model.grad_arena if model.full else model.lora_grad_flat
         if model.grad_sync is not None:
-            model.grad_sync.ready(0, arena.numel())
+            if not model.full:
+                model.grad_sync.ready(0, arena.numel())          # LoRA: one small all-reduce after the backward
             model.grad_scale_from_sync = model.grad_sync.finish()
+            sent = sum(hi - lo for lo, hi in model.grad_sync.launched_slices)
+            if sent != arena.numel():
+                raise RuntimeError(f"gradient sync covered {sent} of {arena.numel()} elements: a parameter's gradient was never reported ready")
         gflat = arena.clone()
         model._last_grad_flat = gflat
         if model.full:
