@@ -215,7 +215,7 @@ class Trainer:
                   "gflat_nan", bool(torch.isnan(comp._last_grad_flat).any()), "static_nan", [k for k, v in st.items() if v.is_floating_point() and bool(torch.isnan(v.float()).any())], flush=True)
         for p, gr in zip(self.params, grads):
             p.grad = gr
-        return loss
+        return loss.clone()        # the static tensor is overwritten by the next replay: callers keep their own value
 
     def train(self, batches: Iterable[dict], max_steps: int):
         losses = []
