@@ -1,0 +1,76 @@
+"""CPU checks of the PixArt / VAE oracle restatements (shapes, mask semantics, ControlNet wiring, posterior algebra) — the host-side logic the
+GPU parity tests lean on."""
+import math
+
+import torch
+
+from oracle import pixart as OP
+from oracle import vae as OV
+
+
+def _pixart_weights(cfg, n_ctrl, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    D = cfg.D
+    P = {}
+
+    def lin(n, o, i):
+        P[n + ".weight"] = torch.randn(o, i, generator=g) / math.sqrt(i)
+        P[n + ".bias"] = torch.randn(o, generator=g) * 0.02
+
+    def blk(p, Q):
+        for a, kd in (("attn1.", D), ("attn2.", D)):
+            for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+                Q[p + a + nm + ".weight"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+                Q[p + a + nm + ".bias"] = torch.randn(D, generator=g) * 0.02
+        Q[p + "ff.net.0.proj.weight"] = torch.randn(4 * D, D, generator=g) / math.sqrt(D); Q[p + "ff.net.0.proj.bias"] = torch.zeros(4 * D)
+        Q[p + "ff.net.2.weight"] = torch.randn(D, 4 * D, generator=g) / math.sqrt(4 * D); Q[p + "ff.net.2.bias"] = torch.zeros(D)
+        Q[p + "scale_shift_table"] = torch.randn(6, D, generator=g) / math.sqrt(D)
+
+    P["pos_embed.proj.weight"] = torch.randn(D, 4, 2, 2, generator=g) / 4; P["pos_embed.proj.bias"] = torch.zeros(D)
+    for e, o in (("timestep_embedder", D), ("resolution_embedder", D // 3), ("aspect_ratio_embedder", D // 3)):
+        lin(f"adaln_single.emb.{e}.linear_1", o, 256); lin(f"adaln_single.emb.{e}.linear_2", o, o)
+    lin("adaln_single.linear", 6 * D, D); lin("caption_projection.linear_1", D, cfg.caption_channels); lin("caption_projection.linear_2", D, D)
+    P["scale_shift_table"] = torch.randn(2, D, generator=g) / math.sqrt(D); lin("proj_out", 4 * cfg.out_channels, D)
+    for i in range(cfg.num_layers):
+        blk(f"transformer_blocks.{i}.", P)
+    C = {}
+    for i in range(n_ctrl):
+        p = f"controlnet_blocks.{i}."
+        blk(p + "transformer_block.", C)
+        if i == 0:
+            C[p + "before_proj.weight"], C[p + "before_proj.bias"] = torch.zeros(D, D), torch.zeros(D)
+        C[p + "after_proj.weight"], C[p + "after_proj.bias"] = torch.zeros(D, D), torch.zeros(D)
+    return P, C
+
+
+def test_pixart_oracle_mask_and_zero_init_controlnet():
+    cfg = OP.PixArtConfig(num_attention_heads=2, attention_head_dim=24, num_layers=3, caption_channels=32, cross_attention_dim=48, sample_size=128)
+    P, C = _pixart_weights(cfg, 2)
+    g = torch.Generator().manual_seed(1)
+    lat, cond = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    enc = torch.randn(2, 6, 32, generator=g)
+    mask = torch.tensor([[1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 0]], dtype=torch.float32)
+    t = torch.tensor([10.0, 700.0])
+    res, ar = torch.tensor([[8.0, 8.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1)
+    base = OP.pixart_forward(P, cfg, lat, enc, mask, t, res, ar)
+    assert base.shape == (2, 8, 8, 8)
+    # masked text tokens must not influence the output (bias -10000 -> exp underflows to exactly 0 in fp32)
+    enc2 = enc.clone(); enc2[0, 3:] += 5.0; enc2[1, 5:] -= 3.0
+    assert torch.allclose(base, OP.pixart_forward(P, cfg, lat, enc2, mask, t, res, ar), atol=1e-5)
+    # zero-initialised before/after projections: the ControlNet wrapper reproduces the trunk exactly (pixart/controlnet.py:37-40, 58-60)
+    ctl = OP.controlnet_forward(P, C, cfg, 2, lat, cond, enc, mask, t, res, ar)
+    assert torch.allclose(base, ctl, atol=1e-5)
+    C["controlnet_blocks.0.after_proj.weight"] += 0.05 * torch.randn(cfg.D, cfg.D, generator=g)
+    assert not torch.allclose(base, OP.controlnet_forward(P, C, cfg, 2, lat, cond, enc, mask, t, res, ar), atol=1e-4)
+    assert OP.pixart_flops_fwd(OP.PixArtConfig(sample_size=256), 256, 256) / 1e12 > 50       # F_fwd ≈ 5.2e13 at 2K
+
+
+def test_vae_posterior_and_scaling():
+    m = torch.randn(2, 8, 4, 4)
+    m[:, 4:] = torch.tensor(40.0)                                     # logvar above the clamp
+    eps = torch.ones(2, 4, 4, 4)
+    z = OV.sample_and_scale(m, OV.VAEConfig(), eps)
+    assert torch.allclose(z, (m[:, :4] + math.exp(10.0)) * 0.13025)   # clamp(logvar, max 20) -> std = e^10
+    zf = OV.sample_and_scale(m, OV.VAEConfig.flux(), None)
+    assert torch.allclose(zf, (m[:, :4] - 0.1159) * 0.3611)           # mode + (z - shift) * scale (foundation_mixins.py:72-74)
+    assert abs(OV.encoder_flops(OV.VAEConfig(), 1024, 1024) / 1e12 - 4.9) < 0.3
