@@ -398,7 +398,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
                          int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale) {
   ST_REQUIRE(Q && K && Vt && O && lse2, "attn_fwd: null pointer");
   ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sq > 0 && Sp % 64 == 0 && Sp >= S && ld_o % 4 == 0, "attn_fwd: bad shape S=%d Sp=%d", S, Sp);
-  if (d != 128 && d != 64) { st355_set_error("attn_fwd: head_dim %d not built", d); return ST355_ENOSYS; }
+  if (d != 128 && d != 64 && d != 96) { st355_set_error("attn_fwd: head_dim %d not built", d); return ST355_ENOSYS; }
   const double flops = 4.0 * (double)B * H * (double)Sq * S * d;
   const double bytes = 2.0 * (double)B * H * (Sq + S) * d * 2.0;
   ProfScope ps(stream, ST355_K_ATTN_FWD, flops, bytes);
@@ -408,7 +408,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // measured 761-786 TFLOP/s in-step.  ST355_ATTN_FWD=2 selects k_attn_fwd2 (8 waves, LDS-DMA, half-tile stagger): correct (same
   // parity tests) but 635-700 TFLOP/s — the forward is VALU/latency-shaped and loses the decoupling of two independent workgroups.
   if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '2') ? 2 : 1; }
-  if (gen == 2 && Sq == S) {
+  if (gen == 2 && Sq == S && d != 96) {
     dim3 grid2((S + 255) / 256, H, B);
     if (d == 128) {
       const int lds = 2 * (KB * 256 + 128 * 128);
@@ -424,7 +424,13 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
     return st355_check_launch("attn_fwd2");
   }
   dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);
-  if (d == 128) {
+  if (d == 96) {                 // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
+    const int lds = 2 * (KB * 192 + 96 * 128);
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(k_attn_fwd<96>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
+  } else if (d == 128) {
     const int lds = 2 * (KB * 256 + 128 * 128);
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }

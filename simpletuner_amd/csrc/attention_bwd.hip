@@ -20,20 +20,26 @@ template <int HD>
 __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ O, int64_t ld_o, const bf16* __restrict__ dO,
                                                       int64_t ld_do, const float* __restrict__ lse2, float* __restrict__ delta,
                                                       float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp) {
-  constexpr int TPR = HD / 8;
+  constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;          // lanes per token (power of two; head_dim 96 leaves 4 of 16 idle)
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TPB];
   const int tid = threadIdx.x;
   const int head = blockIdx.y, b = blockIdx.z;
   const int t0 = blockIdx.x * 64;
   const int c = tid % TPR;
+  const bool cact = c < HD / 8;
   const int64_t bh = (int64_t)b * H + head;
   for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
     const int t = t0 + tl;
     const bool valid = t < S;
     const int tt = valid ? t : S - 1;
-    bf16x8 ov = *(const bf16x8*)(O + ((int64_t)b * S + tt) * ld_o + (int64_t)head * HD + c * 8);
-    bf16x8 gv = *(const bf16x8*)(dO + ((int64_t)b * S + tt) * ld_do + (int64_t)head * HD + c * 8);
+    bf16x8 ov, gv;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ov[j] = f2bf(0.f); gv[j] = f2bf(0.f); }
+    if (cact) {
+      ov = *(const bf16x8*)(O + ((int64_t)b * S + tt) * ld_o + (int64_t)head * HD + c * 8);
+      gv = *(const bf16x8*)(dO + ((int64_t)b * S + tt) * ld_do + (int64_t)head * HD + c * 8);
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; j++) s += bf2f(ov[j]) * bf2f(gv[j]);
@@ -47,10 +53,12 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; j++) gv[j] = f2bf(0.f);
     }
-    uint32_t* tp = (uint32_t*)(&tile[tl * TPB + c * 8]);
-    const u32x4 gw = *(const u32x4*)&gv;
+    if (cact) {
+      uint32_t* tp = (uint32_t*)(&tile[tl * TPB + c * 8]);
+      const u32x4 gw = *(const u32x4*)&gv;
 #pragma unroll
-    for (int j = 0; j < 4; j++) tp[j] = gw[j];
+      for (int j = 0; j < 4; j++) tp[j] = gw[j];
+    }
   }
   __syncthreads();
   for (int i = tid; i < HD * 8; i += 256) {
@@ -77,8 +85,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   constexpr int TT_BYTES = HD * 128;     // K^T tile (HD rows x 64 keys)
   constexpr int BUF = 2 * KT_BYTES + TT_BYTES;
   constexpr int NKS = HD / 16, NDT = HD / 32;
-  constexpr int KCH = KT_BYTES / 16 / NT;
-  constexpr int TCH = TT_BYTES / 16 / NT;
+  constexpr int KTOT = KT_BYTES / 16, TTOT = TT_BYTES / 16;             // 16-byte chunks per tile (head_dim 96: 768, not a multiple of 512)
+  constexpr int KCH = (KTOT + NT - 1) / NT;
+  constexpr int TCH = (TTOT + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -118,6 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
     for (int p = 0; p < KCH; p++) {
       const int id = p * NT + tid;
+      if (KTOT % NT != 0 && id >= KTOT) continue;
       const int row = id / (HD / 8), c = id % (HD / 8);
       const int key = min(key0 + row, Sk - 1);
       kreg[p] = *(const bf16x8*)(Kg + (int64_t)key * HD + c * 8);
@@ -126,6 +136,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
     for (int p = 0; p < TCH; p++) {
       const int id = p * NT + tid;
+      if (TTOT % NT != 0 && id >= TTOT) continue;
       const int row = id >> 3, c = id & 7;
       treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Skp + key0 + c * 8);
     }
@@ -137,6 +148,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
     for (int p = 0; p < KCH; p++) {
       const int id = p * NT + tid;
+      if (KTOT % NT != 0 && id >= KTOT) continue;
       const int row = id / (HD / 8), c = id % (HD / 8);
       *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
       *(bf16x8*)(vs + lds_off<KROWB>(row, c)) = vreg[p];
@@ -144,6 +156,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
     for (int p = 0; p < TCH; p++) {
       const int id = p * NT + tid;
+      if (TTOT % NT != 0 && id >= TTOT) continue;
       const int row = id >> 3, c = id & 7;
       *(bf16x8*)(ts + lds_off<128>(row, c)) = treg[p];
     }
@@ -426,10 +439,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
   constexpr int STAT_BYTES = 2 * 64 * 4;
   constexpr int BUF = 2 * QT_BYTES + 2 * TT_BYTES + STAT_BYTES;
   constexpr int NKS = HD / 16, NDT = HD / 32;
-  constexpr int QPW = QT_BYTES / 1024 / 8;   // 1-KiB DMA pieces per wave per row-major tile (HD=128: 2)
-  constexpr int TPW = TT_BYTES / 1024 / 8;   // ... per transposed tile
-  constexpr int RPP = 1024 / QROWB;          // rows per piece of a row-major tile (HD=128: 4)
-  constexpr int CPR = QROWB / 16;            // 16-byte chunks per row (16)
+  constexpr int QPIECES = QT_BYTES / 1024, TPIECES = TT_BYTES / 1024;   // 1-KiB DMA pieces per tile (HD=96: 12, spread over 8 waves as 2+1)
+  constexpr int QPW = (QPIECES + 7) / 8;     // pieces per wave per row-major tile (HD=128: 2)
+  constexpr int TPW = (TPIECES + 7) / 8;     // ... per transposed tile
+  constexpr int CPR = QROWB / 16;            // 16-byte chunks per row (HD=128: 16, 96: 12, 64: 8)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -478,18 +491,24 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
     asm volatile("" : "+v"(ln));     // everything below is re-derived from the lane id each tile (never spilled, never hoisted)
 #pragma unroll
     for (int p = 0; p < QPW; p++) {
-      const int row = (wv * QPW + p) * RPP + ln / CPR;             // tile row = query
-      const int col = ((ln % CPR) ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7))) * 8;
+      const int piece = wv + 8 * p;                                // wave-uniform
+      if (QPIECES % 8 != 0 && piece >= QPIECES) continue;
+      const int idx = piece * 64 + ln;                             // linear 16-byte chunk index inside the tile image
+      const int row = idx / CPR;                                   // tile row = query
+      const int swz = HD == 128 ? (row & 15) : (HD == 96 ? ((row >> 2) & 3) : ((row >> 1) & 7));
+      const int col = ((idx % CPR) ^ swz) * 8;
       const int qq = min(qq0 + row, Sq - 1);
-      a_glds16(Qg + (uint32_t)(qq * HD + col), qs + (wv * QPW + p) * 1024);
-      a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + (wv * QPW + p) * 1024);
+      a_glds16(Qg + (uint32_t)(qq * HD + col), qs + piece * 1024);
+      a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + piece * 1024);
     }
 #pragma unroll
     for (int p = 0; p < TPW; p++) {
-      const int row = (wv * TPW + p) * 8 + (ln >> 3);              // tile row = head channel
+      const int piece = wv + 8 * p;
+      if (TPIECES % 8 != 0 && piece >= TPIECES) continue;
+      const int row = piece * 8 + (ln >> 3);                       // tile row = head channel
       const uint32_t off = (uint32_t)(row * Sqp + ((ln & 7) ^ ((row >> 1) & 7)) * 8 + qq0);
-      a_glds16(Qtg + off, qts + (wv * TPW + p) * 1024);
-      a_glds16(dOtg + off, gts + (wv * TPW + p) * 1024);
+      a_glds16(Qtg + off, qts + piece * 1024);
+      a_glds16(dOtg + off, gts + piece * 1024);
     }
     if (wv == 0) a_glds4(lse_g + qq0 + ln, stat);
     if (wv == 1) a_glds4(del_g + qq0 + ln, stat + 256);
@@ -499,7 +518,11 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
   // per-lane LDS read bases; every fragment address is base ^ (chunk_pair << 4) + an immediate (the XOR swizzles act on bit 0
   // = lane half h, folded into the base, and on bits 1.. = the k-step, applied per read)
   const int qrow_p = perm23(l31);
-  const int q_base0 = (HD == 128) ? qrow_p * 256 + ((h ^ (qrow_p & 15)) << 4) : qrow_p * 128 + ((h ^ ((qrow_p >> 1) & 7)) << 4);
+  // head_dim 96: a 192-byte row pitch puts row bits into the chunk field (bits 6-7), so the chunk cannot be XOR-ed into the address: the
+  // (2-bit) swizzle is XOR-ed into the chunk NUMBER and the chunk offset is added
+  const int hs96 = h ^ ((qrow_p >> 2) & 3);
+  const int q_base0 = (HD == 128) ? qrow_p * 256 + ((h ^ (qrow_p & 15)) << 4)
+                      : (HD == 96 ? qrow_p * 192 : qrow_p * 128 + ((h ^ ((qrow_p >> 1) & 7)) << 4));
   const int t_base0 = QT_BYTES * 2 + l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
   const int s_base0 = 2 * QT_BYTES + 2 * TT_BYTES + 32 * h;
   stage(0, 0);
@@ -521,8 +544,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
       for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
       for (int k2 = 0; k2 < NKS; k2 += 2) {
-        const char* q0p = smem + (q_base ^ ((2 * k2) << 4)) + qb * 32 * QROWB;
-        const char* q1p = smem + (q_base ^ ((2 * k2 + 2) << 4)) + qb * 32 * QROWB;
+        const char* q0p = (HD == 96) ? smem + q_base + (((2 * k2) ^ hs96) << 4) + qb * 32 * QROWB : smem + (q_base ^ ((2 * k2) << 4)) + qb * 32 * QROWB;
+        const char* q1p = (HD == 96) ? smem + q_base + (((2 * k2 + 2) ^ hs96) << 4) + qb * 32 * QROWB
+                                     : smem + (q_base ^ ((2 * k2 + 2) << 4)) + qb * 32 * QROWB;
         bf16x8 qf0 = *(const bf16x8*)(q0p);
         bf16x8 qf1 = *(const bf16x8*)(q1p);
         bf16x8 gf0 = *(const bf16x8*)(q0p + QT_BYTES);
@@ -608,7 +632,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && Sk > 0 && Skp % 64 == 0 && Skp >= Sk, "attn_bwd: bad shape S=%d Sp=%d Sk=%d Skp=%d", S, Sp, Sk, Skp);
   ST_REQUIRE(ld_v % 8 == 0 && ld_o % 8 == 0 && ld_do % 8 == 0 && ld_dv % 4 == 0, "attn_bwd: leading dimensions must be multiples of 8");
   ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
-  if (d != 128 && d != 64) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
+  if (d != 128 && d != 64 && d != 96) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
   float* delta = (float*)workspace;
   float* lsep = (float*)((char*)workspace + round256((size_t)B * H * Sp * sizeof(float)));
   bf16* dOt = (bf16*)((char*)workspace + 2 * round256((size_t)B * H * Sp * sizeof(float)));
@@ -621,7 +645,9 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   {
     ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
     dim3 grid(Sp / 64, H, B);
-    if (d == 128)
+    if (d == 96)
+      hipLaunchKernelGGL(k_attn_bwd_prep<96>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
+    else if (d == 128)
       hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
     else
       hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
@@ -629,7 +655,23 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 4.0);
-    if (dkv_gen == 2) {
+    if (d == 96 && dkv_gen == 2) {       // head_dim 96 (PixArt's 72, zero-padded): 12 DMA pieces per tile image over the 8 waves
+      dim3 grid((Sk + 255) / 256, H, B);
+      const int lds = 2 * (2 * 64 * 192 + 2 * 96 * 128 + 512);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv2<96>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
+                         key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
+    } else if (d == 96) {        // ST355_ATTN_DKV=1: the register-staged kernel, 4 waves x 32 keys
+      dim3 grid((Sk + 127) / 128, H, B);
+      const int lds = 2 * (2 * 64 * 192 + 2 * 96 * 128 + 512);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv<96>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
+                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
+    } else if (dkv_gen == 2) {
       dim3 grid((Sk + 255) / 256, H, B);
       if (d == 128) {
         const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
@@ -669,7 +711,14 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
-    if (d == 128) {
+    if (d == 96) {
+      const int lds = 2 * (2 * 64 * 192 + 96 * 128);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dq<96>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
+                         scale, scale2);
+    } else if (d == 128) {
       const int lds = 2 * (2 * 64 * 256 + 128 * 128);
       static bool set = false;
       if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }

@@ -18,10 +18,12 @@ __device__ __forceinline__ int perm23(int i) { return (i & ~12) | ((i & 4) << 1)
 // actual row (0..31) held by accumulator register reg of a lane with half h, after the perm23 fetch order
 __device__ __forceinline__ int acc_row(int reg, int h) { return 16 * (reg >> 3) + 8 * h + (reg & 7); }
 
-// swizzled byte offset inside a row-major LDS tile whose rows are ROWB bytes (128 or 256)
+// swizzled byte offset inside a row-major LDS tile whose rows are ROWB bytes (128, 192 or 256)
 template <int ROWB>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   if (ROWB == 256) return row * 256 + ((chunk ^ (row & 15)) << 4);
+  if (ROWB == 192)               // head_dim 96: 12 chunks per row; rows r, r+4, r+8, r+12 share a bank base at a 192-byte pitch -> XOR the low two chunk
+    return row * 192 + ((chunk ^ ((row >> 2) & 3)) << 4);   // bits with (row>>2)&3 (stays inside the aligned group of 4 chunks: a bijection on 0..11)
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 

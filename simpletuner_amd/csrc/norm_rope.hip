@@ -518,7 +518,7 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
 // ================================================================================================
 template <int HD>
 __global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src, int64_t ld, bf16* __restrict__ X, bf16* __restrict__ Xt, int H, int S, int Sp) {
-  constexpr int TPR = HD / 8;
+  constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;          // lanes per token row (power of two; head_dim 96 leaves 4 of 16 idle)
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TP];
   const int tid = threadIdx.x;
@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src
   const int c = tid % TPR;
   const int64_t bh = (int64_t)b * H + h;
   for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    if (c >= HD / 8) continue;
     const int t = t0 + tl;
     const bool valid = t < S;
     const int tt = valid ? t : S - 1;
@@ -557,35 +558,35 @@ __global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src
 }
 template <int HD>
 __global__ void __launch_bounds__(256) k_head_merge(const bf16* __restrict__ dX, bf16* __restrict__ dst, int64_t ld, int H, int S) {
-  constexpr int TPR = HD / 8;
-  const int64_t n = (int64_t)gridDim.z * H * S * TPR;   // gridDim.z = B
-  (void)n;
+  constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;
   const int b = blockIdx.z, h = blockIdx.y;
   const int t = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, c = threadIdx.x % TPR;
-  if (t >= S) return;
+  if (t >= S || c >= HD / 8) return;
   const int64_t bh = (int64_t)b * H + h;
   *(bf16x8*)(dst + ((int64_t)b * S + t) * ld + (int64_t)h * HD + c * 8) = *(const bf16x8*)(dX + (bh * S + t) * HD + c * 8);
 }
 extern "C" int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp) {
   ST_REQUIRE(src && (X || Xt) && ld % 8 == 0 && S > 0 && (!Xt || (Sp % 64 == 0 && Sp >= S)), "head_split: bad args");
-  ST_REQUIRE(d == 128 || d == 64, "head_split: head_dim %d not built", d);
+  ST_REQUIRE(d == 128 || d == 64 || d == 96, "head_split: head_dim %d not built", d);
   ST_REQUIRE(((uintptr_t)src % 16) == 0, "head_split: misaligned source");
   const double n = (double)B * S * H * d;
   ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, (2.0 + (X ? 2.0 : 0.0) + (Xt ? 2.0 : 0.0)) * n);
   dim3 grid((S + 63) / 64, H, B), block(256);
-  if (d == 128) hipLaunchKernelGGL(k_head_split<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
+  if (d == 96) hipLaunchKernelGGL(k_head_split<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
+  else if (d == 128) hipLaunchKernelGGL(k_head_split<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
   else hipLaunchKernelGGL(k_head_split<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
   return st355_check_launch("head_split");
 }
 extern "C" int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S) {
   ST_REQUIRE(dX && dst && ld % 8 == 0 && S > 0, "head_merge: bad args");
-  ST_REQUIRE(d == 128 || d == 64, "head_merge: head_dim %d not built", d);
+  ST_REQUIRE(d == 128 || d == 64 || d == 96, "head_merge: head_dim %d not built", d);
   ST_REQUIRE(((uintptr_t)dst % 16) == 0, "head_merge: misaligned destination");
   const double n = (double)B * S * H * d;
   ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, 4.0 * n);
-  const int tpb = 256 / (d / 8);
+  const int tpb = 256 / (d / 8 <= 8 ? 8 : 16);
   dim3 grid((S + tpb - 1) / tpb, H, B), block(256);
-  if (d == 128) hipLaunchKernelGGL(k_head_merge<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
+  if (d == 96) hipLaunchKernelGGL(k_head_merge<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
+  else if (d == 128) hipLaunchKernelGGL(k_head_merge<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
   else hipLaunchKernelGGL(k_head_merge<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
   return st355_check_launch("head_merge");
 }

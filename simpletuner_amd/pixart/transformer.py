@@ -9,8 +9,8 @@ BASELINE.json configs[4] trains the ControlNet branch only: the trunk is frozen 
 
 Kernels: the MMDiT set (AdaLN modulate, GEMM with GELU / gate-residual epilogues, flash attention fwd/bwd) + the cross-attention entry points with
 the additive key bias of the text mask.  head_dim 72 is not an MFMA-friendly width: the q/k/v projections are stored with each head zero-padded to
-128 channels (and the out-projections with the matching zero K columns), so the head_dim-128 attention kernels run unchanged with scale 1/sqrt(72);
-the padding costs 1.78x on the attention FLOPs — the head_dim-80/96 kernel variants are the open item.
+96 channels = three 32-row MFMA tiles (and the out-projections with the matching zero K columns), and the attention kernels are instantiated for
+head_dim 96 (192-byte LDS rows with a 2-bit XOR swizzle) with scale 1/sqrt(72): 1.33x the attention FLOPs of an exact-72 kernel.
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_N
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-HP = 128          # padded head width
+HP = 96           # padded head width (72 -> 96: three 32-row MFMA tiles; was 128 before the head_dim-96 kernels existed)
 
 
 def sincos_2d_hw(embed_dim: int, h: int, w: int, base_size: int, interpolation_scale: float) -> torch.Tensor:

@@ -206,3 +206,51 @@ def test_cross_attention_fwd_bwd_vs_torch(B, H, Sq, Sk):
     ops.head_merge(dK, dkv[:, :Cm], B, H, d, Sk)
     assert _rel(dq, qf.grad) < 1.2e-2, _rel(dq, qf.grad)
     assert _rel(dkv, kvf.grad) < 1.2e-2, _rel(dkv, kvf.grad)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,cross", [(2, 4, 700, 700, False), (1, 3, 333, 300, True), (2, 2, 1024, 77, True)])
+def test_attention_head_dim_96_padded_72(B, H, Sq, Sk, cross):
+    """PixArt's head_dim 72 runs zero-padded to 96 (scale 1/sqrt(72)): self- and cross-attention forward / backward vs torch on the 72 real dims"""
+    from simpletuner_amd import ops
+    dev = "cuda:0"
+    d, dr = 96, 72
+    torch.manual_seed(7)
+    Cm = H * d
+    pad = torch.zeros(1, H, d, device=dev); pad[:, :, :dr] = 1
+    q = (torch.randn(B * Sq, H, d, device=dev) * pad).reshape(B * Sq, Cm).to(BF16)
+    kv = (torch.randn(B * Sk, 2, H, d, device=dev) * pad[:, None]).reshape(B * Sk, 2 * Cm).to(BF16)
+    kb = None
+    if cross:
+        kb = torch.zeros(B, Sk, device=dev); kb[:, Sk - 40:] = -10000.0
+    scale = 1.0 / math.sqrt(dr)
+    Q, Qt, Sqp = ops.head_split(q, B, H, d, Sq)
+    K, Kt, Skp = ops.head_split(kv[:, :Cm], B, H, d, Sk)
+    _, Vt, _ = ops.head_split(kv[:, Cm:], B, H, d, Sk, want_x=False)
+    O = torch.empty(B * Sq, Cm, dtype=BF16, device=dev)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+    if cross:
+        ops.attn_cross_fwd(Q, K, Vt, O, lse, B, H, Sq, Sk, Skp, d, scale, key_bias=kb)
+    else:
+        ops.attn_fwd(Q, K, Vt, O, lse, B, H, Sq, Sqp, d, scale)
+    qf, kvf = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    qh = qf.view(B, Sq, H, d).transpose(1, 2)
+    kh = kvf[:, :Cm].reshape(B, Sk, H, d).transpose(1, 2)
+    vh = kvf[:, Cm:].reshape(B, Sk, H, d).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if kb is not None:
+        s = s + kb[:, None, None, :]
+    ref = (torch.softmax(s, dim=-1) @ vh).transpose(1, 2).reshape(B * Sq, Cm)
+    assert _rel(O, ref) < 6e-3, _rel(O, ref)
+    dO = (torch.randn(B * Sq, H, d, device=dev) * pad).reshape(B * Sq, Cm).to(BF16)
+    (ref * dO.float()).sum().backward()
+    dQ, dK = torch.empty_like(Q), torch.empty_like(K)
+    dkv = torch.zeros_like(kv)
+    if cross:
+        ops.attn_cross_bwd(Q, K, Qt, Kt, kv[:, Cm:], O, dO, lse, dQ, dK, dkv[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=kb)
+    else:
+        ops.attn_bwd(Q, K, Qt, Kt, kv[:, Cm:], O, dO, lse, dQ, dK, dkv[:, Cm:], B, H, Sq, Sqp, d, scale)
+    dq = torch.empty_like(q)
+    ops.head_merge(dQ, dq, B, H, d, Sq)
+    ops.head_merge(dK, dkv[:, :Cm], B, H, d, Sk)
+    assert _rel(dq, qf.grad) < 1.2e-2, _rel(dq, qf.grad)
+    assert _rel(dkv, kvf.grad) < 1.2e-2, _rel(dkv, kvf.grad)
