@@ -122,6 +122,16 @@ class DDPMSchedule:
     def mix_coefficients(self, timesteps):
         return self._sa[timesteps].contiguous(), self._sb[timesteps].contiguous()
 
+    def snr(self, timesteps):
+        """compute_snr (min_snr_gamma.py:4-46): (alpha/sigma)^2 = acp / (1 - acp)"""
+        a = self.alphas_cumprod.to(timesteps.device)[timesteps.long()].float()
+        return a / (1.0 - a)
+
+    def min_snr_weights(self, timesteps, gamma: float, v_prediction: bool):
+        """common.py:6363-6397: min(snr, gamma) / snr  (epsilon)  or  / (snr + 1)  (v-prediction), one weight per sample"""
+        snr = self.snr(timesteps)
+        return torch.minimum(snr, torch.full_like(snr, float(gamma))) / (snr + 1.0 if v_prediction else snr)
+
     def sample_timesteps(self, bsz: int, segmented: bool = True):
         """uniform weights (generate_timestep_weights default); bsz > 1: one draw from each of bsz equal segments, high to low
         (segmented_timestep_selection, custom_schedule.py:18-58); drawn on the host: no device sync"""
@@ -298,12 +308,20 @@ class ModelFoundation:
             raise NotImplementedError(f"Unsupported Loss Type {loss_type}")
         if prepared_batch.get("loss_mask_type") or prepared_batch.get("conditioning_type") in ("mask", "segmentation"):
             raise NotImplementedError("conditioning-mask losses are not implemented on the st355 path")
+        weight = None
+        if self.PREDICTION_TYPE in (PredictionTypes.EPSILON, PredictionTypes.V_PREDICTION):
+            gamma = getattr(self.config, "snr_gamma", None)
+            if gamma is not None and gamma > 0:                                    # min-SNR weighting (common.py:6363-6397)
+                weight = self.noise_schedule.min_snr_weights(prepared_batch["timesteps"], gamma, self.PREDICTION_TYPE is PredictionTypes.V_PREDICTION)
+                weight = weight.to(device=model_pred.device, dtype=torch.float32).contiguous()
+            elif loss_type == "l2" and float(getattr(self.config, "snr_weight", 1.0)) != 1.0:
+                weight = torch.full((model_pred.shape[0],), float(self.config.snr_weight), dtype=torch.float32, device=model_pred.device)
         if loss_type == "l2":
-            return _MSELossFn.apply(model_pred, target)
+            return _MSELossFn.apply(model_pred, target, weight)
         # huber / smooth_l1 (common.py:6248-6281): one huber_c per sample — constant, or scheduled on the timestep (common.py:6168-6216)
         huber_c = self.compute_scheduled_huber_c(prepared_batch["timesteps"]).to(device=model_pred.device, dtype=torch.float32)
         huber_c = huber_c.reshape(-1).expand(model_pred.shape[0]).contiguous()
-        return _CondLossFn.apply(model_pred, target, loss_type, huber_c)
+        return _CondLossFn.apply(model_pred, target, loss_type, huber_c, weight)
 
     def compute_scheduled_huber_c(self, timesteps: torch.Tensor) -> torch.Tensor:
         """common.py:6168-6216 (flow-matching branch of the "snr" schedule: sigma = ((1 - t/1000) / (t/1000 + 1e-4))^0.5)"""
@@ -317,8 +335,10 @@ class ModelFoundation:
             alpha = -math.log(base) / float(getattr(self.config, "num_train_timesteps", 1000))
             return torch.exp(-alpha * t)
         if schedule == "snr":
-            if self.PREDICTION_TYPE != PredictionTypes.FLOW_MATCHING:
-                raise NotImplementedError("huber_schedule=snr is wired for flow-matching models only on the st355 path")
+            if self.PREDICTION_TYPE != PredictionTypes.FLOW_MATCHING:      # DDPM: sigma = sqrt((1 - acp_t) / acp_t) (common.py:6199-6205)
+                a = self.noise_schedule.alphas_cumprod.to(timesteps.device)[timesteps.long()].float()
+                s_ = ((1.0 - a) / a) ** 0.5
+                return (1 - base) / (1 + s_) ** 2 + base
             s = t / 1000
             s = ((1.0 - s) / (s + 0.0001)) ** 0.5
             return (1 - base) / (1 + s) ** 2 + base
@@ -335,23 +355,23 @@ class _CondLossFn(torch.autograd.Function):
     """huber / smooth_l1 (conditional_loss) -> per-sample mean -> batch mean, gradient from the same kernel pass"""
 
     @staticmethod
-    def forward(ctx, pred, target, loss_type, huber_c):
-        loss, _per, dpred = ops.cond_loss(pred.to(BF16), target.to(BF16), loss_type, huber_c, want_grad=True)
+    def forward(ctx, pred, target, loss_type, huber_c, weight=None):
+        loss, _per, dpred = ops.cond_loss(pred.to(BF16), target.to(BF16), loss_type, huber_c, weight=weight, want_grad=True)
         ctx.save_for_backward(dpred)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None, None
+        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None, None, None
 
 
 class _MSELossFn(torch.autograd.Function):
     """mean_b(mean_chw((pred - target)^2)) in fp32 with the gradient produced by the same kernel pass (K13)."""
 
     @staticmethod
-    def forward(ctx, pred, target):
-        loss, _per, dpred = ops.mse_loss(pred.to(BF16), target.to(BF16), want_grad=True)
+    def forward(ctx, pred, target, weight=None):
+        loss, _per, dpred = ops.mse_loss(pred.to(BF16), target.to(BF16), weight=weight, want_grad=True)
         ctx.save_for_backward(dpred)
         return loss.reshape(())
 
@@ -359,4 +379,4 @@ class _MSELossFn(torch.autograd.Function):
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
         # g is the upstream scalar (1.0, or the loss scale); fold it without a host sync
-        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None
+        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None

@@ -93,3 +93,15 @@ def test_oracle_unet_runs_and_is_conditioned():
     assert y1.shape == (2, 4, 8, 8) and torch.isfinite(y1).all()
     assert not torch.allclose(y1[0], y2[0]) and torch.allclose(y1[1], y2[1], atol=1e-5)       # timestep conditioning is per sample
     assert not torch.allclose(y1, y3)                                                           # cross-attention sees the text tokens
+
+
+def test_min_snr_weights_match_oracle_formula():
+    """DDPMSchedule.min_snr_weights == min(snr, gamma) / snr (epsilon) or / (snr + 1) (v-prediction) with snr from the oracle's compute_snr"""
+    from oracle import train_math as TM
+    s = DDPMSchedule()
+    t = torch.tensor([0, 13, 500, 998, 999])
+    snr = TM.compute_snr(t, s.alphas_cumprod)
+    assert torch.allclose(s.snr(t), snr, rtol=1e-5)
+    for gamma in (1.0, 5.0):
+        assert torch.allclose(s.min_snr_weights(t, gamma, False), torch.minimum(snr, torch.tensor(gamma)) / snr, rtol=1e-5)
+        assert torch.allclose(s.min_snr_weights(t, gamma, True), torch.minimum(snr, torch.tensor(gamma)) / (snr + 1), rtol=1e-5)

@@ -115,3 +115,26 @@ def test_unet_lora_gradients_match_autograd():
             worst = (r, n)
         assert r < 6e-2, (n, r)
     print(f"[unet lora grads] {len(lora)} tensors, worst {worst[1]}: {worst[0]:.3e}")
+
+
+def test_min_snr_weighted_loss_matches_formula():
+    """DDPM epsilon loss with snr_gamma (common.py:6363-6397): mean_b( w_b * mean_chw (pred - noise)^2 ), w = min(snr, gamma)/snr, + its gradient"""
+    from simpletuner_amd.sdxl.model import SDXL
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    dev = torch.device("cuda", 0)
+    cfg = default_config(model_family="sdxl", model_type="full", snr_gamma=5.0)
+    pl = SDXL(cfg, St355Accelerator(dev))
+    pl.setup_training_noise_schedule()
+    g = torch.Generator().manual_seed(0)
+    pred = torch.randn(3, 4, 16, 16, generator=g).to(BF16).to(dev).requires_grad_(True)
+    noise = torch.randn(3, 4, 16, 16, generator=g).to(BF16).to(dev)
+    t = torch.tensor([5, 400, 990], device=dev)
+    loss = pl.loss({"noise": noise, "timesteps": t}, {"model_prediction": pred})
+    loss.backward()
+    snr = pl.noise_schedule.snr(t.cpu())
+    w = torch.minimum(snr, torch.tensor(5.0)) / snr
+    pf = pred.detach().float().cpu().requires_grad_(True)
+    ref = (((pf - noise.float().cpu()) ** 2).mean(dim=(1, 2, 3)) * w).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, ref.item())
+    assert _rel(pred.grad.cpu(), pf.grad) < 1e-2
