@@ -55,7 +55,7 @@ def hbm_traffic_per_gemm_launch():
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "pixart", "vae"],
+    ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "sd15", "pixart", "vae"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
     ap.add_argument("--lora", action="store_true", help="sdxl only: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA)")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
@@ -221,6 +221,21 @@ def main():
         desc = (f"SDXL UNet2DConditionModel (320/640/1280 ch, 2/10-layer transformers at 64^2/32^2, 2.6 B params) "
                 f"{f'LoRA r{args.rank} on attn1/attn2 to_q/to_k/to_v/to_out.0' if sdxl_lora else 'FULL fine-tune bf16'}, "
                 f"{args.res}^2 ({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
+    elif args.model == "sd15":
+        # BASELINE.json configs[0]: SD 1.5 UNet LoRA rank 16, 512^2, batch 1 (the reference's CPU-runnable plumbing case) — run it with
+        # `--model sd15 --rank 16 --res 512 --batch 1`; --full switches to the full fine-tune
+        from simpletuner_amd.sd1x.model import StableDiffusion1
+        from oracle.unet import UNetConfig, unet_flops_fwd
+        sd15_lora = not args.full
+        cfg.model_type, cfg.use_ema, cfg.learning_rate = ("lora" if sd15_lora else "full"), False, (1e-4 if sd15_lora else 1e-5)
+        plugin = StableDiffusion1(cfg, acc)
+        plugin.load_model()
+        S_txt, txt_dim, pooled_dim = 77, 768, 0
+        n_blocks, D_model = 0, 0
+        sdxl_fwd_flops = unet_flops_fwd(UNetConfig.sd15(), args.res // 8, args.res // 8, 77)
+        desc = (f"SD 1.5 UNet2DConditionModel (320/640/1280/1280 ch, 8 heads of width 40/80/160, 0.86 B params) "
+                f"{f'LoRA r{args.rank} on attn1/attn2 to_q/to_k/to_v/to_out.0' if sd15_lora else 'FULL fine-tune bf16'}, {args.res}^2 "
+                f"({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
     elif args.model == "pixart":
         # BASELINE.json configs[4]: PixArt-Sigma DiT, ControlNet branch (13 copied blocks) trained, 2K latents (256^2 x 4), T5 ctx 300 with mask
         from simpletuner_amd.pixart.model import PixartSigma
@@ -252,7 +267,7 @@ def main():
     if args.model == "pixart":
         pass
     elif args.full:
-        if args.model not in ("sd3", "sdxl"):
+        if args.model not in ("sd3", "sdxl", "sd15"):
             raise SystemExit("--full is wired for --model sd3 / sdxl only")
         plugin.enable_full_finetune()
         desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", "FULL fine-tune (2.0 B bf16 params) + EMA")
@@ -267,7 +282,7 @@ def main():
     def make_batch(hh=None, ww=None):
         hh, ww = hh or lat, ww or lat
         b = {
-            "latent_batch": torch.randn(B, 4 if args.model in ("sdxl", "pixart") else 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
+            "latent_batch": torch.randn(B, 4 if args.model in ("sdxl", "pixart", "sd15") else 16, hh, ww, device=dev, generator=gen).to(torch.bfloat16),
             "prompt_embeds": torch.randn(B, S_txt, txt_dim, device=dev, generator=gen).to(torch.bfloat16),
             "add_text_embeds": torch.randn(B, max(pooled_dim, 8), device=dev, generator=gen).to(torch.bfloat16),
         }
@@ -340,9 +355,9 @@ def main():
         step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
         if args.model == "pixart":
             step_flops = pix_step_flops * B
-        elif args.model == "sdxl" and not args.full:   # LoRA: forward + input gradients (no base weight gradients): 2x forward, attention bwd 2x
+        elif args.model in ("sdxl", "sd15") and not args.full:   # LoRA: forward + input gradients (no base weight gradients): 2x forward, attention bwd 2x
             step_flops = 2.0 * sdxl_fwd_flops * B
-        elif args.model == "sdxl":   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
+        elif args.model in ("sdxl", "sd15"):   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
             step_flops = 3.0 * sdxl_fwd_flops * B
         elif args.full:      # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
             step_flops = 3.0 * (n_blocks * 2.0 * (S_img + S_txt) * 12 * D_model * D_model + n_blocks * 4.0 * (S_img + S_txt) ** 2 * D_model) * B
@@ -367,7 +382,7 @@ def main():
                            "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0) if v["ms"] > 0 else None}
                        for k, v in prof.items() if v["launches"]}
         out = {
-            "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL', pixart='PixArt-Sigma')[args.model]} "
+            "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL', sd15='SD 1.5', pixart='PixArt-Sigma')[args.model]} "
                       f"{'ControlNet branch' if args.model == 'pixart' else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -253,6 +253,8 @@ int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W,
 int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad, int pad);   /* adjoint (gather form) */
 /* in-place row softmax of a bf16 matrix: x[r, :n] = softmax(scale * x[r, :n]) (fp32 math) — the single-head d=512 attention of the VAE mid block */
 int st355_softmax_rows(void* stream, void* x, int64_t ldx, int64_t rows, int n, float scale);
+/* its backward, in place on dp: ds = scale * p * (dp - rowsum(dp * p))  (unfused attention of heads wider than 128: SD1.5's 160 at tiny S) */
+int st355_softmax_rows_bwd(void* stream, const void* p, void* dp, int64_t ld, int64_t rows, int n, float scale);
 int st355_upsample2x(void* stream, const void* x /*grid H,W*/, void* y /*grid 2H,2W*/, int B, int H, int W, int C);
 int st355_upsample2x_bwd(void* stream, const void* dy, void* dx, int B, int H, int W, int C);
 int st355_tokens_to_grid(void* stream, const void* tokens /*[B*H*W, C]*/, const void* residual /*grid or NULL*/, void* grid, int B, int H, int W, int C);
@@ -279,6 +281,9 @@ int st355_geglu_bwd(void* stream, const void* h, int64_t ldh, const void* dout, 
 /* plain head split / merge (no norm / RoPE): token-major column block -> [B,H,S,d] and/or transposed [B,H,d,Sp]; and back */
 int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp);
 int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S);
+/* ... with zero padding: token-major heads of width d_src (multiple of 8) <-> d-wide head-major rows, d in {64, 96, 128} (SD1.5's 40 / 80-wide heads) */
+int st355_head_split_pad(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d_src, int d, int S, int Sp);
+int st355_head_merge_pad(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d_src, int d, int S);
 /* cross-attention (UNet attn2 over the text tokens; PixArt cross-attention): Sq queries against Sk keys.  Layouts as st355_attn_fwd/bwd with
  * Q,Qt,O,dO,lse2 over Sq (Sqp) and K,Kt,Vt,v_rows,dv_rows,key_bias over Sk (Skp); workspace = st355_attn_bwd_workspace(B,H,Sq,Sqp,d). */
 int st355_attn_cross_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O, int64_t ld_o, float* lse2,

@@ -510,3 +510,35 @@ extern "C" int st355_softmax_rows(void* stream, void* x, int64_t ldx, int64_t ro
 #undef SM_LAUNCH
   return st355_check_launch("softmax_rows");
 }
+
+// softmax backward in place on dp: ds[r,:] = scale * p[r,:] * (dp[r,:] - sum_j dp[r,j] p[r,j])   (the unfused attention of heads wider than 128:
+// SD1.5's 160-wide heads at the 16^2 / 8^2 levels — tiny score matrices).  One block per row, n <= 16384.
+__global__ void __launch_bounds__(256) k_softmax_rows_bwd(const bf16* __restrict__ p, bf16* __restrict__ dp, int64_t ld, int n, float scale) {
+  __shared__ float red[4];
+  const bf16* pr = p + (int64_t)blockIdx.x * ld;
+  bf16* dr = dp + (int64_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float s = 0.f;
+  for (int i = tid * 8; i < n; i += 2048) {
+    const bf16x8 a = *(const bf16x8*)(pr + i), b = *(const bf16x8*)(dr + i);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += bf2f(a[j]) * bf2f(b[j]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  for (int i = tid * 8; i < n; i += 2048) {
+    const bf16x8 a = *(const bf16x8*)(pr + i), b = *(const bf16x8*)(dr + i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f2bf(scale * bf2f(a[j]) * (bf2f(b[j]) - dot));
+    *(bf16x8*)(dr + i) = o;
+  }
+}
+extern "C" int st355_softmax_rows_bwd(void* stream, const void* p, void* dp, int64_t ld, int64_t rows, int n, float scale) {
+  ST_REQUIRE(p && dp && rows > 0 && n > 0 && n % 8 == 0 && ld % 8 == 0, "softmax_rows_bwd: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 4.0 * rows * n, 6.0 * rows * n);
+  hipLaunchKernelGGL(k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)p, (bf16*)dp, ld, n, scale);
+  return st355_check_launch("softmax_rows_bwd");
+}

@@ -517,7 +517,7 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
 //   merge: dX [B,H,S,d] -> dst [B*S, ld] token-major
 // ================================================================================================
 template <int HD>
-__global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src, int64_t ld, bf16* __restrict__ X, bf16* __restrict__ Xt, int H, int S, int Sp) {
+__global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src, int64_t ld, bf16* __restrict__ X, bf16* __restrict__ Xt, int H, int S, int Sp, int dsrc) {
   constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;          // lanes per token row (power of two; head_dim 96 leaves 4 of 16 idle)
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TP];
@@ -531,7 +531,10 @@ __global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src
     const int t = t0 + tl;
     const bool valid = t < S;
     const int tt = valid ? t : S - 1;
-    const bf16x8 v = *(const bf16x8*)(src + ((int64_t)b * S + tt) * ld + (int64_t)h * HD + c * 8);
+    bf16x8 v;                                    // dsrc < HD: the source heads are dsrc wide, the rest of the HD-wide head is zero padding
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = f2bf(0.f);
+    if (c * 8 < dsrc) v = *(const bf16x8*)(src + ((int64_t)b * S + tt) * ld + (int64_t)h * dsrc + c * 8);
     if (valid && X) *(bf16x8*)(X + (bh * S + t) * HD + c * 8) = v;
     uint32_t* tq = (uint32_t*)(&tile[tl * TP + c * 8]);
     const u32x4 w = *(const u32x4*)&v;
@@ -557,36 +560,43 @@ __global__ void __launch_bounds__(256) k_head_split(const bf16* __restrict__ src
   }
 }
 template <int HD>
-__global__ void __launch_bounds__(256) k_head_merge(const bf16* __restrict__ dX, bf16* __restrict__ dst, int64_t ld, int H, int S) {
+__global__ void __launch_bounds__(256) k_head_merge(const bf16* __restrict__ dX, bf16* __restrict__ dst, int64_t ld, int H, int S, int dsrc) {
   constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;
   const int b = blockIdx.z, h = blockIdx.y;
   const int t = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, c = threadIdx.x % TPR;
-  if (t >= S || c >= HD / 8) return;
+  if (t >= S || c * 8 >= dsrc) return;
   const int64_t bh = (int64_t)b * H + h;
-  *(bf16x8*)(dst + ((int64_t)b * S + t) * ld + (int64_t)h * HD + c * 8) = *(const bf16x8*)(dX + (bh * S + t) * HD + c * 8);
+  *(bf16x8*)(dst + ((int64_t)b * S + t) * ld + (int64_t)h * dsrc + c * 8) = *(const bf16x8*)(dX + (bh * S + t) * HD + c * 8);
 }
-extern "C" int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp) {
-  ST_REQUIRE(src && (X || Xt) && ld % 8 == 0 && S > 0 && (!Xt || (Sp % 64 == 0 && Sp >= S)), "head_split: bad args");
+// d_src <= d: token-major heads of width d_src land zero-padded in d-wide head-major rows (SD1.5's 40 / 80-wide heads on the 64 / 96 kernels)
+extern "C" int st355_head_split_pad(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d_src, int d, int S, int Sp) {
+  ST_REQUIRE(src && (X || Xt) && ld % 8 == 0 && S > 0 && (!Xt || (Sp % 64 == 0 && Sp >= S)) && d_src > 0 && d_src <= d && d_src % 8 == 0, "head_split: bad args");
   ST_REQUIRE(d == 128 || d == 64 || d == 96, "head_split: head_dim %d not built", d);
   ST_REQUIRE(((uintptr_t)src % 16) == 0, "head_split: misaligned source");
   const double n = (double)B * S * H * d;
   ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, (2.0 + (X ? 2.0 : 0.0) + (Xt ? 2.0 : 0.0)) * n);
   dim3 grid((S + 63) / 64, H, B), block(256);
-  if (d == 96) hipLaunchKernelGGL(k_head_split<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
-  else if (d == 128) hipLaunchKernelGGL(k_head_split<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
-  else hipLaunchKernelGGL(k_head_split<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp);
+  if (d == 96) hipLaunchKernelGGL(k_head_split<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp, d_src);
+  else if (d == 128) hipLaunchKernelGGL(k_head_split<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp, d_src);
+  else hipLaunchKernelGGL(k_head_split<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld, (bf16*)X, (bf16*)Xt, H, S, Sp, d_src);
   return st355_check_launch("head_split");
 }
-extern "C" int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S) {
-  ST_REQUIRE(dX && dst && ld % 8 == 0 && S > 0, "head_merge: bad args");
+extern "C" int st355_head_split(void* stream, const void* src, int64_t ld, void* X, void* Xt, int B, int H, int d, int S, int Sp) {
+  return st355_head_split_pad(stream, src, ld, X, Xt, B, H, d, d, S, Sp);
+}
+extern "C" int st355_head_merge_pad(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d_src, int d, int S) {
+  ST_REQUIRE(dX && dst && ld % 8 == 0 && S > 0 && d_src > 0 && d_src <= d && d_src % 8 == 0, "head_merge: bad args");
   ST_REQUIRE(d == 128 || d == 64 || d == 96, "head_merge: head_dim %d not built", d);
   ST_REQUIRE(((uintptr_t)dst % 16) == 0, "head_merge: misaligned destination");
   const double n = (double)B * S * H * d;
   ProfScope ps(stream, ST355_K_QK_ROPE, 0.0, 4.0 * n);
   const int tpb = 256 / (d / 8 <= 8 ? 8 : 16);
   dim3 grid((S + tpb - 1) / tpb, H, B), block(256);
-  if (d == 96) hipLaunchKernelGGL(k_head_merge<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
-  else if (d == 128) hipLaunchKernelGGL(k_head_merge<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
-  else hipLaunchKernelGGL(k_head_merge<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S);
+  if (d == 96) hipLaunchKernelGGL(k_head_merge<96>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S, d_src);
+  else if (d == 128) hipLaunchKernelGGL(k_head_merge<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S, d_src);
+  else hipLaunchKernelGGL(k_head_merge<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dX, (bf16*)dst, ld, H, S, d_src);
   return st355_check_launch("head_merge");
+}
+extern "C" int st355_head_merge(void* stream, const void* dX, void* dst, int64_t ld, int B, int H, int d, int S) {
+  return st355_head_merge_pad(stream, dX, dst, ld, B, H, d, d, S);
 }

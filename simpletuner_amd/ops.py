@@ -793,21 +793,21 @@ def geglu_bwd(h, dout):
     return dh
 
 
-def head_split(src, B: int, H: int, d: int, S: int, want_x: bool = True, want_xt: bool = True):
-    """src: 2-D column-block view [B*S, H*d] (row stride free) -> (X [B,H,S,d] | None, Xt [B,H,d,Sp] | None, Sp)"""
+def head_split(src, B: int, H: int, d: int, S: int, want_x: bool = True, want_xt: bool = True, d_src: Optional[int] = None):
+    """src: 2-D column-block view [B*S, H*d_src] (row stride free) -> (X [B,H,S,d] | None, Xt [B,H,d,Sp] | None, Sp); d_src < d: zero-padded heads"""
     L = _l.load()
     _chk(src, BF16, "src")
     Sp = (S + 63) // 64 * 64
     X = torch.empty(B, H, S, d, dtype=BF16, device=src.device) if want_x else None
     Xt = torch.zeros(B, H, d, Sp, dtype=BF16, device=src.device) if want_xt else None
-    _l.check(L.st355_head_split(_stream(), _ptr(src), _rows(src, "src"), _ptr(X), _ptr(Xt), B, H, d, S, Sp), "head_split")
+    _l.check(L.st355_head_split_pad(_stream(), _ptr(src), _rows(src, "src"), _ptr(X), _ptr(Xt), B, H, d if d_src is None else d_src, d, S, Sp), "head_split")
     return X, Xt, Sp
 
 
-def head_merge(dX, dst, B: int, H: int, d: int, S: int):
+def head_merge(dX, dst, B: int, H: int, d: int, S: int, d_src: Optional[int] = None):
     L = _l.load()
     _chk(dX, BF16, "dX"); _chk(dst, BF16, "dst")
-    _l.check(L.st355_head_merge(_stream(), _ptr(dX), _ptr(dst), _rows(dst, "dst"), B, H, d, S), "head_merge")
+    _l.check(L.st355_head_merge_pad(_stream(), _ptr(dX), _ptr(dst), _rows(dst, "dst"), B, H, d if d_src is None else d_src, d, S), "head_merge")
     return dst
 
 
@@ -838,3 +838,13 @@ def softmax_rows_(x, scale: float = 1.0):
     _chk(x, BF16, "x")
     _l.check(L.st355_softmax_rows(_stream(), _ptr(x), _rows(x, "x"), x.shape[0], x.shape[1], scale), "softmax_rows")
     return x
+
+
+def softmax_rows_bwd_(p, dp, scale: float = 1.0):
+    """in place on dp: ds = scale * p * (dp - rowsum(dp * p))"""
+    L = _l.load()
+    _chk(p, BF16, "p"); _chk(dp, BF16, "dp")
+    if _rows(p, "p") != _rows(dp, "dp"):
+        raise _l.St355Error("softmax_rows_bwd: p and dp must share a row stride")
+    _l.check(L.st355_softmax_rows_bwd(_stream(), _ptr(p), _ptr(dp), _rows(dp, "dp"), p.shape[0], p.shape[1], scale), "softmax_rows_bwd")
+    return dp

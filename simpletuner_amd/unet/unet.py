@@ -92,8 +92,8 @@ class UNet2DConditionModel(nn.Module):
         for ch, nh, typ in zip(block_out_channels, attention_head_dim, down_block_types):
             if ch % 64 or ch % norm_num_groups:
                 raise ValueError("block_out_channels must be multiples of 64 (GEMM K granule) and of the group count")
-            if typ.startswith("CrossAttn") and ch // nh != 64:
-                raise NotImplementedError(f"attention head_dim {ch // nh} is not built on the st355 path (64 only; SD1.5's 40/80/160 are open)")
+            if typ.startswith("CrossAttn") and (ch % nh or (ch // nh) % 8):
+                raise ValueError(f"attention head_dim {ch / nh} must be a multiple of 8")
         if cross_attention_dim % 64 or (addition_embed_type not in (None, "text_time")):
             raise ValueError("unsupported cross_attention_dim / addition_embed_type")
         self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -550,43 +550,116 @@ class UNet2DConditionModel(nn.Module):
         return self._conv3(T, r.conv2, h, B, H, W, residual=sc)
 
     def _self_attn(self, T, qkv, B, S, heads):
-        C_ = heads * 64
-        scale = 0.125
-        Q, Qt, Sp = ops.head_split(qkv[:, :C_], B, heads, 64, S)
-        K, Kt, _ = ops.head_split(qkv[:, C_:2 * C_], B, heads, 64, S)
-        _, Vt, _ = ops.head_split(qkv[:, 2 * C_:], B, heads, 64, S, want_x=False)
-        O = torch.empty(B * S, C_, dtype=BF16, device=qkv.device)
-        lse = torch.empty(B, heads, S, dtype=F32, device=qkv.device)
-        ops.attn_fwd(Q, K, Vt, O, lse, B, heads, S, Sp, 64, scale)
-        if T is not None:
-            def bwd(dO):
-                dqkv = torch.empty_like(qkv)
-                dQ, dK = torch.empty_like(Q), torch.empty_like(K)
-                ops.attn_bwd(Q, K, Qt, Kt, qkv[:, 2 * C_:], O, dO, lse, dQ, dK, dqkv[:, 2 * C_:], B, heads, S, Sp, 64, scale)
-                ops.head_merge(dQ, dqkv[:, :C_], B, heads, 64, S)
-                ops.head_merge(dK, dqkv[:, C_:2 * C_], B, heads, 64, S)
-                return (dqkv,)
-            T.rec([O], [qkv], bwd)
-        return O
+        C_ = qkv.shape[1] // 3
+        return self._attention(T, qkv, qkv, 0, C_, 2 * C_, C_, B, S, S, heads)
 
     def _cross_attn(self, T, q, kv, B, S, Sk, heads):
-        C_ = heads * 64
-        scale = 0.125
-        Q, Qt, Sp = ops.head_split(q, B, heads, 64, S)
-        K, Kt, Skp = ops.head_split(kv[:, :C_], B, heads, 64, Sk)
-        _, Vt, _ = ops.head_split(kv[:, C_:], B, heads, 64, Sk, want_x=False)
-        O = torch.empty(B * S, C_, dtype=BF16, device=q.device)
-        lse = torch.empty(B, heads, S, dtype=F32, device=q.device)
-        ops.attn_cross_fwd(Q, K, Vt, O, lse, B, heads, S, Sk, Skp, 64, scale)
+        C_ = q.shape[1]
+        return self._attention(T, q, kv, 0, 0, C_, C_, B, S, Sk, heads)
+
+    def _attention(self, T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads):
+        """softmax(q k^T / sqrt(hd)) v over `heads` heads of width hd = C_/heads; q / k / v are column blocks (offsets qo / ko / vo) of the token-major
+        projection outputs.  hd in {64, 96, 128}: the flash kernels on the buffers as they are; other hd <= 128 (SD1.5's 40, 80): zero-padded
+        heads; hd > 128 (SD1.5's 160, at <= 256 tokens): unfused GEMM - softmax - GEMM per head."""
+        hd = C_ // heads
+        hp = 64 if hd <= 64 else 96 if hd <= 96 else 128 if hd <= 128 else 0
+        if hp == 0:
+            return self._attention_unfused(T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads)
+        scale = 1.0 / math.sqrt(hd)
+        dev = qsrc.device
+        self_attn = qsrc is kvsrc
+        M, Mk = B * S, B * Sk
+        Q, Qt, Sp = ops.head_split(qsrc[:, qo:qo + C_], B, heads, hp, S, d_src=hd)
+        K, Kt, Skp = ops.head_split(kvsrc[:, ko:ko + C_], B, heads, hp, Sk, d_src=hd)
+        _, Vt, _ = ops.head_split(kvsrc[:, vo:vo + C_], B, heads, hp, Sk, want_x=False, d_src=hd)
+        exact = hp == hd
+        Cp = heads * hp
+        Op = torch.empty(M, Cp, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, S, dtype=F32, device=dev)
+        if self_attn:
+            ops.attn_fwd(Q, K, Vt, Op, lse, B, heads, S, Sp, hp, scale)
+        else:
+            ops.attn_cross_fwd(Q, K, Vt, Op, lse, B, heads, S, Sk, Skp, hp, scale)
+        O = Op if exact else Op.view(M, heads, hp)[:, :, :hd].reshape(M, C_)
+
+        def pad_cols(t2d, rows):                      # [rows, heads*hd] (any row stride) -> [rows, heads*hp] zero-padded heads
+            o = torch.zeros(rows, heads, hp, dtype=BF16, device=dev)
+            o[:, :, :hd] = t2d.reshape(rows, heads, hd)
+            return o.view(rows, Cp)
+
         if T is not None:
             def bwd(dO):
-                dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+                dq_src = torch.empty_like(qsrc)
+                dkv_src = dq_src if self_attn else torch.empty_like(kvsrc)
                 dQ, dK = torch.empty_like(Q), torch.empty_like(K)
-                ops.attn_cross_bwd(Q, K, Qt, Kt, kv[:, C_:], O, dO, lse, dQ, dK, dkv[:, C_:], B, heads, S, Sp, Sk, Skp, 64, scale)
-                ops.head_merge(dQ, dq, B, heads, 64, S)
-                ops.head_merge(dK, dkv[:, :C_], B, heads, 64, Sk)
-                return dq, dkv
-            T.rec([O], [q, kv], bwd)
+                if exact:
+                    v_rows, dv_rows, dOp = kvsrc[:, vo:vo + C_], dkv_src[:, vo:vo + C_], dO
+                else:
+                    v_rows, dOp = pad_cols(kvsrc[:, vo:vo + C_], Mk), pad_cols(dO, M)
+                    dv_rows = torch.empty(Mk, Cp, dtype=BF16, device=dev)
+                if self_attn:
+                    ops.attn_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, hp, scale)
+                else:
+                    ops.attn_cross_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, Sk, Skp, hp, scale)
+                if not exact:
+                    dkv_src[:, vo:vo + C_] = dv_rows.view(Mk, heads, hp)[:, :, :hd].reshape(Mk, C_)
+                ops.head_merge(dQ, dq_src[:, qo:qo + C_], B, heads, hp, S, d_src=hd)
+                ops.head_merge(dK, dkv_src[:, ko:ko + C_], B, heads, hp, Sk, d_src=hd)
+                return (dq_src,) if self_attn else (dq_src, dkv_src)
+            T.rec([O], [qsrc] if self_attn else [qsrc, kvsrc], bwd)
+        return O
+
+    def _attention_unfused(self, T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads):
+        """heads wider than 128 (SD1.5: 160 at the 16^2 / 8^2 levels): per (image, head) scores = q k^T (GEMM), row softmax, p v (GEMM); backward
+        the same way (two TN GEMMs, two NT GEMMs, the softmax-backward kernel).  The score matrices are tiny at these levels."""
+        hd = C_ // heads
+        scale = 1.0 / math.sqrt(hd)
+        dev = qsrc.device
+        self_attn = qsrc is kvsrc
+        dp = (hd + 63) // 64 * 64
+        Sk8, Sk64, S64 = (Sk + 7) // 8 * 8, (Sk + 63) // 64 * 64, (S + 63) // 64 * 64
+
+        def heads_major(t2d, n, width):               # [B*n, heads*hd] column block -> [B, heads, n_pad, width] zero-padded
+            o = torch.zeros(B, heads, (n + 63) // 64 * 64, width, dtype=BF16, device=dev)
+            o[:, :, :n, :hd] = t2d.reshape(B, n, heads, hd).permute(0, 2, 1, 3)
+            return o
+
+        q3 = heads_major(qsrc[:, qo:qo + C_], S, dp)
+        k3 = heads_major(kvsrc[:, ko:ko + C_], Sk, dp)
+        v3 = heads_major(kvsrc[:, vo:vo + C_], Sk, dp)
+        vt3 = torch.zeros(B, heads, hd, Sk64, dtype=BF16, device=dev)
+        vt3[:, :, :, :Sk] = v3[:, :, :Sk, :hd].transpose(2, 3)
+        P = torch.zeros(B, heads, S64, Sk64, dtype=BF16, device=dev)
+        O = torch.empty(B * S, C_, dtype=BF16, device=dev)
+        for b in range(B):
+            for h in range(heads):
+                sc = P[b, h, :S, :Sk8]
+                ops.gemm(q3[b, h, :S], k3[b, h, :Sk8], out=sc)
+                if Sk8 != Sk:
+                    sc[:, Sk:] = -30000.0
+                ops.softmax_rows_(sc, scale)
+                ops.gemm(P[b, h, :S], vt3[b, h], out=O[b * S:(b + 1) * S, h * hd:(h + 1) * hd])
+        if T is not None:
+            def bwd(dO):
+                dq_src = torch.zeros_like(qsrc) if self_attn else torch.empty_like(qsrc)
+                dkv_src = dq_src if self_attn else torch.zeros_like(kvsrc)
+                dO3 = heads_major(dO, S, dp)
+                kt3 = torch.zeros(B, heads, hd, Sk64, dtype=BF16, device=dev)
+                kt3[:, :, :, :Sk] = k3[:, :, :Sk, :hd].transpose(2, 3)
+                dP = torch.zeros(S64, Sk64, dtype=BF16, device=dev)
+                for b in range(B):
+                    for h in range(heads):
+                        p = P[b, h]
+                        dv = ops.gemm_tn(p[:, :Sk8], dO3[b, h, :, :hd])                           # [Sk8, hd] = P^T dO
+                        ds = dP[:S, :Sk8]
+                        ops.gemm(dO3[b, h, :S], v3[b, h, :Sk8], out=ds)                            # dP = dO V^T
+                        ops.softmax_rows_bwd_(p[:S, :Sk8], ds, scale)
+                        ops.gemm(dP[:S], kt3[b, h], out=dq_src[b * S:(b + 1) * S, qo + h * hd:qo + (h + 1) * hd])      # dQ = dS K
+                        dk = ops.gemm_tn(dP[:, :Sk8], q3[b, h, :, :hd])                            # [Sk8, hd] = dS^T Q
+                        dkv_src[b * Sk:(b + 1) * Sk, ko + h * hd:ko + (h + 1) * hd] = dk[:Sk]
+                        dkv_src[b * Sk:(b + 1) * Sk, vo + h * hd:vo + (h + 1) * hd] = dv[:Sk]
+                return (dq_src,) if self_attn else (dq_src, dkv_src)
+            T.rec([O], [qsrc] if self_attn else [qsrc, kvsrc], bwd)
         return O
 
     def _transformer_fwd(self, T, tr, x, ctx2d, B, H, W, Sk):

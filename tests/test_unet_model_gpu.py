@@ -15,6 +15,16 @@ SMALL = dict(block_out_channels=(64, 128), layers_per_block=1, down_block_types=
              projection_class_embeddings_input_dim=64 + 6 * 64, addition_time_embed_dim=64)
 
 
+# SD1.5-style variants: conv proj_in/out, no addition embedding, heads narrower (40, 80 -> zero-padded flash) and wider (160 -> unfused) than the
+# flash kernels' widths
+SD15_NARROW = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                   up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), transformer_layers_per_block=(1, 1), attention_head_dim=(8, 8),
+                   cross_attention_dim=128, use_linear_projection=False, addition_embed_type=None)
+SD15_WIDE = dict(block_out_channels=(64, 320), layers_per_block=1, down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                 up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 1), attention_head_dim=(1, 2),
+                 cross_attention_dim=128, use_linear_projection=False, addition_embed_type=None)
+
+
 def _rel(a, b):
     a, b = a.float(), b.float()
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
@@ -45,9 +55,11 @@ def test_unet_forward_matches_oracle():
     assert out.shape == ref.shape and r < 2e-2 and cos > 0.9995
 
 
-def test_unet_full_finetune_gradients_match_autograd():
+@pytest.mark.parametrize("arch", ["sdxl_small", "sd15_narrow_heads", "sd15_wide_heads"])
+def test_unet_full_finetune_gradients_match_autograd(arch):
     from simpletuner_amd.unet.unet import UNet2DConditionModel
     dev = "cuda:0"
+    SMALL = {"sdxl_small": globals()["SMALL"], "sd15_narrow_heads": SD15_NARROW, "sd15_wide_heads": SD15_WIDE}[arch]
     m = UNet2DConditionModel(device=dev, **SMALL)
     m.init_synthetic(5)
     m.enable_full_finetune()
@@ -55,10 +67,12 @@ def test_unet_full_finetune_gradients_match_autograd():
     P = {k: v.float().cpu().requires_grad_(True) for k, v in sd.items()}
     sample, t, ehs, te, ti = _inputs(2, 16, 16, dev, seed=1)
     target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9))
-    out = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs={"text_embeds": te.to(dev), "time_ids": ti.to(dev)}, return_dict=False)[0]
+    ack = {"text_embeds": te.to(dev), "time_ids": ti.to(dev)} if arch == "sdxl_small" else None
+    out = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs=ack, return_dict=False)[0]
     loss = ((out.float() - target.to(dev)) ** 2).mean()
     loss.backward()
     ref = unet_forward(P, UNetConfig(**SMALL), sample.float(), t, ehs.float(), {"text_embeds": te.float(), "time_ids": ti.float()})
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-2, _rel(out.detach().cpu(), ref.detach())
     lref = ((ref - target) ** 2).mean()
     lref.backward()
     assert abs(loss.item() - lref.item()) < 1e-3 * max(1.0, abs(lref.item())), (loss.item(), lref.item())
@@ -77,7 +91,7 @@ def test_unet_full_finetune_gradients_match_autograd():
         if r / tol > worst[0]:
             worst = (r / tol, f"{s.name}: {r:.3e}")
         assert r < tol, (s.name, r)
-    print(f"[unet grads] {len(m._specs)} tensors, worst (relative to its tolerance) {worst[1]}")
+    print(f"[unet grads {arch}] {len(m._specs)} tensors, worst (relative to its tolerance) {worst[1]}")
 
 
 def test_unet_lora_gradients_match_autograd():
