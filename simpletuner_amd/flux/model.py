@@ -89,7 +89,11 @@ class Flux(ModelFoundation):
         comp = self.get_trained_component()
         guidance = None
         if getattr(comp.config, "guidance_embeds", False):
-            guidance = torch.tensor(self._flux_guidance_scales(prepared_batch, B), device=dev)
+            scales = tuple(self._flux_guidance_scales(prepared_batch, B))
+            gkey = ("guidance", scales)
+            if gkey not in self._ids_cache:               # cached: a host->device copy is not allowed while a hipGraph is being captured
+                self._ids_cache[gkey] = torch.tensor(scales, device=dev)
+            guidance = self._ids_cache[gkey]
         key = (Hh, Ww, prepared_batch["prompt_embeds"].shape[1])
         if key not in self._ids_cache:
             self._ids_cache[key] = (prepare_latent_image_ids(B, Hh, Ww, dev, BF16),

@@ -298,7 +298,9 @@ class FluxTransformer2DModel(nn.Module):
     # rope tables (FluxPosEmbed, theta=1e4, float64 frequencies -> fp32 tables); cached per id layout
     # ------------------------------------------------------------------------------------------------
     def _rope(self, txt_ids: torch.Tensor, img_ids: torch.Tensor):
-        key = (txt_ids.shape[0], img_ids.shape[0], float(img_ids[-1, 1]), float(img_ids[-1, 2]), float(img_ids[0, 0]))
+        # keyed on the id tensors' identity (the plugin caches them per latent shape): no device->host read per step (that was a host sync in
+        # every step, and is illegal while a hipGraph is being captured)
+        key = (txt_ids.data_ptr(), img_ids.data_ptr(), tuple(txt_ids.shape), tuple(img_ids.shape), txt_ids._version, img_ids._version)
         hit = self._rope_cache.get(key)
         if hit is not None:
             return hit

@@ -172,12 +172,16 @@ class Trainer:
         def clone_tree(d):
             return {k: (v.clone() if isinstance(v, torch.Tensor) and v.is_cuda else clone_tree(v) if isinstance(v, dict) else v) for k, v in d.items()}
 
+        def shallow(d):          # plugins may replace entries of the batch dict (Flux divides `timesteps` by 1000): never let that touch `static`
+            return {k: (shallow(v) if isinstance(v, dict) else v) for k, v in d.items()}
+
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in tensors(prepared))
         entry = self._graphs.get(key)
         if entry is None:
             # warm-up ON A SIDE STREAM (workspaces, kernel attributes, allocator pools, and AccumulateGrad nodes bound to the capture-side stream:
             # a node created on the default stream and kept alive breaks capture), then capture one step
             static = clone_tree(prepared)
+            static_inputs = dict(tensors(static))          # name -> the tensors the captured kernels read; filled from each step's batch
             self.last_loss = None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -185,7 +189,7 @@ class Trainer:
                 for _ in range(2):
                     for p in self.params:
                         p.grad = None
-                    loss = self._eager_forward_backward(static)
+                    loss = self._eager_forward_backward(shallow(static))
                     del loss
             torch.cuda.current_stream().wait_stream(side)
             for p in self.params:
@@ -193,26 +197,12 @@ class Trainer:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
-                loss = self._eager_forward_backward(static)
-            entry = self._graphs[key] = (g, static, loss.detach(), [p.grad for p in self.params])
-        g, static, loss, grads = entry
-        st = dict(tensors(static))
+                loss = self._eager_forward_backward(shallow(static))
+            entry = self._graphs[key] = (g, static_inputs, loss.detach(), [p.grad for p in self.params])
+        g, st, loss, grads = entry
         for k, v in tensors(prepared):
             st[k].copy_(v)
-        import os as _os
-        dbg = _os.environ.get("ST355_DEBUG_NAN") in ("1", "post")
-        comp = self.model.get_trained_component()
-        if _os.environ.get("ST355_DEBUG_NAN") == "1":
-            print("[dbg] pre-replay: w_nan", bool(torch.isnan(comp.arena).any()), "inputs_nan", {k: bool(torch.isnan(v.float()).any()) for k, v in st.items() if v.is_floating_point()}, flush=True)
-        gs = _os.environ.get("ST355_GRAPH_SYNC", "")
-        if "pre" in gs:
-            torch.cuda.current_stream().synchronize()
         g.replay()
-        if "post" in gs:
-            torch.cuda.current_stream().synchronize()
-        if dbg:
-            print("[dbg] post-replay: loss", float(loss), "w_nan", bool(torch.isnan(comp.arena).any()), "grad_nan", bool(torch.isnan(comp.grad_arena).any()),
-                  "gflat_nan", bool(torch.isnan(comp._last_grad_flat).any()), "static_nan", [k for k, v in st.items() if v.is_floating_point() and bool(torch.isnan(v.float()).any())], flush=True)
         for p, gr in zip(self.params, grads):
             p.grad = gr
         return loss.clone()        # the static tensor is overwritten by the next replay: callers keep their own value
