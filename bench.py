@@ -207,7 +207,7 @@ def main():
         desc = (f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
                 f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights")
     elif args.model == "sdxl":
-        # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4 (always the full fine-tune)
+        # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4; --lora = the metric's SDXL-LoRA (adapters on attn1/attn2)
         from simpletuner_amd.sdxl.model import SDXL
         from oracle.unet import UNetConfig, unet_flops_fwd     # FLOP counter only (test infrastructure; nothing of the oracle is executed in the step)
         sdxl_lora = bool(args.lora)
