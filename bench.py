@@ -57,6 +57,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "sd15", "pixart", "vae"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
+    ap.add_argument("--fp8", action="store_true", help="pixart only: fp8-native Linears in the frozen trunk blocks (configs[4]: 'fp8 MFMA')")
     ap.add_argument("--lora", action="store_true", help="sdxl only: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA)")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
                     "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
@@ -242,7 +243,7 @@ def main():
         from oracle.pixart import PixArtConfig, pixart_flops_fwd       # FLOP counter only
         cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
         plugin = PixartSigma(cfg, acc)
-        plugin.load_model(sample_size=256 if args.res >= 2048 else 128)
+        plugin.load_model(sample_size=256 if args.res >= 2048 else 128, fp8_base=bool(args.fp8))
         plugin.controlnet_init(num_layers=13, synthetic_adapter=True)
         S_txt, txt_dim, pooled_dim = 300, 4096, 0
         n_blocks, D_model = 0, 0
@@ -254,7 +255,8 @@ def main():
         # for the linears and 2x for attention is folded into 2x here);  adapter (13): forward + dgrad + wgrad = 3x
         pix_step_flops = f_trunk + 2.0 * 27 * f_blk + 3.0 * 13 * f_blk
         desc = (f"PixArt-Sigma XL/2 (28 blocks, 16x72 heads, D=1152) ControlNet-Transformer branch (13 copied blocks + zero-init projections) trained, trunk "
-                f"frozen, {args.res}^2 ({lat_}^2 latents, S={(lat_ // 2) ** 2}), T5 ctx 300 (120 valid), epsilon objective, AdamW, random-init weights")
+                f"frozen{' with fp8-native Linears (e5m2 x e4m3 MFMA)' if args.fp8 else ''}, {args.res}^2 ({lat_}^2 latents, S={(lat_ // 2) ** 2}), T5 ctx 300 (120 valid), "
+                f"epsilon objective, AdamW, random-init weights")
     else:
         from simpletuner_amd.sd3.model import SD3
         plugin = SD3(cfg, acc)
@@ -386,7 +388,7 @@ def main():
                       f"{'ControlNet branch' if args.model == 'pixart' else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16 (+ fp8 e5m2 x e4m3 trunk Linears)" if getattr(args, "fp8", False) else "bf16", "data": "synthetic",
             "config": {"workload": desc,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "hip_graph": bool(args.graph)},
             "step_model_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),

@@ -88,6 +88,7 @@ int st355_unpatchify(void* stream, const void* packed, void* latents, int B, int
 int st355_timestep_proj(void* stream, const float* t /*[B]*/, void* out /*[B,dim] bf16*/, int B, int dim,
                         float scale /* applied to t first, e.g. 1000 */);
 int st355_silu(void* stream, const void* x, void* y, int64_t n);
+int st355_gelu_tanh(void* stream, const void* x, void* y, int64_t n);   /* GELU(approximate="tanh") as a pass of its own (after an fp8 Linear) */
 int st355_add(void* stream, const void* a, const void* b, void* y, int64_t n);
 int st355_silu_bwd(void* stream, const void* x, const void* dy, void* dx, int64_t n);   /* dx = dy * silu'(x) */
 /* out[m,n] = in[m,n] * gate[(m / rows_per_batch) * gate_stride + n]  (gated-residual backward) */

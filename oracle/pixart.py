@@ -92,7 +92,18 @@ def adaln_single(P, cfg: PixArtConfig, timestep, resolution, aspect_ratio, B, dt
     return _lin(F.silu(emb), P, "adaln_single.linear"), emb
 
 
-def _attn(P, p, x, ctx, H, bias=None):
+def lin_fp8(x, P, name):
+    """Fp8NativeLinear (fp8_native.py:25-119): e4m3 row-scaled weight, e5m2 per-call activation, fp32 accumulate, bf16 result"""
+    from . import train_math as TM
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16)
+    q, sc = TM.fp8_quantize_weight(P[name + ".weight"].to(torch.bfloat16))
+    xq, sa = TM.fp8_quantize_act(x2)
+    b = P.get(name + ".bias")
+    return TM.fp8_linear(xq, sa, q, sc, None if b is None else b.to(torch.bfloat16)).float().reshape(*shp[:-1], -1)
+
+
+def _attn(P, p, x, ctx, H, bias=None, _lin=_lin):
     B, S, D = x.shape
     q, k, v = _lin(x, P, p + "to_q"), _lin(ctx, P, p + "to_k"), _lin(ctx, P, p + "to_v")
     d = D // H
@@ -103,14 +114,14 @@ def _attn(P, p, x, ctx, H, bias=None):
     return _lin((s.softmax(-1) @ v).transpose(1, 2).reshape(B, S, D), P, p + "to_out.0")
 
 
-def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6):
-    """pixart/transformer.py:95-145 with timestep [B, 6D]"""
+def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6, _lin=_lin):
+    """pixart/transformer.py:95-145 with timestep [B, 6D]; `_lin` = the Linear implementation of the block (plain, or lin_fp8)"""
     B, S, D = h.shape
     mod = P[p + "scale_shift_table"][None] + t6.reshape(B, 6, D)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
     n = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale_msa) + shift_msa
-    h = gate_msa * _attn(P, p + "attn1.", n, n, cfg.num_attention_heads) + h
-    h = _attn(P, p + "attn2.", h, ctx, cfg.num_attention_heads, ctx_bias) + h
+    h = gate_msa * _attn(P, p + "attn1.", n, n, cfg.num_attention_heads, _lin=_lin) + h
+    h = _attn(P, p + "attn2.", h, ctx, cfg.num_attention_heads, ctx_bias, _lin=_lin) + h
     n = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale_mlp) + shift_mlp
     ff = _lin(F.gelu(_lin(n, P, p + "ff.net.0.proj"), approximate="tanh"), P, p + "ff.net.2")
     return gate_mlp * ff + h
@@ -136,12 +147,12 @@ def _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio):
     return h, t6, emb, ctx, bias
 
 
-def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, mask, timestep, resolution=None, aspect_ratio=None):
-    """PixArtTransformer2DModel.forward -> [B, out_channels, H, W]"""
+def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, mask, timestep, resolution=None, aspect_ratio=None, fp8_blocks: bool = False):
+    """PixArtTransformer2DModel.forward -> [B, out_channels, H, W]; fp8_blocks: the transformer blocks' Linears in the fp8-native form"""
     hh, ww = latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size
     h, t6, emb, ctx, bias = _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio)
     for i in range(cfg.num_layers):
-        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6)
+        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6, _lin=lin_fp8 if fp8_blocks else _lin)
     return _head(P, cfg, h, emb, hh, ww)
 
 

@@ -326,11 +326,12 @@ __global__ void __launch_bounds__(EW_THREADS) k_unary_binary(const bf16* __restr
   const int64_t nvec = n >> 3;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     bf16x8 av = *(const bf16x8*)(a + i * 8), bv, o;
-    if (OP >= 1) bv = *(const bf16x8*)(b + i * 8);
+    if (OP == 1 || OP == 2) bv = *(const bf16x8*)(b + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float f = bf2f(av[j]);
       if (OP == 0) o[j] = f2bf(f / (1.f + __expf(-f)));
+      else if (OP == 3) o[j] = f2bf(gelu_tanh(f));
       else if (OP == 1) o[j] = f2bf(f + bf2f(bv[j]));
       else { const float sg = 1.f / (1.f + __expf(-f)); o[j] = f2bf(bf2f(bv[j]) * sg * (1.f + f * (1.f - sg))); }   // OP 2: dy * silu'(x)
     }
@@ -341,9 +342,16 @@ __global__ void __launch_bounds__(EW_THREADS) k_unary_binary(const bf16* __restr
     int64_t i = (nvec << 3) + threadIdx.x;
     float f = bf2f(a[i]);
     if (OP == 0) y[i] = f2bf(f / (1.f + __expf(-f)));
+    else if (OP == 3) y[i] = f2bf(gelu_tanh(f));
     else if (OP == 1) y[i] = f2bf(f + bf2f(b[i]));
     else { const float sg = 1.f / (1.f + __expf(-f)); y[i] = f2bf(bf2f(b[i]) * sg * (1.f + f * (1.f - sg))); }
   }
+}
+extern "C" int st355_gelu_tanh(void* stream, const void* x, void* y, int64_t n) {       /* GELU(approximate="tanh") as its own pass (fp8 Linear path: no fused epilogue) */
+  ST_REQUIRE(x && y && n > 0, "gelu_tanh: bad args");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 10.0 * n, 4.0 * n);
+  hipLaunchKernelGGL(k_unary_binary<3>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)nullptr, (bf16*)y, n);
+  return st355_check_launch("gelu_tanh");
 }
 extern "C" int st355_silu(void* stream, const void* x, void* y, int64_t n) {
   ST_REQUIRE(x && y && n > 0, "silu: bad args");

@@ -176,6 +176,15 @@ def silu(x):
     return y
 
 
+def gelu_tanh(x):
+    L = _l.load()
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _l.check(L.st355_gelu_tanh(_stream(), _ptr(x), _ptr(y), x.numel()), "gelu_tanh")
+    return y
+
+
 def silu_bwd(x, dy):
     """dx = dy * silu'(x)"""
     L = _l.load()

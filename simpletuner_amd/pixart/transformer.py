@@ -69,6 +69,7 @@ class _Block:
         self.P = P
         self.G: Dict[str, torch.Tensor] = {}          # gradient views (trainable blocks)
         self.W = None                                  # padded working copies
+        self.fp8 = False                               # frozen blocks only: fp8-native Linears (fp8_native.py:25-119)
 
     @torch.no_grad()
     def refresh(self, dev):
@@ -97,8 +98,17 @@ class _Block:
         W.kv2_w, W.kv2_b = pad_rows([P["attn2.to_k.weight"], P["attn2.to_v.weight"]], [P["attn2.to_k.bias"], P["attn2.to_v.bias"]])
         W.out2_w, W.out2_b = pad_cols(P["attn2.to_out.0.weight"]), P["attn2.to_out.0.bias"]
         W.ff1_w, W.ff1_b, W.ff2_w, W.ff2_b = P["ff.net.0.proj.weight"], P["ff.net.0.proj.bias"], P["ff.net.2.weight"], P["ff.net.2.bias"]
-        for n in ("qkv", "out1", "q2", "out2", "ff1", "ff2"):
-            setattr(W, n + "_wT", getattr(W, n + "_w").t().contiguous())
+        for n in ("qkv", "out1", "q2", "kv2", "out2", "ff1", "ff2"):
+            w = getattr(W, n + "_w")
+            if self.fp8:
+                # fp8-native base weights (quantize_weight_to_fp8: e4m3 with one scale per output row); the input gradient uses the DEQUANTISED
+                # weight exactly like _Fp8NativeLinearFn.backward (fp8_native.py:104-111)
+                q, sc = ops.fp8_quantize_weight(w.contiguous())
+                setattr(W, n + "_q", q); setattr(W, n + "_s", sc)
+                w = (q.view(torch.float8_e4m3fn).to(BF16) * sc.to(BF16).unsqueeze(1))
+                setattr(W, n + "_w", None)
+            if n != "kv2":
+                setattr(W, n + "_wT", w.t().contiguous())
         self.W = W
 
 
@@ -106,8 +116,9 @@ class PixArtTransformer2DModel(nn.Module):
     def __init__(self, num_attention_heads: int = 16, attention_head_dim: int = 72, in_channels: int = 4, out_channels: Optional[int] = 8,
                  num_layers: int = 28, cross_attention_dim: Optional[int] = 1152, sample_size: int = 128, patch_size: int = 2,
                  interpolation_scale: Optional[float] = None, use_additional_conditions: Optional[bool] = None, caption_channels: Optional[int] = 4096,
-                 norm_type: str = "ada_norm_single", device=None, **_ignored):
+                 norm_type: str = "ada_norm_single", device=None, fp8_base: bool = False, **_ignored):
         super().__init__()
+        self.fp8_base = bool(fp8_base)             # base_model_precision = fp8 (fp8_native): every Linear of the frozen blocks runs on the fp8 MFMA path
         if norm_type != "ada_norm_single" or patch_size != 2:
             raise NotImplementedError("PixArt(st355): ada_norm_single blocks with patch_size 2 only")
         H, hd = num_attention_heads, attention_head_dim
@@ -178,6 +189,7 @@ class PixArtTransformer2DModel(nn.Module):
     @torch.no_grad()
     def prepare(self):
         for b in self.blocks:
+            b.fp8 = self.fp8_base
             b.refresh(self.device_)
         P = self.P
         self.patch_w = P["pos_embed.proj.weight"].reshape(self.inner_dim, -1)
@@ -245,6 +257,8 @@ class PixArtTransformer2DModel(nn.Module):
         mod = (blk.P["scale_shift_table"].view(1, 6 * D) + t6).contiguous()             # [B, 6D] (tiny)
         m = [mod[:, k * D:(k + 1) * D] for k in range(6)]                               # shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         train = save and blk.trainable
+        if blk.fp8:
+            return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
         qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
         Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S)
@@ -273,6 +287,47 @@ class PixArtTransformer2DModel(nn.Module):
         if save:
             sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
                                  K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
+        return h3, sv
+
+    def _block_fwd_fp8(self, blk: _Block, h, ctx2d, kbias, mod, m, B, S, Sk, save: bool):
+        """the same block with every Linear in the reference's fp8-native form: e5m2 activations (one scale per call), e4m3 weights (row scales),
+        fp8 MFMA with fp32 accumulation, bf16 out; activation functions / gates / residuals are then passes of their own, as in the reference
+        (where they are separate torch ops around Fp8NativeLinear).  Frozen blocks only (the backward needs input gradients, computed with the
+        dequantised weights)."""
+        D, H, W = self.inner_dim, self.H, blk.W
+        Dp = H * HP
+        scale = 1.0 / math.sqrt(self.hd)
+
+        def lin8(x, name, bias):
+            xq, sa = ops.fp8_quantize_act(x)
+            return ops.linear_fp8(xq, sa, getattr(W, name + "_q"), getattr(W, name + "_s"), bias=bias)
+
+        n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
+        qkv = lin8(n1, "qkv", W.qkv_b)
+        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S)
+        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S)
+        _, Vt, _ = ops.head_split(qkv[:, 2 * Dp:], B, H, HP, S, want_x=False)
+        O = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
+        lse = torch.empty(B, H, S, dtype=F32, device=h.device)
+        ops.attn_fwd(Q, K, Vt, O, lse, B, H, S, Sp, HP, scale)
+        h1 = ops.add(h, ops.scale_cols(lin8(O, "out1", W.out1_b), m[2], S))
+        q2 = lin8(h1, "q2", W.q2_b)
+        kv = lin8(ctx2d, "kv2", W.kv2_b)
+        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S)
+        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk)
+        _, V2t, _ = ops.head_split(kv[:, Dp:], B, H, HP, Sk, want_x=False)
+        O2 = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
+        lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)
+        ops.attn_cross_fwd(Q2, K2, V2t, O2, lse2, B, H, S, Sk, Skp, HP, scale, key_bias=kbias)
+        h2 = ops.add(h1, lin8(O2, "out2", W.out2_b))
+        n2 = ops.ln_modulate_fwd(h2, m[4], m[3], S)
+        pre = lin8(n2, "ff1", W.ff1_b)
+        a = ops.gelu_tanh(pre)
+        h3 = ops.add(h2, ops.scale_cols(lin8(a, "ff2", W.ff2_b), m[5], S))
+        sv = None
+        if save:
+            sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=None, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
+                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=None)
         return h3, sv
 
     def _block_bwd(self, blk: _Block, sv, d3, ctx2d, kbias, B, S, Sk):

@@ -87,3 +87,24 @@ def test_pixart_controlnet_branch_gradients_match_autograd():
             worst = (r / tol, f"{k}: {r:.3e}")
         assert r < tol, (k, r)
     print(f"[pixart controlnet grads] {len(names)} tensors, worst (relative to its tolerance) {worst[1]}")
+
+
+def test_pixart_fp8_trunk_matches_fp8_oracle():
+    """base_model_precision fp8 (fp8_native.py): every Linear of the frozen blocks as e5m2 x e4m3 on the fp8 MFMA path vs the oracle with the
+    reference's quantisers in every block Linear.  Tolerances: vs the fp8 oracle rel-L2 <= 5e-2 (same quantisation points, bf16 rounding placement
+    differs); vs the bf16/fp32 oracle <= 2e-1 (that is the fp8 error itself: e5m2 activations carry 2 mantissa bits)."""
+    from simpletuner_amd.pixart.transformer import PixArtTransformer2DModel
+    dev = "cuda:0"
+    arch = dict(num_attention_heads=16, attention_head_dim=72, num_layers=2, caption_channels=128, sample_size=128, cross_attention_dim=1152)
+    m = PixArtTransformer2DModel(device=dev, fp8_base=True, **arch)
+    m.init_synthetic(11)
+    P = {k: v.detach().float().cpu() for k, v in m.named_parameters()}
+    lat, cond, enc, mask, t = _inputs(hw=(16, 16))
+    out = m(lat.to(dev), encoder_hidden_states=enc.to(dev), timestep=t.to(dev), encoder_attention_mask=mask.to(dev), return_dict=False)[0]
+    cfg = PixArtConfig(**arch)
+    res, ar = torch.tensor([[16.0, 16.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1)
+    ref8 = pixart_forward(P, cfg, lat.float(), enc.float(), mask, t, res, ar, fp8_blocks=True)
+    ref = pixart_forward(P, cfg, lat.float(), enc.float(), mask, t, res, ar)
+    r8, r = _rel(out.cpu(), ref8), _rel(out.cpu(), ref)
+    print(f"[pixart fp8 trunk] vs fp8 oracle {r8:.3e}, vs fp32 oracle {r:.3e} (fp8 oracle vs fp32 oracle {_rel(ref8, ref):.3e})")
+    assert r8 < 5e-2 and r < 2e-1
