@@ -612,11 +612,25 @@ def grid_zeros(B: int, H: int, W: int, C_: int, device, pool: bool = False):
     return torch.zeros(grid_rows(B, H, W), C_, dtype=BF16, device=device)
 
 
+def _grid_out(B: int, H: int, W: int, C_: int, device, conv: bool = False):
+    """output buffer of a grid kernel WITHOUT the full zero-fill pass: only the rows the kernel does not write are zeroed —
+    the 64 tail rows for the layout kernels (they write every grid position, borders as zero), plus the first / last W+3 border positions for
+    st355_conv_bf16 (its GEMM covers rows [W+3, rows - W - 3))."""
+    n = B * (H + 2) * (W + 2)
+    t = torch.empty(n + 64, C_, dtype=BF16, device=device)
+    if conv:
+        t[:W + 3].zero_()
+        t[n - (W + 3):].zero_()
+    else:
+        t[n:].zero_()
+    return t
+
+
 def grid_from_nchw(x, Cpad: int):
     L = _l.load()
     _chk(x, BF16, "x")
     B, Cn, H, W = x.shape
-    g = grid_zeros(B, H, W, Cpad, x.device)
+    g = _grid_out(B, H, W, Cpad, x.device)
     _l.check(L.st355_grid_from_nchw(_stream(), _ptr(x.contiguous()), _ptr(g), B, Cn, H, W, Cpad), "grid_from_nchw")
     return g
 
@@ -640,7 +654,7 @@ def conv(x, w, B: int, H: int, W: int, bias=None, img_add=None, residual=None, t
     if x.shape[0] != grid_rows(B, H, W):
         raise _l.St355Error(f"conv: x has {x.shape[0]} rows, a ({B},{H},{W}) grid has {grid_rows(B, H, W)}")
     if out is None:
-        out = grid_zeros(B, H, W, Cout, x.device)
+        out = _grid_out(B, H, W, Cout, x.device, conv=True)
     if bias is not None:
         _chk(bias, BF16, "bias")
     if img_add is not None:
@@ -669,7 +683,7 @@ def im2col3x3(x, B: int, H: int, W: int, stride: int = 1, pad: int = 1):
     _chk(x, BF16, "x")
     Cn = x.shape[1]
     Kpad = (9 * Cn + 63) // 64 * 64
-    col = grid_zeros(B, H // stride, W // stride, Kpad, x.device)
+    col = _grid_out(B, H // stride, W // stride, Kpad, x.device)
     _l.check(L.st355_im2col3x3(_stream(), _ptr(x), _ptr(col), B, H, W, Cn, stride, Kpad, pad), "im2col3x3")
     return col
 
@@ -677,7 +691,7 @@ def im2col3x3(x, B: int, H: int, W: int, stride: int = 1, pad: int = 1):
 def col2im3x3(dcol, B: int, H: int, W: int, Cn: int, stride: int = 1, pad: int = 1):
     L = _l.load()
     _chk(dcol, BF16, "dcol")
-    dx = grid_zeros(B, H, W, Cn, dcol.device)
+    dx = _grid_out(B, H, W, Cn, dcol.device)
     _l.check(L.st355_col2im3x3(_stream(), _ptr(dcol), _ptr(dx), B, H, W, Cn, stride, dcol.shape[1], pad), "col2im3x3")
     return dx
 
@@ -685,7 +699,7 @@ def col2im3x3(dcol, B: int, H: int, W: int, Cn: int, stride: int = 1, pad: int =
 def upsample2x(x, B: int, H: int, W: int):
     L = _l.load()
     _chk(x, BF16, "x")
-    y = grid_zeros(B, 2 * H, 2 * W, x.shape[1], x.device)
+    y = _grid_out(B, 2 * H, 2 * W, x.shape[1], x.device)
     _l.check(L.st355_upsample2x(_stream(), _ptr(x), _ptr(y), B, H, W, x.shape[1]), "upsample2x")
     return y
 
@@ -693,7 +707,7 @@ def upsample2x(x, B: int, H: int, W: int):
 def upsample2x_bwd(dy, B: int, H: int, W: int):
     L = _l.load()
     _chk(dy, BF16, "dy")
-    dx = grid_zeros(B, H, W, dy.shape[1], dy.device)
+    dx = _grid_out(B, H, W, dy.shape[1], dy.device)
     _l.check(L.st355_upsample2x_bwd(_stream(), _ptr(dy), _ptr(dx), B, H, W, dy.shape[1]), "upsample2x_bwd")
     return dx
 
@@ -701,7 +715,7 @@ def upsample2x_bwd(dy, B: int, H: int, W: int):
 def tokens_to_grid(tokens, B: int, H: int, W: int, residual=None):
     L = _l.load()
     _chk(tokens, BF16, "tokens")
-    g = grid_zeros(B, H, W, tokens.shape[1], tokens.device)
+    g = _grid_out(B, H, W, tokens.shape[1], tokens.device)
     _l.check(L.st355_tokens_to_grid(_stream(), _ptr(tokens), _ptr(residual), _ptr(g), B, H, W, tokens.shape[1]), "tokens_to_grid")
     return g
 
@@ -730,7 +744,7 @@ def groupnorm_fwd(x, gamma, beta, B: int, H: int, W: int, groups: int = 32, eps:
     L = _l.load()
     _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
     Cn = x.shape[1]
-    y = torch.empty(B * H * W, Cn, dtype=BF16, device=x.device) if out_tokens else grid_zeros(B, H, W, Cn, x.device)
+    y = torch.empty(B * H * W, Cn, dtype=BF16, device=x.device) if out_tokens else _grid_out(B, H, W, Cn, x.device)
     stats = torch.empty(B, Cn, 2, dtype=F32, device=x.device)
     _l.check(L.st355_groupnorm_fwd(_stream(), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, H, W, Cn, groups, eps, 1 if silu else 0,
                                    1 if out_tokens else 0, _ptr(_gn_workspace(B, H, W, Cn, x.device))), "groupnorm_fwd")
@@ -742,7 +756,7 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, B: int, H: int, W: int, groups: int
     L = _l.load()
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(stats, F32, "stats")
     Cn = x.shape[1]
-    dx = grid_zeros(B, H, W, Cn, x.device)
+    dx = _grid_out(B, H, W, Cn, x.device)
     _l.check(L.st355_groupnorm_bwd(_stream(), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dadd), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                    B, H, W, Cn, groups, 1 if silu else 0, 1 if dy_tokens else 0, 1 if accumulate_params else 0,
                                    _ptr(_gn_workspace(B, H, W, Cn, x.device))), "groupnorm_bwd")
