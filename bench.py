@@ -371,7 +371,7 @@ def main():
             g = prof["gemm"]
             if g["ms"] > 0:
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-                traffic, tsrc = hbm_traffic_per_gemm_launch()
+                traffic, tsrc = hbm_traffic_per_gemm_launch() if args.model == "flux" else (None, None)    # the committed PMC passes are of the default command
                 roof = {"bound": "mfma", "kernel": "k_gemm_* (all schedules / epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes / launch",
                         "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"])),
