@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (images); 4 amortises the 256-CU tile quantisation of M=4608")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (images).  Defaults: flux 8 (M = 36 864 token rows: 1728 tiles of 256x256 = 6.75 "
+                    "waves over 256 CUs, 96 %% wave efficiency; batch 4 is 3.375 waves = 84 %%), sd3 / sdxl / vae 4 (configs[1] names batch 4), sd15 / pixart 1")
     ap.add_argument("--layers", type=int, default=19)
     ap.add_argument("--single-layers", type=int, default=38)
     ap.add_argument("--rank", type=int, default=32)
@@ -77,7 +78,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = {"flux": 8, "sd3": 4, "sdxl": 4, "vae": 4, "sd15": 1, "pixart": 1}[a.model]
+    return a
 
 
 def cpu_baseline(args):
