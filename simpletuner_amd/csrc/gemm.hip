@@ -800,7 +800,7 @@ __device__ __forceinline__ void wait_vm_rt(int n) {    // n = LDS-DMA pieces tha
 // F8 = true: the fp8-native Linear (fp8.hip): A = e5m2 activations, B = e4m3 weights, one byte per element.  The byte geometry of the
 // ring is unchanged (128-byte rows = 128 K-elements per K-tile, same swizzle); a phase then runs 16 MFMAs (8 k-steps of
 // v_mfma_f32_32x32x16_fp8_bf8) on fragments fetched with 8-byte reads, i.e. twice the MFMA work per LDS-DMA byte.
-template <int EPI, bool TN, bool F8 = false>
+template <int EPI, bool TN, bool F8 = false, bool CONV = false>     // CONV: the A operand's K-tiles are row-shifted views (st355_conv_bf16)
 __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   constexpr int ES = F8 ? 1 : 2;               // bytes per operand element
   constexpr int KSN = F8 ? 8 : 4;              // k-steps (MFMAs per accumulator) per K-tile
@@ -845,7 +845,8 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const uint32_t lda_b = (uint32_t)p.lda * ES, ldb_b = (uint32_t)p.ldb * ES;
   const int64_t xk_step = TN ? (int64_t)PQ_BK * lda_b : PQ_BK * 2;     // bytes per K-tile along the contraction
   const int64_t wk_step = TN ? (int64_t)PQ_BK * ldb_b : PQ_BK * 2;
-  const bool conv = !TN && !F8 && p.conv_taps != 0;
+  constexpr bool conv = CONV;                  // compile-time: the tap arithmetic costs the plain GEMM's K loop nothing
+  static_assert(!(CONV && (TN || F8)), "conv mode is the NT bf16 form");
   if (!conv) xbase += t_first * xk_step;
   wbase += t_first * wk_step;
 
@@ -1284,6 +1285,13 @@ static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
   hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq");
 }
+template <int EPI>
+static int launch_pq_conv(void* stream, const GemmGroup& g, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  hipLaunchKernelGGL((k_gemm_pq<EPI, false, false, true>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_pq_conv");
+}
 static int p4_tiles(const GemmP& p) { return ((p.M + P4_BM - 1) / P4_BM) * ((p.N + P4_BN - 1) / P4_BN); }
 
 static int p3_tiles(const GemmP& p) { return ((p.M + P3_BM - 1) / P3_BM) * ((p.N + P3_BN - 1) / P3_BN); }
@@ -1485,7 +1493,7 @@ extern "C" int st355_conv_bf16(void* stream, const void* x, const void* w, const
   if (gemm_impl_choice() >= 4 && p4_tiles(p) >= min_tiles_256()) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
-    return residual ? launch_pq<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_pq<ST355_EPI_NONE>(stream, g, g.tiles0);
+    return residual ? launch_pq_conv<ST355_EPI_ADD>(stream, g, g.tiles0) : launch_pq_conv<ST355_EPI_NONE>(stream, g, g.tiles0);
   }
   return residual ? launch_s2<ST355_EPI_ADD>(stream, p) : launch_s2<ST355_EPI_NONE>(stream, p);
 }
