@@ -105,3 +105,41 @@ def test_min_snr_weights_match_oracle_formula():
     for gamma in (1.0, 5.0):
         assert torch.allclose(s.min_snr_weights(t, gamma, False), torch.minimum(snr, torch.tensor(gamma)) / snr, rtol=1e-5)
         assert torch.allclose(s.min_snr_weights(t, gamma, True), torch.minimum(snr, torch.tensor(gamma)) / (snr + 1), rtol=1e-5)
+
+
+def test_tape_reverse_sweep_sums_fanout_gradients():
+    """the UNet engine's reverse tape (simpletuner_amd/unet/unet.py::Tape) vs autograd on a tiny graph with a skip connection and a shared input
+    (the two places a UNet sums gradients: up-block concatenation skips, the time embedding feeding every ResNet)."""
+    import simpletuner_amd.ops as ops
+    from simpletuner_amd.unet.unet import Tape
+    real_add = ops.add
+    ops.add = lambda a, b: a + b                      # the tape sums meeting gradients with ops.add (a HIP launch on device tensors)
+    try:
+        x = torch.randn(4, 3, dtype=torch.float64, requires_grad=True)
+        e = torch.randn(4, 3, dtype=torch.float64, requires_grad=True)
+        # reference
+        h1 = x * 2 + e
+        h2 = torch.tanh(h1) * e
+        y = torch.cat([h2, h1], dim=1).sum(dim=1, keepdim=True) * h2
+        g = torch.randn_like(y)
+        y.backward(g)
+        # same graph on the tape
+        T = Tape()
+        xd, ed = x.detach(), e.detach()
+        grads = {}
+        T.rec([xd], [None], lambda d: (grads.__setitem__("x", d) or None,))     # leaf sentinels (first on the tape = last in the sweep)
+        T.rec([ed], [None], lambda d: (grads.__setitem__("e", d) or None,))
+        a1 = xd * 2 + ed
+        T.rec([a1], [xd, ed], lambda d: (2 * d, d))
+        a2 = torch.tanh(a1) * ed
+        T.rec([a2], [a1, ed], lambda d: (d * ed * (1 - torch.tanh(a1) ** 2), d * torch.tanh(a1)))
+        c = torch.cat([a2, a1], dim=1)
+        T.rec([c], [a2, a1], lambda d: (d[:, :3], d[:, 3:]))
+        s = c.sum(dim=1, keepdim=True)
+        T.rec([s], [c], lambda d: (d.expand(-1, 6),))
+        out = s * a2
+        T.rec([out], [s, a2], lambda d: ((d * a2).sum(dim=1, keepdim=True), d * s))
+        T.backward(out, g)
+        assert torch.allclose(grads["x"], x.grad) and torch.allclose(grads["e"], e.grad)
+    finally:
+        ops.add = real_add
