@@ -229,8 +229,9 @@ class ModelFoundation:
         mask = batch.get("encoder_attention_mask")
         if mask is not None and hasattr(mask, "to"):
             batch["encoder_attention_mask"] = mask.to(device=dev, dtype=wd)
-        if getattr(self.config, "input_perturbation", 0) != 0 or getattr(self.config, "offset_noise", False):
-            raise NotImplementedError("input_perturbation / offset_noise are not implemented on the st355 path")
+        perturb = getattr(self.config, "input_perturbation", 0) or 0
+        if self.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING and perturb != 0:
+            raise NotImplementedError("input_perturbation with the fused flow-matching noising pass is not implemented on the st355 path")
 
         lat = batch["latents"]
         batch["noise_shape_ref"] = lat
@@ -261,13 +262,24 @@ class ModelFoundation:
             noise = batch.get("noise")
             if noise is None:
                 noise = torch.randn_like(lat)
+                if getattr(self.config, "offset_noise", False):                       # common.py:5940-5949 ([B,C,1,1] offset, drawn with a probability)
+                    import random
+                    prob = float(getattr(self.config, "noise_offset_probability", 1.0))
+                    if prob == 1.0 or random.random() < prob:
+                        noise = noise + float(getattr(self.config, "noise_offset", 0.1)) * torch.randn(lat.shape[0], lat.shape[1], 1, 1, device=dev, dtype=lat.dtype)
+            noise = noise.to(device=dev, dtype=wd)
+            input_noise = noise
+            steps_ = getattr(self.config, "input_perturbation_steps", None)
+            if perturb != 0 and (not steps_ or state.get("global_step", 0) < steps_):     # common.py:5957-5968: perturb the INPUT noise only
+                p_ = float(perturb) * ((1.0 - state.get("global_step", 0) / steps_) if steps_ else 1.0)
+                input_noise = noise + p_ * torch.randn_like(lat)
             a, b = sched.mix_coefficients(batch["timesteps"])
-            noisy, vel = ops.ddpm_noise_mix(lat, noise.to(device=dev, dtype=wd), a, b, want_v=self.PREDICTION_TYPE is PredictionTypes.V_PREDICTION)
+            noisy, _ = ops.ddpm_noise_mix(lat, input_noise, a, b, want_v=False)
             batch["noise"] = noise
-            batch["input_noise"] = noise
+            batch["input_noise"] = input_noise
             batch["noisy_latents"] = noisy
-            if vel is not None:
-                batch["velocity_target"] = vel
+            if self.PREDICTION_TYPE is PredictionTypes.V_PREDICTION:                  # get_velocity uses the un-perturbed noise (common.py:4649-4653)
+                batch["velocity_target"] = ops.ddpm_noise_mix(lat, noise, a, b, want_v=True)[1]
         batch.pop("noise_shape_ref", None)
         return self.prepare_batch_conditions(batch=batch, state=state)
 

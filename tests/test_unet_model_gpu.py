@@ -152,3 +152,23 @@ def test_min_snr_weighted_loss_matches_formula():
     ref.backward()
     assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, ref.item())
     assert _rel(pred.grad.cpu(), pf.grad) < 1e-2
+
+
+def test_ddpm_prepare_batch_offset_noise_and_input_perturbation():
+    """common.py:5940-5968: the offset is part of `noise` (the epsilon target), the perturbation only of `input_noise`; x_t is built from input_noise"""
+    from simpletuner_amd.sdxl.model import SDXL
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    dev = torch.device("cuda", 0)
+    cfg = default_config(model_family="sdxl", model_type="full", offset_noise=True, noise_offset=0.1, noise_offset_probability=1.0, input_perturbation=0.1)
+    pl = SDXL(cfg, St355Accelerator(dev))
+    pl.setup_training_noise_schedule()
+    torch.manual_seed(3)
+    lat = torch.randn(2, 4, 16, 16, device=dev).to(BF16)
+    t = torch.tensor([10, 900])
+    out = pl.prepare_batch({"latent_batch": lat, "prompt_embeds": torch.zeros(2, 9, 128, device=dev, dtype=BF16), "timesteps": t}, {"global_step": 0})
+    n, n_in = out["noise"].float(), out["input_noise"].float()
+    assert not torch.equal(n, n_in) and (n_in - n).std().item() == pytest.approx(0.1, rel=0.2)
+    assert pl.get_prediction_target(out) is out["noise"]
+    a, b = pl.noise_schedule.mix_coefficients(t.to(dev))
+    ref = a.view(-1, 1, 1, 1) * lat.float() + b.view(-1, 1, 1, 1) * n_in
+    assert _rel(out["noisy_latents"], ref) < 5e-3
