@@ -132,19 +132,44 @@ class DDPMSchedule:
         snr = self.snr(timesteps)
         return torch.minimum(snr, torch.full_like(snr, float(gamma))) / (snr + 1.0 if v_prediction else snr)
 
-    def sample_timesteps(self, bsz: int, segmented: bool = True):
-        """uniform weights (generate_timestep_weights default); bsz > 1: one draw from each of bsz equal segments, high to low
-        (segmented_timestep_selection, custom_schedule.py:18-58); drawn on the host: no device sync"""
+    @staticmethod
+    def timestep_weights(config, T: int) -> torch.Tensor:
+        """generate_timestep_weights (custom_schedule.py:61-100): uniform, or a multiplier on the later / earlier / [begin, end) timesteps"""
+        w = torch.ones(T)
+        strat = getattr(config, "timestep_bias_strategy", "none") if config is not None else "none"
+        n = int(float(getattr(config, "timestep_bias_portion", 0.25)) * T) if config is not None else 0
+        if strat == "later":
+            idx = slice(-n, None)
+        elif strat == "earlier":
+            idx = slice(0, n)
+        elif strat == "range":
+            lo, hi = int(config.timestep_bias_begin), int(config.timestep_bias_end)
+            if lo < 0 or hi > T:
+                raise ValueError("timestep_bias_begin / timestep_bias_end must lie inside [0, num_train_timesteps]")
+            idx = slice(lo, hi)
+        else:
+            return w
+        mult = float(getattr(config, "timestep_bias_multiplier", 1.0))
+        if mult <= 0:
+            raise ValueError("timestep_bias_multiplier must be positive (use timestep_bias_strategy=none to disable the bias)")
+        w[idx] *= mult
+        return w / w.sum()
+
+    def sample_timesteps(self, bsz: int, segmented: bool = True, weights: Optional[torch.Tensor] = None):
+        """weights: generate_timestep_weights (uniform by default); bsz > 1: one draw from each of bsz equal segments, high to low
+        (segmented_timestep_selection, custom_schedule.py:18-58, same draw order as the reference); drawn on the host: no device sync"""
         T = self.config.num_train_timesteps
+        weights = torch.ones(T) if weights is None else weights.clone()
         if bsz == 1 or not segmented:
-            return torch.multinomial(torch.ones(T), bsz, replacement=True).long()
+            return torch.multinomial(weights, bsz, replacement=True).long()
         seg = max(T // bsz, 1)
         out = []
         for i in range(bsz):
             start = T - 1 - i * seg
             end = max(start - seg, 0) if i != bsz - 1 else 0
-            w = torch.ones(start + 1 - end)
-            out.append(end + int(torch.multinomial(w / w.sum(), 1).item()))
+            w = weights[end:start + 1]
+            w /= w.sum()                                   # in place on the slice, as the reference does (:50)
+            out.append(end + int(torch.multinomial(w, 1).item()))
         return torch.tensor(out, dtype=torch.long)
 
 
@@ -257,7 +282,8 @@ class ModelFoundation:
             bsz = lat.shape[0]
             given_t = batch.get("timesteps")
             if given_t is None:
-                given_t = sched.sample_timesteps(bsz, segmented=not getattr(self.config, "disable_segmented_timestep_sampling", False))
+                given_t = sched.sample_timesteps(bsz, segmented=not getattr(self.config, "disable_segmented_timestep_sampling", False),
+                                                 weights=DDPMSchedule.timestep_weights(self.config, sched.config.num_train_timesteps))
             batch["timesteps"] = given_t.to(device=dev).long()
             noise = batch.get("noise")
             if noise is None:

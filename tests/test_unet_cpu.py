@@ -143,3 +143,18 @@ def test_tape_reverse_sweep_sums_fanout_gradients():
         assert torch.allclose(grads["x"], x.grad) and torch.allclose(grads["e"], e.grad)
     finally:
         ops.add = real_add
+
+
+def test_ddpm_sampling_matches_reference_code_outputs():
+    """DDPMSchedule.timestep_weights / sample_timesteps vs the outputs of the reference's generate_timestep_weights and
+    segmented_timestep_selection executed with a pinned torch RNG (tools/gen_golden.py::gen_ddpm_sampling -> tests/golden/ddpm_sampling_vectors.pt)"""
+    from pathlib import Path
+    from types import SimpleNamespace
+    G = torch.load(Path(__file__).parent / "golden" / "ddpm_sampling_vectors.pt")
+    for strat, (args, want) in G["weights"].items():
+        got = DDPMSchedule.timestep_weights(SimpleNamespace(**args), 1000)
+        assert torch.equal(got, want), strat
+    s = DDPMSchedule()
+    for bsz, seed, want in G["segmented"]:
+        torch.manual_seed(seed)
+        assert torch.equal(s.sample_timesteps(bsz), want), (bsz, seed)

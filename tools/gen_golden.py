@@ -200,10 +200,35 @@ def gen_fp8():
     print(f"wrote {out_p}: scale_a {float(rec['scale_a'][0])}")
 
 
+def gen_ddpm_sampling():
+    """generate_timestep_weights + segmented_timestep_selection (helpers/training/custom_schedule.py:18-100) executed as written, with the
+    torch RNG pinned -> tests/golden/ddpm_sampling_vectors.pt"""
+    from types import SimpleNamespace
+    p = REF / "helpers" / "training" / "custom_schedule.py"
+    seg, gen_w = extract(p, ["segmented_timestep_selection", "generate_timestep_weights"])
+    G = {"weights": {}, "segmented": []}
+    for strat, extra in (("none", {}), ("later", dict(timestep_bias_portion=0.25, timestep_bias_multiplier=2.0)),
+                         ("earlier", dict(timestep_bias_portion=0.5, timestep_bias_multiplier=3.0)),
+                         ("range", dict(timestep_bias_portion=0.25, timestep_bias_multiplier=4.0, timestep_bias_begin=200, timestep_bias_end=500))):
+        args = SimpleNamespace(timestep_bias_strategy=strat, timestep_bias_portion=0.25, timestep_bias_multiplier=1.0, timestep_bias_begin=0, timestep_bias_end=1000)
+        for k, v in extra.items():
+            setattr(args, k, v)
+        G["weights"][strat] = (dict(vars(args)), gen_w(args, 1000).clone())
+    cfg = SimpleNamespace(refiner_training=False, refiner_training_invert_schedule=False, refiner_training_strength=0.2)
+    for bsz in (2, 4, 7):
+        for seed in (0, 1, 2):
+            torch.manual_seed(seed)
+            G["segmented"].append((bsz, seed, seg(1000, bsz, torch.ones(1000), cfg).clone()))
+    out = OUT.parent / "ddpm_sampling_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
     gen_adamw_bf16()
     gen_loss()
     gen_fp8()
+    gen_ddpm_sampling()
     torch.manual_seed(1234)
     G = {}
     cite = {}
