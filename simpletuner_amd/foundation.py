@@ -214,12 +214,55 @@ class ModelFoundation:
 
     # ---- sigma / timestep sampling (common.py:4994-5090) ----
     def sample_flow_sigmas(self, batch: dict, state: dict):
+        """common.py:4994-5090: mixflow | custom timestep list (fixed-list / round-robin) | sigmoid-normal (default) | uniform | Beta | the
+        "fast" discrete schedule; the cubic-spline distribution is not implemented"""
         cfg = self.config
         bsz = batch["latents"].shape[0]
         dev = self.accelerator.device
-        for unsupported in ("mixflow_enabled", "flow_custom_timesteps", "flux_fast_schedule"):
-            if getattr(cfg, unsupported, None):
-                raise NotImplementedError(f"{unsupported} is not implemented on the st355 path")
+        shape_ref = batch.get("noise_shape_ref", batch.get("noise", batch["latents"]))
+        if getattr(cfg, "flow_cubic_schedule_weights", None):
+            raise NotImplementedError("flow_cubic_schedule_weights is not implemented on the st355 path")
+        if getattr(cfg, "mixflow_enabled", False) is True:
+            # sigma increases toward noise: the paper's t ~ Beta(2,1) becomes sigma = 1 - sqrt(U) ~ Beta(1,2)   (common.py:5001-5007)
+            sigmas = 1.0 - torch.sqrt(torch.rand((bsz,), device=dev))
+            sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
+            return sigmas, sigmas * 1000.0
+        custom = self._normalize_flow_custom_timesteps(getattr(cfg, "flow_custom_timesteps", None))
+        if custom is not None:
+            mode = str(getattr(cfg, "flow_timesteps_mode", "fixed-list") or "fixed-list").replace("_", "-")
+            if mode not in {"fixed-list", "round-robin"}:
+                raise ValueError("flow_timesteps_mode must be either 'fixed-list' or 'round-robin'.")
+            if torch.max(custom) <= 1.0:                                   # values <= 1 are sigmas, otherwise timesteps in [0, 1000]
+                base_s = custom.clamp(0.0, 1.0); base_t = base_s * 1000.0
+            else:
+                base_t = custom.clamp(0.0, 1000.0); base_s = (base_t / 1000.0).clamp(0.0, 1.0)
+            if base_t.numel() == 1:
+                return base_s.expand(bsz), base_t.expand(bsz)
+            if mode == "round-robin":
+                world = int(getattr(self.accelerator, "num_processes", 1) or 1)
+                rank = int(getattr(self.accelerator, "process_index", 0) or 0)
+                gather = getattr(self.accelerator, "gather", None)
+                if world > 1 and callable(gather):                          # ranks may hold different batch sizes (distributed batch layout)
+                    sizes = [int(v) for v in gather(torch.tensor([bsz], device=dev)).reshape(-1).tolist()]
+                    global_bsz, offset = sum(sizes), sum(sizes[:rank])
+                else:
+                    global_bsz, offset = bsz * world, bsz * rank
+                if not hasattr(self, "_flow_custom_timestep_cursor"):
+                    resume = getattr(self, "_flow_custom_timestep_resume_step", None)
+                    done = int(resume if resume is not None else state.get("global_step", 0) or 0)
+                    self._flow_custom_timestep_cursor = (done * global_bsz) % base_t.numel()
+                    if resume is not None:
+                        delattr(self, "_flow_custom_timestep_resume_step")
+                cursor = int(self._flow_custom_timestep_cursor)
+                idx = (torch.arange(bsz, device=dev) + cursor + offset) % base_t.numel()
+                self._flow_custom_timestep_cursor = (cursor + global_bsz) % base_t.numel()
+            else:
+                idx = torch.randint(0, base_t.numel(), (bsz,), device=dev)
+            return base_s[idx], base_t[idx]
+        if getattr(cfg, "flux_fast_schedule", False) and not (getattr(cfg, "flow_use_beta_schedule", False) or getattr(cfg, "flow_use_uniform_schedule", False)):
+            import random
+            sigmas = torch.tensor(random.choices([1.0] * 7 + [0.75, 0.5, 0.25], k=bsz), device=dev)      # no schedule shift on this branch
+            return sigmas, sigmas * 1000.0
         if getattr(cfg, "flow_use_uniform_schedule", False):
             sigmas = torch.rand((bsz,), device=dev)
         elif getattr(cfg, "flow_use_beta_schedule", False):
@@ -228,8 +271,53 @@ class ModelFoundation:
         else:
             normal = torch.randn((bsz,), device=dev)
             sigmas = torch.sigmoid(getattr(cfg, "flow_sigmoid_scale", 1.0) * normal)
-        sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, batch["noise_shape_ref"])
+        sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
         return sigmas, sigmas * 1000.0
+
+    def _normalize_flow_custom_timesteps(self, raw):
+        """common.py:4799-4838: comma / semicolon separated string, JSON list, or array -> finite 1-D fp32 tensor (None when empty)"""
+        import json
+        if raw in (None, "", "None"):
+            return None
+        cand = raw
+        if isinstance(cand, str):
+            st_ = cand.strip()
+            if st_ == "":
+                return None
+            try:
+                cand = json.loads(st_)
+            except Exception:
+                try:
+                    cand = [float(seg.strip()) for seg in st_.replace(";", ",").split(",") if seg.strip()]
+                except Exception:
+                    return None
+        try:
+            t = torch.as_tensor(cand, device=self.accelerator.device, dtype=torch.float32).flatten()
+        except Exception:
+            return None
+        t = t[torch.isfinite(t)]
+        return t if t.numel() else None
+
+    def reset_flow_custom_timestep_cursor(self, global_step: int = 0) -> None:
+        if hasattr(self, "_flow_custom_timestep_cursor"):
+            delattr(self, "_flow_custom_timestep_cursor")
+        self._flow_custom_timestep_resume_step = int(global_step or 0)
+
+    def _mixflow_gamma(self) -> float:
+        gamma = float(getattr(self.config, "mixflow_gamma", 0.8))
+        if not 0.0 <= gamma <= 1.0:
+            raise ValueError("mixflow_gamma must be between 0.0 and 1.0.")
+        return gamma
+
+    def _mixflow_interpolation_sigmas(self, sigmas, slowdown_factors=None):
+        """common.py:4966-4977: the INTERPOLATION time is slowed toward noise, the model still sees `sigmas`"""
+        sv = sigmas.reshape(sigmas.shape[0], -1)[:, 0]
+        gamma = self._mixflow_gamma()
+        if gamma == 0.0:
+            return sv
+        if slowdown_factors is None:
+            slowdown_factors = torch.rand_like(sv)
+        return sv + slowdown_factors * gamma * (1.0 - sv)
 
     # ---- prepare_batch (common.py:5862-6041) ----
     def prepare_batch(self, batch: dict, state: dict) -> dict:
@@ -263,6 +351,11 @@ class ModelFoundation:
         if self.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING:
             batch["sigmas"], batch["timesteps"] = self.sample_flow_sigmas(batch=batch, state=state)
             sig = batch["sigmas"].to(device=dev, dtype=torch.float32).contiguous()
+            if getattr(self.config, "mixflow_enabled", False) is True:          # _prepare_flow_noisy_latents (common.py:4979-4992)
+                gamma = self._mixflow_gamma()
+                slow = torch.rand_like(sig) if gamma > 0.0 else torch.zeros_like(sig)
+                sig = self._mixflow_interpolation_sigmas(sig, slow).contiguous()
+                batch["mixflow_slowdown_factors"], batch["mixflow_interpolation_sigmas"] = slow, sig
             given = batch.get("noise")          # tests / parity runs inject the reference's noise; else Philox in-kernel
             seed = int(getattr(self.config, "seed", 42) or 0) + 1_000_003 * int(getattr(self.accelerator, "process_index", 0))
             per_call = (lat.numel() + 3) // 4
