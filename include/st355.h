@@ -220,6 +220,8 @@ int st355_adamw_bf16_sr_step(void* stream, void* p, const void* g, void* exp_avg
 int st355_ema_update(void* stream, void* shadow, const void* param, int64_t n, float decay, int elem_bytes);
 /* K15: sum of squares (fp32 out[0]) and max-abs (out[1]) of a flat gradient; out zeroed by the call */
 int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2);
+/* clip_grad_value_ (trainer.py:7209-7213): g <- clamp(g, -c, +c) in place (fp32 or bf16 arena) */
+int st355_grad_clamp(void* stream, void* g, int64_t n, int elem_bytes, float c);
 
 /* LoRA operand packing (K12): from fp32 A[r,K], B[N,r] write the bf16 GEMM operands of ONE adapter into the (zero-initialised)
  * block-structured operands of a fused projection group with K2 padded low-rank columns and N_total outputs:

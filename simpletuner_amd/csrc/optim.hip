@@ -306,6 +306,22 @@ extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_
   return st355_check_launch("grad_norm");
 }
 
+// clip_grad_value_ (trainer.py:7209-7213): g <- clamp(g, -c, +c) in place over the flat gradient arena
+template <typename T>
+__global__ void __launch_bounds__(OP_THREADS) k_grad_clamp(T* __restrict__ g, int64_t n, float c) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = (float)g[i];
+    g[i] = (T)fminf(fmaxf(v, -c), c);
+  }
+}
+extern "C" int st355_grad_clamp(void* stream, void* g, int64_t n, int elem_bytes, float c) {
+  ST_REQUIRE(g && n > 0 && c > 0.f && (elem_bytes == 4 || elem_bytes == 2), "grad_clamp: bad args");
+  ProfScope ps(stream, ST355_K_OPTIM, 2.0 * n, 2.0 * elem_bytes * n);
+  if (elem_bytes == 4) hipLaunchKernelGGL(k_grad_clamp<float>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (float*)g, n, c);
+  else hipLaunchKernelGGL(k_grad_clamp<bf16>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (bf16*)g, n, c);
+  return st355_check_launch("grad_clamp");
+}
+
 // LoRA operand packer (block-structured; see st355.h)
 __global__ void __launch_bounds__(OP_THREADS) k_lora_pack(const float* __restrict__ A, const float* __restrict__ Bm, int r, int K, int N,
                                                          float scale, bf16* __restrict__ A_cat, bf16* __restrict__ A_cat_T,

@@ -24,7 +24,7 @@ SYMBOLS = [
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd",
     "st355_attn_fwd", "st355_attn_bwd_workspace", "st355_attn_bwd",
-    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm",
+    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp",
     "st355_lora_pack",
     # UNet path (SDXL / SD1.5)
     "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows",
@@ -120,6 +120,7 @@ def _declare(lib):
                                                vp, u64, u64, f32]),
         "st355_ema_update": (C.c_int, [vp, vp, vp, i64, f32, i32]),
         "st355_grad_norm": (C.c_int, [vp, vp, i64, i32, vp]),
+        "st355_grad_clamp": (C.c_int, [vp, vp, i64, i32, f32]),
         "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),
         "st355_conv_grid_rows": (i64, [i32, i32, i32]),
         "st355_conv_bf16": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32]),

@@ -532,6 +532,16 @@ def grad_norm(g):
     return out
 
 
+def grad_clamp_(g, c: float):
+    """in place: g <- clamp(g, -c, c) (clip_grad_value_)"""
+    L = _l.load()
+    _dev(g, "g")
+    if g.dtype not in (F32, BF16) or not g.is_contiguous():
+        raise _l.St355Error("grad_clamp: expected a contiguous fp32 / bf16 tensor")
+    _l.check(L.st355_grad_clamp(_stream(), _ptr(g), g.numel(), g.element_size(), float(c)), "grad_clamp")
+    return g
+
+
 def lora_pack(A, Bm, scale: float, A_cat, A_cat_T, B_blk, B_blk_T, k2_off: int = 0, n_off: int = 0):
     """write one adapter (A [r,K], B [N,r], fp32) into the block-structured bf16 operands of a fused projection group"""
     L = _l.load()

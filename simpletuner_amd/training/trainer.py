@@ -137,11 +137,17 @@ class Trainer:
             gflat = getattr(comp, "_last_grad_flat", None)
             if gflat is None:
                 raise NotImplementedError("gradient clipping needs the flat gradient arena")
-            stats = ops.grad_norm(gflat)
-            norm = stats[0].sqrt() * grad_scale
-            self.last_grad_norm = norm
-            coef = (cfg.max_grad_norm / (norm + 1e-6)).clamp(max=1.0)
-            grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
+            method = getattr(cfg, "grad_clip_method", "norm")
+            if method == "value":                                                        # accelerator.clip_grad_value_ (:7209-7213)
+                ops.grad_clamp_(gflat, cfg.max_grad_norm / grad_scale)                   # gradients are rank SUMS here; 1/world lives in grad_scale
+            elif method == "norm":
+                stats = ops.grad_norm(gflat)
+                norm = stats[0].sqrt() * grad_scale
+                self.last_grad_norm = norm
+                coef = (cfg.max_grad_norm / (norm + 1e-6)).clamp(max=1.0)
+                grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
+            else:
+                raise ValueError(f"Unknown grad clip method: {method}. Supported methods: value, norm")
         self.optimizer.grad_scale = grad_scale
         self.optimizer.step()                                                            # :7239
         if not self._use_graph:                                                          # graph mode: the captured backward re-writes the same .grad tensors

@@ -599,3 +599,13 @@ def test_gemm_grouped_two_streams(ops):
     for x_, p_, o_ in zip(xs, pre, outs):
         assert rel(p_, x_.float() @ W1.float().t()) < 5e-3
         assert rel(o_, gelu_tanh(p_.float())) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grad_clamp_value_clipping(ops, dtype):
+    """clip_grad_value_ (trainer.py:7209-7213): in-place clamp of the flat gradient arena"""
+    torch.manual_seed(31)
+    g = (torch.randn(100003, device=dev()) * 3).to(dtype)
+    ref = g.clone().clamp_(-1.5, 1.5)
+    ops.grad_clamp_(g, 1.5)
+    assert torch.equal(g, ref)
