@@ -179,6 +179,7 @@ class ModelFoundation:
     PREDICTION_TYPE = PredictionTypes.FLOW_MATCHING
     MODEL_TYPE = ModelTypes.TRANSFORMER
     MODEL_CLASS = None
+    MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 16
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
     DDP_FIND_UNUSED_PARAMETERS = False
@@ -200,6 +201,61 @@ class ModelFoundation:
     @staticmethod
     def unwrap_model(model):
         return getattr(model, "module", model)
+
+    # ---- API parity with the reference plugin surface (common.py:3691-3781) ----
+    def fuse_qkv_projections(self):
+        """no-op: projections that share an input are ALWAYS stored and executed as one matrix on this path; the per-projection diffusers
+        keys are views into it (PackedJointAttnProcessor2_0's fused to_qkv, packed_attention_processors.py:126-187)"""
+        return None
+
+    def unfuse_qkv_projections(self):
+        return None
+
+    # ---- LoRA checkpoints: the reference's layout (save_hooks.py:850-895 -> pipeline.save_lora_weights) ----
+    LORA_WEIGHT_NAME = "pytorch_lora_weights.safetensors"
+
+    def lora_state_dict(self, component=None):
+        """peft.get_peft_model_state_dict layout: `<module>.lora_A.weight` / `<module>.lora_B.weight` (the adapter name is dropped)"""
+        comp = component if component is not None else self.get_trained_component()
+        return {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p.detach()
+                for n, p in comp.named_parameters() if ".lora_" in n}
+
+    def save_lora_weights(self, output_dir, **layers):
+        """writes `pytorch_lora_weights.safetensors` with diffusers' component prefix (`transformer.` / `unet.`), as the diffusers pipelines'
+        save_lora_weights the reference calls (common.py:2072); `layers` = {"<subfolder>_lora_layers": state} or nothing (= the trained component)"""
+        import os
+
+        from safetensors.torch import save_file
+        if not layers:
+            layers = {f"{self.MODEL_SUBFOLDER}_lora_layers": self.lora_state_dict()}
+        flat = {}
+        for key, state in layers.items():
+            if state is None or not key.endswith("_lora_layers"):
+                continue
+            prefix = key[:-len("_lora_layers")]
+            for k, v in state.items():
+                flat[f"{prefix}.{k}"] = v.detach().to("cpu").contiguous()
+        os.makedirs(output_dir, exist_ok=True)
+        path = os.path.join(output_dir, self.LORA_WEIGHT_NAME)
+        save_file(flat, path, metadata={"format": "pt"})
+        return path
+
+    def load_lora_weights(self, models=None, input_dir=None):
+        """common.py:1875: read the file back into the adapters of the trained component (strict on the adapter keys)"""
+        import os
+
+        from safetensors.torch import load_file
+        comp = self.get_trained_component()
+        flat = load_file(os.path.join(input_dir, self.LORA_WEIGHT_NAME))
+        prefix = f"{self.MODEL_SUBFOLDER}."
+        own = {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p for n, p in comp.named_parameters() if ".lora_" in n}
+        missing = [k for k in own if prefix + k not in flat]
+        if missing:
+            raise KeyError(f"LoRA checkpoint is missing {len(missing)} adapter tensors, e.g. {missing[:3]}")
+        with torch.no_grad():
+            for k, p in own.items():
+                p.copy_(flat[prefix + k].to(device=p.device, dtype=p.dtype))
+        return comp
 
     def uses_noise_schedule(self) -> bool:
         return self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING

@@ -158,3 +158,37 @@ def test_ddpm_sampling_matches_reference_code_outputs():
     for bsz, seed, want in G["segmented"]:
         torch.manual_seed(seed)
         assert torch.equal(s.sample_timesteps(bsz), want), (bsz, seed)
+
+
+def test_lora_checkpoint_layout_roundtrip(tmp_path):
+    """save_lora_weights / load_lora_weights: `pytorch_lora_weights.safetensors`, keys `<subfolder>.<module>.lora_A.weight` (peft state-dict layout under
+    diffusers' component prefix — what save_hooks.py:850-895 hands to the pipeline's save_lora_weights)"""
+    from types import SimpleNamespace
+
+    from safetensors.torch import load_file
+
+    from simpletuner_amd.foundation import ModelFoundation
+
+    class Comp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleDict({"0": torch.nn.ModuleDict({"to_q": torch.nn.ModuleDict({"lora_A": torch.nn.ModuleDict({"default": torch.nn.Linear(8, 2, bias=False)}),
+                                                                                                          "lora_B": torch.nn.ModuleDict({"default": torch.nn.Linear(2, 8, bias=False)})})})})
+            self.base = torch.nn.Linear(8, 8)
+
+    class Plug(ModelFoundation):
+        MODEL_SUBFOLDER = "unet"
+
+    m = Plug(SimpleNamespace(), SimpleNamespace(device=torch.device("cpu")))
+    m.model = Comp()
+    path = m.save_lora_weights(str(tmp_path))
+    flat = load_file(path)
+    assert sorted(flat) == ["unet.blocks.0.to_q.lora_A.weight", "unet.blocks.0.to_q.lora_B.weight"]
+    want = {k: v.clone() for k, v in flat.items()}
+    with torch.no_grad():
+        for n, p in m.model.named_parameters():
+            if ".lora_" in n:
+                p.add_(1.0)
+    m.load_lora_weights(input_dir=str(tmp_path))
+    assert torch.equal(m.model.blocks["0"]["to_q"]["lora_A"]["default"].weight, want["unet.blocks.0.to_q.lora_A.weight"])
+    assert torch.equal(m.model.blocks["0"]["to_q"]["lora_B"]["default"].weight, want["unet.blocks.0.to_q.lora_B.weight"])

@@ -131,6 +131,44 @@ def test_unet_lora_gradients_match_autograd():
     print(f"[unet lora grads] {len(lora)} tensors, worst {worst[1]}: {worst[0]:.3e}")
 
 
+def test_lora_checkpoint_roundtrip_on_device(tmp_path):
+    """save_lora_weights -> wipe the adapters -> load_lora_weights: the adapter tensors (views into the K-extended weights) and the prediction come back
+    bit-identical; file layout = pytorch_lora_weights.safetensors with `unet.<module>.lora_{A,B}.weight` keys"""
+    from types import SimpleNamespace
+
+    from safetensors.torch import load_file
+
+    from simpletuner_amd.foundation import ModelFoundation
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    dev = "cuda:0"
+
+    class Plug(ModelFoundation):
+        MODEL_SUBFOLDER = "unet"
+
+    m = UNet2DConditionModel(device=dev, **SMALL)
+    m.init_synthetic(6)
+    m.add_lora_adapter(rank=8, alpha=8.0, seed=4, init_b_std=0.05)
+    plug = Plug(SimpleNamespace(), SimpleNamespace(device=torch.device(dev)))
+    plug.model = m
+    sample, t, ehs, te, ti = _inputs(2, 16, 16, dev, seed=2)
+    ack = {"text_embeds": te.to(dev), "time_ids": ti.to(dev)}
+    with torch.no_grad():
+        before = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs=ack, return_dict=False)[0].clone()
+    path = plug.save_lora_weights(str(tmp_path))
+    flat = load_file(path)
+    assert len(flat) == 2 * 8 * 8 and all(k.startswith("unet.") and (".lora_A.weight" in k or ".lora_B.weight" in k) for k in flat)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if ".lora_" in n:
+                p.zero_()
+        wiped = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs=ack, return_dict=False)[0].clone()
+    assert not torch.equal(wiped, before)
+    plug.load_lora_weights(input_dir=str(tmp_path))
+    with torch.no_grad():
+        after = m(sample.to(dev), t.to(dev), ehs.to(dev), None, added_cond_kwargs=ack, return_dict=False)[0]
+    assert torch.equal(after, before)
+
+
 def test_min_snr_weighted_loss_matches_formula():
     """DDPM epsilon loss with snr_gamma (common.py:6363-6397): mean_b( w_b * mean_chw (pred - noise)^2 ), w = min(snr, gamma)/snr, + its gradient"""
     from simpletuner_amd.sdxl.model import SDXL
