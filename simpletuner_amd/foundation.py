@@ -271,13 +271,11 @@ class ModelFoundation:
     # ---- sigma / timestep sampling (common.py:4994-5090) ----
     def sample_flow_sigmas(self, batch: dict, state: dict):
         """common.py:4994-5090: mixflow | custom timestep list (fixed-list / round-robin) | sigmoid-normal (default) | uniform | Beta | the
-        "fast" discrete schedule; the cubic-spline distribution is not implemented"""
+        "fast" discrete schedule | cubic-spline density (flow_cubic_schedule_weights, training/sigma_density.py)"""
         cfg = self.config
         bsz = batch["latents"].shape[0]
         dev = self.accelerator.device
         shape_ref = batch.get("noise_shape_ref", batch.get("noise", batch["latents"]))
-        if getattr(cfg, "flow_cubic_schedule_weights", None):
-            raise NotImplementedError("flow_cubic_schedule_weights is not implemented on the st355 path")
         if getattr(cfg, "mixflow_enabled", False) is True:
             # sigma increases toward noise: the paper's t ~ Beta(2,1) becomes sigma = 1 - sqrt(U) ~ Beta(1,2)   (common.py:5001-5007)
             sigmas = 1.0 - torch.sqrt(torch.rand((bsz,), device=dev))
@@ -315,6 +313,10 @@ class ModelFoundation:
             else:
                 idx = torch.randint(0, base_t.numel(), (bsz,), device=dev)
             return base_s[idx], base_t[idx]
+        if self._uses_flow_cubic_schedule():                                 # common.py:5058-5061: ahead of every other distribution switch
+            sigmas = self._sample_flow_cubic_values(bsz, dev)
+            sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
+            return sigmas, sigmas * 1000.0
         if getattr(cfg, "flux_fast_schedule", False) and not (getattr(cfg, "flow_use_beta_schedule", False) or getattr(cfg, "flow_use_uniform_schedule", False)):
             import random
             sigmas = torch.tensor(random.choices([1.0] * 7 + [0.75, 0.5, 0.25], k=bsz), device=dev)      # no schedule shift on this branch
@@ -329,6 +331,25 @@ class ModelFoundation:
             sigmas = torch.sigmoid(getattr(cfg, "flow_sigmoid_scale", 1.0) * normal)
         sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
         return sigmas, sigmas * 1000.0
+
+    # cubic-spline sigma density (common.py:4840-4854)
+    def _flow_cubic_schedule_weights(self):
+        from .training.sigma_density import parse_cubic_spline_weights
+        return parse_cubic_spline_weights(getattr(self.config, "flow_cubic_schedule_weights", None))
+
+    def _uses_flow_cubic_schedule(self) -> bool:
+        return self._flow_cubic_schedule_weights() is not None
+
+    def _sample_flow_cubic_values(self, batch_size: int, device) -> torch.Tensor:
+        from .training.sigma_density import CubicSplineDistribution
+        knots = self._flow_cubic_schedule_weights()
+        if knots is None:
+            raise ValueError("flow_cubic_schedule_weights must be configured before sampling its distribution.")
+        key = (knots, str(device))
+        if getattr(self, "_flow_cubic_distribution_cache_key", None) != key:       # the table is built once per (knots, device)
+            self._flow_cubic_distribution = CubicSplineDistribution(knots, device=device)
+            self._flow_cubic_distribution_cache_key = key
+        return self._flow_cubic_distribution.sample((batch_size,))
 
     def _normalize_flow_custom_timesteps(self, raw):
         """common.py:4799-4838: comma / semicolon separated string, JSON list, or array -> finite 1-D fp32 tensor (None when empty)"""

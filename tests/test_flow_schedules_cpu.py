@@ -106,3 +106,78 @@ def test_custom_sigma_list_single_value_and_fast_schedule():
     m = _model(flux_fast_schedule=True)
     s, t = m.sample_flow_sigmas({"latents": torch.zeros(16, 1, 2, 2)}, state={})
     assert set(s.tolist()) <= {1.0, 0.75, 0.5, 0.25} and torch.equal(t, s * 1000.0)
+
+
+# ---- cubic-spline sigma density (flow_cubic_schedule_weights) ----
+# tests/golden/cubic_schedule_vectors.pt = the reference's CubicSplineDistribution executed as written (tools/gen_golden.py::gen_cubic_schedule);
+# the known-answer cases below are the reference's tests/test_flow_cubic_schedule.py:52-108.
+def _cubic_golden():
+    from pathlib import Path
+    return torch.load(Path(__file__).parent / "golden" / "cubic_schedule_vectors.pt", weights_only=False)
+
+
+def test_cubic_density_tables_and_samples_match_reference_vectors():
+    from simpletuner_amd.training.sigma_density import CubicSplineDistribution, pchip_slopes
+    G = _cubic_golden()
+    assert len(G["cases"]) == 7
+    for c in G["cases"]:
+        d = CubicSplineDistribution(c["weights"])
+        torch.testing.assert_close(pchip_slopes(torch.tensor(c["weights"]), 1.0 / (len(c["weights"]) - 1)), c["slopes"], rtol=0, atol=0)
+        torch.testing.assert_close(d.pdf_grid, c["pdf"], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(d.cdf_grid, c["cdf"], rtol=1e-6, atol=1e-7)
+        torch.manual_seed(c["seed"])
+        torch.testing.assert_close(d.sample((257,)), c["samples"], rtol=1e-6, atol=1e-6)
+        lp = d.log_prob(c["query"])
+        assert torch.equal(torch.isinf(lp), torch.isinf(c["log_prob"]))
+        fin = torch.isfinite(c["log_prob"])
+        torch.testing.assert_close(lp[fin], c["log_prob"][fin], rtol=1e-5, atol=1e-5)
+
+
+def test_cubic_weight_parsing_matches_reference_vectors_and_rejects_invalid():
+    import math
+
+    from simpletuner_amd.training.sigma_density import parse_cubic_spline_weights
+    for raw, want in _cubic_golden()["parse"]:
+        assert parse_cubic_spline_weights(raw) == want, (raw, want)
+    for bad in ([1.0, -1.0], [0.0, 0.0], [1.0, math.inf], "1,,2", {"weight": 1}):         # test_flow_cubic_schedule.py:85-89
+        with pytest.raises(ValueError):
+            parse_cubic_spline_weights(bad)
+
+
+def test_cubic_empty_and_single_weight_schedules_are_uniform():
+    from simpletuner_amd.training.sigma_density import CubicSplineDistribution
+    for weights in ([], [0.0], [4.0]):                                                       # test_flow_cubic_schedule.py:53-59
+        torch.manual_seed(17)
+        want = torch.rand(64)
+        torch.manual_seed(17)
+        assert torch.equal(CubicSplineDistribution(weights).sample((64,)), want)
+
+
+def test_cubic_two_weights_define_linear_density_and_bounds():
+    import math
+
+    from simpletuner_amd.training.sigma_density import CubicSplineDistribution
+    d = CubicSplineDistribution([0.0, 1.0])                                                  # test_flow_cubic_schedule.py:61-68
+    torch.testing.assert_close(d.log_prob(torch.tensor([0.25, 0.75])).exp(), torch.tensor([0.5, 1.5]), atol=1e-3, rtol=0)
+    torch.manual_seed(11)
+    assert abs(d.sample((100_000,)).mean().item() - 2.0 / 3.0) < 5e-3
+    d = CubicSplineDistribution([0.0, 1.0, 0.1, 2.0, 0.0])                                  # :70-77
+    s = d.sample((10_000,))
+    assert s.min().item() >= 0.0 and s.max().item() <= 1.0 and torch.isfinite(d.log_prob(s)).all()
+    assert d.log_prob(torch.tensor([-0.1, 1.1])).tolist() == [-math.inf, -math.inf]
+
+
+def test_cubic_schedule_feeds_the_flow_sampler_with_shift():
+    from simpletuner_amd.training.sigma_density import CubicSplineDistribution
+    m = _model(flow_cubic_schedule_weights=[0.0, 1.0], flow_schedule_shift=2.0, flow_timesteps_mode="fixed-list")   # test_flow_cubic_schedule.py:93-108
+    batch = {"latents": torch.zeros(32, 1, 2, 2), "noise": torch.zeros(32, 1, 2, 2)}
+    torch.manual_seed(7)
+    raw = CubicSplineDistribution([0.0, 1.0]).sample((32,))
+    want = (raw * 2.0) / (1.0 + raw)
+    torch.manual_seed(7)
+    sigmas, timesteps = m.sample_flow_sigmas(batch=batch, state={})
+    torch.testing.assert_close(sigmas, want)
+    torch.testing.assert_close(timesteps, want * 1000.0)
+    # the option wins over the uniform / beta / fast switches and is off for None / "" / "none"
+    assert _model(flow_cubic_schedule_weights="none")._uses_flow_cubic_schedule() is False
+    assert _model(flow_cubic_schedule_weights=[])._uses_flow_cubic_schedule() is True

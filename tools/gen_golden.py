@@ -224,7 +224,32 @@ def gen_ddpm_sampling():
     print("wrote", out)
 
 
+def gen_cubic_schedule():
+    """CubicSplineDistribution (helpers/training/timestep_distribution.py:57-187; torch + stdlib only, so the file is loaded as a module as it
+    lies): tabulated pdf / cdf, seeded samples, log_prob -> tests/golden/cubic_schedule_vectors.pt"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_timestep_distribution", REF / "helpers" / "training" / "timestep_distribution.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    G = {"cases": [], "parse": []}
+    for weights in ([0.0, 1.0], [1.0, 0.0], [0.0, 1.0, 0.1, 2.0, 0.0], [1.0, 1.0, 1.0], [0.2, 3.0, 0.2], [0.0, 0.5, 4.0, 4.0, 0.5, 0.0, 1.0], [5.0, 0.0, 0.0, 5.0]):
+        d = mod.CubicSplineDistribution(weights)
+        torch.manual_seed(23)
+        smp = d.sample((257,))
+        q = torch.linspace(-0.1, 1.1, 49)
+        slopes = d._pchip_slopes(torch.tensor(weights), 1.0 / (len(weights) - 1))
+        G["cases"].append(dict(weights=list(weights), pdf=d.pdf_grid.clone(), cdf=d.cdf_grid.clone(), seed=23, samples=smp.clone(), query=q, log_prob=d.log_prob(q).clone(),
+                               slopes=slopes.clone()))
+    for raw in (None, "", "none", "[0, 1, 0.5]", "0,1,0.5", "0; 1 ;0.5", [], [4.0], 3, torch.tensor([[0.0, 2.0]]), (1, 2)):
+        G["parse"].append((raw, mod.parse_cubic_spline_weights(raw)))
+    out = OUT.parent / "cubic_schedule_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_cubic_schedule()
     gen_adamw_bf16()
     gen_loss()
     gen_fp8()
