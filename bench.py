@@ -200,7 +200,8 @@ def main():
     if args.model == "vae":
         return bench_vae(args, dev, rank, world)
 
-    cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42 + rank, lora_init_b_std=1e-3,
+    cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42, lora_init_b_std=1e-3,   # weights / adapter init / rounding seeds are REPLICA-identical; the data RNG below is per rank
+                        
                          model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
                          learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph))
     acc = St355Accelerator(dev)

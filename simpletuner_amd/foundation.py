@@ -173,6 +173,23 @@ class DDPMSchedule:
         return torch.tensor(out, dtype=torch.long)
 
 
+DATA_BACKEND_CONFIGS = {}
+
+
+def get_data_backend_config(backend_id) -> dict:
+    """stand-in for StateTracker.get_data_backend_config (state_tracker.py): unknown / missing ids have an empty config"""
+    src = DATA_BACKEND_CONFIGS
+    cfg = src(backend_id) if callable(src) else src.get(backend_id)
+    return cfg or {}
+
+
+def _process_rank(accelerator=None) -> int:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(getattr(accelerator, "process_index", 0) or 0)
+
+
 class ModelFoundation:
     """the subset of common.py's ModelFoundation that the step loop touches (trainer.py:6951-7568)."""
     NAME = "foundation"
@@ -328,6 +345,9 @@ class ModelFoundation:
             sigmas = dist.sample((bsz,)).to(device=dev)
         else:
             normal = torch.randn((bsz,), device=dev)
+            offset = self._get_dataset_timestep_sampling_offset(batch)      # per-dataset bias of the logit-normal mean (common.py:5069-5071)
+            if offset:
+                normal = normal + offset
             sigmas = torch.sigmoid(getattr(cfg, "flow_sigmoid_scale", 1.0) * normal)
         sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
         return sigmas, sigmas * 1000.0
@@ -379,6 +399,57 @@ class ModelFoundation:
         if hasattr(self, "_flow_custom_timestep_cursor"):
             delattr(self, "_flow_custom_timestep_cursor")
         self._flow_custom_timestep_resume_step = int(global_step or 0)
+
+    # round-robin cursor in checkpoints (common.py:4861-4912): one small JSON per rank next to the optimizer state
+    def _flow_custom_timestep_state_path(self, ckpt_dir: str) -> str:
+        import os
+        rank = _process_rank(self.accelerator)
+        return os.path.join(ckpt_dir, "flow_custom_timestep_state.json" if rank == 0 else f"flow_custom_timestep_state-{rank}.json")
+
+    def save_flow_custom_timestep_state(self, ckpt_dir: str) -> None:
+        import json
+        import os
+        mode = str(getattr(self.config, "flow_timesteps_mode", "fixed-list") or "fixed-list").replace("_", "-")
+        if mode != "round-robin" or self._normalize_flow_custom_timesteps(getattr(self.config, "flow_custom_timesteps", None)) is None:
+            return
+        state = {"rank": _process_rank(self.accelerator)}
+        if hasattr(self, "_flow_custom_timestep_cursor"):
+            state["cursor"] = int(self._flow_custom_timestep_cursor)
+        elif hasattr(self, "_flow_custom_timestep_resume_step"):
+            state["resume_step"] = int(self._flow_custom_timestep_resume_step)
+        else:
+            return
+        os.makedirs(ckpt_dir, exist_ok=True)
+        path = self._flow_custom_timestep_state_path(ckpt_dir)
+        with open(path + ".tmp", "w", encoding="utf-8") as fh:
+            json.dump(state, fh)
+        os.replace(path + ".tmp", path)                                     # atomic: a crash never leaves a half-written cursor
+
+    def load_flow_custom_timestep_state(self, ckpt_dir: str, fallback_global_step: int = 0) -> bool:
+        import json
+        import os
+        own = self._flow_custom_timestep_state_path(ckpt_dir)
+        shared = os.path.join(ckpt_dir, "flow_custom_timestep_state.json")
+        for path in dict.fromkeys((own, shared)):
+            if not os.path.exists(path):
+                continue
+            with open(path, "r", encoding="utf-8") as fh:
+                state = json.load(fh)
+            if state.get("cursor") is not None:
+                self._flow_custom_timestep_cursor = int(state["cursor"])
+                if hasattr(self, "_flow_custom_timestep_resume_step"):
+                    delattr(self, "_flow_custom_timestep_resume_step")
+                return True
+            if state.get("resume_step") is not None:
+                self.reset_flow_custom_timestep_cursor(int(state["resume_step"]))
+                return True
+        self.reset_flow_custom_timestep_cursor(fallback_global_step)
+        return False
+
+    def _get_dataset_timestep_sampling_offset(self, batch: dict) -> float:
+        """common.py:4915-4918: `timestep_sampling_offset` of the dataset the batch came from.  The reference asks its StateTracker; the drop-in
+        asks `DATA_BACKEND_CONFIGS` (a plain {backend_id: config} map the data side fills, or a callable `id -> config`)."""
+        return float(get_data_backend_config(batch.get("data_backend_id")).get("timestep_sampling_offset", 0.0))
 
     def _mixflow_gamma(self) -> float:
         gamma = float(getattr(self.config, "mixflow_gamma", 0.8))

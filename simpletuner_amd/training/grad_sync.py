@@ -76,3 +76,29 @@ class GradSync:
             yield
         finally:
             self.enabled = old
+
+
+def sync_module_states(module: torch.nn.Module, src: int = 0, process_group=None, chunk_bytes: int = 1 << 30) -> int:
+    """What DDP does once at construction (torch's `_sync_module_states`, reached from accelerator.prepare, trainer.py:4515): every replica
+    starts from rank `src`'s parameters and buffers.  Parameters here are views into a few large arenas (weights, K-extended LoRA columns,
+    optimizer-ordered trainables), so the broadcast walks the distinct underlying STORAGES as raw bytes — a handful of GB-sized
+    broadcasts over xGMI instead of thousands of per-tensor ones — and therefore also carries arena padding / fused columns that are not
+    registered parameters.  Returns the number of bytes broadcast (0 when not distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return 0
+    seen, total = set(), 0
+    tensors = list(module.parameters()) + list(module.buffers())
+    for t in tensors:
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key in seen or st.nbytes() == 0:
+            continue
+        seen.add(key)
+        raw = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st)        # the whole allocation, bytes
+        for lo in range(0, raw.numel(), chunk_bytes):
+            dist.broadcast(raw[lo:lo + chunk_bytes], src=src, group=process_group)
+        total += raw.numel()
+    refresh = getattr(module, "_refresh_transposed", None)                        # derived copies (transposed weights for dgrad) follow the new values
+    if callable(refresh):
+        refresh()
+    return total

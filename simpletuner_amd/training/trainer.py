@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from .. import ops
 from .ema import EMAModel
-from .grad_sync import GradSync
+from .grad_sync import GradSync, sync_module_states
 from .multi_process import gather_sample_weighted_scalar
 from .optimizer import OPTIMIZER_CHOICE, St355AdamW, St355AdamWBF16
 
@@ -83,6 +83,8 @@ class Trainer:
         if getattr(config, "use_ema", False):
             self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)
         self._overlapped_sync = config.gradient_accumulation_steps == 1
+        if self.accelerator.num_processes > 1:
+            sync_module_states(comp)                                     # replicas start from rank 0's weights (DDP construction semantics)
         if self.accelerator.num_processes > 1 and self._overlapped_sync:
             # replicas: bucketed all-reduce of the flat gradient arena, overlapped with the hand-written backward
             if getattr(comp, "full", False) and getattr(comp, "grad_arena", None) is not None:

@@ -38,6 +38,23 @@ def _worker(rank, world, init_file, out_dir):
     res["weighted"] = gather_sample_weighted_scalar(loss, 1 if rank == 0 else 3).item()
     # --- C3: epoch-end consensus (MAX) ---
     res["epoch_end"] = any_rank_reached_epoch_end(rank == 1, torch.device("cpu"))
+    # --- replica start state: every distinct storage behind the module's parameters / buffers is broadcast from rank 0 as raw bytes ---
+    from simpletuner_amd.training.grad_sync import sync_module_states
+    torch.manual_seed(100 + rank)                                      # replicas deliberately start apart
+    arena = torch.randn(4096)                                          # one arena, three parameter views + padding that is no parameter
+    mod = torch.nn.Module()
+    mod.a = torch.nn.Parameter(arena[0:1000].view(10, 100))
+    mod.b = torch.nn.Parameter(arena[1024:2048].view(32, 32), requires_grad=False)
+    mod.c = torch.nn.Parameter(torch.randn(7, 3).to(torch.bfloat16))
+    mod.register_buffer("tab", torch.randn(5))
+    calls = []
+    mod._refresh_transposed = lambda: calls.append(1)
+    nbytes = sync_module_states(mod, chunk_bytes=5000)                 # forces the chunked path (arena = 16 KiB)
+    torch.manual_seed(100)
+    want_arena = torch.randn(4096); want_c = torch.randn(7, 3).to(torch.bfloat16); want_tab = torch.randn(5)
+    res["sync_ok"] = (torch.equal(arena, want_arena) and torch.equal(mod.c.data, want_c) and torch.equal(mod.tab, want_tab)
+                      and torch.equal(mod.a.data, want_arena[:1000].view(10, 100)) and calls == [1])
+    res["sync_bytes"] = nbytes
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -54,3 +71,4 @@ def test_two_process_gloo_grad_sync_and_loss_gather():
             assert res["nosync_ok"]
             assert abs(res["weighted"] - 3.5) < 1e-6
             assert res["epoch_end"] is True
+            assert res["sync_ok"] and res["sync_bytes"] == 4096 * 4 + 7 * 3 * 2 + 5 * 4

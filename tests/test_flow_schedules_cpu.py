@@ -181,3 +181,66 @@ def test_cubic_schedule_feeds_the_flow_sampler_with_shift():
     # the option wins over the uniform / beta / fast switches and is off for None / "" / "none"
     assert _model(flow_cubic_schedule_weights="none")._uses_flow_cubic_schedule() is False
     assert _model(flow_cubic_schedule_weights=[])._uses_flow_cubic_schedule() is True
+
+
+# ---- round-robin cursor in checkpoints (reference tests/test_flow_custom_timesteps.py:90-127) ----
+def test_round_robin_resume_reset_overrides_prior_cursor():
+    m = _rr("100,200,300,400,500")
+    m.accelerator.num_processes = 2
+    batch = {"latents": torch.zeros(2, 1, 2, 2)}
+    m.sample_flow_sigmas(batch, state={"global_step": 0})
+    m.reset_flow_custom_timestep_cursor(global_step=1)
+    _, t = m.sample_flow_sigmas(batch, state={"global_step": 1})
+    assert torch.equal(t, torch.tensor([500.0, 100.0]))
+
+
+def test_round_robin_checkpoint_restores_microbatch_cursor(tmp_path):
+    m = _rr("100,200,300,400")
+    batch = {"latents": torch.zeros(1, 1, 2, 2)}
+    for _ in range(3):
+        m.sample_flow_sigmas(batch, state={"global_step": 0})
+    m.save_flow_custom_timestep_state(str(tmp_path))
+    assert (tmp_path / "flow_custom_timestep_state.json").exists()
+    resumed = _rr("100,200,300,400")
+    assert resumed.load_flow_custom_timestep_state(str(tmp_path), fallback_global_step=1) is True
+    _, t = resumed.sample_flow_sigmas(batch, state={"global_step": 1})
+    assert torch.equal(t, torch.tensor([400.0]))
+
+
+def test_round_robin_checkpoint_load_falls_back_to_global_step(tmp_path):
+    m = _rr("100,200,300,400")
+    assert m.load_flow_custom_timestep_state(str(tmp_path), fallback_global_step=1) is False
+    _, t = m.sample_flow_sigmas({"latents": torch.zeros(1, 1, 2, 2)}, state={"global_step": 1})
+    assert torch.equal(t, torch.tensor([200.0]))
+
+
+def test_fixed_list_mode_writes_no_cursor_state(tmp_path):
+    m = _rr("100,200,300", mode="fixed-list")
+    m.sample_flow_sigmas({"latents": torch.zeros(1, 1, 2, 2)}, state={})
+    m.save_flow_custom_timestep_state(str(tmp_path))
+    assert list(tmp_path.iterdir()) == []
+
+
+# ---- per-dataset timestep_sampling_offset (reference tests/test_timestep_bias_sampling.py) ----
+def test_dataset_timestep_sampling_offset_lookup_and_effect():
+    import simpletuner_amd.foundation as F
+    calls = []
+
+    def lookup(backend_id):
+        calls.append(backend_id)
+        return {"ds1": {"timestep_sampling_offset": -0.5}, "ds2": {}}.get(backend_id)
+
+    with patch.object(F, "DATA_BACKEND_CONFIGS", lookup):
+        assert ModelFoundation._get_dataset_timestep_sampling_offset(object(), {"data_backend_id": "ds1"}) == -0.5
+        assert ModelFoundation._get_dataset_timestep_sampling_offset(object(), {"data_backend_id": "ds2"}) == 0.0
+        assert ModelFoundation._get_dataset_timestep_sampling_offset(object(), {}) == 0.0
+        assert calls == ["ds1", "ds2", None]
+        # the offset moves the mean of the logit-normal draw: sigma = sigmoid(scale * (N + offset))      (common.py:5066-5072)
+        m = _model(flow_sigmoid_scale=1.5)
+        batch = {"latents": torch.zeros(4, 1, 2, 2), "noise": torch.zeros(4, 1, 2, 2), "data_backend_id": "ds1"}
+        torch.manual_seed(3)
+        normal = torch.randn(4)
+        torch.manual_seed(3)
+        sigmas, timesteps = m.sample_flow_sigmas(batch, state={})
+        torch.testing.assert_close(sigmas, torch.sigmoid(1.5 * (normal - 0.5)))
+        torch.testing.assert_close(timesteps, sigmas * 1000.0)
