@@ -82,6 +82,7 @@ class Flux(ModelFoundation):
 
     def _model_predict_single(self, prepared_batch: dict):
         """flux/model.py:707-864"""
+        self._require_per_sample_timesteps(prepared_batch)
         lat = prepared_batch["latents"]
         B, Cc, Hh, Ww = lat.shape
         dev = self.accelerator.device

@@ -219,6 +219,17 @@ class ModelFoundation:
     def unwrap_model(model):
         return getattr(model, "module", model)
 
+    def _require_per_sample_timesteps(self, prepared_batch: dict):
+        """The reference's DiT plugins also accept TOKENWISE timesteps [B, S] (CREPA self-flow; tests/test_flux_model.py:213-241,
+        tests/test_sd3_model.py:179-204, tests/test_pixart_model.py:91-115) and clean conditioning tokens appended at t=0 (Flux Kontext,
+        tests/test_flux_model.py:243-272).  Both need per-token modulation, which the fused AdaLN kernels (one [B, 6D] modulation row per image) do
+        not implement: refuse loudly instead of training on the wrong conditioning."""
+        t = prepared_batch["timesteps"]
+        if getattr(t, "ndim", 1) != 1:
+            raise NotImplementedError(f"tokenwise timesteps {tuple(t.shape)} are not implemented on the st355 path (per-sample [B] only)")
+        if prepared_batch.get("conditioning_packed_latents") is not None:
+            raise NotImplementedError("conditioning_packed_latents (reference-image tokens) are not implemented on the st355 path")
+
     # ---- API parity with the reference plugin surface (common.py:3691-3781, SURVEY.md §8b) ----
     def fuse_qkv_projections(self):
         """no-op: projections that share an input are ALWAYS stored and executed as one matrix on this path; the per-projection diffusers
@@ -351,6 +362,35 @@ class ModelFoundation:
             sigmas = torch.sigmoid(getattr(cfg, "flow_sigmoid_scale", 1.0) * normal)
         sigmas = apply_flow_schedule_shift(cfg, self.noise_schedule, sigmas, shape_ref)
         return sigmas, sigmas * 1000.0
+
+    # resolution-dependent shift for schedulers with dynamic shifting (common.py:4730-4797)
+    def _get_patch_size_for_dynamic_shift(self, noise_scheduler):
+        try:
+            comp = self.get_trained_component()
+        except Exception:
+            comp = None
+        for holder in (getattr(comp, "config", None), getattr(noise_scheduler, "config", None), self.config):
+            ps = getattr(holder, "patch_size", None) if holder is not None else None
+            if ps is not None:
+                return ps
+        return None
+
+    def calculate_dynamic_shift_mu(self, noise_scheduler, latents):
+        """mu(seq_len): the line through (base_image_seq_len, base_shift) and (max_image_seq_len, max_shift); seq_len counts patches (x frames
+        for [B,C,F,H,W] latents)"""
+        sc = getattr(noise_scheduler, "config", None)
+        if latents is None or sc is None:
+            return None
+        need = ("base_image_seq_len", "max_image_seq_len", "base_shift", "max_shift")
+        absent = [f for f in need if getattr(sc, f, None) is None]
+        if absent:
+            raise ValueError(f"Cannot compute dynamic timestep shift; scheduler is missing config values: {', '.join(absent)}")
+        ps = self._get_patch_size_for_dynamic_shift(noise_scheduler)
+        if ps is None or ps <= 0:
+            raise ValueError("Cannot compute dynamic timestep shift because no valid `patch_size` was found.")
+        frames = latents.shape[-3] if latents.ndim == 5 else 1
+        seq_len = frames * (int(latents.shape[-2]) // int(ps)) * (int(latents.shape[-1]) // int(ps))
+        return calculate_shift(seq_len, sc.base_image_seq_len, sc.max_image_seq_len, sc.base_shift, sc.max_shift)
 
     # cubic-spline sigma density (common.py:4840-4854)
     def _flow_cubic_schedule_weights(self):

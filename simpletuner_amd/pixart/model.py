@@ -69,6 +69,7 @@ class PixartSigma(ModelFoundation):
         return self._controlnet_predict_single(prepared_batch)
 
     def _model_predict_single(self, prepared_batch: dict):
+        self._require_per_sample_timesteps(prepared_batch)
         dev = self.accelerator.device
         if prepared_batch["noisy_latents"].shape[1] != self.LATENT_CHANNEL_COUNT:
             raise ValueError(f"{self.NAME} requires a latent size of {self.LATENT_CHANNEL_COUNT} channels. Ensure you are using the correct VAE cache path.")
@@ -80,6 +81,7 @@ class PixartSigma(ModelFoundation):
 
     def _controlnet_predict_single(self, prepared_batch: dict) -> dict:
         """pixart/model.py:399-458"""
+        self._require_per_sample_timesteps(prepared_batch)
         dev = self.accelerator.device
         cond = prepared_batch.get("conditioning_latents")
         if cond is None:

@@ -53,6 +53,7 @@ class SD3(ModelFoundation):
 
     def _model_predict_single(self, prepared_batch: dict):
         """sd3/model.py:540-570"""
+        self._require_per_sample_timesteps(prepared_batch)
         dev = self.accelerator.device
         model_pred = self.model(
             hidden_states=prepared_batch["noisy_latents"].to(device=dev, dtype=BF16),

@@ -244,3 +244,19 @@ def test_dataset_timestep_sampling_offset_lookup_and_effect():
         sigmas, timesteps = m.sample_flow_sigmas(batch, state={})
         torch.testing.assert_close(sigmas, torch.sigmoid(1.5 * (normal - 0.5)))
         torch.testing.assert_close(timesteps, sigmas * 1000.0)
+
+
+# ---- dynamic shift mu (reference tests/test_validation_dynamic_shift.py:47-73) ----
+def test_calculate_dynamic_shift_mu_uses_patch_size_and_resolution():
+    sched = SimpleNamespace(config=SimpleNamespace(base_image_seq_len=256, max_image_seq_len=512, base_shift=0.5, max_shift=1.0))
+    m = _model(patch_size=4)
+    m.model = None
+    mu = m.calculate_dynamic_shift_mu(sched, torch.zeros(1, 4, 8, 8))
+    assert mu == pytest.approx(0.5 / (512 - 256) * 4)                         # the reference's expected value (seq_len 4; the line's intercept is 0)
+    assert m.calculate_dynamic_shift_mu(sched, None) is None
+    # video latents count frames; the trained component's patch size wins over the config's
+    m.model = SimpleNamespace(config=SimpleNamespace(patch_size=2))
+    assert m.calculate_dynamic_shift_mu(sched, torch.zeros(1, 4, 3, 8, 8)) == pytest.approx(0.5 / 256 * 48)
+    bad = SimpleNamespace(config=SimpleNamespace(base_image_seq_len=None, max_image_seq_len=512, base_shift=0.5, max_shift=1.0))
+    with pytest.raises(ValueError, match="base_image_seq_len"):
+        m.calculate_dynamic_shift_mu(bad, torch.zeros(1, 4, 4, 4))

@@ -192,3 +192,21 @@ def test_lora_checkpoint_layout_roundtrip(tmp_path):
     m.load_lora_weights(input_dir=str(tmp_path))
     assert torch.equal(m.model.blocks["0"]["to_q"]["lora_A"]["default"].weight, want["unet.blocks.0.to_q.lora_A.weight"])
     assert torch.equal(m.model.blocks["0"]["to_q"]["lora_B"]["default"].weight, want["unet.blocks.0.to_q.lora_B.weight"])
+
+
+def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
+    """the reference's CREPA self-flow / Kontext inputs (tests/test_flux_model.py:213-272) are refused loudly, never silently mis-conditioned"""
+    from types import SimpleNamespace
+
+    import pytest
+
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.pixart.model import PixartSigma
+    from simpletuner_amd.sd3.model import SD3
+    for cls in (Flux, SD3, PixartSigma):
+        m = cls.__new__(cls)
+        m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
+        with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
+            m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
+        with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
+            m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
