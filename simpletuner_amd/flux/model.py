@@ -77,9 +77,6 @@ class Flux(ModelFoundation):
             raise NotImplementedError("only flux_guidance_mode=constant is implemented")
         return [float(getattr(self.config, "flux_guidance_value", 1.0))] * batch_size
 
-    def model_predict(self, prepared_batch: dict):
-        return self._model_predict_single(prepared_batch)
-
     def _model_predict_single(self, prepared_batch: dict):
         """flux/model.py:707-864"""
         self._require_per_sample_timesteps(prepared_batch)

@@ -23,6 +23,7 @@ from typing import Any, Dict, Optional, Type
 import torch
 
 from . import ops
+from .xm import ExplorativeModelingConfig, ExplorativeModelingMixin
 
 BF16 = torch.bfloat16
 
@@ -190,7 +191,7 @@ def _process_rank(accelerator=None) -> int:
     return int(getattr(accelerator, "process_index", 0) or 0)
 
 
-class ModelFoundation:
+class ModelFoundation(ExplorativeModelingMixin):
     """the subset of common.py's ModelFoundation that the step loop touches (trainer.py:6951-7568)."""
     NAME = "foundation"
     PREDICTION_TYPE = PredictionTypes.FLOW_MATCHING
@@ -207,6 +208,28 @@ class ModelFoundation:
         self.model = None
         self.noise_schedule = None
         self._noise_step = 0
+        self.xm_config = ExplorativeModelingConfig.from_config(config)     # common.py:578
+
+    # ---- prediction entry points; XM (off by default) expands the batch with K noise candidates first (flux/model.py:630-636, 940-946) ----
+    def model_predict(self, prepared_batch: dict):
+        return self._xm_wrapped(self._model_predict_single, prepared_batch)
+
+    def controlnet_predict(self, prepared_batch: dict):
+        return self._xm_wrapped(self._controlnet_predict_single, prepared_batch)
+
+    def _xm_wrapped(self, predict, prepared_batch: dict):
+        if self._xm_noise_candidates_enabled(prepared_batch):
+            self._prepare_xm_noise_candidates(prepared_batch)
+            out = predict(prepared_batch)
+            out["xm_candidate_count"] = self.xm_config.candidate_count
+            return out
+        return predict(prepared_batch)
+
+    def _model_predict_single(self, prepared_batch: dict):
+        raise NotImplementedError
+
+    def _controlnet_predict_single(self, prepared_batch: dict):
+        raise NotImplementedError(f"{self.NAME} has no ControlNet path")
 
     # ---- component plumbing (common.py:3691, 3781) ----
     def get_trained_component(self, base_model: bool = False, unwrap_model: bool = True):
@@ -617,7 +640,9 @@ class ModelFoundation:
             return prepared_batch["latents"]
         raise ValueError(f"Unknown prediction type {self.PREDICTION_TYPE}.")
 
-    def loss(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True):
+    def loss(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True, _per_sample_only: bool = False, _row_weight=None):
+        """common.py:6217-6430.  The two private switches serve XM (xm.py): `_per_sample_only` returns (weighted per-row losses [B] fp32, the row
+        weights or None) without touching autograd; `_row_weight` replaces the row weights (it already carries the min-SNR factor)."""
         target = self.get_prediction_target(prepared_batch)
         model_pred = model_output["model_prediction"]
         if target is None:
@@ -635,11 +660,21 @@ class ModelFoundation:
                 weight = weight.to(device=model_pred.device, dtype=torch.float32).contiguous()
             elif loss_type == "l2" and float(getattr(self.config, "snr_weight", 1.0)) != 1.0:
                 weight = torch.full((model_pred.shape[0],), float(self.config.snr_weight), dtype=torch.float32, device=model_pred.device)
+        if _row_weight is not None:
+            weight = _row_weight.to(device=model_pred.device, dtype=torch.float32).contiguous()
+        huber_c = None
+        if loss_type != "l2":
+            # huber / smooth_l1 (common.py:6248-6281): one huber_c per sample — constant, or scheduled on the timestep (common.py:6168-6216)
+            huber_c = self.compute_scheduled_huber_c(prepared_batch["timesteps"]).to(device=model_pred.device, dtype=torch.float32)
+            huber_c = huber_c.reshape(-1).expand(model_pred.shape[0]).contiguous()
+        if _per_sample_only:
+            with torch.no_grad():
+                p_, t_ = model_pred.detach().to(BF16), target.to(BF16)
+                per = (ops.mse_loss(p_, t_, weight=weight, want_grad=False) if loss_type == "l2"
+                       else ops.cond_loss(p_, t_, loss_type, huber_c, weight=weight, want_grad=False))[1]
+            return per, weight
         if loss_type == "l2":
             return _MSELossFn.apply(model_pred, target, weight)
-        # huber / smooth_l1 (common.py:6248-6281): one huber_c per sample — constant, or scheduled on the timestep (common.py:6168-6216)
-        huber_c = self.compute_scheduled_huber_c(prepared_batch["timesteps"]).to(device=model_pred.device, dtype=torch.float32)
-        huber_c = huber_c.reshape(-1).expand(model_pred.shape[0]).contiguous()
         return _CondLossFn.apply(model_pred, target, loss_type, huber_c, weight)
 
     def compute_scheduled_huber_c(self, timesteps: torch.Tensor) -> torch.Tensor:
@@ -664,6 +699,10 @@ class ModelFoundation:
         raise NotImplementedError(f"Unknown Huber loss schedule {schedule}")
 
     def loss_with_logs(self, prepared_batch: dict, model_output, apply_conditioning_mask: bool = True):
+        """xm_mixin.py:476-485"""
+        k = model_output.get("xm_candidate_count") if isinstance(model_output, dict) else None
+        if k:
+            return self._xm_noise_loss_with_logs(prepared_batch, model_output, candidate_count=int(k), apply_conditioning_mask=apply_conditioning_mask)
         return self.loss(prepared_batch, model_output, apply_conditioning_mask), None
 
     def auxiliary_loss(self, model_output, prepared_batch: dict, loss: torch.Tensor):

@@ -62,11 +62,8 @@ class PixartSigma(ModelFoundation):
 
     def model_predict(self, prepared_batch: dict):
         if self.controlnet is not None and prepared_batch.get("conditioning_latents") is not None:
-            return self._controlnet_predict_single(prepared_batch)
-        return self._model_predict_single(prepared_batch)
-
-    def controlnet_predict(self, prepared_batch: dict):
-        return self._controlnet_predict_single(prepared_batch)
+            return self.controlnet_predict(prepared_batch)
+        return super().model_predict(prepared_batch)
 
     def _model_predict_single(self, prepared_batch: dict):
         self._require_per_sample_timesteps(prepared_batch)

@@ -58,9 +58,6 @@ class StableDiffusion1(ModelFoundation):
     def enable_full_finetune(self):
         return self.unwrap_model(self.model).enable_full_finetune()
 
-    def model_predict(self, prepared_batch: dict):
-        return self._model_predict_single(prepared_batch)
-
     def _model_predict_single(self, prepared_batch: dict):
         """sd1x/model.py:224-270"""
         dev = self.accelerator.device

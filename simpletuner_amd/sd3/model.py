@@ -48,9 +48,6 @@ class SD3(ModelFoundation):
         """model_type == "full" (BASELINE.json configs[3]): every transformer parameter trains (bf16 params + bf16 grads in two arenas)"""
         return self.unwrap_model(self.model).enable_full_finetune()
 
-    def model_predict(self, prepared_batch: dict):
-        return self._model_predict_single(prepared_batch)
-
     def _model_predict_single(self, prepared_batch: dict):
         """sd3/model.py:540-570"""
         self._require_per_sample_timesteps(prepared_batch)

@@ -45,9 +45,6 @@ class SDXL(ModelFoundation):
     def enable_full_finetune(self):
         return self.unwrap_model(self.model).enable_full_finetune()
 
-    def model_predict(self, prepared_batch: dict):
-        return self._model_predict_single(prepared_batch)
-
     def _model_predict_single(self, prepared_batch: dict):
         """sdxl/model.py:306-373"""
         dev = self.accelerator.device

@@ -96,6 +96,8 @@ class Trainer:
         self._use_graph = bool(getattr(config, "hip_graph", False))
         if self._use_graph and (self.accelerator.num_processes > 1 or config.gradient_accumulation_steps != 1):
             raise NotImplementedError("hip_graph: single-process, gradient_accumulation_steps == 1 only")
+        if self._use_graph and getattr(getattr(model_plugin, "xm_config", None), "enabled", False):
+            raise NotImplementedError("hip_graph: XM noise candidates read their logs on the host every step and cannot be captured")
         self._graphs = {}
         self._graph_warm = {}
         self.state = {"global_step": 0, "micro_step": 0}
