@@ -118,21 +118,74 @@ class EMAModel:
     def parameter_count(self) -> int:
         return sum(p.numel() for p in self.shadow_params)
 
-    def state_dict(self) -> dict:
-        """ema.py:236-286 layout: scalars + shadow_params.i"""
+    def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False, exclude_params: bool = False) -> dict:
+        """ema.py:500-524 layout: scalars + `shadow_params.{i}`"""
         sd = dict(decay=self.decay, min_decay=self.min_decay, optimization_step=self.optimization_step,
-                  update_after_step=self.update_after_step, use_ema_warmup=self.use_ema_warmup, inv_gamma=self.inv_gamma,
-                  power=self.power, warmup_steps=self.warmup_steps)
+                  update_after_step=self.update_after_step, warmup_steps=self.warmup_steps, use_ema_warmup=self.use_ema_warmup,
+                  inv_gamma=self.inv_gamma, power=self.power)
+        if exclude_params:
+            return sd
         for i, s in enumerate(self.shadow_params):
-            sd[f"shadow_params.{i}"] = s.detach().clone()
+            sd[f"{prefix}shadow_params.{i}"] = s if keep_vars else s.detach().clone()
         return sd
 
-    def load_state_dict(self, state_dict: dict) -> None:
-        sd = copy.copy(state_dict)
-        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power", "warmup_steps"):
+    def save_state_dict(self, path: str) -> None:
+        """ema.py:236-249: the `ema_model.pt` of a checkpoint (save_hooks.py:396-418) — torch.save of state_dict(), tensors on the host so the file
+        loads anywhere"""
+        import os
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save({k: (v.detach().to("cpu") if torch.is_tensor(v) else v) for k, v in self.state_dict().items()}, path)
+
+    def load_state_dict(self, state) -> None:
+        """ema.py:251-286: `state` is the path of an `ema_model.pt` (the reference's call, save_hooks.py:443) or an already loaded dict; the number
+        of shadow tensors must match"""
+        sd = torch.load(state, map_location="cpu", weights_only=True) if isinstance(state, (str, bytes)) or hasattr(state, "__fspath__") else copy.copy(state)
+        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power"):
             if k in sd:
                 setattr(self, k, sd[k])
+        if "warmup_steps" in sd:
+            self.warmup_steps = max(0, int(sd["warmup_steps"] or 0))
+        n = 0
+        while f"shadow_params.{n}" in sd:
+            n += 1
+        if n != len(self.shadow_params):
+            raise ValueError(f"Mismatch in number of shadow parameters: expected {len(self.shadow_params)}, but found {n} in the state dict.")
+        with torch.no_grad():
+            for i, s in enumerate(self.shadow_params):
+                s.copy_(sd[f"shadow_params.{i}"].to(device=s.device, dtype=s.dtype))
+
+    # nn.Module-ish iterators the reference's hooks rely on (ema.py:611-648)
+    def parameters(self, recurse: bool = True):
+        return iter(self.shadow_params)
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True):
         for i, s in enumerate(self.shadow_params):
-            key = f"shadow_params.{i}"
-            if key in sd:
-                s.copy_(sd[key].to(device=s.device, dtype=s.dtype))
+            yield f"{prefix}shadow_params.{i}", s
+
+    def buffers(self, recurse: bool = True):
+        return iter([])
+
+    def named_buffers(self, prefix: str = "", recurse: bool = True):
+        return iter([])
+
+    def children(self):
+        return iter([])
+
+    def named_children(self):
+        return iter([])
+
+    def modules(self):
+        yield self
+
+    def named_modules(self, memo=None, prefix: str = ""):
+        yield prefix, self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        pass

@@ -30,6 +30,26 @@ def _contiguous_run(tensors):
     return True
 
 
+def _unpack_saved_state(opt: torch.optim.Optimizer, state_dict: dict):
+    """torch.optim.Optimizer.load_state_dict's matching rules (groups by position, parameters by position inside a group; saved hyper-parameters
+    replace the live ones) WITHOUT its dtype policy: torch casts every floating state tensor to the parameter's dtype, which would round the fp32
+    moments of bf16 parameters to bf16 on every resume.  Returns {param: saved per-parameter state}."""
+    saved_groups = state_dict["param_groups"]
+    if len(saved_groups) != len(opt.param_groups):
+        raise ValueError("loaded state dict has a different number of parameter groups")
+    by_param = {}
+    for saved, live in zip(saved_groups, opt.param_groups):
+        if len(saved["params"]) != len(live["params"]):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        for k, v in saved.items():
+            if k != "params":
+                live[k] = v
+        for pid, p in zip(saved["params"], live["params"]):
+            if pid in state_dict["state"]:
+                by_param[p] = state_dict["state"][pid]
+    return by_param
+
+
 class St355AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  amsgrad: bool = False, **_ignored):
@@ -58,6 +78,33 @@ class St355AdamW(torch.optim.Optimizer):
                     off += p.numel()
             self._flat[gi] = st
         return st
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict: dict) -> None:
+        """resume (`accelerator.load_state`, save_hooks.py): the saved per-parameter moments are copied INTO the flat fp32 arenas (created here if
+        the optimizer has not stepped yet) so the one-launch path continues from them; step counters are restored"""
+        saved = _unpack_saved_state(self, state_dict)
+        self._flat = {}
+        for p in list(self.state):
+            del self.state[p]
+        for gi, group in enumerate(self.param_groups):
+            st = self._group_flat(gi, group)
+            steps = [0]
+            for p in st["ps"]:
+                old = saved.get(p)
+                if old is None:
+                    continue
+                k = int(float(old["step"]))
+                steps.append(k)
+                if st["ok"]:
+                    mine = self.state[p]
+                    mine["exp_avg"].copy_(old["exp_avg"].to(device=p.device, dtype=F32).view_as(p))
+                    mine["exp_avg_sq"].copy_(old["exp_avg_sq"].to(device=p.device, dtype=F32).view_as(p))
+                    mine["step"] = torch.tensor(float(k))
+                else:
+                    self.state[p] = dict(step=torch.tensor(float(k)), exp_avg=old["exp_avg"].to(device=p.device, dtype=F32).clone().view_as(p),
+                                         exp_avg_sq=old["exp_avg_sq"].to(device=p.device, dtype=F32).clone().view_as(p))
+            st["step"] = max(steps)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -142,6 +189,29 @@ class St355AdamWBF16(torch.optim.Optimizer):
         st["seg_end"] = torch.tensor(ends, dtype=torch.int64, device=dev)
         self._flat[gi] = st
         return st
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict: dict) -> None:
+        """resume: moments / shift copied into the flat bf16 arenas, per-tensor step and the owed decay restored (the delayed-decay phase of every
+        tensor continues where it stopped, optimizers/adamw_bfloat16/__init__.py:80-95)"""
+        saved = _unpack_saved_state(self, state_dict)
+        self._flat = {}
+        for p in list(self.state):
+            del self.state[p]
+        for gi, group in enumerate(self.param_groups):
+            st = self._init_group(gi, group)
+            steps = [0]
+            for p in st["ps"]:
+                old = saved.get(p)
+                if old is None:
+                    continue
+                mine = self.state[p]
+                for k in ("exp_avg", "exp_avg_sq", "shift"):
+                    mine[k].copy_(old[k].to(device=p.device, dtype=torch.bfloat16).view_as(p))
+                mine["step"] = float(old["step"])
+                mine["accumulated_decay"] = float(old["accumulated_decay"])
+                steps.append(int(float(old["step"])))
+            st["step"] = max(steps)
 
     @torch.no_grad()
     def step(self, zero_grad: bool = False, closure=None):

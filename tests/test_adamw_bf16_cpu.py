@@ -3,6 +3,7 @@ container (tools/gen_golden.py::gen_adamw_bf16 -> tests/golden/adamw_bf16_vector
 rounding draw recorded)."""
 from pathlib import Path
 
+import pytest
 import torch
 
 from oracle import train_math as TM
@@ -61,3 +62,48 @@ def test_decay_alpha_modes_differ_only_by_the_alpha_rounding():
     diff = (a[3].float() - b[3].float()).abs()
     bound = dec * a[0].float().abs() * 2.0 ** -7 + a[3].float().abs() * 2.0 ** -7 + 1e-9
     assert (diff <= bound).all() and (diff > 0).any()
+
+
+def test_optimizer_state_dict_resume_keeps_flat_arenas_and_fp32_moments():
+    """accelerator.save_state / load_state round trip (torch.optim.Optimizer.state_dict format): the loaded moments land INSIDE the flat arenas the
+    one-launch step reads, fp32 moments of bf16 parameters stay fp32 (torch's own loader would cast them to the parameter dtype), step counters and
+    AdamWBF16's per-tensor owed decay continue.  (The step itself is a HIP launch: tests/test_optimizer_state_gpu.py.)"""
+    import torch
+
+    from simpletuner_amd.training.optimizer import St355AdamW, St355AdamWBF16
+    arena = torch.zeros(24, dtype=torch.bfloat16)
+    ps = [torch.nn.Parameter(arena[:8].view(2, 4)), torch.nn.Parameter(arena[8:].view(4, 4))]
+    a = St355AdamW(ps, lr=3e-4, weight_decay=0.02)
+    st = a._group_flat(0, a.param_groups[0])
+    st["m"].copy_(torch.arange(24, dtype=torch.float32) * 1e-5 + 1.0 / 3.0)       # not representable in bf16
+    st["v"].copy_(torch.arange(24, dtype=torch.float32) * 1e-7 + 1e-3)
+    st["step"] = 5
+    for p in ps:
+        a.state[p]["step"] = torch.tensor(5.0)
+    sd = a.state_dict()
+    assert set(sd["state"][1]) == {"step", "exp_avg", "exp_avg_sq"} and sd["param_groups"][0]["lr"] == 3e-4
+    arena2 = torch.zeros(24, dtype=torch.bfloat16)
+    ps2 = [torch.nn.Parameter(arena2[:8].view(2, 4)), torch.nn.Parameter(arena2[8:].view(4, 4))]
+    b = St355AdamW(ps2, lr=1.0)
+    b.load_state_dict(sd)
+    sb = b._flat[0]
+    assert sb["ok"] and sb["step"] == 5 and sb["m"].dtype == torch.float32 and torch.equal(sb["m"], st["m"]) and torch.equal(sb["v"], st["v"])
+    assert b.param_groups[0]["lr"] == 3e-4 and b.param_groups[0]["weight_decay"] == 0.02
+    assert b.state[ps2[1]]["exp_avg"].data_ptr() == sb["m"][8:].data_ptr() and float(b.state[ps2[0]]["step"]) == 5.0
+    with pytest.raises(ValueError, match="parameter group"):
+        St355AdamW([torch.nn.Parameter(torch.zeros(3))]).load_state_dict(sd)
+
+    c = St355AdamWBF16(ps, lr=1e-4, weight_decay=0.01)
+    sc = c._init_group(0, c.param_groups[0])
+    sc["m"].copy_(torch.arange(24).to(torch.bfloat16)); sc["v"].fill_(0.25); sc["shift"].fill_(-0.5); sc["step"] = 9
+    for i, p in enumerate(ps):
+        c.state[p]["step"] = 9.0
+        c.state[p]["accumulated_decay"] = 1e-3 * (i + 1)
+    sd2 = c.state_dict()
+    assert set(sd2["state"][0]) == {"step", "exp_avg", "exp_avg_sq", "shift", "accumulated_decay"}
+    d = St355AdamWBF16(ps2, lr=1.0)
+    d.load_state_dict(sd2)
+    sdd = d._flat[0]
+    assert sdd["step"] == 9 and torch.equal(sdd["m"], sc["m"]) and torch.equal(sdd["v"], sc["v"]) and torch.equal(sdd["shift"], sc["shift"])
+    assert [d.state[p]["accumulated_decay"] for p in ps2] == [1e-3, 2e-3] and d.state[ps2[0]]["step"] == 9.0
+    assert d.state[ps2[1]]["shift"].data_ptr() == sdd["shift"][8:].data_ptr() and d.param_groups[0]["lr"] == 1e-4

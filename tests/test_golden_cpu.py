@@ -182,3 +182,37 @@ def test_grad_sync_bucketing_covers_arena_once():
     assert covered[0][0] == 0 and covered[-1][1] == 1000
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))                       # disjoint, gap-free
     assert all(hi - lo >= 300 for lo, hi in covered[1:])                                 # only the last flush may be small
+
+
+def test_ema_checkpoint_file_layout_roundtrip(tmp_path):
+    """`ema_model.pt` as the reference's hooks write / read it (ema.py:236-286, 500-524; save_hooks.py:396-443): torch.save of
+    {decay, min_decay, optimization_step, update_after_step, warmup_steps, use_ema_warmup, inv_gamma, power, shadow_params.{i}}; load takes the PATH"""
+    from types import SimpleNamespace
+
+    from simpletuner_amd.training.ema import EMAModel
+    arena = torch.arange(24, dtype=torch.float32)
+    params = [torch.nn.Parameter(arena[:8].view(2, 4)), torch.nn.Parameter(arena[8:24].view(4, 4))]
+    e = EMAModel(SimpleNamespace(), SimpleNamespace(process_index=0), params, decay=0.99, warmup_steps=3)
+    e.optimization_step = 17
+    path = tmp_path / "ema" / "ema_model.pt"
+    e.save_state_dict(str(path))
+    raw = torch.load(path, map_location="cpu", weights_only=True)               # the reference's own loader call
+    assert sorted(raw) == sorted(["decay", "min_decay", "optimization_step", "update_after_step", "warmup_steps", "use_ema_warmup", "inv_gamma", "power",
+                                  "shadow_params.0", "shadow_params.1"])
+    assert raw["optimization_step"] == 17 and raw["decay"] == 0.99 and raw["warmup_steps"] == 3 and torch.equal(raw["shadow_params.1"], arena[8:24].view(4, 4))
+    assert e.state_dict(exclude_params=True).keys() == {"decay", "min_decay", "optimization_step", "update_after_step", "warmup_steps", "use_ema_warmup", "inv_gamma", "power"}
+    e2 = EMAModel(SimpleNamespace(), SimpleNamespace(process_index=0), [torch.nn.Parameter(torch.zeros(2, 4)), torch.nn.Parameter(torch.zeros(4, 4))])
+    e2.load_state_dict(str(path))
+    assert e2.optimization_step == 17 and e2.decay == 0.99 and e2.warmup_steps == 3
+    assert torch.equal(e2.shadow_params[0], arena[:8].view(2, 4)) and torch.equal(e2.shadow_params[1], arena[8:].view(4, 4))
+    assert [n for n, _ in e2.named_parameters()] == ["shadow_params.0", "shadow_params.1"] and e2.parameter_count() == 24
+    e3 = EMAModel(SimpleNamespace(), SimpleNamespace(process_index=0), [torch.nn.Parameter(torch.zeros(2, 4))])
+    with pytest.raises(ValueError, match="Mismatch in number of shadow parameters"):
+        e3.load_state_dict(str(path))
+    # copy_to / store / restore (ema.py:435-498, 526-609)
+    live = [torch.nn.Parameter(torch.ones(2, 4)), torch.nn.Parameter(torch.ones(4, 4))]
+    e2.store(live)
+    e2.copy_to(live)
+    assert torch.equal(live[1].data, arena[8:].view(4, 4))
+    e2.restore(live)
+    assert torch.equal(live[1].data, torch.ones(4, 4))
