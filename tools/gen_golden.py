@@ -248,7 +248,31 @@ def gen_cubic_schedule():
     print("wrote", out)
 
 
+def gen_collate():
+    """compute_time_ids + gather_conditional_sdxl_size_features (helpers/training/collate.py:59-98, 501-523) executed as written (StateTracker /
+    logger stubbed: not the refiner) -> tests/golden/collate_vectors.pt"""
+    from types import SimpleNamespace
+    stub_log = SimpleNamespace(debug=lambda *a, **k: None)
+    stub_state = SimpleNamespace(is_sdxl_refiner=lambda: False)
+    p = REF / "helpers" / "training" / "collate.py"
+    cti, = extract(p, ["compute_time_ids"], extra_ns={"logger": stub_log, "StateTracker": stub_state})
+    gss, = extract(p, ["gather_conditional_sdxl_size_features"], extra_ns={"logger": stub_log, "StateTracker": stub_state, "compute_time_ids": cti})
+    G = {"time_ids": [], "sdxl": []}
+    for inter, tgt, crop in (((1024, 1024), (4, 128, 128), (0, 0)), ((1344, 896), (4, 96, 160), (64, 32)), ((640, 1536), (4, 192, 80), (0, 128))):
+        for dt in (torch.float32, torch.bfloat16):
+            G["time_ids"].append((inter, tgt, crop, dt, cti(inter, tgt, dt, crop_coordinates=list(crop))))
+    examples = [dict(intermediary_size=(1100, 1024), crop_coordinates=(0, 38), drop_conditioning=False),
+                dict(original_size=(2048, 2048), crop_coordinates=(10, 20), drop_conditioning=True),
+                dict(intermediary_size=(1024, 1400), original_size=(1, 1), crop_coordinates=(188, 0), drop_conditioning=False)]
+    lat = torch.zeros(3, 4, 128, 128)
+    G["sdxl"] = (examples, tuple(lat.shape), gss(examples, lat, torch.bfloat16))
+    out = OUT.parent / "collate_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_collate()
     gen_cubic_schedule()
     gen_adamw_bf16()
     gen_loss()
