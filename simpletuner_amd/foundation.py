@@ -312,8 +312,14 @@ class ModelFoundation(ExplorativeModelingMixin):
         return self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING
 
     def setup_training_noise_schedule(self):
+        """common.py:4518-4556: the TRAINING schedule — DDPM coefficients for epsilon / v families; for flow matching the Euler scheduler with the
+        static shift, its bounds reset to the unshifted ones (fix_flow_match_euler_schedule_bounds)"""
         if self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING:
             self.noise_schedule = DDPMSchedule(prediction_type=self.PREDICTION_TYPE.value, device=self.accelerator.device)
+        else:
+            from .sampling import FlowMatchEulerDiscreteScheduler, fix_flow_match_euler_schedule_bounds
+            self.noise_schedule = fix_flow_match_euler_schedule_bounds(
+                FlowMatchEulerDiscreteScheduler(shift=float(getattr(self.config, "flow_schedule_shift", None) or 1.0)))
         return self.noise_schedule
 
     def flow_matching_target_direction(self) -> float:

@@ -1,0 +1,157 @@
+"""Flow-matching Euler schedule + the sampling loop built on it — SURVEY.md §8(c) `tests/test_flow_match_scheduler_bounds.py` and §8(f)4.
+
+`FlowMatchEulerDiscreteScheduler` restates the scheduler the reference loads as its flow-matching *training* schedule (common.py:4528-4536:
+`diffusers.FlowMatchEulerDiscreteScheduler(shift=flow_schedule_shift)` followed by `fix_flow_match_euler_schedule_bounds`) and steps its
+validation pipelines with.  diffusers is un-vendored; the arithmetic is corroborated in-tree by the vendored copy at
+simpletuner/helpers/models/ace_step/schedulers/scheduling_flow_match_euler_discrete.py:71-330, which tools/gen_golden.py executes (with its
+three diffusers imports shimmed) to produce tests/golden/flow_match_scheduler_vectors.pt.
+
+The one behavioural subtlety the reference tests pin: with a STATIC shift, upstream computes `sigma_min / sigma_max` from the already-shifted
+training sigmas, so `set_timesteps` — which spaces timesteps between those bounds and shifts again — applies the shift twice
+(test_flow_match_scheduler_bounds.py:14-22 keeps that regression visible).  `fix_flow_match_euler_schedule_bounds` (training/flow_match.py:8-20)
+resets the bounds to the unshifted 1/N and 1.0; the vendored ACE-Step copy takes the bounds before shifting and needs no fix.  Both forms
+are here: `bounds="shifted"` (upstream, the default, to be passed through the fix exactly as the reference does) and `bounds="unshifted"`.
+
+Host logic: a few hundred scalars.  The per-step tensor update `x += (sigma_next - sigma) * v` is one fused torch op on whatever device the
+latents live on; the model call inside the loop is the same HIP forward the train step uses.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def fix_flow_match_euler_schedule_bounds(scheduler):
+    """training/flow_match.py:8-20: static-shift schedules get sigma_max = config.sigma_max (1.0) and sigma_min = 1 / num_train_timesteps back"""
+    cfg = getattr(scheduler, "config", None)
+    if cfg is None or getattr(cfg, "use_dynamic_shifting", False):
+        return scheduler
+    n = getattr(cfg, "num_train_timesteps", None)
+    if n is None:
+        return scheduler
+    scheduler.sigma_max = float(getattr(cfg, "sigma_max", 1.0) or 1.0)
+    scheduler.sigma_min = 1.0 / float(n)
+    return scheduler
+
+
+class FlowMatchEulerDiscreteScheduler:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0, use_dynamic_shifting: bool = False, base_shift: Optional[float] = 0.5,
+                 max_shift: Optional[float] = 1.15, base_image_seq_len: Optional[int] = 256, max_image_seq_len: Optional[int] = 4096,
+                 sigma_max: Optional[float] = 1.0, bounds: str = "shifted"):
+        if bounds not in ("shifted", "unshifted"):
+            raise ValueError("bounds must be 'shifted' (upstream diffusers) or 'unshifted' (the vendored ACE-Step form)")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=use_dynamic_shifting, base_shift=base_shift,
+                                      max_shift=max_shift, base_image_seq_len=base_image_seq_len, max_image_seq_len=max_image_seq_len, sigma_max=sigma_max)
+        t = np.linspace(1.0, (sigma_max or 1.0) * num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = torch.from_numpy(t).to(torch.float32) / num_train_timesteps
+        raw_min, raw_max = sig[-1].item(), sig[0].item()
+        if not use_dynamic_shifting:                                   # dynamic: shifted on the fly from the image resolution (set_timesteps(mu=))
+            sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = sig * num_train_timesteps
+        self.sigmas = sig.to("cpu")
+        if bounds == "unshifted":
+            self.sigma_min, self.sigma_max = raw_min, raw_max
+        else:
+            self.sigma_min, self.sigma_max = self.sigmas[-1].item(), self.sigmas[0].item()
+        self.num_inference_steps = None
+        self._step_index = None
+        self._begin_index = None
+
+    step_index = property(lambda self: self._step_index)
+    begin_index = property(lambda self: self._begin_index)
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    def _sigma_to_t(self, sigma):
+        return sigma * self.config.num_train_timesteps
+
+    @staticmethod
+    def time_shift(mu: float, sigma: float, t):
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None, sigmas: Optional[Sequence[float]] = None, mu: Optional[float] = None):
+        """ace_step/.../scheduling_flow_match_euler_discrete.py:196-240"""
+        if self.config.use_dynamic_shifting and mu is None:
+            raise ValueError(" you have a pass a value for `mu` when `use_dynamic_shifting` is set to be `True`")
+        if sigmas is None:
+            self.num_inference_steps = num_inference_steps
+            sigmas = np.linspace(self._sigma_to_t(self.sigma_max), self._sigma_to_t(self.sigma_min), num_inference_steps) / self.config.num_train_timesteps
+        else:
+            sigmas = np.asarray(sigmas, dtype=np.float64)
+            self.num_inference_steps = len(sigmas)
+        if self.config.use_dynamic_shifting:
+            sigmas = self.time_shift(mu, 1.0, sigmas)
+        else:
+            sigmas = self.config.shift * sigmas / (1 + (self.config.shift - 1) * sigmas)
+        sigmas = torch.from_numpy(np.asarray(sigmas)).to(dtype=torch.float32, device=device)
+        self.timesteps = (sigmas * self.config.num_train_timesteps).to(device=device)
+        self.sigmas = torch.cat([sigmas, torch.zeros(1, device=sigmas.device)])
+        self._step_index = None
+        self._begin_index = None
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        sched = self.timesteps if schedule_timesteps is None else schedule_timesteps
+        hits = (sched == timestep).nonzero()
+        return hits[1 if len(hits) > 1 else 0].item()                  # a duplicated first timestep resolves to its second entry (img2img starts)
+
+    def _init_step_index(self, timestep):
+        if self._begin_index is None:
+            if isinstance(timestep, torch.Tensor):
+                timestep = timestep.to(self.timesteps.device)
+            self._step_index = self.index_for_timestep(timestep)
+        else:
+            self._step_index = self._begin_index
+
+    def scale_noise(self, sample: torch.Tensor, timestep: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """forward process at scheduler timesteps: sigma * noise + (1 - sigma) * sample (:128-186)"""
+        sig = self.sigmas.to(device=sample.device, dtype=sample.dtype)
+        sched = self.timesteps.to(sample.device)
+        timestep = timestep.to(sample.device)
+        if self._begin_index is None:
+            idx = [self.index_for_timestep(t, sched) for t in timestep]
+        elif self._step_index is not None:
+            idx = [self._step_index] * timestep.shape[0]
+        else:
+            idx = [self._begin_index] * timestep.shape[0]
+        s = sig[idx].flatten()
+        s = s.reshape(-1, *([1] * (sample.dim() - 1)))
+        return s * noise + (1.0 - s) * sample
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True, **_unused):
+        """x_{i+1} = x_i + (sigma_{i+1} - sigma_i) * v, accumulated in fp32, returned in the model output's dtype (:258-330 with omega = 0)"""
+        if isinstance(timestep, int) or (torch.is_tensor(timestep) and not timestep.is_floating_point()):
+            raise ValueError("Passing integer indices (e.g. from `enumerate(timesteps)`) as timesteps to `EulerDiscreteScheduler.step()` is not supported."
+                             " Make sure to pass one of the `scheduler.timesteps` as a timestep.")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma, sigma_next = self.sigmas[self._step_index], self.sigmas[self._step_index + 1]
+        prev = (sample.to(torch.float32) + (sigma_next - sigma) * model_output).to(model_output.dtype)
+        self._step_index += 1
+        return SimpleNamespace(prev_sample=prev) if return_dict else (prev,)
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+def flow_match_euler_sample(predict: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], latents: torch.Tensor, scheduler: FlowMatchEulerDiscreteScheduler,
+                            num_inference_steps: int, mu: Optional[float] = None, sigmas: Optional[Sequence[float]] = None,
+                            on_step: Optional[Callable[[int, torch.Tensor], None]] = None) -> torch.Tensor:
+    """The denoising loop of the flow-matching pipelines (e.g. flux/pipeline.py `__call__`): start from noise, call `predict(x, t[B])` — the
+    velocity prediction of the trained component, timesteps in scheduler units (0-1000) — and take one Euler step per schedule entry.
+    Conditioning, guidance and packing belong to `predict` (the plugin's own forward), so the loop is family-agnostic."""
+    scheduler.set_timesteps(num_inference_steps, device=latents.device, mu=mu, sigmas=sigmas)
+    x = latents
+    with torch.no_grad():
+        for i, t in enumerate(scheduler.timesteps):
+            v = predict(x, t.expand(x.shape[0]))
+            x = scheduler.step(v, t, x, return_dict=False)[0]
+            if on_step is not None:
+                on_step(i, x)
+    return x

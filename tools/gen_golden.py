@@ -271,7 +271,77 @@ def gen_collate():
     print("wrote", out)
 
 
+def gen_flow_match_scheduler():
+    """the flow-match Euler scheduler vendored in the reference tree (helpers/models/ace_step/schedulers/scheduling_flow_match_euler_discrete.py)
+    loaded as a module with its three diffusers imports shimmed (ConfigMixin / SchedulerMixin / register_to_config / BaseOutput / logging: no
+    arithmetic lives in them) -> tests/golden/flow_match_scheduler_vectors.pt"""
+    import importlib.util
+    import inspect
+    from types import SimpleNamespace
+
+    def register_to_config(init):
+        def wrapped(self, *a, **kw):
+            b = inspect.signature(init).bind(self, *a, **kw)
+            b.apply_defaults()
+            self.config = SimpleNamespace(**{k: v for k, v in b.arguments.items() if k != "self"})
+            init(self, *a, **kw)
+        return wrapped
+
+    class _Out(dict):
+        pass
+
+    shims = {"diffusers": types.ModuleType("diffusers"), "diffusers.configuration_utils": types.ModuleType("diffusers.configuration_utils"),
+             "diffusers.schedulers": types.ModuleType("diffusers.schedulers"), "diffusers.schedulers.scheduling_utils": types.ModuleType("diffusers.schedulers.scheduling_utils"),
+             "diffusers.utils": types.ModuleType("diffusers.utils")}
+    shims["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixin", (), {})
+    shims["diffusers.configuration_utils"].register_to_config = register_to_config
+    shims["diffusers.schedulers.scheduling_utils"].SchedulerMixin = type("SchedulerMixin", (), {})
+    shims["diffusers.utils"].BaseOutput = _Out
+    shims["diffusers.utils"].logging = SimpleNamespace(get_logger=lambda *_a, **_k: SimpleNamespace(warning=print, info=print, debug=lambda *a, **k: None))
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_fm_sched", REF / "helpers" / "models" / "ace_step" / "schedulers" / "scheduling_flow_match_euler_discrete.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    Sch = mod.FlowMatchEulerDiscreteScheduler
+    G = {"cases": []}
+    g = torch.Generator().manual_seed(4)
+    for kw, steps, mu in ((dict(num_train_timesteps=10, shift=3.0), 10, None), (dict(num_train_timesteps=1000, shift=3.0), 28, None),
+                          (dict(num_train_timesteps=1000, shift=1.0), 20, None), (dict(num_train_timesteps=1000, use_dynamic_shifting=True), 28, 1.15),
+                          (dict(num_train_timesteps=1000, use_dynamic_shifting=True), 4, 0.5)):
+        sc = Sch(**kw)
+        rec = dict(kw=kw, steps=steps, mu=mu, init_sigmas=sc.sigmas.clone(), init_timesteps=sc.timesteps.clone(), sigma_min=sc.sigma_min, sigma_max=sc.sigma_max)
+        sc.set_timesteps(num_inference_steps=steps, mu=mu)
+        rec.update(sigmas=sc.sigmas.clone(), timesteps=sc.timesteps.clone())
+        x = torch.randn(2, 4, 8, 8, generator=g)
+        traj = [x.clone()]
+        vs = []
+        for t in sc.timesteps:
+            v = torch.randn(2, 4, 8, 8, generator=g)
+            vs.append(v)
+            x = sc.step(v, t, x, return_dict=False)[0]
+            traj.append(x.clone())
+        rec.update(v=torch.stack(vs), traj=torch.stack(traj))
+        sc2 = Sch(**kw)
+        sc2.set_timesteps(num_inference_steps=steps, mu=mu)
+        smp, noi = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 8, 8, generator=g)
+        ts = sc2.timesteps[[0, steps // 2, steps - 1]]
+        rec.update(sn_sample=smp, sn_noise=noi, sn_t=ts.clone(), sn_out=sc2.scale_noise(smp, ts, noi).clone())
+        G["cases"].append(rec)
+    out = OUT.parent / "flow_match_scheduler_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_flow_match_scheduler()
     gen_collate()
     gen_cubic_schedule()
     gen_adamw_bf16()
