@@ -340,7 +340,45 @@ def gen_flow_match_scheduler():
     print("wrote", out)
 
 
+def gen_cache_names():
+    """VAECache.generate_vae_cache_filename (caching/vae.py:678-703) and TextEmbeddingCache._normalize_key_value / create_hash
+    (caching/text_embeds.py:126-154) lifted as methods and run on stub instances; base data backend's gzip container
+    (data_backend/base.py:126-153) for one payload -> tests/golden/cache_io_vectors.pt"""
+    import gzip
+    import hashlib
+    import os
+    from enum import Enum
+    from hashlib import sha256
+    from io import BytesIO
+    from types import SimpleNamespace
+    gen, = extract(REF / "helpers" / "caching" / "vae.py", ["generate_vae_cache_filename"], class_name="VAECache", extra_ns={"os": os, "sha256": sha256})
+
+    class Key(Enum):
+        CAPTION = "caption"; FILENAME = "filename"; DATASET_AND_FILENAME = "dataset_and_filename"
+    norm, mk = extract(REF / "helpers" / "caching" / "text_embeds.py", ["_normalize_key_value", "create_hash"], class_name="TextEmbeddingCache",
+                       extra_ns={"os": os, "hashlib": hashlib, "TextEmbedCacheKey": Key, "canonicalize_data_uri": lambda x: x})
+    G = {"vae": [], "text": []}
+    for fp, cache_dir, inst, hashed in (("/data/imgs/cat.png", "/cache/vae", "/data/imgs", False), ("/data/imgs/sub/dir/dog.v2.jpeg", "/cache/vae", "/data/imgs", False),
+                                        ("/data/imgs/sub/dog.jpg", "/cache/vae", "/data/imgs", True), ("/elsewhere/bird.webp", "/cache/vae", None, True),
+                                        ("/cache/vae/already.pt", "/cache/vae", "/data/imgs", True)):
+        stub = SimpleNamespace(image_data_backend=SimpleNamespace(), hash_filenames=hashed, cache_dir=cache_dir, instance_data_dir=inst)
+        G["vae"].append((fp, cache_dir, inst, hashed, gen(stub, fp)))
+    for key, prompt, model_type, path_based, key_type in (("a photo of a cat", "a photo of a cat", "flux", False, Key.CAPTION), ("", "", "sdxl", False, Key.CAPTION),
+                                                          ("ünïcode ✓ caption", None, "sd3", False, Key.CAPTION), ("/data/imgs/cat.png", "a cat", "pixart_sigma", True, Key.FILENAME),
+                                                          (None, None, "flux", False, Key.CAPTION)):
+        stub = SimpleNamespace(model_type=model_type, key_type=key_type, _requires_path_based_keys=path_based)
+        stub._normalize_key_value = lambda kv, _s=stub: norm(_s, kv)
+        G["text"].append((key, prompt, model_type, path_based, key_type is Key.FILENAME, mk(stub, key, prompt=prompt)))
+    payload = {"prompt_embeds": torch.arange(12, dtype=torch.float32).reshape(1, 3, 4).to(torch.bfloat16), "pooled_prompt_embeds": torch.ones(1, 4)}
+    comp, = extract(REF / "helpers" / "data_backend" / "base.py", ["_compress_torch"], class_name="BaseDataBackend", extra_ns={"BytesIO": BytesIO, "gzip": gzip})
+    G["gz_payload"], G["gz_bytes"] = payload, comp(SimpleNamespace(), payload)
+    out = OUT.parent / "cache_io_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_cache_names()
     gen_flow_match_scheduler()
     gen_collate()
     gen_cubic_schedule()
