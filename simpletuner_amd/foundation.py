@@ -201,6 +201,10 @@ class ModelFoundation(ExplorativeModelingMixin):
     LATENT_CHANNEL_COUNT = 16
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
     DDP_FIND_UNUSED_PARAMETERS = False
+    PIPELINE_CLASSES: Dict[str, Any] = {}        # validation pipelines are outside this tier (sampling.py holds the denoising loop)
+    TEXT_ENCODER_CONFIGURATION: Dict[str, Any] = {}   # text encoders run offline into the embed cache (training/cache_io.py reads it)
+    AUTOENCODER_CLASS = None                     # set per family below (lazy: the class needs the device library)
+    VAE_CONFIG: Dict[str, Any] = {}              # constructor arguments of the family's AutoencoderKL (upstream `vae/config.json` values)
 
     def __init__(self, config, accelerator):
         self.config = config
@@ -209,6 +213,43 @@ class ModelFoundation(ExplorativeModelingMixin):
         self.noise_schedule = None
         self._noise_step = 0
         self.xm_config = ExplorativeModelingConfig.from_config(config)     # common.py:578
+
+    # ---- latent encode seam (common.py:2653-2772, foundation_mixins.py:66-79) ----
+    @classmethod
+    def autoencoder_class(cls):
+        if cls.AUTOENCODER_CLASS is None:
+            from .vae.autoencoder_kl import AutoencoderKL
+            return AutoencoderKL
+        return cls.AUTOENCODER_CLASS
+
+    def load_vae(self, state_dict=None, move_to_device: bool = True):
+        """common.py:2663: build the family's AutoencoderKL (encoder half; diffusers state-dict keys).  Without a state dict the weights are
+        synthetic (benchmarks, tests) — there is no hub access here."""
+        vae = self.autoencoder_class()(device=self.accelerator.device, **self.VAE_CONFIG)
+        vae.load_state_dict(state_dict if state_dict is not None else vae.synthetic_state_dict(int(getattr(self.config, "seed", 42) or 42)))
+        self.vae = vae
+        return vae
+
+    def get_vae(self):
+        if getattr(self, "vae", None) is None:
+            self.load_vae()
+        return self.vae
+
+    @torch.no_grad()
+    def encode_with_vae(self, vae, samples):
+        return vae.encode(samples)
+
+    def scale_vae_latents_for_cache(self, latents, vae):
+        """foundation_mixins.py:66-79: (z - shift) * scale when the VAE has a shift factor, z * scale otherwise"""
+        if vae is None or not hasattr(vae, "config") or latents is None:
+            return latents
+        shift = getattr(vae.config, "shift_factor", None)
+        scale = getattr(self, "AUTOENCODER_SCALING_FACTOR", getattr(vae.config, "scaling_factor", 1.0))
+        if shift is not None:
+            return (latents - shift) * scale
+        if isinstance(latents, torch.Tensor) and hasattr(vae.config, "scaling_factor"):
+            return latents * scale
+        return latents
 
     # ---- prediction entry points; XM (off by default) expands the batch with K noise candidates first (flux/model.py:630-636, 940-946) ----
     def model_predict(self, prepared_batch: dict):

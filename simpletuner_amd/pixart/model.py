@@ -22,6 +22,8 @@ class PixartSigma(ModelFoundation):
     MODEL_CLASS = PixArtTransformer2DModel
     MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 4
+    VAE_CONFIG = dict(latent_channels=4, scaling_factor=0.13025)
+    DEFAULT_MODEL_FLAVOUR = "900M-1024-v0.6"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
     HUGGINGFACE_PATHS = {"900M-1024-v0.6": "terminusresearch/pixart-900m-1024-ft-v0.6", "600M-2048": "PixArt-alpha/PixArt-Sigma-XL-2-2K-MS"}
 

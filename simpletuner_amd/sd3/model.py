@@ -22,6 +22,7 @@ class SD3(ModelFoundation):
     MODEL_CLASS = SD3Transformer2DModel
     MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 16
+    VAE_CONFIG = dict(latent_channels=16, scaling_factor=1.5305, shift_factor=0.0609, use_quant_conv=False)
     DEFAULT_MODEL_FLAVOUR = "medium"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
     HUGGINGFACE_PATHS = {"medium": "stabilityai/stable-diffusion-3-medium-diffusers", "large": "stabilityai/stable-diffusion-3.5-large"}

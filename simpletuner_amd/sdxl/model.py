@@ -23,6 +23,7 @@ class SDXL(ModelFoundation):
     MODEL_CLASS = UNet2DConditionModel
     MODEL_SUBFOLDER = "unet"
     LATENT_CHANNEL_COUNT = 4
+    VAE_CONFIG = dict(latent_channels=4, scaling_factor=0.13025)
     DEFAULT_MODEL_FLAVOUR = "base-1.0"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
     HUGGINGFACE_PATHS = {"base-1.0": "stabilityai/stable-diffusion-xl-base-1.0"}

@@ -210,3 +210,29 @@ def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
             m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
         with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
             m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
+
+
+def test_vae_seam_attributes_and_latent_scaling_rule():
+    """plugin class attributes the trainer reads (common.py:451-530) and scale_vae_latents_for_cache (foundation_mixins.py:66-79)"""
+    from types import SimpleNamespace
+
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.pixart.model import PixartSigma
+    from simpletuner_amd.sd1x.model import StableDiffusion1
+    from simpletuner_amd.sd3.model import SD3
+    from simpletuner_amd.sdxl.model import SDXL
+    for cls, ch in ((Flux, 16), (SD3, 16), (SDXL, 4), (StableDiffusion1, 4), (PixartSigma, 4)):
+        assert cls.autoencoder_class().__name__ == "AutoencoderKL" and cls.VAE_CONFIG["latent_channels"] == ch == cls.LATENT_CHANNEL_COUNT
+        for attr in ("NAME", "PREDICTION_TYPE", "MODEL_TYPE", "MODEL_CLASS", "MODEL_SUBFOLDER", "PIPELINE_CLASSES", "HUGGINGFACE_PATHS", "DEFAULT_MODEL_FLAVOUR",
+                     "TEXT_ENCODER_CONFIGURATION", "LATENT_CHANNEL_COUNT", "DEFAULT_LORA_TARGET", "DDP_FIND_UNUSED_PARAMETERS"):
+            assert hasattr(cls, attr), (cls.__name__, attr)
+        assert cls.DEFAULT_MODEL_FLAVOUR in cls.HUGGINGFACE_PATHS
+    m = Flux.__new__(Flux)
+    z = torch.tensor([1.0, -2.0])
+    shifted = SimpleNamespace(config=SimpleNamespace(shift_factor=0.1159, scaling_factor=0.3611))
+    plain = SimpleNamespace(config=SimpleNamespace(shift_factor=None, scaling_factor=0.13025))
+    assert torch.allclose(m.scale_vae_latents_for_cache(z, shifted), (z - 0.1159) * 0.3611)
+    assert torch.allclose(m.scale_vae_latents_for_cache(z, plain), z * 0.13025)
+    assert m.scale_vae_latents_for_cache(z, None) is z and m.scale_vae_latents_for_cache(None, plain) is None
+    m.AUTOENCODER_SCALING_FACTOR = 2.0                              # a family-level override wins over the VAE's own factor
+    assert torch.allclose(m.scale_vae_latents_for_cache(z, plain), z * 2.0)

@@ -47,3 +47,20 @@ def test_softmax_rows_kernel():
         ref = torch.softmax(x.float() * 0.7, dim=-1)
         got = ops.softmax_rows_(x.clone(), 0.7)
         assert (got.float() - ref).abs().max().item() < 4e-3 and abs(got.float().sum(-1).mean().item() - 1.0) < 2e-3
+
+
+def test_plugin_vae_seam_encodes_and_scales_like_encode_scaled():
+    """ModelFoundation.load_vae / encode_with_vae / scale_vae_latents_for_cache (common.py:2663-2772, foundation_mixins.py:66-79) on the Flux layout:
+    the three-call form of the reference's VAECache equals the fused encode_scaled() pass"""
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    dev = torch.device("cuda", 0)
+    pl = Flux(default_config(model_family="flux"), St355Accelerator(dev))
+    vae = pl.get_vae()
+    assert vae is pl.vae and vae.config.latent_channels == 16 and vae.config.shift_factor == 0.1159
+    x = (torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(torch.bfloat16).to(dev)
+    dist = pl.encode_with_vae(vae, x).latent_dist
+    z = pl.scale_vae_latents_for_cache(dist.mode(), vae)
+    assert z.shape == (1, 16, 8, 8) and torch.isfinite(z.float()).all()
+    want = vae.encode_scaled(x, sample=False)
+    assert torch.allclose(z.float(), want.float(), rtol=2e-2, atol=2e-2)
