@@ -42,6 +42,8 @@ class Flux(ModelFoundation):
     MODEL_CLASS = FluxTransformer2DModel
     MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 16
+    COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES = {"transformer"}      # flux/model.py:56-57
+    AUTO_LORA_FORMAT_DETECTION = True
     VAE_CONFIG = dict(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False)
     DEFAULT_MODEL_FLAVOUR = "dev"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]

@@ -312,34 +312,101 @@ class ModelFoundation(ExplorativeModelingMixin):
         return {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p.detach()
                 for n, p in comp.named_parameters() if ".lora_" in n}
 
+    COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES = None     # common.py:524; Flux / SD3 / PixArt keep their `transformer.` prefix in ComfyUI files
+    AUTO_LORA_FORMAT_DETECTION = False                  # flux/model.py:56: a diffusers-configured run still recognises a ComfyUI file on load
+
+    def _lora_adapter_metadata(self) -> dict:
+        """what peft records for the adapter (LoraConfig r / lora_alpha): alpha defaults to the rank (common.py:1049-1128)"""
+        r = int(getattr(self.config, "lora_rank", 0) or 0)
+        alpha = getattr(self.config, "lora_alpha", None)
+        return {"r": r, "lora_alpha": float(alpha if alpha is not None else r)}
+
+    def _convert_lora_state_dict_to_comfyui(self, weights: dict, *, adapter_metadata=None, component_adapter_metadata=None) -> dict:
+        from .training.lora_keys import convert_diffusers_to_comfyui
+        return convert_diffusers_to_comfyui(weights, adapter_metadata=adapter_metadata,
+                                            preserve_component_prefixes=self.COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES)
+
+    def _convert_lora_state_dict_from_comfyui(self, weights: dict, *, target_prefix: str):
+        from .training.lora_keys import convert_comfyui_to_diffusers
+        return convert_comfyui_to_diffusers(weights, target_prefix=target_prefix)
+
     def save_lora_weights(self, output_dir, **layers):
         """writes `pytorch_lora_weights.safetensors` with diffusers' component prefix (`transformer.` / `unet.`), as the diffusers pipelines'
-        save_lora_weights the reference calls (common.py:2072); `layers` = {"<subfolder>_lora_layers": state} or nothing (= the trained component)"""
+        save_lora_weights the reference calls (common.py:2072-2120); `layers` = {"<subfolder>_lora_layers": state} or nothing (= the trained
+        component).  `config.lora_format == "comfyui"` converts the keys on the way out (ComfyUI / kohya names + one `.alpha` tensor per module)."""
         import os
 
         from safetensors.torch import save_file
-        if not layers:
-            layers = {f"{self.MODEL_SUBFOLDER}_lora_layers": self.lora_state_dict()}
-        flat = {}
+
+        from .training.lora_keys import PEFTLoRAFormat, normalize_lora_format
+        if not any(k.endswith("_lora_layers") for k in layers):
+            layers = dict(layers, **{f"{self.MODEL_SUBFOLDER}_lora_layers": self.lora_state_dict()})
+        flat, meta, comp_meta = {}, {}, {}
         for key, state in layers.items():
+            if key.endswith("lora_adapter_metadata") and isinstance(state, dict):
+                comp_meta[key[:-len("_lora_adapter_metadata")]] = state
+                meta.update(state)
+                continue
             if state is None or not key.endswith("_lora_layers"):
                 continue
             prefix = key[:-len("_lora_layers")]
             for k, v in state.items():
                 flat[f"{prefix}.{k}"] = v.detach().to("cpu").contiguous()
+        fmt = normalize_lora_format(getattr(self.config, "lora_format", None))
+        if fmt == PEFTLoRAFormat.COMFYUI and not getattr(self, "NATIVE_COMFYUI_LORA_SUPPORT", False):
+            flat = self._convert_lora_state_dict_to_comfyui(flat, adapter_metadata=meta or self._lora_adapter_metadata(), component_adapter_metadata=comp_meta)
+            flat = {k: v.contiguous() for k, v in flat.items()}
         os.makedirs(output_dir, exist_ok=True)
         path = os.path.join(output_dir, self.LORA_WEIGHT_NAME)
         save_file(flat, path, metadata={"format": "pt"})
         return path
 
+    def _kohya_name_map(self) -> dict:
+        """kohya module name -> this component's module path, built forwards from the adapters that exist (the underscore-joined kohya spelling
+        cannot be split back into a dotted path on its own)"""
+        out = {}
+        for n, _p in self.get_trained_component().named_parameters():
+            if ".lora_A." in n:
+                module = n[:n.index(".lora_A.")]
+                out["lora_unet_" + module.replace(".processor.", ".").replace(".", "_")] = module
+        return out
+
     def load_lora_weights(self, models=None, input_dir=None):
-        """common.py:1875: read the file back into the adapters of the trained component (strict on the adapter keys)"""
+        """common.py:1875-2047: read the file back into the adapters of the trained component (strict on the adapter keys).  ComfyUI-dialect files
+        (configured, or detected when AUTO_LORA_FORMAT_DETECTION) are converted first; a per-module alpha that disagrees with the configured
+        adapter scale is an error here — the adapters' alpha/r scale is fixed at construction, loading must not silently change the model."""
         import os
 
         from safetensors.torch import load_file
+
+        from .training.lora_keys import PEFTLoRAFormat, detect_state_dict_format, normalize_lora_format, to_peft_keys
         comp = self.get_trained_component()
         flat = load_file(os.path.join(input_dir, self.LORA_WEIGHT_NAME))
         prefix = f"{self.MODEL_SUBFOLDER}."
+        fmt = normalize_lora_format(getattr(self.config, "lora_format", None))
+        if fmt == PEFTLoRAFormat.DIFFUSERS and self.AUTO_LORA_FORMAT_DETECTION and detect_state_dict_format(flat) == PEFTLoRAFormat.COMFYUI:
+            fmt = PEFTLoRAFormat.COMFYUI
+        if fmt == PEFTLoRAFormat.COMFYUI:
+            alphas = {}
+            if any(k.startswith("lora_unet_") for k in flat):                 # kohya names (SD / SDXL export)
+                back, conv = self._kohya_name_map(), {}
+                for k, v in flat.items():
+                    name, _, tail = k.partition(".")
+                    if name not in back:
+                        continue
+                    if tail == "alpha":
+                        alphas[f"{prefix}{back[name]}.alpha"] = float(v)
+                    else:
+                        conv[f"{prefix}{back[name]}." + {"lora_down.weight": "lora_A.weight", "lora_up.weight": "lora_B.weight"}[tail]] = v
+                flat = conv
+            else:
+                flat, alphas = self._convert_lora_state_dict_from_comfyui(flat, target_prefix=self.MODEL_SUBFOLDER)
+                flat = to_peft_keys(flat)
+            want = self._lora_adapter_metadata()["lora_alpha"]
+            bad = {k: a for k, a in alphas.items() if want and abs(a - want) > 1e-6}
+            if bad:
+                k0 = next(iter(bad))
+                raise ValueError(f"LoRA file alpha {bad[k0]} for {k0} differs from the configured lora_alpha {want}; set lora_alpha to match the file")
         own = {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p for n, p in comp.named_parameters() if ".lora_" in n}
         missing = [k for k in own if prefix + k not in flat]
         if missing:

@@ -59,6 +59,11 @@ class StableDiffusion1(ModelFoundation):
     def enable_full_finetune(self):
         return self.unwrap_model(self.model).enable_full_finetune()
 
+    def _convert_lora_state_dict_to_comfyui(self, weights: dict, *, adapter_metadata=None, component_adapter_metadata=None) -> dict:
+        """sd1x/model.py:51-65: SD-family ComfyUI files use kohya names (`lora_unet_<module path with _>.lora_down/.lora_up.weight` + `.alpha`)"""
+        from ..training.lora_keys import convert_diffusers_to_comfyui_sd_lora
+        return convert_diffusers_to_comfyui_sd_lora(weights, adapter_metadata=adapter_metadata, component_adapter_metadata=component_adapter_metadata, sdxl=False)
+
     def _model_predict_single(self, prepared_batch: dict):
         """sd1x/model.py:224-270"""
         dev = self.accelerator.device

@@ -22,6 +22,7 @@ class SD3(ModelFoundation):
     MODEL_CLASS = SD3Transformer2DModel
     MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 16
+    COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES = {"transformer"}      # sd3/model.py:117
     VAE_CONFIG = dict(latent_channels=16, scaling_factor=1.5305, shift_factor=0.0609, use_quant_conv=False)
     DEFAULT_MODEL_FLAVOUR = "medium"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]

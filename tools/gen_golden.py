@@ -377,7 +377,74 @@ def gen_cache_names():
     print("wrote", out)
 
 
+def _lora_key_cases():
+    """state dicts in every dialect the converters see (shapes only matter through rank / in / out)"""
+    g = torch.Generator().manual_seed(9)
+    def AB(r, i, o):
+        return torch.randn(r, i, generator=g), torch.randn(o, r, generator=g)
+    peft_tr, peft_unet, old = {}, {}, {}
+    for mod, r in (("transformer_blocks.0.attn.to_q", 4), ("transformer_blocks.0.attn.to_out.0", 4), ("single_transformer_blocks.3.attn.to_k", 8)):
+        a, b = AB(r, 16, 16)
+        peft_tr[f"transformer.{mod}.lora_A.weight"], peft_tr[f"transformer.{mod}.lora_B.weight"] = a, b
+    for mod in ("down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q", "mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_v"):
+        a, b = AB(4, 16, 16)
+        peft_unet[f"unet.{mod}.lora_A.weight"], peft_unet[f"unet.{mod}.lora_B.weight"] = a, b
+        old[f"unet.{mod}.lora.down.weight"], old[f"unet.{mod}.lora.up.weight"] = a, b
+    a, b = AB(4, 16, 16)
+    peft_unet["text_encoder.text_model.encoder.layers.0.self_attn.q_proj.lora_A.weight"], peft_unet["text_encoder.text_model.encoder.layers.0.self_attn.q_proj.lora_B.weight"] = a, b
+    a, b = AB(4, 16, 16)
+    peft_unet["text_encoder_2.text_model.encoder.layers.1.mlp.fc1.lora_A.weight"], peft_unet["text_encoder_2.text_model.encoder.layers.1.mlp.fc1.lora_B.weight"] = a, b
+    peft_unet["unet.some.buffer"] = torch.zeros(2)
+    comfy = {}
+    for mod, r, al in (("double_blocks.0.img_attn.qkv", 4, 8.0), ("single_blocks.1.linear1", 8, 8.0)):
+        a, b = AB(r, 16, 16)
+        comfy[f"diffusion_model.{mod}.lora_A.weight"], comfy[f"diffusion_model.{mod}.lora_B.weight"] = a, b
+        comfy[f"diffusion_model.{mod}.alpha"] = torch.tensor(al)
+    comfy["transformer.x.lora_A.weight"], comfy["bare.module.lora_B.weight"] = AB(4, 16, 16)
+    return dict(peft_tr=peft_tr, peft_unet=peft_unet, old=old, comfy=comfy)
+
+
+def gen_lora_keys():
+    """helpers/training/lora_format.py loaded as a module where it lies (torch + stdlib only) and run over the dialect zoo above ->
+    tests/golden/lora_keys_vectors.pt (keys, alpha values, shapes)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_lora_format", REF / "helpers" / "training" / "lora_format.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Z = _lora_key_cases()
+    meta = {"lora_alpha": 16, "alpha_pattern": {"single_transformer_blocks.3.attn.to_k": 2.0}}
+
+    def shape_of(d):
+        return {k: (tuple(v.shape), (float(v) if v.ndim == 0 else None)) for k, v in d.items()}
+    G = {"detect": {n: (None if mod.detect_state_dict_format(d) is None else mod.detect_state_dict_format(d).value) for n, d in dict(Z, empty={}).items()},
+         "normalize": {repr(v): mod.normalize_lora_format(v).value for v in (None, "", "ComfyUI ", "comfyui", "diffusers", "kohya", 3)},
+         "ranks": {n: mod.collect_lora_ranks(d) for n, d in Z.items()},
+         "ranks_stripped": mod.collect_lora_ranks(Z["peft_tr"], prefix_to_strip="transformer."),
+         "alphas": {n: mod.collect_lora_alphas(d) for n, d in Z.items()},
+         "synth": {n: mod.synthesize_missing_lora_alphas_from_ranks(d) for n, d in Z.items()},
+         "synth_existing": mod.synthesize_missing_lora_alphas_from_ranks(Z["peft_tr"], existing_alphas={"x.alpha": 1.0}),
+         "peft_kwargs": {n: mod.peft_lora_config_kwargs_from_state_dict(d) for n, d in Z.items()},
+         "to_comfy": shape_of(mod.convert_diffusers_to_comfyui(Z["peft_tr"])),
+         "to_comfy_keep_meta": shape_of(mod.convert_diffusers_to_comfyui(Z["peft_tr"], adapter_metadata=meta, preserve_component_prefixes={"transformer"})),
+         "to_comfy_old": shape_of(mod.convert_diffusers_to_comfyui(Z["old"], adapter_metadata={"lora_alpha": torch.tensor(4.0)})),
+         "to_kohya_sdxl": shape_of(mod.convert_diffusers_to_comfyui_sd_lora(Z["peft_unet"], adapter_metadata={"lora_alpha": 8},
+                                                                             component_adapter_metadata={"text_encoder": {"lora_alpha": 2}}, sdxl=True)),
+         "to_kohya_sd15": shape_of(mod.convert_diffusers_to_comfyui_sd_lora(Z["old"], sdxl=False)),
+         "from_comfy": (lambda r: (shape_of(r[0]), r[1]))(mod.convert_comfyui_to_diffusers(Z["comfy"], target_prefix="transformer")),
+         "from_comfy_noprefix": (lambda r: (shape_of(r[0]), r[1]))(mod.convert_comfyui_to_diffusers(Z["comfy"]))}
+    conflict = {"m.lora_A.weight": torch.zeros(4, 8), "m.lora_B.weight": torch.zeros(8, 2)}
+    try:
+        mod.collect_lora_ranks(conflict)
+        G["conflict"] = None
+    except ValueError as e:
+        G["conflict"] = str(e)
+    out = OUT.parent / "lora_keys_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_lora_keys()
     gen_cache_names()
     gen_flow_match_scheduler()
     gen_collate()
