@@ -102,12 +102,22 @@ def apply_flow_schedule_shift(args, noise_scheduler, sigmas, noise):
     return sigmas
 
 
+def enforce_zero_terminal_snr(betas: torch.Tensor) -> torch.Tensor:
+    """`rescale_betas_zero_snr` (custom_schedule.py:157-175; "Common Diffusion Noise Schedules and Sample Steps are Flawed", alg. 1): shift
+    sqrt(alphas_cumprod) so the last step carries no signal, rescale so the first step keeps its value, convert back to betas"""
+    root = (1 - betas).cumprod(0).sqrt()
+    first, last = root[0].clone(), root[-1].clone()
+    root = (root - last) * (first / (first - last))
+    bar = root ** 2
+    return 1 - torch.cat([bar[0:1], bar[1:] / bar[:-1]])
+
+
 class DDPMSchedule:
     """the training-side arithmetic of diffusers' DDPMScheduler as the reference configures it for SD1.5 / SDXL (common.py:4529-4550; the
     checkpoint's scheduler_config.json: beta_schedule "scaled_linear", beta_start 0.00085, beta_end 0.012, 1000 steps)."""
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012, beta_schedule: str = "scaled_linear",
-                 prediction_type: str = "epsilon", device=None):
+                 prediction_type: str = "epsilon", device=None, rescale_betas_zero_snr: bool = False):
         from types import SimpleNamespace
         if beta_schedule == "scaled_linear":
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
@@ -115,8 +125,12 @@ class DDPMSchedule:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         else:
             raise NotImplementedError(beta_schedule)
+        if rescale_betas_zero_snr:
+            betas = enforce_zero_terminal_snr(betas)
+        self.betas = betas
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
-        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type, beta_schedule=beta_schedule)
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type, beta_schedule=beta_schedule,
+                                      rescale_betas_zero_snr=bool(rescale_betas_zero_snr))
         self._sa = self.alphas_cumprod.sqrt().to(device)
         self._sb = (1.0 - self.alphas_cumprod).sqrt().to(device)
 
@@ -423,7 +437,8 @@ class ModelFoundation(ExplorativeModelingMixin):
         """common.py:4518-4556: the TRAINING schedule — DDPM coefficients for epsilon / v families; for flow matching the Euler scheduler with the
         static shift, its bounds reset to the unshifted ones (fix_flow_match_euler_schedule_bounds)"""
         if self.PREDICTION_TYPE is not PredictionTypes.FLOW_MATCHING:
-            self.noise_schedule = DDPMSchedule(prediction_type=self.PREDICTION_TYPE.value, device=self.accelerator.device)
+            self.noise_schedule = DDPMSchedule(prediction_type=self.PREDICTION_TYPE.value, device=self.accelerator.device,
+                                               rescale_betas_zero_snr=bool(getattr(self.config, "rescale_betas_zero_snr", False)))
         else:
             from .sampling import FlowMatchEulerDiscreteScheduler, fix_flow_match_euler_schedule_bounds
             self.noise_schedule = fix_flow_match_euler_schedule_bounds(

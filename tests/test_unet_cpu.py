@@ -3,6 +3,7 @@ scaled_linear betas 0.00085 -> 0.012, 1000 steps), the segmented timestep select
 (state-dict round trip through the native layouts) and its FLOP counter against the figures SURVEY.md §8(d) quotes."""
 import math
 
+import pytest
 import torch
 
 from oracle.unet import UNetConfig, unet_flops_fwd, unet_forward
@@ -236,3 +237,18 @@ def test_vae_seam_attributes_and_latent_scaling_rule():
     assert m.scale_vae_latents_for_cache(z, None) is z and m.scale_vae_latents_for_cache(None, plain) is None
     m.AUTOENCODER_SCALING_FACTOR = 2.0                              # a family-level override wins over the VAE's own factor
     assert torch.allclose(m.scale_vae_latents_for_cache(z, plain), z * 2.0)
+
+
+def test_zero_terminal_snr_rescale_matches_reference_code_output():
+    """rescale_betas_zero_snr: enforce_zero_terminal_snr (custom_schedule.py:157-175) executed by tools/gen_golden.py on the scaled-linear betas"""
+    from pathlib import Path
+
+    from simpletuner_amd.foundation import DDPMSchedule, enforce_zero_terminal_snr
+    want = torch.load(Path(__file__).parent / "golden" / "ddpm_sampling_vectors.pt", weights_only=False)["zero_terminal_snr_betas"]
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    torch.testing.assert_close(enforce_zero_terminal_snr(betas), want, rtol=0, atol=0)
+    s = DDPMSchedule(prediction_type="v_prediction", rescale_betas_zero_snr=True)
+    assert s.alphas_cumprod[-1].item() == 0.0 and s.alphas_cumprod[0].item() == pytest.approx(DDPMSchedule().alphas_cumprod[0].item(), rel=1e-6)
+    w = s.min_snr_weights(torch.tensor([0, 500, 999]), 5.0, v_prediction=True)
+    assert torch.isfinite(w).all() and w[-1].item() == 0.0                      # terminal step: snr 0 -> weight 0 with the v-prediction divisor
+    assert DDPMSchedule().config.rescale_betas_zero_snr is False

@@ -214,6 +214,9 @@ def gen_ddpm_sampling():
         for k, v in extra.items():
             setattr(args, k, v)
         G["weights"][strat] = (dict(vars(args)), gen_w(args, 1000).clone())
+    ezt, = extract(p, ["enforce_zero_terminal_snr"])
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    G["zero_terminal_snr_betas"] = ezt(betas.clone()).clone()
     cfg = SimpleNamespace(refiner_training=False, refiner_training_invert_schedule=False, refiner_training_strength=0.2)
     for bsz in (2, 4, 7):
         for seed in (0, 1, 2):
