@@ -79,6 +79,9 @@ class Trainer:
             self.optimizer = St355AdamW(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
                                         eps=config.adam_epsilon, weight_decay=config.adam_weight_decay)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda) if lr_lambda else None
+        if self.lr_scheduler is None and getattr(config, "lr_scheduler", None):             # the reference's named schedules (custom_schedule.py:481-557)
+            from .lr_schedule import get_lr_scheduler
+            self.lr_scheduler = get_lr_scheduler(config, self.optimizer, self.accelerator, None, 0)
         self.ema_model = None
         if getattr(config, "use_ema", False):
             self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)

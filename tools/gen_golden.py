@@ -446,7 +446,46 @@ def gen_lora_keys():
     print("wrote", out)
 
 
+def gen_lr_schedules():
+    """Cosine / CosineAnnealingHardRestarts / Sine / get_polynomial_decay_schedule_with_warmup (helpers/training/custom_schedule.py:102-440) lifted by
+    AST and stepped on a real torch optimizer -> tests/golden/lr_schedule_vectors.pt (the learning rate after every step)"""
+    import logging
+    from torch.optim.lr_scheduler import LambdaLR, LRScheduler
+    path = REF / "helpers" / "training" / "custom_schedule.py"
+    tree = ast.parse(path.read_text())
+    want = {"_enable_get_lr_call", "Cosine", "CosineAnnealingHardRestarts", "Sine", "get_polynomial_decay_schedule_with_warmup"}
+    picked = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
+    assert {n.name for n in picked} == want
+    ns = {"torch": torch, "math": math, "LambdaLR": LambdaLR, "LRScheduler": LRScheduler, "logger": logging.getLogger("ref"), "__builtins__": __builtins__}
+    modl = ast.Module(body=picked, type_ignores=[])
+    ast.fix_missing_locations(modl)
+    exec(compile(modl, str(path), "exec"), ns)
+
+    def run(make, n):
+        p_ = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p_], lr=1e-4)
+        sch = make(opt)
+        out = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            out.append(opt.param_groups[0]["lr"])
+        return out
+    G = {}
+    for T0, eta in ((10, 0.0), (7, 1e-6), (100, 1e-7)):
+        G[("sine", T0, eta)] = run(lambda o: ns["Sine"](optimizer=o, T_0=T0, T_mult=1, eta_min=eta, last_step=-1), 45)
+        G[("cosine", T0, eta)] = run(lambda o: ns["Cosine"](optimizer=o, T_0=T0, T_mult=1, eta_min=eta, last_step=-1), 45)
+        G[("cosine_with_restarts", T0, eta)] = run(lambda o: ns["CosineAnnealingHardRestarts"](optimizer=o, T_0=T0, T_mult=1, eta_min=eta, last_step=-1), 45)
+    for warm, total, end, power in ((5, 30, 1e-7, 1.0), (0, 20, 1e-6, 2.0), (10, 25, 1e-8, 0.5)):
+        G[("polynomial", warm, total, end, power)] = run(lambda o: ns["get_polynomial_decay_schedule_with_warmup"](optimizer=o, num_warmup_steps=warm, num_training_steps=total,
+                                                                                                               lr_end=end, power=power, last_epoch=-1), 40)
+    out = OUT.parent / "lr_schedule_vectors.pt"
+    torch.save(G, out)
+    print("wrote", out)
+
+
 def main():
+    gen_lr_schedules()
     gen_lora_keys()
     gen_cache_names()
     gen_flow_match_scheduler()
