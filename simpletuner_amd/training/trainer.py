@@ -220,6 +220,92 @@ class Trainer:
             p.grad = gr
         return loss.clone()        # the static tensor is overwritten by the next replay: callers keep their own value
 
+    # ---- checkpoints: the files of the reference's save hooks + accelerate.save_state, in one directory (save_hooks.py:368-443, 850-1305) ----
+    def save_state(self, checkpoint_dir: str) -> None:
+        """`<dir>/optimizer.bin`, `scheduler.bin`, `random_states_<rank>.pkl` (accelerate's names and pickled keys), the trained weights
+        (`pytorch_lora_weights.safetensors` for adapters, `<subfolder>/diffusion_pytorch_model.safetensors` for a full fine-tune),
+        `<subfolder>_ema/ema_model.pt`, `training_state.json` (StateTracker.save_training_state keys) and the round-robin timestep cursor.
+        Rank 0 writes the shared files; every rank writes its own RNG / cursor files."""
+        import json
+        import os
+        import pickle
+        import random
+
+        import numpy as np
+        acc, plug = self.accelerator, self.model
+        rank = int(getattr(acc, "process_index", 0) or 0)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        rng = {"random_state": random.getstate(), "numpy_random_seed": np.random.get_state(), "torch_manual_seed": torch.get_rng_state(),
+               "torch_cuda_manual_seed": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None,
+               "st355_noise_step": int(getattr(plug, "_noise_step", 0))}        # the in-kernel Philox stream position of the noising pass
+        with open(os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"), "wb") as fh:
+            pickle.dump(rng, fh)
+        plug.save_flow_custom_timestep_state(checkpoint_dir)
+        if rank != 0:
+            return
+        host = lambda sd: {"state": {k: {n: (v.detach().to("cpu") if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()},
+                           "param_groups": sd["param_groups"]}
+        torch.save(host(self.optimizer.state_dict()), os.path.join(checkpoint_dir, "optimizer.bin"))
+        if self.lr_scheduler is not None:
+            torch.save(self.lr_scheduler.state_dict(), os.path.join(checkpoint_dir, "scheduler.bin"))
+        comp = plug.get_trained_component()
+        if getattr(comp, "full", False) and hasattr(comp, "diffusers_state_dict"):
+            from safetensors.torch import save_file
+            sub = os.path.join(checkpoint_dir, plug.MODEL_SUBFOLDER)
+            os.makedirs(sub, exist_ok=True)
+            save_file({k: v.detach().to("cpu").contiguous() for k, v in comp.diffusers_state_dict().items()},
+                      os.path.join(sub, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
+        else:
+            plug.save_lora_weights(checkpoint_dir)
+        if self.ema_model is not None:
+            self.ema_model.save_state_dict(os.path.join(checkpoint_dir, f"{plug.MODEL_SUBFOLDER}_ema", "ema_model.pt"))
+        with open(os.path.join(checkpoint_dir, "training_state.json"), "w") as fh:
+            json.dump({"global_step": self.state["global_step"], "epoch_step": self.state.get("epoch_step", 0), "epoch": self.state.get("epoch", 1),
+                       "exhausted_backends": list(self.state.get("exhausted_backends", [])), "repeats": dict(self.state.get("repeats", {})),
+                       "micro_step": self.state["micro_step"]}, fh)
+
+    def load_state(self, checkpoint_dir: str) -> None:
+        """the inverse of save_state; a missing per-rank RNG file falls back to rank 0's (resuming on more GPUs than the run was saved with)"""
+        import json
+        import os
+        import pickle
+        import random
+
+        import numpy as np
+        acc, plug = self.accelerator, self.model
+        rank = int(getattr(acc, "process_index", 0) or 0)
+        comp = plug.get_trained_component()
+        full_path = os.path.join(checkpoint_dir, plug.MODEL_SUBFOLDER, "diffusion_pytorch_model.safetensors")
+        if getattr(comp, "full", False) and os.path.exists(full_path):
+            from safetensors.torch import load_file
+            comp.load_diffusers_state(load_file(full_path))
+        else:
+            plug.load_lora_weights(input_dir=checkpoint_dir)
+        self.optimizer.load_state_dict(torch.load(os.path.join(checkpoint_dir, "optimizer.bin"), map_location="cpu", weights_only=False))
+        sched = os.path.join(checkpoint_dir, "scheduler.bin")
+        if self.lr_scheduler is not None and os.path.exists(sched):
+            self.lr_scheduler.load_state_dict(torch.load(sched, map_location="cpu", weights_only=False))
+        if self.ema_model is not None:
+            self.ema_model.load_state_dict(os.path.join(checkpoint_dir, f"{plug.MODEL_SUBFOLDER}_ema", "ema_model.pt"))
+        with open(os.path.join(checkpoint_dir, "training_state.json")) as fh:
+            ts = json.load(fh)
+        self.state.update({k: ts[k] for k in ("global_step", "epoch_step", "epoch", "exhausted_backends", "repeats") if k in ts})
+        self.state["micro_step"] = int(ts.get("micro_step", self.state["global_step"] * self.config.gradient_accumulation_steps))
+        plug.load_flow_custom_timestep_state(checkpoint_dir, fallback_global_step=self.state["global_step"])
+        for name in (f"random_states_{rank}.pkl", "random_states_0.pkl"):
+            path = os.path.join(checkpoint_dir, name)
+            if not os.path.exists(path):
+                continue
+            with open(path, "rb") as fh:
+                rng = pickle.load(fh)
+            random.setstate(rng["random_state"])
+            np.random.set_state(rng["numpy_random_seed"])
+            torch.set_rng_state(rng["torch_manual_seed"])
+            if rng.get("torch_cuda_manual_seed") is not None and torch.cuda.is_available():
+                torch.cuda.set_rng_state_all(rng["torch_cuda_manual_seed"])
+            plug._noise_step = int(rng.get("st355_noise_step", 0))
+            break
+
     def train(self, batches: Iterable[dict], max_steps: int):
         losses = []
         for i, b in enumerate(batches):
