@@ -42,6 +42,7 @@ class EMAModel:
         self.model_cls, self.model_config = model_cls, model_config
         self.rank0_only = rank0_only
         tracked = [p for p in parameters]
+        self._tracked_param_ids = [id(p) for p in tracked]
         self._flat = _contiguous_run([p.data for p in tracked]) and len(tracked) > 0
         if self._flat:
             n = sum(p.numel() for p in tracked)
@@ -98,19 +99,50 @@ class EMAModel:
             else:
                 s.copy_(p.data.to(s.dtype))
 
+    def _align(self, parameters, allow_subset: bool):
+        """ema.py:189-234: shadows are matched to the caller's parameters by IDENTITY, so reordered lists, subsets (allow_subset) and supersets
+        with untracked entries all land on the right tensors.  Deviation, on purpose: when NONE of the given tensors is a tracked parameter but
+        the count matches (a freshly built copy of the model), the match is positional — the reference silently copies nothing in that case."""
+        params = list(parameters)
+        by_id = dict(zip(self._tracked_param_ids, self.shadow_params))
+        hits = [(by_id[id(p)], p) for p in params if id(p) in by_id]
+        if not hits and len(params) == len(self.shadow_params):
+            return list(zip(self.shadow_params, params))
+        if not allow_subset:
+            if len(params) != len(self.shadow_params):
+                raise RuntimeError(f"EMA parameter count mismatch: expected {len(self.shadow_params)} parameters but received {len(params)}.")
+            if len(hits) != len(params):
+                raise RuntimeError(f"EMA parameter mapping failed: received {len(params) - len(hits)} untracked parameter(s). "
+                                   "This usually means the model parameters were recreated after EMA initialization.")
+        return hits
+
     def copy_to(self, parameters: Iterable[torch.nn.Parameter]) -> None:
-        for s, p in zip(self.shadow_params, list(parameters)):
+        for s, p in self._align(parameters, allow_subset=True):
             p.data.copy_(s.to(device=p.device, dtype=p.dtype))
 
     def store(self, parameters: Iterable[torch.nn.Parameter]) -> None:
+        parameters = list(parameters)
         self.temp_stored_params = [p.detach().clone() for p in parameters]
+        self._temp_stored_param_ids = [id(p) for p in parameters]
 
     def restore(self, parameters: Iterable[torch.nn.Parameter]) -> None:
+        """ema.py:540-609: stored copies go back to the SAME parameter objects, whatever order they are passed in"""
         if self.temp_stored_params is None:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
-        for c, p in zip(self.temp_stored_params, parameters):
+        parameters = list(parameters)
+        by_id = dict(zip(self._temp_stored_param_ids, self.temp_stored_params))
+        if all(id(p) in by_id for p in parameters):
+            pairs = [(by_id[id(p)], p) for p in parameters]
+        elif not any(id(p) in by_id for p in parameters) and len(parameters) == len(self.temp_stored_params):
+            pairs = list(zip(self.temp_stored_params, parameters))
+        else:
+            missing = sum(id(p) not in by_id for p in parameters)
+            raise RuntimeError(f"EMA restore failed: received {missing} untracked parameter(s). "
+                               "This usually means the model parameters were recreated after EMA.store().")
+        for c, p in pairs:
             p.data.copy_(c.data)
         self.temp_stored_params = None
+        self._temp_stored_param_ids = None
 
     def to(self, device=None, dtype=None, non_blocking=False):
         return self   # shadows live next to the parameters in HBM (288 GB: no CPU shuttle, ema.py:357-359/432-433 not needed)

@@ -216,3 +216,48 @@ def test_ema_checkpoint_file_layout_roundtrip(tmp_path):
     assert torch.equal(live[1].data, arena[8:].view(4, 4))
     e2.restore(live)
     assert torch.equal(live[1].data, torch.ones(4, 4))
+
+
+def test_ema_alignment_by_parameter_identity():
+    """the reference's tests/test_ema.py:167-295: reordered lists, subsets, supersets with untracked parameters, store / restore in any order"""
+    from simpletuner_amd.training.ema import EMAModel
+
+    class M(torch.nn.Module):
+        def __init__(self, fill=0.0):
+            super().__init__()
+            self.weight_a = torch.nn.Parameter(torch.full((2, 2), fill))
+            self.weight_b = torch.nn.Parameter(torch.full((1, 1, 1, 3), fill))
+
+    args = SimpleNamespace(ema_update_interval=None, ema_device="cpu", ema_cpu_only=True)
+    m = M()
+    e = EMAModel(args, None, m.parameters(), decay=0.5, update_after_step=-1)
+    with torch.no_grad():
+        e.shadow_params[0].fill_(3.0); e.shadow_params[1].fill_(7.0)
+    e.copy_to(reversed(list(m.parameters())))                                  # :167-196
+    assert torch.all(m.weight_a == 3.0) and torch.all(m.weight_b == 7.0)
+    m = M()
+    e = EMAModel(args, None, m.parameters(), decay=0.5, update_after_step=-1)
+    with torch.no_grad():
+        e.shadow_params[0].fill_(5.0); e.shadow_params[1].fill_(9.0)
+    e.copy_to([m.weight_b])                                                    # :198-228 subset
+    assert torch.all(m.weight_a == 0.0) and torch.all(m.weight_b == 9.0)
+    m = M()
+    e = EMAModel(args, None, [m.weight_a], decay=0.5, update_after_step=-1)    # :230-261 superset with an untracked tensor
+    with torch.no_grad():
+        e.shadow_params[0].fill_(4.0)
+    e.copy_to(m.parameters())
+    assert torch.all(m.weight_a == 4.0) and torch.all(m.weight_b == 0.0)
+    m = M(1.0)                                                                 # :263-295
+    before = [p.clone() for p in m.parameters()]
+    e = EMAModel(args, None, m.parameters(), decay=0.5, update_after_step=-1)
+    e.store(m.parameters())
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(5.0)
+    e.restore(reversed(list(m.parameters())))
+    assert all(torch.equal(p, b) for p, b in zip(m.parameters(), before)) and e.temp_stored_params is None
+    with pytest.raises(RuntimeError, match="no `store"):
+        e.restore(m.parameters())
+    e.store(m.parameters())
+    with pytest.raises(RuntimeError, match="untracked parameter"):
+        e.restore([m.weight_a, torch.nn.Parameter(torch.zeros(1, 1, 1, 3))])
