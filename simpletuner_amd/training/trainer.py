@@ -12,7 +12,6 @@ coefficient are folded into the optimizer kernel (grad_scale) instead of extra p
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 from typing import Callable, Iterable, Optional
 
