@@ -126,7 +126,7 @@ def bench_vae(args, dev, rank, world):
     import torch.distributed as dist
     from simpletuner_amd import ops
     from simpletuner_amd.vae.autoencoder_kl import AutoencoderKL
-    from oracle.vae import VAEConfig, encoder_flops          # FLOP counter only
+    from tools.flop_count import vae_encoder_flops as encoder_flops      # arithmetic over the model's own config
     vae = AutoencoderKL(device=dev)
     vae.load_state_dict(vae.synthetic_state_dict(42))
     B = args.batch
@@ -154,7 +154,7 @@ def bench_vae(args, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     if rank == 0:
-        fl = encoder_flops(VAEConfig(), args.res, args.res) * B
+        fl = encoder_flops(vae.config, args.res, args.res) * B
         ms = elapsed / args.steps * 1e3
         roof = kernels = None
         if prof is not None and prof["gemm"]["ms"] > 0:
@@ -215,7 +215,7 @@ def main():
     elif args.model == "sdxl":
         # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4; --lora = the metric's SDXL-LoRA (adapters on attn1/attn2)
         from simpletuner_amd.sdxl.model import SDXL
-        from oracle.unet import UNetConfig, unet_flops_fwd     # FLOP counter only (test infrastructure; nothing of the oracle is executed in the step)
+        from tools.flop_count import unet_flops_fwd            # arithmetic over the model's own config
         sdxl_lora = bool(args.lora)
         args.full = not sdxl_lora
         cfg.model_type, cfg.use_ema, cfg.learning_rate = ("lora" if sdxl_lora else "full"), False, (1e-4 if sdxl_lora else 1e-5)
@@ -223,7 +223,7 @@ def main():
         plugin.load_model()
         S_txt, txt_dim, pooled_dim = 77, 2048, 1280
         n_blocks, D_model = 0, 0
-        sdxl_fwd_flops = unet_flops_fwd(UNetConfig(), args.res // 8, args.res // 8, 77)
+        sdxl_fwd_flops = unet_flops_fwd(plugin.model.config, args.res // 8, args.res // 8, 77)
         desc = (f"SDXL UNet2DConditionModel (320/640/1280 ch, 2/10-layer transformers at 64^2/32^2, 2.6 B params) "
                 f"{f'LoRA r{args.rank} on attn1/attn2 to_q/to_k/to_v/to_out.0' if sdxl_lora else 'FULL fine-tune bf16'}, "
                 f"{args.res}^2 ({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
@@ -231,21 +231,21 @@ def main():
         # BASELINE.json configs[0]: SD 1.5 UNet LoRA rank 16, 512^2, batch 1 (the reference's CPU-runnable plumbing case) — run it with
         # `--model sd15 --rank 16 --res 512 --batch 1`; --full switches to the full fine-tune
         from simpletuner_amd.sd1x.model import StableDiffusion1
-        from oracle.unet import UNetConfig, unet_flops_fwd
+        from tools.flop_count import unet_flops_fwd
         sd15_lora = not args.full
         cfg.model_type, cfg.use_ema, cfg.learning_rate = ("lora" if sd15_lora else "full"), False, (1e-4 if sd15_lora else 1e-5)
         plugin = StableDiffusion1(cfg, acc)
         plugin.load_model()
         S_txt, txt_dim, pooled_dim = 77, 768, 0
         n_blocks, D_model = 0, 0
-        sdxl_fwd_flops = unet_flops_fwd(UNetConfig.sd15(), args.res // 8, args.res // 8, 77)
+        sdxl_fwd_flops = unet_flops_fwd(plugin.model.config, args.res // 8, args.res // 8, 77)
         desc = (f"SD 1.5 UNet2DConditionModel (320/640/1280/1280 ch, 8 heads of width 40/80/160, 0.86 B params) "
                 f"{f'LoRA r{args.rank} on attn1/attn2 to_q/to_k/to_v/to_out.0' if sd15_lora else 'FULL fine-tune bf16'}, {args.res}^2 "
                 f"({args.res // 8}^2 latents), epsilon objective, AdamW, random-init weights")
     elif args.model == "pixart":
         # BASELINE.json configs[4]: PixArt-Sigma DiT, ControlNet branch (13 copied blocks) trained, 2K latents (256^2 x 4), T5 ctx 300 with mask
         from simpletuner_amd.pixart.model import PixartSigma
-        from oracle.pixart import PixArtConfig, pixart_flops_fwd       # FLOP counter only
+        from tools.flop_count import pixart_flops_fwd
         cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
         plugin = PixartSigma(cfg, acc)
         plugin.load_model(sample_size=256 if args.res >= 2048 else 128, fp8_base=bool(args.fp8))
@@ -253,8 +253,7 @@ def main():
         S_txt, txt_dim, pooled_dim = 300, 4096, 0
         n_blocks, D_model = 0, 0
         lat_ = args.res // 8
-        pc = PixArtConfig(sample_size=256 if args.res >= 2048 else 128)
-        f_trunk = pixart_flops_fwd(pc, lat_, lat_, 300, 0)
+        f_trunk = pixart_flops_fwd(plugin.model.config, lat_, lat_, 300, 0)
         f_blk = f_trunk / 28.0
         # trunk: forward (28) + input gradients through blocks 1..27 (2x forward each: attention bwd = 2x fwd, linears dgrad = 1x -> ~1.7x; counted 1x
         # for the linears and 2x for attention is folded into 2x here);  adapter (13): forward + dgrad + wgrad = 3x
@@ -364,7 +363,7 @@ def main():
             step_flops = pix_step_flops * B
         elif args.model in ("sdxl", "sd15") and not args.full:   # LoRA: forward + input gradients (no base weight gradients): 2x forward, attention bwd 2x
             step_flops = 2.0 * sdxl_fwd_flops * B
-        elif args.model in ("sdxl", "sd15"):   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), oracle/unet.py::unet_flops_fwd
+        elif args.model in ("sdxl", "sd15"):   # full fine-tune = 3x the forward (fwd + dgrad + wgrad; attention fwd + 2x bwd), tools/flop_count.py::unet_flops_fwd
             step_flops = 3.0 * sdxl_fwd_flops * B
         elif args.full:      # full fine-tune: fwd + dgrad + wgrad on the linears (3x), attention fwd + 2x bwd (3x)  
             step_flops = 3.0 * (n_blocks * 2.0 * (S_img + S_txt) * 12 * D_model * D_model + n_blocks * 4.0 * (S_img + S_txt) ** 2 * D_model) * B

@@ -173,8 +173,4 @@ def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc,
     return _head(P, cfg, h, emb, hh, ww)
 
 
-def pixart_flops_fwd(cfg: PixArtConfig, H: int, W: int, ctx_len: int = 300, n_ctrl: int = 0) -> float:
-    D = cfg.D
-    S = (H // cfg.patch_size) * (W // cfg.patch_size)
-    blk = 2.0 * S * (4 * D * D + 2 * D * D + 8 * D * D) + 2.0 * ctx_len * 2 * D * D + 4.0 * S * S * D + 4.0 * S * ctx_len * D
-    return (cfg.num_layers + n_ctrl) * blk + n_ctrl * 2.0 * S * D * D + 2.0 * S * D * (cfg.patch_size ** 2) * (cfg.in_channels + cfg.out_channels)
+from tools.flop_count import pixart_flops_fwd  # noqa: E402,F401

@@ -156,49 +156,4 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
     return _conv(x, P, "conv_out")
 
 
-def unet_flops_fwd(cfg: UNetConfig, H: int, W: int, ctx_len: int = 77) -> float:
-    """multiply-add = 2 FLOPs; conv 2*k*k*Cin*Cout*H*W, linears 2*M*N*K, attention 4*Sq*Sk*C; per image (SURVEY.md §8d asks for this counter)"""
-    fl = 0.0
-    ch = cfg.block_out_channels
-    nb = len(ch)
-
-    def conv(cin, cout, h, w, k=3):
-        return 2.0 * k * k * cin * cout * h * w
-
-    def res(cin, cout, h, w):
-        return conv(cin, cout, h, w) + conv(cout, cout, h, w) + (conv(cin, cout, h, w, 1) if cin != cout else 0.0) + 2.0 * 4 * ch[0] * cout
-
-    def tr(c, h, w, n):
-        s = h * w
-        per = 2.0 * s * c * c * 4 + 4.0 * s * s * c + 2.0 * s * c * c * 2 + 2.0 * ctx_len * cfg.cross_attention_dim * c * 2 + 4.0 * s * ctx_len * c \
-            + 2.0 * s * c * 8 * c + 2.0 * s * 4 * c * c
-        return n * per + 2 * 2.0 * s * c * c
-
-    h, w = H, W
-    fl += conv(cfg.in_channels, ch[0], h, w)
-    skip_ch = [ch[0]]
-    cin = ch[0]
-    for i, typ in enumerate(cfg.down_block_types):
-        for j in range(cfg.layers_per_block):
-            fl += res(cin, ch[i], h, w)
-            cin = ch[i]
-            if typ.startswith("CrossAttn"):
-                fl += tr(cin, h, w, cfg.transformer_layers_per_block[i])
-            skip_ch.append(cin)
-        if i < nb - 1:
-            h, w = h // 2, w // 2
-            fl += conv(cin, cin, h, w)
-            skip_ch.append(cin)
-    fl += 2 * res(cin, cin, h, w) + tr(cin, h, w, cfg.transformer_layers_per_block[-1])
-    for i, typ in enumerate(cfg.up_block_types):
-        ri = nb - 1 - i
-        for j in range(cfg.layers_per_block + 1):
-            fl += res(cin + skip_ch.pop(), ch[ri], h, w)
-            cin = ch[ri]
-            if typ.startswith("CrossAttn"):
-                fl += tr(cin, h, w, cfg.transformer_layers_per_block[ri])
-        if i < nb - 1:
-            h, w = 2 * h, 2 * w
-            fl += conv(cin, cin, h, w)
-    fl += conv(cin, cfg.out_channels, h, w)
-    return fl
+from tools.flop_count import unet_flops_fwd  # noqa: E402,F401  (one definition, shared with bench.py)

@@ -88,21 +88,4 @@ def sample_and_scale(moments: torch.Tensor, cfg: VAEConfig, eps: Optional[torch.
     return z * cfg.scaling_factor
 
 
-def encoder_flops(cfg: VAEConfig, H: int, W: int) -> float:
-    """forward FLOPs per image (multiply-add = 2)"""
-    def conv(ci, co, h, w, k=3):
-        return 2.0 * k * k * ci * co * h * w
-    ch = cfg.block_out_channels
-    fl = conv(cfg.in_channels, ch[0], H, W)
-    cin, h, w = ch[0], H, W
-    for i, co in enumerate(ch):
-        for j in range(cfg.layers_per_block):
-            fl += conv(cin, co, h, w) + conv(co, co, h, w) + (conv(cin, co, h, w, 1) if cin != co else 0)
-            cin = co
-        if i < len(ch) - 1:
-            h, w = h // 2, w // 2
-            fl += conv(cin, cin, h, w)
-    s = h * w
-    fl += 4 * conv(cin, cin, h, w) + 2.0 * s * cin * cin * 4 + 4.0 * s * s * cin
-    fl += conv(cin, 2 * cfg.latent_channels, h, w)
-    return fl
+from tools.flop_count import vae_encoder_flops as encoder_flops  # noqa: E402,F401

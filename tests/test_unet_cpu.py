@@ -252,3 +252,39 @@ def test_zero_terminal_snr_rescale_matches_reference_code_output():
     w = s.min_snr_weights(torch.tensor([0, 500, 999]), 5.0, v_prediction=True)
     assert torch.isfinite(w).all() and w[-1].item() == 0.0                      # terminal step: snr 0 -> weight 0 with the v-prediction divisor
     assert DDPMSchedule().config.rescale_betas_zero_snr is False
+
+
+def test_flop_counters_agree_on_product_and_oracle_configs():
+    """bench.py counts FLOPs from the PRODUCT models' config objects (tools/flop_count.py; no oracle import outside its cpu_baseline leg): same
+    numbers as on the oracle's dataclasses for SDXL, SD1.5, PixArt-Sigma 2K and the SDXL VAE"""
+    import ast
+    import inspect
+    from pathlib import Path
+    from types import SimpleNamespace
+
+    from oracle.pixart import PixArtConfig
+    from oracle.vae import VAEConfig
+    from simpletuner_amd.sd1x.model import SD15_ARCH
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    from tools.flop_count import pixart_flops_fwd, unet_flops_fwd, vae_encoder_flops
+
+    def product_unet_cfg(**arch):
+        d = {k: v.default for k, v in inspect.signature(UNet2DConditionModel.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+        d.update(arch)
+        nb = len(d["block_out_channels"])
+        if isinstance(d["transformer_layers_per_block"], int):
+            d["transformer_layers_per_block"] = (d["transformer_layers_per_block"],) * nb
+        return SimpleNamespace(**d)
+
+    assert unet_flops_fwd(product_unet_cfg(), 128, 128, 77) == unet_flops_fwd(UNetConfig(), 128, 128, 77)
+    assert unet_flops_fwd(product_unet_cfg(**SD15_ARCH), 64, 64, 77) == unet_flops_fwd(UNetConfig.sd15(), 64, 64, 77)
+    pix = SimpleNamespace(num_attention_heads=16, attention_head_dim=72, num_layers=28, patch_size=2, in_channels=4, out_channels=8)
+    assert pixart_flops_fwd(pix, 256, 256, 300, 13) == pixart_flops_fwd(PixArtConfig(sample_size=256), 256, 256, 300, 13)
+    vae = SimpleNamespace(in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2)
+    assert vae_encoder_flops(vae, 1024, 1024) == vae_encoder_flops(VAEConfig(), 1024, 1024)
+    # bench.py: the only function that imports the oracle is the cpu_baseline leg
+    tree = ast.parse((Path(__file__).parent.parent / "bench.py").read_text())
+    offenders = {fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef) for n in ast.walk(fn)
+                 if isinstance(n, (ast.Import, ast.ImportFrom)) and (getattr(n, "module", None) or n.names[0].name).startswith("oracle")}
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and (getattr(n, "module", None) or n.names[0].name).startswith("oracle")]
+    assert offenders == {"cpu_baseline"} and not top
