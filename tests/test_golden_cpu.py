@@ -261,3 +261,22 @@ def test_ema_alignment_by_parameter_identity():
     e.store(m.parameters())
     with pytest.raises(RuntimeError, match="untracked parameter"):
         e.restore([m.weight_a, torch.nn.Parameter(torch.zeros(1, 1, 1, 3))])
+
+
+def test_product_package_never_imports_the_checker():
+    """nothing under simpletuner_amd/ may import oracle/, tools/ or tests/ (the oracle is test infrastructure, never a fallback), and
+    __graft_entry__ touches the oracle only inside smoke()"""
+    import ast
+    root = Path(__file__).parent.parent
+    bad = []
+    for f in (root / "simpletuner_amd").rglob("*.py"):
+        for n in ast.walk(ast.parse(f.read_text())):
+            if isinstance(n, ast.ImportFrom) and n.level == 0 and (n.module or "").split(".")[0] in ("oracle", "tools", "tests"):
+                bad.append((f.name, n.lineno))
+            if isinstance(n, ast.Import) and any(a.name.split(".")[0] in ("oracle", "tools", "tests") for a in n.names):
+                bad.append((f.name, n.lineno))
+    assert not bad, bad
+    tree = ast.parse((root / "__graft_entry__.py").read_text())
+    users = {fn.name for fn in tree.body if isinstance(fn, ast.FunctionDef) for n in ast.walk(fn)
+             if isinstance(n, (ast.Import, ast.ImportFrom)) and ((getattr(n, "module", None) or n.names[0].name).split(".")[0] in ("oracle", "tests"))}
+    assert users <= {"smoke", "_smoke_unet"} and "build" not in users, users
