@@ -101,4 +101,7 @@ def sync_module_states(module: torch.nn.Module, src: int = 0, process_group=None
     refresh = getattr(module, "_refresh_transposed", None)                        # derived copies (transposed weights for dgrad) follow the new values
     if callable(refresh):
         refresh()
+    for m in module.modules():                                                    # lazily built K-major copies (`prepare_for_training`) are rebuilt at the next forward
+        if getattr(m, "_prepared", False):
+            m._prepared = False
     return total

@@ -49,11 +49,13 @@ def _worker(rank, world, init_file, out_dir):
     mod.register_buffer("tab", torch.randn(5))
     calls = []
     mod._refresh_transposed = lambda: calls.append(1)
+    mod.inner = torch.nn.Module()
+    mod.inner._prepared = True                                         # a lazily prepared sub-model must be re-prepared from the new weights
     nbytes = sync_module_states(mod, chunk_bytes=5000)                 # forces the chunked path (arena = 16 KiB)
     torch.manual_seed(100)
     want_arena = torch.randn(4096); want_c = torch.randn(7, 3).to(torch.bfloat16); want_tab = torch.randn(5)
     res["sync_ok"] = (torch.equal(arena, want_arena) and torch.equal(mod.c.data, want_c) and torch.equal(mod.tab, want_tab)
-                      and torch.equal(mod.a.data, want_arena[:1000].view(10, 100)) and calls == [1])
+                      and torch.equal(mod.a.data, want_arena[:1000].view(10, 100)) and calls == [1] and mod.inner._prepared is False)
     res["sync_bytes"] = nbytes
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
