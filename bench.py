@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -117,6 +118,51 @@ def cpu_baseline(args):
         "value": round(B / step_s, 6), "unit": "images/s", "cores": cores, "kind": "port",
         "sample": f"oracle (plain torch fp32, autograd) 1 double + 1 single Flux block fwd+bwd at D=3072, S={S_img}+{S_txt}, B=1: "
                   f"{t_double:.1f}s + {t_single:.1f}s, extrapolated x{args.layers}/x{args.single_layers} blocks = {step_s:.0f} s/step",
+    }
+
+
+def cpu_baseline_unet(args, sd15: bool, lora: bool):
+    """BASELINE.json configs[0] literally ("SD 1.5 UNet LoRA rank=16, 512^2, batch=1, CPU reference trainer") and the SDXL analogue: ONE full train
+    step of the oracle restatement on the host cores — UNet forward (fp32), epsilon MSE, autograd backward, torch.optim.AdamW — at the bench's
+    resolution, batch 1, true architecture (859.5 M / 2.57 B parameters), random-init weights.  LoRA: peft-style adapters on every attn1 / attn2
+    to_q, to_k, to_v, to_out.0, applied as merged weights W + (alpha/r) B A with autograd through the merge (adapter gradients only)."""
+    from oracle.unet import UNetConfig, init_params, unet_forward
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = UNetConfig.sd15() if sd15 else UNetConfig()
+    P = init_params(cfg, seed=1)
+    lat, B, r = args.res // 8, 1, int(args.rank)
+    g = torch.Generator().manual_seed(0)
+    x, noise = torch.randn(B, 4, lat, lat, generator=g), torch.randn(B, 4, lat, lat, generator=g)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
+    ack = None
+    if cfg.addition_embed_type == "text_time":
+        ack = {"text_embeds": torch.randn(B, 1280, generator=g), "time_ids": torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * B, dtype=torch.float32)}
+    t = torch.tensor([500.0] * B)
+    if lora:
+        targets = [k[:-len(".weight")] for k in P if k.endswith((".to_q.weight", ".to_k.weight", ".to_v.weight", ".to_out.0.weight"))]
+        A = {n: (torch.randn(r, P[n + ".weight"].shape[1], generator=g) / math.sqrt(P[n + ".weight"].shape[1])).requires_grad_(True) for n in targets}
+        Bm = {n: (1e-3 * torch.randn(P[n + ".weight"].shape[0], r, generator=g)).requires_grad_(True) for n in targets}
+        train = list(A.values()) + list(Bm.values())
+    else:
+        train = [v.requires_grad_(True) for v in P.values()]
+    opt = torch.optim.AdamW(train, lr=1e-4 if lora else 1e-5)
+    t0 = time.time()
+    Pe = dict(P)
+    if lora:
+        for n in targets:
+            Pe[n + ".weight"] = P[n + ".weight"] + Bm[n] @ A[n]          # alpha = r
+    pred = unet_forward(Pe, cfg, x, t, ctx, ack)
+    loss = ((pred - noise) ** 2).mean()
+    loss.backward()
+    opt.step()
+    step_s = time.time() - t0
+    what = f"LoRA r{r} on {len(targets)} attention projections" if lora else "full fine-tune"
+    return {
+        "value": round(B / step_s, 6), "unit": "images/s", "cores": cores, "kind": "port",
+        "sample": f"oracle (plain torch fp32, autograd, torch.optim.AdamW) ONE full {'SD 1.5' if sd15 else 'SDXL'} UNet train step, {what}, {args.res}^2, batch 1: "
+                  f"{step_s:.1f} s (loss {float(loss.detach()):.4f})",
     }
 
 
@@ -404,6 +450,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.model == "flux":
             out["cpu_baseline"] = cpu_baseline(args)
+        elif world == 1 and not args.no_cpu_baseline and args.model in ("sd15", "sdxl"):
+            out["cpu_baseline"] = cpu_baseline_unet(args, sd15=args.model == "sd15", lora=not args.full)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

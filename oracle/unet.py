@@ -157,3 +157,75 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
 
 
 from tools.flop_count import unet_flops_fwd  # noqa: E402,F401  (one definition, shared with bench.py)
+
+
+def init_params(cfg: UNetConfig, seed: int = 0, std_scale: float = 1.0, shapes_only: bool = False) -> Dict[str, torch.Tensor]:
+    """Random weights under diffusers' names and shapes, walked in the order unet_forward consumes them (fan-in scaled normal, bias 0.02 N(0,1),
+    norm weights 1 + 0.1 N(0,1)).  For CPU baselines / self-contained oracle runs; parity tests take their weights from the model under test."""
+    g = torch.Generator().manual_seed(seed)
+    P: Dict[str, torch.Tensor] = {}
+
+    def rnd(*shape):                                     # shapes_only: meta tensors (names + shapes, no memory) for parameter accounting
+        return torch.empty(*shape, device="meta") if shapes_only else torch.randn(*shape, generator=g)
+
+    def lin(name, i, o, bias=True):
+        P[name + ".weight"] = rnd(o, i) * (std_scale / math.sqrt(i))
+        if bias:
+            P[name + ".bias"] = 0.02 * rnd(o)
+
+    def conv(name, i, o, k=3):
+        P[name + ".weight"] = rnd(o, i, k, k) * (std_scale / math.sqrt(i * k * k))
+        P[name + ".bias"] = 0.02 * rnd(o)
+
+    def norm(name, c):
+        P[name + ".weight"] = 1.0 + 0.1 * rnd(c)
+        P[name + ".bias"] = 0.02 * rnd(c)
+
+    ch = cfg.block_out_channels
+    nb, temb = len(ch), 4 * ch[0]
+
+    def res(p, ci, co):
+        norm(p + "norm1", ci); conv(p + "conv1", ci, co); lin(p + "time_emb_proj", temb, co); norm(p + "norm2", co); conv(p + "conv2", co, co)
+        if ci != co:
+            conv(p + "conv_shortcut", ci, co, 1)
+
+    def tr(p, c, n_layers):
+        norm(p + "norm", c)
+        (lin if cfg.use_linear_projection else (lambda n_, i, o: conv(n_, i, o, 1)))(p + "proj_in", c, c)
+        for k in range(n_layers):
+            b = f"{p}transformer_blocks.{k}."
+            for a, kv in (("attn1.", c), ("attn2.", cfg.cross_attention_dim)):
+                lin(b + a + "to_q", c, c, bias=False); lin(b + a + "to_k", kv, c, bias=False); lin(b + a + "to_v", kv, c, bias=False); lin(b + a + "to_out.0", c, c)
+            for n_ in ("norm1", "norm2", "norm3"):
+                norm(b + n_, c)
+            lin(b + "ff.net.0.proj", c, 8 * c); lin(b + "ff.net.2", 4 * c, c)
+        (lin if cfg.use_linear_projection else (lambda n_, i, o: conv(n_, i, o, 1)))(p + "proj_out", c, c)
+
+    lin("time_embedding.linear_1", ch[0], temb); lin("time_embedding.linear_2", temb, temb)
+    if cfg.addition_embed_type == "text_time":
+        lin("add_embedding.linear_1", cfg.projection_class_embeddings_input_dim, temb); lin("add_embedding.linear_2", temb, temb)
+    conv("conv_in", cfg.in_channels, ch[0])
+    skip, cin = [ch[0]], ch[0]
+    for i, typ in enumerate(cfg.down_block_types):
+        for j in range(cfg.layers_per_block):
+            res(f"down_blocks.{i}.resnets.{j}.", cin, ch[i])
+            cin = ch[i]
+            if typ.startswith("CrossAttn"):
+                tr(f"down_blocks.{i}.attentions.{j}.", cin, cfg.transformer_layers_per_block[i])
+            skip.append(cin)
+        if i < nb - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", cin, cin)
+            skip.append(cin)
+    res("mid_block.resnets.0.", cin, cin); tr("mid_block.attentions.0.", cin, cfg.transformer_layers_per_block[-1]); res("mid_block.resnets.1.", cin, cin)
+    for i, typ in enumerate(cfg.up_block_types):
+        ri = nb - 1 - i
+        for j in range(cfg.layers_per_block + 1):
+            res(f"up_blocks.{i}.resnets.{j}.", cin + skip.pop(), ch[ri])
+            cin = ch[ri]
+            if typ.startswith("CrossAttn"):
+                tr(f"up_blocks.{i}.attentions.{j}.", cin, cfg.transformer_layers_per_block[ri])
+        if i < nb - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", cin, cin)
+    norm("conv_norm_out", cin)
+    conv("conv_out", cin, cfg.out_channels)
+    return P

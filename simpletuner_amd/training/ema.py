@@ -10,6 +10,7 @@ behaviour (other ranks skip the update).
 from __future__ import annotations
 
 import copy
+import weakref
 from typing import Any, Dict, Iterable, Optional, Union
 
 import torch
@@ -43,6 +44,7 @@ class EMAModel:
         self.rank0_only = rank0_only
         tracked = [p for p in parameters]
         self._tracked_param_ids = [id(p) for p in tracked]
+        self._tracked_refs = [weakref.ref(p) for p in tracked]      # an id() is only meaningful while its object lives: a freed parameter's id gets reused
         self._flat = _contiguous_run([p.data for p in tracked]) and len(tracked) > 0
         if self._flat:
             n = sum(p.numel() for p in tracked)
@@ -104,7 +106,7 @@ class EMAModel:
         with untracked entries all land on the right tensors.  Deviation, on purpose: when NONE of the given tensors is a tracked parameter but
         the count matches (a freshly built copy of the model), the match is positional — the reference silently copies nothing in that case."""
         params = list(parameters)
-        by_id = dict(zip(self._tracked_param_ids, self.shadow_params))
+        by_id = {id(r()): s for r, s in zip(self._tracked_refs, self.shadow_params) if r() is not None}
         hits = [(by_id[id(p)], p) for p in params if id(p) in by_id]
         if not hits and len(params) == len(self.shadow_params):
             return list(zip(self.shadow_params, params))
@@ -123,14 +125,14 @@ class EMAModel:
     def store(self, parameters: Iterable[torch.nn.Parameter]) -> None:
         parameters = list(parameters)
         self.temp_stored_params = [p.detach().clone() for p in parameters]
-        self._temp_stored_param_ids = [id(p) for p in parameters]
+        self._temp_stored_param_ids = [weakref.ref(p) for p in parameters]
 
     def restore(self, parameters: Iterable[torch.nn.Parameter]) -> None:
         """ema.py:540-609: stored copies go back to the SAME parameter objects, whatever order they are passed in"""
         if self.temp_stored_params is None:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
         parameters = list(parameters)
-        by_id = dict(zip(self._temp_stored_param_ids, self.temp_stored_params))
+        by_id = {id(r()): c for r, c in zip(self._temp_stored_param_ids, self.temp_stored_params) if r() is not None}
         if all(id(p) in by_id for p in parameters):
             pairs = [(by_id[id(p)], p) for p in parameters]
         elif not any(id(p) in by_id for p in parameters) and len(parameters) == len(self.temp_stored_params):

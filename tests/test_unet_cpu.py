@@ -287,4 +287,20 @@ def test_flop_counters_agree_on_product_and_oracle_configs():
     offenders = {fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef) for n in ast.walk(fn)
                  if isinstance(n, (ast.Import, ast.ImportFrom)) and (getattr(n, "module", None) or n.names[0].name).startswith("oracle")}
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and (getattr(n, "module", None) or n.names[0].name).startswith("oracle")]
-    assert offenders == {"cpu_baseline"} and not top
+    assert offenders == {"cpu_baseline", "cpu_baseline_unet"} and not top          # both are cpu_baseline legs
+
+
+def test_oracle_unet_init_params_and_cpu_baseline_leg():
+    """oracle/unet.py::init_params walks diffusers' names exactly as unet_forward consumes them — the parameter totals are the published ones
+    (SD 1.5 UNet 859,520,964; SDXL UNet 2,567,463,684) — and bench.py's UNet cpu_baseline leg (BASELINE.json configs[0]) runs one full oracle
+    train step and reports the contract's fields"""
+    from types import SimpleNamespace
+
+    from oracle.unet import init_params
+    import bench
+    assert sum(v.numel() for v in init_params(UNetConfig.sd15(), 0, shapes_only=True).values()) == 859_520_964
+    shapes = init_params(UNetConfig(), 0, shapes_only=True)
+    assert sum(v.numel() for v in shapes.values()) == 2_567_463_684 and shapes["add_embedding.linear_1.weight"].shape == (1280, 2816)
+    out = bench.cpu_baseline_unet(SimpleNamespace(res=64, rank=4), sd15=True, lora=True)
+    assert set(out) == {"value", "unit", "cores", "kind", "sample"} and out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0
+    assert "LoRA r4 on 128 attention projections" in out["sample"] and "64^2" in out["sample"]
