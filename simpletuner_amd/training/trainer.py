@@ -105,6 +105,7 @@ class Trainer:
         self.state = {"global_step": 0, "micro_step": 0}
         self.last_loss = None          # device scalar, no host sync
         self.last_grad_norm = None
+        self.last_grad_absmax = None
 
     def train_step(self, raw_batch: dict) -> torch.Tensor:
         cfg, acc = self.config, self.accelerator
@@ -150,6 +151,7 @@ class Trainer:
                 stats = ops.grad_norm(gflat)
                 norm = stats[0].sqrt() * grad_scale
                 self.last_grad_norm = norm
+                self.last_grad_absmax = stats[1] * grad_scale          # `_max_grad_value` (trainer.py:6376-6407): same pass, device scalar, read only when logged
                 coef = (cfg.max_grad_norm / (norm + 1e-6)).clamp(max=1.0)
                 grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
             else:
