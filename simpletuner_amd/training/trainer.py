@@ -107,8 +107,23 @@ class Trainer:
         self.last_grad_norm = None
         self.last_grad_absmax = None
 
+    def check_pending_loss(self) -> None:
+        """The reference raises `RuntimeError("Non-finite training loss detected …")` right after the loss is computed (trainer.py:7102-7110), which
+        costs a host sync in the middle of every step.  Here the check is opt-in (`config.check_finite_loss`) and DEFERRED: the loss of step i is
+        inspected at the start of step i+1 (or by calling this), when it has long been computed — same exception, same message fields, one step
+        late, no stall of the launch queue."""
+        pending, self._pending_loss = getattr(self, "_pending_loss", None), None
+        if pending is None:
+            return
+        loss, step, filepaths, backend = pending
+        if not bool(torch.isfinite(loss).all()):
+            raise RuntimeError(f"Non-finite training loss detected (loss={loss.item()}, data_backend_id={backend}, filepaths={filepaths}, "
+                               f"loss_logs={{}}) at optimizer step {step}.")
+
     def train_step(self, raw_batch: dict) -> torch.Tensor:
         cfg, acc = self.config, self.accelerator
+        if getattr(cfg, "check_finite_loss", False):
+            self.check_pending_loss()
         comp = self.model.get_trained_component()
         prepared = self.model.prepare_batch(raw_batch, self.state)                       # trainer.py:6964
         self.state["micro_step"] += 1
@@ -128,6 +143,8 @@ class Trainer:
                 loss = loss / cfg.gradient_accumulation_steps
             self.last_loss = gather_sample_weighted_scalar(loss, prepared["latents"].shape[0], acc)   # :7114 (C2)
             acc.backward(loss)                                                           # :7126
+        if getattr(cfg, "check_finite_loss", False):
+            self._pending_loss = (loss.detach(), self.state["global_step"], prepared.get("filepaths"), prepared.get("data_backend_id"))
         if not boundary:
             return self.last_loss
         grad_scale = getattr(comp, "grad_scale_from_sync", 1.0) if sync is not None else 1.0

@@ -79,3 +79,18 @@ def test_checkpoint_file_set_formats_and_roundtrip(tmp_path):
     assert torch.equal(torch.rand(3), want_draw)                                # the torch RNG stream continues
     _, t = plug2.sample_flow_sigmas({"latents": torch.zeros(2, 1, 2, 2)}, state={"global_step": 6})
     assert torch.equal(t, torch.tensor([300.0, 100.0]))                         # the cursor continues at 2
+
+
+def test_deferred_non_finite_loss_check_raises_the_reference_error():
+    """trainer.py:7102-7110 semantics, deferred by one step (Trainer.check_pending_loss): finite -> silent and cleared, NaN / inf -> RuntimeError
+    naming the loss, the data backend and the file paths"""
+    import pytest
+    tr = Trainer.__new__(Trainer)
+    tr._pending_loss = (torch.tensor(0.25), 3, ["a.png"], "ds1")
+    tr.check_pending_loss()
+    assert tr._pending_loss is None
+    tr.check_pending_loss()                                                     # nothing pending: no-op
+    tr._pending_loss = (torch.tensor(float("nan")), 4, ["b.png", "c.png"], "ds1")
+    with pytest.raises(RuntimeError, match=r"Non-finite training loss detected \(loss=nan, data_backend_id=ds1, filepaths=\['b.png', 'c.png'\]"):
+        tr.check_pending_loss()
+    assert tr._pending_loss is None
