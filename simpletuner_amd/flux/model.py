@@ -75,10 +75,19 @@ class Flux(ModelFoundation):
         return params
 
     def _flux_guidance_scales(self, prepared_batch, batch_size):
+        """flux/model.py:682-705: one guidance value per sample — constant, or uniform in [flux_guidance_min, flux_guidance_max]; under XM the
+        draws are made for the ORIGINAL samples and repeated for every noise candidate (candidate-major)"""
+        import random
         mode = getattr(self.config, "flux_guidance_mode", "constant")
-        if mode != "constant":
-            raise NotImplementedError("only flux_guidance_mode=constant is implemented")
-        return [float(getattr(self.config, "flux_guidance_value", 1.0))] * batch_size
+        if mode == "constant":
+            return [float(getattr(self.config, "flux_guidance_value", 1.0))] * batch_size
+        if mode == "random-range":
+            lo, hi = self.config.flux_guidance_min, self.config.flux_guidance_max
+            k, b0 = prepared_batch.get("xm_candidate_count"), prepared_batch.get("xm_original_batch_size")
+            if k and b0:
+                return [random.uniform(lo, hi) for _ in range(int(b0))] * int(k)
+            return [random.uniform(lo, hi) for _ in range(batch_size)]
+        raise ValueError(f"Unsupported Flux guidance mode: {mode!r}.")
 
     def _model_predict_single(self, prepared_batch: dict):
         """flux/model.py:707-864"""
@@ -91,10 +100,13 @@ class Flux(ModelFoundation):
         guidance = None
         if getattr(comp.config, "guidance_embeds", False):
             scales = tuple(self._flux_guidance_scales(prepared_batch, B))
-            gkey = ("guidance", scales)
-            if gkey not in self._ids_cache:               # cached: a host->device copy is not allowed while a hipGraph is being captured
-                self._ids_cache[gkey] = torch.tensor(scales, device=dev)
-            guidance = self._ids_cache[gkey]
+            if getattr(self.config, "flux_guidance_mode", "constant") == "constant":
+                gkey = ("guidance", scales)
+                if gkey not in self._ids_cache:           # cached: a host->device copy is not allowed while a hipGraph is being captured
+                    self._ids_cache[gkey] = torch.tensor(scales, device=dev)
+                guidance = self._ids_cache[gkey]
+            else:                                         # fresh draws every step: one small H2D copy (not capturable into a hipGraph)
+                guidance = torch.tensor(scales, device=dev)
         key = (Hh, Ww, prepared_batch["prompt_embeds"].shape[1])
         if key not in self._ids_cache:
             self._ids_cache[key] = (prepare_latent_image_ids(B, Hh, Ww, dev, BF16),

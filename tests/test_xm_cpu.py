@@ -135,3 +135,19 @@ def test_model_predict_expands_then_marks_output():
     off._model_predict_single = single
     off.model_predict({"noisy_latents": lat})
     assert seen["B"] == 3
+
+
+def test_flux_guidance_scales_modes_and_xm_replication():
+    """flux/model.py:682-705; the XM case is the reference's tests/test_flux_model.py:93-128 (guidance [1.25, 1.75, 1.25, 1.75])"""
+    from simpletuner_amd.flux.model import Flux
+    m = Flux.__new__(Flux)
+    m.config = SimpleNamespace(flux_guidance_mode="constant", flux_guidance_value=3.5)
+    assert m._flux_guidance_scales({}, 3) == [3.5, 3.5, 3.5]
+    m.config = SimpleNamespace(flux_guidance_mode="random-range", flux_guidance_min=1.0, flux_guidance_max=2.0)
+    with patch("random.uniform", side_effect=[1.25, 1.75]):
+        assert m._flux_guidance_scales({"xm_candidate_count": 2, "xm_original_batch_size": 2}, 4) == [1.25, 1.75, 1.25, 1.75]
+    vals = m._flux_guidance_scales({}, 5)
+    assert len(vals) == 5 and all(1.0 <= v <= 2.0 for v in vals) and len(set(vals)) > 1
+    m.config = SimpleNamespace(flux_guidance_mode="bogus")
+    with pytest.raises(ValueError, match="Unsupported Flux guidance mode: 'bogus'"):
+        m._flux_guidance_scales({}, 1)
