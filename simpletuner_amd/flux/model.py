@@ -66,13 +66,30 @@ class Flux(ModelFoundation):
         """common.py:1049-1128"""
         if getattr(self.config, "model_type", "lora") != "lora":
             raise NotImplementedError("full-rank Flux training is not wired yet (round 2: wgrad GEMM)")
-        targets = "all" if getattr(self.config, "flux_lora_target", "default") in ("all", "all+ffs", "context") else "default"
+        targets = self._lora_target_set()
         params = self.unwrap_model(self.model).add_lora_adapter(rank=int(self.config.lora_rank),
                                                                 alpha=getattr(self.config, "lora_alpha", None), targets=targets,
                                                                 seed=int(getattr(self.config, "seed", 42) or 42) + 7,
                                                                 init_b_std=float(getattr(self.config, "lora_init_b_std", 0.0)))
         self.unwrap_model(self.model).prepare_for_training()
         return params
+
+    # flux/model.py:1235-1380: `flux_lora_target` names a set of wrapped Linears.  Built here: the attention projections — "all" (image + context
+    # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default) and the fall-through DEFAULT_LORA_TARGET (image stream and single
+    # blocks only: what BASELINE.json's config names).  Sets that wrap feed-forward / embedder / norm / ControlNet layers, or only a subset of the
+    # attention projections, need adapter backward paths this round did not build: refused, never silently narrowed.
+    _UNBUILT_LORA_TARGETS = ("context", "context+ffs", "all+ffs", "all+ffs+embedder", "all+ffs+embedder+controlnet", "ai-toolkit", "tiny", "nano", "controlnet")
+
+    def _lora_target_set(self) -> str:
+        want = str(getattr(self.config, "flux_lora_target", "default") or "default")
+        if want in self._UNBUILT_LORA_TARGETS:
+            raise NotImplementedError(f"flux_lora_target={want!r} is not implemented on the st355 path (built: 'all', and the default attention set)")
+        return "all" if want == "all" else "default"
+
+    def get_lora_target_layers(self):
+        if self._lora_target_set() == "all":
+            return ["to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "add_k_proj", "add_q_proj", "add_v_proj", "to_out.0", "to_add_out"]
+        return list(self.DEFAULT_LORA_TARGET)
 
     def _flux_guidance_scales(self, prepared_batch, batch_size):
         """flux/model.py:682-705: one guidance value per sample — constant, or uniform in [flux_guidance_min, flux_guidance_max]; under XM the

@@ -151,3 +151,18 @@ def test_flux_guidance_scales_modes_and_xm_replication():
     m.config = SimpleNamespace(flux_guidance_mode="bogus")
     with pytest.raises(ValueError, match="Unsupported Flux guidance mode: 'bogus'"):
         m._flux_guidance_scales({}, 1)
+
+
+def test_flux_lora_target_sets_are_exact_or_refused():
+    """flux/model.py:1235-1380: 'all' and the fall-through default are built; every other named set is refused instead of being narrowed silently"""
+    from simpletuner_amd.flux.model import Flux
+    m = Flux.__new__(Flux)
+    m.config = SimpleNamespace(flux_lora_target="all")
+    assert m._lora_target_set() == "all" and "to_add_out" in m.get_lora_target_layers() and "add_q_proj" in m.get_lora_target_layers()
+    for v in ("default", None, "mmdit", "something-else"):                       # unknown names fall through to DEFAULT_LORA_TARGET, as in the reference
+        m.config = SimpleNamespace(flux_lora_target=v)
+        assert m._lora_target_set() == "default" and m.get_lora_target_layers() == ["to_k", "to_q", "to_v", "to_out.0"]
+    for v in ("context", "all+ffs", "ai-toolkit", "tiny", "nano", "controlnet", "all+ffs+embedder"):
+        m.config = SimpleNamespace(flux_lora_target=v)
+        with pytest.raises(NotImplementedError, match="flux_lora_target"):
+            m._lora_target_set()
