@@ -70,7 +70,10 @@ class Trainer:
         self.params = (comp.trainable_parameters() if hasattr(comp, "trainable_parameters")
                        else [p for p in comp.parameters() if p.requires_grad])
         # optimizer_param.py:76-96 registry semantics: name -> class (+ default settings)
-        if getattr(config, "optimizer", "st355-adamw") == "adamw_bf16":
+        opt_name = getattr(config, "optimizer", "st355-adamw")
+        if opt_name not in ("adamw_bf16", "st355-adamw", "torch-adamw"):                   # never a silently different optimizer
+            raise NotImplementedError(f"optimizer '{opt_name}' is not built on the st355 path (adamw_bf16, st355-adamw = torch-adamw semantics)")
+        if opt_name == "adamw_bf16":
             self.optimizer = St355AdamWBF16(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
                                             eps=OPTIMIZER_CHOICE["adamw_bf16"]["default_settings"]["eps"], weight_decay=config.adam_weight_decay,
                                             seed=int(getattr(config, "seed", 0) or 0))

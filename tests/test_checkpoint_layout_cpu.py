@@ -94,3 +94,13 @@ def test_deferred_non_finite_loss_check_raises_the_reference_error():
     with pytest.raises(RuntimeError, match=r"Non-finite training loss detected \(loss=nan, data_backend_id=ds1, filepaths=\['b.png', 'c.png'\]"):
         tr.check_pending_loss()
     assert tr._pending_loss is None
+
+
+def test_unknown_optimizer_name_is_refused():
+    import pytest
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    c = default_config(optimizer="lion")
+    plug = _Plug(c, acc)
+    plug.model = _Comp(1)
+    with pytest.raises(NotImplementedError, match="optimizer 'lion'"):
+        Trainer(c, plug, acc)
