@@ -170,18 +170,23 @@ class DDPMSchedule:
         w[idx] *= mult
         return w / w.sum()
 
-    def sample_timesteps(self, bsz: int, segmented: bool = True, weights: Optional[torch.Tensor] = None):
+    def sample_timesteps(self, bsz: int, segmented: bool = True, weights: Optional[torch.Tensor] = None, refiner_training: bool = False,
+                         refiner_invert_schedule: bool = False, refiner_strength: float = 0.2):
         """weights: generate_timestep_weights (uniform by default); bsz > 1: one draw from each of bsz equal segments, high to low
-        (segmented_timestep_selection, custom_schedule.py:18-58, same draw order as the reference); drawn on the host: no device sync"""
+        (segmented_timestep_selection, custom_schedule.py:18-58, same draw order as the reference); SDXL-refiner training restricts the range to
+        the low-noise tail [0, strength*T) — or, inverted, to [strength*T, T) (:21-31).  Drawn on the host: no device sync."""
         T = self.config.num_train_timesteps
         weights = torch.ones(T) if weights is None else weights.clone()
         if bsz == 1 or not segmented:
             return torch.multinomial(weights, bsz, replacement=True).long()
-        seg = max(T // bsz, 1)
+        hi, lo = T - 1, 0
+        if refiner_training:
+            hi, lo = (T - 1, int(refiner_strength * T)) if refiner_invert_schedule else (int(T * refiner_strength) - 1, 0)
+        seg = max((hi - lo + 1) // bsz, 1)
         out = []
         for i in range(bsz):
-            start = T - 1 - i * seg
-            end = max(start - seg, 0) if i != bsz - 1 else 0
+            start = hi - i * seg
+            end = max(start - seg, lo) if i != bsz - 1 else lo
             w = weights[end:start + 1]
             w /= w.sum()                                   # in place on the slice, as the reference does (:50)
             out.append(end + int(torch.multinomial(w, 1).item()))
@@ -716,7 +721,10 @@ class ModelFoundation(ExplorativeModelingMixin):
             given_t = batch.get("timesteps")
             if given_t is None:
                 given_t = sched.sample_timesteps(bsz, segmented=not getattr(self.config, "disable_segmented_timestep_sampling", False),
-                                                 weights=DDPMSchedule.timestep_weights(self.config, sched.config.num_train_timesteps))
+                                                 weights=DDPMSchedule.timestep_weights(self.config, sched.config.num_train_timesteps),
+                                                 refiner_training=bool(getattr(self.config, "refiner_training", False)),
+                                                 refiner_invert_schedule=bool(getattr(self.config, "refiner_training_invert_schedule", False)),
+                                                 refiner_strength=float(getattr(self.config, "refiner_training_strength", 0.2)))
             batch["timesteps"] = given_t.to(device=dev).long()
             noise = batch.get("noise")
             if noise is None:

@@ -304,3 +304,19 @@ def test_oracle_unet_init_params_and_cpu_baseline_leg():
     out = bench.cpu_baseline_unet(SimpleNamespace(res=64, rank=4), sd15=True, lora=True)
     assert set(out) == {"value", "unit", "cores", "kind", "sample"} and out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0
     assert "LoRA r4 on 128 attention projections" in out["sample"] and "64^2" in out["sample"]
+
+
+def test_refiner_training_timestep_ranges_match_reference_code_outputs():
+    """segmented_timestep_selection with refiner_training (custom_schedule.py:21-31), normal and inverted, executed by tools/gen_golden.py"""
+    from pathlib import Path
+    G = torch.load(Path(__file__).parent / "golden" / "ddpm_sampling_vectors.pt", weights_only=False)
+    assert len(G["segmented_refiner"]) == 8
+    s = DDPMSchedule()
+    for invert, strength, bsz, seed, want in G["segmented_refiner"]:
+        torch.manual_seed(seed)
+        got = s.sample_timesteps(bsz, refiner_training=True, refiner_invert_schedule=invert, refiner_strength=strength)
+        assert torch.equal(got, want), (invert, strength, bsz)
+        assert (got >= int(strength * 1000)).all() if invert else (got < int(1000 * strength)).all()
+    for bsz, seed, want in G["segmented"]:                                       # the base-model range is unchanged
+        torch.manual_seed(seed)
+        assert torch.equal(s.sample_timesteps(bsz), want)

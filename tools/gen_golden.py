@@ -222,6 +222,12 @@ def gen_ddpm_sampling():
         for seed in (0, 1, 2):
             torch.manual_seed(seed)
             G["segmented"].append((bsz, seed, seg(1000, bsz, torch.ones(1000), cfg).clone()))
+    G["segmented_refiner"] = []
+    for invert, strength in ((False, 0.2), (True, 0.2), (False, 0.35), (True, 0.8)):
+        rcfg = SimpleNamespace(refiner_training=True, refiner_training_invert_schedule=invert, refiner_training_strength=strength)
+        for bsz in (2, 5):
+            torch.manual_seed(11)
+            G["segmented_refiner"].append((invert, strength, bsz, 11, seg(1000, bsz, torch.ones(1000), rcfg).clone()))
     out = OUT.parent / "ddpm_sampling_vectors.pt"
     torch.save(G, out)
     print("wrote", out)
