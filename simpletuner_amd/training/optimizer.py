@@ -179,11 +179,15 @@ class St355AdamWBF16(torch.optim.Optimizer):
         mk = lambda: torch.zeros(n, dtype=torch.bfloat16, device=dev)
         st["m"], st["v"], st["shift"] = mk(), mk(), mk()
         ends, off = [], 0
+        # "Each weight has its own starting point to avoid simultaneous updates in all weights" (:80-84).  The reference draws these phases from the
+        # global torch RNG; here they come from a generator private to (optimizer seed, group), so data-parallel replicas — whose global RNG streams
+        # differ by rank — release their delayed decay on the same steps and stay bit-identical.
+        phase_rng = torch.Generator().manual_seed(1_000_003 * self.seed + gi)
         for p in ps:
             k = p.numel()
-            # "Each weight has its own starting point to avoid simultaneous updates in all weights" (:80-84)
             self.state[p] = dict(step=0.0, exp_avg=st["m"][off:off + k].view_as(p), exp_avg_sq=st["v"][off:off + k].view_as(p),
-                                 shift=st["shift"][off:off + k].view_as(p), accumulated_decay=float(torch.rand([]) * self.decay_threshold))
+                                 shift=st["shift"][off:off + k].view_as(p),
+                                 accumulated_decay=float(torch.rand([], generator=phase_rng) * self.decay_threshold))
             off += k
             ends.append(off)
         st["seg_end"] = torch.tensor(ends, dtype=torch.int64, device=dev)

@@ -107,3 +107,19 @@ def test_optimizer_state_dict_resume_keeps_flat_arenas_and_fp32_moments():
     assert sdd["step"] == 9 and torch.equal(sdd["m"], sc["m"]) and torch.equal(sdd["v"], sc["v"]) and torch.equal(sdd["shift"], sc["shift"])
     assert [d.state[p]["accumulated_decay"] for p in ps2] == [1e-3, 2e-3] and d.state[ps2[0]]["step"] == 9.0
     assert d.state[ps2[1]]["shift"].data_ptr() == sdd["shift"][8:].data_ptr() and d.param_groups[0]["lr"] == 1e-4
+
+
+def test_decay_phases_are_replica_identical_whatever_the_global_rng():
+    """St355AdamWBF16 draws each tensor's initial delayed-decay phase from (optimizer seed, group), not from the rank-dependent global RNG"""
+    from simpletuner_amd.training.optimizer import St355AdamWBF16
+
+    def phases(global_seed, opt_seed):
+        torch.manual_seed(global_seed)
+        arena = torch.zeros(24, dtype=torch.bfloat16)
+        ps = [torch.nn.Parameter(arena[:8].view(2, 4)), torch.nn.Parameter(arena[8:].view(4, 4))]
+        o = St355AdamWBF16(ps, lr=1e-4, weight_decay=0.01, seed=opt_seed)
+        o._init_group(0, o.param_groups[0])
+        return [o.state[p]["accumulated_decay"] for p in ps]
+
+    a, b, c = phases(42, 7), phases(43, 7), phases(42, 8)
+    assert a == b and a != c and all(0.0 <= x < St355AdamWBF16.decay_threshold for x in a) and a[0] != a[1]
