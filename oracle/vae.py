@@ -89,3 +89,93 @@ def sample_and_scale(moments: torch.Tensor, cfg: VAEConfig, eps: Optional[torch.
 
 
 from tools.flop_count import vae_encoder_flops as encoder_flops  # noqa: E402,F401
+
+
+# ---- decoder (validation images) — restated for the product decoder the next round builds on the same conv / GroupNorm /
+# upsample kernels.  diffusers' Decoder: conv_in (latent -> C_last) -> UNetMidBlock2D -> UpDecoderBlock2D x4 over the REVERSED channel list
+# (layers_per_block + 1 resnets each, nearest-2x Upsample2D + conv3x3 on all but the last) -> GroupNorm -> SiLU -> conv_out (C_0 -> 3);
+# AutoencoderKL.decode applies post_quant_conv (1x1 on the latents) first when the VAE has one.  PARITY UNPINNED, like the encoder; the
+# parameter totals of init_params (encoder + decoder + quant convs) equal the published SD / SDXL VAE size, 83,653,863.
+def unscale_latents(z: torch.Tensor, cfg: VAEConfig) -> torch.Tensor:
+    """inverse of scale_vae_latents_for_cache: what the pipelines do before vae.decode (z / scaling_factor + shift_factor)"""
+    z = z / cfg.scaling_factor
+    return z + cfg.shift_factor if cfg.shift_factor is not None else z
+
+
+def decode(P: Dict[str, torch.Tensor], cfg: VAEConfig, z: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKL.decode(z).sample -> [B, 3, 8H, 8W]"""
+    g = cfg.norm_num_groups
+    if cfg.use_quant_conv:
+        z = _conv(z, P, "post_quant_conv", padding=0)
+    h = _conv(z, P, "decoder.conv_in")
+    h = _resnet(P, "decoder.mid_block.resnets.0.", h, g)
+    h = _mid_attention(P, "decoder.mid_block.attentions.0.", h, g)
+    h = _resnet(P, "decoder.mid_block.resnets.1.", h, g)
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block + 1):
+            h = _resnet(P, f"decoder.up_blocks.{i}.resnets.{j}.", h, g)
+        if i < nb - 1:
+            h = _conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), P, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+    h = F.silu(F.group_norm(h, g, P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"], 1e-6))
+    return _conv(h, P, "decoder.conv_out")
+
+
+def init_params(cfg: VAEConfig, seed: int = 0, shapes_only: bool = False) -> Dict[str, torch.Tensor]:
+    """random weights under diffusers' AutoencoderKL names (encoder, decoder, quant / post_quant convs), fan-in scaled"""
+    gen = torch.Generator().manual_seed(seed)
+    P: Dict[str, torch.Tensor] = {}
+
+    def rnd(*shape):
+        return torch.empty(*shape, device="meta") if shapes_only else torch.randn(*shape, generator=gen)
+
+    def conv(name, ci, co, k=3):
+        P[name + ".weight"] = rnd(co, ci, k, k) * (1.0 / math.sqrt(ci * k * k))
+        P[name + ".bias"] = 0.02 * rnd(co)
+
+    def lin(name, ci, co):
+        P[name + ".weight"] = rnd(co, ci) * (1.0 / math.sqrt(ci))
+        P[name + ".bias"] = 0.02 * rnd(co)
+
+    def norm(name, c):
+        P[name + ".weight"] = 1.0 + 0.1 * rnd(c)
+        P[name + ".bias"] = 0.02 * rnd(c)
+
+    def res(p, ci, co):
+        norm(p + "norm1", ci); conv(p + "conv1", ci, co); norm(p + "norm2", co); conv(p + "conv2", co, co)
+        if ci != co:
+            conv(p + "conv_shortcut", ci, co, 1)
+
+    def mid(p, c):
+        res(p + "resnets.0.", c, c)
+        a = p + "attentions.0."
+        norm(a + "group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(a + n, c, c)
+        res(p + "resnets.1.", c, c)
+
+    ch, L = cfg.block_out_channels, cfg.latent_channels
+    conv("encoder.conv_in", cfg.in_channels, ch[0])
+    cin = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            res(f"encoder.down_blocks.{i}.resnets.{j}.", cin, co)
+            cin = co
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cin, cin)
+    mid("encoder.mid_block.", cin)
+    norm("encoder.conv_norm_out", cin); conv("encoder.conv_out", cin, 2 * L)
+    if cfg.use_quant_conv:
+        conv("quant_conv", 2 * L, 2 * L, 1); conv("post_quant_conv", L, L, 1)
+    rev = tuple(reversed(ch))
+    conv("decoder.conv_in", L, rev[0])
+    mid("decoder.mid_block.", rev[0])
+    cin = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}.", cin, co)
+            cin = co
+        if i < len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin)
+    norm("decoder.conv_norm_out", cin); conv("decoder.conv_out", cin, cfg.in_channels)
+    return P

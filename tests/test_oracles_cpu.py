@@ -74,3 +74,24 @@ def test_vae_posterior_and_scaling():
     zf = OV.sample_and_scale(m, OV.VAEConfig.flux(), None)
     assert torch.allclose(zf, (m[:, :4] - 0.1159) * 0.3611)           # mode + (z - shift) * scale (foundation_mixins.py:72-74)
     assert abs(OV.encoder_flops(OV.VAEConfig(), 1024, 1024) / 1e12 - 4.9) < 0.3
+
+
+def test_vae_oracle_parameter_totals_and_decoder_roundtrip_shapes():
+    """oracle/vae.py::init_params walks diffusers' AutoencoderKL names (encoder + decoder + quant convs): the totals are the published sizes
+    (SD / SDXL VAE 83,653,863; FLUX.1 VAE 83,819,683), and encode -> scale -> unscale -> decode closes on the pixel grid"""
+    import torch
+
+    from oracle.vae import VAEConfig, decode, encode_moments, init_params, sample_and_scale, unscale_latents
+    assert sum(v.numel() for v in init_params(VAEConfig(), 0, shapes_only=True).values()) == 83_653_863
+    assert sum(v.numel() for v in init_params(VAEConfig.flux(), 0, shapes_only=True).values()) == 83_819_683
+    for cfg in (VAEConfig(block_out_channels=(32, 64, 64, 64)), VAEConfig(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False,
+                                                                           block_out_channels=(32, 64, 64, 64))):
+        P = init_params(cfg, 1)
+        assert ("post_quant_conv.weight" in P) == cfg.use_quant_conv
+        x = torch.randn(2, 3, 64, 48, generator=torch.Generator().manual_seed(0)).clamp(-1, 1)
+        z = sample_and_scale(encode_moments(P, cfg, x), cfg)
+        zr = unscale_latents(z, cfg)
+        mean = encode_moments(P, cfg, x).chunk(2, dim=1)[0]
+        torch.testing.assert_close(zr, mean, rtol=1e-5, atol=1e-5)               # unscale inverts scale_vae_latents_for_cache
+        y = decode(P, cfg, zr)
+        assert z.shape == (2, cfg.latent_channels, 8, 6) and y.shape == x.shape and torch.isfinite(y).all()
