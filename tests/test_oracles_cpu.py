@@ -95,3 +95,17 @@ def test_vae_oracle_parameter_totals_and_decoder_roundtrip_shapes():
         torch.testing.assert_close(zr, mean, rtol=1e-5, atol=1e-5)               # unscale inverts scale_vae_latents_for_cache
         y = decode(P, cfg, zr)
         assert z.shape == (2, cfg.latent_channels, 8, 6) and y.shape == x.shape and torch.isfinite(y).all()
+
+
+def test_oracle_architectures_have_the_published_parameter_totals():
+    """The network restatements cannot be pinned to reference tensors (diffusers is un-vendored), but their parameter name / shape walks can be
+    pinned to public facts: the exact parameter totals of the released checkpoints.  FLUX.1-dev transformer 11,901,408,320; SD3-Medium MMDiT
+    2,028,328,000 (UNet and VAE totals: tests/test_unet_cpu.py, test above)."""
+    import math
+
+    from oracle import flux as OF
+    from oracle import sd3 as OS
+    assert sum(math.prod(s) for s in OF.param_shapes(OF.FluxConfig()).values()) == 11_901_408_320
+    sd3m = OS.SD3Config(sample_size=128, num_layers=24, attention_head_dim=64, num_attention_heads=24, joint_attention_dim=4096,
+                        pooled_projection_dim=2048, pos_embed_max_size=192)
+    assert sum(math.prod(s) for s in OS.param_shapes(sd3m).values()) == 2_028_328_000
