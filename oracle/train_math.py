@@ -174,7 +174,7 @@ def scheduled_huber_c(timesteps, schedule: str, base_c: float, flow_matching: bo
 
 
 def compute_snr(timesteps, alphas_cumprod, use_soft_min: bool = False, sigma_data: float = 1.0):
-    """min_snr_gamma.py:4-46: (alpha/sigma)^2 with alpha = sqrt(acp[t]), sigma = sqrt(1 - acp[t]); soft-min variant"""
+    """min_snr_gamma.py:4-41: (alpha/sigma)^2 with alpha = sqrt(acp[t]), sigma = sqrt(1 - acp[t]); soft-min variant"""
     alpha = (alphas_cumprod ** 0.5)[timesteps.long()].float()
     sigma = ((1.0 - alphas_cumprod) ** 0.5)[timesteps.long()].float()
     if use_soft_min:

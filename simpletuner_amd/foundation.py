@@ -138,7 +138,7 @@ class DDPMSchedule:
         return self._sa[timesteps].contiguous(), self._sb[timesteps].contiguous()
 
     def snr(self, timesteps):
-        """compute_snr (min_snr_gamma.py:4-46): (alpha/sigma)^2 = acp / (1 - acp)"""
+        """compute_snr (min_snr_gamma.py:4-41): (alpha/sigma)^2 = acp / (1 - acp)"""
         a = self.alphas_cumprod.to(timesteps.device)[timesteps.long()].float()
         return a / (1.0 - a)
 

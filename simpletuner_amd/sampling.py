@@ -8,7 +8,7 @@ three diffusers imports shimmed) to produce tests/golden/flow_match_scheduler_ve
 
 The one behavioural subtlety the reference tests pin: with a STATIC shift, upstream computes `sigma_min / sigma_max` from the already-shifted
 training sigmas, so `set_timesteps` — which spaces timesteps between those bounds and shifts again — applies the shift twice
-(test_flow_match_scheduler_bounds.py:14-22 keeps that regression visible).  `fix_flow_match_euler_schedule_bounds` (training/flow_match.py:8-20)
+(test_flow_match_scheduler_bounds.py:14-22 keeps that regression visible).  `fix_flow_match_euler_schedule_bounds` (training/flow_match.py:8-19)
 resets the bounds to the unshifted 1/N and 1.0; the vendored ACE-Step copy takes the bounds before shifting and needs no fix.  Both forms
 are here: `bounds="shifted"` (upstream, the default, to be passed through the fix exactly as the reference does) and `bounds="unshifted"`.
 
@@ -26,7 +26,7 @@ import torch
 
 
 def fix_flow_match_euler_schedule_bounds(scheduler):
-    """training/flow_match.py:8-20: static-shift schedules get sigma_max = config.sigma_max (1.0) and sigma_min = 1 / num_train_timesteps back"""
+    """training/flow_match.py:8-19: static-shift schedules get sigma_max = config.sigma_max (1.0) and sigma_min = 1 / num_train_timesteps back"""
     cfg = getattr(scheduler, "config", None)
     if cfg is None or getattr(cfg, "use_dynamic_shifting", False):
         return scheduler
@@ -77,7 +77,7 @@ class FlowMatchEulerDiscreteScheduler:
         return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
 
     def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None, sigmas: Optional[Sequence[float]] = None, mu: Optional[float] = None):
-        """ace_step/.../scheduling_flow_match_euler_discrete.py:196-240"""
+        """simpletuner/helpers/models/ace_step/schedulers/scheduling_flow_match_euler_discrete.py:196-240"""
         if self.config.use_dynamic_shifting and mu is None:
             raise ValueError(" you have a pass a value for `mu` when `use_dynamic_shifting` is set to be `True`")
         if sigmas is None:

@@ -106,7 +106,7 @@ def gen_adamw_bf16():
 
 
 def gen_loss():
-    """conditional_loss / compute_scheduled_huber_c (common.py:6132-6216) and compute_snr (min_snr_gamma.py:4-46): the reference METHODS
+    """conditional_loss / compute_scheduled_huber_c (common.py:6132-6216) and compute_snr (min_snr_gamma.py:4-41): the reference METHODS
     lifted by AST and run on seeded inputs -> tests/golden/loss_vectors.pt (oracle + HIP kernel are pinned to these)."""
     import enum
     import torch.nn.functional as F
@@ -142,7 +142,7 @@ def gen_loss():
     G["snr.t"] = tl
     G["snr"] = compute_snr(tl, sched)
     G["snr.soft_min"] = compute_snr(tl, sched, use_soft_min=True, sigma_data=1.0)
-    G["_cite"] = "simpletuner/helpers/models/common.py:6132-6216; simpletuner/helpers/training/min_snr_gamma.py:4-46"
+    G["_cite"] = "simpletuner/helpers/models/common.py:6132-6216; simpletuner/helpers/training/min_snr_gamma.py:4-41"
     out = OUT.parent / "loss_vectors.pt"
     torch.save(G, out)
     print(f"wrote {out}: {len(G)} entries")
