@@ -173,4 +173,31 @@ def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc,
     return _head(P, cfg, h, emb, hh, ww)
 
 
+def param_shapes(cfg: PixArtConfig) -> Dict[str, tuple]:
+    """diffusers' PixArtTransformer2DModel state-dict names -> shapes, as the functions above consume them.  With use_additional_conditions=False
+    the total is 610,856,096 — the published size of PixArt-Sigma-XL-2 (tests/test_oracles_cpu.py)."""
+    D, sh = cfg.D, {}
+
+    def lin(name, i, o):
+        sh[name + ".weight"], sh[name + ".bias"] = (o, i), (o,)
+
+    sh["pos_embed.proj.weight"], sh["pos_embed.proj.bias"] = (D, cfg.in_channels, cfg.patch_size, cfg.patch_size), (D,)
+    lin("adaln_single.emb.timestep_embedder.linear_1", 256, D); lin("adaln_single.emb.timestep_embedder.linear_2", D, D)
+    if cfg.additional:
+        for n in ("resolution_embedder", "aspect_ratio_embedder"):
+            lin(f"adaln_single.emb.{n}.linear_1", 256, D // 3); lin(f"adaln_single.emb.{n}.linear_2", D // 3, D // 3)
+    lin("adaln_single.linear", D, 6 * D)
+    lin("caption_projection.linear_1", cfg.caption_channels, D); lin("caption_projection.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}."
+        sh[b + "scale_shift_table"] = (6, D)
+        for a in ("attn1.", "attn2."):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                lin(b + a + n, cfg.cross_attention_dim if (a == "attn2." and n in ("to_k", "to_v")) else D, D)
+        lin(b + "ff.net.0.proj", D, 4 * D); lin(b + "ff.net.2", 4 * D, D)
+    sh["scale_shift_table"] = (2, D)
+    lin("proj_out", D, cfg.patch_size * cfg.patch_size * cfg.out_channels)
+    return sh
+
+
 from tools.flop_count import pixart_flops_fwd  # noqa: E402,F401

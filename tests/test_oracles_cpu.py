@@ -109,3 +109,22 @@ def test_oracle_architectures_have_the_published_parameter_totals():
     sd3m = OS.SD3Config(sample_size=128, num_layers=24, attention_head_dim=64, num_attention_heads=24, joint_attention_dim=4096,
                         pooled_projection_dim=2048, pos_embed_max_size=192)
     assert sum(math.prod(s) for s in OS.param_shapes(sd3m).values()) == 2_028_328_000
+
+
+def test_pixart_oracle_names_and_published_total():
+    """PixArt-Sigma-XL-2: 610,856,096 parameters (no additional size conditions); with them (the 1024 alpha-style config) 611,349,152; the name
+    walk equals what pixart_forward reads (a forward over param_shapes-built weights runs)"""
+    import math
+
+    import torch
+
+    from oracle.pixart import PixArtConfig, param_shapes, pixart_forward
+    assert sum(math.prod(s) for s in param_shapes(PixArtConfig(use_additional_conditions=False)).values()) == 610_856_096
+    assert sum(math.prod(s) for s in param_shapes(PixArtConfig(use_additional_conditions=True)).values()) == 611_349_152
+    cfg = PixArtConfig(num_attention_heads=2, attention_head_dim=24, num_layers=2, cross_attention_dim=48, sample_size=16, caption_channels=32,
+                       use_additional_conditions=True)
+    g = torch.Generator().manual_seed(0)
+    P = {k: torch.randn(*s, generator=g) * 0.05 for k, s in param_shapes(cfg).items()}
+    out = pixart_forward(P, cfg, torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 5, 32, generator=g), torch.ones(2, 5), torch.tensor([500.0]),
+                         resolution=torch.tensor([[64.0, 64.0]] * 2), aspect_ratio=torch.tensor([[1.0]] * 2))
+    assert out.shape == (2, 8, 8, 8) and torch.isfinite(out).all()
