@@ -1,0 +1,69 @@
+"""Checkpoint surface of the PRODUCT models, checked without a GPU (parameters are plain torch tensors; only forward / backward need the device):
+their state-dict names and shapes equal the oracle's walks of diffusers' layouts, and their totals equal the published sizes of the released
+checkpoints — FLUX.1-dev 11,901,408,320; SD3-Medium 2,028,328,000; PixArt-Sigma (1024 config, with size conditions) 611,349,152; SD 1.5 UNet
+859,520,964 — so a released checkpoint's keys land one-to-one.  For the UNet the native-layout converter (conv [O,I,3,3] <-> [O, 9*I], padded
+conv_in / conv_out, K-major copies) is additionally round-tripped bit-exactly at full SD 1.5 size."""
+import math
+
+import torch
+
+from oracle import flux as OF
+from oracle import pixart as OP
+from oracle import sd3 as OS
+from oracle.unet import UNetConfig, init_params
+
+
+def _named(m):
+    return {n: tuple(p.shape) for n, p in m.named_parameters()}
+
+
+def test_transformer_families_match_oracle_walks_and_published_totals():
+    from simpletuner_amd.flux.transformer import FluxTransformer2DModel
+    from simpletuner_amd.pixart.transformer import PixArtTransformer2DModel
+    from simpletuner_amd.sd3.transformer import SD3Transformer2DModel
+    flux = _named(FluxTransformer2DModel(device="meta", guidance_embeds=True))
+    assert flux == {k: tuple(v) for k, v in OF.param_shapes(OF.FluxConfig()).items()} and sum(math.prod(s) for s in flux.values()) == 11_901_408_320
+    sd3 = _named(SD3Transformer2DModel(device="meta", sample_size=128, num_layers=24, num_attention_heads=24, attention_head_dim=64,
+                                       caption_projection_dim=1536, pooled_projection_dim=2048, pos_embed_max_size=192))
+    ref = OS.param_shapes(OS.SD3Config(sample_size=128, num_layers=24, attention_head_dim=64, num_attention_heads=24, joint_attention_dim=4096,
+                                       pooled_projection_dim=2048, pos_embed_max_size=192))
+    assert sd3 == {k: tuple(v) for k, v in ref.items()} and sum(math.prod(s) for s in sd3.values()) == 2_028_328_000
+    pix = _named(PixArtTransformer2DModel(device="meta", sample_size=128))
+    assert pix == {k: tuple(v) for k, v in OP.param_shapes(OP.PixArtConfig(sample_size=128)).items()}
+    assert sum(math.prod(s) for s in pix.values()) == 611_349_152
+
+
+def test_sd15_unet_state_dict_surface_and_converter_roundtrip():
+    from simpletuner_amd.sd1x.model import SD15_ARCH
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    m = UNet2DConditionModel(device="cpu", **SD15_ARCH)
+    sd = m.diffusers_state_dict()
+    ref = init_params(UNetConfig.sd15(), 0, shapes_only=True)
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    assert sum(v.numel() for v in sd.values()) == 859_520_964
+    g = torch.Generator().manual_seed(0)
+    new = {k: (torch.randn(v.shape, generator=g) * 0.02).to(torch.bfloat16) for k, v in sd.items()}
+    m.load_diffusers_state(new)
+    back = m.diffusers_state_dict()
+    assert all(torch.equal(back[k].to(torch.bfloat16), new[k]) for k in new)
+
+
+def test_small_sdxl_style_unet_surface():
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    small = dict(block_out_channels=(64, 128), layers_per_block=1, down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                 up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 2), attention_head_dim=(1, 2), cross_attention_dim=128,
+                 projection_class_embeddings_input_dim=64 + 6 * 64, addition_time_embed_dim=64)
+    sd = UNet2DConditionModel(device="cpu", **small).diffusers_state_dict()
+    ref = init_params(UNetConfig(**small), 0, shapes_only=True)
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+
+
+def test_vae_encoder_state_dict_surface():
+    """the product AutoencoderKL reads exactly diffusers' encoder (+ quant_conv) keys, with their shapes, for the SDXL and FLUX.1 layouts"""
+    from oracle.vae import VAEConfig
+    from oracle.vae import init_params as vae_params
+    from simpletuner_amd.vae.autoencoder_kl import AutoencoderKL
+    for cfg, kw in ((VAEConfig(), {}), (VAEConfig.flux(), dict(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False))):
+        sd = AutoencoderKL(device="cpu", **kw).synthetic_state_dict(0)
+        ref = {k: v for k, v in vae_params(cfg, 0, shapes_only=True).items() if k.startswith(("encoder.", "quant_conv"))}
+        assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
