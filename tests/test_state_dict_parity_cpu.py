@@ -67,3 +67,23 @@ def test_vae_encoder_state_dict_surface():
         sd = AutoencoderKL(device="cpu", **kw).synthetic_state_dict(0)
         ref = {k: v for k, v in vae_params(cfg, 0, shapes_only=True).items() if k.startswith(("encoder.", "quant_conv"))}
         assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+
+
+def test_lora_adapter_surfaces_use_peft_names_on_the_reference_target_sets():
+    """add_lora_adapter (common.py:1049-1128): peft key names `<module>.lora_A.default.weight` / `.lora_B.default.weight` on exactly the target
+    modules — Flux 'default' (to_q/k/v, to_out.0; single blocks to_q/k/v) and 'all' (+ add_*_proj, to_add_out) = oracle.flux.lora_targets; at
+    FLUX.1-dev size that is 19*4 + 38*3 = 190 wrapped Linears.  (The UNet's attach builds K-major copies on the
+    device: its 128-module surface is checked by tests/test_unet_model_gpu.py.)"""
+    from simpletuner_amd.flux.transformer import FluxTransformer2DModel
+    from tests import parity_utils as PU
+    for which in ("default", "all"):
+        m = FluxTransformer2DModel(device="cpu", **PU.small_flux_cfg(layers=2, single=3))
+        params = m.add_lora_adapter(rank=8, alpha=8.0, targets=which, seed=1)
+        names = [n for n, _ in m.named_parameters() if ".lora_" in n]
+        mods = {n.split(".lora_")[0] for n in names}
+        assert mods == set(OF.lora_targets(PU.oracle_cfg(m), which)) and len(params) == len(names) == 2 * len(mods)
+        assert all(n.endswith((".lora_A.default.weight", ".lora_B.default.weight")) for n in names)
+        a = dict(m.named_parameters())["transformer_blocks.0.attn.to_q.lora_A.default.weight"]
+        b = dict(m.named_parameters())["transformer_blocks.0.attn.to_q.lora_B.default.weight"]
+        assert a.shape == (8, 256) and b.shape == (256, 8) and a.requires_grad and b.requires_grad
+    assert len(OF.lora_targets(OF.FluxConfig(), "default")) == 190
