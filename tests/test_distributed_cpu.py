@@ -57,6 +57,30 @@ def _worker(rank, world, init_file, out_dir):
     res["sync_ok"] = (torch.equal(arena, want_arena) and torch.equal(mod.c.data, want_c) and torch.equal(mod.tab, want_tab)
                       and torch.equal(mod.a.data, want_arena[:1000].view(10, 100)) and calls == [1] and mod.inner._prepared is False)
     res["sync_bytes"] = nbytes
+    # --- Trainer construction under world 2: replicas leave __init__ with rank 0's trainable weights, adapters' gradient arena gets a GradSync ---
+    from simpletuner_amd.foundation import ModelFoundation
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+
+    class Comp(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            self.flat = (torch.randn(64, generator=torch.Generator().manual_seed(seed)) * 0.1)
+            self.lora_grad_flat = torch.zeros(64)
+            self.a = torch.nn.Parameter(self.flat[:32].view(4, 8))
+            self.b = torch.nn.Parameter(self.flat[32:].view(8, 4))
+            self.grad_sync = None
+
+        def trainable_parameters(self):
+            return [self.a, self.b]
+
+    acc = St355Accelerator(torch.device("cpu"))
+    cfg = default_config(model_type="lora")
+    plug = ModelFoundation(cfg, acc)
+    plug.model = Comp(seed=500 + rank)
+    tr = Trainer(cfg, plug, acc)
+    want = torch.randn(64, generator=torch.Generator().manual_seed(500)) * 0.1
+    res["trainer_sync_ok"] = bool(acc.num_processes == 2 and torch.equal(plug.model.flat, want) and plug.model.grad_sync is not None
+                                  and plug.model.grad_sync.world_size == 2 and len(tr.params) == 2)
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -73,4 +97,5 @@ def test_two_process_gloo_grad_sync_and_loss_gather():
             assert res["nosync_ok"]
             assert abs(res["weighted"] - 3.5) < 1e-6
             assert res["epoch_end"] is True
+            assert res["trainer_sync_ok"]
             assert res["sync_ok"] and res["sync_bytes"] == 4096 * 4 + 7 * 3 * 2 + 5 * 4
