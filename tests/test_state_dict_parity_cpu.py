@@ -87,3 +87,32 @@ def test_lora_adapter_surfaces_use_peft_names_on_the_reference_target_sets():
         b = dict(m.named_parameters())["transformer_blocks.0.attn.to_q.lora_B.default.weight"]
         assert a.shape == (8, 256) and b.shape == (256, 8) and a.requires_grad and b.requires_grad
     assert len(OF.lora_targets(OF.FluxConfig(), "default")) == 190
+
+
+def test_transformer_checkpoint_loaders_fill_fused_storage_through_diffusers_keys():
+    """load_flat_state(diffusers-keyed state dict): every per-projection parameter (a VIEW into fused qkv / modulation / arena storage) ends up
+    holding exactly the bf16 value of its checkpoint tensor — Flux, SD3 and PixArt, random weights in the oracle's (= diffusers') names"""
+    from simpletuner_amd.flux.transformer import FluxTransformer2DModel
+    from simpletuner_amd.pixart.transformer import PixArtTransformer2DModel
+    from simpletuner_amd.sd3.transformer import SD3Transformer2DModel
+    from tests import parity_utils as PU
+
+    def check(model, state):
+        model.load_flat_state(state)
+        bad = [n for n, p in model.named_parameters() if not torch.equal(p.detach().float(), state[n].to(p.dtype).float())]
+        assert not bad, bad[:3]
+
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda shapes: {k: torch.randn(*s, generator=g) * 0.05 for k, s in shapes.items()}
+    fl = FluxTransformer2DModel(device="cpu", **PU.small_flux_cfg(layers=2, single=2))
+    check(fl, rnd(OF.param_shapes(PU.oracle_cfg(fl))))
+    kw = dict(sample_size=32, num_layers=3, num_attention_heads=2, attention_head_dim=64, joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=24)
+    sd3 = SD3Transformer2DModel(device="cpu", caption_projection_dim=128, **kw)
+    st = rnd(OS.param_shapes(OS.SD3Config(**kw)))
+    if hasattr(sd3, "pos_embed") and hasattr(sd3.pos_embed, "pos_embed"):
+        st["pos_embed.pos_embed"] = sd3.pos_embed.pos_embed.detach().float().cpu().clone()          # a buffer of the checkpoint, not a parameter
+    check(sd3, st)
+    pkw = dict(num_attention_heads=8, attention_head_dim=72, num_layers=2, cross_attention_dim=576, sample_size=16, caption_channels=64, use_additional_conditions=True)
+    pcfg = OP.PixArtConfig(**pkw)
+    pix = PixArtTransformer2DModel(device="cpu", **pkw)
+    check(pix, rnd(OP.param_shapes(pcfg)))
