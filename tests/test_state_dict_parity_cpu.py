@@ -116,3 +116,16 @@ def test_transformer_checkpoint_loaders_fill_fused_storage_through_diffusers_key
     pcfg = OP.PixArtConfig(**pkw)
     pix = PixArtTransformer2DModel(device="cpu", **pkw)
     check(pix, rnd(OP.param_shapes(pcfg)))
+
+
+def test_sdxl_unet_state_dict_surface_at_full_size():
+    """SDXL UNet (BASELINE.json configs[1]): the product's diffusers-keyed surface at full size — 1,680 tensors, 2,567,463,684 parameters"""
+    import psutil
+    import pytest
+    if psutil.virtual_memory().available < 24 << 30:
+        pytest.skip("needs ~11 GB of host memory")
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    sd = UNet2DConditionModel(device="cpu").diffusers_state_dict()
+    ref = init_params(UNetConfig(), 0, shapes_only=True)
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    assert sum(v.numel() for v in sd.values()) == 2_567_463_684
