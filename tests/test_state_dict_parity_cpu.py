@@ -129,3 +129,29 @@ def test_sdxl_unet_state_dict_surface_at_full_size():
     ref = init_params(UNetConfig(), 0, shapes_only=True)
     assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
     assert sum(v.numel() for v in sd.values()) == 2_567_463_684
+
+
+def test_pixart_controlnet_adapter_surface_and_init():
+    """PixArtSigmaControlNetTransformerModel (pixart/controlnet.py:17-163): adapter keys `controlnet.controlnet_blocks.{i}.before_proj (block 0 only) |
+    transformer_block.* | after_proj`, zero-initialised projections, blocks copied from trunk blocks 0..N-1 (`from_transformer`), trunk frozen"""
+    from simpletuner_amd.pixart.transformer import PixArtSigmaControlNetTransformerModel, PixArtTransformer2DModel
+    pkw = dict(num_attention_heads=8, attention_head_dim=72, num_layers=4, cross_attention_dim=576, sample_size=16, caption_channels=64, use_additional_conditions=True)
+    trunk = PixArtTransformer2DModel(device="cpu", **pkw)
+    g = torch.Generator().manual_seed(1)
+    trunk.load_flat_state({k: torch.randn(*s, generator=g) * 0.05 for k, s in OP.param_shapes(OP.PixArtConfig(**pkw)).items()})
+    wrap = PixArtSigmaControlNetTransformerModel(trunk, num_layers=2, init_from_transformer=True)
+    named = dict(wrap.named_parameters())
+    train = {n for n, p in named.items() if p.requires_grad}
+    assert train and all(n.startswith("controlnet.controlnet_blocks.") for n in train)
+    assert not [n for n, p in named.items() if not n.startswith("controlnet.") and p.requires_grad]                      # trunk frozen
+    assert "controlnet.controlnet_blocks.0.before_proj.weight" in train and "controlnet.controlnet_blocks.1.before_proj.weight" not in named
+    for i in range(2):
+        for leaf in ("after_proj.weight", "after_proj.bias") + (("before_proj.weight", "before_proj.bias") if i == 0 else ()):
+            assert torch.count_nonzero(named[f"controlnet.controlnet_blocks.{i}.{leaf}"]) == 0
+        pre = f"controlnet.controlnet_blocks.{i}.transformer_block."
+        for n in [n for n in train if n.startswith(pre)]:
+            src = dict(trunk.named_parameters())[f"transformer_blocks.{i}." + n[len(pre):]]
+            assert torch.equal(named[n].detach().float(), src.detach().float()), n
+    per_block = {n[len("controlnet.controlnet_blocks.1."):] for n in train if n.startswith("controlnet.controlnet_blocks.1.")}
+    want = {"transformer_block." + k[len("transformer_blocks.0."):] for k in OP.param_shapes(OP.PixArtConfig(**pkw)) if k.startswith("transformer_blocks.0.")}
+    assert per_block == want | {"after_proj.weight", "after_proj.bias"}
