@@ -74,6 +74,12 @@ int st355_mse_loss(void* stream, const void* pred, const void* target, const flo
  * huber gives one c per sample, common.py:6252-6272; constant = the same value B times); weight as in st355_mse_loss. */
 int st355_cond_loss(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
                     float* loss_out, float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale);
+/* st355_cond_loss with the conditioning-mask branch of ModelFoundation.loss (common.py:6402-6424): the elementwise loss is multiplied by
+ * emask[b, i % mask_period] (fp32 [batch, mask_period], the [B,1,H,W] mask broadcast over channels; mask_period = H*W, a multiple of 8) before
+ * the per-sample mean.  emask NULL = st355_cond_loss.  loss_type 0 (l2) takes huber_c NULL. */
+int st355_cond_loss_masked(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
+                           const float* emask, int64_t mask_period, float* loss_out, float* per_sample_out, void* dpred, int64_t batch,
+                           int64_t per_sample, float grad_scale);
 
 /* ---- K3: Flux 2x2 pack / unpack (flux/__init__.py:25-45) ------------------------------------ */
 int st355_flux_pack(void* stream, const void* latents /*[B,C,H,W]*/, void* packed /*[B,(H/2)(W/2),4C]*/,
@@ -222,6 +228,9 @@ int st355_ema_update(void* stream, void* shadow, const void* param, int64_t n, f
 int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2);
 /* clip_grad_value_ (trainer.py:7209-7213): g <- clamp(g, -c, +c) in place (fp32 or bf16 arena) */
 int st355_grad_clamp(void* stream, void* g, int64_t n, int elem_bytes, float c);
+/* accelerator.clip_grad_norm_ (trainer.py:7201-7208) with the coefficient computed ON THE DEVICE: g *= min(1, max_norm / (sqrt(stats2[0]) * pre_scale
+ * + 1e-6)) in place, stats2 = the two floats st355_grad_norm wrote; pre_scale = 1/world when g still holds rank sums.  No host sync. */
+int st355_grad_clip_norm(void* stream, void* g, int64_t n, int elem_bytes, const float* stats2, float max_norm, float pre_scale);
 
 /* LoRA operand packing (K12): from fp32 A[r,K], B[N,r] write the bf16 GEMM operands of ONE adapter into the (zero-initialised)
  * block-structured operands of a fused projection group with K2 padded low-rank columns and N_total outputs:

@@ -127,26 +127,42 @@ extern "C" int st355_ddpm_noise_mix(void* stream, const void* x, const void* noi
 }
 
 // ---- K13: MSE ---------------------------------------------------------------------------------
+// optional per-element loss mask (common.py:6402-6424: the conditioning mask, [B,1,H,W] broadcast over the channels): the elementwise loss is
+// multiplied by emask[b, i % mask_period] before the per-sample mean; mask_period (= H*W) is a multiple of 8
+__device__ __forceinline__ void load_mask8(const float* __restrict__ em, int64_t off, float (&mk)[8]) {
+  if (em) {
+    const f32x4 a = *(const f32x4*)(em + off), b = *(const f32x4*)(em + off + 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { mk[j] = a[j]; mk[j + 4] = b[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) mk[j] = 1.f;
+  }
+}
 // grid = (blocks_per_sample, B). Each block reduces its slice in fp32 and adds one value per sample.
 __global__ void __launch_bounds__(EW_THREADS) k_mse(const bf16* __restrict__ pred, const bf16* __restrict__ target,
                                                    const float* __restrict__ weight, float* __restrict__ per_sample_acc,
-                                                   bf16* __restrict__ dpred, int64_t per_sample, float dscale) {
+                                                   bf16* __restrict__ dpred, int64_t per_sample, float dscale,
+                                                   const float* __restrict__ emask, int64_t mask_period) {
   const int b = blockIdx.y;
   const float w = weight ? weight[b] : 1.0f;
   const int64_t vecs = per_sample >> 3;
   const bf16* p = pred + (int64_t)b * per_sample;
   const bf16* t = target + (int64_t)b * per_sample;
   bf16* d = dpred ? dpred + (int64_t)b * per_sample : nullptr;
+  const float* em = emask ? emask + (int64_t)b * mask_period : nullptr;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (int64_t)gridDim.x * blockDim.x) {
     bf16x8 pv = *(const bf16x8*)(p + i * 8);
     bf16x8 tv = *(const bf16x8*)(t + i * 8);
     bf16x8 dv;
+    float mk[8];
+    load_mask8(em, (i * 8) % (em ? mask_period : 8), mk);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       float df = bf2f(pv[j]) - bf2f(tv[j]);
-      acc += df * df;
-      dv[j] = f2bf(dscale * w * df);
+      acc += df * df * mk[j];
+      dv[j] = f2bf(dscale * w * df * mk[j]);
     }
     if (d) *(bf16x8*)(d + i * 8) = dv;
   }
@@ -171,20 +187,26 @@ __global__ void k_mse_finalize(float* per_sample_acc, float* loss, int B, float 
     loss[0] = s / (float)B;
   }
 }
-extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target, const float* weight, float* loss_out,
-                              float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
+static int mse_loss_impl(void* stream, const void* pred, const void* target, const float* weight, float* loss_out,
+                         float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale, const float* emask, int64_t mask_period) {
   ST_REQUIRE(pred && target && loss_out && per_sample_out, "mse_loss: null pointer (per_sample_out is required scratch)");
   ST_REQUIRE(per_sample % 8 == 0 && batch > 0 && batch < 65536, "mse_loss: bad shape");
+  ST_REQUIRE(!emask || (mask_period > 0 && mask_period % 8 == 0 && per_sample % mask_period == 0 && ((uintptr_t)emask & 15) == 0),
+             "mse_loss: element mask period must be a multiple of 8 dividing per_sample (16-byte aligned)");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 3.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
   zero_words(stream, per_sample_out, (int)batch);
   int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
   if (bx > 512) bx = 512;
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
   hipLaunchKernelGGL(k_mse, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
-                     (const bf16*)target, weight, per_sample_out, (bf16*)dpred, per_sample, dscale);
+                     (const bf16*)target, weight, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
                      1.0f / (float)per_sample);
   return st355_check_launch("mse_loss");
+}
+extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target, const float* weight, float* loss_out,
+                              float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
+  return mse_loss_impl(stream, pred, target, weight, loss_out, per_sample_out, dpred, batch, per_sample, grad_scale, nullptr, 0);
 }
 
 // ---- K13b: conditional_loss (common.py:6132-6166): l2 | huber | smooth_l1, reduction "none" -> per-sample mean -> batch mean --------
@@ -195,9 +217,10 @@ template <int TYPE>
 __global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict__ pred, const bf16* __restrict__ target,
                                                          const float* __restrict__ weight, const float* __restrict__ huber_c,
                                                          float* __restrict__ per_sample_acc, bf16* __restrict__ dpred,
-                                                         int64_t per_sample, float dscale) {
+                                                         int64_t per_sample, float dscale, const float* __restrict__ emask, int64_t mask_period) {
   const int b = blockIdx.y;
   const float w = weight ? weight[b] : 1.0f;
+  const float* em = emask ? emask + (int64_t)b * mask_period : nullptr;
   const float c = huber_c[b], c2 = c * c;
   const float k = (TYPE == 1) ? 2.f * c : 2.f;
   const int64_t vecs = per_sample >> 3;
@@ -209,12 +232,14 @@ __global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict
     bf16x8 pv = *(const bf16x8*)(p + i * 8);
     bf16x8 tv = *(const bf16x8*)(t + i * 8);
     bf16x8 dv;
+    float mk[8];
+    load_mask8(em, (i * 8) % (em ? mask_period : 8), mk);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const float df = bf2f(pv[j]) - bf2f(tv[j]);
       const float r = sqrtf(df * df + c2);
-      acc += k * (r - c);
-      dv[j] = f2bf(0.5f * dscale * w * k * df / r);      // dscale carries the 2/(n B) of the l2 convention: undo the 2
+      acc += k * (r - c) * mk[j];
+      dv[j] = f2bf(0.5f * dscale * w * k * df / r * mk[j]);      // dscale carries the 2/(n B) of the l2 convention: undo the 2
     }
     if (d) *(bf16x8*)(d + i * 8) = dv;
   }
@@ -228,11 +253,14 @@ __global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict
     atomicAdd(&per_sample_acc[b], s * w);
   }
 }
-extern "C" int st355_cond_loss(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
-                               float* loss_out, float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
-  if (loss_type == 0) return st355_mse_loss(stream, pred, target, weight, loss_out, per_sample_out, dpred, batch, per_sample, grad_scale);
+extern "C" int st355_cond_loss_masked(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
+                                      const float* emask, int64_t mask_period, float* loss_out, float* per_sample_out, void* dpred, int64_t batch,
+                                      int64_t per_sample, float grad_scale) {
+  if (loss_type == 0) return mse_loss_impl(stream, pred, target, weight, loss_out, per_sample_out, dpred, batch, per_sample, grad_scale, emask, mask_period);
   ST_REQUIRE(pred && target && loss_out && per_sample_out && huber_c, "cond_loss: null pointer");
   ST_REQUIRE((loss_type == 1 || loss_type == 2) && per_sample % 8 == 0 && batch > 0 && batch < 65536, "cond_loss: bad args");
+  ST_REQUIRE(!emask || (mask_period > 0 && mask_period % 8 == 0 && per_sample % mask_period == 0 && ((uintptr_t)emask & 15) == 0),
+             "cond_loss: element mask period must be a multiple of 8 dividing per_sample (16-byte aligned)");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 6.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
   zero_words(stream, per_sample_out, (int)batch);
   int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
@@ -240,13 +268,17 @@ extern "C" int st355_cond_loss(void* stream, const void* pred, const void* targe
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
   if (loss_type == 1)
     hipLaunchKernelGGL(k_cond_loss<1>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
-                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale);
+                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   else
     hipLaunchKernelGGL(k_cond_loss<2>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
-                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale);
+                       (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
                      1.0f / (float)per_sample);
   return st355_check_launch("cond_loss");
+}
+extern "C" int st355_cond_loss(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
+                               float* loss_out, float* per_sample_out, void* dpred, int64_t batch, int64_t per_sample, float grad_scale) {
+  return st355_cond_loss_masked(stream, pred, target, weight, huber_c, loss_type, nullptr, 0, loss_out, per_sample_out, dpred, batch, per_sample, grad_scale);
 }
 
 // ---- K3: Flux pack / unpack -------------------------------------------------------------------------

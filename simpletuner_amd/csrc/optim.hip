@@ -322,6 +322,27 @@ extern "C" int st355_grad_clamp(void* stream, void* g, int64_t n, int elem_bytes
   return st355_check_launch("grad_clamp");
 }
 
+// accelerator.clip_grad_norm_ (trainer.py:7201-7208) without the host round trip: the coefficient min(1, max_norm / (||g|| + 1e-6)) is computed
+// on the device from the statistics st355_grad_norm left in HBM, and applied in place (torch's clip_grad_norm_ does the same g.mul_(coef) pass).
+// pre_scale folds the 1/world averaging that lives in the optimizer's grad_scale: the norm that is clipped is the norm of the AVERAGED gradient.
+template <typename T>
+__global__ void __launch_bounds__(OP_THREADS) k_grad_clip_norm(T* __restrict__ g, int64_t n, const float* __restrict__ stats2, float max_norm,
+                                                              float pre_scale) {
+  const float norm = sqrtf(stats2[0]) * pre_scale;
+  const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  if (coef >= 1.f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] = (T)((float)g[i] * coef);
+}
+extern "C" int st355_grad_clip_norm(void* stream, void* g, int64_t n, int elem_bytes, const float* stats2, float max_norm, float pre_scale) {
+  ST_REQUIRE(g && stats2 && n > 0 && max_norm > 0.f && pre_scale > 0.f && (elem_bytes == 4 || elem_bytes == 2), "grad_clip_norm: bad args");
+  ProfScope ps(stream, ST355_K_OPTIM, 1.0 * n, 2.0 * elem_bytes * n);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(k_grad_clip_norm<float>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (float*)g, n, stats2, max_norm, pre_scale);
+  else
+    hipLaunchKernelGGL(k_grad_clip_norm<bf16>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (bf16*)g, n, stats2, max_norm, pre_scale);
+  return st355_check_launch("grad_clip_norm");
+}
+
 // LoRA operand packer (block-structured; see st355.h)
 __global__ void __launch_bounds__(OP_THREADS) k_lora_pack(const float* __restrict__ A, const float* __restrict__ Bm, int r, int K, int N,
                                                          float scale, bf16* __restrict__ A_cat, bf16* __restrict__ A_cat_T,

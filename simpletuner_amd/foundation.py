@@ -131,6 +131,7 @@ class DDPMSchedule:
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type, beta_schedule=beta_schedule,
                                       rescale_betas_zero_snr=bool(rescale_betas_zero_snr))
+        self._acp_dev = {}
         self._sa = self.alphas_cumprod.sqrt().to(device)
         self._sb = (1.0 - self.alphas_cumprod).sqrt().to(device)
 
@@ -139,8 +140,16 @@ class DDPMSchedule:
 
     def snr(self, timesteps):
         """compute_snr (min_snr_gamma.py:4-41): (alpha/sigma)^2 = acp / (1 - acp)"""
-        a = self.alphas_cumprod.to(timesteps.device)[timesteps.long()].float()
+        a = self.acp_on(timesteps.device)[timesteps.long()].float()
         return a / (1.0 - a)
+
+    def acp_on(self, device):
+        """alphas_cumprod resident on `device` (copied once): the SNR / huber paths run inside hipGraph capture, where an H2D copy is illegal"""
+        key = str(torch.device(device))
+        hit = self._acp_dev.get(key)
+        if hit is None:
+            hit = self._acp_dev[key] = self.alphas_cumprod.to(device)
+        return hit
 
     def min_snr_weights(self, timesteps, gamma: float, v_prediction: bool):
         """common.py:6363-6397: min(snr, gamma) / snr  (epsilon)  or  / (snr + 1)  (v-prediction), one weight per sample"""
@@ -230,7 +239,8 @@ class ModelFoundation(ExplorativeModelingMixin):
         self.accelerator = accelerator
         self.model = None
         self.noise_schedule = None
-        self._noise_step = 0
+        self._noise_step = 0            # noising passes issued (diagnostic)
+        self._noise_offset = 0          # CUMULATIVE Philox counter position: every pass consumes its own, non-overlapping counter range whatever its shape
         self.xm_config = ExplorativeModelingConfig.from_config(config)     # common.py:578
 
     # ---- latent encode seam (common.py:2653-2772, foundation_mixins.py:66-79) ----
@@ -704,8 +714,9 @@ class ModelFoundation(ExplorativeModelingMixin):
             given = batch.get("noise")          # tests / parity runs inject the reference's noise; else Philox in-kernel
             seed = int(getattr(self.config, "seed", 42) or 0) + 1_000_003 * int(getattr(self.accelerator, "process_index", 0))
             per_call = (lat.numel() + 3) // 4
-            noisy, target, noise = ops.flow_noise_mix(lat, sig, noise=given, seed=seed, offset=self._noise_step * per_call)
+            noisy, target, noise = ops.flow_noise_mix(lat, sig, noise=given, seed=seed, offset=self._noise_offset)
             self._noise_step += 1
+            self._noise_offset += per_call          # mixed aspect buckets / varying batch: ranges of different steps never overlap
             batch["noise"] = noise
             batch["input_noise"] = noise
             batch["noisy_latents"] = noisy
@@ -787,8 +798,7 @@ class ModelFoundation(ExplorativeModelingMixin):
         loss_type = getattr(self.config, "loss_type", "l2")
         if loss_type not in ("l2", "huber", "smooth_l1"):
             raise NotImplementedError(f"Unsupported Loss Type {loss_type}")
-        if prepared_batch.get("loss_mask_type") or prepared_batch.get("conditioning_type") in ("mask", "segmentation"):
-            raise NotImplementedError("conditioning-mask losses are not implemented on the st355 path")
+        emask = self._conditioning_loss_mask(prepared_batch, model_pred, apply_conditioning_mask)      # common.py:6402-6424
         weight = None
         if self.PREDICTION_TYPE in (PredictionTypes.EPSILON, PredictionTypes.V_PREDICTION):
             gamma = getattr(self.config, "snr_gamma", None)
@@ -807,12 +817,37 @@ class ModelFoundation(ExplorativeModelingMixin):
         if _per_sample_only:
             with torch.no_grad():
                 p_, t_ = model_pred.detach().to(BF16), target.to(BF16)
-                per = (ops.mse_loss(p_, t_, weight=weight, want_grad=False) if loss_type == "l2"
-                       else ops.cond_loss(p_, t_, loss_type, huber_c, weight=weight, want_grad=False))[1]
+                per = ops.cond_loss(p_, t_, loss_type, huber_c, weight=weight, want_grad=False, emask=emask)[1]
             return per, weight
-        if loss_type == "l2":
+        if loss_type == "l2" and emask is None:
             return _MSELossFn.apply(model_pred, target, weight)
-        return _CondLossFn.apply(model_pred, target, loss_type, huber_c, weight)
+        return _CondLossFn.apply(model_pred, target, loss_type, huber_c, weight, emask)
+
+    def _conditioning_loss_mask(self, prepared_batch: dict, model_pred, apply_conditioning_mask: bool):
+        """common.py:6402-6424: `loss_mask_type` (legacy: `conditioning_type`) "mask" multiplies the elementwise loss by the first channel of
+        `conditioning_pixel_values`, area-resized to the latent grid and mapped from [-1,1] to [0,1]; "segmentation" — with probability
+        `masked_loss_probability` — by the binarised channel mean.  Returns the fp32 [B, H*W] element mask the fused loss kernel broadcasts over the
+        channels, or None.  (The area resize of a one-channel image is input preparation, done with torch like the reference does.)"""
+        kind = prepared_batch.get("loss_mask_type")
+        if not kind:
+            legacy = prepared_batch.get("conditioning_type")
+            kind = legacy if legacy in ("mask", "segmentation") else None
+        if kind not in ("mask", "segmentation") or not apply_conditioning_mask:
+            return None
+        if model_pred.dim() != 4:
+            raise NotImplementedError("conditioning-mask losses are built for [B,C,H,W] predictions")
+        cpv = prepared_batch["conditioning_pixel_values"].to(device=model_pred.device, dtype=torch.float32)
+        if kind == "mask":
+            m = cpv[:, 0].unsqueeze(1)
+        else:
+            import random
+            if not random.random() < float(getattr(self.config, "masked_loss_probability", 1.0)):
+                return None
+            m = torch.sum(cpv, dim=1, keepdim=True) / 3
+        m = torch.nn.functional.interpolate(m, size=model_pred.shape[2:], mode="area") / 2 + 0.5
+        if kind == "segmentation":
+            m = (m > 0).to(torch.float32)
+        return m.reshape(m.shape[0], -1).contiguous()
 
     def compute_scheduled_huber_c(self, timesteps: torch.Tensor) -> torch.Tensor:
         """common.py:6168-6216 (flow-matching branch of the "snr" schedule: sigma = ((1 - t/1000) / (t/1000 + 1e-4))^0.5)"""
@@ -823,11 +858,12 @@ class ModelFoundation(ExplorativeModelingMixin):
         if schedule == "constant":
             return torch.full_like(t, base)
         if schedule == "exponential":
-            alpha = -math.log(base) / float(getattr(self.config, "num_train_timesteps", 1000))
+            sched_cfg = getattr(getattr(self, "noise_schedule", None), "config", None)          # common.py:6187: self.noise_schedule.config.num_train_timesteps
+            alpha = -math.log(base) / float(getattr(sched_cfg, "num_train_timesteps", getattr(self.config, "num_train_timesteps", 1000)))
             return torch.exp(-alpha * t)
         if schedule == "snr":
             if self.PREDICTION_TYPE != PredictionTypes.FLOW_MATCHING:      # DDPM: sigma = sqrt((1 - acp_t) / acp_t) (common.py:6199-6205)
-                a = self.noise_schedule.alphas_cumprod.to(timesteps.device)[timesteps.long()].float()
+                a = self.noise_schedule.acp_on(timesteps.device)[timesteps.long()].float()
                 s_ = ((1.0 - a) / a) ** 0.5
                 return (1 - base) / (1 + s_) ** 2 + base
             s = t / 1000
@@ -850,15 +886,15 @@ class _CondLossFn(torch.autograd.Function):
     """huber / smooth_l1 (conditional_loss) -> per-sample mean -> batch mean, gradient from the same kernel pass"""
 
     @staticmethod
-    def forward(ctx, pred, target, loss_type, huber_c, weight=None):
-        loss, _per, dpred = ops.cond_loss(pred.to(BF16), target.to(BF16), loss_type, huber_c, weight=weight, want_grad=True)
+    def forward(ctx, pred, target, loss_type, huber_c, weight=None, emask=None):
+        loss, _per, dpred = ops.cond_loss(pred.to(BF16), target.to(BF16), loss_type, huber_c, weight=weight, want_grad=True, emask=emask)
         ctx.save_for_backward(dpred)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None, None, None
+        return (dpred.float() * g).to(dpred.dtype) if g.numel() == 1 else dpred, None, None, None, None, None
 
 
 class _MSELossFn(torch.autograd.Function):

@@ -17,14 +17,14 @@ LIB_PATH = _HERE / "csrc" / "libst355.so"
 SYMBOLS = [
     "st355_version", "st355_arch", "st355_last_error",
     "st355_prof_enable", "st355_prof_reset", "st355_prof_collect", "st355_prof_dump",
-    "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss", "st355_cond_loss",
+    "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss", "st355_cond_loss", "st355_cond_loss_masked",
     "st355_flux_pack", "st355_flux_unpack", "st355_patchify", "st355_unpatchify",
     "st355_timestep_proj", "st355_silu", "st355_gelu_tanh", "st355_silu_bwd", "st355_add", "st355_scale_cols",
     "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_tn_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_transpose_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn",
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd",
     "st355_attn_fwd", "st355_attn_bwd_workspace", "st355_attn_bwd",
-    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp",
+    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp", "st355_grad_clip_norm",
     "st355_lora_pack",
     # UNet path (SDXL / SD1.5)
     "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows",
@@ -85,6 +85,7 @@ def _declare(lib):
         "st355_ddpm_noise_mix": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64]),
         "st355_mse_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, f32]),
         "st355_cond_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32]),
+        "st355_cond_loss_masked": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, i64, i64, f32]),
         "st355_flux_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_flux_unpack": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_patchify": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32]),
@@ -121,6 +122,7 @@ def _declare(lib):
         "st355_ema_update": (C.c_int, [vp, vp, vp, i64, f32, i32]),
         "st355_grad_norm": (C.c_int, [vp, vp, i64, i32, vp]),
         "st355_grad_clamp": (C.c_int, [vp, vp, i64, i32, f32]),
+        "st355_grad_clip_norm": (C.c_int, [vp, vp, i64, i32, vp, f32, f32]),
         "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),
         "st355_conv_grid_rows": (i64, [i32, i32, i32]),
         "st355_conv_bf16": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32]),

@@ -98,9 +98,10 @@ def mse_loss(pred, target, weight=None, want_grad: bool = True, grad_scale: floa
 LOSS_TYPES = {"l2": 0, "huber": 1, "smooth_l1": 2}
 
 
-def cond_loss(pred, target, loss_type: str = "l2", huber_c=0.1, weight=None, want_grad: bool = True, grad_scale: float = 1.0):
-    """conditional_loss(reduction='none') -> per-sample mean -> batch mean (common.py:6132-6166, 6426-6429) + fused d(loss)/d(pred).
-    huber_c: float or fp32 device tensor [B] (scheduled huber).  Returns (loss[1], per_sample[B], dpred)."""
+def cond_loss(pred, target, loss_type: str = "l2", huber_c=0.1, weight=None, want_grad: bool = True, grad_scale: float = 1.0, emask=None):
+    """conditional_loss(reduction='none') -> [* emask] -> per-sample mean -> batch mean (common.py:6132-6166, 6402-6429) + fused d(loss)/d(pred).
+    huber_c: float or fp32 device tensor [B] (scheduled huber).  emask: fp32 [B, H*W] element mask broadcast over the channels (conditioning-mask
+    losses) or None.  Returns (loss[1], per_sample[B], dpred)."""
     L = _l.load()
     _chk(pred, BF16, "pred"); _chk(target, BF16, "target")
     pred = pred.contiguous(); target = target.contiguous()
@@ -108,13 +109,22 @@ def cond_loss(pred, target, loss_type: str = "l2", huber_c=0.1, weight=None, wan
     loss = torch.empty(1, dtype=F32, device=pred.device)
     per_sample = torch.empty(B, dtype=F32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
-    if not torch.is_tensor(huber_c):
-        huber_c = torch.full((B,), float(huber_c), dtype=F32, device=pred.device)
-    _chk(huber_c, F32, "huber_c")
+    if loss_type != "l2":
+        if not torch.is_tensor(huber_c):
+            huber_c = torch.full((B,), float(huber_c), dtype=F32, device=pred.device)
+        _chk(huber_c, F32, "huber_c")
+        huber_c = huber_c.contiguous()
+    else:
+        huber_c = None
     if weight is not None:
         _chk(weight, F32, "weight")
-    _l.check(L.st355_cond_loss(_stream(), _ptr(pred), _ptr(target), _ptr(weight), _ptr(huber_c.contiguous()), LOSS_TYPES[loss_type], _ptr(loss),
-                               _ptr(per_sample), _ptr(dpred), B, pred.numel() // B, grad_scale), "cond_loss")
+    period = 0
+    if emask is not None:
+        _chk(emask, F32, "emask")
+        emask = emask.reshape(B, -1).contiguous()
+        period = emask.shape[1]
+    _l.check(L.st355_cond_loss_masked(_stream(), _ptr(pred), _ptr(target), _ptr(weight), _ptr(huber_c), LOSS_TYPES[loss_type], _ptr(emask), period,
+                                      _ptr(loss), _ptr(per_sample), _ptr(dpred), B, pred.numel() // B, grad_scale), "cond_loss")
     return loss, per_sample, dpred
 
 
@@ -539,6 +549,16 @@ def grad_clamp_(g, c: float):
     if g.dtype not in (F32, BF16) or not g.is_contiguous():
         raise _l.St355Error("grad_clamp: expected a contiguous fp32 / bf16 tensor")
     _l.check(L.st355_grad_clamp(_stream(), _ptr(g), g.numel(), g.element_size(), float(c)), "grad_clamp")
+    return g
+
+
+def grad_clip_norm_(g, stats, max_norm: float, pre_scale: float = 1.0):
+    """in place: g *= min(1, max_norm / (sqrt(stats[0]) * pre_scale + 1e-6)); stats = grad_norm(g) (device, never read on the host)"""
+    L = _l.load()
+    _dev(g, "g"); _chk(stats, F32, "stats")
+    if g.dtype not in (F32, BF16) or not g.is_contiguous():
+        raise _l.St355Error("grad_clip_norm: expected a contiguous fp32 / bf16 tensor")
+    _l.check(L.st355_grad_clip_norm(_stream(), _ptr(g), g.numel(), g.element_size(), _ptr(stats), float(max_norm), float(pre_scale)), "grad_clip_norm")
     return g
 
 

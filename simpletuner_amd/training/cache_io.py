@@ -52,11 +52,13 @@ def text_embed_cache_filename(key_value, cache_dir: str, model_type: str, prompt
     return os.path.join(cache_dir, f"{h.hexdigest()}-{model_type}.pt")
 
 
-def loads_cache_payload(raw: bytes):
-    """bytes of one cache file -> the saved object on the CPU; transparently unwraps the gzip container of `compress_cache` back-ends"""
+def loads_cache_payload(raw: bytes, allow_pickle: bool = False):
+    """bytes of one cache file -> the saved object on the CPU; transparently unwraps the gzip container of `compress_cache` back-ends.
+    Loaded with `weights_only=True` — what the reference's `torch.load(..., map_location="cpu")` means on current torch — so a cache file from
+    shared / remote storage cannot execute a pickle; `allow_pickle=True` is the explicit opt-in for legacy files that hold arbitrary objects."""
     if raw[:2] == GZIP_MAGIC:
         raw = gzip.decompress(raw)
-    return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=False)
+    return torch.load(io.BytesIO(raw), map_location="cpu", weights_only=not allow_pickle)
 
 
 def dumps_cache_payload(data, compress: bool = False) -> bytes:

@@ -2,12 +2,20 @@
 (trainer.py:1034-1041, 4564-4571), re-designed for MI355X:
 
   * gradients live in ONE flat arena, filled back-to-front as the hand-written backward walks the blocks in reverse;
-  * every time a bucket's worth of finished gradient has accumulated, an asynchronous all-reduce (RCCL over xGMI with the
-    `nccl` backend; `gloo` in CPU tests) is issued on that contiguous slice — it overlaps the remaining backward kernels;
+  * every time a bucket's worth of finished gradient has accumulated, the slice is handed to the COMM STREAM: an event recorded on
+    the compute stream marks "these gradient bytes are final", the comm stream waits for that event (device-side, the host never
+    blocks) and the collective is issued there — RCCL over xGMI with the `nccl` backend, `gloo` in the CPU / shared-GPU tests — so it
+    overlaps the remaining backward kernels; `finish()` joins the comm stream back into the compute stream with one event;
+  * two forms of the exchange (same result, SUM over ranks):
+      - `allreduce`: one all-reduce per bucket — right for the small LoRA arenas (Flux r32: 150 MB fp32, ~0.25 ms of link time);
+      - `rs_ag`: reduce-scatter of the bucket into this rank's 1/N shard, then all-gather of the shards, issued back to back on the
+        comm stream — the direct form for the xGMI full mesh (each of the 7 links carries 2*G/N bytes), used for the
+        4-5 GB full-fine-tune arenas (default: arenas >= 1 GiB).  The shard boundary is where a sharded optimizer / a shard-local
+        gradient-norm would slot in; both collectives run in place on the arena (recv = send + rank * count).
   * SUM is used and the 1/world_size averaging is folded into the optimizer kernel's grad_scale (no extra pass over HBM);
   * `no_sync()` mirrors DDP/accelerate semantics for gradient accumulation (trainer.py:7009).
-Ring-vs-direct algorithm choice is RCCL's; bucket size is chosen for the per-link xGMI bound: 32 MiB slices keep each of
-the 7 links busy for ~0.2 ms (2*G/N per link at ~153 GB/s), long enough to amortise launch latency, short enough to overlap.
+Bucket size is chosen for the per-link xGMI bound: 32 MiB slices keep each of the 7 links busy for ~0.2 ms (2*G/N per link at
+~153 GB/s), long enough to amortise launch latency, short enough to overlap.
 """
 from __future__ import annotations
 
@@ -17,31 +25,77 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+RS_AG_MIN_BYTES = 1 << 30
+
 
 class GradSync:
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto"):
+        if mode not in ("auto", "allreduce", "rs_ag"):
+            raise ValueError(f"GradSync mode {mode!r}: expected auto / allreduce / rs_ag")
         self.flat = flat_grad
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.pg = process_group
         self.enabled = True
+        if mode == "auto":
+            mode = "rs_ag" if flat_grad.numel() * flat_grad.element_size() >= RS_AG_MIN_BYTES else "allreduce"
+        self.mode = mode
         self._works: List = []
         self._lo: Optional[int] = None   # pending [lo, hi) finished-but-unsent region
         self._hi: Optional[int] = None
-        self.launched_slices: List = []  # (lo, hi) of every all-reduce issued in the current backward (tests inspect it)
+        self.launched_slices: List = []  # (lo, hi) of every exchange issued in the current backward (tests inspect it)
+        self.launched_ops: List = []     # ("all_reduce" | "reduce_scatter" | "all_gather", lo, hi) in issue order
+        # explicit comm stream (device arenas only): collectives are enqueued behind an event of the compute stream, never on it
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        self._serial_backend = None      # resolved lazily: gloo runs async works concurrently -> dependent collectives must be waited for
 
     @property
     def world_size(self) -> int:
         return dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
 
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.pg) if dist.is_available() and dist.is_initialized() else 0
+
     def begin(self):
-        self._works, self._lo, self._hi, self.launched_slices = [], None, None, []
+        self._works, self._lo, self._hi, self.launched_slices, self.launched_ops = [], None, None, [], []
+
+    def _stream_ordered(self) -> bool:
+        """True when the backend executes this group's collectives in issue order on one device stream (nccl == RCCL)"""
+        if self._serial_backend is None:
+            self._serial_backend = str(dist.get_backend(self.pg)).lower() == "nccl"
+        return self._serial_backend
+
+    def _comm_ctx(self):
+        if self.comm_stream is None:
+            return contextlib.nullcontext()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.flat.device))       # the gradient bytes of this slice are final at this point of the backward
+        self.comm_stream.wait_event(ev)
+        return torch.cuda.stream(self.comm_stream)
 
     def _fire(self, lo: int, hi: int):
         if hi <= lo:
             return
         self.launched_slices.append((lo, hi))
-        if self.world_size > 1 and self.enabled:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        W = self.world_size
+        if W <= 1 or not self.enabled:
+            return
+        with self._comm_ctx():
+            m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
+            if m > 0:
+                seg = self.flat[lo:lo + m]
+                shard = seg[self.rank * (m // W):(self.rank + 1) * (m // W)]
+                w = dist.reduce_scatter_tensor(shard, seg, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self.launched_ops.append(("reduce_scatter", lo, lo + m))
+                if not self._stream_ordered():
+                    w.wait()                                          # gloo: the gather below must see the reduced shard
+                else:
+                    self._works.append(w)
+                self._works.append(dist.all_gather_into_tensor(seg, shard, group=self.pg, async_op=True))
+                self.launched_ops.append(("all_gather", lo, lo + m))
+            if lo + m < hi:                                            # all-reduce form, and the < world_size tail of an rs_ag slice
+                self._works.append(dist.all_reduce(self.flat[lo + m:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self.launched_ops.append(("all_reduce", lo + m, hi))
 
     def ready(self, lo: int, hi: int):
         """the backward finished gradient elements [lo, hi) (any order; adjacent regions are merged)"""
@@ -59,12 +113,22 @@ class GradSync:
             self._lo = self._hi = None
 
     def finish(self) -> float:
-        """flush, wait (stream-side for nccl) and return the factor the optimizer must fold in (1/world_size)"""
+        """flush, join the comm stream back into the compute stream (device-side for nccl) and return the factor the optimizer must fold
+        in (1/world_size)"""
         if self._lo is not None:
             self._fire(self._lo, self._hi)
             self._lo = self._hi = None
-        for w in self._works:
-            w.wait()
+        if self._works:
+            if self.comm_stream is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    for w in self._works:
+                        w.wait()
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+                torch.cuda.current_stream(self.flat.device).wait_event(done)
+            else:
+                for w in self._works:
+                    w.wait()
         self._works = []
         return 1.0 / self.world_size if self.enabled else 1.0
 

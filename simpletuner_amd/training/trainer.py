@@ -60,6 +60,38 @@ def default_config(**over) -> SimpleNamespace:
     return SimpleNamespace(**cfg)
 
 
+def _safe_load(path: str, allow_pickle: bool = False):
+    """torch.load with `weights_only=True` plus the numpy allow-list accelerate itself uses for its RNG-state files (accelerate.utils.other.load:
+    arrays and dtypes are numbers, not code).  `allow_pickle` (config.allow_unsafe_checkpoint_pickles) is the explicit opt-in for legacy files."""
+    if allow_pickle:
+        return torch.load(path, map_location="cpu", weights_only=False)
+    import numpy as np
+    from _codecs import encode
+    np_core = getattr(np, "_core", None) or np.core
+    allow = [np_core.multiarray._reconstruct, np.ndarray, np.dtype, encode]
+    if hasattr(np, "dtypes") and hasattr(np.dtypes, "UInt32DType"):
+        allow.append(np.dtypes.UInt32DType)
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def _diffusers_config(comp) -> dict:
+    """a diffusers-style config.json for the trained component: `_class_name` + every JSON-representable field of `comp.config`"""
+    import json
+    cfg = getattr(comp, "config", None)
+    items = dict(vars(cfg)) if cfg is not None and hasattr(cfg, "__dict__") else dict(cfg or {})
+    out = {"_class_name": type(comp).__name__, "_diffusers_version": "0.36.0"}
+    for k, v in items.items():
+        if isinstance(v, tuple):
+            v = list(v)
+        try:
+            json.dumps(v)
+        except TypeError:
+            continue
+        out[k] = v
+    return out
+
+
 class Trainer:
     def __init__(self, config, model_plugin, accelerator: Optional[St355Accelerator] = None, lr_lambda: Optional[Callable] = None):
         self.config = config
@@ -161,19 +193,21 @@ class Trainer:
             dist.all_reduce(torch.as_strided(grads[0], (n,), (1,)), op=dist.ReduceOp.SUM)
             grad_scale = 1.0 / acc.num_processes
         if getattr(cfg, "max_grad_norm", 0) and cfg.max_grad_norm > 0:                   # :7138-7217
-            gflat = getattr(comp, "_last_grad_flat", None)
-            if gflat is None:
-                raise NotImplementedError("gradient clipping needs the flat gradient arena")
+            # the flat view is built from the gradients autograd actually holds: with gradient accumulation AccumulateGrad adds later micro-steps IN
+            # PLACE into the first micro-step's buffer, so `p.grad` (not the component's last backward buffer) is what gets clipped, reduced and stepped
+            from .optimizer import _contiguous_run
+            grads = [p.grad for p in self.params]
+            if any(g is None for g in grads) or not _contiguous_run(grads):
+                raise NotImplementedError("gradient clipping needs the trainable gradients as one flat arena (every parameter with a gradient, back to back)")
+            gflat = torch.as_strided(grads[0], (sum(g.numel() for g in grads),), (1,))
             method = getattr(cfg, "grad_clip_method", "norm")
             if method == "value":                                                        # accelerator.clip_grad_value_ (:7209-7213)
                 ops.grad_clamp_(gflat, cfg.max_grad_norm / grad_scale)                   # gradients are rank SUMS here; 1/world lives in grad_scale
             elif method == "norm":
                 stats = ops.grad_norm(gflat)
-                norm = stats[0].sqrt() * grad_scale
-                self.last_grad_norm = norm
-                self.last_grad_absmax = stats[1] * grad_scale          # `_max_grad_value` (trainer.py:6376-6407): same pass, device scalar, read only when logged
-                coef = (cfg.max_grad_norm / (norm + 1e-6)).clamp(max=1.0)
-                grad_scale = grad_scale * float(coef.item())   # one host sync only when clipping is enabled (the reference has several)
+                self.last_grad_norm = stats[0].sqrt() * grad_scale                       # device scalars, read only when logged
+                self.last_grad_absmax = stats[1] * grad_scale          # `_max_grad_value` (trainer.py:6376-6407): same pass
+                ops.grad_clip_norm_(gflat, stats, cfg.max_grad_norm, pre_scale=grad_scale)   # coefficient computed and applied on the device: no host sync
             else:
                 raise ValueError(f"Unknown grad clip method: {method}. Supported methods: value, norm")
         self.optimizer.grad_scale = grad_scale
@@ -249,7 +283,6 @@ class Trainer:
         Rank 0 writes the shared files; every rank writes its own RNG / cursor files."""
         import json
         import os
-        import pickle
         import random
 
         import numpy as np
@@ -258,10 +291,16 @@ class Trainer:
         os.makedirs(checkpoint_dir, exist_ok=True)
         rng = {"random_state": random.getstate(), "numpy_random_seed": np.random.get_state(), "torch_manual_seed": torch.get_rng_state(),
                "torch_cuda_manual_seed": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None,
-               "st355_noise_step": int(getattr(plug, "_noise_step", 0))}        # the in-kernel Philox stream position of the noising pass
-        with open(os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"), "wb") as fh:
-            pickle.dump(rng, fh)
+               "st355_noise_step": int(getattr(plug, "_noise_step", 0)),
+               "st355_noise_offset": int(getattr(plug, "_noise_offset", 0))}    # the in-kernel Philox counter position of the noising pass (cumulative, shape-independent)
+        torch.save(rng, os.path.join(checkpoint_dir, f"random_states_{rank}.pkl"))     # accelerate's save_accelerator_state: torch.save under the .pkl name
         plug.save_flow_custom_timestep_state(checkpoint_dir)
+        ts = {"global_step": self.state["global_step"], "epoch_step": self.state.get("epoch_step", 0), "epoch": self.state.get("epoch", 1),
+              "exhausted_backends": list(self.state.get("exhausted_backends", [])), "repeats": dict(self.state.get("repeats", {})),
+              "micro_step": self.state["micro_step"]}
+        if rank != 0:                                                                   # save_hooks.py:369-373: non-zero ranks write their own state file
+            with open(os.path.join(checkpoint_dir, f"training_state-rank{rank}.json"), "w") as fh:
+                json.dump(ts, fh)
         if rank != 0:
             return
         host = lambda sd: {"state": {k: {n: (v.detach().to("cpu") if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()},
@@ -276,20 +315,21 @@ class Trainer:
             os.makedirs(sub, exist_ok=True)
             save_file({k: v.detach().to("cpu").contiguous() for k, v in comp.diffusers_state_dict().items()},
                       os.path.join(sub, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
+            # `unwrapped_model.save_pretrained` (save_hooks.py:1128) also writes config.json: without it neither diffusers' from_pretrained nor the
+            # reference's resume path can open the folder
+            with open(os.path.join(sub, "config.json"), "w") as fh:
+                json.dump(_diffusers_config(comp), fh, indent=2, sort_keys=True)
         else:
             plug.save_lora_weights(checkpoint_dir)
         if self.ema_model is not None:
             self.ema_model.save_state_dict(os.path.join(checkpoint_dir, f"{plug.MODEL_SUBFOLDER}_ema", "ema_model.pt"))
         with open(os.path.join(checkpoint_dir, "training_state.json"), "w") as fh:
-            json.dump({"global_step": self.state["global_step"], "epoch_step": self.state.get("epoch_step", 0), "epoch": self.state.get("epoch", 1),
-                       "exhausted_backends": list(self.state.get("exhausted_backends", [])), "repeats": dict(self.state.get("repeats", {})),
-                       "micro_step": self.state["micro_step"]}, fh)
+            json.dump(ts, fh)
 
     def load_state(self, checkpoint_dir: str) -> None:
         """the inverse of save_state; a missing per-rank RNG file falls back to rank 0's (resuming on more GPUs than the run was saved with)"""
         import json
         import os
-        import pickle
         import random
 
         import numpy as np
@@ -302,13 +342,17 @@ class Trainer:
             comp.load_diffusers_state(load_file(full_path))
         else:
             plug.load_lora_weights(input_dir=checkpoint_dir)
-        self.optimizer.load_state_dict(torch.load(os.path.join(checkpoint_dir, "optimizer.bin"), map_location="cpu", weights_only=False))
+        unsafe = bool(getattr(self.config, "allow_unsafe_checkpoint_pickles", False))     # explicit opt-in only: the default never executes a pickle
+        self.optimizer.load_state_dict(_safe_load(os.path.join(checkpoint_dir, "optimizer.bin"), unsafe))
         sched = os.path.join(checkpoint_dir, "scheduler.bin")
         if self.lr_scheduler is not None and os.path.exists(sched):
-            self.lr_scheduler.load_state_dict(torch.load(sched, map_location="cpu", weights_only=False))
+            self.lr_scheduler.load_state_dict(_safe_load(sched, unsafe))
         if self.ema_model is not None:
             self.ema_model.load_state_dict(os.path.join(checkpoint_dir, f"{plug.MODEL_SUBFOLDER}_ema", "ema_model.pt"))
-        with open(os.path.join(checkpoint_dir, "training_state.json")) as fh:
+        ts_path = os.path.join(checkpoint_dir, "training_state.json" if rank == 0 else f"training_state-rank{rank}.json")
+        if not os.path.exists(ts_path):                                                  # save_hooks.py:1276-1279: fall back to the default name
+            ts_path = os.path.join(checkpoint_dir, "training_state.json")
+        with open(ts_path) as fh:
             ts = json.load(fh)
         self.state.update({k: ts[k] for k in ("global_step", "epoch_step", "epoch", "exhausted_backends", "repeats") if k in ts})
         self.state["micro_step"] = int(ts.get("micro_step", self.state["global_step"] * self.config.gradient_accumulation_steps))
@@ -317,14 +361,14 @@ class Trainer:
             path = os.path.join(checkpoint_dir, name)
             if not os.path.exists(path):
                 continue
-            with open(path, "rb") as fh:
-                rng = pickle.load(fh)
+            rng = _safe_load(path, unsafe)
             random.setstate(rng["random_state"])
             np.random.set_state(rng["numpy_random_seed"])
             torch.set_rng_state(rng["torch_manual_seed"])
             if rng.get("torch_cuda_manual_seed") is not None and torch.cuda.is_available():
                 torch.cuda.set_rng_state_all(rng["torch_cuda_manual_seed"])
             plug._noise_step = int(rng.get("st355_noise_step", 0))
+            plug._noise_offset = int(rng.get("st355_noise_offset", 0))
             break
 
     def train(self, batches: Iterable[dict], max_steps: int):

@@ -50,6 +50,7 @@ def test_checkpoint_file_set_formats_and_roundtrip(tmp_path):
     tr.ema_model.shadow_flat.fill_(0.125); tr.ema_model.optimization_step = 6
     tr.state.update(global_step=6, micro_step=6, epoch=2, epoch_step=3)
     plug._noise_step = 6
+    plug._noise_offset = 6 * 4099
     plug.sample_flow_sigmas({"latents": torch.zeros(2, 1, 2, 2)}, state={"global_step": 0})      # advances the round-robin cursor to 2
     torch.manual_seed(123)
     ck = tmp_path / "checkpoint-6"
@@ -60,10 +61,11 @@ def test_checkpoint_file_set_formats_and_roundtrip(tmp_path):
     ts = json.loads((ck / "training_state.json").read_text())
     want_ts = {"global_step": 6, "epoch_step": 3, "epoch": 2, "exhausted_backends": [], "repeats": {}}
     assert {k: ts[k] for k in want_ts} == want_ts
-    opt_sd = torch.load(ck / "optimizer.bin", weights_only=False)
+    opt_sd = torch.load(ck / "optimizer.bin", weights_only=True)            # no pickle execution needed for any file of the set
     assert set(opt_sd) == {"state", "param_groups"} and set(opt_sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq", "shift", "accumulated_decay"}
-    rng = pickle.loads((ck / "random_states_0.pkl").read_bytes())
-    assert {"random_state", "numpy_random_seed", "torch_manual_seed", "torch_cuda_manual_seed"} <= set(rng) and rng["st355_noise_step"] == 6
+    from accelerate.utils.other import load as accelerate_load          # accelerate's own reader of its RNG file (weights_only + numpy allow-list)
+    rng = accelerate_load(ck / "random_states_0.pkl")
+    assert {"random_state", "numpy_random_seed", "torch_manual_seed", "torch_cuda_manual_seed"} <= set(rng) and rng["st355_noise_step"] == 6 and rng["st355_noise_offset"] == 6 * 4099
     want_draw = torch.rand(3)                                                   # what the run would have drawn next
 
     tr2, plug2 = _trainer(2)                                                    # a fresh process: different init everywhere
@@ -75,7 +77,7 @@ def test_checkpoint_file_set_formats_and_roundtrip(tmp_path):
     assert [tr2.optimizer.state[p]["accumulated_decay"] for p in tr2.params] == [1e-3, 2e-3]
     assert tr2.lr_scheduler.last_epoch == tr.lr_scheduler.last_epoch == 6 and tr2.optimizer.param_groups[0]["lr"] == tr.optimizer.param_groups[0]["lr"]
     assert torch.equal(tr2.ema_model.shadow_flat, tr.ema_model.shadow_flat) and tr2.ema_model.optimization_step == 6
-    assert tr2.state["global_step"] == 6 and tr2.state["micro_step"] == 6 and tr2.state["epoch"] == 2 and plug2._noise_step == 6
+    assert tr2.state["global_step"] == 6 and tr2.state["micro_step"] == 6 and tr2.state["epoch"] == 2 and plug2._noise_step == 6 and plug2._noise_offset == 6 * 4099
     assert torch.equal(torch.rand(3), want_draw)                                # the torch RNG stream continues
     _, t = plug2.sample_flow_sigmas({"latents": torch.zeros(2, 1, 2, 2)}, state={"global_step": 6})
     assert torch.equal(t, torch.tensor([300.0, 100.0]))                         # the cursor continues at 2

@@ -99,3 +99,52 @@ def test_two_process_gloo_grad_sync_and_loss_gather():
             assert res["epoch_end"] is True
             assert res["trainer_sync_ok"]
             assert res["sync_ok"] and res["sync_bytes"] == 4096 * 4 + 7 * 3 * 2 + 5 * 4
+
+
+def _worker_rs_ag(rank, world, init_file, out_dir):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from simpletuner_amd.training.grad_sync import GradSync
+
+    n = 10_007                                                        # odd: every slice leaves a < world tail for the all-reduce form
+    base = torch.arange(n, dtype=torch.float32)
+    out = {}
+    for mode in ("rs_ag", "allreduce"):
+        flat = base * (rank + 1) + (0.25 if rank == 1 else 0.0)
+        gs = GradSync(flat, bucket_bytes=4 * 1500, mode=mode)
+        gs.begin()
+        edges = list(range(n, 0, -701)) + [0]
+        for hi, lo in zip(edges[:-1], edges[1:]):
+            gs.ready(lo, hi)
+        scale = gs.finish()
+        out[mode] = (flat.clone(), scale, list(gs.launched_ops), list(gs.launched_slices))
+    # auto: small arenas take the all-reduce form, >= RS_AG_MIN_BYTES the reduce-scatter + all-gather form
+    import simpletuner_amd.training.grad_sync as GS
+    out["auto_small"] = GradSync(torch.zeros(64)).mode
+    old = GS.RS_AG_MIN_BYTES
+    GS.RS_AG_MIN_BYTES = 128
+    out["auto_big"] = GradSync(torch.zeros(64)).mode
+    GS.RS_AG_MIN_BYTES = old
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_process_reduce_scatter_all_gather_form_equals_all_reduce():
+    """the rs_ag exchange (reduce-scatter into this rank's shard, all-gather of the shards, in place on the arena; a < world tail of every
+    slice goes through all-reduce) leaves the same SUM in every rank's arena as the all-reduce form, bit for bit"""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_rs_ag, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(d, f"r{r}.pt")) for r in range(2))
+    want = torch.arange(10_007, dtype=torch.float32) * 3 + 0.25
+    for res in (r0, r1):
+        for mode in ("rs_ag", "allreduce"):
+            flat, scale, ops_, slices = res[mode]
+            assert torch.equal(flat, want), mode
+            assert scale == 0.5
+            assert sum(hi - lo for lo, hi in slices) == 10_007
+        kinds = [k for k, _, _ in res["rs_ag"][2]]
+        assert kinds.count("reduce_scatter") == kinds.count("all_gather") >= 3 and "all_reduce" in kinds     # odd slices leave 1-element tails
+        for (k1, lo1, hi1), (k2, lo2, hi2) in zip(res["rs_ag"][2], res["rs_ag"][2][1:]):
+            if k1 == "reduce_scatter":
+                assert (k2, lo2, hi2) == ("all_gather", lo1, hi1) and (hi1 - lo1) % 2 == 0
+        assert all(k == "all_reduce" for k, _, _ in res["allreduce"][2])
+        assert res["auto_small"] == "allreduce" and res["auto_big"] == "rs_ag"
