@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--rank", type=int, default=32)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA secondary measurement appended to the default line")
     ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
     a = ap.parse_args()
@@ -333,10 +334,30 @@ def main():
         if rank == 0:
             print(f"[bench] {dist.get_backend()} process group up: {dist.get_world_size()} ranks (one per GPU), rank 0 on {torch.cuda.get_device_name(dev)}", file=sys.stderr)
 
-    from simpletuner_amd import ops
-    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
     if args.model == "vae":
         return bench_vae(args, dev, rank, world)
+    out = run_workload(args, dev, rank, world)
+    if args.model == "flux" and not args.no_secondary:
+        # the metric names "SDXL-LoRA & Flux-dev 1024^2": the SDXL-LoRA half rides along as a secondary measurement of the same run
+        # (r16 on attn1/attn2 to_q/to_k/to_v/to_out.0, per-GPU batch 4, a few steps; hipGraph replay on one GPU, eager launches under N > 1)
+        import copy
+        a2 = copy.copy(args)
+        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 4, False, world == 1, False
+        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.prof_dump, a2.fp8 = min(args.steps, 5), 2, True, None, False
+        sec = run_workload(a2, dev, rank, world)
+        if rank == 0:
+            out["secondary"] = {"sdxl_lora": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_model_tflops",
+                                                                    "step_frac_of_bf16_mfma_peak", "roofline", "loss")}}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_workload(args, dev, rank, world):
+    """build one workload, run warmup + timed steps, return the JSON dict on rank 0 (None elsewhere)"""
+    from simpletuner_amd import ops
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42, lora_init_b_std=1e-3,   # weights / adapter init / rounding seeds are REPLICA-identical; the data RNG below is per rank
                         
@@ -546,9 +567,8 @@ def main():
             out["cpu_baseline"], out["parity_at_config"] = cpu_baseline(args, dev)
         elif world == 1 and not args.no_cpu_baseline and args.model in ("sd15", "sdxl"):
             out["cpu_baseline"] = cpu_baseline_unet(args, sd15=args.model == "sd15", lora=not args.full)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -299,8 +299,8 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
     g = guidance.float() * 1000 if (guidance is not None and cfg.guidance_embeds) else None
     temb = time_text_embed(P, cfg, t, g, pooled_projections)
     enc = linear(encoder_hidden_states, P, "context_embedder")
-    ids = torch.cat((txt_ids, img_ids), dim=0)
-    cos, sin = rope_tables(ids, cfg.axes_dims_rope)
+    ids = torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0)
+    cos, sin = (t.to(hidden.device) for t in rope_tables(ids, cfg.axes_dims_rope))      # tables in float64 on the host; the oracle itself may run on any device
     if taps is not None:
         taps["temb"] = temb; taps["x_embed"] = hidden; taps["ctx_embed"] = enc
     for i in range(cfg.num_layers):
@@ -327,7 +327,7 @@ def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, 
     packed = pack_latents(noisy_latents)
     img_ids = prepare_latent_image_ids(Hh, Ww)
     txt_ids = torch.zeros(prompt_embeds.shape[1], 3)
-    guidance = torch.full((B,), float(guidance_value)) if cfg.guidance_embeds else None
+    guidance = torch.full((B,), float(guidance_value), device=noisy_latents.device) if cfg.guidance_embeds else None
     out = flux_forward(P, cfg, packed, prompt_embeds, pooled, timesteps / 1000.0, img_ids, txt_ids, guidance, lora, lora_scale,
                        taps=taps)
     return unpack_latents(out, Hh, Ww)

@@ -149,10 +149,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
         ls += p[sb][r];
       }
     l_run = l_run * alpha + ls;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {        // wave-uniform: once the running max is stable the 16*NDT multiplies are skipped
 #pragma unroll
-    for (int dt = 0; dt < NDT; dt++)
+      for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc_o[dt][r] *= alpha;
+        for (int r = 0; r < 16; r++) acc_o[dt][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T ----
     bf16x8 pf[2][2];

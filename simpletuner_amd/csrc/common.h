@@ -34,20 +34,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// tanh-approximated GELU (diffusers "gelu-approximate" / nn.GELU(approximate="tanh"))
-__device__ __forceinline__ float gelu_tanh(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  float t = 1.f - 2.f / (1.f + __expf(2.f * u));  // tanh(u)
-  return 0.5f * x * (1.f + t);
+// tanh-approximated GELU (diffusers "gelu-approximate" / nn.GELU(approximate="tanh")):
+//   0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+// written as ONE v_exp_f32 + ONE v_rcp_f32 + 5 plain VALU ops.  The IEEE division of the textbook form (v_div_scale x2, v_rcp, 4 fma,
+// v_div_fmas, v_div_fixup) made the GELU epilogues of the N = 12288 MLP GEMMs ~25 VALU instructions per element — 128 elements per lane per
+// 256x256 tile, all of it with the matrix pipe idle.  v_rcp_f32 is accurate to 1 ulp; the result is rounded to bf16 right after.
+__device__ __forceinline__ float sigmoid2u(float x, float x2) {
+  // 2u * log2(e) = x * (c0 + c1 x^2):  c0 = 2 sqrt(2/pi) log2(e), c1 = c0 * 0.044715
+  const float c0 = 2.302208198f, c1 = 0.1029432397f;
+  const float e = __builtin_amdgcn_exp2f(-x * (c0 + c1 * x2));        // exp(-2u); inf for very negative x -> rcp(inf) = 0
+  return __builtin_amdgcn_rcpf(1.f + e);
 }
+__device__ __forceinline__ float gelu_tanh(float x) { return x * sigmoid2u(x, x * x); }
+// d/dx [x s(x)] = s + x s (1 - s) * d(2u)/dx,   d(2u)/dx = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float x2 = x * x;
-  float u = k0 * (x + k1 * x * x2);
-  float t = 1.f - 2.f / (1.f + __expf(2.f * u));
-  float du = k0 * (1.f + 3.f * k1 * x2);
-  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+  const float k0 = 1.5957691216057308f, k1 = 0.134145f;
+  const float x2 = x * x;
+  const float s = sigmoid2u(x, x2);
+  return s + x * s * (1.f - s) * (k0 + k0 * k1 * x2);
 }
 
 // ---- Philox4x32-10 ------------------------------------------------------------------------------

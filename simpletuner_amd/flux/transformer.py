@@ -416,19 +416,30 @@ class FluxTransformer2DModel(nn.Module):
             hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
             h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
                                          dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
-            x2_img, x2_txt = ops.gemm_grouped([
-                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
-                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+            if blk is self.double[-1]:
+                # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
+                # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
+                x = torch.empty(B * S, D, dtype=BF16, device=dev)
+                probs = []
+                for b in range(B):
+                    probs.append(dict(a=h_i[b * Si:(b + 1) * Si], w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img[b * Si:(b + 1) * Si],
+                                      gate=mi[b:b + 1, 5 * D:6 * D], rows_per_batch=Si, out=x[b * S + St:(b + 1) * S]))
+                    probs.append(dict(a=h_t[b * St:(b + 1) * St], w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt[b * St:(b + 1) * St],
+                                      gate=mt[b:b + 1, 5 * D:6 * D], rows_per_batch=St, out=x[b * S:b * S + St]))
+                ops.gemm_grouped(probs)
+                x2_img = x2_txt = None
+            else:
+                x2_img, x2_txt = ops.gemm_grouped([
+                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
+                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
             del n2_i, n2_t, h_i, h_t
             if save:
                 ctx.dbl.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
                                                Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
                                                hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
             img, txt = x2_img, x2_txt
-        # ---- joint sequence [txt || img] (flux/transformer.py:1332) ----
-        if B == 1:
-            x = torch.cat([txt, img], dim=0)
-        else:
+        # ---- joint sequence [txt || img] (flux/transformer.py:1332): written in place by the last double block ----
+        if not self.double:
             x = torch.cat([txt.view(B, St, D), img.view(B, Si, D)], dim=1).reshape(B * S, D)
         del img, txt
         # ---- single blocks (flux/transformer.py:473-510) ----
@@ -451,15 +462,13 @@ class FluxTransformer2DModel(nn.Module):
                 ctx.sgl.append(SimpleNamespace(x=x, n=n, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T))
             x = x_out
         # ---- output head (flux/transformer.py:1501-1506): AdaLayerNormContinuous chunk order is (scale, shift) ----
-        if B == 1:
-            x_img = x[St:]
-        else:
-            x_img = x.view(B, S, D)[:, St:].reshape(B * Si, D)
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
-        n_out = ops.ln_modulate_fwd(x_img, mo[:, :D], mo[:, D:2 * D], Si)
+        n_out = torch.empty(B * Si, D, dtype=BF16, device=dev)
+        for b in range(B):          # the image rows of sample b are a strided view of the joint buffer: no gather pass
+            ops.ln_modulate_fwd(x[b * S + St:(b + 1) * S], mo[b:b + 1, :D], mo[b:b + 1, D:2 * D], Si, out=n_out[b * Si:(b + 1) * Si])
         out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
         if save:
-            ctx.x_img_final = x_img
+            ctx.x_final = x
         return out.view(B, Si, -1), ctx
 
     def _engine_backward(self, ctx, dout):
@@ -473,13 +482,11 @@ class FluxTransformer2DModel(nn.Module):
         dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         dn = ops.gemm(dout, self.l_out.wT)
-        dx_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
         dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
-        if B == 1:
-            dx[St:] = dx_img
-        else:
-            dx.view(B, S, D)[:, St:] = dx_img.view(B, Si, D)
-        del dn, dx_img
+        for b in range(B):          # written straight into the image rows of the joint gradient
+            ops.ln_modulate_bwd(dn[b * Si:(b + 1) * Si], ctx.x_final[b * S + St:(b + 1) * S], mo[b:b + 1, :D], Si, out=dx[b * S + St:(b + 1) * S])
+        del dn
+        ctx.x_final = None
 
         def attn_backward(sv, dO, dqkv):
             dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
@@ -505,13 +512,19 @@ class FluxTransformer2DModel(nn.Module):
             if li > 0:
                 gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D]
                 dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx, gate=gprev, want_gated=True)
+            elif self.double:
+                # first single block: its input gradient IS the joint gradient of the double stack — written per (stream, sample) straight into
+                # the two stream-major buffers the double blocks work on (no split / gather pass)
+                d_txt = torch.empty(B * St, D, dtype=BF16, device=dev); d_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
+                for b in range(B):
+                    for (r0, r1, dst) in ((b * S, b * S + St, d_txt[b * St:(b + 1) * St]), (b * S + St, (b + 1) * S, d_img[b * Si:(b + 1) * Si])):
+                        ops.ln_modulate_bwd(dn[r0:r1], sv.x[r0:r1], ms[b:b + 1, D:2 * D], r1 - r0, dres=dx[r0:r1], out=dst)
+                dxg = None
             else:
                 dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
             del dn, dn_mlp, dqkv, sv
-        # ---- split the joint gradient ----
-        if B == 1:
-            d_txt, d_img = dx[:St], dx[St:]
-        else:
+        # ---- split the joint gradient (only when there was no single block to do it) ----
+        if not self.single:
             d_txt = dx.view(B, S, D)[:, :St].reshape(B * St, D); d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
         # ---- double blocks, reversed (img / txt pairs as grouped launches) ----
         for li in range(len(self.double) - 1, -1, -1):

@@ -447,12 +447,16 @@ def ln_modulate_fwd(x, scale, shift, rows_per_batch: int, eps: float = 1e-6, out
     return out
 
 
-def ln_modulate_bwd(dy, x, scale, rows_per_batch: int, dres=None, gate=None, eps: float = 1e-6, want_gated: bool = False):
-    """dx = dres + LNbwd(dy*(1+scale));  dxg = gate[b]*dx (if want_gated).  Returns (dx, dxg)."""
+def ln_modulate_bwd(dy, x, scale, rows_per_batch: int, dres=None, gate=None, eps: float = 1e-6, want_gated: bool = False, out=None):
+    """dx = dres + LNbwd(dy*(1+scale));  dxg = gate[b]*dx (if want_gated).  Returns (dx, dxg).  out: optional destination view for dx (row stride free)."""
     L = _l.load()
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(scale, BF16, "scale")
     rows, D = x.shape
-    dx = torch.empty(rows, D, dtype=BF16, device=x.device)
+    dx = torch.empty(rows, D, dtype=BF16, device=x.device) if out is None else out
+    if out is not None:
+        _chk(out, BF16, "out")
+        if tuple(out.shape) != (rows, D):
+            raise _l.St355Error("ln_modulate_bwd: out shape mismatch")
     dxg = torch.empty(rows, D, dtype=BF16, device=x.device) if want_gated else None
     if dres is not None:
         _chk(dres, BF16, "dres")
@@ -461,7 +465,7 @@ def ln_modulate_bwd(dy, x, scale, rows_per_batch: int, dres=None, gate=None, eps
     _l.check(L.st355_ln_modulate_bwd(_stream(), _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(scale), _rows(scale, "scale"),
                                      rows_per_batch, _ptr(dres), _rows(dres, "dres") if dres is not None else 0,
                                      _ptr(gate) if want_gated else None, _rows(gate, "gate") if want_gated else 0,
-                                     _ptr(dx), D, _ptr(dxg), D, rows, D, eps), "ln_modulate_bwd")
+                                     _ptr(dx), _rows(dx, "dx"), _ptr(dxg), D, rows, D, eps), "ln_modulate_bwd")
     return dx, dxg
 
 

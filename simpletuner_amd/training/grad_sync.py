@@ -46,6 +46,7 @@ class GradSync:
         self.launched_ops: List = []     # ("all_reduce" | "reduce_scatter" | "all_gather", lo, hi) in issue order
         # explicit comm stream (device arenas only): collectives are enqueued behind an event of the compute stream, never on it
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        self._comm_used = False
         self._serial_backend = None      # resolved lazily: gloo runs async works concurrently -> dependent collectives must be waited for
 
     @property
@@ -57,7 +58,7 @@ class GradSync:
         return dist.get_rank(self.pg) if dist.is_available() and dist.is_initialized() else 0
 
     def begin(self):
-        self._works, self._lo, self._hi, self.launched_slices, self.launched_ops = [], None, None, [], []
+        self._works, self._lo, self._hi, self.launched_slices, self.launched_ops, self._comm_used = [], None, None, [], [], False
 
     def _stream_ordered(self) -> bool:
         """True when the backend executes this group's collectives in issue order on one device stream (nccl == RCCL)"""
@@ -71,6 +72,7 @@ class GradSync:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.flat.device))       # the gradient bytes of this slice are final at this point of the backward
         self.comm_stream.wait_event(ev)
+        self._comm_used = True
         return torch.cuda.stream(self.comm_stream)
 
     def _fire(self, lo: int, hi: int):
@@ -82,7 +84,17 @@ class GradSync:
             return
         with self._comm_ctx():
             m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
-            if m > 0:
+            if m > 0 and self.flat.is_cuda and not self._stream_ordered():
+                # gloo with a device arena (the shared-GPU plumbing tests; gloo moves device tensors through the host anyway and has no device
+                # reduce-scatter): the same two collectives on a host copy of the slice, blocking
+                host = self.flat[lo:lo + m].cpu()
+                shard = host[self.rank * (m // W):(self.rank + 1) * (m // W)]
+                dist.reduce_scatter_tensor(shard, host, op=dist.ReduceOp.SUM, group=self.pg)
+                self.launched_ops.append(("reduce_scatter", lo, lo + m))
+                dist.all_gather_into_tensor(host, shard.clone(), group=self.pg)
+                self.launched_ops.append(("all_gather", lo, lo + m))
+                self.flat[lo:lo + m].copy_(host)
+            elif m > 0:
                 seg = self.flat[lo:lo + m]
                 shard = seg[self.rank * (m // W):(self.rank + 1) * (m // W)]
                 w = dist.reduce_scatter_tensor(shard, seg, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -118,18 +130,17 @@ class GradSync:
         if self._lo is not None:
             self._fire(self._lo, self._hi)
             self._lo = self._hi = None
-        if self._works:
-            if self.comm_stream is not None:
-                with torch.cuda.stream(self.comm_stream):
-                    for w in self._works:
-                        w.wait()
-                done = torch.cuda.Event()
-                done.record(self.comm_stream)
-                torch.cuda.current_stream(self.flat.device).wait_event(done)
-            else:
+        if self.comm_stream is not None and self._comm_used:
+            with torch.cuda.stream(self.comm_stream):
                 for w in self._works:
                     w.wait()
-        self._works = []
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+            torch.cuda.current_stream(self.flat.device).wait_event(done)       # the optimizer (compute stream) starts after the last collective
+        else:
+            for w in self._works:
+                w.wait()
+        self._works, self._comm_used = [], False
         return 1.0 / self.world_size if self.enabled else 1.0
 
     @contextlib.contextmanager

@@ -13,11 +13,12 @@ def small_flux_cfg(layers=1, single=1, heads=2, head_dim=128, joint_dim=128, poo
                 joint_attention_dim=joint_dim, pooled_projection_dim=pooled, guidance_embeds=guidance, in_channels=64)
 
 
-def oracle_state(model, dtype=torch.float32):
-    """device model -> ({name: cpu tensor}, {target: (A, B)}, lora_scale)"""
+def oracle_state(model, dtype=torch.float32, device="cpu"):
+    """device model -> ({name: tensor on `device`}, {target: (A, B)}, lora_scale).  device="cuda:0" runs the plain-torch fp32 oracle on the GPU's
+    ATen kernels (full-width shapes, where the host cores would need minutes): still the restatement, not the product path"""
     P, A, B = {}, {}, {}
     for k, v in model.named_parameters():
-        t = v.detach().to("cpu", dtype)
+        t = v.detach().to(device, dtype)
         if ".lora_A." in k:
             A[k.split(".lora_A.")[0]] = t
         elif ".lora_B." in k:
@@ -47,10 +48,10 @@ def cos_sim(a, ref):
     return (torch.dot(a, ref) / (a.norm() * ref.norm() + 1e-30)).item()
 
 
-def make_inputs(B, lat_h, lat_w, S_txt, joint_dim, pooled, device, seed=0):
+def make_inputs(B, lat_h, lat_w, S_txt, joint_dim, pooled, device, seed=0, channels=16):
     g = torch.Generator().manual_seed(seed)
-    latents = torch.randn(B, 16, lat_h, lat_w, generator=g)
-    noise = torch.randn(B, 16, lat_h, lat_w, generator=g)
+    latents = torch.randn(B, channels, lat_h, lat_w, generator=g)
+    noise = torch.randn(B, channels, lat_h, lat_w, generator=g)
     prompt = torch.randn(B, S_txt, joint_dim, generator=g)
     pooled_t = torch.randn(B, pooled, generator=g)
     sigmas = torch.rand(B, generator=g) * 0.8 + 0.1
@@ -61,7 +62,9 @@ def make_inputs(B, lat_h, lat_w, S_txt, joint_dim, pooled, device, seed=0):
 
 
 def oracle_step(P, ocfg, lora, lora_scale, cpu, guidance_value=1.0, dtype=torch.float32):
-    """reference step on the CPU: noising -> model_predict -> MSE -> autograd.  Returns loss, prediction, {name: (dA, dB)}."""
+    """reference step (on the device the weights P live on): noising -> model_predict -> MSE -> autograd.  Returns loss, prediction, {name: (dA, dB)}."""
+    odev = next(iter(P.values())).device
+    cpu = {k: v.to(odev) for k, v in cpu.items()}
     s = cpu["sigmas"].view(-1, 1, 1, 1).to(dtype)
     x, n = cpu["latents"].to(dtype), cpu["noise"].to(dtype)
     noisy = ((1 - s) * x + s * n).to(torch.bfloat16).to(dtype)       # the trainer feeds bf16 noisy latents (common.py:4990)
