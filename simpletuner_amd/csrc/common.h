@@ -45,6 +45,22 @@ __device__ __forceinline__ float sigmoid2u(float x, float x2) {
   const float e = __builtin_amdgcn_exp2f(-x * (c0 + c1 * x2));        // exp(-2u); inf for very negative x -> rcp(inf) = 0
   return __builtin_amdgcn_rcpf(1.f + e);
 }
+#ifdef ST355_GELU_TEXTBOOK      // lab / A-B builds only: the IEEE-division form this replaced
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));
+  return 0.5f * x * (1.f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));
+  float du = k0 * (1.f + 3.f * k1 * x2);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+#else
 __device__ __forceinline__ float gelu_tanh(float x) { return x * sigmoid2u(x, x * x); }
 // d/dx [x s(x)] = s + x s (1 - s) * d(2u)/dx,   d(2u)/dx = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
@@ -53,6 +69,7 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   const float s = sigmoid2u(x, x2);
   return s + x * s * (1.f - s) * (k0 + k0 * k1 * x2);
 }
+#endif
 
 // ---- Philox4x32-10 ------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {

@@ -603,6 +603,10 @@ class FluxTransformer2DModel(nn.Module):
         if timestep.ndim != 1:
             raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
         need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
+        if need_grad and not self._prepared:
+            # the K-major dgrad operands follow the weights: load_flat_state / init_synthetic / the replica start-state broadcast
+            # (training.grad_sync.sync_module_states) mark them stale, the next training forward rebuilds them
+            self.prepare_for_training()
         if need_grad:
             out = _FluxFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids,
                                 *self._lora_params)

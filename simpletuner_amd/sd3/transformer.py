@@ -711,6 +711,8 @@ class SD3Transformer2DModel(nn.Module):
         if timestep.ndim != 1:
             raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
         need_grad = torch.is_grad_enabled() and (len(self._lora_params) > 0 or getattr(self, "full", False))
+        if need_grad and not self._prepared and not getattr(self, "full", False):
+            self.prepare_for_training()      # K-major dgrad operands went stale (new weights / replica start-state broadcast): rebuild lazily
         if need_grad and getattr(self, "full", False):
             out = _SD3FullFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, *self._full_params)
         elif need_grad:
