@@ -1,0 +1,87 @@
+"""Binding the MI355X hot path INTO an installed SimpleTuner.
+
+Where `simpletuner` imports (Python >= 3.12 + diffusers + peft, none of which exist in the build container — SURVEY.md F3), one call
+wires this package behind the reference's own plugin surface:
+
+    import simpletuner_amd.integration as st355
+    st355.register()          # before `Trainer(...)` / `train.py` builds the model
+
+  * every st355 family plugin is re-created as a class that ALSO derives from the reference's `ModelFoundation`
+    (simpletuner/helpers/models/common.py:451) — so `isinstance` checks in the trainer hold — with the st355 class first in the MRO, and
+    is registered with `ModelRegistry.register(family, cls)` (simpletuner/helpers/models/registry.py:74-75), overriding the lazy
+    metadata entry of the same family (`model_families()` lets explicit registrations win, registry.py:95-104);
+  * `optimizer_choices` (simpletuner/helpers/training/optimizer_param.py:76) gains `st355-adamw` and has its `adamw_bf16` entry's class
+    replaced by the fused one-pass implementation (same entry shape: precision / default_settings / class);
+  * `EMAModel` is exported for `trainer.py:4360-4369`'s construction site (same constructor signature, ema.py:29-60).
+
+`tests/test_integration_contract_cpu.py` holds this module to the reference: it AST-scans /root/reference's trainer.py for every
+`self.model.<member>` and optimizer / EMA member the Trainer uses and fails on any name the plugin objects lack, and exercises
+`register()` against stand-in `simpletuner` modules with the reference's own registry source.
+"""
+from __future__ import annotations
+
+import importlib
+from typing import Dict, Optional
+
+FAMILIES = {
+    "flux": ("simpletuner_amd.flux.model", "Flux"),
+    "sd3": ("simpletuner_amd.sd3.model", "SD3"),
+    "sdxl": ("simpletuner_amd.sdxl.model", "SDXL"),
+    "sd1x": ("simpletuner_amd.sd1x.model", "StableDiffusion1"),
+    "pixart_sigma": ("simpletuner_amd.pixart.model", "PixartSigma"),
+}
+
+
+class IntegrationUnavailable(ImportError):
+    pass
+
+
+def _ref(module: str):
+    try:
+        return importlib.import_module(module)
+    except Exception as e:          # ImportError, or a syntax / dependency failure deep inside the reference
+        raise IntegrationUnavailable(f"cannot import {module}: {e}.  simpletuner_amd.integration.register() needs an importable SimpleTuner "
+                                     f"(python >= 3.12 with diffusers / peft); the st355 host harness (simpletuner_amd.training.trainer) "
+                                     f"replays the same step order where it is not installed") from e
+
+
+def plugin_class(family: str, ref_foundation: Optional[type] = None) -> type:
+    """the st355 plugin of `family`; with `ref_foundation` a subclass that also derives from the reference's ModelFoundation"""
+    mod, name = FAMILIES[family]
+    cls = getattr(importlib.import_module(mod), name)
+    if ref_foundation is None or issubclass(cls, ref_foundation):
+        return cls
+    # st355 first in the MRO: every step-path method resolves to the MI355X implementation, the reference base only contributes identity
+    # (isinstance) and whatever out-of-path helper the st355 class does not define
+    return type(f"St355{name}", (cls, ref_foundation), {"__module__": __name__, "__doc__": cls.__doc__, "ST355_NATIVE": True})
+
+
+def register(families=None, overwrite_optimizers: bool = True) -> Dict[str, type]:
+    """register the st355 plugins / optimizers into the installed SimpleTuner; returns {family: registered class}"""
+    reg = _ref("simpletuner.helpers.models.registry").ModelRegistry
+    ref_foundation = getattr(_ref("simpletuner.helpers.models.common"), "ModelFoundation")
+    out = {}
+    for fam in (families or FAMILIES):
+        cls = plugin_class(fam, ref_foundation)
+        reg.register(fam, cls)
+        out[fam] = cls
+    register_optimizers(overwrite=overwrite_optimizers)
+    return out
+
+
+def register_optimizers(overwrite: bool = True) -> Dict[str, dict]:
+    """add / replace the entries of the reference's `optimizer_choices` (same dict shape as optimizer_param.py:76-96)"""
+    from .training.optimizer import OPTIMIZER_CHOICE
+    choices = _ref("simpletuner.helpers.training.optimizer_param").optimizer_choices
+    for name, entry in OPTIMIZER_CHOICE.items():
+        if name in choices and not overwrite:
+            continue
+        merged = dict(choices.get(name, {}))
+        merged.update({"precision": entry["precision"], "default_settings": dict(entry["default_settings"]), "class": entry["class"]})
+        choices[name] = merged
+    return choices
+
+
+def ema_class():
+    from .training.ema import EMAModel
+    return EMAModel

@@ -149,6 +149,15 @@ class EMAModel:
     def to(self, device=None, dtype=None, non_blocking=False):
         return self   # shadows live next to the parameters in HBM (288 GB: no CPU shuttle, ema.py:357-359/432-433 not needed)
 
+    def pin_memory(self) -> None:
+        """ema.py:474-492 pins the shadow for host offload; the shadow lives in HBM on this path: nothing to pin"""
+        return None
+
+    def save_pretrained(self, path, max_shard_size: str = "10GB"):
+        """ema.py:298-320 writes a diffusers model folder from `model_cls` / `model_config`; this path saves the shadow in the reference's
+        `ema_model.pt` dict layout next to the weights (Trainer.save_state) — the folder form needs the diffusers class and is refused loudly"""
+        raise NotImplementedError("EMAModel.save_pretrained: use save_state_dict(<dir>/ema_model.pt) (ema.py:236-296 layout)")
+
     def parameter_count(self) -> int:
         return sum(p.numel() for p in self.shadow_params)
 

@@ -1,0 +1,152 @@
+"""The drop-in boundary as a CONTRACT: every member the reference `Trainer` touches on the model plugin, the
+optimizer, the EMA object and the lr scheduler must exist on the st355 objects — names are taken from the reference source itself by AST scan, so
+a reference call site the mirror forgot fails here, on the CPU, instead of as an AttributeError deep inside a training run on the GPU box.
+`simpletuner_amd.integration.register()` is exercised against stand-in `simpletuner.*` modules that carry the reference's OWN registry source
+(executed from where it lies; SimpleTuner itself cannot be imported here: python 3.10, no diffusers / peft — SURVEY.md F3)."""
+import ast
+import importlib
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+REF = Path("/root/reference/simpletuner/helpers")
+pytestmark = pytest.mark.skipif(not REF.exists(), reason="the reference tree is only present in the build container")
+
+
+def _attr_uses(path: Path, owner: str):
+    """{name: [lines]} of every `self.<owner>.<name>` in the file"""
+    names = {}
+    for node in ast.walk(ast.parse(path.read_text())):
+        if (isinstance(node, ast.Attribute) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name)
+                and node.value.value.id == "self" and node.value.attr == owner):
+            names.setdefault(node.attr, []).append(node.lineno)
+    return names
+
+
+def _plugins():
+    from simpletuner_amd.training.trainer import default_config
+    from simpletuner_amd import integration
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    out = {}
+    for fam in integration.FAMILIES:
+        cls = integration.plugin_class(fam)
+        out[fam] = cls(default_config(model_family=fam), acc)
+    return out
+
+
+def test_every_model_member_the_reference_trainer_uses_exists_on_the_plugins():
+    uses = _attr_uses(REF / "training" / "trainer.py", "model")
+    assert len(uses) >= 50 and "prepare_batch" in uses and "check_user_config" in uses          # the scan sees the file it is meant to see
+    for fam, plug in _plugins().items():
+        missing = {n: l[:3] for n, l in uses.items() if not hasattr(plug, n)}
+        assert not missing, f"{fam}: reference trainer.py uses self.model.<name> the st355 plugin lacks: {missing}"
+
+
+def test_lifecycle_hooks_behave_like_the_reference_defaults():
+    plug = _plugins()["flux"]
+    # trainer.py:329-330 / 2618-2621 / 2944 / 4318 / 4376 / 4450 / 4651 / 6042 in call order: none may raise on a default config
+    plug.check_user_config(); plug.validate_mixflow_config(); plug.load_text_encoder(move_to_device=False); plug.freeze_components()
+    plug.pre_ema_creation(); plug.post_ema_creation(); plug.post_quantization_setup(); plug.before_accelerator_prepare()
+    plug.refresh_representation_alignment_projectors(); plug.unload_text_encoder(); plug.unload_vae(); plug.apply_diffusion_blocks_trainable_filter()
+    plug.diffusion_blocks_init()
+    assert plug.get_text_encoder(0) is None and plug.get_text_encoder(1) is None            # trainer.py:7631-7642: no text-encoder adapters to save
+    assert plug.supports_grounding() is False and plug.text_encoders == [] and plug.tokenizers == [] and plug.vae is None
+    assert plug._ramtorch_base_deferred_until_after_quantization() is False
+    plug.config.mixflow_enabled, plug.config.flux_fast_schedule = True, True                # common.py:4923-4950
+    with pytest.raises(ValueError, match="mixflow_enabled cannot be combined with flux_fast_schedule"):
+        plug.validate_mixflow_config()
+    for refused in (plug.tread_init, plug.get_pipeline, plug.configure_group_offload):       # out-of-path features fail loudly, never silently
+        with pytest.raises(NotImplementedError):
+            refused()
+    plug.unload()
+    assert plug.model is None and plug.pipelines == {}
+
+
+def test_optimizer_ema_and_scheduler_members_the_reference_trainer_uses_exist():
+    from simpletuner_amd.training.ema import EMAModel
+    from simpletuner_amd.training.optimizer import St355AdamW, St355AdamWBF16
+    tr = REF / "training" / "trainer.py"
+    opt_uses = set(_attr_uses(tr, "optimizer")) - {"optimizer", "optimizer_accumulation", "train", "eval"}    # accelerate-wrapper / schedule-free members (guarded by hasattr / is_schedulefree)
+    assert {"step", "zero_grad", "param_groups"} <= opt_uses
+    p = torch.nn.Parameter(torch.zeros(8))
+    for cls in (St355AdamW, St355AdamWBF16):
+        o = cls([p], lr=1e-3)
+        assert not [n for n in opt_uses | {"state_dict", "load_state_dict"} if not hasattr(o, n)], cls
+    ema_uses = set(_attr_uses(tr, "ema_model"))
+    assert {"step", "copy_to", "to"} <= ema_uses
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    ema = EMAModel(SimpleNamespace(ema_device="accelerator", ema_cpu_only=False, ema_update_interval=None), acc, [p], decay=0.99)
+    assert not [n for n in ema_uses | {"store", "restore", "state_dict", "save_pretrained"} if not hasattr(ema, n)]
+    sched_uses = set(_attr_uses(tr, "lr_scheduler")) - {"num_update_steps_per_epoch"}       # guarded by hasattr (trainer.py:3895)
+    from simpletuner_amd.training.lr_schedule import get_lr_scheduler
+    cfg = SimpleNamespace(lr_scheduler="cosine", learning_rate=1e-3, lr_end=1e-5, lr_warmup_steps=2, max_train_steps=10, lr_num_cycles=1, lr_power=1.0,
+                          num_update_steps_per_epoch=5, gradient_accumulation_steps=1, is_schedulefree=False, use_deepspeed_scheduler=False)
+    sch = get_lr_scheduler(cfg, St355AdamW([p], lr=1e-3), acc, None, 0)
+    assert not [n for n in sched_uses if not hasattr(sch, n)]
+
+
+def _stand_in_simpletuner(monkeypatch):
+    """`simpletuner.helpers.models.registry` = the reference's own registry.py executed in place; `common.ModelFoundation` and
+    `optimizer_param.optimizer_choices` as minimal stand-ins with the reference's shapes (their real modules import diffusers)"""
+    mods = {}
+    for name in ("simpletuner", "simpletuner.helpers", "simpletuner.helpers.models", "simpletuner.helpers.training"):
+        mods[name] = types.ModuleType(name)
+        mods[name].__path__ = []
+    reg = types.ModuleType("simpletuner.helpers.models.registry")
+    reg.__file__ = str(REF / "models" / "registry.py")
+    exec(compile((REF / "models" / "registry.py").read_text(), reg.__file__, "exec"), reg.__dict__)
+    common = types.ModuleType("simpletuner.helpers.models.common")
+
+    class ModelFoundation:                       # the reference base: identity for isinstance checks (common.py:451)
+        REFERENCE_BASE = True
+
+        def reference_only_helper(self):
+            return "from the reference base"
+    common.ModelFoundation = ModelFoundation
+    optp = types.ModuleType("simpletuner.helpers.training.optimizer_param")
+    optp.optimizer_choices = {"torch-adamw": {"precision": "any", "default_settings": {"betas": (0.9, 0.999), "weight_decay": 1e-2, "eps": 1e-8},
+                                              "class": torch.optim.AdamW},
+                              "adamw_bf16": {"precision": "bf16", "default_settings": {"betas": (0.9, 0.999), "weight_decay": 1e-2, "eps": 1e-6},
+                                             "class": object, "gradient_precision": "fp32"}}
+    mods.update({reg.__name__: reg, common.__name__: common, optp.__name__: optp})
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    return reg, common, optp
+
+
+def test_register_into_the_reference_registry_and_optimizer_choices(monkeypatch):
+    from simpletuner_amd import integration
+    from simpletuner_amd.training.optimizer import St355AdamW, St355AdamWBF16
+    reg, common, optp = _stand_in_simpletuner(monkeypatch)
+    out = integration.register()
+    fams = reg.ModelRegistry.model_families()                      # the reference's own lookup: explicit registrations override lazy metadata entries
+    for fam in integration.FAMILIES:
+        cls = fams[fam]
+        assert cls is out[fam] and issubclass(cls, common.ModelFoundation) and getattr(cls, "ST355_NATIVE", False)
+        assert cls.__mro__[1].__module__.startswith("simpletuner_amd.")            # st355 implementation first, reference base behind it
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    from simpletuner_amd.training.trainer import default_config
+    plug = fams["flux"](default_config(model_family="flux"), acc)                  # trainer.py:329: ModelRegistry.model_families()[family](config, accelerator)
+    assert isinstance(plug, common.ModelFoundation) and plug.reference_only_helper() == "from the reference base"
+    assert type(plug).prepare_batch.__module__ == "simpletuner_amd.foundation"      # the step path is the MI355X one
+    ch = optp.optimizer_choices
+    assert ch["st355-adamw"]["class"] is St355AdamW and ch["adamw_bf16"]["class"] is St355AdamWBF16
+    assert ch["adamw_bf16"]["gradient_precision"] == "fp32" and ch["adamw_bf16"]["precision"] == "bf16"      # untouched keys of the entry survive
+    assert ch["torch-adamw"]["class"] is torch.optim.AdamW
+    for e in (ch["st355-adamw"], ch["adamw_bf16"]):
+        assert {"precision", "default_settings", "class"} <= set(e)
+    assert integration.ema_class().__name__ == "EMAModel"
+
+
+def test_register_without_simpletuner_fails_loudly(monkeypatch):
+    from simpletuner_amd import integration
+    for k in [k for k in sys.modules if k == "simpletuner" or k.startswith("simpletuner.")]:
+        monkeypatch.delitem(sys.modules, k)
+    monkeypatch.setattr(importlib, "import_module", lambda name, *a, **k: (_ for _ in ()).throw(ImportError(f"No module named {name!r}"))
+                        if name.startswith("simpletuner.") else importlib.__import__(name))
+    with pytest.raises(integration.IntegrationUnavailable, match="needs an importable SimpleTuner"):
+        integration.register()
