@@ -131,8 +131,13 @@ class Flux(ModelFoundation):
         img_ids, text_ids = self._ids_cache[key]
         # "divide it by 1000 for now because we scale it by 1000 in the transformer model" (flux/model.py:739-745, 790)
         prepared_batch["timesteps"] = prepared_batch["timesteps"].to(device=dev, dtype=torch.float32) / 1000.0
-        if getattr(self.config, "flux_attention_masked_training", False):
-            raise NotImplementedError("flux_attention_masked_training is not implemented on the st355 path")
+        attention_mask = None
+        if getattr(self.config, "flux_attention_masked_training", False):          # flux/model.py:813-823
+            attention_mask = prepared_batch.get("encoder_attention_mask")
+            if attention_mask is None:
+                raise ValueError("No attention mask was discovered when attempting validation - this means you need to recreate your text embed cache.")
+            if attention_mask.dim() == 3 and attention_mask.size(1) == 1:
+                attention_mask = attention_mask.squeeze(1)          # [B, 1, S] -> [B, S]
         model_pred = self.model(
             hidden_states=packed,
             timestep=prepared_batch["timesteps"],
@@ -143,6 +148,7 @@ class Flux(ModelFoundation):
             img_ids=img_ids,
             joint_attention_kwargs=None,
             return_dict=False,
+            attention_mask=attention_mask,
         )[0]
         return {
             "model_prediction": _UnpackFn.apply(model_pred, Hh * 8, Ww * 8),

@@ -190,6 +190,9 @@ class FluxTransformer2DModel(nn.Module):
         self._prepared = False
         self.accumulate_lora_grads = False
         self.gradient_checkpointing = False
+        self.gradient_checkpointing_interval = None          # flux/transformer.py:816-818
+        self.gradient_checkpointing_segment_stride = None
+        self.gradient_checkpointing_backend = "torch"
         self.grad_sync = None            # training.grad_sync.GradSync over lora_grad_flat (data-parallel replicas)
         self._last_grad_flat = None
 
@@ -336,7 +339,151 @@ class FluxTransformer2DModel(nn.Module):
             lin.lora.grads(x, T, dy, U, self.accumulate_lora_grads, self.grad_sync)
         return dx
 
-    def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool):
+    # ------------------------------------------------------------------------------------------------
+    # activation checkpointing (SURVEY.md §8(f)3; flux/transformer.py:816-835, 1142-1209, gradient_checkpointing_interval.py:51-120)
+    # ------------------------------------------------------------------------------------------------
+    def set_gradient_checkpointing_interval(self, value):
+        self.gradient_checkpointing_interval = None if value is None else int(value)
+
+    def set_gradient_checkpointing_segment_stride(self, segment_stride):
+        self.gradient_checkpointing_segment_stride = None if segment_stride is None else int(segment_stride)
+
+    def set_gradient_checkpointing_backend(self, backend: str):
+        if backend != "torch":      # "unsloth" = CPU-offloaded checkpoints (pointless with 288 GB), "*-ffn" = FFN-only scope: not built, never silently ignored
+            raise NotImplementedError(f"gradient_checkpointing_backend={backend!r} is not implemented on the st355 path (built: 'torch' = recompute)")
+        self.gradient_checkpointing_backend = backend
+
+    def enable_gradient_checkpointing(self, *a, **k):
+        self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    def _checkpoint_segments(self, n_blocks: int):
+        """[(first block, block count, recompute?)] over one block stack, the reference's three modes:
+             gradient_checkpointing off                  -> every block keeps its activations;
+             on, interval None / <= 1  ("layer")         -> every block is its own checkpoint (only its input is kept, the block is re-run in backward);
+             on, interval k > 1 [, segment_stride s >= k] -> the first k blocks of every s-block window form ONE checkpoint (only the segment input is
+                                                            kept), the s - k blocks of the gap keep their activations  (`checkpoint_sequential_state`)."""
+        if not self.gradient_checkpointing:
+            return [(i, 1, False) for i in range(n_blocks)]
+        k = self.gradient_checkpointing_interval
+        if k is None or k <= 1:
+            return [(i, 1, True) for i in range(n_blocks)]
+        stride = self.gradient_checkpointing_segment_stride or k
+        if stride < k:
+            raise ValueError("segment_stride must be at least segment_size")
+        segs = []
+        for s0 in range(0, n_blocks, stride):
+            n = min(k, n_blocks - s0)
+            segs.append((s0, n, True))
+            segs += [(j, 1, False) for j in range(s0 + n, min(s0 + stride, n_blocks))]
+        return segs
+
+    # ------------------------------------------------------------------------------------------------
+    # forward / backward engines
+    # ------------------------------------------------------------------------------------------------
+    def _alloc_heads(self, env):
+        B, H, hd, S, Sp, dev = env.B, self.H, self.hd, env.S, env.Sp, self.device_
+        Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+        mk = torch.zeros if Sp > S else torch.empty
+        Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        return Q, K, Qt, Kt, Vt
+
+    def _double_fwd(self, bi: int, img, txt, env, save: bool):
+        """one FluxTransformerBlock (flux/transformer.py:607-687).  The img (4096-row) and txt (512-row) streams use different weights but the same
+        epilogues: every pair of projections goes out as ONE grouped launch, so the txt tiles fill the tail wave of the img GEMM.
+        Returns (img', txt', x, saved): the LAST double block writes the joint [txt || img] sequence x of the single blocks in place instead."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, Sp, mod, cos, sin = env.B, env.Si, env.St, env.S, env.Sp, env.mod, env.cos, env.sin
+        blk = self.double[bi]
+        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+        n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
+        qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
+        T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
+        probs = []
+        for b in range(B):
+            kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
+            kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+            probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i))
+            probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t))
+        ops.gemm_grouped(probs)
+        Q, K, Qt, Kt, Vt = self._alloc_heads(env)
+        ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
+        ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
+        O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+        ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+        del Vt
+        x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
+        T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
+        T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
+        probs = []
+        for b in range(B):
+            O_t, O_i = O[b * S:b * S + St], O[b * S + St:(b + 1) * S]
+            kw_i, kw_t = {}, {}
+            if T_o is not None:
+                ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
+                kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
+            if T_ao is not None:
+                ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
+                kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
+            probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
+                              aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
+            probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
+                              aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t))
+        ops.gemm_grouped(probs)
+        # MLPs
+        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+        n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
+        hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
+        h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
+                                     dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
+        x = x2_img = x2_txt = None
+        if bi == len(self.double) - 1:
+            # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
+            # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
+            x = torch.empty(B * S, D, dtype=BF16, device=dev)
+            probs = []
+            for b in range(B):
+                probs.append(dict(a=h_i[b * Si:(b + 1) * Si], w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img[b * Si:(b + 1) * Si],
+                                  gate=mi[b:b + 1, 5 * D:6 * D], rows_per_batch=Si, out=x[b * S + St:(b + 1) * S]))
+                probs.append(dict(a=h_t[b * St:(b + 1) * St], w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt[b * St:(b + 1) * St],
+                                  gate=mt[b:b + 1, 5 * D:6 * D], rows_per_batch=St, out=x[b * S:b * S + St]))
+            ops.gemm_grouped(probs)
+        else:
+            x2_img, x2_txt = ops.gemm_grouped([
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
+                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+        sv = None
+        if save:
+            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O,
+                                 lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
+        return x2_img, x2_txt, x, sv
+
+    def _single_fwd(self, bi: int, x, env, save: bool):
+        """one FluxSingleTransformerBlock (flux/transformer.py:473-510)"""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, S, Sp, mod, cos, sin = env.B, env.S, env.Sp, env.mod, env.cos, env.sin
+        blk = self.single[bi]
+        ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
+        qkv, T = self._lin_fwd(blk.qkv, n)
+        Q, K, Qt, Kt, Vt = self._alloc_heads(env)
+        ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
+        O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+        ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+        del Vt
+        hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
+        hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
+        # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
+        x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
+                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S)
+        sv = SimpleNamespace(x=x, n=n, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
+        return x_out, sv
+
+    def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool, key_bias=None):
         D, H, hd = self.D, self.H, self.hd
         B, Si, _ = hidden_states.shape
         St = encoder_hidden_states.shape[1]
@@ -360,107 +507,31 @@ class FluxTransformer2DModel(nn.Module):
         pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
         temb = ops.add(temb, pemb)
         mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
-        ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, dbl=[], sgl=[])
-        scale = 1.0 / math.sqrt(hd)
-
-        def alloc_heads():
-            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
-            mk = torch.zeros if Sp > S else torch.empty
-            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
-            return Q, K, Qt, Kt, Vt
-
-        # ---- double blocks (flux/transformer.py:607-687) ----
-        # the img (4096-row) and txt (512-row) streams use different weights but the same epilogues: every pair of
-        # projections goes out as ONE grouped launch, so the txt tiles fill the tail wave of the img GEMM.
-        for blk in self.double:
-            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-            n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
-            n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
-            qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-            T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
-            T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
-            probs = []
-            for b in range(B):
-                kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
-                kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
-                probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i))
-                probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t))
-            ops.gemm_grouped(probs)
-            Q, K, Qt, Kt, Vt = alloc_heads()
-            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
-            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
-            del Vt
-            x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
-            T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
-            T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
-            probs = []
-            for b in range(B):
-                O_t, O_i = O[b * S:b * S + St], O[b * S + St:(b + 1) * S]
-                kw_i, kw_t = {}, {}
-                if T_o is not None:
-                    ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
-                    kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
-                if T_ao is not None:
-                    ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
-                    kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
-                probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
-                                  aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
-                probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
-                                  aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t))
-            ops.gemm_grouped(probs)
-            # MLPs
-            n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
-            n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
-            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
-            h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
-                                         dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
-            if blk is self.double[-1]:
-                # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
-                # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
-                x = torch.empty(B * S, D, dtype=BF16, device=dev)
-                probs = []
-                for b in range(B):
-                    probs.append(dict(a=h_i[b * Si:(b + 1) * Si], w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img[b * Si:(b + 1) * Si],
-                                      gate=mi[b:b + 1, 5 * D:6 * D], rows_per_batch=Si, out=x[b * S + St:(b + 1) * S]))
-                    probs.append(dict(a=h_t[b * St:(b + 1) * St], w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt[b * St:(b + 1) * St],
-                                      gate=mt[b:b + 1, 5 * D:6 * D], rows_per_batch=St, out=x[b * S:b * S + St]))
-                ops.gemm_grouped(probs)
-                x2_img = x2_txt = None
-            else:
-                x2_img, x2_txt = ops.gemm_grouped([
-                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
-                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
-            del n2_i, n2_t, h_i, h_t
-            if save:
-                ctx.dbl.append(SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K,
-                                               Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
-                                               hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao))
-            img, txt = x2_img, x2_txt
+        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias)
+        segs_d = self._checkpoint_segments(len(self.double)) if save else [(i, 1, False) for i in range(len(self.double))]
+        segs_s = self._checkpoint_segments(len(self.single)) if save else [(i, 1, False) for i in range(len(self.single))]
+        ctx = SimpleNamespace(env=env, dbl={}, sgl={}, segs_d=segs_d, segs_s=segs_s, ck_d={}, ck_s={})
+        x = None
+        # ---- double blocks ----
+        for (s0, n, ck) in segs_d:
+            if ck:
+                ctx.ck_d[s0] = (img, txt)                     # a checkpointed segment keeps only its input; its blocks are re-run in backward
+            for bi in range(s0, s0 + n):
+                img, txt, x, sv = self._double_fwd(bi, img, txt, env, save and not ck)
+                if sv is not None:
+                    ctx.dbl[bi] = sv
         # ---- joint sequence [txt || img] (flux/transformer.py:1332): written in place by the last double block ----
         if not self.double:
             x = torch.cat([txt.view(B, St, D), img.view(B, Si, D)], dim=1).reshape(B * S, D)
         del img, txt
-        # ---- single blocks (flux/transformer.py:473-510) ----
-        for blk in self.single:
-            ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
-            n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
-            qkv, T = self._lin_fwd(blk.qkv, n)
-            Q, K, Qt, Kt, Vt = alloc_heads()
-            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
-            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
-            del Vt
-            hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
-            hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
-            # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
-            x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
-                             aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S)
-            del hact
-            if save:
-                ctx.sgl.append(SimpleNamespace(x=x, n=n, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T))
-            x = x_out
+        # ---- single blocks ----
+        for (s0, n, ck) in segs_s:
+            if ck:
+                ctx.ck_s[s0] = x
+            for bi in range(s0, s0 + n):
+                x, sv = self._single_fwd(bi, x, env, save and not ck)
+                if sv is not None:
+                    ctx.sgl[bi] = sv
         # ---- output head (flux/transformer.py:1501-1506): AdaLayerNormContinuous chunk order is (scale, shift) ----
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         n_out = torch.empty(B * Si, D, dtype=BF16, device=dev)
@@ -471,14 +542,114 @@ class FluxTransformer2DModel(nn.Module):
             ctx.x_final = x
         return out.view(B, Si, -1), ctx
 
+    def _attn_backward(self, sv, dO, dqkv, env):
+        B, H, hd, S, Sp, D, dev = env.B, self.H, self.hd, env.S, env.Sp, self.D, self.device_
+        dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
+        ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+        return dQ, dK
+
+    def _single_bwd(self, li: int, sv, dx, dxg, env):
+        """backward of single block li.  Returns (dx, dxg, d_txt, d_img): block 0 of a model with double blocks writes its input gradient — the joint
+        gradient of the double stack — per (stream, sample) straight into the two stream-major buffers (no split / gather pass)."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
+        blk = self.single[li]
+        ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
+        dO = ops.gemm(g, blk.proj_out.wT[:D])
+        dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
+        dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
+        del g, dhpre
+        dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
+        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, S, 0, S)
+        del dQ, dK, dO
+        dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
+        d_txt = d_img = None
+        if li > 0:
+            gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D]
+            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx, gate=gprev, want_gated=True)
+        elif self.double:
+            d_txt = torch.empty(B * St, D, dtype=BF16, device=dev); d_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
+            for b in range(B):
+                for (r0, r1, dst) in ((b * S, b * S + St, d_txt[b * St:(b + 1) * St]), (b * S + St, (b + 1) * S, d_img[b * Si:(b + 1) * Si])):
+                    ops.ln_modulate_bwd(dn[r0:r1], sv.x[r0:r1], ms[b:b + 1, D:2 * D], r1 - r0, dres=dx[r0:r1], out=dst)
+            dx = dxg = None
+        else:
+            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
+        return dx, dxg, d_txt, d_img
+
+    def _double_bwd(self, li: int, sv, d_img, d_txt, env):
+        """backward of double block li (img / txt pairs as grouped launches).  Returns (d_img, d_txt) w.r.t. the block's inputs (None, None for
+        block 0: the embedders are frozen, only its adapter gradients remain to compute)."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
+        blk = self.double[li]
+        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+        dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
+                                       dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
+        dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+        del g_i, g_t, dh_i, dh_t
+        dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+        dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
+        del dn2_i, dn2_t
+        # attention output projections: dO rows of both streams (+ adapter grads)
+        dO = torch.empty(B * S, D, dtype=BF16, device=dev)
+        U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
+        U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if blk.to_add_out.lora is not None else None
+        probs = []
+        for b in range(B):
+            kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
+            kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
+            probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S + St:(b + 1) * S], **kw_i))
+            probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S:b * S + St], **kw_t))
+        ops.gemm_grouped(probs)
+        for (lin, U, T_, dxg, lo, rows) in ((blk.to_out, U_i, sv.T_o, dx1g_i, St, Si), (blk.to_add_out, U_t, sv.T_ao, dx1g_t, 0, St)):
+            if lin.lora is not None:
+                O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
+                lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+        del dx1g_i, dx1g_t, U_i, U_t
+        dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
+        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, 0, S)
+        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
+        del dQ, dK, dO
+        last = li == 0
+        if B == 1:
+            dq_i, dq_t = dqkv[St:], dqkv[:St]
+        else:
+            dq_i = dqkv.view(B, S, 3 * D)[:, St:].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, :St].reshape(B * St, 3 * D)
+        streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
+        if last:
+            streams = [s_ for s_ in streams if s_[1].lora is not None]   # frozen embedders: only adapter grads remain to compute
+        probs, Us = [], {}
+        for (name, lin, dq, n_in, T_) in streams:
+            kw = {}
+            if lin.lora is not None:
+                Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
+                kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
+            if not last:
+                probs.append(dict(a=dq, w=lin.wT, **kw))
+        dns = ops.gemm_grouped(probs) if probs else []
+        for (name, lin, dq, n_in, T_) in streams:
+            if lin.lora is not None:
+                lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
+        if last:
+            return None, None
+        d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+        d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
+        return d_img, d_txt
+
     def _engine_backward(self, ctx, dout):
-        """hand-written backward for frozen-base (LoRA) training: dX chain + rank-space adapter gradients."""
+        """hand-written backward for frozen-base (LoRA) training: dX chain + rank-space adapter gradients.  Checkpointed segments are re-run from
+        their kept input first (same kernels, same order: the recomputed activations are bit-identical to the ones a plain forward keeps)."""
         if not self._prepared:
             raise RuntimeError("call prepare_for_training() after loading weights (builds the K-major dgrad operands)")
-        D, H, hd = self.D, self.H, self.hd
-        B, Si, St, S, Sp, mod, cos, sin = ctx.B, ctx.Si, ctx.St, ctx.S, ctx.Sp, ctx.mod, ctx.cos, ctx.sin
+        D = self.D
+        env = ctx.env
+        B, Si, St, S, mod = env.B, env.Si, env.St, env.S, env.mod
         dev = self.device_
-        scale = 1.0 / math.sqrt(hd)
         dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         dn = ops.gemm(dout, self.l_out.wT)
@@ -487,103 +658,28 @@ class FluxTransformer2DModel(nn.Module):
             ops.ln_modulate_bwd(dn[b * Si:(b + 1) * Si], ctx.x_final[b * S + St:(b + 1) * S], mo[b:b + 1, :D], Si, out=dx[b * S + St:(b + 1) * S])
         del dn
         ctx.x_final = None
-
-        def attn_backward(sv, dO, dqkv):
-            dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
-            ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
-            return dQ, dK
-
         # ---- single blocks, reversed ----
-        dxg = None
-        for li in range(len(self.single) - 1, -1, -1):
-            blk, sv = self.single[li], ctx.sgl[li]
-            ctx.sgl[li] = None
-            ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
-            g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
-            dO = ops.gemm(g, blk.proj_out.wT[:D])
-            dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
-            dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
-            del g, dhpre
-            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-            dQ, dK = attn_backward(sv, dO, dqkv)
-            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, S, 0, S)
-            del dQ, dK, dO
-            dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
-            if li > 0:
-                gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D]
-                dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx, gate=gprev, want_gated=True)
-            elif self.double:
-                # first single block: its input gradient IS the joint gradient of the double stack — written per (stream, sample) straight into
-                # the two stream-major buffers the double blocks work on (no split / gather pass)
-                d_txt = torch.empty(B * St, D, dtype=BF16, device=dev); d_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
-                for b in range(B):
-                    for (r0, r1, dst) in ((b * S, b * S + St, d_txt[b * St:(b + 1) * St]), (b * S + St, (b + 1) * S, d_img[b * Si:(b + 1) * Si])):
-                        ops.ln_modulate_bwd(dn[r0:r1], sv.x[r0:r1], ms[b:b + 1, D:2 * D], r1 - r0, dres=dx[r0:r1], out=dst)
-                dxg = None
-            else:
-                dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
-            del dn, dn_mlp, dqkv, sv
+        dxg = d_txt = d_img = None
+        for (s0, n, ck) in reversed(ctx.segs_s):
+            if ck:
+                xr = ctx.ck_s.pop(s0)
+                for bi in range(s0, s0 + n):
+                    xr, ctx.sgl[bi] = self._single_fwd(bi, xr, env, True)
+                del xr
+            for li in range(s0 + n - 1, s0 - 1, -1):
+                dx, dxg, d_txt, d_img = self._single_bwd(li, ctx.sgl.pop(li), dx, dxg, env)
         # ---- split the joint gradient (only when there was no single block to do it) ----
         if not self.single:
             d_txt = dx.view(B, S, D)[:, :St].reshape(B * St, D); d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
-        # ---- double blocks, reversed (img / txt pairs as grouped launches) ----
-        for li in range(len(self.double) - 1, -1, -1):
-            blk, sv = self.double[li], ctx.dbl[li]
-            ctx.dbl[li] = None
-            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
-            dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
-                                           dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
-            dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
-            del g_i, g_t, dh_i, dh_t
-            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
-            dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
-            del dn2_i, dn2_t
-            # attention output projections: dO rows of both streams (+ adapter grads)
-            dO = torch.empty(B * S, D, dtype=BF16, device=dev)
-            U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
-            U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if blk.to_add_out.lora is not None else None
-            probs = []
-            for b in range(B):
-                kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
-                kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
-                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S + St:(b + 1) * S], **kw_i))
-                probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S:b * S + St], **kw_t))
-            ops.gemm_grouped(probs)
-            for (lin, U, T_, dxg, lo, rows) in ((blk.to_out, U_i, sv.T_o, dx1g_i, St, Si), (blk.to_add_out, U_t, sv.T_ao, dx1g_t, 0, St)):
-                if lin.lora is not None:
-                    O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
-                    lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
-            del dx1g_i, dx1g_t, U_i, U_t
-            dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-            dQ, dK = attn_backward(sv, dO, dqkv)
-            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, 0, S)
-            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
-            del dQ, dK, dO
-            last = li == 0
-            if B == 1:
-                dq_i, dq_t = dqkv[St:], dqkv[:St]
-            else:
-                dq_i = dqkv.view(B, S, 3 * D)[:, St:].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, :St].reshape(B * St, 3 * D)
-            streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
-            if last:
-                streams = [s_ for s_ in streams if s_[1].lora is not None]   # frozen embedders: only adapter grads remain to compute
-            probs, Us = [], {}
-            for (name, lin, dq, n_in, T_) in streams:
-                kw = {}
-                if lin.lora is not None:
-                    Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
-                    kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
-                if not last:
-                    probs.append(dict(a=dq, w=lin.wT, **kw))
-            dns = ops.gemm_grouped(probs) if probs else []
-            for (name, lin, dq, n_in, T_) in streams:
-                if lin.lora is not None:
-                    lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
-            if not last:
-                d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
-                d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
-            del dqkv, sv, dns
+        # ---- double blocks, reversed ----
+        for (s0, n, ck) in reversed(ctx.segs_d):
+            if ck:
+                ir, tr = ctx.ck_d.pop(s0)
+                for bi in range(s0, s0 + n):
+                    ir, tr, _, ctx.dbl[bi] = self._double_fwd(bi, ir, tr, env, True)
+                del ir, tr
+            for li in range(s0 + n - 1, s0 - 1, -1):
+                d_img, d_txt = self._double_bwd(li, ctx.dbl.pop(li), d_img, d_txt, env)
         return None
 
     # ------------------------------------------------------------------------------------------------
@@ -591,8 +687,6 @@ class FluxTransformer2DModel(nn.Module):
     # ------------------------------------------------------------------------------------------------
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None, txt_ids=None,
                 guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, **unsupported):
-        if attention_mask is not None:
-            raise NotImplementedError("flux_attention_masked_training is not wired to the HIP path yet")
         for k, v in unsupported.items():
             if v is not None and v is not False:
                 raise NotImplementedError(f"FluxTransformer2DModel(st355): argument {k!r} is not supported on the HIP path")
@@ -602,18 +696,30 @@ class FluxTransformer2DModel(nn.Module):
             img_ids = img_ids[0]
         if timestep.ndim != 1:
             raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
+        key_bias = None
+        if attention_mask is not None:
+            # flux_attention_masked_training (flux/model.py:813-823): the text mask [B, S_txt] is expanded with ones over the image tokens
+            # (expand_flux_attention_mask, flux/transformer.py:227-242) and handed to SDPA as `(mask > 0).bool().to(hidden_states.dtype)`
+            # (:170-173) — a FLOAT mask, which SDPA ADDS to the scores: valid keys get +1.0, padded text keys +0.0.  That additive form is
+            # what the reference trains with, so it is what the attention kernels' per-key bias reproduces here.
+            am = attention_mask
+            if am.dim() == 3 and am.size(1) == 1:
+                am = am.squeeze(1)
+            B_, S_tot = hidden_states.shape[0], hidden_states.shape[1] + encoder_hidden_states.shape[1]
+            key_bias = torch.ones(B_, S_tot, dtype=F32, device=self.device_)
+            key_bias[:, :am.shape[1]] = (am.to(self.device_) > 0).to(F32)
         need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
         if need_grad and not self._prepared:
             # the K-major dgrad operands follow the weights: load_flat_state / init_synthetic / the replica start-state broadcast
             # (training.grad_sync.sync_module_states) mark them stale, the next training forward rebuilds them
             self.prepare_for_training()
         if need_grad:
-            out = _FluxFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids,
+            out = _FluxFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids, key_bias,
                                 *self._lora_params)
         else:
             with torch.no_grad():
                 out, _ = self._engine_forward(hidden_states.to(BF16), encoder_hidden_states.to(BF16), pooled_projections, timestep,
-                                              guidance, img_ids, txt_ids, save=False)
+                                              guidance, img_ids, txt_ids, save=False, key_bias=key_bias)
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
@@ -623,9 +729,9 @@ class _FluxFn(torch.autograd.Function):
     """one autograd node for the whole network: forward = kernel sequence, backward = hand-written kernel sequence"""
 
     @staticmethod
-    def forward(fctx, model, hidden_states, enc, pooled, timestep, guidance, img_ids, txt_ids, *lora_params):
+    def forward(fctx, model, hidden_states, enc, pooled, timestep, guidance, img_ids, txt_ids, key_bias, *lora_params):
         out, ctx = model._engine_forward(hidden_states.detach().to(BF16), enc.detach().to(BF16), pooled.detach(), timestep.detach(),
-                                         None if guidance is None else guidance.detach(), img_ids, txt_ids, save=True)
+                                         None if guidance is None else guidance.detach(), img_ids, txt_ids, save=True, key_bias=key_bias)
         fctx.model, fctx.ectx, fctx.n_lora = model, ctx, len(lora_params)
         return out
 
@@ -647,4 +753,4 @@ class _FluxFn(torch.autograd.Function):
             n = p.numel()
             grads.append(gflat[off:off + n].view_as(p))
             off += n
-        return (None,) * 8 + tuple(grads)
+        return (None,) * 9 + tuple(grads)

@@ -457,6 +457,25 @@ class ModelFoundation(ExplorativeModelingMixin):
         is simpletuner_amd.sampling.flow_match_euler_sample"""
         raise NotImplementedError("diffusers pipelines are not built on the st355 path; use simpletuner_amd.sampling.flow_match_euler_sample")
 
+    def configure_gradient_checkpointing(self):
+        """trainer.py:3635-3646 + common.py:3604-3636: `gradient_checkpointing` turns recomputation on for the trained component,
+        `gradient_checkpointing_interval` (> 1) / `gradient_checkpointing_segment_stride` select the segmented modes, the backend must be the plain
+        recompute one.  A family whose engine has no recompute path refuses instead of silently keeping every activation."""
+        if not getattr(self.config, "gradient_checkpointing", False):
+            return
+        comp = self.get_trained_component()
+        if comp is None or not hasattr(comp, "enable_gradient_checkpointing") or not hasattr(comp, "_checkpoint_segments"):
+            raise NotImplementedError(f"gradient_checkpointing: {self.NAME} has no recompute path on the st355 path (built: Flux); with 288 GB of HBM "
+                                      f"the step keeps its activations — drop the flag")
+        comp.enable_gradient_checkpointing()
+        interval = getattr(self.config, "gradient_checkpointing_interval", None)
+        if interval is not None and int(interval) > 1:
+            comp.set_gradient_checkpointing_interval(int(interval))
+        stride = getattr(self.config, "gradient_checkpointing_segment_stride", None)
+        if stride is not None:
+            comp.set_gradient_checkpointing_segment_stride(int(stride))
+        comp.set_gradient_checkpointing_backend(str(getattr(self.config, "gradient_checkpointing_backend", "torch") or "torch"))
+
     # ---- API parity with the reference plugin surface (common.py:3691-3781, SURVEY.md §8b) ----
     def fuse_qkv_projections(self):
         """no-op: projections that share an input are ALWAYS stored and executed as one matrix on this path; the per-projection diffusers

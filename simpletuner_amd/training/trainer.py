@@ -119,6 +119,8 @@ class Trainer:
         self.ema_model = None
         if getattr(config, "use_ema", False):
             self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)
+        if hasattr(self.model, "configure_gradient_checkpointing"):
+            self.model.configure_gradient_checkpointing()                # trainer.py:3573 / 6792
         self._overlapped_sync = config.gradient_accumulation_steps == 1
         if self.accelerator.num_processes > 1:
             sync_module_states(comp)                                     # replicas start from rank 0's weights (DDP construction semantics)

@@ -117,3 +117,74 @@ def test_ema_and_clipping_in_the_loop():
     for s, e in zip(shadow_ref, trainer.ema_model.shadow_params):
         assert torch.allclose(s, e, atol=1e-6)     # tests/test_ema.py tolerance (atol 1e-6)
     assert any(not torch.equal(a, b.detach()) for a, b in zip(p0, trainer.params))
+
+
+@pytest.mark.parametrize("mode,interval,stride", [("layer", None, None), ("interval2", 2, None), ("seg2-stride4", 2, 4)])
+def test_checkpointed_gradients_equal_direct_gradients(mode, interval, stride):
+    """SURVEY.md §8(f)3 / reference tests/test_gradient_checkpointing_backend.py:49-105 (checkpointed == direct, atol 1e-6): the recompute runs the
+    same kernels in the same order, so prediction, loss and every adapter gradient are BIT-identical to the run that keeps its activations"""
+    def run(ckpt):
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        plugin, trainer, cpu, devt = _build(3, 5, 2, 16, 16, 32, rank=8)
+        plugin.config.gradient_checkpointing = ckpt
+        plugin.config.gradient_checkpointing_interval, plugin.config.gradient_checkpointing_segment_stride = interval, stride
+        plugin.configure_gradient_checkpointing()
+        model = plugin.get_trained_component()
+        assert model.gradient_checkpointing is ckpt
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+        torch.cuda.reset_peak_memory_stats()
+        out = plugin.model_predict(prepared)
+        loss, _ = plugin.loss_with_logs(prepared, out)
+        kept = torch.cuda.memory_allocated()
+        loss.backward()
+        segs = (model._checkpoint_segments(3), model._checkpoint_segments(5))
+        return out["model_prediction"].detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in trainer.params], kept, segs
+    p0, l0, g0, kept0, _ = run(False)
+    p1, l1, g1, kept1, segs = run(True)
+    assert any(ck for seg in segs for (_, _, ck) in seg)
+    assert torch.equal(p0, p1) and torch.equal(l0, l1)
+    assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    print(f"[ckpt] {mode}: activations held between forward and backward {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB, plans {segs}")
+    assert kept1 < kept0
+
+
+def test_flux_attention_masked_training_matches_oracle():
+    """flux_attention_masked_training (flux/model.py:813-823, flux/transformer.py:170-173, 227-242): the reference hands SDPA the FLOAT mask
+    (mask > 0).to(dtype) expanded with ones over the image tokens, i.e. an ADDITIVE +1 on every valid key — restated in the oracle as key_bias"""
+    plugin, trainer, cpu, devt = _build(1, 2, 2, 16, 16, 32)
+    plugin.config.flux_attention_masked_training = True
+    model = plugin.get_trained_component()
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    mask = torch.ones(2, 32); mask[0, 20:] = 0; mask[1, 9:] = 0
+    b = _batch(devt); b["encoder_attention_mask"] = mask.to("cuda:0")
+    prepared = plugin.prepare_batch(b, {"global_step": 0})
+    out = plugin.model_predict(prepared)
+    loss, _ = plugin.loss_with_logs(prepared, out)
+    loss.backward()
+    P, lora, scale = PU.oracle_state(model)
+    ocfg = PU.oracle_cfg(model)
+    kb = torch.ones(2, 32 + 64); kb[:, :32] = (mask > 0).float()
+    s = cpu["sigmas"].view(-1, 1, 1, 1)
+    noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
+    target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
+    lp = {k: (a.clone().requires_grad_(True), bb.clone().requires_grad_(True)) for k, (a, bb) in lora.items()}
+    packed = PU.OF.pack_latents(noisy)
+    o = PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(16, 16), torch.zeros(32, 3),
+                           torch.full((2,), 1.0), lp, scale, key_bias=kb)
+    o_pred = PU.OF.unpack_latents(o, 16, 16)
+    o_loss = ((o_pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    o_loss.backward()
+    r = PU.rel_l2(out["model_prediction"], o_pred)
+    # the mask must matter: the unmasked oracle prediction differs by far more than the parity tolerance
+    o_nomask = PU.OF.unpack_latents(PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(16, 16),
+                                                       torch.zeros(32, 3), torch.full((2,), 1.0), None, 1.0), 16, 16)
+    print(f"[parity] flux masked attention: pred rel_l2={r:.3e}  loss hip={loss.item():.6f} oracle={o_loss.item():.6f}")
+    assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
+    for name, p in model.named_parameters():
+        if ".lora_" in name:
+            ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+            assert PU.rel_l2(p.grad, ref) < 5e-2, name
