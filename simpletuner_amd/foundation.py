@@ -264,7 +264,7 @@ class ModelFoundation(ExplorativeModelingMixin):
         """common.py:2663: build the family's AutoencoderKL (encoder half; diffusers state-dict keys).  Without a state dict the weights are
         synthetic (benchmarks, tests) — there is no hub access here."""
         vae = self.autoencoder_class()(device=self.accelerator.device, **self.VAE_CONFIG)
-        vae.load_state_dict(state_dict if state_dict is not None else vae.synthetic_state_dict(int(getattr(self.config, "seed", 42) or 42)))
+        vae.load_state_dict(state_dict if state_dict is not None else vae.synthetic_state_dict(int(getattr(self.config, "seed", 42) or 42), decoder=True))
         self.vae = vae
         return vae
 

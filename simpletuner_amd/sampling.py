@@ -155,3 +155,33 @@ def flow_match_euler_sample(predict: Callable[[torch.Tensor, torch.Tensor], torc
             if on_step is not None:
                 on_step(i, x)
     return x
+
+
+def sample_images(plugin, prompt_embeds: torch.Tensor, pooled: Optional[torch.Tensor], latent_height: int, latent_width: int, num_inference_steps: int = 20,
+                  generator: Optional[torch.Generator] = None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, mu: Optional[float] = None,
+                  decode: bool = True, extra_batch: Optional[dict] = None) -> torch.Tensor:
+    """The validation sampling loop end to end on the st355 kernels (training/validation.py -> <family>/pipeline.py `__call__`):
+    Gaussian latents -> `num_inference_steps` Euler flow-matching steps over the plugin's OWN forward (`model_predict`, so packing / ids / guidance /
+    timestep conventions are the family's) -> `vae.decode(z / scaling_factor + shift_factor)`.  Returns pixels [B, 3, 8h, 8w] in [-1, 1] (bf16), or
+    the final latents with decode=False.  Classifier-free guidance pairs, IP adapters and the image post-processing of the diffusers pipelines stay
+    outside this tier."""
+    dev = plugin.accelerator.device
+    B = prompt_embeds.shape[0]
+    C = int(plugin.LATENT_CHANNEL_COUNT)
+    x = torch.randn(B, C, latent_height, latent_width, device=dev, dtype=torch.float32, generator=generator).to(torch.bfloat16)
+    scheduler = scheduler or FlowMatchEulerDiscreteScheduler(shift=float(getattr(plugin.config, "flow_schedule_shift", 3.0) or 1.0))
+    pe = prompt_embeds.to(device=dev, dtype=torch.bfloat16)
+    pp = None if pooled is None else pooled.to(device=dev, dtype=torch.bfloat16)
+
+    def predict(xt, t):
+        batch = {"latents": xt, "noisy_latents": xt, "timesteps": t.to(device=dev, dtype=torch.float32), "prompt_embeds": pe, "encoder_hidden_states": pe,
+                 "add_text_embeds": pp, "added_cond_kwargs": {"text_embeds": pp}}
+        if extra_batch:
+            batch.update(extra_batch)
+        return plugin.model_predict(batch)["model_prediction"].to(xt.dtype)
+
+    x = flow_match_euler_sample(predict, x, scheduler, num_inference_steps, mu=mu)
+    if not decode:
+        return x
+    return plugin.get_vae().decode_scaled(x)
+

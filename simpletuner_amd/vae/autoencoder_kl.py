@@ -1,4 +1,4 @@
-"""AutoencoderKL (encoder side) — the VAE latent encode of the hot path on MI355X.
+"""AutoencoderKL — the VAE latent encode of the hot path on MI355X, and the decode of the validation loop.
 
 Mirrors what the reference drives (caching/vae.py:1238-1396 -> models/common.py:2767-2772): `vae.encode(samples)` returns an object whose
 `.latent_dist` has `.sample(generator=None)`, `.mode()`, `.parameters`; `vae.config.scaling_factor / shift_factor` feed
@@ -8,6 +8,12 @@ grid-buffer convolutions-as-GEMM (no im2col except conv_in's 3 -> 8 channels and
 GroupNorm+SiLU kernels, and the single-head dim-512 mid-block attention as two plain GEMMs around a row-softmax kernel (the score matrix
 [HW, HW] bf16 is materialised per image: 512 MiB at 1024^2 — nothing on a 288 GB part).  quant_conv (1x1 on 2L channels) is folded into
 conv_out at load time (both are linear).  Inference only (the VAE is frozen during training).
+
+Decoder (`decode`, `decode_scaled`): diffusers' Decoder as the validation pipelines call it (`vae.decode(z / scaling_factor + shift_factor).sample`,
+e.g. flux/pipeline.py) — [post_quant_conv 1x1] -> conv_in -> UNetMidBlock2D -> 4 UpDecoderBlock2D over the reversed channel list
+(layers_per_block + 1 resnets, nearest-2x upsample + conv3x3 on all but the last) -> GroupNorm -> SiLU -> conv_out — on the same grid-buffer
+convolution / GroupNorm / upsample kernels.  The latent (4 / 16 channels) enters as a 64-channel grid (zero channels above L: the convolution
+GEMM's K granule), conv_out's 3 channels leave through an 8-wide output.  Loaded only when the state dict carries `decoder.*` keys.
 """
 from __future__ import annotations
 
@@ -87,12 +93,41 @@ class AutoencoderKL(nn.Module):
             names.append(("quant_conv", "conv", 2 * c.latent_channels, 2 * c.latent_channels, 1))
         return names
 
+    def _decoder_names(self):
+        c = self.config
+        rev = tuple(reversed(c.block_out_channels))
+        L = c.latent_channels
+
+        def res(p, ci, co):
+            out = [(p + "norm1", "norm", ci, ci, 0), (p + "conv1", "conv", ci, co, 3), (p + "norm2", "norm", co, co, 0), (p + "conv2", "conv", co, co, 3)]
+            if ci != co:
+                out.append((p + "conv_shortcut", "conv", ci, co, 1))
+            return out
+
+        names = []
+        if c.use_quant_conv:
+            names.append(("post_quant_conv", "conv", L, L, 1))
+        names.append(("decoder.conv_in", "conv", L, rev[0], 3))
+        names += res("decoder.mid_block.resnets.0.", rev[0], rev[0])
+        a = "decoder.mid_block.attentions.0."
+        names += [(a + "group_norm", "norm", rev[0], rev[0], 0)] + [(a + n, "lin", rev[0], rev[0], 0) for n in ("to_q", "to_k", "to_v", "to_out.0")]
+        names += res("decoder.mid_block.resnets.1.", rev[0], rev[0])
+        cin = rev[0]
+        for i, co in enumerate(rev):
+            for j in range(c.layers_per_block + 1):
+                names += res(f"decoder.up_blocks.{i}.resnets.{j}.", cin, co)
+                cin = co
+            if i < len(rev) - 1:
+                names.append((f"decoder.up_blocks.{i}.upsamplers.0.conv", "conv", cin, cin, 3))
+        names += [("decoder.conv_norm_out", "norm", cin, cin, 0), ("decoder.conv_out", "conv", cin, c.in_channels, 3)]
+        return names
+
     @torch.no_grad()
-    def synthetic_state_dict(self, seed: int = 0) -> Dict[str, torch.Tensor]:
+    def synthetic_state_dict(self, seed: int = 0, decoder: bool = False) -> Dict[str, torch.Tensor]:
         """random weights in diffusers' names / shapes (bf16-representable fp32), for parity tests and benches without a checkpoint"""
         g = torch.Generator().manual_seed(seed)
         sd = {}
-        for name, kind, ci, co, k in self._names():
+        for name, kind, ci, co, k in self._names() + (self._decoder_names() if decoder else []):
             if kind == "norm":
                 sd[name + ".weight"] = (1.0 + 0.1 * torch.randn(ci, generator=g)).to(BF16).float()
                 sd[name + ".bias"] = (0.02 * torch.randn(ci, generator=g)).to(BF16).float()
@@ -125,9 +160,31 @@ class AutoencoderKL(nn.Module):
                     b = wq @ b + bq
                 W[name + ".weight"] = w.permute(0, 2, 3, 1).reshape(co, -1).to(dev, BF16).contiguous()
                 W[name + ".bias"] = b.to(dev, BF16).contiguous()
-        a = "encoder.mid_block.attentions.0."
-        W[a + "qkv.weight"] = torch.cat([W[a + n + ".weight"] for n in ("to_q", "to_k", "to_v")], 0).contiguous()
-        W[a + "qkv.bias"] = torch.cat([W[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0).contiguous()
+        self.has_decoder = "decoder.conv_in.weight" in sd
+        if self.has_decoder:
+            L = c.latent_channels
+            for name, kind, ci, co, k in self._decoder_names():
+                w, b = sd[name + ".weight"].float(), sd[name + ".bias"].float()
+                if kind == "norm" or kind == "lin":
+                    W[name + ".weight"], W[name + ".bias"] = w.to(dev, BF16).contiguous(), b.to(dev, BF16).contiguous()
+                elif name == "post_quant_conv":                    # 1x1 on the latents: [64 (L used), 64 (L used)] over the 64-channel latent grid
+                    w64, b64 = torch.zeros(64, 64), torch.zeros(64)
+                    w64[:L, :L], b64[:L] = w.view(L, L), b
+                    W[name + ".weight"], W[name + ".bias"] = w64.to(dev, BF16), b64.to(dev, BF16)
+                elif name == "decoder.conv_in":                    # reads the 64-channel latent grid: zero weights on the padding channels
+                    w64 = torch.zeros(co, 9, 64)
+                    w64[:, :, :L] = w.permute(0, 2, 3, 1).reshape(co, 9, L)
+                    W[name + ".weight"], W[name + ".bias"] = w64.reshape(co, 9 * 64).to(dev, BF16).contiguous(), b.to(dev, BF16)
+                elif name == "decoder.conv_out":                   # 3 output channels through an 8-wide output (Cout granule of the conv GEMM)
+                    w8, b8 = torch.zeros(8, 9 * ci), torch.zeros(8)
+                    w8[:co], b8[:co] = w.permute(0, 2, 3, 1).reshape(co, -1), b
+                    W[name + ".weight"], W[name + ".bias"] = w8.to(dev, BF16).contiguous(), b8.to(dev, BF16)
+                else:
+                    W[name + ".weight"] = w.permute(0, 2, 3, 1).reshape(co, -1).to(dev, BF16).contiguous()
+                    W[name + ".bias"] = b.to(dev, BF16).contiguous()
+        for a in ("encoder.mid_block.attentions.0.",) + (("decoder.mid_block.attentions.0.",) if self.has_decoder else ()):
+            W[a + "qkv.weight"] = torch.cat([W[a + n + ".weight"] for n in ("to_q", "to_k", "to_v")], 0).contiguous()
+            W[a + "qkv.bias"] = torch.cat([W[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0).contiguous()
         self.W = W
         return self
 
@@ -166,14 +223,14 @@ class AutoencoderKL(nn.Module):
                 h = ops.conv(col, W[p + ".weight"], B, H, Wd, bias=W[p + ".bias"], taps=1)
                 del col
         h = self._res("encoder.mid_block.resnets.0.", h, B, H, Wd)
-        h = self._mid_attention(h, B, H, Wd)
+        h = self._mid_attention(h, B, H, Wd, "encoder.mid_block.attentions.0.")
         h = self._res("encoder.mid_block.resnets.1.", h, B, H, Wd)
         h, _ = ops.groupnorm_fwd(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], B, H, Wd, groups=c.norm_num_groups, eps=1e-6, silu=True)
         y = ops.conv(h, W["encoder.conv_out.weight"], B, H, Wd, bias=W["encoder.conv_out.bias"])
         return ops.grid_to_nchw(y, B, 2 * c.latent_channels, H, Wd)
 
-    def _mid_attention(self, x, B, H, Wd):
-        W, a = self.W, "encoder.mid_block.attentions.0."
+    def _mid_attention(self, x, B, H, Wd, a):
+        W = self.W
         C_ = x.shape[1]
         S = H * Wd
         n, _ = ops.groupnorm_fwd(x, W[a + "group_norm.weight"], W[a + "group_norm.bias"], B, H, Wd, groups=self.config.norm_num_groups, eps=1e-6, silu=False,
@@ -207,3 +264,44 @@ class AutoencoderKL(nn.Module):
         if c.shift_factor is not None:
             return ((z.float() - c.shift_factor) * c.scaling_factor).to(z.dtype)
         return (z.float() * c.scaling_factor).to(z.dtype)
+
+
+    # ---- decode (validation images) ----
+    @torch.no_grad()
+    def decode(self, z, return_dict: bool = True):
+        """AutoencoderKL.decode(z).sample: [B, L, h, w] latents (already un-scaled) -> [B, 3, 8h, 8w] bf16"""
+        if not getattr(self, "has_decoder", False):
+            raise RuntimeError("AutoencoderKL(st355): the loaded state dict carries no decoder.* weights")
+        c, W = self.config, self.W
+        B, L, H, Wd = z.shape
+        if L != c.latent_channels:
+            raise ValueError(f"decode: expected {c.latent_channels} latent channels, got {L}")
+        h = ops.grid_from_nchw(z.to(device=self.device_, dtype=BF16), 64)
+        if c.use_quant_conv:
+            h = ops.conv(h, W["post_quant_conv.weight"], B, H, Wd, bias=W["post_quant_conv.bias"], taps=1)
+        h = ops.conv(h, W["decoder.conv_in.weight"], B, H, Wd, bias=W["decoder.conv_in.bias"])
+        h = self._res("decoder.mid_block.resnets.0.", h, B, H, Wd)
+        h = self._mid_attention(h, B, H, Wd, "decoder.mid_block.attentions.0.")
+        h = self._res("decoder.mid_block.resnets.1.", h, B, H, Wd)
+        nb = len(c.block_out_channels)
+        for i in range(nb):
+            for j in range(c.layers_per_block + 1):
+                h = self._res(f"decoder.up_blocks.{i}.resnets.{j}.", h, B, H, Wd)
+            if i < nb - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                h = ops.upsample2x(h, B, H, Wd)               # Upsample2D: nearest 2x, then conv3x3
+                H, Wd = 2 * H, 2 * Wd
+                h = ops.conv(h, W[p + ".weight"], B, H, Wd, bias=W[p + ".bias"])
+        h, _ = ops.groupnorm_fwd(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], B, H, Wd, groups=c.norm_num_groups, eps=1e-6, silu=True)
+        y = ops.conv(h, W["decoder.conv_out.weight"], B, H, Wd, bias=W["decoder.conv_out.bias"])
+        img = ops.grid_to_nchw(y, B, c.in_channels, H, Wd)
+        return SimpleNamespace(sample=img) if return_dict else (img,)
+
+    @torch.no_grad()
+    def decode_scaled(self, z):
+        """what the validation pipelines do with cache-scaled latents: vae.decode(z / scaling_factor + shift_factor).sample"""
+        c = self.config
+        z = z.float() / c.scaling_factor
+        if c.shift_factor is not None:
+            z = z + c.shift_factor
+        return self.decode(z.to(BF16), return_dict=False)[0]
