@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--single-layers", type=int, default=38)
     ap.add_argument("--rank", type=int, default=32)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--gradient-checkpointing", action="store_true", help="flux: re-run checkpointed blocks in backward instead of keeping their activations "
+                    "(SURVEY.md §8(f)3); with --ckpt-interval K [--ckpt-stride S] the reference's segmented modes (interval2 = K 2; seg2-stride4 = K 2 S 4)")
+    ap.add_argument("--ckpt-interval", type=int, default=None)
+    ap.add_argument("--ckpt-stride", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA secondary measurement appended to the default line")
     ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
@@ -362,7 +366,9 @@ def run_workload(args, dev, rank, world):
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42, lora_init_b_std=1e-3,   # weights / adapter init / rounding seeds are REPLICA-identical; the data RNG below is per rank
                         
                          model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
-                         learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph))
+                         learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph),
+                         gradient_checkpointing=bool(getattr(args, "gradient_checkpointing", False)) and args.model == "flux",
+                         gradient_checkpointing_interval=getattr(args, "ckpt_interval", None), gradient_checkpointing_segment_stride=getattr(args, "ckpt_stride", None))
     acc = St355Accelerator(dev)
     if args.model == "flux":
         from simpletuner_amd.flux.model import Flux
@@ -553,7 +559,9 @@ def run_workload(args, dev, rank, world):
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (+ fp8 e5m2 x e4m3 trunk Linears)" if getattr(args, "fp8", False) else "bf16", "data": "synthetic",
             "config": {"workload": desc,
-                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "hip_graph": bool(args.graph)},
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "gradient_checkpointing": (f"interval={cfg.gradient_checkpointing_interval} stride={cfg.gradient_checkpointing_segment_stride}"
+                                                  if cfg.gradient_checkpointing else False)},
             "step_model_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),

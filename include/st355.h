@@ -304,6 +304,30 @@ int st355_attn_cross_bwd(void* stream, const void* Q, const void* K, const void*
                          int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, void* dQ, void* dK, void* dv_rows,
                          int64_t ld_dv, int B, int H, int Sq, int Sqp, int Sk, int Skp, int d, float scale, void* workspace);
 
+/* ---- workspace sizing: one query for every op that takes caller-provided scratch (the library never allocates).  dims per op:
+ *   ATTN_BWD {B, H, Sq, Sqp, d}   COLSUM {rows, N, rows_per_batch}   SKINNY_TN {M, P, R}   GROUPNORM {B, H, W, C}   LAYERNORM_PARAM_GRADS {D}
+ *   GEMM_SPLITK {M, N, K} (upper bound: 16 fp32 slabs)   GEMM_TN {P, Q, contraction, taps}.   Returns bytes, or -1 for an unknown op / too few dims. */
+#define ST355_WS_ATTN_BWD 1
+#define ST355_WS_COLSUM 2
+#define ST355_WS_SKINNY_TN 3
+#define ST355_WS_GROUPNORM 4
+#define ST355_WS_LAYERNORM_PARAM_GRADS 5
+#define ST355_WS_GEMM_SPLITK 6
+#define ST355_WS_GEMM_TN 7
+int64_t st355_workspace_bytes(int op, const int64_t* dims, int ndims);
+
+/* ---- C1: gradient exchange of the data-parallel replicas over RCCL / xGMI (reference: torch DDP's reducer, trainer.py:1034-1041, 4564-4571).
+ * One communicator per process (one process per GPU, created on the calling thread's current device).  Rank 0 creates the 128-byte id, the HOST
+ * carries it to the other ranks.  SUM only (1/world lives in the optimizer's grad_scale); elem_kind 0 = fp32, 1 = bf16.  In-place forms as in
+ * RCCL: reduce_scatter recv == send + rank*recv_count, all_gather send == recv + rank*send_count (the flat gradient arena uses both).
+ * librccl is dlopen-ed at first use; ST355_ENOSYS if it cannot be loaded. */
+int st355_comm_unique_id(void* id128);
+int st355_comm_init(void** comm, const void* id128, int world, int rank);
+int st355_comm_destroy(void* comm);
+int st355_comm_all_reduce(void* comm, void* stream, void* buf, int64_t count, int elem_kind);
+int st355_comm_reduce_scatter(void* comm, void* stream, const void* send, void* recv, int64_t recv_count, int elem_kind);
+int st355_comm_all_gather(void* comm, void* stream, const void* send, void* recv, int64_t send_count, int elem_kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ SYMBOLS = [
     "st355_attn_fwd", "st355_attn_bwd_workspace", "st355_attn_bwd",
     "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp", "st355_grad_clip_norm",
     "st355_lora_pack",
+    "st355_workspace_bytes",
+    "st355_comm_unique_id", "st355_comm_init", "st355_comm_destroy", "st355_comm_all_reduce", "st355_comm_reduce_scatter", "st355_comm_all_gather",
     # UNet path (SDXL / SD1.5)
     "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows",
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
@@ -124,6 +126,13 @@ def _declare(lib):
         "st355_grad_clamp": (C.c_int, [vp, vp, i64, i32, f32]),
         "st355_grad_clip_norm": (C.c_int, [vp, vp, i64, i32, vp, f32, f32]),
         "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),
+        "st355_workspace_bytes": (i64, [i32, vp, i32]),
+        "st355_comm_unique_id": (C.c_int, [vp]),
+        "st355_comm_init": (C.c_int, [vp, vp, i32, i32]),
+        "st355_comm_destroy": (C.c_int, [vp]),
+        "st355_comm_all_reduce": (C.c_int, [vp, vp, vp, i64, i32]),
+        "st355_comm_reduce_scatter": (C.c_int, [vp, vp, vp, vp, i64, i32]),
+        "st355_comm_all_gather": (C.c_int, [vp, vp, vp, vp, i64, i32]),
         "st355_conv_grid_rows": (i64, [i32, i32, i32]),
         "st355_conv_bf16": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32]),
         "st355_conv_wgrad_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64]),

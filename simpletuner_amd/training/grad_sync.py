@@ -29,12 +29,13 @@ RS_AG_MIN_BYTES = 1 << 30
 
 
 class GradSync:
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto"):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto", comm=None):
         if mode not in ("auto", "allreduce", "rs_ag"):
             raise ValueError(f"GradSync mode {mode!r}: expected auto / allreduce / rs_ag")
         self.flat = flat_grad
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.pg = process_group
+        self.comm = comm                 # optional training.rccl_comm.St355Comm: the exchange goes through the st355_comm_* C ABI instead of torch.distributed
         self.enabled = True
         if mode == "auto":
             mode = "rs_ag" if flat_grad.numel() * flat_grad.element_size() >= RS_AG_MIN_BYTES else "allreduce"
@@ -51,10 +52,14 @@ class GradSync:
 
     @property
     def world_size(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
 
     @property
     def rank(self) -> int:
+        if self.comm is not None:
+            return self.comm.rank
         return dist.get_rank(self.pg) if dist.is_available() and dist.is_initialized() else 0
 
     def begin(self):
@@ -84,6 +89,13 @@ class GradSync:
             return
         with self._comm_ctx():
             m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
+            if self.comm is not None:                                  # C-ABI RCCL path: stream-ordered on the comm stream, nothing to wait on but the stream
+                if m > 0:
+                    self.comm.reduce_scatter_(self.flat[lo:lo + m]); self.launched_ops.append(("reduce_scatter", lo, lo + m))
+                    self.comm.all_gather_(self.flat[lo:lo + m]); self.launched_ops.append(("all_gather", lo, lo + m))
+                if lo + m < hi:
+                    self.comm.all_reduce_(self.flat[lo + m:hi]); self.launched_ops.append(("all_reduce", lo + m, hi))
+                return
             if m > 0 and self.flat.is_cuda and not self._stream_ordered():
                 # gloo with a device arena (the shared-GPU plumbing tests; gloo moves device tensors through the host anyway and has no device
                 # reduce-scatter): the same two collectives on a host copy of the slice, blocking

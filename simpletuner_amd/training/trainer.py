@@ -126,10 +126,15 @@ class Trainer:
             sync_module_states(comp)                                     # replicas start from rank 0's weights (DDP construction semantics)
         if self.accelerator.num_processes > 1 and self._overlapped_sync:
             # replicas: bucketed all-reduce of the flat gradient arena, overlapped with the hand-written backward
+            import os
+            comm = None
+            if os.environ.get("ST355_COMM") == "native":                  # the st355_comm_* C ABI over RCCL instead of torch.distributed's collectives
+                from .rccl_comm import St355Comm
+                comm = St355Comm.from_process_group()
             if getattr(comp, "full", False) and getattr(comp, "grad_arena", None) is not None:
-                comp.grad_sync = GradSync(comp.grad_arena, bucket_bytes=128 << 20)
+                comp.grad_sync = GradSync(comp.grad_arena, bucket_bytes=128 << 20, comm=comm)
             elif getattr(comp, "lora_grad_flat", None) is not None:
-                comp.grad_sync = GradSync(comp.lora_grad_flat)
+                comp.grad_sync = GradSync(comp.lora_grad_flat, comm=comm)
         # hip_graph: predict + loss + backward of one (shape-keyed) step are captured once into a hipGraph and replayed — the UNet step is
         # ~7000 short launches and otherwise bound by the host's launch rate.  Single process, no gradient accumulation, fixed shapes per key.
         self._use_graph = bool(getattr(config, "hip_graph", False))

@@ -129,3 +129,32 @@ def test_two_replicas_equal_one_process_on_the_concatenated_batch():
         else:                                               # bf16 weights: at most ~1 bf16 ulp of the value (gradients are summed across ranks in bf16)
             ulp = single.abs().clamp_min(1e-3) * 2.0 ** -7
             assert (diff <= 2 * ulp).all() and (diff <= ulp).float().mean().item() > 0.999
+
+
+def test_native_rccl_comm_single_rank_collectives_and_grad_sync():
+    """st355_comm_* (include/st355.h) at world 1 — all a 1-GPU box can run of RCCL: the communicator comes up on the device, the three collectives run
+    on the caller's stream and leave a 1-rank SUM (= the input) in place, and GradSync drives them in the rs_ag form with a forced world of 1.
+    (world > 1 is the same calls with more ranks; the multi-GPU scaling run of the driver exercises the torch.distributed RCCL path.)"""
+    from simpletuner_amd.training.grad_sync import GradSync
+    from simpletuner_amd.training.rccl_comm import St355Comm
+    torch.cuda.set_device(0)
+    comm = St355Comm.from_process_group()
+    assert comm.world == 1 and comm.rank == 0 and len(St355Comm.unique_id()) == 128
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(100_003, device="cuda:0").to(dt)
+        want = x.clone()
+        comm.all_reduce_(x)
+        comm.all_gather_(x)
+        sh = comm.reduce_scatter_(x)
+        torch.cuda.synchronize()
+        assert torch.equal(x, want) and sh.data_ptr() == x.data_ptr() and sh.numel() == x.numel()
+    with pytest.raises(Exception):
+        comm.all_reduce_(torch.zeros(4))                       # host tensor: refused
+    flat = torch.arange(10_000, device="cuda:0", dtype=torch.float32)
+    gs = GradSync(flat, bucket_bytes=4 * 3000, mode="rs_ag", comm=comm)
+    gs.begin()
+    for hi in range(10_000, 0, -2500):
+        gs.ready(hi - 2500, hi)
+    assert gs.finish() == 1.0 and gs.launched_ops == []        # world 1: nothing to exchange, the arena is untouched
+    assert torch.equal(flat, torch.arange(10_000, device="cuda:0", dtype=torch.float32))
+    comm.destroy()

@@ -65,8 +65,9 @@ def test_pixart_controlnet_branch_gradients_match_autograd():
     loss.backward()
     cfg = PixArtConfig(**ARCH)
     ref = controlnet_forward(P, C, cfg, 2, lat.float(), cond.float(), enc.float(), mask, t, torch.tensor([[16.0, 16.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1))
-    assert _rel(out.detach().cpu(), ref.detach()) < 2e-2
     lref = ((ref.chunk(2, dim=1)[0] - target) ** 2).mean()
+    print(f"[pixart controlnet] out rel-L2 {_rel(out.detach().cpu(), ref.detach()):.3e}  loss hip={loss.item():.6f} oracle={lref.item():.6f}")
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-2
     lref.backward()
     assert abs(loss.item() - lref.item()) < 1e-3 * max(1.0, abs(lref.item()))
     worst = (0.0, "")
