@@ -119,7 +119,9 @@ def test_two_replicas_equal_one_process_on_the_concatenated_batch():
         kinds = {k for k, _, _ in ops0}
         assert kinds and (("reduce_scatter" in kinds and "all_gather" in kinds) if fam == "sd3" else kinds == {"all_reduce"}), kinds
         # the logged loss is the sample-weighted mean over ranks == the single process's batch mean
-        assert all(abs(a - b) < 2e-4 * max(1.0, abs(b)) for a, b in zip(l0, single_losses)), (l0, single_losses)
+        # (bf16 weights of the full fine-tune differ by <= 1 ulp after each step, which the next step's loss sees at the 1e-4 level)
+        ltol = 2e-4 if fam == "flux" else 1e-3
+        assert all(abs(a - b) < ltol * max(1.0, abs(b)) for a, b in zip(l0, single_losses)), (l0, single_losses)
         diff = (w0 - single).abs()
         moved = (single - single.new_tensor(0)).abs().max().item()
         print(f"[parity] {fam}: 2 replicas vs 1 process on the concatenated batch after {_K_STEPS} steps: max |dw| = {diff.max().item():.3e} "
