@@ -13,6 +13,11 @@
 
 #define TPB 130
 
+// tile-image swizzle of the kernels that ALSO gather transposed fragments from a row-major tile (dq<.., TR>, dkv3): 16-byte chunk c of row q is stored
+// at c ^ f(q), f(q) = 4 (q & 3) + ((q >> 2) & 3) — a bijection of q & 15 (ds_read_b128 row fragments stay conflict-free) under which 4 consecutive
+// rows differ in bits 2-3 (the 32 eight-byte pieces of a ds_read_b64_tr_b16 lane group fall on 32 distinct bank slots)
+__device__ __forceinline__ int swz_q(int q) { return ((q & 3) << 2) | ((q >> 2) & 3); }
+
 // ------------------------------------------------------------------------------------------------
 // prep
 // ------------------------------------------------------------------------------------------------
@@ -53,13 +58,14 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; j++) gv[j] = f2bf(0.f);
     }
-    if (cact) {
+    if (cact && dOt != nullptr) {
       uint32_t* tp = (uint32_t*)(&tile[tl * TPB + c * 8]);
       const u32x4 gw = *(const u32x4*)&gv;
 #pragma unroll
       for (int j = 0; j < 4; j++) tp[j] = gw[j];
     }
   }
+  if (dOt == nullptr) return;                         // dkv3 (head_dim 128) gathers dO^T fragments by transposing LDS reads: no transposed copy
   __syncthreads();
   for (int i = tid; i < HD * 8; i += 256) {
     const int d = i >> 3, tc = i & 7;
@@ -73,7 +79,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // dQ kernel: 8 waves x 32 queries
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+// TR (head_dim 128): no K^T tile — the K^T fragments of dQ^T += K^T dS^T are gathered from the row-major K tile by transposing LDS reads (the
+// dkv3 recipe: tile image swizzled with f(row)), so the pre-transposed head-major K^T copy in HBM disappears and a key tile is 32 KiB, not 48.
+template <int HD, bool TR = false>
 __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                        const bf16* __restrict__ Kt, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                        const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
@@ -83,11 +91,13 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
   constexpr int TT_BYTES = HD * 128;     // K^T tile (HD rows x 64 keys)
-  constexpr int BUF = 2 * KT_BYTES + TT_BYTES;
+  static_assert(!TR || HD == 128, "the transposing-read form is built for head_dim 128");
+  constexpr int BUF = 2 * KT_BYTES + (TR ? 0 : TT_BYTES);
   constexpr int NKS = HD / 16, NDT = HD / 32;
   constexpr int KTOT = KT_BYTES / 16, TTOT = TT_BYTES / 16;             // 16-byte chunks per tile (head_dim 96: 768, not a multiple of 512)
   constexpr int KCH = (KTOT + NT - 1) / NT;
-  constexpr int TCH = (TTOT + NT - 1) / NT;
+  constexpr int TCH = TR ? 1 : (TTOT + NT - 1) / NT;
+  auto koff = [](int row, int chunk) { return TR ? row * 256 + ((chunk ^ swz_q(row)) << 4) : lds_off<KROWB>(row, chunk); };   // K tile image
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -133,12 +143,14 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
       kreg[p] = *(const bf16x8*)(Kg + (int64_t)key * HD + c * 8);
       vreg[p] = *(const bf16x8*)(Vg + (int64_t)key * ld_v + c * 8);
     }
+    if (!TR) {
 #pragma unroll
-    for (int p = 0; p < TCH; p++) {
-      const int id = p * NT + tid;
-      if (TTOT % NT != 0 && id >= TTOT) continue;
-      const int row = id >> 3, c = id & 7;
-      treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Skp + key0 + c * 8);
+      for (int p = 0; p < TCH; p++) {
+        const int id = p * NT + tid;
+        if (TTOT % NT != 0 && id >= TTOT) continue;
+        const int row = id >> 3, c = id & 7;
+        treg[p] = *(const bf16x8*)(Ktg + (int64_t)row * Skp + key0 + c * 8);
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -150,20 +162,25 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
       const int id = p * NT + tid;
       if (KTOT % NT != 0 && id >= KTOT) continue;
       const int row = id / (HD / 8), c = id % (HD / 8);
-      *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
+      *(bf16x8*)(ks + koff(row, c)) = kreg[p];
       *(bf16x8*)(vs + lds_off<KROWB>(row, c)) = vreg[p];
     }
+    if (!TR) {
 #pragma unroll
-    for (int p = 0; p < TCH; p++) {
-      const int id = p * NT + tid;
-      if (TTOT % NT != 0 && id >= TTOT) continue;
-      const int row = id >> 3, c = id & 7;
-      *(bf16x8*)(ts + lds_off<128>(row, c)) = treg[p];
+      for (int p = 0; p < TCH; p++) {
+        const int id = p * NT + tid;
+        if (TTOT % NT != 0 && id >= TTOT) continue;
+        const int row = id >> 3, c = id & 7;
+        *(bf16x8*)(ts + lds_off<128>(row, c)) = treg[p];
+      }
     }
   };
 
   const int nkt = (Sk + 63) / 64;
   const int krow_p = perm23(l31);
+  // TR: transposed-fragment base (see dkv3): lane = 16 g + 4 r + s, key row 8h + r, chunk (2 ihalf + (s >> 1)) ^ (4 r + 2 h), + (s & 1) * 8
+  const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
+  const int tr_base = (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -183,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
       const int row = 32 * sb + krow_p;
 #pragma unroll
       for (int ks_ = 0; ks_ < NKS; ks_++) {
-        bf16x8 kf = *(const bf16x8*)(ks + lds_off<KROWB>(row, 2 * ks_ + h));
+        bf16x8 kf = *(const bf16x8*)(ks + koff(row, 2 * ks_ + h));
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks_], sacc, 0, 0, 0);
         bf16x8 vf = *(const bf16x8*)(vs + lds_off<KROWB>(row, 2 * ks_ + h));
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks_], dpacc, 0, 0, 0);
@@ -210,7 +227,14 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
         const int trow = 32 * dt + l31;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-          bf16x8 tf = *(const bf16x8*)(ts + lds_off<128>(trow, 4 * sb + 2 * m + h));
+          bf16x8 tf;
+          if (TR) {       // K^T[d = 32 dt + l31][keys 32 sb + 16 m + 8 h + 0..7] from the row-major K tile: two transposing reads (keys +0..3, +4..7)
+            const char* r0 = ks + (tr_base ^ ((4 * dt) << 4)) + (32 * sb + 16 * m) * 256;
+            const char* r1 = ks + (tr_base ^ (((4 * dt) ^ 1) << 4)) + (32 * sb + 16 * m + 4) * 256;
+            tf = lds_tr16x2(r0, r1);
+          } else {
+            tf = *(const bf16x8*)(ts + lds_off<128>(trow, 4 * sb + 2 * m + h));
+          }
           acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[m], acc[dt], 0, 0, 0);
         }
       }
@@ -618,6 +642,183 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// dK/dV kernel, third generation (head_dim 128): the dkv2 schedule WITHOUT the pre-transposed operand copies.  dK^T += Q^T dS and dV^T += dO^T P
+// contract over the QUERIES of the tile; dkv2 read those A operands from separate head-major transposed copies (Q^T from the QKV epilogue
+// kernel, dO^T from the prep kernel), i.e. every query tile came in twice — 64 KiB of LDS-DMA per tile (8 one-KiB pieces per wave at 60-185 issue
+// cycles each, and 1500 cycles of LDS fill at the measured 43.7 B/clk), next to 4096 MFMA cycles per SIMD.  Here the k-fragments are gathered from
+// the SAME row-major Q / dO tile images that feed S = Q K^T and dP = dO V^T, by the transposing LDS read (two ds_read_b64_tr_b16 per fragment: a
+// 16-lane group fetches a [4 queries][16 channels] block, lane j receives channel j of the 4 queries).  Half the DMA pieces, half the fill, no Q^T /
+// dO^T buffers in HBM at all (the QKV epilogue kernel and the prep kernel stop writing them).
+// Tile image: row = query (256 B), 16-byte chunk c stored at c ^ f(row), f = swz_q.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                         const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                         const bf16* __restrict__ dO, int64_t ld_do,
+                                                         const float* __restrict__ lsep, const float* __restrict__ delta,
+                                                         const float* __restrict__ key_bias, bf16* __restrict__ dK,
+                                                         bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, float scale,
+                                                         float scale2) {
+  constexpr int HD = 128;
+  constexpr int QROWB = HD * 2;
+  constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major): 16 KiB each
+  constexpr int STAT_BYTES = 2 * 64 * 4;
+  constexpr int BUF = 2 * QT_BYTES + STAT_BYTES;
+  constexpr int NKS = HD / 16, NDT = HD / 32;
+  constexpr int QPW = QT_BYTES / 1024 / 8;   // 1-KiB DMA pieces per wave per tile image (2)
+  constexpr int CPR = QROWB / 16;            // 16-byte chunks per row (16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + head;
+  const int key = blockIdx.x * 256 + wv * 32 + l31;
+  const int keyi = min(key, Sk - 1);
+
+  const bf16* Qg = Q + bh * (int64_t)Sq * HD;
+  const bf16* dOg = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
+  const float* lse_g = lsep + bh * (int64_t)Sqp;
+  const float* del_g = delta + bh * (int64_t)Sqp;
+
+  bf16x8 kf[NKS], vf[NKS];
+  {
+    const bf16* krow = K + (bh * Sk + keyi) * (int64_t)HD + 8 * h;
+    const bf16* vrow = Vrows + ((int64_t)b * Sk + keyi) * ld_v + (int64_t)head * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      kf[ks] = *(const bf16x8*)(krow + 16 * ks);
+      vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
+    }
+  }
+  const float kb2 = key_bias ? key_bias[(int64_t)b * Sk + keyi] * LOG2E : 0.f;
+
+  f32x16 acc_dk[NDT], acc_dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_dk[dt][r] = 0.f; acc_dv[dt][r] = 0.f; }
+
+  auto stage = [&](int qt, int buf) {
+    const int qq0 = qt * 64;
+    char* qs = smem + buf * BUF;
+    char* gs = qs + QT_BYTES;
+    char* stat = gs + QT_BYTES;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));     // everything below is re-derived from the lane id each tile (never spilled, never hoisted)
+#pragma unroll
+    for (int p = 0; p < QPW; p++) {
+      const int piece = wv + 8 * p;                                // wave-uniform
+      const int idx = piece * 64 + ln;                             // linear 16-byte chunk index inside the tile image
+      const int row = idx / CPR;                                   // tile row = query
+      const int col = ((idx % CPR) ^ swz_q(row)) * 8;              // LDS chunk position c holds source chunk c ^ f(row)
+      const int qq = min(qq0 + row, Sq - 1);
+      a_glds16(Qg + (uint32_t)(qq * HD + col), qs + piece * 1024);
+      a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + piece * 1024);
+    }
+    if (wv == 0) a_glds4(lse_g + qq0 + ln, stat);
+    if (wv == 1) a_glds4(del_g + qq0 + ln, stat + 256);
+  };
+
+  const int nqt = (Sq + 63) / 64;
+  // row fragments (S and dP phases): row = perm23 order, chunk (2 ks + h) ^ f(row)
+  const int qrow_p = perm23(l31);
+  const int q_base0 = qrow_p * 256 + ((h ^ swz_q(qrow_p)) << 4);
+  // transposed fragments (dV / dK phases): lane = 16 g + 4 r + s;  ihalf = g & 1 picks the 16-channel half of the 32-channel d tile, the lane's
+  // address is query 8h + r (+ 4 for the second read, + 16 m + 32 qb) of the tile, channels 16 ihalf + 4 s .. + 3 of d tile dt:
+  //   byte = query * 256 + ((chunk ^ f(query)) << 4) + (s & 1) * 8,  chunk = 4 dt + 2 ihalf + (s >> 1),  f(query) = 4 r + 2 h + jsel
+  const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
+  const int t_base0 = (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;
+  const int s_base0 = 2 * QT_BYTES + 32 * h;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int qt = 0; qt < nqt; qt++) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);      // the other buffer's last reads finished before the previous barrier
+    int q_base = q_base0 + buf * BUF, t_base = t_base0 + buf * BUF, s_base = s_base0 + buf * BUF;
+    asm volatile("" : "+v"(q_base), "+v"(t_base), "+v"(s_base));
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+      for (int k2 = 0; k2 < NKS; k2 += 2) {
+        const char* q0p = smem + (q_base ^ ((2 * k2) << 4)) + qb * 32 * QROWB;
+        const char* q1p = smem + (q_base ^ ((2 * k2 + 2) << 4)) + qb * 32 * QROWB;
+        bf16x8 qf0 = *(const bf16x8*)(q0p);
+        bf16x8 qf1 = *(const bf16x8*)(q1p);
+        bf16x8 gf0 = *(const bf16x8*)(q0p + QT_BYTES);
+        bf16x8 gf1 = *(const bf16x8*)(q1p + QT_BYTES);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf0, kf[k2], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf0, vf[k2], dpacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1, kf[k2 + 1], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf1, vf[k2 + 1], dpacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+#pragma unroll
+        for (int q4 = 0; q4 < 2; q4++) {
+          const float* sp = (const float*)(smem + s_base) + 32 * qb + 16 * m + 4 * q4;
+          const f32x4 lse4 = *(const f32x4*)sp;
+          const f32x4 del4 = *(const f32x4*)(sp + 64);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int ri = 8 * m + 4 * q4 + r;
+            const float pr = fast_exp2(sacc[ri] * scale2 + kb2 - lse4[r]);
+            const float dsv = pr * (dpacc[ri] - del4[r]);
+            pf[m][4 * q4 + r] = f2bf(pr);
+            dsf[m][4 * q4 + r] = f2bf(dsv);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // dV^T[d, key] += dO^T[d, q] P[q, key];  dK^T[d, key] += Q^T[d, q] dS[q, key]:  A fragments (rows d = 32 dt + l31, k-slots = queries
+      // 32 qb + 16 m + 8 h + 0..7) by two transposing reads each (queries +0..3, +4..7).  One (dt, m) at a time: 8 fragment registers live, not 16
+      // (the kernel sits at the 256-VGPR limit; the partner wave of the SIMD covers the LDS latency)
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+          const char* r0 = smem + (t_base ^ ((4 * dt) << 4)) + (32 * qb + 16 * m) * QROWB;            // queries + 0..3
+          const char* r1 = smem + (t_base ^ (((4 * dt) ^ 1) << 4)) + (32 * qb + 16 * m + 4) * QROWB;  // queries + 4..7  (f gains jsel = 1)
+          const bf16x8 qtf = lds_tr16x2(r0, r1);
+          const bf16x8 gtf = lds_tr16x2(r0 + QT_BYTES, r1 + QT_BYTES);
+          acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf[m], acc_dv[dt], 0, 0, 0);
+          acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[m], acc_dk[dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (key < Sk) {
+    bf16* krow = dK + (bh * Sk + key) * (int64_t)HD;
+    bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+          ok[bb] = f2bf(acc_dk[dt][4 * a + bb] * scale);
+          ov[bb] = f2bf(acc_dv[dt][4 * a + bb]);
+        }
+        *(bf16x4*)(krow + 32 * dt + 8 * a + 4 * h) = ok;
+        *(bf16x4*)(vrow + 32 * dt + 8 * a + 4 * h) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {   // S, Sp: the QUERY length and its padding
@@ -628,14 +829,17 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
                               int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp, int Sk, int Skp,
                               int d, float scale, void* workspace) {
-  ST_REQUIRE(Q && K && Qt && Kt && v_rows && O && dO && lse2 && dQ && dK && dv_rows && workspace, "attn_bwd: null pointer");
+  ST_REQUIRE(Q && K && v_rows && O && dO && lse2 && dQ && dK && dv_rows && workspace, "attn_bwd: null pointer");
+  // Qt == NULL selects the third-generation dK/dV kernel, Kt == NULL the transposing-read dQ kernel (head_dim 128): Q^T / dO^T / K^T fragments come
+  // from the row-major tiles by ds_read_b64_tr_b16 instead of pre-transposed head-major copies
+  ST_REQUIRE((Qt && Kt) || d == 128, "attn_bwd: Qt / Kt may only be omitted for head_dim 128 (got %d)", d);
   ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && Sk > 0 && Skp % 64 == 0 && Skp >= Sk, "attn_bwd: bad shape S=%d Sp=%d Sk=%d Skp=%d", S, Sp, Sk, Skp);
   ST_REQUIRE(ld_v % 8 == 0 && ld_o % 8 == 0 && ld_do % 8 == 0 && ld_dv % 4 == 0, "attn_bwd: leading dimensions must be multiples of 8");
   ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
   if (d != 128 && d != 64 && d != 96) { st355_set_error("attn_bwd: head_dim %d not built", d); return ST355_ENOSYS; }
   float* delta = (float*)workspace;
   float* lsep = (float*)((char*)workspace + round256((size_t)B * H * Sp * sizeof(float)));
-  bf16* dOt = (bf16*)((char*)workspace + 2 * round256((size_t)B * H * Sp * sizeof(float)));
+  bf16* dOt = Qt ? (bf16*)((char*)workspace + 2 * round256((size_t)B * H * Sp * sizeof(float))) : nullptr;
   static int dkv_gen = -1;
   if (dkv_gen < 0) { const char* e = getenv("ST355_ATTN_DKV"); dkv_gen = (e && e[0] == '1') ? 1 : 2; }   // A/B: 1 = first-generation kernel
   const float scale2 = scale * LOG2E;
@@ -655,7 +859,14 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 4.0);
-    if (d == 96 && dkv_gen == 2) {       // head_dim 96 (PixArt's 72, zero-padded): 12 DMA pieces per tile image over the 8 waves
+    if (!Qt) {
+      dim3 grid((Sk + 255) / 256, H, B);
+      const int lds = 2 * (2 * 64 * 256 + 512);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv3, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
+                         (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2);
+    } else if (d == 96 && dkv_gen == 2) {       // head_dim 96 (PixArt's 72, zero-padded): 12 DMA pieces per tile image over the 8 waves
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * 192 + 2 * 96 * 128 + 512);
       static bool set = false;
@@ -716,6 +927,13 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       static bool set = false;
       if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
       hipLaunchKernelGGL(k_attn_bwd_dq<96>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
+                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
+                         scale, scale2);
+    } else if (d == 128 && !Kt) {
+      const int lds = 2 * (2 * 64 * 256);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL((k_attn_bwd_dq<128, true>), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)nullptr,
                          (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
                          scale, scale2);
     } else if (d == 128) {

@@ -382,7 +382,11 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict
     uint32_t* tv = (uint32_t*)(&tile[2][tl * TP + c * 8]);
     const u32x4 qw = *(const u32x4*)&qo, kw = *(const u32x4*)&ko, vw = *(const u32x4*)&vv;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { tq[j] = qw[j]; tk[j] = kw[j]; tv[j] = vw[j]; }
+    for (int j = 0; j < 4; j++) {
+      if (Qt) tq[j] = qw[j];
+      if (Kt) tk[j] = kw[j];
+      tv[j] = vw[j];
+    }
   }
   __syncthreads();
   // transposed rows: each thread emits 8 consecutive tokens of one channel
@@ -392,7 +396,9 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict
     const int d = i >> 3, tc = i & 7;
 #pragma unroll
     for (int w = 0; w < 3; w++) {
-      bf16* dst = (w == 0 ? Qt : (w == 1 ? Kt : Vt)) + (bh * HD + d) * (int64_t)Sp + pbase + tc * 8;
+      bf16* tbase = (w == 0 ? Qt : (w == 1 ? Kt : Vt));
+      if (tbase == nullptr) continue;                 // Qt / Kt are optional: the head_dim-128 backward gathers Q^T / K^T fragments by transposing LDS reads
+      bf16* dst = tbase + (bh * HD + d) * (int64_t)Sp + pbase + tc * 8;
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; e++) o[e] = tile[w][(tc * 8 + e) * TP + d];
@@ -410,11 +416,11 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict
 extern "C" int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const void* wq, const void* wk,
                                       const float* cos, const float* sin, void* Q, void* K, void* Qt, void* Kt, void* Vt, int B,
                                       int H, int d, int S_part, int pos0, int S, int Sp, float eps) {
-  ST_REQUIRE(qkv && cos && sin && Q && K && Qt && Kt && Vt, "qk_norm_rope_fwd: null pointer");
+  ST_REQUIRE(qkv && cos && sin && Q && K && Vt, "qk_norm_rope_fwd: null pointer (Qt / Kt may be NULL: head_dim-128 backward without transposed copies)");
   ST_REQUIRE(ld_qkv % 8 == 0 && Sp % 64 == 0 && Sp >= S && pos0 + S_part <= S && S_part > 0, "qk_norm_rope_fwd: bad shape");
   ST_REQUIRE(d == 128 || d == 64, "qk_norm_rope_fwd: head_dim %d not built", d);
   const double n = (double)B * S_part * H * d;
-  ProfScope ps(stream, ST355_K_QK_ROPE, 20.0 * n, (6.0 + 10.0) * n);
+  ProfScope ps(stream, ST355_K_QK_ROPE, 20.0 * n, (6.0 + 6.0 + (Qt ? 2.0 : 0.0) + (Kt ? 2.0 : 0.0)) * n);
   dim3 grid((S_part + 63) / 64, H, B), block(256);
   if (d == 128)
     hipLaunchKernelGGL(k_qk_norm_rope_fwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)qkv, ld_qkv, (const bf16*)wq,
