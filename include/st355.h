@@ -177,7 +177,8 @@ int st355_ln_modulate_bwd(void* stream, const void* dy, int64_t lddy, const void
  * joint positions pos0 .. pos0+S_part-1 (row b*S + pos0 + t) — one call per stream (txt / img) because their norm weights differ.
  * Outputs (joint sequence length S, padded Sp multiple of 64):
  *   Q,K : [B,H,S,d]  bf16 (normed + rotated);  Qt,Kt,Vt : [B,H,d,Sp] bf16 (transposed copies; pad stays 0)
- * cos,sin: [S,d] fp32 interleave-repeated tables (FluxPosEmbed).  wq,wk: [d] bf16 RMSNorm weights (NULL => no norm). */
+ * cos,sin: [S,d] fp32 interleave-repeated tables (FluxPosEmbed).  wq,wk: [d] bf16 RMSNorm weights (NULL => no norm).
+ * Qt / Kt may be NULL (not written): at head_dim 128 st355_attn_bwd gathers the Q^T / K^T fragments from the row-major tiles by transposing LDS reads. */
 int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const void* wq, const void* wk,
                            const float* cos, const float* sin, void* Q, void* K, void* Qt, void* Kt, void* Vt,
                            int B, int H, int d, int S_part, int pos0, int S, int Sp, float eps);
@@ -195,7 +196,9 @@ int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, c
 size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d);
 /* V is read token-major from the qkv buffer: V[b,pos,h,:] = v_base + ((b*S_rows + pos) * ld_v + h*d) ... see DESIGN.md.
  * v_rows: [B*S, >=H*d] token-major with row stride ld_v (joint order).  dV is written the same way (dv_rows, ld_dv).
- * dQ,dK: [B,H,S,d] bf16. */
+ * dQ,dK: [B,H,S,d] bf16.
+ * Qt, Kt: the pre-transposed [B,H,d,Sp] copies written by st355_qk_norm_rope_fwd — or both NULL at head_dim 128, which selects the kernels that need no
+ * transposed copy of Q, K or dO (ds_read_b64_tr_b16 on the row-major tiles: half the LDS fill of the dK/dV kernel, two HBM buffers less per block). */
 int st355_attn_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt,
                    const void* v_rows, int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do,
                    const float* lse2, const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv,

@@ -30,6 +30,7 @@ from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_N
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+_TRANSPOSED_COPIES = __import__("os").environ.get("ST355_ATTN_BWD_T") == "1"      # A/B switch: keep the pre-transposed Q^T / K^T copies (dkv2 / dq kernels) at head_dim 128
 
 
 # ------------------------------------------------------------------------------------------------
@@ -387,7 +388,13 @@ class FluxTransformer2DModel(nn.Module):
         B, H, hd, S, Sp, dev = env.B, self.H, self.hd, env.S, env.Sp, self.device_
         Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
         mk = torch.zeros if Sp > S else torch.empty
-        Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        Qt = Kt = None
+        if hd != 128 or _TRANSPOSED_COPIES:
+            # head_dim 64: the backward kernels read Q^T / K^T from pre-transposed head-major copies.  head_dim 128 (Flux.1): they gather those
+            # fragments from the row-major tiles with transposing LDS reads (attention_bwd.hip dkv3 / dq<TR>) — two of the five head-major buffers and
+            # their HBM passes are gone
+            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
         return Q, K, Qt, Kt, Vt
 
     def _double_fwd(self, bi: int, img, txt, env, save: bool):

@@ -412,6 +412,11 @@ def test_qk_norm_rope_fwd_bwd(ops, d, H, S_txt, S_img):
     assert torch.equal(Vt[..., :S], v.to(BF16).transpose(2, 3))
     if Sp > S:
         assert Qt[..., S:].abs().max().item() == 0 and Vt[..., S:].abs().max().item() == 0
+    # Qt / Kt are optional outputs (head_dim 128 backward without transposed copies): the other three outputs are unchanged
+    Q2 = torch.zeros_like(Q); K2 = torch.zeros_like(K); Vt2 = torch.zeros_like(Vt)
+    for name, Sp_, pos0 in parts:
+        ops.qk_norm_rope_fwd(qkv, wts[name][0], wts[name][1], cos, sin, Q2, K2, None, None, Vt2, B, H, d, Sp_, pos0, S, Sp)
+    assert torch.equal(Q2, Q) and torch.equal(K2, K) and torch.equal(Vt2, Vt)
     # backward
     dQ = torch.randn(B, H, S, d, device=dev()).to(BF16); dK = torch.randn(B, H, S, d, device=dev()).to(BF16)
     (Qr * dQ.float()).sum().backward(retain_graph=True)
@@ -473,6 +478,12 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
     r3, _ = report("attn bwd dV", dqkv[:, 2 * D:].reshape(B, S, H, d).permute(0, 2, 1, 3), vf.grad)
     assert r1 < 2e-2 and r2 < 2e-2 and r3 < 2e-2
     assert dqkv[:, :2 * D].abs().max().item() == 0
+    if d == 128:
+        # head_dim 128 without the pre-transposed Q^T / K^T / dO^T copies (dkv3 + dq<TR>: transposing LDS reads on the row-major tiles): same math,
+        # same summation order per accumulator -> bit-identical to the kernels that read the copies
+        dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
+        ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
+        assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
 @pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64)])
