@@ -19,8 +19,10 @@
 #define QB 128  // queries per workgroup
 #define KB 64   // keys per tile
 
-template <int HD>
-__global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+// NW = waves per workgroup (32 queries each): 4 = two independent workgroups per CU (default); 8 = ONE 256-query workgroup per CU sharing each K / V^T
+// tile (half the LDS fill and half the global->LDS staging work per MFMA, one barrier domain of 8 waves) — A/B with ST355_ATTN_FWD=3
+template <int HD, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
                                                             bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
                                                             int Sq, int S, int Sp, float scale2) {   // Sq queries; S keys (padded Sp)
@@ -30,15 +32,16 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
   constexpr int BUF = KT_BYTES + VT_BYTES;
   constexpr int NKS = HD / 16;           // MFMA k-steps over the head dim
   constexpr int NDT = HD / 32;           // 32-row d tiles of O^T
-  constexpr int KCH = KT_BYTES / 16 / ATT_THREADS;  // 16-B chunks per thread
-  constexpr int VCH = VT_BYTES / 16 / ATT_THREADS;
+  constexpr int ATT_T = 64 * NW;
+  constexpr int KCH = KT_BYTES / 16 / ATT_T;  // 16-B chunks per thread
+  constexpr int VCH = VT_BYTES / 16 / ATT_T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int head = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + head;
-  const int q0 = blockIdx.x * QB + wv * 32;
+  const int q0 = blockIdx.x * (32 * NW) + wv * 32;
   const int qi = min(q0 + l31, Sq - 1);
 
   const bf16* Kg = K + bh * (int64_t)S * HD;
@@ -64,13 +67,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
     const int key0 = kt * KB;
 #pragma unroll
     for (int p = 0; p < KCH; p++) {
-      const int id = p * ATT_THREADS + tid;
+      const int id = p * ATT_T + tid;
       const int row = id / (HD / 8), c = id % (HD / 8);
       kreg[p] = *(const bf16x8*)(Kg + (int64_t)min(key0 + row, S - 1) * HD + c * 8);
     }
 #pragma unroll
     for (int p = 0; p < VCH; p++) {
-      const int id = p * ATT_THREADS + tid;
+      const int id = p * ATT_T + tid;
       const int row = id >> 3, c = id & 7;
       vreg[p] = *(const bf16x8*)(Vg + (int64_t)row * Sp + key0 + c * 8);
     }
@@ -80,13 +83,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) k_attn_fwd(const bf16* __restr
     char* vs = ks + KT_BYTES;
 #pragma unroll
     for (int p = 0; p < KCH; p++) {
-      const int id = p * ATT_THREADS + tid;
+      const int id = p * ATT_T + tid;
       const int row = id / (HD / 8), c = id % (HD / 8);
       *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
     }
 #pragma unroll
     for (int p = 0; p < VCH; p++) {
-      const int id = p * ATT_THREADS + tid;
+      const int id = p * ATT_T + tid;
       const int row = id >> 3, c = id & 7;
       *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
     }
@@ -409,7 +412,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // A/B switch.  Default = the first-generation kernel (4 waves x 32 queries, 2 independent workgroups per CU, register staging):
   // measured 761-786 TFLOP/s in-step.  ST355_ATTN_FWD=2 selects k_attn_fwd2 (8 waves, LDS-DMA, half-tile stagger): correct (same
   // parity tests) but 635-700 TFLOP/s — the forward is VALU/latency-shaped and loses the decoupling of two independent workgroups.
-  if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '2') ? 2 : 1; }
+  if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '2') ? 2 : ((e && e[0] == '3') ? 3 : 1); }
   if (gen == 2 && Sq == S && d != 96) {
     dim3 grid2((S + 255) / 256, H, B);
     if (d == 128) {
@@ -424,6 +427,21 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
                          key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
     }
     return st355_check_launch("attn_fwd2");
+  }
+  if (gen == 3 && (d == 128 || d == 64)) {
+    dim3 grid3((Sq + 255) / 256, H, B);
+    if (d == 128) {
+      const int lds = 2 * (KB * 256 + 128 * 128);
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL((k_attn_fwd<128, 8>), grid3, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                         key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
+    } else {
+      const int lds = 2 * (KB * 128 + 64 * 128);
+      hipLaunchKernelGGL((k_attn_fwd<64, 8>), grid3, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                         key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
+    }
+    return st355_check_launch("attn_fwd3");
   }
   dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);
   if (d == 96) {                 // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)

@@ -1,0 +1,124 @@
+// attn_lab — standalone attention kernel lab for libst355 (no torch: starts in milliseconds on a fresh GPU box).
+//   tools/attn_lab [B H S d]      default 2 24 4608 128 (Flux.1 1024^2 at per-GPU batch 2)
+// Times st355_attn_fwd (generation picked by ST355_ATTN_FWD = 1 | 2 | 3; the lab re-executes itself once per generation) and st355_attn_bwd with and
+// without the pre-transposed Q^T / K^T copies (dkv2 + dq vs dkv3 + dq<TR>), per kernel class through the library's own hipEvent profiler, and checks
+// that the two backward paths agree bit for bit.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast tools/attn_lab.hip -o tools/attn_lab
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include "../simpletuner_amd/csrc/runtime.hip"
+#include "../simpletuner_amd/csrc/attention.hip"
+#include "../simpletuner_amd/csrc/attention_bwd.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define RC(x) do { int r_ = (x); if (r_) { printf("st355 rc=%d: %s (%s:%d)\n", r_, st355_last_error(), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void k_fill(bf16* p, int64_t n, uint32_t seed, float scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    p[i] = (bf16)(((h >> 8) * (1.f / 8388608.f) - 1.f) * scale);
+  }
+}
+// Xt[b,h,c,s] = X[b,h,s,c] (zero padded to Sp)
+__global__ void k_transpose_heads(const bf16* X, bf16* Xt, int64_t BH, int S, int Sp, int d) {
+  const int64_t n = BH * (int64_t)d * Sp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % Sp); const int c = (int)((i / Sp) % d); const int64_t bh = i / ((int64_t)Sp * d);
+    Xt[i] = s < S ? X[(bh * S + s) * d + c] : (bf16)0.f;
+  }
+}
+// Vt[b,h,c,s] = vrows[(b*S+s)*ld + h*d + c]
+__global__ void k_vt(const bf16* vrows, int64_t ld, bf16* Vt, int B, int H, int S, int Sp, int d) {
+  const int64_t n = (int64_t)B * H * d * Sp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % Sp); const int c = (int)((i / Sp) % d); const int h = (int)((i / ((int64_t)Sp * d)) % H); const int b = (int)(i / ((int64_t)Sp * d * H));
+    Vt[i] = s < S ? vrows[((int64_t)b * S + s) * ld + (int64_t)h * d + c] : (bf16)0.f;
+  }
+}
+__global__ void k_diff(const bf16* a, const bf16* b, int64_t n, int64_t ld, int64_t cols, unsigned long long* bad, float* maxd) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = ld ? (i / cols) * ld + (i % cols) : i;
+    const float x = (float)a[idx], y = (float)b[idx];
+    if (!(x == y)) { atomicAdd(bad, 1ull); atomicMax((int*)maxd, __float_as_int(fabsf(x - y))); }
+  }
+}
+
+static void prof_print(const char* what) {
+  double ms[16]; int64_t la[16]; double fl[16], by[16];
+  st355_prof_collect(ms, la, fl, by, 16);
+  const char* names[] = {"gemm", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_prep"};
+  for (int k = 1; k <= 4; k++)
+    if (la[k]) printf("  %-28s %-13s %8.3f ms/launch  %7.1f TFLOP/s (%lld launches)\n", what, names[k], ms[k] / la[k], fl[k] / ms[k] / 1e9, (long long)la[k]);
+  st355_prof_reset();
+}
+
+int main(int argc, char** argv) {
+  if (!getenv("ATTN_LAB_CHILD")) {
+    const char* gens[] = {"1", "3", "2"};
+    for (const char* g : gens) {
+      setenv("ST355_ATTN_FWD", g, 1); setenv("ATTN_LAB_CHILD", "1", 1);
+      fflush(stdout);
+      if (fork() == 0) { execv(argv[0], argv); _exit(3); }
+      int st; wait(&st);
+    }
+    return 0;
+  }
+  const int B = argc > 4 ? atoi(argv[1]) : 2, H = argc > 4 ? atoi(argv[2]) : 24, S = argc > 4 ? atoi(argv[3]) : 4608, d = argc > 4 ? atoi(argv[4]) : 128;
+  const int Sp = (S + 63) / 64 * 64;
+  const int64_t D = (int64_t)H * d, BH = (int64_t)B * H;
+  const char* gen = getenv("ST355_ATTN_FWD");
+  printf("== attn_lab B%d H%d S%d d%d  forward generation %s\n", B, H, S, d, gen);
+  hipStream_t st; CK(hipStreamCreate(&st));
+  bf16 *Q, *K, *Qt, *Kt, *Vt, *qkv, *O, *dO, *dQ, *dK, *dqkv, *dQ2, *dK2, *dqkv2; float* lse2; void* ws;
+  const size_t nh = (size_t)BH * S * d, nt = (size_t)BH * d * Sp, nr = (size_t)B * S * D;
+  CK(hipMalloc(&Q, nh * 2)); CK(hipMalloc(&K, nh * 2)); CK(hipMalloc(&Qt, nt * 2)); CK(hipMalloc(&Kt, nt * 2)); CK(hipMalloc(&Vt, nt * 2));
+  CK(hipMalloc(&qkv, nr * 3 * 2)); CK(hipMalloc(&O, nr * 2)); CK(hipMalloc(&dO, nr * 2));
+  CK(hipMalloc(&dQ, nh * 2)); CK(hipMalloc(&dK, nh * 2)); CK(hipMalloc(&dqkv, nr * 3 * 2)); CK(hipMalloc(&dQ2, nh * 2)); CK(hipMalloc(&dK2, nh * 2)); CK(hipMalloc(&dqkv2, nr * 3 * 2));
+  CK(hipMalloc(&lse2, (size_t)BH * S * 4)); CK(hipMalloc(&ws, st355_attn_bwd_workspace(B, H, S, Sp, d)));
+  k_fill<<<2048, 256, 0, st>>>(Q, nh, 1u, 1.5f); k_fill<<<2048, 256, 0, st>>>(K, nh, 2u, 1.5f);
+  k_fill<<<2048, 256, 0, st>>>(qkv, nr * 3, 3u, 1.f); k_fill<<<2048, 256, 0, st>>>(dO, nr, 4u, 1.f);
+  k_transpose_heads<<<4096, 256, 0, st>>>(Q, Qt, BH, S, Sp, d); k_transpose_heads<<<4096, 256, 0, st>>>(K, Kt, BH, S, Sp, d);
+  bf16* vrows = qkv + 2 * D;
+  k_vt<<<4096, 256, 0, st>>>(vrows, 3 * D, Vt, B, H, S, Sp, d);
+  CK(hipMemsetAsync(dqkv, 0, nr * 3 * 2, st)); CK(hipMemsetAsync(dqkv2, 0, nr * 3 * 2, st));
+  const float scale = 1.f / sqrtf((float)d);
+  const int iters = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 10;
+  // ---- forward ----
+  RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O, D, lse2, B, H, S, Sp, d, scale));
+  CK(hipStreamSynchronize(st));
+  st355_prof_reset(); st355_prof_enable(1);
+  for (int i = 0; i < iters; i++) RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O, D, lse2, B, H, S, Sp, d, scale));
+  CK(hipStreamSynchronize(st));
+  st355_prof_enable(0); prof_print("forward");
+  if (strcmp(gen, "1") != 0) return 0;    // the backward comparison runs once (in the generation-1 child)
+  // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
+  for (int pass = 0; pass < 2; pass++) {
+    const bf16* qt = pass ? nullptr : Qt; const bf16* kt = pass ? nullptr : Kt;
+    bf16 *dq_ = pass ? dQ2 : dQ, *dk_ = pass ? dK2 : dK, *dv_ = (pass ? dqkv2 : dqkv) + 2 * D;
+    RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
+    CK(hipStreamSynchronize(st));
+    st355_prof_reset(); st355_prof_enable(1);
+    for (int i = 0; i < iters; i++) RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
+    CK(hipStreamSynchronize(st));
+    st355_prof_enable(0); prof_print(pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
+  }
+  if (d != 128) return 0;
+  unsigned long long* bad; float* maxd; CK(hipMalloc(&bad, 8)); CK(hipMalloc(&maxd, 4));
+  struct { const char* n; const bf16* a; const bf16* b; int64_t cnt, ld, cols; } cmp[] = {
+      {"dQ", dQ, dQ2, (int64_t)nh, 0, 0}, {"dK", dK, dK2, (int64_t)nh, 0, 0}, {"dV", dqkv + 2 * D, dqkv2 + 2 * D, (int64_t)nr, 3 * D, D}};
+  for (auto& c : cmp) {
+    CK(hipMemsetAsync(bad, 0, 8, st)); CK(hipMemsetAsync(maxd, 0, 4, st));
+    k_diff<<<2048, 256, 0, st>>>(c.a, c.b, c.cnt, c.ld, c.cols, bad, maxd);
+    unsigned long long hb; float hm;
+    CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    printf("  %s: copies vs no-copies path: %llu of %lld elements differ (max |d| %.3e)  %s\n", c.n, hb, (long long)c.cnt, hm, hb ? "MISMATCH" : "bit-identical");
+  }
+  return 0;
+}
