@@ -92,11 +92,18 @@ def _replica_run(rank, world, family):
     plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
     batch = lambda: {"latent_batch": devt["latents"][sl].contiguous(), "prompt_embeds": devt["prompt"][sl].contiguous(),
                      "add_text_embeds": devt["pooled"][sl].contiguous(), "noise": devt["noise"][sl].contiguous()}
+    # one backward by hand first: the synchronised (rank-summed, then 1/world-scaled) gradient itself, before any optimizer touches it
+    prepared = plugin.prepare_batch(batch(), {"global_step": 0})
+    loss0, _ = plugin.loss_with_logs(prepared, plugin.model_predict(prepared))
+    loss0.backward()
+    gscale = getattr(comp, "grad_scale_from_sync", 1.0) if world > 1 else 1.0
+    grad = (torch.cat([p.grad.detach().reshape(-1).float() for p in trainer.params]) * gscale).cpu()
+    trainer.optimizer.zero_grad(set_to_none=True)
     losses = [trainer.train_step(batch()) for _ in range(_K_STEPS)]
     torch.cuda.synchronize()
     ops_seen = list(comp.grad_sync.launched_ops) if world > 1 else []
     flat = torch.cat([p.detach().reshape(-1).float() for p in trainer.params]).cpu()
-    return flat, [float(l) for l in losses], ops_seen
+    return flat, [float(l) for l in losses], ops_seen, grad
 
 
 def _replica_worker(rank, world, init_file, out_dir):
@@ -112,10 +119,16 @@ def test_two_replicas_equal_one_process_on_the_concatenated_batch():
         mp.spawn(_replica_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
         r0, r1 = (torch.load(os.path.join(d, f"rep{r}.pt")) for r in range(2))
     for fam in ("flux", "sd3"):
-        single, single_losses, _ = _replica_run(0, 1, fam)
-        w0, l0, ops0 = r0[fam]
-        w1, l1, _ = r1[fam]
+        single, single_losses, _, g_single = _replica_run(0, 1, fam)
+        w0, l0, ops0, g0 = r0[fam]
+        w1, l1, _, g1 = r1[fam]
         assert torch.equal(w0, w1), f"{fam}: the two replicas diverged"                      # identical reduced gradients -> identical weights
+        # the averaged gradient of the two replicas == the gradient of one process on the concatenated batch (same on both ranks, bit for bit)
+        assert torch.equal(g0, g1)
+        g_rel = ((g0 - g_single).norm() / g_single.norm()).item()
+        print(f"[parity] {fam}: synchronised gradient vs single-process gradient on the concatenated batch: rel-L2 = {g_rel:.3e}, "
+              f"max |dg| = {(g0 - g_single).abs().max().item():.3e} (max |g| {g_single.abs().max().item():.3e})")
+        assert g_rel < (1e-5 if fam == "flux" else 6e-3)            # fp32 adapter arena: summation order only; bf16 arena: two bf16 roundings + a bf16 sum
         kinds = {k for k, _, _ in ops0}
         assert kinds and (("reduce_scatter" in kinds and "all_gather" in kinds) if fam == "sd3" else kinds == {"all_reduce"}), kinds
         # the logged loss is the sample-weighted mean over ranks == the single process's batch mean
@@ -128,9 +141,11 @@ def test_two_replicas_equal_one_process_on_the_concatenated_batch():
               f"(lr*K = {_LR * _K_STEPS:.1e}), exact-equal fraction = {(diff == 0).float().mean().item():.4f}")
         if fam == "flux":                                   # fp32 adapter arena: only the summation order of the rank-space gradient differs
             assert diff.max().item() <= 0.02 * _LR * _K_STEPS
-        else:                                               # bf16 weights: at most ~1 bf16 ulp of the value (gradients are summed across ranks in bf16)
-            ulp = single.abs().clamp_min(1e-3) * 2.0 ** -7
-            assert (diff <= 2 * ulp).all() and (diff <= ulp).float().mean().item() > 0.999
+        else:
+            # bf16 weights after K AdamW steps: Adam's m / (sqrt(v) + eps) is a SIGN-like step for elements whose gradient sits at the bf16 noise
+            # floor, so the two computations can move such an element by up to lr per step in opposite directions (measured r2: 95 % of the elements
+            # bit-equal, max |dw| 2.9e-3 = lr*K).  The gradient check above is the exactness statement; here: bounded by the optimizer's reach
+            assert diff.max().item() <= 2.05 * _LR * _K_STEPS and (diff == 0).float().mean().item() > 0.9
 
 
 def test_native_rccl_comm_single_rank_collectives_and_grad_sync():
