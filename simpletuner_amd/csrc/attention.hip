@@ -13,6 +13,7 @@
 //   * register-staged double buffering: next tile's global loads are issued before the MFMA work and
 //     written to the other LDS buffer after it (T14 async-stage split).
 #include <stdlib.h>
+#include <type_traits>
 #include "attn_common.h"
 
 #define ATT_THREADS 256
@@ -123,22 +124,33 @@ __global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict_
       }
     }
     // ---- scale, bias, mask; online softmax ----
+    // ONE wave-uniform branch per tile picks the variant (plain / ragged last tile / per-key bias): a per-element `if (key_bias || tail)` inside the
+    // unrolled 32-score loop compiled to 96 scalar branches and 32 separately guarded loads per tile, i.e. 32 tiny basic blocks the scheduler could
+    // not interleave with anything (r2: found in the .s; the common case is now 32 v_mul + max3 chains in one block)
     float p[2][16];
     const bool tail = (key0 + KB > S);
     float mt = -INFINITY;
+    auto scores = [&](auto bias_c, auto tail_c) {
+      constexpr bool BIAS = decltype(bias_c)::value, TAIL = decltype(tail_c)::value;
 #pragma unroll
-    for (int sb = 0; sb < 2; sb++)
+      for (int sb = 0; sb < 2; sb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float s = sacc[sb][r] * scale2;
-        if (key_bias != nullptr || tail) {
-          const int key = key0 + 32 * sb + acc_row(r, h);
-          if (key_bias != nullptr) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
-          if (key >= S) s = -INFINITY;
+        for (int r = 0; r < 16; r++) {
+          float s = sacc[sb][r];
+          if (BIAS || TAIL) {
+            s *= scale2;
+            const int key = key0 + 32 * sb + acc_row(r, h);
+            if (BIAS) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
+            if (key >= S) s = -INFINITY;
+          }
+          p[sb][r] = s;                      // plain tiles keep the RAW score: the scale rides in the exponent's fma below
+          mt = fmaxf(mt, s);
         }
-        p[sb][r] = s;
-        mt = fmaxf(mt, s);
-      }
+    };
+    float psc = 1.f;                         // factor still to be applied to p[][] inside exp2(p * psc - m)
+    if (key_bias != nullptr) scores(std::true_type{}, std::true_type{});
+    else if (tail) scores(std::false_type{}, std::true_type{});
+    else { scores(std::false_type{}, std::false_type{}); mt *= scale2; psc = scale2; }      // scale2 > 0: max(scale2 * s) = scale2 * max(s)
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
     const float alpha = fast_exp2(m_run - m_new);
@@ -148,7 +160,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict_
     for (int sb = 0; sb < 2; sb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        p[sb][r] = fast_exp2(p[sb][r] - m_new);
+        p[sb][r] = fast_exp2(fmaf(p[sb][r], psc, -m_new));
         ls += p[sb][r];
       }
     l_run = l_run * alpha + ls;

@@ -9,6 +9,7 @@
 // are read from pre-transposed head-major copies (written by the QKV epilogue kernel / prep), never transposed
 // in LDS.
 #include <stdlib.h>
+#include <type_traits>
 #include "attn_common.h"
 
 #define TPB 130
@@ -206,19 +207,26 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks_], dpacc, 0, 0, 0);
       }
       float ds[16];
+      // one wave-uniform branch per 32-key sub-block (plain / ragged last tile / per-key bias) instead of a guarded block per score (see attention.hip)
+      auto dscores = [&](auto bias_c, auto tail_c) {
+        constexpr bool BIAS = decltype(bias_c)::value, TAIL = decltype(tail_c)::value;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float s = sacc[r] * scale2;
-        float pv;
-        if (key_bias != nullptr || tail) {
-          const int key = key0 + 32 * sb + acc_row(r, h);
-          if (key_bias != nullptr) s += key_bias[(int64_t)b * Sk + min(key, Sk - 1)] * LOG2E;
-          pv = (key < Sk) ? fast_exp2(s - lse_q) : 0.f;
-        } else {
-          pv = fast_exp2(s - lse_q);
+        for (int r = 0; r < 16; r++) {
+          float s = sacc[r] * scale2;
+          float pv;
+          if (BIAS || TAIL) {
+            const int key = key0 + 32 * sb + acc_row(r, h);
+            if (BIAS) s += key_bias[(int64_t)b * Sk + min(key, Sk - 1)] * LOG2E;
+            pv = (key < Sk) ? fast_exp2(s - lse_q) : 0.f;
+          } else {
+            pv = fast_exp2(s - lse_q);
+          }
+          ds[r] = pv * (dpacc[r] - delta_q);
         }
-        ds[r] = pv * (dpacc[r] - delta_q);
-      }
+      };
+      if (key_bias != nullptr) dscores(std::true_type{}, std::true_type{});
+      else if (tail) dscores(std::false_type{}, std::true_type{});
+      else dscores(std::false_type{}, std::false_type{});
       bf16x8 dsf[2];
       dsf[0] = pack8(&ds[0]);
       dsf[1] = pack8(&ds[8]);
