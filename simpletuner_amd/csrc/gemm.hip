@@ -189,7 +189,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[NI][
 // 128-byte lines, and the epilogue arithmetic is still done once in fp32 before the single rounding to bf16.
 #define EPL_PITCH 272                         // bytes per staged token row: 64 fp32 + 16 B pad (bank spread for the b128 writes)
 #define EPL_WAVE (64 * EPL_PITCH)             // 17 KiB per wave
-template <int EPI>
+// CONV / F8: compile-time gates of the convolution (border zeroing, per-image add) and fp8 (row scales) code, so the plain bf16 GEMM carries none of it
+template <int EPI, bool CONV = true, bool F8 = true>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
   const int khalf = lane >> 5, l31 = lane & 31;
   const int rrow = lane >> 3, rc = lane & 7;          // read side: 8 lanes per token row, 8 features each
@@ -203,6 +204,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
 #pragma unroll
     for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
   }
+  // row pointers advance by 8 rows per read-back step: ONE 64-bit multiply per operand up front, then adds of wave-uniform strides (the per-row
+  // `m * ld` form cost ~6 quarter-rate integer instructions per operand per row — as many issue cycles as the GELU arithmetic itself)
+  const int m_first = mw0 + rrow;
+  bf16* c_row = p.C + (int64_t)m_first * p.ldc + n;
+  const bf16* in_row = p.aux_in ? p.aux_in + (int64_t)m_first * p.ld_aux_in + n : nullptr;
+  bf16* out_row = p.aux_out ? p.aux_out + (int64_t)m_first * p.ld_aux_out + n : nullptr;
+  float* part_row = (EPI == EPI_SPLITK) ? p.partial + (int64_t)m_first * p.part_ld + n : nullptr;
+  const int64_t c_step = 8 * p.ldc, in_step = 8 * p.ld_aux_in, out_step = 8 * p.ld_aux_out, part_step = 8 * p.part_ld;
 #pragma unroll
   for (int ps = 0; ps < 2; ps++) {
     // write: token row jj*32 + l31, features i*32 + 8a + 4khalf .. +4
@@ -224,17 +233,21 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
       const int m = mw0 + ps * 64 + row;
       const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
       const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      bf16* const c_ptr = c_row;
+      const bf16* const in_ptr = in_row;
+      bf16* const out_ptr = out_row;
+      float* const part_ptr = part_row;
+      c_row += c_step; in_row += in_step; out_row += out_step; part_row += part_step;
       if (m >= p.M || !n_ok) continue;
       if (EPI == EPI_SPLITK) {                        // fp32 K-slice slab (p.partial already points at this slice)
-        float* dst = p.partial + (int64_t)m * p.part_ld + n;
-        *(f32x4*)dst = lo;
-        *(f32x4*)(dst + 4) = hi;
+        *(f32x4*)part_ptr = lo;
+        *(f32x4*)(part_ptr + 4) = hi;
         continue;
       }
       int img = 0;
-      const bool border = p.conv_taps ? conv_border(p, m, img) : false;
+      const bool border = (CONV && p.conv_taps) ? conv_border(p, m, img) : false;
       float v[8];
-      if (p.scale_b) {                                  // fp8 Linear: row-wise scaling of torch._scaled_mm (fp8_native.py:64-75)
+      if (F8 && p.scale_b) {                            // fp8 Linear: row-wise scaling of torch._scaled_mm (fp8_native.py:64-75)
         const float sa = p.scale_a[0];
         const f32x4 s0 = *(const f32x4*)(p.scale_b + n), s1 = *(const f32x4*)(p.scale_b + n + 4);
 #pragma unroll
@@ -243,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
 #pragma unroll
         for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
       }
-      if (p.img_add) {
+      if (CONV && p.img_add) {
         const bf16x8 tv = *(const bf16x8*)(p.img_add + (int64_t)img * p.img_add_stride + n);
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] += bf2f(tv[b]);
@@ -253,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
           bf16x8 pre;
 #pragma unroll
           for (int b = 0; b < 8; b++) pre[b] = f2bf(v[b]);
-          *(bf16x8*)(p.aux_out + (int64_t)m * p.ld_aux_out + n) = pre;
+          *(bf16x8*)out_ptr = pre;
 #pragma unroll
           for (int b = 0; b < 8; b++) v[b] = bf2f(pre[b]);   // activation of the stored (rounded) pre-activation
         }
@@ -264,26 +277,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
           bf16x8 yv;
 #pragma unroll
           for (int b = 0; b < 8; b++) yv[b] = f2bf(v[b]);
-          *(bf16x8*)(p.aux_out + (int64_t)m * p.ld_aux_out + n) = yv;
+          *(bf16x8*)out_ptr = yv;
         }
         const int64_t bidx = (int64_t)(m / p.rows_per_batch);
         const bf16x8 gv = *(const bf16x8*)(p.gate + bidx * p.gate_stride + n);
-        const bf16x8 rv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+        const bf16x8 rv = *(const bf16x8*)in_ptr;
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] = bf2f(rv[b]) + bf2f(gv[b]) * v[b];
       } else if (EPI == ST355_EPI_ADD) {
-        const bf16x8 rv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+        const bf16x8 rv = *(const bf16x8*)in_ptr;
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] += bf2f(rv[b]);
       } else if (EPI == ST355_EPI_MUL_GELU_GRAD) {
-        const bf16x8 hv = *(const bf16x8*)(p.aux_in + (int64_t)m * p.ld_aux_in + n);
+        const bf16x8 hv = *(const bf16x8*)in_ptr;
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] *= gelu_tanh_grad(bf2f(hv[b]));
       }
       bf16x8 o;
 #pragma unroll
       for (int b = 0; b < 8; b++) o[b] = f2bf(border ? 0.f : v[b]);
-      *(bf16x8*)(p.C + (int64_t)m * p.ldc + n) = o;
+      *(bf16x8*)c_ptr = o;
     }
   }
 }
@@ -431,167 +444,7 @@ __global__ void __launch_bounds__(P3_THREADS, 2) k_gemm_p3(GemmGroup g) {
   gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
-// =================================================================================================
-// k_gemm_p4: 256x256 tile, BK=32, FOUR-slot LDS-DMA ring (4 x 32 KiB), 8 waves (2 x 4), wave tile 128 tokens x 64 features.
-// Doubling the wave tile halves the LDS bytes read per MFMA (0.75 -> 6 fragments per 8 MFMAs vs 4 per 4), which is what
-// bounds k_gemm_p3 (LDS ~80 % busy at 34 % MFMA utilisation).  Loads are issued three K-slots ahead; vmcnt(8) retires the
-// slot needed next (4 LDS-DMAs per wave per slot) and leaves two slots in flight across the raw barrier; fragment loads are
-// software-pipelined one k-step ahead (across slots), and MFMA clusters run at raised wave priority (T5).
-// LDS rows are 64 B: chunk' = chunk ^ ((row>>2)&3) spreads a 16-lane ds_read_b128 group over all 16 slots of a 256-B bank row.
-// =================================================================================================
-#define P4_BM 256
-#define P4_BN 256
-#define P4_BK 32
-#define P4_THREADS 512
-#define P4_XBYTES (P4_BM * P4_BK * 2)       // 16 KiB
-#define P4_SLOT (2 * P4_XBYTES)             // 32 KiB
-#define P4_LDS (4 * P4_SLOT)                // 128 KiB
-
-template <int EPI>
-__global__ void __launch_bounds__(P4_THREADS, 2) k_gemm_p4(GemmGroup g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;     // 2 (tokens, 128 each) x 4 (features, 64 each)
-
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int pi = id >= g.tiles0 ? 1 : 0;
-  if (pi) id -= g.tiles0;
-  const GemmP& p = g.p[pi];
-  const int nbm = (p.M + P4_BM - 1) / P4_BM, nbn = (p.N + P4_BN - 1) / P4_BN;
-  int pm, pn;
-  tile_coords(id, nbm, nbn, pm, pn);
-  const int m0 = pm * P4_BM, n0 = pn * P4_BN;
-  const int nt1 = p.K / P4_BK;
-  const int nt = nt1 + p.K2 / P4_BK;
-
-  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
-  const int64_t la2 = p.lda2, lb2 = p.ldb2;
-  const int M = p.M, N = p.N;
-  // staging: one LDS-DMA instruction = 16 rows x 64 B; this wave issues instructions 2wv, 2wv+1 of the X and of the W tile
-  const int st_row = lane >> 2, st_cp = lane & 3;
-  int64_t xo[2], wo[2];
-  int xrow[2], wrow[2], sc[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int row = (wv * 2 + j) * 16 + st_row;
-    sc[j] = (st_cp ^ ((row >> 2) & 3)) * 8;
-    xrow[j] = min(m0 + row, M - 1);
-    wrow[j] = min(n0 + row, N - 1);
-    xo[j] = (int64_t)xrow[j] * p.lda + sc[j];
-    wo[j] = (int64_t)wrow[j] * p.ldb + sc[j];
-  }
-  auto stage = [&](int t, int slot) {
-    char* xs = smem + slot * P4_SLOT;
-    char* ws = xs + P4_XBYTES;
-    if (t < nt1) {
-      const int k0 = t * P4_BK;
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        glds16(A1 + xo[j] + k0, xs + (wv * 2 + j) * 1024);
-        glds16(B1 + wo[j] + k0, ws + (wv * 2 + j) * 1024);
-      }
-    } else {
-      const int k0 = (t - nt1) * P4_BK;
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        glds16(A2 + (int64_t)xrow[j] * la2 + sc[j] + k0, xs + (wv * 2 + j) * 1024);
-        glds16(B2 + (int64_t)wrow[j] * lb2 + sc[j] + k0, ws + (wv * 2 + j) * 1024);
-      }
-    }
-  };
-
-  int w_off[2], w_sw[2], x_off[4], x_sw[4];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int wr = wn * 64 + i * 32 + (lane & 31);
-    w_off[i] = wr * 64; w_sw[i] = (wr >> 2) & 3;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int xr = wm * 128 + j * 32 + (lane & 31);
-    x_off[j] = xr * 64; x_sw[j] = (xr >> 2) & 3;
-  }
-  const int khalf = lane >> 5;
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  // Software-pipelined fragment loads: the ring invariant is shifted by one iteration (slot t+1 is landed AND published
-  // before iteration t starts), so while the MFMAs of one k-step run, the ds_read_b128s of the next k-step — possibly of the
-  // next slot — are already in flight.  LDS latency no longer serialises with the matrix pipe after every barrier.
-  auto load_frags = [&](int slot, int ks, bf16x8 (&wf)[2], bf16x8 (&xf)[4]) {
-    const char* xs = smem + slot * P4_SLOT;
-    const char* ws = xs + P4_XBYTES;
-    const int c = 2 * ks + khalf;
-#pragma unroll
-    for (int i = 0; i < 2; i++) wf[i] = *(const bf16x8*)(ws + w_off[i] + ((c ^ w_sw[i]) << 4));
-#pragma unroll
-    for (int j = 0; j < 4; j++) xf[j] = *(const bf16x8*)(xs + x_off[j] + ((c ^ x_sw[j]) << 4));
-  };
-  auto mma8 = [&](const bf16x8 (&wf)[2], const bf16x8 (&xf)[4]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  // ---- prologue: three slots in flight; slot 0 retired and published ----
-  stage(0, 0);
-  if (nt > 1) stage(1, 1);
-  if (nt > 2) stage(2, 2);
-  if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  bf16x8 wa[2], xa[4], wb[2], xb[4];
-  load_frags(0, 0, wa, xa);
-  for (int t = 0; t < nt; t++) {
-    const int cur = t & 3;
-    if (t + 3 < nt) stage(t + 3, (t + 3) & 3);        // slot (t-1)&3: its last reads completed before the previous barrier
-    load_frags(cur, 1, wb, xb);                       // k-step 1 of this slot, in flight under the first MFMA cluster
-    mma8(wa, xa);
-    if (t + 1 < nt) {
-      // retire + publish slot t+1 (the oldest outstanding); slots t+2, t+3 stay in flight across the barrier
-      if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of slot `cur` has landed: it may be refilled after the barrier
-      __builtin_amdgcn_s_barrier();
-      load_frags((t + 1) & 3, 0, wa, xa);             // k-step 0 of the next slot, in flight under the second MFMA cluster
-    }
-    mma8(wb, xb);
-  }
-  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-}
-
-// =================================================================================================
-// k_gemm_pp: 256x256 tile, BK=32, four-slot LDS-DMA ring — the PING-PONG schedule (cdna_hip_programming.md T3+T4+T5).
-// The 8 waves are two groups (wm = 0 / 1 = the two 128-token halves; one wave of each group per SIMD).  Group 1 runs ONE
-// barrier behind group 0, so in every barrier interval one wave of each SIMD issues its 8 MFMAs (256 matrix-pipe cycles, at
-// raised priority) while its partner issues the ds_read_b128s of its next phase + one LDS-DMA piece: the matrix pipe never
-// waits for LDS latency, and the loads never wait for the matrix pipe.
-// A k-step (K=32, slot = t&3) is two phases:  A(t): W(64 feat) x X0(64 tok) -> acc[:,0:2];  B(t): W(kept) x X1 -> acc[:,2:4].
-// Ring protocol (q = global phase, R_q / M_q = its load / MFMA section):
-//   * W(t+2) is issued in R_A(t), X(t+3) in R_B(t): a region is refilled >= 2 phases after its last read (one phase for the
-//     lgkmcnt, one for the other group's stagger) — WAR-safe without extra barriers;
-//   * the only VM wait is at the end of R_B(t): vmcnt(6) retires everything of k-step t+1 (three 2-piece issues stay in
-//     flight across the barriers); k-step t+1 is first read one phase later (R_A(t+1)) — RAW-safe for both groups.
-// =================================================================================================
-#define PP_BM 256
-#define PP_BN 256
-#define PP_BK 32
-#define PP_THREADS 512
-#define PP_XBYTES (PP_BM * PP_BK * 2)       // 16 KiB
-#define PP_SLOT (2 * PP_XBYTES)             // 32 KiB
-#define PP_LDS (4 * PP_SLOT)                // 128 KiB
+// raw workgroup barrier (no vmcnt / lgkmcnt drain: the schedule keeps LDS-DMA in flight across it and waits with counted s_waitcnt)
 #define PP_BARRIER()                                   \
   do {                                                 \
     asm volatile("" ::: "memory");                     \
@@ -599,160 +452,10 @@ __global__ void __launch_bounds__(P4_THREADS, 2) k_gemm_p4(GemmGroup g) {
     asm volatile("" ::: "memory");                     \
   } while (0)
 
-template <int EPI>
-__global__ void __launch_bounds__(PP_THREADS, 2) k_gemm_pp(GemmGroup g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;     // wm: group (128-token half); wn: 64-feature column of the tile
-
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int pi = id >= g.tiles0 ? 1 : 0;
-  if (pi) id -= g.tiles0;
-  const GemmP& p = g.p[pi];
-  const int nbm = (p.M + PP_BM - 1) / PP_BM, nbn = (p.N + PP_BN - 1) / PP_BN;
-  int pm, pn;
-  tile_coords(id, nbm, nbn, pm, pn);
-  const int m0 = pm * PP_BM, n0 = pn * PP_BN;
-  const int nt1 = p.K / PP_BK;
-  const int nt = nt1 + p.K2 / PP_BK;
-
-  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
-  const int64_t la2 = p.lda2, lb2 = p.ldb2;
-  const int M = p.M, N = p.N;
-  // staging: one LDS-DMA instruction = 16 rows x 64 B; this wave issues pieces 2wv, 2wv+1 of the X and of the W tile
-  const int st_row = lane >> 2, st_cp = lane & 3;
-  int64_t xo[2], wo[2];
-  int xrow[2], wrow[2], sc[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int row = (wv * 2 + j) * 16 + st_row;
-    sc[j] = (st_cp ^ ((row >> 2) & 3)) * 8;
-    xrow[j] = min(m0 + row, M - 1);
-    wrow[j] = min(n0 + row, N - 1);
-    xo[j] = (int64_t)xrow[j] * p.lda + sc[j];
-    wo[j] = (int64_t)wrow[j] * p.ldb + sc[j];
-  }
-  auto stage_x = [&](int u) {
-    char* xs = smem + (u & 3) * PP_SLOT;
-    if (u < nt1) {
-#pragma unroll
-      for (int j = 0; j < 2; j++) glds16(A1 + xo[j] + u * PP_BK, xs + (wv * 2 + j) * 1024);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; j++) glds16(A2 + (int64_t)xrow[j] * la2 + sc[j] + (u - nt1) * PP_BK, xs + (wv * 2 + j) * 1024);
-    }
-  };
-  auto stage_w = [&](int u) {
-    char* ws = smem + (u & 3) * PP_SLOT + PP_XBYTES;
-    if (u < nt1) {
-#pragma unroll
-      for (int j = 0; j < 2; j++) glds16(B1 + wo[j] + u * PP_BK, ws + (wv * 2 + j) * 1024);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; j++) glds16(B2 + (int64_t)wrow[j] * lb2 + sc[j] + (u - nt1) * PP_BK, ws + (wv * 2 + j) * 1024);
-    }
-  };
-
-  // fragment addresses (bytes inside a slot's X / W image; 64-B rows, chunk' = chunk ^ ((row>>2)&3))
-  const int khalf = lane >> 5;
-  int w_a[2][2], x_a[4][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int wr = wn * 64 + i * 32 + (lane & 31);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) w_a[i][ks] = PP_XBYTES + wr * 64 + (((2 * ks + khalf) ^ ((wr >> 2) & 3)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int xr = wm * 128 + j * 32 + (lane & 31);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) x_a[j][ks] = xr * 64 + (((2 * ks + khalf) ^ ((xr >> 2) & 3)) << 4);
-  }
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  // ---- prologue: X(0) W(0) X(1) W(1) X(2) in the ring's issue order; k-step 0 retired + published ----
-  stage_x(0); stage_w(0);
-  if (nt > 1) { stage_x(1); stage_w(1); }
-  if (nt > 2) stage_x(2);
-  if (nt > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_BARRIER();
-  if (wm == 1) PP_BARRIER();                           // group 1 runs one barrier interval behind group 0
-
-  bf16x8 wf[2][2], xf[2][2];
-  TR_DECL;
-  for (int t = 0; t < nt; t++) {
-    const char* sl = smem + (t & 3) * PP_SLOT;
-    // ---------------- phase A: W x X0 ----------------
-    TR(t, 0);
-    if (t + 2 < nt) stage_w(t + 2);
-    TR(t, 1);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) wf[i][ks] = *(const bf16x8*)(sl + w_a[i][ks]);
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) xf[j][ks] = *(const bf16x8*)(sl + x_a[j][ks]);
-    TR(t, 2);
-    PP_BARRIER();
-    TR(t, 3);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    TR(t, 4);
-    PP_BARRIER();
-    // ---------------- phase B: W (kept) x X1 ----------------
-    TR(t, 5);
-    if (t + 3 < nt) stage_x(t + 3);
-    TR(t, 6);
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) xf[j][ks] = *(const bf16x8*)(sl + x_a[2 + j][ks]);
-    if (t + 1 < nt) {                                  // retire k-step t+1: X(t+2) W(t+2) X(t+3) may stay in flight
-      if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    TR(t, 7);
-    PP_BARRIER();
-    TR(t, 8);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], xf[j][ks], acc[i][2 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    TR(t, 9);
-    PP_BARRIER();
-    TR(t, 10);
-  }
-  TR_FLUSH(wv, lane);
-  if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
-  gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-}
-
 // =================================================================================================
 // k_gemm_pq: 256x256 tile, BK=64 (128-byte rows = whole cache lines: the LDS-DMA path moves 43.7 B/clk/CU with 128-B rows but
-// only 29 B/clk/CU with 64-B rows — tools/probes/glds_probe.hip), ping-pong schedule as k_gemm_pp.
+// only 29 B/clk/CU with 64-B rows — tools/probes/glds_probe.hip), ping-pong schedule (T3+T4+T5): two groups of 4 waves, one wave of each per SIMD,
+// group 1 one barrier interval behind, so one wave of a SIMD issues MFMAs at raised priority while its partner issues ds_reads + one LDS-DMA refill.
 // A K-tile (64 KiB) is four 16-KiB REGIONS, grouped by the phase that reads them rather than by tile rows:
 //   XA = the first 64 tokens of each group's 128 (tile rows 0-63, 128-191)   XB = the last 64 (64-127, 192-255)
 //   WA = the first 32 features of each wave's 64                            WB = the last 32
@@ -1073,14 +776,14 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     ps.partial = p.partial + (int64_t)slice * p.M * p.part_ld + (int64_t)wtap * p.N;
     ps.bias = nullptr;
     ps.conv_taps = 0;
-    gemm_epilogue_lds<EPI>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+    gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   } else if (wtaps > 1) {
     GemmP ps = p;
     ps.C = p.C + (int64_t)wtap * p.N;
     if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
     ps.conv_taps = 0;
-    gemm_epilogue_lds<EPI>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
-  } else if (epl_aligned(p)) gemm_epilogue_lds<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+    gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (epl_aligned(p)) gemm_epilogue_lds<EPI, CONV, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   else gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
@@ -1265,20 +968,6 @@ static int launch_p3(void* stream, const GemmGroup& g, int tiles) {
 }
 
 template <int EPI>
-static int launch_p4(void* stream, const GemmGroup& g, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_p4<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS); attr_set = true; }
-  hipLaunchKernelGGL(k_gemm_p4<EPI>, dim3(tiles), dim3(P4_THREADS), P4_LDS, (hipStream_t)stream, g);
-  return st355_check_launch("gemm_p4");
-}
-template <int EPI>
-static int launch_pp(void* stream, const GemmGroup& g, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pp<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); attr_set = true; }
-  hipLaunchKernelGGL(k_gemm_pp<EPI>, dim3(tiles), dim3(PP_THREADS), PP_LDS, (hipStream_t)stream, g);
-  return st355_check_launch("gemm_pp");
-}
-template <int EPI>
 static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
@@ -1292,20 +981,19 @@ static int launch_pq_conv(void* stream, const GemmGroup& g, int tiles) {
   hipLaunchKernelGGL((k_gemm_pq<EPI, false, false, true>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq_conv");
 }
-static int p4_tiles(const GemmP& p) { return ((p.M + P4_BM - 1) / P4_BM) * ((p.N + P4_BN - 1) / P4_BN); }
+static int p4_tiles(const GemmP& p) { return ((p.M + PQ_BM - 1) / PQ_BM) * ((p.N + PQ_BN - 1) / PQ_BN); }   // 256x256 tiles
 
 static int p3_tiles(const GemmP& p) { return ((p.M + P3_BM - 1) / P3_BM) * ((p.N + P3_BN - 1) / P3_BN); }
 
 static int gemm_impl_choice() {
   static int c = -1;
   if (c < 0) {
-    // A/B testing: ST355_GEMM_IMPL = s2 (128x128 only) | p3 (+256x128 ring) | p4 (+256x256 lock-step ring) | pp (256x256 BK=32 ping-pong) | pq (default: 256x256 BK=64 ping-pong)
+    // A/B testing: ST355_GEMM_IMPL = s2 (128x128 only) | p3 (+256x128 ring) | pq (default: + 256x256 BK=64 ping-pong).  The two earlier 256x256
+    // schedules (p4 lock-step ring, pp BK=32 ping-pong) were retired in round 2: pq superseded both on every shape.
     const char* e = getenv("ST355_GEMM_IMPL");
     c = 4;
-    if (e && e[0] == 'p' && e[1] == 'p') c = 3;
-    else if (e && e[0] == 's') c = 0;
+    if (e && e[0] == 's') c = 0;
     else if (e && e[0] == 'p' && e[1] == '3') c = 1;
-    else if (e && e[0] == 'p' && e[1] == '4') c = 2;
   }
   return c;
 }
@@ -1318,10 +1006,7 @@ static int min_tiles_256() {
 }
 
 template <int EPI>
-static int launch_256(void* stream, const GemmGroup& g, int tiles) {
-  const int c = gemm_impl_choice();
-  return c == 4 ? launch_pq<EPI>(stream, g, tiles) : (c == 3 ? launch_pp<EPI>(stream, g, tiles) : launch_p4<EPI>(stream, g, tiles));
-}
+static int launch_256(void* stream, const GemmGroup& g, int tiles) { return launch_pq<EPI>(stream, g, tiles); }
 
 #define DISPATCH_EPI(fn, epi, ...)                                                           \
   switch (epi) {                                                                             \

@@ -1,5 +1,5 @@
 // gemm_lab — standalone GEMM schedule lab for libst355 (no torch: starts in milliseconds on a fresh GPU box).
-//   tools/gemm_lab [impl ...]      impl in {s2,p3,p4,pp}; default: all.  Re-executes itself per impl (the choice is cached per process).
+//   tools/gemm_lab [impl ...]      impl in {s2,p3,pq}; default: all.  Re-executes itself per impl (the choice is cached per process).
 // For every shape: checks st355_gemm_bf16 against a naive fp32-accumulate reference kernel on uniform random operands (every
 // element, transpose-detecting), then times 30 launches with hipEvents and prints TFLOP/s.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DST355_TRACE] tools/gemm_lab.hip -o tools/gemm_lab
@@ -122,6 +122,42 @@ int main(int argc, char** argv) {
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     if (A2) { CK(hipFree(A2)); CK(hipFree(B2)); }
   };
+  if (getenv("LAB_EPI")) {        // the step's big shapes with their fused epilogues (Flux.1 LoRA at per-GPU batch 8: 36 864 joint tokens)
+    struct ES { int M, N, K, K2, epi; const char* what; };
+    const ES list[] = {{36864, 12288, 3072, 0, ST355_EPI_NONE, "MLP up, plain"}, {36864, 12288, 3072, 0, ST355_EPI_GELU, "MLP up, GELU + pre-act store"},
+                       {36864, 12288, 3072, 0, ST355_EPI_MUL_GELU_GRAD, "dgrad, x GELU'(pre-act)"}, {36864, 3072, 12288, 0, ST355_EPI_NONE, "MLP down, plain"},
+                       {36864, 3072, 12288, 0, ST355_EPI_GATE_RESIDUAL, "MLP down, gate * y + residual"}, {36864, 9216, 3072, 128, ST355_EPI_NONE, "QKV + LoRA K-ext"},
+                       {36864, 3072, 9216, 128, ST355_EPI_ADD, "dQKV dgrad + LoRA K-ext + add"}, {36864, 3072, 3072, 0, ST355_EPI_NONE, "3072^2, plain"}};
+    for (const ES& e : list) {
+      bf16 *A, *B, *A2 = nullptr, *B2 = nullptr, *C, *aux, *gate, *bias;
+      CK(hipMalloc(&A, (size_t)e.M * e.K * 2)); CK(hipMalloc(&B, (size_t)e.N * e.K * 2)); CK(hipMalloc(&C, (size_t)e.M * e.N * 2));
+      CK(hipMalloc(&aux, (size_t)e.M * e.N * 2)); CK(hipMalloc(&gate, (size_t)8 * e.N * 2)); CK(hipMalloc(&bias, (size_t)e.N * 2));
+      k_fill<<<1024, 256, 0, st>>>(A, (int64_t)e.M * e.K, 1u, 1.f); k_fill<<<1024, 256, 0, st>>>(B, (int64_t)e.N * e.K, 2u, 0.05f);
+      k_fill<<<1024, 256, 0, st>>>(aux, (int64_t)e.M * e.N, 5u, 1.f); k_fill<<<64, 256, 0, st>>>(gate, (int64_t)8 * e.N, 6u, 1.f); k_fill<<<64, 256, 0, st>>>(bias, e.N, 7u, 0.1f);
+      if (e.K2) {
+        CK(hipMalloc(&A2, (size_t)e.M * e.K2 * 2)); CK(hipMalloc(&B2, (size_t)e.N * e.K2 * 2));
+        k_fill<<<256, 256, 0, st>>>(A2, (int64_t)e.M * e.K2, 3u, 1.f); k_fill<<<256, 256, 0, st>>>(B2, (int64_t)e.N * e.K2, 4u, 0.05f);
+      }
+      st355_gemm_args a;
+      memset(&a, 0, sizeof(a));
+      a.A = A; a.lda = e.K; a.B = B; a.ldb = e.K; a.A2 = A2; a.lda2 = e.K2; a.B2 = B2; a.ldb2 = e.K2; a.C = C; a.ldc = e.N;
+      a.M = e.M; a.N = e.N; a.K = e.K; a.K2 = e.K2; a.epilogue = e.epi; a.bias = bias;
+      if (e.epi == ST355_EPI_GELU) { a.aux_out = aux; a.ld_aux_out = e.N; }
+      if (e.epi == ST355_EPI_MUL_GELU_GRAD || e.epi == ST355_EPI_ADD || e.epi == ST355_EPI_GATE_RESIDUAL) { a.aux_in = aux; a.ld_aux_in = e.N; }
+      if (e.epi == ST355_EPI_GATE_RESIDUAL) { a.gate = gate; a.gate_stride = e.N; a.rows_per_batch = e.M / 8; }
+      for (int i = 0; i < 3; i++) { int rc = st355_gemm_bf16(st, &a); if (rc) { printf("rc=%d %s\n", rc, st355_last_error()); exit(2); } }
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      const int iters = 10;
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; i++) st355_gemm_bf16(st, &a);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+      printf("  EPI %-34s %6d x %6d x %6d+%3d: %8.1f us  %8.1f TFLOP/s\n", e.what, e.M, e.N, e.K, e.K2, ms * 1e3, 2.0 * e.M * e.N * (double)(e.K + e.K2) / ms / 1e9);
+      CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(aux)); CK(hipFree(gate)); CK(hipFree(bias));
+      if (A2) { CK(hipFree(A2)); CK(hipFree(B2)); }
+    }
+    return 0;
+  }
   if (const char* one = getenv("LAB_SHAPE")) {          // LAB_SHAPE=M,N,K : one timed shape only (for rocprofv3 --pmc runs)
     Shape s = {0, 0, 0, 0};
     sscanf(one, "%d,%d,%d", &s.M, &s.N, &s.K);
