@@ -468,10 +468,17 @@ def run_workload(args, dev, rank, world):
     if args.buckets:
         if args.model != "sd3":
             raise SystemExit("--buckets is wired for --model sd3 only (Flux bench keeps the single 1024^2 bucket of configs[2])")
-        shapes = [(128, 128), (96, 168), (168, 96), (112, 144), (144, 112)]
-        shapes = shapes[rank % 5:] + shapes[:rank % 5]
-        batches = [make_batch(h_, w_) for (h_, w_) in shapes]
-        desc += "; mixed aspect buckets " + ",".join(f"{h_}x{w_}" for h_, w_ in shapes) + " (latent), one per step"
+        # the replicas walk ONE shared, seeded bucket schedule (training/bucket_split.py): every step runs the same bucket — the same token count — on
+        # every rank, each rank drawing from its own slice of that bucket (the reference lets ranks draw buckets independently, sampler.py:1041-1146)
+        from simpletuner_amd.training.bucket_split import TokenBalancedSchedule, split_buckets_between_processes
+        shape_of = {"128x128": (128, 128), "96x168": (96, 168), "168x96": (168, 96), "112x144": (112, 144), "144x112": (144, 112)}
+        n_sched = max(args.steps, args.warmup)
+        per_bucket = (-(-n_sched // len(shape_of)) + 1) * B * world
+        local = split_buckets_between_processes({k: [f"{k}/{i}" for i in range(per_bucket)] for k in shape_of}, B, world, rank, seed=42, backend_id="bench")
+        sched = TokenBalancedSchedule(local, B, seed=42, epoch=0, tokens_of={k: (h_ // 2) * (w_ // 2) + S_txt for k, (h_, w_) in shape_of.items()})
+        by_shape = {k: make_batch(*hw) for k, hw in shape_of.items()}
+        batches = [by_shape[b_] for b_ in sched.order[:n_sched]]
+        desc += "; mixed aspect buckets " + ",".join(sorted(shape_of)) + " (latent), one shared token-balanced schedule over all ranks"
     else:
         batches = [make_batch() for _ in range(2)]   # resident in HBM before the timed region
     nb_ = len(batches)
