@@ -118,6 +118,8 @@ typedef struct st355_gemm_args {
   const void* gate; int64_t gate_stride; int64_t rows_per_batch; /* EPI_GATE_RESIDUAL: gate[b*stride+n] */
   void*       workspace; int64_t workspace_bytes; /* optional fp32 scratch (256-B aligned): lets thin problems (N <= 128, e.g. the
                                                     LoRA down-projection x A^T) run split-K over all CUs; NULL => never split */
+  int32_t K2_real;                  /* how many of the K2 extension columns carry adapter data (the rest is zero padding to the 64-column K granule);
+                                       0 = all of them.  Only the profiler's ALGORITHMIC flop / byte counts use it: padding is not work. */
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two

@@ -945,9 +945,11 @@ static GemmP to_p(const st355_gemm_args* a) {
   return p;
 }
 
-static double gemm_flops(const st355_gemm_args* a) { return 2.0 * a->M * a->N * ((double)a->K + a->K2); }
+// algorithmic work: the zero-padded columns of the LoRA K-extension (rank 32 -> 64-column granule) are executed but are not work
+static double k2_alg(const st355_gemm_args* a) { return (a->K2_real > 0 && a->K2_real < a->K2) ? a->K2_real : a->K2; }
+static double gemm_flops(const st355_gemm_args* a) { return 2.0 * a->M * a->N * ((double)a->K + k2_alg(a)); }
 static double gemm_bytes(const st355_gemm_args* a) {
-  return 2.0 * ((double)a->M * (a->K + a->K2) + (double)a->N * (a->K + a->K2) + (double)a->M * a->N);
+  return 2.0 * ((double)a->M * (a->K + k2_alg(a)) + (double)a->N * (a->K + k2_alg(a)) + (double)a->M * a->N);
 }
 
 template <int EPI>

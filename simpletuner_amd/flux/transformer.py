@@ -63,6 +63,7 @@ class LoraGroup:
         self.r_pad = 32 if rank <= 32 else 64
         assert rank <= 64, "LoRA rank > 64 not supported by the rank-space kernels yet"
         self.K2 = (len(targets) * self.r_pad + 63) // 64 * 64
+        self.k2_real = len(targets) * rank          # adapter columns inside the padded extension (algorithmic-work accounting of the profiler)
         z = lambda *s: torch.zeros(*s, dtype=BF16, device=device)
         self.A_cat, self.A_cat_T = z(self.K2, K), z(K, self.K2)
         self.B_blk, self.B_blk_T = z(N_total, self.K2), z(self.K2, N_total)
@@ -326,7 +327,7 @@ class FluxTransformer2DModel(nn.Module):
         T = None
         if lin.lora is not None:
             T = ops.gemm(x, lin.lora.A_cat)
-            kw.update(a2=T, b2=lin.lora.B_blk)
+            kw.update(a2=T, b2=lin.lora.B_blk, k2_real=lin.lora.k2_real)
         return ops.gemm(x, lin.w, bias=lin.b, **kw), T
 
     def _lin_bwd(self, lin, dy, x=None, T=None, **kw):
@@ -334,7 +335,7 @@ class FluxTransformer2DModel(nn.Module):
         U = None
         if lin.lora is not None:
             U = ops.gemm(dy, lin.lora.B_blk_T)
-            kw.update(a2=U, b2=lin.lora.A_cat_T)
+            kw.update(a2=U, b2=lin.lora.A_cat_T, k2_real=lin.lora.k2_real)
         dx = ops.gemm(dy, lin.wT, **kw)
         if lin.lora is not None:
             lin.lora.grads(x, T, dy, U, self.accumulate_lora_grads, self.grad_sync)
@@ -412,8 +413,8 @@ class FluxTransformer2DModel(nn.Module):
         T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
         probs = []
         for b in range(B):
-            kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
-            kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+            kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
+            kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
             probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i))
             probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t))
         ops.gemm_grouped(probs)
@@ -432,10 +433,10 @@ class FluxTransformer2DModel(nn.Module):
             kw_i, kw_t = {}, {}
             if T_o is not None:
                 ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
-                kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
+                kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk, k2_real=blk.to_out.lora.k2_real)
             if T_ao is not None:
                 ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
-                kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
+                kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
             probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
                               aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
             probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
@@ -607,8 +608,8 @@ class FluxTransformer2DModel(nn.Module):
         U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if blk.to_add_out.lora is not None else None
         probs = []
         for b in range(B):
-            kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
-            kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
+            kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T, k2_real=blk.to_out.lora.k2_real) if U_i is not None else {}
+            kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T, k2_real=blk.to_add_out.lora.k2_real) if U_t is not None else {}
             probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S + St:(b + 1) * S], **kw_i))
             probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S:b * S + St], **kw_t))
         ops.gemm_grouped(probs)
@@ -635,7 +636,7 @@ class FluxTransformer2DModel(nn.Module):
             kw = {}
             if lin.lora is not None:
                 Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
-                kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
+                kw = dict(a2=Us[name], b2=lin.lora.A_cat_T, k2_real=lin.lora.k2_real)
             if not last:
                 probs.append(dict(a=dq, w=lin.wT, **kw))
         dns = ops.gemm_grouped(probs) if probs else []

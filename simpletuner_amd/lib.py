@@ -66,6 +66,7 @@ class GemmArgs(C.Structure):
         ("aux_in", C.c_void_p), ("ld_aux_in", C.c_int64),
         ("gate", C.c_void_p), ("gate_stride", C.c_int64), ("rows_per_batch", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("K2_real", C.c_int32),
     ]
 
 

@@ -244,7 +244,7 @@ def _gemm_workspace(dev, nbytes: int = _GEMM_WS_BYTES):
 
 
 def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
-               gate=None, rows_per_batch: int = 0):
+               gate=None, rows_per_batch: int = 0, k2_real: int = 0):
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
     M, K = a.shape
     N, Kw = w.shape
@@ -263,6 +263,7 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
         g.A2, g.lda2 = _ptr(a2), _rows(a2, "a2")
         g.B2, g.ldb2 = _ptr(b2), _rows(b2, "b2")
         g.K2 = a2.shape[1]
+        g.K2_real = int(k2_real)          # adapter columns inside the 64-column granule (profiler accounting only)
     if bias is not None:
         _chk(bias, BF16, "bias")
         if not bias.is_contiguous():
