@@ -9,9 +9,9 @@ R=$PWD
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out/bench_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $out/bench_pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-prof > $out/bench_pmc_$c.log 2>&1
 done
 cd $R
 python tools/profile_summarise.py $out $tag
