@@ -20,10 +20,9 @@
 #define QB 128  // queries per workgroup
 #define KB 64   // keys per tile
 
-// NW = waves per workgroup (32 queries each): 4 = two independent workgroups per CU (default); 8 = ONE 256-query workgroup per CU sharing each K / V^T
-// tile (half the LDS fill and half the global->LDS staging work per MFMA, one barrier domain of 8 waves) — A/B with ST355_ATTN_FWD=3
-template <int HD, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+// First generation (r01): kept ONLY as the A/B baseline of the r02 kernel below (ST355_ATTN_FWD=1; tools/attn_lab times both).
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
                                                             bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
                                                             int Sq, int S, int Sp, float scale2) {   // Sq queries; S keys (padded Sp)
@@ -33,6 +32,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict_
   constexpr int BUF = KT_BYTES + VT_BYTES;
   constexpr int NKS = HD / 16;           // MFMA k-steps over the head dim
   constexpr int NDT = HD / 32;           // 32-row d tiles of O^T
+  constexpr int NW = 4;
   constexpr int ATT_T = 64 * NW;
   constexpr int KCH = KT_BYTES / 16 / ATT_T;  // 16-B chunks per thread
   constexpr int VCH = VT_BYTES / 16 / ATT_T;
@@ -40,9 +40,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
   const int64_t bh = (int64_t)b * H + head;
-  const int q0 = blockIdx.x * (32 * NW) + wv * 32;
+  const int q0 = wg.tile * (32 * NW) + wv * 32;
   const int qi = min(q0 + l31, Sq - 1);
 
   const bf16* Kg = K + bh * (int64_t)S * HD;
@@ -212,50 +213,61 @@ __global__ void __launch_bounds__(64 * NW, 2) k_attn_fwd(const bf16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// second generation (the recipe that took the dK/dV kernel from 553 to 950 TFLOP/s): 8 waves x 32 queries = 256 queries per
-// workgroup share one K / V^T tile (half the LDS fill per MFMA of the 4-wave kernel), the tiles arrive by LDS-DMA into a double
-// buffer (no staging VGPRs, no ds_write pass), address arithmetic is re-derived from the lane id each tile (nothing hoisted,
-// nothing spilled), and the O accumulators are only rescaled when some lane's running max actually moved.
+// Second generation (r02, the default): the generation-1 shape (4 waves x 32 queries, two independent workgroups per CU, register staging) with the per-tile
+// VALU stream cut down and software-pipelined against the MFMAs INSIDE a wave.  Found in the generation-1 .s: per tile and wave 32 MFMAs (1024
+// cycles) sat next to ~195 VALU instructions + 33 v_exp — of which 32 were v_mov phi copies (the three score variants merged into one p[] array),
+// one ds_bpermute + s_waitcnt lgkmcnt(0) for the half-wave max (which also drains every V^T fragment read in flight), and the PV loop ran dt-outer
+// so all 32 exponentials had to retire before the 2nd..4th MFMA.  Here:
+//   * BIAS is a kernel template parameter and the ragged last tile is peeled (tile<TAIL>): the steady-state tile is straight-line code;
+//   * scores stay in the MFMA accumulator registers (masked variants rewrite them in place), no phi copies;
+//   * half-wave exchange by v_permlane32_swap (VALU, no LDS round trip, no lgkmcnt drain);
+//   * PV runs (sb, m)-outer / dt-inner: the 8 exponentials + pack of k-slice (sb, m) are issued just before its NDT MFMAs, so the exponentials of
+//     slice g+1 execute under the MFMAs of slice g (independent accumulators acc_o[0..NDT-1] back to back, no dependent-MFMA stalls).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void f_glds16(const void* g, char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+__device__ __forceinline__ float xhalf_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// STAG: the two waves of every SIMD (wave w and w+4) run half a key tile apart — one does QK^T + softmax (MFMA then VALU) while the other does
-// PV (MFMA) — so the matrix pipe and the VALU are both busy; two barriers per key tile; every half ends by retiring the LDS-DMA pieces
-// the wave issued in its PREVIOUS half (counted vmcnt), which is exactly what the other group's next half reads.
-template <int HD, bool STAG>
-__global__ void __launch_bounds__(512, 2) k_attn_fwd2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                     const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
-                                                     bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H, int S, int Sp,
-                                                     float scale2) {
+template <int HD, bool BIAS>
+__global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                      const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
+                                                      bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
+                                                      int Sq, int S, int Sp, float scale2) {
+  constexpr int NW = 4;
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = KB * KROWB;
   constexpr int VT_BYTES = HD * 128;
   constexpr int BUF = KT_BYTES + VT_BYTES;
-  constexpr int NKS = HD / 16, NDT = HD / 32;
-  constexpr int KPW = KT_BYTES / 1024 / 8;     // K pieces per wave (HD=128: 2, HD=64: 1)
-  constexpr int VPW = VT_BYTES / 1024 / 8;
-  constexpr int RPP = 1024 / KROWB;            // K rows per piece
-  constexpr int CPR = KROWB / 16;              // 16-byte chunks per K row
+  constexpr int NKS = HD / 16;
+  constexpr int NDT = HD / 32;
+  constexpr int ATT_T = 64 * NW;
+  constexpr int KCH = KT_BYTES / 16 / ATT_T;
+  constexpr int VCH = VT_BYTES / 16 / ATT_T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
   const int64_t bh = (int64_t)b * H + head;
-  const int q0 = blockIdx.x * 256 + wv * 32;
-  const int qi = min(q0 + l31, S - 1);
+  const int q0 = wg.tile * (32 * NW) + wv * 32;
+  const int qi = min(q0 + l31, Sq - 1);
+
   const bf16* Kg = K + bh * (int64_t)S * HD;
   const bf16* Vg = Vt + bh * (int64_t)HD * Sp;
 
   bf16x8 qf[NKS];
   {
-    const bf16* qrow = Q + (bh * S + qi) * (int64_t)HD + 8 * h;
+    const bf16* qrow = Q + (bh * Sq + qi) * (int64_t)HD + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
   }
+
   f32x16 acc_o[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; dt++)
@@ -263,141 +275,132 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd2(const bf16* __restrict__ Q
     for (int r = 0; r < 16; r++) acc_o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  auto stage_k = [&](int kt) {
-    char* ks = smem + (kt & 1) * BUF;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
+  bf16x8 kreg[KCH], vreg[VCH];
+  // Staging addresses: a K tile is KT_BYTES of CONTIGUOUS memory (rows key0..key0+63 of one head), so thread t's p-th 16-byte chunk sits at
+  // tile base + (p * ATT_T + t) * 16; V^T chunks at a per-thread 32-bit offset from a wave-uniform base.  Uniform base (SGPR) + 32-bit lane offset
+  // is the saddr form of global_load: no per-load 64-bit VALU arithmetic (generation 1 spent ~20 VALU per tile on it).  Only the ragged last tile
+  // clamps rows (K rows past S would read the next head, or past the allocation for the last one).
+  const uint32_t koff0 = (uint32_t)tid * 16u;
+  const uint32_t voff0 = ((uint32_t)(tid >> 3) * (uint32_t)Sp + (uint32_t)(tid & 7) * 8u) * 2u;
+  auto load_tile = [&](int kt) {
+    const int key0 = kt * KB;
+    const char* kb = (const char*)Kg + (size_t)key0 * KROWB;
+    if (key0 + KB <= S) {
 #pragma unroll
-    for (int p = 0; p < KPW; p++) {
-      const int row = (wv * KPW + p) * RPP + ln / CPR;
-      const int col = ((ln % CPR) ^ (HD == 128 ? (row & 15) : ((row >> 1) & 7))) * 8;
-      f_glds16(Kg + (uint32_t)(min(kt * KB + row, S - 1) * HD + col), ks + (wv * KPW + p) * 1024);
-    }
-  };
-  auto stage_v = [&](int kt) {
-    char* vs = smem + (kt & 1) * BUF + KT_BYTES;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
+      for (int p = 0; p < KCH; p++) kreg[p] = *(const bf16x8*)(kb + (koff0 + (uint32_t)(p * ATT_T * 16)));
+    } else {
 #pragma unroll
-    for (int p = 0; p < VPW; p++) {
-      const int row = (wv * VPW + p) * 8 + (ln >> 3);
-      f_glds16(Vg + (uint32_t)(row * Sp + ((ln & 7) ^ ((row >> 1) & 7)) * 8 + kt * KB), vs + (wv * VPW + p) * 1024);
+      for (int p = 0; p < KCH; p++) {
+        const int id = p * ATT_T + tid;
+        const int row = id / (HD / 8), c = id % (HD / 8);
+        kreg[p] = *(const bf16x8*)(Kg + (int64_t)min(key0 + row, S - 1) * HD + c * 8);
+      }
     }
+    const char* vb = (const char*)Vg + (size_t)key0 * 2;
+#pragma unroll
+    for (int p = 0; p < VCH; p++) vreg[p] = *(const bf16x8*)(vb + (size_t)p * (ATT_T / 8) * Sp * 2 + voff0);
   };
-  auto wait_pieces = [&](int n) {                 // n pieces may stay in flight (n in {0, 1, 2})
-    if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  auto half_end = [&](int in_flight) {
-    wait_pieces(in_flight);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+  auto store_tile = [&](int buf) {
+    char* ks = smem + buf * BUF;
+    char* vs = ks + KT_BYTES;
+#pragma unroll
+    for (int p = 0; p < KCH; p++) {
+      const int id = p * ATT_T + tid;
+      const int row = id / (HD / 8), c = id % (HD / 8);
+      *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
+    }
+#pragma unroll
+    for (int p = 0; p < VCH; p++) {
+      const int id = p * ATT_T + tid;
+      const int row = id >> 3, c = id & 7;
+      *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
+    }
   };
 
   const int nkt = (S + KB - 1) / KB;
   const int krow_p = perm23(l31);
-  const int k_base0 = (HD == 128) ? krow_p * 256 + ((h ^ (krow_p & 15)) << 4) : krow_p * 128 + ((h ^ ((krow_p >> 1) & 7)) << 4);
-  const int v_base0 = KT_BYTES + l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
-  const bool late = STAG && wv >= 4;               // group 1 runs one half behind
-  stage_k(0); stage_v(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (late) {                                      // its "PV half of tile -1": only the K(1) issue
-    int fl = 0;
-    if (1 < nkt) { stage_k(1); fl = KPW; }
-    half_end(fl);
-  }
-  bf16x8 pf[2][2];
-  float alpha = 1.f;
-  for (int kt = 0; kt < nkt; kt++) {
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  auto tile = [&](int kt, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;      // ragged last tile and/or per-key bias: scores are rewritten in place, already scaled
     const int buf = kt & 1;
-    int k_base = k_base0 + buf * BUF, v_base = v_base0 + buf * BUF;
-    asm volatile("" : "+v"(k_base), "+v"(v_base));
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* ks = smem + buf * BUF;
+    const char* vs = ks + KT_BYTES;
     const int key0 = kt * KB;
-    // ================= half 1: S^T = K Q^T, online softmax =================
-    int fl = 0;
-    if (!STAG) { if (kt + 1 < nkt) { stage_k(kt + 1); stage_v(kt + 1); } }
-    else if (!late) { if (kt + 1 < nkt) { stage_k(kt + 1); fl = KPW; } }
-    else { if (kt + 1 < nkt) { stage_v(kt + 1); fl = VPW; } }
+
     f32x16 sacc[2];
+    float mt = -INFINITY;
 #pragma unroll
     for (int sb = 0; sb < 2; sb++) {
 #pragma unroll
       for (int r = 0; r < 16; r++) sacc[sb][r] = 0.f;
+      const int row = 32 * sb + krow_p;
 #pragma unroll
       for (int ks_ = 0; ks_ < NKS; ks_++) {
-        const bf16x8 kf = *(const bf16x8*)(smem + (k_base ^ ((2 * ks_) << 4)) + sb * 32 * KROWB);
+        bf16x8 kf = *(const bf16x8*)(ks + lds_off<KROWB>(row, 2 * ks_ + h));
         sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks_], sacc[sb], 0, 0, 0);
       }
     }
-    const bool tail = (key0 + KB > S);
-    float mt = -INFINITY;
 #pragma unroll
     for (int sb = 0; sb < 2; sb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float sv = sacc[sb][r] * scale2;
-        if (key_bias != nullptr || tail) {
+        if (MASKED) {
+          float s = sacc[sb][r] * scale2;
           const int key = key0 + 32 * sb + acc_row(r, h);
-          if (key_bias != nullptr) sv += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
-          if (key >= S) sv = -INFINITY;
+          if (BIAS) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
+          if (key >= S) s = -INFINITY;
+          sacc[sb][r] = s;
         }
-        sacc[sb][r] = sv;
-        mt = fmaxf(mt, sv);
+        mt = fmaxf(mt, sacc[sb][r]);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float psc = MASKED ? 1.f : scale2;               // plain tiles keep the RAW score: the scale rides in the exponent's fma
+    if (!MASKED) mt *= scale2;                             // scale2 > 0: max(scale2 * s) = scale2 * max(s)
+    mt = xhalf_max(mt);
     const float m_new = fmaxf(m_run, mt);
-    alpha = fast_exp2(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
-    float ls = 0.f;
-#pragma unroll
-    for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-      for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const float e = fast_exp2(sacc[sb][8 * m + r] - m_new);
-          ls += e;
-          pf[sb][m][r] = f2bf(e);
-        }
-    l_run = l_run * alpha + ls;
-    if (STAG) half_end(fl);
-    // ================= half 2: O^T += V^T P^T =================
-    fl = 0;
-    if (STAG) {
-      if (!late) { if (kt + 1 < nkt) { stage_v(kt + 1); fl = VPW; } }
-      else { if (kt + 2 < nkt) { stage_k(kt + 2); fl = KPW; } }
-    }
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {        // wave-uniform: skip the 64 multiplies once the running max is stable
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // wave-uniform: once the running max is stable the 16*NDT multiplies are skipped
 #pragma unroll
       for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc_o[dt][r] *= alpha;
     }
+    float ls[2] = {0.f, 0.f};
 #pragma unroll
-    for (int dt = 0; dt < NDT; dt++) {
+    for (int sb = 0; sb < 2; sb++)
 #pragma unroll
-      for (int sb = 0; sb < 2; sb++)
+      for (int m = 0; m < 2; m++) {
+        float e[8];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-          const bf16x8 vf = *(const bf16x8*)(smem + (v_base ^ ((4 * sb + 2 * m) << 4)) + dt * 4096);
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sb][m], acc_o[dt], 0, 0, 0);
+        for (int r = 0; r < 8; r++) {
+          e[r] = fast_exp2(fmaf(sacc[sb][8 * m + r], psc, -m_new));
+          ls[r & 1] += e[r];
         }
-    }
-    half_end(STAG ? fl : 0);
-  }
-  if (STAG && !late) {                             // pairs with group 1's extra half
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const bf16x8 pf = pack8(e);
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++) {
+          bf16x8 vf = *(const bf16x8*)(vs + lds_off<128>(32 * dt + l31, 4 * sb + 2 * m + h));
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[dt], 0, 0, 0);
+        }
+      }
+    l_run = l_run * alpha + (ls[0] + ls[1]);
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  };
+  const int nfull = BIAS ? 0 : S / KB;                     // tiles with all 64 keys valid and no bias take the plain path
+  for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
+  for (int kt = nfull; kt < nkt; kt++) tile(kt, std::true_type{});
+
+  const float l_tot = xhalf_sum(l_run);
   const float inv = 1.f / l_tot;
   const int q = q0 + l31;
-  if (q < S) {
-    bf16* orow = O + ((int64_t)b * S + q) * ld_o + (int64_t)head * HD;
+  if (q < Sq) {
+    bf16* orow = O + ((int64_t)b * Sq + q) * ld_o + (int64_t)head * HD;
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -407,9 +410,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd2(const bf16* __restrict__ Q
         for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc_o[dt][4 * a + bb] * inv);
         *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
       }
-    if (h == 0) lse2[bh * S + q] = m_run + __log2f(l_tot);
+    if (h == 0) lse2[bh * Sq + q] = m_run + __log2f(l_tot);
   }
 }
+
 
 static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
                          int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale) {
@@ -420,59 +424,34 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   const double bytes = 2.0 * (double)B * H * (Sq + S) * d * 2.0;
   ProfScope ps(stream, ST355_K_ATTN_FWD, flops, bytes);
   const float scale2 = scale * LOG2E;
+  // Default = k_attn_fwd4 (r02).  ST355_ATTN_FWD=1 selects the r01 kernel for A/B runs: r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s.
+  // (Also measured and deleted in r02: an 8-wave/256-query workgroup variant, 843 TFLOP/s, and an 8-wave LDS-DMA half-tile-stagger variant, 738 —
+  // the forward is latency-shaped and wants two INDEPENDENT workgroups per CU; logs under profiles/r02_attn_lab_*.log.)
   static int gen = -1;
-  // A/B switch.  Default = the first-generation kernel (4 waves x 32 queries, 2 independent workgroups per CU, register staging):
-  // measured 761-786 TFLOP/s in-step.  ST355_ATTN_FWD=2 selects k_attn_fwd2 (8 waves, LDS-DMA, half-tile stagger): correct (same
-  // parity tests) but 635-700 TFLOP/s — the forward is VALU/latency-shaped and loses the decoupling of two independent workgroups.
-  if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '2') ? 2 : ((e && e[0] == '3') ? 3 : 1); }
-  if (gen == 2 && Sq == S && d != 96) {
-    dim3 grid2((S + 255) / 256, H, B);
-    if (d == 128) {
-      const int lds = 2 * (KB * 256 + 128 * 128);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd2<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL((k_attn_fwd2<128, true>), grid2, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                         key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
-    } else {
-      const int lds = 2 * (KB * 128 + 64 * 128);
-      hipLaunchKernelGGL((k_attn_fwd2<64, true>), grid2, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                         key_bias, (bf16*)O, ld_o, lse2, H, S, Sp, scale2);
-    }
-    return st355_check_launch("attn_fwd2");
-  }
-  if (gen == 3 && (d == 128 || d == 64)) {
-    dim3 grid3((Sq + 255) / 256, H, B);
-    if (d == 128) {
-      const int lds = 2 * (KB * 256 + 128 * 128);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL((k_attn_fwd<128, 8>), grid3, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                         key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
-    } else {
-      const int lds = 2 * (KB * 128 + 64 * 128);
-      hipLaunchKernelGGL((k_attn_fwd<64, 8>), grid3, dim3(512), lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                         key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
-    }
-    return st355_check_launch("attn_fwd3");
-  }
+  if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '1') ? 1 : 4; }
   dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);
-  if (d == 96) {                 // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
-    const int lds = 2 * (KB * 192 + 96 * 128);
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-    hipLaunchKernelGGL(k_attn_fwd<96>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
-  } else if (d == 128) {
-    const int lds = 2 * (KB * 256 + 128 * 128);
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-    hipLaunchKernelGGL(k_attn_fwd<128>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
+  const int lds = 2 * (KB * d * 2 + d * 128);
+#define ST355_FWD_LAUNCH(KERN)                                                                                                           \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    hipLaunchKernelGGL((KERN), grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, key_bias,         \
+                       (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);                                                                     \
+  } while (0)
+  if (gen == 1) {
+    if (d == 128) ST355_FWD_LAUNCH(k_attn_fwd<128>);
+    else if (d == 96) ST355_FWD_LAUNCH(k_attn_fwd<96>);          // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
+    else ST355_FWD_LAUNCH(k_attn_fwd<64>);
+  } else if (key_bias) {
+    if (d == 128) ST355_FWD_LAUNCH((k_attn_fwd4<128, true>));
+    else if (d == 96) ST355_FWD_LAUNCH((k_attn_fwd4<96, true>));
+    else ST355_FWD_LAUNCH((k_attn_fwd4<64, true>));
   } else {
-    const int lds = 2 * (KB * 128 + 64 * 128);
-    hipLaunchKernelGGL(k_attn_fwd<64>, grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
-                       key_bias, (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);
+    if (d == 128) ST355_FWD_LAUNCH((k_attn_fwd4<128, false>));
+    else if (d == 96) ST355_FWD_LAUNCH((k_attn_fwd4<96, false>));
+    else ST355_FWD_LAUNCH((k_attn_fwd4<64, false>));
   }
+#undef ST355_FWD_LAUNCH
   return st355_check_launch("attn_fwd");
 }
 extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,

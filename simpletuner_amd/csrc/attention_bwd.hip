@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // TR (head_dim 128): no K^T tile — the K^T fragments of dQ^T += K^T dS^T are gathered from the row-major K tile by transposing LDS reads (the
 // dkv3 recipe: tile image swizzled with f(row)), so the pre-transposed head-major K^T copy in HBM disappears and a key tile is 32 KiB, not 48.
-template <int HD, bool TR = false>
+// BIAS is a kernel template parameter and the ragged last key tile is peeled (tile<MASKED>), as in the forward: the steady-state tile is straight-line
+// code (no merge copies of the score registers between variants, and the scheduler may run the dS arithmetic of one 32-key block under the MFMAs of
+// the next).
+template <int HD, bool TR = false, bool BIAS = false>
 __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                        const bf16* __restrict__ Kt, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                        const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
@@ -103,9 +106,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
   const int64_t bh = (int64_t)b * H + head;
-  const int q0 = blockIdx.x * 256 + wv * 32;
+  const int q0 = wg.tile * 256 + wv * 32;
   const int q = q0 + l31;
   const int qi = min(q, Sq - 1);
 
@@ -185,14 +189,14 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   load_tile(0);
   store_tile(0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; kt++) {
+  auto tile = [&](int kt, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
     const char* ks = smem + buf * BUF;
     const char* vs = ks + KT_BYTES;
     const char* ts = vs + KT_BYTES;
     const int key0 = kt * 64;
-    const bool tail = key0 + 64 > Sk;
 #pragma unroll
     for (int sb = 0; sb < 2; sb++) {
       f32x16 sacc, dpacc;
@@ -207,26 +211,19 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
         dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks_], dpacc, 0, 0, 0);
       }
       float ds[16];
-      // one wave-uniform branch per 32-key sub-block (plain / ragged last tile / per-key bias) instead of a guarded block per score (see attention.hip)
-      auto dscores = [&](auto bias_c, auto tail_c) {
-        constexpr bool BIAS = decltype(bias_c)::value, TAIL = decltype(tail_c)::value;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+      for (int r = 0; r < 16; r++) {
+        float pv;
+        if (MASKED) {
           float s = sacc[r] * scale2;
-          float pv;
-          if (BIAS || TAIL) {
-            const int key = key0 + 32 * sb + acc_row(r, h);
-            if (BIAS) s += key_bias[(int64_t)b * Sk + min(key, Sk - 1)] * LOG2E;
-            pv = (key < Sk) ? fast_exp2(s - lse_q) : 0.f;
-          } else {
-            pv = fast_exp2(s - lse_q);
-          }
-          ds[r] = pv * (dpacc[r] - delta_q);
+          const int key = key0 + 32 * sb + acc_row(r, h);
+          if (BIAS) s += key_bias[(int64_t)b * Sk + min(key, Sk - 1)] * LOG2E;
+          pv = (key < Sk) ? fast_exp2(s - lse_q) : 0.f;
+        } else {
+          pv = fast_exp2(fmaf(sacc[r], scale2, -lse_q));
         }
-      };
-      if (key_bias != nullptr) dscores(std::true_type{}, std::true_type{});
-      else if (tail) dscores(std::false_type{}, std::true_type{});
-      else dscores(std::false_type{}, std::false_type{});
+        ds[r] = pv * (dpacc[r] - delta_q);
+      }
       bf16x8 dsf[2];
       dsf[0] = pack8(&ds[0]);
       dsf[1] = pack8(&ds[8]);
@@ -249,7 +246,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     }
     if (kt + 1 < nkt) store_tile(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int nfull = BIAS ? 0 : Sk / 64;                    // key tiles with all 64 keys valid and no bias take the plain path
+  for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
+  for (int kt = nfull; kt < nkt; kt++) tile(kt, std::true_type{});
   if (q < Sq) {
     bf16* orow = dQ + (bh * Sq + q) * (int64_t)HD;
 #pragma unroll
@@ -260,186 +260,6 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
         for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
         *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dK/dV kernel: 4 waves x 32 keys, one wave per SIMD (accumulators: 2 x HD x 32 fp32 per wave)
-// ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ void __launch_bounds__(256, 1) k_attn_bwd_dkv(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                        const bf16* __restrict__ Qt, const bf16* __restrict__ Vrows, int64_t ld_v,
-                                                        const bf16* __restrict__ dO, int64_t ld_do, const bf16* __restrict__ dOt,
-                                                        const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                        const float* __restrict__ key_bias, bf16* __restrict__ dK,
-                                                        bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, int Skp, float scale,
-                                                        float scale2) {
-  constexpr int NT = 256;
-  constexpr int QROWB = HD * 2;
-  constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major)
-  constexpr int TT_BYTES = HD * 128;     // Q^T tile / dO^T tile (HD rows x 64 queries)
-  constexpr int STAT_BYTES = 2 * 64 * 4; // lse2 + delta for the 64 queries
-  constexpr int BUF = 2 * QT_BYTES + 2 * TT_BYTES + STAT_BYTES;
-  constexpr int NKS = HD / 16, NDT = HD / 32;
-  constexpr int QCH = QT_BYTES / 16 / NT;
-  constexpr int TCH = TT_BYTES / 16 / NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int64_t bh = (int64_t)b * H + head;
-  const int key = blockIdx.x * 128 + wv * 32 + l31;
-  const int keyi = min(key, Sk - 1);
-
-  const bf16* Qg = Q + bh * (int64_t)Sq * HD;
-  const bf16* Qtg = Qt + bh * (int64_t)HD * Sqp;
-  const bf16* dOtg = dOt + bh * (int64_t)HD * Sqp;
-  const bf16* dOg = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
-
-  bf16x8 kf[NKS], vf[NKS];
-  {
-    const bf16* krow = K + (bh * Sk + keyi) * (int64_t)HD + 8 * h;
-    const bf16* vrow = Vrows + ((int64_t)b * Sk + keyi) * ld_v + (int64_t)head * HD + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks++) {
-      kf[ks] = *(const bf16x8*)(krow + 16 * ks);
-      vf[ks] = *(const bf16x8*)(vrow + 16 * ks);
-    }
-  }
-  const float kb2 = key_bias ? key_bias[(int64_t)b * Sk + keyi] * LOG2E : 0.f;
-
-  f32x16 acc_dk[NDT], acc_dv[NDT];
-#pragma unroll
-  for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc_dk[dt][r] = 0.f; acc_dv[dt][r] = 0.f; }
-
-  bf16x8 qreg[QCH], greg[QCH], qtreg[TCH], gtreg[TCH];
-  float st_lse = 0.f, st_delta = 0.f;
-  auto load_tile = [&](int qt) {
-    const int qq0 = qt * 64;
-#pragma unroll
-    for (int p = 0; p < QCH; p++) {
-      const int id = p * NT + tid;
-      const int row = id / (HD / 8), c = id % (HD / 8);
-      const int qq = min(qq0 + row, Sq - 1);
-      qreg[p] = *(const bf16x8*)(Qg + (int64_t)qq * HD + c * 8);
-      greg[p] = *(const bf16x8*)(dOg + (int64_t)qq * ld_do + c * 8);
-    }
-#pragma unroll
-    for (int p = 0; p < TCH; p++) {
-      const int id = p * NT + tid;
-      const int row = id >> 3, c = id & 7;
-      qtreg[p] = *(const bf16x8*)(Qtg + (int64_t)row * Sqp + qq0 + c * 8);
-      gtreg[p] = *(const bf16x8*)(dOtg + (int64_t)row * Sqp + qq0 + c * 8);
-    }
-    if (tid < 64) {
-      const int qq = qq0 + tid;
-      st_lse = (qq < Sq) ? lse2[bh * (int64_t)Sqp + qq] : INFINITY;     // lse2 = the padded copy written by prep   // +inf -> P = exp2(-inf) = 0 for padded queries
-      st_delta = (qq < Sq) ? delta[bh * (int64_t)Sqp + qq] : 0.f;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* qs = smem + buf * BUF;
-    char* gs = qs + QT_BYTES;
-    char* qts = gs + QT_BYTES;
-    char* gts = qts + TT_BYTES;
-    float* stat = (float*)(gts + TT_BYTES);
-#pragma unroll
-    for (int p = 0; p < QCH; p++) {
-      const int id = p * NT + tid;
-      const int row = id / (HD / 8), c = id % (HD / 8);
-      *(bf16x8*)(qs + lds_off<QROWB>(row, c)) = qreg[p];
-      *(bf16x8*)(gs + lds_off<QROWB>(row, c)) = greg[p];
-    }
-#pragma unroll
-    for (int p = 0; p < TCH; p++) {
-      const int id = p * NT + tid;
-      const int row = id >> 3, c = id & 7;
-      *(bf16x8*)(qts + lds_off<128>(row, c)) = qtreg[p];
-      *(bf16x8*)(gts + lds_off<128>(row, c)) = gtreg[p];
-    }
-    if (tid < 64) { stat[tid] = st_lse; stat[64 + tid] = st_delta; }
-  };
-
-  const int nqt = (Sq + 63) / 64;
-  const int qrow_p = perm23(l31);
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int qt = 0; qt < nqt; qt++) {
-    const int buf = qt & 1;
-    if (qt + 1 < nqt) load_tile(qt + 1);
-    const char* qs = smem + buf * BUF;
-    const char* gs = qs + QT_BYTES;
-    const char* qts = gs + QT_BYTES;
-    const char* gts = qts + TT_BYTES;
-    const float* stat = (const float*)(gts + TT_BYTES);
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
-      f32x16 sacc, dpacc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-      const int row = 32 * qb + qrow_p;
-#pragma unroll
-      for (int ks_ = 0; ks_ < NKS; ks_++) {
-        bf16x8 qf = *(const bf16x8*)(qs + lds_off<QROWB>(row, 2 * ks_ + h));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks_], sacc, 0, 0, 0);
-        bf16x8 gf = *(const bf16x8*)(gs + lds_off<QROWB>(row, 2 * ks_ + h));
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks_], dpacc, 0, 0, 0);
-      }
-      // accumulator register r <-> query 32qb + 16(r>>3) + 8h + (r&7): stats are contiguous 8-float runs
-      float lse_r[16], del_r[16];
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        const float* sp = stat + 32 * qb + 16 * m + 8 * h;
-        *(f32x4*)&lse_r[8 * m] = *(const f32x4*)sp;
-        *(f32x4*)&lse_r[8 * m + 4] = *(const f32x4*)(sp + 4);
-        *(f32x4*)&del_r[8 * m] = *(const f32x4*)(sp + 64);
-        *(f32x4*)&del_r[8 * m + 4] = *(const f32x4*)(sp + 68);
-      }
-      float pr[16], ds[16];
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        pr[r] = fast_exp2(sacc[r] * scale2 + kb2 - lse_r[r]);
-        ds[r] = pr[r] * (dpacc[r] - del_r[r]);
-      }
-      bf16x8 pf[2], dsf[2];
-      pf[0] = pack8(&pr[0]); pf[1] = pack8(&pr[8]);
-      dsf[0] = pack8(&ds[0]); dsf[1] = pack8(&ds[8]);
-#pragma unroll
-      for (int dt = 0; dt < NDT; dt++) {
-        const int trow = 32 * dt + l31;
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-          const int ch = 4 * qb + 2 * m + h;
-          bf16x8 gtf = *(const bf16x8*)(gts + lds_off<128>(trow, ch));
-          acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf, pf[m], acc_dv[dt], 0, 0, 0);
-          bf16x8 qtf = *(const bf16x8*)(qts + lds_off<128>(trow, ch));
-          acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[m], acc_dk[dt], 0, 0, 0);
-        }
-      }
-    }
-    if (qt + 1 < nqt) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-  if (key < Sk) {
-    bf16* krow = dK + (bh * Sk + key) * (int64_t)HD;
-    bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
-#pragma unroll
-    for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        bf16x4 ok, ov;
-#pragma unroll
-        for (int bb = 0; bb < 4; bb++) {
-          ok[bb] = f2bf(acc_dk[dt][4 * a + bb] * scale);
-          ov[bb] = f2bf(acc_dv[dt][4 * a + bb]);
-        }
-        *(bf16x4*)(krow + 32 * dt + 8 * a + 4 * h) = ok;
-        *(bf16x4*)(vrow + 32 * dt + 8 * a + 4 * h) = ov;
       }
   }
 }
@@ -480,9 +300,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
   const int64_t bh = (int64_t)b * H + head;
-  const int key = blockIdx.x * 256 + wv * 32 + l31;
+  const int key = wg.tile * 256 + wv * 32 + l31;
   const int keyi = min(key, Sk - 1);
 
   const bf16* Qg = Q + bh * (int64_t)Sq * HD;
@@ -679,9 +500,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
   const int64_t bh = (int64_t)b * H + head;
-  const int key = blockIdx.x * 256 + wv * 32 + l31;
+  const int key = wg.tile * 256 + wv * 32 + l31;
   const int keyi = min(key, Sk - 1);
 
   const bf16* Qg = Q + bh * (int64_t)Sq * HD;
@@ -848,8 +670,6 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   float* delta = (float*)workspace;
   float* lsep = (float*)((char*)workspace + round256((size_t)B * H * Sp * sizeof(float)));
   bf16* dOt = Qt ? (bf16*)((char*)workspace + 2 * round256((size_t)B * H * Sp * sizeof(float))) : nullptr;
-  static int dkv_gen = -1;
-  if (dkv_gen < 0) { const char* e = getenv("ST355_ATTN_DKV"); dkv_gen = (e && e[0] == '1') ? 1 : 2; }   // A/B: 1 = first-generation kernel
   const float scale2 = scale * LOG2E;
   const double fl_unit = 2.0 * (double)B * H * (double)S * Sk * d;  // one Sq x Sk x d contraction
   hipStream_t st = (hipStream_t)stream;
@@ -874,89 +694,49 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
       hipLaunchKernelGGL(k_attn_bwd_dkv3, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
                          (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2);
-    } else if (d == 96 && dkv_gen == 2) {       // head_dim 96 (PixArt's 72, zero-padded): 12 DMA pieces per tile image over the 8 waves
+    } else {                                   // head-major Q^T / dO^T copies supplied: the LDS-DMA kernel over four tile images (head_dim 64 / 96 / 128)
       dim3 grid((Sk + 255) / 256, H, B);
-      const int lds = 2 * (2 * 64 * 192 + 2 * 96 * 128 + 512);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv2<96>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
-                         key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-    } else if (d == 96) {        // ST355_ATTN_DKV=1: the register-staged kernel, 4 waves x 32 keys
-      dim3 grid((Sk + 127) / 128, H, B);
-      const int lds = 2 * (2 * 64 * 192 + 2 * 96 * 128 + 512);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv<96>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
-                         (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-    } else if (dkv_gen == 2) {
-      dim3 grid((Sk + 255) / 256, H, B);
-      if (d == 128) {
-        const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
-        static bool set = false;
-        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-        hipLaunchKernelGGL(k_attn_bwd_dkv2<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
-                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-      } else {
-        const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
-        static bool set = false;
-        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-        hipLaunchKernelGGL(k_attn_bwd_dkv2<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta,
-                           key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-      }
-    } else {
-      dim3 grid((Sk + 127) / 128, H, B);
-      if (d == 128) {
-        const int lds = 2 * (2 * 64 * 256 + 2 * 128 * 128 + 512);
-        static bool set = false;
-        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-        hipLaunchKernelGGL(k_attn_bwd_dkv<128>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
-                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-      } else {
-        const int lds = 2 * (2 * 64 * 128 + 2 * 64 * 128 + 512);
-        static bool set = false;
-        if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-        hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt,
-                           (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias,
-                           (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);
-      }
-  }
+      const int lds = 2 * (2 * 64 * d * 2 + 2 * d * 128 + 512);
+#define ST355_DKV2_LAUNCH(KERN)                                                                                                          \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt, (const bf16*)v_rows, ld_v,     \
+                       (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK,           \
+                       (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);                                                        \
+  } while (0)
+      if (d == 128) ST355_DKV2_LAUNCH(k_attn_bwd_dkv2<128>);
+      else if (d == 96) ST355_DKV2_LAUNCH(k_attn_bwd_dkv2<96>);     // PixArt's 72, zero-padded: 12 DMA pieces per tile image over the 8 waves
+      else ST355_DKV2_LAUNCH(k_attn_bwd_dkv2<64>);
+#undef ST355_DKV2_LAUNCH
+    }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
-    if (d == 96) {
-      const int lds = 2 * (2 * 64 * 192 + 96 * 128);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dq<96>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
-                         scale, scale2);
-    } else if (d == 128 && !Kt) {
-      const int lds = 2 * (2 * 64 * 256);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL((k_attn_bwd_dq<128, true>), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)nullptr,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
-                         scale, scale2);
-    } else if (d == 128) {
-      const int lds = 2 * (2 * 64 * 256 + 128 * 128);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dq<128>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
-                         scale, scale2);
+    const int ktb = 64 * d * 2;                                   // one row-major 64-key tile
+    const bool tr = (d == 128 && !Kt);                            // no K^T copy: transposing-read kernel (head_dim 128 only)
+    const int lds = 2 * (2 * ktb + (tr ? 0 : d * 128));
+#define ST355_DQ_LAUNCH(KERN)                                                                                                            \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt, (const bf16*)v_rows, ld_v,     \
+                       (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2);        \
+  } while (0)
+    if (key_bias) {
+      if (d == 96) ST355_DQ_LAUNCH((k_attn_bwd_dq<96, false, true>));
+      else if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, true, true>));
+      else if (d == 128) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, false, true>));
+      else ST355_DQ_LAUNCH((k_attn_bwd_dq<64, false, true>));
     } else {
-      const int lds = 2 * (2 * 64 * 128 + 64 * 128);
-      hipLaunchKernelGGL(k_attn_bwd_dq<64>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt,
-                         (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp,
-                         scale, scale2);
+      if (d == 96) ST355_DQ_LAUNCH((k_attn_bwd_dq<96, false, false>));
+      else if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, true, false>));
+      else if (d == 128) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, false, false>));
+      else ST355_DQ_LAUNCH((k_attn_bwd_dq<64, false, false>));
     }
+#undef ST355_DQ_LAUNCH
     if ((rc = st355_check_launch("attn_bwd_dq")) != 0) return rc;
   }
   return ST355_OK;

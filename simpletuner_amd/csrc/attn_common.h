@@ -35,3 +35,24 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// XCD-aware workgroup -> (tile, head, batch) mapping for the attention kernels.  Grids stay (tiles, H, B); the hardware hands consecutive linear
+// workgroup ids (x fastest) to the 8 XCDs round-robin, so with the identity mapping the tiles of ONE head are spread over all 8 XCDs and every
+// XCD's private L2 streams the K/V (or Q/dO) tiles of every head — 8 L2 fills per tile, and each XCD's L2 holds 14 heads' working windows at once.
+// Here linear id L goes to head*batch index (L % 8) + 8 * ((L / 8) / tiles): all tiles of a head run on one XCD, each K/V tile is filled into one L2
+// once and then hit by the other workgroups of that head.  Needs H*B % 8 == 0 (Flux 24 x B, SD3 24 x B, PixArt 16 x B, SDXL 10/20 x even B);
+// otherwise the identity mapping is kept.  ST355_ATTN_NO_XCD (lab builds) compiles the identity mapping for A/B runs.
+struct WgMap { int tile, head, b; };
+__device__ __forceinline__ WgMap attn_wg_map() {
+  const int gx = gridDim.x, H = gridDim.y, HB = H * gridDim.z;
+  int tile = blockIdx.x, hb = blockIdx.y + H * blockIdx.z;
+#ifndef ST355_ATTN_NO_XCD
+  if ((HB & 7) == 0) {
+    const int L = tile + gx * hb, slot = L >> 3, grp = slot / gx;
+    hb = (L & 7) + 8 * grp;
+    tile = slot - grp * gx;
+  }
+#endif
+  WgMap m; m.tile = tile; m.b = hb / H; m.head = hb - m.b * H;
+  return m;
+}

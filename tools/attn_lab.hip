@@ -1,6 +1,7 @@
 // attn_lab — standalone attention kernel lab for libst355 (no torch: starts in milliseconds on a fresh GPU box).
 //   tools/attn_lab [B H S d]      default 2 24 4608 128 (Flux.1 1024^2 at per-GPU batch 2)
-// Times st355_attn_fwd (generation picked by ST355_ATTN_FWD = 1 | 2 | 3; the lab re-executes itself once per generation) and st355_attn_bwd with and
+// Times st355_attn_fwd (ST355_ATTN_FWD=1: the r01 kernel, otherwise the default r02 kernel; the lab re-executes itself once per generation, and the
+// second child checks its output against the r01 kernel launched directly) and st355_attn_bwd with and
 // without the pre-transposed Q^T / K^T copies (dkv2 + dq vs dkv3 + dq<TR>), per kernel class through the library's own hipEvent profiler, and checks
 // that the two backward paths agree bit for bit.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast tools/attn_lab.hip -o tools/attn_lab
@@ -61,7 +62,7 @@ static void prof_print(const char* what) {
 
 int main(int argc, char** argv) {
   if (!getenv("ATTN_LAB_CHILD")) {
-    const char* gens[] = {"1", "3", "2"};
+    const char* gens[] = {"1", "4"};
     for (const char* g : gens) {
       setenv("ST355_ATTN_FWD", g, 1); setenv("ATTN_LAB_CHILD", "1", 1);
       fflush(stdout);
@@ -97,6 +98,19 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; i++) RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O, D, lse2, B, H, S, Sp, d, scale));
   CK(hipStreamSynchronize(st));
   st355_prof_enable(0); prof_print("forward");
+  if (strcmp(gen, "1") != 0 && d == 128) {   // other generations: compare O / lse2 with the generation-1 kernel launched directly
+    bf16* O1; float* lse1; CK(hipMalloc(&O1, nr * 2)); CK(hipMalloc(&lse1, (size_t)BH * S * 4));
+    const int lds = 2 * (KB * 256 + 128 * 128);
+    CK(hipFuncSetAttribute((const void*)k_attn_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k_attn_fwd<128>, dim3((S + QB - 1) / QB, H, B), dim3(ATT_THREADS), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt,
+                       (const float*)nullptr, O1, D, lse1, H, S, S, Sp, scale * LOG2E);
+    unsigned long long* bad; float* maxd; CK(hipMalloc(&bad, 8)); CK(hipMalloc(&maxd, 4));
+    CK(hipMemsetAsync(bad, 0, 8, st)); CK(hipMemsetAsync(maxd, 0, 4, st));
+    k_diff<<<2048, 256, 0, st>>>(O, O1, (int64_t)nr, 0, 0, bad, maxd);
+    unsigned long long hb; float hm;
+    CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    printf("  O vs generation 1: %llu of %lld elements differ (max |d| %.3e)\n", hb, (long long)nr, hm);
+  }
   if (strcmp(gen, "1") != 0) return 0;    // the backward comparison runs once (in the generation-1 child)
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
   for (int pass = 0; pass < 2; pass++) {
