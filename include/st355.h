@@ -120,6 +120,12 @@ typedef struct st355_gemm_args {
                                                     LoRA down-projection x A^T) run split-K over all CUs; NULL => never split */
   int32_t K2_real;                  /* how many of the K2 extension columns carry adapter data (the rest is zero padding to the 64-column K granule);
                                        0 = all of them.  Only the profiler's ALGORITHMIC flop / byte counts use it: padding is not work. */
+  /* Segmented rows (0 = off): the M logical rows are M / seg_rows equal segments; logical row m of operand X in {A, A2, C, aux_in, aux_out} lives
+   * at physical row (m / seg_rows) * seg_X + m % seg_rows from X's base pointer (seg_X = 0 means compact, i.e. seg_rows).  This is how the
+   * per-sample row blocks of a joint [B, S, *] buffer — e.g. the image rows of every sample of [txt || img] (flux/transformer.py:1332) — form ONE
+   * problem instead of B launches that each fill the 256 CUs badly, with no gather/scatter copy on either side.  seg_rows must be a multiple of 256
+   * (a tile never straddles two segments) and divide M; EPI_GATE_RESIDUAL's rows_per_batch keeps counting LOGICAL rows.  NT bf16 GEMM only. */
+  int64_t seg_rows, seg_a, seg_a2, seg_c, seg_in, seg_out;
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two
@@ -163,6 +169,11 @@ size_t st355_skinny_tn_workspace(int64_t M, int64_t P, int Rn);
 int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr,
                     float* out, int64_t so_p, int64_t so_r, int64_t M, int64_t P, int Rn, int r_used,
                     float alpha, int accumulate, void* workspace);
+/* the same over segmented rows (see st355_gemm_args.seg_rows): logical row m of L / R lives at physical row (m / seg_rows) * seg_l + m % seg_rows
+ * (resp. seg_r; 0 = compact).  seg_rows: a multiple of 256 that divides M, or 0. */
+int st355_skinny_tn_seg(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr,
+                        float* out, int64_t so_p, int64_t so_r, int64_t M, int64_t P, int Rn, int r_used,
+                        float alpha, int accumulate, void* workspace, int64_t seg_rows, int64_t seg_l, int64_t seg_r);
 
 /* ---- K5: AdaLN modulate  y = LN(x; eps, no affine) * (1 + scale_b) + shift_b  (flux/transformer.py:396-403) */
 int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,

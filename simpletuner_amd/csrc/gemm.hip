@@ -70,7 +70,26 @@ struct GemmP {
   int conv_taps, conv_tpt, conv_wp, conv_hp;
   int64_t conv_row0;                            // grid position of GEMM row 0 (border test / image index)
   const bf16* img_add; int64_t img_add_stride;
+  // segmented rows (st355_gemm_args.seg_rows): logical row m of the problem lives at physical row (m / seg_rows) * stride_X + m % seg_rows of operand X.
+  // seg_xX = (stride_X - seg_rows) * ld_X, the extra ELEMENTS to skip per segment: a tile (whose rows never straddle a segment: seg_rows is a multiple
+  // of 256) just shifts its operand base pointers by (m0 / seg_rows) * seg_xX (seg_view below) — the K loop and the epilogues are untouched.
+  int seg_rows = 0;
+  int64_t seg_xa = 0, seg_xa2 = 0, seg_xc = 0, seg_xin = 0, seg_xout = 0;
 };
+
+// the tile at row m0 of a segmented problem sees plain operands whose base pointers are shifted to its segment
+__device__ __forceinline__ GemmP seg_view(const GemmP& p0, int m0) {
+  GemmP p = p0;
+  if (p0.seg_rows) {
+    const int64_t s = m0 / p0.seg_rows;
+    p.A = p0.A + s * p0.seg_xa;
+    p.A2 = p0.A2 ? p0.A2 + s * p0.seg_xa2 : nullptr;
+    p.C = p0.C + s * p0.seg_xc;
+    p.aux_in = p0.aux_in ? p0.aux_in + s * p0.seg_xin : nullptr;
+    p.aux_out = p0.aux_out ? p0.aux_out + s * p0.seg_xout : nullptr;
+  }
+  return p;
+}
 
 // grid position -> (is border, image index)
 __device__ __forceinline__ bool conv_border(const GemmP& p, int m, int& img) {
@@ -352,11 +371,12 @@ __global__ void __launch_bounds__(P3_THREADS, 2) k_gemm_p3(GemmGroup g) {
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int pi = id >= g.tiles0 ? 1 : 0;
   if (pi) id -= g.tiles0;
-  const GemmP& p = g.p[pi];
-  const int nbm = (p.M + P3_BM - 1) / P3_BM, nbn = (p.N + P3_BN - 1) / P3_BN;
+  const GemmP& p0 = g.p[pi];
+  const int nbm = (p0.M + P3_BM - 1) / P3_BM, nbn = (p0.N + P3_BN - 1) / P3_BN;
   int pm, pn;
   tile_coords(id, nbm, nbn, pm, pn);
   const int m0 = pm * P3_BM, n0 = pn * P3_BN;
+  const GemmP p = seg_view(p0, m0);
   const int nt1 = p.K / BK;
   const int nt = nt1 + p.K2 / BK;
 
@@ -519,16 +539,17 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   int id = (EPI == EPI_SPLITK) ? xcd_remap(blockIdx.x % g.tiles0, g.tiles0) : xcd_remap(blockIdx.x, gridDim.x);
   const int pi = id >= g.tiles0 ? 1 : 0;
   if (pi) id -= g.tiles0;
-  const GemmP& p = g.p[pi];
-  const int nbm = (p.M + PQ_BM - 1) / PQ_BM, nbn = (p.N + PQ_BN - 1) / PQ_BN;
+  const GemmP& p0 = g.p[pi];
+  const int nbm = (p0.M + PQ_BM - 1) / PQ_BM, nbn = (p0.N + PQ_BN - 1) / PQ_BN;
   // TN with conv_taps == 9 (weight gradient of a 3x3 convolution, st355_conv_wgrad_bf16): the nine taps are nine column blocks of the output
   // ([P, 9*N], block tap at columns tap*N) whose R operand is the SAME matrix shifted by (ty*Wp + tx) contraction rows: one launch for all taps
-  const int wtaps = (TN && p.conv_taps == 9) ? 9 : 1;
+  const int wtaps = (TN && p0.conv_taps == 9) ? 9 : 1;
   int pm, pn;
   tile_coords(id, nbm, nbn * wtaps, pm, pn);
   const int wtap = pn / nbn;
   pn -= wtap * nbn;
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
+  const GemmP p = seg_view(p0, m0);            // (TN / conv / fp8 problems never carry segments: validate())
   const int nt_all = p.K / (PQ_BK * 2 / ES);
   const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
   const int t_first = slice * per;
@@ -798,19 +819,20 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #define S2_LDS (2 * S2_STAGE)
 
 template <int EPI>
-__global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p) {
+__global__ void __launch_bounds__(S2_THREADS, 2) k_gemm_s2(GemmP p_in) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;
-  const int nbm = (p.M + S2_BM - 1) / S2_BM, nbn = (p.N + S2_BN - 1) / S2_BN;
+  const int nbm = (p_in.M + S2_BM - 1) / S2_BM, nbn = (p_in.N + S2_BN - 1) / S2_BN;
   int pm, pn;
   // split-K: blockIdx.x = slice * tiles + tile; slice s owns K-tiles [s*per, min(nt1, (s+1)*per))  (no K2 segment when splitting)
   const int tiles = nbm * nbn;
   const int slice = (EPI == EPI_SPLITK) ? blockIdx.x / tiles : 0;
   tile_coords(xcd_remap((EPI == EPI_SPLITK) ? blockIdx.x % tiles : blockIdx.x, tiles), nbm, nbn, pm, pn);
   const int m0 = pm * S2_BM, n0 = pn * S2_BN;
+  const GemmP p = seg_view(p_in, m0);
   const int nt1 = p.K / BK;
   const int per = (EPI == EPI_SPLITK) ? (nt1 + p.ksplit - 1) / p.ksplit : 0;
   const int t_first = (EPI == EPI_SPLITK) ? slice * per : 0;
@@ -926,6 +948,12 @@ static int validate(const st355_gemm_args* a) {
   if ((a->epilogue == ST355_EPI_GELU || a->epilogue == ST355_EPI_GATE_RESIDUAL) && a->aux_out)
     ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
   ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_ADD, "gemm: unknown epilogue %d", a->epilogue);
+  if (a->seg_rows) {
+    ST_REQUIRE(a->seg_rows > 0 && a->seg_rows % 256 == 0 && a->M % a->seg_rows == 0, "gemm: seg_rows (%lld) must be a multiple of 256 that divides M (%d)",
+               (long long)a->seg_rows, a->M);
+    ST_REQUIRE(a->seg_a >= 0 && a->seg_a2 >= 0 && a->seg_c >= 0 && a->seg_in >= 0 && a->seg_out >= 0, "gemm: negative segment stride");
+    ST_REQUIRE((a->seg_a == 0 || a->seg_a >= a->seg_rows) && (a->seg_c == 0 || a->seg_c >= a->seg_rows), "gemm: segment stride smaller than seg_rows");
+  }
   ST_REQUIRE(256 * (a->lda > a->ldb ? a->lda : a->ldb) * 2 + (int64_t)a->K * 2 < ((int64_t)1 << 31), "gemm: a 256-row tile must fit 32-bit buffer offsets");
   return ST355_OK;
 }
@@ -942,6 +970,12 @@ static GemmP to_p(const st355_gemm_args* a) {
   p.partial = nullptr; p.ksplit = 1; p.part_ld = a->N;
   p.scale_a = nullptr; p.scale_b = nullptr;
   p.conv_taps = 0; p.conv_tpt = 1; p.conv_wp = 0; p.conv_hp = 0; p.conv_row0 = 0; p.img_add = nullptr; p.img_add_stride = 0;
+  if (a->seg_rows) {
+    auto extra = [&](int64_t stride, int64_t ld) { return stride ? (stride - a->seg_rows) * ld : (int64_t)0; };
+    p.seg_rows = (int)a->seg_rows;
+    p.seg_xa = extra(a->seg_a, a->lda); p.seg_xa2 = extra(a->seg_a2, a->lda2); p.seg_xc = extra(a->seg_c, a->ldc);
+    p.seg_xin = extra(a->seg_in, a->ld_aux_in); p.seg_xout = extra(a->seg_out, a->ld_aux_out);
+  }
   return p;
 }
 
@@ -1037,7 +1071,7 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   GemmP p = to_p(a);
   // thin problems (the LoRA rank-space projections: N <= 128, K in the thousands) stream A once and have only M/128 tiles: split
   // K so that >= 2 workgroups per CU are in flight, partial sums through the caller's fp32 workspace (fixed-order reduce)
-  if (a->workspace && p.N <= S2_BN && p.K2 == 0 && a->epilogue == ST355_EPI_NONE && p.K >= 1024 && p.M >= 512) {
+  if (a->workspace && p.N <= S2_BN && p.K2 == 0 && a->epilogue == ST355_EPI_NONE && p.K >= 1024 && p.M >= 512 && !(a->seg_rows && a->seg_c)) {   // (the slab reduce writes compact C rows)
     const int tiles = (p.M + S2_BM - 1) / S2_BM;
     int ks = (512 + tiles - 1) / tiles;
     const int nt1 = p.K / BK;

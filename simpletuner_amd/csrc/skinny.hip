@@ -15,7 +15,7 @@
 
 template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
-                                                  float* __restrict__ ws, int64_t M, int64_t P) {
+                                                  float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr) {
   constexpr int RT = RN / 16;
   __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS][SK_PT];
   __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS][RN];
@@ -23,6 +23,11 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
   const int pg = tid & 15, rg = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
   const int64_t mbase = (int64_t)blockIdx.y * SK_MC;
+  if (seg_rows) {          // segmented rows (st355_skinny_tn_seg): this 256-row chunk lies inside segment mbase / seg_rows; shift both operand bases to it
+    const int64_t sgi = mbase / seg_rows;
+    L += sgi * seg_xl;
+    R += sgi * seg_xr;
+  }
   float acc[8][RT];
 #pragma unroll
   for (int i = 0; i < 8; i++)
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
 #define SK_LP (SK_PT + 32)      // 160 elements = 320 B
 template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
-                                                       float* __restrict__ ws, int64_t M, int64_t P) {
+                                                       float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr) {
   constexpr int RT = RN / 32;                  // 32-wide r blocks
   constexpr int RP = (RN == 32) ? 32 : 96;     // R tile pitch in elements (64 B / 192 B)
   __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS * SK_LP];
@@ -95,6 +100,11 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
   const int64_t mbase = (int64_t)blockIdx.y * SK_MC;
+  if (seg_rows) {          // segmented rows (st355_skinny_tn_seg): this 256-row chunk lies inside segment mbase / seg_rows; shift both operand bases to it
+    const int64_t sgi = mbase / seg_rows;
+    L += sgi * seg_xl;
+    R += sgi * seg_xr;
+  }
   f32x16 acc[RT];
 #pragma unroll
   for (int j = 0; j < RT; j++)
@@ -188,9 +198,15 @@ extern "C" size_t st355_skinny_tn_workspace(int64_t M, int64_t P, int Rn) {
   return (size_t)cdiv64(M, SK_MC) * (size_t)P * (size_t)Rn * sizeof(float);
 }
 
-extern "C" int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* out, int64_t so_p,
-                               int64_t so_r, int64_t M, int64_t P, int Rn, int r_used, float alpha, int accumulate, void* workspace) {
+// seg_rows > 0: logical row m of L / R lives at physical row (m / seg_rows) * seg_l + m % seg_rows (resp. seg_r; 0 = compact) — the same segmented-row
+// view as st355_gemm_args.seg_rows, so the rank-space gradients read the per-sample row blocks of a joint [B, S, *] buffer in place.
+extern "C" int st355_skinny_tn_seg(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* out, int64_t so_p,
+                                   int64_t so_r, int64_t M, int64_t P, int Rn, int r_used, float alpha, int accumulate, void* workspace,
+                                   int64_t seg_rows, int64_t seg_l, int64_t seg_r) {
   ST_REQUIRE(L && R && out && workspace, "skinny_tn: null pointer");
+  ST_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % SK_MC == 0 && M % seg_rows == 0 && (seg_l == 0 || seg_l >= seg_rows) && (seg_r == 0 || seg_r >= seg_rows)),
+             "skinny_tn: seg_rows (%lld) must be a multiple of %d that divides M; strides >= seg_rows", (long long)seg_rows, SK_MC);
+  const int64_t seg_xl = (seg_rows && seg_l) ? (seg_l - seg_rows) * ldl : 0, seg_xr = (seg_rows && seg_r) ? (seg_r - seg_rows) * ldr : 0;
   ST_REQUIRE((Rn == 32 || Rn == 64) && r_used > 0 && r_used <= Rn, "skinny_tn: Rn must be 32 or 64 (got %d)", Rn);
   ST_REQUIRE(M > 0 && P > 0 && P % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0, "skinny_tn: bad shape");
   const int nchunks = (int)cdiv64(M, SK_MC);
@@ -200,20 +216,24 @@ extern "C" int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const v
   if (gen < 0) { const char* e = getenv("ST355_SKINNY"); gen = (e && e[0] == '1') ? 1 : 2; }
   if (gen == 2 && Rn == 32)
     hipLaunchKernelGGL(k_skinny_tn_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
   else if (gen == 2)
     hipLaunchKernelGGL(k_skinny_tn_mfma<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
   else if (Rn == 32)
     hipLaunchKernelGGL(k_skinny_tn<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
   else
     hipLaunchKernelGGL(k_skinny_tn<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
   int rc = st355_check_launch("skinny_tn");
   if (rc) return rc;
   const int64_t n = P * r_used;
   hipLaunchKernelGGL(k_skinny_reduce, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out,
                      so_p, so_r, P, Rn, r_used, nchunks, alpha, accumulate);
   return st355_check_launch("skinny_reduce");
+}
+extern "C" int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* out, int64_t so_p,
+                               int64_t so_r, int64_t M, int64_t P, int Rn, int r_used, float alpha, int accumulate, void* workspace) {
+  return st355_skinny_tn_seg(stream, L, ldl, R, ldr, out, so_p, so_r, M, P, Rn, r_used, alpha, accumulate, workspace, 0, 0, 0);
 }

@@ -82,7 +82,7 @@ class LoraGroup:
         """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r])."""
         for g, (_, n_off, N) in enumerate(self.targets):
             c0 = g * self.r_pad
-            ops.skinny_tn(dy[:, n_off:n_off + N], T[:, c0:c0 + self.r_pad], self.gB[g], self.rank, 1, self.rank,
+            ops.skinny_tn(dy[..., n_off:n_off + N], T[:, c0:c0 + self.r_pad], self.gB[g], self.rank, 1, self.rank,
                           alpha=self.scale, accumulate=accumulate)
             ops.skinny_tn(x, U[:, c0:c0 + self.r_pad], self.gA[g], 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
         if sync is not None:
@@ -385,6 +385,44 @@ class FluxTransformer2DModel(nn.Module):
     # ------------------------------------------------------------------------------------------------
     # forward / backward engines
     # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _rows_of(joint, lo: int, rows: int, env):
+        """rows [lo, lo + rows) of every sample of a joint [B * S, C] buffer, as a GEMM / skinny operand: a [B, rows, C] strided view (no copy)"""
+        return joint.view(env.B, env.S, -1)[:, lo:lo + rows]
+
+    @staticmethod
+    def _problems(env, rows: int, pr: dict):
+        """One projection over the `rows`-row block of every sample.  Operands may be compact [B * rows, C] tensors or [B, rows, C] views of joint
+        buffers (_rows_of).  When the blocks are tile-aligned (rows % 256 == 0) that is ONE segmented problem (st355_gemm_args.seg_rows: one grid of
+        B * rows / 256 row tiles instead of B launches that each fill the 256 CUs badly); otherwise one problem per sample, as before."""
+        B = env.B
+        ROWED = ("a", "a2", "out", "aux_in", "aux_out")
+        if B == 1:
+            return [{k: (v[0] if k in ROWED and torch.is_tensor(v) and v.dim() == 3 else v) for k, v in pr.items()}]
+        if rows % 256 == 0:
+            return [pr]
+        out = []
+        for b in range(B):
+            q = {}
+            for k, v in pr.items():
+                if k in ROWED and torch.is_tensor(v):
+                    q[k] = v[b] if v.dim() == 3 else v[b * rows:(b + 1) * rows]
+                elif k == "gate":
+                    q[k] = v[b:b + 1]
+                else:
+                    q[k] = v
+            out.append(q)
+        return out
+
+    @staticmethod
+    def _compact(t, env, rows: int):
+        """a [B, rows, C] view as an operand of the rank-space gradient kernels: as is when they can walk it segmented, else a compact copy"""
+        if t.dim() != 3:
+            return t
+        if env.B == 1:
+            return t[0]
+        return t if rows % 256 == 0 else t.reshape(env.B * rows, -1)
+
     def _alloc_heads(self, env):
         B, H, hd, S, Sp, dev = env.B, self.H, self.hd, env.S, env.Sp, self.device_
         Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
@@ -411,13 +449,11 @@ class FluxTransformer2DModel(nn.Module):
         qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
         T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
-        probs = []
-        for b in range(B):
-            kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
-            kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
-            probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S + St:(b + 1) * S], **kw_i))
-            probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S:b * S + St], **kw_t))
-        ops.gemm_grouped(probs)
+        kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
+        kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
+        # both streams project into the joint [txt || img] rows of qkv (flux/transformer.py:171-190 concatenates q, k, v of the two streams)
+        ops.gemm_grouped(self._problems(env, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=self._rows_of(qkv, St, Si, env), **kw_i))
+                         + self._problems(env, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=self._rows_of(qkv, 0, St, env), **kw_t)))
         Q, K, Qt, Kt, Vt = self._alloc_heads(env)
         ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
         ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
@@ -427,21 +463,20 @@ class FluxTransformer2DModel(nn.Module):
         x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
         T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
         T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
-        probs = []
-        for b in range(B):
-            O_t, O_i = O[b * S:b * S + St], O[b * S + St:(b + 1) * S]
-            kw_i, kw_t = {}, {}
-            if T_o is not None:
-                ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
-                kw_i = dict(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk, k2_real=blk.to_out.lora.k2_real)
-            if T_ao is not None:
-                ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
-                kw_t = dict(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
-            probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
-                              aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
-            probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St], epilogue=EPI_GATE_RESIDUAL,
-                              aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St, **kw_t))
-        ops.gemm_grouped(probs)
+        O_i, O_t = self._rows_of(O, St, Si, env), self._rows_of(O, 0, St, env)       # the attention output is split back by rows, in place
+        kw_i, kw_t = {}, {}
+        if T_o is not None:
+            for pr in self._problems(env, Si, dict(a=O_i, w=blk.to_out.lora.A_cat, out=T_o)):
+                ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+            kw_i = dict(a2=T_o, b2=blk.to_out.lora.B_blk, k2_real=blk.to_out.lora.k2_real)
+        if T_ao is not None:
+            for pr in self._problems(env, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao)):
+                ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+            kw_t = dict(a2=T_ao, b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
+        ops.gemm_grouped(self._problems(env, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
+                                                      gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
+                         + self._problems(env, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
+                                                        aux_in=txt, gate=mt[:, 2 * D:3 * D], rows_per_batch=St, **kw_t)))
         # MLPs
         n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
         n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
@@ -453,13 +488,10 @@ class FluxTransformer2DModel(nn.Module):
             # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
             # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
             x = torch.empty(B * S, D, dtype=BF16, device=dev)
-            probs = []
-            for b in range(B):
-                probs.append(dict(a=h_i[b * Si:(b + 1) * Si], w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img[b * Si:(b + 1) * Si],
-                                  gate=mi[b:b + 1, 5 * D:6 * D], rows_per_batch=Si, out=x[b * S + St:(b + 1) * S]))
-                probs.append(dict(a=h_t[b * St:(b + 1) * St], w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt[b * St:(b + 1) * St],
-                                  gate=mt[b:b + 1, 5 * D:6 * D], rows_per_batch=St, out=x[b * S:b * S + St]))
-            ops.gemm_grouped(probs)
+            ops.gemm_grouped(self._problems(env, Si, dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img,
+                                                          gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, out=self._rows_of(x, St, Si, env)))
+                             + self._problems(env, St, dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt,
+                                                            gate=mt[:, 5 * D:6 * D], rows_per_batch=St, out=self._rows_of(x, 0, St, env))))
         else:
             x2_img, x2_txt = ops.gemm_grouped([
                 dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
@@ -606,17 +638,13 @@ class FluxTransformer2DModel(nn.Module):
         dO = torch.empty(B * S, D, dtype=BF16, device=dev)
         U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
         U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if blk.to_add_out.lora is not None else None
-        probs = []
-        for b in range(B):
-            kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T, k2_real=blk.to_out.lora.k2_real) if U_i is not None else {}
-            kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T, k2_real=blk.to_add_out.lora.k2_real) if U_t is not None else {}
-            probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S + St:(b + 1) * S], **kw_i))
-            probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S:b * S + St], **kw_t))
-        ops.gemm_grouped(probs)
+        kw_i = dict(a2=U_i, b2=blk.to_out.lora.A_cat_T, k2_real=blk.to_out.lora.k2_real) if U_i is not None else {}
+        kw_t = dict(a2=U_t, b2=blk.to_add_out.lora.A_cat_T, k2_real=blk.to_add_out.lora.k2_real) if U_t is not None else {}
+        ops.gemm_grouped(self._problems(env, Si, dict(a=dx1g_i, w=blk.to_out.wT, out=self._rows_of(dO, St, Si, env), **kw_i))
+                         + self._problems(env, St, dict(a=dx1g_t, w=blk.to_add_out.wT, out=self._rows_of(dO, 0, St, env), **kw_t)))
         for (lin, U, T_, dxg, lo, rows) in ((blk.to_out, U_i, sv.T_o, dx1g_i, St, Si), (blk.to_add_out, U_t, sv.T_ao, dx1g_t, 0, St)):
-            if lin.lora is not None:
-                O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
-                lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+            if lin.lora is not None:       # dA = U^T O over this stream's rows of the joint attention output, read in place
+                lin.lora.grads(self._compact(self._rows_of(sv.O, lo, rows, env), env, rows), T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
         del dx1g_i, dx1g_t, U_i, U_t
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         dQ, dK = self._attn_backward(sv, dO, dqkv, env)
@@ -624,25 +652,27 @@ class FluxTransformer2DModel(nn.Module):
         ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
         del dQ, dK, dO
         last = li == 0
-        if B == 1:
-            dq_i, dq_t = dqkv[St:], dqkv[:St]
-        else:
-            dq_i = dqkv.view(B, S, 3 * D)[:, St:].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, :St].reshape(B * St, 3 * D)
-        streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
+        # the two streams' rows of the joint dqkv, in place (the reference's autograd splits the concatenated gradient the same way)
+        dq_i, dq_t = self._rows_of(dqkv, St, Si, env), self._rows_of(dqkv, 0, St, env)
+        streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img, Si), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt, St)]
         if last:
             streams = [s_ for s_ in streams if s_[1].lora is not None]   # frozen embedders: only adapter grads remain to compute
-        probs, Us = [], {}
-        for (name, lin, dq, n_in, T_) in streams:
+        probs, Us, dns = [], {}, []
+        for (name, lin, dq, n_in, T_, rows) in streams:
             kw = {}
             if lin.lora is not None:
-                Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
+                Us[name] = torch.empty(B * rows, lin.lora.B_blk_T.shape[0], dtype=BF16, device=dev)
+                for pr in self._problems(env, rows, dict(a=dq, w=lin.lora.B_blk_T, out=Us[name])):
+                    ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
                 kw = dict(a2=Us[name], b2=lin.lora.A_cat_T, k2_real=lin.lora.k2_real)
             if not last:
-                probs.append(dict(a=dq, w=lin.wT, **kw))
-        dns = ops.gemm_grouped(probs) if probs else []
-        for (name, lin, dq, n_in, T_) in streams:
+                dns.append(torch.empty(B * rows, D, dtype=BF16, device=dev))
+                probs += self._problems(env, rows, dict(a=dq, w=lin.wT, out=dns[-1], **kw))
+        if probs:
+            ops.gemm_grouped(probs)
+        for (name, lin, dq, n_in, T_, rows) in streams:
             if lin.lora is not None:
-                lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
+                lin.lora.grads(n_in, T_, self._compact(dq, env, rows), Us[name], self.accumulate_lora_grads, self.grad_sync)
         if last:
             return None, None
         d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)

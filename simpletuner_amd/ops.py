@@ -44,6 +44,24 @@ def _rows(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
+def _seg(t: torch.Tensor, name: str):
+    """A GEMM / skinny operand is either a 2-D row-major view or a 3-D view [segments, rows, cols] with unit inner stride whose segment stride is a
+    whole number of rows: the per-sample row blocks of a joint [B, S, *] buffer, e.g. `qkv.view(B, S, 3 * D)[:, St:]` (st355_gemm_args.seg_rows).
+    Returns (rows_total, cols, ld, seg_rows, seg_stride_rows); seg_rows = 0 for a plain 2-D operand."""
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1], _rows(t, name), 0, 0
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) <= 0 or t.stride(0) % t.stride(1) != 0:
+        raise _l.St355Error(f"{name}: expected a 2-D row-major view or a 3-D [segments, rows, cols] view whose segment stride is a whole number of rows, "
+                            f"got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.shape[0] * t.shape[1], t.shape[2], t.stride(1), t.shape[1], t.stride(0) // t.stride(1)
+
+
+def _seg_join(cur: int, new: int, name: str) -> int:
+    if new and cur and new != cur:
+        raise _l.St355Error(f"{name}: segmented operands of one problem must share seg_rows ({new} vs {cur})")
+    return cur or new
+
+
 # ------------------------------------------------------------------------------------------------
 # streaming ops
 # ------------------------------------------------------------------------------------------------
@@ -245,24 +263,29 @@ def _gemm_workspace(dev, nbytes: int = _GEMM_WS_BYTES):
 
 def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
                gate=None, rows_per_batch: int = 0, k2_real: int = 0):
+    """a, a2, out, aux_in, aux_out may be 3-D [segments, rows, cols] strided views (see _seg): one problem over the row blocks of a joint buffer."""
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
-    M, K = a.shape
+    M, K, g.lda, seg, g.seg_a = _seg(a, "a")
     N, Kw = w.shape
     if K != Kw:
         raise _l.St355Error(f"gemm: K mismatch {K} vs {Kw}")
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    g.A, g.lda = _ptr(a), _rows(a, "a")
-    g.B, g.ldb = _ptr(w), _rows(w, "w")
-    g.C, g.ldc = _ptr(out), _rows(out, "out")
+    Mo, No, g.ldc, sr, g.seg_c = _seg(out, "out")
+    if (Mo, No) != (M, N):
+        raise _l.St355Error(f"gemm: out is {Mo}x{No}, expected {M}x{N}")
+    seg = _seg_join(seg, sr, "gemm")
+    g.A, g.B, g.ldb, g.C = _ptr(a), _ptr(w), _rows(w, "w"), _ptr(out)
     g.M, g.N, g.K, g.K2 = M, N, K, 0
     if a2 is not None:
         _chk(a2, BF16, "a2"); _chk(b2, BF16, "b2")
-        if a2.shape[0] != M or b2.shape[0] != N or a2.shape[1] != b2.shape[1]:
+        M2, K2, g.lda2, sr, g.seg_a2 = _seg(a2, "a2")
+        seg = _seg_join(seg, sr, "gemm")
+        if M2 != M or b2.shape[0] != N or K2 != b2.shape[1]:
             raise _l.St355Error("gemm: low-rank extension shape mismatch")
-        g.A2, g.lda2 = _ptr(a2), _rows(a2, "a2")
+        g.A2 = _ptr(a2)
         g.B2, g.ldb2 = _ptr(b2), _rows(b2, "b2")
-        g.K2 = a2.shape[1]
+        g.K2 = K2
         g.K2_real = int(k2_real)          # adapter columns inside the 64-column granule (profiler accounting only)
     if bias is not None:
         _chk(bias, BF16, "bias")
@@ -275,14 +298,19 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
         g.workspace, g.workspace_bytes = _ptr(ws), ws.numel() * 4
     if aux_out is not None:
         _chk(aux_out, BF16, "aux_out")
-        g.aux_out, g.ld_aux_out = _ptr(aux_out), _rows(aux_out, "aux_out")
+        _, _, g.ld_aux_out, sr, g.seg_out = _seg(aux_out, "aux_out")
+        seg = _seg_join(seg, sr, "gemm")
+        g.aux_out = _ptr(aux_out)
     if aux_in is not None:
         _chk(aux_in, BF16, "aux_in")
-        g.aux_in, g.ld_aux_in = _ptr(aux_in), _rows(aux_in, "aux_in")
+        _, _, g.ld_aux_in, sr, g.seg_in = _seg(aux_in, "aux_in")
+        seg = _seg_join(seg, sr, "gemm")
+        g.aux_in = _ptr(aux_in)
     if gate is not None:
         _chk(gate, BF16, "gate")
         g.gate, g.gate_stride = _ptr(gate), _rows(gate, "gate")
         g.rows_per_batch = rows_per_batch
+    g.seg_rows = seg
     return out
 
 
@@ -414,19 +442,22 @@ _skinny_ws = {}
 
 
 def skinny_tn(Lm, R, out, so_p: int, so_r: int, r_used: int, alpha: float = 1.0, accumulate: bool = False):
-    """out[p*so_p + r*so_r] (+)= alpha * sum_m Lm[m,p] * R[m,r]   (fp32 out; rank-space LoRA gradients)."""
+    """out[p*so_p + r*so_r] (+)= alpha * sum_m Lm[m,p] * R[m,r]   (fp32 out; rank-space LoRA gradients).  Lm / R may be 3-D segmented views (_seg)."""
     L = _l.load()
     _chk(Lm, BF16, "L"); _chk(R, BF16, "R"); _chk(out, F32, "out")
-    M, P = Lm.shape
-    Rn = R.shape[1]
+    M, P, ldl, seg, seg_l = _seg(Lm, "L")
+    Mr, Rn, ldr, sr, seg_r = _seg(R, "R")
+    if Mr != M:
+        raise _l.St355Error(f"skinny_tn: L has {M} rows, R has {Mr}")
+    seg = _seg_join(seg, sr, "skinny_tn")
     need = L.st355_skinny_tn_workspace(M, P, Rn)
     key = (Lm.device.index,)
     ws = _skinny_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=F32, device=Lm.device)
         _skinny_ws[key] = ws
-    _l.check(L.st355_skinny_tn(_stream(), _ptr(Lm), _rows(Lm, "L"), _ptr(R), _rows(R, "R"), _ptr(out), so_p, so_r, M, P, Rn,
-                               r_used, alpha, 1 if accumulate else 0, _ptr(ws)), "skinny_tn")
+    _l.check(L.st355_skinny_tn_seg(_stream(), _ptr(Lm), ldl, _ptr(R), ldr, _ptr(out), so_p, so_r, M, P, Rn,
+                                   r_used, alpha, 1 if accumulate else 0, _ptr(ws), seg, seg_l, seg_r), "skinny_tn")
     return out
 
 

@@ -34,7 +34,9 @@ def _batch(devt):
     return {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
 
 
-@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(1, 1, 1, 16, 16, 64), (2, 2, 2, 16, 16, 32), (1, 2, 1, 16, 24, 40)])
+# the last case has tile-aligned streams (256 image + 256 text rows, B = 2): the double blocks then run their per-stream projections as segmented-row
+# problems over the joint buffers (FluxTransformer2DModel._problems) instead of one problem per sample
+@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(1, 1, 1, 16, 16, 64), (2, 2, 2, 16, 16, 32), (1, 2, 1, 16, 24, 40), (2, 1, 2, 32, 32, 256)])
 def test_flux_step_matches_oracle(layers, single, B, lat_h, lat_w, S_txt):
     plugin, trainer, cpu, devt = _build(layers, single, B, lat_h, lat_w, S_txt)
     model = plugin.get_trained_component()

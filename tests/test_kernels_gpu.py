@@ -341,6 +341,45 @@ def test_skinny_tn(ops, M, P, Rn, r):
     assert report("skinny_tn^T acc", outT, 1.0 + (Lm.float().t() @ R.float()[:, :r]).t())[0] < 1e-4
 
 
+@pytest.mark.parametrize("B,rows,lo,S,N,K", [(3, 256, 256, 768, 512, 256), (8, 512, 0, 4608, 256, 192), (2, 4096, 512, 4608, 768, 256)])
+def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, S, N, K):
+    """st355_gemm_args.seg_rows: the per-sample row blocks [lo, lo + rows) of joint [B, S, *] buffers as ONE problem (3-D strided views), on the A side, the
+    C side, the LoRA extension and the residual — bit-identical to one GEMM per sample on the same tiles, with a gated-residual epilogue on top
+    (flux/transformer.py:1332 `torch.cat` / the per-stream projections of a double block)."""
+    torch.manual_seed(41)
+    d = dev()
+    A_joint = torch.randn(B, S, K, device=d).to(BF16)                  # A rows taken out of a joint buffer
+    W = (torch.randn(N, K, device=d) * 0.05).to(BF16); bias = torch.randn(N, device=d).to(BF16)
+    T = torch.randn(B * rows, 64, device=d).to(BF16)                   # compact LoRA down-projection
+    Bs = (torch.randn(N, 64, device=d) * 0.05).to(BF16)
+    res = torch.randn(B, S, N, device=d).to(BF16)                      # residual in a joint buffer
+    gate = torch.randn(B, N, device=d).to(BF16)
+    out_joint = torch.full((B, S, N), 7.0, device=d, dtype=BF16)
+    ops.gemm(A_joint[:, lo:lo + rows], W, bias=bias, a2=T, b2=Bs, out=out_joint[:, lo:lo + rows], epilogue=ops.EPI_GATE_RESIDUAL,
+             aux_in=res[:, lo:lo + rows], gate=gate, rows_per_batch=rows)
+    ref = torch.full((B, S, N), 7.0, device=d, dtype=BF16)
+    for b in range(B):
+        ops.gemm(A_joint[b, lo:lo + rows], W, bias=bias, a2=T[b * rows:(b + 1) * rows], b2=Bs, out=ref[b, lo:lo + rows], epilogue=ops.EPI_GATE_RESIDUAL,
+                 aux_in=res[b, lo:lo + rows], gate=gate[b:b + 1], rows_per_batch=rows)
+    assert torch.equal(out_joint, ref)                                 # rows outside the blocks untouched (7.0), rows inside bit-equal
+    exact = res[:, lo:lo + rows].float() + gate.float()[:, None] * (A_joint[:, lo:lo + rows].float() @ W.float().t() + bias.float()
+                                                                    + (T.float() @ Bs.float().t()).view(B, rows, N))
+    assert report("segmented gemm vs fp32", out_joint[:, lo:lo + rows], exact)[0] < 6e-3
+    # grouped form: a segmented problem next to a plain one
+    o1 = torch.empty(B * rows, N, device=d, dtype=BF16); x2 = torch.randn(512, K, device=d).to(BF16)
+    o1b, o2 = ops.gemm_grouped([dict(a=A_joint[:, lo:lo + rows], w=W, out=o1), dict(a=x2, w=W)])
+    assert torch.equal(o1b.view(B, rows, N), torch.stack([ops.gemm(A_joint[b, lo:lo + rows], W) for b in range(B)]))
+    assert torch.equal(o2, ops.gemm(x2, W))
+    # rank-space gradients over the same segmented rows
+    dy = torch.randn(B, S, N, device=d).to(BF16)
+    g_seg = torch.zeros(N, 32, device=d); g_ref = torch.zeros(N, 32, device=d)
+    ops.skinny_tn(dy[:, lo:lo + rows], T, g_seg, 32, 1, 32, alpha=0.5)
+    ops.skinny_tn(dy[:, lo:lo + rows].reshape(B * rows, N), T, g_ref, 32, 1, 32, alpha=0.5)
+    assert torch.equal(g_seg, g_ref)
+    with pytest.raises(Exception):
+        ops.gemm(A_joint[:, 1:1 + 200], W)                              # 200-row segments: not a multiple of the 256-row tile
+
+
 # ------------------------------------------------------------------------------------------------
 # AdaLN, RMSNorm + RoPE
 # ------------------------------------------------------------------------------------------------
