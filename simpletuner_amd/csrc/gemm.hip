@@ -81,7 +81,7 @@ struct GemmP {
 __device__ __forceinline__ GemmP seg_view(const GemmP& p0, int m0) {
   GemmP p = p0;
   if (p0.seg_rows) {
-    const int64_t s = m0 / p0.seg_rows;
+    const int64_t s = __builtin_amdgcn_readfirstlane(m0 / p0.seg_rows);    // (the division runs on the VALU: keep the uniform quotient, and the pointers, scalar)
     p.A = p0.A + s * p0.seg_xa;
     p.A2 = p0.A2 ? p0.A2 + s * p0.seg_xa2 : nullptr;
     p.C = p0.C + s * p0.seg_xc;
@@ -539,24 +539,28 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   int id = (EPI == EPI_SPLITK) ? xcd_remap(blockIdx.x % g.tiles0, g.tiles0) : xcd_remap(blockIdx.x, gridDim.x);
   const int pi = id >= g.tiles0 ? 1 : 0;
   if (pi) id -= g.tiles0;
-  const GemmP& p0 = g.p[pi];
-  const int nbm = (p0.M + PQ_BM - 1) / PQ_BM, nbn = (p0.N + PQ_BN - 1) / PQ_BN;
+  const GemmP& p = g.p[pi];
+  const int nbm = (p.M + PQ_BM - 1) / PQ_BM, nbn = (p.N + PQ_BN - 1) / PQ_BN;
   // TN with conv_taps == 9 (weight gradient of a 3x3 convolution, st355_conv_wgrad_bf16): the nine taps are nine column blocks of the output
   // ([P, 9*N], block tap at columns tap*N) whose R operand is the SAME matrix shifted by (ty*Wp + tx) contraction rows: one launch for all taps
-  const int wtaps = (TN && p0.conv_taps == 9) ? 9 : 1;
+  const int wtaps = (TN && p.conv_taps == 9) ? 9 : 1;
   int pm, pn;
   tile_coords(id, nbm, nbn * wtaps, pm, pn);
   const int wtap = pn / nbn;
   pn -= wtap * nbn;
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;
-  const GemmP p = seg_view(p0, m0);            // (TN / conv / fp8 problems never carry segments: validate())
+  // segmented rows: this tile's segment index.  Only the two staging bases (below) and the epilogue's private GemmP copy (at the end) see it — the
+  // K loop's registers are exactly those of the plain kernel (a by-value seg_view() copy up here cost the aux_in epilogues 15 VGPRs and 15 % speed).
+  // seg_x* are 0 for absent operands and when segments are off (to_p), so the pointer arithmetic is unconditional.
+  // (readfirstlane: the integer division is expanded on the VALU, which would leave a wave-uniform value — and every pointer derived from it — in VGPRs)
+  const int64_t segi = (!TN && !F8 && !CONV && p.seg_rows) ? __builtin_amdgcn_readfirstlane(m0 / p.seg_rows) : 0;
   const int nt_all = p.K / (PQ_BK * 2 / ES);
   const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
   const int t_first = slice * per;
   const int nt1 = (EPI == EPI_SPLITK) ? max(0, min(nt_all, t_first + per) - t_first) : nt_all;
   const int nt = nt1 + ((EPI == EPI_SPLITK) ? 0 : p.K2 / PQ_BK);
 
-  const bf16* A1 = p.A; const bf16* B1 = p.B; const bf16* A2 = p.A2; const bf16* B2 = p.B2;
+  const bf16* A1 = p.A + segi * p.seg_xa; const bf16* B1 = p.B; const bf16* A2 = p.A2 + segi * p.seg_xa2; const bf16* B2 = p.B2;
   const int64_t la2 = p.lda2, lb2 = p.ldb2;
   const int M = p.M, N = p.N;
   // staging: a piece = 8 region rows x 128 B; this wave issues pieces 2wv, 2wv+1 of whichever region is being refilled.
@@ -804,6 +808,13 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
     ps.conv_taps = 0;
     gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (!TN && !F8 && !CONV) {      // plain NT bf16 GEMM: the epilogue sees this tile's segment of C / aux rows (segi = 0, extras = 0: unchanged)
+    GemmP ps = p;
+    ps.C = p.C + segi * p.seg_xc;
+    ps.aux_in = p.aux_in + segi * p.seg_xin;
+    ps.aux_out = p.aux_out + segi * p.seg_xout;
+    if (epl_aligned(ps)) gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+    else gemm_epilogue<EPI, 2, 4>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane);
   } else if (epl_aligned(p)) gemm_epilogue_lds<EPI, CONV, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   else gemm_epilogue<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
@@ -973,8 +984,8 @@ static GemmP to_p(const st355_gemm_args* a) {
   if (a->seg_rows) {
     auto extra = [&](int64_t stride, int64_t ld) { return stride ? (stride - a->seg_rows) * ld : (int64_t)0; };
     p.seg_rows = (int)a->seg_rows;
-    p.seg_xa = extra(a->seg_a, a->lda); p.seg_xa2 = extra(a->seg_a2, a->lda2); p.seg_xc = extra(a->seg_c, a->ldc);
-    p.seg_xin = extra(a->seg_in, a->ld_aux_in); p.seg_xout = extra(a->seg_out, a->ld_aux_out);
+    p.seg_xa = extra(a->seg_a, a->lda); p.seg_xa2 = (a->A2 && a->K2) ? extra(a->seg_a2, a->lda2) : 0; p.seg_xc = extra(a->seg_c, a->ldc);
+    p.seg_xin = a->aux_in ? extra(a->seg_in, a->ld_aux_in) : 0; p.seg_xout = a->aux_out ? extra(a->seg_out, a->ld_aux_out) : 0;
   }
   return p;
 }
