@@ -205,6 +205,10 @@ int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const v
  * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
 int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias,
                    void* O, int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale);
+/* The same with V ROW-major: v_rows = token rows of a [B*S, ld_v] projection buffer, head h at columns h*d (e.g. the V third of the QKV output; what
+ * st355_attn_bwd already takes).  The V^T fragments are gathered by transposing LDS reads: no head-major V^T copy exists at all.  d = 128 only. */
+int st355_attn_fwd_vrows(void* stream, const void* Q, const void* K, const void* v_rows, int64_t ld_v, const float* key_bias,
+                         void* O, int64_t ld_o, float* lse2, int B, int H, int S, int d, float scale);
 /* workspace bytes for st355_attn_bwd (holds delta and a padded lse copy [B,H,Sp] fp32 and dO^T [B,H,d,Sp] bf16) */
 size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d);
 /* V is read token-major from the qkv buffer: V[b,pos,h,:] = v_base + ((b*S_rows + pos) * ld_v + h*d) ... see DESIGN.md.

@@ -233,11 +233,18 @@ __device__ __forceinline__ float xhalf_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int HD, bool BIAS>
+// VROW (head_dim 128): V comes ROW-major (token rows of a [B*S, ld_v] projection buffer, head h at columns h*128, e.g. the V third of a fused QKV
+// output) instead of the pre-transposed head-major V^T copy: the V tile is staged as [64 keys][128 channels] with the swz_q chunk swizzle of the
+// backward kernels and the V^T fragments of O^T += V^T P^T are gathered by transposing LDS reads (two ds_read_b64_tr_b16 per fragment, same LDS
+// bytes as the one ds_read_b128 of the V^T form) — no V^T buffer, no transposing pass over V anywhere (Vt is then Vrows, Sp is ld_v).
+__device__ __forceinline__ int swz_kv(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }      // = swz_q of attention_bwd.hip
+
+template <int HD, bool BIAS, bool VROW = false>
 __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
                                                       bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
                                                       int Sq, int S, int Sp, float scale2) {
+  static_assert(!VROW || HD == 128, "row-major V is built for head_dim 128");
   constexpr int NW = 4;
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = KB * KROWB;
@@ -259,7 +266,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
   const int qi = min(q0 + l31, Sq - 1);
 
   const bf16* Kg = K + bh * (int64_t)S * HD;
-  const bf16* Vg = Vt + bh * (int64_t)HD * Sp;
+  const bf16* Vg = VROW ? Vt + (int64_t)b * S * Sp + (int64_t)head * HD      // VROW: Sp carries ld_v
+                        : Vt + bh * (int64_t)HD * Sp;
 
   bf16x8 qf[NKS];
   {
@@ -281,7 +289,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
   // is the saddr form of global_load: no per-load 64-bit VALU arithmetic (generation 1 spent ~20 VALU per tile on it).  Only the ragged last tile
   // clamps rows (K rows past S would read the next head, or past the allocation for the last one).
   const uint32_t koff0 = (uint32_t)tid * 16u;
-  const uint32_t voff0 = ((uint32_t)(tid >> 3) * (uint32_t)Sp + (uint32_t)(tid & 7) * 8u) * 2u;
+  const uint32_t voff0 = VROW ? ((uint32_t)(tid >> 4) * (uint32_t)Sp + (uint32_t)(tid & 15) * 8u) * 2u      // VROW: 16 chunks per key row, 16 rows per pass
+                              : ((uint32_t)(tid >> 3) * (uint32_t)Sp + (uint32_t)(tid & 7) * 8u) * 2u;
   auto load_tile = [&](int kt) {
     const int key0 = kt * KB;
     const char* kb = (const char*)Kg + (size_t)key0 * KROWB;
@@ -296,9 +305,23 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
         kreg[p] = *(const bf16x8*)(Kg + (int64_t)min(key0 + row, S - 1) * HD + c * 8);
       }
     }
-    const char* vb = (const char*)Vg + (size_t)key0 * 2;
+    if (VROW) {
+      const char* vb = (const char*)Vg + (size_t)key0 * Sp * 2;
+      if (key0 + KB <= S) {
 #pragma unroll
-    for (int p = 0; p < VCH; p++) vreg[p] = *(const bf16x8*)(vb + (size_t)p * (ATT_T / 8) * Sp * 2 + voff0);
+        for (int p = 0; p < VCH; p++) vreg[p] = *(const bf16x8*)(vb + (size_t)p * (ATT_T / 16) * Sp * 2 + voff0);
+      } else {                 // ragged last tile: clamp the key row (its P column is exactly 0, the value only has to be finite)
+#pragma unroll
+        for (int p = 0; p < VCH; p++) {
+          const int row = p * (ATT_T / 16) + (tid >> 4);
+          vreg[p] = *(const bf16x8*)(Vg + (int64_t)min(key0 + row, S - 1) * Sp + (tid & 15) * 8);
+        }
+      }
+    } else {
+      const char* vb = (const char*)Vg + (size_t)key0 * 2;
+#pragma unroll
+      for (int p = 0; p < VCH; p++) vreg[p] = *(const bf16x8*)(vb + (size_t)p * (ATT_T / 8) * Sp * 2 + voff0);
+    }
   };
   auto store_tile = [&](int buf) {
     char* ks = smem + buf * BUF;
@@ -312,13 +335,22 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
 #pragma unroll
     for (int p = 0; p < VCH; p++) {
       const int id = p * ATT_T + tid;
-      const int row = id >> 3, c = id & 7;
-      *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
+      if (VROW) {
+        const int row = id >> 4, c = id & 15;
+        *(bf16x8*)(vs + row * 256 + ((c ^ swz_kv(row)) << 4)) = vreg[p];
+      } else {
+        const int row = id >> 3, c = id & 7;
+        *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
+      }
     }
   };
 
   const int nkt = (S + KB - 1) / KB;
   const int krow_p = perm23(l31);
+  // VROW: transposed-fragment base (attention_bwd.hip dkv3): lane = 16 g + 4 r + s reads key row 8h + r (+4 for the second read), channels
+  // 16 (g & 1) + 4 s .. + 3 of the 32-channel d tile: byte = key * 256 + ((chunk ^ f(key)) << 4) + (s & 1) * 8, chunk = 4 dt + 2 (g & 1) + (s >> 1)
+  const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
+  const int tr_base = (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;
 
   load_tile(0);
   store_tile(0);
@@ -384,7 +416,14 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
         const bf16x8 pf = pack8(e);
 #pragma unroll
         for (int dt = 0; dt < NDT; dt++) {
-          bf16x8 vf = *(const bf16x8*)(vs + lds_off<128>(32 * dt + l31, 4 * sb + 2 * m + h));
+          bf16x8 vf;
+          if (VROW) {     // V^T[d = 32 dt + l31][keys 32 sb + 16 m + 8 h + 0..7]: two transposing reads (keys +0..3, +4..7)
+            const char* r0 = vs + (tr_base ^ ((4 * dt) << 4)) + (32 * sb + 16 * m) * 256;
+            const char* r1 = vs + (tr_base ^ (((4 * dt) ^ 1) << 4)) + (32 * sb + 16 * m + 4) * 256;
+            vf = lds_tr16x2(r0, r1);
+          } else {
+            vf = *(const bf16x8*)(vs + lds_off<128>(32 * dt + l31, 4 * sb + 2 * m + h));
+          }
           acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[dt], 0, 0, 0);
         }
       }
@@ -415,10 +454,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
 }
 
 
+// vrow != 0: Vt is the ROW-major V (token rows, head h at columns h*d) and Sp its leading dimension (k_attn_fwd4<128, *, true>)
 static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
-                         int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale) {
+                         int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale, int vrow = 0) {
   ST_REQUIRE(Q && K && Vt && O && lse2, "attn_fwd: null pointer");
-  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sq > 0 && Sp % 64 == 0 && Sp >= S && ld_o % 4 == 0, "attn_fwd: bad shape S=%d Sp=%d", S, Sp);
+  ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sq > 0 && ld_o % 4 == 0 && (vrow ? (Sp % 8 == 0 && Sp >= H * d && d == 128) : (Sp % 64 == 0 && Sp >= S)),
+             "attn_fwd: bad shape S=%d Sp(ld_v)=%d", S, Sp);
   if (d != 128 && d != 64 && d != 96) { st355_set_error("attn_fwd: head_dim %d not built", d); return ST355_ENOSYS; }
   const double flops = 4.0 * (double)B * H * (double)Sq * S * d;
   const double bytes = 2.0 * (double)B * H * (Sq + S) * d * 2.0;
@@ -438,7 +479,10 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
     hipLaunchKernelGGL((KERN), grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, key_bias,         \
                        (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);                                                                     \
   } while (0)
-  if (gen == 1) {
+  if (vrow) {
+    if (key_bias) ST355_FWD_LAUNCH((k_attn_fwd4<128, true, true>));
+    else ST355_FWD_LAUNCH((k_attn_fwd4<128, false, true>));
+  } else if (gen == 1) {
     if (d == 128) ST355_FWD_LAUNCH(k_attn_fwd<128>);
     else if (d == 96) ST355_FWD_LAUNCH(k_attn_fwd<96>);          // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
     else ST355_FWD_LAUNCH(k_attn_fwd<64>);
@@ -457,6 +501,11 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
 extern "C" int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
                               int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale) {
   return attn_fwd_impl(stream, Q, K, Vt, key_bias, O, ld_o, lse2, B, H, S, S, Sp, d, scale);
+}
+extern "C" int st355_attn_fwd_vrows(void* stream, const void* Q, const void* K, const void* v_rows, int64_t ld_v, const float* key_bias, void* O,
+                                    int64_t ld_o, float* lse2, int B, int H, int S, int d, float scale) {
+  ST_REQUIRE(ld_v > 0 && ld_v < ((int64_t)1 << 31), "attn_fwd_vrows: bad ld_v");
+  return attn_fwd_impl(stream, Q, K, v_rows, key_bias, O, ld_o, lse2, B, H, S, S, (int)ld_v, d, scale, 1);
 }
 // cross-attention (UNet attn2 over the 77 text tokens, PixArt cross-attention): Sq queries [B,H,Sq,d] against Sk keys [B,H,Sk,d], Vt [B,H,d,Skp];
 // O: [B*Sq, ld_o] token-major, lse2 [B,H,Sq]; key_bias [B,Sk] additive or NULL

@@ -528,6 +528,14 @@ def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale: float, key_bias=None):
                               B, H, S, Sp, d, scale), "attn_fwd")
 
 
+def attn_fwd_vrows(Q, K, v_rows, O, lse2, B, H, S, d, scale: float, key_bias=None):
+    """attn_fwd with V row-major: v_rows is a 2-D token-major view [B*S, >= H*d] (head h at columns h*d); no V^T copy.  d = 128."""
+    L = _l.load()
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(v_rows, BF16, "v_rows"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    _l.check(L.st355_attn_fwd_vrows(_stream(), _ptr(Q), _ptr(K), _ptr(v_rows), _rows(v_rows, "v_rows"), _ptr(key_bias), _ptr(O), _rows(O, "O"),
+                                    _ptr(lse2), B, H, S, d, scale), "attn_fwd_vrows")
+
+
 _attn_ws = {}
 
 

@@ -98,6 +98,21 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; i++) RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O, D, lse2, B, H, S, Sp, d, scale));
   CK(hipStreamSynchronize(st));
   st355_prof_enable(0); prof_print("forward");
+  if (strcmp(gen, "1") != 0 && d == 128) {   // row-major V (transposing LDS reads, no V^T buffer): timed, and bit-compared with the V^T form above
+    bf16* O2; float* lse3; CK(hipMalloc(&O2, nr * 2)); CK(hipMalloc(&lse3, (size_t)BH * S * 4));
+    RC(st355_attn_fwd_vrows(st, Q, K, vrows, 3 * D, nullptr, O2, D, lse3, B, H, S, d, scale));
+    CK(hipStreamSynchronize(st));
+    st355_prof_reset(); st355_prof_enable(1);
+    for (int i = 0; i < iters; i++) RC(st355_attn_fwd_vrows(st, Q, K, vrows, 3 * D, nullptr, O2, D, lse3, B, H, S, d, scale));
+    CK(hipStreamSynchronize(st));
+    st355_prof_enable(0); prof_print("forward, row-major V");
+    unsigned long long* bad; float* maxd; CK(hipMalloc(&bad, 8)); CK(hipMalloc(&maxd, 4));
+    CK(hipMemsetAsync(bad, 0, 8, st)); CK(hipMemsetAsync(maxd, 0, 4, st));
+    k_diff<<<2048, 256, 0, st>>>(O, O2, (int64_t)nr, 0, 0, bad, maxd);
+    unsigned long long hb; float hm;
+    CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    printf("  O, row-major V vs V^T form: %llu of %lld elements differ (max |d| %.3e)  %s\n", hb, (long long)nr, hm, hb ? "MISMATCH" : "bit-identical");
+  }
   if (strcmp(gen, "1") != 0 && d == 128) {   // other generations: compare O / lse2 with the generation-1 kernel launched directly
     bf16* O1; float* lse1; CK(hipMalloc(&O1, nr * 2)); CK(hipMalloc(&lse1, (size_t)BH * S * 4));
     const int lds = 2 * (KB * 256 + 128 * 128);
