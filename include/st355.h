@@ -102,7 +102,26 @@ int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* ga
                      int64_t rows_per_batch, void* out, int64_t ld_out, int64_t M, int64_t N);
 
 /* ---- GEMM family (K4,K8,K9,K11,K12): C[M,N] = A[M,K] B[N,K]^T (+ A2[M,K2] B2[N,K2]^T) ---------- */
-enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3, ST355_EPI_ADD = 4 /* C = acc + aux_in */ };
+enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3, ST355_EPI_ADD = 4 /* C = acc + aux_in */,
+       ST355_EPI_QK_NORM_ROPE = 5 /* fused QKV projection: see st355_qk_rope */ };
+/* ST355_EPI_QK_NORM_ROPE — the attention input projection with its RMSNorm(q), RMSNorm(k) and RoPE fused into the GEMM epilogue
+ * (FluxAttnProcessor2_0: flux/transformer.py:140-207; replaces the separate st355_qk_norm_rope_fwd pass).  The problem is x[M,K] @ Wqkv[3D,K]^T
+ * (+ bias, + LoRA extension), D = H*128.  Output columns [0,D) / [D,2D): q / k heads -> per-head RMSNorm (wq / wk, NULL = none), rotation of the
+ * interleaved channel pairs (2i, 2i+1) by cos/sin[S,64] — ONE angle per pair, i.e. every second column of the full-width tables the reference builds
+ * with repeat_interleave(2) — at joint position pos0 + m % rows_per_batch, one rounding to bf16, written HEAD-major to Q / K [B,H,S,128] for sample
+ * m / rows_per_batch; 1/rms goes to rrms[(b*S + pos) * 2H + {0,H} + head] (fp32) for st355_qk_rope_norm_bwd.  Columns [2D,3D): v heads, plain
+ * rows of args->C (C[row * ldc + n - 2D], row through the segment view): the row-major V that st355_attn_fwd_vrows / st355_attn_bwd read.
+ * Requirements: head_dim 128, H even, N = 3D, rows_per_batch a multiple of 256 that divides M (set args->rows_per_batch), 16-byte aligned rows. */
+typedef struct st355_qk_rope {
+  void* Q; void* K;
+  float* rrms;
+  const void* wq; const void* wk;
+  const float* cos; const float* sin;
+  int32_t H, S, pos0;
+  float eps;
+  void* Vt; int32_t Sp;             /* optional: also write the v heads as the head-major V^T [B,H,128,Sp] st355_attn_fwd streams (NULL: row-major V only,
+                                       for st355_attn_fwd_vrows).  Columns [S,Sp) are the caller's to zero. */
+} st355_qk_rope;
 typedef struct st355_gemm_args {
   const void* A;  int64_t lda;      /* activations [M,K]  bf16                                         */
   const void* B;  int64_t ldb;      /* weights     [N,K]  bf16 (nn.Linear.weight layout)               */
@@ -126,6 +145,7 @@ typedef struct st355_gemm_args {
    * problem instead of B launches that each fill the 256 CUs badly, with no gather/scatter copy on either side.  seg_rows must be a multiple of 256
    * (a tile never straddles two segments) and divide M; EPI_GATE_RESIDUAL's rows_per_batch keeps counting LOGICAL rows.  NT bf16 GEMM only. */
   int64_t seg_rows, seg_a, seg_a2, seg_c, seg_in, seg_out;
+  const st355_qk_rope* rope;        /* ST355_EPI_QK_NORM_ROPE only (host pointer, read at launch) */
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two
@@ -199,6 +219,12 @@ int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const 
 int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv,
                            const void* wq, const void* wk, const float* cos, const float* sin,
                            void* dqkv, int64_t ld_dqkv, int B, int H, int d, int S_part, int pos0, int S, float eps);
+
+/* backward of the FUSED form (ST355_EPI_QK_NORM_ROPE): starts from the roped head-major Q / K that the attention backward keeps anyway and the 1/rms
+ * the epilogue wrote (rrms [B*S, 2H]); the pre-norm projection is never stored.  Norm weights must be non-zero.  d = 128. */
+int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const void* Q, const void* K, const float* rrms,
+                           const void* wq, const void* wk, const float* cos, const float* sin,
+                           void* dqkv, int64_t ld_dqkv, int B, int H, int d, int S_part, int pos0, int S);
 
 /* ---- K7: joint non-causal attention over [txt || img] tokens ------------------------------- */
 /* O: [B,S,H*d] token-major bf16 (row stride ld_o elements); lse2: [B,H,S] fp32 (log2-domain logsumexp of

@@ -75,6 +75,15 @@ struct GemmP {
   // of 256) just shifts its operand base pointers by (m0 / seg_rows) * seg_xX (seg_view below) — the K loop and the epilogues are untouched.
   int seg_rows = 0;
   int64_t seg_xa = 0, seg_xa2 = 0, seg_xc = 0, seg_xin = 0, seg_xout = 0;
+  // ST355_EPI_QK_NORM_ROPE (st355_gemm_args.rope): the fused QKV projection of an MMDiT attention (flux/transformer.py:140-207).  Output columns
+  // [0, D) are q heads, [D, 2D) k heads, [2D, 3D) v heads (D = rH * 128).  q / k tiles: per-head RMSNorm (weights rwq / rwk, NULL = none) and RoPE from
+  // the fp32 accumulators, written head-major to rq / rk [B, rH, rS, 128] at joint position rpos0 + m % rows_per_batch of sample m / rows_per_batch,
+  // plus 1/rms to rrms [B*rS, 2*rH] for the backward; v tiles: plain rows of C (column n - 2D), through the segment view.
+  bf16* rq = nullptr; bf16* rk = nullptr; float* rrms = nullptr; bf16* rvt = nullptr; int rSp = 0;     // rvt: optional head-major V^T [B, rH, 128, rSp]
+  const bf16* rwq = nullptr; const bf16* rwk = nullptr;
+  const float* rcos = nullptr; const float* rsin = nullptr;
+  int rH = 0, rS = 0, rpos0 = 0;
+  float reps = 0.f;
 };
 
 // the tile at row m0 of a segmented problem sees plain operands whose base pointers are shifted to its segment
@@ -319,6 +328,157 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x16 (&acc)[
     }
   }
 }
+// ---- ST355_EPI_QK_NORM_ROPE: q / k tiles of the fused QKV projection (256x256 schedule only) ----
+// Same wave-private fp32 transpose as above (two 64-token passes).  A 128-channel head spans the two waves wn, wn^1 of a 128-token group: each wave
+// reduces sum(x^2) over its 64 channels (8 lanes per token row, xor-shuffles), the halves meet through a 4 KiB exchange area behind the transpose
+// slices (one workgroup barrier per pass; the V tiles of the same launch are other workgroups and take the plain epilogue).  Normalisation, the
+// rotation and the single rounding to bf16 all happen on the fp32 accumulator values — the unfused form (st355_qk_norm_rope_fwd) rounded the
+// projection to bf16 first and spent one full HBM read + write pass of the [tokens, 3D] tensor on it.
+#define QKR_XCHG (2 * 8 * 64 * 4)               // [pass][wave][64 rows] fp32
+__device__ __forceinline__ void gemm_epilogue_qkrope(const GemmP& p, f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn, int wv, int lane, char* smem) {
+  char* stage = smem + wv * EPL_WAVE;
+  float* xchg = (float*)(smem + 8 * EPL_WAVE);
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const int Dm = p.rH * 128;
+  const int part = n0 >= Dm ? 1 : 0;                                    // 0: q, 1: k  (workgroup-uniform)
+  const int ncol = n0 - part * Dm + wn * 64;                            // first column of this wave inside the part
+  const int head = ncol >> 7, half = (ncol >> 6) & 1;
+  const int cch = half * 64 + rc * 8;                                   // head channel of this lane's first feature
+  const bf16* w = part ? p.rwk : p.rwq;
+  bf16* dst = part ? p.rk : p.rq;
+  float w8[8], bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { w8[j] = w ? bf2f(w[cch + j]) : 1.f; bias8[j] = p.bias ? bf2f(p.bias[n0 + wn * 64 + rc * 8 + j]) : 0.f; }
+  const int rpb = (int)p.rows_per_batch;
+  const int bsm = __builtin_amdgcn_readfirstlane(m0 / rpb);             // sample of this tile (rows_per_batch is a multiple of 256)
+  const int mw0 = m0 + wm * 128;
+  const int pos_w = p.rpos0 + (mw0 - bsm * rpb);                        // joint sequence position of the wave's first token
+  bf16* dst_h = dst + ((int64_t)bsm * p.rH + head) * (int64_t)p.rS * 128 + cch;
+  float* rr_out = p.rrms + (int64_t)bsm * p.rS * (2 * p.rH) + part * p.rH + head;
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+    float* xw = xchg + (ps * 8 + wv) * 64;
+    const float* xp = xchg + (ps * 8 + (wv ^ 1)) * 64;
+    // pass 1: this wave's half of sum((x + bias)^2) per token row
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      float sq = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { const float x0 = lo[b] + bias8[b], x1 = hi[b] + bias8[4 + b]; sq += x0 * x0 + x1 * x1; }
+      sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+      if (rc == 0) xw[row] = sq;
+    }
+    __syncthreads();
+    // pass 2: normalise, rotate, store head-major
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      const float rr = w ? rsqrtf((xw[row] + xp[row]) * (1.f / 128.f) + p.reps) : 1.f;
+      const int pos = pos_w + ps * 64 + row;
+      float y[8];
+      if (m < p.M) {
+        // one (cos, sin) per rotation pair: [S, 64] tables (the full-width tables of flux/transformer.py:73-98 repeat every entry twice; read from them
+        // the epilogue pulled 4x its own output bytes through the CU's L2 port — the two heads of a tile and the two entries of a pair — and cost more
+        // than the pass it replaced)
+        const f32x4 cs = *(const f32x4*)(p.rcos + (int64_t)pos * 64 + (cch >> 1));
+        const f32x4 sn = *(const f32x4*)(p.rsin + (int64_t)pos * 64 + (cch >> 1));
+#pragma unroll
+        for (int b = 0; b < 4; b++) { y[b] = (lo[b] + bias8[b]) * rr * w8[b]; y[4 + b] = (hi[b] + bias8[4 + b]) * rr * w8[4 + b]; }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {      // out = x*cos + rot(x)*sin on interleaved pairs (flux/transformer.py:91-98), as k_qk_norm_rope_fwd
+          o[j] = f2bf(y[j] * cs[j >> 1] - y[j + 1] * sn[j >> 1]);
+          o[j + 1] = f2bf(y[j + 1] * cs[j >> 1] + y[j] * sn[j >> 1]);
+        }
+        *(bf16x8*)(dst_h + (int64_t)pos * 128) = o;
+        if (rc == 0 && half == 0) rr_out[(int64_t)pos * (2 * p.rH)] = rr;
+      }
+    }
+  }
+}
+
+// v tiles of the same launch: the row-major V rows (what the backward reads) as in gemm_epilogue_lds, plus — when rvt is given — the head-major V^T
+// [B, H, 128, Sp] the forward attention kernel streams, read back TRANSPOSED from the same fp32 staging slice (8 lanes = 64 consecutive tokens of one
+// channel = one 128-byte line): the transposed copy costs one extra write of V and no read pass.
+__device__ __forceinline__ void gemm_epilogue_vdual(const GemmP& p, bf16* C, f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn, int wv, int lane, char* smem) {
+  char* stage = smem + wv * EPL_WAVE;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const int Dm = p.rH * 128;
+  const int ncol = n0 - 2 * Dm + wn * 64;                               // first column of this wave inside the v part
+  const int head = ncol >> 7, half = (ncol >> 6) & 1;
+  const int n = n0 + wn * 64 + rc * 8;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) bias8[j] = p.bias ? bf2f(p.bias[n + j]) : 0.f;
+  const int rpb = (int)p.rows_per_batch;
+  const int bsm = __builtin_amdgcn_readfirstlane(m0 / rpb);
+  const int mw0 = m0 + wm * 128;
+  const int pos_w = p.rpos0 + (mw0 - bsm * rpb);
+  bf16* c_row = C + (int64_t)(mw0 + rrow) * p.ldc + (n - 2 * Dm);
+  const int64_t c_step = 8 * p.ldc;
+  // transposed side: lane = (channel fsub of 8, token group tg of 8 tokens)
+  const int fsub = lane >> 3, tg = lane & 7;
+  bf16* vt_w = p.rvt ? p.rvt + (((int64_t)bsm * p.rH + head) * 128 + half * 64) * (int64_t)p.rSp + pos_w + tg * 8 : nullptr;
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      bf16* const c_ptr = c_row;
+      c_row += c_step;
+      if (m >= p.M) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { o[b] = f2bf(lo[b] + bias8[b]); o[4 + b] = f2bf(hi[b] + bias8[4 + b]); }
+      *(bf16x8*)c_ptr = o;
+    }
+    if (vt_w) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int f = it * 8 + fsub;                                      // channel inside the wave's 64
+        const float bf_ = p.bias ? bf2f(p.bias[n0 + wn * 64 + f]) : 0.f;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = f2bf(*(const float*)(stage + (tg * 8 + e) * EPL_PITCH + f * 4) + bf_);
+        if (mw0 + ps * 64 + tg * 8 < p.M) *(bf16x8*)(vt_w + (int64_t)f * p.rSp + ps * 64) = o;
+      }
+    }
+  }
+}
+
 // the coalesced path needs 16-byte alignment of every row it touches with bf16x8 accesses
 __device__ __forceinline__ bool epl_aligned(const GemmP& p) {
   bool ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
@@ -808,6 +968,12 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
     ps.conv_taps = 0;
     gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (EPI == ST355_EPI_QK_NORM_ROPE) {
+    if (n0 >= 2 * p.rH * 128) {            // v heads: rows of the V buffer (column n - 2D) in this tile's segment (+ the head-major V^T)
+      gemm_epilogue_vdual(p, p.C + segi * p.seg_xc, acc, m0, n0, wm, wn, wv, lane, smem);
+    } else {
+      gemm_epilogue_qkrope(p, acc, m0, n0, wm, wn, wv, lane, smem);
+    }
   } else if (!TN && !F8 && !CONV) {      // plain NT bf16 GEMM: the epilogue sees this tile's segment of C / aux rows (segi = 0, extras = 0: unchanged)
     GemmP ps = p;
     ps.C = p.C + segi * p.seg_xc;
@@ -958,7 +1124,18 @@ static int validate(const st355_gemm_args* a) {
     ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad/add epilogue needs aux_in");
   if ((a->epilogue == ST355_EPI_GELU || a->epilogue == ST355_EPI_GATE_RESIDUAL) && a->aux_out)
     ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
-  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_ADD, "gemm: unknown epilogue %d", a->epilogue);
+  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_QK_NORM_ROPE, "gemm: unknown epilogue %d", a->epilogue);
+  if (a->epilogue == ST355_EPI_QK_NORM_ROPE) {
+    const st355_qk_rope* r = a->rope;
+    ST_REQUIRE(r && r->Q && r->K && r->rrms && r->cos && r->sin, "gemm: EPI_QK_NORM_ROPE needs args->rope with Q, K, rrms, cos, sin");
+    ST_REQUIRE(r->H > 0 && r->H % 2 == 0 && a->N == 3 * r->H * 128, "gemm: EPI_QK_NORM_ROPE is built for head_dim 128, even H, N = 3*H*128 (N=%d H=%d)", a->N, r->H);
+    ST_REQUIRE(a->rows_per_batch > 0 && a->rows_per_batch % 256 == 0 && a->M % a->rows_per_batch == 0 && r->pos0 >= 0 && r->pos0 + a->rows_per_batch <= r->S,
+               "gemm: EPI_QK_NORM_ROPE rows_per_batch (%lld) must be a multiple of 256 dividing M, pos0 + rows_per_batch <= S", (long long)a->rows_per_batch);
+    ST_REQUIRE(a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0) && ((uintptr_t)r->Q % 16 == 0) && ((uintptr_t)r->K % 16 == 0) && ((uintptr_t)r->cos % 16 == 0) &&
+               ((uintptr_t)r->sin % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0), "gemm: EPI_QK_NORM_ROPE operands must be 16-byte aligned");
+    ST_REQUIRE(!a->seg_rows || a->seg_rows == a->rows_per_batch, "gemm: EPI_QK_NORM_ROPE segments are the per-sample row blocks (seg_rows == rows_per_batch)");
+    ST_REQUIRE(!r->Vt || (r->Sp >= r->S && r->Sp % 8 == 0 && r->pos0 % 8 == 0 && ((uintptr_t)r->Vt % 16 == 0)), "gemm: EPI_QK_NORM_ROPE V^T needs Sp >= S, Sp and pos0 multiples of 8");
+  }
   if (a->seg_rows) {
     ST_REQUIRE(a->seg_rows > 0 && a->seg_rows % 256 == 0 && a->M % a->seg_rows == 0, "gemm: seg_rows (%lld) must be a multiple of 256 that divides M (%d)",
                (long long)a->seg_rows, a->M);
@@ -986,6 +1163,12 @@ static GemmP to_p(const st355_gemm_args* a) {
     p.seg_rows = (int)a->seg_rows;
     p.seg_xa = extra(a->seg_a, a->lda); p.seg_xa2 = (a->A2 && a->K2) ? extra(a->seg_a2, a->lda2) : 0; p.seg_xc = extra(a->seg_c, a->ldc);
     p.seg_xin = a->aux_in ? extra(a->seg_in, a->ld_aux_in) : 0; p.seg_xout = a->aux_out ? extra(a->seg_out, a->ld_aux_out) : 0;
+  }
+  if (a->epilogue == ST355_EPI_QK_NORM_ROPE && a->rope) {
+    const st355_qk_rope* r = a->rope;
+    p.rq = (bf16*)r->Q; p.rk = (bf16*)r->K; p.rrms = r->rrms; p.rwq = (const bf16*)r->wq; p.rwk = (const bf16*)r->wk;
+    p.rcos = r->cos; p.rsin = r->sin; p.rH = r->H; p.rS = r->S; p.rpos0 = r->pos0; p.reps = r->eps; p.rvt = (bf16*)r->Vt; p.rSp = r->Sp;
+    p.rows_per_batch = a->rows_per_batch;
   }
   return p;
 }
@@ -1016,9 +1199,10 @@ static int launch_p3(void* stream, const GemmGroup& g, int tiles) {
 
 template <int EPI>
 static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
+  constexpr int lds = PQ_LDS + (EPI == ST355_EPI_QK_NORM_ROPE ? QKR_XCHG : 0);        // + the half-head sum exchange of the fused q/k epilogue
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
-  hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), lds, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq");
 }
 template <int EPI>
@@ -1092,6 +1276,11 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   }
   // the deep-pipelined schedule needs enough tiles to fill 256 CUs; tiny problems stay on the 128x128 schedule
   // 256x256 tiles only when they (nearly) fill the 256 CUs at one workgroup each
+  if (a->epilogue == ST355_EPI_QK_NORM_ROPE) {          // the fused q/k epilogue exists in the 256x256 schedule only
+    GemmGroup g;
+    g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    return launch_pq<ST355_EPI_QK_NORM_ROPE>(stream, g, g.tiles0);
+  }
   if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256()) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
@@ -1254,6 +1443,18 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
   }
   int i = 0;
   while (i < count) {
+    if (i + 1 < count && args[i].epilogue == ST355_EPI_QK_NORM_ROPE) {      // img + txt projections of one block: one grid
+      GemmGroup g;
+      g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);
+      g.tiles0 = p4_tiles(g.p[0]);
+      const int tiles = g.tiles0 + p4_tiles(g.p[1]);
+      ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),
+                   "%d&%dx%dx%d+%d e%d", args[i].M, args[i + 1].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
+      int rc = launch_pq<ST355_EPI_QK_NORM_ROPE>(stream, g, tiles);
+      if (rc) return rc;
+      i += 2;
+      continue;
+    }
     if (i + 1 < count && gemm_impl_choice() >= 2) {
       GemmGroup g;
       g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);

@@ -517,6 +517,94 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
   return st355_check_launch("qk_norm_rope_bwd");
 }
 
+// backward of the FUSED projection epilogue (ST355_EPI_QK_NORM_ROPE): the pre-norm q / k are never stored, so the backward starts from what the
+// attention backward keeps anyway — the roped head-major Q / K (z) — and the 1/rms the epilogue wrote:
+//   y = R^T z (the rotation is orthogonal),  x_hat = y / w,  dy = R^T dz,  dx = r * (w * dy - x_hat * mean(dy * y))      [w * dy * x_hat = dy * y]
+// With no norm weight (w == NULL): dx = dy.  Channels whose norm weight is exactly 0 have no recoverable x_hat (their y is 0): the caller keeps the
+// unfused path for such weights (FluxTransformer2DModel checks min |w| when it prepares for training).
+template <int HD>
+__global__ void __launch_bounds__(256) k_qk_rope_norm_bwd_z(const bf16* __restrict__ dQ, const bf16* __restrict__ dK, const bf16* __restrict__ Qz,
+                                                           const bf16* __restrict__ Kz, const float* __restrict__ rrms,
+                                                           const bf16* __restrict__ wq, const bf16* __restrict__ wk,
+                                                           const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                           bf16* __restrict__ dqkv, int64_t ldd, int H, int S_part, int pos0, int S) {
+  constexpr int TPR = HD / 8;
+  constexpr int TOK_PER_PASS = 256 / TPR;
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = blockIdx.x * 64;
+  const int c = tid % TPR;
+  const int64_t Dm = (int64_t)H * HD;
+  const int64_t bh = (int64_t)b * H + h;
+  float wv[2][8], wi[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    wv[0][j] = wq ? bf2f(wq[c * 8 + j]) : 1.f;
+    wv[1][j] = wk ? bf2f(wk[c * 8 + j]) : 1.f;
+    wi[0][j] = 1.f / wv[0][j];
+    wi[1][j] = 1.f / wv[1][j];
+  }
+  for (int tl = tid / TPR; tl < 64; tl += TOK_PER_PASS) {
+    const int t = t0 + tl;
+    const bool valid = t < S_part;
+    const int tt = valid ? t : S_part - 1;
+    const int pos = pos0 + tt;
+    const float* cp = cosT + (int64_t)pos * HD + c * 8;
+    const float* sp = sinT + (int64_t)pos * HD + c * 8;
+    float cs[8], sn[8];
+    *(f32x4*)&cs[0] = *(const f32x4*)cp; *(f32x4*)&cs[4] = *(const f32x4*)(cp + 4);
+    *(f32x4*)&sn[0] = *(const f32x4*)sp; *(f32x4*)&sn[4] = *(const f32x4*)(sp + 4);
+    bf16* drow = dqkv + ((int64_t)b * S + pos) * ldd + (int64_t)h * HD + c * 8;
+    const int64_t go = (bh * S + pos) * HD + c * 8;
+    const float* rrow = rrms + ((int64_t)b * S + pos) * (2 * H) + h;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const bool has_norm = (w == 0) ? (wq != nullptr) : (wk != nullptr);
+      const bf16x8 gv = *(const bf16x8*)((w == 0 ? dQ : dK) + go);
+      const bf16x8 zv = *(const bf16x8*)((w == 0 ? Qz : Kz) + go);
+      float g[8], z[8], dy[8], y[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { g[j] = bf2f(gv[j]); z[j] = bf2f(zv[j]); }
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        // forward: o0 = y0*c0 - y1*s0 ; o1 = y1*c1 + y0*s1   =>  transpose (= inverse): v0 = o0*c0 + o1*s1 ; v1 = o1*c1 - o0*s0
+        dy[j] = g[j] * cs[j] + g[j + 1] * sn[j + 1];
+        dy[j + 1] = g[j + 1] * cs[j + 1] - g[j] * sn[j];
+        y[j] = z[j] * cs[j] + z[j + 1] * sn[j + 1];
+        y[j + 1] = z[j + 1] * cs[j + 1] - z[j] * sn[j];
+      }
+      bf16x8 o;
+      if (has_norm) {
+        float sdy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sdy += dy[j] * y[j];
+        const float r = rrow[w * H];
+        const float mdy = group_sum<HD>(sdy) / (float)HD;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = f2bf(r * (wv[w][j] * dy[j] - y[j] * wi[w][j] * mdy));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = f2bf(dy[j]);
+      }
+      if (valid) *(bf16x8*)(drow + w * Dm) = o;
+    }
+  }
+}
+
+extern "C" int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const void* Q, const void* K, const float* rrms, const void* wq,
+                                      const void* wk, const float* cos, const float* sin, void* dqkv, int64_t ld_dqkv, int B, int H, int d,
+                                      int S_part, int pos0, int S) {
+  ST_REQUIRE(dQ && dK && Q && K && rrms && cos && sin && dqkv, "qk_rope_norm_bwd: null pointer");
+  ST_REQUIRE(ld_dqkv % 8 == 0 && pos0 + S_part <= S && S_part > 0, "qk_rope_norm_bwd: bad shape");
+  ST_REQUIRE(d == 128, "qk_rope_norm_bwd: head_dim %d not built (the fused projection epilogue is head_dim 128)", d);
+  const double n = (double)B * S_part * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 34.0 * n, 12.0 * n);
+  dim3 grid((S_part + 63) / 64, H, B), block(256);
+  hipLaunchKernelGGL(k_qk_rope_norm_bwd_z<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK, (const bf16*)Q, (const bf16*)K,
+                     rrms, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S);
+  return st355_check_launch("qk_rope_norm_bwd");
+}
+
 // ================================================================================================
 // plain head split / merge (no norm, no RoPE): the UNet's attention (diffusers Attention with AttnProcessor2_0: q,k,v -> [B,H,S,d]).
 //   split: src [B*S, ld] token-major (the caller offsets the pointer to the q / k / v column block) -> X [B,H,S,d] and/or Xt [B,H,d,Sp]

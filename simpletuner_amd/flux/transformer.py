@@ -26,10 +26,12 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE
+from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+_FUSED_QKV = __import__("os").environ.get("ST355_FUSED_QKV", "1") != "0"      # A/B switch: 0 = separate RMSNorm + RoPE pass after the QKV projection
+_FUSED_VT = __import__("os").environ.get("ST355_FUSED_VT", "1") != "0"        # A/B switch: 0 = no V^T from the fused epilogue, forward attention reads row-major V
 _TRANSPOSED_COPIES = __import__("os").environ.get("ST355_ATTN_BWD_T") == "1"      # A/B switch: keep the pre-transposed Q^T / K^T copies (dkv2 / dq kernels) at head_dim 128
 
 
@@ -189,6 +191,7 @@ class FluxTransformer2DModel(nn.Module):
         self.lora_grad_flat: Optional[torch.Tensor] = None
         self._lora_params: List[nn.Parameter] = []
         self._rope_cache: Dict = {}
+        self._norm_w_ok: Dict = {}
         self._prepared = False
         self.accumulate_lora_grads = False
         self.gradient_checkpointing = False
@@ -212,6 +215,7 @@ class FluxTransformer2DModel(nn.Module):
             if k in own:
                 own[k].data.copy_(v.to(device=own[k].device, dtype=own[k].dtype))
         self._prepared = False
+        self._norm_w_ok.clear()
 
     @torch.no_grad()
     def init_synthetic(self, seed: int = 42):
@@ -227,6 +231,7 @@ class FluxTransformer2DModel(nn.Module):
             else:
                 p.data.copy_(torch.randn(p.shape, generator=g, device=self.device_, dtype=BF16) * (1.0 / math.sqrt(p.shape[1])))
         self._prepared = False
+        self._norm_w_ok.clear()
 
     @torch.no_grad()
     def prepare_for_training(self):
@@ -315,7 +320,9 @@ class FluxTransformer2DModel(nn.Module):
             freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
             f = torch.outer(ids[:, i].to(torch.float64), freqs)
             cos_l.append(f.cos().repeat_interleave(2, dim=1).float()); sin_l.append(f.sin().repeat_interleave(2, dim=1).float())
-        out = (torch.cat(cos_l, -1).contiguous().to(self.device_), torch.cat(sin_l, -1).contiguous().to(self.device_))
+        cos, sin = torch.cat(cos_l, -1).contiguous(), torch.cat(sin_l, -1).contiguous()
+        # + one (cos, sin) per interleaved pair, [S, hd/2]: what the fused projection epilogue reads (half the table bytes through the CU's L2 port)
+        out = tuple(t.to(self.device_) for t in (cos, sin, cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous()))
         self._rope_cache[key] = out
         return out
 
@@ -423,6 +430,29 @@ class FluxTransformer2DModel(nn.Module):
             return t[0]
         return t if rows % 256 == 0 else t.reshape(env.B * rows, -1)
 
+    def _fused_qkv_ok(self, rows_list, norms) -> bool:
+        """May this attention's input projection run with RMSNorm + RoPE + the head-major re-layout fused into the GEMM epilogue (ST355_EPI_QK_NORM_ROPE,
+        the form the fused processors name: flux/transformer.py:140-207)?  Built for head_dim 128 with an even head count and tile-aligned streams;
+        the backward then recovers the normalised activations from the roped Q / K (x_hat = R^T z / w), which needs non-zero norm weights — checked here
+        per call on the tiny [128] weight vectors of a frozen-base run (cached: they do not train under LoRA).  ST355_FUSED_QKV=0 keeps the separate pass."""
+        if not _FUSED_QKV or self.hd != 128 or self.H % 2 or _TRANSPOSED_COPIES or any(r % 256 for r in rows_list):
+            return False
+        key = tuple(id(w) for w in norms)
+        ok = self._norm_w_ok.get(key)
+        if ok is None:
+            ok = all(w is None or (not w.requires_grad and float(w.detach().abs().min()) > 1e-3) for w in norms)
+            self._norm_w_ok[key] = ok
+        return ok
+
+    def _attn_forward_fused(self, Q, K, V, Vt, O, lse2, env):
+        """attention after the fused projection: from the head-major V^T the epilogue also wrote (default), or — ST355_FUSED_VT=0 — straight from the
+        row-major V by transposing LDS reads (no V^T at all; measured r02: the forward kernel is ~4-8 % slower that way, the extra V^T write is cheaper)"""
+        B, H, hd, S = env.B, self.H, self.hd, env.S
+        if Vt is not None:
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, env.scale, key_bias=env.key_bias)
+        else:
+            ops.attn_fwd_vrows(Q, K, V, O, lse2, B, H, S, hd, env.scale, key_bias=env.key_bias)
+
     def _alloc_heads(self, env):
         B, H, hd, S, Sp, dev = env.B, self.H, self.hd, env.S, env.Sp, self.device_
         Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
@@ -446,20 +476,39 @@ class FluxTransformer2DModel(nn.Module):
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
         n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
         n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
-        qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
         T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
         kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
         kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
-        # both streams project into the joint [txt || img] rows of qkv (flux/transformer.py:171-190 concatenates q, k, v of the two streams)
-        ops.gemm_grouped(self._problems(env, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=self._rows_of(qkv, St, Si, env), **kw_i))
-                         + self._problems(env, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=self._rows_of(qkv, 0, St, env), **kw_t)))
-        Q, K, Qt, Kt, Vt = self._alloc_heads(env)
-        ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
-        ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-        ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
-        del Vt
+        fused = self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
+        qkv = V = rrms = Qt = Kt = None
+        if fused:
+            # RMSNorm(q), RMSNorm(k), RoPE and the head-major re-layout ride in the projection's epilogue: q / k leave the GEMM as the roped head-major
+            # Q / K of the joint sequence, v as rows of the joint V (read row-major by the attention kernels), 1/rms for the backward — one launch for
+            # both streams, no [tokens, 3D] intermediate, no pass over it
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+            V = torch.empty(B * S, D, dtype=BF16, device=dev); rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev)
+            Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev) if _FUSED_VT else None      # (S is a multiple of 256 here: no padded columns)
+            ops.gemm_grouped(self._problems(env, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=self._rows_of(V, St, Si, env), epilogue=EPI_QK_NORM_ROPE,
+                                                          rope=ops.qk_rope(Q, K, rrms, blk.norm_q, blk.norm_k, env.cos_p, env.sin_p, H, S, St, Vt=Vt),
+                                                          rows_per_batch=Si, **kw_i))
+                             + self._problems(env, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=self._rows_of(V, 0, St, env),
+                                                            epilogue=EPI_QK_NORM_ROPE, rows_per_batch=St,
+                                                            rope=ops.qk_rope(Q, K, rrms, blk.norm_added_q, blk.norm_added_k, env.cos_p, env.sin_p, H, S, 0, Vt=Vt),
+                                                            **kw_t)))
+            self._attn_forward_fused(Q, K, V, Vt, O, lse2, env)
+            del Vt
+        else:
+            qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+            # both streams project into the joint [txt || img] rows of qkv (flux/transformer.py:171-190 concatenates q, k, v of the two streams)
+            ops.gemm_grouped(self._problems(env, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=self._rows_of(qkv, St, Si, env), **kw_i))
+                             + self._problems(env, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=self._rows_of(qkv, 0, St, env), **kw_t)))
+            Q, K, Qt, Kt, Vt = self._alloc_heads(env)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+            del Vt
         x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
         T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
         T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
@@ -498,7 +547,7 @@ class FluxTransformer2DModel(nn.Module):
                 dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
         sv = None
         if save:
-            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O,
+            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O,
                                  lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
         return x2_img, x2_txt, x, sv
 
@@ -509,18 +558,28 @@ class FluxTransformer2DModel(nn.Module):
         blk = self.single[bi]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
         n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
-        qkv, T = self._lin_fwd(blk.qkv, n)
-        Q, K, Qt, Kt, Vt = self._alloc_heads(env)
-        ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-        ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
-        del Vt
+        qkv = V = rrms = Qt = Kt = None
+        if self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k)):
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+            V = torch.empty(B * S, D, dtype=BF16, device=dev); rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev)
+            Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev) if _FUSED_VT else None
+            _, T = self._lin_fwd(blk.qkv, n, out=V, epilogue=EPI_QK_NORM_ROPE, rows_per_batch=S,
+                                 rope=ops.qk_rope(Q, K, rrms, blk.norm_q, blk.norm_k, env.cos_p, env.sin_p, H, S, 0, Vt=Vt))
+            self._attn_forward_fused(Q, K, V, Vt, O, lse2, env)
+            del Vt
+        else:
+            qkv, T = self._lin_fwd(blk.qkv, n)
+            Q, K, Qt, Kt, Vt = self._alloc_heads(env)
+            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+            del Vt
         hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
         hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
         # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
         x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
                          aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S)
-        sv = SimpleNamespace(x=x, n=n, qkv=qkv, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
+        sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
         return x_out, sv
 
     def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool, key_bias=None):
@@ -532,7 +591,7 @@ class FluxTransformer2DModel(nn.Module):
         dev = self.device_
         for g in self.lora_groups:
             g.pack()
-        cos, sin = self._rope(txt_ids, img_ids)
+        cos, sin, cos_p, sin_p = self._rope(txt_ids, img_ids)
         # ---- embeddings (flux/transformer.py:1001-1064) ----
         img = ops.gemm(hidden_states.reshape(B * Si, -1).contiguous(), self.l_x.w, bias=self.l_x.b)
         txt = ops.gemm(encoder_hidden_states.reshape(B * St, -1).contiguous(), self.l_ctx.w, bias=self.l_ctx.b)
@@ -547,7 +606,7 @@ class FluxTransformer2DModel(nn.Module):
         pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
         temb = ops.add(temb, pemb)
         mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
-        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias)
+        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, cos_p=cos_p, sin_p=sin_p, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias)
         segs_d = self._checkpoint_segments(len(self.double)) if save else [(i, 1, False) for i in range(len(self.double))]
         segs_s = self._checkpoint_segments(len(self.single)) if save else [(i, 1, False) for i in range(len(self.single))]
         ctx = SimpleNamespace(env=env, dbl={}, sgl={}, segs_d=segs_d, segs_s=segs_s, ck_d={}, ck_s={})
@@ -585,8 +644,18 @@ class FluxTransformer2DModel(nn.Module):
     def _attn_backward(self, sv, dO, dqkv, env):
         B, H, hd, S, Sp, D, dev = env.B, self.H, self.hd, env.S, env.Sp, self.D, self.device_
         dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
-        ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+        v_rows = sv.V if sv.V is not None else sv.qkv[:, 2 * D:]          # fused projection: V has its own [B*S, D] rows
+        ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, v_rows, sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
         return dQ, dK
+
+    def _rope_backward(self, sv, dQ, dK, wq, wk, dqkv, env, rows, pos0):
+        """dq, dk columns of dqkv for the `rows` tokens at joint position pos0: from the roped Q / K + 1/rms when the projection ran fused, else from
+        the kept pre-norm projection"""
+        B, H, hd, S = env.B, self.H, self.hd, env.S
+        if sv.rrms is not None:
+            ops.qk_rope_norm_bwd(dQ, dK, sv.Q, sv.K, sv.rrms, wq, wk, env.cos, env.sin, dqkv, B, H, hd, rows, pos0, S)
+        else:
+            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, wq, wk, env.cos, env.sin, dqkv, B, H, hd, rows, pos0, S)
 
     def _single_bwd(self, li: int, sv, dx, dxg, env):
         """backward of single block li.  Returns (dx, dxg, d_txt, d_img): block 0 of a model with double blocks writes its input gradient — the joint
@@ -602,7 +671,7 @@ class FluxTransformer2DModel(nn.Module):
         del g, dhpre
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         dQ, dK = self._attn_backward(sv, dO, dqkv, env)
-        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, S, 0, S)
+        self._rope_backward(sv, dQ, dK, blk.norm_q, blk.norm_k, dqkv, env, S, 0)
         del dQ, dK, dO
         dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
         d_txt = d_img = None
@@ -648,8 +717,8 @@ class FluxTransformer2DModel(nn.Module):
         del dx1g_i, dx1g_t, U_i, U_t
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         dQ, dK = self._attn_backward(sv, dO, dqkv, env)
-        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, 0, S)
-        ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, St, S)
+        self._rope_backward(sv, dQ, dK, blk.norm_added_q, blk.norm_added_k, dqkv, env, St, 0)
+        self._rope_backward(sv, dQ, dK, blk.norm_q, blk.norm_k, dqkv, env, Si, St)
         del dQ, dK, dO
         last = li == 0
         # the two streams' rows of the joint dqkv, in place (the reference's autograd splits the concatenated gradient the same way)

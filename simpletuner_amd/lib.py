@@ -22,7 +22,7 @@ SYMBOLS = [
     "st355_timestep_proj", "st355_silu", "st355_gelu_tanh", "st355_silu_bwd", "st355_add", "st355_scale_cols",
     "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_tn_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_transpose_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg",
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
-    "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd",
+    "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd", "st355_qk_rope_norm_bwd",
     "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd",
     "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp", "st355_grad_clip_norm",
     "st355_lora_pack",
@@ -41,7 +41,7 @@ KERNEL_CLASSES = [
     "ln_mod", "qk_rope", "skinny", "elementwise", "optim",
 ]
 
-EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_QK_NORM_ROPE = 0, 1, 2, 3, 4, 5
 
 
 class St355Unavailable(RuntimeError):
@@ -50,6 +50,15 @@ class St355Unavailable(RuntimeError):
 
 class St355Error(RuntimeError):
     pass
+
+
+class QkRope(C.Structure):
+    """st355_qk_rope (include/st355.h): operands of the fused QKV projection epilogue ST355_EPI_QK_NORM_ROPE"""
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("rrms", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
+        ("H", C.c_int32), ("S", C.c_int32), ("pos0", C.c_int32), ("eps", C.c_float),
+        ("Vt", C.c_void_p), ("Sp", C.c_int32),
+    ]
 
 
 class GemmArgs(C.Structure):
@@ -68,6 +77,7 @@ class GemmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("K2_real", C.c_int32),
         ("seg_rows", C.c_int64), ("seg_a", C.c_int64), ("seg_a2", C.c_int64), ("seg_c", C.c_int64), ("seg_in", C.c_int64), ("seg_out", C.c_int64),
+        ("rope", C.POINTER(QkRope)),
     ]
 
 
@@ -116,6 +126,7 @@ def _declare(lib):
         "st355_ln_modulate_bwd": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, f32]),
         "st355_qk_norm_rope_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32]),
         "st355_qk_norm_rope_bwd": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32]),
+        "st355_qk_rope_norm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32]),
         "st355_attn_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32]),
         "st355_attn_fwd_vrows": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32]),
         "st355_attn_bwd_workspace": (sz, [i32, i32, i32, i32, i32]),

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import lib as _l
-from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, GemmArgs  # noqa: F401
+from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE, GemmArgs, QkRope  # noqa: F401
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -261,19 +261,44 @@ def _gemm_workspace(dev, nbytes: int = _GEMM_WS_BYTES):
     return ws
 
 
+def qk_rope(Q, K, rrms, wq, wk, cos, sin, H: int, S: int, pos0: int, eps: float = 1e-6, Vt=None):
+    """operands of the fused QKV projection epilogue (EPI_QK_NORM_ROPE; st355_qk_rope in st355.h): pass as gemm(..., rope=qk_rope(...)).
+    Q, K: [B,H,S,128] bf16 outputs; rrms: [B*S, 2H] fp32 output; wq / wk: RMSNorm weights [128] or None; cos / sin: [S,64] fp32, one angle per
+    interleaved channel pair (= full_table[:, 0::2])."""
+    if cos.shape != (S, 64) or sin.shape != (S, 64) or not cos.is_contiguous() or not sin.is_contiguous():
+        raise _l.St355Error(f"qk_rope: cos / sin must be contiguous [S={S}, 64] per-pair tables, got {tuple(cos.shape)}")
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(rrms, F32, "rrms"); _chk(cos, F32, "cos"); _chk(sin, F32, "sin")
+    r = QkRope()
+    r.Q, r.K, r.rrms, r.wq, r.wk, r.cos, r.sin = _ptr(Q), _ptr(K), _ptr(rrms), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin)
+    r.H, r.S, r.pos0, r.eps = H, S, pos0, eps
+    if Vt is not None:                  # also emit the head-major V^T [B,H,128,Sp] for attn_fwd (else: row-major V only, for attn_fwd_vrows)
+        _chk(Vt, BF16, "Vt")
+        r.Vt, r.Sp = _ptr(Vt), Vt.shape[-1]
+    r._keep = (Q, K, rrms, wq, wk, cos, sin, Vt)
+    return r
+
+
 def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
-               gate=None, rows_per_batch: int = 0, k2_real: int = 0):
-    """a, a2, out, aux_in, aux_out may be 3-D [segments, rows, cols] strided views (see _seg): one problem over the row blocks of a joint buffer."""
+               gate=None, rows_per_batch: int = 0, k2_real: int = 0, rope=None):
+    """a, a2, out, aux_in, aux_out may be 3-D [segments, rows, cols] strided views (see _seg): one problem over the row blocks of a joint buffer.
+    epilogue=EPI_QK_NORM_ROPE (rope=qk_rope(...), rows_per_batch=rows of this stream per sample): `out` is the V destination [M, N/3] (q / k go
+    head-major to rope.Q / rope.K)."""
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
     M, K, g.lda, seg, g.seg_a = _seg(a, "a")
     N, Kw = w.shape
     if K != Kw:
         raise _l.St355Error(f"gemm: K mismatch {K} vs {Kw}")
-    if out is None:
+    if epilogue == EPI_QK_NORM_ROPE:
+        if rope is None or out is None:
+            raise _l.St355Error("gemm: EPI_QK_NORM_ROPE needs rope=qk_rope(...) and out= (the V destination)")
+        g.rope = C.pointer(rope)
+        g._rope_keep = rope
+        g.rows_per_batch = rows_per_batch
+    elif out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     Mo, No, g.ldc, sr, g.seg_c = _seg(out, "out")
-    if (Mo, No) != (M, N):
-        raise _l.St355Error(f"gemm: out is {Mo}x{No}, expected {M}x{N}")
+    if (Mo, No) != (M, N if epilogue != EPI_QK_NORM_ROPE else N // 3):
+        raise _l.St355Error(f"gemm: out is {Mo}x{No}, expected {M}x{N if epilogue != EPI_QK_NORM_ROPE else N // 3}")
     seg = _seg_join(seg, sr, "gemm")
     g.A, g.B, g.ldb, g.C = _ptr(a), _ptr(w), _rows(w, "w"), _ptr(out)
     g.M, g.N, g.K, g.K2 = M, N, K, 0
@@ -515,6 +540,14 @@ def qk_norm_rope_bwd(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0,
     _l.check(L.st355_qk_norm_rope_bwd(_stream(), _ptr(dQ), _ptr(dK), _ptr(qkv), _rows(qkv, "qkv"), _ptr(wq), _ptr(wk),
                                       _ptr(cos), _ptr(sin), _ptr(dqkv), _rows(dqkv, "dqkv"), B, H, d, S_part, pos0, S, eps),
              "qk_norm_rope_bwd")
+
+
+def qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S):
+    """backward of the fused projection epilogue: from the roped head-major Q / K and the saved 1/rms (no pre-norm projection kept)"""
+    L = _l.load()
+    _chk(dQ, BF16, "dQ"); _chk(dK, BF16, "dK"); _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(rrms, F32, "rrms"); _chk(dqkv, BF16, "dqkv")
+    _l.check(L.st355_qk_rope_norm_bwd(_stream(), _ptr(dQ), _ptr(dK), _ptr(Q), _ptr(K), _ptr(rrms), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin),
+                                      _ptr(dqkv), _rows(dqkv, "dqkv"), B, H, d, S_part, pos0, S), "qk_rope_norm_bwd")
 
 
 # ------------------------------------------------------------------------------------------------

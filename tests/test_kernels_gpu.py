@@ -470,6 +470,80 @@ def test_qk_norm_rope_fwd_bwd(ops, d, H, S_txt, S_img):
     assert dqkv[:, 2 * D:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("lora", [False, True])
+def test_fused_qkv_projection_epilogue(ops, lora):
+    """ST355_EPI_QK_NORM_ROPE: the QKV projection with RMSNorm(q), RMSNorm(k), RoPE and the head-major re-layout in the GEMM epilogue
+    (FluxAttnProcessor2_0, flux/transformer.py:140-207) and its backward from the roped Q / K + 1/rms, for both streams of a double block written into the
+    joint buffers (segmented V rows).  Checked against fp32 autograd of the same maths and against the unfused kernel chain; V is bit-equal to it."""
+    torch.manual_seed(77)
+    d_ = dev()
+    B, H, hd, St, Si, Kin = 2, 2, 128, 256, 512, 192
+    S, D = St + Si, H * hd
+    cos, sin = _rope_tables(S, hd, d_)
+    cos_p, sin_p = cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous()        # one angle per interleaved pair: what the fused epilogue reads
+    streams = {}
+    for name, rows, pos0 in (("txt", St, 0), ("img", Si, St)):
+        streams[name] = dict(rows=rows, pos0=pos0, x=torch.randn(B * rows, Kin, device=d_).to(BF16), W=(torch.randn(3 * D, Kin, device=d_) * 0.08).to(BF16),
+                             bias=(0.1 * torch.randn(3 * D, device=d_)).to(BF16), wq=(1 + 0.2 * torch.randn(hd, device=d_)).to(BF16),
+                             wk=(1 + 0.2 * torch.randn(hd, device=d_)).to(BF16), T=torch.randn(B * rows, 64, device=d_).to(BF16),
+                             Bs=(torch.randn(3 * D, 64, device=d_) * 0.05).to(BF16))
+    Q = torch.zeros(B, H, S, hd, device=d_, dtype=BF16); K = torch.zeros_like(Q)
+    rrms = torch.zeros(B * S, 2 * H, device=d_)
+    V = torch.zeros(B * S, D, device=d_, dtype=BF16)
+    Vt = torch.zeros(B, H, hd, S, device=d_, dtype=BF16)
+    probs = []
+    for name, st in streams.items():
+        kw = dict(a2=st["T"], b2=st["Bs"]) if lora else {}
+        probs.append(dict(a=st["x"], w=st["W"], bias=st["bias"], out=V.view(B, S, D)[:, st["pos0"]:st["pos0"] + st["rows"]], epilogue=ops.EPI_QK_NORM_ROPE,
+                          rope=ops.qk_rope(Q, K, rrms, st["wq"], st["wk"], cos_p, sin_p, H, S, st["pos0"], Vt=Vt), rows_per_batch=st["rows"], **kw))
+    ops.gemm_grouped(probs)
+    assert torch.equal(Vt, V.view(B, S, H, hd).permute(0, 2, 3, 1))           # the head-major V^T copy of the same launch
+    # the unfused chain: projection rounded to bf16, then the separate norm + rope + re-layout pass
+    qkv_u = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+    Sp = (S + 63) // 64 * 64
+    Qu = torch.zeros_like(Q); Ku = torch.zeros_like(K); Vtu = torch.zeros(B, H, hd, Sp, device=d_, dtype=BF16)
+    x_refs = {}
+    for name, st in streams.items():
+        kw = dict(a2=st["T"], b2=st["Bs"]) if lora else {}
+        ops.gemm(st["x"], st["W"], bias=st["bias"], out=qkv_u.view(B, S, 3 * D)[:, st["pos0"]:st["pos0"] + st["rows"]], **kw)
+        ops.qk_norm_rope_fwd(qkv_u, st["wq"], st["wk"], cos, sin, Qu, Ku, None, None, Vtu, B, H, hd, st["rows"], st["pos0"], S, Sp)
+        pre = st["x"].float() @ st["W"].float().t() + st["bias"].float()
+        if lora:
+            pre = pre + st["T"].float() @ st["Bs"].float().t()
+        x_refs[name] = pre.view(B, st["rows"], 3, H, hd)
+    assert torch.equal(V, qkv_u[:, 2 * D:])                                   # same accumulators, same single rounding
+    # fp32 reference of the fused maths (joint order: txt rows then img rows)
+    pre = torch.cat([x_refs["txt"], x_refs["img"]], 1)                        # [B, S, 3, H, hd]
+    q = pre[:, :, 0].permute(0, 2, 1, 3).contiguous().requires_grad_(True); k = pre[:, :, 1].permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    wq_full = torch.cat([streams["txt"]["wq"].float().expand(St, hd), streams["img"]["wq"].float().expand(Si, hd)], 0)
+    wk_full = torch.cat([streams["txt"]["wk"].float().expand(St, hd), streams["img"]["wk"].float().expand(Si, hd)], 0)
+    Qr = _ref_norm_rope(q, wq_full, cos, sin); Kr = _ref_norm_rope(k, wk_full, cos, sin)
+    eq, ek = report("fused Q vs fp32", Q, Qr)[0], report("fused K vs fp32", K, Kr)[0]
+    uq = report("unfused Q vs fp32", Qu, Qr)[0]
+    assert eq < 3e-3 and ek < 3e-3 and eq <= uq * 1.02                         # one rounding instead of two: at least as close as the unfused chain
+    rr_ref = torch.cat([torch.rsqrt(q.detach().pow(2).mean(-1) + 1e-6), torch.rsqrt(k.detach().pow(2).mean(-1) + 1e-6)], 1)   # [B, 2H, S]
+    assert report("rrms", rrms.view(B, S, 2 * H).permute(0, 2, 1), rr_ref)[0] < 1e-5
+    # backward from (Q, K, rrms)
+    dQ = torch.randn(B, H, S, hd, device=d_).to(BF16); dK = torch.randn(B, H, S, hd, device=d_).to(BF16)
+    (Qr * dQ.float()).sum().backward(retain_graph=True); (Kr * dK.float()).sum().backward()
+    dqkv = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+    for name, st in streams.items():
+        ops.qk_rope_norm_bwd(dQ, dK, Q, K, rrms, st["wq"], st["wk"], cos, sin, dqkv, B, H, hd, st["rows"], st["pos0"], S)
+    ref_dq = q.grad.permute(0, 2, 1, 3).reshape(B * S, D); ref_dk = k.grad.permute(0, 2, 1, 3).reshape(B * S, D)
+    assert report("fused-form bwd dq", dqkv[:, :D], ref_dq)[0] < 8e-3
+    assert report("fused-form bwd dk", dqkv[:, D:2 * D], ref_dk)[0] < 8e-3
+    assert dqkv[:, 2 * D:].abs().max().item() == 0
+    # no norm weights (RoPE only): rrms is 1, the backward is the transposed rotation
+    Q2 = torch.zeros_like(Q); K2 = torch.zeros_like(K); rr2 = torch.zeros_like(rrms); V2 = torch.zeros_like(V)
+    st = streams["img"]
+    ops.gemm(st["x"], st["W"], out=V2.view(B, S, D)[:, St:], epilogue=ops.EPI_QK_NORM_ROPE, rope=ops.qk_rope(Q2, K2, rr2, None, None, cos_p, sin_p, H, S, St),
+             rows_per_batch=Si)
+    pre2 = (st["x"].float() @ st["W"].float().t()).view(B, Si, 3, H, hd)
+    q2 = pre2[:, :, 0].permute(0, 2, 1, 3)
+    assert report("rope only Q", Q2[:, :, St:], _ref_norm_rope(q2, None, cos[St:], sin[St:]))[0] < 3e-3
+    assert torch.all(rr2.view(B, S, 2 * H)[:, St:] == 1.0) and Q2[:, :, :St].abs().max().item() == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
