@@ -7,11 +7,15 @@ tokens), bf16, AdamW; synthetic latents / text embeddings and random-init weight
 One "step" = prepare_batch (in-kernel noise + flow noising + target) -> MMDiT forward -> MSE -> hand-written backward ->
 (bucketed RCCL all-reduce for N>1) -> fused AdamW, exactly what Trainer.train_step runs.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W            (N>1: one rank per GPU over RCCL.  Started under torch.distributed.run the
+                                                              ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment;
+                                                              started bare, bench.py re-executes itself under torch.distributed.run
+                                                              --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1)
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel class (the bf16 MFMA
-GEMM, measured live with hipEvent pairs on the launch stream by libst355's profiler) and `cpu_baseline` (the oracle timed on
-the host cores for a bounded sample, N=1 only).
+GEMM, measured live with hipEvent pairs on the launch stream by libst355's profiler), `cpu_baseline` (the oracle timed on the
+host cores for a bounded sample, N=1 only) and `parity_at_config` (the same sample through the HIP model, compared).  The default
+(Flux) line also carries `secondary.sdxl_lora`: the SDXL-LoRA half of BASELINE.json's metric, measured after the Flux timing.
 """
 from __future__ import annotations
 
