@@ -220,6 +220,16 @@ int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const v
                            const void* wq, const void* wk, const float* cos, const float* sin,
                            void* dqkv, int64_t ld_dqkv, int B, int H, int d, int S_part, int pos0, int S, float eps);
 
+/* Self-attention backward with that RoPE + RMSNorm backward fused into the dQ / dK kernels' epilogues (head_dim 128): dq, dk, dv all land in the rows of
+ * the projection gradient dqkv [B*S, ld_dqkv] (column blocks q | k | v, each H*128 wide); no head-major dQ / dK is written or read.  Q, K: the roped
+ * head-major tensors of the fused projection; rrms its 1/rms output; cos_p / sin_p [S,64] per-pair tables.  Two norm-weight sets: joint positions < split
+ * use w*_lo (the text stream's norm_added_q / norm_added_k), the others w*_hi; pass the same pointer twice (split = 0) for a single-stream block, NULL
+ * for no norm.  workspace: st355_attn_bwd_workspace(B, H, S, Sp, 128). */
+int st355_attn_bwd_rope(void* stream, const void* Q, const void* K, const void* v_rows, int64_t ld_v, const void* O, int64_t ld_o,
+                        const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, const float* rrms,
+                        const void* wq_lo, const void* wk_lo, const void* wq_hi, const void* wk_hi, int split,
+                        const float* cos_p, const float* sin_p, void* dqkv, int64_t ld_dqkv, int B, int H, int S, int Sp, int d, float scale,
+                        void* workspace);
 /* backward of the FUSED form (ST355_EPI_QK_NORM_ROPE): starts from the roped head-major Q / K that the attention backward keeps anyway and the 1/rms
  * the epilogue wrote (rrms [B*S, 2H]); the pre-norm projection is never stored.  Norm weights must be non-zero.  d = 128. */
 int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const void* Q, const void* K, const float* rrms,

@@ -224,14 +224,6 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16* __restrict__ Q,
 //   * PV runs (sb, m)-outer / dt-inner: the 8 exponentials + pack of k-slice (sb, m) are issued just before its NDT MFMAs, so the exponentials of
 //     slice g+1 execute under the MFMAs of slice g (independent accumulators acc_o[0..NDT-1] back to back, no dependent-MFMA stalls).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float xhalf_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // VROW (head_dim 128): V comes ROW-major (token rows of a [B*S, ld_v] projection buffer, head h at columns h*128, e.g. the V third of a fused QKV
 // output) instead of the pre-transposed head-major V^T copy: the V tile is staged as [64 keys][128 channels] with the swz_q chunk swizzle of the

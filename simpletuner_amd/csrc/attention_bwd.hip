@@ -78,6 +78,81 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused RoPE + RMSNorm backward in the dQ / dK epilogues (st355_attn_bwd_rope, head_dim 128).  The accumulator layout gives a lane 64 of the 128
+// channels of ONE token (register 4a + b <-> channel 32 dt + 8a + 4h + b): whole rotation pairs (2i, 2i+1) sit in one lane, the 128-channel RMSNorm
+// reduction is an in-lane sum + one half-wave exchange.  So the gradient w.r.t. the roped head-major Q / K never goes to HBM: the epilogue un-rotates it
+// (dy = R^T g), un-rotates the kept roped activation (y = R^T z), applies dx = r (w dy - (y / w) mean(dy y)) and writes the PROJECTION-gradient rows
+// dqkv[(b S + pos), part D + head 128 + c] directly — the standalone pass (k_qk_rope_norm_bwd_z) read dQ, dK, Q, K and wrote dqkv once more.
+// Two norm-weight sets: joint positions < split use w_lo (the text stream's norm_added_q / _k), the rest w_hi (single blocks: split = 0).
+// ------------------------------------------------------------------------------------------------
+struct RopeBwd {
+  const float* rrms;                     // [B*S, 2H] 1/rms from the fused projection epilogue
+  const bf16* w_lo; const bf16* w_hi;    // RMSNorm weights [128] (both NULL: no norm)
+  const float* cos_p; const float* sin_p;   // [S, 64] one angle per rotation pair
+  bf16* out; int64_t ldo;                // projection-gradient rows (already offset to the q or k column block); out == NULL: plain head-major store
+  int split, H, S;
+  int rr_off;                            // 0 for q heads, H for k heads inside a rrms row
+};
+// Layout change first: the accumulator layout gives a lane 8-byte pieces of one token at a 256-byte token pitch — read Q / cos / sin / w and write the
+// output that way and every wave instruction touches 64 separate cache lines for 8 useful bytes each (measured: +47 us per workgroup, slower than the pass it
+// replaced).  So the wave parks its 32 tokens x 128 channels (already scaled, rounded to bf16 exactly like the head-major dQ / dK of the unfused path) in
+// its own 8 KiB slice of the idle LDS ring, XOR-swizzled by token, and reads it back with 16 lanes per token x 16 bytes: all global traffic is then whole
+// 256-byte token rows, the RMSNorm reduction a 16-lane xor-shuffle tree.
+__device__ __forceinline__ void rope_bwd_store(const RopeBwd& rp, const f32x16 (&acc)[4], float scale, const bf16* zhead, int b, int head, int tok0, int ntok,
+                                               int lane, char* stage) {   // zhead: roped head-major activations of (b, head); tok0: the wave's first token
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      bf16x4 o;
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
+      const int ch16 = 4 * dt + a;                                        // 16-byte chunk of the token row; h picks its 8-byte half
+      *(bf16x4*)(stage + l31 * 256 + ((ch16 ^ (l31 & 15)) << 4) + 8 * h) = o;
+    }
+  const int tl = lane >> 4, c = lane & 15;                                // read side: token tl of each group of 4, 16-byte chunk c (channels 8c .. 8c+7)
+  float wlo[8], whi[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { wlo[j] = rp.w_lo ? bf2f(rp.w_lo[c * 8 + j]) : 1.f; whi[j] = rp.w_hi ? bf2f(rp.w_hi[c * 8 + j]) : 1.f; }
+  const bool has_norm = rp.w_hi != nullptr;
+#pragma unroll 2
+  for (int it = 0; it < 8; it++) {
+    const int t = it * 4 + tl;
+    const int tok = min(tok0 + t, ntok - 1);
+    const bf16x8 gv = *(const bf16x8*)(stage + t * 256 + ((c ^ (t & 15)) << 4));
+    const bf16x8 zv = *(const bf16x8*)(zhead + (int64_t)tok * 128 + c * 8);
+    const f32x4 cs = *(const f32x4*)(rp.cos_p + (int64_t)tok * 64 + c * 4);
+    const f32x4 sn = *(const f32x4*)(rp.sin_p + (int64_t)tok * 64 + c * 4);
+    float dy[8], y[8], sdy = 0.f;
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      const float g0 = bf2f(gv[2 * pr]), g1 = bf2f(gv[2 * pr + 1]), z0 = bf2f(zv[2 * pr]), z1 = bf2f(zv[2 * pr + 1]);
+      // forward: o0 = y0 c - y1 s ; o1 = y1 c + y0 s   =>   R^T v = (v0 c + v1 s, v1 c - v0 s)
+      dy[2 * pr] = g0 * cs[pr] + g1 * sn[pr]; dy[2 * pr + 1] = g1 * cs[pr] - g0 * sn[pr];
+      y[2 * pr] = z0 * cs[pr] + z1 * sn[pr]; y[2 * pr + 1] = z1 * cs[pr] - z0 * sn[pr];
+      sdy += dy[2 * pr] * y[2 * pr] + dy[2 * pr + 1] * y[2 * pr + 1];
+    }
+    bf16x8 o;
+    if (has_norm) {
+      sdy += __shfl_xor(sdy, 8, 64); sdy += __shfl_xor(sdy, 4, 64); sdy += __shfl_xor(sdy, 2, 64); sdy += __shfl_xor(sdy, 1, 64);
+      const float m = sdy * (1.f / 128.f);
+      const float r = rp.rrms[((int64_t)b * rp.S + tok) * (2 * rp.H) + rp.rr_off + head];
+      const bool lo = tok < rp.split;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float wj = lo ? wlo[j] : whi[j];
+        o[j] = f2bf(r * (wj * dy[j] - y[j] * __builtin_amdgcn_rcpf(wj) * m));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[j] = f2bf(dy[j]);
+    }
+    if (tok0 + t < ntok) *(bf16x8*)(rp.out + ((int64_t)b * rp.S + tok) * rp.ldo + (int64_t)head * 128 + c * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dQ kernel: 8 waves x 32 queries
 // ------------------------------------------------------------------------------------------------
 // TR (head_dim 128): no K^T tile — the K^T fragments of dQ^T += K^T dS^T are gathered from the row-major K tile by transposing LDS reads (the
@@ -90,7 +165,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
                                                        const bf16* __restrict__ Kt, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                        const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                        const float* __restrict__ delta, const float* __restrict__ key_bias,
-                                                       bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk, int Skp, float scale, float scale2) {
+                                                       bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk, int Skp, float scale, float scale2,
+                                                       RopeBwd rp) {
   constexpr int NT = 512;
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
@@ -250,6 +326,11 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   const int nfull = BIAS ? 0 : Sk / 64;                    // key tiles with all 64 keys valid and no bias take the plain path
   for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
   for (int kt = nfull; kt < nkt; kt++) tile(kt, std::true_type{});
+  if (HD == 128 && rp.out != nullptr) {          // fused RoPE + RMSNorm backward: straight to the projection-gradient rows (all lanes take part in the exchange)
+    // (the key-tile loop ended on a workgroup barrier: the LDS ring is idle, each wave takes its own 8 KiB slice)
+    if constexpr (HD == 128) rope_bwd_store(rp, acc, scale, Q + bh * (int64_t)Sq * HD, b, head, q0, Sq, lane, smem + wv * 8192);
+    return;
+  }
   if (q < Sq) {
     bf16* orow = dQ + (bh * Sq + q) * (int64_t)HD;
 #pragma unroll
@@ -486,7 +567,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
                                                          const float* __restrict__ lsep, const float* __restrict__ delta,
                                                          const float* __restrict__ key_bias, bf16* __restrict__ dK,
                                                          bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, float scale,
-                                                         float scale2) {
+                                                         float scale2, RopeBwd rp) {
   constexpr int HD = 128;
   constexpr int QROWB = HD * 2;
   constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major): 16 KiB each
@@ -629,6 +710,29 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  if (rp.out != nullptr) {       // dK through the fused RoPE + RMSNorm backward (straight to the k columns of the projection gradient); dV as before
+    // every index is re-derived from the (laundered) thread id: nothing the epilogue needs may stay live across the main loop, which sits at the
+    // 256-VGPR limit (a first version that reused key / keyi / h spilled eight fragment registers INTO the loop)
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int h = (t2 >> 5) & 1;
+    const int wv2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
+    const int key = wg.tile * 256 + wv2 * 32 + (t2 & 31);
+    rope_bwd_store(rp, acc_dk, scale, K + bh * (int64_t)Sk * HD, b, head, wg.tile * 256 + wv2 * 32, Sk, t2 & 63, smem + wv2 * 8192);
+    if (key < Sk) {
+      bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          bf16x4 ov;
+#pragma unroll
+          for (int bb = 0; bb < 4; bb++) ov[bb] = f2bf(acc_dv[dt][4 * a + bb]);
+          *(bf16x4*)(vrow + 32 * dt + 8 * a + 4 * h) = ov;
+        }
+    }
+    return;
+  }
   if (key < Sk) {
     bf16* krow = dK + (bh * Sk + key) * (int64_t)HD;
     bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
@@ -658,8 +762,9 @@ extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
 static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
                               int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp, int Sk, int Skp,
-                              int d, float scale, void* workspace) {
-  ST_REQUIRE(Q && K && v_rows && O && dO && lse2 && dQ && dK && dv_rows && workspace, "attn_bwd: null pointer");
+                              int d, float scale, void* workspace, const RopeBwd* rope_q = nullptr, const RopeBwd* rope_k = nullptr) {
+  const RopeBwd rq = rope_q ? *rope_q : RopeBwd{}, rk = rope_k ? *rope_k : RopeBwd{};       // out == NULL: head-major dQ / dK as before
+  ST_REQUIRE(Q && K && v_rows && O && dO && lse2 && (dQ || rq.out) && (dK || rk.out) && dv_rows && workspace, "attn_bwd: null pointer");
   // Qt == NULL selects the third-generation dK/dV kernel, Kt == NULL the transposing-read dQ kernel (head_dim 128): Q^T / dO^T / K^T fragments come
   // from the row-major tiles by ds_read_b64_tr_b16 instead of pre-transposed head-major copies
   ST_REQUIRE((Qt && Kt) || d == 128, "attn_bwd: Qt / Kt may only be omitted for head_dim 128 (got %d)", d);
@@ -693,7 +798,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       static bool set = false;
       if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
       hipLaunchKernelGGL(k_attn_bwd_dkv3, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
-                         (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2);
+                         (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);
     } else {                                   // head-major Q^T / dO^T copies supplied: the LDS-DMA kernel over four tile images (head_dim 64 / 96 / 128)
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * d * 2 + 2 * d * 128 + 512);
@@ -723,7 +828,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     static bool set = false;                                                                                                             \
     if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
     hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt, (const bf16*)v_rows, ld_v,     \
-                       (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2);        \
+                       (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2, rq);    \
   } while (0)
     if (key_bias) {
       if (d == 96) ST355_DQ_LAUNCH((k_attn_bwd_dq<96, false, true>));
@@ -746,6 +851,21 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp,
                               int d, float scale, void* workspace) {
   return attn_bwd_impl(stream, Q, K, Qt, Kt, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, dQ, dK, dv_rows, ld_dv, B, H, S, Sp, S, Sp, d, scale, workspace);
+}
+// Self-attention backward with the RoPE + RMSNorm backward fused into the dQ / dK epilogues (head_dim 128, the fused-projection form): dq, dk and dv all
+// land in the rows of the projection gradient dqkv [B*S, ld] (column blocks q | k | v of width D = H*128); no head-major dQ / dK exists.
+extern "C" int st355_attn_bwd_rope(void* stream, const void* Q, const void* K, const void* v_rows, int64_t ld_v, const void* O, int64_t ld_o,
+                                   const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, const float* rrms, const void* wq_lo,
+                                   const void* wk_lo, const void* wq_hi, const void* wk_hi, int split, const float* cos_p, const float* sin_p,
+                                   void* dqkv, int64_t ld_dqkv, int B, int H, int S, int Sp, int d, float scale, void* workspace) {
+  ST_REQUIRE(d == 128, "attn_bwd_rope: head_dim %d not built (128 only)", d);
+  ST_REQUIRE(rrms && cos_p && sin_p && dqkv && ld_dqkv % 8 == 0 && ld_dqkv >= 3 * (int64_t)H * d && split >= 0 && split <= S, "attn_bwd_rope: bad arguments");
+  ST_REQUIRE((wq_lo == nullptr) == (wq_hi == nullptr) && (wk_lo == nullptr) == (wk_hi == nullptr), "attn_bwd_rope: a norm weight needs both position ranges");
+  const int64_t D = (int64_t)H * d;
+  RopeBwd rq{rrms, (const bf16*)wq_lo, (const bf16*)wq_hi, cos_p, sin_p, (bf16*)dqkv, ld_dqkv, split, H, S, 0};
+  RopeBwd rk{rrms, (const bf16*)wk_lo, (const bf16*)wk_hi, cos_p, sin_p, (bf16*)dqkv + D, ld_dqkv, split, H, S, H};
+  return attn_bwd_impl(stream, Q, K, nullptr, nullptr, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, nullptr, nullptr, (bf16*)dqkv + 2 * D, ld_dqkv,
+                       B, H, S, Sp, S, Sp, d, scale, workspace, &rq, &rk);
 }
 // cross-attention backward: Q,Qt over Sq (padded Sqp) queries; K,Kt, v_rows / dv_rows ([B*Sk, ld]) over Sk (padded Skp) keys; workspace sized for (Sq, Sqp)
 extern "C" int st355_attn_cross_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,

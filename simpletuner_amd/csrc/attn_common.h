@@ -36,6 +36,16 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// exchange between the two 32-lane halves of a wave (v_permlane32_swap: VALU, no LDS round trip): every lane gets max / sum of lanes l and l ^ 32
+__device__ __forceinline__ float xhalf_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // XCD-aware workgroup -> (tile, head, batch) mapping for the attention kernels.  Grids stay (tiles, H, B); the hardware hands consecutive linear
 // workgroup ids (x fastest) to the 8 XCDs round-robin, so with the identity mapping the tiles of ONE head are spread over all 8 XCDs and every
 // XCD's private L2 streams the K/V (or Q/dO) tiles of every head — 8 L2 fills per tile, and each XCD's L2 holds 14 heads' working windows at once.

@@ -31,6 +31,7 @@ from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_N
 BF16 = torch.bfloat16
 F32 = torch.float32
 _FUSED_QKV = __import__("os").environ.get("ST355_FUSED_QKV", "1") != "0"      # A/B switch: 0 = separate RMSNorm + RoPE pass after the QKV projection
+_FUSED_ROPE_BWD = __import__("os").environ.get("ST355_FUSED_ROPE_BWD", "1") != "0"   # A/B switch: 0 = RoPE / RMSNorm backward as its own pass after the attention backward
 _FUSED_VT = __import__("os").environ.get("ST355_FUSED_VT", "1") != "0"        # A/B switch: 0 = no V^T from the fused epilogue, forward attention reads row-major V
 _TRANSPOSED_COPIES = __import__("os").environ.get("ST355_ATTN_BWD_T") == "1"      # A/B switch: keep the pre-transposed Q^T / K^T copies (dkv2 / dq kernels) at head_dim 128
 
@@ -648,6 +649,20 @@ class FluxTransformer2DModel(nn.Module):
         ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, v_rows, sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
         return dQ, dK
 
+    def _attn_rope_backward(self, sv, dO, dqkv, env, w_lo, w_hi, split: int):
+        """attention backward + RoPE / RMSNorm backward -> all three column blocks of dqkv.  After a fused projection (head_dim 128) the second half
+        runs in the dQ / dK kernels' epilogues (one call, no head-major dQ / dK); otherwise attention backward, then the separate pass per stream:
+        joint positions < split carry the text stream's norm weights w_lo = (q, k), the rest w_hi."""
+        B, H, hd, S, Sp = env.B, self.H, self.hd, env.S, env.Sp
+        if sv.rrms is not None and _FUSED_ROPE_BWD:
+            ops.attn_bwd_rope(sv.Q, sv.K, sv.V, sv.O, dO, sv.lse2, sv.rrms, w_lo[0], w_lo[1], w_hi[0], w_hi[1], split, env.cos_p, env.sin_p, dqkv,
+                              B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
+            return
+        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
+        if split > 0:
+            self._rope_backward(sv, dQ, dK, w_lo[0], w_lo[1], dqkv, env, split, 0)
+        self._rope_backward(sv, dQ, dK, w_hi[0], w_hi[1], dqkv, env, S - split, split)
+
     def _rope_backward(self, sv, dQ, dK, wq, wk, dqkv, env, rows, pos0):
         """dq, dk columns of dqkv for the `rows` tokens at joint position pos0: from the roped Q / K + 1/rms when the projection ran fused, else from
         the kept pre-norm projection"""
@@ -670,9 +685,8 @@ class FluxTransformer2DModel(nn.Module):
         dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
         del g, dhpre
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
-        self._rope_backward(sv, dQ, dK, blk.norm_q, blk.norm_k, dqkv, env, S, 0)
-        del dQ, dK, dO
+        self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_q, blk.norm_k), (blk.norm_q, blk.norm_k), 0)
+        del dO
         dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
         d_txt = d_img = None
         if li > 0:
@@ -716,10 +730,8 @@ class FluxTransformer2DModel(nn.Module):
                 lin.lora.grads(self._compact(self._rows_of(sv.O, lo, rows, env), env, rows), T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
         del dx1g_i, dx1g_t, U_i, U_t
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
-        self._rope_backward(sv, dQ, dK, blk.norm_added_q, blk.norm_added_k, dqkv, env, St, 0)
-        self._rope_backward(sv, dQ, dK, blk.norm_q, blk.norm_k, dqkv, env, Si, St)
-        del dQ, dK, dO
+        self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_added_q, blk.norm_added_k), (blk.norm_q, blk.norm_k), St)
+        del dO
         last = li == 0
         # the two streams' rows of the joint dqkv, in place (the reference's autograd splits the concatenated gradient the same way)
         dq_i, dq_t = self._rows_of(dqkv, St, Si, env), self._rows_of(dqkv, 0, St, env)

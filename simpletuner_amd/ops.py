@@ -586,6 +586,22 @@ def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d,
              "attn_bwd")
 
 
+def attn_bwd_rope(Q, K, v_rows, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, split: int, cos_p, sin_p, dqkv, B, H, S, Sp, d, scale: float, key_bias=None):
+    """attention backward with the RoPE + RMSNorm backward fused into the dQ / dK epilogues (head_dim 128, after a fused QKV projection): dq, dk, dv are
+    written straight into the rows of the projection gradient dqkv [B*S, >= 3*H*d]; joint positions < split use the *_lo norm weights."""
+    L = _l.load()
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(rrms, F32, "rrms"); _chk(dqkv, BF16, "dqkv"); _chk(cos_p, F32, "cos_p"); _chk(sin_p, F32, "sin_p")
+    need = L.st355_attn_bwd_workspace(B, H, S, Sp, d)
+    key = (Q.device.index,)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
+        _attn_ws[key] = ws
+    _l.check(L.st355_attn_bwd_rope(_stream(), _ptr(Q), _ptr(K), _ptr(v_rows), _rows(v_rows, "v_rows"), _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"),
+                                   _ptr(lse2), _ptr(key_bias), _ptr(rrms), _ptr(wq_lo), _ptr(wk_lo), _ptr(wq_hi), _ptr(wk_hi), split, _ptr(cos_p), _ptr(sin_p),
+                                   _ptr(dqkv), _rows(dqkv, "dqkv"), B, H, S, Sp, d, scale, _ptr(ws)), "attn_bwd_rope")
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser / EMA
 # ------------------------------------------------------------------------------------------------

@@ -380,6 +380,44 @@ def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, 
         ops.gemm(A_joint[:, 1:1 + 200], W)                              # 200-row segments: not a multiple of the 256-row tile
 
 
+@pytest.mark.parametrize("with_norm,split", [(True, 256), (True, 0), (False, 0)])
+def test_attention_backward_with_fused_rope_norm_backward(ops, with_norm, split):
+    """st355_attn_bwd_rope: dq / dk / dv straight into the projection-gradient rows, the RoPE + RMSNorm backward running in the dQ / dK kernels' epilogues,
+    against the two-step chain (st355_attn_bwd -> head-major dQ, dK -> st355_qk_rope_norm_bwd).  The fused form skips the bf16 rounding of dQ / dK in between,
+    so it is compared with a tolerance; dV is bit-equal."""
+    torch.manual_seed(91)
+    d_ = dev()
+    B, H, S, hd = 2, 2, 512, 128
+    D = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    cos, sin = _rope_tables(S, hd, d_)
+    cos_p, sin_p = cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous()
+    Q = torch.randn(B, H, S, hd, device=d_).to(BF16); K = torch.randn(B, H, S, hd, device=d_).to(BF16)      # roped head-major activations (z)
+    V = torch.randn(B * S, D, device=d_).to(BF16)
+    Vt = V.view(B, S, H, hd).permute(0, 2, 3, 1).contiguous()
+    rrms = (0.5 + torch.rand(B * S, 2 * H, device=d_)).contiguous()
+    mk = lambda: (1 + 0.2 * torch.randn(hd, device=d_)).to(BF16) if with_norm else None
+    wq_lo, wk_lo, wq_hi, wk_hi = mk(), mk(), mk(), mk()
+    if split == 0:
+        wq_lo, wk_lo = wq_hi, wk_hi
+    O = torch.empty(B * S, D, device=d_, dtype=BF16); lse2 = torch.empty(B, H, S, device=d_)
+    ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, scale)
+    dO = torch.randn(B * S, D, device=d_).to(BF16)
+    # two-step chain
+    dQ = torch.empty_like(Q); dK = torch.empty_like(K)
+    ref = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+    ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, ref[:, 2 * D:], B, H, S, S, hd, scale)
+    if split > 0:
+        ops.qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq_lo, wk_lo, cos, sin, ref, B, H, hd, split, 0, S)
+    ops.qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq_hi, wk_hi, cos, sin, ref, B, H, hd, S - split, split, S)
+    # fused
+    out = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+    ops.attn_bwd_rope(Q, K, V, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, split, cos_p, sin_p, out, B, H, S, S, hd, scale)
+    assert torch.equal(out[:, 2 * D:], ref[:, 2 * D:])
+    assert report("fused rope-bwd dq", out[:, :D], ref[:, :D])[0] < 6e-3
+    assert report("fused rope-bwd dk", out[:, D:2 * D], ref[:, D:2 * D])[0] < 6e-3
+
+
 # ------------------------------------------------------------------------------------------------
 # AdaLN, RMSNorm + RoPE
 # ------------------------------------------------------------------------------------------------
