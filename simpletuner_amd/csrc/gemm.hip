@@ -662,6 +662,16 @@ __global__ void __launch_bounds__(P3_THREADS, 2) k_gemm_p3(GemmGroup g) {
 #define PQ_ABL 0                            // lab-only ablations (wrong results!): bit 0 = no fragment reads in the loop, bit 1 = no LDS-DMA refills
 #endif
 #ifndef PQ_PRIO
+#ifndef PQ_F8_MX
+#define PQ_F8_MX 1                          // fp8-native Linear on the K = 64 f8f6f4 MFMA (2x the bf16 issue rate) with unit block scales; 0 = the K = 16 fp8_bf8 form
+#endif
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 frag32(const long* p) {       // four consecutive 8-byte fragment pieces -> the 32-byte operand of the K = 64 MFMA
+  i32x8 v;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { v[2 * q] = (int)(p[q] & 0xffffffffl); v[2 * q + 1] = (int)(p[q] >> 32); }
+  return v;
+}
 #define PQ_PRIO 1                           // raise the wave priority around the MFMA clusters (T5)
 #endif
 #ifndef PQ_GL
@@ -831,11 +841,19 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const int t_row = (8 * (tg >> 1) + tti) * 256 + (tts & 1) * 8;
   const int xt = t_row + (((wm * 8 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);                  // ^ (j<<6), + ks*4096 + rd*1024
   const int wt = 2 * PQ_REGION + t_row + (((wn * 4 + 2 * (tg & 1) + (tts >> 1)) ^ (tti << 2)) << 4);
-  // fp8: lane reads the 8 bytes k = 16 ks + 8 khalf .. +8 of its row: 16-byte chunk ks (swizzled), half khalf
+  // fp8 fragments, eight 8-byte pieces per row and K-tile (128 K-elements):
+  //   PQ_F8_MX = 0  v_mfma_f32_32x32x16_fp8_bf8 (issues at the bf16 rate): piece ks = the k-slice 16 ks + 8 khalf .. +8: chunk ks (swizzled), half khalf
+  //   PQ_F8_MX = 1  v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127) — the K = 64 form that issues at TWICE the bf16 rate; the row scales of
+  //                 the reference's fp8-native Linear (fp8_native.py:64-75) stay in the epilogue, so MX scaling itself is not used.  A lane supplies 32 bytes
+  //                 of its row per MFMA: pieces 4 s .. 4 s + 3 = bytes 64 s + 32 khalf .. +32 (two swizzled 16-byte chunks).  Both operands use the same
+  //                 lane -> K mapping, and the MFMA pairs equal byte positions of the A and the B lane, so any mapping that covers the 64 K-elements of a
+  //                 step once is correct: no knowledge of the instruction's internal K order is needed.
   int xk8[8], wk8[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ks++) {
-    const int ch = ((ks ^ ((l31 >> 1) & 7)) << 4) + khalf * 8;
+    const int chunk = PQ_F8_MX ? 4 * (ks >> 2) + 2 * khalf + ((ks & 3) >> 1) : ks;
+    const int half8 = PQ_F8_MX ? (ks & 1) : khalf;
+    const int ch = ((chunk ^ ((l31 >> 1) & 7)) << 4) + half8 * 8;
     xk8[ks] = (wm * 64 + l31) * 128 + ch;
     wk8[ks] = 2 * PQ_REGION + (wn * 32 + l31) * 128 + ch;
   }
@@ -873,7 +891,12 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 #define PQ_MMA(WF, I, J0, T, PH)                                                                              \
   do {                                                                                                        \
     if (PQ_PRIO) __builtin_amdgcn_s_setprio(1);                                                               \
-    if (F8) {                                                                                                 \
+    if (F8 && PQ_F8_MX) {                                                                                     \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; s2++)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
+          acc[I][J0 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag32(&WF##8[4 * s2]), frag32(&xf8[j][4 * s2]), acc[I][J0 + j], \
+                                                                            0 /* A = e4m3 weights */, 1 /* B = e5m2 activations */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+    } else if (F8) {                                                                                          \
       _Pragma("unroll") for (int ks = 0; ks < 8; ks++)                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
           acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(WF##8[ks], xf8[j][ks], acc[I][J0 + j], 0, 0, 0); \
