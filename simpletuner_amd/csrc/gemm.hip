@@ -1289,9 +1289,14 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   GemmP p = to_p(a);
   // thin problems (the LoRA rank-space projections: N <= 128, K in the thousands) stream A once and have only M/128 tiles: split
   // K so that >= 2 workgroups per CU are in flight, partial sums through the caller's fp32 workspace (fixed-order reduce)
-  if (a->workspace && p.N <= S2_BN && p.K2 == 0 && a->epilogue == ST355_EPI_NONE && p.K >= 1024 && p.M >= 512 && !(a->seg_rows && a->seg_c)) {   // (the slab reduce writes compact C rows)
+  static int thin_splitk = -1;
+  if (thin_splitk < 0) { const char* e = getenv("ST355_THIN_SPLITK"); thin_splitk = (e && e[0] == '0') ? 0 : 1; }      // A/B: 0 = no split-K for thin problems
+  if (thin_splitk && a->workspace && p.N <= S2_BN && p.K2 == 0 && a->epilogue == ST355_EPI_NONE && p.K >= 1024 && p.M >= 512 && !(a->seg_rows && a->seg_c)) {   // (the slab reduce writes compact C rows)
     const int tiles = (p.M + S2_BM - 1) / S2_BM;
     int ks = (512 + tiles - 1) / tiles;
+    // more than one round of resident workgroups already (288 row tiles for the LoRA projections of a 36 864-token batch): a split only adds slab traffic
+    // and a ragged second round — measured 83 us (ks = 2) / 77 (ks = 3) against 65 us on the 256x128 schedule without a split, which the code below picks
+    if (tiles > 256) ks = 1;
     const int nt1 = p.K / BK;
     if (ks > nt1 / 4) ks = nt1 / 4;                       // >= 4 K-tiles per slice
     if (ks > 16) ks = 16;
