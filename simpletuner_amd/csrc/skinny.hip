@@ -10,19 +10,19 @@
 #include "common.h"
 
 #define SK_PT 128   // columns of L per workgroup
-#define SK_MC 256   // rows of L per workgroup (split-M chunk)
+#define SK_MC 256   // smallest split-M chunk: rows of L per workgroup (the launch picks 256 / 512 / 1024, see skinny_chunk)
 #define SK_MS 32    // rows per LDS sub-tile
 
 template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
-                                                  float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr) {
+                                                  float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr, int mc) {
   constexpr int RT = RN / 16;
   __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS][SK_PT];
   __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS][RN];
   const int tid = threadIdx.x;
   const int pg = tid & 15, rg = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
-  const int64_t mbase = (int64_t)blockIdx.y * SK_MC;
+  const int64_t mbase = (int64_t)blockIdx.y * mc;
   if (seg_rows) {          // segmented rows (st355_skinny_tn_seg): this 256-row chunk lies inside segment mbase / seg_rows; shift both operand bases to it
     const int64_t sgi = mbase / seg_rows;
     L += sgi * seg_xl;
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
 #pragma unroll
     for (int j = 0; j < RT; j++) acc[i][j] = 0.f;
 
-  for (int ms = 0; ms < SK_MC; ms += SK_MS) {
+  for (int ms = 0; ms < mc; ms += SK_MS) {
     // stage L sub-tile: 32 x 128 -> 512 chunks of 16 B
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -92,14 +92,14 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
 #define SK_LP (SK_PT + 32)      // 160 elements = 320 B
 template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
-                                                       float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr) {
+                                                       float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr, int mc) {
   constexpr int RT = RN / 32;                  // 32-wide r blocks
   constexpr int RP = (RN == 32) ? 32 : 96;     // R tile pitch in elements (64 B / 192 B)
   __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS * SK_LP];
   __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS * RP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
-  const int64_t mbase = (int64_t)blockIdx.y * SK_MC;
+  const int64_t mbase = (int64_t)blockIdx.y * mc;
   if (seg_rows) {          // segmented rows (st355_skinny_tn_seg): this 256-row chunk lies inside segment mbase / seg_rows; shift both operand bases to it
     const int64_t sgi = mbase / seg_rows;
     L += sgi * seg_xl;
@@ -148,10 +148,10 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
     if (tid < SK_MS * RN / 8) *(bf16x8*)(&Rs[(tid / (RN / 8)) * RP + (tid % (RN / 8)) * 8]) = rreg;
   };
   load(0);
-  for (int ms = 0; ms < SK_MC; ms += SK_MS) {
+  for (int ms = 0; ms < mc; ms += SK_MS) {
     store();
     __syncthreads();
-    if (ms + SK_MS < SK_MC) load(ms + SK_MS);          // next sub-tile's global loads fly under the MFMAs
+    if (ms + SK_MS < mc) load(ms + SK_MS);          // next sub-tile's global loads fly under the MFMAs
 #pragma unroll
     for (int ks = 0; ks < SK_MS / 16; ks++) {
       const bf16* lp = &Ls[(16 * ks + row_l) * SK_LP + a_col];
@@ -194,6 +194,15 @@ __global__ void __launch_bounds__(256) k_skinny_reduce(const float* __restrict__
   *o = (accumulate ? *o : 0.f) + alpha * s;
 }
 
+// Rows per workgroup.  Every chunk leaves a [P, Rn] fp32 partial that is written and read once more by the reduce: at 256 rows the partials of a
+// 36 864-row product are half as many bytes again as the L operand itself.  So: the largest chunk that (a) divides the segment length when the operands
+// are segmented and (b) still leaves >= 512 workgroups (two per CU) in the grid.
+static int skinny_chunk(int64_t M, int64_t P, int64_t seg_rows) {
+  const int64_t pt = cdiv64(P, SK_PT);
+  for (int mc = 1024; mc > SK_MC; mc >>= 1)
+    if ((seg_rows == 0 || seg_rows % mc == 0) && cdiv64(M, mc) * pt >= 512) return mc;
+  return SK_MC;
+}
 extern "C" size_t st355_skinny_tn_workspace(int64_t M, int64_t P, int Rn) {
   return (size_t)cdiv64(M, SK_MC) * (size_t)P * (size_t)Rn * sizeof(float);
 }
@@ -209,23 +218,24 @@ extern "C" int st355_skinny_tn_seg(void* stream, const void* L, int64_t ldl, con
   const int64_t seg_xl = (seg_rows && seg_l) ? (seg_l - seg_rows) * ldl : 0, seg_xr = (seg_rows && seg_r) ? (seg_r - seg_rows) * ldr : 0;
   ST_REQUIRE((Rn == 32 || Rn == 64) && r_used > 0 && r_used <= Rn, "skinny_tn: Rn must be 32 or 64 (got %d)", Rn);
   ST_REQUIRE(M > 0 && P > 0 && P % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0, "skinny_tn: bad shape");
-  const int nchunks = (int)cdiv64(M, SK_MC);
+  const int mc = skinny_chunk(M, P, seg_rows);
+  const int nchunks = (int)cdiv64(M, mc);
   ProfScope ps(stream, ST355_K_SKINNY, 2.0 * M * P * Rn, 2.0 * M * (P + Rn) + 8.0 * nchunks * P * Rn);
   dim3 grid((unsigned)cdiv64(P, SK_PT), nchunks);
   static int gen = -1;
   if (gen < 0) { const char* e = getenv("ST355_SKINNY"); gen = (e && e[0] == '1') ? 1 : 2; }
   if (gen == 2 && Rn == 32)
     hipLaunchKernelGGL(k_skinny_tn_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr, mc);
   else if (gen == 2)
     hipLaunchKernelGGL(k_skinny_tn_mfma<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr, mc);
   else if (Rn == 32)
     hipLaunchKernelGGL(k_skinny_tn<32>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr, mc);
   else
     hipLaunchKernelGGL(k_skinny_tn<64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr,
-                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr);
+                       (float*)workspace, M, P, seg_rows, seg_xl, seg_xr, mc);
   int rc = st355_check_launch("skinny_tn");
   if (rc) return rc;
   const int64_t n = P * r_used;
