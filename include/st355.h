@@ -195,6 +195,12 @@ int st355_skinny_tn_seg(void* stream, const void* L, int64_t ldl, const void* R,
                         float* out, int64_t so_p, int64_t so_r, int64_t M, int64_t P, int Rn, int r_used,
                         float alpha, int accumulate, void* workspace, int64_t seg_rows, int64_t seg_l, int64_t seg_r);
 
+/* nout (1..4) adapters sharing L: outs[g][p*so_p + r*so_r] (+)= alpha * sum_m L[m,p] * R[m, 32 g + r], r < r_used <= 32; R has 128 columns (row stride ldr).
+ * One pass over L instead of nout (the q / k / v adapters of a fused projection).  workspace: st355_skinny_tn_workspace(M, P, 128) bytes. */
+int st355_skinny_tn_multi(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* const* outs, int nout,
+                          int64_t so_p, int64_t so_r, int64_t M, int64_t P, int r_used, float alpha, int accumulate, void* workspace,
+                          int64_t seg_rows, int64_t seg_l, int64_t seg_r);
+
 /* ---- K5: AdaLN modulate  y = LN(x; eps, no affine) * (1 + scale_b) + shift_b  (flux/transformer.py:396-403) */
 int st355_ln_modulate_fwd(void* stream, const void* x, int64_t ldx, const void* scale, const void* shift,
                           int64_t mod_stride /* elements between batches in scale/shift */,

@@ -94,7 +94,7 @@ template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
                                                        float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr, int mc) {
   constexpr int RT = RN / 32;                  // 32-wide r blocks
-  constexpr int RP = (RN == 32) ? 32 : 96;     // R tile pitch in elements (64 B / 192 B)
+  constexpr int RP = (RN == 32) ? 32 : (RN == 64 ? 96 : 160);     // R tile pitch in elements (64 B / 192 B / 320 B)
   __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS * SK_LP];
   __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS * RP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
   const int a_col = 32 * wv + 16 * (g & 1) + 4 * tsg;                    // this wave's 32 columns of the L tile
   const int b_col = 16 * (g & 1) + 4 * tsg;                              // + 32*j
 
-  bf16x8 lreg[2], rreg;
+  constexpr int RCH = (SK_MS * RN / 8 + 255) / 256;      // 16-byte R chunks per thread (1; 2 for RN = 128)
+  bf16x8 lreg[2], rreg[RCH];
   auto load = [&](int ms) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -129,13 +130,17 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
         for (int j = 0; j < 8; j++) lreg[k][j] = f2bf(0.f);
       }
     }
-    if (tid < SK_MS * RN / 8) {
-      const int row = tid / (RN / 8), c = tid % (RN / 8);
-      const int64_t m = mbase + ms + row;
-      if (m < M) rreg = *(const bf16x8*)(R + m * ldr + c * 8);
-      else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rreg[j] = f2bf(0.f);
+    for (int q = 0; q < RCH; q++) {
+      const int id = q * 256 + tid;
+      if (id < SK_MS * RN / 8) {
+        const int row = id / (RN / 8), c = id % (RN / 8);
+        const int64_t m = mbase + ms + row;
+        if (m < M) rreg[q] = *(const bf16x8*)(R + m * ldr + c * 8);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) rreg[q][j] = f2bf(0.f);
+        }
       }
     }
   };
@@ -145,7 +150,11 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
       const int id = k * 256 + tid;
       *(bf16x8*)(&Ls[(id >> 4) * SK_LP + (id & 15) * 8]) = lreg[k];
     }
-    if (tid < SK_MS * RN / 8) *(bf16x8*)(&Rs[(tid / (RN / 8)) * RP + (tid % (RN / 8)) * 8]) = rreg;
+#pragma unroll
+    for (int q = 0; q < RCH; q++) {
+      const int id = q * 256 + tid;
+      if (id < SK_MS * RN / 8) *(bf16x8*)(&Rs[(id / (RN / 8)) * RP + (id % (RN / 8)) * 8]) = rreg[q];
+    }
   };
   load(0);
   for (int ms = 0; ms < mc; ms += SK_MS) {
@@ -242,6 +251,45 @@ extern "C" int st355_skinny_tn_seg(void* stream, const void* L, int64_t ldl, con
   hipLaunchKernelGGL(k_skinny_reduce, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out,
                      so_p, so_r, P, Rn, r_used, nchunks, alpha, accumulate);
   return st355_check_launch("skinny_reduce");
+}
+// several adapters that share the L operand (the q / k / v adapters of one fused projection: dA_g = U_g^T x): ONE pass over L against the [M, 32 * nout]
+// column blocks of R, block g reduced into its own output.  L is the big operand (226 MB at 36 864 x 3072): reading it once instead of nout times is the point.
+struct SkinnyOuts { float* o[4]; };
+__global__ void __launch_bounds__(256) k_skinny_reduce_multi(const float* __restrict__ ws, SkinnyOuts outs, int64_t so_p, int64_t so_r, int64_t P, int RN,
+                                                            int r_used, int nout, int nchunks, float alpha, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * r_used * nout) return;
+  const int r = (int)(i % r_used);
+  const int g = (int)((i / r_used) % nout);
+  const int64_t p = i / ((int64_t)r_used * nout);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; c++) s += ws[((int64_t)c * P + p) * RN + 32 * g + r];
+  float* o = outs.o[g] + p * so_p + r * so_r;
+  *o = (accumulate ? *o : 0.f) + alpha * s;
+}
+extern "C" int st355_skinny_tn_multi(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* const* outs, int nout, int64_t so_p,
+                                     int64_t so_r, int64_t M, int64_t P, int r_used, float alpha, int accumulate, void* workspace,
+                                     int64_t seg_rows, int64_t seg_l, int64_t seg_r) {
+  ST_REQUIRE(L && R && outs && workspace && nout >= 1 && nout <= 4, "skinny_tn_multi: bad arguments (1..4 outputs)");
+  for (int g = 0; g < nout; g++) ST_REQUIRE(outs[g] != nullptr, "skinny_tn_multi: null output %d", g);
+  ST_REQUIRE(seg_rows == 0 || (seg_rows > 0 && seg_rows % SK_MC == 0 && M % seg_rows == 0 && (seg_l == 0 || seg_l >= seg_rows) && (seg_r == 0 || seg_r >= seg_rows)),
+             "skinny_tn_multi: seg_rows (%lld) must be a multiple of %d that divides M; strides >= seg_rows", (long long)seg_rows, SK_MC);
+  ST_REQUIRE(r_used > 0 && r_used <= 32 && M > 0 && P > 0 && P % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0 && ldr >= 128, "skinny_tn_multi: bad shape (R needs 128 columns)");
+  const int64_t seg_xl = (seg_rows && seg_l) ? (seg_l - seg_rows) * ldl : 0, seg_xr = (seg_rows && seg_r) ? (seg_r - seg_rows) * ldr : 0;
+  const int mc = skinny_chunk(M, P, seg_rows);
+  const int nchunks = (int)cdiv64(M, mc);
+  ProfScope ps(stream, ST355_K_SKINNY, 2.0 * M * P * 32.0 * nout, 2.0 * M * (P + 128) + 8.0 * nchunks * P * 128);
+  dim3 grid((unsigned)cdiv64(P, SK_PT), nchunks);
+  hipLaunchKernelGGL(k_skinny_tn_mfma<128>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)L, ldl, (const bf16*)R, ldr, (float*)workspace, M, P,
+                     seg_rows, seg_xl, seg_xr, mc);
+  int rc = st355_check_launch("skinny_tn_multi");
+  if (rc) return rc;
+  SkinnyOuts so{};
+  for (int g = 0; g < nout; g++) so.o[g] = outs[g];
+  const int64_t n = P * r_used * nout;
+  hipLaunchKernelGGL(k_skinny_reduce_multi, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, so, so_p, so_r, P, 128,
+                     r_used, nout, nchunks, alpha, accumulate);
+  return st355_check_launch("skinny_reduce_multi");
 }
 extern "C" int st355_skinny_tn(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, float* out, int64_t so_p,
                                int64_t so_r, int64_t M, int64_t P, int Rn, int r_used, float alpha, int accumulate, void* workspace) {

@@ -83,11 +83,15 @@ class LoraGroup:
 
     def grads(self, x, T, dy, U, accumulate: bool, sync=None):
         """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r])."""
+        multi = len(self.targets) > 1 and self.r_pad == 32 and U.shape[1] >= 128        # q / k / v share x: dA of all three in ONE pass over x
         for g, (_, n_off, N) in enumerate(self.targets):
             c0 = g * self.r_pad
             ops.skinny_tn(dy[..., n_off:n_off + N], T[:, c0:c0 + self.r_pad], self.gB[g], self.rank, 1, self.rank,
                           alpha=self.scale, accumulate=accumulate)
-            ops.skinny_tn(x, U[:, c0:c0 + self.r_pad], self.gA[g], 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
+            if not multi:
+                ops.skinny_tn(x, U[:, c0:c0 + self.r_pad], self.gA[g], 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
+        if multi:
+            ops.skinny_tn_multi(x, U, self.gA, 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
         if sync is not None:
             sync.ready(self.flat_lo, self.flat_hi)
 

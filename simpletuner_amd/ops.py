@@ -486,6 +486,29 @@ def skinny_tn(Lm, R, out, so_p: int, so_r: int, r_used: int, alpha: float = 1.0,
     return out
 
 
+def skinny_tn_multi(Lm, R, outs, so_p: int, so_r: int, r_used: int, alpha: float = 1.0, accumulate: bool = False):
+    """outs[g][p*so_p + r*so_r] (+)= alpha * sum_m Lm[m,p] * R[m, 32 g + r] for the len(outs) <= 4 adapters that share Lm: ONE pass over Lm (R: [M, >= 128])."""
+    L = _l.load()
+    _chk(Lm, BF16, "L"); _chk(R, BF16, "R")
+    M, P, ldl, seg, seg_l = _seg(Lm, "L")
+    Mr, Rn, ldr, sr, seg_r = _seg(R, "R")
+    if Mr != M or Rn < 128 or not (1 <= len(outs) <= 4):
+        raise _l.St355Error(f"skinny_tn_multi: L has {M} rows, R {Mr} x {Rn} (needs 128 columns), {len(outs)} outputs (1..4)")
+    seg = _seg_join(seg, sr, "skinny_tn_multi")
+    for o in outs:
+        _chk(o, F32, "out")
+    need = L.st355_skinny_tn_workspace(M, P, 128)
+    key = (Lm.device.index,)
+    ws = _skinny_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=F32, device=Lm.device)
+        _skinny_ws[key] = ws
+    arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    _l.check(L.st355_skinny_tn_multi(_stream(), _ptr(Lm), ldl, _ptr(R), ldr, arr, len(outs), so_p, so_r, M, P, r_used, alpha, 1 if accumulate else 0,
+                                     _ptr(ws), seg, seg_l, seg_r), "skinny_tn_multi")
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------
 # AdaLN / RMSNorm + RoPE
 # ------------------------------------------------------------------------------------------------

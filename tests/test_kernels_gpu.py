@@ -341,6 +341,24 @@ def test_skinny_tn(ops, M, P, Rn, r):
     assert report("skinny_tn^T acc", outT, 1.0 + (Lm.float().t() @ R.float()[:, :r]).t())[0] < 1e-4
 
 
+def test_skinny_tn_multi_equals_separate_products(ops):
+    """st355_skinny_tn_multi: the dA products of the q / k / v adapters that share x in one pass over x — bit-equal to three st355_skinny_tn calls"""
+    torch.manual_seed(16)
+    M, P, r = 4608, 3072, 32
+    x = torch.randn(M, P, device=dev()).to(BF16)
+    U = torch.randn(M, 128, device=dev()).to(BF16)
+    outs = [torch.zeros(r, P, device=dev()) for _ in range(3)]
+    ops.skinny_tn_multi(x, U, outs, 1, P, r, alpha=0.75)
+    for g in range(3):
+        ref = torch.zeros(r, P, device=dev())
+        ops.skinny_tn(x, U[:, 32 * g:32 * g + 32], ref, 1, P, r, alpha=0.75)
+        assert torch.equal(outs[g], ref)
+        assert report(f"skinny multi block {g}", outs[g], 0.75 * (x.float().t() @ U.float()[:, 32 * g:32 * g + 32]).t())[0] < 1e-4
+    acc = [o.clone() for o in outs]
+    ops.skinny_tn_multi(x, U, acc, 1, P, r, alpha=0.75, accumulate=True)
+    assert all(torch.equal(a, 2 * o) for a, o in zip(acc, outs))
+
+
 @pytest.mark.parametrize("B,rows,lo,S,N,K", [(3, 256, 256, 768, 512, 256), (8, 512, 0, 4608, 256, 192), (2, 4096, 512, 4608, 768, 256)])
 def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, S, N, K):
     """st355_gemm_args.seg_rows: the per-sample row blocks [lo, lo + rows) of joint [B, S, *] buffers as ONE problem (3-D strided views), on the A side, the
