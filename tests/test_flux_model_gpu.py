@@ -121,14 +121,17 @@ def test_ema_and_clipping_in_the_loop():
     assert any(not torch.equal(a, b.detach()) for a, b in zip(p0, trainer.params))
 
 
-@pytest.mark.parametrize("mode,interval,stride", [("layer", None, None), ("interval2", 2, None), ("seg2-stride4", 2, 4)])
-def test_checkpointed_gradients_equal_direct_gradients(mode, interval, stride):
+# "aligned": 256 image + 256 text rows per sample — the fused QKV projection epilogue, the fused RoPE backward and the segmented per-stream problems are
+# the paths that get re-run from the checkpoints (the other cases have unaligned streams and take the separate passes)
+@pytest.mark.parametrize("mode,interval,stride,shape", [("layer", None, None, (16, 16, 32)), ("interval2", 2, None, (16, 16, 32)), ("seg2-stride4", 2, 4, (16, 16, 32)),
+                                                        ("interval2-aligned", 2, None, (32, 32, 256))])
+def test_checkpointed_gradients_equal_direct_gradients(mode, interval, stride, shape):
     """SURVEY.md §8(f)3 / reference tests/test_gradient_checkpointing_backend.py:49-105 (checkpointed == direct, atol 1e-6): the recompute runs the
     same kernels in the same order, so prediction, loss and every adapter gradient are BIT-identical to the run that keeps its activations"""
     def run(ckpt):
         import gc
         gc.collect(); torch.cuda.empty_cache()
-        plugin, trainer, cpu, devt = _build(3, 5, 2, 16, 16, 32, rank=8)
+        plugin, trainer, cpu, devt = _build(3, 5, 2, *shape, rank=8)
         plugin.config.gradient_checkpointing = ckpt
         plugin.config.gradient_checkpointing_interval, plugin.config.gradient_checkpointing_segment_stride = interval, stride
         plugin.configure_gradient_checkpointing()
