@@ -156,15 +156,17 @@ def test_checkpointed_gradients_equal_direct_gradients(mode, interval, stride, s
     assert kept1 < kept0
 
 
-def test_flux_attention_masked_training_matches_oracle():
+@pytest.mark.parametrize("lat,St", [(16, 32), (32, 256)])       # (32, 256): aligned streams -> fused projection epilogue + bias variants of the fused kernels
+def test_flux_attention_masked_training_matches_oracle(lat, St):
     """flux_attention_masked_training (flux/model.py:813-823, flux/transformer.py:170-173, 227-242): the reference hands SDPA the FLOAT mask
     (mask > 0).to(dtype) expanded with ones over the image tokens, i.e. an ADDITIVE +1 on every valid key — restated in the oracle as key_bias"""
-    plugin, trainer, cpu, devt = _build(1, 2, 2, 16, 16, 32)
+    plugin, trainer, cpu, devt = _build(1, 2, 2, lat, lat, St)
+    Si = (lat // 2) ** 2
     plugin.config.flux_attention_masked_training = True
     model = plugin.get_trained_component()
     sig = devt["sigmas"]
     plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
-    mask = torch.ones(2, 32); mask[0, 20:] = 0; mask[1, 9:] = 0
+    mask = torch.ones(2, St); mask[0, (5 * St) // 8:] = 0; mask[1, (9 * St) // 32:] = 0
     b = _batch(devt); b["encoder_attention_mask"] = mask.to("cuda:0")
     prepared = plugin.prepare_batch(b, {"global_step": 0})
     out = plugin.model_predict(prepared)
@@ -172,21 +174,21 @@ def test_flux_attention_masked_training_matches_oracle():
     loss.backward()
     P, lora, scale = PU.oracle_state(model)
     ocfg = PU.oracle_cfg(model)
-    kb = torch.ones(2, 32 + 64); kb[:, :32] = (mask > 0).float()
+    kb = torch.ones(2, St + Si); kb[:, :St] = (mask > 0).float()
     s = cpu["sigmas"].view(-1, 1, 1, 1)
     noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
     target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
     lp = {k: (a.clone().requires_grad_(True), bb.clone().requires_grad_(True)) for k, (a, bb) in lora.items()}
     packed = PU.OF.pack_latents(noisy)
-    o = PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(16, 16), torch.zeros(32, 3),
+    o = PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(lat, lat), torch.zeros(St, 3),
                            torch.full((2,), 1.0), lp, scale, key_bias=kb)
-    o_pred = PU.OF.unpack_latents(o, 16, 16)
+    o_pred = PU.OF.unpack_latents(o, lat, lat)
     o_loss = ((o_pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
     o_loss.backward()
     r = PU.rel_l2(out["model_prediction"], o_pred)
     # the mask must matter: the unmasked oracle prediction differs by far more than the parity tolerance
-    o_nomask = PU.OF.unpack_latents(PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(16, 16),
-                                                       torch.zeros(32, 3), torch.full((2,), 1.0), None, 1.0), 16, 16)
+    o_nomask = PU.OF.unpack_latents(PU.OF.flux_forward(P, ocfg, packed, cpu["prompt"], cpu["pooled"], cpu["sigmas"], PU.OF.prepare_latent_image_ids(lat, lat),
+                                                       torch.zeros(St, 3), torch.full((2,), 1.0), None, 1.0), lat, lat)
     print(f"[parity] flux masked attention: pred rel_l2={r:.3e}  loss hip={loss.item():.6f} oracle={o_loss.item():.6f}")
     assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
     for name, p in model.named_parameters():

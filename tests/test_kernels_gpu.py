@@ -398,8 +398,8 @@ def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, 
         ops.gemm(A_joint[:, 1:1 + 200], W)                              # 200-row segments: not a multiple of the 256-row tile
 
 
-@pytest.mark.parametrize("with_norm,split", [(True, 256), (True, 0), (False, 0)])
-def test_attention_backward_with_fused_rope_norm_backward(ops, with_norm, split):
+@pytest.mark.parametrize("with_norm,split,with_bias", [(True, 256, False), (True, 0, False), (False, 0, False), (True, 256, True)])
+def test_attention_backward_with_fused_rope_norm_backward(ops, with_norm, split, with_bias):
     """st355_attn_bwd_rope: dq / dk / dv straight into the projection-gradient rows, the RoPE + RMSNorm backward running in the dQ / dK kernels' epilogues,
     against the two-step chain (st355_attn_bwd -> head-major dQ, dK -> st355_qk_rope_norm_bwd).  The fused form skips the bf16 rounding of dQ / dK in between,
     so it is compared with a tolerance; dV is bit-equal."""
@@ -419,18 +419,22 @@ def test_attention_backward_with_fused_rope_norm_backward(ops, with_norm, split)
     if split == 0:
         wq_lo, wk_lo = wq_hi, wk_hi
     O = torch.empty(B * S, D, device=d_, dtype=BF16); lse2 = torch.empty(B, H, S, device=d_)
-    ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, scale)
+    kb = None
+    if with_bias:            # the attention-masked training form: an additive per-key bias (flux/transformer.py:170-173)
+        kb = torch.zeros(B, S, device=d_); kb[:, :split] = (torch.rand(B, split, device=d_) > 0.3).float()
+        kb[:, split:] = 1.0
+    ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, scale, key_bias=kb)
     dO = torch.randn(B * S, D, device=d_).to(BF16)
     # two-step chain
     dQ = torch.empty_like(Q); dK = torch.empty_like(K)
     ref = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
-    ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, ref[:, 2 * D:], B, H, S, S, hd, scale)
+    ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, ref[:, 2 * D:], B, H, S, S, hd, scale, key_bias=kb)
     if split > 0:
         ops.qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq_lo, wk_lo, cos, sin, ref, B, H, hd, split, 0, S)
     ops.qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq_hi, wk_hi, cos, sin, ref, B, H, hd, S - split, split, S)
     # fused
     out = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
-    ops.attn_bwd_rope(Q, K, V, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, split, cos_p, sin_p, out, B, H, S, S, hd, scale)
+    ops.attn_bwd_rope(Q, K, V, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, split, cos_p, sin_p, out, B, H, S, S, hd, scale, key_bias=kb)
     assert torch.equal(out[:, 2 * D:], ref[:, 2 * D:])
     assert report("fused rope-bwd dq", out[:, :D], ref[:, :D])[0] < 6e-3
     assert report("fused rope-bwd dk", out[:, D:2 * D], ref[:, D:2 * D])[0] < 6e-3
