@@ -383,6 +383,16 @@ __device__ __forceinline__ void gemm_epilogue_qkrope(const GemmP& p, f32x16 (&ac
       sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
       if (rc == 0) xw[row] = sq;
     }
+    // one (cos, sin) per rotation pair: [S, 64] tables (the full-width tables of flux/transformer.py:73-98 repeat every entry twice; read from them the
+    // epilogue pulled 4x its own output bytes through the CU's L2 port — the two heads of a tile and the two entries of a pair — and cost more than the
+    // pass it replaced).  Issued BEFORE the barrier: their L2 latency hides behind the wait for the partner wave's half sums.
+    f32x4 csv[8], snv[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int pos = min(pos_w + ps * 64 + it * 8 + rrow, p.rS - 1);
+      csv[it] = *(const f32x4*)(p.rcos + (int64_t)pos * 64 + (cch >> 1));
+      snv[it] = *(const f32x4*)(p.rsin + (int64_t)pos * 64 + (cch >> 1));
+    }
     __syncthreads();
     // pass 2: normalise, rotate, store head-major
 #pragma unroll
@@ -395,11 +405,7 @@ __device__ __forceinline__ void gemm_epilogue_qkrope(const GemmP& p, f32x16 (&ac
       const int pos = pos_w + ps * 64 + row;
       float y[8];
       if (m < p.M) {
-        // one (cos, sin) per rotation pair: [S, 64] tables (the full-width tables of flux/transformer.py:73-98 repeat every entry twice; read from them
-        // the epilogue pulled 4x its own output bytes through the CU's L2 port — the two heads of a tile and the two entries of a pair — and cost more
-        // than the pass it replaced)
-        const f32x4 cs = *(const f32x4*)(p.rcos + (int64_t)pos * 64 + (cch >> 1));
-        const f32x4 sn = *(const f32x4*)(p.rsin + (int64_t)pos * 64 + (cch >> 1));
+        const f32x4 cs = csv[it], sn = snv[it];
 #pragma unroll
         for (int b = 0; b < 4; b++) { y[b] = (lo[b] + bias8[b]) * rr * w8[b]; y[4 + b] = (hi[b] + bias8[4 + b]) * rr * w8[4 + b]; }
         bf16x8 o;
