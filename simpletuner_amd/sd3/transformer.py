@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..flux.transformer import LoraGroup, _attach, _frozen
+from ..flux.transformer import FluxTransformer2DModel as _FluxEngine, LoraGroup, _attach, _frozen
 from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD
 
 BF16 = torch.bfloat16
@@ -42,6 +42,35 @@ def sincos_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scal
         return torch.cat([out.sin(), out.cos()], dim=1)
 
     return torch.cat([one_d(embed_dim // 2, gw), one_d(embed_dim // 2, gh)], dim=1).float()
+
+
+
+def _rows3(joint, lo: int, rows: int, B: int, S: int):
+    """rows [lo, lo + rows) of every sample of a joint [B * S, C] buffer as a GEMM operand ([B, rows, C] strided view, no copy)"""
+    return _FluxEngine._rows_of(joint, lo, rows, SimpleNamespace(B=B, S=S))
+
+
+def _stream_problems(B: int, S: int, rows: int, pr: dict, after: Optional[list] = None):
+    """one projection over the `rows`-row block of every sample as ONE problem: segmented operands when the block is tile-aligned (the 4096 image rows,
+    FluxTransformer2DModel._problems); otherwise (the 154 text rows) through compact copies of the joint-buffer operands — the rows are gathered before the
+    GEMM, a joint-buffer `out` is written to a compact temporary and scattered back by the closures appended to `after` (run them once the launch is
+    issued).  A few MB of copies instead of B tiny launches per projection (measured: the per-sample form of the text stream cost as much as the image
+    stream's segmentation saved)."""
+    if B == 1 or rows % 256 == 0 or after is None:
+        return _FluxEngine._problems(SimpleNamespace(B=B, S=S), rows, pr)
+    q = dict(pr)
+    for k in ("a", "a2", "aux_in"):
+        v = q.get(k)
+        if torch.is_tensor(v) and v.dim() == 3:
+            q[k] = v.reshape(B * rows, v.shape[-1])                         # gather (copy)
+    for k in ("out", "aux_out"):
+        v = q.get(k)
+        if torch.is_tensor(v) and v.dim() == 3:
+            tmp = torch.empty(B * rows, v.shape[-1], dtype=v.dtype, device=v.device)
+            q[k] = tmp
+            after.append(lambda dst=v, src=tmp: dst.copy_(src.view(B, rows, -1)))      # scatter back into the joint rows
+    return [q]
+
 
 
 class SD3Transformer2DModel(nn.Module):
@@ -340,13 +369,14 @@ class SD3Transformer2DModel(nn.Module):
             qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
             T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
             T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
-            probs = []
-            for b in range(B):
-                kw_i = dict(a2=T_img[b * Si:(b + 1) * Si], b2=blk.qkv.lora.B_blk) if T_img is not None else {}
-                kw_t = dict(a2=T_txt[b * St:(b + 1) * St], b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
-                probs.append(dict(a=n_img[b * Si:(b + 1) * Si], w=blk.qkv.w, bias=blk.qkv.b, out=qkv[b * S:b * S + Si], **kw_i))
-                probs.append(dict(a=n_txt[b * St:(b + 1) * St], w=blk.add_qkv.w, bias=blk.add_qkv.b, out=qkv[b * S + Si:(b + 1) * S], **kw_t))
-            ops.gemm_grouped(probs)
+            kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+            kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
+            # the image stream (4096 rows per sample: tile-aligned) is ONE segmented problem over the joint buffer; the 154 text rows stay per sample
+            after = []
+            ops.gemm_grouped(_stream_problems(B, S, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=_rows3(qkv, 0, Si, B, S), **kw_i), after)
+                             + _stream_problems(B, S, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=_rows3(qkv, Si, St, B, S), **kw_t), after))
+            for f in after:
+                f()
             Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
             mk = torch.zeros if Sp > S else torch.empty
             Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
@@ -361,27 +391,31 @@ class SD3Transformer2DModel(nn.Module):
             T_ao = (torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev)
                     if (not blk.last and blk.to_add_out.lora is not None) else None)
             ya_i, ya_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
-            probs = []
-            for b in range(B):
-                O_i, O_t = O[b * S:b * S + Si], O[b * S + Si:(b + 1) * S]
-                kw_i, kw_t = {}, {}
-                if ya_i is not None:
-                    kw_i["aux_out"] = ya_i[b * Si:(b + 1) * Si]
-                if ya_t is not None:
-                    kw_t["aux_out"] = ya_t[b * St:(b + 1) * St]
-                if T_o is not None:
-                    ops.gemm(O_i, blk.to_out.lora.A_cat, out=T_o[b * Si:(b + 1) * Si])
-                    kw_i.update(a2=T_o[b * Si:(b + 1) * Si], b2=blk.to_out.lora.B_blk)
-                probs.append(dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img[b * Si:(b + 1) * Si], epilogue=EPI_GATE_RESIDUAL,
-                                  aux_in=img[b * Si:(b + 1) * Si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
-                if not blk.last:
-                    if T_ao is not None:
-                        ops.gemm(O_t, blk.to_add_out.lora.A_cat, out=T_ao[b * St:(b + 1) * St])
-                        kw_t.update(a2=T_ao[b * St:(b + 1) * St], b2=blk.to_add_out.lora.B_blk)
-                    probs.append(dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt[b * St:(b + 1) * St],
-                                      epilogue=EPI_GATE_RESIDUAL, aux_in=txt[b * St:(b + 1) * St], gate=mt[b:b + 1, 2 * D:3 * D],
-                                      rows_per_batch=St, **kw_t))
+            O_i, O_t = _rows3(O, 0, Si, B, S), _rows3(O, Si, St, B, S)
+            kw_i, kw_t = {}, {}
+            if ya_i is not None:
+                kw_i["aux_out"] = ya_i
+            if ya_t is not None:
+                kw_t["aux_out"] = ya_t
+            after = []
+            if B > 1 and St % 256:
+                O_t = O_t.reshape(B * St, D)                                  # the text rows of the attention output, gathered once for both uses below
+            if T_o is not None:
+                for pr in _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.lora.A_cat, out=T_o), after):
+                    ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+                kw_i.update(a2=T_o, b2=blk.to_out.lora.B_blk)
+            probs = _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
+                                                    gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i), after)
+            if not blk.last:
+                if T_ao is not None:
+                    for pr in _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao), after):
+                        ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+                    kw_t.update(a2=T_ao, b2=blk.to_add_out.lora.B_blk)
+                probs += _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
+                                                         aux_in=txt, gate=mt[:, 2 * D:3 * D], rows_per_batch=St, **kw_t), after)
             ops.gemm_grouped(probs)
+            for f in after:
+                f()
             n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
             hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
             hpre_txt = x2_txt = n2_t = h_t = None
@@ -454,21 +488,22 @@ class SD3Transformer2DModel(nn.Module):
             dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
             U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
             U_t = ops.gemm(dx1g_t, blk.to_add_out.lora.B_blk_T) if (not blk.last and blk.to_add_out.lora is not None) else None
-            probs = []
-            for b in range(B):
-                kw_i = dict(a2=U_i[b * Si:(b + 1) * Si], b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
-                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S:b * S + Si], **kw_i))
-                if not blk.last:
-                    kw_t = dict(a2=U_t[b * St:(b + 1) * St], b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
-                    probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S + Si:(b + 1) * S], **kw_t))
+            after = []
+            kw_i = dict(a2=U_i, b2=blk.to_out.lora.A_cat_T) if U_i is not None else {}
+            probs = _stream_problems(B, S, Si, dict(a=dx1g_i, w=blk.to_out.wT, out=_rows3(dO, 0, Si, B, S), **kw_i), after)
+            if not blk.last:
+                kw_t = dict(a2=U_t, b2=blk.to_add_out.lora.A_cat_T) if U_t is not None else {}
+                probs += _stream_problems(B, S, St, dict(a=dx1g_t, w=blk.to_add_out.wT, out=_rows3(dO, Si, St, B, S), **kw_t), after)
             ops.gemm_grouped(probs)
+            for f in after:
+                f()
             pairs = [(blk.to_out, U_i, sv.T_o, dx1g_i, 0, Si)]
             if not blk.last:
                 pairs.append((blk.to_add_out, U_t, sv.T_ao, dx1g_t, Si, St))
+            envs = SimpleNamespace(B=B, S=S)
             for (lin, U, T_, dxg, lo, rows) in pairs:
-                if lin.lora is not None:
-                    O_rows = sv.O[lo:lo + rows] if B == 1 else sv.O.view(B, S, D)[:, lo:lo + rows].reshape(B * rows, D)
-                    lin.lora.grads(O_rows, T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+                if lin.lora is not None:       # this stream's rows of the joint attention output: read in place when tile-aligned (image rows), else a compact copy
+                    lin.lora.grads(_FluxEngine._compact(_rows3(sv.O, lo, rows, B, S), envs, rows), T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
             del dx1g_i, dx1g_t, U_i, U_t
             dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
             dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
@@ -477,23 +512,24 @@ class SD3Transformer2DModel(nn.Module):
             ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, Si, S)
             del dQ, dK, dO
             first = li == 0
-            if B == 1:
-                dq_i, dq_t = dqkv[:Si], dqkv[Si:]
-            else:
-                dq_i = dqkv.view(B, S, 3 * D)[:, :Si].reshape(B * Si, 3 * D); dq_t = dqkv.view(B, S, 3 * D)[:, Si:].reshape(B * St, 3 * D)
-            streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt)]
+            # the two streams' rows of the joint dqkv: the image rows in place (segmented operands), the 154 text rows as a compact copy
+            dq_i = _FluxEngine._compact(_rows3(dqkv, 0, Si, B, S), envs, Si); dq_t = _FluxEngine._compact(_rows3(dqkv, Si, St, B, S), envs, St)
+            streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img, Si), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt, St)]
             if first:
                 streams = [s_ for s_ in streams if s_[1].lora is not None]     # frozen embedders: only adapter grads remain
-            probs, Us = [], {}
-            for (name, lin, dq, n_in, T_) in streams:
+            probs, Us, dns = [], {}, []
+            for (name, lin, dq, n_in, T_, rows) in streams:
                 kw = {}
                 if lin.lora is not None:
-                    Us[name] = ops.gemm(dq, lin.lora.B_blk_T)
+                    Us[name] = torch.empty(B * rows, lin.lora.B_blk_T.shape[0], dtype=BF16, device=dev)
+                    ops.gemm(dq, lin.lora.B_blk_T, out=Us[name])
                     kw = dict(a2=Us[name], b2=lin.lora.A_cat_T)
                 if not first:
-                    probs.append(dict(a=dq, w=lin.wT, **kw))
-            dns = ops.gemm_grouped(probs) if probs else []
-            for (name, lin, dq, n_in, T_) in streams:
+                    dns.append(torch.empty(B * rows, D, dtype=BF16, device=dev))
+                    probs.append(dict(a=dq, w=lin.wT, out=dns[-1], **kw))
+            if probs:
+                ops.gemm_grouped(probs)
+            for (name, lin, dq, n_in, T_, rows) in streams:
                 if lin.lora is not None:
                     lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
             if not first:
@@ -635,12 +671,13 @@ class SD3Transformer2DModel(nn.Module):
             O_i = rows_of(sv.O, 0, Si)
             wgrad(blk.to_out, dx1g_i, O_i)
             dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
-            probs = []
-            for b in range(B):
-                probs.append(dict(a=dx1g_i[b * Si:(b + 1) * Si], w=blk.to_out.wT, out=dO[b * S:b * S + Si]))
-                if not blk.last:
-                    probs.append(dict(a=dx1g_t[b * St:(b + 1) * St], w=blk.to_add_out.wT, out=dO[b * S + Si:(b + 1) * S]))
+            after = []
+            probs = _stream_problems(B, S, Si, dict(a=dx1g_i, w=blk.to_out.wT, out=_rows3(dO, 0, Si, B, S)), after)
+            if not blk.last:
+                probs += _stream_problems(B, S, St, dict(a=dx1g_t, w=blk.to_add_out.wT, out=_rows3(dO, Si, St, B, S)), after)
             ops.gemm_grouped(probs)
+            for f in after:
+                f()
             if not blk.last:
                 wgrad(blk.to_add_out, dx1g_t, rows_of(sv.O, Si, St))
             del dx1g_i, dx1g_t, O_i
