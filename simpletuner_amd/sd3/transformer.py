@@ -56,7 +56,7 @@ def _stream_problems(B: int, S: int, rows: int, pr: dict, after: Optional[list] 
     GEMM, a joint-buffer `out` is written to a compact temporary and scattered back by the closures appended to `after` (run them once the launch is
     issued).  A few MB of copies instead of B tiny launches per projection (measured: the per-sample form of the text stream cost as much as the image
     stream's segmentation saved)."""
-    if B == 1 or rows % 256 == 0 or after is None:
+    if B == 1 or rows % 256 == 0 or after is None or rows >= 1024:       # big unaligned blocks (odd aspect buckets): one problem per sample beats copying them
         return _FluxEngine._problems(SimpleNamespace(B=B, S=S), rows, pr)
     q = dict(pr)
     for k in ("a", "a2", "aux_in"):
