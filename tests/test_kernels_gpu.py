@@ -398,6 +398,29 @@ def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, 
         ops.gemm(A_joint[:, 1:1 + 200], W)                              # 200-row segments: not a multiple of the 256-row tile
 
 
+@pytest.mark.parametrize("S,with_bias", [(512, False), (300, False), (448, True)])
+def test_attention_forward_row_major_v_is_bit_equal(ops, S, with_bias):
+    """st355_attn_fwd_vrows: V read row-major (token rows of a [B*S, ld] projection buffer) through transposing LDS reads — the same fragments as the
+    head-major V^T form, so O and the LSE are bit-identical; ragged last tile and the key-bias variant included"""
+    torch.manual_seed(92)
+    d_ = dev()
+    B, H, hd = 2, 3, 128
+    D = H * hd
+    Sp = (S + 63) // 64 * 64
+    scale = 1.0 / math.sqrt(hd)
+    Q = torch.randn(B, H, S, hd, device=d_).to(BF16); K = torch.randn(B, H, S, hd, device=d_).to(BF16)
+    qkv = torch.randn(B * S, 3 * D, device=d_).to(BF16)                    # V = the last third of a projection buffer: ld = 3 D
+    V = qkv[:, 2 * D:]
+    Vt = torch.zeros(B, H, hd, Sp, device=d_, dtype=BF16)
+    Vt[..., :S] = V.reshape(B, S, H, hd).permute(0, 2, 3, 1)
+    kb = (torch.rand(B, S, device=d_) > 0.25).float() if with_bias else None
+    O1 = torch.empty(B * S, D, device=d_, dtype=BF16); l1 = torch.empty(B, H, S, device=d_)
+    O2 = torch.empty_like(O1); l2 = torch.empty_like(l1)
+    ops.attn_fwd(Q, K, Vt, O1, l1, B, H, S, Sp, hd, scale, key_bias=kb)
+    ops.attn_fwd_vrows(Q, K, V, O2, l2, B, H, S, hd, scale, key_bias=kb)
+    assert torch.equal(O1, O2) and torch.equal(l1, l2)
+
+
 @pytest.mark.parametrize("with_norm,split,with_bias", [(True, 256, False), (True, 0, False), (False, 0, False), (True, 256, True)])
 def test_attention_backward_with_fused_rope_norm_backward(ops, with_norm, split, with_bias):
     """st355_attn_bwd_rope: dq / dk / dv straight into the projection-gradient rows, the RoPE + RMSNorm backward running in the dQ / dK kernels' epilogues,
