@@ -67,3 +67,40 @@ def test_rows_of_and_problem_expansion():
     assert M._compact(img, env, Si) is img                                     # aligned: walked in place
     assert M._compact(out2, env2, 300).shape == (B * 300, C)                    # unaligned: compact copy
     assert M._compact(M._rows_of(j1, St, Si, env1), env1, Si).dim() == 2
+
+
+def test_sd3_stream_problems_policy():
+    """SD3's joint blocks: aligned image rows -> one segmented problem; the short unaligned text rows -> ONE compact problem with gather copies of the
+    joint-buffer inputs and a scatter-back closure for a joint-buffer output; big unaligned blocks (odd aspect buckets) -> one problem per sample."""
+    from simpletuner_amd.sd3.transformer import _rows3, _stream_problems
+
+    B, Si, St, C = 3, 512, 154, 8
+    S = Si + St
+    joint = torch.arange(B * S * C, dtype=torch.float32).view(B * S, C)
+    w = torch.zeros(C, C)
+    # aligned: untouched, nothing to do afterwards
+    after = []
+    pr = dict(a=torch.zeros(B * Si, C), w=w, out=_rows3(joint, 0, Si, B, S))
+    assert _stream_problems(B, S, Si, pr, after) == [pr] and after == []
+    # text rows: compact gather of the joint input, temporary + scatter for the joint output
+    out_joint = torch.zeros(B * S, C)
+    a_view = _rows3(joint, Si, St, B, S)
+    (q,) = _stream_problems(B, S, St, dict(a=a_view, w=w, out=_rows3(out_joint, Si, St, B, S), gate=torch.zeros(B, C), rows_per_batch=St), after)
+    assert q["a"].shape == (B * St, C) and torch.equal(q["a"].view(B, St, C), a_view) and q["a"].data_ptr() != joint.data_ptr()
+    assert q["out"].shape == (B * St, C) and len(after) == 1 and q["gate"].shape == (B, C)
+    q["out"].copy_(torch.arange(B * St * C, dtype=torch.float32).view(B * St, C) + 1000.0)      # "the GEMM wrote its result"
+    after[0]()
+    assert torch.equal(out_joint.view(B, S, C)[:, Si:], q["out"].view(B, St, C)) and out_joint.view(B, S, C)[:, :Si].abs().max() == 0
+    # compact operands of an unaligned stream need no copies at all
+    after2 = []
+    (q2,) = _stream_problems(B, S, St, dict(a=torch.zeros(B * St, C), w=w, out=torch.zeros(B * St, C)), after2)
+    assert after2 == [] and q2["a"].dim() == 2
+    # a big unaligned block stays per sample (no after-closures, views per sample)
+    Sb = 1100 + St
+    jb = torch.zeros(B * Sb, C)
+    after3 = []
+    ps = _stream_problems(B, Sb, 1100, dict(a=torch.zeros(B * 1100, C), w=w, out=_rows3(jb, 0, 1100, B, Sb)), after3)
+    assert len(ps) == B and after3 == [] and ps[1]["out"].data_ptr() == jb[Sb].data_ptr()
+    # batch 1: plain 2-D slices
+    (p1,) = _stream_problems(1, S, St, dict(a=_rows3(joint[:S], Si, St, 1, S), w=w), [])
+    assert p1["a"].dim() == 2 and p1["a"].data_ptr() == joint[Si].data_ptr()
