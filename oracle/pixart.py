@@ -11,7 +11,10 @@ Control flow follows the reference's in-tree files:
 Leaf modules are diffusers' (un-vendored): PatchEmbed (conv p=2 + 2-D sincos table with interpolation_scale / base_size),
 AdaLayerNormSingle (PixArtAlphaCombinedTimestepSizeEmbeddings + SiLU + Linear D->6D), PixArtAlphaTextProjection (Linear, GELU-tanh, Linear),
 Attention (bias on q/k/v/out), FeedForward("gelu-approximate").
-PARITY UNPINNED: the reference holds no golden tensor for this network.
+PINNED (round 3): this file reproduces, to <= 1e-5 in fp32 (outputs and every gradient), the outputs of the reference's OWN model files executed in the
+build container over leaf-module shims (tools/ref_shim.py, tools/gen_ref_models.py -> tests/golden/ref_pixart_model.pt; tests/test_ref_models_cpu.py).
+The control flow above the leaves is therefore pinned to executed reference code; the leaves (Linear / LayerNorm / SiLU compositions of diffusers, which is
+absent from /root/reference) remain restatements, partly cross-checked against in-tree vendored copies.
 """
 from __future__ import annotations
 

@@ -379,20 +379,8 @@ class FluxTransformer2DModel(nn.Module):
              on, interval None / <= 1  ("layer")         -> every block is its own checkpoint (only its input is kept, the block is re-run in backward);
              on, interval k > 1 [, segment_stride s >= k] -> the first k blocks of every s-block window form ONE checkpoint (only the segment input is
                                                             kept), the s - k blocks of the gap keep their activations  (`checkpoint_sequential_state`)."""
-        if not self.gradient_checkpointing:
-            return [(i, 1, False) for i in range(n_blocks)]
-        k = self.gradient_checkpointing_interval
-        if k is None or k <= 1:
-            return [(i, 1, True) for i in range(n_blocks)]
-        stride = self.gradient_checkpointing_segment_stride or k
-        if stride < k:
-            raise ValueError("segment_stride must be at least segment_size")
-        segs = []
-        for s0 in range(0, n_blocks, stride):
-            n = min(k, n_blocks - s0)
-            segs.append((s0, n, True))
-            segs += [(j, 1, False) for j in range(s0 + n, min(s0 + stride, n_blocks))]
-        return segs
+        from ..training.checkpoint_plan import segments
+        return segments(n_blocks, self.gradient_checkpointing, self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride)
 
     # ------------------------------------------------------------------------------------------------
     # forward / backward engines
