@@ -1170,6 +1170,9 @@ static int validate(const st355_gemm_args* a) {
                (long long)a->seg_rows, a->M);
     ST_REQUIRE(a->seg_a >= 0 && a->seg_a2 >= 0 && a->seg_c >= 0 && a->seg_in >= 0 && a->seg_out >= 0, "gemm: negative segment stride");
     ST_REQUIRE((a->seg_a == 0 || a->seg_a >= a->seg_rows) && (a->seg_c == 0 || a->seg_c >= a->seg_rows), "gemm: segment stride smaller than seg_rows");
+    ST_REQUIRE(a->K2 <= 0 || a->seg_a2 == 0 || a->seg_a2 >= a->seg_rows, "gemm: A2 segment stride smaller than seg_rows");
+    ST_REQUIRE(!a->aux_in || a->seg_in == 0 || a->seg_in >= a->seg_rows, "gemm: aux_in segment stride smaller than seg_rows");
+    ST_REQUIRE(!a->aux_out || a->seg_out == 0 || a->seg_out >= a->seg_rows, "gemm: aux_out segment stride smaller than seg_rows");
   }
   ST_REQUIRE(256 * (a->lda > a->ldb ? a->lda : a->ldb) * 2 + (int64_t)a->K * 2 < ((int64_t)1 << 31), "gemm: a 256-row tile must fit 32-bit buffer offsets");
   return ST355_OK;

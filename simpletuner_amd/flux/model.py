@@ -47,6 +47,29 @@ class Flux(ModelFoundation):
     VAE_CONFIG = dict(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False)
     DEFAULT_MODEL_FLAVOUR = "dev"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]
+
+    def convert_text_embed_for_pipeline(self, text_embedding: dict) -> dict:
+        """flux/model.py:453-472: prompt / pooled embeddings (+ the text mask as `prompt_mask` only under flux_attention_masked_training)"""
+        out = self._convert_text_embed(text_embedding, negative=False)
+        m = text_embedding.get("attention_masks", None)
+        if m is not None and m.dim() == 1:
+            m = m.unsqueeze(0)
+        out["prompt_mask"] = m if getattr(self.config, "flux_attention_masked_training", False) else None
+        return out
+
+    def convert_negative_text_embed_for_pipeline(self, text_embedding: dict) -> dict:
+        """flux/model.py:474-497: no negative branch unless real CFG is on (validation_guidance_real > 1)"""
+        g = getattr(self.config, "validation_guidance_real", None)
+        if g is None or g <= 1.0:
+            return {}
+        out = self._convert_text_embed(text_embedding, negative=True)
+        m = text_embedding.get("attention_masks", None)
+        if m is not None and m.dim() == 1:
+            m = m.unsqueeze(0)
+        out["negative_mask"] = m if getattr(self.config, "flux_attention_masked_training", False) else None
+        out["guidance_scale_real"] = float(g)
+        out["no_cfg_until_timestep"] = int(getattr(self.config, "validation_no_cfg_until_timestep", 0) or 0)
+        return out
     HUGGINGFACE_PATHS = {"dev": "black-forest-labs/flux.1-dev", "schnell": "black-forest-labs/flux.1-schnell"}
 
     def __init__(self, config, accelerator):

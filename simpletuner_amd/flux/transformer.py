@@ -430,7 +430,9 @@ class FluxTransformer2DModel(nn.Module):
         per call on the tiny [128] weight vectors of a frozen-base run (cached: they do not train under LoRA).  ST355_FUSED_QKV=0 keeps the separate pass."""
         if not _FUSED_QKV or self.hd != 128 or self.H % 2 or _TRANSPOSED_COPIES or any(r % 256 for r in rows_list):
             return False
-        key = tuple(id(w) for w in norms)
+        # keyed on identity AND the tensors' in-place version counters / requires_grad: weights loaded in place later (load_state_dict, copy_), a later
+        # requires_grad_(True) or an id reused after a free can never hit a stale verdict; no device read on the hit path
+        key = tuple((id(w), w._version, w.requires_grad, w.data_ptr()) if w is not None else None for w in norms)
         ok = self._norm_w_ok.get(key)
         if ok is None:
             ok = all(w is None or (not w.requires_grad and float(w.detach().abs().min()) > 1e-3) for w in norms)

@@ -365,6 +365,37 @@ class ModelFoundation(ExplorativeModelingMixin):
         """common.py:2949.  Text encoders are not part of the per-step path (embeddings come from the cache, caching/text_embeds.py): nothing is loaded"""
         self.text_encoders, self.tokenizers = [], []
 
+    # ---- text-embed cache record -> validation-pipeline kwargs (the three members besides model_predict that the reference's ABC declares
+    # abstract, common.py:1744-1766; a class registered into ModelRegistry must define them to be instantiable) -------------------------------------
+    # (cache-record key, pipeline kwarg, rank WITH the batch dimension); per family as written in <family>/model.py `convert_text_embed_for_pipeline`
+    TEXT_EMBED_FIELDS = (("prompt_embeds", "prompt_embeds", 3), ("pooled_prompt_embeds", "pooled_prompt_embeds", 2))
+
+    def _convert_text_embed(self, text_embedding: dict, negative: bool) -> dict:
+        out = {}
+        for src, dst, rank in self.TEXT_EMBED_FIELDS:
+            t = text_embedding[src]
+            if t.dim() == rank - 1:                  # "Add batch dimension if missing" (e.g. sd3/model.py:392-396)
+                t = t.unsqueeze(0)
+            out[("negative_" + dst) if negative else dst] = t
+        return out
+
+    def convert_text_embed_for_pipeline(self, text_embedding: dict) -> dict:
+        """e.g. sd3/model.py:387-401, sdxl/model.py:135-149, sd1x/model.py:112-122, pixart/model.py:194-208 (Flux overrides: prompt_mask)"""
+        return self._convert_text_embed(text_embedding, negative=False)
+
+    def convert_negative_text_embed_for_pipeline(self, text_embedding: dict) -> dict:
+        """e.g. sd3/model.py:403-417: the same record under the `negative_*` kwarg names (the CFG half of the validation pair)"""
+        return self._convert_text_embed(text_embedding, negative=True)
+
+    def _encode_prompts(self, prompts: list, is_negative_prompt: bool = False):
+        """common.py:1744-1750.  Running the CLIP / T5 text encoders is outside the per-step path (text-embed caching is offline
+        preprocessing): the st355 plugins consume cached embeddings.  Under `integration.register()` with an importable SimpleTuner the registered
+        class also derives from the reference's own family class, whose `_encode_prompts` is then the one that runs."""
+        for base in type(self).__mro__:
+            if base.__module__.startswith("simpletuner.") and "_encode_prompts" in base.__dict__ and not getattr(base.__dict__["_encode_prompts"], "__isabstractmethod__", False):
+                return base.__dict__["_encode_prompts"](self, prompts, is_negative_prompt)
+        raise NotImplementedError("text encoders are not part of the st355 per-step path: feed cached text embeddings (collate_fn / DirectCacheFeeder)")
+
     def get_text_encoder(self, index: int):
         """common.py:3130"""
         if self.text_encoders is not None:

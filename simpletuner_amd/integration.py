@@ -45,15 +45,35 @@ def _ref(module: str):
                                      f"replays the same step order where it is not installed") from e
 
 
-def plugin_class(family: str, ref_foundation: Optional[type] = None) -> type:
-    """the st355 plugin of `family`; with `ref_foundation` a subclass that also derives from the reference's ModelFoundation"""
+def plugin_class(family: str, ref_foundation: Optional[type] = None, ref_family: Optional[type] = None) -> type:
+    """the st355 plugin of `family`; with `ref_foundation` a subclass that also derives from the reference's ModelFoundation — through the
+    reference's OWN family class (`ref_family`, e.g. simpletuner.helpers.models.flux.model.Flux) when that is importable, so that everything off the
+    step path (text encoders / `_encode_prompts`, pipelines, checkpoint loading) keeps resolving to the reference's implementation"""
     mod, name = FAMILIES[family]
     cls = getattr(importlib.import_module(mod), name)
     if ref_foundation is None or issubclass(cls, ref_foundation):
         return cls
-    # st355 first in the MRO: every step-path method resolves to the MI355X implementation, the reference base only contributes identity
-    # (isinstance) and whatever out-of-path helper the st355 class does not define
-    return type(f"St355{name}", (cls, ref_foundation), {"__module__": __name__, "__doc__": cls.__doc__, "ST355_NATIVE": True})
+    base = ref_family if (isinstance(ref_family, type) and issubclass(ref_family, ref_foundation)) else ref_foundation
+    # st355 first in the MRO: every step-path method resolves to the MI355X implementation; the reference class behind it contributes identity
+    # (isinstance) and whatever out-of-path member the st355 class does not define
+    new = type(f"St355{name}", (cls, base), {"__module__": __name__, "__doc__": cls.__doc__, "ST355_NATIVE": True})
+    left = sorted(getattr(new, "__abstractmethods__", ()))
+    if left:           # an ABC base with members neither side implements: the class could be registered but never constructed — fail at register() time
+        raise TypeError(f"St355{name} would be abstract: {left} are declared abstract by {base.__name__} and implemented by neither class")
+    return new
+
+
+def _reference_family_class(reg, family: str) -> Optional[type]:
+    """the reference's own class of `family`, if its module imports here (registry.py:77-90: explicit registration, else the lazy metadata entry)"""
+    try:
+        got = reg.get(family)
+        if got is None:
+            return None
+        if hasattr(got, "get_real_class"):
+            got = got.get_real_class()
+        return got if isinstance(got, type) and not getattr(got, "ST355_NATIVE", False) else None
+    except Exception:
+        return None
 
 
 def register(families=None, overwrite_optimizers: bool = True) -> Dict[str, type]:
@@ -62,7 +82,7 @@ def register(families=None, overwrite_optimizers: bool = True) -> Dict[str, type
     ref_foundation = getattr(_ref("simpletuner.helpers.models.common"), "ModelFoundation")
     out = {}
     for fam in (families or FAMILIES):
-        cls = plugin_class(fam, ref_foundation)
+        cls = plugin_class(fam, ref_foundation, _reference_family_class(reg, fam))
         reg.register(fam, cls)
         out[fam] = cls
     register_optimizers(overwrite=overwrite_optimizers)

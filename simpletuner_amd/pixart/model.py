@@ -22,6 +22,7 @@ class PixartSigma(ModelFoundation):
     MODEL_CLASS = PixArtTransformer2DModel
     MODEL_SUBFOLDER = "transformer"
     LATENT_CHANNEL_COUNT = 4
+    TEXT_EMBED_FIELDS = (("prompt_embeds", "prompt_embeds", 3), ("attention_mask", "prompt_attention_mask", 2))      # pixart/model.py:194-224
     COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES = {"transformer"}      # pixart/model.py:51
     VAE_CONFIG = dict(latent_channels=4, scaling_factor=0.13025)
     DEFAULT_MODEL_FLAVOUR = "900M-1024-v0.6"

@@ -29,6 +29,7 @@ class StableDiffusion1(ModelFoundation):
     MODEL_CLASS = UNet2DConditionModel
     MODEL_SUBFOLDER = "unet"
     LATENT_CHANNEL_COUNT = 4
+    TEXT_EMBED_FIELDS = (("prompt_embeds", "prompt_embeds", 3),)                     # sd1x/model.py:112-134
     VAE_CONFIG = dict(latent_channels=4, scaling_factor=0.18215)
     DEFAULT_MODEL_FLAVOUR = "1.5"
     DEFAULT_LORA_TARGET = ["to_k", "to_q", "to_v", "to_out.0"]

@@ -4,8 +4,8 @@ Two pieces:
 
   * `split_buckets_between_processes` — the arithmetic of the reference's `MetadataBackend.split_buckets_between_processes`
     (helpers/metadata/backends/base.py:741-937): every bucket's sample list is canonically ordered, shuffled with the RUN seed (identical on every
-    rank: `random.Random(f"{seed}:{id}:{bucket}")`), trimmed to whole effective batches (batch x ranks x grad-accum), and cut into contiguous
-    per-rank slices (remainder to the low ranks; optional padding to equal length); buckets that cannot fill one effective batch raise the reference's
+    rank: `random.Random(f"{seed}:{id}:{bucket}")`), passed through the reference's trim (which never removes a sample: its bound
+    ceil(total / effective) * effective is >= len(images) always — restated as written) and cut into contiguous per-rank slices (remainder to the low ranks; optional padding to equal length); buckets that cannot fill one effective batch raise the reference's
     ValueError, or — with oversubscription — are cycled up to a whole number of effective batches.  Pinned to the reference method executed here
     (tools/gen_bucket_golden.py -> tests/golden/bucket_split_vectors.pt).
 
@@ -74,14 +74,19 @@ def split_buckets_between_processes(buckets: Dict[str, Sequence], batch_size: in
 
 class TokenBalancedSchedule:
     """one shared bucket order for all ranks (see module docstring).  `local_buckets` = this rank's split; `micro_batches_per_bucket` must be the SAME
-    on every rank (it is when the split was padded / trimmed to whole effective batches: pass `counts` computed from rank 0's view, or let every
-    rank compute min over ranks once at start-up).  Iteration yields (bucket, [samples of this rank's micro-batch])."""
+    on every rank: with `counts=None` it is taken as the min over ranks of len(local bucket) // batch_size (`shared_counts`: one all-reduce when a
+    multi-rank process group is initialised, the local value otherwise).  Iteration yields (bucket, [samples of this rank's micro-batch])."""
 
     def __init__(self, local_buckets: Dict[str, Sequence], batch_size: int, seed: int = 0, epoch: int = 0, counts: Optional[Dict[str, int]] = None,
                  tokens_of: Optional[Dict[str, int]] = None):
         self.local = {b: list(v) for b, v in local_buckets.items()}
         self.batch_size = int(batch_size)
-        self.counts = dict(counts) if counts is not None else {b: len(v) // self.batch_size for b, v in self.local.items()}
+        if counts is None:
+            # under an initialised multi-rank process group the per-rank slices differ by one sample whenever len % world != 0 (the reference's trim is a
+            # no-op: trim >= len(images) always, helpers/metadata/backends/base.py:760-763), so counts derived from THIS rank's slice would make the ranks
+            # walk different bucket sequences: take the min over ranks (one tiny all-reduce at start-up) instead of silently diverging
+            counts = shared_counts(self.local, self.batch_size)
+        self.counts = dict(counts)
         for b, n in self.counts.items():
             if n * self.batch_size > len(self.local.get(b, ())):
                 raise ValueError(f"bucket {b}: schedule asks for {n} micro-batches of {batch_size}, this rank holds {len(self.local.get(b, ()))} samples")

@@ -59,7 +59,8 @@ class DirectCacheFeeder:
         self._todo: "queue.Queue" = queue.Queue()
         self._ready: "queue.Queue" = queue.Queue(maxsize=max(1, int(depth)))
         self._err: Optional[BaseException] = None
-        self._custom_read = None if reader.read_bytes.__name__ == "_read_local" else reader.read_bytes
+        from . import cache_io as _cio
+        self._custom_read = None if reader.read_bytes is _cio._read_local else reader.read_bytes     # identity, not __name__: partials / callable objects are custom readers
         self._t = threading.Thread(target=self._run, name="st355-cache-feed", daemon=True)
         self._t.start()
 
@@ -78,7 +79,7 @@ class DirectCacheFeeder:
             slot["pinned"][key] = buf
         return buf
 
-    def _sample(self, slot, i, B, ex, shapes, lock):
+    def _sample(self, slot, i, B, ex, shapes, lock, counts):
         path = self.reader.latent_path(ex["image_path"])
         lat, _meta = latent_from_payload(load_cache_file(path, self._custom_read))
         if lat.dim() == 5:
@@ -95,6 +96,9 @@ class DirectCacheFeeder:
                 if t.dim() == 3 and t.shape[0] != 1:
                     raise ValueError(f"text-embed cache entry {src} holds {t.shape[0]} rows; one example per record expected")
                 fields[dst] = t[0] if t.dim() == 3 else t          # collate_tensors (collate.py:409-451): [1,S,D] records are concatenated, [S,D] / [D] stacked
+        with lock:
+            for key in fields:
+                counts[key] = counts.get(key, 0) + 1
         for key, t in fields.items():
             with lock:
                 want = shapes.setdefault(key, tuple(t.shape))
@@ -118,9 +122,12 @@ class DirectCacheFeeder:
                 self._next_slot = (self._next_slot + 1) % len(self.slots)
                 if slot["done"] is not None:
                     slot["done"].synchronize()                               # the slab's previous DMA has left the host
-                B, shapes, lock = len(examples), {}, threading.Lock()
-                self._sample(slot, 0, B, examples[0], shapes, lock)           # the first sample fixes the shapes (slab allocation)
-                list(self.pool.map(lambda ie: self._sample(slot, ie[0], B, ie[1], shapes, lock), list(enumerate(examples))[1:]))
+                B, shapes, lock, counts = len(examples), {}, threading.Lock(), {}
+                self._sample(slot, 0, B, examples[0], shapes, lock, counts)   # the first sample fixes the shapes (slab allocation)
+                list(self.pool.map(lambda ie: self._sample(slot, ie[0], B, ie[1], shapes, lock, counts), list(enumerate(examples))[1:]))
+                short = {k: c for k, c in counts.items() if c != B}
+                if short:       # the slabs are reused: a row no sample wrote would carry the PREVIOUS batch's data into this one
+                    raise ValueError(f"batch fields not present in every sample (rows written of {B}): {short}")
                 ars = {ex.get("aspect_ratio") for ex in examples if ex.get("aspect_ratio") is not None}
                 if len(ars) > 1:
                     raise ValueError(f"Aspect ratio mismatch inside one batch: {sorted(ars)}")

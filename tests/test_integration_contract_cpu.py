@@ -101,12 +101,25 @@ def _stand_in_simpletuner(monkeypatch):
     exec(compile((REF / "models" / "registry.py").read_text(), reg.__file__, "exec"), reg.__dict__)
     common = types.ModuleType("simpletuner.helpers.models.common")
 
-    class ModelFoundation:                       # the reference base: identity for isinstance checks (common.py:451)
-        REFERENCE_BASE = True
+    import abc
+    import ast as _ast
+    tree = _ast.parse((REF / "models" / "common.py").read_text())
+    ref_cls = next(n for n in tree.body if isinstance(n, _ast.ClassDef) and n.name == "ModelFoundation")
+    abstract = [f.name for f in ref_cls.body if isinstance(f, _ast.FunctionDef)
+                and any((isinstance(d, _ast.Name) and d.id == "abstractmethod") or (isinstance(d, _ast.Attribute) and d.attr == "abstractmethod") for d in f.decorator_list)]
+    assert {"model_predict", "_encode_prompts", "convert_text_embed_for_pipeline", "convert_negative_text_embed_for_pipeline"} <= set(abstract), abstract
 
-        def reference_only_helper(self):
-            return "from the reference base"
+    def _abstract(name):
+        def f(self, *a, **k):
+            raise NotImplementedError(name)
+        f.__name__ = name
+        return abc.abstractmethod(f)
+
+    ns = {n: _abstract(n) for n in abstract}         # the reference base IS an ABC (common.py:443): every abstract member it declares, by name
+    ns.update(REFERENCE_BASE=True, reference_only_helper=lambda self: "from the reference base")
+    ModelFoundation = abc.ABCMeta("ModelFoundation", (abc.ABC,), ns)
     common.ModelFoundation = ModelFoundation
+    common.ABSTRACT = abstract
     optp = types.ModuleType("simpletuner.helpers.training.optimizer_param")
     optp.optimizer_choices = {"torch-adamw": {"precision": "any", "default_settings": {"betas": (0.9, 0.999), "weight_decay": 1e-2, "eps": 1e-8},
                                               "class": torch.optim.AdamW},
@@ -132,6 +145,17 @@ def test_register_into_the_reference_registry_and_optimizer_choices(monkeypatch)
     from simpletuner_amd.training.trainer import default_config
     plug = fams["flux"](default_config(model_family="flux"), acc)                  # trainer.py:329: ModelRegistry.model_families()[family](config, accelerator)
     assert isinstance(plug, common.ModelFoundation) and plug.reference_only_helper() == "from the reference base"
+    for fam in integration.FAMILIES:                                                # the reference base is an ABC: every registered class must be CONSTRUCTIBLE
+        assert not getattr(fams[fam], "__abstractmethods__", None), (fam, fams[fam].__abstractmethods__)
+        inst = fams[fam](default_config(model_family=fam), acc)
+        rec = {"prompt_embeds": torch.zeros(5, 8), "pooled_prompt_embeds": torch.zeros(6), "attention_mask": torch.ones(5), "attention_masks": torch.ones(5)}
+        pos, neg = inst.convert_text_embed_for_pipeline(rec), inst.convert_negative_text_embed_for_pipeline(rec)
+        assert pos["prompt_embeds"].shape == (1, 5, 8)
+        assert fam == "flux" or neg["negative_prompt_embeds"].shape == (1, 5, 8)           # Flux: {} unless real CFG is configured (flux/model.py:476-478)
+        with pytest.raises(NotImplementedError, match="text encoders are not part of the st355 per-step path"):
+            inst._encode_prompts(["a prompt"])
+    assert fams["pixart_sigma"](default_config(model_family="pixart_sigma"), acc).convert_text_embed_for_pipeline(
+        {"prompt_embeds": torch.zeros(5, 8), "attention_mask": torch.ones(5)})["prompt_attention_mask"].shape == (1, 5)
     assert type(plug).prepare_batch.__module__ == "simpletuner_amd.foundation"      # the step path is the MI355X one
     ch = optp.optimizer_choices
     assert ch["st355-adamw"]["class"] is St355AdamW and ch["adamw_bf16"]["class"] is St355AdamWBF16
