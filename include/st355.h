@@ -151,6 +151,10 @@ int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two
  * streams (img / txt) of an MMDiT block, or the per-batch slices of a joint buffer. */
 int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count);
+/* Schedule choice for the 256x256-tile problems (tuning / A-B hook; results are bit-identical either way): 1 = persistent workgroups that walk the
+ * tile list and keep the LDS ring running across tile seams (k_gemm_pz: full tiles, > one round of tiles, plain NT bf16 with the five elementwise
+ * epilogues), 0 = one tile per workgroup everywhere (k_gemm_pq), -1 = the default (environment ST355_GEMM_PERSIST, on).  Returns the previous setting. */
+int st355_gemm_set_persistent(int mode);
 
 /* ---- K19: fp8-native Linear (helpers/training/quantisation/fp8_native.py:25-119) ------------------------------------------------------
  * weights: OCP e4m3fn bytes [N,K] + one fp32 scale per output row (quantize_weight_to_fp8: scale = max(amax_row,1e-12)/448);

@@ -1015,6 +1015,354 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 }
 
 // =================================================================================================
+// k_gemm_pz: the PERSISTENT form of k_gemm_pq (round 3).  One workgroup per CU walks tiles  q, q + G, q + 2G, ...  (q = XCD-remapped block id,
+// G = grid size <= number of CUs), and the LDS ring simply keeps running across the tile seam: in the last two K-tiles of a tile the region
+// refills address the NEXT tile's first K-tiles (same ring slots, same counted waits), so the next tile's prologue — a cold HBM round trip per
+// tile in the one-tile-per-workgroup kernel — is hidden behind the current tile's tail and epilogue, and the epilogue's stores drain under the
+// next tile's first K-tiles instead of under an idle CU (the workgroup does not end).  Measured in the round-2 profile: the K = 3072 shapes of
+// the Flux step (48 K-tiles per tile) ran at ~1000-1060 TFLOP/s against ~1400 for K = 12288 — about 12 K-tile times of prologue + epilogue per tile.
+//   * NT bf16 only, full tiles only (M % 256 == 0, N % 256 == 0), K-tiles >= 4, one problem per launch; LoRA K-extension and segmented rows supported;
+//     everything else stays on k_gemm_pq (the dispatcher checks).
+//   * LDS = 160 KiB: the 128-KiB ring + 32 KiB.  The epilogue transposes through 8 KiB per wave (32 tokens x 64 fp32 features, XOR-swizzled instead
+//     of padded), placed where the ring is idle at the seam: the XB and WB regions of the buffer of the LAST K-tile (their next refills come after
+//     the epilogue) + the spare 32 KiB.  The XA / WA regions of that buffer and the whole other buffer are already receiving the next tile.
+//   * vmcnt with stores in the queue: a counted  s_waitcnt vmcnt(N)  stays CORRECT when older stores are outstanding (N counts the loads younger than
+//     the one to retire; loads return in order; a store can only make the wait stricter) but it would wait for the epilogue's stores to be
+//     acknowledged.  So the two regions still in flight at the seam are retired BEFORE the stores are issued (vmcnt(4)), and K-tile 0 of a
+//     non-first tile skips the waits of its first two phases (nothing to retire there); the first counted wait after the stores is in phase 2.
+//   * results are bit-identical to k_gemm_pq: same accumulation order, same fp32 epilogue arithmetic (tests/test_kernels_gpu.py).
+// =================================================================================================
+#define PZ_LDS (2 * PQ_BUF + 32768)         // 160 KiB
+#define PZ_STAGE 8192                       // epilogue staging bytes per wave
+
+// 32 tokens x 64 features (fp32) per sub-pass through an XOR-swizzled 8-KiB slice: 16-byte chunk c of token row r lives at chunk c ^ (r & 15).
+// Writes (a lane owns one token of the 32 and 4 consecutive features per register quad) and the token-major read-back (8 lanes per token row,
+// 8 features each) are both bank-conflict free: 16 consecutive lanes always touch 16 distinct chunks.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds8(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const int n = nw0 + rc * 8;
+  float bias8[8];
+#pragma unroll
+  for (int b = 0; b < 8; b++) bias8[b] = 0.f;
+  if (p.bias) {
+    const bf16x8 bv = *(const bf16x8*)(p.bias + n);
+#pragma unroll
+    for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
+  }
+  const int m_first = mw0 + rrow;
+  bf16* c_row = p.C + (int64_t)m_first * p.ldc + n;
+  const bf16* in_row = p.aux_in ? p.aux_in + (int64_t)m_first * p.ld_aux_in + n : nullptr;
+  bf16* out_row = p.aux_out ? p.aux_out + (int64_t)m_first * p.ld_aux_out + n : nullptr;
+  const int64_t c_step = 8 * p.ldc, in_step = 8 * p.ld_aux_in, out_step = 8 * p.ld_aux_out;
+  // write side: chunk (i*8 + 2a + khalf) ^ (l31 & 15) of row l31 = row base ^ ((khalf ^ (l31 & 15)) << 4) ^ ((i*8 + 2a) << 4): ONE lane-dependent base, the
+  // eight positions are XORs with constants — recomputed per sub-pass (the base is made opaque there) instead of living in eight registers.
+  // read side: row = it*8 + rrow, so row & 15 = rrow | 8*(it & 1): two bases (even / odd `it`) per 16-byte half, the row advance is an immediate offset.
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  const uint32_t stage_u = (uint32_t)(uintptr_t)(lds_char*)stage;             // LDS byte address of this wave's staging slice
+  const uint32_t wbase0 = stage_u + (uint32_t)(l31 * 256 + ((khalf ^ (l31 & 15)) << 4));
+  const uint32_t rb = stage_u + (uint32_t)(rrow * 256);
+  const uint32_t r_lo_e = rb + (uint32_t)((((2 * rc) ^ rrow)) << 4), r_hi_e = rb + (uint32_t)((((2 * rc + 1) ^ rrow)) << 4);
+  const uint32_t r_lo_o = rb + (uint32_t)((((2 * rc) ^ (rrow | 8))) << 4), r_hi_o = rb + (uint32_t)((((2 * rc + 1) ^ (rrow | 8))) << 4);
+  // the residual / pre-activation rows an epilogue READS are fetched ONE SUB-PASS AHEAD (32 rows = 4 x 16 B per lane, double-buffered): issued in the
+  // loop below they were 16 dependent HBM round trips per tile (a C store may alias them, so the compiler cannot hoist them itself) — measured r03:
+  // the x GELU' epilogue at 1183 TFLOP/s against 1355 for the plain one on the same shape.  Row r of the tile is read before row r is written
+  // (in-place residual adds stay correct): a prefetched row is never one an earlier sub-pass stores.
+  constexpr bool AUXIN = (EPI == ST355_EPI_GATE_RESIDUAL || EPI == ST355_EPI_ADD || EPI == ST355_EPI_MUL_GELU_GRAD);
+  bf16x8 auxv[2][4], gatev[2][4];
+  const bf16* in_pre = in_row;
+  int m_pre = m_first;
+  auto preload = [&](bf16x8 (&av)[4], bf16x8 (&gv)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      if (AUXIN) av[it] = *(const bf16x8*)in_pre;
+      if (EPI == ST355_EPI_GATE_RESIDUAL) gv[it] = *(const bf16x8*)(p.gate + (int64_t)(m_pre / p.rows_per_batch) * p.gate_stride + n);
+      in_pre += in_step; m_pre += 8;
+    }
+  };
+  if (AUXIN) preload(auxv[0], gatev[0]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t wb = wbase0;
+    asm volatile("" : "+v"(wb));
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        f32x4 v;
+#pragma unroll
+        for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
+        *(lds_f32x4*)(wb ^ (uint32_t)((i * 8 + 2 * a) << 4)) = v;
+      }
+    if (AUXIN && j < 3) preload(auxv[(j + 1) & 1], gatev[(j + 1) & 1]);
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const f32x4 lo = *(const lds_f32x4*)(((it & 1) ? r_lo_o : r_lo_e) + (uint32_t)(it * 2048));
+      const f32x4 hi = *(const lds_f32x4*)(((it & 1) ? r_hi_o : r_hi_e) + (uint32_t)(it * 2048));
+      bf16* const c_ptr = c_row;
+      bf16* const out_ptr = out_row;
+      c_row += c_step; out_row += out_step;
+      float v[8];
+#pragma unroll
+      for (int b = 0; b < 4; b++) { v[b] = lo[b] + bias8[b]; v[4 + b] = hi[b] + bias8[4 + b]; }
+      if (EPI == ST355_EPI_GELU) {
+        if (p.aux_out) {
+          bf16x8 pre;
+#pragma unroll
+          for (int b = 0; b < 8; b++) pre[b] = f2bf(v[b]);
+          *(bf16x8*)out_ptr = pre;
+#pragma unroll
+          for (int b = 0; b < 8; b++) v[b] = bf2f(pre[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = gelu_tanh(v[b]);
+      } else if (EPI == ST355_EPI_GATE_RESIDUAL) {
+        if (p.aux_out) {
+          bf16x8 yv;
+#pragma unroll
+          for (int b = 0; b < 8; b++) yv[b] = f2bf(v[b]);
+          *(bf16x8*)out_ptr = yv;
+        }
+        const bf16x8 gv = gatev[j & 1][it];
+        const bf16x8 rv = auxv[j & 1][it];
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = bf2f(rv[b]) + bf2f(gv[b]) * v[b];
+      } else if (EPI == ST355_EPI_ADD) {
+        const bf16x8 rv = auxv[j & 1][it];
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] += bf2f(rv[b]);
+      } else if (EPI == ST355_EPI_MUL_GELU_GRAD) {
+        const bf16x8 hv = auxv[j & 1][it];
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] *= gelu_tanh_grad(bf2f(hv[b]));
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int b = 0; b < 8; b++) o[b] = f2bf(v[b]);
+      *(bf16x8*)c_ptr = o;
+    }
+  }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pz(GemmP p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  const int nbm = p.M / PQ_BM, nbn = p.N / PQ_BN;
+  const int nt1 = p.K / PQ_BK;
+  const int nt = nt1 + p.K2 / PQ_BK;
+  const int G = gridDim.x;
+  const uint32_t lda_b = (uint32_t)p.lda * 2, ldb_b = (uint32_t)p.ldb * 2;
+  const int64_t la2 = p.lda2, lb2 = p.ldb2;
+
+  // tile -> scalar bases
+  struct Tile { int m0, n0; const char* xb; const char* wb; const bf16* a2; const bf16* b2; int64_t segi; };
+  auto tile_at = [&](int id) {
+    Tile t;
+    int pm, pn;
+    tile_coords(id, nbm, nbn, pm, pn);
+    t.m0 = __builtin_amdgcn_readfirstlane(pm * PQ_BM);
+    t.n0 = __builtin_amdgcn_readfirstlane(pn * PQ_BN);
+    t.segi = p.seg_rows ? (int64_t)__builtin_amdgcn_readfirstlane(t.m0 / p.seg_rows) : 0;
+    t.xb = (const char*)(p.A + t.segi * p.seg_xa) + (int64_t)t.m0 * lda_b;
+    t.wb = (const char*)p.B + (int64_t)t.n0 * ldb_b;
+    t.a2 = p.A2 + t.segi * p.seg_xa2 + (int64_t)t.m0 * la2;
+    t.b2 = p.B2 + (int64_t)t.n0 * lb2;
+    return t;
+  };
+
+  int tile_id = xcd_remap(blockIdx.x, G);
+  Tile cur = tile_at(tile_id);
+  int par = 0;                                   // ring parity of this tile's K-tile 0
+  bool first = true;
+
+  while (true) {
+    // per-lane addressing state is REBUILT per tile from an opaque copy of the lane id: nothing of it stays live across the epilogue (kept live, it and the
+    // epilogue's hoisted address arithmetic pushed the accumulators into scratch — and every scratch reload waits vmcnt(0), i.e. for the epilogue's stores)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    uint32_t xo[2][2], wo[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int lr = (wv * 2 + j) * 8 + (ln >> 3);
+      const uint32_t scb = (uint32_t)(((ln & 7) ^ ((lr >> 1) & 7)) * 16);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        xo[r][j] = (uint32_t)((lr >> 6) * 128 + (lr & 63) + r * 64) * lda_b + scb;
+        wo[r][j] = (uint32_t)((lr >> 5) * 64 + (lr & 31) + r * 32) * ldb_b + scb;
+      }
+    }
+    const int khalf = ln >> 5;
+    const int l31 = ln & 31;
+    int xk[4], wk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int ch = ((2 * ks + khalf) ^ ((l31 >> 1) & 7)) << 4;
+      xk[ks] = (wm * 64 + l31) * 128 + ch;
+      wk[ks] = 2 * PQ_REGION + (wn * 32 + l31) * 128 + ch;
+    }
+    auto ld_x = [&](const char* base, int j, int ks) -> bf16x8 { return *(const bf16x8*)(base + xk[ks] + j * 4096); };
+    auto ld_w = [&](const char* base, int ks) -> bf16x8 { return *(const bf16x8*)(base + wk[ks]); };
+    const bool has_next = tile_id + G < ntiles;
+    const Tile nxt = has_next ? tile_at(tile_id + G) : cur;
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)cur.xb, 0, 0x7FFFFFFF, 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)cur.wb, 0, 0x7FFFFFFF, 0x00020000);
+    const auto xn_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.xb, 0, 0x7FFFFFFF, 0x00020000);
+    const auto wn_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)nxt.wb, 0, 0x7FFFFFFF, 0x00020000);
+
+    // region refill of ring K-tile u (u counts from this tile's K-tile 0; u >= nt: K-tile u - nt of the next tile)
+    auto stage_x = [&](int u, int r, int mode) {
+      char* dst = smem + (((u & 1) ^ par) * PQ_BUF) + r * PQ_REGION + wv * 2048;
+      const bool nx = mode == 1 && u >= nt;
+      const int uu = nx ? u - nt : u;
+      if (uu < nt1) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(nx ? xn_rsrc : x_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, xo[r][j], uu * (PQ_BK * 2), 0, 0);
+      } else {
+        const bf16* base = nx ? nxt.a2 : cur.a2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int lr = (wv * 2 + j) * 8 + (ln >> 3);
+          glds16(base + (int64_t)((lr >> 6) * 128 + (lr & 63) + r * 64) * la2 + ((ln & 7) ^ ((lr >> 1) & 7)) * 8 + (uu - nt1) * PQ_BK, dst + j * 1024);
+        }
+      }
+    };
+    auto stage_w = [&](int u, int r, int mode) {
+      char* dst = smem + (((u & 1) ^ par) * PQ_BUF) + (2 + r) * PQ_REGION + wv * 2048;
+      const bool nx = mode == 1 && u >= nt;
+      const int uu = nx ? u - nt : u;
+      if (uu < nt1) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(nx ? wn_rsrc : w_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, wo[r][j], uu * (PQ_BK * 2), 0, 0);
+      } else {
+        const bf16* base = nx ? nxt.b2 : cur.b2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int lr = (wv * 2 + j) * 8 + (ln >> 3);
+          glds16(base + (int64_t)((lr >> 5) * 64 + (lr & 31) + r * 32) * lb2 + ((ln & 7) ^ ((lr >> 1) & 7)) * 8 + (uu - nt1) * PQ_BK, dst + j * 1024);
+        }
+      }
+    };
+    // MODE 0: steady state (every refill exists, in this tile).  MODE 1: the last two K-tiles of a tile that HAS a successor (refills beyond nt address
+    // the next tile; waits as in steady state).  MODE 2: the last two K-tiles of the workgroup's last tile (refills beyond nt skipped, waits shortened).
+    auto refill = [&](int t, int ph, int mode) {
+      const int u = (ph < 2) ? t + 1 : t + 2;
+      if (mode == 2 && u >= nt) return;
+      if (ph == 0) stage_w(u, 1, mode);
+      else if (ph == 1) stage_x(u, 1, mode);
+      else if (ph == 2) stage_x(u, 0, mode);
+      else stage_w(u, 0, mode);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    if (first) {
+      // prologue of the workgroup's first tile (as k_gemm_pq): XA(0) WA(0) WB(0) XB(0) XA(1) WA(1) in ring order; XA(0), WA(0) retired + published
+      stage_x(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_x(0, 1, 0);
+      stage_x(1, 0, 0); stage_w(1, 0, 0);
+      wait_vm_rt(8);
+      PP_BARRIER();
+    }
+    if (wm == 1) PP_BARRIER();                         // group 1 runs one barrier interval behind group 0
+
+    bf16x8 xf[2][4], w0f[4], w1f[4];
+#define PZ_MMA(WF, I, J0)                                                                                     \
+  do {                                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ks++)                                                          \
+      _Pragma("unroll") for (int j = 0; j < 2; j++)                                                           \
+        acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ks], xf[j][ks], acc[I][J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+  } while (0)
+
+    // FIRSTK: K-tile 0 of a non-first tile — WB(0) / XB(0) were retired at the seam, before the epilogue's stores entered the queue: no wait in P0 / P1
+    auto body = [&](int t, auto mode_c, auto firstk_c) {
+      constexpr int MODE = decltype(mode_c)::value;
+      constexpr bool FIRSTK = decltype(firstk_c)::value;
+      const char* bf = smem + (((t & 1) ^ par) * PQ_BUF);
+      const int rem = nt - 1 - t;
+      // ---------------- P0: WA x XA ----------------
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf, j, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) w0f[ks] = ld_w(bf, ks);
+      refill(t, 0, MODE);
+      if (MODE != 2) { if (!FIRSTK) wait_vm_rt(8); } else wait_vm_rt(rem >= 1 ? 8 : 2);
+      PP_BARRIER();
+      PZ_MMA(w0f, 0, 0);
+      PP_BARRIER();
+      // ---------------- P1: WB x XA ----------------
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) w1f[ks] = ld_w(bf + PQ_REGION, ks);
+      refill(t, 1, MODE);
+      if (MODE != 2) { if (!FIRSTK) wait_vm_rt(8); } else wait_vm_rt(rem >= 1 ? 8 : 0);
+      PP_BARRIER();
+      PZ_MMA(w1f, 1, 0);
+      PP_BARRIER();
+      // ---------------- P2: WB x XB ----------------
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) xf[j][ks] = ld_x(bf + PQ_REGION, j, ks);
+      refill(t, 2, MODE);
+      if (MODE != 2) wait_vm_rt(8); else wait_vm_rt(rem >= 1 ? 6 : 0);
+      PP_BARRIER();
+      PZ_MMA(w1f, 1, 2);
+      PP_BARRIER();
+      // ---------------- P3: WA x XB ----------------
+      refill(t, 3, MODE);
+      if (MODE != 2) wait_vm_rt(8); else wait_vm_rt(rem >= 1 ? 4 : 0);
+      PP_BARRIER();
+      PZ_MMA(w0f, 0, 2);
+      PP_BARRIER();
+    };
+    int t = 0;
+    if (!first) { body(0, std::integral_constant<int, 0>{}, std::true_type{}); t = 1; }
+    for (; t < nt - 2; t++) body(t, std::integral_constant<int, 0>{}, std::false_type{});
+    // the workgroup's LAST tile prefetches "its successor" too (nxt = cur: two K-tiles of valid, unused operand rows): one tail for every tile keeps
+    // the control flow — and the register allocation at the epilogue — single-path (a separate no-prefetch tail cost ~90 spilled accumulators)
+    for (; t < nt; t++) body(t, std::integral_constant<int, 1>{}, std::false_type{});
+#undef PZ_MMA
+    if (wm == 0) PP_BARRIER();                         // pairs with group 1's extra barrier: every wave is past its last ring read of this tile
+    // in flight now (has_next): WB(n0) XB(n0) [issued in the last K-tile's P0 / P1] and XA(n1) WA(n1) [P2 / P3]; retire the first two BEFORE any store
+    wait_vm_rt(4);
+    {
+      GemmP ps = p;
+      ps.C = p.C + cur.segi * p.seg_xc;
+      ps.aux_in = p.aux_in ? p.aux_in + cur.segi * p.seg_xin : nullptr;
+      ps.aux_out = p.aux_out ? p.aux_out + cur.segi * p.seg_xout : nullptr;
+      // staging: the XB / WB regions of the LAST K-tile's buffer (refilled only after the epilogue) and the spare 32 KiB above the ring
+      char* const lastbuf = smem + ((((nt - 1) & 1) ^ par) * PQ_BUF);
+      char* const stg = wv < 2 ? lastbuf + PQ_REGION + wv * PZ_STAGE : (wv < 4 ? lastbuf + 3 * PQ_REGION + (wv - 2) * PZ_STAGE : smem + 2 * PQ_BUF + (wv - 4) * PZ_STAGE);
+      int le = lane;
+      asm volatile("" : "+v"(le));           // the epilogue's address arithmetic starts here, not above the K loop
+      gemm_epilogue_lds8<EPI>(ps, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, le, stg);
+    }
+    if (!has_next) { wait_vm_rt(0); break; }           // (the dummy prefetch of the last tile lands before the wave ends)
+    PP_BARRIER();                                      // every wave has read its staging slice back: the ring slots may be refilled
+    par ^= (nt & 1);
+    tile_id += G;
+    cur = nxt;
+    first = false;
+  }
+}
+
+// =================================================================================================
 // k_gemm_s2: 128x128x64, 4 waves, double buffer (small problems)
 // =================================================================================================
 #define S2_BM 128
@@ -1268,8 +1616,49 @@ static int min_tiles_256() {
   return v;
 }
 
+static int g_persist_override = -1;          // lab / test hook (tools/gemm_lab.hip compiles this file in): 0 / 1 force the choice, -1 = environment
+static int persist_enabled() {
+  if (g_persist_override >= 0) return g_persist_override;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ST355_GEMM_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }      // A/B: 0 = one tile per workgroup (k_gemm_pq) everywhere
+  return v;
+}
+static int device_cus() {
+  static int v = -1;
+  if (v < 0) {
+    int dev = 0; hipGetDevice(&dev);
+    hipDeviceProp_t pr;
+    v = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    if (const char* e = getenv("ST355_GEMM_PERSIST_WGS")) { const int o = atoi(e); if (o > 0) v = o; }
+  }
+  return v;
+}
+// the persistent kernel covers the plain NT bf16 problems made of full 256x256 tiles (k_gemm_pz header); everything else keeps k_gemm_pq
+static bool pz_ok(const GemmP& p, int tiles) {
+  if (!persist_enabled() || p.M % PQ_BM || p.N % PQ_BN || p.K % PQ_BK || p.K2 % PQ_BK) return false;
+  if (p.K / PQ_BK + p.K2 / PQ_BK < 4 || p.K / PQ_BK < 2 || p.conv_taps || p.scale_b || p.partial || p.img_add) return false;
+  if (tiles <= device_cus()) return false;            // one round of tiles: nothing to overlap
+  bool ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (((uintptr_t)p.A & 15) == 0) && (((uintptr_t)p.B & 15) == 0) && p.lda % 8 == 0 && p.ldb % 8 == 0;
+  if (p.bias) ok = ok && (((uintptr_t)p.bias & 15) == 0);
+  if (p.aux_out) ok = ok && (p.ld_aux_out % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0);
+  if (p.aux_in) ok = ok && (p.ld_aux_in % 8 == 0) && (((uintptr_t)p.aux_in & 15) == 0);
+  if (p.gate) ok = ok && (p.gate_stride % 8 == 0) && (((uintptr_t)p.gate & 15) == 0);
+  return ok;
+}
 template <int EPI>
-static int launch_256(void* stream, const GemmGroup& g, int tiles) { return launch_pq<EPI>(stream, g, tiles); }
+static int launch_pz(void* stream, const GemmP& p, int tiles) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pz<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PZ_LDS); attr_set = true; }
+  const int wgs = tiles < device_cus() ? tiles : device_cus();
+  hipLaunchKernelGGL((k_gemm_pz<EPI>), dim3(wgs), dim3(PQ_THREADS), PZ_LDS, (hipStream_t)stream, p, tiles);
+  return st355_check_launch("gemm_pz");
+}
+
+template <int EPI>
+static int launch_256(void* stream, const GemmGroup& g, int tiles) {
+  if (tiles == g.tiles0 && pz_ok(g.p[0], tiles)) return launch_pz<EPI>(stream, g.p[0], tiles);     // (a two-problem grid stays one-tile-per-workgroup)
+  return launch_pq<EPI>(stream, g, tiles);
+}
 
 #define DISPATCH_EPI(fn, epi, ...)                                                           \
   switch (epi) {                                                                             \
@@ -1330,6 +1719,12 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     DISPATCH_EPI(launch_p3, a->epilogue, stream, g, g.tiles0);
   }
   DISPATCH_EPI(launch_s2, a->epilogue, stream, p);
+}
+
+extern "C" int st355_gemm_set_persistent(int mode) {
+  const int prev = g_persist_override;
+  g_persist_override = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
 }
 
 extern "C" int st355_gemm_bf16(void* stream, const st355_gemm_args* a) {
@@ -1497,6 +1892,16 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
       g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);
       g.tiles0 = p4_tiles(g.p[0]);
       const int tiles = g.tiles0 + p4_tiles(g.p[1]);
+      if (pz_ok(g.p[0], g.tiles0) && pz_ok(g.p[1], tiles - g.tiles0)) {     // both fill the chip alone: nothing to gain from sharing a grid — two persistent launches
+        for (int k = 0; k < 2; k++) {
+          ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i + k]), gemm_bytes(&args[i + k]), "%dx%dx%d+%d e%d g", args[i + k].M, args[i + k].N, args[i + k].K,
+                       args[i + k].K2, args[i + k].epilogue);
+          int rc = run_one(stream, &args[i + k]);
+          if (rc) return rc;
+        }
+        i += 2;
+        continue;
+      }
       if (tiles >= min_tiles_256()) {
         ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),
                      "%d&%dx%dx%d+%d e%d", args[i].M, args[i + 1].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);

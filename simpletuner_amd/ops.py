@@ -349,6 +349,11 @@ def gemm(a, w, **kw):
     return out
 
 
+def gemm_set_persistent(mode: int) -> int:
+    """st355_gemm_set_persistent: 1 = persistent tile walk (k_gemm_pz) where it applies, 0 = one tile per workgroup, -1 = default; returns the previous mode"""
+    return int(_l.load().st355_gemm_set_persistent(int(mode)))
+
+
 def gemm_grouped(problems):
     """run several independent GEMMs that share one epilogue kind in as few launches as possible.
     problems: list of dicts with keys a, w and the kwargs of gemm().  Returns the list of outputs."""

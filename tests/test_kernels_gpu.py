@@ -398,6 +398,93 @@ def test_gemm_segmented_rows_bit_equal_to_per_sample_problems(ops, B, rows, lo, 
         ops.gemm(A_joint[:, 1:1 + 200], W)                              # 200-row segments: not a multiple of the 256-row tile
 
 
+@pytest.mark.parametrize("epi", ["none", "gelu", "gate_residual", "add", "mul_gelu_grad", "segmented_gate_residual_lora"])
+def test_gemm_persistent_schedule_is_bit_equal_to_one_tile_per_workgroup(ops, epi):
+    """k_gemm_pz (persistent workgroups, LDS ring running across tile seams, epilogue staged in the ring's idle regions, residual rows prefetched a
+    sub-pass ahead) against k_gemm_pq on problems of more than one round of 256x256 tiles: every output BIT-identical, three launches each (a seam race
+    would show as a non-repeatable difference), odd and even K-tile counts (the ring parity flips per tile when odd), and against fp32 torch."""
+    torch.manual_seed(77)
+    d = dev()
+    M, N, K = (5 * 256 * 4, 18 * 256, 320) if epi != "segmented_gate_residual_lora" else (4 * 1024, 20 * 256, 448)       # 360 / 320 tiles, 5 / 7(+1) K-tiles
+    x = torch.randn(M, K, device=d).to(BF16)
+    W = (torch.randn(N, K, device=d) * 0.05).to(BF16)
+    bias = torch.randn(N, device=d).to(BF16)
+    aux = torch.randn(M, N, device=d).to(BF16)
+    gate = torch.randn(4, N, device=d).to(BF16)
+    kw, ref = dict(bias=bias), x.float() @ W.float().t() + bias.float()
+    outs = {}
+    if epi == "gelu":
+        kw.update(epilogue=ops.EPI_GELU)
+        ref = torch.nn.functional.gelu(ref.to(BF16).float(), approximate="tanh")
+    elif epi == "gate_residual":
+        kw.update(epilogue=ops.EPI_GATE_RESIDUAL, aux_in=aux, gate=gate, rows_per_batch=M // 4)
+        ref = aux.float() + gate.float().repeat_interleave(M // 4, dim=0) * ref
+    elif epi == "add":
+        kw.update(epilogue=ops.EPI_ADD, aux_in=aux)
+        ref = ref + aux.float()
+    elif epi == "mul_gelu_grad":
+        kw.update(epilogue=ops.EPI_MUL_GELU_GRAD, aux_in=aux)
+        h = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(h, approximate="tanh").sum().backward()
+        ref = ref * h.grad
+    elif epi == "segmented_gate_residual_lora":
+        B, rows, S, lo = 4, 1024, 1536, 256
+        xj = torch.randn(B, S, K, device=d).to(BF16)
+        T = torch.randn(B * rows, 64, device=d).to(BF16); Bs = (torch.randn(N, 64, device=d) * 0.05).to(BF16)
+        resj = torch.randn(B, S, N, device=d).to(BF16)
+    for mode in (0, 1):
+        prev = ops.gemm_set_persistent(mode)
+        try:
+            got = []
+            for rep in range(3):
+                if epi == "segmented_gate_residual_lora":
+                    o = torch.full((B, S, N), 7.0, device=d, dtype=BF16)
+                    ops.gemm(xj[:, lo:lo + rows], W, bias=bias, a2=T, b2=Bs, out=o[:, lo:lo + rows], epilogue=ops.EPI_GATE_RESIDUAL,
+                             aux_in=resj[:, lo:lo + rows], gate=gate, rows_per_batch=rows)
+                    got.append((o, None))
+                elif epi == "gelu":
+                    pre = torch.empty(M, N, device=d, dtype=BF16)
+                    got.append((ops.gemm(x, W, aux_out=pre, **kw), pre))
+                else:
+                    got.append((ops.gemm(x, W, **kw), None))
+            for o, pre in got[1:]:
+                assert torch.equal(o, got[0][0]) and (pre is None or torch.equal(pre, got[0][1]))
+            outs[mode] = got[0]
+        finally:
+            ops.gemm_set_persistent(prev)
+    assert torch.equal(outs[0][0], outs[1][0]), "persistent schedule differs from the one-tile-per-workgroup schedule"
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    if epi == "segmented_gate_residual_lora":
+        exact = resj[:, lo:lo + rows].float() + gate.float()[:, None] * (xj[:, lo:lo + rows].float() @ W.float().t() + bias.float()
+                                                                        + (T.float() @ Bs.float().t()).view(B, rows, N))
+        assert report("persistent segmented gemm vs fp32", outs[1][0][:, lo:lo + rows], exact)[0] < 6e-3
+        assert (outs[1][0][:, :lo] == 7.0).all() and (outs[1][0][:, lo + rows:] == 7.0).all()
+    else:
+        assert report(f"persistent gemm [{epi}] vs fp32", outs[1][0], ref)[0] < 8e-3
+
+
+def test_gemm_grouped_launches_under_the_persistent_schedule(ops):
+    """two problems that share one grid (st355_gemm_bf16_grouped) must never be handed to the single-problem persistent kernel as one tile list; pairs whose
+    members each fill the chip run one after the other on it.  (r03: the first build walked problem 0 over both problems' tiles — a memory fault.)"""
+    torch.manual_seed(78)
+    d = dev()
+    K, N = 320, 12 * 256
+    W = (torch.randn(N, K, device=d) * 0.05).to(BF16)
+    big, big2, small = (torch.randn(m, K, device=d).to(BF16) for m in (24 * 256, 23 * 256, 512))
+    res = {}
+    for mode in (0, 1):
+        prev = ops.gemm_set_persistent(mode)
+        try:
+            res[mode] = ops.gemm_grouped([dict(a=big, w=W), dict(a=small, w=W)]) + ops.gemm_grouped([dict(a=big, w=W), dict(a=big2, w=W)])
+        finally:
+            ops.gemm_set_persistent(prev)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for o, x in zip(res[1], (big, small, big, big2)):
+        assert report("grouped gemm vs fp32", o, x.float() @ W.float().t())[0] < 5e-3
+
+
 @pytest.mark.parametrize("S,with_bias", [(512, False), (300, False), (448, True)])
 def test_attention_forward_row_major_v_is_bit_equal(ops, S, with_bias):
     """st355_attn_fwd_vrows: V read row-major (token rows of a [B*S, ld] projection buffer) through transposing LDS reads — the same fragments as the

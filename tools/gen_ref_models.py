@@ -11,7 +11,7 @@ a seeded value, runs the reference `forward` + torch autograd on seeded inputs a
           attention), non-square latents, TREAD routing (router permutations recorded for replay), plus — per activation-checkpoint mode —
           WHICH blocks the reference wrapped (recorded by intercepting its checkpoint function).  tests/test_ref_models_cpu.py pins
           oracle/{flux,sd3,pixart}.py to these at <= 1e-5 (fp32).
-  "hip"   (the head widths the HIP kernels are built for: 2 x 128 Flux, 2 x 64 SD3, 2 x 72 PixArt): NO weights stored — both sides rebuild
+  "hip"   (the head widths the HIP kernels are built for: 2 x 128 Flux, 2 x 64 SD3, 8 x 72 PixArt): NO weights stored — both sides rebuild
           them with tests/ref_fixture_utils.seeded_state (bf16-representable values; checksum stored).  Stored: inputs, output, input gradients
           and, for the adapters, the LoRA gradients the reference's dL/dW implies (peft: W' = W + s B A  =>  dA = s B^T dW', dB = s dW' A^T).
           tests/test_ref_models_gpu.py runs the HIP models against these — the product is compared with executed reference code, not only
@@ -205,7 +205,7 @@ def gen_flux():
 
     # ---- hip tier: 2 heads x 128, 2 double + 2 single blocks, LoRA r4 alpha 8 on the reference's default targets ----
     hcfg = dict(patch_size=1, in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2,
-                joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+                joint_attention_dim=64, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
     model = T.FluxTransformer2DModel(**hcfg)
     st = seed_params(model, 141, bf16=True)
     model.eval()
@@ -221,7 +221,7 @@ def gen_flux():
     hin = {
         "hidden_states": pack_latents(latents, B, 16, Hl, Wl),
         "encoder_hidden_states": bf(torch.randn(B, Tt, 64, generator=g)),
-        "pooled_projections": bf(torch.randn(B, 32, generator=g)),
+        "pooled_projections": bf(torch.randn(B, 64, generator=g)),
         "timestep": torch.tensor([0.25, 0.8125]),
         "img_ids": prepare_latent_image_ids(B, Hl, Wl, "cpu", torch.float32),
         "txt_ids": torch.zeros(Tt, 3),
@@ -380,16 +380,17 @@ def gen_pixart():
     r["grads"] = {k[len("controlnet."):]: v for k, v in r["_full_grads"].items() if k.startswith("controlnet.")}
     tiny["cases"]["controlnet"] = strip(r)
 
-    # ---- hip: 2 heads x 72, 3 trunk blocks, 2 adapter blocks ----
-    hcfg = dict(num_attention_heads=2, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=3, cross_attention_dim=144, sample_size=128,
+    # ---- hip: 8 heads x 72 (the product needs the inner width to be a multiple of 64), 3 trunk blocks, 2 adapter blocks ----
+    hcfg = dict(num_attention_heads=8, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=3, cross_attention_dim=576, sample_size=128,
                 patch_size=2, caption_channels=64, use_additional_conditions=True)
     trunk, adapter, st, ast_, hin = make(hcfg, 2, 181, True, 2, 16, 24, 24, 64, 282)
     rt = run(trunk, call_trunk, {k: v for k, v in hin.items() if k != "controlnet_cond"}, 383)
     wrap = C.PixArtSigmaControlNetTransformerModel(trunk, adapter, training=True)
     r = run(wrap, call_wrap, hin, 385)
-    keep = ["controlnet_blocks.0.before_proj.weight", "controlnet_blocks.0.after_proj.weight", "controlnet_blocks.1.after_proj.bias",
-            "controlnet_blocks.0.transformer_block.scale_shift_table", "controlnet_blocks.0.transformer_block.attn1.to_q.weight",
-            "controlnet_blocks.1.transformer_block.attn2.to_k.weight", "controlnet_blocks.1.transformer_block.ff.net.0.proj.bias",
+    keep = ["controlnet_blocks.1.after_proj.weight", "controlnet_blocks.1.after_proj.bias",
+            "controlnet_blocks.0.transformer_block.scale_shift_table", "controlnet_blocks.0.transformer_block.attn1.to_q.bias",
+            "controlnet_blocks.1.transformer_block.attn2.to_v.bias", "controlnet_blocks.1.transformer_block.ff.net.0.proj.bias",
+            "controlnet_blocks.1.transformer_block.ff.net.2.bias", "controlnet_blocks.0.before_proj.bias",
             "controlnet_blocks.1.transformer_block.attn1.to_out.0.bias"]
     hip = {"config": hcfg, "n_ctrl": 2, "seed": 181, "adapter_seed": 191, "state_checksum": state_checksum(st), "adapter_checksum": state_checksum(ast_),
            "inputs": hin, "trunk_out": rt["out"], "trunk_w": rt["w"], "trunk_input_grads": rt["input_grads"],
