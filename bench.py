@@ -355,7 +355,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()                  # the Flux workload's cached blocks go back before the UNet's capture pool is built
         a2 = copy.copy(args)
-        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, world == 1, False
+        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False      # hipGraph replay at every N (r03)
         a2.steps, a2.warmup, a2.no_cpu_baseline, a2.prof_dump, a2.fp8 = min(args.steps, 5), 2, True, None, False
         sec = run_workload(a2, dev, rank, world)
         if rank == 0:

@@ -185,6 +185,10 @@ int st355_colsum_prod(void* stream, const void* a, int64_t lda, const void* b, i
                       const void* shift, const void* scale, int64_t mod_stride, int accumulate, void* workspace);
 /* dst[c, r] = src[r, c]  (bf16; rows, cols multiples of 8): refreshes the K-major weight copies after an optimizer step */
 int st355_transpose_bf16(void* stream, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols);
+/* The local half of the fp32-accumulating gradient reduce-scatter (replaces the bf16 SUM inside DDP's / RCCL's reducer, trainer.py:1034-1041): after an
+ * all-to-all delivered chunk j of every rank to rank j, out[i] = bf16(sum_w float(chunks[w * n + i])), w in rank order — deterministic, one rounding.
+ * n % 8 == 0 when world > 1 (every chunk 16-byte aligned). */
+int st355_sum_chunks_bf16(void* stream, const void* chunks, int world, int64_t n, void* out);
 
 /* skinny transposed product for rank-space LoRA gradients (K12 backward):
  * out[p*so_p + r*so_r] (+)= alpha * sum_m L[m,p] * R[m,r],  L:[M,P] bf16, R:[M,Rn] bf16 (Rn in {32,64}), out fp32.

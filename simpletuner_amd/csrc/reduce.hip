@@ -124,3 +124,43 @@ extern "C" int st355_transpose_bf16(void* stream, const void* src, int64_t ld_sr
                      (bf16*)dst, ld_dst, rows, cols);
   return st355_check_launch("transpose_bf16");
 }
+
+
+// ---- fp32-accumulating reduce of the chunks a rank receives in the all-to-all form of the gradient reduce-scatter (training/grad_sync.py) ----------
+// out[i] = bf16( float(in[0][i]) + float(in[1][i]) + ... + float(in[W-1][i]) ), chunks summed in rank order: deterministic, one rounding.
+// HBM-bound: (W + 1) * 2 bytes per output element; 16-byte accesses, grid-stride.
+__global__ void __launch_bounds__(256) k_sum_chunks_bf16(const bf16* __restrict__ in, int W, int64_t n, bf16* __restrict__ out) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int w = 0; w < W; w++) {
+      const bf16x8 v = *(const bf16x8*)(in + (int64_t)w * n + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[j] += bf2f(v[j]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f2bf(acc[j]);
+    *(bf16x8*)(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {          // ragged tail (< 8 elements)
+    const int64_t i = (n8 << 3) + threadIdx.x;
+    float a = 0.f;
+    for (int w = 0; w < W; w++) a += bf2f(in[(int64_t)w * n + i]);
+    out[i] = f2bf(a);
+  }
+}
+
+extern "C" int st355_sum_chunks_bf16(void* stream, const void* chunks, int world, int64_t n, void* out) {
+  ST_REQUIRE(chunks && out && world >= 1 && n >= 0, "sum_chunks_bf16: bad args");
+  ST_REQUIRE(((uintptr_t)chunks & 15) == 0 && ((uintptr_t)out & 15) == 0, "sum_chunks_bf16: 16-byte aligned buffers");
+  if (n == 0) return ST355_OK;
+  ST_REQUIRE(world == 1 || n % 8 == 0, "sum_chunks_bf16: the chunk length must keep every chunk 16-byte aligned (n % 8 == 0)");
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0.0, (double)(world + 1) * n * 2, "sum_chunks %dx%lld", world, (long long)n);
+  const int64_t n8 = n >> 3;
+  const unsigned grid = (unsigned)(n8 < 1 ? 1 : (n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(k_sum_chunks_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)chunks, world, n, (bf16*)out);
+  return st355_check_launch("sum_chunks_bf16");
+}

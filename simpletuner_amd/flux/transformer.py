@@ -859,7 +859,8 @@ class _FluxFn(torch.autograd.Function):
             model.grad_scale_from_sync = model.grad_sync.finish()   # all slices reduced (SUM); optimizer folds 1/world
         # hand autograd a private flat copy (one 4 B/param copy) so .grad never aliases the arena the next backward overwrites;
         # the per-parameter grads stay views of ONE contiguous buffer, which the fused optimizer / RCCL all-reduce exploit.
-        gflat = model.lora_grad_flat.clone()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.lora_grad_flat)
         model._last_grad_flat = gflat
         grads, off = [], 0
         for p in model._lora_params:

@@ -315,11 +315,21 @@ class ModelFoundation(ExplorativeModelingMixin):
         return self.unwrap_model(self.model) if unwrap_model else self.model
 
     def set_prepared_model(self, model, base_model: bool = False):
+        """common.py:3691 / trainer.py:4577: the trainer hands back what `accelerator.prepare` returned.  A torch DistributedDataParallel around an st355
+        component gets the st355 communication hook (the component's own in-backward exchange, training.ddp_seam) unless it already has one; an
+        `St355DistributedDataParallel` wrapper, or the bare component, is stored as is."""
         self.model = model
+        if type(model).__name__ == "DistributedDataParallel" and hasattr(model, "register_comm_hook") and getattr(model, "_st355_seam", None) is None:
+            from .training.ddp_seam import install_ddp_comm_hook
+            install_ddp_comm_hook(model)
 
     @staticmethod
     def unwrap_model(model):
-        return getattr(model, "module", model)
+        """common.py:3700 (accelerator.unwrap_model): strip DDP-style wrappers (`.module`), however nested"""
+        seen = 0
+        while hasattr(model, "module") and isinstance(getattr(model, "module"), torch.nn.Module) and seen < 4:
+            model, seen = model.module, seen + 1
+        return model
 
     def _require_per_sample_timesteps(self, prepared_batch: dict):
         """The reference's DiT plugins also accept TOKENWISE timesteps [B, S] (CREPA self-flow; tests/test_flux_model.py:213-241,

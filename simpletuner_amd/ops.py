@@ -349,6 +349,17 @@ def gemm(a, w, **kw):
     return out
 
 
+def sum_chunks_bf16(chunks, world: int, out):
+    """out[i] = bf16(sum_w float(chunks[w * n + i])), n = out.numel(): the fp32-accumulating local half of the all-to-all reduce-scatter (grad_sync)"""
+    L = _l.load()
+    _chk(chunks, BF16, "chunks"); _chk(out, BF16, "out")
+    n = out.numel()
+    if chunks.numel() != world * n:
+        raise _l.St355Error(f"sum_chunks_bf16: chunks holds {chunks.numel()} elements, expected world * n = {world * n}")
+    _l.check(L.st355_sum_chunks_bf16(_stream(), _ptr(chunks), int(world), int(n), _ptr(out)), "sum_chunks_bf16")
+    return out
+
+
 def gemm_set_persistent(mode: int) -> int:
     """st355_gemm_set_persistent: 1 = persistent tile walk (k_gemm_pz) where it applies, 0 = one tile per workgroup, -1 = default; returns the previous mode"""
     return int(_l.load().st355_gemm_set_persistent(int(mode)))

@@ -635,7 +635,8 @@ class _CtrlFn(torch.autograd.Function):
         if model.grad_sync is not None:
             model.grad_sync.ready(0, model.grad_arena.numel())
             model.grad_scale_from_sync = model.grad_sync.finish()
-        gflat = model.grad_arena.clone()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.grad_arena)
         model._last_grad_flat = gflat
         grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._offsets, model._params)]
         return (None,) * 7 + tuple(grads)

@@ -780,7 +780,8 @@ class _SD3Fn(torch.autograd.Function):
         fctx.ectx = None
         if model.grad_sync is not None:
             model.grad_scale_from_sync = model.grad_sync.finish()
-        gflat = model.lora_grad_flat.clone()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.lora_grad_flat)
         model._last_grad_flat = gflat
         grads, off = [], 0
         for p in model._lora_params:
@@ -808,7 +809,8 @@ class _SD3FullFn(torch.autograd.Function):
         fctx.ectx = None
         if model.grad_sync is not None:
             model.grad_scale_from_sync = model.grad_sync.finish()   # every slice reduced (SUM over replicas); the optimizer folds 1/world
-        gflat = model.grad_arena.clone()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.grad_arena)
         model._last_grad_flat = gflat
         grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]
         return (None,) * 5 + tuple(grads)

@@ -13,13 +13,21 @@
         4-5 GB full-fine-tune arenas (default: arenas >= 1 GiB).  The shard boundary is where a sharded optimizer / a shard-local
         gradient-norm would slot in; both collectives run in place on the arena (recv = send + rank * count).
   * SUM is used and the 1/world_size averaging is folded into the optimizer kernel's grad_scale (no extra pass over HBM);
-  * `no_sync()` mirrors DDP/accelerate semantics for gradient accumulation (trainer.py:7009).
+  * `no_sync()` mirrors DDP/accelerate semantics for gradient accumulation (trainer.py:7009);
+  * `fp32_reduce` (default for bf16 arenas in the `rs_ag` form): the reduce-scatter half becomes an ALL-TO-ALL of the bf16 chunks — chunk j of every
+    rank travels straight to rank j over its own xGMI link, the same (N-1)/N * G bytes per rank as a reduce-scatter — followed by a local sum of the
+    N received chunks in fp32, in rank order (st355_sum_chunks_bf16: deterministic, ONE rounding to bf16), then the all-gather of the reduced shards.
+    A bf16 RCCL SUM rounds after every hop of its ring / tree; this form accumulates the 2-billion-element full-fine-tune gradient in fp32
+    without putting fp32 on the wire;
+  * `ST355_COMM_TIMING=1`: every slice's collective is bracketed by timing events on the comm stream and the backward by events on the compute stream;
+    `overlap_report()` turns them into per-bucket timestamps, the exposed tail and the overlap fraction (what a SCALE run reports).
 Bucket size is chosen for the per-link xGMI bound: 32 MiB slices keep each of the 7 links busy for ~0.2 ms (2*G/N per link at
 ~153 GB/s), long enough to amortise launch latency, short enough to overlap.
 """
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
@@ -28,8 +36,22 @@ import torch.distributed as dist
 RS_AG_MIN_BYTES = 1 << 30
 
 
+def hand_over_gradients(model, arena: torch.Tensor) -> torch.Tensor:
+    """What every st355 backward does last: give autograd a PRIVATE flat copy of the gradient arena (so `.grad` never aliases the buffer the next backward
+    overwrites; the per-parameter gradients stay views of one contiguous tensor, which the fused optimizer and the exchange exploit).  Under a DDP-style
+    wrapper (training.ddp_seam) the same pass applies 1/world_size — DDP hands out AVERAGED gradients — and the wrapper's end-of-backward callback is queued
+    on the autograd engine."""
+    scale = getattr(model, "_handover_scale", None)
+    gflat = arena.clone() if scale is None else arena * scale
+    cb = getattr(model, "_post_backward_cb", None)
+    if cb is not None:
+        torch.autograd.Variable._execution_engine.queue_callback(cb)
+    return gflat
+
+
 class GradSync:
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto", comm=None):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto", comm=None,
+                 fp32_reduce: Optional[bool] = None):
         if mode not in ("auto", "allreduce", "rs_ag"):
             raise ValueError(f"GradSync mode {mode!r}: expected auto / allreduce / rs_ag")
         self.flat = flat_grad
@@ -49,6 +71,12 @@ class GradSync:
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._comm_used = False
         self._serial_backend = None      # resolved lazily: gloo runs async works concurrently -> dependent collectives must be waited for
+        # bf16 arenas in the rs_ag form accumulate in fp32 by default (module docstring); the C-ABI comm path keeps RCCL's own reduce-scatter
+        self.fp32_reduce = (flat_grad.dtype == torch.bfloat16) if fp32_reduce is None else bool(fp32_reduce)
+        self._recv: Optional[torch.Tensor] = None
+        self.timing = bool(os.environ.get("ST355_COMM_TIMING")) and flat_grad.is_cuda
+        self._ev_begin = self._ev_end = None
+        self._ev_slices: List = []
 
     @property
     def world_size(self) -> int:
@@ -64,6 +92,10 @@ class GradSync:
 
     def begin(self):
         self._works, self._lo, self._hi, self.launched_slices, self.launched_ops, self._comm_used = [], None, None, [], [], False
+        if self.timing:
+            self._ev_begin = torch.cuda.Event(enable_timing=True)
+            self._ev_begin.record(torch.cuda.current_stream(self.flat.device))
+            self._ev_slices, self._ev_end = [], None
 
     def _stream_ordered(self) -> bool:
         """True when the backend executes this group's collectives in issue order on one device stream (nccl == RCCL)"""
@@ -88,7 +120,41 @@ class GradSync:
         if W <= 1 or not self.enabled:
             return
         with self._comm_ctx():
+            ev0 = None
+            if self.timing:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(self.comm_stream)
+            self._fire_on_comm_stream(lo, hi, W)
+            if ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record(self.comm_stream)
+                self._ev_slices.append((lo, hi, ev0, ev1))
+
+    def _sum_chunks(self, recv: torch.Tensor, W: int, out: torch.Tensor):
+        """out[i] = bf16(sum over w, in rank order, of float(recv[w, i])) — the local half of the fp32-accumulating reduce-scatter"""
+        if recv.is_cuda:
+            from .. import ops
+            ops.sum_chunks_bf16(recv, W, out)
+        else:                                                          # gloo / CPU plumbing tests
+            out.copy_(recv.view(W, -1).to(torch.float32).sum(dim=0))
+
+    def _fire_on_comm_stream(self, lo: int, hi: int, W: int):
             m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
+            if m > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and (self.flat.is_cuda == self._stream_ordered()):
+                seg = self.flat[lo:lo + m]
+                if self._recv is None or self._recv.numel() < m:
+                    self._recv = torch.empty(m, dtype=seg.dtype, device=seg.device)
+                recv = self._recv[:m]
+                shard = seg[self.rank * (m // W):(self.rank + 1) * (m // W)]
+                dist.all_to_all_single(recv, seg, group=self.pg)       # chunk j of every rank -> rank j (point-to-point over xGMI; stream-ordered under RCCL)
+                self.launched_ops.append(("all_to_all", lo, lo + m))
+                self._sum_chunks(recv, W, shard)
+                self._works.append(dist.all_gather_into_tensor(seg, shard, group=self.pg, async_op=True))
+                self.launched_ops.append(("all_gather", lo, lo + m))
+                if lo + m < hi:
+                    self._works.append(dist.all_reduce(self.flat[lo + m:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self.launched_ops.append(("all_reduce", lo + m, hi))
+                return
             if self.comm is not None:                                  # C-ABI RCCL path: stream-ordered on the comm stream, nothing to wait on but the stream
                 if m > 0:
                     self.comm.reduce_scatter_(self.flat[lo:lo + m]); self.launched_ops.append(("reduce_scatter", lo, lo + m))
@@ -136,12 +202,36 @@ class GradSync:
             self._fire(self._lo, self._hi)
             self._lo = self._hi = None
 
+    def all_reduce_now(self, flat: torch.Tensor):
+        """blocking SUM of an arbitrary flat tensor over the group (the boundary step of a gradient accumulation: training.ddp_seam)"""
+        if self.world_size <= 1:
+            return
+        if self.comm is not None:
+            self.comm.all_reduce_(flat)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def overlap_report(self) -> Optional[dict]:
+        """ST355_COMM_TIMING=1: timestamps (ms from the start of the backward) of every slice's exchange on the comm stream, the end of the backward on the
+        compute stream, the comm time left exposed after it and the overlapped fraction of the total comm time.  Synchronises; call between steps."""
+        if not self.timing or self._ev_begin is None or self._ev_end is None:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        t_bwd = self._ev_begin.elapsed_time(self._ev_end)
+        sl = [dict(lo=lo, hi=hi, start_ms=self._ev_begin.elapsed_time(e0), end_ms=self._ev_begin.elapsed_time(e1)) for lo, hi, e0, e1 in self._ev_slices]
+        comm = sum(s_["end_ms"] - s_["start_ms"] for s_ in sl)
+        exposed = max(0.0, (max((s_["end_ms"] for s_ in sl), default=0.0)) - t_bwd)
+        return dict(backward_ms=t_bwd, comm_ms=comm, exposed_ms=exposed, overlap_frac=(1.0 - exposed / comm) if comm > 0 else 1.0, slices=sl)
+
     def finish(self) -> float:
         """flush, join the comm stream back into the compute stream (device-side for nccl) and return the factor the optimizer must fold
         in (1/world_size)"""
         if self._lo is not None:
             self._fire(self._lo, self._hi)
             self._lo = self._hi = None
+        if self.timing and self._ev_begin is not None:
+            self._ev_end = torch.cuda.Event(enable_timing=True)
+            self._ev_end.record(torch.cuda.current_stream(self.flat.device))     # the last backward kernel has been enqueued: everything after is exposed comm
         if self.comm_stream is not None and self._comm_used:
             with torch.cuda.stream(self.comm_stream):
                 for w in self._works:

@@ -121,7 +121,18 @@ class Trainer:
             self.ema_model = EMAModel(config, self.accelerator, self.params, decay=config.ema_decay)
         if hasattr(self.model, "configure_gradient_checkpointing"):
             self.model.configure_gradient_checkpointing()                # trainer.py:3573 / 6792
-        self._overlapped_sync = config.gradient_accumulation_steps == 1
+        # hip_graph: predict + loss + backward of one (shape-keyed) step are captured once into a hipGraph and replayed — the UNet step is
+        # ~7000 short launches and otherwise bound by the host's launch rate.  No gradient accumulation, fixed shapes per key.  With N > 1 ranks the
+        # gradient exchange runs right AFTER the replay, stream-ordered on the flat gradient buffer (the same code as the boundary step of a gradient
+        # accumulation below), unless ST355_GRAPH_CAPTURE_COMM=1 and the backend can be captured (RCCL): then GradSync's collectives — issued on the
+        # comm stream behind events of the capture stream — become nodes of the graph and overlap the captured backward like the eager path's do.
+        self._use_graph = bool(getattr(config, "hip_graph", False))
+        import os as _os
+        from .ddp_seam import capture_safe
+        self._graph_comm_in_graph = (self._use_graph and self.accelerator.num_processes > 1 and _os.environ.get("ST355_GRAPH_CAPTURE_COMM") == "1"
+                                     and capture_safe())
+        self._overlapped_sync = config.gradient_accumulation_steps == 1 and (not self._use_graph or self._graph_comm_in_graph
+                                                                            or self.accelerator.num_processes == 1)
         if self.accelerator.num_processes > 1:
             sync_module_states(comp)                                     # replicas start from rank 0's weights (DDP construction semantics)
         if self.accelerator.num_processes > 1 and self._overlapped_sync:
@@ -135,11 +146,8 @@ class Trainer:
                 comp.grad_sync = GradSync(comp.grad_arena, bucket_bytes=128 << 20, comm=comm)
             elif getattr(comp, "lora_grad_flat", None) is not None:
                 comp.grad_sync = GradSync(comp.lora_grad_flat, comm=comm)
-        # hip_graph: predict + loss + backward of one (shape-keyed) step are captured once into a hipGraph and replayed — the UNet step is
-        # ~7000 short launches and otherwise bound by the host's launch rate.  Single process, no gradient accumulation, fixed shapes per key.
-        self._use_graph = bool(getattr(config, "hip_graph", False))
-        if self._use_graph and (self.accelerator.num_processes > 1 or config.gradient_accumulation_steps != 1):
-            raise NotImplementedError("hip_graph: single-process, gradient_accumulation_steps == 1 only")
+        if self._use_graph and config.gradient_accumulation_steps != 1:
+            raise NotImplementedError("hip_graph: gradient_accumulation_steps == 1 only")
         if self._use_graph and getattr(getattr(model_plugin, "xm_config", None), "enabled", False):
             raise NotImplementedError("hip_graph: XM noise candidates read their logs on the host every step and cannot be captured")
         self._graphs = {}

@@ -849,7 +849,8 @@ class _UNetFn(torch.autograd.Function):
             sent = sum(hi - lo for lo, hi in model.grad_sync.launched_slices)
             if sent != arena.numel():
                 raise RuntimeError(f"gradient sync covered {sent} of {arena.numel()} elements: a parameter's gradient was never reported ready")
-        gflat = arena.clone()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, arena)
         model._last_grad_flat = gflat
         if model.full:
             grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]

@@ -175,3 +175,122 @@ def test_native_rccl_comm_single_rank_collectives_and_grad_sync():
     assert gs.finish() == 1.0 and gs.launched_ops == []        # world 1: nothing to exchange, the arena is untouched
     assert torch.equal(flat, torch.arange(10_000, device="cuda:0", dtype=torch.float32))
     comm.destroy()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# r03: (1) hipGraph replay with N > 1 — the SDXL-style UNet LoRA step captured per rank, the gradient exchange stream-ordered right after the replay;
+# (2) the real Flux component under torch's own DistributedDataParallel + the st355 communication hook and under the reducer-free wrapper, driven in the
+# reference Trainer's call order (prepare -> set_prepared_model -> accumulate/no_sync micro-steps -> synchronised backward).
+# ------------------------------------------------------------------------------------------------------------------------
+def _unet_graph_run(rank, world, graph):
+    from simpletuner_amd.sdxl.model import SDXL
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+    from tests.test_trainer_graph_gpu import SMALL
+    dev = torch.device("cuda", 0)
+    Bg = 4
+    per = Bg // world
+    cfg = default_config(model_family="sdxl", model_type="lora", train_batch_size=per, learning_rate=1e-4, hip_graph=graph, lora_rank=16, lora_init_b_std=0.02, seed=5)
+    acc = St355Accelerator(dev)
+    pl = SDXL(cfg, acc)
+    torch.manual_seed(0)
+    pl.load_model(**SMALL)
+    pl.add_lora_adapter()
+    tr = Trainer(cfg, pl, acc)
+    g = torch.Generator(device=dev).manual_seed(1)
+    losses = []
+    sl = slice(rank * per, (rank + 1) * per)
+    for i in range(4):
+        full = {"latent_batch": torch.randn(Bg, 4, 16, 16, device=dev, generator=g).to(torch.bfloat16),
+                "prompt_embeds": torch.randn(Bg, 9, 128, device=dev, generator=g).to(torch.bfloat16),
+                "add_text_embeds": torch.randn(Bg, 64, device=dev, generator=g).to(torch.bfloat16),
+                "batch_time_ids": torch.tensor([[128., 128, 0, 0, 128, 128]] * Bg, device=dev, dtype=torch.bfloat16),
+                "timesteps": torch.tensor([100 + i, 700 - i, 300 + i, 500 - i]), "noise": torch.randn(Bg, 4, 16, 16, device=dev, generator=g).to(torch.bfloat16)}
+        losses.append(float(tr.train_step({k: v[sl].contiguous() for k, v in full.items()})))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1).float() for p in tr.params]).cpu()
+    return flat, losses, bool(tr._use_graph), len(tr._graphs)
+
+
+def _flux_ddp_run(rank, world, how):
+    """how: 'ddp_hook' (torch DDP + install_ddp_comm_hook through set_prepared_model) | 'wrapper' (St355DistributedDataParallel) | 'single' (world 1, whole batch)"""
+    from tests import parity_utils as PU
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.ddp_seam import St355DistributedDataParallel
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    dev = torch.device("cuda", 0)
+    Bg = 4
+    per = Bg // world
+    cfg = default_config(model_family="flux", lora_rank=8, train_batch_size=per, seed=3, lora_init_b_std=0.02)
+    plugin = Flux(cfg, St355Accelerator(dev))
+    plugin.load_model(**PU.small_flux_cfg(layers=1, single=1))
+    plugin.add_lora_adapter()
+    comp = plugin.get_trained_component()
+    if how == "ddp_hook":
+        wrapped = torch.nn.parallel.DistributedDataParallel(comp, device_ids=[0])          # what accelerator.prepare builds (trainer.py:4564-4571)
+        plugin.set_prepared_model(wrapped)                                                  # trainer.py:4577 — installs the st355 comm hook
+        assert getattr(wrapped, "_st355_seam", None) is not None
+    elif how == "wrapper":
+        wrapped = St355DistributedDataParallel(comp)
+        plugin.set_prepared_model(wrapped)
+    else:
+        wrapped = comp
+    assert plugin.get_trained_component() is comp
+    _, devt = PU.make_inputs(2 * Bg, 16, 16, 32, 128, 64, dev, seed=9)
+    params = comp.trainable_parameters()
+
+    def micro(idx, lo):
+        sl = slice(lo + rank * per, lo + (rank + 1) * per)
+        sig = devt["sigmas"][sl].contiguous()
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        b = {"latent_batch": devt["latents"][sl].contiguous(), "prompt_embeds": devt["prompt"][sl].contiguous(), "add_text_embeds": devt["pooled"][sl].contiguous(),
+             "noise": devt["noise"][sl].contiguous()}
+        prepared = plugin.prepare_batch(b, {"global_step": idx})
+        loss, _ = plugin.loss_with_logs(prepared, plugin.model_predict(prepared))
+        (loss / 2).backward()
+
+    out = {}
+    # (a) a plain synchronised step
+    micro(0, 0)
+    out["sync"] = torch.cat([p.grad.detach().reshape(-1).float() for p in params]).cpu()
+    for p in params:
+        p.grad = None
+    # (b) accelerator.accumulate: one no_sync micro-step, then the boundary step (trainer.py:7009)
+    ctx = wrapped.no_sync() if how != "single" else __import__("contextlib").nullcontext()
+    with ctx:
+        micro(1, 0)
+    micro(2, Bg)
+    out["accum"] = torch.cat([p.grad.detach().reshape(-1).float() for p in params]).cpu()
+    torch.cuda.synchronize()
+    return out
+
+
+def _r03_worker(rank, world, init_file, out_dir):
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    out = {"unet_graph": _unet_graph_run(rank, world, True), "ddp_hook": _flux_ddp_run(rank, world, "ddp_hook"), "wrapper": _flux_ddp_run(rank, world, "wrapper")}
+    torch.save(out, os.path.join(out_dir, f"r03_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_hip_graph_with_two_ranks_and_the_ddp_seam_on_a_real_component():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_r03_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(d, f"r03_{r}.pt")) for r in range(2))
+    # (1) graph replay at N = 2
+    w0, l0, used0, n0 = r0["unet_graph"]
+    w1, l1, used1, _ = r1["unet_graph"]
+    assert used0 and used1 and n0 == 1, "the two-rank run must stay in hipGraph mode"
+    assert torch.equal(w0, w1), "replicas diverged under graph replay"
+    single, ls, _, _ = _unet_graph_run(0, 1, False)                      # one process, whole batch, eager launches
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(b)) for a, b in zip(l0, ls)), (l0, ls)          # logged loss = sample-weighted mean over ranks
+    diff = (w0 - single).abs().max().item()
+    print(f"[r03] UNet LoRA, hipGraph at N=2 vs one eager process on the concatenated batch after 4 steps: max |dw| = {diff:.3e}; losses {l0} vs {ls}")
+    assert diff <= 4 * 1e-4 * 0.5
+    # (2) DDP seam on the real Flux component: mean over ranks of the (accumulated) gradients == one process on the concatenated micro-batches
+    ref = _flux_ddp_run(0, 1, "single")
+    for how in ("ddp_hook", "wrapper"):
+        for k in ("sync", "accum"):
+            assert torch.equal(r0[how][k], r1[how][k]), (how, k)
+            rel = ((r0[how][k] - ref[k]).norm() / ref[k].norm()).item()
+            print(f"[r03] flux under {how}: {k} gradient vs single process: rel-L2 {rel:.3e}")
+            assert rel < 2e-5, (how, k, rel)
