@@ -96,6 +96,13 @@ int st355_timestep_proj(void* stream, const float* t /*[B]*/, void* out /*[B,dim
 int st355_silu(void* stream, const void* x, void* y, int64_t n);
 int st355_gelu_tanh(void* stream, const void* x, void* y, int64_t n);   /* GELU(approximate="tanh") as a pass of its own (after an fp8 Linear) */
 int st355_add(void* stream, const void* a, const void* b, void* y, int64_t n);
+/* TREAD token routing (helpers/training/tread.py:118-159, TREADRouter.start_route / end_route): per-sample row gather / scatter over [B, S, D] bf16 token
+ * buffers; idx [B, K] int32 = the kept positions (a prefix of the router's permutation: no duplicates inside a sample).  Row and batch strides in elements.
+ *   gather : out[b, j, :] = x[b, idx[b, j], :]         scatter: dst[b, idx[b, j], :] = src[b, j, :] */
+int st355_gather_rows(void* stream, const void* x, int64_t ld_x, int64_t batch_stride_x, const int* idx, void* out, int64_t ld_out, int64_t batch_stride_out,
+                      int B, int K, int D);
+int st355_scatter_rows(void* stream, const void* src, int64_t ld_src, int64_t batch_stride_src, const int* idx, void* dst, int64_t ld_dst, int64_t batch_stride_dst,
+                       int B, int K, int D);
 int st355_silu_bwd(void* stream, const void* x, const void* dy, void* dx, int64_t n);   /* dx = dy * silu'(x) */
 /* out[m,n] = in[m,n] * gate[(m / rows_per_batch) * gate_stride + n]  (gated-residual backward) */
 int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* gate, int64_t gate_stride,

@@ -582,3 +582,42 @@ extern "C" int st355_softmax_rows_bwd(void* stream, const void* p, void* dp, int
   hipLaunchKernelGGL(k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)p, (bf16*)dp, ld, n, scale);
   return st355_check_launch("softmax_rows_bwd");
 }
+
+
+// ---- TREAD token routing (helpers/training/tread.py:118-159): per-sample row gather / scatter over [B, S, D] token buffers ---------------------------
+// gather : out[b, j, :] = x[b, idx[b, j], :]      (start_route: kept tokens first, truncated to K; also the adjoint of the scatter below)
+// scatter: dst[b, idx[b, j], :] = src[b, j, :]    (end_route: routed tokens back into their slots of a copy of the pre-route sequence; idx rows are
+//                                                  duplicates-free — a permutation prefix — so plain stores, no atomics)
+// HBM-bound row copies: one 16-byte chunk per lane, grid-stride over B*K*(D/8) chunks.
+__global__ void __launch_bounds__(EW_THREADS) k_route_rows(const bf16* __restrict__ src, int64_t src_ld, int64_t src_bs, const int* __restrict__ idx,
+                                                          bf16* __restrict__ dst, int64_t dst_ld, int64_t dst_bs, int B, int K, int D8, int scatter) {
+  const int64_t total = (int64_t)B * K * D8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D8);
+    const int64_t r = i / D8;
+    const int j = (int)(r % K), b = (int)(r / K);
+    const int t = idx[(int64_t)b * K + j];
+    const int64_t so = scatter ? (int64_t)b * src_bs + (int64_t)j * src_ld : (int64_t)b * src_bs + (int64_t)t * src_ld;
+    const int64_t dof = scatter ? (int64_t)b * dst_bs + (int64_t)t * dst_ld : (int64_t)b * dst_bs + (int64_t)j * dst_ld;
+    *(bf16x8*)(dst + dof + c * 8) = *(const bf16x8*)(src + so + c * 8);
+  }
+}
+static int route_rows(void* stream, const void* src, int64_t src_ld, int64_t src_bs, const int* idx, void* dst, int64_t dst_ld, int64_t dst_bs, int B, int K, int D,
+                      int scatter, const char* what) {
+  ST_REQUIRE(src && idx && dst && B > 0 && K > 0 && D > 0 && D % 8 == 0, "route_rows: bad args (D must be a multiple of 8)");
+  ST_REQUIRE(src_ld % 8 == 0 && dst_ld % 8 == 0 && src_bs % 8 == 0 && dst_bs % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+             "route_rows: 16-byte aligned rows");
+  const int64_t n = (int64_t)B * K * D;
+  ProfScope ps(stream, ST355_K_ELEMENTWISE, 0.0, 4.0 * n);
+  hipLaunchKernelGGL(k_route_rows, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)src, src_ld, src_bs, idx, (bf16*)dst, dst_ld,
+                     dst_bs, B, K, D / 8, scatter);
+  return st355_check_launch(what);
+}
+extern "C" int st355_gather_rows(void* stream, const void* x, int64_t ld_x, int64_t batch_stride_x, const int* idx, void* out, int64_t ld_out,
+                                 int64_t batch_stride_out, int B, int K, int D) {
+  return route_rows(stream, x, ld_x, batch_stride_x, idx, out, ld_out, batch_stride_out, B, K, D, 0, "gather_rows");
+}
+extern "C" int st355_scatter_rows(void* stream, const void* src, int64_t ld_src, int64_t batch_stride_src, const int* idx, void* dst, int64_t ld_dst,
+                                  int64_t batch_stride_dst, int B, int K, int D) {
+  return route_rows(stream, src, ld_src, batch_stride_src, idx, dst, ld_dst, batch_stride_dst, B, K, D, 1, "scatter_rows");
+}

@@ -483,8 +483,16 @@ class ModelFoundation(ExplorativeModelingMixin):
         raise NotImplementedError(f"{self.NAME} has no ControlNet path on st355 (PixArt-Sigma has: pixart/model.py)")
 
     def tread_init(self):
-        """common.py:1737 raises in the base class too; TREAD token routing is SURVEY.md §8(f)3 (not built)"""
-        raise NotImplementedError("tread_init: TREAD routing is not implemented on the st355 path")
+        """<family>/model.py `tread_init` (e.g. sd3/model.py:326-347): hand the trained component a TREADRouter seeded from the run seed and the routes of
+        `config.tread_config`.  Built for the components that expose `set_router` (SD3; training/tread.py); the others refuse — never a silent no-op."""
+        tc = getattr(self.config, "tread_config", None)
+        if not tc or tc.get("routes", None) is None:
+            raise ValueError("TREAD training requires you to configure the routes in the TREAD config")
+        comp = self.get_trained_component()
+        if comp is None or not hasattr(comp, "set_router"):
+            raise NotImplementedError(f"tread_init: TREAD routing is not implemented for {self.NAME} on the st355 path (built: SD3)")
+        from .training.tread import TREADRouter
+        comp.set_router(TREADRouter(seed=getattr(self.config, "seed", None) or 42, device=self.accelerator.device), tc["routes"])
 
     def diffusion_blocks_init(self) -> None:
         if getattr(self.config, "diffusion_blocks_config", None):
@@ -506,8 +514,8 @@ class ModelFoundation(ExplorativeModelingMixin):
             return
         comp = self.get_trained_component()
         if comp is None or not hasattr(comp, "enable_gradient_checkpointing") or not hasattr(comp, "_checkpoint_segments"):
-            raise NotImplementedError(f"gradient_checkpointing: {self.NAME} has no recompute path on the st355 path (built: Flux); with 288 GB of HBM "
-                                      f"the step keeps its activations — drop the flag")
+            raise NotImplementedError(f"gradient_checkpointing: {self.NAME} has no recompute path on the st355 path (built: Flux, SD3, PixArt-Sigma + its "
+                                      f"ControlNet branch, the SDXL / SD1.x UNet); with 288 GB of HBM the step keeps its activations — drop the flag")
         comp.enable_gradient_checkpointing()
         interval = getattr(self.config, "gradient_checkpointing_interval", None)
         if interval is not None and int(interval) > 1:

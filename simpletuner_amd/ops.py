@@ -232,6 +232,32 @@ def add(a, b):
     return y
 
 
+def gather_rows(x, idx, out=None):
+    """out[b, j, :] = x[b, idx[b, j], :]; x [B, S, D] bf16 (last dim contiguous), idx [B, K] int32 -> [B, K, D]  (TREADRouter.start_route)"""
+    L = _l.load()
+    _dev(x, "x"); _dev(idx, "idx")
+    if x.dtype != BF16 or x.dim() != 3 or x.stride(2) != 1 or idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise _l.St355Error("gather_rows: x [B, S, D] bf16 with contiguous rows, idx [B, K] contiguous int32")
+    B, S, D = x.shape
+    K = idx.shape[1]
+    if out is None:
+        out = torch.empty(B, K, D, dtype=BF16, device=x.device)
+    _l.check(L.st355_gather_rows(_stream(), _ptr(x), x.stride(1), x.stride(0), _ptr(idx), _ptr(out), out.stride(1), out.stride(0), B, K, D), "gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, dst):
+    """dst[b, idx[b, j], :] = src[b, j, :] in place; src [B, K, D], dst [B, S, D] bf16, idx [B, K] int32  (TREADRouter.end_route)"""
+    L = _l.load()
+    _dev(src, "src"); _dev(dst, "dst"); _dev(idx, "idx")
+    if src.dtype != BF16 or dst.dtype != BF16 or src.dim() != 3 or dst.dim() != 3 or src.stride(2) != 1 or dst.stride(2) != 1 or idx.dtype != torch.int32:
+        raise _l.St355Error("scatter_rows: src [B, K, D] / dst [B, S, D] bf16 with contiguous rows, idx [B, K] int32")
+    B, K, D = src.shape
+    _l.check(L.st355_scatter_rows(_stream(), _ptr(src), src.stride(1), src.stride(0), _ptr(idx.contiguous()), _ptr(dst), dst.stride(1), dst.stride(0), B, K, D),
+             "scatter_rows")
+    return dst
+
+
 def scale_cols(x, gate, rows_per_batch: int, out=None):
     """out[m,n] = x[m,n] * gate[m // rows_per_batch, n]"""
     L = _l.load()

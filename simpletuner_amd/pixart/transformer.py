@@ -24,6 +24,7 @@ import torch.nn as nn
 from .. import ops
 from ..flux.transformer import _attach, _frozen
 from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE
+from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -250,7 +251,9 @@ class PixArtTransformer2DModel(nn.Module):
         return ops.gemm(e, P["caption_projection.linear_2.weight"], bias=P["caption_projection.linear_2.bias"])
 
     # ---- one block: forward (optionally saving) and backward ----
-    def _block_fwd(self, blk: _Block, h, ctx2d, kbias, t6, B, S, Sk, save: bool):
+    def _block_fwd(self, blk: _Block, h, ctx2d, kbias, t6, B, S, Sk, save: bool, exact: bool = False):
+        """`exact`: a forward whose activations are NOT kept but whose values must equal the keeping forward's bit for bit (the first pass over a checkpointed
+        segment): the GELU epilogue then also rounds its pre-activation through a (discarded) bf16 buffer, as the keeping form does"""
         D, H, W = self.inner_dim, self.H, blk.W
         Dp = H * HP
         scale = 1.0 / math.sqrt(self.hd)
@@ -279,7 +282,7 @@ class PixArtTransformer2DModel(nn.Module):
         ops.attn_cross_fwd(Q2, K2, V2t, O2, lse2, B, H, S, Sk, Skp, HP, scale, key_bias=kbias)
         h2 = ops.gemm(O2, W.out2_w, bias=W.out2_b, epilogue=EPI_ADD, aux_in=h1)
         n2 = ops.ln_modulate_fwd(h2, m[4], m[3], S)
-        pre = torch.empty(B * S, 4 * D, dtype=BF16, device=h.device) if save else None
+        pre = torch.empty(B * S, 4 * D, dtype=BF16, device=h.device) if (save or exact) else None
         a = ops.gemm(n2, W.ff1_w, bias=W.ff1_b, epilogue=EPI_GELU, aux_out=pre)
         yf = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
         h3 = ops.gemm(a, W.ff2_w, bias=W.ff2_b, epilogue=EPI_GATE_RESIDUAL, gate=m[5], aux_in=h2, rows_per_batch=S, aux_out=yf)
@@ -465,7 +468,7 @@ class PixArtTransformer2DModel(nn.Module):
         return (out,) if not return_dict else SimpleNamespace(sample=out)
 
 
-class PixArtSigmaControlNetTransformerModel(nn.Module):
+class PixArtSigmaControlNetTransformerModel(CheckpointPlanMixin, nn.Module):
     """trunk (frozen) + ControlNet adapter (trainable): pixart/controlnet.py:166-326.  `num_layers` copied blocks; `from_transformer` semantics:
     the adapter blocks start as copies of trunk blocks 0..N-1, before/after projections start at zero."""
 
@@ -563,23 +566,36 @@ class PixArtSigmaControlNetTransformerModel(nn.Module):
         t6, emb = T._conditioning(timestep, added_cond_kwargs, B, Hh, Ww)
         ctx2d = T._caption(enc)
         kb = T._key_bias(mask, B, Sk, dev)
-        ctx = SimpleNamespace(B=B, S=S, Sk=Sk, hh=hh, ww=ww, ctx2d=ctx2d, kb=kb, trunk=[], ctrl=[], cs_in=[], cs0=cs)
-        for i, tb in enumerate(T.blocks):
-            if 0 < i <= self.blocks_num:
-                blk, ex = self.cblocks[i - 1]
-                if i == 1:
-                    cs = ops.gemm(cs, ex.before_proj_weight, bias=ex.before_proj_bias, epilogue=EPI_ADD, aux_in=h)
-                cs, svc = T._block_fwd(blk, cs, ctx2d, kb, t6, B, S, Sk, save)
-                h = ops.gemm(cs, ex.after_proj_weight, bias=ex.after_proj_bias, epilogue=EPI_ADD, aux_in=h)
-                if save:
-                    ctx.ctrl.append(svc); ctx.cs_in.append(cs)
-            h, sv = T._block_fwd(tb, h, ctx2d, kb, t6, B, S, Sk, save and i >= 1)
-            if save:
-                ctx.trunk.append(sv)
+        ctx = SimpleNamespace(B=B, S=S, Sk=Sk, hh=hh, ww=ww, ctx2d=ctx2d, kb=kb, t6=t6, trunk={}, ctrl={}, cs_in={}, cs0=cs, ck={})
+        # activation-checkpoint plan over the UNITS of the wrapper's loop (unit i = control block i-1, if any, + trunk block i).  The reference's wrapper leaves
+        # checkpointing as a TODO (pixart/controlnet.py:270-273) and its trunk plans per block (pixart/transformer.py:627-700); same planner here
+        ctx.segs = self._checkpoint_segments(len(T.blocks)) if save else [(i, 1, False) for i in range(len(T.blocks))]
+        for (s0, n, ck) in ctx.segs:
+            if ck:
+                ctx.ck[s0] = (h, cs)
+            for i in range(s0, s0 + n):
+                h, cs = self._unit_fwd(i, h, cs, ctx, save and not ck)
         out, mod_out = T._head(h, emb, B, hh, ww)
         if save:
             ctx.h_final, ctx.mod_out = h, mod_out
         return out, ctx
+
+    def _unit_fwd(self, i: int, h, cs, ctx, save: bool):
+        """unit i of the wrapper's loop (pixart/controlnet.py:266-297): control block i-1 into the trunk's residual stream, then trunk block i"""
+        T = self.transformer
+        B, S, Sk, ctx2d, kb, t6 = ctx.B, ctx.S, ctx.Sk, ctx.ctx2d, ctx.kb, ctx.t6
+        if 0 < i <= self.blocks_num:
+            blk, ex = self.cblocks[i - 1]
+            if i == 1:
+                cs = ops.gemm(cs, ex.before_proj_weight, bias=ex.before_proj_bias, epilogue=EPI_ADD, aux_in=h)
+            cs, svc = T._block_fwd(blk, cs, ctx2d, kb, t6, B, S, Sk, save, exact=True)
+            h = ops.gemm(cs, ex.after_proj_weight, bias=ex.after_proj_bias, epilogue=EPI_ADD, aux_in=h)
+            if save:
+                ctx.ctrl[i - 1], ctx.cs_in[i - 1] = svc, cs
+        h, sv = T._block_fwd(T.blocks[i], h, ctx2d, kb, t6, B, S, Sk, save and i >= 1, exact=True)
+        if save:
+            ctx.trunk[i] = sv
+        return h, cs
 
     def _engine_backward(self, ctx, dout):
         T = self.transformer
@@ -587,19 +603,23 @@ class PixArtSigmaControlNetTransformerModel(nn.Module):
         dh = T._head_bwd(dout, ctx.h_final, ctx.mod_out, B, ctx.hh, ctx.ww)
         dcs = None
         for i in range(len(T.blocks) - 1, 0, -1):                  # trunk block 0 has nothing trainable upstream of it
-            dh = T._block_bwd(T.blocks[i], ctx.trunk[i], dh, ctx.ctx2d, ctx.kb, B, S, Sk)
-            ctx.trunk[i] = None
+            if i not in ctx.trunk:                                   # a checkpointed segment: re-run it from its kept input, keeping the activations this time
+                s0, n = next((a, c) for (a, c, ck) in ctx.segs if ck and a <= i < a + c)
+                hr, cr = ctx.ck.pop(s0)
+                for u in range(s0, s0 + n):
+                    hr, cr = self._unit_fwd(u, hr, cr, ctx, True)
+                del hr, cr
+            dh = T._block_bwd(T.blocks[i], ctx.trunk.pop(i), dh, ctx.ctx2d, ctx.kb, B, S, Sk)
             if i <= self.blocks_num:
                 blk, ex = self.cblocks[i - 1]
-                cs_out = ctx.cs_in[i - 1]
+                cs_out = ctx.cs_in.pop(i - 1)
                 # h' = h + after_proj(cs_out):  d after_proj, d cs_out (+ what the next control block sent back)
                 ops.gemm_tn(_p64(dh), _p64(cs_out), out=ex.G["after_proj.weight"])
                 tb = torch.empty(1, dh.shape[1], dtype=F32, device=dh.device)
                 ops.colsum_prod(dh, tb); ex.G["after_proj.bias"].copy_(tb[0])
                 wT = ex.after_proj_weight.t().contiguous()
                 dcs = ops.gemm(dh, wT) if dcs is None else ops.gemm(dh, wT, epilogue=EPI_ADD, aux_in=dcs)
-                dcs = T._block_bwd(blk, ctx.ctrl[i - 1], dcs, ctx.ctx2d, ctx.kb, B, S, Sk)
-                ctx.ctrl[i - 1] = None
+                dcs = T._block_bwd(blk, ctx.ctrl.pop(i - 1), dcs, ctx.ctx2d, ctx.kb, B, S, Sk)
                 if i == 1:                                         # cs_in = h + before_proj(cs0): h gets dcs too (unused: nothing trainable before it)
                     ops.gemm_tn(_p64(dcs), _p64(ctx.cs0), out=ex.G["before_proj.weight"])
                     ops.colsum_prod(dcs, tb); ex.G["before_proj.bias"].copy_(tb[0])

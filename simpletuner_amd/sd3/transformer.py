@@ -25,6 +25,7 @@ import torch.nn as nn
 from .. import ops
 from ..flux.transformer import FluxTransformer2DModel as _FluxEngine, LoraGroup, _attach, _frozen
 from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD
+from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -73,7 +74,7 @@ def _stream_problems(B: int, S: int, rows: int, pr: dict, after: Optional[list] 
 
 
 
-class SD3Transformer2DModel(nn.Module):
+class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
     def __init__(self, sample_size: int = 128, patch_size: int = 2, in_channels: int = 16, num_layers: int = 18,
                  attention_head_dim: int = 64, num_attention_heads: int = 18, joint_attention_dim: int = 4096,
                  caption_projection_dim: int = 1152, pooled_projection_dim: int = 2048, out_channels: int = 16,
@@ -123,6 +124,9 @@ class SD3Transformer2DModel(nn.Module):
         self._prepared = False
         self.accumulate_lora_grads = False
         self.gradient_checkpointing = False
+        self.gradient_checkpointing_interval = None
+        self.gradient_checkpointing_segment_stride = None
+        self._tread_router, self._tread_routes = None, None
         self.grad_sync = None
         self._last_grad_flat = None
         self.full = False
@@ -328,6 +332,99 @@ class SD3Transformer2DModel(nn.Module):
             self._cache[key] = hit
         return hit
 
+    def _block_fwd(self, blk, img, txt, env, save: bool):
+        """one JointTransformerBlock (sd3/transformer.py:145-241 `_sd3_apply_joint_transformer_block`): returns (img', txt' | None, saved activations | None).
+        Also the RECOMPUTE unit of the activation-checkpoint plans (training/checkpoint_plan.py): run again from a segment's kept input in backward, it
+        launches the same kernels in the same order on the same values — bit-identical activations, hence bit-identical gradients."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, Sp, cos, sin, mod, scale, full = env.B, env.Si, env.St, env.S, env.Sp, env.cos, env.sin, env.mod, env.scale, env.full
+        ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
+
+        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
+        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+        if blk.last:
+            mt = mod[:, blk.mod_off_c:blk.mod_off_c + 2 * D]
+            n_txt = ops.ln_modulate_fwd(txt, mt[:, :D], mt[:, D:2 * D], St)          # AdaLayerNormContinuous: (scale, shift)
+        else:
+            mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+            n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
+        qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
+        T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
+        kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk) if T_img is not None else {}
+        kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
+        # the image stream (4096 rows per sample: tile-aligned) is ONE segmented problem over the joint buffer; the 154 text rows stay per sample
+        after = []
+        ops.gemm_grouped(_stream_problems(B, S, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=_rows3(qkv, 0, Si, B, S), **kw_i), after)
+                         + _stream_problems(B, S, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=_rows3(qkv, Si, St, B, S), **kw_t), after))
+        for f in after:
+            f()
+        Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
+        mk = torch.zeros if Sp > S else torch.empty
+        Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, 0, S, Sp)
+        ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, Si, S, Sp)
+        O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+        ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
+        del Vt
+        x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
+        x1_txt = None if blk.last else torch.empty(B * St, D, dtype=BF16, device=dev)
+        T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
+        T_ao = (torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev)
+                if (not blk.last and blk.to_add_out.lora is not None) else None)
+        ya_i, ya_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
+        O_i, O_t = _rows3(O, 0, Si, B, S), _rows3(O, Si, St, B, S)
+        kw_i, kw_t = {}, {}
+        if ya_i is not None:
+            kw_i["aux_out"] = ya_i
+        if ya_t is not None:
+            kw_t["aux_out"] = ya_t
+        after = []
+        if B > 1 and St % 256:
+            O_t = O_t.reshape(B * St, D)                                  # the text rows of the attention output, gathered once for both uses below
+        if T_o is not None:
+            for pr in _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.lora.A_cat, out=T_o), after):
+                ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+            kw_i.update(a2=T_o, b2=blk.to_out.lora.B_blk)
+        probs = _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
+                                                gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i), after)
+        if not blk.last:
+            if T_ao is not None:
+                for pr in _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao), after):
+                    ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
+                kw_t.update(a2=T_ao, b2=blk.to_add_out.lora.B_blk)
+            probs += _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
+                                                     aux_in=txt, gate=mt[:, 2 * D:3 * D], rows_per_batch=St, **kw_t), after)
+        ops.gemm_grouped(probs)
+        for f in after:
+            f()
+        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+        hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
+        hpre_txt = x2_txt = n2_t = h_t = None
+        yf_i, yf_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
+        kf_i = dict(aux_out=yf_i) if yf_i is not None else {}
+        kf_t = dict(aux_out=yf_t) if yf_t is not None else {}
+        if blk.last:
+            h_i = ops.gemm(n2_i, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
+            x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D],
+                              rows_per_batch=Si, **kf_i)
+        else:
+            n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
+            hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
+            h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
+                                         dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
+            x2_img, x2_txt = ops.gemm_grouped([
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
+                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
+        if save:
+            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K,
+                                 Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
+                                 hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
+            if full:    # a full fine-tune also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
+                sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
+            return x2_img, x2_txt, sv
+        return x2_img, x2_txt, None
+
     def _engine_forward(self, latents, enc, pooled, timestep, save: bool, full: bool = False):
         D, H, hd = self.D, self.H, self.hd
         B, C, Hh, Ww = latents.shape
@@ -357,91 +454,41 @@ class SD3Transformer2DModel(nn.Module):
             ctx.emb = SimpleNamespace(patches=patches, enc2d=enc2d, tproj=tproj, t1=t1, st1=st1, pooled=pooled_b, p1=p1, sp1=sp1, temb=temb, st=st)
         ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
         scale = 1.0 / math.sqrt(hd)
-        for blk in self.blocks:
-            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
-            n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
-            if blk.last:
-                mt = mod[:, blk.mod_off_c:blk.mod_off_c + 2 * D]
-                n_txt = ops.ln_modulate_fwd(txt, mt[:, :D], mt[:, D:2 * D], St)          # AdaLayerNormContinuous: (scale, shift)
-            else:
-                mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-                n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
-            qkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
-            T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
-            T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
-            kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk) if T_img is not None else {}
-            kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk) if T_txt is not None else {}
-            # the image stream (4096 rows per sample: tile-aligned) is ONE segmented problem over the joint buffer; the 154 text rows stay per sample
-            after = []
-            ops.gemm_grouped(_stream_problems(B, S, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=_rows3(qkv, 0, Si, B, S), **kw_i), after)
-                             + _stream_problems(B, S, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=_rows3(qkv, Si, St, B, S), **kw_t), after))
-            for f in after:
-                f()
-            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
-            mk = torch.zeros if Sp > S else torch.empty
-            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, 0, S, Sp)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, Si, S, Sp)
-            O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
-            del Vt
-            x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
-            x1_txt = None if blk.last else torch.empty(B * St, D, dtype=BF16, device=dev)
-            T_o = torch.empty(B * Si, blk.to_out.lora.K2, dtype=BF16, device=dev) if blk.to_out.lora is not None else None
-            T_ao = (torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev)
-                    if (not blk.last and blk.to_add_out.lora is not None) else None)
-            ya_i, ya_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
-            O_i, O_t = _rows3(O, 0, Si, B, S), _rows3(O, Si, St, B, S)
-            kw_i, kw_t = {}, {}
-            if ya_i is not None:
-                kw_i["aux_out"] = ya_i
-            if ya_t is not None:
-                kw_t["aux_out"] = ya_t
-            after = []
-            if B > 1 and St % 256:
-                O_t = O_t.reshape(B * St, D)                                  # the text rows of the attention output, gathered once for both uses below
-            if T_o is not None:
-                for pr in _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.lora.A_cat, out=T_o), after):
-                    ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
-                kw_i.update(a2=T_o, b2=blk.to_out.lora.B_blk)
-            probs = _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
-                                                    gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i), after)
-            if not blk.last:
-                if T_ao is not None:
-                    for pr in _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao), after):
-                        ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
-                    kw_t.update(a2=T_ao, b2=blk.to_add_out.lora.B_blk)
-                probs += _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
-                                                         aux_in=txt, gate=mt[:, 2 * D:3 * D], rows_per_batch=St, **kw_t), after)
-            ops.gemm_grouped(probs)
-            for f in after:
-                f()
-            n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
-            hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
-            hpre_txt = x2_txt = n2_t = h_t = None
-            yf_i, yf_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
-            kf_i = dict(aux_out=yf_i) if yf_i is not None else {}
-            kf_t = dict(aux_out=yf_t) if yf_t is not None else {}
-            if blk.last:
-                h_i = ops.gemm(n2_i, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
-                x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D],
-                                  rows_per_batch=Si, **kf_i)
-            else:
-                n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
-                hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
-                h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
-                                             dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
-                x2_img, x2_txt = ops.gemm_grouped([
-                    dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
-                    dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
-            if save:
-                sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K,
-                                     Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
-                                     hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
-                if full:    # a full fine-tune also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
-                    sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
-                ctx.blocks.append(sv)
-            img, txt = x2_img, x2_txt
+        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, scale=scale, full=full)
+        ctx.env, ctx.blocks, ctx.ck = env, [None] * len(self.blocks), {}
+        # activation-checkpoint plan (sd3/transformer.py:716-833; training/checkpoint_plan.py): a checkpointed segment keeps only its input
+        from ..training.checkpoint_plan import segments as _segments
+        ctx.segs = _segments(len(self.blocks), bool(save and self.gradient_checkpointing), self.gradient_checkpointing_interval,
+                             self.gradient_checkpointing_segment_stride)
+        # TREAD routing (sd3/transformer.py:694-706, 796-803; training/tread.py): only while training, between the route's two blocks the IMAGE stream is a
+        # per-sample subset of its tokens.  Under routing the reference drops the segmented checkpoint form for the per-block one (:716-728)
+        from ..training.tread import normalise_routes
+        routes = normalise_routes(self._tread_routes, len(self.blocks)) if (save and self.training and self._tread_router is not None) else []
+        if routes:
+            from ..training.checkpoint_plan import per_block as _per_block
+            ctx.segs = _per_block(len(self.blocks), bool(self.gradient_checkpointing), self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride)
+        ctx.envs, ctx.route_start, ctx.route_end = [env] * len(self.blocks), {}, {}
+        rp, info, saved, env_cur = 0, None, None, env
+        for (s0, n, ck) in ctx.segs:
+            for bi in range(s0, s0 + n):
+                if rp < len(routes) and info is None and bi == routes[rp]["start_layer_idx"]:
+                    info = self._tread_router.get_mask(img.view(B, Si, D), mask_ratio=routes[rp]["selection_ratio"], force_keep=getattr(self, "_force_keep_mask", None))
+                    saved = img
+                    img = ops.gather_rows(img.view(B, Si, D), info.keep_i32()).view(-1, D)          # TREADRouter.start_route
+                    K = info.ids_keep.shape[1]
+                    env_cur = SimpleNamespace(**{**vars(env), "Si": K, "S": K + St, "Sp": (K + St + 63) // 64 * 64})
+                    ctx.route_start[bi] = info
+                if ck and bi == s0:
+                    ctx.ck[s0] = (img, txt)
+                ctx.envs[bi] = env_cur
+                img, txt, ctx.blocks[bi] = self._block_fwd(self.blocks[bi], img, txt, env_cur, save and not ck)
+                if info is not None and bi == routes[rp]["end_layer_idx"]:
+                    full_seq = saved.clone()                                                        # TREADRouter.end_route(original_x=saved)
+                    ops.scatter_rows(img.view(B, env_cur.Si, D), info.keep_i32(), full_seq.view(B, Si, D))
+                    img, ctx.route_end[bi] = full_seq, info
+                    info, saved, env_cur, rp = None, None, env, rp + 1
+        if info is not None:
+            raise ValueError("TREAD route does not end inside the block stack (end_layer_idx)")
         # ---- output head: AdaLayerNormContinuous (scale, shift), proj_out, unpatchify "nhwpqc->nchpwq" ----
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         n_out = ops.ln_modulate_fwd(img, mo[:, :D], mo[:, D:2 * D], Si)
@@ -451,6 +498,17 @@ class SD3Transformer2DModel(nn.Module):
             if full:
                 ctx.n_out = n_out
         return ops.unpatchify(out.view(B, Si, -1), self.out_channels, Hh, Ww, order=1), ctx
+
+    def set_router(self, router, routes):
+        """sd3/transformer.py:407-409: TREAD router + [{selection_ratio, start_layer_idx, end_layer_idx}] (training/tread.py)"""
+        self._tread_router, self._tread_routes = router, routes
+
+    def _recompute_segment(self, ctx, li: int):
+        """backward reached block `li` of a checkpointed segment: re-run the segment's forward from its kept input, this time keeping the activations"""
+        s0, n = next((a, c) for (a, c, ck) in ctx.segs if ck and a <= li < a + c)
+        img, txt = ctx.ck.pop(s0)
+        for bi in range(s0, s0 + n):
+            img, txt, ctx.blocks[bi] = self._block_fwd(self.blocks[bi], img, txt, ctx.envs[bi], True)
 
     def _engine_backward(self, ctx, dout):
         if not self._prepared:
@@ -466,6 +524,13 @@ class SD3Transformer2DModel(nn.Module):
         d_txt = None
         del dn, dpk
         for li in range(len(self.blocks) - 1, -1, -1):
+            if ctx.blocks[li] is None:
+                self._recompute_segment(ctx, li)
+            if li in ctx.route_end:                       # backward enters a TREAD route at its END: the routed blocks see only the kept tokens' gradient rows
+                r_info = ctx.route_end[li]
+                d_full = d_img
+                d_img = ops.gather_rows(d_full.view(B, ctx.Si, D), r_info.keep_i32()).view(-1, D)
+            Si, S, Sp = ctx.envs[li].Si, ctx.envs[li].S, ctx.envs[li].Sp
             blk, sv = self.blocks[li], ctx.blocks[li]
             ctx.blocks[li] = None
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
@@ -537,6 +602,9 @@ class SD3Transformer2DModel(nn.Module):
                 c_scale = mt[:, :D] if blk.last else mt[:, D:2 * D]
                 d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, c_scale, St, dres=dx1_t)
             del dqkv, sv, dns
+            if li in ctx.route_start and d_img is not None:   # ... and leaves it at its START: skipped tokens keep the gradient they had at the route's end
+                ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
+                d_img, d_full = d_full, None
         return None
 
     # ------------------------------------------------------------------------------------------------
@@ -636,6 +704,13 @@ class SD3Transformer2DModel(nn.Module):
         if sync is not None:
             sync.ready(self._head_arena_lo, self.grad_arena.numel())        # proj_out gradients are final
         for li in range(len(self.blocks) - 1, -1, -1):
+            if ctx.blocks[li] is None:
+                self._recompute_segment(ctx, li)
+            if li in ctx.route_end:                       # backward enters a TREAD route at its END: the routed blocks see only the kept tokens' gradient rows
+                r_info = ctx.route_end[li]
+                d_full = d_img
+                d_img = ops.gather_rows(d_full.view(B, ctx.Si, D), r_info.keep_i32()).view(-1, D)
+            Si, S, Sp = ctx.envs[li].Si, ctx.envs[li].S, ctx.envs[li].Sp
             blk, sv = self.blocks[li], ctx.blocks[li]
             ctx.blocks[li] = None
             if sync is not None and li + 1 < len(self.blocks):
@@ -701,6 +776,10 @@ class SD3Transformer2DModel(nn.Module):
                 mod_grads(dn_t, sv.n_txt, mt, St, 0, 1, dmt)
                 d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
             del dqkv, sv, dn_i, dn_t, dq_i, dq_t
+            if li in ctx.route_start:
+                ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
+                d_img, d_full = d_full, None
+        Si, S, Sp = ctx.Si, ctx.S, ctx.Sp
         # ---- embedders ----
         em = ctx.emb
         wgrad(self.l_patch, d_img, em.patches)                              # PatchEmbed conv == GEMM on the patches; the position table is a buffer
@@ -739,7 +818,8 @@ class SD3Transformer2DModel(nn.Module):
     # public forward (reference signature: sd3/transformer.py:560-575)
     # ------------------------------------------------------------------------------------------------
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, block_controlnet_hidden_states=None,
-                joint_attention_kwargs=None, return_dict: bool = True, **unsupported):
+                joint_attention_kwargs=None, return_dict: bool = True, force_keep_mask=None, **unsupported):
+        self._force_keep_mask = force_keep_mask            # TREAD: tokens that may never be routed away (sd3/transformer.py:571, 699-703)
         if block_controlnet_hidden_states is not None:
             raise NotImplementedError("SD3 ControlNet residuals are not wired to the st355 path yet")
         for k, v in unsupported.items():

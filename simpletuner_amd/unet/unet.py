@@ -27,6 +27,7 @@ import torch.nn as nn
 from .. import ops
 from ..flux.transformer import LoraGroup, _attach, _frozen
 from ..ops import EPI_ADD, EPI_NONE
+from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -50,7 +51,8 @@ class Tape:
     def rec(self, outs, ins, fn):
         self.ops.append((outs, ins, fn))
 
-    def backward(self, out, dout):
+    def backward(self, out, dout, wrt=None):
+        """sweep the record backwards from d(out) = dout; `wrt`: tensors whose accumulated gradients are returned (a checkpointed unit's inputs)"""
         grads = {id(out): dout}
         while self.ops:
             outs, ins, fn = self.ops.pop()          # popping frees the closure's saved activations as the sweep proceeds
@@ -63,9 +65,10 @@ class Tape:
                     continue
                 k = id(i)
                 grads[k] = ops.add(grads[k], d) if k in grads else d
+        return None if wrt is None else [grads.get(id(t)) for t in wrt]
 
 
-class UNet2DConditionModel(nn.Module):
+class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
     def __init__(self, in_channels: int = 4, out_channels: int = 4, block_out_channels=(320, 640, 1280), layers_per_block: int = 2,
                  down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
                  up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 2, 10),
@@ -689,10 +692,38 @@ class UNet2DConditionModel(nn.Module):
         return y
 
     # ------------------------------------------------------------------------------------------------
+    def _ckpt_unit(self, T, fn, x, cond):
+        """One checkpoint unit = one ResnetBlock2D or one Transformer2DModel (diffusers wraps exactly these when `enable_gradient_checkpointing()` is on:
+        the reference's UNet families use diffusers' own flag, common.py:3560-3636; interval / stride select units as `should_checkpoint_block` does).
+        Checkpointed: the unit runs WITHOUT a tape, and ONE record stands for it whose backward re-runs it on a private tape — same kernels, same order,
+        same values: bit-identical gradients — and sweeps that tape.  fn(T, x, cond) -> y; gradients flow to x and cond."""
+        idx = self._unit_counter
+        self._unit_counter += 1
+        k, s_ = self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride
+        on = self.gradient_checkpointing and (k is None or k <= 1 or (idx % k == 0 if s_ is None else idx % s_ < k))
+        if T is None:
+            return fn(None, x, cond)
+        if not on:
+            # kept unit: recorded on a private tape as well, so that its input gradients are summed in the SAME association as in the recomputed form
+            # (bf16 sums are not associative: x also feeds skip connections) — checkpointed and direct runs then agree bit for bit
+            Tk = Tape()
+            yk = fn(Tk, x, cond)
+            T.rec([yk], [x, cond], lambda dy: tuple(Tk.backward(yk, dy, wrt=[x, cond])))
+            return yk
+        y = fn(None, x, cond)
+
+        def bwd(dy):
+            T2 = Tape()
+            y2 = fn(T2, x, cond)
+            return tuple(T2.backward(y2, dy, wrt=[x, cond]))
+        T.rec([y], [x, cond], bwd)
+        return y
+
     def _engine_forward(self, sample, timestep, ehs, text_embeds, time_ids, save: bool):
         c = self.config
         dev = self.device_
         T = Tape() if save else None
+        self._unit_counter = 0
         for g_ in self.lora_groups:
             g_.pack()
         B, Cin, H, W = sample.shape
@@ -737,17 +768,17 @@ class UNet2DConditionModel(nn.Module):
         h_, w_ = H, W
         for i, blk in enumerate(self.down):
             for j, r in enumerate(blk.resnets):
-                x = self._resnet_fwd(T, r, x, se, B, h_, w_)
+                x = self._ckpt_unit(T, lambda T_, x_, se_, r=r, h_=h_, w_=w_: self._resnet_fwd(T_, r, x_, se_, B, h_, w_), x, se)
                 if blk.attns:
-                    x = self._transformer_fwd(T, blk.attns[j], x, ctx2d, B, h_, w_, Sk)
+                    x = self._ckpt_unit(T, lambda T_, x_, c_, a=blk.attns[j], h_=h_, w_=w_: self._transformer_fwd(T_, a, x_, c_, B, h_, w_, Sk), x, ctx2d)
                 skips.append(x)
             if blk.down is not None:
                 x = self._downsample(T, blk.down, x, B, h_, w_)
                 h_, w_ = h_ // 2, w_ // 2
                 skips.append(x)
-        x = self._resnet_fwd(T, self.mid.r0, x, se, B, h_, w_)
-        x = self._transformer_fwd(T, self.mid.attn, x, ctx2d, B, h_, w_, Sk)
-        x = self._resnet_fwd(T, self.mid.r1, x, se, B, h_, w_)
+        x = self._ckpt_unit(T, lambda T_, x_, se_, h_=h_, w_=w_: self._resnet_fwd(T_, self.mid.r0, x_, se_, B, h_, w_), x, se)
+        x = self._ckpt_unit(T, lambda T_, x_, c_, h_=h_, w_=w_: self._transformer_fwd(T_, self.mid.attn, x_, c_, B, h_, w_, Sk), x, ctx2d)
+        x = self._ckpt_unit(T, lambda T_, x_, se_, h_=h_, w_=w_: self._resnet_fwd(T_, self.mid.r1, x_, se_, B, h_, w_), x, se)
         for i, blk in enumerate(self.up):
             for j, r in enumerate(blk.resnets):
                 sk = skips.pop()
@@ -755,9 +786,9 @@ class UNet2DConditionModel(nn.Module):
                 cat = torch.cat([x, sk], dim=1)
                 if T is not None:
                     T.rec([cat], [x, sk], (lambda c1_: (lambda d: (d[:, :c1_].contiguous(), d[:, c1_:].contiguous())))(c1))
-                x = self._resnet_fwd(T, r, cat, se, B, h_, w_)
+                x = self._ckpt_unit(T, lambda T_, x_, se_, r=r, h_=h_, w_=w_: self._resnet_fwd(T_, r, x_, se_, B, h_, w_), cat, se)
                 if blk.attns:
-                    x = self._transformer_fwd(T, blk.attns[j], x, ctx2d, B, h_, w_, Sk)
+                    x = self._ckpt_unit(T, lambda T_, x_, c_, a=blk.attns[j], h_=h_, w_=w_: self._transformer_fwd(T_, a, x_, c_, B, h_, w_, Sk), x, ctx2d)
             if blk.up is not None:
                 u = ops.upsample2x(x, B, h_, w_)
                 if T is not None:

@@ -112,3 +112,37 @@ def test_pixart_fp8_trunk_matches_fp8_oracle():
     r8, r = _rel(out.cpu(), ref8), _rel(out.cpu(), ref)
     print(f"[pixart fp8 trunk] vs fp8 oracle {r8:.3e}, vs fp32 oracle {r:.3e} (fp8 oracle vs fp32 oracle {_rel(ref8, ref):.3e})")
     assert r8 < 5e-2 and r < 2e-1
+
+
+@pytest.mark.parametrize("mode,interval,stride", [("layer", None, None), ("seg2_stride3", 2, 3)])
+def test_pixart_controlnet_checkpointed_gradients_equal_direct_gradients(mode, interval, stride):
+    """SURVEY.md §8(f)3 for the PixArt path (planner of pixart/transformer.py:627-700 over the ControlNet wrapper's loop units): recomputed segments give the
+    BIT-identical adapter gradient arena and prediction, holding fewer activations between forward and backward"""
+    from simpletuner_amd.pixart.transformer import PixArtSigmaControlNetTransformerModel, PixArtTransformer2DModel
+    dev = "cuda:0"
+
+    def run(ckpt):
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        m = PixArtTransformer2DModel(device=dev, **ARCH)
+        m.init_synthetic(5)
+        cn = PixArtSigmaControlNetTransformerModel(m, num_layers=3)
+        cn.init_adapter_synthetic(seed=9, std=0.05)
+        if ckpt:
+            cn.enable_gradient_checkpointing()
+            cn.set_gradient_checkpointing_interval(interval)
+            cn.set_gradient_checkpointing_segment_stride(stride)
+        lat, cond, enc, mask, t = (v.to(dev) for v in _inputs())
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        out = cn(lat, encoder_hidden_states=enc, timestep=t, controlnet_cond=cond, encoder_attention_mask=mask, return_dict=False)[0]
+        loss = (out.float() ** 2).mean()
+        kept = torch.cuda.memory_allocated() - base
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), cn.grad_arena.detach().clone(), kept
+    o0, g0, kept0 = run(False)
+    o1, g1, kept1 = run(True)
+    assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.float().abs().sum().item() > 0
+    print(f"[ckpt pixart controlnet] {mode}: memory held between forward and backward {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB")
+    assert kept1 < kept0

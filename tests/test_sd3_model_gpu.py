@@ -252,3 +252,115 @@ def test_flow_match_sampling_loop_runs_the_plugin_forward_and_matches_manual_eul
         x = (x.float() + (sig[i + 1] - sig[i]) * v).to(v.dtype)          # diffusers' arithmetic: the 0-dim sigma difference scales v in v's dtype
     assert torch.isfinite(out.float()).all() and torch.equal(out, x)
     assert torch.equal(flow_match_euler_sample(predict, x0.clone(), sched, num_inference_steps=3), out)
+
+
+@pytest.mark.parametrize("mode,interval,stride,full", [("layer", None, None, False), ("seg2_stride3", 2, 3, False), ("interval2", 2, None, True), ("layer", None, None, True)])
+def test_sd3_checkpointed_gradients_equal_direct_gradients(mode, interval, stride, full):
+    """SURVEY.md §8(f)3 for SD3 (sd3/transformer.py:716-833; the published-table rows `layer` / `interval2` / `seg2-stride4`,
+    documentation/experimental/SEGMENTED_CHECKPOINTING.md:801-805): a checkpointed segment keeps only its input and is re-run in backward with the same kernels in
+    the same order — prediction and every gradient (LoRA adapters, or every parameter of the full fine-tune) are BIT-identical to the run that keeps everything"""
+    def run(ckpt):
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        plugin, trainer, cpu, devt = _build(4, 2, 16, 16, 24, rank=8)
+        model = plugin.get_trained_component()
+        if full:
+            del plugin, trainer, model
+            from simpletuner_amd.sd3.model import SD3
+            from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+            cfg = default_config(model_family="sd3", model_type="full", train_batch_size=2, seed=3, learning_rate=1e-4, flow_schedule_shift=3.0)
+            acc = St355Accelerator(torch.device("cuda:0"))
+            plugin = SD3(cfg, acc)
+            plugin.load_model(**_arch(4))
+            plugin.enable_full_finetune()
+            trainer = Trainer(cfg, plugin, acc)
+            model = plugin.get_trained_component()
+        plugin.config.gradient_checkpointing = ckpt
+        plugin.config.gradient_checkpointing_interval, plugin.config.gradient_checkpointing_segment_stride = interval, stride
+        plugin.configure_gradient_checkpointing()
+        assert model.gradient_checkpointing is ckpt
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+        base = torch.cuda.memory_allocated()
+        out = plugin.model_predict(prepared)
+        loss, _ = plugin.loss_with_logs(prepared, out)
+        kept = torch.cuda.memory_allocated() - base                    # what the forward left alive for the backward
+        loss.backward()
+        return out["model_prediction"].detach().clone(), [p.grad.detach().clone() for p in trainer.params], kept, model._checkpoint_segments(4)
+    p0, g0, kept0, _ = run(False)
+    p1, g1, kept1, segs = run(True)
+    assert any(ck for (_, _, ck) in segs)
+    assert torch.equal(p0, p1)
+    assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    print(f"[ckpt sd3 {'full' if full else 'lora'}] {mode}: activations held {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB, plan {segs}")
+    assert kept1 < kept0
+
+
+def test_sd3_tread_routing_matches_executed_reference_and_oracle():
+    """TREAD (helpers/training/tread.py; sd3/transformer.py:694-706, 796-803).  (1) the row gather / scatter kernels against torch indexing; (2) a routed SD3
+    LoRA step on the HIP path against the oracle replaying the SAME router permutations (the oracle's routing itself is pinned to the executed reference model:
+    tests/test_ref_models_cpu.py::test_sd3_oracle_reproduces_reference_model[sd3-tread]); (3) per-block checkpointing under routing is bit-identical."""
+    from simpletuner_amd import ops
+    from simpletuner_amd.training.tread import ReplayRouter, TREADRouter
+    dev = "cuda:0"
+    x = torch.randn(3, 40, 64, device=dev).to(torch.bfloat16)
+    r = TREADRouter(seed=5, device=dev)
+    info = r.get_mask(x, mask_ratio=0.5)
+    assert info.ids_keep.shape == (3, 20) and torch.equal(torch.sort(info.ids_shuffle, dim=1)[0], torch.arange(40, device=dev).expand(3, -1))
+    small = r.start_route(x, info)
+    assert torch.equal(small, torch.take_along_dim(x, info.ids_keep.unsqueeze(-1).expand(-1, -1, 64), dim=1))
+    back = r.end_route(small * 2, info, original_x=x)
+    want = x.clone(); want.scatter_(1, info.ids_keep.unsqueeze(-1).expand(-1, -1, 64), small * 2)
+    assert torch.equal(back, want)
+
+    def run(ckpt):
+        plugin, trainer, cpu, devt = _build(4, 2, 16, 16, 24, rank=8)
+        model = plugin.get_trained_component()
+        g = torch.Generator().manual_seed(11)
+        B, Si = 2, 64
+        perm = torch.stack([torch.randperm(Si, generator=g) for _ in range(B)])
+        K = Si - int(round(Si * 0.5))
+        rec = {"mask": torch.ones(B, Si, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+               "ids_restore": torch.argsort(perm, dim=1)}
+        routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]
+        model.set_router(ReplayRouter([rec]), routes)
+        model.train()
+        if ckpt:
+            model.enable_gradient_checkpointing()
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        P, lora, scale = _oracle_state(model)
+        prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+        out = plugin.model_predict(prepared)
+        loss, _ = plugin.loss_with_logs(prepared, out)
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if ".lora_" in n}
+        return plugin, model, cpu, P, lora, scale, out["model_prediction"].detach().clone(), loss.detach().clone(), grads, rec, routes
+
+    plugin, model, cpu, P, lora, scale, pred, loss, grads, rec, routes = run(False)
+    s = cpu["sigmas"].view(-1, 1, 1, 1)
+    noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
+    target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    o_pred = OS.sd3_forward(P, _ocfg(model), noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, lora=lp, lora_scale=scale,
+                            tread={"routes": routes, "mask_infos": [rec]})
+    o_loss = ((o_pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    o_loss.backward()
+    rr, cc = PU.rel_l2(pred, o_pred), PU.cos_sim(pred, o_pred)
+    print(f"[tread sd3] routed prediction vs oracle (same permutations): rel-L2 {rr:.3e} cos {cc:.6f}; loss hip {loss.item():.6f} oracle {o_loss.item():.6f}")
+    assert rr < 2e-2 and cc > 0.9995 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
+    # and routing changed the result (the route is live): the un-routed oracle prediction differs
+    plain = OS.sd3_forward(P, _ocfg(model), noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, lora={k: (a.detach(), b.detach()) for k, (a, b) in lp.items()},
+                           lora_scale=scale)
+    assert PU.rel_l2(plain, o_pred) > 5e-2
+    worst = 0.0
+    for name, g in grads.items():
+        key = name.split(".lora_")[0]
+        ref = lp[key][0 if ".lora_A." in name else 1].grad
+        rg = PU.rel_l2(g, ref)
+        worst = max(worst, rg)
+        assert rg < 5e-2, (name, rg)
+    print(f"[tread sd3] worst adapter gradient rel-L2 {worst:.3e}")
+    _, _, _, _, _, _, pred_c, _, grads_c, _, _ = run(True)
+    assert torch.equal(pred, pred_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)

@@ -210,3 +210,43 @@ def test_ddpm_prepare_batch_offset_noise_and_input_perturbation():
     a, b = pl.noise_schedule.mix_coefficients(t.to(dev))
     ref = a.view(-1, 1, 1, 1) * lat.float() + b.view(-1, 1, 1, 1) * n_in
     assert _rel(out["noisy_latents"], ref) < 5e-3
+
+
+@pytest.mark.parametrize("mode,interval,stride,lora", [("layer", None, None, False), ("layer", None, None, True), ("every_second_unit", 2, None, False)])
+def test_unet_checkpointed_gradients_equal_direct_gradients(mode, interval, stride, lora):
+    """SURVEY.md §8(f)3 for the UNet families (diffusers' `enable_gradient_checkpointing`: every ResnetBlock2D / transformer is its own checkpoint — the `layer`
+    rows of documentation/experimental/SEGMENTED_CHECKPOINTING.md:774-776, 834-836): a checkpointed unit runs without a tape and is re-run on a private tape in
+    backward — prediction and the gradient arena are BIT-identical to the run that records everything, with fewer activations alive between forward and backward"""
+    from simpletuner_amd.unet.unet import UNet2DConditionModel
+    dev = "cuda:0"
+
+    def run(ckpt):
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        m = UNet2DConditionModel(device=dev, **SMALL)
+        m.init_synthetic(5)
+        if lora:
+            m.add_lora_adapter(rank=8, alpha=8.0, seed=4, init_b_std=0.05)
+        else:
+            m.enable_full_finetune()
+        if ckpt:
+            m.enable_gradient_checkpointing()
+            m.set_gradient_checkpointing_interval(interval)
+            m.set_gradient_checkpointing_segment_stride(stride)
+        sample, t, ehs, te, ti = _inputs(2, 16, 16, dev, seed=1)
+        target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9)).to(dev)
+        args = (sample.to(dev), t.to(dev), ehs.to(dev), None)
+        ack = {"text_embeds": te.to(dev), "time_ids": ti.to(dev)}
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        out = m(*args, added_cond_kwargs=ack, return_dict=False)[0]
+        loss = ((out.float() - target) ** 2).mean()
+        kept = torch.cuda.memory_allocated() - base                    # what the forward left alive for the backward
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), torch.cat([p.grad.detach().reshape(-1).float() for p in m.trainable_parameters()]).clone(), kept, m._unit_counter
+    o0, g0, kept0, _ = run(False)
+    o1, g1, kept1, units = run(True)
+    assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.abs().sum().item() > 0
+    print(f"[ckpt unet {'lora' if lora else 'full'}] {mode}: {units} units, memory held between forward and backward {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB")
+    assert kept1 < kept0
