@@ -157,31 +157,167 @@ def flow_match_euler_sample(predict: Callable[[torch.Tensor, torch.Tensor], torc
     return x
 
 
+class DDIMScheduler:
+    """The reference's DEFAULT validation scheduler of its epsilon / v-prediction families (`DEFAULT_NOISE_SCHEDULER = "ddim"`: sdxl/model.py:55,
+    sd1x/model.py:45, pixart/model.py:57; `SCHEDULER_NAME_MAP`, training/validation.py:88-102) — diffusers' DDIMScheduler, deterministic form (eta = 0),
+    with the Stable Diffusion scheduler_config defaults (scaled_linear betas 0.00085-0.012, 1000 steps, `timestep_spacing="leading"`, `steps_offset=1`,
+    `clip_sample=False`, `set_alpha_to_one=False`).  diffusers is un-vendored and no copy of this class exists in the reference tree: the update is the
+    published DDIM rule (Song et al., eq. 12 with sigma = 0),
+        x0 = (x_t - sqrt(1 - a_t) eps) / sqrt(a_t),      x_{t'} = sqrt(a_{t'}) x0 + sqrt(1 - a_{t'}) eps,
+    pinned here by its exact-recovery property (with the true eps of x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps every step lands on the same x0 / eps pair:
+    tests/test_sampling_cpu.py) and sharing its alpha-bar table with the training-side DDPMSchedule (foundation.py), which IS pinned to reference code."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012, beta_schedule: str = "scaled_linear",
+                 clip_sample: bool = False, set_alpha_to_one: bool = False, steps_offset: int = 1, prediction_type: str = "epsilon",
+                 timestep_spacing: str = "leading", rescale_betas_zero_snr: bool = False):
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"{beta_schedule} is not implemented for DDIMScheduler(st355)")
+        if rescale_betas_zero_snr:
+            from .foundation import enforce_zero_terminal_snr
+            betas = enforce_zero_terminal_snr(betas)
+        if prediction_type not in ("epsilon", "v_prediction", "sample"):
+            raise ValueError(f"prediction_type given as {prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
+        if clip_sample:
+            raise NotImplementedError("clip_sample is a pixel-space option; latent models run with clip_sample=False")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule,
+                                      clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset, prediction_type=prediction_type,
+                                      timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.int64)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        if num_inference_steps > T:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`: {T}")
+        self.num_inference_steps = num_inference_steps
+        sp = self.config.timestep_spacing
+        if sp == "linspace":
+            ts = np.linspace(0, T - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        elif sp == "leading":
+            ts = (np.arange(0, num_inference_steps) * (T // num_inference_steps)).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        elif sp == "trailing":
+            ts = np.round(np.arange(T, 0, -T / num_inference_steps)).astype(np.int64) - 1
+        else:
+            raise ValueError(f"{sp} is not supported. Please make sure to choose one of 'leading' or 'trailing'.")
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0, return_dict: bool = True, **_unused):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if eta != 0.0:
+            raise NotImplementedError("DDIMScheduler(st355): the deterministic form (eta = 0) is built")
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t].to(torch.float32).item()
+        a_prev = (self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod).to(torch.float32).item()
+        x, out = sample.to(torch.float32), model_output.to(torch.float32)
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            x0 = (x - (1 - a_t) ** 0.5 * out) / a_t ** 0.5
+            eps = out
+        elif pt == "sample":
+            x0 = out
+            eps = (x - a_t ** 0.5 * x0) / (1 - a_t) ** 0.5
+        else:                                                           # v_prediction
+            x0 = a_t ** 0.5 * x - (1 - a_t) ** 0.5 * out
+            eps = a_t ** 0.5 * out + (1 - a_t) ** 0.5 * x
+        prev = (a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps).to(model_output.dtype)
+        return SimpleNamespace(prev_sample=prev, pred_original_sample=x0.to(model_output.dtype)) if return_dict else (prev,)
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+def ddim_sample(predict: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], latents: torch.Tensor, scheduler: DDIMScheduler, num_inference_steps: int,
+                on_step: Optional[Callable[[int, torch.Tensor], None]] = None) -> torch.Tensor:
+    """the denoising loop of the epsilon / v pipelines (sdxl/pipeline.py `__call__` :592+, sd1x/pipeline.py): x_T ~ N(0, I) * init_noise_sigma, one
+    scheduler step per entry of `scheduler.timesteps`, `predict(x, t[B])` with integer training timesteps"""
+    scheduler.set_timesteps(num_inference_steps, device=latents.device)
+    x = latents * scheduler.init_noise_sigma
+    with torch.no_grad():
+        for i, t in enumerate(scheduler.timesteps):
+            out = predict(scheduler.scale_model_input(x, t), t.expand(x.shape[0]))
+            x = scheduler.step(out, t, x, return_dict=False)[0]
+            if on_step is not None:
+                on_step(i, x)
+    return x
+
+
+def cfg_combine(pred_pair: torch.Tensor, guidance_scale: float) -> torch.Tensor:
+    """classifier-free guidance on a [2B, ...] prediction of the batch [negative ; positive] (sd3/pipeline.py:1769-1785, sdxl/pipeline.py):
+    uncond + g * (text - uncond), combined in fp32"""
+    u, c = pred_pair.float().chunk(2)
+    return (u + guidance_scale * (c - u)).to(pred_pair.dtype)
+
+
 def sample_images(plugin, prompt_embeds: torch.Tensor, pooled: Optional[torch.Tensor], latent_height: int, latent_width: int, num_inference_steps: int = 20,
-                  generator: Optional[torch.Generator] = None, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None, mu: Optional[float] = None,
-                  decode: bool = True, extra_batch: Optional[dict] = None) -> torch.Tensor:
+                  generator: Optional[torch.Generator] = None, scheduler=None, mu: Optional[float] = None,
+                  decode: bool = True, extra_batch: Optional[dict] = None, guidance_scale: float = 1.0, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                  negative_pooled: Optional[torch.Tensor] = None, negative_extra_batch: Optional[dict] = None, latents: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The validation sampling loop end to end on the st355 kernels (training/validation.py -> <family>/pipeline.py `__call__`):
-    Gaussian latents -> `num_inference_steps` Euler flow-matching steps over the plugin's OWN forward (`model_predict`, so packing / ids / guidance /
-    timestep conventions are the family's) -> `vae.decode(z / scaling_factor + shift_factor)`.  Returns pixels [B, 3, 8h, 8w] in [-1, 1] (bf16), or
-    the final latents with decode=False.  Classifier-free guidance pairs, IP adapters and the image post-processing of the diffusers pipelines stay
-    outside this tier."""
+    Gaussian latents -> `num_inference_steps` steps over the plugin's OWN forward (`model_predict`, so packing / ids / guidance / timestep conventions are the
+    family's) -> `vae.decode(z / scaling_factor + shift_factor)`.  The scheduler follows the family's prediction type: flow matching -> Euler
+    (FlowMatchEulerDiscreteScheduler), epsilon / v-prediction -> DDIM (the reference's default, DEFAULT_NOISE_SCHEDULER).  Classifier-free guidance
+    (`guidance_scale` > 1 with negative embeddings): every step runs the model ONCE on the batch [negative ; positive] and combines the halves
+    (sd3/pipeline.py:1769-1785).  Returns pixels [B, 3, 8h, 8w] in [-1, 1] (bf16), or the final latents with decode=False.  IP adapters, skip-layer guidance,
+    CFG-zero* and the image post-processing of the diffusers pipelines stay outside this tier."""
     dev = plugin.accelerator.device
     B = prompt_embeds.shape[0]
     C = int(plugin.LATENT_CHANNEL_COUNT)
-    x = torch.randn(B, C, latent_height, latent_width, device=dev, dtype=torch.float32, generator=generator).to(torch.bfloat16)
-    scheduler = scheduler or FlowMatchEulerDiscreteScheduler(shift=float(getattr(plugin.config, "flow_schedule_shift", 3.0) or 1.0))
-    pe = prompt_embeds.to(device=dev, dtype=torch.bfloat16)
-    pp = None if pooled is None else pooled.to(device=dev, dtype=torch.bfloat16)
+    x = latents if latents is not None else torch.randn(B, C, latent_height, latent_width, device=dev, dtype=torch.float32, generator=generator)
+    x = x.to(device=dev, dtype=torch.bfloat16)
+    from .foundation import PredictionTypes
+    flow = plugin.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING
+    if scheduler is None:
+        if flow:
+            scheduler = FlowMatchEulerDiscreteScheduler(shift=float(getattr(plugin.config, "flow_schedule_shift", 3.0) or 1.0))
+        else:
+            scheduler = DDIMScheduler(prediction_type="v_prediction" if plugin.PREDICTION_TYPE is PredictionTypes.V_PREDICTION else "epsilon",
+                                      rescale_betas_zero_snr=bool(getattr(plugin.config, "rescale_betas_zero_snr", False)))
+    do_cfg = guidance_scale is not None and guidance_scale > 1.0 and negative_prompt_embeds is not None
+    bf = lambda t: None if t is None else t.to(device=dev, dtype=torch.bfloat16)
+    pe, pp = bf(prompt_embeds), bf(pooled)
+    if do_cfg:                                                        # [negative ; positive], as the pipelines concatenate them
+        pe = torch.cat([bf(negative_prompt_embeds), pe], dim=0)
+        pp = None if pp is None else torch.cat([bf(negative_pooled if negative_pooled is not None else torch.zeros_like(pooled)), pp], dim=0)
+
+    def pair(v_pos, v_neg):
+        if not torch.is_tensor(v_pos):
+            return v_pos
+        v_neg = v_pos if v_neg is None else v_neg
+        return torch.cat([v_neg.to(v_pos.device), v_pos], dim=0)
 
     def predict(xt, t):
-        batch = {"latents": xt, "noisy_latents": xt, "timesteps": t.to(device=dev, dtype=torch.float32), "prompt_embeds": pe, "encoder_hidden_states": pe,
+        xin, tin = (torch.cat([xt, xt], dim=0), torch.cat([t, t], dim=0)) if do_cfg else (xt, t)
+        batch = {"latents": xin, "noisy_latents": xin, "timesteps": tin.to(device=dev, dtype=torch.float32), "prompt_embeds": pe, "encoder_hidden_states": pe,
                  "add_text_embeds": pp, "added_cond_kwargs": {"text_embeds": pp}}
         if extra_batch:
-            batch.update(extra_batch)
-        return plugin.model_predict(batch)["model_prediction"].to(xt.dtype)
+            neg = negative_extra_batch or {}
+            for k, v in extra_batch.items():
+                if isinstance(v, dict):                               # e.g. added_cond_kwargs: merged into the entry built above (keeps text_embeds)
+                    merged = dict(batch.get(k) or {})
+                    merged.update({kk: (pair(vv, (neg.get(k) or {}).get(kk)) if do_cfg else vv) for kk, vv in v.items()})
+                    batch[k] = merged
+                else:
+                    batch[k] = pair(v, neg.get(k)) if do_cfg else v
+        out = plugin.model_predict(batch)["model_prediction"].to(xt.dtype)
+        return cfg_combine(out, float(guidance_scale)) if do_cfg else out
 
-    x = flow_match_euler_sample(predict, x, scheduler, num_inference_steps, mu=mu)
+    if flow:
+        x = flow_match_euler_sample(predict, x, scheduler, num_inference_steps, mu=mu)
+    else:
+        x = ddim_sample(predict, x, scheduler, num_inference_steps)
     if not decode:
         return x
     return plugin.get_vae().decode_scaled(x)
-

@@ -73,3 +73,80 @@ def test_sampling_loop_integrates_a_known_velocity_field():
     out = flow_match_euler_sample(predict, n.clone(), sc, num_inference_steps=7)
     torch.testing.assert_close(out, x0, rtol=0, atol=1e-5)
     assert len(seen) == 7 and all(t.shape == (2,) for t in seen) and seen[0][0].item() == pytest.approx(1000.0) and seen[-1][0].item() > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# r03: DDIM (the reference's default validation scheduler of the epsilon / v families) and classifier-free guidance
+# ------------------------------------------------------------------------------------------------------------------------
+def test_ddim_timestep_spacing_and_alpha_table():
+    from simpletuner_amd.foundation import DDPMSchedule
+    from simpletuner_amd.sampling import DDIMScheduler
+    sc = DDIMScheduler()
+    sc.set_timesteps(20)
+    assert sc.timesteps.tolist() == [951 - 50 * i for i in range(20)]            # "leading" spacing, steps_offset 1: the SD / SDXL scheduler_config
+    tr = DDIMScheduler(timestep_spacing="trailing")
+    tr.set_timesteps(4)
+    assert tr.timesteps.tolist() == [999, 749, 499, 249]
+    # the same alpha-bar table as the training-side DDPM schedule (pinned to reference code: tests/test_unet_cpu.py)
+    assert torch.equal(sc.alphas_cumprod, DDPMSchedule().alphas_cumprod)
+
+
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction", "sample"])
+def test_ddim_with_the_true_prediction_walks_the_exact_forward_marginals(ptype):
+    """exact-recovery property of deterministic DDIM: fed the TRUE prediction for x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps, every step lands on
+    sqrt(a_t') x0 + sqrt(1 - a_t') eps with the same (x0, eps), and the last step returns sqrt(a_0) x0 + sqrt(1 - a_0) eps (set_alpha_to_one=False)"""
+    from simpletuner_amd.sampling import DDIMScheduler, ddim_sample
+    g = torch.Generator().manual_seed(3)
+    x0, eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64), torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    sc = DDIMScheduler(prediction_type=ptype)
+    sc.set_timesteps(10)
+    acp = sc.alphas_cumprod.double()
+    marg = lambda a: a.sqrt() * x0 + (1 - a).sqrt() * eps
+
+    def predict(x, t):
+        a = acp[int(t[0])]
+        torch.testing.assert_close(x, marg(a), rtol=0, atol=1e-5)                   # the walk stays on the marginals
+        return {"epsilon": eps, "sample": x0, "v_prediction": a.sqrt() * eps - (1 - a).sqrt() * x0}[ptype]   # get_velocity (common.py:4649-4653)
+
+    out = ddim_sample(predict, marg(acp[int(sc.timesteps[0])]), sc, 10)
+    torch.testing.assert_close(out, marg(sc.final_alpha_cumprod.double()), rtol=0, atol=1e-5)
+
+
+def test_cfg_pair_batching_runs_the_model_once_per_step_on_negative_then_positive():
+    """sd3/pipeline.py:1769-1785: one forward on [negative ; positive], noise_pred = uncond + g (text - uncond)"""
+    from types import SimpleNamespace
+    from simpletuner_amd.foundation import PredictionTypes
+    from simpletuner_amd.sampling import cfg_combine, sample_images
+    calls = []
+
+    class Plug:
+        PREDICTION_TYPE = PredictionTypes.EPSILON
+        LATENT_CHANNEL_COUNT = 4
+        config = SimpleNamespace()
+        accelerator = SimpleNamespace(device=torch.device("cpu"))
+
+        def model_predict(self, batch):
+            calls.append({k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in batch.items() if k in ("noisy_latents", "prompt_embeds", "add_text_embeds")})
+            ehs = batch["encoder_hidden_states"].float()
+            # prediction = latents scaled by the prompt's mean: the two halves of the pair differ only through their conditioning
+            return {"model_prediction": batch["noisy_latents"].float() * ehs.mean(dim=(1, 2)).view(-1, 1, 1, 1)}
+
+    pe, ne = torch.full((2, 3, 5), 2.0), torch.full((2, 3, 5), -1.0)
+    x0 = torch.randn(2, 4, 4, 4, generator=torch.Generator().manual_seed(0))
+    out = sample_images(Plug(), pe, torch.ones(2, 6), 4, 4, num_inference_steps=3, decode=False, guidance_scale=4.0, negative_prompt_embeds=ne,
+                        negative_pooled=torch.zeros(2, 6), latents=x0)
+    assert len(calls) == 3 and all(c["noisy_latents"] == (4, 4, 4, 4) and c["prompt_embeds"] == (4, 3, 5) and c["add_text_embeds"] == (4, 6) for c in calls)
+    # replay by hand: eps = x * (uncond + g (cond - uncond)) with uncond = -1, cond = 2
+    from simpletuner_amd.sampling import DDIMScheduler
+    sc = DDIMScheduler()
+    sc.set_timesteps(3)
+    x = x0.to(torch.bfloat16)
+    for t in sc.timesteps:
+        pair = torch.cat([x.float() * -1.0, x.float() * 2.0]).to(torch.bfloat16)
+        x = sc.step(cfg_combine(pair, 4.0), t, x, return_dict=False)[0]
+    torch.testing.assert_close(out.float(), x.float(), rtol=0, atol=0)
+    assert torch.equal(cfg_combine(torch.tensor([[1.0], [3.0]]), 2.0), torch.tensor([[5.0]]))
+    # without negative embeddings (or g <= 1) the model sees the plain batch
+    calls.clear()
+    sample_images(Plug(), pe, torch.ones(2, 6), 4, 4, num_inference_steps=2, decode=False, guidance_scale=1.0, latents=x0)
+    assert all(c["noisy_latents"] == (2, 4, 4, 4) for c in calls)

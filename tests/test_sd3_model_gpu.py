@@ -364,3 +364,31 @@ def test_sd3_tread_routing_matches_executed_reference_and_oracle():
     print(f"[tread sd3] worst adapter gradient rel-L2 {worst:.3e}")
     _, _, _, _, _, _, pred_c, _, grads_c, _, _ = run(True)
     assert torch.equal(pred, pred_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+
+
+def test_sd3_cfg_sampling_trajectory_matches_oracle_forward():
+    """§8(f)4: `sample_images` with classifier-free guidance (one forward per step on [negative ; positive], sd3/pipeline.py:1769-1785) on the HIP path against
+    the SAME loop driven by the fp32 oracle forward (oracle/sd3.py, pinned to the executed reference model): 4 Euler steps, final latents rel-L2 <= 3e-2"""
+    from simpletuner_amd.sampling import FlowMatchEulerDiscreteScheduler, cfg_combine, sample_images
+    plugin, _tr, cpu, devt = _build(2, 2, 16, 16, 20)
+    model = plugin.get_trained_component()
+    P, lora, scale = _oracle_state(model)
+    lp = {k: (a, b) for k, (a, b) in lora.items()}
+    g = torch.Generator().manual_seed(21)
+    neg_p, neg_pool = torch.randn(2, 20, 128, generator=g).to(torch.bfloat16), torch.randn(2, 64, generator=g).to(torch.bfloat16)
+    x0 = torch.randn(2, 16, 16, 16, generator=g).to(torch.bfloat16)
+    gs = 3.5
+    with torch.no_grad():
+        out = sample_images(plugin, devt["prompt"], devt["pooled"], 16, 16, num_inference_steps=4, decode=False, guidance_scale=gs,
+                            negative_prompt_embeds=neg_p, negative_pooled=neg_pool, latents=x0.clone(),
+                            scheduler=FlowMatchEulerDiscreteScheduler(shift=3.0, bounds="unshifted"))
+    sc = FlowMatchEulerDiscreteScheduler(shift=3.0, bounds="unshifted")
+    sc.set_timesteps(4)
+    x = x0.float()
+    pe = torch.cat([neg_p.float(), cpu["prompt"]], 0); pp = torch.cat([neg_pool.float(), cpu["pooled"]], 0)
+    for i, t in enumerate(sc.timesteps):
+        pred = OS.sd3_forward(P, _ocfg(model), torch.cat([x, x], 0), pe, pp, t.expand(4), lora=lp, lora_scale=scale)
+        x = x + (sc.sigmas[i + 1] - sc.sigmas[i]) * cfg_combine(pred, gs)
+    r = PU.rel_l2(out, x)
+    print(f"[sampling sd3] CFG {gs}, 4 Euler steps: final latents HIP vs oracle-driven loop rel-L2 {r:.3e}")
+    assert torch.isfinite(out.float()).all() and r < 3e-2

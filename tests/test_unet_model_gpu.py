@@ -250,3 +250,36 @@ def test_unet_checkpointed_gradients_equal_direct_gradients(mode, interval, stri
     assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.abs().sum().item() > 0
     print(f"[ckpt unet {'lora' if lora else 'full'}] {mode}: {units} units, memory held between forward and backward {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB")
     assert kept1 < kept0
+
+
+def test_sdxl_ddim_cfg_sampling_trajectory_matches_oracle_forward():
+    """§8(f)4 for the epsilon families: DDIM (the reference's DEFAULT_NOISE_SCHEDULER for SDXL / SD1.x / PixArt) + classifier-free guidance through the SDXL
+    plugin's own forward (time ids / pooled text embeds paired [negative ; positive]) against the same loop driven by the fp32 oracle UNet: 4 steps"""
+    from types import SimpleNamespace
+    from simpletuner_amd.sampling import DDIMScheduler, cfg_combine, sample_images
+    from simpletuner_amd.sdxl.model import SDXL
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    dev = torch.device("cuda:0")
+    cfg = default_config(model_family="sdxl", model_type="lora", train_batch_size=2)
+    pl = SDXL(cfg, St355Accelerator(dev))
+    torch.manual_seed(0)
+    pl.load_model(**SMALL)
+    m = pl.get_trained_component()
+    P = {k: v.float().cpu() for k, v in m.diffusers_state_dict().items()}
+    sample, _, ehs, te, ti = _inputs(2, 16, 16, dev, seed=4)
+    g = torch.Generator().manual_seed(5)
+    neg_e, neg_te = torch.randn(2, 9, 128, generator=g).to(BF16), torch.randn(2, 64, generator=g).to(BF16)
+    gs = 5.0
+    with torch.no_grad():
+        out = sample_images(pl, ehs, te, 16, 16, num_inference_steps=4, decode=False, guidance_scale=gs, negative_prompt_embeds=neg_e, negative_pooled=neg_te,
+                            latents=sample.clone(), extra_batch={"added_cond_kwargs": {"time_ids": ti.to(dev)}})
+    sc = DDIMScheduler()
+    sc.set_timesteps(4)
+    x = sample.float()
+    e2, t2, i2 = torch.cat([neg_e.float(), ehs.float()]), torch.cat([neg_te.float(), te.float()]), torch.cat([ti.float(), ti.float()])
+    for t in sc.timesteps:
+        pred = unet_forward(P, UNetConfig(**SMALL), torch.cat([x, x]), t.float().expand(4), e2, {"text_embeds": t2, "time_ids": i2})
+        x = sc.step(cfg_combine(pred, gs), t, x, return_dict=False)[0]
+    r = _rel(out.cpu(), x)
+    print(f"[sampling sdxl] DDIM 4 steps, CFG {gs}: final latents HIP vs oracle-driven loop rel-L2 {r:.3e}")
+    assert torch.isfinite(out.float()).all() and r < 3e-2
