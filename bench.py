@@ -15,7 +15,9 @@ One "step" = prepare_batch (in-kernel noise + flow noising + target) -> MMDiT fo
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel class (the bf16 MFMA
 GEMM, measured live with hipEvent pairs on the launch stream by libst355's profiler), `cpu_baseline` (the oracle timed on the
 host cores for a bounded sample, N=1 only) and `parity_at_config` (the same sample through the HIP model, compared).  The default
-(Flux) line also carries `secondary.sdxl_lora`: the SDXL-LoRA half of BASELINE.json's metric, measured after the Flux timing.
+(Flux) line also carries `secondary.sdxl_lora` (the SDXL-LoRA half of BASELINE.json's metric) and `secondary.sd3_full_buckets` (configs[3]: SD3-Medium full
+fine-tune + EMA over mixed aspect buckets — the full-parameter gradient exchange), measured after the Flux timing at the same N.  `ms_per_step_stats` =
+median / p95 / min / max of the per-step device timestamps; `--model sd15 | sdxl | sd3 --full | pixart` lines carry their own `parity_at_config`.
 """
 from __future__ import annotations
 
@@ -34,6 +36,30 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table); never the 2:1-sparse figure
+
+
+# the rows of the reference's own benchmark sweep (documentation/experimental/SEGMENTED_CHECKPOINTING.md:795-805, example sd3.peft-lora:
+# SD3 LoRA r128 / alpha 128, 1024^2, train_batch_size 3, adamw_bf16, bf16; sec/step post-warm-up on ONE H100) that this bench can run as configured there:
+#   python bench.py --model sd3 --rank 128 --batch 3 --optimizer adamw_bf16 [--gradient-checkpointing [--ckpt-interval 2 [--ckpt-stride 4]]]
+PUBLISHED_SD3_LORA_R128_BS3 = {"none": 0.529, "layer": 0.721, "interval2": 0.723, "seg2-stride4": 0.620}
+
+
+def published_row(args):
+    """-> (mode, H100 sec/step) when the command line is one of the published SD3 rows, else None"""
+    if not (args.model == "sd3" and not args.full and int(args.rank) == 128 and int(args.batch) == 3 and args.res == 1024 and args.optimizer == "adamw_bf16"
+            and args.layers == 19 and not args.buckets):
+        return None
+    if not args.gradient_checkpointing:
+        mode = "none"
+    elif args.ckpt_interval in (None, 1) and args.ckpt_stride is None:
+        mode = "layer"
+    elif args.ckpt_interval == 2 and args.ckpt_stride is None:
+        mode = "interval2"
+    elif args.ckpt_interval == 2 and args.ckpt_stride == 4:
+        mode = "seg2-stride4"
+    else:
+        return None
+    return mode, PUBLISHED_SD3_LORA_R128_BS3[mode]
 
 
 def train_flops_per_image(n_blocks: int, D: int, S: int) -> float:
@@ -80,12 +106,12 @@ def parse():
     ap.add_argument("--single-layers", type=int, default=38)
     ap.add_argument("--rank", type=int, default=32)
     ap.add_argument("--res", type=int, default=1024)
-    ap.add_argument("--gradient-checkpointing", action="store_true", help="flux: re-run checkpointed blocks in backward instead of keeping their activations "
+    ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run checkpointed blocks in backward instead of keeping their activations "
                     "(SURVEY.md §8(f)3); with --ckpt-interval K [--ckpt-stride S] the reference's segmented modes (interval2 = K 2; seg2-stride4 = K 2 S 4)")
     ap.add_argument("--ckpt-interval", type=int, default=None)
     ap.add_argument("--ckpt-stride", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA secondary measurement appended to the default line")
+    ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA and SD3 full-fine-tune (mixed buckets) secondary measurements appended to the default line")
     ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
     a = ap.parse_args()
@@ -95,21 +121,25 @@ def parse():
 
 
 def cpu_baseline(args, dev=None):
-    """the oracle (plain-torch restatement of the reference path) on the host cores: a 1 double + 1 single block Flux at full width
-    (D=3072, 24x128 heads) and full sequence (4096 + 512 tokens), LoRA r32, forward + autograd backward, fp32.  The two block times are
-    extrapolated linearly in block count to the 19+38 stack.  The SAME weights, adapters and inputs then go through the
+    """the oracle (plain-torch restatement of the reference path) on the host cores: a 2 double + 4 single block Flux at full width
+    (D=3072, 24x128 heads) and full sequence (4096 + 512 tokens), LoRA r32 — forward, autograd backward (fp32) and torch.optim.AdamW over the
+    adapters.  One untimed warm-up pass (thread pool, first-touch pages), then 3 timed passes; each pass times its double-block and single-block
+    sections (forward and backward separately) and the optimizer step; the MEDIAN per-block times are extrapolated linearly in block count to the
+    19+38 stack, the optimizer step in adapter-parameter count.  The SAME weights, adapters and inputs then go through the
     HIP model on the device and the outputs are compared: `parity_at_config` = prediction rel-L2 / cosine and the worst adapter-gradient
     rel-L2 at the BASELINE shape (the oracle is the checker here, never the thing measured as the product)."""
+    import statistics
+
     import torch.nn.functional as F
 
     from oracle import flux as OF
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    cfg = OF.FluxConfig(num_layers=1, num_single_layers=1)
+    ND, NS = 2, 4
+    cfg = OF.FluxConfig(num_layers=ND, num_single_layers=NS)
     P = OF.init_params(cfg, seed=1)
     P = {k: v.to(torch.bfloat16).float() for k, v in P.items()}           # both sides start from the same bf16-representable weights
-    D = cfg.inner_dim
     lat = args.res // 8
     S_img, S_txt = (lat // 2) ** 2, 512
     B, r = 1, int(args.rank)
@@ -122,57 +152,88 @@ def cpu_baseline(args, dev=None):
     guidance = torch.full((B,), 1.0)
     lora = OF.init_lora(cfg, P, r, seed=7, b_std=2e-2)
     lora = {k: (bf(a).requires_grad_(True), bf(b).requires_grad_(True)) for k, (a, b) in lora.items()}
+    lora0 = {k: (a.detach().clone(), b.detach().clone()) for k, (a, b) in lora.items()}
     img_ids, txt_ids = OF.prepare_latent_image_ids(lat, lat), torch.zeros(S_txt, 3)
     cos, sin = OF.rope_tables(torch.cat([txt_ids, img_ids], 0))
-    # embedders + tail are a few GFLOP: outside the timed block regions
-    hid0 = OF.linear(packed, P, "x_embedder").detach().requires_grad_(True)
-    enc0 = OF.linear(prompt, P, "context_embedder").detach().requires_grad_(True)
-    temb = OF.time_text_embed(P, cfg, tstep * 1000, guidance * 1000, pooled).detach()
-    t0 = time.time()
-    enc1, hid1 = OF.double_block(P, cfg, 0, hid0, enc0, temb, cos, sin, lora, 1.0)
-    t_fd = time.time() - t0
-    x1 = torch.cat([enc1, hid1], dim=1)
-    t0 = time.time()
-    x2 = OF.single_block(P, cfg, 0, x1, temb, cos, sin, lora, 1.0)
-    t_fs = time.time() - t0
-    scale_o, shift_o = OF.linear(F.silu(temb), P, "norm_out.linear").chunk(2, dim=1)
-    pred = OF.linear(OF.layer_norm(x2[:, S_txt:]) * (1 + scale_o[:, None]) + shift_o[:, None], P, "proj_out")
-    loss = pred.float().pow(2).mean()
-    (gx2,) = torch.autograd.grad(loss, [x2], retain_graph=True)
     s_names = [k for k in lora if k.startswith("single_")]
     d_names = [k for k in lora if k.startswith("transformer_blocks")]
     s_par = [t for k in s_names for t in lora[k]]
     d_par = [t for k in d_names for t in lora[k]]
-    t0 = time.time()
-    gs = torch.autograd.grad([x2], [x1] + s_par, grad_outputs=[gx2], retain_graph=True)
-    t_bs = time.time() - t0
-    t0 = time.time()
-    gd = torch.autograd.grad([x1], [hid0, enc0] + d_par, grad_outputs=[gs[0]])
-    t_bd = time.time() - t0
-    t_double, t_single = t_fd + t_bd, t_fs + t_bs
-    step_s = t_double * args.layers + t_single * args.single_layers
-    ograd = {}
-    for names, grads in ((s_names, gs[1:]), (d_names, gd[2:])):
-        for i, k in enumerate(names):
-            ograd[k] = (grads[2 * i], grads[2 * i + 1])
+    opt = torch.optim.AdamW(d_par + s_par, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    # embedders + tail are a few GFLOP: outside the timed block regions
+    temb = OF.time_text_embed(P, cfg, tstep * 1000, guidance * 1000, pooled).detach()
+
+    def one_pass(nd, ns, step):
+        """forward / backward over the first nd double and ns single blocks; returns the section times and what the parity leg compares"""
+        hid0 = OF.linear(packed, P, "x_embedder").detach().requires_grad_(True)
+        enc0 = OF.linear(prompt, P, "context_embedder").detach().requires_grad_(True)
+        t0 = time.time()
+        enc, hid = enc0, hid0
+        for i in range(nd):
+            enc, hid = OF.double_block(P, cfg, i, hid, enc, temb, cos, sin, lora, 1.0)
+        t_fd = time.time() - t0
+        x1 = torch.cat([enc, hid], dim=1)
+        t0 = time.time()
+        x2 = x1
+        for i in range(ns):
+            x2 = OF.single_block(P, cfg, i, x2, temb, cos, sin, lora, 1.0)
+        t_fs = time.time() - t0
+        scale_o, shift_o = OF.linear(F.silu(temb), P, "norm_out.linear").chunk(2, dim=1)
+        pred = OF.linear(OF.layer_norm(x2[:, S_txt:]) * (1 + scale_o[:, None]) + shift_o[:, None], P, "proj_out")
+        loss = pred.float().pow(2).mean()
+        (gx2,) = torch.autograd.grad(loss, [x2], retain_graph=True)
+        sp = [t for k in s_names if int(k.split(".")[1]) < ns for t in lora[k]]
+        dp = [t for k in d_names if int(k.split(".")[1]) < nd for t in lora[k]]
+        t0 = time.time()
+        gs = torch.autograd.grad([x2], [x1] + sp, grad_outputs=[gx2], retain_graph=True)
+        t_bs = time.time() - t0
+        t0 = time.time()
+        gd = torch.autograd.grad([x1], [hid0, enc0] + dp, grad_outputs=[gs[0]])
+        t_bd = time.time() - t0
+        t_opt = 0.0
+        if step:
+            for t_, g_ in zip(sp + dp, list(gs[1:]) + list(gd[2:])):
+                t_.grad = g_
+            t0 = time.time()
+            opt.step()
+            t_opt = time.time() - t0
+        return (t_fd + t_bd, t_fs + t_bs, t_opt), pred.detach(), (sp, gs[1:], dp, gd[2:])
+
+    one_pass(1, 1, False)                                                   # warm-up, untimed
+    # the first timed pass runs from the initial adapters and is the one the device is compared with; AdamW moves the adapters after each pass
+    times, pred, keep = [], None, None
+    for it in range(3):
+        tt, pr, kp = one_pass(ND, NS, True)
+        times.append(tt)
+        if it == 0:
+            pred = pr
+            keep = {id(t_): g_.detach().clone() for ts, gs_ in ((kp[0], kp[1]), (kp[2], kp[3])) for t_, g_ in zip(ts, gs_)}
+    t_double = statistics.median(t[0] for t in times) / ND
+    t_single = statistics.median(t[1] for t in times) / NS
+    n_adapter_sample = sum(t.numel() for t in d_par + s_par)
+    t_opt = statistics.median(t[2] for t in times) * (args.layers * 4 + args.single_layers * 3) / max(1, ND * 4 + NS * 3)
+    step_s = t_double * args.layers + t_single * args.single_layers + t_opt
+    ograd = {k: (keep[id(lora[k][0])], keep[id(lora[k][1])]) for k in lora}
     out = {
         "value": round(B / step_s, 6), "unit": "images/s", "cores": cores, "kind": "port",
-        "sample": f"oracle (plain torch fp32, autograd) 1 double + 1 single Flux block fwd+bwd at D=3072, S={S_img}+{S_txt}, B=1, LoRA r{r}: "
-                  f"{t_double:.1f}s + {t_single:.1f}s, extrapolated x{args.layers}/x{args.single_layers} blocks = {step_s:.0f} s/step",
+        "sample": f"oracle (plain torch fp32, autograd, torch.optim.AdamW) {ND} double + {NS} single Flux blocks fwd+bwd+optimizer at D=3072, S={S_img}+{S_txt}, "
+                  f"B=1, LoRA r{r} ({n_adapter_sample / 1e6:.1f} M adapter parameters): 1 warm-up pass, median of 3 timed passes = {t_double:.2f} s per double block, "
+                  f"{t_single:.2f} s per single block, extrapolated x{args.layers}/x{args.single_layers} blocks + AdamW {t_opt * 1e3:.0f} ms = {step_s:.0f} s/step "
+                  f"(per-pass block seconds: {[round(t[0] + t[1], 1) for t in times]})",
     }
     parity = None
     if dev is not None:
         # the same weights / adapters / inputs through the HIP model (C ABI) on the device
         from simpletuner_amd.flux.transformer import FluxTransformer2DModel
-        m = FluxTransformer2DModel(num_layers=1, num_single_layers=1, guidance_embeds=True, device=dev)
+        m = FluxTransformer2DModel(num_layers=ND, num_single_layers=NS, guidance_embeds=True, device=dev)
         m.load_flat_state(P)
         m.add_lora_adapter(rank=r, alpha=float(r))
         with torch.no_grad():
             for name, p_ in m.named_parameters():
                 if ".lora_A." in name:
-                    p_.copy_(lora[name.split(".lora_A.")[0]][0].detach())
+                    p_.copy_(lora0[name.split(".lora_A.")[0]][0])
                 elif ".lora_B." in name:
-                    p_.copy_(lora[name.split(".lora_B.")[0]][1].detach())
+                    p_.copy_(lora0[name.split(".lora_B.")[0]][1])
         m.prepare_for_training()
         to = lambda t, dt=torch.bfloat16: t.to(device=dev, dtype=dt)
         hp = m(hidden_states=to(packed), encoder_hidden_states=to(prompt), pooled_projections=to(pooled), timestep=to(tstep, torch.float32),
@@ -186,7 +247,7 @@ def cpu_baseline(args, dev=None):
             if ".lora_" in name:
                 key = name.split(".lora_")[0]
                 worst = max(worst, (rel(p_.grad, ograd[key][0 if ".lora_A." in name else 1]), name))
-        parity = {"what": f"1 double + 1 single block Flux (D=3072, 24x128 heads, S={S_img}+{S_txt}, LoRA r{r}): HIP bf16 vs oracle fp32, same weights / inputs",
+        parity = {"what": f"{ND} double + {NS} single block Flux (D=3072, 24x128 heads, S={S_img}+{S_txt}, LoRA r{r}): HIP bf16 vs oracle fp32, same weights / inputs",
                   "pred_rel_l2": round(rel(hp, pred), 6), "pred_cos": round(float(torch.dot(hpf, opf) / (hpf.norm() * opf.norm())), 7),
                   "lora_grad_worst_rel_l2": round(worst[0], 6), "lora_grad_worst_at": worst[1], "lora_grads_compared": len(ograd) * 2,
                   "tolerance": "pred rel_l2 <= 2e-2, cos >= 0.9995, adapter grads rel_l2 <= 5e-2 (DESIGN.md §3; parity unpinned: the reference holds no golden tensor)"}
@@ -359,8 +420,20 @@ def main():
         a2.steps, a2.warmup, a2.no_cpu_baseline, a2.prof_dump, a2.fp8 = min(args.steps, 5), 2, True, None, False
         sec = run_workload(a2, dev, rank, world)
         if rank == 0:
-            out["secondary"] = {"sdxl_lora": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "step_model_tflops",
-                                                                    "step_frac_of_bf16_mfma_peak", "roofline", "loss")}}
+            out["secondary"] = {"sdxl_lora": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config",
+                                                                    "step_model_tflops", "step_frac_of_bf16_mfma_peak", "roofline", "loss")}}
+        # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
+        # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
+        del sec
+        gc.collect()
+        torch.cuda.empty_cache()
+        a3 = copy.copy(args)
+        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
+        a3.steps, a3.warmup, a3.no_cpu_baseline, a3.prof_dump, a3.fp8, a3.gradient_checkpointing = min(args.steps, 5), 2, True, None, False, False
+        sec = run_workload(a3, dev, rank, world)
+        if rank == 0:
+            out["secondary"]["sd3_full_buckets"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config",
+                                                                          "step_model_tflops", "step_frac_of_bf16_mfma_peak", "roofline", "loss")}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -376,7 +449,7 @@ def run_workload(args, dev, rank, world):
                         
                          model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
                          learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph),
-                         gradient_checkpointing=bool(getattr(args, "gradient_checkpointing", False)) and args.model == "flux",
+                         gradient_checkpointing=bool(getattr(args, "gradient_checkpointing", False)),
                          gradient_checkpointing_interval=getattr(args, "ckpt_interval", None), gradient_checkpointing_segment_stride=getattr(args, "ckpt_stride", None))
     acc = St355Accelerator(dev)
     if args.model == "flux":
@@ -506,9 +579,12 @@ def run_workload(args, dev, rank, world):
     prof_live = (not args.no_prof) and not args.graph        # hipGraph replays run no host code: the per-launch events are taken from one eager step below
     if prof_live:
         ops.prof_reset(); ops.prof_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step device timestamps on the stream the step's kernels run on
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = trainer.train_step(dict(batches[i % nb_]))
+        marks[i + 1].record()
         if trace_loss:
             comp_ = plugin.get_trained_component()
             gf_ = getattr(comp_, "_last_grad_flat", None)
@@ -516,6 +592,9 @@ def run_workload(args, dev, rank, world):
                   f"w_nan {bool(torch.isnan(comp_.arena.float()).any()) if hasattr(comp_, 'arena') else None}", file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_stats = {"median": round(per_step_ms[len(per_step_ms) // 2], 2), "p95": round(per_step_ms[min(len(per_step_ms) - 1, int(0.95 * len(per_step_ms)))], 2),
+                  "min": round(per_step_ms[0], 2), "max": round(per_step_ms[-1], 2), "source": "device timestamps (hipEvents on the compute stream) per step, this rank"}
     prof = None
     prof_steps = args.steps
     if args.graph and not args.no_prof:
@@ -572,7 +651,7 @@ def run_workload(args, dev, rank, world):
             "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL', sd15='SD 1.5', pixart='PixArt-Sigma')[args.model]} "
                       f"{'ControlNet branch' if args.model == 'pixart' else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 2), "ms_per_step_stats": step_stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (+ fp8 e5m2 x e4m3 trunk Linears)" if getattr(args, "fp8", False) else "bf16", "data": "synthetic",
             "config": {"workload": desc,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
@@ -585,12 +664,31 @@ def run_workload(args, dev, rank, world):
             "kernels": kernels,
             "cpu_baseline": None,
         }
+        pub = published_row(args)
+        if pub is not None and world == 1:
+            ref_ips = B / pub[1]
+            out["vs_baseline"] = round(value / ref_ips, 3)
+            out["published"] = {"row": f"SD3 LoRA r128 1024^2 bs 3, bf16, adamw_bf16, checkpointing mode {pub[0]!r} (example sd3.peft-lora)", "sec_per_step": pub[1],
+                                "images_per_s": round(ref_ips, 3), "hardware": "1x H100 (the reference's own sweep; BASELINE.md §1)",
+                                "source": "documentation/experimental/SEGMENTED_CHECKPOINTING.md:795-805", "this_run_sec_per_step": round(ms_per_step / 1e3, 4)}
         if world == 1 and not args.no_cpu_baseline and args.model == "flux":
             del trainer, plugin, batches
             torch.cuda.empty_cache()
             out["cpu_baseline"], out["parity_at_config"] = cpu_baseline(args, dev)
         elif world == 1 and not args.no_cpu_baseline and args.model in ("sd15", "sdxl"):
+            del trainer, plugin, batches
+            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline_unet(args, sd15=args.model == "sd15", lora=not args.full)
+            from tests import parity_at_config as PC       # the oracle as the checker of the HIP component at this configuration (never the thing timed)
+            out["parity_at_config"] = PC.unet(args.model, args.res, dev, lora=not args.full, rank=int(args.rank))
+        elif world == 1 and not args.no_cpu_baseline and args.model in ("sd3", "pixart"):
+            del trainer, plugin, batches
+            torch.cuda.empty_cache()
+            from tests import parity_at_config as PC
+            if args.model == "pixart":
+                out["parity_at_config"] = PC.pixart_controlnet(args.res, dev)
+            elif args.full:
+                out["parity_at_config"] = PC.sd3_full(args.res, dev)
         return out
     return None
 

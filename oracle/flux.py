@@ -325,12 +325,19 @@ def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bi
 
 
 def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
-                 guidance=None, lora=None, lora_scale: float = 1.0, key_bias=None, taps=None, tread=None):
+                 guidance=None, lora=None, lora_scale: float = 1.0, key_bias=None, taps=None, tread=None, checkpoint: bool = False):
     """flux/transformer.py:940-1513.  hidden_states [B,S_img,64] packed latents; timestep in [0,1] (multiplied by 1000 here,
     :1003); guidance likewise (:1007).  Returns [B,S_img,64].
     tread = {"routes": [{start_layer_idx, end_layer_idx, ...}], "mask_infos": [{ids_shuffle, ids_restore, ids_keep}, ...]}: TREAD routing
     (:1095-1241 double blocks, :1394-1486 single blocks) with the router's permutations replayed; layer indices are global over
-    double + single blocks, negative = from the end (:1120-1133)."""
+    double + single blocks, negative = from the end (:1120-1133).
+    checkpoint=True re-runs each block in the backward (torch.utils.checkpoint, the reference's gradient_checkpointing branch :1137-1160): same values,
+    bounded activation memory — what lets the full 19 + 38 block depth run as an fp32 checker."""
+    if checkpoint:
+        import torch.utils.checkpoint as _ck
+        run = lambda fn, *a: _ck.checkpoint(fn, *a, use_reentrant=False)
+    else:
+        run = lambda fn, *a: fn(*a)
     hidden = linear(hidden_states, P, "x_embedder")
     t = timestep.float() * 1000
     g = guidance.float() * 1000 if (guidance is not None and cfg.guidance_embeds) else None
@@ -351,7 +358,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
             info, saved = infos[ptr], hidden
             hidden = tread_start(hidden, info)
             ccos, csin = tread_rope(cos, sin, T, info, hidden.shape[1], B)
-        enc, hidden = double_block(P, cfg, i, hidden, enc, temb, ccos, csin, lora, lora_scale, key_bias, taps)
+        enc, hidden = run(double_block, P, cfg, i, hidden, enc, temb, ccos, csin, lora, lora_scale, key_bias, taps)
         if info is not None and gidx == routes[ptr]["end_layer_idx"]:
             hidden = tread_end(hidden, info, saved)
             info, saved, ptr, ccos, csin = None, None, ptr + 1, cos, sin
@@ -365,7 +372,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
             img = tread_start(x[:, T:], info)
             x = torch.cat([x[:, :T], img], dim=1)
             ccos, csin = tread_rope(cos, sin, T, info, img.shape[1], B)
-        x = single_block(P, cfg, i, x, temb, ccos, csin, lora, lora_scale, key_bias)
+        x = run(single_block, P, cfg, i, x, temb, ccos, csin, lora, lora_scale, key_bias)
         if info is not None and gidx == routes[ptr]["end_layer_idx"]:
             x = torch.cat([x[:, :T], tread_end(x[:, T:], info, saved)], dim=1)
             info, saved, ptr, ccos, csin = None, None, ptr + 1, cos, sin
@@ -380,7 +387,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
 
 
 def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, guidance_value: float = 1.0, lora=None,
-                       lora_scale=1.0, taps=None):
+                       lora_scale=1.0, taps=None, checkpoint: bool = False):
     """Flux._model_predict_single (flux/model.py:707-864): pack, ids, t/1000, guidance vector, transformer, unpack."""
     B, C, Hh, Ww = noisy_latents.shape
     packed = pack_latents(noisy_latents)
@@ -388,7 +395,7 @@ def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, 
     txt_ids = torch.zeros(prompt_embeds.shape[1], 3)
     guidance = torch.full((B,), float(guidance_value), device=noisy_latents.device) if cfg.guidance_embeds else None
     out = flux_forward(P, cfg, packed, prompt_embeds, pooled, timesteps / 1000.0, img_ids, txt_ids, guidance, lora, lora_scale,
-                       taps=taps)
+                       taps=taps, checkpoint=checkpoint)
     return unpack_latents(out, Hh, Ww)
 
 

@@ -79,7 +79,7 @@ def patch_embed(P, cfg: PixArtConfig, x, prefix="pos_embed."):
     B, C, H, W = x.shape
     h, w = H // cfg.patch_size, W // cfg.patch_size
     t = F.conv2d(x, P[prefix + "proj.weight"], P[prefix + "proj.bias"], stride=cfg.patch_size).flatten(2).transpose(1, 2)
-    pos = sincos_2d_hw(cfg.D, h, w, cfg.sample_size // cfg.patch_size, cfg.interp).to(t.dtype)
+    pos = sincos_2d_hw(cfg.D, h, w, cfg.sample_size // cfg.patch_size, cfg.interp).to(t)      # table built in float64 on the host; the oracle itself may run on any device
     return t + pos[None]
 
 
@@ -111,10 +111,14 @@ def _attn(P, p, x, ctx, H, bias=None, _lin=_lin):
     q, k, v = _lin(x, P, p + "to_q"), _lin(ctx, P, p + "to_k"), _lin(ctx, P, p + "to_v")
     d = D // H
     q, k, v = (t.view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
-    s = q @ k.transpose(-1, -2) / math.sqrt(d)
-    if bias is not None:
-        s = s + bias[:, None, None, :]
-    return _lin((s.softmax(-1) @ v).transpose(1, 2).reshape(B, S, D), P, p + "to_out.0")
+    def rows(qc):
+        s = qc @ k.transpose(-1, -2) / math.sqrt(d)
+        if bias is not None:
+            s = s + bias[:, None, None, :]
+        return s.softmax(-1) @ v
+    # softmax is per query row: 4096-query slabs give the same values and keep the fp32 score matrix of a 16384-token (2K) self-attention at 4 GiB a slab
+    o = rows(q) if q.shape[2] * k.shape[2] <= (1 << 26) else torch.cat([rows(qc) for qc in q.split(4096, dim=2)], dim=2)
+    return _lin(o.transpose(1, 2).reshape(B, S, D), P, p + "to_out.0")
 
 
 def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6, _lin=_lin):
@@ -159,9 +163,15 @@ def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, 
     return _head(P, cfg, h, emb, hh, ww)
 
 
-def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc, mask, timestep, resolution=None, aspect_ratio=None):
+def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc, mask, timestep, resolution=None, aspect_ratio=None, checkpoint: bool = False):
     """PixArtSigmaControlNetTransformerModel.forward (pixart/controlnet.py:208-326).  P: trunk weights; C: adapter weights
-    (`controlnet_blocks.{i}.before_proj|transformer_block.*|after_proj`)."""
+    (`controlnet_blocks.{i}.before_proj|transformer_block.*|after_proj`).  checkpoint=True: every block re-run in the backward (torch.utils.checkpoint,
+    the reference's gradient-checkpointing branch :262-296) — same values, one block's activations alive at a time (2K latents as an fp32 checker)."""
+    if checkpoint:
+        import torch.utils.checkpoint as _ck
+        run = lambda *a: _ck.checkpoint(block, *a, use_reentrant=False)
+    else:
+        run = block
     hh, ww = latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size
     h, t6, emb, ctx, bias = _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio)
     cs = patch_embed(P, cfg, cond)
@@ -170,9 +180,9 @@ def controlnet_forward(P, C, cfg: PixArtConfig, n_ctrl: int, latents, cond, enc,
             p = f"controlnet_blocks.{i - 1}."
             if i == 1:
                 cs = h + _lin(cs, C, p + "before_proj")
-            cs = block(C, p + "transformer_block.", cfg, cs, ctx, bias, t6)
+            cs = run(C, p + "transformer_block.", cfg, cs, ctx, bias, t6)
             h = h + _lin(cs, C, p + "after_proj")
-        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6)
+        h = run(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6)
     return _head(P, cfg, h, emb, hh, ww)
 
 

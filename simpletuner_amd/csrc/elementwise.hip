@@ -139,8 +139,10 @@ __device__ __forceinline__ void load_mask8(const float* __restrict__ em, int64_t
     for (int j = 0; j < 8; j++) mk[j] = 1.f;
   }
 }
-// grid = (blocks_per_sample, B). Each block reduces its slice in fp32 and adds one value per sample.
-__global__ void __launch_bounds__(EW_THREADS) k_mse(const bf16* __restrict__ pred, const bf16* __restrict__ target,
+// grid = (1, B), LOSS_THREADS threads: ONE workgroup per sample reduces it in a fixed order (lane tree -> 16 wave partials summed in wave order): the logged
+// loss is bit-reproducible run to run.  (r02 used several blocks per sample and an atomicAdd: the last bits then depended on block arrival order.)
+#define LOSS_THREADS 1024
+__global__ void __launch_bounds__(LOSS_THREADS) k_mse(const bf16* __restrict__ pred, const bf16* __restrict__ target,
                                                    const float* __restrict__ weight, float* __restrict__ per_sample_acc,
                                                    bf16* __restrict__ dpred, int64_t per_sample, float dscale,
                                                    const float* __restrict__ emask, int64_t mask_period) {
@@ -167,13 +169,13 @@ __global__ void __launch_bounds__(EW_THREADS) k_mse(const bf16* __restrict__ pre
     if (d) *(bf16x8*)(d + i * 8) = dv;
   }
   acc = wave_sum(acc);
-  __shared__ float red[EW_THREADS / WAVE];
+  __shared__ float red[LOSS_THREADS / WAVE];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int i = 0; i < EW_THREADS / WAVE; i++) s += red[i];
-    atomicAdd(&per_sample_acc[b], s * w);
+    for (int i = 0; i < (int)(blockDim.x / WAVE); i++) s += red[i];
+    per_sample_acc[b] = s * w;
   }
 }
 __global__ void k_mse_finalize(float* per_sample_acc, float* loss, int B, float inv_per_sample) {
@@ -194,11 +196,8 @@ static int mse_loss_impl(void* stream, const void* pred, const void* target, con
   ST_REQUIRE(!emask || (mask_period > 0 && mask_period % 8 == 0 && per_sample % mask_period == 0 && ((uintptr_t)emask & 15) == 0),
              "mse_loss: element mask period must be a multiple of 8 dividing per_sample (16-byte aligned)");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 3.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
-  zero_words(stream, per_sample_out, (int)batch);
-  int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
-  if (bx > 512) bx = 512;
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
-  hipLaunchKernelGGL(k_mse, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+  hipLaunchKernelGGL(k_mse, dim3(1, (unsigned)batch), dim3(LOSS_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
                      (const bf16*)target, weight, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
                      1.0f / (float)per_sample);
@@ -214,7 +213,7 @@ extern "C" int st355_mse_loss(void* stream, const void* pred, const void* target
 //   smooth_l1: 2  (sqrt(d^2 + c^2) - c)        d/dpred = 2  d / sqrt(d^2 + c^2)
 // huber_c is per sample (scheduled huber, common.py:6252-6272) or one value broadcast by the host; weight[b] as in st355_mse_loss.
 template <int TYPE>
-__global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict__ pred, const bf16* __restrict__ target,
+__global__ void __launch_bounds__(LOSS_THREADS) k_cond_loss(const bf16* __restrict__ pred, const bf16* __restrict__ target,
                                                          const float* __restrict__ weight, const float* __restrict__ huber_c,
                                                          float* __restrict__ per_sample_acc, bf16* __restrict__ dpred,
                                                          int64_t per_sample, float dscale, const float* __restrict__ emask, int64_t mask_period) {
@@ -244,13 +243,13 @@ __global__ void __launch_bounds__(EW_THREADS) k_cond_loss(const bf16* __restrict
     if (d) *(bf16x8*)(d + i * 8) = dv;
   }
   acc = wave_sum(acc);
-  __shared__ float red[EW_THREADS / WAVE];
+  __shared__ float red[LOSS_THREADS / WAVE];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int i = 0; i < EW_THREADS / WAVE; i++) s += red[i];
-    atomicAdd(&per_sample_acc[b], s * w);
+    for (int i = 0; i < (int)(blockDim.x / WAVE); i++) s += red[i];
+    per_sample_acc[b] = s * w;
   }
 }
 extern "C" int st355_cond_loss_masked(void* stream, const void* pred, const void* target, const float* weight, const float* huber_c, int loss_type,
@@ -262,15 +261,12 @@ extern "C" int st355_cond_loss_masked(void* stream, const void* pred, const void
   ST_REQUIRE(!emask || (mask_period > 0 && mask_period % 8 == 0 && per_sample % mask_period == 0 && ((uintptr_t)emask & 15) == 0),
              "cond_loss: element mask period must be a multiple of 8 dividing per_sample (16-byte aligned)");
   ProfScope ps(stream, ST355_K_ELEMENTWISE, 6.0 * batch * per_sample, (dpred ? 6.0 : 4.0) * batch * per_sample);
-  zero_words(stream, per_sample_out, (int)batch);
-  int bx = (int)cdiv64(per_sample / 8, EW_THREADS);
-  if (bx > 512) bx = 512;
   const float dscale = grad_scale * 2.0f / ((float)per_sample * (float)batch);
   if (loss_type == 1)
-    hipLaunchKernelGGL(k_cond_loss<1>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+    hipLaunchKernelGGL(k_cond_loss<1>, dim3(1, (unsigned)batch), dim3(LOSS_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
                        (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   else
-    hipLaunchKernelGGL(k_cond_loss<2>, dim3(bx, (unsigned)batch), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
+    hipLaunchKernelGGL(k_cond_loss<2>, dim3(1, (unsigned)batch), dim3(LOSS_THREADS), 0, (hipStream_t)stream, (const bf16*)pred,
                        (const bf16*)target, weight, huber_c, per_sample_out, (bf16*)dpred, per_sample, dscale, emask, mask_period);
   hipLaunchKernelGGL(k_mse_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample_out, loss_out, (int)batch,
                      1.0f / (float)per_sample);

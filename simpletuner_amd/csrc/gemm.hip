@@ -1638,6 +1638,10 @@ static bool pz_ok(const GemmP& p, int tiles) {
   if (!persist_enabled() || p.M % PQ_BM || p.N % PQ_BN || p.K % PQ_BK || p.K2 % PQ_BK) return false;
   if (p.K / PQ_BK + p.K2 / PQ_BK < 4 || p.K / PQ_BK < 2 || p.conv_taps || p.scale_b || p.partial || p.img_add) return false;
   if (tiles <= device_cus()) return false;            // one round of tiles: nothing to overlap
+  // long plain-K problems (the feed-forward down projections, K = 12288 with no K-extension): 96+ k-iterations amortise the one-tile-per-workgroup
+  // seam already and the dynamic workgroup dispatch balances the last round better — measured in-step (profiles/r03_flux_step_gemm_persistent_ab.txt):
+  // 1327 -> 1266 TFLOP/s under the persistent schedule, every other shape class +0.5 ... +8 %
+  if (g_persist_override < 0 && p.K >= 12288 && p.K2 == 0) return false;      // (a forced schedule, set_persistent(1), ignores the heuristic)
   bool ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (((uintptr_t)p.A & 15) == 0) && (((uintptr_t)p.B & 15) == 0) && p.lda % 8 == 0 && p.ldb % 8 == 0;
   if (p.bias) ok = ok && (((uintptr_t)p.bias & 15) == 0);
   if (p.aux_out) ok = ok && (p.ld_aux_out % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0);

@@ -275,8 +275,13 @@ extern "C" int st355_ema_update(void* stream, void* shadow, const void* param, i
   return st355_check_launch("ema_update");
 }
 
+// Fixed-order two-stage reduction (r03; r02 added the block partials with atomicAdd, so the clip coefficient's last bits depended on block arrival order):
+// GN_BLOCKS workgroups write one (sum of squares, max |g|) pair each into a library-owned scratch, a single wave then combines them in index order.
+// The scratch is one buffer per process: st355_grad_norm calls are stream-ordered on the training stream (one training thread per rank).
+#define GN_BLOCKS 1024
+__device__ float g_gn_part[2 * GN_BLOCKS];
 template <typename T>
-__global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ g, int64_t n, float* __restrict__ out2) {
+__global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ g, int64_t n) {
   float ss = 0.f, mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float f = (float)g[i];
@@ -291,18 +296,27 @@ __global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ 
   if (threadIdx.x == 0) {
     float a = 0.f, b = 0.f;
     for (int i = 0; i < OP_THREADS / WAVE; i++) { a += rs[i]; b = fmaxf(b, rm[i]); }
-    atomicAdd(&out2[0], a);
-    atomicMax((unsigned int*)&out2[1], __float_as_uint(b));  // non-negative floats order like uints
+    g_gn_part[blockIdx.x] = a;
+    g_gn_part[GN_BLOCKS + blockIdx.x] = b;
   }
+}
+__global__ void __launch_bounds__(WAVE) k_grad_norm_final(int nblocks, float* __restrict__ out2) {
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += WAVE) { a += g_gn_part[i]; b = fmaxf(b, g_gn_part[GN_BLOCKS + i]); }     // lane l: blocks l, l + 64, ... in order
+  a = wave_sum(a);                                                                                                 // fixed lane tree
+  b = wave_max(b);
+  if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
 }
 extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2) {
   ST_REQUIRE(g && out2 && n > 0 && (elem_bytes == 4 || elem_bytes == 2), "grad_norm: bad args");
   ProfScope ps(stream, ST355_K_OPTIM, 3.0 * n, (double)elem_bytes * n);
-  zero_words(stream, out2, 2);
+  int64_t nb = cdiv64(n, OP_THREADS);
+  if (nb > GN_BLOCKS) nb = GN_BLOCKS;
   if (elem_bytes == 4)
-    hipLaunchKernelGGL(k_grad_norm<float>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (const float*)g, n, out2);
+    hipLaunchKernelGGL(k_grad_norm<float>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const float*)g, n);
   else
-    hipLaunchKernelGGL(k_grad_norm<bf16>, dim3(op_blocks(n)), dim3(OP_THREADS), 0, (hipStream_t)stream, (const bf16*)g, n, out2);
+    hipLaunchKernelGGL(k_grad_norm<bf16>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const bf16*)g, n);
+  hipLaunchKernelGGL(k_grad_norm_final, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, (int)nb, out2);
   return st355_check_launch("grad_norm");
 }
 

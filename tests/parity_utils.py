@@ -61,7 +61,7 @@ def make_inputs(B, lat_h, lat_w, S_txt, joint_dim, pooled, device, seed=0, chann
     return cpu, dev
 
 
-def oracle_step(P, ocfg, lora, lora_scale, cpu, guidance_value=1.0, dtype=torch.float32):
+def oracle_step(P, ocfg, lora, lora_scale, cpu, guidance_value=1.0, dtype=torch.float32, checkpoint=False):
     """reference step (on the device the weights P live on): noising -> model_predict -> MSE -> autograd.  Returns loss, prediction, {name: (dA, dB)}."""
     odev = next(iter(P.values())).device
     cpu = {k: v.to(odev) for k, v in cpu.items()}
@@ -69,10 +69,10 @@ def oracle_step(P, ocfg, lora, lora_scale, cpu, guidance_value=1.0, dtype=torch.
     x, n = cpu["latents"].to(dtype), cpu["noise"].to(dtype)
     noisy = ((1 - s) * x + s * n).to(torch.bfloat16).to(dtype)       # the trainer feeds bf16 noisy latents (common.py:4990)
     target = (n - x).to(torch.bfloat16).to(dtype)
-    Pd = {k: v.to(dtype) for k, v in P.items()}
+    Pd = P if all(v.dtype == dtype for v in P.values()) else {k: v.to(dtype) for k, v in P.items()}
     lp = {k: (a.to(dtype).requires_grad_(True), b.to(dtype).requires_grad_(True)) for k, (a, b) in lora.items()}
     pred = OF.flux_model_predict(Pd, ocfg, noisy, cpu["prompt"].to(dtype), cpu["pooled"].to(dtype), cpu["sigmas"].to(dtype) * 1000.0,
-                                 guidance_value, lora=lp, lora_scale=lora_scale)
+                                 guidance_value, lora=lp, lora_scale=lora_scale, checkpoint=checkpoint)
     loss = ((pred.float() - target.float()) ** 2).mean(dim=(1, 2, 3)).mean()
     loss.backward()
     grads = {k: (a.grad, b.grad) for k, (a, b) in lp.items()}

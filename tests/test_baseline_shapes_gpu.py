@@ -144,7 +144,7 @@ def test_pixart_cross_attention_at_2k(ops):
 # ------------------------------------------------------------------------------------------------------------------------
 # full-width train steps through the plugin surface
 # ------------------------------------------------------------------------------------------------------------------------
-def _check_step(tag, plugin, model, out, loss, o_loss, o_pred, o_grads, grad_tol=5e-2):
+def _check_step(tag, plugin, model, out, loss, o_loss, o_pred, o_grads, grad_tol=5e-2, pred_tol=2e-2, cos_tol=0.999):
     r, c = PU.rel_l2(out["model_prediction"], o_pred), PU.cos_sim(out["model_prediction"], o_pred)
     worst = (0.0, "")
     n = 0
@@ -156,10 +156,10 @@ def _check_step(tag, plugin, model, out, loss, o_loss, o_pred, o_grads, grad_tol
         rg, cg = PU.rel_l2(p.grad, ref), PU.cos_sim(p.grad, ref)
         worst = max(worst, (rg, name))
         n += 1
-        assert rg < grad_tol and cg > 0.999, f"{name}: rel={rg:.3e} cos={cg:.5f}"
+        assert rg < grad_tol and cg > cos_tol, f"{name}: rel={rg:.3e} cos={cg:.5f}"
     print(f"[parity@config] {tag}: pred rel_l2={r:.3e} cos={c:.6f}  loss hip={loss.item():.6f} oracle={o_loss.item():.6f}  "
           f"{n} adapter gradients, worst rel_l2={worst[0]:.3e} at {worst[1]}")
-    assert r < 2e-2 and c > 0.9995
+    assert r < pred_tol and c > 0.9995
     assert abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
 
 
@@ -188,6 +188,41 @@ def test_flux_full_width_step_matches_oracle():
     loss.backward()
     o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu)
     _check_step("flux D=3072 S=4096+512 (1 double + 1 single)", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads)
+
+
+def test_flux_full_depth_step_matches_oracle():
+    """BASELINE.json configs[1] at its real depth: Flux.1-dev, 19 double + 38 single blocks, D=3072, 24x128 heads, 4096 image + 512 text tokens,
+    LoRA r32 on the default target set, B=1 — one train step (forward, flow-matching MSE, backward into the adapter factors of all 190 target projections) against the fp32
+    restatement run at the same depth on the device's ATen kernels with per-block recomputation (oracle.flux.flux_forward(checkpoint=True)).
+    What the two-block tests cannot see: error growth through 57 residual updates, the activation arena / segment bookkeeping at full depth, 57 blocks
+    of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 3e-2 and cosine >= 0.9995, |delta loss| <= 1e-3 x loss, every adapter gradient
+    rel-L2 <= 1e-1 with cosine >= 0.995 (bf16 storage of the residual stream over 57 blocks).  Measured r3: prediction rel-L2 1.73e-2, cosine 0.99985,
+    loss 3.030217 vs 3.030492, worst of the 380 adapter gradients 3.5e-2 (single block 31 to_k lora_A)."""
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+
+    dev = torch.device(DEV)
+    cfg = default_config(lora_rank=32, train_batch_size=1, seed=21, lora_init_b_std=0.02, flow_schedule_shift=3.0)
+    acc = St355Accelerator(dev)
+    plugin = Flux(cfg, acc)
+    plugin.load_model(guidance_embeds=True)                                              # every hyper-parameter = the Flux.1-dev default
+    plugin.add_lora_adapter()
+    model = plugin.get_trained_component()
+    assert model.config.num_layers == 19 and model.config.num_single_layers == 38 and model.D == 3072
+    cpu, devt = PU.make_inputs(1, 128, 128, 512, 4096, 768, dev, seed=21)
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    batch = {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
+    prepared = plugin.prepare_batch(batch, {"global_step": 0})
+    out = plugin.model_predict(prepared)
+    loss, _ = plugin.loss_with_logs(prepared, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    P, lora, scale = PU.oracle_state(model, device=DEV)                                   # 12 B parameters in fp32 on the device: 48 GB of the 288
+    o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu, checkpoint=True)
+    assert len(o_grads) == len(lora) >= 19 * 4 + 38 * 3
+    _check_step("flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads, grad_tol=1e-1,
+                pred_tol=3e-2, cos_tol=0.995)
 
 
 def test_sd3_full_width_step_matches_oracle():
@@ -231,53 +266,80 @@ def test_sd3_full_width_step_matches_oracle():
                 {k: (a.grad, b.grad) for k, (a, b) in lp.items()})
 
 
-@pytest.mark.parametrize("lr,abs_tol,rel_tol", [(1e-4, 1.5e-3, 1e-3), (1e-3, None, 2e-3)])
-def test_flux_loss_curve_100_steps_matches_oracle_adamw(lr, abs_tol, rel_tol):
+@pytest.mark.parametrize("shape,lr,abs_tol,rel_tol", [("baseline-width", 1e-4, 1e-3, 1e-3), ("toy", 1e-4, 1.5e-3, 1e-3), ("toy", 1e-3, None, 2e-3)])
+def test_flux_loss_curve_100_steps_matches_oracle_adamw(shape, lr, abs_tol, rel_tol):
     """north star / SURVEY.md §8(c): 100 optimizer steps on identical noise / timesteps, HIP (bf16 compute, fused fp32 AdamW over the flat adapter
     arena) vs oracle (fp32 autograd, torch.optim.AdamW).
-      * lr 1e-4 — the learning rate of the reference's Flux LoRA examples: |delta loss| <= 1e-3 of the loss at every step (the north-star criterion read
-        relative to a loss of ~3.3; measured r2: max relative 3.4e-4, max ABSOLUTE 1.14e-3 at step 79 — the absolute reading of "1e-3" is missed by 14 %
-        on this config, stated in DESIGN.md; step 0 alone differs by 3.1e-4, the bf16-vs-fp32 forward error);
-      * lr 1e-3 — ten times that, the loss falls from 3.6 to 2.0 inside the 100 steps: two trajectories that differ by bf16 rounding drift apart along
-        the steep part (measured r2: max |delta| 3.5e-3 at step 45, loss 2.25), bounded here RELATIVE to the loss at that step (2e-3)."""
+      * "baseline-width", lr 1e-4 (the learning rate of the reference's Flux LoRA examples) — Flux.1-dev width and sequence (D=3072, 24x128 heads,
+        4096 image + 512 text tokens, 1 double + 1 single block, LoRA r32, B=1), oracle on the device's ATen fp32 kernels: the north-star criterion as
+        written, |delta loss| <= 1e-3 ABSOLUTE at every step.  A third curve — the same oracle under torch.autocast(bf16), i.e. the precision the
+        reference itself trains at (mixed_precision=bf16) — is printed beside it: the distance of the reference's OWN bf16 run from the fp32 curve.
+        Measured r3: HIP vs fp32 oracle max |delta| 4.5e-4 (step 17); autocast-bf16 oracle vs fp32 oracle 4.8e-4 (step 11).
+      * "toy" (D=256, 16x16 latents, B=2: 8192 loss elements), lr 1e-4: max relative 3.4e-4, max ABSOLUTE 1.14e-3 at step 79 (r2; r3: 1.25e-3 at step 89) — the absolute reading
+        is missed by 14 % on this small-sample config (a loss averaged over 250x fewer elements than the baseline shape); bound kept at 1.5e-3 and
+        stated as a miss in DESIGN.md.
+      * "toy", lr 1e-3 — ten times that, the loss falls from 3.6 to 2.0 inside the 100 steps: two trajectories that differ by bf16 rounding drift apart
+        along the steep part (measured r2: max |delta| 3.5e-3 at step 45, loss 2.25), bounded here RELATIVE to the loss at that step (2e-3)."""
     from simpletuner_amd.flux.model import Flux
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
     dev = torch.device(DEV)
-    cfg = default_config(lora_rank=8, train_batch_size=2, seed=3, lora_init_b_std=0.02, learning_rate=lr, flow_schedule_shift=3.0)
+    wide = shape == "baseline-width"
+    cfg = default_config(lora_rank=32 if wide else 8, train_batch_size=1 if wide else 2, seed=3, lora_init_b_std=0.02, learning_rate=lr,
+                         flow_schedule_shift=3.0)
     acc = St355Accelerator(dev)
     plugin = Flux(cfg, acc)
-    plugin.load_model(**PU.small_flux_cfg(layers=1, single=1))
+    if wide:
+        plugin.load_model(num_layers=1, num_single_layers=1, guidance_embeds=True)
+    else:
+        plugin.load_model(**PU.small_flux_cfg(layers=1, single=1))
     plugin.add_lora_adapter()
     trainer = Trainer(cfg, plugin, acc)
-    cpu, devt = PU.make_inputs(2, 16, 16, 32, 128, 64, dev, seed=3)
+    cpu, devt = PU.make_inputs(1, 128, 128, 512, 4096, 768, dev, seed=3) if wide else PU.make_inputs(2, 16, 16, 32, 128, 64, dev, seed=3)
     model = plugin.get_trained_component()
     sig = devt["sigmas"]
     plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
-    P, lora, scale = PU.oracle_state(model)
+    odev = DEV if wide else "cpu"
+    P, lora, scale = PU.oracle_state(model, device=odev)
     ocfg = PU.oracle_cfg(model)
     names = sorted(lora)
-    params = {k: (torch.nn.Parameter(lora[k][0].clone()), torch.nn.Parameter(lora[k][1].clone())) for k in names}
-    opt = torch.optim.AdamW([t for k in names for t in params[k]], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ins = {k: v.to(odev) for k, v in cpu.items()}
+    s = ins["sigmas"].view(-1, 1, 1, 1)
+    noisy = ((1 - s) * ins["latents"] + s * ins["noise"]).to(BF16).float()
+    target = (ins["noise"] - ins["latents"]).to(BF16).float()
+
+    class Twin:                                           # one oracle trajectory: its own adapter copies + torch.optim.AdamW
+        def __init__(self, autocast):
+            self.params = {k: (torch.nn.Parameter(lora[k][0].clone()), torch.nn.Parameter(lora[k][1].clone())) for k in names}
+            self.opt = torch.optim.AdamW([t for k in names for t in self.params[k]], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+            self.autocast, self.curve = autocast, []
+
+        def step(self):
+            self.opt.zero_grad()
+            with torch.autocast("cuda" if wide else "cpu", dtype=BF16, enabled=self.autocast):
+                pred = PU.OF.flux_model_predict(P, ocfg, noisy, ins["prompt"], ins["pooled"], ins["sigmas"] * 1000.0, 1.0, lora=self.params, lora_scale=scale)
+            l = ((pred.float() - target) ** 2).mean(dim=(1, 2, 3)).mean()
+            l.backward(); self.opt.step()
+            self.curve.append(l.item())
+
+    twins = [Twin(False)] + ([Twin(True)] if wide else [])
     batch = lambda: {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
-    s = cpu["sigmas"].view(-1, 1, 1, 1)
-    noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(BF16).float()
-    target = (cpu["noise"] - cpu["latents"]).to(BF16).float()
-    hip, ora = [], []
+    hip = []
     for step in range(100):
         hip.append(trainer.train_step(batch()))
-        opt.zero_grad()
-        pred = PU.OF.flux_model_predict(P, ocfg, noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, 1.0,
-                                        lora={k: params[k] for k in names}, lora_scale=scale)
-        l = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
-        l.backward(); opt.step()
-        ora.append(l.item())
+        for t in twins:
+            t.step()
+    ora = twins[0].curve
     hip = [float(x) for x in torch.stack([h.reshape(()) for h in hip]).cpu()]
     d = [abs(a - b) for a, b in zip(hip, ora)]
-    print("[parity] 100-step loss curve hip   :", [round(x, 5) for x in hip[::10]], "...", round(hip[-1], 5))
-    print("[parity] 100-step loss curve oracle:", [round(x, 5) for x in ora[::10]], "...", round(ora[-1], 5))
+    print(f"[parity] {shape} 100-step loss curve hip   :", [round(x, 5) for x in hip[::10]], "...", round(hip[-1], 5))
+    print(f"[parity] {shape} 100-step loss curve oracle:", [round(x, 5) for x in ora[::10]], "...", round(ora[-1], 5))
     rel = [x / max(1e-6, abs(o)) for x, o in zip(d, ora)]
-    print(f"[parity] lr={lr:g}: max |delta loss| over 100 steps = {max(d):.3e} (at step {d.index(max(d))}), max relative = {max(rel):.3e}")
+    print(f"[parity] {shape} lr={lr:g}: max |delta loss| over 100 steps = {max(d):.3e} (at step {d.index(max(d))}), max relative = {max(rel):.3e}")
+    if wide:
+        d16 = [abs(a - b) for a, b in zip(twins[1].curve, ora)]
+        print(f"[parity] {shape} lr={lr:g}: the oracle under torch.autocast(bf16) (the reference's own training precision) vs the fp32 oracle: "
+              f"max |delta loss| = {max(d16):.3e} (at step {d16.index(max(d16))})")
     if abs_tol is not None:
         assert max(d) < abs_tol
     if rel_tol is not None:

@@ -39,6 +39,30 @@ def test_vae_encode_matches_oracle(kind):
     assert s.shape == (2, cfg.latent_channels, 12, 8) and torch.isfinite(s.float()).all()
 
 
+@pytest.mark.parametrize("kind", ["sdxl", "flux"])
+def test_vae_encode_at_true_widths_1024(kind):
+    """SURVEY.md §8 row 1 at BASELINE.json's size: the production encoder widths (128, 256, 512, 512), a 1024 x 1024 image (the 16384-token mid-block
+    attention, the 1024^2 x 128-channel first stage) — the small-width case above exercises neither.  Oracle on the device's ATen fp32 kernels."""
+    from simpletuner_amd.vae.autoencoder_kl import AutoencoderKL
+    dev = "cuda:0"
+    cfg = VAEConfig() if kind == "sdxl" else VAEConfig(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False)
+    assert tuple(cfg.block_out_channels) == (128, 256, 512, 512)
+    vae = AutoencoderKL(latent_channels=cfg.latent_channels, block_out_channels=cfg.block_out_channels, scaling_factor=cfg.scaling_factor,
+                        shift_factor=cfg.shift_factor, use_quant_conv=cfg.use_quant_conv, device=dev)
+    sd = vae.synthetic_state_dict(5)
+    vae.load_state_dict(sd)
+    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(2)).clamp(-1, 1)
+    got = vae.encode_moments(x.to(dev))
+    with torch.no_grad():
+        ref = encode_moments({k: v.to(dev).float() for k, v in sd.items()}, cfg, x.to(torch.bfloat16).float().to(dev))
+    assert got.shape == ref.shape == (1, 2 * cfg.latent_channels, 128, 128)
+    r = _rel(got, ref)
+    z, zr = vae.encode_scaled(x.to(dev), sample=False), sample_and_scale(ref, cfg)
+    rz = _rel(z, zr)
+    print(f"[parity@config] vae {kind} encode 1024^2, widths {tuple(cfg.block_out_channels)}: moments rel-L2 {r:.3e}, scaled latents (mode) rel-L2 {rz:.3e}")
+    assert r < 2e-2 and rz < 2.5e-2
+
+
 def test_softmax_rows_kernel():
     from simpletuner_amd import ops
     dev = "cuda:0"
