@@ -408,32 +408,51 @@ def main():
     out = run_workload(args, dev, rank, world)
     if args.model == "flux" and not args.no_secondary:
         # the metric names "SDXL-LoRA & Flux-dev 1024^2": the SDXL-LoRA half rides along as a secondary measurement of the same run
-        # (r16 on attn1/attn2 to_q/to_k/to_v/to_out.0, a few steps; hipGraph replay on one GPU, eager launches under N > 1).  Per-GPU batch 16: the UNet's
+        # (r16 on attn1/attn2 to_q/to_k/to_v/to_out.0, a few steps; hipGraph replay at every N — the gradient exchange follows each replay).  Per-GPU batch 16: the UNet's
         # 32^2 / 64^2 levels give a 256-CU chip too few tiles per launch at batch 4 (measured r02, same box: batch 4 / 8 / 16 = 23.8 / 29.9 / 37.3 images/s,
         # GEMM class 496 / 613 / 820 TFLOP/s) and 288 GB holds batch 16 many times over; `--model sdxl --lora --rank 16 --batch 4` is configs[1]'s batch
         import copy
         import gc
-        gc.collect()
-        torch.cuda.empty_cache()                  # the Flux workload's cached blocks go back before the UNet's capture pool is built
+        keys = ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config", "step_model_tflops", "step_frac_of_bf16_mfma_peak",
+                "roofline", "loss")
         a2 = copy.copy(args)
-        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False      # hipGraph replay at every N (r03)
-        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.prof_dump, a2.fp8 = min(args.steps, 5), 2, True, None, False
-        sec = run_workload(a2, dev, rank, world)
-        if rank == 0:
-            out["secondary"] = {"sdxl_lora": {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config",
-                                                                    "step_model_tflops", "step_frac_of_bf16_mfma_peak", "roofline", "loss")}}
+        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
-        del sec
-        gc.collect()
-        torch.cuda.empty_cache()
         a3 = copy.copy(args)
         a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
-        a3.steps, a3.warmup, a3.no_cpu_baseline, a3.prof_dump, a3.fp8, a3.gradient_checkpointing = min(args.steps, 5), 2, True, None, False, False
-        sec = run_workload(a3, dev, rank, world)
         if rank == 0:
-            out["secondary"]["sd3_full_buckets"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config",
-                                                                          "step_model_tflops", "step_frac_of_bf16_mfma_peak", "roofline", "loss")}
+            out["secondary"] = {}
+        for name, a_ in (("sdxl_lora", a2), ("sd3_full_buckets", a3)):
+            a_.steps, a_.warmup, a_.no_cpu_baseline, a_.prof_dump, a_.fp8, a_.gradient_checkpointing = min(args.steps, 5), 2, True, None, False, False
+            gc.collect()
+            torch.cuda.empty_cache()              # the previous workload's cached blocks go back before the next one's pools are built
+            try:                                  # a secondary must never take the headline line down with it (every rank runs the same code: they fail together)
+                sec = run_workload(a_, dev, rank, world)
+                if rank == 0:
+                    out["secondary"][name] = {k: sec[k] for k in keys}
+                del sec
+            except Exception as e:                # noqa: BLE001
+                if rank == 0:
+                    out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if world == 1 and not args.no_cpu_baseline and rank == 0:
+            # the oracle as the CHECKER of the HIP components at the other four BASELINE.json configurations (true widths / sequence lengths; the UNets at their
+            # true depth, the transformer stacks at a reduced block count) — tests/parity_at_config.py, the same functions the GPU tests assert on
+            from tests import parity_at_config as PC
+            others = {}
+            for name, fn in (("configs[0] sd15_lora_r16_512", lambda: PC.unet("sd15", 512, dev, lora=True, rank=16)),
+                             ("configs[1] sdxl_lora_r16_1024", lambda: PC.unet("sdxl", 1024, dev, lora=True, rank=16)),
+                             ("configs[3] sd3_full_finetune_1024", lambda: PC.sd3_full(1024, dev)),
+                             ("configs[4] pixart_controlnet_2k", lambda: PC.pixart_controlnet(2048, dev))):
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    t0 = time.time()
+                    others[name] = fn()
+                    others[name]["seconds"] = round(time.time() - t0, 1)
+                except Exception as e:            # noqa: BLE001
+                    others[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            out["parity_at_other_configs"] = others
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -7,7 +7,10 @@ architecture UNCORROBORATED in-tree) restated from its published definition: con
 embedding: GroupNorm32 eps 1e-6 -> SiLU -> conv3x3 -> GroupNorm -> SiLU -> conv3x3, 1x1 conv_shortcut on channel change; Downsample2D with
 padding 0 = F.pad(x,(0,1,0,1)) + conv3x3 stride 2) -> UNetMidBlock2D (resnet, single-head attention of dim C with GroupNorm + residual, resnet)
 -> GroupNorm -> SiLU -> conv_out (2*latent channels) [-> quant_conv 1x1] -> DiagonalGaussianDistribution(mean, logvar clamp [-30, 20]).
-PARITY UNPINNED: no golden tensor exists in the reference for this network and diffusers is not installable here.
+PINNED (round 3): the reference vendors this KL autoencoder once WITH a converter from diffusers' AutoencoderKL key names
+(simpletuner/helpers/models/ideogram/autoencoder.py:29-273 network, :321-392 `convert_diffusers_state_dict`).  tools/gen_ref_models.py `gen_vae` executes it on a
+seeded diffusers-named checkpoint (its converter accepted exactly this file's key names, its load_state_dict their shapes); tests/test_ref_models_cpu.py holds
+`encode_moments` / `decode` and their input gradients to <= 1e-5 of its outputs (tests/golden/ref_vae_model.pt), SDXL-layout (quant convs) and FLUX-layout (none).
 """
 from __future__ import annotations
 

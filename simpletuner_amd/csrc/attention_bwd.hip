@@ -171,8 +171,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
   constexpr int TT_BYTES = HD * 128;     // K^T tile (HD rows x 64 keys)
-  static_assert(!TR || HD == 128, "the transposing-read form is built for head_dim 128");
-  constexpr int BUF = 2 * KT_BYTES + (TR ? 0 : TT_BYTES);
+  // TR: the K tile image keeps a 256-byte row pitch at every head_dim (16 chunk slots per key row, HD / 8 of them used): the swz_q chunk swizzle and the
+  // transposing-read lane layout of dkv3 were derived for that pitch; head_dim 64 / 96 leave slots empty instead of needing a second swizzle
+  constexpr int KI_BYTES = TR ? 64 * 256 : KT_BYTES;
+  constexpr int BUF = KI_BYTES + KT_BYTES + (TR ? 0 : TT_BYTES);
   constexpr int NKS = HD / 16, NDT = HD / 32;
   constexpr int KTOT = KT_BYTES / 16, TTOT = TT_BYTES / 16;             // 16-byte chunks per tile (head_dim 96: 768, not a multiple of 512)
   constexpr int KCH = (KTOT + NT - 1) / NT;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   };
   auto store_tile = [&](int buf) {
     char* ks = smem + buf * BUF;
-    char* vs = ks + KT_BYTES;
+    char* vs = ks + KI_BYTES;
     char* ts = vs + KT_BYTES;
 #pragma unroll
     for (int p = 0; p < KCH; p++) {
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
     const char* ks = smem + buf * BUF;
-    const char* vs = ks + KT_BYTES;
+    const char* vs = ks + KI_BYTES;
     const char* ts = vs + KT_BYTES;
     const int key0 = kt * 64;
 #pragma unroll
@@ -561,6 +563,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv2(const bf16* __restrict
 // dO^T buffers in HBM at all (the QKV epilogue kernel and the prep kernel stop writing them).
 // Tile image: row = query (256 B), 16-byte chunk c stored at c ^ f(row), f = swz_q.
 // ------------------------------------------------------------------------------------------------
+// head_dim 64 / 96 (r3): same kernel, same 256-byte row pitch of the tile images (16 chunk slots per query row, HD / 8 used — the DMA lanes of the empty
+// slots are masked off), NKS / NDT from the head_dim; the fused RoPE epilogue stays head_dim 128 only.
+template <int HD>
 __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                          const bf16* __restrict__ Vrows, int64_t ld_v,
                                                          const bf16* __restrict__ dO, int64_t ld_do,
@@ -568,8 +573,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
                                                          const float* __restrict__ key_bias, bf16* __restrict__ dK,
                                                          bf16* __restrict__ dVrows, int64_t ld_dv, int H, int Sq, int Sqp, int Sk, float scale,
                                                          float scale2, RopeBwd rp) {
-  constexpr int HD = 128;
-  constexpr int QROWB = HD * 2;
+  constexpr int QROWB = 256;             // row pitch of the tile images (= the head_dim 128 row; narrower heads leave chunk slots empty)
   constexpr int QT_BYTES = 64 * QROWB;   // Q tile / dO tile (64 queries, row-major): 16 KiB each
   constexpr int STAT_BYTES = 2 * 64 * 4;
   constexpr int BUF = 2 * QT_BYTES + STAT_BYTES;
@@ -624,8 +628,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
       const int row = idx / CPR;                                   // tile row = query
       const int col = ((idx % CPR) ^ swz_q(row)) * 8;              // LDS chunk position c holds source chunk c ^ f(row)
       const int qq = min(qq0 + row, Sq - 1);
-      a_glds16(Qg + (uint32_t)(qq * HD + col), qs + piece * 1024);
-      a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + piece * 1024);
+      if (HD == 128 || col < HD) {                                 // (head_dim 64 / 96: the slots of source chunks >= HD / 8 stay unwritten and unread)
+        a_glds16(Qg + (uint32_t)(qq * HD + col), qs + piece * 1024);
+        a_glds16(dOg + ((int64_t)qq * ld_do + col), gs + piece * 1024);
+      }
     }
     if (wv == 0) a_glds4(lse_g + qq0 + ln, stat);
     if (wv == 1) a_glds4(del_g + qq0 + ln, stat + 256);
@@ -718,7 +724,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
     const int h = (t2 >> 5) & 1;
     const int wv2 = __builtin_amdgcn_readfirstlane(t2 >> 6);
     const int key = wg.tile * 256 + wv2 * 32 + (t2 & 31);
-    rope_bwd_store(rp, acc_dk, scale, K + bh * (int64_t)Sk * HD, b, head, wg.tile * 256 + wv2 * 32, Sk, t2 & 63, smem + wv2 * 8192);
+    if constexpr (HD == 128) rope_bwd_store(rp, acc_dk, scale, K + bh * (int64_t)Sk * HD, b, head, wg.tile * 256 + wv2 * 32, Sk, t2 & 63, smem + wv2 * 8192);
     if (key < Sk) {
       bf16* vrow = dVrows + ((int64_t)b * Sk + key) * ld_dv + (int64_t)head * HD;
 #pragma unroll
@@ -767,7 +773,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   ST_REQUIRE(Q && K && v_rows && O && dO && lse2 && (dQ || rq.out) && (dK || rk.out) && dv_rows && workspace, "attn_bwd: null pointer");
   // Qt == NULL selects the third-generation dK/dV kernel, Kt == NULL the transposing-read dQ kernel (head_dim 128): Q^T / dO^T / K^T fragments come
   // from the row-major tiles by ds_read_b64_tr_b16 instead of pre-transposed head-major copies
-  ST_REQUIRE((Qt && Kt) || d == 128, "attn_bwd: Qt / Kt may only be omitted for head_dim 128 (got %d)", d);
+  ST_REQUIRE((rq.out == nullptr && rk.out == nullptr) || d == 128, "attn_bwd: the fused RoPE epilogues are built for head_dim 128 (got %d)", d);
   ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sp % 64 == 0 && Sp >= S && Sk > 0 && Skp % 64 == 0 && Skp >= Sk, "attn_bwd: bad shape S=%d Sp=%d Sk=%d Skp=%d", S, Sp, Sk, Skp);
   ST_REQUIRE(ld_v % 8 == 0 && ld_o % 8 == 0 && ld_do % 8 == 0 && ld_dv % 4 == 0, "attn_bwd: leading dimensions must be multiples of 8");
   ST_REQUIRE(((uintptr_t)workspace & 255) == 0, "attn_bwd: workspace must be 256-byte aligned");
@@ -795,10 +801,18 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     if (!Qt) {
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * 256 + 512);
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv3, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
-                         (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);
+#define ST355_DKV3_LAUNCH(HD_)                                                                                                            \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    hipLaunchKernelGGL(k_attn_bwd_dkv3<HD_>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v,        \
+                       (const bf16*)dO, ld_do, (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S,  \
+                       Sp, Sk, scale, scale2, rk);                                                                                        \
+  } while (0)
+      if (d == 128) ST355_DKV3_LAUNCH(128);
+      else if (d == 96) ST355_DKV3_LAUNCH(96);
+      else ST355_DKV3_LAUNCH(64);
+#undef ST355_DKV3_LAUNCH
     } else {                                   // head-major Q^T / dO^T copies supplied: the LDS-DMA kernel over four tile images (head_dim 64 / 96 / 128)
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * d * 2 + 2 * d * 128 + 512);
@@ -821,8 +835,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int ktb = 64 * d * 2;                                   // one row-major 64-key tile
-    const bool tr = (d == 128 && !Kt);                            // no K^T copy: transposing-read kernel (head_dim 128 only)
-    const int lds = 2 * (2 * ktb + (tr ? 0 : d * 128));
+    const bool tr = !Kt;                                          // no K^T copy: transposing-read kernel (K tile image at a 256-byte row pitch)
+    const int lds = 2 * ((tr ? 64 * 256 : ktb) + ktb + (tr ? 0 : d * 128));
 #define ST355_DQ_LAUNCH(KERN)                                                                                                            \
   do {                                                                                                                                   \
     static bool set = false;                                                                                                             \
@@ -830,17 +844,20 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt, (const bf16*)v_rows, ld_v,     \
                        (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2, rq);    \
   } while (0)
-    if (key_bias) {
-      if (d == 96) ST355_DQ_LAUNCH((k_attn_bwd_dq<96, false, true>));
-      else if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, true, true>));
-      else if (d == 128) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, false, true>));
-      else ST355_DQ_LAUNCH((k_attn_bwd_dq<64, false, true>));
-    } else {
-      if (d == 96) ST355_DQ_LAUNCH((k_attn_bwd_dq<96, false, false>));
-      else if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, true, false>));
-      else if (d == 128) ST355_DQ_LAUNCH((k_attn_bwd_dq<128, false, false>));
-      else ST355_DQ_LAUNCH((k_attn_bwd_dq<64, false, false>));
-    }
+#define ST355_DQ_PICK(HD_)                                                                   \
+  do {                                                                                       \
+    if (key_bias) {                                                                          \
+      if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<HD_, true, true>));                             \
+      else ST355_DQ_LAUNCH((k_attn_bwd_dq<HD_, false, true>));                               \
+    } else {                                                                                 \
+      if (tr) ST355_DQ_LAUNCH((k_attn_bwd_dq<HD_, true, false>));                            \
+      else ST355_DQ_LAUNCH((k_attn_bwd_dq<HD_, false, false>));                              \
+    }                                                                                        \
+  } while (0)
+    if (d == 128) ST355_DQ_PICK(128);
+    else if (d == 96) ST355_DQ_PICK(96);
+    else ST355_DQ_PICK(64);
+#undef ST355_DQ_PICK
 #undef ST355_DQ_LAUNCH
     if ((rc = st355_check_launch("attn_bwd_dq")) != 0) return rc;
   }

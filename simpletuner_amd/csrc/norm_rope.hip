@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_fwd(const bf16* __restrict
 extern "C" int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const void* wq, const void* wk,
                                       const float* cos, const float* sin, void* Q, void* K, void* Qt, void* Kt, void* Vt, int B,
                                       int H, int d, int S_part, int pos0, int S, int Sp, float eps) {
-  ST_REQUIRE(qkv && cos && sin && Q && K && Vt, "qk_norm_rope_fwd: null pointer (Qt / Kt may be NULL: head_dim-128 backward without transposed copies)");
+  ST_REQUIRE(qkv && cos && sin && Q && K && Vt, "qk_norm_rope_fwd: null pointer (Qt / Kt may be NULL: backward without transposed copies)");
   ST_REQUIRE(ld_qkv % 8 == 0 && Sp % 64 == 0 && Sp >= S && pos0 + S_part <= S && S_part > 0, "qk_norm_rope_fwd: bad shape");
   ST_REQUIRE(d == 128 || d == 64, "qk_norm_rope_fwd: head_dim %d not built", d);
   const double n = (double)B * S_part * H * d;

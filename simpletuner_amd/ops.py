@@ -6,6 +6,7 @@ shapes/dtypes, allocates the outputs, and passes raw device pointers + the curre
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -635,6 +636,10 @@ def attn_fwd_vrows(Q, K, v_rows, O, lse2, B, H, S, d, scale: float, key_bias=Non
 
 
 _attn_ws = {}
+
+
+# ST355_ATTN_TR=0: the engines build head-major Q^T / K^T copies and the backward reads them (dkv2 / dq); default: no copies, transposing LDS reads
+ATTN_TR = os.environ.get("ST355_ATTN_TR", "1") != "0"
 
 
 def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale: float, key_bias=None):

@@ -264,8 +264,8 @@ class PixArtTransformer2DModel(nn.Module):
             return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
         qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
-        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S)
-        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S)
+        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
+        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
         _, Vt, _ = ops.head_split(qkv[:, 2 * Dp:], B, H, HP, S, want_x=False)
         O = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
         lse = torch.empty(B, H, S, dtype=F32, device=h.device)
@@ -274,8 +274,8 @@ class PixArtTransformer2DModel(nn.Module):
         h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=S, aux_out=ya)
         q2 = ops.gemm(h1, W.q2_w, bias=W.q2_b)
         kv = ops.gemm(ctx2d, W.kv2_w, bias=W.kv2_b)
-        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S)
-        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk)
+        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S, want_xt=not ops.ATTN_TR)
+        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk, want_xt=not ops.ATTN_TR)
         _, V2t, _ = ops.head_split(kv[:, Dp:], B, H, HP, Sk, want_x=False)
         O2 = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
         lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)
@@ -307,8 +307,8 @@ class PixArtTransformer2DModel(nn.Module):
 
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
         qkv = lin8(n1, "qkv", W.qkv_b)
-        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S)
-        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S)
+        Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
+        K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
         _, Vt, _ = ops.head_split(qkv[:, 2 * Dp:], B, H, HP, S, want_x=False)
         O = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
         lse = torch.empty(B, H, S, dtype=F32, device=h.device)
@@ -316,8 +316,8 @@ class PixArtTransformer2DModel(nn.Module):
         h1 = ops.add(h, ops.scale_cols(lin8(O, "out1", W.out1_b), m[2], S))
         q2 = lin8(h1, "q2", W.q2_b)
         kv = lin8(ctx2d, "kv2", W.kv2_b)
-        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S)
-        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk)
+        Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S, want_xt=not ops.ATTN_TR)
+        K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk, want_xt=not ops.ATTN_TR)
         _, V2t, _ = ops.head_split(kv[:, Dp:], B, H, HP, Sk, want_x=False)
         O2 = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
         lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)

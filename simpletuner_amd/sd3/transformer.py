@@ -361,7 +361,12 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             f()
         Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
         mk = torch.zeros if Sp > S else torch.empty
-        Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        # head-major Q^T / K^T copies only for the copy-reading backward kernels (ST355_ATTN_TR=0); the default backward gathers those fragments by
+        # transposing LDS reads from the row-major tiles (attention_bwd.hip dkv3 / dq<TR>, r3: head_dim 64 too)
+        Qt = Kt = None
+        if not ops.ATTN_TR:
+            Qt = mk(B, H, hd, Sp, dtype=BF16, device=dev); Kt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
+        Vt = mk(B, H, hd, Sp, dtype=BF16, device=dev)
         ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, 0, S, Sp)
         ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, Si, S, Sp)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)

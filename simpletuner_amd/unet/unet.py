@@ -572,8 +572,8 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         dev = qsrc.device
         self_attn = qsrc is kvsrc
         M, Mk = B * S, B * Sk
-        Q, Qt, Sp = ops.head_split(qsrc[:, qo:qo + C_], B, heads, hp, S, d_src=hd)
-        K, Kt, Skp = ops.head_split(kvsrc[:, ko:ko + C_], B, heads, hp, Sk, d_src=hd)
+        Q, Qt, Sp = ops.head_split(qsrc[:, qo:qo + C_], B, heads, hp, S, d_src=hd, want_xt=not ops.ATTN_TR)
+        K, Kt, Skp = ops.head_split(kvsrc[:, ko:ko + C_], B, heads, hp, Sk, d_src=hd, want_xt=not ops.ATTN_TR)
         _, Vt, _ = ops.head_split(kvsrc[:, vo:vo + C_], B, heads, hp, Sk, want_x=False, d_src=hd)
         exact = hp == hd
         Cp = heads * hp

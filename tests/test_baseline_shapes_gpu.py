@@ -104,7 +104,7 @@ def test_self_attention_at_baseline_shapes(ops, name, B, H, S, d, d_valid):
     assert dqkv[:, :2 * D].abs().max().item() == 0                      # only the V columns of the token-major buffer are written
     if d_valid < d:
         assert dQ[..., d_valid:].abs().max().item() == 0 and dK[..., d_valid:].abs().max().item() == 0
-    if d == 128:        # the production path of Flux: no Q^T / K^T / dO^T copies (dkv3 + dq<TR>), bit-identical to the copy-reading kernels
+    if d in (64, 96, 128):        # the production path: no Q^T / K^T / dO^T copies (dkv3 + dq<TR>), bit-identical to the copy-reading kernels
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO_rows, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale)
         assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)

@@ -761,15 +761,15 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
     r3, _ = report("attn bwd dV", dqkv[:, 2 * D:].reshape(B, S, H, d).permute(0, 2, 1, 3), vf.grad)
     assert r1 < 2e-2 and r2 < 2e-2 and r3 < 2e-2
     assert dqkv[:, :2 * D].abs().max().item() == 0
-    if d == 128:
-        # head_dim 128 without the pre-transposed Q^T / K^T / dO^T copies (dkv3 + dq<TR>: transposing LDS reads on the row-major tiles): same math,
-        # same summation order per accumulator -> bit-identical to the kernels that read the copies
+    if d in (64, 96, 128):
+        # without the pre-transposed Q^T / K^T / dO^T copies (dkv3 + dq<TR>: transposing LDS reads on the row-major tiles; r3: head_dim 64 / 96 too, on
+        # tile images that keep the 256-byte row pitch): same math, same summation order per accumulator -> bit-identical to the kernels that read the copies
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
         assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
-@pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64)])
+@pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64), (1, 2, 333, 96), (2, 2, 512, 96)])
 def test_attention_fwd_bwd(ops, B, H, S, d):
     _attn_case(ops, B, H, S, d)
 
@@ -778,6 +778,7 @@ def test_attention_key_bias_and_rescale_branch(ops):
     _attn_case(ops, 1, 2, 320, 128, bias=True)
     _attn_case(ops, 1, 2, 448, 128, spike=True)
     _attn_case(ops, 1, 2, 200, 64, bias=True, spike=True)
+    _attn_case(ops, 1, 2, 300, 96, bias=True)
 
 
 # ------------------------------------------------------------------------------------------------

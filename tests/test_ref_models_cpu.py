@@ -257,3 +257,30 @@ def test_pixart_oracle_block_equals_the_reference_tokenwise_block():
     bc = G["block_case"]
     out = OP.block(P, f"transformer_blocks.{bc['block_index']}.", cfg, bc["h"], bc["ctx"], bc["bias"][:, 0, :], bc["t6"])
     assert rel_l2(out, bc["out_tokenwise_reference_code"]) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# VAE: the KL autoencoder the reference vendors together with a diffusers-key converter (tools/gen_ref_models.py gen_vae)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["sdxl_layout", "flux_layout"])
+def test_vae_oracle_reproduces_the_reference_autoencoder(case):
+    """oracle/vae.py (AutoencoderKL.encode -> moments, .decode -> pixels, under diffusers' key names) against the reference's own vendored KL autoencoder
+    EXECUTED on the same seeded checkpoint (its `convert_diffusers_state_dict` accepted exactly the oracle's key names, its `load_state_dict` their shapes):
+    moments, pixels and the input gradients of both halves, fp32, <= 1e-5."""
+    from oracle import vae as OV
+    G = torch.load(os.path.join(GOLD, "ref_vae_model.pt"))
+    c = G["cases"][case]
+    cfg = OV.VAEConfig(latent_channels=c["latent_channels"], block_out_channels=tuple(c["block_out_channels"]), use_quant_conv=c["use_quant_conv"])
+    shapes = {k: tuple(v.shape) for k, v in OV.init_params(cfg, shapes_only=True).items()}
+    st = seeded_state(shapes, c["seed"])
+    P = {k: (1.0 + 0.1 * v if (("norm" in k) and k.endswith(".weight")) else v) for k, v in st.items()}      # norm scales around 1, as the generator
+    assert abs(state_checksum(P) - c["state_checksum"]) < 1e-6 * max(1.0, abs(c["state_checksum"]))       # same names, same shapes, same values
+    x = c["x"].clone().requires_grad_(True)
+    z = c["z"].clone().requires_grad_(True)
+    m = OV.encode_moments(P, cfg, x)
+    (m * c["w_m"]).sum().backward()
+    px = OV.decode(P, cfg, z)
+    (px * c["w_p"]).sum().backward()
+    errs = {"moments": rel_l2(m, c["moments"]), "pixels": rel_l2(px, c["pixels"]), "dx": rel_l2(x.grad, c["dx"]), "dz": rel_l2(z.grad, c["dz"])}
+    print(f"[ref-pin] vae {case}:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 1e-5 for v in errs.values()), errs

@@ -201,6 +201,10 @@ def test_cross_attention_fwd_bwd_vs_torch(B, H, Sq, Sk):
     dK = torch.empty_like(K)
     dkv = torch.zeros_like(kv)
     ops.attn_cross_bwd(Q, K, Qt, Kt, kv[:, Cm:], O, dO, lse, dQ, dK, dkv[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale)
+    # the same backward without the head-major Q^T / K^T / dO^T copies (transposing LDS reads, r3: head_dim 64 / 96 too): bit-identical
+    dQ2, dK2, dkv2 = torch.empty_like(Q), torch.empty_like(K), torch.zeros_like(kv)
+    ops.attn_cross_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale)
+    assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dkv2[:, Cm:], dkv[:, Cm:])
     dq = torch.empty_like(q)
     ops.head_merge(dQ, dq, B, H, d, Sq)
     ops.head_merge(dK, dkv[:, :Cm], B, H, d, Sk)
@@ -249,6 +253,12 @@ def test_attention_head_dim_96_padded_72(B, H, Sq, Sk, cross):
         ops.attn_cross_bwd(Q, K, Qt, Kt, kv[:, Cm:], O, dO, lse, dQ, dK, dkv[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=kb)
     else:
         ops.attn_bwd(Q, K, Qt, Kt, kv[:, Cm:], O, dO, lse, dQ, dK, dkv[:, Cm:], B, H, Sq, Sqp, d, scale)
+    dQ2, dK2, dkv2 = torch.empty_like(Q), torch.empty_like(K), torch.zeros_like(kv)
+    if cross:
+        ops.attn_cross_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=kb)
+    else:
+        ops.attn_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, d, scale)
+    assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dkv2[:, Cm:], dkv[:, Cm:])      # no-copies form: bit-identical
     dq = torch.empty_like(q)
     ops.head_merge(dQ, dq, B, H, d, Sq)
     ops.head_merge(dK, dkv[:, :Cm], B, H, d, Sk)

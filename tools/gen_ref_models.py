@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/ref_{flux,sd3,pixart}_model.pt by EXECUTING THE REFERENCE'S OWN MODEL FILES in this container.
 
-    python tools/gen_ref_models.py [flux] [sd3] [pixart]
+    python tools/gen_ref_models.py [flux] [sd3] [pixart] [vae]
 
 `tools/ref_shim.py` makes `simpletuner.helpers.models.{flux,sd3,pixart}.transformer` / `pixart.controlnet` importable unmodified (a fake
 `diffusers` holding only leaf modules; no reference `__init__` runs).  This script builds the reference's model CLASSES, gives every parameter
@@ -402,7 +402,92 @@ def gen_pixart():
     print("pixart tiny:", {k: tuple(v["out"].shape) for k, v in tiny["cases"].items()}, "hip out", tuple(hip["out"].shape))
 
 
+def vae_shapes(ch, latent, quant_conv, layers=2):
+    """diffusers AutoencoderKL state-dict names -> shapes for block_out_channels `ch` (what a released VAE checkpoint holds; the reference's own
+    `convert_diffusers_state_dict` below accepts exactly these names and its `load_state_dict` these shapes)"""
+    sh = {}
+
+    def conv(n, ci, co, k=3):
+        sh[n + ".weight"], sh[n + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm(n, c):
+        sh[n + ".weight"], sh[n + ".bias"] = (c,), (c,)
+
+    def res(p_, ci, co):
+        norm(p_ + "norm1", ci); conv(p_ + "conv1", ci, co); norm(p_ + "norm2", co); conv(p_ + "conv2", co, co)
+        if ci != co:
+            conv(p_ + "conv_shortcut", ci, co, 1)
+
+    def mid(p_, c):
+        res(p_ + "resnets.0.", c, c)
+        norm(p_ + "attentions.0.group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            sh[p_ + f"attentions.0.{n}.weight"], sh[p_ + f"attentions.0.{n}.bias"] = (c, c), (c,)
+        res(p_ + "resnets.1.", c, c)
+
+    conv("encoder.conv_in", 3, ch[0])
+    cin = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(layers):
+            res(f"encoder.down_blocks.{i}.resnets.{j}.", cin, co)
+            cin = co
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cin, cin)
+    mid("encoder.mid_block.", cin)
+    norm("encoder.conv_norm_out", cin); conv("encoder.conv_out", cin, 2 * latent)
+    if quant_conv:
+        conv("quant_conv", 2 * latent, 2 * latent, 1); conv("post_quant_conv", latent, latent, 1)
+    rev = tuple(reversed(ch))
+    conv("decoder.conv_in", latent, rev[0])
+    mid("decoder.mid_block.", rev[0])
+    cin = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(layers + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}.", cin, co)
+            cin = co
+        if i < len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin)
+    norm("decoder.conv_norm_out", cin); conv("decoder.conv_out", cin, 3)
+    return sh
+
+
+def gen_vae():
+    """The KL autoencoder the reference vendors WITH a diffusers-key converter (models/ideogram/autoencoder.py: Encoder / Decoder / AttnBlock / ResnetBlock
+    in the original latent-diffusion layout + `convert_diffusers_state_dict`): the reference's own statement of what an `AutoencoderKL` checkpoint computes.
+    Seeded diffusers-named weights -> its converter -> its `load_state_dict` -> its `encoder(x)` (moments) and `decoder(z)` (pixels)."""
+    A = ref_shim.ref_module("simpletuner.helpers.models.ideogram.autoencoder")
+    cases = {}
+    for name, latent, quant, hw, seed in (("sdxl_layout", 4, True, (32, 48), 301), ("flux_layout", 16, False, (48, 32), 311)):
+        ch = (32, 64, 64, 64)
+        shapes = vae_shapes(ch, latent, quant)
+        st = seeded_state(shapes, seed)
+        st = {k: (1.0 + 0.1 * v if (("norm" in k) and k.endswith(".weight")) else v) for k, v in st.items()}       # norm scales around 1
+        sd = dict(st)
+        if not quant:      # a checkpoint without quant convs (FLUX.1 VAE): the vendored Encoder / Decoder always hold them -> identity there
+            sd["quant_conv.weight"] = torch.eye(2 * latent).view(2 * latent, 2 * latent, 1, 1); sd["quant_conv.bias"] = torch.zeros(2 * latent)
+            sd["post_quant_conv.weight"] = torch.eye(latent).view(latent, latent, 1, 1); sd["post_quant_conv.bias"] = torch.zeros(latent)
+        model = A.AutoEncoder(A.AutoEncoderParams(resolution=hw[0], in_channels=3, ch=32, out_ch=3, ch_mult=[1, 2, 2, 2], num_res_blocks=2, z_channels=latent))
+        missing, unexpected = model.load_state_dict(A.convert_diffusers_state_dict(sd), strict=False)
+        assert not unexpected and all(k.startswith("bn.") for k in missing), (missing, unexpected)
+        model.eval()
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(2, 3, *hw, generator=g).clamp(-1, 1).requires_grad_(True)
+        z = torch.randn(2, latent, hw[0] // 8, hw[1] // 8, generator=g).requires_grad_(True)
+        w_m = torch.randn(2, 2 * latent, hw[0] // 8, hw[1] // 8, generator=g)
+        w_p = torch.randn(2, 3, *hw, generator=g)
+        moments = model.encoder(x)
+        (moments * w_m).sum().backward()
+        pixels = model.decoder(z)
+        (pixels * w_p).sum().backward()
+        cases[name] = {"block_out_channels": ch, "latent_channels": latent, "use_quant_conv": quant, "seed": seed, "state_checksum": state_checksum(st),
+                       "x": x.detach(), "z": z.detach(), "w_m": w_m, "w_p": w_p, "moments": moments.detach(), "pixels": pixels.detach(),
+                       "dx": x.grad.detach(), "dz": z.grad.detach()}
+    torch.save({"cases": cases, "_cite": "simpletuner/helpers/models/ideogram/autoencoder.py:29-57 (AttnBlock), :59-87 (ResnetBlock), :89-110 (Down/Upsample), "
+                                         ":113-186 (Encoder), :189-273 (Decoder), :321-392 (convert_diffusers_state_dict)"}, OUT / "ref_vae_model.pt")
+    print("vae:", {k: (tuple(v["moments"].shape), tuple(v["pixels"].shape)) for k, v in cases.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["flux", "sd3", "pixart"]
+    which = sys.argv[1:] or ["flux", "sd3", "pixart", "vae"]
     for w_ in which:
-        {"flux": gen_flux, "sd3": gen_sd3, "pixart": gen_pixart}[w_]()
+        {"flux": gen_flux, "sd3": gen_sd3, "pixart": gen_pixart, "vae": gen_vae}[w_]()

@@ -15,3 +15,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python tools/profile_summarise.py $out $tag
+cp profiles/${tag}_* $R/gpurun_out/ 2>/dev/null
