@@ -240,6 +240,14 @@ int st355_qk_norm_rope_fwd(void* stream, const void* qkv, int64_t ld_qkv, const 
 int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv,
                            const void* wq, const void* wk, const float* cos, const float* sin,
                            void* dqkv, int64_t ld_dqkv, int B, int H, int d, int S_part, int pos0, int S, float eps);
+/* the same backward, also producing d loss / d norm_q.weight and d loss / d norm_k.weight (the q/k RMSNorm of SD3.5, sd3/transformer.py:155-165, 190-197:
+ * trainable in a full fine-tune): gwq / gwk bf16 [d] (NULL = that weight is absent or frozen), accumulate != 0 adds to them; fixed-order two-stage
+ * reduction through `workspace` (st355_qk_norm_wgrad_workspace bytes of fp32 partials). */
+size_t st355_qk_norm_wgrad_workspace(int B, int H, int d, int S_part);
+int st355_qk_norm_rope_bwd_wgrad(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv,
+                                 const void* wq, const void* wk, const float* cos, const float* sin,
+                                 void* dqkv, int64_t ld_dqkv, int B, int H, int d, int S_part, int pos0, int S, float eps,
+                                 void* gwq, void* gwk, int accumulate, void* workspace);
 
 /* Self-attention backward with that RoPE + RMSNorm backward fused into the dQ / dK kernels' epilogues (head_dim 128): dq, dk, dv all land in the rows of
  * the projection gradient dqkv [B*S, ld_dqkv] (column blocks q | k | v, each H*128 wide); no head-major dQ / dK is written or read.  Q, K: the roped

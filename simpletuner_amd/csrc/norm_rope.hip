@@ -438,13 +438,20 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_bwd(const bf16* __restrict
                                                          const bf16* __restrict__ qkv, int64_t ld, const bf16* __restrict__ wq,
                                                          const bf16* __restrict__ wk, const float* __restrict__ cosT,
                                                          const float* __restrict__ sinT, bf16* __restrict__ dqkv, int64_t ldd, int H,
-                                                         int S_part, int pos0, int S, float eps) {
+                                                         int S_part, int pos0, int S, float eps, float* __restrict__ wg_part) {
   constexpr int TPR = HD / 8;
   constexpr int TOK_PER_PASS = 256 / TPR;
   const int tid = threadIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   const int t0 = blockIdx.x * 64;
   const int c = tid % TPR;
+  // wg_part != NULL (full fine-tune of a q/k-RMSNorm model, SD3.5): this workgroup's share of d loss / d norm weight, dw[ch] = sum over its tokens of
+  // dy[ch] * x_hat[ch] (y = x_hat * w), reduced in a fixed order; k_qk_norm_wgrad_final adds the workgroups up in index order
+  float wacc[2][8];
+#pragma unroll
+  for (int w = 0; w < 2; w++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) wacc[w][j] = 0.f;
   const int64_t Dm = (int64_t)H * HD;
   const int64_t bh = (int64_t)b * H + h;
   float wv[2][8];
@@ -490,12 +497,52 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_bwd(const bf16* __restrict
         const float r3m = r * r * r * m;
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = f2bf(r * wv[w][j] * dy[j] - xf[j] * r3m);
+        if (wg_part != nullptr && valid) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) wacc[w][j] += dy[j] * xf[j] * r;
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = f2bf(dy[j]);
       }
       if (valid) *(bf16x8*)(drow + w * Dm) = o;
     }
+  }
+  if (wg_part != nullptr) {
+    __shared__ float red[256 * 8];
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[tid * 8 + j] = wacc[w][j];
+      __syncthreads();
+      if (tid < HD) {
+        const int cc = tid >> 3, jj = tid & 7;
+        float sum = 0.f;
+        for (int tl = 0; tl < TOK_PER_PASS; tl++) sum += red[(tl * TPR + cc) * 8 + jj];
+        wg_part[((int64_t)w * nblk + blk) * HD + tid] = sum;
+      }
+    }
+  }
+}
+
+// out[w][ch] (+)= sum over the workgroups (index order) of the partials above.  grid = 2 (q, k), HD threads x 4 interleaved partial chains
+template <int HD>
+__global__ void k_qk_norm_wgrad_final(const float* __restrict__ part, int nblk, bf16* __restrict__ gwq, bf16* __restrict__ gwk, int accumulate) {
+  __shared__ float red[4][HD];
+  const int ch = threadIdx.x % HD, k = threadIdx.x / HD, w = blockIdx.x;
+  bf16* dst = w == 0 ? gwq : gwk;
+  if (dst == nullptr) return;
+  float s = 0.f;
+  for (int i = k; i < nblk; i += 4) s += part[((int64_t)w * nblk + i) * HD + ch];
+  red[k][ch] = s;
+  __syncthreads();
+  if (k == 0) {
+    float t = ((red[0][ch] + red[1][ch]) + red[2][ch]) + red[3][ch];
+    if (accumulate) t += bf2f(dst[ch]);
+    dst[ch] = f2bf(t);
   }
 }
 
@@ -510,11 +557,39 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
   dim3 grid((S_part + 63) / 64, H, B), block(256);
   if (d == 128)
     hipLaunchKernelGGL(k_qk_norm_rope_bwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK,
-                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps);
+                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)nullptr);
   else
     hipLaunchKernelGGL(k_qk_norm_rope_bwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK,
-                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps);
+                       (const bf16*)qkv, ld_qkv, (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)nullptr);
   return st355_check_launch("qk_norm_rope_bwd");
+}
+
+// the same backward, also producing d loss / d (norm_q.weight, norm_k.weight) (sd3/transformer.py:155-165 q/k RMSNorm of SD3.5; the weights train in a full
+// fine-tune): workspace = st355_qk_norm_wgrad_workspace(B, H, d, S_part) bytes of fp32 partials; gwq / gwk bf16 [d] (NULL: that weight is absent / frozen)
+extern "C" size_t st355_qk_norm_wgrad_workspace(int B, int H, int d, int S_part) {
+  return (size_t)2 * ((size_t)(S_part + 63) / 64) * H * B * d * sizeof(float);
+}
+extern "C" int st355_qk_norm_rope_bwd_wgrad(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv, const void* wq,
+                                            const void* wk, const float* cos, const float* sin, void* dqkv, int64_t ld_dqkv, int B, int H,
+                                            int d, int S_part, int pos0, int S, float eps, void* gwq, void* gwk, int accumulate, void* workspace) {
+  ST_REQUIRE(dQ && dK && qkv && cos && sin && dqkv && workspace, "qk_norm_rope_bwd_wgrad: null pointer");
+  ST_REQUIRE((gwq == nullptr || wq != nullptr) && (gwk == nullptr || wk != nullptr), "qk_norm_rope_bwd_wgrad: a weight gradient needs its norm weight");
+  ST_REQUIRE(ld_qkv % 8 == 0 && ld_dqkv % 8 == 0 && pos0 + S_part <= S && S_part > 0, "qk_norm_rope_bwd_wgrad: bad shape");
+  ST_REQUIRE(d == 128 || d == 64, "qk_norm_rope_bwd_wgrad: head_dim %d not built", d);
+  const double n = (double)B * S_part * H * d;
+  ProfScope ps(stream, ST355_K_QK_ROPE, 34.0 * n, 12.0 * n);
+  dim3 grid((S_part + 63) / 64, H, B), block(256);
+  const int nblk = (int)(grid.x * grid.y * grid.z);
+  if (d == 128) {
+    hipLaunchKernelGGL(k_qk_norm_rope_bwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)workspace);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_final<128>, dim3(2), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, nblk, (bf16*)gwq, (bf16*)gwk, accumulate);
+  } else {
+    hipLaunchKernelGGL(k_qk_norm_rope_bwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK, (const bf16*)qkv, ld_qkv,
+                       (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)workspace);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_final<64>, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, (bf16*)gwq, (bf16*)gwk, accumulate);
+  }
+  return st355_check_launch("qk_norm_rope_bwd_wgrad");
 }
 
 // backward of the FUSED projection epilogue (ST355_EPI_QK_NORM_ROPE): the pre-norm q / k are never stored, so the backward starts from what the

@@ -63,8 +63,9 @@ class LoraGroup:
     def __init__(self, K: int, N_total: int, targets: List[Tuple[str, int, int]], rank: int, alpha: float, device):
         self.K, self.N_total, self.targets = K, N_total, targets
         self.rank, self.scale = rank, alpha / rank
-        self.r_pad = 32 if rank <= 32 else 64
-        assert rank <= 64, "LoRA rank > 64 not supported by the rank-space kernels yet"
+        # adapter columns inside the K-extension: 32 / 64 (one pass of the rank-space kernels), above 64 a multiple of 64 walked in 64-column slabs
+        # (the reference's sd3.peft-lora example trains rank 128)
+        self.r_pad = 32 if rank <= 32 else (rank + 63) // 64 * 64
         self.K2 = (len(targets) * self.r_pad + 63) // 64 * 64
         self.k2_real = len(targets) * rank          # adapter columns inside the padded extension (algorithmic-work accounting of the profiler)
         z = lambda *s: torch.zeros(*s, dtype=BF16, device=device)
@@ -84,12 +85,13 @@ class LoraGroup:
     def grads(self, x, T, dy, U, accumulate: bool, sync=None):
         """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r])."""
         multi = len(self.targets) > 1 and self.r_pad == 32 and U.shape[1] >= 128        # q / k / v share x: dA of all three in ONE pass over x
+        cw = min(self.r_pad, 64)                                 # rank-space kernels take 32 or 64 adapter columns per pass
         for g, (_, n_off, N) in enumerate(self.targets):
-            c0 = g * self.r_pad
-            ops.skinny_tn(dy[..., n_off:n_off + N], T[:, c0:c0 + self.r_pad], self.gB[g], self.rank, 1, self.rank,
-                          alpha=self.scale, accumulate=accumulate)
-            if not multi:
-                ops.skinny_tn(x, U[:, c0:c0 + self.r_pad], self.gA[g], 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
+            for s0 in range(0, self.rank, cw):
+                c0, r_used = g * self.r_pad + s0, min(cw, self.rank - s0)
+                ops.skinny_tn(dy[..., n_off:n_off + N], T[:, c0:c0 + cw], self.gB[g][:, s0:], self.rank, 1, r_used, alpha=self.scale, accumulate=accumulate)
+                if not multi:
+                    ops.skinny_tn(x, U[:, c0:c0 + cw], self.gA[g][s0:], 1, self.K, r_used, alpha=1.0, accumulate=accumulate)
         if multi:
             ops.skinny_tn_multi(x, U, self.gA, 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
         if sync is not None:

@@ -608,6 +608,26 @@ def qk_norm_rope_bwd(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0,
              "qk_norm_rope_bwd")
 
 
+_qkwg_ws = {}
+
+
+def qk_norm_rope_bwd_wgrad(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S, gwq, gwk, accumulate: bool = False, eps: float = 1e-6):
+    """qk_norm_rope_bwd + d loss / d (norm_q.weight, norm_k.weight) into the bf16 [d] views gwq / gwk (None: absent / frozen)"""
+    L = _l.load()
+    _chk(dQ, BF16, "dQ"); _chk(dK, BF16, "dK"); _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
+    for g in (gwq, gwk):
+        if g is not None:
+            _chk(g, BF16, "gw")
+    need = L.st355_qk_norm_wgrad_workspace(B, H, d, S_part)
+    ws = _qkwg_ws.get(dQ.device.index)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=F32, device=dQ.device)
+        _qkwg_ws[dQ.device.index] = ws
+    _l.check(L.st355_qk_norm_rope_bwd_wgrad(_stream(), _ptr(dQ), _ptr(dK), _ptr(qkv), _rows(qkv, "qkv"), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin),
+                                            _ptr(dqkv), _rows(dqkv, "dqkv"), B, H, d, S_part, pos0, S, eps, _ptr(gwq), _ptr(gwk),
+                                            1 if accumulate else 0, _ptr(ws)), "qk_norm_rope_bwd_wgrad")
+
+
 def qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S):
     """backward of the fused projection epilogue: from the roped head-major Q / K and the saved 1/rms (no pre-norm projection kept)"""
     L = _l.load()

@@ -83,8 +83,9 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         super().__init__()
         if patch_size != 2:
             raise ValueError("patch_size must be 2 (the patchify kernels are 2x2)")
-        if tuple(dual_attention_layers):
-            raise NotImplementedError("SD3.5 dual attention layers are not built on the st355 path yet")
+        self.dual_layers = frozenset(int(i) for i in (dual_attention_layers or ()))
+        if any(i < 0 or i >= num_layers - 1 for i in self.dual_layers):
+            raise ValueError("dual_attention_layers must name regular (not context_pre_only) blocks")      # sd3/transformer.py:295: the last block never is
         if attention_head_dim not in (64, 128):
             raise ValueError("attention_head_dim must be 64 or 128 (kernels built for these)")
         if qk_norm not in (None, "rms_norm"):
@@ -98,7 +99,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                                       attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
                                       joint_attention_dim=joint_attention_dim, caption_projection_dim=caption_projection_dim,
                                       pooled_projection_dim=pooled_projection_dim, out_channels=out_channels,
-                                      pos_embed_max_size=pos_embed_max_size, dual_attention_layers=(), qk_norm=qk_norm)
+                                      pos_embed_max_size=pos_embed_max_size, dual_attention_layers=tuple(sorted(self.dual_layers)), qk_norm=qk_norm)
         self.out_channels = out_channels
         if D % 64 or joint_attention_dim % 64 or pooled_projection_dim % 64 or (4 * in_channels) % 64:
             raise ValueError("all contraction dims must be multiples of 64")
@@ -167,7 +168,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         self.l_p2 = lin("time_text_embed.text_embedder.linear_2", D, D)
         self.l_ctx = lin("context_embedder", D, joint_attention_dim)
 
-        self.mod_total = (num_layers * 12 - 4 + 2) * D          # last block: norm1_context is AdaLayerNormContinuous (2D)
+        # last block: norm1_context is AdaLayerNormContinuous (2D); a dual-attention block's norm1 is SD35AdaLayerNormZeroX (9 chunks instead of 6)
+        self.mod_total = (num_layers * 12 - 4 + 2 + 3 * len(self.dual_layers)) * D
         self.mod_w, self.mod_b = e(self.mod_total, D), e(self.mod_total)
         off = 0
 
@@ -199,8 +201,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         self._blocks_arena_lo = self._arena_numel
         for i in range(num_layers):
             p = f"transformer_blocks.{i}."
-            blk = SimpleNamespace(last=(i == num_layers - 1), arena_lo=self._arena_numel)
-            blk.mod_off = mod_slice(p + "norm1.linear", 6 * D)
+            blk = SimpleNamespace(last=(i == num_layers - 1), arena_lo=self._arena_numel, dual=(i in self.dual_layers))
+            blk.mod_off = mod_slice(p + "norm1.linear", (9 if blk.dual else 6) * D)
             blk.mod_off_c = mod_slice(p + "norm1_context.linear", (2 if blk.last else 6) * D)
             blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
             blk.add_qkv = fused(p + "attn.", ["add_q_proj", "add_k_proj", "add_v_proj"], D, D)
@@ -208,6 +210,10 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             blk.to_add_out = None if blk.last else fused(p + "attn.", ["to_add_out"], D, D)
             blk.norm_q, blk.norm_k = normw(p + "attn.norm_q"), normw(p + "attn.norm_k")
             blk.norm_added_q, blk.norm_added_k = normw(p + "attn.norm_added_q"), normw(p + "attn.norm_added_k")
+            # SD3.5 dual attention (sd3/transformer.py:155-165, 190-197): a second, image-only self-attention fed by the 7th-9th modulation chunks
+            blk.qkv2 = fused(p + "attn2.", ["to_q", "to_k", "to_v"], D, D) if blk.dual else None
+            blk.to_out2 = fused(p + "attn2.", ["to_out.0"], D, D) if blk.dual else None
+            blk.norm_q2, blk.norm_k2 = (normw(p + "attn2.norm_q"), normw(p + "attn2.norm_k")) if blk.dual else (None, None)
             blk.ff1 = fused(p, ["ff.net.0.proj"], 4 * D, D)
             blk.ff2 = fused(p, ["ff.net.2"], D, 4 * D)
             blk.ffc1 = None if blk.last else fused(p, ["ff_context.net.0.proj"], 4 * D, D)
@@ -259,7 +265,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
     def prepare_for_training(self):
         """K-major transposed copies for the dgrad GEMMs (frozen base => built once)"""
         for blk in self.blocks:
-            for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2):
+            for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.qkv2, blk.to_out2, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2):
                 if l is not None:
                     l.wT = l.w.t().contiguous()
         self.l_out.wT = self.l_out.w.t().contiguous()
@@ -286,6 +292,10 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             p = f"transformer_blocks.{i}.attn."
             group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
             group(blk.to_out, p, ["to_out.0"], D)
+            if blk.dual:       # peft matches target modules by suffix: attn2.to_q / to_k / to_v / to_out.0 carry adapters too
+                p2 = f"transformer_blocks.{i}.attn2."
+                group(blk.qkv2, p2, ["to_q", "to_k", "to_v"], D)
+                group(blk.to_out2, p2, ["to_out.0"], D)
             if targets == "all":
                 group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
                 if blk.to_add_out is not None:
@@ -403,6 +413,35 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         ops.gemm_grouped(probs)
         for f in after:
             f()
+        d2 = None
+        if blk.dual:
+            # attn2: self-attention over the image tokens only, input = LN(img) modulated by chunks 7 / 8 (shift_msa2, scale_msa2), residual gated by chunk 9
+            # onto the stream AFTER the joint-attention residual (sd3/transformer.py:190-197)
+            mi9 = mod[:, blk.mod_off:blk.mod_off + 9 * D]
+            Sip = (Si + 63) // 64 * 64
+            n2a = ops.ln_modulate_fwd(img, mi9[:, 7 * D:8 * D], mi9[:, 6 * D:7 * D], Si)
+            T2 = ops.gemm(n2a, blk.qkv2.lora.A_cat) if blk.qkv2.lora is not None else None
+            kwq = dict(a2=T2, b2=blk.qkv2.lora.B_blk) if T2 is not None else {}
+            qkv2 = ops.gemm(n2a, blk.qkv2.w, bias=blk.qkv2.b, **kwq)
+            Q2 = torch.empty(B, H, Si, hd, dtype=BF16, device=dev); K2 = torch.empty_like(Q2)
+            mk2 = torch.zeros if Sip > Si else torch.empty
+            Q2t = K2t = None
+            if not ops.ATTN_TR:
+                Q2t = mk2(B, H, hd, Sip, dtype=BF16, device=dev); K2t = mk2(B, H, hd, Sip, dtype=BF16, device=dev)
+            V2t = mk2(B, H, hd, Sip, dtype=BF16, device=dev)
+            ops.qk_norm_rope_fwd(qkv2, blk.norm_q2, blk.norm_k2, cos, sin, Q2, K2, Q2t, K2t, V2t, B, H, hd, Si, 0, Si, Sip)
+            O2 = torch.empty(B * Si, D, dtype=BF16, device=dev); lse2b = torch.empty(B, H, Si, dtype=F32, device=dev)
+            ops.attn_fwd(Q2, K2, V2t, O2, lse2b, B, H, Si, Sip, hd, scale)
+            del V2t
+            ya2 = ybuf(B * Si)
+            kw2 = dict(aux_out=ya2) if ya2 is not None else {}
+            T_o2 = None
+            if blk.to_out2.lora is not None:
+                T_o2 = ops.gemm(O2, blk.to_out2.lora.A_cat)
+                kw2.update(a2=T_o2, b2=blk.to_out2.lora.B_blk)
+            x1b_img = ops.gemm(O2, blk.to_out2.w, bias=blk.to_out2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi9[:, 8 * D:9 * D], rows_per_batch=Si, **kw2)
+            d2 = SimpleNamespace(n2a=n2a, qkv2=qkv2, T2=T2, Q2=Q2, K2=K2, Q2t=Q2t, K2t=K2t, O2=O2, lse2b=lse2b, ya2=ya2, T_o2=T_o2, Sip=Sip)
+            x1_img = x1b_img                       # what the MLP branch (and its residual) sees
         n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
         hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
         hpre_txt = x2_txt = n2_t = h_t = None
@@ -424,7 +463,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         if save:
             sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K,
                                  Qt=Qt, Kt=Kt, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img,
-                                 hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
+                                 hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao, d2=d2)
             if full:    # a full fine-tune also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
                 sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
             return x2_img, x2_txt, sv
@@ -552,7 +591,30 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
                 dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
                 del g_t, dh_t, dn2_t
-            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+            dn2a = None
+            if blk.dual:
+                # the MLP's LayerNorm read the stream AFTER the attn2 residual: its gated gradient feeds attn2's output projection, the un-gated one is the
+                # gradient of the stream after the joint-attention residual (dx1) — attn2 first, then the joint attention as for a regular block
+                d2, mi9 = sv.d2, mod[:, blk.mod_off:blk.mod_off + 9 * D]
+                dx1_i, dxg2 = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi9[:, 8 * D:9 * D], want_gated=True)
+                lo2, lq2 = blk.to_out2.lora, blk.qkv2.lora
+                U2 = ops.gemm(dxg2, lo2.B_blk_T) if lo2 is not None else None
+                dO2 = ops.gemm(dxg2, blk.to_out2.wT, **(dict(a2=U2, b2=lo2.A_cat_T) if U2 is not None else {}))
+                if lo2 is not None:
+                    lo2.grads(d2.O2, d2.T_o2, dxg2, U2, self.accumulate_lora_grads, self.grad_sync)
+                dqkv2 = torch.empty(B * Si, 3 * D, dtype=BF16, device=dev)
+                dQ2 = torch.empty(B, H, Si, hd, dtype=BF16, device=dev); dK2 = torch.empty_like(dQ2)
+                ops.attn_bwd(d2.Q2, d2.K2, d2.Q2t, d2.K2t, d2.qkv2[:, 2 * D:], d2.O2, dO2, d2.lse2b, dQ2, dK2, dqkv2[:, 2 * D:], B, H, Si, d2.Sip, hd, scale)
+                ops.qk_norm_rope_bwd(dQ2, dK2, d2.qkv2, blk.norm_q2, blk.norm_k2, cos, sin, dqkv2, B, H, hd, Si, 0, Si)
+                Uq2 = ops.gemm(dqkv2, lq2.B_blk_T) if lq2 is not None else None
+                if li != 0:
+                    dn2a = ops.gemm(dqkv2, blk.qkv2.wT, **(dict(a2=Uq2, b2=lq2.A_cat_T) if Uq2 is not None else {}))
+                if lq2 is not None:
+                    lq2.grads(d2.n2a, d2.T2, dqkv2, Uq2, self.accumulate_lora_grads, self.grad_sync)
+                dx1g_i = ops.scale_cols(dx1_i, mi[:, 2 * D:3 * D], Si)
+                del dxg2, dO2, dQ2, dK2, dqkv2, U2, Uq2, d2
+            else:
+                dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
             del g_i, dh_i, dn2_i
             # attention output projections -> dO rows of both streams (+ adapter grads); a context_pre_only block has no txt rows
             dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
@@ -604,6 +666,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                     lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
             if not first:
                 d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+                if dn2a is not None:             # the second reader of LN(img): attn2's modulated input (scale_msa2)
+                    d_img, _ = ops.ln_modulate_bwd(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dres=d_img)
                 c_scale = mt[:, :D] if blk.last else mt[:, D:2 * D]
                 d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, c_scale, St, dres=dx1_t)
             del dqkv, sv, dns
@@ -618,13 +682,11 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
     def _all_linears(self):
         ls = [self.l_patch, self.l_t1, self.l_t2, self.l_p1, self.l_p2, self.l_ctx, self.l_out]
         for blk in self.blocks:
-            ls += [l for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2) if l is not None]
+            ls += [l for l in (blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.qkv2, blk.to_out2, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2) if l is not None]
         return ls
 
     def enable_full_finetune(self):
         """gradient arena with the weight arena's layout; every base parameter becomes trainable (bf16 params, bf16 grads)"""
-        if self.config.qk_norm is not None:
-            raise NotImplementedError("full fine-tune with q/k RMSNorm weights is not built yet (SD3-Medium has none)")
         if self.lora_groups:
             raise RuntimeError("full fine-tune and LoRA adapters are exclusive")
         self.full = True
@@ -637,6 +699,10 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
 
         for l in self._all_linears():
             l.gw, l.gb = gview(l.w), gview(l.b)
+        for blk in self.blocks:          # q/k RMSNorm weights (SD3.5): gradient views like every other parameter
+            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k", "norm_q2", "norm_k2"):
+                w = getattr(blk, nm, None)
+                setattr(blk, "g_" + nm, gview(w) if w is not None else None)
         self.g_mod_w, self.g_mod_b = gview(self.mod_w), gview(self.mod_b)
         ps = sorted([p for n, p in self.named_parameters() if ".lora_" not in n], key=lambda p: p.data_ptr())
         for p in ps:
@@ -692,6 +758,13 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=n_saved, rows_per_batch=rows, mode=1, prev=dsh,
                             shift=m[:, k_shift * D:(k_shift + 1) * D], scale=m[:, k_scale * D:(k_scale + 1) * D])
 
+        def qk_bwd(dQ_, dK_, qkv_, wq, wk, dqkv_, rows, pos0, S_, gq, gk):
+            """RMSNorm (+ identity RoPE) backward of one stream's q / k; with norm weights (SD3.5) also their gradients (sd3/transformer.py:155-165)"""
+            if wq is None and wk is None:
+                ops.qk_norm_rope_bwd(dQ_, dK_, qkv_, wq, wk, cos, sin, dqkv_, B, H, hd, rows, pos0, S_)
+            else:
+                ops.qk_norm_rope_bwd_wgrad(dQ_, dK_, qkv_, wq, wk, cos, sin, dqkv_, B, H, hd, rows, pos0, S_, gq, gk)
+
         def rows_of(t, lo, n):                       # rows [lo, lo+n) of every batch element of a joint [B*S, C] buffer, contiguous
             return t[lo:lo + n] if B == 1 else t.view(B, S, -1)[:, lo:lo + n].reshape(B * n, -1)
 
@@ -732,7 +805,25 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             wgrad(blk.ff1, dh_i, sv.n2_i)
             dn2_i = ops.gemm(dh_i, blk.ff1.wT)
             mod_grads(dn2_i, sv.n2_i, mi, Si, 3, 4, dmi)
-            dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+            dn2a = None
+            if blk.dual:
+                d2 = sv.d2
+                mi9 = mod[:, blk.mod_off:blk.mod_off + 9 * D]; dmi9 = dmod[:, blk.mod_off:blk.mod_off + 9 * D]
+                dx1_i, dxg2 = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi9[:, 8 * D:9 * D], want_gated=True)
+                ops.colsum_prod(dx1_i, dmi9[:, 8 * D:9 * D], b=d2.ya2, rows_per_batch=Si)        # d gate_msa2
+                wgrad(blk.to_out2, dxg2, d2.O2)
+                dO2 = ops.gemm(dxg2, blk.to_out2.wT)
+                dqkv2 = torch.empty(B * Si, 3 * D, dtype=BF16, device=dev)
+                dQ2 = torch.empty(B, H, Si, hd, dtype=BF16, device=dev); dK2 = torch.empty_like(dQ2)
+                ops.attn_bwd(d2.Q2, d2.K2, d2.Q2t, d2.K2t, d2.qkv2[:, 2 * D:], d2.O2, dO2, d2.lse2b, dQ2, dK2, dqkv2[:, 2 * D:], B, H, Si, d2.Sip, hd, scale)
+                qk_bwd(dQ2, dK2, d2.qkv2, blk.norm_q2, blk.norm_k2, dqkv2, Si, 0, Si, blk.g_norm_q2, blk.g_norm_k2)
+                wgrad(blk.qkv2, dqkv2, d2.n2a)
+                dn2a = ops.gemm(dqkv2, blk.qkv2.wT)
+                mod_grads(dn2a, d2.n2a, mi9, Si, 6, 7, dmi9)
+                dx1g_i = ops.scale_cols(dx1_i, mi[:, 2 * D:3 * D], Si)
+                del dxg2, dO2, dQ2, dK2, dqkv2, d2
+            else:
+                dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
             ops.colsum_prod(dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)           # d gate_msa
             del g_i, dh_i, dn2_i
             dx1_t = dx1g_t = None
@@ -765,8 +856,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
             dQ = torch.empty(B, H, S, hd, dtype=BF16, device=dev); dK = torch.empty_like(dQ)
             ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * D:], sv.O, dO, sv.lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
-            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, cos, sin, dqkv, B, H, hd, Si, 0, S)
-            ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, dqkv, B, H, hd, St, Si, S)
+            qk_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, dqkv, Si, 0, S, blk.g_norm_q, blk.g_norm_k)
+            qk_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, dqkv, St, Si, S, blk.g_norm_added_q, blk.g_norm_added_k)
             del dQ, dK, dO
             dq_i, dq_t = rows_of(dqkv, 0, Si), rows_of(dqkv, Si, St)
             wgrad(blk.qkv, dq_i, sv.n_img)
@@ -774,6 +865,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             dn_i, dn_t = ops.gemm_grouped([dict(a=dq_i, w=blk.qkv.wT), dict(a=dq_t, w=blk.add_qkv.wT)])
             mod_grads(dn_i, sv.n_img, mi, Si, 0, 1, dmi)
             d_img, _ = ops.ln_modulate_bwd(dn_i, sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+            if dn2a is not None:                  # the second reader of LN(img): attn2's modulated input (scale_msa2)
+                d_img, _ = ops.ln_modulate_bwd(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dres=d_img)
             if blk.last:
                 mod_grads(dn_t, sv.n_txt, mt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
                 d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, :D], St, dres=None)

@@ -15,16 +15,17 @@ from oracle import sd3 as OS  # noqa: E402
 from tests import parity_utils as PU  # noqa: E402
 
 
-def _arch(layers, heads=2, head_dim=64, joint_dim=128, pooled=64, qk_norm=None):
+def _arch(layers, heads=2, head_dim=64, joint_dim=128, pooled=64, qk_norm=None, dual=()):
     return dict(sample_size=32, num_layers=layers, num_attention_heads=heads, attention_head_dim=head_dim, joint_attention_dim=joint_dim,
-                caption_projection_dim=heads * head_dim, pooled_projection_dim=pooled, pos_embed_max_size=24, qk_norm=qk_norm)
+                caption_projection_dim=heads * head_dim, pooled_projection_dim=pooled, pos_embed_max_size=24, qk_norm=qk_norm, dual_attention_layers=tuple(dual))
 
 
 def _ocfg(model):
     c = model.config
     return OS.SD3Config(sample_size=c.sample_size, num_layers=c.num_layers, attention_head_dim=c.attention_head_dim,
                         num_attention_heads=c.num_attention_heads, joint_attention_dim=c.joint_attention_dim,
-                        pooled_projection_dim=c.pooled_projection_dim, pos_embed_max_size=c.pos_embed_max_size, qk_norm=c.qk_norm)
+                        pooled_projection_dim=c.pooled_projection_dim, pos_embed_max_size=c.pos_embed_max_size, qk_norm=c.qk_norm,
+                        dual_attention_layers=tuple(c.dual_attention_layers))
 
 
 def _build(layers, B, lat_h, lat_w, S_txt, rank=16, seed=3, lr=1e-3, **arch_kw):
@@ -113,6 +114,34 @@ def test_sd3_step_matches_oracle(layers, B, lat_h, lat_w, S_txt, qk_norm):
     print(f"[parity] sd3 lora grads: worst rel_l2={worst[0]:.3e} at {worst[1]}")
 
 
+@pytest.mark.parametrize("rank", [80, 128])
+def test_sd3_lora_rank_above_64_matches_oracle(rank):
+    """the reference's sd3.peft-lora example trains rank 128: adapter ranks above 64 ride in a K-extension padded to a multiple of 64 and
+    their rank-space gradients are produced in 64-column slabs (rank 80 = one full slab + a 16-column one)"""
+    plugin, trainer, cpu, devt = _build(2, 2, 16, 16, 24, rank=rank)
+    model = plugin.get_trained_component()
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    P, lora, scale = _oracle_state(model)
+    prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+    out = plugin.model_predict(prepared)
+    loss, _ = plugin.loss_with_logs(prepared, out)
+    loss.backward()
+    o_loss, o_pred, o_grads = _oracle_step(P, _ocfg(model), lora, scale, cpu)
+    r = PU.rel_l2(out["model_prediction"], o_pred)
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        ref = o_grads[name.split(".lora_")[0]][0 if ".lora_A." in name else 1]
+        assert tuple(p.grad.shape) == tuple(ref.shape) and p.grad.shape[0 if ".lora_A." in name else 1] == rank
+        rg, cg = PU.rel_l2(p.grad, ref), PU.cos_sim(p.grad, ref)
+        worst = max(worst, (rg, name))
+        assert rg < 5e-2 and cg > 0.999, f"{name}: rel={rg:.3e} cos={cg:.5f}"
+    print(f"[parity] sd3 LoRA rank {rank}: pred rel_l2={r:.3e}, worst adapter gradient {worst[0]:.3e} at {worst[1]}")
+    assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
+
+
 def test_sd3_loss_curve_matches_oracle_adamw():
     plugin, trainer, cpu, devt = _build(2, 2, 16, 16, 24, rank=8, lr=2e-3)
     model = plugin.get_trained_component()
@@ -144,7 +173,7 @@ def test_sd3_loss_curve_matches_oracle_adamw():
 # ------------------------------------------------------------------------------------------------
 # full fine-tune (BASELINE.json configs[3]): gradients of EVERY parameter vs autograd on the oracle
 # ------------------------------------------------------------------------------------------------
-def _build_full(layers, B, lat_h, lat_w, S_txt, seed=5, lr=1e-4):
+def _build_full(layers, B, lat_h, lat_w, S_txt, seed=5, lr=1e-4, **arch_kw):
     from simpletuner_amd.sd3.model import SD3
     from simpletuner_amd.training.trainer import St355Accelerator, default_config
 
@@ -152,19 +181,24 @@ def _build_full(layers, B, lat_h, lat_w, S_txt, seed=5, lr=1e-4):
     cfg = default_config(model_family="sd3", model_type="full", train_batch_size=B, seed=seed, learning_rate=lr, flow_schedule_shift=3.0)
     acc = St355Accelerator(dev)
     plugin = SD3(cfg, acc)
-    plugin.load_model(**_arch(layers))
+    plugin.load_model(**_arch(layers, **arch_kw))
     plugin.enable_full_finetune()
     cpu, devt = PU.make_inputs(B, lat_h, lat_w, S_txt, 128, 64, dev, seed=seed)
     return plugin, cfg, acc, cpu, devt
 
 
-@pytest.mark.parametrize("layers,B,lat_h,lat_w,S_txt", [(2, 1, 16, 16, 40), (3, 2, 16, 24, 33), (2, 2, 32, 32, 24)])
-def test_sd3_full_finetune_gradients_match_oracle(layers, B, lat_h, lat_w, S_txt):
+@pytest.mark.parametrize("layers,B,lat_h,lat_w,S_txt,sd35", [(2, 1, 16, 16, 40, False), (3, 2, 16, 24, 33, False), (2, 2, 32, 32, 24, False), (3, 2, 16, 24, 33, True)])
+def test_sd3_full_finetune_gradients_match_oracle(layers, B, lat_h, lat_w, S_txt, sd35):
     """every weight / bias / modulation row: HIP backward (TN weight-gradient GEMMs, token-axis reductions) vs fp32 autograd.
     Tolerances: bf16 kernels + bf16 gradient storage vs fp32 oracle — per-tensor rel-L2 <= 6e-2 and cosine >= 0.998 for tensors that
     carry real signal (norm >= 1e-3 of the largest gradient norm); prediction / loss as in the LoRA test."""
-    plugin, cfg, acc, cpu, devt = _build_full(layers, B, lat_h, lat_w, S_txt)
+    plugin, cfg, acc, cpu, devt = _build_full(layers, B, lat_h, lat_w, S_txt, **(dict(qk_norm="rms_norm", dual=(0, 1)) if sd35 else {}))
     model = plugin.get_trained_component()
+    if sd35:        # SD3.5: q/k RMSNorm weights (trainable: their gradients are checked below like every other tensor) + dual attention in blocks 0, 1
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if ".norm_q." in n_ or ".norm_k." in n_ or ".norm_added_" in n_:
+                    p_.copy_(1.0 + 0.2 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(n_))).to(p_))
     sig = devt["sigmas"]
     plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
     P, _, _ = _oracle_state(model)
