@@ -387,7 +387,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
 
 
 def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, guidance_value: float = 1.0, lora=None,
-                       lora_scale=1.0, taps=None, checkpoint: bool = False):
+                       lora_scale=1.0, taps=None, checkpoint: bool = False, tread=None):
     """Flux._model_predict_single (flux/model.py:707-864): pack, ids, t/1000, guidance vector, transformer, unpack."""
     B, C, Hh, Ww = noisy_latents.shape
     packed = pack_latents(noisy_latents)
@@ -395,7 +395,7 @@ def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, 
     txt_ids = torch.zeros(prompt_embeds.shape[1], 3)
     guidance = torch.full((B,), float(guidance_value), device=noisy_latents.device) if cfg.guidance_embeds else None
     out = flux_forward(P, cfg, packed, prompt_embeds, pooled, timesteps / 1000.0, img_ids, txt_ids, guidance, lora, lora_scale,
-                       taps=taps, checkpoint=checkpoint)
+                       taps=taps, checkpoint=checkpoint, tread=tread)
     return unpack_latents(out, Hh, Ww)
 
 

@@ -205,6 +205,7 @@ class FluxTransformer2DModel(nn.Module):
         self.gradient_checkpointing_interval = None          # flux/transformer.py:816-818
         self.gradient_checkpointing_segment_stride = None
         self.gradient_checkpointing_backend = "torch"
+        self._tread_router, self._tread_routes, self._force_keep_mask = None, None, None
         self.grad_sync = None            # training.grad_sync.GradSync over lora_grad_flat (data-parallel replicas)
         self._last_grad_flat = None
 
@@ -441,6 +442,17 @@ class FluxTransformer2DModel(nn.Module):
             self._norm_w_ok[key] = ok
         return ok
 
+    def _qk_fwd(self, env, qkv, wq, wk, Q, K, Qt, Kt, Vt, rows: int, pos0: int):
+        """RMSNorm + RoPE + head-major re-layout of one stream's q / k / v rows (the separate pass of the unfused projection).  Under TREAD routing every
+        sample carries its OWN position table (the kept image tokens' positions, flux/transformer.py:1211-1241 `_route_rope`): one call per sample."""
+        B, H, hd, S, Sp = env.B, self.H, self.hd, env.S, env.Sp
+        if not getattr(env, "routed", False):
+            ops.qk_norm_rope_fwd(qkv, wq, wk, env.cos, env.sin, Q, K, Qt, Kt, Vt, B, H, hd, rows, pos0, S, Sp)
+            return
+        for b in range(B):
+            ops.qk_norm_rope_fwd(qkv[b * S:(b + 1) * S], wq, wk, env.cos_b[b], env.sin_b[b], Q[b:b + 1], K[b:b + 1],
+                                 None if Qt is None else Qt[b:b + 1], None if Kt is None else Kt[b:b + 1], Vt[b:b + 1], 1, H, hd, rows, pos0, S, Sp)
+
     def _attn_forward_fused(self, Q, K, V, Vt, O, lse2, env):
         """attention after the fused projection: from the head-major V^T the epilogue also wrote (default), or — ST355_FUSED_VT=0 — straight from the
         row-major V by transposing LDS reads (no V^T at all; measured r02: the forward kernel is ~4-8 % slower that way, the extra V^T write is cheaper)"""
@@ -478,7 +490,7 @@ class FluxTransformer2DModel(nn.Module):
         kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
         kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-        fused = self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
+        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
         qkv = V = rrms = Qt = Kt = None
         if fused:
             # RMSNorm(q), RMSNorm(k), RoPE and the head-major re-layout ride in the projection's epilogue: q / k leave the GEMM as the roped head-major
@@ -502,8 +514,8 @@ class FluxTransformer2DModel(nn.Module):
             ops.gemm_grouped(self._problems(env, Si, dict(a=n_img, w=blk.qkv.w, bias=blk.qkv.b, out=self._rows_of(qkv, St, Si, env), **kw_i))
                              + self._problems(env, St, dict(a=n_txt, w=blk.add_qkv.w, bias=blk.add_qkv.b, out=self._rows_of(qkv, 0, St, env), **kw_t)))
             Q, K, Qt, Kt, Vt = self._alloc_heads(env)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_added_q, blk.norm_added_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, St, 0, S, Sp)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, Si, St, S, Sp)
+            self._qk_fwd(env, qkv, blk.norm_added_q, blk.norm_added_k, Q, K, Qt, Kt, Vt, St, 0)
+            self._qk_fwd(env, qkv, blk.norm_q, blk.norm_k, Q, K, Qt, Kt, Vt, Si, St)
             ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
             del Vt
         x1_img = torch.empty(B * Si, D, dtype=BF16, device=dev); x1_txt = torch.empty(B * St, D, dtype=BF16, device=dev)
@@ -557,7 +569,7 @@ class FluxTransformer2DModel(nn.Module):
         n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
         qkv = V = rrms = Qt = Kt = None
-        if self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k)):
+        if (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k)):
             Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
             V = torch.empty(B * S, D, dtype=BF16, device=dev); rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev)
             Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev) if _FUSED_VT else None
@@ -568,7 +580,7 @@ class FluxTransformer2DModel(nn.Module):
         else:
             qkv, T = self._lin_fwd(blk.qkv, n)
             Q, K, Qt, Kt, Vt = self._alloc_heads(env)
-            ops.qk_norm_rope_fwd(qkv, blk.norm_q, blk.norm_k, cos, sin, Q, K, Qt, Kt, Vt, B, H, hd, S, 0, S, Sp)
+            self._qk_fwd(env, qkv, blk.norm_q, blk.norm_k, Q, K, Qt, Kt, Vt, S, 0)
             ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
             del Vt
         hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
@@ -606,28 +618,93 @@ class FluxTransformer2DModel(nn.Module):
         env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, cos_p=cos_p, sin_p=sin_p, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias)
         segs_d = self._checkpoint_segments(len(self.double)) if save else [(i, 1, False) for i in range(len(self.double))]
         segs_s = self._checkpoint_segments(len(self.single)) if save else [(i, 1, False) for i in range(len(self.single))]
-        ctx = SimpleNamespace(env=env, dbl={}, sgl={}, segs_d=segs_d, segs_s=segs_s, ck_d={}, ck_s={})
+        # TREAD routing (flux/transformer.py:1101-1133, 1211-1241 double blocks, 1394-1486 single blocks; training/tread.py): only while training; between a route's
+        # two blocks the IMAGE stream is a per-sample subset of its tokens, the text tokens all stay.  Layer indices run over double + single blocks.  Under
+        # routing the reference drops the segmented checkpoint form for the per-block one (:1144-1157 `not use_routing`).
+        from ..training.tread import normalise_routes
+        nd, ns = len(self.double), len(self.single)
+        routes = normalise_routes(self._tread_routes, nd + ns) if (save and self.training and self._tread_router is not None) else []
+        if routes:
+            from ..training.checkpoint_plan import per_block as _per_block
+            gc_, iv_, sd_ = bool(self.gradient_checkpointing), self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride
+            segs_d, segs_s = _per_block(nd, gc_, iv_, sd_), _per_block(ns, gc_, iv_, sd_)
+        ctx = SimpleNamespace(env=env, dbl={}, sgl={}, segs_d=segs_d, segs_s=segs_s, ck_d={}, ck_s={}, env_d=[env] * nd, env_s=[env] * ns,
+                              route_start={}, route_end={})
+        rt = SimpleNamespace(ptr=0, info=None, saved=None, env=env)          # the open route: its mask, the full image stream at its start, the routed env
+
+        def start_route(img_full, g):
+            """img_full [B*Si, D] (contiguous) -> the kept tokens [B*K, D]; opens the route"""
+            info = self._tread_router.get_mask(img_full.view(B, Si, D), mask_ratio=routes[rt.ptr]["selection_ratio"], force_keep=getattr(self, "_force_keep_mask", None))
+            K = info.ids_keep.shape[1]
+            idx = info.ids_keep.to(dev)
+            # position tables [text | kept image tokens] per sample (`_route_rope`, flux/transformer.py:909-938)
+            cos_b = torch.cat([cos[:St][None].expand(B, -1, -1), cos[St:][idx]], dim=1).contiguous()
+            sin_b = torch.cat([sin[:St][None].expand(B, -1, -1), sin[St:][idx]], dim=1).contiguous()
+            kb = None if key_bias is None else key_bias[:, :St + K].contiguous()          # image keys are never masked (expand_flux_attention_mask)
+            rt.info, rt.saved = info, img_full
+            rt.env = SimpleNamespace(**{**vars(env), "Si": K, "S": St + K, "Sp": (St + K + 63) // 64 * 64, "routed": True, "cos_b": cos_b, "sin_b": sin_b, "key_bias": kb})
+            ctx.route_start[g] = info
+            return ops.gather_rows(img_full.view(B, Si, D), info.keep_i32()).view(-1, D)
+
+        def end_route(img_r, g):
+            """the processed kept tokens [B*K, D] back into their slots of the stream as it was at the route's start (TREADRouter.end_route)"""
+            full = rt.saved.clone()
+            ops.scatter_rows(img_r.view(B, rt.env.Si, D), rt.info.keep_i32(), full.view(B, Si, D))
+            ctx.route_end[g] = rt.info
+            rt.info, rt.saved, rt.env, rt.ptr = None, None, env, rt.ptr + 1
+            return full
+
+        def starts(g):
+            return rt.ptr < len(routes) and rt.info is None and g == routes[rt.ptr]["start_layer_idx"]
+
+        def ends(g):
+            return rt.info is not None and g == routes[rt.ptr]["end_layer_idx"]
+
         x = None
         # ---- double blocks ----
         for (s0, n, ck) in segs_d:
-            if ck:
-                ctx.ck_d[s0] = (img, txt)                     # a checkpointed segment keeps only its input; its blocks are re-run in backward
             for bi in range(s0, s0 + n):
-                img, txt, x, sv = self._double_fwd(bi, img, txt, env, save and not ck)
+                if starts(bi):
+                    img = start_route(img, bi)
+                if ck and bi == s0:
+                    ctx.ck_d[s0] = (img, txt)                 # a checkpointed segment keeps only its input; its blocks are re-run in backward
+                ctx.env_d[bi] = rt.env
+                img, txt, x, sv = self._double_fwd(bi, img, txt, rt.env, save and not ck)
                 if sv is not None:
                     ctx.dbl[bi] = sv
+                if ends(bi):
+                    if x is not None:                         # the last double block wrote the joint [txt || kept img] sequence: re-open it
+                        xv = x.view(B, rt.env.S, D)
+                        t_part = xv[:, :St]
+                        full = end_route(xv[:, St:].contiguous().view(-1, D), bi)
+                        x = torch.cat([t_part, full.view(B, Si, D)], dim=1).reshape(B * S, D)
+                    else:
+                        img = end_route(img, bi)
         # ---- joint sequence [txt || img] (flux/transformer.py:1332): written in place by the last double block ----
         if not self.double:
             x = torch.cat([txt.view(B, St, D), img.view(B, Si, D)], dim=1).reshape(B * S, D)
         del img, txt
         # ---- single blocks ----
         for (s0, n, ck) in segs_s:
-            if ck:
-                ctx.ck_s[s0] = x
             for bi in range(s0, s0 + n):
-                x, sv = self._single_fwd(bi, x, env, save and not ck)
+                g = nd + bi
+                if starts(g):
+                    xv = x.view(B, S, D)
+                    t_part = xv[:, :St]
+                    x = torch.cat([t_part, start_route(xv[:, St:].contiguous().view(-1, D), g).view(B, -1, D)], dim=1).reshape(-1, D)
+                if ck and bi == s0:
+                    ctx.ck_s[s0] = x
+                ctx.env_s[bi] = rt.env
+                x, sv = self._single_fwd(bi, x, rt.env, save and not ck)
                 if sv is not None:
                     ctx.sgl[bi] = sv
+                if ends(g):
+                    xv = x.view(B, rt.env.S, D)
+                    t_part = xv[:, :St]
+                    full = end_route(xv[:, St:].contiguous().view(-1, D), g)
+                    x = torch.cat([t_part, full.view(B, Si, D)], dim=1).reshape(B * S, D)
+        if rt.info is not None:
+            raise ValueError("TREAD route does not end inside the block stack (end_layer_idx)")
         # ---- output head (flux/transformer.py:1501-1506): AdaLayerNormContinuous chunk order is (scale, shift) ----
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         n_out = torch.empty(B * Si, D, dtype=BF16, device=dev)
@@ -665,6 +742,10 @@ class FluxTransformer2DModel(nn.Module):
         B, H, hd, S = env.B, self.H, self.hd, env.S
         if sv.rrms is not None:
             ops.qk_rope_norm_bwd(dQ, dK, sv.Q, sv.K, sv.rrms, wq, wk, env.cos, env.sin, dqkv, B, H, hd, rows, pos0, S)
+        elif getattr(env, "routed", False):         # TREAD: per-sample position tables (see _qk_fwd)
+            for b in range(B):
+                ops.qk_norm_rope_bwd(dQ[b:b + 1], dK[b:b + 1], sv.qkv[b * S:(b + 1) * S], wq, wk, env.cos_b[b], env.sin_b[b], dqkv[b * S:(b + 1) * S],
+                                     1, H, hd, rows, pos0, S)
         else:
             ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, wq, wk, env.cos, env.sin, dqkv, B, H, hd, rows, pos0, S)
 
@@ -774,15 +855,34 @@ class FluxTransformer2DModel(nn.Module):
         del dn
         ctx.x_final = None
         # ---- single blocks, reversed ----
-        dxg = d_txt = d_img = None
+        # TREAD: the backward enters a route at its END block (the routed blocks see only the kept tokens' gradient rows; the skipped tokens' gradient stays in
+        # d_full) and leaves it at its START block (the kept rows go back into d_full: the gradient of the full stream at the route's start)
+        nd = len(self.double)
+        dxg = d_txt = d_img = d_full = None
+        keep_of = lambda info: info.keep_i32()
         for (s0, n, ck) in reversed(ctx.segs_s):
             if ck:
                 xr = ctx.ck_s.pop(s0)
                 for bi in range(s0, s0 + n):
-                    xr, ctx.sgl[bi] = self._single_fwd(bi, xr, env, True)
+                    xr, ctx.sgl[bi] = self._single_fwd(bi, xr, ctx.env_s[bi], True)
                 del xr
             for li in range(s0 + n - 1, s0 - 1, -1):
-                dx, dxg, d_txt, d_img = self._single_bwd(li, ctx.sgl.pop(li), dx, dxg, env)
+                g, e = nd + li, ctx.env_s[li]
+                if g in ctx.route_end:
+                    dxv = dx.view(B, S, D)
+                    d_full = dxv[:, St:].contiguous()
+                    dx = torch.cat([dxv[:, :St], ops.gather_rows(d_full, keep_of(ctx.route_end[g]))], dim=1).reshape(-1, D)
+                    dxg = None
+                dx, dxg, d_txt, d_img = self._single_bwd(li, ctx.sgl.pop(li), dx, dxg, e)
+                if g in ctx.route_start:
+                    if dx is None:                               # single block 0 under double blocks: its input gradient came back stream-major
+                        ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[g]), d_full)
+                        d_img, d_full = d_full.view(-1, D), None
+                    else:
+                        dxv = dx.view(B, e.S, D)
+                        ops.scatter_rows(dxv[:, St:].contiguous(), keep_of(ctx.route_start[g]), d_full)
+                        dx = torch.cat([dxv[:, :St], d_full], dim=1).reshape(B * S, D)
+                        dxg, d_full = None, None
         # ---- split the joint gradient (only when there was no single block to do it) ----
         if not self.single:
             d_txt = dx.view(B, S, D)[:, :St].reshape(B * St, D); d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
@@ -791,17 +891,29 @@ class FluxTransformer2DModel(nn.Module):
             if ck:
                 ir, tr = ctx.ck_d.pop(s0)
                 for bi in range(s0, s0 + n):
-                    ir, tr, _, ctx.dbl[bi] = self._double_fwd(bi, ir, tr, env, True)
+                    ir, tr, _, ctx.dbl[bi] = self._double_fwd(bi, ir, tr, ctx.env_d[bi], True)
                 del ir, tr
             for li in range(s0 + n - 1, s0 - 1, -1):
-                d_img, d_txt = self._double_bwd(li, ctx.dbl.pop(li), d_img, d_txt, env)
+                e = ctx.env_d[li]
+                if li in ctx.route_end:
+                    d_full = d_img.view(B, Si, D)
+                    d_img = ops.gather_rows(d_full, keep_of(ctx.route_end[li])).view(-1, D)
+                d_img, d_txt = self._double_bwd(li, ctx.dbl.pop(li), d_img, d_txt, e)
+                if li in ctx.route_start and d_img is not None:
+                    ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[li]), d_full)
+                    d_img, d_full = d_full.reshape(-1, D), None
         return None
 
     # ------------------------------------------------------------------------------------------------
     # public forward (reference signature: flux/transformer.py:940-960)
     # ------------------------------------------------------------------------------------------------
+    def set_router(self, router, routes):
+        """flux/transformer.py:829-831: TREAD router + [{selection_ratio, start_layer_idx, end_layer_idx}] (training/tread.py)"""
+        self._tread_router, self._tread_routes = router, routes
+
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None, txt_ids=None,
-                guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, **unsupported):
+                guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, force_keep_mask=None, **unsupported):
+        self._force_keep_mask = force_keep_mask            # TREAD: tokens that may never be routed away (flux/transformer.py:958, 1216-1220)
         for k, v in unsupported.items():
             if v is not None and v is not False:
                 raise NotImplementedError(f"FluxTransformer2DModel(st355): argument {k!r} is not supported on the HIP path")

@@ -484,13 +484,13 @@ class ModelFoundation(ExplorativeModelingMixin):
 
     def tread_init(self):
         """<family>/model.py `tread_init` (e.g. sd3/model.py:326-347): hand the trained component a TREADRouter seeded from the run seed and the routes of
-        `config.tread_config`.  Built for the components that expose `set_router` (SD3; training/tread.py); the others refuse — never a silent no-op."""
+        `config.tread_config`.  Built for the components that expose `set_router` (SD3, Flux; training/tread.py); the others refuse — never a silent no-op."""
         tc = getattr(self.config, "tread_config", None)
         if not tc or tc.get("routes", None) is None:
             raise ValueError("TREAD training requires you to configure the routes in the TREAD config")
         comp = self.get_trained_component()
         if comp is None or not hasattr(comp, "set_router"):
-            raise NotImplementedError(f"tread_init: TREAD routing is not implemented for {self.NAME} on the st355 path (built: SD3)")
+            raise NotImplementedError(f"tread_init: TREAD routing is not implemented for {self.NAME} on the st355 path (built: SD3, Flux)")
         from .training.tread import TREADRouter
         comp.set_router(TREADRouter(seed=getattr(self.config, "seed", None) or 42, device=self.accelerator.device), tc["routes"])
 

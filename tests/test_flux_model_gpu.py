@@ -197,3 +197,65 @@ def test_flux_attention_masked_training_matches_oracle(lat, St):
         if ".lora_" in name:
             ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
             assert PU.rel_l2(p.grad, ref) < 5e-2, name
+
+
+
+@pytest.mark.parametrize("start,end,ckpt", [(1, 2, False), (1, -2, True), (3, 5, False), (4, -1, False), (0, 1, True)])
+def test_flux_tread_routing_matches_oracle(start, end, ckpt):
+    """TREAD on Flux (helpers/training/tread.py; flux/transformer.py:1101-1133, 1211-1241, 1394-1486): 3 double + 4 single blocks, half of the image tokens routed
+    around the blocks [start, end] (global layer indices, negative = from the end) — inside the double stack ending on its LAST block (the joint sequence is
+    re-opened), across the double/single boundary, starting on single block 0, ending on the last block, starting on block 0.  The HIP step against the
+    oracle replaying the SAME permutations (the oracle's routing is pinned to the executed reference model: tests/test_ref_models_cpu.py tread_double /
+    tread_single); with per-block recomputation (what the reference falls back to under routing) the result is bit-identical."""
+    from simpletuner_amd.training.tread import ReplayRouter
+
+    def run(with_ckpt):
+        plugin, trainer, cpu, devt = _build(3, 4, 2, 16, 16, 32, rank=8)
+        model = plugin.get_trained_component()
+        g = torch.Generator().manual_seed(17)
+        B, Si = 2, 64
+        perm = torch.stack([torch.randperm(Si, generator=g) for _ in range(B)])
+        K = Si - int(round(Si * 0.5))
+        rec = {"mask": torch.ones(B, Si, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+               "ids_restore": torch.argsort(perm, dim=1)}
+        routes = [{"selection_ratio": 0.5, "start_layer_idx": start, "end_layer_idx": end}]
+        model.set_router(ReplayRouter([rec]), routes)
+        model.train()
+        if with_ckpt:
+            model.enable_gradient_checkpointing()
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        P, lora, scale = PU.oracle_state(model)
+        prepared = plugin.prepare_batch(_batch(devt), {"global_step": 0})
+        out = plugin.model_predict(prepared)
+        loss, _ = plugin.loss_with_logs(prepared, out)
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if ".lora_" in n}
+        return model, cpu, P, lora, scale, out["model_prediction"].detach().clone(), loss.detach().clone(), grads, rec, routes
+
+    model, cpu, P, lora, scale, pred, loss, grads, rec, routes = run(False)
+    s = cpu["sigmas"].view(-1, 1, 1, 1)
+    noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
+    target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    ocfg = PU.oracle_cfg(model)
+    o_pred = PU.OF.flux_model_predict(P, ocfg, noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, 1.0, lora=lp, lora_scale=scale,
+                                      tread={"routes": routes, "mask_infos": [rec]})
+    o_loss = ((o_pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+    o_loss.backward()
+    rr, cc = PU.rel_l2(pred, o_pred), PU.cos_sim(pred, o_pred)
+    print(f"[tread flux] route [{start}, {end}]: routed prediction vs oracle (same permutations): rel-L2 {rr:.3e} cos {cc:.6f}; loss hip {loss.item():.6f} oracle {o_loss.item():.6f}")
+    assert rr < 2e-2 and cc > 0.9995 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, abs(o_loss.item()))
+    plain = PU.OF.flux_model_predict(P, ocfg, noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, 1.0,
+                                     lora={k: (a.detach(), b.detach()) for k, (a, b) in lp.items()}, lora_scale=scale)
+    assert PU.rel_l2(plain, o_pred) > 2e-2                  # the route is live: the un-routed prediction differs
+    worst = (0.0, "")
+    for name, g_ in grads.items():
+        ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+        rg = PU.rel_l2(g_, ref)
+        worst = max(worst, (rg, name))
+        assert rg < 5e-2, (name, rg)
+    print(f"[tread flux] worst adapter gradient rel-L2 {worst[0]:.3e} at {worst[1]}")
+    if ckpt:
+        _, _, _, _, _, pred_c, _, grads_c, _, _ = run(True)
+        assert torch.equal(pred, pred_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)

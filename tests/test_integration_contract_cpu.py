@@ -62,7 +62,7 @@ def test_lifecycle_hooks_behave_like_the_reference_defaults():
     with pytest.raises(ValueError, match="configure the routes"):                             # sd3/model.py:329-337: TREAD without routes is a configuration error
         plug.tread_init()
     plug.config.tread_config = {"routes": [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]}
-    for refused in (plug.tread_init, plug.get_pipeline, plug.configure_group_offload):       # out-of-path features fail loudly, never silently (TREAD: built for SD3)
+    for refused in (plug.tread_init, plug.get_pipeline, plug.configure_group_offload):       # out-of-path features fail loudly, never silently (TREAD: built for SD3 and Flux; without a loaded component it refuses)
         with pytest.raises(NotImplementedError):
             refused()
     plug.unload()
