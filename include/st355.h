@@ -348,6 +348,25 @@ int st355_grid_to_nchw(void* stream, const void* grid, void* y, int B, int C, in
  * pad 1: symmetric padding 1 (UNet Downsample2D, conv_in);  pad 0 (stride 2 only): the VAE encoder's Downsample2D = F.pad(x,(0,1,0,1)) + pad-0 conv */
 int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad, int pad);
 int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad, int pad);   /* adjoint (gather form) */
+/* AutoencoderKL.encode as ONE entry point (SURVEY.md §8(b)7 `st355_vae_encode`; reference seam: VAECache.encode_images -> vae.encode(x).latent_dist,
+ * helpers/caching/vae.py:1238-1396, models/common.py:2767-2772): pixels [B, in_channels, H, W] bf16 -> the distribution parameters
+ * [B, 2*latent_channels, H/2^(n_levels-1), W/2^(n_levels-1)] bf16 (mean | logvar).  It sequences the grid / GroupNorm / conv-as-GEMM / softmax / GEMM entry
+ * points above in the order of the diffusers encoder; every intermediate lives in the caller's workspace.  `tensors`: device pointers (bf16) in this walk:
+ *   conv_in {w [ch0, 128] = 9 taps x 8 zero-padded input channels, b};
+ *   per level i, per resnet: norm1 {w, b}, conv1 {w [co, 9*ci], b}, norm2 {w, b}, conv2 {w [co, 9*co], b}, and when ci != co conv_shortcut {w [co, ci], b};
+ *   per level but the last: downsample conv {w [c, 9*c], b};
+ *   mid resnet 0 (as above); mid attention: group_norm {w, b}, to_q|to_k|to_v stacked {w [3c, c], b [3c]}, to_out.0 {w [c, c], b}; mid resnet 1;
+ *   conv_norm_out {w, b}; conv_out {w [2L, 9*c], b} with the 1x1 quant_conv (when the checkpoint has one) folded in by the host.
+ * conv weights are torch Conv2d weights permuted (0, 2, 3, 1) and flattened per output channel. */
+typedef struct st355_vae_encoder {
+  int32_t in_channels, latent_channels, n_levels, layers_per_block, norm_num_groups;
+  int32_t block_out_channels[8];
+  int32_t n_tensors;
+  const void* const* tensors;
+} st355_vae_encoder;
+size_t st355_vae_encode_workspace(const st355_vae_encoder* enc, int B, int H, int W);
+int st355_vae_encode(void* stream, const st355_vae_encoder* enc, const void* pixels, void* moments, int B, int H, int W, void* workspace,
+                     size_t workspace_bytes);
 /* in-place row softmax of a bf16 matrix: x[r, :n] = softmax(scale * x[r, :n]) (fp32 math) — the single-head d=512 attention of the VAE mid block */
 int st355_softmax_rows(void* stream, void* x, int64_t ldx, int64_t rows, int n, float scale);
 /* its backward, in place on dp: ds = scale * p * (dp - rowsum(dp * p))  (unfused attention of heads wider than 128: SD1.5's 160 at tiny S) */

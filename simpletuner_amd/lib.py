@@ -29,7 +29,7 @@ SYMBOLS = [
     "st355_workspace_bytes",
     "st355_comm_unique_id", "st355_comm_init", "st355_comm_destroy", "st355_comm_all_reduce", "st355_comm_reduce_scatter", "st355_comm_all_gather",
     # UNet path (SDXL / SD1.5)
-    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows",
+    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows", "st355_vae_encode_workspace", "st355_vae_encode",
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
     "st355_groupnorm_workspace", "st355_groupnorm_fwd", "st355_groupnorm_bwd",
     "st355_layernorm_fwd", "st355_layernorm_bwd", "st355_layernorm_param_grads_workspace", "st355_layernorm_param_grads",
@@ -58,6 +58,14 @@ class QkRope(C.Structure):
         ("Q", C.c_void_p), ("K", C.c_void_p), ("rrms", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
         ("H", C.c_int32), ("S", C.c_int32), ("pos0", C.c_int32), ("eps", C.c_float),
         ("Vt", C.c_void_p), ("Sp", C.c_int32),
+    ]
+
+
+class VaeEncoder(C.Structure):
+    """st355_vae_encoder (include/st355.h): architecture + the device-pointer table of st355_vae_encode"""
+    _fields_ = [
+        ("in_channels", C.c_int32), ("latent_channels", C.c_int32), ("n_levels", C.c_int32), ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32),
+        ("block_out_channels", C.c_int32 * 8), ("n_tensors", C.c_int32), ("tensors", C.POINTER(C.c_void_p)),
     ]
 
 
@@ -164,6 +172,8 @@ def _declare(lib):
         "st355_im2col3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
         "st355_col2im3x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
         "st355_softmax_rows": (C.c_int, [vp, vp, i64, i64, i32, f32]),
+        "st355_vae_encode_workspace": (sz, [C.POINTER(VaeEncoder), i32, i32, i32]),
+        "st355_vae_encode": (C.c_int, [vp, C.POINTER(VaeEncoder), vp, vp, i32, i32, i32, vp, sz]),
         "st355_upsample2x": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_upsample2x_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_tokens_to_grid": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),

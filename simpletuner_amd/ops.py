@@ -925,6 +925,47 @@ def upsample2x_bwd(dy, B: int, H: int, W: int):
     return dx
 
 
+class VaeEncoderTable:
+    """the architecture + device-pointer table st355_vae_encode walks (include/st355.h lists the order); keeps the tensors alive"""
+
+    def __init__(self, in_channels: int, latent_channels: int, block_out_channels, layers_per_block: int, norm_num_groups: int, tensors):
+        self.tensors = list(tensors)
+        for t in self.tensors:
+            _chk(t, BF16, "vae tensor")
+            if not t.is_contiguous():
+                raise _l.St355Error("vae_encode: table tensors must be contiguous")
+        n = len(self.tensors)
+        self._ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
+        st = _l.VaeEncoder()
+        st.in_channels, st.latent_channels, st.n_levels, st.layers_per_block, st.norm_num_groups = in_channels, latent_channels, len(block_out_channels), layers_per_block, norm_num_groups
+        for i, c in enumerate(block_out_channels):
+            st.block_out_channels[i] = int(c)
+        st.n_tensors, st.tensors = n, C.cast(self._ptrs, C.POINTER(C.c_void_p))
+        self.struct = st
+
+
+_vae_ws = {}
+
+
+def vae_encode(table: VaeEncoderTable, x):
+    """AutoencoderKL.encode as one C call: pixels [B, C, H, W] bf16 -> moments [B, 2L, H/2^(n-1), W/2^(n-1)] bf16"""
+    L = _l.load()
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    st = table.struct
+    f = 1 << (st.n_levels - 1)
+    need = L.st355_vae_encode_workspace(C.byref(st), B, H, W)
+    if need == 0:
+        raise _l.St355Error("vae_encode: " + L.st355_last_error().decode("utf-8", "replace"))
+    ws = _vae_ws.get(x.device.index)
+    if ws is None or ws.numel() < need:
+        ws = _vae_ws[x.device.index] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty(B, 2 * st.latent_channels, H // f, W // f, dtype=BF16, device=x.device)
+    _l.check(L.st355_vae_encode(_stream(), C.byref(st), _ptr(x), _ptr(out), B, H, W, _ptr(ws), ws.numel()), "vae_encode")
+    return out
+
+
 def tokens_to_grid(tokens, B: int, H: int, W: int, residual=None):
     L = _l.load()
     _chk(tokens, BF16, "tokens")

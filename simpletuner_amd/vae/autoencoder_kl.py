@@ -210,24 +210,25 @@ class AutoencoderKL(nn.Module):
         nb = len(c.block_out_channels)
         if H % (1 << (nb - 1)) or Wd % (1 << (nb - 1)):
             raise ValueError("image sides must be divisible by 2^(levels-1)")
-        col = ops.im2col3x3(ops.grid_from_nchw(x.to(device=self.device_, dtype=BF16), 8), B, H, Wd, stride=1)
-        h = ops.conv(col, W["encoder.conv_in.weight"], B, H, Wd, bias=W["encoder.conv_in.bias"], taps=1)
-        del col
-        for i in range(nb):
-            for j in range(c.layers_per_block):
-                h = self._res(f"encoder.down_blocks.{i}.resnets.{j}.", h, B, H, Wd)
-            if i < nb - 1:
-                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
-                col = ops.im2col3x3(h, B, H, Wd, stride=2, pad=0)
-                H, Wd = H // 2, Wd // 2
-                h = ops.conv(col, W[p + ".weight"], B, H, Wd, bias=W[p + ".bias"], taps=1)
-                del col
-        h = self._res("encoder.mid_block.resnets.0.", h, B, H, Wd)
-        h = self._mid_attention(h, B, H, Wd, "encoder.mid_block.attentions.0.")
-        h = self._res("encoder.mid_block.resnets.1.", h, B, H, Wd)
-        h, _ = ops.groupnorm_fwd(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], B, H, Wd, groups=c.norm_num_groups, eps=1e-6, silu=True)
-        y = ops.conv(h, W["encoder.conv_out.weight"], B, H, Wd, bias=W["encoder.conv_out.bias"])
-        return ops.grid_to_nchw(y, B, 2 * c.latent_channels, H, Wd)
+        # ONE C entry point (st355_vae_encode): the whole encoder — conv_in over pre-gathered columns, the DownEncoderBlock2D levels, the mid
+        # block with its single-head attention, GroupNorm + SiLU + conv_out — is sequenced inside libst355 over a caller-owned workspace
+        return ops.vae_encode(self._encoder_table(), x.to(device=self.device_, dtype=BF16))
+
+    def _encoder_table(self):
+        """the device-pointer table of st355_vae_encode, in the walk include/st355.h states (conv weights in the native [Cout, taps*Cin] layout)"""
+        t = getattr(self, "_enc_table", None)
+        if t is None or t[0] is not self.W:
+            c, W = self.config, self.W
+            ts = []
+            a = "encoder.mid_block.attentions.0."
+            for name, kind, ci, co, k in self._names():
+                if name == "quant_conv" or (name.startswith(a) and name[len(a):] in ("to_k", "to_v")):
+                    continue                              # folded into conv_out / stacked into the qkv matrix by load_state_dict
+                key = a + "qkv" if name == a + "to_q" else name
+                ts += [W[key + ".weight"], W[key + ".bias"]]
+            t = (self.W, ops.VaeEncoderTable(c.in_channels, c.latent_channels, c.block_out_channels, c.layers_per_block, c.norm_num_groups, ts))
+            self._enc_table = t
+        return t[1]
 
     def _mid_attention(self, x, B, H, Wd, a):
         W = self.W

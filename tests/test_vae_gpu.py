@@ -147,3 +147,43 @@ def test_validation_sampling_loop_ends_in_pixels():
         v = pl.model_predict(b)["model_prediction"]
         x = (x.float() + (sch.sigmas[i + 1] - sch.sigmas[i]) * v.float()).to(torch.bfloat16)
     assert torch.allclose(lat.float(), x.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("kind,hw", [("sdxl", (96, 64)), ("flux", (128, 128)), ("sdxl", (64, 192))])
+def test_vae_encode_c_entry_point_equals_the_per_kernel_sequencing(kind, hw):
+    """st355_vae_encode (the whole AutoencoderKL encoder as ONE C symbol over a caller-owned workspace) launches the same kernels in the same
+    order on the same operands as sequencing the per-kernel entry points from the host: bit-identical moments.  (96 x 64 px: a 12 x 8 latent grid, S = 96 mid-block
+    tokens -> the zero-padded contraction of the P V product; 128 x 128: S = 256, no padding.)"""
+    from simpletuner_amd import ops
+    from simpletuner_amd.vae.autoencoder_kl import AutoencoderKL
+    dev = "cuda:0"
+    cfg = VAEConfig(block_out_channels=(64, 128, 128, 128)) if kind == "sdxl" else VAEConfig(latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159,
+                                                                                               use_quant_conv=False, block_out_channels=(64, 128, 128, 128))
+    vae = AutoencoderKL(latent_channels=cfg.latent_channels, block_out_channels=cfg.block_out_channels, scaling_factor=cfg.scaling_factor,
+                        shift_factor=cfg.shift_factor, use_quant_conv=cfg.use_quant_conv, device=dev)
+    vae.load_state_dict(vae.synthetic_state_dict(7))
+    x = torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(dev, torch.bfloat16)
+    got = vae.encode_moments(x)
+
+    # the host-side sequencing of the same entry points (what encode_moments was before the C entry point existed)
+    c, W = vae.config, vae.W
+    B, _, H, Wd = x.shape
+    nb = len(c.block_out_channels)
+    col = ops.im2col3x3(ops.grid_from_nchw(x, 8), B, H, Wd, stride=1)
+    h = ops.conv(col, W["encoder.conv_in.weight"], B, H, Wd, bias=W["encoder.conv_in.bias"], taps=1)
+    for i in range(nb):
+        for j in range(c.layers_per_block):
+            h = vae._res(f"encoder.down_blocks.{i}.resnets.{j}.", h, B, H, Wd)
+        if i < nb - 1:
+            p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            col = ops.im2col3x3(h, B, H, Wd, stride=2, pad=0)
+            H, Wd = H // 2, Wd // 2
+            h = ops.conv(col, W[p + ".weight"], B, H, Wd, bias=W[p + ".bias"], taps=1)
+    h = vae._res("encoder.mid_block.resnets.0.", h, B, H, Wd)
+    h = vae._mid_attention(h, B, H, Wd, "encoder.mid_block.attentions.0.")
+    h = vae._res("encoder.mid_block.resnets.1.", h, B, H, Wd)
+    h, _ = ops.groupnorm_fwd(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], B, H, Wd, groups=c.norm_num_groups, eps=1e-6, silu=True)
+    y = ops.conv(h, W["encoder.conv_out.weight"], B, H, Wd, bias=W["encoder.conv_out.bias"])
+    want = ops.grid_to_nchw(y, B, 2 * c.latent_channels, H, Wd)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert torch.isfinite(got.float()).all()
