@@ -348,6 +348,50 @@ int st355_grid_to_nchw(void* stream, const void* grid, void* y, int B, int C, in
  * pad 1: symmetric padding 1 (UNet Downsample2D, conv_in);  pad 0 (stride 2 only): the VAE encoder's Downsample2D = F.pad(x,(0,1,0,1)) + pad-0 conv */
 int st355_im2col3x3(void* stream, const void* x, void* col, int B, int H, int W, int C, int stride, int Kpad, int pad);
 int st355_col2im3x3(void* stream, const void* dcol, void* dx, int B, int H, int W, int C, int stride, int Kpad, int pad);   /* adjoint (gather form) */
+/* ---- block-level entry points ---------------------------------------------------------------------------------------------------
+ * One FluxSingleTransformerBlock (flux/transformer.py:473-510) forward / backward as ONE call: the functions sequence the entry points above (AdaLN
+ * modulate, the fused QKV projection, attention, the GELU and gated-residual GEMMs; their backward forms and the rank-space adapter gradients) in the order
+ * of the reference block — bit-identical to issuing them one by one.  Every buffer is the caller's.  Built for the production form: head_dim 128 (D = H * 128),
+ * S (tokens per sample) a multiple of 256, optional LoRA adapters on to_q / to_k / to_v in the K-extension (K2 = 0: none).  bf16 unless noted; row-major,
+ * unit inner stride, leading dimension = the logical width unless a stride is given.  mod_*: this block's [B, D] slices of the modulation vector (row stride
+ * mod_stride elements): shift, scale, gate of AdaLayerNormZeroSingle. */
+typedef struct st355_flux_single_fwd_args {
+  int32_t B, S, H, D, K2, k2_real;
+  float scale;                                              /* softmax scale 1/sqrt(128) */
+  const void* x;                                            /* [B*S, D] block input */
+  const void* mod_shift; const void* mod_scale; const void* mod_gate; int64_t mod_stride;
+  const void* w_qkv; const void* b_qkv;                     /* [3D, D], [3D] */
+  const void* A_cat; const void* B_blk;                     /* adapters: [K2, D] down, [3D, K2] scaled block-diagonal up (NULL when K2 == 0) */
+  const void* norm_q; const void* norm_k;                   /* RMSNorm weights [128] or NULL */
+  const void* w_mlp; const void* b_mlp;                     /* [4D, D], [4D] */
+  const void* w_out; int64_t ld_w_out; const void* b_out;   /* [D, 5D] (attention columns first), [D] */
+  const float* cos_p; const float* sin_p;                   /* [S, 64] per-pair RoPE tables */
+  const float* key_bias;                                    /* fp32 [B, S] additive key bias or NULL */
+  void* n; void* V; float* rrms; void* Q; void* K; void* O; float* lse2; void* hpre; void* T;   /* kept for the backward: LN-modulated input [B*S,D], V rows [B*S,D],
+                                                               1/rms [B*S,2H] fp32, roped head-major Q / K [B,H,S,128], attention output [B*S,D], lse [B,H,S] fp32,
+                                                               GELU pre-activation [B*S,4D], adapter down-projection [B*S,K2] */
+  void* Vt; void* hact;                                     /* scratch: head-major V^T [B,H,128,S], GELU output [B*S,4D] */
+  void* gemm_ws; int64_t gemm_ws_bytes;                     /* fp32 split-K scratch of the thin adapter GEMM */
+  void* x_out;                                              /* [B*S, D] */
+} st355_flux_single_fwd_args;
+int st355_block_flux_single_fwd(void* stream, const st355_flux_single_fwd_args* args);
+typedef struct st355_flux_single_bwd_args {
+  int32_t B, S, H, D, K2, k2_real, n_targets, rank, r_pad, accumulate;
+  float scale, lora_scale;
+  const void* x; const void* n; const void* V; const float* rrms; const void* Q; const void* K; const void* O; const float* lse2; const void* hpre; const void* T;
+  const void* mod_scale; const void* mod_gate; int64_t mod_stride;
+  const void* gate_prev;                                    /* the previous block's gate slice (its backward then receives d x pre-gated in dxg_out) or NULL */
+  const void* wT_qkv; const void* wT_mlp; const void* wT_out;   /* K-major copies: [D, 3D], [D, 4D], [5D, D] */
+  const void* A_cat_T; const void* B_blk_T;                 /* [D, K2], [K2, 3D] */
+  const void* norm_q; const void* norm_k; const float* cos_p; const float* sin_p; const float* key_bias;
+  const void* dx; const void* dxg;                          /* d loss / d x_out [B*S, D]; the same already multiplied by this block's gate, or NULL */
+  float* gA[4]; float* gB[4];                               /* adapter gradients, fp32: [rank, D] and [D, rank] per target (to_q, to_k, to_v) */
+  void* g; void* dO; void* dhpre; void* dn_mlp; void* dqkv; void* U; void* dn;   /* scratch: [B*S,D], [B*S,D], [B*S,4D], [B*S,D], [B*S,3D], [B*S,K2], [B*S,D] */
+  void* gemm_ws; int64_t gemm_ws_bytes; void* attn_ws; void* skinny_ws;   /* st355_attn_bwd_workspace(B,H,S,S,128), st355_skinny_tn_workspace(B*S, D, 128) bytes */
+  void* dx_out; void* dxg_out;                              /* d loss / d x [B*S, D]; gate_prev * that, or NULL */
+} st355_flux_single_bwd_args;
+int st355_block_flux_single_bwd(void* stream, const st355_flux_single_bwd_args* args);
+
 /* AutoencoderKL.encode as ONE entry point (SURVEY.md §8(b)7 `st355_vae_encode`; reference seam: VAECache.encode_images -> vae.encode(x).latent_dist,
  * helpers/caching/vae.py:1238-1396, models/common.py:2767-2772): pixels [B, in_channels, H, W] bf16 -> the distribution parameters
  * [B, 2*latent_channels, H/2^(n_levels-1), W/2^(n_levels-1)] bf16 (mean | logvar).  It sequences the grid / GroupNorm / conv-as-GEMM / softmax / GEMM entry

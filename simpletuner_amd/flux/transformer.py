@@ -33,6 +33,7 @@ F32 = torch.float32
 _FUSED_QKV = __import__("os").environ.get("ST355_FUSED_QKV", "1") != "0"      # A/B switch: 0 = separate RMSNorm + RoPE pass after the QKV projection
 _FUSED_ROPE_BWD = __import__("os").environ.get("ST355_FUSED_ROPE_BWD", "1") != "0"   # A/B switch: 0 = RoPE / RMSNorm backward as its own pass after the attention backward
 _FUSED_VT = __import__("os").environ.get("ST355_FUSED_VT", "1") != "0"        # A/B switch: 0 = no V^T from the fused epilogue, forward attention reads row-major V
+_BLOCK_ABI = __import__("os").environ.get("ST355_BLOCK_ABI", "1") != "0"          # A/B switch: 0 = sequence the single blocks' kernels from the host instead of st355_block_flux_single_*
 _TRANSPOSED_COPIES = __import__("os").environ.get("ST355_ATTN_BWD_T") == "1"      # A/B switch: keep the pre-transposed Q^T / K^T copies (dkv2 / dq kernels) at head_dim 128
 
 
@@ -566,10 +567,28 @@ class FluxTransformer2DModel(nn.Module):
         B, S, Sp, mod, cos, sin = env.B, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.single[bi]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
+        if fused and _BLOCK_ABI and _FUSED_VT and x.is_contiguous():
+            # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
+            # as the host-side sequencing below
+            lo = blk.qkv.lora
+            n = torch.empty(B * S, D, dtype=BF16, device=dev); O = torch.empty_like(n); V = torch.empty_like(n); x_out = torch.empty_like(n)
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q); Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev)
+            rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+            hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev); hact = torch.empty_like(hpre)
+            T = torch.empty(B * S, lo.K2, dtype=BF16, device=dev) if lo is not None else None
+            ops.block_flux_single_fwd(B=B, S=S, H=H, D=D, K2=lo.K2 if lo is not None else 0, k2_real=lo.k2_real if lo is not None else 0, scale=env.scale,
+                                      x=x, mod_shift=ms[:, :D], mod_scale=ms[:, D:2 * D], mod_gate=ms[:, 2 * D:3 * D], mod_stride=ms.stride(0),
+                                      w_qkv=blk.qkv.w, b_qkv=blk.qkv.b, A_cat=lo.A_cat if lo is not None else None, B_blk=lo.B_blk if lo is not None else None,
+                                      norm_q=blk.norm_q, norm_k=blk.norm_k, w_mlp=blk.proj_mlp.w, b_mlp=blk.proj_mlp.b,
+                                      w_out=blk.proj_out.w, ld_w_out=blk.proj_out.w.stride(0), b_out=blk.proj_out.b, cos_p=env.cos_p, sin_p=env.sin_p,
+                                      key_bias=env.key_bias, n=n, V=V, rrms=rrms, Q=Q, K=K, O=O, lse2=lse2, hpre=hpre, T=T, Vt=Vt, hact=hact, x_out=x_out)
+            sv = SimpleNamespace(x=x, n=n, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
+            return x_out, sv
         n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
         qkv = V = rrms = Qt = Kt = None
-        if (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k)):
+        if fused:
             Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q)
             V = torch.empty(B * S, D, dtype=BF16, device=dev); rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev)
             Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev) if _FUSED_VT else None
@@ -756,6 +775,28 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.single[li]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        if (_BLOCK_ABI and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
+                and dx.is_contiguous() and (dxg is None or dxg.is_contiguous())):
+            # ONE C entry point (st355_block_flux_single_bwd): the launches of the host-side sequencing below, in its order, on its operands
+            lo = blk.qkv.lora
+            gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D] if li > 0 else None
+            mk = lambda c: torch.empty(B * S, c, dtype=BF16, device=dev)
+            dx_out = mk(D)
+            dxg_out = mk(D) if gprev is not None else None
+            ops.block_flux_single_bwd([t for t in lo.gA] if lo is not None else None, [t for t in lo.gB] if lo is not None else None,
+                                      B=B, S=S, H=H, D=D, K2=lo.K2 if lo is not None else 0, k2_real=lo.k2_real if lo is not None else 0,
+                                      n_targets=len(lo.targets) if lo is not None else 0, rank=lo.rank if lo is not None else 0, r_pad=lo.r_pad if lo is not None else 0,
+                                      accumulate=1 if self.accumulate_lora_grads else 0, scale=env.scale, lora_scale=lo.scale if lo is not None else 0.0,
+                                      x=sv.x, n=sv.n, V=sv.V, rrms=sv.rrms, Q=sv.Q, K=sv.K, O=sv.O, lse2=sv.lse2, hpre=sv.hpre, T=sv.T,
+                                      mod_scale=ms[:, D:2 * D], mod_gate=ms[:, 2 * D:3 * D], mod_stride=ms.stride(0), gate_prev=gprev,
+                                      wT_qkv=blk.qkv.wT, wT_mlp=blk.proj_mlp.wT, wT_out=blk.proj_out.wT,
+                                      A_cat_T=lo.A_cat_T if lo is not None else None, B_blk_T=lo.B_blk_T if lo is not None else None,
+                                      norm_q=blk.norm_q, norm_k=blk.norm_k, cos_p=env.cos_p, sin_p=env.sin_p, key_bias=env.key_bias, dx=dx, dxg=dxg,
+                                      g=mk(D) if dxg is None else None, dO=mk(D), dhpre=mk(4 * D), dn_mlp=mk(D), dqkv=mk(3 * D),
+                                      U=mk(lo.K2) if lo is not None else None, dn=mk(D), dx_out=dx_out, dxg_out=dxg_out)
+            if lo is not None and self.grad_sync is not None:
+                self.grad_sync.ready(lo.flat_lo, lo.flat_hi)
+            return dx_out, dxg_out, None, None
         g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
         dO = ops.gemm(g, blk.proj_out.wT[:D])
         dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)

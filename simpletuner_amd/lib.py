@@ -29,7 +29,7 @@ SYMBOLS = [
     "st355_workspace_bytes",
     "st355_comm_unique_id", "st355_comm_init", "st355_comm_destroy", "st355_comm_all_reduce", "st355_comm_reduce_scatter", "st355_comm_all_gather",
     # UNet path (SDXL / SD1.5)
-    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows", "st355_vae_encode_workspace", "st355_vae_encode",
+    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows", "st355_vae_encode_workspace", "st355_vae_encode", "st355_block_flux_single_fwd", "st355_block_flux_single_bwd",
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
     "st355_groupnorm_workspace", "st355_groupnorm_fwd", "st355_groupnorm_bwd",
     "st355_layernorm_fwd", "st355_layernorm_bwd", "st355_layernorm_param_grads_workspace", "st355_layernorm_param_grads",
@@ -58,6 +58,49 @@ class QkRope(C.Structure):
         ("Q", C.c_void_p), ("K", C.c_void_p), ("rrms", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
         ("H", C.c_int32), ("S", C.c_int32), ("pos0", C.c_int32), ("eps", C.c_float),
         ("Vt", C.c_void_p), ("Sp", C.c_int32),
+    ]
+
+
+class FluxSingleFwdArgs(C.Structure):
+    """st355_flux_single_fwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("K2", C.c_int32), ("k2_real", C.c_int32),
+        ("scale", C.c_float),
+        ("x", C.c_void_p),
+        ("mod_shift", C.c_void_p), ("mod_scale", C.c_void_p), ("mod_gate", C.c_void_p), ("mod_stride", C.c_int64),
+        ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
+        ("A_cat", C.c_void_p), ("B_blk", C.c_void_p),
+        ("norm_q", C.c_void_p), ("norm_k", C.c_void_p),
+        ("w_mlp", C.c_void_p), ("b_mlp", C.c_void_p),
+        ("w_out", C.c_void_p), ("ld_w_out", C.c_int64), ("b_out", C.c_void_p),
+        ("cos_p", C.c_void_p), ("sin_p", C.c_void_p),
+        ("key_bias", C.c_void_p),
+        ("n", C.c_void_p), ("V", C.c_void_p), ("rrms", C.c_void_p), ("Q", C.c_void_p), ("K", C.c_void_p), ("O", C.c_void_p), ("lse2", C.c_void_p),
+        ("hpre", C.c_void_p), ("T", C.c_void_p),
+        ("Vt", C.c_void_p), ("hact", C.c_void_p),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_int64),
+        ("x_out", C.c_void_p),
+    ]
+
+
+class FluxSingleBwdArgs(C.Structure):
+    """st355_flux_single_bwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("K2", C.c_int32), ("k2_real", C.c_int32), ("n_targets", C.c_int32),
+        ("rank", C.c_int32), ("r_pad", C.c_int32), ("accumulate", C.c_int32),
+        ("scale", C.c_float), ("lora_scale", C.c_float),
+        ("x", C.c_void_p), ("n", C.c_void_p), ("V", C.c_void_p), ("rrms", C.c_void_p), ("Q", C.c_void_p), ("K", C.c_void_p), ("O", C.c_void_p),
+        ("lse2", C.c_void_p), ("hpre", C.c_void_p), ("T", C.c_void_p),
+        ("mod_scale", C.c_void_p), ("mod_gate", C.c_void_p), ("mod_stride", C.c_int64),
+        ("gate_prev", C.c_void_p),
+        ("wT_qkv", C.c_void_p), ("wT_mlp", C.c_void_p), ("wT_out", C.c_void_p),
+        ("A_cat_T", C.c_void_p), ("B_blk_T", C.c_void_p),
+        ("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("cos_p", C.c_void_p), ("sin_p", C.c_void_p), ("key_bias", C.c_void_p),
+        ("dx", C.c_void_p), ("dxg", C.c_void_p),
+        ("gA", C.c_void_p * 4), ("gB", C.c_void_p * 4),
+        ("g", C.c_void_p), ("dO", C.c_void_p), ("dhpre", C.c_void_p), ("dn_mlp", C.c_void_p), ("dqkv", C.c_void_p), ("U", C.c_void_p), ("dn", C.c_void_p),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_int64), ("attn_ws", C.c_void_p), ("skinny_ws", C.c_void_p),
+        ("dx_out", C.c_void_p), ("dxg_out", C.c_void_p),
     ]
 
 
@@ -174,6 +217,8 @@ def _declare(lib):
         "st355_softmax_rows": (C.c_int, [vp, vp, i64, i64, i32, f32]),
         "st355_vae_encode_workspace": (sz, [C.POINTER(VaeEncoder), i32, i32, i32]),
         "st355_vae_encode": (C.c_int, [vp, C.POINTER(VaeEncoder), vp, vp, i32, i32, i32, vp, sz]),
+        "st355_block_flux_single_fwd": (C.c_int, [vp, C.POINTER(FluxSingleFwdArgs)]),
+        "st355_block_flux_single_bwd": (C.c_int, [vp, C.POINTER(FluxSingleBwdArgs)]),
         "st355_upsample2x": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_upsample2x_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_tokens_to_grid": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -925,6 +925,51 @@ def upsample2x_bwd(dy, B: int, H: int, W: int):
     return dx
 
 
+def _fill(st, **kw):
+    """tensors -> device pointers, None -> NULL, numbers as they are"""
+    keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            _dev(v, k)
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(st, k, v)
+    st._keep = keep
+    return st
+
+
+def block_flux_single_fwd(**kw):
+    """st355_block_flux_single_fwd: one FluxSingleTransformerBlock forward as ONE C call (field names of st355_flux_single_fwd_args)"""
+    L = _l.load()
+    ws = _gemm_workspace(kw["x"].device)
+    a = _fill(_l.FluxSingleFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
+    _l.check(L.st355_block_flux_single_fwd(_stream(), C.byref(a)), "block_flux_single_fwd")
+
+
+def block_flux_single_bwd(gA, gB, **kw):
+    """st355_block_flux_single_bwd (field names of st355_flux_single_bwd_args); gA / gB: lists of the adapters' fp32 gradient views"""
+    L = _l.load()
+    dev = kw["x"].device
+    B, S, H, D = kw["B"], kw["S"], kw["H"], kw["D"]
+    ws = _gemm_workspace(dev)
+    need = L.st355_attn_bwd_workspace(B, H, S, S, 128)
+    aws = _attn_ws.get((dev.index,))
+    if aws is None or aws.numel() < need:
+        aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
+    sws = None
+    if kw.get("K2"):
+        need = L.st355_skinny_tn_workspace(B * S, D, 128)
+        sws = _skinny_ws.get((dev.index,))
+        if sws is None or sws.numel() * 4 < need:
+            sws = _skinny_ws[(dev.index,)] = torch.empty((need + 3) // 4, dtype=F32, device=dev)
+    a = _fill(_l.FluxSingleBwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, attn_ws=aws, skinny_ws=sws, **kw)
+    for i, t in enumerate(gA or []):
+        _chk(t, F32, "gA"); a.gA[i] = t.data_ptr()
+    for i, t in enumerate(gB or []):
+        _chk(t, F32, "gB"); a.gB[i] = t.data_ptr()
+    _l.check(L.st355_block_flux_single_bwd(_stream(), C.byref(a)), "block_flux_single_bwd")
+
+
 class VaeEncoderTable:
     """the architecture + device-pointer table st355_vae_encode walks (include/st355.h lists the order); keeps the tensors alive"""
 

@@ -259,3 +259,36 @@ def test_flux_tread_routing_matches_oracle(start, end, ckpt):
     if ckpt:
         _, _, _, _, _, pred_c, _, grads_c, _, _ = run(True)
         assert torch.equal(pred, pred_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+
+
+@pytest.mark.parametrize("layers,single,masked", [(1, 3, False), (0, 2, False), (1, 2, True)])
+def test_flux_single_block_c_entry_points_equal_host_sequencing(layers, single, masked, monkeypatch):
+    """st355_block_flux_single_fwd / _bwd (one FluxSingleTransformerBlock forward / backward as ONE C call) issue the same launches in the
+    same order on the same operands as sequencing the per-kernel entry points from the host: prediction, loss and every adapter gradient bit-identical.
+    Tile-aligned streams (256 image + 256 text tokens per sample) = the production form the entry points are built for; (0, 2): no double blocks, so single
+    block 0 runs through the C backward too (no previous gate); masked: the key-bias variants."""
+    import simpletuner_amd.flux.transformer as FT
+
+    def run(block_abi):
+        monkeypatch.setattr(FT, "_BLOCK_ABI", block_abi)
+        plugin, trainer, cpu, devt = _build(layers, single, 2, 32, 32, 256, rank=16)
+        model = plugin.get_trained_component()
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        if masked:
+            plugin.config.flux_attention_masked_training = True
+        batch = _batch(devt)
+        if masked:
+            m = torch.ones(2, 256, device="cuda:0"); m[0, 100:] = 0; m[1, 180:] = 0
+            batch["encoder_attention_mask"] = m
+        prepared = plugin.prepare_batch(batch, {"global_step": 0})
+        out = plugin.model_predict(prepared)
+        loss, _ = plugin.loss_with_logs(prepared, out)
+        loss.backward()
+        return out["model_prediction"].detach().clone(), loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if ".lora_" in n}
+
+    p0, l0, g0 = run(False)
+    p1, l1, g1 = run(True)
+    assert torch.equal(p0, p1) and torch.equal(l0, l1)
+    assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    assert any(".single_transformer_blocks." in k or k.startswith("single_transformer_blocks.") for k in g0)
