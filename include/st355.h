@@ -392,6 +392,54 @@ typedef struct st355_flux_single_bwd_args {
 } st355_flux_single_bwd_args;
 int st355_block_flux_single_bwd(void* stream, const st355_flux_single_bwd_args* args);
 
+/* One FluxTransformerBlock ("double" block, flux/transformer.py:607-687) forward as ONE call.  img [B*Si, D] / txt [B*St, D]: the two residual streams; joint
+ * buffers (V, O: [B*(St+Si), D], text rows first per sample; Q, K, Vt head-major over the joint sequence) are written in place through segmented-row operands.
+ * mod_img / mod_txt: this block's [B, 6D] modulation slices (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp), row stride mod_stride.
+ * Adapters (optional) on the image stream's to_q|to_k|to_v (A_qkv [K2_qkv, D], Bb_qkv [3D, K2_qkv]) and to_out.0 (A_out, Bb_out).  Kept for the backward:
+ * n_img, n_txt, V, rrms, Q, K, O, lse2, x1_*, hpre_*, T_img, T_o; scratch: Vt, n2_*, h_*.  Output: out_img + out_txt, or — the last double block —
+ * out_joint, the [txt || img] sequence of the single blocks (flux/transformer.py:1332).  Built for head_dim 128 and Si, St multiples of 256. */
+typedef struct st355_flux_double_fwd_args {
+  int32_t B; int32_t Si; int32_t St; int32_t H; int32_t D; int32_t K2_qkv; int32_t k2r_qkv; int32_t K2_out;
+  int32_t k2r_out;
+  float scale;
+  void* img; void* txt; void* mod_img; void* mod_txt;
+  int64_t mod_stride;
+  void* w_qkv; void* b_qkv; void* w_add_qkv; void* b_add_qkv; void* A_qkv; void* Bb_qkv; void* A_out; void* Bb_out;
+  void* norm_q; void* norm_k; void* norm_added_q; void* norm_added_k; void* w_out; void* b_out; void* w_add_out; void* b_add_out;
+  void* w_ff1; void* b_ff1; void* w_ff2; void* b_ff2; void* w_ffc1; void* b_ffc1; void* w_ffc2; void* b_ffc2;
+  void* cos_p; void* sin_p; void* key_bias; void* n_img; void* n_txt; void* V; void* rrms; void* Q;
+  void* K; void* O; void* lse2; void* x1_img; void* x1_txt; void* hpre_img; void* hpre_txt; void* T_img;
+  void* T_o; void* Vt; void* n2_img; void* n2_txt; void* h_img; void* h_txt; void* gemm_ws;
+  int64_t gemm_ws_bytes;
+  void* out_img; void* out_txt; void* out_joint;
+} st355_flux_double_fwd_args;
+int st355_block_flux_double_fwd(void* stream, const st355_flux_double_fwd_args* args);
+
+/* ... and its backward (for a double block that is not the first: both input gradients are produced; block 0's frozen-embedder case stays on the host).
+ * Kept activations as written by the forward; wT_*: K-major weight copies ([in, out]); At_* / Bbt_*: the adapters' transposed packed operands; gA_* / gB_*:
+ * fp32 adapter gradients ([rank, D] / [D, rank] per target: to_q, to_k, to_v; to_out.0); d_img / d_txt: gradients of the block outputs; every other pointer
+ * is scratch of the stated logical shape ([rows, D] unless the name says otherwise: dh_* [rows, 4D], dqkv [B*S, 3D], dO [B*S, D], U_* [B*Si, K2]);
+ * attn_ws: st355_attn_bwd_workspace(B, H, S, S, 128) bytes, skinny_ws: st355_skinny_tn_workspace(B*Si, D, 128) bytes. */
+typedef struct st355_flux_double_bwd_args {
+  int32_t B; int32_t Si; int32_t St; int32_t H; int32_t D; int32_t K2_qkv; int32_t k2r_qkv; int32_t K2_out;
+  int32_t k2r_out; int32_t rank_qkv; int32_t rpad_qkv; int32_t rank_out; int32_t rpad_out; int32_t accumulate;
+  float scale; float scale_qkv; float scale_out;
+  void* img; void* txt; void* n_img; void* V; void* rrms; void* Q; void* K; void* O;
+  void* lse2; void* x1_img; void* x1_txt; void* hpre_img; void* hpre_txt; void* T_img; void* T_o; void* mod_img;
+  void* mod_txt;
+  int64_t mod_stride;
+  void* wT_qkv; void* wT_add_qkv; void* wT_out; void* wT_add_out; void* wT_ff1; void* wT_ff2; void* wT_ffc1; void* wT_ffc2;
+  void* At_qkv; void* Bbt_qkv; void* At_out; void* Bbt_out; void* norm_q; void* norm_k; void* norm_added_q; void* norm_added_k;
+  void* cos_p; void* sin_p; void* key_bias; void* d_img; void* d_txt;
+  float* gA_qkv[4]; float* gB_qkv[4]; float* gA_out[4]; float* gB_out[4];
+  void* g_img; void* g_txt; void* dh_img; void* dh_txt; void* dn2_img; void* dn2_txt; void* dx1_img; void* dx1g_img;
+  void* dx1_txt; void* dx1g_txt; void* dO; void* dqkv; void* U_qkv; void* U_out; void* dn_img; void* dn_txt;
+  void* gemm_ws;
+  int64_t gemm_ws_bytes;
+  void* attn_ws; void* skinny_ws; void* d_img_out; void* d_txt_out;
+} st355_flux_double_bwd_args;
+int st355_block_flux_double_bwd(void* stream, const st355_flux_double_bwd_args* args);
+
 /* AutoencoderKL.encode as ONE entry point (SURVEY.md §8(b)7 `st355_vae_encode`; reference seam: VAECache.encode_images -> vae.encode(x).latent_dist,
  * helpers/caching/vae.py:1238-1396, models/common.py:2767-2772): pixels [B, in_channels, H, W] bf16 -> the distribution parameters
  * [B, 2*latent_channels, H/2^(n_levels-1), W/2^(n_levels-1)] bf16 (mean | logvar).  It sequences the grid / GroupNorm / conv-as-GEMM / softmax / GEMM entry

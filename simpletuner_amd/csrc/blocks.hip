@@ -134,3 +134,211 @@ extern "C" int st355_block_flux_single_bwd(void* stream, const st355_flux_single
                                 p->dxg_out, D, M, D, 1e-6f));
   return q.rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// FluxTransformerBlock ("double" block, flux/transformer.py:607-687): the image and the text stream use different weights but the same epilogues; every
+// pair of projections goes out as ONE grouped launch.  Joint buffers ([B*S, *], sample b = rows [b*S, (b+1)*S), text rows first) are read and written in
+// place through segmented-row operands (st355_gemm_args.seg_rows): the image rows of every sample are one problem, the text rows another.
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rows { const void* p; int64_t ld; int64_t seg; };                 // seg: physical rows from one sample's block to the next (0 = compact rows)
+Rows joint_rows(const void* base, int64_t ld, int lo, int S) { return Rows{(const char*)base + (size_t)lo * ld * 2, ld, S}; }
+Rows compact_rows(const void* base, int64_t ld) { return Rows{base, ld, 0}; }
+// one stream's problem over `rows` rows per sample: plain 2-D when B == 1, else ONE segmented problem (the host side's FluxTransformer2DModel._problems)
+st355_gemm_args GS(int B, int rows, Rows A, const void* W, int64_t ldw, Rows C, int N, int K) {
+  st355_gemm_args a = G(A.p, A.ld, W, ldw, (void*)C.p, C.ld, B * rows, N, K);
+  if (B > 1) { a.seg_rows = rows; a.seg_a = A.seg; a.seg_c = C.seg; }
+  return a;
+}
+void ext(st355_gemm_args& a, int B, Rows A2, const void* B2, int K2, int k2_real) {
+  if (!K2) return;
+  a.A2 = A2.p; a.lda2 = A2.ld; a.B2 = B2; a.ldb2 = K2; a.K2 = K2; a.K2_real = k2_real;
+  if (B > 1) a.seg_a2 = A2.seg;
+}
+}  // namespace
+
+extern "C" int st355_block_flux_double_fwd(void* stream, const st355_flux_double_fwd_args* p) {
+  ST_REQUIRE(p && p->img && p->txt && p->n_img && p->n_txt && p->V && p->rrms && p->Q && p->K && p->Vt && p->O && p->lse2 && p->x1_img && p->x1_txt && p->hpre_img &&
+             p->hpre_txt && p->n2_img && p->n2_txt && p->h_img && p->h_txt, "block_flux_double_fwd: null pointer");
+  ST_REQUIRE((p->out_joint != nullptr) != (p->out_img != nullptr && p->out_txt != nullptr), "block_flux_double_fwd: give either the joint output or the two stream outputs");
+  ST_REQUIRE(p->B > 0 && p->Si > 0 && p->St > 0 && p->Si % 256 == 0 && p->St % 256 == 0 && p->H > 0 && p->H % 2 == 0 && p->D == p->H * 128,
+             "block_flux_double_fwd: built for head_dim 128, even H, both streams a multiple of 256 rows per sample");
+  ST_REQUIRE((p->K2_qkv == 0) == (p->A_qkv == nullptr) && (p->K2_qkv == 0 || (p->Bb_qkv && p->T_img)) && (p->K2_out == 0) == (p->A_out == nullptr) &&
+             (p->K2_out == 0 || (p->Bb_out && p->T_o)), "block_flux_double_fwd: inconsistent adapter operands");
+  const int B = p->B, Si = p->Si, St = p->St, S = Si + St, H = p->H, D = p->D;
+  const int64_t ms = p->mod_stride;
+  const bf16* mi = (const bf16*)p->mod_img; const bf16* mt = (const bf16*)p->mod_txt;       // [B, 6D] slices: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+  Seq q{stream, 0};
+  q.run(st355_ln_modulate_fwd(stream, p->img, D, mi + D, mi, ms, Si, p->n_img, D, (int64_t)B * Si, D, 1e-6f));
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->txt, D, mt + D, mt, ms, St, p->n_txt, D, (int64_t)B * St, D, 1e-6f));
+  if (p->K2_qkv) {
+    st355_gemm_args t = G(p->n_img, D, p->A_qkv, D, p->T_img, p->K2_qkv, B * Si, p->K2_qkv, D);
+    thin_ws(t, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(t);
+  }
+  // both streams project into the joint [txt || img] sequence: q / k head-major with RMSNorm + RoPE in the epilogue, v rows + V^T (flux/transformer.py:140-207)
+  st355_qk_rope ri, rt;
+  memset(&ri, 0, sizeof(ri));
+  ri.Q = p->Q; ri.K = p->K; ri.rrms = (float*)p->rrms; ri.cos = (const float*)p->cos_p; ri.sin = (const float*)p->sin_p; ri.H = H; ri.S = S; ri.eps = 1e-6f; ri.Vt = p->Vt; ri.Sp = S;
+  rt = ri;
+  ri.wq = p->norm_q; ri.wk = p->norm_k; ri.pos0 = St;
+  rt.wq = p->norm_added_q; rt.wk = p->norm_added_k; rt.pos0 = 0;
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = GS(B, Si, compact_rows(p->n_img, D), p->w_qkv, D, joint_rows(p->V, D, St, S), 3 * D, D);
+    g2[0].bias = p->b_qkv; g2[0].epilogue = ST355_EPI_QK_NORM_ROPE; g2[0].rope = &ri; g2[0].rows_per_batch = Si;
+    ext(g2[0], B, compact_rows(p->T_img, p->K2_qkv), p->Bb_qkv, p->K2_qkv, p->k2r_qkv);
+    g2[1] = GS(B, St, compact_rows(p->n_txt, D), p->w_add_qkv, D, joint_rows(p->V, D, 0, S), 3 * D, D);
+    g2[1].bias = p->b_add_qkv; g2[1].epilogue = ST355_EPI_QK_NORM_ROPE; g2[1].rope = &rt; g2[1].rows_per_batch = St;
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (q.ok()) q.run(st355_attn_fwd(stream, p->Q, p->K, p->Vt, (const float*)p->key_bias, p->O, D, (float*)p->lse2, B, H, S, S, 128, p->scale));
+  // attention output projections, gated onto the two residual streams (the attention output is split back by rows, in place)
+  const Rows O_i = joint_rows(p->O, D, St, S), O_t = joint_rows(p->O, D, 0, S);
+  if (p->K2_out) {
+    st355_gemm_args t = GS(B, Si, O_i, p->A_out, D, compact_rows(p->T_o, p->K2_out), p->K2_out, D);
+    thin_ws(t, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(t);
+  }
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = GS(B, Si, O_i, p->w_out, D, compact_rows(p->x1_img, D), D, D);
+    g2[0].bias = p->b_out; g2[0].epilogue = ST355_EPI_GATE_RESIDUAL; g2[0].aux_in = p->img; g2[0].ld_aux_in = D; g2[0].gate = mi + 2 * D; g2[0].gate_stride = ms;
+    g2[0].rows_per_batch = Si;
+    ext(g2[0], B, compact_rows(p->T_o, p->K2_out), p->Bb_out, p->K2_out, p->k2r_out);
+    g2[1] = GS(B, St, O_t, p->w_add_out, D, compact_rows(p->x1_txt, D), D, D);
+    g2[1].bias = p->b_add_out; g2[1].epilogue = ST355_EPI_GATE_RESIDUAL; g2[1].aux_in = p->txt; g2[1].ld_aux_in = D; g2[1].gate = mt + 2 * D; g2[1].gate_stride = ms;
+    g2[1].rows_per_batch = St;
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  // the two MLPs
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->x1_img, D, mi + 4 * D, mi + 3 * D, ms, Si, p->n2_img, D, (int64_t)B * Si, D, 1e-6f));
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->x1_txt, D, mt + 4 * D, mt + 3 * D, ms, St, p->n2_txt, D, (int64_t)B * St, D, 1e-6f));
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = G(p->n2_img, D, p->w_ff1, D, p->h_img, 4 * D, B * Si, 4 * D, D);
+    g2[0].bias = p->b_ff1; g2[0].epilogue = ST355_EPI_GELU; g2[0].aux_out = p->hpre_img; g2[0].ld_aux_out = 4 * D;
+    g2[1] = G(p->n2_txt, D, p->w_ffc1, D, p->h_txt, 4 * D, B * St, 4 * D, D);
+    g2[1].bias = p->b_ffc1; g2[1].epilogue = ST355_EPI_GELU; g2[1].aux_out = p->hpre_txt; g2[1].ld_aux_out = 4 * D;
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    if (p->out_joint) {      // the LAST double block writes the joint [txt || img] sequence of the single blocks in place (flux/transformer.py:1332 `torch.cat`)
+      g2[0] = GS(B, Si, compact_rows(p->h_img, 4 * D), p->w_ff2, 4 * D, joint_rows(p->out_joint, D, St, S), D, 4 * D);
+      g2[1] = GS(B, St, compact_rows(p->h_txt, 4 * D), p->w_ffc2, 4 * D, joint_rows(p->out_joint, D, 0, S), D, 4 * D);
+    } else {
+      g2[0] = G(p->h_img, 4 * D, p->w_ff2, 4 * D, p->out_img, D, B * Si, D, 4 * D);
+      g2[1] = G(p->h_txt, 4 * D, p->w_ffc2, 4 * D, p->out_txt, D, B * St, D, 4 * D);
+    }
+    g2[0].bias = p->b_ff2; g2[0].epilogue = ST355_EPI_GATE_RESIDUAL; g2[0].aux_in = p->x1_img; g2[0].ld_aux_in = D; g2[0].gate = mi + 5 * D; g2[0].gate_stride = ms;
+    g2[0].rows_per_batch = Si;
+    g2[1].bias = p->b_ffc2; g2[1].epilogue = ST355_EPI_GATE_RESIDUAL; g2[1].aux_in = p->x1_txt; g2[1].ld_aux_in = D; g2[1].gate = mt + 5 * D; g2[1].gate_stride = ms;
+    g2[1].rows_per_batch = St;
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  return q.rc;
+}
+
+namespace {
+// LoraGroup.grads of the host side for ONE stream's projection group: dB_t = s dy_t^T T_t, dA_t = U_t^T x.  dy: the projection gradient (columns t * Nt),
+// x: the projection input; either may be rows of a joint buffer (seg != 0, B > 1).
+void lora_grads(Seq& q, int B, int rows, Rows dy, int Nt, Rows x, int K, const void* T, const void* U, int K2, int n_targets, int rank, int r_pad, float s,
+                float* const* gA, float* const* gB, int accumulate, void* ws) {
+  const int cw = r_pad < 64 ? r_pad : 64;
+  const bool multi = n_targets > 1 && r_pad == 32 && K2 >= 128;
+  const int64_t M = (int64_t)B * rows;
+  const int64_t seg = B > 1 && (dy.seg || x.seg) ? rows : 0;
+  for (int t = 0; t < n_targets && q.ok(); t++)
+    for (int s0 = 0; s0 < rank && q.ok(); s0 += cw) {
+      const int c0 = t * r_pad + s0, r_used = (rank - s0) < cw ? (rank - s0) : cw;
+      q.run(st355_skinny_tn_seg(q.st, (const char*)dy.p + (size_t)t * Nt * 2, dy.ld, (const char*)T + (size_t)c0 * 2, K2, gB[t] + s0, rank, 1, M, Nt, cw, r_used, s,
+                                accumulate, ws, (B > 1 && dy.seg) ? rows : 0, (B > 1) ? dy.seg : 0, 0));
+      if (!multi && q.ok())
+        q.run(st355_skinny_tn_seg(q.st, x.p, x.ld, (const char*)U + (size_t)c0 * 2, K2, gA[t] + (size_t)s0 * K, 1, K, M, K, cw, r_used, 1.0f, accumulate, ws,
+                                  (B > 1 && x.seg) ? rows : 0, (B > 1) ? x.seg : 0, 0));
+    }
+  if (multi && q.ok())
+    q.run(st355_skinny_tn_multi(q.st, x.p, x.ld, U, K2, gA, n_targets, 1, K, M, K, rank, 1.0f, accumulate, ws, (B > 1 && x.seg) ? rows : 0, (B > 1) ? x.seg : 0, 0));
+  (void)seg;
+}
+}  // namespace
+
+// backward of a double block that is NOT the first one (its input gradients are needed; block 0's embedders are frozen and the host keeps that special case)
+extern "C" int st355_block_flux_double_bwd(void* stream, const st355_flux_double_bwd_args* p) {
+  ST_REQUIRE(p && p->img && p->txt && p->n_img && p->V && p->rrms && p->Q && p->K && p->O && p->lse2 && p->x1_img && p->x1_txt && p->hpre_img && p->hpre_txt &&
+             p->d_img && p->d_txt && p->d_img_out && p->d_txt_out, "block_flux_double_bwd: null pointer");
+  ST_REQUIRE(p->g_img && p->g_txt && p->dh_img && p->dh_txt && p->dn2_img && p->dn2_txt && p->dx1_img && p->dx1g_img && p->dx1_txt && p->dx1g_txt && p->dO && p->dqkv &&
+             p->dn_img && p->dn_txt && p->attn_ws, "block_flux_double_bwd: null scratch pointer");
+  ST_REQUIRE(p->B > 0 && p->Si > 0 && p->St > 0 && p->Si % 256 == 0 && p->St % 256 == 0 && p->H > 0 && p->H % 2 == 0 && p->D == p->H * 128,
+             "block_flux_double_bwd: built for head_dim 128, even H, both streams a multiple of 256 rows per sample");
+  ST_REQUIRE((p->K2_qkv == 0) == (p->At_qkv == nullptr) && (p->K2_qkv == 0 || (p->Bbt_qkv && p->T_img && p->U_qkv && p->skinny_ws)) &&
+             (p->K2_out == 0) == (p->At_out == nullptr) && (p->K2_out == 0 || (p->Bbt_out && p->T_o && p->U_out && p->skinny_ws)), "block_flux_double_bwd: inconsistent adapter operands");
+  const int B = p->B, Si = p->Si, St = p->St, S = Si + St, H = p->H, D = p->D;
+  const int64_t ms = p->mod_stride, Mi = (int64_t)B * Si, Mt = (int64_t)B * St;
+  const bf16* mi = (const bf16*)p->mod_img; const bf16* mt = (const bf16*)p->mod_txt;
+  Seq q{stream, 0};
+  // ---- the two MLPs ----
+  q.run(st355_scale_cols(stream, p->d_img, D, mi + 5 * D, ms, Si, p->g_img, D, Mi, D));
+  if (q.ok()) q.run(st355_scale_cols(stream, p->d_txt, D, mt + 5 * D, ms, St, p->g_txt, D, Mt, D));
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = G(p->g_img, D, p->wT_ff2, D, p->dh_img, 4 * D, (int)Mi, 4 * D, D);
+    g2[0].epilogue = ST355_EPI_MUL_GELU_GRAD; g2[0].aux_in = p->hpre_img; g2[0].ld_aux_in = 4 * D;
+    g2[1] = G(p->g_txt, D, p->wT_ffc2, D, p->dh_txt, 4 * D, (int)Mt, 4 * D, D);
+    g2[1].epilogue = ST355_EPI_MUL_GELU_GRAD; g2[1].aux_in = p->hpre_txt; g2[1].ld_aux_in = 4 * D;
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = G(p->dh_img, 4 * D, p->wT_ff1, 4 * D, p->dn2_img, D, (int)Mi, D, 4 * D);
+    g2[1] = G(p->dh_txt, 4 * D, p->wT_ffc1, 4 * D, p->dn2_txt, D, (int)Mt, D, 4 * D);
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn2_img, D, p->x1_img, D, mi + 4 * D, ms, Si, p->d_img, D, mi + 2 * D, ms, p->dx1_img, D, p->dx1g_img, D, Mi, D, 1e-6f));
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn2_txt, D, p->x1_txt, D, mt + 4 * D, ms, St, p->d_txt, D, mt + 2 * D, ms, p->dx1_txt, D, p->dx1g_txt, D, Mt, D, 1e-6f));
+  // ---- attention output projections -> dO rows of both streams (+ the to_out.0 adapter gradients) ----
+  if (p->K2_out) {
+    st355_gemm_args u = G(p->dx1g_img, D, p->Bbt_out, D, p->U_out, p->K2_out, (int)Mi, p->K2_out, D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = GS(B, Si, compact_rows(p->dx1g_img, D), p->wT_out, D, joint_rows(p->dO, D, St, S), D, D);
+    ext(g2[0], B, compact_rows(p->U_out, p->K2_out), p->At_out, p->K2_out, p->k2r_out);
+    g2[1] = GS(B, St, compact_rows(p->dx1g_txt, D), p->wT_add_out, D, joint_rows(p->dO, D, 0, S), D, D);
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (p->K2_out && q.ok())
+    lora_grads(q, B, Si, compact_rows(p->dx1g_img, D), D, joint_rows(p->O, D, St, S), D, p->T_o, p->U_out, p->K2_out, 1, p->rank_out, p->rpad_out, p->scale_out,
+               p->gA_out, p->gB_out, p->accumulate, p->skinny_ws);
+  // ---- attention (+ RoPE / RMSNorm backward in its epilogues): text positions < St carry the norm_added weights ----
+  if (q.ok())
+    q.run(st355_attn_bwd_rope(stream, p->Q, p->K, p->V, D, p->O, D, p->dO, D, (const float*)p->lse2, (const float*)p->key_bias, (const float*)p->rrms, p->norm_added_q,
+                              p->norm_added_k, p->norm_q, p->norm_k, St, (const float*)p->cos_p, (const float*)p->sin_p, p->dqkv, 3 * D, B, H, S, S, 128, p->scale, p->attn_ws));
+  // ---- input projections: the two streams' rows of the joint dqkv, in place ----
+  const Rows dq_i = joint_rows(p->dqkv, 3 * D, St, S), dq_t = joint_rows(p->dqkv, 3 * D, 0, S);
+  if (p->K2_qkv) {
+    st355_gemm_args u = GS(B, Si, dq_i, p->Bbt_qkv, 3 * D, compact_rows(p->U_qkv, p->K2_qkv), p->K2_qkv, 3 * D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  if (q.ok()) {
+    st355_gemm_args g2[2];
+    g2[0] = GS(B, Si, dq_i, p->wT_qkv, 3 * D, compact_rows(p->dn_img, D), D, 3 * D);
+    ext(g2[0], B, compact_rows(p->U_qkv, p->K2_qkv), p->At_qkv, p->K2_qkv, p->k2r_qkv);
+    g2[1] = GS(B, St, dq_t, p->wT_add_qkv, 3 * D, compact_rows(p->dn_txt, D), D, 3 * D);
+    q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (p->K2_qkv && q.ok())
+    lora_grads(q, B, Si, dq_i, D, compact_rows(p->n_img, D), D, p->T_img, p->U_qkv, p->K2_qkv, 3, p->rank_qkv, p->rpad_qkv, p->scale_qkv, p->gA_qkv, p->gB_qkv,
+               p->accumulate, p->skinny_ws);
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn_img, D, p->img, D, mi + D, ms, Si, p->dx1_img, D, nullptr, 0, p->d_img_out, D, nullptr, D, Mi, D, 1e-6f));
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn_txt, D, p->txt, D, mt + D, ms, St, p->dx1_txt, D, nullptr, 0, p->d_txt_out, D, nullptr, D, Mt, D, 1e-6f));
+  return q.rc;
+}

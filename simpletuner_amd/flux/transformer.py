@@ -484,6 +484,40 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, Sp, mod, cos, sin = env.B, env.Si, env.St, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.double[bi]
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
+        if (fused and _BLOCK_ABI and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
+            # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
+            # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
+            mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
+            lq, lo_ = blk.qkv.lora, blk.to_out.lora
+            n_img, n_txt = mk(B * Si, D), mk(B * St, D)
+            T_img = mk(B * Si, lq.K2) if lq is not None else None
+            last_blk = bi == len(self.double) - 1
+            Q = torch.empty(B, H, S, hd, dtype=BF16, device=dev); K = torch.empty_like(Q); Vt = torch.empty(B, H, hd, S, dtype=BF16, device=dev)
+            V, O = mk(B * S, D), mk(B * S, D)
+            rrms = torch.empty(B * S, 2 * H, dtype=F32, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
+            x1_img, x1_txt = mk(B * Si, D), mk(B * St, D)
+            hpre_img, hpre_txt = mk(B * Si, 4 * D), mk(B * St, 4 * D)
+            T_o = mk(B * Si, lo_.K2) if lo_ is not None else None
+            x = mk(B * S, D) if last_blk else None
+            x2_img, x2_txt = (None, None) if last_blk else (mk(B * Si, D), mk(B * St, D))
+            ops.block_flux_double_fwd(B=B, Si=Si, St=St, H=H, D=D, K2_qkv=lq.K2 if lq is not None else 0, k2r_qkv=lq.k2_real if lq is not None else 0,
+                                      K2_out=lo_.K2 if lo_ is not None else 0, k2r_out=lo_.k2_real if lo_ is not None else 0, scale=env.scale, img=img, txt=txt,
+                                      mod_img=mi, mod_txt=mt, mod_stride=mod.stride(0), w_qkv=blk.qkv.w, b_qkv=blk.qkv.b, w_add_qkv=blk.add_qkv.w, b_add_qkv=blk.add_qkv.b,
+                                      A_qkv=lq.A_cat if lq is not None else None, Bb_qkv=lq.B_blk if lq is not None else None,
+                                      A_out=lo_.A_cat if lo_ is not None else None, Bb_out=lo_.B_blk if lo_ is not None else None,
+                                      norm_q=blk.norm_q, norm_k=blk.norm_k, norm_added_q=blk.norm_added_q, norm_added_k=blk.norm_added_k,
+                                      w_out=blk.to_out.w, b_out=blk.to_out.b, w_add_out=blk.to_add_out.w, b_add_out=blk.to_add_out.b,
+                                      w_ff1=blk.ff1.w, b_ff1=blk.ff1.b, w_ff2=blk.ff2.w, b_ff2=blk.ff2.b, w_ffc1=blk.ffc1.w, b_ffc1=blk.ffc1.b, w_ffc2=blk.ffc2.w, b_ffc2=blk.ffc2.b,
+                                      cos_p=env.cos_p, sin_p=env.sin_p, key_bias=env.key_bias, n_img=n_img, n_txt=n_txt, V=V, rrms=rrms, Q=Q, K=K, O=O, lse2=lse2,
+                                      x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_o=T_o, Vt=Vt,
+                                      n2_img=mk(B * Si, D), n2_txt=mk(B * St, D), h_img=mk(B * Si, 4 * D), h_txt=mk(B * St, 4 * D),
+                                      out_img=x2_img, out_txt=x2_txt, out_joint=x)
+            sv = None
+            if save:
+                sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=None, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, x1_img=x1_img,
+                                     x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=None, T_o=T_o, T_ao=None)
+            return x2_img, x2_txt, x, sv
         n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
         n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
         T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
@@ -491,7 +525,6 @@ class FluxTransformer2DModel(nn.Module):
         kw_t = dict(a2=T_txt, b2=blk.add_qkv.lora.B_blk, k2_real=blk.add_qkv.lora.k2_real) if T_txt is not None else {}
         kw_i = dict(a2=T_img, b2=blk.qkv.lora.B_blk, k2_real=blk.qkv.lora.k2_real) if T_img is not None else {}
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
-        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
         qkv = V = rrms = Qt = Kt = None
         if fused:
             # RMSNorm(q), RMSNorm(k), RoPE and the head-major re-layout ride in the projection's epilogue: q / k leave the GEMM as the roped head-major
@@ -827,6 +860,36 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.double[li]
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        if (_BLOCK_ABI and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
+                and Si % 256 == 0 and St % 256 == 0 and d_img.is_contiguous() and d_txt.is_contiguous()):
+            # ONE C entry point (st355_block_flux_double_bwd): the launches of the host-side sequencing below, in its order, on its operands
+            lq, lo_ = blk.qkv.lora, blk.to_out.lora
+            mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
+            d_img_out, d_txt_out = mk(B * Si, D), mk(B * St, D)
+            ops.block_flux_double_bwd(
+                {"gA_qkv": list(lq.gA) if lq is not None else None, "gB_qkv": list(lq.gB) if lq is not None else None,
+                 "gA_out": list(lo_.gA) if lo_ is not None else None, "gB_out": list(lo_.gB) if lo_ is not None else None},
+                B=B, Si=Si, St=St, H=H, D=D, K2_qkv=lq.K2 if lq is not None else 0, k2r_qkv=lq.k2_real if lq is not None else 0,
+                K2_out=lo_.K2 if lo_ is not None else 0, k2r_out=lo_.k2_real if lo_ is not None else 0,
+                rank_qkv=lq.rank if lq is not None else 0, rpad_qkv=lq.r_pad if lq is not None else 0, rank_out=lo_.rank if lo_ is not None else 0,
+                rpad_out=lo_.r_pad if lo_ is not None else 0, accumulate=1 if self.accumulate_lora_grads else 0, scale=env.scale,
+                scale_qkv=lq.scale if lq is not None else 0.0, scale_out=lo_.scale if lo_ is not None else 0.0,
+                img=sv.img, txt=sv.txt, n_img=sv.n_img, V=sv.V, rrms=sv.rrms, Q=sv.Q, K=sv.K, O=sv.O, lse2=sv.lse2, x1_img=sv.x1_img, x1_txt=sv.x1_txt,
+                hpre_img=sv.hpre_img, hpre_txt=sv.hpre_txt, T_img=sv.T_img, T_o=sv.T_o, mod_img=mi, mod_txt=mt, mod_stride=mod.stride(0),
+                wT_qkv=blk.qkv.wT, wT_add_qkv=blk.add_qkv.wT, wT_out=blk.to_out.wT, wT_add_out=blk.to_add_out.wT, wT_ff1=blk.ff1.wT, wT_ff2=blk.ff2.wT,
+                wT_ffc1=blk.ffc1.wT, wT_ffc2=blk.ffc2.wT, At_qkv=lq.A_cat_T if lq is not None else None, Bbt_qkv=lq.B_blk_T if lq is not None else None,
+                At_out=lo_.A_cat_T if lo_ is not None else None, Bbt_out=lo_.B_blk_T if lo_ is not None else None,
+                norm_q=blk.norm_q, norm_k=blk.norm_k, norm_added_q=blk.norm_added_q, norm_added_k=blk.norm_added_k, cos_p=env.cos_p, sin_p=env.sin_p,
+                key_bias=env.key_bias, d_img=d_img, d_txt=d_txt,
+                g_img=mk(B * Si, D), g_txt=mk(B * St, D), dh_img=mk(B * Si, 4 * D), dh_txt=mk(B * St, 4 * D), dn2_img=mk(B * Si, D), dn2_txt=mk(B * St, D),
+                dx1_img=mk(B * Si, D), dx1g_img=mk(B * Si, D), dx1_txt=mk(B * St, D), dx1g_txt=mk(B * St, D), dO=mk(B * S, D), dqkv=mk(B * S, 3 * D),
+                U_qkv=mk(B * Si, lq.K2) if lq is not None else None, U_out=mk(B * Si, lo_.K2) if lo_ is not None else None,
+                dn_img=mk(B * Si, D), dn_txt=mk(B * St, D), d_img_out=d_img_out, d_txt_out=d_txt_out)
+            if self.grad_sync is not None:                     # the host-side order: to_out.0's adapters first, then to_q / to_k / to_v's
+                for lg in (lo_, lq):
+                    if lg is not None:
+                        self.grad_sync.ready(lg.flat_lo, lg.flat_hi)
+            return d_img_out, d_txt_out
         g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
         dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
                                        dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])

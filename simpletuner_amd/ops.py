@@ -946,6 +946,38 @@ def block_flux_single_fwd(**kw):
     _l.check(L.st355_block_flux_single_fwd(_stream(), C.byref(a)), "block_flux_single_fwd")
 
 
+def block_flux_double_fwd(**kw):
+    """st355_block_flux_double_fwd: one FluxTransformerBlock forward as ONE C call (field names of st355_flux_double_fwd_args)"""
+    L = _l.load()
+    ws = _gemm_workspace(kw["img"].device)
+    a = _fill(_l.FluxDoubleFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
+    _l.check(L.st355_block_flux_double_fwd(_stream(), C.byref(a)), "block_flux_double_fwd")
+
+
+def block_flux_double_bwd(grads, **kw):
+    """st355_block_flux_double_bwd (field names of st355_flux_double_bwd_args); grads: {"gA_qkv": [...], "gB_qkv": [...], "gA_out": [...], "gB_out": [...]}"""
+    L = _l.load()
+    dev = kw["img"].device
+    B, S, H, D = kw["B"], kw["Si"] + kw["St"], kw["H"], kw["D"]
+    ws = _gemm_workspace(dev)
+    need = L.st355_attn_bwd_workspace(B, H, S, S, 128)
+    aws = _attn_ws.get((dev.index,))
+    if aws is None or aws.numel() < need:
+        aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
+    sws = None
+    if kw.get("K2_qkv") or kw.get("K2_out"):
+        need = L.st355_skinny_tn_workspace(B * kw["Si"], D, 128)
+        sws = _skinny_ws.get((dev.index,))
+        if sws is None or sws.numel() * 4 < need:
+            sws = _skinny_ws[(dev.index,)] = torch.empty((need + 3) // 4, dtype=F32, device=dev)
+    a = _fill(_l.FluxDoubleBwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, attn_ws=aws, skinny_ws=sws, **kw)
+    for name, ts in (grads or {}).items():
+        arr = getattr(a, name)
+        for i, t in enumerate(ts or []):
+            _chk(t, F32, name); arr[i] = t.data_ptr()
+    _l.check(L.st355_block_flux_double_bwd(_stream(), C.byref(a)), "block_flux_double_bwd")
+
+
 def block_flux_single_bwd(gA, gB, **kw):
     """st355_block_flux_single_bwd (field names of st355_flux_single_bwd_args); gA / gB: lists of the adapters' fp32 gradient views"""
     L = _l.load()

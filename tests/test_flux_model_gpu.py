@@ -261,12 +261,13 @@ def test_flux_tread_routing_matches_oracle(start, end, ckpt):
         assert torch.equal(pred, pred_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
 
 
-@pytest.mark.parametrize("layers,single,masked", [(1, 3, False), (0, 2, False), (1, 2, True)])
-def test_flux_single_block_c_entry_points_equal_host_sequencing(layers, single, masked, monkeypatch):
-    """st355_block_flux_single_fwd / _bwd (one FluxSingleTransformerBlock forward / backward as ONE C call) issue the same launches in the
-    same order on the same operands as sequencing the per-kernel entry points from the host: prediction, loss and every adapter gradient bit-identical.
-    Tile-aligned streams (256 image + 256 text tokens per sample) = the production form the entry points are built for; (0, 2): no double blocks, so single
-    block 0 runs through the C backward too (no previous gate); masked: the key-bias variants."""
+@pytest.mark.parametrize("layers,single,masked", [(1, 3, False), (0, 2, False), (1, 2, True), (3, 2, False), (3, 0, True)])
+def test_flux_block_c_entry_points_equal_host_sequencing(layers, single, masked, monkeypatch):
+    """st355_block_flux_single_fwd / _bwd and st355_block_flux_double_fwd / _bwd (one transformer block forward / backward as ONE C call) issue
+    the same launches in the same order on the same operands as sequencing the per-kernel entry points from the host: prediction, loss and every adapter
+    gradient bit-identical.  Tile-aligned streams (256 image + 256 text tokens per sample, B = 2: segmented-row operands over the joint buffers) = the production
+    form the entry points are built for; (0, 2): no double blocks, so single block 0 runs through the C backward too (no previous gate); (3, *): double blocks
+    1 and 2 through the C backward (block 0 keeps the host's frozen-embedder case), the last one writing the joint sequence in place; masked: the key-bias variants."""
     import simpletuner_amd.flux.transformer as FT
 
     def run(block_abi):
@@ -291,4 +292,4 @@ def test_flux_single_block_c_entry_points_equal_host_sequencing(layers, single, 
     p1, l1, g1 = run(True)
     assert torch.equal(p0, p1) and torch.equal(l0, l1)
     assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0)
-    assert any(".single_transformer_blocks." in k or k.startswith("single_transformer_blocks.") for k in g0)
+    assert len(g0) > 0
