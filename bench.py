@@ -148,7 +148,7 @@ def cpu_baseline(args, dev=None):
 
     from oracle import flux as OF
 
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("ST355_CPU_LEG_THREADS", "0")) or (os.cpu_count() or 1)      # `cores` of the JSON = the intra-op threads actually used
     torch.set_num_threads(cores)
     ND, NS = (int(v) for v in os.environ.get("ST355_CPU_LEG_BLOCKS", "1,1").split(","))
     cfg = OF.FluxConfig(num_layers=ND, num_single_layers=NS)
@@ -177,6 +177,16 @@ def cpu_baseline(args, dev=None):
     opt = torch.optim.AdamW(d_par + s_par, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
     # embedders + tail are a few GFLOP: outside the timed block regions
     temb = OF.time_text_embed(P, cfg, tstep * 1000, guidance * 1000, pooled).detach()
+
+    def adamw_step():
+        """torch.optim.AdamW over the 1.4 M adapter parameters: a handful of tiny element-wise passes, run on 16 threads — with all 256 host cores every pass
+        pays a 256-way fork / join and one step costs 13 s (measured r3), which no CPU trainer would do"""
+        torch.set_num_threads(min(cores, 16))
+        t0 = time.time()
+        opt.step()
+        dt = time.time() - t0
+        torch.set_num_threads(cores)
+        return dt
 
     def one_pass(n_img, step):
         """forward / backward over all blocks on the first n_img image tokens (n_img = S_img: the full shape)"""
@@ -209,14 +219,15 @@ def cpu_baseline(args, dev=None):
         if step:
             for t_, g_ in zip(s_par + d_par, list(gs[1:]) + list(gd[2:])):
                 t_.grad = g_
-            t0 = time.time()
-            opt.step()
-            t_opt = time.time() - t0
+            t_opt = adamw_step()
         return (t_fd + t_bd, t_fs + t_bs, t_opt), pred.detach(), (gs[1:], gd[2:])
 
     _log("cpu_baseline: warm-up pass (256 image tokens)")
-    one_pass(256, True)                                                     # warm-up, untimed (also creates the AdamW state: the timed steps are steady-state steps)
-    with torch.no_grad():                                                   # ... and back to the initial adapters: the first timed pass is the one the device is compared with
+    one_pass(256, False)                                                    # warm-up, untimed
+    for t_ in s_par + d_par:                                                # ... and one optimizer step on zero gradients: creates the AdamW state, so the timed steps are
+        t_.grad = torch.zeros_like(t_)                                      # steady-state steps; then back to the initial adapters (the first timed pass is the one the
+    adamw_step()                                                            # device is compared with)
+    with torch.no_grad():
         for k, (a, b) in lora.items():
             a.copy_(lora0[k][0]); b.copy_(lora0[k][1])
     # the first timed pass runs from the initial adapters and is the one the device is compared with; AdamW moves the adapters after each pass
@@ -242,7 +253,7 @@ def cpu_baseline(args, dev=None):
         "sample": f"oracle (plain torch fp32, autograd, torch.optim.AdamW) {ND} double + {NS} single Flux blocks fwd+bwd+optimizer at D=3072, S={S_img}+{S_txt}, "
                   f"B=1, LoRA r{r} ({n_adapter_sample / 1e6:.1f} M adapter parameters): 1 warm-up pass at a short sequence, median of {len(times)} timed pass(es) "
                   f"(bounded at {CPU_LEG_BUDGET_S:.0f} s of wall clock) = {t_double:.2f} s per double block, {t_single:.2f} s per single block, extrapolated "
-                  f"x{args.layers}/x{args.single_layers} blocks + AdamW {t_opt * 1e3:.0f} ms = {step_s:.0f} s/step (per-pass block seconds: {[round(t[0] + t[1], 1) for t in times]})",
+                  f"x{args.layers}/x{args.single_layers} blocks + AdamW (16 threads) {t_opt * 1e3:.0f} ms = {step_s:.0f} s/step (per-pass block seconds: {[round(t[0] + t[1], 1) for t in times]})",
     }
     parity = None
     if dev is not None:
