@@ -148,7 +148,10 @@ def cpu_baseline(args, dev=None):
 
     from oracle import flux as OF
 
-    cores = int(os.environ.get("ST355_CPU_LEG_THREADS", "0")) or (os.cpu_count() or 1)      # `cores` of the JSON = the intra-op threads actually used
+    # `cores` of the JSON = the intra-op threads actually used.  The GPU box shows 256 logical cpus but the container gets a fraction of them: measured r3
+    # (tools/probes/cpu_threads_probe.py, profiles/r03_cpu_threads_probe.log) an fp32 4608 x 3072 x 12288 linear runs at 1.51 / 1.68 / 1.30 / 0.95 / 0.47 TFLOP/s on
+    # 16 / 32 / 64 / 128 / 256 threads — 32 threads is the fastest this host gets, 256 is 3.6x slower
+    cores = int(os.environ.get("ST355_CPU_LEG_THREADS", "0")) or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     ND, NS = (int(v) for v in os.environ.get("ST355_CPU_LEG_BLOCKS", "1,1").split(","))
     cfg = OF.FluxConfig(num_layers=ND, num_single_layers=NS)
@@ -179,8 +182,8 @@ def cpu_baseline(args, dev=None):
     temb = OF.time_text_embed(P, cfg, tstep * 1000, guidance * 1000, pooled).detach()
 
     def adamw_step():
-        """torch.optim.AdamW over the 1.4 M adapter parameters: a handful of tiny element-wise passes, run on 16 threads — with all 256 host cores every pass
-        pays a 256-way fork / join and one step costs 13 s (measured r3), which no CPU trainer would do"""
+        """torch.optim.AdamW over the 1.4 M adapter parameters: a handful of tiny element-wise passes, run on 16 threads (with 256 threads every pass paid a
+        256-way fork / join: 13 s per step, measured r3)"""
         torch.set_num_threads(min(cores, 16))
         t0 = time.time()
         opt.step()
@@ -296,7 +299,7 @@ def cpu_baseline_unet(args, sd15: bool, lora: bool):
     to_q, to_k, to_v, to_out.0, applied as merged weights W + (alpha/r) B A with autograd through the merge (adapter gradients only)."""
     from oracle.unet import UNetConfig, init_params, unet_forward
 
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("ST355_CPU_LEG_THREADS", "0")) or min(os.cpu_count() or 1, 32)          # see cpu_baseline: 32 threads is this host's fastest
     torch.set_num_threads(cores)
     cfg = UNetConfig.sd15() if sd15 else UNetConfig()
     P = init_params(cfg, seed=1)
