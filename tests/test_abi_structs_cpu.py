@@ -1,0 +1,44 @@
+"""The ctypes mirrors of the C-ABI argument structs (simpletuner_amd/lib.py) against the header itself: include/st355.h is compiled with the host C compiler and
+sizeof / offsetof of every field are compared with the ctypes layout — a field added on one side only, or in another order, fails here instead of corrupting
+pointers on the GPU box."""
+import ctypes as C
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+from simpletuner_amd import lib
+
+ROOT = Path(__file__).resolve().parent.parent
+PAIRS = [("st355_gemm_args", lib.GemmArgs), ("st355_qk_rope", lib.QkRope), ("st355_vae_encoder", lib.VaeEncoder),
+         ("st355_flux_single_fwd_args", lib.FluxSingleFwdArgs), ("st355_flux_single_bwd_args", lib.FluxSingleBwdArgs),
+         ("st355_flux_double_fwd_args", lib.FluxDoubleFwdArgs), ("st355_flux_double_bwd_args", lib.FluxDoubleBwdArgs)]
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no host C compiler")
+def test_ctypes_structs_match_the_header(tmp_path):
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "st355.h"', "int main(void) {"]
+    for cname, py in PAIRS:
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in py._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c11", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)     # a missing / renamed field fails to compile
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, py in PAIRS:
+        assert got[(cname, "sizeof")] == C.sizeof(py), (cname, got[(cname, "sizeof")], C.sizeof(py))
+        for fname, _ in py._fields_:
+            assert got[(cname, fname)] == getattr(py, fname).offset, (cname, fname, got[(cname, fname)], getattr(py, fname).offset)
+    # and the other direction: the header declares no field the mirror lacks (same size + every mirrored field at its offset + equal field counts)
+    hdr = (ROOT / "include" / "st355.h").read_text()
+    for cname, py in PAIRS:
+        body = hdr[hdr.index(f"typedef struct {cname} {{"):hdr.index(f"}} {cname};")]
+        assert all(fname in body for fname, _ in py._fields_), cname
