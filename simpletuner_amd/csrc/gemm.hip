@@ -1612,7 +1612,8 @@ static int gemm_impl_choice() {
 // the 256x256 schedules run one workgroup per CU: only worth it when the tiles (nearly) fill the 256 CUs
 static int min_tiles_256() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("ST355_GEMM_MIN_TILES"); v = e ? atoi(e) : 200; }
+  // measured r3 (same box, SDXL-LoRA batch 4 graph / SD3 full fine-tune): 200 -> 128 tiles: 162.9 -> 160.0 ms and 337.0 -> 336.0 ms; 64: 164.6 / 336.2
+  if (v < 0) { const char* e = getenv("ST355_GEMM_MIN_TILES"); v = e ? atoi(e) : 128; }
   return v;
 }
 
