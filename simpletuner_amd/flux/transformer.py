@@ -33,7 +33,12 @@ F32 = torch.float32
 _FUSED_QKV = __import__("os").environ.get("ST355_FUSED_QKV", "1") != "0"      # A/B switch: 0 = separate RMSNorm + RoPE pass after the QKV projection
 _FUSED_ROPE_BWD = __import__("os").environ.get("ST355_FUSED_ROPE_BWD", "1") != "0"   # A/B switch: 0 = RoPE / RMSNorm backward as its own pass after the attention backward
 _FUSED_VT = __import__("os").environ.get("ST355_FUSED_VT", "1") != "0"        # A/B switch: 0 = no V^T from the fused epilogue, forward attention reads row-major V
-_BLOCK_ABI = __import__("os").environ.get("ST355_BLOCK_ABI", "1") != "0"          # A/B switch: 0 = sequence the single blocks' kernels from the host instead of st355_block_flux_single_*
+_BLOCK_ABI = __import__("os").environ.get("ST355_BLOCK_ABI", "1") != "0"          # A/B switch: 0 = sequence the blocks' kernels from the host instead of st355_block_flux_*
+_BLOCK_ABI_ONLY = __import__("os").environ.get("ST355_BLOCK_ABI_ONLY", "")           # debugging aid: "single" / "double" / "fwd" / "bwd" restricts the C entry points to that subset
+
+
+def _block_abi_ok() -> bool:
+    return _BLOCK_ABI
 _TRANSPOSED_COPIES = __import__("os").environ.get("ST355_ATTN_BWD_T") == "1"      # A/B switch: keep the pre-transposed Q^T / K^T copies (dkv2 / dq kernels) at head_dim 128
 
 
@@ -485,7 +490,7 @@ class FluxTransformer2DModel(nn.Module):
         blk = self.double[bi]
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
         fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
-        if (fused and _BLOCK_ABI and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
+        if (fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
             # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
             # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
             mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
@@ -601,7 +606,7 @@ class FluxTransformer2DModel(nn.Module):
         blk = self.single[bi]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
         fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
-        if fused and _BLOCK_ABI and _FUSED_VT and x.is_contiguous():
+        if fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
             # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
             # as the host-side sequencing below
             lo = blk.qkv.lora
@@ -808,7 +813,7 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.single[li]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
-        if (_BLOCK_ABI and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
+        if (_block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
                 and dx.is_contiguous() and (dxg is None or dxg.is_contiguous())):
             # ONE C entry point (st355_block_flux_single_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lo = blk.qkv.lora
@@ -860,7 +865,7 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.double[li]
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-        if (_BLOCK_ABI and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
+        if (_block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
                 and Si % 256 == 0 and St % 256 == 0 and d_img.is_contiguous() and d_txt.is_contiguous()):
             # ONE C entry point (st355_block_flux_double_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lq, lo_ = blk.qkv.lora, blk.to_out.lora

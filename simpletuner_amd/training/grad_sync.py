@@ -106,9 +106,11 @@ class GradSync:
     def _comm_ctx(self):
         if self.comm_stream is None:
             return contextlib.nullcontext()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.flat.device))       # the gradient bytes of this slice are final at this point of the backward
-        self.comm_stream.wait_event(ev)
+        # the gradient bytes of this slice are final at this point of the backward: the comm stream waits for the compute stream's work enqueued so far.
+        # wait_stream, NOT a temporary torch.cuda.Event + wait_event: the Python event died at the end of this function while the wait was still queued, and
+        # once the host ran far enough ahead of the device (the block-level C entry points: fewer host calls per block) the comm stream's barrier referenced a
+        # destroyed signal — a GPU memory-access fault in the first step of every 2-rank run (r3: 7 of 7 runs; 0 of 6 with this form; gpurun_out/dbg_n2_*)
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
         self._comm_used = True
         return torch.cuda.stream(self.comm_stream)
 
@@ -236,9 +238,7 @@ class GradSync:
             with torch.cuda.stream(self.comm_stream):
                 for w in self._works:
                     w.wait()
-            done = torch.cuda.Event()
-            done.record(self.comm_stream)
-            torch.cuda.current_stream(self.flat.device).wait_event(done)       # the optimizer (compute stream) starts after the last collective
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)       # the optimizer (compute stream) starts after the last collective
         else:
             for w in self._works:
                 w.wait()

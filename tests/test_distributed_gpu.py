@@ -1,6 +1,7 @@
 """Replica start state with DEVICE storages (two processes sharing cuda:0 over gloo — a 1-GPU box cannot run RCCL between two ranks; the RCCL
 path is the same code with backend "nccl"): sync_module_states broadcasts the raw bytes of every distinct storage behind the module, including
 bytes that belong to no registered parameter (arena padding / fused LoRA columns)."""
+import math
 import os
 import tempfile
 
@@ -294,3 +295,48 @@ def test_hip_graph_with_two_ranks_and_the_ddp_seam_on_a_real_component():
             rel = ((r0[how][k] - ref[k]).norm() / ref[k].norm()).item()
             print(f"[r03] flux under {how}: {k} gradient vs single process: rel-L2 {rel:.3e}")
             assert rel < 2e-5, (how, k, rel)
+
+
+# ---- r3: the gradient exchange behind a host that runs far ahead of the device (block-level C entry points; tile-aligned streams) ----
+def _aligned_flux_run(rank, world):
+    from tests import parity_utils as PU
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+    dev = torch.device("cuda", 0)
+    cfg = default_config(model_family="flux", model_type="lora", lora_rank=8, train_batch_size=2, seed=3, lora_init_b_std=0.02, learning_rate=_LR, use_ema=False)
+    acc = St355Accelerator(dev)
+    plugin = Flux(cfg, acc)
+    plugin.load_model(**PU.small_flux_cfg(layers=3, single=6))
+    plugin.add_lora_adapter()
+    trainer = Trainer(cfg, plugin, acc)
+    comp = plugin.get_trained_component()
+    assert comp.grad_sync is not None and comp.grad_sync.comm_stream is not None
+    _, devt = PU.make_inputs(4, 32, 32, 256, 128, 64, dev, seed=12)           # 256 image + 256 text tokens per sample: the fused / block-entry-point form
+    sl = slice(rank * 2, rank * 2 + 2)
+    sig = devt["sigmas"][sl].contiguous()
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    batch = lambda: {"latent_batch": devt["latents"][sl].contiguous(), "prompt_embeds": devt["prompt"][sl].contiguous(),
+                     "add_text_embeds": devt["pooled"][sl].contiguous(), "noise": devt["noise"][sl].contiguous()}
+    losses = [float(trainer.train_step(batch())) for _ in range(6)]
+    torch.cuda.synchronize()
+    return torch.cat([p.detach().reshape(-1).float() for p in trainer.params]).cpu(), losses, sorted({k for k, _, _ in comp.grad_sync.launched_ops})
+
+
+def _aligned_worker(rank, world, init_file, out_dir):
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.save(_aligned_flux_run(rank, world), os.path.join(out_dir, f"al{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_block_entry_points_and_the_comm_stream_hand_over():
+    """Regression (r3): with the Flux blocks going through the C entry points the host runs far ahead of the device; the compute -> comm stream hand-over of every
+    gradient slice then must not depend on a Python event object that dies while the wait is still queued (GradSync._comm_ctx: `wait_stream`).  The old form
+    (temporary torch.cuda.Event + wait_event) ended every such 2-rank run in a GPU memory-access fault inside the first step.  Here: two ranks on the device over
+    gloo, tile-aligned streams, 3 double + 6 single blocks, six steps — the run completes, the exchange happened, the replicas stay identical."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_aligned_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        (w0, l0, ops0), (w1, l1, ops1) = (torch.load(os.path.join(d, f"al{r}.pt")) for r in range(2))
+    assert ops0 == ops1 == ["all_reduce"]
+    assert torch.equal(w0, w1)                                                     # identical reduced gradients -> identical adapters on both ranks
+    assert all(math.isfinite(x) for x in l0 + l1) and l0[-1] < l0[0]
