@@ -77,12 +77,22 @@ __global__ void __launch_bounds__(256) k_fp8_quant_weight(const bf16* __restrict
 __global__ void __launch_bounds__(256) k_absmax(const bf16* __restrict__ x, int64_t ldx, int64_t M, int K, uint32_t* __restrict__ amax_bits) {
   float m = 0.f;
   const int64_t nv = M * (K / 8);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / (K / 8);
-    const int c = (int)(i % (K / 8)) * 8;
-    const bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+  if (ldx == K) {                                            // dense rows (every caller today): one linear 16-byte stream, no per-element index division
+    const bf16x8* xv = (const bf16x8*)x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+      const bf16x8 v = xv[i];
 #pragma unroll
-    for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v[j])));
+      for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v[j])));
+    }
+  } else {
+    const uint32_t kv = (uint32_t)(K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / kv;
+      const int c = (int)(i - r * kv) * 8;
+      const bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+#pragma unroll
+      for (int j = 0; j < 8; j++) m = fmaxf(m, fabsf(bf2f(v[j])));
+    }
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
@@ -98,10 +108,7 @@ __global__ void __launch_bounds__(256) k_fp8_quant_act(const bf16* __restrict__ 
   const float is = fminf(bf2f(f2bf(rcp * 57344.0f)), 57344.0f);
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_a[0] = bf2f(f2bf(1.0f / is));
   const int64_t nv = M * (K / 8);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / (K / 8);
-    const int c = (int)(i % (K / 8)) * 8;
-    const bf16x8 v = *(const bf16x8*)(x + r * ldx + c);
+  auto q8 = [&](const bf16x8& v) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -110,7 +117,25 @@ __global__ void __launch_bounds__(256) k_fp8_quant_act(const bf16* __restrict__ 
     }
     u32x2 o;
     o[0] = lo; o[1] = hi;
-    *(u32x2*)(q + r * K + c) = o;
+    return o;
+  };
+  if (ldx == K) {                                            // dense rows: a linear stream, 16 elements (two 16-byte loads, one 16-byte store) per thread and step
+    const bf16x8* xv = (const bf16x8*)x;
+    const int64_t np = nv / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (int64_t)gridDim.x * blockDim.x) {
+      const u32x2 a = q8(xv[2 * i]), b = q8(xv[2 * i + 1]);
+      u32x4 o;
+      o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+      *(u32x4*)(q + 16 * i) = o;
+    }
+    if ((nv & 1) && blockIdx.x == 0 && threadIdx.x == 0) *(u32x2*)(q + 8 * (nv - 1)) = q8(xv[nv - 1]);
+    return;
+  }
+  const uint32_t kv = (uint32_t)(K / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / kv;
+    const int c = (int)(i - r * kv) * 8;
+    *(u32x2*)(q + r * K + c) = q8(*(const bf16x8*)(x + r * ldx + c));
   }
 }
 
