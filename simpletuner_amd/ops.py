@@ -928,7 +928,10 @@ def upsample2x_bwd(dy, B: int, H: int, W: int):
 def _fill(st, **kw):
     """tensors -> device pointers, None -> NULL, numbers as they are"""
     keep = []
+    names = {f[0] for f in type(st)._fields_}
     for k, v in kw.items():
+        if k not in names:
+            raise _l.St355Error(f"{type(st).__name__}: no field {k!r} (include/st355.h)")
         if torch.is_tensor(v):
             _dev(v, k)
             keep.append(v)

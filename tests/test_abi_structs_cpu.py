@@ -42,3 +42,30 @@ def test_ctypes_structs_match_the_header(tmp_path):
     for cname, py in PAIRS:
         body = hdr[hdr.index(f"typedef struct {cname} {{"):hdr.index(f"}} {cname};")]
         assert all(fname in body for fname, _ in py._fields_), cname
+
+
+def test_block_entry_point_call_sites_name_every_struct_field():
+    """the Flux engine fills the block-level argument structs by keyword (ops._fill): every keyword must be a field of the struct (a typo would otherwise go
+    unnoticed on a CPU box) and every field but the workspaces the wrapper owns must be given — checked on the source, no GPU needed"""
+    import re
+    src = (ROOT / "simpletuner_amd" / "flux" / "transformer.py").read_text()
+    owned = {"gemm_ws", "gemm_ws_bytes", "attn_ws", "skinny_ws", "gA", "gB", "gA_qkv", "gB_qkv", "gA_out", "gB_out"}
+    for fn, st in (("block_flux_single_fwd", lib.FluxSingleFwdArgs), ("block_flux_double_fwd", lib.FluxDoubleFwdArgs),
+                   ("block_flux_single_bwd", lib.FluxSingleBwdArgs), ("block_flux_double_bwd", lib.FluxDoubleBwdArgs)):
+        i = src.index("ops." + fn + "(")
+        depth, j = 0, i
+        while True:
+            if src[j] == "(":
+                depth += 1
+            elif src[j] == ")":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        names = set(re.findall(r"[\(,\s]([A-Za-z_][A-Za-z0-9_]*)=", src[i:j])) - {"dtype", "device"}
+        fields = {f[0] for f in st._fields_}
+        assert names <= fields, (fn, sorted(names - fields))
+        assert fields - owned <= names, (fn, sorted(fields - owned - names))
+    with pytest.raises(Exception):
+        from simpletuner_amd import ops
+        ops._fill(lib.FluxSingleFwdArgs(), not_a_field=1)
