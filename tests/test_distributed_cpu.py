@@ -148,3 +148,58 @@ def test_two_process_reduce_scatter_all_gather_form_equals_all_reduce():
                 assert (k2, lo2, hi2) == ("all_gather", lo1, hi1) and (hi1 - lo1) % 2 == 0
         assert all(k == "all_reduce" for k, _, _ in res["allreduce"][2])
         assert res["auto_small"] == "allreduce" and res["auto_big"] == "rs_ag"
+
+
+def _worker_world4(rank, world, init_file, out_dir):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from simpletuner_amd.training.grad_sync import GradSync
+    n = 20_011                                                        # prime: slices leave 1..3-element tails for the all-reduce form
+    out = {}
+    # fp32 arena, both forms
+    for mode in ("rs_ag", "allreduce"):
+        flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        gs = GradSync(flat, bucket_bytes=4 * 3000, mode=mode)
+        gs.begin()
+        edges = list(range(n, 0, -1303)) + [0]
+        for hi, lo in zip(edges[:-1], edges[1:]):
+            gs.ready(lo, hi)
+        scale = gs.finish()                                           # (joins the async works: read the arena only after it)
+        out[mode] = (flat.clone(), scale, sorted({k for k, _, _ in gs.launched_ops}))
+    # bf16 arena: the fp32-accumulating form (all-to-all of the W chunks, fp32 sum in rank order, all-gather)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(n, generator=g).to(torch.bfloat16)
+    flat = mine.clone()
+    gs = GradSync(flat, bucket_bytes=2 * 4096, mode="rs_ag")
+    gs.begin()
+    for hi in range(n, 0, -2777):
+        gs.ready(max(0, hi - 2777), hi)
+    scale = gs.finish()
+    out["bf16"] = (flat.clone(), scale, sorted({k for k, _, _ in gs.launched_ops}), list(gs.launched_slices))
+    torch.save(out, os.path.join(out_dir, f"w4_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_four_process_gradient_exchange_all_forms():
+    """the driver's scaling run uses 2, 4 and 8 ranks: the same exchange at world 4 over gloo — both fp32 forms leave the exact SUM, the bf16 arena's
+    fp32-accumulating form (all-to-all + local fp32 sum in rank order + all-gather; a < world tail of every slice through all-reduce) leaves the sum of the four
+    ranks' values accumulated in fp32 and rounded once, identical on every rank; scale = 1/4"""
+    W = 4
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_world4, args=(W, os.path.join(d, "init"), d), nprocs=W, join=True)
+        res = [torch.load(os.path.join(d, f"w4_{r}.pt")) for r in range(W)]
+    n = 20_011
+    want = torch.arange(n, dtype=torch.float32) * (1 + 2 + 3 + 4)
+    vals = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(W)]
+    exact = (vals[0].float() + vals[1].float() + vals[2].float() + vals[3].float()).to(torch.bfloat16)
+    for r in res:
+        for mode in ("rs_ag", "allreduce"):
+            flat, scale, kinds = r[mode]
+            assert torch.equal(flat, want) and scale == 0.25, mode
+        assert "reduce_scatter" in res[0]["rs_ag"][2] and "all_gather" in res[0]["rs_ag"][2] and res[0]["allreduce"][2] == ["all_reduce"]
+        flat, scale, kinds, slices = r["bf16"]
+        assert scale == 0.25 and "all_to_all" in kinds and "all_gather" in kinds
+        assert sum(hi - lo for lo, hi in slices) == n
+        assert torch.equal(flat, res[0]["bf16"][0])                                   # every rank holds the same reduced arena
+        # the rs_ag part is the exactly-rounded fp32 sum; the < world tails went through a bf16 all-reduce (pairwise bf16 adds): compare those loosely
+        diff = (flat.float() - exact.float()).abs()
+        assert (diff == 0).float().mean().item() > 0.99 and diff.max().item() <= 0.0625 * exact.float().abs().max().item()
