@@ -511,7 +511,7 @@ def run_workload(args, dev, rank, world):
 
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42, lora_init_b_std=1e-3,   # weights / adapter init / rounding seeds are REPLICA-identical; the data RNG below is per rank
                         
-                         model_type="full" if args.full else "lora", use_ema=bool(args.full), optimizer=args.optimizer,
+                         model_type="full" if args.full else "lora", use_ema=bool(args.full) and args.model != "flux", optimizer=args.optimizer,
                          learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph),
                          gradient_checkpointing=bool(getattr(args, "gradient_checkpointing", False)),
                          gradient_checkpointing_interval=getattr(args, "ckpt_interval", None), gradient_checkpointing_segment_stride=getattr(args, "ckpt_stride", None))
@@ -584,10 +584,11 @@ def run_workload(args, dev, rank, world):
     if args.model == "pixart":
         pass
     elif args.full:
-        if args.model not in ("sd3", "sdxl", "sd15"):
-            raise SystemExit("--full is wired for --model sd3 / sdxl only")
+        if args.model not in ("sd3", "sdxl", "sd15", "flux"):
+            raise SystemExit("--full is wired for --model flux / sd3 / sdxl / sd15")
         plugin.enable_full_finetune()
-        desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", "FULL fine-tune (2.0 B bf16 params) + EMA")
+        n_par = sum(p.numel() for p in plugin.get_trained_component().trainable_parameters())
+        desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", f"FULL-rank training ({n_par / 1e9:.1f} B bf16 params){' + EMA' if cfg.use_ema else ''}")
     elif args.model != "pixart":
         plugin.add_lora_adapter()
     trainer = Trainer(cfg, plugin, acc)

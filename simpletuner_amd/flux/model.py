@@ -88,7 +88,7 @@ class Flux(ModelFoundation):
     def add_lora_adapter(self):
         """common.py:1049-1128"""
         if getattr(self.config, "model_type", "lora") != "lora":
-            raise NotImplementedError("full-rank Flux training is not wired yet (round 2: wgrad GEMM)")
+            raise RuntimeError("model_type == 'full' trains every transformer parameter: call enable_full_finetune() instead of add_lora_adapter()")
         targets = self._lora_target_set()
         params = self.unwrap_model(self.model).add_lora_adapter(rank=int(self.config.lora_rank),
                                                                 alpha=getattr(self.config, "lora_alpha", None), targets=targets,
@@ -96,6 +96,11 @@ class Flux(ModelFoundation):
                                                                 init_b_std=float(getattr(self.config, "lora_init_b_std", 0.0)))
         self.unwrap_model(self.model).prepare_for_training()
         return params
+
+    def enable_full_finetune(self):
+        """model_type == "full" — the reference's multi-GPU Flux datapoint (documentation/DISTRIBUTED.md:291-298) trains the whole 12 B-parameter transformer:
+        every weight, bias, q / k RMSNorm weight and modulation row (bf16 parameters + bf16 gradients in two arenas of one layout)"""
+        return self.unwrap_model(self.model).enable_full_finetune()
 
     # flux/model.py:1235-1380: `flux_lora_target` names a set of wrapped Linears.  Built here: the attention projections — "all" (image + context
     # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default) and the fall-through DEFAULT_LORA_TARGET (image stream and single

@@ -14,7 +14,9 @@ Storage layout (designed for 288 GB HBM, not for a 24 GB card):
     is ONE skinny GEMM on SiLU(temb) instead of 115 launches;
   * frozen-base (LoRA) training keeps a K-major transposed copy of every weight used by a dgrad GEMM (W^T), so the
     backward reuses the same NT kernel (costs +1x weights of HBM; 2 x 24 GB for Flux.1-dev);
-  * LoRA adapters live in two flat fp32 arenas (params, grads) -> one fused AdamW(+EMA) launch and one RCCL all-reduce.
+  * LoRA adapters live in two flat fp32 arenas (params, grads) -> one fused AdamW(+EMA) launch and one RCCL all-reduce;
+  * every base parameter is a view of ONE bf16 arena; full-rank training (`enable_full_finetune`, `_engine_backward_full`) adds a gradient arena of the
+    same layout: one fused optimizer launch over 12 B parameters, contiguous per-block slices for the gradient exchange.
 """
 from __future__ import annotations
 
@@ -125,13 +127,57 @@ class FluxTransformer2DModel(nn.Module):
             raise ValueError("all contraction dims must be multiples of 64")
         self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         dev = self.device_
-        e = lambda *s: torch.zeros(*s, dtype=BF16, device=dev)
+        # every weight / bias / norm weight / modulation row is a view of ONE bf16 arena (allocation order = arena order): full-rank training then has one
+        # gradient arena of the same layout, ONE fused optimizer launch and contiguous slices for the gradient exchange (as in sd3/transformer.py).  Pass 1
+        # counts on meta tensors, pass 2 hands out the views.  Every tensor of Flux.1 holds a multiple of 64 elements, so all views start 128-byte aligned.
+        self._arena_numel, self._counting = 0, True
+        self._build()
+        self.arena = torch.zeros(self._arena_numel, dtype=BF16, device=dev)
+        self._arena_numel, self._counting = 0, False
+        self._build()
+
+        self.lora_groups: List[LoraGroup] = []
+        self.lora_flat: Optional[torch.Tensor] = None
+        self.lora_grad_flat: Optional[torch.Tensor] = None
+        self._lora_params: List[nn.Parameter] = []
+        self._rope_cache: Dict = {}
+        self._norm_w_ok: Dict = {}
+        self._prepared = False
+        self.accumulate_lora_grads = False
+        self.gradient_checkpointing = False
+        self.gradient_checkpointing_interval = None          # flux/transformer.py:816-818
+        self.gradient_checkpointing_segment_stride = None
+        self.gradient_checkpointing_backend = "torch"
+        self._tread_router, self._tread_routes, self._force_keep_mask = None, None, None
+        self.grad_sync = None            # training.grad_sync.GradSync over lora_grad_flat / grad_arena (data-parallel replicas)
+        self._last_grad_flat = None
+        self.full = False                # enable_full_finetune(): every base parameter trains
+
+    def _alloc(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        off = self._arena_numel
+        self._arena_numel += (n + 7) // 8 * 8               # every tensor starts 16-byte aligned inside the arena
+        if self._counting:
+            return torch.empty(*shape, dtype=BF16, device="meta")
+        return self.arena[off:off + n].view(*shape)
+
+    def _reg(self, name, param):
+        if not self._counting:
+            _attach(self, name, param)
+
+    def _build(self):
+        c = self.config
+        D, dev, e = self.D, self.device_, self._alloc
+        patch_size, in_channels, num_layers, num_single_layers = c.patch_size, c.in_channels, c.num_layers, c.num_single_layers
+        joint_attention_dim, pooled_projection_dim, guidance_embeds = c.joint_attention_dim, c.pooled_projection_dim, c.guidance_embeds
 
         # ---- embedders ----
         def lin(name, out_f, in_f):
             w, b = e(out_f, in_f), e(out_f)
-            _attach(self, name + ".weight", _frozen(w)); _attach(self, name + ".bias", _frozen(b))
-            return SimpleNamespace(w=w, b=b, wT=None)
+            self._reg(name + ".weight", _frozen(w)); self._reg(name + ".bias", _frozen(b))
+            return SimpleNamespace(w=w, b=b, wT=None, lora=None)
 
         self.l_x = lin("x_embedder", D, in_channels)
         self.l_ctx = lin("context_embedder", D, joint_attention_dim)
@@ -150,7 +196,7 @@ class FluxTransformer2DModel(nn.Module):
 
         def mod_slice(name, n):
             nonlocal off
-            _attach(self, name + ".weight", _frozen(self.mod_w[off:off + n])); _attach(self, name + ".bias", _frozen(self.mod_b[off:off + n]))
+            self._reg(name + ".weight", _frozen(self.mod_w[off:off + n])); self._reg(name + ".bias", _frozen(self.mod_b[off:off + n]))
             o = off
             off += n
             return o
@@ -159,19 +205,21 @@ class FluxTransformer2DModel(nn.Module):
             n = len(names)
             w, b = e(n * out_each, in_f), e(n * out_each)
             for j, nm in enumerate(names):
-                _attach(self, f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
-                _attach(self, f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
+                self._reg(f"{prefix}{nm}.weight", _frozen(w[j * out_each:(j + 1) * out_each]))
+                self._reg(f"{prefix}{nm}.bias", _frozen(b[j * out_each:(j + 1) * out_each]))
             return SimpleNamespace(w=w, b=b, wT=None, lora=None)
 
         def normw(name):
-            w = torch.ones(self.hd, dtype=BF16, device=dev)
-            _attach(self, name + ".weight", _frozen(w))
+            w = e(self.hd)
+            if not self._counting:
+                w.fill_(1.0)
+            self._reg(name + ".weight", _frozen(w))
             return w
 
         self.double: List[SimpleNamespace] = []
         for i in range(num_layers):
             p = f"transformer_blocks.{i}."
-            blk = SimpleNamespace()
+            blk = SimpleNamespace(arena_lo=self._arena_numel)
             blk.mod_off = mod_slice(p + "norm1.linear", 6 * D)
             blk.mod_off_c = mod_slice(p + "norm1_context.linear", 6 * D)
             blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
@@ -184,36 +232,23 @@ class FluxTransformer2DModel(nn.Module):
             blk.ff2 = fused(p, ["ff.net.2"], D, 4 * D)
             blk.ffc1 = fused(p, ["ff_context.net.0.proj"], 4 * D, D)
             blk.ffc2 = fused(p, ["ff_context.net.2"], D, 4 * D)
+            blk.arena_hi = self._arena_numel
             self.double.append(blk)
         self.single: List[SimpleNamespace] = []
         for i in range(num_single_layers):
             p = f"single_transformer_blocks.{i}."
-            blk = SimpleNamespace()
+            blk = SimpleNamespace(arena_lo=self._arena_numel)
             blk.mod_off = mod_slice(p + "norm.linear", 3 * D)
             blk.qkv = fused(p + "attn.", ["to_q", "to_k", "to_v"], D, D)
             blk.norm_q, blk.norm_k = normw(p + "attn.norm_q"), normw(p + "attn.norm_k")
             blk.proj_mlp = fused(p, ["proj_mlp"], 4 * D, D)
             blk.proj_out = fused(p, ["proj_out"], D, 5 * D)
+            blk.arena_hi = self._arena_numel
             self.single.append(blk)
         self.mod_off_out = mod_slice("norm_out.linear", 2 * D)
         assert off == self.mod_total
+        self._head_arena_lo = self._arena_numel
         self.l_out = lin("proj_out", patch_size * patch_size * self.out_channels, D)
-
-        self.lora_groups: List[LoraGroup] = []
-        self.lora_flat: Optional[torch.Tensor] = None
-        self.lora_grad_flat: Optional[torch.Tensor] = None
-        self._lora_params: List[nn.Parameter] = []
-        self._rope_cache: Dict = {}
-        self._norm_w_ok: Dict = {}
-        self._prepared = False
-        self.accumulate_lora_grads = False
-        self.gradient_checkpointing = False
-        self.gradient_checkpointing_interval = None          # flux/transformer.py:816-818
-        self.gradient_checkpointing_segment_stride = None
-        self.gradient_checkpointing_backend = "torch"
-        self._tread_router, self._tread_routes, self._force_keep_mask = None, None, None
-        self.grad_sync = None            # training.grad_sync.GradSync over lora_grad_flat (data-parallel replicas)
-        self._last_grad_flat = None
 
     # ------------------------------------------------------------------------------------------------
     # weights
@@ -259,6 +294,9 @@ class FluxTransformer2DModel(nn.Module):
             for l in (blk.qkv, blk.proj_mlp, blk.proj_out):
                 tr(l)
         tr(self.l_out)
+        if getattr(self, "full", False):            # full-rank training also back-propagates through the conditioning MLPs' second linears
+            for l in (self.l_t2, self.l_p2) + ((self.l_g2,) if self.config.guidance_embeds else ()):
+                tr(l)
         self._prepared = True
 
     # ------------------------------------------------------------------------------------------------
@@ -316,7 +354,7 @@ class FluxTransformer2DModel(nn.Module):
         return self._lora_params
 
     def trainable_parameters(self):
-        return list(self._lora_params)
+        return list(self._full_params) if self.full else list(self._lora_params)
 
     # ------------------------------------------------------------------------------------------------
     # rope tables (FluxPosEmbed, theta=1e4, float64 frequencies -> fp32 tables); cached per id layout
@@ -489,7 +527,8 @@ class FluxTransformer2DModel(nn.Module):
         B, Si, St, S, Sp, mod, cos, sin = env.B, env.Si, env.St, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.double[bi]
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
+        full = getattr(env, "full", False)        # full-rank training: norm weights train (no fused projection epilogue), extra activations are kept
+        fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
         if (fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
             # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
             # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
@@ -562,14 +601,19 @@ class FluxTransformer2DModel(nn.Module):
         T_ao = torch.empty(B * St, blk.to_add_out.lora.K2, dtype=BF16, device=dev) if blk.to_add_out.lora is not None else None
         O_i, O_t = self._rows_of(O, St, Si, env), self._rows_of(O, 0, St, env)       # the attention output is split back by rows, in place
         kw_i, kw_t = {}, {}
+        ya_i = ya_t = yf_i = yf_t = None
+        if full and save:            # the un-gated branch outputs (gate gradients: d gate = sum_rows dOut * y)
+            ya_i, yf_i = (torch.empty(B * Si, D, dtype=BF16, device=dev) for _ in range(2))
+            ya_t, yf_t = (torch.empty(B * St, D, dtype=BF16, device=dev) for _ in range(2))
+            kw_i["aux_out"], kw_t["aux_out"] = ya_i, ya_t
         if T_o is not None:
             for pr in self._problems(env, Si, dict(a=O_i, w=blk.to_out.lora.A_cat, out=T_o)):
                 ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
-            kw_i = dict(a2=T_o, b2=blk.to_out.lora.B_blk, k2_real=blk.to_out.lora.k2_real)
+            kw_i.update(a2=T_o, b2=blk.to_out.lora.B_blk, k2_real=blk.to_out.lora.k2_real)
         if T_ao is not None:
             for pr in self._problems(env, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao)):
                 ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
-            kw_t = dict(a2=T_ao, b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
+            kw_t.update(a2=T_ao, b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
         ops.gemm_grouped(self._problems(env, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
                                                       gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
                          + self._problems(env, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
@@ -581,22 +625,26 @@ class FluxTransformer2DModel(nn.Module):
         h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
                                      dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
         x = x2_img = x2_txt = None
+        kf_i = dict(aux_out=yf_i) if yf_i is not None else {}
+        kf_t = dict(aux_out=yf_t) if yf_t is not None else {}
         if bi == len(self.double) - 1:
             # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
             # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
             x = torch.empty(B * S, D, dtype=BF16, device=dev)
             ops.gemm_grouped(self._problems(env, Si, dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img,
-                                                          gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, out=self._rows_of(x, St, Si, env)))
+                                                          gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, out=self._rows_of(x, St, Si, env), **kf_i))
                              + self._problems(env, St, dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt,
-                                                            gate=mt[:, 5 * D:6 * D], rows_per_batch=St, out=self._rows_of(x, 0, St, env))))
+                                                            gate=mt[:, 5 * D:6 * D], rows_per_batch=St, out=self._rows_of(x, 0, St, env), **kf_t)))
         else:
             x2_img, x2_txt = ops.gemm_grouped([
-                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si),
-                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St)])
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
+                dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
         sv = None
         if save:
-            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if T_txt is not None else None, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O,
+            sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O,
                                  lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
+            if full:    # full-rank training also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
+                sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
         return x2_img, x2_txt, x, sv
 
     def _single_fwd(self, bi: int, x, env, save: bool):
@@ -605,7 +653,8 @@ class FluxTransformer2DModel(nn.Module):
         B, S, Sp, mod, cos, sin = env.B, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.single[bi]
         ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
-        fused = (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
+        full = getattr(env, "full", False)
+        fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
         if fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
             # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
             # as the host-side sequencing below
@@ -643,12 +692,15 @@ class FluxTransformer2DModel(nn.Module):
         hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
         hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
         # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
+        y = torch.empty(B * S, D, dtype=BF16, device=dev) if (full and save) else None          # the un-gated branch output (gate gradient)
         x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
-                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S)
+                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S, **(dict(aux_out=y) if y is not None else {}))
         sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
+        if sv is not None and full:
+            sv.hact, sv.y = hact, y
         return x_out, sv
 
-    def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool, key_bias=None):
+    def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool, key_bias=None, full: bool = False):
         D, H, hd = self.D, self.H, self.hd
         B, Si, _ = hidden_states.shape
         St = encoder_hidden_states.shape[1]
@@ -659,20 +711,28 @@ class FluxTransformer2DModel(nn.Module):
             g.pack()
         cos, sin, cos_p, sin_p = self._rope(txt_ids, img_ids)
         # ---- embeddings (flux/transformer.py:1001-1064) ----
-        img = ops.gemm(hidden_states.reshape(B * Si, -1).contiguous(), self.l_x.w, bias=self.l_x.b)
-        txt = ops.gemm(encoder_hidden_states.reshape(B * St, -1).contiguous(), self.l_ctx.w, bias=self.l_ctx.b)
+        em = SimpleNamespace()        # the embedders' intermediates (kept for their weight gradients under full-rank training)
+        em.x2d, em.enc2d = hidden_states.reshape(B * Si, -1).contiguous(), encoder_hidden_states.reshape(B * St, -1).contiguous()
+        img = ops.gemm(em.x2d, self.l_x.w, bias=self.l_x.b)
+        txt = ops.gemm(em.enc2d, self.l_ctx.w, bias=self.l_ctx.b)
         t32 = timestep.to(device=dev, dtype=F32).contiguous()
-        temb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(t32, 256, 1000.0), self.l_t1.w, bias=self.l_t1.b)), self.l_t2.w, bias=self.l_t2.b)
+        em.tproj = ops.timestep_proj(t32, 256, 1000.0)
+        em.t1 = ops.gemm(em.tproj, self.l_t1.w, bias=self.l_t1.b); em.st1 = ops.silu(em.t1)
+        temb = ops.gemm(em.st1, self.l_t2.w, bias=self.l_t2.b)
         if self.config.guidance_embeds:
             if guidance is None:
                 raise ValueError("guidance_embeds=True requires a guidance tensor")
             g32 = guidance.to(device=dev, dtype=F32).contiguous()
-            gemb = ops.gemm(ops.silu(ops.gemm(ops.timestep_proj(g32, 256, 1000.0), self.l_g1.w, bias=self.l_g1.b)), self.l_g2.w, bias=self.l_g2.b)
-            temb = ops.add(temb, gemb)
-        pemb = ops.gemm(ops.silu(ops.gemm(pooled.to(BF16).contiguous(), self.l_p1.w, bias=self.l_p1.b)), self.l_p2.w, bias=self.l_p2.b)
-        temb = ops.add(temb, pemb)
-        mod = ops.gemm(ops.silu(temb), self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
-        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, cos_p=cos_p, sin_p=sin_p, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias)
+            em.gproj = ops.timestep_proj(g32, 256, 1000.0)
+            em.g1 = ops.gemm(em.gproj, self.l_g1.w, bias=self.l_g1.b); em.sg1 = ops.silu(em.g1)
+            temb = ops.add(temb, ops.gemm(em.sg1, self.l_g2.w, bias=self.l_g2.b))
+        em.pooled = pooled.to(BF16).contiguous()
+        em.p1 = ops.gemm(em.pooled, self.l_p1.w, bias=self.l_p1.b); em.sp1 = ops.silu(em.p1)
+        temb = ops.add(temb, ops.gemm(em.sp1, self.l_p2.w, bias=self.l_p2.b))
+        em.temb, em.st = temb, ops.silu(temb)
+        mod = ops.gemm(em.st, self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
+        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, cos_p=cos_p, sin_p=sin_p, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias,
+                              full=bool(full))
         segs_d = self._checkpoint_segments(len(self.double)) if save else [(i, 1, False) for i in range(len(self.double))]
         segs_s = self._checkpoint_segments(len(self.single)) if save else [(i, 1, False) for i in range(len(self.single))]
         # TREAD routing (flux/transformer.py:1101-1133, 1211-1241 double blocks, 1394-1486 single blocks; training/tread.py): only while training; between a route's
@@ -681,6 +741,8 @@ class FluxTransformer2DModel(nn.Module):
         from ..training.tread import normalise_routes
         nd, ns = len(self.double), len(self.single)
         routes = normalise_routes(self._tread_routes, nd + ns) if (save and self.training and self._tread_router is not None) else []
+        if routes and full:
+            raise NotImplementedError("TREAD routing under full-rank Flux training is not built on the st355 path (LoRA training routes)")
         if routes:
             from ..training.checkpoint_plan import per_block as _per_block
             gc_, iv_, sd_ = bool(self.gradient_checkpointing), self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride
@@ -770,6 +832,8 @@ class FluxTransformer2DModel(nn.Module):
         out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
         if save:
             ctx.x_final = x
+            if full:
+                ctx.n_out, ctx.emb = n_out, em
         return out.view(B, Si, -1), ctx
 
     def _attn_backward(self, sv, dO, dqkv, env):
@@ -1014,6 +1078,262 @@ class FluxTransformer2DModel(nn.Module):
         return None
 
     # ------------------------------------------------------------------------------------------------
+    # full-rank training (`model_type == "full"`: the reference's multi-GPU Flux datapoint trains the whole transformer, documentation/DISTRIBUTED.md:291-298):
+    # every weight, bias, q / k RMSNorm weight and modulation row trains.  bf16 parameters and bf16 gradients in two arenas of one layout.
+    # ------------------------------------------------------------------------------------------------
+    def _all_linears(self):
+        ls = [self.l_x, self.l_ctx, self.l_t1, self.l_t2, self.l_p1, self.l_p2, self.l_out]
+        if self.config.guidance_embeds:
+            ls += [self.l_g1, self.l_g2]
+        for blk in self.double:
+            ls += [blk.qkv, blk.add_qkv, blk.to_out, blk.to_add_out, blk.ff1, blk.ff2, blk.ffc1, blk.ffc2]
+        for blk in self.single:
+            ls += [blk.qkv, blk.proj_mlp, blk.proj_out]
+        return ls
+
+    def enable_full_finetune(self):
+        """gradient arena with the weight arena's layout; every base parameter becomes trainable (one fused optimizer launch, contiguous exchange slices)"""
+        if self.lora_groups:
+            raise RuntimeError("full-rank training and LoRA adapters are exclusive")
+        self.full = True
+        self.grad_arena = torch.zeros_like(self.arena)
+        base = self.arena.data_ptr()
+
+        def gview(t):
+            off = (t.data_ptr() - base) // 2
+            return self.grad_arena[off:off + t.numel()].view(t.shape)
+
+        for l in self._all_linears():
+            l.gw, l.gb = gview(l.w), gview(l.b)
+        for blk in self.double + self.single:
+            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                w = getattr(blk, nm, None)
+                if w is not None:
+                    setattr(blk, "g_" + nm, gview(w))
+        self.g_mod_w, self.g_mod_b = gview(self.mod_w), gview(self.mod_b)
+        ps = sorted([p for n, p in self.named_parameters() if ".lora_" not in n], key=lambda p: p.data_ptr())
+        for p in ps:
+            p.requires_grad_(True)
+        self._full_params = ps
+        self._full_offsets = [((p.data_ptr() - base) // 2, p.numel()) for p in ps]
+        self.prepare_for_training()
+        return ps
+
+    def _refresh_transposed(self):
+        """W^T follows the weights (2 B read + 2 B write per parameter per step: ~12 ms for Flux.1-dev's 12 B parameters)"""
+        for l in self._all_linears():
+            if getattr(l, "wT", None) is not None:
+                ops.transpose(l.w, out=l.wT)
+
+    def diffusers_state_dict(self) -> Dict[str, torch.Tensor]:
+        """{diffusers checkpoint key: tensor} of the base parameters (the parameter names ARE the checkpoint keys): what `save_pretrained` writes"""
+        return {k: v.detach() for k, v in self.named_parameters() if ".lora_" not in k}
+
+    def load_diffusers_state(self, state: Dict[str, torch.Tensor]):
+        self.load_flat_state(state)
+
+    def _single_bwd_full(self, li: int, sv, dx, env, fb):
+        """backward of single block li with every parameter gradient; returns the gradient of the block's input (joint [txt || img] rows)"""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, S, mod = env.B, env.S, env.mod
+        blk = self.single[li]
+        ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]; dms = fb.dmod[:, blk.mod_off:blk.mod_off + 3 * D]
+        ops.colsum_prod(dx, dms[:, 2 * D:3 * D], b=sv.y, rows_per_batch=S)                         # d gate
+        g = ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
+        # proj_out reads [attention output | MLP activation] as two K segments: its weight gradient is written as the two column blocks
+        gp = fb.P64(g)
+        ops.gemm_tn(gp, fb.P64(sv.O), out=blk.proj_out.gw[:, :D])
+        ops.gemm_tn(gp, fb.P64(sv.hact), out=blk.proj_out.gw[:, D:])
+        fb.bgrad(blk.proj_out, g)
+        dO = ops.gemm(g, blk.proj_out.wT[:D])
+        dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
+        del g, gp
+        fb.wgrad(blk.proj_mlp, dhpre, sv.n)
+        dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
+        del dhpre
+        dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
+        ops.qk_norm_rope_bwd_wgrad(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, env.cos, env.sin, dqkv, B, H, hd, S, 0, S, blk.g_norm_q, blk.g_norm_k)
+        del dQ, dK, dO
+        fb.wgrad(blk.qkv, dqkv, sv.n)
+        dn = ops.gemm(dqkv, blk.qkv.wT, epilogue=EPI_ADD, aux_in=dn_mlp)
+        fb.mod_grads(dn, sv.x, S, 0, 1, dms)
+        dx_in, _ = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
+        return dx_in
+
+    def _double_bwd_full(self, li: int, sv, d_img, d_txt, env, fb):
+        """backward of double block li with every parameter gradient; returns (d_img, d_txt) w.r.t. the block's inputs"""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, mod = env.B, env.Si, env.St, env.S, env.mod
+        blk = self.double[li]
+        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        dmi = fb.dmod[:, blk.mod_off:blk.mod_off + 6 * D]; dmt = fb.dmod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        rows = lambda t, lo, n: t[lo:lo + n] if B == 1 else t.view(B, S, -1)[:, lo:lo + n].reshape(B * n, -1)
+        # ---- MLP branches ----
+        ops.colsum_prod(d_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)                  # d gate_mlp
+        ops.colsum_prod(d_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
+        g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+        fb.wgrad(blk.ff2, g_i, sv.h_i); fb.wgrad(blk.ffc2, g_t, sv.h_t)
+        dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
+                                       dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
+        fb.wgrad(blk.ff1, dh_i, sv.n2_i); fb.wgrad(blk.ffc1, dh_t, sv.n2_t)
+        dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+        del g_i, g_t, dh_i, dh_t
+        fb.mod_grads(dn2_i, sv.x1_img, Si, 3, 4, dmi); fb.mod_grads(dn2_t, sv.x1_txt, St, 3, 4, dmt)
+        dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+        dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
+        del dn2_i, dn2_t
+        ops.colsum_prod(dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)                  # d gate_msa
+        ops.colsum_prod(dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
+        # ---- attention output projections (joint order [txt || img]) ----
+        fb.wgrad(blk.to_out, dx1g_i, rows(sv.O, St, Si)); fb.wgrad(blk.to_add_out, dx1g_t, rows(sv.O, 0, St))
+        dO = torch.empty(B * S, D, dtype=BF16, device=dev)
+        ops.gemm_grouped(self._problems(env, Si, dict(a=dx1g_i, w=blk.to_out.wT, out=self._rows_of(dO, St, Si, env)))
+                         + self._problems(env, St, dict(a=dx1g_t, w=blk.to_add_out.wT, out=self._rows_of(dO, 0, St, env))))
+        del dx1g_i, dx1g_t
+        # ---- attention, RoPE / RMSNorm (+ norm weight gradients) ----
+        dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
+        dQ, dK = self._attn_backward(sv, dO, dqkv, env)
+        ops.qk_norm_rope_bwd_wgrad(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, env.cos, env.sin, dqkv, B, H, hd, St, 0, S, blk.g_norm_added_q, blk.g_norm_added_k)
+        ops.qk_norm_rope_bwd_wgrad(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, env.cos, env.sin, dqkv, B, H, hd, Si, St, S, blk.g_norm_q, blk.g_norm_k)
+        del dQ, dK, dO
+        dq_i, dq_t = rows(dqkv, St, Si), rows(dqkv, 0, St)
+        fb.wgrad(blk.qkv, dq_i, sv.n_img); fb.wgrad(blk.add_qkv, dq_t, sv.n_txt)
+        dn_i, dn_t = ops.gemm_grouped([dict(a=dq_i, w=blk.qkv.wT), dict(a=dq_t, w=blk.add_qkv.wT)])
+        fb.mod_grads(dn_i, sv.img, Si, 0, 1, dmi); fb.mod_grads(dn_t, sv.txt, St, 0, 1, dmt)
+        d_img_in, _ = ops.ln_modulate_bwd(dn_i, sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+        d_txt_in, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
+        return d_img_in, d_txt_in
+
+    def _engine_backward_full(self, ctx, dout):
+        """hand-written backward of full-rank training: the dX chain of `_engine_backward` plus a TN weight-gradient GEMM and a bias column sum per Linear,
+        token-axis reductions for the modulation rows / gates, the q / k RMSNorm weight gradients, and the embedders.  Checkpointed segments are re-run from
+        their kept input first (same kernels, same order, bit-identical activations)."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        env = ctx.env
+        B, Si, St, S, mod = env.B, env.Si, env.St, env.S, env.mod
+        self._refresh_transposed()
+        fb = SimpleNamespace(dmod=torch.zeros(B, self.mod_total, dtype=F32, device=dev))        # d loss / d (modulation linear output)
+        tmp_b = {}
+
+        def P64(t):
+            """zero-padded copy with a multiple of 64 rows (the TN GEMM's contraction granule); no copy when already aligned"""
+            r = t.shape[0]
+            if r % 64 == 0 and t.is_contiguous():
+                return t
+            o = torch.zeros((r + 63) // 64 * 64, t.shape[1], dtype=BF16, device=dev)
+            o[:r] = t
+            return o
+
+        def bgrad(lin, dy):
+            N = dy.shape[1]
+            t = tmp_b.get(N)
+            if t is None:
+                t = tmp_b[N] = torch.empty(1, N, dtype=F32, device=dev)
+            ops.colsum_prod(dy, t)
+            lin.gb.copy_(t[0])
+
+        def wgrad(lin, dy, x):
+            """dW = dY^T X ; db = colsum(dY)   (into the gradient arena views of `lin`)"""
+            ops.gemm_tn(P64(dy), P64(x), out=lin.gw)
+            bgrad(lin, dy)
+
+        def mod_grads(dn, x_in, rows, k_shift, k_scale, dm, xhat=None):
+            """d shift = sum_t dY, d scale = sum_t dY * LN(x) of one AdaLN instance (chunk indices k_* inside its slice dm of the modulation gradient);
+            x_in = the LayerNorm's input (or xhat = LN(x) when the caller already has it)"""
+            ops.colsum_prod(dn, dm[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=rows)
+            ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in) if xhat is None else xhat, rows_per_batch=rows)
+
+        fb.P64, fb.bgrad, fb.wgrad, fb.mod_grads = P64, bgrad, wgrad, mod_grads
+        sync = self.grad_sync
+        # ---- output head (AdaLayerNormContinuous: chunk order (scale, shift)) ----
+        dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
+        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        dmo = fb.dmod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        wgrad(self.l_out, dout, ctx.n_out)
+        dn = ops.gemm(dout, self.l_out.wT)
+        xhat = torch.empty(B * Si, D, dtype=BF16, device=dev)
+        for b in range(B):          # LN of the image rows of the joint sequence (strided per-sample views)
+            ops.layer_norm_xhat(ctx.x_final[b * S + St:(b + 1) * S], out=xhat[b * Si:(b + 1) * Si])
+        mod_grads(dn, None, Si, 1, 0, dmo, xhat=xhat)
+        del xhat
+        dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
+        for b in range(B):
+            ops.ln_modulate_bwd(dn[b * Si:(b + 1) * Si], ctx.x_final[b * S + St:(b + 1) * S], mo[b:b + 1, :D], Si, out=dx[b * S + St:(b + 1) * S])
+        del dn
+        ctx.x_final = ctx.n_out = None
+        if sync is not None:
+            sync.ready(self._head_arena_lo, self.grad_arena.numel())        # proj_out gradients are final
+        # ---- single blocks, reversed ----
+        for (s0, n, ck) in reversed(ctx.segs_s):
+            if ck:
+                xr = ctx.ck_s.pop(s0)
+                for bi in range(s0, s0 + n):
+                    xr, ctx.sgl[bi] = self._single_fwd(bi, xr, ctx.env_s[bi], True)
+                del xr
+            for li in range(s0 + n - 1, s0 - 1, -1):
+                dx = self._single_bwd_full(li, ctx.sgl.pop(li), dx, ctx.env_s[li], fb)
+                if sync is not None:
+                    sync.ready(self.single[li].arena_lo, self.single[li].arena_hi)
+        # ---- split the joint gradient [txt || img] ----
+        dxv = dx.view(B, S, D)
+        d_txt, d_img = dxv[:, :St].reshape(B * St, D), dxv[:, St:].reshape(B * Si, D)
+        del dx, dxv
+        # ---- double blocks, reversed ----
+        for (s0, n, ck) in reversed(ctx.segs_d):
+            if ck:
+                ir, tr = ctx.ck_d.pop(s0)
+                for bi in range(s0, s0 + n):
+                    ir, tr, _, ctx.dbl[bi] = self._double_fwd(bi, ir, tr, ctx.env_d[bi], True)
+                del ir, tr
+            for li in range(s0 + n - 1, s0 - 1, -1):
+                d_img, d_txt = self._double_bwd_full(li, ctx.dbl.pop(li), d_img, d_txt, ctx.env_d[li], fb)
+                if sync is not None:
+                    sync.ready(self.double[li].arena_lo, self.double[li].arena_hi)
+        # ---- embedders ----
+        em = ctx.emb
+        wgrad(self.l_x, d_img, em.x2d)
+        wgrad(self.l_ctx, d_txt, em.enc2d)
+        # modulation linear: mod = silu(temb) W_mod^T + b
+        Bp = (B + 63) // 64 * 64
+        dmod_p = torch.zeros(Bp, self.mod_total, dtype=BF16, device=dev); dmod_p[:B] = fb.dmod
+        st_p = torch.zeros(Bp, D, dtype=BF16, device=dev); st_p[:B] = em.st
+        ops.gemm_tn(dmod_p, st_p, out=self.g_mod_w)
+        tb = torch.empty(1, self.mod_total, dtype=F32, device=dev)
+        ops.colsum_prod(dmod_p, tb)
+        self.g_mod_b.copy_(tb[0])
+        # d silu(temb) = dmod @ W_mod -> [B, D], as (W_mod^T dmod^T)^T with the TN GEMM.  The contraction runs over the mod_total rows of W_mod (1.06 M for
+        # Flux.1-dev): walked in row blocks that stay inside the TN GEMM's 2 GiB operand window, accumulated into one [D, B8] output
+        B8 = 8 * ((B + 7) // 8)
+        dmod_t = ops.transpose(dmod_p[:B8])                                   # [mod_total, B8]
+        blk_rows = max(64, (getattr(self, "_tn_window_bytes", (1 << 31) - 1) // (2 * max(D, B8))) // 64 * 64)        # (attribute: tests shrink the window)
+        acc = torch.empty(D, B8, dtype=BF16, device=dev)
+        for i, r0 in enumerate(range(0, self.mod_total, blk_rows)):
+            r1 = min(self.mod_total, r0 + blk_rows)
+            ops.gemm_tn(self.mod_w[r0:r1], dmod_t[r0:r1], out=acc, accumulate=i > 0)
+        dst = ops.transpose(acc)[:B].contiguous()
+        dtemb = ops.silu_bwd(em.temb, dst)
+
+        def mlp_bwd(l1, l2, x_in, pre1, act1, dy):
+            """TimestepEmbedding / guidance / pooled-text projection: y = l2(silu(l1(x)))"""
+            pad = lambda t: torch.cat([t, torch.zeros(Bp - B, t.shape[1], dtype=BF16, device=dev)], dim=0)
+            dyp = pad(dy)
+            ops.gemm_tn(dyp, pad(act1), out=l2.gw)
+            bgrad(l2, dyp)
+            d1p = pad(ops.silu_bwd(pre1, ops.gemm(dy, l2.wT)))
+            ops.gemm_tn(d1p, pad(x_in), out=l1.gw)
+            bgrad(l1, d1p)
+
+        mlp_bwd(self.l_t1, self.l_t2, em.tproj, em.t1, em.st1, dtemb)
+        if self.config.guidance_embeds:
+            mlp_bwd(self.l_g1, self.l_g2, em.gproj, em.g1, em.sg1, dtemb)
+        mlp_bwd(self.l_p1, self.l_p2, em.pooled, em.p1, em.sp1, dtemb)
+        if sync is not None:
+            lo = self.double[0].arena_lo if self.double else (self.single[0].arena_lo if self.single else self._head_arena_lo)
+            sync.ready(0, lo)                                                  # embedders + the modulation matrix
+        return None
+
+    # ------------------------------------------------------------------------------------------------
     # public forward (reference signature: flux/transformer.py:940-960)
     # ------------------------------------------------------------------------------------------------
     def set_router(self, router, routes):
@@ -1044,12 +1364,15 @@ class FluxTransformer2DModel(nn.Module):
             B_, S_tot = hidden_states.shape[0], hidden_states.shape[1] + encoder_hidden_states.shape[1]
             key_bias = torch.ones(B_, S_tot, dtype=F32, device=self.device_)
             key_bias[:, :am.shape[1]] = (am.to(self.device_) > 0).to(F32)
-        need_grad = torch.is_grad_enabled() and len(self._lora_params) > 0
+        need_grad = torch.is_grad_enabled() and (len(self._lora_params) > 0 or self.full)
         if need_grad and not self._prepared:
             # the K-major dgrad operands follow the weights: load_flat_state / init_synthetic / the replica start-state broadcast
             # (training.grad_sync.sync_module_states) mark them stale, the next training forward rebuilds them
             self.prepare_for_training()
-        if need_grad:
+        if need_grad and self.full:
+            out = _FluxFullFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids, key_bias,
+                                    *self._full_params)
+        elif need_grad:
             out = _FluxFn.apply(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids, txt_ids, key_bias,
                                 *self._lora_params)
         else:
@@ -1090,4 +1413,30 @@ class _FluxFn(torch.autograd.Function):
             n = p.numel()
             grads.append(gflat[off:off + n].view_as(p))
             off += n
+        return (None,) * 9 + tuple(grads)
+
+
+class _FluxFullFn(torch.autograd.Function):
+    """full-rank training: one autograd node; backward fills the bf16 gradient arena and hands autograd views of a private copy"""
+
+    @staticmethod
+    def forward(fctx, model, hidden_states, enc, pooled, timestep, guidance, img_ids, txt_ids, key_bias, *params):
+        out, ctx = model._engine_forward(hidden_states.detach().to(BF16), enc.detach().to(BF16), pooled.detach(), timestep.detach(),
+                                         None if guidance is None else guidance.detach(), img_ids, txt_ids, save=True, key_bias=key_bias, full=True)
+        fctx.model, fctx.ectx = model, ctx
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
+        model._engine_backward_full(fctx.ectx, dout)
+        fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_scale_from_sync = model.grad_sync.finish()   # every slice reduced (SUM over replicas); the optimizer folds 1/world
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.grad_arena)
+        model._last_grad_flat = gflat
+        grads = [gflat[off:off + n].view_as(p) for (off, n), p in zip(model._full_offsets, model._full_params)]
         return (None,) * 9 + tuple(grads)

@@ -570,6 +570,21 @@ def ln_modulate_fwd(x, scale, shift, rows_per_batch: int, eps: float = 1e-6, out
     return out
 
 
+_zero_rows = {}
+
+
+def layer_norm_xhat(x, eps: float = 1e-6, out=None):
+    """xhat = LN(x) with no modulation (ln_modulate_fwd with scale = shift = 0): the factor of the modulation-SCALE gradient, d scale_b = sum_t dY * xhat.
+    The engines compute that sum from xhat itself; recovering xhat from the saved modulated output as (n - shift) / (1 + scale) (colsum_prod mode 1) is
+    singular where a scale entry is exactly -1 in bf16 — which random-init modulation tables hit in a few entries per step."""
+    _chk(x, BF16, "x")
+    key = (str(x.device), x.shape[1])
+    z = _zero_rows.get(key)
+    if z is None:
+        z = _zero_rows[key] = torch.zeros(1, x.shape[1], dtype=BF16, device=x.device)
+    return ln_modulate_fwd(x, z, z, x.shape[0], eps=eps, out=out)
+
+
 def ln_modulate_bwd(dy, x, scale, rows_per_batch: int, dres=None, gate=None, eps: float = 1e-6, want_gated: bool = False, out=None):
     """dx = dres + LNbwd(dy*(1+scale));  dxg = gate[b]*dx (if want_gated).  Returns (dx, dxg).  out: optional destination view for dx (row stride free)."""
     L = _l.load()

@@ -370,12 +370,12 @@ class PixArtTransformer2DModel(nn.Module):
                 blk.G[nm + ".weight"].copy_(gw); blk.G[nm + ".bias"].copy_(gb)
             return f
 
-        def mod_grads(dn, n_saved, k_shift, k_scale):
+        def mod_grads(dn, x_in, k_shift, k_scale):
+            """d shift = sum_t dY, d scale = sum_t dY * LN(x); x_in = the LayerNorm's input (LN(x) recomputed: no division by 1 + scale)"""
             if not tr:
                 return
-            dsh = dmod[:, k_shift * D:(k_shift + 1) * D]
-            ops.colsum_prod(dn, dsh, rows_per_batch=S)
-            ops.colsum_prod(dn, dmod[:, k_scale * D:(k_scale + 1) * D], b=n_saved, rows_per_batch=S, mode=1, prev=dsh, shift=m[k_shift], scale=m[k_scale])
+            ops.colsum_prod(dn, dmod[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=S)
+            ops.colsum_prod(dn, dmod[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in), rows_per_batch=S)
 
         # ---- feed-forward ----
         dyf = ops.scale_cols(d3, m[5], S)
@@ -385,7 +385,7 @@ class PixArtTransformer2DModel(nn.Module):
         dpre = ops.gemm(dyf, W.ff2_wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.pre)
         wgrad("ff1", dpre, sv.n2, plain("ff.net.0.proj"))
         dn2 = ops.gemm(dpre, W.ff1_wT)
-        mod_grads(dn2, sv.n2, 3, 4)
+        mod_grads(dn2, sv.h2, 3, 4)
         d2, _ = ops.ln_modulate_bwd(dn2, sv.h2, m[4], S, dres=d3)
         # ---- cross-attention (no pre-norm, no gate) ----
         wgrad("out2", d2, sv.O2, unpad_cols("attn2.to_out.0"))
@@ -412,7 +412,7 @@ class PixArtTransformer2DModel(nn.Module):
         ops.head_merge(dK, dqkv[:, Dp:2 * Dp], B, H, HP, S)
         wgrad("qkv", dqkv, sv.n1, unpad_rows(["attn1.to_q", "attn1.to_k", "attn1.to_v"]))
         dn1 = ops.gemm(dqkv, W.qkv_wT)
-        mod_grads(dn1, sv.n1, 0, 1)
+        mod_grads(dn1, sv.h, 0, 1)
         d0, _ = ops.ln_modulate_bwd(dn1, sv.h, m[1], S, dres=d1)
         if tr:
             blk.G["scale_shift_table"].copy_(dmod.sum(0).view(6, D))

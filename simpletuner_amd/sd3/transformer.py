@@ -10,8 +10,8 @@ the Flux double block at D = 1536 / head_dim 64:
   * the last block is `context_pre_only`: its context stream only feeds K/V/Q (AdaLayerNormContinuous, chunk order scale,shift);
   * every AdaLN modulation linear of all blocks (+norm_out) is one matrix -> one skinny GEMM per step;
   * unpatchify "nhwpqc->nchpwq" is the order-1 permute kernel.
-Frozen-base (LoRA) training only for now: the full fine-tune of BASELINE.json configs[3] needs the TN weight-gradient GEMM
-(DESIGN.md §7).
+Two training modes: frozen-base LoRA (`add_lora_adapter`) and the full fine-tune of BASELINE.json configs[3] (`enable_full_finetune`: TN weight-gradient
+GEMMs, token-axis reductions for the modulation rows, q / k RMSNorm weight gradients; `_engine_backward_full`).
 """
 from __future__ import annotations
 
@@ -717,6 +717,16 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
     def trainable_parameters(self):
         return list(self._full_params) if getattr(self, "full", False) else list(self._lora_params)
 
+    def diffusers_state_dict(self) -> Dict[str, torch.Tensor]:
+        """{diffusers checkpoint key: tensor} of the base parameters + the position table (the parameter names ARE the checkpoint keys): what `save_pretrained`
+        writes for a full fine-tune (training/trainer.py save_state)"""
+        sd = {k: v.detach() for k, v in self.named_parameters() if ".lora_" not in k}
+        sd["pos_embed.pos_embed"] = self.pos_embed.pos_embed.detach()
+        return sd
+
+    def load_diffusers_state(self, state: Dict[str, torch.Tensor]):
+        self.load_flat_state(state)
+
     def _refresh_transposed(self):
         """W^T follows the weights (2 B read + 2 B write per parameter; ~1 ms for SD3-Medium)"""
         for l in self._all_linears():
@@ -751,12 +761,11 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             ops.colsum_prod(dy, t)
             lin.gb.copy_(t[0])
 
-        def mod_grads(dn, n_saved, m, rows, k_shift, k_scale, dm):
-            """d shift / d scale of one AdaLN instance (chunk indices k_* inside its modulation slice m / dm)"""
-            dsh = dm[:, k_shift * D:(k_shift + 1) * D]
-            ops.colsum_prod(dn, dsh, rows_per_batch=rows)
-            ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=n_saved, rows_per_batch=rows, mode=1, prev=dsh,
-                            shift=m[:, k_shift * D:(k_shift + 1) * D], scale=m[:, k_scale * D:(k_scale + 1) * D])
+        def mod_grads(dn, x_in, rows, k_shift, k_scale, dm):
+            """d shift = sum_t dY, d scale = sum_t dY * LN(x) of one AdaLN instance (chunk indices k_* inside its slice dm of the modulation gradient); x_in = the
+            LayerNorm's input.  (LN(x) is recomputed: recovering it from the saved modulated output divides by 1 + scale, singular where a scale entry is -1.)"""
+            ops.colsum_prod(dn, dm[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=rows)
+            ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in), rows_per_batch=rows)
 
         def qk_bwd(dQ_, dK_, qkv_, wq, wk, dqkv_, rows, pos0, S_, gq, gk):
             """RMSNorm (+ identity RoPE) backward of one stream's q / k; with norm weights (SD3.5) also their gradients (sd3/transformer.py:155-165)"""
@@ -774,7 +783,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         dmo = dmod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         wgrad(self.l_out, dpk, ctx.n_out)
         dn = ops.gemm(dpk, self.l_out.wT)
-        mod_grads(dn, ctx.n_out, mo, Si, 1, 0, dmo)                        # AdaLayerNormContinuous: (scale, shift)
+        mod_grads(dn, ctx.x_img_final, Si, 1, 0, dmo)                        # AdaLayerNormContinuous: (scale, shift)
         d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
         d_txt = None
         del dn, dpk
@@ -804,7 +813,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
             wgrad(blk.ff1, dh_i, sv.n2_i)
             dn2_i = ops.gemm(dh_i, blk.ff1.wT)
-            mod_grads(dn2_i, sv.n2_i, mi, Si, 3, 4, dmi)
+            mod_grads(dn2_i, sv.x1_img, Si, 3, 4, dmi)
             dn2a = None
             if blk.dual:
                 d2 = sv.d2
@@ -819,7 +828,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 qk_bwd(dQ2, dK2, d2.qkv2, blk.norm_q2, blk.norm_k2, dqkv2, Si, 0, Si, blk.g_norm_q2, blk.g_norm_k2)
                 wgrad(blk.qkv2, dqkv2, d2.n2a)
                 dn2a = ops.gemm(dqkv2, blk.qkv2.wT)
-                mod_grads(dn2a, d2.n2a, mi9, Si, 6, 7, dmi9)
+                mod_grads(dn2a, sv.img, Si, 6, 7, dmi9)
                 dx1g_i = ops.scale_cols(dx1_i, mi[:, 2 * D:3 * D], Si)
                 del dxg2, dO2, dQ2, dK2, dqkv2, d2
             else:
@@ -834,7 +843,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 dh_t = ops.gemm(g_t, blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)
                 wgrad(blk.ffc1, dh_t, sv.n2_t)
                 dn2_t = ops.gemm(dh_t, blk.ffc1.wT)
-                mod_grads(dn2_t, sv.n2_t, mt, St, 3, 4, dmt)
+                mod_grads(dn2_t, sv.x1_txt, St, 3, 4, dmt)
                 dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
                 ops.colsum_prod(dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
                 del g_t, dh_t, dn2_t
@@ -863,15 +872,15 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             wgrad(blk.qkv, dq_i, sv.n_img)
             wgrad(blk.add_qkv, dq_t, sv.n_txt)
             dn_i, dn_t = ops.gemm_grouped([dict(a=dq_i, w=blk.qkv.wT), dict(a=dq_t, w=blk.add_qkv.wT)])
-            mod_grads(dn_i, sv.n_img, mi, Si, 0, 1, dmi)
+            mod_grads(dn_i, sv.img, Si, 0, 1, dmi)
             d_img, _ = ops.ln_modulate_bwd(dn_i, sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
             if dn2a is not None:                  # the second reader of LN(img): attn2's modulated input (scale_msa2)
                 d_img, _ = ops.ln_modulate_bwd(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dres=d_img)
             if blk.last:
-                mod_grads(dn_t, sv.n_txt, mt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
+                mod_grads(dn_t, sv.txt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
                 d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, :D], St, dres=None)
             else:
-                mod_grads(dn_t, sv.n_txt, mt, St, 0, 1, dmt)
+                mod_grads(dn_t, sv.txt, St, 0, 1, dmt)
                 d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
             del dqkv, sv, dn_i, dn_t, dq_i, dq_t
             if li in ctx.route_start:

@@ -1,0 +1,471 @@
+"""CPU emulation of the kernel CONTRACTS behind `simpletuner_amd.ops` — TEST INFRASTRUCTURE ONLY.
+
+The engines (flux/transformer.py, ...) are host code that sequences libst355 launches: which kernel, on which operand view, into which buffer, with
+which saved activation.  That sequencing is most of what can go wrong in a hand-written backward, and none of it needs a GPU to be wrong.  `install()`
+monkeypatches the wrappers of `simpletuner_amd.ops` with plain-torch functions that honour the same argument contracts (st355.h): operands stay bf16
+in memory, the arithmetic is fp32 with one bf16 rounding at each store (as the kernels do), outputs are written IN PLACE into the views the engine
+passes (strided row blocks of joint buffers included), and the preconditions the C entry points enforce (dtypes, unit inner strides, the 64-row
+contraction granule of the TN GEMM, ...) raise here too.  A `-m "not gpu"` test can then run an engine's forward + backward on the CPU and compare with
+the oracle's autograd — the GPU parity tests remain the proof for the kernels themselves.
+
+Nothing in the product imports this module; the product has no CPU path (ops.* raise on host tensors).  Kernels that only the fused fast paths use
+(ST355_EPI_QK_NORM_ROPE, attn_bwd_rope, the block-level entry points) are NOT emulated: tests switch those paths off, exactly like the A/B env switches do.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from simpletuner_amd.lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE      # the ST355_EPI_* values (st355.h)
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class EmuError(RuntimeError):
+    pass
+
+
+def _need(cond, msg):
+    if not cond:
+        raise EmuError(msg)
+
+
+def _chk(t, dtype, name):
+    _need(torch.is_tensor(t) and t.dtype == dtype, f"{name}: expected {dtype}, got {getattr(t, 'dtype', type(t))}")
+
+
+def _rows(t, name):
+    _need(t.dim() == 2 and t.stride(1) == 1, f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.stride(0)
+
+
+def _seg(t, name):
+    """the operand forms ops._seg accepts: 2-D row-major, or [segments, rows, cols] whose segment stride is a whole number of rows"""
+    if t.dim() == 2:
+        _rows(t, name)
+        return t
+    _need(t.dim() == 3 and t.stride(2) == 1 and t.stride(1) > 0 and t.stride(0) % t.stride(1) == 0, f"{name}: not a segmented row view: {tuple(t.shape)} {t.stride()}")
+    return t
+
+
+def _flat(t):
+    return t.reshape(-1, t.shape[-1]).float()
+
+
+def _put(dst, val):
+    """store fp32 values into a (possibly strided / segmented) bf16 or fp32 destination view, in place"""
+    dst.copy_(val.reshape(dst.shape).to(dst.dtype))
+    return dst
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+def _gelu_grad(x):
+    u = 0.7978845608028654 * (x + 0.044715 * x ** 3)
+    t = torch.tanh(u)
+    return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * 0.7978845608028654 * (1.0 + 3 * 0.044715 * x * x)
+
+
+def _per_batch(v, rows_total, rows_per_batch):
+    """[nb, N] per-sample rows -> [rows_total, N]"""
+    nb = rows_total // rows_per_batch
+    _need(nb * rows_per_batch == rows_total and v.shape[0] >= nb, f"per-batch operand: {rows_total} rows / {rows_per_batch} per batch vs {v.shape[0]} rows")
+    return v[:nb].float().repeat_interleave(rows_per_batch, dim=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None, gate=None, rows_per_batch=0, k2_real=0, rope=None):
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    _seg(a, "a"); _rows(w, "w")
+    _need(epilogue != EPI_QK_NORM_ROPE, "the fused QKV epilogue is not emulated (switch the fused path off in CPU tests)")
+    A = _flat(a)
+    M, K = A.shape
+    N = w.shape[0]
+    _need(w.shape[1] == K, f"gemm: K mismatch {K} vs {w.shape[1]}")
+    _need(K % 64 == 0, f"gemm: K = {K} is not a multiple of 64")
+    acc = A @ w.float().t()
+    if a2 is not None:
+        _chk(a2, BF16, "a2"); _chk(b2, BF16, "b2"); _seg(a2, "a2"); _rows(b2, "b2")
+        A2 = _flat(a2)
+        _need(A2.shape[0] == M and b2.shape == (N, A2.shape[1]) and A2.shape[1] % 64 == 0, "gemm: low-rank / second-segment shape mismatch")
+        acc = acc + A2 @ b2.float().t()
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+        _need(bias.is_contiguous() and bias.numel() == N, "gemm: bias")
+        acc = acc + bias.float()
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    _chk(out, BF16, "out"); _seg(out, "out")
+    _need(out.numel() == M * N and out.shape[-1] == N, f"gemm: out is {tuple(out.shape)}, expected {M}x{N}")
+    if aux_in is not None:
+        _chk(aux_in, BF16, "aux_in"); _seg(aux_in, "aux_in")
+        _need(aux_in.numel() == M * N, "gemm: aux_in shape")
+    if aux_out is not None:
+        _chk(aux_out, BF16, "aux_out"); _seg(aux_out, "aux_out")
+        _need(aux_out.numel() == M * N, "gemm: aux_out shape")
+    if epilogue == EPI_NONE:
+        val = acc
+    elif epilogue == EPI_ADD:
+        _need(aux_in is not None, "gemm: EPI_ADD needs aux_in")
+        val = acc + _flat(aux_in)
+    elif epilogue == EPI_GELU:
+        if aux_out is not None:
+            _put(aux_out, acc)                      # the pre-activation, for the backward
+        val = _gelu(acc)
+    elif epilogue == EPI_MUL_GELU_GRAD:
+        _need(aux_in is not None, "gemm: EPI_MUL_GELU_GRAD needs aux_in (the saved pre-activation)")
+        val = acc * _gelu_grad(_flat(aux_in))
+    elif epilogue == EPI_GATE_RESIDUAL:
+        _need(aux_in is not None and gate is not None and rows_per_batch > 0, "gemm: EPI_GATE_RESIDUAL needs aux_in, gate, rows_per_batch")
+        _chk(gate, BF16, "gate"); _rows(gate, "gate")
+        if aux_out is not None:
+            _put(aux_out, acc)                      # the un-gated branch output
+        val = _flat(aux_in) + _per_batch(gate, M, rows_per_batch) * acc
+    else:
+        raise EmuError(f"gemm: epilogue {epilogue}")
+    return _put(out, val)
+
+
+def gemm_grouped(problems):
+    outs = []
+    for pr in problems:
+        pr = dict(pr)
+        outs.append(gemm(pr.pop("a"), pr.pop("w"), **pr))
+    return outs
+
+
+def gemm_tn(Lm, R, out=None, accumulate=False):
+    _chk(Lm, BF16, "L"); _chk(R, BF16, "R"); _rows(Lm, "L"); _rows(R, "R")
+    M, P = Lm.shape
+    _need(R.shape[0] == M, "gemm_tn: operands must share the contraction length")
+    _need(M % 64 == 0, f"gemm_tn: contraction length {M} is not a multiple of 64 (zero-pad the rows)")
+    val = Lm.float().t() @ R.float()
+    if out is None:
+        _need(not accumulate, "gemm_tn: accumulate needs an output tensor")
+        out = torch.empty(P, R.shape[1], dtype=BF16, device=Lm.device)
+    _chk(out, BF16, "out"); _rows(out, "out")
+    _need(tuple(out.shape) == (P, R.shape[1]), f"gemm_tn: out is {tuple(out.shape)}, expected {(P, R.shape[1])}")
+    if accumulate:
+        val = val + out.float()
+    return _put(out, val)
+
+
+def colsum_prod(a, out, b=None, rows_per_batch=None, mode=0, prev=None, shift=None, scale=None, accumulate=False):
+    _chk(a, BF16, "a"); _chk(out, F32, "out"); _rows(a, "a"); _rows(out, "out")
+    rows, N = a.shape
+    rpb = rows if rows_per_batch is None else rows_per_batch
+    nb = rows // rpb
+    _need(nb * rpb == rows and out.shape[0] >= nb and out.shape[1] == N, f"colsum_prod: {rows} rows, {rpb} per batch, out {tuple(out.shape)}")
+    prod = a.float()
+    if b is not None:
+        _chk(b, BF16, "b"); _rows(b, "b")
+        _need(tuple(b.shape) == (rows, N), "colsum_prod: b shape")
+        prod = prod * b.float()
+    s = prod.view(nb, rpb, N).sum(dim=1)
+    if mode == 1:
+        _chk(shift, BF16, "shift"); _chk(scale, BF16, "scale"); _chk(prev, F32, "prev")
+        _need(_rows(shift, "shift") == _rows(scale, "scale"), "colsum_prod: shift and scale must share a row stride")
+        sc = 1.0 + scale[:nb].float()
+        sc = torch.where(sc.abs() > 1e-6, sc, torch.where(sc < 0, torch.full_like(sc, -1e-6), torch.full_like(sc, 1e-6)))      # k_colsum_finalize's guard
+        s = (s - shift[:nb].float() * prev[:nb]) / sc
+    if accumulate:
+        s = s + out[:nb]
+    out[:nb] = s
+    return out
+
+
+def transpose(src, out=None):
+    _chk(src, BF16, "src"); _rows(src, "src")
+    R, Cn = src.shape
+    _need(R % 8 == 0 and Cn % 8 == 0, f"transpose: {R} x {Cn} (rows, cols multiples of 8)")
+    if out is None:
+        out = torch.empty(Cn, R, dtype=BF16, device=src.device)
+    _chk(out, BF16, "out"); _rows(out, "out")
+    _need(tuple(out.shape) == (Cn, R), "transpose: out shape")
+    out.copy_(src.t())
+    return out
+
+
+def skinny_tn(Lm, R, out, so_p, so_r, r_used, alpha=1.0, accumulate=False):
+    _chk(Lm, BF16, "L"); _chk(R, BF16, "R"); _chk(out, F32, "out")
+    _seg(Lm, "L"); _seg(R, "R")
+    L2, R2 = _flat(Lm), _flat(R)
+    _need(L2.shape[0] == R2.shape[0] and R2.shape[1] in (32, 64) and r_used <= R2.shape[1], f"skinny_tn: L {tuple(L2.shape)}, R {tuple(R2.shape)}, r_used {r_used}")
+    val = alpha * (L2.t() @ R2[:, :r_used])
+    dst = torch.as_strided(out, (L2.shape[1], r_used), (so_p, so_r))
+    dst.copy_(val + dst if accumulate else val)
+    return out
+
+
+def skinny_tn_multi(Lm, R, outs, so_p, so_r, r_used, alpha=1.0, accumulate=False):
+    L2, R2 = _flat(_seg(Lm, "L")), _flat(_seg(R, "R"))
+    _need(L2.shape[0] == R2.shape[0] and R2.shape[1] >= 128 and 1 <= len(outs) <= 4 and r_used <= 32, "skinny_tn_multi: shapes")
+    for g, o in enumerate(outs):
+        _chk(o, F32, "out")
+        val = alpha * (L2.t() @ R2[:, 32 * g:32 * g + r_used])
+        dst = torch.as_strided(o, (L2.shape[1], r_used), (so_p, so_r))
+        dst.copy_(val + dst if accumulate else val)
+    return outs
+
+
+def lora_pack(A, Bm, scale, A_cat, A_cat_T, B_blk, B_blk_T, k2_off=0, n_off=0):
+    _chk(A, F32, "A"); _chk(Bm, F32, "B")
+    r, K = A.shape
+    N = Bm.shape[0]
+    K2, N_total = A_cat.shape[0], B_blk.shape[0]
+    _need(A_cat.shape == (K2, K) and A_cat_T.shape == (K, K2) and B_blk.shape == (N_total, K2) and B_blk_T.shape == (K2, N_total), "lora_pack: operand shapes inconsistent")
+    A_cat[k2_off:k2_off + r] = A.to(BF16)
+    A_cat_T[:, k2_off:k2_off + r] = A.t().to(BF16)
+    B_blk[n_off:n_off + N, k2_off:k2_off + r] = (scale * Bm).to(BF16)
+    B_blk_T[k2_off:k2_off + r, n_off:n_off + N] = (scale * Bm).t().to(BF16)
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming ops
+# ------------------------------------------------------------------------------------------------
+def timestep_proj(t, dim, scale=1.0):
+    _chk(t, F32, "t")
+    half = dim // 2
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)
+    a = t[:, None] * scale * f[None]
+    return torch.cat([a.cos(), a.sin()], dim=1).to(BF16)
+
+
+def patchify(latents, order=0):
+    """[B,C,H,W] -> [B,(H/2)(W/2),4C]; order 0 = (c,dh,dw) features (Flux pack / PatchEmbed im2col), 1 = (dh,dw,c) (SD3 / PixArt proj_out layout)"""
+    _chk(latents, BF16, "latents")
+    B, Cn, H, W = latents.shape
+    x = latents.reshape(B, Cn, H // 2, 2, W // 2, 2)
+    x = x.permute(0, 2, 4, 1, 3, 5) if order == 0 else x.permute(0, 2, 4, 3, 5, 1)
+    return x.reshape(B, (H // 2) * (W // 2), 4 * Cn).contiguous()
+
+
+def unpatchify(packed, Cc, H, W, order=0):
+    _chk(packed, BF16, "packed")
+    B = packed.shape[0]
+    if order == 0:
+        x = packed.reshape(B, H // 2, W // 2, Cc, 2, 2).permute(0, 3, 1, 4, 2, 5)
+    else:
+        x = packed.reshape(B, H // 2, W // 2, 2, 2, Cc).permute(0, 5, 1, 3, 2, 4)
+    return x.reshape(B, Cc, H, W).contiguous()
+
+
+def silu(x):
+    _chk(x, BF16, "x")
+    f = x.float()
+    return (f * torch.sigmoid(f)).to(BF16)
+
+
+def silu_bwd(x, dy):
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
+    f = x.float()
+    sg = torch.sigmoid(f)
+    return (dy.float() * sg * (1.0 + f * (1.0 - sg))).to(BF16)
+
+
+def add(a, b):
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    return (a.float() + b.float()).to(BF16)
+
+
+def scale_cols(x, gate, rows_per_batch, out=None):
+    _chk(x, BF16, "x"); _chk(gate, BF16, "gate"); _rows(x, "x"); _rows(gate, "gate")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    return _put(out, x.float() * _per_batch(gate, M, rows_per_batch))
+
+
+def gather_rows(x, idx, out=None):
+    _need(x.dtype == BF16 and x.dim() == 3 and idx.dtype == torch.int32 and idx.is_contiguous(), "gather_rows: x [B, S, D] bf16, idx [B, K] contiguous int32")
+    val = torch.gather(x, 1, idx.long()[:, :, None].expand(-1, -1, x.shape[2]))
+    if out is None:
+        return val.contiguous()
+    out.copy_(val)
+    return out
+
+
+def scatter_rows(src, idx, dst):
+    _need(src.dtype == BF16 and dst.dtype == BF16 and src.dim() == 3 and dst.dim() == 3 and idx.dtype == torch.int32, "scatter_rows: operands")
+    dst.scatter_(1, idx.long()[:, :, None].expand(-1, -1, src.shape[2]), src)
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# AdaLN / RMSNorm + RoPE
+# ------------------------------------------------------------------------------------------------
+def _ln_stats(x, eps):
+    mu = x.mean(dim=1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    return (x - mu) * rstd, rstd
+
+
+def ln_modulate_fwd(x, scale, shift, rows_per_batch, eps=1e-6, out=None):
+    _chk(x, BF16, "x"); _chk(scale, BF16, "scale"); _chk(shift, BF16, "shift")
+    _rows(x, "x")
+    _need(_rows(scale, "scale") == _rows(shift, "shift"), "ln_modulate_fwd: scale and shift must share a row stride")
+    rows, D = x.shape
+    xhat, _ = _ln_stats(x.float(), eps)
+    val = xhat * (1.0 + _per_batch(scale, rows, rows_per_batch)) + _per_batch(shift, rows, rows_per_batch)
+    if out is None:
+        out = torch.empty(rows, D, dtype=BF16, device=x.device)
+    _rows(out, "out")
+    return _put(out, val)
+
+
+def layer_norm_xhat(x, eps=1e-6, out=None):
+    z = torch.zeros(1, x.shape[1], dtype=BF16)
+    return ln_modulate_fwd(x, z, z, x.shape[0], eps=eps, out=out)
+
+
+def ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=None, gate=None, eps=1e-6, want_gated=False, out=None):
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(scale, BF16, "scale")
+    _rows(dy, "dy"); _rows(x, "x"); _rows(scale, "scale")
+    rows, D = x.shape
+    _need(tuple(dy.shape) == (rows, D), "ln_modulate_bwd: dy shape")
+    xhat, rstd = _ln_stats(x.float(), eps)
+    g = dy.float() * (1.0 + _per_batch(scale, rows, rows_per_batch))
+    dx = rstd * (g - g.mean(dim=1, keepdim=True) - xhat * (g * xhat).mean(dim=1, keepdim=True))
+    if dres is not None:
+        _chk(dres, BF16, "dres"); _rows(dres, "dres")
+        _need(tuple(dres.shape) == (rows, D), "ln_modulate_bwd: dres shape")
+        dx = dx + dres.float()
+    dst = torch.empty(rows, D, dtype=BF16, device=x.device) if out is None else out
+    _chk(dst, BF16, "out"); _rows(dst, "out")
+    _need(tuple(dst.shape) == (rows, D), "ln_modulate_bwd: out shape mismatch")
+    _put(dst, dx)
+    dxg = None
+    if want_gated:
+        _chk(gate, BF16, "gate"); _rows(gate, "gate")
+        dxg = (dx * _per_batch(gate, rows, rows_per_batch)).to(BF16)
+    return dst, dxg
+
+
+def _rot(x, cos, sin):
+    """o0 = x0 c0 - x1 s0 ; o1 = x1 c1 + x0 s1 on interleaved pairs; cos / sin [T, d] broadcast over [B, T, H, d]"""
+    c, s = cos[None, :, None, :], sin[None, :, None, :]
+    x0, x1 = x[..., 0::2], x[..., 1::2]
+    o = torch.empty_like(x)
+    o[..., 0::2] = x0 * c[..., 0::2] - x1 * s[..., 0::2]
+    o[..., 1::2] = x1 * c[..., 1::2] + x0 * s[..., 1::2]
+    return o
+
+
+def _rot_T(g, cos, sin):
+    """the transpose of _rot: dy0 = g0 c0 + g1 s1 ; dy1 = g1 c1 - g0 s0"""
+    c, s = cos[None, :, None, :], sin[None, :, None, :]
+    g0, g1 = g[..., 0::2], g[..., 1::2]
+    o = torch.empty_like(g)
+    o[..., 0::2] = g0 * c[..., 0::2] + g1 * s[..., 1::2]
+    o[..., 1::2] = g1 * c[..., 1::2] - g0 * s[..., 0::2]
+    return o
+
+
+def _stream_rows(qkv, B, S, pos0, S_part):
+    ld = _rows(qkv, "qkv")
+    _need(qkv.shape[0] >= B * S, f"qkv: {qkv.shape[0]} rows for B * S = {B * S}")
+    return torch.as_strided(qkv, (B, S_part, qkv.shape[1]), (S * ld, ld, 1), qkv.storage_offset() + pos0 * ld)
+
+
+def qk_norm_rope_fwd(qkv, wq, wk, cos, sin, Q, K, Qt, Kt, Vt, B, H, d, S_part, pos0, S, Sp, eps=1e-6):
+    _chk(qkv, BF16, "qkv"); _chk(cos, F32, "cos"); _chk(sin, F32, "sin")
+    _need(d in (64, 128) and pos0 + S_part <= S and cos.shape[1] == d and cos.shape[0] >= pos0 + S_part, "qk_norm_rope_fwd: bad shape")
+    D = H * d
+    rows = _stream_rows(qkv, B, S, pos0, S_part).float()
+    c, s = cos[pos0:pos0 + S_part], sin[pos0:pos0 + S_part]
+    for j, (w, dst, dst_t) in enumerate(((wq, Q, Qt), (wk, K, Kt))):
+        x = rows[..., j * D:(j + 1) * D].reshape(B, S_part, H, d)
+        if w is not None:
+            x = x * torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + eps) * w.float()
+        z = _rot(x, c, s)
+        dst[:, :, pos0:pos0 + S_part] = z.permute(0, 2, 1, 3).to(BF16)
+        if dst_t is not None:
+            dst_t[:, :, :, pos0:pos0 + S_part] = z.permute(0, 2, 3, 1).to(BF16)
+    v = rows[..., 2 * D:3 * D].reshape(B, S_part, H, d)
+    Vt[:, :, :, pos0:pos0 + S_part] = v.permute(0, 2, 3, 1).to(BF16)
+
+
+def qk_norm_rope_bwd_wgrad(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S, gwq, gwk, accumulate=False, eps=1e-6):
+    _chk(dQ, BF16, "dQ"); _chk(dK, BF16, "dK"); _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
+    _need((gwq is None or wq is not None) and (gwk is None or wk is not None), "qk_norm_rope_bwd_wgrad: a weight gradient needs its norm weight")
+    _need(d in (64, 128) and pos0 + S_part <= S and S_part > 0, "qk_norm_rope_bwd: bad shape")
+    D = H * d
+    rows = _stream_rows(qkv, B, S, pos0, S_part).float()
+    drows = _stream_rows(dqkv, B, S, pos0, S_part)
+    c, s = cos[pos0:pos0 + S_part], sin[pos0:pos0 + S_part]
+    for j, (w, g_heads, gw) in enumerate(((wq, dQ, gwq), (wk, dK, gwk))):
+        x = rows[..., j * D:(j + 1) * D].reshape(B, S_part, H, d)
+        g = g_heads[:, :, pos0:pos0 + S_part].float().permute(0, 2, 1, 3)
+        dy = _rot_T(g, c, s)
+        if w is not None:
+            wf = w.float()
+            r = torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + eps)
+            m = (x * wf * dy).mean(dim=-1, keepdim=True)
+            dx = r * wf * dy - x * r ** 3 * m
+            if gw is not None:
+                _chk(gw, BF16, "gw")
+                t = (dy * x * r).sum(dim=(0, 1, 2))
+                gw.copy_((t + gw.float() if accumulate else t).to(BF16))
+        else:
+            dx = dy
+        drows[..., j * D:(j + 1) * D] = dx.reshape(B, S_part, D).to(BF16)
+
+
+def qk_norm_rope_bwd(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S, eps=1e-6):
+    qk_norm_rope_bwd_wgrad(dQ, dK, qkv, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S, None, None, eps=eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _scores(q, k, B, S, scale, key_bias):
+    sc = (q @ k.transpose(-1, -2)) * scale
+    if key_bias is not None:
+        sc = sc + key_bias[:, None, None, :S].float()
+    return sc
+
+
+def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=None):
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    _rows(O, "O")
+    _need(tuple(Q.shape) == (B, H, S, d) and tuple(K.shape) == (B, H, S, d) and tuple(Vt.shape) == (B, H, d, Sp) and Sp % 64 == 0 and Sp >= S, "attn_fwd: shapes")
+    q, k, v = Q.float(), K.float(), Vt[..., :S].float().transpose(-1, -2)
+    sc = _scores(q, k, B, S, scale, key_bias)
+    lse2.copy_(torch.logsumexp(sc, dim=-1) * 1.4426950408889634)
+    o = torch.softmax(sc, dim=-1) @ v                                      # [B, H, S, d]
+    O.view(B, S, -1)[:, :, :H * d] = o.permute(0, 2, 1, 3).reshape(B, S, H * d).to(BF16)
+
+
+def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale, key_bias=None):
+    for t, nm in ((Q, "Q"), (K, "K"), (v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dv_rows, "dv_rows")):
+        _chk(t, BF16, nm)
+    for t, nm in ((v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dv_rows, "dv_rows")):
+        _rows(t, nm)
+        _need(t.shape[0] == B * S and t.shape[1] >= H * d, f"attn_bwd: {nm} is {tuple(t.shape)}")
+    heads = lambda t: t[:, :H * d].reshape(B, S, H, d).permute(0, 2, 1, 3).float()
+    q, k, v = Q.float().requires_grad_(True), K.float().requires_grad_(True), heads(v_rows).requires_grad_(True)
+    with torch.enable_grad():
+        o = torch.softmax(_scores(q, k, B, S, scale, key_bias), dim=-1) @ v
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), heads(dO))
+    dQ.copy_(gq.to(BF16)); dK.copy_(gk.to(BF16))
+    dv_rows[:, :H * d] = gv.permute(0, 2, 1, 3).reshape(B * S, H * d).to(BF16)
+
+
+_EMULATED = ("gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+             "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
+             "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
+
+
+def install(monkeypatch):
+    """replace the emulated wrappers of simpletuner_amd.ops (pytest's monkeypatch restores them); every other wrapper still raises on host tensors"""
+    from simpletuner_amd import ops
+    g = globals()
+    for name in _EMULATED:
+        monkeypatch.setattr(ops, name, g[name])
+    return ops

@@ -1,0 +1,130 @@
+"""The SD3 / SD3.5 engine's HOST SEQUENCING on the CPU (see tests/test_flux_host_sequencing_cpu.py and tests/ops_emulator.py): forward + hand-written backward
+of sd3/transformer.py against the kernel-contract emulator, compared with autograd on the oracle — the LoRA path (pins the emulator on a path the GPU tests
+already prove) and the full fine-tune of BASELINE.json configs[3] (every parameter's gradient, SD3.5 dual attention + q/k RMSNorm weights included)."""
+import pytest
+import torch
+
+from oracle import sd3 as OS
+from tests import ops_emulator as EMU
+from tests import parity_utils as PU
+
+BF16 = torch.bfloat16
+
+
+def _arch(layers, heads=2, head_dim=64, joint_dim=128, pooled=64, qk_norm=None, dual=()):
+    return dict(sample_size=32, num_layers=layers, num_attention_heads=heads, attention_head_dim=head_dim, joint_attention_dim=joint_dim,
+                caption_projection_dim=heads * head_dim, pooled_projection_dim=pooled, pos_embed_max_size=24, qk_norm=qk_norm, dual_attention_layers=tuple(dual))
+
+
+def _ocfg(model):
+    c = model.config
+    return OS.SD3Config(sample_size=c.sample_size, num_layers=c.num_layers, attention_head_dim=c.attention_head_dim,
+                        num_attention_heads=c.num_attention_heads, joint_attention_dim=c.joint_attention_dim,
+                        pooled_projection_dim=c.pooled_projection_dim, pos_embed_max_size=c.pos_embed_max_size, qk_norm=c.qk_norm,
+                        dual_attention_layers=tuple(c.dual_attention_layers))
+
+
+def _model(monkeypatch, layers, sd35=False, seed=11):
+    EMU.install(monkeypatch)
+    from simpletuner_amd.sd3 import transformer as T
+    model = T.SD3Transformer2DModel(device="cpu", **_arch(layers, **(dict(qk_norm="rms_norm", dual=(0, 1)) if sd35 else {})))
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ".norm_q." in name or ".norm_k." in name or ".norm_added_" in name:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith(".bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) / (p[0].numel() ** 0.5))
+        c = model.config
+        model.pos_embed.pos_embed.copy_(T.sincos_2d(model.D, c.pos_embed_max_size, c.sample_size // c.patch_size)[None])
+    return model
+
+
+def _inputs(B, lat_h, lat_w, S_txt, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(BF16)
+    return dict(lat=bf(torch.randn(B, 16, lat_h, lat_w, generator=g)), prompt=bf(torch.randn(B, S_txt, 128, generator=g)), pooled=bf(torch.randn(B, 64, generator=g)),
+                t=(torch.rand(B, generator=g) * 0.8 + 0.1) * 1000.0, target=bf(torch.randn(B, 16, lat_h, lat_w, generator=g)))
+
+
+def _hip_side(model, d):
+    out = model(hidden_states=d["lat"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["t"], return_dict=False)[0]
+    loss = ((out.float() - d["target"].float()) ** 2).mean()
+    loss.backward()
+    return out.detach(), loss.detach()
+
+
+def _oracle_side(model, d, params_need_grad, lora=None, lora_scale=1.0):
+    P, _, _ = PU.oracle_state(model)
+    P = {k: (v.clone().requires_grad_(True) if params_need_grad else v) for k, v in P.items()}
+    P["pos_embed.pos_embed"] = model.pos_embed.pos_embed.detach().float()
+    lp = None if lora is None else {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    out = OS.sd3_forward(P, _ocfg(model), d["lat"].float(), d["prompt"].float(), d["pooled"].float(), d["t"], lora=lp, lora_scale=lora_scale)
+    loss = ((out - d["target"].float()) ** 2).mean()
+    loss.backward()
+    return out.detach(), loss.detach(), P, lp
+
+
+@pytest.mark.parametrize("sd35", [False, True])
+def test_lora_path_through_the_emulator_matches_the_oracle(monkeypatch, sd35):
+    model = _model(monkeypatch, 3, sd35)
+    model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
+    d = _inputs(2, 16, 24, 33)
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        worst = max(worst, PU.rel_l2(p.grad, ref))
+        assert PU.rel_l2(p.grad, ref) < 5e-2, name
+    print(f"[emu] sd3{'.5' if sd35 else ''} LoRA host sequencing: pred rel_l2={PU.rel_l2(out, o_out):.3e}, worst adapter gradient rel_l2={worst:.3e}")
+
+
+@pytest.mark.parametrize("layers,B,lat_h,lat_w,S_txt,sd35", [(2, 1, 16, 16, 40, False), (3, 2, 16, 24, 33, False), (3, 2, 16, 24, 33, True)])
+def test_full_finetune_gradients_of_every_parameter_match_the_oracle(monkeypatch, layers, B, lat_h, lat_w, S_txt, sd35):
+    model = _model(monkeypatch, layers, sd35)
+    model.enable_full_finetune()
+    d = _inputs(B, lat_h, lat_w, S_txt)
+    out, loss = _hip_side(model, d)
+    o_out, o_loss, P, _ = _oracle_side(model, d, True)
+    r = PU.rel_l2(out, o_out)
+    assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    gmax = max(v.grad.norm().item() for k, v in P.items() if k != "pos_embed.pos_embed")
+    worst, checked = (0.0, ""), 0
+    for name, p in model.named_parameters():
+        ref = P[name].grad
+        assert p.grad is not None, name
+        if ref.norm().item() < 1e-3 * gmax:
+            assert p.grad.float().norm().item() < 3e-3 * gmax, name
+            continue
+        rg, cg = PU.rel_l2(p.grad, ref), PU.cos_sim(p.grad, ref)
+        worst = max(worst, (rg, name)); checked += 1
+        assert rg < 6e-2 and cg > 0.998, f"{name}: rel={rg:.3e} cos={cg:.5f} |ref|={ref.norm().item():.3e}"
+    print(f"[emu] sd3{'.5' if sd35 else ''} full fine-tune host sequencing L{layers} B{B}: pred rel_l2={r:.3e}; {checked} tensors, worst gradient rel_l2={worst[0]:.3e} at {worst[1]}")
+    assert checked > 20
+
+
+def test_modulation_scale_gradient_survives_a_scale_entry_of_exactly_minus_one(monkeypatch):
+    """d scale = sum_t dY * LN(x) is computed from LN(x) itself.  The earlier form recovered LN(x) from the saved modulated output as (n - shift) / (1 + scale),
+    which is singular where a modulation scale equals -1 in bf16 — a value random-init tables produce in a few entries per step.  Force one and check."""
+    model = _model(monkeypatch, 2)
+    model.enable_full_finetune()
+    with torch.no_grad():            # bias of block 0's norm1 scale_msa chunk, channel 5: large negative weight row zeroed, bias -1 => scale == -1 for every sample
+        blk = model.blocks[0]
+        D = model.D
+        model.mod_w[blk.mod_off + D + 5].zero_()
+        model.mod_b[blk.mod_off + D + 5] = -1.0
+    d = _inputs(2, 16, 16, 24)
+    _hip_side(model, d)
+    _, _, P, _ = _oracle_side(model, d, True)
+    name = "transformer_blocks.0.norm1.linear.bias"
+    got, ref = dict(model.named_parameters())[name].grad, P[name].grad
+    assert torch.isfinite(got.float()).all()
+    assert PU.rel_l2(got, ref) < 6e-2, PU.rel_l2(got, ref)
