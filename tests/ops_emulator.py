@@ -457,7 +457,60 @@ def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d,
     dv_rows[:, :H * d] = gv.permute(0, 2, 1, 3).reshape(B * S, H * d).to(BF16)
 
 
-_EMULATED = ("gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale, key_bias=None):
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    _rows(O, "O")
+    _need(tuple(Q.shape) == (B, H, Sq, d) and tuple(K.shape) == (B, H, Sk, d) and tuple(Vt.shape) == (B, H, d, Skp) and Skp % 64 == 0 and Skp >= Sk, "attn_cross_fwd: shapes")
+    sc = _scores(Q.float(), K.float(), B, Sk, scale, key_bias)
+    lse2.copy_(torch.logsumexp(sc, dim=-1) * 1.4426950408889634)
+    o = torch.softmax(sc, dim=-1) @ Vt[..., :Sk].float().transpose(-1, -2)
+    O[:, :H * d] = o.permute(0, 2, 1, 3).reshape(B * Sq, H * d).to(BF16)
+
+
+def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=None):
+    for t, nm in ((Q, "Q"), (K, "K"), (v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dv_rows, "dv_rows")):
+        _chk(t, BF16, nm)
+    for t, nm, n in ((v_rows, "v_rows", Sk), (O, "O", Sq), (dO, "dO", Sq), (dv_rows, "dv_rows", Sk)):
+        _rows(t, nm)
+        _need(t.shape[0] == B * n and t.shape[1] >= H * d, f"attn_cross_bwd: {nm} is {tuple(t.shape)}")
+    heads = lambda t, n: t[:, :H * d].reshape(B, n, H, d).permute(0, 2, 1, 3).float()
+    q, k, v = Q.float().requires_grad_(True), K.float().requires_grad_(True), heads(v_rows, Sk).requires_grad_(True)
+    with torch.enable_grad():
+        o = torch.softmax(_scores(q, k, B, Sk, scale, key_bias), dim=-1) @ v
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), heads(dO, Sq))
+    dQ.copy_(gq.to(BF16)); dK.copy_(gk.to(BF16))
+    dv_rows[:, :H * d] = gv.permute(0, 2, 1, 3).reshape(B * Sk, H * d).to(BF16)
+
+
+def head_split(src, B, H, d, S, want_x=True, want_xt=True, d_src=None):
+    """src [B*S, H*d_src] (row stride free) -> (X [B,H,S,d] | None, Xt [B,H,d,Sp] | None, Sp); d_src < d: zero-padded heads"""
+    _chk(src, BF16, "src"); _rows(src, "src")
+    ds = d if d_src is None else d_src
+    _need(src.shape[0] == B * S and src.shape[1] >= H * ds, f"head_split: src {tuple(src.shape)}")
+    Sp = (S + 63) // 64 * 64
+    x = torch.zeros(B, H, S, d, dtype=BF16)
+    x[..., :ds] = src[:, :H * ds].reshape(B, S, H, ds).permute(0, 2, 1, 3)
+    Xt = None
+    if want_xt:
+        Xt = torch.zeros(B, H, d, Sp, dtype=BF16)
+        Xt[..., :S] = x.transpose(-1, -2)
+    return (x if want_x else None), Xt, Sp
+
+
+def head_merge(dX, dst, B, H, d, S, d_src=None):
+    _chk(dX, BF16, "dX"); _chk(dst, BF16, "dst"); _rows(dst, "dst")
+    ds = d if d_src is None else d_src
+    _need(tuple(dX.shape) == (B, H, S, d) and dst.shape[0] == B * S and dst.shape[1] >= H * ds, "head_merge: shapes")
+    dst[:, :H * ds] = dX[..., :ds].permute(0, 2, 1, 3).reshape(B * S, H * ds)
+    return dst
+
+
+def gelu_tanh(x):
+    _chk(x, BF16, "x")
+    return _gelu(x.float()).to(BF16)
+
+
+_EMULATED = ("attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
 
