@@ -49,6 +49,23 @@ def _seg(t, name):
     return t
 
 
+def _al(t, nbytes, name):
+    """pointer alignment the C entry points require (host allocations are 64-byte aligned, so a view's offset decides, as on the device)"""
+    _need(t.data_ptr() % nbytes == 0, f"{name}: pointer not {nbytes}-byte aligned")
+
+
+def _ld(t, mult, name):
+    """leading dimension (row stride in elements) of a 2-D / segmented operand must be a multiple of `mult`"""
+    ld = t.stride(-2)
+    _need(ld % mult == 0, f"{name}: leading dimension {ld} is not a multiple of {mult}")
+    return ld
+
+
+def _segcheck(t, M, name):
+    if t.dim() == 3:
+        _need(t.shape[1] % 256 == 0 and M % t.shape[1] == 0 and t.stride(0) // t.stride(1) >= t.shape[1], f"{name}: seg_rows {t.shape[1]} must be a multiple of 256 dividing M = {M}")
+
+
 def _flat(t):
     return t.reshape(-1, t.shape[-1]).float()
 
@@ -88,9 +105,13 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out
     N = w.shape[0]
     _need(w.shape[1] == K, f"gemm: K mismatch {K} vs {w.shape[1]}")
     _need(K % 64 == 0, f"gemm: K = {K} is not a multiple of 64")
+    _need(N % 4 == 0, f"gemm: N = {N} must be a multiple of 4")
+    _al(a, 16, "a"); _al(w, 16, "w"); lda = _ld(a, 8, "a"); ldb = _ld(w, 8, "w"); _segcheck(a, M, "a")
+    _need(256 * max(lda, ldb) * 2 + K * 2 < (1 << 31), "gemm: a 256-row tile must fit 32-bit buffer offsets")
     acc = A @ w.float().t()
     if a2 is not None:
         _chk(a2, BF16, "a2"); _chk(b2, BF16, "b2"); _seg(a2, "a2"); _rows(b2, "b2")
+        _al(a2, 16, "a2"); _al(b2, 16, "b2"); _ld(a2, 8, "a2"); _ld(b2, 8, "b2"); _segcheck(a2, M, "a2")
         A2 = _flat(a2)
         _need(A2.shape[0] == M and b2.shape == (N, A2.shape[1]) and A2.shape[1] % 64 == 0, "gemm: low-rank / second-segment shape mismatch")
         acc = acc + A2 @ b2.float().t()
@@ -102,12 +123,15 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk(out, BF16, "out"); _seg(out, "out")
     _need(out.numel() == M * N and out.shape[-1] == N, f"gemm: out is {tuple(out.shape)}, expected {M}x{N}")
+    _al(out, 8, "out"); _ld(out, 4, "out"); _segcheck(out, M, "out")
     if aux_in is not None:
         _chk(aux_in, BF16, "aux_in"); _seg(aux_in, "aux_in")
         _need(aux_in.numel() == M * N, "gemm: aux_in shape")
+        _ld(aux_in, 4, "aux_in"); _segcheck(aux_in, M, "aux_in")
     if aux_out is not None:
         _chk(aux_out, BF16, "aux_out"); _seg(aux_out, "aux_out")
         _need(aux_out.numel() == M * N, "gemm: aux_out shape")
+        _ld(aux_out, 4, "aux_out"); _segcheck(aux_out, M, "aux_out")
     if epilogue == EPI_NONE:
         val = acc
     elif epilogue == EPI_ADD:
@@ -144,12 +168,16 @@ def gemm_tn(Lm, R, out=None, accumulate=False):
     M, P = Lm.shape
     _need(R.shape[0] == M, "gemm_tn: operands must share the contraction length")
     _need(M % 64 == 0, f"gemm_tn: contraction length {M} is not a multiple of 64 (zero-pad the rows)")
+    _need(P % 8 == 0 and R.shape[1] % 8 == 0, "gemm_tn: P, Q must be multiples of 8")
+    _al(Lm, 16, "L"); _al(R, 16, "R")
+    _need(M * max(_ld(Lm, 8, "L"), _ld(R, 8, "R")) * 2 < (1 << 31), "gemm_tn: operand too large for the 32-bit buffer offsets (2 GiB)")
     val = Lm.float().t() @ R.float()
     if out is None:
         _need(not accumulate, "gemm_tn: accumulate needs an output tensor")
         out = torch.empty(P, R.shape[1], dtype=BF16, device=Lm.device)
     _chk(out, BF16, "out"); _rows(out, "out")
     _need(tuple(out.shape) == (P, R.shape[1]), f"gemm_tn: out is {tuple(out.shape)}, expected {(P, R.shape[1])}")
+    _al(out, 16, "out"); _ld(out, 8, "out")
     if accumulate:
         val = val + out.float()
     return _put(out, val)
@@ -161,9 +189,10 @@ def colsum_prod(a, out, b=None, rows_per_batch=None, mode=0, prev=None, shift=No
     rpb = rows if rows_per_batch is None else rows_per_batch
     nb = rows // rpb
     _need(nb * rpb == rows and out.shape[0] >= nb and out.shape[1] == N, f"colsum_prod: {rows} rows, {rpb} per batch, out {tuple(out.shape)}")
+    _need(N % 8 == 0, "colsum_prod: N must be a multiple of 8"); _al(a, 16, "a"); _ld(a, 8, "a")
     prod = a.float()
     if b is not None:
-        _chk(b, BF16, "b"); _rows(b, "b")
+        _chk(b, BF16, "b"); _rows(b, "b"); _al(b, 16, "b"); _ld(b, 8, "b")
         _need(tuple(b.shape) == (rows, N), "colsum_prod: b shape")
         prod = prod * b.float()
     s = prod.view(nb, rpb, N).sum(dim=1)
@@ -311,6 +340,7 @@ def ln_modulate_fwd(x, scale, shift, rows_per_batch, eps=1e-6, out=None):
     _rows(x, "x")
     _need(_rows(scale, "scale") == _rows(shift, "shift"), "ln_modulate_fwd: scale and shift must share a row stride")
     rows, D = x.shape
+    _need(D % 8 == 0 and D <= 4096, "ln_modulate_fwd: D"); _ld(x, 8, "x"); _ld(scale, 8, "scale")
     xhat, _ = _ln_stats(x.float(), eps)
     val = xhat * (1.0 + _per_batch(scale, rows, rows_per_batch)) + _per_batch(shift, rows, rows_per_batch)
     if out is None:
@@ -329,6 +359,7 @@ def ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=None, gate=None, eps=1e-6
     _rows(dy, "dy"); _rows(x, "x"); _rows(scale, "scale")
     rows, D = x.shape
     _need(tuple(dy.shape) == (rows, D), "ln_modulate_bwd: dy shape")
+    _need(D % 8 == 0 and D <= 4096, "ln_modulate_bwd: D"); _ld(x, 8, "x"); _ld(dy, 8, "dy"); _ld(scale, 8, "scale")
     xhat, rstd = _ln_stats(x.float(), eps)
     g = dy.float() * (1.0 + _per_batch(scale, rows, rows_per_batch))
     dx = rstd * (g - g.mean(dim=1, keepdim=True) - xhat * (g * xhat).mean(dim=1, keepdim=True))
