@@ -587,7 +587,8 @@ def run_workload(args, dev, rank, world):
         if args.model not in ("sd3", "sdxl", "sd15", "flux"):
             raise SystemExit("--full is wired for --model flux / sd3 / sdxl / sd15")
         plugin.enable_full_finetune()
-        n_par = sum(p.numel() for p in plugin.get_trained_component().trainable_parameters())
+        comp_ = plugin.get_trained_component()
+        n_par = sum(p.numel() for p in (comp_.trainable_parameters() if hasattr(comp_, "trainable_parameters") else [q for q in comp_.parameters() if q.requires_grad]))
         desc = desc.replace(f"LoRA r{args.rank} on attn to_q/to_k/to_v/to_out.0", f"FULL-rank training ({n_par / 1e9:.1f} B bf16 params){' + EMA' if cfg.use_ema else ''}")
     elif args.model != "pixart":
         plugin.add_lora_adapter()
@@ -727,6 +728,7 @@ def run_workload(args, dev, rank, world):
             "step_model_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
             "roofline": roof,
             "kernels": kernels,
             "cpu_baseline": None,
@@ -738,6 +740,11 @@ def run_workload(args, dev, rank, world):
             out["published"] = {"row": f"SD3 LoRA r128 1024^2 bs 3, bf16, checkpointing mode {pub[0]!r} (example sd3.peft-lora; its optimizer is adamw_bf16, here fp32 AdamW on an fp32 adapter arena)", "sec_per_step": pub[1],
                                 "images_per_s": round(ref_ips, 3), "hardware": "1x H100 (the reference's own sweep; BASELINE.md §1)",
                                 "source": "documentation/experimental/SEGMENTED_CHECKPOINTING.md:795-805", "this_run_sec_per_step": round(ms_per_step / 1e3, 4)}
+        if args.model == "flux" and args.full:
+            # context only (vs_baseline stays null: a 32-GPU multi-node DeepSpeed figure incl. its inter-node exchange is not this configuration)
+            out["published_context"] = {"row": "Flux.1-dev (12B) full-rank, 1024 px buckets, batch 8 per accelerator, 4 nodes x 8 H100 SXM5, DeepSpeed: 15 s/step (anecdotal)",
+                                        "images_per_s_per_gpu": round(8 / 15.0, 3), "source": "documentation/DISTRIBUTED.md:291-298 (BASELINE.md section 1)",
+                                        "this_run_images_per_s_per_gpu": round(value / world, 3)}
         if world == 1 and not args.no_cpu_baseline and args.model == "flux":
             del trainer, plugin, batches
             torch.cuda.empty_cache()
