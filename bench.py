@@ -111,7 +111,7 @@ def parse():
     ap.add_argument("--ckpt-interval", type=int, default=None)
     ap.add_argument("--ckpt-stride", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA and SD3 full-fine-tune (mixed buckets) secondary measurements appended to the default line")
+    ap.add_argument("--no-secondary", action="store_true", help="flux only: skip the SDXL-LoRA, SD3 full-fine-tune (mixed buckets) and Flux full-rank secondary measurements appended to the default line")
     ap.add_argument("--prof-dump", default=None, help="write one CSV line per launch of the timed steps (class,ms,flops,bytes,shape)")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-launch hipEvent profiler (roofline becomes null)")
     a = ap.parse_args()
@@ -453,17 +453,25 @@ def main():
         import copy
         import gc
         keys = ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config", "step_model_tflops", "step_frac_of_bf16_mfma_peak",
-                "roofline", "loss")
+                "roofline", "loss", "peak_hbm_gib", "published_context")
         a2 = copy.copy(args)
         a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
         a3 = copy.copy(args)
         a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
+        # Flux.1-dev FULL-rank (11.9 B bf16 parameters, AdamWBF16, per-GPU batch 8 — the configuration of the reference's multi-GPU Flux datapoint,
+        # documentation/DISTRIBUTED.md:291-298): hand-written backward with every weight / bias / modulation / norm gradient, one fused optimizer launch over the
+        # parameter arena, and at N > 1 the whole 24 GB bf16 gradient arena exchanged per step (fp32-accumulating reduce-scatter + all-gather buckets behind the
+        # backward).  Checkpoint plan interval 3 / stride 4: three of every four blocks are recomputed, the fourth keeps its activations (peak 211 GiB of 268)
+        a4 = copy.copy(args)
+        a4.model, a4.lora, a4.rank, a4.batch, a4.full, a4.graph, a4.buckets = "flux", False, 32, 8, True, False, False
         if rank == 0:
             out["secondary"] = {}
-        for name, a_ in (("sdxl_lora", a2), ("sd3_full_buckets", a3)):
+        for name, a_ in (("sdxl_lora", a2), ("sd3_full_buckets", a3), ("flux_full_rank", a4)):
             a_.steps, a_.warmup, a_.no_cpu_baseline, a_.prof_dump, a_.fp8, a_.gradient_checkpointing = min(args.steps, 5), 2, True, None, False, False
+            if name == "flux_full_rank":
+                a_.steps, a_.warmup, a_.optimizer, a_.gradient_checkpointing, a_.ckpt_interval, a_.ckpt_stride = min(args.steps, 3), 1, "adamw_bf16", True, 3, 4
             gc.collect()
             torch.cuda.empty_cache()              # the previous workload's cached blocks go back before the next one's pools are built
             try:                                  # a secondary must never take the headline line down with it (every rank runs the same code: they fail together)
@@ -471,7 +479,7 @@ def main():
                     _log(f"secondary {name}")
                 sec = run_workload(a_, dev, rank, world)
                 if rank == 0:
-                    out["secondary"][name] = {k: sec[k] for k in keys}
+                    out["secondary"][name] = {k: sec[k] for k in keys if k in sec}
                 del sec
             except Exception as e:                # noqa: BLE001
                 if rank == 0:
@@ -506,6 +514,7 @@ def main():
 
 def run_workload(args, dev, rank, world):
     """build one workload, run warmup + timed steps, return the JSON dict on rank 0 (None elsewhere)"""
+    torch.cuda.reset_peak_memory_stats(dev)          # `peak_hbm_gib` is per workload
     from simpletuner_amd import ops
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
