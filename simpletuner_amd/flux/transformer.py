@@ -767,11 +767,11 @@ class FluxTransformer2DModel(nn.Module):
 
         def end_route(img_r, g):
             """the processed kept tokens [B*K, D] back into their slots of the stream as it was at the route's start (TREADRouter.end_route)"""
-            full = rt.saved.clone()
-            ops.scatter_rows(img_r.view(B, rt.env.Si, D), rt.info.keep_i32(), full.view(B, Si, D))
+            whole = rt.saved.clone()
+            ops.scatter_rows(img_r.view(B, rt.env.Si, D), rt.info.keep_i32(), whole.view(B, Si, D))
             ctx.route_end[g] = rt.info
             rt.info, rt.saved, rt.env, rt.ptr = None, None, env, rt.ptr + 1
-            return full
+            return whole
 
         def starts(g):
             return rt.ptr < len(routes) and rt.info is None and g == routes[rt.ptr]["start_layer_idx"]
@@ -795,8 +795,8 @@ class FluxTransformer2DModel(nn.Module):
                     if x is not None:                         # the last double block wrote the joint [txt || kept img] sequence: re-open it
                         xv = x.view(B, rt.env.S, D)
                         t_part = xv[:, :St]
-                        full = end_route(xv[:, St:].contiguous().view(-1, D), bi)
-                        x = torch.cat([t_part, full.view(B, Si, D)], dim=1).reshape(B * S, D)
+                        restored = end_route(xv[:, St:].contiguous().view(-1, D), bi)
+                        x = torch.cat([t_part, restored.view(B, Si, D)], dim=1).reshape(B * S, D)
                     else:
                         img = end_route(img, bi)
         # ---- joint sequence [txt || img] (flux/transformer.py:1332): written in place by the last double block ----
@@ -820,8 +820,8 @@ class FluxTransformer2DModel(nn.Module):
                 if ends(g):
                     xv = x.view(B, rt.env.S, D)
                     t_part = xv[:, :St]
-                    full = end_route(xv[:, St:].contiguous().view(-1, D), g)
-                    x = torch.cat([t_part, full.view(B, Si, D)], dim=1).reshape(B * S, D)
+                    restored = end_route(xv[:, St:].contiguous().view(-1, D), g)
+                    x = torch.cat([t_part, restored.view(B, Si, D)], dim=1).reshape(B * S, D)
         if rt.info is not None:
             raise ValueError("TREAD route does not end inside the block stack (end_layer_idx)")
         # ---- output head (flux/transformer.py:1501-1506): AdaLayerNormContinuous chunk order is (scale, shift) ----

@@ -140,3 +140,45 @@ def test_full_rank_parameters_are_one_contiguous_run_and_the_fused_optimizer_wou
     assert sum(p.numel() for p in params) == model.arena.numel() == model.grad_arena.numel()
     _hip_side(model, _inputs(1, 8, 8, 24))
     assert _contiguous_run([p.grad for p in params])                 # views of ONE private copy of the gradient arena, in arena order
+
+
+@pytest.mark.parametrize("start,end,ckpt", [(1, 2, False), (1, -2, True), (3, 5, False), (4, -1, False), (0, 1, True)])
+def test_tread_routing_through_the_emulator_matches_the_oracle(monkeypatch, start, end, ckpt):
+    """the routes of tests/test_flux_model_gpu.py::test_flux_tread_routing_matches_oracle on the CPU: 3 double + 4 single blocks, half of the image tokens routed
+    around blocks [start, end] (inside the double stack ending on its last block, across the double / single boundary, starting on single block 0, ending on the
+    last block, starting on block 0); LoRA gradients vs the oracle replaying the same permutation; with per-block recomputation the result is bit-identical"""
+    from simpletuner_amd.training.tread import ReplayRouter
+    d = _inputs(2, 16, 16, 32)
+    B, Si = 2, 64
+    g = torch.Generator().manual_seed(17)
+    perm = torch.stack([torch.randperm(Si, generator=g) for _ in range(B)])
+    K = Si - int(round(Si * 0.5))
+    rec = {"mask": torch.ones(B, Si, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+           "ids_restore": torch.argsort(perm, dim=1)}
+    routes = [{"selection_ratio": 0.5, "start_layer_idx": start, "end_layer_idx": end}]
+
+    def run(with_ckpt):
+        model = _model(monkeypatch, 3, 4)
+        model.add_lora_adapter(rank=8, alpha=8.0, targets="default", init_b_std=0.02)
+        model.set_router(ReplayRouter([rec]), routes)
+        model.train()
+        if with_ckpt:
+            model.enable_gradient_checkpointing()
+        out, loss = _hip_side(model, d)
+        return model, out, loss, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}
+
+    model, out, loss, grads = run(False)
+    P, lora, scale = PU.oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    f = lambda k: d[k].float()
+    o_out = OF.flux_forward(P, PU.oracle_cfg(model), f("packed"), f("prompt"), f("pooled"), d["t"], d["img_ids"], d["txt_ids"], d["guidance"], lp, scale,
+                            tread={"routes": routes, "mask_infos": [rec]})
+    o_loss = ((o_out - f("target")) ** 2).mean()
+    o_loss.backward()
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    for name, g_ in grads.items():
+        ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+        assert PU.rel_l2(g_, ref) < 5e-2, (name, PU.rel_l2(g_, ref))
+    if ckpt:
+        _, out_c, _, grads_c = run(True)
+        assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
