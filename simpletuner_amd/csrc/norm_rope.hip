@@ -528,7 +528,22 @@ __global__ void __launch_bounds__(256) k_qk_norm_rope_bwd(const bf16* __restrict
   }
 }
 
-// out[w][ch] (+)= sum over the workgroups (index order) of the partials above.  grid = 2 (q, k), HD threads x 4 interleaved partial chains
+// first level of the reduction over the workgroups' partials: slice `blockIdx.y` of weight `blockIdx.x` (q, k) sums its `per` consecutive partials (4 interleaved
+// chains, fixed order) into part2[w][slice][ch].  A Flux.1 block at batch 8 leaves 13 824 partials per weight: walked by the two workgroups of the final kernel alone
+// that was 0.96 ms per call (rocprofv3, r03r: 72 ms per full-rank step); 64 slices x 2 weights put it on 128 CUs.
+template <int HD>
+__global__ void k_qk_norm_wgrad_slices(const float* __restrict__ part, int nblk, int per, float* __restrict__ part2) {
+  __shared__ float red[4][HD];
+  const int ch = threadIdx.x % HD, k = threadIdx.x / HD, w = blockIdx.x, sl = blockIdx.y, ns = gridDim.y;
+  const int i0 = sl * per, i1 = min(nblk, i0 + per);
+  float s = 0.f;
+  for (int i = i0 + k; i < i1; i += 4) s += part[((int64_t)w * nblk + i) * HD + ch];
+  red[k][ch] = s;
+  __syncthreads();
+  if (k == 0) part2[((int64_t)w * ns + sl) * HD + ch] = ((red[0][ch] + red[1][ch]) + red[2][ch]) + red[3][ch];
+}
+
+// out[w][ch] (+)= sum over the slices (index order) of the sums above.  grid = 2 (q, k), HD threads x 4 interleaved partial chains
 template <int HD>
 __global__ void k_qk_norm_wgrad_final(const float* __restrict__ part, int nblk, bf16* __restrict__ gwq, bf16* __restrict__ gwk, int accumulate) {
   __shared__ float red[4][HD];
@@ -567,7 +582,7 @@ extern "C" int st355_qk_norm_rope_bwd(void* stream, const void* dQ, const void* 
 // the same backward, also producing d loss / d (norm_q.weight, norm_k.weight) (sd3/transformer.py:155-165 q/k RMSNorm of SD3.5; the weights train in a full
 // fine-tune): workspace = st355_qk_norm_wgrad_workspace(B, H, d, S_part) bytes of fp32 partials; gwq / gwk bf16 [d] (NULL: that weight is absent / frozen)
 extern "C" size_t st355_qk_norm_wgrad_workspace(int B, int H, int d, int S_part) {
-  return (size_t)2 * ((size_t)(S_part + 63) / 64) * H * B * d * sizeof(float);
+  return ((size_t)2 * ((size_t)(S_part + 63) / 64) * H * B + (size_t)2 * 64) * d * sizeof(float);        // per-workgroup partials + the <= 64 slice sums per weight
 }
 extern "C" int st355_qk_norm_rope_bwd_wgrad(void* stream, const void* dQ, const void* dK, const void* qkv, int64_t ld_qkv, const void* wq,
                                             const void* wk, const float* cos, const float* sin, void* dqkv, int64_t ld_dqkv, int B, int H,
@@ -580,14 +595,19 @@ extern "C" int st355_qk_norm_rope_bwd_wgrad(void* stream, const void* dQ, const 
   ProfScope ps(stream, ST355_K_QK_ROPE, 34.0 * n, 12.0 * n);
   dim3 grid((S_part + 63) / 64, H, B), block(256);
   const int nblk = (int)(grid.x * grid.y * grid.z);
+  // two-level fixed-order reduction of the nblk per-workgroup partials: <= 64 slices per weight, then the slices
+  const int ns = nblk < 64 * 32 ? (nblk + 31) / 32 : 64, per = (nblk + ns - 1) / ns;
+  float* part2 = (float*)workspace + (size_t)2 * nblk * d;
   if (d == 128) {
     hipLaunchKernelGGL(k_qk_norm_rope_bwd<128>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK, (const bf16*)qkv, ld_qkv,
                        (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)workspace);
-    hipLaunchKernelGGL(k_qk_norm_wgrad_final<128>, dim3(2), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, nblk, (bf16*)gwq, (bf16*)gwk, accumulate);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_slices<128>, dim3(2, ns), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, nblk, per, part2);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_final<128>, dim3(2), dim3(512), 0, (hipStream_t)stream, (const float*)part2, ns, (bf16*)gwq, (bf16*)gwk, accumulate);
   } else {
     hipLaunchKernelGGL(k_qk_norm_rope_bwd<64>, grid, block, 0, (hipStream_t)stream, (const bf16*)dQ, (const bf16*)dK, (const bf16*)qkv, ld_qkv,
                        (const bf16*)wq, (const bf16*)wk, cos, sin, (bf16*)dqkv, ld_dqkv, H, S_part, pos0, S, eps, (float*)workspace);
-    hipLaunchKernelGGL(k_qk_norm_wgrad_final<64>, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, (bf16*)gwq, (bf16*)gwk, accumulate);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_slices<64>, dim3(2, ns), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, per, part2);
+    hipLaunchKernelGGL(k_qk_norm_wgrad_final<64>, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, ns, (bf16*)gwq, (bf16*)gwk, accumulate);
   }
   return st355_check_launch("qk_norm_rope_bwd_wgrad");
 }
