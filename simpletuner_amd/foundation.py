@@ -435,6 +435,13 @@ class ModelFoundation(ExplorativeModelingMixin):
             for n, p_ in self.unwrap_model(self.model).named_parameters():
                 if ".lora_" not in n:
                     p_.requires_grad_(False)
+        elif str(getattr(self.config, "model_type", "lora")) == "full" and self.model is not None:
+            # the reference leaves a full-rank model as diffusers loaded it — every parameter trainable — and `Trainer._get_trainable_parameters` collects
+            # `requires_grad` parameters (trainer.py:3668-3673).  Here trainability is a mode of the component (gradient arena + full backward): entered at the same
+            # point of the lifecycle, so an unmodified Trainer needs no extra call
+            comp = self.unwrap_model(self.model)
+            if hasattr(comp, "enable_full_finetune") and not getattr(comp, "full", False):
+                comp.enable_full_finetune()
 
     def pre_ema_creation(self):
         """common.py:2125: the reference fuses qkv here so EMA shapes line up; fused storage is the only layout on this path"""

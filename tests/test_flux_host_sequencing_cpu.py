@@ -182,3 +182,23 @@ def test_tread_routing_through_the_emulator_matches_the_oracle(monkeypatch, star
     if ckpt:
         _, out_c, _, grads_c = run(True)
         assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+
+
+def test_model_type_full_enters_full_rank_training_at_freeze_components(monkeypatch):
+    """the reference Trainer never asks for full-rank training explicitly: the loaded model simply has every parameter trainable and `freeze_components()` freezes
+    nothing for model_type == "full" (common.py:3700-3709; trainer.py:3668-3673 collects `requires_grad` parameters).  The plugin enters the mode at that call."""
+    from types import SimpleNamespace
+    EMU.install(monkeypatch)
+    from simpletuner_amd.flux import transformer as T
+    from simpletuner_amd.flux.model import Flux
+    monkeypatch.setattr(T, "_FUSED_QKV", False); monkeypatch.setattr(T, "_BLOCK_ABI", False)
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    plug = Flux(SimpleNamespace(model_type="full", model_family="flux", seed=3), acc)
+    plug.model = T.FluxTransformer2DModel(device="cpu", **PU.small_flux_cfg(layers=1, single=1))
+    assert not any(p.requires_grad for p in plug.model.parameters())
+    plug.freeze_components()
+    comp = plug.get_trained_component()
+    assert comp.full and all(p.requires_grad for p in comp.parameters())
+    assert [id(p) for p in comp.trainable_parameters()] == [id(p) for p in sorted(comp.parameters(), key=lambda q: q.data_ptr())]
+    plug.freeze_components()                                   # idempotent
+    assert comp.full
