@@ -541,7 +541,244 @@ def gelu_tanh(x):
     return _gelu(x.float()).to(BF16)
 
 
-_EMULATED = ("attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+# ------------------------------------------------------------------------------------------------
+# UNet path: zero-bordered NHWC grid buffers ([B*(H+2)*(W+2) + 64, C]; st355.h), convolution-as-GEMM, GroupNorm, GEGLU, affine LayerNorm
+# ------------------------------------------------------------------------------------------------
+def grid_rows(B, H, W):
+    return B * (H + 2) * (W + 2) + 64
+
+
+def _interior(g, B, H, W, reads_borders=True):
+    """grid [rows, C] -> fp32 [B, H, W, C] (the image positions).  reads_borders: the kernel being emulated reads border / tail rows as the zero padding of its
+    shifted taps (convolutions, GroupNorm statistics over whole rows ...), so they must hold zero; gather-form kernels only touch image positions"""
+    _chk(g, BF16, "grid"); _rows(g, "grid")
+    _need(g.shape[0] == grid_rows(B, H, W), f"grid: {g.shape[0]} rows, a ({B},{H},{W}) grid has {grid_rows(B, H, W)}")
+    n = B * (H + 2) * (W + 2)
+    full = g[:n].reshape(B, H + 2, W + 2, g.shape[1]).float()
+    if reads_borders:
+        border = full.clone(); border[:, 1:H + 1, 1:W + 1] = 0
+        _need(float(border.abs().max()) == 0.0 and float(g[n:].float().abs().max()) == 0.0, "grid: border / tail positions must hold zero")
+    return full[:, 1:H + 1, 1:W + 1]
+
+
+def _to_grid(img, out=None):
+    """fp32 [B, H, W, C] -> grid buffer (borders and the 64 tail rows zero)"""
+    B, H, W, Cn = img.shape
+    g = torch.zeros(grid_rows(B, H, W), Cn, dtype=BF16) if out is None else out
+    if out is not None:
+        _chk(out, BF16, "out"); _need(tuple(out.shape) == (grid_rows(B, H, W), Cn), "grid out shape")
+        out.zero_()
+    g[:B * (H + 2) * (W + 2)].view(B, H + 2, W + 2, Cn)[:, 1:H + 1, 1:W + 1] = img.to(BF16)
+    return g
+
+
+def grid_zeros(B, H, W, C_, device, pool=False):
+    return torch.zeros(grid_rows(B, H, W), C_, dtype=BF16)
+
+
+def grid_from_nchw(x, Cpad):
+    _chk(x, BF16, "x")
+    B, Cn, H, W = x.shape
+    img = torch.zeros(B, H, W, Cpad)
+    img[..., :Cn] = x.float().permute(0, 2, 3, 1)
+    return _to_grid(img)
+
+
+def grid_to_nchw(g, B, Cn, H, W):
+    return _interior(g, B, H, W)[..., :Cn].permute(0, 3, 1, 2).contiguous().to(BF16)
+
+
+def tokens_to_grid(tokens, B, H, W, residual=None):
+    _chk(tokens, BF16, "tokens"); _rows(tokens, "tokens")
+    _need(tokens.shape[0] == B * H * W, "tokens_to_grid: rows")
+    img = tokens.float().reshape(B, H, W, -1)
+    if residual is not None:
+        img = img + _interior(residual, B, H, W)
+    return _to_grid(img)
+
+
+def grid_to_tokens(g, B, H, W):
+    return _interior(g, B, H, W).reshape(B * H * W, -1).to(BF16)
+
+
+def conv(x, w, B, H, W, bias=None, img_add=None, residual=None, taps=9, out=None):
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    Cin, Cout = x.shape[1], w.shape[0]
+    _need(taps in (1, 9) and w.shape[1] == taps * Cin and w.is_contiguous() and x.is_contiguous(), f"conv: weight {tuple(w.shape)} vs taps*Cin = {taps}*{Cin}")
+    _need(Cin % 64 == 0 and Cout % 8 == 0, f"conv: Cin ({Cin}) must be a multiple of 64 and Cout ({Cout}) of 8")
+    _al(x, 16, "x"); _al(w, 16, "w")
+    xi = _interior(x, B, H, W)
+    if taps == 9:
+        wt = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        y = torch.nn.functional.conv2d(xi.permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
+    else:
+        y = xi @ w.float().t()
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+        y = y + bias.float()
+    if img_add is not None:
+        _chk(img_add, BF16, "img_add"); _rows(img_add, "img_add")
+        _need(img_add.shape[0] >= B and img_add.shape[1] >= Cout, "conv: img_add rows")
+        y = y + img_add[:B, :Cout].float()[:, None, None, :]
+    if residual is not None:
+        y = y + _interior(residual, B, H, W)
+    return _to_grid(y, out)
+
+
+def conv_wgrad(x, dy, dw, B, H, W, taps=9, accumulate=False):
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(dw, BF16, "dw")
+    Cin, Cout = x.shape[1], dy.shape[1]
+    _need(tuple(dw.shape) == (Cout, taps * Cin) and dw.is_contiguous(), f"conv_wgrad: dw must be a contiguous [{Cout}, {taps * Cin}] tensor")
+    xi, di = _interior(x, B, H, W), _interior(dy, B, H, W)
+    if taps == 9:
+        xp = torch.nn.functional.pad(xi, (0, 0, 1, 1, 1, 1))
+        cols = [torch.einsum("bhwo,bhwi->oi", di, xp[:, ky:ky + H, kx:kx + W]) for ky in range(3) for kx in range(3)]
+        val = torch.stack(cols, dim=1).reshape(Cout, 9 * Cin)
+    else:
+        val = torch.einsum("bhwo,bhwi->oi", di, xi)
+    dw.copy_((val + dw.float() if accumulate else val).to(BF16))
+    return dw
+
+
+def _im2col(xi, stride, pad):
+    """[B, H, W, C] -> [B, H/stride, W/stride, 9, C]: tap (ky, kx) of output (yo, xo) reads input (yo*stride + ky - pad, xo*stride + kx - pad), zero outside"""
+    B, H, W, Cn = xi.shape
+    Ho, Wo = H // stride, W // stride
+    xp = torch.nn.functional.pad(xi, (0, 0, pad, 3, pad, 3))
+    taps = [xp[:, ky:ky + Ho * stride:stride, kx:kx + Wo * stride:stride] for ky in range(3) for kx in range(3)]
+    return torch.stack(taps, dim=3)
+
+
+def im2col3x3(x, B, H, W, stride=1, pad=1):
+    _need(stride in (1, 2) and pad in (0, 1), "im2col3x3: stride / pad")
+    Cn = x.shape[1]
+    Kpad = (9 * Cn + 63) // 64 * 64
+    col = _im2col(_interior(x, B, H, W), stride, pad).reshape(B, H // stride, W // stride, 9 * Cn)
+    return _to_grid(torch.nn.functional.pad(col, (0, Kpad - 9 * Cn)))
+
+
+def col2im3x3(dcol, B, H, W, Cn, stride=1, pad=1):
+    d = _interior(dcol, B, H // stride, W // stride, reads_borders=False)[..., :9 * Cn].reshape(B, H // stride, W // stride, 9, Cn)
+    x = torch.zeros(B, H, W, Cn, requires_grad=True)
+    with torch.enable_grad():
+        (g,) = torch.autograd.grad(_im2col(x, stride, pad), x, d)
+    return _to_grid(g)
+
+
+def upsample2x(x, B, H, W):
+    xi = _interior(x, B, H, W)
+    return _to_grid(xi.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2))
+
+
+def upsample2x_bwd(dy, B, H, W):
+    d = _interior(dy, B, 2 * H, 2 * W)
+    return _to_grid(d.reshape(B, H, 2, W, 2, -1).sum(dim=(2, 4)))
+
+
+def _silu_grad(z):
+    sg = torch.sigmoid(z)
+    return sg * (1.0 + z * (1.0 - sg))
+
+
+def groupnorm_fwd(x, gamma, beta, B, H, W, groups=32, eps=1e-5, silu=True, out_tokens=False):
+    _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    xi = _interior(x, B, H, W)
+    Cn = xi.shape[-1]
+    _need(Cn % groups == 0, "groupnorm: C % groups")
+    xg = xi.reshape(B, H * W, groups, Cn // groups)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    y = ((xg - mean) * rstd).reshape(B, H, W, Cn) * gamma.float() + beta.float()
+    if silu:
+        y = y * torch.sigmoid(y)
+    stats = torch.stack([mean.expand(B, 1, groups, Cn // groups).reshape(B, Cn), rstd.expand(B, 1, groups, Cn // groups).reshape(B, Cn)], dim=2).contiguous()
+    return (y.reshape(B * H * W, Cn).to(BF16) if out_tokens else _to_grid(y)), stats
+
+
+def groupnorm_bwd(dy, x, gamma, beta, stats, B, H, W, groups=32, silu=True, dy_tokens=False, dadd=None, dgamma=None, dbeta=None, accumulate_params=False):
+    _chk(stats, F32, "stats")
+    xi = _interior(x, B, H, W)
+    Cn = xi.shape[-1]
+    d = dy.float().reshape(B, H, W, Cn) if dy_tokens else _interior(dy, B, H, W)
+    mean, rstd = stats[..., 0][:, None, None, :], stats[..., 1][:, None, None, :]
+    xhat = (xi - mean) * rstd
+    if silu:
+        d = d * _silu_grad(xhat * gamma.float() + beta.float())
+    for dst, val in ((dgamma, (d * xhat).sum(dim=(0, 1, 2))), (dbeta, d.sum(dim=(0, 1, 2)))):
+        if dst is not None:
+            _chk(dst, F32, "dgamma/dbeta")
+            dst.copy_(val + dst if accumulate_params else val)
+    g = (d * gamma.float()).reshape(B, H * W, groups, Cn // groups)
+    xh = xhat.reshape(B, H * W, groups, Cn // groups)
+    dx = rstd.reshape(B, 1, groups, Cn // groups) * (g - g.mean(dim=(1, 3), keepdim=True) - xh * (g * xh).mean(dim=(1, 3), keepdim=True))
+    dx = dx.reshape(B, H, W, Cn)
+    if dadd is not None:
+        dx = dx + _interior(dadd, B, H, W)
+    return _to_grid(dx)
+
+
+def layernorm_fwd(x, weight, bias, eps=1e-5, out=None):
+    _chk(x, BF16, "x"); _chk(weight, BF16, "weight"); _chk(bias, BF16, "bias"); _rows(x, "x")
+    xhat, _ = _ln_stats(x.float(), eps)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16)
+    return _put(out, xhat * weight.float() + bias.float())
+
+
+def layernorm_bwd(dy, x, weight, dres=None, eps=1e-5):
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(weight, BF16, "weight"); _rows(dy, "dy"); _rows(x, "x")
+    xhat, rstd = _ln_stats(x.float(), eps)
+    g = dy.float() * weight.float()
+    dx = rstd * (g - g.mean(dim=1, keepdim=True) - xhat * (g * xhat).mean(dim=1, keepdim=True))
+    if dres is not None:
+        _chk(dres, BF16, "dres")
+        dx = dx + dres.float()
+    return dx.to(BF16)
+
+
+def layernorm_param_grads(dy, x, dweight, dbias, eps=1e-5, accumulate=False):
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dweight, F32, "dweight"); _chk(dbias, F32, "dbias")
+    xhat, _ = _ln_stats(x.float(), eps)
+    for dst, val in ((dweight, (dy.float() * xhat).sum(0)), (dbias, dy.float().sum(0))):
+        dst.copy_(val + dst if accumulate else val)
+
+
+def _gelu_erf(g):
+    return 0.5 * g * (1.0 + torch.erf(g * 0.7071067811865476))
+
+
+def geglu_fwd(h):
+    _chk(h, BF16, "h"); _rows(h, "h")
+    F_ = h.shape[1] // 2
+    return (h[:, :F_].float() * _gelu_erf(h[:, F_:].float())).to(BF16)
+
+
+def geglu_bwd(h, dout):
+    _chk(h, BF16, "h"); _chk(dout, BF16, "dout")
+    F_ = h.shape[1] // 2
+    v, g, d = h[:, :F_].float(), h[:, F_:].float(), dout.float()
+    gg = 0.5 * (1.0 + torch.erf(g * 0.7071067811865476)) + g * 0.3989422804014327 * torch.exp(-0.5 * g * g)
+    return torch.cat([d * _gelu_erf(g), d * v * gg], dim=1).to(BF16)
+
+
+def softmax_rows_(x, scale=1.0):
+    _chk(x, BF16, "x"); _rows(x, "x")
+    x.copy_(torch.softmax(x.float() * scale, dim=1).to(BF16))
+    return x
+
+
+def softmax_rows_bwd_(p, dp, scale=1.0):
+    _chk(p, BF16, "p"); _chk(dp, BF16, "dp")
+    _need(_rows(p, "p") == _rows(dp, "dp"), "softmax_rows_bwd: p and dp must share a row stride")
+    pf, df = p.float(), dp.float()
+    dp.copy_((scale * pf * (df - (df * pf).sum(dim=1, keepdim=True))).to(BF16))
+    return dp
+
+
+_EMULATED = ("grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
+             "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
+             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
 
