@@ -907,8 +907,6 @@ class ModelFoundation(ExplorativeModelingMixin):
         if mask is not None and hasattr(mask, "to"):
             batch["encoder_attention_mask"] = mask.to(device=dev, dtype=wd)
         perturb = getattr(self.config, "input_perturbation", 0) or 0
-        if self.PREDICTION_TYPE is PredictionTypes.FLOW_MATCHING and perturb != 0:
-            raise NotImplementedError("input_perturbation with the fused flow-matching noising pass is not implemented on the st355 path")
 
         lat = batch["latents"]
         batch["noise_shape_ref"] = lat
@@ -926,8 +924,17 @@ class ModelFoundation(ExplorativeModelingMixin):
             noisy, target, noise = ops.flow_noise_mix(lat, sig, noise=given, seed=seed, offset=self._noise_offset)
             self._noise_step += 1
             self._noise_offset += per_call          # mixed aspect buckets / varying batch: ranges of different steps never overlap
+            input_noise = noise
+            steps_ = getattr(self.config, "input_perturbation_steps", None)
+            if perturb != 0 and (not steps_ or state.get("global_step", 0) < steps_):
+                # common.py:5957-5968 + _prepare_flow_noisy_latents (:4975-4992): the INPUT noise is perturbed — x_t = (1 - sigma) x + sigma (n + p e) — while the target
+                # keeps the un-perturbed n - x (get_prediction_target reads batch["noise"], :4610-4611).  The first pass above produced n and the target; the mix is
+                # redone with the perturbed noise (an option off by default: one extra streaming pass when it is on)
+                p_ = float(perturb) * ((1.0 - state.get("global_step", 0) / steps_) if steps_ else 1.0)
+                input_noise = (noise + p_ * torch.randn_like(lat)).to(noise.dtype)
+                noisy, _, _ = ops.flow_noise_mix(lat, sig, noise=input_noise)
             batch["noise"] = noise
-            batch["input_noise"] = noise
+            batch["input_noise"] = input_noise
             batch["noisy_latents"] = noisy
             batch["flow_target"] = target      # n - x (common.py:4610-4611), consumed by get_prediction_target
             self.expand_sigmas(batch)

@@ -257,6 +257,22 @@ def lora_pack(A, Bm, scale, A_cat, A_cat_T, B_blk, B_blk_T, k2_off=0, n_off=0):
 # ------------------------------------------------------------------------------------------------
 # streaming ops
 # ------------------------------------------------------------------------------------------------
+def flow_noise_mix(x, sigma, noise=None, seed=0, offset=0, want_target=True):
+    """x_t = (1 - sigma) x + sigma n ; target = n - x.  noise=None: the kernel draws Philox normals from (seed, offset) — here torch's generator seeded the same way
+    (a different stream: distributional equivalence only, as DESIGN.md states for the product vs torch.randn)"""
+    _chk(x, BF16, "x"); _chk(sigma, F32, "sigma")
+    B = x.shape[0]
+    _need((x.numel() // B) % 8 == 0, "flow_noise_mix: per_sample must be a multiple of 8")
+    if noise is None:
+        noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(int(seed) * 1_000_003 + int(offset))).to(BF16)
+    else:
+        _chk(noise, BF16, "noise")
+    s = sigma.float().view(B, *([1] * (x.dim() - 1)))
+    x_t = ((1.0 - s) * x.float() + s * noise.float()).to(BF16)
+    target = (noise.float() - x.float()).to(BF16) if want_target else None
+    return x_t, target, noise
+
+
 def timestep_proj(t, dim, scale=1.0):
     _chk(t, F32, "t")
     half = dim // 2
@@ -778,7 +794,7 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
 
 _EMULATED = ("grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
-             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
 
