@@ -38,7 +38,7 @@ class SD3(ModelFoundation):
 
     def add_lora_adapter(self):
         if getattr(self.config, "model_type", "lora") != "lora":
-            raise NotImplementedError("full-rank SD3 training needs the TN weight-gradient GEMM (not built yet)")
+            raise RuntimeError("model_type == 'full' trains every transformer parameter: call enable_full_finetune() (or freeze_components()) instead of add_lora_adapter()")
         comp = self.unwrap_model(self.model)
         params = comp.add_lora_adapter(rank=int(self.config.lora_rank), alpha=getattr(self.config, "lora_alpha", None),
                                        targets="default", seed=int(getattr(self.config, "seed", 42) or 42) + 7,
