@@ -9,7 +9,7 @@ wires this package behind the reference's own plugin surface:
   * every st355 family plugin is re-created as a class that ALSO derives from the reference's `ModelFoundation`
     (simpletuner/helpers/models/common.py:451) — so `isinstance` checks in the trainer hold — with the st355 class first in the MRO, and
     is registered with `ModelRegistry.register(family, cls)` (simpletuner/helpers/models/registry.py:74-75), overriding the lazy
-    metadata entry of the same family (`model_families()` lets explicit registrations win, registry.py:95-104);
+    metadata entry of the same family (`model_families()` lets explicit registrations win, helpers/models/registry.py:87-98);
   * `optimizer_choices` (simpletuner/helpers/training/optimizer_param.py:76) gains `st355-adamw` and has its `adamw_bf16` entry's class
     replaced by the fused one-pass implementation (same entry shape: precision / default_settings / class);
   * `EMAModel` is exported for `trainer.py:4360-4369`'s construction site (same constructor signature, ema.py:29-60).

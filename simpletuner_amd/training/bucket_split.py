@@ -26,14 +26,14 @@ from typing import Dict, List, Optional, Sequence
 def split_buckets_between_processes(buckets: Dict[str, Sequence], batch_size: int, num_processes: int, rank: int, gradient_accumulation_steps: int = 1,
                                     repeats: int = 0, seed: Optional[int] = 0, backend_id: str = "", shuffle: bool = True, apply_padding: bool = False,
                                     allow_oversubscription: bool = False, user_set_repeats: bool = False) -> Dict[str, List]:
-    """base.py:741-937 for a TRAINING dataset (eval datasets use an effective batch of 1 there and are outside the step path)"""
+    """helpers/metadata/backends/base.py:741-937 for a TRAINING dataset (eval datasets use an effective batch of 1 there and are outside the step path)"""
     effective = batch_size * num_processes * gradient_accumulation_steps
     failing = {b: len(v) for b, v in buckets.items() if v and len(v) * (repeats + 1) < effective}
     auto_repeats: Dict[str, int] = {}
     if failing:
         needed = {b: ceil(effective / n) - 1 for b, n in failing.items()}
         if allow_oversubscription and not user_set_repeats:
-            auto_repeats = needed                      # pad only the undersized buckets (base.py:813-823)
+            auto_repeats = needed                      # pad only the undersized buckets (metadata/backends/base.py:813-823)
         else:
             lines = "".join(f"  - Bucket {b}: {n} samples x {repeats + 1} (with repeats) = {n * (repeats + 1)} samples; minimum repeats required: {needed[b]}\n"
                             for b, n in failing.items())
@@ -48,7 +48,7 @@ def split_buckets_between_processes(buckets: Dict[str, Sequence], batch_size: in
             continue
         images = list(images)
         if shuffle:
-            images = sorted(images, key=str)           # canonical order first: every rank shuffles an identical sequence (base.py:884-887)
+            images = sorted(images, key=str)           # canonical order first: every rank shuffles an identical sequence (metadata/backends/base.py:884-887)
             random.Random(f"{seed}:{backend_id}:{bucket}").shuffle(images)
         if bucket in auto_repeats:
             logical = len(images) * (auto_repeats[bucket] + 1)
