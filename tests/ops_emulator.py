@@ -273,6 +273,97 @@ def flow_noise_mix(x, sigma, noise=None, seed=0, offset=0, want_target=True):
     return x_t, target, noise
 
 
+def ddpm_noise_mix(x, noise, sqrt_acp, sqrt_1macp, want_v=True):
+    _chk(x, BF16, "x"); _chk(noise, BF16, "noise"); _chk(sqrt_acp, F32, "sqrt_acp"); _chk(sqrt_1macp, F32, "sqrt_1macp")
+    B = x.shape[0]
+    a, b = (t.float().view(B, *([1] * (x.dim() - 1))) for t in (sqrt_acp, sqrt_1macp))
+    x_t = (a * x.float() + b * noise.float()).to(BF16)
+    return x_t, ((a * noise.float() - b * x.float()).to(BF16) if want_v else None)
+
+
+def flux_pack(latents):
+    return patchify(latents, order=0)
+
+
+def flux_unpack(packed, Cc, H, W):
+    return unpatchify(packed, Cc, H, W, order=0)
+
+
+def _loss_common(pred, target, weight, emask, want_grad, grad_scale, elem, delem):
+    """per-element loss `elem(d)` / derivative `delem(d)` -> [* emask] -> per-sample mean (* w_b) -> batch mean; dpred = grad_scale * d loss / d pred"""
+    _chk(pred, BF16, "pred"); _chk(target, BF16, "target")
+    B = pred.shape[0]
+    per = pred.numel() // B
+    _need(per % 8 == 0, "loss: per-sample size must be a multiple of 8")
+    d = pred.float().reshape(B, per) - target.float().reshape(B, per)
+    mk = torch.ones(B, per)
+    if emask is not None:
+        _chk(emask, F32, "emask")
+        em = emask.reshape(B, -1)
+        mk = em.repeat(1, per // em.shape[1])
+    w = torch.ones(B) if weight is None else weight.float()
+    per_sample = (elem(d) * mk).sum(dim=1) * w / per
+    loss = per_sample.mean().reshape(1)
+    dpred = (grad_scale * (delem(d) * mk) * w[:, None] / (per * B)).reshape(pred.shape).to(BF16) if want_grad else None
+    return loss, per_sample, dpred
+
+
+def mse_loss(pred, target, weight=None, want_grad=True, grad_scale=1.0):
+    return _loss_common(pred, target, weight, None, want_grad, grad_scale, lambda d: d * d, lambda d: 2.0 * d)
+
+
+def cond_loss(pred, target, loss_type="l2", huber_c=0.1, weight=None, want_grad=True, grad_scale=1.0, emask=None):
+    B = pred.shape[0]
+    if loss_type == "l2":
+        return _loss_common(pred, target, weight, emask, want_grad, grad_scale, lambda d: d * d, lambda d: 2.0 * d)
+    c = (huber_c if torch.is_tensor(huber_c) else torch.full((B,), float(huber_c))).float().reshape(B, 1)
+    k = 2.0 * c if loss_type == "huber" else torch.full_like(c, 2.0)
+    return _loss_common(pred, target, weight, emask, want_grad, grad_scale, lambda d: k * (torch.sqrt(d * d + c * c) - c), lambda d: k * d / torch.sqrt(d * d + c * c))
+
+
+def adamw_ema_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0, ema=None, ema_decay=0.0, p_bf16=None):
+    """torch.optim.AdamW's single-tensor order of operations over a flat arena (fp32 p / g, or bf16 p / g with fp32 moments), optional fused EMA"""
+    _need(step >= 1 and p.dim() == 1 and p.is_contiguous() and g.is_contiguous(), "adamw_ema_step: flat contiguous arenas, step >= 1")
+    _need(p.dtype in (F32, BF16) and g.dtype == p.dtype and m.dtype == F32 and v.dtype == F32, "adamw_ema_step: dtypes")
+    _need(p.dtype == F32 or p.numel() % 8 == 0, "adamw_ema_step_bf16: n must be a multiple of 8")
+    gf = g.float() * grad_scale
+    pf = p.float() * (1.0 - lr * weight_decay)
+    m.add_((gf - m) * (1.0 - beta1))
+    v.mul_(beta2).add_((1.0 - beta2) * gf * gf)
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    pf = pf - (lr / bc1) * (m / (v.sqrt() / math.sqrt(bc2) + eps))
+    p.copy_(pf.to(p.dtype))
+    if ema is not None:
+        ema.copy_((ema.float() - (1.0 - ema_decay) * (ema.float() - p.float())).to(ema.dtype))
+    if p_bf16 is not None:
+        p_bf16.copy_(pf.to(BF16))
+
+
+def ema_update(shadow, param, decay):
+    """s -= (1 - d) (s - p), the difference materialised in the parameter dtype (ema.py:423)"""
+    _need(shadow.dtype == param.dtype, "ema_update: dtype mismatch")
+    diff = (shadow.float() - param.float()).to(shadow.dtype)
+    shadow.copy_((shadow.float() - (1.0 - decay) * diff.float()).to(shadow.dtype))
+
+
+def grad_norm(g):
+    return torch.stack([(g.float() ** 2).sum(), g.float().abs().max()])
+
+
+def grad_clamp_(g, c):
+    _need(g.dtype in (F32, BF16) and g.is_contiguous(), "grad_clamp: expected a contiguous fp32 / bf16 tensor")
+    g.clamp_(-c, c)
+    return g
+
+
+def grad_clip_norm_(g, stats, max_norm, pre_scale=1.0):
+    _chk(stats, F32, "stats")
+    coef = min(max_norm / (float(stats[0].sqrt()) * pre_scale + 1e-6), 1.0)
+    if coef < 1.0:
+        g.copy_((g.float() * coef).to(g.dtype))
+    return g
+
+
 def timestep_proj(t, dim, scale=1.0):
     _chk(t, F32, "t")
     half = dim // 2
@@ -794,7 +885,7 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
 
 _EMULATED = ("grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
-             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
 

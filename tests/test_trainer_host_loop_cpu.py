@@ -1,0 +1,83 @@
+"""The whole training step's HOST LOGIC on the CPU (kernels replaced by tests/ops_emulator.py): `Trainer.train_step` — prepare_batch (noising), model_predict (the Flux
+engine, pack / unpack), loss_with_logs (fused loss + gradient), backward, gradient clipping, the fused optimizer over the flat arena, LR schedule, EMA — against the oracle
+stepped by `torch.optim.AdamW` (the GPU form of this run is tests/test_flux_model_gpu.py::test_flux_loss_curve_matches_oracle_adamw), and a full-rank run with EMA + clipping."""
+from types import SimpleNamespace
+
+import torch
+
+from tests import ops_emulator as EMU
+from tests import parity_utils as PU
+
+
+def _acc():
+    return SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True, gradient_accumulation_steps=1, sync_gradients=True,
+                           backward=lambda loss: loss.backward(), wait_for_everyone=lambda: None)
+
+
+def _build(monkeypatch, layers, single, B, lat_h, lat_w, S_txt, **cfg_kw):
+    EMU.install(monkeypatch)
+    from simpletuner_amd.flux import transformer as T
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import Trainer, default_config
+    monkeypatch.setattr(T, "_FUSED_QKV", False); monkeypatch.setattr(T, "_BLOCK_ABI", False)
+    cfg = default_config(train_batch_size=B, seed=3, flow_schedule_shift=3.0, **cfg_kw)
+    acc = _acc()
+    plugin = Flux(cfg, acc)
+    plugin.load_model(**PU.small_flux_cfg(layers=layers, single=single))
+    if cfg.model_type == "lora":
+        plugin.add_lora_adapter()
+    else:
+        plugin.freeze_components()                       # model_type == "full": the mode is entered here, as under the reference Trainer
+    trainer = Trainer(cfg, plugin, acc)
+    cpu, devt = PU.make_inputs(B, lat_h, lat_w, S_txt, 128, 64, "cpu", seed=3)
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    return plugin, trainer, cpu, devt
+
+
+def _batch(devt):
+    return {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
+
+
+def test_lora_loss_curve_of_the_whole_step_matches_the_oracle_under_adamw(monkeypatch):
+    plugin, trainer, cpu, devt = _build(monkeypatch, 1, 1, 2, 16, 16, 32, lora_rank=8, lora_init_b_std=0.02, learning_rate=2e-3)
+    model = plugin.get_trained_component()
+    P, lora, scale = PU.oracle_state(model)
+    ocfg = PU.oracle_cfg(model)
+    names = sorted(lora)
+    params = {k: (torch.nn.Parameter(lora[k][0].clone()), torch.nn.Parameter(lora[k][1].clone())) for k in names}
+    opt = torch.optim.AdamW([t for k in names for t in params[k]], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    hip, ora = [], []
+    for _ in range(6):
+        hip.append(trainer.train_step(_batch(devt)).item())
+        opt.zero_grad()
+        s = cpu["sigmas"].view(-1, 1, 1, 1)
+        noisy = ((1 - s) * cpu["latents"] + s * cpu["noise"]).to(torch.bfloat16).float()
+        target = (cpu["noise"] - cpu["latents"]).to(torch.bfloat16).float()
+        pred = PU.OF.flux_model_predict(P, ocfg, noisy, cpu["prompt"], cpu["pooled"], cpu["sigmas"] * 1000.0, 1.0, lora={k: params[k] for k in names}, lora_scale=scale)
+        l = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+        l.backward(); opt.step()
+        ora.append(l.item())
+    d = max(abs(a - b) for a, b in zip(hip, ora))
+    print(f"[emu] whole-step loss curve (6 AdamW steps): max |delta| {d:.2e}; emulated {[round(x, 4) for x in hip]}")
+    assert d < 2e-3 * max(1.0, max(ora)) and hip[-1] < hip[0]
+    assert trainer.state["global_step"] == 6
+    assert all(p.grad is None for p in model.trainable_parameters())          # zero_grad(set_to_none=True) after the step (trainer.py:7253)
+
+
+def test_full_rank_steps_with_ema_and_norm_clipping(monkeypatch):
+    plugin, trainer, cpu, devt = _build(monkeypatch, 1, 1, 2, 8, 8, 24, model_type="full", learning_rate=2e-4, use_ema=True, ema_decay=0.9, max_grad_norm=0.5)
+    model = plugin.get_trained_component()
+    assert model.full and trainer.ema_model is not None
+    before = model.arena.clone()
+    losses = [trainer.train_step(_batch(devt)).item() for _ in range(4)]
+    print(f"[emu] full-rank whole-step losses (EMA + clip): {[round(x, 4) for x in losses]}")
+    assert losses[-1] < losses[0]
+    assert not torch.equal(before, model.arena)                               # ONE fused optimizer step over the arena moved the weights
+    assert float(trainer.last_grad_norm) > 0.5                                # the un-clipped norm is logged; the clip coefficient was applied on the arena
+    # the shadow lags the weights: s_k = s_{k-1} - (1 - d)(s_{k-1} - p_k)
+    sh = trainer.ema_model.shadow_flat if hasattr(trainer.ema_model, "shadow_flat") else None
+    if sh is not None:
+        lag = (sh.float() - model.arena.float()).abs().max().item()
+        moved = (before.float() - model.arena.float()).abs().max().item()
+        assert 0.0 < lag < moved
