@@ -81,3 +81,71 @@ def test_full_rank_steps_with_ema_and_norm_clipping(monkeypatch):
         lag = (sh.float() - model.arena.float()).abs().max().item()
         moved = (before.float() - model.arena.float()).abs().max().item()
         assert 0.0 < lag < moved
+
+
+def test_full_rank_checkpoint_resume_continues_bit_for_bit(monkeypatch, tmp_path):
+    """save_state after two steps (the trained component as `<dir>/transformer/diffusion_pytorch_model.safetensors` + config.json — what `save_pretrained` writes —, optimizer
+    moments, step counters), load_state into a freshly built trainer with different initial weights, two more steps: the same losses and the same arena as the
+    uninterrupted run"""
+    import json
+    import os
+    plugin, trainer, cpu, devt = _build(monkeypatch, 1, 1, 2, 8, 8, 24, model_type="full", learning_rate=2e-4)
+    for _ in range(2):
+        trainer.train_step(_batch(devt))
+    ck = str(tmp_path / "checkpoint-2")
+    trainer.save_state(ck)
+    tail_a = [trainer.train_step(_batch(devt)).item() for _ in range(2)]
+    arena_a = plugin.get_trained_component().arena.clone()
+    sub = os.path.join(ck, "transformer")
+    assert os.path.exists(os.path.join(sub, "diffusion_pytorch_model.safetensors"))
+    assert json.load(open(os.path.join(sub, "config.json")))["_class_name"] == "FluxTransformer2DModel"
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(sub, "diffusion_pytorch_model.safetensors"))
+    assert set(sd) == {n for n, _ in plugin.get_trained_component().named_parameters()}          # diffusers checkpoint keys, one tensor each
+
+    plugin2, trainer2, _, _ = _build(monkeypatch, 1, 1, 2, 8, 8, 24, model_type="full", learning_rate=2e-4)
+    with torch.no_grad():
+        plugin2.get_trained_component().arena.add_(0.25)                                         # a different start: everything must come from the checkpoint
+    trainer2.load_state(ck)
+    assert trainer2.state["global_step"] == 2
+    tail_b = [trainer2.train_step(_batch(devt)).item() for _ in range(2)]
+    assert tail_a == tail_b
+    assert torch.equal(arena_a, plugin2.get_trained_component().arena)
+
+
+def test_sd3_full_fine_tune_checkpoint_resume_continues_bit_for_bit(monkeypatch, tmp_path):
+    """the same round trip for the SD3 full fine-tune (BASELINE.json configs[3]): the saved component carries the position table next to the parameters"""
+    import os
+    EMU.install(monkeypatch)
+    from simpletuner_amd.sd3.model import SD3
+    from simpletuner_amd.training.trainer import Trainer, default_config
+    arch = dict(sample_size=32, num_layers=2, num_attention_heads=2, attention_head_dim=64, joint_attention_dim=128, caption_projection_dim=128, pooled_projection_dim=64,
+                pos_embed_max_size=24)
+
+    def build():
+        cfg = default_config(model_family="sd3", model_type="full", train_batch_size=2, seed=5, learning_rate=2e-4, flow_schedule_shift=3.0)
+        plugin = SD3(cfg, _acc())
+        plugin.load_model(**arch)
+        plugin.freeze_components()
+        trainer = Trainer(cfg, plugin, plugin.accelerator)
+        _, devt = PU.make_inputs(2, 16, 16, 24, 128, 64, "cpu", seed=5)
+        sig = devt["sigmas"]
+        plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+        return plugin, trainer, devt
+
+    plugin, trainer, devt = build()
+    assert plugin.get_trained_component().full
+    for _ in range(2):
+        trainer.train_step(_batch(devt))
+    ck = str(tmp_path / "checkpoint-2")
+    trainer.save_state(ck)
+    tail_a = [trainer.train_step(_batch(devt)).item() for _ in range(2)]
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(ck, "transformer", "diffusion_pytorch_model.safetensors"))
+    assert "pos_embed.pos_embed" in sd and "pos_embed.proj.weight" in sd and sd["pos_embed.proj.weight"].dim() == 4       # the Conv2d tensor keeps its checkpoint shape
+    plugin2, trainer2, _ = build()
+    with torch.no_grad():
+        plugin2.get_trained_component().arena.add_(0.25)
+    trainer2.load_state(ck)
+    tail_b = [trainer2.train_step(_batch(devt)).item() for _ in range(2)]
+    assert tail_a == tail_b and torch.equal(plugin.get_trained_component().arena, plugin2.get_trained_component().arena)
