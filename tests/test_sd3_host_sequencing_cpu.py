@@ -128,3 +128,61 @@ def test_modulation_scale_gradient_survives_a_scale_entry_of_exactly_minus_one(m
     got, ref = dict(model.named_parameters())[name].grad, P[name].grad
     assert torch.isfinite(got.float()).all()
     assert PU.rel_l2(got, ref) < 6e-2, PU.rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_tread_routing_and_checkpoint_plans_through_the_emulator(monkeypatch, full):
+    """TREAD on SD3 (sd3/transformer.py:694-706, 796-803): 4 blocks, half of the image tokens routed around blocks [1, -2]; LoRA adapter gradients (or, full fine-tune, every
+    parameter's gradient) against the oracle replaying the same permutation; the per-block recompute the reference falls back to under routing is bit-identical; and a
+    segmented checkpoint plan (interval 2 / stride 3) without routing is bit-identical to keeping every activation"""
+    from simpletuner_amd.training.tread import ReplayRouter
+    d = _inputs(2, 16, 16, 24)
+    B, Si = 2, 64
+    g = torch.Generator().manual_seed(11)
+    perm = torch.stack([torch.randperm(Si, generator=g) for _ in range(B)])
+    K = Si - int(round(Si * 0.5))
+    rec = {"mask": torch.ones(B, Si, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+           "ids_restore": torch.argsort(perm, dim=1)}
+    routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]
+
+    def run(route, ckpt, interval=None, stride=None):
+        model = _model(monkeypatch, 4)
+        if full:
+            model.enable_full_finetune()
+        else:
+            model.add_lora_adapter(rank=8, alpha=8.0, init_b_std=0.02)
+        if route:
+            model.set_router(ReplayRouter([rec]), routes)
+        model.train()
+        if ckpt:
+            model.gradient_checkpointing = True
+            model.gradient_checkpointing_interval, model.gradient_checkpointing_segment_stride = interval, stride
+        out, loss = _hip_side(model, d)
+        return model, out, loss, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    model, out, loss, grads = run(True, False)
+    P, lora, scale = PU.oracle_state(model)
+    P = {k: (v.clone().requires_grad_(True) if full else v) for k, v in P.items()}
+    P["pos_embed.pos_embed"] = model.pos_embed.pos_embed.detach().float()
+    lp = None if full else {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    o_out = OS.sd3_forward(P, _ocfg(model), d["lat"].float(), d["prompt"].float(), d["pooled"].float(), d["t"], lora=lp, lora_scale=scale,
+                           tread={"routes": routes, "mask_infos": [rec]})
+    o_loss = ((o_out - d["target"].float()) ** 2).mean()
+    o_loss.backward()
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    gmax = max(v.grad.norm().item() for k, v in P.items() if k != "pos_embed.pos_embed") if full else None
+    for name, g_ in grads.items():
+        if full:
+            ref = P[name].grad
+            if ref.norm().item() < 1e-3 * gmax:
+                continue
+            assert PU.rel_l2(g_, ref) < 6e-2, (name, PU.rel_l2(g_, ref))
+        else:
+            ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+            assert PU.rel_l2(g_, ref) < 5e-2, (name, PU.rel_l2(g_, ref))
+    _, out_c, _, grads_c = run(True, True)
+    assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+    _, out_p, _, grads_p = run(False, False)
+    _, out_s, _, grads_s = run(False, True, 2, 3)
+    assert torch.equal(out_p, out_s) and all(torch.equal(grads_p[k], grads_s[k]) for k in grads_p)
+    assert not torch.equal(out, out_p)                         # the route is live
