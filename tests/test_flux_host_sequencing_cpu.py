@@ -202,3 +202,30 @@ def test_model_type_full_enters_full_rank_training_at_freeze_components(monkeypa
     assert [id(p) for p in comp.trainable_parameters()] == [id(p) for p in sorted(comp.parameters(), key=lambda q: q.data_ptr())]
     plug.freeze_components()                                   # idempotent
     assert comp.full
+
+
+def test_attention_masked_training_through_the_emulator_matches_the_oracle(monkeypatch):
+    """flux_attention_masked_training (flux/model.py:813-823, flux/transformer.py:170-173, 227-242): the text mask becomes an ADDITIVE +1 on every valid key (the reference
+    hands SDPA a float mask); the transformer-level `attention_mask` argument through the per-key bias of the attention kernels, forward and backward"""
+    model = _model(monkeypatch, 1, 2)
+    model.add_lora_adapter(rank=8, alpha=8.0, targets="default", init_b_std=0.02)
+    d = _inputs(2, 16, 16, 32)
+    St, Si = 32, 64
+    mask = torch.ones(2, St); mask[0, 20:] = 0; mask[1, 9:] = 0
+    out = model(hidden_states=d["packed"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["t"], img_ids=d["img_ids"], txt_ids=d["txt_ids"],
+                guidance=d["guidance"], attention_mask=mask, return_dict=False)[0]
+    loss = ((out.float() - d["target"].float()) ** 2).mean()
+    loss.backward()
+    P, lora, scale = PU.oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    kb = torch.ones(2, St + Si); kb[:, :St] = (mask > 0).float()
+    f = lambda k: d[k].float()
+    o = OF.flux_forward(P, PU.oracle_cfg(model), f("packed"), f("prompt"), f("pooled"), d["t"], d["img_ids"], d["txt_ids"], d["guidance"], lp, scale, key_bias=kb)
+    o_plain = OF.flux_forward(P, PU.oracle_cfg(model), f("packed"), f("prompt"), f("pooled"), d["t"], d["img_ids"], d["txt_ids"], d["guidance"],
+                              {k: (a.detach(), b.detach()) for k, (a, b) in lp.items()}, scale)
+    ((o - f("target")) ** 2).mean().backward()
+    assert PU.rel_l2(out, o) < 2e-2 and PU.rel_l2(o_plain, o) > 2e-2          # parity, and the mask matters
+    for name, p in model.named_parameters():
+        if ".lora_" in name:
+            ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+            assert PU.rel_l2(p.grad, ref) < 5e-2, name

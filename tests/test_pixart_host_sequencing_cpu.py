@@ -75,3 +75,29 @@ def test_controlnet_branch_gradients_through_the_emulator_match_autograd(monkeyp
         worst = max(worst, (r / tol, f"{k}: {r:.3e}"))
         assert r < tol, (k, r)
     print(f"[emu] pixart controlnet host sequencing: {len(names)} tensors, worst (relative to its tolerance) {worst[1]}")
+
+
+def test_controlnet_checkpoint_plans_through_the_emulator_are_bit_identical(monkeypatch):
+    """the planner of pixart/transformer.py:627-700 over the ControlNet wrapper's loop units: recomputed segments (per layer, and interval 2 / stride 3) give the bit-identical
+    prediction and adapter gradient arena"""
+    EMU.install(monkeypatch)
+    from simpletuner_amd.pixart.transformer import PixArtSigmaControlNetTransformerModel, PixArtTransformer2DModel
+
+    def run(ckpt, interval=None, stride=None):
+        m = PixArtTransformer2DModel(device="cpu", **ARCH)
+        m.init_synthetic(5)
+        cn = PixArtSigmaControlNetTransformerModel(m, num_layers=3)
+        cn.init_adapter_synthetic(seed=9, std=0.05)
+        if ckpt:
+            cn.enable_gradient_checkpointing()
+            cn.set_gradient_checkpointing_interval(interval)
+            cn.set_gradient_checkpointing_segment_stride(stride)
+        lat, cond, enc, mask, t = _inputs()
+        out = cn(lat, encoder_hidden_states=enc, timestep=t, controlnet_cond=cond, encoder_attention_mask=mask, return_dict=False)[0]
+        (out.float() ** 2).mean().backward()
+        return out.detach().clone(), cn.grad_arena.detach().clone()
+
+    o0, g0 = run(False)
+    for plan in ((None, None), (2, 3)):
+        o1, g1 = run(True, *plan)
+        assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.float().abs().sum().item() > 0

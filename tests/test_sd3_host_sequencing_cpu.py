@@ -186,3 +186,38 @@ def test_tread_routing_and_checkpoint_plans_through_the_emulator(monkeypatch, fu
     _, out_s, _, grads_s = run(False, True, 2, 3)
     assert torch.equal(out_p, out_s) and all(torch.equal(grads_p[k], grads_s[k]) for k in grads_p)
     assert not torch.equal(out, out_p)                         # the route is live
+
+
+def test_cfg_sampling_trajectory_through_the_emulator_matches_the_oracle_driven_loop(monkeypatch):
+    """§8(f)4: `sample_images` with classifier-free guidance (one forward per step on [negative ; positive], sd3/pipeline.py:1769-1785) through the SD3 plugin on the CPU
+    against the same 4-step Euler loop driven by the oracle forward"""
+    from types import SimpleNamespace
+    EMU.install(monkeypatch)
+    from simpletuner_amd.sampling import FlowMatchEulerDiscreteScheduler, cfg_combine, sample_images
+    from simpletuner_amd.sd3.model import SD3
+    from simpletuner_amd.training.trainer import default_config
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    plugin = SD3(default_config(model_family="sd3", lora_rank=8, train_batch_size=2, seed=3, lora_init_b_std=0.02, flow_schedule_shift=3.0), acc)
+    plugin.load_model(**_arch(2))
+    plugin.add_lora_adapter()
+    model = plugin.get_trained_component()
+    P, lora, scale = PU.oracle_state(model)
+    P["pos_embed.pos_embed"] = model.pos_embed.pos_embed.detach().float()
+    g = torch.Generator().manual_seed(21)
+    bf = lambda t: t.to(BF16)
+    pos_p, pos_pool = bf(torch.randn(2, 20, 128, generator=g)), bf(torch.randn(2, 64, generator=g))
+    neg_p, neg_pool = bf(torch.randn(2, 20, 128, generator=g)), bf(torch.randn(2, 64, generator=g))
+    x0 = bf(torch.randn(2, 16, 16, 16, generator=g))
+    gs = 3.5
+    with torch.no_grad():
+        out = sample_images(plugin, pos_p, pos_pool, 16, 16, num_inference_steps=4, decode=False, guidance_scale=gs, negative_prompt_embeds=neg_p, negative_pooled=neg_pool,
+                            latents=x0.clone(), scheduler=FlowMatchEulerDiscreteScheduler(shift=3.0, bounds="unshifted"))
+    sc = FlowMatchEulerDiscreteScheduler(shift=3.0, bounds="unshifted")
+    sc.set_timesteps(4)
+    x = x0.float()
+    pe, pp = torch.cat([neg_p.float(), pos_p.float()], 0), torch.cat([neg_pool.float(), pos_pool.float()], 0)
+    with torch.no_grad():
+        for i, t in enumerate(sc.timesteps):
+            pred = OS.sd3_forward(P, _ocfg(model), torch.cat([x, x], 0), pe, pp, t.expand(4), lora=lora, lora_scale=scale)
+            x = x + (sc.sigmas[i + 1] - sc.sigmas[i]) * cfg_combine(pred, gs)
+    assert torch.isfinite(out.float()).all() and PU.rel_l2(out, x) < 3e-2

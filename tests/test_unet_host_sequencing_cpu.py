@@ -106,3 +106,28 @@ def test_lora_gradients_through_the_emulator_match_autograd(monkeypatch):
     for n, p in m.named_parameters():
         if ".lora_" in n:
             assert _rel(p.grad, lora[n].grad) < 6e-2, (n, _rel(p.grad, lora[n].grad))
+
+
+@pytest.mark.parametrize("interval,stride,lora", [(None, None, False), (2, 3, True)])
+def test_checkpoint_plans_through_the_emulator_are_bit_identical(monkeypatch, interval, stride, lora):
+    """diffusers' `enable_gradient_checkpointing` over the UNet's units (every ResnetBlock2D / transformer its own checkpoint, or the interval / stride plans): a checkpointed
+    unit runs without a tape and is re-run on a private tape in backward — prediction and the gradient arena are bit-identical to the run that records everything"""
+    def run(ckpt):
+        m, _ = _unet(monkeypatch, "sdxl_small", 5)
+        if lora:
+            m.add_lora_adapter(rank=8, alpha=8.0, seed=4, init_b_std=0.05)
+        else:
+            m.enable_full_finetune()
+        if ckpt:
+            m.enable_gradient_checkpointing()
+            m.set_gradient_checkpointing_interval(interval)
+            m.set_gradient_checkpointing_segment_stride(stride)
+        sample, t, ehs, te, ti = _inputs(2, 16, 16, seed=1)
+        target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9))
+        out = m(sample, t, ehs, None, added_cond_kwargs={"text_embeds": te, "time_ids": ti}, return_dict=False)[0]
+        ((out.float() - target) ** 2).mean().backward()
+        return out.detach().clone(), torch.cat([p.grad.detach().reshape(-1).float() for p in m.trainable_parameters()]).clone()
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.abs().sum().item() > 0
