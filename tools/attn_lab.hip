@@ -16,6 +16,7 @@
 #include "../simpletuner_amd/csrc/runtime.hip"
 #include "../simpletuner_amd/csrc/attention.hip"
 #include "../simpletuner_amd/csrc/attention_bwd.hip"
+#include "attn_fwd_variants.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #define RC(x) do { int r_ = (x); if (r_) { printf("st355 rc=%d: %s (%s:%d)\n", r_, st355_last_error(), __FILE__, __LINE__); exit(2); } } while (0)
@@ -125,6 +126,30 @@ int main(int argc, char** argv) {
     unsigned long long hb; float hm;
     CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
     printf("  O vs generation 1: %llu of %lld elements differ (max |d| %.3e)\n", hb, (long long)nr, hm);
+  }
+  if (strcmp(gen, "1") != 0 && d == 128 && S % 64 == 0) {   // LAB-ONLY variant: stale-maximum rescale (tools/attn_fwd_variants.hip), timed with events, compared with the product's O
+    bf16* O3; float* lse4; CK(hipMalloc(&O3, nr * 2)); CK(hipMalloc(&lse4, (size_t)BH * S * 4));
+    const int lds = 2 * (KB * 256 + 128 * 128);
+    CK(hipFuncSetAttribute((const void*)k_attn_fwd4_stale<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    dim3 grid((S + QB - 1) / QB, H, B), block(ATT_THREADS);
+    auto launch = [&]() {
+      hipLaunchKernelGGL(k_attn_fwd4_stale<128>, grid, block, lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, O3, D, lse4, H, S, S, Sp, scale * LOG2E);
+    };
+    launch(); CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; i++) launch();
+    CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = 4.0 * (double)BH * S * S * d;
+    printf("  %-28s %-13s %8.3f ms/launch  %7.1f TFLOP/s (%d launches)\n", "forward, stale-max (LAB)", "attn_fwd", ms / iters, flops / (ms / iters) / 1e9, iters);
+    float* maxd; double *sd, *sr; CK(hipMalloc(&maxd, 4)); CK(hipMalloc(&sd, 8)); CK(hipMalloc(&sr, 8));
+    CK(hipMemsetAsync(maxd, 0, 4, st)); CK(hipMemsetAsync(sd, 0, 8, st)); CK(hipMemsetAsync(sr, 0, 8, st));
+    k_absdiff<<<2048, 256, 0, st>>>(O3, O, (int64_t)nr, maxd, sd, sr);
+    float hm; double hd, hr;
+    CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hd, sd, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hr, sr, 8, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    printf("  O, stale-max variant vs product kernel: rel-L2 %.3e, max |d| %.3e  %s\n", sqrt(hd / (hr + 1e-30)), hm, sqrt(hd / (hr + 1e-30)) < 4e-3 ? "within bf16 rounding" : "MISMATCH");
   }
   if (strcmp(gen, "1") != 0) return 0;    // the backward comparison runs once (in the generation-1 child)
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
