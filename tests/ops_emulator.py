@@ -8,8 +8,11 @@ passes (strided row blocks of joint buffers included), and the preconditions the
 contraction granule of the TN GEMM, ...) raise here too.  A `-m "not gpu"` test can then run an engine's forward + backward on the CPU and compare with
 the oracle's autograd — the GPU parity tests remain the proof for the kernels themselves.
 
-Nothing in the product imports this module; the product has no CPU path (ops.* raise on host tensors).  Kernels that only the fused fast paths use
-(ST355_EPI_QK_NORM_ROPE, attn_bwd_rope, the block-level entry points) are NOT emulated: tests switch those paths off, exactly like the A/B env switches do.
+Covered: the GEMM family and its epilogues, the TN weight-gradient GEMM, token-axis reductions, AdaLN / LayerNorm / GroupNorm / RMSNorm + RoPE forward and backward,
+self- and cross-attention, the grid-buffer convolution path of the UNet / VAE (conv-as-GEMM, im2col, up / down sampling), GEGLU, rank-space LoRA products, noising,
+the fused losses, AdamW (+ EMA), gradient norm / clipping — 62 wrappers (`_EMULATED`).  Nothing in the product imports this module; the product has no CPU path (ops.* raise
+on host tensors; tests/test_product_isolation_cpu.py).  Kernels that only the fused fast paths use (ST355_EPI_QK_NORM_ROPE, attn_bwd_rope, the block-level entry points,
+st355_vae_encode, the fp8 Linears, AdamWBF16's stochastic rounding) are NOT emulated: tests switch those paths off, exactly like the A/B env switches do.
 """
 from __future__ import annotations
 
