@@ -10,9 +10,10 @@ the oracle's autograd — the GPU parity tests remain the proof for the kernels 
 
 Covered: the GEMM family and its epilogues, the TN weight-gradient GEMM, token-axis reductions, AdaLN / LayerNorm / GroupNorm / RMSNorm + RoPE forward and backward,
 self- and cross-attention, the grid-buffer convolution path of the UNet / VAE (conv-as-GEMM, im2col, up / down sampling), GEGLU, rank-space LoRA products, noising,
-the fused losses, AdamW (+ EMA), gradient norm / clipping — 62 wrappers (`_EMULATED`).  Nothing in the product imports this module; the product has no CPU path (ops.* raise
-on host tensors; tests/test_product_isolation_cpu.py).  Kernels that only the fused fast paths use (ST355_EPI_QK_NORM_ROPE, attn_bwd_rope, the block-level entry points,
-st355_vae_encode, the fp8 Linears, AdamWBF16's stochastic rounding) are NOT emulated: tests switch those paths off, exactly like the A/B env switches do.
+the fused losses, AdamW (+ EMA), gradient norm / clipping — 66 wrappers (`_EMULATED`).  Nothing in the product imports this module; the product has no CPU path (ops.* raise
+on host tensors; tests/test_product_isolation_cpu.py).  NOT emulated: the block-level C entry points (st355_block_flux_*, st355_vae_encode), the fp8 Linears and AdamWBF16's
+stochastic rounding — tests switch those paths off, exactly like the A/B env switches do.  The fused QKV projection epilogue (ST355_EPI_QK_NORM_ROPE) and the attention
+backward with its RoPE / RMSNorm epilogues ARE emulated: that is Flux's default host path at head_dim 128 with tile-aligned streams.
 """
 from __future__ import annotations
 
@@ -99,10 +100,69 @@ def _per_batch(v, rows_total, rows_per_batch):
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+class _QkRope:
+    """what ops.qk_rope hands to gemm(..., rope=...): the operands of the fused QKV epilogue (st355_qk_rope in st355.h), as tensors"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def qk_rope(Q, K, rrms, wq, wk, cos, sin, H, S, pos0, eps=1e-6, Vt=None):
+    _need(tuple(cos.shape) == (S, 64) and tuple(sin.shape) == (S, 64) and cos.is_contiguous() and sin.is_contiguous(), f"qk_rope: cos / sin must be contiguous [S={S}, 64] per-pair tables")
+    _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(rrms, F32, "rrms"); _chk(cos, F32, "cos"); _chk(sin, F32, "sin")
+    _need(H % 2 == 0 and Q.shape[1] == H and Q.shape[2] == S and Q.shape[3] == 128, "qk_rope: head_dim 128, even H")
+    if Vt is not None:
+        _chk(Vt, BF16, "Vt")
+        _need(Vt.shape[-1] >= S and Vt.shape[-1] % 8 == 0 and pos0 % 8 == 0, "qk_rope: V^T needs Sp >= S, Sp and pos0 multiples of 8")
+    return _QkRope(Q=Q, K=K, rrms=rrms, wq=wq, wk=wk, cos=cos, sin=sin, H=H, S=S, pos0=pos0, eps=eps, Vt=Vt)
+
+
+def _rot_pairs(x, cos_p, sin_p):
+    """rotation of the interleaved channel pairs by ONE angle per pair: cos_p / sin_p [T, d/2] broadcast over [B, T, H, d]"""
+    c, s = cos_p[None, :, None, :], sin_p[None, :, None, :]
+    x0, x1 = x[..., 0::2], x[..., 1::2]
+    o = torch.empty_like(x)
+    o[..., 0::2] = x0 * c - x1 * s
+    o[..., 1::2] = x1 * c + x0 * s
+    return o
+
+
+def _rot_pairs_T(g, cos_p, sin_p):
+    c, s = cos_p[None, :, None, :], sin_p[None, :, None, :]
+    g0, g1 = g[..., 0::2], g[..., 1::2]
+    o = torch.empty_like(g)
+    o[..., 0::2] = g0 * c + g1 * s
+    o[..., 1::2] = g1 * c - g0 * s
+    return o
+
+
+def _fused_qkv_epilogue(acc, out, rope, rows_per_batch):
+    """ST355_EPI_QK_NORM_ROPE (st355.h): acc [M, 3D] -> roped head-major Q / K at joint positions pos0 + m % rows_per_batch, 1/rms, row-major V (+ V^T)"""
+    M, N = acc.shape
+    H, S, pos0 = rope.H, rope.S, rope.pos0
+    D = H * 128
+    _need(N == 3 * D and rows_per_batch > 0 and rows_per_batch % 256 == 0 and M % rows_per_batch == 0 and pos0 + rows_per_batch <= S,
+          "gemm: EPI_QK_NORM_ROPE rows_per_batch must be a multiple of 256 dividing M, pos0 + rows_per_batch <= S, N = 3 * H * 128")
+    B, R = M // rows_per_batch, rows_per_batch
+    c, s = rope.cos[pos0:pos0 + R], rope.sin[pos0:pos0 + R]
+    rr = rope.rrms.view(B, S, 2 * H)
+    for j, (w, dst) in enumerate(((rope.wq, rope.Q), (rope.wk, rope.K))):
+        x = acc[:, j * D:(j + 1) * D].reshape(B, R, H, 128)
+        r = torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + rope.eps) if w is not None else torch.ones(B, R, H, 1)
+        y = x * r * (w.float() if w is not None else 1.0)
+        dst[:, :, pos0:pos0 + R] = _rot_pairs(y, c, s).permute(0, 2, 1, 3).to(BF16)
+        rr[:, pos0:pos0 + R, j * H:(j + 1) * H] = r[..., 0]
+    v = acc[:, 2 * D:]
+    _put(out, v)
+    if rope.Vt is not None:
+        rope.Vt[:, :, :, pos0:pos0 + R] = v.reshape(B, R, H, 128).permute(0, 2, 3, 1).to(BF16)
+    return out
+
+
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None, gate=None, rows_per_batch=0, k2_real=0, rope=None):
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
     _seg(a, "a"); _rows(w, "w")
-    _need(epilogue != EPI_QK_NORM_ROPE, "the fused QKV epilogue is not emulated (switch the fused path off in CPU tests)")
+    _need(epilogue != EPI_QK_NORM_ROPE or (rope is not None and out is not None), "gemm: EPI_QK_NORM_ROPE needs rope=qk_rope(...) and out= (the V destination)")
     A = _flat(a)
     M, K = A.shape
     N = w.shape[0]
@@ -122,6 +182,11 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out
         _chk(bias, BF16, "bias")
         _need(bias.is_contiguous() and bias.numel() == N, "gemm: bias")
         acc = acc + bias.float()
+    if epilogue == EPI_QK_NORM_ROPE:
+        _chk(out, BF16, "out"); _seg(out, "out"); _al(out, 16, "out"); _ld(out, 8, "out"); _segcheck(out, M, "out")
+        _need(out.numel() == M * (N // 3) and out.shape[-1] == N // 3, f"gemm: the V destination is {tuple(out.shape)}, expected {M}x{N // 3}")
+        _need(out.dim() == 2 or out.shape[1] == rows_per_batch, "gemm: EPI_QK_NORM_ROPE segments are the per-sample row blocks (seg_rows == rows_per_batch)")
+        return _fused_qkv_epilogue(acc, out, rope, rows_per_batch)
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk(out, BF16, "out"); _seg(out, "out")
@@ -598,6 +663,65 @@ def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d,
     dv_rows[:, :H * d] = gv.permute(0, 2, 1, 3).reshape(B * S, H * d).to(BF16)
 
 
+def attn_fwd_vrows(Q, K, v_rows, O, lse2, B, H, S, d, scale, key_bias=None):
+    """attn_fwd with V row-major (token rows, head h at columns h*d): no V^T copy.  d = 128."""
+    _chk(v_rows, BF16, "v_rows"); _rows(v_rows, "v_rows")
+    _need(d == 128 and v_rows.shape[0] == B * S and v_rows.shape[1] >= H * d, "attn_fwd_vrows: shapes")
+    Sp = (S + 63) // 64 * 64
+    Vt = torch.zeros(B, H, d, Sp, dtype=BF16)
+    Vt[..., :S] = v_rows[:, :H * d].reshape(B, S, H, d).permute(0, 2, 3, 1)
+    attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=key_bias)
+
+
+def _qk_from_z(dz, z, rrms_part, w, cos_p, sin_p):
+    """backward of RMSNorm(w) + pair rotation starting from the roped output z and the saved 1/rms (st355_qk_rope_norm_bwd): y = R^T z, x_hat = y / w,
+    dy = R^T dz, dx = r (w dy - x_hat mean(dy y))"""
+    dy = _rot_pairs_T(dz, cos_p, sin_p)
+    if w is None:
+        return dy
+    y = _rot_pairs_T(z, cos_p, sin_p)
+    wf = w.float()
+    _need(float(wf.abs().min()) > 0.0, "qk_rope_norm_bwd: norm weights must be non-zero")
+    xhat = y / wf
+    return rrms_part[..., None] * (wf * dy - xhat * (dy * y).mean(dim=-1, keepdim=True))
+
+
+def qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq, wk, cos, sin, dqkv, B, H, d, S_part, pos0, S):
+    """from head-major dQ / dK: the dq / dk column blocks of dqkv for the S_part tokens at joint position pos0.  cos / sin here are the FULL-width [S, d] tables"""
+    _need(d == 128, "qk_rope_norm_bwd: head_dim 128")
+    D = H * d
+    drows = _stream_rows(dqkv, B, S, pos0, S_part)
+    rr = rrms.view(B, S, 2 * H)[:, pos0:pos0 + S_part]
+    c, s = cos[pos0:pos0 + S_part, 0::2], sin[pos0:pos0 + S_part, 0::2]
+    for j, (w, g, z) in enumerate(((wq, dQ, Q), (wk, dK, K))):
+        gz = g[:, :, pos0:pos0 + S_part].float().permute(0, 2, 1, 3)
+        zz = z[:, :, pos0:pos0 + S_part].float().permute(0, 2, 1, 3)
+        dx = _qk_from_z(gz, zz, rr[..., j * H:(j + 1) * H], w, c, s)
+        drows[..., j * D:(j + 1) * D] = dx.reshape(B, S_part, D).to(BF16)
+
+
+def attn_bwd_rope(Q, K, v_rows, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, split, cos_p, sin_p, dqkv, B, H, S, Sp, d, scale, key_bias=None):
+    """attention backward with the RoPE + RMSNorm backward in the dQ / dK epilogues: dq, dk, dv land in the rows of dqkv [B*S, >= 3*H*d]; joint positions < split use
+    the *_lo norm weights.  cos_p / sin_p: per-pair tables [S, 64]"""
+    _need(d == 128 and 0 <= split <= S and dqkv.shape[1] >= 3 * H * d, "attn_bwd_rope: bad arguments")
+    _need((wq_lo is None) == (wq_hi is None) and (wk_lo is None) == (wk_hi is None), "attn_bwd_rope: a norm weight needs both position ranges")
+    _chk(rrms, F32, "rrms"); _chk(dqkv, BF16, "dqkv"); _chk(cos_p, F32, "cos_p"); _chk(sin_p, F32, "sin_p")
+    D = H * d
+    dQ = torch.empty(B, H, S, d, dtype=BF16); dK = torch.empty_like(dQ)
+    attn_bwd(Q, K, None, None, v_rows, O, dO, lse2, dQ, dK, dqkv[:, 2 * D:3 * D], B, H, S, Sp, d, scale, key_bias=key_bias)
+    rr = rrms.view(B, S, 2 * H)
+    rows = dqkv.view(B, S, -1) if dqkv.is_contiguous() else _stream_rows(dqkv, B, S, 0, S)
+    for lo, hi, wq, wk in ((0, split, wq_lo, wk_lo), (split, S, wq_hi, wk_hi)):
+        if hi <= lo:
+            continue
+        c, s = cos_p[lo:hi], sin_p[lo:hi]
+        for j, (w, g, z) in enumerate(((wq, dQ, Q), (wk, dK, K))):
+            gz = g[:, :, lo:hi].float().permute(0, 2, 1, 3)
+            zz = z[:, :, lo:hi].float().permute(0, 2, 1, 3)
+            dx = _qk_from_z(gz, zz, rr[:, lo:hi, j * H:(j + 1) * H], w, c, s)
+            rows[:, lo:hi, j * D:(j + 1) * D] = dx.reshape(B, hi - lo, D).to(BF16)
+
+
 def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale, key_bias=None):
     _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
     _rows(O, "O")
@@ -886,7 +1010,7 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
     return dp
 
 
-_EMULATED = ("grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
+_EMULATED = ("qk_rope", "attn_fwd_vrows", "attn_bwd_rope", "qk_rope_norm_bwd", "grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
              "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
