@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--lora", action="store_true", help="sdxl only: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA)")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
                     "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
-    ap.add_argument("--full", action="store_true", help="sd3 only: full fine-tune (every parameter trains, bf16 AdamW arena) + EMA — BASELINE configs[3]")
+    ap.add_argument("--full", action="store_true", help="flux / sd3 / sdxl / sd15: full-parameter training (every parameter trains, bf16 arena, one fused optimizer launch); sd3 + EMA = BASELINE configs[3], flux = the reference's full-rank datapoint")
     ap.add_argument("--optimizer", default="st355-adamw", choices=["st355-adamw", "adamw_bf16"])
     ap.add_argument("--buckets", action="store_true",
                     help="sd3: cycle the mixed aspect buckets of SURVEY.md §8(d) (latents 128x128, 96x168, 168x96, 112x144, 144x112), one bucket "
