@@ -1,13 +1,11 @@
-"""Pins tests/ops_emulator.py to the kernels it stands in for: every emulated wrapper on random operands, the emulator on the CPU against libst355 on the MI355X
-(bf16 rounding apart).  OPT-IN (`ST355_EMULATOR_CROSSCHECK=1 python -m pytest tests/test_ops_emulator_crosscheck_gpu.py -m gpu`): written in round 3 after the GPU budget
-was spent, so it has not run yet and must not be able to stop the default GPU suite; the CPU host-sequencing tests pin the emulator indirectly (their LoRA cases
-reproduce, through the emulator, results the GPU suite proves through the kernels)."""
-import os
-
+"""Pins tests/ops_emulator.py to the kernels it stands in for: the emulated wrappers on random operands, the emulator on the CPU against libst355 on the MI355X
+(bf16 rounding apart) — GEMM epilogues, the TN GEMM, token-axis reductions, AdaLN forward / backward, RMSNorm + RoPE forward / backward with the norm-weight gradients,
+attention forward / backward with a key bias, the UNet's grid-buffer ops (layout, GroupNorm, 3x3 convolution and its weight gradient, upsampling), the fused loss and AdamW.
+First run: round 3, `profiles/r03t_emulator_crosscheck.log` (5 passed).  The CPU host-sequencing tests then carry the kernels' semantics, not just the emulator's."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("ST355_EMULATOR_CROSSCHECK") != "1", reason="opt-in: ST355_EMULATOR_CROSSCHECK=1")]
+pytestmark = pytest.mark.gpu
 BF16, F32 = torch.bfloat16, torch.float32
 DEV = "cuda:0"
 
