@@ -98,19 +98,9 @@ struct RopeBwd {
 // replaced).  So the wave parks its 32 tokens x 128 channels (already scaled, rounded to bf16 exactly like the head-major dQ / dK of the unfused path) in
 // its own 8 KiB slice of the idle LDS ring, XOR-swizzled by token, and reads it back with 16 lanes per token x 16 bytes: all global traffic is then whole
 // 256-byte token rows, the RMSNorm reduction a 16-lane xor-shuffle tree.
-__device__ __forceinline__ void rope_bwd_store(const RopeBwd& rp, const f32x16 (&acc)[4], float scale, const bf16* zhead, int b, int head, int tok0, int ntok,
-                                               int lane, char* stage) {   // zhead: roped head-major activations of (b, head); tok0: the wave's first token
-  const int h = lane >> 5, l31 = lane & 31;
-#pragma unroll
-  for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-      bf16x4 o;
-#pragma unroll
-      for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
-      const int ch16 = 4 * dt + a;                                        // 16-byte chunk of the token row; h picks its 8-byte half
-      *(bf16x4*)(stage + l31 * 256 + ((ch16 ^ (l31 & 15)) << 4) + 8 * h) = o;
-    }
+// second half of rope_bwd_store: the wave's 32 tokens x 128 channels are parked in `stage` (bf16, token rows of 256 bytes, 16-byte chunk c of token t at
+// c ^ (t & 15)); read them back 16 lanes per token and finish (k_attn_bwd_dq64 parks from its hand-scheduled body and calls this directly)
+__device__ __forceinline__ void rope_bwd_finish(const RopeBwd& rp, const bf16* zhead, int b, int head, int tok0, int ntok, int lane, const char* stage) {
   const int tl = lane >> 4, c = lane & 15;                                // read side: token tl of each group of 4, 16-byte chunk c (channels 8c .. 8c+7)
   float wlo[8], whi[8];
 #pragma unroll
@@ -150,6 +140,21 @@ __device__ __forceinline__ void rope_bwd_store(const RopeBwd& rp, const f32x16 (
     }
     if (tok0 + t < ntok) *(bf16x8*)(rp.out + ((int64_t)b * rp.S + tok) * rp.ldo + (int64_t)head * 128 + c * 8) = o;
   }
+}
+__device__ __forceinline__ void rope_bwd_store(const RopeBwd& rp, const f32x16 (&acc)[4], float scale, const bf16* zhead, int b, int head, int tok0, int ntok,
+                                               int lane, char* stage) {   // zhead: roped head-major activations of (b, head); tok0: the wave's first token
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      bf16x4 o;
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
+      const int ch16 = 4 * dt + a;                                        // 16-byte chunk of the token row; h picks its 8-byte half
+      *(bf16x4*)(stage + l31 * 256 + ((ch16 ^ (l31 & 15)) << 4) + 8 * h) = o;
+    }
+  rope_bwd_finish(rp, zhead, b, head, tok0, ntok, lane, stage);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,10 +764,97 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// dQ kernel, second generation (head_dim 128, r4): 4 waves x 64 queries — ONE wave per SIMD with the whole 512-register file.
+// Why: in k_attn_bwd_dq every MFMA fetches a fresh 1-KiB operand fragment from LDS (one resident operand, 32 queries per wave), so the LDS pipe has to
+// run at the matrix pipe's rate; with 64 queries per wave each K / V / K^T fragment feeds TWO MFMAs (0.5 fragment reads per MFMA).  That needs dQ^T
+// 64 q x 128 d (128 registers) + the Q and dO fragments of 64 queries (128) + two generations of score accumulators (128): a one-wave-per-SIMD budget
+// that hipcc's allocator does not manage (the plain-HIP form of this kernel compiled to 256 + 256 registers, 117 spills and ~540 v_accvgpr copies per
+// tile).  So the main loop is ONE asm statement with an asm-owned register map, generated by tools/kgen/dq64.py (structure, pipeline and the
+// wait-state rules it keeps are documented there); HIP code computes the lane addresses in front of it and finishes behind it.
+//   pipeline over 32-key blocks j:   A(j) S^T, dP^T (32 MFMAs)   B(j) dS (VALU)   C(j) dQ^T += K^T dS^T (16 MFMAs);  step j = [A(j+1) | B(j)] ; C(j)
+//   K / V tiles (row-major, 256-byte pitch, swz_q chunk swizzle) arrive by LDS-DMA into a ring of three 32-KiB slots, one tile ahead, one barrier per tile
+//   dQ leaves through the (idle) ring: parked as bf16 token rows, read back 16 lanes per token by rope_bwd_finish (fused RoPE + RMSNorm backward) or
+//   stored as whole 256-byte rows (plain head-major dQ)
+// Same arithmetic, same accumulation order as k_attn_bwd_dq<128, true, false>: results are bit-identical (tools/attn_lab checks).
+// Built for Sk % 64 == 0 and no key bias (the Flux / PixArt-2K self-attention shapes); everything else keeps k_attn_bwd_dq.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                          const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
+                                                          const float* __restrict__ delta, bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk,
+                                                          float scale, float scale2, RopeBwd rp) {
+  constexpr int HD = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
+  const int64_t bh = (int64_t)b * H + head;
+  const int q0 = wg.tile * 256 + wv * 64;
+  {
+    const int qi0 = min(q0 + l31, Sq - 1), qi1 = min(q0 + 32 + l31, Sq - 1);
+    const bf16* qp0 = Q + (bh * Sq + qi0) * (int64_t)HD + 8 * h;
+    const bf16* qp1 = Q + (bh * Sq + qi1) * (int64_t)HD + 8 * h;
+    const bf16* dp0 = dO + ((int64_t)b * Sq + qi0) * ld_do + (int64_t)head * HD + 8 * h;
+    const bf16* dp1 = dO + ((int64_t)b * Sq + qi1) * ld_do + (int64_t)head * HD + 8 * h;
+    const float nlse0 = -lse2[bh * Sq + qi0], nlse1 = -lse2[bh * Sq + qi1];
+    const float del0 = delta[bh * (int64_t)Sqp + qi0], del1 = delta[bh * (int64_t)Sqp + qi1];
+    // LDS-DMA lane offsets of the wave's first piece (piece = wave + 4 p; chunk idx = piece * 64 + lane): LDS chunk position c of row r holds source chunk c ^ f(r)
+    const int row = wv * 4 + (lane >> 4);
+    const int col = ((lane & 15) ^ swz_q(row)) * 8;
+    const uint32_t koff = (uint32_t)(row * HD + col) * 2u;
+    const uint32_t voff = (uint32_t)((int64_t)row * ld_v + col) * 2u;
+    const uint32_t vrow16 = (uint32_t)(16 * ld_v * 2), vstep = (uint32_t)(64 * ld_v * 2);
+    const int rowp = perm23(l31);
+    const uint32_t rowb = rowp * 256 + ((h ^ swz_q(rowp)) << 4);                     // row fragments: chunk (2 ks + h) ^ f(row)
+    const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
+    const uint32_t trb = (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;   // transposed fragments (dq<TR>)
+    const uint32_t park = l31 * 256 + ((l31 & 15) << 4) + 8 * h;
+    const bf16* kbase = K + bh * (int64_t)Sk * HD;
+    const bf16* vbase = Vrows + (int64_t)b * Sk * ld_v + (int64_t)head * HD;
+    const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t wvoff = (uint32_t)wv * 1024u;
+    const uint32_t nkt = (uint32_t)(Sk / 64);
+    asm volatile(
+#include "gen/attn_dq64_body.inc"
+        :
+        : [qp0] "v"(qp0), [qp1] "v"(qp1), [dp0] "v"(dp0), [dp1] "v"(dp1), [nlse0] "v"(nlse0), [nlse1] "v"(nlse1), [del0] "v"(del0), [del1] "v"(del1),
+          [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [trb] "v"(trb), [park] "v"(park), [kbase] "s"(kbase), [vbase] "s"(vbase),
+          [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vstep] "s"(vstep), [vrow16] "s"(vrow16), [scale2] "s"(scale2), [scale] "s"(scale)
+        : "memory", "vcc", "scc",
+#include "gen/attn_dq64_clobbers.inc"
+    );
+  }
+  // every index below is re-derived: nothing needs to live across the statement above
+  const char* mine = smem + wv * 16384;
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const int tok0 = q0 + 32 * qb;
+    if (rp.out != nullptr) {
+      rope_bwd_finish(rp, Q + bh * (int64_t)Sq * HD, b, head, tok0, Sq, lane, mine + qb * 8192);
+    } else {
+      const int tl = lane >> 4, c = lane & 15;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int t = it * 4 + tl;
+        if (tok0 + t < Sq) *(bf16x8*)(dQ + (bh * Sq + tok0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + qb * 8192 + t * 256 + ((c ^ (t & 15)) << 4));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {   // S, Sp: the QUERY length and its padding
   return 2 * round256((size_t)B * H * Sp * sizeof(float)) + round256((size_t)B * H * d * Sp * 2);   // delta, lse (padded) + dO^T
+}
+
+// dQ kernel choice: 64 = k_attn_bwd_dq64 where it applies (default), 32 = always k_attn_bwd_dq.  ST355_ATTN_DQ overrides; tools/attn_lab sets the variable directly.
+int g_attn_dq_impl = -1;
+static int attn_dq_impl() {
+  if (g_attn_dq_impl < 0) { const char* e = getenv("ST355_ATTN_DQ"); g_attn_dq_impl = (e && atoi(e) == 32) ? 32 : 64; }
+  return g_attn_dq_impl;
 }
 
 static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
@@ -831,7 +923,16 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
-  {
+  if (d == 128 && !Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
+    ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
+    dim3 grid((S + 255) / 256, H, B);
+    const int lds = 3 * 2 * 64 * 256;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(k_attn_bwd_dq64, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2,
+                       (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq);
+    if ((rc = st355_check_launch("attn_bwd_dq64")) != 0) return rc;
+  } else {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int ktb = 64 * d * 2;                                   // one row-major 64-key tile

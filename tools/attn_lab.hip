@@ -153,20 +153,22 @@ int main(int argc, char** argv) {
   }
   if (strcmp(gen, "1") != 0) return 0;    // the backward comparison runs once (in the generation-1 child)
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
-  for (int pass = 0; pass < 2; pass++) {
+  bf16* dQ3; CK(hipMalloc(&dQ3, nh * 2)); CK(hipMemsetAsync(dQ3, 0, nh * 2, st));
+  for (int pass = 0; pass < 3; pass++) {     // 0: transposed copies (dkv2 + dq)   1: no copies, 32-query dQ kernel (dkv3 + dq<TR>)   2: no copies, dq64
+    g_attn_dq_impl = pass == 2 ? 64 : 32;
     const bf16* qt = pass ? nullptr : Qt; const bf16* kt = pass ? nullptr : Kt;
-    bf16 *dq_ = pass ? dQ2 : dQ, *dk_ = pass ? dK2 : dK, *dv_ = (pass ? dqkv2 : dqkv) + 2 * D;
+    bf16 *dq_ = pass == 2 ? dQ3 : pass ? dQ2 : dQ, *dk_ = pass ? dK2 : dK, *dv_ = (pass ? dqkv2 : dqkv) + 2 * D;
     RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
     CK(hipStreamSynchronize(st));
     st355_prof_reset(); st355_prof_enable(1);
     for (int i = 0; i < iters; i++) RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
     CK(hipStreamSynchronize(st));
-    st355_prof_enable(0); prof_print(pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
+    st355_prof_enable(0); prof_print(pass == 2 ? "bwd, no copies, dq64" : pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
   }
   if (d != 128 && d != 64 && d != 96) return 0;
   unsigned long long* bad; float* maxd; CK(hipMalloc(&bad, 8)); CK(hipMalloc(&maxd, 4));
   struct { const char* n; const bf16* a; const bf16* b; int64_t cnt, ld, cols; } cmp[] = {
-      {"dQ", dQ, dQ2, (int64_t)nh, 0, 0}, {"dK", dK, dK2, (int64_t)nh, 0, 0}, {"dV", dqkv + 2 * D, dqkv2 + 2 * D, (int64_t)nr, 3 * D, D}};
+      {"dQ (dq64 vs dq)", dQ2, dQ3, (int64_t)nh, 0, 0}, {"dQ", dQ, dQ2, (int64_t)nh, 0, 0}, {"dK", dK, dK2, (int64_t)nh, 0, 0}, {"dV", dqkv + 2 * D, dqkv2 + 2 * D, (int64_t)nr, 3 * D, D}};
   for (auto& c : cmp) {
     CK(hipMemsetAsync(bad, 0, 8, st)); CK(hipMemsetAsync(maxd, 0, 4, st));
     k_diff<<<2048, 256, 0, st>>>(c.a, c.b, c.cnt, c.ld, c.cols, bad, maxd);
