@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
 __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                           const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                           const float* __restrict__ delta, bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk,
-                                                          float scale, float scale2, RopeBwd rp) {
+                                                          float scale, float scale2, RopeBwd rp, unsigned long long* trace) {
   constexpr int HD = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -792,6 +792,9 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
   const int64_t bh = (int64_t)b * H + head;
   const int q0 = wg.tile * 256 + wv * 64;
   {
+    // (lab builds of the body stamp s_memtime at the phase boundaries and dump them through `trace`; the product body ignores these three operands)
+    const uint32_t blk0 = blockIdx.x | blockIdx.y | blockIdx.z;
+    const uint32_t tracelo = (uint32_t)(uintptr_t)trace, tracehi = (uint32_t)((uintptr_t)trace >> 32);
     const int qi0 = min(q0 + l31, Sq - 1), qi1 = min(q0 + 32 + l31, Sq - 1);
     const bf16* qp0 = Q + (bh * Sq + qi0) * (int64_t)HD + 8 * h;
     const bf16* qp1 = Q + (bh * Sq + qi1) * (int64_t)HD + 8 * h;
@@ -816,11 +819,16 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
     const uint32_t wvoff = (uint32_t)wv * 1024u;
     const uint32_t nkt = (uint32_t)(Sk / 64);
     asm volatile(
+#ifdef ST355_DQ64_BODY_INC       // tools/attn_lab builds: a generator variant under test
+#include ST355_DQ64_BODY_INC
+#else
 #include "gen/attn_dq64_body.inc"
+#endif
         :
         : [qp0] "v"(qp0), [qp1] "v"(qp1), [dp0] "v"(dp0), [dp1] "v"(dp1), [nlse0] "v"(nlse0), [nlse1] "v"(nlse1), [del0] "v"(del0), [del1] "v"(del1),
           [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [trb] "v"(trb), [park] "v"(park), [kbase] "s"(kbase), [vbase] "s"(vbase),
-          [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vstep] "s"(vstep), [vrow16] "s"(vrow16), [scale2] "s"(scale2), [scale] "s"(scale)
+          [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vstep] "s"(vstep), [vrow16] "s"(vrow16), [scale2] "s"(scale2), [scale] "s"(scale),
+          [blk0] "s"(blk0), [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)
         : "memory", "vcc", "scc",
 #include "gen/attn_dq64_clobbers.inc"
     );
@@ -852,6 +860,7 @@ extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
 
 // dQ kernel choice: 64 = k_attn_bwd_dq64 where it applies (default), 32 = always k_attn_bwd_dq.  ST355_ATTN_DQ overrides; tools/attn_lab sets the variable directly.
 int g_attn_dq_impl = -1;
+unsigned long long* g_attn_dq_trace = nullptr;     // tools/attn_lab, trace builds of the dq64 body only
 static int attn_dq_impl() {
   if (g_attn_dq_impl < 0) { const char* e = getenv("ST355_ATTN_DQ"); g_attn_dq_impl = (e && atoi(e) == 32) ? 32 : 64; }
   return g_attn_dq_impl;
@@ -930,7 +939,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
     hipLaunchKernelGGL(k_attn_bwd_dq64, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2,
-                       (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq);
+                       (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq, g_attn_dq_trace);
     if ((rc = st355_check_launch("attn_bwd_dq64")) != 0) return rc;
   } else {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);

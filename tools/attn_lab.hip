@@ -154,6 +154,7 @@ int main(int argc, char** argv) {
   if (strcmp(gen, "1") != 0) return 0;    // the backward comparison runs once (in the generation-1 child)
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
   bf16* dQ3; CK(hipMalloc(&dQ3, nh * 2)); CK(hipMemsetAsync(dQ3, 0, nh * 2, st));
+  if (getenv("LAB_DQ_TRACE")) { CK(hipMalloc(&g_attn_dq_trace, 4 * 128)); CK(hipMemsetAsync(g_attn_dq_trace, 0, 4 * 128, st)); }
   for (int pass = 0; pass < 3; pass++) {     // 0: transposed copies (dkv2 + dq)   1: no copies, 32-query dQ kernel (dkv3 + dq<TR>)   2: no copies, dq64
     g_attn_dq_impl = pass == 2 ? 64 : 32;
     const bf16* qt = pass ? nullptr : Qt; const bf16* kt = pass ? nullptr : Kt;
@@ -164,6 +165,14 @@ int main(int argc, char** argv) {
     for (int i = 0; i < iters; i++) RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
     CK(hipStreamSynchronize(st));
     st355_prof_enable(0); prof_print(pass == 2 ? "bwd, no copies, dq64" : pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
+  }
+  if (g_attn_dq_trace) {      // s_memtime stamps of block 0's LAST main-loop iteration: loop top, after A / after C of step 1, after A / after C of step 2
+    unsigned long long t[64]; CK(hipMemcpy(t, g_attn_dq_trace, sizeof(t), hipMemcpyDeviceToHost));
+    for (int w = 0; w < 4; w++) {
+      const unsigned long long* u = t + 16 * w;
+      printf("  dq64 trace wave %d: A1 %llu  C1 %llu  A2 %llu  C2 %llu  (tile %llu cycles) | prologue %llu  loop+last %llu  park %llu  (statement %llu)\n", w, u[1] - u[0],
+             u[2] - u[1], u[3] - u[2], u[4] - u[3], u[4] - u[0], u[6] - u[5], u[7] - u[6], u[8] - u[7], u[8] - u[5]);
+    }
   }
   if (d != 128 && d != 64 && d != 96) return 0;
   unsigned long long* bad; float* maxd; CK(hipMalloc(&bad, 8)); CK(hipMalloc(&maxd, 4));
