@@ -446,6 +446,85 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Third generation (r04, head_dim 128, no bias, S % 64 == 0): 4 waves x 64 queries — ONE wave per SIMD with the whole 512-register file, every K / V^T fragment
+// feeding TWO MFMAs (half the LDS operand traffic per MFMA of k_attn_fwd4), O^T and the Q fragments in AGPRs.  hipcc's allocator does not manage that budget
+// (512 VGPRs + 180 spills), so the main loop is ONE asm statement with an asm-owned register map generated by tools/kgen/fwd64.py (pipeline,
+// stale-reference softmax and wait-state rules are documented there); HIP code computes the lane addresses in front of it and stores O / lse2 behind it
+// (O leaves through the idle LDS ring as whole 256-byte token rows).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt, bf16* __restrict__ O,
+                                                       int64_t ld_o, float* __restrict__ lse2, int H, int Sq, int S, int Sp, float scale2,
+                                                       unsigned long long* trace) {
+  constexpr int HD = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
+  const int64_t bh = (int64_t)b * H + head;
+  const int q0 = wg.tile * 256 + wv * 64;
+  float lse0, lse1;
+  {
+    const int qi0 = min(q0 + l31, Sq - 1), qi1 = min(q0 + 32 + l31, Sq - 1);
+    const bf16* qp0 = Q + (bh * Sq + qi0) * (int64_t)HD + 8 * h;
+    const bf16* qp1 = Q + (bh * Sq + qi1) * (int64_t)HD + 8 * h;
+    // LDS-DMA lane offsets of the wave's first K piece (rows 4 wave + lane / 16, chunk swizzle swz_kv) and first V^T piece (channel rows 8 wave + lane / 8)
+    const int krow = wv * 4 + (lane >> 4);
+    const uint32_t koff = (uint32_t)(krow * HD + ((lane & 15) ^ swz_kv(krow)) * 8) * 2u;
+    const int vrow = wv * 8 + (lane >> 3);
+    const uint32_t voff = (uint32_t)(vrow * Sp + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8) * 2u;
+    const uint32_t vrow32 = (uint32_t)(32 * Sp * 2);
+    const int rowp = perm23(l31);
+    const uint32_t rowb = rowp * 256 + ((h ^ swz_kv(rowp)) << 4);                     // K row fragments: chunk (2 ks + h) ^ f(row)
+    const uint32_t vtb = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);                   // V^T fragments: row 32 dt + l31, chunk (4 sb + 2 m + h) ^ ((row >> 1) & 7)
+    const uint32_t park = l31 * 256 + ((l31 & 15) << 4) + 8 * h;
+    const bf16* kbase = K + bh * (int64_t)S * HD;
+    const bf16* vbase = Vt + bh * (int64_t)HD * Sp;
+    const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t wvoff = (uint32_t)wv * 1024u;
+    const uint32_t nkt = (uint32_t)(S / 64);
+    const uint32_t blk0 = blockIdx.x | blockIdx.y | blockIdx.z;
+    const uint32_t tracelo = (uint32_t)(uintptr_t)trace, tracehi = (uint32_t)((uintptr_t)trace >> 32);
+    asm volatile(
+#ifdef ST355_FWD64_BODY_INC       // tools/attn_lab builds: a generator variant under test
+#include ST355_FWD64_BODY_INC
+#else
+#include "gen/attn_fwd64_body.inc"
+#endif
+        : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
+        : [qp0] "v"(qp0), [qp1] "v"(qp1), [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [vtb] "v"(vtb), [park] "v"(park), [kbase] "s"(kbase),
+          [vbase] "s"(vbase), [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vrow32] "s"(vrow32), [scale2] "s"(scale2), [blk0] "s"(blk0),
+          [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)
+        : "memory", "vcc", "scc",
+#include "gen/attn_fwd64_clobbers.inc"
+    );
+  }
+  const char* mine = smem + wv * 16384;
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const int tok0 = q0 + 32 * qb;
+    const int tl = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int t = it * 4 + tl;
+      if (tok0 + t < Sq)
+        *(bf16x8*)(O + ((int64_t)b * Sq + tok0 + t) * ld_o + (int64_t)head * HD + c * 8) = *(const bf16x8*)(mine + qb * 8192 + t * 256 + ((c ^ (t & 15)) << 4));
+    }
+    const int q = tok0 + l31;
+    if (h == 0 && q < Sq) lse2[bh * Sq + q] = qb ? lse1 : lse0;
+  }
+}
+
+// forward kernel choice where k_attn_fwd64 applies: 64 (default) or 32 = k_attn_fwd4.  ST355_ATTN_FWD64=0 overrides; tools/attn_lab sets the variable directly.
+int g_attn_fwd_impl = -1;
+unsigned long long* g_attn_fwd_trace = nullptr;    // tools/attn_lab, trace builds of the fwd64 body only
+static int attn_fwd_impl64() {
+  if (g_attn_fwd_impl < 0) { const char* e = getenv("ST355_ATTN_FWD64"); g_attn_fwd_impl = (e && e[0] == '0') ? 32 : 64; }
+  return g_attn_fwd_impl;
+}
+
 // vrow != 0: Vt is the ROW-major V (token rows, head h at columns h*d) and Sp its leading dimension (k_attn_fwd4<128, *, true>)
 static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
                          int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale, int vrow = 0) {
@@ -462,6 +541,15 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // the forward is latency-shaped and wants two INDEPENDENT workgroups per CU; logs under profiles/r02_attn_lab_*.log.)
   static int gen = -1;
   if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '1') ? 1 : 4; }
+  if (gen == 4 && !vrow && !key_bias && d == 128 && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
+    dim3 grid64((Sq + 255) / 256, H, B);
+    const int lds64 = 4 * 2 * 64 * 256;
+    static bool set64 = false;
+    if (!set64) { hipFuncSetAttribute((const void*)k_attn_fwd64, hipFuncAttributeMaxDynamicSharedMemorySize, lds64); set64 = true; }
+    hipLaunchKernelGGL(k_attn_fwd64, grid64, dim3(256), lds64, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, ld_o, lse2, H, Sq, S, Sp,
+                       scale2, g_attn_fwd_trace);
+    return st355_check_launch("attn_fwd64");
+  }
   dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);
   const int lds = 2 * (KB * d * 2 + d * 128);
 #define ST355_FWD_LAUNCH(KERN)                                                                                                           \

@@ -93,6 +93,8 @@ int main(int argc, char** argv) {
   const float scale = 1.f / sqrtf((float)d);
   const int iters = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 10;
   // ---- forward ----
+  g_attn_fwd_impl = 32;                      // the 32-queries-per-wave kernels first (generation 1 or 4 by ST355_ATTN_FWD); fwd64 is timed and compared below
+  if (getenv("LAB_FWD_TRACE")) { CK(hipMalloc(&g_attn_fwd_trace, 4 * 128)); CK(hipMemsetAsync(g_attn_fwd_trace, 0, 4 * 128, st)); }
   RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O, D, lse2, B, H, S, Sp, d, scale));
   CK(hipStreamSynchronize(st));
   st355_prof_reset(); st355_prof_enable(1);
@@ -127,7 +129,34 @@ int main(int argc, char** argv) {
     CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
     printf("  O vs generation 1: %llu of %lld elements differ (max |d| %.3e)\n", hb, (long long)nr, hm);
   }
-  if (strcmp(gen, "1") != 0 && d == 128 && S % 64 == 0) {   // LAB-ONLY variant: stale-maximum rescale (tools/attn_fwd_variants.hip), timed with events, compared with the product's O
+  if (strcmp(gen, "1") != 0 && d == 128 && S % 64 == 0) {   // k_attn_fwd64 (one wave per SIMD, 64 queries per wave): timed, O and lse2 compared with k_attn_fwd4
+    bf16* O6; float* lse6; CK(hipMalloc(&O6, nr * 2)); CK(hipMalloc(&lse6, (size_t)BH * S * 4));
+    CK(hipMemsetAsync(O6, 0, nr * 2, st)); CK(hipMemsetAsync(lse6, 0, (size_t)BH * S * 4, st));
+    g_attn_fwd_impl = 64;
+    RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O6, D, lse6, B, H, S, Sp, d, scale));
+    CK(hipStreamSynchronize(st));
+    st355_prof_reset(); st355_prof_enable(1);
+    for (int i = 0; i < iters; i++) RC(st355_attn_fwd(st, Q, K, Vt, nullptr, O6, D, lse6, B, H, S, Sp, d, scale));
+    CK(hipStreamSynchronize(st));
+    st355_prof_enable(0); prof_print("forward, fwd64");
+    g_attn_fwd_impl = 32;
+    float* maxd; double *sd, *sr; CK(hipMalloc(&maxd, 4)); CK(hipMalloc(&sd, 8)); CK(hipMalloc(&sr, 8));
+    CK(hipMemsetAsync(maxd, 0, 4, st)); CK(hipMemsetAsync(sd, 0, 8, st)); CK(hipMemsetAsync(sr, 0, 8, st));
+    k_absdiff<<<2048, 256, 0, st>>>(O6, O, (int64_t)nr, maxd, sd, sr);
+    float hm; double hd, hr;
+    CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hd, sd, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hr, sr, 8, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    printf("  O, fwd64 vs fwd4: rel-L2 %.3e, max |d| %.3e  %s\n", sqrt(hd / (hr + 1e-30)), hm, sqrt(hd / (hr + 1e-30)) < 4e-3 ? "within bf16 rounding" : "MISMATCH");
+    float* hl = (float*)malloc((size_t)BH * S * 4); float* hl6 = (float*)malloc((size_t)BH * S * 4);
+    CK(hipMemcpy(hl, lse2, (size_t)BH * S * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl6, lse6, (size_t)BH * S * 4, hipMemcpyDeviceToHost));
+    double ml = 0; for (size_t i = 0; i < (size_t)BH * S; i++) { double e = fabs((double)hl[i] - hl6[i]); if (!(e <= ml)) ml = e; }
+    printf("  lse2, fwd64 vs fwd4: max |d| %.3e  %s\n", ml, ml < 2e-3 ? "ok" : "MISMATCH");
+    if (g_attn_fwd_trace) {
+      unsigned long long t[64]; CK(hipMemcpy(t, g_attn_fwd_trace, sizeof(t), hipMemcpyDeviceToHost));
+      for (int w = 0; w < 4; w++) printf("  fwd64 trace wave %d: A %llu  C %llu  (step %llu cycles)\n", w, t[16 * w + 1] - t[16 * w], t[16 * w + 2] - t[16 * w + 1], t[16 * w + 2] - t[16 * w]);
+    }
+  }
+  if (strcmp(gen, "1") != 0 && d == 128 && S % 64 == 0 && getenv("LAB_STALE")) {   // LAB-ONLY variant: stale-maximum rescale (tools/attn_fwd_variants.hip), timed with events, compared with the product's O
     bf16* O3; float* lse4; CK(hipMalloc(&O3, nr * 2)); CK(hipMalloc(&lse4, (size_t)BH * S * 4));
     const int lds = 2 * (KB * 256 + 128 * 128);
     CK(hipFuncSetAttribute((const void*)k_attn_fwd4_stale<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
