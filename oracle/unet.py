@@ -12,7 +12,17 @@ CrossAttnDown blocks of ResnetBlock2D (GroupNorm32 eps 1e-5 -> SiLU -> conv3x3 -
 self-attention -> LayerNorm -> cross-attention over the text tokens -> LayerNorm -> GEGLU feed-forward, all residual -> proj_out -> + input);
 Downsample2D (conv3x3 stride 2 pad 1); mid block; Up blocks (concat skip, resnets, nearest-2x Upsample2D + conv3x3); conv_norm_out -> SiLU ->
 conv_out.  State-dict keys and tensor shapes are diffusers' (conv weights [O,I,kh,kw]).
-PARITY UNPINNED: the reference holds no golden tensor for this network and diffusers is not installable here.
+PARITY: LEAVES PINNED, WALK RESTATED.  The reference holds no golden tensor for this network and diffusers is not installable here, but
+the leaves below are checked against reference code executed in the build container (tools/gen_ref_unet_leaves.py -> tests/golden/ref_unet_leaves.pt,
+tests/test_ref_unet_leaves_cpu.py, forward and every gradient <= 1e-5):
+  * `resnet` (norm -> SiLU -> conv3x3 -> norm -> SiLU -> conv3x3, GroupNorm(32), 1x1 conv_shortcut), `upsample` (nearest 2x + conv3x3), the stride-2 3x3
+    convolution of `downsample`, and `_attention` + GroupNorm + residual against the KL-autoencoder blocks the reference vendors
+    (helpers/models/ideogram/autoencoder.py:29-110) fed through its own diffusers-key converter (:321-392);
+  * `timestep_proj` + the Linear -> SiLU -> Linear embedder against Timesteps / TimestepEmbedding lifted from helpers/models/heartmula/codec/transformer.py.
+What stays RESTATED (from the published diffusers modules; the reference carries no copy): the `+ time_emb_proj(SiLU(emb))` add inside `resnet` (one line),
+the symmetric padding-1 of Downsample2D, `basic_block` / GEGLU / multi-head cross-attention (cross-checked only against tools/ref_shim.py's independent
+restatement of the same public definition), the GroupNorm(1e-6) -> proj_in -> blocks -> proj_out wiring of `transformer2d`, and the block-to-block walk of
+`unet_forward` (down / mid / reversed up path with skip concatenation, the "text_time" addition embedding).
 """
 from __future__ import annotations
 
@@ -73,6 +83,21 @@ def resnet(P, p, x, emb, groups, eps):
     return x + h
 
 
+def downsample(P, name, x, padding=1):
+    """Downsample2D: 3x3 convolution, stride 2 (diffusers' UNet form: symmetric padding 1)"""
+    return _conv(x, P, name, stride=2, padding=padding)
+
+
+def upsample(P, name, x):
+    """Upsample2D: nearest-neighbour 2x, then 3x3 convolution"""
+    return _conv(F.interpolate(x, scale_factor=2.0, mode="nearest"), P, name)
+
+
+def time_embedding(P, name, t_emb):
+    """TimestepEmbedding: Linear -> SiLU -> Linear"""
+    return _lin(F.silu(_lin(t_emb, P, name + ".linear_1")), P, name + ".linear_2")
+
+
 def _attention(P, p, x, ctx, heads):
     B, S, C = x.shape
     q = _lin(x, P, p + "to_q")
@@ -118,12 +143,12 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
     dt = sample.dtype
     c0 = cfg.block_out_channels[0]
     t_emb = timestep_proj(timesteps.to(sample.device).expand(sample.shape[0]), c0).to(dt)
-    emb = _lin(F.silu(_lin(t_emb, P, "time_embedding.linear_1")), P, "time_embedding.linear_2")
+    emb = time_embedding(P, "time_embedding", t_emb)
     if cfg.addition_embed_type == "text_time":
         text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
         tid = timestep_proj(time_ids.flatten(), cfg.addition_time_embed_dim).reshape(text_embeds.shape[0], -1)
         add = torch.cat([text_embeds.to(dt), tid.to(dt)], dim=-1)
-        emb = emb + _lin(F.silu(_lin(add, P, "add_embedding.linear_1")), P, "add_embedding.linear_2")
+        emb = emb + time_embedding(P, "add_embedding", add)
     ctx = encoder_hidden_states.to(dt)
     x = _conv(sample, P, "conv_in")
     skips = [x]
@@ -136,7 +161,7 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
                                   cfg.use_linear_projection)
             skips.append(x)
         if i < nb - 1:
-            x = _conv(x, P, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+            x = downsample(P, f"down_blocks.{i}.downsamplers.0.conv", x)
             skips.append(x)
     x = resnet(P, "mid_block.resnets.0.", x, emb, g, eps)
     x = transformer2d(P, "mid_block.attentions.0.", x, ctx, cfg.attention_head_dim[-1], cfg.transformer_layers_per_block[-1], g, cfg.use_linear_projection)
@@ -150,8 +175,7 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
                 x = transformer2d(P, f"up_blocks.{i}.attentions.{j}.", x, ctx, cfg.attention_head_dim[ri], cfg.transformer_layers_per_block[ri], g,
                                   cfg.use_linear_projection)
         if i < nb - 1:
-            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = _conv(x, P, f"up_blocks.{i}.upsamplers.0.conv")
+            x = upsample(P, f"up_blocks.{i}.upsamplers.0.conv", x)
     x = F.silu(F.group_norm(x, g, P["conv_norm_out.weight"], P["conv_norm_out.bias"], eps))
     return _conv(x, P, "conv_out")
 

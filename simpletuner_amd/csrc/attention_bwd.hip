@@ -866,6 +866,15 @@ static int attn_dq_impl() {
   return g_attn_dq_impl;
 }
 
+extern int g_attn_fwd_impl;                        // attention.hip
+extern "C" int st355_attn_set_impl(int fwd, int dq) {
+  if (g_attn_fwd_impl < 0) { const char* e = getenv("ST355_ATTN_FWD64"); g_attn_fwd_impl = (e && e[0] == '0') ? 32 : 64; }
+  const int prev = g_attn_fwd_impl * 256 + attn_dq_impl();
+  if (fwd == 32 || fwd == 64) g_attn_fwd_impl = fwd;
+  if (dq == 32 || dq == 64) g_attn_dq_impl = dq;
+  return prev;
+}
+
 static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
                               int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp, int Sk, int Skp,

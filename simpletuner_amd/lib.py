@@ -23,7 +23,7 @@ SYMBOLS = [
     "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_set_persistent", "st355_gemm_tn_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_transpose_bf16", "st355_sum_chunks_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg", "st355_skinny_tn_multi",
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd", "st355_qk_norm_wgrad_workspace", "st355_qk_norm_rope_bwd_wgrad", "st355_qk_rope_norm_bwd",
-    "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd", "st355_attn_bwd_rope",
+    "st355_attn_set_impl", "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd", "st355_attn_bwd_rope",
     "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp", "st355_grad_clip_norm",
     "st355_lora_pack",
     "st355_workspace_bytes",
@@ -230,6 +230,7 @@ def _declare(lib):
         "st355_qk_norm_wgrad_workspace": (sz, [i32, i32, i32, i32]),
         "st355_qk_norm_rope_bwd_wgrad": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]),
         "st355_qk_rope_norm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32]),
+        "st355_attn_set_impl": (C.c_int, [i32, i32]),
         "st355_attn_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32]),
         "st355_attn_fwd_vrows": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32]),
         "st355_attn_bwd_rope": (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp]),

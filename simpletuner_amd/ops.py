@@ -392,6 +392,13 @@ def gemm_set_persistent(mode: int) -> int:
     return int(_l.load().st355_gemm_set_persistent(int(mode)))
 
 
+def attn_set_impl(fwd: int = -1, dq: int = -1):
+    """st355_attn_set_impl: 64 = the hand-scheduled 64-rows-per-wave kernels where they apply (default), 32 = the 32-row kernels everywhere, -1 = unchanged;
+    returns the previous (fwd, dq)"""
+    prev = int(_l.load().st355_attn_set_impl(int(fwd), int(dq)))
+    return prev // 256, prev % 256
+
+
 def gemm_grouped(problems):
     """run several independent GEMMs that share one epilogue kind in as few launches as possible.
     problems: list of dicts with keys a, w and the kwargs of gemm().  Returns the list of outputs."""

@@ -503,9 +503,59 @@ def test_attention_forward_row_major_v_is_bit_equal(ops, S, with_bias):
     kb = (torch.rand(B, S, device=d_) > 0.25).float() if with_bias else None
     O1 = torch.empty(B * S, D, device=d_, dtype=BF16); l1 = torch.empty(B, H, S, device=d_)
     O2 = torch.empty_like(O1); l2 = torch.empty_like(l1)
-    ops.attn_fwd(Q, K, Vt, O1, l1, B, H, S, Sp, hd, scale, key_bias=kb)
+    prev = ops.attn_set_impl(fwd=32)                                       # the row-major-V kernel is a form of the 32-query kernel: compare with that one
+    try:
+        ops.attn_fwd(Q, K, Vt, O1, l1, B, H, S, Sp, hd, scale, key_bias=kb)
+    finally:
+        ops.attn_set_impl(fwd=prev[0])
     ops.attn_fwd_vrows(Q, K, V, O2, l2, B, H, S, hd, scale, key_bias=kb)
     assert torch.equal(O1, O2) and torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 4, 512), (1, 8, 320), (1, 3, 64), (1, 2, 1152)])
+def test_attention_64_row_kernels_against_the_32_row_kernels(ops, B, H, S):
+    """k_attn_fwd64 / k_attn_bwd_dq64 (one wave per SIMD, 64 queries per wave, hand-scheduled bodies from tools/kgen) against k_attn_fwd4 / k_attn_bwd_dq on the
+    shapes they take over (head_dim 128, no bias, S % 64 == 0; query counts that leave the last 256-query workgroup ragged; one to eighteen key tiles, odd and
+    even: prologue-only, loop and both tail paths).  dQ is BIT-identical (same arithmetic, same accumulation order), with and without the fused RoPE epilogue;
+    O agrees to bf16 rounding (the 64-row forward takes exponentials against a reference maximum that may lag by up to 2^8), lse2 to 1e-5.  One row of Q is
+    spiked against one key in a late tile so that the forward's out-of-line re-reference runs after the first tile as well."""
+    torch.manual_seed(93)
+    d_ = dev()
+    hd = 128
+    D = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    Q = torch.randn(B, H, S, hd, device=d_).to(BF16); K = torch.randn(B, H, S, hd, device=d_).to(BF16)
+    if S >= 192:
+        Q[0, 0, 5] = (K[0, 0, S - 40].float() * 6).to(BF16)               # a score ~ 6 * 128 / sqrt(128) = 68 nats in the last tile: far beyond the bound
+    V = torch.randn(B * S, D, device=d_).to(BF16)
+    Vt = V.view(B, S, H, hd).permute(0, 2, 3, 1).contiguous()
+    dO = torch.randn(B * S, D, device=d_).to(BF16)
+    res = {}
+    prev = ops.attn_set_impl()
+    try:
+        for impl in (32, 64):
+            ops.attn_set_impl(fwd=impl, dq=impl)
+            O = torch.empty(B * S, D, device=d_, dtype=BF16); lse2 = torch.empty(B, H, S, device=d_)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, scale)
+            res[impl] = [O, lse2]
+        O, lse2 = res[32]                                                  # one forward state for both backward kernels
+        cos, sin = _rope_tables(S, hd, d_)
+        cos_p, sin_p = cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous()
+        rrms = (0.5 + torch.rand(B * S, 2 * H, device=d_)).contiguous()
+        w = [(1 + 0.2 * torch.randn(hd, device=d_)).to(BF16) for _ in range(2)]
+        for impl in (32, 64):
+            ops.attn_set_impl(fwd=impl, dq=impl)
+            dQ = torch.empty_like(Q); dK = torch.empty_like(K); dqkv = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+            ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, S, hd, scale)
+            fused = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+            ops.attn_bwd_rope(Q, K, V, O, dO, lse2, rrms, w[0], w[1], w[0], w[1], 0, cos_p, sin_p, fused, B, H, S, S, hd, scale)
+            res[impl] += [dQ, fused]
+    finally:
+        ops.attn_set_impl(fwd=prev[0], dq=prev[1])
+    assert report("fwd64 O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
+    assert float((res[64][1] - res[32][1]).abs().max()) < 1e-4
+    assert torch.equal(res[64][2], res[32][2]), "dq64 is not bit-identical to dq"
+    assert torch.equal(res[64][3], res[32][3]), "dq64 with the fused RoPE epilogue is not bit-identical to dq"
 
 
 @pytest.mark.parametrize("with_norm,split,with_bias", [(True, 256, False), (True, 0, False), (False, 0, False), (True, 256, True)])

@@ -247,8 +247,9 @@ def build() -> str:
     def step(g_cur: int, site: str, full: bool, loop_body: bool) -> None:
         """full: [A(t+1) -> generation g_cur ^ 1 | B(t)] ; C(t) with barrier, LDS-DMA of tile min(t+3, nkt-1), address rebuilds.   not full: B(t) ; C(t)."""
         bm = [] if "nob" in DBG else b_max(g_cur, 0, site) + b_max(g_cur, 1, site)
-        for qb in range(2):
-            out_of_line.extend(rescale_block(qb, site))
+        if "nob" not in DBG:
+            for qb in range(2):
+                out_of_line.extend(rescale_block(qb, site))
         chunks = {(sb, m): ([] if "nob" in DBG else b_exp(g_cur, sb, 0, m) + b_exp(g_cur, sb, 1, m)) for sb in range(2) for m in range(2)}
         barrier = [] if "nobarrier" in DBG else ["s_waitcnt vmcnt(0)", "s_barrier"]
         if not full:
@@ -281,7 +282,7 @@ def build() -> str:
         segs.append((rowa_update(S_SLOT[2]), 27, na + 26))                 # K addresses of tile t+2: after A's last request (group 26), before C's iteration 14
         segs.append((dma, na + 3, len(groups) - 1))
         lines = weave_budget(groups, segs, CAP)
-        if TRACE:
+        if TRACE and site == "l0":
             k = max(i for i, x in enumerate(lines) if x == ag[-1][-1])
             lines = lines[:k + 1] + ["s_memtime s[66:67]", "s_waitcnt lgkmcnt(0)"] + lines[k + 1:]
         st.extend(lines)

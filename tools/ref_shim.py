@@ -186,8 +186,20 @@ class GELU(nn.Module):
         return F.gelu(self.proj(x), approximate=self.approximate)
 
 
+class GEGLU(nn.Module):
+    """diffusers.models.activations.GEGLU: one Linear to 2 x dim_out, hidden * gelu(gate) (exact gelu) — the UNet's feed-forward activation"""
+
+    def __init__(self, dim_in, dim_out, bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+
+    def forward(self, x):
+        hidden, gate = self.proj(x).chunk(2, dim=-1)
+        return hidden * F.gelu(gate)
+
+
 class FeedForward(nn.Module):
-    """diffusers.models.attention.FeedForward (activation_fn in {"gelu", "gelu-approximate"}): net = [GELU(proj), Dropout, Linear]"""
+    """diffusers.models.attention.FeedForward (activation_fn in {"gelu", "gelu-approximate", "geglu"}): net = [act(proj), Dropout, Linear]"""
 
     def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", final_dropout=False, inner_dim=None, bias=True):
         super().__init__()
@@ -197,6 +209,8 @@ class FeedForward(nn.Module):
             act = GELU(dim, inner_dim, bias=bias)
         elif activation_fn == "gelu-approximate":
             act = GELU(dim, inner_dim, approximate="tanh", bias=bias)
+        elif activation_fn == "geglu":
+            act = GEGLU(dim, inner_dim, bias=bias)
         else:
             raise NotImplementedError(activation_fn)
         self.net = nn.ModuleList([act, nn.Dropout(dropout), nn.Linear(inner_dim, dim_out, bias=bias)])
@@ -543,7 +557,7 @@ class BasicTransformerBlock(nn.Module):
                  attention_type="default", positional_embeddings=None, num_positional_embeddings=None, ff_inner_dim=None,
                  ff_bias=True, attention_out_bias=True):
         super().__init__()
-        assert norm_type == "ada_norm_single" and positional_embeddings is None
+        assert norm_type in ("ada_norm_single", "layer_norm") and positional_embeddings is None
         self.dim = dim
         self.norm_type = norm_type
         self.only_cross_attention = only_cross_attention
@@ -561,12 +575,23 @@ class BasicTransformerBlock(nn.Module):
             self.norm2 = nn.LayerNorm(dim, norm_eps, norm_elementwise_affine)
             self.attn2 = None
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout, inner_dim=ff_inner_dim, bias=ff_bias)
-        self.scale_shift_table = nn.Parameter(torch.randn(6, dim) / dim ** 0.5)
+        if norm_type == "ada_norm_single":
+            self.scale_shift_table = nn.Parameter(torch.randn(6, dim) / dim ** 0.5)
+        else:                                  # "layer_norm" (the conv UNets' Transformer2DModel): a third LayerNorm in front of the feed-forward
+            self.norm3 = nn.LayerNorm(dim, norm_eps, norm_elementwise_affine)
         self._chunk_size = None
         self._chunk_dim = 0
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, timestep=None,
                 cross_attention_kwargs=None, class_labels=None, added_cond_kwargs=None):
+        if self.norm_type == "layer_norm":     # diffusers BasicTransformerBlock.forward, norm_type == "layer_norm": three pre-norm residual branches
+            attn_output = self.attn1(self.norm1(hidden_states), encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
+                                     attention_mask=attention_mask)
+            hidden_states = attn_output + hidden_states
+            if self.attn2 is not None:
+                attn_output = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask)
+                hidden_states = attn_output + hidden_states
+            return self.ff(self.norm3(hidden_states)) + hidden_states
         batch_size = hidden_states.shape[0]
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (
             self.scale_shift_table[None] + timestep.reshape(batch_size, 6, -1)).chunk(6, dim=1)
