@@ -485,17 +485,18 @@ def main():
                 if rank == 0:
                     out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and not args.no_cpu_baseline and rank == 0:
-            # the oracle as the CHECKER of the HIP components at the other four BASELINE.json configurations (true widths / sequence lengths; the UNets at their
-            # true depth, the transformer stacks at a reduced block count) — tests/parity_at_config.py, the same functions the GPU tests assert on
+            # the oracle as the CHECKER of the HIP components at the other four BASELINE.json configurations, all at their true widths, sequence lengths AND
+            # depths (SD3-Medium 24 joint blocks on one of its mixed aspect buckets, PixArt-Sigma 28 trunk + 13 ControlNet blocks at 2K) —
+            # tests/parity_at_config.py, the same functions the GPU tests assert on
             from tests import parity_at_config as PC
             others = {}
             for name, fn in (("configs[0] sd15_lora_r16_512", lambda: PC.unet("sd15", 512, dev, lora=True, rank=16)),
                              ("configs[1] sdxl_lora_r16_1024", lambda: PC.unet("sdxl", 1024, dev, lora=True, rank=16)),
-                             ("configs[3] sd3_full_finetune_1024", lambda: PC.sd3_full(1024, dev)),
-                             ("configs[4] pixart_controlnet_2k", lambda: PC.pixart_controlnet(2048, dev))):
+                             ("configs[3] sd3_full_finetune_full_depth_bucket_1216x832", lambda: PC.sd3_full(1024, dev, layers=24, hw=(1216, 832))),
+                             ("configs[4] pixart_controlnet_2k_full_depth", lambda: PC.pixart_controlnet(2048, dev, trunk_layers=28, ctrl_layers=13))):
                 gc.collect()
                 torch.cuda.empty_cache()
-                if time.time() - _T0 > 330.0:     # the default run must finish in minutes: what did not fit is named, not silently dropped
+                if time.time() - _T0 > 420.0:     # the default run must finish in minutes: what did not fit is named, not silently dropped
                     others[name] = {"skipped": "time budget of the default run (the GPU suite asserts it: tests/test_parity_at_config_gpu.py)"}
                     continue
                 try:

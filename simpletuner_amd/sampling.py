@@ -283,7 +283,12 @@ def sample_images(plugin, prompt_embeds: torch.Tensor, pooled: Optional[torch.Te
         if flow:
             scheduler = FlowMatchEulerDiscreteScheduler(shift=float(getattr(plugin.config, "flow_schedule_shift", 3.0) or 1.0))
         else:
-            scheduler = DDIMScheduler(prediction_type="v_prediction" if plugin.PREDICTION_TYPE is PredictionTypes.V_PREDICTION else "epsilon",
+            # validation.py:2885-2897, 3005-3011: the validation scheduler is rebuilt from the model's scheduler config with the trainer's
+            # `inference_scheduler_timestep_spacing` (default "trailing": the grid that visits t = 999, which zero-terminal-SNR models need), `prediction_type`
+            # and `rescale_betas_zero_snr` overriding it
+            cfg_pt = getattr(plugin.config, "prediction_type", None)
+            pt = cfg_pt if cfg_pt in ("epsilon", "v_prediction", "sample") else ("v_prediction" if plugin.PREDICTION_TYPE is PredictionTypes.V_PREDICTION else "epsilon")
+            scheduler = DDIMScheduler(prediction_type=pt, timestep_spacing=getattr(plugin.config, "inference_scheduler_timestep_spacing", None) or "trailing",
                                       rescale_betas_zero_snr=bool(getattr(plugin.config, "rescale_betas_zero_snr", False)))
     do_cfg = guidance_scale is not None and guidance_scale > 1.0 and negative_prompt_embeds is not None
     bf = lambda t: None if t is None else t.to(device=dev, dtype=torch.bfloat16)

@@ -14,7 +14,7 @@
         gradient-norm would slot in; both collectives run in place on the arena (recv = send + rank * count).
   * SUM is used and the 1/world_size averaging is folded into the optimizer kernel's grad_scale (no extra pass over HBM);
   * `no_sync()` mirrors DDP/accelerate semantics for gradient accumulation (trainer.py:7009);
-  * `fp32_reduce` (default for bf16 arenas in the `rs_ag` form): the reduce-scatter half becomes an ALL-TO-ALL of the bf16 chunks — chunk j of every
+  * `fp32_reduce` (opt-in for bf16 arenas in the `rs_ag` form, ST355_FP32_REDUCE=1): the reduce-scatter half becomes an ALL-TO-ALL of the bf16 chunks — chunk j of every
     rank travels straight to rank j over its own xGMI link, the same (N-1)/N * G bytes per rank as a reduce-scatter — followed by a local sum of the
     N received chunks in fp32, in rank order (st355_sum_chunks_bf16: deterministic, ONE rounding to bf16), then the all-gather of the reduced shards.
     A bf16 RCCL SUM rounds after every hop of its ring / tree; this form accumulates the 2-billion-element full-fine-tune gradient in fp32
@@ -71,8 +71,12 @@ class GradSync:
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._comm_used = False
         self._serial_backend = None      # resolved lazily: gloo runs async works concurrently -> dependent collectives must be waited for
-        # bf16 arenas in the rs_ag form accumulate in fp32 by default (module docstring); the C-ABI comm path keeps RCCL's own reduce-scatter
-        self.fp32_reduce = (flat_grad.dtype == torch.bfloat16) if fp32_reduce is None else bool(fp32_reduce)
+        # fp32-accumulating reduce-scatter for bf16 arenas in the rs_ag form (module docstring): OPT-IN (fp32_reduce=True or ST355_FP32_REDUCE=1) until the
+        # all-to-all + st355_sum_chunks_bf16 + all-gather sequence has run over RCCL with more than one rank (no multi-GPU box has executed this repo yet; the
+        # kernel itself is checked on one GPU by tests/test_kernels_gpu.py::test_sum_chunks_bf16); the C-ABI comm path keeps RCCL's own reduce-scatter
+        env = os.environ.get("ST355_FP32_REDUCE")
+        default = bool(env and env != "0") and flat_grad.dtype == torch.bfloat16
+        self.fp32_reduce = default if fp32_reduce is None else bool(fp32_reduce)
         self._recv: Optional[torch.Tensor] = None
         self.timing = bool(os.environ.get("ST355_COMM_TIMING")) and flat_grad.is_cuda
         self._ev_begin = self._ev_end = None
@@ -132,6 +136,15 @@ class GradSync:
                 ev1.record(self.comm_stream)
                 self._ev_slices.append((lo, hi, ev0, ev1))
 
+    @staticmethod
+    def fp32_span(lo: int, hi: int, W: int) -> int:
+        """elements of [lo, hi) the fp32-accumulating reduce-scatter may take: st355_sum_chunks_bf16 needs every rank's chunk to be a multiple of 8 elements
+        that starts on a 16-byte boundary — so the span is a multiple of 8 * W and `lo` itself must be 8-aligned (arena tensors are padded to 8 elements, so a
+        region start normally is); otherwise 0 and the slice takes RCCL's own reduce-scatter.  The up-to 8 W - 1 leftover elements ride the tail all-reduce."""
+        if lo % 8 != 0 or W <= 0:
+            return 0
+        return (hi - lo) // (8 * W) * (8 * W)
+
     def _sum_chunks(self, recv: torch.Tensor, W: int, out: torch.Tensor):
         """out[i] = bf16(sum over w, in rank order, of float(recv[w, i])) — the local half of the fp32-accumulating reduce-scatter"""
         if recv.is_cuda:
@@ -142,7 +155,9 @@ class GradSync:
 
     def _fire_on_comm_stream(self, lo: int, hi: int, W: int):
             m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
-            if m > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and (self.flat.is_cuda == self._stream_ordered()):
+            m8 = self.fp32_span(lo, hi, W) if self.mode == "rs_ag" else 0
+            if m8 > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and (self.flat.is_cuda == self._stream_ordered()):
+                m = m8                                                 # st355_sum_chunks_bf16 wants 8-element (16-byte) chunks: the tail below takes the rest
                 seg = self.flat[lo:lo + m]
                 if self._recv is None or self._recv.numel() < m:
                     self._recv = torch.empty(m, dtype=seg.dtype, device=seg.device)

@@ -13,7 +13,8 @@ import torch
 
 BF16 = torch.bfloat16
 TOL = ("pred rel_l2 <= 2e-2, cos >= 0.9995; gradient tensors rel_l2 <= 6e-2 (bias / norm / modulation rows 8e-2; LoRA factors of the true-depth UNets 1e-1) and "
-       "cosine >= 0.995 where they carry signal (DESIGN.md §3)")
+       "cosine >= 0.995 where they carry signal; tensors whose reference norm is below 1e-3 of the largest are held to the same bound in absolute terms, "
+       "|got - want| <= tol * 1e-3 * max norm (DESIGN.md §3)")
 
 
 def _rel(a, b):
@@ -27,23 +28,27 @@ def _cos(a, b):
 
 
 def _summary(what, out, ref, pairs, floor_frac=1e-3):
-    """pairs: [(name, got, want, tol)] -> the JSON-able report; gradient tensors below `floor_frac` of the largest reference norm carry no signal
-    (rounding noise on both sides) and are counted, not compared"""
+    """pairs: [(name, got, want, tol)] -> the JSON-able report.  EVERY tensor is compared: its error norm is measured against max(|want|, floor_frac * the
+    largest reference norm), i.e. a tensor whose reference gradient is below the floor (rounding noise on both sides: e.g. a key-projection bias, to which the
+    softmax is invariant) must still stay within tol * floor * gmax in ABSOLUTE terms — a zeroed, stale or mis-indexed small tensor fails, it is not skipped.
+    The cosine is only meaningful (and only asserted) where the reference carries signal."""
     gmax = max(float(w.float().norm()) for _, _, w, _ in pairs)
-    worst, worst_rel, worst_cos, n_cmp, n_small = (0.0, "", 0.0), 0.0, 1.0, 0, 0
+    worst, worst_rel, worst_cos, n_abs = (0.0, "", 0.0), 0.0, 1.0, 0
     for name, got, want, tol in pairs:
-        if float(want.float().norm()) < floor_frac * gmax:
-            n_small += 1
-            continue
-        r = _rel(got, want)
-        n_cmp += 1
+        wn = float(want.float().norm())
+        err = float((got.detach().float() - want.detach().float().to(got.device)).norm())
+        if wn < floor_frac * gmax:
+            n_abs += 1
+            r = err / (floor_frac * gmax)
+        else:
+            r = err / wn
+            worst_cos = min(worst_cos, _cos(got, want))
         worst_rel = max(worst_rel, r)
-        worst_cos = min(worst_cos, _cos(got, want))
         if r / tol > worst[0]:
             worst = (r / tol, name, r)
     return {"what": what, "pred_rel_l2": round(_rel(out, ref), 6), "pred_cos": round(_cos(out, ref), 7),
             "grad_worst_rel_l2": round(worst_rel, 6), "grad_worst_cos": round(worst_cos, 6), "grad_worst_vs_its_tolerance": round(worst[0], 4), "grad_worst_at": worst[1],
-            "grads_compared": n_cmp, "grads_below_noise_floor": n_small, "tolerance": TOL}
+            "grads_compared": len(pairs), "grads_below_noise_floor": 0, "grads_on_the_absolute_bound": n_abs, "tolerance": TOL}
 
 
 def unet(kind: str, res: int, dev, lora: bool, rank: int = 16, seed: int = 4):
@@ -88,6 +93,18 @@ def unet(kind: str, res: int, dev, lora: bool, rank: int = 16, seed: int = 4):
                 Pe[base + ".weight"] = P[base + ".weight"] + (alpha / rank) * lp[base + ".lora_B.default.weight"] @ lp[n]
         ref = unet_forward(Pe, ocfg, x.float().to(dev), t.to(dev), ctx.float().to(dev), ack_o)
         ((ref - target.to(dev)) ** 2).mean().backward()
+        # What does bf16 storage alone cost at this depth?  The SAME restatement, autograd, with weights / activations held in bf16 (ATen kernels), against
+        # its fp32 self: the distance every bf16 implementation of this network sits at, measured, not assumed — reported next to the HIP path's distance
+        lb = {n: v.detach().to(BF16).requires_grad_(True) for n, v in lp.items()}
+        Pb = {k: v.to(BF16) for k, v in P.items()}
+        for n in lb:
+            if ".lora_A." in n:
+                base = n.replace(".lora_A.default.weight", "")
+                Pb[base + ".weight"] = (P[base + ".weight"] + (alpha / rank) * lb[base + ".lora_B.default.weight"].float() @ lb[n].float()).to(BF16)
+        ackb = {k: v.to(BF16) for k, v in ack_o.items()} if ack_o else None
+        refb = unet_forward(Pb, ocfg, x.to(dev), t.to(dev), ctx.to(dev), ackb)
+        ((refb.float() - target.to(dev)) ** 2).mean().backward()
+        bf16_noise = {n: _rel(lb[n].grad, lp[n].grad) for n in lp if lb[n].grad is not None and float(lp[n].grad.norm()) > 0}
         for n, p in m.named_parameters():
             if ".lora_" in n:
                 # adapter factors at the TRUE depth (70 transformer layers in SDXL, the rank-space products of activations that carry the whole stack's
@@ -110,13 +127,20 @@ def unet(kind: str, res: int, dev, lora: bool, rank: int = 16, seed: int = 4):
     what = (f"{'SD 1.5' if kind == 'sd15' else 'SDXL'} UNet at its true architecture, {mode}, {res}^2 ({lat}^2 latents), batch 1: HIP bf16 vs oracle fp32 "
             f"(autograd), same weights / inputs")
     rep = _summary(what, out, ref.detach(), pairs)
+    if lora and bf16_noise:
+        worst_n = max(bf16_noise, key=bf16_noise.get)
+        rep["bf16_autograd_of_the_oracle_vs_its_fp32_self"] = {
+            "what": "oracle.unet in bf16 (torch autograd, ATen kernels) vs the same restatement in fp32: what bf16 storage alone costs at this depth",
+            "pred_rel_l2": round(_rel(refb, ref.detach()), 6), "grad_worst_rel_l2": round(bf16_noise[worst_n], 6), "grad_worst_at": worst_n,
+            "at_the_hip_paths_worst_tensor": round(bf16_noise.get(rep["grad_worst_at"], float("nan")), 6)}
     del m
     return rep
 
 
-def sd3_full(res: int, dev, layers: int = 2, seed: int = 6):
-    """configs[3]: SD3-Medium width and sequence (D=1536, 24x64 heads, (res/16)^2 image + 231 text tokens), `layers` joint blocks (a regular one and the
-    context_pre_only last one), FULL fine-tune: every weight / bias / modulation gradient vs fp32 autograd"""
+def sd3_full(res: int, dev, layers: int = 2, seed: int = 6, hw=None):
+    """configs[3]: SD3-Medium width and sequence (D=1536, 24x64 heads, (res/16)^2 image + 231 text tokens), `layers` joint blocks (24 = the real depth; the
+    last one context_pre_only), FULL fine-tune: every weight / bias / modulation gradient vs fp32 autograd.  hw = (height, width) in pixels: one of the
+    configuration's mixed aspect buckets instead of the square one (the cropped position table, ragged key tiles)."""
     from oracle import sd3 as OS
     from simpletuner_amd.sd3.model import SD3
     from simpletuner_amd.training.trainer import St355Accelerator, default_config
@@ -129,7 +153,8 @@ def sd3_full(res: int, dev, layers: int = 2, seed: int = 6):
     plugin.enable_full_finetune()
     model = plugin.get_trained_component()
     lat = res // 8
-    cpu, devt = PU.make_inputs(1, lat, lat, 231, 4096, 2048, dev, seed=seed)
+    lat_h, lat_w = (hw[0] // 8, hw[1] // 8) if hw else (lat, lat)
+    cpu, devt = PU.make_inputs(1, lat_h, lat_w, 231, 4096, 2048, dev, seed=seed)
     sig = devt["sigmas"]
     plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
     batch = {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
@@ -156,8 +181,8 @@ def sd3_full(res: int, dev, layers: int = 2, seed: int = 6):
     for name, p in model.named_parameters():
         tol = 6e-2 if (name.endswith(".weight") and p.dim() > 1) else 8e-2
         pairs.append((name, p.grad, Pg[name].grad, tol))
-    what = (f"SD3-Medium (D=1536, 24x64 heads, S={(lat // 2) ** 2}+231), {layers} joint blocks, FULL fine-tune, batch 1: HIP bf16 vs oracle fp32 (autograd), "
-            f"same weights / noised latents / timesteps")
+    what = (f"SD3-Medium (D=1536, 24x64 heads, {lat_h * 8}x{lat_w * 8} px, S={(lat_h // 2) * (lat_w // 2)}+231), {layers} joint blocks, FULL fine-tune, batch 1: "
+            f"HIP bf16 vs oracle fp32 (autograd), same weights / noised latents / timesteps")
     rep = _summary(what, out["model_prediction"], pred.detach(), pairs)
     rep["loss_hip"], rep["loss_oracle"] = round(float(loss), 6), round(float(o_loss), 6)
     return rep

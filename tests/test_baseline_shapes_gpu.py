@@ -195,7 +195,7 @@ def test_flux_full_depth_step_matches_oracle():
     LoRA r32 on the default target set, B=1 — one train step (forward, flow-matching MSE, backward into the adapter factors of all 190 target projections) against the fp32
     restatement run at the same depth on the device's ATen kernels with per-block recomputation (oracle.flux.flux_forward(checkpoint=True)).
     What the two-block tests cannot see: error growth through 57 residual updates, the activation arena / segment bookkeeping at full depth, 57 blocks
-    of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 3e-2 and cosine >= 0.9995, |delta loss| <= 1e-3 x loss, every adapter gradient
+    of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 2e-2 and cosine >= 0.9995 (the stated §8(c) bound, also at full depth), |delta loss| <= 1e-3 x loss, every adapter gradient
     rel-L2 <= 1e-1 with cosine >= 0.995 (bf16 storage of the residual stream over 57 blocks).  Measured r3: prediction rel-L2 1.73e-2, cosine 0.99985,
     loss 3.030217 vs 3.030492, worst of the 380 adapter gradients 3.5e-2 (single block 31 to_k lora_A)."""
     from simpletuner_amd.flux.model import Flux
@@ -222,7 +222,7 @@ def test_flux_full_depth_step_matches_oracle():
     o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu, checkpoint=True)
     assert len(o_grads) == len(lora) >= 19 * 4 + 38 * 3
     _check_step("flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads, grad_tol=1e-1,
-                pred_tol=3e-2, cos_tol=0.995)
+                pred_tol=2e-2, cos_tol=0.995)
 
 
 def test_sd3_full_width_step_matches_oracle():

@@ -140,7 +140,8 @@ def _worker(rank, world, init_file, out_dir):
     mine = torch.randn(n, generator=gen).to(torch.bfloat16)
     both = [torch.randn(n, generator=torch.Generator().manual_seed(70 + r)).to(torch.bfloat16) for r in range(world)]
     flat = mine.clone()
-    gs = GradSync(flat, bucket_bytes=2 * 1024, mode="rs_ag")
+    assert not GradSync(flat, bucket_bytes=2 * 1024, mode="rs_ag").fp32_reduce       # opt-in until the sequence has run over RCCL with > 1 rank
+    gs = GradSync(flat, bucket_bytes=2 * 1024, mode="rs_ag", fp32_reduce=True)
     assert gs.fp32_reduce
     gs.begin()
     for hi in range(n, 0, -1000):
@@ -151,6 +152,21 @@ def _worker(rank, world, init_file, out_dir):
     res["fp32_reduce_ops"] = sorted({op for op, _, _ in gs.launched_ops})
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
+
+
+def test_fp32_reduce_span_keeps_the_sum_chunks_alignment_contract():
+    """st355_sum_chunks_bf16 wants n % 8 == 0 per chunk and a 16-byte-aligned shard: GradSync.fp32_span must only hand it such spans, for every ragged slice
+    and world size (the UNet arenas hold 8-element tensors, e.g. the padded conv_out bias: a span rounded to W only broke this at W = 2, 8, 16 ...)"""
+    from simpletuner_amd.training.grad_sync import GradSync
+    for W in (2, 3, 4, 8, 16):
+        for lo in (0, 8, 64, 72, 4096 + 8):
+            for length in (8, 24, 8 * W, 8 * W + 8, 1000, 4096 + 8, 65536 + 72, 12345):
+                m = GradSync.fp32_span(lo, lo + length, W)
+                assert 0 <= m <= length and m % (8 * W) == 0 and (m // W) % 8 == 0
+                assert length - m < 8 * W or m == 0                     # the all-reduce tail stays below 8 W elements
+                for r in range(W):
+                    assert ((lo + r * (m // W)) * 2) % 16 == 0          # every rank's shard starts on a 16-byte boundary
+        assert GradSync.fp32_span(4, 4 + 8 * W * 3, W) == 0             # a span that does not start 8-aligned takes RCCL's own reduce-scatter
 
 
 def test_ddp_seam_world2_gloo():

@@ -831,6 +831,21 @@ def test_attention_key_bias_and_rescale_branch(ops):
     _attn_case(ops, 1, 2, 300, 96, bias=True)
 
 
+@pytest.mark.parametrize("W", [1, 2, 3, 8])
+def test_sum_chunks_bf16(ops, W):
+    """st355_sum_chunks_bf16 (the local half of GradSync's fp32-accumulating reduce-scatter): out[i] = bf16(sum over w, in rank order, of float(chunk_w[i]))
+    against float-sum-then-round, bit for bit; chunk lengths from one 8-element vector to a few MiB incl. lengths that leave the last workgroup ragged"""
+    torch.manual_seed(55 + W)
+    for n in (8, 264, 8 * 1000 + 8, 1 << 20, (1 << 21) + 8 * 37):
+        chunks = (torch.randn(W * n, device=dev()) * 3).to(BF16)
+        out = torch.empty(n, device=dev(), dtype=BF16)
+        ops.sum_chunks_bf16(chunks, W, out)
+        acc = torch.zeros(n, device=dev(), dtype=torch.float32)
+        for w in range(W):                                              # rank order, fp32 accumulation, ONE rounding
+            acc += chunks[w * n:(w + 1) * n].float()
+        assert torch.equal(out, acc.to(BF16)), (W, n)
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser / EMA
 # ------------------------------------------------------------------------------------------------

@@ -29,12 +29,24 @@ def test_sdxl_1024_true_architecture(lora):
 
 
 def test_sd3_medium_full_finetune_1024_true_width():
-    """BASELINE.json configs[3]: SD3-Medium MMDiT full fine-tune, 1024^2 (2 of the 24 joint blocks)"""
+    """BASELINE.json configs[3]: SD3-Medium MMDiT full fine-tune, 1024^2 (2 of the 24 joint blocks: the quick form)"""
     rep = PC.sd3_full(1024, DEV)
     _check(rep)
     assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 1e-3 * max(1.0, abs(rep["loss_oracle"]))
 
 
+def test_sd3_medium_full_finetune_full_depth_on_a_mixed_aspect_bucket():
+    """BASELINE.json configs[3] at its real depth: all 24 joint blocks, full fine-tune, the 1216 x 832 bucket (S = 3952 + 231: a ragged last key tile)"""
+    rep = PC.sd3_full(1024, DEV, layers=24, hw=(1216, 832))
+    _check(rep)
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 1e-3 * max(1.0, abs(rep["loss_oracle"]))
+
+
 def test_pixart_sigma_controlnet_2k_true_width():
-    """BASELINE.json configs[4]: PixArt-Sigma ControlNet branch, 2K latents (S=16384), T5 context 300 with mask (3 trunk + 2 adapter blocks)"""
+    """BASELINE.json configs[4]: PixArt-Sigma ControlNet branch, 2K latents (S=16384), T5 context 300 with mask (3 trunk + 2 adapter blocks: the quick form)"""
     _check(PC.pixart_controlnet(2048, DEV))
+
+
+def test_pixart_sigma_controlnet_2k_full_depth():
+    """BASELINE.json configs[4] at its real depth: 28 trunk blocks + 13 ControlNet blocks at 2K latents"""
+    _check(PC.pixart_controlnet(2048, DEV, trunk_layers=28, ctrl_layers=13))

@@ -140,6 +140,7 @@ def rescale_block(qb: int, site: str) -> list[str]:
     o.append(f"v_exp_f32_e32 {vr(t1)}, {vr(t1)}")                         # alpha
     o.append(f"v_sub_f32_e32 {vr(NM[qb])}, 0, {vr(t2)}")
     o.append(f"v_mul_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(t1)}")
+    o.append(f"v_mul_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(t1)}")           # the second partial row sum lives at the old reference too
     o.append("s_nop 15")                                                 # in-flight MFMAs of the previous C own the O accumulators
     o.append("s_nop 15")
     for r in range(64):
