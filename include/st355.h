@@ -269,7 +269,7 @@ int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const v
 /* O: [B,S,H*d] token-major bf16 (row stride ld_o elements); lse2: [B,H,S] fp32 (log2-domain logsumexp of
  * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
 /* Kernel choice for the head_dim-128, no-bias, S % 64 == 0 self-attention shapes (tuning / A-B hook): fwd = 64 selects the hand-scheduled one-wave-per-SIMD
- * forward (k_attn_fwd64: 64 queries per wave, stale-reference softmax; O agrees with the 32-query kernel to bf16 rounding, lse2 to ~1e-6), 32 the 32-query kernel
+ * forward (k_attn_fwd64: 64 queries per wave, stale-reference softmax; O agrees with the 32-query kernel to bf16 rounding, lse2 to ~1e-3: Q is pre-scaled by scale * log2(e) and re-rounded), 32 the 32-query kernel
  * (k_attn_fwd4) everywhere; dq = 64 selects k_attn_bwd_dq64 (bit-identical to the 32-query k_attn_bwd_dq), 32 the latter everywhere; -1 leaves a choice unchanged.
  * Defaults: 64 / 64 (environment ST355_ATTN_FWD64=0, ST355_ATTN_DQ=32 flip them).  Returns (previous fwd) * 256 + (previous dq). */
 int st355_attn_set_impl(int fwd, int dq);

@@ -20,198 +20,6 @@
 #define QB 128  // queries per workgroup
 #define KB 64   // keys per tile
 
-// First generation (r01): kept ONLY as the A/B baseline of the r02 kernel below (ST355_ATTN_FWD=1; tools/attn_lab times both).
-template <int HD>
-__global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                            const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
-                                                            bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
-                                                            int Sq, int S, int Sp, float scale2) {   // Sq queries; S keys (padded Sp)
-  constexpr int KROWB = HD * 2;          // bytes per K tile row
-  constexpr int KT_BYTES = KB * KROWB;   // K tile
-  constexpr int VT_BYTES = HD * 128;     // V^T tile: HD rows x 64 keys
-  constexpr int BUF = KT_BYTES + VT_BYTES;
-  constexpr int NKS = HD / 16;           // MFMA k-steps over the head dim
-  constexpr int NDT = HD / 32;           // 32-row d tiles of O^T
-  constexpr int NW = 4;
-  constexpr int ATT_T = 64 * NW;
-  constexpr int KCH = KT_BYTES / 16 / ATT_T;  // 16-B chunks per thread
-  constexpr int VCH = VT_BYTES / 16 / ATT_T;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const WgMap wg = attn_wg_map();
-  const int head = wg.head, b = wg.b;
-  const int64_t bh = (int64_t)b * H + head;
-  const int q0 = wg.tile * (32 * NW) + wv * 32;
-  const int qi = min(q0 + l31, Sq - 1);
-
-  const bf16* Kg = K + bh * (int64_t)S * HD;
-  const bf16* Vg = Vt + bh * (int64_t)HD * Sp;
-
-  // Q fragments (MFMA B operand): lane -> query l31, head channels 16ks + 8h .. +8
-  bf16x8 qf[NKS];
-  {
-    const bf16* qrow = Q + (bh * Sq + qi) * (int64_t)HD + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks++) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
-  }
-
-  f32x16 acc_o[NDT];
-#pragma unroll
-  for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc_o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  bf16x8 kreg[KCH], vreg[VCH];
-  auto load_tile = [&](int kt) {
-    const int key0 = kt * KB;
-#pragma unroll
-    for (int p = 0; p < KCH; p++) {
-      const int id = p * ATT_T + tid;
-      const int row = id / (HD / 8), c = id % (HD / 8);
-      kreg[p] = *(const bf16x8*)(Kg + (int64_t)min(key0 + row, S - 1) * HD + c * 8);
-    }
-#pragma unroll
-    for (int p = 0; p < VCH; p++) {
-      const int id = p * ATT_T + tid;
-      const int row = id >> 3, c = id & 7;
-      vreg[p] = *(const bf16x8*)(Vg + (int64_t)row * Sp + key0 + c * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* ks = smem + buf * BUF;
-    char* vs = ks + KT_BYTES;
-#pragma unroll
-    for (int p = 0; p < KCH; p++) {
-      const int id = p * ATT_T + tid;
-      const int row = id / (HD / 8), c = id % (HD / 8);
-      *(bf16x8*)(ks + lds_off<KROWB>(row, c)) = kreg[p];
-    }
-#pragma unroll
-    for (int p = 0; p < VCH; p++) {
-      const int id = p * ATT_T + tid;
-      const int row = id >> 3, c = id & 7;
-      *(bf16x8*)(vs + lds_off<128>(row, c)) = vreg[p];
-    }
-  };
-
-  const int nkt = (S + KB - 1) / KB;
-  const int krow_p = perm23(l31);  // K tile row (within a 32-key sub-block) this lane feeds as MFMA A row l31
-
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    const char* ks = smem + buf * BUF;
-    const char* vs = ks + KT_BYTES;
-    const int key0 = kt * KB;
-
-    // ---- S^T = K Q^T for the two 32-key sub-blocks ----
-    f32x16 sacc[2];
-#pragma unroll
-    for (int sb = 0; sb < 2; sb++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) sacc[sb][r] = 0.f;
-      const int row = 32 * sb + krow_p;
-#pragma unroll
-      for (int ks_ = 0; ks_ < NKS; ks_++) {
-        bf16x8 kf = *(const bf16x8*)(ks + lds_off<KROWB>(row, 2 * ks_ + h));
-        sacc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks_], sacc[sb], 0, 0, 0);
-      }
-    }
-    // ---- scale, bias, mask; online softmax ----
-    // ONE wave-uniform branch per tile picks the variant (plain / ragged last tile / per-key bias): a per-element `if (key_bias || tail)` inside the
-    // unrolled 32-score loop compiled to 96 scalar branches and 32 separately guarded loads per tile, i.e. 32 tiny basic blocks the scheduler could
-    // not interleave with anything (r2: found in the .s; the common case is now 32 v_mul + max3 chains in one block)
-    float p[2][16];
-    const bool tail = (key0 + KB > S);
-    float mt = -INFINITY;
-    auto scores = [&](auto bias_c, auto tail_c) {
-      constexpr bool BIAS = decltype(bias_c)::value, TAIL = decltype(tail_c)::value;
-#pragma unroll
-      for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float s = sacc[sb][r];
-          if (BIAS || TAIL) {
-            s *= scale2;
-            const int key = key0 + 32 * sb + acc_row(r, h);
-            if (BIAS) s += key_bias[(int64_t)b * S + min(key, S - 1)] * LOG2E;
-            if (key >= S) s = -INFINITY;
-          }
-          p[sb][r] = s;                      // plain tiles keep the RAW score: the scale rides in the exponent's fma below
-          mt = fmaxf(mt, s);
-        }
-    };
-    float psc = 1.f;                         // factor still to be applied to p[][] inside exp2(p * psc - m)
-    if (key_bias != nullptr) scores(std::true_type{}, std::true_type{});
-    else if (tail) scores(std::false_type{}, std::true_type{});
-    else { scores(std::false_type{}, std::false_type{}); mt *= scale2; psc = scale2; }      // scale2 > 0: max(scale2 * s) = scale2 * max(s)
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float ls = 0.f;
-#pragma unroll
-    for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        p[sb][r] = fast_exp2(fmaf(p[sb][r], psc, -m_new));
-        ls += p[sb][r];
-      }
-    l_run = l_run * alpha + ls;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {        // wave-uniform: once the running max is stable the 16*NDT multiplies are skipped
-#pragma unroll
-      for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc_o[dt][r] *= alpha;
-    }
-
-    // ---- O^T += V^T P^T ----
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-      for (int m = 0; m < 2; m++) pf[sb][m] = pack8(&p[sb][8 * m]);
-#pragma unroll
-    for (int dt = 0; dt < NDT; dt++) {
-      const int row = 32 * dt + l31;
-#pragma unroll
-      for (int sb = 0; sb < 2; sb++)
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-          bf16x8 vf = *(const bf16x8*)(vs + lds_off<128>(row, 4 * sb + 2 * m + h));
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sb][m], acc_o[dt], 0, 0, 0);
-        }
-    }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- finish: combine the two half-lanes' partial sums, normalise, store ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  const int q = q0 + l31;
-  if (q < Sq) {
-    bf16* orow = O + ((int64_t)b * Sq + q) * ld_o + (int64_t)head * HD;
-#pragma unroll
-    for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        bf16x4 o;
-#pragma unroll
-        for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc_o[dt][4 * a + bb] * inv);
-        *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
-      }
-    if (h == 0) lse2[bh * Sq + q] = m_run + __log2f(l_tot);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Second generation (r02, the default): the generation-1 shape (4 waves x 32 queries, two independent workgroups per CU, register staging) with the per-tile
 // VALU stream cut down and software-pipelined against the MFMAs INSIDE a wave.  Found in the generation-1 .s: per tile and wave 32 MFMAs (1024
@@ -536,12 +344,10 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   const double bytes = 2.0 * (double)B * H * (Sq + S) * d * 2.0;
   ProfScope ps(stream, ST355_K_ATTN_FWD, flops, bytes);
   const float scale2 = scale * LOG2E;
-  // Default = k_attn_fwd4 (r02).  ST355_ATTN_FWD=1 selects the r01 kernel for A/B runs: r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s.
-  // (Also measured and deleted in r02: an 8-wave/256-query workgroup variant, 843 TFLOP/s, and an 8-wave LDS-DMA half-tile-stagger variant, 738 —
-  // the forward is latency-shaped and wants two INDEPENDENT workgroups per CU; logs under profiles/r02_attn_lab_*.log.)
-  static int gen = -1;
-  if (gen < 0) { const char* e = getenv("ST355_ATTN_FWD"); gen = (e && e[0] == '1') ? 1 : 4; }
-  if (gen == 4 && !vrow && !key_bias && d == 128 && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
+  // k_attn_fwd4 (r02) is the general kernel; k_attn_fwd64 (r04) takes the head_dim-128, no-bias, S % 64 == 0 shapes.  The r01 kernel lives on in
+  // tools/attn_fwd_variants.hip as the lab's A/B baseline (r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s).  Measured and deleted in r02: an 8-wave /
+  // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/r02_attn_lab_*.log.
+  if (!vrow && !key_bias && d == 128 && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
     dim3 grid64((Sq + 255) / 256, H, B);
     const int lds64 = 4 * 2 * 64 * 256;
     static bool set64 = false;
@@ -562,13 +368,9 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   if (vrow) {
     if (key_bias) ST355_FWD_LAUNCH((k_attn_fwd4<128, true, true>));
     else ST355_FWD_LAUNCH((k_attn_fwd4<128, false, true>));
-  } else if (gen == 1) {
-    if (d == 128) ST355_FWD_LAUNCH(k_attn_fwd<128>);
-    else if (d == 96) ST355_FWD_LAUNCH(k_attn_fwd<96>);          // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
-    else ST355_FWD_LAUNCH(k_attn_fwd<64>);
   } else if (key_bias) {
     if (d == 128) ST355_FWD_LAUNCH((k_attn_fwd4<128, true>));
-    else if (d == 96) ST355_FWD_LAUNCH((k_attn_fwd4<96, true>));
+    else if (d == 96) ST355_FWD_LAUNCH((k_attn_fwd4<96, true>));          // PixArt's head_dim 72 zero-padded to 96 (3 d-tiles of 32, 6 k-steps of 16)
     else ST355_FWD_LAUNCH((k_attn_fwd4<64, true>));
   } else {
     if (d == 128) ST355_FWD_LAUNCH((k_attn_fwd4<128, false>));

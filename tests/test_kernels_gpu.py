@@ -517,7 +517,7 @@ def test_attention_64_row_kernels_against_the_32_row_kernels(ops, B, H, S):
     """k_attn_fwd64 / k_attn_bwd_dq64 (one wave per SIMD, 64 queries per wave, hand-scheduled bodies from tools/kgen) against k_attn_fwd4 / k_attn_bwd_dq on the
     shapes they take over (head_dim 128, no bias, S % 64 == 0; query counts that leave the last 256-query workgroup ragged; one to eighteen key tiles, odd and
     even: prologue-only, loop and both tail paths).  dQ is BIT-identical (same arithmetic, same accumulation order), with and without the fused RoPE epilogue;
-    O agrees to bf16 rounding (the 64-row forward takes exponentials against a reference maximum that may lag by up to 2^8), lse2 to 1e-5.  One row of Q is
+    O agrees to bf16 rounding (the 64-row forward takes exponentials against a reference maximum that may lag by up to 2^8 and pre-scales Q), lse2 to 4e-3.  One row of Q is
     spiked against one key in a late tile so that the forward's out-of-line re-reference runs after the first tile as well."""
     torch.manual_seed(93)
     d_ = dev()
@@ -553,7 +553,9 @@ def test_attention_64_row_kernels_against_the_32_row_kernels(ops, B, H, S):
     finally:
         ops.attn_set_impl(fwd=prev[0], dq=prev[1])
     assert report("fwd64 O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
-    assert float((res[64][1] - res[32][1]).abs().max()) < 1e-4
+    # the 64-row kernel multiplies its Q fragments by scale * log2(e) once (fp32 multiply, re-rounded to bf16) instead of scaling every score: the scores —
+    # and with them lse2 — move by the bf16 rounding of q, ~1e-3 in log2 units on scores of a few units (the exponentials by ~0.1 %, below P's own bf16 rounding)
+    assert float((res[64][1] - res[32][1]).abs().max()) < 4e-3
     assert torch.equal(res[64][2], res[32][2]), "dq64 is not bit-identical to dq"
     assert torch.equal(res[64][3], res[32][3]), "dq64 with the fused RoPE epilogue is not bit-identical to dq"
 

@@ -4,9 +4,14 @@
 
 Per 64-key tile t, both 32-query blocks qb of the wave (scores TRANSPOSED as in k_attn_fwd4: a lane owns one query column):
     A(t): S^T = K Q^T                      32 MFMAs   (2 key blocks sb x 8 k-steps x 2 qb; every K row fragment feeds both query blocks)
-    B(t): online softmax, VALU: tile maximum (v_max3 chains + half-wave swap), p = exp2(S * scale2 - m_ref), row sums, bf16 packing into PF(sb, qb, m)
+    B(t): online softmax, VALU: p = exp2(S), row sums, bf16 packing into PF(sb, qb, m);  and the tile maximum of tile t+1 (v_max3 chains + half-wave swap)
     C(t): O^T += V^T P^T                   32 MFMAs   (iterations v = (sb, m, dt); every V^T fragment feeds both query blocks)
-Pipeline: step t = [A(t+1) with B(t) in its MFMA gaps] ; [C(t) with the rest of B(t) in its gaps].  Two generations of S registers alternate.
+Pipeline: step t = [A(t+1) with B(t) in its MFMA gaps] ; [C(t) with the rest of B(t) and the maximum of tile t+1 in its gaps] ; re-reference decision for t+1.
+Two generations of S registers alternate.
+The score arithmetic is folded into the MFMAs: the Q fragments are multiplied by scale * log2(e) once per workgroup (fp32 multiply, one rounding to bf16) and
+every S accumulation chain STARTS from -m_ref (srcC = a 16-register block holding it), so the accumulators come out as  s * scale2 - m_ref  and p is one
+v_exp_f32 away: 3 VALU instructions per score (exp, row-sum add, half a bf16 pack, half a max3) instead of 4.2 — the difference between fitting the
+5-issues-per-MFMA-gap budget of a one-wave-per-SIMD stream and not fitting it.
 
 The running maximum is a REFERENCE m_ref that may go stale: exponentials are taken against m_ref as long as no score of the tile exceeds it by more than
 THR (log2 units; P then reaches 2^THR instead of 1 — same relative precision in bf16, numerator and denominator share the reference, lse2 = m_ref + log2(l)
@@ -18,10 +23,10 @@ LDS: ring of four 32-KiB slots [K image 64 keys x 256 B, swz_q chunk swizzle | V
 t % 4, staged THREE tiles ahead by LDS-DMA (8 pieces per wave and tile in C's gaps, right after the per-tile barrier).
 
 Registers (the kernel lists v[32:255], a[0:255], s[40:83] as clobbers):
-    a[0:127]    O^T accumulators OACC(qb, dt)          a[128:191] Q fragments QF(qb, ks)            a[192:255] unused
+    a[0:127]    O^T accumulators OACC(qb, dt)          a[128:191] Q fragments QF(qb, ks) (pre-scaled)   a[192:203] K row fragments (3 deep)   a[204:215] V^T fragments (3 deep)
     v[64:127]   generation 0: S(sb, qb) at 64 + 32 sb + 16 qb        v[128:191] generation 1
-    v[192:223]  P fragments PF(sb, qb, m)              v[224:235] K row fragments (3 deep)          v[236:247] V^T fragments (3 deep)
-    v[248:251]  -m_ref(qb), l(qb)                      v[32:39] ROWA[ks]    v[40:43] VTA[2 sb + m]   v[44:51] LDS-DMA lane offsets   v[52:63] scratch
+    v[192:223]  P fragments PF(sb, qb, m)              v[224:239], v[240:255] -m_ref blocks NMB(qb) (16 equal registers each: the srcC of every S chain's first MFMA)
+    v[32:39] ROWA[ks]    v[40:43] VTA[2 sb + m]   v[44:51] LDS-DMA lane offsets   v[52:61] scratch   v[62:63] l(qb)
 """
 from __future__ import annotations
 
@@ -41,15 +46,16 @@ def OACC(qb, dt): return ar(16 * (4 * qb + dt), 16)
 def QF(qb, ks): return ar(128 + 4 * (8 * qb + ks), 4)
 def S(g, sb, qb): return 64 + 64 * g + 32 * sb + 16 * qb
 def PF(sb, qb, m): return 192 + 4 * (4 * sb + 2 * qb + m)
-def KF(i): return vr(224 + 4 * (i % 3), 4)
-def VF(i): return vr(236 + 4 * (i % 3), 4)
-NM = [248, 249]          # -m_ref per query block
-L = [250, 251]           # running row sum per query block (this lane's half of the keys)
+def KF(i): return ar(192 + 4 * (i % 3), 4)
+def VF(i): return ar(204 + 4 * (i % 3), 4)
+def NMB(qb): return 224 + 16 * qb          # 16 registers, all -m_ref of query block qb
+NM = [NMB(0), NMB(1)]                      # (the first register of each block doubles as the scalar)
+L = [62, 63]             # running row sum per query block (this lane's half of the keys)
 ROWA = [32 + k for k in range(8)]
 VTA = [40 + k for k in range(4)]
 KOF = [44, 45, 46, 47]
 VOF = [48, 49, 50, 51]
-T = [52 + k for k in range(12)]        # scratch v52..v63
+T = [52 + k for k in range(10)]        # scratch v52..v61
 # SGPRs
 S_KP, S_VP = 40, 42
 S_CNT = 44
@@ -58,7 +64,7 @@ S_M0, S_T0, S_T1, S_INCK, S_INCV = 49, 50, 51, 52, 53
 
 TRACE = bool(os.environ.get("FWD64_TRACE"))
 DBG = set(filter(None, os.environ.get("FWD64_DBG", "").split(",")))
-CAP = float(os.environ.get("FWD64_CAP", "6"))        # the forward carries ~4.7 VALU / LDS issues per MFMA: a 5-issue budget does not hold all of B
+CAP = float(os.environ.get("FWD64_CAP", "5"))        # issues per MFMA gap besides the MFMA
 
 
 def k_request(u: int) -> list[str]:
@@ -82,15 +88,16 @@ def vta_update(slot_sgpr: int) -> list[str]:
     return [f"v_add_u32_e32 {vr(VTA[0])}, s{slot_sgpr}, %[vtb]"] + [f"v_xor_b32_e32 {vr(VTA[j])}, {hex((2 * j) << 4)}, {vr(VTA[0])}" for j in range(1, 4)]
 
 
-def a_groups(g_new: int, tail: list[list[str]]) -> list[list[str]]:
-    """A: 16 fragments u x 2 MFMAs.  Group u waits for fragment u and requests u + 2; u = 14, 15 carry tail[0 / 1] (C's first two fragments)."""
+def a_groups(g_new: int, tail: list[list[str]], from_zero: bool = False) -> list[list[str]]:
+    """A: 16 fragments u x 2 MFMAs.  Group u waits for fragment u and requests u + 2; u = 14, 15 carry tail[0 / 1] (C's first two fragments).
+    Every accumulation chain starts from -m_ref (srcC = NMB(qb)); from_zero: the prologue's tile 0, whose reference is chosen afterwards."""
     groups = []
     for u in range(16):
         sb, ks = u >> 3, u & 7
         head = [f"@wait:K{u}"] + (k_request(u + 2) if u < 14 else tail[u - 14])
-        c = (lambda r: "0") if ks == 0 else (lambda r: r)
-        groups.append(head + [f"{MFMA} {vr(S(g_new, sb, 0), 16)}, {KF(u)}, {QF(0, ks)}, {c(vr(S(g_new, sb, 0), 16))}"])
-        groups.append([f"{MFMA} {vr(S(g_new, sb, 1), 16)}, {KF(u)}, {QF(1, ks)}, {c(vr(S(g_new, sb, 1), 16))}"])
+        c = (lambda r, qb: ("0" if from_zero else vr(NMB(qb), 16))) if ks == 0 else (lambda r, qb: r)
+        groups.append(head + [f"{MFMA} {vr(S(g_new, sb, 0), 16)}, {KF(u)}, {QF(0, ks)}, {c(vr(S(g_new, sb, 0), 16), 0)}"])
+        groups.append([f"{MFMA} {vr(S(g_new, sb, 1), 16)}, {KF(u)}, {QF(1, ks)}, {c(vr(S(g_new, sb, 1), 16), 1)}"])
     return groups
 
 
@@ -107,59 +114,67 @@ def c_groups(tail: list[list[str]], extra_at: dict[int, list[str]] | None = None
     return groups
 
 
-def b_max(g: int, qb: int, site: str) -> list:
-    """tile maximum of query block qb (32 scores per lane), stale-reference check, branch to the out-of-line rescale.  Scratch: T[4 qb .. 4 qb + 3]."""
-    t0, t1, t2, t3 = (T[4 * qb + i] for i in range(4))
+def b_max(g: int, qb: int) -> list:
+    """maximum over the 32 scores per lane of generation g, query block qb (already relative to the reference: s * scale2 - m_ref), both half-waves -> T[4 qb]"""
+    t0, t1 = T[4 * qb], T[4 * qb + 1]
     s0, s1 = S(g, 0, qb), S(g, 1, qb)
     ops: list = []
-    # two independent max3 chains (key blocks 0 and 1), 8 + 8 instructions
-    ops.append(f"v_max3_f32 {vr(t0)}, {vr(s0)}, {vr(s0 + 1)}, {vr(s0 + 2)}")
+    ops.append(f"v_max3_f32 {vr(t0)}, {vr(s0)}, {vr(s0 + 1)}, {vr(s0 + 2)}")          # two independent max3 chains (key blocks 0 and 1)
     ops.append(f"v_max3_f32 {vr(t1)}, {vr(s1)}, {vr(s1 + 1)}, {vr(s1 + 2)}")
     for i in range(3, 15, 2):
         ops.append(f"v_max3_f32 {vr(t0)}, {vr(t0)}, {vr(s0 + i)}, {vr(s0 + i + 1)}")
         ops.append(f"v_max3_f32 {vr(t1)}, {vr(t1)}, {vr(s1 + i)}, {vr(s1 + i + 1)}")
     ops.append(f"v_max3_f32 {vr(t0)}, {vr(t0)}, {vr(s0 + 15)}, {vr(t1)}")
     ops.append(f"v_max_f32_e32 {vr(t0)}, {vr(t0)}, {vr(s1 + 15)}")
-    # both half-waves of a query column: t0 <- max over lanes l, l ^ 32
-    ops.append([f"v_mov_b32_e32 {vr(t1)}, {vr(t0)}", "s_nop 1", f"v_permlane32_swap_b32_e32 {vr(t0)}, {vr(t1)}"])
+    ops.append([f"v_mov_b32_e32 {vr(t1)}, {vr(t0)}", "s_nop 1", f"v_permlane32_swap_b32_e32 {vr(t0)}, {vr(t1)}"])     # lanes l and l ^ 32 share a query column
     ops.append(f"v_max_f32_e32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
-    ops.append(f"v_mul_f32_e32 {vr(t0)}, %[scale2], {vr(t0)}")            # scale2 > 0: max(scale2 * s) = scale2 * max(s)
-    ops.append(f"v_add_f32_e32 {vr(t2)}, {vr(t0)}, {vr(NM[qb])}")        # tile maximum - m_ref
-    # any lane beyond the bound (or m_ref still -inf): re-reference in the out-of-line block, which returns to .Lback
-    ops.append([f"v_cmp_lt_f32_e32 vcc, {THR_BITS}, {vr(t2)}", f"s_cbranch_vccnz .Lf64_resc_{site}_{qb}_%=", f".Lf64_back_{site}_{qb}_%=:"])
     return ops
 
 
-def rescale_block(qb: int, site: str) -> list[str]:
-    """out of line: m_new = max(m_ref, tile max) ; alpha = exp2(m_ref - m_new) ; l *= alpha ; O(qb) *= alpha ; m_ref = m_new.   T[4 qb] = scaled tile max."""
-    t0, t1, t2, t3 = (T[4 * qb + i] for i in range(4))
-    o = [f".Lf64_resc_{site}_{qb}_%=:"]
-    o.append(f"v_sub_f32_e32 {vr(t1)}, 0, {vr(NM[qb])}")                  # m_ref
-    o.append(f"v_max_f32_e32 {vr(t2)}, {vr(t1)}, {vr(t0)}")               # m_new
-    o.append(f"v_sub_f32_e32 {vr(t1)}, {vr(t1)}, {vr(t2)}")               # m_ref - m_new  (<= 0; -inf - finite = -inf on the first tile)
-    o.append(f"v_exp_f32_e32 {vr(t1)}, {vr(t1)}")                         # alpha
-    o.append(f"v_sub_f32_e32 {vr(NM[qb])}, 0, {vr(t2)}")
-    o.append(f"v_mul_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(t1)}")
-    o.append(f"v_mul_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(t1)}")           # the second partial row sum lives at the old reference too
-    o.append("s_nop 15")                                                 # in-flight MFMAs of the previous C own the O accumulators
-    o.append("s_nop 15")
-    for r in range(64):
-        a = 64 * qb + r
-        o.append(f"v_accvgpr_read_b32 {vr(t3)}, a{a}")
-        o.append(f"v_mul_f32_e32 {vr(t3)}, {vr(t3)}, {vr(t1)}")
-        o.append(f"v_accvgpr_write_b32 a{a}, {vr(t3)}")
+def decide(g: int, qb: int, site: str) -> list[str]:
+    """any lane whose tile maximum exceeds the reference by more than THR: re-reference in the out-of-line block (which returns to .Lback)"""
+    return [f"v_cmp_lt_f32_e32 vcc, {THR_BITS}, {vr(T[4 * qb])}", f"s_cbranch_vccnz .Lf64_resc_{site}_{qb}_%=", f".Lf64_back_{site}_{qb}_%=:"]
+
+
+def rescale_ops(g: int, qb: int, first: bool) -> list[str]:
+    """d = max(tile maximum - m_ref, 0) (first tile: the maximum itself): m_ref += d, i.e. NMB -= d; the scores of the tile (generation g, taken against the old
+    reference) -= d; and unless this is the first tile: alpha = exp2(-d), l *= alpha, O(qb) *= alpha."""
+    t0, t1, t3 = T[4 * qb], T[4 * qb + 1], T[4 * qb + 3]
+    o = []
+    if not first:
+        o.append(f"v_max_f32_e32 {vr(t0)}, 0, {vr(t0)}")                  # lanes at or below their reference keep it
+        o.append(f"v_sub_f32_e32 {vr(t1)}, 0, {vr(t0)}")
+        o.append(f"v_exp_f32_e32 {vr(t1)}, {vr(t1)}")                     # alpha
+    o.append(f"v_sub_f32_e32 {vr(NMB(qb))}, {vr(NMB(qb))}, {vr(t0)}")
+    for r in range(1, 16):
+        o.append(f"v_mov_b32_e32 {vr(NMB(qb) + r)}, {vr(NMB(qb))}")
+    for sb in range(2):
+        for r in range(16):
+            o.append(f"v_sub_f32_e32 {vr(S(g, sb, qb) + r)}, {vr(S(g, sb, qb) + r)}, {vr(t0)}")
+    if not first:
+        o.append(f"v_mul_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(t1)}")
+        o.append(f"v_mul_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(t1)}")       # the second partial row sum lives at the old reference too
+        o.append("s_nop 15")                                             # the last MFMAs of C own the O accumulators
+        o.append("s_nop 15")
+        for r in range(64):
+            a = 64 * qb + r
+            o.append(f"v_accvgpr_read_b32 {vr(t3)}, a{a}")
+            o.append(f"v_mul_f32_e32 {vr(t3)}, {vr(t3)}, {vr(t1)}")
+            o.append(f"v_accvgpr_write_b32 a{a}, {vr(t3)}")
     o.append("s_nop 1")
-    o.append(f"s_branch .Lf64_back_{site}_{qb}_%=")
     return o
 
 
+def rescale_block(g: int, qb: int, site: str) -> list[str]:
+    return [f".Lf64_resc_{site}_{qb}_%=:"] + rescale_ops(g, qb, False) + [f"s_branch .Lf64_back_{site}_{qb}_%="]
+
+
 def b_exp(g: int, sb: int, qb: int, m: int) -> list[str]:
-    """8 scores (registers 8 m .. 8 m + 7 of S(sb, qb)) -> p = exp2(s * scale2 - m_ref), row-sum partials, PF(sb, qb, m)"""
+    """8 scores (registers 8 m .. 8 m + 7 of S(sb, qb), already s * scale2 - m_ref) -> p = exp2(.), row-sum partials, PF(sb, qb, m)"""
     rs = [S(g, sb, qb) + 8 * m + i for i in range(8)]
     ops = []
     for h4 in (0, 4):
         q = rs[h4:h4 + 4]
-        ops += [f"v_fma_f32 {vr(r)}, {vr(r)}, %[scale2], {vr(NM[qb])}" for r in q]
         ops += [f"v_exp_f32_e32 {vr(r)}, {vr(r)}" for r in q]
         # two partial sums per query block break the dependent-add chain: L[qb] and T[8 + qb]
         ops += [f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[0])}", f"v_add_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(q[1])}",
@@ -198,15 +213,26 @@ def build() -> str:
     out_of_line: list[str] = []
     st.comment("---- prologue")
     o(f"s_mov_b32 s{S_M0}, m0")
+    # Q fragments -> v[128:191] -> * scale2 (fp32 multiply, one rounding to bf16) -> a[128:191]
     for qb in range(2):
         for ks in range(8):
-            o(f"global_load_dwordx4 {QF(qb, ks)}, %[qp{qb}], off offset:{32 * ks}")
+            o(f"global_load_dwordx4 {vr(128 + 4 * (8 * qb + ks), 4)}, %[qp{qb}], off offset:{32 * ks}")
     for i in range(128):
         o(f"v_accvgpr_write_b32 a{i}, 0")
     for qb in range(2):
-        o(f"v_mov_b32_e32 {vr(NM[qb])}, 0x7f800000")        # -m_ref = +inf
+        for r in range(16):
+            o(f"v_mov_b32_e32 {vr(NMB(qb) + r)}, 0")        # the reference is chosen after tile 0 (whose chains start from 0)
         o(f"v_mov_b32_e32 {vr(L[qb])}, 0")
         o(f"v_mov_b32_e32 {vr(T[8 + qb])}, 0")
+    o("s_waitcnt vmcnt(0)")
+    for i in range(64):
+        src, lo, hi = 128 + i, T[0], T[1]
+        o(f"v_lshlrev_b32_e32 {vr(lo)}, 16, {vr(src)}")
+        o(f"v_and_b32_e32 {vr(hi)}, 0xffff0000, {vr(src)}")
+        o(f"v_mul_f32_e32 {vr(lo)}, %[scale2], {vr(lo)}")
+        o(f"v_mul_f32_e32 {vr(hi)}, %[scale2], {vr(hi)}")
+        o(f"v_cvt_pk_bf16_f32 {vr(lo)}, {vr(lo)}, {vr(hi)}")
+        o(f"v_accvgpr_write_b32 a{128 + i}, {vr(lo)}")
     o(f"v_mov_b32_e32 {vr(KOF[0])}, %[koff]")
     o(f"v_mov_b32_e32 {vr(VOF[0])}, %[voff]")
     for p in range(1, 4):
@@ -233,12 +259,17 @@ def build() -> str:
     st.extend(vta_update(S_SLOT[0]))
     st.extend(k_request(0))
     st.extend(k_request(1))
-    for g in a_groups(0, [[], []]):
+    for g in a_groups(0, [[], []], from_zero=True):
         st.extend(g)
     st.extend(rowa_update(S_SLOT[1]))
     st.extend(k_request(0))
     st.extend(k_request(1))
     o("s_nop 7")
+    st.comment("---- the first reference: m_ref = maximum of tile 0 per query column (O and l are still zero: nothing to rescale)")
+    for qb in range(2):
+        for item in b_max(0, qb):
+            st.extend([item] if isinstance(item, str) else item)
+        st.extend(rescale_ops(0, qb, True))
 
     def stamp(k: int) -> None:
         if TRACE:
@@ -246,19 +277,15 @@ def build() -> str:
             o("s_waitcnt lgkmcnt(0)")
 
     def step(g_cur: int, site: str, full: bool, loop_body: bool) -> None:
-        """full: [A(t+1) -> generation g_cur ^ 1 | B(t)] ; C(t) with barrier, LDS-DMA of tile min(t+3, nkt-1), address rebuilds.   not full: B(t) ; C(t)."""
-        bm = [] if "nob" in DBG else b_max(g_cur, 0, site) + b_max(g_cur, 1, site)
-        if "nob" not in DBG:
-            for qb in range(2):
-                out_of_line.extend(rescale_block(qb, site))
-        chunks = {(sb, m): ([] if "nob" in DBG else b_exp(g_cur, sb, 0, m) + b_exp(g_cur, sb, 1, m)) for sb in range(2) for m in range(2)}
+        """full: [A(t+1) -> generation g_cur ^ 1 | B(t)] ; C(t) with barrier, LDS-DMA of tile min(t+3, nkt-1), address rebuilds, the maximum of tile t+1 in its
+        gaps ; the re-reference decision for tile t+1 (so that A(t+2) already starts from the new reference).   not full: B(t) ; C(t)."""
+        nob = "nob" in DBG
+        chunks = {(sb, m): ([] if nob else b_exp(g_cur, sb, 0, m) + b_exp(g_cur, sb, 1, m)) for sb in range(2) for m in range(2)}
         barrier = [] if "nobarrier" in DBG else ["s_waitcnt vmcnt(0)", "s_barrier"]
         if not full:
             st.extend(vta_update(S_SLOT[0]))
             st.extend(v_request(0))
             st.extend(v_request(1))
-            for item in bm:
-                st.extend([item] if isinstance(item, str) else item)
             for key in ((0, 0), (0, 1), (1, 0), (1, 1)):
                 st.extend(chunks[key])
             o("s_nop 1")
@@ -273,20 +300,25 @@ def build() -> str:
         na = len(ag)
         pcs = stage_pieces()
         dma = [] if "nostage" in DBG else [stage_begin(S_SLOT[3]) + pcs[0]] + pcs[1:]
-        segs: list[tuple[list, int, int]] = []
+        bm = [] if nob else b_max(g_cur ^ 1, 0) + b_max(g_cur ^ 1, 1)
+        segs: list[tuple] = []
         segs.append((vta_update(S_SLOT[0]), 0, 20))                        # C(t)'s V^T addresses (first request: A's fragment 14, group 28)
-        segs.append((bm, 0, na - 8, "chain"))                              # the re-reference decision comes before every exponential of the tile
         segs.append((chunks[(0, 0)], 0, na - 1, "chain"))                  # PF(0, ., 0): before C's first MFMA
         segs.append((chunks[(0, 1)], 0, na + 7, "chain"))                  # PF(0, ., 1): before C's iteration 4 (group na + 8)
         segs.append((chunks[(1, 0)], 0, na + 15, "chain"))
         segs.append((chunks[(1, 1)], 0, na + 23, "chain"))
         segs.append((rowa_update(S_SLOT[2]), 27, na + 26))                 # K addresses of tile t+2: after A's last request (group 26), before C's iteration 14
         segs.append((dma, na + 3, len(groups) - 1))
+        segs.append((bm, na + 8, len(groups) - 1))                         # tile t+1's scores are complete 12 states after A's last MFMA (group na - 1)
         lines = weave_budget(groups, segs, CAP)
         if TRACE and site == "l0":
             k = max(i for i, x in enumerate(lines) if x == ag[-1][-1])
             lines = lines[:k + 1] + ["s_memtime s[66:67]", "s_waitcnt lgkmcnt(0)"] + lines[k + 1:]
         st.extend(lines)
+        if not nob:
+            for qb in range(2):
+                st.extend(decide(g_cur ^ 1, qb, site))
+                out_of_line.extend(rescale_block(g_cur ^ 1, qb, site))
         st.extend(stage_advance(f"s{S_INCK}", f"s{S_INCV}"))
         st.extend(rotate_slots())
 
