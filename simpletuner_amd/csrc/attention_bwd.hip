@@ -764,6 +764,87 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// dK/dV kernel, fourth generation (head_dim 128, no key bias, r4): the geometry of dkv3 (8 waves x 32 keys, two waves per SIMD, 256 registers per wave, the
+// same LDS images and transposing reads) with a HAND-SCHEDULED body generated by tools/kgen/dkv.py: the statistics ride in the MFMA chains (S chains start
+// from +lse and accumulate q . (-scale2 k), dP chains start from +delta and accumulate dO . (-v): three VALU instructions per score instead of five, no
+// statistics registers), P / dS are packed in place, fragments are requested two MFMAs ahead into a four-deep ring with counted waits.  K is multiplied by
+// -scale * log2(e) once per workgroup and re-rounded to bf16: dK / dV agree with dkv3 to bf16 rounding, not bit for bit.  HIP code computes the lane
+// addresses in front of the statement and finishes behind it (dK through the fused RoPE + RMSNorm backward or as head-major rows, dV as token rows).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
+                                                          const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lsep,
+                                                          const float* __restrict__ delta, bf16* __restrict__ dK, bf16* __restrict__ dVrows, int64_t ld_dv,
+                                                          int H, int Sq, int Sqp, int Sk, float scale, float scale2, RopeBwd rp) {
+  constexpr int HD = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WgMap wg = attn_wg_map();
+  const int head = wg.head, b = wg.b;
+  const int64_t bh = (int64_t)b * H + head;
+  {
+    const int h = lane >> 5, l31 = lane & 31;
+    const int keyi = min(wg.tile * 256 + wv * 32 + l31, Sk - 1);
+    const bf16* kbase = K + bh * (int64_t)Sk * HD;
+    const bf16* vbase = Vrows + (int64_t)b * Sk * ld_v + (int64_t)head * HD;
+    const uint32_t koffs = (uint32_t)(keyi * HD + 8 * h) * 2u;
+    const uint32_t voffs = (uint32_t)((int64_t)keyi * ld_v + 8 * h) * 2u;
+    const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int qrow_p = perm23(l31);
+    const uint32_t rowb = lds + qrow_p * 256 + ((h ^ swz_q(qrow_p)) << 4);            // row fragments: chunk (2 ks + h) ^ f(row)
+    const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
+    const uint32_t trb = lds + (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;
+    const uint32_t statb = lds + 32 * h;
+    // LDS-DMA: piece = wave + 8 p, chunk idx = piece * 64 + lane: row = piece * 4 + lane / 16, LDS chunk position c holds source chunk c ^ f(row)
+    const int drow_i = wv * 4 + (lane >> 4);
+    const uint32_t drow = (uint32_t)drow_i;
+    const uint32_t dcol = (uint32_t)(((lane & 15) ^ swz_q(drow_i)) * 8) * 2u;
+    const bf16* qbase = Q + bh * (int64_t)Sq * HD;
+    const bf16* gbase = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
+    const float* lbase = lsep + bh * (int64_t)Sqp;
+    const float* dbase = delta + bh * (int64_t)Sqp;
+    const uint32_t nqt = (uint32_t)((Sq + 63) / 64), sq = (uint32_t)Sq, stmax = (uint32_t)(Sqp - 64), ldo2 = (uint32_t)(ld_do * 2);
+    const uint32_t wvu = (uint32_t)wv;
+    const float nscale2 = -scale2;
+    asm volatile(
+#ifdef ST355_DKV4_BODY_INC        // tools/attn_lab builds: a generator variant under test
+#include ST355_DKV4_BODY_INC
+#else
+#include "gen/attn_dkv4_body.inc"
+#endif
+        :
+        : [koffs] "v"(koffs), [voffs] "v"(voffs), [rowb] "v"(rowb), [trb] "v"(trb), [statb] "v"(statb), [drow] "v"(drow), [dcol] "v"(dcol),
+          [kbase] "s"(kbase), [vbase] "s"(vbase), [qbase] "s"(qbase), [gbase] "s"(gbase), [lbase] "s"(lbase), [dbase] "s"(dbase), [lds] "s"(lds), [wv] "s"(wvu),
+          [nqt] "s"(nqt), [sq] "s"(sq), [stmax] "s"(stmax), [ldo2] "s"(ldo2), [scale] "s"(scale), [nscale2] "s"(nscale2)
+        : "memory", "vcc", "scc",
+#include "gen/attn_dkv4_clobbers.inc"
+    );
+  }
+  // every index below is re-derived: nothing needs to live across the statement above
+  const char* mine = smem + wv * 16384;
+  const int key0 = wg.tile * 256 + wv * 32;
+  if (rp.out != nullptr) {
+    rope_bwd_finish(rp, K + bh * (int64_t)Sk * HD, b, head, key0, Sk, lane, mine);
+  } else {
+    const int tl = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int t = it * 4 + tl;
+      if (key0 + t < Sk) *(bf16x8*)(dK + (bh * Sk + key0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + t * 256 + ((c ^ (t & 15)) << 4));
+    }
+  }
+  {
+    const int tl = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int t = it * 4 + tl;
+      if (key0 + t < Sk)
+        *(bf16x8*)(dVrows + ((int64_t)b * Sk + key0 + t) * ld_dv + (int64_t)head * HD + c * 8) = *(const bf16x8*)(mine + 8192 + t * 256 + ((c ^ (t & 15)) << 4));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dQ kernel, second generation (head_dim 128, r4): 4 waves x 64 queries — ONE wave per SIMD with the whole 512-register file.
 // Why: in k_attn_bwd_dq every MFMA fetches a fresh 1-KiB operand fragment from LDS (one resident operand, 32 queries per wave), so the LDS pipe has to
 // run at the matrix pipe's rate; with 64 queries per wave each K / V / K^T fragment feeds TWO MFMAs (0.5 fragment reads per MFMA).  That needs dQ^T
@@ -861,6 +942,12 @@ extern "C" size_t st355_attn_bwd_workspace(int B, int H, int S, int Sp, int d) {
 // dQ kernel choice: 64 = k_attn_bwd_dq64 where it applies (default), 32 = always k_attn_bwd_dq.  ST355_ATTN_DQ overrides; tools/attn_lab sets the variable directly.
 int g_attn_dq_impl = -1;
 unsigned long long* g_attn_dq_trace = nullptr;     // tools/attn_lab, trace builds of the dq64 body only
+// dK/dV kernel choice for head_dim 128 without key bias: 4 = k_attn_bwd_dkv4 (hand-scheduled body), 3 = k_attn_bwd_dkv3.  ST355_ATTN_DKV=3 overrides.
+int g_attn_dkv_impl = -1;
+static int attn_dkv_impl() {
+  if (g_attn_dkv_impl < 0) { const char* e = getenv("ST355_ATTN_DKV"); g_attn_dkv_impl = (e && atoi(e) == 3) ? 3 : 4; }
+  return g_attn_dkv_impl;
+}
 static int attn_dq_impl() {
   if (g_attn_dq_impl < 0) { const char* e = getenv("ST355_ATTN_DQ"); g_attn_dq_impl = (e && atoi(e) == 32) ? 32 : 64; }
   return g_attn_dq_impl;
@@ -908,7 +995,14 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 4.0);
-    if (!Qt) {
+    if (!Qt && d == 128 && !key_bias && attn_dkv_impl() == 4) {       // hand-scheduled body (k_attn_bwd_dkv4)
+      dim3 grid((Sk + 255) / 256, H, B);
+      const int lds = 8 * 16384;                                       // the two ring slots (66.5 KiB); 16 KiB per wave for the parked dK / dV rows
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv4, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_dkv4, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
+                         (const float*)lsep, (const float*)delta, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);
+    } else if (!Qt) {
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * 256 + 512);
 #define ST355_DKV3_LAUNCH(HD_)                                                                                                            \

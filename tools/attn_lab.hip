@@ -180,16 +180,18 @@ int main(int argc, char** argv) {
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
   bf16* dQ3; CK(hipMalloc(&dQ3, nh * 2)); CK(hipMemsetAsync(dQ3, 0, nh * 2, st));
   if (getenv("LAB_DQ_TRACE")) { CK(hipMalloc(&g_attn_dq_trace, 4 * 128)); CK(hipMemsetAsync(g_attn_dq_trace, 0, 4 * 128, st)); }
-  for (int pass = 0; pass < 3; pass++) {     // 0: transposed copies (dkv2 + dq)   1: no copies, 32-query dQ kernel (dkv3 + dq<TR>)   2: no copies, dq64
-    g_attn_dq_impl = pass == 2 ? 64 : 32;
+  bf16 *dK4, *dqkv4; CK(hipMalloc(&dK4, nh * 2)); CK(hipMalloc(&dqkv4, nr * 3 * 2)); CK(hipMemsetAsync(dK4, 0, nh * 2, st)); CK(hipMemsetAsync(dqkv4, 0, nr * 3 * 2, st));
+  for (int pass = 0; pass < 4; pass++) {     // 0: transposed copies (dkv2 + dq)   1: no copies (dkv3 + dq<TR>)   2: dkv3 + dq64   3: dkv4 + dq64
+    g_attn_dq_impl = pass >= 2 ? 64 : 32;
+    g_attn_dkv_impl = pass == 3 ? 4 : 3;
     const bf16* qt = pass ? nullptr : Qt; const bf16* kt = pass ? nullptr : Kt;
-    bf16 *dq_ = pass == 2 ? dQ3 : pass ? dQ2 : dQ, *dk_ = pass ? dK2 : dK, *dv_ = (pass ? dqkv2 : dqkv) + 2 * D;
+    bf16 *dq_ = pass >= 2 ? dQ3 : pass ? dQ2 : dQ, *dk_ = pass == 3 ? dK4 : pass ? dK2 : dK, *dv_ = (pass == 3 ? dqkv4 : pass ? dqkv2 : dqkv) + 2 * D;
     RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
     CK(hipStreamSynchronize(st));
     st355_prof_reset(); st355_prof_enable(1);
     for (int i = 0; i < iters; i++) RC(st355_attn_bwd(st, Q, K, qt, kt, vrows, 3 * D, O, D, dO, D, lse2, nullptr, dq_, dk_, dv_, 3 * D, B, H, S, Sp, d, scale, ws));
     CK(hipStreamSynchronize(st));
-    st355_prof_enable(0); prof_print(pass == 2 ? "bwd, no copies, dq64" : pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
+    st355_prof_enable(0); prof_print(pass == 3 ? "bwd, dkv4 + dq64" : pass == 2 ? "bwd, no copies, dq64" : pass ? "bwd, no transposed copies" : "bwd, Q^T/K^T/dO^T copies");
   }
   if (g_attn_dq_trace) {      // s_memtime stamps of block 0's LAST main-loop iteration: loop top, after A / after C of step 1, after A / after C of step 2
     unsigned long long t[64]; CK(hipMemcpy(t, g_attn_dq_trace, sizeof(t), hipMemcpyDeviceToHost));
@@ -197,6 +199,18 @@ int main(int argc, char** argv) {
       const unsigned long long* u = t + 16 * w;
       printf("  dq64 trace wave %d: A1 %llu  C1 %llu  A2 %llu  C2 %llu  (tile %llu cycles) | prologue %llu  loop+last %llu  park %llu  (statement %llu)\n", w, u[1] - u[0],
              u[2] - u[1], u[3] - u[2], u[4] - u[3], u[4] - u[0], u[6] - u[5], u[7] - u[6], u[8] - u[7], u[8] - u[5]);
+    }
+  }
+  if (d == 128) {          // dkv4 vs dkv3: K is pre-scaled and re-rounded in dkv4 -> agreement to bf16 rounding
+    float* maxd; double *sd, *sr; CK(hipMalloc(&maxd, 4)); CK(hipMalloc(&sd, 8)); CK(hipMalloc(&sr, 8));
+    struct { const char* n; const bf16* a; const bf16* b; int64_t cnt; } c4[] = {{"dK", dK4, dK2, (int64_t)nh}, {"dV (whole dqkv rows)", dqkv4, dqkv2, (int64_t)nr * 3}};
+    for (auto& c : c4) {
+      CK(hipMemsetAsync(maxd, 0, 4, st)); CK(hipMemsetAsync(sd, 0, 8, st)); CK(hipMemsetAsync(sr, 0, 8, st));
+      k_absdiff<<<2048, 256, 0, st>>>(c.a, c.b, c.cnt, maxd, sd, sr);
+      float hm; double hd, hr;
+      CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hd, sd, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hr, sr, 8, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      printf("  %s, dkv4 vs dkv3: rel-L2 %.3e, max |d| %.3e  %s\n", c.n, sqrt(hd / (hr + 1e-30)), hm, sqrt(hd / (hr + 1e-30)) < 6e-3 ? "within bf16 rounding" : "MISMATCH");
     }
   }
   if (d != 128 && d != 64 && d != 96) return 0;
