@@ -268,11 +268,15 @@ int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const v
 /* ---- K7: joint non-causal attention over [txt || img] tokens ------------------------------- */
 /* O: [B,S,H*d] token-major bf16 (row stride ld_o elements); lse2: [B,H,S] fp32 (log2-domain logsumexp of
  * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
-/* Kernel choice for the head_dim-128, no-bias, S % 64 == 0 self-attention shapes (tuning / A-B hook): fwd = 64 selects the hand-scheduled one-wave-per-SIMD
- * forward (k_attn_fwd64: 64 queries per wave, stale-reference softmax; O agrees with the 32-query kernel to bf16 rounding, lse2 to ~1e-3: Q is pre-scaled by scale * log2(e) and re-rounded), 32 the 32-query kernel
- * (k_attn_fwd4) everywhere; dq = 64 selects k_attn_bwd_dq64 (bit-identical to the 32-query k_attn_bwd_dq), 32 the latter everywhere; -1 leaves a choice unchanged.
- * Defaults: 64 / 64 (environment ST355_ATTN_FWD64=0, ST355_ATTN_DQ=32 flip them).  Returns (previous fwd) * 256 + (previous dq). */
-int st355_attn_set_impl(int fwd, int dq);
+/* Kernel choice for the head_dim-128, no-bias self-attention shapes (tuning / A-B hook).
+ *   fwd: 64 = the hand-scheduled one-wave-per-SIMD forward where S % 64 == 0 (k_attn_fwd64: 64 queries per wave, stale-reference softmax; the scores are
+ *        the same fp32 sums: O agrees with the 32-query kernel to bf16 rounding, lse2 to fp32 rounding), 32 = k_attn_fwd4;
+ *   dq:  64 = k_attn_bwd_dq64 where Sk % 64 == 0 (bit-identical to the 32-query k_attn_bwd_dq), 32 = the latter everywhere;
+ *   dkv: 4 = k_attn_bwd_dkv4 (hand-scheduled body, statistics folded into the MFMA chains; same scores, another summation order: dK / dV agree
+ *        with dkv3 to ~3e-4), 3 = k_attn_bwd_dkv3;
+ *   -1 leaves a choice unchanged.  Defaults: 64 / 64 / 4 (environment ST355_ATTN_FWD64=0, ST355_ATTN_DQ=32, ST355_ATTN_DKV=3 flip them).
+ * Returns (previous fwd) * 65536 + (previous dq) * 256 + (previous dkv). */
+int st355_attn_set_impl(int fwd, int dq, int dkv);
 int st355_attn_fwd(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias,
                    void* O, int64_t ld_o, float* lse2, int B, int H, int S, int Sp, int d, float scale);
 /* The same with V ROW-major: v_rows = token rows of a [B*S, ld_v] projection buffer, head h at columns h*d (e.g. the V third of the QKV output; what

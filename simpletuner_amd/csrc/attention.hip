@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
     const uint32_t nkt = (uint32_t)(S / 64);
     const uint32_t blk0 = blockIdx.x | blockIdx.y | blockIdx.z;
     const uint32_t tracelo = (uint32_t)(uintptr_t)trace, tracehi = (uint32_t)((uintptr_t)trace >> 32);
+    const float thr = 8.0f / scale2;                    // the stale-reference bound (2^8 on the exponentials) in the accumulators' raw-score units
     asm volatile(
 #ifdef ST355_FWD64_BODY_INC       // tools/attn_lab builds: a generator variant under test
 #include ST355_FWD64_BODY_INC
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
 #endif
         : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
         : [qp0] "v"(qp0), [qp1] "v"(qp1), [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [vtb] "v"(vtb), [park] "v"(park), [kbase] "s"(kbase),
-          [vbase] "s"(vbase), [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vrow32] "s"(vrow32), [scale2] "s"(scale2), [blk0] "s"(blk0),
+          [vbase] "s"(vbase), [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vrow32] "s"(vrow32), [scale2] "s"(scale2), [thr] "s"(thr), [blk0] "s"(blk0),
           [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)
         : "memory", "vcc", "scc",
 #include "gen/attn_fwd64_clobbers.inc"

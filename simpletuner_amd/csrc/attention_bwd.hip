@@ -25,7 +25,7 @@ __device__ __forceinline__ int swz_q(int q) { return ((q & 3) << 2) | ((q >> 2) 
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ O, int64_t ld_o, const bf16* __restrict__ dO,
                                                       int64_t ld_do, const float* __restrict__ lse2, float* __restrict__ delta,
-                                                      float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp) {
+                                                      float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp, float lse_mul) {
   constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;          // lanes per token (power of two; head_dim 96 leaves 4 of 16 idle)
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TPB];
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
     for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (c == 0) {   // stats are written in the padded [B*H, Sp] layout: padded queries get delta 0 and lse +inf (=> P = 0)
       delta[bh * Sp + t] = valid ? s : 0.f;
-      lsep[bh * Sp + t] = valid ? lse2[bh * S + t] : INFINITY;
+      lsep[bh * Sp + t] = valid ? lse2[bh * S + t] * lse_mul : INFINITY;      // lse_mul = 1 / scale2 for k_attn_bwd_dkv4 (its score chains start from it), else 1
     }
     if (!valid) {
 #pragma unroll
@@ -766,9 +766,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
 // ------------------------------------------------------------------------------------------------
 // dK/dV kernel, fourth generation (head_dim 128, no key bias, r4): the geometry of dkv3 (8 waves x 32 keys, two waves per SIMD, 256 registers per wave, the
 // same LDS images and transposing reads) with a HAND-SCHEDULED body generated by tools/kgen/dkv.py: the statistics ride in the MFMA chains (S chains start
-// from +lse and accumulate q . (-scale2 k), dP chains start from +delta and accumulate dO . (-v): three VALU instructions per score instead of five, no
-// statistics registers), P / dS are packed in place, fragments are requested two MFMAs ahead into a four-deep ring with counted waits.  K is multiplied by
-// -scale * log2(e) once per workgroup and re-rounded to bf16: dK / dV agree with dkv3 to bf16 rounding, not bit for bit.  HIP code computes the lane
+// from lse / scale2 and accumulate q . (-k), dP chains start from +delta and accumulate dO . (-v): four VALU instructions per score instead of five, no
+// statistics registers), P / dS are packed in place, fragments are requested two MFMAs ahead into a four-deep ring with counted waits.  The scores are the
+// same fp32 sums as dkv3's (K and V only change sign); dK / dV differ from dkv3 by fp32 summation order only (bf16-rounding agreement, not bit for bit).  HIP code computes the lane
 // addresses in front of the statement and finishes behind it (dK through the fused RoPE + RMSNorm backward or as head-major rows, dV as token rows).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
@@ -954,11 +954,12 @@ static int attn_dq_impl() {
 }
 
 extern int g_attn_fwd_impl;                        // attention.hip
-extern "C" int st355_attn_set_impl(int fwd, int dq) {
+extern "C" int st355_attn_set_impl(int fwd, int dq, int dkv) {
   if (g_attn_fwd_impl < 0) { const char* e = getenv("ST355_ATTN_FWD64"); g_attn_fwd_impl = (e && e[0] == '0') ? 32 : 64; }
-  const int prev = g_attn_fwd_impl * 256 + attn_dq_impl();
+  const int prev = g_attn_fwd_impl * 65536 + attn_dq_impl() * 256 + attn_dkv_impl();
   if (fwd == 32 || fwd == 64) g_attn_fwd_impl = fwd;
   if (dq == 32 || dq == 64) g_attn_dq_impl = dq;
+  if (dkv == 3 || dkv == 4) g_attn_dkv_impl = dkv;
   return prev;
 }
 
@@ -982,20 +983,22 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   const double fl_unit = 2.0 * (double)B * H * (double)S * Sk * d;  // one Sq x Sk x d contraction
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  const bool use_dkv4 = !Qt && d == 128 && !key_bias && attn_dkv_impl() == 4;
   {
     ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
     dim3 grid(Sp / 64, H, B);
+    const float lse_mul = use_dkv4 ? 1.f / scale2 : 1.f;
     if (d == 96)
-      hipLaunchKernelGGL(k_attn_bwd_prep<96>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
+      hipLaunchKernelGGL(k_attn_bwd_prep<96>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
     else if (d == 128)
-      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
+      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
     else
-      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp);
+      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
     if ((rc = st355_check_launch("attn_bwd_prep")) != 0) return rc;
   }
   {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DKV, 4.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 4.0);
-    if (!Qt && d == 128 && !key_bias && attn_dkv_impl() == 4) {       // hand-scheduled body (k_attn_bwd_dkv4)
+    if (use_dkv4) {                                                    // hand-scheduled body (k_attn_bwd_dkv4)
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 8 * 16384;                                       // the two ring slots (66.5 KiB); 16 KiB per wave for the parked dK / dV rows
       static bool set = false;

@@ -230,7 +230,7 @@ def _declare(lib):
         "st355_qk_norm_wgrad_workspace": (sz, [i32, i32, i32, i32]),
         "st355_qk_norm_rope_bwd_wgrad": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]),
         "st355_qk_rope_norm_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32]),
-        "st355_attn_set_impl": (C.c_int, [i32, i32]),
+        "st355_attn_set_impl": (C.c_int, [i32, i32, i32]),
         "st355_attn_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32]),
         "st355_attn_fwd_vrows": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32]),
         "st355_attn_bwd_rope": (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp]),

@@ -392,11 +392,11 @@ def gemm_set_persistent(mode: int) -> int:
     return int(_l.load().st355_gemm_set_persistent(int(mode)))
 
 
-def attn_set_impl(fwd: int = -1, dq: int = -1):
-    """st355_attn_set_impl: 64 = the hand-scheduled 64-rows-per-wave kernels where they apply (default), 32 = the 32-row kernels everywhere, -1 = unchanged;
-    returns the previous (fwd, dq)"""
-    prev = int(_l.load().st355_attn_set_impl(int(fwd), int(dq)))
-    return prev // 256, prev % 256
+def attn_set_impl(fwd: int = -1, dq: int = -1, dkv: int = -1):
+    """st355_attn_set_impl: fwd / dq 64 = the hand-scheduled 64-rows-per-wave kernels where they apply (default), 32 = the 32-row kernels everywhere;
+    dkv 4 = the hand-scheduled dK/dV body (default), 3 = k_attn_bwd_dkv3; -1 = unchanged.  Returns the previous (fwd, dq, dkv)."""
+    prev = int(_l.load().st355_attn_set_impl(int(fwd), int(dq), int(dkv)))
+    return prev // 65536, (prev // 256) % 256, prev % 256
 
 
 def gemm_grouped(problems):

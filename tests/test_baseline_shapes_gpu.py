@@ -107,7 +107,19 @@ def test_self_attention_at_baseline_shapes(ops, name, B, H, S, d, d_valid):
     if d in (64, 96, 128):        # the production path: no Q^T / K^T / dO^T copies (dkv3 + dq<TR>), bit-identical to the copy-reading kernels
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO_rows, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale)
-        assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
+        assert torch.equal(dQ2, dQ)                                       # (head_dim 128: k_attn_bwd_dq64 where S % 64 == 0 — bit-identical too)
+        if d == 128:              # head_dim 128 takes k_attn_bwd_dkv4 (K pre-scaled and re-rounded): bf16-rounding agreement, and the same bound against fp32
+            assert _rel(dK2, dK) < 6e-3 and _rel(dqkv2[:, 2 * D:], dqkv[:, 2 * D:]) < 6e-3
+            assert _rel(dK2, dk_ref) < 2e-2 and _rel(_rows_to_heads(dqkv2[:, 2 * D:], B, H, S, d), dv_ref) < 2e-2
+            prev = ops.attn_set_impl(dkv=3)
+            try:
+                dK3 = torch.zeros_like(dK); dqkv3 = torch.zeros_like(dqkv)
+                ops.attn_bwd(q, k, None, None, v_rows, O, dO_rows, lse2, dQ2, dK3, dqkv3[:, 2 * D:], B, H, S, Sp, d, scale)
+            finally:
+                ops.attn_set_impl(dkv=prev[2])
+            assert torch.equal(dK3, dK) and torch.equal(dqkv3, dqkv)     # dkv3 stays bit-identical to the copy-reading kernel
+        else:
+            assert torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
 def test_pixart_cross_attention_at_2k(ops):

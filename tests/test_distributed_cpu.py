@@ -166,13 +166,15 @@ def _worker_world4(rank, world, init_file, out_dir):
         scale = gs.finish()                                           # (joins the async works: read the arena only after it)
         out[mode] = (flat.clone(), scale, sorted({k for k, _, _ in gs.launched_ops}))
     # bf16 arena: the fp32-accumulating form (all-to-all of the W chunks, fp32 sum in rank order, all-gather)
+    # (arena regions start on 8-element boundaries — tensors are padded to 8 — which the fp32 form needs: st355_sum_chunks_bf16's 16-byte shards)
+    n2 = 20_008
     g = torch.Generator().manual_seed(100 + rank)
-    mine = torch.randn(n, generator=g).to(torch.bfloat16)
+    mine = torch.randn(n2, generator=g).to(torch.bfloat16)
     flat = mine.clone()
-    gs = GradSync(flat, bucket_bytes=2 * 4096, mode="rs_ag")
+    gs = GradSync(flat, bucket_bytes=2 * 4096, mode="rs_ag", fp32_reduce=True)        # (opt-in: grad_sync.py)
     gs.begin()
-    for hi in range(n, 0, -2777):
-        gs.ready(max(0, hi - 2777), hi)
+    for hi in range(n2, 0, -2776):
+        gs.ready(max(0, hi - 2776), hi)
     scale = gs.finish()
     out["bf16"] = (flat.clone(), scale, sorted({k for k, _, _ in gs.launched_ops}), list(gs.launched_slices))
     torch.save(out, os.path.join(out_dir, f"w4_{rank}.pt"))
@@ -181,7 +183,7 @@ def _worker_world4(rank, world, init_file, out_dir):
 
 def test_four_process_gradient_exchange_all_forms():
     """the driver's scaling run uses 2, 4 and 8 ranks: the same exchange at world 4 over gloo — both fp32 forms leave the exact SUM, the bf16 arena's
-    fp32-accumulating form (all-to-all + local fp32 sum in rank order + all-gather; a < world tail of every slice through all-reduce) leaves the sum of the four
+    fp32-accumulating form (all-to-all + local fp32 sum in rank order + all-gather; a < 8 x world tail of every slice through all-reduce) leaves the sum of the four
     ranks' values accumulated in fp32 and rounded once, identical on every rank; scale = 1/4"""
     W = 4
     with tempfile.TemporaryDirectory() as d:
@@ -189,7 +191,8 @@ def test_four_process_gradient_exchange_all_forms():
         res = [torch.load(os.path.join(d, f"w4_{r}.pt")) for r in range(W)]
     n = 20_011
     want = torch.arange(n, dtype=torch.float32) * (1 + 2 + 3 + 4)
-    vals = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(W)]
+    n2 = 20_008
+    vals = [torch.randn(n2, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16) for r in range(W)]
     exact = (vals[0].float() + vals[1].float() + vals[2].float() + vals[3].float()).to(torch.bfloat16)
     for r in res:
         for mode in ("rs_ag", "allreduce"):
@@ -198,8 +201,8 @@ def test_four_process_gradient_exchange_all_forms():
         assert "reduce_scatter" in res[0]["rs_ag"][2] and "all_gather" in res[0]["rs_ag"][2] and res[0]["allreduce"][2] == ["all_reduce"]
         flat, scale, kinds, slices = r["bf16"]
         assert scale == 0.25 and "all_to_all" in kinds and "all_gather" in kinds
-        assert sum(hi - lo for lo, hi in slices) == n
+        assert sum(hi - lo for lo, hi in slices) == n2
         assert torch.equal(flat, res[0]["bf16"][0])                                   # every rank holds the same reduced arena
-        # the rs_ag part is the exactly-rounded fp32 sum; the < world tails went through a bf16 all-reduce (pairwise bf16 adds): compare those loosely
+        # the rs_ag part is the exactly-rounded fp32 sum; the < 8 x world tails went through a bf16 all-reduce (pairwise bf16 adds): compare those loosely
         diff = (flat.float() - exact.float()).abs()
         assert (diff == 0).float().mean().item() > 0.99 and diff.max().item() <= 0.0625 * exact.float().abs().max().item()

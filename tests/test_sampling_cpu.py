@@ -138,7 +138,7 @@ def test_cfg_pair_batching_runs_the_model_once_per_step_on_negative_then_positiv
     assert len(calls) == 3 and all(c["noisy_latents"] == (4, 4, 4, 4) and c["prompt_embeds"] == (4, 3, 5) and c["add_text_embeds"] == (4, 6) for c in calls)
     # replay by hand: eps = x * (uncond + g (cond - uncond)) with uncond = -1, cond = 2
     from simpletuner_amd.sampling import DDIMScheduler
-    sc = DDIMScheduler()
+    sc = DDIMScheduler(timestep_spacing="trailing")                   # validation.py:2889-2892: the trainer's inference_scheduler_timestep_spacing default
     sc.set_timesteps(3)
     x = x0.to(torch.bfloat16)
     for t in sc.timesteps:

@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
     float* hl = (float*)malloc((size_t)BH * S * 4); float* hl6 = (float*)malloc((size_t)BH * S * 4);
     CK(hipMemcpy(hl, lse2, (size_t)BH * S * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl6, lse6, (size_t)BH * S * 4, hipMemcpyDeviceToHost));
     double ml = 0; for (size_t i = 0; i < (size_t)BH * S; i++) { double e = fabs((double)hl[i] - hl6[i]); if (!(e <= ml)) ml = e; }
-    printf("  lse2, fwd64 vs fwd4: max |d| %.3e  %s\n", ml, ml < 4e-3 ? "ok" : "MISMATCH");
+    printf("  lse2, fwd64 vs fwd4: max |d| %.3e  %s\n", ml, ml < 1e-4 ? "ok" : "MISMATCH");
     if (g_attn_fwd_trace) {
       unsigned long long t[64]; CK(hipMemcpy(t, g_attn_fwd_trace, sizeof(t), hipMemcpyDeviceToHost));
       for (int w = 0; w < 4; w++) printf("  fwd64 trace wave %d: A %llu  C %llu  (step %llu cycles)\n", w, t[16 * w + 1] - t[16 * w], t[16 * w + 2] - t[16 * w + 1], t[16 * w + 2] - t[16 * w]);

@@ -6,11 +6,12 @@ Why a hand-scheduled body at the SAME geometry as k_attn_bwd_dkv3 (64 keys per w
 budget holds it): dkv3 sits at the 256-register limit, so hipcc consumes its LDS fragments in pairs right behind their requests (sched_barrier pins) and
 spends five VALU instructions per score; the matrix pipe idles ~45 % of the time although the LDS pipe is only half used (256 B/clk/CU for b64 / b128
 reads, MI355X_MICROARCH.md LDS table).  Here
-  * both VALU subtractions ride in the MFMAs: every S chain STARTS from +lse (the accumulator block is loaded from the stats image with four
-    ds_read_b128 instead of being zeroed) and accumulates  q . (-scale2 k):  acc = lse - s * scale2,  p = exp2(-acc) (the negation is a free input modifier);
-    every dP chain starts from +delta and accumulates  dO . (-v):  acc = delta - dP,  dS = p * (-acc).  K is multiplied by -scale * log2(e) once per workgroup
-    (fp32 multiply, one rounding to bf16), V is negated (exact).  Three VALU instructions per score (exp, mul, two half packs) instead of five, and no
-    registers for the statistics;
+  * both VALU subtractions ride in the MFMAs: every S chain STARTS from lse / scale2 (the prep kernel writes the padded statistics row pre-divided; the
+    accumulator block is loaded from the stats image with four ds_read_b128 instead of being zeroed) and accumulates  q . (-k):  acc = lse / scale2 - s,
+    p = exp2(-scale2 * acc);  every dP chain starts from +delta and accumulates  dO . (-v):  acc = delta - dP,  dS = p * (-acc).  K and V are NEGATED
+    (exact: the scores are the same fp32 sums of bf16 products the other kernels form; a first version pre-multiplied K by -scale2 and re-rounded it, which
+    moved extreme scores by ~2^-9 |s| against the forward's lse — up to 4 % on the dominant P of a spiked row).  Four VALU instructions per score (mul,
+    exp, mul, two half packs) instead of five, and no registers for the statistics;
   * P and dS are packed IN PLACE into the first halves of the S / dP accumulator blocks;
   * operand fragments are requested two MFMAs ahead into a ring of four 4-register buffers (counted lgkmcnt), C's first two during B, the next block's
     statistics behind C's last MFMA.
@@ -108,14 +109,15 @@ def a_groups(slot: int, qb: int, tail: list[list[str]]) -> list[list[str]]:
 
 
 def b_ops() -> list[str]:
-    """p = exp2(-(lse - s')) ; dS = p * -(delta - dP) ; P -> bf16 pairs in S[0:7], dS -> bf16 pairs in dP[0:7] (in place, ascending)"""
+    """p = exp2(-scale2 * (lse / scale2 - s)) ; dS = p * -(delta - dP) ; P -> bf16 pairs in S[0:7], dS -> bf16 pairs in dP[0:7] (in place, ascending)"""
     ops = []
     if "nob" in DBG:
         return ops
     for r0 in range(0, 16, 4):
         rs = [SACC + r0 + i for i in range(4)]
         ps = [DPACC + r0 + i for i in range(4)]
-        ops += [f"v_exp_f32_e64 {vr(r)}, -{vr(r)}" for r in rs]
+        ops += [f"v_mul_f32_e32 {vr(r)}, %[nscale2], {vr(r)}" for r in rs]       # -scale2 * (lse / scale2 - s) = s * scale2 - lse
+        ops += [f"v_exp_f32_e32 {vr(r)}, {vr(r)}" for r in rs]
         ops += [f"v_mul_f32_e64 {vr(p)}, {vr(r)}, -{vr(p)}" for r, p in zip(rs, ps)]
         ops += [f"v_cvt_pk_bf16_f32 {vr(SACC + (r0 >> 1) + i)}, {vr(rs[2 * i])}, {vr(rs[2 * i + 1])}" for i in range(2)]
         ops += [f"v_cvt_pk_bf16_f32 {vr(DPACC + (r0 >> 1) + i)}, {vr(ps[2 * i])}, {vr(ps[2 * i + 1])}" for i in range(2)]
@@ -167,7 +169,7 @@ def stat_stage(slot: int) -> list[str]:
 def build() -> str:
     st = Stream()
     o = st.op
-    st.comment("---- prologue: K' = bf16(-scale2 * K), V' = -V fragments; zero accumulators; stage tile 0")
+    st.comment("---- prologue: K' = -K, V' = -V fragments; zero accumulators; stage tile 0")
     o(f"s_mov_b32 s{S_M0}, m0")
     for ks in range(8):
         o(f"global_load_dwordx4 {KFR(ks)}, %[koffs], %[kbase] offset:{32 * ks}")
@@ -187,16 +189,8 @@ def build() -> str:
         st.extend(chn)
     st.extend(stat_stage(0))
     o("s_waitcnt vmcnt(0)")
-    for ks in range(8):
-        for j in range(4):
-            r = 32 + 4 * ks + j
-            lo, hi = T[0], T[1]
-            o(f"v_lshlrev_b32_e32 {vr(lo)}, 16, {vr(r)}")
-            o(f"v_and_b32_e32 {vr(hi)}, 0xffff0000, {vr(r)}")
-            o(f"v_mul_f32_e32 {vr(lo)}, %[nscale2], {vr(lo)}")
-            o(f"v_mul_f32_e32 {vr(hi)}, %[nscale2], {vr(hi)}")
-            o(f"v_cvt_pk_bf16_f32 {vr(r)}, {vr(lo)}, {vr(hi)}")
-            o(f"v_xor_b32_e32 {vr(64 + 4 * ks + j)}, 0x80008000, {vr(64 + 4 * ks + j)}")
+    for r in range(32, 96):
+        o(f"v_xor_b32_e32 {vr(r)}, 0x80008000, {vr(r)}")       # K' = -K, V' = -V (both bf16 halves of every register)
     o(f"s_mov_b32 s{S_CNT}, %[nqt]")
     # static priority for the second-dispatched half of the workgroup (waves 4-7): it is the arbitration loser of every SIMD pair otherwise
     # (MI355X_MICROARCH.md 'Two waves per SIMD' item 4; lab, same box: 1280-1285 -> 1302-1303 TFLOP/s; "lo" = waves 0-3 instead: 1268)

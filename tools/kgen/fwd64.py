@@ -8,10 +8,12 @@ Per 64-key tile t, both 32-query blocks qb of the wave (scores TRANSPOSED as in 
     C(t): O^T += V^T P^T                   32 MFMAs   (iterations v = (sb, m, dt); every V^T fragment feeds both query blocks)
 Pipeline: step t = [A(t+1) with B(t) in its MFMA gaps] ; [C(t) with the rest of B(t) and the maximum of tile t+1 in its gaps] ; re-reference decision for t+1.
 Two generations of S registers alternate.
-The score arithmetic is folded into the MFMAs: the Q fragments are multiplied by scale * log2(e) once per workgroup (fp32 multiply, one rounding to bf16) and
-every S accumulation chain STARTS from -m_ref (srcC = a 16-register block holding it), so the accumulators come out as  s * scale2 - m_ref  and p is one
-v_exp_f32 away: 3 VALU instructions per score (exp, row-sum add, half a bf16 pack, half a max3) instead of 4.2 — the difference between fitting the
-5-issues-per-MFMA-gap budget of a one-wave-per-SIMD stream and not fitting it.
+The reference subtraction is folded into the MFMAs: every S accumulation chain STARTS from -m_ref / scale2 (srcC = a 16-register block holding it), so the
+accumulators come out as  s - m_ref / scale2  and p = exp2(scale2 * acc): a multiply, an exponential, a row-sum add, half a pack and half a max3 per score.
+The scores stay the exact fp32 sums of bf16 products every other attention kernel forms (lse2 agrees with k_attn_fwd4's to fp32 rounding).  FWD64_EXACT=0
+builds the variant that also folds the scale into the Q fragments (multiplied by scale * log2(e) once per workgroup and re-rounded to bf16): one VALU less
+per score, 2688 instead of 2892 cycles per tile — but the scores then move by ~2^-9 |s|, i.e. lse2 moves against the scores the BACKWARD kernels form
+(1e-3 typical, 2e-2 on a spiked row: up to 1-4 % on that row's dominant P in dK / dV); not adopted.
 
 The running maximum is a REFERENCE m_ref that may go stale: exponentials are taken against m_ref as long as no score of the tile exceeds it by more than
 THR (log2 units; P then reaches 2^THR instead of 1 — same relative precision in bf16, numerator and denominator share the reference, lse2 = m_ref + log2(l)
@@ -64,7 +66,9 @@ S_M0, S_T0, S_T1, S_INCK, S_INCV = 49, 50, 51, 52, 53
 
 TRACE = bool(os.environ.get("FWD64_TRACE"))
 DBG = set(filter(None, os.environ.get("FWD64_DBG", "").split(",")))
-CAP = float(os.environ.get("FWD64_CAP", "5"))        # issues per MFMA gap besides the MFMA
+CAP = float(os.environ.get("FWD64_CAP", "6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5"))      # issues per MFMA gap besides the MFMA
+EXACT = os.environ.get("FWD64_EXACT", "1") != "0"    # scores as the exact fp32 sums of bf16 products (chains start from -m_ref / scale2, p = exp2(scale2 * acc));
+                                                     # "0": Q pre-multiplied by scale2 and re-rounded (one VALU less per score, scores move by ~2^-9 |s|)
 
 
 def k_request(u: int) -> list[str]:
@@ -133,7 +137,8 @@ def b_max(g: int, qb: int) -> list:
 
 def decide(g: int, qb: int, site: str) -> list[str]:
     """any lane whose tile maximum exceeds the reference by more than THR: re-reference in the out-of-line block (which returns to .Lback)"""
-    return [f"v_cmp_lt_f32_e32 vcc, {THR_BITS}, {vr(T[4 * qb])}", f"s_cbranch_vccnz .Lf64_resc_{site}_{qb}_%=", f".Lf64_back_{site}_{qb}_%=:"]
+    thr = "%[thr]" if EXACT else THR_BITS                  # EXACT: the accumulators are in raw-score units: THR / scale2
+    return [f"v_cmp_lt_f32_e32 vcc, {thr}, {vr(T[4 * qb])}", f"s_cbranch_vccnz .Lf64_resc_{site}_{qb}_%=", f".Lf64_back_{site}_{qb}_%=:"]
 
 
 def rescale_ops(g: int, qb: int, first: bool) -> list[str]:
@@ -143,7 +148,10 @@ def rescale_ops(g: int, qb: int, first: bool) -> list[str]:
     o = []
     if not first:
         o.append(f"v_max_f32_e32 {vr(t0)}, 0, {vr(t0)}")                  # lanes at or below their reference keep it
-        o.append(f"v_sub_f32_e32 {vr(t1)}, 0, {vr(t0)}")
+        if EXACT:
+            o.append(f"v_mul_f32_e64 {vr(t1)}, -{vr(t0)}, %[scale2]")     # the accumulators are in raw-score units
+        else:
+            o.append(f"v_sub_f32_e32 {vr(t1)}, 0, {vr(t0)}")
         o.append(f"v_exp_f32_e32 {vr(t1)}, {vr(t1)}")                     # alpha
     o.append(f"v_sub_f32_e32 {vr(NMB(qb))}, {vr(NMB(qb))}, {vr(t0)}")
     for r in range(1, 16):
@@ -175,6 +183,8 @@ def b_exp(g: int, sb: int, qb: int, m: int) -> list[str]:
     ops = []
     for h4 in (0, 4):
         q = rs[h4:h4 + 4]
+        if EXACT:
+            ops += [f"v_mul_f32_e32 {vr(r)}, %[scale2], {vr(r)}" for r in q]
         ops += [f"v_exp_f32_e32 {vr(r)}, {vr(r)}" for r in q]
         # two partial sums per query block break the dependent-add chain: L[qb] and T[8 + qb]
         ops += [f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[0])}", f"v_add_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(q[1])}",
@@ -213,10 +223,14 @@ def build() -> str:
     out_of_line: list[str] = []
     st.comment("---- prologue")
     o(f"s_mov_b32 s{S_M0}, m0")
-    # Q fragments -> v[128:191] -> * scale2 (fp32 multiply, one rounding to bf16) -> a[128:191]
-    for qb in range(2):
-        for ks in range(8):
-            o(f"global_load_dwordx4 {vr(128 + 4 * (8 * qb + ks), 4)}, %[qp{qb}], off offset:{32 * ks}")
+    if EXACT:
+        for qb in range(2):
+            for ks in range(8):
+                o(f"global_load_dwordx4 {QF(qb, ks)}, %[qp{qb}], off offset:{32 * ks}")
+    else:        # Q fragments -> v[128:191] -> * scale2 (fp32 multiply, one rounding to bf16) -> a[128:191]
+        for qb in range(2):
+            for ks in range(8):
+                o(f"global_load_dwordx4 {vr(128 + 4 * (8 * qb + ks), 4)}, %[qp{qb}], off offset:{32 * ks}")
     for i in range(128):
         o(f"v_accvgpr_write_b32 a{i}, 0")
     for qb in range(2):
@@ -224,15 +238,16 @@ def build() -> str:
             o(f"v_mov_b32_e32 {vr(NMB(qb) + r)}, 0")        # the reference is chosen after tile 0 (whose chains start from 0)
         o(f"v_mov_b32_e32 {vr(L[qb])}, 0")
         o(f"v_mov_b32_e32 {vr(T[8 + qb])}, 0")
-    o("s_waitcnt vmcnt(0)")
-    for i in range(64):
-        src, lo, hi = 128 + i, T[0], T[1]
-        o(f"v_lshlrev_b32_e32 {vr(lo)}, 16, {vr(src)}")
-        o(f"v_and_b32_e32 {vr(hi)}, 0xffff0000, {vr(src)}")
-        o(f"v_mul_f32_e32 {vr(lo)}, %[scale2], {vr(lo)}")
-        o(f"v_mul_f32_e32 {vr(hi)}, %[scale2], {vr(hi)}")
-        o(f"v_cvt_pk_bf16_f32 {vr(lo)}, {vr(lo)}, {vr(hi)}")
-        o(f"v_accvgpr_write_b32 a{128 + i}, {vr(lo)}")
+    if not EXACT:
+        o("s_waitcnt vmcnt(0)")
+        for i in range(64):
+            src, lo, hi = 128 + i, T[0], T[1]
+            o(f"v_lshlrev_b32_e32 {vr(lo)}, 16, {vr(src)}")
+            o(f"v_and_b32_e32 {vr(hi)}, 0xffff0000, {vr(src)}")
+            o(f"v_mul_f32_e32 {vr(lo)}, %[scale2], {vr(lo)}")
+            o(f"v_mul_f32_e32 {vr(hi)}, %[scale2], {vr(hi)}")
+            o(f"v_cvt_pk_bf16_f32 {vr(lo)}, {vr(lo)}, {vr(hi)}")
+            o(f"v_accvgpr_write_b32 a{128 + i}, {vr(lo)}")
     o(f"v_mov_b32_e32 {vr(KOF[0])}, %[koff]")
     o(f"v_mov_b32_e32 {vr(VOF[0])}, %[voff]")
     for p in range(1, 4):
@@ -369,7 +384,10 @@ def build() -> str:
         o(f"v_log_f32_e32 {vr(T[2])}, {vr(L[qb])}")
         o(f"v_rcp_f32_e32 {vr(T[3])}, {vr(L[qb])}")
         o("s_nop 0")
-        o(f"v_sub_f32_e32 {vr(T[4 + qb])}, {vr(T[2])}, {vr(NM[qb])}")      # lse2 = log2(l) + m_ref   -> output operand copy below
+        if EXACT:
+            o(f"v_fma_f32 {vr(T[4 + qb])}, -{vr(NM[qb])}, %[scale2], {vr(T[2])}")     # lse2 = log2(l) + m_ref,  m_ref = -NM * scale2
+        else:
+            o(f"v_sub_f32_e32 {vr(T[4 + qb])}, {vr(T[2])}, {vr(NM[qb])}")      # lse2 = log2(l) + m_ref   -> output operand copy below
         for dt in range(4):
             for a in range(4):
                 base = 16 * (4 * qb + dt) + 4 * a
