@@ -261,10 +261,19 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
 // stale-reference softmax and wait-state rules are documented there); HIP code computes the lane addresses in front of it and stores O / lse2 behind it
 // (O leaves through the idle LDS ring as whole 256-byte token rows).
 // ------------------------------------------------------------------------------------------------
+#define ST355_FWD64_OPERANDS                                                                                                                           \
+        : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)                                                                                                   \
+        : [qp0] "v"(qp0), [qp1] "v"(qp1), [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [vtb] "v"(vtb), [park] "v"(park), [kbase] "s"(kbase), \
+          [vbase] "s"(vbase), [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vrow32] "s"(vrow32), [scale2] "s"(scale2), [thr] "s"(thr), [blk0] "s"(blk0), \
+          [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)                                                                                            \
+        : "memory", "vcc", "scc",
+
+// HD = 128 (Flux) or 96 (PixArt-Sigma's head_dim 72, zero padded: 6 k-steps, 3 d tiles; the K tile image keeps the 256-byte row pitch, the V^T image holds 96 rows)
+template <int HD>
 __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt, bf16* __restrict__ O,
                                                        int64_t ld_o, float* __restrict__ lse2, int H, int Sq, int S, int Sp, float scale2,
                                                        unsigned long long* trace) {
-  constexpr int HD = 128;
+  static_assert(HD == 128 || HD == 96, "k_attn_fwd64: head_dim 128 or 96");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,7 +289,9 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
     const bf16* qp1 = Q + (bh * Sq + qi1) * (int64_t)HD + 8 * h;
     // LDS-DMA lane offsets of the wave's first K piece (rows 4 wave + lane / 16, chunk swizzle swz_kv) and first V^T piece (channel rows 8 wave + lane / 8)
     const int krow = wv * 4 + (lane >> 4);
-    const uint32_t koff = (uint32_t)(krow * HD + ((lane & 15) ^ swz_kv(krow)) * 8) * 2u;
+    int kchunk = (lane & 15) ^ swz_kv(krow);
+    if (kchunk >= HD / 8) kchunk = 0;                    // (head_dim 96: slots of source chunks >= 12 are never read; their lanes re-fetch chunk 0)
+    const uint32_t koff = (uint32_t)(krow * HD + kchunk * 8) * 2u;
     const int vrow = wv * 8 + (lane >> 3);
     const uint32_t voff = (uint32_t)(vrow * Sp + ((lane & 7) ^ ((vrow >> 1) & 7)) * 8) * 2u;
     const uint32_t vrow32 = (uint32_t)(32 * Sp * 2);
@@ -296,19 +307,23 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
     const uint32_t blk0 = blockIdx.x | blockIdx.y | blockIdx.z;
     const uint32_t tracelo = (uint32_t)(uintptr_t)trace, tracehi = (uint32_t)((uintptr_t)trace >> 32);
     const float thr = 8.0f / scale2;                    // the stale-reference bound (2^8 on the exponentials) in the accumulators' raw-score units
-    asm volatile(
+    if constexpr (HD == 128) {
+      asm volatile(
 #ifdef ST355_FWD64_BODY_INC       // tools/attn_lab builds: a generator variant under test
 #include ST355_FWD64_BODY_INC
 #else
 #include "gen/attn_fwd64_body.inc"
 #endif
-        : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
-        : [qp0] "v"(qp0), [qp1] "v"(qp1), [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [vtb] "v"(vtb), [park] "v"(park), [kbase] "s"(kbase),
-          [vbase] "s"(vbase), [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vrow32] "s"(vrow32), [scale2] "s"(scale2), [thr] "s"(thr), [blk0] "s"(blk0),
-          [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)
-        : "memory", "vcc", "scc",
+          ST355_FWD64_OPERANDS
 #include "gen/attn_fwd64_clobbers.inc"
-    );
+      );
+    } else {
+      asm volatile(
+#include "gen/attn_fwd64_hd96_body.inc"
+          ST355_FWD64_OPERANDS
+#include "gen/attn_fwd64_clobbers.inc"
+      );
+    }
   }
   const char* mine = smem + wv * 16384;
 #pragma unroll
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
 #pragma unroll
     for (int it = 0; it < 8; it++) {
       const int t = it * 4 + tl;
-      if (tok0 + t < Sq)
+      if (tok0 + t < Sq && c < HD / 8)
         *(bf16x8*)(O + ((int64_t)b * Sq + tok0 + t) * ld_o + (int64_t)head * HD + c * 8) = *(const bf16x8*)(mine + qb * 8192 + t * 256 + ((c ^ (t & 15)) << 4));
     }
     const int q = tok0 + l31;
@@ -348,13 +363,19 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // k_attn_fwd4 (r02) is the general kernel; k_attn_fwd64 (r04) takes the head_dim-128, no-bias, S % 64 == 0 shapes.  The r01 kernel lives on in
   // tools/attn_fwd_variants.hip as the lab's A/B baseline (r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s).  Measured and deleted in r02: an 8-wave /
   // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/r02_attn_lab_*.log.
-  if (!vrow && !key_bias && d == 128 && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
+  if (!vrow && !key_bias && (d == 128 || d == 96) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
     dim3 grid64((Sq + 255) / 256, H, B);
     const int lds64 = 4 * 2 * 64 * 256;
-    static bool set64 = false;
-    if (!set64) { hipFuncSetAttribute((const void*)k_attn_fwd64, hipFuncAttributeMaxDynamicSharedMemorySize, lds64); set64 = true; }
-    hipLaunchKernelGGL(k_attn_fwd64, grid64, dim3(256), lds64, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, ld_o, lse2, H, Sq, S, Sp,
-                       scale2, g_attn_fwd_trace);
+#define ST355_FWD64_LAUNCH(HD_)                                                                                                           \
+  do {                                                                                                                                   \
+    static bool set64 = false;                                                                                                           \
+    if (!set64) { hipFuncSetAttribute((const void*)k_attn_fwd64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64); set64 = true; } \
+    hipLaunchKernelGGL(k_attn_fwd64<HD_>, grid64, dim3(256), lds64, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, ld_o, lse2, \
+                       H, Sq, S, Sp, scale2, g_attn_fwd_trace);                                                                          \
+  } while (0)
+    if (d == 128) ST355_FWD64_LAUNCH(128);
+    else ST355_FWD64_LAUNCH(96);
+#undef ST355_FWD64_LAUNCH
     return st355_check_launch("attn_fwd64");
   }
   dim3 grid((Sq + QB - 1) / QB, H, B), block(ATT_THREADS);

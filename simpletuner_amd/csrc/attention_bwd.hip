@@ -771,11 +771,20 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv3(const bf16* __restrict
 // same fp32 sums as dkv3's (K and V only change sign); dK / dV differ from dkv3 by fp32 summation order only (bf16-rounding agreement, not bit for bit).  HIP code computes the lane
 // addresses in front of the statement and finishes behind it (dK through the fused RoPE + RMSNorm backward or as head-major rows, dV as token rows).
 // ------------------------------------------------------------------------------------------------
+#define ST355_DKV4_OPERANDS                                                                                                                            \
+        :                                                                                                                                          \
+        : [koffs] "v"(koffs), [voffs] "v"(voffs), [rowb] "v"(rowb), [trb] "v"(trb), [statb] "v"(statb), [drow] "v"(drow), [dcol] "v"(dcol),          \
+          [kbase] "s"(kbase), [vbase] "s"(vbase), [qbase] "s"(qbase), [gbase] "s"(gbase), [lbase] "s"(lbase), [dbase] "s"(dbase), [lds] "s"(lds), [wv] "s"(wvu), \
+          [nqt] "s"(nqt), [sq] "s"(sq), [stmax] "s"(stmax), [ldo2] "s"(ldo2), [q2] "s"(q2), [scale] "s"(scale), [nscale2] "s"(nscale2)                \
+        : "memory", "vcc", "scc",
+
+// HD = 128 (Flux) or 96 (PixArt-Sigma's head_dim 72, zero padded); the fused RoPE epilogue is head_dim 128 only
+template <int HD>
 __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                           const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lsep,
                                                           const float* __restrict__ delta, bf16* __restrict__ dK, bf16* __restrict__ dVrows, int64_t ld_dv,
                                                           int H, int Sq, int Sqp, int Sk, float scale, float scale2, RopeBwd rp) {
-  constexpr int HD = 128;
+  static_assert(HD == 128 || HD == 96, "k_attn_bwd_dkv4: head_dim 128 or 96");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -798,39 +807,45 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
     // LDS-DMA: piece = wave + 8 p, chunk idx = piece * 64 + lane: row = piece * 4 + lane / 16, LDS chunk position c holds source chunk c ^ f(row)
     const int drow_i = wv * 4 + (lane >> 4);
     const uint32_t drow = (uint32_t)drow_i;
-    const uint32_t dcol = (uint32_t)(((lane & 15) ^ swz_q(drow_i)) * 8) * 2u;
+    int dchunk = (lane & 15) ^ swz_q(drow_i);
+    if (dchunk >= HD / 8) dchunk = 0;                    // (head_dim 96: slots of source chunks >= 12 are never read; their lanes re-fetch chunk 0)
+    const uint32_t dcol = (uint32_t)(dchunk * 8) * 2u;
     const bf16* qbase = Q + bh * (int64_t)Sq * HD;
     const bf16* gbase = dO + (int64_t)b * Sq * ld_do + (int64_t)head * HD;
     const float* lbase = lsep + bh * (int64_t)Sqp;
     const float* dbase = delta + bh * (int64_t)Sqp;
-    const uint32_t nqt = (uint32_t)((Sq + 63) / 64), sq = (uint32_t)Sq, stmax = (uint32_t)(Sqp - 64), ldo2 = (uint32_t)(ld_do * 2);
+    const uint32_t nqt = (uint32_t)((Sq + 63) / 64), sq = (uint32_t)Sq, stmax = (uint32_t)(Sqp - 64), ldo2 = (uint32_t)(ld_do * 2), q2 = (uint32_t)(HD * 2);
     const uint32_t wvu = (uint32_t)wv;
     const float nscale2 = -scale2;
-    asm volatile(
+    if constexpr (HD == 128) {
+      asm volatile(
 #ifdef ST355_DKV4_BODY_INC        // tools/attn_lab builds: a generator variant under test
 #include ST355_DKV4_BODY_INC
 #else
 #include "gen/attn_dkv4_body.inc"
 #endif
-        :
-        : [koffs] "v"(koffs), [voffs] "v"(voffs), [rowb] "v"(rowb), [trb] "v"(trb), [statb] "v"(statb), [drow] "v"(drow), [dcol] "v"(dcol),
-          [kbase] "s"(kbase), [vbase] "s"(vbase), [qbase] "s"(qbase), [gbase] "s"(gbase), [lbase] "s"(lbase), [dbase] "s"(dbase), [lds] "s"(lds), [wv] "s"(wvu),
-          [nqt] "s"(nqt), [sq] "s"(sq), [stmax] "s"(stmax), [ldo2] "s"(ldo2), [scale] "s"(scale), [nscale2] "s"(nscale2)
-        : "memory", "vcc", "scc",
+          ST355_DKV4_OPERANDS
 #include "gen/attn_dkv4_clobbers.inc"
-    );
+      );
+    } else {
+      asm volatile(
+#include "gen/attn_dkv4_hd96_body.inc"
+          ST355_DKV4_OPERANDS
+#include "gen/attn_dkv4_clobbers.inc"
+      );
+    }
   }
   // every index below is re-derived: nothing needs to live across the statement above
   const char* mine = smem + wv * 16384;
   const int key0 = wg.tile * 256 + wv * 32;
-  if (rp.out != nullptr) {
-    rope_bwd_finish(rp, K + bh * (int64_t)Sk * HD, b, head, key0, Sk, lane, mine);
+  if (HD == 128 && rp.out != nullptr) {
+    if constexpr (HD == 128) rope_bwd_finish(rp, K + bh * (int64_t)Sk * HD, b, head, key0, Sk, lane, mine);
   } else {
     const int tl = lane >> 4, c = lane & 15;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
       const int t = it * 4 + tl;
-      if (key0 + t < Sk) *(bf16x8*)(dK + (bh * Sk + key0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + t * 256 + ((c ^ (t & 15)) << 4));
+      if (key0 + t < Sk && c < HD / 8) *(bf16x8*)(dK + (bh * Sk + key0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + t * 256 + ((c ^ (t & 15)) << 4));
     }
   }
   {
@@ -838,7 +853,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
 #pragma unroll
     for (int it = 0; it < 8; it++) {
       const int t = it * 4 + tl;
-      if (key0 + t < Sk)
+      if (key0 + t < Sk && c < HD / 8)
         *(bf16x8*)(dVrows + ((int64_t)b * Sk + key0 + t) * ld_dv + (int64_t)head * HD + c * 8) = *(const bf16x8*)(mine + 8192 + t * 256 + ((c ^ (t & 15)) << 4));
     }
   }
@@ -859,11 +874,22 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
 // Same arithmetic, same accumulation order as k_attn_bwd_dq<128, true, false>: results are bit-identical (tools/attn_lab checks).
 // Built for Sk % 64 == 0 and no key bias (the Flux / PixArt-2K self-attention shapes); everything else keeps k_attn_bwd_dq.
 // ------------------------------------------------------------------------------------------------
+#define ST355_DQ64_OPERANDS                                                                                                                            \
+        :                                                                                                                                          \
+        : [qp0] "v"(qp0), [qp1] "v"(qp1), [dp0] "v"(dp0), [dp1] "v"(dp1), [nlse0] "v"(nlse0), [nlse1] "v"(nlse1), [del0] "v"(del0), [del1] "v"(del1), \
+          [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [trb] "v"(trb), [park] "v"(park), [kbase] "s"(kbase), [vbase] "s"(vbase),           \
+          [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vstep] "s"(vstep), [vrow16] "s"(vrow16), [scale2] "s"(scale2), [scale] "s"(scale),   \
+          [blk0] "s"(blk0), [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)                                                                          \
+        : "memory", "vcc", "scc",
+
+// HD = 128 (Flux) or 96 (PixArt-Sigma's head_dim 72, zero padded: 6 k-steps, 3 d tiles; tile images keep the 256-byte row pitch, the DMA lanes of the unused
+// chunk slots fetch chunk 0 again); the fused RoPE epilogue is head_dim 128 only
+template <int HD>
 __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vrows, int64_t ld_v,
                                                           const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                           const float* __restrict__ delta, bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk,
                                                           float scale, float scale2, RopeBwd rp, unsigned long long* trace) {
-  constexpr int HD = 128;
+  static_assert(HD == 128 || HD == 96, "k_attn_bwd_dq64: head_dim 128 or 96");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -885,7 +911,9 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
     const float del0 = delta[bh * (int64_t)Sqp + qi0], del1 = delta[bh * (int64_t)Sqp + qi1];
     // LDS-DMA lane offsets of the wave's first piece (piece = wave + 4 p; chunk idx = piece * 64 + lane): LDS chunk position c of row r holds source chunk c ^ f(r)
     const int row = wv * 4 + (lane >> 4);
-    const int col = ((lane & 15) ^ swz_q(row)) * 8;
+    int chunk = (lane & 15) ^ swz_q(row);
+    if (chunk >= HD / 8) chunk = 0;                    // (head_dim 96: slots of source chunks >= 12 are never read; their lanes re-fetch chunk 0)
+    const int col = chunk * 8;
     const uint32_t koff = (uint32_t)(row * HD + col) * 2u;
     const uint32_t voff = (uint32_t)((int64_t)row * ld_v + col) * 2u;
     const uint32_t vrow16 = (uint32_t)(16 * ld_v * 2), vstep = (uint32_t)(64 * ld_v * 2);
@@ -899,34 +927,38 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
     const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t wvoff = (uint32_t)wv * 1024u;
     const uint32_t nkt = (uint32_t)(Sk / 64);
-    asm volatile(
+    if constexpr (HD == 128) {
+      asm volatile(
 #ifdef ST355_DQ64_BODY_INC       // tools/attn_lab builds: a generator variant under test
 #include ST355_DQ64_BODY_INC
 #else
 #include "gen/attn_dq64_body.inc"
 #endif
-        :
-        : [qp0] "v"(qp0), [qp1] "v"(qp1), [dp0] "v"(dp0), [dp1] "v"(dp1), [nlse0] "v"(nlse0), [nlse1] "v"(nlse1), [del0] "v"(del0), [del1] "v"(del1),
-          [koff] "v"(koff), [voff] "v"(voff), [rowb] "v"(rowb), [trb] "v"(trb), [park] "v"(park), [kbase] "s"(kbase), [vbase] "s"(vbase),
-          [lds] "s"(lds), [wvoff] "s"(wvoff), [nkt] "s"(nkt), [vstep] "s"(vstep), [vrow16] "s"(vrow16), [scale2] "s"(scale2), [scale] "s"(scale),
-          [blk0] "s"(blk0), [tracelo] "s"(tracelo), [tracehi] "s"(tracehi)
-        : "memory", "vcc", "scc",
+          ST355_DQ64_OPERANDS
 #include "gen/attn_dq64_clobbers.inc"
-    );
+      );
+    } else {
+      asm volatile(
+#include "gen/attn_dq64_hd96_body.inc"
+          ST355_DQ64_OPERANDS
+#include "gen/attn_dq64_clobbers.inc"
+      );
+    }
   }
   // every index below is re-derived: nothing needs to live across the statement above
   const char* mine = smem + wv * 16384;
 #pragma unroll
   for (int qb = 0; qb < 2; qb++) {
     const int tok0 = q0 + 32 * qb;
-    if (rp.out != nullptr) {
-      rope_bwd_finish(rp, Q + bh * (int64_t)Sq * HD, b, head, tok0, Sq, lane, mine + qb * 8192);
+    if (HD == 128 && rp.out != nullptr) {
+      if constexpr (HD == 128) rope_bwd_finish(rp, Q + bh * (int64_t)Sq * HD, b, head, tok0, Sq, lane, mine + qb * 8192);
     } else {
       const int tl = lane >> 4, c = lane & 15;
 #pragma unroll
       for (int it = 0; it < 8; it++) {
         const int t = it * 4 + tl;
-        if (tok0 + t < Sq) *(bf16x8*)(dQ + (bh * Sq + tok0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + qb * 8192 + t * 256 + ((c ^ (t & 15)) << 4));
+        if (tok0 + t < Sq && c < HD / 8)
+          *(bf16x8*)(dQ + (bh * Sq + tok0 + t) * (int64_t)HD + c * 8) = *(const bf16x8*)(mine + qb * 8192 + t * 256 + ((c ^ (t & 15)) << 4));
       }
     }
   }
@@ -983,7 +1015,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   const double fl_unit = 2.0 * (double)B * H * (double)S * Sk * d;  // one Sq x Sk x d contraction
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  const bool use_dkv4 = !Qt && d == 128 && !key_bias && attn_dkv_impl() == 4;
+  const bool use_dkv4 = !Qt && (d == 128 || d == 96) && !key_bias && attn_dkv_impl() == 4;
   {
     ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
     dim3 grid(Sp / 64, H, B);
@@ -1001,10 +1033,16 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     if (use_dkv4) {                                                    // hand-scheduled body (k_attn_bwd_dkv4)
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 8 * 16384;                                       // the two ring slots (66.5 KiB); 16 KiB per wave for the parked dK / dV rows
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv4, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_dkv4, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,
-                         (const float*)lsep, (const float*)delta, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);
+#define ST355_DKV4_LAUNCH(HD_)                                                                                                            \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv4<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    hipLaunchKernelGGL(k_attn_bwd_dkv4<HD_>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,  \
+                       (const float*)lsep, (const float*)delta, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);      \
+  } while (0)
+      if (d == 128) ST355_DKV4_LAUNCH(128);
+      else ST355_DKV4_LAUNCH(96);
+#undef ST355_DKV4_LAUNCH
     } else if (!Qt) {
       dim3 grid((Sk + 255) / 256, H, B);
       const int lds = 2 * (2 * 64 * 256 + 512);
@@ -1038,14 +1076,20 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
-  if (d == 128 && !Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
+  if ((d == 128 || d == 96) && !Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int lds = 3 * 2 * 64 * 256;
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-    hipLaunchKernelGGL(k_attn_bwd_dq64, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2,
-                       (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq, g_attn_dq_trace);
+#define ST355_DQ64_LAUNCH(HD_)                                                                                                            \
+  do {                                                                                                                                   \
+    static bool set = false;                                                                                                             \
+    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    hipLaunchKernelGGL(k_attn_bwd_dq64<HD_>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, \
+                       (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq, g_attn_dq_trace);                                \
+  } while (0)
+    if (d == 128) ST355_DQ64_LAUNCH(128);
+    else ST355_DQ64_LAUNCH(96);
+#undef ST355_DQ64_LAUNCH
     if ((rc = st355_check_launch("attn_bwd_dq64")) != 0) return rc;
   } else {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);

@@ -273,7 +273,7 @@ def test_sdxl_ddim_cfg_sampling_trajectory_matches_oracle_forward():
     with torch.no_grad():
         out = sample_images(pl, ehs, te, 16, 16, num_inference_steps=4, decode=False, guidance_scale=gs, negative_prompt_embeds=neg_e, negative_pooled=neg_te,
                             latents=sample.clone(), extra_batch={"added_cond_kwargs": {"time_ids": ti.to(dev)}})
-    sc = DDIMScheduler()
+    sc = DDIMScheduler(timestep_spacing="trailing")      # validation.py:2889-2892: the trainer default the sampler now reads
     sc.set_timesteps(4)
     x = sample.float()
     e2, t2, i2 = torch.cat([neg_e.float(), ehs.float()]), torch.cat([neg_te.float(), te.float()]), torch.cat([ti.float(), ti.float()])

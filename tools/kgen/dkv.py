@@ -38,10 +38,13 @@ STAT = 0                   # slot layout [lse 64 f32 | delta 64 f32 | Q image | 
 QOFF = 512
 GOFF = 512 + QT
 BUF = 2 * QT + 512         # one slot
+HD = int(os.environ.get("DKV_HD", "128"))        # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded); tile images keep the 256-byte row pitch
+assert HD in (96, 128)
+NKS, NDT = HD // 16, HD // 32
 
 
 def DK(dt): return ar(16 * dt, 16)
-def DV(dt): return ar(64 + 16 * dt, 16)
+def DV(dt): return ar(16 * NDT + 16 * dt, 16)
 def KFR(ks): return vr(32 + 4 * ks, 4)
 def VFR(ks): return vr(64 + 4 * ks, 4)
 SACC, DPACC = 96, 112
@@ -97,9 +100,9 @@ def stat_request(slot: int, qb: int) -> list[str]:
 def a_groups(slot: int, qb: int, tail: list[list[str]]) -> list[list[str]]:
     """16 MFMAs: S += Q_frag x K'(ks), dP += dO_frag x V'(ks), alternating.  Group i waits for fragment i and requests i + 2; the last two carry tail[0 / 1]."""
     groups = []
-    for i in range(16):
+    for i in range(2 * NKS):
         ks, which = i >> 1, i & 1
-        head = [f"@wait:R{i}"] + (row_request(i + 2, slot, qb) if i < 14 else tail[i - 14])
+        head = [f"@wait:R{i}"] + (row_request(i + 2, slot, qb) if i < 2 * NKS - 2 else tail[i - (2 * NKS - 2)])
         if i == 0:
             head = ["@wait:ST"] + head
         acc = DPACC if which else SACC
@@ -127,9 +130,9 @@ def b_ops() -> list[str]:
 def c_groups(slot: int, qb: int, tail: list[list[str]]) -> list[list[str]]:
     """16 MFMAs: dV^T(dt) += dO^T_frag x P(m), dK^T(dt) += Q^T_frag x dS(m).  Group i waits for fragment i and requests i + 2; the last two carry tail."""
     groups = []
-    for i in range(16):
+    for i in range(4 * NDT):
         dt, m, which = i >> 2, (i >> 1) & 1, i & 1
-        head = [f"@wait:C{i}"] + (tr_request(i + 2, slot, qb) if i < 14 else tail[i - 14])
+        head = [f"@wait:C{i}"] + (tr_request(i + 2, slot, qb) if i < 4 * NDT - 2 else tail[i - (4 * NDT - 2)])
         if which == 0:
             groups.append(head + [f"{MFMA} {DV(dt)}, {vr(RING(i), 4)}, {vr(SACC + 4 * m, 4)}, {DV(dt)}"])
         else:
@@ -145,7 +148,7 @@ def stage_ops(slot: int) -> list:
         t0, t1 = T[0], T[1]
         src = f"s{S_QQ0}" if p == 0 else f"s{S_T2}"           # S_T2 = S_QQ0 + 32: the wave's second piece starts 32 rows further down
         ch.append(([f"s_add_u32 s{S_T2}, s{S_QQ0}, 32"] if p else []) + [f"v_add_u32_e32 {vr(t0)}, {src}, %[drow]", f"v_min_u32_e32 {vr(t0)}, s{S_SQ1}, {vr(t0)}"])
-        ch.append([f"v_lshl_add_u32 {vr(t1)}, {vr(t0)}, 8, %[dcol]",
+        ch.append([f"v_mad_u32_u24 {vr(t1)}, {vr(t0)}, %[q2], %[dcol]",            # Q rows are head_dim * 2 bytes apart
                    f"s_add_u32 m0, s{S_T0}, {slot * BUF + QOFF + p * 8192}", "s_nop 0", f"global_load_lds_dwordx4 {vr(t1)}, s[{S_QP}:{S_QP + 1}]"])
         ch.append([f"v_mad_u32_u24 {vr(t1)}, {vr(t0)}, %[ldo2], %[dcol]",
                    f"s_add_u32 m0, s{S_T0}, {slot * BUF + GOFF + p * 8192}", "s_nop 0", f"global_load_lds_dwordx4 {vr(t1)}, s[{S_GP}:{S_GP + 1}]"])
@@ -171,10 +174,10 @@ def build() -> str:
     o = st.op
     st.comment("---- prologue: K' = -K, V' = -V fragments; zero accumulators; stage tile 0")
     o(f"s_mov_b32 s{S_M0}, m0")
-    for ks in range(8):
+    for ks in range(NKS):
         o(f"global_load_dwordx4 {KFR(ks)}, %[koffs], %[kbase] offset:{32 * ks}")
         o(f"global_load_dwordx4 {VFR(ks)}, %[voffs], %[vbase] offset:{32 * ks}")
-    for i in range(128):
+    for i in range(32 * NDT):
         o(f"v_accvgpr_write_b32 a{i}, 0")
     o(f"s_mov_b64 s[{S_QP}:{S_QP + 1}], %[qbase]")
     o(f"s_mov_b64 s[{S_GP}:{S_GP + 1}], %[gbase]")
@@ -189,7 +192,7 @@ def build() -> str:
         st.extend(chn)
     st.extend(stat_stage(0))
     o("s_waitcnt vmcnt(0)")
-    for r in range(32, 96):
+    for r in list(range(32, 32 + 4 * NKS)) + list(range(64, 64 + 4 * NKS)):
         o(f"v_xor_b32_e32 {vr(r)}, 0x80008000, {vr(r)}")       # K' = -K, V' = -V (both bf16 halves of every register)
     o(f"s_mov_b32 s{S_CNT}, %[nqt]")
     # static priority for the second-dispatched half of the workgroup (waves 4-7): it is the arbitration loser of every SIMD pair otherwise
@@ -214,7 +217,7 @@ def build() -> str:
         b = b_ops()
         # A | 12 states for the MFMA results | B | C.  B cannot ride in this wave's own A or C gaps (it needs A's results, C needs its results): the partner
         # wave's MFMAs cover it.  Fillers (LDS-DMA of the next tile) ride in A's and C's gaps.
-        segs = [(fill, 0, 15)] if fill else []
+        segs = [(fill, 0, 2 * NKS - 1)] if fill else []
         st.extend(weave_budget(ag, segs, CAP) if segs else [x for g in ag for x in g])
         o("s_nop 11")
         st.extend(b)
@@ -283,9 +286,9 @@ def build() -> str:
     o(f"v_lshl_add_u32 {vr(T[0])}, {vr(T[1])}, 4, {vr(T[0])}")             # + (l31 & 15) << 4
     o(f"v_add_u32_e32 {vr(T[0])}, s{S_T1}, {vr(T[0])}")
     for which in range(2):
-        for dt in range(4):
+        for dt in range(NDT):
             for a in range(4):
-                base = 64 * which + 16 * dt + 4 * a
+                base = 16 * NDT * which + 16 * dt + 4 * a
                 t = 96 + 4 * ((4 * dt + a) & 3)
                 for bb in range(4):
                     o(f"v_accvgpr_read_b32 {vr(t + bb)}, a{base + bb}")
@@ -308,13 +311,14 @@ def build() -> str:
 
 
 def main() -> None:
-    out = os.environ.get("DKV_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", "attn_dkv4_body.inc")
+    name = "attn_dkv4_body.inc" if HD == 128 else f"attn_dkv4_hd{HD}_body.inc"
+    out = os.environ.get("DKV_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     body = build()
     with open(out, "w") as f:
         f.write("// GENERATED by tools/kgen/dkv.py — do not edit; regenerate with  python -m tools.kgen.dkv\n")
         f.write(body)
-    if not os.environ.get("DKV_OUT"):
+    if not os.environ.get("DKV_OUT") and HD == 128:
         regs = [f'"v{i}"' for i in range(10, 128)] + [f'"a{i}"' for i in range(128)] + [f'"s{i}"' for i in range(40, 76)]
         with open(os.path.join(os.path.dirname(out), "attn_dkv4_clobbers.inc"), "w") as f:
             f.write("// GENERATED by tools/kgen/dkv.py — the registers the dkv4 body owns\n")

@@ -29,13 +29,17 @@ import sys
 from .emit import Stream, ar, check_hazards, resolve_lgkm, vr, weave, weave_budget
 
 MFMA = "v_mfma_f32_32x32x16_bf16"
-TILE = 16384           # one tile image
+TILE = 16384           # one tile image (256-byte row pitch at every head_dim: narrower heads leave chunk slots unused, as in k_attn_bwd_dq<., TR>)
 SLOT = 2 * TILE
+HD = int(os.environ.get("DQ64_HD", "128"))       # head_dim: 128 (Flux), 96 (PixArt's 72, zero padded), 64 (SD3)
+assert HD in (64, 96, 128)
+NKS, NDT = HD // 16, HD // 32                     # MFMA k-steps over the head dim, 32-row d tiles of dQ^T
+NACC = 2 * NDT * 16                               # dQ^T accumulator registers; Q fragments follow, then dO fragments
 
 
-def ACC(qb, dt): return ar(16 * (4 * qb + dt), 16)
-def QF(qb, ks): return ar(128 + 4 * (8 * qb + ks), 4)
-def DOF(qb, ks): return ar(192 + 4 * (8 * qb + ks), 4)
+def ACC(qb, dt): return ar(16 * (NDT * qb + dt), 16)
+def QF(qb, ks): return ar(NACC + 4 * (NKS * qb + ks), 4)
+def DOF(qb, ks): return ar(NACC + 8 * NKS + 4 * (NKS * qb + ks), 4)
 def S(g, qb): return 64 + 64 * g + 16 * qb
 def P(g, qb): return 96 + 64 * g + 16 * qb
 def DSF(qb, m): return 192 + 4 * (2 * qb + m)
@@ -48,7 +52,7 @@ V_ROWN, V_RA = 56, 57                                             # scratch (par
 ROWA = [32 + k for k in range(8)]                                 # (slot + lane row base) ^ (ks << 5): K / V row fragments of k-step ks
 TRX = [0x00, 0x10, 0x40, 0x50, 0x80, 0x90, 0xc0, 0xd0]            # chunk XORs of the transposed reads: (4 dt) << 4 and ((4 dt) ^ 1) << 4
 TRA = [40 + k for k in range(8)]                                  # (slot + lane tr base) ^ TRX[j]
-CAP = float(os.environ.get("DQ64_CAP", "5"))                        # issues per MFMA gap besides the MFMA
+CAP = float(os.environ.get("DQ64_CAP", "5" if int(os.environ.get("DQ64_HD", "128")) == 128 else "6"))    # issues per MFMA gap besides the MFMA (narrower heads: the same VALU per score under fewer MFMAs)
 # SGPRs
 S_KP, S_VP = 40, 42          # global pointers of the tile to stage next (64-bit), always a valid tile
 S_CNT = 44                   # main-loop trips left
@@ -66,17 +70,17 @@ def a_request(ks: int, sb: int) -> list[str]:
 
 
 def rowa_update(slot_sgpr: int) -> list[str]:
-    return [f"v_add_u32_e32 {vr(ROWA[0])}, s{slot_sgpr}, %[rowb]"] + [f"v_xor_b32_e32 {vr(ROWA[k])}, {hex(k << 5)}, {vr(ROWA[0])}" for k in range(1, 8)]
+    return [f"v_add_u32_e32 {vr(ROWA[0])}, s{slot_sgpr}, %[rowb]"] + [f"v_xor_b32_e32 {vr(ROWA[k])}, {hex(k << 5)}, {vr(ROWA[0])}" for k in range(1, NKS)]
 
 
 def tra_update(slot_sgpr: int) -> list[str]:
-    return [f"v_add_u32_e32 {vr(TRA[0])}, s{slot_sgpr}, %[trb]"] + [f"v_xor_b32_e32 {vr(TRA[j])}, {hex(TRX[j])}, {vr(TRA[0])}" for j in range(1, 8)]
+    return [f"v_add_u32_e32 {vr(TRA[0])}, s{slot_sgpr}, %[trb]"] + [f"v_xor_b32_e32 {vr(TRA[j])}, {hex(TRX[j])}, {vr(TRA[0])}" for j in range(1, 2 * NDT)]
 
 
 def c_request(i: int, sb: int) -> list[str]:
     """request the K^T fragment of C iteration i (m = i >> 2, dt = i & 3: every accumulator still sees m = 0 before m = 1): two transposing reads
     from the C block's tile (addresses in TRA)"""
-    dt, m = i & 3, i >> 2
+    dt, m = i % NDT, i // NDT
     t = TF(i)
     return [f"ds_read_b64_tr_b16 {vr(t, 2)}, {vr(TRA[2 * dt])} offset:{sb * 8192 + 16 * m * 256} ;@ld:C{i}",
             f"ds_read_b64_tr_b16 {vr(t + 2, 2)}, {vr(TRA[2 * dt + 1])} offset:{sb * 8192 + (16 * m + 4) * 256} ;@ld:C{i}"]
@@ -86,9 +90,9 @@ def a_groups(g_new: int, sb: int, tail_requests: list[list[str]]) -> list[list[s
     """A of one 32-key block into generation g_new: 8 k-steps x 4 MFMAs.  Group ks waits for fragment ks and requests fragment ks + 2;
     k-steps 6 and 7 carry tail_requests[0 / 1] instead (the first two fragments of the C that follows)."""
     groups: list[list[str]] = []
-    for ks in range(8):
+    for ks in range(NKS):
         head = [f"@wait:A{ks}"]
-        head += a_request(ks + 2, sb) if ks < 6 else tail_requests[ks - 6]
+        head += a_request(ks + 2, sb) if ks < NKS - 2 else tail_requests[ks - (NKS - 2)]
         c = (lambda r: "0") if ks == 0 else (lambda r: r)
         groups.append(head + [f"{MFMA} {vr(S(g_new, 0), 16)}, {KF(ks)}, {QF(0, ks)}, {c(vr(S(g_new, 0), 16))}"])
         groups.append([f"{MFMA} {vr(P(g_new, 0), 16)}, {VF(ks)}, {DOF(0, ks)}, {c(vr(P(g_new, 0), 16))}"])
@@ -123,10 +127,10 @@ def c_groups(sb: int, tail_requests: list[list[str]], extra_at: dict[int, list[s
     tail_requests[0 / 1] (the first two fragments of the next A block).  extra_at[i]: lines placed in front of the request of iteration i."""
     extra_at = extra_at or {}
     groups: list[list[str]] = []
-    for i in range(8):
-        dt, m = i & 3, i >> 2
+    for i in range(2 * NDT):
+        dt, m = i % NDT, i // NDT
         head = [f"@wait:C{i}"] + extra_at.get(i, [])
-        head += c_request(i + 2, sb) if i < 6 else tail_requests[i - 6]
+        head += c_request(i + 2, sb) if i < 2 * NDT - 2 else tail_requests[i - (2 * NDT - 2)]
         t = vr(TF(i), 4)
         groups.append(head + [f"{MFMA} {ACC(0, dt)}, {t}, {vr(DSF(0, m), 4)}, {ACC(0, dt)}"])
         groups.append([f"{MFMA} {ACC(1, dt)}, {t}, {vr(DSF(1, m), 4)}, {ACC(1, dt)}"])
@@ -167,16 +171,16 @@ def build(b_in_a: int = 144) -> str:
     if TRACE:
         o("s_memtime s[74:75]")
     for qb in range(2):
-        for ks in range(8):
+        for ks in range(NKS):
             o(f"global_load_dwordx4 {QF(qb, ks)}, %[qp{qb}], off offset:{32 * ks}")
             o(f"global_load_dwordx4 {DOF(qb, ks)}, %[dp{qb}], off offset:{32 * ks}")
-    for i in range(128):
+    for i in range(NACC):
         o(f"v_accvgpr_write_b32 a{i}, 0")
-    # lane offsets of the DMA pieces: piece p of this wave starts 16 rows (K: 4096 B, V: 16 * ld_v * 2 B = %[vrow16]) after piece p - 1
+    # lane offsets of the DMA pieces: piece p of this wave starts 16 rows (K: 16 * head_dim * 2 B, V: 16 * ld_v * 2 B = %[vrow16]) after piece p - 1
     o(f"v_mov_b32_e32 {vr(KOF[0])}, %[koff]")
     o(f"v_mov_b32_e32 {vr(VOF[0])}, %[voff]")
     for p in range(1, 4):
-        o(f"v_add_u32_e32 {vr(KOF[p])}, {p * 4096}, {vr(KOF[0])}")
+        o(f"v_add_u32_e32 {vr(KOF[p])}, {p * 16 * HD * 2}, {vr(KOF[0])}")
         o(f"v_add_u32_e32 {vr(VOF[p])}, %[vrow16], {vr(VOF[p - 1])}")
     o(f"s_mov_b64 s[{S_KP}:{S_KP + 1}], %[kbase]")
     o(f"s_mov_b64 s[{S_VP}:{S_VP + 1}], %[vbase]")
@@ -191,14 +195,14 @@ def build(b_in_a: int = 144) -> str:
         st.extend(pc)
     o("s_cmp_lt_u32 %[nkt], 2")
     o("s_cbranch_scc1 .Ldq64_one_tile_%=")
-    st.extend(stage_advance(str(64 * 256), "%[vstep]"))
+    st.extend(stage_advance(str(64 * HD * 2), "%[vstep]"))
     o(f"s_mov_b32 s{S_STG}, s{S_NXT}")
     st.extend(stage_begin())
     for pc in stage_pieces():
         st.extend(pc)
     o("s_cmp_lt_u32 %[nkt], 3")
     o("s_cbranch_scc1 .Ldq64_one_tile_%=")
-    st.extend(stage_advance(str(64 * 256), "%[vstep]"))
+    st.extend(stage_advance(str(64 * HD * 2), "%[vstep]"))
     o(".Ldq64_one_tile_%=:")
     o(f"s_mov_b32 s{S_STG}, s{S_T1}")
     o(f"s_sub_u32 s{S_CNT}, %[nkt], 1")                      # main-loop trips: tiles 0 .. nkt-2 (the last tile is peeled)
@@ -253,9 +257,9 @@ def build(b_in_a: int = 144) -> str:
             for k, ch in enumerate(chunks):
                 segs.append(([ch], k * stride, min(k * stride + stride - 1, len(groups) - 1)))
         if early:
-            segs.append((early, 0, na - 9))
+            segs.append((early, 0, max(0, na - 9)))
         segs.append((b[:half], 0, na - 1))                # DSF(., 0): before C's first MFMA (its head's wait + reads keep the two states to the MFMA)
-        segs.append((b[half:], 0, na + 7))                # DSF(., 1): before C's iteration 4 (group na + 8)
+        segs.append((b[half:], 0, na + 2 * NDT - 1))      # DSF(., 1): before C's iteration NDT (group na + 2 NDT)
         if mid:
             segs.append((mid, mid_window[0], mid_window[1]))
         if late:
@@ -278,12 +282,13 @@ def build(b_in_a: int = 144) -> str:
     stamp(0)
     barrier = [] if "nobarrier" in DBG else ["s_waitcnt vmcnt(0)", "s_barrier"]
     # ROWA still serves A(kt, 1)'s requests up to A's group 20 (k-step 5 requests k-step 7); C's iteration 6 (group 44) requests from the next tile
-    step(0, 0, 1, 0, {5: barrier}, early=None, mid=rowa_update(S_NXT), mid_window=(21, 42), mid_stamp=1)
+    # ROWA serves A(kt, 1)'s requests up to k-step NKS - 3 (which requests the last fragment): group 4 (NKS - 3); C's iteration 2 NDT - 2 requests from the next tile
+    step(0, 0, 1, 0, {2 * NDT - 3: barrier}, early=None, mid=rowa_update(S_NXT), mid_window=(4 * (NKS - 3) + 1, 4 * NKS + 2 * (2 * NDT - 2) - 2), mid_stamp=1)
     stamp(2)
     st.comment("step 2: A(kt+1, 0) -> gen 0 | B(gen 1) ; C(kt, 1) with the LDS-DMA of tile min(kt+2, nkt-1) in its last gaps; then the first fragments of A(kt+1, 1)")
     # pointer increments for after this stage: advance only while another tile exists (trips left >= 3  <=>  kt + 3 <= nkt - 1)
     o(f"s_cmp_ge_u32 s{S_CNT}, 3")
-    o(f"s_cselect_b32 s{S_INCK}, {64 * 256}, 0")
+    o(f"s_cselect_b32 s{S_INCK}, {64 * HD * 2}, 0")
     o(f"s_cselect_b32 s{S_INCV}, %[vstep], 0")
     pcs = stage_pieces()
     dma = [] if "nostage" in DBG else [stage_begin() + pcs[0]] + pcs[1:]
@@ -291,7 +296,7 @@ def build(b_in_a: int = 144) -> str:
         stride = int(os.environ["DQ64_DMA_IN_A"])
         step(1, 1, 0, 1, None, early=None, mid=None, mid_stamp=3, spread=(dma, stride))
     else:
-        step(1, 1, 0, 1, None, late=dma, late_from=int(os.environ.get("DQ64_DMA_FROM", "4")), mid_stamp=3)
+        step(1, 1, 0, 1, None, late=dma, late_from=int(os.environ.get("DQ64_DMA_FROM", str(min(4, 2 * NDT - 2)))), mid_stamp=3)
     stamp(4)
     st.extend(stage_advance(f"s{S_INCK}", f"s{S_INCV}"))
     st.extend(rotate_slots())
@@ -315,9 +320,9 @@ def build(b_in_a: int = 144) -> str:
     o(f"s_add_u32 s{S_T0}, s{S_T0}, %[lds]")
     o(f"v_add_u32_e32 {vr(V_ROWN)}, s{S_T0}, %[park]")
     for qb in range(2):
-        for dt in range(4):
+        for dt in range(NDT):
             for a in range(4):
-                base = 16 * (4 * qb + dt) + 4 * a
+                base = 16 * (NDT * qb + dt) + 4 * a
                 t = 64 + 4 * ((4 * dt + a) & 3)       # rotate through 4 temp quads
                 for bb in range(4):
                     o(f"v_accvgpr_read_b32 {vr(t + bb)}, a{base + bb}")
@@ -359,14 +364,15 @@ def build(b_in_a: int = 144) -> str:
 
 
 def main() -> None:
-    out = os.environ.get("DQ64_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", "attn_dq64_body.inc")
+    name = "attn_dq64_body.inc" if HD == 128 else f"attn_dq64_hd{HD}_body.inc"
+    out = os.environ.get("DQ64_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     b_in_a = int(os.environ.get("DQ64_B_IN_A", "144"))
     body = build(b_in_a)
     with open(out, "w") as f:
         f.write("// GENERATED by tools/kgen/dq64.py — do not edit; regenerate with  python -m tools.kgen.dq64\n")
         f.write(body)
-    if not os.environ.get("DQ64_OUT"):
+    if not os.environ.get("DQ64_OUT") and HD == 128:
         regs = [f'"v{i}"' for i in range(32, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 84)]
         with open(os.path.join(os.path.dirname(out), "attn_dq64_clobbers.inc"), "w") as f:
             f.write("// GENERATED by tools/kgen/dq64.py — the registers the dq64 body owns\n")

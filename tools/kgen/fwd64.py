@@ -42,10 +42,14 @@ TILE = 16384
 SLOT = 2 * TILE
 NSLOT = 4
 THR_BITS = "0x41000000"     # 8.0f
+HD = int(os.environ.get("FWD64_HD", "128"))      # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded)
+assert HD in (96, 128)
+NKS, NDT = HD // 16, HD // 32                     # MFMA k-steps over the head dim; 32-row d tiles of O^T
+NU, NV = 2 * NKS, 4 * NDT                         # K fragments (A groups) and V^T fragments (C iterations) per 64-key tile
 
 
-def OACC(qb, dt): return ar(16 * (4 * qb + dt), 16)
-def QF(qb, ks): return ar(128 + 4 * (8 * qb + ks), 4)
+def OACC(qb, dt): return ar(16 * (NDT * qb + dt), 16)
+def QF(qb, ks): return ar(128 + 4 * (NKS * qb + ks), 4)
 def S(g, sb, qb): return 64 + 64 * g + 32 * sb + 16 * qb
 def PF(sb, qb, m): return 192 + 4 * (4 * sb + 2 * qb + m)
 def KF(i): return ar(192 + 4 * (i % 3), 4)
@@ -66,25 +70,25 @@ S_M0, S_T0, S_T1, S_INCK, S_INCV = 49, 50, 51, 52, 53
 
 TRACE = bool(os.environ.get("FWD64_TRACE"))
 DBG = set(filter(None, os.environ.get("FWD64_DBG", "").split(",")))
-CAP = float(os.environ.get("FWD64_CAP", "6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5"))      # issues per MFMA gap besides the MFMA
+CAP = float(os.environ.get("FWD64_CAP", ("6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5") if int(os.environ.get("FWD64_HD", "128")) == 128 else "7"))      # issues per MFMA gap besides the MFMA
 EXACT = os.environ.get("FWD64_EXACT", "1") != "0"    # scores as the exact fp32 sums of bf16 products (chains start from -m_ref / scale2, p = exp2(scale2 * acc));
                                                      # "0": Q pre-multiplied by scale2 and re-rounded (one VALU less per score, scores move by ~2^-9 |s|)
 
 
 def k_request(u: int) -> list[str]:
     """K row fragment u = 8 sb + ks of the A tile (addresses in ROWA) into buffer u % 3"""
-    sb, ks = u >> 3, u & 7
+    sb, ks = divmod(u, NKS)
     return [f"ds_read_b128 {KF(u)}, {vr(ROWA[ks])} offset:{sb * 8192} ;@ld:K{u}"]
 
 
 def v_request(v: int) -> list[str]:
     """V^T fragment v = 8 sb + 4 m + dt of the C tile (addresses in VTA) into buffer v % 3"""
-    sb, m, dt = v >> 3, (v >> 2) & 1, v & 3
+    sb, m, dt = v // (2 * NDT), (v // NDT) & 1, v % NDT
     return [f"ds_read_b128 {VF(v)}, {vr(VTA[2 * sb + m])} offset:{TILE + dt * 4096} ;@ld:V{v}"]
 
 
 def rowa_update(slot_sgpr: int) -> list[str]:
-    return [f"v_add_u32_e32 {vr(ROWA[0])}, s{slot_sgpr}, %[rowb]"] + [f"v_xor_b32_e32 {vr(ROWA[k])}, {hex(k << 5)}, {vr(ROWA[0])}" for k in range(1, 8)]
+    return [f"v_add_u32_e32 {vr(ROWA[0])}, s{slot_sgpr}, %[rowb]"] + [f"v_xor_b32_e32 {vr(ROWA[k])}, {hex(k << 5)}, {vr(ROWA[0])}" for k in range(1, NKS)]
 
 
 def vta_update(slot_sgpr: int) -> list[str]:
@@ -96,9 +100,9 @@ def a_groups(g_new: int, tail: list[list[str]], from_zero: bool = False) -> list
     """A: 16 fragments u x 2 MFMAs.  Group u waits for fragment u and requests u + 2; u = 14, 15 carry tail[0 / 1] (C's first two fragments).
     Every accumulation chain starts from -m_ref (srcC = NMB(qb)); from_zero: the prologue's tile 0, whose reference is chosen afterwards."""
     groups = []
-    for u in range(16):
-        sb, ks = u >> 3, u & 7
-        head = [f"@wait:K{u}"] + (k_request(u + 2) if u < 14 else tail[u - 14])
+    for u in range(NU):
+        sb, ks = divmod(u, NKS)
+        head = [f"@wait:K{u}"] + (k_request(u + 2) if u < NU - 2 else tail[u - (NU - 2)])
         c = (lambda r, qb: ("0" if from_zero else vr(NMB(qb), 16))) if ks == 0 else (lambda r, qb: r)
         groups.append(head + [f"{MFMA} {vr(S(g_new, sb, 0), 16)}, {KF(u)}, {QF(0, ks)}, {c(vr(S(g_new, sb, 0), 16), 0)}"])
         groups.append([f"{MFMA} {vr(S(g_new, sb, 1), 16)}, {KF(u)}, {QF(1, ks)}, {c(vr(S(g_new, sb, 1), 16), 1)}"])
@@ -110,9 +114,9 @@ def c_groups(tail: list[list[str]], extra_at: dict[int, list[str]] | None = None
     (the next A's first two K fragments).  extra_at[v]: lines in front of iteration v's request."""
     extra_at = extra_at or {}
     groups = []
-    for v in range(16):
-        sb, m, dt = v >> 3, (v >> 2) & 1, v & 3
-        head = [f"@wait:V{v}"] + extra_at.get(v, []) + (v_request(v + 2) if v < 14 else tail[v - 14])
+    for v in range(NV):
+        sb, m, dt = v // (2 * NDT), (v // NDT) & 1, v % NDT
+        head = [f"@wait:V{v}"] + extra_at.get(v, []) + (v_request(v + 2) if v < NV - 2 else tail[v - (NV - 2)])
         groups.append(head + [f"{MFMA} {OACC(0, dt)}, {VF(v)}, {vr(PF(sb, 0, m), 4)}, {OACC(0, dt)}"])
         groups.append([f"{MFMA} {OACC(1, dt)}, {VF(v)}, {vr(PF(sb, 1, m), 4)}, {OACC(1, dt)}"])
     return groups
@@ -164,8 +168,8 @@ def rescale_ops(g: int, qb: int, first: bool) -> list[str]:
         o.append(f"v_mul_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(t1)}")       # the second partial row sum lives at the old reference too
         o.append("s_nop 15")                                             # the last MFMAs of C own the O accumulators
         o.append("s_nop 15")
-        for r in range(64):
-            a = 64 * qb + r
+        for r in range(16 * NDT):
+            a = 16 * NDT * qb + r
             o.append(f"v_accvgpr_read_b32 {vr(t3)}, a{a}")
             o.append(f"v_mul_f32_e32 {vr(t3)}, {vr(t3)}, {vr(t1)}")
             o.append(f"v_accvgpr_write_b32 a{a}, {vr(t3)}")
@@ -197,7 +201,7 @@ def stage_pieces() -> list[list[str]]:
     pcs = []
     for p in range(4):
         pcs.append([f"s_add_u32 m0, s{S_T0}, {p * 4096}", "s_nop 0", f"global_load_lds_dwordx4 {vr(KOF[p])}, s[{S_KP}:{S_KP + 1}]"])
-    for p in range(4):
+    for p in range(NDT):       # the V^T image holds head_dim rows of 128 bytes: head_dim / 8 pieces, head_dim / 32 per wave
         pcs.append([f"s_add_u32 m0, s{S_T0}, {p * 4096 + TILE}", "s_nop 0", f"global_load_lds_dwordx4 {vr(VOF[p])}, s[{S_VP}:{S_VP + 1}]"])
     return pcs
 
@@ -225,13 +229,13 @@ def build() -> str:
     o(f"s_mov_b32 s{S_M0}, m0")
     if EXACT:
         for qb in range(2):
-            for ks in range(8):
+            for ks in range(NKS):
                 o(f"global_load_dwordx4 {QF(qb, ks)}, %[qp{qb}], off offset:{32 * ks}")
     else:        # Q fragments -> v[128:191] -> * scale2 (fp32 multiply, one rounding to bf16) -> a[128:191]
         for qb in range(2):
-            for ks in range(8):
-                o(f"global_load_dwordx4 {vr(128 + 4 * (8 * qb + ks), 4)}, %[qp{qb}], off offset:{32 * ks}")
-    for i in range(128):
+            for ks in range(NKS):
+                o(f"global_load_dwordx4 {vr(128 + 4 * (NKS * qb + ks), 4)}, %[qp{qb}], off offset:{32 * ks}")
+    for i in range(2 * NDT * 16):
         o(f"v_accvgpr_write_b32 a{i}, 0")
     for qb in range(2):
         for r in range(16):
@@ -240,7 +244,7 @@ def build() -> str:
         o(f"v_mov_b32_e32 {vr(T[8 + qb])}, 0")
     if not EXACT:
         o("s_waitcnt vmcnt(0)")
-        for i in range(64):
+        for i in range(8 * NKS):
             src, lo, hi = 128 + i, T[0], T[1]
             o(f"v_lshlrev_b32_e32 {vr(lo)}, 16, {vr(src)}")
             o(f"v_and_b32_e32 {vr(hi)}, 0xffff0000, {vr(src)}")
@@ -251,7 +255,7 @@ def build() -> str:
     o(f"v_mov_b32_e32 {vr(KOF[0])}, %[koff]")
     o(f"v_mov_b32_e32 {vr(VOF[0])}, %[voff]")
     for p in range(1, 4):
-        o(f"v_add_u32_e32 {vr(KOF[p])}, {p * 4096}, {vr(KOF[0])}")
+        o(f"v_add_u32_e32 {vr(KOF[p])}, {p * 16 * HD * 2}, {vr(KOF[0])}")
         o(f"v_add_u32_e32 {vr(VOF[p])}, %[vrow32], {vr(VOF[p - 1])}")
     o(f"s_mov_b64 s[{S_KP}:{S_KP + 1}], %[kbase]")
     o(f"s_mov_b64 s[{S_VP}:{S_VP + 1}], %[vbase]")
@@ -264,7 +268,7 @@ def build() -> str:
             st.extend(pc)
         o(f"s_cmp_lt_u32 %[nkt], {k + 2}")
         o("s_cbranch_scc1 .Lf64_staged_%=")
-        st.extend(stage_advance(str(64 * 256), "128"))
+        st.extend(stage_advance(str(64 * HD * 2), "128"))
     o(".Lf64_staged_%=:")
     o(f"s_sub_u32 s{S_CNT}, %[nkt], 1")                      # full steps (with an A for the next tile): tiles 0 .. nkt-2
     o("s_waitcnt vmcnt(0)")
@@ -317,12 +321,12 @@ def build() -> str:
         dma = [] if "nostage" in DBG else [stage_begin(S_SLOT[3]) + pcs[0]] + pcs[1:]
         bm = [] if nob else b_max(g_cur ^ 1, 0) + b_max(g_cur ^ 1, 1)
         segs: list[tuple] = []
-        segs.append((vta_update(S_SLOT[0]), 0, 20))                        # C(t)'s V^T addresses (first request: A's fragment 14, group 28)
+        segs.append((vta_update(S_SLOT[0]), 0, 2 * (NU - 2) - 4))          # C(t)'s V^T addresses (first request: A's fragment NU - 2, group 2 (NU - 2))
         segs.append((chunks[(0, 0)], 0, na - 1, "chain"))                  # PF(0, ., 0): before C's first MFMA
-        segs.append((chunks[(0, 1)], 0, na + 7, "chain"))                  # PF(0, ., 1): before C's iteration 4 (group na + 8)
-        segs.append((chunks[(1, 0)], 0, na + 15, "chain"))
-        segs.append((chunks[(1, 1)], 0, na + 23, "chain"))
-        segs.append((rowa_update(S_SLOT[2]), 27, na + 26))                 # K addresses of tile t+2: after A's last request (group 26), before C's iteration 14
+        segs.append((chunks[(0, 1)], 0, na + 2 * NDT - 1, "chain"))        # PF(0, ., 1): before C's iteration NDT (group na + 2 NDT)
+        segs.append((chunks[(1, 0)], 0, na + 4 * NDT - 1, "chain"))
+        segs.append((chunks[(1, 1)], 0, na + 6 * NDT - 1, "chain"))
+        segs.append((rowa_update(S_SLOT[2]), 2 * (NU - 3) + 1, na + 2 * (NV - 2) - 2))    # K addresses of tile t+2: after A's last request, before C's iteration NV - 2
         segs.append((dma, na + 3, len(groups) - 1))
         segs.append((bm, na + 8, len(groups) - 1))                         # tile t+1's scores are complete 12 states after A's last MFMA (group na - 1)
         lines = weave_budget(groups, segs, CAP)
@@ -340,7 +344,7 @@ def build() -> str:
     def inc_select() -> None:
         # pointer increments after this step's stage (tile min(t+3, nkt-1)): advance while tile t+4 exists  <=>  full steps left (incl. this one) >= 4
         o(f"s_cmp_ge_u32 s{S_CNT}, 4")
-        o(f"s_cselect_b32 s{S_INCK}, {64 * 256}, 0")
+        o(f"s_cselect_b32 s{S_INCK}, {64 * HD * 2}, 0")
         o(f"s_cselect_b32 s{S_INCV}, 128, 0")
 
     st.comment("---- main loop: two full steps (tiles t, t+1) per trip while at least two full steps are left")
@@ -388,9 +392,9 @@ def build() -> str:
             o(f"v_fma_f32 {vr(T[4 + qb])}, -{vr(NM[qb])}, %[scale2], {vr(T[2])}")     # lse2 = log2(l) + m_ref,  m_ref = -NM * scale2
         else:
             o(f"v_sub_f32_e32 {vr(T[4 + qb])}, {vr(T[2])}, {vr(NM[qb])}")      # lse2 = log2(l) + m_ref   -> output operand copy below
-        for dt in range(4):
+        for dt in range(NDT):
             for a in range(4):
-                base = 16 * (4 * qb + dt) + 4 * a
+                base = 16 * (NDT * qb + dt) + 4 * a
                 t = 64 + 4 * ((4 * dt + a) & 3)
                 for bb in range(4):
                     o(f"v_accvgpr_read_b32 {vr(t + bb)}, a{base + bb}")
@@ -435,13 +439,14 @@ def build() -> str:
 
 
 def main() -> None:
-    out = os.environ.get("FWD64_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", "attn_fwd64_body.inc")
+    name = "attn_fwd64_body.inc" if HD == 128 else f"attn_fwd64_hd{HD}_body.inc"
+    out = os.environ.get("FWD64_OUT") or os.path.join(os.path.dirname(__file__), "..", "..", "simpletuner_amd", "csrc", "gen", name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     body = build()
     with open(out, "w") as f:
         f.write("// GENERATED by tools/kgen/fwd64.py — do not edit; regenerate with  python -m tools.kgen.fwd64\n")
         f.write(body)
-    if not os.environ.get("FWD64_OUT"):
+    if not os.environ.get("FWD64_OUT") and HD == 128:
         regs = [f'"v{i}"' for i in range(32, 256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(40, 84)]
         with open(os.path.join(os.path.dirname(out), "attn_fwd64_clobbers.inc"), "w") as f:
             f.write("// GENERATED by tools/kgen/fwd64.py — the registers the fwd64 body owns\n")
