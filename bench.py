@@ -468,7 +468,7 @@ def main():
         import copy
         import gc
         keys = ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config", "step_model_tflops", "step_frac_of_bf16_mfma_peak",
-                "roofline", "loss", "peak_hbm_gib", "published_context")
+                "roofline", "loss", "peak_hbm_gib", "published_context", "comm")
         a2 = copy.copy(args)
         a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients

@@ -841,6 +841,50 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
             assert torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
+@pytest.mark.parametrize("B,H,S", [(1, 16, 1024), (2, 4, 320)])
+def test_attention_64_row_kernels_head_dim_96(ops, B, H, S):
+    """the head_dim-96 builds of the 64-row kernels (PixArt-Sigma's head_dim 72, zero padded to 96: 6 k-steps, 3 d tiles, tile images at the 256-byte pitch)
+    against the 32-row kernels: O to bf16 rounding, lse2 to fp32 rounding, dQ bit-identical, dK / dV to fp32 summation order; the padded channels stay zero"""
+    torch.manual_seed(94)
+    d_ = dev()
+    hd, dv_ = 96, 72
+    D = H * hd
+    scale = 1.0 / math.sqrt(dv_)
+    mk = lambda *sh: torch.randn(*sh, device=d_)
+    Q, K = mk(B, H, S, hd), mk(B, H, S, hd)
+    Q[..., dv_:] = 0; K[..., dv_:] = 0
+    Q, K = Q.to(BF16), K.to(BF16)
+    V = mk(B * S, H, hd); V[..., dv_:] = 0
+    V = V.reshape(B * S, D).to(BF16)
+    Vt = V.view(B, S, H, hd).permute(0, 2, 3, 1).contiguous()
+    dO = mk(B * S, H, hd); dO[..., dv_:] = 0
+    dO = dO.reshape(B * S, D).to(BF16)
+    res = {}
+    prev = ops.attn_set_impl()
+    try:
+        for impl in (32, 64):
+            ops.attn_set_impl(fwd=impl, dq=impl, dkv=3 if impl == 32 else 4)
+            O = torch.empty(B * S, D, device=d_, dtype=BF16); lse2 = torch.empty(B, H, S, device=d_)
+            ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, S, hd, scale)
+            res[impl] = [O, lse2]
+        O, lse2 = res[32]
+        for impl in (32, 64):
+            ops.attn_set_impl(fwd=impl, dq=impl, dkv=3 if impl == 32 else 4)
+            dQ = torch.empty_like(Q); dK = torch.empty_like(K); dqkv = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+            ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, S, hd, scale)
+            res[impl] += [dQ, dK, dqkv]
+    finally:
+        ops.attn_set_impl(fwd=prev[0], dq=prev[1], dkv=prev[2])
+    assert report("fwd64<96> O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
+    assert float((res[64][1] - res[32][1]).abs().max()) < 1e-4
+    assert torch.equal(res[64][2], res[32][2]), "dq64<96> is not bit-identical to dq"
+    assert report("dkv4<96> dK vs dkv3", res[64][3], res[32][3])[0] < 2e-3
+    assert report("dkv4<96> dV vs dkv3", res[64][4][:, 2 * D:], res[32][4][:, 2 * D:])[0] < 2e-3
+    for t in (res[64][2], res[64][3]):
+        assert t[..., dv_:].abs().max().item() == 0
+    assert res[64][0].view(B * S, H, hd)[..., dv_:].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64), (1, 2, 333, 96), (2, 2, 512, 96)])
 def test_attention_fwd_bwd(ops, B, H, S, d):
     _attn_case(ops, B, H, S, d)

@@ -258,9 +258,23 @@ def test_attention_head_dim_96_padded_72(B, H, Sq, Sk, cross):
         ops.attn_cross_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=kb)
     else:
         ops.attn_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, d, scale)
-    assert torch.equal(dQ2, dQ) and torch.equal(dK2, dK) and torch.equal(dkv2[:, Cm:], dkv[:, Cm:])      # no-copies form: bit-identical
-    dq = torch.empty_like(q)
-    ops.head_merge(dQ, dq, B, H, d, Sq)
-    ops.head_merge(dK, dkv[:, :Cm], B, H, d, Sk)
-    assert _rel(dq, qf.grad) < 1.2e-2, _rel(dq, qf.grad)
-    assert _rel(dkv, kvf.grad) < 1.2e-2, _rel(dkv, kvf.grad)
+    assert torch.equal(dQ2, dQ)                                                                            # no-copies form: bit-identical
+    if cross:
+        assert torch.equal(dK2, dK) and torch.equal(dkv2[:, Cm:], dkv[:, Cm:])
+    else:
+        # self-attention at head_dim 96 without copies runs k_attn_bwd_dkv4<96> (statistics folded into the MFMA chains: fp32 summation order differs); the
+        # 32-key kernel it replaces stays bit-identical to the copy-reading one
+        assert _rel(dK2, dK) < 2e-3 and _rel(dkv2[:, Cm:], dkv[:, Cm:]) < 2e-3
+        prev = ops.attn_set_impl(dkv=3)
+        try:
+            dQ3, dK3, dkv3 = torch.empty_like(Q), torch.empty_like(K), torch.zeros_like(kv)
+            ops.attn_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ3, dK3, dkv3[:, Cm:], B, H, Sq, Sqp, d, scale)
+        finally:
+            ops.attn_set_impl(dkv=prev[2])
+        assert torch.equal(dK3, dK) and torch.equal(dkv3[:, Cm:], dkv[:, Cm:])
+    for dQx, dKx, dkvx in ((dQ, dK, dkv), (dQ2, dK2, dkv2)):
+        dq = torch.empty_like(q)
+        ops.head_merge(dQx, dq, B, H, d, Sq)
+        ops.head_merge(dKx, dkvx[:, :Cm], B, H, d, Sk)
+        assert _rel(dq, qf.grad) < 1.2e-2, _rel(dq, qf.grad)
+        assert _rel(dkvx, kvf.grad) < 1.2e-2, _rel(dkvx, kvf.grad)
