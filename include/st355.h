@@ -449,6 +449,111 @@ typedef struct st355_flux_double_bwd_args {
 } st355_flux_double_bwd_args;
 int st355_block_flux_double_bwd(void* stream, const st355_flux_double_bwd_args* args);
 
+/* One PixArt BasicTransformerBlock(ada_norm_single) (helpers/models/pixart/transformer.py:95-145 `_pixart_apply_block`; the trunk blocks and the ControlNet
+ * branch's copies) forward as ONE call: AdaLN-single modulate, self-attention (heads of true width 72 run zero padded to d_pad = 96: Dp = H * 96 columns; the
+ * padded weight rows / columns are zero, so the padded lanes stay zero), gated residual, cross-attention over the Sk caption tokens (no pre-norm, no gate;
+ * fp32 additive key bias for the caption mask), AdaLN-single modulate, GELU(tanh) feed-forward, gated residual.  mod: this block's [B, 6D] rows
+ * (scale_shift_table + the timestep embedding: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp; row stride mod_stride elements).
+ * Weights in nn.Linear layout over the padded head columns: w_qkv [3Dp, D], w_out1 [D, Dp], w_q2 [Dp, D], w_kv2 [2Dp, D], w_out2 [D, Dp], w_ff1 [4D, D],
+ * w_ff2 [D, 4D].  Kept for the backward (caller's buffers): n1 [B*S, D], qkv [B*S, 3Dp], Q / K [B, H, S, 96], O [B*S, Dp], lse [B, H, S] fp32, h1 [B*S, D],
+ * q2 [B*S, Dp], kv [B*Sk, 2Dp], Q2 [B, H, S, 96], K2 [B, H, Sk, 96], O2 [B*S, Dp], lse_x [B, H, S] fp32, h2, n2 [B*S, D], pre, act [B*S, 4D]; optional
+ * (a trainable block's gate gradients): ya, yf [B*S, D] = the un-gated attention / feed-forward branch outputs, or NULL.  Scratch: Vt [B, H, 96, Sp],
+ * V2t [B, H, 96, Skp] with Sp / Skp = S / Sk rounded up to 64 — the columns beyond S / Sk must hold zeros on entry (no kernel writes them).
+ * Bit-identical to issuing the same entry points one by one. */
+typedef struct st355_pixart_block_fwd_args {
+  int32_t B; int32_t S; int32_t Sk; int32_t H; int32_t D; int32_t d_pad;
+  float scale;                                              /* 1 / sqrt(true head width) */
+  void* h; void* ctx; void* mod;
+  int64_t mod_stride;
+  void* key_bias;
+  void* w_qkv; void* b_qkv; void* w_out1; void* b_out1; void* w_q2; void* b_q2; void* w_kv2; void* b_kv2;
+  void* w_out2; void* b_out2; void* w_ff1; void* b_ff1; void* w_ff2; void* b_ff2;
+  void* n1; void* qkv; void* Q; void* K; void* O; void* lse; void* ya; void* h1;
+  void* q2; void* kv; void* Q2; void* K2; void* O2; void* lse_x; void* h2; void* n2;
+  void* pre; void* act; void* yf; void* Vt; void* V2t;
+  void* out;                                                /* [B*S, D] */
+} st355_pixart_block_fwd_args;
+int st355_block_pixart_fwd(void* stream, const st355_pixart_block_fwd_args* args);
+/* ... and the data path of its backward: d_out = d loss / d block output -> d_in = d loss / d block input.  Every intermediate gradient is left in the
+ * caller's buffers so that a TRAINABLE block (the ControlNet branch) can take its weight / bias / modulation gradients from them afterwards
+ * (st355_gemm_tn_bf16 / st355_colsum_prod over: dyf [B*S, D] with `act`, dpre [B*S, 4D] with n2, dn2 with h2, d2 with O2, dq2 [B*S, Dp] with h1,
+ * dkv [B*Sk, 2Dp] with ctx, dya with O, dqkv [B*S, 3Dp] with n1, dn1 with h; d1 = the gradient at the self-attention residual).  wT_*: K-major weight
+ * copies ([in, out]).  dO / dO2 [B*S, Dp], dQ / dK [B, H, max(S, Sk), 96] scratch; attn_ws: st355_attn_bwd_workspace(B, H, S, Sp, 96) bytes. */
+typedef struct st355_pixart_block_bwd_args {
+  int32_t B; int32_t S; int32_t Sk; int32_t H; int32_t D; int32_t d_pad;
+  float scale;
+  void* h; void* mod;
+  int64_t mod_stride;
+  void* key_bias;
+  void* wT_qkv; void* wT_out1; void* wT_q2; void* wT_out2; void* wT_ff1; void* wT_ff2;
+  void* qkv; void* Q; void* K; void* O; void* lse; void* q2; void* kv; void* Q2;
+  void* K2; void* O2; void* lse_x; void* h2; void* pre;
+  void* d_out;
+  void* dyf; void* dpre; void* dn2; void* d2; void* dO2; void* dq2; void* dkv; void* d1;
+  void* dya; void* dO; void* dqkv; void* dn1; void* dQ; void* dK; void* attn_ws;
+  void* d_in;
+} st355_pixart_block_bwd_args;
+int st355_block_pixart_bwd(void* stream, const st355_pixart_block_bwd_args* args);
+
+/* One SD3 JointTransformerBlock (helpers/models/sd3/transformer.py:145-241 `_sd3_apply_joint_transformer_block`; the single-attention form of SD3-Medium /
+ * SD3.5-Large — the dual-attention blocks of SD3.5-Medium stay sequenced by the host) forward as ONE call.  Streams: img [B*Si, D], txt [B*St, D]; joint buffers
+ * hold [img || txt] per sample (qkv [B*S, 3D], O [B*S, D], S = Si + St, image rows first; Q, K [B, H, S, hd] head-major, Vt [B, H, hd, Sp] with Sp = S
+ * rounded up to 64 and the columns beyond S zero on entry).  mod_img: this block's [B, 6D] modulation rows (shift_msa, scale_msa, gate_msa, shift_mlp,
+ * scale_mlp, gate_mlp); mod_txt: the same for the context stream, or — `last` != 0, the context_pre_only block — the [B, 2D] (scale, shift) rows of its
+ * AdaLayerNormContinuous: the text stream then only feeds the attention (x1_txt, hpre_txt, n2_txt, h_txt, out_txt, T_ao unused).  Row stride mod_stride.
+ * cos / sin: [S, hd] fp32 tables of st355_qk_norm_rope_fwd (identity for SD3); norm_*: q / k RMSNorm weights [hd] or NULL.
+ * Adapters (optional, K2_* = 0: none) on the fused to_q|to_k|to_v (A_qkv [K2, D], Bb_qkv [3D, K2]), add_q|k|v_proj (A_aqkv, Bb_aqkv), to_out.0 (A_out [K2, D],
+ * Bb_out [D, K2]) and to_add_out (A_aout, Bb_aout); their down-projections T_* [rows, K2] are kept for the backward.
+ * Row blocks that are not tile-aligned (rows % 256 != 0 with B > 1; the 154 text rows) follow the host side's policy: blocks of >= 1024 rows run as one problem per
+ * sample, smaller ones through compact copies in c_img / c_txt (B * rows * 3D bf16 each, NULL when that stream never needs one).
+ * Kept for the backward: n_img, n_txt, qkv, Q, K, O, lse2, x1_img, x1_txt, hpre_img, hpre_txt, T_*; a full fine-tune also keeps n2_*, h_* and asks for the
+ * un-gated branch outputs ya_* (attention), yf_* (feed-forward) — NULL otherwise.  Bit-identical to the host-side sequencing. */
+typedef struct st355_sd3_joint_fwd_args {
+  int32_t B; int32_t Si; int32_t St; int32_t H; int32_t D; int32_t hd; int32_t last; int32_t K2_qkv;
+  int32_t k2r_qkv; int32_t K2_aqkv; int32_t k2r_aqkv; int32_t K2_out; int32_t k2r_out; int32_t K2_aout; int32_t k2r_aout;
+  float scale;
+  void* img; void* txt; void* mod_img; void* mod_txt;
+  int64_t mod_stride;
+  void* w_qkv; void* b_qkv; void* w_add_qkv; void* b_add_qkv; void* w_out; void* b_out; void* w_add_out; void* b_add_out;
+  void* w_ff1; void* b_ff1; void* w_ff2; void* b_ff2; void* w_ffc1; void* b_ffc1; void* w_ffc2; void* b_ffc2;
+  void* A_qkv; void* Bb_qkv; void* A_aqkv; void* Bb_aqkv; void* A_out; void* Bb_out; void* A_aout; void* Bb_aout;
+  void* norm_q; void* norm_k; void* norm_added_q; void* norm_added_k; void* cos; void* sin;
+  void* n_img; void* n_txt; void* qkv; void* Q; void* K; void* O; void* lse2; void* x1_img;
+  void* x1_txt; void* hpre_img; void* hpre_txt; void* T_img; void* T_txt; void* T_o; void* T_ao;
+  void* ya_img; void* ya_txt; void* yf_img; void* yf_txt;
+  void* n2_img; void* n2_txt; void* h_img; void* h_txt; void* Vt; void* c_img; void* c_txt; void* gemm_ws;
+  int64_t gemm_ws_bytes;
+  void* out_img; void* out_txt;
+} st355_sd3_joint_fwd_args;
+int st355_block_sd3_joint_fwd(void* stream, const st355_sd3_joint_fwd_args* args);
+/* ... and the data path of its backward: d_img / d_txt (gradients of the block outputs; d_txt unused for the `last` block) -> d_img_out / d_txt_out
+ * (`need_input_grads` = 0, block 0 under frozen embedders: the input projections' data gradients and d_*_out are skipped).  The K-extension terms of the
+ * adapters ride in the data gradients (U_* = dY (sB)^T [rows, K2], kept); every intermediate gradient stays in the caller's buffers, so the host takes the
+ * rank-space adapter gradients (st355_skinny_tn*) or — full fine-tune — the weight / bias / modulation gradients (st355_gemm_tn_bf16, st355_colsum_prod)
+ * from them afterwards: g_* = gate_mlp * d_* [rows, D], dh_* [rows, 4D], dn2_*, dx1_* (gradient at the attention residual), dx1g_* (gate_msa * dx1_*),
+ * dO [B*S, D] (zero-filled by the caller when `last`: the text rows get no write), dqkv [B*S, 3D] (a stream's rows of it are also left as a compact copy in
+ * c_img / c_txt — B * rows * 3D bf16 — exactly when B > 1 and rows % 256 != 0: the operand form the input projections' gradients then use), dn_* [rows, D].  wT_*: K-major weight copies; Bbt_* [K2, N] / At_* [D, K2]: the adapters' transposed packed operands.
+ * dQ, dK [B, H, S, hd] scratch; attn_ws: st355_attn_bwd_workspace(B, H, S, Sp, hd) bytes. */
+typedef struct st355_sd3_joint_bwd_args {
+  int32_t B; int32_t Si; int32_t St; int32_t H; int32_t D; int32_t hd; int32_t last; int32_t need_input_grads;
+  int32_t K2_qkv; int32_t k2r_qkv; int32_t K2_aqkv; int32_t k2r_aqkv; int32_t K2_out; int32_t k2r_out; int32_t K2_aout; int32_t k2r_aout;
+  float scale;
+  void* img; void* txt; void* mod_img; void* mod_txt;
+  int64_t mod_stride;
+  void* qkv; void* Q; void* K; void* O; void* lse2; void* x1_img; void* x1_txt; void* hpre_img;
+  void* hpre_txt;
+  void* wT_qkv; void* wT_add_qkv; void* wT_out; void* wT_add_out; void* wT_ff1; void* wT_ff2; void* wT_ffc1; void* wT_ffc2;
+  void* At_qkv; void* Bbt_qkv; void* At_aqkv; void* Bbt_aqkv; void* At_out; void* Bbt_out; void* At_aout; void* Bbt_aout;
+  void* norm_q; void* norm_k; void* norm_added_q; void* norm_added_k; void* cos; void* sin;
+  void* d_img; void* d_txt;
+  void* g_img; void* g_txt; void* dh_img; void* dh_txt; void* dn2_img; void* dn2_txt; void* dx1_img; void* dx1g_img;
+  void* dx1_txt; void* dx1g_txt; void* U_o; void* U_ao; void* dO; void* dqkv; void* dQ; void* dK;
+  void* U_qkv; void* U_aqkv; void* dn_img; void* dn_txt; void* c_img; void* c_txt; void* gemm_ws;
+  int64_t gemm_ws_bytes;
+  void* attn_ws; void* d_img_out; void* d_txt_out;
+} st355_sd3_joint_bwd_args;
+int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd_args* args);
+
 /* AutoencoderKL.encode as ONE entry point (SURVEY.md §8(b)7 `st355_vae_encode`; reference seam: VAECache.encode_images -> vae.encode(x).latent_dist,
  * helpers/caching/vae.py:1238-1396, models/common.py:2767-2772): pixels [B, in_channels, H, W] bf16 -> the distribution parameters
  * [B, 2*latent_channels, H/2^(n_levels-1), W/2^(n_levels-1)] bf16 (mean | logvar).  It sequences the grid / GroupNorm / conv-as-GEMM / softmax / GEMM entry

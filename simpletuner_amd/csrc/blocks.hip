@@ -342,3 +342,425 @@ extern "C" int st355_block_flux_double_bwd(void* stream, const st355_flux_double
     q.run(st355_ln_modulate_bwd(stream, p->dn_txt, D, p->txt, D, mt + D, ms, St, p->dx1_txt, D, nullptr, 0, p->d_txt_out, D, nullptr, D, Mt, D, 1e-6f));
   return q.rc;
 }
+
+// =====================================================================================================================================================
+// PixArt BasicTransformerBlock(ada_norm_single): reference seam helpers/models/pixart/transformer.py:95-145 (`_pixart_apply_block`) and the autograd
+// through it.  Same launches, order and operands as simpletuner_amd/pixart/transformer.py `_block_fwd` / `_block_bwd` (which calls these by default).
+// =====================================================================================================================================================
+extern "C" int st355_block_pixart_fwd(void* stream, const st355_pixart_block_fwd_args* p) {
+  ST_REQUIRE(p && p->h && p->ctx && p->mod && p->n1 && p->qkv && p->Q && p->K && p->O && p->lse && p->h1 && p->q2 && p->kv && p->Q2 && p->K2 && p->O2 && p->lse_x
+                 && p->h2 && p->n2 && p->act && p->Vt && p->V2t && p->out, "block_pixart_fwd: null pointer");
+  ST_REQUIRE(p->w_qkv && p->w_out1 && p->w_q2 && p->w_kv2 && p->w_out2 && p->w_ff1 && p->w_ff2, "block_pixart_fwd: null weight pointer");
+  ST_REQUIRE(p->B > 0 && p->S > 0 && p->Sk > 0 && p->H > 0 && p->D > 0 && p->D % 64 == 0 && (p->d_pad == 64 || p->d_pad == 96 || p->d_pad == 128),
+             "block_pixart_fwd: D %% 64 == 0 and a padded head width of 64 / 96 / 128");
+  const int B = p->B, S = p->S, Sk = p->Sk, H = p->H, D = p->D, hd = p->d_pad, Dp = H * hd, M = B * S, Mk = B * Sk;
+  const int Sp = (S + 63) / 64 * 64, Skp = (Sk + 63) / 64 * 64;
+  const int64_t ms = p->mod_stride;
+  const char* m = (const char*)p->mod;
+  auto chunk = [&](int k) { return (const void*)(m + (size_t)k * D * 2); };
+  char* qkv = (char*)p->qkv; char* kv = (char*)p->kv;
+  Seq q{stream, 0};
+  // norm_hidden = LN(h) * (1 + scale_msa) + shift_msa;  q | k | v                                              (pixart/transformer.py:107-113)
+  q.run(st355_ln_modulate_fwd(stream, p->h, D, chunk(1), chunk(0), ms, S, p->n1, D, M, D, 1e-6f));
+  {
+    st355_gemm_args a = G(p->n1, D, p->w_qkv, D, p->qkv, 3 * Dp, M, 3 * Dp, D);
+    a.bias = p->b_qkv;
+    q.gemm(a);
+  }
+  if (q.ok()) q.run(st355_head_split_pad(stream, qkv, 3 * Dp, p->Q, nullptr, B, H, hd, hd, S, Sp));
+  if (q.ok()) q.run(st355_head_split_pad(stream, qkv + (size_t)Dp * 2, 3 * Dp, p->K, nullptr, B, H, hd, hd, S, Sp));
+  if (q.ok()) q.run(st355_head_split_pad(stream, qkv + (size_t)2 * Dp * 2, 3 * Dp, nullptr, p->Vt, B, H, hd, hd, S, Sp));
+  if (q.ok()) q.run(st355_attn_fwd(stream, p->Q, p->K, p->Vt, nullptr, p->O, Dp, (float*)p->lse, B, H, S, Sp, hd, p->scale));
+  // h1 = h + gate_msa * (attn W_o^T + b)                                                                        (:114-115)
+  {
+    st355_gemm_args a = G(p->O, Dp, p->w_out1, Dp, p->h1, D, M, D, Dp);
+    a.bias = p->b_out1; a.epilogue = ST355_EPI_GATE_RESIDUAL; a.gate = chunk(2); a.gate_stride = ms; a.rows_per_batch = S; a.aux_in = p->h; a.ld_aux_in = D;
+    if (p->ya) { a.aux_out = p->ya; a.ld_aux_out = D; }
+    q.gemm(a);
+  }
+  // cross-attention over the caption tokens: no pre-norm, no gate                                               (:117-129)
+  {
+    st355_gemm_args a = G(p->h1, D, p->w_q2, D, p->q2, Dp, M, Dp, D);
+    a.bias = p->b_q2;
+    q.gemm(a);
+    st355_gemm_args b = G(p->ctx, D, p->w_kv2, D, p->kv, 2 * Dp, Mk, 2 * Dp, D);
+    b.bias = p->b_kv2;
+    q.gemm(b);
+  }
+  if (q.ok()) q.run(st355_head_split_pad(stream, p->q2, Dp, p->Q2, nullptr, B, H, hd, hd, S, Sp));
+  if (q.ok()) q.run(st355_head_split_pad(stream, kv, 2 * Dp, p->K2, nullptr, B, H, hd, hd, Sk, Skp));
+  if (q.ok()) q.run(st355_head_split_pad(stream, kv + (size_t)Dp * 2, 2 * Dp, nullptr, p->V2t, B, H, hd, hd, Sk, Skp));
+  if (q.ok())
+    q.run(st355_attn_cross_fwd(stream, p->Q2, p->K2, p->V2t, (const float*)p->key_bias, p->O2, Dp, (float*)p->lse_x, B, H, S, Sk, Skp, hd, p->scale));
+  {
+    st355_gemm_args a = G(p->O2, Dp, p->w_out2, Dp, p->h2, D, M, D, Dp);
+    a.bias = p->b_out2; a.epilogue = ST355_EPI_ADD; a.aux_in = p->h1; a.ld_aux_in = D;
+    q.gemm(a);
+  }
+  // feed-forward: LN(h2) * (1 + scale_mlp) + shift_mlp -> GELU(tanh) MLP -> gated residual                      (:131-143)
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->h2, D, chunk(4), chunk(3), ms, S, p->n2, D, M, D, 1e-6f));
+  {
+    st355_gemm_args a = G(p->n2, D, p->w_ff1, D, p->act, 4 * D, M, 4 * D, D);
+    a.bias = p->b_ff1; a.epilogue = ST355_EPI_GELU;
+    if (p->pre) { a.aux_out = p->pre; a.ld_aux_out = 4 * D; }
+    q.gemm(a);
+  }
+  {
+    st355_gemm_args a = G(p->act, 4 * D, p->w_ff2, 4 * D, p->out, D, M, D, 4 * D);
+    a.bias = p->b_ff2; a.epilogue = ST355_EPI_GATE_RESIDUAL; a.gate = chunk(5); a.gate_stride = ms; a.rows_per_batch = S; a.aux_in = p->h2; a.ld_aux_in = D;
+    if (p->yf) { a.aux_out = p->yf; a.ld_aux_out = D; }
+    q.gemm(a);
+  }
+  return q.rc;
+}
+
+extern "C" int st355_block_pixart_bwd(void* stream, const st355_pixart_block_bwd_args* p) {
+  ST_REQUIRE(p && p->h && p->mod && p->qkv && p->Q && p->K && p->O && p->lse && p->q2 && p->kv && p->Q2 && p->K2 && p->O2 && p->lse_x && p->h2 && p->pre && p->d_out,
+             "block_pixart_bwd: null pointer");
+  ST_REQUIRE(p->wT_qkv && p->wT_out1 && p->wT_q2 && p->wT_out2 && p->wT_ff1 && p->wT_ff2, "block_pixart_bwd: null weight pointer");
+  ST_REQUIRE(p->dyf && p->dpre && p->dn2 && p->d2 && p->dO2 && p->dq2 && p->dkv && p->d1 && p->dya && p->dO && p->dqkv && p->dn1 && p->dQ && p->dK && p->attn_ws && p->d_in,
+             "block_pixart_bwd: null scratch pointer");
+  ST_REQUIRE(p->B > 0 && p->S > 0 && p->Sk > 0 && p->H > 0 && p->D > 0 && p->D % 64 == 0 && (p->d_pad == 64 || p->d_pad == 96 || p->d_pad == 128),
+             "block_pixart_bwd: D %% 64 == 0 and a padded head width of 64 / 96 / 128");
+  const int B = p->B, S = p->S, Sk = p->Sk, H = p->H, D = p->D, hd = p->d_pad, Dp = H * hd, M = B * S;
+  const int Sp = (S + 63) / 64 * 64, Skp = (Sk + 63) / 64 * 64;
+  const int64_t ms = p->mod_stride;
+  const char* m = (const char*)p->mod;
+  auto chunk = [&](int k) { return (const void*)(m + (size_t)k * D * 2); };
+  const char* qkv = (const char*)p->qkv; const char* kv = (const char*)p->kv;
+  char* dqkv = (char*)p->dqkv; char* dkv = (char*)p->dkv;
+  Seq q{stream, 0};
+  // ---- feed-forward ----
+  q.run(st355_scale_cols(stream, p->d_out, D, chunk(5), ms, S, p->dyf, D, M, D));
+  {
+    st355_gemm_args a = G(p->dyf, D, p->wT_ff2, D, p->dpre, 4 * D, M, 4 * D, D);
+    a.epilogue = ST355_EPI_MUL_GELU_GRAD; a.aux_in = p->pre; a.ld_aux_in = 4 * D;
+    q.gemm(a);
+  }
+  q.gemm(G(p->dpre, 4 * D, p->wT_ff1, 4 * D, p->dn2, D, M, D, 4 * D));
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn2, D, p->h2, D, chunk(4), ms, S, p->d_out, D, nullptr, 0, p->d2, D, nullptr, D, M, D, 1e-6f));
+  // ---- cross-attention (no pre-norm, no gate) ----
+  q.gemm(G(p->d2, D, p->wT_out2, D, p->dO2, Dp, M, Dp, D));
+  if (q.ok())
+    q.run(st355_attn_cross_bwd(stream, p->Q2, p->K2, nullptr, nullptr, kv + (size_t)Dp * 2, 2 * Dp, p->O2, Dp, p->dO2, Dp, (const float*)p->lse_x,
+                               (const float*)p->key_bias, p->dQ, p->dK, dkv + (size_t)Dp * 2, 2 * Dp, B, H, S, Sp, Sk, Skp, hd, p->scale, p->attn_ws));
+  if (q.ok()) q.run(st355_head_merge_pad(stream, p->dQ, p->dq2, Dp, B, H, hd, hd, S));
+  if (q.ok()) q.run(st355_head_merge_pad(stream, p->dK, dkv, 2 * Dp, B, H, hd, hd, Sk));
+  {
+    st355_gemm_args a = G(p->dq2, Dp, p->wT_q2, Dp, p->d1, D, M, D, Dp);
+    a.epilogue = ST355_EPI_ADD; a.aux_in = p->d2; a.ld_aux_in = D;
+    q.gemm(a);
+  }
+  // ---- self-attention ----
+  if (q.ok()) q.run(st355_scale_cols(stream, p->d1, D, chunk(2), ms, S, p->dya, D, M, D));
+  q.gemm(G(p->dya, D, p->wT_out1, D, p->dO, Dp, M, Dp, D));
+  if (q.ok())
+    q.run(st355_attn_bwd(stream, p->Q, p->K, nullptr, nullptr, qkv + (size_t)2 * Dp * 2, 3 * Dp, p->O, Dp, p->dO, Dp, (const float*)p->lse, nullptr, p->dQ, p->dK,
+                         dqkv + (size_t)2 * Dp * 2, 3 * Dp, B, H, S, Sp, hd, p->scale, p->attn_ws));
+  if (q.ok()) q.run(st355_head_merge_pad(stream, p->dQ, dqkv, 3 * Dp, B, H, hd, hd, S));
+  if (q.ok()) q.run(st355_head_merge_pad(stream, p->dK, dqkv + (size_t)Dp * 2, 3 * Dp, B, H, hd, hd, S));
+  q.gemm(G(p->dqkv, 3 * Dp, p->wT_qkv, 3 * Dp, p->dn1, D, M, D, 3 * Dp));
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn1, D, p->h, D, chunk(1), ms, S, p->d1, D, nullptr, 0, p->d_in, D, nullptr, D, M, D, 1e-6f));
+  return q.rc;
+}
+
+// =====================================================================================================================================================
+// SD3 JointTransformerBlock: reference seam helpers/models/sd3/transformer.py:145-241 (`_sd3_apply_joint_transformer_block`) and the autograd through it.
+// Same launches, order and operands as simpletuner_amd/sd3/transformer.py `_block_fwd` / the block body of `_engine_backward` (which call these by default).
+// Joint buffers hold [img || txt] per sample.  A stream's row block is ONE problem when B == 1 or the block is tile-aligned (segmented rows); other blocks
+// follow `_stream_problems` of the host side: >= 1024 rows -> one problem per sample, fewer -> compact copies (gathered before / scattered after the launch).
+// =====================================================================================================================================================
+#include <vector>
+
+namespace {
+enum StreamMode { SM_SINGLE, SM_PER_SAMPLE, SM_COMPACT };
+StreamMode stream_mode(int B, int rows) { return (B == 1 || rows % 256 == 0) ? SM_SINGLE : (rows >= 1024 ? SM_PER_SAMPLE : SM_COMPACT); }
+
+struct Scatter { void* dst; size_t dpitch; const void* src; size_t spitch; size_t width; int B; };
+int copy2d(void* st, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int B) {
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)st) == hipSuccess ? 0 : 1;
+}
+// rows of a joint buffer -> compact [B * rows, ld] (what `t.reshape(B * rows, -1)` of a [B, rows, C] view copies on the host side)
+int gather_block(void* st, void* dst, Rows src, int rows, int B) {
+  return copy2d(st, dst, (size_t)rows * src.ld * 2, src.p, (size_t)src.seg * src.ld * 2, (size_t)rows * src.ld * 2, B);
+}
+
+struct StreamOps { Rows A, A2, C, In, Out; };            // .p == nullptr: absent
+// Append one stream's projection (row operands in `o`, everything else in `proto`) to `v`.  COMPACT mode: joint inputs are gathered into `scratch` now (A only —
+// the call sites never have two joint inputs), a joint output goes to `scratch` and is scattered back by the entry appended to `sc` (run after the launch).
+void stream_probs(Seq& q, std::vector<st355_gemm_args>& v, std::vector<Scatter>& sc, int B, int rows, const st355_gemm_args& proto, StreamOps o, void* scratch) {
+  const StreamMode mode = stream_mode(B, rows);
+  auto fill = [&](st355_gemm_args& a, const StreamOps& s, int64_t off_rows_scale) {
+    (void)off_rows_scale;
+    a.A = s.A.p; a.lda = s.A.ld; a.C = (void*)s.C.p; a.ldc = s.C.ld;
+    if (s.A2.p) { a.A2 = s.A2.p; a.lda2 = s.A2.ld; }
+    if (s.In.p) { a.aux_in = s.In.p; a.ld_aux_in = s.In.ld; }
+    if (s.Out.p) { a.aux_out = (void*)s.Out.p; a.ld_aux_out = s.Out.ld; }
+  };
+  if (mode == SM_COMPACT) {
+    if (o.A.seg) {
+      q.run(gather_block(q.st, scratch, o.A, rows, B));
+      o.A = compact_rows(scratch, o.A.ld);
+    } else if (o.C.seg) {
+      sc.push_back(Scatter{(void*)o.C.p, (size_t)o.C.seg * o.C.ld * 2, scratch, (size_t)rows * o.C.ld * 2, (size_t)rows * o.C.ld * 2, B});
+      o.C = compact_rows(scratch, o.C.ld);
+    }
+  }
+  if (mode == SM_SINGLE || mode == SM_COMPACT) {
+    st355_gemm_args a = proto;
+    fill(a, o, 0);
+    a.M = B * rows;
+    if (B > 1 && mode == SM_SINGLE) { a.seg_rows = rows; a.seg_a = o.A.seg; a.seg_a2 = o.A2.seg; a.seg_c = o.C.seg; a.seg_in = o.In.seg; a.seg_out = o.Out.seg; }
+    v.push_back(a);
+    return;
+  }
+  for (int b = 0; b < B; b++) {
+    auto at = [&](Rows r) { return r.p ? Rows{(const char*)r.p + (size_t)b * (r.seg ? r.seg : rows) * r.ld * 2, r.ld, 0} : r; };
+    st355_gemm_args a = proto;
+    fill(a, StreamOps{at(o.A), at(o.A2), at(o.C), at(o.In), at(o.Out)}, 0);
+    a.M = rows;
+    if (a.gate) a.gate = (const char*)a.gate + (size_t)b * a.gate_stride * 2;
+    v.push_back(a);
+  }
+}
+void run_scatters(Seq& q, std::vector<Scatter>& sc) {
+  for (const Scatter& s : sc)
+    if (q.ok()) q.run(copy2d(q.st, s.dst, s.dpitch, s.src, s.spitch, s.width, s.B));
+  sc.clear();
+}
+void run_grouped(Seq& q, std::vector<st355_gemm_args>& v) {
+  if (q.ok() && !v.empty()) q.run(st355_gemm_bf16_grouped(q.st, v.data(), (int)v.size()));
+  v.clear();
+}
+st355_gemm_args proto_of(const void* W, int64_t ldw, int N, int K) {
+  st355_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.B = W; a.ldb = ldw; a.N = N; a.K = K; a.epilogue = ST355_EPI_NONE;
+  return a;
+}
+void proto_ext(st355_gemm_args& a, const void* B2, int K2, int k2_real) {
+  if (!K2) return;
+  a.B2 = B2; a.ldb2 = K2; a.K2 = K2; a.K2_real = k2_real;
+}
+}  // namespace
+
+extern "C" int st355_block_sd3_joint_fwd(void* stream, const st355_sd3_joint_fwd_args* p) {
+  ST_REQUIRE(p && p->img && p->txt && p->mod_img && p->mod_txt && p->n_img && p->n_txt && p->qkv && p->Q && p->K && p->O && p->lse2 && p->x1_img && p->hpre_img &&
+             p->n2_img && p->h_img && p->Vt && p->out_img && p->cos && p->sin, "block_sd3_joint_fwd: null pointer");
+  ST_REQUIRE(p->last || (p->x1_txt && p->hpre_txt && p->n2_txt && p->h_txt && p->out_txt), "block_sd3_joint_fwd: null text-stream pointer");
+  ST_REQUIRE(p->B > 0 && p->Si > 0 && p->St > 0 && p->H > 0 && (p->hd == 64 || p->hd == 128) && p->D == p->H * p->hd, "block_sd3_joint_fwd: D = H * hd, hd 64 / 128");
+  ST_REQUIRE((p->K2_qkv == 0 || (p->A_qkv && p->Bb_qkv && p->T_img)) && (p->K2_aqkv == 0 || (p->A_aqkv && p->Bb_aqkv && p->T_txt)) &&
+             (p->K2_out == 0 || (p->A_out && p->Bb_out && p->T_o)) && (p->K2_aout == 0 || p->last || (p->A_aout && p->Bb_aout && p->T_ao)),
+             "block_sd3_joint_fwd: inconsistent adapter operands");
+  const int B = p->B, Si = p->Si, St = p->St, S = Si + St, Sp = (S + 63) / 64 * 64, H = p->H, D = p->D, hd = p->hd;
+  const bool last = p->last != 0;
+  ST_REQUIRE((stream_mode(B, Si) != SM_COMPACT || p->c_img) && (stream_mode(B, St) != SM_COMPACT || p->c_txt), "block_sd3_joint_fwd: a stream needs its compact-copy scratch");
+  const int64_t ms = p->mod_stride;
+  const bf16* mi = (const bf16*)p->mod_img; const bf16* mt = (const bf16*)p->mod_txt;
+  Seq q{stream, 0};
+  std::vector<st355_gemm_args> v;
+  std::vector<Scatter> sc;
+  // norm_hidden = LN(x) * (1 + scale_msa) + shift_msa; the context_pre_only block's text norm is AdaLayerNormContinuous: (scale, shift)      (:150-160)
+  q.run(st355_ln_modulate_fwd(stream, p->img, D, mi + D, mi, ms, Si, p->n_img, D, (int64_t)B * Si, D, 1e-6f));
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->txt, D, last ? mt : mt + D, last ? mt + D : mt, ms, St, p->n_txt, D, (int64_t)B * St, D, 1e-6f));
+  if (p->K2_qkv) {
+    st355_gemm_args t = G(p->n_img, D, p->A_qkv, D, p->T_img, p->K2_qkv, B * Si, p->K2_qkv, D);
+    thin_ws(t, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(t);
+  }
+  if (p->K2_aqkv) {
+    st355_gemm_args t = G(p->n_txt, D, p->A_aqkv, D, p->T_txt, p->K2_aqkv, B * St, p->K2_aqkv, D);
+    thin_ws(t, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(t);
+  }
+  // q | k | v of both streams into the joint [img || txt] rows (+ adapters in the K-extension)                                                (:162-176)
+  {
+    st355_gemm_args a = proto_of(p->w_qkv, D, 3 * D, D);
+    a.bias = p->b_qkv; proto_ext(a, p->Bb_qkv, p->K2_qkv, p->k2r_qkv);
+    stream_probs(q, v, sc, B, Si, a, StreamOps{compact_rows(p->n_img, D), p->K2_qkv ? compact_rows(p->T_img, p->K2_qkv) : Rows{nullptr, 0, 0},
+                                                 joint_rows(p->qkv, 3 * D, 0, S), Rows{nullptr, 0, 0}, Rows{nullptr, 0, 0}}, p->c_img);
+    st355_gemm_args t = proto_of(p->w_add_qkv, D, 3 * D, D);
+    t.bias = p->b_add_qkv; proto_ext(t, p->Bb_aqkv, p->K2_aqkv, p->k2r_aqkv);
+    stream_probs(q, v, sc, B, St, t, StreamOps{compact_rows(p->n_txt, D), p->K2_aqkv ? compact_rows(p->T_txt, p->K2_aqkv) : Rows{nullptr, 0, 0},
+                                                 joint_rows(p->qkv, 3 * D, Si, S), Rows{nullptr, 0, 0}, Rows{nullptr, 0, 0}}, p->c_txt);
+    run_grouped(q, v);
+    run_scatters(q, sc);
+  }
+  // per-head RMSNorm of q / k (SD3.5), head-major re-layout, V^T                                                                               (:178-186)
+  if (q.ok())
+    q.run(st355_qk_norm_rope_fwd(stream, p->qkv, 3 * D, p->norm_q, p->norm_k, (const float*)p->cos, (const float*)p->sin, p->Q, p->K, nullptr, nullptr, p->Vt, B, H, hd, Si, 0,
+                                 S, Sp, 1e-6f));
+  if (q.ok())
+    q.run(st355_qk_norm_rope_fwd(stream, p->qkv, 3 * D, p->norm_added_q, p->norm_added_k, (const float*)p->cos, (const float*)p->sin, p->Q, p->K, nullptr, nullptr, p->Vt, B,
+                                 H, hd, St, Si, S, Sp, 1e-6f));
+  if (q.ok()) q.run(st355_attn_fwd(stream, p->Q, p->K, p->Vt, nullptr, p->O, D, (float*)p->lse2, B, H, S, Sp, hd, p->scale));
+  // attention output projections, gated onto the residual streams                                                                               (:199-214)
+  Rows O_i = joint_rows(p->O, D, 0, S), O_t = joint_rows(p->O, D, Si, S);
+  if (B > 1 && St % 256 != 0) {                                            // the text rows of the attention output, gathered once for both uses below
+    if (q.ok()) q.run(gather_block(stream, p->c_txt, O_t, St, B));
+    O_t = compact_rows(p->c_txt, D);
+  }
+  if (stream_mode(B, Si) == SM_COMPACT) {                                  // (the host side gathers inside each use; the bytes are the same)
+    if (q.ok()) q.run(gather_block(stream, p->c_img, O_i, Si, B));
+    O_i = compact_rows(p->c_img, D);
+  }
+  const Rows none{nullptr, 0, 0};
+  if (p->K2_out) {                                                         // thin adapter down-projections: one launch per problem, as on the host side
+    st355_gemm_args a = proto_of(p->A_out, D, p->K2_out, D);
+    stream_probs(q, v, sc, B, Si, a, StreamOps{O_i, none, compact_rows(p->T_o, p->K2_out), none, none}, nullptr);
+    for (auto& g : v) { thin_ws(g, p->gemm_ws, p->gemm_ws_bytes); q.gemm(g); }
+    v.clear();
+  }
+  if (!last && p->K2_aout) {
+    st355_gemm_args a = proto_of(p->A_aout, D, p->K2_aout, D);
+    stream_probs(q, v, sc, B, St, a, StreamOps{O_t, none, compact_rows(p->T_ao, p->K2_aout), none, none}, nullptr);
+    for (auto& g : v) { thin_ws(g, p->gemm_ws, p->gemm_ws_bytes); q.gemm(g); }
+    v.clear();
+  }
+  {
+    st355_gemm_args a = proto_of(p->w_out, D, D, D);
+    a.bias = p->b_out; a.epilogue = ST355_EPI_GATE_RESIDUAL; a.gate = mi + 2 * D; a.gate_stride = ms; a.rows_per_batch = Si; proto_ext(a, p->Bb_out, p->K2_out, p->k2r_out);
+    stream_probs(q, v, sc, B, Si, a, StreamOps{O_i, p->K2_out ? compact_rows(p->T_o, p->K2_out) : none, compact_rows(p->x1_img, D), compact_rows(p->img, D),
+                                                 p->ya_img ? compact_rows(p->ya_img, D) : none}, nullptr);
+    if (!last) {
+      st355_gemm_args t = proto_of(p->w_add_out, D, D, D);
+      t.bias = p->b_add_out; t.epilogue = ST355_EPI_GATE_RESIDUAL; t.gate = mt + 2 * D; t.gate_stride = ms; t.rows_per_batch = St; proto_ext(t, p->Bb_aout, p->K2_aout, p->k2r_aout);
+      stream_probs(q, v, sc, B, St, t, StreamOps{O_t, p->K2_aout ? compact_rows(p->T_ao, p->K2_aout) : none, compact_rows(p->x1_txt, D), compact_rows(p->txt, D),
+                                                   p->ya_txt ? compact_rows(p->ya_txt, D) : none}, nullptr);
+    }
+    run_grouped(q, v);
+  }
+  // the feed-forward branches                                                                                                                  (:216-239)
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->x1_img, D, mi + 4 * D, mi + 3 * D, ms, Si, p->n2_img, D, (int64_t)B * Si, D, 1e-6f));
+  st355_gemm_args f1 = G(p->n2_img, D, p->w_ff1, D, p->h_img, 4 * D, B * Si, 4 * D, D);
+  f1.bias = p->b_ff1; f1.epilogue = ST355_EPI_GELU; f1.aux_out = p->hpre_img; f1.ld_aux_out = 4 * D;
+  st355_gemm_args f2 = G(p->h_img, 4 * D, p->w_ff2, 4 * D, p->out_img, D, B * Si, D, 4 * D);
+  f2.bias = p->b_ff2; f2.epilogue = ST355_EPI_GATE_RESIDUAL; f2.aux_in = p->x1_img; f2.ld_aux_in = D; f2.gate = mi + 5 * D; f2.gate_stride = ms; f2.rows_per_batch = Si;
+  if (p->yf_img) { f2.aux_out = p->yf_img; f2.ld_aux_out = D; }
+  if (last) {
+    q.gemm(f1);
+    q.gemm(f2);
+    return q.rc;
+  }
+  if (q.ok()) q.run(st355_ln_modulate_fwd(stream, p->x1_txt, D, mt + 4 * D, mt + 3 * D, ms, St, p->n2_txt, D, (int64_t)B * St, D, 1e-6f));
+  st355_gemm_args c1 = G(p->n2_txt, D, p->w_ffc1, D, p->h_txt, 4 * D, B * St, 4 * D, D);
+  c1.bias = p->b_ffc1; c1.epilogue = ST355_EPI_GELU; c1.aux_out = p->hpre_txt; c1.ld_aux_out = 4 * D;
+  st355_gemm_args c2 = G(p->h_txt, 4 * D, p->w_ffc2, 4 * D, p->out_txt, D, B * St, D, 4 * D);
+  c2.bias = p->b_ffc2; c2.epilogue = ST355_EPI_GATE_RESIDUAL; c2.aux_in = p->x1_txt; c2.ld_aux_in = D; c2.gate = mt + 5 * D; c2.gate_stride = ms; c2.rows_per_batch = St;
+  if (p->yf_txt) { c2.aux_out = p->yf_txt; c2.ld_aux_out = D; }
+  if (q.ok()) { st355_gemm_args g2[2] = {f1, c1}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
+  if (q.ok()) { st355_gemm_args g2[2] = {f2, c2}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
+  return q.rc;
+}
+
+extern "C" int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd_args* p) {
+  ST_REQUIRE(p && p->img && p->txt && p->mod_img && p->mod_txt && p->qkv && p->Q && p->K && p->O && p->lse2 && p->x1_img && p->hpre_img && p->d_img && p->cos && p->sin,
+             "block_sd3_joint_bwd: null pointer");
+  ST_REQUIRE(p->g_img && p->dh_img && p->dn2_img && p->dx1_img && p->dx1g_img && p->dO && p->dqkv && p->dQ && p->dK && p->attn_ws, "block_sd3_joint_bwd: null scratch pointer");
+  ST_REQUIRE(p->last || (p->x1_txt && p->hpre_txt && p->d_txt && p->g_txt && p->dh_txt && p->dn2_txt && p->dx1_txt && p->dx1g_txt), "block_sd3_joint_bwd: null text-stream pointer");
+  ST_REQUIRE(!p->need_input_grads || (p->dn_img && p->dn_txt && p->d_img_out && p->d_txt_out && p->wT_qkv && p->wT_add_qkv), "block_sd3_joint_bwd: null input-gradient pointer");
+  ST_REQUIRE(p->B > 0 && p->Si > 0 && p->St > 0 && p->H > 0 && (p->hd == 64 || p->hd == 128) && p->D == p->H * p->hd, "block_sd3_joint_bwd: D = H * hd, hd 64 / 128");
+  ST_REQUIRE((p->K2_qkv == 0 || (p->Bbt_qkv && p->U_qkv && (!p->need_input_grads || p->At_qkv))) && (p->K2_aqkv == 0 || (p->Bbt_aqkv && p->U_aqkv && (!p->need_input_grads || p->At_aqkv))) &&
+             (p->K2_out == 0 || (p->Bbt_out && p->At_out && p->U_o)) && (p->K2_aout == 0 || p->last || (p->Bbt_aout && p->At_aout && p->U_ao)),
+             "block_sd3_joint_bwd: inconsistent adapter operands");
+  const int B = p->B, Si = p->Si, St = p->St, S = Si + St, Sp = (S + 63) / 64 * 64, H = p->H, D = p->D, hd = p->hd;
+  const bool last = p->last != 0;
+  const bool cp_i = B > 1 && Si % 256 != 0, cp_t = B > 1 && St % 256 != 0;          // the streams' rows of dqkv go through compact copies (`_compact` of the host side)
+  ST_REQUIRE((!(cp_i || stream_mode(B, Si) == SM_COMPACT) || p->c_img) && (!(cp_t || stream_mode(B, St) == SM_COMPACT) || p->c_txt), "block_sd3_joint_bwd: a stream needs its compact-copy scratch");
+  const int64_t ms = p->mod_stride;
+  const bf16* mi = (const bf16*)p->mod_img; const bf16* mt = (const bf16*)p->mod_txt;
+  const int64_t Mi = (int64_t)B * Si, Mt = (int64_t)B * St;
+  const Rows none{nullptr, 0, 0};
+  Seq q{stream, 0};
+  std::vector<st355_gemm_args> v;
+  std::vector<Scatter> sc;
+  // ---- feed-forward branches: g = gate_mlp * d, d h = (g W2) * GELU'(pre), d norm2 = d h W1; d x1 = d + LN'(.), and gate_msa * d x1 in the same pass ----
+  q.run(st355_scale_cols(stream, p->d_img, D, mi + 5 * D, ms, Si, p->g_img, D, Mi, D));
+  st355_gemm_args h_i = G(p->g_img, D, p->wT_ff2, D, p->dh_img, 4 * D, B * Si, 4 * D, D);
+  h_i.epilogue = ST355_EPI_MUL_GELU_GRAD; h_i.aux_in = p->hpre_img; h_i.ld_aux_in = 4 * D;
+  st355_gemm_args n_i = G(p->dh_img, 4 * D, p->wT_ff1, 4 * D, p->dn2_img, D, B * Si, D, 4 * D);
+  if (last) {
+    q.gemm(h_i);
+    q.gemm(n_i);
+  } else {
+    if (q.ok()) q.run(st355_scale_cols(stream, p->d_txt, D, mt + 5 * D, ms, St, p->g_txt, D, Mt, D));
+    st355_gemm_args h_t = G(p->g_txt, D, p->wT_ffc2, D, p->dh_txt, 4 * D, B * St, 4 * D, D);
+    h_t.epilogue = ST355_EPI_MUL_GELU_GRAD; h_t.aux_in = p->hpre_txt; h_t.ld_aux_in = 4 * D;
+    st355_gemm_args n_t = G(p->dh_txt, 4 * D, p->wT_ffc1, 4 * D, p->dn2_txt, D, B * St, D, 4 * D);
+    if (q.ok()) { st355_gemm_args g2[2] = {h_i, h_t}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
+    if (q.ok()) { st355_gemm_args g2[2] = {n_i, n_t}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
+    if (q.ok())
+      q.run(st355_ln_modulate_bwd(stream, p->dn2_txt, D, p->x1_txt, D, mt + 4 * D, ms, St, p->d_txt, D, mt + 2 * D, ms, p->dx1_txt, D, p->dx1g_txt, D, Mt, D, 1e-6f));
+  }
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn2_img, D, p->x1_img, D, mi + 4 * D, ms, Si, p->d_img, D, mi + 2 * D, ms, p->dx1_img, D, p->dx1g_img, D, Mi, D, 1e-6f));
+  // ---- attention output projections -> the dO rows of both streams (a context_pre_only block writes no text rows: the caller zero-filled dO) ----
+  if (p->K2_out) {
+    st355_gemm_args u = G(p->dx1g_img, D, p->Bbt_out, D, p->U_o, p->K2_out, B * Si, p->K2_out, D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  if (!last && p->K2_aout) {
+    st355_gemm_args u = G(p->dx1g_txt, D, p->Bbt_aout, D, p->U_ao, p->K2_aout, B * St, p->K2_aout, D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  {
+    st355_gemm_args a = proto_of(p->wT_out, D, D, D);
+    proto_ext(a, p->At_out, p->K2_out, p->k2r_out);
+    stream_probs(q, v, sc, B, Si, a, StreamOps{compact_rows(p->dx1g_img, D), p->K2_out ? compact_rows(p->U_o, p->K2_out) : none, joint_rows(p->dO, D, 0, S), none, none}, p->c_img);
+    if (!last) {
+      st355_gemm_args t = proto_of(p->wT_add_out, D, D, D);
+      proto_ext(t, p->At_aout, p->K2_aout, p->k2r_aout);
+      stream_probs(q, v, sc, B, St, t, StreamOps{compact_rows(p->dx1g_txt, D), p->K2_aout ? compact_rows(p->U_ao, p->K2_aout) : none, joint_rows(p->dO, D, Si, S), none, none}, p->c_txt);
+    }
+    run_grouped(q, v);
+    run_scatters(q, sc);
+  }
+  // ---- attention, then the RMSNorm (+ identity RoPE) backward of each stream's q / k into the projection-gradient rows ----
+  const char* qkv = (const char*)p->qkv; char* dqkv = (char*)p->dqkv;
+  if (q.ok())
+    q.run(st355_attn_bwd(stream, p->Q, p->K, nullptr, nullptr, qkv + (size_t)2 * D * 2, 3 * D, p->O, D, p->dO, D, (const float*)p->lse2, nullptr, p->dQ, p->dK,
+                         dqkv + (size_t)2 * D * 2, 3 * D, B, H, S, Sp, hd, p->scale, p->attn_ws));
+  if (q.ok())
+    q.run(st355_qk_norm_rope_bwd(stream, p->dQ, p->dK, p->qkv, 3 * D, p->norm_q, p->norm_k, (const float*)p->cos, (const float*)p->sin, p->dqkv, 3 * D, B, H, hd, Si, 0, S, 1e-6f));
+  if (q.ok())
+    q.run(st355_qk_norm_rope_bwd(stream, p->dQ, p->dK, p->qkv, 3 * D, p->norm_added_q, p->norm_added_k, (const float*)p->cos, (const float*)p->sin, p->dqkv, 3 * D, B, H, hd, St,
+                                 Si, S, 1e-6f));
+  // ---- input projections: each stream's rows of dqkv in place (segmented) when tile-aligned or B == 1, else a compact copy ----
+  Rows dq_i = joint_rows(p->dqkv, 3 * D, 0, S), dq_t = joint_rows(p->dqkv, 3 * D, Si, S);
+  if (cp_i) { if (q.ok()) q.run(gather_block(stream, p->c_img, dq_i, Si, B)); dq_i = compact_rows(p->c_img, 3 * D); }
+  if (cp_t) { if (q.ok()) q.run(gather_block(stream, p->c_txt, dq_t, St, B)); dq_t = compact_rows(p->c_txt, 3 * D); }
+  auto whole = [&](Rows A, const void* W, int64_t ldw, void* C, int64_t ldc, int rows, int N, int K) {       // ONE problem over the stream's rows (2-D or segmented)
+    st355_gemm_args a = G(A.p, A.ld, W, ldw, C, ldc, B * rows, N, K);
+    if (B > 1 && A.seg) { a.seg_rows = rows; a.seg_a = A.seg; }
+    return a;
+  };
+  if (p->K2_qkv) {
+    st355_gemm_args u = whole(dq_i, p->Bbt_qkv, 3 * D, p->U_qkv, p->K2_qkv, Si, p->K2_qkv, 3 * D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  if (p->K2_aqkv) {
+    st355_gemm_args u = whole(dq_t, p->Bbt_aqkv, 3 * D, p->U_aqkv, p->K2_aqkv, St, p->K2_aqkv, 3 * D);
+    thin_ws(u, p->gemm_ws, p->gemm_ws_bytes);
+    q.gemm(u);
+  }
+  if (!p->need_input_grads) return q.rc;
+  {
+    st355_gemm_args g2[2];
+    g2[0] = whole(dq_i, p->wT_qkv, 3 * D, p->dn_img, D, Si, D, 3 * D);
+    if (p->K2_qkv) { g2[0].A2 = p->U_qkv; g2[0].lda2 = p->K2_qkv; g2[0].B2 = p->At_qkv; g2[0].ldb2 = p->K2_qkv; g2[0].K2 = p->K2_qkv; g2[0].K2_real = p->k2r_qkv; }
+    g2[1] = whole(dq_t, p->wT_add_qkv, 3 * D, p->dn_txt, D, St, D, 3 * D);
+    if (p->K2_aqkv) { g2[1].A2 = p->U_aqkv; g2[1].lda2 = p->K2_aqkv; g2[1].B2 = p->At_aqkv; g2[1].ldb2 = p->K2_aqkv; g2[1].K2 = p->K2_aqkv; g2[1].K2_real = p->k2r_aqkv; }
+    if (q.ok()) q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn_img, D, p->img, D, mi + D, ms, Si, p->dx1_img, D, nullptr, 0, p->d_img_out, D, nullptr, D, Mi, D, 1e-6f));
+  if (q.ok())
+    q.run(st355_ln_modulate_bwd(stream, p->dn_txt, D, p->txt, D, last ? mt : mt + D, ms, St, last ? nullptr : p->dx1_txt, last ? 0 : D, nullptr, 0, p->d_txt_out, D, nullptr, D, Mt,
+                                D, 1e-6f));
+  return q.rc;
+}

@@ -29,7 +29,7 @@ SYMBOLS = [
     "st355_workspace_bytes",
     "st355_comm_unique_id", "st355_comm_init", "st355_comm_destroy", "st355_comm_all_reduce", "st355_comm_reduce_scatter", "st355_comm_all_gather",
     # UNet path (SDXL / SD1.5)
-    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows", "st355_vae_encode_workspace", "st355_vae_encode", "st355_block_flux_single_fwd", "st355_block_flux_single_bwd", "st355_block_flux_double_fwd", "st355_block_flux_double_bwd",
+    "st355_conv_grid_rows", "st355_conv_bf16", "st355_conv_wgrad_bf16", "st355_grid_from_nchw", "st355_grid_to_nchw", "st355_im2col3x3", "st355_col2im3x3", "st355_softmax_rows", "st355_vae_encode_workspace", "st355_vae_encode", "st355_block_flux_single_fwd", "st355_block_flux_single_bwd", "st355_block_flux_double_fwd", "st355_block_flux_double_bwd", "st355_block_pixart_fwd", "st355_block_pixart_bwd", "st355_block_sd3_joint_fwd", "st355_block_sd3_joint_bwd",
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
     "st355_groupnorm_workspace", "st355_groupnorm_fwd", "st355_groupnorm_bwd",
     "st355_layernorm_fwd", "st355_layernorm_bwd", "st355_layernorm_param_grads_workspace", "st355_layernorm_param_grads",
@@ -146,6 +146,72 @@ class FluxDoubleBwdArgs(C.Structure):
         ("U_qkv", C.c_void_p), ("U_out", C.c_void_p), ("dn_img", C.c_void_p), ("dn_txt", C.c_void_p), ("gemm_ws", C.c_void_p),
         ("gemm_ws_bytes", C.c_int64),
         ("attn_ws", C.c_void_p), ("skinny_ws", C.c_void_p), ("d_img_out", C.c_void_p), ("d_txt_out", C.c_void_p),
+    ]
+
+
+class PixartBlockFwdArgs(C.Structure):
+    """st355_pixart_block_fwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("S", C.c_int32), ("Sk", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("d_pad", C.c_int32), ("scale", C.c_float),
+        ("h", C.c_void_p), ("ctx", C.c_void_p), ("mod", C.c_void_p), ("mod_stride", C.c_int64), ("key_bias", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
+        ("w_out1", C.c_void_p), ("b_out1", C.c_void_p), ("w_q2", C.c_void_p), ("b_q2", C.c_void_p), ("w_kv2", C.c_void_p), ("b_kv2", C.c_void_p), ("w_out2", C.c_void_p),
+        ("b_out2", C.c_void_p), ("w_ff1", C.c_void_p), ("b_ff1", C.c_void_p), ("w_ff2", C.c_void_p), ("b_ff2", C.c_void_p), ("n1", C.c_void_p), ("qkv", C.c_void_p),
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("O", C.c_void_p), ("lse", C.c_void_p), ("ya", C.c_void_p), ("h1", C.c_void_p), ("q2", C.c_void_p),
+        ("kv", C.c_void_p), ("Q2", C.c_void_p), ("K2", C.c_void_p), ("O2", C.c_void_p), ("lse_x", C.c_void_p), ("h2", C.c_void_p), ("n2", C.c_void_p),
+        ("pre", C.c_void_p), ("act", C.c_void_p), ("yf", C.c_void_p), ("Vt", C.c_void_p), ("V2t", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+class PixartBlockBwdArgs(C.Structure):
+    """st355_pixart_block_bwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("S", C.c_int32), ("Sk", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("d_pad", C.c_int32), ("scale", C.c_float),
+        ("h", C.c_void_p), ("mod", C.c_void_p), ("mod_stride", C.c_int64), ("key_bias", C.c_void_p), ("wT_qkv", C.c_void_p), ("wT_out1", C.c_void_p), ("wT_q2", C.c_void_p),
+        ("wT_out2", C.c_void_p), ("wT_ff1", C.c_void_p), ("wT_ff2", C.c_void_p), ("qkv", C.c_void_p), ("Q", C.c_void_p), ("K", C.c_void_p), ("O", C.c_void_p),
+        ("lse", C.c_void_p), ("q2", C.c_void_p), ("kv", C.c_void_p), ("Q2", C.c_void_p), ("K2", C.c_void_p), ("O2", C.c_void_p), ("lse_x", C.c_void_p),
+        ("h2", C.c_void_p), ("pre", C.c_void_p), ("d_out", C.c_void_p), ("dyf", C.c_void_p), ("dpre", C.c_void_p), ("dn2", C.c_void_p), ("d2", C.c_void_p),
+        ("dO2", C.c_void_p), ("dq2", C.c_void_p), ("dkv", C.c_void_p), ("d1", C.c_void_p), ("dya", C.c_void_p), ("dO", C.c_void_p), ("dqkv", C.c_void_p),
+        ("dn1", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("attn_ws", C.c_void_p), ("d_in", C.c_void_p),
+    ]
+
+
+class Sd3JointFwdArgs(C.Structure):
+    """st355_sd3_joint_fwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("Si", C.c_int32), ("St", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("hd", C.c_int32),
+        ("last", C.c_int32), ("K2_qkv", C.c_int32), ("k2r_qkv", C.c_int32), ("K2_aqkv", C.c_int32), ("k2r_aqkv", C.c_int32), ("K2_out", C.c_int32),
+        ("k2r_out", C.c_int32), ("K2_aout", C.c_int32), ("k2r_aout", C.c_int32), ("scale", C.c_float), ("img", C.c_void_p), ("txt", C.c_void_p),
+        ("mod_img", C.c_void_p), ("mod_txt", C.c_void_p), ("mod_stride", C.c_int64), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("w_add_qkv", C.c_void_p),
+        ("b_add_qkv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p), ("w_add_out", C.c_void_p), ("b_add_out", C.c_void_p), ("w_ff1", C.c_void_p),
+        ("b_ff1", C.c_void_p), ("w_ff2", C.c_void_p), ("b_ff2", C.c_void_p), ("w_ffc1", C.c_void_p), ("b_ffc1", C.c_void_p), ("w_ffc2", C.c_void_p),
+        ("b_ffc2", C.c_void_p), ("A_qkv", C.c_void_p), ("Bb_qkv", C.c_void_p), ("A_aqkv", C.c_void_p), ("Bb_aqkv", C.c_void_p), ("A_out", C.c_void_p),
+        ("Bb_out", C.c_void_p), ("A_aout", C.c_void_p), ("Bb_aout", C.c_void_p), ("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("norm_added_q", C.c_void_p),
+        ("norm_added_k", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p), ("n_img", C.c_void_p), ("n_txt", C.c_void_p), ("qkv", C.c_void_p),
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("O", C.c_void_p), ("lse2", C.c_void_p), ("x1_img", C.c_void_p), ("x1_txt", C.c_void_p),
+        ("hpre_img", C.c_void_p), ("hpre_txt", C.c_void_p), ("T_img", C.c_void_p), ("T_txt", C.c_void_p), ("T_o", C.c_void_p), ("T_ao", C.c_void_p),
+        ("ya_img", C.c_void_p), ("ya_txt", C.c_void_p), ("yf_img", C.c_void_p), ("yf_txt", C.c_void_p), ("n2_img", C.c_void_p), ("n2_txt", C.c_void_p),
+        ("h_img", C.c_void_p), ("h_txt", C.c_void_p), ("Vt", C.c_void_p), ("c_img", C.c_void_p), ("c_txt", C.c_void_p), ("gemm_ws", C.c_void_p),
+        ("gemm_ws_bytes", C.c_int64), ("out_img", C.c_void_p), ("out_txt", C.c_void_p),
+    ]
+
+
+class Sd3JointBwdArgs(C.Structure):
+    """st355_sd3_joint_bwd_args (include/st355.h)"""
+    _fields_ = [
+        ("B", C.c_int32), ("Si", C.c_int32), ("St", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("hd", C.c_int32),
+        ("last", C.c_int32), ("need_input_grads", C.c_int32), ("K2_qkv", C.c_int32), ("k2r_qkv", C.c_int32), ("K2_aqkv", C.c_int32), ("k2r_aqkv", C.c_int32),
+        ("K2_out", C.c_int32), ("k2r_out", C.c_int32), ("K2_aout", C.c_int32), ("k2r_aout", C.c_int32), ("scale", C.c_float), ("img", C.c_void_p),
+        ("txt", C.c_void_p), ("mod_img", C.c_void_p), ("mod_txt", C.c_void_p), ("mod_stride", C.c_int64), ("qkv", C.c_void_p), ("Q", C.c_void_p),
+        ("K", C.c_void_p), ("O", C.c_void_p), ("lse2", C.c_void_p), ("x1_img", C.c_void_p), ("x1_txt", C.c_void_p), ("hpre_img", C.c_void_p),
+        ("hpre_txt", C.c_void_p), ("wT_qkv", C.c_void_p), ("wT_add_qkv", C.c_void_p), ("wT_out", C.c_void_p), ("wT_add_out", C.c_void_p), ("wT_ff1", C.c_void_p),
+        ("wT_ff2", C.c_void_p), ("wT_ffc1", C.c_void_p), ("wT_ffc2", C.c_void_p), ("At_qkv", C.c_void_p), ("Bbt_qkv", C.c_void_p), ("At_aqkv", C.c_void_p),
+        ("Bbt_aqkv", C.c_void_p), ("At_out", C.c_void_p), ("Bbt_out", C.c_void_p), ("At_aout", C.c_void_p), ("Bbt_aout", C.c_void_p), ("norm_q", C.c_void_p),
+        ("norm_k", C.c_void_p), ("norm_added_q", C.c_void_p), ("norm_added_k", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p), ("d_img", C.c_void_p),
+        ("d_txt", C.c_void_p), ("g_img", C.c_void_p), ("g_txt", C.c_void_p), ("dh_img", C.c_void_p), ("dh_txt", C.c_void_p), ("dn2_img", C.c_void_p),
+        ("dn2_txt", C.c_void_p), ("dx1_img", C.c_void_p), ("dx1g_img", C.c_void_p), ("dx1_txt", C.c_void_p), ("dx1g_txt", C.c_void_p), ("U_o", C.c_void_p),
+        ("U_ao", C.c_void_p), ("dO", C.c_void_p), ("dqkv", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("U_qkv", C.c_void_p),
+        ("U_aqkv", C.c_void_p), ("dn_img", C.c_void_p), ("dn_txt", C.c_void_p), ("c_img", C.c_void_p), ("c_txt", C.c_void_p), ("gemm_ws", C.c_void_p),
+        ("gemm_ws_bytes", C.c_int64), ("attn_ws", C.c_void_p), ("d_img_out", C.c_void_p), ("d_txt_out", C.c_void_p),
     ]
 
 
@@ -267,6 +333,10 @@ def _declare(lib):
         "st355_block_flux_single_bwd": (C.c_int, [vp, C.POINTER(FluxSingleBwdArgs)]),
         "st355_block_flux_double_fwd": (C.c_int, [vp, C.POINTER(FluxDoubleFwdArgs)]),
         "st355_block_flux_double_bwd": (C.c_int, [vp, C.POINTER(FluxDoubleBwdArgs)]),
+        "st355_block_pixart_fwd": (C.c_int, [vp, C.POINTER(PixartBlockFwdArgs)]),
+        "st355_block_pixart_bwd": (C.c_int, [vp, C.POINTER(PixartBlockBwdArgs)]),
+        "st355_block_sd3_joint_fwd": (C.c_int, [vp, C.POINTER(Sd3JointFwdArgs)]),
+        "st355_block_sd3_joint_bwd": (C.c_int, [vp, C.POINTER(Sd3JointBwdArgs)]),
         "st355_upsample2x": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_upsample2x_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32]),
         "st355_tokens_to_grid": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32]),

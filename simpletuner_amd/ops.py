@@ -1027,6 +1027,48 @@ def block_flux_single_bwd(gA, gB, **kw):
     _l.check(L.st355_block_flux_single_bwd(_stream(), C.byref(a)), "block_flux_single_bwd")
 
 
+def block_pixart_fwd(**kw):
+    """st355_block_pixart_fwd: one PixArt BasicTransformerBlock(ada_norm_single) forward as ONE C call (field names of st355_pixart_block_fwd_args)"""
+    L = _l.load()
+    a = _fill(_l.PixartBlockFwdArgs(), **kw)
+    _l.check(L.st355_block_pixart_fwd(_stream(), C.byref(a)), "block_pixart_fwd")
+
+
+def block_pixart_bwd(**kw):
+    """st355_block_pixart_bwd: the data path of that block's backward as ONE C call (field names of st355_pixart_block_bwd_args)"""
+    L = _l.load()
+    dev = kw["h"].device
+    Sp = (kw["S"] + 63) // 64 * 64
+    need = L.st355_attn_bwd_workspace(kw["B"], kw["H"], kw["S"], Sp, kw["d_pad"])
+    aws = _attn_ws.get((dev.index,))
+    if aws is None or aws.numel() < need:
+        aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
+    a = _fill(_l.PixartBlockBwdArgs(), attn_ws=aws, **kw)
+    _l.check(L.st355_block_pixart_bwd(_stream(), C.byref(a)), "block_pixart_bwd")
+
+
+def block_sd3_joint_fwd(**kw):
+    """st355_block_sd3_joint_fwd: one SD3 JointTransformerBlock forward as ONE C call (field names of st355_sd3_joint_fwd_args)"""
+    L = _l.load()
+    ws = _gemm_workspace(kw["img"].device)
+    a = _fill(_l.Sd3JointFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
+    _l.check(L.st355_block_sd3_joint_fwd(_stream(), C.byref(a)), "block_sd3_joint_fwd")
+
+
+def block_sd3_joint_bwd(**kw):
+    """st355_block_sd3_joint_bwd: the data path of that block's backward as ONE C call (field names of st355_sd3_joint_bwd_args)"""
+    L = _l.load()
+    dev = kw["img"].device
+    S = kw["Si"] + kw["St"]
+    need = L.st355_attn_bwd_workspace(kw["B"], kw["H"], S, (S + 63) // 64 * 64, kw["hd"])
+    aws = _attn_ws.get((dev.index,))
+    if aws is None or aws.numel() < need:
+        aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = _gemm_workspace(dev)
+    a = _fill(_l.Sd3JointBwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, attn_ws=aws, **kw)
+    _l.check(L.st355_block_sd3_joint_bwd(_stream(), C.byref(a)), "block_sd3_joint_bwd")
+
+
 class VaeEncoderTable:
     """the architecture + device-pointer table st355_vae_encode walks (include/st355.h lists the order); keeps the tensors alive"""
 

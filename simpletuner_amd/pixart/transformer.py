@@ -28,6 +28,7 @@ from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+_BLOCK_ABI = __import__("os").environ.get("ST355_BLOCK_ABI", "1") != "0"      # A/B switch: 0 = sequence the blocks' kernels from the host instead of st355_block_pixart_*
 HP = 96           # padded head width (72 -> 96: three 32-row MFMA tiles; was 128 before the head_dim-96 kernels existed)
 
 
@@ -262,6 +263,30 @@ class PixArtTransformer2DModel(nn.Module):
         train = save and blk.trainable
         if blk.fp8:
             return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
+        if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous():
+            # the block as ONE C entry point (st355_block_pixart_fwd): the launches of the host-side sequencing below, in its order, on its
+            # operands (every buffer allocated here, kept ones handed to the backward as before) — bit-identical to it (ST355_BLOCK_ABI=0 restores it)
+            dev = h.device
+            Sp, Skp = (S + 63) // 64 * 64, (Sk + 63) // 64 * 64
+            e = lambda *sh, dt=BF16: torch.empty(*sh, dtype=dt, device=dev)
+            n1, qkv, O, h1, q2, kv, O2, h2, n2, a, h3 = (e(B * S, D), e(B * S, 3 * Dp), e(B * S, Dp), e(B * S, D), e(B * S, Dp), e(B * Sk, 2 * Dp), e(B * S, Dp),
+                                                         e(B * S, D), e(B * S, D), e(B * S, 4 * D), e(B * S, D))
+            Q, K, Q2, K2 = e(B, H, S, HP), e(B, H, S, HP), e(B, H, S, HP), e(B, H, Sk, HP)
+            lse, lse2 = e(B, H, S, dt=F32), e(B, H, S, dt=F32)
+            Vt = (torch.zeros if Sp > S else torch.empty)(B, H, HP, Sp, dtype=BF16, device=dev)
+            V2t = (torch.zeros if Skp > Sk else torch.empty)(B, H, HP, Skp, dtype=BF16, device=dev)
+            ya, yf = (e(B * S, D), e(B * S, D)) if train else (None, None)
+            pre = e(B * S, 4 * D) if (save or exact) else None
+            ops.block_pixart_fwd(B=B, S=S, Sk=Sk, H=H, D=D, d_pad=HP, scale=scale, h=h, ctx=ctx2d, mod=mod, mod_stride=6 * D, key_bias=kbias,
+                                 w_qkv=W.qkv_w, b_qkv=W.qkv_b, w_out1=W.out1_w, b_out1=W.out1_b, w_q2=W.q2_w, b_q2=W.q2_b, w_kv2=W.kv2_w, b_kv2=W.kv2_b,
+                                 w_out2=W.out2_w, b_out2=W.out2_b, w_ff1=W.ff1_w, b_ff1=W.ff1_b, w_ff2=W.ff2_w, b_ff2=W.ff2_b,
+                                 n1=n1, qkv=qkv, Q=Q, K=K, O=O, lse=lse, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2, K2=K2, O2=O2, lse_x=lse2, h2=h2, n2=n2,
+                                 pre=pre, act=a, yf=yf, Vt=Vt, V2t=V2t, out=h3)
+            sv = None
+            if save:
+                sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=None, K=K, Kt=None, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2,
+                                     Q2t=None, K2=K2, K2t=None, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
+            return h3, sv
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
         qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
         Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
@@ -377,6 +402,35 @@ class PixArtTransformer2DModel(nn.Module):
             ops.colsum_prod(dn, dmod[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=S)
             ops.colsum_prod(dn, dmod[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in), rows_per_batch=S)
 
+        if _BLOCK_ABI and ops.ATTN_TR and sv.Qt is None and sv.pre is not None and d3.is_contiguous() and getattr(W, "ff2_wT", None) is not None:
+            # the data path of the backward as ONE C entry point (st355_block_pixart_bwd); every intermediate gradient stays in the buffers allocated here, and a
+            # trainable block takes its weight / bias / modulation gradients from them afterwards — the same launches on the same operands as the host-side
+            # sequencing below, the weight-gradient launches after the data path instead of between its steps (independent of it: bit-identical results)
+            dev = d3.device
+            e = lambda *sh: torch.empty(*sh, dtype=BF16, device=dev)
+            dyf, dpre, dn2, d2, dO2, dq2, dkv, d1, dya, dO, dqkv, dn1, d0 = (e(B * S, D), e(B * S, 4 * D), e(B * S, D), e(B * S, D), e(B * S, Dp), e(B * S, Dp),
+                                                                            e(B * Sk, 2 * Dp), e(B * S, D), e(B * S, D), e(B * S, Dp), e(B * S, 3 * Dp),
+                                                                            e(B * S, D), e(B * S, D))
+            dQ, dK = e(B, H, S, HP), e(B, H, max(S, Sk), HP)
+            ops.block_pixart_bwd(B=B, S=S, Sk=Sk, H=H, D=D, d_pad=HP, scale=scale, h=sv.h, mod=sv.mod, mod_stride=6 * D, key_bias=kbias,
+                                 wT_qkv=W.qkv_wT, wT_out1=W.out1_wT, wT_q2=W.q2_wT, wT_out2=W.out2_wT, wT_ff1=W.ff1_wT, wT_ff2=W.ff2_wT,
+                                 qkv=sv.qkv, Q=sv.Q, K=sv.K, O=sv.O, lse=sv.lse, q2=sv.q2, kv=sv.kv, Q2=sv.Q2, K2=sv.K2, O2=sv.O2, lse_x=sv.lse2, h2=sv.h2, pre=sv.pre,
+                                 d_out=d3, dyf=dyf, dpre=dpre, dn2=dn2, d2=d2, dO2=dO2, dq2=dq2, dkv=dkv, d1=d1, dya=dya, dO=dO, dqkv=dqkv, dn1=dn1, dQ=dQ, dK=dK,
+                                 d_in=d0)
+            if tr:
+                ops.colsum_prod(d3, dmod[:, 5 * D:6 * D], b=sv.yf, rows_per_batch=S)
+                wgrad("ff2", dyf, sv.a, plain("ff.net.2"))
+                wgrad("ff1", dpre, sv.n2, plain("ff.net.0.proj"))
+                mod_grads(dn2, sv.h2, 3, 4)
+                wgrad("out2", d2, sv.O2, unpad_cols("attn2.to_out.0"))
+                wgrad("q2", dq2, sv.h1, unpad_rows(["attn2.to_q"]))
+                wgrad("kv2", dkv, ctx2d, unpad_rows(["attn2.to_k", "attn2.to_v"]))
+                ops.colsum_prod(d1, dmod[:, 2 * D:3 * D], b=sv.ya, rows_per_batch=S)
+                wgrad("out1", dya, sv.O, unpad_cols("attn1.to_out.0"))
+                wgrad("qkv", dqkv, sv.n1, unpad_rows(["attn1.to_q", "attn1.to_k", "attn1.to_v"]))
+                mod_grads(dn1, sv.h, 0, 1)
+                blk.G["scale_shift_table"].copy_(dmod.sum(0).view(6, D))
+            return d0
         # ---- feed-forward ----
         dyf = ops.scale_cols(d3, m[5], S)
         if tr:

@@ -29,6 +29,7 @@ from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+_BLOCK_ABI = __import__("os").environ.get("ST355_BLOCK_ABI", "1") != "0"      # A/B switch: 0 = sequence the blocks' kernels from the host instead of st355_block_sd3_joint_*
 
 
 def sincos_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scale: float = 1.0) -> torch.Tensor:
@@ -349,6 +350,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, Si, St, S, Sp, cos, sin, mod, scale, full = env.B, env.Si, env.St, env.S, env.Sp, env.cos, env.sin, env.mod, env.scale, env.full
         ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
+        if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and img.is_contiguous() and txt.is_contiguous():
+            return self._block_fwd_c(blk, img, txt, env, save, ybuf)
 
         mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
         n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
@@ -469,6 +472,104 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             return x2_img, x2_txt, sv
         return x2_img, x2_txt, None
 
+    @staticmethod
+    def _lk(lin):
+        """(K2, k2_real, A_cat, B_blk, A_cat_T, B_blk_T) of a Linear's adapter group, zeros / None without one"""
+        g = lin.lora if lin is not None else None
+        if g is None:
+            return 0, 0, None, None, None, None
+        return g.K2, getattr(g, "k2_real", 0), g.A_cat, g.B_blk, g.A_cat_T, g.B_blk_T
+
+    def _block_fwd_c(self, blk, img, txt, env, save: bool, ybuf):
+        """_block_fwd through st355_block_sd3_joint_fwd: ONE C call sequences the launches of the host-side form below on the same operands —
+        every buffer is allocated here and the kept ones go to the backward as before; bit-identical to it (ST355_BLOCK_ABI=0 restores the host sequencing)."""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, Sp, mod, full = env.B, env.Si, env.St, env.S, env.Sp, env.mod, env.full
+        e = lambda *sh, dt=BF16: torch.empty(*sh, dtype=dt, device=dev)
+        last = blk.last
+        K2q, kr_q, A_q, Bb_q, _, _ = self._lk(blk.qkv)
+        K2a, kr_a, A_a, Bb_a, _, _ = self._lk(blk.add_qkv)
+        K2o, kr_o, A_o, Bb_o, _, _ = self._lk(blk.to_out)
+        K2t, kr_t, A_t, Bb_t, _, _ = self._lk(None if last else blk.to_add_out)
+        n_img, n_txt, qkv, O, x1_img, hpre_img, n2_i, h_i, x2_img = (e(B * Si, D), e(B * St, D), e(B * S, 3 * D), e(B * S, D), e(B * Si, D), e(B * Si, 4 * D),
+                                                                     e(B * Si, D), e(B * Si, 4 * D), e(B * Si, D))
+        Q, K, lse2 = e(B, H, S, hd), e(B, H, S, hd), e(B, H, S, dt=F32)
+        Vt = (torch.zeros if Sp > S else torch.empty)(B, H, hd, Sp, dtype=BF16, device=dev)
+        x1_txt = hpre_txt = n2_t = h_t = x2_txt = None
+        if not last:
+            x1_txt, hpre_txt, n2_t, h_t, x2_txt = e(B * St, D), e(B * St, 4 * D), e(B * St, D), e(B * St, 4 * D), e(B * St, D)
+        T_img = e(B * Si, K2q) if K2q else None
+        T_txt = e(B * St, K2a) if K2a else None
+        T_o = e(B * Si, K2o) if K2o else None
+        T_ao = e(B * St, K2t) if K2t else None
+        ya_i, ya_t, yf_i, yf_t = ybuf(B * Si), (None if last else ybuf(B * St)), ybuf(B * Si), (None if last else ybuf(B * St))
+        c_img = e(B * Si, 3 * D) if (B > 1 and Si % 256) else None
+        c_txt = e(B * St, 3 * D) if (B > 1 and St % 256) else None
+        ops.block_sd3_joint_fwd(
+            B=B, Si=Si, St=St, H=H, D=D, hd=hd, last=int(last), K2_qkv=K2q, k2r_qkv=kr_q, K2_aqkv=K2a, k2r_aqkv=kr_a, K2_out=K2o, k2r_out=kr_o, K2_aout=K2t, k2r_aout=kr_t,
+            scale=env.scale, img=img, txt=txt, mod_img=mod[:, blk.mod_off:], mod_txt=mod[:, blk.mod_off_c:], mod_stride=mod.stride(0),
+            w_qkv=blk.qkv.w, b_qkv=blk.qkv.b, w_add_qkv=blk.add_qkv.w, b_add_qkv=blk.add_qkv.b, w_out=blk.to_out.w, b_out=blk.to_out.b,
+            w_add_out=None if last else blk.to_add_out.w, b_add_out=None if last else blk.to_add_out.b,
+            w_ff1=blk.ff1.w, b_ff1=blk.ff1.b, w_ff2=blk.ff2.w, b_ff2=blk.ff2.b,
+            w_ffc1=None if last else blk.ffc1.w, b_ffc1=None if last else blk.ffc1.b, w_ffc2=None if last else blk.ffc2.w, b_ffc2=None if last else blk.ffc2.b,
+            A_qkv=A_q, Bb_qkv=Bb_q, A_aqkv=A_a, Bb_aqkv=Bb_a, A_out=A_o, Bb_out=Bb_o, A_aout=A_t, Bb_aout=Bb_t,
+            norm_q=blk.norm_q, norm_k=blk.norm_k, norm_added_q=blk.norm_added_q, norm_added_k=blk.norm_added_k, cos=env.cos, sin=env.sin,
+            n_img=n_img, n_txt=n_txt, qkv=qkv, Q=Q, K=K, O=O, lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt,
+            T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao, ya_img=ya_i, ya_txt=ya_t, yf_img=yf_i, yf_txt=yf_t,
+            n2_img=n2_i, n2_txt=n2_t, h_img=h_i, h_txt=h_t, Vt=Vt, c_img=c_img, c_txt=c_txt, out_img=x2_img, out_txt=x2_txt)
+        if not save:
+            return x2_img, x2_txt, None
+        sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2,
+                             x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao, d2=None)
+        if full:
+            sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
+        return x2_img, x2_txt, sv
+
+    def _block_bwd_c(self, blk, sv, env_li, mod, cos, sin, d_img, d_txt, need_input_grads: bool):
+        """the data path of one block's backward through st355_block_sd3_joint_bwd: returns (d_img', d_txt', G) with every intermediate gradient in G — the
+        adapter gradients (LoRA) or the weight / bias / modulation gradients (full fine-tune) are taken from them by the caller, the same launches on the same
+        operands as the host-side form, after the data path instead of between its steps (independent of it: bit-identical results)"""
+        D, H, hd, dev = self.D, self.H, self.hd, self.device_
+        B, Si, St, S, Sp = env_li.B, env_li.Si, env_li.St, env_li.S, env_li.Sp
+        e = lambda *sh: torch.empty(*sh, dtype=BF16, device=dev)
+        last = blk.last
+        K2q, kr_q, _, _, At_q, Bbt_q = self._lk(blk.qkv)
+        K2a, kr_a, _, _, At_a, Bbt_a = self._lk(blk.add_qkv)
+        K2o, kr_o, _, _, At_o, Bbt_o = self._lk(blk.to_out)
+        K2t, kr_t, _, _, At_t, Bbt_t = self._lk(None if last else blk.to_add_out)
+        G = SimpleNamespace(g_i=e(B * Si, D), dh_i=e(B * Si, 4 * D), dn2_i=e(B * Si, D), dx1_i=e(B * Si, D), dx1g_i=e(B * Si, D),
+                            g_t=None, dh_t=None, dn2_t=None, dx1_t=None, dx1g_t=None,
+                            dO=(torch.zeros if last else torch.empty)(B * S, D, dtype=BF16, device=dev), dqkv=e(B * S, 3 * D),
+                            U_o=e(B * Si, K2o) if K2o else None, U_ao=e(B * St, K2t) if K2t else None, U_q=e(B * Si, K2q) if K2q else None,
+                            U_a=e(B * St, K2a) if K2a else None, dn_i=None, dn_t=None, c_img=None, c_txt=None)
+        if not last:
+            G.g_t, G.dh_t, G.dn2_t, G.dx1_t, G.dx1g_t = e(B * St, D), e(B * St, 4 * D), e(B * St, D), e(B * St, D), e(B * St, D)
+        if B > 1 and Si % 256:
+            G.c_img = e(B * Si, 3 * D)
+        if B > 1 and St % 256:
+            G.c_txt = e(B * St, 3 * D)
+        d_img_out = d_txt_out = None
+        if need_input_grads:
+            G.dn_i, G.dn_t, d_img_out, d_txt_out = e(B * Si, D), e(B * St, D), e(B * Si, D), e(B * St, D)
+        dQ, dK = e(B, H, S, hd), e(B, H, S, hd)
+        ops.block_sd3_joint_bwd(
+            B=B, Si=Si, St=St, H=H, D=D, hd=hd, last=int(last), need_input_grads=int(need_input_grads),
+            K2_qkv=K2q, k2r_qkv=kr_q, K2_aqkv=K2a, k2r_aqkv=kr_a, K2_out=K2o, k2r_out=kr_o, K2_aout=K2t, k2r_aout=kr_t, scale=1.0 / math.sqrt(hd),
+            img=sv.img, txt=sv.txt, mod_img=mod[:, blk.mod_off:], mod_txt=mod[:, blk.mod_off_c:], mod_stride=mod.stride(0),
+            qkv=sv.qkv, Q=sv.Q, K=sv.K, O=sv.O, lse2=sv.lse2, x1_img=sv.x1_img, x1_txt=sv.x1_txt, hpre_img=sv.hpre_img, hpre_txt=sv.hpre_txt,
+            wT_qkv=blk.qkv.wT, wT_add_qkv=blk.add_qkv.wT, wT_out=blk.to_out.wT, wT_add_out=None if last else blk.to_add_out.wT,
+            wT_ff1=blk.ff1.wT, wT_ff2=blk.ff2.wT, wT_ffc1=None if last else blk.ffc1.wT, wT_ffc2=None if last else blk.ffc2.wT,
+            At_qkv=At_q, Bbt_qkv=Bbt_q, At_aqkv=At_a, Bbt_aqkv=Bbt_a, At_out=At_o, Bbt_out=Bbt_o, At_aout=At_t, Bbt_aout=Bbt_t,
+            norm_q=blk.norm_q, norm_k=blk.norm_k, norm_added_q=blk.norm_added_q, norm_added_k=blk.norm_added_k, cos=cos, sin=sin,
+            d_img=d_img, d_txt=d_txt, g_img=G.g_i, g_txt=G.g_t, dh_img=G.dh_i, dh_txt=G.dh_t, dn2_img=G.dn2_i, dn2_txt=G.dn2_t, dx1_img=G.dx1_i, dx1g_img=G.dx1g_i,
+            dx1_txt=G.dx1_t, dx1g_txt=G.dx1g_t, U_o=G.U_o, U_ao=G.U_ao, dO=G.dO, dqkv=G.dqkv, dQ=dQ, dK=dK, U_qkv=G.U_q, U_aqkv=G.U_a,
+            dn_img=G.dn_i, dn_txt=G.dn_t, c_img=G.c_img, c_txt=G.c_txt, d_img_out=d_img_out, d_txt_out=d_txt_out)
+        # each stream's rows of dqkv in the operand form the C entry used: in place (a 3-D view, segmented) when B == 1 or tile-aligned, else its compact copy
+        envs = SimpleNamespace(B=B, S=S)
+        G.dq_i = G.c_img if G.c_img is not None else _FluxEngine._compact(_rows3(G.dqkv, 0, Si, B, S), envs, Si)
+        G.dq_t = G.c_txt if G.c_txt is not None else _FluxEngine._compact(_rows3(G.dqkv, Si, St, B, S), envs, St)
+        return d_img_out, d_txt_out, G
+
     def _engine_forward(self, latents, enc, pooled, timestep, save: bool, full: bool = False):
         D, H, hd = self.D, self.H, self.hd
         B, C, Hh, Ww = latents.shape
@@ -579,6 +680,24 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             ctx.blocks[li] = None
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + (2 if blk.last else 6) * D]
+            if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and sv.Qt is None and d_img.is_contiguous() and (d_txt is None or d_txt.is_contiguous()):
+                # the data path as ONE C entry point (st355_block_sd3_joint_bwd), then the rank-space adapter gradients from the gradients it left behind
+                envs = SimpleNamespace(B=B, S=S)
+                d_img, d_txt, G = self._block_bwd_c(blk, sv, ctx.envs[li], mod, cos, sin, d_img, d_txt, li != 0)
+                pairs = [(blk.to_out, G.U_o, sv.T_o, G.dx1g_i, 0, Si)]
+                if not blk.last:
+                    pairs.append((blk.to_add_out, G.U_ao, sv.T_ao, G.dx1g_t, Si, St))
+                for (lin, U, T_, dxg, lo, rows) in pairs:
+                    if lin.lora is not None:
+                        lin.lora.grads(_FluxEngine._compact(_rows3(sv.O, lo, rows, B, S), envs, rows), T_, dxg, U, self.accumulate_lora_grads, self.grad_sync)
+                for (lin, dq, n_in, T_, U) in ((blk.qkv, G.dq_i, sv.n_img, sv.T_img, G.U_q), (blk.add_qkv, G.dq_t, sv.n_txt, sv.T_txt, G.U_a)):
+                    if lin.lora is not None:
+                        lin.lora.grads(n_in, T_, dq, U, self.accumulate_lora_grads, self.grad_sync)
+                del sv, G
+                if li in ctx.route_start and d_img is not None:
+                    ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
+                    d_img, d_full = d_full, None
+                continue
             g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)
             if blk.last:
                 dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
@@ -806,6 +925,38 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; dmi = dmod[:, blk.mod_off:blk.mod_off + 6 * D]
             nct = 2 if blk.last else 6
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + nct * D]; dmt = dmod[:, blk.mod_off_c:blk.mod_off_c + nct * D]
+            if (_BLOCK_ABI and not blk.dual and ops.ATTN_TR and sv.Qt is None and d_img.is_contiguous() and (d_txt is None or d_txt.is_contiguous())
+                    and blk.norm_q is None and blk.norm_k is None and blk.norm_added_q is None and blk.norm_added_k is None):
+                # the data path as ONE C entry point (st355_block_sd3_joint_bwd), then every weight / bias / modulation gradient of the block from the gradients
+                # it left behind (SD3.5's trainable q / k norm weights take the host-side form: their gradient rides in the RMSNorm backward pass)
+                d_in_img, d_in_txt = d_img, d_txt
+                d_img, d_txt, G = self._block_bwd_c(blk, sv, ctx.envs[li], mod, cos, sin, d_img, d_txt, True)
+                ops.colsum_prod(d_in_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)           # d gate_mlp
+                wgrad(blk.ff2, G.g_i, sv.h_i)
+                wgrad(blk.ff1, G.dh_i, sv.n2_i)
+                mod_grads(G.dn2_i, sv.x1_img, Si, 3, 4, dmi)
+                ops.colsum_prod(G.dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)            # d gate_msa
+                if not blk.last:
+                    ops.colsum_prod(d_in_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
+                    wgrad(blk.ffc2, G.g_t, sv.h_t)
+                    wgrad(blk.ffc1, G.dh_t, sv.n2_t)
+                    mod_grads(G.dn2_t, sv.x1_txt, St, 3, 4, dmt)
+                    ops.colsum_prod(G.dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
+                wgrad(blk.to_out, G.dx1g_i, rows_of(sv.O, 0, Si))
+                if not blk.last:
+                    wgrad(blk.to_add_out, G.dx1g_t, rows_of(sv.O, Si, St))
+                wgrad(blk.qkv, rows_of(G.dqkv, 0, Si), sv.n_img)
+                wgrad(blk.add_qkv, rows_of(G.dqkv, Si, St), sv.n_txt)
+                mod_grads(G.dn_i, sv.img, Si, 0, 1, dmi)
+                if blk.last:
+                    mod_grads(G.dn_t, sv.txt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
+                else:
+                    mod_grads(G.dn_t, sv.txt, St, 0, 1, dmt)
+                del sv, G, d_in_img, d_in_txt
+                if li in ctx.route_start:
+                    ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
+                    d_img, d_full = d_full, None
+                continue
             # ---- MLP branch ----
             ops.colsum_prod(d_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)           # d gate_mlp
             g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)

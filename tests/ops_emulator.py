@@ -18,6 +18,7 @@ backward with its RoPE / RMSNorm epilogues ARE emulated: that is Flux's default 
 from __future__ import annotations
 
 import math
+from types import SimpleNamespace
 
 import torch
 
@@ -1010,11 +1011,211 @@ def softmax_rows_bwd_(p, dp, scale=1.0):
     return dp
 
 
+BLOCK_CALLS = {}          # how often each emulated block-level entry point ran (tests assert the engines really take them)
+
+
+def block_pixart_fwd(**a):
+    """st355_block_pixart_fwd (csrc/blocks.hip) restated over the emulated entry points, in its order, writing the caller's buffers: what the C function does with
+    the struct fields.  It checks the HOST side of the boundary on a CPU box (which buffer goes into which field, shapes, the zero-pad contract of Vt / V2t); the
+    C++ sequencing itself is checked on the MI355X against the host-side sequencing (tests/test_pixart_model_gpu.py)."""
+    A = SimpleNamespace(**a)
+    BLOCK_CALLS["pixart_fwd"] = BLOCK_CALLS.get("pixart_fwd", 0) + 1
+    B, S, Sk, H, D, hd = A.B, A.S, A.Sk, A.H, A.D, A.d_pad
+    Dp = H * hd
+    Sp, Skp = (S + 63) // 64 * 64, (Sk + 63) // 64 * 64
+    assert A.mod.shape == (B, 6 * D) and A.mod_stride == A.mod.stride(0)
+    for t, sh in ((A.n1, (B * S, D)), (A.qkv, (B * S, 3 * Dp)), (A.Q, (B, H, S, hd)), (A.K, (B, H, S, hd)), (A.O, (B * S, Dp)), (A.lse, (B, H, S)), (A.h1, (B * S, D)),
+                  (A.q2, (B * S, Dp)), (A.kv, (B * Sk, 2 * Dp)), (A.Q2, (B, H, S, hd)), (A.K2, (B, H, Sk, hd)), (A.O2, (B * S, Dp)), (A.lse_x, (B, H, S)),
+                  (A.h2, (B * S, D)), (A.n2, (B * S, D)), (A.act, (B * S, 4 * D)), (A.Vt, (B, H, hd, Sp)), (A.V2t, (B, H, hd, Skp)), (A.out, (B * S, D))):
+        assert tuple(t.shape) == sh and t.is_contiguous(), (tuple(t.shape), sh)
+    assert Sp == S or float(A.Vt[..., S:].abs().max()) == 0, "Vt: the columns beyond S must be zero on entry"
+    assert Skp == Sk or float(A.V2t[..., Sk:].abs().max()) == 0, "V2t: the columns beyond Sk must be zero on entry"
+    m = [A.mod[:, k * D:(k + 1) * D] for k in range(6)]
+    ln_modulate_fwd(A.h, m[1], m[0], S, out=A.n1)
+    gemm(A.n1, A.w_qkv, bias=A.b_qkv, out=A.qkv)
+    A.Q.copy_(head_split(A.qkv[:, :Dp], B, H, hd, S, want_xt=False)[0])
+    A.K.copy_(head_split(A.qkv[:, Dp:2 * Dp], B, H, hd, S, want_xt=False)[0])
+    A.Vt.copy_(head_split(A.qkv[:, 2 * Dp:], B, H, hd, S, want_x=False)[1])
+    attn_fwd(A.Q, A.K, A.Vt, A.O, A.lse, B, H, S, Sp, hd, A.scale)
+    gemm(A.O, A.w_out1, bias=A.b_out1, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=A.h, rows_per_batch=S, aux_out=A.ya, out=A.h1)
+    gemm(A.h1, A.w_q2, bias=A.b_q2, out=A.q2)
+    gemm(A.ctx, A.w_kv2, bias=A.b_kv2, out=A.kv)
+    A.Q2.copy_(head_split(A.q2, B, H, hd, S, want_xt=False)[0])
+    A.K2.copy_(head_split(A.kv[:, :Dp], B, H, hd, Sk, want_xt=False)[0])
+    A.V2t.copy_(head_split(A.kv[:, Dp:], B, H, hd, Sk, want_x=False)[1])
+    attn_cross_fwd(A.Q2, A.K2, A.V2t, A.O2, A.lse_x, B, H, S, Sk, Skp, hd, A.scale, key_bias=A.key_bias)
+    gemm(A.O2, A.w_out2, bias=A.b_out2, epilogue=EPI_ADD, aux_in=A.h1, out=A.h2)
+    ln_modulate_fwd(A.h2, m[4], m[3], S, out=A.n2)
+    gemm(A.n2, A.w_ff1, bias=A.b_ff1, epilogue=EPI_GELU, aux_out=A.pre, out=A.act)
+    gemm(A.act, A.w_ff2, bias=A.b_ff2, epilogue=EPI_GATE_RESIDUAL, gate=m[5], aux_in=A.h2, rows_per_batch=S, aux_out=A.yf, out=A.out)
+
+
+def block_pixart_bwd(**a):
+    """st355_block_pixart_bwd restated over the emulated entry points (see block_pixart_fwd)"""
+    A = SimpleNamespace(**a)
+    BLOCK_CALLS["pixart_bwd"] = BLOCK_CALLS.get("pixart_bwd", 0) + 1
+    B, S, Sk, H, D, hd = A.B, A.S, A.Sk, A.H, A.D, A.d_pad
+    Dp = H * hd
+    Sp, Skp = (S + 63) // 64 * 64, (Sk + 63) // 64 * 64
+    for t, sh in ((A.dyf, (B * S, D)), (A.dpre, (B * S, 4 * D)), (A.dn2, (B * S, D)), (A.d2, (B * S, D)), (A.dO2, (B * S, Dp)), (A.dq2, (B * S, Dp)),
+                  (A.dkv, (B * Sk, 2 * Dp)), (A.d1, (B * S, D)), (A.dya, (B * S, D)), (A.dO, (B * S, Dp)), (A.dqkv, (B * S, 3 * Dp)), (A.dn1, (B * S, D)),
+                  (A.d_in, (B * S, D)), (A.d_out, (B * S, D))):
+        assert tuple(t.shape) == sh and t.is_contiguous(), (tuple(t.shape), sh)
+    assert A.dQ.numel() >= B * H * S * hd and A.dK.numel() >= B * H * max(S, Sk) * hd
+    m = [A.mod[:, k * D:(k + 1) * D] for k in range(6)]
+    scale_cols(A.d_out, m[5], S, out=A.dyf)
+    gemm(A.dyf, A.wT_ff2, epilogue=EPI_MUL_GELU_GRAD, aux_in=A.pre, out=A.dpre)
+    gemm(A.dpre, A.wT_ff1, out=A.dn2)
+    ln_modulate_bwd(A.dn2, A.h2, m[4], S, dres=A.d_out, out=A.d2)
+    gemm(A.d2, A.wT_out2, out=A.dO2)
+    dQ = A.dQ.view(-1)[:B * H * S * hd].view(B, H, S, hd); dKx = A.dK.view(-1)[:B * H * Sk * hd].view(B, H, Sk, hd)
+    attn_cross_bwd(A.Q2, A.K2, None, None, A.kv[:, Dp:], A.O2, A.dO2, A.lse_x, dQ, dKx, A.dkv[:, Dp:], B, H, S, Sp, Sk, Skp, hd, A.scale, key_bias=A.key_bias)
+    head_merge(dQ, A.dq2, B, H, hd, S)
+    head_merge(dKx, A.dkv[:, :Dp], B, H, hd, Sk)
+    gemm(A.dq2, A.wT_q2, epilogue=EPI_ADD, aux_in=A.d2, out=A.d1)
+    scale_cols(A.d1, m[2], S, out=A.dya)
+    gemm(A.dya, A.wT_out1, out=A.dO)
+    dKs = A.dK.view(-1)[:B * H * S * hd].view(B, H, S, hd)
+    attn_bwd(A.Q, A.K, None, None, A.qkv[:, 2 * Dp:], A.O, A.dO, A.lse, dQ, dKs, A.dqkv[:, 2 * Dp:], B, H, S, Sp, hd, A.scale)
+    head_merge(dQ, A.dqkv[:, :Dp], B, H, hd, S)
+    head_merge(dKs, A.dqkv[:, Dp:2 * Dp], B, H, hd, S)
+    gemm(A.dqkv, A.wT_qkv, out=A.dn1)
+    ln_modulate_bwd(A.dn1, A.h, m[1], S, dres=A.d1, out=A.d_in)
+
+
+def _sample_rows(buf, b, lo, rows, S):
+    """rows [lo, lo + rows) of sample b of a joint [B * S, C] buffer (a contiguous 2-D slice)"""
+    return buf[b * S + lo:b * S + lo + rows]
+
+
+def block_sd3_joint_fwd(**a):
+    """st355_block_sd3_joint_fwd (csrc/blocks.hip) restated over the emulated entry points, writing the caller's buffers.  Joint-buffer operands are walked one
+    sample at a time here (the C function's single / per-sample / compact-copy problem forms are launch shapes of the same arithmetic).  See block_pixart_fwd."""
+    A = SimpleNamespace(**a)
+    BLOCK_CALLS["sd3_fwd"] = BLOCK_CALLS.get("sd3_fwd", 0) + 1
+    B, Si, St, H, D, hd = A.B, A.Si, A.St, A.H, A.D, A.hd
+    S = Si + St
+    Sp = (S + 63) // 64 * 64
+    last = bool(A.last)
+    assert D == H * hd and A.mod_stride == A.mod_img.stride(0) == A.mod_txt.stride(0)
+    for t, sh in ((A.n_img, (B * Si, D)), (A.n_txt, (B * St, D)), (A.qkv, (B * S, 3 * D)), (A.Q, (B, H, S, hd)), (A.K, (B, H, S, hd)), (A.O, (B * S, D)),
+                  (A.lse2, (B, H, S)), (A.x1_img, (B * Si, D)), (A.hpre_img, (B * Si, 4 * D)), (A.n2_img, (B * Si, D)), (A.h_img, (B * Si, 4 * D)),
+                  (A.Vt, (B, H, hd, Sp)), (A.out_img, (B * Si, D))):
+        assert tuple(t.shape) == sh and t.is_contiguous(), (tuple(t.shape), sh)
+    assert Sp == S or float(A.Vt[..., S:].abs().max()) == 0, "Vt: the columns beyond S must be zero on entry"
+    for rows, c in ((Si, A.c_img), (St, A.c_txt)):
+        assert not (B > 1 and rows % 256) or (c is not None and c.numel() >= B * rows * 3 * D), "a stream that is not tile-aligned needs its compact-copy scratch"
+    mi = A.mod_img[:, :6 * D]
+    mt = A.mod_txt[:, :(2 if last else 6) * D]
+    ln_modulate_fwd(A.img, mi[:, D:2 * D], mi[:, :D], Si, out=A.n_img)
+    if last:
+        ln_modulate_fwd(A.txt, mt[:, :D], mt[:, D:2 * D], St, out=A.n_txt)
+    else:
+        ln_modulate_fwd(A.txt, mt[:, D:2 * D], mt[:, :D], St, out=A.n_txt)
+    if A.K2_qkv:
+        gemm(A.n_img, A.A_qkv, out=A.T_img)
+    if A.K2_aqkv:
+        gemm(A.n_txt, A.A_aqkv, out=A.T_txt)
+    for b in range(B):
+        kw = dict(a2=A.T_img[b * Si:(b + 1) * Si], b2=A.Bb_qkv) if A.K2_qkv else {}
+        gemm(A.n_img[b * Si:(b + 1) * Si], A.w_qkv, bias=A.b_qkv, out=_sample_rows(A.qkv, b, 0, Si, S), **kw)
+        kw = dict(a2=A.T_txt[b * St:(b + 1) * St], b2=A.Bb_aqkv) if A.K2_aqkv else {}
+        gemm(A.n_txt[b * St:(b + 1) * St], A.w_add_qkv, bias=A.b_add_qkv, out=_sample_rows(A.qkv, b, Si, St, S), **kw)
+    qk_norm_rope_fwd(A.qkv, A.norm_q, A.norm_k, A.cos, A.sin, A.Q, A.K, None, None, A.Vt, B, H, hd, Si, 0, S, Sp)
+    qk_norm_rope_fwd(A.qkv, A.norm_added_q, A.norm_added_k, A.cos, A.sin, A.Q, A.K, None, None, A.Vt, B, H, hd, St, Si, S, Sp)
+    attn_fwd(A.Q, A.K, A.Vt, A.O, A.lse2, B, H, S, Sp, hd, A.scale)
+    for b in range(B):
+        O_i, O_t = _sample_rows(A.O, b, 0, Si, S), _sample_rows(A.O, b, Si, St, S)
+        si, st = slice(b * Si, (b + 1) * Si), slice(b * St, (b + 1) * St)
+        kw = {}
+        if A.K2_out:
+            gemm(O_i, A.A_out, out=A.T_o[si])
+            kw = dict(a2=A.T_o[si], b2=A.Bb_out)
+        gemm(O_i, A.w_out, bias=A.b_out, epilogue=EPI_GATE_RESIDUAL, aux_in=A.img[si], gate=mi[b:b + 1, 2 * D:3 * D], rows_per_batch=Si,
+             aux_out=None if A.ya_img is None else A.ya_img[si], out=A.x1_img[si], **kw)
+        if not last:
+            kw = {}
+            if A.K2_aout:
+                gemm(O_t, A.A_aout, out=A.T_ao[st])
+                kw = dict(a2=A.T_ao[st], b2=A.Bb_aout)
+            gemm(O_t, A.w_add_out, bias=A.b_add_out, epilogue=EPI_GATE_RESIDUAL, aux_in=A.txt[st], gate=mt[b:b + 1, 2 * D:3 * D], rows_per_batch=St,
+                 aux_out=None if A.ya_txt is None else A.ya_txt[st], out=A.x1_txt[st], **kw)
+    ln_modulate_fwd(A.x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si, out=A.n2_img)
+    gemm(A.n2_img, A.w_ff1, bias=A.b_ff1, epilogue=EPI_GELU, aux_out=A.hpre_img, out=A.h_img)
+    gemm(A.h_img, A.w_ff2, bias=A.b_ff2, epilogue=EPI_GATE_RESIDUAL, aux_in=A.x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, aux_out=A.yf_img, out=A.out_img)
+    if not last:
+        ln_modulate_fwd(A.x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St, out=A.n2_txt)
+        gemm(A.n2_txt, A.w_ffc1, bias=A.b_ffc1, epilogue=EPI_GELU, aux_out=A.hpre_txt, out=A.h_txt)
+        gemm(A.h_txt, A.w_ffc2, bias=A.b_ffc2, epilogue=EPI_GATE_RESIDUAL, aux_in=A.x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, aux_out=A.yf_txt, out=A.out_txt)
+
+
+def block_sd3_joint_bwd(**a):
+    """st355_block_sd3_joint_bwd restated over the emulated entry points (see block_sd3_joint_fwd)"""
+    A = SimpleNamespace(**a)
+    BLOCK_CALLS["sd3_bwd"] = BLOCK_CALLS.get("sd3_bwd", 0) + 1
+    B, Si, St, H, D, hd = A.B, A.Si, A.St, A.H, A.D, A.hd
+    S = Si + St
+    Sp = (S + 63) // 64 * 64
+    last = bool(A.last)
+    for t, sh in ((A.g_img, (B * Si, D)), (A.dh_img, (B * Si, 4 * D)), (A.dn2_img, (B * Si, D)), (A.dx1_img, (B * Si, D)), (A.dx1g_img, (B * Si, D)),
+                  (A.dO, (B * S, D)), (A.dqkv, (B * S, 3 * D)), (A.dQ, (B, H, S, hd)), (A.dK, (B, H, S, hd)), (A.d_img, (B * Si, D))):
+        assert tuple(t.shape) == sh and t.is_contiguous(), (tuple(t.shape), sh)
+    for rows, c in ((Si, A.c_img), (St, A.c_txt)):
+        assert not (B > 1 and rows % 256) or (c is not None and c.numel() >= B * rows * 3 * D), "a stream that is not tile-aligned needs its compact-copy scratch"
+    mi = A.mod_img[:, :6 * D]
+    mt = A.mod_txt[:, :(2 if last else 6) * D]
+    scale_cols(A.d_img, mi[:, 5 * D:6 * D], Si, out=A.g_img)
+    gemm(A.g_img, A.wT_ff2, epilogue=EPI_MUL_GELU_GRAD, aux_in=A.hpre_img, out=A.dh_img)
+    gemm(A.dh_img, A.wT_ff1, out=A.dn2_img)
+    if not last:
+        scale_cols(A.d_txt, mt[:, 5 * D:6 * D], St, out=A.g_txt)
+        gemm(A.g_txt, A.wT_ffc2, epilogue=EPI_MUL_GELU_GRAD, aux_in=A.hpre_txt, out=A.dh_txt)
+        gemm(A.dh_txt, A.wT_ffc1, out=A.dn2_txt)
+        _, dxg = ln_modulate_bwd(A.dn2_txt, A.x1_txt, mt[:, 4 * D:5 * D], St, dres=A.d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True, out=A.dx1_txt)
+        A.dx1g_txt.copy_(dxg)
+    _, dxg = ln_modulate_bwd(A.dn2_img, A.x1_img, mi[:, 4 * D:5 * D], Si, dres=A.d_img, gate=mi[:, 2 * D:3 * D], want_gated=True, out=A.dx1_img)
+    A.dx1g_img.copy_(dxg)
+    if last:
+        assert float(A.dO.view(B, S, D)[:, Si:].abs().max()) == 0, "dO: a context_pre_only block needs the text rows zero-filled on entry"
+    if A.K2_out:
+        gemm(A.dx1g_img, A.Bbt_out, out=A.U_o)
+    if not last and A.K2_aout:
+        gemm(A.dx1g_txt, A.Bbt_aout, out=A.U_ao)
+    for b in range(B):
+        si, st = slice(b * Si, (b + 1) * Si), slice(b * St, (b + 1) * St)
+        kw = dict(a2=A.U_o[si], b2=A.At_out) if A.K2_out else {}
+        gemm(A.dx1g_img[si], A.wT_out, out=_sample_rows(A.dO, b, 0, Si, S), **kw)
+        if not last:
+            kw = dict(a2=A.U_ao[st], b2=A.At_aout) if A.K2_aout else {}
+            gemm(A.dx1g_txt[st], A.wT_add_out, out=_sample_rows(A.dO, b, Si, St, S), **kw)
+    attn_bwd(A.Q, A.K, None, None, A.qkv[:, 2 * D:], A.O, A.dO, A.lse2, A.dQ, A.dK, A.dqkv[:, 2 * D:], B, H, S, Sp, hd, A.scale)
+    qk_norm_rope_bwd(A.dQ, A.dK, A.qkv, A.norm_q, A.norm_k, A.cos, A.sin, A.dqkv, B, H, hd, Si, 0, S)
+    qk_norm_rope_bwd(A.dQ, A.dK, A.qkv, A.norm_added_q, A.norm_added_k, A.cos, A.sin, A.dqkv, B, H, hd, St, Si, S)
+    for rows, lo, c in ((Si, 0, A.c_img), (St, Si, A.c_txt)):
+        if B > 1 and rows % 256:                      # the compact copy the caller reads the stream's rows of dqkv from afterwards
+            c.view(-1)[:B * rows * 3 * D].view(B, rows, 3 * D).copy_(A.dqkv.view(B, S, 3 * D)[:, lo:lo + rows])
+    for b in range(B):
+        si, st = slice(b * Si, (b + 1) * Si), slice(b * St, (b + 1) * St)
+        dq_i, dq_t = _sample_rows(A.dqkv, b, 0, Si, S), _sample_rows(A.dqkv, b, Si, St, S)
+        if A.K2_qkv:
+            gemm(dq_i, A.Bbt_qkv, out=A.U_qkv[si])
+        if A.K2_aqkv:
+            gemm(dq_t, A.Bbt_aqkv, out=A.U_aqkv[st])
+        if A.need_input_grads:
+            kw = dict(a2=A.U_qkv[si], b2=A.At_qkv) if A.K2_qkv else {}
+            gemm(dq_i, A.wT_qkv, out=A.dn_img[si], **kw)
+            kw = dict(a2=A.U_aqkv[st], b2=A.At_aqkv) if A.K2_aqkv else {}
+            gemm(dq_t, A.wT_add_qkv, out=A.dn_txt[st], **kw)
+    if A.need_input_grads:
+        ln_modulate_bwd(A.dn_img, A.img, mi[:, D:2 * D], Si, dres=A.dx1_img, out=A.d_img_out)
+        ln_modulate_bwd(A.dn_txt, A.txt, mt[:, :D] if last else mt[:, D:2 * D], St, dres=None if last else A.dx1_txt, out=A.d_txt_out)
+
+
 _EMULATED = ("qk_rope", "attn_fwd_vrows", "attn_bwd_rope", "qk_rope_norm_bwd", "grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
              "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
-             "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd")
+             "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd", "block_pixart_fwd", "block_pixart_bwd", "block_sd3_joint_fwd", "block_sd3_joint_bwd")
 
 
 def install(monkeypatch):

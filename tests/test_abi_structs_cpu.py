@@ -14,7 +14,9 @@ from simpletuner_amd import lib
 ROOT = Path(__file__).resolve().parent.parent
 PAIRS = [("st355_gemm_args", lib.GemmArgs), ("st355_qk_rope", lib.QkRope), ("st355_vae_encoder", lib.VaeEncoder),
          ("st355_flux_single_fwd_args", lib.FluxSingleFwdArgs), ("st355_flux_single_bwd_args", lib.FluxSingleBwdArgs),
-         ("st355_flux_double_fwd_args", lib.FluxDoubleFwdArgs), ("st355_flux_double_bwd_args", lib.FluxDoubleBwdArgs)]
+         ("st355_flux_double_fwd_args", lib.FluxDoubleFwdArgs), ("st355_flux_double_bwd_args", lib.FluxDoubleBwdArgs),
+         ("st355_pixart_block_fwd_args", lib.PixartBlockFwdArgs), ("st355_pixart_block_bwd_args", lib.PixartBlockBwdArgs),
+         ("st355_sd3_joint_fwd_args", lib.Sd3JointFwdArgs), ("st355_sd3_joint_bwd_args", lib.Sd3JointBwdArgs)]
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="no host C compiler")
@@ -48,10 +50,12 @@ def test_block_entry_point_call_sites_name_every_struct_field():
     """the Flux engine fills the block-level argument structs by keyword (ops._fill): every keyword must be a field of the struct (a typo would otherwise go
     unnoticed on a CPU box) and every field but the workspaces the wrapper owns must be given — checked on the source, no GPU needed"""
     import re
-    src = (ROOT / "simpletuner_amd" / "flux" / "transformer.py").read_text()
+    flux = (ROOT / "simpletuner_amd" / "flux" / "transformer.py").read_text()
+    pixart = (ROOT / "simpletuner_amd" / "pixart" / "transformer.py").read_text()
     owned = {"gemm_ws", "gemm_ws_bytes", "attn_ws", "skinny_ws", "gA", "gB", "gA_qkv", "gB_qkv", "gA_out", "gB_out"}
-    for fn, st in (("block_flux_single_fwd", lib.FluxSingleFwdArgs), ("block_flux_double_fwd", lib.FluxDoubleFwdArgs),
-                   ("block_flux_single_bwd", lib.FluxSingleBwdArgs), ("block_flux_double_bwd", lib.FluxDoubleBwdArgs)):
+    for src, fn, st in ((flux, "block_flux_single_fwd", lib.FluxSingleFwdArgs), (flux, "block_flux_double_fwd", lib.FluxDoubleFwdArgs),
+                        (flux, "block_flux_single_bwd", lib.FluxSingleBwdArgs), (flux, "block_flux_double_bwd", lib.FluxDoubleBwdArgs),
+                        (pixart, "block_pixart_fwd", lib.PixartBlockFwdArgs), (pixart, "block_pixart_bwd", lib.PixartBlockBwdArgs)):
         i = src.index("ops." + fn + "(")
         depth, j = 0, i
         while True:

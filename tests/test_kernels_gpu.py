@@ -826,8 +826,8 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
         assert torch.equal(dQ2, dQ)                                       # (k_attn_bwd_dq64, where it applies, is bit-identical as well)
-        if d == 128 and kb is None:
-            # head_dim 128 without a key bias takes the hand-scheduled k_attn_bwd_dkv4 (same scores; the statistics ride in the MFMA chains: another
+        if d in (96, 128) and kb is None:
+            # head_dim 128 / 96 without a key bias take the hand-scheduled k_attn_bwd_dkv4 (same scores; the statistics ride in the MFMA chains: another
             # summation order): fp32-rounding agreement; dkv3 itself stays bit-identical to the copy-reading kernel
             assert report("dkv4 dK vs dkv2", dK2, dK)[0] < 2e-3 and report("dkv4 dV vs dkv2", dqkv2[:, 2 * D:], dqkv[:, 2 * D:])[0] < 2e-3
             prev = ops.attn_set_impl(dkv=3)

@@ -52,6 +52,7 @@ def test_controlnet_branch_gradients_through_the_emulator_match_autograd(monkeyp
     C = {k: v.float().clone().requires_grad_(True) for k, v in cn.adapter_state_dict().items()}
     lat, cond, enc, mask, t = _inputs()
     target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4))
+    EMU.BLOCK_CALLS.clear()
     out = cn(lat, encoder_hidden_states=enc, timestep=t, controlnet_cond=cond, encoder_attention_mask=mask, return_dict=False)[0]
     loss = ((out.chunk(2, dim=1)[0].float() - target) ** 2).mean()
     loss.backward()
@@ -59,6 +60,8 @@ def test_controlnet_branch_gradients_through_the_emulator_match_autograd(monkeyp
     lref = ((ref.chunk(2, dim=1)[0] - target) ** 2).mean()
     assert _rel(out.detach(), ref.detach()) < 2e-2 and abs(loss.item() - lref.item()) < 2e-3 * max(1.0, abs(lref.item()))
     lref.backward()
+    # every block ran through the block-level entry points (their emulation restates csrc/blocks.hip): st355_block_pixart_fwd / _bwd are the default path
+    assert EMU.BLOCK_CALLS.get("pixart_fwd", 0) >= ARCH["num_layers"] + 2 and EMU.BLOCK_CALLS.get("pixart_bwd", 0) >= 2, EMU.BLOCK_CALLS
     names = {}
     for i, (blk, ex) in enumerate(cn.cblocks):
         for k, g in blk.G.items():

@@ -146,3 +146,30 @@ def test_pixart_controlnet_checkpointed_gradients_equal_direct_gradients(mode, i
     assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.float().abs().sum().item() > 0
     print(f"[ckpt pixart controlnet] {mode}: memory held between forward and backward {kept0 / 2**20:.1f} MiB -> {kept1 / 2**20:.1f} MiB")
     assert kept1 < kept0
+
+
+@pytest.mark.parametrize("hw,Sk", [((16, 16), 20), ((16, 24), 77)])
+def test_pixart_block_c_entry_points_equal_host_sequencing(hw, Sk, monkeypatch):
+    """st355_block_pixart_fwd / st355_block_pixart_bwd (one BasicTransformerBlock(ada_norm_single) forward / the data path of its backward as
+    ONE C call each) issue the launches of the host-side sequencing (ST355_BLOCK_ABI=0) on the same operands: the ControlNet training step's prediction and
+    every gradient of the branch (weights, biases, modulation tables; the frozen trunk blocks behind the injection points carry the data gradient) are
+    bit-identical.  256 / 384 image tokens (S % 64 == 0: the 64-row attention kernels), 20 / 77 caption tokens (key padding inside the last 64-key tile)."""
+    import simpletuner_amd.pixart.transformer as PT
+    dev = "cuda:0"
+
+    def run(block_abi):
+        monkeypatch.setattr(PT, "_BLOCK_ABI", block_abi)
+        m = PT.PixArtTransformer2DModel(device=dev, **ARCH)
+        m.init_synthetic(5)
+        cn = PT.PixArtSigmaControlNetTransformerModel(m, num_layers=2)
+        cn.init_adapter_synthetic(seed=9, std=0.05)
+        lat, cond, enc, mask, t = (v.to(dev) for v in _inputs(hw=hw, Sk=Sk))
+        out = cn(lat, encoder_hidden_states=enc, timestep=t, controlnet_cond=cond, encoder_attention_mask=mask, return_dict=False)[0]
+        (out.float() ** 2).mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), cn.grad_arena.detach().clone()
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1) and g0.float().abs().sum().item() > 0
+    assert torch.equal(g0, g1), f"{(g0 != g1).sum().item()} of {g0.numel()} gradient elements differ"

@@ -72,7 +72,12 @@ def test_lora_path_through_the_emulator_matches_the_oracle(monkeypatch, sd35):
     model = _model(monkeypatch, 3, sd35)
     model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
     d = _inputs(2, 16, 24, 33)
+    EMU.BLOCK_CALLS.clear()
     out, loss = _hip_side(model, d)
+    # the single-attention blocks ran through the block-level entry points (their emulation restates csrc/blocks.hip), SD3.5's dual-attention blocks through
+    # the host-side sequencing
+    n_c = sum(1 for b in model.blocks if not b.dual)
+    assert EMU.BLOCK_CALLS.get("sd3_fwd", 0) == n_c and EMU.BLOCK_CALLS.get("sd3_bwd", 0) == n_c, (EMU.BLOCK_CALLS, n_c)
     _, lora, scale = PU.oracle_state(model)
     o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
     assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
@@ -92,7 +97,10 @@ def test_full_finetune_gradients_of_every_parameter_match_the_oracle(monkeypatch
     model = _model(monkeypatch, layers, sd35)
     model.enable_full_finetune()
     d = _inputs(B, lat_h, lat_w, S_txt)
+    EMU.BLOCK_CALLS.clear()
     out, loss = _hip_side(model, d)
+    n_c = sum(1 for b in model.blocks if not b.dual)
+    assert EMU.BLOCK_CALLS.get("sd3_fwd", 0) == n_c and EMU.BLOCK_CALLS.get("sd3_bwd", 0) == (0 if sd35 else n_c), (EMU.BLOCK_CALLS, n_c)
     o_out, o_loss, P, _ = _oracle_side(model, d, True)
     r = PU.rel_l2(out, o_out)
     assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())

@@ -426,3 +426,50 @@ def test_sd3_cfg_sampling_trajectory_matches_oracle_forward():
     r = PU.rel_l2(out, x)
     print(f"[sampling sd3] CFG {gs}, 4 Euler steps: final latents HIP vs oracle-driven loop rel-L2 {r:.3e}")
     assert torch.isfinite(out.float()).all() and r < 3e-2
+
+
+@pytest.mark.parametrize("mode,B,lat_h,lat_w,S_txt,kw", [
+    ("lora", 2, 32, 32, 33, {}),                                    # image rows tile-aligned (256: one segmented problem), 33 text rows through compact copies
+    ("lora_all", 2, 16, 24, 33, {}),                                # both streams through compact copies, adapters on the context projections too
+    ("lora_all", 1, 16, 24, 40, dict(qk_norm="rms_norm")),          # B = 1: plain 2-D problems; q / k RMSNorm weights (SD3.5-Large's form)
+    ("lora", 2, 80, 56, 24, dict(pos_embed_max_size=48)),           # 1120 image rows per sample, not tile-aligned: one problem per sample
+    ("full", 2, 32, 32, 33, {}),
+    ("full", 3, 16, 24, 154, {}),
+    ("full", 1, 16, 16, 40, {}),
+])
+def test_sd3_block_c_entry_points_equal_host_sequencing(mode, B, lat_h, lat_w, S_txt, kw, monkeypatch):
+    """st355_block_sd3_joint_fwd / st355_block_sd3_joint_bwd (one JointTransformerBlock forward / the data path of its backward as ONE C call
+    each, the context_pre_only last block included) against the host-side sequencing (ST355_BLOCK_ABI=0): prediction and every gradient — adapter gradients under
+    LoRA (default targets, and `all`: adapters on add_q/k/v_proj and to_add_out), every weight / bias / modulation gradient in a full fine-tune — bit-identical,
+    for every launch-shape policy of a stream's row block (single segmented problem, per sample, compact copies)."""
+    import simpletuner_amd.sd3.transformer as T
+    dev = "cuda:0"
+    arch = _arch(3)
+    arch.update(kw)
+
+    def run(block_abi):
+        monkeypatch.setattr(T, "_BLOCK_ABI", block_abi)
+        torch.manual_seed(0)
+        model = T.SD3Transformer2DModel(device=dev, **arch)
+        model.init_synthetic(seed=11)
+        model.prepare_for_training()
+        if mode == "full":
+            model.enable_full_finetune()
+        else:
+            model.add_lora_adapter(rank=16, alpha=16.0, targets="all" if mode == "lora_all" else "default", init_b_std=0.02)
+        g = torch.Generator().manual_seed(5)
+        bf = lambda t: t.to(torch.bfloat16).to(dev)
+        lat, prompt, pooled = bf(torch.randn(B, 16, lat_h, lat_w, generator=g)), bf(torch.randn(B, S_txt, 128, generator=g)), bf(torch.randn(B, 64, generator=g))
+        t = ((torch.rand(B, generator=g) * 0.8 + 0.1) * 1000.0).to(dev)
+        out = model(hidden_states=lat, encoder_hidden_states=prompt, pooled_projections=pooled, timestep=t, return_dict=False)[0]
+        (out.float() ** 2).mean().backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return out.detach().clone(), grads
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1), f"prediction: {(o0 != o1).sum().item()} of {o0.numel()} elements differ"
+    assert set(g0) == set(g1) and len(g0) > 0
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, bad[:8]
