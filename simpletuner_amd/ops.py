@@ -947,6 +947,9 @@ def upsample2x_bwd(dy, B: int, H: int, W: int):
     return dx
 
 
+BLOCK_CALLS = {}          # block-level entry point -> how often it ran (the GPU suite asserts that the engines really take them)
+
+
 def _fill(st, **kw):
     """tensors -> device pointers, None -> NULL, numbers as they are"""
     keep = []
@@ -969,6 +972,7 @@ def block_flux_single_fwd(**kw):
     ws = _gemm_workspace(kw["x"].device)
     a = _fill(_l.FluxSingleFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
     _l.check(L.st355_block_flux_single_fwd(_stream(), C.byref(a)), "block_flux_single_fwd")
+    BLOCK_CALLS["block_flux_single_fwd"] = BLOCK_CALLS.get("block_flux_single_fwd", 0) + 1
 
 
 def block_flux_double_fwd(**kw):
@@ -977,6 +981,7 @@ def block_flux_double_fwd(**kw):
     ws = _gemm_workspace(kw["img"].device)
     a = _fill(_l.FluxDoubleFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
     _l.check(L.st355_block_flux_double_fwd(_stream(), C.byref(a)), "block_flux_double_fwd")
+    BLOCK_CALLS["block_flux_double_fwd"] = BLOCK_CALLS.get("block_flux_double_fwd", 0) + 1
 
 
 def block_flux_double_bwd(grads, **kw):
@@ -1001,6 +1006,7 @@ def block_flux_double_bwd(grads, **kw):
         for i, t in enumerate(ts or []):
             _chk(t, F32, name); arr[i] = t.data_ptr()
     _l.check(L.st355_block_flux_double_bwd(_stream(), C.byref(a)), "block_flux_double_bwd")
+    BLOCK_CALLS["block_flux_double_bwd"] = BLOCK_CALLS.get("block_flux_double_bwd", 0) + 1
 
 
 def block_flux_single_bwd(gA, gB, **kw):
@@ -1025,6 +1031,7 @@ def block_flux_single_bwd(gA, gB, **kw):
     for i, t in enumerate(gB or []):
         _chk(t, F32, "gB"); a.gB[i] = t.data_ptr()
     _l.check(L.st355_block_flux_single_bwd(_stream(), C.byref(a)), "block_flux_single_bwd")
+    BLOCK_CALLS["block_flux_single_bwd"] = BLOCK_CALLS.get("block_flux_single_bwd", 0) + 1
 
 
 def block_pixart_fwd(**kw):
@@ -1032,6 +1039,7 @@ def block_pixart_fwd(**kw):
     L = _l.load()
     a = _fill(_l.PixartBlockFwdArgs(), **kw)
     _l.check(L.st355_block_pixart_fwd(_stream(), C.byref(a)), "block_pixart_fwd")
+    BLOCK_CALLS["block_pixart_fwd"] = BLOCK_CALLS.get("block_pixart_fwd", 0) + 1
 
 
 def block_pixart_bwd(**kw):
@@ -1045,6 +1053,7 @@ def block_pixart_bwd(**kw):
         aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
     a = _fill(_l.PixartBlockBwdArgs(), attn_ws=aws, **kw)
     _l.check(L.st355_block_pixart_bwd(_stream(), C.byref(a)), "block_pixart_bwd")
+    BLOCK_CALLS["block_pixart_bwd"] = BLOCK_CALLS.get("block_pixart_bwd", 0) + 1
 
 
 def block_sd3_joint_fwd(**kw):
@@ -1053,6 +1062,7 @@ def block_sd3_joint_fwd(**kw):
     ws = _gemm_workspace(kw["img"].device)
     a = _fill(_l.Sd3JointFwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, **kw)
     _l.check(L.st355_block_sd3_joint_fwd(_stream(), C.byref(a)), "block_sd3_joint_fwd")
+    BLOCK_CALLS["block_sd3_joint_fwd"] = BLOCK_CALLS.get("block_sd3_joint_fwd", 0) + 1
 
 
 def block_sd3_joint_bwd(**kw):
@@ -1067,6 +1077,7 @@ def block_sd3_joint_bwd(**kw):
     ws = _gemm_workspace(dev)
     a = _fill(_l.Sd3JointBwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, attn_ws=aws, **kw)
     _l.check(L.st355_block_sd3_joint_bwd(_stream(), C.byref(a)), "block_sd3_joint_bwd")
+    BLOCK_CALLS["block_sd3_joint_bwd"] = BLOCK_CALLS.get("block_sd3_joint_bwd", 0) + 1
 
 
 class VaeEncoderTable:

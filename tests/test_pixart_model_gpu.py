@@ -169,7 +169,11 @@ def test_pixart_block_c_entry_points_equal_host_sequencing(hw, Sk, monkeypatch):
         torch.cuda.synchronize()
         return out.detach().clone(), cn.grad_arena.detach().clone()
 
+    from simpletuner_amd import ops
     o0, g0 = run(False)
+    ops.BLOCK_CALLS.clear()
     o1, g1 = run(True)
+    # 4 trunk blocks + 2 branch blocks forward; backward: the branch blocks and the trunk blocks behind the first injection point
+    assert ops.BLOCK_CALLS.get("block_pixart_fwd", 0) == 6 and ops.BLOCK_CALLS.get("block_pixart_bwd", 0) >= 4, ops.BLOCK_CALLS
     assert torch.equal(o0, o1) and g0.float().abs().sum().item() > 0
     assert torch.equal(g0, g1), f"{(g0 != g1).sum().item()} of {g0.numel()} gradient elements differ"

@@ -467,8 +467,11 @@ def test_sd3_block_c_entry_points_equal_host_sequencing(mode, B, lat_h, lat_w, S
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         return out.detach().clone(), grads
 
+    from simpletuner_amd import ops
     o0, g0 = run(False)
+    ops.BLOCK_CALLS.clear()
     o1, g1 = run(True)
+    assert ops.BLOCK_CALLS.get("block_sd3_joint_fwd", 0) == 3 and ops.BLOCK_CALLS.get("block_sd3_joint_bwd", 0) == 3, ops.BLOCK_CALLS
     assert torch.equal(o0, o1), f"prediction: {(o0 != o1).sum().item()} of {o0.numel()} elements differ"
     assert set(g0) == set(g1) and len(g0) > 0
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
