@@ -138,19 +138,27 @@ def lora_targets(cfg: SD3Config):
     return t
 
 
-def joint_block(P, cfg: SD3Config, i: int, hidden, enc, temb, lora=None, lora_scale=1.0):
-    """sd3/transformer.py:145-241 (no dual attention).  Returns (enc | None, hidden)."""
+def joint_block(P, cfg: SD3Config, i: int, hidden, enc, temb, lora=None, lora_scale=1.0, temb_context=None):
+    """sd3/transformer.py:145-241.  Returns (enc | None, hidden).  temb [B, D]; or TOKENWISE, temb [B, S_img, D] with temb_context [B, D] = its mean over the
+    tokens (:126-142 `_sd3_apply_ada_layer_norm_zero`, :680-685): the image stream's shift / scale / gate rows are then per token, the context stream's per sample."""
     pfx = f"transformer_blocks.{i}."
     last = i == cfg.num_layers - 1
     H = cfg.num_attention_heads
-    st = F.silu(temb)
+    tokenwise = temb.ndim == 3
+    st_i = F.silu(temb)
+    st = F.silu(temb_context) if tokenwise else st_i
     dual = i in cfg.dual_attention_layers
     if dual:            # SD35AdaLayerNormZeroX: 9 chunks, the last three modulate the input of the second (image-only) attention
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp, shift_msa2, scale_msa2, gate_msa2 = linear(st, P, pfx + "norm1.linear").chunk(9, dim=1)
+        if tokenwise:
+            raise ValueError("tokenwise timesteps with SD3.5 dual-attention blocks: the reference hands the [B, S, D] embedding to SD35AdaLayerNormZeroX, "
+                             "which chunks dim 1 (the tokens) — not a defined computation")
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp, shift_msa2, scale_msa2, gate_msa2 = linear(st_i, P, pfx + "norm1.linear").chunk(9, dim=1)
         n2a = layer_norm(hidden) * (1 + scale_msa2[:, None]) + shift_msa2[:, None]
     else:
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = linear(st, P, pfx + "norm1.linear").chunk(6, dim=1)
-    n = layer_norm(hidden) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = linear(st_i, P, pfx + "norm1.linear").chunk(6, dim=-1)
+    if not tokenwise:
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (t[:, None] for t in (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp))
+    n = layer_norm(hidden) * (1 + scale_msa) + shift_msa
     if last:
         c_scale, c_shift = linear(st, P, pfx + "norm1_context.linear").chunk(2, dim=1)      # AdaLayerNormContinuous: scale first
         cn = layer_norm(enc) * (1 + c_scale[:, None]) + c_shift[:, None]
@@ -169,7 +177,7 @@ def joint_block(P, cfg: SD3Config, i: int, hidden, enc, temb, lora=None, lora_sc
     o = o.transpose(1, 2).reshape(B, S, -1)
     Si = hidden.shape[1]
     io, co = o[:, :Si], o[:, Si:]
-    hidden = hidden + gate_msa[:, None] * linear(io, P, a + "to_out.0", lora, lora_scale)
+    hidden = hidden + gate_msa * linear(io, P, a + "to_out.0", lora, lora_scale)
     if dual:            # sd3/transformer.py:190-197: attn2 = self-attention over the image tokens only, added after the joint-attention residual
         a2 = pfx + "attn2."
         q2, k2, v2 = (_heads(linear(n2a, P, a2 + nm, lora, lora_scale), H) for nm in ("to_q", "to_k", "to_v"))
@@ -177,8 +185,8 @@ def joint_block(P, cfg: SD3Config, i: int, hidden, enc, temb, lora=None, lora_sc
             q2 = rms_norm(q2, P[a2 + "norm_q.weight"]); k2 = rms_norm(k2, P[a2 + "norm_k.weight"])
         o2 = sdpa(q2, k2, v2).transpose(1, 2).reshape(B, Si, -1)
         hidden = hidden + gate_msa2[:, None] * linear(o2, P, a2 + "to_out.0", lora, lora_scale)
-    n2 = layer_norm(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-    hidden = hidden + gate_mlp[:, None] * linear(F.gelu(linear(n2, P, pfx + "ff.net.0.proj"), approximate="tanh"), P, pfx + "ff.net.2")
+    n2 = layer_norm(hidden) * (1 + scale_mlp) + shift_mlp
+    hidden = hidden + gate_mlp * linear(F.gelu(linear(n2, P, pfx + "ff.net.0.proj"), approximate="tanh"), P, pfx + "ff.net.2")
     if last:
         return None, hidden
     enc = enc + c_gate_msa[:, None] * linear(co, P, a + "to_add_out", lora, lora_scale)
@@ -198,8 +206,18 @@ def sd3_forward(P, cfg: SD3Config, latents, encoder_hidden_states, pooled_projec
     x = F.conv2d(latents, P["pos_embed.proj.weight"], P["pos_embed.proj.bias"], stride=p).flatten(2).transpose(1, 2)   # [B, hw, D]
     hidden = x + cropped_pos_embed(P["pos_embed.pos_embed"][0], cfg.pos_embed_max_size, h, w)[None].to(x.dtype)
     dt = pooled_projections.dtype
-    temb = mlp_embed(timestep_proj(timestep.float()).to(dt), P, "time_text_embed.timestep_embedder") + \
-        mlp_embed(pooled_projections, P, "time_text_embed.text_embedder")
+    temb_context = None
+    if timestep.ndim == 2:          # TOKENWISE timesteps [B, S_img] (:61-75 `_sd3_tokenwise_conditioning`, :625-626, :680-685): one conditioning row per image token
+        if timestep.shape != (B, h * w):
+            raise ValueError(f"SD3 tokenwise timesteps expected sequence length {h * w}, got {timestep.shape[1]}.")
+        temb = mlp_embed(timestep_proj(timestep.reshape(-1).float()).to(dt), P, "time_text_embed.timestep_embedder").view(B, h * w, -1) + \
+            mlp_embed(pooled_projections, P, "time_text_embed.text_embedder")[:, None]
+        temb_context = temb.mean(dim=1)
+        if tread:
+            raise ValueError("tokenwise timesteps under TREAD routing are not restated")
+    else:
+        temb = mlp_embed(timestep_proj(timestep.float()).to(dt), P, "time_text_embed.timestep_embedder") + \
+            mlp_embed(pooled_projections, P, "time_text_embed.text_embedder")
     enc = linear(encoder_hidden_states, P, "context_embedder")
     routes = [dict(r, start_layer_idx=r["start_layer_idx"] % cfg.num_layers, end_layer_idx=r["end_layer_idx"] % cfg.num_layers)
               for r in (tread or {}).get("routes", [])]
@@ -209,12 +227,14 @@ def sd3_forward(P, cfg: SD3Config, latents, encoder_hidden_states, pooled_projec
         if ptr < len(routes) and i == routes[ptr]["start_layer_idx"]:
             info, saved = infos[ptr], hidden
             hidden = tread_start(hidden, info)
-        enc, hidden = joint_block(P, cfg, i, hidden, enc, temb, lora, lora_scale)
+        enc, hidden = joint_block(P, cfg, i, hidden, enc, temb, lora, lora_scale, temb_context)
         if info is not None and i == routes[ptr]["end_layer_idx"]:
             hidden = tread_end(hidden, info, saved)
             info, saved, ptr = None, None, ptr + 1
-    scale, shift = linear(F.silu(temb), P, "norm_out.linear").chunk(2, dim=1)
-    hidden = layer_norm(hidden) * (1 + scale[:, None]) + shift[:, None]
+    scale, shift = linear(F.silu(temb), P, "norm_out.linear").chunk(2, dim=-1)          # :876 norm_out takes temb_hidden: per token when tokenwise
+    if temb.ndim == 2:
+        scale, shift = scale[:, None], shift[:, None]
+    hidden = layer_norm(hidden) * (1 + scale) + shift
     out = linear(hidden, P, "proj_out")                                    # [B, hw, p*p*C]
     out = out.reshape(B, h, w, p, p, cfg.out_channels)
     return torch.einsum("nhwpqc->nchpwq", out).reshape(B, cfg.out_channels, h * p, w * p)

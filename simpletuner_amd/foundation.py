@@ -331,13 +331,15 @@ class ModelFoundation(ExplorativeModelingMixin):
             model, seen = model.module, seen + 1
         return model
 
-    def _require_per_sample_timesteps(self, prepared_batch: dict):
+    def _require_per_sample_timesteps(self, prepared_batch: dict, tokenwise_ok: bool = False):
         """The reference's DiT plugins also accept TOKENWISE timesteps [B, S] (CREPA self-flow; tests/test_flux_model.py:213-241,
         tests/test_sd3_model.py:179-204, tests/test_pixart_model.py:91-115) and clean conditioning tokens appended at t=0 (Flux Kontext,
-        tests/test_flux_model.py:243-272).  Both need per-token modulation, which the fused AdaLN kernels (one [B, 6D] modulation row per image) do
-        not implement: refuse loudly instead of training on the wrong conditioning."""
+        tests/test_flux_model.py:243-272).  Both need per-token modulation rows.  Built for SD3 (`tokenwise_ok`: sd3/transformer.py runs the AdaLN /
+        gated-residual kernels with one modulation row per image token); Flux and PixArt refuse loudly instead of training on the wrong conditioning."""
         t = prepared_batch["timesteps"]
-        if getattr(t, "ndim", 1) != 1:
+        if getattr(t, "ndim", 1) == 2 and tokenwise_ok:
+            pass
+        elif getattr(t, "ndim", 1) != 1:
             raise NotImplementedError(f"tokenwise timesteps {tuple(t.shape)} are not implemented on the st355 path (per-sample [B] only)")
         if prepared_batch.get("conditioning_packed_latents") is not None:
             raise NotImplementedError("conditioning_packed_latents (reference-image tokens) are not implemented on the st355 path")

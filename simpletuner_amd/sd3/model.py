@@ -52,7 +52,7 @@ class SD3(ModelFoundation):
 
     def _model_predict_single(self, prepared_batch: dict):
         """sd3/model.py:540-570"""
-        self._require_per_sample_timesteps(prepared_batch)
+        self._require_per_sample_timesteps(prepared_batch, tokenwise_ok=True)      # [B] or tokenwise [B, S_img], handed through unchanged (sd3/model.py:542)
         dev = self.accelerator.device
         model_pred = self.model(
             hidden_states=prepared_batch["noisy_latents"].to(device=dev, dtype=BF16),

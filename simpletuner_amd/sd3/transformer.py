@@ -350,11 +350,12 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, Si, St, S, Sp, cos, sin, mod, scale, full = env.B, env.Si, env.St, env.S, env.Sp, env.cos, env.sin, env.mod, env.scale, env.full
         ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
-        if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and img.is_contiguous() and txt.is_contiguous():
+        rpb = 1 if env.rpb_i == 1 else Si     # rows of the image stream that share one modulation row: the sample's (inside a TREAD route: its kept) rows, or 1 under tokenwise timesteps
+        if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and img.is_contiguous() and txt.is_contiguous() and rpb == Si:
             return self._block_fwd_c(blk, img, txt, env, save, ybuf)
 
-        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
-        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+        mi = env.mod_i[:, blk.mod_off:blk.mod_off + 6 * D]
+        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], rpb)
         if blk.last:
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + 2 * D]
             n_txt = ops.ln_modulate_fwd(txt, mt[:, :D], mt[:, D:2 * D], St)          # AdaLayerNormContinuous: (scale, shift)
@@ -405,7 +406,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
             kw_i.update(a2=T_o, b2=blk.to_out.lora.B_blk)
         probs = _stream_problems(B, S, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
-                                                gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i), after)
+                                                gate=mi[:, 2 * D:3 * D], rows_per_batch=rpb, **kw_i), after)
         if not blk.last:
             if T_ao is not None:
                 for pr in _stream_problems(B, S, St, dict(a=O_t, w=blk.to_add_out.lora.A_cat, out=T_ao), after):
@@ -420,7 +421,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         if blk.dual:
             # attn2: self-attention over the image tokens only, input = LN(img) modulated by chunks 7 / 8 (shift_msa2, scale_msa2), residual gated by chunk 9
             # onto the stream AFTER the joint-attention residual (sd3/transformer.py:190-197)
-            mi9 = mod[:, blk.mod_off:blk.mod_off + 9 * D]
+            mi9 = mod[:, blk.mod_off:blk.mod_off + 9 * D]                        # (dual blocks never run tokenwise: refused in _engine_forward)
             Sip = (Si + 63) // 64 * 64
             n2a = ops.ln_modulate_fwd(img, mi9[:, 7 * D:8 * D], mi9[:, 6 * D:7 * D], Si)
             T2 = ops.gemm(n2a, blk.qkv2.lora.A_cat) if blk.qkv2.lora is not None else None
@@ -445,7 +446,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             x1b_img = ops.gemm(O2, blk.to_out2.w, bias=blk.to_out2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi9[:, 8 * D:9 * D], rows_per_batch=Si, **kw2)
             d2 = SimpleNamespace(n2a=n2a, qkv2=qkv2, T2=T2, Q2=Q2, K2=K2, Q2t=Q2t, K2t=K2t, O2=O2, lse2b=lse2b, ya2=ya2, T_o2=T_o2, Sip=Sip)
             x1_img = x1b_img                       # what the MLP branch (and its residual) sees
-        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], rpb)
         hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev)
         hpre_txt = x2_txt = n2_t = h_t = None
         yf_i, yf_t = ybuf(B * Si), (None if blk.last else ybuf(B * St))
@@ -454,14 +455,14 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         if blk.last:
             h_i = ops.gemm(n2_i, blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img)
             x2_img = ops.gemm(h_i, blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D],
-                              rows_per_batch=Si, **kf_i)
+                              rows_per_batch=rpb, **kf_i)
         else:
             n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
             hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
             h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
                                          dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
             x2_img, x2_txt = ops.gemm_grouped([
-                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=rpb, **kf_i),
                 dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
         if save:
             sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=n_txt if (T_txt is not None or full) else None, qkv=qkv, Q=Q, K=K,
@@ -586,20 +587,47 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         img = ops.gemm(patches, self.l_patch.w, bias=self.l_patch.b, epilogue=EPI_ADD, aux_in=pos)
         enc2d = enc.reshape(B * St, -1).contiguous()
         txt = ops.gemm(enc2d, self.l_ctx.w, bias=self.l_ctx.b)
-        t32 = timestep.to(device=dev, dtype=F32).contiguous()
+        tokenwise = timestep.dim() == 2
+        if tokenwise and tuple(timestep.shape) != (B, Si):
+            raise ValueError(f"SD3 tokenwise timesteps expected sequence length {Si}, got {timestep.shape[1]}.")      # sd3/transformer.py:625-626
+        t32 = timestep.to(device=dev, dtype=F32).reshape(-1).contiguous()
         tproj = ops.timestep_proj(t32, 256, 1.0)
         t1 = ops.gemm(tproj, self.l_t1.w, bias=self.l_t1.b); st1 = ops.silu(t1)
         pooled_b = pooled.to(BF16).contiguous()
         p1 = ops.gemm(pooled_b, self.l_p1.w, bias=self.l_p1.b); sp1 = ops.silu(p1)
-        temb = ops.add(ops.gemm(st1, self.l_t2.w, bias=self.l_t2.b), ops.gemm(sp1, self.l_p2.w, bias=self.l_p2.b))
+        mod_i, rpb_i = None, Si
+        if tokenwise:
+            # TOKENWISE timesteps [B, S_img] (CREPA self-flow; sd3/transformer.py:61-75, 126-142, 680-685, 876): one conditioning row per image token — the image
+            # stream's shift / scale / gate rows and norm_out's (scale, shift) are per TOKEN (the AdaLN / gated-residual kernels index their modulation row by
+            # row // rows_per_batch: rows_per_batch = 1), the context stream is conditioned on the mean over the tokens.  The per-token modulation rows of every
+            # block are ONE GEMM [B * S_img, D] x [mod_total, D]^T (B * S_img * mod_total bf16: 14 GB for SD3-Medium at 1024^2, batch 8 — HBM holds it).
+            if full:
+                raise NotImplementedError("tokenwise timesteps under a full fine-tune (per-token modulation gradients) are not implemented on the st355 path")
+            if any(b.dual for b in self.blocks):
+                raise NotImplementedError("tokenwise timesteps with SD3.5 dual-attention blocks: the reference chunks SD35AdaLayerNormZeroX's [B, S, 9D] output along the "
+                                          "token axis (sd3/transformer.py:155-164) — not a defined computation")
+            if B > 1 and Si % 256:
+                raise NotImplementedError(f"tokenwise timesteps with per-GPU batch > 1 need the image rows per sample ({Si}) to be a multiple of 256 (per-sample "
+                                          "problem forms slice the modulation rows per sample)")
+            pe = ops.gemm(sp1, self.l_p2.w, bias=self.l_p2.b)                                         # [B, D]: the pooled-text embedding, shared by a sample's tokens
+            temb_tok = ops.gemm(st1, self.l_t2.w, bias=self.l_t2.b, epilogue=EPI_ADD, aux_in=pe[:, None, :].expand(B, Si, D).reshape(B * Si, D))
+            tsum = torch.empty(B, D, dtype=F32, device=dev)
+            ops.colsum_prod(temb_tok, tsum, rows_per_batch=Si)
+            temb = (tsum / Si).to(BF16)                                                               # temb_context = temb.mean(dim=1)   (:681-682)
+            mod_i = ops.gemm(ops.silu(temb_tok), self.mod_w, bias=self.mod_b)                         # [B * S_img, mod_total]
+            rpb_i = 1
+        else:
+            temb = ops.add(ops.gemm(st1, self.l_t2.w, bias=self.l_t2.b), ops.gemm(sp1, self.l_p2.w, bias=self.l_p2.b))
         st = ops.silu(temb)
         mod = ops.gemm(st, self.mod_w, bias=self.mod_b)
-        ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, blocks=[], C=C, Hh=Hh, Ww=Ww)
+        if mod_i is None:
+            mod_i = mod
+        ctx = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, mod_i=mod_i, rpb_i=rpb_i, blocks=[], C=C, Hh=Hh, Ww=Ww)
         if full and save:
             ctx.emb = SimpleNamespace(patches=patches, enc2d=enc2d, tproj=tproj, t1=t1, st1=st1, pooled=pooled_b, p1=p1, sp1=sp1, temb=temb, st=st)
         ybuf = (lambda rows: torch.empty(rows, D, dtype=BF16, device=dev)) if (full and save) else (lambda rows: None)
         scale = 1.0 / math.sqrt(hd)
-        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, scale=scale, full=full)
+        env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, mod=mod, mod_i=mod_i, rpb_i=rpb_i, scale=scale, full=full)
         ctx.env, ctx.blocks, ctx.ck = env, [None] * len(self.blocks), {}
         # activation-checkpoint plan (sd3/transformer.py:716-833; training/checkpoint_plan.py): a checkpointed segment keeps only its input
         from ..training.checkpoint_plan import segments as _segments
@@ -609,6 +637,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         # per-sample subset of its tokens.  Under routing the reference drops the segmented checkpoint form for the per-block one (:716-728)
         from ..training.tread import normalise_routes
         routes = normalise_routes(self._tread_routes, len(self.blocks)) if (save and self.training and self._tread_router is not None) else []
+        if routes and tokenwise:
+            raise NotImplementedError("tokenwise timesteps under TREAD routing (the routed tokens' modulation rows would be gathered too) are not implemented")
         if routes:
             from ..training.checkpoint_plan import per_block as _per_block
             ctx.segs = _per_block(len(self.blocks), bool(self.gradient_checkpointing), self.gradient_checkpointing_interval, self.gradient_checkpointing_segment_stride)
@@ -635,8 +665,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         if info is not None:
             raise ValueError("TREAD route does not end inside the block stack (end_layer_idx)")
         # ---- output head: AdaLayerNormContinuous (scale, shift), proj_out, unpatchify "nhwpqc->nchpwq" ----
-        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
-        n_out = ops.ln_modulate_fwd(img, mo[:, :D], mo[:, D:2 * D], Si)
+        mo = mod_i[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        n_out = ops.ln_modulate_fwd(img, mo[:, :D], mo[:, D:2 * D], rpb_i)
         out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
         if save:
             ctx.x_img_final = img
@@ -663,9 +693,10 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         dev = self.device_
         scale = 1.0 / math.sqrt(hd)
         dpk = ops.patchify(dout.to(BF16).contiguous(), order=1).view(B * Si, -1)
-        mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
+        mod_i, rpb = ctx.mod_i, ctx.rpb_i          # the image stream's modulation rows: per sample, or per token under tokenwise timesteps (rows_per_batch = 1)
+        mo = mod_i[:, self.mod_off_out:self.mod_off_out + 2 * D]
         dn = ops.gemm(dpk, self.l_out.wT)
-        d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], Si)
+        d_img, _ = ops.ln_modulate_bwd(dn, ctx.x_img_final, mo[:, :D], rpb)
         d_txt = None
         del dn, dpk
         for li in range(len(self.blocks) - 1, -1, -1):
@@ -678,9 +709,10 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             Si, S, Sp = ctx.envs[li].Si, ctx.envs[li].S, ctx.envs[li].Sp
             blk, sv = self.blocks[li], ctx.blocks[li]
             ctx.blocks[li] = None
-            mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]
+            mi = mod_i[:, blk.mod_off:blk.mod_off + 6 * D]
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + (2 if blk.last else 6) * D]
-            if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and sv.Qt is None and d_img.is_contiguous() and (d_txt is None or d_txt.is_contiguous()):
+            rpb_i = rpb if rpb == 1 else Si             # (inside a TREAD route Si is the kept-token count)
+            if _BLOCK_ABI and not blk.dual and ops.ATTN_TR and sv.Qt is None and d_img.is_contiguous() and (d_txt is None or d_txt.is_contiguous()) and rpb != 1:
                 # the data path as ONE C entry point (st355_block_sd3_joint_bwd), then the rank-space adapter gradients from the gradients it left behind
                 envs = SimpleNamespace(B=B, S=S)
                 d_img, d_txt, G = self._block_bwd_c(blk, sv, ctx.envs[li], mod, cos, sin, d_img, d_txt, li != 0)
@@ -698,7 +730,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                     ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
                     d_img, d_full = d_full, None
                 continue
-            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)
+            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], rpb_i)
             if blk.last:
                 dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
                 dn2_i = ops.gemm(dh_i, blk.ff1.wT)
@@ -733,7 +765,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 dx1g_i = ops.scale_cols(dx1_i, mi[:, 2 * D:3 * D], Si)
                 del dxg2, dO2, dQ2, dK2, dqkv2, U2, Uq2, d2
             else:
-                dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+                dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], rpb_i, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
             del g_i, dh_i, dn2_i
             # attention output projections -> dO rows of both streams (+ adapter grads); a context_pre_only block has no txt rows
             dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
@@ -784,7 +816,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 if lin.lora is not None:
                     lin.lora.grads(n_in, T_, dq, Us[name], self.accumulate_lora_grads, self.grad_sync)
             if not first:
-                d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+                d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], rpb_i, dres=dx1_i)
                 if dn2a is not None:             # the second reader of LN(img): attn2's modulated input (scale_msa2)
                     d_img, _ = ops.ln_modulate_bwd(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dres=d_img)
                 c_scale = mt[:, :D] if blk.last else mt[:, D:2 * D]
@@ -1083,8 +1115,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         for k, v in unsupported.items():
             if v is not None and v is not False:
                 raise NotImplementedError(f"SD3Transformer2DModel(st355): argument {k!r} is not supported on the HIP path")
-        if timestep.ndim != 1:
-            raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
+        if timestep.ndim not in (1, 2):
+            raise ValueError(f"timestep: expected [B] or tokenwise [B, S_img], got {tuple(timestep.shape)}")
         need_grad = torch.is_grad_enabled() and (len(self._lora_params) > 0 or getattr(self, "full", False))
         if need_grad and not self._prepared and not getattr(self, "full", False):
             self.prepare_for_training()      # K-major dgrad operands went stale (new weights / replica start-state broadcast): rebuild lazily

@@ -170,6 +170,30 @@ def test_sd3_oracle_reproduces_reference_model(variant, case):
     print(f"[pinned] sd3 {variant}/{case}: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
 
 
+def test_sd3_oracle_reproduces_reference_model_with_tokenwise_timesteps():
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; reference tests/test_sd3_model.py:179-204): the reference's SD3Transformer2DModel executed with one
+    timestep per image token (tools/gen_ref_tokenwise.py) — per-token AdaLN rows on the image stream and in norm_out, their mean on the context stream; output
+    and EVERY parameter / input gradient of oracle.sd3 to <= 1e-5"""
+    V = _load("ref_tokenwise.pt")["sd3"]
+    cfg = _sd3_cfg(V["config"])
+    P = _sd3_params(cfg, V["seed"], V["state_checksum"])
+    assert rel_l2(P["pos_embed.pos_embed"], V["pos_embed_table"]) <= 1e-6
+    P = {k: (v.requires_grad_(True) if k != "pos_embed.pos_embed" else v) for k, v in P.items()}
+    R = V["case"]
+    I = R["inputs"]
+    assert I["timestep"].ndim == 2
+    leaves = {k: I[k].clone().requires_grad_(True) for k in ("hidden_states", "encoder_hidden_states", "pooled_projections")}
+    out = OS.sd3_forward(P, cfg, leaves["hidden_states"], leaves["encoder_hidden_states"], leaves["pooled_projections"], I["timestep"])
+    r = rel_l2(out, R["out"])
+    assert r <= TOL, f"sd3 tokenwise: output rel-L2 {r:.3e}"
+    (out * R["w"]).sum().backward()
+    worst = _check_grads(P, R["grads"], "sd3 tokenwise")
+    for k, g in R["input_grads"].items():
+        if k in leaves:
+            assert rel_l2(leaves[k].grad, g) <= TOL, k
+    print(f"[pinned] sd3 tokenwise: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
+
+
 @pytest.mark.parametrize("variant", ["sd3", "sd35"])
 def test_sd3_oracle_reproduces_reference_model_at_kernel_head_width(variant):
     H = _load("ref_sd3_model.pt")["hip"][variant]

@@ -229,3 +229,42 @@ def test_cfg_sampling_trajectory_through_the_emulator_matches_the_oracle_driven_
             pred = OS.sd3_forward(P, _ocfg(model), torch.cat([x, x], 0), pe, pp, t.expand(4), lora=lora, lora_scale=scale)
             x = x + (sc.sigmas[i + 1] - sc.sigmas[i]) * cfg_combine(pred, gs)
     assert torch.isfinite(out.float()).all() and PU.rel_l2(out, x) < 3e-2
+
+
+@pytest.mark.parametrize("B,lat_h,lat_w", [(1, 16, 24), (2, 32, 32)])
+def test_tokenwise_timesteps_through_the_emulator_match_the_oracle(monkeypatch, B, lat_h, lat_w):
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; the reference's tests/test_sd3_model.py:179-204 hands them to the transformer; oracle branch pinned to the
+    executed reference by tests/test_ref_models_cpu.py): per-token AdaLN rows on the image stream and in norm_out (rows_per_batch = 1), the token mean on the
+    context stream; prediction and LoRA gradients against autograd on the oracle.  B = 2 with 256 image rows per sample: segmented problems over per-token gates."""
+    model = _model(monkeypatch, 3)
+    model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
+    d = _inputs(B, lat_h, lat_w, 33)
+    Si = (lat_h // 2) * (lat_w // 2)
+    d["t"] = torch.rand(B, Si, generator=torch.Generator().manual_seed(8)) * 900.0 + 50.0
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    # ... and it is not the batch-wise forward in disguise: conditioning every token on its sample's mean timestep moves the prediction
+    d_flat = dict(d, t=d["t"].mean(dim=1))
+    with torch.no_grad():
+        out_flat = model(hidden_states=d_flat["lat"], encoder_hidden_states=d_flat["prompt"], pooled_projections=d_flat["pooled"], timestep=d_flat["t"], return_dict=False)[0]
+    assert PU.rel_l2(out_flat, o_out) > 5e-2
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        worst = max(worst, PU.rel_l2(p.grad, ref))
+        assert PU.rel_l2(p.grad, ref) < 5e-2, name
+    print(f"[emu] sd3 tokenwise timesteps B{B}: pred rel_l2={PU.rel_l2(out, o_out):.3e}, worst adapter gradient rel_l2={worst:.3e}")
+
+
+def test_tokenwise_timesteps_refusals(monkeypatch):
+    model = _model(monkeypatch, 2)
+    d = _inputs(2, 16, 24, 33)
+    with torch.no_grad(), pytest.raises(ValueError, match="expected sequence length"):
+        model(hidden_states=d["lat"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=torch.rand(2, 7) * 1000, return_dict=False)
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="multiple of 256"):
+        model(hidden_states=d["lat"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=torch.rand(2, 96) * 1000, return_dict=False)

@@ -476,3 +476,41 @@ def test_sd3_block_c_entry_points_equal_host_sequencing(mode, B, lat_h, lat_w, S
     assert set(g0) == set(g1) and len(g0) > 0
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("B,lat_h,lat_w,S_txt", [(1, 16, 24, 33), (2, 32, 32, 40)])
+def test_sd3_tokenwise_timesteps_match_oracle(B, lat_h, lat_w, S_txt):
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; reference tests/test_sd3_model.py:179-204; sd3/transformer.py:61-75, 126-142, 680-685, 876) on the HIP
+    path: the AdaLN / gated-residual / scale kernels run with ONE modulation row per image token (rows_per_batch = 1), the context stream on the token mean.
+    Prediction and LoRA gradients vs autograd on the oracle, whose tokenwise branch is pinned to the executed reference (tests/test_ref_models_cpu.py)."""
+    import simpletuner_amd.sd3.transformer as T
+    dev = "cuda:0"
+    model = T.SD3Transformer2DModel(device=dev, **_arch(3))
+    model.init_synthetic(seed=11)
+    model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
+    g = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16)
+    Si = (lat_h // 2) * (lat_w // 2)
+    lat, prompt, pooled = bf(torch.randn(B, 16, lat_h, lat_w, generator=g)), bf(torch.randn(B, S_txt, 128, generator=g)), bf(torch.randn(B, 64, generator=g))
+    t = torch.rand(B, Si, generator=g) * 900.0 + 50.0
+    target = bf(torch.randn(B, 16, lat_h, lat_w, generator=g))
+    out = model(hidden_states=lat.to(dev), encoder_hidden_states=prompt.to(dev), pooled_projections=pooled.to(dev), timestep=t.to(dev), return_dict=False)[0]
+    loss = ((out.float() - target.to(dev).float()) ** 2).mean()
+    loss.backward()
+    P, lora, scale = _oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    o_out = OS.sd3_forward(P, _ocfg(model), lat.float(), prompt.float(), pooled.float(), t, lora=lp, lora_scale=scale)
+    o_loss = ((o_out - target.float()) ** 2).mean()
+    o_loss.backward()
+    r = PU.rel_l2(out.detach().cpu(), o_out.detach())
+    assert r < 2e-2 and PU.cos_sim(out.detach().cpu(), o_out.detach()) > 0.9995 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, o_loss.item())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        rg = PU.rel_l2(p.grad.cpu(), ref)
+        worst = max(worst, rg)
+        assert rg < 5e-2, (name, rg)
+    print(f"[sd3 tokenwise] B{B} S_img {Si}: pred rel-L2 {r:.3e}, worst adapter gradient rel-L2 {worst:.3e}")

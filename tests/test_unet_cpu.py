@@ -207,10 +207,33 @@ def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
     for cls in (Flux, SD3, PixartSigma):
         m = cls.__new__(cls)
         m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
-        with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
-            m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
+        if cls is not SD3:               # SD3 takes tokenwise timesteps (test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer below)
+            with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
+                m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
         with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
             m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
+
+
+def test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer():
+    """the reference's tests/test_sd3_model.py:179-204 (test_model_predict_accepts_tokenwise_timesteps) on the st355 plugin: [B, S_img] timesteps reach the
+    transformer's `timestep` argument unchanged (0..1000 scale, fp32)"""
+    from types import SimpleNamespace
+
+    from simpletuner_amd.sd3.model import SD3
+    m = SD3.__new__(SD3)
+    m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
+    seen = {}
+
+    def fake(**kw):
+        seen.update(kw)
+        return (torch.randn(1, 16, 4, 4),)
+
+    m.model = fake
+    batch = {"noisy_latents": torch.randn(1, 16, 4, 4), "timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "encoder_hidden_states": torch.randn(1, 3, 64),
+             "add_text_embeds": torch.randn(1, 32)}
+    out = m._model_predict_single(batch)
+    assert out["model_prediction"].shape == (1, 16, 4, 4)
+    assert seen["timestep"].dtype == torch.float32 and torch.equal(seen["timestep"], batch["timesteps"])
 
 
 def test_vae_seam_attributes_and_latent_scaling_rule():

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_tokenwise.pt by EXECUTING THE REFERENCE'S OWN MODEL FILES with TOKENWISE timesteps ([B, S_img]: one timestep per image token;
+CREPA self-flow, reference tests tests/test_sd3_model.py:179-204, tests/test_flux_model.py:213-272, tests/test_pixart_model.py:91-115).
+
+    python tools/gen_ref_tokenwise.py
+
+Same machinery as tools/gen_ref_models.py (tools/ref_shim.py makes the reference's transformer modules importable unmodified): the reference's model CLASS
+gets seeded parameters, runs forward + torch autograd on seeded inputs; stored: inputs, output, d(sum(output * w)) / d(parameters, inputs).
+tests/test_ref_models_cpu.py pins the oracle's tokenwise branch to these at <= 1e-5 (fp32).  /root/reference is read ONLY here, never at test time."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from tests.ref_fixture_utils import state_checksum  # noqa: E402
+from tools import ref_shim  # noqa: E402
+from tools.gen_ref_models import run, seed_params, strip  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+
+def gen_sd3():
+    T = ref_shim.ref_module("simpletuner.helpers.models.sd3.transformer")
+
+    def call(m, a):
+        return m(hidden_states=a["hidden_states"], encoder_hidden_states=a["encoder_hidden_states"], pooled_projections=a["pooled_projections"],
+                 timestep=a["timestep"], return_dict=False)[0]
+
+    cfg = dict(sample_size=8, patch_size=2, in_channels=4, num_layers=4, attention_head_dim=16, num_attention_heads=2, joint_attention_dim=24,
+               caption_projection_dim=32, pooled_projection_dim=20, out_channels=4, pos_embed_max_size=12)
+    model = T.SD3Transformer2DModel(**cfg)
+    st = seed_params(model, 411)
+    model.eval()
+    g = torch.Generator().manual_seed(412)
+    B, Hl, Wl = 2, 8, 12
+    Si = (Hl // 2) * (Wl // 2)
+    inputs = {"hidden_states": torch.randn(B, 4, Hl, Wl, generator=g), "encoder_hidden_states": torch.randn(B, 7, 24, generator=g),
+              "pooled_projections": torch.randn(B, 20, generator=g), "timestep": torch.rand(B, Si, generator=g) * 1000.0}
+    r = strip(run(model, call, inputs, 413))
+    r["inputs"] = inputs
+    # the same weights with every token of a sample at that sample's timestep must reproduce the batch-wise forward (the two code paths of the reference agree)
+    flat = dict(inputs, timestep=torch.tensor([137.0, 842.0]))
+    tok = dict(inputs, timestep=flat["timestep"][:, None].expand(B, Si).contiguous())
+    with torch.no_grad():
+        a, b = call(model, flat), call(model, tok)
+    assert (a - b).norm() / a.norm() < 1e-5, "reference: a constant tokenwise timestep differs from the batch-wise forward"
+    return {"config": cfg, "seed": 411, "state_checksum": state_checksum(st), "pos_embed_table": model.pos_embed.pos_embed.detach().clone(), "case": r,
+            "_cite": "simpletuner/helpers/models/sd3/transformer.py:61-75 (_sd3_tokenwise_conditioning), :126-142 (AdaLN with a [B, S, D] embedding), :625-626, :680-685, :876"}
+
+
+if __name__ == "__main__":
+    G = {"sd3": gen_sd3()}
+    torch.save(G, OUT / "ref_tokenwise.pt")
+    print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items()})
