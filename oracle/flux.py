@@ -265,15 +265,21 @@ def _heads(x, H):
     return x.view(B, S, H, D // H).transpose(1, 2)
 
 
-def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None, taps=None):
+def _rows(t):
+    """a modulation chunk as it multiplies [B, S, D] activations: [B, D] rows per sample broadcast over the tokens, [B, S, D] rows per token as they are"""
+    return t if t.ndim == 3 else t[:, None]
+
+
+def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None, taps=None, temb_txt=None):
+    """flux/transformer.py:607-687.  temb [B, D]; or TOKENWISE (:396-403, 1068-1086): temb [B, S_img, D] = one conditioning row per image token (the image stream's
+    shift / scale / gate rows are then per token) with temb_txt [B, D] = its mean over the tokens for the text stream."""
     p = f"transformer_blocks.{i}."
     H = cfg.num_attention_heads
-    st = F.silu(temb)
-    m = linear(st, P, p + "norm1.linear")
-    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = m.chunk(6, dim=1)
-    c = linear(st, P, p + "norm1_context.linear")
+    m = linear(F.silu(temb), P, p + "norm1.linear")
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (_rows(t) for t in m.chunk(6, dim=-1))
+    c = linear(F.silu(temb if temb_txt is None else temb_txt), P, p + "norm1_context.linear")
     c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c.chunk(6, dim=1)
-    n = layer_norm(hidden) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    n = layer_norm(hidden) * (1 + scale_msa) + shift_msa
     cn = layer_norm(enc) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
 
     a = p + "attn."
@@ -292,12 +298,12 @@ def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1
     co, io = o[:, :T], o[:, T:]
     if taps is not None:
         taps[f"d{i}.attn"] = o
-    hidden = hidden + gate_msa[:, None] * linear(io, P, a + "to_out.0", lora, lora_scale)
+    hidden = hidden + gate_msa * linear(io, P, a + "to_out.0", lora, lora_scale)
     enc = enc + c_gate_msa[:, None] * linear(co, P, a + "to_add_out", lora, lora_scale)
 
-    n2 = layer_norm(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    n2 = layer_norm(hidden) * (1 + scale_mlp) + shift_mlp
     ff = linear(F.gelu(linear(n2, P, p + "ff.net.0.proj"), approximate="tanh"), P, p + "ff.net.2")
-    hidden = hidden + gate_mlp[:, None] * ff
+    hidden = hidden + gate_mlp * ff
     cn2 = layer_norm(enc) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
     cff = linear(F.gelu(linear(cn2, P, p + "ff_context.net.0.proj"), approximate="tanh"), P, p + "ff_context.net.2")
     enc = enc + c_gate_mlp[:, None] * cff
@@ -308,9 +314,9 @@ def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1
 def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None):
     p = f"single_transformer_blocks.{i}."
     H = cfg.num_attention_heads
-    m = linear(F.silu(temb), P, p + "norm.linear")
-    shift, scale, gate = m.chunk(3, dim=1)
-    n = layer_norm(x) * (1 + scale[:, None]) + shift[:, None]
+    m = linear(F.silu(temb), P, p + "norm.linear")          # temb [B, D], or tokenwise [B, S_txt + S_img, D] (`temb_single`, :1075-1083)
+    shift, scale, gate = (_rows(t) for t in m.chunk(3, dim=-1))
+    n = layer_norm(x) * (1 + scale) + shift
     a = p + "attn."
     q = rms_norm(_heads(linear(n, P, a + "to_q", lora, lora_scale), H), P[a + "norm_q.weight"])
     k = rms_norm(_heads(linear(n, P, a + "to_k", lora, lora_scale), H), P[a + "norm_k.weight"])
@@ -320,7 +326,7 @@ def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bi
     B, _, S, _ = o.shape
     o = o.transpose(1, 2).reshape(B, S, -1)
     mlp = F.gelu(linear(n, P, p + "proj_mlp"), approximate="tanh")
-    out = x + gate[:, None] * linear(torch.cat([o, mlp], dim=2), P, p + "proj_out")
+    out = x + gate * linear(torch.cat([o, mlp], dim=2), P, p + "proj_out")
     return torch.nan_to_num(out, nan=0.0, posinf=65504, neginf=-65504)
 
 
@@ -341,8 +347,25 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
     hidden = linear(hidden_states, P, "x_embedder")
     t = timestep.float() * 1000
     g = guidance.float() * 1000 if (guidance is not None and cfg.guidance_embeds) else None
-    temb = time_text_embed(P, cfg, t, g, pooled_projections)
     enc = linear(encoder_hidden_states, P, "context_embedder")
+    temb_txt = temb_single = None
+    if timestep.ndim == 2:
+        # TOKENWISE timesteps [B, S_img] (:245-294 `_flux_tokenwise_conditioning`, :1068-1086): one conditioning row per image token; the text tokens take the
+        # mean over the image tokens; the single blocks see [mean x S_txt || per token] along their joint sequence; norm_out takes the per-token rows (:1505)
+        Bq, Sq = timestep.shape
+        if Sq != hidden.shape[1]:
+            raise ValueError(f"Flux expected tokenwise timesteps with sequence length {hidden.shape[1]}, got {Sq}.")
+        if tread:
+            raise ValueError("tokenwise timesteps under TREAD routing are not restated")
+        gg = None
+        if g is not None:
+            gg = (g.expand(Bq) if g.numel() == 1 else g)
+            gg = gg[:, None].expand(Bq, Sq).reshape(-1) if gg.ndim == 1 else gg.reshape(-1)
+        temb = time_text_embed(P, cfg, t.reshape(-1), gg, pooled_projections[:, None, :].expand(-1, Sq, -1).reshape(Bq * Sq, -1)).view(Bq, Sq, -1)
+        temb_txt = temb.mean(dim=1)
+        temb_single = torch.cat([temb_txt[:, None].expand(-1, enc.shape[1], -1), temb], dim=1)
+    else:
+        temb = time_text_embed(P, cfg, t, g, pooled_projections)
     ids = torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0)
     cos, sin = (t.to(hidden.device) for t in rope_tables(ids, cfg.axes_dims_rope))      # tables in float64 on the host; the oracle itself may run on any device
     if taps is not None:
@@ -358,7 +381,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
             info, saved = infos[ptr], hidden
             hidden = tread_start(hidden, info)
             ccos, csin = tread_rope(cos, sin, T, info, hidden.shape[1], B)
-        enc, hidden = run(double_block, P, cfg, i, hidden, enc, temb, ccos, csin, lora, lora_scale, key_bias, taps)
+        enc, hidden = run(double_block, P, cfg, i, hidden, enc, temb, ccos, csin, lora, lora_scale, key_bias, taps, temb_txt)
         if info is not None and gidx == routes[ptr]["end_layer_idx"]:
             hidden = tread_end(hidden, info, saved)
             info, saved, ptr, ccos, csin = None, None, ptr + 1, cos, sin
@@ -372,7 +395,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
             img = tread_start(x[:, T:], info)
             x = torch.cat([x[:, :T], img], dim=1)
             ccos, csin = tread_rope(cos, sin, T, info, img.shape[1], B)
-        x = run(single_block, P, cfg, i, x, temb, ccos, csin, lora, lora_scale, key_bias)
+        x = run(single_block, P, cfg, i, x, temb if temb_single is None else temb_single, ccos, csin, lora, lora_scale, key_bias)
         if info is not None and gidx == routes[ptr]["end_layer_idx"]:
             x = torch.cat([x[:, :T], tread_end(x[:, T:], info, saved)], dim=1)
             info, saved, ptr, ccos, csin = None, None, ptr + 1, cos, sin
@@ -381,8 +404,8 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
         gidx += 1
     hidden = x[:, T:]
     emb = linear(F.silu(temb), P, "norm_out.linear")
-    scale, shift = emb.chunk(2, dim=1)          # AdaLayerNormContinuous: scale FIRST
-    hidden = layer_norm(hidden) * (1 + scale[:, None]) + shift[:, None]
+    scale, shift = emb.chunk(2, dim=-1)         # AdaLayerNormContinuous: scale FIRST
+    hidden = layer_norm(hidden) * (1 + _rows(scale)) + _rows(shift)
     return linear(hidden, P, "proj_out")
 
 

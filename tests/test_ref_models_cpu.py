@@ -96,6 +96,26 @@ def test_flux_oracle_reproduces_reference_model(case):
     print(f"[pinned] flux {case}: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
 
 
+def test_flux_oracle_reproduces_reference_model_with_tokenwise_timesteps():
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; reference tests/test_flux_model.py:213-241): the reference's FluxTransformer2DModel executed with one timestep
+    per image token (tools/gen_ref_tokenwise.py) — per-token AdaLN rows on the image stream of the double blocks, the token mean on the text stream, [mean x S_txt ||
+    per token] along the single blocks' joint sequence, per-token rows in norm_out; output and EVERY parameter / input gradient of oracle.flux to <= 1e-5"""
+    G = _load("ref_tokenwise.pt")["flux"]
+    cfg = _flux_cfg(G["config"])
+    P = {k: v.requires_grad_(True) for k, v in _state(OF.param_shapes(cfg), G["seed"], G["state_checksum"]).items()}
+    R = G["case"]
+    assert R["inputs"]["timestep"].ndim == 2
+    out, leaves = _flux_run(P, cfg, R["inputs"])
+    r = rel_l2(out, R["out"])
+    assert r <= TOL, f"flux tokenwise: output rel-L2 {r:.3e}"
+    _backward(out, R["w"], list(P.values()) + list(leaves.values()))
+    worst = _check_grads(P, R["grads"], "flux tokenwise")
+    for k, g in R["input_grads"].items():
+        if k in leaves:
+            assert rel_l2(leaves[k].grad, g) <= TOL, k
+    print(f"[pinned] flux tokenwise: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
+
+
 def test_flux_oracle_reproduces_reference_model_at_kernel_head_width():
     """the "hip" tier (2 heads x 128, LoRA r4): weights rebuilt from the seed, LoRA applied as an adapter in the oracle; the reference ran the MERGED weight"""
     G = _load("ref_flux_model.pt")["hip"]

@@ -52,7 +52,37 @@ def gen_sd3():
             "_cite": "simpletuner/helpers/models/sd3/transformer.py:61-75 (_sd3_tokenwise_conditioning), :126-142 (AdaLN with a [B, S, D] embedding), :625-626, :680-685, :876"}
 
 
+def gen_flux():
+    T = ref_shim.ref_module("simpletuner.helpers.models.flux.transformer")
+    (prepare_latent_image_ids,) = ref_shim.lift(ref_shim.REF / "helpers/models/flux/__init__.py", ["prepare_latent_image_ids"])
+
+    def call(m, a):
+        return m(hidden_states=a["hidden_states"], encoder_hidden_states=a["encoder_hidden_states"], pooled_projections=a["pooled_projections"],
+                 timestep=a["timestep"], img_ids=a["img_ids"], txt_ids=a["txt_ids"], guidance=a["guidance"], return_dict=False)[0]
+
+    cfg = dict(patch_size=1, in_channels=16, num_layers=2, num_single_layers=3, attention_head_dim=16, num_attention_heads=2,
+               joint_attention_dim=24, pooled_projection_dim=12, guidance_embeds=True, axes_dims_rope=(4, 6, 6))
+    model = T.FluxTransformer2DModel(**cfg)
+    st = seed_params(model, 421)
+    model.eval()
+    g = torch.Generator().manual_seed(422)
+    B, Hl, Wl, Tt = 2, 8, 12, 5
+    S = (Hl // 2) * (Wl // 2)
+    inputs = {"hidden_states": torch.randn(B, S, 16, generator=g), "encoder_hidden_states": torch.randn(B, Tt, 24, generator=g),
+              "pooled_projections": torch.randn(B, 12, generator=g), "timestep": torch.rand(B, S, generator=g),
+              "img_ids": prepare_latent_image_ids(B, Hl, Wl, "cpu", torch.float32), "txt_ids": torch.zeros(Tt, 3), "guidance": torch.tensor([1.0, 3.5])}
+    r = strip(run(model, call, inputs, 423))
+    r["inputs"] = inputs
+    flat = dict(inputs, timestep=torch.tensor([0.137, 0.842]))
+    tok = dict(inputs, timestep=flat["timestep"][:, None].expand(B, S).contiguous())
+    with torch.no_grad():
+        a, b = call(model, flat), call(model, tok)
+    assert (a - b).norm() / a.norm() < 1e-5, "reference: a constant tokenwise timestep differs from the batch-wise forward"
+    return {"config": cfg, "seed": 421, "state_checksum": state_checksum(st), "latent_hw": (Hl, Wl), "case": r,
+            "_cite": "simpletuner/helpers/models/flux/transformer.py:245-294 (_flux_tokenwise_conditioning), :386-412 (AdaLN with a [B, S, D] embedding), :1068-1086 (temb_img / temb_txt / temb_single), :1505"}
+
+
 if __name__ == "__main__":
-    G = {"sd3": gen_sd3()}
+    G = {"sd3": gen_sd3(), "flux": gen_flux()}
     torch.save(G, OUT / "ref_tokenwise.pt")
     print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items()})
