@@ -136,7 +136,7 @@ class Flux(ModelFoundation):
 
     def _model_predict_single(self, prepared_batch: dict):
         """flux/model.py:707-864"""
-        self._require_per_sample_timesteps(prepared_batch)
+        self._require_per_sample_timesteps(prepared_batch, tokenwise_ok=True)      # [B] or tokenwise [B, S_img] (flux/model.py:560-600 `_normalize_timesteps`)
         lat = prepared_batch["latents"]
         B, Cc, Hh, Ww = lat.shape
         dev = self.accelerator.device
@@ -158,7 +158,16 @@ class Flux(ModelFoundation):
                                     torch.zeros(prepared_batch["prompt_embeds"].shape[1], 3, device=dev, dtype=torch.float32))
         img_ids, text_ids = self._ids_cache[key]
         # "divide it by 1000 for now because we scale it by 1000 in the transformer model" (flux/model.py:739-745, 790)
-        prepared_batch["timesteps"] = prepared_batch["timesteps"].to(device=dev, dtype=torch.float32) / 1000.0
+        ts = prepared_batch["timesteps"].to(device=dev, dtype=torch.float32)
+        if ts.ndim == 2:                                  # tokenwise: one timestep per packed image token (flux/model.py:582-595)
+            seq = (Hh // 2) * (Ww // 2)
+            if ts.shape[1] != seq:
+                raise ValueError(f"Flux expected tokenwise timesteps with sequence length {seq}, got {ts.shape[1]}.")
+            if ts.shape[0] == 1:
+                ts = ts.expand(B, -1)
+            elif ts.shape[0] != B:
+                raise ValueError(f"Flux expected tokenwise timesteps for batch size {B}, got {ts.shape[0]}.")
+        prepared_batch["timesteps"] = ts / 1000.0
         attention_mask = None
         if getattr(self.config, "flux_attention_masked_training", False):          # flux/model.py:813-823
             attention_mask = prepared_batch.get("encoder_attention_mask")

@@ -526,10 +526,13 @@ class FluxTransformer2DModel(nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, Si, St, S, Sp, mod, cos, sin = env.B, env.Si, env.St, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.double[bi]
-        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        # the image stream's modulation rows: per sample, or — tokenwise timesteps (_engine_forward) — per image token (rows_per_batch 1); the text stream's stay per sample
+        tokw = getattr(env, "tokenwise", False)
+        mi = (env.mod_img if tokw else mod)[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        rpi = 1 if tokw else Si
         full = getattr(env, "full", False)        # full-rank training: norm weights train (no fused projection epilogue), extra activations are kept
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
-        if (fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
+        if (fused and not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
             # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
             # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
             mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
@@ -562,7 +565,7 @@ class FluxTransformer2DModel(nn.Module):
                 sv = SimpleNamespace(img=img, txt=txt, n_img=n_img, n_txt=None, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, x1_img=x1_img,
                                      x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=None, T_o=T_o, T_ao=None)
             return x2_img, x2_txt, x, sv
-        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], Si)
+        n_img = ops.ln_modulate_fwd(img, mi[:, D:2 * D], mi[:, :D], rpi)
         n_txt = ops.ln_modulate_fwd(txt, mt[:, D:2 * D], mt[:, :D], St)
         T_img = ops.gemm(n_img, blk.qkv.lora.A_cat) if blk.qkv.lora is not None else None
         T_txt = ops.gemm(n_txt, blk.add_qkv.lora.A_cat) if blk.add_qkv.lora is not None else None
@@ -615,11 +618,11 @@ class FluxTransformer2DModel(nn.Module):
                 ops.gemm(pr.pop("a"), pr.pop("w"), **pr)
             kw_t.update(a2=T_ao, b2=blk.to_add_out.lora.B_blk, k2_real=blk.to_add_out.lora.k2_real)
         ops.gemm_grouped(self._problems(env, Si, dict(a=O_i, w=blk.to_out.w, bias=blk.to_out.b, out=x1_img, epilogue=EPI_GATE_RESIDUAL, aux_in=img,
-                                                      gate=mi[:, 2 * D:3 * D], rows_per_batch=Si, **kw_i))
+                                                      gate=mi[:, 2 * D:3 * D], rows_per_batch=rpi, **kw_i))
                          + self._problems(env, St, dict(a=O_t, w=blk.to_add_out.w, bias=blk.to_add_out.b, out=x1_txt, epilogue=EPI_GATE_RESIDUAL,
                                                         aux_in=txt, gate=mt[:, 2 * D:3 * D], rows_per_batch=St, **kw_t)))
         # MLPs
-        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], Si)
+        n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], rpi)
         n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
         hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
         h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
@@ -632,12 +635,12 @@ class FluxTransformer2DModel(nn.Module):
             # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
             x = torch.empty(B * S, D, dtype=BF16, device=dev)
             ops.gemm_grouped(self._problems(env, Si, dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img,
-                                                          gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, out=self._rows_of(x, St, Si, env), **kf_i))
+                                                          gate=mi[:, 5 * D:6 * D], rows_per_batch=rpi, out=self._rows_of(x, St, Si, env), **kf_i))
                              + self._problems(env, St, dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt,
                                                             gate=mt[:, 5 * D:6 * D], rows_per_batch=St, out=self._rows_of(x, 0, St, env), **kf_t)))
         else:
             x2_img, x2_txt = ops.gemm_grouped([
-                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=Si, **kf_i),
+                dict(a=h_i, w=blk.ff2.w, bias=blk.ff2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_img, gate=mi[:, 5 * D:6 * D], rows_per_batch=rpi, **kf_i),
                 dict(a=h_t, w=blk.ffc2.w, bias=blk.ffc2.b, epilogue=EPI_GATE_RESIDUAL, aux_in=x1_txt, gate=mt[:, 5 * D:6 * D], rows_per_batch=St, **kf_t)])
         sv = None
         if save:
@@ -652,10 +655,12 @@ class FluxTransformer2DModel(nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, S, Sp, mod, cos, sin = env.B, env.S, env.Sp, env.mod, env.cos, env.sin
         blk = self.single[bi]
-        ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        tokw = getattr(env, "tokenwise", False)       # tokenwise timesteps: one modulation row per token of the joint [txt || img] sequence (env.mod_x: columns from env.xoff on)
+        ms = env.mod_x[:, blk.mod_off - env.xoff:blk.mod_off - env.xoff + 3 * D] if tokw else mod[:, blk.mod_off:blk.mod_off + 3 * D]
+        rpx = 1 if tokw else S
         full = getattr(env, "full", False)
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
-        if fused and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
+        if fused and not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
             # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
             # as the host-side sequencing below
             lo = blk.qkv.lora
@@ -672,7 +677,7 @@ class FluxTransformer2DModel(nn.Module):
                                       key_bias=env.key_bias, n=n, V=V, rrms=rrms, Q=Q, K=K, O=O, lse2=lse2, hpre=hpre, T=T, Vt=Vt, hact=hact, x_out=x_out)
             sv = SimpleNamespace(x=x, n=n, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
             return x_out, sv
-        n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], S)
+        n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], rpx)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
         qkv = V = rrms = Qt = Kt = None
         if fused:
@@ -694,7 +699,7 @@ class FluxTransformer2DModel(nn.Module):
         # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
         y = torch.empty(B * S, D, dtype=BF16, device=dev) if (full and save) else None          # the un-gated branch output (gate gradient)
         x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
-                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=S, **(dict(aux_out=y) if y is not None else {}))
+                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx, **(dict(aux_out=y) if y is not None else {}))
         sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
         if sv is not None and full:
             sv.hact, sv.y = hact, y
@@ -715,24 +720,58 @@ class FluxTransformer2DModel(nn.Module):
         em.x2d, em.enc2d = hidden_states.reshape(B * Si, -1).contiguous(), encoder_hidden_states.reshape(B * St, -1).contiguous()
         img = ops.gemm(em.x2d, self.l_x.w, bias=self.l_x.b)
         txt = ops.gemm(em.enc2d, self.l_ctx.w, bias=self.l_ctx.b)
-        t32 = timestep.to(device=dev, dtype=F32).contiguous()
+        tokenwise = timestep.dim() == 2
+        if tokenwise and tuple(timestep.shape) != (B, Si):
+            raise ValueError(f"Flux expected tokenwise timesteps with sequence length {Si}, got {timestep.shape[1]}.")     # flux/transformer.py:1068-1072
+        t32 = timestep.to(device=dev, dtype=F32).reshape(-1).contiguous()
         em.tproj = ops.timestep_proj(t32, 256, 1000.0)
         em.t1 = ops.gemm(em.tproj, self.l_t1.w, bias=self.l_t1.b); em.st1 = ops.silu(em.t1)
-        temb = ops.gemm(em.st1, self.l_t2.w, bias=self.l_t2.b)
+        temb = ops.gemm(em.st1, self.l_t2.w, bias=self.l_t2.b)                   # [B, D], or tokenwise [B * S_img, D]
+        cond = None                                                              # the per-SAMPLE part of the conditioning: guidance + pooled text
         if self.config.guidance_embeds:
             if guidance is None:
                 raise ValueError("guidance_embeds=True requires a guidance tensor")
             g32 = guidance.to(device=dev, dtype=F32).contiguous()
+            if tokenwise and g32.dim() != 1:
+                raise NotImplementedError("tokenwise timesteps take a per-sample guidance vector on the st355 path (a [B, S] guidance tensor is not implemented)")
             em.gproj = ops.timestep_proj(g32, 256, 1000.0)
             em.g1 = ops.gemm(em.gproj, self.l_g1.w, bias=self.l_g1.b); em.sg1 = ops.silu(em.g1)
-            temb = ops.add(temb, ops.gemm(em.sg1, self.l_g2.w, bias=self.l_g2.b))
+            cond = ops.gemm(em.sg1, self.l_g2.w, bias=self.l_g2.b)
         em.pooled = pooled.to(BF16).contiguous()
         em.p1 = ops.gemm(em.pooled, self.l_p1.w, bias=self.l_p1.b); em.sp1 = ops.silu(em.p1)
-        temb = ops.add(temb, ops.gemm(em.sp1, self.l_p2.w, bias=self.l_p2.b))
+        pe = ops.gemm(em.sp1, self.l_p2.w, bias=self.l_p2.b)
+        mod_img = mod_x = None
+        xoff = 0
+        if tokenwise:
+            # TOKENWISE timesteps [B, S_img] (CREPA self-flow; flux/transformer.py:245-294, 386-412, 1068-1086, 1505): one conditioning row per image token.  The image
+            # stream of the double blocks and norm_out take per-token shift / scale / gate rows (the AdaLN / gated-residual / scale kernels index their modulation row
+            # by row // rows_per_batch: rows_per_batch = 1), the text stream the mean over the tokens, the single blocks [mean x S_txt || per token] along their joint
+            # sequence.  The per-token rows of every block are ONE GEMM [B * S_img, D] x [mod_total, D]^T (B * S_img * mod_total bf16: 8.7 GB per 1024^2 image of
+            # Flux.1 — HBM holds it); the joint-sequence rows of the single blocks + norm_out are assembled from them and the per-sample rows.
+            if full:
+                raise NotImplementedError("tokenwise timesteps under full-rank training (per-token modulation gradients) are not implemented on the st355 path")
+            if B > 1 and (Si % 256 or St % 256):
+                raise NotImplementedError(f"tokenwise timesteps with per-GPU batch > 1 need the rows per sample of both streams ({Si}, {St}) to be multiples of 256 "
+                                          "(per-sample problem forms slice the modulation rows per sample)")
+            # the three embedders' sum, fp32 accumulation order of the batch-wise path: timestep + guidance, then + pooled
+            if cond is not None:
+                temb = ops.add(temb, cond[:, None, :].expand(B, Si, D).reshape(B * Si, D))
+            temb_tok = ops.add(temb, pe[:, None, :].expand(B, Si, D).reshape(B * Si, D))
+            tsum = torch.empty(B, D, dtype=F32, device=dev)
+            ops.colsum_prod(temb_tok, tsum, rows_per_batch=Si)
+            temb = (tsum / Si).to(BF16)                                                               # temb_txt = temb.mean(dim=1)   (:1073-1074)
+            mod_img = ops.gemm(ops.silu(temb_tok), self.mod_w, bias=self.mod_b)                       # [B * S_img, mod_total]
+        else:
+            if cond is not None:
+                temb = ops.add(temb, cond)
+            temb = ops.add(temb, pe)
         em.temb, em.st = temb, ops.silu(temb)
         mod = ops.gemm(em.st, self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
+        if tokenwise:
+            xoff = self.single[0].mod_off if self.single else self.mod_off_out          # the single blocks' and norm_out's columns follow the double blocks'
+            mod_x = torch.cat([mod[:, None, xoff:].expand(B, St, self.mod_total - xoff), mod_img.view(B, Si, -1)[:, :, xoff:]], dim=1).reshape(B * S, self.mod_total - xoff)
         env = SimpleNamespace(B=B, Si=Si, St=St, S=S, Sp=Sp, cos=cos, sin=sin, cos_p=cos_p, sin_p=sin_p, mod=mod, scale=1.0 / math.sqrt(hd), key_bias=key_bias,
-                              full=bool(full))
+                              full=bool(full), tokenwise=tokenwise, mod_img=mod_img, mod_x=mod_x, xoff=xoff)
         segs_d = self._checkpoint_segments(len(self.double)) if save else [(i, 1, False) for i in range(len(self.double))]
         segs_s = self._checkpoint_segments(len(self.single)) if save else [(i, 1, False) for i in range(len(self.single))]
         # TREAD routing (flux/transformer.py:1101-1133, 1211-1241 double blocks, 1394-1486 single blocks; training/tread.py): only while training; between a route's
@@ -741,6 +780,8 @@ class FluxTransformer2DModel(nn.Module):
         from ..training.tread import normalise_routes
         nd, ns = len(self.double), len(self.single)
         routes = normalise_routes(self._tread_routes, nd + ns) if (save and self.training and self._tread_router is not None) else []
+        if routes and tokenwise:
+            raise NotImplementedError("tokenwise timesteps under TREAD routing (the routed tokens' modulation rows would be gathered too) are not implemented")
         if routes and full:
             raise NotImplementedError("TREAD routing under full-rank Flux training is not built on the st355 path (LoRA training routes)")
         if routes:
@@ -828,6 +869,10 @@ class FluxTransformer2DModel(nn.Module):
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         n_out = torch.empty(B * Si, D, dtype=BF16, device=dev)
         for b in range(B):          # the image rows of sample b are a strided view of the joint buffer: no gather pass
+            if tokenwise:           # per-token (scale, shift) rows: norm_out takes temb_img (flux/transformer.py:1505)
+                mo_b = env.mod_img[b * Si:(b + 1) * Si, self.mod_off_out:self.mod_off_out + 2 * D]
+                ops.ln_modulate_fwd(x[b * S + St:(b + 1) * S], mo_b[:, :D], mo_b[:, D:2 * D], 1, out=n_out[b * Si:(b + 1) * Si])
+                continue
             ops.ln_modulate_fwd(x[b * S + St:(b + 1) * S], mo[b:b + 1, :D], mo[b:b + 1, D:2 * D], Si, out=n_out[b * Si:(b + 1) * Si])
         out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
         if save:
@@ -876,8 +921,11 @@ class FluxTransformer2DModel(nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.single[li]
-        ms = mod[:, blk.mod_off:blk.mod_off + 3 * D]
-        if (_block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
+        tokw = getattr(env, "tokenwise", False)       # one modulation row per token of the joint sequence (see _single_fwd)
+        msl = (lambda j: env.mod_x[:, self.single[j].mod_off - env.xoff:self.single[j].mod_off - env.xoff + 3 * D]) if tokw else (lambda j: mod[:, self.single[j].mod_off:self.single[j].mod_off + 3 * D])
+        ms = msl(li)
+        rpx = 1 if tokw else S
+        if (not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
                 and dx.is_contiguous() and (dxg is None or dxg.is_contiguous())):
             # ONE C entry point (st355_block_flux_single_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lo = blk.qkv.lora
@@ -899,7 +947,7 @@ class FluxTransformer2DModel(nn.Module):
             if lo is not None and self.grad_sync is not None:
                 self.grad_sync.ready(lo.flat_lo, lo.flat_hi)
             return dx_out, dxg_out, None, None
-        g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], S)
+        g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], rpx)
         dO = ops.gemm(g, blk.proj_out.wT[:D])
         dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
         dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
@@ -910,16 +958,16 @@ class FluxTransformer2DModel(nn.Module):
         dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
         d_txt = d_img = None
         if li > 0:
-            gprev = mod[:, self.single[li - 1].mod_off + 2 * D:self.single[li - 1].mod_off + 3 * D]
-            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx, gate=gprev, want_gated=True)
+            gprev = msl(li - 1)[:, 2 * D:3 * D]
+            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], rpx, dres=dx, gate=gprev, want_gated=True)
         elif self.double:
             d_txt = torch.empty(B * St, D, dtype=BF16, device=dev); d_img = torch.empty(B * Si, D, dtype=BF16, device=dev)
             for b in range(B):
                 for (r0, r1, dst) in ((b * S, b * S + St, d_txt[b * St:(b + 1) * St]), (b * S + St, (b + 1) * S, d_img[b * Si:(b + 1) * Si])):
-                    ops.ln_modulate_bwd(dn[r0:r1], sv.x[r0:r1], ms[b:b + 1, D:2 * D], r1 - r0, dres=dx[r0:r1], out=dst)
+                    ops.ln_modulate_bwd(dn[r0:r1], sv.x[r0:r1], ms[r0:r1, D:2 * D] if tokw else ms[b:b + 1, D:2 * D], 1 if tokw else r1 - r0, dres=dx[r0:r1], out=dst)
             dx = dxg = None
         else:
-            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], S, dres=dx)
+            dx, dxg = ops.ln_modulate_bwd(dn, sv.x, ms[:, D:2 * D], rpx, dres=dx)
         return dx, dxg, d_txt, d_img
 
     def _double_bwd(self, li: int, sv, d_img, d_txt, env):
@@ -928,8 +976,10 @@ class FluxTransformer2DModel(nn.Module):
         D, H, hd, dev = self.D, self.H, self.hd, self.device_
         B, Si, St, S, mod, cos, sin = env.B, env.Si, env.St, env.S, env.mod, env.cos, env.sin
         blk = self.double[li]
-        mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
-        if (_block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
+        tokw = getattr(env, "tokenwise", False)       # per-token modulation rows on the image stream (see _double_fwd)
+        mi = (env.mod_img if tokw else mod)[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        rpi = 1 if tokw else Si
+        if (not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
                 and Si % 256 == 0 and St % 256 == 0 and d_img.is_contiguous() and d_txt.is_contiguous()):
             # ONE C entry point (st355_block_flux_double_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lq, lo_ = blk.qkv.lora, blk.to_out.lora
@@ -959,12 +1009,12 @@ class FluxTransformer2DModel(nn.Module):
                     if lg is not None:
                         self.grad_sync.ready(lg.flat_lo, lg.flat_hi)
             return d_img_out, d_txt_out
-        g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
+        g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], rpi); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
         dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
                                        dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
         dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
         del g_i, g_t, dh_i, dh_t
-        dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
+        dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], rpi, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
         dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
         del dn2_i, dn2_t
         # attention output projections: dO rows of both streams (+ adapter grads)
@@ -1006,7 +1056,7 @@ class FluxTransformer2DModel(nn.Module):
                 lin.lora.grads(n_in, T_, self._compact(dq, env, rows), Us[name], self.accumulate_lora_grads, self.grad_sync)
         if last:
             return None, None
-        d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
+        d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], rpi, dres=dx1_i)
         d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
         return d_img, d_txt
 
@@ -1024,6 +1074,10 @@ class FluxTransformer2DModel(nn.Module):
         dn = ops.gemm(dout, self.l_out.wT)
         dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
         for b in range(B):          # written straight into the image rows of the joint gradient
+            if getattr(env, "tokenwise", False):          # norm_out's (scale, shift) rows are per image token (flux/transformer.py:1505 takes temb_img)
+                ops.ln_modulate_bwd(dn[b * Si:(b + 1) * Si], ctx.x_final[b * S + St:(b + 1) * S], env.mod_img[b * Si:(b + 1) * Si, self.mod_off_out:self.mod_off_out + D], 1,
+                                    out=dx[b * S + St:(b + 1) * S])
+                continue
             ops.ln_modulate_bwd(dn[b * Si:(b + 1) * Si], ctx.x_final[b * S + St:(b + 1) * S], mo[b:b + 1, :D], Si, out=dx[b * S + St:(b + 1) * S])
         del dn
         ctx.x_final = None
@@ -1350,8 +1404,8 @@ class FluxTransformer2DModel(nn.Module):
             txt_ids = txt_ids[0]
         if img_ids.ndim == 3:
             img_ids = img_ids[0]
-        if timestep.ndim != 1:
-            raise NotImplementedError("tokenwise timesteps are not supported on the HIP path")
+        if timestep.ndim not in (1, 2):
+            raise ValueError(f"timestep: expected [B] or tokenwise [B, S_img], got {tuple(timestep.shape)}")
         key_bias = None
         if attention_mask is not None:
             # flux_attention_masked_training (flux/model.py:813-823): the text mask [B, S_txt] is expanded with ones over the image tokens

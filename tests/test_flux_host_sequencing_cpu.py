@@ -281,3 +281,34 @@ def test_fused_projection_path_through_the_emulator_matches_the_oracle(monkeypat
         ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
         assert PU.rel_l2(g_, ref) < 5e-2, (name, PU.rel_l2(g_, ref))
         assert PU.rel_l2(grads_u[name], ref) < 5e-2, name
+
+
+@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(2, 2, 1, 16, 16, 64), (1, 2, 2, 32, 32, 256), (0, 2, 1, 16, 8, 24)])
+def test_tokenwise_timesteps_through_the_emulator_match_the_oracle(monkeypatch, layers, single, B, lat_h, lat_w, S_txt):
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; the reference's tests/test_flux_model.py:213-241 hands them to the transformer; oracle branch pinned to the
+    executed reference class by tests/test_ref_models_cpu.py): per-token AdaLN rows on the image stream of the double blocks and in norm_out, the token mean on
+    the text stream, [mean x S_txt || per token] rows along the single blocks' joint sequence (rows_per_batch = 1); prediction and LoRA gradients (all targets)
+    against autograd on the oracle.  B = 2 with 256 image / 256 text rows per sample: segmented problems over per-token gates.  (0, 2): single blocks only."""
+    model = _model(monkeypatch, layers, single)
+    model.add_lora_adapter(rank=16, alpha=16.0, targets="all", init_b_std=0.02)
+    d = _inputs(B, lat_h, lat_w, S_txt)
+    Si = (lat_h // 2) * (lat_w // 2)
+    d["t"] = torch.rand(B, Si, generator=torch.Generator().manual_seed(8)) * 0.9 + 0.05
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    d_flat = dict(d, t=d["t"].mean(dim=1))           # not the batch-wise forward in disguise
+    with torch.no_grad():
+        out_flat = model(hidden_states=d["packed"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d_flat["t"], img_ids=d["img_ids"],
+                         txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0]
+    assert PU.rel_l2(out_flat, o_out) > 5e-2
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        worst = max(worst, PU.rel_l2(p.grad, ref))
+        assert PU.rel_l2(p.grad, ref) < 5e-2, name
+    print(f"[emu] flux tokenwise timesteps L{layers}+{single} B{B}: pred rel_l2={PU.rel_l2(out, o_out):.3e}, worst adapter gradient rel_l2={worst:.3e}")

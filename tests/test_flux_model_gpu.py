@@ -293,3 +293,49 @@ def test_flux_block_c_entry_points_equal_host_sequencing(layers, single, masked,
     assert torch.equal(p0, p1) and torch.equal(l0, l1)
     assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0)
     assert len(g0) > 0
+
+
+@pytest.mark.parametrize("layers,single,B,lat,S_txt", [(1, 2, 1, 32, 256), (2, 1, 2, 32, 256), (1, 1, 1, 16, 64)])
+def test_flux_tokenwise_timesteps_match_oracle(layers, single, B, lat, S_txt):
+    """TOKENWISE timesteps [B, S_img] (CREPA self-flow; reference tests/test_flux_model.py:213-241; flux/transformer.py:245-294, 386-412, 1068-1086, 1505) on the HIP
+    path: the AdaLN / gated-residual / scale kernels run with ONE modulation row per token (rows_per_batch = 1) — per image token in the double blocks and norm_out,
+    [mean x S_txt || per token] along the single blocks' joint sequence, the token mean on the text stream; the fused QKV + RMSNorm + RoPE projection and the fused
+    RoPE backward stay in use (256-row streams), the block-level C entry points step aside.  Prediction and LoRA gradients vs autograd on the oracle, whose
+    tokenwise branch is pinned to the executed reference class (tests/test_ref_models_cpu.py)."""
+    from oracle import flux as OF
+    from simpletuner_amd.flux.transformer import FluxTransformer2DModel
+    dev = "cuda:0"
+    model = FluxTransformer2DModel(device=dev, **PU.small_flux_cfg(layers=layers, single=single))
+    model.init_synthetic(seed=11)
+    model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
+    g = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16)
+    latents = bf(torch.randn(B, 16, lat, lat, generator=g))
+    packed = bf(OF.pack_latents(latents.float()))
+    Si = packed.shape[1]
+    prompt, pooled = bf(torch.randn(B, S_txt, 128, generator=g)), bf(torch.randn(B, 64, generator=g))
+    t = torch.rand(B, Si, generator=g) * 0.9 + 0.05
+    target = bf(torch.randn(packed.shape, generator=g))
+    img_ids, txt_ids = OF.prepare_latent_image_ids(lat, lat), torch.zeros(S_txt, 3)
+    guidance = torch.full((B,), 3.5) if model.config.guidance_embeds else None
+    out = model(hidden_states=packed.to(dev), encoder_hidden_states=prompt.to(dev), pooled_projections=pooled.to(dev), timestep=t.to(dev), img_ids=img_ids.to(dev),
+                txt_ids=txt_ids.to(dev), guidance=None if guidance is None else guidance.to(dev), return_dict=False)[0]
+    loss = ((out.float() - target.to(dev).float()) ** 2).mean()
+    loss.backward()
+    P, lora, scale = PU.oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    o_out = OF.flux_forward(P, PU.oracle_cfg(model), packed.float(), prompt.float(), pooled.float(), t, img_ids, txt_ids, guidance, lp, scale)
+    o_loss = ((o_out - target.float()) ** 2).mean()
+    o_loss.backward()
+    r = PU.rel_l2(out.detach().cpu(), o_out.detach())
+    assert r < 2e-2 and PU.cos_sim(out.detach().cpu(), o_out.detach()) > 0.9995 and abs(loss.item() - o_loss.item()) < 1e-3 * max(1.0, o_loss.item())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        rg = PU.rel_l2(p.grad.cpu(), ref)
+        worst = max(worst, rg)
+        assert rg < 5e-2, (name, rg)
+    print(f"[flux tokenwise] L{layers}+{single} B{B} S_img {Si}: pred rel-L2 {r:.3e}, worst adapter gradient rel-L2 {worst:.3e}")

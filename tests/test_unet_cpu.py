@@ -207,7 +207,7 @@ def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
     for cls in (Flux, SD3, PixartSigma):
         m = cls.__new__(cls)
         m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
-        if cls is not SD3:               # SD3 takes tokenwise timesteps (test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer below)
+        if cls is PixartSigma:           # SD3 and Flux take tokenwise timesteps (test_*_plugin_hands_tokenwise_timesteps_to_the_transformer below)
             with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
                 m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
         with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
@@ -234,6 +234,38 @@ def test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer():
     out = m._model_predict_single(batch)
     assert out["model_prediction"].shape == (1, 16, 4, 4)
     assert seen["timestep"].dtype == torch.float32 and torch.equal(seen["timestep"], batch["timesteps"])
+
+
+def test_flux_plugin_hands_tokenwise_timesteps_to_the_transformer():
+    """the reference's tests/test_flux_model.py:213-241 (test_model_predict_accepts_tokenwise_timesteps) on the st355 plugin: [B, S_img] timesteps reach the
+    transformer divided by 1000 (the transformer multiplies them back, flux/model.py:739-745)"""
+    from types import SimpleNamespace
+
+    from simpletuner_amd.flux.model import Flux
+    m = Flux.__new__(Flux)
+    m.config, m.accelerator, m._ids_cache = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu")), {}
+    seen = {}
+
+    def fake(**kw):
+        seen.update(kw)
+        return (torch.randn(1, 4, 64).to(torch.bfloat16),)
+
+    m.model = fake
+    m.get_trained_component = lambda: SimpleNamespace(config=SimpleNamespace(guidance_embeds=False))
+    import simpletuner_amd.flux.model as FM
+    orig, orig_pack = FM._UnpackFn.apply, FM.pack_latents
+    FM._UnpackFn.apply = staticmethod(lambda packed, h, w: torch.zeros(packed.shape[0], 16, h // 8, w // 8))
+    FM.pack_latents = lambda x: x.reshape(x.shape[0], -1, 64)             # (the device pack kernel is not what this test is about)
+    try:
+        batch = {"noisy_latents": torch.randn(1, 16, 4, 4), "latents": torch.randn(1, 16, 4, 4), "timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]),
+                 "prompt_embeds": torch.randn(1, 3, 16), "add_text_embeds": torch.randn(1, 8)}
+        out = m._model_predict_single(batch)
+        assert out["model_prediction"].shape == (1, 16, 4, 4)
+        assert torch.allclose(seen["timestep"], torch.tensor([[0.1, 0.9, 0.5, 0.7]]))
+        with pytest.raises(ValueError, match="sequence length"):
+            m._model_predict_single(dict(batch, timesteps=torch.tensor([[100.0, 900.0, 500.0]])))
+    finally:
+        FM._UnpackFn.apply, FM.pack_latents = orig, orig_pack
 
 
 def test_vae_seam_attributes_and_latent_scaling_rule():
