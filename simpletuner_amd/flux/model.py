@@ -106,17 +106,20 @@ class Flux(ModelFoundation):
     # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default) and the fall-through DEFAULT_LORA_TARGET (image stream and single
     # blocks only: what BASELINE.json's config names).  Sets that wrap feed-forward / embedder / norm / ControlNet layers, or only a subset of the
     # attention projections, need adapter backward paths this round did not build: refused, never silently narrowed.
-    _UNBUILT_LORA_TARGETS = ("context", "context+ffs", "all+ffs", "all+ffs+embedder", "all+ffs+embedder+controlnet", "ai-toolkit", "tiny", "nano", "controlnet")
+    _UNBUILT_LORA_TARGETS = ("context+ffs", "all+ffs", "all+ffs+embedder", "all+ffs+embedder+controlnet", "ai-toolkit", "tiny", "nano", "controlnet")
 
     def _lora_target_set(self) -> str:
         want = str(getattr(self.config, "flux_lora_target", "default") or "default")
         if want in self._UNBUILT_LORA_TARGETS:
-            raise NotImplementedError(f"flux_lora_target={want!r} is not implemented on the st355 path (built: 'all', and the default attention set)")
-        return "all" if want == "all" else "default"
+            raise NotImplementedError(f"flux_lora_target={want!r} is not implemented on the st355 path (built: 'all', 'context', and the default attention set)")
+        return want if want in ("all", "context") else "default"
 
     def get_lora_target_layers(self):
-        if self._lora_target_set() == "all":
+        which = self._lora_target_set()
+        if which == "all":
             return ["to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "add_k_proj", "add_q_proj", "add_v_proj", "to_out.0", "to_add_out"]
+        if which == "context":                       # flux/model.py:1263-1271
+            return ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out"]
         return list(self.DEFAULT_LORA_TARGET)
 
     def _flux_guidance_scales(self, prepared_batch, batch_size):

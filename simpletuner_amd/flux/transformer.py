@@ -305,7 +305,7 @@ class FluxTransformer2DModel(nn.Module):
     def add_lora_adapter(self, rank: int = 32, alpha: Optional[float] = None, targets: str = "default", seed: int = 7,
                          init_b_std: float = 0.0):
         """common.py:1049-1128 (LoraConfig(r, lora_alpha, target_modules)).  targets: 'default' = attn to_q,to_k,to_v,to_out.0
-        (+ single-block to_q,to_k,to_v); 'all' adds the context-stream projections."""
+        (+ single-block to_q,to_k,to_v); 'all' adds the context-stream projections; 'context' = only those (flux/model.py:1263-1271)."""
         alpha = float(rank if alpha is None else alpha)
         D, dev = self.D, self.device_
         plan = []  # (group, name, n_off, N, K)
@@ -319,15 +319,21 @@ class FluxTransformer2DModel(nn.Module):
             for (name, n_off, N) in g.targets:
                 plan.append((g, name, N, K))
 
+        if targets not in ("default", "all", "context"):
+            raise ValueError(f"add_lora_adapter: unknown target set {targets!r} (built: 'default', 'all', 'context')")
+        if targets == "context" and not self.double:
+            raise ValueError("add_lora_adapter: the 'context' target set names the double blocks' context-stream projections; this model has no double block")
         for i, blk in enumerate(self.double):
             p = f"transformer_blocks.{i}.attn."
-            group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
-            group(blk.to_out, p, ["to_out.0"], D)
-            if targets == "all":
+            if targets != "context":
+                group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
+                group(blk.to_out, p, ["to_out.0"], D)
+            if targets in ("all", "context"):       # flux/model.py:1263-1271 "context": add_q/k/v_proj + to_add_out only (the single blocks have no such layers)
                 group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
                 group(blk.to_add_out, p, ["to_add_out"], D)
-        for i, blk in enumerate(self.single):
-            group(blk.qkv, f"single_transformer_blocks.{i}.attn.", ["to_q", "to_k", "to_v"], D)
+        if targets != "context":
+            for i, blk in enumerate(self.single):
+                group(blk.qkv, f"single_transformer_blocks.{i}.attn.", ["to_q", "to_k", "to_v"], D)
         total = sum(rank * K + N * rank for (_, _, N, K) in plan)
         total = (total + 7) // 8 * 8
         self.lora_flat = torch.zeros(total, dtype=F32, device=dev)

@@ -312,3 +312,24 @@ def test_tokenwise_timesteps_through_the_emulator_match_the_oracle(monkeypatch, 
         worst = max(worst, PU.rel_l2(p.grad, ref))
         assert PU.rel_l2(p.grad, ref) < 5e-2, name
     print(f"[emu] flux tokenwise timesteps L{layers}+{single} B{B}: pred rel_l2={PU.rel_l2(out, o_out):.3e}, worst adapter gradient rel_l2={worst:.3e}")
+
+
+def test_context_target_set_through_the_emulator_matches_the_oracle(monkeypatch):
+    """flux_lora_target = "context" (flux/model.py:1263-1271): adapters ONLY on the double blocks' context-stream projections (add_q/k/v_proj, to_add_out); the image
+    stream and the single blocks carry no adapter (their backward is the pure data path, block 0 of the double stack still yields its context adapters' gradients)"""
+    model = _model(monkeypatch, 2, 2)
+    model.add_lora_adapter(rank=16, alpha=16.0, targets="context", init_b_std=0.02)
+    names = [n for n, _ in model.named_parameters() if ".lora_" in n]
+    assert names and all(("add_" in n or "to_add_out" in n) for n in names) and len(names) == 2 * 2 * 4
+    d = _inputs(2, 16, 8, 24)
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    assert set(lora) == {n.split(".lora_")[0] for n in names}
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))

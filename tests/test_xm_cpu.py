@@ -154,7 +154,7 @@ def test_flux_guidance_scales_modes_and_xm_replication():
 
 
 def test_flux_lora_target_sets_are_exact_or_refused():
-    """flux/model.py:1235-1380: 'all' and the fall-through default are built; every other named set is refused instead of being narrowed silently"""
+    """flux/model.py:1235-1380: 'all', 'context' and the fall-through default are built; every other named set is refused instead of being narrowed silently"""
     from simpletuner_amd.flux.model import Flux
     m = Flux.__new__(Flux)
     m.config = SimpleNamespace(flux_lora_target="all")
@@ -162,7 +162,9 @@ def test_flux_lora_target_sets_are_exact_or_refused():
     for v in ("default", None, "mmdit", "something-else"):                       # unknown names fall through to DEFAULT_LORA_TARGET, as in the reference
         m.config = SimpleNamespace(flux_lora_target=v)
         assert m._lora_target_set() == "default" and m.get_lora_target_layers() == ["to_k", "to_q", "to_v", "to_out.0"]
-    for v in ("context", "all+ffs", "ai-toolkit", "tiny", "nano", "controlnet", "all+ffs+embedder"):
+    m.config = SimpleNamespace(flux_lora_target="context")                       # flux/model.py:1263-1271 (built in round 4)
+    assert m._lora_target_set() == "context" and m.get_lora_target_layers() == ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out"]
+    for v in ("context+ffs", "all+ffs", "ai-toolkit", "tiny", "nano", "controlnet", "all+ffs+embedder"):
         m.config = SimpleNamespace(flux_lora_target=v)
         with pytest.raises(NotImplementedError, match="flux_lora_target"):
             m._lora_target_set()
