@@ -84,14 +84,19 @@ def patch_embed(P, cfg: PixArtConfig, x, prefix="pos_embed."):
 
 
 def adaln_single(P, cfg: PixArtConfig, timestep, resolution, aspect_ratio, B, dtype):
-    """-> (linear(silu(emb)) [B,6D], emb [B,D])"""
+    """-> (linear(silu(emb)) [B,6D], emb [B,D]); TOKENWISE timesteps [B, S] (pixart/transformer.py:790-850 `_embed_timesteps`): ([B,S,6D], [B,S,D]) — one
+    timestep embedding per token, the size conditions shared by a sample's tokens"""
     def tee(x, p):
         return _lin(F.silu(_lin(x, P, p + ".linear_1")), P, p + ".linear_2")
-    emb = tee(timestep_proj(timestep.expand(B), 256).to(dtype), "adaln_single.emb.timestep_embedder")
+    if timestep.ndim == 2:
+        emb = tee(timestep_proj(timestep.reshape(-1).float(), 256).to(dtype), "adaln_single.emb.timestep_embedder").view(B, timestep.shape[1], -1)
+    else:
+        emb = tee(timestep_proj(timestep.expand(B), 256).to(dtype), "adaln_single.emb.timestep_embedder")
     if cfg.additional:
         r = tee(timestep_proj(resolution.flatten().float(), 256).to(dtype), "adaln_single.emb.resolution_embedder").reshape(B, -1)
         a = tee(timestep_proj(aspect_ratio.flatten().float(), 256).to(dtype), "adaln_single.emb.aspect_ratio_embedder").reshape(B, -1)
-        emb = emb + torch.cat([r, a], dim=1)
+        size = torch.cat([r, a], dim=1)
+        emb = emb + (size[:, None] if emb.ndim == 3 else size)
     return _lin(F.silu(emb), P, "adaln_single.linear"), emb
 
 
@@ -124,8 +129,12 @@ def _attn(P, p, x, ctx, H, bias=None, _lin=_lin):
 def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6, _lin=_lin):
     """pixart/transformer.py:95-145 with timestep [B, 6D]; `_lin` = the Linear implementation of the block (plain, or lin_fp8)"""
     B, S, D = h.shape
-    mod = P[p + "scale_shift_table"][None] + t6.reshape(B, 6, D)
-    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
+    if t6.ndim == 3:        # tokenwise (:82-97): one modulation row per token
+        mod = P[p + "scale_shift_table"][None, None] + t6.reshape(B, S, 6, D)
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (t.squeeze(2) for t in mod.chunk(6, dim=2))
+    else:
+        mod = P[p + "scale_shift_table"][None] + t6.reshape(B, 6, D)
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
     n = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale_msa) + shift_msa
     h = gate_msa * _attn(P, p + "attn1.", n, n, cfg.num_attention_heads, _lin=_lin) + h
     h = _attn(P, p + "attn2.", h, ctx, cfg.num_attention_heads, ctx_bias, _lin=_lin) + h
@@ -136,7 +145,11 @@ def block(P, p, cfg: PixArtConfig, h, ctx, ctx_bias, t6, _lin=_lin):
 
 def _head(P, cfg: PixArtConfig, h, emb, hh, ww):
     D = cfg.D
-    shift, scale = (P["scale_shift_table"][None] + emb[:, None]).chunk(2, dim=1)
+    if emb.ndim == 3:       # tokenwise (:749-753)
+        shift, scale = ((P["scale_shift_table"][None, None] + emb[:, :, None]).chunk(2, dim=2))
+        shift, scale = shift.squeeze(2), scale.squeeze(2)
+    else:
+        shift, scale = (P["scale_shift_table"][None] + emb[:, None]).chunk(2, dim=1)
     h = F.layer_norm(h, (D,), eps=1e-6) * (1 + scale) + shift
     h = _lin(h, P, "proj_out")
     p = cfg.patch_size

@@ -334,8 +334,8 @@ class ModelFoundation(ExplorativeModelingMixin):
     def _require_per_sample_timesteps(self, prepared_batch: dict, tokenwise_ok: bool = False):
         """The reference's DiT plugins also accept TOKENWISE timesteps [B, S] (CREPA self-flow; tests/test_flux_model.py:213-241,
         tests/test_sd3_model.py:179-204, tests/test_pixart_model.py:91-115) and clean conditioning tokens appended at t=0 (Flux Kontext,
-        tests/test_flux_model.py:243-272).  Both need per-token modulation rows.  Tokenwise timesteps are built for SD3 and Flux (`tokenwise_ok`: their engines run the AdaLN /
-        gated-residual kernels with one modulation row per token); PixArt, and the reference-image tokens everywhere, refuse loudly instead of training on the wrong conditioning."""
+        tests/test_flux_model.py:243-272).  Both need per-token modulation rows.  Tokenwise timesteps are built for SD3, Flux and the PixArt trunk (`tokenwise_ok`: their engines run the AdaLN /
+        gated-residual kernels with one modulation row per token); the PixArt ControlNet wrapper, and the reference-image tokens everywhere, refuse loudly instead of training on the wrong conditioning."""
         t = prepared_batch["timesteps"]
         if getattr(t, "ndim", 1) == 2 and tokenwise_ok:
             pass

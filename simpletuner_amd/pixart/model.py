@@ -70,7 +70,7 @@ class PixartSigma(ModelFoundation):
         return super().model_predict(prepared_batch)
 
     def _model_predict_single(self, prepared_batch: dict):
-        self._require_per_sample_timesteps(prepared_batch)
+        self._require_per_sample_timesteps(prepared_batch, tokenwise_ok=True)      # [B] or tokenwise [B, S] handed through unchanged (tests/test_pixart_model.py:91-115)
         dev = self.accelerator.device
         if prepared_batch["noisy_latents"].shape[1] != self.LATENT_CHANNEL_COUNT:
             raise ValueError(f"{self.NAME} requires a latent size of {self.LATENT_CHANNEL_COUNT} channels. Ensure you are using the correct VAE cache path.")

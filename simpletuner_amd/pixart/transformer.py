@@ -226,9 +226,14 @@ class PixArtTransformer2DModel(nn.Module):
                         bias=P[prefix + ".linear_2.bias"])
 
     def _conditioning(self, timestep, added_cond_kwargs, B, Hh, Ww):
-        """AdaLayerNormSingle: (t6 [B,6D], emb [B,D])"""
+        """AdaLayerNormSingle: (t6 [B,6D], emb [B,D]).  TOKENWISE timesteps [B, S] (CREPA self-flow; pixart/transformer.py:790-850 `_embed_timesteps`): one row per token,
+        (t6 [B*S,6D], emb [B*S,D]) — the blocks and the head then index their modulation rows per token (rows_per_batch = 1)"""
         dev = self.device_
-        t32 = timestep.to(device=dev, dtype=F32).reshape(-1).expand(B).contiguous()
+        tok = timestep.dim() == 2
+        S_tok = (Hh // 2) * (Ww // 2)
+        if tok and tuple(timestep.shape) != (B, S_tok):
+            raise ValueError(f"PixArt tokenwise timestep embedding expected shape ({B}, {S_tok}), got {tuple(timestep.shape)}.")       # pixart/transformer.py:807-810
+        t32 = timestep.to(device=dev, dtype=F32).reshape(-1).contiguous() if tok else timestep.to(device=dev, dtype=F32).reshape(-1).expand(B).contiguous()
         emb = self._mlp(ops.timestep_proj(t32, 256, 1.0), "adaln_single.emb.timestep_embedder")
         if self.use_additional_conditions:
             ack = added_cond_kwargs or {}
@@ -240,7 +245,10 @@ class PixArtTransformer2DModel(nn.Module):
                 ar = torch.tensor([[float(Hh / Ww)]], device=dev, dtype=F32).expand(B, -1)
             r = self._mlp(ops.timestep_proj(res.to(device=dev, dtype=F32).reshape(-1).contiguous(), 256, 1.0), "adaln_single.emb.resolution_embedder").reshape(B, -1)
             a = self._mlp(ops.timestep_proj(ar.to(device=dev, dtype=F32).reshape(-1).contiguous(), 256, 1.0), "adaln_single.emb.aspect_ratio_embedder").reshape(B, -1)
-            emb = ops.add(emb, torch.cat([r, a], dim=1).contiguous())
+            size = torch.cat([r, a], dim=1).contiguous()
+            if tok:         # the size conditions are shared by a sample's tokens (:840-843)
+                size = size[:, None, :].expand(B, S_tok, size.shape[1]).reshape(B * S_tok, -1)
+            emb = ops.add(emb, size)
         t6 = ops.gemm(ops.silu(emb), self.P["adaln_single.linear.weight"], bias=self.P["adaln_single.linear.bias"])
         return t6, emb
 
@@ -258,12 +266,16 @@ class PixArtTransformer2DModel(nn.Module):
         D, H, W = self.inner_dim, self.H, blk.W
         Dp = H * HP
         scale = 1.0 / math.sqrt(self.hd)
-        mod = (blk.P["scale_shift_table"].view(1, 6 * D) + t6).contiguous()             # [B, 6D] (tiny)
+        mod = (blk.P["scale_shift_table"].view(1, 6 * D) + t6).contiguous()             # [B, 6D] (tiny); tokenwise timesteps: [B*S, 6D], one row per token
         m = [mod[:, k * D:(k + 1) * D] for k in range(6)]                               # shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        rpb = (B * S) // mod.shape[0]                                                   # rows that share a modulation row: S, or 1 (tokenwise)
         train = save and blk.trainable
+        if rpb != S and (train or blk.fp8):
+            raise NotImplementedError("PixArt tokenwise timesteps: the frozen bf16 trunk forward only (the reference's ControlNet wrapper takes per-sample timesteps, "
+                                      "pixart/controlnet.py:241-246; the fp8 trunk form is not built for them)")
         if blk.fp8:
             return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
-        if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous():
+        if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous() and rpb == S:
             # the block as ONE C entry point (st355_block_pixart_fwd): the launches of the host-side sequencing below, in its order, on its
             # operands (every buffer allocated here, kept ones handed to the backward as before) — bit-identical to it (ST355_BLOCK_ABI=0 restores it)
             dev = h.device
@@ -287,7 +299,7 @@ class PixArtTransformer2DModel(nn.Module):
                 sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=None, K=K, Kt=None, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2,
                                      Q2t=None, K2=K2, K2t=None, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
             return h3, sv
-        n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
+        n1 = ops.ln_modulate_fwd(h, m[1], m[0], rpb)
         qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
         Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
         K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
@@ -296,7 +308,7 @@ class PixArtTransformer2DModel(nn.Module):
         lse = torch.empty(B, H, S, dtype=F32, device=h.device)
         ops.attn_fwd(Q, K, Vt, O, lse, B, H, S, Sp, HP, scale)
         ya = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
-        h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=S, aux_out=ya)
+        h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=rpb, aux_out=ya)
         q2 = ops.gemm(h1, W.q2_w, bias=W.q2_b)
         kv = ops.gemm(ctx2d, W.kv2_w, bias=W.kv2_b)
         Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S, want_xt=not ops.ATTN_TR)
@@ -306,11 +318,11 @@ class PixArtTransformer2DModel(nn.Module):
         lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)
         ops.attn_cross_fwd(Q2, K2, V2t, O2, lse2, B, H, S, Sk, Skp, HP, scale, key_bias=kbias)
         h2 = ops.gemm(O2, W.out2_w, bias=W.out2_b, epilogue=EPI_ADD, aux_in=h1)
-        n2 = ops.ln_modulate_fwd(h2, m[4], m[3], S)
+        n2 = ops.ln_modulate_fwd(h2, m[4], m[3], rpb)
         pre = torch.empty(B * S, 4 * D, dtype=BF16, device=h.device) if (save or exact) else None
         a = ops.gemm(n2, W.ff1_w, bias=W.ff1_b, epilogue=EPI_GELU, aux_out=pre)
         yf = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
-        h3 = ops.gemm(a, W.ff2_w, bias=W.ff2_b, epilogue=EPI_GATE_RESIDUAL, gate=m[5], aux_in=h2, rows_per_batch=S, aux_out=yf)
+        h3 = ops.gemm(a, W.ff2_w, bias=W.ff2_b, epilogue=EPI_GATE_RESIDUAL, gate=m[5], aux_in=h2, rows_per_batch=rpb, aux_out=yf)
         sv = None
         if save:
             sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
@@ -474,8 +486,8 @@ class PixArtTransformer2DModel(nn.Module):
 
     def _head(self, h, emb, B, hh, ww):
         D = self.inner_dim
-        mod = (self.P["scale_shift_table"].view(1, 2 * D) + torch.cat([emb, emb], dim=1)).contiguous()      # (shift, scale)
-        n = ops.ln_modulate_fwd(h, mod[:, D:], mod[:, :D], hh * ww)
+        mod = (self.P["scale_shift_table"].view(1, 2 * D) + torch.cat([emb, emb], dim=1)).contiguous()      # (shift, scale); tokenwise: one row per token
+        n = ops.ln_modulate_fwd(h, mod[:, D:], mod[:, :D], (B * hh * ww) // mod.shape[0])
         pk = ops.gemm(n, self.P["proj_out.weight"], bias=self.P["proj_out.bias"])
         out = ops.unpatchify(pk.view(B, hh * ww, -1), self.out_channels, 2 * hh, 2 * ww, order=1)
         return out, mod
@@ -486,7 +498,7 @@ class PixArtTransformer2DModel(nn.Module):
         dp = torch.zeros(dpk.shape[0], self.proj_out_wT.shape[1], dtype=BF16, device=dpk.device)
         dp[:, :dpk.shape[1]] = dpk
         dn = ops.gemm(dp, self.proj_out_wT)
-        dh, _ = ops.ln_modulate_bwd(dn, h_final, mod[:, D:], hh * ww)
+        dh, _ = ops.ln_modulate_bwd(dn, h_final, mod[:, D:], (B * hh * ww) // mod.shape[0])
         return dh
 
     @staticmethod
@@ -617,6 +629,8 @@ class PixArtSigmaControlNetTransformerModel(CheckpointPlanMixin, nn.Module):
             blk.refresh(dev)                                   # the adapter's padded working copies follow its parameters
         h = T._patch_embed(latents)
         cs = T._patch_embed(cond)
+        if timestep.dim() != 1 and timestep.numel() != 1:
+            raise NotImplementedError("PixArt ControlNet wrapper: per-sample timesteps only (the reference's wrapper calls adaln_single directly, pixart/controlnet.py:241-246)")
         t6, emb = T._conditioning(timestep, added_cond_kwargs, B, Hh, Ww)
         ctx2d = T._caption(enc)
         kb = T._key_bias(mask, B, Sk, dev)

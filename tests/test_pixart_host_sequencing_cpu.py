@@ -1,6 +1,7 @@
 """The PixArt-Sigma ControlNet-Transformer engine's HOST SEQUENCING on the CPU (see tests/ops_emulator.py): trunk forward, and the trained ControlNet branch's
 hand-written backward (copied blocks with 72 -> 80 padded heads, zero-init projections, `scale_shift_table` rows) against autograd on the oracle — the
 configuration of BASELINE.json configs[4] at toy width.  The kernels are proven by tests/test_pixart_model_gpu.py; this runs the same engine code without a GPU."""
+import pytest
 import torch
 
 from oracle.pixart import PixArtConfig, controlnet_forward, pixart_forward
@@ -104,3 +105,26 @@ def test_controlnet_checkpoint_plans_through_the_emulator_are_bit_identical(monk
     for plan in ((None, None), (2, 3)):
         o1, g1 = run(True, *plan)
         assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.float().abs().sum().item() > 0
+
+
+def test_trunk_forward_with_tokenwise_timesteps_through_the_emulator_matches_the_oracle(monkeypatch):
+    """TOKENWISE timesteps [B, S] (CREPA self-flow; reference tests/test_pixart_model.py:91-115; oracle branch pinned to the executed reference class): per-token
+    AdaLN-single rows in every block and in the head (rows_per_batch = 1), the size conditions shared by a sample's tokens"""
+    EMU.install(monkeypatch)
+    from simpletuner_amd.pixart.transformer import PixArtTransformer2DModel
+    m = PixArtTransformer2DModel(device="cpu", **ARCH)
+    m.init_synthetic(3)
+    P = {k: v.detach().float() for k, v in m.named_parameters()}
+    lat, cond, enc, mask, t = _inputs()
+    B, S = lat.shape[0], (lat.shape[2] // 2) * (lat.shape[3] // 2)
+    tt = torch.rand(B, S, generator=torch.Generator().manual_seed(8)) * 900.0 + 50.0
+    EMU.BLOCK_CALLS.clear()
+    out = m(lat, encoder_hidden_states=enc, timestep=tt, encoder_attention_mask=mask, return_dict=False)[0]
+    assert EMU.BLOCK_CALLS.get("pixart_fwd", 0) == 0            # per-token rows: the host-side sequencing, not the per-sample C entry point
+    res = torch.tensor([[float(lat.shape[2]), float(lat.shape[3])]]).expand(B, -1)
+    ar = torch.tensor([[lat.shape[2] / lat.shape[3]]]).expand(B, -1)
+    ref = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, tt, res, ar)
+    flat = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, tt.mean(dim=1), res, ar)
+    assert _rel(out, ref) < 2e-2 and _rel(flat, ref) > 5e-2, (_rel(out, ref), _rel(flat, ref))
+    with pytest.raises(ValueError, match="tokenwise timestep embedding expected shape"):
+        m(lat, encoder_hidden_states=enc, timestep=tt[:, :5], encoder_attention_mask=mask, return_dict=False)

@@ -177,3 +177,25 @@ def test_pixart_block_c_entry_points_equal_host_sequencing(hw, Sk, monkeypatch):
     assert ops.BLOCK_CALLS.get("block_pixart_fwd", 0) == 6 and ops.BLOCK_CALLS.get("block_pixart_bwd", 0) >= 4, ops.BLOCK_CALLS
     assert torch.equal(o0, o1) and g0.float().abs().sum().item() > 0
     assert torch.equal(g0, g1), f"{(g0 != g1).sum().item()} of {g0.numel()} gradient elements differ"
+
+
+def test_pixart_trunk_tokenwise_timesteps_match_oracle():
+    """TOKENWISE timesteps [B, S] (CREPA self-flow; reference tests/test_pixart_model.py:91-115; pixart/transformer.py:60-145, 749-753, 790-850) through the trunk on
+    the HIP path: one AdaLN-single modulation row per token in every block and in the head (rows_per_batch = 1 in the AdaLN and gated-residual kernels).  The
+    oracle's tokenwise branch is pinned to the executed reference class (tests/test_ref_models_cpu.py)."""
+    from simpletuner_amd.pixart.transformer import PixArtTransformer2DModel
+    dev = "cuda:0"
+    m = PixArtTransformer2DModel(device=dev, **ARCH)
+    m.init_synthetic(3)
+    P = {k: v.detach().float().cpu() for k, v in m.named_parameters()}
+    lat, cond, enc, mask, t = _inputs(hw=(16, 24))
+    B, S = 2, 8 * 12
+    tt = torch.rand(B, S, generator=torch.Generator().manual_seed(8)) * 900.0 + 50.0
+    out = m(lat.to(dev), encoder_hidden_states=enc.to(dev), timestep=tt.to(dev), encoder_attention_mask=mask.to(dev), return_dict=False)[0]
+    res, ar = torch.tensor([[16.0, 24.0]]).expand(2, -1), torch.tensor([[16.0 / 24.0]]).expand(2, -1)
+    ref = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, tt, res, ar)
+    flat = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, tt.mean(dim=1), res, ar)
+    r = _rel(out.cpu(), ref)
+    cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), ref.flatten(), dim=0).item()
+    print(f"[pixart tokenwise fwd] rel-L2 {r:.3e} cos {cos:.6f}; the batch-wise forward at the mean timestep sits {_rel(flat, ref):.3e} away")
+    assert r < 2e-2 and cos > 0.9995 and _rel(flat, ref) > 5e-2

@@ -196,7 +196,8 @@ def test_lora_checkpoint_layout_roundtrip(tmp_path):
 
 
 def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
-    """the reference's CREPA self-flow / Kontext inputs (tests/test_flux_model.py:213-272) are refused loudly, never silently mis-conditioned"""
+    """the reference's Kontext inputs (clean conditioning tokens, tests/test_flux_model.py:243-272) are refused loudly, never silently mis-conditioned; tokenwise
+    timesteps are taken by all three DiT plugins since round 4 (the PixArt ControlNet wrapper refuses them, as the reference's does not handle them)"""
     from types import SimpleNamespace
 
     import pytest
@@ -207,9 +208,9 @@ def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
     for cls in (Flux, SD3, PixartSigma):
         m = cls.__new__(cls)
         m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
-        if cls is PixartSigma:           # SD3 and Flux take tokenwise timesteps (test_*_plugin_hands_tokenwise_timesteps_to_the_transformer below)
+        if cls is PixartSigma:
             with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
-                m._model_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 16, 4, 4)})
+                m._controlnet_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 4, 4, 4)})
         with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
             m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
 
@@ -234,6 +235,26 @@ def test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer():
     out = m._model_predict_single(batch)
     assert out["model_prediction"].shape == (1, 16, 4, 4)
     assert seen["timestep"].dtype == torch.float32 and torch.equal(seen["timestep"], batch["timesteps"])
+
+
+def test_pixart_plugin_hands_tokenwise_timesteps_to_the_transformer():
+    """the reference's tests/test_pixart_model.py:91-115 on the st355 plugin: [B, S] timesteps reach the transformer unchanged"""
+    from types import SimpleNamespace
+
+    from simpletuner_amd.pixart.model import PixartSigma
+    m = PixartSigma.__new__(PixartSigma)
+    m.config, m.accelerator = SimpleNamespace(), SimpleNamespace(device=torch.device("cpu"))
+    seen = {}
+
+    def fake(*a, **kw):
+        seen.update(kw)
+        return (torch.randn(1, 8, 4, 4),)
+
+    m.model = fake
+    batch = {"noisy_latents": torch.randn(1, 4, 4, 4), "timesteps": torch.tensor([[100, 900, 200, 800]]), "encoder_hidden_states": torch.randn(1, 4, 16),
+             "encoder_attention_mask": torch.ones(1, 4), "resolution": torch.tensor([[4.0, 4.0]]), "aspect_ratio": torch.tensor([[1.0]])}
+    out = m._model_predict_single(batch)
+    assert out["model_prediction"].shape == (1, 4, 4, 4) and torch.equal(seen["timestep"], batch["timesteps"])
 
 
 def test_flux_plugin_hands_tokenwise_timesteps_to_the_transformer():

@@ -82,7 +82,39 @@ def gen_flux():
             "_cite": "simpletuner/helpers/models/flux/transformer.py:245-294 (_flux_tokenwise_conditioning), :386-412 (AdaLN with a [B, S, D] embedding), :1068-1086 (temb_img / temb_txt / temb_single), :1505"}
 
 
+def gen_pixart():
+    T = ref_shim.ref_module("simpletuner.helpers.models.pixart.transformer")
+
+    def call(m, a):
+        return m(a["hidden_states"], encoder_hidden_states=a["encoder_hidden_states"], timestep=a["timestep"],
+                 added_cond_kwargs={"resolution": a["resolution"], "aspect_ratio": a["aspect_ratio"]}, encoder_attention_mask=a["encoder_attention_mask"],
+                 return_dict=False)[0]
+
+    cfg = dict(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=3, cross_attention_dim=48, sample_size=16,
+               patch_size=2, caption_channels=20, use_additional_conditions=True)
+    model = T.PixArtTransformer2DModel(**cfg)
+    st = seed_params(model, 431)
+    model.eval()
+    g = torch.Generator().manual_seed(432)
+    B, Hl, Wl, L = 2, 8, 12, 6
+    S = (Hl // 2) * (Wl // 2)
+    mask = torch.ones(B, L)
+    mask[0, L - 2:] = 0
+    inputs = {"hidden_states": torch.randn(B, 4, Hl, Wl, generator=g), "encoder_hidden_states": torch.randn(B, L, 20, generator=g),
+              "timestep": torch.rand(B, S, generator=g) * 1000.0, "resolution": torch.tensor([[float(Hl * 8), float(Wl * 8)]] * B),
+              "aspect_ratio": torch.tensor([[float(Hl) / float(Wl)]] * B), "encoder_attention_mask": mask}
+    r = strip(run(model, call, inputs, 433))
+    r["inputs"] = inputs
+    flat = dict(inputs, timestep=torch.tensor([137.0, 842.0]))
+    tok = dict(inputs, timestep=flat["timestep"][:, None].expand(B, S).contiguous())
+    with torch.no_grad():
+        a, b = call(model, flat), call(model, tok)
+    assert (a - b).norm() / a.norm() < 1e-5, "reference: a constant tokenwise timestep differs from the batch-wise forward"
+    return {"config": cfg, "seed": 431, "state_checksum": state_checksum(st), "case": r,
+            "_cite": "simpletuner/helpers/models/pixart/transformer.py:60-145 (tokenwise block), :749-753 (head), :790-850 (_embed_timesteps)"}
+
+
 if __name__ == "__main__":
-    G = {"sd3": gen_sd3(), "flux": gen_flux()}
+    G = {"sd3": gen_sd3(), "flux": gen_flux(), "pixart": gen_pixart()}
     torch.save(G, OUT / "ref_tokenwise.pt")
     print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items()})
