@@ -139,7 +139,8 @@ class Flux(ModelFoundation):
 
     def _model_predict_single(self, prepared_batch: dict):
         """flux/model.py:707-864"""
-        self._require_per_sample_timesteps(prepared_batch, tokenwise_ok=True)      # [B] or tokenwise [B, S_img] (flux/model.py:560-600 `_normalize_timesteps`)
+        # [B] or tokenwise [B, S_img] timesteps (flux/model.py:560-600 `_normalize_timesteps`); Kontext's clean reference-image tokens ride along at t = 0 (:602-618, 762-778)
+        self._require_per_sample_timesteps(prepared_batch, tokenwise_ok=True, conditioning_ok=True)
         lat = prepared_batch["latents"]
         B, Cc, Hh, Ww = lat.shape
         dev = self.accelerator.device
@@ -171,6 +172,21 @@ class Flux(ModelFoundation):
             elif ts.shape[0] != B:
                 raise ValueError(f"Flux expected tokenwise timesteps for batch size {B}, got {ts.shape[0]}.")
         prepared_batch["timesteps"] = ts / 1000.0
+        # Kontext (flux/model.py:762-778, 602-618): the packed reference-image tokens are appended to the scene tokens, their position ids to the image ids, and they are
+        # conditioned on t = 0 — which makes the timesteps tokenwise: [t ... t | 0 ... 0] per sample
+        cond_seq, cond_ids = prepared_batch.get("conditioning_packed_latents"), prepared_batch.get("conditioning_ids")
+        use_cond = cond_seq is not None
+        scene_len = packed.shape[1]
+        if use_cond:
+            if cond_ids is None:
+                raise ValueError("conditioning_packed_latents needs conditioning_ids (the reference-image tokens' position ids)")
+            ts = prepared_batch["timesteps"]
+            if ts.ndim == 1:
+                ts = ts[:, None].expand(-1, scene_len)
+            prepared_batch["timesteps"] = torch.cat([ts, torch.zeros(B, cond_seq.shape[1], device=dev, dtype=torch.float32)], dim=1)
+            packed = torch.cat([packed, cond_seq.to(device=dev, dtype=BF16)], dim=1)
+            ids_b = img_ids[None].expand(B, -1, -1) if img_ids.dim() == 2 else img_ids
+            img_ids = torch.cat([ids_b, cond_ids.to(device=dev, dtype=ids_b.dtype)], dim=1)
         attention_mask = None
         if getattr(self.config, "flux_attention_masked_training", False):          # flux/model.py:813-823
             attention_mask = prepared_batch.get("encoder_attention_mask")
@@ -190,6 +206,8 @@ class Flux(ModelFoundation):
             return_dict=False,
             attention_mask=attention_mask,
         )[0]
+        if use_cond and getattr(self.config, "model_flavour", None) == "kontext":      # drop the reference-image tokens before unpacking (flux/model.py:844-847)
+            model_pred = model_pred[:, :scene_len, :]
         return {
             "model_prediction": _UnpackFn.apply(model_pred, Hh * 8, Ww * 8),
             "crepa_hidden_states": None,

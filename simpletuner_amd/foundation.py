@@ -331,7 +331,7 @@ class ModelFoundation(ExplorativeModelingMixin):
             model, seen = model.module, seen + 1
         return model
 
-    def _require_per_sample_timesteps(self, prepared_batch: dict, tokenwise_ok: bool = False):
+    def _require_per_sample_timesteps(self, prepared_batch: dict, tokenwise_ok: bool = False, conditioning_ok: bool = False):
         """The reference's DiT plugins also accept TOKENWISE timesteps [B, S] (CREPA self-flow; tests/test_flux_model.py:213-241,
         tests/test_sd3_model.py:179-204, tests/test_pixart_model.py:91-115) and clean conditioning tokens appended at t=0 (Flux Kontext,
         tests/test_flux_model.py:243-272).  Both need per-token modulation rows.  Tokenwise timesteps are built for SD3, Flux and the PixArt trunk (`tokenwise_ok`: their engines run the AdaLN /
@@ -341,7 +341,7 @@ class ModelFoundation(ExplorativeModelingMixin):
             pass
         elif getattr(t, "ndim", 1) != 1:
             raise NotImplementedError(f"tokenwise timesteps {tuple(t.shape)} are not implemented on the st355 path (per-sample [B] only)")
-        if prepared_batch.get("conditioning_packed_latents") is not None:
+        if prepared_batch.get("conditioning_packed_latents") is not None and not conditioning_ok:
             raise NotImplementedError("conditioning_packed_latents (reference-image tokens) are not implemented on the st355 path")
 
     # ---- lifecycle hooks the reference Trainer calls on `self.model` outside the step loop (trainer.py:329-330, 2618-2621, 2944, 3243-3292, 3353,

@@ -333,3 +333,36 @@ def test_context_target_set_through_the_emulator_matches_the_oracle(monkeypatch)
         key, which = name.split(".lora_")
         ref = lp[key][0 if which.startswith("A") else 1].grad
         assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))
+
+
+def test_reference_image_tokens_at_t_zero_through_the_emulator_match_the_oracle(monkeypatch):
+    """Kontext (flux/model.py:762-778, 602-618): 16 clean reference-image tokens appended to the 64 scene tokens, their position ids appended to the image ids (ids
+    handed over per sample, [B, S, 3]), conditioned on t = 0 through tokenwise timesteps [t ... t | 0 ... 0]; prediction (all 80 tokens) and LoRA gradients of a loss
+    on the scene tokens against autograd on the oracle"""
+    model = _model(monkeypatch, 1, 2)
+    model.add_lora_adapter(rank=16, alpha=16.0, init_b_std=0.02)
+    d = _inputs(1, 16, 16, 64)
+    g = torch.Generator().manual_seed(21)
+    Ss, Sc = d["packed"].shape[1], 16
+    cond = torch.randn(1, Sc, 64, generator=g).to(BF16)
+    cond_ids = OF.prepare_latent_image_ids(8, 8).clone(); cond_ids[:, 0] = 1.0          # the reference image's own position grid, first id channel 1
+    d = dict(d, packed=torch.cat([d["packed"], cond], dim=1), img_ids=torch.cat([d["img_ids"], cond_ids], dim=0)[None],
+             t=torch.cat([torch.full((1, Ss), 0.37), torch.zeros(1, Sc)], dim=1), target=torch.cat([d["target"], torch.zeros(1, Sc, 64).to(BF16)], dim=1))
+
+    def loss_of(out):
+        return ((out[:, :Ss].float() - d["target"][:, :Ss].float()) ** 2).mean()
+
+    out = model(hidden_states=d["packed"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["t"], img_ids=d["img_ids"],
+                txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0]
+    loss_of(out).backward()
+    P, lora, scale = PU.oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    f = lambda k: d[k].float()
+    o_out = OF.flux_forward(P, PU.oracle_cfg(model), f("packed"), f("prompt"), f("pooled"), d["t"], d["img_ids"][0], d["txt_ids"], d["guidance"], lp, scale)
+    loss_of(o_out).backward()
+    assert out.shape == o_out.shape == (1, Ss + Sc, 64) and PU.rel_l2(out.detach(), o_out.detach()) < 2e-2
+    for name, p in model.named_parameters():
+        if ".lora_" in name:
+            key, which = name.split(".lora_")
+            ref = lp[key][0 if which.startswith("A") else 1].grad
+            assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))

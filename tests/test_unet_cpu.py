@@ -211,8 +211,9 @@ def test_dit_plugins_refuse_tokenwise_timesteps_and_reference_tokens():
         if cls is PixartSigma:
             with pytest.raises(NotImplementedError, match="tokenwise timesteps"):
                 m._controlnet_predict_single({"timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]), "latents": torch.zeros(1, 4, 4, 4)})
-        with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
-            m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
+        if cls is not Flux:              # Flux appends them at t = 0 (test_flux_plugin_appends_clean_conditioning_tokens_at_t_zero)
+            with pytest.raises(NotImplementedError, match="conditioning_packed_latents"):
+                m._model_predict_single({"timesteps": torch.tensor([100.0]), "latents": torch.zeros(1, 16, 4, 4), "conditioning_packed_latents": torch.zeros(1, 2, 64)})
 
 
 def test_sd3_plugin_hands_tokenwise_timesteps_to_the_transformer():
@@ -285,6 +286,43 @@ def test_flux_plugin_hands_tokenwise_timesteps_to_the_transformer():
         assert torch.allclose(seen["timestep"], torch.tensor([[0.1, 0.9, 0.5, 0.7]]))
         with pytest.raises(ValueError, match="sequence length"):
             m._model_predict_single(dict(batch, timesteps=torch.tensor([[100.0, 900.0, 500.0]])))
+    finally:
+        FM._UnpackFn.apply, FM.pack_latents = orig, orig_pack
+
+
+def test_flux_plugin_appends_clean_conditioning_tokens_at_t_zero():
+    """the reference's tests/test_flux_model.py:243-272 (test_model_predict_appends_clean_conditioning_timesteps) on the st355 plugin: Kontext's packed reference-image
+    tokens are appended to the scene tokens (and their ids to the image ids), conditioned on t = 0 — timesteps [[0.1, 0.9, 0.5, 0.7, 0.0, 0.0]] — and dropped from
+    the prediction before unpacking"""
+    from types import SimpleNamespace
+
+    import simpletuner_amd.flux.model as FM
+    m = FM.Flux.__new__(FM.Flux)
+    m.config, m.accelerator, m._ids_cache = SimpleNamespace(model_flavour="kontext"), SimpleNamespace(device=torch.device("cpu")), {}
+    seen = {}
+
+    def fake(**kw):
+        seen.update(kw)
+        return (torch.arange(6 * 64, dtype=torch.float32).view(1, 6, 64).to(torch.bfloat16),)
+
+    m.model = fake
+    m.get_trained_component = lambda: SimpleNamespace(config=SimpleNamespace(guidance_embeds=False))
+    orig, orig_pack = FM._UnpackFn.apply, FM.pack_latents
+    got = {}
+    FM._UnpackFn.apply = staticmethod(lambda packed, h, w: got.setdefault("packed", packed) is None or torch.zeros(packed.shape[0], 16, h // 8, w // 8))
+    FM.pack_latents = lambda x: x.reshape(x.shape[0], -1, 64)
+    try:
+        batch = {"noisy_latents": torch.randn(1, 16, 4, 4), "latents": torch.randn(1, 16, 4, 4), "timesteps": torch.tensor([[100.0, 900.0, 500.0, 700.0]]),
+                 "prompt_embeds": torch.randn(1, 3, 16), "add_text_embeds": torch.randn(1, 8), "conditioning_packed_latents": torch.randn(1, 2, 64),
+                 "conditioning_ids": torch.zeros(1, 2, 3)}
+        out = m._model_predict_single(batch)
+        assert out["model_prediction"].shape == (1, 16, 4, 4)
+        assert torch.allclose(seen["timestep"], torch.tensor([[0.1, 0.9, 0.5, 0.7, 0.0, 0.0]]))
+        assert seen["hidden_states"].shape == (1, 6, 64) and seen["img_ids"].shape == (1, 6, 3)
+        assert got["packed"].shape == (1, 4, 64)                                    # the two reference-image tokens were dropped
+        # per-sample timesteps are broadcast over the scene tokens first (flux/model.py:616-617)
+        m._model_predict_single(dict(batch, timesteps=torch.tensor([250.0])))
+        assert torch.allclose(seen["timestep"], torch.tensor([[0.25, 0.25, 0.25, 0.25, 0.0, 0.0]]))
     finally:
         FM._UnpackFn.apply, FM.pack_latents = orig, orig_pack
 
