@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
                                                           const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lsep,
                                                           const float* __restrict__ delta, bf16* __restrict__ dK, bf16* __restrict__ dVrows, int64_t ld_dv,
                                                           int H, int Sq, int Sqp, int Sk, float scale, float scale2, RopeBwd rp) {
-  static_assert(HD == 128 || HD == 96, "k_attn_bwd_dkv4: head_dim 128 or 96");
+  static_assert(HD == 128 || HD == 96 || HD == 64, "k_attn_bwd_dkv4: head_dim 128, 96 or 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -827,9 +827,15 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
           ST355_DKV4_OPERANDS
 #include "gen/attn_dkv4_clobbers.inc"
       );
-    } else {
+    } else if constexpr (HD == 96) {
       asm volatile(
 #include "gen/attn_dkv4_hd96_body.inc"
+          ST355_DKV4_OPERANDS
+#include "gen/attn_dkv4_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "gen/attn_dkv4_hd64_body.inc"
           ST355_DKV4_OPERANDS
 #include "gen/attn_dkv4_clobbers.inc"
       );
@@ -889,7 +895,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
                                                           const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                           const float* __restrict__ delta, bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk,
                                                           float scale, float scale2, RopeBwd rp, unsigned long long* trace) {
-  static_assert(HD == 128 || HD == 96, "k_attn_bwd_dq64: head_dim 128 or 96");
+  static_assert(HD == 128 || HD == 96 || HD == 64, "k_attn_bwd_dq64: head_dim 128, 96 or 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -937,9 +943,15 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
           ST355_DQ64_OPERANDS
 #include "gen/attn_dq64_clobbers.inc"
       );
-    } else {
+    } else if constexpr (HD == 96) {
       asm volatile(
 #include "gen/attn_dq64_hd96_body.inc"
+          ST355_DQ64_OPERANDS
+#include "gen/attn_dq64_clobbers.inc"
+      );
+    } else {
+      asm volatile(
+#include "gen/attn_dq64_hd64_body.inc"
           ST355_DQ64_OPERANDS
 #include "gen/attn_dq64_clobbers.inc"
       );
@@ -1015,7 +1027,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   const double fl_unit = 2.0 * (double)B * H * (double)S * Sk * d;  // one Sq x Sk x d contraction
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  const bool use_dkv4 = !Qt && (d == 128 || d == 96) && !key_bias && attn_dkv_impl() == 4;
+  const bool use_dkv4 = !Qt && !key_bias && attn_dkv_impl() == 4;                // head_dim 128 / 96 / 64 (every head_dim built)
   {
     ProfScope ps(stream, ST355_K_ATTN_PREP, 2.0 * B * H * (double)S * d, 6.0 * B * H * (double)S * d);
     dim3 grid(Sp / 64, H, B);
@@ -1041,7 +1053,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
                        (const float*)lsep, (const float*)delta, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);      \
   } while (0)
       if (d == 128) ST355_DKV4_LAUNCH(128);
-      else ST355_DKV4_LAUNCH(96);
+      else if (d == 96) ST355_DKV4_LAUNCH(96);
+      else ST355_DKV4_LAUNCH(64);
 #undef ST355_DKV4_LAUNCH
     } else if (!Qt) {
       dim3 grid((Sk + 255) / 256, H, B);
@@ -1076,7 +1089,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
-  if ((d == 128 || d == 96) && !Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
+  if (!Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int lds = 3 * 2 * 64 * 256;
@@ -1088,7 +1101,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
                        (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq, g_attn_dq_trace);                                \
   } while (0)
     if (d == 128) ST355_DQ64_LAUNCH(128);
-    else ST355_DQ64_LAUNCH(96);
+    else if (d == 96) ST355_DQ64_LAUNCH(96);
+    else ST355_DQ64_LAUNCH(64);
 #undef ST355_DQ64_LAUNCH
     if ((rc = st355_check_launch("attn_bwd_dq64")) != 0) return rc;
   } else {

@@ -826,8 +826,8 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
         assert torch.equal(dQ2, dQ)                                       # (k_attn_bwd_dq64, where it applies, is bit-identical as well)
-        if d in (96, 128) and kb is None:
-            # head_dim 128 / 96 without a key bias take the hand-scheduled k_attn_bwd_dkv4 (same scores; the statistics ride in the MFMA chains: another
+        if kb is None:
+            # every head_dim without a key bias takes the hand-scheduled k_attn_bwd_dkv4 (same scores; the statistics ride in the MFMA chains: another
             # summation order): fp32-rounding agreement; dkv3 itself stays bit-identical to the copy-reading kernel
             assert report("dkv4 dK vs dkv2", dK2, dK)[0] < 2e-3 and report("dkv4 dV vs dkv2", dqkv2[:, 2 * D:], dqkv[:, 2 * D:])[0] < 2e-3
             prev = ops.attn_set_impl(dkv=3)
@@ -841,18 +841,21 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
             assert torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 16, 1024), (2, 4, 320)])
-def test_attention_64_row_kernels_head_dim_96(ops, B, H, S):
-    """the head_dim-96 builds of the 64-row kernels (PixArt-Sigma's head_dim 72, zero padded to 96: 6 k-steps, 3 d tiles, tile images at the 256-byte pitch)
-    against the 32-row kernels: O to bf16 rounding, lse2 to fp32 rounding, dQ bit-identical, dK / dV to fp32 summation order; the padded channels stay zero"""
+@pytest.mark.parametrize("B,H,S,hd,dv_", [(1, 16, 1024, 96, 72), (2, 4, 320, 96, 72), (2, 10, 1024, 64, 64), (1, 5, 4096, 64, 64), (2, 3, 192, 64, 64)])
+def test_attention_64_row_kernels_narrow_heads(ops, B, H, S, hd, dv_):
+    """the head_dim-96 (PixArt-Sigma's 72, zero padded: 6 k-steps, 3 d tiles) and head_dim-64 (SDXL / SD3 / SD 1.x: 4 k-steps, 2 d tiles; SDXL's two self-attention
+    shapes) builds of the 64-row kernels — tile images at the 256-byte pitch — against the 32-row kernels: O to bf16 rounding, lse2 to fp32 rounding, dQ
+    bit-identical, dK / dV to fp32 summation order; padded channels stay zero.  One row of Q is spiked against a key of a late tile (the forward's out-of-line
+    re-reference)."""
     torch.manual_seed(94)
     d_ = dev()
-    hd, dv_ = 96, 72
     D = H * hd
     scale = 1.0 / math.sqrt(dv_)
     mk = lambda *sh: torch.randn(*sh, device=d_)
     Q, K = mk(B, H, S, hd), mk(B, H, S, hd)
     Q[..., dv_:] = 0; K[..., dv_:] = 0
+    if S >= 192:
+        Q[0, 0, 5] = K[0, 0, S - 40] * 6
     Q, K = Q.to(BF16), K.to(BF16)
     V = mk(B * S, H, hd); V[..., dv_:] = 0
     V = V.reshape(B * S, D).to(BF16)
@@ -875,14 +878,15 @@ def test_attention_64_row_kernels_head_dim_96(ops, B, H, S):
             res[impl] += [dQ, dK, dqkv]
     finally:
         ops.attn_set_impl(fwd=prev[0], dq=prev[1], dkv=prev[2])
-    assert report("fwd64<96> O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
+    assert report(f"fwd64<{hd}> O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
     assert float((res[64][1] - res[32][1]).abs().max()) < 1e-4
-    assert torch.equal(res[64][2], res[32][2]), "dq64<96> is not bit-identical to dq"
-    assert report("dkv4<96> dK vs dkv3", res[64][3], res[32][3])[0] < 2e-3
-    assert report("dkv4<96> dV vs dkv3", res[64][4][:, 2 * D:], res[32][4][:, 2 * D:])[0] < 2e-3
-    for t in (res[64][2], res[64][3]):
-        assert t[..., dv_:].abs().max().item() == 0
-    assert res[64][0].view(B * S, H, hd)[..., dv_:].abs().max().item() == 0
+    assert torch.equal(res[64][2], res[32][2]), f"dq64<{hd}> is not bit-identical to dq"
+    assert report(f"dkv4<{hd}> dK vs dkv3", res[64][3], res[32][3])[0] < 2e-3
+    assert report(f"dkv4<{hd}> dV vs dkv3", res[64][4][:, 2 * D:], res[32][4][:, 2 * D:])[0] < 2e-3
+    if dv_ < hd:
+        for t in (res[64][2], res[64][3]):
+            assert t[..., dv_:].abs().max().item() == 0
+        assert res[64][0].view(B * S, H, hd)[..., dv_:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("B,H,S,d", [(1, 2, 128, 128), (2, 3, 300, 128), (1, 2, 1024, 128), (2, 2, 231, 64), (1, 4, 640, 64), (1, 2, 333, 96), (2, 2, 512, 96)])

@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&hm, maxd, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
     printf("  O vs generation 1: %llu of %lld elements differ (max |d| %.3e)\n", hb, (long long)nr, hm);
   }
-  if (strcmp(gen, "1") != 0 && (d == 128 || d == 96) && S % 64 == 0) {   // k_attn_fwd64 (one wave per SIMD, 64 queries per wave): timed, O and lse2 compared with k_attn_fwd4
+  if (strcmp(gen, "1") != 0 && S % 64 == 0) {   // k_attn_fwd64 (one wave per SIMD, 64 queries per wave): timed, O and lse2 compared with k_attn_fwd4
     bf16* O6; float* lse6; CK(hipMalloc(&O6, nr * 2)); CK(hipMalloc(&lse6, (size_t)BH * S * 4));
     CK(hipMemsetAsync(O6, 0, nr * 2, st)); CK(hipMemsetAsync(lse6, 0, (size_t)BH * S * 4, st));
     g_attn_fwd_impl = 64;
@@ -201,7 +201,7 @@ int main(int argc, char** argv) {
              u[2] - u[1], u[3] - u[2], u[4] - u[3], u[4] - u[0], u[6] - u[5], u[7] - u[6], u[8] - u[7], u[8] - u[5]);
     }
   }
-  if (d == 128 || d == 96) {          // dkv4 vs dkv3: K is pre-scaled and re-rounded in dkv4 -> agreement to bf16 rounding
+  if (d == 128 || d == 96 || d == 64) {          // dkv4 vs dkv3: K is pre-scaled and re-rounded in dkv4 -> agreement to bf16 rounding
     float* maxd; double *sd, *sr; CK(hipMalloc(&maxd, 4)); CK(hipMalloc(&sd, 8)); CK(hipMalloc(&sr, 8));
     struct { const char* n; const bf16* a; const bf16* b; int64_t cnt; } c4[] = {{"dK", dK4, dK2, (int64_t)nh}, {"dV (whole dqkv rows)", dqkv4, dqkv2, (int64_t)nr * 3}};
     for (auto& c : c4) {

@@ -52,7 +52,7 @@ V_ROWN, V_RA = 56, 57                                             # scratch (par
 ROWA = [32 + k for k in range(8)]                                 # (slot + lane row base) ^ (ks << 5): K / V row fragments of k-step ks
 TRX = [0x00, 0x10, 0x40, 0x50, 0x80, 0x90, 0xc0, 0xd0]            # chunk XORs of the transposed reads: (4 dt) << 4 and ((4 dt) ^ 1) << 4
 TRA = [40 + k for k in range(8)]                                  # (slot + lane tr base) ^ TRX[j]
-CAP = float(os.environ.get("DQ64_CAP", "5" if int(os.environ.get("DQ64_HD", "128")) == 128 else "6"))    # issues per MFMA gap besides the MFMA (narrower heads: the same VALU per score under fewer MFMAs)
+CAP = float(os.environ.get("DQ64_CAP", {128: "5", 96: "6", 64: "9"}[int(os.environ.get("DQ64_HD", "128"))]))    # issues per MFMA gap besides the MFMA (narrower heads: the same VALU per score under fewer MFMAs)
 # SGPRs
 S_KP, S_VP = 40, 42          # global pointers of the tile to stage next (64-bit), always a valid tile
 S_CNT = 44                   # main-loop trips left

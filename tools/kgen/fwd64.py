@@ -70,7 +70,7 @@ S_M0, S_T0, S_T1, S_INCK, S_INCV = 49, 50, 51, 52, 53
 
 TRACE = bool(os.environ.get("FWD64_TRACE"))
 DBG = set(filter(None, os.environ.get("FWD64_DBG", "").split(",")))
-CAP = float(os.environ.get("FWD64_CAP", ("6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5") if int(os.environ.get("FWD64_HD", "128")) == 128 else "7"))      # issues per MFMA gap besides the MFMA
+CAP = float(os.environ.get("FWD64_CAP", {128: ("6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5"), 96: "7", 64: "10"}[int(os.environ.get("FWD64_HD", "128"))]))      # issues per MFMA gap besides the MFMA
 EXACT = os.environ.get("FWD64_EXACT", "1") != "0"    # scores as the exact fp32 sums of bf16 products (chains start from -m_ref / scale2, p = exp2(scale2 * acc));
                                                      # "0": Q pre-multiplied by scale2 and re-rounded (one VALU less per score, scores move by ~2^-9 |s|)
 
