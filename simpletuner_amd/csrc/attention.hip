@@ -269,12 +269,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
         : "memory", "vcc", "scc",
 
 // HD = 128 (Flux), 96 (PixArt-Sigma's head_dim 72, zero padded: 6 k-steps, 3 d tiles; the K tile image keeps the 256-byte row pitch, the V^T image holds 96 rows)
-// or 64 (SDXL / SD3 / SD 1.x: 4 k-steps, 2 d tiles — half the MFMAs per tile under the same softmax work: the generator weaves up to 10 issues into each MFMA gap)
+// (head_dim 64 — SDXL / SD3 / SD 1.x — keeps k_attn_fwd4: a generated 64-row body exists, `FWD64_HD=64 python -m tools.kgen.fwd64`, but with half the MFMAs per tile under the
+// same softmax work it is issue-bound at one wave per SIMD: 653 vs 740 TFLOP/s at B4 H10 S4096, 433 vs 515 at B4 H20 S1024 — profiles/r04_attn_lab_hd64_64_row_kernels.log)
 template <int HD>
 __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt, bf16* __restrict__ O,
                                                        int64_t ld_o, float* __restrict__ lse2, int H, int Sq, int S, int Sp, float scale2,
                                                        unsigned long long* trace) {
-  static_assert(HD == 128 || HD == 96 || HD == 64, "k_attn_fwd64: head_dim 128, 96 or 64");
+  static_assert(HD == 128 || HD == 96, "k_attn_fwd64: head_dim 128 or 96");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,15 +319,9 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
           ST355_FWD64_OPERANDS
 #include "gen/attn_fwd64_clobbers.inc"
       );
-    } else if constexpr (HD == 96) {
-      asm volatile(
-#include "gen/attn_fwd64_hd96_body.inc"
-          ST355_FWD64_OPERANDS
-#include "gen/attn_fwd64_clobbers.inc"
-      );
     } else {
       asm volatile(
-#include "gen/attn_fwd64_hd64_body.inc"
+#include "gen/attn_fwd64_hd96_body.inc"
           ST355_FWD64_OPERANDS
 #include "gen/attn_fwd64_clobbers.inc"
       );
@@ -370,7 +365,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // k_attn_fwd4 (r02) is the general kernel; k_attn_fwd64 (r04) takes the head_dim-128, no-bias, S % 64 == 0 shapes.  The r01 kernel lives on in
   // tools/attn_fwd_variants.hip as the lab's A/B baseline (r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s).  Measured and deleted in r02: an 8-wave /
   // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/r02_attn_lab_*.log.
-  if (!vrow && !key_bias && (d == 128 || d == 96 || d == 64) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
+  if (!vrow && !key_bias && (d == 128 || d == 96) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
     dim3 grid64((Sq + 255) / 256, H, B);
     const int lds64 = 4 * 2 * 64 * 256;
 #define ST355_FWD64_LAUNCH(HD_)                                                                                                           \
@@ -381,8 +376,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
                        H, Sq, S, Sp, scale2, g_attn_fwd_trace);                                                                          \
   } while (0)
     if (d == 128) ST355_FWD64_LAUNCH(128);
-    else if (d == 96) ST355_FWD64_LAUNCH(96);
-    else ST355_FWD64_LAUNCH(64);
+    else ST355_FWD64_LAUNCH(96);
 #undef ST355_FWD64_LAUNCH
     return st355_check_launch("attn_fwd64");
   }

@@ -878,6 +878,8 @@ def test_attention_64_row_kernels_narrow_heads(ops, B, H, S, hd, dv_):
             res[impl] += [dQ, dK, dqkv]
     finally:
         ops.attn_set_impl(fwd=prev[0], dq=prev[1], dkv=prev[2])
+    if hd == 64:             # head_dim 64 keeps the 32-row forward (the generated 64-row body measured slower): the same kernel either way
+        assert torch.equal(res[64][0], res[32][0]) and torch.equal(res[64][1], res[32][1])
     assert report(f"fwd64<{hd}> O vs fwd4", res[64][0], res[32][0])[0] < 5e-3
     assert float((res[64][1] - res[32][1]).abs().max()) < 1e-4
     assert torch.equal(res[64][2], res[32][2]), f"dq64<{hd}> is not bit-identical to dq"
