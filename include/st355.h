@@ -320,6 +320,9 @@ int st355_adamw_bf16_sr_step(void* stream, void* p, const void* g, void* exp_avg
 int st355_ema_update(void* stream, void* shadow, const void* param, int64_t n, float decay, int elem_bytes);
 /* K15: sum of squares (fp32 out[0]) and max-abs (out[1]) of a flat gradient; out zeroed by the call */
 int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2);
+/* the same with the caller's scratch for the per-block partials (2 * 1024 floats; NULL = the library-owned one, which is ONE buffer per process: st355_grad_norm
+ * calls must be ordered on one stream).  One scratch per stream lets norms be computed concurrently (a side-stream EMA / ControlNet norm, capture next to eager calls). */
+int st355_grad_norm_ws(void* stream, const void* g, int64_t n, int elem_bytes, float* out2, float* workspace);
 /* clip_grad_value_ (trainer.py:7209-7213): g <- clamp(g, -c, +c) in place (fp32 or bf16 arena) */
 int st355_grad_clamp(void* stream, void* g, int64_t n, int elem_bytes, float c);
 /* accelerator.clip_grad_norm_ (trainer.py:7201-7208) with the coefficient computed ON THE DEVICE: g *= min(1, max_norm / (sqrt(stats2[0]) * pre_scale

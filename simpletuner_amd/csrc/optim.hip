@@ -279,9 +279,10 @@ extern "C" int st355_ema_update(void* stream, void* shadow, const void* param, i
 // GN_BLOCKS workgroups write one (sum of squares, max |g|) pair each into a library-owned scratch, a single wave then combines them in index order.
 // The scratch is one buffer per process: st355_grad_norm calls are stream-ordered on the training stream (one training thread per rank).
 #define GN_BLOCKS 1024
-__device__ float g_gn_part[2 * GN_BLOCKS];
+__device__ float g_gn_part[2 * GN_BLOCKS];          // st355_grad_norm's library-owned scratch; st355_grad_norm_ws takes the caller's (2 * GN_BLOCKS floats)
 template <typename T>
-__global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ g, int64_t n) {
+__global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ g, int64_t n, float* __restrict__ part) {
+  if (part == nullptr) part = g_gn_part;
   float ss = 0.f, mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float f = (float)g[i];
@@ -296,29 +297,33 @@ __global__ void __launch_bounds__(OP_THREADS) k_grad_norm(const T* __restrict__ 
   if (threadIdx.x == 0) {
     float a = 0.f, b = 0.f;
     for (int i = 0; i < OP_THREADS / WAVE; i++) { a += rs[i]; b = fmaxf(b, rm[i]); }
-    g_gn_part[blockIdx.x] = a;
-    g_gn_part[GN_BLOCKS + blockIdx.x] = b;
+    part[blockIdx.x] = a;
+    part[GN_BLOCKS + blockIdx.x] = b;
   }
 }
-__global__ void __launch_bounds__(WAVE) k_grad_norm_final(int nblocks, float* __restrict__ out2) {
+__global__ void __launch_bounds__(WAVE) k_grad_norm_final(int nblocks, float* __restrict__ out2, const float* __restrict__ part) {
+  if (part == nullptr) part = g_gn_part;
   float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += WAVE) { a += g_gn_part[i]; b = fmaxf(b, g_gn_part[GN_BLOCKS + i]); }     // lane l: blocks l, l + 64, ... in order
+  for (int i = threadIdx.x; i < nblocks; i += WAVE) { a += part[i]; b = fmaxf(b, part[GN_BLOCKS + i]); }     // lane l: blocks l, l + 64, ... in order
   a = wave_sum(a);                                                                                                 // fixed lane tree
   b = wave_max(b);
   if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
 }
-extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2) {
+// workspace: NULL = the library-owned scratch (ONE per process: calls must then be ordered on one stream), else 2 * 1024 floats of the caller's — one per stream
+// that computes norms concurrently (a side-stream EMA / ControlNet norm, capture overlapping eager calls)
+extern "C" int st355_grad_norm_ws(void* stream, const void* g, int64_t n, int elem_bytes, float* out2, float* workspace) {
   ST_REQUIRE(g && out2 && n > 0 && (elem_bytes == 4 || elem_bytes == 2), "grad_norm: bad args");
   ProfScope ps(stream, ST355_K_OPTIM, 3.0 * n, (double)elem_bytes * n);
   int64_t nb = cdiv64(n, OP_THREADS);
   if (nb > GN_BLOCKS) nb = GN_BLOCKS;
   if (elem_bytes == 4)
-    hipLaunchKernelGGL(k_grad_norm<float>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const float*)g, n);
+    hipLaunchKernelGGL(k_grad_norm<float>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const float*)g, n, workspace);
   else
-    hipLaunchKernelGGL(k_grad_norm<bf16>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const bf16*)g, n);
-  hipLaunchKernelGGL(k_grad_norm_final, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, (int)nb, out2);
+    hipLaunchKernelGGL(k_grad_norm<bf16>, dim3((unsigned)nb), dim3(OP_THREADS), 0, (hipStream_t)stream, (const bf16*)g, n, workspace);
+  hipLaunchKernelGGL(k_grad_norm_final, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, (int)nb, out2, (const float*)workspace);
   return st355_check_launch("grad_norm");
 }
+extern "C" int st355_grad_norm(void* stream, const void* g, int64_t n, int elem_bytes, float* out2) { return st355_grad_norm_ws(stream, g, n, elem_bytes, out2, nullptr); }
 
 // clip_grad_value_ (trainer.py:7209-7213): g <- clamp(g, -c, +c) in place over the flat gradient arena
 template <typename T>

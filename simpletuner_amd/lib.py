@@ -24,7 +24,7 @@ SYMBOLS = [
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd", "st355_qk_norm_wgrad_workspace", "st355_qk_norm_rope_bwd_wgrad", "st355_qk_rope_norm_bwd",
     "st355_attn_set_impl", "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd", "st355_attn_bwd_rope",
-    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_clamp", "st355_grad_clip_norm",
+    "st355_adamw_ema_step", "st355_adamw_ema_step_bf16", "st355_adamw_bf16_sr_step", "st355_ema_update", "st355_grad_norm", "st355_grad_norm_ws", "st355_grad_clamp", "st355_grad_clip_norm",
     "st355_lora_pack",
     "st355_workspace_bytes",
     "st355_comm_unique_id", "st355_comm_init", "st355_comm_destroy", "st355_comm_all_reduce", "st355_comm_reduce_scatter", "st355_comm_all_gather",
@@ -309,6 +309,7 @@ def _declare(lib):
                                                vp, u64, u64, f32]),
         "st355_ema_update": (C.c_int, [vp, vp, vp, i64, f32, i32]),
         "st355_grad_norm": (C.c_int, [vp, vp, i64, i32, vp]),
+        "st355_grad_norm_ws": (C.c_int, [vp, vp, i64, i32, vp, vp]),
         "st355_grad_clamp": (C.c_int, [vp, vp, i64, i32, f32]),
         "st355_grad_clip_norm": (C.c_int, [vp, vp, i64, i32, vp, f32, f32]),
         "st355_lora_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, i32, i32]),

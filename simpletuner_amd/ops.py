@@ -739,11 +739,20 @@ def ema_update(shadow, param, decay: float):
     _l.check(L.st355_ema_update(_stream(), _ptr(shadow), _ptr(param), shadow.numel(), decay, shadow.element_size()), "ema_update")
 
 
+_gn_ws = {}
+
+
 def grad_norm(g):
-    """returns fp32 [2] device tensor: (sum of squares, max |g|)"""
+    """returns fp32 [2] device tensor: (sum of squares, max |g|).  The per-block partials live in a scratch of this (device, stream): norms on different streams
+    (a side-stream EMA / ControlNet norm, a hipGraph capture next to eager calls) never share one"""
     L = _l.load()
     out = torch.empty(2, dtype=F32, device=g.device)
-    _l.check(L.st355_grad_norm(_stream(), _ptr(g), g.numel(), g.element_size(), _ptr(out)), "grad_norm")
+    st = _stream()
+    key = (g.device.index, int(st) if st is not None else 0)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = _gn_ws[key] = torch.empty(2 * 1024, dtype=F32, device=g.device)
+    _l.check(L.st355_grad_norm_ws(st, _ptr(g), g.numel(), g.element_size(), _ptr(out), _ptr(ws)), "grad_norm")
     return out
 
 
