@@ -56,11 +56,54 @@ def plugin_class(family: str, ref_foundation: Optional[type] = None, ref_family:
     base = ref_family if (isinstance(ref_family, type) and issubclass(ref_family, ref_foundation)) else ref_foundation
     # st355 first in the MRO: every step-path method resolves to the MI355X implementation; the reference class behind it contributes identity
     # (isinstance) and whatever out-of-path member the st355 class does not define
-    new = type(f"St355{name}", (cls, base), {"__module__": __name__, "__doc__": cls.__doc__, "ST355_NATIVE": True})
+    ns = {"__module__": __name__, "__doc__": cls.__doc__, "ST355_NATIVE": True}
+    ns.update(_guards_for_reference_members(cls, base, ref_foundation, name))
+    new = type(f"St355{name}", (cls, base), ns)
     left = sorted(getattr(new, "__abstractmethods__", ()))
     if left:           # an ABC base with members neither side implements: the class could be registered but never constructed — fail at register() time
         raise TypeError(f"St355{name} would be abstract: {left} are declared abstract by {base.__name__} and implemented by neither class")
     return new
+
+
+# members of a reference FAMILY class that may keep resolving to reference code although they mention the trained component: they only read its `config`, hand it
+# to the reference's own pipeline / text-encoder code, or are hooks the st355 foundation answers through a differently named method
+REFERENCE_MEMBERS_OK = frozenset({
+    "_format_text_embedding", "_encode_prompts", "convert_text_embed_for_pipeline", "convert_negative_text_embed_for_pipeline", "update_pipeline_call_kwargs",
+    "pretrained_load_args", "get_pipeline", "_load_pipeline", "setup_model_flavour", "custom_model_card_schedule_info", "custom_model_card_code_example",
+})
+
+
+def _guards_for_reference_members(cls: type, base: type, ref_foundation: type, name: str) -> dict:
+    """A family class of the reference defines helpers next to its step path that reach into `self.model` as a diffusers module (`_prepare_model_predict_timesteps`,
+    `control_init`, `post_model_load_setup`, `_maybe_load_assistant_lora`, …).  With the reference family class behind the st355 class in the MRO, such a member the
+    st355 class does not define would silently run reference code against the st355 component.  Every function that the reference FAMILY class itself adds (not its
+    ModelFoundation), that the st355 class does not define, whose source touches the trained component, and that is not in REFERENCE_MEMBERS_OK is replaced by a
+    stub that refuses loudly, naming itself.  (Source not retrievable -> the member is left alone.)"""
+    import inspect
+    out = {}
+    if base is ref_foundation:
+        return out
+    for klass in base.__mro__:
+        if klass is ref_foundation or klass is object or issubclass(ref_foundation, klass):
+            continue                                  # ModelFoundation and its own bases: the contract the st355 foundation mirrors (test_integration_contract_cpu.py)
+        for attr, val in vars(klass).items():
+            if attr.startswith("__") or attr in out or attr in REFERENCE_MEMBERS_OK or not inspect.isfunction(val):
+                continue
+            if any(attr in vars(k) for k in cls.__mro__ if k is not object):
+                continue                              # the st355 side defines it: its implementation wins the MRO anyway
+            try:
+                src = inspect.getsource(val)
+            except (OSError, TypeError):
+                continue
+            if not any(tok in src for tok in ("self.model", "get_trained_component", "unwrap_model", "self.controlnet")):
+                continue
+
+            def refuse(self, *a, _attr=attr, _klass=klass.__name__, **k):
+                raise NotImplementedError(f"St355{name}.{_attr}: this member of the reference's {_klass} reaches into the trained component as a diffusers module and "
+                                          f"has no st355 implementation (simpletuner_amd.integration.REFERENCE_MEMBERS_OK lists the members that may resolve to reference code)")
+            refuse.__name__, refuse.__qualname__ = attr, f"St355{name}.{attr}"
+            out[attr] = refuse
+    return out
 
 
 def _reference_family_class(reg, family: str) -> Optional[type]:

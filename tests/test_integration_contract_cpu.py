@@ -177,3 +177,40 @@ def test_register_without_simpletuner_fails_loudly(monkeypatch):
                         if name.startswith("simpletuner.") else importlib.__import__(name))
     with pytest.raises(integration.IntegrationUnavailable, match="needs an importable SimpleTuner"):
         integration.register()
+
+
+def test_reference_family_members_that_reach_into_the_component_are_guarded(monkeypatch, tmp_path):
+    """`plugin_class(family, ModelFoundation, <the reference's own family class>)`: helpers of the reference FAMILY class that touch `self.model` as a diffusers module
+    and have no st355 implementation refuse loudly instead of silently running against the st355 component; members that do not touch it, members the st355 class
+    defines, and the allow-listed ones keep resolving as before"""
+    import importlib.util
+    from simpletuner_amd import integration
+    _, common, _ = _stand_in_simpletuner(monkeypatch)
+    src = tmp_path / "fake_ref_flux.py"
+    src.write_text(
+        "from simpletuner.helpers.models.common import ModelFoundation\n"
+        "class Flux(ModelFoundation):\n"
+        "    def control_init(self):\n"
+        "        return self.unwrap_model(self.model).x_embedder.weight\n"
+        "    def _maybe_load_assistant_lora(self):\n"
+        "        return self.get_trained_component().load_lora_adapter('x')\n"
+        "    def custom_model_card_schedule_info(self):\n"
+        "        return [str(self.model)]\n"
+        "    def harmless_helper(self):\n"
+        "        return 'no component involved'\n"
+        "    def model_predict(self, batch):\n"
+        "        return self.model(**batch)\n")
+    spec = importlib.util.spec_from_file_location("fake_ref_flux", src)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cls = integration.plugin_class("flux", common.ModelFoundation, mod.Flux)
+    assert issubclass(cls, mod.Flux) and cls.__mro__[1].__module__.startswith("simpletuner_amd.")
+    acc = SimpleNamespace(device=torch.device("cpu"), num_processes=1, process_index=0, is_main_process=True)
+    from simpletuner_amd.training.trainer import default_config
+    inst = cls(default_config(model_family="flux"), acc)
+    for name in ("control_init", "_maybe_load_assistant_lora"):
+        with pytest.raises(NotImplementedError, match=f"St355Flux.{name}: this member of the reference's Flux"):
+            getattr(inst, name)()
+    assert inst.harmless_helper() == "no component involved"                       # does not touch the component: reference code, as before
+    assert cls.custom_model_card_schedule_info is mod.Flux.custom_model_card_schedule_info          # allow-listed
+    assert cls.model_predict.__module__.startswith("simpletuner_amd.")             # the st355 class defines it: the MRO picks the MI355X implementation
