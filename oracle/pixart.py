@@ -167,12 +167,39 @@ def _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio):
     return h, t6, emb, ctx, bias
 
 
-def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, mask, timestep, resolution=None, aspect_ratio=None, fp8_blocks: bool = False):
-    """PixArtTransformer2DModel.forward -> [B, out_channels, H, W]; fp8_blocks: the transformer blocks' Linears in the fp8-native form"""
+def lora_targets(cfg: PixArtConfig):
+    """pixart/model.py:59 DEFAULT_LORA_TARGET = to_k, to_q, to_v, to_out.0 — peft matches by suffix: attn1 and attn2 of every block"""
+    return [f"transformer_blocks.{i}.{a}.{n}" for i in range(cfg.num_layers) for a in ("attn1", "attn2") for n in ("to_q", "to_k", "to_v", "to_out.0")]
+
+
+def pixart_forward(P: Dict[str, torch.Tensor], cfg: PixArtConfig, latents, enc, mask, timestep, resolution=None, aspect_ratio=None, fp8_blocks: bool = False,
+                   lora=None, lora_scale: float = 1.0, tread=None):
+    """PixArtTransformer2DModel.forward -> [B, out_channels, H, W]; fp8_blocks: the transformer blocks' Linears in the fp8-native form.
+    lora = {module name: (A [r, in], B [out, r])}: peft adapters y += scale * B A x on the named Linears.  tread: as oracle.flux.flux_forward — token routing between
+    two block indices (pixart/transformer.py:487-489 `set_router` and the routed span of the block loop) with the router's permutations replayed."""
+    from .flux import tread_end, tread_start
     hh, ww = latents.shape[-2] // cfg.patch_size, latents.shape[-1] // cfg.patch_size
     h, t6, emb, ctx, bias = _prep(P, cfg, latents, enc, mask, timestep, resolution, aspect_ratio)
+    base = lin_fp8 if fp8_blocks else _lin
+
+    def lin(x, P_, name):
+        y = base(x, P_, name)
+        if lora is not None and name in lora:
+            A, B_ = lora[name]
+            y = y + lora_scale * ((x @ A.t().to(x.dtype)) @ B_.t().to(x.dtype))
+        return y
+
+    routes = [dict(r, start_layer_idx=r["start_layer_idx"] % cfg.num_layers, end_layer_idx=r["end_layer_idx"] % cfg.num_layers) for r in (tread or {}).get("routes", [])]
+    infos = (tread or {}).get("mask_infos", [])
+    ptr, info, saved = 0, None, None
     for i in range(cfg.num_layers):
-        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6, _lin=lin_fp8 if fp8_blocks else _lin)
+        if ptr < len(routes) and i == routes[ptr]["start_layer_idx"]:
+            info, saved = infos[ptr], h
+            h = tread_start(h, info)
+        h = block(P, f"transformer_blocks.{i}.", cfg, h, ctx, bias, t6, _lin=lin)
+        if info is not None and i == routes[ptr]["end_layer_idx"]:
+            h = tread_end(h, info, saved)
+            info, saved, ptr = None, None, ptr + 1
     return _head(P, cfg, h, emb, hh, ww)
 
 

@@ -493,13 +493,13 @@ class ModelFoundation(ExplorativeModelingMixin):
 
     def tread_init(self):
         """<family>/model.py `tread_init` (e.g. sd3/model.py:326-347): hand the trained component a TREADRouter seeded from the run seed and the routes of
-        `config.tread_config`.  Built for the components that expose `set_router` (SD3, Flux; training/tread.py); the others refuse — never a silent no-op."""
+        `config.tread_config`.  Built for the components that expose `set_router` (SD3, Flux, the PixArt trunk under LoRA; training/tread.py); the others refuse — never a silent no-op."""
         tc = getattr(self.config, "tread_config", None)
         if not tc or tc.get("routes", None) is None:
             raise ValueError("TREAD training requires you to configure the routes in the TREAD config")
         comp = self.get_trained_component()
         if comp is None or not hasattr(comp, "set_router"):
-            raise NotImplementedError(f"tread_init: TREAD routing is not implemented for {self.NAME} on the st355 path (built: SD3, Flux)")
+            raise NotImplementedError(f"tread_init: TREAD routing is not implemented for {self.NAME} on the st355 path (built: SD3, Flux, the PixArt trunk)")
         from .training.tread import TREADRouter
         comp.set_router(TREADRouter(seed=getattr(self.config, "seed", None) or 42, device=self.accelerator.device), tc["routes"])
 
@@ -549,8 +549,9 @@ class ModelFoundation(ExplorativeModelingMixin):
     def lora_state_dict(self, component=None):
         """peft.get_peft_model_state_dict layout: `<module>.lora_A.weight` / `<module>.lora_B.weight` (the adapter name is dropped)"""
         comp = component if component is not None else self.get_trained_component()
-        return {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p.detach()
-                for n, p in comp.named_parameters() if ".lora_" in n}
+        src = comp.lora_state_dict().items() if hasattr(comp, "lora_state_dict") else ((n, p.detach()) for n, p in comp.named_parameters() if ".lora_" in n)
+        # (a component whose working layout pads the adapter factors — PixArt's 72 -> 96 head lanes — hands out the true peft shapes itself)
+        return {n.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): p for n, p in src}
 
     COMFYUI_LORA_PRESERVE_COMPONENT_PREFIXES = None     # common.py:524; Flux / SD3 / PixArt keep their `transformer.` prefix in ComfyUI files
     AUTO_LORA_FORMAT_DETECTION = False                  # flux/model.py:56: a diffusers-configured run still recognises a ComfyUI file on load
@@ -652,8 +653,11 @@ class ModelFoundation(ExplorativeModelingMixin):
         if missing:
             raise KeyError(f"LoRA checkpoint is missing {len(missing)} adapter tensors, e.g. {missing[:3]}")
         with torch.no_grad():
-            for k, p in own.items():
-                p.copy_(flat[prefix + k].to(device=p.device, dtype=p.dtype))
+            if hasattr(comp, "load_lora_state_dict"):              # working layout differs from the peft shapes (PixArt's head padding)
+                comp.load_lora_state_dict({k: flat[prefix + k] for k in own})
+            else:
+                for k, p in own.items():
+                    p.copy_(flat[prefix + k].to(device=p.device, dtype=p.dtype))
         return comp
 
     def uses_noise_schedule(self) -> bool:

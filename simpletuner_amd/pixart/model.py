@@ -51,7 +51,12 @@ class PixartSigma(ModelFoundation):
         return self.unwrap_model(comp) if unwrap_model else comp
 
     def add_lora_adapter(self):
-        raise NotImplementedError("PixArt LoRA is not built on the st355 path yet (ControlNet-branch training only)")
+        """pixart/model.py:59 DEFAULT_LORA_TARGET (to_k, to_q, to_v, to_out.0 of attn1 and attn2 in every trunk block)"""
+        if self.controlnet is not None:
+            raise NotImplementedError("PixArt: a LoRA on the trunk together with the ControlNet branch is not built on the st355 path")
+        comp = self.unwrap_model(self.model)
+        return comp.add_lora_adapter(rank=int(self.config.lora_rank), alpha=getattr(self.config, "lora_alpha", None),
+                                     seed=int(getattr(self.config, "seed", 42) or 42) + 7, init_b_std=float(getattr(self.config, "lora_init_b_std", 0.0)))
 
     def _build_added_cond_kwargs(self, prepared_batch: dict) -> dict:
         """pixart/model.py:360-379"""

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..flux.transformer import _attach, _frozen
+from ..flux.transformer import LoraGroup, _attach, _frozen
 from ..ops import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE
 from ..training.checkpoint_plan import CheckpointPlanMixin
 
@@ -72,6 +72,7 @@ class _Block:
         self.G: Dict[str, torch.Tensor] = {}          # gradient views (trainable blocks)
         self.W = None                                  # padded working copies
         self.fp8 = False                               # frozen blocks only: fp8-native Linears (fp8_native.py:25-119)
+        self.lora = None                               # LoRA adapter groups of this block's attention projections (PixArtTransformer2DModel.add_lora_adapter)
 
     @torch.no_grad()
     def refresh(self, dev):
@@ -163,6 +164,101 @@ class PixArtTransformer2DModel(nn.Module):
         self.blocks: List[_Block] = [_Block(self, f"transformer_blocks.{i}.", D, H, hd, D, alloc, trainable=False) for i in range(num_layers)]
         self._prepared = False
         self._cache: Dict = {}
+        self.lora_groups: List[LoraGroup] = []
+        self._lora_params: List[nn.Parameter] = []
+        self.accumulate_lora_grads = False
+        self.grad_sync = None
+        self._tread_router, self._tread_routes = None, None
+
+    # ---- LoRA (peft naming; pixart/model.py:59 DEFAULT_LORA_TARGET = to_k, to_q, to_v, to_out.0: attn1 and attn2 of every block) ----
+    def add_lora_adapter(self, rank: int = 32, alpha: Optional[float] = None, seed: int = 7, init_b_std: float = 0.0):
+        """Adapters on attn1 / attn2 to_q, to_k, to_v, to_out.0 of every trunk block, riding in the K-extension of the projections' GEMMs.  The working layout pads
+        every head from 72 to 96 lanes, so the adapter factors live in that layout too: lora_B of to_q / to_k / to_v has H * 96 rows and lora_A of to_out.0 has
+        H * 96 columns, the pad rows / columns initialised to ZERO.  They stay zero: the gradient of a pad row of B is dY_pad^T T and dY is exactly zero on the pad
+        lanes (K / Q / W_out pad lanes are zero), the gradient of a pad column of A is U^T O_pad with O_pad = 0 — and AdamW leaves a zero parameter with a zero
+        gradient at zero.  `lora_state_dict()` hands out the true-shaped (peft) tensors."""
+        if self.fp8_base:
+            raise NotImplementedError("PixArt LoRA over an fp8-native trunk is not built on the st355 path")
+        alpha = float(rank if alpha is None else alpha)
+        D, H, hd, dev = self.inner_dim, self.H, self.hd, self.device_
+        Dp = H * HP
+        plan = []
+        self.lora_groups = []
+        for i, blk in enumerate(self.blocks):
+            p = f"transformer_blocks.{i}."
+            mk = lambda K, N, targets: LoraGroup(K, N, targets, rank, alpha, dev)
+            blk.lora = SimpleNamespace(
+                qkv=mk(D, 3 * Dp, [(p + "attn1.to_q", 0, Dp), (p + "attn1.to_k", Dp, Dp), (p + "attn1.to_v", 2 * Dp, Dp)]),
+                out1=mk(Dp, D, [(p + "attn1.to_out.0", 0, D)]),
+                q2=mk(D, Dp, [(p + "attn2.to_q", 0, Dp)]),
+                kv2=mk(D, 2 * Dp, [(p + "attn2.to_k", 0, Dp), (p + "attn2.to_v", Dp, Dp)]),
+                out2=mk(Dp, D, [(p + "attn2.to_out.0", 0, D)]))
+            for g in (blk.lora.qkv, blk.lora.out1, blk.lora.q2, blk.lora.kv2, blk.lora.out2):
+                self.lora_groups.append(g)
+                for (name, _, N) in g.targets:
+                    plan.append((g, name, N, g.K))
+        total = (sum(rank * K + N * rank for (_, _, N, K) in plan) + 7) // 8 * 8
+        self.lora_flat = torch.zeros(total, dtype=F32, device=dev)
+        self.lora_grad_flat = torch.zeros(total, dtype=F32, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        off = 0
+        self._lora_params = []
+        pad_rows = torch.zeros(H, HP, dtype=torch.bool, device=dev); pad_rows[:, hd:] = True          # the pad lanes of a head-padded axis
+        pad_rows = pad_rows.reshape(-1)
+        for (g, name, N, K) in plan:
+            if not g.A:
+                g.flat_lo = off
+            a = self.lora_flat[off:off + rank * K].view(rank, K); ga = self.lora_grad_flat[off:off + rank * K].view(rank, K)
+            off += rank * K
+            b = self.lora_flat[off:off + N * rank].view(N, rank); gb = self.lora_grad_flat[off:off + N * rank].view(N, rank)
+            off += N * rank
+            g.flat_hi = off
+            k_true = D                                                           # kaiming_uniform(a=sqrt(5)) on the TRUE [r, in_features] (peft default for lora_A)
+            a.copy_((torch.rand(rank, K, generator=gen, device=dev) * 2 - 1) * (1.0 / math.sqrt(k_true)))
+            if K == Dp:
+                a[:, pad_rows] = 0
+            if init_b_std > 0:
+                b.copy_(torch.randn(N, rank, generator=gen, device=dev) * init_b_std)
+                if N == Dp:
+                    b[pad_rows] = 0
+            pa, pb = nn.Parameter(a), nn.Parameter(b)
+            _attach(self, name + ".lora_A.default.weight", pa); _attach(self, name + ".lora_B.default.weight", pb)
+            g.A.append(pa.data); g.B.append(pb.data); g.gA.append(ga); g.gB.append(gb)
+            self._lora_params += [pa, pb]
+        return self._lora_params
+
+    def lora_state_dict(self) -> Dict[str, torch.Tensor]:
+        """the adapters in their TRUE (peft) shapes: the pad lanes of the head-padded axes dropped"""
+        H, hd, Dp = self.H, self.hd, self.H * HP
+        out = {}
+        for name, p in self.named_parameters():
+            if ".lora_A." in name and p.shape[1] == Dp:
+                out[name] = p.detach().view(p.shape[0], H, HP)[:, :, :hd].reshape(p.shape[0], H * hd).clone()
+            elif ".lora_B." in name and p.shape[0] == Dp:
+                out[name] = p.detach().view(H, HP, p.shape[1])[:, :hd].reshape(H * hd, p.shape[1]).clone()
+            elif ".lora_" in name:
+                out[name] = p.detach().clone()
+        return out
+
+    @torch.no_grad()
+    def load_lora_state_dict(self, state: Dict[str, torch.Tensor]):
+        """true-shaped (peft) adapter tensors, keyed `<module>.lora_A[.default].weight`, into the head-padded working layout (pad lanes zero)"""
+        H, hd, Dp = self.H, self.hd, self.H * HP
+        norm = {k.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B."): v for k, v in state.items()}
+        for name, p in self.named_parameters():
+            if ".lora_" not in name:
+                continue
+            v = norm[name.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")].to(device=p.device, dtype=p.dtype)
+            if ".lora_A." in name and p.shape[1] == Dp:
+                p.zero_(); p.view(p.shape[0], H, HP)[:, :, :hd].copy_(v.view(p.shape[0], H, hd))
+            elif ".lora_B." in name and p.shape[0] == Dp:
+                p.zero_(); p.view(H, HP, p.shape[1])[:, :hd].copy_(v.view(H, hd, p.shape[1]))
+            else:
+                p.copy_(v)
+
+    def set_router(self, router, routes):
+        """pixart/transformer.py:487-489: TREAD router + [{selection_ratio, start_layer_idx, end_layer_idx}] (training/tread.py)"""
+        self._tread_router, self._tread_routes = router, routes
 
     # ---- weights ----
     @torch.no_grad()
@@ -275,7 +371,11 @@ class PixArtTransformer2DModel(nn.Module):
                                       "pixart/controlnet.py:241-246; the fp8 trunk form is not built for them)")
         if blk.fp8:
             return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
-        if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous() and rpb == S:
+        L = blk.lora
+        if L is not None and (blk.fp8 or rpb != S):
+            raise NotImplementedError("PixArt LoRA: bf16 trunk with per-sample timesteps")
+        kx = (lambda g, T: dict(a2=T, b2=g.B_blk, k2_real=g.k2_real)) if L is not None else (lambda g, T: {})
+        if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous() and rpb == S and L is None:
             # the block as ONE C entry point (st355_block_pixart_fwd): the launches of the host-side sequencing below, in its order, on its
             # operands (every buffer allocated here, kept ones handed to the backward as before) — bit-identical to it (ST355_BLOCK_ABI=0 restores it)
             dev = h.device
@@ -300,7 +400,8 @@ class PixArtTransformer2DModel(nn.Module):
                                      Q2t=None, K2=K2, K2t=None, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
             return h3, sv
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], rpb)
-        qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b)
+        T_qkv = ops.gemm(n1, L.qkv.A_cat) if L is not None else None
+        qkv = ops.gemm(n1, W.qkv_w, bias=W.qkv_b, **kx(L.qkv if L is not None else None, T_qkv))
         Q, Qt, Sp = ops.head_split(qkv[:, :Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
         K, Kt, _ = ops.head_split(qkv[:, Dp:2 * Dp], B, H, HP, S, want_xt=not ops.ATTN_TR)
         _, Vt, _ = ops.head_split(qkv[:, 2 * Dp:], B, H, HP, S, want_x=False)
@@ -308,16 +409,20 @@ class PixArtTransformer2DModel(nn.Module):
         lse = torch.empty(B, H, S, dtype=F32, device=h.device)
         ops.attn_fwd(Q, K, Vt, O, lse, B, H, S, Sp, HP, scale)
         ya = torch.empty(B * S, D, dtype=BF16, device=h.device) if train else None
-        h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=rpb, aux_out=ya)
-        q2 = ops.gemm(h1, W.q2_w, bias=W.q2_b)
-        kv = ops.gemm(ctx2d, W.kv2_w, bias=W.kv2_b)
+        T_o1 = ops.gemm(O, L.out1.A_cat) if L is not None else None
+        h1 = ops.gemm(O, W.out1_w, bias=W.out1_b, epilogue=EPI_GATE_RESIDUAL, gate=m[2], aux_in=h, rows_per_batch=rpb, aux_out=ya, **kx(L.out1 if L is not None else None, T_o1))
+        T_q2 = ops.gemm(h1, L.q2.A_cat) if L is not None else None
+        q2 = ops.gemm(h1, W.q2_w, bias=W.q2_b, **kx(L.q2 if L is not None else None, T_q2))
+        T_kv = ops.gemm(ctx2d, L.kv2.A_cat) if L is not None else None
+        kv = ops.gemm(ctx2d, W.kv2_w, bias=W.kv2_b, **kx(L.kv2 if L is not None else None, T_kv))
         Q2, Q2t, _ = ops.head_split(q2, B, H, HP, S, want_xt=not ops.ATTN_TR)
         K2, K2t, Skp = ops.head_split(kv[:, :Dp], B, H, HP, Sk, want_xt=not ops.ATTN_TR)
         _, V2t, _ = ops.head_split(kv[:, Dp:], B, H, HP, Sk, want_x=False)
         O2 = torch.empty(B * S, Dp, dtype=BF16, device=h.device)
         lse2 = torch.empty(B, H, S, dtype=F32, device=h.device)
         ops.attn_cross_fwd(Q2, K2, V2t, O2, lse2, B, H, S, Sk, Skp, HP, scale, key_bias=kbias)
-        h2 = ops.gemm(O2, W.out2_w, bias=W.out2_b, epilogue=EPI_ADD, aux_in=h1)
+        T_o2 = ops.gemm(O2, L.out2.A_cat) if L is not None else None
+        h2 = ops.gemm(O2, W.out2_w, bias=W.out2_b, epilogue=EPI_ADD, aux_in=h1, **kx(L.out2 if L is not None else None, T_o2))
         n2 = ops.ln_modulate_fwd(h2, m[4], m[3], rpb)
         pre = torch.empty(B * S, 4 * D, dtype=BF16, device=h.device) if (save or exact) else None
         a = ops.gemm(n2, W.ff1_w, bias=W.ff1_b, epilogue=EPI_GELU, aux_out=pre)
@@ -326,7 +431,7 @@ class PixArtTransformer2DModel(nn.Module):
         sv = None
         if save:
             sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=ya, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
-                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf)
+                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=yf, T_qkv=T_qkv, T_o1=T_o1, T_q2=T_q2, T_kv=T_kv, T_o2=T_o2)
         return h3, sv
 
     def _block_fwd_fp8(self, blk: _Block, h, ctx2d, kbias, mod, m, B, S, Sk, save: bool):
@@ -414,7 +519,19 @@ class PixArtTransformer2DModel(nn.Module):
             ops.colsum_prod(dn, dmod[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=S)
             ops.colsum_prod(dn, dmod[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in), rows_per_batch=S)
 
-        if _BLOCK_ABI and ops.ATTN_TR and sv.Qt is None and sv.pre is not None and d3.is_contiguous() and getattr(W, "ff2_wT", None) is not None:
+        L = blk.lora
+        acc, sync = self.accumulate_lora_grads, self.grad_sync
+
+        def lora_dgrad(g, dy, wT, x, T, **kw):
+            """d x = dy W (+ (dy sB) A) with the adapter's K-extension, and its rank-space gradients (x: the projection's input; None wT: no input gradient wanted)"""
+            if g is None:
+                return ops.gemm(dy, wT, **kw)
+            U = ops.gemm(dy, g.B_blk_T)
+            dx = ops.gemm(dy, wT, a2=U, b2=g.A_cat_T, k2_real=g.k2_real, **kw) if wT is not None else None
+            g.grads(x, T, dy, U, acc, sync)
+            return dx
+
+        if _BLOCK_ABI and ops.ATTN_TR and sv.Qt is None and sv.pre is not None and d3.is_contiguous() and getattr(W, "ff2_wT", None) is not None and L is None:
             # the data path of the backward as ONE C entry point (st355_block_pixart_bwd); every intermediate gradient stays in the buffers allocated here, and a
             # trainable block takes its weight / bias / modulation gradients from them afterwards — the same launches on the same operands as the host-side
             # sequencing below, the weight-gradient launches after the data path instead of between its steps (independent of it: bit-identical results)
@@ -455,7 +572,7 @@ class PixArtTransformer2DModel(nn.Module):
         d2, _ = ops.ln_modulate_bwd(dn2, sv.h2, m[4], S, dres=d3)
         # ---- cross-attention (no pre-norm, no gate) ----
         wgrad("out2", d2, sv.O2, unpad_cols("attn2.to_out.0"))
-        dO2 = ops.gemm(d2, W.out2_wT)
+        dO2 = lora_dgrad(L.out2 if L is not None else None, d2, W.out2_wT, sv.O2, getattr(sv, "T_o2", None))
         dq2 = torch.empty_like(sv.q2)
         dkv = torch.empty_like(sv.kv)
         dQ, dK = torch.empty_like(sv.Q2), torch.empty_like(sv.K2)
@@ -464,20 +581,22 @@ class PixArtTransformer2DModel(nn.Module):
         ops.head_merge(dK, dkv[:, :Dp], B, H, HP, Sk)
         wgrad("q2", dq2, sv.h1, unpad_rows(["attn2.to_q"]))
         wgrad("kv2", dkv, ctx2d, unpad_rows(["attn2.to_k", "attn2.to_v"]))
-        d1 = ops.gemm(dq2, W.q2_wT, epilogue=EPI_ADD, aux_in=d2)
+        d1 = lora_dgrad(L.q2 if L is not None else None, dq2, W.q2_wT, sv.h1, getattr(sv, "T_q2", None), epilogue=EPI_ADD, aux_in=d2)
+        if L is not None:
+            lora_dgrad(L.kv2, dkv, None, ctx2d, sv.T_kv)                 # the caption projection is frozen: only the adapters' gradients
         # ---- self-attention ----
         dya = ops.scale_cols(d1, m[2], S)
         if tr:
             ops.colsum_prod(d1, dmod[:, 2 * D:3 * D], b=sv.ya, rows_per_batch=S)
         wgrad("out1", dya, sv.O, unpad_cols("attn1.to_out.0"))
-        dO = ops.gemm(dya, W.out1_wT)
+        dO = lora_dgrad(L.out1 if L is not None else None, dya, W.out1_wT, sv.O, getattr(sv, "T_o1", None))
         dqkv = torch.empty_like(sv.qkv)
         dQ, dK = torch.empty_like(sv.Q), torch.empty_like(sv.K)
         ops.attn_bwd(sv.Q, sv.K, sv.Qt, sv.Kt, sv.qkv[:, 2 * Dp:], sv.O, dO, sv.lse, dQ, dK, dqkv[:, 2 * Dp:], B, H, S, sv.Sp, HP, scale)
         ops.head_merge(dQ, dqkv[:, :Dp], B, H, HP, S)
         ops.head_merge(dK, dqkv[:, Dp:2 * Dp], B, H, HP, S)
         wgrad("qkv", dqkv, sv.n1, unpad_rows(["attn1.to_q", "attn1.to_k", "attn1.to_v"]))
-        dn1 = ops.gemm(dqkv, W.qkv_wT)
+        dn1 = lora_dgrad(L.qkv if L is not None else None, dqkv, W.qkv_wT, sv.n1, getattr(sv, "T_qkv", None))
         mod_grads(dn1, sv.h, 0, 1)
         d0, _ = ops.ln_modulate_bwd(dn1, sv.h, m[1], S, dres=d1)
         if tr:
@@ -523,15 +642,110 @@ class PixArtTransformer2DModel(nn.Module):
         out, _ = self._head(h, emb, B, hh, ww)
         return out
 
+    # ---- LoRA training of the trunk (pixart/model.py adapter path; the reference's published PixArt rows are adapter runs) ----
+    def _engine_forward_lora(self, latents, enc, mask, timestep, added_cond_kwargs, save: bool):
+        """the trunk forward keeping what the backward needs; TREAD routing (pixart/transformer.py:487-489 `set_router`, the routed span of the block loop) while
+        training: between a route's two blocks every sample keeps a subset of its tokens (absolute position embeddings were added at the patch embedding, the
+        AdaLN-single rows are per sample: nothing else to re-route)"""
+        if not self._prepared:
+            self.prepare()
+        for g in self.lora_groups:
+            g.pack()
+        B, _, Hh, Ww = latents.shape
+        hh, ww = Hh // 2, Ww // 2
+        S, Sk, D = hh * ww, enc.shape[1], self.inner_dim
+        h = self._patch_embed(latents)
+        t6, emb = self._conditioning(timestep, added_cond_kwargs, B, Hh, Ww)
+        if t6.shape[0] != B:
+            raise NotImplementedError("PixArt LoRA training takes per-sample timesteps (tokenwise: the frozen forward only)")
+        ctx2d = self._caption(enc)
+        kb = self._key_bias(mask, B, Sk, self.device_)
+        n = len(self.blocks)
+        from ..training.tread import normalise_routes
+        routes = normalise_routes(self._tread_routes, n) if (save and self.training and self._tread_router is not None) else []
+        ctx = SimpleNamespace(B=B, S=S, Sk=Sk, hh=hh, ww=ww, ctx2d=ctx2d, kb=kb, blocks=[None] * n, S_of=[S] * n, route_start={}, route_end={})
+        rp, info, saved, S_cur = 0, None, None, S
+        for i, blk in enumerate(self.blocks):
+            if rp < len(routes) and info is None and i == routes[rp]["start_layer_idx"]:
+                info = self._tread_router.get_mask(h.view(B, S, D), mask_ratio=routes[rp]["selection_ratio"], force_keep=getattr(self, "_force_keep_mask", None))
+                saved = h
+                h = ops.gather_rows(h.view(B, S, D), info.keep_i32()).view(-1, D)                    # TREADRouter.start_route
+                S_cur = info.ids_keep.shape[1]
+                ctx.route_start[i] = info
+            ctx.S_of[i] = S_cur
+            h, ctx.blocks[i] = self._block_fwd(blk, h, ctx2d, kb, t6, B, S_cur, Sk, save)
+            if info is not None and i == routes[rp]["end_layer_idx"]:
+                full_seq = saved.clone()                                                             # TREADRouter.end_route(original_x=saved)
+                ops.scatter_rows(h.view(B, S_cur, D), info.keep_i32(), full_seq.view(B, S, D))
+                h, ctx.route_end[i] = full_seq, info
+                info, saved, S_cur, rp = None, None, S, rp + 1
+        if info is not None:
+            raise ValueError("TREAD route does not end inside the block stack (end_layer_idx)")
+        out, mod_out = self._head(h, emb, B, hh, ww)
+        if save:
+            ctx.h_final, ctx.mod_out = h, mod_out
+        return out, ctx
+
+    def _engine_backward_lora(self, ctx, dout):
+        B, S, Sk, D = ctx.B, ctx.S, ctx.Sk, self.inner_dim
+        dh = self._head_bwd(dout, ctx.h_final, ctx.mod_out, B, ctx.hh, ctx.ww)
+        d_full = None
+        for i in range(len(self.blocks) - 1, -1, -1):
+            if i in ctx.route_end:                          # backward enters a route at its END: the routed blocks see only the kept tokens' gradient rows
+                d_full = dh
+                dh = ops.gather_rows(d_full.view(B, S, D), ctx.route_end[i].keep_i32()).view(-1, D)
+            sv, ctx.blocks[i] = ctx.blocks[i], None
+            dh = self._block_bwd(self.blocks[i], sv, dh, ctx.ctx2d, ctx.kb, B, ctx.S_of[i], Sk)
+            if i in ctx.route_start:                        # ... and leaves it at its START: skipped tokens keep the gradient they had at the route's end
+                ops.scatter_rows(dh.view(B, ctx.S_of[i], D), ctx.route_start[i].keep_i32(), d_full.view(B, S, D))
+                dh, d_full = d_full, None
+        return None
+
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None, cross_attention_kwargs=None, attention_mask=None,
-                encoder_attention_mask=None, return_dict: bool = True, **unsupported):
+                encoder_attention_mask=None, return_dict: bool = True, force_keep_mask=None, **unsupported):
+        self._force_keep_mask = force_keep_mask            # TREAD: tokens that may never be routed away
         for k, v in unsupported.items():
             if v is not None and v is not False:
                 raise NotImplementedError(f"PixArtTransformer2DModel(st355): argument {k!r} is not supported on the HIP path")
         if attention_mask is not None or cross_attention_kwargs:
             raise NotImplementedError("PixArt(st355): self-attention masks / cross_attention_kwargs are not supported")
-        out = self._forward_trunk(hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs)
+        if torch.is_grad_enabled() and self._lora_params:
+            out = _PixArtLoraFn.apply(self, hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs, *self._lora_params)
+        elif self._lora_params:
+            with torch.no_grad():
+                out, _ = self._engine_forward_lora(hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs, save=False)
+        else:
+            out = self._forward_trunk(hidden_states, encoder_hidden_states, encoder_attention_mask, timestep, added_cond_kwargs)
         return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+
+class _PixArtLoraFn(torch.autograd.Function):
+    """one autograd node for the whole trunk under LoRA training (see flux/transformer.py::_FluxFn)"""
+
+    @staticmethod
+    def forward(fctx, model, latents, enc, mask, timestep, ack, *lora_params):
+        out, ctx = model._engine_forward_lora(latents.detach(), enc.detach(), None if mask is None else mask.detach(), timestep.detach(), ack, True)
+        fctx.model, fctx.ectx = model, ctx
+        return out
+
+    @staticmethod
+    def backward(fctx, dout):
+        model = fctx.model
+        if model.grad_sync is not None:
+            model.grad_sync.begin()
+        model._engine_backward_lora(fctx.ectx, dout)
+        fctx.ectx = None
+        if model.grad_sync is not None:
+            model.grad_scale_from_sync = model.grad_sync.finish()
+        from ..training.grad_sync import hand_over_gradients
+        gflat = hand_over_gradients(model, model.lora_grad_flat)
+        model._last_grad_flat = gflat
+        grads, off = [], 0
+        for p in model._lora_params:
+            n = p.numel()
+            grads.append(gflat[off:off + n].view_as(p))
+            off += n
+        return (None,) * 6 + tuple(grads)
 
 
 class PixArtSigmaControlNetTransformerModel(CheckpointPlanMixin, nn.Module):

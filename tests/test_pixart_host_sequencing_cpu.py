@@ -128,3 +128,106 @@ def test_trunk_forward_with_tokenwise_timesteps_through_the_emulator_matches_the
     assert _rel(out, ref) < 2e-2 and _rel(flat, ref) > 5e-2, (_rel(out, ref), _rel(flat, ref))
     with pytest.raises(ValueError, match="tokenwise timestep embedding expected shape"):
         m(lat, encoder_hidden_states=enc, timestep=tt[:, :5], encoder_attention_mask=mask, return_dict=False)
+
+
+def _true_lora(model):
+    """the adapters of the HIP model in their true (peft) shapes, as float leaves for the oracle: {module: (A [r, in], B [out, r])}"""
+    sd = model.lora_state_dict()
+    out = {}
+    for k, v in sd.items():
+        mod, which = k.split(".lora_")
+        out.setdefault(mod, [None, None])[0 if which.startswith("A") else 1] = v.float().clone().requires_grad_(True)
+    return {k: tuple(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("route", [False, True])
+def test_trunk_lora_gradients_through_the_emulator_match_autograd(monkeypatch, route):
+    """PixArt LoRA (pixart/model.py:59: to_k, to_q, to_v, to_out.0 of attn1 and attn2 in every block) on the trunk: adapters in the K-extension of the head-padded
+    projections, prediction and every adapter gradient — compared in their true (un-padded) shapes — against autograd on the oracle; the pad rows / columns of the
+    working-layout factors keep zero gradients.  route: TREAD on the trunk (pixart/transformer.py:487-489), half of the tokens routed around blocks [1, -2], the
+    oracle replaying the same permutation."""
+    EMU.install(monkeypatch)
+    from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
+    from simpletuner_amd.training.tread import ReplayRouter
+    m = PixArtTransformer2DModel(device="cpu", **ARCH)
+    m.init_synthetic(5)
+    m.add_lora_adapter(rank=8, alpha=16.0, init_b_std=0.05)
+    lat, cond, enc, mask, t = _inputs()
+    B, S = lat.shape[0], (lat.shape[2] // 2) * (lat.shape[3] // 2)
+    routes, rec = [], None
+    if route:
+        g = torch.Generator().manual_seed(11)
+        perm = torch.stack([torch.randperm(S, generator=g) for _ in range(B)])
+        K = S - int(round(S * 0.5))
+        rec = {"mask": torch.ones(B, S, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+               "ids_restore": torch.argsort(perm, dim=1)}
+        routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]
+        m.set_router(ReplayRouter([rec]), routes)
+    m.train()
+    target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4))
+    EMU.BLOCK_CALLS.clear()
+    out = m(lat, encoder_hidden_states=enc, timestep=t, encoder_attention_mask=mask, return_dict=False)[0]
+    assert EMU.BLOCK_CALLS.get("pixart_fwd", 0) == 0               # adapters ride in the K-extension: the host-side sequencing, not the adapter-less C entry point
+    loss = ((out.chunk(2, dim=1)[0].float() - target) ** 2).mean()
+    loss.backward()
+    P = {k: v.detach().float() for k, v in m.named_parameters() if ".lora_" not in k}
+    lp = _true_lora(m)
+    assert len(lp) == ARCH["num_layers"] * 8
+    res, ar = torch.tensor([[16.0, 16.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1)
+    ref = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, t, res, ar, lora=lp, lora_scale=16.0 / 8,
+                         tread={"routes": routes, "mask_infos": [rec]} if route else None)
+    lref = ((ref.chunk(2, dim=1)[0] - target) ** 2).mean()
+    lref.backward()
+    assert _rel(out.detach(), ref.detach()) < 2e-2 and abs(loss.item() - lref.item()) < 2e-3 * max(1.0, abs(lref.item()))
+    H, hd = ARCH["num_attention_heads"], ARCH["attention_head_dim"]
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        if ".lora_" not in name:
+            continue
+        mod, which = name.split(".lora_")
+        g = p.grad
+        if which.startswith("A") and g.shape[1] == H * HP:          # head-padded input axis: the pad columns carry no gradient
+            g3 = g.view(g.shape[0], H, HP)
+            assert float(g3[:, :, hd:].abs().max()) == 0
+            g = g3[:, :, :hd].reshape(g.shape[0], H * hd)
+        if which.startswith("B") and g.shape[0] == H * HP:
+            g3 = g.view(H, HP, g.shape[1])
+            assert float(g3[:, hd:].abs().max()) == 0
+            g = g3[:, :hd].reshape(H * hd, g.shape[1])
+        want = lp[mod][0 if which.startswith("A") else 1].grad
+        r = _rel(g, want)
+        worst = max(worst, (r, name))
+        assert r < 6e-2, (name, r)
+    print(f"[emu] pixart trunk LoRA{' + TREAD' if route else ''}: pred rel_l2={_rel(out.detach(), ref.detach()):.3e}, worst adapter gradient rel_l2={worst[0]:.3e} at {worst[1]}")
+
+
+def test_pixart_lora_file_round_trip_in_true_peft_shapes(tmp_path):
+    """save_lora_weights writes the adapters in their TRUE shapes ([r, 1152] / [1152, r], diffusers `transformer.` prefix: what the reference's pipelines load); loading
+    them back fills the head-padded working layout with zero pad lanes"""
+    from types import SimpleNamespace
+
+    from safetensors.torch import load_file
+
+    from simpletuner_amd.pixart.model import PixartSigma
+    from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
+    m = PixArtTransformer2DModel(device="cpu", **ARCH)
+    m.add_lora_adapter(rank=4, alpha=4.0, init_b_std=0.1)
+    plug = PixartSigma.__new__(PixartSigma)
+    plug.config, plug.accelerator, plug.model, plug.controlnet = SimpleNamespace(lora_rank=4, lora_alpha=4.0, lora_format=None), SimpleNamespace(device=torch.device("cpu")), m, None
+    plug.save_lora_weights(str(tmp_path))
+    flat = load_file(str(tmp_path / plug.LORA_WEIGHT_NAME))
+    H, hd = ARCH["num_attention_heads"], ARCH["attention_head_dim"]
+    assert len(flat) == ARCH["num_layers"] * 8 * 2
+    assert flat["transformer.transformer_blocks.0.attn1.to_q.lora_B.weight"].shape == (H * hd, 4)
+    assert flat["transformer.transformer_blocks.1.attn2.to_out.0.lora_A.weight"].shape == (4, H * hd)
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if ".lora_" in n}
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if ".lora_" in n:
+                p.fill_(7.0)
+    plug.load_lora_weights(input_dir=str(tmp_path))
+    for n, p in m.named_parameters():
+        if ".lora_" in n:
+            assert torch.equal(p, before[n]), n
+    b = dict(m.named_parameters())["transformer_blocks.0.attn1.to_k.lora_B.default.weight"]
+    assert b.shape == (H * HP, 4) and float(b.detach().view(H, HP, 4)[:, hd:].abs().max()) == 0

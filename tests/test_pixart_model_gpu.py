@@ -199,3 +199,63 @@ def test_pixart_trunk_tokenwise_timesteps_match_oracle():
     cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), ref.flatten(), dim=0).item()
     print(f"[pixart tokenwise fwd] rel-L2 {r:.3e} cos {cos:.6f}; the batch-wise forward at the mean timestep sits {_rel(flat, ref):.3e} away")
     assert r < 2e-2 and cos > 0.9995 and _rel(flat, ref) > 5e-2
+
+
+@pytest.mark.parametrize("route", [False, True])
+def test_pixart_trunk_lora_gradients_match_autograd(route):
+    """PixArt LoRA (pixart/model.py:59: to_k, to_q, to_v, to_out.0 of attn1 / attn2 in every trunk block) on the HIP path: the adapters ride in the K-extension of
+    the head-padded projections (72 -> 96 lanes per head; the pad rows / columns of the working-layout factors are zero and keep zero gradients); prediction and
+    every adapter gradient, in true peft shapes, vs autograd on the oracle.  route: TREAD on the trunk (pixart/transformer.py:487-489), half of the tokens routed
+    around blocks [1, -2], the oracle replaying the same permutation."""
+    from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
+    from simpletuner_amd.training.tread import ReplayRouter
+    dev = "cuda:0"
+    m = PixArtTransformer2DModel(device=dev, **ARCH)
+    m.init_synthetic(5)
+    m.add_lora_adapter(rank=8, alpha=16.0, init_b_std=0.05)
+    lat, cond, enc, mask, t = _inputs()
+    B, S = 2, 64
+    routes, rec = [], None
+    if route:
+        g = torch.Generator().manual_seed(11)
+        perm = torch.stack([torch.randperm(S, generator=g) for _ in range(B)])
+        K = S - int(round(S * 0.5))
+        rec = {"mask": torch.ones(B, S, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+               "ids_restore": torch.argsort(perm, dim=1)}
+        routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]
+        m.set_router(ReplayRouter([rec]), routes)
+    m.train()
+    target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4))
+    out = m(lat.to(dev), encoder_hidden_states=enc.to(dev), timestep=t.to(dev), encoder_attention_mask=mask.to(dev), return_dict=False)[0]
+    loss = ((out.chunk(2, dim=1)[0].float() - target.to(dev)) ** 2).mean()
+    loss.backward()
+    P = {k: v.detach().float().cpu() for k, v in m.named_parameters() if ".lora_" not in k}
+    lp = {}
+    for k, v in m.lora_state_dict().items():
+        mod, which = k.split(".lora_")
+        lp.setdefault(mod, [None, None])[0 if which.startswith("A") else 1] = v.float().cpu().clone().requires_grad_(True)
+    lp = {k: tuple(v) for k, v in lp.items()}
+    ref = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, t, torch.tensor([[16.0, 16.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1),
+                         lora=lp, lora_scale=2.0, tread={"routes": routes, "mask_infos": [rec]} if route else None)
+    lref = ((ref.chunk(2, dim=1)[0] - target) ** 2).mean()
+    lref.backward()
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-2 and abs(loss.item() - lref.item()) < 2e-3 * max(1.0, abs(lref.item()))
+    H, hd = ARCH["num_attention_heads"], ARCH["attention_head_dim"]
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        if ".lora_" not in name:
+            continue
+        mod, which = name.split(".lora_")
+        g = p.grad
+        if which.startswith("A") and g.shape[1] == H * HP:
+            g3 = g.view(g.shape[0], H, HP)
+            assert float(g3[:, :, hd:].abs().max()) == 0
+            g = g3[:, :, :hd].reshape(g.shape[0], H * hd)
+        if which.startswith("B") and g.shape[0] == H * HP:
+            g3 = g.view(H, HP, g.shape[1])
+            assert float(g3[:, hd:].abs().max()) == 0
+            g = g3[:, :hd].reshape(H * hd, g.shape[1])
+        r = _rel(g.cpu(), lp[mod][0 if which.startswith("A") else 1].grad)
+        worst = max(worst, (r, name))
+        assert r < 6e-2, (name, r)
+    print(f"[pixart trunk LoRA{' + TREAD' if route else ''}] pred rel-L2 {_rel(out.detach().cpu(), ref.detach()):.3e}, worst adapter gradient rel-L2 {worst[0]:.3e} at {worst[1]}")
