@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--model", default="flux", choices=["flux", "sd3", "sdxl", "sd15", "pixart", "vae"],
                     help="flux = the headline workload (BASELINE.json configs[2]); sd3 = SD3-Medium MMDiT LoRA r32 (joint blocks, D=1536), secondary")
     ap.add_argument("--fp8", action="store_true", help="pixart only: fp8-native Linears in the frozen trunk blocks (configs[4]: 'fp8 MFMA')")
-    ap.add_argument("--lora", action="store_true", help="sdxl only: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA)")
+    ap.add_argument("--lora", action="store_true", help="sdxl: LoRA on the attention projections instead of the full fine-tune (the metric's SDXL-LoRA); pixart: LoRA on the trunk's attention projections instead of the ControlNet branch")
     ap.add_argument("--graph", action="store_true", help="capture predict + loss + backward into a hipGraph after two eager steps and replay it (launch-bound "
                     "steps: the SDXL UNet); the per-kernel breakdown is then taken from ONE extra eager step after the timed region")
     ap.add_argument("--full", action="store_true", help="flux / sd3 / sdxl / sd15: full-parameter training (every parameter trains, bf16 arena, one fused optimizer launch); sd3 + EMA = BASELINE configs[3], flux = the reference's full-rank datapoint")
@@ -582,21 +582,27 @@ def run_workload(args, dev, rank, world):
         # BASELINE.json configs[4]: PixArt-Sigma DiT, ControlNet branch (13 copied blocks) trained, 2K latents (256^2 x 4), T5 ctx 300 with mask
         from simpletuner_amd.pixart.model import PixartSigma
         from tools.flop_count import pixart_flops_fwd
-        cfg.model_type, cfg.use_ema, cfg.learning_rate = "full", False, 1e-5
+        pix_lora = bool(args.lora)          # --lora: a LoRA on the trunk's attention projections (pixart/model.py:59) instead of the ControlNet branch
+        cfg.model_type, cfg.use_ema, cfg.learning_rate = ("lora" if pix_lora else "full"), False, (1e-4 if pix_lora else 1e-5)
         plugin = PixartSigma(cfg, acc)
         plugin.load_model(sample_size=256 if args.res >= 2048 else 128, fp8_base=bool(args.fp8))
-        plugin.controlnet_init(num_layers=13, synthetic_adapter=True)
+        if pix_lora:
+            plugin.add_lora_adapter()
+        else:
+            plugin.controlnet_init(num_layers=13, synthetic_adapter=True)
         S_txt, txt_dim, pooled_dim = 300, 4096, 0
         n_blocks, D_model = 0, 0
         lat_ = args.res // 8
         f_trunk = pixart_flops_fwd(plugin.model.config, lat_, lat_, 300, 0)
         f_blk = f_trunk / 28.0
         # trunk: forward (28) + input gradients through blocks 1..27 (2x forward each: attention bwd = 2x fwd, linears dgrad = 1x -> ~1.7x; counted 1x
-        # for the linears and 2x for attention is folded into 2x here);  adapter (13): forward + dgrad + wgrad = 3x
-        pix_step_flops = f_trunk + 2.0 * 27 * f_blk + 3.0 * 13 * f_blk
-        desc = (f"PixArt-Sigma XL/2 (28 blocks, 16x72 heads, D=1152) ControlNet-Transformer branch (13 copied blocks + zero-init projections) trained, trunk "
-                f"frozen{' with fp8-native Linears (e5m2 x e4m3 MFMA)' if args.fp8 else ''}, {args.res}^2 ({lat_}^2 latents, S={(lat_ // 2) ** 2}), T5 ctx 300 (120 valid), "
-                f"epsilon objective, AdamW, random-init weights")
+        # for the linears and 2x for attention is folded into 2x here);  adapter (13): forward + dgrad + wgrad = 3x.  LoRA on the trunk: forward + input gradients
+        # through all 28 blocks (the rank-space products are < 1 % of them)
+        pix_step_flops = (f_trunk + 2.0 * 28 * f_blk) if pix_lora else (f_trunk + 2.0 * 27 * f_blk + 3.0 * 13 * f_blk)
+        desc = ((f"PixArt-Sigma XL/2 (28 blocks, 16x72 heads, D=1152) LoRA r{args.rank} on attn1 / attn2 to_q/to_k/to_v/to_out.0 of every block, " if pix_lora else
+                 f"PixArt-Sigma XL/2 (28 blocks, 16x72 heads, D=1152) ControlNet-Transformer branch (13 copied blocks + zero-init projections) trained, trunk "
+                 f"frozen{' with fp8-native Linears (e5m2 x e4m3 MFMA)' if args.fp8 else ''}, ")
+                + f"{args.res}^2 ({lat_}^2 latents, S={(lat_ // 2) ** 2}), T5 ctx 300 (120 valid), epsilon objective, AdamW, random-init weights")
     else:
         from simpletuner_amd.sd3.model import SD3
         plugin = SD3(cfg, acc)
@@ -636,7 +642,8 @@ def run_workload(args, dev, rank, world):
             del b["add_text_embeds"]
             m_ = torch.zeros(B, S_txt, device=dev, dtype=torch.bfloat16); m_[:, :120] = 1
             b["encoder_attention_mask"] = m_
-            b["conditioning_latents"] = torch.randn(B, 4, hh, ww, device=dev, generator=gen).to(torch.bfloat16)
+            if not args.lora:
+                b["conditioning_latents"] = torch.randn(B, 4, hh, ww, device=dev, generator=gen).to(torch.bfloat16)
         return b
     if args.buckets:
         if args.model != "sd3":
@@ -742,7 +749,7 @@ def run_workload(args, dev, rank, world):
                        for k, v in prof.items() if v["launches"]}
         out = {
             "metric": f"training images/sec (whole node), {dict(flux='Flux.1-dev', sd3='SD3-Medium', sdxl='SDXL', sd15='SD 1.5', pixart='PixArt-Sigma')[args.model]} "
-                      f"{'ControlNet branch' if args.model == 'pixart' else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
+                      f"{'ControlNet branch' if (args.model == 'pixart' and not args.lora) else ('full fine-tune' + (' + EMA' if cfg.use_ema else '')) if args.full else f'LoRA r{args.rank}'} {args.res}^2 train step",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "ms_per_step_stats": step_stats, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (+ fp8 e5m2 x e4m3 trunk Linears)" if getattr(args, "fp8", False) else "bf16", "data": "synthetic",
@@ -787,7 +794,9 @@ def run_workload(args, dev, rank, world):
             del trainer, plugin, batches
             torch.cuda.empty_cache()
             from tests import parity_at_config as PC
-            if args.model == "pixart":
+            if args.model == "pixart" and args.lora:
+                pass                                  # (the LoRA-on-the-trunk mode is a secondary measurement: its parity is the GPU suite's, tests/test_pixart_model_gpu.py)
+            elif args.model == "pixart":
                 out["parity_at_config"] = PC.pixart_controlnet(args.res, dev)
             elif args.full:
                 out["parity_at_config"] = PC.sd3_full(args.res, dev)
