@@ -65,8 +65,15 @@ class PixartSigma(ModelFoundation):
         B, h, w = lat.shape[0], lat.shape[-2], lat.shape[-1]
         res = prepared_batch.get("resolution")
         ar = prepared_batch.get("aspect_ratio")
-        res = torch.tensor([[h, w]], device=dev).expand(B, -1) if res is None else res.to(device=dev)
-        ar = torch.tensor([[float(h / w)]], device=dev).expand(B, -1) if ar is None else ar.to(device=dev)
+        if res is None or ar is None:           # the defaults are cached per latent shape: a host->device copy is not allowed while a hipGraph is being captured
+            cache = self.__dict__.setdefault("_cond_cache", {})
+            key = (B, h, w, str(dev))
+            if key not in cache:
+                cache[key] = (torch.tensor([[h, w]], device=dev).expand(B, -1), torch.tensor([[float(h / w)]], device=dev).expand(B, -1))
+            res = cache[key][0] if res is None else res.to(device=dev)
+            ar = cache[key][1] if ar is None else ar.to(device=dev)
+        else:
+            res, ar = res.to(device=dev), ar.to(device=dev)
         return {"resolution": res, "aspect_ratio": ar}
 
     def model_predict(self, prepared_batch: dict):
