@@ -481,12 +481,19 @@ def main():
         # backward).  Checkpoint plan interval 3 / stride 4: three of every four blocks are recomputed, the fourth keeps its activations (peak 211 GiB of 268)
         a4 = copy.copy(args)
         a4.model, a4.lora, a4.rank, a4.batch, a4.full, a4.graph, a4.buckets = "flux", False, 32, 8, True, False, False
+        # The reference's own published single-GPU row that this path covers like for like (example sd3.peft-lora — SD3-Medium LoRA r128, 1024^2,
+        # batch 3, bf16, no activation checkpointing: 0.529 s/step on one H100): hipGraph replay of the captured step; `published` + `vs_baseline` ride on its entry
+        a5 = copy.copy(args)
+        a5.model, a5.lora, a5.rank, a5.batch, a5.full, a5.graph, a5.buckets, a5.res = "sd3", False, 128, 3, False, True, False, 1024
         if rank == 0:
             out["secondary"] = {}
-        for name, a_ in (("sdxl_lora", a2), ("sd3_full_buckets", a3), ("flux_full_rank", a4)):
+        keys = keys + ("published", "vs_baseline")
+        for name, a_ in (("sdxl_lora", a2), ("sd3_full_buckets", a3), ("flux_full_rank", a4), ("sd3_lora_r128_bs3_published_row", a5)):
             a_.steps, a_.warmup, a_.no_cpu_baseline, a_.prof_dump, a_.fp8, a_.gradient_checkpointing = min(args.steps, 5), 2, True, None, False, False
             if name == "flux_full_rank":
                 a_.steps, a_.warmup, a_.optimizer, a_.gradient_checkpointing, a_.ckpt_interval, a_.ckpt_stride = min(args.steps, 3), 1, "adamw_bf16", True, 3, 4
+            if name == "sd3_lora_r128_bs3_published_row":
+                a_.steps, a_.warmup = max(min(args.steps, 8), 5), 3          # two eager steps precede the capture
             gc.collect()
             torch.cuda.empty_cache()              # the previous workload's cached blocks go back before the next one's pools are built
             try:                                  # a secondary must never take the headline line down with it (every rank runs the same code: they fail together)

@@ -207,7 +207,7 @@ def sd3_full(res: int, dev, layers: int = 2, seed: int = 6, hw=None):
     what = (f"SD3-Medium (D=1536, 24x64 heads, {lat_h * 8}x{lat_w * 8} px, S={(lat_h // 2) * (lat_w // 2)}+231), {layers} joint blocks, FULL fine-tune, batch 1: "
             f"HIP bf16 vs oracle fp32 (autograd), same weights / noised latents / timesteps")
     rep = _summary(what, out["model_prediction"], pred.detach(), pairs)
-    rep["loss_hip"], rep["loss_oracle"] = round(float(loss), 6), round(float(o_loss), 6)
+    rep["loss_hip"], rep["loss_oracle"] = round(float(loss.detach()), 6), round(float(o_loss.detach()), 6)
     return rep
 
 
