@@ -83,8 +83,11 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> ha((size_t)M * K), hb((size_t)N * K);
     uint32_t s = 12345u + ki;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; const float v = ((int)((s >> 9) & 0xffff) - 32768) / 32768.0f; uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x8000u) >> 16); };
-    for (auto& x : ha) x = rnd();
-    for (auto& x : hb) x = rnd();
+    const bool zero = getenv("LAB_ZERO") != nullptr;        // zero-filled operands: no data toggling, the chip holds a higher clock (what the kernels do when power is not the limit)
+    if (!zero) {
+      for (auto& x : ha) x = rnd();
+      for (auto& x : hb) x = rnd();
+    }
     bf16 *A, *B, *C0, *C1;
     CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
     CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
@@ -100,7 +103,7 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> c0((size_t)M * N), c1((size_t)M * N);
     CK(hipMemcpy(c0.data(), C0, c0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), C1, c1.size() * 2, hipMemcpyDeviceToHost));
     size_t diff = 0; double num = 0, den = 0;
-    for (size_t i = 0; i < c0.size(); i++) {
+    for (size_t i = 0; i < (zero ? (size_t)4096 : c0.size()); i++) {
       if (c0[i] != c1[i]) diff++;
       uint32_t u0 = (uint32_t)c0[i] << 16, u1 = (uint32_t)c1[i] << 16; float f0, f1; memcpy(&f0, &u0, 4); memcpy(&f1, &u1, 4);
       num += (double)(f0 - f1) * (f0 - f1); den += (double)f0 * f0;
