@@ -747,7 +747,12 @@ def run_workload(args, dev, rank, world):
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes / launch",
                         "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"])),
                         "launches_per_step": g["launches"] // prof_steps, "avg_launch_us": round(g["ms"] * 1e3 / max(1, g["launches"]), 1),
-                        "share_of_step": round(g["ms"] / prof_steps / (elapsed / args.steps * 1e3), 3)}
+                        "share_of_step": round(g["ms"] / prof_steps / (elapsed / args.steps * 1e3), 3),
+                        # the ceiling MEASURED on an MI355X of this pool next to the vendor-stated peak — hipBLASLt (torch.matmul) on the step's
+                        # bf16 shapes with random operands: 1202-1392 TFLOP/s (zero-filled operands: up to 2034: the difference is the clock under the power cap)
+                        "measured_vendor_gemm_ceiling": {"tflops": 1391.6, "frac_of_it": round(ach / 1391.6, 3),
+                                                         "what": "hipBLASLt bf16 NT 36864 x 12288 x 3072, random operands (its best of the step's shapes)",
+                                                         "source": "profiles/r04_hipblaslt_ceiling.log (tools/hipblaslt_ceiling.py)"}}
                 if args.graph:
                     roof["measured_on"] = "one eager step after the timed region (the timed steps are hipGraph replays, which run no host-side event code)"
             kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 2), "launches_per_step": v["launches"] // prof_steps,
