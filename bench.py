@@ -366,20 +366,6 @@ def bench_vae(args, dev, rank, world):
     prof = None
     if not args.no_prof:
         ops.prof_enable(False); prof = ops.prof_collect(); ops.prof_reset()
-    comm_rep = None
-    if world > 1:
-        gs_ = getattr(plugin.get_trained_component(), "grad_sync", None)
-        rep_ = gs_.overlap_report() if gs_ is not None else None      # the LAST timed step's exchange (device timestamps; synchronises)
-        if rep_ is not None:
-            durs = [round((s_["end_ms"] - s_["start_ms"]) * 1e3, 1) for s_ in rep_["slices"]]
-            comm_rep = {"path": "st355_comm_* C ABI over RCCL (ST355_COMM=native)" if gs_.comm is not None else f"torch.distributed {dist.get_backend()} (RCCL) collectives on a comm stream",
-                        "mode": gs_.mode, "fp32_reduce": bool(gs_.fp32_reduce), "bucket_bytes": int(gs_.bucket_elems * gs_.flat.element_size()),
-                        "arena_bytes": int(gs_.flat.numel() * gs_.flat.element_size()), "backward_ms": round(rep_["backward_ms"], 3),
-                        "comm_ms_sum_over_buckets": round(rep_["comm_ms"], 3), "exposed_tail_ms": round(rep_["exposed_ms"], 3),
-                        "overlap_frac": round(rep_["overlap_frac"], 4), "buckets": len(durs), "bucket_us": durs[:64],
-                        "what": "last timed step, rank 0: per-bucket collective durations on the comm stream, comm time left after the last backward kernel"}
-        elif gs_ is None:
-            comm_rep = {"path": "gradient exchange after the step (hipGraph replay or gradient accumulation): no overlapped GradSync on this workload"}
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -717,6 +703,20 @@ def run_workload(args, dev, rank, world):
         if args.prof_dump and rank == 0:
             ops.prof_dump(args.prof_dump)
         ops.prof_reset()
+    comm_rep = None
+    if world > 1:
+        gs_ = getattr(plugin.get_trained_component(), "grad_sync", None)
+        rep_ = gs_.overlap_report() if gs_ is not None else None      # the LAST timed step's exchange (device timestamps; synchronises)
+        if rep_ is not None:
+            durs = [round((s_["end_ms"] - s_["start_ms"]) * 1e3, 1) for s_ in rep_["slices"]]
+            comm_rep = {"path": "st355_comm_* C ABI over RCCL (ST355_COMM=native)" if gs_.comm is not None else f"torch.distributed {dist.get_backend()} (RCCL) collectives on a comm stream",
+                        "mode": gs_.mode, "fp32_reduce": bool(gs_.fp32_reduce), "bucket_bytes": int(gs_.bucket_elems * gs_.flat.element_size()),
+                        "arena_bytes": int(gs_.flat.numel() * gs_.flat.element_size()), "backward_ms": round(rep_["backward_ms"], 3),
+                        "comm_ms_sum_over_buckets": round(rep_["comm_ms"], 3), "exposed_tail_ms": round(rep_["exposed_ms"], 3),
+                        "overlap_frac": round(rep_["overlap_frac"], 4), "buckets": len(durs), "bucket_us": durs[:64],
+                        "what": "last timed step, rank 0: per-bucket collective durations on the comm stream, comm time left after the last backward kernel"}
+        elif gs_ is None:
+            comm_rep = {"path": "gradient exchange after the step (hipGraph replay or gradient accumulation): no overlapped GradSync on this workload"}
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
