@@ -238,7 +238,7 @@ class GradSync:
         sl = [dict(lo=lo, hi=hi, start_ms=self._ev_begin.elapsed_time(e0), end_ms=self._ev_begin.elapsed_time(e1)) for lo, hi, e0, e1 in self._ev_slices]
         comm = sum(s_["end_ms"] - s_["start_ms"] for s_ in sl)
         exposed = max(0.0, (max((s_["end_ms"] for s_ in sl), default=0.0)) - t_bwd)
-        return dict(backward_ms=t_bwd, comm_ms=comm, exposed_ms=exposed, overlap_frac=(1.0 - exposed / comm) if comm > 0 else 1.0, slices=sl)
+        return dict(backward_ms=t_bwd, comm_ms=comm, exposed_ms=exposed, overlap_frac=max(0.0, 1.0 - exposed / comm) if comm > 0 else 1.0, slices=sl)
 
     def finish(self) -> float:
         """flush, join the comm stream back into the compute stream (device-side for nccl) and return the factor the optimizer must fold

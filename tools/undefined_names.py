@@ -41,7 +41,7 @@ def main():
     n_bad = 0
     for f in files:
         for scope, line, name in check(f):
-            print(f"{f.relative_to(ROOT) if f.is_absolute() else f}:{line}: name {name!r} is read in {scope} but never bound")
+            print(f"{f.relative_to(ROOT) if (f.is_absolute() and ROOT in f.parents) else f}:{line}: name {name!r} is read in {scope} but never bound")
             n_bad += 1
     print(f"{len(files)} files, {n_bad} unbound names")
     return 1 if n_bad else 0
