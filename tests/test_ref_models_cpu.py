@@ -260,6 +260,25 @@ def _adapter_shapes(cfg, n_ctrl):
     return sh
 
 
+def test_pixart_oracle_reproduces_reference_model_with_a_tread_route():
+    """the reference's PixArtTransformer2DModel EXECUTED in train mode with a TREAD router (pixart/transformer.py:487-489, 677-741; tools/gen_ref_tokenwise.py::gen_pixart_tread,
+    the router's permutation recorded): oracle.pixart with the same route replayed — output and every parameter / input gradient to <= 1e-5"""
+    G = _load("ref_tokenwise.pt")["pixart_tread"]
+    cfg = _pix_cfg(G["config"])
+    P = {k: v.requires_grad_(True) for k, v in _state(OP.param_shapes(cfg), G["seed"], G["state_checksum"], False).items()}
+    R = G["case"]
+    I = R["inputs"]
+    lat = I["hidden_states"].clone().requires_grad_(True)
+    out = OP.pixart_forward(P, cfg, lat, I["encoder_hidden_states"], I["encoder_attention_mask"], I["timestep"], I["resolution"], I["aspect_ratio"],
+                            tread={"routes": R["routes"], "mask_infos": R["mask_infos"]})
+    r = rel_l2(out, R["out"])
+    assert r <= TOL, f"pixart tread: rel-L2 {r:.3e}"
+    (out * R["w"]).sum().backward()
+    worst = _check_grads(P, R["grads"], "pixart tread")
+    assert rel_l2(lat.grad, R["input_grads"]["hidden_states"]) <= TOL
+    print(f"[pinned] pixart TREAD route: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
+
+
 def test_pixart_oracle_reproduces_reference_model_with_tokenwise_timesteps():
     """TOKENWISE timesteps [B, S] (CREPA self-flow; reference tests/test_pixart_model.py:91-115): the reference's PixArtTransformer2DModel executed with one timestep
     per token (tools/gen_ref_tokenwise.py) — per-token AdaLN-single rows in every block and in the head, the size conditions shared by a sample's tokens;

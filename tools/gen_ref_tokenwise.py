@@ -114,7 +114,40 @@ def gen_pixart():
             "_cite": "simpletuner/helpers/models/pixart/transformer.py:60-145 (tokenwise block), :749-753 (head), :790-850 (_embed_timesteps)"}
 
 
+def gen_pixart_tread():
+    """the reference's PixArt trunk with a TREAD route (pixart/transformer.py:487-489, 588-612, 677-741): the router's permutation recorded for replay"""
+    from tools.gen_ref_models import RecordingRouter
+    T = ref_shim.ref_module("simpletuner.helpers.models.pixart.transformer")
+    tread = ref_shim.ref_module("simpletuner.helpers.training.tread")
+
+    def call(m, a):
+        return m(a["hidden_states"], encoder_hidden_states=a["encoder_hidden_states"], timestep=a["timestep"],
+                 added_cond_kwargs={"resolution": a["resolution"], "aspect_ratio": a["aspect_ratio"]}, encoder_attention_mask=a["encoder_attention_mask"],
+                 return_dict=False)[0]
+
+    cfg = dict(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=4, cross_attention_dim=48, sample_size=16,
+               patch_size=2, caption_channels=20, use_additional_conditions=True)
+    model = T.PixArtTransformer2DModel(**cfg)
+    st = seed_params(model, 441)
+    g = torch.Generator().manual_seed(442)
+    B, Hl, Wl, L = 2, 8, 12, 6
+    mask = torch.ones(B, L)
+    mask[1, L - 1:] = 0
+    inputs = {"hidden_states": torch.randn(B, 4, Hl, Wl, generator=g), "encoder_hidden_states": torch.randn(B, L, 20, generator=g),
+              "timestep": torch.tensor([137.0, 842.0]), "resolution": torch.tensor([[float(Hl * 8), float(Wl * 8)]] * B),
+              "aspect_ratio": torch.tensor([[float(Hl) / float(Wl)]] * B), "encoder_attention_mask": mask}
+    routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": -2}]
+    rr = RecordingRouter(tread.TREADRouter(seed=9, device="cpu"))
+    model.set_router(rr, routes)
+    model.train()
+    r = strip(run(model, call, inputs, 443))
+    r["inputs"], r["routes"], r["mask_infos"] = inputs, routes, rr.infos
+    assert len(rr.infos) == 1
+    return {"config": cfg, "seed": 441, "state_checksum": state_checksum(st), "case": r,
+            "_cite": "simpletuner/helpers/models/pixart/transformer.py:487-489 (set_router), :588-612, :677-741 (the routed span of the block loop)"}
+
+
 if __name__ == "__main__":
-    G = {"sd3": gen_sd3(), "flux": gen_flux(), "pixart": gen_pixart()}
+    G = {"sd3": gen_sd3(), "flux": gen_flux(), "pixart": gen_pixart(), "pixart_tread": gen_pixart_tread()}
     torch.save(G, OUT / "ref_tokenwise.pt")
     print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items()})
