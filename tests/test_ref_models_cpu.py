@@ -279,6 +279,26 @@ def test_pixart_oracle_reproduces_reference_model_with_a_tread_route():
     print(f"[pinned] pixart TREAD route: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
 
 
+def test_pixart_oracle_lora_reproduces_the_reference_model_with_merged_adapters():
+    """PixArt LoRA (pixart/model.py:59 targets) in oracle.pixart — adapters as separate factors — against the reference trunk executed with the MERGED weights
+    W' = W + (alpha / r) B A: same output, same input gradient, and the adapter gradients dL/dW' implies"""
+    G = _load("ref_tokenwise.pt")["pixart_lora"]
+    cfg = _pix_cfg(G["config"])
+    shapes = OP.param_shapes(cfg)
+    P = _state(shapes, G["seed"], G["state_checksum"], False)
+    lora = {k: (a.requires_grad_(True), b.requires_grad_(True)) for k, (a, b) in seeded_lora(G["lora_targets"], shapes, G["lora_rank"], G["lora_seed"]).items()}
+    assert sorted(lora) == sorted(OP.lora_targets(cfg))
+    I = G["inputs"]
+    lat = I["hidden_states"].clone().requires_grad_(True)
+    out = OP.pixart_forward(P, cfg, lat, I["encoder_hidden_states"], I["encoder_attention_mask"], I["timestep"], I["resolution"], I["aspect_ratio"], lora=lora,
+                            lora_scale=G["lora_alpha"] / G["lora_rank"])
+    assert rel_l2(out, G["out"]) <= TOL
+    (out * G["w"]).sum().backward()
+    assert rel_l2(lat.grad, G["input_grads"]["hidden_states"]) <= TOL
+    for k, (dA, dB) in G["lora_grads"].items():
+        assert rel_l2(lora[k][0].grad, dA) <= 5 * TOL and rel_l2(lora[k][1].grad, dB) <= 5 * TOL, k
+
+
 def test_pixart_oracle_reproduces_reference_model_with_tokenwise_timesteps():
     """TOKENWISE timesteps [B, S] (CREPA self-flow; reference tests/test_pixart_model.py:91-115): the reference's PixArtTransformer2DModel executed with one timestep
     per token (tools/gen_ref_tokenwise.py) — per-token AdaLN-single rows in every block and in the head, the size conditions shared by a sample's tokens;

@@ -147,7 +147,42 @@ def gen_pixart_tread():
             "_cite": "simpletuner/helpers/models/pixart/transformer.py:487-489 (set_router), :588-612, :677-741 (the routed span of the block loop)"}
 
 
+def gen_pixart_lora():
+    """peft LoRA on the PixArt trunk's attention projections (pixart/model.py:59), as the reference trains it: the executed model carries the MERGED weights
+    W' = W + s B A; the adapter gradients are the ones dL/dW' implies (dA = s B^T dW', dB = s dW' A^T) — the same derivation as the Flux / SD3 tiers of gen_ref_models.py"""
+    from tests.ref_fixture_utils import seeded_lora
+    from tools.gen_ref_models import lora_grads, merge_lora
+    T = ref_shim.ref_module("simpletuner.helpers.models.pixart.transformer")
+
+    def call(m, a):
+        return m(a["hidden_states"], encoder_hidden_states=a["encoder_hidden_states"], timestep=a["timestep"],
+                 added_cond_kwargs={"resolution": a["resolution"], "aspect_ratio": a["aspect_ratio"]}, encoder_attention_mask=a["encoder_attention_mask"],
+                 return_dict=False)[0]
+
+    cfg = dict(num_attention_heads=2, attention_head_dim=24, in_channels=4, out_channels=8, num_layers=3, cross_attention_dim=48, sample_size=16,
+               patch_size=2, caption_channels=20, use_additional_conditions=True)
+    model = T.PixArtTransformer2DModel(**cfg)
+    st = seed_params(model, 451)
+    model.eval()
+    shapes = {n: tuple(p.shape) for n, p in model.named_parameters()}
+    g = torch.Generator().manual_seed(452)
+    B, Hl, Wl, L = 2, 8, 12, 6
+    mask = torch.ones(B, L)
+    mask[0, L - 2:] = 0
+    inputs = {"hidden_states": torch.randn(B, 4, Hl, Wl, generator=g), "encoder_hidden_states": torch.randn(B, L, 20, generator=g),
+              "timestep": torch.tensor([137.0, 842.0]), "resolution": torch.tensor([[float(Hl * 8), float(Wl * 8)]] * B),
+              "aspect_ratio": torch.tensor([[float(Hl) / float(Wl)]] * B), "encoder_attention_mask": mask}
+    targets = [f"transformer_blocks.{i}.{a}.{n}" for i in range(3) for a in ("attn1", "attn2") for n in ("to_q", "to_k", "to_v", "to_out.0")]
+    rank, alpha = 4, 8.0
+    lora = seeded_lora(targets, shapes, rank, 453)
+    merge_lora(model, lora, alpha / rank)
+    r = run(model, call, inputs, 454)
+    return {"config": cfg, "seed": 451, "state_checksum": state_checksum(st), "inputs": inputs, "lora_seed": 453, "lora_rank": rank, "lora_alpha": alpha, "lora_targets": targets,
+            "out": r["out"], "w": r["w"], "input_grads": r["input_grads"], "lora_grads": lora_grads(r["_full_grads"], lora, alpha / rank),
+            "_cite": "simpletuner/helpers/models/pixart/model.py:59 (DEFAULT_LORA_TARGET); peft LoraLayer: W' = W + (alpha / r) B A"}
+
+
 if __name__ == "__main__":
-    G = {"sd3": gen_sd3(), "flux": gen_flux(), "pixart": gen_pixart(), "pixart_tread": gen_pixart_tread()}
+    G = {"sd3": gen_sd3(), "flux": gen_flux(), "pixart": gen_pixart(), "pixart_tread": gen_pixart_tread(), "pixart_lora": gen_pixart_lora()}
     torch.save(G, OUT / "ref_tokenwise.pt")
-    print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items()})
+    print({k: (tuple(v["case"]["out"].shape), len(v["case"]["grads"])) for k, v in G.items() if "case" in v}, {"pixart_lora": len(G["pixart_lora"]["lora_grads"])})
