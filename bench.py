@@ -15,8 +15,11 @@ One "step" = prepare_batch (in-kernel noise + flow noising + target) -> MMDiT fo
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel class (the bf16 MFMA
 GEMM, measured live with hipEvent pairs on the launch stream by libst355's profiler), `cpu_baseline` (the oracle timed on the
 host cores for a bounded sample, N=1 only) and `parity_at_config` (the same sample through the HIP model, compared).  The default
-(Flux) line also carries `secondary.sdxl_lora` (the SDXL-LoRA half of BASELINE.json's metric) and `secondary.sd3_full_buckets` (configs[3]: SD3-Medium full
-fine-tune + EMA over mixed aspect buckets — the full-parameter gradient exchange), measured after the Flux timing at the same N.  `ms_per_step_stats` =
+(Flux) line also carries `secondary.sdxl_lora` (the SDXL-LoRA half of BASELINE.json's metric), `secondary.sd3_full_buckets` (configs[3]: SD3-Medium full
+fine-tune + EMA over mixed aspect buckets — the full-parameter gradient exchange), `secondary.flux_full_rank` (Flux.1-dev full-rank, AdamWBF16) and
+`secondary.sd3_lora_r128_bs3_published_row` (the reference's own published single-GPU row run like for like under hipGraph replay: `published` + `vs_baseline`),
+measured after the Flux timing at the same N; at N > 1 every entry carries `comm` (the gradient exchange's per-bucket timings).  `roofline` also names the
+MEASURED vendor GEMM ceiling of this pool's boxes (`measured_vendor_gemm_ceiling`, tools/hipblaslt_ceiling.py).  `ms_per_step_stats` =
 median / p95 / min / max of the per-step device timestamps; `--model sd15 | sdxl | sd3 --full | pixart` lines carry their own `parity_at_config`.
 """
 from __future__ import annotations
