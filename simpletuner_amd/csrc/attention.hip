@@ -321,7 +321,11 @@ __global__ void __launch_bounds__(256, 1) k_attn_fwd64(const bf16* __restrict__ 
       );
     } else {
       asm volatile(
+#ifdef ST355_FWD64_HD96_BODY_INC
+#include ST355_FWD64_HD96_BODY_INC
+#else
 #include "gen/attn_fwd64_hd96_body.inc"
+#endif
           ST355_FWD64_OPERANDS
 #include "gen/attn_fwd64_clobbers.inc"
       );

@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&qkv, nr * 3 * 2)); CK(hipMalloc(&O, nr * 2)); CK(hipMalloc(&dO, nr * 2));
   CK(hipMalloc(&dQ, nh * 2)); CK(hipMalloc(&dK, nh * 2)); CK(hipMalloc(&dqkv, nr * 3 * 2)); CK(hipMalloc(&dQ2, nh * 2)); CK(hipMalloc(&dK2, nh * 2)); CK(hipMalloc(&dqkv2, nr * 3 * 2));
   CK(hipMalloc(&lse2, (size_t)BH * S * 4)); CK(hipMalloc(&ws, st355_attn_bwd_workspace(B, H, S, Sp, d)));
-  k_fill<<<2048, 256, 0, st>>>(Q, nh, 1u, 1.5f); k_fill<<<2048, 256, 0, st>>>(K, nh, 2u, 1.5f);
+  const float qs = getenv("LAB_QSCALE") ? (float)atof(getenv("LAB_QSCALE")) : 1.5f;      // 6: the tile maxima climb past the stale reference by more than 2^8 (the out-of-line rescale runs)
+  k_fill<<<2048, 256, 0, st>>>(Q, nh, 1u, qs); k_fill<<<2048, 256, 0, st>>>(K, nh, 2u, 1.5f);
   k_fill<<<2048, 256, 0, st>>>(qkv, nr * 3, 3u, 1.f); k_fill<<<2048, 256, 0, st>>>(dO, nr, 4u, 1.f);
   k_transpose_heads<<<4096, 256, 0, st>>>(Q, Qt, BH, S, Sp, d); k_transpose_heads<<<4096, 256, 0, st>>>(K, Kt, BH, S, Sp, d);
   bf16* vrows = qkv + 2 * D;
@@ -148,6 +149,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hl, lse2, (size_t)BH * S * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl6, lse6, (size_t)BH * S * 4, hipMemcpyDeviceToHost));
     double ml = 0; for (size_t i = 0; i < (size_t)BH * S; i++) { double e = fabs((double)hl[i] - hl6[i]); if (!(e <= ml)) ml = e; }
     printf("  lse2, fwd64 vs fwd4: max |d| %.3e  %s\n", ml, ml < 1e-4 ? "ok" : "MISMATCH");
+    {   // FNV-1a over the bytes of O and lse2: two lab binaries (tools/kgen/variants.sh) whose lines agree produced bit-identical results
+      unsigned short* ho = (unsigned short*)malloc((size_t)nr * 2); CK(hipMemcpy(ho, O6, (size_t)nr * 2, hipMemcpyDeviceToHost));
+      unsigned long long f = 1469598103934665603ull;
+      for (size_t i = 0; i < (size_t)nr; i++) { f = (f ^ ho[i]) * 1099511628211ull; }
+      unsigned long long g = 1469598103934665603ull;
+      for (size_t i = 0; i < (size_t)BH * S; i++) { unsigned u; memcpy(&u, &hl6[i], 4); g = (g ^ u) * 1099511628211ull; }
+      printf("  fwd64 checksums: O %016llx  lse2 %016llx\n", f, g);
+      free(ho);
+    }
     if (g_attn_fwd_trace) {
       unsigned long long t[64]; CK(hipMemcpy(t, g_attn_fwd_trace, sizeof(t), hipMemcpyDeviceToHost));
       for (int w = 0; w < 4; w++) printf("  fwd64 trace wave %d: A %llu  C %llu  (step %llu cycles)\n", w, t[16 * w + 1] - t[16 * w], t[16 * w + 2] - t[16 * w + 1], t[16 * w + 2] - t[16 * w]);
@@ -177,6 +187,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     printf("  O, stale-max variant vs product kernel: rel-L2 %.3e, max |d| %.3e  %s\n", sqrt(hd / (hr + 1e-30)), hm, sqrt(hd / (hr + 1e-30)) < 4e-3 ? "within bf16 rounding" : "MISMATCH");
   }
+  if (getenv("LAB_FWD_ONLY")) { printf("  (LAB_FWD_ONLY: backward skipped)\n"); return 0; }
   // ---- backward: with the transposed copies (dkv2 + dq) and without (dkv3 + dq<TR>) ----
   bf16* dQ3; CK(hipMalloc(&dQ3, nh * 2)); CK(hipMemsetAsync(dQ3, 0, nh * 2, st));
   if (getenv("LAB_DQ_TRACE")) { CK(hipMalloc(&g_attn_dq_trace, 4 * 128)); CK(hipMemsetAsync(g_attn_dq_trace, 0, 4 * 128, st)); }

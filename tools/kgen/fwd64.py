@@ -56,12 +56,16 @@ def KF(i): return ar(192 + 4 * (i % 3), 4)
 def VF(i): return ar(204 + 4 * (i % 3), 4)
 def NMB(qb): return 224 + 16 * qb          # 16 registers, all -m_ref of query block qb
 NM = [NMB(0), NMB(1)]                      # (the first register of each block doubles as the scalar)
-L = [62, 63]             # running row sum per query block (this lane's half of the keys)
+PK = os.environ.get("FWD64_PK", "0") != "0"     # packed fp32 VALU: one v_pk_mul_f32 scales two scores, one v_pk_add_f32 feeds both partial row sums (same operations
+                                                # in the same order as the scalar forms: bit-identical output, 8 issues less per 8 scores)
+L = [60, 62] if PK else [62, 63]             # running row sum per query block (this lane's half of the keys)
+L2 = [61, 63] if PK else [60, 61]            # the second partial row sum (breaks the dependent-add chain); PK: the aligned pair v[L : L2]
+S_SC2 = 54                                   # PK: s[54:55] = (scale2, scale2), the scalar operand of v_pk_mul_f32
 ROWA = [32 + k for k in range(8)]
 VTA = [40 + k for k in range(4)]
 KOF = [44, 45, 46, 47]
 VOF = [48, 49, 50, 51]
-T = [52 + k for k in range(10)]        # scratch v52..v61
+T = [52 + k for k in range(8)]         # scratch v52..v59 (v60..v63: the row sums L / L2)
 # SGPRs
 S_KP, S_VP = 40, 42
 S_CNT = 44
@@ -165,7 +169,7 @@ def rescale_ops(g: int, qb: int, first: bool) -> list[str]:
             o.append(f"v_sub_f32_e32 {vr(S(g, sb, qb) + r)}, {vr(S(g, sb, qb) + r)}, {vr(t0)}")
     if not first:
         o.append(f"v_mul_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(t1)}")
-        o.append(f"v_mul_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(t1)}")       # the second partial row sum lives at the old reference too
+        o.append(f"v_mul_f32_e32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(t1)}")       # the second partial row sum lives at the old reference too
         o.append("s_nop 15")                                             # the last MFMAs of C own the O accumulators
         o.append("s_nop 15")
         for r in range(16 * NDT):
@@ -187,12 +191,17 @@ def b_exp(g: int, sb: int, qb: int, m: int) -> list[str]:
     ops = []
     for h4 in (0, 4):
         q = rs[h4:h4 + 4]
-        if EXACT:
+        if EXACT and PK:
+            ops += [f"v_pk_mul_f32 {vr(q[i], 2)}, {vr(q[i], 2)}, s[{S_SC2}:{S_SC2 + 1}]" for i in (0, 2)]
+        elif EXACT:
             ops += [f"v_mul_f32_e32 {vr(r)}, %[scale2], {vr(r)}" for r in q]
         ops += [f"v_exp_f32_e32 {vr(r)}, {vr(r)}" for r in q]
-        # two partial sums per query block break the dependent-add chain: L[qb] and T[8 + qb]
-        ops += [f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[0])}", f"v_add_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(q[1])}",
-                f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[2])}", f"v_add_f32_e32 {vr(T[8 + qb])}, {vr(T[8 + qb])}, {vr(q[3])}"]
+        # two partial sums per query block break the dependent-add chain: L[qb] and L2[qb]
+        if PK:
+            ops += [f"v_pk_add_f32 {vr(L[qb], 2)}, {vr(L[qb], 2)}, {vr(q[i], 2)}" for i in (0, 2)]
+        else:
+            ops += [f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[0])}", f"v_add_f32_e32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(q[1])}",
+                    f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(q[2])}", f"v_add_f32_e32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(q[3])}"]
         ops += [f"v_cvt_pk_bf16_f32 {vr(PF(sb, qb, m) + (h4 >> 1) + i)}, {vr(q[2 * i])}, {vr(q[2 * i + 1])}" for i in range(2)]
     return ops
 
@@ -227,6 +236,9 @@ def build() -> str:
     out_of_line: list[str] = []
     st.comment("---- prologue")
     o(f"s_mov_b32 s{S_M0}, m0")
+    if PK:
+        o(f"s_mov_b32 s{S_SC2}, %[scale2]")
+        o(f"s_mov_b32 s{S_SC2 + 1}, %[scale2]")
     if EXACT:
         for qb in range(2):
             for ks in range(NKS):
@@ -241,7 +253,7 @@ def build() -> str:
         for r in range(16):
             o(f"v_mov_b32_e32 {vr(NMB(qb) + r)}, 0")        # the reference is chosen after tile 0 (whose chains start from 0)
         o(f"v_mov_b32_e32 {vr(L[qb])}, 0")
-        o(f"v_mov_b32_e32 {vr(T[8 + qb])}, 0")
+        o(f"v_mov_b32_e32 {vr(L2[qb])}, 0")
     if not EXACT:
         o("s_waitcnt vmcnt(0)")
         for i in range(8 * NKS):
@@ -380,7 +392,7 @@ def build() -> str:
     o(f"s_add_u32 s{S_T0}, s{S_T0}, %[lds]")
     o(f"v_add_u32_e32 {vr(T[0])}, s{S_T0}, %[park]")
     for qb in range(2):
-        o(f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(T[8 + qb])}")
+        o(f"v_add_f32_e32 {vr(L[qb])}, {vr(L[qb])}, {vr(L2[qb])}")
         o(f"v_mov_b32_e32 {vr(T[1])}, {vr(L[qb])}")
         o("s_nop 1")
         o(f"v_permlane32_swap_b32_e32 {vr(L[qb])}, {vr(T[1])}")
