@@ -112,17 +112,34 @@ def init_params(cfg: FluxConfig, seed: int = 42, dtype=torch.float32, std: float
 
 
 def lora_targets(cfg: FluxConfig, which: str = "default"):
-    """peft target modules for Flux (flux/model.py:65 DEFAULT_LORA_TARGET = to_k,to_q,to_v,to_out.0 (+add_*_proj, to_add_out
-    for 'all')).  'default' here = the attention projections of both streams + single blocks."""
+    """peft target modules for Flux (flux/model.py:65 DEFAULT_LORA_TARGET = to_k,to_q,to_v,to_out.0; flux/model.py:1249-1375 the `flux_lora_target` sets).
+    'default' here = the attention projections of the image stream + single blocks; 'all' adds the context-stream projections, 'context' = only those;
+    '+ffs' adds the feed-forward Linears (all+ffs: both streams' ff.net.* and the single blocks' proj_mlp / proj_out; context+ffs: ff_context.net.*);
+    'tiny' / 'nano' = single_transformer_blocks.{7, 20}.proj_out / .7.proj_out (flux/model.py:1363-1375)."""
+    if which in ("tiny", "nano"):
+        blocks = (7, 20) if which == "tiny" else (7,)
+        return [f"single_transformer_blocks.{i}.proj_out" for i in blocks if i < cfg.num_single_layers]
+    base, ffs = (which[:-4], True) if which.endswith("+ffs") else (which, False)
     t = []
     for i in range(cfg.num_layers):
-        p = f"transformer_blocks.{i}.attn."
-        t += [p + n for n in ("to_q", "to_k", "to_v", "to_out.0")]
-        if which == "all":
+        b = f"transformer_blocks.{i}."
+        p = b + "attn."
+        if base != "context":
+            t += [p + n for n in ("to_q", "to_k", "to_v", "to_out.0")]
+        if base in ("all", "context"):
             t += [p + n for n in ("add_q_proj", "add_k_proj", "add_v_proj", "to_add_out")]
-    for i in range(cfg.num_single_layers):
-        p = f"single_transformer_blocks.{i}.attn."
-        t += [p + n for n in ("to_q", "to_k", "to_v")]
+        if ffs and base == "all":
+            t += [b + n for n in ("ff.net.0.proj", "ff.net.2")]
+        if ffs:
+            t += [b + n for n in ("ff_context.net.0.proj", "ff_context.net.2")]
+    if base != "context":
+        for i in range(cfg.num_single_layers):
+            b = f"single_transformer_blocks.{i}."
+            t += [b + "attn." + n for n in ("to_q", "to_k", "to_v")]
+            if ffs:
+                t += [b + "proj_mlp", b + "proj_out"]
+        if ffs:
+            t += ["proj_out"]          # peft's suffix rule: the entry "proj_out" also names the model's own output projection
     return t
 
 
@@ -302,10 +319,10 @@ def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1
     enc = enc + c_gate_msa[:, None] * linear(co, P, a + "to_add_out", lora, lora_scale)
 
     n2 = layer_norm(hidden) * (1 + scale_mlp) + shift_mlp
-    ff = linear(F.gelu(linear(n2, P, p + "ff.net.0.proj"), approximate="tanh"), P, p + "ff.net.2")
+    ff = linear(F.gelu(linear(n2, P, p + "ff.net.0.proj", lora, lora_scale), approximate="tanh"), P, p + "ff.net.2", lora, lora_scale)
     hidden = hidden + gate_mlp * ff
     cn2 = layer_norm(enc) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-    cff = linear(F.gelu(linear(cn2, P, p + "ff_context.net.0.proj"), approximate="tanh"), P, p + "ff_context.net.2")
+    cff = linear(F.gelu(linear(cn2, P, p + "ff_context.net.0.proj", lora, lora_scale), approximate="tanh"), P, p + "ff_context.net.2", lora, lora_scale)
     enc = enc + c_gate_mlp[:, None] * cff
     enc = torch.nan_to_num(enc, nan=0.0, posinf=65504, neginf=-65504)
     return enc, hidden
@@ -325,8 +342,8 @@ def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bi
     o = sdpa(q, k, v, key_bias)
     B, _, S, _ = o.shape
     o = o.transpose(1, 2).reshape(B, S, -1)
-    mlp = F.gelu(linear(n, P, p + "proj_mlp"), approximate="tanh")
-    out = x + gate * linear(torch.cat([o, mlp], dim=2), P, p + "proj_out")
+    mlp = F.gelu(linear(n, P, p + "proj_mlp", lora, lora_scale), approximate="tanh")
+    out = x + gate * linear(torch.cat([o, mlp], dim=2), P, p + "proj_out", lora, lora_scale)
     return torch.nan_to_num(out, nan=0.0, posinf=65504, neginf=-65504)
 
 
@@ -406,7 +423,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
     emb = linear(F.silu(temb), P, "norm_out.linear")
     scale, shift = emb.chunk(2, dim=-1)         # AdaLayerNormContinuous: scale FIRST
     hidden = layer_norm(hidden) * (1 + _rows(scale)) + _rows(shift)
-    return linear(hidden, P, "proj_out")
+    return linear(hidden, P, "proj_out", lora, lora_scale)
 
 
 def flux_model_predict(P, cfg, noisy_latents, prompt_embeds, pooled, timesteps, guidance_value: float = 1.0, lora=None,

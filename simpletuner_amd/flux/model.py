@@ -103,23 +103,36 @@ class Flux(ModelFoundation):
         return self.unwrap_model(self.model).enable_full_finetune()
 
     # flux/model.py:1235-1380: `flux_lora_target` names a set of wrapped Linears.  Built here: the attention projections — "all" (image + context
-    # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default) and the fall-through DEFAULT_LORA_TARGET (image stream and single
-    # blocks only: what BASELINE.json's config names).  Sets that wrap feed-forward / embedder / norm / ControlNet layers, or only a subset of the
-    # attention projections, need adapter backward paths this round did not build: refused, never silently narrowed.
-    _UNBUILT_LORA_TARGETS = ("context+ffs", "all+ffs", "all+ffs+embedder", "all+ffs+embedder+controlnet", "ai-toolkit", "tiny", "nano", "controlnet")
+    # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default), "context", the fall-through DEFAULT_LORA_TARGET (image stream and single
+    # blocks only: what BASELINE.json's config names) — the feed-forward sets "all+ffs" / "context+ffs" (ff.net.*, ff_context.net.*, proj_mlp, proj_out) and
+    # "tiny" / "nano" (single_transformer_blocks.7(.20).proj_out).  Sets that wrap embedder / AdaLN-modulation / ControlNet layers need adapter backward paths
+    # that are not built (the modulation rows have no backward under a frozen base): refused, never silently narrowed.
+    _UNBUILT_LORA_TARGETS = ("all+ffs+embedder", "all+ffs+embedder+controlnet", "ai-toolkit", "controlnet")
+    _BUILT_LORA_TARGETS = ("all", "context", "all+ffs", "context+ffs", "tiny", "nano")
 
     def _lora_target_set(self) -> str:
         want = str(getattr(self.config, "flux_lora_target", "default") or "default")
         if want in self._UNBUILT_LORA_TARGETS:
-            raise NotImplementedError(f"flux_lora_target={want!r} is not implemented on the st355 path (built: 'all', 'context', and the default attention set)")
-        return want if want in ("all", "context") else "default"
+            raise NotImplementedError(f"flux_lora_target={want!r} is not implemented on the st355 path (built: {', '.join(repr(t) for t in self._BUILT_LORA_TARGETS)} "
+                                      f"and the default attention set)")
+        return want if want in self._BUILT_LORA_TARGETS else "default"
 
     def get_lora_target_layers(self):
         which = self._lora_target_set()
+        attn_all = ["to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "add_k_proj", "add_q_proj", "add_v_proj", "to_out.0", "to_add_out"]
+        ctx = ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out"]                     # flux/model.py:1263-1271
         if which == "all":
-            return ["to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "add_k_proj", "add_q_proj", "add_v_proj", "to_out.0", "to_add_out"]
-        if which == "context":                       # flux/model.py:1263-1271
-            return ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out"]
+            return attn_all
+        if which == "context":
+            return ctx
+        if which == "context+ffs":                   # flux/model.py:1272-1282
+            return ctx + ["ff_context.net.0.proj", "ff_context.net.2"]
+        if which == "all+ffs":                       # flux/model.py:1283-1301
+            return attn_all + ["ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "proj_mlp", "proj_out"]
+        if which == "tiny":                          # flux/model.py:1363-1369
+            return ["single_transformer_blocks.7.proj_out", "single_transformer_blocks.20.proj_out"]
+        if which == "nano":                          # flux/model.py:1370-1375
+            return ["single_transformer_blocks.7.proj_out"]
         return list(self.DEFAULT_LORA_TARGET)
 
     def _flux_guidance_scales(self, prepared_batch, batch_size):

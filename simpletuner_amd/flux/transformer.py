@@ -91,15 +91,18 @@ class LoraGroup:
                           k2_off=g * self.r_pad, n_off=n_off)
 
     def grads(self, x, T, dy, U, accumulate: bool, sync=None):
-        """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r])."""
-        multi = len(self.targets) > 1 and self.r_pad == 32 and U.shape[1] >= 128        # q / k / v share x: dA of all three in ONE pass over x
+        """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r]).  x: the projection's input, or — an input that only
+        exists as K segments (the single block's proj_out reads [attn | mlp] as a two-segment K loop) — a list of (segment, first input column)."""
+        segs = x if isinstance(x, (list, tuple)) else [(x, 0)]
+        multi = len(segs) == 1 and len(self.targets) > 1 and self.r_pad == 32 and U.shape[1] >= 128        # q / k / v share x: dA of all three in ONE pass over x
         cw = min(self.r_pad, 64)                                 # rank-space kernels take 32 or 64 adapter columns per pass
         for g, (_, n_off, N) in enumerate(self.targets):
             for s0 in range(0, self.rank, cw):
                 c0, r_used = g * self.r_pad + s0, min(cw, self.rank - s0)
                 ops.skinny_tn(dy[..., n_off:n_off + N], T[:, c0:c0 + cw], self.gB[g][:, s0:], self.rank, 1, r_used, alpha=self.scale, accumulate=accumulate)
                 if not multi:
-                    ops.skinny_tn(x, U[:, c0:c0 + cw], self.gA[g][s0:], 1, self.K, r_used, alpha=1.0, accumulate=accumulate)
+                    for (xs, k0) in segs:
+                        ops.skinny_tn(xs, U[:, c0:c0 + cw], self.gA[g][s0:, k0:], 1, self.K, r_used, alpha=1.0, accumulate=accumulate)
         if multi:
             ops.skinny_tn_multi(x, U, self.gA, 1, self.K, self.rank, alpha=1.0, accumulate=accumulate)
         if sync is not None:
@@ -305,7 +308,10 @@ class FluxTransformer2DModel(nn.Module):
     def add_lora_adapter(self, rank: int = 32, alpha: Optional[float] = None, targets: str = "default", seed: int = 7,
                          init_b_std: float = 0.0):
         """common.py:1049-1128 (LoraConfig(r, lora_alpha, target_modules)).  targets: 'default' = attn to_q,to_k,to_v,to_out.0
-        (+ single-block to_q,to_k,to_v); 'all' adds the context-stream projections; 'context' = only those (flux/model.py:1263-1271)."""
+        (+ single-block to_q,to_k,to_v); 'all' adds the context-stream projections; 'context' = only those (flux/model.py:1263-1271); 'all+ffs' / 'context+ffs' add
+        the feed-forward Linears of that set's streams (flux/model.py:1272-1301: ff.net.*, ff_context.net.*, the single blocks' proj_mlp / proj_out); 'tiny' / 'nano' =
+        single_transformer_blocks.{7, 20}.proj_out / .7.proj_out only (flux/model.py:1363-1375).  A block that carries a feed-forward adapter is sequenced from the
+        host (the block-level C entry points know the attention adapters only)."""
         alpha = float(rank if alpha is None else alpha)
         D, dev = self.D, self.device_
         plan = []  # (group, name, n_off, N, K)
@@ -319,21 +325,48 @@ class FluxTransformer2DModel(nn.Module):
             for (name, n_off, N) in g.targets:
                 plan.append((g, name, N, K))
 
-        if targets not in ("default", "all", "context"):
-            raise ValueError(f"add_lora_adapter: unknown target set {targets!r} (built: 'default', 'all', 'context')")
-        if targets == "context" and not self.double:
-            raise ValueError("add_lora_adapter: the 'context' target set names the double blocks' context-stream projections; this model has no double block")
-        for i, blk in enumerate(self.double):
-            p = f"transformer_blocks.{i}.attn."
-            if targets != "context":
-                group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
-                group(blk.to_out, p, ["to_out.0"], D)
-            if targets in ("all", "context"):       # flux/model.py:1263-1271 "context": add_q/k/v_proj + to_add_out only (the single blocks have no such layers)
-                group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
-                group(blk.to_add_out, p, ["to_add_out"], D)
-        if targets != "context":
-            for i, blk in enumerate(self.single):
-                group(blk.qkv, f"single_transformer_blocks.{i}.attn.", ["to_q", "to_k", "to_v"], D)
+        sets = ("default", "all", "context", "all+ffs", "context+ffs", "tiny", "nano")
+        if targets not in sets:
+            raise ValueError(f"add_lora_adapter: unknown target set {targets!r} (built: {', '.join(repr(t) for t in sets)})")
+        base, ffs = (targets[:-4], True) if targets.endswith("+ffs") else (targets, False)
+        if base == "context" and not self.double:
+            raise ValueError(f"add_lora_adapter: the {targets!r} target set names the double blocks' context-stream layers; this model has no double block")
+        if targets in ("tiny", "nano"):            # flux/model.py:1363-1375: single_transformer_blocks.7(.20).proj_out — nothing else carries an adapter
+            want = (7, 20) if targets == "tiny" else (7,)
+            if max(want) >= len(self.single):
+                raise ValueError(f"add_lora_adapter: the {targets!r} target set names single_transformer_blocks.{max(want)}.proj_out; this model has {len(self.single)} single blocks")
+            for i in want:
+                group(self.single[i].proj_out, f"single_transformer_blocks.{i}.", ["proj_out"], 5 * D)
+        else:
+            for i, blk in enumerate(self.double):
+                b = f"transformer_blocks.{i}."
+                p = b + "attn."
+                if base != "context":
+                    group(blk.qkv, p, ["to_q", "to_k", "to_v"], D)
+                    group(blk.to_out, p, ["to_out.0"], D)
+                if base in ("all", "context"):       # flux/model.py:1263-1271 "context": add_q/k/v_proj + to_add_out only (the single blocks have no such layers)
+                    group(blk.add_qkv, p, ["add_q_proj", "add_k_proj", "add_v_proj"], D)
+                    group(blk.to_add_out, p, ["to_add_out"], D)
+                if ffs and base == "all":             # flux/model.py:1283-1301 "all+ffs": + ff.net.0.proj, ff.net.2, ff_context.*, proj_mlp, proj_out
+                    group(blk.ff1, b, ["ff.net.0.proj"], D)
+                    group(blk.ff2, b, ["ff.net.2"], 4 * D)
+                if ffs:                               # flux/model.py:1272-1282 "context+ffs": + ff_context.net.0.proj, ff_context.net.2
+                    group(blk.ffc1, b, ["ff_context.net.0.proj"], D)
+                    group(blk.ffc2, b, ["ff_context.net.2"], 4 * D)
+            if base != "context":
+                for i, blk in enumerate(self.single):
+                    b = f"single_transformer_blocks.{i}."
+                    group(blk.qkv, b + "attn.", ["to_q", "to_k", "to_v"], D)
+                    if ffs:
+                        group(blk.proj_mlp, b, ["proj_mlp"], D)
+                        group(blk.proj_out, b, ["proj_out"], 5 * D)
+                if ffs:                               # peft wraps every module whose name ends with an entry: "proj_out" is also the model's output projection
+                    group(self.l_out, "", ["proj_out"], D)
+        # the backward stops below the first block (execution order: double stack, then single stack) that carries an adapter: nothing upstream of it trains
+        # ('tiny' / 'nano': single block 7 — the 19 double and 7 single blocks below it run no backward at all)
+        carries = [any(l.lora is not None for l in (b.qkv, b.add_qkv, b.to_out, b.to_add_out, b.ff1, b.ff2, b.ffc1, b.ffc2)) for b in self.double] \
+            + [any(l.lora is not None for l in (b.qkv, b.proj_mlp, b.proj_out)) for b in self.single]
+        self._bwd_stop = carries.index(True) if True in carries else 0
         total = sum(rank * K + N * rank for (_, _, N, K) in plan)
         total = (total + 7) // 8 * 8
         self.lora_flat = torch.zeros(total, dtype=F32, device=dev)
@@ -538,7 +571,8 @@ class FluxTransformer2DModel(nn.Module):
         rpi = 1 if tokw else Si
         full = getattr(env, "full", False)        # full-rank training: norm weights train (no fused projection epilogue), extra activations are kept
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
-        if (fused and not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
+        ff_lora = any(l.lora is not None for l in (blk.ff1, blk.ff2, blk.ffc1, blk.ffc2))      # '+ffs' adapters: host sequencing
+        if (fused and not tokw and not ff_lora and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
             # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
             # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
             mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
@@ -631,11 +665,18 @@ class FluxTransformer2DModel(nn.Module):
         n2_i = ops.ln_modulate_fwd(x1_img, mi[:, 4 * D:5 * D], mi[:, 3 * D:4 * D], rpi)
         n2_t = ops.ln_modulate_fwd(x1_txt, mt[:, 4 * D:5 * D], mt[:, 3 * D:4 * D], St)
         hpre_img = torch.empty(B * Si, 4 * D, dtype=BF16, device=dev); hpre_txt = torch.empty(B * St, 4 * D, dtype=BF16, device=dev)
-        h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img),
-                                     dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt)])
+        # '+ffs' adapters (flux/model.py:1272-1301): the same K-extension as the attention projections' — T = x A^T first, then [x | T] [W | sB]^T in the projection's launch
+        ext = lambda lg, T_: dict(a2=T_, b2=lg.B_blk, k2_real=lg.k2_real) if lg is not None else {}
+        T_f1 = ops.gemm(n2_i, blk.ff1.lora.A_cat) if blk.ff1.lora is not None else None
+        T_c1 = ops.gemm(n2_t, blk.ffc1.lora.A_cat) if blk.ffc1.lora is not None else None
+        h_i, h_t = ops.gemm_grouped([dict(a=n2_i, w=blk.ff1.w, bias=blk.ff1.b, epilogue=EPI_GELU, aux_out=hpre_img, **ext(blk.ff1.lora, T_f1)),
+                                     dict(a=n2_t, w=blk.ffc1.w, bias=blk.ffc1.b, epilogue=EPI_GELU, aux_out=hpre_txt, **ext(blk.ffc1.lora, T_c1))])
+        T_f2 = ops.gemm(h_i, blk.ff2.lora.A_cat) if blk.ff2.lora is not None else None
+        T_c2 = ops.gemm(h_t, blk.ffc2.lora.A_cat) if blk.ffc2.lora is not None else None
         x = x2_img = x2_txt = None
         kf_i = dict(aux_out=yf_i) if yf_i is not None else {}
         kf_t = dict(aux_out=yf_t) if yf_t is not None else {}
+        kf_i.update(ext(blk.ff2.lora, T_f2)); kf_t.update(ext(blk.ffc2.lora, T_c2))
         if bi == len(self.double) - 1:
             # the last double block's MLP down-projections write the joint [txt || img] sequence of the single blocks in place
             # (flux/transformer.py:1332 `torch.cat`): one problem per (stream, sample), no concat pass
@@ -654,6 +695,10 @@ class FluxTransformer2DModel(nn.Module):
                                  lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
             if full:    # full-rank training also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
                 sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
+            if ff_lora:  # the feed-forward adapters' gradients read their Linear's input (dA = U^T x) and T = x A^T (dB = s dy^T T)
+                sv.ff = SimpleNamespace(n2_i=n2_i if blk.ff1.lora is not None else None, n2_t=n2_t if blk.ffc1.lora is not None else None,
+                                        h_i=h_i if blk.ff2.lora is not None else None, h_t=h_t if blk.ffc2.lora is not None else None,
+                                        T_f1=T_f1, T_c1=T_c1, T_f2=T_f2, T_c2=T_c2)
         return x2_img, x2_txt, x, sv
 
     def _single_fwd(self, bi: int, x, env, save: bool):
@@ -666,7 +711,8 @@ class FluxTransformer2DModel(nn.Module):
         rpx = 1 if tokw else S
         full = getattr(env, "full", False)
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
-        if fused and not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
+        ff_lora = blk.proj_mlp.lora is not None or blk.proj_out.lora is not None      # '+ffs' / 'tiny' / 'nano' adapters: host sequencing (the C entry point knows the q / k / v adapters)
+        if fused and not tokw and not ff_lora and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
             # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
             # as the host-side sequencing below
             lo = blk.qkv.lora
@@ -681,7 +727,7 @@ class FluxTransformer2DModel(nn.Module):
                                       norm_q=blk.norm_q, norm_k=blk.norm_k, w_mlp=blk.proj_mlp.w, b_mlp=blk.proj_mlp.b,
                                       w_out=blk.proj_out.w, ld_w_out=blk.proj_out.w.stride(0), b_out=blk.proj_out.b, cos_p=env.cos_p, sin_p=env.sin_p,
                                       key_bias=env.key_bias, n=n, V=V, rrms=rrms, Q=Q, K=K, O=O, lse2=lse2, hpre=hpre, T=T, Vt=Vt, hact=hact, x_out=x_out)
-            sv = SimpleNamespace(x=x, n=n, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
+            sv = SimpleNamespace(x=x, n=n, qkv=None, V=V, rrms=rrms, Q=Q, K=K, Qt=None, Kt=None, O=O, lse2=lse2, hpre=hpre, T=T, T_m=None, T_p=None) if save else None
             return x_out, sv
         n = ops.ln_modulate_fwd(x, ms[:, D:2 * D], ms[:, :D], rpx)
         O = torch.empty(B * S, D, dtype=BF16, device=dev); lse2 = torch.empty(B, H, S, dtype=F32, device=dev)
@@ -701,14 +747,23 @@ class FluxTransformer2DModel(nn.Module):
             ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, env.scale, key_bias=env.key_bias)
             del Vt
         hpre = torch.empty(B * S, 4 * D, dtype=BF16, device=dev)
-        hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre)
+        lm, lp = blk.proj_mlp.lora, blk.proj_out.lora
+        T_m = ops.gemm(n, lm.A_cat) if lm is not None else None
+        hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre,
+                        **(dict(a2=T_m, b2=lm.B_blk, k2_real=lm.k2_real) if lm is not None else {}))
         # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
         y = torch.empty(B * S, D, dtype=BF16, device=dev) if (full and save) else None          # the un-gated branch output (gate gradient)
+        x_in, T_p = x, None
+        if lp is not None:
+            # proj_out's adapter: T = [attn | mlp] A^T as the same two-segment K loop; both K segments of the projection are taken, so the low-rank term goes
+            # out as its own gated-residual launch first:  x' = x + gate * (T (sB)^T),  then  x_out = x' + gate * ([attn | mlp] W^T + b)
+            T_p = ops.gemm(O, lp.A_cat[:, :D], a2=hact, b2=lp.A_cat[:, D:])
+            x_in = ops.gemm(T_p, lp.B_blk, epilogue=EPI_GATE_RESIDUAL, aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx)
         x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
-                         aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx, **(dict(aux_out=y) if y is not None else {}))
-        sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T) if save else None
-        if sv is not None and full:
-            sv.hact, sv.y = hact, y
+                         aux_in=x_in, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx, **(dict(aux_out=y) if y is not None else {}))
+        sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T, T_m=T_m, T_p=T_p) if save else None
+        if sv is not None and (full or lp is not None):
+            sv.hact, sv.y = hact, y           # (proj_out's adapter gradient dA = U^T [attn | mlp] reads the activated MLP rows)
         return x_out, sv
 
     def _engine_forward(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, img_ids, txt_ids, save: bool, key_bias=None, full: bool = False):
@@ -880,11 +935,13 @@ class FluxTransformer2DModel(nn.Module):
                 ops.ln_modulate_fwd(x[b * S + St:(b + 1) * S], mo_b[:, :D], mo_b[:, D:2 * D], 1, out=n_out[b * Si:(b + 1) * Si])
                 continue
             ops.ln_modulate_fwd(x[b * S + St:(b + 1) * S], mo[b:b + 1, :D], mo[b:b + 1, D:2 * D], Si, out=n_out[b * Si:(b + 1) * Si])
-        out = ops.gemm(n_out, self.l_out.w, bias=self.l_out.b)
+        out, T_out = self._lin_fwd(self.l_out, n_out)          # ('all+ffs' also wraps the model's own proj_out: peft matches the name suffix, flux/model.py:1283-1301)
         if save:
             ctx.x_final = x
             if full:
                 ctx.n_out, ctx.emb = n_out, em
+            elif self.l_out.lora is not None:
+                ctx.n_out, ctx.T_out = n_out, T_out
         return out.view(B, Si, -1), ctx
 
     def _attn_backward(self, sv, dO, dqkv, env):
@@ -931,7 +988,8 @@ class FluxTransformer2DModel(nn.Module):
         msl = (lambda j: env.mod_x[:, self.single[j].mod_off - env.xoff:self.single[j].mod_off - env.xoff + 3 * D]) if tokw else (lambda j: mod[:, self.single[j].mod_off:self.single[j].mod_off + 3 * D])
         ms = msl(li)
         rpx = 1 if tokw else S
-        if (not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
+        lm, lp = blk.proj_mlp.lora, blk.proj_out.lora
+        if (not tokw and lm is None and lp is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
                 and dx.is_contiguous() and (dxg is None or dxg.is_contiguous())):
             # ONE C entry point (st355_block_flux_single_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lo = blk.qkv.lora
@@ -954,9 +1012,23 @@ class FluxTransformer2DModel(nn.Module):
                 self.grad_sync.ready(lo.flat_lo, lo.flat_hi)
             return dx_out, dxg_out, None, None
         g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], rpx)
-        dO = ops.gemm(g, blk.proj_out.wT[:D])
-        dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre)
-        dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
+        kw_o = kw_h = {}
+        if lp is not None:         # proj_out's adapter: dx_in += (g sB) A, split over the two K segments [attn | mlp] of its input
+            U_p = ops.gemm(g, lp.B_blk_T)
+            kw_o = dict(a2=U_p, b2=lp.A_cat_T[:D], k2_real=lp.k2_real)
+            kw_h = dict(a2=U_p, b2=lp.A_cat_T[D:], k2_real=lp.k2_real)
+        dO = ops.gemm(g, blk.proj_out.wT[:D], **kw_o)
+        dhpre = ops.gemm(g, blk.proj_out.wT[D:], epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre, **kw_h)
+        if lp is not None:
+            lp.grads([(sv.O, 0), (sv.hact, D)], sv.T_p, g, U_p, self.accumulate_lora_grads, self.grad_sync)
+            del U_p
+        if lm is not None:
+            U_m = ops.gemm(dhpre, lm.B_blk_T)
+            dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT, a2=U_m, b2=lm.A_cat_T, k2_real=lm.k2_real)
+            lm.grads(sv.n, sv.T_m, dhpre, U_m, self.accumulate_lora_grads, self.grad_sync)
+            del U_m
+        else:
+            dn_mlp = ops.gemm(dhpre, blk.proj_mlp.wT)
         del g, dhpre
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_q, blk.norm_k), (blk.norm_q, blk.norm_k), 0)
@@ -985,7 +1057,8 @@ class FluxTransformer2DModel(nn.Module):
         tokw = getattr(env, "tokenwise", False)       # per-token modulation rows on the image stream (see _double_fwd)
         mi = (env.mod_img if tokw else mod)[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
         rpi = 1 if tokw else Si
-        if (not tokw and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
+        ff = getattr(sv, "ff", None)              # '+ffs' adapters on this block's feed-forward Linears (host sequencing)
+        if (not tokw and ff is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
                 and Si % 256 == 0 and St % 256 == 0 and d_img.is_contiguous() and d_txt.is_contiguous()):
             # ONE C entry point (st355_block_flux_double_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lq, lo_ = blk.qkv.lora, blk.to_out.lora
@@ -1016,9 +1089,26 @@ class FluxTransformer2DModel(nn.Module):
                         self.grad_sync.ready(lg.flat_lo, lg.flat_hi)
             return d_img_out, d_txt_out
         g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], rpi); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
-        dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
-                                       dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
-        dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+        if ff is None:
+            dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
+                                           dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)])
+            dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT), dict(a=dh_t, w=blk.ffc1.wT)])
+        else:
+            # dx = dy W + (dy sB) A as a K-extension of the dgrad launch (U = dy sB first); then the rank-space adapter gradients dB = s dy^T T, dA = U^T x
+            back = lambda lg, dy: ops.gemm(dy, lg.B_blk_T) if lg is not None else None
+            ext = lambda lg, U_: dict(a2=U_, b2=lg.A_cat_T, k2_real=lg.k2_real) if lg is not None else {}
+            U_f2, U_c2 = back(blk.ff2.lora, g_i), back(blk.ffc2.lora, g_t)
+            dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img, **ext(blk.ff2.lora, U_f2)),
+                                           dict(a=g_t, w=blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt, **ext(blk.ffc2.lora, U_c2))])
+            for (lg, x_in, T_, dy, U_) in ((blk.ff2.lora, ff.h_i, ff.T_f2, g_i, U_f2), (blk.ffc2.lora, ff.h_t, ff.T_c2, g_t, U_c2)):
+                if lg is not None:
+                    lg.grads(x_in, T_, dy, U_, self.accumulate_lora_grads, self.grad_sync)
+            U_f1, U_c1 = back(blk.ff1.lora, dh_i), back(blk.ffc1.lora, dh_t)
+            dn2_i, dn2_t = ops.gemm_grouped([dict(a=dh_i, w=blk.ff1.wT, **ext(blk.ff1.lora, U_f1)), dict(a=dh_t, w=blk.ffc1.wT, **ext(blk.ffc1.lora, U_c1))])
+            for (lg, x_in, T_, dy, U_) in ((blk.ff1.lora, ff.n2_i, ff.T_f1, dh_i, U_f1), (blk.ffc1.lora, ff.n2_t, ff.T_c1, dh_t, U_c1)):
+                if lg is not None:
+                    lg.grads(x_in, T_, dy, U_, self.accumulate_lora_grads, self.grad_sync)
+            del U_f2, U_c2, U_f1, U_c1
         del g_i, g_t, dh_i, dh_t
         dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], rpi, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
         dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
@@ -1077,7 +1167,7 @@ class FluxTransformer2DModel(nn.Module):
         dev = self.device_
         dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
-        dn = ops.gemm(dout, self.l_out.wT)
+        dn = self._lin_bwd(self.l_out, dout, x=getattr(ctx, "n_out", None), T=getattr(ctx, "T_out", None))
         dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
         for b in range(B):          # written straight into the image rows of the joint gradient
             if getattr(env, "tokenwise", False):          # norm_out's (scale, shift) rows are per image token (flux/transformer.py:1505 takes temb_img)
@@ -1091,6 +1181,7 @@ class FluxTransformer2DModel(nn.Module):
         # TREAD: the backward enters a route at its END block (the routed blocks see only the kept tokens' gradient rows; the skipped tokens' gradient stays in
         # d_full) and leaves it at its START block (the kept rows go back into d_full: the gradient of the full stream at the route's start)
         nd = len(self.double)
+        stop = getattr(self, "_bwd_stop", 0)          # global index of the first block with an adapter (add_lora_adapter)
         dxg = d_txt = d_img = d_full = None
         keep_of = lambda info: info.keep_i32()
         for (s0, n, ck) in reversed(ctx.segs_s):
@@ -1107,6 +1198,8 @@ class FluxTransformer2DModel(nn.Module):
                     dx = torch.cat([dxv[:, :St], ops.gather_rows(d_full, keep_of(ctx.route_end[g]))], dim=1).reshape(-1, D)
                     dxg = None
                 dx, dxg, d_txt, d_img = self._single_bwd(li, ctx.sgl.pop(li), dx, dxg, e)
+                if g == stop and g > 0:
+                    return None
                 if g in ctx.route_start:
                     if dx is None:                               # single block 0 under double blocks: its input gradient came back stream-major
                         ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[g]), d_full)
@@ -1132,6 +1225,8 @@ class FluxTransformer2DModel(nn.Module):
                     d_full = d_img.view(B, Si, D)
                     d_img = ops.gather_rows(d_full, keep_of(ctx.route_end[li])).view(-1, D)
                 d_img, d_txt = self._double_bwd(li, ctx.dbl.pop(li), d_img, d_txt, e)
+                if li == stop and li > 0:
+                    return None
                 if li in ctx.route_start and d_img is not None:
                     ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[li]), d_full)
                     d_img, d_full = d_full.reshape(-1, D), None

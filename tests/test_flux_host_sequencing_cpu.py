@@ -366,3 +366,133 @@ def test_reference_image_tokens_at_t_zero_through_the_emulator_match_the_oracle(
             key, which = name.split(".lora_")
             ref = lp[key][0 if which.startswith("A") else 1].grad
             assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))
+
+
+def _check_adapter_set(model, d, expect_names):
+    names = [n for n, _ in model.named_parameters() if ".lora_" in n]
+    keys = {n.split(".lora_")[0] for n in names}
+    assert keys == set(expect_names), (sorted(keys ^ set(expect_names)))
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    r = PU.rel_l2(out, o_out)
+    assert r < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item()), (r, loss.item(), o_loss.item())
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, which = name.split(".lora_")
+        ref = lp[key][0 if which.startswith("A") else 1].grad
+        assert p.grad is not None and ref.norm().item() > 0, name
+        worst = max(worst, (PU.rel_l2(p.grad, ref), name))
+        assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))
+    return r, worst
+
+
+@pytest.mark.parametrize("which,B,lat_h,lat_w,S_txt,rank", [("all+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 16, 16, 64, 16), ("context+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 8, 8, 40, 80)])
+def test_feed_forward_target_sets_through_the_emulator_match_the_oracle(monkeypatch, which, B, lat_h, lat_w, S_txt, rank):
+    """flux_lora_target = "all+ffs" / "context+ffs" (flux/model.py:1272-1301): adapters on ff.net.0.proj / ff.net.2 / ff_context.net.* of the double blocks and on
+    proj_mlp / proj_out of the single blocks, next to the attention projections of the set.  proj_out reads [attn | mlp] as two K segments: its adapter's T = x A^T and
+    dA = U^T x walk the same two segments; its low-rank term leaves as a gated-residual launch of its own.  Rank 80 walks the rank-space kernels in 64-column slabs."""
+    model = _model(monkeypatch, 2, 2)
+    model.add_lora_adapter(rank=rank, alpha=float(rank), targets=which, init_b_std=0.02)
+    r, worst = _check_adapter_set(model, _inputs(B, lat_h, lat_w, S_txt), OF.lora_targets(PU.oracle_cfg(model), which))
+    print(f"[emu] flux {which} rank {rank} B{B}: pred rel_l2={r:.3e}, worst adapter gradient {worst[1]} rel_l2={worst[0]:.3e}")
+
+
+@pytest.mark.parametrize("which,single", [("nano", 9), ("tiny", 22)])
+def test_single_layer_target_sets_through_the_emulator_match_the_oracle(monkeypatch, which, single):
+    """flux_lora_target = "nano" / "tiny" (flux/model.py:1363-1375): single_transformer_blocks.7(.20).proj_out and nothing else.  The backward stops below single
+    block 7: no block upstream of it runs a backward launch (counted on the emulator's call log)."""
+    model = _model(monkeypatch, 1, single)
+    model.add_lora_adapter(rank=16, alpha=16.0, targets=which, init_b_std=0.02)
+    assert model._bwd_stop == 1 + 7
+    seen = []
+    from simpletuner_amd.flux import transformer as T
+    real_single, real_double = T.FluxTransformer2DModel._single_bwd, T.FluxTransformer2DModel._double_bwd
+    monkeypatch.setattr(T.FluxTransformer2DModel, "_single_bwd", lambda self, li, *a, **k: (seen.append(("s", li)), real_single(self, li, *a, **k))[1])
+    monkeypatch.setattr(T.FluxTransformer2DModel, "_double_bwd", lambda self, li, *a, **k: (seen.append(("d", li)), real_double(self, li, *a, **k))[1])
+    r, worst = _check_adapter_set(model, _inputs(2, 8, 8, 24), OF.lora_targets(PU.oracle_cfg(model), which))
+    assert seen == [("s", li) for li in range(single - 1, 6, -1)], seen
+    print(f"[emu] flux {which}: pred rel_l2={r:.3e}, worst adapter gradient {worst[1]} rel_l2={worst[0]:.3e}; backward ran single blocks {single - 1}..7 only")
+
+
+def test_single_layer_target_sets_refuse_a_model_without_that_block(monkeypatch):
+    model = _model(monkeypatch, 1, 4)
+    with pytest.raises(ValueError, match="single_transformer_blocks.7.proj_out"):
+        model.add_lora_adapter(rank=16, targets="nano")
+
+
+def test_feed_forward_adapters_under_tread_routing_and_recomputation(monkeypatch):
+    """all+ffs with half of the image tokens routed around double block 1 .. single block 1 (across the stack boundary): adapter gradients vs the oracle replaying
+    the permutation; with per-block recomputation the forward and every gradient are bit-identical to the run that kept its activations"""
+    from simpletuner_amd.training.tread import ReplayRouter
+    d = _inputs(2, 16, 16, 32)
+    B, Si = 2, 64
+    perm = torch.stack([torch.randperm(Si, generator=torch.Generator().manual_seed(17 + b)) for b in range(B)])
+    K = Si - int(round(Si * 0.5))
+    rec = {"mask": torch.ones(B, Si, dtype=torch.bool).scatter_(1, perm[:, :K], False), "ids_keep": perm[:, :K], "ids_mask": perm[:, K:], "ids_shuffle": perm,
+           "ids_restore": torch.argsort(perm, dim=1)}
+    routes = [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": 3}]
+
+    def run(with_ckpt):
+        model = _model(monkeypatch, 2, 3)
+        model.add_lora_adapter(rank=8, alpha=8.0, targets="all+ffs", init_b_std=0.02)
+        model.set_router(ReplayRouter([rec]), routes)
+        model.train()
+        if with_ckpt:
+            model.enable_gradient_checkpointing()
+        out, loss = _hip_side(model, d)
+        return model, out, loss, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}
+
+    model, out, loss, grads = run(False)
+    P, lora, scale = PU.oracle_state(model)
+    lp = {k: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for k, (a, b) in lora.items()}
+    f = lambda k: d[k].float()
+    o_out = OF.flux_forward(P, PU.oracle_cfg(model), f("packed"), f("prompt"), f("pooled"), d["t"], d["img_ids"], d["txt_ids"], d["guidance"], lp, scale,
+                            tread={"routes": routes, "mask_infos": [rec]})
+    ((o_out - f("target")) ** 2).mean().backward()
+    assert PU.rel_l2(out, o_out) < 2e-2
+    assert any("ff.net.2" in n for n in grads) and any("proj_out" in n for n in grads)
+    for name, g_ in grads.items():
+        ref = lp[name.split(".lora_")[0]][0 if ".lora_A." in name else 1].grad
+        assert PU.rel_l2(g_, ref) < 5e-2, (name, PU.rel_l2(g_, ref))
+    _, out_c, _, grads_c = run(True)
+    assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+
+
+def test_feed_forward_adapters_with_tokenwise_timesteps(monkeypatch):
+    """all+ffs under per-token timesteps: the feed-forward gates are per-token rows on the image stream and along the single blocks' joint sequence — proj_out's
+    low-rank launch takes the same per-token gate rows as the projection itself"""
+    model = _model(monkeypatch, 1, 2)
+    model.add_lora_adapter(rank=16, alpha=16.0, targets="all+ffs", init_b_std=0.02)
+    d = _inputs(1, 16, 8, 24)
+    d["t"] = torch.rand(1, 32, generator=torch.Generator().manual_seed(8)) * 0.9 + 0.05
+    r, worst = _check_adapter_set(model, d, OF.lora_targets(PU.oracle_cfg(model), "all+ffs"))
+    print(f"[emu] flux all+ffs tokenwise: pred rel_l2={r:.3e}, worst adapter gradient {worst[1]} rel_l2={worst[0]:.3e}")
+
+
+def test_nano_with_recomputation_is_bit_identical_and_recomputes_only_what_it_differentiates(monkeypatch):
+    """'nano' + gradient checkpointing: the segments below single block 7 are never re-run (the backward returns there)"""
+    d = _inputs(1, 8, 8, 24)
+    from simpletuner_amd.flux import transformer as T
+
+    def run(with_ckpt):
+        model = _model(monkeypatch, 1, 9)
+        model.add_lora_adapter(rank=16, alpha=16.0, targets="nano", init_b_std=0.02)
+        model.train()
+        fwd_calls = []
+        if with_ckpt:
+            model.enable_gradient_checkpointing()
+            real = T.FluxTransformer2DModel._single_fwd
+            monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", lambda self, bi, x, env, save: (fwd_calls.append((bi, save)), real(self, bi, x, env, save))[1])
+        out, _ = _hip_side(model, d)
+        if with_ckpt:
+            monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", real)
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}, fwd_calls
+
+    out, grads, _ = run(False)
+    out_c, grads_c, calls = run(True)
+    assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+    recomputed = [bi for (bi, save) in calls[9:]]            # the first 9 calls are the forward itself
+    assert recomputed == [8, 7], calls                        # per-block segments: blocks 6 .. 0 are never re-run

@@ -116,6 +116,33 @@ def test_flux_oracle_reproduces_reference_model_with_tokenwise_timesteps():
     print(f"[pinned] flux tokenwise: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
 
 
+@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "nano", "tiny"])
+def test_flux_oracle_lora_target_sets_reproduce_the_reference_model_with_merged_adapters(which):
+    """`flux_lora_target` sets (flux/model.py:1235-1380) in oracle.flux — adapters as separate factors on `lora_targets(cfg, which)` — against the reference's
+    FluxTransformer2DModel executed with the MERGED weights W' = W + (alpha / r) B A on the modules peft's suffix rule selects from the reference's OWN lists
+    (tools/gen_ref_flux_lora_sets.py reads them with `ast`): the same module set (note "proj_out" in all+ffs also names the model's output projection), the same
+    output and input gradients, and the adapter gradients dL/dW' implies"""
+    G = _load("ref_flux_lora_sets.pt")[which]
+    cfg = _flux_cfg(G["config"])
+    shapes = OF.param_shapes(cfg)
+    P = _state(shapes, G["seed"], G["state_checksum"])
+    assert sorted(OF.lora_targets(cfg, which)) == sorted(G["lora_targets"])
+    lora = {k: (a.requires_grad_(True), b.requires_grad_(True)) for k, (a, b) in seeded_lora(G["lora_targets"], shapes, G["lora_rank"], G["lora_seed"]).items()}
+    out, leaves = _flux_run(P, cfg, G["inputs"], lora=lora, lora_scale=G["lora_alpha"] / G["lora_rank"])
+    r = rel_l2(out, G["out"])
+    assert r <= TOL, f"flux {which}: output rel-L2 {r:.3e}"
+    (out * G["w"]).sum().backward()
+    for k, g in G["input_grads"].items():
+        if k in leaves:
+            assert rel_l2(leaves[k].grad, g) <= TOL, (which, k)
+    worst = (0.0, "")
+    for k, (dA, dB) in G["lora_grads"].items():
+        ra, rb = rel_l2(lora[k][0].grad, dA), rel_l2(lora[k][1].grad, dB)
+        worst = max(worst, (ra, k + ".A"), (rb, k + ".B"))
+        assert ra <= 5 * TOL and rb <= 5 * TOL, (which, k, ra, rb)
+    print(f"[pinned] flux lora target set {which}: {len(G['lora_targets'])} wrapped modules, out rel-L2 {r:.2e}, worst adapter gradient {worst[0]:.2e} ({worst[1]})")
+
+
 def test_flux_oracle_reproduces_reference_model_at_kernel_head_width():
     """the "hip" tier (2 heads x 128, LoRA r4): weights rebuilt from the seed, LoRA applied as an adapter in the oracle; the reference ran the MERGED weight"""
     G = _load("ref_flux_model.pt")["hip"]

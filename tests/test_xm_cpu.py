@@ -154,7 +154,8 @@ def test_flux_guidance_scales_modes_and_xm_replication():
 
 
 def test_flux_lora_target_sets_are_exact_or_refused():
-    """flux/model.py:1235-1380: 'all', 'context' and the fall-through default are built; every other named set is refused instead of being narrowed silently"""
+    """flux/model.py:1235-1380: 'all', 'context', the '+ffs' sets, 'tiny' / 'nano' and the fall-through default are built; every other named set is refused
+    instead of being narrowed silently"""
     from simpletuner_amd.flux.model import Flux
     m = Flux.__new__(Flux)
     m.config = SimpleNamespace(flux_lora_target="all")
@@ -164,7 +165,16 @@ def test_flux_lora_target_sets_are_exact_or_refused():
         assert m._lora_target_set() == "default" and m.get_lora_target_layers() == ["to_k", "to_q", "to_v", "to_out.0"]
     m.config = SimpleNamespace(flux_lora_target="context")                       # flux/model.py:1263-1271 (built in round 4)
     assert m._lora_target_set() == "context" and m.get_lora_target_layers() == ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out"]
-    for v in ("context+ffs", "all+ffs", "ai-toolkit", "tiny", "nano", "controlnet", "all+ffs+embedder"):
+    # the feed-forward sets and TheLastBen's single-layer sets (flux/model.py:1272-1301, 1363-1375): built, with the reference's own layer lists
+    want = {"context+ffs": ["add_k_proj", "add_q_proj", "add_v_proj", "add_qkv_proj", "to_add_out", "ff_context.net.0.proj", "ff_context.net.2"],
+            "all+ffs": ["to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "add_k_proj", "add_q_proj", "add_v_proj", "to_out.0", "to_add_out",
+                        "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "proj_mlp", "proj_out"],
+            "tiny": ["single_transformer_blocks.7.proj_out", "single_transformer_blocks.20.proj_out"],
+            "nano": ["single_transformer_blocks.7.proj_out"]}
+    for v, layers in want.items():
+        m.config = SimpleNamespace(flux_lora_target=v)
+        assert m._lora_target_set() == v and m.get_lora_target_layers() == layers
+    for v in ("ai-toolkit", "controlnet", "all+ffs+embedder"):                      # AdaLN-modulation / embedder / ControlNet adapters: not built, refused
         m.config = SimpleNamespace(flux_lora_target=v)
         with pytest.raises(NotImplementedError, match="flux_lora_target"):
             m._lora_target_set()
