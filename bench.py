@@ -108,6 +108,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=19)
     ap.add_argument("--single-layers", type=int, default=38)
     ap.add_argument("--rank", type=int, default=32)
+    ap.add_argument("--lora-target", default="default", choices=["default", "all", "context", "all+ffs", "context+ffs", "tiny", "nano"],
+                    help="flux only: the reference's flux_lora_target set (flux/model.py:1235-1380); 'default' = attn to_q/to_k/to_v/to_out.0, what BASELINE.json's config names")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run checkpointed blocks in backward instead of keeping their activations "
                     "(SURVEY.md §8(f)3); with --ckpt-interval K [--ckpt-stride S] the reference's segmented modes (interval2 = K 2; seg2-stride4 = K 2 S 4)")
@@ -531,6 +533,7 @@ def run_workload(args, dev, rank, world):
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
     cfg = default_config(model_family=args.model, lora_rank=args.rank, train_batch_size=args.batch, seed=42, lora_init_b_std=1e-3,   # weights / adapter init / rounding seeds are REPLICA-identical; the data RNG below is per rank
+                         flux_lora_target=getattr(args, "lora_target", "default"),
                         
                          model_type="full" if args.full else "lora", use_ema=bool(args.full) and args.model != "flux", optimizer=args.optimizer,
                          learning_rate=1e-5 if args.full else 1e-4, hip_graph=bool(args.graph),
@@ -542,8 +545,9 @@ def run_workload(args, dev, rank, world):
         plugin = Flux(cfg, acc)
         plugin.load_model(num_layers=args.layers, num_single_layers=args.single_layers, guidance_embeds=True)
         n_blocks, D_model, S_txt, txt_dim, pooled_dim = args.layers + args.single_layers, 3072, 512, 4096, 768
+        tset = getattr(args, "lora_target", "default")
         desc = (f"Flux.1-dev MMDiT ({args.layers} double + {args.single_layers} single, D=3072, 24x128 heads) LoRA r{args.rank} "
-                f"on attn to_q/to_k/to_v/to_out.0, {args.res}^2 (S=4096+512), AdamW, random-init weights")
+                f"on {'attn to_q/to_k/to_v/to_out.0' if tset == 'default' else 'flux_lora_target=' + tset}, {args.res}^2 (S=4096+512), AdamW, random-init weights")
     elif args.model == "sdxl":
         # BASELINE.json configs[1]: SDXL UNet full fine-tune bf16, 1024^2 bucket, batch 4; --lora = the metric's SDXL-LoRA (adapters on attn1/attn2)
         from simpletuner_amd.sdxl.model import SDXL
