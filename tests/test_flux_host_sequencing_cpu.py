@@ -496,3 +496,23 @@ def test_nano_with_recomputation_is_bit_identical_and_recomputes_only_what_it_di
     assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
     recomputed = [bi for (bi, save) in calls[9:]]            # the first 9 calls are the forward itself
     assert recomputed == [8, 7], calls                        # per-block segments: blocks 6 .. 0 are never re-run
+
+
+@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "nano", "tiny"])
+def test_adapter_names_are_the_modules_peft_wraps_in_the_executed_reference(monkeypatch, which):
+    """the product's adapter parameters (and so the keys of the saved LoRA file) against tests/golden/ref_flux_lora_sets.pt: the module names peft's target_modules
+    rule selected on the reference's FluxTransformer2DModel from the reference's own `flux_lora_target` list, for a model of the same depth"""
+    import os
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_flux_lora_sets.pt"), weights_only=False)[which]
+    model = _model(monkeypatch, G["config"]["num_layers"], G["config"]["num_single_layers"])
+    model.add_lora_adapter(rank=4, alpha=8.0, targets=which)
+    names = [n for n, _ in model.named_parameters() if ".lora_" in n]
+    assert {n.split(".lora_")[0] for n in names} == set(G["lora_targets"])
+    assert len(names) == 2 * len(G["lora_targets"]) and all(n.endswith((".lora_A.default.weight", ".lora_B.default.weight")) for n in names)
+    shapes = {n: tuple(p.shape) for n, p in model.named_parameters()}
+    for t in G["lora_targets"]:          # peft shapes: A [r, in_features], B [out_features, r]
+        w = model.get_parameter(t + ".weight") if t + ".weight" in shapes else None
+        a, b = shapes[t + ".lora_A.default.weight"], shapes[t + ".lora_B.default.weight"]
+        assert a[0] == 4 and b[1] == 4
+        if w is not None:
+            assert (b[0], a[1]) == tuple(w.shape), (t, a, b, tuple(w.shape))
