@@ -119,8 +119,10 @@ def lora_targets(cfg: FluxConfig, which: str = "default"):
     if which in ("tiny", "nano"):
         blocks = (7, 20) if which == "tiny" else (7,)
         return [f"single_transformer_blocks.{i}.proj_out" for i in blocks if i < cfg.num_single_layers]
+    emb = which.endswith("+embedder")          # all+ffs+embedder (flux/model.py:1320-1339): all+ffs + x_embedder
+    which = which[:-len("+embedder")] if emb else which
     base, ffs = (which[:-4], True) if which.endswith("+ffs") else (which, False)
-    t = []
+    t = ["x_embedder"] if emb else []
     for i in range(cfg.num_layers):
         b = f"transformer_blocks.{i}."
         p = b + "attn."
@@ -361,7 +363,7 @@ def flux_forward(P, cfg: FluxConfig, hidden_states, encoder_hidden_states, poole
         run = lambda fn, *a: _ck.checkpoint(fn, *a, use_reentrant=False)
     else:
         run = lambda fn, *a: fn(*a)
-    hidden = linear(hidden_states, P, "x_embedder")
+    hidden = linear(hidden_states, P, "x_embedder", lora, lora_scale)
     t = timestep.float() * 1000
     g = guidance.float() * 1000 if (guidance is not None and cfg.guidance_embeds) else None
     enc = linear(encoder_hidden_states, P, "context_embedder")

@@ -325,9 +325,12 @@ class FluxTransformer2DModel(nn.Module):
             for (name, n_off, N) in g.targets:
                 plan.append((g, name, N, K))
 
-        sets = ("default", "all", "context", "all+ffs", "context+ffs", "tiny", "nano")
+        sets = ("default", "all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "tiny", "nano")
         if targets not in sets:
             raise ValueError(f"add_lora_adapter: unknown target set {targets!r} (built: {', '.join(repr(t) for t in sets)})")
+        if targets == "all+ffs+embedder":          # flux/model.py:1320-1339: all+ffs + x_embedder (the packed-latent input projection, K = in_channels)
+            group(self.l_x, "", ["x_embedder"], self.l_x.w.shape[1])
+            targets = "all+ffs"
         base, ffs = (targets[:-4], True) if targets.endswith("+ffs") else (targets, False)
         if base == "context" and not self.double:
             raise ValueError(f"add_lora_adapter: the {targets!r} target set names the double blocks' context-stream layers; this model has no double block")
@@ -779,7 +782,7 @@ class FluxTransformer2DModel(nn.Module):
         # ---- embeddings (flux/transformer.py:1001-1064) ----
         em = SimpleNamespace()        # the embedders' intermediates (kept for their weight gradients under full-rank training)
         em.x2d, em.enc2d = hidden_states.reshape(B * Si, -1).contiguous(), encoder_hidden_states.reshape(B * St, -1).contiguous()
-        img = ops.gemm(em.x2d, self.l_x.w, bias=self.l_x.b)
+        img, T_x = self._lin_fwd(self.l_x, em.x2d)          # ('all+ffs+embedder' wraps x_embedder)
         txt = ops.gemm(em.enc2d, self.l_ctx.w, bias=self.l_ctx.b)
         tokenwise = timestep.dim() == 2
         if tokenwise and tuple(timestep.shape) != (B, Si):
@@ -942,6 +945,8 @@ class FluxTransformer2DModel(nn.Module):
                 ctx.n_out, ctx.emb = n_out, em
             elif self.l_out.lora is not None:
                 ctx.n_out, ctx.T_out = n_out, T_out
+            if self.l_x.lora is not None:
+                ctx.x2d, ctx.T_x = em.x2d, T_x
         return out.view(B, Si, -1), ctx
 
     def _attn_backward(self, sv, dO, dqkv, env):
@@ -1128,7 +1133,7 @@ class FluxTransformer2DModel(nn.Module):
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_added_q, blk.norm_added_k), (blk.norm_q, blk.norm_k), St)
         del dO
-        last = li == 0
+        last = li == 0 and self.l_x.lora is None          # (an adapter on x_embedder needs the image stream's input gradient of block 0)
         # the two streams' rows of the joint dqkv, in place (the reference's autograd splits the concatenated gradient the same way)
         dq_i, dq_t = self._rows_of(dqkv, St, Si, env), self._rows_of(dqkv, 0, St, env)
         streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img, Si), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt, St)]
@@ -1230,6 +1235,12 @@ class FluxTransformer2DModel(nn.Module):
                 if li in ctx.route_start and d_img is not None:
                     ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[li]), d_full)
                     d_img, d_full = d_full.reshape(-1, D), None
+        lx = self.l_x.lora
+        if lx is not None:          # 'all+ffs+embedder': dy of x_embedder = the image stream's gradient at block 0's input; its own input (the packed latents) needs none
+            if d_img is None:       # no double block: the image rows of the joint gradient at single block 0's input
+                d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
+            U_x = ops.gemm(d_img, lx.B_blk_T)
+            lx.grads(ctx.x2d, ctx.T_x, d_img, U_x, self.accumulate_lora_grads, self.grad_sync)
         return None
 
     # ------------------------------------------------------------------------------------------------

@@ -389,7 +389,8 @@ def _check_adapter_set(model, d, expect_names):
     return r, worst
 
 
-@pytest.mark.parametrize("which,B,lat_h,lat_w,S_txt,rank", [("all+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 16, 16, 64, 16), ("context+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 8, 8, 40, 80)])
+@pytest.mark.parametrize("which,B,lat_h,lat_w,S_txt,rank", [("all+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 16, 16, 64, 16), ("context+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 8, 8, 40, 80),
+                                                           ("all+ffs+embedder", 2, 16, 8, 24, 16)])
 def test_feed_forward_target_sets_through_the_emulator_match_the_oracle(monkeypatch, which, B, lat_h, lat_w, S_txt, rank):
     """flux_lora_target = "all+ffs" / "context+ffs" (flux/model.py:1272-1301): adapters on ff.net.0.proj / ff.net.2 / ff_context.net.* of the double blocks and on
     proj_mlp / proj_out of the single blocks, next to the attention projections of the set.  proj_out reads [attn | mlp] as two K segments: its adapter's T = x A^T and
@@ -498,7 +499,7 @@ def test_nano_with_recomputation_is_bit_identical_and_recomputes_only_what_it_di
     assert recomputed == [8, 7], calls                        # per-block segments: blocks 6 .. 0 are never re-run
 
 
-@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "nano", "tiny"])
+@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "nano", "tiny"])
 def test_adapter_names_are_the_modules_peft_wraps_in_the_executed_reference(monkeypatch, which):
     """the product's adapter parameters (and so the keys of the saved LoRA file) against tests/golden/ref_flux_lora_sets.pt: the module names peft's target_modules
     rule selected on the reference's FluxTransformer2DModel from the reference's own `flux_lora_target` list, for a model of the same depth"""
@@ -516,3 +517,11 @@ def test_adapter_names_are_the_modules_peft_wraps_in_the_executed_reference(monk
         assert a[0] == 4 and b[1] == 4
         if w is not None:
             assert (b[0], a[1]) == tuple(w.shape), (t, a, b, tuple(w.shape))
+
+
+def test_embedder_adapter_on_a_model_without_double_blocks(monkeypatch):
+    """all+ffs+embedder with single blocks only: x_embedder's dy is the image rows of the joint gradient at single block 0's input"""
+    model = _model(monkeypatch, 0, 2)
+    model.add_lora_adapter(rank=16, alpha=16.0, targets="all+ffs+embedder", init_b_std=0.02)
+    r, worst = _check_adapter_set(model, _inputs(2, 16, 8, 24), OF.lora_targets(PU.oracle_cfg(model), "all+ffs+embedder"))
+    print(f"[emu] flux all+ffs+embedder, single blocks only: pred rel_l2={r:.3e}, worst adapter gradient {worst[1]} rel_l2={worst[0]:.3e}")
