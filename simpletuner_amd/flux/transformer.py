@@ -885,15 +885,18 @@ class FluxTransformer2DModel(nn.Module):
             return rt.info is not None and g == routes[rt.ptr]["end_layer_idx"]
 
         x = None
+        # nothing below the first block that carries an adapter is differentiated (add_lora_adapter: 'tiny' / 'nano' start at single block 7): those blocks keep
+        # no activations and no checkpoint inputs
+        stop = 0 if full else getattr(self, "_bwd_stop", 0)
         # ---- double blocks ----
         for (s0, n, ck) in segs_d:
             for bi in range(s0, s0 + n):
                 if starts(bi):
                     img = start_route(img, bi)
-                if ck and bi == s0:
+                if ck and bi == s0 and save and s0 + n - 1 >= stop:
                     ctx.ck_d[s0] = (img, txt)                 # a checkpointed segment keeps only its input; its blocks are re-run in backward
                 ctx.env_d[bi] = rt.env
-                img, txt, x, sv = self._double_fwd(bi, img, txt, rt.env, save and not ck)
+                img, txt, x, sv = self._double_fwd(bi, img, txt, rt.env, save and not ck and bi >= stop)
                 if sv is not None:
                     ctx.dbl[bi] = sv
                 if ends(bi):
@@ -916,10 +919,10 @@ class FluxTransformer2DModel(nn.Module):
                     xv = x.view(B, S, D)
                     t_part = xv[:, :St]
                     x = torch.cat([t_part, start_route(xv[:, St:].contiguous().view(-1, D), g).view(B, -1, D)], dim=1).reshape(-1, D)
-                if ck and bi == s0:
+                if ck and bi == s0 and save and nd + s0 + n - 1 >= stop:
                     ctx.ck_s[s0] = x
                 ctx.env_s[bi] = rt.env
-                x, sv = self._single_fwd(bi, x, rt.env, save and not ck)
+                x, sv = self._single_fwd(bi, x, rt.env, save and not ck and g >= stop)
                 if sv is not None:
                     ctx.sgl[bi] = sv
                 if ends(g):

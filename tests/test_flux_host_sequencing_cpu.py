@@ -482,19 +482,23 @@ def test_nano_with_recomputation_is_bit_identical_and_recomputes_only_what_it_di
         model = _model(monkeypatch, 1, 9)
         model.add_lora_adapter(rank=16, alpha=16.0, targets="nano", init_b_std=0.02)
         model.train()
-        fwd_calls = []
+        fwd_calls, dbl_saves = [], []
         if with_ckpt:
             model.enable_gradient_checkpointing()
-            real = T.FluxTransformer2DModel._single_fwd
-            monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", lambda self, bi, x, env, save: (fwd_calls.append((bi, save)), real(self, bi, x, env, save))[1])
+        real, real_d = T.FluxTransformer2DModel._single_fwd, T.FluxTransformer2DModel._double_fwd
+        monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", lambda self, bi, x, env, save: (fwd_calls.append((bi, save)), real(self, bi, x, env, save))[1])
+        monkeypatch.setattr(T.FluxTransformer2DModel, "_double_fwd", lambda self, bi, i_, t_, env, save: (dbl_saves.append(save), real_d(self, bi, i_, t_, env, save))[1])
         out, _ = _hip_side(model, d)
-        if with_ckpt:
-            monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", real)
-        return out, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}, fwd_calls
+        monkeypatch.setattr(T.FluxTransformer2DModel, "_single_fwd", real)
+        monkeypatch.setattr(T.FluxTransformer2DModel, "_double_fwd", real_d)
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}, fwd_calls, dbl_saves
 
-    out, grads, _ = run(False)
-    out_c, grads_c, calls = run(True)
+    out, grads, calls_direct, dbl_direct = run(False)
+    # without recomputation: only single blocks 7 and 8 keep their activations; the double block and single blocks 0 .. 6 run as in inference
+    assert calls_direct == [(bi, bi >= 7) for bi in range(9)] and dbl_direct == [False], (calls_direct, dbl_direct)
+    out_c, grads_c, calls, _ = run(True)
     assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+    assert all(not save for (_, save) in calls[:9])
     recomputed = [bi for (bi, save) in calls[9:]]            # the first 9 calls are the forward itself
     assert recomputed == [8, 7], calls                        # per-block segments: blocks 6 .. 0 are never re-run
 
