@@ -94,10 +94,11 @@ def sample_and_scale(moments: torch.Tensor, cfg: VAEConfig, eps: Optional[torch.
 from tools.flop_count import vae_encoder_flops as encoder_flops  # noqa: E402,F401
 
 
-# ---- decoder (validation images) — restated for the product decoder the next round builds on the same conv / GroupNorm /
-# upsample kernels.  diffusers' Decoder: conv_in (latent -> C_last) -> UNetMidBlock2D -> UpDecoderBlock2D x4 over the REVERSED channel list
+# ---- decoder (validation images; the product decoder runs on the same conv / GroupNorm /
+# upsample kernels).  diffusers' Decoder: conv_in (latent -> C_last) -> UNetMidBlock2D -> UpDecoderBlock2D x4 over the REVERSED channel list
 # (layers_per_block + 1 resnets each, nearest-2x Upsample2D + conv3x3 on all but the last) -> GroupNorm -> SiLU -> conv_out (C_0 -> 3);
-# AutoencoderKL.decode applies post_quant_conv (1x1 on the latents) first when the VAE has one.  PARITY UNPINNED, like the encoder; the
+# AutoencoderKL.decode applies post_quant_conv (1x1 on the latents) first when the VAE has one.  PINNED like the encoder (the vendored Decoder,
+# simpletuner/helpers/models/ideogram/autoencoder.py:189-273, executed through its converter: tests/test_ref_models_cpu.py); the
 # parameter totals of init_params (encoder + decoder + quant convs) equal the published SD / SDXL VAE size, 83,653,863.
 def unscale_latents(z: torch.Tensor, cfg: VAEConfig) -> torch.Tensor:
     """inverse of scale_vae_latents_for_cache: what the pipelines do before vae.decode (z / scaling_factor + shift_factor)"""
