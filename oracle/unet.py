@@ -12,7 +12,11 @@ CrossAttnDown blocks of ResnetBlock2D (GroupNorm32 eps 1e-5 -> SiLU -> conv3x3 -
 self-attention -> LayerNorm -> cross-attention over the text tokens -> LayerNorm -> GEGLU feed-forward, all residual -> proj_out -> + input);
 Downsample2D (conv3x3 stride 2 pad 1); mid block; Up blocks (concat skip, resnets, nearest-2x Upsample2D + conv3x3); conv_norm_out -> SiLU ->
 conv_out.  State-dict keys and tensor shapes are diffusers' (conv weights [O,I,kh,kw]).
-PARITY: LEAVES PINNED, WALK RESTATED.  The reference holds no golden tensor for this network and diffusers is not installable here, but
+PARITY: LEAVES PINNED, DOWN HALF OF THE WALK PINNED, BLOCK INTERIORS AND THE UP PATH RESTATED.  The reference holds no golden tensor for this network
+ and diffusers is not installable here, but (a) `unet_down_mid` — the embeddings incl. SDXL's "text_time" embedder, conv_in, the order of the skip
+tensors, the mid block, the head-count meaning of `attention_head_dim` — is checked against diffusers' ControlNetModel, which the reference VENDORS
+(helpers/models/kolors/controlnet.py:132-931: the same constructor wiring and forward up to the mid block), executed in the build container over block stand-ins made
+of this file's leaves (tools/gen_ref_unet_walk.py -> tests/golden/ref_unet_walk.pt, tests/test_ref_unet_walk_cpu.py: bit-identical outputs and gradients), and (b)
 the leaves below are checked against reference code executed in the build container (tools/gen_ref_unet_leaves.py -> tests/golden/ref_unet_leaves.pt,
 tests/test_ref_unet_leaves_cpu.py, forward and every gradient <= 1e-5):
   * `resnet` (norm -> SiLU -> conv3x3 -> norm -> SiLU -> conv3x3, GroupNorm(32), 1x1 conv_shortcut), `upsample` (nearest 2x + conv3x3), the stride-2 3x3
@@ -21,8 +25,8 @@ tests/test_ref_unet_leaves_cpu.py, forward and every gradient <= 1e-5):
   * `timestep_proj` + the Linear -> SiLU -> Linear embedder against Timesteps / TimestepEmbedding lifted from helpers/models/heartmula/codec/transformer.py.
 What stays RESTATED (from the published diffusers modules; the reference carries no copy): the `+ time_emb_proj(SiLU(emb))` add inside `resnet` (one line),
 the symmetric padding-1 of Downsample2D, `basic_block` / GEGLU / multi-head cross-attention (cross-checked only against tools/ref_shim.py's independent
-restatement of the same public definition), the GroupNorm(1e-6) -> proj_in -> blocks -> proj_out wiring of `transformer2d`, and the block-to-block walk of
-`unet_forward` (down / mid / reversed up path with skip concatenation, the "text_time" addition embedding).
+restatement of the same public definition), the GroupNorm(1e-6) -> proj_in -> blocks -> proj_out wiring of `transformer2d`, the order resnet -> attention ->
+(downsampler) inside a block, and the second half of `unet_forward` (the reversed up path with skip concatenation, conv_norm_out, conv_out).
 """
 from __future__ import annotations
 
@@ -137,8 +141,14 @@ def transformer2d(P, p, x, ctx, heads, n_layers, groups, linear_proj):
     return h + res
 
 
-def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None):
-    """UNet2DConditionModel.forward -> [B, out_channels, H, W]"""
+def unet_down_mid(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None, cond_residual=None):
+    """The first half of UNet2DConditionModel.forward: embeddings -> conv_in -> down blocks (every resnet / attention / downsampler output is a skip) -> mid
+    block.  Returns (skips, mid, emb).  PINNED: this is also the whole of diffusers' ControlNetModel.forward up to its 1x1 output convolutions, and the reference
+    vendors that class (simpletuner/helpers/models/kolors/controlnet.py:132-931: its constructor wiring — time_embed_dim = 4 * block_out_channels[0], the
+    "text_time" embedder over projection_class_embeddings_input_dim, `num_attention_heads or attention_head_dim` as the HEAD COUNT — and its forward:
+    time_ids.flatten() -> add_time_proj -> reshape(B, -1) -> cat([text_embeds, time_embeds]) -> add_embedding, emb = time + aug, conv_in (+ the conditioning
+    embedding: `cond_residual`), the down-block loop collecting (sample,) + res_samples, the mid block).  tools/gen_ref_unet_walk.py executes it over block
+    stand-ins built from this file's leaves; tests/test_ref_unet_walk_cpu.py holds this function to its outputs and gradients <= 1e-5."""
     g, eps = cfg.norm_num_groups, cfg.norm_eps
     dt = sample.dtype
     c0 = cfg.block_out_channels[0]
@@ -151,6 +161,8 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
         emb = emb + time_embedding(P, "add_embedding", add)
     ctx = encoder_hidden_states.to(dt)
     x = _conv(sample, P, "conv_in")
+    if cond_residual is not None:
+        x = x + cond_residual
     skips = [x]
     nb = len(cfg.block_out_channels)
     for i, typ in enumerate(cfg.down_block_types):
@@ -166,6 +178,16 @@ def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps,
     x = resnet(P, "mid_block.resnets.0.", x, emb, g, eps)
     x = transformer2d(P, "mid_block.attentions.0.", x, ctx, cfg.attention_head_dim[-1], cfg.transformer_layers_per_block[-1], g, cfg.use_linear_projection)
     x = resnet(P, "mid_block.resnets.1.", x, emb, g, eps)
+    return skips, x, emb
+
+
+def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, sample, timesteps, encoder_hidden_states, added_cond_kwargs=None):
+    """UNet2DConditionModel.forward -> [B, out_channels, H, W]"""
+    g, eps = cfg.norm_num_groups, cfg.norm_eps
+    skips, x, emb = unet_down_mid(P, cfg, sample, timesteps, encoder_hidden_states, added_cond_kwargs)
+    skips = list(skips)
+    ctx = encoder_hidden_states.to(sample.dtype)
+    nb = len(cfg.block_out_channels)
     for i, typ in enumerate(cfg.up_block_types):
         ri = nb - 1 - i                                   # the up path walks the channel list in reverse
         for j in range(cfg.layers_per_block + 1):
