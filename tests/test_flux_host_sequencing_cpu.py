@@ -529,3 +529,33 @@ def test_embedder_adapter_on_a_model_without_double_blocks(monkeypatch):
     model.add_lora_adapter(rank=16, alpha=16.0, targets="all+ffs+embedder", init_b_std=0.02)
     r, worst = _check_adapter_set(model, _inputs(2, 16, 8, 24), OF.lora_targets(PU.oracle_cfg(model), "all+ffs+embedder"))
     print(f"[emu] flux all+ffs+embedder, single blocks only: pred rel_l2={r:.3e}, worst adapter gradient {worst[1]} rel_l2={worst[0]:.3e}")
+
+
+@pytest.mark.parametrize("fmt", ["diffusers", "comfyui"])
+def test_lora_file_round_trip_with_the_widest_adapter_set(monkeypatch, tmp_path, fmt):
+    """save_lora_weights / load_lora_weights through the Flux plugin with flux_lora_target = "all+ffs+embedder": every wrapped module lands in the file under its peft name
+    (`transformer.<module>.lora_A.weight` / `.lora_B.weight`; "comfyui" adds one `.alpha` per module) and comes back into a freshly initialised adapter bit for bit"""
+    from types import SimpleNamespace
+
+    from safetensors.torch import load_file
+
+    from simpletuner_amd.flux.model import Flux
+    model = _model(monkeypatch, 1, 2)
+    model.add_lora_adapter(rank=4, alpha=8.0, targets="all+ffs+embedder", init_b_std=0.05)
+    plug = Flux(SimpleNamespace(lora_format=fmt, lora_alpha=8.0, lora_rank=4, flux_lora_target="all+ffs+embedder", model_type="lora"), SimpleNamespace(device=torch.device("cpu")))
+    plug.model = model
+    path = plug.save_lora_weights(str(tmp_path))
+    flat = load_file(path)
+    want_modules = set(OF.lora_targets(PU.oracle_cfg(model), "all+ffs+embedder"))
+    got_modules = {k[len("transformer."):].rsplit(".lora_", 1)[0] for k in flat if ".lora_" in k}
+    assert got_modules == want_modules and all(k.startswith("transformer.") for k in flat)
+    assert len([k for k in flat if k.endswith(".alpha")]) == (len(want_modules) if fmt == "comfyui" else 0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if ".lora_" in n}
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".lora_" in n:
+                p.zero_()
+    plug.load_lora_weights(input_dir=str(tmp_path))
+    for n, p in model.named_parameters():
+        if ".lora_" in n:
+            assert torch.equal(p, before[n]), n
