@@ -108,7 +108,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=19)
     ap.add_argument("--single-layers", type=int, default=38)
     ap.add_argument("--rank", type=int, default=32)
-    ap.add_argument("--lora-target", default="default", choices=["default", "all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "tiny", "nano"],
+    ap.add_argument("--lora-target", default="default", choices=["default", "all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "ai-toolkit", "tiny", "nano"],
                     help="flux only: the reference's flux_lora_target set (flux/model.py:1235-1380); 'default' = attn to_q/to_k/to_v/to_out.0, what BASELINE.json's config names")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--gradient-checkpointing", action="store_true", help="re-run checkpointed blocks in backward instead of keeping their activations "

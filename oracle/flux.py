@@ -121,6 +121,10 @@ def lora_targets(cfg: FluxConfig, which: str = "default"):
         return [f"single_transformer_blocks.{i}.proj_out" for i in blocks if i < cfg.num_single_layers]
     emb = which.endswith("+embedder")          # all+ffs+embedder (flux/model.py:1320-1339): all+ffs + x_embedder
     which = which[:-len("+embedder")] if emb else which
+    if which == "ai-toolkit":                  # flux/model.py:1340-1362: all+ffs + the AdaLN modulation Linears of every block
+        mods = [f"transformer_blocks.{i}.{n}" for i in range(cfg.num_layers) for n in ("norm1.linear", "norm1_context.linear")] + \
+               [f"single_transformer_blocks.{i}.norm.linear" for i in range(cfg.num_single_layers)]
+        return mods + lora_targets(cfg, "all+ffs")
     base, ffs = (which[:-4], True) if which.endswith("+ffs") else (which, False)
     t = ["x_embedder"] if emb else []
     for i in range(cfg.num_layers):
@@ -294,9 +298,9 @@ def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1
     shift / scale / gate rows are then per token) with temb_txt [B, D] = its mean over the tokens for the text stream."""
     p = f"transformer_blocks.{i}."
     H = cfg.num_attention_heads
-    m = linear(F.silu(temb), P, p + "norm1.linear")
+    m = linear(F.silu(temb), P, p + "norm1.linear", lora, lora_scale)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (_rows(t) for t in m.chunk(6, dim=-1))
-    c = linear(F.silu(temb if temb_txt is None else temb_txt), P, p + "norm1_context.linear")
+    c = linear(F.silu(temb if temb_txt is None else temb_txt), P, p + "norm1_context.linear", lora, lora_scale)
     c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = c.chunk(6, dim=1)
     n = layer_norm(hidden) * (1 + scale_msa) + shift_msa
     cn = layer_norm(enc) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
@@ -333,7 +337,7 @@ def double_block(P, cfg, i, hidden, enc, temb, cos, sin, lora=None, lora_scale=1
 def single_block(P, cfg, i, x, temb, cos, sin, lora=None, lora_scale=1.0, key_bias=None):
     p = f"single_transformer_blocks.{i}."
     H = cfg.num_attention_heads
-    m = linear(F.silu(temb), P, p + "norm.linear")          # temb [B, D], or tokenwise [B, S_txt + S_img, D] (`temb_single`, :1075-1083)
+    m = linear(F.silu(temb), P, p + "norm.linear", lora, lora_scale)          # temb [B, D], or tokenwise [B, S_txt + S_img, D] (`temb_single`, :1075-1083)
     shift, scale, gate = (_rows(t) for t in m.chunk(3, dim=-1))
     n = layer_norm(x) * (1 + scale) + shift
     a = p + "attn."

@@ -105,10 +105,10 @@ class Flux(ModelFoundation):
     # flux/model.py:1235-1380: `flux_lora_target` names a set of wrapped Linears.  Built here: the attention projections — "all" (image + context
     # stream: to_q/k/v, add_q/k/v_proj, to_out.0, to_add_out; the reference's default), "context", the fall-through DEFAULT_LORA_TARGET (image stream and single
     # blocks only: what BASELINE.json's config names) — the feed-forward sets "all+ffs" / "context+ffs" (ff.net.*, ff_context.net.*, proj_mlp, proj_out) and
-    # "all+ffs+embedder" (+ x_embedder), "tiny" / "nano" (single_transformer_blocks.7(.20).proj_out).  Sets that wrap AdaLN-modulation / ControlNet layers need adapter backward paths
-    # that are not built (the modulation rows have no backward under a frozen base): refused, never silently narrowed.
-    _UNBUILT_LORA_TARGETS = ("ai-toolkit", "controlnet")
-    _BUILT_LORA_TARGETS = ("all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "tiny", "nano")
+    # "all+ffs+embedder" (+ x_embedder), "ai-toolkit" (+ the AdaLN modulation Linears), "tiny" / "nano" (single_transformer_blocks.7(.20).proj_out).  "controlnet" wraps the
+    # layers of a Flux ControlNet, a model this path does not build: refused, never silently narrowed.
+    _UNBUILT_LORA_TARGETS = ("controlnet",)
+    _BUILT_LORA_TARGETS = ("all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "ai-toolkit", "tiny", "nano")
 
     def _lora_target_set(self) -> str:
         want = str(getattr(self.config, "flux_lora_target", "default") or "default")
@@ -132,6 +132,9 @@ class Flux(ModelFoundation):
         if which == "all+ffs+embedder":              # flux/model.py:1320-1339
             return ["x_embedder", "to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "to_out.0", "add_k_proj", "add_q_proj", "add_v_proj", "to_add_out",
                     "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "proj_mlp", "proj_out"]
+        if which == "ai-toolkit":                    # flux/model.py:1340-1362 (ostris' ai-toolkit layout)
+            return ["to_q", "to_k", "to_qkv", "add_qkv_proj", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out", "ff.net.0.proj", "ff.net.2",
+                    "ff_context.net.0.proj", "ff_context.net.2", "norm.linear", "norm1.linear", "norm1_context.linear", "proj_mlp", "proj_out"]
         if which == "tiny":                          # flux/model.py:1363-1369
             return ["single_transformer_blocks.7.proj_out", "single_transformer_blocks.20.proj_out"]
         if which == "nano":                          # flux/model.py:1370-1375

@@ -94,7 +94,7 @@ class LoraGroup:
         """dB_g = s * dy_g^T T_g ; dA_g = U_g^T x   (rank-space backward: both products are [*, r]).  x: the projection's input, or — an input that only
         exists as K segments (the single block's proj_out reads [attn | mlp] as a two-segment K loop) — a list of (segment, first input column)."""
         segs = x if isinstance(x, (list, tuple)) else [(x, 0)]
-        multi = len(segs) == 1 and len(self.targets) > 1 and self.r_pad == 32 and U.shape[1] >= 128        # q / k / v share x: dA of all three in ONE pass over x
+        multi = len(segs) == 1 and 1 < len(self.targets) <= 4 and self.r_pad == 32 and U.shape[1] >= 128   # q / k / v share x: dA of all three in ONE pass over x
         cw = min(self.r_pad, 64)                                 # rank-space kernels take 32 or 64 adapter columns per pass
         for g, (_, n_off, N) in enumerate(self.targets):
             for s0 in range(0, self.rank, cw):
@@ -140,6 +140,8 @@ class FluxTransformer2DModel(nn.Module):
         self._build()
 
         self.lora_groups: List[LoraGroup] = []
+        self.mod_lora: Optional[LoraGroup] = None          # 'ai-toolkit': adapters on every block's AdaLN modulation Linear (one group over the fused modulation GEMM)
+        self._dmod: Optional[torch.Tensor] = None          # d loss / d (modulation rows) of the backward in flight (only with mod_lora)
         self.lora_flat: Optional[torch.Tensor] = None
         self.lora_grad_flat: Optional[torch.Tensor] = None
         self._lora_params: List[nn.Parameter] = []
@@ -325,11 +327,25 @@ class FluxTransformer2DModel(nn.Module):
             for (name, n_off, N) in g.targets:
                 plan.append((g, name, N, K))
 
-        sets = ("default", "all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "tiny", "nano")
+        sets = ("default", "all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "ai-toolkit", "tiny", "nano")
         if targets not in sets:
             raise ValueError(f"add_lora_adapter: unknown target set {targets!r} (built: {', '.join(repr(t) for t in sets)})")
         if targets == "all+ffs+embedder":          # flux/model.py:1320-1339: all+ffs + x_embedder (the packed-latent input projection, K = in_channels)
             group(self.l_x, "", ["x_embedder"], self.l_x.w.shape[1])
+            targets = "all+ffs"
+        self.mod_lora = None
+        if targets == "ai-toolkit":                # flux/model.py:1340-1362: all+ffs + the AdaLN modulation Linears norm1.linear / norm1_context.linear / norm.linear
+            # every block's modulation is a row slice of ONE fused GEMM over silu(temb): its adapters are one group that shares that input (like q / k / v share theirs)
+            slices = []
+            for i, blk in enumerate(self.double):
+                slices += [(f"transformer_blocks.{i}.norm1.linear", blk.mod_off, 6 * D), (f"transformer_blocks.{i}.norm1_context.linear", blk.mod_off_c, 6 * D)]
+            for i, blk in enumerate(self.single):
+                slices.append((f"single_transformer_blocks.{i}.norm.linear", blk.mod_off, 3 * D))
+            g = LoraGroup(D, self.mod_total, slices, rank, alpha, dev)
+            self.mod_lora = g
+            self.lora_groups.append(g)
+            for (name, n_off, N) in g.targets:
+                plan.append((g, name, N, D))
             targets = "all+ffs"
         base, ffs = (targets[:-4], True) if targets.endswith("+ffs") else (targets, False)
         if base == "context" and not self.double:
@@ -575,7 +591,8 @@ class FluxTransformer2DModel(nn.Module):
         full = getattr(env, "full", False)        # full-rank training: norm weights train (no fused projection epilogue), extra activations are kept
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((Si, St), (blk.norm_q, blk.norm_k, blk.norm_added_q, blk.norm_added_k))
         ff_lora = any(l.lora is not None for l in (blk.ff1, blk.ff2, blk.ffc1, blk.ffc2))      # '+ffs' adapters: host sequencing
-        if (fused and not tokw and not ff_lora and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
+        keep_y = (full or self.mod_lora is not None) and save        # the un-gated branch outputs: gate gradients (full-rank training; adapters on the modulation Linears)
+        if (fused and not tokw and not ff_lora and self.mod_lora is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "fwd") and _FUSED_VT and blk.add_qkv.lora is None and blk.to_add_out.lora is None and img.is_contiguous() and txt.is_contiguous()):
             # the production form of the block as ONE C entry point (st355_block_flux_double_fwd): the same launches on the same operands as
             # the host-side sequencing below (adapters on the image stream's to_q / to_k / to_v / to_out.0, the reference's default target set)
             mk = lambda r, c: torch.empty(r, c, dtype=BF16, device=dev)
@@ -648,7 +665,7 @@ class FluxTransformer2DModel(nn.Module):
         O_i, O_t = self._rows_of(O, St, Si, env), self._rows_of(O, 0, St, env)       # the attention output is split back by rows, in place
         kw_i, kw_t = {}, {}
         ya_i = ya_t = yf_i = yf_t = None
-        if full and save:            # the un-gated branch outputs (gate gradients: d gate = sum_rows dOut * y)
+        if keep_y:                   # the un-gated branch outputs (gate gradients: d gate = sum_rows dOut * y)
             ya_i, yf_i = (torch.empty(B * Si, D, dtype=BF16, device=dev) for _ in range(2))
             ya_t, yf_t = (torch.empty(B * St, D, dtype=BF16, device=dev) for _ in range(2))
             kw_i["aux_out"], kw_t["aux_out"] = ya_i, ya_t
@@ -698,6 +715,8 @@ class FluxTransformer2DModel(nn.Module):
                                  lse2=lse2, x1_img=x1_img, x1_txt=x1_txt, hpre_img=hpre_img, hpre_txt=hpre_txt, T_img=T_img, T_txt=T_txt, T_o=T_o, T_ao=T_ao)
             if full:    # full-rank training also needs every Linear's input (weight gradients) and the un-gated branch outputs (gate gradients)
                 sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
+            elif keep_y:
+                sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = ya_i, ya_t, yf_i, yf_t
             if ff_lora:  # the feed-forward adapters' gradients read their Linear's input (dA = U^T x) and T = x A^T (dB = s dy^T T)
                 sv.ff = SimpleNamespace(n2_i=n2_i if blk.ff1.lora is not None else None, n2_t=n2_t if blk.ffc1.lora is not None else None,
                                         h_i=h_i if blk.ff2.lora is not None else None, h_t=h_t if blk.ffc2.lora is not None else None,
@@ -715,7 +734,8 @@ class FluxTransformer2DModel(nn.Module):
         full = getattr(env, "full", False)
         fused = (not full) and (not getattr(env, "routed", False)) and self._fused_qkv_ok((S,), (blk.norm_q, blk.norm_k))
         ff_lora = blk.proj_mlp.lora is not None or blk.proj_out.lora is not None      # '+ffs' / 'tiny' / 'nano' adapters: host sequencing (the C entry point knows the q / k / v adapters)
-        if fused and not tokw and not ff_lora and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
+        keep_y = (full or self.mod_lora is not None) and save
+        if fused and not tokw and not ff_lora and self.mod_lora is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "fwd") and _FUSED_VT and x.is_contiguous():
             # the production form of the block as ONE C entry point (st355_block_flux_single_fwd): the same launches on the same operands
             # as the host-side sequencing below
             lo = blk.qkv.lora
@@ -755,7 +775,7 @@ class FluxTransformer2DModel(nn.Module):
         hact = ops.gemm(n, blk.proj_mlp.w, bias=blk.proj_mlp.b, epilogue=EPI_GELU, aux_out=hpre,
                         **(dict(a2=T_m, b2=lm.B_blk, k2_real=lm.k2_real) if lm is not None else {}))
         # cat[attn, mlp] @ Wout^T is a two-segment K loop: no [B,S,5D] concat buffer is ever materialised
-        y = torch.empty(B * S, D, dtype=BF16, device=dev) if (full and save) else None          # the un-gated branch output (gate gradient)
+        y = torch.empty(B * S, D, dtype=BF16, device=dev) if keep_y else None          # the un-gated branch output (gate gradient)
         x_in, T_p = x, None
         if lp is not None:
             # proj_out's adapter: T = [attn | mlp] A^T as the same two-segment K loop; both K segments of the projection are taken, so the low-rank term goes
@@ -764,8 +784,10 @@ class FluxTransformer2DModel(nn.Module):
             x_in = ops.gemm(T_p, lp.B_blk, epilogue=EPI_GATE_RESIDUAL, aux_in=x, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx)
         x_out = ops.gemm(O, blk.proj_out.w[:, :D], bias=blk.proj_out.b, a2=hact, b2=blk.proj_out.w[:, D:], epilogue=EPI_GATE_RESIDUAL,
                          aux_in=x_in, gate=ms[:, 2 * D:3 * D], rows_per_batch=rpx, **(dict(aux_out=y) if y is not None else {}))
+        if y is not None and lp is not None:          # the gate gradient wants the WHOLE un-gated branch: the projection's output + its adapter's low-rank term
+            y = ops.gemm(T_p, lp.B_blk, epilogue=EPI_ADD, aux_in=y)
         sv = SimpleNamespace(x=x, n=n, qkv=qkv, V=V, rrms=rrms, Q=Q, K=K, Qt=Qt, Kt=Kt, O=O, lse2=lse2, hpre=hpre, T=T, T_m=T_m, T_p=T_p) if save else None
-        if sv is not None and (full or lp is not None):
+        if sv is not None and (full or lp is not None or keep_y):
             sv.hact, sv.y = hact, y           # (proj_out's adapter gradient dA = U^T [attn | mlp] reads the activated MLP rows)
         return x_out, sv
 
@@ -787,6 +809,8 @@ class FluxTransformer2DModel(nn.Module):
         tokenwise = timestep.dim() == 2
         if tokenwise and tuple(timestep.shape) != (B, Si):
             raise ValueError(f"Flux expected tokenwise timesteps with sequence length {Si}, got {timestep.shape[1]}.")     # flux/transformer.py:1068-1072
+        if self.mod_lora is not None and (tokenwise or full):
+            raise NotImplementedError("flux_lora_target='ai-toolkit' (adapters on the AdaLN modulation Linears) takes per-sample timesteps under LoRA training on the st355 path")
         t32 = timestep.to(device=dev, dtype=F32).reshape(-1).contiguous()
         em.tproj = ops.timestep_proj(t32, 256, 1000.0)
         em.t1 = ops.gemm(em.tproj, self.l_t1.w, bias=self.l_t1.b); em.st1 = ops.silu(em.t1)
@@ -830,7 +854,9 @@ class FluxTransformer2DModel(nn.Module):
                 temb = ops.add(temb, cond)
             temb = ops.add(temb, pe)
         em.temb, em.st = temb, ops.silu(temb)
-        mod = ops.gemm(em.st, self.mod_w, bias=self.mod_b)        # [B, mod_total]: every block's modulation at once
+        ml = self.mod_lora
+        T_mod = ops.gemm(em.st, ml.A_cat) if ml is not None else None
+        mod = ops.gemm(em.st, self.mod_w, bias=self.mod_b, **(dict(a2=T_mod, b2=ml.B_blk, k2_real=ml.k2_real) if ml is not None else {}))   # [B, mod_total]: every block's modulation at once
         if tokenwise:
             xoff = self.single[0].mod_off if self.single else self.mod_off_out          # the single blocks' and norm_out's columns follow the double blocks'
             mod_x = torch.cat([mod[:, None, xoff:].expand(B, St, self.mod_total - xoff), mod_img.view(B, Si, -1)[:, :, xoff:]], dim=1).reshape(B * S, self.mod_total - xoff)
@@ -846,6 +872,8 @@ class FluxTransformer2DModel(nn.Module):
         routes = normalise_routes(self._tread_routes, nd + ns) if (save and self.training and self._tread_router is not None) else []
         if routes and tokenwise:
             raise NotImplementedError("tokenwise timesteps under TREAD routing (the routed tokens' modulation rows would be gathered too) are not implemented")
+        if routes and ml is not None:
+            raise NotImplementedError("TREAD routing with flux_lora_target='ai-toolkit' (modulation-row gradients over routed token subsets) is not built on the st355 path")
         if routes and full:
             raise NotImplementedError("TREAD routing under full-rank Flux training is not built on the st355 path (LoRA training routes)")
         if routes:
@@ -950,6 +978,8 @@ class FluxTransformer2DModel(nn.Module):
                 ctx.n_out, ctx.T_out = n_out, T_out
             if self.l_x.lora is not None:
                 ctx.x2d, ctx.T_x = em.x2d, T_x
+            if ml is not None:
+                ctx.st, ctx.T_mod = em.st, T_mod
         return out.view(B, Si, -1), ctx
 
     def _attn_backward(self, sv, dO, dqkv, env):
@@ -986,6 +1016,13 @@ class FluxTransformer2DModel(nn.Module):
         else:
             ops.qk_norm_rope_bwd(dQ, dK, sv.qkv, wq, wk, env.cos, env.sin, dqkv, B, H, hd, rows, pos0, S)
 
+    def _mod_grads(self, dn, x_in, rows: int, k_shift: int, k_scale: int, dm):
+        """d shift = sum_rows dY, d scale = sum_rows dY * LN(x) of one AdaLN instance, per sample, into chunks k_shift / k_scale of its slice `dm` of the modulation-row
+        gradient (the reductions of the full-rank engine's `mod_grads`; here for adapters on the modulation Linears under a frozen base)"""
+        D = self.D
+        ops.colsum_prod(dn, dm[:, k_shift * D:(k_shift + 1) * D], rows_per_batch=rows)
+        ops.colsum_prod(dn, dm[:, k_scale * D:(k_scale + 1) * D], b=ops.layer_norm_xhat(x_in), rows_per_batch=rows)
+
     def _single_bwd(self, li: int, sv, dx, dxg, env):
         """backward of single block li.  Returns (dx, dxg, d_txt, d_img): block 0 of a model with double blocks writes its input gradient — the joint
         gradient of the double stack — per (stream, sample) straight into the two stream-major buffers (no split / gather pass)."""
@@ -997,7 +1034,8 @@ class FluxTransformer2DModel(nn.Module):
         ms = msl(li)
         rpx = 1 if tokw else S
         lm, lp = blk.proj_mlp.lora, blk.proj_out.lora
-        if (not tokw and lm is None and lp is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
+        dm = self._dmod[:, blk.mod_off:blk.mod_off + 3 * D] if self._dmod is not None else None      # 'ai-toolkit': this block's slice of d loss / d (modulation rows)
+        if (not tokw and lm is None and lp is None and dm is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "single", "bwd") and _FUSED_ROPE_BWD and sv.rrms is not None and not getattr(env, "routed", False) and (li > 0 or not self.double)
                 and dx.is_contiguous() and (dxg is None or dxg.is_contiguous())):
             # ONE C entry point (st355_block_flux_single_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lo = blk.qkv.lora
@@ -1019,6 +1057,8 @@ class FluxTransformer2DModel(nn.Module):
             if lo is not None and self.grad_sync is not None:
                 self.grad_sync.ready(lo.flat_lo, lo.flat_hi)
             return dx_out, dxg_out, None, None
+        if dm is not None:
+            ops.colsum_prod(dx, dm[:, 2 * D:3 * D], b=sv.y, rows_per_batch=S)                        # d gate = sum_rows dOut * (un-gated branch output)
         g = dxg if dxg is not None else ops.scale_cols(dx, ms[:, 2 * D:3 * D], rpx)
         kw_o = kw_h = {}
         if lp is not None:         # proj_out's adapter: dx_in += (g sB) A, split over the two K segments [attn | mlp] of its input
@@ -1042,6 +1082,8 @@ class FluxTransformer2DModel(nn.Module):
         self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_q, blk.norm_k), (blk.norm_q, blk.norm_k), 0)
         del dO
         dn = self._lin_bwd(blk.qkv, dqkv, x=sv.n, T=sv.T, epilogue=EPI_ADD, aux_in=dn_mlp)
+        if dm is not None:
+            self._mod_grads(dn, sv.x, S, 0, 1, dm)
         d_txt = d_img = None
         if li > 0:
             gprev = msl(li - 1)[:, 2 * D:3 * D]
@@ -1066,7 +1108,10 @@ class FluxTransformer2DModel(nn.Module):
         mi = (env.mod_img if tokw else mod)[:, blk.mod_off:blk.mod_off + 6 * D]; mt = mod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
         rpi = 1 if tokw else Si
         ff = getattr(sv, "ff", None)              # '+ffs' adapters on this block's feed-forward Linears (host sequencing)
-        if (not tokw and ff is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
+        dmi = dmt = None                          # 'ai-toolkit': the two streams' slices of d loss / d (modulation rows): chunks (shift, scale, gate)_msa, (shift, scale, gate)_mlp
+        if self._dmod is not None:
+            dmi, dmt = self._dmod[:, blk.mod_off:blk.mod_off + 6 * D], self._dmod[:, blk.mod_off_c:blk.mod_off_c + 6 * D]
+        if (not tokw and ff is None and dmi is None and _block_abi_ok() and _BLOCK_ABI_ONLY in ("", "double", "bwd") and _FUSED_ROPE_BWD and li > 0 and sv.rrms is not None and not getattr(env, "routed", False) and sv.T_txt is None and sv.T_ao is None
                 and Si % 256 == 0 and St % 256 == 0 and d_img.is_contiguous() and d_txt.is_contiguous()):
             # ONE C entry point (st355_block_flux_double_bwd): the launches of the host-side sequencing below, in its order, on its operands
             lq, lo_ = blk.qkv.lora, blk.to_out.lora
@@ -1096,6 +1141,9 @@ class FluxTransformer2DModel(nn.Module):
                     if lg is not None:
                         self.grad_sync.ready(lg.flat_lo, lg.flat_hi)
             return d_img_out, d_txt_out
+        if dmi is not None:
+            ops.colsum_prod(d_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)                  # d gate_mlp
+            ops.colsum_prod(d_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
         g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], rpi); g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
         if ff is None:
             dh_i, dh_t = ops.gemm_grouped([dict(a=g_i, w=blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img),
@@ -1118,9 +1166,14 @@ class FluxTransformer2DModel(nn.Module):
                     lg.grads(x_in, T_, dy, U_, self.accumulate_lora_grads, self.grad_sync)
             del U_f2, U_c2, U_f1, U_c1
         del g_i, g_t, dh_i, dh_t
+        if dmi is not None:
+            self._mod_grads(dn2_i, sv.x1_img, Si, 3, 4, dmi); self._mod_grads(dn2_t, sv.x1_txt, St, 3, 4, dmt)
         dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], rpi, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
         dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
         del dn2_i, dn2_t
+        if dmi is not None:
+            ops.colsum_prod(dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)                  # d gate_msa
+            ops.colsum_prod(dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
         # attention output projections: dO rows of both streams (+ adapter grads)
         dO = torch.empty(B * S, D, dtype=BF16, device=dev)
         U_i = ops.gemm(dx1g_i, blk.to_out.lora.B_blk_T) if blk.to_out.lora is not None else None
@@ -1136,7 +1189,7 @@ class FluxTransformer2DModel(nn.Module):
         dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
         self._attn_rope_backward(sv, dO, dqkv, env, (blk.norm_added_q, blk.norm_added_k), (blk.norm_q, blk.norm_k), St)
         del dO
-        last = li == 0 and self.l_x.lora is None          # (an adapter on x_embedder needs the image stream's input gradient of block 0)
+        last = li == 0 and self.l_x.lora is None and dmi is None      # (an adapter on x_embedder needs the image stream's input gradient of block 0; the modulation adapters d n of both streams)
         # the two streams' rows of the joint dqkv, in place (the reference's autograd splits the concatenated gradient the same way)
         dq_i, dq_t = self._rows_of(dqkv, St, Si, env), self._rows_of(dqkv, 0, St, env)
         streams = [("img", blk.qkv, dq_i, sv.n_img, sv.T_img, Si), ("txt", blk.add_qkv, dq_t, sv.n_txt, sv.T_txt, St)]
@@ -1160,6 +1213,8 @@ class FluxTransformer2DModel(nn.Module):
                 lin.lora.grads(n_in, T_, self._compact(dq, env, rows), Us[name], self.accumulate_lora_grads, self.grad_sync)
         if last:
             return None, None
+        if dmi is not None:
+            self._mod_grads(dns[0], sv.img, Si, 0, 1, dmi); self._mod_grads(dns[1], sv.txt, St, 0, 1, dmt)
         d_img, _ = ops.ln_modulate_bwd(dns[0], sv.img, mi[:, D:2 * D], rpi, dres=dx1_i)
         d_txt, _ = ops.ln_modulate_bwd(dns[1], sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
         return d_img, d_txt
@@ -1176,6 +1231,7 @@ class FluxTransformer2DModel(nn.Module):
         dout = dout.reshape(B * Si, -1).to(BF16).contiguous()
         mo = mod[:, self.mod_off_out:self.mod_off_out + 2 * D]
         dn = self._lin_bwd(self.l_out, dout, x=getattr(ctx, "n_out", None), T=getattr(ctx, "T_out", None))
+        self._dmod = torch.zeros(B, self.mod_total, dtype=F32, device=dev) if self.mod_lora is not None else None
         dx = torch.zeros(B * S, D, dtype=BF16, device=dev)      # the txt rows of the last single block get no gradient
         for b in range(B):          # written straight into the image rows of the joint gradient
             if getattr(env, "tokenwise", False):          # norm_out's (scale, shift) rows are per image token (flux/transformer.py:1505 takes temb_img)
@@ -1244,6 +1300,12 @@ class FluxTransformer2DModel(nn.Module):
                 d_img = dx.view(B, S, D)[:, St:].reshape(B * Si, D)
             U_x = ops.gemm(d_img, lx.B_blk_T)
             lx.grads(ctx.x2d, ctx.T_x, d_img, U_x, self.accumulate_lora_grads, self.grad_sync)
+        ml = self.mod_lora
+        if ml is not None:          # 'ai-toolkit': the modulation Linears' adapters — dy = the accumulated modulation-row gradient [B, mod_total], x = silu(temb) [B, D]
+            dmod = self._dmod.to(BF16)
+            self._dmod = None
+            U_m = ops.gemm(dmod, ml.B_blk_T)
+            ml.grads(ctx.st, ctx.T_mod, dmod, U_m, self.accumulate_lora_grads, self.grad_sync)
         return None
 
     # ------------------------------------------------------------------------------------------------

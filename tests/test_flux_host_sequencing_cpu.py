@@ -390,7 +390,7 @@ def _check_adapter_set(model, d, expect_names):
 
 
 @pytest.mark.parametrize("which,B,lat_h,lat_w,S_txt,rank", [("all+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 16, 16, 64, 16), ("context+ffs", 2, 16, 8, 24, 16), ("all+ffs", 1, 8, 8, 40, 80),
-                                                           ("all+ffs+embedder", 2, 16, 8, 24, 16)])
+                                                           ("all+ffs+embedder", 2, 16, 8, 24, 16), ("ai-toolkit", 2, 16, 8, 24, 16), ("ai-toolkit", 1, 16, 16, 64, 16)])
 def test_feed_forward_target_sets_through_the_emulator_match_the_oracle(monkeypatch, which, B, lat_h, lat_w, S_txt, rank):
     """flux_lora_target = "all+ffs" / "context+ffs" (flux/model.py:1272-1301): adapters on ff.net.0.proj / ff.net.2 / ff_context.net.* of the double blocks and on
     proj_mlp / proj_out of the single blocks, next to the attention projections of the set.  proj_out reads [attn | mlp] as two K segments: its adapter's T = x A^T and
@@ -503,7 +503,7 @@ def test_nano_with_recomputation_is_bit_identical_and_recomputes_only_what_it_di
     assert recomputed == [8, 7], calls                        # per-block segments: blocks 6 .. 0 are never re-run
 
 
-@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "nano", "tiny"])
+@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "ai-toolkit", "nano", "tiny"])
 def test_adapter_names_are_the_modules_peft_wraps_in_the_executed_reference(monkeypatch, which):
     """the product's adapter parameters (and so the keys of the saved LoRA file) against tests/golden/ref_flux_lora_sets.pt: the module names peft's target_modules
     rule selected on the reference's FluxTransformer2DModel from the reference's own `flux_lora_target` list, for a model of the same depth"""
@@ -559,3 +559,36 @@ def test_lora_file_round_trip_with_the_widest_adapter_set(monkeypatch, tmp_path,
     for n, p in model.named_parameters():
         if ".lora_" in n:
             assert torch.equal(p, before[n]), n
+
+
+def test_modulation_adapters_recompute_bit_identically_and_refuse_what_is_not_built(monkeypatch):
+    """flux_lora_target = "ai-toolkit" (flux/model.py:1340-1362: all+ffs + norm1.linear / norm1_context.linear / norm.linear): the modulation Linears' adapters are ONE group
+    over the fused modulation GEMM; their dy is the per-sample modulation-row gradient (shift / scale / gate column sums the frozen-base backward otherwise never forms).
+    With per-block recomputation every gradient is bit-identical; tokenwise timesteps and TREAD routes are refused for this set."""
+    d = _inputs(2, 16, 8, 24)
+
+    def run(ckpt):
+        model = _model(monkeypatch, 2, 2)
+        model.add_lora_adapter(rank=8, alpha=8.0, targets="ai-toolkit", init_b_std=0.02)
+        model.train()
+        if ckpt:
+            model.enable_gradient_checkpointing()
+        out, _ = _hip_side(model, d)
+        return model, out, {n: p.grad.clone() for n, p in model.named_parameters() if ".lora_" in n}
+
+    model, out, grads = run(False)
+    mods = [n for n in grads if ".norm1.linear." in n or ".norm1_context.linear." in n or ".norm.linear." in n]
+    assert len(mods) == 2 * (2 * 2 + 2) and all(grads[n].abs().max() > 0 for n in mods)
+    assert model.mod_lora is not None and len(model.mod_lora.targets) == 6 and model._dmod is None
+    _, out_c, grads_c = run(True)
+    assert torch.equal(out, out_c) and all(torch.equal(grads[k], grads_c[k]) for k in grads)
+    tok = dict(d, t=torch.rand(2, 32) * 0.8 + 0.1)
+    with pytest.raises(NotImplementedError, match="ai-toolkit"):
+        _hip_side(model, tok)
+    from simpletuner_amd.training.tread import ReplayRouter
+    perm = torch.stack([torch.randperm(32, generator=torch.Generator().manual_seed(b)) for b in range(2)])
+    rec = {"mask": torch.ones(2, 32, dtype=torch.bool).scatter_(1, perm[:, :16], False), "ids_keep": perm[:, :16], "ids_mask": perm[:, 16:], "ids_shuffle": perm,
+           "ids_restore": torch.argsort(perm, dim=1)}
+    model.set_router(ReplayRouter([rec]), [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": 2}])
+    with pytest.raises(NotImplementedError, match="ai-toolkit"):
+        _hip_side(model, d)

@@ -73,6 +73,14 @@ def test_flux_embedder_target_set_matches_oracle():
     _run("all+ffs+embedder", 1, 2, 2, 16, 16, 32)
 
 
+@pytest.mark.skipif(os.environ.get("ST355_GPU_NOT_YET_RUN") != "1",
+                    reason="written after round 4's GPU budget was spent: the modulation-Linear adapters (`ai-toolkit`: per-sample column sums into the modulation-row "
+                           "gradient, rank-space gradients over M = batch rows) are checked on the CPU through the ops emulator only; ST355_GPU_NOT_YET_RUN=1 runs it")
+@pytest.mark.parametrize("layers,single,B,lat,S_txt", [(2, 2, 2, 16, 32), (1, 1, 2, 32, 256)])
+def test_flux_ai_toolkit_target_set_matches_oracle(layers, single, B, lat, S_txt):
+    _run("ai-toolkit", layers, single, B, lat, lat, S_txt)
+
+
 def test_flux_nano_target_set_matches_oracle_and_stops_the_backward_at_block_7():
     model = _run("nano", 1, 9, 2, 16, 16, 32)
     assert model._bwd_stop == 8

@@ -116,7 +116,7 @@ def test_flux_oracle_reproduces_reference_model_with_tokenwise_timesteps():
     print(f"[pinned] flux tokenwise: out rel-L2 {r:.2e}, worst of {len(R['grads'])} parameter gradients {worst[0]:.2e} ({worst[1]})")
 
 
-@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "nano", "tiny"])
+@pytest.mark.parametrize("which", ["all", "context", "all+ffs", "context+ffs", "all+ffs+embedder", "ai-toolkit", "nano", "tiny"])
 def test_flux_oracle_lora_target_sets_reproduce_the_reference_model_with_merged_adapters(which):
     """`flux_lora_target` sets (flux/model.py:1235-1380) in oracle.flux — adapters as separate factors on `lora_targets(cfg, which)` — against the reference's
     FluxTransformer2DModel executed with the MERGED weights W' = W + (alpha / r) B A on the modules peft's suffix rule selects from the reference's OWN lists

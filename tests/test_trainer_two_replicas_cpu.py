@@ -87,6 +87,11 @@ def test_two_replicas_with_gradient_accumulation_reduce_once_at_the_boundary():
     _check(False, accum=2)
 
 
+def test_two_replicas_with_modulation_adapters():
+    """flux_lora_target = "ai-toolkit": the modulation Linears' adapter group is the LAST slice handed to the exchange (its dy is complete only after block 0)"""
+    _check(False, target="ai-toolkit")
+
+
 def test_two_replicas_with_feed_forward_and_embedder_adapters():
     """flux_lora_target = "all+ffs+embedder": the feed-forward, proj_mlp / proj_out, output-projection and x_embedder adapter groups hand their slices of the flat gradient to
     the exchange as the host-sequenced backward produces them (the output projection first, x_embedder last); two replicas end on identical weights, equal to one

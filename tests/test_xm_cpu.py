@@ -171,12 +171,14 @@ def test_flux_lora_target_sets_are_exact_or_refused():
                         "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "proj_mlp", "proj_out"],
             "all+ffs+embedder": ["x_embedder", "to_k", "to_q", "to_v", "to_qkv", "add_qkv_proj", "to_out.0", "add_k_proj", "add_q_proj", "add_v_proj", "to_add_out",
                                  "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "proj_mlp", "proj_out"],
+            "ai-toolkit": ["to_q", "to_k", "to_qkv", "add_qkv_proj", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out", "ff.net.0.proj", "ff.net.2",
+                           "ff_context.net.0.proj", "ff_context.net.2", "norm.linear", "norm1.linear", "norm1_context.linear", "proj_mlp", "proj_out"],
             "tiny": ["single_transformer_blocks.7.proj_out", "single_transformer_blocks.20.proj_out"],
             "nano": ["single_transformer_blocks.7.proj_out"]}
     for v, layers in want.items():
         m.config = SimpleNamespace(flux_lora_target=v)
         assert m._lora_target_set() == v and m.get_lora_target_layers() == layers
-    for v in ("ai-toolkit", "controlnet"):                                          # AdaLN-modulation / ControlNet adapters: not built, refused
+    for v in ("controlnet",):                                                       # the layers of a Flux ControlNet (a model this path does not build): refused
         m.config = SimpleNamespace(flux_lora_target=v)
         with pytest.raises(NotImplementedError, match="flux_lora_target"):
             m._lora_target_set()

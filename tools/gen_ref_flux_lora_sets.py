@@ -89,6 +89,7 @@ if __name__ == "__main__":
          "all+ffs": gen("all+ffs", lists["all+ffs"], 2, 3, 511), "context+ffs": gen("context+ffs", lists["context+ffs"], 2, 2, 521),
          "context": gen("context", lists["context"], 2, 2, 531), "all": gen("all", lists["all"], 2, 2, 541),
          "nano": gen("nano", lists["nano"], 1, 9, 551), "tiny": gen("tiny", lists["tiny"], 1, 22, 561),
-         "all+ffs+embedder": gen("all+ffs+embedder", lists["all+ffs+embedder"], 1, 2, 571)}
+         "all+ffs+embedder": gen("all+ffs+embedder", lists["all+ffs+embedder"], 1, 2, 571),
+         "ai-toolkit": gen("ai-toolkit", lists["ai-toolkit"], 2, 2, 581)}
     torch.save(G, OUT / "ref_flux_lora_sets.pt")
     print({k: (len(v["lora_targets"]), tuple(v["out"].shape)) for k, v in G.items() if isinstance(v, dict)})
