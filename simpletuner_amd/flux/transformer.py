@@ -335,7 +335,9 @@ class FluxTransformer2DModel(nn.Module):
             targets = "all+ffs"
         self.mod_lora = None
         if targets == "ai-toolkit":                # flux/model.py:1340-1362: all+ffs + the AdaLN modulation Linears norm1.linear / norm1_context.linear / norm.linear
-            # every block's modulation is a row slice of ONE fused GEMM over silu(temb): its adapters are one group that shares that input (like q / k / v share theirs)
+            # every block's modulation is a row slice of ONE fused GEMM over silu(temb): its adapters are one group that shares that input (like q / k / v share theirs).
+            # The K-extension operand is block-diagonal and stored dense: [mod_total, 76 * 32] bf16 = 5.2 GB for Flux.1 (+ its transpose) — HBM holds it; the GEMM has
+            # M = batch rows, so the extra read is ~1 ms per step
             slices = []
             for i, blk in enumerate(self.double):
                 slices += [(f"transformer_blocks.{i}.norm1.linear", blk.mod_off, 6 * D), (f"transformer_blocks.{i}.norm1_context.linear", blk.mod_off_c, 6 * D)]
