@@ -514,8 +514,8 @@ class FluxTransformer2DModel(nn.Module):
             for k, v in pr.items():
                 if k in ROWED and torch.is_tensor(v):
                     q[k] = v[b] if v.dim() == 3 else v[b * rows:(b + 1) * rows]
-                elif k == "gate":
-                    q[k] = v[b:b + 1]
+                elif k == "gate":          # one gate row per sample, or — tokenwise timesteps — one per token row of this stream
+                    q[k] = v[b:b + 1] if v.shape[0] == B else v[b * rows:(b + 1) * rows]
                 else:
                     q[k] = v
             out.append(q)
@@ -840,9 +840,6 @@ class FluxTransformer2DModel(nn.Module):
             # Flux.1 — HBM holds it); the joint-sequence rows of the single blocks + norm_out are assembled from them and the per-sample rows.
             if full:
                 raise NotImplementedError("tokenwise timesteps under full-rank training (per-token modulation gradients) are not implemented on the st355 path")
-            if B > 1 and (Si % 256 or St % 256):
-                raise NotImplementedError(f"tokenwise timesteps with per-GPU batch > 1 need the rows per sample of both streams ({Si}, {St}) to be multiples of 256 "
-                                          "(per-sample problem forms slice the modulation rows per sample)")
             # the three embedders' sum, fp32 accumulation order of the batch-wise path: timestep + guidance, then + pooled
             if cond is not None:
                 temb = ops.add(temb, cond[:, None, :].expand(B, Si, D).reshape(B * Si, D))

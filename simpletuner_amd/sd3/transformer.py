@@ -606,9 +606,6 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             if any(b.dual for b in self.blocks):
                 raise NotImplementedError("tokenwise timesteps with SD3.5 dual-attention blocks: the reference chunks SD35AdaLayerNormZeroX's [B, S, 9D] output along the "
                                           "token axis (sd3/transformer.py:155-164) — not a defined computation")
-            if B > 1 and Si % 256:
-                raise NotImplementedError(f"tokenwise timesteps with per-GPU batch > 1 need the image rows per sample ({Si}) to be a multiple of 256 (per-sample "
-                                          "problem forms slice the modulation rows per sample)")
             pe = ops.gemm(sp1, self.l_p2.w, bias=self.l_p2.b)                                         # [B, D]: the pooled-text embedding, shared by a sample's tokens
             temb_tok = ops.gemm(st1, self.l_t2.w, bias=self.l_t2.b, epilogue=EPI_ADD, aux_in=pe[:, None, :].expand(B, Si, D).reshape(B * Si, D))
             tsum = torch.empty(B, D, dtype=F32, device=dev)

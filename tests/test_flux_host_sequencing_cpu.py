@@ -283,7 +283,7 @@ def test_fused_projection_path_through_the_emulator_matches_the_oracle(monkeypat
         assert PU.rel_l2(grads_u[name], ref) < 5e-2, name
 
 
-@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(2, 2, 1, 16, 16, 64), (1, 2, 2, 32, 32, 256), (0, 2, 1, 16, 8, 24)])
+@pytest.mark.parametrize("layers,single,B,lat_h,lat_w,S_txt", [(2, 2, 1, 16, 16, 64), (1, 2, 2, 32, 32, 256), (0, 2, 1, 16, 8, 24), (2, 2, 2, 16, 8, 24)])      # last: B = 2, 32 / 24 rows per sample
 def test_tokenwise_timesteps_through_the_emulator_match_the_oracle(monkeypatch, layers, single, B, lat_h, lat_w, S_txt):
     """TOKENWISE timesteps [B, S_img] (CREPA self-flow; the reference's tests/test_flux_model.py:213-241 hands them to the transformer; oracle branch pinned to the
     executed reference class by tests/test_ref_models_cpu.py): per-token AdaLN rows on the image stream of the double blocks and in norm_out, the token mean on

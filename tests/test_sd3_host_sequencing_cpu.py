@@ -231,7 +231,7 @@ def test_cfg_sampling_trajectory_through_the_emulator_matches_the_oracle_driven_
     assert torch.isfinite(out.float()).all() and PU.rel_l2(out, x) < 3e-2
 
 
-@pytest.mark.parametrize("B,lat_h,lat_w", [(1, 16, 24), (2, 32, 32)])
+@pytest.mark.parametrize("B,lat_h,lat_w", [(1, 16, 24), (2, 32, 32), (2, 16, 24)])      # (2, 16, 24): 96 image rows per sample — per-sample problems slice the per-token gate rows
 def test_tokenwise_timesteps_through_the_emulator_match_the_oracle(monkeypatch, B, lat_h, lat_w):
     """TOKENWISE timesteps [B, S_img] (CREPA self-flow; the reference's tests/test_sd3_model.py:179-204 hands them to the transformer; oracle branch pinned to the
     executed reference by tests/test_ref_models_cpu.py): per-token AdaLN rows on the image stream and in norm_out (rows_per_batch = 1), the token mean on the
@@ -266,5 +266,3 @@ def test_tokenwise_timesteps_refusals(monkeypatch):
     d = _inputs(2, 16, 24, 33)
     with torch.no_grad(), pytest.raises(ValueError, match="expected sequence length"):
         model(hidden_states=d["lat"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=torch.rand(2, 7) * 1000, return_dict=False)
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="multiple of 256"):
-        model(hidden_states=d["lat"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=torch.rand(2, 96) * 1000, return_dict=False)
