@@ -592,3 +592,36 @@ def test_modulation_adapters_recompute_bit_identically_and_refuse_what_is_not_bu
     model.set_router(ReplayRouter([rec]), [{"selection_ratio": 0.5, "start_layer_idx": 1, "end_layer_idx": 2}])
     with pytest.raises(NotImplementedError, match="ai-toolkit"):
         _hip_side(model, d)
+
+
+@pytest.mark.parametrize("which,layers,single,B,lat_h,lat_w,S_txt,ckpt", [
+    ("all+ffs", 2, 0, 2, 8, 8, 40, True), ("context+ffs", 2, 0, 2, 32, 32, 256, False), ("ai-toolkit", 2, 0, 1, 16, 8, 24, True), ("all+ffs+embedder", 2, 0, 2, 32, 32, 256, True),
+    ("all+ffs", 0, 2, 2, 32, 32, 256, False), ("ai-toolkit", 0, 2, 2, 8, 8, 40, True), ("ai-toolkit", 2, 3, 2, 32, 32, 256, True), ("all+ffs+embedder", 2, 3, 1, 16, 8, 24, True),
+    ("context", 2, 0, 1, 16, 8, 24, False), ("all", 2, 0, 2, 8, 8, 40, True)])
+def test_adapter_sets_across_depths_shapes_and_recomputation(monkeypatch, which, layers, single, B, lat_h, lat_w, S_txt, ckpt):
+    """a sample of the (set x depth x shape x recomputation) grid swept while the sets were built (70 configurations, none failed): double-only and single-only models,
+    tile-aligned and ragged streams, per-block recomputation.  In a model WITHOUT single blocks the context stream of the last double block is discarded, so adapters that
+    feed only that output (its add_q_proj, to_add_out, ff_context.*) have an exactly zero gradient in the reference — and must have one here."""
+    model = _model(monkeypatch, layers, single)
+    model.add_lora_adapter(rank=8, alpha=8.0, targets=which, init_b_std=0.02)
+    model.train()
+    if ckpt:
+        model.enable_gradient_checkpointing()
+    d = _inputs(B, lat_h, lat_w, S_txt)
+    out, loss = _hip_side(model, d)
+    _, lora, scale = PU.oracle_state(model)
+    assert set(lora) == set(OF.lora_targets(PU.oracle_cfg(model), which))
+    o_out, o_loss, _, lp = _oracle_side(model, d, False, lora, scale)
+    assert PU.rel_l2(out, o_out) < 2e-2 and abs(loss.item() - o_loss.item()) < 2e-3 * max(1.0, o_loss.item())
+    zeros = 0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        key, ab = name.split(".lora_")
+        ref = lp[key][0 if ab.startswith("A") else 1].grad
+        if ref.norm().item() == 0:
+            zeros += 1
+            assert p.grad is None or p.grad.abs().max().item() == 0, name
+        else:
+            assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))
+    assert (zeros > 0) == (single == 0 and which != "default" and any(t in which for t in ("all", "context", "ai-toolkit")))
