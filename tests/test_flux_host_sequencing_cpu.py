@@ -625,3 +625,64 @@ def test_adapter_sets_across_depths_shapes_and_recomputation(monkeypatch, which,
         else:
             assert PU.rel_l2(p.grad, ref) < 5e-2, (name, PU.rel_l2(p.grad, ref))
     assert (zeros > 0) == (single == 0 and which != "default" and any(t in which for t in ("all", "context", "ai-toolkit")))
+
+
+class _Reached(Exception):
+    pass
+
+
+@pytest.mark.parametrize("entry", ["block_flux_double_fwd", "block_flux_single_fwd", "block_flux_double_bwd", "block_flux_single_bwd"])
+def test_block_entry_call_sites_build_their_arguments_on_the_default_path_and_step_aside_for_wider_sets(monkeypatch, entry):
+    """The Flux block-level C entry points cannot run on the CPU, but their CALL SITES can be driven up to the call: with the entry point replaced by a stub that records
+    its keyword arguments, the default adapter set on tile-aligned streams reaches it (every argument expression of the call site is evaluated — a name that does not exist
+    would fail here, not on the GPU box), and the sets the entry points do not know (feed-forward / modulation adapters) never reach it."""
+    from simpletuner_amd import ops as real_ops
+
+    def build(which, abi_fwd, abi_bwd):
+        EMU.install(monkeypatch)
+        from simpletuner_amd.flux import transformer as T
+        monkeypatch.setattr(T, "_FUSED_QKV", True)
+        model = T.FluxTransformer2DModel(device="cpu", **PU.small_flux_cfg(layers=2, single=2))
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif name.endswith(".bias"):
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5))
+        model.add_lora_adapter(rank=16, alpha=16.0, targets=which, init_b_std=0.02)
+        return T, model
+
+    seen = {}
+
+    def stub(name):
+        def f(*a, **k):
+            seen[name] = dict(k)
+            raise _Reached(name)
+        return f
+
+    fwd = entry.endswith("_fwd")
+    d = _inputs(2, 32, 32, 256)
+    for which, expect in (("default", True), ("all+ffs", False), ("ai-toolkit", False)):
+        seen.clear()
+        T, model = build(which, fwd, not fwd)
+        monkeypatch.setattr(T, "_BLOCK_ABI", fwd)                    # forward entries: on from the start; backward entries: the forward runs host-sequenced (fused projection)
+        for n in ("block_flux_double_fwd", "block_flux_single_fwd", "block_flux_double_bwd", "block_flux_single_bwd"):
+            monkeypatch.setattr(real_ops, n, stub(n))
+        only = "double" if "double" in entry else "single"
+        monkeypatch.setattr(T, "_BLOCK_ABI_ONLY", only)
+        try:
+            out = model(hidden_states=d["packed"], encoder_hidden_states=d["prompt"], pooled_projections=d["pooled"], timestep=d["t"], img_ids=d["img_ids"],
+                        txt_ids=d["txt_ids"], guidance=d["guidance"], return_dict=False)[0]
+            if not fwd:
+                monkeypatch.setattr(T, "_BLOCK_ABI", True)
+                ((out.float() - d["target"].float()) ** 2).mean().backward()
+            reached = False
+        except _Reached as e:
+            reached = str(e) == entry
+        assert reached == expect, (entry, which, sorted(seen))
+        if expect:
+            kw = seen[entry]
+            assert kw["B"] == 2 and kw["D"] == model.D and all(v is None or isinstance(v, (int, float, torch.Tensor, list)) for v in kw.values()), sorted(kw)
