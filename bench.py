@@ -733,6 +733,13 @@ def run_workload(args, dev, rank, world):
     if rank == 0:
         S_img = (lat // 2) ** 2
         step_flops = train_flops_per_image(n_blocks, D_model, S_img + S_txt) * B
+        if args.model == "flux" and not args.full and getattr(args, "lora_target", "default") in ("tiny", "nano"):
+            # single_transformer_blocks.7(.20).proj_out only: the backward runs from the last block down to single block 7 and stops — forward over every block, backward
+            # (1x linears, 2x attention) over the blocks at or above it
+            S_ = S_img + S_txt
+            per_lin, per_att = 2.0 * S_ * 12 * D_model * D_model, 4.0 * S_ * S_ * D_model
+            n_bwd = max(0, args.single_layers - 7)
+            step_flops = (n_blocks * (per_lin + per_att) + n_bwd * (per_lin + 2 * per_att)) * B
         if args.model == "pixart":
             step_flops = pix_step_flops * B
         elif args.model in ("sdxl", "sd15") and not args.full:   # LoRA: forward + input gradients (no base weight gradients): 2x forward, attention bwd 2x
