@@ -128,8 +128,11 @@ __device__ __forceinline__ void glds16(const bf16* gsrc, char* lds_dst_wave_unif
 }
 
 // grouped tile order: GROUP consecutive m-tiles share one W panel
+#ifndef ST355_TILE_GROUP          // tools/gemm_lab builds: the tile-order experiment (tools/r05_gemm_tile_order.sh); the library always builds with 8
+#define ST355_TILE_GROUP 8
+#endif
 __device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& pm, int& pn) {
-  const int GROUP = 8;
+  const int GROUP = ST355_TILE_GROUP;
   const int width = GROUP * nbn;
   const int group_id = id / width;
   const int first_m = group_id * GROUP;
