@@ -131,8 +131,10 @@ __device__ __forceinline__ void glds16(const bf16* gsrc, char* lds_dst_wave_unif
 #ifndef ST355_TILE_GROUP          // tools/gemm_lab builds: the tile-order experiment (tools/r05_gemm_tile_order.sh); the library always builds with 8
 #define ST355_TILE_GROUP 8
 #endif
-__device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& pm, int& pn) {
-  const int GROUP = ST355_TILE_GROUP;
+// measured r5 (profiles/r05_gemm_power.md): 8 sits at the fetch minimum for K <= 3072 (8 x 4 concurrent tiles per XCD: 12 operand panels per 32 tiles); with
+// K >= 8192 panels (4-6 MB, above the XCD's L2) 4 is 2.8 % faster (1325 vs 1290 TFLOP/s at 36864 x 3072 x 12288) at equal fetch
+__device__ __forceinline__ int tile_group_for(int K) { return (ST355_TILE_GROUP == 8 && K >= 8192) ? 4 : ST355_TILE_GROUP; }
+__device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& pm, int& pn, const int GROUP = ST355_TILE_GROUP) {
   const int width = GROUP * nbn;
   const int group_id = id / width;
   const int first_m = group_id * GROUP;
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // ([P, 9*N], block tap at columns tap*N) whose R operand is the SAME matrix shifted by (ty*Wp + tx) contraction rows: one launch for all taps
   const int wtaps = (TN && p.conv_taps == 9) ? 9 : 1;
   int pm, pn;
-  tile_coords(id, nbm, nbn * wtaps, pm, pn);
+  tile_coords(id, nbm, nbn * wtaps, pm, pn, TN ? ST355_TILE_GROUP : tile_group_for(p.K));
   const int wtap = pn / nbn;
   pn -= wtap * nbn;
   const int m0 = pm * PQ_BM, n0 = pn * PQ_BN;

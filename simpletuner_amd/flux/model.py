@@ -7,6 +7,9 @@ the reference (flux/model.py:739-745; pinned by tests/test_flux_model.py:213 the
 """
 from __future__ import annotations
 
+import hashlib
+import random
+
 import torch
 
 from .. import ops
@@ -180,6 +183,7 @@ class Flux(ModelFoundation):
             self._ids_cache[key] = (prepare_latent_image_ids(B, Hh, Ww, dev, BF16),
                                     torch.zeros(prepared_batch["prompt_embeds"].shape[1], 3, device=dev, dtype=torch.float32))
         img_ids, text_ids = self._ids_cache[key]
+        rope_key = ("flux_ids",) + key                    # names the id layout for the engine's RoPE-table cache (never tensor identity)
         # "divide it by 1000 for now because we scale it by 1000 in the transformer model" (flux/model.py:739-745, 790)
         ts = prepared_batch["timesteps"].to(device=dev, dtype=torch.float32)
         if ts.ndim == 2:                                  # tokenwise: one timestep per packed image token (flux/model.py:582-595)
@@ -205,6 +209,10 @@ class Flux(ModelFoundation):
             prepared_batch["timesteps"] = torch.cat([ts, torch.zeros(B, cond_seq.shape[1], device=dev, dtype=torch.float32)], dim=1)
             packed = torch.cat([packed, cond_seq.to(device=dev, dtype=BF16)], dim=1)
             ids_b = img_ids[None].expand(B, -1, -1) if img_ids.dim() == 2 else img_ids
+            # the reference-image ids are data: their layout is named by a digest of their contents when they arrive on the host, otherwise the engine
+            # computes the tables from the ids on the device every step (no cache entry, no host read)
+            rope_key = rope_key + (hashlib.blake2b(cond_ids.detach().float().contiguous().numpy().tobytes(), digest_size=16).hexdigest(),) \
+                if cond_ids.device.type == "cpu" else None
             img_ids = torch.cat([ids_b, cond_ids.to(device=dev, dtype=ids_b.dtype)], dim=1)
         attention_mask = None
         if getattr(self.config, "flux_attention_masked_training", False):          # flux/model.py:813-823
@@ -224,6 +232,7 @@ class Flux(ModelFoundation):
             joint_attention_kwargs=None,
             return_dict=False,
             attention_mask=attention_mask,
+            rope_layout_key=rope_key,
         )[0]
         if use_cond and getattr(self.config, "model_flavour", None) == "kontext":      # drop the reference-image tokens before unpacking (flux/model.py:844-847)
             model_pred = model_pred[:, :scene_len, :]

@@ -146,6 +146,7 @@ class FluxTransformer2DModel(nn.Module):
         self.lora_grad_flat: Optional[torch.Tensor] = None
         self._lora_params: List[nn.Parameter] = []
         self._rope_cache: Dict = {}
+        self._rope_layout_key = None
         self._norm_w_ok: Dict = {}
         self._prepared = False
         self.accumulate_lora_grads = False
@@ -419,23 +420,33 @@ class FluxTransformer2DModel(nn.Module):
     # ------------------------------------------------------------------------------------------------
     # rope tables (FluxPosEmbed, theta=1e4, float64 frequencies -> fp32 tables); cached per id layout
     # ------------------------------------------------------------------------------------------------
+    _ROPE_CACHE_MAX = 32
+
     def _rope(self, txt_ids: torch.Tensor, img_ids: torch.Tensor):
-        # keyed on the id tensors' identity (the plugin caches them per latent shape): no device->host read per step (that was a host sync in
-        # every step, and is illegal while a hipGraph is being captured)
-        key = (txt_ids.data_ptr(), img_ids.data_ptr(), tuple(txt_ids.shape), tuple(img_ids.shape), txt_ids._version, img_ids._version)
-        hit = self._rope_cache.get(key)
-        if hit is not None:
-            return hit
-        ids = torch.cat((txt_ids, img_ids), dim=0).float().cpu()
+        """Tables for the id layout of this call.  Cached only under an explicit layout key the caller supplies (`forward(rope_layout_key=...)`: the plugin
+        names the layout by what it was built from — latent grid, text length, a digest of the reference-image ids).  Never keyed on tensor identity: the
+        caching allocator hands a freshly concatenated id tensor the same address step after step while its contents change (transposed aspect buckets,
+        reference images of another size with the same token count).  Without a key the tables are computed on the device from the ids themselves: no
+        device->host read (a host sync per step, and illegal while a hipGraph is being captured), nothing retained."""
+        key = self._rope_layout_key
+        if key is not None:
+            key = (key, tuple(txt_ids.shape), tuple(img_ids.shape))
+            hit = self._rope_cache.get(key)
+            if hit is not None:
+                return hit
+        ids = torch.cat((txt_ids.to(self.device_), img_ids.to(self.device_)), dim=0).to(torch.float64)
         cos_l, sin_l = [], []
         for i, d in enumerate(self.config.axes_dims_rope):
-            freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
-            f = torch.outer(ids[:, i].to(torch.float64), freqs)
+            freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64, device=ids.device)[: d // 2] / d))
+            f = torch.outer(ids[:, i], freqs)
             cos_l.append(f.cos().repeat_interleave(2, dim=1).float()); sin_l.append(f.sin().repeat_interleave(2, dim=1).float())
         cos, sin = torch.cat(cos_l, -1).contiguous(), torch.cat(sin_l, -1).contiguous()
         # + one (cos, sin) per interleaved pair, [S, hd/2]: what the fused projection epilogue reads (half the table bytes through the CU's L2 port)
-        out = tuple(t.to(self.device_) for t in (cos, sin, cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous()))
-        self._rope_cache[key] = out
+        out = (cos, sin, cos[:, 0::2].contiguous(), sin[:, 0::2].contiguous())
+        if key is not None:
+            while len(self._rope_cache) >= self._ROPE_CACHE_MAX:          # bounded: oldest layout out
+                self._rope_cache.pop(next(iter(self._rope_cache)))
+            self._rope_cache[key] = out
         return out
 
     # ------------------------------------------------------------------------------------------------
@@ -1571,7 +1582,8 @@ class FluxTransformer2DModel(nn.Module):
         self._tread_router, self._tread_routes = router, routes
 
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None, txt_ids=None,
-                guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, force_keep_mask=None, **unsupported):
+                guidance=None, joint_attention_kwargs=None, return_dict: bool = True, attention_mask=None, force_keep_mask=None, rope_layout_key=None, **unsupported):
+        self._rope_layout_key = rope_layout_key            # hashable name of the id layout (see _rope); None = compute the tables from the ids
         self._force_keep_mask = force_keep_mask            # TREAD: tokens that may never be routed away (flux/transformer.py:958, 1216-1220)
         for k, v in unsupported.items():
             if v is not None and v is not False:

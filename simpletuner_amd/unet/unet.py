@@ -124,6 +124,7 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         self.lora_groups: List[LoraGroup] = []
         self.lora_flat = self.lora_grad_flat = None
         self._lora_params: List[nn.Parameter] = []
+        self._probe = None
 
     # ------------------------------------------------------------------------------------------------
     # construction: parameter slots in arena order + the layer graph
@@ -489,6 +490,8 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
                     U = ops.gemm(dy, lo.B_blk_T)
                     lo.grads(x, Tl, dy, U, False, None)
                     kb = dict(a2=U, b2=lo.A_cat_T)
+                if self._probe is not None:               # lab hook (tools/sdxl_lora_outlier_probe.py): the operands of this layer's backward, by reference
+                    self._probe("linear", l.name, dict(x=x, dy=dy, y=y))
                 dx = ops.gemm(dy, l.wT, **kb) if need_dx else None
                 return dx, (dy if residual is not None else None)
             T.rec([y], [x if need_dx else None, residual], bwd)
@@ -608,6 +611,8 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
                     dkv_src[:, vo:vo + C_] = dv_rows.view(Mk, heads, hp)[:, :, :hd].reshape(Mk, C_)
                 ops.head_merge(dQ, dq_src[:, qo:qo + C_], B, heads, hp, S, d_src=hd)
                 ops.head_merge(dK, dkv_src[:, ko:ko + C_], B, heads, hp, Sk, d_src=hd)
+                if self._probe is not None:
+                    self._probe("attn", None, dict(qsrc=qsrc, kvsrc=kvsrc, O=O, dO=dO, dq_src=dq_src, dkv_src=dkv_src, heads=heads, B=B, S=S, Sk=Sk, self_attn=self_attn))
                 return (dq_src,) if self_attn else (dq_src, dkv_src)
             T.rec([O], [qsrc] if self_attn else [qsrc, kvsrc], bwd)
         return O

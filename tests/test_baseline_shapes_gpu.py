@@ -207,8 +207,8 @@ def test_flux_full_depth_step_matches_oracle():
     LoRA r32 on the default target set, B=1 — one train step (forward, flow-matching MSE, backward into the adapter factors of all 190 target projections) against the fp32
     restatement run at the same depth on the device's ATen kernels with per-block recomputation (oracle.flux.flux_forward(checkpoint=True)).
     What the two-block tests cannot see: error growth through 57 residual updates, the activation arena / segment bookkeeping at full depth, 57 blocks
-    of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 2e-2 and cosine >= 0.9995 (the stated §8(c) bound, also at full depth), |delta loss| <= 1e-3 x loss, every adapter gradient
-    rel-L2 <= 1e-1 with cosine >= 0.995 (bf16 storage of the residual stream over 57 blocks).  Measured r3: prediction rel-L2 1.73e-2, cosine 0.99985,
+    of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 2e-2 and cosine >= 0.9995 (the stated §8(c) bound, also at full depth; asserted in _check_step), |delta loss| <= 1e-3 x loss,
+    every adapter gradient rel-L2 <= 5e-2 with cosine >= 0.999 (the same bounds as the two-block test: no widening for depth).  Measured r3: prediction rel-L2 1.73e-2, cosine 0.99985,
     loss 3.030217 vs 3.030492, worst of the 380 adapter gradients 3.5e-2 (single block 31 to_k lora_A)."""
     from simpletuner_amd.flux.model import Flux
     from simpletuner_amd.training.trainer import St355Accelerator, default_config
@@ -233,8 +233,8 @@ def test_flux_full_depth_step_matches_oracle():
     P, lora, scale = PU.oracle_state(model, device=DEV)                                   # 12 B parameters in fp32 on the device: 48 GB of the 288
     o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu, checkpoint=True)
     assert len(o_grads) == len(lora) >= 19 * 4 + 38 * 3
-    _check_step("flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads, grad_tol=1e-1,
-                pred_tol=2e-2, cos_tol=0.995)
+    _check_step("flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads, grad_tol=5e-2,
+                pred_tol=2e-2, cos_tol=0.999)
 
 
 def test_sd3_full_width_step_matches_oracle():
@@ -278,10 +278,14 @@ def test_sd3_full_width_step_matches_oracle():
                 {k: (a.grad, b.grad) for k, (a, b) in lp.items()})
 
 
-@pytest.mark.parametrize("shape,lr,abs_tol,rel_tol", [("baseline-width", 1e-4, 1e-3, 1e-3), ("toy", 1e-4, 1.5e-3, 1e-3), ("toy", 1e-3, None, 2e-3)])
+@pytest.mark.parametrize("shape,lr,abs_tol,rel_tol", [("baseline-width", 1e-4, 1e-3, 1e-3), ("baseline-depth", 1e-4, 1e-3, 1e-3), ("toy", 1e-4, 1.5e-3, 1e-3),
+                                                      ("toy", 1e-3, None, 2e-3)])
 def test_flux_loss_curve_100_steps_matches_oracle_adamw(shape, lr, abs_tol, rel_tol):
     """north star / SURVEY.md §8(c): 100 optimizer steps on identical noise / timesteps, HIP (bf16 compute, fused fp32 AdamW over the flat adapter
     arena) vs oracle (fp32 autograd, torch.optim.AdamW).
+      * "baseline-depth", lr 1e-4 — BASELINE.json's Flux configuration at its real depth (19 double + 38 single blocks, D=3072, 4096 + 512 tokens, LoRA r32 on all
+        190 target projections, B=1), 20 optimizer steps; the oracle runs at the same depth on the device's fp32 ATen kernels with per-block recomputation
+        (oracle.flux.flux_forward(checkpoint=True)): |delta loss| <= 1e-3 ABSOLUTE at every step — the north-star criterion at the depth it is stated for.
       * "baseline-width", lr 1e-4 (the learning rate of the reference's Flux LoRA examples) — Flux.1-dev width and sequence (D=3072, 24x128 heads,
         4096 image + 512 text tokens, 1 double + 1 single block, LoRA r32, B=1), oracle on the device's ATen fp32 kernels: the north-star criterion as
         written, |delta loss| <= 1e-3 ABSOLUTE at every step.  A third curve — the same oracle under torch.autocast(bf16), i.e. the precision the
@@ -296,12 +300,16 @@ def test_flux_loss_curve_100_steps_matches_oracle_adamw(shape, lr, abs_tol, rel_
     from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
 
     dev = torch.device(DEV)
-    wide = shape == "baseline-width"
+    deep = shape == "baseline-depth"
+    wide = shape == "baseline-width" or deep
+    n_steps = 20 if deep else 100
     cfg = default_config(lora_rank=32 if wide else 8, train_batch_size=1 if wide else 2, seed=3, lora_init_b_std=0.02, learning_rate=lr,
                          flow_schedule_shift=3.0)
     acc = St355Accelerator(dev)
     plugin = Flux(cfg, acc)
-    if wide:
+    if deep:
+        plugin.load_model(guidance_embeds=True)                                              # every hyper-parameter = the Flux.1-dev default
+    elif wide:
         plugin.load_model(num_layers=1, num_single_layers=1, guidance_embeds=True)
     else:
         plugin.load_model(**PU.small_flux_cfg(layers=1, single=1))
@@ -329,26 +337,28 @@ def test_flux_loss_curve_100_steps_matches_oracle_adamw(shape, lr, abs_tol, rel_
         def step(self):
             self.opt.zero_grad()
             with torch.autocast("cuda" if wide else "cpu", dtype=BF16, enabled=self.autocast):
-                pred = PU.OF.flux_model_predict(P, ocfg, noisy, ins["prompt"], ins["pooled"], ins["sigmas"] * 1000.0, 1.0, lora=self.params, lora_scale=scale)
+                pred = PU.OF.flux_model_predict(P, ocfg, noisy, ins["prompt"], ins["pooled"], ins["sigmas"] * 1000.0, 1.0, lora=self.params, lora_scale=scale,
+                                                checkpoint=deep)
             l = ((pred.float() - target) ** 2).mean(dim=(1, 2, 3)).mean()
             l.backward(); self.opt.step()
             self.curve.append(l.item())
 
-    twins = [Twin(False)] + ([Twin(True)] if wide else [])
+    twins = [Twin(False)] + ([Twin(True)] if wide and not deep else [])
     batch = lambda: {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
     hip = []
-    for step in range(100):
+    for step in range(n_steps):
         hip.append(trainer.train_step(batch()))
         for t in twins:
             t.step()
     ora = twins[0].curve
     hip = [float(x) for x in torch.stack([h.reshape(()) for h in hip]).cpu()]
     d = [abs(a - b) for a, b in zip(hip, ora)]
-    print(f"[parity] {shape} 100-step loss curve hip   :", [round(x, 5) for x in hip[::10]], "...", round(hip[-1], 5))
-    print(f"[parity] {shape} 100-step loss curve oracle:", [round(x, 5) for x in ora[::10]], "...", round(ora[-1], 5))
+    stride = max(1, n_steps // 10)
+    print(f"[parity] {shape} {n_steps}-step loss curve hip   :", [round(x, 5) for x in hip[::stride]], "...", round(hip[-1], 5))
+    print(f"[parity] {shape} {n_steps}-step loss curve oracle:", [round(x, 5) for x in ora[::stride]], "...", round(ora[-1], 5))
     rel = [x / max(1e-6, abs(o)) for x, o in zip(d, ora)]
-    print(f"[parity] {shape} lr={lr:g}: max |delta loss| over 100 steps = {max(d):.3e} (at step {d.index(max(d))}), max relative = {max(rel):.3e}")
-    if wide:
+    print(f"[parity] {shape} lr={lr:g}: max |delta loss| over {n_steps} steps = {max(d):.3e} (at step {d.index(max(d))}), max relative = {max(rel):.3e}")
+    if len(twins) > 1:
         d16 = [abs(a - b) for a, b in zip(twins[1].curve, ora)]
         print(f"[parity] {shape} lr={lr:g}: the oracle under torch.autocast(bf16) (the reference's own training precision) vs the fp32 oracle: "
               f"max |delta loss| = {max(d16):.3e} (at step {d16.index(max(d16))})")

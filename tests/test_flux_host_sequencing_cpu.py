@@ -686,3 +686,67 @@ def test_block_entry_call_sites_build_their_arguments_on_the_default_path_and_st
         if expect:
             kw = seen[entry]
             assert kw["B"] == 2 and kw["D"] == model.D and all(v is None or isinstance(v, (int, float, torch.Tensor, list)) for v in kw.values()), sorted(kw)
+
+
+def test_rope_tables_follow_the_id_contents_not_the_tensor_address(monkeypatch):
+    """Two Kontext-shaped calls with the same token counts and different reference-image ids (a transposed position grid: what a 832x1216 reference image after a
+    1216x832 one looks like).  The tables must follow the contents: without a layout key they are computed from the ids every call (nothing cached), with a key the
+    cache is hit only for the layout the key names, and it stays bounded."""
+    model = _model(monkeypatch, 1, 1)
+    d = _inputs(1, 16, 16, 64)
+    a = OF.prepare_latent_image_ids(4, 16).clone(); a[:, 0] = 1.0
+    b = OF.prepare_latent_image_ids(16, 4).clone(); b[:, 0] = 1.0                     # same 16 tokens, transposed grid
+    ids_a, ids_b = torch.cat([d["img_ids"], a], 0), torch.cat([d["img_ids"], b], 0)
+    assert ids_a.shape == ids_b.shape and not torch.equal(ids_a, ids_b)
+
+    def oracle_tables(ids):
+        full = torch.cat([d["txt_ids"], ids], 0).double()
+        cs = []
+        for i, dim in enumerate(model.config.axes_dims_rope):
+            f = torch.outer(full[:, i], 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim)))
+            cs.append(f.cos().repeat_interleave(2, dim=1).float())
+        return torch.cat(cs, -1)
+
+    model._rope_layout_key = None
+    buf = ids_a.clone()
+    ca = model._rope(d["txt_ids"], buf)[0].clone()
+    buf.copy_(ids_b)                                                                  # same storage, same shape, new contents: the allocator-reuse case
+    cb = model._rope(d["txt_ids"], buf)[0].clone()
+    assert torch.equal(ca, oracle_tables(ids_a)) and torch.equal(cb, oracle_tables(ids_b)) and not torch.equal(ca, cb)
+    assert len(model._rope_cache) == 0
+    model._rope_layout_key = ("layout", "a")
+    assert torch.equal(model._rope(d["txt_ids"], ids_a)[0], ca) and len(model._rope_cache) == 1
+    assert model._rope(d["txt_ids"], ids_a)[0] is model._rope(d["txt_ids"], ids_a)[0]          # hit
+    model._rope_layout_key = ("layout", "b")
+    assert torch.equal(model._rope(d["txt_ids"], ids_b)[0], cb)
+    for i in range(3 * model._ROPE_CACHE_MAX):
+        model._rope_layout_key = ("layout", i)
+        model._rope(d["txt_ids"], ids_a)
+    assert len(model._rope_cache) <= model._ROPE_CACHE_MAX
+    model._rope_layout_key = None
+
+
+def test_flux_plugin_names_the_rope_layout_by_content():
+    """the plugin's layout key: latent grid + text length, plus a digest of the reference-image ids when they arrive on the host (never tensor identity)"""
+    from types import SimpleNamespace
+
+    import simpletuner_amd.flux.model as FM
+    m = FM.Flux.__new__(FM.Flux)
+    m.config, m.accelerator, m._ids_cache = SimpleNamespace(model_flavour="kontext"), SimpleNamespace(device=torch.device("cpu")), {}
+    keys = []
+    m.model = lambda **kw: (keys.append(kw["rope_layout_key"]), (torch.zeros(1, kw["hidden_states"].shape[1], 64, dtype=torch.bfloat16),))[1]
+    m.get_trained_component = lambda: SimpleNamespace(config=SimpleNamespace(guidance_embeds=False))
+    orig, orig_pack = FM._UnpackFn.apply, FM.pack_latents
+    FM._UnpackFn.apply = staticmethod(lambda packed, h, w: torch.zeros(packed.shape[0], 16, h // 8, w // 8))
+    FM.pack_latents = lambda x: x.reshape(x.shape[0], -1, 64)
+    try:
+        batch = {"noisy_latents": torch.randn(1, 16, 4, 4), "latents": torch.randn(1, 16, 4, 4), "timesteps": torch.tensor([500.0]),
+                 "prompt_embeds": torch.randn(1, 3, 16), "add_text_embeds": torch.randn(1, 8)}
+        m._model_predict_single(dict(batch))
+        ia, ib = torch.zeros(1, 2, 3), torch.zeros(1, 2, 3); ib[0, 1, 2] = 1.0
+        for ids in (ia, ib, ia.clone()):
+            m._model_predict_single(dict(batch, conditioning_packed_latents=torch.randn(1, 2, 64), conditioning_ids=ids))
+    finally:
+        FM._UnpackFn.apply, FM.pack_latents = orig, orig_pack
+    assert keys[0] == ("flux_ids", 4, 4, 3)
+    assert keys[1] != keys[2] and keys[1] == keys[3] and keys[1][:4] == keys[0] and all(k is not None for k in keys)

@@ -66,16 +66,10 @@ def test_flux_feed_forward_target_sets_match_oracle(which, layers, single, B, la
     _run(which, layers, single, B, lat_h, lat_w, S_txt, rank)
 
 
-@pytest.mark.skipif(os.environ.get("ST355_GPU_NOT_YET_RUN") != "1",
-                    reason="written after round 4's GPU budget was spent: the x_embedder adapter (K = 64 projection with a K-extension, P = 64 rank-space gradients) is checked "
-                           "on the CPU through the ops emulator only; ST355_GPU_NOT_YET_RUN=1 runs it — first GPU call of the next round")
 def test_flux_embedder_target_set_matches_oracle():
     _run("all+ffs+embedder", 1, 2, 2, 16, 16, 32)
 
 
-@pytest.mark.skipif(os.environ.get("ST355_GPU_NOT_YET_RUN") != "1",
-                    reason="written after round 4's GPU budget was spent: the modulation-Linear adapters (`ai-toolkit`: per-sample column sums into the modulation-row "
-                           "gradient, rank-space gradients over M = batch rows) are checked on the CPU through the ops emulator only; ST355_GPU_NOT_YET_RUN=1 runs it")
 @pytest.mark.parametrize("layers,single,B,lat,S_txt", [(2, 2, 2, 16, 32), (1, 1, 2, 32, 256)])
 def test_flux_ai_toolkit_target_set_matches_oracle(layers, single, B, lat, S_txt):
     _run("ai-toolkit", layers, single, B, lat, lat, S_txt)
