@@ -25,6 +25,7 @@ median / p95 / min / max of the per-step device timestamps; `--model sd15 | sdxl
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import math
 import os
@@ -44,7 +45,8 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip t
 # the rows of the reference's own benchmark sweep (documentation/experimental/SEGMENTED_CHECKPOINTING.md:795-805, example sd3.peft-lora:
 # SD3 LoRA r128 / alpha 128, 1024^2, train_batch_size 3, adamw_bf16, bf16; sec/step post-warm-up on ONE H100) that this bench can run as configured there:
 #   python bench.py --model sd3 --rank 128 --batch 3 [--gradient-checkpointing [--ckpt-interval 2 [--ckpt-stride 4]]]
-# (the example's optimizer is adamw_bf16 over bf16 adapters; the adapters here are an fp32 arena under the fused fp32 AdamW — 0.1 % of the step either way)
+# (the example's optimizer is adamw_bf16 over bf16 adapters: `--optimizer adamw_bf16` trains bf16 adapter values under the fused AdamWBF16 — the default line's
+# secondary runs the row that way and carries the fused-fp32-AdamW figure as a second field)
 PUBLISHED_SD3_LORA_R128_BS3 = {"none": 0.529, "layer": 0.721, "interval2": 0.723, "seg2-stride4": 0.620}
 
 
@@ -436,9 +438,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("ST355_COMM_TIMING", "1")      # GradSync brackets every bucket's collective with events on the comm stream: `comm` on the JSON line
         if os.environ.get("ST355_BENCH_SHARE_GPU") == "1":
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)   # nccl == RCCL over xGMI on ROCm
+            # nccl == RCCL over xGMI on ROCm; a collective that a peer never joins aborts after 10 minutes (the watchdog raises on every rank) instead of waiting forever
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree (n_gpus in the JSON line is the rank count)")
     if world > 1:
@@ -465,7 +468,9 @@ def main():
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
         a3 = copy.copy(args)
-        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
+        # one GPU: one captured step per aspect bucket, replayed (the eager step leaves ~4 % of the device idle between its ~1600 launches); N > 1 stays eager — there
+        # the gradient exchange overlaps the hand-written backward bucket by bucket, which a replayed graph followed by the exchange would give up
+        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, world == 1, True
         # Flux.1-dev FULL-rank (11.9 B bf16 parameters, AdamWBF16, per-GPU batch 8 — the configuration of the reference's multi-GPU Flux datapoint,
         # documentation/DISTRIBUTED.md:291-298): hand-written backward with every weight / bias / modulation / norm gradient, one fused optimizer launch over the
         # parameter arena, and at N > 1 the whole 24 GB bf16 gradient arena exchanged per step (fp32-accumulating reduce-scatter + all-gather buckets behind the
@@ -485,6 +490,7 @@ def main():
                 a_.steps, a_.warmup, a_.optimizer, a_.gradient_checkpointing, a_.ckpt_interval, a_.ckpt_stride = min(args.steps, 3), 1, "adamw_bf16", True, 3, 4
             if name == "sd3_lora_r128_bs3_published_row":
                 a_.steps, a_.warmup = max(min(args.steps, 8), 5), 3          # two eager steps precede the capture
+                a_.optimizer = "adamw_bf16"                                  # the example's optimizer (simpletuner/examples/sd3.peft-lora/config.json): like for like
             gc.collect()
             torch.cuda.empty_cache()              # the previous workload's cached blocks go back before the next one's pools are built
             try:                                  # a secondary must never take the headline line down with it (every rank runs the same code: they fail together)
@@ -494,6 +500,14 @@ def main():
                 if rank == 0:
                     out["secondary"][name] = {k: sec[k] for k in keys if k in sec}
                 del sec
+                if name == "sd3_lora_r128_bs3_published_row":             # second field: the same row under the fused fp32 AdamW over the fp32 adapter arena
+                    a6 = copy.copy(a_)
+                    a6.optimizer = "st355-adamw"
+                    gc.collect(); torch.cuda.empty_cache()
+                    sec = run_workload(a6, dev, rank, world)
+                    if rank == 0:
+                        out["secondary"][name]["same_row_under_fp32_adamw"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "vs_baseline", "loss") if k in sec}
+                    del sec
             except Exception as e:                # noqa: BLE001
                 if rank == 0:
                     out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"[:400]}
@@ -671,6 +685,9 @@ def run_workload(args, dev, rank, world):
     trace_loss = os.environ.get("ST355_BENCH_TRACE_LOSS") == "1"      # debugging aid: per-step loss (forces a host sync per step)
     if rank == 0:
         _log(f"{args.model}: model + batches built, {args.warmup} warm-up + {args.steps} timed steps")
+    if args.graph and args.buckets:            # one capture per bucket shape before the warm-up proper (each first encounter = 2 eager steps + capture + replay), untimed
+        for k_ in sorted(by_shape):
+            trainer.train_step(dict(by_shape[k_]))
     for i in range(args.warmup):
         l_ = trainer.train_step(dict(batches[i % nb_]))
         if trace_loss:
@@ -797,7 +814,7 @@ def run_workload(args, dev, rank, world):
         if pub is not None and world == 1:
             ref_ips = B / pub[1]
             out["vs_baseline"] = round(value / ref_ips, 3)
-            out["published"] = {"row": f"SD3 LoRA r128 1024^2 bs 3, bf16, checkpointing mode {pub[0]!r} (example sd3.peft-lora; its optimizer is adamw_bf16, here fp32 AdamW on an fp32 adapter arena)", "sec_per_step": pub[1],
+            out["published"] = {"row": f"SD3 LoRA r128 1024^2 bs 3, bf16, checkpointing mode {pub[0]!r} (example sd3.peft-lora, optimizer adamw_bf16; this run: optimizer {args.optimizer!r}" + (" — bf16 adapter values and bf16 gradients under the fused AdamWBF16, as in the example)" if args.optimizer == "adamw_bf16" else " — fused fp32 AdamW over the fp32 adapter arena, NOT the example's optimizer)"), "sec_per_step": pub[1],
                                 "images_per_s": round(ref_ips, 3), "hardware": "1x H100 (the reference's own sweep; BASELINE.md §1)",
                                 "source": "documentation/experimental/SEGMENTED_CHECKPOINTING.md:795-805", "this_run_sec_per_step": round(ms_per_step / 1e3, 4)}
         if args.model == "flux" and args.full:
@@ -830,5 +847,28 @@ def run_workload(args, dev, rank, world):
     return None
 
 
+def _guarded_main():
+    """a rank that fails must take the job down, never leave its peers waiting in a collective: print what failed (incl. the library's own last error), then exit
+    non-zero WITHOUT running finalisers (a process-group destructor can itself block on the peers); the launcher (torch.distributed.run) then stops the other ranks.
+    A rank that stops making progress is caught by the collective timeout set at init_process_group (below the driver's own limit)."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:          # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        last = ""
+        try:
+            from simpletuner_amd import lib as _lib
+            last = _lib.load().st355_last_error().decode("utf-8", "replace")
+        except Exception:               # noqa: BLE001
+            pass
+        print(f"[bench] rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} FAILED: {type(e).__name__}: {e}; st355_last_error: {last!r}",
+              file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(1)
+
+
 if __name__ == "__main__":
-    main()
+    _guarded_main()

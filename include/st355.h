@@ -268,7 +268,8 @@ int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const v
 /* ---- K7: joint non-causal attention over [txt || img] tokens ------------------------------- */
 /* O: [B,S,H*d] token-major bf16 (row stride ld_o elements); lse2: [B,H,S] fp32 (log2-domain logsumexp of
  * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
-/* Kernel choice for the head_dim-128, no-bias self-attention shapes (tuning / A-B hook).
+/* Kernel choice for the no-bias self-attention shapes (tuning / A-B hook): the forward choice applies at head_dim 128 and 96, the dq / dkv choices at
+ * head_dim 128, 96 and 64; every other shape (key bias, cross attention, row-major V) keeps the 32-query kernels whatever is set here.
  *   fwd: 64 = the hand-scheduled one-wave-per-SIMD forward where S % 64 == 0 (k_attn_fwd64: 64 queries per wave, stale-reference softmax; the scores are
  *        the same fp32 sums: O agrees with the 32-query kernel to bf16 rounding, lse2 to fp32 rounding), 32 = k_attn_fwd4;
  *   dq:  64 = k_attn_bwd_dq64 where Sk % 64 == 0 (bit-identical to the 32-query k_attn_bwd_dq), 32 = the latter everywhere;
@@ -616,6 +617,18 @@ int st355_attn_cross_fwd(void* stream, const void* Q, const void* K, const void*
 int st355_attn_cross_bwd(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows, int64_t ld_v, const void* O,
                          int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, void* dQ, void* dK, void* dv_rows,
                          int64_t ld_dv, int B, int H, int Sq, int Sqp, int Sk, int Skp, int d, float scale, void* workspace);
+
+/* The same two pairs with the ROUNDING RESIDUAL of the attention output: the forward also writes O_res = bf16(O_fp32 - O) (O's layout and ld_o), the backward takes
+ * delta = rowsum(dO * (O + O_res)).  Flash-style backwards (this one, and the SDPA kernels the reference trains through on a GPU:
+ * helpers/models/sdxl / sd1x -> diffusers Attention -> F.scaled_dot_product_attention) read delta from the bf16 output; the inconsistency dO.(O_fp32 - O) enters every
+ * dS row and is multiplied by the common component of K (dQ) / Q (dK) over tokens, which exact arithmetic cancels.  Where projections follow a LayerNorm with a large
+ * common component (the UNet families' attn1: 0.97 of the row norm at SDXL's 32^2 level) that is a 0.26 rel-L2 error of dQ against the fp32 oracle; with the residual
+ * the backward sits at bf16 rounding (profiles/r05_sdxl_lora_outlier_probe.log).  Self-attention: Sq = Sk, Sqp = Skp.  The forward runs k_attn_fwd4 for every shape. */
+int st355_attn_fwd_res(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O, int64_t ld_o, void* O_res, float* lse2,
+                       int B, int H, int Sq, int Sk, int Skp, int d, float scale);
+int st355_attn_bwd_res(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows, int64_t ld_v, const void* O,
+                       int64_t ld_o, const void* O_res, const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, void* dQ, void* dK,
+                       void* dv_rows, int64_t ld_dv, int B, int H, int Sq, int Sqp, int Sk, int Skp, int d, float scale, void* workspace);
 
 /* ---- workspace sizing: one query for every op that takes caller-provided scratch (the library never allocates).  dims per op:
  *   ATTN_BWD {B, H, Sq, Sqp, d}   COLSUM {rows, N, rows_per_batch}   SKINNY_TN {M, P, R}   GROUPNORM {B, H, W, C}   LAYERNORM_PARAM_GRADS {D}

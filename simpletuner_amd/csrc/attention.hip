@@ -43,7 +43,7 @@ template <int HD, bool BIAS, bool VROW = false>
 __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ Vt, const float* __restrict__ key_bias,
                                                       bf16* __restrict__ O, int64_t ld_o, float* __restrict__ lse2, int H,
-                                                      int Sq, int S, int Sp, float scale2) {
+                                                      int Sq, int S, int Sp, float scale2, bf16* __restrict__ Ores = nullptr) {
   static_assert(!VROW || HD == 128, "row-major V is built for head_dim 128");
   constexpr int NW = 4;
   constexpr int KROWB = HD * 2;
@@ -248,6 +248,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd4(const bf16* __restrict__ Q
 #pragma unroll
         for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc_o[dt][4 * a + bb] * inv);
         *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
+        if (Ores) {     // the rounding residual of O (st355_attn_fwd_res): O + Ores carries 16 mantissa bits of the fp32 output for the backward's delta = rowsum(dO * O)
+          bf16x4 r;
+#pragma unroll
+          for (int bb = 0; bb < 4; bb++) r[bb] = f2bf(acc_o[dt][4 * a + bb] * inv - bf2f(o[bb]));
+          *(bf16x4*)(Ores + (orow - O) + 32 * dt + 8 * a + 4 * h) = r;
+        }
       }
     if (h == 0) lse2[bh * Sq + q] = m_run + __log2f(l_tot);
   }
@@ -357,7 +363,7 @@ static int attn_fwd_impl64() {
 
 // vrow != 0: Vt is the ROW-major V (token rows, head h at columns h*d) and Sp its leading dimension (k_attn_fwd4<128, *, true>)
 static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O,
-                         int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale, int vrow = 0) {
+                         int64_t ld_o, float* lse2, int B, int H, int Sq, int S, int Sp, int d, float scale, int vrow = 0, void* O_res = nullptr) {
   ST_REQUIRE(Q && K && Vt && O && lse2, "attn_fwd: null pointer");
   ST_REQUIRE(B > 0 && H > 0 && S > 0 && Sq > 0 && ld_o % 4 == 0 && (vrow ? (Sp % 8 == 0 && Sp >= H * d && d == 128) : (Sp % 64 == 0 && Sp >= S)),
              "attn_fwd: bad shape S=%d Sp(ld_v)=%d", S, Sp);
@@ -369,13 +375,13 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   // k_attn_fwd4 (r02) is the general kernel; k_attn_fwd64 (r04) takes the head_dim-128, no-bias, S % 64 == 0 shapes.  The r01 kernel lives on in
   // tools/attn_fwd_variants.hip as the lab's A/B baseline (r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s).  Measured and deleted in r02: an 8-wave /
   // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/r02_attn_lab_*.log.
-  if (!vrow && !key_bias && (d == 128 || d == 96) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
+  if (!vrow && !key_bias && !O_res && (d == 128 || d == 96) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
     dim3 grid64((Sq + 255) / 256, H, B);
     const int lds64 = 4 * 2 * 64 * 256;
 #define ST355_FWD64_LAUNCH(HD_)                                                                                                           \
   do {                                                                                                                                   \
-    static bool set64 = false;                                                                                                           \
-    if (!set64) { hipFuncSetAttribute((const void*)k_attn_fwd64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64); set64 = true; } \
+    static St355AttrOnce set64;                                                                                                           \
+    if (set64.need()) { hipFuncSetAttribute((const void*)k_attn_fwd64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64); } \
     hipLaunchKernelGGL(k_attn_fwd64<HD_>, grid64, dim3(256), lds64, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, ld_o, lse2, \
                        H, Sq, S, Sp, scale2, g_attn_fwd_trace);                                                                          \
   } while (0)
@@ -388,10 +394,10 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   const int lds = 2 * (KB * d * 2 + d * 128);
 #define ST355_FWD_LAUNCH(KERN)                                                                                                           \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }                 \
     hipLaunchKernelGGL((KERN), grid, block, lds, (hipStream_t)stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, key_bias,         \
-                       (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2);                                                                     \
+                       (bf16*)O, ld_o, lse2, H, Sq, S, Sp, scale2, (bf16*)O_res);                                                       \
   } while (0)
   if (vrow) {
     if (key_bias) ST355_FWD_LAUNCH((k_attn_fwd4<128, true, true>));
@@ -416,6 +422,15 @@ extern "C" int st355_attn_fwd_vrows(void* stream, const void* Q, const void* K, 
                                     int64_t ld_o, float* lse2, int B, int H, int S, int d, float scale) {
   ST_REQUIRE(ld_v > 0 && ld_v < ((int64_t)1 << 31), "attn_fwd_vrows: bad ld_v");
   return attn_fwd_impl(stream, Q, K, v_rows, key_bias, O, ld_o, lse2, B, H, S, S, (int)ld_v, d, scale, 1);
+}
+// st355_attn_fwd / st355_attn_cross_fwd that ALSO write the rounding residual of the output, O_res = bf16(O_fp32 - O) in O's layout (same ld_o): the backward's
+// delta = rowsum(dO * O) is then taken from O + O_res (st355_attn_bwd_res).  With O alone every dS row carries the error P_ij * dO_i.(O_fp32 - O)_i, which the
+// dQ = dS K and dK = dS^T Q products multiply by the COMMON component of K / Q over tokens — exact arithmetic cancels that component (sum_j dS_ij = 0); measured on the
+// SDXL UNet's 32^2 self-attention (LayerNorm outputs with |mean_j x_j| / rms |x_j| = 0.97): dQ rel-L2 0.26 -> profiles/r05_sdxl_lora_outlier_probe.log
+extern "C" int st355_attn_fwd_res(void* stream, const void* Q, const void* K, const void* Vt, const float* key_bias, void* O, int64_t ld_o, void* O_res,
+                                  float* lse2, int B, int H, int Sq, int Sk, int Skp, int d, float scale) {
+  ST_REQUIRE(O_res, "attn_fwd_res: null residual pointer");
+  return attn_fwd_impl(stream, Q, K, Vt, key_bias, O, ld_o, lse2, B, H, Sq, Sk, Skp, d, scale, 0, O_res);
 }
 // cross-attention (UNet attn2 over the 77 text tokens, PixArt cross-attention): Sq queries [B,H,Sq,d] against Sk keys [B,H,Sk,d], Vt [B,H,d,Skp];
 // O: [B*Sq, ld_o] token-major, lse2 [B,H,Sq]; key_bias [B,Sk] additive or NULL

@@ -25,7 +25,8 @@ __device__ __forceinline__ int swz_q(int q) { return ((q & 3) << 2) | ((q >> 2) 
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ O, int64_t ld_o, const bf16* __restrict__ dO,
                                                       int64_t ld_do, const float* __restrict__ lse2, float* __restrict__ delta,
-                                                      float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp, float lse_mul) {
+                                                      float* __restrict__ lsep, bf16* __restrict__ dOt, int H, int S, int Sp, float lse_mul,
+                                                      const bf16* __restrict__ Ores = nullptr) {
   constexpr int TPR = (HD / 8 <= 8) ? 8 : 16;          // lanes per token (power of two; head_dim 96 leaves 4 of 16 idle)
   constexpr int TOK_PER_PASS = 256 / TPR;
   __shared__ __attribute__((aligned(16))) bf16 tile[64 * TPB];
@@ -49,6 +50,13 @@ __global__ void __launch_bounds__(256) k_attn_bwd_prep(const bf16* __restrict__ 
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; j++) s += bf2f(ov[j]) * bf2f(gv[j]);
+    if (Ores && cact) {          // + dO . (O_fp32 - O): delta from the un-rounded attention output (st355_attn_bwd_res)
+      const bf16x8 rv = *(const bf16x8*)(Ores + ((int64_t)b * S + tt) * ld_o + (int64_t)head * HD + c * 8);
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) s2 += bf2f(rv[j]) * bf2f(gv[j]);
+      s += s2;
+    }
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (c == 0) {   // stats are written in the padded [B*H, Sp] layout: padded queries get delta 0 and lse +inf (=> P = 0)
@@ -829,7 +837,11 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dkv4(const bf16* __restrict
       );
     } else if constexpr (HD == 96) {
       asm volatile(
+#ifdef ST355_DKV4_HD96_BODY_INC
+#include ST355_DKV4_HD96_BODY_INC
+#else
 #include "gen/attn_dkv4_hd96_body.inc"
+#endif
           ST355_DKV4_OPERANDS
 #include "gen/attn_dkv4_clobbers.inc"
       );
@@ -945,7 +957,11 @@ __global__ void __launch_bounds__(256, 1) k_attn_bwd_dq64(const bf16* __restrict
       );
     } else if constexpr (HD == 96) {
       asm volatile(
+#ifdef ST355_DQ64_HD96_BODY_INC
+#include ST355_DQ64_HD96_BODY_INC
+#else
 #include "gen/attn_dq64_hd96_body.inc"
+#endif
           ST355_DQ64_OPERANDS
 #include "gen/attn_dq64_clobbers.inc"
       );
@@ -1010,7 +1026,7 @@ extern "C" int st355_attn_set_impl(int fwd, int dq, int dkv) {
 static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows,
                               int64_t ld_v, const void* O, int64_t ld_o, const void* dO, int64_t ld_do, const float* lse2,
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp, int Sk, int Skp,
-                              int d, float scale, void* workspace, const RopeBwd* rope_q = nullptr, const RopeBwd* rope_k = nullptr) {
+                              int d, float scale, void* workspace, const RopeBwd* rope_q = nullptr, const RopeBwd* rope_k = nullptr, const void* O_res = nullptr) {
   const RopeBwd rq = rope_q ? *rope_q : RopeBwd{}, rk = rope_k ? *rope_k : RopeBwd{};       // out == NULL: head-major dQ / dK as before
   ST_REQUIRE(Q && K && v_rows && O && dO && lse2 && (dQ || rq.out) && (dK || rk.out) && dv_rows && workspace, "attn_bwd: null pointer");
   // Qt == NULL selects the third-generation dK/dV kernel, Kt == NULL the transposing-read dQ kernel (head_dim 128): Q^T / dO^T / K^T fragments come
@@ -1033,11 +1049,11 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     dim3 grid(Sp / 64, H, B);
     const float lse_mul = use_dkv4 ? 1.f / scale2 : 1.f;
     if (d == 96)
-      hipLaunchKernelGGL(k_attn_bwd_prep<96>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
+      hipLaunchKernelGGL(k_attn_bwd_prep<96>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul, (const bf16*)O_res);
     else if (d == 128)
-      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
+      hipLaunchKernelGGL(k_attn_bwd_prep<128>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul, (const bf16*)O_res);
     else
-      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul);
+      hipLaunchKernelGGL(k_attn_bwd_prep<64>, grid, dim3(256), 0, st, (const bf16*)O, ld_o, (const bf16*)dO, ld_do, lse2, delta, lsep, dOt, H, S, Sp, lse_mul, (const bf16*)O_res);
     if ((rc = st355_check_launch("attn_bwd_prep")) != 0) return rc;
   }
   {
@@ -1047,8 +1063,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       const int lds = 8 * 16384;                                       // the two ring slots (66.5 KiB); 16 KiB per wave for the parked dK / dV rows
 #define ST355_DKV4_LAUNCH(HD_)                                                                                                            \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv4<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv4<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }   \
     hipLaunchKernelGGL(k_attn_bwd_dkv4<HD_>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do,  \
                        (const float*)lsep, (const float*)delta, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, scale, scale2, rk);      \
   } while (0)
@@ -1061,8 +1077,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       const int lds = 2 * (2 * 64 * 256 + 512);
 #define ST355_DKV3_LAUNCH(HD_)                                                                                                            \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)k_attn_bwd_dkv3<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }   \
     hipLaunchKernelGGL(k_attn_bwd_dkv3<HD_>, grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v,        \
                        (const bf16*)dO, ld_do, (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK, (bf16*)dv_rows, ld_dv, H, S,  \
                        Sp, Sk, scale, scale2, rk);                                                                                        \
@@ -1076,8 +1092,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
       const int lds = 2 * (2 * 64 * d * 2 + 2 * d * 128 + 512);
 #define ST355_DKV2_LAUNCH(KERN)                                                                                                          \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }                 \
     hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Qt, (const bf16*)v_rows, ld_v,     \
                        (const bf16*)dO, ld_do, (const bf16*)dOt, (const float*)lsep, (const float*)delta, key_bias, (bf16*)dK,           \
                        (bf16*)dv_rows, ld_dv, H, S, Sp, Sk, Skp, scale, scale2);                                                        \
@@ -1095,8 +1111,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     const int lds = 3 * 2 * 64 * 256;
 #define ST355_DQ64_LAUNCH(HD_)                                                                                                            \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)k_attn_bwd_dq64<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }   \
     hipLaunchKernelGGL(k_attn_bwd_dq64<HD_>, grid, dim3(256), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)v_rows, ld_v, (const bf16*)dO, ld_do, lse2, \
                        (const float*)delta, (bf16*)dQ, H, S, Sp, Sk, scale, scale2, rq, g_attn_dq_trace);                                \
   } while (0)
@@ -1113,8 +1129,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     const int lds = 2 * ((tr ? 64 * 256 : ktb) + ktb + (tr ? 0 : d * 128));
 #define ST355_DQ_LAUNCH(KERN)                                                                                                            \
   do {                                                                                                                                   \
-    static bool set = false;                                                                                                             \
-    if (!set) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }                 \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }                 \
     hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, (const bf16*)Q, (const bf16*)K, (const bf16*)Kt, (const bf16*)v_rows, ld_v,     \
                        (const bf16*)dO, ld_do, lse2, (const float*)delta, key_bias, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2, rq);    \
   } while (0)
@@ -1142,6 +1158,14 @@ extern "C" int st355_attn_bwd(void* stream, const void* Q, const void* K, const 
                               const float* key_bias, void* dQ, void* dK, void* dv_rows, int64_t ld_dv, int B, int H, int S, int Sp,
                               int d, float scale, void* workspace) {
   return attn_bwd_impl(stream, Q, K, Qt, Kt, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, dQ, dK, dv_rows, ld_dv, B, H, S, Sp, S, Sp, d, scale, workspace);
+}
+// st355_attn_bwd / st355_attn_cross_bwd with delta = rowsum(dO * (O + O_res)): O_res is what st355_attn_fwd_res wrote (attention.hip has the why)
+extern "C" int st355_attn_bwd_res(void* stream, const void* Q, const void* K, const void* Qt, const void* Kt, const void* v_rows, int64_t ld_v, const void* O,
+                                  int64_t ld_o, const void* O_res, const void* dO, int64_t ld_do, const float* lse2, const float* key_bias, void* dQ, void* dK,
+                                  void* dv_rows, int64_t ld_dv, int B, int H, int Sq, int Sqp, int Sk, int Skp, int d, float scale, void* workspace) {
+  ST_REQUIRE(O_res, "attn_bwd_res: null residual pointer");
+  return attn_bwd_impl(stream, Q, K, Qt, Kt, v_rows, ld_v, O, ld_o, dO, ld_do, lse2, key_bias, dQ, dK, dv_rows, ld_dv, B, H, Sq, Sqp, Sk, Skp, d, scale, workspace,
+                       nullptr, nullptr, O_res);
 }
 // Self-attention backward with the RoPE + RMSNorm backward fused into the dQ / dK epilogues (head_dim 128, the fused-projection form): dq, dk and dv all
 // land in the rows of the projection gradient dqkv [B*S, ld] (column blocks q | k | v of width D = H*128); no head-major dQ / dK exists.

@@ -133,4 +133,10 @@ struct ProfScope {
     }                                        \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: one flag per (launch site, device), so a process that launches on a second GPU
+// sets it there too (a single process-wide flag would skip it and the launch would fail)
+struct St355AttrOnce {
+  bool done[32] = {};
+  bool need() { int d = 0; if (hipGetDevice(&d) != hipSuccess) return true; d &= 31; if (done[d]) return false; done[d] = true; return true; }
+};
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

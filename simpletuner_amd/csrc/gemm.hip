@@ -1567,8 +1567,8 @@ static double gemm_bytes(const st355_gemm_args* a) {
 
 template <int EPI>
 static int launch_s2(void* stream, const GemmP& p) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); }
   const int nbm = (p.M + S2_BM - 1) / S2_BM, nbn = (p.N + S2_BN - 1) / S2_BN;
   hipLaunchKernelGGL(k_gemm_s2<EPI>, dim3(nbm * nbn), dim3(S2_THREADS), S2_LDS, (hipStream_t)stream, p);
   return st355_check_launch("gemm_s2");
@@ -1576,8 +1576,8 @@ static int launch_s2(void* stream, const GemmP& p) {
 
 template <int EPI>
 static int launch_p3(void* stream, const GemmGroup& g, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_p3<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_p3<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS); }
   hipLaunchKernelGGL(k_gemm_p3<EPI>, dim3(tiles), dim3(P3_THREADS), P3_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_p3");
 }
@@ -1585,15 +1585,15 @@ static int launch_p3(void* stream, const GemmGroup& g, int tiles) {
 template <int EPI>
 static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
   constexpr int lds = PQ_LDS + (EPI == ST355_EPI_QK_NORM_ROPE ? QKR_XCHG : 0);        // + the half-head sum exchange of the fused q/k epilogue
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
   hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), lds, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq");
 }
 template <int EPI>
 static int launch_pq_conv(void* stream, const GemmGroup& g, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); }
   hipLaunchKernelGGL((k_gemm_pq<EPI, false, false, true>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq_conv");
 }
@@ -1657,8 +1657,8 @@ static bool pz_ok(const GemmP& p, int tiles) {
 }
 template <int EPI>
 static int launch_pz(void* stream, const GemmP& p, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pz<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PZ_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pz<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PZ_LDS); }
   const int wgs = tiles < device_cus() ? tiles : device_cus();
   hipLaunchKernelGGL((k_gemm_pz<EPI>), dim3(wgs), dim3(PQ_THREADS), PZ_LDS, (hipStream_t)stream, p, tiles);
   return st355_check_launch("gemm_pz");
@@ -1680,8 +1680,8 @@ static int launch_256(void* stream, const GemmGroup& g, int tiles) {
   }
 
 static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int ksplit) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); }
   p.partial = (float*)a->workspace; p.ksplit = ksplit;
   const int tiles = ((p.M + S2_BM - 1) / S2_BM) * ((p.N + S2_BN - 1) / S2_BN);
   hipLaunchKernelGGL(k_gemm_s2<EPI_SPLITK>, dim3(tiles * ksplit), dim3(S2_THREADS), S2_LDS, (hipStream_t)stream, p);
@@ -1760,8 +1760,8 @@ extern "C" int st355_linear_fp8(void* stream, const void* xq, int64_t ldx, const
   g.p[0] = p; g.p[1] = p;
   g.tiles0 = ((M + PQ_BM - 1) / PQ_BM) * ((N + PQ_BN - 1) / PQ_BN);
   ProfScope ps(stream, ST355_K_GEMM, 2.0 * (double)M * N * K, (double)M * K + (double)N * K + 2.0 * (double)M * N, "F8 %dx%dx%d", M, N, K);
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<ST355_EPI_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<ST355_EPI_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); }
   hipLaunchKernelGGL((k_gemm_pq<ST355_EPI_NONE, false, true>), dim3(g.tiles0), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("linear_fp8");
 }
@@ -1769,8 +1769,8 @@ extern "C" int st355_linear_fp8(void* stream, const void* xq, int64_t ldx, const
 // ---- weight-gradient form -------------------------------------------------------------------------------------------------------
 template <int EPI>
 static int launch_tn(void* stream, const GemmGroup& g, int tiles) {
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); }
   hipLaunchKernelGGL((k_gemm_pq<EPI, true>), dim3(tiles), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
   return st355_check_launch("gemm_tn");
 }
@@ -1803,8 +1803,8 @@ static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R,
   if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * taps * 4 <= workspace_bytes) {
     g.p[0].partial = (float*)workspace; g.p[0].ksplit = ks; g.p[0].aux_in = nullptr;
     g.p[1] = g.p[0];
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI_SPLITK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); attr_set = true; }
+    static St355AttrOnce attr_set;
+    if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI_SPLITK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); }
     hipLaunchKernelGGL((k_gemm_pq<EPI_SPLITK, true>), dim3(g.tiles0 * ks), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
     int rc = st355_check_launch("gemm_tn_splitk");
     if (rc) return rc;
@@ -1911,6 +1911,31 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
         }
         i += 2;
         continue;
+      }
+      // a small partner that pushes a well-quantised problem into one more round of 256x256 tiles (SD3-Medium at batch 8: 768 image tiles = 3.0 rounds over 256 CUs,
+      // + 48 text tiles = 4 rounds at 80 %): the partner alone runs on the 128x128 schedule in about half a round — two launches, the big one on the persistent
+      // schedule where it qualifies.  Cost in 256x256 tile-times of this K: grouped ceil((t0 + t1) / CUs); apart ceil(t0 / CUs) + 0.5 * ceil(t1_128 / (2 CUs)) + 0.1.
+      // Every problem's result is independent of the grouping (same kernels' tiles, same summation order per output element within a schedule).
+      {
+        static int ungroup = -1;
+        if (ungroup < 0) { const char* e = getenv("ST355_GEMM_UNGROUP"); ungroup = (e && e[0] == '0') ? 0 : 1; }      // A/B: 0 = always share one grid
+        const int cus = device_cus(), t0 = g.tiles0, t1 = tiles - g.tiles0;
+        const GemmP& q1 = g.p[1];
+        if (ungroup && t1 < min_tiles_256() && t0 >= cus) {
+          const int t128 = ((q1.M + S2_BM - 1) / S2_BM) * ((q1.N + S2_BN - 1) / S2_BN);
+          const double grouped = (double)((t0 + t1 + cus - 1) / cus);
+          const double apart = (double)((t0 + cus - 1) / cus) + 0.5 * (double)((t128 + 2 * cus - 1) / (2 * cus)) + 0.1;
+          if (apart + 0.15 < grouped) {
+            for (int k = 0; k < 2; k++) {
+              ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i + k]), gemm_bytes(&args[i + k]), "%dx%dx%d+%d e%d u", args[i + k].M, args[i + k].N, args[i + k].K,
+                           args[i + k].K2, args[i + k].epilogue);
+              int rc = run_one(stream, &args[i + k]);
+              if (rc) return rc;
+            }
+            i += 2;
+            continue;
+          }
+        }
       }
       if (tiles >= min_tiles_256()) {
         ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),

@@ -1260,9 +1260,12 @@ class FluxTransformer2DModel(nn.Module):
         keep_of = lambda info: info.keep_i32()
         for (s0, n, ck) in reversed(ctx.segs_s):
             if ck:
+                # a segment that straddles the stop block: blocks below it are re-run (their outputs feed the ones above) but keep nothing — the backward returns at `stop`
                 xr = ctx.ck_s.pop(s0)
                 for bi in range(s0, s0 + n):
-                    xr, ctx.sgl[bi] = self._single_fwd(bi, xr, ctx.env_s[bi], True)
+                    xr, sv = self._single_fwd(bi, xr, ctx.env_s[bi], nd + bi >= stop)
+                    if nd + bi >= stop:
+                        ctx.sgl[bi] = sv
                 del xr
             for li in range(s0 + n - 1, s0 - 1, -1):
                 g, e = nd + li, ctx.env_s[li]
@@ -1273,6 +1276,7 @@ class FluxTransformer2DModel(nn.Module):
                     dxg = None
                 dx, dxg, d_txt, d_img = self._single_bwd(li, ctx.sgl.pop(li), dx, dxg, e)
                 if g == stop and g > 0:
+                    ctx.sgl.clear(); ctx.dbl.clear(); ctx.ck_s.clear(); ctx.ck_d.clear()
                     return None
                 if g in ctx.route_start:
                     if dx is None:                               # single block 0 under double blocks: its input gradient came back stream-major
@@ -1291,7 +1295,9 @@ class FluxTransformer2DModel(nn.Module):
             if ck:
                 ir, tr = ctx.ck_d.pop(s0)
                 for bi in range(s0, s0 + n):
-                    ir, tr, _, ctx.dbl[bi] = self._double_fwd(bi, ir, tr, ctx.env_d[bi], True)
+                    ir, tr, _, sv = self._double_fwd(bi, ir, tr, ctx.env_d[bi], bi >= stop)
+                    if bi >= stop:
+                        ctx.dbl[bi] = sv
                 del ir, tr
             for li in range(s0 + n - 1, s0 - 1, -1):
                 e = ctx.env_d[li]
@@ -1300,6 +1306,7 @@ class FluxTransformer2DModel(nn.Module):
                     d_img = ops.gather_rows(d_full, keep_of(ctx.route_end[li])).view(-1, D)
                 d_img, d_txt = self._double_bwd(li, ctx.dbl.pop(li), d_img, d_txt, e)
                 if li == stop and li > 0:
+                    ctx.dbl.clear(); ctx.ck_d.clear()
                     return None
                 if li in ctx.route_start and d_img is not None:
                     ops.scatter_rows(d_img.view(B, e.Si, D), keep_of(ctx.route_start[li]), d_full)

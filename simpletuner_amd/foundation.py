@@ -453,6 +453,15 @@ class ModelFoundation(ExplorativeModelingMixin):
         """common.py:2131"""
         return None
 
+    def post_model_load_setup(self):
+        """common.py:3638 / 6704 (ImageModelFoundation).  The reference attaches its representation-alignment regularisers here (LayerSync, internal guidance,
+        NextLat, CREPA / U-REPA: hooks into a diffusers module's blocks).  None of them is built on the st355 path: asking for one is refused, otherwise there is
+        nothing to set up — defined here so that a reference flow calling it never reaches the reference's regulariser initialisers through the MRO."""
+        for flag in ("crepa_enabled", "irepa_enabled", "urepa_enabled", "layersync_enabled", "internal_guidance_enabled", "nextlat_enabled"):
+            if getattr(self.config, flag, False):
+                raise NotImplementedError(f"{flag}: representation-alignment regularisers hook diffusers modules and are not built on the st355 path")
+        return None
+
     def post_quantization_setup(self):
         """common.py:3650"""
         return None

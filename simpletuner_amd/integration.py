@@ -70,6 +70,8 @@ def plugin_class(family: str, ref_foundation: Optional[type] = None, ref_family:
 REFERENCE_MEMBERS_OK = frozenset({
     "_format_text_embedding", "_encode_prompts", "convert_text_embed_for_pipeline", "convert_negative_text_embed_for_pipeline", "update_pipeline_call_kwargs",
     "pretrained_load_args", "get_pipeline", "_load_pipeline", "setup_model_flavour", "custom_model_card_schedule_info", "custom_model_card_code_example",
+    # helpers that only read the component's `config` (PixArt: the kwargs its reference `_load_pipeline` builds, the latent sequence length)
+    "_pixart_from_pretrained_kwargs", "_latent_sequence_length",
 })
 
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     "st355_upsample2x", "st355_upsample2x_bwd", "st355_tokens_to_grid", "st355_grid_to_tokens",
     "st355_groupnorm_workspace", "st355_groupnorm_fwd", "st355_groupnorm_bwd",
     "st355_layernorm_fwd", "st355_layernorm_bwd", "st355_layernorm_param_grads_workspace", "st355_layernorm_param_grads",
-    "st355_geglu_fwd", "st355_geglu_bwd", "st355_head_split", "st355_head_merge", "st355_head_split_pad", "st355_head_merge_pad", "st355_softmax_rows_bwd", "st355_attn_cross_fwd", "st355_attn_cross_bwd",
+    "st355_geglu_fwd", "st355_geglu_bwd", "st355_head_split", "st355_head_merge", "st355_head_split_pad", "st355_head_merge_pad", "st355_softmax_rows_bwd", "st355_attn_cross_fwd", "st355_attn_cross_bwd", "st355_attn_fwd_res", "st355_attn_bwd_res",
 ]
 
 KERNEL_CLASSES = [
@@ -359,6 +359,9 @@ def _declare(lib):
         "st355_attn_cross_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, f32]),
         "st355_attn_cross_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64,
                                             i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+        "st355_attn_fwd_res": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, f32]),
+        "st355_attn_bwd_res": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64,
+                                          i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

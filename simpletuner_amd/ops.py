@@ -661,10 +661,21 @@ def qk_rope_norm_bwd(dQ, dK, Q, K, rrms, wq, wk, cos, sin, dqkv, B, H, d, S_part
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale: float, key_bias=None):
-    """O: 2-D token-major view [B*S, >=H*d]; lse2 [B,H,S] fp32."""
+def _res_ok(O, O_res):
+    _chk(O_res, BF16, "O_res")
+    if O_res.shape != O.shape or _rows(O_res, "O_res") != _rows(O, "O"):
+        raise _l.St355Error("attention: O_res must have O's shape and row stride")
+
+
+def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale: float, key_bias=None, O_res=None):
+    """O: 2-D token-major view [B*S, >=H*d]; lse2 [B,H,S] fp32.  O_res (same layout): also write the rounding residual bf16(O_fp32 - O) for attn_bwd(O_res=...)."""
     L = _l.load()
     _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    if O_res is not None:
+        _res_ok(O, O_res)
+        _l.check(L.st355_attn_fwd_res(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(O_res), _ptr(lse2),
+                                      B, H, S, S, Sp, d, scale), "attn_fwd_res")
+        return
     _l.check(L.st355_attn_fwd(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(lse2),
                               B, H, S, Sp, d, scale), "attn_fwd")
 
@@ -684,7 +695,7 @@ _attn_ws = {}
 ATTN_TR = os.environ.get("ST355_ATTN_TR", "1") != "0"
 
 
-def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale: float, key_bias=None):
+def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale: float, key_bias=None, O_res=None):
     L = _l.load()
     need = L.st355_attn_bwd_workspace(B, H, S, Sp, d)
     key = (Q.device.index,)
@@ -692,6 +703,12 @@ def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
         _attn_ws[key] = ws
+    if O_res is not None:          # delta = rowsum(dO * (O + O_res))
+        _res_ok(O, O_res)
+        _l.check(L.st355_attn_bwd_res(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
+                                      _ptr(O), _rows(O, "O"), _ptr(O_res), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
+                                      _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, S, Sp, S, Sp, d, scale, _ptr(ws)), "attn_bwd_res")
+        return
     _l.check(L.st355_attn_bwd(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
                               _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
                               _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, S, Sp, d, scale, _ptr(ws)),
@@ -1252,14 +1269,19 @@ def head_merge(dX, dst, B: int, H: int, d: int, S: int, d_src: Optional[int] = N
     return dst
 
 
-def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale: float, key_bias=None):
+def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale: float, key_bias=None, O_res=None):
     L = _l.load()
     _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
+    if O_res is not None:
+        _res_ok(O, O_res)
+        _l.check(L.st355_attn_fwd_res(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(O_res), _ptr(lse2),
+                                      B, H, Sq, Sk, Skp, d, scale), "attn_fwd_res")
+        return
     _l.check(L.st355_attn_cross_fwd(_stream(), _ptr(Q), _ptr(K), _ptr(Vt), _ptr(key_bias), _ptr(O), _rows(O, "O"), _ptr(lse2),
                                     B, H, Sq, Sk, Skp, d, scale), "attn_cross_fwd")
 
 
-def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale: float, key_bias=None):
+def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale: float, key_bias=None, O_res=None):
     L = _l.load()
     need = L.st355_attn_bwd_workspace(B, H, Sq, Sqp, d)
     key = (Q.device.index,)
@@ -1267,6 +1289,12 @@ def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=Q.device)
         _attn_ws[key] = ws
+    if O_res is not None:
+        _res_ok(O, O_res)
+        _l.check(L.st355_attn_bwd_res(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
+                                      _ptr(O), _rows(O, "O"), _ptr(O_res), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
+                                      _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, Sq, Sqp, Sk, Skp, d, scale, _ptr(ws)), "attn_bwd_res")
+        return
     _l.check(L.st355_attn_cross_bwd(_stream(), _ptr(Q), _ptr(K), _ptr(Qt), _ptr(Kt), _ptr(v_rows), _rows(v_rows, "v_rows"),
                                     _ptr(O), _rows(O, "O"), _ptr(dO), _rows(dO, "dO"), _ptr(lse2), _ptr(key_bias),
                                     _ptr(dQ), _ptr(dK), _ptr(dv_rows), _rows(dv_rows, "dv_rows"), B, H, Sq, Sqp, Sk, Skp, d, scale, _ptr(ws)),

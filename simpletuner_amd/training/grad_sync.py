@@ -78,6 +78,7 @@ class GradSync:
         default = bool(env and env != "0") and flat_grad.dtype == torch.bfloat16
         self.fp32_reduce = default if fp32_reduce is None else bool(fp32_reduce)
         self._recv: Optional[torch.Tensor] = None
+        self._fp32_fallback_logged = False
         self.timing = bool(os.environ.get("ST355_COMM_TIMING")) and flat_grad.is_cuda
         self._ev_begin = self._ev_end = None
         self._ev_slices: List = []
@@ -156,6 +157,12 @@ class GradSync:
     def _fire_on_comm_stream(self, lo: int, hi: int, W: int):
             m = (hi - lo) // W * W if self.mode == "rs_ag" else 0
             m8 = self.fp32_span(lo, hi, W) if self.mode == "rs_ag" else 0
+            if self.fp32_reduce and self.mode == "rs_ag" and m > 0 and m8 == 0 and not self._fp32_fallback_logged:
+                self._fp32_fallback_logged = True        # say it once: a requested fp32-accumulating reduce must not degrade silently
+                import logging
+                logging.getLogger("st355.grad_sync").warning(
+                    "fp32_reduce requested, but the slice [%d, %d) cannot take it (start not 8-element aligned or shorter than 8 x world): "
+                    "this slice uses the backend's own reduce-scatter in the arena dtype", lo, hi)
             if m8 > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and (self.flat.is_cuda == self._stream_ordered()):
                 m = m8                                                 # st355_sum_chunks_bf16 wants 8-element (16-byte) chunks: the tail below takes the rest
                 seg = self.flat[lo:lo + m]

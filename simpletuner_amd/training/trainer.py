@@ -105,8 +105,12 @@ class Trainer:
         opt_name = getattr(config, "optimizer", "st355-adamw")
         if opt_name not in ("adamw_bf16", "st355-adamw", "torch-adamw"):                   # never a silently different optimizer
             raise NotImplementedError(f"optimizer '{opt_name}' is not built on the st355 path (adamw_bf16, st355-adamw = torch-adamw semantics)")
+        self._bf16_shadow = None
         if opt_name == "adamw_bf16":
-            self.optimizer = St355AdamWBF16(self.params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
+            opt_params = self.params
+            if any(p.dtype != torch.bfloat16 for p in self.params):
+                opt_params = self._make_bf16_shadow()
+            self.optimizer = St355AdamWBF16(opt_params, lr=config.learning_rate, betas=(config.adam_beta1, config.adam_beta2),
                                             eps=OPTIMIZER_CHOICE["adamw_bf16"]["default_settings"]["eps"], weight_decay=config.adam_weight_decay,
                                             seed=int(getattr(config, "seed", 0) or 0))
         else:
@@ -151,11 +155,36 @@ class Trainer:
         if self._use_graph and getattr(getattr(model_plugin, "xm_config", None), "enabled", False):
             raise NotImplementedError("hip_graph: XM noise candidates read their logs on the host every step and cannot be captured")
         self._graphs = {}
+        self._graph_pool = None
         self._graph_warm = {}
         self.state = {"global_step": 0, "micro_step": 0}
         self.last_loss = None          # device scalar, no host sync
         self.last_grad_norm = None
         self.last_grad_absmax = None
+
+    def _make_bf16_shadow(self):
+        """adamw_bf16 over an fp32 adapter arena (LoRA): the reference's example trains bf16 adapter weights with bf16 gradients under AdamWBF16
+        (simpletuner/examples/sd3.peft-lora/config.json: optimizer adamw_bf16, mixed_precision bf16; optimizers/adamw_bfloat16/__init__.py:66 asserts bf16).
+        The trained values live in a bf16 arena that the optimizer steps (compensated stochastic-rounding update, its `shift` buffer); the engine's fp32
+        arena mirrors it exactly (every value is a bf16 number), and the fp32 rank-space gradients are rounded to bf16 once per step — what autograd hands
+        a bf16 parameter.  Returns the bf16 parameters the optimizer owns (same order, same shapes)."""
+        from .optimizer import _contiguous_run
+        if not _contiguous_run([p.data for p in self.params]):
+            raise NotImplementedError("adamw_bf16 over fp32 trainables needs them as one flat arena (the LoRA adapter arena)")
+        n = sum(p.numel() for p in self.params)
+        flat32 = torch.as_strided(self.params[0].data, (n,), (1,))
+        master = flat32.to(torch.bfloat16)
+        flat32.copy_(master)                                  # the engine computes with exactly the values the optimizer holds
+        grad16 = torch.zeros(n, dtype=torch.bfloat16, device=flat32.device)
+        shadow, off = [], 0
+        for p in self.params:
+            k = p.numel()
+            q = torch.nn.Parameter(master[off:off + k].view_as(p))
+            q.grad = grad16[off:off + k].view_as(p)
+            shadow.append(q)
+            off += k
+        self._bf16_shadow = SimpleNamespace(flat32=flat32, master=master, grad16=grad16, params=shadow, n=n)
+        return shadow
 
     def check_pending_loss(self) -> None:
         """The reference raises `RuntimeError("Non-finite training loss detected …")` right after the loss is computed (trainer.py:7102-7110), which
@@ -226,9 +255,22 @@ class Trainer:
             else:
                 raise ValueError(f"Unknown grad clip method: {method}. Supported methods: value, norm")
         self.optimizer.grad_scale = grad_scale
-        self.optimizer.step()                                                            # :7239
-        if not self._use_graph:                                                          # graph mode: the captured backward re-writes the same .grad tensors
-            self.optimizer.zero_grad(set_to_none=True)                                   # :7253
+        sh = self._bf16_shadow
+        if sh is not None:                                                               # adamw_bf16 over the fp32 adapter arena: bf16 gradients in, bf16 weights out
+            from .optimizer import _contiguous_run
+            grads = [p.grad for p in self.params]
+            if any(g is None for g in grads) or not _contiguous_run(grads):
+                raise RuntimeError("adamw_bf16 (LoRA): the adapter gradients are not one flat arena")
+            sh.grad16.copy_(torch.as_strided(grads[0], (sh.n,), (1,)))
+            self.optimizer.step()
+            sh.flat32.copy_(sh.master)
+            if not self._use_graph:
+                for p in self.params:
+                    p.grad = None
+        else:
+            self.optimizer.step()                                                        # :7239
+            if not self._use_graph:                                                      # graph mode: the captured backward re-writes the same .grad tensors
+                self.optimizer.zero_grad(set_to_none=True)                               # :7253
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()                                                     # :7293
         self.state["global_step"] += 1
@@ -279,7 +321,11 @@ class Trainer:
                 p.grad = None
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
+            # one memory pool for every captured step of this trainer (one graph per batch shape: the aspect buckets): replays never overlap, so the graphs share
+            # their intermediates' memory — five bucket graphs of a full fine-tune cost the LARGEST step's activations, not their sum
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, stream=side, pool=self._graph_pool):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
                 loss = self._eager_forward_backward(shallow(static))
             entry = self._graphs[key] = (g, static_inputs, loss.detach(), [p.grad for p in self.params])
         g, st, loss, grads = entry

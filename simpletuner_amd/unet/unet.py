@@ -582,10 +582,14 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         Cp = heads * hp
         Op = torch.empty(M, Cp, dtype=BF16, device=dev)
         lse = torch.empty(B, heads, S, dtype=F32, device=dev)
+        # training: the forward also keeps the rounding residual of O, so that the backward's delta = rowsum(dO * O) is taken from the un-rounded output.  The UNet's
+        # attention inputs are LayerNorm outputs with a large component common to all tokens (0.97 of the row norm at SDXL's 32^2 level); a flash-style backward that
+        # reads delta from the bf16 O leaves that component un-cancelled in dQ / dK (rel-L2 0.26 on dQ there: profiles/r05_sdxl_lora_outlier_probe.log)
+        Ores = torch.empty_like(Op) if T is not None else None
         if self_attn:
-            ops.attn_fwd(Q, K, Vt, Op, lse, B, heads, S, Sp, hp, scale)
+            ops.attn_fwd(Q, K, Vt, Op, lse, B, heads, S, Sp, hp, scale, O_res=Ores)
         else:
-            ops.attn_cross_fwd(Q, K, Vt, Op, lse, B, heads, S, Sk, Skp, hp, scale)
+            ops.attn_cross_fwd(Q, K, Vt, Op, lse, B, heads, S, Sk, Skp, hp, scale, O_res=Ores)
         O = Op if exact else Op.view(M, heads, hp)[:, :, :hd].reshape(M, C_)
 
         def pad_cols(t2d, rows):                      # [rows, heads*hd] (any row stride) -> [rows, heads*hp] zero-padded heads
@@ -604,9 +608,9 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
                     v_rows, dOp = pad_cols(kvsrc[:, vo:vo + C_], Mk), pad_cols(dO, M)
                     dv_rows = torch.empty(Mk, Cp, dtype=BF16, device=dev)
                 if self_attn:
-                    ops.attn_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, hp, scale)
+                    ops.attn_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, hp, scale, O_res=Ores)
                 else:
-                    ops.attn_cross_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, Sk, Skp, hp, scale)
+                    ops.attn_cross_bwd(Q, K, Qt, Kt, v_rows, Op, dOp, lse, dQ, dK, dv_rows, B, heads, S, Sp, Sk, Skp, hp, scale, O_res=Ores)
                 if not exact:
                     dkv_src[:, vo:vo + C_] = dv_rows.view(Mk, heads, hp)[:, :, :hd].reshape(Mk, C_)
                 ops.head_merge(dQ, dq_src[:, qo:qo + C_], B, heads, hp, S, d_src=hd)

@@ -408,6 +408,27 @@ def adamw_ema_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
         p_bf16.copy_(pf.to(BF16))
 
 
+def adamw_bf16_sr_step(p, g, m, v, shift, step, lr, beta1, beta2, eps, seg_end=None, seg_decay=None, rand_bits=None, seed=0, offset=0, grad_scale=1.0):
+    """st355_adamw_bf16_sr_step's contract over flat bf16 arenas through the oracle's restatement of the reference update (oracle.train_math.adamw_bf16_step);
+    the stochastic-rounding draws are host-drawn here (the kernel's Philox stream is a GPU matter: tests/test_adamw_bf16_gpu.py pins it bit for bit)"""
+    from oracle import train_math as TM
+    for t, nm in ((p, "p"), (g, "g"), (m, "exp_avg"), (v, "exp_avg_sq"), (shift, "shift")):
+        _need(t.dtype == BF16 and t.is_contiguous() and t.numel() == p.numel(), f"adamw_bf16_sr_step: {nm} must be a contiguous bf16 arena of the same length")
+    n = p.numel()
+    ends = [n] if seg_end is None else [int(e) for e in seg_end]
+    decs = [0.0] * len(ends) if seg_decay is None else [float(d) for d in seg_decay]
+    gen = torch.Generator().manual_seed(int(seed) * 7919 + int(offset) % 1000003)
+    gs = (g.float() * grad_scale).to(BF16)
+    lo = 0
+    for hi, dec in zip(ends, decs):
+        k = hi - lo
+        draws = [rand_bits[j, lo:hi] for j in range(4)] if rand_bits is not None else [torch.randint(0, 1 << 16, (k,), generator=gen, dtype=torch.int32) for _ in range(4)]
+        o = TM.adamw_bf16_step(p[lo:hi], gs[lo:hi], m[lo:hi], v[lo:hi], shift[lo:hi], int(step), lr, beta1, beta2, eps, dec, draws)
+        for dst, src in zip((p, m, v, shift), o):
+            dst[lo:hi].copy_(src)
+        lo = hi
+
+
 def ema_update(shadow, param, decay):
     """s -= (1 - d) (s - p), the difference materialised in the parameter dtype (ema.py:423)"""
     _need(shadow.dtype == param.dtype, "ema_update: dtype mismatch")
@@ -638,7 +659,7 @@ def _scores(q, k, B, S, scale, key_bias):
     return sc
 
 
-def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=None):
+def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=None, O_res=None):
     _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
     _rows(O, "O")
     _need(tuple(Q.shape) == (B, H, S, d) and tuple(K.shape) == (B, H, S, d) and tuple(Vt.shape) == (B, H, d, Sp) and Sp % 64 == 0 and Sp >= S, "attn_fwd: shapes")
@@ -646,10 +667,15 @@ def attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, d, scale, key_bias=None):
     sc = _scores(q, k, B, S, scale, key_bias)
     lse2.copy_(torch.logsumexp(sc, dim=-1) * 1.4426950408889634)
     o = torch.softmax(sc, dim=-1) @ v                                      # [B, H, S, d]
-    O.view(B, S, -1)[:, :, :H * d] = o.permute(0, 2, 1, 3).reshape(B, S, H * d).to(BF16)
+    of = o.permute(0, 2, 1, 3).reshape(B, S, H * d)
+    O.view(B, S, -1)[:, :, :H * d] = of.to(BF16)
+    if O_res is not None:                  # the rounding residual of O (st355_attn_fwd_res); the emulated backward is exact autograd and has no use for it
+        _chk(O_res, BF16, "O_res")
+        _need(O_res.shape == O.shape and O_res.stride() == O.stride(), "attn_fwd: O_res must have O's layout")
+        O_res.view(B, S, -1)[:, :, :H * d] = (of - of.to(BF16).float()).to(BF16)
 
 
-def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale, key_bias=None):
+def attn_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, S, Sp, d, scale, key_bias=None, O_res=None):
     for t, nm in ((Q, "Q"), (K, "K"), (v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dv_rows, "dv_rows")):
         _chk(t, BF16, nm)
     for t, nm in ((v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dv_rows, "dv_rows")):
@@ -723,17 +749,21 @@ def attn_bwd_rope(Q, K, v_rows, O, dO, lse2, rrms, wq_lo, wk_lo, wq_hi, wk_hi, s
             rows[:, lo:hi, j * D:(j + 1) * D] = dx.reshape(B, hi - lo, D).to(BF16)
 
 
-def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale, key_bias=None):
+def attn_cross_fwd(Q, K, Vt, O, lse2, B, H, Sq, Sk, Skp, d, scale, key_bias=None, O_res=None):
     _chk(Q, BF16, "Q"); _chk(K, BF16, "K"); _chk(Vt, BF16, "Vt"); _chk(O, BF16, "O"); _chk(lse2, F32, "lse2")
     _rows(O, "O")
     _need(tuple(Q.shape) == (B, H, Sq, d) and tuple(K.shape) == (B, H, Sk, d) and tuple(Vt.shape) == (B, H, d, Skp) and Skp % 64 == 0 and Skp >= Sk, "attn_cross_fwd: shapes")
     sc = _scores(Q.float(), K.float(), B, Sk, scale, key_bias)
     lse2.copy_(torch.logsumexp(sc, dim=-1) * 1.4426950408889634)
     o = torch.softmax(sc, dim=-1) @ Vt[..., :Sk].float().transpose(-1, -2)
-    O[:, :H * d] = o.permute(0, 2, 1, 3).reshape(B * Sq, H * d).to(BF16)
+    of = o.permute(0, 2, 1, 3).reshape(B * Sq, H * d)
+    O[:, :H * d] = of.to(BF16)
+    if O_res is not None:
+        _chk(O_res, BF16, "O_res")
+        O_res[:, :H * d] = (of - of.to(BF16).float()).to(BF16)
 
 
-def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=None):
+def attn_cross_bwd(Q, K, Qt, Kt, v_rows, O, dO, lse2, dQ, dK, dv_rows, B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=None, O_res=None):
     for t, nm in ((Q, "Q"), (K, "K"), (v_rows, "v_rows"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dv_rows, "dv_rows")):
         _chk(t, BF16, nm)
     for t, nm, n in ((v_rows, "v_rows", Sk), (O, "O", Sq), (dO, "dO", Sq), (dv_rows, "dv_rows", Sk)):
@@ -1213,7 +1243,7 @@ def block_sd3_joint_bwd(**a):
 
 _EMULATED = ("qk_rope", "attn_fwd_vrows", "attn_bwd_rope", "qk_rope_norm_bwd", "grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
-             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
+             "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "adamw_bf16_sr_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
              "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd", "block_pixart_fwd", "block_pixart_bwd", "block_sd3_joint_fwd", "block_sd3_joint_bwd")
 

@@ -14,8 +14,8 @@ import torch
 BF16 = torch.bfloat16
 TOL = ("pred rel_l2 <= 2e-2, cos >= 0.9995; gradient tensors rel_l2 <= 6e-2 (bias / norm / modulation rows 8e-2; LoRA factors of the true-depth UNets 1e-1) and "
        "cosine >= 0.995 where they carry signal; tensors whose reference norm is below 1e-3 of the largest are held to the same bound in absolute terms, "
-       "|got - want| <= tol * 1e-3 * max norm; LoRA legs: a tensor's bound is max(tol, 2 x the distance (1.25 x its worst over all tensors) torch's own bf16 autograd of the restatement sits at on "
-       "that tensor, measured in the same run) (DESIGN.md §3)")
+       "|got - want| <= tol * 1e-3 * max norm.  Every bound is a stated constant: none is derived from a distance measured in the run (the bf16-autograd distance "
+       "of the restatement is REPORTED beside the HIP path's, never used as a bound) (DESIGN.md §3)")
 
 
 def _rel(a, b):
@@ -34,10 +34,9 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
     softmax is invariant) must still stay within tol * floor * gmax in ABSOLUTE terms — a zeroed, stale or mis-indexed small tensor fails, it is not skipped.
     The cosine is only meaningful (and only asserted) where the reference carries signal.
     noise: {name: gradient of the SAME restatement run in bf16 (torch autograd, ATen kernels)} — what bf16 storage alone costs on that tensor at this depth,
-    measured with the same denominator.  Where given, a tensor's bound is max(tol, 2 x that measured distance, 1.25 x the WORST such distance over all tensors): no bf16 implementation of the network
-    sits much closer to the fp32 result than torch's own bf16 autograd does (r4, SDXL-LoRA at true depth: the HIP path's worst tensor sits at 1.55 x it), and the report says for which tensors the stated tolerance was exceeded that way."""
+    measured with the same denominator.  REPORTED only (worst distance, worst HIP / bf16-autograd ratio): every tensor is held to its stated bound `tol`."""
     gmax = max(float(w.float().norm()) for _, _, w, _ in pairs)
-    worst, worst_rel, worst_cos, n_abs, n_noise, worst_ratio = (0.0, "", 0.0), 0.0, 1.0, 0, 0, (0.0, "")
+    worst, worst_rel, worst_cos, n_abs, worst_ratio = (0.0, "", 0.0), 0.0, 1.0, 0, (0.0, "")
     noise_worst = 0.0
     if noise is not None:         # the worst distance torch's own bf16 autograd reaches on ANY tensor of this network (same denominators)
         for name, got, want, tol in pairs:
@@ -56,11 +55,8 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
         r = err / den
         if noise is not None and noise.get(name) is not None:
             rn = float((noise[name].detach().float().to(got.device) - wf).norm()) / den
-            if r > tol and max(2.0 * rn, 1.25 * noise_worst) > tol:
-                n_noise += 1
             if rn > 0 and r / rn > worst_ratio[0]:
                 worst_ratio = (r / rn, name)
-            tol = max(tol, 2.0 * rn, 1.25 * noise_worst)
         worst_rel = max(worst_rel, r)
         if r / tol > worst[0]:
             worst = (r / tol, name, r)
@@ -69,7 +65,6 @@ def _summary(what, out, ref, pairs, floor_frac=1e-3, noise=None):
            "grads_compared": len(pairs), "grads_below_noise_floor": 0, "grads_on_the_absolute_bound": n_abs, "tolerance": TOL}
     if noise is not None:
         rep["bf16_autograd_worst_distance_same_denominators"] = round(noise_worst, 6)
-        rep["grads_held_to_the_measured_bf16_autograd_distance"] = n_noise
         rep["hip_error_over_bf16_autograd_error_worst"] = {"ratio": round(worst_ratio[0], 3), "at": worst_ratio[1]}
     return rep
 
@@ -150,6 +145,11 @@ def unet(kind: str, res: int, dev, lora: bool, rank: int = 16, seed: int = 4):
     what = (f"{'SD 1.5' if kind == 'sd15' else 'SDXL'} UNet at its true architecture, {mode}, {res}^2 ({lat}^2 latents), batch 1: HIP bf16 vs oracle fp32 "
             f"(autograd), same weights / inputs")
     rep = _summary(what, out, ref.detach(), pairs, noise={n: lb[n].grad for n in lb} if lora else None)
+    rep["oracle_pinning"] = ("oracle.unet: every leaf (ResnetBlock2D, Transformer2DModel, BasicTransformerBlock, attention, GEGLU, GroupNorm, up / down samplers, time / "
+                             "text-time embeddings) and the conv_in -> down blocks -> mid block half of the walk are PINNED to executed code vendored in the reference "
+                             "(tests/golden/ref_unet_leaves.pt, ref_unet_walk.pt); the UP path (skip concatenation order, up-block / upsampler sequencing, conv_out) is a "
+                             "RESTATEMENT of diffusers' UNet2DConditionModel (the reference imports it, diffusers 0.36, not vendored): nothing in /root/reference to execute "
+                             "=> parity of that half is UNPINNED, the figures on this entry are HIP vs that restatement")
     if lora and bf16_noise:
         worst_n = max(bf16_noise, key=bf16_noise.get)
         rep["bf16_autograd_of_the_oracle_vs_its_fp32_self"] = {

@@ -206,3 +206,63 @@ def test_four_process_gradient_exchange_all_forms():
         # the rs_ag part is the exactly-rounded fp32 sum; the < 8 x world tails went through a bf16 all-reduce (pairwise bf16 adds): compare those loosely
         diff = (flat.float() - exact.float()).abs()
         assert (diff == 0).float().mean().item() > 0.99 and diff.max().item() <= 0.0625 * exact.float().abs().max().item()
+
+
+def _worker_world3_fp32_selection(rank, world, init_file, out_dir):
+    import logging
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from simpletuner_amd.training.grad_sync import GradSync
+    out = {}
+    n = 30_000 + 16                                                    # ragged: the slices below are no multiple of 8 x 3
+    vals = [torch.randn(n, generator=torch.Generator().manual_seed(300 + r)).to(torch.bfloat16) for r in range(world)]
+
+    def run(flat, lo_edges, **kw):
+        gs = GradSync(flat, bucket_bytes=2 * 4000, mode="rs_ag", **kw)
+        gs.begin()
+        for hi, lo in zip(lo_edges[:-1], lo_edges[1:]):
+            gs.ready(lo, hi)
+        gs.finish()
+        return gs
+    edges = list(range(n, 0, -4104)) + [0]                             # 4104 = 8 * 513: every slice starts 8-aligned
+    # default: RCCL / gloo's own reduce-scatter in the arena dtype (bf16 on the wire AND in the adds)
+    os.environ.pop("ST355_FP32_REDUCE", None)
+    gs = run(vals[rank].clone(), edges)
+    out["default_flag"], out["default_ops"] = gs.fp32_reduce, sorted({k for k, _, _ in gs.launched_ops})
+    # ST355_FP32_REDUCE=1: all-to-all + fp32 sum in rank order + all-gather
+    os.environ["ST355_FP32_REDUCE"] = "1"
+    flat = vals[rank].clone()
+    gs = run(flat, edges)
+    out["env_flag"], out["env_ops"], out["env_flat"] = gs.fp32_reduce, sorted({k for k, _, _ in gs.launched_ops}), flat
+    out["env_on_fp32_arena"] = GradSync(torch.zeros(64), mode="rs_ag").fp32_reduce          # the flag only concerns bf16 arenas
+    # an unaligned region start: the fp32 form steps aside for that slice, and says so once
+    seen = []
+    h = logging.Handler(); h.emit = lambda rec: seen.append(rec.getMessage())
+    logging.getLogger("st355.grad_sync").addHandler(h)
+    flat2 = vals[rank].clone()
+    gs = run(flat2, [n, 4 + 8 * 3 * 100, 4, 0])                        # [4 + 2400, n) is 8-aligned?  no: lo = 2404 -> falls back; [4, 2404) too
+    out["unaligned_ops"], out["unaligned_logged"], out["unaligned_flat"] = sorted({k for k, _, _ in gs.launched_ops}), len(seen), flat2
+    os.environ.pop("ST355_FP32_REDUCE", None)
+    torch.save(out, os.path.join(out_dir, f"w3_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_fp32_reduce_selection_default_env_and_unaligned_fallback_world3():
+    """the default exchange of a bf16 arena is the backend's own reduce-scatter; ST355_FP32_REDUCE=1 selects all-to-all + fp32 sum + all-gather (world 3,
+    ragged slices: the sum of three ranks accumulated in fp32 and rounded once, the same arena on every rank); a slice whose start is not 8-element aligned falls back
+    to the backend's reduce-scatter for that slice and logs it once"""
+    W = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_world3_fp32_selection, args=(W, os.path.join(d, "init"), d), nprocs=W, join=True)
+        res = [torch.load(os.path.join(d, f"w3_{r}.pt")) for r in range(W)]
+    n = 30_000 + 16
+    vals = [torch.randn(n, generator=torch.Generator().manual_seed(300 + r)).to(torch.bfloat16) for r in range(W)]
+    exact = (vals[0].float() + vals[1].float() + vals[2].float()).to(torch.bfloat16)
+    for r in res:
+        assert r["default_flag"] is False and "all_to_all" not in r["default_ops"] and "reduce_scatter" in r["default_ops"]
+        assert r["env_flag"] is True and "all_to_all" in r["env_ops"] and "reduce_scatter" not in r["env_ops"] and r["env_on_fp32_arena"] is False
+        assert torch.equal(r["env_flat"], res[0]["env_flat"])
+        diff = (r["env_flat"].float() - exact.float()).abs()
+        assert (diff == 0).float().mean().item() > 0.99                 # all but the < 8 x world tails of the slices are the exactly-rounded fp32 sum
+        assert "reduce_scatter" in r["unaligned_ops"] and r["unaligned_logged"] == 1
+        assert torch.equal(r["unaligned_flat"], res[0]["unaligned_flat"])
+        assert (r["unaligned_flat"].float() - exact.float()).abs().max().item() <= 0.0625 * exact.float().abs().max().item()

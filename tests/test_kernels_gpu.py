@@ -841,6 +841,61 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
             assert torch.equal(dK2, dK) and torch.equal(dqkv2, dqkv)
 
 
+@pytest.mark.parametrize("B,H,S,d,cross", [(1, 20, 1024, 64, False), (2, 4, 320, 128, False), (1, 8, 1024, 64, True)])
+def test_attention_backward_with_the_output_residual_cancels_the_common_component(ops, B, H, S, d, cross):
+    """st355_attn_fwd_res / st355_attn_bwd_res: q and k share a component common to all tokens 4 x larger than their per-token part (what a LayerNorm output with a
+    dominant mean pattern gives the UNet's attn1: SDXL 32^2 level, 20 heads of 64).  Exact arithmetic cancels that component in dQ (sum_j dS_ij = 0) and in the key-sum
+    of dK.  With delta read from the bf16 O the cancellation fails at O's rounding error (dQ rel-L2 ~1e-1 here); with the residual the backward is back at bf16
+    rounding.  O itself is bit-identical with and without the residual; fp64 reference on the device."""
+    torch.manual_seed(5)
+    dv = dev()
+    Sk = 77 if cross else S
+    Sp, Skp = (S + 63) // 64 * 64, (Sk + 63) // 64 * 64
+    D = H * d
+    scale = 1.0 / math.sqrt(d)
+    cq, ck = torch.randn(1, H, 1, d, device=dv) * 4.0, torch.randn(1, H, 1, d, device=dv) * 4.0
+    q = (torch.randn(B, H, S, d, device=dv) + cq).to(BF16)
+    k = (torch.randn(B, H, Sk, d, device=dv) * 0.5 + ck * 0.25).to(BF16)
+    v_rows = torch.randn(B * Sk, D, device=dv).to(BF16)
+    v = v_rows.view(B, Sk, H, d).permute(0, 2, 1, 3)
+    Vt = torch.zeros(B, H, d, Skp, device=dv, dtype=BF16); Vt[..., :Sk] = v.transpose(2, 3)
+    dO = torch.randn(B * S, D, device=dv).to(BF16)
+    q64, k64, v64 = q.double().requires_grad_(True), k.double().requires_grad_(True), v.double().requires_grad_(True)
+    o64 = torch.softmax(q64 @ k64.transpose(2, 3) * scale, -1) @ v64
+    o64.backward(dO.double().view(B, S, H, d).permute(0, 2, 1, 3))
+    out = {}
+    for res in (False, True):
+        O = torch.empty(B * S, D, device=dv, dtype=BF16); lse2 = torch.empty(B, H, S, device=dv)
+        Ores = torch.empty_like(O) if res else None
+        dQ = torch.empty(B, H, S, d, device=dv, dtype=BF16); dK = torch.empty(B, H, Sk, d, device=dv, dtype=BF16); dV = torch.empty(B * Sk, D, device=dv, dtype=BF16)
+        if cross:
+            ops.attn_cross_fwd(q, k, Vt, O, lse2, B, H, S, Sk, Skp, d, scale, O_res=Ores)
+            ops.attn_cross_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ, dK, dV, B, H, S, Sp, Sk, Skp, d, scale, O_res=Ores)
+        else:
+            prev = ops.attn_set_impl(fwd=32)                 # the residual form runs k_attn_fwd4: compare O against the same kernel
+            try:
+                ops.attn_fwd(q, k, Vt, O, lse2, B, H, S, Sp, d, scale, O_res=Ores)
+            finally:
+                ops.attn_set_impl(fwd=prev[0])
+            ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ, dK, dV, B, H, S, Sp, d, scale, O_res=Ores)
+        rq, rk = PU_rel(dQ, q64.grad), PU_rel(dK, k64.grad)
+        rv = PU_rel(dV.view(B, Sk, H, d).permute(0, 2, 1, 3), v64.grad)
+        ksum = dK.double().sum(2).norm().item() / dK.double().norm(dim=3).sum().item()
+        out[res] = (O, Ores, rq, rk, rv, ksum)
+        print(f"[parity] attention backward, common component, residual={res} cross={cross}: dQ {rq:.3e} dK {rk:.3e} dV {rv:.3e}  |sum_j dK_j| / sum_j |dK_j| = {ksum:.2e}")
+    assert torch.equal(out[False][0], out[True][0])                                              # the same O
+    o_t = o64.detach().permute(0, 2, 1, 3).reshape(B * S, D)
+    assert PU_rel(out[True][0].double() + out[True][1].double(), o_t) < 2e-4                     # O + O_res carries ~16 mantissa bits of the fp32 output
+    assert out[True][2] < 1e-2 and out[True][3] < 1e-2 and out[True][4] < 1e-2                   # bf16 rounding level
+    assert out[False][2] > 3 * out[True][2]                                                      # what the residual buys on dQ
+    assert out[True][5] < 0.5 * out[False][5] or out[False][5] < 1e-4
+
+
+def PU_rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
 @pytest.mark.parametrize("B,H,S,hd,dv_", [(1, 16, 1024, 96, 72), (2, 4, 320, 96, 72), (2, 10, 1024, 64, 64), (1, 5, 4096, 64, 64), (2, 3, 192, 64, 64)])
 def test_attention_64_row_kernels_narrow_heads(ops, B, H, S, hd, dv_):
     """the head_dim-96 (PixArt-Sigma's 72, zero padded: 6 k-steps, 3 d tiles) and head_dim-64 (SDXL / SD3 / SD 1.x: 4 k-steps, 2 d tiles; SDXL's two self-attention

@@ -149,3 +149,25 @@ def test_sd3_full_fine_tune_checkpoint_resume_continues_bit_for_bit(monkeypatch,
     trainer2.load_state(ck)
     tail_b = [trainer2.train_step(_batch(devt)).item() for _ in range(2)]
     assert tail_a == tail_b and torch.equal(plugin.get_trained_component().arena, plugin2.get_trained_component().arena)
+
+
+def test_lora_under_adamw_bf16_trains_bf16_adapter_values(monkeypatch):
+    """the reference's LoRA examples train with optimizer=adamw_bf16 over bf16 adapter weights (simpletuner/examples/sd3.peft-lora/config.json;
+    optimizers/adamw_bfloat16/__init__.py:66 asserts bf16): over the engine's fp32 adapter arena the trainer keeps a bf16 arena the optimizer steps and mirrors it
+    into the fp32 one — every trained value stays a bf16 number, the gradients reach the optimizer rounded to bf16, the loss falls"""
+    plugin, trainer, cpu, devt = _build(monkeypatch, 1, 1, 2, 16, 16, 32, lora_rank=8, lora_init_b_std=0.02, learning_rate=2e-3, optimizer="adamw_bf16")
+    from simpletuner_amd.training.optimizer import St355AdamWBF16
+    model = plugin.get_trained_component()
+    sh = trainer._bf16_shadow
+    assert isinstance(trainer.optimizer, St355AdamWBF16) and sh is not None
+    assert all(q.dtype == torch.bfloat16 and q.shape == p.shape for q, p in zip(sh.params, trainer.params))
+    assert torch.equal(model.lora_flat[:sh.n], sh.master.float())                      # the start values were rounded once: engine == optimizer
+    before = sh.master.clone()
+    losses = [trainer.train_step(_batch(devt)).item() for _ in range(6)]
+    print(f"[emu] LoRA under adamw_bf16: {[round(x, 4) for x in losses]}")
+    assert losses[-1] < losses[0] and not torch.equal(before, sh.master)
+    assert torch.equal(model.lora_flat[:sh.n], sh.master.float())                      # mirrored after every step
+    assert trainer.optimizer._launches == 6                                            # ONE fused launch per step over the bf16 arena
+    assert all(p.grad is None for p in model.trainable_parameters())
+    st = trainer.optimizer.state[sh.params[0]]
+    assert st["step"] == 6.0 and st["exp_avg"].dtype == torch.bfloat16 and float(st["exp_avg"].float().abs().sum()) > 0

@@ -21,11 +21,13 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #define RC(x) do { int r_ = (x); if (r_) { printf("st355 rc=%d: %s (%s:%d)\n", r_, st355_last_error(), __FILE__, __LINE__); exit(2); } } while (0)
 
-__global__ void k_fill(bf16* p, int64_t n, uint32_t seed, float scale) {
+// channels >= dvalid of every head are zero (LAB_DVALID: a head_dim zero-padded to the kernels' width — PixArt-Sigma's 72, SD 1.5's 80 inside 96; every buffer here
+// has the head channel as i % d)
+__global__ void k_fill(bf16* p, int64_t n, uint32_t seed, float scale, int d = 1, int dvalid = 1) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t h = (uint32_t)i * 2654435761u ^ seed;
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-    p[i] = (bf16)(((h >> 8) * (1.f / 8388608.f) - 1.f) * scale);
+    p[i] = (int)(i % d) < dvalid ? (bf16)(((h >> 8) * (1.f / 8388608.f) - 1.f) * scale) : (bf16)0.f;
   }
 }
 // Xt[b,h,c,s] = X[b,h,s,c] (zero padded to Sp)
@@ -75,8 +77,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dQ, nh * 2)); CK(hipMalloc(&dK, nh * 2)); CK(hipMalloc(&dqkv, nr * 3 * 2)); CK(hipMalloc(&dQ2, nh * 2)); CK(hipMalloc(&dK2, nh * 2)); CK(hipMalloc(&dqkv2, nr * 3 * 2));
   CK(hipMalloc(&lse2, (size_t)BH * S * 4)); CK(hipMalloc(&ws, st355_attn_bwd_workspace(B, H, S, Sp, d)));
   const float qs = getenv("LAB_QSCALE") ? (float)atof(getenv("LAB_QSCALE")) : 1.5f;      // 6: the tile maxima climb past the stale reference by more than 2^8 (the out-of-line rescale runs)
-  k_fill<<<2048, 256, 0, st>>>(Q, nh, 1u, qs); k_fill<<<2048, 256, 0, st>>>(K, nh, 2u, 1.5f);
-  k_fill<<<2048, 256, 0, st>>>(qkv, nr * 3, 3u, 1.f); k_fill<<<2048, 256, 0, st>>>(dO, nr, 4u, 1.f);
+  const int dvalid = getenv("LAB_DVALID") ? atoi(getenv("LAB_DVALID")) : d;
+  k_fill<<<2048, 256, 0, st>>>(Q, nh, 1u, qs, d, dvalid); k_fill<<<2048, 256, 0, st>>>(K, nh, 2u, 1.5f, d, dvalid);
+  k_fill<<<2048, 256, 0, st>>>(qkv, nr * 3, 3u, 1.f, d, dvalid); k_fill<<<2048, 256, 0, st>>>(dO, nr, 4u, 1.f, d, dvalid);
   k_transpose_heads<<<4096, 256, 0, st>>>(Q, Qt, BH, S, Sp, d); k_transpose_heads<<<4096, 256, 0, st>>>(K, Kt, BH, S, Sp, d);
   bf16* vrows = qkv + 2 * D;
   k_vt<<<4096, 256, 0, st>>>(vrows, 3 * D, Vt, B, H, S, Sp, d);
