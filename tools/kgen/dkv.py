@@ -40,7 +40,7 @@ GOFF = 512 + QT
 BUF = 2 * QT + 512         # one slot
 HD = int(os.environ.get("DKV_HD", "128"))        # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded); tile images keep the 256-byte row pitch
 assert HD in (64, 96, 128)
-NKS, NDT = int(os.environ.get("DKV_KS", {128: 8, 96: 5, 64: 4}[HD])), HD // 32
+NKS, NDT = int(os.environ.get("DKV_KS", {128: 8, 96: 6, 64: 4}[HD])), HD // 32
 
 
 def DK(dt): return ar(16 * dt, 16)

@@ -33,7 +33,7 @@ TILE = 16384           # one tile image (256-byte row pitch at every head_dim: n
 SLOT = 2 * TILE
 HD = int(os.environ.get("DQ64_HD", "128"))       # head_dim: 128 (Flux), 96 (PixArt's 72, zero padded), 64 (SD3)
 assert HD in (64, 96, 128)
-NKS, NDT = int(os.environ.get("DQ64_KS", {128: 8, 96: 5, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim, 32-row d tiles of dQ^T
+NKS, NDT = int(os.environ.get("DQ64_KS", {128: 8, 96: 6, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim, 32-row d tiles of dQ^T
 NACC = 2 * NDT * 16                               # dQ^T accumulator registers; Q fragments follow, then dO fragments
 
 

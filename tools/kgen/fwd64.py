@@ -44,7 +44,7 @@ NSLOT = 4
 THR_BITS = "0x41000000"     # 8.0f
 HD = int(os.environ.get("FWD64_HD", "128"))      # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded)
 assert HD in (64, 96, 128)
-NKS, NDT = int(os.environ.get("FWD64_KS", {128: 8, 96: 5, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim; 32-row d tiles of O^T
+NKS, NDT = int(os.environ.get("FWD64_KS", {128: 8, 96: 6, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim; 32-row d tiles of O^T
 NU, NV = 2 * NKS, 4 * NDT                         # K fragments (A groups) and V^T fragments (C iterations) per 64-key tile
 
 
