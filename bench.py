@@ -686,7 +686,7 @@ def run_workload(args, dev, rank, world):
     if rank == 0:
         _log(f"{args.model}: model + batches built, {args.warmup} warm-up + {args.steps} timed steps")
     if args.graph and args.buckets:            # one capture per bucket shape before the warm-up proper (each first encounter = 2 eager steps + capture + replay), untimed
-        for k_ in sorted(by_shape):
+        for k_ in sorted(by_shape, key=lambda k__: -shape_of[k__][0] * shape_of[k__][1]):      # largest token count first: the later, smaller captures reuse its pool blocks
             trainer.train_step(dict(by_shape[k_]))
     for i in range(args.warmup):
         l_ = trainer.train_step(dict(batches[i % nb_]))

@@ -267,7 +267,9 @@ int st355_qk_rope_norm_bwd(void* stream, const void* dQ, const void* dK, const v
 
 /* ---- K7: joint non-causal attention over [txt || img] tokens ------------------------------- */
 /* O: [B,S,H*d] token-major bf16 (row stride ld_o elements); lse2: [B,H,S] fp32 (log2-domain logsumexp of
- * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL. */
+ * scale*q.k); key_bias: fp32 [B,S] additive (natural-log units) or NULL.
+ * d = 64, 96 or 128.  d = 96 is the width of a ZERO-PADDED narrower head (PixArt-Sigma's 72, SD 1.5's 80): channels [80, 96) of Q, K, V and dO must be zero — the
+ * 64-row forward / dQ kernels contract q.k and dO.v over 80 channels (5 MFMA k-steps instead of 6; the d-output side keeps 96).  A head wider than 80 pads to 128. */
 /* Kernel choice for the no-bias self-attention shapes (tuning / A-B hook): the forward choice applies at head_dim 128 and 96, the dq / dkv choices at
  * head_dim 128, 96 and 64; every other shape (key bias, cross attention, row-major V) keeps the 32-query kernels whatever is set here.
  *   fwd: 64 = the hand-scheduled one-wave-per-SIMD forward where S % 64 == 0 (k_attn_fwd64: 64 queries per wave, stale-reference softmax; the scores are

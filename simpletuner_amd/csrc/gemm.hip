@@ -1912,31 +1912,9 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
         i += 2;
         continue;
       }
-      // a small partner that pushes a well-quantised problem into one more round of 256x256 tiles (SD3-Medium at batch 8: 768 image tiles = 3.0 rounds over 256 CUs,
-      // + 48 text tiles = 4 rounds at 80 %): the partner alone runs on the 128x128 schedule in about half a round — two launches, the big one on the persistent
-      // schedule where it qualifies.  Cost in 256x256 tile-times of this K: grouped ceil((t0 + t1) / CUs); apart ceil(t0 / CUs) + 0.5 * ceil(t1_128 / (2 CUs)) + 0.1.
-      // Every problem's result is independent of the grouping (same kernels' tiles, same summation order per output element within a schedule).
-      {
-        static int ungroup = -1;
-        if (ungroup < 0) { const char* e = getenv("ST355_GEMM_UNGROUP"); ungroup = (e && e[0] == '0') ? 0 : 1; }      // A/B: 0 = always share one grid
-        const int cus = device_cus(), t0 = g.tiles0, t1 = tiles - g.tiles0;
-        const GemmP& q1 = g.p[1];
-        if (ungroup && t1 < min_tiles_256() && t0 >= cus) {
-          const int t128 = ((q1.M + S2_BM - 1) / S2_BM) * ((q1.N + S2_BN - 1) / S2_BN);
-          const double grouped = (double)((t0 + t1 + cus - 1) / cus);
-          const double apart = (double)((t0 + cus - 1) / cus) + 0.5 * (double)((t128 + 2 * cus - 1) / (2 * cus)) + 0.1;
-          if (apart + 0.15 < grouped) {
-            for (int k = 0; k < 2; k++) {
-              ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i + k]), gemm_bytes(&args[i + k]), "%dx%dx%d+%d e%d u", args[i + k].M, args[i + k].N, args[i + k].K,
-                           args[i + k].K2, args[i + k].epilogue);
-              int rc = run_one(stream, &args[i + k]);
-              if (rc) return rc;
-            }
-            i += 2;
-            continue;
-          }
-        }
-      }
+      // (measured r5, SD3-Medium full fine-tune at batch 8: launching a small text-stream partner apart from an image problem whose 768 tiles quantise to exactly 3
+      // rounds — partner on the 128x128 schedule — did NOT pay: 319.6 vs 317.2 ms per step, GEMM class 152.2 vs 151.8 ms; the rule was removed.
+      // profiles/r05_sd3_full_b8_ungroup_rule_ab.txt)
       if (tiles >= min_tiles_256()) {
         ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + gemm_flops(&args[i + 1]), gemm_bytes(&args[i]) + gemm_bytes(&args[i + 1]),
                      "%d&%dx%dx%d+%d e%d", args[i].M, args[i + 1].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);

@@ -262,6 +262,10 @@ class Trainer:
             if any(g is None for g in grads) or not _contiguous_run(grads):
                 raise RuntimeError("adamw_bf16 (LoRA): the adapter gradients are not one flat arena")
             sh.grad16.copy_(torch.as_strided(grads[0], (sh.n,), (1,)))
+            off = 0
+            for q in sh.params:                    # (a zero_grad(set_to_none=True) by the caller must not detach the optimizer's parameters from their gradient arena)
+                q.grad = sh.grad16[off:off + q.numel()].view_as(q)
+                off += q.numel()
             self.optimizer.step()
             sh.flat32.copy_(sh.master)
             if not self._use_graph:
@@ -320,6 +324,7 @@ class Trainer:
             for p in self.params:
                 p.grad = None
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()               # the eager warm-up's cached blocks go back before the capture builds its own pool
             g = torch.cuda.CUDAGraph()
             # one memory pool for every captured step of this trainer (one graph per batch shape: the aspect buckets): replays never overlap, so the graphs share
             # their intermediates' memory — five bucket graphs of a full fine-tune cost the LARGEST step's activations, not their sum

@@ -565,10 +565,10 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
 
     def _attention(self, T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads):
         """softmax(q k^T / sqrt(hd)) v over `heads` heads of width hd = C_/heads; q / k / v are column blocks (offsets qo / ko / vo) of the token-major
-        projection outputs.  hd in {64, 96, 128}: the flash kernels on the buffers as they are; other hd <= 128 (SD1.5's 40, 80): zero-padded
+        projection outputs.  hd in {64, 128}: the flash kernels on the buffers as they are; other hd <= 128 (SD1.5's 40 -> 64, 80 -> 96; 81..128 -> 128): zero-padded
         heads; hd > 128 (SD1.5's 160, at <= 256 tokens): unfused GEMM - softmax - GEMM per head."""
         hd = C_ // heads
-        hp = 64 if hd <= 64 else 96 if hd <= 96 else 128 if hd <= 128 else 0
+        hp = 64 if hd <= 64 else 96 if hd <= 80 else 128 if hd <= 128 else 0      # (the head_dim-96 kernels contract over 80 channels: a head wider than 80 pads to 128)
         if hp == 0:
             return self._attention_unfused(T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads)
         scale = 1.0 / math.sqrt(hd)

@@ -44,7 +44,9 @@ NSLOT = 4
 THR_BITS = "0x41000000"     # 8.0f
 HD = int(os.environ.get("FWD64_HD", "128"))      # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded)
 assert HD in (64, 96, 128)
-NKS, NDT = int(os.environ.get("FWD64_KS", {128: 8, 96: 6, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim; 32-row d tiles of O^T
+# head_dim 96 is only ever a zero-padded narrower head (PixArt-Sigma 72, SD 1.5 80): the d-CONTRACTIONS (S^T = K Q^T) take 5 k-steps of 16 = 80 channels, the
+# d-OUTPUT side (O^T tiles, the V^T image) keeps 96.  r5 lab, B1 H16 S16384: 1.407 -> 1.335 ms, O unchanged (profiles/r05_attn_lab_hd96_contraction_k_steps.log)
+NKS, NDT = int(os.environ.get("FWD64_KS", {128: 8, 96: 5, 64: 4}[HD])), HD // 32                     # MFMA k-steps over the head dim; 32-row d tiles of O^T
 NU, NV = 2 * NKS, 4 * NDT                         # K fragments (A groups) and V^T fragments (C iterations) per 64-key tile
 
 
@@ -74,7 +76,7 @@ S_M0, S_T0, S_T1, S_INCK, S_INCV = 49, 50, 51, 52, 53
 
 TRACE = bool(os.environ.get("FWD64_TRACE"))
 DBG = set(filter(None, os.environ.get("FWD64_DBG", "").split(",")))
-CAP = float(os.environ.get("FWD64_CAP", {128: ("6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5"), 96: "7", 64: "10"}[int(os.environ.get("FWD64_HD", "128"))]))      # issues per MFMA gap besides the MFMA
+CAP = float(os.environ.get("FWD64_CAP", {128: ("6" if os.environ.get("FWD64_EXACT", "1") != "0" else "5"), 96: "8.5", 64: "10"}[int(os.environ.get("FWD64_HD", "128"))]))      # issues per MFMA gap besides the MFMA
 EXACT = os.environ.get("FWD64_EXACT", "1") != "0"    # scores as the exact fp32 sums of bf16 products (chains start from -m_ref / scale2, p = exp2(scale2 * acc));
                                                      # "0": Q pre-multiplied by scale2 and re-rounded (one VALU less per score, scores move by ~2^-9 |s|)
 
