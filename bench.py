@@ -468,9 +468,9 @@ def main():
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
         a3 = copy.copy(args)
-        # one GPU: one captured step per aspect bucket, replayed (the eager step leaves ~4 % of the device idle between its ~1600 launches); N > 1 stays eager — there
-        # the gradient exchange overlaps the hand-written backward bucket by bucket, which a replayed graph followed by the exchange would give up
-        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, world == 1, True
+        # (eager at every N: one captured step per aspect bucket — `--buckets --graph` — does not fit: torch gives every capture its own ~40 GB of pool for this step and
+        # five of them next to the eager warm-up exceed the 288 GB, measured r5 with a shared pool handle as well; the single-bucket graph saves 12 ms of 336)
+        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
         # Flux.1-dev FULL-rank (11.9 B bf16 parameters, AdamWBF16, per-GPU batch 8 — the configuration of the reference's multi-GPU Flux datapoint,
         # documentation/DISTRIBUTED.md:291-298): hand-written backward with every weight / bias / modulation / norm gradient, one fused optimizer launch over the
         # parameter arena, and at N > 1 the whole 24 GB bf16 gradient arena exchanged per step (fp32-accumulating reduce-scatter + all-gather buckets behind the

@@ -155,7 +155,6 @@ class Trainer:
         if self._use_graph and getattr(getattr(model_plugin, "xm_config", None), "enabled", False):
             raise NotImplementedError("hip_graph: XM noise candidates read their logs on the host every step and cannot be captured")
         self._graphs = {}
-        self._graph_pool = None
         self._graph_warm = {}
         self.state = {"global_step": 0, "micro_step": 0}
         self.last_loss = None          # device scalar, no host sync
@@ -326,11 +325,7 @@ class Trainer:
             torch.cuda.synchronize()
             torch.cuda.empty_cache()               # the eager warm-up's cached blocks go back before the capture builds its own pool
             g = torch.cuda.CUDAGraph()
-            # one memory pool for every captured step of this trainer (one graph per batch shape: the aspect buckets): replays never overlap, so the graphs share
-            # their intermediates' memory — five bucket graphs of a full fine-tune cost the LARGEST step's activations, not their sum
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g, stream=side, pool=self._graph_pool):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
+            with torch.cuda.graph(g, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
                 loss = self._eager_forward_backward(shallow(static))
             entry = self._graphs[key] = (g, static_inputs, loss.detach(), [p.grad for p in self.params])
         g, st, loss, grads = entry
