@@ -261,10 +261,11 @@ class Trainer:
             if any(g is None for g in grads) or not _contiguous_run(grads):
                 raise RuntimeError("adamw_bf16 (LoRA): the adapter gradients are not one flat arena")
             sh.grad16.copy_(torch.as_strided(grads[0], (sh.n,), (1,)))
-            off = 0
-            for q in sh.params:                    # (a zero_grad(set_to_none=True) by the caller must not detach the optimizer's parameters from their gradient arena)
-                q.grad = sh.grad16[off:off + q.numel()].view_as(q)
-                off += q.numel()
+            if any(q.grad is None for q in sh.params):      # (a zero_grad(set_to_none=True) by the caller must not detach the optimizer's parameters from their gradient arena)
+                off = 0
+                for q in sh.params:
+                    q.grad = sh.grad16[off:off + q.numel()].view_as(q)
+                    off += q.numel()
             self.optimizer.step()
             sh.flat32.copy_(sh.master)
             if not self._use_graph:
