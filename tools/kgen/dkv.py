@@ -40,7 +40,6 @@ GOFF = 512 + QT
 BUF = 2 * QT + 512         # one slot
 HD = int(os.environ.get("DKV_HD", "128"))        # head_dim: 128 (Flux) or 96 (PixArt-Sigma's 72, zero padded); tile images keep the 256-byte row pitch
 assert HD in (64, 96, 128)
-# (head_dim 96 keeps all 6 k-steps here: a 5-k-step build of THIS body was 4.5 % faster but wrong — dK / dV 0.15 rel-L2 off the 32-row kernel, r5 lab; not chased)
 NKS, NDT = int(os.environ.get("DKV_KS", {128: 8, 96: 6, 64: 4}[HD])), HD // 32
 
 
@@ -49,7 +48,10 @@ def DV(dt): return ar(16 * NDT + 16 * dt, 16)
 def KFR(ks): return vr(32 + 4 * ks, 4)
 def VFR(ks): return vr(64 + 4 * ks, 4)
 SACC, DPACC = 96, 112
-def RING(i): return 16 + 4 * (i % 4)     # four buffers: 16 fragments per phase keep the ring's phase from block to block
+def RING(i, ph=0): return 16 + 4 * ((i + ph) % 4)     # four buffers.  ph = the ring position at which the phase (A or C of a block) starts: with an even k-step count
+                                                       # every phase advances the ring by a multiple of four (ph stays 0); 5 k-steps (head_dim 96) advance A by 10, so the
+                                                       # position is carried from phase to phase (PHASE below) — fragment i + 2 must never land in the buffer fragment i is read from
+PHASE = [0]                                            # ring position of the A phase of the block being emitted
 T = [10, 11, None, None, 12, 13, 14, 15]     # scratch v10..v15 (T[0], T[1]: DMA / park; T[4], T[5]: transposed addresses; T[6], T[7]: row addresses)
 # SGPRs
 S_QP, S_GP, S_LP, S_DP = 40, 42, 44, 46      # global bases: Q head, dO head, lse row, delta row (64-bit)
@@ -59,7 +61,7 @@ CAP = float(os.environ.get("DKV_CAP", "6"))
 DBG = set(filter(None, os.environ.get("DKV_DBG", "").split(",")))
 
 
-def row_request(i: int, slot: int, qb: int) -> list[str]:
+def row_request(i: int, slot: int, qb: int, ph: int = 0) -> list[str]:
     """A-phase fragment i = 2 ks + which (0: Q row fragment, 1: dO row fragment) of query block qb into ring buffer i"""
     ks, which = i >> 1, i & 1
     x = ks << 5
@@ -67,11 +69,11 @@ def row_request(i: int, slot: int, qb: int) -> list[str]:
     out = [f"v_xor_b32_e32 {vr(t)}, {hex(x)}, %[rowb]"] if x else []
     addr = t if x else None
     a = vr(addr) if addr is not None else "%[rowb]"
-    out.append(f"ds_read_b128 {vr(RING(i), 4)}, {a} offset:{slot * BUF + (GOFF if which else QOFF) + qb * 8192} ;@ld:R{i}")
+    out.append(f"ds_read_b128 {vr(RING(i, ph), 4)}, {a} offset:{slot * BUF + (GOFF if which else QOFF) + qb * 8192} ;@ld:R{i}")
     return out
 
 
-def tr_request(i: int, slot: int, qb: int) -> list[str]:
+def tr_request(i: int, slot: int, qb: int, ph: int = 0) -> list[str]:
     """C-phase fragment i = 4 dt + 2 m + which (0: dO^T fragment -> dV, 1: Q^T fragment -> dK) of query block qb: two transposing reads into ring buffer i"""
     dt, m, which = i >> 2, (i >> 1) & 1, i & 1
     x0, x1 = (4 * dt) << 4, ((4 * dt) ^ 1) << 4
@@ -81,7 +83,7 @@ def tr_request(i: int, slot: int, qb: int) -> list[str]:
     if which == 0:           # the Q^T fragment of the same (dt, m) follows with the same two addresses
         out.append(f"v_xor_b32_e32 {vr(t0)}, {hex(x0)}, %[trb]" if x0 else f"v_mov_b32_e32 {vr(t0)}, %[trb]")
         out.append(f"v_xor_b32_e32 {vr(t1)}, {hex(x1)}, %[trb]")
-    r = RING(i)
+    r = RING(i, ph)
     out.append(f"ds_read_b64_tr_b16 {vr(r, 2)}, {vr(t0)} offset:{base} ;@ld:C{i}")
     out.append(f"ds_read_b64_tr_b16 {vr(r + 2, 2)}, {vr(t1)} offset:{base + 1024} ;@ld:C{i}")
     return out
@@ -98,17 +100,17 @@ def stat_request(slot: int, qb: int) -> list[str]:
     return out
 
 
-def a_groups(slot: int, qb: int, tail: list[list[str]]) -> list[list[str]]:
+def a_groups(slot: int, qb: int, tail: list[list[str]], ph: int = 0) -> list[list[str]]:
     """16 MFMAs: S += Q_frag x K'(ks), dP += dO_frag x V'(ks), alternating.  Group i waits for fragment i and requests i + 2; the last two carry tail[0 / 1]."""
     groups = []
     for i in range(2 * NKS):
         ks, which = i >> 1, i & 1
-        head = [f"@wait:R{i}"] + (row_request(i + 2, slot, qb) if i < 2 * NKS - 2 else tail[i - (2 * NKS - 2)])
+        head = [f"@wait:R{i}"] + (row_request(i + 2, slot, qb, ph) if i < 2 * NKS - 2 else tail[i - (2 * NKS - 2)])
         if i == 0:
             head = ["@wait:ST"] + head
         acc = DPACC if which else SACC
         opb = VFR(ks) if which else KFR(ks)
-        groups.append(head + [f"{MFMA} {vr(acc, 16)}, {vr(RING(i), 4)}, {opb}, {vr(acc, 16)}"])
+        groups.append(head + [f"{MFMA} {vr(acc, 16)}, {vr(RING(i, ph), 4)}, {opb}, {vr(acc, 16)}"])
     return groups
 
 
@@ -128,16 +130,16 @@ def b_ops() -> list[str]:
     return ops
 
 
-def c_groups(slot: int, qb: int, tail: list[list[str]]) -> list[list[str]]:
+def c_groups(slot: int, qb: int, tail: list[list[str]], ph: int = 0) -> list[list[str]]:
     """16 MFMAs: dV^T(dt) += dO^T_frag x P(m), dK^T(dt) += Q^T_frag x dS(m).  Group i waits for fragment i and requests i + 2; the last two carry tail."""
     groups = []
     for i in range(4 * NDT):
         dt, m, which = i >> 2, (i >> 1) & 1, i & 1
-        head = [f"@wait:C{i}"] + (tr_request(i + 2, slot, qb) if i < 4 * NDT - 2 else tail[i - (4 * NDT - 2)])
+        head = [f"@wait:C{i}"] + (tr_request(i + 2, slot, qb, ph) if i < 4 * NDT - 2 else tail[i - (4 * NDT - 2)])
         if which == 0:
-            groups.append(head + [f"{MFMA} {DV(dt)}, {vr(RING(i), 4)}, {vr(SACC + 4 * m, 4)}, {DV(dt)}"])
+            groups.append(head + [f"{MFMA} {DV(dt)}, {vr(RING(i, ph), 4)}, {vr(SACC + 4 * m, 4)}, {DV(dt)}"])
         else:
-            groups.append(head + [f"{MFMA} {DK(dt)}, {vr(RING(i), 4)}, {vr(DPACC + 4 * m, 4)}, {DK(dt)}"])
+            groups.append(head + [f"{MFMA} {DK(dt)}, {vr(RING(i, ph), 4)}, {vr(DPACC + 4 * m, 4)}, {DK(dt)}"])
     return groups
 
 
@@ -208,13 +210,17 @@ def build() -> str:
 
     def block(slot: int, qb: int, nxt: tuple[int, int] | None, fill: list | None = None) -> None:
         """statistics + first two row fragments of this block were requested by the previous one; nxt = (slot, qb) of the following block or None"""
-        tail_a = [tr_request(0, slot, qb), tr_request(1, slot, qb)]
-        ag = a_groups(slot, qb, tail_a)
+        pa = PHASE[0]
+        pc = (pa + 2 * NKS) % 4                               # C's ring position; the next block's A starts 4 NDT fragments further
+        pn = (pc + 4 * NDT) % 4
+        tail_a = [tr_request(0, slot, qb, pc), tr_request(1, slot, qb, pc)]
+        ag = a_groups(slot, qb, tail_a, pa)
         if nxt is not None:
-            tail_c = [row_request(0, nxt[0], nxt[1]), row_request(1, nxt[0], nxt[1])]
+            tail_c = [row_request(0, nxt[0], nxt[1], pn), row_request(1, nxt[0], nxt[1], pn)]
         else:
             tail_c = [[], []]
-        cg = c_groups(slot, qb, tail_c)
+        cg = c_groups(slot, qb, tail_c, pc)
+        PHASE[0] = pn
         b = b_ops()
         # A | 12 states for the MFMA results | B | C.  B cannot ride in this wave's own A or C gaps (it needs A's results, C needs its results): the partner
         # wave's MFMAs cover it.  Fillers (LDS-DMA of the next tile) ride in A's and C's gaps.
@@ -245,8 +251,8 @@ def build() -> str:
             o("s_waitcnt vmcnt(0)")
             o("s_barrier")
             st.extend(stat_request(slot ^ 1, 0))
-            st.extend(row_request(0, slot ^ 1, 0))
-            st.extend(row_request(1, slot ^ 1, 0))
+            st.extend(row_request(0, slot ^ 1, 0, PHASE[0]))
+            st.extend(row_request(1, slot ^ 1, 0, PHASE[0]))
 
     st.comment("---- first block's statistics and fragments")
     st.extend(stat_request(0, 0))
@@ -256,8 +262,10 @@ def build() -> str:
     o(f"s_cmp_lt_u32 s{S_CNT}, 3")
     o("s_cbranch_scc1 .Ldkv_tail_%=")
     o(".Ldkv_loop_%=:")
+    assert PHASE[0] == 0
     tile(0, False)
     tile(1, False)
+    assert PHASE[0] == 0, "four blocks per trip must bring the fragment ring back to its entry position"
     o(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")
     o(f"s_cmp_ge_u32 s{S_CNT}, 3")
     o("s_cbranch_scc1 .Ldkv_loop_%=")
@@ -265,10 +273,12 @@ def build() -> str:
     st.comment("---- tail: one or two tiles left")
     o(f"s_cmp_eq_u32 s{S_CNT}, 1")
     o("s_cbranch_scc1 .Ldkv_one_%=")
+    PHASE[0] = 0                                              # (both tails are entered at the loop's entry position)
     tile(0, False)
     tile(1, True)
     o("s_branch .Ldkv_done_%=")
     o(".Ldkv_one_%=:")
+    PHASE[0] = 0
     tile(0, True)
     o(".Ldkv_done_%=:")
     st.comment("---- park dK^T * scale and dV^T as bf16 token rows (rope_bwd_store's image): dK at lds + wave * 16384, dV 8 KiB behind it")
