@@ -1647,11 +1647,9 @@ static bool pz_ok(const GemmP& p, int tiles) {
   // long plain-K problems (the feed-forward down projections, K = 12288 with no K-extension): 96+ k-iterations amortise the one-tile-per-workgroup
   // seam already and the dynamic workgroup dispatch balances the last round better — measured in-step (profiles/r03_flux_step_gemm_persistent_ab.txt):
   // 1327 -> 1266 TFLOP/s under the persistent schedule, every other shape class +0.5 ... +8 %
-  // r5: the same holds for a long contraction made of TWO segments (the Flux single block's proj_out: K = 3072 attention columns + K2 = 12288 MLP columns, 8 % of the
-  // Flux step, 1189 TFLOP/s under the persistent schedule against 1310 for the plain K = 12288 problem of the same size): ST355_GEMM_PZ_LONGK=0 restores "K2 == 0 only"
-  static int longk2 = -1;
-  if (longk2 < 0) { const char* e = getenv("ST355_GEMM_PZ_LONGK"); longk2 = (e && e[0] == '0') ? 0 : 1; }
-  if (g_persist_override < 0 && ((p.K >= 12288 && p.K2 == 0) || (longk2 && p.K + p.K2 >= 12288))) return false;      // (a forced schedule, set_persistent(1), ignores the heuristic)
+  // (r5 A/B: a long contraction made of TWO segments — the Flux single block's proj_out, K = 3072 + K2 = 12288 — is the other way round: 1210-1214 TFLOP/s under the
+  // persistent schedule, 1186-1200 on one tile per workgroup, same box, two runs each; it stays persistent)
+  if (g_persist_override < 0 && p.K >= 12288 && p.K2 == 0) return false;      // (a forced schedule, set_persistent(1), ignores the heuristic)
   bool ok = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (((uintptr_t)p.A & 15) == 0) && (((uintptr_t)p.B & 15) == 0) && p.lda % 8 == 0 && p.ldb % 8 == 0;
   if (p.bias) ok = ok && (((uintptr_t)p.bias & 15) == 0);
   if (p.aux_out) ok = ok && (p.ld_aux_out % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0);
