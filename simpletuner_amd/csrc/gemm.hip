@@ -1801,6 +1801,28 @@ static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R,
   int ks = (384 + g.tiles0 - 1) / g.tiles0;
   if (ks > nt_all / 8) ks = nt_all / 8;                // >= 8 K-tiles per slice
   if (ks > 16) ks = 16;
+  {
+    // r5: the slice count from a cost model instead of "about 384 workgroups": rounds of workgroups over the CUs x (K-tiles per slice + ~6 K-tiles' worth of
+    // prologue / slab epilogue), plus the reduce pass's read of one fp32 slab per slice (tiles0 * 256 KiB at ~4.8 TB/s ~= 0.026 K-tile times per tile).  The old rule
+    // gave 144 output tiles 3 slices = 1.69 rounds (2 rounds for 84 % of the work); 5 or 7 slices fill their last round.  ST355_TN_KS: 0 = this model, -1 = the old
+    // rule, n = n slices (lab).
+    static int mode = -2;
+    if (mode == -2) { const char* e = getenv("ST355_TN_KS"); mode = e ? atoi(e) : 0; }
+    if (mode > 0) ks = mode;
+    else if (mode == 0 && g.tiles0 < 2 * device_cus()) {
+      const int cus = device_cus();
+      double best = 1e30; int best_ks = 1;
+      const int ks_max = nt_all / 8 < 16 ? (nt_all / 8 < 1 ? 1 : nt_all / 8) : 16;
+      for (int k = 1; k <= ks_max; k++) {
+        const int per = (nt_all + k - 1) / k;
+        const int rounds = (g.tiles0 * k + cus - 1) / cus;
+        const double cost = (double)rounds * (per + 6) + (k > 1 ? 0.026 * g.tiles0 * k : 0.0);
+        if (cost < best - 1e-9) { best = cost; best_ks = k; }
+      }
+      ks = best_ks;
+    }
+  }
+  while (ks >= 2 && workspace && (int64_t)ks * P * Q * taps * 4 > workspace_bytes) ks--;      // as many slices as the caller's slab space holds (never fall back to ONE round of full-K tiles)
   if (ks >= 2) { const int per = (nt_all + ks - 1) / ks; ks = (nt_all + per - 1) / per; }   // no empty K-slices (the ring prologue assumes >= 1 K-tile)
   if (ks >= 2 && workspace && ((uintptr_t)workspace % 16 == 0) && (int64_t)ks * P * Q * taps * 4 <= workspace_bytes) {
     g.p[0].partial = (float*)workspace; g.p[0].ksplit = ks; g.p[0].aux_in = nullptr;

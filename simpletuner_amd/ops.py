@@ -467,7 +467,7 @@ def gemm_tn(Lm, R, out=None, accumulate: bool = False):
             raise _l.St355Error("gemm_tn: accumulate needs an output tensor")
         out = torch.empty(P, Q, dtype=BF16, device=Lm.device)
     _chk(out, BF16, "out")
-    ws = _gemm_workspace(Lm.device, 256 << 20)
+    ws = _gemm_workspace(Lm.device, 512 << 20)          # fp32 split-K slabs: up to 7 slices of a 6144 x 1536 gradient (264 MB)
     _l.check(L.st355_gemm_tn_bf16(_stream(), _ptr(Lm), _rows(Lm, "L"), _ptr(R), _rows(R, "R"), _ptr(out), _rows(out, "out"), M, P, Q,
                                   1 if accumulate else 0, _ptr(ws), ws.numel() * 4), "gemm_tn_bf16")
     return out

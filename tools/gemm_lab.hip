@@ -254,6 +254,27 @@ int main(int argc, char** argv) {
     CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(sa)); CK(hipFree(ws));
   }
   if (getenv("LAB_F8")) return 0;
+  if (const char* tn = getenv("LAB_TN")) {                  // LAB_TN=P,Q,Mc : one weight-gradient problem, timed (ST355_TN_KS picks the K-slice count: tools/r05 ks sweep)
+    Shape s = {0, 0, 0, 0};
+    sscanf(tn, "%d,%d,%d", &s.M, &s.N, &s.K);
+    bf16 *Lm, *Rm, *C; void* tws;
+    CK(hipMalloc(&tws, (size_t)1024 << 20));
+    CK(hipMalloc(&Lm, (size_t)s.K * s.M * 2)); CK(hipMalloc(&Rm, (size_t)s.K * s.N * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
+    k_fill<<<1024, 256, 0, st>>>(Lm, (int64_t)s.K * s.M, 5u, 1.f);
+    k_fill<<<1024, 256, 0, st>>>(Rm, (int64_t)s.K * s.N, 6u, 0.05f);
+    for (int i = 0; i < 3; i++) st355_gemm_tn_bf16(st, Lm, s.M, Rm, s.N, C, s.N, s.K, s.M, s.N, 0, tws, (int64_t)1024 << 20);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 20; i++) st355_gemm_tn_bf16(st, Lm, s.M, Rm, s.N, C, s.N, s.K, s.M, s.N, 0, tws, (int64_t)1024 << 20);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    // checksum of C: two slice counts must agree to fp32 summation order (bf16 output)
+    unsigned short* hc = (unsigned short*)malloc((size_t)s.M * s.N * 2); CK(hipMemcpy(hc, C, (size_t)s.M * s.N * 2, hipMemcpyDeviceToHost));
+    double sum = 0, sq = 0; for (size_t i = 0; i < (size_t)s.M * s.N; i++) { unsigned u = (unsigned)hc[i] << 16; float f; memcpy(&f, &u, 4); sum += f; sq += (double)f * f; }
+    printf("  TN %6d x %6d over %6d (ST355_TN_KS=%s): %8.1f us  %8.1f TFLOP/s   sum %.6e  l2 %.6e\n", s.M, s.N, s.K, getenv("ST355_TN_KS") ? getenv("ST355_TN_KS") : "-", ms * 1e3,
+           2.0 * s.M * s.N * (double)s.K / ms / 1e9, sum, sqrt(sq));
+    return 0;
+  }
   // weight-gradient (TN) form: C[P,Q] = L[M,P]^T R[M,Q]; Shape {M=P, N=Q, K=contraction}
   for (const Shape& s : {Shape{3072, 3072, 4608, 0}, Shape{12288, 3072, 4608, 0}, Shape{3072, 12288, 18432, 0}, Shape{1536, 1536, 16384, 0},
                          Shape{6144, 1536, 16384, 0}, Shape{8192, 8192, 8192, 0}}) {
