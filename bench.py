@@ -735,7 +735,7 @@ def run_workload(args, dev, rank, world):
         rep_ = gs_.overlap_report() if gs_ is not None else None      # the LAST timed step's exchange (device timestamps; synchronises)
         if rep_ is not None:
             durs = [round((s_["end_ms"] - s_["start_ms"]) * 1e3, 1) for s_ in rep_["slices"]]
-            comm_rep = {"path": "st355_comm_* C ABI over RCCL (ST355_COMM=native)" if gs_.comm is not None else f"torch.distributed {dist.get_backend()} (RCCL) collectives on a comm stream",
+            comm_rep = {"path": "st355_comm_* C ABI over RCCL (ST355_COMM=native)" if gs_.comm is not None else (f"torch.distributed {dist.get_backend()} collectives on a comm stream" + (" (nccl = RCCL over xGMI)" if str(dist.get_backend()).lower() == "nccl" else " (gloo: the shared-GPU plumbing run)")),
                         "mode": gs_.mode, "fp32_reduce": bool(gs_.fp32_reduce), "bucket_bytes": int(gs_.bucket_elems * gs_.flat.element_size()),
                         "arena_bytes": int(gs_.flat.numel() * gs_.flat.element_size()), "backward_ms": round(rep_["backward_ms"], 3),
                         "comm_ms_sum_over_buckets": round(rep_["comm_ms"], 3), "exposed_tail_ms": round(rep_["exposed_ms"], 3),
