@@ -100,15 +100,30 @@ def adaln_single(P, cfg: PixArtConfig, timestep, resolution, aspect_ratio, B, dt
     return _lin(F.silu(emb), P, "adaln_single.linear"), emb
 
 
+class _Fp8NativeLinearFn(torch.autograd.Function):
+    """_Fp8NativeLinearFn (fp8_native.py:33-111): forward = e5m2 per-call activation x e4m3 row-scaled weight, fp32 accumulate, bf16 result; backward = grad_output @ the
+    DEQUANTISED weight (:104-111) — the quantisers are not differentiated, the base weight gets no gradient"""
+
+    @staticmethod
+    def forward(ctx, x2, w, b):
+        from . import train_math as TM
+        q, sc = TM.fp8_quantize_weight(w.to(torch.bfloat16))
+        xq, sa = TM.fp8_quantize_act(x2.to(torch.bfloat16))
+        ctx.save_for_backward(q, sc)
+        return TM.fp8_linear(xq, sa, q, sc, None if b is None else b.to(torch.bfloat16)).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        q, sc = ctx.saved_tensors
+        w = q.to(torch.bfloat16) * sc.to(torch.bfloat16).unsqueeze(1)          # `weight.to(grad_output.dtype) * weight_scale.to(grad_output.dtype).unsqueeze(1)`, bf16 in training
+        return g @ w.float(), None, None
+
+
 def lin_fp8(x, P, name):
-    """Fp8NativeLinear (fp8_native.py:25-119): e4m3 row-scaled weight, e5m2 per-call activation, fp32 accumulate, bf16 result"""
-    from . import train_math as TM
+    """Fp8NativeLinear (fp8_native.py:25-119): e4m3 row-scaled weight, e5m2 per-call activation, fp32 accumulate, bf16 result; differentiable in x as the reference's
+    autograd Function is (adapters over an fp8-native trunk)"""
     shp = x.shape
-    x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16)
-    q, sc = TM.fp8_quantize_weight(P[name + ".weight"].to(torch.bfloat16))
-    xq, sa = TM.fp8_quantize_act(x2)
-    b = P.get(name + ".bias")
-    return TM.fp8_linear(xq, sa, q, sc, None if b is None else b.to(torch.bfloat16)).float().reshape(*shp[:-1], -1)
+    return _Fp8NativeLinearFn.apply(x.reshape(-1, shp[-1]), P[name + ".weight"], P.get(name + ".bias")).reshape(*shp[:-1], -1)
 
 
 def _attn(P, p, x, ctx, H, bias=None, _lin=_lin):

@@ -177,8 +177,8 @@ class PixArtTransformer2DModel(nn.Module):
         H * 96 columns, the pad rows / columns initialised to ZERO.  They stay zero: the gradient of a pad row of B is dY_pad^T T and dY is exactly zero on the pad
         lanes (K / Q / W_out pad lanes are zero), the gradient of a pad column of A is U^T O_pad with O_pad = 0 — and AdamW leaves a zero parameter with a zero
         gradient at zero.  `lora_state_dict()` hands out the true-shaped (peft) tensors."""
-        if self.fp8_base:
-            raise NotImplementedError("PixArt LoRA over an fp8-native trunk is not built on the st355 path")
+        # over an fp8-native trunk (base_model_precision fp8 + adapters: the reference's published sweeps carry such rows, SEGMENTED_CHECKPOINTING.md:786,819,846) the
+        # base Linear runs on the fp8 pipe and the low-rank term is added in bf16 (peft's LoraLayer around Fp8NativeLinear): `_block_fwd_fp8`
         alpha = float(rank if alpha is None else alpha)
         D, H, hd, dev = self.inner_dim, self.H, self.hd, self.device_
         Dp = H * HP
@@ -372,8 +372,8 @@ class PixArtTransformer2DModel(nn.Module):
         if blk.fp8:
             return self._block_fwd_fp8(blk, h, ctx2d, kbias, mod, m, B, S, Sk, save)
         L = blk.lora
-        if L is not None and (blk.fp8 or rpb != S):
-            raise NotImplementedError("PixArt LoRA: bf16 trunk with per-sample timesteps")
+        if L is not None and rpb != S:
+            raise NotImplementedError("PixArt LoRA: per-sample timesteps only")
         kx = (lambda g, T: dict(a2=T, b2=g.B_blk, k2_real=g.k2_real)) if L is not None else (lambda g, T: {})
         if _BLOCK_ABI and ops.ATTN_TR and h.is_contiguous() and ctx2d.is_contiguous() and rpb == S and L is None:
             # the block as ONE C entry point (st355_block_pixart_fwd): the launches of the host-side sequencing below, in its order, on its
@@ -443,9 +443,17 @@ class PixArtTransformer2DModel(nn.Module):
         Dp = H * HP
         scale = 1.0 / math.sqrt(self.hd)
 
+        L = blk.lora
+        Ts = {}
+
         def lin8(x, name, bias):
             xq, sa = ops.fp8_quantize_act(x)
-            return ops.linear_fp8(xq, sa, getattr(W, name + "_q"), getattr(W, name + "_s"), bias=bias)
+            y = ops.linear_fp8(xq, sa, getattr(W, name + "_q"), getattr(W, name + "_s"), bias=bias)
+            g = getattr(L, name, None) if L is not None else None
+            if g is not None:             # peft's LoraLayer around the fp8-native base Linear: y + s B (A x), the low-rank term in bf16 on the un-quantised input
+                T = Ts[name] = ops.gemm(x, g.A_cat)
+                y = ops.gemm(T, g.B_blk, epilogue=EPI_ADD, aux_in=y)
+            return y
 
         n1 = ops.ln_modulate_fwd(h, m[1], m[0], S)
         qkv = lin8(n1, "qkv", W.qkv_b)
@@ -472,7 +480,8 @@ class PixArtTransformer2DModel(nn.Module):
         sv = None
         if save:
             sv = SimpleNamespace(h=h, mod=mod, m=m, n1=n1, qkv=qkv, Q=Q, Qt=Qt, K=K, Kt=Kt, O=O, lse=lse, Sp=Sp, ya=None, h1=h1, q2=q2, kv=kv, Q2=Q2, Q2t=Q2t, K2=K2,
-                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=None)
+                                 K2t=K2t, Skp=Skp, O2=O2, lse2=lse2, h2=h2, n2=n2, pre=pre, a=a, yf=None, T_qkv=Ts.get("qkv"), T_o1=Ts.get("out1"), T_q2=Ts.get("q2"),
+                                 T_kv=Ts.get("kv2"), T_o2=Ts.get("out2"))
         return h3, sv
 
     def _block_bwd(self, blk: _Block, sv, d3, ctx2d, kbias, B, S, Sk):

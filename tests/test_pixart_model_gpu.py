@@ -201,6 +201,54 @@ def test_pixart_trunk_tokenwise_timesteps_match_oracle():
     assert r < 2e-2 and cos > 0.9995 and _rel(flat, ref) > 5e-2
 
 
+def test_pixart_lora_over_the_fp8_native_trunk_matches_the_fp8_oracle():
+    """base_model_precision fp8 + LoRA (the reference's sweeps carry such rows: SEGMENTED_CHECKPOINTING.md:786, 819, 846): every base Linear of the trunk on the fp8 pipe
+    (e5m2 activations x e4m3 weights), the adapters' low-rank term added in bf16 on the un-quantised input (peft's LoraLayer around Fp8NativeLinear), the backward through
+    the DEQUANTISED weights (fp8_native.py:104-111).  Against the oracle with the same quantisers in every block Linear and an autograd Function restating that backward.
+    Tolerances: prediction vs the fp8 oracle rel-L2 <= 5e-2 (same quantisation points, bf16 rounding placement differs — the bound of the adapter-free fp8 test);
+    adapter gradients rel-L2 <= 1.5e-1: the two sides quantise activations that already differ by bf16 rounding, and an e5m2 value that lands in the neighbouring bin moves
+    by 25 % (2 mantissa bits) — the fp8 forward's own noise, which the bf16 trunk test (6e-2) does not have."""
+    from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
+    dev = "cuda:0"
+    m = PixArtTransformer2DModel(device=dev, fp8_base=True, **ARCH)
+    m.init_synthetic(5)
+    m.add_lora_adapter(rank=8, alpha=16.0, init_b_std=0.05)
+    lat, cond, enc, mask, t = _inputs()
+    m.train()
+    target = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4))
+    out = m(lat.to(dev), encoder_hidden_states=enc.to(dev), timestep=t.to(dev), encoder_attention_mask=mask.to(dev), return_dict=False)[0]
+    loss = ((out.chunk(2, dim=1)[0].float() - target.to(dev)) ** 2).mean()
+    loss.backward()
+    P = {k: v.detach().float().cpu() for k, v in m.named_parameters() if ".lora_" not in k}
+    lp = {}
+    for k, v in m.lora_state_dict().items():
+        mod, which = k.split(".lora_")
+        lp.setdefault(mod, [None, None])[0 if which.startswith("A") else 1] = v.float().cpu().clone().requires_grad_(True)
+    lp = {k: tuple(v) for k, v in lp.items()}
+    res, ar = torch.tensor([[16.0, 16.0]]).expand(2, -1), torch.tensor([[1.0]]).expand(2, -1)
+    ref = pixart_forward(P, PixArtConfig(**ARCH), lat.float(), enc.float(), mask, t, res, ar, fp8_blocks=True, lora=lp, lora_scale=2.0)
+    lref = ((ref.chunk(2, dim=1)[0] - target) ** 2).mean()
+    lref.backward()
+    r8 = _rel(out.detach().cpu(), ref.detach())
+    H, hd = ARCH["num_attention_heads"], ARCH["attention_head_dim"]
+    worst, n = (0.0, ""), 0
+    for name, p in m.named_parameters():
+        if ".lora_" not in name:
+            continue
+        mod, which = name.split(".lora_")
+        g = p.grad
+        assert g is not None, name
+        if which.startswith("A") and g.shape[1] == H * HP:
+            g = g.view(g.shape[0], H, HP)[:, :, :hd].reshape(g.shape[0], H * hd)
+        if which.startswith("B") and g.shape[0] == H * HP:
+            g = g.view(H, HP, g.shape[1])[:, :hd].reshape(H * hd, g.shape[1])
+        r = _rel(g.cpu(), lp[mod][0 if which.startswith("A") else 1].grad)
+        worst = max(worst, (r, name)); n += 1
+    print(f"[pixart LoRA over the fp8 trunk] pred vs fp8 oracle {r8:.3e}, loss hip {loss.item():.5f} oracle {lref.item():.5f}, {n} adapter gradients, worst rel-L2 {worst[0]:.3e} at {worst[1]}")
+    assert r8 < 5e-2 and abs(loss.item() - lref.item()) < 2e-2 * max(1.0, abs(lref.item()))
+    assert worst[0] < 1.5e-1, worst
+
+
 @pytest.mark.parametrize("route", [False, True])
 def test_pixart_trunk_lora_gradients_match_autograd(route):
     """PixArt LoRA (pixart/model.py:59: to_k, to_q, to_v, to_out.0 of attn1 / attn2 in every trunk block) on the HIP path: the adapters ride in the K-extension of
