@@ -210,6 +210,7 @@ def test_pixart_lora_over_the_fp8_native_trunk_matches_the_fp8_oracle():
     by 25 % (2 mantissa bits) — the fp8 forward's own noise, which the bf16 trunk test (6e-2) does not have."""
     from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
     dev = "cuda:0"
+    ARCH = dict(num_attention_heads=16, attention_head_dim=72, num_layers=2, caption_channels=128, sample_size=128, cross_attention_dim=1152)      # D = 1152: K % 128 == 0 for the fp8 GEMM
     m = PixArtTransformer2DModel(device=dev, fp8_base=True, **ARCH)
     m.init_synthetic(5)
     m.add_lora_adapter(rank=8, alpha=16.0, init_b_std=0.05)
