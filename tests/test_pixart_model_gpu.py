@@ -206,7 +206,7 @@ def test_pixart_lora_over_the_fp8_native_trunk_matches_the_fp8_oracle():
     (e5m2 activations x e4m3 weights), the adapters' low-rank term added in bf16 on the un-quantised input (peft's LoraLayer around Fp8NativeLinear), the backward through
     the DEQUANTISED weights (fp8_native.py:104-111).  Against the oracle with the same quantisers in every block Linear and an autograd Function restating that backward.
     Tolerances: prediction vs the fp8 oracle rel-L2 <= 5e-2 (same quantisation points, bf16 rounding placement differs — the bound of the adapter-free fp8 test);
-    adapter gradients rel-L2 <= 1.5e-1: the two sides quantise activations that already differ by bf16 rounding, and an e5m2 value that lands in the neighbouring bin moves
+    adapter gradients rel-L2 <= 1e-1 (measured r5: prediction 2.75e-2, worst of 32 adapter gradients 5.9e-2): the two sides quantise activations that already differ by bf16 rounding, and an e5m2 value that lands in the neighbouring bin moves
     by 25 % (2 mantissa bits) — the fp8 forward's own noise, which the bf16 trunk test (6e-2) does not have."""
     from simpletuner_amd.pixart.transformer import HP, PixArtTransformer2DModel
     dev = "cuda:0"
@@ -247,7 +247,7 @@ def test_pixart_lora_over_the_fp8_native_trunk_matches_the_fp8_oracle():
         worst = max(worst, (r, name)); n += 1
     print(f"[pixart LoRA over the fp8 trunk] pred vs fp8 oracle {r8:.3e}, loss hip {loss.item():.5f} oracle {lref.item():.5f}, {n} adapter gradients, worst rel-L2 {worst[0]:.3e} at {worst[1]}")
     assert r8 < 5e-2 and abs(loss.item() - lref.item()) < 2e-2 * max(1.0, abs(lref.item()))
-    assert worst[0] < 1.5e-1, worst
+    assert worst[0] < 1e-1, worst
 
 
 @pytest.mark.parametrize("route", [False, True])
