@@ -688,7 +688,7 @@ def run_workload(args, dev, rank, world):
     if args.graph and args.buckets:            # one capture per bucket shape before the warm-up proper (each first encounter = 2 eager steps + capture + replay), untimed
         for k_ in sorted(by_shape, key=lambda k__: -shape_of[k__][0] * shape_of[k__][1]):      # largest token count first: the later, smaller captures reuse its pool blocks
             trainer.train_step(dict(by_shape[k_]))
-    if os.environ.get("ST355_BENCH_FAIL_RANK") == str(rank) and world > 1:      # lab hook (tools/r05_gpu_13.sh): this rank dies before its first step — the job must end non-zero, promptly
+    if os.environ.get("ST355_BENCH_FAIL_RANK") == str(rank) and world > 1:      # lab hook (tools/gpu_lease.sh two_ranks): this rank dies before its first step — the job must end non-zero, promptly
         raise RuntimeError(f"ST355_BENCH_FAIL_RANK: rank {rank} fails on purpose")
     for i in range(args.warmup):
         l_ = trainer.train_step(dict(batches[i % nb_]))

@@ -128,7 +128,7 @@ __device__ __forceinline__ void glds16(const bf16* gsrc, char* lds_dst_wave_unif
 }
 
 // grouped tile order: GROUP consecutive m-tiles share one W panel
-#ifndef ST355_TILE_GROUP          // tools/gemm_lab builds: the tile-order experiment (tools/r05_gemm_tile_order.sh); the library always builds with 8
+#ifndef ST355_TILE_GROUP          // tools/gemm_lab builds: the tile-order experiment (tools/gpu_lease.sh gemm_power); the library always builds with 8
 #define ST355_TILE_GROUP 8
 #endif
 // measured r5 (profiles/r05_gemm_power.md): 8 sits at the fetch minimum for K <= 3072 (8 x 4 concurrent tiles per XCD: 12 operand panels per 32 tiles); with

@@ -404,6 +404,10 @@ class Trainer:
             comp.load_diffusers_state(load_file(full_path))
         else:
             plug.load_lora_weights(input_dir=checkpoint_dir)
+            sh = self._bf16_shadow
+            if sh is not None:                    # adamw_bf16 over the adapter arena: the optimizer's bf16 values follow the loaded weights (the saved adapters ARE bf16 numbers
+                sh.master.copy_(sh.flat32)        # when this trainer wrote them; a foreign file is rounded once, as at construction), and the engine's arena mirrors them
+                sh.flat32.copy_(sh.master)
         unsafe = bool(getattr(self.config, "allow_unsafe_checkpoint_pickles", False))     # explicit opt-in only: the default never executes a pickle
         self.optimizer.load_state_dict(_safe_load(os.path.join(checkpoint_dir, "optimizer.bin"), unsafe))
         sched = os.path.join(checkpoint_dir, "scheduler.bin")

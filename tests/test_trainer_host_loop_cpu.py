@@ -171,3 +171,21 @@ def test_lora_under_adamw_bf16_trains_bf16_adapter_values(monkeypatch):
     assert all(p.grad is None for p in model.trainable_parameters())
     st = trainer.optimizer.state[sh.params[0]]
     assert st["step"] == 6.0 and st["exp_avg"].dtype == torch.bfloat16 and float(st["exp_avg"].float().abs().sum()) > 0
+
+
+def test_lora_under_adamw_bf16_resumes_with_the_optimizer_following_the_loaded_weights(monkeypatch, tmp_path):
+    """save_state / load_state with adamw_bf16 over the adapter arena: the fresh trainer's bf16 arena (what the optimizer steps) must follow the LOADED adapter weights —
+    otherwise the first resumed step would mirror its own stale start values over them — and the resumed run must continue bit for bit like the uninterrupted one"""
+    plug_a, tr_a, cpu, devt = _build(monkeypatch, 1, 1, 2, 16, 16, 32, lora_rank=8, lora_init_b_std=0.02, learning_rate=2e-3, optimizer="adamw_bf16")
+    for _ in range(2):
+        tr_a.train_step(_batch(devt))
+    ck = tmp_path / "checkpoint-2"
+    tr_a.save_state(str(ck))
+    plug_b, tr_b, _, _ = _build(monkeypatch, 1, 1, 2, 16, 16, 32, lora_rank=8, lora_init_b_std=0.05, learning_rate=2e-3, optimizer="adamw_bf16")   # other start values
+    assert not torch.equal(tr_b._bf16_shadow.master, tr_a._bf16_shadow.master)
+    tr_b.load_state(str(ck))
+    sa, sb = tr_a._bf16_shadow, tr_b._bf16_shadow
+    assert torch.equal(sb.master, sa.master) and torch.equal(sb.flat32, sa.flat32) and torch.equal(sb.flat32, sb.master.float())
+    la, lb = tr_a.train_step(_batch(devt)), tr_b.train_step(_batch(devt))
+    assert torch.equal(la, lb) and torch.equal(sb.master, sa.master)          # same loss from the loaded weights, same bf16 weights after the resumed step
+    assert tr_b.state["global_step"] == 3
