@@ -7,8 +7,8 @@ out=$R/gpurun_out/attn_pmc_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
 export ATTN_LAB_CHILD=1 ST355_ATTN_FWD=${ATTN_GEN:-4} LAB_ITERS=4      # ATTN_GEN=1: the child that also runs both backward forms
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/p1 -o p1 --output-format csv -- $R/tools/attn_lab 8 24 4608 128 > $out/p1.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $out/p2 -o p2 --output-format csv -- $R/tools/attn_lab 8 24 4608 128 > $out/p2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/p1 -o p1 --output-format csv -- $R/tools/attn_lab ${ATTN_SHAPE:-8 24 4608 128} > $out/p1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $out/p2 -o p2 --output-format csv -- $R/tools/attn_lab ${ATTN_SHAPE:-8 24 4608 128} > $out/p2.log 2>&1
 cd $R
 python - <<PY
 import csv, glob, collections
