@@ -131,3 +131,17 @@ def test_checkpoint_plans_through_the_emulator_are_bit_identical(monkeypatch, in
     o0, g0 = run(False)
     o1, g1 = run(True)
     assert torch.equal(o0, o1) and torch.equal(g0, g1) and g0.abs().sum().item() > 0
+
+
+def test_head_widths_pick_the_padded_kernel_width_the_contract_allows():
+    """include/st355.h: head_dim 96 is the width of a zero-padded narrower head whose channels [80, 96) are zero — the 64-row kernels contract over 80 channels.  The UNet's
+    attention therefore pads heads of up to 80 channels to 96 and anything wider (81 … 128) to 128; 64 and below to 64; above 128 the unfused path."""
+    import inspect
+
+    from simpletuner_amd.unet import unet as U
+    src = inspect.getsource(U.UNet2DConditionModel._attention)
+    ns = {}
+    line = next(l for l in src.splitlines() if l.strip().startswith("hp = "))
+    for hd, want in ((40, 64), (64, 64), (72, 96), (80, 96), (81, 128), (96, 128), (128, 128), (160, 0)):
+        exec(line.strip().split("#")[0], {"hd": hd}, ns)
+        assert ns["hp"] == want, (hd, ns["hp"], want)
