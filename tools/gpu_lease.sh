@@ -10,6 +10,7 @@
 #   sd3_stats     rocprofv3 --kernel-trace --stats of the SD3-Medium full fine-tune step by kernel name           (profiles/r05_sd3_full_b8_rocprofv3_kernel_stats.csv)
 #   shapes MODEL… per-shape launch table of a bench workload: tools/gpu_lease.sh shapes --model sd3 --full --batch 8   (profiles/r05_*_shapes.txt)
 #   two_ranks     bench.py --gpus 2 on one device over gloo (plumbing) + a rank that fails on purpose             (profiles/r05_two_ranks_*)
+#   sanity        smoke(), the resume / graph / golden GPU tests, the headline step without secondaries (two minutes)
 #   pmc           PMC passes (matrix-pipe busy, LDS, waits) over the labs: GEMM on the step's shapes, attention at the Flux / PixArt 2K shapes   (profiles/r05_pmc_mfma_lds.md)
 #   ab NAME ENV=a ENV=b -- bench args…   the same bench command under two environments, back to back            (every same-box A/B in profiles/)
 cd ${GRAFT_REPO_ROOT:-$PWD}; mkdir -p gpurun_out
@@ -103,6 +104,10 @@ PY
     for rep in 1 2; do for e in "${envs[@]}"; do
       env "$e" timeout 500 python bench.py "$@" --no-cpu-baseline > gpurun_out/ab_${name}_${e//[^A-Za-z0-9]/_}.json 2> gpurun_out/ab_${name}.log; echo "[$e]"; line gpurun_out/ab_${name}_${e//[^A-Za-z0-9]/_}.json
     done; done ;;
+  sanity)       # two minutes: smoke(), the resume / graph / golden GPU tests, the headline step without its secondaries
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "amdgpu.ids" | tail -3
+    timeout 600 python -m pytest tests/test_optimizer_state_gpu.py tests/test_trainer_graph_gpu.py tests/test_golden_gpu.py tests/test_adamw_bf16_gpu.py -q 2>&1 | tail -2
+    timeout 300 python bench.py --steps 6 --warmup 2 --no-secondary --no-cpu-baseline > gpurun_out/sanity_line.json 2> /dev/null; line gpurun_out/sanity_line.json ;;
   pmc)          # matrix-pipe busy / LDS activity / wait fraction by PMC (counters only + --kernel-trace): the GEMM on the step's shapes, attention at the Flux and PixArt 2K shapes
     for sh in 36864,12288,3072 36864,3072,12288 36864,3072,3072; do tools/gemm_pmc.sh r05_$(echo $sh | tr ',' 'x') $sh | cut -c1-330; done
     tools/attn_pmc.sh r05_flux | cut -c1-330
