@@ -182,6 +182,12 @@ int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, 
                        int64_t Mc, int P, int Q, int accumulate, void* workspace /* optional fp32 scratch for split-K */,
                        int64_t workspace_bytes);
 
+/* the same product with a SEGMENTED contraction axis: logical contraction row m of operand X in {L, R} lives at physical row (m / seg_rows) * seg_X + m % seg_rows
+ * from X's pointer (seg_X = 0: compact).  seg_rows: a multiple of 64, >= 128, dividing Mc.  A stream's rows of a joint [B, S, *] buffer — the image rows of the
+ * attention output or of the projection gradient — are contracted in place, with no gathered copy. */
+int st355_gemm_tn_seg_bf16(void* stream, const void* L, int64_t ldl, int64_t seg_l, const void* R, int64_t ldr, int64_t seg_r, void* C, int64_t ldc,
+                           int64_t Mc, int64_t seg_rows, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes);
+
 /* token-axis reductions of the full fine-tune backward (bias gradients, AdaLN modulation shift / scale / gate gradients):
  *   out[b*out_stride + n] (+)= sum_{t in batch b} a[t,n] * (b ? b[t,n] : 1)        rows = nb * rows_per_batch, fp32 out
  * mode 1 finishes a modulation-scale gradient from the saved LN output n = xhat(1+scale)+shift:
@@ -190,6 +196,34 @@ size_t st355_colsum_workspace(int64_t rows, int N, int64_t rows_per_batch);
 int st355_colsum_prod(void* stream, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int N,
                       int64_t rows_per_batch, float* out, int64_t out_stride, int mode, const float* prev, int64_t prev_stride,
                       const void* shift, const void* scale, int64_t mod_stride, int accumulate, void* workspace);
+/* ---- the same token-axis sums FUSED into the passes that already stream their operands (round 6; csrc/stats.hip) ----------------------------------
+ * One destination of a fused column sum: per-batch fp32 rows out[b * stride + n] (the slices of the modulation-gradient buffer), or — reduce_batches —
+ * ONE row summed over every batch element (a bias gradient), fp32 or bf16 (out_bf16: straight into the bf16 gradient arena).  out == NULL: not wanted. */
+typedef struct st355_stat_out {
+  void*   out;
+  int64_t stride;
+  int32_t reduce_batches, out_bf16, accumulate, _pad;
+} st355_stat_out;
+/* fp32 scratch bytes for `nsums` fused sums over rows x N with batches of rows_per_batch (one partial row per 64 rows and sum) */
+size_t st355_stats_workspace(int64_t rows, int N, int64_t rows_per_batch, int nsums);
+/* st355_ln_modulate_bwd + what autograd accumulates around one AdaLN instance (sd3/transformer.py:150-160, 216-239; flux/transformer.py:607-687):
+ *   d_shift = sum_t dy      d_scale = sum_t dy * LN(x)                                    (the modulation linear's output gradient, per batch element)
+ *   d_gate  = sum_t dx * y_branch      (dx as written; y_branch = the un-gated output of the branch whose residual gradient dx is)          [optional]
+ *   d_bias  = sum_{b,t} dxg            (dxg as written = the output gradient of the Linear that produced y_branch: its bias gradient)        [optional]
+ * workspace: st355_stats_workspace(rows, D, rows_per_batch, 4).  D <= 3072. */
+int st355_ln_modulate_bwd_stats(void* stream, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* scale, int64_t mod_stride,
+                                int64_t rows_per_batch, const void* dres, int64_t lddres, const void* gate, int64_t gate_stride, void* dx, int64_t lddx,
+                                void* dxg, int64_t lddxg, int64_t rows, int D, float eps, const void* y_branch, int64_t ld_y,
+                                const st355_stat_out* d_shift, const st355_stat_out* d_scale, const st355_stat_out* d_gate, const st355_stat_out* d_bias,
+                                void* workspace);
+/* st355_scale_cols (out = gate_b * in) + d_gate = sum_t in * y_branch (optional) + d_bias = sum_{b,t} out (as written).  workspace: (M, N, rows_per_batch, 2) */
+int st355_scale_cols_stats(void* stream, const void* in, int64_t ld_in, const void* gate, int64_t gate_stride, int64_t rows_per_batch, void* out,
+                           int64_t ld_out, int64_t M, int N, const void* y_branch, int64_t ld_y, const st355_stat_out* d_gate, const st355_stat_out* d_bias,
+                           void* workspace);
+/* plain column sums of nb row blocks of rows_per_batch rows whose block b starts at physical row b * batch_stride_rows of a (a stream's rows of a joint
+ * [B, S, *] buffer are summed in place).  workspace: (nb * rows_per_batch, N, rows_per_batch, 1) */
+int st355_colsum_rows(void* stream, const void* a, int64_t lda, int64_t rows_per_batch, int64_t batch_stride_rows, int nb, int N,
+                      const st355_stat_out* out, void* workspace);
 /* dst[c, r] = src[r, c]  (bf16; rows, cols multiples of 8): refreshes the K-major weight copies after an optimizer step */
 int st355_transpose_bf16(void* stream, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols);
 /* The local half of the fp32-accumulating gradient reduce-scatter (replaces the bf16 SUM inside DDP's / RCCL's reducer, trainer.py:1034-1041): after an
@@ -557,6 +591,17 @@ typedef struct st355_sd3_joint_bwd_args {
   void* U_qkv; void* U_aqkv; void* dn_img; void* dn_txt; void* c_img; void* c_txt; void* gemm_ws;
   int64_t gemm_ws_bytes;
   void* attn_ws; void* d_img_out; void* d_txt_out;
+  /* Full fine-tune (round 6): the modulation / gate / bias gradients ride in this entry's own passes (csrc/stats.hip) instead of separate st355_colsum_prod
+   * passes over the gradients it leaves behind.  dmod_img != NULL turns the form on (needs need_input_grads): dmod_img / dmod_txt = this block's slices of the fp32
+   * modulation-gradient buffer (row stride dmod_stride; chunks shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp — the `last` block's text slice:
+   * scale, shift of its AdaLayerNormContinuous), overwritten; ya_* / yf_* = the un-gated attention / feed-forward branch outputs the forward kept; gb_* = the bf16
+   * bias-gradient rows of ff2, ff1, to_out, qkv (img) and ffc2, ffc1, to_add_out, add_qkv (txt), overwritten; stats_ws: st355_stats_workspace(B * max(Si, St), 4 * D,
+   * max(Si, St), 1) bytes of fp32 scratch. */
+  void* dmod_img; void* dmod_txt;
+  int64_t dmod_stride;
+  void* ya_img; void* ya_txt; void* yf_img; void* yf_txt;
+  void* gb_ff2; void* gb_ff1; void* gb_out; void* gb_qkv; void* gb_ffc2; void* gb_ffc1; void* gb_add_out; void* gb_add_qkv;
+  void* stats_ws;
 } st355_sd3_joint_bwd_args;
 int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd_args* args);
 

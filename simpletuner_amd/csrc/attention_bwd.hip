@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
                                                        const bf16* __restrict__ dO, int64_t ld_do, const float* __restrict__ lse2,
                                                        const float* __restrict__ delta, const float* __restrict__ key_bias,
                                                        bf16* __restrict__ dQ, int H, int Sq, int Sqp, int Sk, int Skp, float scale, float scale2,
-                                                       RopeBwd rp) {
+                                                       RopeBwd rp, int kt0 = 0, int accumulate = 0) {
+  // kt0 / accumulate: the RAGGED-TAIL form behind k_attn_bwd_dq64 — the backward is separable over keys once lse2 and delta are known
+  // (dQ_i = sum_j P_ij (dP_ij - delta_i) K_j), so the 64-row kernel takes the full 64-key tiles [0, kt0) and this kernel adds the contribution of
+  // the keys [64 kt0, Sk) to the dQ it left behind (one extra rounding of the sum to bf16)
   constexpr int NT = 512;
   constexpr int KROWB = HD * 2;
   constexpr int KT_BYTES = 64 * KROWB;   // K tile and V tile (row-major, 64 keys)
@@ -277,8 +280,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
   // TR: transposed-fragment base (see dkv3): lane = 16 g + 4 r + s, key row 8h + r, chunk (2 ihalf + (s >> 1)) ^ (4 r + 2 h), + (s & 1) * 8
   const int tr_r = (lane >> 2) & 3, tr_s = lane & 3, tr_ih = (lane >> 4) & 1;
   const int tr_base = (8 * h + tr_r) * 256 + ((((2 * tr_ih + (tr_s >> 1)) ^ (4 * tr_r + 2 * h))) << 4) + (tr_s & 1) * 8;
-  load_tile(0);
-  store_tile(0);
+  load_tile(kt0);
+  store_tile(kt0 & 1);
   __syncthreads();
   auto tile = [&](int kt, auto masked_c) {
     constexpr bool MASKED = decltype(masked_c)::value;
@@ -339,8 +342,8 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
     __syncthreads();
   };
   const int nfull = BIAS ? 0 : Sk / 64;                    // key tiles with all 64 keys valid and no bias take the plain path
-  for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
-  for (int kt = nfull; kt < nkt; kt++) tile(kt, std::true_type{});
+  for (int kt = kt0; kt < nfull; kt++) tile(kt, std::false_type{});
+  for (int kt = max(kt0, nfull); kt < nkt; kt++) tile(kt, std::true_type{});
   if (HD == 128 && rp.out != nullptr) {          // fused RoPE + RMSNorm backward: straight to the projection-gradient rows (all lanes take part in the exchange)
     // (the key-tile loop ended on a workgroup barrier: the LDS ring is idle, each wave takes its own 8 KiB slice)
     if constexpr (HD == 128) rope_bwd_store(rp, acc, scale, Q + bh * (int64_t)Sq * HD, b, head, q0, Sq, lane, smem + wv * 8192);
@@ -353,8 +356,14 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd_dq(const bf16* __restrict__
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         bf16x4 o;
+        if (accumulate) {
+          const bf16x4 prev = *(const bf16x4*)(orow + 32 * dt + 8 * a + 4 * h);
 #pragma unroll
-        for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
+          for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(fmaf(acc[dt][4 * a + bb], scale, bf2f(prev[bb])));
+        } else {
+#pragma unroll
+          for (int bb = 0; bb < 4; bb++) o[bb] = f2bf(acc[dt][4 * a + bb] * scale);
+        }
         *(bf16x4*)(orow + 32 * dt + 8 * a + 4 * h) = o;
       }
   }
@@ -1105,7 +1114,10 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     }
     if ((rc = st355_check_launch("attn_bwd_dkv")) != 0) return rc;
   }
-  if (!Kt && !key_bias && Sk % 64 == 0 && attn_dq_impl() == 64) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
+  // the 64-row kernel takes the full 64-key tiles; a ragged key tail (SD3's S = 4096 + 231, every mixed-aspect bucket) is added by the general kernel restricted
+  // to the last tile (kt0 / accumulate above).  The fused-RoPE epilogue (head_dim 128, Flux: S % 64 == 0 always) writes projection rows, not dQ: no tail form.
+  const bool dq_tail = Sk % 64 != 0;
+  if (!Kt && !key_bias && attn_dq_impl() == 64 && Sk >= 64 && (!dq_tail || (rq.out == nullptr && dQ != nullptr))) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int lds = 3 * 2 * 64 * 256;
@@ -1121,6 +1133,21 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     else ST355_DQ64_LAUNCH(64);
 #undef ST355_DQ64_LAUNCH
     if ((rc = st355_check_launch("attn_bwd_dq64")) != 0) return rc;
+    if (dq_tail) {
+      const int lds_t = 2 * (64 * 256 + 64 * d * 2);
+#define ST355_DQT_LAUNCH(HD_)                                                                                                             \
+  do {                                                                                                                                   \
+    static St355AttrOnce set;                                                                                                             \
+    if (set.need()) { hipFuncSetAttribute((const void*)k_attn_bwd_dq<HD_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t); } \
+    hipLaunchKernelGGL((k_attn_bwd_dq<HD_, true, false>), grid, dim3(512), lds_t, st, (const bf16*)Q, (const bf16*)K, (const bf16*)nullptr, (const bf16*)v_rows, ld_v, \
+                       (const bf16*)dO, ld_do, lse2, (const float*)delta, (const float*)nullptr, (bf16*)dQ, H, S, Sp, Sk, Skp, scale, scale2, rq, Sk / 64, 1);   \
+  } while (0)
+      if (d == 128) ST355_DQT_LAUNCH(128);
+      else if (d == 96) ST355_DQT_LAUNCH(96);
+      else ST355_DQT_LAUNCH(64);
+#undef ST355_DQT_LAUNCH
+      if ((rc = st355_check_launch("attn_bwd_dq_tail")) != 0) return rc;
+    }
   } else {
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);

@@ -676,7 +676,19 @@ extern "C" int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd
   Seq q{stream, 0};
   std::vector<st355_gemm_args> v;
   std::vector<Scatter> sc;
+  // full fine-tune: the modulation / gate / bias gradients ride in the passes below (csrc/stats.hip)
+  const bool stats = p->dmod_img != nullptr;
+  ST_REQUIRE(!stats || (p->need_input_grads && p->dmod_txt && p->dmod_stride > 0 && p->ya_img && p->yf_img && p->gb_ff2 && p->gb_ff1 && p->gb_out && p->gb_qkv &&
+                        p->gb_add_qkv && p->stats_ws && (last || (p->ya_txt && p->yf_txt && p->gb_ffc2 && p->gb_ffc1 && p->gb_add_out))),
+             "block_sd3_joint_bwd: the fused-statistics form needs every modulation / bias gradient destination, the kept branch outputs and stats_ws");
+  float* dmi = (float*)p->dmod_img; float* dmt = (float*)p->dmod_txt;
+  auto per_batch = [&](float* base, int chunk) { st355_stat_out o; memset(&o, 0, sizeof(o)); o.out = base + (int64_t)chunk * D; o.stride = p->dmod_stride; return o; };
+  auto bias_row = [&](void* gb) { st355_stat_out o; memset(&o, 0, sizeof(o)); o.out = gb; o.reduce_batches = 1; o.out_bf16 = 1; return o; };
   // ---- feed-forward branches: g = gate_mlp * d, d h = (g W2) * GELU'(pre), d norm2 = d h W1; d x1 = d + LN'(.), and gate_msa * d x1 in the same pass ----
+  if (stats) {
+    const st355_stat_out dg = per_batch(dmi, 5), db = bias_row(p->gb_ff2);            // d gate_mlp = sum d * y_ff, d b_ff2 = sum g
+    q.run(st355_scale_cols_stats(stream, p->d_img, D, mi + 5 * D, ms, Si, p->g_img, D, Mi, D, p->yf_img, D, &dg, &db, p->stats_ws));
+  } else
   q.run(st355_scale_cols(stream, p->d_img, D, mi + 5 * D, ms, Si, p->g_img, D, Mi, D));
   st355_gemm_args h_i = G(p->g_img, D, p->wT_ff2, D, p->dh_img, 4 * D, B * Si, 4 * D, D);
   h_i.epilogue = ST355_EPI_MUL_GELU_GRAD; h_i.aux_in = p->hpre_img; h_i.ld_aux_in = 4 * D;
@@ -685,15 +697,33 @@ extern "C" int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd
     q.gemm(h_i);
     q.gemm(n_i);
   } else {
+    if (stats) {
+      const st355_stat_out dg = per_batch(dmt, 5), db = bias_row(p->gb_ffc2);
+      if (q.ok()) q.run(st355_scale_cols_stats(stream, p->d_txt, D, mt + 5 * D, ms, St, p->g_txt, D, Mt, D, p->yf_txt, D, &dg, &db, p->stats_ws));
+    } else
     if (q.ok()) q.run(st355_scale_cols(stream, p->d_txt, D, mt + 5 * D, ms, St, p->g_txt, D, Mt, D));
     st355_gemm_args h_t = G(p->g_txt, D, p->wT_ffc2, D, p->dh_txt, 4 * D, B * St, 4 * D, D);
     h_t.epilogue = ST355_EPI_MUL_GELU_GRAD; h_t.aux_in = p->hpre_txt; h_t.ld_aux_in = 4 * D;
     st355_gemm_args n_t = G(p->dh_txt, 4 * D, p->wT_ffc1, 4 * D, p->dn2_txt, D, B * St, D, 4 * D);
     if (q.ok()) { st355_gemm_args g2[2] = {h_i, h_t}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
     if (q.ok()) { st355_gemm_args g2[2] = {n_i, n_t}; q.run(st355_gemm_bf16_grouped(stream, g2, 2)); }
+    if (stats) {          // + d shift_mlp, d scale_mlp, d gate_msa = sum d x1 * y_attn, d b_add_out = sum gate_msa * d x1;  d b_ffc1 = sum d h
+      const st355_stat_out dsh = per_batch(dmt, 3), dsc = per_batch(dmt, 4), dg = per_batch(dmt, 2), db = bias_row(p->gb_add_out), dbh = bias_row(p->gb_ffc1);
+      if (q.ok())
+        q.run(st355_ln_modulate_bwd_stats(stream, p->dn2_txt, D, p->x1_txt, D, mt + 4 * D, ms, St, p->d_txt, D, mt + 2 * D, ms, p->dx1_txt, D, p->dx1g_txt, D, Mt, D, 1e-6f,
+                                          p->ya_txt, D, &dsh, &dsc, &dg, &db, p->stats_ws));
+      if (q.ok()) q.run(st355_colsum_rows(stream, p->dh_txt, 4 * D, St, St, B, 4 * D, &dbh, p->stats_ws));
+    } else
     if (q.ok())
       q.run(st355_ln_modulate_bwd(stream, p->dn2_txt, D, p->x1_txt, D, mt + 4 * D, ms, St, p->d_txt, D, mt + 2 * D, ms, p->dx1_txt, D, p->dx1g_txt, D, Mt, D, 1e-6f));
   }
+  if (stats) {
+    const st355_stat_out dsh = per_batch(dmi, 3), dsc = per_batch(dmi, 4), dg = per_batch(dmi, 2), db = bias_row(p->gb_out), dbh = bias_row(p->gb_ff1);
+    if (q.ok())
+      q.run(st355_ln_modulate_bwd_stats(stream, p->dn2_img, D, p->x1_img, D, mi + 4 * D, ms, Si, p->d_img, D, mi + 2 * D, ms, p->dx1_img, D, p->dx1g_img, D, Mi, D, 1e-6f,
+                                        p->ya_img, D, &dsh, &dsc, &dg, &db, p->stats_ws));
+    if (q.ok()) q.run(st355_colsum_rows(stream, p->dh_img, 4 * D, Si, Si, B, 4 * D, &dbh, p->stats_ws));
+  } else
   if (q.ok())
     q.run(st355_ln_modulate_bwd(stream, p->dn2_img, D, p->x1_img, D, mi + 4 * D, ms, Si, p->d_img, D, mi + 2 * D, ms, p->dx1_img, D, p->dx1g_img, D, Mi, D, 1e-6f));
   // ---- attention output projections -> the dO rows of both streams (a context_pre_only block writes no text rows: the caller zero-filled dO) ----
@@ -729,6 +759,11 @@ extern "C" int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd
   if (q.ok())
     q.run(st355_qk_norm_rope_bwd(stream, p->dQ, p->dK, p->qkv, 3 * D, p->norm_added_q, p->norm_added_k, (const float*)p->cos, (const float*)p->sin, p->dqkv, 3 * D, B, H, hd, St,
                                  Si, S, 1e-6f));
+  if (stats) {          // d b_qkv / d b_add_qkv: column sums of each stream's rows of the joint dqkv, in place
+    const st355_stat_out dbi = bias_row(p->gb_qkv), dbt = bias_row(p->gb_add_qkv);
+    if (q.ok()) q.run(st355_colsum_rows(stream, p->dqkv, 3 * D, Si, S, B, 3 * D, &dbi, p->stats_ws));
+    if (q.ok()) q.run(st355_colsum_rows(stream, (const char*)p->dqkv + (size_t)Si * 3 * D * 2, 3 * D, St, S, B, 3 * D, &dbt, p->stats_ws));
+  }
   // ---- input projections: each stream's rows of dqkv in place (segmented) when tile-aligned or B == 1, else a compact copy ----
   Rows dq_i = joint_rows(p->dqkv, 3 * D, 0, S), dq_t = joint_rows(p->dqkv, 3 * D, Si, S);
   if (cp_i) { if (q.ok()) q.run(gather_block(stream, p->c_img, dq_i, Si, B)); dq_i = compact_rows(p->c_img, 3 * D); }
@@ -756,6 +791,16 @@ extern "C" int st355_block_sd3_joint_bwd(void* stream, const st355_sd3_joint_bwd
     g2[1] = whole(dq_t, p->wT_add_qkv, 3 * D, p->dn_txt, D, St, D, 3 * D);
     if (p->K2_aqkv) { g2[1].A2 = p->U_aqkv; g2[1].lda2 = p->K2_aqkv; g2[1].B2 = p->At_aqkv; g2[1].ldb2 = p->K2_aqkv; g2[1].K2 = p->K2_aqkv; g2[1].K2_real = p->k2r_aqkv; }
     if (q.ok()) q.run(st355_gemm_bf16_grouped(stream, g2, 2));
+  }
+  if (stats) {          // + d shift_msa, d scale_msa (the `last` block's text norm is AdaLayerNormContinuous: chunks (scale, shift))
+    const st355_stat_out ish = per_batch(dmi, 0), isc = per_batch(dmi, 1), tsh = per_batch(dmt, last ? 1 : 0), tsc = per_batch(dmt, last ? 0 : 1);
+    if (q.ok())
+      q.run(st355_ln_modulate_bwd_stats(stream, p->dn_img, D, p->img, D, mi + D, ms, Si, p->dx1_img, D, nullptr, 0, p->d_img_out, D, nullptr, D, Mi, D, 1e-6f, nullptr, 0,
+                                        &ish, &isc, nullptr, nullptr, p->stats_ws));
+    if (q.ok())
+      q.run(st355_ln_modulate_bwd_stats(stream, p->dn_txt, D, p->txt, D, last ? mt : mt + D, ms, St, last ? nullptr : p->dx1_txt, last ? 0 : D, nullptr, 0, p->d_txt_out, D,
+                                        nullptr, D, Mt, D, 1e-6f, nullptr, 0, &tsh, &tsc, nullptr, nullptr, p->stats_ws));
+    return q.rc;
   }
   if (q.ok())
     q.run(st355_ln_modulate_bwd(stream, p->dn_img, D, p->img, D, mi + D, ms, Si, p->dx1_img, D, nullptr, 0, p->d_img_out, D, nullptr, D, Mi, D, 1e-6f));

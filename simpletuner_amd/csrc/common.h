@@ -1,5 +1,6 @@
 // common.h — shared device helpers + host-side launch bookkeeping for libst355 (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -135,8 +136,14 @@ struct ProfScope {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: one flag per (launch site, device), so a process that launches on a second GPU
 // sets it there too (a single process-wide flag would skip it and the launch would fail)
+// (devices >= 32 are not cached: the attribute is simply set at every launch there; the flags are relaxed atomics — two host threads racing on a first launch
+// both set the attribute, which is idempotent)
 struct St355AttrOnce {
-  bool done[32] = {};
-  bool need() { int d = 0; if (hipGetDevice(&d) != hipSuccess) return true; d &= 31; if (done[d]) return false; done[d] = true; return true; }
+  std::atomic<bool> done[32] = {};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
+    return !done[d].exchange(true, std::memory_order_relaxed);
+  }
 };
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

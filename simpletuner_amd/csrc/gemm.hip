@@ -75,6 +75,9 @@ struct GemmP {
   // of 256) just shifts its operand base pointers by (m0 / seg_rows) * seg_xX (seg_view below) — the K loop and the epilogues are untouched.
   int seg_rows = 0;
   int64_t seg_xa = 0, seg_xa2 = 0, seg_xc = 0, seg_xin = 0, seg_xout = 0;
+  // TN form with a SEGMENTED contraction axis (st355_gemm_tn_seg_bf16): K-tile u of operand X starts tn_skip_X extra BYTES further for every whole segment of
+  // tn_tps K-tiles before it (tn_magic = ceil(2^32 / tn_tps): u / tn_tps = umulhi(u, tn_magic), exact for u < 2^16).  0 / 0 / 0: plain.
+  uint32_t tn_magic = 0; int tn_skip_a = 0, tn_skip_b = 0;
   // ST355_EPI_QK_NORM_ROPE (st355_gemm_args.rope): the fused QKV projection of an MMDiT attention (flux/transformer.py:140-207).  Output columns
   // [0, D) are q heads, [D, 2D) k heads, [2D, 3D) v heads (D = rH * 128).  q / k tiles: per-head RMSNorm (weights rwq / rwk, NULL = none) and RoPE from
   // the fp32 accumulators, written head-major to rq / rk [B, rH, rS, 128] at joint position rpos0 + m % rows_per_batch of sample m / rows_per_batch,
@@ -798,7 +801,8 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   auto stage_x = [&](int u, int r) {        // r = 0: XA, 1: XB
     char* dst = smem + (u & 1) * PQ_BUF + r * PQ_REGION + wv * 2048;
     if (u < nt1) {
-      const int x_ko = conv ? (int)(conv_koff(p, u + t_first, p.lda, PQ_BK) * 2) : (int)(u * xk_step);
+      const int x_ko = conv ? (int)(conv_koff(p, u + t_first, p.lda, PQ_BK) * 2)
+                            : (int)(u * xk_step) + (TN ? (int)__umulhi((uint32_t)(u + t_first), p.tn_magic) * p.tn_skip_a : 0);
       if (PQ_BUFLD) {       // measured +6..7 % over global_load_lds with 64-bit per-lane addresses (8192^3: 1317 -> 1414 TFLOP/s)
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -815,13 +819,14 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   auto stage_w = [&](int u, int r) {        // r = 0: WA, 1: WB
     char* dst = smem + (u & 1) * PQ_BUF + (2 + r) * PQ_REGION + wv * 2048;
     if (u < nt1) {
+      const int w_ko = (int)(u * wk_step) + (TN ? (int)__umulhi((uint32_t)(u + t_first), p.tn_magic) * p.tn_skip_b : 0);
       if (PQ_BUFLD) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, wo[r][j], (int)(u * wk_step), 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, wo[r][j], w_ko, 0, 0);
         return;
       }
-      const char* kb = wbase + u * wk_step;
+      const char* kb = wbase + w_ko;
 #pragma unroll
       for (int j = 0; j < 2; j++) glds16((const bf16*)(kb + wo[r][j]), dst + j * 1024);
     } else {
@@ -1779,8 +1784,16 @@ static int launch_tn(void* stream, const GemmGroup& g, int tiles) {
 
 // taps == 9: C is [P, 9*Q]; column block `tap` = L^T (R shifted by (tap/3)*wp + tap%3 rows)  — the 3x3 convolution weight gradient in one launch
 static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
-                        int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes, int taps, int wp) {
+                        int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes, int taps, int wp,
+                        int64_t seg_rows = 0, int64_t seg_l = 0, int64_t seg_r = 0) {
   ST_REQUIRE(L && R && C && Mc > 0 && P > 0 && Q > 0, "gemm_tn: bad args");
+  if (seg_rows) {
+    ST_REQUIRE(taps == 1 && seg_rows >= 2 * PQ_BK && seg_rows % PQ_BK == 0 && Mc % seg_rows == 0 && (seg_l == 0 || seg_l >= seg_rows) && (seg_r == 0 || seg_r >= seg_rows),
+               "gemm_tn_seg: segments of %lld contraction rows (a multiple of 64, >= 128, that divides Mc = %lld), physical segment strides >= that", (long long)seg_rows, (long long)Mc);
+    const int64_t nseg = Mc / seg_rows;
+    const int64_t span_l = ((nseg - 1) * (seg_l ? seg_l : seg_rows) + seg_rows) * ldl * 2, span_r = ((nseg - 1) * (seg_r ? seg_r : seg_rows) + seg_rows) * ldr * 2;
+    ST_REQUIRE(span_l < ((int64_t)1 << 31) && span_r < ((int64_t)1 << 31) && Mc / PQ_BK < 65536, "gemm_tn_seg: operand too large for the 32-bit buffer offsets (2 GiB)");
+  }
   ST_REQUIRE(Mc % PQ_BK == 0, "gemm_tn: the contraction length (%lld rows) must be a multiple of 64 (pad the operands with zero rows)", (long long)Mc);
   ST_REQUIRE(P % 8 == 0 && Q % 8 == 0 && ldl % 8 == 0 && ldr % 8 == 0 && ldc % 8 == 0, "gemm_tn: P, Q and the leading dimensions must be multiples of 8");
   ST_REQUIRE(((uintptr_t)L % 16 == 0) && ((uintptr_t)R % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_tn: misaligned pointer");
@@ -1790,6 +1803,12 @@ static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R,
   p.A = (const bf16*)L; p.lda = ldl; p.B = (const bf16*)R; p.ldb = ldr; p.C = (bf16*)C; p.ldc = ldc;
   p.M = P; p.N = Q; p.K = (int)Mc; p.K2 = 0; p.ksplit = 1; p.part_ld = (int64_t)taps * Q;
   p.conv_taps = taps == 9 ? 9 : 0; p.conv_wp = wp;
+  if (seg_rows && Mc > seg_rows && ((seg_l && seg_l != seg_rows) || (seg_r && seg_r != seg_rows))) {
+    const uint32_t tps = (uint32_t)(seg_rows / PQ_BK);                                     // >= 2 (checked above): ceil(2^32 / tps) fits 32 bits
+    p.tn_magic = (uint32_t)((((uint64_t)1 << 32) + tps - 1) / tps);
+    p.tn_skip_a = (int)((seg_l ? seg_l - seg_rows : 0) * ldl * 2);
+    p.tn_skip_b = (int)((seg_r ? seg_r - seg_rows : 0) * ldr * 2);
+  }
   if (accumulate) { p.aux_in = (const bf16*)C; p.ld_aux_in = ldc; }
   GemmGroup g;
   g.p[0] = p; g.p[1] = p;
@@ -1843,6 +1862,15 @@ static int gemm_tn_impl(void* stream, const void* L, int64_t ldl, const void* R,
 extern "C" int st355_gemm_tn_bf16(void* stream, const void* L, int64_t ldl, const void* R, int64_t ldr, void* C, int64_t ldc,
                                   int64_t Mc, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes) {
   return gemm_tn_impl(stream, L, ldl, R, ldr, C, ldc, Mc, P, Q, accumulate, workspace, workspace_bytes, 1, 0);
+}
+
+// the same product with a SEGMENTED contraction axis: logical contraction row m of operand X in {L, R} lives at physical row (m / seg_rows) * seg_X + m % seg_rows
+// (seg_X = 0: compact).  A stream's rows of a joint [B, S, *] buffer (the image rows of the attention output, of the projection gradient) are then contracted in
+// place — round 5 gathered them into a compact copy first (100-300 MB read + written per operand and block).  seg_rows: a multiple of 64 (>= 128) that divides Mc.
+extern "C" int st355_gemm_tn_seg_bf16(void* stream, const void* L, int64_t ldl, int64_t seg_l, const void* R, int64_t ldr, int64_t seg_r, void* C, int64_t ldc,
+                                      int64_t Mc, int64_t seg_rows, int P, int Q, int accumulate, void* workspace, int64_t workspace_bytes) {
+  ST_REQUIRE(seg_rows > 0, "gemm_tn_seg: seg_rows");
+  return gemm_tn_impl(stream, L, ldl, R, ldr, C, ldc, Mc, P, Q, accumulate, workspace, workspace_bytes, 1, 0, seg_rows, seg_l, seg_r);
 }
 
 // ---- convolution over a zero-bordered NHWC grid (SDXL / SD1.5 UNet, VAE: diffusers ResnetBlock2D / Downsample2D / Upsample2D convs) -------

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(OP_THREADS) k_adamw_bf16(bf16* __restrict__ p,
     if (ema) {
       bf16x8 eb = *(bf16x8*)(ema + i * 8);
 #pragma unroll
-      for (int j = 0; j < 8; j++) { float e = bf2f(eb[j]); eb[j] = f2bf(e - c.ema_omd * (e - bf2f(pb[j]))); }
+      for (int j = 0; j < 8; j++) { const float e = bf2f(eb[j]); const float diff = bf2f(f2bf(e - bf2f(pb[j]))); eb[j] = f2bf(e - c.ema_omd * diff); }   // as k_ema<bf16>: (s - p) materialised in bf16 (ema.py:393-433)
       *(bf16x8*)(ema + i * 8) = eb;
     }
   }

@@ -20,7 +20,7 @@ SYMBOLS = [
     "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss", "st355_cond_loss", "st355_cond_loss_masked",
     "st355_flux_pack", "st355_flux_unpack", "st355_patchify", "st355_unpatchify",
     "st355_timestep_proj", "st355_silu", "st355_gelu_tanh", "st355_silu_bwd", "st355_add", "st355_gather_rows", "st355_scatter_rows", "st355_scale_cols",
-    "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_set_persistent", "st355_gemm_tn_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_transpose_bf16", "st355_sum_chunks_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg", "st355_skinny_tn_multi",
+    "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_set_persistent", "st355_gemm_tn_bf16", "st355_gemm_tn_seg_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_stats_workspace", "st355_ln_modulate_bwd_stats", "st355_scale_cols_stats", "st355_colsum_rows", "st355_transpose_bf16", "st355_sum_chunks_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg", "st355_skinny_tn_multi",
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd", "st355_qk_norm_wgrad_workspace", "st355_qk_norm_rope_bwd_wgrad", "st355_qk_rope_norm_bwd",
     "st355_attn_set_impl", "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd", "st355_attn_bwd_rope",
@@ -212,7 +212,15 @@ class Sd3JointBwdArgs(C.Structure):
         ("U_ao", C.c_void_p), ("dO", C.c_void_p), ("dqkv", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("U_qkv", C.c_void_p),
         ("U_aqkv", C.c_void_p), ("dn_img", C.c_void_p), ("dn_txt", C.c_void_p), ("c_img", C.c_void_p), ("c_txt", C.c_void_p), ("gemm_ws", C.c_void_p),
         ("gemm_ws_bytes", C.c_int64), ("attn_ws", C.c_void_p), ("d_img_out", C.c_void_p), ("d_txt_out", C.c_void_p),
+        ("dmod_img", C.c_void_p), ("dmod_txt", C.c_void_p), ("dmod_stride", C.c_int64), ("ya_img", C.c_void_p), ("ya_txt", C.c_void_p), ("yf_img", C.c_void_p),
+        ("yf_txt", C.c_void_p), ("gb_ff2", C.c_void_p), ("gb_ff1", C.c_void_p), ("gb_out", C.c_void_p), ("gb_qkv", C.c_void_p), ("gb_ffc2", C.c_void_p),
+        ("gb_ffc1", C.c_void_p), ("gb_add_out", C.c_void_p), ("gb_add_qkv", C.c_void_p), ("stats_ws", C.c_void_p),
     ]
+
+
+class StatOut(C.Structure):
+    """st355_stat_out (include/st355.h): one destination of a fused column sum"""
+    _fields_ = [("out", C.c_void_p), ("stride", C.c_int64), ("reduce_batches", C.c_int32), ("out_bf16", C.c_int32), ("accumulate", C.c_int32), ("_pad", C.c_int32)]
 
 
 class VaeEncoder(C.Structure):
@@ -279,12 +287,18 @@ def _declare(lib):
         "st355_gemm_set_persistent": (C.c_int, [i32]),
         "st355_colsum_workspace": (sz, [i64, i32, i64]),
         "st355_colsum_prod": (C.c_int, [vp, vp, i64, vp, i64, i64, i32, i64, vp, i64, i32, vp, i64, vp, vp, i64, i32, vp]),
+        "st355_stats_workspace": (sz, [i64, i32, i64, i32]),
+        "st355_ln_modulate_bwd_stats": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, f32, vp, i64,
+                                                  C.POINTER(StatOut), C.POINTER(StatOut), C.POINTER(StatOut), C.POINTER(StatOut), vp]),
+        "st355_scale_cols_stats": (C.c_int, [vp, vp, i64, vp, i64, i64, vp, i64, i64, i32, vp, i64, C.POINTER(StatOut), C.POINTER(StatOut), vp]),
+        "st355_colsum_rows": (C.c_int, [vp, vp, i64, i64, i64, i32, i32, C.POINTER(StatOut), vp]),
         "st355_transpose_bf16": (C.c_int, [vp, vp, i64, vp, i64, i32, i32]),
         "st355_sum_chunks_bf16": (C.c_int, [vp, vp, i32, i64, vp]),
         "st355_fp8_quantize_weight": (C.c_int, [vp, vp, i64, vp, vp, i32, i32]),
         "st355_fp8_quantize_act": (C.c_int, [vp, vp, i64, vp, vp, i64, i32, vp]),
         "st355_linear_fp8": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32]),
         "st355_gemm_tn_bf16": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, vp, i64]),
+        "st355_gemm_tn_seg_bf16": (C.c_int, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32, i32, i32, vp, i64]),
         "st355_skinny_tn_workspace": (sz, [i64, i64, i32]),
         "st355_skinny_tn": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, i32, f32, i32, vp]),
         "st355_skinny_tn_seg": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, i32, f32, i32, vp, i64, i64, i64]),

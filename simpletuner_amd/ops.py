@@ -279,10 +279,18 @@ _gemm_ws = {}
 _GEMM_WS_BYTES = 64 << 20
 
 
+_ws_retired = []       # outgrown scratch buffers stay alive: a captured hipGraph may still hold their addresses
+
+
 def _gemm_workspace(dev, nbytes: int = _GEMM_WS_BYTES):
-    """caller-owned fp32 scratch for the split-K paths (thin GEMMs, weight gradients); libst355 never allocates"""
+    """caller-owned fp32 scratch for the split-K paths (thin GEMMs, weight gradients); libst355 never allocates.  Grow-only; an outgrown buffer is retired, never
+    freed (a hipGraph captured earlier keeps its address), and growing DURING a capture is refused (the capture would bake in a pointer of its private pool)"""
     ws = _gemm_ws.get(dev.index)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _l.St355Error(f"the shared GEMM scratch would have to grow ({ws.numel() * 4} -> {nbytes} bytes) inside a hipGraph capture: run one eager step first")
+            _ws_retired.append(ws)
         ws = torch.empty(nbytes // 4, dtype=F32, device=dev)
         _gemm_ws[dev.index] = ws
     return ws
@@ -454,21 +462,40 @@ def linear_fp8(xq, scale_a, wq, w_scale, bias=None, out=None):
     return out
 
 
+def _tn_operand(t, name: str):
+    """a TN operand: 2-D [M, C] (row stride free) or a 3-D [B, rows, C] view of a joint buffer (row stride ld, segment stride a multiple of it):
+    -> (pointer tensor, ld, logical rows M, C, seg_rows or 0, physical segment stride in rows or 0)"""
+    _chk(t, BF16, name)
+    if t.dim() == 2:
+        return t, _rows(t, name), t.shape[0], t.shape[1], 0, 0
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) <= 0 or t.stride(0) % t.stride(1) != 0:
+        raise _l.St355Error(f"gemm_tn: {name} must be [M, C] or a [B, rows, C] view whose batch stride is a whole number of rows")
+    B, rows, Cn = t.shape
+    return t, t.stride(1), B * rows, Cn, rows, t.stride(0) // t.stride(1)
+
+
 def gemm_tn(Lm, R, out=None, accumulate: bool = False):
-    """out[P,Q] (+)= Lm[M,P]^T @ R[M,Q]  — the weight-gradient form (dW = dY^T X).  M must be a multiple of 64 (zero-padded rows)."""
+    """out[P,Q] (+)= Lm[M,P]^T @ R[M,Q]  — the weight-gradient form (dW = dY^T X).  M must be a multiple of 64 (zero-padded rows).  Either operand may be a
+    3-D [B, rows, C] strided view (a stream's rows of a joint buffer, rows a multiple of 64): contracted in place (st355_gemm_tn_seg_bf16)."""
     L = _l.load()
-    _chk(Lm, BF16, "L"); _chk(R, BF16, "R")
-    M, P = Lm.shape
-    if R.shape[0] != M:
+    Lm, ldl, M, P, seg_a, str_a = _tn_operand(Lm, "L")
+    R, ldr, M2, Q, seg_b, str_b = _tn_operand(R, "R")
+    if M2 != M:
         raise _l.St355Error("gemm_tn: operands must share the contraction length")
-    Q = R.shape[1]
     if out is None:
         if accumulate:
             raise _l.St355Error("gemm_tn: accumulate needs an output tensor")
         out = torch.empty(P, Q, dtype=BF16, device=Lm.device)
     _chk(out, BF16, "out")
     ws = _gemm_workspace(Lm.device, 512 << 20)          # fp32 split-K slabs: up to 7 slices of a 6144 x 1536 gradient (264 MB)
-    _l.check(L.st355_gemm_tn_bf16(_stream(), _ptr(Lm), _rows(Lm, "L"), _ptr(R), _rows(R, "R"), _ptr(out), _rows(out, "out"), M, P, Q,
+    if seg_a or seg_b:
+        seg = seg_a or seg_b
+        if seg_a and seg_b and seg_a != seg_b:
+            raise _l.St355Error("gemm_tn: two segmented operands must share the segment length")
+        _l.check(L.st355_gemm_tn_seg_bf16(_stream(), _ptr(Lm), ldl, str_a if seg_a else 0, _ptr(R), ldr, str_b if seg_b else 0, _ptr(out), _rows(out, "out"),
+                                          M, seg, P, Q, 1 if accumulate else 0, _ptr(ws), ws.numel() * 4), "gemm_tn_seg_bf16")
+        return out
+    _l.check(L.st355_gemm_tn_bf16(_stream(), _ptr(Lm), ldl, _ptr(R), ldr, _ptr(out), _rows(out, "out"), M, P, Q,
                                   1 if accumulate else 0, _ptr(ws), ws.numel() * 4), "gemm_tn_bf16")
     return out
 
@@ -498,6 +525,78 @@ def colsum_prod(a, out, b=None, rows_per_batch: Optional[int] = None, mode: int 
     _l.check(L.st355_colsum_prod(_stream(), _ptr(a), _rows(a, "a"), _ptr(b), _rows(b, "b") if b is not None else 0, rows, N, rpb, _ptr(out),
                                  _rows(out, "out"), mode, _ptr(prev), _rows(prev, "prev") if prev is not None else 0, _ptr(shift), _ptr(scale),
                                  ms, 1 if accumulate else 0, _ptr(ws)), "colsum_prod")
+    return out
+
+
+_stats_ws = {}
+
+
+def _stats_workspace(dev, nbytes: int):
+    ws = _stats_ws.get(dev.index)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
+        ws = _stats_ws[dev.index] = torch.empty((nbytes + 3) // 4, dtype=F32, device=dev)
+    return ws
+
+
+def stat_out(out, reduce_batches: bool = False, accumulate: bool = False):
+    """st355_stat_out of a destination tensor: fp32 2-D view [nb, N] (per-batch rows, row stride free) or — reduce_batches — one fp32 / bf16 row [N]"""
+    o = _l.StatOut()
+    if out is None:
+        return o
+    if out.dtype not in (F32, BF16) or (out.dtype == BF16 and not reduce_batches):
+        raise _l.St355Error("stat_out: per-batch sums are fp32; a bf16 destination is one row summed over the batches")
+    _dev(out, "stat_out")
+    o.out, o.stride = out.data_ptr(), (0 if reduce_batches else _rows(out, "stat_out"))
+    o.reduce_batches, o.out_bf16, o.accumulate = int(reduce_batches), int(out.dtype == BF16), int(accumulate)
+    o._keep = out
+    return o
+
+
+def ln_modulate_bwd_stats(dy, x, scale, rows_per_batch: int, d_shift, d_scale, dres=None, gate=None, y_branch=None, d_gate=None, d_bias=None, eps: float = 1e-6,
+                          want_gated: bool = False, out=None):
+    """ln_modulate_bwd + the sums autograd accumulates around the AdaLN instance (st355_ln_modulate_bwd_stats): d_shift / d_scale fp32 [nb, D] views,
+    d_gate = sum dx * y_branch (fp32 [nb, D]), d_bias = sum gate * dx over all rows (one fp32 / bf16 row).  Returns (dx, dxg)."""
+    L = _l.load()
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(scale, BF16, "scale")
+    rows, D = x.shape
+    dx = torch.empty(rows, D, dtype=BF16, device=x.device) if out is None else out
+    dxg = torch.empty(rows, D, dtype=BF16, device=x.device) if want_gated else None
+    ws = _stats_workspace(x.device, L.st355_stats_workspace(rows, D, rows_per_batch, 4))
+    outs = [stat_out(d_shift), stat_out(d_scale), stat_out(d_gate), stat_out(d_bias, reduce_batches=True)]
+    _l.check(L.st355_ln_modulate_bwd_stats(_stream(), _ptr(dy), _rows(dy, "dy"), _ptr(x), _rows(x, "x"), _ptr(scale), _rows(scale, "scale"), rows_per_batch,
+                                           _ptr(dres), _rows(dres, "dres") if dres is not None else 0, _ptr(gate) if want_gated else None,
+                                           _rows(gate, "gate") if want_gated else 0, _ptr(dx), _rows(dx, "dx"), _ptr(dxg), D, rows, D, eps,
+                                           _ptr(y_branch), _rows(y_branch, "y_branch") if y_branch is not None else 0,
+                                           C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2]), C.byref(outs[3]), _ptr(ws)), "ln_modulate_bwd_stats")
+    return dx, dxg
+
+
+def scale_cols_stats(x, gate, rows_per_batch: int, y_branch=None, d_gate=None, d_bias=None, out=None):
+    """scale_cols + d_gate = sum_t x * y_branch (fp32 [nb, N]) + d_bias = sum over all rows of the output (one fp32 / bf16 row)"""
+    L = _l.load()
+    _chk(x, BF16, "x"); _chk(gate, BF16, "gate")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    ws = _stats_workspace(x.device, L.st355_stats_workspace(M, N, rows_per_batch, 2))
+    og, ob = stat_out(d_gate), stat_out(d_bias, reduce_batches=True)
+    _l.check(L.st355_scale_cols_stats(_stream(), _ptr(x), _rows(x, "x"), _ptr(gate), _rows(gate, "gate"), rows_per_batch, _ptr(out), _rows(out, "out"), M, N,
+                                      _ptr(y_branch), _rows(y_branch, "y_branch") if y_branch is not None else 0, C.byref(og), C.byref(ob), _ptr(ws)),
+             "scale_cols_stats")
+    return out
+
+
+def colsum_rows(a, rows_per_batch: int, batch_stride_rows: int, nb: int, out, per_batch: bool = False, accumulate: bool = False):
+    """column sums of nb row blocks of `a` (block b = rows [b * batch_stride_rows, + rows_per_batch) of the 2-D tensor a, in place): one row over all blocks
+    (fp32 / bf16 [N]) or per-block fp32 rows [nb, N]"""
+    L = _l.load()
+    _chk(a, BF16, "a")
+    N = a.shape[1]
+    ws = _stats_workspace(a.device, L.st355_stats_workspace(nb * rows_per_batch, N, rows_per_batch, 1))
+    o = stat_out(out, reduce_batches=not per_batch, accumulate=accumulate)
+    _l.check(L.st355_colsum_rows(_stream(), _ptr(a), _rows(a, "a"), rows_per_batch, batch_stride_rows, nb, N, C.byref(o), _ptr(ws)), "colsum_rows")
     return out
 
 
@@ -1101,6 +1200,9 @@ def block_sd3_joint_bwd(**kw):
     if aws is None or aws.numel() < need:
         aws = _attn_ws[(dev.index,)] = torch.empty(need, dtype=torch.uint8, device=dev)
     ws = _gemm_workspace(dev)
+    if kw.get("dmod_img") is not None:          # the fused-statistics form (full fine-tune): fp32 partial rows of its column sums
+        rmax = max(kw["Si"], kw["St"])
+        kw["stats_ws"] = _stats_workspace(dev, L.st355_stats_workspace(kw["B"] * rmax, 4 * kw["D"], rmax, 1))
     a = _fill(_l.Sd3JointBwdArgs(), gemm_ws=ws, gemm_ws_bytes=ws.numel() * 4, attn_ws=aws, **kw)
     _l.check(L.st355_block_sd3_joint_bwd(_stream(), C.byref(a)), "block_sd3_joint_bwd")
     BLOCK_CALLS["block_sd3_joint_bwd"] = BLOCK_CALLS.get("block_sd3_joint_bwd", 0) + 1

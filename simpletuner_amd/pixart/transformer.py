@@ -126,8 +126,10 @@ class PixArtTransformer2DModel(nn.Module):
             raise NotImplementedError("PixArt(st355): ada_norm_single blocks with patch_size 2 only")
         H, hd = num_attention_heads, attention_head_dim
         D = H * hd
-        if hd > HP or D % 64 or (cross_attention_dim or D) != D or caption_channels is None or caption_channels % 64:
-            raise ValueError("PixArt(st355): head_dim <= 128, inner dim a multiple of 64, cross_attention_dim == inner dim, caption_channels % 64 == 0")
+        # head_dim-96 attention contract (include/st355.h): a 96-wide head is a zero-padded narrower one and the 64-row bodies contract q.k / dO.v over
+        # 80 channels only — a real head wider than 80 would silently lose channels [80, 96) on those paths, so it is refused here (PixArt heads are 72)
+        if hd > 80 or D % 64 or (cross_attention_dim or D) != D or caption_channels is None or caption_channels % 64:
+            raise ValueError("PixArt(st355): head_dim <= 80 (zero-padded to 96), inner dim a multiple of 64, cross_attention_dim == inner dim, caption_channels % 64 == 0")
         if use_additional_conditions is None:
             use_additional_conditions = sample_size == 128
         out_channels = in_channels if out_channels is None else out_channels

@@ -47,6 +47,20 @@ def sincos_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scal
 
 
 
+def _pad64_empty(rows: int, cols: int, dev):
+    """[rows, cols] bf16, uninitialised, as the head of a parent buffer whose row count is rounded up to 64 and whose tail rows are ZERO: the weight-gradient GEMM
+    (contraction granule 64 rows) reads the parent directly instead of a zero-padded copy of the tensor (round 5: two launches and a full copy per text-stream
+    operand, 192 hipMemcpy + 224 fill launches per SD3 full fine-tune step).  The view remembers its parent in `_st355_pad64`."""
+    rp = (rows + 63) // 64 * 64
+    if rp == rows:
+        return torch.empty(rows, cols, dtype=BF16, device=dev)
+    par = torch.empty(rp, cols, dtype=BF16, device=dev)
+    par[rows:].zero_()
+    t = par[:rows]
+    t._st355_pad64 = par
+    return t
+
+
 def _rows3(joint, lo: int, rows: int, B: int, S: int):
     """rows [lo, lo + rows) of every sample of a joint [B * S, C] buffer as a GEMM operand ([B, rows, C] strided view, no copy)"""
     return _FluxEngine._rows_of(joint, lo, rows, SimpleNamespace(B=B, S=S))
@@ -492,13 +506,16 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         K2a, kr_a, A_a, Bb_a, _, _ = self._lk(blk.add_qkv)
         K2o, kr_o, A_o, Bb_o, _, _ = self._lk(blk.to_out)
         K2t, kr_t, A_t, Bb_t, _, _ = self._lk(None if last else blk.to_add_out)
-        n_img, n_txt, qkv, O, x1_img, hpre_img, n2_i, h_i, x2_img = (e(B * Si, D), e(B * St, D), e(B * S, 3 * D), e(B * S, D), e(B * Si, D), e(B * Si, 4 * D),
+        et = (lambda r, c: _pad64_empty(r, c, dev)) if (full and save) else e        # text-stream tensors a full fine-tune contracts over tokens: zero-tailed to 64 rows
+        n_img, n_txt, qkv, O, x1_img, hpre_img, n2_i, h_i, x2_img = (e(B * Si, D), et(B * St, D), e(B * S, 3 * D), e(B * S, D), e(B * Si, D), e(B * Si, 4 * D),
                                                                      e(B * Si, D), e(B * Si, 4 * D), e(B * Si, D))
         Q, K, lse2 = e(B, H, S, hd), e(B, H, S, hd), e(B, H, S, dt=F32)
-        Vt = (torch.zeros if Sp > S else torch.empty)(B, H, hd, Sp, dtype=BF16, device=dev)
+        Vt = e(B, H, hd, Sp)
+        if Sp > S:
+            Vt[..., S:].zero_()                                 # only the pad columns need the zeros (the rest is written by the re-layout pass)
         x1_txt = hpre_txt = n2_t = h_t = x2_txt = None
         if not last:
-            x1_txt, hpre_txt, n2_t, h_t, x2_txt = e(B * St, D), e(B * St, 4 * D), e(B * St, D), e(B * St, 4 * D), e(B * St, D)
+            x1_txt, hpre_txt, n2_t, h_t, x2_txt = e(B * St, D), e(B * St, 4 * D), et(B * St, D), et(B * St, 4 * D), e(B * St, D)
         T_img = e(B * Si, K2q) if K2q else None
         T_txt = e(B * St, K2a) if K2a else None
         T_o = e(B * Si, K2o) if K2o else None
@@ -526,7 +543,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             sv.n2_i, sv.n2_t, sv.h_i, sv.h_t, sv.ya_i, sv.ya_t, sv.yf_i, sv.yf_t = n2_i, n2_t, h_i, h_t, ya_i, ya_t, yf_i, yf_t
         return x2_img, x2_txt, sv
 
-    def _block_bwd_c(self, blk, sv, env_li, mod, cos, sin, d_img, d_txt, need_input_grads: bool):
+    def _block_bwd_c(self, blk, sv, env_li, mod, cos, sin, d_img, d_txt, need_input_grads: bool, dmod=None):
         """the data path of one block's backward through st355_block_sd3_joint_bwd: returns (d_img', d_txt', G) with every intermediate gradient in G — the
         adapter gradients (LoRA) or the weight / bias / modulation gradients (full fine-tune) are taken from them by the caller, the same launches on the same
         operands as the host-side form, after the data path instead of between its steps (independent of it: bit-identical results)"""
@@ -543,17 +560,24 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                             dO=(torch.zeros if last else torch.empty)(B * S, D, dtype=BF16, device=dev), dqkv=e(B * S, 3 * D),
                             U_o=e(B * Si, K2o) if K2o else None, U_ao=e(B * St, K2t) if K2t else None, U_q=e(B * Si, K2q) if K2q else None,
                             U_a=e(B * St, K2a) if K2a else None, dn_i=None, dn_t=None, c_img=None, c_txt=None)
+        et = (lambda r, c: _pad64_empty(r, c, dev)) if dmod is not None else e       # (full fine-tune: the text-stream gradients are weight-gradient operands)
         if not last:
-            G.g_t, G.dh_t, G.dn2_t, G.dx1_t, G.dx1g_t = e(B * St, D), e(B * St, 4 * D), e(B * St, D), e(B * St, D), e(B * St, D)
+            G.g_t, G.dh_t, G.dn2_t, G.dx1_t, G.dx1g_t = et(B * St, D), et(B * St, 4 * D), e(B * St, D), e(B * St, D), et(B * St, D)
         if B > 1 and Si % 256:
             G.c_img = e(B * Si, 3 * D)
         if B > 1 and St % 256:
-            G.c_txt = e(B * St, 3 * D)
+            G.c_txt = et(B * St, 3 * D)
         d_img_out = d_txt_out = None
         if need_input_grads:
             G.dn_i, G.dn_t, d_img_out, d_txt_out = e(B * Si, D), e(B * St, D), e(B * Si, D), e(B * St, D)
         dQ, dK = e(B, H, S, hd), e(B, H, S, hd)
-        ops.block_sd3_joint_bwd(
+        st = {}
+        if dmod is not None:
+            # full fine-tune: the block's modulation / gate / bias gradients ride in the entry's own passes (csrc/stats.hip) — dmod = the fp32 [B, mod_total] buffer
+            st = dict(dmod_img=dmod[:, blk.mod_off:], dmod_txt=dmod[:, blk.mod_off_c:], dmod_stride=dmod.stride(0), ya_img=sv.ya_i, ya_txt=sv.ya_t, yf_img=sv.yf_i,
+                      yf_txt=sv.yf_t, gb_ff2=blk.ff2.gb, gb_ff1=blk.ff1.gb, gb_out=blk.to_out.gb, gb_qkv=blk.qkv.gb, gb_add_qkv=blk.add_qkv.gb,
+                      gb_ffc2=None if last else blk.ffc2.gb, gb_ffc1=None if last else blk.ffc1.gb, gb_add_out=None if last else blk.to_add_out.gb)
+        ops.block_sd3_joint_bwd(**st,
             B=B, Si=Si, St=St, H=H, D=D, hd=hd, last=int(last), need_input_grads=int(need_input_grads),
             K2_qkv=K2q, k2r_qkv=kr_q, K2_aqkv=K2a, k2r_aqkv=kr_a, K2_out=K2o, k2r_out=kr_o, K2_aout=K2t, k2r_aout=kr_t, scale=1.0 / math.sqrt(hd),
             img=sv.img, txt=sv.txt, mod_img=mod[:, blk.mod_off:], mod_txt=mod[:, blk.mod_off_c:], mod_stride=mod.stride(0),
@@ -890,18 +914,30 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         dmod = torch.zeros(B, self.mod_total, dtype=F32, device=dev)        # d loss / d (modulation linear output)
         tmp_b = {}
 
+        def pad64_rows(rows, cols):
+            """an uninitialised [rows, cols] buffer that lives in a zero-tailed parent with a multiple of 64 rows: P64 hands the parent to the TN GEMM, no copy"""
+            return _pad64_empty(rows, cols, dev)
+
         def P64(t):
-            """zero-padded copy with a multiple of 64 rows (the TN GEMM's contraction granule); no copy when already aligned"""
+            """the operand with a multiple of 64 contraction rows (the TN GEMM's granule): as is when aligned or segmented, its zero-tailed parent when it was
+            allocated by _pad64_empty, else a zero-padded copy"""
+            if t.dim() == 3:
+                return t
             r = t.shape[0]
             if r % 64 == 0 and t.is_contiguous():
                 return t
+            par = getattr(t, "_st355_pad64", None)
+            if par is not None:
+                return par
             o = torch.zeros((r + 63) // 64 * 64, t.shape[1], dtype=BF16, device=dev)
             o[:r] = t
             return o
 
-        def wgrad(lin, dy, x):
-            """dW = dY^T X ; db = colsum(dY)   (into the gradient arena views of `lin`)"""
+        def wgrad(lin, dy, x, bias: bool = True):
+            """dW = dY^T X ; db = colsum(dY)   (into the gradient arena views of `lin`; bias=False: the bias gradient was already taken by a fused pass)"""
             ops.gemm_tn(P64(dy), P64(x), out=lin.gw)
+            if not bias:
+                return
             N = dy.shape[1]
             t = tmp_b.get(N)
             if t is None:
@@ -922,8 +958,18 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             else:
                 ops.qk_norm_rope_bwd_wgrad(dQ_, dK_, qkv_, wq, wk, cos, sin, dqkv_, B, H, hd, rows, pos0, S_, gq, gk)
 
-        def rows_of(t, lo, n):                       # rows [lo, lo+n) of every batch element of a joint [B*S, C] buffer, contiguous
-            return t[lo:lo + n] if B == 1 else t.view(B, S, -1)[:, lo:lo + n].reshape(B * n, -1)
+        def rows_of(t, lo, n, seg: bool = False):
+            """rows [lo, lo+n) of every batch element of a joint [B*S, C] buffer as a weight-gradient operand.  seg: in place — a [B, n, C] strided view, the
+            segmented-contraction form of st355_gemm_tn_seg_bf16 — when n is a whole number of 64-row K-tiles (the image rows of every bucket); else (the text
+            rows, and callers that also read the operand as a plain matrix) a compact copy, its row count zero-tailed to 64 (P64 below takes it as is)"""
+            if B == 1:
+                return t[lo:lo + n]
+            v = t.view(B, S, -1)[:, lo:lo + n]
+            if seg and n % 64 == 0 and n >= 128:
+                return v
+            o = pad64_rows(B * n, t.shape[1])
+            o.view(B, n, -1).copy_(v)
+            return o
 
         # ---- head ----
         dpk = ops.patchify(dout.to(BF16).contiguous(), order=1).view(B * Si, -1)
@@ -958,30 +1004,20 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                     and blk.norm_q is None and blk.norm_k is None and blk.norm_added_q is None and blk.norm_added_k is None):
                 # the data path as ONE C entry point (st355_block_sd3_joint_bwd), then every weight / bias / modulation gradient of the block from the gradients
                 # it left behind (SD3.5's trainable q / k norm weights take the host-side form: their gradient rides in the RMSNorm backward pass)
-                d_in_img, d_in_txt = d_img, d_txt
-                d_img, d_txt, G = self._block_bwd_c(blk, sv, ctx.envs[li], mod, cos, sin, d_img, d_txt, True)
-                ops.colsum_prod(d_in_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)           # d gate_mlp
-                wgrad(blk.ff2, G.g_i, sv.h_i)
-                wgrad(blk.ff1, G.dh_i, sv.n2_i)
-                mod_grads(G.dn2_i, sv.x1_img, Si, 3, 4, dmi)
-                ops.colsum_prod(G.dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)            # d gate_msa
+                # (every bias / modulation-shift / -scale / gate gradient of the block is written by the entry itself — the column sums ride in its scale_cols and
+                # LayerNorm-backward passes, csrc/stats.hip; only the weight gradients are left, taken from the gradients it kept)
+                d_img, d_txt, G = self._block_bwd_c(blk, sv, ctx.envs[li], mod, cos, sin, d_img, d_txt, True, dmod=dmod)
+                wgrad(blk.ff2, G.g_i, sv.h_i, bias=False)
+                wgrad(blk.ff1, G.dh_i, sv.n2_i, bias=False)
                 if not blk.last:
-                    ops.colsum_prod(d_in_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
-                    wgrad(blk.ffc2, G.g_t, sv.h_t)
-                    wgrad(blk.ffc1, G.dh_t, sv.n2_t)
-                    mod_grads(G.dn2_t, sv.x1_txt, St, 3, 4, dmt)
-                    ops.colsum_prod(G.dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
-                wgrad(blk.to_out, G.dx1g_i, rows_of(sv.O, 0, Si))
+                    wgrad(blk.ffc2, G.g_t, sv.h_t, bias=False)
+                    wgrad(blk.ffc1, G.dh_t, sv.n2_t, bias=False)
+                wgrad(blk.to_out, G.dx1g_i, rows_of(sv.O, 0, Si, seg=True), bias=False)
                 if not blk.last:
-                    wgrad(blk.to_add_out, G.dx1g_t, rows_of(sv.O, Si, St))
-                wgrad(blk.qkv, rows_of(G.dqkv, 0, Si), sv.n_img)
-                wgrad(blk.add_qkv, rows_of(G.dqkv, Si, St), sv.n_txt)
-                mod_grads(G.dn_i, sv.img, Si, 0, 1, dmi)
-                if blk.last:
-                    mod_grads(G.dn_t, sv.txt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
-                else:
-                    mod_grads(G.dn_t, sv.txt, St, 0, 1, dmt)
-                del sv, G, d_in_img, d_in_txt
+                    wgrad(blk.to_add_out, G.dx1g_t, rows_of(sv.O, Si, St), bias=False)
+                wgrad(blk.qkv, G.c_img if G.c_img is not None else rows_of(G.dqkv, 0, Si, seg=True), sv.n_img, bias=False)       # (c_*: the compact copy the entry left)
+                wgrad(blk.add_qkv, G.c_txt if G.c_txt is not None else rows_of(G.dqkv, Si, St), sv.n_txt, bias=False)
+                del sv, G
                 if li in ctx.route_start:
                     ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
                     d_img, d_full = d_full, None

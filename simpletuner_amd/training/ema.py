@@ -101,6 +101,27 @@ class EMAModel:
             else:
                 s.copy_(p.data.to(s.dtype))
 
+    # ---- fused form: the update rides in the optimizer's own launch (st355_adamw_ema_step*: `ema` pointer + decay) ----
+    def fused_decay(self, parameters, global_step: int):
+        """The decay `step(parameters, global_step)` would apply, or None when that call would not be ONE flat-arena update of these parameters (interval skip,
+        rank0_only on another rank, non-contiguous parameters).  Pure: the trainer hands (shadow_flat, decay) to the optimizer — decay is known before
+        `optimizer.step()` because it depends on the step count alone (ema.py:322-349) — and calls `commit_fused` once the fused launch has run."""
+        if not should_update_ema(self.args, global_step):
+            return None
+        if self.rank0_only and getattr(self.accelerator, "process_index", 0) != 0:
+            return None
+        parameters = list(parameters)
+        if len(parameters) != len(self.shadow_params) or not self._flat or not _contiguous_run([p.data for p in parameters]):
+            return None
+        if parameters[0].dtype != self.shadow_flat.dtype:
+            return None
+        return self.get_decay(global_step)
+
+    def commit_fused(self, global_step: int, decay: float) -> None:
+        """bookkeeping of `step()` after the optimizer's launch applied s -= (1 - decay)(s - p_new) itself"""
+        self.optimization_step = global_step
+        self.cur_decay_value = decay
+
     def _align(self, parameters, allow_subset: bool):
         """ema.py:189-234: shadows are matched to the caller's parameters by IDENTITY, so reordered lists, subsets (allow_subset) and supersets
         with untracked entries all land on the right tensors.  Deviation, on purpose: when NONE of the given tensors is a tracked parameter but

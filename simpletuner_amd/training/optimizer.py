@@ -59,6 +59,7 @@ class St355AdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0           # set by the gradient-sync layer (1/world_size) or by clipping: folded into the kernel
         self.ema_shadow_flat: Optional[torch.Tensor] = None   # optional fused EMA (flat arena path only)
         self.ema_decay = 0.0
+        self.ema_applied = False
         self._flat = {}
 
     def _group_flat(self, gi, group):
@@ -121,8 +122,11 @@ class St355AdamW(torch.optim.Optimizer):
             if st["ok"] and len(ps) == len(st["ps"]) and _contiguous_run(grads):
                 pflat = torch.as_strided(ps[0].data, (st["n"],), (1,))
                 gflat = torch.as_strided(grads[0], (st["n"],), (1,))
+                ema = self.ema_shadow_flat if (self.ema_shadow_flat is not None and len(self.param_groups) == 1
+                                               and self.ema_shadow_flat.numel() == st["n"] and self.ema_shadow_flat.dtype == pflat.dtype) else None
                 ops.adamw_ema_step(pflat, gflat, st["m"], st["v"], step, group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                                   grad_scale=self.grad_scale, ema=self.ema_shadow_flat, ema_decay=self.ema_decay)
+                                   grad_scale=self.grad_scale, ema=ema, ema_decay=self.ema_decay)
+                self.ema_applied = ema is not None      # the trainer falls back to EMAModel.step when the fused form did not run
                 for p in ps:
                     self.state[p]["step"] += 1
                 continue

@@ -254,6 +254,7 @@ class Trainer:
             else:
                 raise ValueError(f"Unknown grad clip method: {method}. Supported methods: value, norm")
         self.optimizer.grad_scale = grad_scale
+        ema_fused = False
         sh = self._bf16_shadow
         if sh is not None:                                                               # adamw_bf16 over the fp32 adapter arena: bf16 gradients in, bf16 weights out
             from .optimizer import _contiguous_run
@@ -272,14 +273,28 @@ class Trainer:
                 for p in self.params:
                     p.grad = None
         else:
+            # EMA fused into the optimizer's launch (north star: "fused AdamW, EMA update"): the decay of ema_model.step(params, global_step + 1) depends on the
+            # step count alone (ema.py:322-349), so it is known here; the kernel applies s -= (1 - d)(s - p_new) to the element it just updated — the same
+            # arithmetic as the separate pass (ema.py:393-433), minus its 3 x 2 B/param of HBM traffic and one launch
+            ema_decay = None
+            if self.ema_model is not None and isinstance(self.optimizer, St355AdamW):
+                ema_decay = self.ema_model.fused_decay(self.params, self.state["global_step"] + 1)
+            if ema_decay is not None:
+                self.optimizer.ema_shadow_flat, self.optimizer.ema_decay, self.optimizer.ema_applied = self.ema_model.shadow_flat, float(ema_decay), False
             self.optimizer.step()                                                        # :7239
+            if ema_decay is not None:
+                self.optimizer.ema_shadow_flat = None
+                ema_fused = bool(self.optimizer.ema_applied)
             if not self._use_graph:                                                      # graph mode: the captured backward re-writes the same .grad tensors
                 self.optimizer.zero_grad(set_to_none=True)                               # :7253
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()                                                     # :7293
         self.state["global_step"] += 1
         if self.ema_model is not None:
-            self.ema_model.step(self.params, self.state["global_step"])                  # :7352
+            if ema_fused:
+                self.ema_model.commit_fused(self.state["global_step"], ema_decay)
+            else:
+                self.ema_model.step(self.params, self.state["global_step"])              # :7352
         return self.last_loss
 
     # ------------------------------------------------------------------------------------------------

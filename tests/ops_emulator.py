@@ -233,6 +233,16 @@ def gemm_grouped(problems):
 
 
 def gemm_tn(Lm, R, out=None, accumulate=False):
+    segs = []
+    for t in (Lm, R):               # a 3-D [B, rows, C] strided view = the segmented-contraction form (st355_gemm_tn_seg_bf16): rows % 64 == 0, >= 128
+        if t.dim() == 3:
+            _need(t.stride(2) == 1 and t.stride(0) % t.stride(1) == 0 and t.shape[1] % 64 == 0 and t.shape[1] >= 128, f"gemm_tn: bad segmented operand {tuple(t.shape)} {t.stride()}")
+            segs.append(t.shape[1])
+    _need(len(set(segs)) <= 1, "gemm_tn: two segmented operands must share the segment length")
+    if segs:
+        Lm = Lm.reshape(-1, Lm.shape[-1]) if Lm.dim() == 3 else Lm
+        R = R.reshape(-1, R.shape[-1]) if R.dim() == 3 else R
+        _need(Lm.shape[0] % segs[0] == 0, "gemm_tn: the segment length must divide the contraction length")
     _chk(Lm, BF16, "L"); _chk(R, BF16, "R"); _rows(Lm, "L"); _rows(R, "R")
     M, P = Lm.shape
     _need(R.shape[0] == M, "gemm_tn: operands must share the contraction length")
@@ -403,7 +413,7 @@ def adamw_ema_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
     pf = pf - (lr / bc1) * (m / (v.sqrt() / math.sqrt(bc2) + eps))
     p.copy_(pf.to(p.dtype))
     if ema is not None:
-        ema.copy_((ema.float() - (1.0 - ema_decay) * (ema.float() - p.float())).to(ema.dtype))
+        ema.copy_((ema.float() - (1.0 - ema_decay) * (ema.float() - p.float()).to(ema.dtype).float()).to(ema.dtype))      # (s - p) materialised in the shadow dtype, as k_ema
     if p_bf16 is not None:
         p_bf16.copy_(pf.to(BF16))
 
@@ -1239,6 +1249,28 @@ def block_sd3_joint_bwd(**a):
     if A.need_input_grads:
         ln_modulate_bwd(A.dn_img, A.img, mi[:, D:2 * D], Si, dres=A.dx1_img, out=A.d_img_out)
         ln_modulate_bwd(A.dn_txt, A.txt, mt[:, :D] if last else mt[:, D:2 * D], St, dres=None if last else A.dx1_txt, out=A.d_txt_out)
+    if getattr(A, "dmod_img", None) is not None:
+        # the fused-statistics form (csrc/stats.hip): fp32 sums over the bf16 tensors the entry wrote; LN(x) in fp32 (the kernel never rounds it)
+        assert A.need_input_grads and A.dmod_stride == A.dmod_img.stride(0) == A.dmod_txt.stride(0)
+        xhat = lambda x: torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6)
+        per_b = lambda t, rows: t.view(B, rows, -1).sum(dim=1)
+
+        def stream(dm, rows, d_in, yf, g, dh, dn2, x1, dx1, ya, dx1g, gb2, gb1, gbo, lo, gbq, dn, x_in, k_shift, k_scale, mlp):
+            if mlp:
+                dm[:, 5 * D:6 * D] = per_b(d_in.float() * yf.float(), rows)
+                gb2.copy_(g.float().sum(dim=0)); gb1.copy_(dh.float().sum(dim=0))
+                dm[:, 3 * D:4 * D] = per_b(dn2.float(), rows)
+                dm[:, 4 * D:5 * D] = per_b(dn2.float() * xhat(x1), rows)
+                dm[:, 2 * D:3 * D] = per_b(dx1.float() * ya.float(), rows)
+                gbo.copy_(dx1g.float().sum(dim=0))
+            gbq.copy_(A.dqkv.view(B, S, 3 * D)[:, lo:lo + rows].float().sum(dim=(0, 1)))
+            dm[:, k_shift * D:(k_shift + 1) * D] = per_b(dn.float(), rows)
+            dm[:, k_scale * D:(k_scale + 1) * D] = per_b(dn.float() * xhat(x_in), rows)
+
+        stream(A.dmod_img, Si, A.d_img, A.yf_img, A.g_img, A.dh_img, A.dn2_img, A.x1_img, A.dx1_img, A.ya_img, A.dx1g_img, A.gb_ff2, A.gb_ff1, A.gb_out, 0, A.gb_qkv,
+               A.dn_img, A.img, 0, 1, True)
+        stream(A.dmod_txt, St, A.d_txt, A.yf_txt, A.g_txt, A.dh_txt, A.dn2_txt, A.x1_txt, A.dx1_txt, A.ya_txt, A.dx1g_txt, A.gb_ffc2, A.gb_ffc1, A.gb_add_out, Si,
+               A.gb_add_qkv, A.dn_txt, A.txt, 1 if last else 0, 0 if last else 1, not last)
 
 
 _EMULATED = ("qk_rope", "attn_fwd_vrows", "attn_bwd_rope", "qk_rope_norm_bwd", "grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",

@@ -1,0 +1,175 @@
+"""GPU parity of the round-6 kernels, through the C ABI: the fused token-axis statistics (csrc/stats.hip), the segmented-contraction weight-gradient GEMM
+(st355_gemm_tn_seg_bf16), the ragged key tail behind the 64-row attention dQ kernel, the EMA update inside the AdamW launch.  References: the unfused entry points
+(bit-exact where the arithmetic is the same) and plain fp32 torch on the same seeded inputs (tolerances stated per assert)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, ref):
+    a = a.double(); ref = ref.double()
+    return ((a - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simpletuner_amd import ops as o
+
+    return o
+
+
+@pytest.mark.parametrize("B,S,D", [(3, 231, 1536), (2, 4096, 1536), (2, 300, 3072), (4, 64, 256), (1, 1000, 1152)])
+def test_ln_modulate_bwd_with_fused_modulation_gate_and_bias_sums(ops, B, S, D):
+    """st355_ln_modulate_bwd_stats: dx / dxg BIT-identical to st355_ln_modulate_bwd; d shift = sum dy, d scale = sum dy * LN(x) (LN in fp32, never rounded),
+    d gate = sum dx * y (dx as stored), d bias = sum dxg (as stored) against fp32 torch sums of the same bf16 tensors: fp32 summation order only (<= 2e-5 rel)."""
+    torch.manual_seed(61)
+    d_ = dev()
+    x = torch.randn(B * S, D, device=d_).to(BF16); dy = (torch.randn(B * S, D, device=d_) * 0.3).to(BF16)
+    dres = torch.randn(B * S, D, device=d_).to(BF16); ya = torch.randn(B * S, D, device=d_).to(BF16)
+    mod = (torch.randn(B, 3 * D, device=d_) * 0.3).to(BF16)
+    scale, gate = mod[:, :D], mod[:, 2 * D:]
+    dx0, dxg0 = ops.ln_modulate_bwd(dy, x, scale, S, dres=dres, gate=gate, want_gated=True)
+    dmod = torch.full((B, 4 * D), 7.0, device=d_, dtype=F32)                       # destinations are OVERWRITTEN (strided slices of one buffer)
+    gb = torch.full((D,), 3.0, device=d_, dtype=BF16)
+    dx, dxg = ops.ln_modulate_bwd_stats(dy, x, scale, S, dmod[:, :D], dmod[:, D:2 * D], dres=dres, gate=gate, y_branch=ya, d_gate=dmod[:, 2 * D:3 * D], d_bias=gb,
+                                        want_gated=True)
+    assert torch.equal(dx, dx0) and torch.equal(dxg, dxg0)
+    xh = torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6)
+    pb = lambda t: t.view(B, S, D).sum(1)
+    assert rel(dmod[:, :D], pb(dy.float())) < 2e-5
+    assert rel(dmod[:, D:2 * D], pb(dy.float() * xh)) < 2e-5
+    assert rel(dmod[:, 2 * D:3 * D], pb(dx0.float() * ya.float())) < 2e-5
+    assert float(dmod[:, 3 * D:].min()) == 7.0 and float(dmod[:, 3 * D:].max()) == 7.0          # nothing written next to the slices
+    ref_b = dxg0.float().sum(0)
+    assert rel(gb.float(), ref_b) < 4e-3                                              # one rounding of the sum to bf16
+    # the two-sum form (no gate statistics), no residual, fp32 bias row
+    d2 = torch.zeros(B, 2 * D, device=d_, dtype=F32)
+    dx1, _ = ops.ln_modulate_bwd_stats(dy, x, scale, S, d2[:, D:], d2[:, :D])
+    dx1_ref, _ = ops.ln_modulate_bwd(dy, x, scale, S)
+    assert torch.equal(dx1, dx1_ref)
+    assert rel(d2[:, D:], pb(dy.float())) < 2e-5 and rel(d2[:, :D], pb(dy.float() * xh)) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,N", [(3, 231, 1536), (2, 4096, 1536), (8, 154, 3072), (2, 100, 520)])
+def test_scale_cols_with_fused_gate_and_bias_sums_and_strided_colsum_rows(ops, B, S, N):
+    torch.manual_seed(62)
+    d_ = dev()
+    x = torch.randn(B * S, N, device=d_).to(BF16); y = torch.randn(B * S, N, device=d_).to(BF16)
+    gate = (torch.randn(B, 2 * N, device=d_) * 0.5).to(BF16)[:, N:]
+    g0 = ops.scale_cols(x, gate, S)
+    dg = torch.zeros(B, N, device=d_, dtype=F32); gb = torch.zeros(N, device=d_, dtype=BF16)
+    g = ops.scale_cols_stats(x, gate, S, y_branch=y, d_gate=dg, d_bias=gb)
+    assert torch.equal(g, g0)
+    assert rel(dg, (x.float() * y.float()).view(B, S, N).sum(1)) < 2e-5
+    assert rel(gb.float(), g0.float().sum(0)) < 4e-3
+    # plain column sums of a stream's rows of a joint [B, S + T, N] buffer, in place: one bf16 row over all samples, fp32 per-sample rows, accumulate
+    T = 37
+    joint = torch.randn(B * (S + T), N, device=d_).to(BF16)
+    rows = joint.view(B, S + T, N)[:, T:]
+    one = torch.zeros(N, device=d_, dtype=F32)
+    ops.colsum_rows(joint[T:], S, S + T, B, one)
+    assert rel(one, rows.float().sum((0, 1))) < 2e-5
+    ops.colsum_rows(joint[T:], S, S + T, B, one, accumulate=True)
+    assert rel(one, 2 * rows.float().sum((0, 1))) < 2e-5
+    per = torch.zeros(B, N, device=d_, dtype=F32)
+    ops.colsum_rows(joint[T:], S, S + T, B, per, per_batch=True)
+    assert rel(per, rows.float().sum(1)) < 2e-5
+    b16 = torch.zeros(N, device=d_, dtype=BF16)
+    ops.colsum_rows(joint[T:], S, S + T, B, b16)
+    assert rel(b16.float(), rows.float().sum((0, 1))) < 4e-3
+
+
+@pytest.mark.parametrize("B,rows,lo,S,P,Q", [(8, 4096, 0, 4327, 1536, 1536), (3, 4032, 0, 4263, 4608, 1536), (2, 128, 64, 320, 256, 512), (4, 1024, 77, 1101, 640, 640),
+                                             (8, 4096, 0, 4327, 256, 256)])
+def test_gemm_tn_over_a_segmented_contraction_axis_is_bit_equal_to_the_gathered_copy(ops, B, rows, lo, S, P, Q):
+    """st355_gemm_tn_seg_bf16: the rows [lo, lo + rows) of every sample of a joint [B * S, C] buffer contracted IN PLACE (either operand, or both) == st355_gemm_tn_bf16
+    on the gathered compact copy, bit for bit (same tiles, same K-slices, same accumulation order; only the K-tile addresses differ)"""
+    torch.manual_seed(63)
+    d_ = dev()
+    jl = (torch.randn(B * S, P, device=d_) * 0.5).to(BF16); jr = torch.randn(B * S, Q, device=d_).to(BF16)
+    vl, vr = jl.view(B, S, P)[:, lo:lo + rows], jr.view(B, S, Q)[:, lo:lo + rows]
+    cl, cr = vl.reshape(B * rows, P), vr.reshape(B * rows, Q)
+    ref = ops.gemm_tn(cl, cr)
+    assert rel(ref, cl.float().t() @ cr.float()) < 5e-3
+    assert torch.equal(ops.gemm_tn(vl, cr), ref), "segmented L"
+    assert torch.equal(ops.gemm_tn(cl, vr), ref), "segmented R"
+    assert torch.equal(ops.gemm_tn(vl, vr), ref), "both segmented"
+    acc0 = torch.randn(P, Q, device=d_).to(BF16)
+    a1, a2 = acc0.clone(), acc0.clone()
+    ops.gemm_tn(cl, cr, out=a1, accumulate=True); ops.gemm_tn(vl, cr, out=a2, accumulate=True)
+    assert torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("B,H,S,hd", [(1, 24, 4327, 64), (2, 3, 4183, 64), (2, 4, 231 + 64, 64), (1, 5, 1000, 64), (1, 2, 333, 96), (2, 2, 300, 128), (1, 2, 65, 64)])
+def test_attention_dq_64_row_kernel_with_a_ragged_key_tail(ops, B, H, S, hd):
+    """S % 64 != 0 (SD3: 4096 + 231; every mixed-aspect bucket): k_attn_bwd_dq64 takes the full 64-key tiles, the general kernel adds the last (ragged) tile to the dQ it
+    left — the backward is separable over keys given lse2 and delta.  Against the 32-row kernel alone: equal up to ONE extra bf16 rounding of the sum (rel-L2 <= 3e-3,
+    stated; measured ~1.5e-3), and against fp32 torch autograd within the bf16 bound of the suite's attention test (2e-2).  dK / dV are untouched by the dispatch."""
+    torch.manual_seed(64)
+    d_ = dev()
+    D = H * hd
+    dv_ = 72 if hd == 96 else hd
+    scale = 1.0 / math.sqrt(dv_)
+    mk = lambda *sh: torch.randn(*sh, device=d_)
+    Q, K = mk(B, H, S, hd), mk(B, H, S, hd)
+    Q[..., dv_:] = 0; K[..., dv_:] = 0
+    Q, K = Q.to(BF16), K.to(BF16)
+    V = mk(B * S, H, hd); V[..., dv_:] = 0
+    V = V.reshape(B * S, D).to(BF16)
+    Sp = (S + 63) // 64 * 64
+    Vt = torch.zeros(B, H, hd, Sp, device=d_, dtype=BF16); Vt[..., :S] = V.view(B, S, H, hd).permute(0, 2, 3, 1)
+    dO = mk(B * S, H, hd); dO[..., dv_:] = 0
+    dO = dO.reshape(B * S, D).to(BF16)
+    O = torch.empty(B * S, D, device=d_, dtype=BF16); lse2 = torch.empty(B, H, S, device=d_)
+    ops.attn_fwd(Q, K, Vt, O, lse2, B, H, S, Sp, hd, scale)
+    res = {}
+    prev = ops.attn_set_impl()
+    try:
+        for impl in (32, 64):
+            ops.attn_set_impl(dq=impl)
+            dQ = torch.empty_like(Q); dK = torch.empty_like(K); dqkv = torch.zeros(B * S, 3 * D, device=d_, dtype=BF16)
+            ops.attn_bwd(Q, K, None, None, V, O, dO, lse2, dQ, dK, dqkv[:, 2 * D:], B, H, S, Sp, hd, scale)
+            res[impl] = (dQ, dK, dqkv)
+    finally:
+        ops.attn_set_impl(fwd=prev[0], dq=prev[1], dkv=prev[2])
+    r = rel(res[64][0], res[32][0])
+    print(f"[parity] dq64 + ragged tail vs dq (B{B} H{H} S{S} d{hd}): rel_l2={r:.3e}")
+    assert r < 3e-3
+    assert torch.equal(res[64][1], res[32][1]) and torch.equal(res[64][2], res[32][2])
+    q, k = Q.float().requires_grad_(True), K.float().requires_grad_(True)
+    v = V.float().view(B, S, H, hd).permute(0, 2, 1, 3)
+    o = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v
+    (o * dO.float().view(B, S, H, hd).permute(0, 2, 1, 3)).sum().backward()
+    assert rel(res[64][0], q.grad) < 2e-2
+    if dv_ < hd:
+        assert res[64][0][..., 80:].abs().max().item() == 0
+
+
+def test_ema_update_inside_the_adamw_launch_is_bit_equal_to_the_separate_pass(ops):
+    """st355_adamw_ema_step_bf16 with the `ema` pointer == the same step followed by st355_ema_update (ema.py:393-433: (s - p) materialised in the parameter dtype)"""
+    torch.manual_seed(65)
+    d_ = dev()
+    n = 8 * 100_003
+    p0 = torch.randn(n, device=d_).to(BF16); g = (torch.randn(n, device=d_) * 0.1).to(BF16)
+    s0 = (p0.float() + 0.01 * torch.randn(n, device=d_)).to(BF16)
+    out = []
+    for fused in (False, True):
+        p, s = p0.clone(), s0.clone()
+        m = torch.zeros(n, device=d_); v = torch.zeros(n, device=d_)
+        for step in (1, 2, 3):
+            ops.adamw_ema_step(p, g, m, v, step, 1e-3, grad_scale=0.5, ema=s if fused else None, ema_decay=0.999)
+            if not fused:
+                ops.ema_update(s, p, 0.999)
+        out.append((p, s, m, v))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[0][1], s0)

@@ -1,5 +1,6 @@
 """AutoencoderKL.encode on the HIP path vs the fp32 oracle restatement (oracle/vae.py) on identical weights / pixels.
-PARITY UNPINNED against the reference (diffusers un-vendored; no golden tensors): bf16 HIP vs fp32 oracle, moments rel-L2 <= 2e-2 (stated here)."""
+The oracle is pinned to the KL autoencoder the reference vendors (simpletuner/helpers/models/ideogram/autoencoder.py executed through tools/ref_shim.py ->
+tests/golden/ref_vae_model.pt, checked on the CPU by tests/test_ref_models_cpu.py); here: bf16 HIP vs that fp32 oracle, moments rel-L2 <= 2e-2 (stated here)."""
 import pytest
 import torch
 
