@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd_stats(const bf16* __restrict
         for (int j = 0; j < 8; j++) {
           const float xh = (v[c][j] - mean) * rstd;
           v[c][j] = xh;
-          const float g = dv[c][j] * scm[c][j];
+          const float g = __fmul_rn(dv[c][j], scm[c][j]);          // materialised (never contracted into the adds below): dx is bit-identical to k_ln_mod_bwd's
           sg += g;
           sgx += g * xh;
           a_sh[c][j] += dv[c][j];
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd_stats(const bf16* __restrict
       if (idx < D) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = rstd * (dv[c][j] * scm[c][j] - c1 - v[c][j] * c2);
+        for (int j = 0; j < 8; j++) o[j] = rstd * (__fmul_rn(dv[c][j], scm[c][j]) - c1 - v[c][j] * c2);
         if (dres) {
           const bf16x8 rr = *(const bf16x8*)(dres + row * lddres + idx);
 #pragma unroll

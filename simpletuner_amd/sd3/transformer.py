@@ -862,20 +862,31 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         if self.lora_groups:
             raise RuntimeError("full fine-tune and LoRA adapters are exclusive")
         self.full = True
-        self.grad_arena = torch.zeros_like(self.arena)
+        # TWO gradient arenas (round 6): the backward fills one and hands it to autograd as it is; the next backward fills the other.  Round 5 cloned the arena at
+        # the end of every backward so that `.grad` never aliased the buffer the next backward overwrites (4 GB read + written per SD3-Medium step); with two
+        # arenas the hand-over is free, and under gradient accumulation autograd adds the new arena into the one `.grad` still holds (_pick_grad_arena)
+        self._grad_arenas = [torch.zeros_like(self.arena), torch.zeros_like(self.arena)]
+        self._grad_sel = 0
+        self.grad_arena = self._grad_arenas[0]
         base = self.arena.data_ptr()
+        self._grad_views = ([], [])          # per arena: (owner, attribute, view) of every gradient view the backward writes through
 
-        def gview(t):
+        def gview(owner, attr, t):
             off = (t.data_ptr() - base) // 2
-            return self.grad_arena[off:off + t.numel()].view(t.shape)
+            for k in (0, 1):
+                self._grad_views[k].append((owner, attr, None if t is None else self._grad_arenas[k][off:off + t.numel()].view(t.shape)))
+            setattr(owner, attr, self._grad_views[0][-1][2])
 
         for l in self._all_linears():
-            l.gw, l.gb = gview(l.w), gview(l.b)
+            gview(l, "gw", l.w); gview(l, "gb", l.b)
         for blk in self.blocks:          # q/k RMSNorm weights (SD3.5): gradient views like every other parameter
             for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k", "norm_q2", "norm_k2"):
                 w = getattr(blk, nm, None)
-                setattr(blk, "g_" + nm, gview(w) if w is not None else None)
-        self.g_mod_w, self.g_mod_b = gview(self.mod_w), gview(self.mod_b)
+                if w is not None:
+                    gview(blk, "g_" + nm, w)
+                else:
+                    setattr(blk, "g_" + nm, None)
+        gview(self, "g_mod_w", self.mod_w); gview(self, "g_mod_b", self.mod_b)
         ps = sorted([p for n, p in self.named_parameters() if ".lora_" not in n], key=lambda p: p.data_ptr())
         for p in ps:
             p.requires_grad_(True)
@@ -885,6 +896,29 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         for l in (self.l_t2, self.l_p2):
             l.wT = l.w.t().contiguous()
         return ps
+
+    def _pick_grad_arena(self):
+        """before a full fine-tune backward: write into the arena `.grad` does NOT alias (after optimizer.zero_grad(set_to_none=True): either; in the middle of a
+        gradient accumulation: the one autograd is not accumulating into)"""
+        g = self._full_params[0].grad if self._full_params else None
+        if g is not None:
+            off0 = self._full_offsets[0][0] * 2
+            if g.data_ptr() == self._grad_arenas[self._grad_sel].data_ptr() + off0:
+                self._select_grad_arena(1 - self._grad_sel)
+
+    def _select_grad_arena(self, k: int):
+        if k == self._grad_sel:
+            return
+        self._grad_sel = k
+        self.grad_arena = self._grad_arenas[k]
+        for owner, attr, view in self._grad_views[k]:
+            setattr(owner, attr, view)
+        if self.grad_sync is not None:
+            self.grad_sync.flat = self.grad_arena                     # the exchange walks the arena this backward fills (same offsets)
+
+    def _swap_grad_arena(self):
+        """training.grad_sync.hand_over_gradients: the arena just filled now belongs to autograd; the next backward takes the other one"""
+        self._select_grad_arena(1 - self._grad_sel)
 
     def trainable_parameters(self):
         return list(self._full_params) if getattr(self, "full", False) else list(self._lora_params)
@@ -1022,21 +1056,22 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                     ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
                     d_img, d_full = d_full, None
                 continue
-            # ---- MLP branch ----
-            ops.colsum_prod(d_img, dmi[:, 5 * D:6 * D], b=sv.yf_i, rows_per_batch=Si)           # d gate_mlp
-            g_i = ops.scale_cols(d_img, mi[:, 5 * D:6 * D], Si)
-            wgrad(blk.ff2, g_i, sv.h_i)
+            # ---- MLP branch (host-sequenced form: SD3.5 dual-attention blocks, trainable q / k norms, TREAD, ST355_BLOCK_ABI=0).  Every modulation / gate / bias
+            # gradient rides in the pass that streams its operands — the same fused entry points the C block sequences (csrc/stats.hip) ----
+            g_i = ops.scale_cols_stats(d_img, mi[:, 5 * D:6 * D], Si, y_branch=sv.yf_i, d_gate=dmi[:, 5 * D:6 * D], d_bias=blk.ff2.gb)     # + d gate_mlp, d b_ff2
+            wgrad(blk.ff2, g_i, sv.h_i, bias=False)
             dh_i = ops.gemm(g_i, blk.ff2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_img)
-            wgrad(blk.ff1, dh_i, sv.n2_i)
+            wgrad(blk.ff1, dh_i, sv.n2_i, bias=False)
             dn2_i = ops.gemm(dh_i, blk.ff1.wT)
-            mod_grads(dn2_i, sv.x1_img, Si, 3, 4, dmi)
             dn2a = None
             if blk.dual:
                 d2 = sv.d2
                 mi9 = mod[:, blk.mod_off:blk.mod_off + 9 * D]; dmi9 = dmod[:, blk.mod_off:blk.mod_off + 9 * D]
-                dx1_i, dxg2 = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi9[:, 8 * D:9 * D], want_gated=True)
-                ops.colsum_prod(dx1_i, dmi9[:, 8 * D:9 * D], b=d2.ya2, rows_per_batch=Si)        # d gate_msa2
-                wgrad(blk.to_out2, dxg2, d2.O2)
+                # + d shift_mlp, d scale_mlp, d gate_msa2 = sum d x1 * y_attn2, d b_to_out2 = sum gate_msa2 * d x1
+                dx1_i, dxg2 = ops.ln_modulate_bwd_stats(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dmi[:, 3 * D:4 * D], dmi[:, 4 * D:5 * D], dres=d_img,
+                                                        gate=mi9[:, 8 * D:9 * D], y_branch=d2.ya2, d_gate=dmi9[:, 8 * D:9 * D], d_bias=blk.to_out2.gb, want_gated=True)
+                ops.colsum_rows(dh_i, Si, Si, B, blk.ff1.gb)
+                wgrad(blk.to_out2, dxg2, d2.O2, bias=False)
                 dO2 = ops.gemm(dxg2, blk.to_out2.wT)
                 dqkv2 = torch.empty(B * Si, 3 * D, dtype=BF16, device=dev)
                 dQ2 = torch.empty(B, H, Si, hd, dtype=BF16, device=dev); dK2 = torch.empty_like(dQ2)
@@ -1044,28 +1079,28 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
                 qk_bwd(dQ2, dK2, d2.qkv2, blk.norm_q2, blk.norm_k2, dqkv2, Si, 0, Si, blk.g_norm_q2, blk.g_norm_k2)
                 wgrad(blk.qkv2, dqkv2, d2.n2a)
                 dn2a = ops.gemm(dqkv2, blk.qkv2.wT)
-                mod_grads(dn2a, sv.img, Si, 6, 7, dmi9)
-                dx1g_i = ops.scale_cols(dx1_i, mi[:, 2 * D:3 * D], Si)
+                dx1g_i = ops.scale_cols_stats(dx1_i, mi[:, 2 * D:3 * D], Si, y_branch=sv.ya_i, d_gate=dmi[:, 2 * D:3 * D], d_bias=blk.to_out.gb)   # + d gate_msa, d b_to_out
                 del dxg2, dO2, dQ2, dK2, dqkv2, d2
             else:
-                dx1_i, dx1g_i = ops.ln_modulate_bwd(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dres=d_img, gate=mi[:, 2 * D:3 * D], want_gated=True)
-            ops.colsum_prod(dx1_i, dmi[:, 2 * D:3 * D], b=sv.ya_i, rows_per_batch=Si)           # d gate_msa
+                # + d shift_mlp, d scale_mlp, d gate_msa = sum d x1 * y_attn, d b_to_out = sum gate_msa * d x1
+                dx1_i, dx1g_i = ops.ln_modulate_bwd_stats(dn2_i, sv.x1_img, mi[:, 4 * D:5 * D], Si, dmi[:, 3 * D:4 * D], dmi[:, 4 * D:5 * D], dres=d_img,
+                                                          gate=mi[:, 2 * D:3 * D], y_branch=sv.ya_i, d_gate=dmi[:, 2 * D:3 * D], d_bias=blk.to_out.gb, want_gated=True)
+                ops.colsum_rows(dh_i, Si, Si, B, blk.ff1.gb)
             del g_i, dh_i, dn2_i
             dx1_t = dx1g_t = None
             if not blk.last:
-                ops.colsum_prod(d_txt, dmt[:, 5 * D:6 * D], b=sv.yf_t, rows_per_batch=St)
-                g_t = ops.scale_cols(d_txt, mt[:, 5 * D:6 * D], St)
-                wgrad(blk.ffc2, g_t, sv.h_t)
+                g_t = ops.scale_cols_stats(d_txt, mt[:, 5 * D:6 * D], St, y_branch=sv.yf_t, d_gate=dmt[:, 5 * D:6 * D], d_bias=blk.ffc2.gb)
+                wgrad(blk.ffc2, g_t, sv.h_t, bias=False)
                 dh_t = ops.gemm(g_t, blk.ffc2.wT, epilogue=EPI_MUL_GELU_GRAD, aux_in=sv.hpre_txt)
-                wgrad(blk.ffc1, dh_t, sv.n2_t)
+                wgrad(blk.ffc1, dh_t, sv.n2_t, bias=False)
                 dn2_t = ops.gemm(dh_t, blk.ffc1.wT)
-                mod_grads(dn2_t, sv.x1_txt, St, 3, 4, dmt)
-                dx1_t, dx1g_t = ops.ln_modulate_bwd(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dres=d_txt, gate=mt[:, 2 * D:3 * D], want_gated=True)
-                ops.colsum_prod(dx1_t, dmt[:, 2 * D:3 * D], b=sv.ya_t, rows_per_batch=St)
+                dx1_t, dx1g_t = ops.ln_modulate_bwd_stats(dn2_t, sv.x1_txt, mt[:, 4 * D:5 * D], St, dmt[:, 3 * D:4 * D], dmt[:, 4 * D:5 * D], dres=d_txt,
+                                                          gate=mt[:, 2 * D:3 * D], y_branch=sv.ya_t, d_gate=dmt[:, 2 * D:3 * D], d_bias=blk.to_add_out.gb, want_gated=True)
+                ops.colsum_rows(dh_t, St, St, B, blk.ffc1.gb)
                 del g_t, dh_t, dn2_t
             # ---- attention output projections ----
             O_i = rows_of(sv.O, 0, Si)
-            wgrad(blk.to_out, dx1g_i, O_i)
+            wgrad(blk.to_out, dx1g_i, O_i, bias=False)
             dO = (torch.zeros if blk.last else torch.empty)(B * S, D, dtype=BF16, device=dev)
             after = []
             probs = _stream_problems(B, S, Si, dict(a=dx1g_i, w=blk.to_out.wT, out=_rows3(dO, 0, Si, B, S)), after)
@@ -1075,7 +1110,7 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             for f in after:
                 f()
             if not blk.last:
-                wgrad(blk.to_add_out, dx1g_t, rows_of(sv.O, Si, St))
+                wgrad(blk.to_add_out, dx1g_t, rows_of(sv.O, Si, St), bias=False)
             del dx1g_i, dx1g_t, O_i
             # ---- attention ----
             dqkv = torch.empty(B * S, 3 * D, dtype=BF16, device=dev)
@@ -1084,20 +1119,20 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             qk_bwd(dQ, dK, sv.qkv, blk.norm_q, blk.norm_k, dqkv, Si, 0, S, blk.g_norm_q, blk.g_norm_k)
             qk_bwd(dQ, dK, sv.qkv, blk.norm_added_q, blk.norm_added_k, dqkv, St, Si, S, blk.g_norm_added_q, blk.g_norm_added_k)
             del dQ, dK, dO
+            ops.colsum_rows(dqkv, Si, S, B, blk.qkv.gb)                    # d b_qkv / d b_add_qkv: each stream's rows of the joint dqkv, summed in place
+            ops.colsum_rows(dqkv[Si:], St, S, B, blk.add_qkv.gb)
             dq_i, dq_t = rows_of(dqkv, 0, Si), rows_of(dqkv, Si, St)
-            wgrad(blk.qkv, dq_i, sv.n_img)
-            wgrad(blk.add_qkv, dq_t, sv.n_txt)
+            wgrad(blk.qkv, dq_i, sv.n_img, bias=False)
+            wgrad(blk.add_qkv, dq_t, sv.n_txt, bias=False)
             dn_i, dn_t = ops.gemm_grouped([dict(a=dq_i, w=blk.qkv.wT), dict(a=dq_t, w=blk.add_qkv.wT)])
-            mod_grads(dn_i, sv.img, Si, 0, 1, dmi)
-            d_img, _ = ops.ln_modulate_bwd(dn_i, sv.img, mi[:, D:2 * D], Si, dres=dx1_i)
-            if dn2a is not None:                  # the second reader of LN(img): attn2's modulated input (scale_msa2)
-                d_img, _ = ops.ln_modulate_bwd(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dres=d_img)
-            if blk.last:
-                mod_grads(dn_t, sv.txt, St, 1, 0, dmt)                # AdaLayerNormContinuous: (scale, shift)
-                d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, :D], St, dres=None)
+            d_img, _ = ops.ln_modulate_bwd_stats(dn_i, sv.img, mi[:, D:2 * D], Si, dmi[:, :D], dmi[:, D:2 * D], dres=dx1_i)      # + d shift_msa, d scale_msa
+            if dn2a is not None:                  # the second reader of LN(img): attn2's modulated input (shift_msa2, scale_msa2)
+                d_img, _ = ops.ln_modulate_bwd_stats(dn2a, sv.img, mod[:, blk.mod_off + 7 * D:blk.mod_off + 8 * D], Si, dmi9[:, 6 * D:7 * D], dmi9[:, 7 * D:8 * D],
+                                                     dres=d_img)
+            if blk.last:                          # AdaLayerNormContinuous: chunks (scale, shift)
+                d_txt, _ = ops.ln_modulate_bwd_stats(dn_t, sv.txt, mt[:, :D], St, dmt[:, D:2 * D], dmt[:, :D], dres=None)
             else:
-                mod_grads(dn_t, sv.txt, St, 0, 1, dmt)
-                d_txt, _ = ops.ln_modulate_bwd(dn_t, sv.txt, mt[:, D:2 * D], St, dres=dx1_t)
+                d_txt, _ = ops.ln_modulate_bwd_stats(dn_t, sv.txt, mt[:, D:2 * D], St, dmt[:, :D], dmt[:, D:2 * D], dres=dx1_t)
             del dqkv, sv, dn_i, dn_t, dq_i, dq_t
             if li in ctx.route_start:
                 ops.scatter_rows(d_img.view(B, Si, D), ctx.route_start[li].keep_i32(), d_full.view(B, ctx.Si, D))
@@ -1206,6 +1241,7 @@ class _SD3FullFn(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dout):
         model = fctx.model
+        model._pick_grad_arena()
         if model.grad_sync is not None:
             model.grad_sync.begin()
         model._engine_backward_full(fctx.ectx, dout)

@@ -37,12 +37,19 @@ RS_AG_MIN_BYTES = 1 << 30
 
 
 def hand_over_gradients(model, arena: torch.Tensor) -> torch.Tensor:
-    """What every st355 backward does last: give autograd a PRIVATE flat copy of the gradient arena (so `.grad` never aliases the buffer the next backward
+    """What every st355 backward does last: give autograd a PRIVATE flat gradient buffer — a copy of the arena, or the arena itself when the model double-buffers
+    it (`_swap_grad_arena`) — (so `.grad` never aliases the buffer the next backward
     overwrites; the per-parameter gradients stay views of one contiguous tensor, which the fused optimizer and the exchange exploit).  Under a DDP-style
     wrapper (training.ddp_seam) the same pass applies 1/world_size — DDP hands out AVERAGED gradients — and the wrapper's end-of-backward callback is queued
     on the autograd engine."""
     scale = getattr(model, "_handover_scale", None)
-    gflat = arena.clone() if scale is None else arena * scale
+    swap = getattr(model, "_swap_grad_arena", None)
+    if scale is None and swap is not None and getattr(model, "grad_arena", None) is arena:
+        # double-buffered arena (sd3 full fine-tune): the arena goes to autograd as it is and the model's next backward fills the other one — no 4 GB clone per step
+        gflat = arena
+        swap()
+    else:
+        gflat = arena.clone() if scale is None else arena * scale
     cb = getattr(model, "_post_backward_cb", None)
     if cb is not None:
         torch.autograd.Variable._execution_engine.queue_callback(cb)
@@ -108,6 +115,11 @@ class GradSync:
             self._serial_backend = str(dist.get_backend(self.pg)).lower() == "nccl"
         return self._serial_backend
 
+    def _fp32_alltoall_ok(self) -> bool:
+        """the all-to-all + local fp32 sum + all-gather form needs the three steps ordered: a device arena under a stream-ordered backend (RCCL), or a host arena
+        under gloo (whose blocking all-to-all orders them)"""
+        return self.flat.is_cuda == self._stream_ordered()
+
     def _comm_ctx(self):
         if self.comm_stream is None:
             return contextlib.nullcontext()
@@ -163,7 +175,7 @@ class GradSync:
                 logging.getLogger("st355.grad_sync").warning(
                     "fp32_reduce requested, but the slice [%d, %d) cannot take it (start not 8-element aligned or shorter than 8 x world): "
                     "this slice uses the backend's own reduce-scatter in the arena dtype", lo, hi)
-            if m8 > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and (self.flat.is_cuda == self._stream_ordered()):
+            if m8 > 0 and self.fp32_reduce and self.comm is None and self.flat.dtype == torch.bfloat16 and self._fp32_alltoall_ok():
                 m = m8                                                 # st355_sum_chunks_bf16 wants 8-element (16-byte) chunks: the tail below takes the rest
                 seg = self.flat[lo:lo + m]
                 if self._recv is None or self._recv.numel() < m:

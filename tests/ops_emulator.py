@@ -287,6 +287,55 @@ def colsum_prod(a, out, b=None, rows_per_batch=None, mode=0, prev=None, shift=No
     return out
 
 
+def _stat_put(dst, val, reduce_batches, accumulate=False):
+    """st355_stat_out semantics: per-batch fp32 rows, or one row over the batches (fp32 / bf16); overwrite unless accumulate"""
+    if dst is None:
+        return
+    v = val.sum(dim=0) if reduce_batches else val
+    _need(dst.dtype == F32 or (reduce_batches and dst.dtype == BF16), "stat_out: per-batch sums are fp32; a bf16 destination is one row over the batches")
+    _need(tuple(dst.shape) == tuple(v.shape), f"stat_out: destination {tuple(dst.shape)}, sums {tuple(v.shape)}")
+    dst.copy_((dst.float() + v if accumulate else v).to(dst.dtype))
+
+
+def ln_modulate_bwd_stats(dy, x, scale, rows_per_batch, d_shift, d_scale, dres=None, gate=None, y_branch=None, d_gate=None, d_bias=None, eps=1e-6, want_gated=False,
+                          out=None):
+    """st355_ln_modulate_bwd_stats: ln_modulate_bwd + d shift = sum dy, d scale = sum dy * LN(x) (fp32 LN), d gate = sum dx * y (dx as stored), d bias = sum dxg"""
+    dx, dxg = ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=dres, gate=gate, eps=eps, want_gated=want_gated, out=out)
+    rows, D = x.shape
+    nb = rows // rows_per_batch
+    _need(nb * rows_per_batch == rows and D <= 3072, "ln_modulate_bwd_stats: rows % rows_per_batch, D <= 3072")
+    pb = lambda t: t.view(nb, rows_per_batch, D).sum(dim=1)
+    xh = torch.nn.functional.layer_norm(x.float(), (D,), eps=eps)
+    _stat_put(d_shift, pb(dy.float()), False); _stat_put(d_scale, pb(dy.float() * xh), False)
+    if d_gate is not None:
+        _need(y_branch is not None, "ln_modulate_bwd_stats: the gate gradient needs the branch output")
+        _stat_put(d_gate, pb(dx.float() * y_branch.float()), False)
+    if d_bias is not None:
+        _need(dxg is not None, "ln_modulate_bwd_stats: the bias gradient is the column sum of the gated output")
+        _stat_put(d_bias, pb(dxg.float()), True)
+    return dx, dxg
+
+
+def scale_cols_stats(x, gate, rows_per_batch, y_branch=None, d_gate=None, d_bias=None, out=None):
+    g = scale_cols(x, gate, rows_per_batch, out=out)
+    M, N = x.shape
+    nb = M // rows_per_batch
+    pb = lambda t: t.view(nb, rows_per_batch, N).sum(dim=1)
+    if d_gate is not None:
+        _need(y_branch is not None, "scale_cols_stats: the gate gradient needs the branch output")
+        _stat_put(d_gate, pb(x.float() * y_branch.float()), False)
+    _stat_put(d_bias, pb(g.float()), True)
+    return g
+
+
+def colsum_rows(a, rows_per_batch, batch_stride_rows, nb, out, per_batch=False, accumulate=False):
+    _chk(a, BF16, "a"); _al(a, 16, "a"); _ld(a, 8, "a")
+    _need(batch_stride_rows >= rows_per_batch and a.shape[0] >= (nb - 1) * batch_stride_rows + rows_per_batch, "colsum_rows: the row blocks leave the tensor")
+    v = torch.stack([a[b * batch_stride_rows:b * batch_stride_rows + rows_per_batch].float().sum(dim=0) for b in range(nb)])
+    _stat_put(out, v, not per_batch, accumulate)
+    return out
+
+
 def transpose(src, out=None):
     _chk(src, BF16, "src"); _rows(src, "src")
     R, Cn = src.shape
@@ -1276,7 +1325,7 @@ def block_sd3_joint_bwd(**a):
 _EMULATED = ("qk_rope", "attn_fwd_vrows", "attn_bwd_rope", "qk_rope_norm_bwd", "grid_rows", "grid_zeros", "grid_from_nchw", "grid_to_nchw", "tokens_to_grid", "grid_to_tokens", "conv", "conv_wgrad", "im2col3x3", "col2im3x3", "upsample2x",
              "upsample2x_bwd", "groupnorm_fwd", "groupnorm_bwd", "layernorm_fwd", "layernorm_bwd", "layernorm_param_grads", "geglu_fwd", "geglu_bwd", "softmax_rows_",
              "softmax_rows_bwd_", "attn_cross_fwd", "attn_cross_bwd", "head_split", "head_merge", "gelu_tanh", "gemm", "gemm_grouped", "gemm_tn", "colsum_prod", "transpose", "skinny_tn", "skinny_tn_multi", "lora_pack", "flow_noise_mix", "ddpm_noise_mix", "flux_pack", "flux_unpack", "mse_loss", "cond_loss", "adamw_ema_step", "adamw_bf16_sr_step", "ema_update", "grad_norm", "grad_clamp_", "grad_clip_norm_", "timestep_proj", "patchify", "unpatchify", "silu", "silu_bwd",
-             "add", "scale_cols", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
+             "add", "scale_cols", "scale_cols_stats", "colsum_rows", "ln_modulate_bwd_stats", "gather_rows", "scatter_rows", "ln_modulate_fwd", "ln_modulate_bwd", "layer_norm_xhat", "qk_norm_rope_fwd", "qk_norm_rope_bwd",
              "qk_norm_rope_bwd_wgrad", "attn_fwd", "attn_bwd", "block_pixart_fwd", "block_pixart_bwd", "block_sd3_joint_fwd", "block_sd3_joint_bwd")
 
 
