@@ -523,7 +523,7 @@ def main():
                              ("configs[4] pixart_controlnet_2k_full_depth", lambda: PC.pixart_controlnet(2048, dev, trunk_layers=28, ctrl_layers=13))):
                 gc.collect()
                 torch.cuda.empty_cache()
-                if time.time() - _T0 > 420.0:     # the default run must finish in minutes: what did not fit is named, not silently dropped
+                if time.time() - _T0 > 480.0:     # the default run must finish in minutes: what did not fit is named, not silently dropped
                     others[name] = {"skipped": "time budget of the default run (the GPU suite asserts it: tests/test_parity_at_config_gpu.py)"}
                     continue
                 try:
@@ -736,7 +736,7 @@ def run_workload(args, dev, rank, world):
         if rep_ is not None:
             durs = [round((s_["end_ms"] - s_["start_ms"]) * 1e3, 1) for s_ in rep_["slices"]]
             comm_rep = {"path": "st355_comm_* C ABI over RCCL (ST355_COMM=native)" if gs_.comm is not None else (f"torch.distributed {dist.get_backend()} collectives on a comm stream" + (" (nccl = RCCL over xGMI)" if str(dist.get_backend()).lower() == "nccl" else " (gloo: the shared-GPU plumbing run)")),
-                        "mode": gs_.mode, "fp32_reduce": bool(gs_.fp32_reduce), "bucket_bytes": int(gs_.bucket_elems * gs_.flat.element_size()),
+                        "ranks": int(dist.get_world_size()), "mode": gs_.mode, "fp32_reduce": bool(gs_.fp32_reduce), "bucket_bytes": int(gs_.bucket_elems * gs_.flat.element_size()),
                         "arena_bytes": int(gs_.flat.numel() * gs_.flat.element_size()), "backward_ms": round(rep_["backward_ms"], 3),
                         "comm_ms_sum_over_buckets": round(rep_["comm_ms"], 3), "exposed_tail_ms": round(rep_["exposed_ms"], 3),
                         "overlap_frac": round(rep_["overlap_frac"], 4), "buckets": len(durs), "bucket_us": durs[:64],
@@ -810,6 +810,10 @@ def run_workload(args, dev, rank, world):
             "kernels": kernels,
             "cpu_baseline": None,
         }
+        if getattr(args, "fp8", False):
+            out["note"] = ("coverage row, not a speed row: the fp8-native trunk is byte-exact to the reference's quantisers but 7 % SLOWER than bf16 end to end "
+                           "(400.4 vs 374.0 ms, same box: profiles/r05_pixart_2k_fp8_ab.txt) — the per-call amax + quantise passes cost more than the forward third "
+                           "of the trunk's GEMMs gains on the fp8 pipe")
         if world > 1:
             out["comm"] = comm_rep
         pub = published_row(args)
@@ -829,6 +833,20 @@ def run_workload(args, dev, rank, world):
             torch.cuda.empty_cache()
             _log("flux: timed region done, host-core leg")
             out["cpu_baseline"], out["parity_at_config"] = cpu_baseline(args, dev)
+            if out["parity_at_config"] is not None and args.layers == 19 and args.single_layers == 38 and not args.full and time.time() - _T0 < 240.0:
+                # the same check at the configuration's REAL depth (19 + 38 blocks, all 380 adapter gradients): the figures the GPU suite asserts
+                # (tests/test_baseline_shapes_gpu.py::test_flux_full_depth_step_matches_oracle) — the 1 + 1-block form above is what the host-core leg timed
+                try:
+                    import gc
+                    from tests import parity_at_config as PC
+                    gc.collect(); torch.cuda.empty_cache()
+                    _log("flux: parity at full depth")
+                    t0_ = time.time()
+                    out["parity_at_config"] = {"full_depth": PC.flux_lora_full_depth(dev, rank=int(args.rank)), "one_plus_one_blocks_of_the_host_core_leg": out["parity_at_config"]}
+                    out["parity_at_config"]["full_depth"]["seconds"] = round(time.time() - t0_, 1)
+                    gc.collect(); torch.cuda.empty_cache()
+                except Exception as e:            # noqa: BLE001
+                    out["parity_at_config"] = {"full_depth": {"error": f"{type(e).__name__}: {e}"[:300]}, "one_plus_one_blocks_of_the_host_core_leg": out["parity_at_config"]}
         elif world == 1 and not args.no_cpu_baseline and args.model in ("sd15", "sdxl"):
             del trainer, plugin, batches
             torch.cuda.empty_cache()

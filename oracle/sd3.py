@@ -195,8 +195,11 @@ def joint_block(P, cfg: SD3Config, i: int, hidden, enc, temb, lora=None, lora_sc
     return enc, hidden
 
 
-def sd3_forward(P, cfg: SD3Config, latents, encoder_hidden_states, pooled_projections, timestep, lora=None, lora_scale: float = 1.0, tread=None):
+def sd3_forward(P, cfg: SD3Config, latents, encoder_hidden_states, pooled_projections, timestep, lora=None, lora_scale: float = 1.0, tread=None,
+                checkpoint: bool = False):
     """sd3/transformer.py:560-911.  latents [B,16,H,W]; timestep [B] in 0..1000.  Returns [B,16,H,W].
+    checkpoint: re-run every joint block in the backward instead of keeping its activations (torch.utils.checkpoint, non-reentrant): the same fp32 arithmetic, so
+    that a multi-step full-depth trajectory fits next to the model under test (as oracle.flux.flux_forward(checkpoint=True)).
     tread: as oracle.flux.flux_forward — routing over the image tokens between two block indices (:694-706, 796-803; no RoPE to re-route)."""
     from .flux import tread_end, tread_start
     B, C, Hh, Ww = latents.shape
@@ -227,7 +230,11 @@ def sd3_forward(P, cfg: SD3Config, latents, encoder_hidden_states, pooled_projec
         if ptr < len(routes) and i == routes[ptr]["start_layer_idx"]:
             info, saved = infos[ptr], hidden
             hidden = tread_start(hidden, info)
-        enc, hidden = joint_block(P, cfg, i, hidden, enc, temb, lora, lora_scale, temb_context)
+        if checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint as _ckpt
+            enc, hidden = _ckpt(lambda h_, e_, t_, i_=i: joint_block(P, cfg, i_, h_, e_, t_, lora, lora_scale, temb_context), hidden, enc, temb, use_reentrant=False)
+        else:
+            enc, hidden = joint_block(P, cfg, i, hidden, enc, temb, lora, lora_scale, temb_context)
         if info is not None and i == routes[ptr]["end_layer_idx"]:
             hidden = tread_end(hidden, info, saved)
             info, saved, ptr = None, None, ptr + 1

@@ -96,26 +96,54 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd_stats(const bf16* __restrict
       for (int j = 0; j < 8; j++) { a_g[c][j] = 0.f; a_b[c][j] = 0.f; }
     }
   }
+  // One memory round trip per row, issued ONE ROW AHEAD: every operand of row r + 4 (x, dy, residual, branch output) is requested before row r's reductions start,
+  // so the four dependent wave reductions of a row run under the next row's loads (first form: two dependent round trips per row and nothing in flight during the
+  // reductions — 2.7 TB/s, rocprofv3 r06; the unfused k_ln_mod_bwd hides the same latency with 4x the resident waves, which the accumulators here do not leave room for)
   const int64_t r_end = min((int64_t)(chunk + 1) * SR_ROWS, rows_per_batch);
-  for (int64_t r = (int64_t)chunk * SR_ROWS + wv; r < r_end; r += 4) {
+  bf16x8 rx[NC], rdy[NC], rres[NC], rya[NC], gvr[NC];
+  const bool has_y = GS && yb != nullptr;
+  auto issue = [&](int64_t r) {
     const int64_t row = (int64_t)bi * rows_per_batch + r;
-    const bf16* xr = x + row * ldx;
-    const bf16* dyr = dy + row * lddy;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int idx = (c * 64 + lane) * 8;
+      if (idx < D) {
+        rx[c] = *(const bf16x8*)(x + row * ldx + idx);
+        rdy[c] = *(const bf16x8*)(dy + row * lddy + idx);
+        if (NC <= 4) {                      // (NC = 6: these two are fetched where they are used, as k_ln_mod_bwd does)
+          if (dres) rres[c] = *(const bf16x8*)(dres + row * lddres + idx);
+          if (has_y) rya[c] = *(const bf16x8*)(yb + row * ldyb + idx);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int idx = (c * 64 + lane) * 8;
+    if (NC <= 4 && dxg && idx < D) gvr[c] = *(const bf16x8*)(gate + (int64_t)bi * gate_stride + idx);
+  }
+  constexpr bool PREF = NC <= 4;          // D = 3072 (NC = 6): the second row's operands do not fit the register file next to the accumulators — plain order there
+  int64_t r = (int64_t)chunk * SR_ROWS + wv;
+  if (PREF && r < r_end) issue(r);
+  for (; r < r_end; r += 4) {
+    const int64_t row = (int64_t)bi * rows_per_batch + r;
+    if (!PREF) issue(r);
     float v[NC][8], dv[NC][8];
+    bf16x8 cres[NC], cya[NC];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
       const int idx = (c * 64 + lane) * 8;
       if (idx < D) {
-        const bf16x8 t = *(const bf16x8*)(xr + idx);
-        const bf16x8 d = *(const bf16x8*)(dyr + idx);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { v[c][j] = bf2f(t[j]); s += v[c][j]; dv[c][j] = bf2f(d[j]); }
+        for (int j = 0; j < 8; j++) { v[c][j] = bf2f(rx[c][j]); s += v[c][j]; dv[c][j] = bf2f(rdy[c][j]); }
+        if (NC <= 4) { cres[c] = rres[c]; cya[c] = rya[c]; }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) { v[c][j] = 0.f; dv[c][j] = 0.f; }
       }
     }
+    if (PREF && r + 4 < r_end) issue(r + 4);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -136,7 +164,7 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd_stats(const bf16* __restrict
         for (int j = 0; j < 8; j++) {
           const float xh = (v[c][j] - mean) * rstd;
           v[c][j] = xh;
-          const float g = __fmul_rn(dv[c][j], scm[c][j]);          // materialised (never contracted into the adds below): dx is bit-identical to k_ln_mod_bwd's
+          const float g = dv[c][j] * scm[c][j];
           sg += g;
           sgx += g * xh;
           a_sh[c][j] += dv[c][j];
@@ -152,28 +180,28 @@ __global__ void __launch_bounds__(256) k_ln_mod_bwd_stats(const bf16* __restrict
       if (idx < D) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = rstd * (__fmul_rn(dv[c][j], scm[c][j]) - c1 - v[c][j] * c2);
+        for (int j = 0; j < 8; j++) o[j] = rstd * (dv[c][j] * scm[c][j] - c1 - v[c][j] * c2);
         if (dres) {
-          const bf16x8 rr = *(const bf16x8*)(dres + row * lddres + idx);
+          if (NC > 4) cres[c] = *(const bf16x8*)(dres + row * lddres + idx);
 #pragma unroll
-          for (int j = 0; j < 8; j++) o[j] += bf2f(rr[j]);
+          for (int j = 0; j < 8; j++) o[j] += bf2f(cres[c][j]);
         }
         bf16x8 ov;
 #pragma unroll
         for (int j = 0; j < 8; j++) ov[j] = f2bf(o[j]);
         *(bf16x8*)(dx + row * lddx + idx) = ov;
         if (GS) {
-          if (yb) {
-            const bf16x8 yv = *(const bf16x8*)(yb + row * ldyb + idx);
+          if (has_y) {
+            if (NC > 4) cya[c] = *(const bf16x8*)(yb + row * ldyb + idx);
 #pragma unroll
-            for (int j = 0; j < 8; j++) a_g[c][j] += bf2f(ov[j]) * bf2f(yv[j]);
+            for (int j = 0; j < 8; j++) a_g[c][j] += bf2f(ov[j]) * bf2f(cya[c][j]);
           }
         }
         if (dxg) {
-          const bf16x8 gv = *(const bf16x8*)(gate + (int64_t)bi * gate_stride + idx);
           bf16x8 og;
+          if (NC > 4) gvr[c] = *(const bf16x8*)(gate + (int64_t)bi * gate_stride + idx);
 #pragma unroll
-          for (int j = 0; j < 8; j++) og[j] = f2bf(bf2f(ov[j]) * bf2f(gv[j]));
+          for (int j = 0; j < 8; j++) og[j] = f2bf(bf2f(ov[j]) * bf2f(gvr[c][j]));
           *(bf16x8*)(dxg + row * lddxg + idx) = og;
           if (GS) {
 #pragma unroll

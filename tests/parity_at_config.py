@@ -260,3 +260,44 @@ def pixart_controlnet(res: int, dev, trunk_layers: int = 3, ctrl_layers: int = 2
     rep = _summary(what, out, ref.detach(), pairs)
     del cn, m
     return rep
+
+
+def flux_lora_full_depth(dev, seed: int = 21, rank: int = 32):
+    """configs[2] at its real depth — Flux.1-dev, 19 double + 38 single blocks, D = 3072, 24 x 128 heads, 4096 image + 512 text tokens, LoRA r32 on the default target
+    set, batch 1: one train step (prediction, flow-matching loss, the adapter gradients of all 190 target projections) against the fp32 restatement at the same depth on
+    the device's ATen kernels with per-block recomputation (oracle.flux.flux_forward(checkpoint=True)).  The figures of tests/test_baseline_shapes_gpu.py::
+    test_flux_full_depth_step_matches_oracle, as a report (bench.py prints it as the headline's `parity_at_config.full_depth`)."""
+    from simpletuner_amd.flux.model import Flux
+    from simpletuner_amd.training.trainer import St355Accelerator, default_config
+    from tests import parity_utils as PU
+
+    cfg = default_config(lora_rank=rank, train_batch_size=1, seed=seed, lora_init_b_std=0.02, flow_schedule_shift=3.0)
+    plugin = Flux(cfg, St355Accelerator(dev))
+    plugin.load_model(guidance_embeds=True)                                              # every hyper-parameter = the Flux.1-dev default
+    plugin.add_lora_adapter()
+    model = plugin.get_trained_component()
+    cpu, devt = PU.make_inputs(1, 128, 128, 512, 4096, 768, dev, seed=seed)
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    batch = {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
+    prepared = plugin.prepare_batch(batch, {"global_step": 0})
+    out = plugin.model_predict(prepared)
+    loss, _ = plugin.loss_with_logs(prepared, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    P, lora, scale = PU.oracle_state(model, device=dev)
+    o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu, checkpoint=True)
+    worst, worst_cos, n = (0.0, ""), 1.0, 0
+    for name, p in model.named_parameters():
+        if ".lora_" not in name:
+            continue
+        ref = o_grads[name.split(".lora_")[0]][0 if ".lora_A." in name else 1]
+        worst = max(worst, (PU.rel_l2(p.grad, ref), name))
+        worst_cos = min(worst_cos, PU.cos_sim(p.grad, ref))
+        n += 1
+    return {"what": f"Flux.1-dev at FULL depth ({model.config.num_layers} double + {model.config.num_single_layers} single blocks, D=3072, S=4096+512, LoRA r{rank}, batch 1): "
+                    "one train step, HIP bf16 vs oracle fp32 (autograd, per-block recompute), same weights / noised latents / timesteps",
+            "pred_rel_l2": round(PU.rel_l2(out["model_prediction"], o_pred), 6), "pred_cos": round(PU.cos_sim(out["model_prediction"], o_pred), 7),
+            "loss_hip": round(float(loss.detach()), 6), "loss_oracle": round(float(o_loss), 6), "lora_grads_compared": n,
+            "lora_grad_worst_rel_l2": round(worst[0], 6), "lora_grad_worst_at": worst[1], "lora_grad_worst_cos": round(worst_cos, 6),
+            "tolerance": "pred rel_l2 <= 2e-2, cos >= 0.9995, |loss delta| <= 1e-3 x loss, every adapter gradient rel_l2 <= 5e-2 with cos >= 0.999 (DESIGN.md §3; no widening for depth)"}

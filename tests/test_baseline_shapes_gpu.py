@@ -210,31 +210,13 @@ def test_flux_full_depth_step_matches_oracle():
     of gate / modulation indexing.  Tolerances: prediction rel-L2 <= 2e-2 and cosine >= 0.9995 (the stated §8(c) bound, also at full depth; asserted in _check_step), |delta loss| <= 1e-3 x loss,
     every adapter gradient rel-L2 <= 5e-2 with cosine >= 0.999 (the same bounds as the two-block test: no widening for depth).  Measured r3: prediction rel-L2 1.73e-2, cosine 0.99985,
     loss 3.030217 vs 3.030492, worst of the 380 adapter gradients 3.5e-2 (single block 31 to_k lora_A)."""
-    from simpletuner_amd.flux.model import Flux
-    from simpletuner_amd.training.trainer import St355Accelerator, default_config
-
-    dev = torch.device(DEV)
-    cfg = default_config(lora_rank=32, train_batch_size=1, seed=21, lora_init_b_std=0.02, flow_schedule_shift=3.0)
-    acc = St355Accelerator(dev)
-    plugin = Flux(cfg, acc)
-    plugin.load_model(guidance_embeds=True)                                              # every hyper-parameter = the Flux.1-dev default
-    plugin.add_lora_adapter()
-    model = plugin.get_trained_component()
-    assert model.config.num_layers == 19 and model.config.num_single_layers == 38 and model.D == 3072
-    cpu, devt = PU.make_inputs(1, 128, 128, 512, 4096, 768, dev, seed=21)
-    sig = devt["sigmas"]
-    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
-    batch = {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
-    prepared = plugin.prepare_batch(batch, {"global_step": 0})
-    out = plugin.model_predict(prepared)
-    loss, _ = plugin.loss_with_logs(prepared, out)
-    loss.backward()
-    torch.cuda.synchronize()
-    P, lora, scale = PU.oracle_state(model, device=DEV)                                   # 12 B parameters in fp32 on the device: 48 GB of the 288
-    o_loss, o_pred, o_grads = PU.oracle_step(P, PU.oracle_cfg(model), lora, scale, cpu, checkpoint=True)
-    assert len(o_grads) == len(lora) >= 19 * 4 + 38 * 3
-    _check_step("flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32", plugin, model, out, loss, o_loss.cpu(), o_pred, o_grads, grad_tol=5e-2,
-                pred_tol=2e-2, cos_tol=0.999)
+    from tests import parity_at_config as PC
+    rep = PC.flux_lora_full_depth(torch.device(DEV))
+    print("[parity@config] flux FULL DEPTH 19+38 blocks, D=3072 S=4096+512 r32:", {k: v for k, v in rep.items() if k not in ("what", "tolerance")})
+    assert rep["lora_grads_compared"] == 2 * (19 * 4 + 38 * 3)
+    assert rep["pred_rel_l2"] < 2e-2 and rep["pred_cos"] > 0.9995
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 1e-3 * max(1.0, abs(rep["loss_oracle"]))
+    assert rep["lora_grad_worst_rel_l2"] < 5e-2 and rep["lora_grad_worst_cos"] > 0.999, rep
 
 
 def test_sd3_full_width_step_matches_oracle():

@@ -50,3 +50,108 @@ def test_pixart_sigma_controlnet_2k_true_width():
 def test_pixart_sigma_controlnet_2k_full_depth():
     """BASELINE.json configs[4] at its real depth: 28 trunk blocks + 13 ControlNet blocks at 2K latents"""
     _check(PC.pixart_controlnet(2048, DEV, trunk_layers=28, ctrl_layers=13))
+
+
+def test_sd3_medium_full_finetune_ema_loss_curve_at_full_depth():
+    """BASELINE.json configs[3] as a TRAJECTORY (north star: "loss curve matching reference within 1e-3" on the SD3 DiT train step): SD3-Medium at its real depth
+    (24 joint blocks, D = 1536, 1024^2: S = 4096 + 231), batch 1, FULL fine-tune + EMA (decay 0.9999 under the reference's default ramp, ema.py:322-349), 20 optimizer
+    steps on identical noised latents / timesteps.
+      HIP     bf16 parameter arena + bf16 gradients, St355AdamW (fp32 moments, ONE launch, EMA inside it), bf16 EMA shadow
+      oracle  fp32 autograd (oracle.sd3, per-block recompute, the device's ATen fp32 kernels) stepping torch.optim.AdamW, EMA by oracle.train_math —
+              (a) fp32 parameter + shadow storage; (b) the SAME oracle with its parameters and shadow rounded to bf16 after every update: what bf16 STORAGE alone
+              costs against (a), printed beside the HIP curve.
+    Asserted: |loss_hip - loss_a| <= 1e-3 at every step; EMA shadow rel-L2 vs (b) <= 1e-3 and vs (a) <= 2.5e-3 (a bf16-stored shadow sits 2^-9 / sqrt(3) = 1.1e-3
+    rms from ANY fp32 tensor it rounds — the (b)-vs-(a) distance printed beside it is that floor, not a HIP error)."""
+    import gc
+
+    from oracle import sd3 as OS
+    from oracle import train_math as TM
+    from simpletuner_amd.sd3.model import SD3
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+    from tests import parity_utils as PU
+
+    BF16 = torch.bfloat16
+    n_steps, lr, decay = 20, 1e-5, 0.9999
+    cfg = default_config(model_family="sd3", model_type="full", train_batch_size=1, seed=6, learning_rate=lr, flow_schedule_shift=3.0, use_ema=True, ema_decay=decay)
+    acc = St355Accelerator(DEV)
+    plugin = SD3(cfg, acc)
+    plugin.load_model(sample_size=128, num_layers=24, num_attention_heads=24, attention_head_dim=64, caption_projection_dim=1536, pooled_projection_dim=2048,
+                      pos_embed_max_size=192)
+    plugin.enable_full_finetune()
+    model = plugin.get_trained_component()
+    trainer = Trainer(cfg, plugin, acc)
+    cpu, devt = PU.make_inputs(1, 128, 128, 231, 4096, 2048, DEV, seed=6)
+    sig = devt["sigmas"]
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    P0, _, _ = PU.oracle_state(model, device=DEV)                                   # the start weights, fp32 copies (every value a bf16 number)
+    pos = model.pos_embed.pos_embed.detach().float().clone()
+    c = model.config
+    ocfg = OS.SD3Config(sample_size=c.sample_size, num_layers=c.num_layers, attention_head_dim=c.attention_head_dim, num_attention_heads=c.num_attention_heads,
+                        joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim, pos_embed_max_size=c.pos_embed_max_size, qk_norm=c.qk_norm)
+    names = [n for n, _ in model.named_parameters()]
+    by_param = {id(p): n for n, p in model.named_parameters()}
+    batch = lambda: {"latent_batch": devt["latents"], "prompt_embeds": devt["prompt"], "add_text_embeds": devt["pooled"], "noise": devt["noise"]}
+    hip = [trainer.train_step(batch()) for _ in range(n_steps)]
+    hip = [float(x) for x in torch.stack([h.reshape(()) for h in hip]).cpu()]
+    assert trainer.optimizer.ema_applied, "the EMA update did not ride in the optimizer launch"
+    shadow_hip = {by_param[id(p)]: s.detach().float().clone() for p, s in zip(trainer.params, trainer.ema_model.shadow_params)}
+    assert trainer.ema_model.optimization_step == n_steps
+    del trainer, plugin, model, acc
+    gc.collect(); torch.cuda.empty_cache()
+
+    g = {k: v.to(DEV) for k, v in cpu.items()}
+    s_ = g["sigmas"].view(-1, 1, 1, 1)
+    noisy = ((1 - s_) * g["latents"] + s_ * g["noise"]).to(BF16).float()
+    target = (g["noise"] - g["latents"]).to(BF16).float()
+
+    def oracle_run(bf16_storage: bool):
+        params = {k: torch.nn.Parameter(P0[k].clone()) for k in names}
+        opt = torch.optim.AdamW([params[k] for k in names], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        shadow = {k: params[k].detach().clone() for k in names}
+        curve = []
+        for step in range(1, n_steps + 1):
+            opt.zero_grad(set_to_none=True)
+            P = dict(params); P["pos_embed.pos_embed"] = pos
+            pred = OS.sd3_forward(P, ocfg, noisy, g["prompt"], g["pooled"], g["sigmas"] * 1000.0, checkpoint=True)
+            loss = ((pred - target) ** 2).mean(dim=(1, 2, 3)).mean()
+            loss.backward()
+            if bf16_storage:                       # bf16 gradients in, as the engine's arena holds them
+                for k in names:
+                    params[k].grad = params[k].grad.to(BF16).float()
+            opt.step()
+            d = TM.ema_get_decay(step, decay)
+            with torch.no_grad():
+                for k in names:
+                    if bf16_storage:
+                        params[k].copy_(params[k].to(BF16).float())
+                        diff = (shadow[k] - params[k]).to(BF16).float()             # (s - p) materialised in the storage dtype (ema.py:393-433)
+                        shadow[k] = (shadow[k] - (1 - d) * diff).to(BF16).float()
+                    else:
+                        shadow[k] = TM.ema_update(shadow[k], params[k].detach(), d)
+            curve.append(float(loss.detach()))
+        return curve, shadow
+
+    def shadow_dist(a, b):
+        num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in names)
+        den = sum(float((b[k].double() ** 2).sum()) for k in names)
+        return (num / den) ** 0.5
+
+    curve_a, shadow_a = oracle_run(False)
+    d_a = [abs(x - y) for x, y in zip(hip, curve_a)]
+    r_a = shadow_dist(shadow_hip, shadow_a)
+    shadow_a_small = {k: v.to(BF16) for k, v in shadow_a.items()}                   # (kept rounded only for the (b)-vs-(a) distance: 4 GB instead of 8)
+    ra_b16 = shadow_dist({k: v.float() for k, v in shadow_a_small.items()}, shadow_a)
+    del shadow_a
+    gc.collect(); torch.cuda.empty_cache()
+    curve_b, shadow_b = oracle_run(True)
+    d_b = [abs(x - y) for x, y in zip(hip, curve_b)]
+    d_ab = [abs(x - y) for x, y in zip(curve_b, curve_a)]
+    r_b = shadow_dist(shadow_hip, shadow_b)
+    r_ab = shadow_dist(shadow_b, {k: v.float() for k, v in shadow_a_small.items()})
+    print(f"[parity] sd3 full fine-tune + EMA, 24 blocks, 1024^2, B1, {n_steps} steps: loss hip    {[round(x, 5) for x in hip[::3]]} ... {hip[-1]:.5f}")
+    print(f"[parity]   oracle (a) fp32 storage              : loss           {[round(x, 5) for x in curve_a[::3]]} ... {curve_a[-1]:.5f}")
+    print(f"[parity]   oracle (b) bf16 storage              : loss           {[round(x, 5) for x in curve_b[::3]]} ... {curve_b[-1]:.5f}")
+    print(f"[parity]   max |delta loss|: hip vs (a) {max(d_a):.3e} (step {d_a.index(max(d_a))}), hip vs (b) {max(d_b):.3e}, (b) vs (a) {max(d_ab):.3e}  [what bf16 storage alone costs]")
+    print(f"[parity]   EMA shadow rel-L2 after {n_steps} steps: hip vs (a) {r_a:.3e}, hip vs (b) {r_b:.3e}, (b) vs (a) {r_ab:.3e}, bf16(a) vs (a) {ra_b16:.3e}  [the storage floor]")
+    assert max(d_a) <= 1e-3, (max(d_a), d_a.index(max(d_a)))
+    assert r_b <= 1e-3 and r_a <= 2.5e-3, (r_a, r_b)
