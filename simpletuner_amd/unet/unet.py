@@ -585,7 +585,9 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         # training: the forward also keeps the rounding residual of O, so that the backward's delta = rowsum(dO * O) is taken from the un-rounded output.  The UNet's
         # attention inputs are LayerNorm outputs with a large component common to all tokens (0.97 of the row norm at SDXL's 32^2 level); a flash-style backward that
         # reads delta from the bf16 O leaves that component un-cancelled in dQ / dK (rel-L2 0.26 on dQ there: profiles/r05_sdxl_lora_outlier_probe.log)
-        Ores = torch.empty_like(Op) if T is not None else None
+        # Self-attention only: the common component comes from the LayerNorm output feeding BOTH q and k; over the 77 text keys of attn2 there is no such common key
+        # component to cancel, and the residual cost every cross-attention an O-sized write + read with no measured benefit (r5 advice)
+        Ores = torch.empty_like(Op) if (T is not None and self_attn) else None
         if self_attn:
             ops.attn_fwd(Q, K, Vt, Op, lse, B, heads, S, Sp, hp, scale, O_res=Ores)
         else:
