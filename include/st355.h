@@ -110,7 +110,18 @@ int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* ga
 
 /* ---- GEMM family (K4,K8,K9,K11,K12): C[M,N] = A[M,K] B[N,K]^T (+ A2[M,K2] B2[N,K2]^T) ---------- */
 enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3, ST355_EPI_ADD = 4 /* C = acc + aux_in */,
-       ST355_EPI_QK_NORM_ROPE = 5 /* fused QKV projection: see st355_qk_rope */ };
+       ST355_EPI_QK_NORM_ROPE = 5 /* fused QKV projection: see st355_qk_rope */,
+       ST355_EPI_GEGLU = 6, ST355_EPI_GEGLU_GRAD = 7 /* the UNet feed-forward's GEGLU inside its two GEMMs: see below */ };
+/* ST355_EPI_GEGLU / ST355_EPI_GEGLU_GRAD — diffusers FeedForward(activation_fn="geglu") of the UNet's BasicTransformerBlock (proj -> [value | gate],
+ * out = value * gelu(gate), exact erf GELU) without its two streaming passes (st355_geglu_fwd / _bwd).  The projection weight rows (and bias) are given in the
+ * INTERLEAVED order  c' = 64 * (j / 32) + j % 32  for value feature j and  c' + 32  for gate feature j  (j in [0, F), N = 2F a multiple of 64), so that a wave's
+ * 64-column accumulator tile holds 32 values and the 32 gates of the SAME features register for register:
+ *   EPI_GEGLU       (the ff.net.0.proj GEMM, N = 2F):  aux_out[M, 2F] = the pre-activation in interleaved column order (kept for the backward), C[M, F] (ldc >= F) =
+ *                   value * gelu(gate) in natural feature order; both halves rounded to bf16 before the activation, as the unfused pass reads them.
+ *   EPI_GEGLU_GRAD  (the ff.net.2 dgrad GEMM, N = F: acc = d out):  aux_in = that pre-activation [M, 2F]; C[M, 2F] (ldc >= 2F) = the projection-output gradient in
+ *                   the same interleaved order: d value = d out * gelu(gate), d gate = d out * value * gelu'(gate).
+ * The next dgrad GEMM contracts C against the interleaved weights' K-major copy, so no un-permutation exists anywhere (frozen feed-forward weights: LoRA runs).
+ * 256x256 schedule only; N % 64 == 0, 16-byte aligned rows. */
 /* ST355_EPI_QK_NORM_ROPE — the attention input projection with its RMSNorm(q), RMSNorm(k) and RoPE fused into the GEMM epilogue
  * (FluxAttnProcessor2_0: flux/transformer.py:140-207; replaces the separate st355_qk_norm_rope_fwd pass).  The problem is x[M,K] @ Wqkv[3D,K]^T
  * (+ bias, + LoRA extension), D = H*128.  Output columns [0,D) / [D,2D): q / k heads -> per-head RMSNorm (wq / wk, NULL = none), rotation of the

@@ -46,6 +46,11 @@ __device__ __forceinline__ float sigmoid2u(float x, float x2) {
   const float e = __builtin_amdgcn_exp2f(-x * (c0 + c1 * x2));        // exp(-2u); inf for very negative x -> rcp(inf) = 0
   return __builtin_amdgcn_rcpf(1.f + e);
 }
+// exact (erf) GELU of the UNet's GEGLU feed-forward (F.gelu default) and its derivative
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.39894228040143268f * __expf(-0.5f * g * g);
+}
 #ifdef ST355_GELU_TEXTBOOK      // lab / A-B builds only: the IEEE-division form this replaced
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;

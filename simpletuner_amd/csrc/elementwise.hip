@@ -432,10 +432,6 @@ extern "C" int st355_scale_cols(void* stream, const void* in, int64_t ld_in, con
 
 // ---- GEGLU (diffusers FeedForward activation_fn="geglu" inside the UNet's BasicTransformerBlock): proj -> [value | gate], out = value * gelu(gate),
 // gelu = the exact erf form (F.gelu default).  h: [M, 2F] row stride ldh; out: [M, F].  Backward writes dh = [dout*gelu(gate) | dout*value*gelu'(gate)].
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float g) {
-  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.39894228040143268f * __expf(-0.5f * g * g);
-}
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_geglu(const bf16* __restrict__ h, int64_t ldh, const bf16* __restrict__ dout, bf16* __restrict__ out, int64_t ldo, int64_t M,
                                               int F) {

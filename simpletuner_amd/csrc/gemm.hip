@@ -493,6 +493,123 @@ __device__ __forceinline__ void gemm_epilogue_vdual(const GemmP& p, bf16* C, f32
   }
 }
 
+// ---- ST355_EPI_GEGLU / ST355_EPI_GEGLU_GRAD (256x256 schedule): the UNet feed-forward's value * gelu(gate) inside the two GEMMs around it (st355.h) ----
+// Same wave-private fp32 transpose as gemm_epilogue_lds (two 64-token passes; read side: 8 lanes per token row, 8 features each).  With the interleaved weight
+// rows a wave's 64 columns are [32 values | the 32 gates of the same features]: lanes rc < 4 read their 8 values AND the 8 gates 32 columns further from the
+// staging row, no cross-wave exchange.  Forward: every lane stores its 8 pre-activations (the backward's operand, interleaved order), lanes rc < 4 the 8 outputs.
+__device__ __forceinline__ void gemm_epilogue_geglu(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const int n = nw0 + rc * 8;                                  // interleaved column of this lane's 8 pre-activations
+  const bool n_ok = n < p.N;
+  float bias8[8], biasg[8];
+#pragma unroll
+  for (int b = 0; b < 8; b++) { bias8[b] = 0.f; biasg[b] = 0.f; }
+  if (p.bias && n_ok) {
+    const bf16x8 bv = *(const bf16x8*)(p.bias + n);
+#pragma unroll
+    for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
+    if (rc < 4) {
+      const bf16x8 gv = *(const bf16x8*)(p.bias + n + 32);
+#pragma unroll
+      for (int b = 0; b < 8; b++) biasg[b] = bf2f(gv[b]);
+    }
+  }
+  const int jf = (nw0 >> 1) + (rc & 3) * 8;                    // output feature of lanes rc < 4: 32 * (nw0 / 64) + 8 rc
+  const int m_first = mw0 + rrow;
+  bf16* c_row = p.C + (int64_t)m_first * p.ldc + jf;
+  bf16* out_row = p.aux_out + (int64_t)m_first * p.ld_aux_out + n;
+  const int64_t c_step = 8 * p.ldc, out_step = 8 * p.ld_aux_out;
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      bf16* const c_ptr = c_row;
+      bf16* const out_ptr = out_row;
+      c_row += c_step; out_row += out_step;
+      if (m >= p.M || !n_ok) continue;
+      bf16x8 pre;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { pre[b] = f2bf(lo[b] + bias8[b]); pre[4 + b] = f2bf(hi[b] + bias8[4 + b]); }
+      *(bf16x8*)out_ptr = pre;
+      if (rc < 4) {
+        const f32x4 glo = *(const f32x4*)(stage + row * EPL_PITCH + (rc + 4) * 32);
+        const f32x4 ghi = *(const f32x4*)(stage + row * EPL_PITCH + (rc + 4) * 32 + 16);
+        bf16x8 o;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          o[b] = f2bf(bf2f(pre[b]) * gelu_erf(bf2f(f2bf(glo[b] + biasg[b]))));            // both halves rounded to bf16 first, as st355_geglu_fwd reads them
+          o[4 + b] = f2bf(bf2f(pre[4 + b]) * gelu_erf(bf2f(f2bf(ghi[b] + biasg[4 + b]))));
+        }
+        *(bf16x8*)c_ptr = o;
+      }
+    }
+  }
+}
+// backward: acc = d out for the wave's 64 features j (two interleave groups of 32): lane (row, rc) owns features 8 rc .. 8 rc + 7, i.e. group rc >> 2, offset
+// 8 (rc & 3): it reads value / gate of those features from the kept pre-activation (columns 64 G + off and + 32) and writes d value / d gate to the same columns of C
+__device__ __forceinline__ void gemm_epilogue_geglu_grad(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const bool n_ok = nw0 + rc * 8 < p.N;
+  const int col = 2 * nw0 + 64 * (rc >> 2) + (rc & 3) * 8;     // 64 * (nw0 / 32 + (rc >> 2)) + 8 (rc & 3)
+  const int m_first = mw0 + rrow;
+  bf16* c_row = p.C + (int64_t)m_first * p.ldc + col;
+  const bf16* in_row = p.aux_in + (int64_t)m_first * p.ld_aux_in + col;
+  const int64_t c_step = 8 * p.ldc, in_step = 8 * p.ld_aux_in;
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      bf16* const c_ptr = c_row;
+      const bf16* const in_ptr = in_row;
+      c_row += c_step; in_row += in_step;
+      if (m >= p.M || !n_ok) continue;
+      const bf16x8 vv = *(const bf16x8*)in_ptr, gv = *(const bf16x8*)(in_ptr + 32);
+      bf16x8 dv, dg;
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const float d = bf2f(f2bf(b < 4 ? lo[b] : hi[b - 4]));                           // d out rounded to bf16, as the unfused pair (GEMM store, st355_geglu_bwd read)
+        const float g = bf2f(gv[b]);
+        dv[b] = f2bf(d * gelu_erf(g));
+        dg[b] = f2bf(d * bf2f(vv[b]) * gelu_erf_grad(g));
+      }
+      *(bf16x8*)c_ptr = dv;
+      *(bf16x8*)(c_ptr + 32) = dg;
+    }
+  }
+}
+
 // the coalesced path needs 16-byte alignment of every row it touches with bf16x8 accesses
 __device__ __forceinline__ bool epl_aligned(const GemmP& p) {
   bool ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
@@ -1007,6 +1124,10 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
     ps.conv_taps = 0;
     gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (EPI == ST355_EPI_GEGLU) {
+    gemm_epilogue_geglu(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (EPI == ST355_EPI_GEGLU_GRAD) {
+    gemm_epilogue_geglu_grad(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   } else if (EPI == ST355_EPI_QK_NORM_ROPE) {
     if (n0 >= 2 * p.rH * 128) {            // v heads: rows of the V buffer (column n - 2D) in this tile's segment (+ the head-major V^T)
       gemm_epilogue_vdual(p, p.C + segi * p.seg_xc, acc, m0, n0, wm, wn, wv, lane, smem);
@@ -1511,7 +1632,16 @@ static int validate(const st355_gemm_args* a) {
     ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad/add epilogue needs aux_in");
   if ((a->epilogue == ST355_EPI_GELU || a->epilogue == ST355_EPI_GATE_RESIDUAL) && a->aux_out)
     ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
-  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_QK_NORM_ROPE, "gemm: unknown epilogue %d", a->epilogue);
+  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_GEGLU_GRAD, "gemm: unknown epilogue %d", a->epilogue);
+  if (a->epilogue == ST355_EPI_GEGLU || a->epilogue == ST355_EPI_GEGLU_GRAD) {
+    const bool fwd = a->epilogue == ST355_EPI_GEGLU;
+    ST_REQUIRE(a->N % 64 == 0 && a->K2 == 0 && !a->seg_rows && !a->gate, "gemm: the GEGLU epilogues take a plain problem with N %% 64 == 0 (N=%d)", a->N);
+    ST_REQUIRE(a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0) && a->ldc >= (fwd ? a->N / 2 : 2 * a->N), "gemm: GEGLU C rows: 16-byte aligned, ldc >= %s", fwd ? "N / 2" : "2 N");
+    if (fwd) ST_REQUIRE(a->aux_out && a->ld_aux_out % 8 == 0 && a->ld_aux_out >= a->N && ((uintptr_t)a->aux_out % 16 == 0) && (!a->bias || (uintptr_t)a->bias % 16 == 0),
+                        "gemm: EPI_GEGLU keeps the interleaved pre-activation in aux_out [M, N] (16-byte aligned rows)");
+    else ST_REQUIRE(a->aux_in && a->ld_aux_in % 8 == 0 && a->ld_aux_in >= 2 * a->N && ((uintptr_t)a->aux_in % 16 == 0) && !a->bias,
+                    "gemm: EPI_GEGLU_GRAD reads the interleaved pre-activation from aux_in [M, 2 N] (16-byte aligned rows); no bias");
+  }
   if (a->epilogue == ST355_EPI_QK_NORM_ROPE) {
     const st355_qk_rope* r = a->rope;
     ST_REQUIRE(r && r->Q && r->K && r->rrms && r->cos && r->sin, "gemm: EPI_QK_NORM_ROPE needs args->rope with Q, K, rrms, cos, sin");
@@ -1686,6 +1816,127 @@ static int launch_256(void* stream, const GemmGroup& g, int tiles) {
     default: return fn<ST355_EPI_ADD>(__VA_ARGS__);                                          \
   }
 
+// =================================================================================================
+// k_gemm_thin: C[M, N <= 128] = A[M, K] B[N, K]^T for the rank-space projections of the LoRA path (x A^T, dY (sB)): N = 64 / 128 output columns, K in the
+// thousands, M = every token of the batch.  The problem is ONE streaming pass over A (42 MB at the SDXL 32^2 level) — HBM-bound, no reuse worth a ring: round 5 ran
+// it as split-K 128x128 tiles + a slab reduce (15.8 + 5.4 us per launch against ~9 us of A traffic; 620 launches per SDXL-LoRA step, rocprofv3 r06).
+// Here a workgroup owns 64 rows; its four waves split the K-tiles (wave w takes tiles w, w + 4, ...), each with the whole 64 x N accumulator; operands go straight
+// from global memory to MFMA fragments (no LDS staging: nothing is reused inside a wave beyond the two row fragments per weight fragment).  A lane owns 64
+// contiguous BYTES of its row per K-tile (k-half = lane >> 5): both operands use the same lane -> k mapping, so any order that covers the tile once is a correct
+// contraction.  Next tile's loads are issued before the current tile's MFMAs.  The four partial accumulators meet in LDS (fixed order), one bf16 store.
+// =================================================================================================
+template <int NT, bool PREF>          // NT = N / 32 column tiles (2 or 4); PREF: next tile's fragments requested before this tile's MFMAs (N = 64; N = 128 keeps one
+                                      // fragment set — its 128 accumulators leave no room for two — and hides the latency with two waves per SIMD instead)
+__global__ void __launch_bounds__(256) k_gemm_thin(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                  int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;                                     // [4 waves][64 rows][N] fp32
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int m0 = blockIdx.x * 64;
+  const int nkt = K / 64;
+  const bf16* arow[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) arow[j] = A + (int64_t)min(m0 + 32 * j + l31, M - 1) * lda + khalf * 32;
+  const bf16* brow[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++) brow[i] = B + (int64_t)min(32 * i + l31, N - 1) * ldb + khalf * 32;
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  bf16x8 xa[2][4], wa[NT][4], xb[2][4], wb[NT][4];
+  auto load = [&](int t, bf16x8 (&x)[2][4], bf16x8 (&w)[NT][4]) {
+    const int k0 = t * 64;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) x[j][q] = *(const bf16x8*)(arow[j] + k0 + 8 * q);
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) w[i][q] = *(const bf16x8*)(brow[i] + k0 + 8 * q);
+  };
+  auto mma = [&](bf16x8 (&x)[2][4], bf16x8 (&w)[NT][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i][q], x[j][q], acc[i][j], 0, 0, 0);
+  };
+  int t = wv;
+  if (PREF) {
+    if (t < nkt) load(t, xa, wa);
+    while (t < nkt) {
+      if (t + 4 < nkt) load(t + 4, xb, wb);
+      mma(xa, wa);
+      t += 4;
+      if (t >= nkt) break;
+      if (t + 4 < nkt) load(t + 4, xa, wa);
+      mma(xb, wb);
+      t += 4;
+    }
+  } else {
+    for (; t < nkt; t += 4) { load(t, xa, wa); mma(xa, wa); }
+  }
+  // partials -> LDS: acc[i][j][4a + b] = D[feature 32 i + 8 a + 4 khalf + b][token 32 j + l31]
+  float* mine = red + (size_t)wv * 64 * N;
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        f32x4 v;
+#pragma unroll
+        for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
+        *(f32x4*)(mine + (size_t)(32 * j + l31) * N + 32 * i + 8 * a + 4 * khalf) = v;
+      }
+  __syncthreads();
+  const int n8 = N / 8;
+  for (int idx = threadIdx.x; idx < 64 * n8; idx += 256) {
+    const int row = idx / n8, c = (idx % n8) * 8;
+    if (m0 + row >= M) continue;
+    float v[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const f32x4 lo = *(const f32x4*)(red + ((size_t)w * 64 + row) * N + c), hi = *(const f32x4*)(red + ((size_t)w * 64 + row) * N + c + 4);
+#pragma unroll
+      for (int b = 0; b < 4; b++) { v[b] += lo[b]; v[4 + b] += hi[b]; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int b = 0; b < 8; b++) o[b] = f2bf(v[b]);
+    *(bf16x8*)(C + (int64_t)(m0 + row) * ldc + c) = o;
+  }
+}
+static bool thin_ok(const st355_gemm_args* a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ST355_GEMM_THIN"); on = (e && e[0] == '0') ? 0 : 1; }          // A/B: 0 = the split-K tile path
+  return on && (a->N == 64 || a->N == 128) && a->K2 == 0 && a->epilogue == ST355_EPI_NONE && !a->bias && !a->seg_rows && a->K >= 256 && a->M >= 1024 &&
+         a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0);
+}
+static int launch_thin(void* stream, const st355_gemm_args* a) {
+  const int lds = 4 * 64 * a->N * 4;
+  const dim3 grid((a->M + 63) / 64), block(256);
+  if (a->N == 64) {
+    static St355AttrOnce set;
+    if (set.need()) { hipFuncSetAttribute((const void*)k_gemm_thin<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+    hipLaunchKernelGGL((k_gemm_thin<2, true>), grid, block, lds, (hipStream_t)stream, (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, (bf16*)a->C, a->ldc, a->M, a->N, a->K);
+  } else {
+    static St355AttrOnce set;
+    if (set.need()) { hipFuncSetAttribute((const void*)k_gemm_thin<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+    hipLaunchKernelGGL((k_gemm_thin<4, false>), grid, block, lds, (hipStream_t)stream, (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, (bf16*)a->C, a->ldc, a->M, a->N, a->K);
+  }
+  return st355_check_launch("gemm_thin");
+}
+
 static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int ksplit) {
   static St355AttrOnce attr_set;
   if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_s2<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); }
@@ -1701,6 +1952,7 @@ static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int k
 }
 
 static int run_one(void* stream, const st355_gemm_args* a) {
+  if (thin_ok(a)) return launch_thin(stream, a);
   GemmP p = to_p(a);
   // thin problems (the LoRA rank-space projections: N <= 128, K in the thousands) stream A once and have only M/128 tiles: split
   // K so that >= 2 workgroups per CU are in flight, partial sums through the caller's fp32 workspace (fixed-order reduce)
@@ -1723,6 +1975,11 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
     return launch_pq<ST355_EPI_QK_NORM_ROPE>(stream, g, g.tiles0);
+  }
+  if (a->epilogue == ST355_EPI_GEGLU || a->epilogue == ST355_EPI_GEGLU_GRAD) {      // likewise the GEGLU pair
+    GemmGroup g;
+    g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    return a->epilogue == ST355_EPI_GEGLU ? launch_pq<ST355_EPI_GEGLU>(stream, g, g.tiles0) : launch_pq<ST355_EPI_GEGLU_GRAD>(stream, g, g.tiles0);
   }
   if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256()) {
     GemmGroup g;

@@ -41,7 +41,7 @@ KERNEL_CLASSES = [
     "ln_mod", "qk_rope", "skinny", "elementwise", "optim",
 ]
 
-EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_QK_NORM_ROPE = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_QK_NORM_ROPE, EPI_GEGLU, EPI_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class St355Unavailable(RuntimeError):

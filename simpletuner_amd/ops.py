@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import lib as _l
-from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE, GemmArgs, QkRope  # noqa: F401
+from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE, GemmArgs, QkRope  # noqa: F401
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -329,11 +329,13 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
         g.rope = C.pointer(rope)
         g._rope_keep = rope
         g.rows_per_batch = rows_per_batch
-    elif out is None:
-        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    # output width: N, except the fused-QKV form (the V third), EPI_GEGLU (value * gelu(gate): N / 2) and EPI_GEGLU_GRAD (d value | d gate interleaved: 2 N)
+    n_out = N // 3 if epilogue == EPI_QK_NORM_ROPE else N // 2 if epilogue == EPI_GEGLU else 2 * N if epilogue == EPI_GEGLU_GRAD else N
+    if epilogue != EPI_QK_NORM_ROPE and out is None:
+        out = torch.empty(M, n_out, dtype=BF16, device=a.device)
     Mo, No, g.ldc, sr, g.seg_c = _seg(out, "out")
-    if (Mo, No) != (M, N if epilogue != EPI_QK_NORM_ROPE else N // 3):
-        raise _l.St355Error(f"gemm: out is {Mo}x{No}, expected {M}x{N if epilogue != EPI_QK_NORM_ROPE else N // 3}")
+    if (Mo, No) != (M, n_out):
+        raise _l.St355Error(f"gemm: out is {Mo}x{No}, expected {M}x{n_out}")
     seg = _seg_join(seg, sr, "gemm")
     g.A, g.B, g.ldb, g.C = _ptr(a), _ptr(w), _rows(w, "w"), _ptr(out)
     g.M, g.N, g.K, g.K2 = M, N, K, 0
@@ -393,6 +395,18 @@ def sum_chunks_bf16(chunks, world: int, out):
         raise _l.St355Error(f"sum_chunks_bf16: chunks holds {chunks.numel()} elements, expected world * n = {world * n}")
     _l.check(L.st355_sum_chunks_bf16(_stream(), _ptr(chunks), int(world), int(n), _ptr(out)), "sum_chunks_bf16")
     return out
+
+
+def geglu_interleave(w, bias=None):
+    """the feed-forward projection's rows (nn.Linear.weight [2F, K] = [value rows | gate rows]) in the order the EPI_GEGLU / EPI_GEGLU_GRAD epilogues contract
+    them: every 64 rows = 32 value features followed by the 32 gate features of the SAME indices (st355.h).  Returns (w_il, bias_il); built once for frozen weights."""
+    N2, K = w.shape
+    F_ = N2 // 2
+    if N2 % 64 or F_ % 32:
+        raise _l.St355Error(f"geglu_interleave: 2F = {N2} must be a multiple of 64")
+    wi = torch.stack([w[:F_].view(F_ // 32, 32, K), w[F_:].view(F_ // 32, 32, K)], dim=1).reshape(N2, K).contiguous()
+    bi = None if bias is None else torch.stack([bias[:F_].view(F_ // 32, 32), bias[F_:].view(F_ // 32, 32)], dim=1).reshape(N2).contiguous()
+    return wi, bi
 
 
 def gemm_set_persistent(mode: int) -> int:
@@ -1359,7 +1373,11 @@ def head_split(src, B: int, H: int, d: int, S: int, want_x: bool = True, want_xt
     _chk(src, BF16, "src")
     Sp = (S + 63) // 64 * 64
     X = torch.empty(B, H, S, d, dtype=BF16, device=src.device) if want_x else None
-    Xt = torch.zeros(B, H, d, Sp, dtype=BF16, device=src.device) if want_xt else None
+    Xt = None
+    if want_xt:                               # only the pad columns [S, Sp) need zeros: the kernel writes every column < S (a full-size fill per attention before r6)
+        Xt = torch.empty(B, H, d, Sp, dtype=BF16, device=src.device)
+        if Sp > S:
+            Xt[..., S:].zero_()
     _l.check(L.st355_head_split_pad(_stream(), _ptr(src), _rows(src, "src"), _ptr(X), _ptr(Xt), B, H, d if d_src is None else d_src, d, S, Sp), "head_split")
     return X, Xt, Sp
 

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..flux.transformer import LoraGroup, _attach, _frozen
-from ..ops import EPI_ADD, EPI_NONE
+from ..ops import EPI_ADD, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_NONE
 from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
@@ -48,18 +48,24 @@ class Tape:
     def __init__(self):
         self.ops: List[tuple] = []
 
-    def rec(self, outs, ins, fn):
-        self.ops.append((outs, ins, fn))
+    def rec(self, outs, ins, fn, acc: Optional[int] = None):
+        """acc = index of an input whose backward closure ADDS INTO the gradient already accumulated on that tensor: `fn(*douts, dres=<that gradient or None>)`
+        returns the sum for it (the LayerNorm backward kernel's residual operand: the sum rides in its own pass instead of a separate ops.add launch —
+        210 adds per SDXL step, 7 ms at batch 16: rocprofv3 r06)"""
+        self.ops.append((outs, ins, fn, acc))
 
     def backward(self, out, dout, wrt=None):
         """sweep the record backwards from d(out) = dout; `wrt`: tensors whose accumulated gradients are returned (a checkpointed unit's inputs)"""
         grads = {id(out): dout}
         while self.ops:
-            outs, ins, fn = self.ops.pop()          # popping frees the closure's saved activations as the sweep proceeds
+            outs, ins, fn, acc = self.ops.pop()     # popping frees the closure's saved activations as the sweep proceeds
             douts = [grads.pop(id(o), None) for o in outs]
             if all(d is None for d in douts):
                 continue
-            dins = fn(*douts)
+            if acc is not None and ins[acc] is not None:
+                dins = fn(*douts, dres=grads.pop(id(ins[acc]), None))
+            else:
+                dins = fn(*douts)
             for i, d in zip(ins, dins):
                 if i is None or d is None:
                     continue
@@ -139,13 +145,14 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
 
     def _lin(self, name, out_f, in_f, bias=True):
         return SimpleNamespace(kind="lin", name=name, w=self._slot(name + ".weight", out_f, in_f), b=self._slot(name + ".bias", out_f, kind="b") if bias else None,
-                               wT=None, N=out_f, K=in_f, lora=None)
+                               wT=None, N=out_f, K=in_f, lora=None, is_geglu_proj=name.endswith("ff.net.0.proj"), w_il=None, b_il=None, wT_il=None)
 
     def _lin_fused(self, prefix, names, out_each, in_f):
         """projections that share an input stored as one matrix; the per-projection diffusers keys are row-slices (registered as views later)"""
         views = [(f"{prefix}{nm}.weight", j * out_each, (j + 1) * out_each) for j, nm in enumerate(names)]
         l = SimpleNamespace(kind="lin", name=prefix + "+".join(names), w=self._slot(prefix + "+".join(names) + ".weight", len(names) * out_each, in_f, views=views),
-                            b=None, wT=None, N=len(names) * out_each, K=in_f, fused=(prefix, names, out_each), lora=None)
+                            b=None, wT=None, N=len(names) * out_each, K=in_f, fused=(prefix, names, out_each), lora=None, is_geglu_proj=False, w_il=None, b_il=None,
+                            wT_il=None)
         return l
 
     def _conv(self, name, cin, cout, taps=9, cout_pad=None, cin_cols=None):
@@ -446,6 +453,8 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
                 l.wT[:, :72].view(l.cin, 9, 8).copy_(l.w.t.view(8, 9, l.cin).flip(1).permute(2, 1, 0))
             else:
                 ops.transpose(l.w.t, out=l.wT)
+        if not self.full:
+            self._prepare_geglu()                       # the interleaved feed-forward copies follow the (frozen) weights
 
     def _ready(self, *slots):
         """gradient slices that are final: hand them to the bucketed all-reduce (overlaps the rest of the backward); adjacent slices merge"""
@@ -535,15 +544,15 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
     def _ln(self, T, nm, h):
         n = ops.layernorm_fwd(h, nm.w.t, nm.b.t, eps=1e-5)
         if T is not None:
-            def bwd(dn):
+            def bwd(dn, dres=None):
                 if self.full:
                     D = h.shape[1]
                     dw, db = self._f32(D), self._f32(D, 1)
                     ops.layernorm_param_grads(dn, h, dw, db.view(D), eps=1e-5)
                     nm.w.g.copy_(dw); nm.b.g.copy_(db.view(D))
                     self._ready(nm.b, nm.w)
-                return (ops.layernorm_bwd(dn, h, nm.w.t, eps=1e-5),)
-            T.rec([n], [h], bwd)
+                return (ops.layernorm_bwd(dn, h, nm.w.t, dres=dres, eps=1e-5),)       # + the gradient the residual stream already carries (Tape.rec acc)
+            T.rec([n], [h], bwd, acc=0)
         return n
 
     def _resnet_fwd(self, T, r, x, se, B, H, W):
@@ -691,6 +700,9 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
             o2 = self._cross_attn(T, q, kv, B, S, Sk, tr.heads)
             h = self._linear(T, blk.out2, o2, residual=h)
             n3 = self._ln(T, blk.norm3, h)
+            if blk.ff1.w_il is not None and n3.shape[0] >= 256:
+                h = self._ffn_geglu_fused(T, blk, n3, h)
+                continue
             f = self._linear(T, blk.ff1, n3)
             g = ops.geglu_fwd(f)
             if T is not None:
@@ -701,6 +713,35 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         if T is not None:
             T.rec([y], [h, x], lambda dy: (ops.grid_to_tokens(dy, B, H, W), dy))
         return y
+
+    def _ffn_geglu_fused(self, T, blk, n3, h):
+        """FeedForward(geglu) of a BasicTransformerBlock with the activation INSIDE its two GEMMs (ST355_EPI_GEGLU / ST355_EPI_GEGLU_GRAD): no [M, 2F] read-back for
+        value * gelu(gate), no separate pass for its backward.  Frozen feed-forward weights only (LoRA runs): the projection rows are contracted in the interleaved
+        order built once by _prepare_geglu; the weight-gradient path of a full fine-tune keeps the unfused form (its gradients must land in checkpoint order)."""
+        l1, l2 = blk.ff1, blk.ff2
+        M = n3.shape[0]
+        f_il = torch.empty(M, l1.N, dtype=BF16, device=n3.device)
+        g = ops.gemm(n3, l1.w_il, bias=l1.b_il, epilogue=EPI_GEGLU, aux_out=f_il)
+        y = ops.gemm(g, l2.w.t, bias=None if l2.b is None else l2.b.t, epilogue=EPI_ADD, aux_in=h)
+        if T is not None:
+            def bwd(dy):
+                df = ops.gemm(dy, l2.wT, epilogue=EPI_GEGLU_GRAD, aux_in=f_il)           # [M, 2F] interleaved: d value | d gate
+                return ops.gemm(df, l1.wT_il), dy
+            T.rec([y], [n3, h], bwd)
+        return y
+
+    def _prepare_geglu(self):
+        """interleaved copies of every frozen feed-forward projection (ops.geglu_interleave) + their K-major transposes for the dgrad; ST355_GEGLU_FUSED=0 keeps
+        the separate st355_geglu_fwd / _bwd passes (A/B switch)"""
+        import os
+        on = os.environ.get("ST355_GEGLU_FUSED", "1") != "0" and not self.full
+        for l in self._all_layers():
+            if l.kind == "lin" and getattr(l, "is_geglu_proj", False):
+                if on and l.lora is None and l.N % 64 == 0:
+                    l.w_il, l.b_il = ops.geglu_interleave(l.w.t, None if l.b is None else l.b.t)
+                    l.wT_il = ops.transpose(l.w_il)
+                else:
+                    l.w_il = l.b_il = l.wT_il = None
 
     # ------------------------------------------------------------------------------------------------
     def _ckpt_unit(self, T, fn, x, cond):

@@ -22,7 +22,7 @@ from types import SimpleNamespace
 
 import torch
 
-from simpletuner_amd.lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE      # the ST355_EPI_* values (st355.h)
+from simpletuner_amd.lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE      # the ST355_EPI_* values (st355.h)
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -188,6 +188,33 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out
         _need(out.numel() == M * (N // 3) and out.shape[-1] == N // 3, f"gemm: the V destination is {tuple(out.shape)}, expected {M}x{N // 3}")
         _need(out.dim() == 2 or out.shape[1] == rows_per_batch, "gemm: EPI_QK_NORM_ROPE segments are the per-sample row blocks (seg_rows == rows_per_batch)")
         return _fused_qkv_epilogue(acc, out, rope, rows_per_batch)
+    if epilogue in (EPI_GEGLU, EPI_GEGLU_GRAD):
+        # the UNet feed-forward's GEGLU inside its two GEMMs (st355.h): interleaved columns — every 64 = [32 values | the 32 gates of the same features]
+        _need(N % 64 == 0 and a2 is None and gate is None and a.dim() == 2, "gemm: the GEGLU epilogues take a plain problem with N % 64 == 0")
+        erf_gelu = lambda t: torch.nn.functional.gelu(t)
+        if epilogue == EPI_GEGLU:
+            _need(aux_out is not None and tuple(aux_out.shape) == (M, N), "gemm: EPI_GEGLU keeps the interleaved pre-activation in aux_out [M, N]")
+            _chk(aux_out, BF16, "aux_out"); _al(aux_out, 16, "aux_out"); _ld(aux_out, 8, "aux_out")
+            pre = acc.to(BF16)
+            aux_out.copy_(pre)
+            pv = pre.float().view(M, N // 64, 2, 32)
+            val = (pv[:, :, 0] * erf_gelu(pv[:, :, 1])).reshape(M, N // 2)
+            if out is None:
+                out = torch.empty(M, N // 2, dtype=BF16, device=a.device)
+            _need(tuple(out.shape) == (M, N // 2), f"gemm: EPI_GEGLU out is {tuple(out.shape)}, expected {M}x{N // 2}")
+        else:
+            _need(bias is None and aux_in is not None and tuple(aux_in.shape) == (M, 2 * N), "gemm: EPI_GEGLU_GRAD reads the interleaved pre-activation from aux_in [M, 2N]; no bias")
+            _chk(aux_in, BF16, "aux_in"); _al(aux_in, 16, "aux_in"); _ld(aux_in, 8, "aux_in")
+            pv = aux_in.float().view(M, N // 32, 2, 32)
+            d = acc.to(BF16).float().view(M, N // 32, 32)
+            gt = pv[:, :, 1].double()
+            dgelu = (0.5 * (1 + torch.erf(gt / math.sqrt(2.0))) + gt * torch.exp(-0.5 * gt * gt) / math.sqrt(2.0 * math.pi)).float()
+            val = torch.stack([d * erf_gelu(pv[:, :, 1]), d * pv[:, :, 0] * dgelu], dim=2).reshape(M, 2 * N)
+            if out is None:
+                out = torch.empty(M, 2 * N, dtype=BF16, device=a.device)
+            _need(tuple(out.shape) == (M, 2 * N), f"gemm: EPI_GEGLU_GRAD out is {tuple(out.shape)}, expected {M}x{2 * N}")
+        _chk(out, BF16, "out"); _al(out, 16, "out"); _ld(out, 8, "out")
+        return _put(out, val)
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     _chk(out, BF16, "out"); _seg(out, "out")

@@ -177,3 +177,56 @@ def test_ema_update_inside_the_adamw_launch_is_bit_equal_to_the_separate_pass(op
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert not torch.equal(out[0][1], s0)
+
+
+@pytest.mark.parametrize("M,K,F", [(4096, 1280, 5120), (1024, 640, 2560), (300, 320, 1280), (16384, 1280, 5120)])
+def test_geglu_inside_the_feed_forward_gemms(ops, M, K, F):
+    """ST355_EPI_GEGLU / ST355_EPI_GEGLU_GRAD on interleaved projection rows (ops.geglu_interleave) against the unfused sequence GEMM -> st355_geglu_fwd and
+    GEMM -> st355_geglu_bwd -> GEMM: the forward output bit-identical (same bf16 pre-activation, same erf GELU), the kept pre-activation = the unfused one with its
+    columns interleaved, the input gradient to bf16 rounding of d out (<= 4e-3 rel-L2: the fused epilogue rounds the same values at the same points; only the last
+    GEMM's contraction ORDER over the 2F columns differs)."""
+    torch.manual_seed(66)
+    d_ = dev()
+    x = torch.randn(M, K, device=d_).to(BF16)
+    w1 = (torch.randn(2 * F, K, device=d_) / math.sqrt(K)).to(BF16); b1 = (torch.randn(2 * F, device=d_) * 0.1).to(BF16)
+    w2 = (torch.randn(K, F, device=d_) / math.sqrt(F)).to(BF16)
+    dy = torch.randn(M, K, device=d_).to(BF16)
+    # unfused
+    f = ops.gemm(x, w1, bias=b1)
+    g0 = ops.geglu_fwd(f)
+    dg = ops.gemm(dy, w2.t().contiguous())                     # d out [M, F] = dy W2   (W2^T as the NT weight operand)
+    df = ops.geglu_bwd(f, dg)
+    dx0 = ops.gemm(df, w1.t().contiguous())
+    # fused
+    w_il, b_il = ops.geglu_interleave(w1, b1)
+    f_il = torch.empty(M, 2 * F, device=d_, dtype=BF16)
+    g1 = ops.gemm(x, w_il, bias=b_il, epilogue=ops.EPI_GEGLU, aux_out=f_il)
+    perm = torch.stack([torch.arange(F).view(F // 32, 32), F + torch.arange(F).view(F // 32, 32)], dim=1).reshape(-1).to(d_)
+    df_il = ops.gemm(dy, w2.t().contiguous(), epilogue=ops.EPI_GEGLU_GRAD, aux_in=f_il)
+    if M >= 1024:             # both forms on the 256x256 schedule: the same accumulators
+        assert torch.equal(g1, g0) and torch.equal(f_il, f[:, perm]) and torch.equal(df_il, df[:, perm])
+    else:                     # (a small problem's unfused GEMMs run on the 128x128 schedule: same formula, another tile walk)
+        assert rel(g1, g0) < 2e-3 and rel(f_il, f[:, perm]) < 2e-3 and rel(df_il, df[:, perm]) < 4e-3
+    dx1 = ops.gemm(df_il, ops.transpose(w_il))
+    assert rel(dx1, dx0) < 4e-3
+    ref = (torch.nn.functional.gelu(f.float()[:, F:]) * f.float()[:, :F])
+    assert rel(g1, ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,K", [(16384, 1280), (65536, 640), (16384, 3840), (1024, 256), (5000, 704)])
+def test_thin_rank_space_gemm(ops, M, K):
+    """k_gemm_thin (N = 64: the LoRA down projections x A^T and dY (sB)): one streaming pass over the activations, against fp32 torch (bf16 output rounding + the
+    fp32 accumulation order of four interleaved K partials: rel-L2 <= 4e-3) and against the tile path it replaces (ST355_GEMM_THIN=0 cannot be toggled in-process:
+    compared through an N = 128 problem whose first 64 output columns are the same products)."""
+    torch.manual_seed(67)
+    d_ = dev()
+    x = torch.randn(M, K, device=d_).to(BF16)
+    w = (torch.randn(128, K, device=d_) / math.sqrt(K)).to(BF16)
+    y = ops.gemm(x, w[:64])
+    ref = x.float() @ w[:64].float().t()
+    assert rel(y, ref) < 4e-3
+    y128 = ops.gemm(x, w)                                   # N = 128: the split-K tile path
+    assert rel(y, y128[:, :64]) < 3e-3
+    wide = torch.zeros(M, 192, device=d_, dtype=BF16)       # a strided destination (a column block of a wider buffer)
+    ops.gemm(x, w[:64], out=wide[:, 64:128])
+    assert torch.equal(wide[:, 64:128], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 128:].abs().max()) == 0
