@@ -46,11 +46,20 @@ __device__ __forceinline__ float sigmoid2u(float x, float x2) {
   const float e = __builtin_amdgcn_exp2f(-x * (c0 + c1 * x2));        // exp(-2u); inf for very negative x -> rcp(inf) = 0
   return __builtin_amdgcn_rcpf(1.f + e);
 }
-// exact (erf) GELU of the UNet's GEGLU feed-forward (F.gelu default) and its derivative
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float g) {
-  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.39894228040143268f * __expf(-0.5f * g * g);
+// exact (erf) GELU of the UNet's GEGLU feed-forward (F.gelu default) and its derivative.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
+// rounding of every consumer) on ONE v_rcp_f32 + ONE v_exp_f32 + 8 plain VALU operations: libm's erff is ~60 instructions, which made the GEGLU passes — and, with
+// the matrix pipe idle behind them, the GEGLU GEMM epilogues — VALU-bound (r6: the fused ff.net.0 epilogue cost 216 us per launch with erff).  e = exp(-g^2 / 2) is
+// shared between erf(g / sqrt 2) and the Gaussian term of the derivative.
+__device__ __forceinline__ void gelu_erf_parts(float g, float& phi, float& gauss) {      // phi = Phi(g) = 0.5 (1 + erf(g / sqrt 2));  gauss = exp(-g^2 / 2)
+  const float ax = fabsf(g) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  gauss = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float half_erfc = 0.5f * poly * gauss;                   // 0.5 erfc(|x|)
+  phi = g >= 0.f ? 1.f - half_erfc : half_erfc;
 }
+__device__ __forceinline__ float gelu_erf(float g) { float phi, e; gelu_erf_parts(g, phi, e); return g * phi; }
+__device__ __forceinline__ float gelu_erf_grad(float g) { float phi, e; gelu_erf_parts(g, phi, e); return fmaf(g * 0.39894228040143268f, e, phi); }
 #ifdef ST355_GELU_TEXTBOOK      // lab / A-B builds only: the IEEE-division form this replaced
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;

@@ -500,22 +500,23 @@ __device__ __forceinline__ void gemm_epilogue_vdual(const GemmP& p, bf16* C, f32
 __device__ __forceinline__ void gemm_epilogue_geglu(const GemmP& p, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
   const int khalf = lane >> 5, l31 = lane & 31;
   const int rrow = lane >> 3, rc = lane & 7;
-  const int n = nw0 + rc * 8;                                  // interleaved column of this lane's 8 pre-activations
+  const int n = nw0 + rc * 8;                                  // interleaved column of the 8 pre-activations this lane stores
   const bool n_ok = n < p.N;
-  float bias8[8], biasg[8];
+  // the activation uses ALL lanes: lane (row, rc) produces outputs 4 rc .. 4 rc + 3 of the wave's 32 features (value at staging column 4 rc, gate at 32 + 4 rc)
+  float bias8[8], biasv[4], biasg[4];
 #pragma unroll
-  for (int b = 0; b < 8; b++) { bias8[b] = 0.f; biasg[b] = 0.f; }
+  for (int b = 0; b < 8; b++) bias8[b] = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; b++) { biasv[b] = 0.f; biasg[b] = 0.f; }
   if (p.bias && n_ok) {
     const bf16x8 bv = *(const bf16x8*)(p.bias + n);
 #pragma unroll
     for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
-    if (rc < 4) {
-      const bf16x8 gv = *(const bf16x8*)(p.bias + n + 32);
+    const bf16x4 vv = *(const bf16x4*)(p.bias + nw0 + 4 * rc), gv = *(const bf16x4*)(p.bias + nw0 + 32 + 4 * rc);
 #pragma unroll
-      for (int b = 0; b < 8; b++) biasg[b] = bf2f(gv[b]);
-    }
+    for (int b = 0; b < 4; b++) { biasv[b] = bf2f(vv[b]); biasg[b] = bf2f(gv[b]); }
   }
-  const int jf = (nw0 >> 1) + (rc & 3) * 8;                    // output feature of lanes rc < 4: 32 * (nw0 / 64) + 8 rc
+  const int jf = (nw0 >> 1) + 4 * rc;                          // first output feature of this lane: 32 * (nw0 / 64) + 4 rc
   const int m_first = mw0 + rrow;
   bf16* c_row = p.C + (int64_t)m_first * p.ldc + jf;
   bf16* out_row = p.aux_out + (int64_t)m_first * p.ld_aux_out + n;
@@ -539,6 +540,8 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmP& p, f32x16 (&acc
       const int m = mw0 + ps * 64 + row;
       const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
       const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      const f32x4 av = *(const f32x4*)(stage + row * EPL_PITCH + rc * 16);               // values 4 rc .. 4 rc + 3
+      const f32x4 ag = *(const f32x4*)(stage + row * EPL_PITCH + 128 + rc * 16);         // their gates (staging column 32 + 4 rc)
       bf16* const c_ptr = c_row;
       bf16* const out_ptr = out_row;
       c_row += c_step; out_row += out_step;
@@ -547,17 +550,11 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmP& p, f32x16 (&acc
 #pragma unroll
       for (int b = 0; b < 4; b++) { pre[b] = f2bf(lo[b] + bias8[b]); pre[4 + b] = f2bf(hi[b] + bias8[4 + b]); }
       *(bf16x8*)out_ptr = pre;
-      if (rc < 4) {
-        const f32x4 glo = *(const f32x4*)(stage + row * EPL_PITCH + (rc + 4) * 32);
-        const f32x4 ghi = *(const f32x4*)(stage + row * EPL_PITCH + (rc + 4) * 32 + 16);
-        bf16x8 o;
+      bf16x4 o;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          o[b] = f2bf(bf2f(pre[b]) * gelu_erf(bf2f(f2bf(glo[b] + biasg[b]))));            // both halves rounded to bf16 first, as st355_geglu_fwd reads them
-          o[4 + b] = f2bf(bf2f(pre[4 + b]) * gelu_erf(bf2f(f2bf(ghi[b] + biasg[4 + b]))));
-        }
-        *(bf16x8*)c_ptr = o;
-      }
+      for (int b = 0; b < 4; b++)                                                       // both halves rounded to bf16 first, as st355_geglu_fwd reads them
+        o[b] = f2bf(bf2f(f2bf(av[b] + biasv[b])) * gelu_erf(bf2f(f2bf(ag[b] + biasg[b]))));
+      *(bf16x4*)c_ptr = o;
     }
   }
 }
@@ -1830,7 +1827,7 @@ template <int NT, bool PREF>          // NT = N / 32 column tiles (2 or 4); PREF
 __global__ void __launch_bounds__(256) k_gemm_thin(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
                                                   int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;                                     // [4 waves][64 rows][N] fp32
+  float* red = (float*)smem;                                     // [2 regions][64 rows][N] fp32
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int m0 = blockIdx.x * 64;
@@ -1883,36 +1880,50 @@ __global__ void __launch_bounds__(256) k_gemm_thin(const bf16* __restrict__ A, i
   } else {
     for (; t < nkt; t += 4) { load(t, xa, wa); mma(xa, wa); }
   }
-  // partials -> LDS: acc[i][j][4a + b] = D[feature 32 i + 8 a + 4 khalf + b][token 32 j + l31]
-  float* mine = red + (size_t)wv * 64 * N;
+  // the four K-partials meet in a fixed order through TWO 64 x N fp32 regions: (0 += 2, 1 += 3), then 0 += 1.  acc[i][j][4a + b] = D[feature 32 i + 8 a + 4 khalf + b][token 32 j + l31]
+  auto put = [&](float* reg) {
 #pragma unroll
-  for (int i = 0; i < NT; i++)
+    for (int i = 0; i < NT; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int a = 0; a < 4; a++) {
-        f32x4 v;
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
 #pragma unroll
-        for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
-        *(f32x4*)(mine + (size_t)(32 * j + l31) * N + 32 * i + 8 * a + 4 * khalf) = v;
-      }
+          for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
+          *(f32x4*)(reg + (size_t)(32 * j + l31) * N + 32 * i + 8 * a + 4 * khalf) = v;
+        }
+  };
+  auto add = [&](const float* reg) {
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const f32x4 v = *(const f32x4*)(reg + (size_t)(32 * j + l31) * N + 32 * i + 8 * a + 4 * khalf);
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc[i][j][4 * a + b] += v[b];
+        }
+  };
+  float* reg0 = red;
+  float* reg1 = red + (size_t)64 * N;
+  if (wv >= 2) put(wv == 2 ? reg0 : reg1);
+  __syncthreads();
+  if (wv < 2) add(wv == 0 ? reg0 : reg1);
+  __syncthreads();
+  if (wv == 1) put(reg0);
+  __syncthreads();
+  if (wv == 0) { add(reg0); put(reg1); }
   __syncthreads();
   const int n8 = N / 8;
   for (int idx = threadIdx.x; idx < 64 * n8; idx += 256) {
     const int row = idx / n8, c = (idx % n8) * 8;
     if (m0 + row >= M) continue;
-    float v[8];
-#pragma unroll
-    for (int b = 0; b < 8; b++) v[b] = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const f32x4 lo = *(const f32x4*)(red + ((size_t)w * 64 + row) * N + c), hi = *(const f32x4*)(red + ((size_t)w * 64 + row) * N + c + 4);
-#pragma unroll
-      for (int b = 0; b < 4; b++) { v[b] += lo[b]; v[4 + b] += hi[b]; }
-    }
+    const f32x4 lo = *(const f32x4*)(reg1 + (size_t)row * N + c), hi = *(const f32x4*)(reg1 + (size_t)row * N + c + 4);
     bf16x8 o;
 #pragma unroll
-    for (int b = 0; b < 8; b++) o[b] = f2bf(v[b]);
+    for (int b = 0; b < 4; b++) { o[b] = f2bf(lo[b]); o[4 + b] = f2bf(hi[b]); }
     *(bf16x8*)(C + (int64_t)(m0 + row) * ldc + c) = o;
   }
 }
@@ -1923,7 +1934,7 @@ static bool thin_ok(const st355_gemm_args* a) {
          a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0);
 }
 static int launch_thin(void* stream, const st355_gemm_args* a) {
-  const int lds = 4 * 64 * a->N * 4;
+  const int lds = 2 * 64 * a->N * 4;
   const dim3 grid((a->M + 63) / 64), block(256);
   if (a->N == 64) {
     static St355AttrOnce set;

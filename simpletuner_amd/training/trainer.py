@@ -341,7 +341,11 @@ class Trainer:
             torch.cuda.synchronize()
             torch.cuda.empty_cache()               # the eager warm-up's cached blocks go back before the capture builds its own pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
+            # one memory pool for every captured shape (mixed aspect buckets: one graph per bucket): the graphs never run concurrently, so the activations of
+            # one capture are the next capture's free blocks — five private ~40 GB pools did not fit next to the model (r5), one shared pool does
+            if getattr(self, "_graph_pool", None) is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=side):      # the SAME stream as the warm-up: the parameters' AccumulateGrad nodes are bound to it
                 loss = self._eager_forward_backward(shallow(static))
             entry = self._graphs[key] = (g, static_inputs, loss.detach(), [p.grad for p in self.params])
         g, st, loss, grads = entry

@@ -107,7 +107,10 @@ def test_self_attention_at_baseline_shapes(ops, name, B, H, S, d, d_valid):
     if d in (64, 96, 128):        # the production path: no Q^T / K^T / dO^T copies (dkv3 + dq<TR>), bit-identical to the copy-reading kernels
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO_rows, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale)
-        assert torch.equal(dQ2, dQ)                                       # (head_dim 128: k_attn_bwd_dq64 where S % 64 == 0 — bit-identical too)
+        if S % 64 == 0:
+            assert torch.equal(dQ2, dQ)                                   # (k_attn_bwd_dq64 is bit-identical to the copy-reading kernel)
+        else:                                                             # ragged key tail: dq64 + the general kernel on the last tile (r6): one extra bf16 rounding of the sum
+            assert _rel(dQ2, dQ) < 3e-3
         if d in (64, 96, 128):    # every head_dim takes k_attn_bwd_dkv4 (statistics folded into the MFMA chains): fp32-summation-order agreement, and the same bound against fp32
             assert _rel(dK2, dK) < 6e-3 and _rel(dqkv2[:, 2 * D:], dqkv[:, 2 * D:]) < 6e-3
             assert _rel(dK2, dk_ref) < 2e-2 and _rel(_rows_to_heads(dqkv2[:, 2 * D:], B, H, S, d), dv_ref) < 2e-2

@@ -830,7 +830,10 @@ def _attn_case(ops, B, H, S, d, bias=False, spike=False, seed=30):
         # tile images that keep the 256-byte row pitch): same math, same summation order per accumulator -> bit-identical to the kernels that read the copies
         dQ2 = torch.zeros_like(dQ); dK2 = torch.zeros_like(dK); dqkv2 = torch.zeros_like(dqkv)
         ops.attn_bwd(q, k, None, None, v_rows, O, dO, lse2, dQ2, dK2, dqkv2[:, 2 * D:], B, H, S, Sp, d, scale, key_bias=kb)
-        assert torch.equal(dQ2, dQ)                                       # (k_attn_bwd_dq64, where it applies, is bit-identical as well)
+        if S % 64 == 0 or kb is not None:
+            assert torch.equal(dQ2, dQ)                                   # (k_attn_bwd_dq64, where it applies, is bit-identical as well)
+        else:                                                             # ragged key tail: dq64 + the general kernel on the last tile (r6): one extra bf16 rounding of the sum
+            assert report("dq64 + tail vs dq", dQ2, dQ)[0] < 3e-3
         if kb is None:
             # every head_dim without a key bias takes the hand-scheduled k_attn_bwd_dkv4 (same scores; the statistics ride in the MFMA chains: another
             # summation order): fp32-rounding agreement; dkv3 itself stays bit-identical to the copy-reading kernel

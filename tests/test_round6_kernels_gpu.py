@@ -216,8 +216,8 @@ def test_geglu_inside_the_feed_forward_gemms(ops, M, K, F):
 @pytest.mark.parametrize("M,K", [(16384, 1280), (65536, 640), (16384, 3840), (1024, 256), (5000, 704)])
 def test_thin_rank_space_gemm(ops, M, K):
     """k_gemm_thin (N = 64: the LoRA down projections x A^T and dY (sB)): one streaming pass over the activations, against fp32 torch (bf16 output rounding + the
-    fp32 accumulation order of four interleaved K partials: rel-L2 <= 4e-3) and against the tile path it replaces (ST355_GEMM_THIN=0 cannot be toggled in-process:
-    compared through an N = 128 problem whose first 64 output columns are the same products)."""
+    fp32 accumulation order of four interleaved K partials: rel-L2 <= 4e-3), its N = 128 form, and the tile path through an N = 256 problem whose first columns are
+    the same products."""
     torch.manual_seed(67)
     d_ = dev()
     x = torch.randn(M, K, device=d_).to(BF16)
@@ -225,8 +225,11 @@ def test_thin_rank_space_gemm(ops, M, K):
     y = ops.gemm(x, w[:64])
     ref = x.float() @ w[:64].float().t()
     assert rel(y, ref) < 4e-3
-    y128 = ops.gemm(x, w)                                   # N = 128: the split-K tile path
+    y128 = ops.gemm(x, w)                                   # N = 128: the single-buffer form of the same kernel (another accumulation order)
+    assert rel(y128, x.float() @ w.float().t()) < 4e-3
     assert rel(y, y128[:, :64]) < 3e-3
+    y256 = ops.gemm(x, torch.cat([w, w], 0))                # N = 256: the tile path
+    assert rel(y128, y256[:, :128]) < 3e-3
     wide = torch.zeros(M, 192, device=d_, dtype=BF16)       # a strided destination (a column block of a wider buffer)
     ops.gemm(x, w[:64], out=wide[:, 64:128])
     assert torch.equal(wide[:, 64:128], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 128:].abs().max()) == 0

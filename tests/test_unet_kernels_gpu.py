@@ -206,7 +206,10 @@ def test_cross_attention_fwd_bwd_vs_torch(B, H, Sq, Sk):
     ops.attn_cross_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale)
     # dQ: bit-identical (k_attn_bwd_dq64<64> where Sk % 64 == 0, else the 32-row kernel).  dK / dV without copies and without a key bias run k_attn_bwd_dkv4<64>
     # (r4: statistics folded into the MFMA chains — another fp32 summation order); the 32-key kernel it replaces stays bit-identical to the copy-reading one
-    assert torch.equal(dQ2, dQ)
+    if Sk % 64 == 0 or Sk < 64:
+        assert torch.equal(dQ2, dQ)
+    else:                     # ragged key tail: dq64 + the general kernel on the last tile (r6): one extra bf16 rounding of the sum
+        assert _rel(dQ2, dQ) < 3e-3
     assert _rel(dK2, dK) < 2e-3 and _rel(dkv2[:, Cm:], dkv[:, Cm:]) < 2e-3
     prev = ops.attn_set_impl(dkv=3)
     try:
@@ -269,7 +272,10 @@ def test_attention_head_dim_96_padded_72(B, H, Sq, Sk, cross):
         ops.attn_cross_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, Sk, Skp, d, scale, key_bias=kb)
     else:
         ops.attn_bwd(Q, K, None, None, kv[:, Cm:], O, dO, lse, dQ2, dK2, dkv2[:, Cm:], B, H, Sq, Sqp, d, scale)
-    assert torch.equal(dQ2, dQ)                                                                            # no-copies form: bit-identical
+    if Sk % 64 == 0 or Sk < 64 or kb is not None:
+        assert torch.equal(dQ2, dQ)                                                                        # no-copies form: bit-identical
+    else:                     # ragged key tail: dq64 + the general kernel on the last tile (r6): one extra bf16 rounding of the sum
+        assert _rel(dQ2, dQ) < 3e-3
     if cross:
         assert torch.equal(dK2, dK) and torch.equal(dkv2[:, Cm:], dkv[:, Cm:])
     else:
