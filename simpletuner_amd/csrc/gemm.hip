@@ -1992,7 +1992,12 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
     return a->epilogue == ST355_EPI_GEGLU ? launch_pq<ST355_EPI_GEGLU>(stream, g, g.tiles0) : launch_pq<ST355_EPI_GEGLU_GRAD>(stream, g, g.tiles0);
   }
-  if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256()) {
+  // tile quantisation (r6 experiment knob ST355_GEMM_P3_WINDOW=lo,hi): a problem whose 256x256 tiles leave the chip's last round mostly empty — 320 tiles on
+  // 256 CUs: two rounds for 1.25 rounds of work, the N = 1280 projections of the SDXL 32^2 level at batch 16 — may run better as 256x128 tiles (2.5 rounds of half the size)
+  static int p3_lo = -1, p3_hi = -1;
+  if (p3_lo < 0) { const char* e = getenv("ST355_GEMM_P3_WINDOW"); p3_lo = 0; p3_hi = 0; if (e) sscanf(e, "%d,%d", &p3_lo, &p3_hi); }
+  const bool p3_window = p3_hi > 0 && p4_tiles(p) >= p3_lo && p4_tiles(p) < p3_hi;
+  if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256() && !p3_window) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
     DISPATCH_EPI(launch_256, a->epilogue, stream, g, g.tiles0);

@@ -11,14 +11,16 @@
 
 #define SK_PT 128   // columns of L per workgroup
 #define SK_MC 256   // smallest split-M chunk: rows of L per workgroup (the launch picks 256 / 512 / 1024, see skinny_chunk)
-#define SK_MS 32    // rows per LDS sub-tile
+#define SK_MS 64    // rows per LDS sub-tile of the MFMA kernel (r6: 32 -> 64: half as many load -> LDS -> MFMA round trips per workgroup, twice the bytes in flight:
+                    // the kernel was latency-bound per sub-tile — 2.7 TB/s at the SDXL 32^2 level, rocprofv3 r06)
+#define SK_MS1 32   // ... of the first-generation fp32-VALU kernel (A/B only)
 
 template <int RN>
 __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, int64_t ldl, const bf16* __restrict__ R, int64_t ldr,
                                                   float* __restrict__ ws, int64_t M, int64_t P, int64_t seg_rows, int64_t seg_xl, int64_t seg_xr, int mc) {
   constexpr int RT = RN / 16;
-  __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS][SK_PT];
-  __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS][RN];
+  __shared__ __attribute__((aligned(16))) bf16 Ls[SK_MS1][SK_PT];
+  __shared__ __attribute__((aligned(16))) bf16 Rs[SK_MS1][RN];
   const int tid = threadIdx.x;
   const int pg = tid & 15, rg = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * SK_PT;
@@ -34,7 +36,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
 #pragma unroll
     for (int j = 0; j < RT; j++) acc[i][j] = 0.f;
 
-  for (int ms = 0; ms < mc; ms += SK_MS) {
+  for (int ms = 0; ms < mc; ms += SK_MS1) {
     // stage L sub-tile: 32 x 128 -> 512 chunks of 16 B
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
       }
       *(bf16x8*)(&Ls[row][c * 8]) = v;
     }
-    if (tid < SK_MS * RN / 8) {
+    if (tid < SK_MS1 * RN / 8) {
       const int row = tid / (RN / 8), c = tid % (RN / 8);
       const int64_t m = mbase + ms + row;
       bf16x8 v;
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn(const bf16* __restrict__ L, i
     }
     __syncthreads();
 #pragma unroll 4
-    for (int m = 0; m < SK_MS; m++) {
+    for (int m = 0; m < SK_MS1; m++) {
       bf16x8 lv = *(const bf16x8*)(&Ls[m][pg * 8]);
       float rv[RT];
 #pragma unroll
@@ -117,10 +119,11 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
   const int b_col = 16 * (g & 1) + 4 * tsg;                              // + 32*j
 
   constexpr int RCH = (SK_MS * RN / 8 + 255) / 256;      // 16-byte R chunks per thread (1; 2 for RN = 128)
-  bf16x8 lreg[2], rreg[RCH];
+  constexpr int LCH = SK_MS / 16;                        // 16-byte L chunks per thread (SK_MS rows x 16 chunks over 256 threads)
+  bf16x8 lreg[LCH], rreg[RCH];
   auto load = [&](int ms) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < LCH; k++) {
       const int id = k * 256 + tid;
       const int row = id >> 4, c = id & 15;
       const int64_t m = mbase + ms + row;
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(256) k_skinny_tn_mfma(const bf16* __restrict__
   };
   auto store = [&]() {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < LCH; k++) {
       const int id = k * 256 + tid;
       *(bf16x8*)(&Ls[(id >> 4) * SK_LP + (id & 15) * 8]) = lreg[k];
     }
