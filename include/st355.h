@@ -111,7 +111,21 @@ int st355_scale_cols(void* stream, const void* in, int64_t ld_in, const void* ga
 /* ---- GEMM family (K4,K8,K9,K11,K12): C[M,N] = A[M,K] B[N,K]^T (+ A2[M,K2] B2[N,K2]^T) ---------- */
 enum { ST355_EPI_NONE = 0, ST355_EPI_GELU = 1, ST355_EPI_GATE_RESIDUAL = 2, ST355_EPI_MUL_GELU_GRAD = 3, ST355_EPI_ADD = 4 /* C = acc + aux_in */,
        ST355_EPI_QK_NORM_ROPE = 5 /* fused QKV projection: see st355_qk_rope */,
-       ST355_EPI_GEGLU = 6, ST355_EPI_GEGLU_GRAD = 7 /* the UNet feed-forward's GEGLU inside its two GEMMs: see below */ };
+       ST355_EPI_GEGLU = 6, ST355_EPI_GEGLU_GRAD = 7 /* the UNet feed-forward's GEGLU inside its two GEMMs: see below */,
+       ST355_EPI_HEADS = 8 /* attention input projection of 64-wide heads written head-major: see st355_heads */ };
+/* ST355_EPI_HEADS — the attention input projection of a head_dim-64 attention WITHOUT q / k norm and RoPE (the UNets' attn1 / attn2: diffusers Attention with
+ * AttnProcessor2_0; SD3-Medium's joint attention, packed_attention_processors.py:126-187, whose q / k norms are absent and whose rotation is the identity) with the
+ * head split in the GEMM epilogue instead of a separate pass over the [tokens, 3D] projection (st355_head_split / st355_qk_norm_rope_fwd).  Output columns
+ * [0, n_q) are q heads, [n_q, n_q + n_k) k heads, the rest v heads (64 columns per head; n_q / n_k multiples of 64, either may be 0).  q / k heads go to
+ * Q / K [B, H, S, 64] at sequence position pos0 + m % rows_per_batch of sample m / rows_per_batch (args->rows_per_batch: this stream's rows per sample; ANY
+ * positive value — rows are mapped one by one); v heads go to the rows of args->C (column n - n_q - n_k: the row-major V the backward reads) AND, when Vt is given,
+ * to the head-major V^T [B, H, 64, Sp] the forward attention streams (needs rows_per_batch % 8 == 0 and pos0 % 8 == 0; columns [S, Sp) are the caller's to zero).
+ * bias is added before the split.  256x256 schedule; 16-byte aligned operands. */
+typedef struct st355_heads {
+  void* Q; void* K; void* Vt;
+  int32_t H, S, pos0, Sp;
+  int32_t n_q, n_k;
+} st355_heads;
 /* ST355_EPI_GEGLU / ST355_EPI_GEGLU_GRAD — diffusers FeedForward(activation_fn="geglu") of the UNet's BasicTransformerBlock (proj -> [value | gate],
  * out = value * gelu(gate), exact erf GELU) without its two streaming passes (st355_geglu_fwd / _bwd).  The projection weight rows (and bias) are given in the
  * INTERLEAVED order  c' = 64 * (j / 32) + j % 32  for value feature j and  c' + 32  for gate feature j  (j in [0, F), N = 2F a multiple of 64), so that a wave's
@@ -164,6 +178,7 @@ typedef struct st355_gemm_args {
    * (a tile never straddles two segments) and divide M; EPI_GATE_RESIDUAL's rows_per_batch keeps counting LOGICAL rows.  NT bf16 GEMM only. */
   int64_t seg_rows, seg_a, seg_a2, seg_c, seg_in, seg_out;
   const st355_qk_rope* rope;        /* ST355_EPI_QK_NORM_ROPE only (host pointer, read at launch) */
+  const st355_heads* heads;         /* ST355_EPI_HEADS only (host pointer, read at launch) */
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two

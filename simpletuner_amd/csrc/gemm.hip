@@ -87,6 +87,9 @@ struct GemmP {
   const float* rcos = nullptr; const float* rsin = nullptr;
   int rH = 0, rS = 0, rpos0 = 0;
   float reps = 0.f;
+  // ST355_EPI_HEADS (st355_heads; reuses rq / rk / rvt / rH / rS / rpos0 / rSp and rows_per_batch): output columns [0, hq) are q heads, [hq, hq + hk) k heads, the
+  // rest v heads, 64 columns per head
+  int hq = 0, hk = 0;
 };
 
 // the tile at row m0 of a segmented problem sees plain operands whose base pointers are shifted to its segment
@@ -607,6 +610,75 @@ __device__ __forceinline__ void gemm_epilogue_geglu_grad(const GemmP& p, f32x16 
   }
 }
 
+// ---- ST355_EPI_HEADS (256x256 schedule): 64-wide heads written head-major straight from the accumulators (st355.h) ----
+// A wave's 64 columns are exactly one head.  Same wave-private fp32 transpose as gemm_epilogue_lds; the read side (8 lanes per token row, 8 features each) stores a
+// token's 64 head channels as one 128-byte line of Q / K [B, H, S, 64]; v heads keep their row-major C rows and — as gemm_epilogue_vdual — leave through a
+// transposed read of the staging slice as well (8 lanes = 64 consecutive tokens of one channel) when the V^T destination is given.  The sample / position of a row
+// come from one integer division per row (rows_per_batch is arbitrary: SD3's 231 text rows, a UNet level's 1024).
+__device__ __forceinline__ void gemm_epilogue_heads(const GemmP& p, bf16* C, f32x16 (&acc)[2][4], int mw0, int nw0, int lane, char* stage) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int rrow = lane >> 3, rc = lane & 7;
+  const int part = nw0 < p.hq ? 0 : (nw0 < p.hq + p.hk ? 1 : 2);                   // wave-uniform: q, k or v head
+  const int ncol = nw0 - (part == 0 ? 0 : part == 1 ? p.hq : p.hq + p.hk);        // first column of this wave inside its part
+  const int head = ncol >> 6;
+  const bool n_ok = nw0 < p.N;
+  float bias8[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) bias8[j] = (p.bias && n_ok) ? bf2f(p.bias[nw0 + rc * 8 + j]) : 0.f;
+  const int rpb = (int)p.rows_per_batch;
+  bf16* hm = part == 0 ? p.rq : p.rk;
+  const int fsub = lane >> 3, tg = lane & 7;                                        // transposed side (v heads): channel fsub of 8, token group tg of 8 tokens
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          f32x4 v;
+#pragma unroll
+          for (int b = 0; b < 4; b++) v[b] = acc[i][2 * ps + jj][4 * a + b];
+          *(f32x4*)(stage + (jj * 32 + l31) * EPL_PITCH + (i * 32 + 8 * a + 4 * khalf) * 4) = v;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + rrow;
+      const int m = mw0 + ps * 64 + row;
+      const f32x4 lo = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32);
+      const f32x4 hi = *(const f32x4*)(stage + row * EPL_PITCH + rc * 32 + 16);
+      if (m >= p.M || !n_ok) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { o[b] = f2bf(lo[b] + bias8[b]); o[4 + b] = f2bf(hi[b] + bias8[4 + b]); }
+      if (part < 2) {
+        const int bsm = m / rpb;
+        const int pos = p.rpos0 + (m - bsm * rpb);
+        *(bf16x8*)(hm + (((int64_t)bsm * p.rH + head) * p.rS + pos) * 64 + rc * 8) = o;
+      } else {
+        *(bf16x8*)(C + (int64_t)m * p.ldc + ncol + rc * 8) = o;
+      }
+    }
+    if (part == 2 && p.rvt && n_ok) {
+      const int m8 = mw0 + ps * 64 + tg * 8;                                        // first of this lane's 8 consecutive tokens (same sample: rows_per_batch % 8 == 0)
+      if (m8 < p.M) {
+        const int bsm = m8 / rpb;
+        const int pos = p.rpos0 + (m8 - bsm * rpb);
+        bf16* vt = p.rvt + (((int64_t)bsm * p.rH + head) * 64) * (int64_t)p.rSp + pos;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int f = it * 8 + fsub;
+          const float bf_ = p.bias ? bf2f(p.bias[nw0 + f]) : 0.f;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] = f2bf(*(const float*)(stage + (tg * 8 + e) * EPL_PITCH + f * 4) + bf_);
+          *(bf16x8*)(vt + (int64_t)f * p.rSp) = o;
+        }
+      }
+    }
+  }
+}
+
 // the coalesced path needs 16-byte alignment of every row it touches with bf16x8 accesses
 __device__ __forceinline__ bool epl_aligned(const GemmP& p) {
   bool ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
@@ -1121,6 +1193,8 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
     if (ps.aux_in) ps.aux_in = p.aux_in + (int64_t)wtap * p.N;
     ps.conv_taps = 0;
     gemm_epilogue_lds<EPI, false, false>(ps, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
+  } else if (EPI == ST355_EPI_HEADS) {
+    gemm_epilogue_heads(p, p.C + segi * p.seg_xc, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   } else if (EPI == ST355_EPI_GEGLU) {
     gemm_epilogue_geglu(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wv * EPL_WAVE);
   } else if (EPI == ST355_EPI_GEGLU_GRAD) {
@@ -1629,7 +1703,20 @@ static int validate(const st355_gemm_args* a) {
     ST_REQUIRE(a->aux_in && a->ld_aux_in % 4 == 0, "gemm: gelu-grad/add epilogue needs aux_in");
   if ((a->epilogue == ST355_EPI_GELU || a->epilogue == ST355_EPI_GATE_RESIDUAL) && a->aux_out)
     ST_REQUIRE(a->ld_aux_out % 4 == 0, "gemm: ld_aux_out must be a multiple of 4");
-  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_GEGLU_GRAD, "gemm: unknown epilogue %d", a->epilogue);
+  ST_REQUIRE(a->epilogue >= 0 && a->epilogue <= ST355_EPI_HEADS, "gemm: unknown epilogue %d", a->epilogue);
+  if (a->epilogue == ST355_EPI_HEADS) {
+    const st355_heads* h = a->heads;
+    ST_REQUIRE(h && h->H > 0 && h->S > 0 && h->n_q >= 0 && h->n_k >= 0 && h->n_q % 64 == 0 && h->n_k % 64 == 0 && a->N % 64 == 0 && h->n_q + h->n_k <= a->N,
+               "gemm: EPI_HEADS needs args->heads with 64-column head blocks (N=%d)", a->N);
+    const int n_v = a->N - h->n_q - h->n_k;
+    ST_REQUIRE((h->n_q == 0 || (h->Q && h->n_q == h->H * 64)) && (h->n_k == 0 || (h->K && h->n_k == h->H * 64)) && (n_v == 0 || n_v == h->H * 64),
+               "gemm: EPI_HEADS: every present part (q / k / v) is H heads of 64 columns");
+    ST_REQUIRE(a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0 && h->pos0 >= 0 && h->pos0 + a->rows_per_batch <= h->S, "gemm: EPI_HEADS rows_per_batch / pos0 / S");
+    ST_REQUIRE(!a->seg_rows && a->K2 >= 0 && a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0) && (!h->Q || (uintptr_t)h->Q % 16 == 0) && (!h->K || (uintptr_t)h->K % 16 == 0) &&
+               (!a->bias || (uintptr_t)a->bias % 16 == 0), "gemm: EPI_HEADS operands must be 16-byte aligned, no segmented rows");
+    ST_REQUIRE(!h->Vt || (n_v > 0 && a->rows_per_batch % 8 == 0 && h->pos0 % 8 == 0 && h->Sp % 8 == 0 && h->Sp >= h->S && ((uintptr_t)h->Vt % 16 == 0)),
+               "gemm: EPI_HEADS V^T needs v heads, rows_per_batch / pos0 / Sp multiples of 8, Sp >= S");
+  }
   if (a->epilogue == ST355_EPI_GEGLU || a->epilogue == ST355_EPI_GEGLU_GRAD) {
     const bool fwd = a->epilogue == ST355_EPI_GEGLU;
     ST_REQUIRE(a->N % 64 == 0 && a->K2 == 0 && !a->seg_rows && !a->gate, "gemm: the GEGLU epilogues take a plain problem with N %% 64 == 0 (N=%d)", a->N);
@@ -1680,6 +1767,11 @@ static GemmP to_p(const st355_gemm_args* a) {
     p.seg_rows = (int)a->seg_rows;
     p.seg_xa = extra(a->seg_a, a->lda); p.seg_xa2 = (a->A2 && a->K2) ? extra(a->seg_a2, a->lda2) : 0; p.seg_xc = extra(a->seg_c, a->ldc);
     p.seg_xin = a->aux_in ? extra(a->seg_in, a->ld_aux_in) : 0; p.seg_xout = a->aux_out ? extra(a->seg_out, a->ld_aux_out) : 0;
+  }
+  if (a->epilogue == ST355_EPI_HEADS && a->heads) {
+    const st355_heads* h = a->heads;
+    p.rq = (bf16*)h->Q; p.rk = (bf16*)h->K; p.rvt = (bf16*)h->Vt; p.rH = h->H; p.rS = h->S; p.rpos0 = h->pos0; p.rSp = h->Sp; p.hq = h->n_q; p.hk = h->n_k;
+    p.rows_per_batch = a->rows_per_batch;
   }
   if (a->epilogue == ST355_EPI_QK_NORM_ROPE && a->rope) {
     const st355_qk_rope* r = a->rope;
@@ -1987,6 +2079,11 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
     return launch_pq<ST355_EPI_QK_NORM_ROPE>(stream, g, g.tiles0);
   }
+  if (a->epilogue == ST355_EPI_HEADS) {                 // ... and the head-splitting one
+    GemmGroup g;
+    g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    return launch_pq<ST355_EPI_HEADS>(stream, g, g.tiles0);
+  }
   if (a->epilogue == ST355_EPI_GEGLU || a->epilogue == ST355_EPI_GEGLU_GRAD) {      // likewise the GEGLU pair
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
@@ -2210,6 +2307,26 @@ extern "C" int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args
   }
   int i = 0;
   while (i < count) {
+    if (args[i].epilogue == ST355_EPI_GEGLU || args[i].epilogue == ST355_EPI_GEGLU_GRAD) {      // (one launch per problem: these two exist as plain problems only)
+      ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]), gemm_bytes(&args[i]), "%dx%dx%d+%d e%d g", args[i].M, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
+      int rc = run_one(stream, &args[i]);
+      if (rc) return rc;
+      i += 1;
+      continue;
+    }
+    if (args[i].epilogue == ST355_EPI_HEADS) {             // img + txt projections of one joint attention: one grid (or the last, odd problem alone)
+      GemmGroup g;
+      const int n2 = i + 1 < count ? 2 : 1;
+      g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + n2 - 1]);
+      g.tiles0 = p4_tiles(g.p[0]);
+      const int tiles = g.tiles0 + (n2 == 2 ? p4_tiles(g.p[1]) : 0);
+      ProfScope ps(stream, ST355_K_GEMM, gemm_flops(&args[i]) + (n2 == 2 ? gemm_flops(&args[i + 1]) : 0.0), gemm_bytes(&args[i]) + (n2 == 2 ? gemm_bytes(&args[i + 1]) : 0.0),
+                   "%d&%dx%dx%d+%d e%d", args[i].M, n2 == 2 ? args[i + 1].M : 0, args[i].N, args[i].K, args[i].K2, args[i].epilogue);
+      int rc = launch_pq<ST355_EPI_HEADS>(stream, g, tiles);
+      if (rc) return rc;
+      i += n2;
+      continue;
+    }
     if (i + 1 < count && args[i].epilogue == ST355_EPI_QK_NORM_ROPE) {      // img + txt projections of one block: one grid
       GemmGroup g;
       g.p[0] = to_p(&args[i]); g.p[1] = to_p(&args[i + 1]);

@@ -41,7 +41,7 @@ KERNEL_CLASSES = [
     "ln_mod", "qk_rope", "skinny", "elementwise", "optim",
 ]
 
-EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_QK_NORM_ROPE, EPI_GEGLU, EPI_GEGLU_GRAD = 0, 1, 2, 3, 4, 5, 6, 7
+EPI_NONE, EPI_GELU, EPI_GATE_RESIDUAL, EPI_MUL_GELU_GRAD, EPI_ADD, EPI_QK_NORM_ROPE, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_HEADS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class St355Unavailable(RuntimeError):
@@ -231,6 +231,12 @@ class VaeEncoder(C.Structure):
     ]
 
 
+class Heads(C.Structure):
+    """st355_heads (include/st355.h): destinations of the head-splitting projection epilogue ST355_EPI_HEADS"""
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("H", C.c_int32), ("S", C.c_int32), ("pos0", C.c_int32), ("Sp", C.c_int32),
+                ("n_q", C.c_int32), ("n_k", C.c_int32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("lda", C.c_int64),
@@ -248,6 +254,7 @@ class GemmArgs(C.Structure):
         ("K2_real", C.c_int32),
         ("seg_rows", C.c_int64), ("seg_a", C.c_int64), ("seg_a2", C.c_int64), ("seg_c", C.c_int64), ("seg_in", C.c_int64), ("seg_out", C.c_int64),
         ("rope", C.POINTER(QkRope)),
+        ("heads", C.POINTER(Heads)),
     ]
 
 

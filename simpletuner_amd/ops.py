@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import lib as _l
-from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE, GemmArgs, QkRope  # noqa: F401
+from .lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_HEADS, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE, GemmArgs, Heads, QkRope  # noqa: F401
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -313,8 +313,23 @@ def qk_rope(Q, K, rrms, wq, wk, cos, sin, H: int, S: int, pos0: int, eps: float 
     return r
 
 
+def heads(Q, K, Vt, H: int, S: int, pos0: int, n_q: int, n_k: int):
+    """destinations of the head-splitting projection epilogue (EPI_HEADS; st355_heads in st355.h): pass as gemm(..., epilogue=EPI_HEADS, heads=heads(...),
+    rows_per_batch=rows of this stream per sample).  Q / K: [B, H, S, 64] bf16 (None when the projection has no such part); Vt: [B, H, 64, Sp] or None."""
+    h = Heads()
+    for t, nm in ((Q, "Q"), (K, "K"), (Vt, "Vt")):
+        if t is not None:
+            _chk(t, BF16, nm)
+            if not t.is_contiguous():
+                raise _l.St355Error(f"heads: {nm} must be contiguous")
+    h.Q, h.K, h.Vt = _ptr(Q), _ptr(K), _ptr(Vt)
+    h.H, h.S, h.pos0, h.Sp, h.n_q, h.n_k = H, S, pos0, (Vt.shape[-1] if Vt is not None else 0), n_q, n_k
+    h._keep = (Q, K, Vt)
+    return h
+
+
 def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None,
-               gate=None, rows_per_batch: int = 0, k2_real: int = 0, rope=None):
+               gate=None, rows_per_batch: int = 0, k2_real: int = 0, rope=None, heads=None):
     """a, a2, out, aux_in, aux_out may be 3-D [segments, rows, cols] strided views (see _seg): one problem over the row blocks of a joint buffer.
     epilogue=EPI_QK_NORM_ROPE (rope=qk_rope(...), rows_per_batch=rows of this stream per sample): `out` is the V destination [M, N/3] (q / k go
     head-major to rope.Q / rope.K)."""
@@ -329,8 +344,19 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
         g.rope = C.pointer(rope)
         g._rope_keep = rope
         g.rows_per_batch = rows_per_batch
-    # output width: N, except the fused-QKV form (the V third), EPI_GEGLU (value * gelu(gate): N / 2) and EPI_GEGLU_GRAD (d value | d gate interleaved: 2 N)
+    # output width: N, except the fused-QKV form (the V third), EPI_HEADS (the v heads), EPI_GEGLU (value * gelu(gate): N / 2) and EPI_GEGLU_GRAD (d value | d gate: 2 N)
     n_out = N // 3 if epilogue == EPI_QK_NORM_ROPE else N // 2 if epilogue == EPI_GEGLU else 2 * N if epilogue == EPI_GEGLU_GRAD else N
+    if epilogue == EPI_HEADS:
+        if heads is None:
+            raise _l.St355Error("gemm: EPI_HEADS needs heads=heads(...)")
+        n_out = N - heads.n_q - heads.n_k
+        g.heads = C.pointer(heads)
+        g._heads_keep = heads
+        g.rows_per_batch = rows_per_batch
+        if n_out == 0:                     # no v part (a q-only / k-only projection): C is never written — an [M, 8] scratch satisfies the argument checks
+            if out is not None:
+                raise _l.St355Error("gemm: EPI_HEADS without v heads takes no out=")
+            n_out = 8
     if epilogue != EPI_QK_NORM_ROPE and out is None:
         out = torch.empty(M, n_out, dtype=BF16, device=a.device)
     Mo, No, g.ldc, sr, g.seg_c = _seg(out, "out")

@@ -327,7 +327,11 @@ class Trainer:
             static = clone_tree(prepared)
             static_inputs = dict(tensors(static))          # name -> the tensors the captured kernels read; filled from each step's batch
             self.last_loss = None
-            side = torch.cuda.Stream()
+            # ONE side stream for every capture: the caching allocator keys its free blocks by stream, so a fresh stream per bucket shape made every capture take a
+            # new ~40 GB of the shared pool instead of the blocks the previous capture had freed (r6 probe: reserved +25 GiB per bucket at batch 4, allocated flat)
+            if getattr(self, "_graph_stream", None) is None:
+                self._graph_stream = torch.cuda.Stream()
+            side = self._graph_stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):

@@ -18,6 +18,7 @@ arena of the same layout (one fused optimizer launch, contiguous slices for RCCL
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -26,7 +27,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..flux.transformer import LoraGroup, _attach, _frozen
-from ..ops import EPI_ADD, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_NONE
+from ..ops import EPI_ADD, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_HEADS, EPI_NONE
 from ..training.checkpoint_plan import CheckpointPlanMixin
 
 BF16 = torch.bfloat16
@@ -40,6 +41,10 @@ def _p64(t):
     o = torch.zeros((r + 63) // 64 * 64, t.shape[1], dtype=BF16, device=t.device)
     o[:r] = t
     return o
+
+
+# ST355_HEADS_FUSED=0: the attention input projections write [M, 3C] / [M, C] and st355_head_split_pad re-lays them out (A/B switch for ST355_EPI_HEADS)
+_HEADS_FUSED = os.environ.get("ST355_HEADS_FUSED", "1") != "0"
 
 
 class Tape:
@@ -489,22 +494,26 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         y = ops.gemm(x, l.w.t, bias=None if l.b is None else l.b.t, epilogue=EPI_ADD if residual is not None else EPI_NONE, aux_in=residual, **kw)
         if T is not None:
             def bwd(dy):
-                if self.full:
-                    ops.gemm_tn(_p64(dy), _p64(x), out=l.w.g)
-                    if l.b is not None:
-                        self._bias_grad(dy, l.b)
-                    self._ready(l.b, l.w) if (l.b is not None and l.b.off > l.w.off) else self._ready(l.w, l.b)
-                kb = {}
-                if lo is not None:
-                    U = ops.gemm(dy, lo.B_blk_T)
-                    lo.grads(x, Tl, dy, U, False, None)
-                    kb = dict(a2=U, b2=lo.A_cat_T)
-                if self._probe is not None:               # lab hook (tools/sdxl_lora_outlier_probe.py): the operands of this layer's backward, by reference
-                    self._probe("linear", l.name, dict(x=x, dy=dy, y=y))
-                dx = ops.gemm(dy, l.wT, **kb) if need_dx else None
-                return dx, (dy if residual is not None else None)
+                return self._linear_bwd(l, x, Tl, dy, need_dx, y=y), (dy if residual is not None else None)
             T.rec([y], [x if need_dx else None, residual], bwd)
         return y
+
+    def _linear_bwd(self, l, x, Tl, dy, need_dx=True, y=None):
+        """weight / bias / adapter gradients of y = x W^T (+ low-rank term) from dy, and dx = dy W (+ rank-space term)"""
+        lo = l.lora
+        if self.full:
+            ops.gemm_tn(_p64(dy), _p64(x), out=l.w.g)
+            if l.b is not None:
+                self._bias_grad(dy, l.b)
+            self._ready(l.b, l.w) if (l.b is not None and l.b.off > l.w.off) else self._ready(l.w, l.b)
+        kb = {}
+        if lo is not None:
+            U = ops.gemm(dy, lo.B_blk_T)
+            lo.grads(x, Tl, dy, U, False, None)
+            kb = dict(a2=U, b2=lo.A_cat_T)
+        if self._probe is not None:               # lab hook (tools/sdxl_lora_outlier_probe.py): the operands of this layer's backward, by reference
+            self._probe("linear", l.name, dict(x=x, dy=dy, y=y))
+        return ops.gemm(dy, l.wT, **kb) if need_dx else None
 
     def _conv3(self, T, l, x, B, H, W, img_add=None, residual=None):
         y = ops.conv(x, l.w.t, B, H, W, bias=l.b.t, img_add=img_add, residual=residual, taps=l.taps)
@@ -632,6 +641,76 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
             T.rec([O], [qsrc] if self_attn else [qsrc, kvsrc], bwd)
         return O
 
+    def _heads_fused_ok(self, C_, heads, B, S):
+        """the head-splitting projection epilogue (ST355_EPI_HEADS) applies: 64-wide heads, the transposing-read backward (no Q^T / K^T copies), 8-token V^T granules"""
+        return _HEADS_FUSED and ops.ATTN_TR and self._probe is None and C_ == heads * 64 and S % 8 == 0 and B * S >= 256
+
+    def _lora_fwd(self, l, x):
+        lo = l.lora
+        if lo is None:
+            return None, {}
+        Tl = ops.gemm(x, lo.A_cat)
+        return Tl, dict(a2=Tl, b2=lo.B_blk)
+
+    def _self_attn_proj_fused(self, T, l, n1, B, S, heads):
+        """attn1 of a BasicTransformerBlock (to_q | to_k | to_v as ONE projection, then softmax(q k^T / 8) v) with the head split inside the projection GEMM's
+        epilogue (ST355_EPI_HEADS): q / k leave head-major, v row-major + head-major V^T — the three st355_head_split_pad passes over the [M, 3C] projection of the
+        unfused form are gone, and [M, 3C] itself is never stored.  Same accumulators, bias add and bf16 rounding: bit-identical attention operands."""
+        C_ = l.N // 3
+        M = B * S
+        dev = n1.device
+        Sp = (S + 63) // 64 * 64
+        Q = torch.empty(B, heads, S, 64, dtype=BF16, device=dev)
+        K = torch.empty(B, heads, S, 64, dtype=BF16, device=dev)
+        Vt = torch.empty(B, heads, 64, Sp, dtype=BF16, device=dev)
+        if Sp > S:
+            Vt[..., S:].zero_()
+        v_rows = torch.empty(M, C_, dtype=BF16, device=dev)
+        Tl, kw = self._lora_fwd(l, n1)
+        ops.gemm(n1, l.w.t, bias=None if l.b is None else l.b.t, out=v_rows, epilogue=EPI_HEADS, heads=ops.heads(Q, K, Vt, heads, S, 0, C_, C_), rows_per_batch=S, **kw)
+        scale = 0.125
+        Op = torch.empty(M, C_, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, S, dtype=F32, device=dev)
+        Ores = torch.empty_like(Op) if T is not None else None          # (see _attention: delta from the un-rounded output)
+        ops.attn_fwd(Q, K, Vt, Op, lse, B, heads, S, Sp, 64, scale, O_res=Ores)
+        if T is not None:
+            def bwd(dO):
+                dqkv = torch.empty(M, 3 * C_, dtype=BF16, device=dev)
+                dQ, dK = torch.empty_like(Q), torch.empty_like(K)
+                ops.attn_bwd(Q, K, None, None, v_rows, Op, dO, lse, dQ, dK, dqkv[:, 2 * C_:], B, heads, S, Sp, 64, scale, O_res=Ores)
+                ops.head_merge(dQ, dqkv[:, :C_], B, heads, 64, S, d_src=64)
+                ops.head_merge(dK, dqkv[:, C_:2 * C_], B, heads, 64, S, d_src=64)
+                return (self._linear_bwd(l, n1, Tl, dqkv),)
+            T.rec([Op], [n1], bwd)
+        return Op
+
+    def _cross_attn_proj_fused(self, T, lq, n2, kv, B, S, Sk, heads):
+        """attn2: the query projection writes head-major q from its epilogue (ST355_EPI_HEADS, q part only); the 77 text keys keep the head-split kernel"""
+        C_ = lq.N
+        M, Mk = B * S, B * Sk
+        dev = n2.device
+        Sp = (S + 63) // 64 * 64
+        Q = torch.empty(B, heads, S, 64, dtype=BF16, device=dev)
+        Tl, kw = self._lora_fwd(lq, n2)
+        ops.gemm(n2, lq.w.t, bias=None if lq.b is None else lq.b.t, epilogue=EPI_HEADS, heads=ops.heads(Q, None, None, heads, S, 0, C_, 0), rows_per_batch=S, **kw)
+        K, _, Skp = ops.head_split(kv[:, :C_], B, heads, 64, Sk, d_src=64, want_xt=False)
+        _, Vt, _ = ops.head_split(kv[:, C_:], B, heads, 64, Sk, want_x=False, d_src=64)
+        scale = 0.125
+        Op = torch.empty(M, C_, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, S, dtype=F32, device=dev)
+        ops.attn_cross_fwd(Q, K, Vt, Op, lse, B, heads, S, Sk, Skp, 64, scale)
+        if T is not None:
+            def bwd(dO):
+                dq_src = torch.empty(M, C_, dtype=BF16, device=dev)
+                dkv = torch.empty_like(kv)
+                dQ, dK = torch.empty_like(Q), torch.empty_like(K)
+                ops.attn_cross_bwd(Q, K, None, None, kv[:, C_:], Op, dO, lse, dQ, dK, dkv[:, C_:], B, heads, S, Sp, Sk, Skp, 64, scale)
+                ops.head_merge(dQ, dq_src, B, heads, 64, S, d_src=64)
+                ops.head_merge(dK, dkv[:, :C_], B, heads, 64, Sk, d_src=64)
+                return self._linear_bwd(lq, n2, Tl, dq_src), dkv
+            T.rec([Op], [n2, kv], bwd)
+        return Op
+
     def _attention_unfused(self, T, qsrc, kvsrc, qo, ko, vo, C_, B, S, Sk, heads):
         """heads wider than 128 (SD1.5: 160 at the 16^2 / 8^2 levels): per (image, head) scores = q k^T (GEMM), row softmax, p v (GEMM); backward
         the same way (two TN GEMMs, two NT GEMMs, the softmax-backward kernel).  The score matrices are tiny at these levels."""
@@ -690,14 +769,21 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
         n = self._gn(T, tr.norm, x, B, H, W, 1e-6, silu=False, tokens=True)
         h = self._linear(T, tr.proj_in, n)
         for blk in tr.blocks:
+            fused = self._heads_fused_ok(tr.C, tr.heads, B, S)
             n1 = self._ln(T, blk.norm1, h)
-            qkv = self._linear(T, blk.qkv, n1)
-            o = self._self_attn(T, qkv, B, S, tr.heads)
+            if fused:
+                o = self._self_attn_proj_fused(T, blk.qkv, n1, B, S, tr.heads)
+            else:
+                qkv = self._linear(T, blk.qkv, n1)
+                o = self._self_attn(T, qkv, B, S, tr.heads)
             h = self._linear(T, blk.out1, o, residual=h)
             n2 = self._ln(T, blk.norm2, h)
-            q = self._linear(T, blk.q2, n2)
             kv = self._linear(T, blk.kv2, ctx2d, need_dx=False)
-            o2 = self._cross_attn(T, q, kv, B, S, Sk, tr.heads)
+            if fused:
+                o2 = self._cross_attn_proj_fused(T, blk.q2, n2, kv, B, S, Sk, tr.heads)
+            else:
+                q = self._linear(T, blk.q2, n2)
+                o2 = self._cross_attn(T, q, kv, B, S, Sk, tr.heads)
             h = self._linear(T, blk.out2, o2, residual=h)
             n3 = self._ln(T, blk.norm3, h)
             if blk.ff1.w_il is not None and n3.shape[0] >= 256:

@@ -22,7 +22,7 @@ from types import SimpleNamespace
 
 import torch
 
-from simpletuner_amd.lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE      # the ST355_EPI_* values (st355.h)
+from simpletuner_amd.lib import EPI_ADD, EPI_GATE_RESIDUAL, EPI_GEGLU, EPI_GEGLU_GRAD, EPI_GELU, EPI_HEADS, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_QK_NORM_ROPE      # the ST355_EPI_* values (st355.h)
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -160,7 +160,52 @@ def _fused_qkv_epilogue(acc, out, rope, rows_per_batch):
     return out
 
 
-def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None, gate=None, rows_per_batch=0, k2_real=0, rope=None):
+class _Heads:
+    """what ops.heads hands to gemm(..., heads=...): the destinations of the head-splitting epilogue (st355_heads in st355.h), as tensors"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def heads(Q, K, Vt, H, S, pos0, n_q, n_k):
+    for t, nm in ((Q, "Q"), (K, "K"), (Vt, "Vt")):
+        if t is not None:
+            _chk(t, BF16, nm); _al(t, 16, nm)
+            _need(t.is_contiguous(), f"heads: {nm} must be contiguous")
+    _need(n_q % 64 == 0 and n_k % 64 == 0 and (n_q == 0 or (Q is not None and n_q == H * 64)) and (n_k == 0 or (K is not None and n_k == H * 64)),
+          "heads: every present part is H heads of 64 columns")
+    for t in (Q, K):
+        _need(t is None or (t.shape[1] == H and t.shape[2] == S and t.shape[3] == 64), "heads: Q / K are [B, H, S, 64]")
+    if Vt is not None:
+        _need(Vt.shape[1] == H and Vt.shape[2] == 64 and Vt.shape[3] >= S and Vt.shape[3] % 8 == 0 and pos0 % 8 == 0, "heads: V^T is [B, H, 64, Sp], Sp >= S, Sp and pos0 multiples of 8")
+    return _Heads(Q=Q, K=K, Vt=Vt, H=H, S=S, pos0=pos0, n_q=n_q, n_k=n_k)
+
+
+def _heads_epilogue(acc, out, h, rows_per_batch):
+    """ST355_EPI_HEADS (st355.h): acc [M, n_q + n_k + n_v] -> head-major Q / K at positions pos0 + m % rows_per_batch, row-major V rows (+ head-major V^T)"""
+    M, N = acc.shape
+    n_v = N - h.n_q - h.n_k
+    _need(N % 64 == 0 and (n_v == 0 or n_v == h.H * 64), "gemm: EPI_HEADS: the v part is H heads of 64 columns")
+    _need(rows_per_batch > 0 and M % rows_per_batch == 0 and h.pos0 >= 0 and h.pos0 + rows_per_batch <= h.S, "gemm: EPI_HEADS rows_per_batch / pos0 / S")
+    B, R, p0 = M // rows_per_batch, rows_per_batch, h.pos0
+    col = 0
+    for n, dst in ((h.n_q, h.Q), (h.n_k, h.K)):
+        if n:
+            dst[:B, :, p0:p0 + R] = acc[:, col:col + n].reshape(B, R, h.H, 64).permute(0, 2, 1, 3).to(BF16)
+            col += n
+    if n_v:
+        _need(out is not None and tuple(out.shape) == (M, n_v), f"gemm: EPI_HEADS out is the row-major V [{M}, {n_v}]")
+        v = acc[:, col:]
+        _put(out, v)
+        if h.Vt is not None:
+            _need(R % 8 == 0, "gemm: EPI_HEADS V^T needs rows_per_batch % 8 == 0")
+            h.Vt[:B, :, :, p0:p0 + R] = v.reshape(B, R, h.H, 64).permute(0, 2, 3, 1).to(BF16)
+    else:
+        _need(h.Vt is None, "gemm: EPI_HEADS V^T without v heads")
+    return out
+
+
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out=None, aux_in=None, gate=None, rows_per_batch=0, k2_real=0, rope=None, heads=None):
     _chk(a, BF16, "a"); _chk(w, BF16, "w")
     _seg(a, "a"); _rows(w, "w")
     _need(epilogue != EPI_QK_NORM_ROPE or (rope is not None and out is not None), "gemm: EPI_QK_NORM_ROPE needs rope=qk_rope(...) and out= (the V destination)")
@@ -188,6 +233,16 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, a2=None, b2=None, aux_out
         _need(out.numel() == M * (N // 3) and out.shape[-1] == N // 3, f"gemm: the V destination is {tuple(out.shape)}, expected {M}x{N // 3}")
         _need(out.dim() == 2 or out.shape[1] == rows_per_batch, "gemm: EPI_QK_NORM_ROPE segments are the per-sample row blocks (seg_rows == rows_per_batch)")
         return _fused_qkv_epilogue(acc, out, rope, rows_per_batch)
+    if epilogue == EPI_HEADS:
+        _need(heads is not None and a.dim() == 2, "gemm: EPI_HEADS needs heads=heads(...) and a plain (unsegmented) problem")
+        n_v = N - heads.n_q - heads.n_k
+        if n_v:
+            if out is None:
+                out = torch.empty(M, n_v, dtype=BF16, device=a.device)
+            _chk(out, BF16, "out"); _al(out, 16, "out"); _ld(out, 8, "out")
+        else:
+            _need(out is None, "gemm: EPI_HEADS without v heads takes no out=")
+        return _heads_epilogue(acc, out, heads, rows_per_batch)
     if epilogue in (EPI_GEGLU, EPI_GEGLU_GRAD):
         # the UNet feed-forward's GEGLU inside its two GEMMs (st355.h): interleaved columns — every 64 = [32 values | the 32 gates of the same features]
         _need(N % 64 == 0 and a2 is None and gate is None and a.dim() == 2, "gemm: the GEGLU epilogues take a plain problem with N % 64 == 0")

@@ -233,3 +233,60 @@ def test_thin_rank_space_gemm(ops, M, K):
     wide = torch.zeros(M, 192, device=d_, dtype=BF16)       # a strided destination (a column block of a wider buffer)
     ops.gemm(x, w[:64], out=wide[:, 64:128])
     assert torch.equal(wide[:, 64:128], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,R,S,pos0,H,K,parts,lora,with_bias,with_vt", [
+    (2, 1024, 1024, 0, 20, 1280, "qkv", True, False, True),        # SDXL 32^2 level attn1 (LoRA on the fused projection)
+    (1, 4096, 4096, 0, 10, 640, "qkv", False, True, True),         # SDXL 64^2 level
+    (2, 512, 768, 256, 4, 256, "qkv", False, True, True),          # a stream's rows inside a joint sequence (pos0 > 0)
+    (3, 231, 743, 512, 6, 384, "qkv", True, True, False),          # ragged rows per sample (SD3's 231 text rows): no V^T
+    (2, 1024, 1024, 0, 20, 1280, "q", True, False, False),         # attn2: the query projection alone
+    (2, 200, 200, 0, 2, 128, "qk", False, False, False),
+])
+def test_gemm_head_split_epilogue_is_bit_equal_to_projection_then_head_split(ops, B, R, S, pos0, H, K, parts, lora, with_bias, with_vt):
+    """ST355_EPI_HEADS: head-major q / k, row-major v and head-major V^T straight from the projection GEMM's accumulators == st355_gemm_bf16 (EPI_NONE) followed by
+    st355_head_split_pad, bit for bit (same accumulation, bias add and ONE bf16 rounding; only the store addresses differ)"""
+    torch.manual_seed(65)
+    d_ = dev()
+    C_ = H * 64
+    n_q = C_ if "q" in parts else 0
+    n_k = C_ if "k" in parts else 0
+    n_v = C_ if "v" in parts else 0
+    N = n_q + n_k + n_v
+    M = B * R
+    x = torch.randn(M, K, device=d_).to(BF16)
+    w = (torch.randn(N, K, device=d_) / math.sqrt(K)).to(BF16)
+    bias = torch.randn(N, device=d_).to(BF16) if with_bias else None
+    kw = {}
+    if lora:
+        kw = dict(a2=torch.randn(M, 64, device=d_).to(BF16), b2=(torch.randn(N, 64, device=d_) * 0.1).to(BF16))
+    ref = ops.gemm(x, w, bias=bias, **kw)                                                       # [M, N]
+    Sp = (S + 63) // 64 * 64
+    mk = lambda: torch.full((B, H, S, 64), 7.0, device=d_, dtype=BF16)
+    Q = mk() if n_q else None
+    Kh = mk() if n_k else None
+    Vt = torch.full((B, H, 64, Sp), 7.0, device=d_, dtype=BF16) if with_vt else None
+    out = torch.full((M, n_v), 7.0, device=d_, dtype=BF16) if n_v else None
+    okw = dict(out=out) if n_v else {}
+    ops.gemm(x, w, bias=bias, epilogue=ops.EPI_HEADS, heads=ops.heads(Q, Kh, Vt, H, S, pos0, n_q, n_k), rows_per_batch=R, **okw, **kw)
+    col = 0
+    for n, dst, nm in ((n_q, Q, "q"), (n_k, Kh, "k")):
+        if not n:
+            continue
+        want = ref[:, col:col + n].reshape(B, R, H, 64).permute(0, 2, 1, 3)
+        assert torch.equal(dst[:, :, pos0:pos0 + R], want), nm
+        rest = torch.cat([dst[:, :, :pos0].reshape(-1), dst[:, :, pos0 + R:].reshape(-1)])
+        assert rest.numel() == 0 or (float(rest.float().min()) == 7.0 and float(rest.float().max()) == 7.0), nm + ": rows outside [pos0, pos0 + R) untouched"
+        col += n
+    if n_v:
+        assert torch.equal(out, ref[:, col:]), "v rows"
+        if with_vt:
+            assert torch.equal(Vt[..., pos0:pos0 + R], ref[:, col:].reshape(B, R, H, 64).permute(0, 2, 3, 1)), "v^T"
+            rest = torch.cat([Vt[..., :pos0].reshape(-1), Vt[..., pos0 + R:].reshape(-1)])
+            assert rest.numel() == 0 or (float(rest.float().min()) == 7.0 and float(rest.float().max()) == 7.0)
+    if parts == "qkv" and pos0 == 0 and R == S:                                                # and against the kernel it replaces
+        Xq, _, _ = ops.head_split(ref[:, :C_], B, H, 64, S, want_xt=False)
+        _, Xvt, _ = ops.head_split(ref[:, 2 * C_:], B, H, 64, S, want_x=False)
+        assert torch.equal(Xq, Q)
+        if with_vt:
+            assert torch.equal(Xvt[..., :S], Vt[..., :S])
