@@ -75,10 +75,13 @@ def train_flops_per_image(n_blocks: int, D: int, S: int) -> float:
     return 2 * lin + 3 * att
 
 
-def hbm_traffic_per_gemm_launch():
-    """average HBM bytes per GEMM launch from the newest committed PMC summary (tools/profile_round.sh: separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 correction applied) — or null if none is committed."""
-    files = sorted((ROOT / "profiles").glob("*_hbm_traffic.json"))
+def hbm_traffic_per_gemm_launch(workload: str = ""):
+    """average HBM bytes per GEMM launch from the newest committed PMC summary of this workload (tools/profile_round.sh: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over the same command, gfx950 correction applied) — or null if none is committed.  workload "" = the default (Flux) command:
+    profiles/rNN_hbm_traffic.json; "sdxl_lora": profiles/rNN_sdxl_lora_hbm_traffic.json."""
+    import re
+    pat = re.compile(r"^r\d+[a-z]*_" + (re.escape(workload) + "_" if workload else "") + r"hbm_traffic\.json$")
+    files = sorted(f for f in (ROOT / "profiles").glob("*_hbm_traffic.json") if pat.match(f.name))
     if not files:
         return None, None
     d = json.loads(files[-1].read_text())
@@ -775,7 +778,9 @@ def run_workload(args, dev, rank, world):
             g = prof["gemm"]
             if g["ms"] > 0:
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-                traffic, tsrc = hbm_traffic_per_gemm_launch() if args.model == "flux" else (None, None)    # the committed PMC passes are of the default command
+                # the committed PMC passes: of the default command, and of the metric's second workload (SDXL-LoRA, eager launches of the same kernels)
+                traffic, tsrc = (hbm_traffic_per_gemm_launch() if (args.model == "flux" and not args.full) else
+                                 hbm_traffic_per_gemm_launch("sdxl_lora") if (args.model == "sdxl" and args.lora) else (None, None))
                 roof = {"bound": "mfma", "kernel": "k_gemm_* (all schedules / epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes / launch",
                         "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"])),

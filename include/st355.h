@@ -179,6 +179,11 @@ typedef struct st355_gemm_args {
   int64_t seg_rows, seg_a, seg_a2, seg_c, seg_in, seg_out;
   const st355_qk_rope* rope;        /* ST355_EPI_QK_NORM_ROPE only (host pointer, read at launch) */
   const st355_heads* heads;         /* ST355_EPI_HEADS only (host pointer, read at launch) */
+  /* optional, with `workspace`: 1024 int32 arrival counters, ZERO before the first call (every launch leaves them zero).  Given both, a problem whose 256x256
+   * tiles leave the chip's last round at most half full (320 tiles on 256 CUs) has that round's tiles cut along K over the idle CUs (stream-K tail: fp32 slabs in
+   * `workspace`, added in slice order by the tile's last slice, which then runs the ordinary epilogue — deterministic, but not bit-equal to the uncut schedule: the
+   * fp32 sum is associated differently).  One stream at a time per (workspace, tile_flags) pair. */
+  void* tile_flags;
 } st355_gemm_args;
 int st355_gemm_bf16(void* stream, const st355_gemm_args* args);
 /* `count` independent problems with the SAME epilogue kind in as few launches as possible (pairs share one grid): the two
@@ -188,6 +193,9 @@ int st355_gemm_bf16_grouped(void* stream, const st355_gemm_args* args, int count
  * tile list and keep the LDS ring running across tile seams (k_gemm_pz: full tiles, > one round of tiles, plain NT bf16 with the five elementwise
  * epilogues), 0 = one tile per workgroup everywhere (k_gemm_pq), -1 = the default (environment ST355_GEMM_PERSIST, on).  Returns the previous setting. */
 int st355_gemm_set_persistent(int mode);
+/* the stream-K tail of st355_gemm_bf16 (st355_gemm_args.tile_flags): 1 = on where it applies (default), 0 = off (the uncut schedules, bit-equal across shapes),
+ * -1 = back to the environment (ST355_GEMM_TAIL).  Returns the previous mode. */
+int st355_gemm_set_tail_split(int mode);
 
 /* ---- K19: fp8-native Linear (helpers/training/quantisation/fp8_native.py:25-119) ------------------------------------------------------
  * weights: OCP e4m3fn bytes [N,K] + one fp32 scale per output row (quantize_weight_to_fp8: scale = max(amax_row,1e-12)/448);

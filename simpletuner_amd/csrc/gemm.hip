@@ -126,6 +126,11 @@ __device__ __forceinline__ int64_t conv_koff(const GemmP& p, int u, int64_t lda,
 struct GemmGroup {
   GemmP p[2];
   int tiles0;  // tiles of problem 0 (blocks with id >= tiles0 work on problem 1)
+  // stream-K tail (k_gemm_pq<..., SK = true>; run_one): blocks [0, sk_first) run whole tiles, the tiles [sk_first, tiles0) of the last, mostly empty round are
+  // cut into sk_s K-slices each (one workgroup per slice)
+  int sk_first = 0x7fffffff, sk_s = 1;
+  float* sk_ws = nullptr;     // fp32 slabs of the slices 0 .. sk_s - 2 of every cut tile: [tile][slice][256 x 256]
+  int* sk_flags = nullptr;    // one arrival counter per cut tile; zero before and after the launch
 };
 
 __device__ __forceinline__ void glds16(const bf16* gsrc, char* lds_dst_wave_uniform) {
@@ -893,8 +898,16 @@ __device__ __forceinline__ void wait_vm_rt(int n) {    // n = LDS-DMA pieces tha
 // F8 = true: the fp8-native Linear (fp8.hip): A = e5m2 activations, B = e4m3 weights, one byte per element.  The byte geometry of the
 // ring is unchanged (128-byte rows = 128 K-elements per K-tile, same swizzle); a phase then runs 16 MFMAs (8 k-steps of
 // v_mfma_f32_32x32x16_fp8_bf8) on fragments fetched with 8-byte reads, i.e. twice the MFMA work per LDS-DMA byte.
-template <int EPI, bool TN, bool F8 = false, bool CONV = false>     // CONV: the A operand's K-tiles are row-shifted views (st355_conv_bf16)
+// SK = 2 / 3 / 4 (slices per cut tile): the stream-K tail.  A problem whose 256x256 tiles leave the chip's last round mostly empty (320 tiles on 256 CUs: the N = 1280 projections of the SDXL
+// 32^2 level at batch 16 ran two rounds for 1.25 rounds of work — 733 TFLOP/s against 1137 for the N = 3840 projection of the same rows, rocprofv3 r06) has the
+// tiles of that round cut along K: block sk_first + l runs K-slice (l >> 3) % sk_s of tile sk_first + 8 * ((l >> 3) / sk_s) + (l & 7) (the slices of a tile share
+// an XCD).  Slices 0 .. sk_s - 2 leave their fp32 accumulators in a slab (lane-linear: one 16-byte store per lane and register quad), wait for the L2's write
+// acknowledgements (same XCD = same L2: no cache-wide write-back / invalidate) and count themselves in; the LAST slice — which also owns the low-rank K-extension — waits for the count, adds the slabs in slice order (fixed order:
+// deterministic) and runs the tile's ordinary epilogue, then zeroes the counter for the next launch.  At most 128 waiting workgroups exist and the slices they wait
+// for never wait themselves, so every slice is scheduled whatever else the chip is running.
+template <int EPI, bool TN, bool F8 = false, bool CONV = false, int SK = 0>     // SK: slices per cut tile (0 = no stream-K tail); CONV: the A operand's K-tiles are row-shifted views (st355_conv_bf16)
 __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
+  static_assert(!SK || (!TN && !F8 && !CONV && EPI != EPI_SPLITK), "the stream-K tail is built for the plain NT bf16 problems");
   constexpr int ES = F8 ? 1 : 2;               // bytes per operand element
   constexpr int KSN = F8 ? 8 : 4;              // k-steps (MFMAs per accumulator) per K-tile
   static_assert(!(F8 && TN), "fp8 weight gradients are not built");
@@ -905,8 +918,18 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   const int wm = wv >> 2, wn = wv & 3;     // wm: group (128-token half); wn: 64-feature column of the tile
 
   // split-K (EPI_SPLITK): blockIdx = slice * tiles0 + tile; slice s owns K-tiles [s*per, min(all, (s+1)*per)) and writes an fp32 slab
-  const int slice = (EPI == EPI_SPLITK) ? blockIdx.x / g.tiles0 : 0;
-  int id = (EPI == EPI_SPLITK) ? xcd_remap(blockIdx.x % g.tiles0, g.tiles0) : xcd_remap(blockIdx.x, gridDim.x);
+  int slice = (EPI == EPI_SPLITK) ? blockIdx.x / g.tiles0 : 0;
+  int id = (EPI == EPI_SPLITK) ? xcd_remap(blockIdx.x % g.tiles0, g.tiles0) : xcd_remap(blockIdx.x, SK ? min((int)gridDim.x, g.sk_first) : (int)gridDim.x);
+  int sk_n = 1, sk_tl = 0;                 // SK: slices of this block's tile, the tile's index among the cut tiles
+  if (SK && (int)blockIdx.x >= g.sk_first) {
+    const int l = blockIdx.x - g.sk_first;
+    sk_n = SK;
+    const int lq = __builtin_amdgcn_readfirstlane((l >> 3) / sk_n);       // (readfirstlane: the division is expanded on the VALU — see segi below)
+    slice = (l >> 3) - lq * sk_n;
+    sk_tl = 8 * lq + (l & 7);
+    if (sk_tl >= g.tiles0 - g.sk_first) return;         // (the cut-tile count rounded up to the 8 XCDs)
+    id = g.sk_first + sk_tl;
+  }
   const int pi = id >= g.tiles0 ? 1 : 0;
   if (pi) id -= g.tiles0;
   const GemmP& p = g.p[pi];
@@ -925,10 +948,10 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   // (readfirstlane: the integer division is expanded on the VALU, which would leave a wave-uniform value — and every pointer derived from it — in VGPRs)
   const int64_t segi = (!TN && !F8 && !CONV && p.seg_rows) ? __builtin_amdgcn_readfirstlane(m0 / p.seg_rows) : 0;
   const int nt_all = p.K / (PQ_BK * 2 / ES);
-  const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : nt_all;
+  const int per = (EPI == EPI_SPLITK) ? (nt_all + p.ksplit - 1) / p.ksplit : SK ? __builtin_amdgcn_readfirstlane((nt_all + sk_n - 1) / sk_n) : nt_all;
   const int t_first = slice * per;
-  const int nt1 = (EPI == EPI_SPLITK) ? max(0, min(nt_all, t_first + per) - t_first) : nt_all;
-  const int nt = nt1 + ((EPI == EPI_SPLITK) ? 0 : p.K2 / PQ_BK);
+  const int nt1 = (EPI == EPI_SPLITK || SK) ? max(0, min(nt_all, t_first + per) - t_first) : nt_all;
+  const int nt = nt1 + ((EPI == EPI_SPLITK || (SK && slice != sk_n - 1)) ? 0 : p.K2 / PQ_BK);
 
   const bf16* A1 = p.A + segi * p.seg_xa; const bf16* B1 = p.B; const bf16* A2 = p.A2 + segi * p.seg_xa2; const bf16* B2 = p.B2;
   const int64_t la2 = p.lda2, lb2 = p.ldb2;
@@ -1181,6 +1204,56 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
   TR_FLUSH(wv, lane);
   if (wm == 0) PP_BARRIER();                           // pairs with group 1's extra barrier
   // every wave is past its last ring read and no LDS-DMA is in flight: the ring is free for the epilogue transpose
+  if (SK && sk_n > 1) {
+    float* slab = g.sk_ws + ((int64_t)sk_tl * (sk_n - 1)) * (PQ_BM * PQ_BN) + tid * 4;
+    int* flag = g.sk_flags + sk_tl;
+    if (slice < sk_n - 1) {
+      slab += (int64_t)slice * (PQ_BM * PQ_BN);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            f32x4 v;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v[b] = acc[i][j][4 * a + b];
+            *(f32x4*)(slab + ((i * 4 + j) * 4 + a) * (PQ_THREADS * 4)) = v;
+          }
+      // The slices of a tile run on ONE XCD (block ids congruent mod 8), so writer and reader meet in the same L2: the slab stores only have to be acknowledged
+      // by it (vmcnt(0): the per-CU cache is write-through) before the count, and the reader's first touch of a slab line misses its CU's cache by construction.
+      // No cache-wide write-back / invalidate: the device-scope fences of the first form (buffer_wbl2 / buffer_inv sc1 from every wave of 256 workgroups) made
+      // the cut round 100 us slower than the uncut one (r06, SDXL-LoRA batch 16: 173 vs 77 us per 16384 x 1280 x 1280 launch).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0)
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk_n - 1) __builtin_amdgcn_s_sleep(4);
+    __syncthreads();
+    asm volatile("" ::: "memory");                       // the slab loads below are issued after the count was seen complete
+    // 8 dependent round trips, each with the (i, j) quads of EVERY slab in flight (4 (SK - 1) quads per lane).  Measured r06 (SDXL-LoRA batch 16, per launch of the
+    // cut shapes): one slab at a time (24 round trips at SK = 4) and an LDS-DMA landing zone (6 round trips of 16 KB per wave, nothing overlapped) were both slower.
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        f32x4 v[SK > 1 ? SK - 1 : 1][4];
+#pragma unroll
+        for (int k = 0; k < SK - 1; k++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) v[k][a] = *(const f32x4*)(slab + (int64_t)k * (PQ_BM * PQ_BN) + ((i * 4 + j) * 4 + a) * (PQ_THREADS * 4));
+#pragma unroll
+        for (int k = 0; k < SK - 1; k++)                 // slice order
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[i][j][4 * a + b] += v[k][a][b];
+        asm volatile("" ::: "memory");
+      }
+    if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (EPI == EPI_SPLITK) {
     GemmP ps = p;
     ps.partial = p.partial + (int64_t)slice * p.M * p.part_ld + (int64_t)wtap * p.N;
@@ -1814,6 +1887,17 @@ static int launch_pq(void* stream, const GemmGroup& g, int tiles) {
   hipLaunchKernelGGL((k_gemm_pq<EPI, false>), dim3(tiles), dim3(PQ_THREADS), lds, (hipStream_t)stream, g);
   return st355_check_launch("gemm_pq");
 }
+template <int EPI, int S>
+static int launch_pq_sk_s(void* stream, const GemmGroup& g, int blocks) {
+  static St355AttrOnce attr_set;
+  if (attr_set.need()) { hipFuncSetAttribute((const void*)k_gemm_pq<EPI, false, false, false, S>, hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS); }
+  hipLaunchKernelGGL((k_gemm_pq<EPI, false, false, false, S>), dim3(blocks), dim3(PQ_THREADS), PQ_LDS, (hipStream_t)stream, g);
+  return st355_check_launch("gemm_pq_sk");
+}
+template <int EPI>
+static int launch_pq_sk(void* stream, const GemmGroup& g, int blocks) {
+  return g.sk_s == 2 ? launch_pq_sk_s<EPI, 2>(stream, g, blocks) : g.sk_s == 3 ? launch_pq_sk_s<EPI, 3>(stream, g, blocks) : launch_pq_sk_s<EPI, 4>(stream, g, blocks);
+}
 template <int EPI>
 static int launch_pq_conv(void* stream, const GemmGroup& g, int tiles) {
   static St355AttrOnce attr_set;
@@ -2054,6 +2138,45 @@ static int launch_splitk(void* stream, GemmP& p, const st355_gemm_args* a, int k
   return st355_check_launch("gemm_splitk_reduce");
 }
 
+// ---- stream-K tail plan (k_gemm_pq<..., SK>) ----
+static int g_tail_override = -1;             // st355_gemm_set_tail_split: 0 / 1 force, -1 = environment (ST355_GEMM_TAIL=0 turns it off)
+static int tail_enabled() {
+  if (g_tail_override >= 0) return g_tail_override;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ST355_GEMM_TAIL"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+// true: run `p` as g (blocks = *blocks).  The last round of 256x256 tiles is cut when it fills at most half the chip and the problem is short enough for that
+// round to matter (<= 6 full rounds before it); 2..4 slices of >= 4 K-tiles each, slabs in the caller's workspace.
+static bool tail_plan(const st355_gemm_args* a, const GemmP& p, GemmGroup& g, int* blocks) {
+  if (!tail_enabled() || !a->workspace || !a->tile_flags || ((uintptr_t)a->workspace % 16) || p.partial || p.scale_b || p.conv_taps || p.img_add) return false;
+  const int cus = device_cus();
+  const int T = p4_tiles(p), rounds = T / cus, rem = T % cus;
+  static int max_rounds = -1, min_tiles = -1;
+  if (max_rounds < 0) { const char* e = getenv("ST355_GEMM_TAIL_ROUNDS"); max_rounds = e ? atoi(e) : 6; }
+  if (min_tiles < 0) { const char* e = getenv("ST355_GEMM_TAIL_MIN_TILES"); min_tiles = e ? atoi(e) : 128; }       // problems below one round: from this many tiles
+  if (rem == 0 || 2 * rem > cus || rounds > max_rounds || T < min_tiles || rem > 1024) return false;
+  int s = cus / rem;
+  if (s > 4) s = 4;
+  const int nt_all = p.K / PQ_BK;
+  // the fix-up costs ~10 us at two slices and ~40 at four (three slabs per cut tile exceed the XCD's L2: measured r06), a tile ~28 us per 1000 of K: four slices pay from K ~ 4000
+  static int k4 = -1;
+  if (k4 < 0) { const char* e = getenv("ST355_GEMM_TAIL_K4"); k4 = e ? atoi(e) : 4096; }
+  if (p.K + p.K2 < k4 && s > 2) s = 2;
+  // below K ~ 2000 the cut round does not pay at all (r06: 16384 x 1280 x 1280+64: 74.7 us cut in two vs 76.9 uncut, 93.7 vs 83.0 with the residual-add epilogue)
+  static int kmin = -1;
+  if (kmin < 0) { const char* e = getenv("ST355_GEMM_TAIL_KMIN"); kmin = e ? atoi(e) : 2048; }
+  if (p.K + p.K2 < kmin) return false;
+  if (s > nt_all / 4) s = nt_all / 4;
+  if (s < 2) return false;
+  if ((nt_all + s - 1) / s * (s - 1) >= nt_all) return false;               // (every slice owns at least one K-tile)
+  if ((int64_t)rem * (s - 1) * PQ_BM * PQ_BN * 4 > a->workspace_bytes) return false;
+  g.p[0] = p; g.p[1] = p; g.tiles0 = T;
+  g.sk_first = rounds * cus; g.sk_s = s; g.sk_ws = (float*)a->workspace; g.sk_flags = (int*)a->tile_flags;
+  *blocks = g.sk_first + (rem + 7) / 8 * 8 * s;
+  return true;
+}
+
 static int run_one(void* stream, const st355_gemm_args* a) {
   if (thin_ok(a)) return launch_thin(stream, a);
   GemmP p = to_p(a);
@@ -2094,6 +2217,11 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   static int p3_lo = -1, p3_hi = -1;
   if (p3_lo < 0) { const char* e = getenv("ST355_GEMM_P3_WINDOW"); p3_lo = 0; p3_hi = 0; if (e) sscanf(e, "%d,%d", &p3_lo, &p3_hi); }
   const bool p3_window = p3_hi > 0 && p4_tiles(p) >= p3_lo && p4_tiles(p) < p3_hi;
+  if (gemm_impl_choice() >= 2 && !p3_window) {
+    GemmGroup g;
+    int blocks = 0;
+    if (tail_plan(a, p, g, &blocks)) { DISPATCH_EPI(launch_pq_sk, a->epilogue, stream, g, blocks); }
+  }
   if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256() && !p3_window) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
@@ -2106,6 +2234,12 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     DISPATCH_EPI(launch_p3, a->epilogue, stream, g, g.tiles0);
   }
   DISPATCH_EPI(launch_s2, a->epilogue, stream, p);
+}
+
+extern "C" int st355_gemm_set_tail_split(int mode) {
+  const int prev = g_tail_override;
+  g_tail_override = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
 }
 
 extern "C" int st355_gemm_set_persistent(int mode) {

@@ -276,7 +276,20 @@ def scale_cols(x, gate, rows_per_batch: int, out=None):
 # GEMM family
 # ------------------------------------------------------------------------------------------------
 _gemm_ws = {}
-_GEMM_WS_BYTES = 64 << 20
+_GEMM_WS_BYTES = 128 << 20           # (the stream-K tail of a 256x256-tile problem keeps up to 128 x 3 fp32 tile slabs: 96 MiB)
+_gemm_flags = {}
+
+
+def _gemm_tile_flags(dev):
+    """st355_gemm_args.tile_flags: 1024 arrival counters of the stream-K tail, zero once — every launch leaves them zero"""
+    f = _gemm_flags.get(dev.index)
+    if f is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _l.St355Error("the GEMM tile counters would be allocated inside a hipGraph capture: run one eager step first")
+        f = torch.zeros(1024, dtype=torch.int32, device=dev)
+        _gemm_flags[dev.index] = f
+    return f
+
 
 
 _ws_retired = []       # outgrown scratch buffers stay alive: a captured hipGraph may still hold their addresses
@@ -381,9 +394,10 @@ def _gemm_args(g, a, w, bias=None, out=None, epilogue: int = EPI_NONE, a2=None, 
             raise _l.St355Error("gemm: bias must be contiguous")
         g.bias = _ptr(bias)
     g.epilogue = epilogue
-    if N <= 128 and M >= 1024:
+    if (N <= 128 and M >= 1024) or (M * N >= 128 * 65536 and epilogue <= EPI_ADD):       # thin problems (split-K slabs); 128+ tiles of 256x256 (stream-K tail)
         ws = _gemm_workspace(a.device)
         g.workspace, g.workspace_bytes = _ptr(ws), ws.numel() * 4
+        g.tile_flags = _ptr(_gemm_tile_flags(a.device))
     if aux_out is not None:
         _chk(aux_out, BF16, "aux_out")
         _, _, g.ld_aux_out, sr, g.seg_out = _seg(aux_out, "aux_out")
@@ -433,6 +447,11 @@ def geglu_interleave(w, bias=None):
     wi = torch.stack([w[:F_].view(F_ // 32, 32, K), w[F_:].view(F_ // 32, 32, K)], dim=1).reshape(N2, K).contiguous()
     bi = None if bias is None else torch.stack([bias[:F_].view(F_ // 32, 32), bias[F_:].view(F_ // 32, 32)], dim=1).reshape(N2).contiguous()
     return wi, bi
+
+
+def gemm_set_tail_split(mode: int) -> int:
+    """st355_gemm_set_tail_split: 1 = stream-K tail where it applies (default), 0 = the uncut schedules, -1 = environment; returns the previous mode"""
+    return int(_l.load().st355_gemm_set_tail_split(int(mode)))
 
 
 def gemm_set_persistent(mode: int) -> int:

@@ -786,7 +786,7 @@ class UNet2DConditionModel(CheckpointPlanMixin, nn.Module):
                 o2 = self._cross_attn(T, q, kv, B, S, Sk, tr.heads)
             h = self._linear(T, blk.out2, o2, residual=h)
             n3 = self._ln(T, blk.norm3, h)
-            if blk.ff1.w_il is not None and n3.shape[0] >= 256:
+            if blk.ff1.w_il is not None:          # (at every row count: a replica's step and the concatenated batch's must take the same arithmetic path)
                 h = self._ffn_geglu_fused(T, blk, n3, h)
                 continue
             f = self._linear(T, blk.ff1, n3)

@@ -290,3 +290,61 @@ def test_gemm_head_split_epilogue_is_bit_equal_to_projection_then_head_split(ops
         assert torch.equal(Xq, Q)
         if with_vt:
             assert torch.equal(Xvt[..., :S], Vt[..., :S])
+
+
+@pytest.mark.parametrize("M,N,K,epi,lora,with_bias", [
+    (16384, 1280, 2560, "none", True, False),        # 320 tiles: one full round + 64 tiles cut in two (K + K2 < 4096), the adapter's K-extension on the last slice
+    (16384, 1280, 5120, "add", False, True),         # ... cut in four: the SDXL 32^2 level's feed-forward down projection at batch 16
+    (16384, 1280, 10240, "add", True, True),
+    (16000, 1280, 2048, "gelu", False, True),        # ragged last row tile: 315 tiles, 59 cut (the cut count is not a multiple of the 8 XCDs)
+    (16384, 1280, 1280, "none", True, False),        # short contraction: not cut (bit-equal)
+    (8192, 1280, 2560, "none", False, False),        # 160 tiles: below one round, more than half the chip -> not cut
+    (34816, 1536, 6144, "gate_residual", False, True),   # 816 tiles = 3 rounds + 48 tiles cut in four (SD3-Medium rows)
+    (32768, 256, 2048, "none", False, False),        # 128 tiles, no full round: every tile cut in two
+])
+def test_gemm_stream_k_tail_matches_the_uncut_schedule(ops, M, N, K, epi, lora, with_bias):
+    """the stream-K tail (k_gemm_pq<..., SK>): the tiles of a mostly empty last round cut along K over the idle CUs.  Against the uncut schedule (set_tail_split(0)):
+    the same products summed in fp32 with a different association — equal up to the bf16 rounding of the output (rel-L2 <= 2e-3 stated, measured ~1e-4; no element
+    more than 2 bf16 ulps apart where the value is not tiny), against fp32 torch within the suite's GEMM bound (5e-3); repeated launches are bit-identical (fixed
+    slice order, counters left at zero)."""
+    torch.manual_seed(66)
+    d_ = dev()
+    x = torch.randn(M, K, device=d_).to(BF16)
+    w = (torch.randn(N, K, device=d_) / math.sqrt(K)).to(BF16)
+    kw = {}
+    if with_bias:
+        kw["bias"] = torch.randn(N, device=d_).to(BF16)
+    if lora:
+        kw.update(a2=torch.randn(M, 64, device=d_).to(BF16), b2=(torch.randn(N, 64, device=d_) * 0.1).to(BF16))
+    ref = x.float() @ w.float().t()
+    if lora:
+        ref = ref + kw["a2"].float() @ kw["b2"].float().t()
+    if with_bias:
+        ref = ref + kw["bias"].float()
+    if epi == "add":
+        res = torch.randn(M, N, device=d_).to(BF16)
+        kw.update(epilogue=ops.EPI_ADD, aux_in=res)
+        ref = ref + res.float()
+    elif epi == "gelu":
+        kw.update(epilogue=ops.EPI_GELU)
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    elif epi == "gate_residual":
+        rpb = M // 8
+        res = torch.randn(M, N, device=d_).to(BF16); gate = torch.randn(8, N, device=d_).to(BF16)
+        kw.update(epilogue=ops.EPI_GATE_RESIDUAL, aux_in=res, gate=gate, rows_per_batch=rpb)
+        ref = res.float() + gate.float().repeat_interleave(rpb, dim=0) * ref
+    prev = ops.gemm_set_tail_split(0)
+    try:
+        y0 = ops.gemm(x, w, **kw)
+        ops.gemm_set_tail_split(1)
+        y1 = ops.gemm(x, w, **kw)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(x, w, **kw), y1), "repeated launches"
+    finally:
+        ops.gemm_set_tail_split(prev)
+    r = rel(y1, y0)
+    print(f"[parity] stream-K tail vs uncut {M}x{N}x{K} {epi}: rel_l2={r:.3e} vs fp32 {rel(y1, ref):.3e} (uncut vs fp32 {rel(y0, ref):.3e})")
+    assert r < 2e-3
+    big = y0.float().abs() > 0.05
+    assert float(((y1.float() - y0.float()).abs() / y0.float().abs().clamp_min(0.05))[big].max()) <= 2 ** -6
+    assert rel(y1, ref) < 5e-3
