@@ -159,7 +159,7 @@ def cpu_baseline(args, dev=None):
     from oracle import flux as OF
 
     # `cores` of the JSON = the intra-op threads actually used.  The GPU box shows 256 logical cpus but the container gets a fraction of them: measured r3
-    # (tools/probes/cpu_threads_probe.py, profiles/r03_cpu_threads_probe.log) an fp32 4608 x 3072 x 12288 linear runs at 1.51 / 1.68 / 1.30 / 0.95 / 0.47 TFLOP/s on
+    # (tools/probes/cpu_threads_probe.py, profiles/archive/r03_cpu_threads_probe.log) an fp32 4608 x 3072 x 12288 linear runs at 1.51 / 1.68 / 1.30 / 0.95 / 0.47 TFLOP/s on
     # 16 / 32 / 64 / 128 / 256 threads — 32 threads is the fastest this host gets, 256 is 3.6x slower
     cores = int(os.environ.get("ST355_CPU_LEG_THREADS", "0")) or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -471,8 +471,8 @@ def main():
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
         a3 = copy.copy(args)
-        # (eager at every N: one captured step per aspect bucket — `--buckets --graph` — does not fit: torch gives every capture its own ~40 GB of pool for this step and
-        # five of them next to the eager warm-up exceed the 288 GB, measured r5 with a shared pool handle as well; the single-bucket graph saves 12 ms of 336)
+        # (eager at every N: one captured step per aspect bucket — `--buckets --graph` — fits since r6 (every capture on ONE side stream + one shared pool: 84 GiB
+        # peak for the five bucket graphs) but buys nothing: 302.5 ms under replay against ~300 eager on the same tree — this step is not launch-bound)
         a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
         # Flux.1-dev FULL-rank (11.9 B bf16 parameters, AdamWBF16, per-GPU batch 8 — the configuration of the reference's multi-GPU Flux datapoint,
         # documentation/DISTRIBUTED.md:291-298): hand-written backward with every weight / bias / modulation / norm gradient, one fused optimizer launch over the

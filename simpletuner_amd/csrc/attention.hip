@@ -374,7 +374,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
   const float scale2 = scale * LOG2E;
   // k_attn_fwd4 (r02) is the general kernel; k_attn_fwd64 (r04) takes the head_dim-128, no-bias, S % 64 == 0 shapes.  The r01 kernel lives on in
   // tools/attn_fwd_variants.hip as the lab's A/B baseline (r02 lab, B8 H24 S4608 d128: 862 -> 927 TFLOP/s).  Measured and deleted in r02: an 8-wave /
-  // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/r02_attn_lab_*.log.
+  // 256-query workgroup variant (843 TFLOP/s) and an 8-wave LDS-DMA half-tile-stagger variant (738); logs under profiles/archive/r02_attn_lab_*.log.
   if (!vrow && !key_bias && !O_res && (d == 128 || d == 96) && S % 64 == 0 && attn_fwd_impl64() == 64) {      // hand-scheduled 64-queries-per-wave kernel
     dim3 grid64((Sq + 255) / 256, H, B);
     const int lds64 = 4 * 2 * 64 * 256;

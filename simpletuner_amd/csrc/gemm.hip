@@ -68,6 +68,7 @@ struct GemmP {
   // K-tile u reads the A rows shifted by (ty*Wp + tx) positions, tap = u / conv_tpt = 3*ty + tx (taps == 9; no shift when taps == 1);
   // the epilogue adds img_add[image, n] and writes ZERO on border positions.  conv_taps == 0: plain GEMM.
   int conv_taps, conv_tpt, conv_wp, conv_hp;
+  int skip_dead = 1;            // conv mode: waves whose 64 output columns lie beyond N issue no MFMAs (ST355_CONV_SKIP_DEAD=0: A/B)
   int64_t conv_row0;                            // grid position of GEMM row 0 (border test / image index)
   const bf16* img_add; int64_t img_add_stride;
   // segmented rows (st355_gemm_args.seg_rows): logical row m of the problem lives at physical row (m / seg_rows) * stride_X + m % seg_rows of operand X.
@@ -1112,6 +1113,9 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
 
   bf16x8 xf[2][4], w0f[4], w1f[4];
   long xf8[2][8], w0f8[8], w1f8[8];              // fp8 fragments (the unused set is dead code for the other instantiation)
+  // conv mode (the UNet's N = 320 / 640 channel counts: the last column tile is 64 / 128 of 256 wide): a wave whose 64 columns lie beyond N keeps staging and
+  // meeting the barriers but issues no MFMAs — its accumulators are never stored, and under the package power cap the matrix pipe's idle share is clock
+  const bool mma_live = !CONV || !p.skip_dead || (n0 + wn * 64 < N);
   TR_DECL;
 #define PQ_MMA(WF, I, J0, T, PH)                                                                              \
   do {                                                                                                        \
@@ -1125,7 +1129,7 @@ __global__ void __launch_bounds__(PQ_THREADS, 2) k_gemm_pq(GemmGroup g) {
       _Pragma("unroll") for (int ks = 0; ks < 8; ks++)                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
           acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(WF##8[ks], xf8[j][ks], acc[I][J0 + j], 0, 0, 0); \
-    } else                                                                                                    \
+    } else if (!CONV || mma_live)                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                        \
       _Pragma("unroll") for (int j = 0; j < 2; j++)                                                           \
         acc[I][J0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ks], xf[j][ks], acc[I][J0 + j], 0, 0, 0); \
@@ -1953,7 +1957,7 @@ static bool pz_ok(const GemmP& p, int tiles) {
   if (p.K / PQ_BK + p.K2 / PQ_BK < 4 || p.K / PQ_BK < 2 || p.conv_taps || p.scale_b || p.partial || p.img_add) return false;
   if (tiles <= device_cus()) return false;            // one round of tiles: nothing to overlap
   // long plain-K problems (the feed-forward down projections, K = 12288 with no K-extension): 96+ k-iterations amortise the one-tile-per-workgroup
-  // seam already and the dynamic workgroup dispatch balances the last round better — measured in-step (profiles/r03_flux_step_gemm_persistent_ab.txt):
+  // seam already and the dynamic workgroup dispatch balances the last round better — measured in-step (profiles/archive/r03_flux_step_gemm_persistent_ab.txt):
   // 1327 -> 1266 TFLOP/s under the persistent schedule, every other shape class +0.5 ... +8 %
   // (r5 A/B: a long contraction made of TWO segments — the Flux single block's proj_out, K = 3072 + K2 = 12288 — is the other way round: 1210-1214 TFLOP/s under the
   // persistent schedule, 1186-1200 on one tile per workgroup, same box, two runs each; it stays persistent)
@@ -2404,6 +2408,7 @@ extern "C" int st355_conv_bf16(void* stream, const void* x, const void* w, const
   p.bias = (const bf16*)bias;
   if (residual) { p.aux_in = (const bf16*)residual + p0 * Cout; p.ld_aux_in = Cout; }
   p.conv_taps = taps; p.conv_tpt = Cin / BK; p.conv_wp = Wp; p.conv_hp = Hp; p.conv_row0 = p0;
+  { static int sd = -1; if (sd < 0) { const char* e = getenv("ST355_CONV_SKIP_DEAD"); sd = (e && e[0] == '0') ? 0 : 1; } p.skip_dead = sd; }
   p.img_add = (const bf16*)img_add; p.img_add_stride = img_add_stride;
   // the first / last Wp+1 positions are border positions that no GEMM row covers: they keep the caller's zeros (grid buffers are allocated
   // zero-filled and no kernel ever writes a border position non-zero), which saves two memset launches per convolution

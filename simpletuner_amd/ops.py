@@ -276,7 +276,8 @@ def scale_cols(x, gate, rows_per_batch: int, out=None):
 # GEMM family
 # ------------------------------------------------------------------------------------------------
 _gemm_ws = {}
-_GEMM_WS_BYTES = 128 << 20           # (the stream-K tail of a 256x256-tile problem keeps up to 128 x 3 fp32 tile slabs: 96 MiB)
+_GEMM_WS_BYTES = 512 << 20           # ONE size for every caller (r5 advice: a smaller first request made a later one re-allocate under captured graphs): the largest
+                                     # user is the weight-gradient split-K (7 slices of a 6144 x 1536 gradient: 264 MB); the stream-K tail keeps up to 128 x 3 tile slabs (96 MiB)
 _gemm_flags = {}
 
 
@@ -546,7 +547,7 @@ def gemm_tn(Lm, R, out=None, accumulate: bool = False):
             raise _l.St355Error("gemm_tn: accumulate needs an output tensor")
         out = torch.empty(P, Q, dtype=BF16, device=Lm.device)
     _chk(out, BF16, "out")
-    ws = _gemm_workspace(Lm.device, 512 << 20)          # fp32 split-K slabs: up to 7 slices of a 6144 x 1536 gradient (264 MB)
+    ws = _gemm_workspace(Lm.device)                     # fp32 split-K slabs: up to 7 slices of a 6144 x 1536 gradient (264 MB)
     if seg_a or seg_b:
         seg = seg_a or seg_b
         if seg_a and seg_b and seg_a != seg_b:
@@ -1091,7 +1092,7 @@ def conv_wgrad(x, dy, dw, B: int, H: int, W: int, taps: int = 9, accumulate: boo
     Cin, Cout = x.shape[1], dy.shape[1]
     if tuple(dw.shape) != (Cout, taps * Cin) or not dw.is_contiguous():
         raise _l.St355Error(f"conv_wgrad: dw must be a contiguous [{Cout}, {taps * Cin}] tensor")
-    ws = _gemm_workspace(x.device, 256 << 20)
+    ws = _gemm_workspace(x.device)
     _l.check(L.st355_conv_wgrad_bf16(_stream(), _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, taps, 1 if accumulate else 0, _ptr(ws),
                                      ws.numel() * 4), "conv_wgrad_bf16")
     return dw

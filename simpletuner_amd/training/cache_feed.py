@@ -15,7 +15,7 @@ Here, per batch:
     encoder_attention_mask, filepaths, prompts, data_backend_id).
 `slots` batches are in flight (slab reuse is fenced by the previous copy's event), so file reads, host copies and DMA of batch i+1.. overlap the
 train step of batch i.  Caption dropout / conditioning inputs keep going through `assemble_batch` + `PinnedBatchStager` (collate.py) — same
-results, two more host copies.  Throughput evidence: tools/cache_feed_bench.py -> profiles/r02_cache_feed.json.
+results, two more host copies.  Throughput evidence: tools/cache_feed_bench.py -> profiles/archive/r02_cache_feed.json.
 """
 from __future__ import annotations
 

@@ -1,7 +1,7 @@
 """Pins tests/ops_emulator.py to the kernels it stands in for: the emulated wrappers on random operands, the emulator on the CPU against libst355 on the MI355X
 (bf16 rounding apart) — GEMM epilogues, the TN GEMM, token-axis reductions, AdaLN forward / backward, RMSNorm + RoPE forward / backward with the norm-weight gradients,
 attention forward / backward with a key bias, the UNet's grid-buffer ops (layout, GroupNorm, 3x3 convolution and its weight gradient, upsampling), the fused loss and AdamW.
-First run: round 3, `profiles/r03t_emulator_crosscheck.log` (5 passed).  The CPU host-sequencing tests then carry the kernels' semantics, not just the emulator's."""
+First run: round 3, `profiles/archive/r03t_emulator_crosscheck.log` (5 passed).  The CPU host-sequencing tests then carry the kernels' semantics, not just the emulator's."""
 import pytest
 import torch
 

@@ -5,7 +5,7 @@
 // multiplies of O when no row maximum of the wave moved).  Here a row is re-referenced only when its tile maximum exceeds the reference by more than STALE_BOUND
 // (log2 units), wave-uniformly: between re-references p = 2^(s - m_ref) may reach 2^STALE_BOUND instead of 1 — representable in bf16 at the same relative precision,
 // and numerator (O) and denominator (l) share the reference, so the normalised output and lse2 = m_ref + log2(l) are the same quantities.
-// Why: tools/isa_mix.py counts 1016 vector-ALU cycles against 1024 matrix-pipe cycles per wave and tile in the product loop (profiles/r03_isa_mix_hot_loops.md);
+// Why: tools/isa_mix.py counts 1016 vector-ALU cycles against 1024 matrix-pipe cycles per wave and tile in the product loop (profiles/archive/r03_isa_mix_hot_loops.md);
 // the accumulator rescale is 256 of them, the alpha / l_run bookkeeping a few more; with trained (peaked) score rows some row of the 32 moves in almost every tile,
 // so the exact-equality skip of the product rarely fires in the early tiles.
 // STATUS: written in round 3 after the GPU budget was spent — compiled for gfx950, NOT yet run.  tools/attn_lab times it and compares its O / lse2 with the product kernel.

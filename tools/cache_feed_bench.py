@@ -76,7 +76,7 @@ def main():
     run_direct()                                                   # warm the page cache and the pinned allocator for both paths
     n1, t1 = run_direct()
     n2, t2 = run_collate()
-    step_rate = 5.4                                                # images/s of one MI355X on the Flux LoRA step (profiles/r02_bench_line.json)
+    step_rate = 5.4                                                # images/s of one MI355X on the Flux LoRA step (profiles/archive/r02_bench_line.json)
     print(json.dumps({"what": "cache feed throughput, Flux-shaped latent + text-embed cache files on local disk (page cache warm)", "samples": a.samples,
                       "batch": a.batch, "workers": a.workers, "bytes_per_image": per_image,
                       "direct_feeder": {"images_per_s": round(n1 / t1, 1), "GB_per_s": round(n1 * per_image / t1 / 1e9, 2)},

@@ -2,7 +2,7 @@
 accumulator tile in 256 AGPRs), emitted with the same instruction-stream model as the attention bodies (tools/kgen/emit.py).
 
 Why it exists: the shipped GEMM (csrc/gemm.hip k_gemm_pq / k_gemm_pz: 8 waves as two ping-pong groups, 128 x 64 outputs per wave, hipcc-scheduled) keeps the
-matrix pipe 68-74 % busy (profiles/r03_gemm_pmc_mfma_lds.md).  The attention kernels went from 0.47 to 0.61-0.73 busy on a one-wave-per-SIMD structure whose
+matrix pipe 68-74 % busy (profiles/archive/r03_gemm_pmc_mfma_lds.md).  The attention kernels went from 0.47 to 0.61-0.73 busy on a one-wave-per-SIMD structure whose
 fragments feed more MFMAs each; the same structure for the GEMM reads 8 LDS fragments per 16 MFMAs (the shipped kernel: 6 per 8) and has no second wave group to
 synchronise with.  This generator + tools/gemm_kg_lab.hip MEASURE that structure's main loop before anybody rebuilds the product kernel's seven epilogues around it
 (DESIGN.md §7).  Not part of libst355.

@@ -18,3 +18,4 @@ done
 cd $R
 python tools/profile_summarise.py $out $tag
 cp profiles/${tag}_* $R/gpurun_out/ 2>/dev/null
+rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE      # the raw traces (hundreds of MB for the UNet steps) stay on the box: gpurun merges at most 64 MiB back
