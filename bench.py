@@ -459,21 +459,24 @@ def main():
         _log(f"{args.model}: workload done")
     if args.model == "flux" and not args.no_secondary:
         # the metric names "SDXL-LoRA & Flux-dev 1024^2": the SDXL-LoRA half rides along as a secondary measurement of the same run
-        # (r16 on attn1/attn2 to_q/to_k/to_v/to_out.0, a few steps; hipGraph replay at every N — the gradient exchange follows each replay).  Per-GPU batch 16: the UNet's
-        # 32^2 / 64^2 levels give a 256-CU chip too few tiles per launch at batch 4 (measured r02, same box: batch 4 / 8 / 16 = 23.8 / 29.9 / 37.3 images/s,
-        # GEMM class 496 / 613 / 820 TFLOP/s) and 288 GB holds batch 16 many times over; `--model sdxl --lora --rank 16 --batch 4` is configs[1]'s batch
+        # (r16 on attn1/attn2 to_q/to_k/to_v/to_out.0, a few steps; hipGraph replay at every N — the gradient exchange follows each replay).  Per-GPU batch 32 (r6; 16
+        # until r5, kept as the `same_tree_at_batch_16` field): the UNet's 32^2 / 64^2 levels give a 256-CU chip too few tiles per launch at small batches (measured
+        # r02, same box: batch 4 / 8 / 16 = 23.8 / 29.9 / 37.3 images/s; r06, same box and tree: batch 16 / 24 / 32 / 36 = 41.3 / 43.7 / 45.1 / 44.8 images/s) and the
+        # captured step of batch 32 peaks at 180 GiB of the 288; `--model sdxl --lora --rank 16 --batch 4` is configs[1]'s batch
         import copy
         import gc
         keys = ("metric", "value", "unit", "ms_per_step", "ms_per_step_stats", "steps", "warmup", "config", "step_model_tflops", "step_frac_of_bf16_mfma_peak",
                 "roofline", "loss", "peak_hbm_gib", "published_context", "comm")
         a2 = copy.copy(args)
-        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 16, False, True, False
+        a2.model, a2.lora, a2.rank, a2.batch, a2.full, a2.graph, a2.buckets = "sdxl", True, 16, 32, False, True, False
         # BASELINE.json configs[3]: SD3-Medium full fine-tune + EMA over the mixed aspect buckets — the full-parameter gradient exchange (2.0 B bf16 gradients
         # per step, reduce-scatter + all-gather buckets behind the backward) and the shared token-balanced bucket schedule run at every N the driver launches
         a3 = copy.copy(args)
         # (eager at every N: one captured step per aspect bucket — `--buckets --graph` — fits since r6 (every capture on ONE side stream + one shared pool: 84 GiB
         # peak for the five bucket graphs) but buys nothing: 302.5 ms under replay against ~300 eager on the same tree — this step is not launch-bound)
-        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 8, True, False, True
+        # per-GPU batch 16 (r6; 8 until r5, kept as `same_tree_at_batch_8`): the fused optimizer + EMA pass (9 ms over 2.0 B parameters) and the split-K weight gradients
+        # amortise over twice the tokens — r06, same box and tree: batch 8 / 12 / 16 / 24 / 32 = 26.7 / 28.3 / 28.8 / 29.4 / 29.9 images/s at 84 / 108 / 133 / 183 / 233 GiB
+        a3.model, a3.lora, a3.rank, a3.batch, a3.full, a3.graph, a3.buckets = "sd3", False, 32, 16, True, False, True
         # Flux.1-dev FULL-rank (11.9 B bf16 parameters, AdamWBF16, per-GPU batch 8 — the configuration of the reference's multi-GPU Flux datapoint,
         # documentation/DISTRIBUTED.md:291-298): hand-written backward with every weight / bias / modulation / norm gradient, one fused optimizer launch over the
         # parameter arena, and at N > 1 the whole 24 GB bf16 gradient arena exchanged per step (fp32-accumulating reduce-scatter + all-gather buckets behind the
@@ -503,6 +506,14 @@ def main():
                 if rank == 0:
                     out["secondary"][name] = {k: sec[k] for k in keys if k in sec}
                 del sec
+                if name in ("sdxl_lora", "sd3_full_buckets"):              # second field: the batch of rounds 2-5, same tree and box (round-over-round comparison)
+                    a7 = copy.copy(a_)
+                    a7.batch = 16 if name == "sdxl_lora" else 8
+                    gc.collect(); torch.cuda.empty_cache()
+                    sec = run_workload(a7, dev, rank, world)
+                    if rank == 0:
+                        out["secondary"][name][f"same_tree_at_batch_{a7.batch}"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "step_frac_of_bf16_mfma_peak", "loss", "peak_hbm_gib", "roofline") if k in sec}
+                    del sec
                 if name == "sd3_lora_r128_bs3_published_row":             # second field: the same row under the fused fp32 AdamW over the fp32 adapter arena
                     a6 = copy.copy(a_)
                     a6.optimizer = "st355-adamw"
@@ -722,6 +733,7 @@ def run_workload(args, dev, rank, world):
     if args.graph and not args.no_prof:
         trainer._use_graph = False
         trainer.optimizer.zero_grad(set_to_none=True)
+        trainer.release_graphs()                 # the captured step's pool (173 GiB at SDXL-LoRA batch 32) goes back before the eager step needs its own activations
         ops.prof_reset(); ops.prof_enable(True)
         trainer.train_step(dict(batches[0]))
         sync()
@@ -780,7 +792,7 @@ def run_workload(args, dev, rank, world):
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
                 # the committed PMC passes: of the default command, and of the metric's second workload (SDXL-LoRA, eager launches of the same kernels)
                 traffic, tsrc = (hbm_traffic_per_gemm_launch() if (args.model == "flux" and not args.full) else
-                                 hbm_traffic_per_gemm_launch("sdxl_lora") if (args.model == "sdxl" and args.lora) else (None, None))
+                                 hbm_traffic_per_gemm_launch("sdxl_lora") if (args.model == "sdxl" and args.lora and B == 16) else (None, None))     # (that counter pass is of batch 16; at batch 32 rocprofv3 --pmc aborts with an AQL packet error, r06)
                 roof = {"bound": "mfma", "kernel": "k_gemm_* (all schedules / epilogues)", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes / launch",
                         "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"])),

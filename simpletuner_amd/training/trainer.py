@@ -12,6 +12,8 @@ coefficient are folded into the optimizer kernel (grad_scale) instead of extra p
 """
 from __future__ import annotations
 
+import os
+import sys
 from types import SimpleNamespace
 from typing import Callable, Iterable, Optional
 
@@ -305,6 +307,14 @@ class Trainer:
         self.accelerator.backward(loss)
         return loss
 
+    def release_graphs(self) -> None:
+        """drop every captured step and the shared capture pool (their activations go back to the allocator): before eager steps that need the memory"""
+        import gc
+        self._graphs.clear()
+        self._graph_pool = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
     def _graph_forward_backward(self, prepared):
         def tensors(d, prefix=""):
             for k, v in d.items():
@@ -344,6 +354,9 @@ class Trainer:
                 p.grad = None
             torch.cuda.synchronize()
             torch.cuda.empty_cache()               # the eager warm-up's cached blocks go back before the capture builds its own pool
+            if os.environ.get("ST355_GRAPH_MEM_DEBUG"):
+                print(f"[graph] before capture: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, "
+                      f"peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
             g = torch.cuda.CUDAGraph()
             # one memory pool for every captured shape (mixed aspect buckets: one graph per bucket): the graphs never run concurrently, so the activations of
             # one capture are the next capture's free blocks — five private ~40 GB pools did not fit next to the model (r5), one shared pool does
