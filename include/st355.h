@@ -196,6 +196,11 @@ int st355_gemm_set_persistent(int mode);
 /* the stream-K tail of st355_gemm_bf16 (st355_gemm_args.tile_flags): 1 = on where it applies (default), 0 = off (the uncut schedules, bit-equal across shapes),
  * -1 = back to the environment (ST355_GEMM_TAIL).  Returns the previous mode. */
 int st355_gemm_set_tail_split(int mode);
+/* The tail's fix-up relies on the slices of a tile (workgroup ids congruent mod 8) running on one XCD.  libst355 checks that once per device, before the first cut
+ * launch: 512 probe workgroups record XCC_ID into `workspace`, the host compares them — ONE hipStreamSynchronize in the life of the process, never inside a stream
+ * capture (a capture that comes first keeps the uncut schedule).  Returns this device's state: 0 = not probed yet, 1 = confirmed (tail in use), 2 = not confirmed
+ * (uncut schedules for good). */
+int st355_gemm_tail_placement(void);
 
 /* ---- K19: fp8-native Linear (helpers/training/quantisation/fp8_native.py:25-119) ------------------------------------------------------
  * weights: OCP e4m3fn bytes [N,K] + one fp32 scale per output row (quantize_weight_to_fp8: scale = max(amax_row,1e-12)/448);

@@ -2150,9 +2150,44 @@ static int tail_enabled() {
   if (v < 0) { const char* e = getenv("ST355_GEMM_TAIL"); v = (e && e[0] == '0') ? 0 : 1; }
   return v;
 }
+// The fix-up of the stream-K tail is only correct when the slices of a tile (block ids congruent mod 8) run on ONE XCD — the hardware's round-robin dispatch of
+// consecutive workgroups over the 8 XCDs.  That is checked, not assumed: once per device, before the first cut launch, 512 probe workgroups record their XCC_ID
+// register and the host compares them (one stream synchronisation in the life of the process; never inside a hipGraph capture — a capture that arrives before
+// the probe has run simply keeps the uncut schedule).  A device that places workgroups differently (another partition mode) keeps the uncut schedule for good.
+__global__ void k_xcc_probe(int* out) {
+  int x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = x;
+}
+static std::atomic<int> g_tail_placement[32];  // per device: 0 = not probed, 1 = round-robin confirmed, 2 = not confirmed
+static int tail_placement_ok(void* stream, void* scratch) {
+  std::atomic<int>* ok = g_tail_placement;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return 0;
+  const int v = ok[d].load(std::memory_order_relaxed);
+  if (v) return v == 1;
+  if (const char* e = getenv("ST355_GEMM_TAIL_PROBE")) if (e[0] == '0') { ok[d] = 1; return 1; }      // lab: trust the placement
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
+  constexpr int NB = 512;
+  int host[NB];
+  hipLaunchKernelGGL(k_xcc_probe, dim3(NB), dim3(64), 0, (hipStream_t)stream, (int*)scratch);
+  if (hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    (void)hipGetLastError();
+    ok[d] = 2;
+    return 0;
+  }
+  bool good = true;
+  for (int b = 8; b < NB && good; b++) good = host[b] == host[b & 7];
+  for (int i = 0; i < 8 && good; i++)
+    for (int j = 0; j < i && good; j++) good = host[i] != host[j];
+  ok[d] = good ? 1 : 2;
+  return good;
+}
+
 // true: run `p` as g (blocks = *blocks).  The last round of 256x256 tiles is cut when it fills at most half the chip and the problem is short enough for that
 // round to matter (<= 6 full rounds before it); 2..4 slices of >= 4 K-tiles each, slabs in the caller's workspace.
-static bool tail_plan(const st355_gemm_args* a, const GemmP& p, GemmGroup& g, int* blocks) {
+static bool tail_plan(void* stream, const st355_gemm_args* a, const GemmP& p, GemmGroup& g, int* blocks) {
   if (!tail_enabled() || !a->workspace || !a->tile_flags || ((uintptr_t)a->workspace % 16) || p.partial || p.scale_b || p.conv_taps || p.img_add) return false;
   const int cus = device_cus();
   const int T = p4_tiles(p), rounds = T / cus, rem = T % cus;
@@ -2178,7 +2213,7 @@ static bool tail_plan(const st355_gemm_args* a, const GemmP& p, GemmGroup& g, in
   g.p[0] = p; g.p[1] = p; g.tiles0 = T;
   g.sk_first = rounds * cus; g.sk_s = s; g.sk_ws = (float*)a->workspace; g.sk_flags = (int*)a->tile_flags;
   *blocks = g.sk_first + (rem + 7) / 8 * 8 * s;
-  return true;
+  return tail_placement_ok(stream, a->workspace) != 0;
 }
 
 static int run_one(void* stream, const st355_gemm_args* a) {
@@ -2224,7 +2259,7 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   if (gemm_impl_choice() >= 2 && !p3_window) {
     GemmGroup g;
     int blocks = 0;
-    if (tail_plan(a, p, g, &blocks)) { DISPATCH_EPI(launch_pq_sk, a->epilogue, stream, g, blocks); }
+    if (tail_plan(stream, a, p, g, &blocks)) { DISPATCH_EPI(launch_pq_sk, a->epilogue, stream, g, blocks); }
   }
   if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256() && !p3_window) {
     GemmGroup g;
@@ -2238,6 +2273,12 @@ static int run_one(void* stream, const st355_gemm_args* a) {
     DISPATCH_EPI(launch_p3, a->epilogue, stream, g, g.tiles0);
   }
   DISPATCH_EPI(launch_s2, a->epilogue, stream, p);
+}
+
+extern "C" int st355_gemm_tail_placement(void) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return 2;
+  return g_tail_placement[d].load(std::memory_order_relaxed);
 }
 
 extern "C" int st355_gemm_set_tail_split(int mode) {

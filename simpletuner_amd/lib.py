@@ -20,7 +20,7 @@ SYMBOLS = [
     "st355_flow_noise_mix", "st355_ddpm_noise_mix", "st355_mse_loss", "st355_cond_loss", "st355_cond_loss_masked",
     "st355_flux_pack", "st355_flux_unpack", "st355_patchify", "st355_unpatchify",
     "st355_timestep_proj", "st355_silu", "st355_gelu_tanh", "st355_silu_bwd", "st355_add", "st355_gather_rows", "st355_scatter_rows", "st355_scale_cols",
-    "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_set_persistent", "st355_gemm_set_tail_split", "st355_gemm_tn_bf16", "st355_gemm_tn_seg_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_stats_workspace", "st355_ln_modulate_bwd_stats", "st355_scale_cols_stats", "st355_colsum_rows", "st355_transpose_bf16", "st355_sum_chunks_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg", "st355_skinny_tn_multi",
+    "st355_gemm_bf16", "st355_gemm_bf16_grouped", "st355_gemm_set_persistent", "st355_gemm_set_tail_split", "st355_gemm_tail_placement", "st355_gemm_tn_bf16", "st355_gemm_tn_seg_bf16", "st355_fp8_quantize_weight", "st355_fp8_quantize_act", "st355_linear_fp8", "st355_colsum_workspace", "st355_colsum_prod", "st355_stats_workspace", "st355_ln_modulate_bwd_stats", "st355_scale_cols_stats", "st355_colsum_rows", "st355_transpose_bf16", "st355_sum_chunks_bf16", "st355_skinny_tn_workspace", "st355_skinny_tn", "st355_skinny_tn_seg", "st355_skinny_tn_multi",
     "st355_ln_modulate_fwd", "st355_ln_modulate_bwd",
     "st355_qk_norm_rope_fwd", "st355_qk_norm_rope_bwd", "st355_qk_norm_wgrad_workspace", "st355_qk_norm_rope_bwd_wgrad", "st355_qk_rope_norm_bwd",
     "st355_attn_set_impl", "st355_attn_fwd", "st355_attn_fwd_vrows", "st355_attn_bwd_workspace", "st355_attn_bwd", "st355_attn_bwd_rope",
@@ -294,6 +294,7 @@ def _declare(lib):
         "st355_gemm_bf16_grouped": (C.c_int, [vp, C.POINTER(GemmArgs), i32]),
         "st355_gemm_set_persistent": (C.c_int, [i32]),
         "st355_gemm_set_tail_split": (C.c_int, [i32]),
+        "st355_gemm_tail_placement": (C.c_int, []),
         "st355_colsum_workspace": (sz, [i64, i32, i64]),
         "st355_colsum_prod": (C.c_int, [vp, vp, i64, vp, i64, i64, i32, i64, vp, i64, i32, vp, i64, vp, vp, i64, i32, vp]),
         "st355_stats_workspace": (sz, [i64, i32, i64, i32]),

@@ -455,6 +455,11 @@ def gemm_set_tail_split(mode: int) -> int:
     return int(_l.load().st355_gemm_set_tail_split(int(mode)))
 
 
+def gemm_tail_placement() -> int:
+    """st355_gemm_tail_placement: 0 = the XCD placement probe has not run on this device, 1 = round-robin confirmed (stream-K tail in use), 2 = not confirmed"""
+    return int(_l.load().st355_gemm_tail_placement())
+
+
 def gemm_set_persistent(mode: int) -> int:
     """st355_gemm_set_persistent: 1 = persistent tile walk (k_gemm_pz) where it applies, 0 = one tile per workgroup, -1 = default; returns the previous mode"""
     return int(_l.load().st355_gemm_set_persistent(int(mode)))

@@ -342,6 +342,7 @@ def test_gemm_stream_k_tail_matches_the_uncut_schedule(ops, M, N, K, epi, lora, 
             assert torch.equal(ops.gemm(x, w, **kw), y1), "repeated launches"
     finally:
         ops.gemm_set_tail_split(prev)
+    assert ops.gemm_tail_placement() in (0, 1), "the XCD placement probe refused the stream-K tail on this device"      # (0: no launch of this process was cut yet)
     r = rel(y1, y0)
     print(f"[parity] stream-K tail vs uncut {M}x{N}x{K} {epi}: rel_l2={r:.3e} vs fp32 {rel(y1, ref):.3e} (uncut vs fp32 {rel(y0, ref):.3e})")
     assert r < 2e-3
