@@ -207,6 +207,113 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_apply_bwd(const bf16* __restr
   }
 }
 
+
+// ---- row-walking apply passes (r6) ----
+// The first form (k_gn_apply_fwd / k_gn_apply_bwd above, kept for A/B: ST355_GN_APPLY=1) maps one flat index to (position, channel chunk): two integer divisions, the
+// border test and 16 (forward) / 40 (backward) scalar loads of per-channel statistics and coefficients for every 16 bytes of payload — 3.3 TB/s in the SDXL-LoRA step
+// (rocprofv3 r06: 23.6 ms of a 700 ms step at batch 32).  Here a thread OWNS its 8 channels (statistics, gamma / beta, coefficients in registers, loaded once) and
+// walks the rows of its chunk of one image; the grid position advances incrementally (no division in the loop); loads are unconditional (a border position of a grid
+// buffer holds zero; a token-layout operand is read at a clamped row) and the border is a select.  Same arithmetic in the same order: bit-identical outputs.
+__global__ void __launch_bounds__(GN_THREADS) k_gn_apply_fwd_rows(const bf16* __restrict__ x, const float* __restrict__ stats, const bf16* __restrict__ gamma,
+                                                                const bf16* __restrict__ beta, bf16* __restrict__ y, int H, int W, int C, int silu, int out_tokens,
+                                                                int rows_per_chunk, int cw, int RT) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int Wp = W + 2, rows_img = (H + 2) * Wp;
+  const int r0 = chunk * rows_per_chunk, r1 = min(rows_img, r0 + rows_per_chunk);
+  const int c8 = C / 8;
+  const int ch = blockIdx.z * cw + (int)threadIdx.x % cw, rl = (int)threadIdx.x / cw;
+  if (ch >= c8 || rl >= RT) return;
+  float mu[8], rs[8], ga[8], be[8];
+  {
+    const bf16x8 gv = *(const bf16x8*)(gamma + ch * 8), bv = *(const bf16x8*)(beta + ch * 8);
+    const float* st = stats + ((int64_t)b * C + ch * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { mu[j] = st[2 * j]; rs[j] = st[2 * j + 1]; ga[j] = bf2f(gv[j]); be[j] = bf2f(bv[j]); }
+  }
+  int r = r0 + rl;
+  int yy = r / Wp, xx = r - yy * Wp;
+  const bf16* xp = x + ((int64_t)b * rows_img) * C + ch * 8;
+  for (; r < r1; r += RT) {
+    const bool inside = yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+    const bf16x8 xv = *(const bf16x8*)(xp + (int64_t)r * C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float z = (bf2f(xv[j]) - mu[j]) * rs[j] * ga[j] + be[j];
+      if (silu) z = silu_f(z);
+      o[j] = f2bf(inside ? z : 0.f);
+    }
+    if (out_tokens) {
+      if (inside) *(bf16x8*)(y + (((int64_t)b * H + yy - 1) * W + xx - 1) * C + ch * 8) = o;
+    } else {
+      *(bf16x8*)(y + ((int64_t)b * rows_img + r) * C + ch * 8) = o;
+    }
+    xx += RT;
+    while (xx >= Wp) { xx -= Wp; yy++; }
+  }
+}
+
+__global__ void __launch_bounds__(GN_THREADS) k_gn_apply_bwd_rows(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ stats,
+                                                                const bf16* __restrict__ gamma, const bf16* __restrict__ beta, const float* __restrict__ coef,
+                                                                const bf16* __restrict__ dadd, bf16* __restrict__ dx, int H, int W, int C, int silu, int dy_tokens,
+                                                                int rows_per_chunk, int cw, int RT) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int Wp = W + 2, rows_img = (H + 2) * Wp;
+  const int r0 = chunk * rows_per_chunk, r1 = min(rows_img, r0 + rows_per_chunk);
+  const int c8 = C / 8;
+  const int ch = blockIdx.z * cw + (int)threadIdx.x % cw, rl = (int)threadIdx.x / cw;
+  if (ch >= c8 || rl >= RT) return;
+  float mu[8], rs[8], ga[8], be[8], c1[8], c2[8], c3[8];
+  {
+    const bf16x8 gv = *(const bf16x8*)(gamma + ch * 8), bv = *(const bf16x8*)(beta + ch * 8);
+    const float* st = stats + ((int64_t)b * C + ch * 8) * 2;
+    const float* cf = coef + ((int64_t)b * C + ch * 8) * 3;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      mu[j] = st[2 * j]; rs[j] = st[2 * j + 1]; ga[j] = bf2f(gv[j]); be[j] = bf2f(bv[j]);
+      c1[j] = cf[3 * j]; c2[j] = cf[3 * j + 1]; c3[j] = cf[3 * j + 2];
+    }
+  }
+  int r = r0 + rl;
+  int yy = r / Wp, xx = r - yy * Wp;
+  const int64_t img0 = (int64_t)b * rows_img;
+  for (; r < r1; r += RT) {
+    const bool inside = yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+    const int64_t pos = img0 + r;
+    const int64_t drow = dy_tokens ? (inside ? ((int64_t)b * H + yy - 1) * W + xx - 1 : 0) : pos;
+    const bf16x8 xv = *(const bf16x8*)(x + pos * C + ch * 8);
+    const bf16x8 dv = *(const bf16x8*)(dy + drow * C + ch * 8);
+    bf16x8 av;
+    if (dadd) av = *(const bf16x8*)(dadd + pos * C + ch * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float xh = (bf2f(xv[j]) - mu[j]) * rs[j];
+      float g = bf2f(dv[j]);
+      if (silu) g *= silu_grad_f(xh * ga[j] + be[j]);
+      float d = c1[j] * g + c2[j] * xh + c3[j];
+      if (dadd) d += bf2f(av[j]);
+      o[j] = f2bf(inside ? d : 0.f);
+    }
+    *(bf16x8*)(dx + pos * C + ch * 8) = o;
+    xx += RT;
+    while (xx >= Wp) { xx -= Wp; yy++; }
+  }
+}
+static int gn_apply_form() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ST355_GN_APPLY"); v = (e && e[0] == '1') ? 1 : 2; }
+  return v;
+}
+// launch geometry of the row-walking passes: channel windows of <= 256 chunks of equal width, RT rows per pass
+static void gn_rows_geom(int C, int* nwin, int* cw, int* RT) {
+  const int c8 = C / 8;
+  *nwin = (c8 + GN_THREADS - 1) / GN_THREADS;
+  *cw = (c8 + *nwin - 1) / *nwin;
+  *RT = GN_THREADS / *cw;
+  if (*RT < 1) *RT = 1;
+}
+
 static int gn_chunks(int B, int H, int W, int* rows_per_chunk) {
   const int rows_img = (H + 2) * (W + 2);
   int nch = (768 + B - 1) / B;
@@ -234,6 +341,13 @@ extern "C" int st355_groupnorm_fwd(void* stream, const void* x, const void* gamm
                      (const bf16*)nullptr, (const bf16*)nullptr, partial, H, W, C, rpc, nch, 0, 0);
   hipLaunchKernelGGL(k_gn_finalize_fwd, dim3(groups, B), dim3(64), 0, (hipStream_t)stream, (const float*)partial, stats, C, groups, nch,
                      (float)((double)H * W * (C / groups)), eps);
+  if (gn_apply_form() == 2) {
+    int nwin, cw, RT;
+    gn_rows_geom(C, &nwin, &cw, &RT);
+    hipLaunchKernelGGL(k_gn_apply_fwd_rows, dim3(nch, B, nwin), dim3(cw * RT), 0, (hipStream_t)stream, (const bf16*)x, (const float*)stats, (const bf16*)gamma,
+                       (const bf16*)beta, (bf16*)y, H, W, C, silu, out_tokens, rpc, cw, RT);
+    return st355_check_launch("groupnorm_fwd");
+  }
   const int64_t n = (int64_t)B * (H + 2) * (W + 2) * (C / 8);
   hipLaunchKernelGGL(k_gn_apply_fwd, dim3((unsigned)std::min<int64_t>(cdiv64(n, GN_THREADS), 65536)), dim3(GN_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
                      (const float*)stats, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, B, H, W, C, silu, out_tokens);
@@ -256,6 +370,13 @@ extern "C" int st355_groupnorm_bwd(void* stream, const void* dy, const void* x, 
                      (float)((double)H * W * (C / groups)));
   if (dgamma && dbeta)
     hipLaunchKernelGGL(k_gn_param_grads, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)partial, dgamma, dbeta, B, C, nch, accumulate_params);
+  if (gn_apply_form() == 2) {
+    int nwin, cw, RT;
+    gn_rows_geom(C, &nwin, &cw, &RT);
+    hipLaunchKernelGGL(k_gn_apply_bwd_rows, dim3(nch, B, nwin), dim3(cw * RT), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, stats, (const bf16*)gamma,
+                       (const bf16*)beta, (const float*)coef, (const bf16*)dadd, (bf16*)dx, H, W, C, silu, dy_tokens, rpc, cw, RT);
+    return st355_check_launch("groupnorm_bwd");
+  }
   const int64_t n = (int64_t)B * (H + 2) * (W + 2) * (C / 8);
   hipLaunchKernelGGL(k_gn_apply_bwd, dim3((unsigned)std::min<int64_t>(cdiv64(n, GN_THREADS), 65536)), dim3(GN_THREADS), 0, (hipStream_t)stream, (const bf16*)x,
                      (const bf16*)dy, stats, (const bf16*)gamma, (const bf16*)beta, (const float*)coef, (const bf16*)dadd, (bf16*)dx, B, H, W, C, silu, dy_tokens);
