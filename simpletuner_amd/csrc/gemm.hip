@@ -2110,7 +2110,15 @@ __global__ void __launch_bounds__(256) k_gemm_thin(const bf16* __restrict__ A, i
 static bool thin_ok(const st355_gemm_args* a) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("ST355_GEMM_THIN"); on = (e && e[0] == '0') ? 0 : 1; }          // A/B: 0 = the split-K tile path
-  return on && (a->N == 64 || a->N == 128) && a->K2 == 0 && a->epilogue == ST355_EPI_NONE && !a->bias && !a->seg_rows && a->K >= 256 && a->M >= 1024 &&
+  // N = 128 (three adapters of a fused projection): a 64-row workgroup re-reads the whole [128, K] weight block — at Flux's K = 3072 that is 2x the bytes of its A
+  // rows through the CU's L1, and the launch ran 262 us against ~130 on the tile schedules (rocprofv3 r06: +14 ms per Flux step); at the SDXL shapes it was a wash
+  // (75.5 vs 74.1 us at K = 3840).  So N = 128 stays on the tile schedules (ST355_GEMM_THIN128=1: A/B)
+  static int on128 = -1;
+  if (on128 < 0) { const char* e = getenv("ST355_GEMM_THIN128"); on128 = (e && e[0] == '1') ? 1 : 0; }
+  // N = 64: wins where the tile path needs a split-K + reduce pair or K is long (SDXL 32^2 level at batch 16: 19.7 vs 21.2 us; Flux M = 36 864, K = 3072: -3 ms per
+  // step); with 32 768+ rows of a short K the tile schedules fill the chip by themselves (SDXL-LoRA batch 32: 659.8 ms without it vs 664.7, same box, r06)
+  if (a->N == 64 && a->M > 24576 && a->K < 2048 && !on128) return false;
+  return on && (a->N == 64 || (a->N == 128 && on128)) && a->K2 == 0 && a->epilogue == ST355_EPI_NONE && !a->bias && !a->seg_rows && a->K >= 256 && a->M >= 1024 &&
          a->ldc % 8 == 0 && ((uintptr_t)a->C % 16 == 0);
 }
 static int launch_thin(void* stream, const st355_gemm_args* a) {
