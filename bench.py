@@ -445,6 +445,16 @@ def main():
         else:
             # nccl == RCCL over xGMI on ROCm; a collective that a peer never joins aborts after 10 minutes (the watchdog raises on every rank) instead of waiting forever
             dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
+    single_rank_pg = world == 1 and os.environ.get("ST355_BENCH_SINGLE_RANK_PG") == "1"
+    if single_rank_pg:
+        # lab hook for a 1-GPU box: a torch.distributed nccl (= RCCL) group of ONE rank, with GradSync issuing every bucket's collectives anyway
+        # (ST355_COMM_SINGLE_RANK): the overlapped exchange of the real step at its real arena size runs over RCCL — stream ordering, work handles, the
+        # comm-stream join — and `comm` on the line gives the collectives' own device time (no peer, so no wire time); the step's numbers must not move
+        import tempfile
+        os.environ["ST355_COMM_SINGLE_RANK"] = "1"
+        os.environ.setdefault("ST355_COMM_TIMING", "1")
+        dist.init_process_group(backend="nccl", init_method=f"file://{tempfile.mkdtemp()}/pg", rank=0, world_size=1, device_id=dev,
+                                timeout=datetime.timedelta(seconds=600))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree (n_gpus in the JSON line is the rank count)")
     if world > 1:
@@ -549,8 +559,15 @@ def main():
                     others[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             out["parity_at_other_configs"] = others
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        # RCCL writes its version banner through C stdio: with stdout redirected to a file or pipe those bytes sit in libc's buffer until exit and would land AFTER
+        # the JSON line (seen on the MI355X, r06) — flush them out first so that the JSON line is the last line of stdout at every N
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:               # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -745,7 +762,7 @@ def run_workload(args, dev, rank, world):
             ops.prof_dump(args.prof_dump)
         ops.prof_reset()
     comm_rep = None
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         gs_ = getattr(plugin.get_trained_component(), "grad_sync", None)
         rep_ = gs_.overlap_report() if gs_ is not None else None      # the LAST timed step's exchange (device timestamps; synchronises)
         if rep_ is not None:
@@ -831,7 +848,7 @@ def run_workload(args, dev, rank, world):
             out["note"] = ("coverage row, not a speed row: the fp8-native trunk is byte-exact to the reference's quantisers but 7 % SLOWER than bf16 end to end "
                            "(400.4 vs 374.0 ms, same box: profiles/r05_pixart_2k_fp8_ab.txt) — the per-call amax + quantise passes cost more than the forward third "
                            "of the trunk's GEMMs gains on the fp8 pipe")
-        if world > 1:
+        if world > 1 or comm_rep is not None:
             out["comm"] = comm_rep
         pub = published_row(args)
         if pub is not None and world == 1:

@@ -1018,6 +1018,27 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         sync = self.grad_sync
         if sync is not None:
             sync.ready(self._head_arena_lo, self.grad_arena.numel())        # proj_out gradients are final
+        # The fused modulation matrix (every block's adaLN Linear as rows of ONE [mod_total, D] matrix: a third of SD3-Medium's parameters, 1.35 GB of gradient) gets its
+        # gradient rows block by block (r6) — dW_mod[r0:r1] = dmod[:, r0:r1]^T silu(temb) as soon as the block that owns rows [r0, r1) has run — so that the exchange
+        # can take them behind the backward; as one product at the end of the backward the whole region left as one exposed 1.5 GB slice.  Same arithmetic per row
+        # (one 64-deep contraction over the zero-padded batch), so the gradient is bit-equal to the one-product form.
+        Bp = (B + 63) // 64 * 64
+        st_p = torch.zeros(Bp, D, dtype=BF16, device=dev); st_p[:B] = ctx.emb.st
+        mw_lo = (self.mod_w.data_ptr() - self.arena.data_ptr()) // 2
+        mw_hi = mw_lo + self.mod_total * D
+        mod_rows_lo = [self.mod_total]                    # rows [mod_rows_lo, mod_total) of dW_mod are written (and handed over)
+
+        def mod_rows_grad(r0):
+            r1 = mod_rows_lo[0]
+            if r1 <= r0:
+                return
+            dp = torch.zeros(Bp, r1 - r0, dtype=BF16, device=dev); dp[:B] = dmod[:, r0:r1]
+            ops.gemm_tn(dp, st_p, out=self.g_mod_w[r0:r1])
+            mod_rows_lo[0] = r0
+            if sync is not None and 0 <= mw_lo and mw_hi <= self._blocks_arena_lo:
+                sync.ready(mw_lo + r0 * D, mw_lo + r1 * D)
+
+        mod_rows_grad(self.mod_off_out)                   # norm_out's (scale, shift) rows: final since mod_grads above
         for li in range(len(self.blocks) - 1, -1, -1):
             if ctx.blocks[li] is None:
                 self._recompute_segment(ctx, li)
@@ -1028,9 +1049,11 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
             Si, S, Sp = ctx.envs[li].Si, ctx.envs[li].S, ctx.envs[li].Sp
             blk, sv = self.blocks[li], ctx.blocks[li]
             ctx.blocks[li] = None
-            if sync is not None and li + 1 < len(self.blocks):
+            if li + 1 < len(self.blocks):
                 nb = self.blocks[li + 1]
-                sync.ready(nb.arena_lo, nb.arena_hi)                          # the block processed last iteration: its slice can go out
+                if sync is not None:
+                    sync.ready(nb.arena_lo, nb.arena_hi)                      # the block processed last iteration: its slice can go out
+                mod_rows_grad(nb.mod_off)                                     # ... and so can its rows of the modulation matrix
             mi = mod[:, blk.mod_off:blk.mod_off + 6 * D]; dmi = dmod[:, blk.mod_off:blk.mod_off + 6 * D]
             nct = 2 if blk.last else 6
             mt = mod[:, blk.mod_off_c:blk.mod_off_c + nct * D]; dmt = dmod[:, blk.mod_off_c:blk.mod_off_c + nct * D]
@@ -1143,10 +1166,8 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         wgrad(self.l_patch, d_img, em.patches)                              # PatchEmbed conv == GEMM on the patches; the position table is a buffer
         wgrad(self.l_ctx, d_txt, em.enc2d)
         # modulation linear: mod = silu(temb) W_mod^T + b
-        Bp = (B + 63) // 64 * 64
         dmod_p = torch.zeros(Bp, self.mod_total, dtype=BF16, device=dev); dmod_p[:B] = dmod
-        st_p = torch.zeros(Bp, D, dtype=BF16, device=dev); st_p[:B] = em.st
-        ops.gemm_tn(dmod_p, st_p, out=self.g_mod_w)
+        mod_rows_grad(0)                                                    # block 0's rows (every other block's went out behind the block after it)
         tb = torch.empty(1, self.mod_total, dtype=F32, device=dev)
         ops.colsum_prod(dmod_p, tb)
         self.g_mod_b.copy_(tb[0])
@@ -1169,7 +1190,11 @@ class SD3Transformer2DModel(CheckpointPlanMixin, nn.Module):
         mlp_bwd(self.l_t1, self.l_t2, em.tproj, em.t1, em.st1, dtemb)
         mlp_bwd(self.l_p1, self.l_p2, em.pooled, em.p1, em.sp1, dtemb)
         if sync is not None:
-            sync.ready(0, self.blocks[0].arena_hi)                            # embedders, modulation matrix, block 0
+            if 0 <= mw_lo and mw_hi <= self._blocks_arena_lo:                 # embedders, modulation bias, block 0: what lies around the modulation matrix's rows
+                sync.ready(mw_hi, self.blocks[0].arena_hi)
+                sync.ready(0, mw_lo)
+            else:
+                sync.ready(0, self.blocks[0].arena_hi)
         return None
 
     # ------------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ def hand_over_gradients(model, arena: torch.Tensor) -> torch.Tensor:
 
 class GradSync:
     def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, process_group=None, mode: str = "auto", comm=None,
-                 fp32_reduce: Optional[bool] = None):
+                 fp32_reduce: Optional[bool] = None, single_rank_exchange: Optional[bool] = None):
         if mode not in ("auto", "allreduce", "rs_ag"):
             raise ValueError(f"GradSync mode {mode!r}: expected auto / allreduce / rs_ag")
         self.flat = flat_grad
@@ -70,8 +70,14 @@ class GradSync:
             mode = "rs_ag" if flat_grad.numel() * flat_grad.element_size() >= RS_AG_MIN_BYTES else "allreduce"
         self.mode = mode
         self._works: List = []
-        self._lo: Optional[int] = None   # pending [lo, hi) finished-but-unsent region
-        self._hi: Optional[int] = None
+        self._pending: List[List[int]] = []   # finished-but-unsent regions [lo, hi), disjoint, in the order they were opened (adjacent ready() ranges merge into them)
+        # no collective is issued over more than max_slice_elems elements (ST355_COMM_MAX_SLICE_MB, default 256 MiB): a region that grew past it — the 1.5 GB front of the
+        # SD3-Medium arena (embedders + the fused modulation matrix) — goes out as consecutive sub-slices.  Found on the MI355X in r06
+        # (tools/probes/rccl_large_slice_probe.py): all_to_all_single over RCCL 2.26.6 delivers only the first HALF of a per-peer chunk larger than 1 GiB (a 1531 MiB
+        # chunk arrived intact up to 766 MiB, a 2 GiB one up to 1 GiB; all-reduce / reduce-scatter / all-gather were right at every size tried), so the
+        # fp32-accumulating form silently summed garbage for the tail of such a slice.  The cap also bounds the receive buffer of that form.
+        env_cap = os.environ.get("ST355_COMM_MAX_SLICE_MB")
+        self.max_slice_elems = max(1, (int(env_cap) if env_cap else 256) * (1 << 20) // flat_grad.element_size())
         self.launched_slices: List = []  # (lo, hi) of every exchange issued in the current backward (tests inspect it)
         self.launched_ops: List = []     # ("all_reduce" | "reduce_scatter" | "all_gather", lo, hi) in issue order
         # explicit comm stream (device arenas only): collectives are enqueued behind an event of the compute stream, never on it
@@ -86,6 +92,11 @@ class GradSync:
         self.fp32_reduce = default if fp32_reduce is None else bool(fp32_reduce)
         self._recv: Optional[torch.Tensor] = None
         self._fp32_fallback_logged = False
+        # a world of ONE normally exchanges nothing.  single_rank_exchange (or ST355_COMM_SINGLE_RANK=1) issues every collective anyway: on a 1-GPU box this is
+        # the only way the stream-ordered branch below (async work handles parked until finish(), the comm-stream join, the all-to-all + fp32 sum form) runs over
+        # RCCL itself rather than over gloo — a 1-rank SUM leaves the arena as it was, so the step's numbers must not move (tests/test_distributed_gpu.py)
+        env1 = os.environ.get("ST355_COMM_SINGLE_RANK")
+        self.single_rank_exchange = bool(env1 and env1 != "0") if single_rank_exchange is None else bool(single_rank_exchange)
         self.timing = bool(os.environ.get("ST355_COMM_TIMING")) and flat_grad.is_cuda
         self._ev_begin = self._ev_end = None
         self._ev_slices: List = []
@@ -103,7 +114,7 @@ class GradSync:
         return dist.get_rank(self.pg) if dist.is_available() and dist.is_initialized() else 0
 
     def begin(self):
-        self._works, self._lo, self._hi, self.launched_slices, self.launched_ops, self._comm_used = [], None, None, [], [], False
+        self._works, self._pending, self.launched_slices, self.launched_ops, self._comm_used = [], [], [], [], False
         if self.timing:
             self._ev_begin = torch.cuda.Event(enable_timing=True)
             self._ev_begin.record(torch.cuda.current_stream(self.flat.device))
@@ -132,11 +143,21 @@ class GradSync:
         return torch.cuda.stream(self.comm_stream)
 
     def _fire(self, lo: int, hi: int):
+        """hand [lo, hi) to the exchange, in sub-slices of at most max_slice_elems (cut on multiples of 8 * world elements from `lo`, so that an 8-aligned region keeps
+        every sub-slice eligible for the fp32-accumulating form)"""
+        W = max(1, self.world_size)
+        step = max(8 * W, self.max_slice_elems // (8 * W) * (8 * W))
+        while hi - lo > step:
+            self._fire_one(lo, lo + step)
+            lo += step
+        self._fire_one(lo, hi)
+
+    def _fire_one(self, lo: int, hi: int):
         if hi <= lo:
             return
         self.launched_slices.append((lo, hi))
         W = self.world_size
-        if W <= 1 or not self.enabled:
+        if not self.enabled or W < 1 or (W == 1 and not (self.single_rank_exchange and (self.comm is not None or (dist.is_available() and dist.is_initialized())))):
             return
         with self._comm_ctx():
             ev0 = None
@@ -224,19 +245,30 @@ class GradSync:
                 self.launched_ops.append(("all_reduce", lo + m, hi))
 
     def ready(self, lo: int, hi: int):
-        """the backward finished gradient elements [lo, hi) (any order; adjacent regions are merged)"""
-        if self._lo is None:
-            self._lo, self._hi = lo, hi
-        elif hi == self._lo:
-            self._lo = lo
-        elif lo == self._hi:
-            self._hi = hi
-        else:                                  # not adjacent: flush what we have, start a new region
-            self._fire(self._lo, self._hi)
-            self._lo, self._hi = lo, hi
-        if self._hi - self._lo >= self.bucket_elems:
-            self._fire(self._lo, self._hi)
-            self._lo = self._hi = None
+        """the backward finished gradient elements [lo, hi) (any order).  A range adjacent to a pending region merges into it; a range adjacent to none opens a
+        new one — several regions may be pending at once (the SD3 full fine-tune walks its blocks AND the rows of its fused modulation matrix back to front, two
+        interleaved descending sequences); a region goes out as soon as it holds a bucket's worth.  The slices and their order depend only on the sequence of
+        ready() calls, which is the same on every replica."""
+        if hi <= lo:
+            return
+        for r in self._pending:
+            if hi == r[0]:
+                r[0] = lo
+                break
+            if lo == r[1]:
+                r[1] = hi
+                break
+        else:
+            r = [lo, hi]
+            self._pending.append(r)
+        for q in self._pending:                      # a range that closed the gap between two pending regions joins them
+            if q is not r and (q[1] == r[0] or r[1] == q[0]):
+                r[0], r[1] = min(r[0], q[0]), max(r[1], q[1])
+                self._pending.remove(q)
+                break
+        if r[1] - r[0] >= self.bucket_elems:
+            self._pending.remove(r)
+            self._fire(r[0], r[1])
 
     def all_reduce_now(self, flat: torch.Tensor):
         """blocking SUM of an arbitrary flat tensor over the group (the boundary step of a gradient accumulation: training.ddp_seam)"""
@@ -262,9 +294,9 @@ class GradSync:
     def finish(self) -> float:
         """flush, join the comm stream back into the compute stream (device-side for nccl) and return the factor the optimizer must fold
         in (1/world_size)"""
-        if self._lo is not None:
-            self._fire(self._lo, self._hi)
-            self._lo = self._hi = None
+        for r in self._pending:
+            self._fire(r[0], r[1])
+        self._pending = []
         if self.timing and self._ev_begin is not None:
             self._ev_end = torch.cuda.Event(enable_timing=True)
             self._ev_end.record(torch.cuda.current_stream(self.flat.device))     # the last backward kernel has been enqueued: everything after is exposed comm

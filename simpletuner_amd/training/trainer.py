@@ -141,7 +141,10 @@ class Trainer:
                                                                             or self.accelerator.num_processes == 1)
         if self.accelerator.num_processes > 1:
             sync_module_states(comp)                                     # replicas start from rank 0's weights (DDP construction semantics)
-        if self.accelerator.num_processes > 1 and self._overlapped_sync:
+        # ST355_COMM_SINGLE_RANK=1 under an initialised process group of ONE rank: the exchange is set up and issued anyway (GradSync.single_rank_exchange) — how a
+        # 1-GPU box runs this step's collectives over RCCL itself; a 1-rank SUM changes nothing, so the step's numbers are those of the plain single-process step
+        single_rank = self.accelerator.num_processes == 1 and dist.is_available() and dist.is_initialized() and _os.environ.get("ST355_COMM_SINGLE_RANK", "0") not in ("", "0")
+        if (self.accelerator.num_processes > 1 or single_rank) and self._overlapped_sync:
             # replicas: bucketed all-reduce of the flat gradient arena, overlapped with the hand-written backward
             import os
             comm = None

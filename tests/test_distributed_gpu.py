@@ -340,3 +340,106 @@ def test_two_ranks_with_block_entry_points_and_the_comm_stream_hand_over():
     assert ops0 == ops1 == ["all_reduce"]
     assert torch.equal(w0, w1)                                                     # identical reduced gradients -> identical adapters on both ranks
     assert all(math.isfinite(x) for x in l0 + l1) and l0[-1] < l0[0]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# r06: torch.distributed's OWN nccl (= RCCL) backend on the one GPU a lease has.  A process group of one rank with GradSync.single_rank_exchange: every
+# collective of the stream-ordered branch (async work handles parked until finish(), comm-stream join, reduce-scatter + all-gather, the all-to-all +
+# st355_sum_chunks_bf16 + all-gather fp32 form, the tail all-reduce) is ISSUED over RCCL and must leave a 1-rank SUM = the arena as it was; a Flux LoRA step and
+# a full fine-tune step driven through Trainer under ST355_COMM_SINGLE_RANK=1 must reproduce the plain single-process step bit for bit.
+# ------------------------------------------------------------------------------------------------------------------------
+def _nccl_single_rank_worker(rank, world, init_file, out_dir):
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"file://{init_file}", rank=0, world_size=1, device_id=dev)
+    from simpletuner_amd.training.grad_sync import GradSync
+    os.environ["ST355_COMM_TIMING"] = "1"
+    rep = {"backend": str(dist.get_backend()), "cases": []}
+    for dt, mode, fp32 in ((torch.float32, "allreduce", False), (torch.float32, "rs_ag", False), (torch.bfloat16, "rs_ag", False), (torch.bfloat16, "rs_ag", True),
+                           (torch.bfloat16, "allreduce", False)):
+        torch.manual_seed(7)
+        flat = torch.randn(1_000_003, device=dev).to(dt)
+        want = flat.clone()
+        gs = GradSync(flat, bucket_bytes=flat.element_size() * 200_000, mode=mode, fp32_reduce=fp32, single_rank_exchange=True)
+        assert gs._stream_ordered()
+        for _ in range(2):                                     # twice: the parked work handles and the receive buffer of the fp32 form are reused
+            gs.begin()
+            hi = flat.numel()
+            gs.ready(hi - 3, hi)                               # the backward's first region ends 3 elements past an 8-element boundary: every later one starts aligned
+            hi -= 3
+            while hi > 0:
+                lo = max(0, hi - 100_000)
+                gs.ready(lo, hi)
+                hi = lo
+            scale = gs.finish()
+            torch.cuda.synchronize()
+            assert scale == 1.0
+            assert torch.equal(flat, want), (dt, mode, fp32)
+        kinds = sorted({k for k, _, _ in gs.launched_ops})
+        orep = gs.overlap_report()
+        assert orep is not None and len(orep["slices"]) == len(gs.launched_slices) and orep["comm_ms"] > 0
+        covered = sum(hi_ - lo_ for lo_, hi_ in gs.launched_slices)
+        assert covered == flat.numel()
+        rep["cases"].append({"dtype": str(dt), "mode": mode, "fp32_reduce": fp32, "ops": kinds, "slices": len(gs.launched_slices), "comm_ms": orep["comm_ms"]})
+    # the train step: SDXL-style UNet LoRA (lora_grad_flat, fp32) with and without the exchange
+    os.environ["ST355_COMM_SINGLE_RANK"] = "0"
+    flat0, losses0, _, _ = _unet_graph_run(0, 1, False)
+    os.environ["ST355_COMM_SINGLE_RANK"] = "1"
+    flat1, losses1, _, _ = _unet_graph_run(0, 1, False)
+    rep["unet_lora_bit_equal"] = bool(torch.equal(flat0, flat1)) and losses0 == losses1
+    # ... and an SD3 full fine-tune (bf16 gradient arena, 128 MiB buckets) + the fp32-accumulating form
+    for fp32 in ("0", "1"):
+        outs = []
+        for single in ("0", "1"):
+            os.environ["ST355_COMM_SINGLE_RANK"], os.environ["ST355_FP32_REDUCE"] = single, fp32
+            outs.append(_sd3_full_run())
+        rep[f"sd3_full_bit_equal_fp32_reduce_{fp32}"] = bool(torch.equal(outs[0][0], outs[1][0])) and outs[0][1] == outs[1][1]
+        rep[f"sd3_full_ops_fp32_reduce_{fp32}"] = outs[1][2]
+        assert outs[0][2] == [] and outs[1][2] != []
+    os.environ.pop("ST355_FP32_REDUCE", None)
+    torch.save(rep, os.path.join(out_dir, "nccl1.pt"))
+    dist.destroy_process_group()
+
+
+def _sd3_full_run():
+    from tests import parity_utils as PU
+    from simpletuner_amd.sd3.model import SD3
+    from simpletuner_amd.training.trainer import St355Accelerator, Trainer, default_config
+    import simpletuner_amd.training.grad_sync as GS
+    dev = torch.device("cuda", 0)
+    cfg = default_config(model_family="sd3", model_type="full", train_batch_size=2, learning_rate=_LR, seed=3, use_ema=False)
+    acc = St355Accelerator(dev)
+    plugin = SD3(cfg, acc)
+    plugin.load_model(sample_size=32, num_layers=2, num_attention_heads=2, attention_head_dim=64, joint_attention_dim=128, caption_projection_dim=128,
+                      pooled_projection_dim=64, pos_embed_max_size=24)
+    plugin.enable_full_finetune()
+    GS.RS_AG_MIN_BYTES = 1                                    # the tiny arena takes the reduce-scatter + all-gather form of the 4-5 GB ones
+    tr = Trainer(cfg, plugin, acc)
+    GS.RS_AG_MIN_BYTES = 1 << 30
+    comp = plugin.get_trained_component()
+    _, devt = PU.make_inputs(2, 16, 16, 32, 128, 64, dev, seed=9)
+    sig = devt["sigmas"].contiguous()
+    plugin.sample_flow_sigmas = lambda batch, state: (sig, sig * 1000.0)
+    losses = []
+    for i in range(3):
+        losses.append(float(tr.train_step({"latent_batch": devt["latents"].contiguous(), "prompt_embeds": devt["prompt"].contiguous(),
+                                           "add_text_embeds": devt["pooled"].contiguous(), "noise": devt["noise"].contiguous()})))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1).float() for p in tr.params]).cpu()
+    sync = getattr(comp, "grad_sync", None)
+    return flat, losses, ([] if sync is None else sorted({k for k, _, _ in sync.launched_ops}))
+
+
+def test_torch_nccl_backend_single_rank_runs_the_stream_ordered_exchange_over_rccl():
+    with tempfile.TemporaryDirectory() as d:
+        init = os.path.join(d, "init")
+        mp.spawn(_nccl_single_rank_worker, args=(1, init, d), nprocs=1, join=True)
+        rep = torch.load(os.path.join(d, "nccl1.pt"))
+    assert rep["backend"] == "nccl"
+    by = {(c["dtype"], c["mode"], c["fp32_reduce"]): c for c in rep["cases"]}
+    assert by[("torch.float32", "allreduce", False)]["ops"] == ["all_reduce"]
+    assert by[("torch.bfloat16", "rs_ag", False)]["ops"] == ["all_gather", "reduce_scatter"]
+    assert by[("torch.bfloat16", "rs_ag", True)]["ops"] == ["all_gather", "all_reduce", "all_to_all"]        # 1 000 003 elements: the 3-element tail rides an all-reduce
+    assert rep["unet_lora_bit_equal"]
+    assert rep["sd3_full_bit_equal_fp32_reduce_0"] and rep["sd3_full_bit_equal_fp32_reduce_1"]
+    print("nccl single rank:", rep)
