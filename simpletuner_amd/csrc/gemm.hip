@@ -2264,12 +2264,18 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   static int p3_lo = -1, p3_hi = -1;
   if (p3_lo < 0) { const char* e = getenv("ST355_GEMM_P3_WINDOW"); p3_lo = 0; p3_hi = 0; if (e) sscanf(e, "%d,%d", &p3_lo, &p3_hi); }
   const bool p3_window = p3_hi > 0 && p4_tiles(p) >= p3_lo && p4_tiles(p) < p3_hi;
-  if (gemm_impl_choice() >= 2 && !p3_window) {
+  // N <= 128 (the N = 128 adapter projections of a long batch: 36 864 x 128 x 3072 in the Flux step, 95 launches): a 256x256 tile would carry 128 dead columns —
+  // half of its staging and MFMAs — on 144 workgroups; the 256x128 schedule is the one that fits (lab r3: 65 us; the 256-wide rule took these problems over when its
+  // tile threshold went from 200 to 128 in r3 and ran them at ~130 us in-step).  ST355_GEMM_N128_P3=0: A/B
+  static int n128_p3 = -1;
+  if (n128_p3 < 0) { const char* e = getenv("ST355_GEMM_N128_P3"); n128_p3 = (e && e[0] == '0') ? 0 : 1; }
+  const bool narrow = n128_p3 && p.N <= P3_BN && p.K2 == 0 && gemm_impl_choice() >= 1 && p.M > 128 && p3_tiles(p) >= 128;
+  if (gemm_impl_choice() >= 2 && !p3_window && !narrow) {
     GemmGroup g;
     int blocks = 0;
     if (tail_plan(stream, a, p, g, &blocks)) { DISPATCH_EPI(launch_pq_sk, a->epilogue, stream, g, blocks); }
   }
-  if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256() && !p3_window) {
+  if (gemm_impl_choice() >= 2 && p4_tiles(p) >= min_tiles_256() && !p3_window && !narrow) {
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
     DISPATCH_EPI(launch_256, a->epilogue, stream, g, g.tiles0);
