@@ -2107,6 +2107,155 @@ __global__ void __launch_bounds__(256) k_gemm_thin(const bf16* __restrict__ A, i
     *(bf16x8*)(C + (int64_t)(m0 + row) * ldc + c) = o;
   }
 }
+// k_gemm_rows (r6): the same problem with the ROWS split over the waves instead of K.  A workgroup of two waves owns 64 rows, each wave 32 of them over the whole K
+// (no partial sums to meet: k_gemm_thin spends four barriers and two 64 x N fp32 round trips through LDS per 64 rows, a third of its time at K = 1280); the
+// [N, 64] weight K-tile is staged ONCE per workgroup in LDS (XOR-swizzled 16-byte chunks: the 8 lanes a ds_read_b128 serves per clock hit 8 distinct chunks) and
+// double-buffered — one barrier per K-tile —, the A fragments go from global memory straight to registers one K-tile ahead.  128-thread workgroups, 16 / 32 KiB
+// of LDS: 4+ workgroups per CU keep the A stream's loads in flight.  Same lane -> k mapping as k_gemm_thin (a lane owns 64 contiguous bytes of its row per K-tile).
+template <int NT>
+__global__ void __launch_bounds__(128) k_gemm_rows(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb, bf16* __restrict__ C, int64_t ldc,
+                                                  int M, int K) {
+  constexpr int N = 32 * NT;
+  constexpr int WCH = N * 8 / 128;                               // 16-byte chunks of a weight K-tile per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x [N rows x 128 B] weight K-tiles; afterwards 2 x [32 rows x N] fp32 output staging
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int m0 = blockIdx.x * 64 + wv * 32;
+  const int nkt = K / 64;
+  // A: COALESCED requests (8 lanes per 128-byte row segment of the K-tile; a row-per-lane request touches 32 lines for 16 bytes each) into registers three
+  // K-tiles ahead, through the wave's own swizzled LDS slice one K-tile ahead, read back as MFMA fragments (row l31, chunks 4 khalf .. 4 khalf + 3)
+  const bf16* asrc[4];
+  int adst[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int idx = lane + 64 * c, row = idx >> 3, ch = idx & 7;
+    asrc[c] = A + (int64_t)min(m0 + row, M - 1) * lda + ch * 8;
+    adst[c] = row * 128 + ((ch ^ (row & 7)) << 4);
+  }
+  int ard[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) ard[q] = l31 * 128 + (((khalf * 4 + q) ^ (l31 & 7)) << 4);
+  char* abuf = smem + 2 * (N * 128) + wv * 8192;                 // this wave's two 4-KiB A K-tiles
+  const bf16* wsrc[WCH];
+  int wdst[WCH];
+#pragma unroll
+  for (int c = 0; c < WCH; c++) {
+    const int idx = tid + 128 * c, row = idx >> 3, ch = idx & 7;
+    wsrc[c] = B + (int64_t)row * ldb + ch * 8;
+    wdst[c] = row * 128 + ((ch ^ (row & 7)) << 4);
+  }
+  int wrd[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = 32 * i + l31;
+      wrd[i][q] = col * 128 + (((khalf * 4 + q) ^ (col & 7)) << 4);
+    }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  // rings: A chunks three K-tiles ahead in registers (x[t & 3]), weight chunks two ahead (wr[t & 1]); both are put into LDS one K-tile ahead (buffers t & 1)
+  bf16x8 x[4][4], wr[2][WCH];
+  auto load_x = [&](int t, bf16x8 (&xx)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) xx[c] = *(const bf16x8*)(asrc[c] + t * 64);
+  };
+  auto load_w = [&](int t, bf16x8 (&ww)[WCH]) {
+#pragma unroll
+    for (int c = 0; c < WCH; c++) ww[c] = *(const bf16x8*)(wsrc[c] + t * 64);
+  };
+  auto put_x = [&](int buf, bf16x8 (&xx)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) *(bf16x8*)(abuf + buf * 4096 + adst[c]) = xx[c];
+  };
+  auto put_w = [&](int buf, bf16x8 (&ww)[WCH]) {
+#pragma unroll
+    for (int c = 0; c < WCH; c++) *(bf16x8*)(smem + buf * (N * 128) + wdst[c]) = ww[c];
+  };
+  auto mma = [&](int buf) {
+    const char* wb = smem + buf * (N * 128);
+    const char* ab = abuf + buf * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bf16x8 xf = *(const bf16x8*)(ab + ard[q]);
+#pragma unroll
+      for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wb + wrd[i][q]), xf, acc[i], 0, 0, 0);
+    }
+  };
+  // branch-free body (nkt % 4 == 0, the launcher checks): requests past the last K-tile are clamped to it — a conditional request makes the compiler's
+  // s_waitcnt bookkeeping assume the shorter queue at every join and the counted waits collapse to vmcnt(0)
+  const int last = nkt - 1;
+  load_w(0, wr[0]);
+  load_x(0, x[0]);
+  load_w(min(1, last), wr[1]);
+  load_x(min(1, last), x[1]);
+  load_x(min(2, last), x[2]);
+  put_w(0, wr[0]);
+  put_x(0, x[0]);
+  __syncthreads();
+  for (int t0 = 0; t0 < nkt; t0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = t0 + u;
+      load_w(min(t + 2, last), wr[u & 1]);
+      load_x(min(t + 3, last), x[(u + 3) & 3]);
+      mma(u & 1);
+      put_w((u + 1) & 1, wr[(u + 1) & 1]);
+      put_x((u + 1) & 1, x[(u + 1) & 3]);
+      __syncthreads();
+    }
+  }
+  // acc[i][4a + b] = D[feature 32 i + 8 a + 4 khalf + b][token l31]: through the wave's [32 tokens x N] fp32 slice (the weight buffers are idle: every wave passed
+  // the last barrier), then 16-byte row stores
+  float* st = (float*)smem + (size_t)wv * 32 * N;
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      f32x4 v;
+#pragma unroll
+      for (int b = 0; b < 4; b++) v[b] = acc[i][4 * a + b];
+      const int cch = (32 * i + 8 * a + 4 * khalf) >> 2;                       // 16-byte chunk of the token's fp32 row, swizzled by the token
+      *(f32x4*)(st + (size_t)l31 * N + ((cch ^ (l31 & 7)) << 2)) = v;
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                                          // lgkmcnt(0): the wave reads back what its own lanes wrote
+  __builtin_amdgcn_wave_barrier();
+  constexpr int n8 = N / 8;
+  for (int idx = lane; idx < 32 * n8; idx += 64) {
+    const int row = idx / n8, c8 = idx % n8;
+    if (m0 + row >= M) continue;
+    const f32x4 lo = *(const f32x4*)(st + (size_t)row * N + (((2 * c8) ^ (row & 7)) << 2)), hi = *(const f32x4*)(st + (size_t)row * N + (((2 * c8 + 1) ^ (row & 7)) << 2));
+    bf16x8 o;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { o[b] = f2bf(lo[b]); o[4 + b] = f2bf(hi[b]); }
+    *(bf16x8*)(C + (int64_t)(m0 + row) * ldc + c8 * 8) = o;
+  }
+}
+// Measured r6 (tools/probes/rows_gemm_bench.py, operands flushed from the caches between launches; same box): 32768 x 64 x 1280 46.0 -> 35.7 us, 16384 x 64 x 1280
+// 26.3 -> 21.6, 32768 x 128 x 1280 49.1 -> 40.9; from K ~ 3000 the tile schedules win at N = 128 (36864 x 128 x 9216: 211 vs 252 us) and k_gemm_thin is level at
+// N = 64 (the Flux step did not move).  In-step, same box: SDXL-LoRA batch 32 695.4 -> 690.7 ms.  So: N = 64 / 128 with K < 2048.
+static int rows_mode() {          // ST355_GEMM_ROWS: 0 = off, 1 (default) = K < 2048, 2 = every K, 64 / 128 = that width only (every K)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ST355_GEMM_ROWS"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static bool rows_ok(const st355_gemm_args* a) {
+  const int m = rows_mode();
+  if (!m || !(a->N == 64 || a->N == 128) || (m > 2 && m != a->N) || (m == 1 && a->K >= 2048)) return false;
+  return a->K2 == 0 && a->epilogue == ST355_EPI_NONE && !a->bias && !a->seg_rows && a->K >= 256 && a->K % 256 == 0 && a->M >= 1024 && a->ldc % 8 == 0 &&
+         a->lda % 8 == 0 && a->ldb % 8 == 0 && ((uintptr_t)a->C % 16 == 0) && ((uintptr_t)a->A % 16 == 0) && ((uintptr_t)a->B % 16 == 0);
+}
+static int launch_rows(void* stream, const st355_gemm_args* a) {
+  const dim3 grid((a->M + 63) / 64), block(128);
+  if (a->N == 64)
+    hipLaunchKernelGGL((k_gemm_rows<2>), grid, block, 2 * 64 * 128 + 16384, (hipStream_t)stream, (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, (bf16*)a->C, a->ldc, a->M, a->K);
+  else
+    hipLaunchKernelGGL((k_gemm_rows<4>), grid, block, 2 * 128 * 128 + 16384, (hipStream_t)stream, (const bf16*)a->A, a->lda, (const bf16*)a->B, a->ldb, (bf16*)a->C, a->ldc, a->M, a->K);
+  return st355_check_launch("gemm_rows");
+}
 static bool thin_ok(const st355_gemm_args* a) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("ST355_GEMM_THIN"); on = (e && e[0] == '0') ? 0 : 1; }          // A/B: 0 = the split-K tile path
@@ -2225,6 +2374,7 @@ static bool tail_plan(void* stream, const st355_gemm_args* a, const GemmP& p, Ge
 }
 
 static int run_one(void* stream, const st355_gemm_args* a) {
+  if (rows_ok(a)) return launch_rows(stream, a);
   if (thin_ok(a)) return launch_thin(stream, a);
   GemmP p = to_p(a);
   // thin problems (the LoRA rank-space projections: N <= 128, K in the thousands) stream A once and have only M/128 tiles: split

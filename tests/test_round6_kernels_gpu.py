@@ -213,9 +213,9 @@ def test_geglu_inside_the_feed_forward_gemms(ops, M, K, F):
     assert rel(g1, ref) < 4e-3
 
 
-@pytest.mark.parametrize("M,K", [(16384, 1280), (65536, 640), (16384, 3840), (1024, 256), (5000, 704)])
+@pytest.mark.parametrize("M,K", [(16384, 1280), (65536, 640), (16384, 3840), (1024, 256), (5000, 704), (16421, 1280), (1061, 512), (4096, 1792)])
 def test_thin_rank_space_gemm(ops, M, K):
-    """k_gemm_thin (N = 64: the LoRA down projections x A^T and dY (sB)): one streaming pass over the activations, against fp32 torch (bf16 output rounding + the
+    """k_gemm_rows (K < 2048, K % 256 == 0: rows split over the waves, operands staged through LDS — ragged last row blocks included) / k_gemm_thin (N = 64: the LoRA down projections x A^T and dY (sB)): one streaming pass over the activations, against fp32 torch (bf16 output rounding + the
     fp32 accumulation order of four interleaved K partials: rel-L2 <= 4e-3), its N = 128 form, and the tile path through an N = 256 problem whose first columns are
     the same products."""
     torch.manual_seed(67)
