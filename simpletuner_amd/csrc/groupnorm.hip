@@ -49,22 +49,37 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_stats(const bf16* __restrict_
           ga[j] = bf2f(gv[j]); be[j] = bf2f(bv[j]);
         }
       }
-      for (int r = r0 + rl; r < r1; r += RT) {
-        const int64_t pos = (int64_t)b * rows_img + r;
-        const bf16x8 xv = *(const bf16x8*)(x + pos * C + ch * 8);
-        if (MODE == 0) {
+      // four rows per trip: all their requests leave before the first sum needs one (one request in flight per thread kept 12 KB per CU outstanding — the stats
+      // passes ran at 2.0-3.5 TB/s, rocprofv3 r6); the sums are still taken row by row in the same order: bit-identical partials
+      for (int r = r0 + rl; r < r1; r += 4 * RT) {
+        bf16x8 xv[4], dv[4];
+        bool ok[4];
 #pragma unroll
-          for (int j = 0; j < 8; j++) { const float v = bf2f(xv[j]); s0[j] += v; s1[j] += v * v; }
-        } else {
-          int64_t drow = pos;
-          if (dy_tokens) { drow = token_of(pos, H, W); if (drow < 0) continue; }
-          const bf16x8 dv = *(const bf16x8*)(dy + drow * C + ch * 8);
+        for (int u = 0; u < 4; u++) {
+          const int rr = r + u * RT;
+          ok[u] = rr < r1;
+          const int64_t pos = (int64_t)b * rows_img + (ok[u] ? rr : r);
+          xv[u] = *(const bf16x8*)(x + pos * C + ch * 8);
+          if (MODE == 1) {
+            int64_t drow = pos;
+            if (dy_tokens) { drow = token_of(pos, H, W); if (drow < 0) { ok[u] = false; drow = 0; } }
+            dv[u] = *(const bf16x8*)(dy + drow * C + ch * 8);
+          }
+        }
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float xh = (bf2f(xv[j]) - mu[j]) * rs[j];
-            float g = bf2f(dv[j]);
-            if (silu) g *= silu_grad_f(xh * ga[j] + be[j]);
-            s0[j] += g; s1[j] += g * xh;
+        for (int u = 0; u < 4; u++) {
+          if (!ok[u]) continue;
+          if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float v = bf2f(xv[u][j]); s0[j] += v; s1[j] += v * v; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float xh = (bf2f(xv[u][j]) - mu[j]) * rs[j];
+              float g = bf2f(dv[u][j]);
+              if (silu) g *= silu_grad_f(xh * ga[j] + be[j]);
+              s0[j] += g; s1[j] += g * xh;
+            }
           }
         }
       }
