@@ -321,12 +321,13 @@ class GradSync:
             self.enabled = old
 
 
-def sync_module_states(module: torch.nn.Module, src: int = 0, process_group=None, chunk_bytes: int = 1 << 30) -> int:
+def sync_module_states(module: torch.nn.Module, src: int = 0, process_group=None, chunk_bytes: int = 256 << 20) -> int:
     """What DDP does once at construction (torch's `_sync_module_states`, reached from accelerator.prepare, trainer.py:4515): every replica
     starts from rank `src`'s parameters and buffers.  Parameters here are views into a few large arenas (weights, K-extended LoRA columns,
     optimizer-ordered trainables), so the broadcast walks the distinct underlying STORAGES as raw bytes — a handful of GB-sized
     broadcasts over xGMI instead of thousands of per-tensor ones — and therefore also carries arena padding / fused columns that are not
-    registered parameters.  Returns the number of bytes broadcast (0 when not distributed)."""
+    registered parameters.  Returns the number of bytes broadcast (0 when not distributed).  256 MiB per broadcast: the same bound GradSync keeps on every
+    collective since RCCL's point-to-point path was seen delivering half of a > 1 GiB chunk (GradSync.max_slice_elems)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
         return 0
     seen, total = set(), 0
