@@ -1331,8 +1331,12 @@ __device__ __forceinline__ void gemm_epilogue_lds8(const GemmP& p, f32x16 (&acc)
     for (int b = 0; b < 8; b++) bias8[b] = bf2f(bv[b]);
   }
   const int m_first = mw0 + rrow;
-  bf16* c_row = p.C + (int64_t)m_first * p.ldc + n;
-  const bf16* in_row = p.aux_in ? p.aux_in + (int64_t)m_first * p.ld_aux_in + n : nullptr;
+  // ST355_EPI_GEGLU_GRAD (r6, as gemm_epilogue_geglu_grad of the one-tile-per-workgroup kernel): the lane's 8 features 8 rc .. 8 rc + 7 of the wave's 64 are group
+  // rc >> 2, offset 8 (rc & 3) of the interleaved pre-activation — value columns nc, gate columns nc + 32 of both the kept pre-activation and C (d value | d gate)
+  constexpr bool GG = EPI == ST355_EPI_GEGLU_GRAD;
+  const int nc = GG ? 2 * nw0 + 64 * (rc >> 2) + (rc & 3) * 8 : n;
+  bf16* c_row = p.C + (int64_t)m_first * p.ldc + nc;
+  const bf16* in_row = p.aux_in ? p.aux_in + (int64_t)m_first * p.ld_aux_in + nc : nullptr;
   bf16* out_row = p.aux_out ? p.aux_out + (int64_t)m_first * p.ld_aux_out + n : nullptr;
   const int64_t c_step = 8 * p.ldc, in_step = 8 * p.ld_aux_in, out_step = 8 * p.ld_aux_out;
   // write side: chunk (i*8 + 2a + khalf) ^ (l31 & 15) of row l31 = row base ^ ((khalf ^ (l31 & 15)) << 4) ^ ((i*8 + 2a) << 4): ONE lane-dependent base, the
@@ -1349,7 +1353,7 @@ __device__ __forceinline__ void gemm_epilogue_lds8(const GemmP& p, f32x16 (&acc)
   // loop below they were 16 dependent HBM round trips per tile (a C store may alias them, so the compiler cannot hoist them itself) — measured r03:
   // the x GELU' epilogue at 1183 TFLOP/s against 1355 for the plain one on the same shape.  Row r of the tile is read before row r is written
   // (in-place residual adds stay correct): a prefetched row is never one an earlier sub-pass stores.
-  constexpr bool AUXIN = (EPI == ST355_EPI_GATE_RESIDUAL || EPI == ST355_EPI_ADD || EPI == ST355_EPI_MUL_GELU_GRAD);
+  constexpr bool AUXIN = (EPI == ST355_EPI_GATE_RESIDUAL || EPI == ST355_EPI_ADD || EPI == ST355_EPI_MUL_GELU_GRAD || GG);
   bf16x8 auxv[2][4], gatev[2][4];
   const bf16* in_pre = in_row;
   int m_pre = m_first;
@@ -1358,6 +1362,7 @@ __device__ __forceinline__ void gemm_epilogue_lds8(const GemmP& p, f32x16 (&acc)
     for (int it = 0; it < 4; it++) {
       if (AUXIN) av[it] = *(const bf16x8*)in_pre;
       if (EPI == ST355_EPI_GATE_RESIDUAL) gv[it] = *(const bf16x8*)(p.gate + (int64_t)(m_pre / p.rows_per_batch) * p.gate_stride + n);
+      if (GG) gv[it] = *(const bf16x8*)(in_pre + 32);
       in_pre += in_step; m_pre += 8;
     }
   };
@@ -1416,6 +1421,20 @@ __device__ __forceinline__ void gemm_epilogue_lds8(const GemmP& p, f32x16 (&acc)
         const bf16x8 hv = auxv[j & 1][it];
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] *= gelu_tanh_grad(bf2f(hv[b]));
+      }
+      if (GG) {
+        const bf16x8 vv = auxv[j & 1][it], gv = gatev[j & 1][it];
+        bf16x8 dv, dg;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const float d = bf2f(f2bf(v[b]));                 // d out rounded to bf16, as the unfused pair (GEMM store, st355_geglu_bwd read)
+          const float g = bf2f(gv[b]);
+          dv[b] = f2bf(d * gelu_erf(g));
+          dg[b] = f2bf(d * bf2f(vv[b]) * gelu_erf_grad(g));
+        }
+        *(bf16x8*)c_ptr = dv;
+        *(bf16x8*)(c_ptr + 32) = dg;
+        continue;
       }
       bf16x8 o;
 #pragma unroll
@@ -2407,6 +2426,11 @@ static int run_one(void* stream, const st355_gemm_args* a) {
   if (a->epilogue == ST355_EPI_GEGLU || a->epilogue == ST355_EPI_GEGLU_GRAD) {      // likewise the GEGLU pair
     GemmGroup g;
     g.p[0] = p; g.p[1] = p; g.tiles0 = p4_tiles(p);
+    // the backward epilogue (reads the kept pre-activation, writes d value | d gate: 2.7 GB per launch at the SDXL 32^2 level of batch 32 against 0.43 PFLOP of
+    // MFMA work) on the PERSISTENT schedule when the problem is made of full tiles (r6): the next tile's first K-tiles load under it.  ST355_GEGLU_GRAD_PZ=0: A/B
+    static int gg_pz = -1;
+    if (gg_pz < 0) { const char* e = getenv("ST355_GEGLU_GRAD_PZ"); gg_pz = (e && e[0] == '0') ? 0 : 1; }
+    if (gg_pz && a->epilogue == ST355_EPI_GEGLU_GRAD && !a->bias && pz_ok(p, g.tiles0)) return launch_pz<ST355_EPI_GEGLU_GRAD>(stream, p, g.tiles0);
     return a->epilogue == ST355_EPI_GEGLU ? launch_pq<ST355_EPI_GEGLU>(stream, g, g.tiles0) : launch_pq<ST355_EPI_GEGLU_GRAD>(stream, g, g.tiles0);
   }
   // tile quantisation (r6 experiment knob ST355_GEMM_P3_WINDOW=lo,hi): a problem whose 256x256 tiles leave the chip's last round mostly empty — 320 tiles on
