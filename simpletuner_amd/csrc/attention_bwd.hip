@@ -1117,7 +1117,12 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
   // the 64-row kernel takes the full 64-key tiles; a ragged key tail (SD3's S = 4096 + 231, every mixed-aspect bucket) is added by the general kernel restricted
   // to the last tile (kt0 / accumulate above).  The fused-RoPE epilogue (head_dim 128, Flux: S % 64 == 0 always) writes projection rows, not dQ: no tail form.
   const bool dq_tail = Sk % 64 != 0;
-  if (!Kt && !key_bias && attn_dq_impl() == 64 && Sk >= 64 && (!dq_tail || (rq.out == nullptr && dQ != nullptr))) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
+  // a SHORT ragged key axis (the UNets' cross-attention: 77 text keys = one full tile + 13 keys) goes through the general kernel in ONE pass: as 64-row kernel + tail
+  // it was two memory-bound passes over Q / dO / dQ with a bf16 round trip of dQ between them (r6; ST355_ATTN_DQ_SHORT=0: A/B)
+  static int dq_short = -1;
+  if (dq_short < 0) { const char* e = getenv("ST355_ATTN_DQ_SHORT"); dq_short = (e && e[0] == '0') ? 0 : 1; }
+  const bool short_ragged = dq_short && dq_tail && Sk < 128;
+  if (!Kt && !key_bias && attn_dq_impl() == 64 && Sk >= 64 && !short_ragged && (!dq_tail || (rq.out == nullptr && dQ != nullptr))) {      // hand-scheduled 64-queries-per-wave kernel (k_attn_bwd_dq64)
     ProfScope ps(stream, ST355_K_ATTN_BWD_DQ, 3.0 * fl_unit, 2.0 * (double)B * H * (S + Sk) * d * 3.0);
     dim3 grid((S + 255) / 256, H, B);
     const int lds = 3 * 2 * 64 * 256;
